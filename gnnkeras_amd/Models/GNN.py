@@ -1,0 +1,362 @@
+"""Homogeneous recurrent GNN (Scarselli et al. 2009) on MI355X: node-, arc- and graph-focused models.
+
+Host-side mirror of the reference's `GNN/Models/GNN.py` — same constructor, `compile`, `call`, `process_inputs`,
+`condition`, `convergence`, `apply_filters`, `Loop`, `evaluate` / `predict` names and argument meaning — with the
+whole `Loop` (reference `GNN.py:245-274`) executed by `gnn_loop_forward` of libgnnloop.so: hand-written HIP kernels,
+`max_iteration` gated launches, no host synchronisation per iteration; `k` comes back as a device scalar.
+The Python `while` of the reference (`tf.while_loop` in eager mode, `GNN.py:265`) does not exist here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from ..sparse import SparseMatrix
+from .MLP import Sequential
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# losses / metrics of the Keras-style evaluate(): tiny torch reductions on the device, outside the hot path
+# ----------------------------------------------------------------------------------------------------------------------
+def _loss_fn(loss):
+    if callable(loss): return loss
+    name = str(loss).lower()
+    eps = 1e-7
+    if name in ('categorical_crossentropy', 'cce'):
+        def f(y, p):
+            p = p / p.sum(-1, keepdim=True)
+            return -(y * torch.log(p.clamp(eps, 1 - eps))).sum(-1)
+        return f
+    if name in ('binary_crossentropy', 'bce'):
+        def f(y, p):
+            p = p.clamp(eps, 1 - eps)
+            return -(y * torch.log(p) + (1 - y) * torch.log(1 - p)).mean(-1)
+        return f
+    if name in ('mse', 'mean_squared_error'): return lambda y, p: ((y - p) ** 2).mean(-1)
+    if name in ('mae', 'mean_absolute_error'): return lambda y, p: (y - p).abs().mean(-1)
+    raise ValueError(f'unknown loss {loss!r}')
+
+
+def _metric_fn(metric, n_targets):
+    if callable(metric): return getattr(metric, '__name__', 'metric'), metric
+    name = str(metric).lower()
+    if name in ('accuracy', 'acc'):
+        if n_targets > 1: return 'accuracy', lambda y, p: (y.argmax(-1) == p.argmax(-1)).float()
+        return 'accuracy', lambda y, p: ((p > 0.5).float() == y).float().mean(-1)
+    if name in ('categorical_accuracy',): return name, lambda y, p: (y.argmax(-1) == p.argmax(-1)).float()
+    if name in ('binary_accuracy',): return name, lambda y, p: ((p > 0.5).float() == y).float().mean(-1)
+    if name in ('mse', 'mae'): return name, _loss_fn(name)
+    raise ValueError(f'unknown metric {metric!r}')
+
+
+class _LoopModel:
+    """What the reference gets from `tf.keras.Model`: compile / evaluate / predict / fit plumbing around `call`."""
+
+    def _engine_init(self):
+        self.optimizer, self.loss, self.metrics_spec = None, None, []
+        self.average_st_grads = None
+        self._ws = None
+        self._mask_cache = {}
+
+    def compile(self, *args, average_st_grads=False, **kwargs):
+        """`compile(optimizer, loss, metrics=[...], average_st_grads=False)`; `run_eagerly` is accepted and irrelevant
+        (reference forces it, GNN.py:157)."""
+        names = ['optimizer', 'loss', 'metrics']
+        for n, v in zip(names, args): kwargs.setdefault(n, v)
+        self.optimizer = kwargs.get('optimizer', None)
+        self.loss = kwargs.get('loss', None)
+        self.metrics_spec = list(kwargs.get('metrics', None) or [])
+        self.average_st_grads = average_st_grads
+
+    def __call__(self, inputs, training: bool = False, mask=None):
+        return self.call(inputs, training=training, mask=mask)
+
+    def predict(self, sequencer, **kwargs):
+        """Outputs of every batch, concatenated (Keras `predict` semantics)."""
+        outs = [self.call(sequencer[i][0], training=False) for i in range(len(sequencer))]
+        return torch.cat(outs, dim=0).cpu().numpy() if outs else np.zeros((0, 0), np.float32)
+
+    def evaluate(self, sequencer, return_dict: bool = False, **kwargs):
+        """Sample-weighted mean loss and metrics over the sequencer (Keras `evaluate` semantics)."""
+        if self.loss is None: raise RuntimeError('compile() the model with a loss before evaluate()')
+        lossf = _loss_fn(self.loss)
+        tot_loss = tot_w = None
+        mets = None
+        for i in range(len(sequencer)):
+            x, y, sw = sequencer[i]
+            p = self.call(x, training=False)
+            if mets is None:
+                mets = [(n, f, torch.zeros((), device=p.device)) for n, f in (_metric_fn(m, y.shape[-1]) for m in self.metrics_spec)]
+                tot_loss, tot_w = torch.zeros((), device=p.device), torch.zeros((), device=p.device)
+                cnt = torch.zeros((), device=p.device)
+            sw = sw.to(p.device)
+            tot_loss = tot_loss + (lossf(y, p) * sw).sum()
+            tot_w = tot_w + sw.sum()
+            cnt = cnt + sw.sum()
+            mets = [(n, f, acc + (f(y, p) * sw).sum()) for n, f, acc in mets]
+        res = {'loss': float(tot_loss / tot_w)}
+        for n, f, acc in mets: res[n] = float(acc / cnt)
+        return res if return_dict else [res['loss']] + [res[n] for n, _, _ in mets]
+
+    def fit(self, *args, **kwargs):
+        raise NotImplementedError('fit(): the backward pass / train_step (reference GNN.py:277-306) is the next row of '
+                                  'SURVEY.md §8f and is not built yet; there is deliberately no CPU fallback.')
+
+    # workspace and mask-index caches ---------------------------------------------------------------------------------
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _out_index(self, set_mask, output_mask):
+        key = (set_mask.data_ptr(), set_mask._version, output_mask.data_ptr(), output_mask._version, len(set_mask))
+        hit = self._mask_cache.get(key)
+        if hit is None:
+            idx = torch.nonzero(torch.logical_and(set_mask, output_mask)).reshape(-1).to(torch.int32)
+            if len(self._mask_cache) > 4096: self._mask_cache.clear()
+            hit = self._mask_cache[key] = (idx, set_mask, output_mask)   # keep the masks alive: ptr is the key
+        return hit[0]
+
+
+def _squeeze_last(x):
+    return x.squeeze(-1) if isinstance(x, torch.Tensor) and x.dim() > 1 and x.shape[-1] == 1 else x
+
+
+def _arc_endpoints(adjacency: SparseMatrix, device):
+    key = ('endpoints', str(device))
+    if key not in adjacency._dev:
+        idx = torch.from_numpy(adjacency.indices.astype(np.int32)).to(device)
+        adjacency._dev[key] = (idx[:, 0].contiguous(), idx[:, 1].contiguous())
+    return adjacency._dev[key]
+
+
+#######################################################################################################################
+class GNNnodeBased(_LoopModel):
+    """GNN for node-focused problems (reference GNN.py:8-306)."""
+    name = "node"
+    _focus = 'n'
+
+    def __init__(self, net_state: Sequential, net_output: Sequential, state_vect_dim: int, max_iteration: int,
+                 state_threshold: float) -> None:
+        assert state_vect_dim >= 0
+        assert max_iteration >= 0
+        assert state_threshold >= 0
+        self.net_state = net_state
+        self.net_output = net_output
+        self.state_vect_dim = int(state_vect_dim)
+        self.max_iteration = int(max_iteration)
+        self.state_threshold = state_threshold
+        self.native_flags = 0          # OR of _native.FLAG_* (tests use FLAG_UNFUSED)
+        self._engine_init()
+
+    # ---- copy / config / persistence ---------------------------------------------------------------------------------
+    def copy(self, copy_weights: bool = True):
+        config = self.get_config()
+        config["net_state"] = config["net_state"].clone(copy_weights)
+        config["net_output"] = config["net_output"].clone(copy_weights)
+        return self.from_config(config)
+
+    def get_config(self):
+        return {"net_state": self.net_state, "net_output": self.net_output, "state_vect_dim": self.state_vect_dim,
+                "max_iteration": self.max_iteration, "state_threshold": self.state_threshold}
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        return cls(**config)
+
+    def __repr__(self):
+        return f"GNN(type={self.name}, state_dim={self.state_vect_dim}, " \
+               f"threshold={self.state_threshold}, max_iter={self.max_iteration}), avg={self.average_st_grads}"
+
+    __str__ = __repr__
+
+    @staticmethod
+    def _save_net(net: Sequential, folder: str):
+        os.makedirs(folder, exist_ok=True)
+        np.savez(os.path.join(folder, 'weights.npz'), *net.get_weights())
+        with open(os.path.join(folder, 'config.json'), 'w') as f: json.dump(net.get_config(), f)
+
+    @staticmethod
+    def _load_net(folder: str) -> Sequential:
+        with open(os.path.join(folder, 'config.json')) as f: cfg = json.load(f)
+        data = np.load(os.path.join(folder, 'weights.npz'))
+        return Sequential(**cfg, weights=[data[f'arr_{i}'] for i in range(len(data.files))])
+
+    def save(self, path: str, *args, **kwargs):
+        """`<path>/net_state/`, `<path>/net_output/`, `<path>/config.json` with the reference's keys (GNN.py:94-115);
+        each network is weights.npz (Keras get_weights() order) + its layer config."""
+        if path[-1] != '/': path += '/'
+        config = self.get_config()
+        self._save_net(config.pop("net_state"), f'{path}net_state/')
+        self._save_net(config.pop("net_output"), f'{path}net_output/')
+        with open(f'{path}config.json', 'w') as json_file: json.dump(config, json_file)
+
+    @classmethod
+    def load(cls, path: str, *args, **kwargs):
+        if path[-1] != '/': path += '/'
+        with open(f'{path}config.json', 'r') as read_file: config = json.loads(read_file.read())
+        return cls(net_state=cls._load_net(f'{path}net_state/'), net_output=cls._load_net(f'{path}net_output/'), **config)
+
+    def summary(self, *args, **kwargs):
+        print(repr(self))
+        for net in [self.net_state, self.net_output]:
+            print('\n')
+            net.summary(*args, **kwargs)
+
+    # ---- call ---------------------------------------------------------------------------------------------------------
+    def call(self, inputs, training: bool = False, mask=None):
+        """`inputs` = the list a sequencer's `__getitem__` yields; returns `out` (eval) or `(k, state, out)`."""
+        inputs = self.process_inputs(inputs)
+        k, state, out = self.Loop(*inputs, training=training)
+        if training: return k, state, out
+        return out
+
+    @staticmethod
+    def process_inputs(inputs):
+        """Squeeze [2] dim_node_label, [3] set_mask, [4] output_mask; turn [5:] triples into `SparseMatrix`
+        (reference GNN.py:181-193 rebuilds tf.SparseTensor there; here the cached CSR is reused)."""
+        inputs = list(inputs)
+        inputs[2:5] = [_squeeze_last(k) for k in inputs[2:5]]
+        inputs[5:] = [SparseMatrix.from_triple(k) for k in inputs[5:]]
+        return inputs
+
+    # ---- pieces of the loop, callable on their own (tests, LGNN-style callers) ----------------------------------------
+    def condition(self, k, state, state_old, *args):
+        """Device-side predicate of reference GNN.py:196-214; returns a 0-dim bool tensor (no host sync)."""
+        nat.require_device(state, 'state')
+        state = state.contiguous()
+        so = None if state_old is None else state_old.contiguous()
+        flag = torch.empty(1, dtype=torch.int32, device=state.device)
+        nat.check(nat.lib().gnn_converged(nat.ptr(state), nat.ptr(so), state.shape[0], state.shape[1], state.shape[1],
+                                          float(self.state_threshold), nat.ptr(flag), nat.current_stream(state.device)))
+        kk = k if isinstance(k, torch.Tensor) else torch.tensor(float(k), device=state.device)
+        return torch.logical_and(flag[0] != 0, kk.to(state.device) < self.max_iteration)
+
+    def convergence(self, k, state, state_old, nodes, adjacency, aggregated_nodes, aggregated_arcs, training, *,
+                    arcs=None, arcnode=None):
+        """One state-transition step (reference GNN.py:217-236) through `gnn_state_step`. The reference threads the
+        pre-aggregated label / arc tensors through the loop; the native step recomputes them from `arcs`/`arcnode`
+        when given, which is what `Loop` does once per call."""
+        if arcs is None or arcnode is None:
+            raise ValueError('convergence() needs arcs= and arcnode= to rebuild the iteration constants on device')
+        args, keep = self._build_args(nodes, arcs, adjacency, arcnode, None, None, state0=state, training=training,
+                                      with_output=False)
+        new = torch.empty_like(state)
+        flag = torch.empty(1, dtype=torch.int32, device=state.device)
+        nat.check(nat.lib().gnn_state_step(C.byref(args), nat.ptr(state.contiguous()), nat.ptr(new), nat.ptr(flag)))
+        return k + 1, new, state, nodes, adjacency, aggregated_nodes, aggregated_arcs, training
+
+    def apply_filters(self, state_converged, nodes, adjacency, arcs_label, mask):
+        """Rows of [state | labels] (or state) where mask (reference GNN.py:239-242). In `Loop` this gather is fused
+        into the output network's first layer; this standalone version exists for API parity."""
+        if self.state_vect_dim: state_converged = torch.cat([state_converged, nodes], dim=1)
+        return state_converged[mask]
+
+    # ---- the loop -----------------------------------------------------------------------------------------------------
+    def _check_training(self, training):
+        if training and (self.net_state.batch_normalization or self.net_output.batch_normalization
+                         or self.net_state.dropout_rate or self.net_output.dropout_rate):
+            raise NotImplementedError('training=True forward needs BatchNormalization batch statistics / dropout on '
+                                      'device (SURVEY.md §8f, next row); inference forward is the built path')
+
+    def _build_args(self, nodes, arcs, adjacency, arcnode, nodegraph, out_index, state0, training, with_output=True):
+        self._check_training(bool(training))
+        nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs')
+        dev = nodes.device
+        nodes = nodes.to(torch.float32).contiguous()
+        arcs = arcs.to(torch.float32).contiguous()
+        N, L = nodes.shape
+        E, A = arcs.shape[0], arcs.shape[1] - 2
+        adjacency, arcnode = SparseMatrix.from_triple(adjacency), SparseMatrix.from_triple(arcnode)
+        adj, arcn = adjacency.device_csr(dev), arcnode.device_csr(dev)
+        keep = [nodes, arcs, adj, arcn]
+
+        a = nat.LoopArgs()
+        a.abi_version, a.composite = nat.GNN_ABI_VERSION, 0
+        a.n_nodes, a.n_arcs, a.dim_node_label, a.dim_arc_label = N, E, L, A
+        a.nodes, a.ld_nodes = nat.ptr(nodes), L
+        a.arc_labels, a.ld_arcs = C.c_void_p(arcs.data_ptr() + 8), arcs.shape[1]
+        a.adjacency, a.arcnode = nat.make_csr(adj), nat.make_csr(arcn)
+        a.n_types = 1
+        a.net_state[0] = self.net_state.to(dev).native()
+        a.net_output = self.net_output.to(dev).native()
+        a.state_dim, a.max_iteration, a.state_threshold = self.state_vect_dim, self.max_iteration, float(self.state_threshold)
+        if self.state_vect_dim > 0:
+            if state0 is None: raise ValueError('state0 missing')
+            state0 = state0.to(dev, torch.float32).contiguous()
+            if tuple(state0.shape) != (N, self.state_vect_dim): raise ValueError('state0 must be (n_nodes, state_vect_dim)')
+            a.state0 = nat.ptr(state0); keep.append(state0)
+        a.focus = nat.FOCUS[self._focus]
+        if with_output:
+            a.n_out, a.out_index = len(out_index), nat.ptr(out_index)
+            keep.append(out_index)
+            if self._focus == 'a':
+                es, ed = _arc_endpoints(adjacency, dev)
+                a.arc_src, a.arc_dst = nat.ptr(es), nat.ptr(ed); keep += [es, ed]
+            if self._focus == 'g':
+                ng = SparseMatrix.from_triple(nodegraph).device_csr(dev)
+                a.nodegraph = nat.make_csr(ng); keep.append(ng)
+        a.flags = self.native_flags
+        a.stream = nat.current_stream(dev)
+        nbytes = nat.lib().gnn_loop_workspace_bytes(C.byref(a))
+        if nbytes == 0: nat.check(1)
+        ws = self._workspace(nbytes, dev)
+        base = ws.data_ptr()
+        aligned = (base + 255) & ~255
+        a.workspace, a.workspace_bytes = C.c_void_p(aligned), ws.numel() - (aligned - base)
+        return a, keep
+
+    def Loop(self, nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph,
+             training: bool = False, *, state0=None, seed=None):
+        """(k, state, out) for one (merged) graph — reference GNN.py:245-274.
+
+        Additive keyword arguments: `state0` replaces the reference's `tf.random.normal(stddev=0.1)`
+        draw when `state_vect_dim > 0`; otherwise it is drawn on the device with `seed`."""
+        nat.require_device(nodes, 'nodes')
+        dev = nodes.device
+        set_mask, output_mask = _squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev)
+        out_index = self._out_index(set_mask, output_mask)
+        N = nodes.shape[0]
+        if self.state_vect_dim > 0 and state0 is None:
+            gen = None
+            if seed is not None:
+                gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
+            state0 = torch.randn((N, self.state_vect_dim), generator=gen, device=dev, dtype=torch.float32) * 0.1
+        a, keep = self._build_args(nodes, arcs, adjacency, arcnode, nodegraph, out_index, state0, training)
+        S = self.state_vect_dim if self.state_vect_dim > 0 else nodes.shape[1]
+        T = self.net_output.units[-1]
+        n_rows_out = a.nodegraph.n_dst if self._focus == 'g' else len(out_index)
+        k = torch.empty((), dtype=torch.float32, device=dev)
+        state = torch.empty((N, S), dtype=torch.float32, device=dev)
+        out = torch.empty((n_rows_out, T), dtype=torch.float32, device=dev)
+        a.k_out, a.state_out, a.out = nat.ptr(k), nat.ptr(state), nat.ptr(out)
+        nat.check(nat.lib().gnn_loop_forward(C.byref(a)))
+        return k, state, out
+
+
+#######################################################################################################################
+class GNNarcBased(GNNnodeBased):
+    """GNN for arc-focused problems (reference GNN.py:312-330): output network sees
+    [state_src | label_src | state_dst | label_dst | arc label] of every masked arc."""
+    name = "arc"
+    _focus = 'a'
+
+    def apply_filters(self, state_converged, nodes, adjacency, arcs_label, mask):
+        if self.state_vect_dim: state_converged = torch.cat([state_converged, nodes], dim=1)
+        adjacency = SparseMatrix.from_triple(adjacency)
+        idx = torch.from_numpy(adjacency.indices).to(state_converged.device)
+        states = state_converged[idx].reshape(arcs_label.shape[0], 2 * state_converged.shape[1])
+        return torch.cat([states, arcs_label], dim=1)[mask]
+
+
+#######################################################################################################################
+class GNNgraphBased(GNNnodeBased):
+    """GNN for graph-focused problems (reference GNN.py:336-346): per-graph mean of the node outputs through
+    NodeGraph, pooled on the device as one more CSR walk."""
+    name = "graph"
+    _focus = 'g'

@@ -1,0 +1,184 @@
+"""Batch assembly for the MI355X loop: merge B graphs into one block-diagonal graph, once, and keep it in HBM.
+
+Mirror of the reference's `GNN/Sequencers/GraphSequencers.py` (`tf.keras.utils.Sequence` subclasses): same
+constructors, `__len__`, `__getitem__ -> (x_list, targets, sample_weight)`, `on_epoch_end`, `set_batch_size`,
+`get_batch`, `copy`, `get_config/from_config`. `x_list` has the reference's layout
+(`GraphSequencers.py:108-120`, `:239-244`):
+
+  homogeneous : [nodes, arcs, dim_node_label(1,1), set_mask(N,1), output_mask(N,1), Adjacency, ArcNode, NodeGraph]
+  composite   : [nodes, arcs, dim_node_label(T,1), type_mask(T,N,1), set_mask, output_mask, [CompositeAdjacency]*T,
+                 Adjacency, ArcNode, NodeGraph]
+
+with each sparse matrix as the `(indices, values[...,None], dense_shape)` triple — a `SparseTriple` that also carries
+the by-destination CSR built at merge time, so the model never re-derives it (the reference rebuilds three
+`tf.SparseTensor`s per call, `GNN.py:192`).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..composite_graph_class import CompositeGraphObject, CompositeGraphTensor
+from ..graph_class import GraphObject, GraphTensor
+from ..sparse import default_device
+
+
+class MultiGraphSequencer:
+    """Sequencer for a dataset of many homogeneous graphs (reference GraphSequencers.py:12-127)."""
+
+    merge = classmethod(lambda cls, *a, **k: GraphObject.merge(*a, **k))
+    to_graph_tensor = classmethod(lambda cls, g, device=None: GraphTensor.fromGraphObject(g, device))
+
+    def __init__(self, graphs, focus: str, aggregation_mode: str, batch_size: int = 32, shuffle: bool = True,
+                 device=None):
+        self.data = graphs if isinstance(graphs, list) else [graphs]
+        self.focus = focus
+        self.aggregation_mode = aggregation_mode
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.dtype = 'float32'
+        self.device = torch.device(device) if device is not None else default_device()
+        self.build_batches()
+
+    def build_batches(self):
+        """Slice the graph list by batch_size, merge each slice, move it to the device (reference :42-46)."""
+        graphs = [self.merge(self.data[i * self.batch_size: (i + 1) * self.batch_size], focus=self.focus,
+                             aggregation_mode=self.aggregation_mode) for i in range(len(self))]
+        self.graph_tensors = [self.to_graph_tensor(g, self.device) for g in graphs]
+        self._items = [None] * len(self.graph_tensors)
+
+    def copy(self):
+        config = self.get_config()
+        config["graphs"] = [g.copy() for g in config["graphs"]]
+        return self.from_config(config)
+
+    def get_config(self):
+        return {"graphs": self.data, "focus": self.focus, "aggregation_mode": self.aggregation_mode,
+                "batch_size": self.batch_size, "shuffle": self.shuffle}
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        return cls(**config)
+
+    def __repr__(self):
+        problem = {'a': 'edge', 'n': 'node', 'g': 'graph'}[self.focus]
+        return f"graph_sequencer(type=multiple {problem}-focused, len={len(self)}, " \
+               f"aggregation='{self.aggregation_mode}', batch_size={self.batch_size}, shuffle={self.shuffle})"
+
+    __str__ = __repr__
+
+    def set_batch_size(self, new_batch_size):
+        self.batch_size = new_batch_size
+        self.build_batches()
+
+    def get_batch(self, index):
+        g = self.graph_tensors[index]
+        return g, g.set_mask
+
+    def __len__(self):
+        return int(np.ceil(len(self.data) / self.batch_size))
+
+    def _x_list(self, g):
+        newaxis = lambda x: x[..., None]
+        return [g.nodes, g.arcs] + [newaxis(i) for i in [g.DIM_NODE_LABEL, g.set_mask, g.output_mask]] + \
+               [m.triple(self.device) for m in [g.Adjacency, g.ArcNode, g.NodeGraph]]
+
+    def __getitem__(self, index):
+        """(x_list, targets, sample_weight) of batch `index`; device tensors, built once per batch and reused."""
+        if self._items[index] is not None:
+            return self._items[index]
+        g, set_mask = self.get_batch(index)
+        out = self._x_list(g)
+        if self.focus == 'g': mask = torch.ones((g.targets.shape[0]), dtype=torch.bool, device=g.targets.device)
+        else: mask = set_mask[g.output_mask]
+        item = (out, g.targets[mask], g.sample_weight[mask])
+        if set_mask is g.set_mask: self._items[index] = item
+        return item
+
+    def on_epoch_end(self):
+        """Reshuffle the graph list and re-merge every batch (reference :123-127)."""
+        if self.shuffle:
+            np.random.shuffle(self.data)
+            self.build_batches()
+
+
+class SingleGraphSequencer(MultiGraphSequencer):
+    """Sequencer for a dataset made of one homogeneous graph: a batch is a subset of set_mask
+    (reference GraphSequencers.py:133-208). As in the reference, `x` carries the graph's full set_mask while targets are
+    filtered with the batch mask — kept faithfully."""
+
+    def __init__(self, graph: GraphObject, focus: str, batch_size: int = 32, shuffle: bool = True, device=None):
+        self.data = graph
+        self.device = torch.device(device) if device is not None else default_device()
+        self.graph_tensor = self.to_graph_tensor(graph, self.device)
+        self.focus = focus
+        self.batch_size = batch_size
+        self.shuffle = shuffle
+        self.dtype = 'float32'
+        self.set_mask_idx = np.argwhere(self.data.set_mask).reshape(-1)
+        self.build_batches()
+
+    def build_batches(self):
+        self.batch_masks = np.zeros((len(self), len(self.data.set_mask)), dtype=bool)
+        for i in range(len(self)):
+            self.batch_masks[i, self.set_mask_idx[i * self.batch_size: (i + 1) * self.batch_size]] = True
+        self._items = [None] * len(self)
+
+    def copy(self):
+        config = self.get_config()
+        config["graph"] = config["graph"].copy()
+        return self.from_config(config)
+
+    def get_config(self):
+        return {"graph": self.data, "focus": self.focus, "batch_size": self.batch_size, "shuffle": self.shuffle}
+
+    def __repr__(self):
+        problem = {'a': 'edge', 'n': 'node', 'g': 'graph'}[self.focus]
+        return f"graph_sequencer(type=single {problem}-focused, " \
+               f"len={len(self)}, batch_size={self.batch_size}, shuffle={self.shuffle})"
+
+    __str__ = __repr__
+
+    def get_batch(self, index):
+        return self.graph_tensor, torch.as_tensor(self.batch_masks[index], dtype=torch.bool, device=self.device)
+
+    def __len__(self):
+        return int(np.ceil(np.sum(self.data.set_mask) / self.batch_size))
+
+    def on_epoch_end(self):
+        if self.shuffle:
+            np.random.shuffle(self.set_mask_idx)
+            self.build_batches()
+
+
+class CompositeMultiGraphSequencer(MultiGraphSequencer):
+    """Sequencer for many heterogeneous graphs (reference GraphSequencers.py:214-245)."""
+
+    merge = classmethod(lambda cls, *a, **k: CompositeGraphObject.merge(*a, **k))
+    to_graph_tensor = classmethod(lambda cls, g, device=None: CompositeGraphTensor.fromGraphObject(g, device))
+
+    def __init__(self, graphs, *args, **kwargs):
+        super().__init__(graphs, *args, **kwargs)
+
+    def __repr__(self):
+        return f"composite_{super().__repr__()}"
+
+    __str__ = __repr__
+
+    def _x_list(self, g):
+        out = super()._x_list(g)
+        out.insert(3, g.type_mask[..., None])
+        out.insert(-3, [ca.triple(self.device) for ca in g.CompositeAdjacencies])
+        return out
+
+
+class CompositeSingleGraphSequencer(SingleGraphSequencer, CompositeMultiGraphSequencer):
+    """Sequencer for one heterogeneous graph (reference GraphSequencers.py:252-266)."""
+
+    def __init__(self, graph: CompositeGraphObject, *args, **kwargs):
+        SingleGraphSequencer.__init__(self, graph, *args, **kwargs)
+
+    def __repr__(self):
+        return f"composite_{super().__repr__()}"
+
+    __str__ = __repr__

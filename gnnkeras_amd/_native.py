@@ -1,0 +1,140 @@
+"""ctypes binding of libgnnloop.so (C ABI: include/gnnloop.h) — the only way the Python host code reaches the GPU
+arithmetic of the loop.  There is deliberately no CPU fallback: if the shared library is missing or the tensors are
+not on a HIP device, the calls raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libgnnloop.so')
+
+GNN_ABI_VERSION = 1
+GNN_MAX_LAYERS = 8
+GNN_MAX_TYPES = 8
+
+ACTIVATIONS = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'tanh': 3, 'sigmoid': 4, 'elu': 5, 'softplus': 6,
+               'softmax': 7}
+FOCUS = {'n': 0, 'a': 1, 'g': 2}
+FLAG_UNFUSED = 1
+FLAG_NO_EARLY_EXIT = 2
+
+EXPORTS = ['gnn_last_error', 'gnn_abi_version', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_aggregate',
+           'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step']
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+class CSR(C.Structure):
+    _fields_ = [('n_dst', C.c_int32), ('n_src', C.c_int32), ('nnz', C.c_int32),
+                ('rowptr', C.c_void_p), ('src', C.c_void_p), ('w', C.c_void_p), ('row_scale', C.c_void_p)]
+
+
+class MLP(C.Structure):
+    _fields_ = [('in_dim', C.c_int32), ('n_layers', C.c_int32),
+                ('units', C.c_int32 * GNN_MAX_LAYERS), ('activation', C.c_int32 * GNN_MAX_LAYERS),
+                ('kernel', C.c_void_p * GNN_MAX_LAYERS), ('bias', C.c_void_p * GNN_MAX_LAYERS),
+                ('has_bn', C.c_int32), ('bn_eps', C.c_float),
+                ('bn_gamma', C.c_void_p), ('bn_beta', C.c_void_p), ('bn_mean', C.c_void_p), ('bn_var', C.c_void_p)]
+
+
+class LoopArgs(C.Structure):
+    _fields_ = [('abi_version', C.c_int32), ('composite', C.c_int32),
+                ('n_nodes', C.c_int32), ('n_arcs', C.c_int32), ('dim_node_label', C.c_int32),
+                ('dim_arc_label', C.c_int32),
+                ('nodes', C.c_void_p), ('ld_nodes', C.c_int32),
+                ('arc_labels', C.c_void_p), ('ld_arcs', C.c_int32),
+                ('adjacency', CSR), ('arcnode', CSR),
+                ('n_types', C.c_int32), ('type_dim_label', C.c_int32 * GNN_MAX_TYPES),
+                ('type_nodes', C.c_void_p), ('type_offsets', C.c_int32 * (GNN_MAX_TYPES + 1)),
+                ('composite_adjacency', CSR * GNN_MAX_TYPES),
+                ('net_state', MLP * GNN_MAX_TYPES), ('net_output', MLP),
+                ('state_dim', C.c_int32), ('max_iteration', C.c_int32), ('state_threshold', C.c_float),
+                ('state0', C.c_void_p),
+                ('focus', C.c_int32), ('n_out', C.c_int32), ('out_index', C.c_void_p),
+                ('arc_src', C.c_void_p), ('arc_dst', C.c_void_p), ('nodegraph', CSR),
+                ('k_out', C.c_void_p), ('state_out', C.c_void_p), ('out', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('stream', C.c_void_p),
+                ('flags', C.c_int32)]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libgnnloop.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(['make', '-C', CSRC], capture_output=True, text=True)
+    if verbose or res.returncode:
+        print(res.stdout, res.stderr)
+    if res.returncode:
+        raise NativeError('building libgnnloop.so failed:\n' + res.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                              f'or `make -C {CSRC}`. There is no CPU fallback for the HIP path.')
+        l = C.CDLL(LIB_PATH)
+        l.gnn_last_error.restype = C.c_char_p
+        l.gnn_abi_version.restype = C.c_int
+        l.gnn_loop_workspace_bytes.restype = C.c_size_t
+        l.gnn_loop_workspace_bytes.argtypes = [C.POINTER(LoopArgs)]
+        l.gnn_loop_forward.restype = C.c_int
+        l.gnn_loop_forward.argtypes = [C.POINTER(LoopArgs)]
+        l.gnn_aggregate.restype = C.c_int
+        l.gnn_aggregate.argtypes = [C.POINTER(CSR), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        l.gnn_mlp_workspace_bytes.restype = C.c_size_t
+        l.gnn_mlp_workspace_bytes.argtypes = [C.POINTER(MLP), C.c_int32]
+        l.gnn_mlp_forward.restype = C.c_int
+        l.gnn_mlp_forward.argtypes = [C.POINTER(MLP), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gnn_converged.restype = C.c_int
+        l.gnn_converged.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                    C.c_void_p]
+        l.gnn_state_step.restype = C.c_int
+        l.gnn_state_step.argtypes = [C.POINTER(LoopArgs), C.c_void_p, C.c_void_p, C.c_void_p]
+        if l.gnn_abi_version() != GNN_ABI_VERSION:
+            raise NativeError('libgnnloop.so ABI version mismatch: rebuild it')
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise NativeError(lib().gnn_last_error().decode())
+
+
+def require_device(t: torch.Tensor, name: str):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise NativeError(f'{name} must be a tensor on a HIP device: the message-passing loop has no CPU path')
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def make_csr(d: dict | None) -> CSR:
+    """ctypes view of `SparseMatrix.device_csr()`; tensors must be kept alive by the caller."""
+    c = CSR()
+    if d is None:
+        return c
+    c.n_dst, c.n_src, c.nnz = d['n_dst'], d['n_src'], d['nnz']
+    c.rowptr, c.src, c.w, c.row_scale = ptr(d['rowptr']), ptr(d['src']), ptr(d['w']), ptr(d['row_scale'])
+    return c

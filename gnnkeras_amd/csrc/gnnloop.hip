@@ -1,0 +1,600 @@
+// libgnnloop.so — host side of the C ABI declared in include/gnnloop.h (gfx950 only).
+//
+// gnn_loop_forward enqueues, on the caller's stream and with no host<->device synchronisation:
+//   setup   : BN folding of the first Dense of every network; ArcNode scatter-add (reference GNN.py:254) and neighbour
+//             label aggregate (:258) as CSR walks; the iteration-invariant part of the first state layer folded into
+//             a per-node constant  C = [labels | agg labels | agg arcs] . W1[const rows] + b1   (SURVEY §7);
+//   loop    : `max_iteration` gated iterations (fused kernel, or aggregate + dense + predicate when un-fused);
+//             iteration i runs only if flags[i] != 0 and raises flags[i+1] when any node is still moving;
+//   output  : apply_filters (:239-242 / :317-330) as row-index segments of the output network's first layer,
+//             the output MLP on the f32 matrix cores, optional graph pooling (:341-346).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/gnnloop.h"
+#include "kernels_general.hpp"
+#include "kernel_state_fused.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define HIP_OK(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define LAUNCH_OK() HIP_OK(hipGetLastError())
+#define TRY(expr)                \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_) return rc_;     \
+    } while (0)
+
+#define FUSED_OK(expr)                                                                                  \
+    do {                                                                                                \
+        if (expr) return fail("fused state kernel launch failed: %s", hipGetErrorString(hipGetLastError())); \
+    } while (0)
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// padded leading dimension of the internal state buffers: rows start 16-byte aligned; power of two in [16, 128] so a
+// node's row is covered by 4..32 lanes of one wave loading 16 B each and by whole 16-column MFMA tiles.
+int state_ld(int S) {
+    if (S <= 128) {
+        int p = 16;
+        while (p < S) p <<= 1;
+        return p;
+    }
+    return round_up(S, 4);
+}
+
+// --- workspace carving: same code computes the size (base == nullptr) and hands out the pointers --------------------
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *b) : base((char *)b) {}
+    template <typename T>
+    T *take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T *p = base ? (T *)(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+int max_units(const gnn_mlp_t &m) {
+    int h = 1;
+    for (int i = 0; i < m.n_layers; ++i) h = std::max(h, (int)m.units[i]);
+    return h;
+}
+
+int check_mlp(const gnn_mlp_t &m, const char *name, bool need_ptrs) {
+    if (m.n_layers < 1 || m.n_layers > GNN_MAX_LAYERS) return fail("%s: n_layers %d out of [1,%d]", name, m.n_layers, GNN_MAX_LAYERS);
+    if (m.in_dim < 1) return fail("%s: in_dim %d < 1", name, m.in_dim);
+    for (int i = 0; i < m.n_layers; ++i) {
+        if (m.units[i] < 1) return fail("%s: layer %d has %d units", name, i, m.units[i]);
+        if (m.activation[i] < 0 || m.activation[i] > GNN_ACT_SOFTMAX) return fail("%s: layer %d unknown activation %d", name, i, m.activation[i]);
+        if (need_ptrs && (!m.kernel[i] || !m.bias[i])) return fail("%s: layer %d kernel/bias is NULL", name, i);
+    }
+    if (need_ptrs && m.has_bn && (!m.bn_gamma || !m.bn_beta || !m.bn_mean || !m.bn_var)) return fail("%s: BatchNormalization arrays are NULL", name);
+    return 0;
+}
+
+int check_csr(const gnn_csr_t &c, const char *name, int n_dst, int n_src) {
+    if (c.n_dst != n_dst || c.n_src != n_src) return fail("%s: shape (%d x %d)^T expected, got n_src=%d n_dst=%d", name, n_src, n_dst, c.n_src, c.n_dst);
+    if (c.nnz < 0) return fail("%s: nnz < 0", name);
+    if (!c.rowptr) return fail("%s: rowptr is NULL", name);
+    if (c.nnz > 0 && !c.src) return fail("%s: src is NULL", name);
+    return 0;
+}
+
+// --- launchers -------------------------------------------------------------------------------------------------------
+int launch_aggregate(const int *gate, const gnn_csr_t &c, const float *X, int ldx, int F, float *out, int ldo, hipStream_t st) {
+    if (c.n_dst == 0 || F == 0) return 0;
+    int G = 4;
+    while (G < F && G < 64) G <<= 1;
+    const int groups = 256 / G;
+    const int grid = std::min(cdiv(c.n_dst, groups), 256 * 16);
+#define AGG(GG) gnn::k_aggregate<GG><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, ldx, F, out, ldo)
+    switch (G) {
+        case 4: AGG(4); break;
+        case 8: AGG(8); break;
+        case 16: AGG(16); break;
+        case 32: AGG(32); break;
+        default: AGG(64); break;
+    }
+#undef AGG
+    LAUNCH_OK();
+    return 0;
+}
+
+int launch_segdense(gnn::SegDenseArgs &a, hipStream_t st) {
+    if (a.M == 0) return 0;
+    gnn::k_segdense<<<cdiv(a.M, gnn::SD_TM), 256, 0, st>>>(a);
+    LAUNCH_OK();
+    return 0;
+}
+
+int launch_softmax(const int *gate, float *Y, int M, int H, int ldy, const int *rowidx, hipStream_t st) {
+    if (M == 0) return 0;
+    gnn::k_softmax_rows<<<cdiv(M, 256), 256, 0, st>>>(gate, Y, M, H, ldy, rowidx);
+    LAUNCH_OK();
+    return 0;
+}
+
+int launch_converge(const int *gate, const float *s, const float *so, int N, int S, int ld_s, int ld_so, float thr,
+                    int *flag_out, float *k_out, float k_val, hipStream_t st) {
+    const int grid = std::max(1, std::min(cdiv(N, 16), 256 * 8));
+    gnn::k_converge<<<grid, 256, 0, st>>>(gate, s, so, N, S, ld_s, ld_so, thr, flag_out, k_out, k_val);
+    LAUNCH_OK();
+    return 0;
+}
+
+int launch_fold(const gnn_mlp_t &m, float *Wf, float *bf, hipStream_t st) {
+    const int H = m.units[0];
+    gnn::k_fold_bn<<<cdiv(H, 256), 256, 0, st>>>(m.kernel[0], m.bias[0], m.in_dim, H, m.has_bn ? m.bn_gamma : nullptr,
+                                                 m.bn_beta, m.bn_mean, m.bn_var, m.bn_eps, Wf, bf);
+    LAUNCH_OK();
+    return 0;
+}
+
+int launch_copy2d(const int *gate, const float *src, int ld_src, float *dst, int ld_dst, int rows, int width, int fill_to, hipStream_t st) {
+    if (rows == 0 || fill_to == 0) return 0;
+    const long total = (long)rows * fill_to;
+    gnn::k_copy2d<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, st>>>(gate, src, ld_src, dst, ld_dst, rows, width, fill_to);
+    LAUNCH_OK();
+    return 0;
+}
+
+// Run a reference MLP whose first layer has already been BN-folded into (Wf, bf).  The first layer reads the virtual
+// concatenation described by `segs`; `addend` (optional) is a per-row constant already containing the bias.
+struct MlpRun {
+    const gnn_mlp_t *mlp;
+    const float *Wf, *bf;
+    gnn::Seg segs[GNN_MAX_SEGS];
+    int nseg = 0;
+    const float *addend = nullptr; int ld_add = 0; const int *add_rowidx = nullptr;
+    int M = 0;
+    float *hid[2] = {nullptr, nullptr}; int ld_hid = 0;
+    float *Y = nullptr; int ldy = 0; const int *out_rowidx = nullptr;
+    const int *gate = nullptr;
+};
+
+int run_mlp(const MlpRun &r, hipStream_t st) {
+    const gnn_mlp_t &m = *r.mlp;
+    const float *cur = nullptr;
+    int cur_ld = 0;
+    for (int l = 0; l < m.n_layers; ++l) {
+        const bool last = (l == m.n_layers - 1);
+        gnn::SegDenseArgs a;
+        memset(&a, 0, sizeof(a));
+        a.gate = r.gate;
+        a.M = r.M;
+        a.H = m.units[l];
+        if (l == 0) {
+            a.nseg = r.nseg;
+            for (int s = 0; s < r.nseg; ++s) a.seg[s] = r.segs[s];
+            a.W = r.Wf;
+            a.bias = r.addend ? nullptr : r.bf;
+            a.addend = r.addend; a.ld_add = r.ld_add; a.add_rowidx = r.add_rowidx;
+        } else {
+            a.nseg = 1;
+            a.seg[0] = gnn::Seg{cur, nullptr, cur_ld, m.units[l - 1], 0};
+            a.W = m.kernel[l];
+            a.bias = m.bias[l];
+        }
+        a.ldw = a.H;
+        a.act = m.activation[l] == GNN_ACT_SOFTMAX ? GNN_ACT_LINEAR : m.activation[l];
+        if (last) { a.Y = r.Y; a.ldy = r.ldy; a.out_rowidx = r.out_rowidx; }
+        else      { a.Y = r.hid[l & 1]; a.ldy = r.ld_hid; a.out_rowidx = nullptr; }
+        TRY(launch_segdense(a, st));
+        if (m.activation[l] == GNN_ACT_SOFTMAX) TRY(launch_softmax(r.gate, a.Y, a.M, a.H, a.ldy, a.out_rowidx, st));
+        cur = a.Y; cur_ld = a.ldy;
+    }
+    return 0;
+}
+
+// --- the loop plan ---------------------------------------------------------------------------------------------------
+struct TypePlan {
+    const gnn_mlp_t *net;
+    const int *rows;       // node ids of this type (nullptr = all nodes, homogeneous)
+    int count;
+    float *Wf, *bf;        // folded first layer [in_dim x H1], [H1]
+    int wrow_state, wrow_agg;
+    gnn::Seg cseg[GNN_MAX_SEGS];   // iteration-invariant segments (rowidx filled with `rows`)
+    int ncseg;
+};
+
+struct Plan {
+    int N, E, S, SP, L, A, T;        // S = state width, SP = padded leading dimension of internal state buffers
+    int H1max, Hmax_state, Hmax_out, Tout, M, G;
+    bool composite, fused;
+    TypePlan tp[GNN_MAX_TYPES];
+    // workspace
+    int *flags;
+    float *agg_arcs, *agg_nodes; int ld_agg_nodes;
+    float *C; int ldC;
+    float *buf[2], *agg;
+    float *hid[2]; int ld_hid;
+    float *Wf_out, *bf_out;
+    float *ohid[2]; int ld_ohid;
+    float *out_nodes;
+    int *idx_src, *idx_dst;
+    size_t bytes;
+};
+
+int state_width(const gnn_loop_args_t &a) { return a.state_dim > 0 ? a.state_dim : a.dim_node_label; }
+
+int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
+    memset(&p, 0, sizeof(p));
+    if (a.abi_version != GNN_ABI_VERSION) return fail("abi_version %d != %d", a.abi_version, GNN_ABI_VERSION);
+    if (a.n_nodes < 0 || a.n_arcs < 0) return fail("negative graph size");
+    if (a.state_dim < 0 || a.max_iteration < 0 || !(a.state_threshold >= 0.0f)) return fail("state_dim, max_iteration, state_threshold must be >= 0");
+    p.composite = a.composite != 0;
+    p.T = p.composite ? a.n_types : 1;
+    if (p.T < 1 || p.T > GNN_MAX_TYPES) return fail("n_types %d out of [1,%d]", p.T, GNN_MAX_TYPES);
+    if (p.composite && a.max_iteration < 1) return fail("composite GNN requires max_iteration > 0");
+    p.N = a.n_nodes; p.E = a.n_arcs; p.L = a.dim_node_label; p.A = a.dim_arc_label;
+    p.S = state_width(a);
+    if (p.S < 1) return fail("state width is 0 (state_dim == 0 and dim_node_label == 0)");
+    p.SP = state_ld(p.S);
+    if (a.focus < GNN_FOCUS_NODE || a.focus > GNN_FOCUS_GRAPH) return fail("unknown focus %d", a.focus);
+    p.M = a.n_out;
+    if (p.M < 0) return fail("n_out < 0");
+
+    int sum_dt = 0;
+    for (int t = 0; t < p.T; ++t) {
+        TRY(check_mlp(a.net_state[t], "net_state", validate_ptrs));
+        const gnn_mlp_t &ns = a.net_state[t];
+        int expect;
+        if (p.composite) {
+            if (a.type_dim_label[t] < 0 || a.type_dim_label[t] > p.L) return fail("type_dim_label[%d]=%d out of [0,%d]", t, a.type_dim_label[t], p.L);
+            sum_dt += a.type_dim_label[t];
+        }
+        (void)expect;
+        if (ns.units[ns.n_layers - 1] != p.S) return fail("net_state[%d] output width %d != state width %d", t, ns.units[ns.n_layers - 1], p.S);
+        p.H1max = std::max(p.H1max, (int)ns.units[0]);
+        p.Hmax_state = std::max(p.Hmax_state, max_units(ns));
+    }
+    for (int t = 0; t < p.T; ++t) {
+        const gnn_mlp_t &ns = a.net_state[t];
+        const int expect = p.composite ? a.type_dim_label[t] + 2 * p.S + sum_dt + p.A
+                                       : (a.state_dim > 0 ? 2 * p.S + 2 * p.L + p.A : 2 * p.S + p.A);
+        if (ns.in_dim != expect) return fail("net_state[%d].in_dim %d != %d expected from the graph dims", t, ns.in_dim, expect);
+    }
+    TRY(check_mlp(a.net_output, "net_output", validate_ptrs));
+    {
+        const int node_part = p.composite ? p.S : (a.state_dim > 0 ? p.S + p.L : p.S);
+        const int expect = a.focus == GNN_FOCUS_ARC ? 2 * node_part + p.A : node_part;
+        if (a.net_output.in_dim != expect) return fail("net_output.in_dim %d != %d expected for this focus", a.net_output.in_dim, expect);
+    }
+    p.Hmax_out = max_units(a.net_output);
+    p.Tout = a.net_output.units[a.net_output.n_layers - 1];
+    p.G = a.focus == GNN_FOCUS_GRAPH ? a.nodegraph.n_dst : 0;
+
+    if (validate_ptrs) {
+        TRY(check_csr(a.adjacency, "adjacency", p.N, p.N));
+        TRY(check_csr(a.arcnode, "arcnode", p.N, p.E));
+        if (p.N > 0 && !a.nodes) return fail("nodes is NULL");
+        if (p.E > 0 && p.A > 0 && !a.arc_labels) return fail("arc_labels is NULL");
+        if (a.state_dim > 0 && p.N > 0 && !a.state0) return fail("state0 is required when state_dim > 0");
+        if (!a.k_out || !a.state_out || !a.out) return fail("k_out / state_out / out must be non-NULL");
+        if (p.M > 0 && !a.out_index) return fail("out_index is NULL");
+        if (a.focus == GNN_FOCUS_ARC && p.E > 0 && (!a.arc_src || !a.arc_dst)) return fail("arc focus needs arc_src / arc_dst");
+        if (a.focus == GNN_FOCUS_GRAPH) {
+            if (a.nodegraph.n_src != p.M) return fail("graph focus: NodeGraph has %d rows but %d nodes pass the mask (the reference's matmul would fail too)", a.nodegraph.n_src, p.M);
+            TRY(check_csr(a.nodegraph, "nodegraph", a.nodegraph.n_dst, p.M));
+        }
+        if (p.composite) {
+            if (!a.type_nodes && p.N > 0) return fail("type_nodes is NULL");
+            if (a.type_offsets[0] != 0 || a.type_offsets[p.T] != p.N) return fail("type_offsets must span [0, n_nodes]");
+            for (int t = 0; t < p.T; ++t) TRY(check_csr(a.composite_adjacency[t], "composite_adjacency", p.N, p.N));
+        }
+    }
+
+    // ---- carve ----
+    Carver c(ws);
+    p.flags = c.take<int>(a.max_iteration + 2);
+    for (int t = 0; t < p.T; ++t) {
+        p.tp[t].Wf = c.take<float>((size_t)a.net_state[t].in_dim * a.net_state[t].units[0]);
+        p.tp[t].bf = c.take<float>(a.net_state[t].units[0]);
+    }
+    p.Wf_out = c.take<float>((size_t)a.net_output.in_dim * a.net_output.units[0]);
+    p.bf_out = c.take<float>(a.net_output.units[0]);
+    p.agg_arcs = c.take<float>((size_t)p.N * std::max(p.A, 1));
+    p.ld_agg_nodes = p.composite ? sum_dt : (a.state_dim > 0 ? p.L : 0);
+    p.agg_nodes = c.take<float>((size_t)p.N * std::max(p.ld_agg_nodes, 1));
+    p.ldC = p.H1max;
+    p.C = c.take<float>((size_t)p.N * p.ldC);
+    p.buf[0] = c.take<float>((size_t)p.N * p.SP + 64);
+    p.buf[1] = c.take<float>((size_t)p.N * p.SP + 64);
+    p.agg = c.take<float>((size_t)p.N * p.SP);
+    p.ld_hid = p.Hmax_state;
+    p.hid[0] = c.take<float>((size_t)p.N * p.ld_hid);
+    p.hid[1] = c.take<float>((size_t)p.N * p.ld_hid);
+    p.ld_ohid = p.Hmax_out;
+    p.ohid[0] = c.take<float>((size_t)p.M * p.ld_ohid);
+    p.ohid[1] = c.take<float>((size_t)p.M * p.ld_ohid);
+    p.out_nodes = c.take<float>((size_t)p.M * p.Tout);
+    p.idx_src = c.take<int>(std::max(p.M, 1));
+    p.idx_dst = c.take<int>(std::max(p.M, 1));
+    p.bytes = (c.off + 255) & ~(size_t)255;
+
+    // ---- per-type first-layer layout ----
+    for (int t = 0; t < p.T; ++t) {
+        TypePlan &tp = p.tp[t];
+        tp.net = &a.net_state[t];
+        tp.ncseg = 0;
+        if (!p.composite) {
+            tp.rows = nullptr; tp.count = p.N;
+            if (a.state_dim > 0) {   // [state | nodes | agg_state | agg_nodes | agg_arcs]   (GNN.py:222-231)
+                tp.wrow_state = 0; tp.wrow_agg = p.S + p.L;
+                tp.cseg[tp.ncseg++] = gnn::Seg{a.nodes, nullptr, a.ld_nodes, p.L, p.S};
+                tp.cseg[tp.ncseg++] = gnn::Seg{p.agg_nodes, nullptr, p.ld_agg_nodes, p.L, 2 * p.S + p.L};
+                if (p.A > 0) tp.cseg[tp.ncseg++] = gnn::Seg{p.agg_arcs, nullptr, p.A, p.A, 2 * p.S + 2 * p.L};
+            } else {                 // [state | agg_state | agg_arcs]
+                tp.wrow_state = 0; tp.wrow_agg = p.S;
+                if (p.A > 0) tp.cseg[tp.ncseg++] = gnn::Seg{p.agg_arcs, nullptr, p.A, p.A, 2 * p.S};
+            }
+        } else {                     // [nodes[:, :d_t] | state | agg_state | agg_nodes_0.. | agg_arcs]  (CompositeGNN.py:224)
+            const int dt = a.type_dim_label[t];
+            tp.rows = a.type_nodes ? a.type_nodes + a.type_offsets[t] : nullptr;
+            tp.count = a.type_offsets[t + 1] - a.type_offsets[t];
+            tp.wrow_state = dt; tp.wrow_agg = dt + p.S;
+            if (dt > 0) tp.cseg[tp.ncseg++] = gnn::Seg{a.nodes, tp.rows, a.ld_nodes, dt, 0};
+            if (sum_dt > 0) tp.cseg[tp.ncseg++] = gnn::Seg{p.agg_nodes, tp.rows, p.ld_agg_nodes, sum_dt, dt + 2 * p.S};
+            if (p.A > 0) tp.cseg[tp.ncseg++] = gnn::Seg{p.agg_arcs, tp.rows, p.A, p.A, dt + 2 * p.S + sum_dt};
+        }
+    }
+    return 0;
+}
+
+// one un-fused iteration: agg = A^T state ; state_new = net_state([state | agg] + C) per type ; predicate.
+int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src, float *dst,
+                      int *flag_next, float *k_out, float k_val, hipStream_t st) {
+    TRY(launch_aggregate(gate, a.adjacency, src, p.SP, p.S, p.agg, p.SP, st));
+    for (int t = 0; t < p.T; ++t) {
+        const TypePlan &tp = p.tp[t];
+        if (tp.count == 0) continue;
+        MlpRun r;
+        r.mlp = tp.net; r.Wf = tp.Wf; r.bf = tp.bf;
+        r.nseg = 2;
+        r.segs[0] = gnn::Seg{src, tp.rows, p.SP, p.S, tp.wrow_state};
+        r.segs[1] = gnn::Seg{p.agg, tp.rows, p.SP, p.S, tp.wrow_agg};
+        r.addend = p.C; r.ld_add = p.ldC; r.add_rowidx = tp.rows;
+        r.M = tp.count;
+        r.hid[0] = p.hid[0]; r.hid[1] = p.hid[1]; r.ld_hid = p.ld_hid;
+        r.Y = dst; r.ldy = p.SP; r.out_rowidx = tp.rows;
+        r.gate = gate;
+        TRY(run_mlp(r, st));
+    }
+    if (flag_next) TRY(launch_converge(gate, dst, src, p.N, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
+    return 0;
+}
+
+int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
+    // BN folding of every first layer
+    for (int t = 0; t < p.T; ++t) TRY(launch_fold(a.net_state[t], p.tp[t].Wf, p.tp[t].bf, st));
+    TRY(launch_fold(a.net_output, p.Wf_out, p.bf_out, st));
+    // ArcNode scatter-add (GNN.py:254) and neighbour-label aggregates (GNN.py:258 / CompositeGNN.py:251)
+    if (p.A > 0) TRY(launch_aggregate(nullptr, a.arcnode, a.arc_labels, a.ld_arcs, p.A, p.agg_arcs, p.A, st));
+    if (!p.composite) {
+        if (a.state_dim > 0) TRY(launch_aggregate(nullptr, a.adjacency, a.nodes, a.ld_nodes, p.L, p.agg_nodes, p.ld_agg_nodes, st));
+    } else {
+        int col = 0;
+        for (int t = 0; t < p.T; ++t) {
+            const int dt = a.type_dim_label[t];
+            if (dt > 0) TRY(launch_aggregate(nullptr, a.composite_adjacency[t], a.nodes, a.ld_nodes, dt, p.agg_nodes + col, p.ld_agg_nodes, st));
+            col += dt;
+        }
+    }
+    // C[j] = const segments . Wf[const rows] + bf     (written row-scattered per type; every node has one type)
+    for (int t = 0; t < p.T; ++t) {
+        const TypePlan &tp = p.tp[t];
+        if (tp.count == 0) continue;
+        gnn::SegDenseArgs d;
+        memset(&d, 0, sizeof(d));
+        d.M = tp.count; d.H = tp.net->units[0];
+        d.nseg = tp.ncseg;
+        for (int s = 0; s < tp.ncseg; ++s) d.seg[s] = tp.cseg[s];
+        d.W = tp.Wf; d.ldw = d.H; d.bias = tp.bf; d.act = GNN_ACT_LINEAR;
+        d.Y = p.C; d.ldy = p.ldC; d.out_rowidx = tp.rows;
+        TRY(launch_segdense(d, st));
+    }
+    return 0;
+}
+
+__global__ void k_arc_endpoints(const int *__restrict__ out_index, const int *__restrict__ arc_src,
+                                const int *__restrict__ arc_dst, int M, int *__restrict__ idx_src, int *__restrict__ idx_dst) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < M) { const int e = out_index[m]; idx_src[m] = arc_src[e]; idx_dst[m] = arc_dst[e]; }
+}
+
+int output_stage(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
+    if (p.M == 0) return 0;
+    const bool with_labels = !p.composite && a.state_dim > 0;
+    MlpRun r;
+    r.mlp = &a.net_output; r.Wf = p.Wf_out; r.bf = p.bf_out;
+    r.M = p.M;
+    int wrow = 0;
+    if (a.focus == GNN_FOCUS_ARC) {
+        k_arc_endpoints<<<cdiv(p.M, 256), 256, 0, st>>>(a.out_index, a.arc_src, a.arc_dst, p.M, p.idx_src, p.idx_dst);
+        LAUNCH_OK();
+        const int *ends[2] = {p.idx_src, p.idx_dst};
+        for (int s = 0; s < 2; ++s) {
+            r.segs[r.nseg++] = gnn::Seg{a.state_out, ends[s], p.S, p.S, wrow}; wrow += p.S;
+            if (with_labels) { r.segs[r.nseg++] = gnn::Seg{a.nodes, ends[s], a.ld_nodes, p.L, wrow}; wrow += p.L; }
+        }
+        if (p.A > 0) r.segs[r.nseg++] = gnn::Seg{a.arc_labels, a.out_index, a.ld_arcs, p.A, wrow};
+    } else {
+        r.segs[r.nseg++] = gnn::Seg{a.state_out, a.out_index, p.S, p.S, 0};
+        if (with_labels) r.segs[r.nseg++] = gnn::Seg{a.nodes, a.out_index, a.ld_nodes, p.L, p.S};
+    }
+    r.hid[0] = p.ohid[0]; r.hid[1] = p.ohid[1]; r.ld_hid = p.ld_ohid;
+    if (a.focus == GNN_FOCUS_GRAPH) { r.Y = p.out_nodes; r.ldy = p.Tout; }
+    else                            { r.Y = a.out;       r.ldy = p.Tout; }
+    TRY(run_mlp(r, st));
+    if (a.focus == GNN_FOCUS_GRAPH)   // GNN.py:345: NodeGraph^T . out_nodes
+        TRY(launch_aggregate(nullptr, a.nodegraph, p.out_nodes, p.Tout, p.Tout, a.out, p.Tout, st));
+    return 0;
+}
+
+bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
+    if (a.flags & GNN_FLAG_UNFUSED) return false;
+    if (p.SP > 64) return false;   // LDS: [64 x 2SP] tile + [2SP x SP] weights must leave room for 2 workgroups per CU
+    for (int t = 0; t < p.T; ++t)
+        if (a.net_state[t].n_layers != 1 || a.net_state[t].activation[0] == GNN_ACT_SOFTMAX) return false;
+    return true;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+extern "C" {
+
+const char *gnn_last_error(void) { return g_err; }
+int gnn_abi_version(void) { return GNN_ABI_VERSION; }
+
+size_t gnn_loop_workspace_bytes(const gnn_loop_args_t *args) {
+    if (!args) { fail("args is NULL"); return 0; }
+    Plan p;
+    if (make_plan(*args, nullptr, p, false)) return 0;
+    return p.bytes;
+}
+
+int gnn_loop_forward(const gnn_loop_args_t *args) {
+    if (!args) return fail("args is NULL");
+    const gnn_loop_args_t &a = *args;
+    Plan p;
+    TRY(make_plan(a, a.workspace, p, true));
+    if (!a.workspace || a.workspace_bytes < p.bytes) return fail("workspace too small: %zu < %zu bytes", a.workspace_bytes, p.bytes);
+    if (((uintptr_t)a.workspace & 255) != 0) return fail("workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)a.stream;
+
+    HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (a.max_iteration + 2), st));
+    HIP_OK(hipMemsetAsync(a.k_out, 0, sizeof(float), st));
+    TRY(setup_constants(a, p, st));
+
+    // state_0 (GNN.py:256-259) into the padded buffer; state_old_0 = ones is implicit in the first predicate (:261)
+    if (a.state_dim > 0) TRY(launch_copy2d(nullptr, a.state0, p.S, p.buf[0], p.SP, p.N, p.S, p.SP, st));
+    else                 TRY(launch_copy2d(nullptr, a.nodes, a.ld_nodes, p.buf[0], p.SP, p.N, p.S, p.SP, st));
+    if (p.SP != p.S) HIP_OK(hipMemsetAsync(p.buf[1], 0, sizeof(float) * (size_t)p.N * p.SP, st));
+    TRY(launch_converge(nullptr, p.buf[0], nullptr, p.N, p.S, p.SP, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
+
+    const bool fused = can_fuse(a, p);
+    const bool no_exit = (a.flags & GNN_FLAG_NO_EARLY_EXIT) != 0;
+    for (int it = 0; it < a.max_iteration; ++it) {
+        const int *gate = no_exit ? nullptr : p.flags + it;
+        const float *src = p.buf[it & 1];
+        float *dst = p.buf[(it + 1) & 1];
+        if (fused) FUSED_OK(gnn::launch_state_fused(a, p.T, p.N, p.S, p.SP, gate, src, dst, p.C, p.ldC,
+                                               [&](int t) { return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg, (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0]}; },
+                                               p.flags + it + 1, a.k_out, (float)(it + 1), st));
+        else       TRY(iteration_unfused(a, p, gate, src, dst, p.flags + it + 1, a.k_out, (float)(it + 1), st));
+    }
+
+    // converged state -> caller's compact [N, S] buffer; k (device) tells which of the two buffers holds it
+    {
+        const long total = (long)p.N * p.S;
+        if (total > 0) {
+            gnn::k_select_state<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, st>>>(a.k_out, p.buf[0], p.buf[1], p.SP, a.state_out, p.S, p.N, p.S);
+            LAUNCH_OK();
+        }
+    }
+    TRY(output_stage(a, p, st));
+    return 0;
+}
+
+int gnn_aggregate(const gnn_csr_t *csr, const float *X, int32_t ldx, int32_t F, float *out, int32_t ldo, void *stream) {
+    if (!csr) return fail("csr is NULL");
+    if (F < 0 || ldx < F || ldo < F) return fail("bad F / leading dimensions");
+    TRY(check_csr(*csr, "csr", csr->n_dst, csr->n_src));
+    if (csr->n_dst > 0 && F > 0 && (!X || !out)) return fail("X / out is NULL");
+    return launch_aggregate(nullptr, *csr, X, ldx, F, out, ldo, (hipStream_t)stream);
+}
+
+size_t gnn_mlp_workspace_bytes(const gnn_mlp_t *mlp, int32_t M) {
+    if (!mlp || check_mlp(*mlp, "mlp", false)) return 0;
+    Carver c(nullptr);
+    c.take<float>((size_t)mlp->in_dim * mlp->units[0]);
+    c.take<float>(mlp->units[0]);
+    const int h = max_units(*mlp);
+    c.take<float>((size_t)std::max(M, 1) * h);
+    c.take<float>((size_t)std::max(M, 1) * h);
+    return (c.off + 255) & ~(size_t)255;
+}
+
+int gnn_mlp_forward(const gnn_mlp_t *mlp, const float *X, int32_t ldx, int32_t M, float *Y, int32_t ldy,
+                    void *workspace, size_t workspace_bytes, void *stream) {
+    if (!mlp) return fail("mlp is NULL");
+    TRY(check_mlp(*mlp, "mlp", true));
+    if (M < 0 || ldx < mlp->in_dim || ldy < mlp->units[mlp->n_layers - 1]) return fail("bad M / leading dimensions");
+    if (M > 0 && (!X || !Y)) return fail("X / Y is NULL");
+    const size_t need = gnn_mlp_workspace_bytes(mlp, M);
+    if (!workspace || workspace_bytes < need) return fail("workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    Carver c(workspace);
+    float *Wf = c.take<float>((size_t)mlp->in_dim * mlp->units[0]);
+    float *bf = c.take<float>(mlp->units[0]);
+    const int h = max_units(*mlp);
+    MlpRun r;
+    r.hid[0] = c.take<float>((size_t)std::max(M, 1) * h);
+    r.hid[1] = c.take<float>((size_t)std::max(M, 1) * h);
+    r.ld_hid = h;
+    TRY(launch_fold(*mlp, Wf, bf, st));
+    r.mlp = mlp; r.Wf = Wf; r.bf = bf;
+    r.nseg = 1;
+    r.segs[0] = gnn::Seg{X, nullptr, ldx, mlp->in_dim, 0};
+    r.M = M; r.Y = Y; r.ldy = ldy;
+    return run_mlp(r, st);
+}
+
+int gnn_converged(const float *state, const float *state_old, int32_t n, int32_t dim, int32_t ld, float threshold,
+                  int32_t *flag, void *stream) {
+    if (n < 0 || dim < 1 || ld < dim) return fail("bad n / dim / ld");
+    if (!flag || (n > 0 && !state)) return fail("state / flag is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
+    return launch_converge(nullptr, state, state_old, n, dim, ld, ld, threshold, flag, nullptr, 0.f, st);
+}
+
+int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *state_out, int32_t *flag_out) {
+    if (!args) return fail("args is NULL");
+    const gnn_loop_args_t &a = *args;
+    if (a.composite) return fail("gnn_state_step: homogeneous graphs only");
+    Plan p;
+    TRY(make_plan(a, a.workspace, p, false));
+    TRY(check_csr(a.adjacency, "adjacency", p.N, p.N));
+    TRY(check_csr(a.arcnode, "arcnode", p.N, p.E));
+    TRY(check_mlp(a.net_state[0], "net_state", true));
+    if (!state_in || !state_out) return fail("state_in / state_out is NULL");
+    if (!a.workspace || a.workspace_bytes < p.bytes) return fail("workspace too small: %zu < %zu bytes", a.workspace_bytes, p.bytes);
+    hipStream_t st = (hipStream_t)a.stream;
+    TRY(setup_constants(a, p, st));
+    TRY(launch_copy2d(nullptr, state_in, p.S, p.buf[0], p.SP, p.N, p.S, p.SP, st));
+    if (p.SP != p.S) HIP_OK(hipMemsetAsync(p.buf[1], 0, sizeof(float) * (size_t)p.N * p.SP, st));
+    if (flag_out) HIP_OK(hipMemsetAsync(flag_out, 0, sizeof(int32_t), st));
+    if (can_fuse(a, p))
+        FUSED_OK(gnn::launch_state_fused(a, p.T, p.N, p.S, p.SP, nullptr, p.buf[0], p.buf[1], p.C, p.ldC,
+                                    [&](int t) { return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg, (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0]}; },
+                                    flag_out, nullptr, 0.f, st));
+    else
+        TRY(iteration_unfused(a, p, nullptr, p.buf[0], p.buf[1], flag_out, nullptr, 0.f, st));
+    return launch_copy2d(nullptr, p.buf[1], p.SP, state_out, p.S, p.N, p.S, p.S, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+// General (un-fused) gfx950 kernels of the message-passing loop: CSR aggregate, segmented dense layer on f32 MFMA,
+// convergence predicate, softmax, BN folding, small copies.  Every kernel takes an optional `gate` word: when it
+// points at 0 the launch returns immediately — that is how the host enqueues `max_iteration` iterations with no
+// host synchronisation while the device stops doing work once the predicate (reference GNN.py:196-214) says stop.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gnnloop.h"
+
+namespace gnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool gate_closed(const int *gate) { return gate != nullptr && *gate == 0; }
+
+// Keras activations (elementwise ones; softmax is a row kernel).  selu follows TF's `scale*alpha*(exp(x)-1)`.
+__device__ __forceinline__ float activate(int act, float x) {
+    switch (act) {
+        case GNN_ACT_RELU: return fmaxf(x, 0.0f);
+        case GNN_ACT_SELU: return x > 0.0f ? 1.0507009873554805f * x
+                                           : (1.0507009873554805f * 1.6732632423543772f) * (expf(x) - 1.0f);
+        case GNN_ACT_TANH: return tanhf(x);
+        case GNN_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+        case GNN_ACT_ELU: return x > 0.0f ? x : expf(x) - 1.0f;
+        case GNN_ACT_SOFTPLUS: return x > 20.0f ? x : log1pf(expf(x));
+        default: return x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out[j, :F] = row_scale[j] * sum_e w_e X[src_e, :F]     (tf.sparse.sparse_dense_matmul(A, X, adjoint_a=True))
+// G lanes walk one destination row together: lane f reads column f of every source row (coalesced per row), the
+// per-destination sum runs in ascending-source order like the reference's CPU kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int G>
+__global__ void __launch_bounds__(256)
+k_aggregate(const int *gate, int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src,
+            const float *__restrict__ w, const float *__restrict__ row_scale, const float *__restrict__ X, int ldx,
+            int F, float *__restrict__ out, int ldo) {
+    if (gate_closed(gate)) return;
+    const int lane = threadIdx.x % G;
+    const int groups = blockDim.x / G;
+    for (int j = blockIdx.x * groups + threadIdx.x / G; j < n_dst; j += gridDim.x * groups) {
+        const int beg = rowptr[j], end = rowptr[j + 1];
+        const float scale = row_scale ? row_scale[j] : 1.0f;
+        for (int f = lane; f < F; f += G) {
+            float acc = 0.0f;
+            if (w) {
+                for (int e = beg; e < end; ++e) acc = fmaf(w[e], X[(size_t)src[e] * ldx + f], acc);
+            } else {
+                for (int e = beg; e < end; ++e) acc += X[(size_t)src[e] * ldx + f];
+            }
+            out[(size_t)j * ldo + f] = acc * scale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Segmented dense layer on the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32, k-ordered fma chain):
+//   Y[orow(m), :H] = act( sum_s X_s[row_s(m), :] . W[wrow_s : wrow_s + width_s, :H] + bias + addend[arow(m), :H] )
+// The input row is the *virtual* concatenation of up to 6 column segments, each with its own base pointer, leading
+// dimension and optional row-index list, so neither the reference's tf.concat (GNN.py:231, :241, :327) nor its
+// boolean_mask / gather (GNN.py:242, :322) is ever materialised.
+// ---------------------------------------------------------------------------------------------------------------------
+#define GNN_MAX_SEGS 6
+struct Seg {
+    const float *ptr;
+    const int *rowidx;   // nullable: row of `ptr` for logical row m is rowidx ? rowidx[m] : m
+    int ld, width, wrow;
+};
+struct SegDenseArgs {
+    const int *gate;
+    int M, H, nseg;
+    Seg seg[GNN_MAX_SEGS];
+    const float *W; int ldw;
+    const float *bias;
+    const float *addend; int ld_add; const int *add_rowidx;
+    int act;
+    float *Y; int ldy; const int *out_rowidx;
+};
+
+constexpr int SD_TM = 64, SD_TN = 64, SD_KC = 32, SD_LDX = 34, SD_LDW = 80;
+
+__global__ void __launch_bounds__(256) k_segdense(SegDenseArgs a) {
+    if (gate_closed(a.gate)) return;
+    __shared__ float Xs[SD_TM * SD_LDX];
+    __shared__ float Ws[SD_KC * SD_LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * SD_TM;
+
+    for (int n0 = 0; n0 < a.H; n0 += SD_TN) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int s = 0; s < a.nseg; ++s) {
+            const Seg sg = a.seg[s];
+            for (int k0 = 0; k0 < sg.width; k0 += SD_KC) {
+                const int kc = min(SD_KC, sg.width - k0);
+                for (int i = tid; i < SD_TM * SD_KC; i += 256) {
+                    const int rr = i / SD_KC, cc = i % SD_KC, m = m0 + rr;
+                    float v = 0.0f;
+                    if (m < a.M && cc < kc) {
+                        const size_t row = sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m;
+                        v = sg.ptr[row * sg.ld + k0 + cc];
+                    }
+                    Xs[rr * SD_LDX + cc] = v;
+                }
+                for (int i = tid; i < SD_KC * SD_TN; i += 256) {
+                    const int kk = i / SD_TN, nn = i % SD_TN;
+                    float v = 0.0f;
+                    if (kk < kc && n0 + nn < a.H) v = a.W[(size_t)(sg.wrow + k0 + kk) * a.ldw + n0 + nn];
+                    Ws[kk * SD_LDW + nn] = v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int s4 = 0; s4 < SD_KC / 4; ++s4) {
+                    const float av = Xs[(16 * wave + r) * SD_LDX + 4 * s4 + g];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float bv = Ws[(4 * s4 + g) * SD_LDW + 16 * c + r];
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[c], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = n0 + 16 * c + r;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = m0 + 16 * wave + 4 * g + reg;
+                if (m < a.M && col < a.H) {
+                    float v = acc[c][reg];
+                    if (a.bias) v += a.bias[col];
+                    if (a.addend) {
+                        const size_t ar = a.add_rowidx ? (size_t)a.add_rowidx[m] : (size_t)m;
+                        v += a.addend[ar * a.ld_add + col];
+                    }
+                    const size_t orow = a.out_rowidx ? (size_t)a.out_rowidx[m] : (size_t)m;
+                    a.Y[orow * a.ldy + col] = activate(a.act, v);
+                }
+            }
+        }
+    }
+}
+
+// row softmax in place (Keras 'softmax' activation of the output network, starter.py:28): max-subtracted.
+__global__ void __launch_bounds__(256)
+k_softmax_rows(const int *gate, float *Y, int M, int H, int ldy, const int *rowidx) {
+    if (gate_closed(gate)) return;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float *row = Y + (rowidx ? (size_t)rowidx[m] : (size_t)m) * ldy;
+    float mx = row[0];
+    for (int h = 1; h < H; ++h) mx = fmaxf(mx, row[h]);
+    float sum = 0.0f;
+    for (int h = 0; h < H; ++h) { const float e = expf(row[h] - mx); row[h] = e; sum += e; }
+    for (int h = 0; h < H; ++h) row[h] = row[h] / sum;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// convergence predicate (GNN.py:196-212): flag |= any_j( sqrt(sum (s-so)^2) > thr * sqrt(sum so^2) ), strict.
+// 16 lanes per node.  `so == nullptr` means state_old = ones (GNN.py:261).  Optionally records k (float, Q6).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_converge(const int *gate, const float *__restrict__ s, const float *__restrict__ so, int N, int S, int ld_s,
+           int ld_so, float thr, int *flag_out, float *k_out, float k_val) {
+    if (gate_closed(gate)) return;
+    const int lane = threadIdx.x & 15;
+    const int groups = blockDim.x / 16;
+    int any = 0;
+    for (int j0 = blockIdx.x * groups; j0 < N; j0 += gridDim.x * groups) {
+        const int j = j0 + threadIdx.x / 16;
+        float d2 = 0.0f, n2 = 0.0f;
+        if (j < N) {
+            for (int f = lane; f < S; f += 16) {
+                const float o = so ? so[(size_t)j * ld_so + f] : 1.0f;
+                const float d = s[(size_t)j * ld_s + f] - o;
+                d2 = fmaf(d, d, d2);
+                n2 = fmaf(o, o, n2);
+            }
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            d2 += __shfl_xor(d2, off, 16);
+            n2 += __shfl_xor(n2, off, 16);
+        }
+        if (j < N && sqrtf(d2) > thr * sqrtf(n2)) any = 1;
+    }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) {
+        if (any) atomicOr(flag_out, 1);
+        if (blockIdx.x == 0 && k_out) *k_out = k_val;
+    }
+}
+
+// Fold an inference BatchNormalization into the Dense layer that follows it (Keras: y = x*inv + (beta - mean*inv),
+// inv = gamma / sqrt(var + eps)):  Wf[k][h] = inv[k] * W[k][h],  bf[h] = b[h] + sum_k (beta[k] - mean[k]*inv[k]) W[k][h].
+__global__ void __launch_bounds__(256)
+k_fold_bn(const float *__restrict__ W, const float *__restrict__ b, int K, int H, const float *gamma,
+          const float *beta, const float *mean, const float *var, float eps, float *__restrict__ Wf,
+          float *__restrict__ bf) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    float acc = b ? b[h] : 0.0f;
+    for (int k = 0; k < K; ++k) {
+        float inv = 1.0f, shift = 0.0f;
+        if (gamma) {
+            inv = gamma[k] / sqrtf(var[k] + eps);
+            shift = beta[k] - mean[k] * inv;
+        }
+        const float wv = W[(size_t)k * H + h];
+        Wf[(size_t)k * H + h] = wv * inv;
+        acc = fmaf(shift, wv, acc);
+    }
+    bf[h] = acc;
+}
+
+// dst[i, :width] = src[i, :width] with independent leading dimensions; pads dst columns [width, ld_dst_fill) with 0.
+__global__ void __launch_bounds__(256)
+k_copy2d(const int *gate, const float *__restrict__ src, int ld_src, float *__restrict__ dst, int ld_dst, int rows,
+         int width, int fill_to) {
+    if (gate_closed(gate)) return;
+    const size_t total = (size_t)rows * fill_to;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t rr = i / fill_to;
+        const int cc = (int)(i % fill_to);
+        dst[rr * ld_dst + cc] = cc < width ? src[rr * ld_src + cc] : 0.0f;
+    }
+}
+
+// state_out = (k odd ? buf1 : buf0): picks the buffer that holds the state after k iterations, k read on device.
+__global__ void __launch_bounds__(256)
+k_select_state(const float *k_ptr, const float *__restrict__ buf0, const float *__restrict__ buf1, int ld_buf,
+               float *__restrict__ dst, int ld_dst, int rows, int width) {
+    const int k = (int)(*k_ptr);
+    const float *src = (k & 1) ? buf1 : buf0;
+    const size_t total = (size_t)rows * width;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t rr = i / width;
+        const int cc = (int)(i % width);
+        dst[rr * ld_dst + cc] = src[rr * ld_buf + cc];
+    }
+}
+
+}  // namespace gnn

@@ -1,0 +1,168 @@
+"""Sparse operand of the message-passing loop: the stand-in for `tf.SparseTensor` on the MI355X path.
+
+The reference moves three sparse matrices through its sequencer as `(indices[nnz,2] i64, values[nnz,1] f32,
+dense_shape[2] i64)` triples (reference `GNN/Sequencers/GraphSequencers.py:108-110`) and rebuilds a
+`tf.SparseTensor` from each in `process_inputs` (`GNN/Models/GNN.py:181-193`). Every use on the hot path is
+`sparse_dense_matmul(A, X, adjoint_a=True)` = AᵀX, i.e. a *gather by destination*. `SparseMatrix` keeps the same COO
+triple for API compatibility and caches, built once per batch, what the HIP kernels actually walk: the CSR of Aᵀ
+(row pointer by destination, int32 source ids, optional per-arc weights) resident in HBM.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def default_device() -> torch.device:
+    """`cuda:<current>` on a GPU box, CPU otherwise (host-logic tests only: the kernels never run on CPU)."""
+    if torch.cuda.is_available():
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+class CSRByDestination:
+    """CSR of Aᵀ for a COO matrix A (rows = sources / arcs, columns = destinations).
+
+    rowptr : int32 [n_dst + 1]
+    src    : int32 [nnz]   A-row index of every entry, grouped by destination; inside a destination the entries keep
+                           the row-major (`tf.sparse.reorder`) order of A, i.e. ascending source — the accumulation
+                           order of TF's CPU kernel for `adjoint_a=True`.
+    w      : float32 [nnz] or None. None means "every entry of destination j has the same value row_scale[j]"
+             (true for 'sum', 'average' and 'normalized': reference `graph_class.py:105-121`), which saves 4 B per arc
+             per iteration of HBM traffic.
+    row_scale : float32 [n_dst] or None (None with w None = all ones).
+    """
+    __slots__ = ('rowptr', 'src', 'w', 'row_scale', 'n_src', 'n_dst', 'nnz', 'max_degree')
+
+    def __init__(self, rowptr, src, w, row_scale, n_src, n_dst):
+        self.rowptr, self.src, self.w, self.row_scale = rowptr, src, w, row_scale
+        self.n_src, self.n_dst, self.nnz = int(n_src), int(n_dst), int(len(src))
+        self.max_degree = int(np.max(np.diff(rowptr))) if n_dst > 0 and len(rowptr) > 1 else 0
+
+    @classmethod
+    def from_coo(cls, rows, cols, values, shape, uniform_rows: bool = True):
+        rows = np.asarray(rows, dtype=np.int64).reshape(-1)
+        cols = np.asarray(cols, dtype=np.int64).reshape(-1)
+        values = np.asarray(values, dtype=np.float32).reshape(-1)
+        n_src, n_dst = int(shape[0]), int(shape[1])
+        if len(rows) and (rows.min() < 0 or rows.max() >= n_src or cols.min() < 0 or cols.max() >= n_dst):
+            raise ValueError('sparse indices out of range of dense_shape')
+        if n_src >= 2 ** 31 or len(rows) >= 2 ** 31:
+            raise ValueError('graph too large for int32 ids')
+        order = np.argsort(cols, kind='stable')
+        counts = np.bincount(cols, minlength=n_dst)
+        rowptr = np.zeros(n_dst + 1, dtype=np.int64)
+        np.cumsum(counts, out=rowptr[1:])
+        src = rows[order].astype(np.int32)
+        w = values[order]
+        row_scale = None
+        if uniform_rows and len(w):
+            first = np.ones(n_dst, dtype=np.float32)
+            nz = counts > 0
+            first[nz] = w[rowptr[:-1][nz]]
+            if np.array_equal(w, np.repeat(first, counts)):
+                row_scale = None if np.all(first == 1) else first
+                w = None
+        elif uniform_rows:
+            w = None
+        return cls(rowptr.astype(np.int32), src, w, row_scale, n_src, n_dst)
+
+
+class SparseMatrix:
+    """COO triple with `tf.SparseTensor`'s attribute names (`indices`, `values`, `dense_shape`/`shape`), entries in
+    canonical row-major order, plus the cached by-destination CSR (host and device copies)."""
+
+    def __init__(self, indices, values, dense_shape, *, reorder: bool = True):
+        indices = np.asarray(indices, dtype=np.int64).reshape(-1, 2)
+        values = np.asarray(values, dtype=np.float32).reshape(-1)
+        if len(indices) != len(values):
+            raise ValueError('indices / values length mismatch')
+        if reorder and len(values):
+            order = np.lexsort((indices[:, 1], indices[:, 0]))
+            if not np.array_equal(order, np.arange(len(order))):
+                indices, values = indices[order], values[order]
+        self.indices = indices
+        self.values = values
+        self.dense_shape = tuple(int(i) for i in np.asarray(dense_shape).reshape(-1))
+        self._csr = None
+        self._dev = {}
+
+    # tf.SparseTensor-like surface -----------------------------------------------------------------------------------
+    @property
+    def shape(self):
+        return self.dense_shape
+
+    @property
+    def nnz(self):
+        return len(self.values)
+
+    @classmethod
+    def from_scipy(cls, coo):
+        """Reference `GraphTensor.COO2SparseTensor` (`graph_class.py:551-560`): empty matrix -> indices (0, 2)."""
+        coo = coo.tocoo()
+        if coo.size > 0:
+            idx = np.stack([coo.row, coo.col], axis=1)
+        else:
+            idx = np.zeros((0, 2), dtype=np.int64)
+        return cls(idx, coo.data, coo.shape)
+
+    @classmethod
+    def from_triple(cls, triple):
+        """Accept what the sequencer emits: `(indices, values[nnz,1], dense_shape)`; torch or numpy."""
+        if isinstance(triple, SparseMatrix):
+            return triple
+        if isinstance(triple, SparseTriple):
+            return triple.matrix
+        to_np = lambda x: x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+        idx, val, shp = (to_np(t) for t in triple)
+        return cls(idx, val.reshape(-1), shp.reshape(-1))
+
+    def to_scipy(self):
+        from scipy.sparse import coo_matrix
+        return coo_matrix((self.values, (self.indices[:, 0], self.indices[:, 1])), shape=self.dense_shape,
+                          dtype=np.float32)
+
+    def copy(self):
+        return SparseMatrix(self.indices.copy(), self.values.copy(), self.dense_shape, reorder=False)
+
+    # by-destination CSR ---------------------------------------------------------------------------------------------
+    def csr(self, uniform_rows: bool = True) -> CSRByDestination:
+        if self._csr is None or self._csr[0] != uniform_rows:
+            self._csr = (uniform_rows, CSRByDestination.from_coo(self.indices[:, 0], self.indices[:, 1], self.values,
+                                                                 self.dense_shape, uniform_rows))
+        return self._csr[1]
+
+    def device_csr(self, device=None, uniform_rows: bool = True):
+        """dict(rowptr, src, w|None, row_scale|None) of torch tensors on `device`, uploaded once and cached."""
+        device = torch.device(device) if device is not None else default_device()
+        key = (str(device), uniform_rows)
+        if key not in self._dev:
+            c = self.csr(uniform_rows)
+            up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
+            self._dev[key] = dict(rowptr=up(c.rowptr), src=up(c.src), w=up(c.w), row_scale=up(c.row_scale),
+                                  n_src=c.n_src, n_dst=c.n_dst, nnz=c.nnz, max_degree=c.max_degree)
+        return self._dev[key]
+
+    def triple(self, device=None):
+        """The `(indices, values[...,None], dense_shape)` tuple of `GraphSequencers.py:110`, carrying this matrix."""
+        device = torch.device(device) if device is not None else default_device()
+        key = ('triple', str(device))
+        if key not in self._dev:
+            self._dev[key] = SparseTriple(self, device)
+        return self._dev[key]
+
+    def __repr__(self):
+        return f'SparseMatrix(shape={self.dense_shape}, nnz={self.nnz})'
+
+
+class SparseTriple(tuple):
+    """3-tuple `(indices i64[nnz,2], values f32[nnz,1], dense_shape i64[2])` exactly as the reference sequencer emits
+    it, that also remembers the `SparseMatrix` it came from so the model does not rebuild the CSR per call."""
+
+    def __new__(cls, matrix: SparseMatrix, device=None):
+        device = torch.device(device) if device is not None else default_device()
+        self = super().__new__(cls, (torch.from_numpy(matrix.indices).to(device),
+                                     torch.from_numpy(matrix.values).to(device)[..., None],
+                                     torch.tensor(matrix.dense_shape, dtype=torch.int64)))
+        self.matrix = matrix
+        return self

@@ -1,0 +1,157 @@
+/* gnnloop.h — C ABI of libgnnloop.so: the MI355X (gfx950) implementation of GNNkeras' convergent message-passing loop.
+ *
+ * Drop-in boundary.  The reference has no FFI: its seam is the Python method
+ * `GNNnodeBased.Loop` (reference GNN/Models/GNN.py:245-274) and the TensorFlow ops it dispatches.  Each entry point
+ * below replaces one of those call sites and is what a binding for this path binds (ctypes stub: INTEGRATION.md;
+ * in-tree binding: gnnkeras_amd/_native.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM of the current HIP device) unless marked HOST;
+ *   - inputs are borrowed and never written; outputs are caller-allocated;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing in this library synchronises the
+ *     host with the device: the loop runs `max_iteration` gated launches and the iteration count comes back as a
+ *     device scalar;
+ *   - all arithmetic is float32 (tf.keras.backend.floatx(), reference graph_class.py:43); ids are int32;
+ *   - return value: 0 = ok, non-zero = error, message via gnn_last_error() (thread-local). Never aborts.
+ */
+#ifndef GNNLOOP_H
+#define GNNLOOP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNN_ABI_VERSION 1
+
+/* Keras activation names accepted by the reference MLP builder (GNN/Models/MLP.py:16). */
+enum gnn_activation {
+    GNN_ACT_LINEAR = 0, GNN_ACT_RELU = 1, GNN_ACT_SELU = 2, GNN_ACT_TANH = 3, GNN_ACT_SIGMOID = 4,
+    GNN_ACT_ELU = 5, GNN_ACT_SOFTPLUS = 6, GNN_ACT_SOFTMAX = 7
+};
+
+/* problem focus: GNNnodeBased / GNNarcBased / GNNgraphBased (GNN.py:8, :312, :336). */
+enum gnn_focus { GNN_FOCUS_NODE = 0, GNN_FOCUS_ARC = 1, GNN_FOCUS_GRAPH = 2 };
+
+enum gnn_flags {
+    GNN_FLAG_UNFUSED = 1,      /* run the iteration as separate aggregate / dense / predicate kernels            */
+    GNN_FLAG_NO_EARLY_EXIT = 2 /* debugging: ignore the convergence predicate (always max_iteration iterations)  */
+};
+
+/* A sparse operator A (n_src x n_dst, COO in the reference: tf.SparseTensor) stored as the CSR of its transpose:
+ * the form in which `tf.sparse.sparse_dense_matmul(A, X, adjoint_a=True)` (GNN.py:228,254,258,345) walks it.
+ * Entry values are either per entry (`w`), or one value per destination (`row_scale`), or all 1 (both NULL). */
+typedef struct gnn_csr {
+    int32_t n_dst;            /* columns of A = rows of the result                                              */
+    int32_t n_src;            /* rows of A    = rows of the dense operand                                       */
+    int32_t nnz;
+    const int32_t *rowptr;    /* [n_dst + 1]                                                                    */
+    const int32_t *src;       /* [nnz] row of A (source node / arc id), ascending inside a destination          */
+    const float *w;           /* [nnz] or NULL                                                                  */
+    const float *row_scale;   /* [n_dst] or NULL                                                                */
+} gnn_csr_t;
+
+/* Keras Sequential built by the reference MLP() (MLP.py:12-78): optional BatchNormalization first, then Dense x n.
+ * Arrays are in Keras get_weights() order: BN -> gamma, beta, moving_mean, moving_variance; Dense -> kernel
+ * (row-major [in][out]), bias [out]. */
+#define GNN_MAX_LAYERS 8
+typedef struct gnn_mlp {
+    int32_t in_dim;
+    int32_t n_layers;
+    int32_t units[GNN_MAX_LAYERS];
+    int32_t activation[GNN_MAX_LAYERS];
+    const float *kernel[GNN_MAX_LAYERS];
+    const float *bias[GNN_MAX_LAYERS];
+    int32_t has_bn;
+    float bn_eps;
+    const float *bn_gamma, *bn_beta, *bn_mean, *bn_var;   /* [in_dim] each */
+} gnn_mlp_t;
+
+#define GNN_MAX_TYPES 8
+/* Whole forward pass of one (merged) graph.
+ * Homogeneous: replaces GNNnodeBased.Loop (GNN.py:245-274), GNNarcBased.apply_filters (:317-330),
+ *              GNNgraphBased.Loop (:341-346).            n_types = 1, type_* unused.
+ * Composite:   replaces CompositeGNNnodeBased.Loop (CompositeGNN.py:242-272), arc (:315-327), graph (:338-343).
+ *              n_types = T > 1 (or composite != 0). */
+typedef struct gnn_loop_args {
+    int32_t abi_version;      /* GNN_ABI_VERSION                                                               */
+    int32_t composite;        /* 0 homogeneous input layout, 1 composite input layout                           */
+    /* graph --------------------------------------------------------------------------------------------------- */
+    int32_t n_nodes, n_arcs;
+    int32_t dim_node_label;   /* width of `nodes` (homogeneous: L; composite: max_t d_t)                        */
+    int32_t dim_arc_label;    /* A                                                                              */
+    const float *nodes;       /* [n_nodes, ld_nodes]                                                            */
+    int32_t ld_nodes;
+    const float *arc_labels;  /* &arcs[0][2], row stride ld_arcs (= 2 + A for the reference arcs matrix)        */
+    int32_t ld_arcs;
+    gnn_csr_t adjacency;      /* n_src = n_dst = n_nodes                                                        */
+    gnn_csr_t arcnode;        /* n_src = n_arcs, n_dst = n_nodes                                                */
+    /* composite only ------------------------------------------------------------------------------------------ */
+    int32_t n_types;
+    int32_t type_dim_label[GNN_MAX_TYPES];   /* d_t                                                              */
+    const int32_t *type_nodes;               /* node ids grouped by type, ascending inside a type [n_nodes]      */
+    int32_t type_offsets[GNN_MAX_TYPES + 1]; /* HOST values: type t owns type_nodes[off[t] : off[t+1]]           */
+    gnn_csr_t composite_adjacency[GNN_MAX_TYPES];
+    /* networks ------------------------------------------------------------------------------------------------ */
+    gnn_mlp_t net_state[GNN_MAX_TYPES];      /* [0] for homogeneous                                              */
+    gnn_mlp_t net_output;
+    int32_t state_dim;        /* state_vect_dim d >= 0; 0 => state0 = nodes (GNN.py:259)                        */
+    int32_t max_iteration;
+    float state_threshold;
+    const float *state0;      /* [n_nodes, state_dim] row-major, required when state_dim > 0 (replaces the
+                                 tf.random.normal draw of GNN.py:257)                               */
+    /* output stage --------------------------------------------------------------------------------------------- */
+    int32_t focus;            /* enum gnn_focus                                                                 */
+    int32_t n_out;            /* rows that pass `set_mask & output_mask` (GNN.py:269)                           */
+    const int32_t *out_index; /* [n_out] ascending node ids (node/graph focus) or arc ids (arc focus)           */
+    const int32_t *arc_src;   /* [n_arcs] arc focus: adjacency.indices[:,0] in arcs order                       */
+    const int32_t *arc_dst;   /* [n_arcs] arc focus: adjacency.indices[:,1]                                     */
+    gnn_csr_t nodegraph;      /* graph focus: n_src = n_out, n_dst = #graphs                                    */
+    /* results -------------------------------------------------------------------------------------------------- */
+    float *k_out;             /* [1] iterations executed, float like the reference                  */
+    float *state_out;         /* [n_nodes, S] S = state_dim, or dim of the state when state_dim == 0            */
+    float *out;               /* [n_out, T] (node / arc focus) or [#graphs, T] (graph focus)                    */
+    /* execution ------------------------------------------------------------------------------------------------ */
+    void *workspace;          /* >= gnn_loop_workspace_bytes(args) bytes, 256-byte aligned                      */
+    size_t workspace_bytes;
+    void *stream;
+    int32_t flags;            /* enum gnn_flags                                                                 */
+} gnn_loop_args_t;
+
+const char *gnn_last_error(void);
+int gnn_abi_version(void);
+
+/* bytes of scratch HBM gnn_loop_forward needs for `args` (only sizes / dims of `args` are read). */
+size_t gnn_loop_workspace_bytes(const gnn_loop_args_t *args);
+
+/* (k, state, out) = Loop(...)  — see gnn_loop_args. */
+int gnn_loop_forward(const gnn_loop_args_t *args);
+
+/* out[j, 0:F] = sum_{e in row j} w_e * X[src_e, 0:F]   == tf.sparse.sparse_dense_matmul(A, X, adjoint_a=True)
+ * (ArcNode scatter-add GNN.py:254, label aggregate :258, state aggregate :228, graph pooling :345). */
+int gnn_aggregate(const gnn_csr_t *csr, const float *X, int32_t ldx, int32_t F, float *out, int32_t ldo, void *stream);
+
+/* Y[M, units_last] = Sequential(X[M, in_dim])  — Keras inference call of a reference MLP (GNN.py:234, :273).
+ * workspace: >= gnn_mlp_workspace_bytes(mlp, M). */
+size_t gnn_mlp_workspace_bytes(const gnn_mlp_t *mlp, int32_t M);
+int gnn_mlp_forward(const gnn_mlp_t *mlp, const float *X, int32_t ldx, int32_t M, float *Y, int32_t ldy,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* *flag = any_j( ||state_j - old_j||_2 > threshold * ||old_j||_2 )   (GNN.py:196-212; `old` NULL = all ones,
+ * the state_old of iteration 0, GNN.py:261).  flag is an int32 device word, overwritten with 0 / 1. */
+int gnn_converged(const float *state, const float *state_old, int32_t n, int32_t dim, int32_t ld, float threshold,
+                  int32_t *flag, void *stream);
+
+/* One state-transition step (GNN.py:217-236) for a homogeneous graph with pre-aggregated constants:
+ *   state_new = net_state([state | nodes (if state_dim>0) | A^T state | agg_nodes | agg_arcs])
+ * and *flag_out = predicate(state_new, state) for the next iteration.  Mostly for tests / LGNN-style callers;
+ * gnn_loop_forward does the same with the constants folded once.  `args` supplies graph, nets and workspace;
+ * state_in/state_out are [n_nodes, S] row-major. */
+int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *state_out, int32_t *flag_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNLOOP_H */

@@ -1,0 +1,162 @@
+#!/opt/conda/bin/python3.9
+"""Generate the golden fixtures of the graph data layer by RUNNING THE REFERENCE'S OWN numpy/scipy code.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py
+
+How the reference is made importable: every reference module does `import tensorflow as tf` at import
+time, but the numpy/scipy part of `GraphObject` / `CompositeGraphObject` (ctor, buildArcNode, buildAdjacency,
+buildNodeGraph, buildCompositeAdjacency, merge, setAggregation) uses TensorFlow for exactly one thing: the dtype string
+`tf.keras.backend.floatx()`. A throw-away module named `tensorflow` exposing only that (and an empty `Tensor` class for
+one annotation) is created in a temp dir at run time; it never enters this repository. scipy 1.7.1 of the conda
+interpreter is required. Nothing in TensorFlow's arithmetic is exercised or pinned by these fixtures:
+they pin rows a13-a16 and a18 of SURVEY.md §8 (graph operands), not the Loop.
+
+The reference's `load_MUTAG.py` cannot run at HEAD: its text is read from /root/reference at run time,
+the multi-character delimiter is patched to ',' and the broken composite tail is cut; the rest executes unmodified.
+
+Outputs (committed): tests/golden/graph_fixtures.npz
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_tf_stub():
+    d = tempfile.mkdtemp(prefix='tfstub_')
+    os.makedirs(os.path.join(d, 'tensorflow'))
+    with open(os.path.join(d, 'tensorflow', '__init__.py'), 'w') as f:
+        f.write("class Tensor: pass\n"
+                "class _B:\n"
+                "    @staticmethod\n"
+                "    def floatx(): return 'float32'\n"
+                "class keras:\n"
+                "    backend = _B\n")
+    sys.path.insert(0, d)
+
+
+def _coo(m):
+    m = m.tocoo()
+    return np.stack([m.row.astype(np.float64), m.col.astype(np.float64), m.data.astype(np.float64)], axis=1)
+
+
+def main():
+    _install_tf_stub()
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    from GNN.graph_class import GraphObject
+    from GNN.composite_graph_class import CompositeGraphObject
+
+    # ---- MUTAG through the reference loader (patched as described above) ------------------------------------------
+    src = open(os.path.join(REF, 'load_MUTAG.py')).read()
+    src = src.replace("delimiter=', '", "delimiter=','")
+    src = src[:src.index('# HETEROGENEOUS GRAPHS')]
+    ns = {}
+    exec(compile(src, 'load_MUTAG.py(patched at run time)', 'exec'), ns)
+    graphs = ns['graphs']
+    assert len(graphs) == 4337
+
+    out = {}
+    stats = np.array([[g.nodes.shape[0], g.arcs.shape[0]] for g in graphs])
+    out['mutag_stats'] = stats                                  # per-graph (N, E) of all 4337 graphs
+    out['mutag_targets'] = np.concatenate([g.targets for g in graphs], axis=0)
+    # a checksum of every graph's arcs / nodes so the whole loader is pinned without shipping it twice
+    out['mutag_arcs_checksum'] = np.array([float(np.sum(g.arcs * np.arange(1, g.arcs.shape[1] + 1))) for g in graphs])
+    out['mutag_nodes_checksum'] = np.array([float(np.sum(g.nodes * np.arange(1, g.nodes.shape[1] + 1)[None, :]
+                                                         * np.arange(1, g.nodes.shape[0] + 1)[:, None])) for g in graphs])
+
+    # full arrays for a few single graphs, incl. one with isolated nodes (Q9) and the largest
+    iso = [i for i, g in enumerate(graphs) if len(np.unique(g.arcs[:, :2])) != g.nodes.shape[0]]
+    picks = [0, 1, 2, int(iso[0]), int(np.argmax(stats[:, 0]))]
+    out['single_ids'] = np.array(picks)
+    for i in picks:
+        for mode in ['sum', 'average', 'normalized']:
+            g = graphs[i].copy()
+            g.setAggregation(mode)
+            p = f'single{i}_{mode}_'
+            out[p + 'nodes'], out[p + 'arcs'], out[p + 'targets'] = g.nodes, g.arcs, g.targets
+            out[p + 'ArcNode'], out[p + 'Adjacency'], out[p + 'NodeGraph'] = _coo(g.ArcNode), _coo(g.Adjacency), _coo(g.NodeGraph)
+            out[p + 'NodeGraph_shape'] = np.array(g.NodeGraph.shape)
+
+    # merged batch: first 32 graphs in file order (BASELINE config C2: N=935, E=1922), all three aggregations, focus g
+    for mode in ['sum', 'average', 'normalized']:
+        gl = [g.copy() for g in graphs[:32]]
+        for g in gl: g.setAggregation(mode)
+        m = GraphObject.merge(gl, focus='g', aggregation_mode=mode)
+        p = f'merge32_{mode}_'
+        out[p + 'nodes'], out[p + 'arcs'], out[p + 'targets'] = m.nodes, m.arcs, m.targets
+        out[p + 'set_mask'], out[p + 'output_mask'], out[p + 'sample_weight'] = m.set_mask, m.output_mask, m.sample_weight
+        out[p + 'ArcNode'], out[p + 'Adjacency'], out[p + 'NodeGraph'] = _coo(m.ArcNode), _coo(m.Adjacency), _coo(m.NodeGraph)
+        out[p + 'NodeGraph_shape'] = np.array(m.NodeGraph.shape)
+    merged_stats = []
+    for b in range(0, len(graphs), 32):
+        m = GraphObject.merge(graphs[b:b + 32], focus='g', aggregation_mode='sum')
+        merged_stats.append([m.nodes.shape[0], m.arcs.shape[0]])
+    out['merge32_all_stats'] = np.array(merged_stats)           # 136 batches
+
+    # ---- a node-focused toy graph with masks, duplicate arcs and an isolated node -----------------------------------
+    rng = np.random.default_rng(7)
+    nodes = rng.normal(size=(7, 3))
+    arcs = np.array([[0, 1, .5, 1.], [1, 0, .25, 2.], [2, 1, 1., 3.], [3, 1, 2., 4.], [1, 2, 3., 5.], [4, 5, 1., 6.],
+                     [5, 4, 2., 7.], [0, 1, .5, 1.], [3, 2, 7., 8.]])       # row 7 duplicates row 0; node 6 isolated
+    targets = rng.normal(size=(7, 2))
+    set_mask = np.array([1, 1, 1, 0, 1, 1, 1])
+    output_mask = np.array([1, 0, 1, 1, 1, 1, 0])
+    for mode in ['sum', 'average', 'normalized']:
+        g = GraphObject(nodes=nodes, arcs=arcs, targets=targets[:4], focus='n', set_mask=set_mask,
+                        output_mask=output_mask, sample_weight=2.5, aggregation_mode=mode)
+        p = f'toy_{mode}_'
+        out[p + 'arcs_out'] = g.arcs
+        out[p + 'ArcNode'], out[p + 'Adjacency'], out[p + 'NodeGraph'] = _coo(g.ArcNode), _coo(g.Adjacency), _coo(g.NodeGraph)
+        out[p + 'NodeGraph_shape'] = np.array(g.NodeGraph.shape)
+        out[p + 'sample_weight'] = g.sample_weight
+    out['toy_nodes'], out['toy_arcs'], out['toy_targets'] = nodes, arcs, targets
+    out['toy_set_mask'], out['toy_output_mask'] = set_mask, output_mask
+
+    # ---- composite toy graphs: 3 node types, all four aggregation modes, and a merge --------------------------------
+    def composite_toy(seed, n, e):
+        r = np.random.default_rng(seed)
+        nd = r.normal(size=(n, 4))
+        pairs = set()
+        while len(pairs) < e:
+            a, b = r.integers(0, n, 2)
+            if a != b: pairs.add((int(a), int(b)))
+        pairs = np.array(sorted(pairs), dtype=float)
+        ar = np.concatenate([pairs, r.normal(size=(e, 2))], axis=1)
+        types = r.integers(0, 3, n)
+        types[:3] = [0, 1, 2]
+        tm = np.zeros((n, 3), dtype=bool)
+        tm[np.arange(n), types] = True
+        tg = r.normal(size=(n, 2))
+        return nd, ar, tg, tm
+
+    dim_node_label = (4, 2, 3)
+    toys = [composite_toy(11, 9, 20), composite_toy(12, 6, 11)]
+    for ti, (nd, ar, tg, tm) in enumerate(toys):
+        out[f'ctoy{ti}_nodes'], out[f'ctoy{ti}_arcs'], out[f'ctoy{ti}_targets'], out[f'ctoy{ti}_type_mask'] = nd, ar, tg, tm
+    out['ctoy_dim_node_label'] = np.array(dim_node_label)
+    for mode in ['sum', 'average', 'normalized', 'composite_average']:
+        cgs = [CompositeGraphObject(nodes=nd, arcs=ar, targets=tg, type_mask=tm, dim_node_label=dim_node_label,
+                                    focus='n', aggregation_mode=mode) for nd, ar, tg, tm in toys]
+        for ti, cg in enumerate(cgs + [CompositeGraphObject.merge(cgs, focus='n', aggregation_mode=mode)]):
+            p = f'ctoy{ti}_{mode}_'
+            out[p + 'arcs_out'] = cg.arcs
+            out[p + 'type_mask_out'] = cg.type_mask
+            out[p + 'ArcNode'], out[p + 'Adjacency'] = _coo(cg.ArcNode), _coo(cg.Adjacency)
+            for t, ca in enumerate(cg.CompositeAdjacencies):
+                out[p + f'CA{t}'] = _coo(ca)
+
+    path = os.path.join(HERE, 'graph_fixtures.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes;', len(out), 'arrays; isolated-node graphs:', len(iso))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,211 @@
+"""Composite (heterogeneous) recurrent GNN on MI355X: one state network per node type.
+
+Host-side mirror of the reference's `GNN/Models/CompositeGNN.py`. The reference applies each `net_state[t]` to the
+`tf.boolean_mask`ed rows of type t and `tf.scatter_nd`s them back, summing T full-size tensors per iteration
+(`CompositeGNN.py:223-232`). Here nodes are grouped by type once (an index list per type); each iteration is one fused
+launch per type that gathers, multiplies with that type's weights on the matrix cores and writes its rows in place.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from ..sparse import SparseMatrix
+from .GNN import GNNnodeBased, _LoopModel, _squeeze_last, _arc_endpoints
+from .MLP import Sequential
+
+
+class CompositeGNNnodeBased(GNNnodeBased):
+    """Composite GNN for node-focused problems (reference CompositeGNN.py:8-304)."""
+    name = "node"
+    _focus = 'n'
+
+    def __init__(self, net_state: list, net_output: Sequential, state_vect_dim: int, max_iteration: int,
+                 state_threshold: float) -> None:
+        assert state_vect_dim >= 0
+        assert max_iteration > 0
+        assert state_threshold >= 0
+        self.net_state = list(net_state)
+        self.net_output = net_output
+        self.state_vect_dim = int(state_vect_dim)
+        self.max_iteration = int(max_iteration)
+        self.state_threshold = state_threshold
+        self.native_flags = 0
+        self._engine_init()
+        self._type_cache = {}
+
+    def copy(self, copy_weights: bool = True):
+        config = self.get_config()
+        config["net_state"] = [i.clone(copy_weights) for i in config["net_state"]]
+        config["net_output"] = config["net_output"].clone(copy_weights)
+        return self.from_config(config)
+
+    def __repr__(self):
+        return f"CompositeGNN(type={self.name}, state_dim={self.state_vect_dim}, " \
+               f"threshold={self.state_threshold}, max_iter={self.max_iteration}), avg={self.average_st_grads}"
+
+    __str__ = __repr__
+
+    def save(self, path: str, *args, **kwargs):
+        """`<path>/net_state_{i}/`, `<path>/net_output/`, `<path>/config.json` (reference CompositeGNN.py:87-108)."""
+        if path[-1] != '/': path += '/'
+        config = self.get_config()
+        for i, elem in enumerate(config.pop("net_state")): self._save_net(elem, f'{path}net_state_{i}/')
+        self._save_net(config.pop("net_output"), f'{path}net_output/')
+        with open(f'{path}config.json', 'w') as json_file: json.dump(config, json_file)
+
+    @classmethod
+    def load(cls, path: str, *args, **kwargs):
+        import os
+        if path[-1] != '/': path += '/'
+        with open(f'{path}config.json', 'r') as read_file: config = json.loads(read_file.read())
+        n = len([d for d in os.listdir(path) if d.startswith('net_state_')])
+        netS = [cls._load_net(f'{path}net_state_{i}/') for i in range(n)]
+        return cls(net_state=netS, net_output=cls._load_net(f'{path}net_output/'), **config)
+
+    def summary(self, *args, **kwargs):
+        print(repr(self))
+        for net in self.net_state + [self.net_output]:
+            print('\n')
+            net.summary(*args, **kwargs)
+
+    @staticmethod
+    def process_inputs(inputs):
+        """Squeeze [2] dim_node_label, [3] type_mask, [4] set_mask, [5] output_mask; [6] list of composite adjacency
+        triples and [7:] triples -> `SparseMatrix` (reference CompositeGNN.py:178-191)."""
+        inputs = list(inputs)
+        inputs[2:6] = [_squeeze_last(k) for k in inputs[2:6]]
+        inputs[6] = [SparseMatrix.from_triple(k) for k in inputs[6]]
+        inputs[7:] = [SparseMatrix.from_triple(k) for k in inputs[7:]]
+        return inputs
+
+    def apply_filters(self, state_converged, nodes, adjacency, arcs_label, mask):
+        """State only, no label concat (reference CompositeGNN.py:237-239)."""
+        return state_converged[mask]
+
+    def convergence(self, *args, **kwargs):
+        raise NotImplementedError('a standalone composite step is not exported; use Loop()')
+
+    def _check_training(self, training):
+        nets = self.net_state + [self.net_output]
+        if training and any(n.batch_normalization or n.dropout_rate for n in nets):
+            raise NotImplementedError('training=True forward needs BatchNormalization batch statistics / dropout on '
+                                      'device (SURVEY.md §8f, next row); inference forward is the built path')
+
+    def _type_lists(self, type_mask: torch.Tensor):
+        """(node ids grouped by type int32 [N] on device, host offsets [T+1]); cached per type_mask tensor."""
+        key = (type_mask.data_ptr(), type_mask._version, tuple(type_mask.shape))
+        hit = self._type_cache.get(key)
+        if hit is None:
+            tm = type_mask.to(torch.bool)
+            if tm.dim() != 2: raise ValueError('type_mask must be (n_types, n_nodes)')
+            per_node = tm.sum(0)
+            if not bool(torch.all(per_node == 1)):
+                raise ValueError('type_mask must be one-hot: every node needs exactly one type')
+            t_idx, n_idx = torch.nonzero(tm, as_tuple=True)           # row-major: grouped by type, ascending node id
+            counts = torch.bincount(t_idx, minlength=tm.shape[0]).cpu().numpy()
+            offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            if len(self._type_cache) > 1024: self._type_cache.clear()
+            hit = self._type_cache[key] = (n_idx.to(torch.int32).contiguous(), offsets, type_mask)
+        return hit[0], hit[1]
+
+    def Loop(self, nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, composite_adjacencies, adjacency,
+             arcnode, nodegraph, training: bool = False, *, state0=None, seed=None):
+        """(k, state, out) for one (merged) heterogeneous graph — reference CompositeGNN.py:242-272.
+        `state0` / `seed` as in `GNNnodeBased.Loop`."""
+        self._check_training(bool(training))
+        nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs')
+        dev = nodes.device
+        nodes = nodes.to(torch.float32).contiguous()
+        arcs = arcs.to(torch.float32).contiguous()
+        N, Lw = nodes.shape
+        E, A = arcs.shape[0], arcs.shape[1] - 2
+        dims = [int(d) for d in (dim_node_label.reshape(-1).tolist() if isinstance(dim_node_label, torch.Tensor)
+                                 else np.asarray(dim_node_label).reshape(-1))]
+        T = len(dims)
+        if T != len(self.net_state): raise ValueError(f'{T} node types but {len(self.net_state)} state networks')
+        if T > nat.GNN_MAX_TYPES: raise ValueError(f'at most {nat.GNN_MAX_TYPES} node types are supported')
+        type_mask = _squeeze_last(type_mask).to(dev)
+        set_mask, output_mask = _squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev)
+        out_index = self._out_index(set_mask, output_mask)
+        type_nodes, offsets = self._type_lists(type_mask)
+
+        adjacency, arcnode = SparseMatrix.from_triple(adjacency), SparseMatrix.from_triple(arcnode)
+        adj, arcn = adjacency.device_csr(dev), arcnode.device_csr(dev)
+        cas = [SparseMatrix.from_triple(c).device_csr(dev) for c in composite_adjacencies]
+        keep = [nodes, arcs, adj, arcn, cas, type_nodes, out_index]
+
+        S = self.state_vect_dim if self.state_vect_dim > 0 else Lw
+        if self.state_vect_dim > 0:
+            if state0 is None:
+                gen = None
+                if seed is not None:
+                    gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
+                state0 = torch.randn((N, S), generator=gen, device=dev, dtype=torch.float32) * 0.1
+            state0 = state0.to(dev, torch.float32).contiguous()
+            if tuple(state0.shape) != (N, S): raise ValueError('state0 must be (n_nodes, state_vect_dim)')
+            keep.append(state0)
+
+        a = nat.LoopArgs()
+        a.abi_version, a.composite = nat.GNN_ABI_VERSION, 1
+        a.n_nodes, a.n_arcs, a.dim_node_label, a.dim_arc_label = N, E, Lw, A
+        a.nodes, a.ld_nodes = nat.ptr(nodes), Lw
+        a.arc_labels, a.ld_arcs = C.c_void_p(arcs.data_ptr() + 8), arcs.shape[1]
+        a.adjacency, a.arcnode = nat.make_csr(adj), nat.make_csr(arcn)
+        a.n_types = T
+        a.type_nodes = nat.ptr(type_nodes)
+        for t in range(T):
+            a.type_dim_label[t] = dims[t]
+            a.type_offsets[t] = int(offsets[t])
+            a.composite_adjacency[t] = nat.make_csr(cas[t])
+            a.net_state[t] = self.net_state[t].to(dev).native()
+        a.type_offsets[T] = int(offsets[T])
+        a.net_output = self.net_output.to(dev).native()
+        a.state_dim, a.max_iteration, a.state_threshold = self.state_vect_dim, self.max_iteration, float(self.state_threshold)
+        if self.state_vect_dim > 0: a.state0 = nat.ptr(state0)
+        a.focus = nat.FOCUS[self._focus]
+        a.n_out, a.out_index = len(out_index), nat.ptr(out_index)
+        if self._focus == 'a':
+            es, ed = _arc_endpoints(adjacency, dev)
+            a.arc_src, a.arc_dst = nat.ptr(es), nat.ptr(ed); keep += [es, ed]
+        if self._focus == 'g':
+            ng = SparseMatrix.from_triple(nodegraph).device_csr(dev)
+            a.nodegraph = nat.make_csr(ng); keep.append(ng)
+        a.flags = self.native_flags
+        a.stream = nat.current_stream(dev)
+        nbytes = nat.lib().gnn_loop_workspace_bytes(C.byref(a))
+        if nbytes == 0: nat.check(1)
+        ws = self._workspace(nbytes, dev)
+        base = ws.data_ptr()
+        aligned = (base + 255) & ~255
+        a.workspace, a.workspace_bytes = C.c_void_p(aligned), ws.numel() - (aligned - base)
+
+        n_rows_out = a.nodegraph.n_dst if self._focus == 'g' else len(out_index)
+        k = torch.empty((), dtype=torch.float32, device=dev)
+        state = torch.empty((N, S), dtype=torch.float32, device=dev)
+        out = torch.empty((n_rows_out, self.net_output.units[-1]), dtype=torch.float32, device=dev)
+        a.k_out, a.state_out, a.out = nat.ptr(k), nat.ptr(state), nat.ptr(out)
+        nat.check(nat.lib().gnn_loop_forward(C.byref(a)))
+        return k, state, out
+
+
+class CompositeGNNarcBased(CompositeGNNnodeBased):
+    """Composite GNN for arc-focused problems (reference CompositeGNN.py:310-327): [state_src | state_dst | arc label]."""
+    name = "arc"
+    _focus = 'a'
+
+    def apply_filters(self, state_converged, nodes, adjacency, arcs_label, mask):
+        adjacency = SparseMatrix.from_triple(adjacency)
+        idx = torch.from_numpy(adjacency.indices).to(state_converged.device)
+        states = state_converged[idx].reshape(arcs_label.shape[0], 2 * state_converged.shape[1])
+        return torch.cat([states, arcs_label], dim=1)[mask]
+
+
+class CompositeGNNgraphBased(CompositeGNNnodeBased):
+    """Composite GNN for graph-focused problems (reference CompositeGNN.py:333-343)."""
+    name = "graph"
+    _focus = 'g'

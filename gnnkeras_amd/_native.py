@@ -23,7 +23,7 @@ FOCUS = {'n': 0, 'a': 1, 'g': 2}
 FLAG_UNFUSED = 1
 FLAG_NO_EARLY_EXIT = 2
 
-EXPORTS = ['gnn_last_error', 'gnn_abi_version', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_aggregate',
+EXPORTS = ['gnn_last_error', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_aggregate',
            'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step']
 
 _f32p = C.POINTER(C.c_float)
@@ -106,8 +106,13 @@ def lib():
                                     C.c_void_p]
         l.gnn_state_step.restype = C.c_int
         l.gnn_state_step.argtypes = [C.POINTER(LoopArgs), C.c_void_p, C.c_void_p, C.c_void_p]
+        l.gnn_struct_size.restype = C.c_size_t
+        l.gnn_struct_size.argtypes = [C.c_int]
         if l.gnn_abi_version() != GNN_ABI_VERSION:
             raise NativeError('libgnnloop.so ABI version mismatch: rebuild it')
+        if (l.gnn_struct_size(0), l.gnn_struct_size(1), l.gnn_struct_size(2), l.gnn_struct_size(3)) != \
+                (C.sizeof(CSR), C.sizeof(MLP), C.sizeof(LoopArgs), LoopArgs.flags.offset):
+            raise NativeError('ctypes struct layout does not match libgnnloop.so: rebuild it')
         _lib = l
     return _lib
 

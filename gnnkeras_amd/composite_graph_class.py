@@ -136,7 +136,7 @@ class CompositeGraphTensor(GraphTensor):
         GraphTensor.save_graph(graph_npz_path, g, compressed, **data, **kwargs)
 
     @classmethod
-    def load(cls, graph_npz_path, **kwargs):
+    def load(cls, graph_npz_path, device=None, **kwargs):
         if '.npz' not in graph_npz_path: graph_npz_path += '.npz'
         data = dict(np.load(graph_npz_path, **kwargs))
         data['aggregation_mode'] = str(data['aggregation_mode'])
@@ -144,7 +144,7 @@ class CompositeGraphTensor(GraphTensor):
             data[i] = SparseMatrix(data[i][:, 1:].astype(np.int64), data[i][:, 0], data.pop(i + '_shape'))
         CA = [data.pop(f"CompositeAdjacencies_{idx}") for idx, _ in enumerate(data['dim_node_label'])]
         CA = [SparseMatrix(adj[:, 1:].astype(np.int64), adj[:, 0], data['Adjacency'].shape) for adj in CA]
-        return cls(**data, CompositeAdjacencies=CA)
+        return cls(**data, CompositeAdjacencies=CA, device=device)
 
     @classmethod
     def fromGraphObject(cls, g: CompositeGraphObject, device=None):

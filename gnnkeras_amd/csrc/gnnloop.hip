@@ -10,6 +10,7 @@
 //             the output MLP on the f32 matrix cores, optional graph pooling (:341-346).
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
@@ -292,7 +293,9 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
         if (p.N > 0 && !a.nodes) return fail("nodes is NULL");
         if (p.E > 0 && p.A > 0 && !a.arc_labels) return fail("arc_labels is NULL");
         if (a.state_dim > 0 && p.N > 0 && !a.state0) return fail("state0 is required when state_dim > 0");
-        if (!a.k_out || !a.state_out || !a.out) return fail("k_out / state_out / out must be non-NULL");
+        if (!a.k_out) return fail("k_out is NULL");
+        if (p.N > 0 && !a.state_out) return fail("state_out is NULL");
+        if (!a.out && (a.focus == GNN_FOCUS_GRAPH ? a.nodegraph.n_dst : p.M) > 0) return fail("out is NULL");
         if (p.M > 0 && !a.out_index) return fail("out_index is NULL");
         if (a.focus == GNN_FOCUS_ARC && p.E > 0 && (!a.arc_src || !a.arc_dst)) return fail("arc focus needs arc_src / arc_dst");
         if (a.focus == GNN_FOCUS_GRAPH) {
@@ -468,6 +471,15 @@ extern "C" {
 
 const char *gnn_last_error(void) { return g_err; }
 int gnn_abi_version(void) { return GNN_ABI_VERSION; }
+size_t gnn_struct_size(int which) {
+    switch (which) {
+        case 0: return sizeof(gnn_csr_t);
+        case 1: return sizeof(gnn_mlp_t);
+        case 2: return sizeof(gnn_loop_args_t);
+        case 3: return offsetof(gnn_loop_args_t, flags);
+        default: return 0;
+    }
+}
 
 size_t gnn_loop_workspace_bytes(const gnn_loop_args_t *args) {
     if (!args) { fail("args is NULL"); return 0; }

@@ -301,13 +301,13 @@ class GraphTensor:
             output_mask=t(g.output_mask), **GraphTensor._sparse_dict(g), **kwargs)
 
     @classmethod
-    def load(cls, graph_npz_path, **kwargs):
+    def load(cls, graph_npz_path, device=None, **kwargs):
         if '.npz' not in graph_npz_path: graph_npz_path += '.npz'
         data = dict(np.load(graph_npz_path, **kwargs))
         data['aggregation_mode'] = str(data['aggregation_mode'])
         for i in ['Adjacency', 'ArcNode', 'NodeGraph']:
             data[i] = SparseMatrix(data[i][:, 1:].astype(np.int64), data[i][:, 0], data.pop(i + '_shape'))
-        return cls(**data)
+        return cls(**data, device=device)
 
     @classmethod
     def fromGraphObject(cls, g: GraphObject, device=None):

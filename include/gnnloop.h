@@ -122,6 +122,9 @@ typedef struct gnn_loop_args {
 
 const char *gnn_last_error(void);
 int gnn_abi_version(void);
+/* sizeof() of the ABI structs as this library was compiled (0 gnn_csr_t, 1 gnn_mlp_t, 2 gnn_loop_args_t; 3 = offsetof
+ * (gnn_loop_args_t, flags)): lets a foreign-language binding verify its struct layout at load time. */
+size_t gnn_struct_size(int which);
 
 /* bytes of scratch HBM gnn_loop_forward needs for `args` (only sizes / dims of `args` are read). */
 size_t gnn_loop_workspace_bytes(const gnn_loop_args_t *args);

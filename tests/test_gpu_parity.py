@@ -1,0 +1,478 @@
+"""Parity tests proper: the HIP path (through the C ABI, libgnnloop.so) against the oracle on identical inputs.
+
+Tolerance (BASELINE.json north_star): float32 node state and output within 1e-5 relative —
+`max|a-b| / max|b|` — against the float32 restatement, with both also compared to the float64 restatement.
+k (iteration count) must match exactly when pinned by threshold 0."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from gnnkeras_amd import _native as nat
+from gnnkeras_amd import GraphObject, CompositeGraphObject, SparseMatrix
+from gnnkeras_amd.Models.MLP import MLP, Sequential, get_inout_dims
+from gnnkeras_amd.Models.GNN import GNNnodeBased, GNNarcBased, GNNgraphBased
+from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased, CompositeGNNarcBased, CompositeGNNgraphBased
+from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer, CompositeMultiGraphSequencer
+from gnnkeras_amd.synth import er_graph, er_composite_graph
+from oracle import gnn_oracle as O
+from oracle.harness import oracle_loop, oracle_composite_loop, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+CLS = {'n': GNNnodeBased, 'a': GNNarcBased, 'g': GNNgraphBased}
+CCLS = {'n': CompositeGNNnodeBased, 'a': CompositeGNNarcBased, 'g': CompositeGNNgraphBased}
+
+
+def dev(x):
+    return torch.as_tensor(np.asarray(x)).cuda()
+
+
+def starter_nets(focus, d, L=14, A=3, T=2, hidden_state=None, hidden_out=None, act='selu', scale=1.0, bn=True):
+    inp, lay = get_inout_dims('state', L, A, T, focus, d, hidden_units=hidden_state)
+    acts = [act] * len(lay)
+    ns = MLP(inp[0], lay, acts, 'lecun_normal', 'lecun_normal', rng=0, batch_normalization=bn)
+    inp, lay = get_inout_dims('output', L, A, T, focus, d, hidden_units=hidden_out)
+    no = MLP(inp[0], lay, ['tanh'] * (len(lay) - 1) + ['softmax'], 'glorot_normal', 'glorot_normal', rng=1,
+             batch_normalization=bn)
+    if scale != 1.0:
+        w = ns.get_weights()
+        ns.set_weights([a * scale if a.ndim == 2 else a for a in w])
+    return ns, no
+
+
+def refocus(graphs, focus, rng):
+    if focus == 'g': return graphs
+    out = []
+    for g in graphs:
+        n = (g.nodes if focus == 'n' else g.arcs).shape[0]
+        om = rng.random(n) < 0.7
+        out.append(GraphObject(nodes=g.nodes, arcs=g.arcs, targets=rng.normal(size=(int(om.sum()), 2)), focus=focus,
+                               set_mask=rng.random(n) < 0.8, output_mask=om))
+    return out
+
+
+def check(model, x, s0, tol=TOL, pin_k=True, oracle=oracle_loop):
+    k64, st64, o64 = oracle(model, x, s0, np.float64)
+    k32, st32, o32 = oracle(model, x, s0, np.float32)
+    res = {}
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k, st, o = model.Loop(*model.process_inputs(x), state0=None if s0 is None else dev(s0))
+        torch.cuda.synchronize()
+        k, st, o = float(k), st.cpu().numpy(), o.cpu().numpy()
+        assert st.shape == st32.shape and o.shape == o32.shape
+        if pin_k:
+            assert k == float(k32) == float(k64), (k, k32, k64)
+        assert np.all(np.isfinite(st)) and np.all(np.isfinite(o))
+        e = dict(st32=rel_err(st, st32), st64=rel_err(st, st64), o32=rel_err(o, o32), o64=rel_err(o, o64),
+                 ref=rel_err(st32, st64))
+        assert e['st32'] <= tol and e['st64'] <= tol, (flags, e)
+        assert e['o32'] <= tol and e['o64'] <= tol, (flags, e)
+        res[flags] = (k, st, o)
+    assert rel_err(res[0][1], res[nat.FLAG_UNFUSED][1]) <= tol
+    return res[0]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# C2: MUTAG batch = first 32 graphs in file order (N=935, E=1922), d=32, max_iteration=50
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('focus', ['g', 'n', 'a'])
+def test_c2_mutag_batch_state_dim_32_k_pinned(mutag_graphs, focus):
+    gl = refocus(mutag_graphs[:32], focus, np.random.default_rng(5))
+    seq = MultiGraphSequencer(gl, focus, 'average', 32, shuffle=False)
+    x, y, sw = seq[0]
+    assert x[0].shape[0] == 935 and x[1].shape[0] == 1922
+    ns, no = starter_nets(focus, 32)
+    model = CLS[focus](ns, no, 32, 50, 0.0)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (935, 32)).astype(np.float32)
+    k, st, o = check(model, x, s0)
+    assert k == 50.0
+    if focus == 'g': assert o.shape == (32, 2) and np.allclose(o.sum(1), 1, atol=1e-5)
+
+
+def test_c2_realistic_threshold_converges_early(mutag_graphs):
+    """threshold 0.01 with a contractive state network: k < max_iteration, equal to the oracle's (reported, H3)."""
+    seq = MultiGraphSequencer(mutag_graphs[:32], 'g', 'average', 32, shuffle=False)
+    x = seq[0][0]
+    ns, no = starter_nets('g', 32, scale=0.25)
+    model = GNNgraphBased(ns, no, 32, 50, 0.01)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (935, 32)).astype(np.float32)
+    k, st, o = check(model, x, s0)
+    assert 2 <= k < 50
+
+
+def test_c1_starter_config_state_dim_0(mutag_graphs):
+    """starter.py: dim_state=0, max_iter=5, threshold=0.01, 'average', graph focus; several batches incl. the ragged last one."""
+    gs = [g.copy() for g in mutag_graphs[:100]]
+    for g in gs: g.setAggregation('average')
+    seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False)
+    ns, no = starter_nets('g', 0)
+    model = GNNgraphBased(ns, no, 0, 5, 0.01)
+    for i in range(len(seq)):
+        check(model, seq[i][0], None)
+
+
+@pytest.mark.parametrize('mode', ['sum', 'normalized'])
+def test_other_aggregation_modes(mutag_graphs, mode):
+    seq = MultiGraphSequencer(mutag_graphs[32:64], 'g', mode, 32, shuffle=False)
+    ns, no = starter_nets('g', 16, scale=0.5)
+    model = GNNgraphBased(ns, no, 16, 8, 0.0)
+    N = seq[0][0][0].shape[0]
+    check(model, seq[0][0], np.random.default_rng(2).normal(0, 0.1, (N, 16)).astype(np.float32))
+
+
+def test_per_arc_weights_path(mutag_graphs):
+    """A user-supplied ArcNode with non-uniform values forces the per-arc weight array (w != NULL) kernels."""
+    rng = np.random.default_rng(3)
+    m = GraphObject.merge(mutag_graphs[:16], 'g', 'sum')
+    an = m.getArcNode(); an.data = rng.uniform(0.2, 1.0, len(an.data)).astype(np.float32)
+    m = GraphObject(nodes=m.nodes, arcs=m.arcs, targets=m.targets, focus='g', ArcNode=an, NodeGraph=m.NodeGraph)
+    seq = MultiGraphSequencer([m], 'g', 'sum', 1, shuffle=False)
+    # the sequencer's merge re-derives ArcNode for its mode: put the custom operands back on the batch
+    seq.graph_tensors[0].ArcNode = SparseMatrix.from_scipy(m.ArcNode)
+    seq.graph_tensors[0].Adjacency = SparseMatrix.from_scipy(m.Adjacency)
+    seq._items = [None]
+    x = seq[0][0]
+    assert x[5].matrix.csr().w is not None
+    ns, no = starter_nets('g', 32, scale=0.3)
+    model = GNNgraphBased(ns, no, 32, 10, 0.0)
+    N = x[0].shape[0]
+    check(model, x, rng.normal(0, 0.1, (N, 32)).astype(np.float32))
+
+
+@pytest.mark.parametrize('act', ['tanh', 'relu', 'sigmoid', 'linear', 'elu', 'softplus'])
+def test_multilayer_networks_and_activations(mutag_graphs, act):
+    """Hidden layers in both networks take the un-fused general path (segmented MFMA dense chain)."""
+    seq = MultiGraphSequencer(mutag_graphs[:32], 'g', 'average', 32, shuffle=False)
+    x = seq[0][0]
+    ns, no = starter_nets('g', 24, hidden_state=[40, 17], hidden_out=[9], act=act, scale=0.5)
+    model = GNNgraphBased(ns, no, 24, 6, 0.0)
+    check(model, x, np.random.default_rng(4).normal(0, 0.1, (935, 24)).astype(np.float32))
+
+
+@pytest.mark.parametrize('d', [1, 3, 14, 20, 33, 64, 100])
+def test_odd_state_widths(mutag_graphs, d):
+    seq = MultiGraphSequencer(refocus(mutag_graphs[:16], 'n', np.random.default_rng(d)), 'n', 'average', 16, shuffle=False)
+    x = seq[0][0]
+    ns, no = starter_nets('n', d, scale=0.5, bn=(d % 2 == 0))
+    model = GNNnodeBased(ns, no, d, 4, 0.0)
+    N = x[0].shape[0]
+    check(model, x, np.random.default_rng(d).normal(0, 0.1, (N, d)).astype(np.float32))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# known answers and edge cases through the GPU
+# ----------------------------------------------------------------------------------------------------------------------
+def _toy(focus='n', mode='sum', n=7):
+    rng = np.random.default_rng(7)
+    nodes = rng.normal(size=(n, 3))
+    arcs = np.array([[0, 1, .5, 1.], [1, 0, .25, 2.], [2, 1, 1., 3.], [3, 1, 2., 4.], [1, 2, 3., 5.], [4, 5, 1., 6.],
+                     [5, 4, 2., 7.], [3, 2, 7., 8.]])                  # node 6 isolated
+    nt = {'n': n, 'a': len(arcs), 'g': 1}[focus]
+    return GraphObject(nodes=nodes, arcs=arcs, targets=rng.normal(size=(nt, 2)), focus=focus, aggregation_mode=mode)
+
+
+def test_zero_weights_converge_at_k2_on_gpu():
+    g = _toy()
+    seq = MultiGraphSequencer([g], 'n', 'sum', 1, shuffle=False)
+    d = 5
+    b = np.array([.3, -.2, 1.5, 0., -3.], np.float32)
+    ns = Sequential(2 * d + 2 * 3 + 2, [d], ['selu'], batch_normalization=False,
+                    weights=[np.zeros((2 * d + 8, d)), b])
+    no = Sequential(d + 3, [2], ['linear'], batch_normalization=False, weights=[np.ones((d + 3, 2)), np.zeros(2)])
+    for thr in (0.0, 0.5):
+        model = GNNnodeBased(ns, no, d, 10, thr)
+        k, st, o = check(model, seq[0][0], np.full((7, d), 0.1, np.float32))
+        assert k == 2.0
+        assert np.allclose(st, np.tile(O.activation('selu', b, np.float32), (7, 1)), atol=1e-6)
+
+
+def test_max_iteration_zero_and_threshold_huge():
+    g = _toy()
+    seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)
+    ns, no = starter_nets('n', 8, L=3, A=2)
+    s0 = np.random.default_rng(0).normal(0, .1, (7, 8)).astype(np.float32)
+    k, st, o = check(GNNnodeBased(ns, no, 8, 0, 0.0), seq[0][0], s0)
+    assert k == 0.0 and np.array_equal(st, s0)
+    # ||s0 - 1|| > thr * sqrt(d) is false for a huge threshold: the loop never starts (GNN.py:196-214 at k = 0)
+    k, st, o = check(GNNnodeBased(ns, no, 8, 10, 100.0), seq[0][0], s0)
+    assert k == 0.0 and np.array_equal(st, s0)
+
+
+def test_empty_mask_no_arcs_single_node():
+    ns, no = starter_nets('n', 4, L=3, A=2)
+    model = GNNnodeBased(ns, no, 4, 3, 0.0)
+    g = _toy()
+    g0 = GraphObject(g.nodes, g.arcs, np.zeros((0, 2)), focus='n', set_mask=np.zeros(7, bool), output_mask=np.zeros(7, bool))
+    x = MultiGraphSequencer([g0], 'n', 'sum', 1, shuffle=False)[0][0]
+    k, st, o = check(model, x, np.zeros((7, 4), np.float32) + .1)
+    assert o.shape == (0, 2)
+    g1 = GraphObject(np.ones((1, 3)), np.zeros((0, 4)), np.ones((1, 2)), focus='n')
+    x = MultiGraphSequencer([g1], 'n', 'average', 1, shuffle=False)[0][0]
+    k, st, o = check(model, x, np.full((1, 4), .1, np.float32))
+    assert o.shape == (1, 2)
+
+
+def test_merged_equals_separate_on_gpu(mutag_graphs):
+    """Block-diagonal batching invariance ('average'), with k pinned."""
+    gs = mutag_graphs[:6]
+    ns, no = starter_nets('g', 16)
+    model = GNNgraphBased(ns, no, 16, 7, 0.0)
+    rng = np.random.default_rng(8)
+    s0s = [rng.normal(0, .1, (g.nodes.shape[0], 16)).astype(np.float32) for g in gs]
+    big = MultiGraphSequencer(gs, 'g', 'average', 6, shuffle=False)
+    k, st, o = model.Loop(*model.process_inputs(big[0][0]), state0=dev(np.concatenate(s0s)))
+    off = 0
+    small = MultiGraphSequencer(gs, 'g', 'average', 1, shuffle=False)
+    for i, g in enumerate(gs):
+        ki, sti, oi = model.Loop(*model.process_inputs(small[i][0]), state0=dev(s0s[i]))
+        n = g.nodes.shape[0]
+        assert float(ki) == float(k)
+        assert rel_err(st[off:off + n].cpu().numpy(), sti.cpu().numpy()) <= TOL
+        assert rel_err(o[i:i + 1].cpu().numpy(), oi.cpu().numpy()) <= TOL
+        off += n
+
+
+def test_golden_reference_operands_through_gpu(golden, mutag_graphs):
+    """Feed the Adjacency / ArcNode / NodeGraph produced by the REFERENCE's own numpy code (golden fixture) straight
+    into the device loop and into the oracle."""
+    p = 'merge32_average_'
+    N, E = golden[p + 'nodes'].shape[0], golden[p + 'arcs'].shape[0]
+    trip = lambda key, shape: (golden[p + key][:, :2].astype(np.int64), golden[p + key][:, 2:3].astype(np.float32),
+                               np.array(shape))
+    x = [dev(golden[p + 'nodes']), dev(golden[p + 'arcs']), torch.tensor([[14]], dtype=torch.int32),
+         dev(golden[p + 'set_mask'])[:, None], dev(golden[p + 'output_mask'])[:, None],
+         trip('Adjacency', (N, N)), trip('ArcNode', (E, N)), trip('NodeGraph', tuple(golden[p + 'NodeGraph_shape']))]
+    ns, no = starter_nets('g', 32)
+    model = GNNgraphBased(ns, no, 32, 50, 0.0)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, 32)).astype(np.float32)
+    k, st, o = check(model, x, s0)
+    seq = MultiGraphSequencer(mutag_graphs[:32], 'g', 'average', 32, shuffle=False)
+    model.native_flags = 0
+    k2, st2, o2 = model.Loop(*model.process_inputs(seq[0][0]), state0=dev(s0))
+    assert np.array_equal(st2.cpu().numpy(), st) and np.array_equal(o2.cpu().numpy(), o)
+
+
+def test_bitwise_run_to_run_determinism(mutag_graphs):
+    seq = MultiGraphSequencer(mutag_graphs[:32], 'g', 'average', 32, shuffle=False)
+    ns, no = starter_nets('g', 32)
+    model = GNNgraphBased(ns, no, 32, 20, 0.0)
+    s0 = dev(np.random.default_rng(1).normal(0, 0.1, (935, 32)).astype(np.float32))
+    inputs = model.process_inputs(seq[0][0])
+    a = [t.clone() for t in model.Loop(*inputs, state0=s0)]
+    for _ in range(3):
+        b = model.Loop(*inputs, state0=s0)
+        assert all(torch.equal(p, q) for p, q in zip(a, b))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# separately callable pieces of the ABI
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('F', [1, 3, 14, 32, 70])
+def test_gnn_aggregate_matches_adjoint_spmm(F):
+    rng = np.random.default_rng(F)
+    n_src, n_dst, nnz = 300, 200, 1500
+    idx = np.unique(np.stack([rng.integers(0, n_src, nnz), rng.integers(0, n_dst, nnz)], 1), axis=0)
+    val = rng.normal(size=len(idx)).astype(np.float32)
+    X = rng.normal(size=(n_src, F)).astype(np.float32)
+    want = O.sparse_dense_matmul_adjoint(idx, val, (n_src, n_dst), X, np.float32)
+    m = SparseMatrix(idx, val, (n_src, n_dst))
+    c = m.device_csr('cuda')
+    Xd = dev(X)
+    out = torch.empty((n_dst, F), dtype=torch.float32, device='cuda')
+    csr = nat.make_csr(c)
+    nat.check(nat.lib().gnn_aggregate(C.byref(csr), nat.ptr(Xd), F, F, nat.ptr(out), F, nat.current_stream(Xd.device)))
+    assert rel_err(out.cpu().numpy(), want) <= TOL
+
+
+def test_sequential_call_matches_oracle_mlp():
+    rng = np.random.default_rng(0)
+    net = MLP((37,), [50, 70, 5], ['selu', 'tanh', 'softmax'], 'glorot_normal', 'lecun_normal', rng=0)
+    w = net.get_weights()
+    w[0:4] = [rng.uniform(.5, 1.5, 37), rng.normal(size=37), rng.normal(size=37), rng.uniform(.5, 2, 37)]
+    net.set_weights(w)
+    x = rng.normal(size=(333, 37)).astype(np.float32)
+    got = net(dev(x)).cpu().numpy()
+    spec, ww = net.spec()
+    assert rel_err(got, O.mlp_apply(spec, ww, x, False, np.float64)) <= TOL
+    assert net(dev(x[:0])).shape == (0, 5)
+
+
+def test_condition_truth_table_on_gpu():
+    ns, no = starter_nets('n', 2, L=3, A=2)
+    cases = [([[1., 1.]], [[1., 1.]], 5, 0.0, 0, False), ([[0., 0.]], [[0., 0.]], 5, 0.5, 0, False),
+             ([[1., 0.]], [[0., 0.]], 5, 10., 0, True), ([[1.1, 1.]], [[1., 1.]], 5, 0.05, 0, True),
+             ([[1.1, 1.]], [[1., 1.]], 5, 0.1, 0, False), ([[9., 9.]], [[1., 1.]], 5, 0.0, 5, False),
+             ([[1., 1.], [5., 5.]], [[1., 1.], [1., 1.]], 5, 0.1, 0, True)]
+    for s, so, mx, thr, k, want in cases:
+        m = GNNnodeBased(ns, no, 2, mx, thr)
+        got = bool(m.condition(k, dev(np.array(s, np.float32)), dev(np.array(so, np.float32))))
+        assert got is want is O.condition(k, np.array(s, np.float32), np.array(so, np.float32), mx, thr, np.float32)
+    m = GNNnodeBased(ns, no, 2, 5, 0.5)
+    assert bool(m.condition(0, dev(np.full((3, 2), .1, np.float32)), None)) is True     # state_old = ones
+
+
+def test_convergence_step_matches_oracle(mutag_graphs):
+    seq = MultiGraphSequencer(mutag_graphs[:8], 'g', 'average', 8, shuffle=False)
+    x = seq[0][0]
+    ns, no = starter_nets('g', 32)
+    model = GNNgraphBased(ns, no, 32, 5, 0.0)
+    nodes, arcs, _, _, _, adj, an, ng = model.process_inputs(x)
+    N = nodes.shape[0]
+    s = np.random.default_rng(0).normal(0, .1, (N, 32)).astype(np.float32)
+    a = (adj.indices, adj.values, np.array(adj.shape))
+    agg_nodes = O.sparse_dense_matmul_adjoint(*a, nodes.cpu().numpy(), np.float64)
+    agg_arcs = O.sparse_dense_matmul_adjoint(an.indices, an.values, np.array(an.shape), arcs.cpu().numpy()[:, 2:], np.float64)
+    want = O.convergence(s.astype(np.float64), nodes.cpu().numpy().astype(np.float64), a, agg_nodes, agg_arcs,
+                         ns.spec(), 32, False, np.float64)
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k1, new, old, *_ = model.convergence(0, dev(s), None, nodes, adj, None, None, False, arcs=arcs, arcnode=an)
+        assert k1 == 1 and rel_err(new.cpu().numpy(), want) <= TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# composite (heterogeneous) GNN
+# ----------------------------------------------------------------------------------------------------------------------
+def composite_nets(dims, A, D, T, focus, rng_seed=0, scale=0.5, hidden=None):
+    inp, lay = get_inout_dims('state', dims, A, T, focus, D, hidden_units=hidden)
+    ns = [MLP(i, lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=rng_seed + t) for t, i in enumerate(inp)]
+    for n in ns:
+        n.set_weights([a * scale if a.ndim == 2 else a for a in n.get_weights()])
+    inp, lay = get_inout_dims('output', dims, A, T, focus, D)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=99)
+    return ns, no
+
+
+@pytest.mark.parametrize('focus', ['n', 'a', 'g'])
+@pytest.mark.parametrize('mode', ['composite_average', 'average', 'sum'])
+def test_composite_small_graphs(focus, mode):
+    rng = np.random.default_rng(21)
+    dims = (4, 2, 3)
+
+    def cg(n, e):
+        pairs = set()
+        while len(pairs) < e:
+            a, b = rng.integers(0, n, 2)
+            if a != b: pairs.add((int(a), int(b)))
+        ids = np.array(sorted(pairs), dtype=float)
+        arcs = np.concatenate([ids, rng.normal(size=(e, 2))], 1)
+        types = rng.integers(0, 3, n); types[:3] = [0, 1, 2]
+        tm = np.zeros((n, 3), bool); tm[np.arange(n), types] = True
+        nt = {'n': n, 'a': e, 'g': 1}[focus]
+        return CompositeGraphObject(nodes=rng.normal(size=(n, 4)), arcs=arcs, targets=rng.normal(size=(nt, 2)),
+                                    type_mask=tm, dim_node_label=dims, focus=focus, aggregation_mode=mode)
+    gl = [cg(40, 130), cg(25, 60), cg(70, 200)]
+    seq = CompositeMultiGraphSequencer(gl, focus, mode, 3, shuffle=False)
+    x = seq[0][0]
+    ns, no = composite_nets(dims, 2, 6, 2, focus)
+    model = CCLS[focus](ns, no, 6, 7, 0.0)
+    N = x[0].shape[0]
+    check(model, x, rng.normal(0, .1, (N, 6)).astype(np.float32), oracle=oracle_composite_loop)
+
+
+def test_composite_hidden_layers_and_state_dim_0():
+    g = er_composite_graph(3000, 20000, dim_node_label=(5, 5, 5), aggregation_mode='composite_average', seed=3)
+    seq = CompositeMultiGraphSequencer([g], 'n', 'composite_average', 1, shuffle=False)
+    x = seq[0][0]
+    ns, no = composite_nets((5, 5, 5), 3, 12, 2, 'n', hidden=[20])
+    check(CompositeGNNnodeBased(ns, no, 12, 4, 0.0), x, np.random.default_rng(0).normal(0, .1, (3000, 12)).astype(np.float32),
+          oracle=oracle_composite_loop)
+    # state_vect_dim == 0: state0 = nodes (CompositeGNN.py:258), every net maps back to the label width
+    inp = [(5 + 2 * 5 + 15 + 3,)] * 3
+    ns0 = [MLP(i, [5], 'tanh', 'lecun_normal', 'zeros', rng=t) for t, i in enumerate(inp)]
+    no0 = MLP((5,), [2], 'softmax', 'glorot_normal', 'zeros', rng=9)
+    check(CompositeGNNnodeBased(ns0, no0, 0, 3, 0.0), x, None, oracle=oracle_composite_loop)
+
+
+def test_composite_type_mask_must_be_one_hot():
+    g = er_composite_graph(50, 200, dim_node_label=(3, 3), seed=1)
+    seq = CompositeMultiGraphSequencer([g], 'n', 'sum', 1, shuffle=False)
+    x = list(seq[0][0])
+    tm = x[3].clone(); tm[:, 0] = True
+    x[3] = tm
+    ns, no = composite_nets((3, 3), 3, 4, 2, 'n')
+    with pytest.raises(ValueError):
+        CompositeGNNnodeBased(ns, no, 4, 2, 0.0)(x)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE full sizes: size-independent properties + oracle on a few iterations (fast scipy path)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode', ['average', 'sum'])
+def test_c3_er_100k_1m(mode):
+    N, E, d = 100_000, 1_000_000, 64
+    g = er_graph(N, E, aggregation_mode=mode)
+    seq = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)
+    x = seq[0][0]
+    ns, no = starter_nets('n', d, scale=1.0 if mode == 'average' else 0.1)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
+    model = GNNnodeBased(ns, no, d, 3, 0.0)
+    k32, st32, o32 = oracle_loop(model, x, s0, np.float32, exact_order=False)
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    outs = {}
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k, st, o = model.Loop(*model.process_inputs(x), state0=dev(s0))
+        assert float(k) == 3.0 == float(k32)
+        outs[flags] = st
+        assert rel_err(st.cpu().numpy(), st32) <= TOL and rel_err(st.cpu().numpy(), st64) <= TOL
+        assert rel_err(o.cpu().numpy(), o32) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL
+    assert rel_err(outs[0].cpu().numpy(), outs[nat.FLAG_UNFUSED].cpu().numpy()) <= TOL
+
+
+def test_c4_er_1m_10m_properties():
+    """Full C4 size: (i) fused == un-fused (two independent device implementations), (ii) permutation equivariance:
+    relabelling the nodes permutes the states, (iii) k pinned, (iv) the loop is deterministic."""
+    N, E, d = 1_000_000, 10_000_000, 64
+    g = er_graph(N, E, aggregation_mode='average')
+    seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)
+    x = seq[0][0]
+    ns, no = starter_nets('n', d)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
+    model = GNNnodeBased(ns, no, d, 5, 0.0)
+    inputs = model.process_inputs(x)
+    k, st, o = model.Loop(*inputs, state0=dev(s0))
+    k2, st2, o2 = model.Loop(*inputs, state0=dev(s0))
+    assert float(k) == 5.0 and torch.equal(st, st2) and torch.equal(o, o2)
+    model.native_flags = nat.FLAG_UNFUSED
+    ku, stu, ou = model.Loop(*inputs, state0=dev(s0))
+    assert float(ku) == 5.0
+    assert rel_err(st.cpu().numpy(), stu.cpu().numpy()) <= TOL and rel_err(o.cpu().numpy(), ou.cpu().numpy()) <= TOL
+    del stu, ou, st2, o2
+    model.native_flags = 0
+    perm = np.random.default_rng(2).permutation(N); inv = np.argsort(perm)      # new id of old node i is inv[i]
+    arcs_p = g.arcs.astype(np.float64); arcs_p[:, :2] = inv[g.arc_ids]
+    gp = GraphObject(nodes=g.nodes[perm], arcs=arcs_p, targets=g.targets[perm], focus='n', aggregation_mode='average')
+    xp = MultiGraphSequencer([gp], 'n', 'average', 1, shuffle=False)[0][0]
+    kp, stp, op = model.Loop(*model.process_inputs(xp), state0=dev(s0[perm]))
+    assert rel_err(stp.cpu().numpy(), st.cpu().numpy()[perm]) <= TOL
+    assert rel_err(op.cpu().numpy(), o.cpu().numpy()[perm]) <= TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Keras-style evaluate / predict on top of the loop
+# ----------------------------------------------------------------------------------------------------------------------
+def test_evaluate_and_predict(mutag_graphs):
+    gs = [g.copy() for g in mutag_graphs[:96]]
+    for g in gs: g.setAggregation('average')
+    seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False)
+    ns, no = starter_nets('g', 0)
+    model = GNNgraphBased(ns, no, 0, 5, 0.01)
+    model.compile(optimizer=None, loss='categorical_crossentropy', metrics=['accuracy'])
+    pred = model.predict(seq)
+    assert pred.shape == (96, 2)
+    outs, ys = [], []
+    for i in range(len(seq)):
+        x, y, sw = seq[i]
+        outs.append(oracle_loop(model, x, None, np.float64)[2]); ys.append(y.cpu().numpy())
+    want, y = np.concatenate(outs), np.concatenate(ys)
+    assert rel_err(pred, want) <= TOL
+    res = model.evaluate(seq, return_dict=True)
+    loss = float(np.mean(-np.sum(y * np.log(np.clip(want, 1e-7, 1 - 1e-7)), axis=1)))
+    acc = float(np.mean(want.argmax(1) == y.argmax(1)))
+    assert abs(res['loss'] - loss) < 1e-5 and abs(res['accuracy'] - acc) < 1e-6
+    with pytest.raises(NotImplementedError):
+        model.fit(seq, epochs=1)

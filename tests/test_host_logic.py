@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference interface: dims arithmetic, builders, error behaviour, sequencer tuple layout,
+on-disk formats. No GPU."""
+import numpy as np
+import pytest
+import torch
+
+from gnnkeras_amd import GraphObject, GraphTensor, CompositeGraphObject, SparseMatrix
+from gnnkeras_amd.Models.MLP import MLP, Sequential, get_inout_dims, initialize
+from gnnkeras_amd.Models.GNN import GNNnodeBased, GNNarcBased, GNNgraphBased
+from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased
+from gnnkeras_amd.Sequencers.GraphSequencers import (MultiGraphSequencer, SingleGraphSequencer,
+                                                     CompositeMultiGraphSequencer)
+
+
+def test_get_inout_dims_mutag():
+    # MUTAG d=32 => state in 14+14+3+64 = 95 -> 32; output in 46 -> 2; d=0 => 31 -> 14 and 14 -> 2
+    assert get_inout_dims('state', 14, 3, 2, 'g', 32) == ([(95,)], [32])
+    assert get_inout_dims('output', 14, 3, 2, 'g', 32) == ([(46,)], [2])
+    assert get_inout_dims('state', 14, 3, 2, 'g', 0) == ([(31,)], [14])
+    assert get_inout_dims('output', 14, 3, 2, 'g', 0) == ([(14,)], [2])
+    assert get_inout_dims('output', 14, 3, 2, 'a', 32) == ([(2 * 46 + 3,)], [2])
+    assert get_inout_dims('state', 14, 3, 2, 'n', 64, hidden_units=[100, 50]) == ([(159,)], [100, 50, 64])
+    # composite: one input shape per node type: d_t + sum(d) + A + 2D   (MLP.py:117-121)
+    assert get_inout_dims('state', (4, 2, 3), 2, 2, 'n', 5)[0] == [(4 + 9 + 2 + 10,), (2 + 9 + 2 + 10,), (3 + 9 + 2 + 10,)]
+    assert get_inout_dims('output', (4, 2, 3), 2, 2, 'n', 5) == ([(5,)], [2])
+    # LGNN layer > 0 rule with state and output fed forward (MLP.py:107-113)
+    assert get_inout_dims('state', 14, 3, 2, 'g', 0, layer=1, get_state=True, get_output=True)[0] == [(2 * 30 + 3,)]
+    with pytest.raises(ValueError):
+        get_inout_dims('hidden', 14, 3, 2, 'g', 0)
+    with pytest.raises(AssertionError):
+        get_inout_dims('state', 14, 3, 2, 'x', 0)
+
+
+def test_mlp_builder_weight_order_and_errors():
+    m = MLP((95,), [64, 32], ['selu', 'linear'], 'lecun_normal', 'zeros', rng=0, device='cpu')
+    w = m.get_weights()
+    assert [a.shape for a in w] == [(95,)] * 4 + [(95, 64), (64,), (64, 32), (32,)]
+    assert np.all(w[0] == 1) and np.all(w[1] == 0) and np.all(w[2] == 0) and np.all(w[3] == 1)   # BN at init (Q10)
+    assert abs(w[4].std() - np.sqrt(1 / 95)) < 0.01 and np.abs(w[4]).max() <= 2 * np.sqrt(1 / 95) / 0.8796 + 1e-6
+    assert np.all(w[5] == 0)
+    assert len(m.trainable_variables) == 2 + 4
+    m2 = MLP((10,), [3], 'softmax', 'glorot_normal', 'glorot_normal', batch_normalization=False, device='cpu')
+    assert [a.shape for a in m2.get_weights()] == [(10, 3), (3,)]
+    with pytest.raises(ValueError):
+        MLP((10,), [3, 2], ['relu'], 'zeros', 'zeros', device='cpu')
+    with pytest.raises(ValueError):
+        MLP((10,), [3], 'relu', 'zeros', 'zeros', dropout_rate=[0.1, 0.2], dropout_pos=[0], device='cpu')
+    with pytest.raises(ValueError):
+        MLP((10,), [3], 'swishh', 'zeros', 'zeros', device='cpu')
+    with pytest.raises(ValueError):
+        m2.set_weights([np.zeros((10, 4)), np.zeros(3)])
+    c = m.clone()
+    assert all(np.array_equal(a, b) for a, b in zip(c.get_weights(), m.get_weights()))
+    same = MLP((95,), [64, 32], ['selu', 'linear'], 'lecun_normal', 'zeros', rng=0, device='cpu')
+    assert all(np.array_equal(a, b) for a, b in zip(same.get_weights(), m.get_weights()))       # seeded
+
+
+def test_initializer_statistics():
+    rng = np.random.default_rng(0)
+    g = initialize('glorot_normal', (200, 100), rng)
+    assert abs(g.std() - np.sqrt(2 / 300)) < 2e-3
+    u = initialize('glorot_uniform', (200, 100), rng)
+    assert np.abs(u).max() <= np.sqrt(6 / 300)
+    b = initialize('lecun_normal', (50,), rng)         # 1-D: fan_in = fan_out = 50
+    assert b.shape == (50,) and np.abs(b).max() <= 2 * np.sqrt(1 / 50) / 0.8796 + 1e-6
+
+
+def test_model_ctor_asserts_and_config():
+    ns = MLP((31,), [14], 'selu', 'zeros', 'zeros', device='cpu')
+    no = MLP((14,), [2], 'softmax', 'zeros', 'zeros', device='cpu')
+    for bad in [dict(state_vect_dim=-1, max_iteration=1, state_threshold=0.1),
+                dict(state_vect_dim=0, max_iteration=-1, state_threshold=0.1),
+                dict(state_vect_dim=0, max_iteration=1, state_threshold=-0.1)]:
+        with pytest.raises(AssertionError):
+            GNNnodeBased(ns, no, **bad)
+    g = GNNgraphBased(ns, no, 0, 0, 0.01)               # homogeneous allows max_iteration == 0 (Q13)
+    assert g.get_config()['max_iteration'] == 0 and g.name == 'graph'
+    with pytest.raises(AssertionError):
+        CompositeGNNnodeBased([ns], no, 0, 0, 0.01)     # composite requires max_iteration > 0 (CompositeGNN.py:27)
+    c = g.copy()
+    assert c is not g and c.net_state is not g.net_state and c.state_threshold == 0.01
+    g.compile(optimizer='adam', loss='categorical_crossentropy', metrics=['accuracy'], average_st_grads=True,
+              run_eagerly=True)
+    assert g.average_st_grads is True and 'avg=True' in repr(g)
+    assert GNNarcBased.name == 'arc'
+
+
+def test_model_requires_device_tensors_no_cpu_fallback():
+    from gnnkeras_amd._native import NativeError
+    ns = MLP((31,), [14], 'selu', 'zeros', 'zeros', device='cpu')
+    no = MLP((14,), [2], 'softmax', 'zeros', 'zeros', device='cpu')
+    g = GraphObject(nodes=np.eye(14)[:5], arcs=np.array([[0, 1, 1, 0, 0], [1, 2, 0, 1, 0]]), targets=np.ones((1, 2)), focus='g')
+    seq = MultiGraphSequencer([g], 'g', 'sum', 1, shuffle=False, device='cpu')
+    with pytest.raises(NativeError):
+        GNNgraphBased(ns, no, 0, 3, 0.01)(seq[0][0])
+
+
+def test_graphobject_errors():
+    nodes, arcs, t = np.ones((3, 2)), np.array([[0, 1, 1.], [1, 2, 1.]]), np.ones((3, 1))
+    with pytest.raises(ValueError):
+        GraphObject(nodes, arcs, t, set_mask=np.ones(3), output_mask=np.ones(2))
+    with pytest.raises(ValueError):
+        GraphObject(nodes, arcs, t, aggregation_mode='mean')
+    with pytest.raises(ValueError):
+        CompositeGraphObject(nodes, arcs, t, type_mask=np.ones((3, 1)), dim_node_label=(2,), aggregation_mode='bogus')
+    g = GraphObject(nodes, arcs, t, focus='a')
+    assert len(g.set_mask) == 2 and g.NodeGraph.shape == (1, 0)
+    assert g.DIM_ARC_LABEL == 1 and g.DIM_TARGET == 1 and list(g.DIM_NODE_LABEL) == [2]
+
+
+def test_sequencer_tuple_layout(mutag_graphs):
+    gs = mutag_graphs[:70]
+    seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False, device='cpu')
+    assert len(seq) == 3
+    x, y, sw = seq[0]
+    assert len(x) == 8
+    nodes, arcs, dnl, sm, om, adj, an, ng = x
+    N, E = nodes.shape[0], arcs.shape[0]
+    assert arcs.shape[1] == 5 and tuple(dnl.shape) == (1, 1) and dnl.dtype == torch.int32 and int(dnl) == 14
+    assert tuple(sm.shape) == (N, 1) and sm.dtype == torch.bool and tuple(om.shape) == (N, 1)
+    for trip, shape in [(adj, (N, N)), (an, (E, N)), (ng, (N, 32))]:
+        idx, val, shp = trip
+        assert idx.dtype == torch.int64 and idx.shape[1] == 2 and tuple(val.shape) == (idx.shape[0], 1)
+        assert shp.dtype == torch.int64 and tuple(shp.tolist()) == shape
+    assert tuple(y.shape) == (32, 2) and tuple(sw.shape) == (32,)
+    assert seq[2][1].shape[0] == 70 - 64
+    # process_inputs squeezes [2:5] and turns [5:] into sparse matrices (GNN.py:181-193)
+    p = GNNgraphBased.process_inputs(x)
+    assert tuple(p[3].shape) == (N,) and isinstance(p[5], SparseMatrix) and p[5] is adj.matrix
+    # node-focused: targets rows = set_mask[output_mask]
+    rng = np.random.default_rng(0)
+    def node_graph(g):
+        om_ = rng.random(g.nodes.shape[0]) < .6
+        return GraphObject(g.nodes, g.arcs, rng.normal(size=(int(om_.sum()), 2)), focus='n',
+                           set_mask=rng.random(g.nodes.shape[0]) < .7, output_mask=om_)
+    ngs = [node_graph(g) for g in gs[:8]]
+    sq = MultiGraphSequencer(ngs, 'n', 'sum', 8, shuffle=False, device='cpu')
+    x, y, sw = sq[0]
+    sm, om_ = x[3].reshape(-1), x[4].reshape(-1)
+    assert y.shape[0] == int((sm & om_).sum()) == sw.shape[0]
+    sq.set_batch_size(3)
+    assert len(sq) == 3
+    assert len(sq.copy()) == 3 and 'node-focused' in repr(sq)
+
+
+def test_sequencer_shuffle_rebuilds():
+    rng = np.random.default_rng(1)
+    gs = [GraphObject(rng.normal(size=(n, 2)), np.array([[i, (i + 1) % n, 1.] for i in range(n)]), np.ones((1, 1)) * n,
+                      focus='g') for n in range(3, 13)]
+    seq = MultiGraphSequencer(gs, 'g', 'sum', 4, shuffle=True, device='cpu')
+    before = [float(t) for i in range(len(seq)) for t in seq[i][1].reshape(-1)]
+    np.random.seed(0)
+    seq.on_epoch_end()
+    after = [float(t) for i in range(len(seq)) for t in seq[i][1].reshape(-1)]
+    assert sorted(before) == sorted(after) and before != after
+
+
+def test_single_graph_sequencer_q7():
+    rng = np.random.default_rng(2)
+    n = 20
+    g = GraphObject(rng.normal(size=(n, 2)), np.array([[i, (i + 1) % n, 1.] for i in range(n)]), rng.normal(size=(n, 1)),
+                    focus='n', set_mask=np.arange(n) < 10)
+    seq = SingleGraphSequencer(g, 'n', batch_size=4, shuffle=False, device='cpu')
+    assert len(seq) == 3
+    x, y, sw = seq[0]
+    assert int(x[3].sum()) == 10 and y.shape[0] == 4      # x carries the full set_mask, targets the batch
+
+
+def test_composite_sequencer_layout():
+    rng = np.random.default_rng(3)
+    def cg(n):
+        tm = np.zeros((n, 2), bool); tm[np.arange(n), rng.integers(0, 2, n)] = True
+        return CompositeGraphObject(rng.normal(size=(n, 3)), np.array([[i, (i + 1) % n, 1.] for i in range(n)]),
+                                    rng.normal(size=(n, 1)), type_mask=tm, dim_node_label=(3, 2), focus='n')
+    seq = CompositeMultiGraphSequencer([cg(5), cg(7)], 'n', 'composite_average', 2, shuffle=False, device='cpu')
+    x, y, sw = seq[0]
+    assert len(x) == 10 and tuple(x[2].shape) == (2, 1) and tuple(x[3].shape) == (2, 12, 1)
+    assert isinstance(x[6], list) and len(x[6]) == 2 and tuple(x[7][2].tolist()) == (12, 12)
+    p = CompositeGNNnodeBased.process_inputs(x)
+    assert tuple(p[3].shape) == (2, 12) and isinstance(p[6][0], SparseMatrix)
+
+
+def test_npz_round_trip(tmp_path, mutag_graphs):
+    m = GraphObject.merge(mutag_graphs[:4], focus='g', aggregation_mode='average')
+    m.save(str(tmp_path / 'g.npz'))
+    back = GraphObject.load(str(tmp_path / 'g'), focus='g', aggregation_mode='average')
+    assert np.array_equal(back.arcs, m.arcs) and np.array_equal(back.nodes, m.nodes)
+    assert np.array_equal(back.NodeGraph.toarray(), m.NodeGraph.toarray())
+    assert np.array_equal(back.Adjacency.toarray(), m.Adjacency.toarray())
+    gt = GraphTensor.fromGraphObject(m, device='cpu')
+    gt.save(str(tmp_path / 't.npz'))
+    data = np.load(str(tmp_path / 't.npz'))
+    assert data['Adjacency'].shape == (m.arcs.shape[0], 3)          # [value, row, col] triples (graph_class.py:513)
+    assert tuple(data['Adjacency_shape']) == m.Adjacency.shape
+    back = GraphTensor.load(str(tmp_path / 't'), device='cpu')
+    assert np.array_equal(back.Adjacency.indices, gt.Adjacency.indices)
+    assert np.array_equal(back.ArcNode.values, gt.ArcNode.values)
+    again = GraphObject.fromGraphTensor(back, 'g')
+    assert np.array_equal(again.arcs, m.arcs) and np.array_equal(again.NodeGraph.toarray(), m.NodeGraph.toarray())
+    m.savetxt(str(tmp_path / 'txt'))
+    t = GraphObject.load_txt(str(tmp_path / 'txt'), focus='g', aggregation_mode='average')
+    assert np.allclose(t.arcs, m.arcs) and np.allclose(t.NodeGraph.toarray(), m.NodeGraph.toarray())
+
+
+def test_model_save_load(tmp_path):
+    ns = MLP((31,), [20, 14], ['selu', 'tanh'], 'lecun_normal', 'lecun_normal', rng=3, device='cpu')
+    no = MLP((14,), [2], 'softmax', 'glorot_normal', 'zeros', rng=4, device='cpu')
+    g = GNNgraphBased(ns, no, 0, 5, 0.01)
+    g.save(str(tmp_path / 'model'))
+    import json
+    assert json.load(open(tmp_path / 'model' / 'config.json')) == {'state_vect_dim': 0, 'max_iteration': 5, 'state_threshold': 0.01}
+    b = GNNgraphBased.load(str(tmp_path / 'model'))
+    assert b.max_iteration == 5 and b.net_state.units == [20, 14] and b.net_state.activations == ['selu', 'tanh']
+    assert all(np.array_equal(x, y) for x, y in zip(b.net_state.get_weights(), ns.get_weights()))

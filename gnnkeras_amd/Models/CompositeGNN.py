@@ -35,6 +35,7 @@ class CompositeGNNnodeBased(GNNnodeBased):
         self.max_iteration = int(max_iteration)
         self.state_threshold = state_threshold
         self.native_flags = 0
+        self.loop_events = None
         self._engine_init()
         self._type_cache = {}
 
@@ -176,6 +177,8 @@ class CompositeGNNnodeBased(GNNnodeBased):
             ng = SparseMatrix.from_triple(nodegraph).device_csr(dev)
             a.nodegraph = nat.make_csr(ng); keep.append(ng)
         a.flags = self.native_flags
+        if self.loop_events is not None:
+            a.ev_loop_begin, a.ev_loop_end = (C.c_void_p(e.cuda_event) for e in self.loop_events)
         a.stream = nat.current_stream(dev)
         nbytes = nat.lib().gnn_loop_workspace_bytes(C.byref(a))
         if nbytes == 0: nat.check(1)

@@ -152,6 +152,7 @@ class GNNnodeBased(_LoopModel):
         self.max_iteration = int(max_iteration)
         self.state_threshold = state_threshold
         self.native_flags = 0          # OR of _native.FLAG_* (tests use FLAG_UNFUSED)
+        self.loop_events = None        # optional (begin, end) torch.cuda.Event pair recorded around the iterations
         self._engine_init()
 
     # ---- copy / config / persistence ---------------------------------------------------------------------------------
@@ -302,6 +303,8 @@ class GNNnodeBased(_LoopModel):
                 ng = SparseMatrix.from_triple(nodegraph).device_csr(dev)
                 a.nodegraph = nat.make_csr(ng); keep.append(ng)
         a.flags = self.native_flags
+        if self.loop_events is not None:
+            a.ev_loop_begin, a.ev_loop_end = (C.c_void_p(e.cuda_event) for e in self.loop_events)
         a.stream = nat.current_stream(dev)
         nbytes = nat.lib().gnn_loop_workspace_bytes(C.byref(a))
         if nbytes == 0: nat.check(1)

@@ -60,7 +60,7 @@ class LoopArgs(C.Structure):
                 ('arc_src', C.c_void_p), ('arc_dst', C.c_void_p), ('nodegraph', CSR),
                 ('k_out', C.c_void_p), ('state_out', C.c_void_p), ('out', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('stream', C.c_void_p),
-                ('flags', C.c_int32)]
+                ('flags', C.c_int32), ('ev_loop_begin', C.c_void_p), ('ev_loop_end', C.c_void_p)]
 
 
 class NativeError(RuntimeError):

@@ -509,6 +509,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
 
     const bool fused = can_fuse(a, p);
     const bool no_exit = (a.flags & GNN_FLAG_NO_EARLY_EXIT) != 0;
+    if (a.ev_loop_begin) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_begin, st));
     for (int it = 0; it < a.max_iteration; ++it) {
         const int *gate = no_exit ? nullptr : p.flags + it;
         const float *src = p.buf[it & 1];
@@ -518,6 +519,8 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
                                                p.flags + it + 1, a.k_out, (float)(it + 1), st));
         else       TRY(iteration_unfused(a, p, gate, src, dst, p.flags + it + 1, a.k_out, (float)(it + 1), st));
     }
+
+    if (a.ev_loop_end) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_end, st));
 
     // converged state -> caller's compact [N, S] buffer; k (device) tells which of the two buffers holds it
     {

@@ -118,6 +118,9 @@ typedef struct gnn_loop_args {
     size_t workspace_bytes;
     void *stream;
     int32_t flags;            /* enum gnn_flags                                                                 */
+    /* measurement (optional) ------------------------------------------------------------------------------------ */
+    void *ev_loop_begin;      /* hipEvent_t or NULL: recorded on `stream` right before the first iteration launch */
+    void *ev_loop_end;        /* hipEvent_t or NULL: recorded right after the last iteration launch               */
 } gnn_loop_args_t;
 
 const char *gnn_last_error(void);

@@ -12,6 +12,7 @@
 #include <stdarg.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "../../include/gnnloop.h"
 #include "kernels_general.hpp"
 #include "kernel_state_fused.hpp"
+#include "kernel_state_fused2.hpp"
 
 namespace {
 
@@ -456,6 +458,61 @@ int output_stage(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     return 0;
 }
 
+// which fused kernel: GNN_FUSED_VARIANT = 1 (first generation), 2 (pipelined, 64-node tiles; default), 3 (pipelined,
+// 32-node tiles, 3 workgroups per CU).  Read once; a tuning knob, never a correctness switch.
+int fused_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GNN_FUSED_VARIANT");
+        v = e ? atoi(e) : 2;
+        if (v < 1 || v > 3) v = 2;
+    }
+    return v;
+}
+
+int device_cus() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        n_cu = prop.multiProcessorCount;
+    }
+    return n_cu;
+}
+
+// one fused iteration over every node type (one launch per type)
+int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, int n_gate, int gate_stride,
+                    const float *src, float *dst, int row_base, int *flag_next, float *k_out, float k_val,
+                    hipStream_t st) {
+    auto type_of = [&](int t) {
+        return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg,
+                              (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0]};
+    };
+    const int variant = fused_variant();
+    if (variant == 1 && row_base == 0 && n_gate <= 1) {
+        FUSED_OK(gnn::launch_state_fused(a, p.T, p.N, p.S, p.SP, n_gate ? gate : nullptr, src, dst, p.C, p.ldC, type_of,
+                                         flag_next, k_out, k_val, st));
+        return 0;
+    }
+    bool k_written = false;
+    for (int t = 0; t < p.T; ++t) {
+        gnn::Fused2Args fa;
+        fa.gate = n_gate ? gate : nullptr; fa.n_gate = n_gate; fa.gate_stride = gate_stride;
+        fa.rowptr = a.adjacency.rowptr; fa.src = a.adjacency.src; fa.w = a.adjacency.w; fa.row_scale = a.adjacency.row_scale;
+        fa.state_in = src; fa.state_out = dst; fa.row_base = row_base;
+        fa.C = p.C; fa.ldC = p.ldC;
+        fa.tp = type_of(t);
+        fa.S = p.S; fa.thr = a.state_threshold;
+        fa.flag_next = flag_next;
+        fa.k_out = k_written ? nullptr : k_out; fa.k_val = k_val;
+        if (fa.tp.count == 0) continue;
+        k_written = true;
+        FUSED_OK(gnn::launch_fused2(fa, p.SP, variant == 3 ? 32 : 64, device_cus(), st));
+    }
+    return 0;
+}
+
 bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
     if (a.flags & GNN_FLAG_UNFUSED) return false;
     if (p.SP > 64) return false;   // LDS: [64 x 2SP] tile + [2SP x SP] weights must leave room for 2 workgroups per CU
@@ -514,9 +571,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         const int *gate = no_exit ? nullptr : p.flags + it;
         const float *src = p.buf[it & 1];
         float *dst = p.buf[(it + 1) & 1];
-        if (fused) FUSED_OK(gnn::launch_state_fused(a, p.T, p.N, p.S, p.SP, gate, src, dst, p.C, p.ldC,
-                                               [&](int t) { return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg, (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0]}; },
-                                               p.flags + it + 1, a.k_out, (float)(it + 1), st));
+        if (fused) TRY(iteration_fused(a, p, gate, gate ? 1 : 0, 0, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
         else       TRY(iteration_unfused(a, p, gate, src, dst, p.flags + it + 1, a.k_out, (float)(it + 1), st));
     }
 
@@ -604,9 +659,7 @@ int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *st
     if (p.SP != p.S) HIP_OK(hipMemsetAsync(p.buf[1], 0, sizeof(float) * (size_t)p.N * p.SP, st));
     if (flag_out) HIP_OK(hipMemsetAsync(flag_out, 0, sizeof(int32_t), st));
     if (can_fuse(a, p))
-        FUSED_OK(gnn::launch_state_fused(a, p.T, p.N, p.S, p.SP, nullptr, p.buf[0], p.buf[1], p.C, p.ldC,
-                                    [&](int t) { return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg, (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0]}; },
-                                    flag_out, nullptr, 0.f, st));
+        TRY(iteration_fused(a, p, nullptr, 0, 0, p.buf[0], p.buf[1], 0, flag_out, nullptr, 0.f, st));
     else
         TRY(iteration_unfused(a, p, nullptr, p.buf[0], p.buf[1], flag_out, nullptr, 0.f, st));
     return launch_copy2d(nullptr, p.buf[1], p.SP, state_out, p.S, p.N, p.S, p.S, st);

@@ -1,0 +1,334 @@
+// Fused state-transition iteration, second generation (the hot kernel of the loop on gfx950).
+//
+// Same contract as kernel_state_fused.hpp (one launch = `convergence` + next `condition`, reference
+// GNN/Models/GNN.py:217-236, :196-214) with the memory pipeline rebuilt around what the first profile showed — the
+// kernel was latency-bound on the dependent chain  node id -> rowptr -> source ids -> state rows  (rocprof r01_v1):
+//   * node slots are software-pipelined: while the state rows of slot s are in flight, the source ids of slot s+1,
+//     the row pointers of slot s+2 and the node id of slot s+3 are already being fetched, across tile boundaries;
+//   * the <=16 source ids of a node arrive with ONE coalesced load per lane group and are broadcast with
+//     ds_bpermute; all of a node's neighbour rows (16 B per lane, one 256-B row per 16 lanes at d = 64) are issued
+//     before the first is consumed, then summed in ascending-source order;
+//   * the per-node constant C is loaded straight into the MFMA accumulators at tile start (D = A.B + C), so its
+//     latency hides under the gather instead of stalling the epilogue;
+//   * W1 sits un-padded in LDS behind an XOR swizzle (conflict-free B fragments), A rows use an odd-pair stride.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernel_state_fused.hpp"
+
+namespace gnn {
+
+struct Fused2Args {
+    const int *gate; int n_gate, gate_stride;      // run iff OR of gate[i * gate_stride], i < n_gate, is non-zero
+    const int *rowptr, *src;                       // CSR by (local) destination; src ids index rows of state_in
+    const float *w, *row_scale;
+    const float *state_in;                         // [n_src_rows, SP]
+    float *state_out;                              // rows written at (row_base + j)
+    int row_base;                                  // own rows of local node j live at row_base + j (0 on one GPU)
+    const float *C; int ldC;
+    FusedType tp;
+    int S;
+    float thr;
+    int *flag_next;
+    float *k_out; float k_val;
+};
+
+template <int SP, int TM>
+struct Fused2Cfg {
+    static constexpr int LPR = SP / 4;               // lanes per node row (16 B each)
+    static constexpr int NPP = 256 / LPR;            // node slots per pass of the workgroup
+    static constexpr int NPASS = TM / NPP;
+    static constexpr int IPL = 16 / LPR;             // source ids held per lane (16 per node and chunk)
+    static constexpr int LDX = 2 * SP + 2;           // A rows: stride == 2 (mod 32) dwords -> conflict-free ds_read_b32
+    static constexpr bool SWZ = SP >= 32;            // W1 un-padded, column ^= 16 on odd k
+    static constexpr int LDW = SWZ ? SP : SP + 32;
+    static constexpr int NCT = SP / 16;              // 16-column MFMA tiles
+    static constexpr int RW = TM / 16;               // waves along rows
+    static constexpr int CW = 4 / RW;                // waves along columns
+    static constexpr int CT_PER_WAVE = NCT / CW;
+    static_assert(NPASS >= 1 && TM % NPP == 0, "tile must be a whole number of passes");
+    static_assert(RW >= 1 && RW <= 4 && NCT % CW == 0, "unsupported tile / width combination");
+    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)TM * LDX + 2 * SP * LDW) + sizeof(int) * TM;
+};
+
+template <int SP, bool HAS_W, int TM>
+__global__ void __launch_bounds__(256, 2) k_state_fused2(Fused2Args a) {
+    {
+        int open = a.gate == nullptr;
+        for (int i = 0; i < a.n_gate && !open; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
+        if (!open) return;
+    }
+    using Cfg = Fused2Cfg<SP, TM>;
+    constexpr int LPR = Cfg::LPR, IPL = Cfg::IPL, LDX = Cfg::LDX, LDW = Cfg::LDW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Xs = reinterpret_cast<float *>(smem);                         // [TM][LDX]  : [state | agg]
+    float *Ws = Xs + TM * LDX;                                           // [2SP][LDW] : W1 rows (state ; agg)
+    int *jid = reinterpret_cast<int *>(Ws + 2 * SP * LDW);               // [TM] local node id per tile row, -1 = pad
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int S = a.S;
+    const int count = a.tp.count;
+    const int *__restrict__ rows = a.tp.rows;
+
+    for (int i = tid; i < 2 * SP * SP; i += 256) {
+        const int k = i / SP, n = i % SP;
+        const int kk = k < SP ? k : k - SP;
+        float v = 0.0f;
+        if (kk < S && n < S) v = a.tp.Wf[(size_t)((k < SP ? a.tp.wrow_state : a.tp.wrow_agg) + kk) * a.tp.H + n];
+        Ws[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = v;
+    }
+
+    // XCD-contiguous tile ranges (workgroups b, b+8, .. share an XCD under round-robin dispatch; speed only)
+    const int ntiles = (count + TM - 1) / TM;
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const int blk_per_xcd = (gridDim.x + 7 - xcd) >> 3;
+    const int tpx = (ntiles + 7) >> 3;
+    const int t_end = min(ntiles, (xcd + 1) * tpx);
+    const int t_first = xcd * tpx + lb;
+
+    const int q = tid / LPR;          // node slot inside a pass
+    const int l4 = tid % LPR;         // 16-B column chunk of the row owned by this lane
+
+    // ---- slot pipeline: slot index n counts (tile, pass) pairs of this workgroup -------------------------------------
+    auto slot_m = [&](int n) -> int {               // global row number m of slot n for this lane group, or -1
+        const int tile = t_first + (n / Cfg::NPASS) * blk_per_xcd;
+        if (tile >= t_end) return -1;
+        const int m = tile * TM + (n % Cfg::NPASS) * Cfg::NPP + q;
+        return m < count ? m : -1;
+    };
+    auto node_of = [&](int m) -> int { return m < 0 ? -1 : (rows ? rows[m] : m); };
+
+    int n_slot = 0;
+    int j0, beg0 = 0, end0 = 0, j1, beg1 = 0, end1 = 0, j2, j3;
+    int ids0[IPL]; float ws0[IPL];
+    j0 = node_of(slot_m(0)); j1 = node_of(slot_m(1)); j2 = node_of(slot_m(2)); j3 = node_of(slot_m(3));
+    if (j0 >= 0) { beg0 = a.rowptr[j0]; end0 = a.rowptr[j0 + 1]; }
+    if (j1 >= 0) { beg1 = a.rowptr[j1]; end1 = a.rowptr[j1 + 1]; }
+#pragma unroll
+    for (int u = 0; u < IPL; ++u) {
+        const int e = beg0 + u * LPR + l4;
+        ids0[u] = e < end0 ? a.src[e] : 0;
+        ws0[u] = (HAS_W && e < end0) ? a.w[e] : 0.0f;
+    }
+
+    int any = 0;
+    for (int tile = t_first; tile < t_end; tile += blk_per_xcd) {
+        __syncthreads();   // previous tile's Xs fully consumed (and, first time, the W fill is visible)
+
+        // accumulators start from the per-node constant C: D = [state|agg].W1 + C
+        f32x4 c[Cfg::CT_PER_WAVE];
+        int jrow[4];
+        const int rt = wave % Cfg::RW, cw = wave / Cfg::RW;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = tile * TM + 16 * rt + 4 * g + reg;
+            jrow[reg] = m < count ? (rows ? rows[m] : m) : -1;
+        }
+#pragma unroll
+        for (int ci = 0; ci < Cfg::CT_PER_WAVE; ++ci) {
+            const int col = 16 * (cw * Cfg::CT_PER_WAVE + ci) + r;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                c[ci][reg] = (jrow[reg] >= 0 && col < S) ? a.C[(size_t)jrow[reg] * a.ldC + col] : 0.0f;
+        }
+
+        // ---- A. gather + aggregate, one node slot per lane group and pass --------------------------------------------
+#pragma unroll 1
+        for (int pass = 0; pass < Cfg::NPASS; ++pass) {
+            // prefetch for later slots first (their addresses are already known)
+            int ids1[IPL]; float ws1[IPL];
+#pragma unroll
+            for (int u = 0; u < IPL; ++u) {
+                const int e = beg1 + u * LPR + l4;
+                ids1[u] = e < end1 ? a.src[e] : 0;
+                ws1[u] = (HAS_W && e < end1) ? a.w[e] : 0.0f;
+            }
+            int beg2 = 0, end2 = 0;
+            if (j2 >= 0) { beg2 = a.rowptr[j2]; end2 = a.rowptr[j2 + 1]; }
+            const int j4 = node_of(slot_m(n_slot + 4));
+
+            // current slot: every neighbour row in flight before the first add
+            f32x4 own = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
+            const int deg = end0 - beg0;
+            if (j0 >= 0) own = *reinterpret_cast<const f32x4 *>(a.state_in + (size_t)(a.row_base + j0) * SP + 4 * l4);
+            {
+                f32x4 v[16];
+                int sid[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sid[i] = __shfl(ids0[i / LPR], i % LPR, LPR);
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i < deg) v[i] = *reinterpret_cast<const f32x4 *>(a.state_in + (size_t)sid[i] * SP + 4 * l4);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float wv = HAS_W ? __shfl(ws0[i / LPR], i % LPR, LPR) : 1.0f;
+                    if (i < deg) { if (HAS_W) acc += wv * v[i]; else acc += v[i]; }
+                }
+            }
+            for (int e0 = beg0 + 16; e0 < end0; e0 += 16) {        // rare: in-degree > 16, not pipelined
+                int idx[IPL]; float wx[IPL];
+#pragma unroll
+                for (int u = 0; u < IPL; ++u) {
+                    const int e = e0 + u * LPR + l4;
+                    idx[u] = e < end0 ? a.src[e] : 0;
+                    wx[u] = (HAS_W && e < end0) ? a.w[e] : 0.0f;
+                }
+                const int rem = end0 - e0;
+                f32x4 v[16];
+                int sid[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sid[i] = __shfl(idx[i / LPR], i % LPR, LPR);
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i < rem) v[i] = *reinterpret_cast<const f32x4 *>(a.state_in + (size_t)sid[i] * SP + 4 * l4);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float wv = HAS_W ? __shfl(wx[i / LPR], i % LPR, LPR) : 1.0f;
+                    if (i < rem) { if (HAS_W) acc += wv * v[i]; else acc += v[i]; }
+                }
+            }
+            if (a.row_scale && j0 >= 0) acc *= a.row_scale[j0];
+
+            const int nl = pass * Cfg::NPP + q;
+            float *xr = Xs + nl * LDX + 4 * l4;                     // rows are 8-B aligned: two b64 stores each
+            *reinterpret_cast<float2 *>(xr) = make_float2(own[0], own[1]);
+            *reinterpret_cast<float2 *>(xr + 2) = make_float2(own[2], own[3]);
+            *reinterpret_cast<float2 *>(xr + SP) = make_float2(acc[0], acc[1]);
+            *reinterpret_cast<float2 *>(xr + SP + 2) = make_float2(acc[2], acc[3]);
+            if (l4 == 0) jid[nl] = j0;
+
+            // rotate the pipeline
+            j0 = j1; beg0 = beg1; end0 = end1;
+#pragma unroll
+            for (int u = 0; u < IPL; ++u) { ids0[u] = ids1[u]; ws0[u] = ws1[u]; }
+            j1 = j2; beg1 = beg2; end1 = end2;
+            j2 = j3; j3 = j4;
+            ++n_slot;
+        }
+        __syncthreads();
+
+        // ---- B. [state | agg] . W1 on the f32 matrix cores ------------------------------------------------------------
+        const float *xrow = Xs + (16 * rt + r) * LDX + g;
+#pragma unroll 8
+        for (int s4 = 0; s4 < 2 * SP / 4; ++s4) {
+            const float av = xrow[4 * s4];
+            const int k = 4 * s4 + g;
+#pragma unroll
+            for (int ci = 0; ci < Cfg::CT_PER_WAVE; ++ci) {
+                const int n = 16 * (cw * Cfg::CT_PER_WAVE + ci) + r;
+                const float bv = Ws[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)];
+                c[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c[ci], 0, 0, 0);
+            }
+        }
+
+        // ---- C. activation, predicate, stage new rows ----------------------------------------------------------------
+        // C/D layout: col = 16*ct + (lane & 15), row = 16*rt + 4*(lane >> 4) + reg.  With CW > 1 a row's columns are
+        // split over CW waves: partial sums meet in LDS (the agg half of Xs is dead after the MFMA loop).
+        float d2r[4], n2r[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 16 * rt + 4 * g + reg;
+            float d2 = 0.0f, n2 = 0.0f;
+#pragma unroll
+            for (int ci = 0; ci < Cfg::CT_PER_WAVE; ++ci) {
+                const int col = 16 * (cw * Cfg::CT_PER_WAVE + ci) + r;
+                const float nv = (jrow[reg] >= 0 && col < S) ? activate(a.tp.act, c[ci][reg]) : 0.0f;
+                const float ov = Xs[row * LDX + col];
+                const float d = nv - ov;
+                d2 = fmaf(d, d, d2);
+                n2 = fmaf(ov, ov, n2);
+                c[ci][reg] = nv;
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                d2 += __shfl_xor(d2, off, 16);
+                n2 += __shfl_xor(n2, off, 16);
+            }
+            d2r[reg] = d2; n2r[reg] = n2;
+        }
+        if (Cfg::CW > 1) {
+            __syncthreads();                                   // every wave is done reading Xs (A fragments, old state)
+            if (r == 0) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 16 * rt + 4 * g + reg;
+                    Xs[row * LDX + SP + 2 * cw] = d2r[reg];
+                    Xs[row * LDX + SP + 2 * cw + 1] = n2r[reg];
+                }
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 16 * rt + 4 * g + reg;
+#pragma unroll
+            for (int ci = 0; ci < Cfg::CT_PER_WAVE; ++ci)
+                Xs[row * LDX + 16 * (cw * Cfg::CT_PER_WAVE + ci) + r] = c[ci][reg];   // own (row, col) slot only
+        }
+        __syncthreads();
+        if (Cfg::CW > 1) {
+            if (cw == 0 && r == 0) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 16 * rt + 4 * g + reg;
+                    float d2 = 0.0f, n2 = 0.0f;
+                    for (int w2 = 0; w2 < Cfg::CW; ++w2) { d2 += Xs[row * LDX + SP + 2 * w2]; n2 += Xs[row * LDX + SP + 2 * w2 + 1]; }
+                    if (jrow[reg] >= 0 && sqrtf(d2) > a.thr * sqrtf(n2)) any = 1;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (jrow[reg] >= 0 && sqrtf(d2r[reg]) > a.thr * sqrtf(n2r[reg])) any = 1;
+        }
+        // whole-row (4*SP bytes) coalesced stores of the new state
+#pragma unroll 1
+        for (int pass = 0; pass < Cfg::NPASS; ++pass) {
+            const int nl = pass * Cfg::NPP + q;
+            const int j = jid[nl];
+            if (j >= 0) {
+                const float *xr = Xs + nl * LDX + 4 * l4;
+                const float2 lo = *reinterpret_cast<const float2 *>(xr), hi = *reinterpret_cast<const float2 *>(xr + 2);
+                *reinterpret_cast<f32x4 *>(a.state_out + (size_t)(a.row_base + j) * SP + 4 * l4) = (f32x4){lo.x, lo.y, hi.x, hi.y};
+            }
+        }
+    }
+
+    any = __syncthreads_or(any);
+    if (tid == 0) {
+        if (any && a.flag_next) atomicOr(a.flag_next, 1);
+        if (blockIdx.x == 0 && a.k_out) *a.k_out = a.k_val;
+    }
+}
+
+template <int SP, bool HAS_W, int TM>
+int launch_fused2_one(const Fused2Args &fa, int n_cu, hipStream_t st) {
+    using Cfg = Fused2Cfg<SP, TM>;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)k_state_fused2<SP, HAS_W, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
+        attr = true;
+    }
+    const int ntiles = (fa.tp.count + TM - 1) / TM;
+    const int blocks_per_cu = std::max(1, std::min(4, (int)(160 * 1024 / Cfg::LDS_BYTES)));
+    int grid = std::min(ntiles, blocks_per_cu * n_cu);
+    grid = std::max(8, (grid + 7) / 8 * 8);
+    k_state_fused2<SP, HAS_W, TM><<<grid, 256, Cfg::LDS_BYTES, st>>>(fa);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+template <int SP, int TM>
+int launch_fused2_w(const Fused2Args &fa, int n_cu, hipStream_t st) {
+    return fa.w ? launch_fused2_one<SP, true, TM>(fa, n_cu, st) : launch_fused2_one<SP, false, TM>(fa, n_cu, st);
+}
+
+inline int launch_fused2(const Fused2Args &fa, int SP, int tm, int n_cu, hipStream_t st) {
+    switch (SP) {
+        case 16: return launch_fused2_w<16, 64>(fa, n_cu, st);
+        case 32: return tm == 32 ? launch_fused2_w<32, 32>(fa, n_cu, st) : launch_fused2_w<32, 64>(fa, n_cu, st);
+        case 64: return tm == 32 ? launch_fused2_w<64, 32>(fa, n_cu, st) : launch_fused2_w<64, 64>(fa, n_cu, st);
+        default: return 1;
+    }
+}
+
+}  // namespace gnn

@@ -195,7 +195,7 @@ def main():
     achieved = b_iter / t_iter
     roofline = {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK, 'traffic': None,
-                'kernel': 'k_state_fused<64,false>' if not args.unfused else 'k_aggregate+k_segdense+k_converge',
+                'kernel': 'k_state_fused2<64,false,64,8>' if not args.unfused else 'k_aggregate+k_segdense+k_converge',
                 'algorithmic_bytes_per_launch': b_iter, 'avg_launch_us': 1e6 * t_iter}
     traffic_file = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     if os.path.exists(traffic_file) and world == 1 and not args.unfused:

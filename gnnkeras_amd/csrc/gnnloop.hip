@@ -458,14 +458,15 @@ int output_stage(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     return 0;
 }
 
-// which fused kernel: GNN_FUSED_VARIANT = 1 (first generation), 2 (pipelined, 64-node tiles; default), 3 (pipelined,
-// 32-node tiles, 3 workgroups per CU).  Read once; a tuning knob, never a correctness switch.
+// which fused kernel: GNN_FUSED_VARIANT = 1 (first generation), 2 (pipelined, 64-node tiles, 4 waves), 3 (pipelined,
+// 32-node tiles, 3 workgroups per CU), 4 (pipelined, 64-node tiles, 8 waves, 16 waves per CU; default).
+// Read once; a tuning knob, never a correctness switch.
 int fused_variant() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("GNN_FUSED_VARIANT");
-        v = e ? atoi(e) : 2;
-        if (v < 1 || v > 3) v = 2;
+        v = e ? atoi(e) : 4;
+        if (v < 1 || v > 4) v = 4;
     }
     return v;
 }
@@ -508,7 +509,7 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
         fa.k_out = k_written ? nullptr : k_out; fa.k_val = k_val;
         if (fa.tp.count == 0) continue;
         k_written = true;
-        FUSED_OK(gnn::launch_fused2(fa, p.SP, variant == 3 ? 32 : 64, device_cus(), st));
+        FUSED_OK(gnn::launch_fused2(fa, p.SP, variant, device_cus(), st));
     }
     return 0;
 }

@@ -32,10 +32,11 @@ struct Fused2Args {
     float *k_out; float k_val;
 };
 
-template <int SP, int TM>
+template <int SP, int TM, int NW>
 struct Fused2Cfg {
+    static constexpr int NT = 64 * NW;               // threads per workgroup
     static constexpr int LPR = SP / 4;               // lanes per node row (16 B each)
-    static constexpr int NPP = 256 / LPR;            // node slots per pass of the workgroup
+    static constexpr int NPP = NT / LPR;             // node slots per pass of the workgroup
     static constexpr int NPASS = TM / NPP;
     static constexpr int IPL = 16 / LPR;             // source ids held per lane (16 per node and chunk)
     static constexpr int LDX = 2 * SP + 2;           // A rows: stride == 2 (mod 32) dwords -> conflict-free ds_read_b32
@@ -43,21 +44,22 @@ struct Fused2Cfg {
     static constexpr int LDW = SWZ ? SP : SP + 32;
     static constexpr int NCT = SP / 16;              // 16-column MFMA tiles
     static constexpr int RW = TM / 16;               // waves along rows
-    static constexpr int CW = 4 / RW;                // waves along columns
+    static constexpr int CW = NW / RW;               // waves along columns
     static constexpr int CT_PER_WAVE = NCT / CW;
     static_assert(NPASS >= 1 && TM % NPP == 0, "tile must be a whole number of passes");
-    static_assert(RW >= 1 && RW <= 4 && NCT % CW == 0, "unsupported tile / width combination");
+    static_assert(RW >= 1 && RW <= NW && NW % RW == 0 && NCT % CW == 0, "unsupported tile / width combination");
     static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)TM * LDX + 2 * SP * LDW) + sizeof(int) * TM;
 };
 
-template <int SP, bool HAS_W, int TM>
-__global__ void __launch_bounds__(256, 2) k_state_fused2(Fused2Args a) {
+template <int SP, bool HAS_W, int TM, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) k_state_fused2(Fused2Args a) {
     {
         int open = a.gate == nullptr;
         for (int i = 0; i < a.n_gate && !open; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
         if (!open) return;
     }
-    using Cfg = Fused2Cfg<SP, TM>;
+    using Cfg = Fused2Cfg<SP, TM, NW>;
+    constexpr int NT = Cfg::NT;
     constexpr int LPR = Cfg::LPR, IPL = Cfg::IPL, LDX = Cfg::LDX, LDW = Cfg::LDW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *Xs = reinterpret_cast<float *>(smem);                         // [TM][LDX]  : [state | agg]
@@ -70,7 +72,7 @@ __global__ void __launch_bounds__(256, 2) k_state_fused2(Fused2Args a) {
     const int count = a.tp.count;
     const int *__restrict__ rows = a.tp.rows;
 
-    for (int i = tid; i < 2 * SP * SP; i += 256) {
+    for (int i = tid; i < 2 * SP * SP; i += NT) {
         const int k = i / SP, n = i % SP;
         const int kk = k < SP ? k : k - SP;
         float v = 0.0f;
@@ -86,6 +88,7 @@ __global__ void __launch_bounds__(256, 2) k_state_fused2(Fused2Args a) {
     const int t_end = min(ntiles, (xcd + 1) * tpx);
     const int t_first = xcd * tpx + lb;
 
+    const char *__restrict__ sbase = reinterpret_cast<const char *>(a.state_in);   // state_in spans < 4 GiB (checked by the launcher)
     const int q = tid / LPR;          // node slot inside a pass
     const int l4 = tid % LPR;         // 16-B column chunk of the row owned by this lane
 
@@ -127,9 +130,12 @@ __global__ void __launch_bounds__(256, 2) k_state_fused2(Fused2Args a) {
 #pragma unroll
         for (int ci = 0; ci < Cfg::CT_PER_WAVE; ++ci) {
             const int col = 16 * (cw * Cfg::CT_PER_WAVE + ci) + r;
+            const int colc = min(col, S - 1);
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                c[ci][reg] = (jrow[reg] >= 0 && col < S) ? a.C[(size_t)jrow[reg] * a.ldC + col] : 0.0f;
+            for (int reg = 0; reg < 4; ++reg) {          // always-valid address, value masked afterwards: no branches
+                const float cv = a.C[(size_t)max(jrow[reg], 0) * a.ldC + colc];
+                c[ci][reg] = (jrow[reg] >= 0 && col < S) ? cv : 0.0f;
+            }
         }
 
         // ---- A. gather + aggregate, one node slot per lane group and pass --------------------------------------------
@@ -152,39 +158,38 @@ __global__ void __launch_bounds__(256, 2) k_state_fused2(Fused2Args a) {
             const int deg = end0 - beg0;
             if (j0 >= 0) own = *reinterpret_cast<const f32x4 *>(a.state_in + (size_t)(a.row_base + j0) * SP + 4 * l4);
             {
-                f32x4 v[16];
-                int sid[16];
+                // chunks of 16 neighbours; the first chunk's ids were prefetched a slot ago, later chunks (in-degree
+                // > 16, rare) fetch theirs in line.  One copy of the 16-load block: keeps the kernel near 128 VGPRs.
+                int idc[IPL]; float wsc[IPL];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sid[i] = __shfl(ids0[i / LPR], i % LPR, LPR);
+                for (int u = 0; u < IPL; ++u) { idc[u] = ids0[u]; wsc[u] = ws0[u]; }
+                int rem = deg;
+                int eb = beg0;
+#pragma unroll 1
+                while (true) {
+                    f32x4 v[16];
+                    unsigned off[16];   // 32-bit byte offsets off a wave-uniform base: SGPR base + VGPR offset addressing
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (i < deg) v[i] = *reinterpret_cast<const f32x4 *>(a.state_in + (size_t)sid[i] * SP + 4 * l4);
+                    for (int i = 0; i < 16; ++i) {
+                        off[i] = (unsigned)__shfl(idc[i / LPR], i % LPR, LPR) * (unsigned)(SP * 4) + 16u * l4;
+                        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float wv = HAS_W ? __shfl(ws0[i / LPR], i % LPR, LPR) : 1.0f;
-                    if (i < deg) { if (HAS_W) acc += wv * v[i]; else acc += v[i]; }
-                }
-            }
-            for (int e0 = beg0 + 16; e0 < end0; e0 += 16) {        // rare: in-degree > 16, not pipelined
-                int idx[IPL]; float wx[IPL];
+                    for (int i = 0; i < 16; ++i)
+                        if (i < rem) v[i] = *reinterpret_cast<const f32x4 *>(sbase + off[i]);
 #pragma unroll
-                for (int u = 0; u < IPL; ++u) {
-                    const int e = e0 + u * LPR + l4;
-                    idx[u] = e < end0 ? a.src[e] : 0;
-                    wx[u] = (HAS_W && e < end0) ? a.w[e] : 0.0f;
-                }
-                const int rem = end0 - e0;
-                f32x4 v[16];
-                int sid[16];
+                    for (int i = 0; i < 16; ++i) {
+                        if (HAS_W) acc += __shfl(wsc[i / LPR], i % LPR, LPR) * v[i];
+                        else acc += v[i];
+                    }
+                    rem -= 16; eb += 16;
+                    if (!__any(rem > 0)) break;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sid[i] = __shfl(idx[i / LPR], i % LPR, LPR);
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (i < rem) v[i] = *reinterpret_cast<const f32x4 *>(a.state_in + (size_t)sid[i] * SP + 4 * l4);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float wv = HAS_W ? __shfl(wx[i / LPR], i % LPR, LPR) : 1.0f;
-                    if (i < rem) { if (HAS_W) acc += wv * v[i]; else acc += v[i]; }
+                    for (int u = 0; u < IPL; ++u) {
+                        const int e = eb + u * LPR + l4;
+                        idc[u] = e < end0 ? a.src[e] : 0;
+                        wsc[u] = (HAS_W && e < end0) ? a.w[e] : 0.0f;
+                    }
                 }
             }
             if (a.row_scale && j0 >= 0) acc *= a.row_scale[j0];
@@ -300,12 +305,12 @@ __global__ void __launch_bounds__(256, 2) k_state_fused2(Fused2Args a) {
     }
 }
 
-template <int SP, bool HAS_W, int TM>
+template <int SP, bool HAS_W, int TM, int NW>
 int launch_fused2_one(const Fused2Args &fa, int n_cu, hipStream_t st) {
-    using Cfg = Fused2Cfg<SP, TM>;
+    using Cfg = Fused2Cfg<SP, TM, NW>;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)k_state_fused2<SP, HAS_W, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)k_state_fused2<SP, HAS_W, TM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
         attr = true;
     }
@@ -313,20 +318,23 @@ int launch_fused2_one(const Fused2Args &fa, int n_cu, hipStream_t st) {
     const int blocks_per_cu = std::max(1, std::min(4, (int)(160 * 1024 / Cfg::LDS_BYTES)));
     int grid = std::min(ntiles, blocks_per_cu * n_cu);
     grid = std::max(8, (grid + 7) / 8 * 8);
-    k_state_fused2<SP, HAS_W, TM><<<grid, 256, Cfg::LDS_BYTES, st>>>(fa);
+    k_state_fused2<SP, HAS_W, TM, NW><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-template <int SP, int TM>
+template <int SP, int TM, int NW>
 int launch_fused2_w(const Fused2Args &fa, int n_cu, hipStream_t st) {
-    return fa.w ? launch_fused2_one<SP, true, TM>(fa, n_cu, st) : launch_fused2_one<SP, false, TM>(fa, n_cu, st);
+    return fa.w ? launch_fused2_one<SP, true, TM, NW>(fa, n_cu, st) : launch_fused2_one<SP, false, TM, NW>(fa, n_cu, st);
 }
 
-inline int launch_fused2(const Fused2Args &fa, int SP, int tm, int n_cu, hipStream_t st) {
+// variant 2: 64-node tiles, 4 waves; 3: 32-node tiles, 4 waves; 4: 64-node tiles, 8 waves (twice the rows in flight)
+inline int launch_fused2(const Fused2Args &fa, int SP, int variant, int n_cu, hipStream_t st) {
     switch (SP) {
-        case 16: return launch_fused2_w<16, 64>(fa, n_cu, st);
-        case 32: return tm == 32 ? launch_fused2_w<32, 32>(fa, n_cu, st) : launch_fused2_w<32, 64>(fa, n_cu, st);
-        case 64: return tm == 32 ? launch_fused2_w<64, 32>(fa, n_cu, st) : launch_fused2_w<64, 64>(fa, n_cu, st);
+        case 16: return launch_fused2_w<16, 64, 4>(fa, n_cu, st);
+        case 32: return variant == 3 ? launch_fused2_w<32, 32, 4>(fa, n_cu, st)
+                      : variant == 4 ? launch_fused2_w<32, 64, 8>(fa, n_cu, st) : launch_fused2_w<32, 64, 4>(fa, n_cu, st);
+        case 64: return variant == 3 ? launch_fused2_w<64, 32, 4>(fa, n_cu, st)
+                      : variant == 4 ? launch_fused2_w<64, 64, 8>(fa, n_cu, st) : launch_fused2_w<64, 64, 4>(fa, n_cu, st);
         default: return 1;
     }
 }

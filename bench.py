@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-mutag', action='store_true')
     ap.add_argument('--unfused', action='store_true')
+    ap.add_argument('--force-sharded', action='store_true', help='run the N>1 code path even with one rank (smoke test)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -119,9 +120,11 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the message-passing loop has no CPU path')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from gnnkeras_amd import _native as nat
@@ -136,7 +139,7 @@ def main():
     gnn = GNNnodeBased(ns, no, d, K_it, 0.0)
     if args.unfused: gnn.native_flags = nat.FLAG_UNFUSED
 
-    if world == 1:
+    if not sharded:
         seq = MultiGraphSequencer([graph], 'n', args.aggregation, 1, shuffle=False, device=device)
         x = seq[0][0]
         inputs = gnn.process_inputs(x)
@@ -166,11 +169,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         k, state, out = step()
-        if world == 1:
-            ks.append(k)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -180,17 +181,17 @@ def main():
     value = E * k_val * args.steps / elapsed
 
     # dominant kernel: fused iteration; duration from the HIP events the library records around the 50 launches
-    if world == 1:
+    if not sharded:
         t_loop_ms = []
         for _ in range(5):
             step(); torch.cuda.synchronize()
             t_loop_ms.append(ev[0].elapsed_time(ev[1]))
         t_iter = 1e-3 * float(np.median(t_loop_ms)) / max(k_val, 1)
     else:
-        t_iter = sl.kernel_seconds_per_iteration()
+        t_iter = sl.kernel_seconds_per_iteration(s0)
     h1 = ns.units[0]
-    n_local = N if world == 1 else sl.n_local
-    e_local = E if world == 1 else sl.e_local
+    n_local = N if not sharded else sl.n_local
+    e_local = E if not sharded else sl.e_local
     b_iter = algorithmic_bytes_per_iteration(n_local, e_local, d, h1, per_arc_w)
     achieved = b_iter / t_iter
     roofline = {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
@@ -198,7 +199,7 @@ def main():
                 'kernel': 'k_state_fused2<64,false,64,8>' if not args.unfused else 'k_aggregate+k_segdense+k_converge',
                 'algorithmic_bytes_per_launch': b_iter, 'avg_launch_us': 1e6 * t_iter}
     traffic_file = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(traffic_file) and world == 1 and not args.unfused:
+    if os.path.exists(traffic_file) and not sharded and not args.unfused:
         try:
             tr = json.load(open(traffic_file))
             if tr.get('workload_nodes') == N and tr.get('workload_arcs') == E:
@@ -214,14 +215,14 @@ def main():
         'config': {'workload': f'C4 Erdos-Renyi {N} nodes / {E} arcs, state_dim={d}, max_iteration={K_it}, '
                                f'threshold=0 (k={k_val:g}), node-focused, {args.aggregation} aggregation, '
                                f'BN+Dense({ns.input_dim}->{h1},selu) state net',
-                   'sharding': 'single GPU' if world == 1 else f'node-range shards over {world} GPUs, '
+                   'sharding': 'single GPU' if not sharded else f'node-range shards over {world} GPUs, '
                                                                f'RCCL all-gather of state slices per iteration'},
         'roofline': roofline,
-        'loop_only_updates_per_s': E * k_val / (t_iter * k_val) if world == 1 else None,
+        'loop_only_updates_per_s': E / t_iter if not sharded else None,
         'fwd_ms_per_graph': ms_per_step,
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
         from oracle import torch_cpu
         from oracle.harness import _np, _triple
         it_cpu = 3
@@ -235,12 +236,12 @@ def main():
                                             f'restatement of the TF op sequence (not TensorFlow), '
                                             f'{os.cpu_count()} host cpus'}
         result['speedup_vs_cpu_loop'] = (E / t_iter) / result['cpu_baseline']['value']
-    if rank == 0 and world == 1 and not args.no_mutag:
+    if rank == 0 and not sharded and not args.no_mutag:
         result['mutag'] = mutag_section(device, cpu=not args.no_cpu_baseline)
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         dist.destroy_process_group()
 

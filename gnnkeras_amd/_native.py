@@ -24,7 +24,8 @@ FLAG_UNFUSED = 1
 FLAG_NO_EARLY_EXIT = 2
 
 EXPORTS = ['gnn_last_error', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_aggregate',
-           'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step']
+           'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_ld',
+           'gnn_shard_setup', 'gnn_shard_iteration', 'gnn_shard_output']
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -60,7 +61,8 @@ class LoopArgs(C.Structure):
                 ('arc_src', C.c_void_p), ('arc_dst', C.c_void_p), ('nodegraph', CSR),
                 ('k_out', C.c_void_p), ('state_out', C.c_void_p), ('out', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('stream', C.c_void_p),
-                ('flags', C.c_int32), ('ev_loop_begin', C.c_void_p), ('ev_loop_end', C.c_void_p)]
+                ('flags', C.c_int32), ('nodes_src', C.c_void_p), ('ld_nodes_src', C.c_int32),
+                ('ev_loop_begin', C.c_void_p), ('ev_loop_end', C.c_void_p)]
 
 
 class NativeError(RuntimeError):
@@ -106,6 +108,15 @@ def lib():
                                     C.c_void_p]
         l.gnn_state_step.restype = C.c_int
         l.gnn_state_step.argtypes = [C.POINTER(LoopArgs), C.c_void_p, C.c_void_p, C.c_void_p]
+        l.gnn_state_ld.restype = C.c_int32
+        l.gnn_state_ld.argtypes = [C.c_int32]
+        l.gnn_shard_setup.restype = C.c_int
+        l.gnn_shard_setup.argtypes = [C.POINTER(LoopArgs)]
+        l.gnn_shard_iteration.restype = C.c_int
+        l.gnn_shard_iteration.argtypes = [C.POINTER(LoopArgs), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                          C.c_int32, C.c_void_p, C.c_int32]
+        l.gnn_shard_output.restype = C.c_int
+        l.gnn_shard_output.argtypes = [C.POINTER(LoopArgs), C.c_void_p, C.c_void_p, C.c_int32]
         l.gnn_struct_size.restype = C.c_size_t
         l.gnn_struct_size.argtypes = [C.c_int]
         if l.gnn_abi_version() != GNN_ABI_VERSION:

@@ -290,9 +290,10 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     p.G = a.focus == GNN_FOCUS_GRAPH ? a.nodegraph.n_dst : 0;
 
     if (validate_ptrs) {
-        TRY(check_csr(a.adjacency, "adjacency", p.N, p.N));
+        TRY(check_csr(a.adjacency, "adjacency", p.N, a.nodes_src ? a.adjacency.n_src : p.N));
         TRY(check_csr(a.arcnode, "arcnode", p.N, p.E));
         if (p.N > 0 && !a.nodes) return fail("nodes is NULL");
+        if (a.nodes_src && p.composite) return fail("sharded composite graphs are not supported yet");
         if (p.E > 0 && p.A > 0 && !a.arc_labels) return fail("arc_labels is NULL");
         if (a.state_dim > 0 && p.N > 0 && !a.state0) return fail("state0 is required when state_dim > 0");
         if (!a.k_out) return fail("k_out is NULL");
@@ -369,9 +370,11 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
 }
 
 // one un-fused iteration: agg = A^T state ; state_new = net_state([state | agg] + C) per type ; predicate.
-int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src, float *dst,
-                      int *flag_next, float *k_out, float k_val, hipStream_t st) {
-    TRY(launch_aggregate(gate, a.adjacency, src, p.SP, p.S, p.agg, p.SP, st));
+int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src_full, float *dst_full,
+                      int row_base, int *flag_next, float *k_out, float k_val, hipStream_t st) {
+    TRY(launch_aggregate(gate, a.adjacency, src_full, p.SP, p.S, p.agg, p.SP, st));
+    const float *src = src_full + (size_t)row_base * p.SP;     // own rows
+    float *dst = dst_full + (size_t)row_base * p.SP;
     for (int t = 0; t < p.T; ++t) {
         const TypePlan &tp = p.tp[t];
         if (tp.count == 0) continue;
@@ -398,7 +401,8 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     // ArcNode scatter-add (GNN.py:254) and neighbour-label aggregates (GNN.py:258 / CompositeGNN.py:251)
     if (p.A > 0) TRY(launch_aggregate(nullptr, a.arcnode, a.arc_labels, a.ld_arcs, p.A, p.agg_arcs, p.A, st));
     if (!p.composite) {
-        if (a.state_dim > 0) TRY(launch_aggregate(nullptr, a.adjacency, a.nodes, a.ld_nodes, p.L, p.agg_nodes, p.ld_agg_nodes, st));
+        if (a.state_dim > 0) TRY(launch_aggregate(nullptr, a.adjacency, a.nodes_src ? a.nodes_src : a.nodes,
+                                                  a.nodes_src ? a.ld_nodes_src : a.ld_nodes, p.L, p.agg_nodes, p.ld_agg_nodes, st));
     } else {
         int col = 0;
         for (int t = 0; t < p.T; ++t) {
@@ -573,7 +577,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         const float *src = p.buf[it & 1];
         float *dst = p.buf[(it + 1) & 1];
         if (fused) TRY(iteration_fused(a, p, gate, gate ? 1 : 0, 0, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
-        else       TRY(iteration_unfused(a, p, gate, src, dst, p.flags + it + 1, a.k_out, (float)(it + 1), st));
+        else       TRY(iteration_unfused(a, p, gate, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
     }
 
     if (a.ev_loop_end) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_end, st));
@@ -662,8 +666,70 @@ int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *st
     if (can_fuse(a, p))
         TRY(iteration_fused(a, p, nullptr, 0, 0, p.buf[0], p.buf[1], 0, flag_out, nullptr, 0.f, st));
     else
-        TRY(iteration_unfused(a, p, nullptr, p.buf[0], p.buf[1], flag_out, nullptr, 0.f, st));
+        TRY(iteration_unfused(a, p, nullptr, p.buf[0], p.buf[1], 0, flag_out, nullptr, 0.f, st));
     return launch_copy2d(nullptr, p.buf[1], p.SP, state_out, p.S, p.N, p.S, p.S, st);
+}
+
+__global__ void k_or_flags(const int *gate, int n_gate, int gate_stride, int *out) {
+    int v = 0;
+    for (int i = threadIdx.x; i < n_gate; i += blockDim.x) v |= gate[(size_t)i * gate_stride] != 0;
+    v = __syncthreads_or(v);
+    if (threadIdx.x == 0) *out = v;
+}
+
+int32_t gnn_state_ld(int32_t state_width) { return state_width > 0 ? state_ld(state_width) : 0; }
+
+int gnn_shard_setup(const gnn_loop_args_t *args) {
+    if (!args) return fail("args is NULL");
+    const gnn_loop_args_t &a = *args;
+    Plan p;
+    TRY(make_plan(a, a.workspace, p, true));
+    if (!a.nodes_src) return fail("gnn_shard_setup: nodes_src is NULL (not a shard)");
+    if (!a.workspace || a.workspace_bytes < p.bytes) return fail("workspace too small: %zu < %zu bytes", a.workspace_bytes, p.bytes);
+    hipStream_t st = (hipStream_t)a.stream;
+    HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (a.max_iteration + 2), st));
+    HIP_OK(hipMemsetAsync(a.k_out, 0, sizeof(float), st));
+    return setup_constants(a, p, st);
+}
+
+int gnn_shard_iteration(const gnn_loop_args_t *args, const float *state_in_full, float *state_out_full,
+                        int32_t row_base, const int32_t *gate, int32_t n_gate, int32_t gate_stride, int32_t *flag_out,
+                        int32_t iteration) {
+    if (!args) return fail("args is NULL");
+    const gnn_loop_args_t &a = *args;
+    if (!state_in_full || !state_out_full || !flag_out) return fail("state buffers / flag_out are NULL");
+    if (iteration < 0 || iteration >= a.max_iteration) return fail("iteration %d out of [0, max_iteration)", iteration);
+    if (n_gate < 0 || (n_gate > 0 && !gate)) return fail("bad gate list");
+    Plan p;
+    TRY(make_plan(a, a.workspace, p, false));
+    if (row_base < 0 || row_base + p.N > a.adjacency.n_src) return fail("row_base out of the full buffer");
+    hipStream_t st = (hipStream_t)a.stream;
+    const int *g = nullptr;
+    if (n_gate > 0 && !(a.flags & GNN_FLAG_NO_EARLY_EXIT)) {
+        k_or_flags<<<1, 64, 0, st>>>(gate, n_gate, gate_stride, p.flags + iteration);
+        LAUNCH_OK();
+        g = p.flags + iteration;
+    }
+    HIP_OK(hipMemsetAsync(flag_out, 0, sizeof(int32_t), st));
+    if (can_fuse(a, p))
+        return iteration_fused(a, p, g, g ? 1 : 0, 0, state_in_full, state_out_full, row_base, flag_out, a.k_out, (float)(iteration + 1), st);
+    return iteration_unfused(a, p, g, state_in_full, state_out_full, row_base, flag_out, a.k_out, (float)(iteration + 1), st);
+}
+
+int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const float *buf1_full, int32_t row_base) {
+    if (!args) return fail("args is NULL");
+    const gnn_loop_args_t &a = *args;
+    if (!buf0_full || !buf1_full) return fail("state buffers are NULL");
+    Plan p;
+    TRY(make_plan(a, a.workspace, p, true));
+    hipStream_t st = (hipStream_t)a.stream;
+    const long total = (long)p.N * p.S;
+    if (total > 0) {
+        gnn::k_select_state<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, st>>>(
+            a.k_out, buf0_full + (size_t)row_base * p.SP, buf1_full + (size_t)row_base * p.SP, p.SP, a.state_out, p.S, p.N, p.S);
+        LAUNCH_OK();
+    }
+    return output_stage(a, p, st);
 }
 
 }  // extern "C"

@@ -1,0 +1,236 @@
+"""Node-range sharding of the message-passing loop over the GPUs of one node.
+
+One process per GPU, `torch.distributed` over RCCL (backend "nccl" on ROCm). The reference has nothing like this
+(single process, single device, eager — SURVEY §2); the algorithm it must reproduce is the same `Loop`
+(reference GNN/Models/GNN.py:245-274) on the whole graph.
+
+Layout. With R ranks and chunk = ceil(N / R), rank r owns destination nodes [r·chunk, min(N, (r+1)·chunk)). The
+exchanged state lives in two *full* buffers of R slices; a slice is `chunk` state rows followed by ONE flag row whose
+first word is that rank's "some node of mine still moves" flag, so the global `reduce_any` of the reference's
+`condition` (GNN.py:212) travels inside the same all-gather as the states:
+
+    full buffer = [ slice_0 | slice_1 | ... | slice_{R-1} ],   slice_r = [ chunk rows of SP floats | flag row ]
+    padded row of global node g = (g // chunk) * (chunk + 1) + g % chunk
+
+Per iteration rank r runs ONE fused kernel over its destinations (reading any row of the current full buffer, writing
+its slice of the other one) and ONE in-place `all_gather_into_tensor`. Every rank also holds the labels of all nodes
+in padded-row order (the one-off halo of the neighbour-label aggregate, GNN.py:258); arcs are stored with their
+destination, so the ArcNode scatter-add (GNN.py:254) is local. No host synchronisation anywhere in the loop.
+
+ER graphs have no locality: ~(R-1)/R of the arcs are remote and every node is somebody's halo, hence the full
+all-gather; graphs with locality could exchange compacted halos instead (not built).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _native as nat
+from .graph_class import GraphObject
+from .sparse import CSRByDestination
+
+
+def partition(n_nodes: int, world_size: int):
+    """(chunk, [(lo, hi)] per rank): contiguous node ranges of equal nominal size."""
+    chunk = -(-n_nodes // world_size)
+    return chunk, [(min(n_nodes, r * chunk), min(n_nodes, (r + 1) * chunk)) for r in range(world_size)]
+
+
+def padded_row(g, chunk):
+    g = np.asarray(g, dtype=np.int64)
+    return (g // chunk) * (chunk + 1) + g % chunk
+
+
+class ShardPlan:
+    """Host-side (numpy) description of one rank's shard: local CSR operators in padded-row space."""
+
+    def __init__(self, graph: GraphObject, rank: int, world_size: int):
+        N = graph.nodes.shape[0]
+        self.N, self.rank, self.world_size = N, rank, world_size
+        self.chunk, self.ranges = partition(N, world_size)
+        self.lo, self.hi = self.ranges[rank]
+        self.n_local = self.hi - self.lo
+        self.rows_per_slice = self.chunk + 1
+        self.n_rows_full = world_size * self.rows_per_slice
+        self.row_base = rank * self.rows_per_slice
+        dst = graph.arc_ids[:, 1]
+        mine = (dst >= self.lo) & (dst < self.hi)
+        self.arc_index = np.flatnonzero(mine)                       # global arc ids of the local (incoming) arcs
+        self.e_local = int(mine.sum())
+        values = graph.ArcNode.data[mine]                           # aggregation weights computed on the WHOLE graph
+        src_rows = padded_row(graph.arc_ids[mine, 0], self.chunk)
+        dst_local = dst[mine] - self.lo
+        # COO (rows = sources, cols = local destinations) -> by-destination CSR, ascending source inside a row
+        self.adjacency = CSRByDestination.from_coo(src_rows, dst_local, values, (self.n_rows_full, self.n_local))
+        self.arcnode = CSRByDestination.from_coo(np.arange(self.e_local), dst_local, values,
+                                                 (self.e_local, self.n_local))
+        self.arc_labels = np.ascontiguousarray(graph.arcs[mine][:, 2:])
+        self.nodes_local = np.ascontiguousarray(graph.nodes[self.lo:self.hi])
+        nodes_full = np.zeros((self.n_rows_full, graph.nodes.shape[1]), dtype=np.float32)
+        nodes_full[padded_row(np.arange(N), self.chunk)] = graph.nodes
+        self.nodes_full = nodes_full
+        sm, om = graph.set_mask[self.lo:self.hi], graph.output_mask[self.lo:self.hi]
+        self.out_index = np.flatnonzero(sm & om).astype(np.int32)
+        self.per_arc_weights = self.adjacency.w is not None
+
+    def pad_state(self, state: np.ndarray, SP: int) -> np.ndarray:
+        """[N, S] -> full padded buffer [n_rows_full, SP] (flag rows and padding zero)."""
+        full = np.zeros((self.n_rows_full, SP), dtype=np.float32)
+        full[padded_row(np.arange(self.N), self.chunk), :state.shape[1]] = state
+        return full
+
+
+class ShardedLoop:
+    """Forward pass of a node-focused homogeneous GNN on one rank's node range.
+
+        sl = ShardedLoop(model, graph, rank, world_size, device)      # graph replicated on the hosts
+        k, state_local, out_local = sl.forward(state0_full)           # collective: every rank calls it
+
+    `state_local` / `out_local` cover the rank's own nodes [lo, hi) (masked ones for `out`)."""
+
+    def __init__(self, model, graph: GraphObject, rank: int, world_size: int, device, group=None):
+        if model._focus != 'n':
+            raise NotImplementedError('sharding is built for node-focused models (BASELINE config C4)')
+        self.model, self.group = model, group
+        self.rank, self.world_size = rank, world_size
+        self.device = torch.device(device)
+        self.plan = p = ShardPlan(graph, rank, world_size)
+        self.n_local, self.e_local, self.per_arc_weights = p.n_local, p.e_local, p.per_arc_weights
+        self.S = model.state_vect_dim if model.state_vect_dim > 0 else graph.nodes.shape[1]
+        self.L, self.A = graph.nodes.shape[1], graph.arcs.shape[1] - 2
+        self.SP = self._state_ld(self.S)
+        self._upload()
+        self.buf = [torch.zeros((p.n_rows_full, self.SP), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._iter_events = None
+
+    # ---- device-specific pieces (the gloo/CPU tests override these four with numpy stand-ins) --------------------------
+    def _state_ld(self, S):
+        return int(nat.lib().gnn_state_ld(S))
+
+    def _upload(self):
+        p, dev = self.plan, self.device
+        up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        csr = lambda c: dict(rowptr=up(c.rowptr), src=up(c.src), w=up(c.w), row_scale=up(c.row_scale), n_src=c.n_src,
+                             n_dst=c.n_dst, nnz=c.nnz)
+        self.d_adj, self.d_an = csr(p.adjacency), csr(p.arcnode)
+        self.d_nodes, self.d_nodes_full = up(p.nodes_local), up(p.nodes_full)
+        self.d_arc_labels, self.d_out_index = up(p.arc_labels), up(p.out_index)
+        m = self.model
+        a = nat.LoopArgs()
+        a.abi_version, a.composite = nat.GNN_ABI_VERSION, 0
+        a.n_nodes, a.n_arcs, a.dim_node_label, a.dim_arc_label = p.n_local, p.e_local, self.L, self.A
+        a.nodes, a.ld_nodes = nat.ptr(self.d_nodes), self.L
+        a.nodes_src, a.ld_nodes_src = nat.ptr(self.d_nodes_full), self.L
+        a.arc_labels, a.ld_arcs = nat.ptr(self.d_arc_labels), max(self.A, 1)
+        a.adjacency, a.arcnode = nat.make_csr(self.d_adj), nat.make_csr(self.d_an)
+        a.n_types = 1
+        a.net_state[0] = m.net_state.to(dev).native()
+        a.net_output = m.net_output.to(dev).native()
+        a.state_dim, a.max_iteration, a.state_threshold = m.state_vect_dim, m.max_iteration, float(m.state_threshold)
+        a.focus = nat.FOCUS['n']
+        a.n_out, a.out_index = len(p.out_index), nat.ptr(self.d_out_index)
+        a.flags = m.native_flags
+        self.k = torch.zeros((), dtype=torch.float32, device=dev)
+        self.state_local = torch.empty((p.n_local, self.S), dtype=torch.float32, device=dev)
+        self.out_local = torch.empty((len(p.out_index), m.net_output.units[-1]), dtype=torch.float32, device=dev)
+        a.k_out, a.state_out, a.out = nat.ptr(self.k), nat.ptr(self.state_local), nat.ptr(self.out_local)
+        # state0 only matters for validation in make_plan: point it at the own rows of buffer 0 later
+        nbytes = nat.lib().gnn_loop_workspace_bytes(C.byref(a))
+        if nbytes == 0: nat.check(1)
+        self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        aligned = (self._ws.data_ptr() + 255) & ~255
+        a.workspace, a.workspace_bytes = C.c_void_p(aligned), nbytes
+        self.args = a
+
+    def _setup(self):
+        a = self.args
+        a.stream = nat.current_stream(self.device)
+        a.state0 = nat.ptr(self.buf[0])                      # non-NULL placeholder for the pointer validation
+        nat.check(nat.lib().gnn_shard_setup(C.byref(a)))
+
+    def _initial_flags(self):
+        """flag of slice r in buffer 0 = predicate(state0 rows of r, ones): every rank evaluates all slices itself, so
+        the loop starts without an exchange (GNN.py:261: state_old_0 = ones)."""
+        p, lib = self.plan, nat.lib()
+        thr = float(self.model.state_threshold)
+        for r, (lo, hi) in enumerate(p.ranges):
+            base = r * p.rows_per_slice
+            rows = self.buf[0][base:base + (hi - lo)]
+            flag = self.buf[0][base + p.chunk]               # the slice's flag row; word 0 reinterpreted as int32
+            nat.check(lib.gnn_converged(nat.ptr(rows), None, hi - lo, self.S, self.SP, thr, nat.ptr(flag),
+                                        nat.current_stream(self.device)))
+
+    def _iteration(self, it: int):
+        p = self.plan
+        src, dst = self.buf[it & 1], self.buf[(it + 1) & 1]
+        gate = src.data_ptr() + 4 * p.chunk * self.SP        # flag word of slice 0
+        flag_out = dst.data_ptr() + 4 * (p.row_base + p.chunk) * self.SP
+        nat.check(nat.lib().gnn_shard_iteration(C.byref(self.args), nat.ptr(src), nat.ptr(dst), p.row_base,
+                                                C.c_void_p(gate), self.world_size, p.rows_per_slice * self.SP,
+                                                C.c_void_p(flag_out), it))
+
+    def _output(self):
+        nat.check(nat.lib().gnn_shard_output(C.byref(self.args), nat.ptr(self.buf[0]), nat.ptr(self.buf[1]),
+                                             self.plan.row_base))
+        return self.k, self.state_local, self.out_local
+
+    # ---- backend-independent orchestration ------------------------------------------------------------------------------
+    def _load_state0(self, state0_full):
+        p = self.plan
+        if isinstance(state0_full, torch.Tensor):
+            s0 = state0_full.to(self.device, torch.float32)
+            rows = torch.from_numpy(padded_row(np.arange(p.N), p.chunk)).to(self.device)
+            self.buf[0].zero_()
+            self.buf[0][rows, :s0.shape[1]] = s0
+        else:
+            self.buf[0].copy_(torch.from_numpy(p.pad_state(np.asarray(state0_full, dtype=np.float32), self.SP)))
+
+    def _exchange(self, buf: torch.Tensor):
+        """In-place all-gather of the slices of `buf` (states + flag rows): the one exchange step per iteration."""
+        if self.world_size == 1:
+            return
+        p = self.plan
+        flat = buf.view(-1)
+        n = p.rows_per_slice * self.SP
+        dist.all_gather_into_tensor(flat, flat[self.rank * n:(self.rank + 1) * n], group=self.group)
+
+    def forward(self, state0_full=None):
+        m = self.model
+        if m.state_vect_dim > 0:
+            if state0_full is None: raise ValueError('state0 (all nodes) is required when state_vect_dim > 0')
+            self._load_state0(state0_full)
+        else:
+            self._load_state0(self.plan_nodes_as_state())
+        self._setup()
+        self._initial_flags()
+        ev = self._iter_events
+        for it in range(m.max_iteration):
+            if ev is not None: ev[it][0].record()
+            self._iteration(it)
+            if ev is not None: ev[it][1].record()
+            self._exchange(self.buf[(it + 1) & 1])
+        return self._output()
+
+    def plan_nodes_as_state(self):
+        """state_vect_dim == 0: state0 = node labels (GNN.py:259)."""
+        return np.ascontiguousarray(self._graph_nodes())
+
+    def _graph_nodes(self):
+        p = self.plan
+        full = p.nodes_full.reshape(self.world_size, p.rows_per_slice, -1)[:, :p.chunk].reshape(-1, p.nodes_full.shape[1])
+        return full[:p.N]
+
+    def kernel_seconds_per_iteration(self, state0_full=None) -> float:
+        """Average device time of the iteration launches alone (no exchange), measured with HIP events on the launch
+        stream in one extra forward; used for the roofline figure of bench.py at N > 1."""
+        n = self.model.max_iteration
+        self._iter_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        self.forward(state0_full)
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._iter_events]
+        self._iter_events = None
+        k = max(float(self.k), 1.0)
+        return 1e-3 * sum(ms[:int(k)]) / k

@@ -118,6 +118,12 @@ typedef struct gnn_loop_args {
     size_t workspace_bytes;
     void *stream;
     int32_t flags;            /* enum gnn_flags                                                                 */
+    /* node-range shard of a larger graph (multi-GPU; all zero / NULL on one GPU) -------------------------------------
+     * The shard owns n_nodes destination nodes; adjacency.n_src rows of the exchanged full state buffer are visible.
+     * `nodes` holds the OWN labels [n_nodes, L]; `nodes_src` the labels of every source row [adjacency.n_src, L] in
+     * the row order of the full state buffer (the one-off halo of the label aggregate, GNN.py:258). */
+    const float *nodes_src;
+    int32_t ld_nodes_src;
     /* measurement (optional) ------------------------------------------------------------------------------------ */
     void *ev_loop_begin;      /* hipEvent_t or NULL: recorded on `stream` right before the first iteration launch */
     void *ev_loop_end;        /* hipEvent_t or NULL: recorded right after the last iteration launch               */
@@ -156,6 +162,23 @@ int gnn_converged(const float *state, const float *state_old, int32_t n, int32_t
  * gnn_loop_forward does the same with the constants folded once.  `args` supplies graph, nets and workspace;
  * state_in/state_out are [n_nodes, S] row-major. */
 int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *state_out, int32_t *flag_out);
+
+/* ---- node-range sharded loop -------------------------------------------------------------------------
+ * One process per GPU; rank r owns a contiguous node range and, per iteration, (1) runs gnn_shard_iteration on its
+ * rows reading the full (all-gathered) state buffer and writing its own slice of the other full buffer, (2) the host
+ * all-gathers the slices (RCCL, torch.distributed).  The convergence flag of a slice travels inside it (one trailing
+ * flag row per slice), so there is exactly one exchange per iteration and still no host synchronisation.
+ * Full state buffers: [adjacency.n_src, gnn_state_ld(S)] float32, rows of rank r at row_base_r .. */
+int32_t gnn_state_ld(int32_t state_width);          /* padded row length (floats) of exchanged state buffers */
+int gnn_shard_setup(const gnn_loop_args_t *args);   /* once per forward: BN folding, label / arc aggregates, C */
+/* gates: run iff OR_i gate[i * gate_stride] != 0 (the flag words of every slice of state_in_full), i < n_gate.
+ * flag_out: this shard's flag word inside state_out_full (zeroed, then raised if any own node still moves). */
+int gnn_shard_iteration(const gnn_loop_args_t *args, const float *state_in_full, float *state_out_full,
+                        int32_t row_base, const int32_t *gate, int32_t n_gate, int32_t gate_stride, int32_t *flag_out,
+                        int32_t iteration);
+/* picks the buffer holding the state after k iterations (k read on the device from args->k_out), copies the own rows
+ * to args->state_out [n_nodes, S] and runs the output network on them into args->out. */
+int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const float *buf1_full, int32_t row_base);
 
 #ifdef __cplusplus
 }

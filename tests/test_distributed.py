@@ -1,0 +1,166 @@
+"""N > 1 path on CPU: world_size-2 `gloo` processes run the node-range sharded loop's orchestration (partition,
+padded-row layout, local CSR operators, in-place all-gather of state slices with the piggy-backed convergence flags,
+gated iterations, k) with the per-rank device step replaced by a NumPy stand-in built from the oracle, and must
+reproduce the single-process oracle result. The stand-in is test code; the product path (gnnkeras_amd/distributed.py)
+calls libgnnloop.so and has no CPU fallback."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from gnnkeras_amd import GraphObject
+from gnnkeras_amd.distributed import ShardedLoop, ShardPlan, partition, padded_row
+from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+from gnnkeras_amd.Models.GNN import GNNnodeBased
+from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+from gnnkeras_amd.synth import er_graph
+from oracle import gnn_oracle as O
+from oracle.harness import oracle_loop, rel_err
+
+
+def csr_to_coo(c):
+    dst = np.repeat(np.arange(c.n_dst), np.diff(c.rowptr))
+    w = np.ones(c.nnz, np.float32) if c.w is None else c.w
+    if c.row_scale is not None: w = w * c.row_scale[dst]
+    return np.stack([c.src.astype(np.int64), dst], 1), w, np.array([c.n_src, c.n_dst])
+
+
+class OracleShardedLoop(ShardedLoop):
+    """Device pieces replaced by the NumPy oracle's ops (float64); everything else is the product's orchestration."""
+    dtype = np.float64
+
+    def _state_ld(self, S):
+        p = 16
+        while p < S: p *= 2
+        return p
+
+    def _upload(self):
+        self.k = torch.zeros((), dtype=torch.float32)
+
+    def _flag(self, buf, row):
+        return buf.view(torch.int32)[row, 0]
+
+    def _setup(self):
+        p = self.plan
+        self.adj, self.an = csr_to_coo(p.adjacency), csr_to_coo(p.arcnode)
+        self.agg_arcs = O.sparse_dense_matmul_adjoint(*self.an, p.arc_labels, self.dtype)
+        self.agg_nodes = O.sparse_dense_matmul_adjoint(*self.adj, p.nodes_full, self.dtype) \
+            if self.model.state_vect_dim > 0 else np.zeros((p.n_local, 0))
+        self.k.zero_()
+
+    def _initial_flags(self):
+        p, m = self.plan, self.model
+        b = self.buf[0].numpy()
+        for r, (lo, hi) in enumerate(p.ranges):
+            base = r * p.rows_per_slice
+            s = b[base:base + hi - lo, :self.S].astype(self.dtype)
+            self.buf[0].view(torch.int32)[base + p.chunk, 0] = int(O.condition(0, s, np.ones_like(s), 1, m.state_threshold, self.dtype))
+
+    def _iteration(self, it):
+        p, m = self.plan, self.model
+        src, dst = self.buf[it & 1], self.buf[(it + 1) & 1]
+        dst.view(torch.int32)[p.row_base + p.chunk, 0] = 0
+        if not any(int(src.view(torch.int32)[r * p.rows_per_slice + p.chunk, 0]) for r in range(self.world_size)):
+            return
+        full = src.numpy()[:, :self.S].astype(self.dtype)
+        own = full[p.row_base:p.row_base + p.n_local]
+        agg = O.sparse_dense_matmul_adjoint(*self.adj, full, self.dtype)
+        comps = [own, p.nodes_local, agg, self.agg_nodes, self.agg_arcs] if m.state_vect_dim > 0 else [own, agg, self.agg_arcs]
+        new = O.mlp_apply(*m.net_state.spec(), np.concatenate(comps, axis=1), False, self.dtype)
+        dst[p.row_base:p.row_base + p.n_local, :self.S] = torch.from_numpy(new.astype(np.float32))
+        dst.view(torch.int32)[p.row_base + p.chunk, 0] = int(O.condition(0, new, own, 1, m.state_threshold, self.dtype))
+        self.k.fill_(it + 1)
+
+    def _output(self):
+        p, m = self.plan, self.model
+        buf = self.buf[int(self.k) & 1].numpy()
+        state = buf[p.row_base:p.row_base + p.n_local, :self.S]
+        inp = np.concatenate([state, p.nodes_local], 1) if m.state_vect_dim > 0 else state
+        out = O.mlp_apply(*m.net_output.spec(), inp[p.out_index], False, self.dtype)
+        return self.k, torch.from_numpy(state.copy()), torch.from_numpy(out.astype(np.float32))
+
+
+def _problem(threshold, d=6, max_it=12):
+    rng = np.random.default_rng(0)
+    g = er_graph(203, 1500, dim_node_label=5, dim_arc_label=2, seed=7)          # 203 is not a multiple of 2 or 3
+    om = rng.random(203) < 0.7
+    g = GraphObject(g.nodes, g.arcs, rng.normal(size=(int(om.sum()), 2)), focus='n', set_mask=rng.random(203) < 0.8,
+                    output_mask=om, aggregation_mode='average')
+    inp, lay = get_inout_dims('state', 5, 2, 2, 'n', d)
+    ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=0, device='cpu')
+    ns.set_weights([w * 0.4 if w.ndim == 2 else w for w in ns.get_weights()])
+    inp, lay = get_inout_dims('output', 5, 2, 2, 'n', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1, device='cpu')
+    model = GNNnodeBased(ns, no, d, max_it, threshold)
+    s0 = rng.normal(0, 0.1, (203, d)).astype(np.float32) if d else None
+    return g, model, s0
+
+
+def _worker(rank, world, port, threshold, d, out_q):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g, model, s0 = _problem(threshold, d)
+        sl = OracleShardedLoop(model, g, rank, world, 'cpu')
+        k, state, out = sl.forward(s0)
+        out_q.put((rank, float(k), state.numpy(), out.numpy(), sl.plan.lo, sl.plan.hi))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('threshold,d', [(0.0, 6), (0.02, 6), (0.0, 0)])
+def test_sharded_loop_matches_single_process_oracle(world, threshold, d):
+    g, model, s0 = _problem(threshold, d)
+    seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False, device='cpu')
+    k_ref, st_ref, out_ref = oracle_loop(model, seq[0][0], s0, np.float64)
+    if threshold > 0: assert 1 < k_ref < model.max_iteration              # early exit really happens
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + world * 7 + int(threshold * 100) + d) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, threshold, d, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=180) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world))
+    assert all(r[1] == float(k_ref) for r in res)
+    state = np.concatenate([r[2] for r in res])
+    out = np.concatenate([r[3] for r in res])
+    assert state.shape == st_ref.shape and out.shape == out_ref.shape
+    assert rel_err(state, st_ref) < 1e-6 and rel_err(out, out_ref) < 1e-6
+
+
+def test_partition_and_padded_rows():
+    chunk, ranges = partition(10, 4)
+    assert chunk == 3 and ranges == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert list(padded_row(np.arange(10), 3)) == [0, 1, 2, 4, 5, 6, 8, 9, 10, 12]
+    chunk, ranges = partition(5, 8)                                       # more ranks than chunks: empty tails
+    assert chunk == 1 and ranges[5:] == [(5, 5)] * 3
+
+
+def test_shard_plan_covers_every_arc_once():
+    g = er_graph(300, 2500, dim_node_label=4, dim_arc_label=2, seed=3)
+    plans = [ShardPlan(g, r, 4) for r in range(4)]
+    assert sum(p.e_local for p in plans) == 2500 and sum(p.n_local for p in plans) == 300
+    assert np.array_equal(np.sort(np.concatenate([p.arc_index for p in plans])), np.arange(2500))
+    for p in plans:
+        # local rows keep ascending-source order and the whole-graph aggregation weights ('average' = 1/in-degree)
+        for j in range(p.n_local):
+            s = p.adjacency.src[p.adjacency.rowptr[j]:p.adjacency.rowptr[j + 1]]
+            assert np.all(np.diff(s) > 0)
+        indeg = np.bincount(g.arc_ids[:, 1], minlength=300)[p.lo:p.hi]
+        assert np.array_equal(np.diff(p.adjacency.rowptr), indeg)
+        assert p.adjacency.w is None and np.allclose(p.adjacency.row_scale[indeg > 0], 1 / indeg[indeg > 0])
+        full = p.pad_state(np.arange(300 * 2, dtype=np.float32).reshape(300, 2), 16)
+        assert full.shape == (4 * (p.chunk + 1), 16)
+        assert np.array_equal(full[padded_row(np.arange(300), p.chunk), :2].reshape(-1), np.arange(600))
+        assert np.all(full[p.chunk::p.chunk + 1] == 0)                    # flag rows start clear

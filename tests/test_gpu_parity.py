@@ -476,3 +476,66 @@ def test_evaluate_and_predict(mutag_graphs):
     assert abs(res['loss'] - loss) < 1e-5 and abs(res['accuracy'] - acc) < 1e-6
     with pytest.raises(NotImplementedError):
         model.fit(seq, epochs=1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# node-range sharded loop (multi-GPU path) with the native kernels: R shards emulated on ONE device, the all-gather
+# replaced by explicit slice copies between the shards' full buffers (what RCCL does across GPUs)
+# ----------------------------------------------------------------------------------------------------------------------
+def _run_shards_on_one_gpu(model, g, s0, R):
+    from gnnkeras_amd.distributed import ShardedLoop
+    shards = [ShardedLoop(model, g, r, R, 'cuda') for r in range(R)]
+    for sl in shards:
+        sl._load_state0(s0 if s0 is not None else sl.plan_nodes_as_state())
+        sl._setup()
+        sl._initial_flags()
+    n = shards[0].plan.rows_per_slice * shards[0].SP
+    for it in range(model.max_iteration):
+        for sl in shards: sl._iteration(it)
+        for r, src in enumerate(shards):                     # "all-gather": slice r of rank r's buffer -> everyone
+            piece = src.buf[(it + 1) & 1].view(-1)[r * n:(r + 1) * n]
+            for dst in shards:
+                if dst is not src: dst.buf[(it + 1) & 1].view(-1)[r * n:(r + 1) * n].copy_(piece)
+    outs = [sl._output() for sl in shards]
+    torch.cuda.synchronize()
+    ks = [float(o[0]) for o in outs]
+    return ks, np.concatenate([o[1].cpu().numpy() for o in outs]), np.concatenate([o[2].cpu().numpy() for o in outs])
+
+
+@pytest.mark.parametrize('R', [1, 2, 3, 8])
+@pytest.mark.parametrize('threshold', [0.0, 0.02])
+def test_sharded_native_kernels_match_oracle(R, threshold):
+    rng = np.random.default_rng(0)
+    N, d = 5003, 64
+    g = er_graph(N, 40000, seed=7)
+    om = rng.random(N) < 0.7
+    g = GraphObject(g.nodes, g.arcs, rng.normal(size=(int(om.sum()), 2)), focus='n', set_mask=rng.random(N) < 0.8,
+                    output_mask=om, aggregation_mode='average')
+    ns, no = starter_nets('n', d, scale=0.3)
+    model = GNNnodeBased(ns, no, d, 12, threshold)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    if threshold > 0: assert 1 < k64 < 12
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        ks, st, o = _run_shards_on_one_gpu(model, g, s0, R)
+        assert all(k == float(k64) for k in ks), (ks, k64)
+        assert rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL
+
+
+def test_sharded_state_dim_0_and_per_arc_weights():
+    rng = np.random.default_rng(1)
+    N = 3000
+    g = er_graph(N, 20000, seed=9, aggregation_mode='sum')
+    an = g.getArcNode(); an.data = rng.uniform(0.05, 0.3, len(an.data)).astype(np.float32)
+    g = GraphObject(g.nodes, g.arcs, g.targets, focus='n', ArcNode=an)
+    ns, no = starter_nets('n', 0)
+    model = GNNnodeBased(ns, no, 0, 5, 0.0)
+    seq = MultiGraphSequencer([g], 'n', 'sum', 1, shuffle=False)
+    seq.graph_tensors[0].ArcNode = SparseMatrix.from_scipy(g.ArcNode)
+    seq.graph_tensors[0].Adjacency = SparseMatrix.from_scipy(g.Adjacency)
+    seq._items = [None]
+    k64, st64, o64 = oracle_loop(model, seq[0][0], None, np.float64)
+    ks, st, o = _run_shards_on_one_gpu(model, g, None, 4)
+    assert all(k == 5.0 for k in ks) and rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL

@@ -103,9 +103,52 @@ class _LoopModel:
         for n, f, acc in mets: res[n] = float(acc / cnt)
         return res if return_dict else [res['loss']] + [res[n] for n, _, _ in mets]
 
-    def fit(self, *args, **kwargs):
-        raise NotImplementedError('fit(): the backward pass / train_step (reference GNN.py:277-306) is the next row of '
-                                  'SURVEY.md §8f and is not built yet; there is deliberately no CPU fallback.')
+    def _optimizer_obj(self):
+        from .training import get_optimizer
+        if getattr(self, '_opt_obj', None) is None or self._opt_src is not self.optimizer:
+            self._opt_obj, self._opt_src = get_optimizer(self.optimizer), self.optimizer
+        return self._opt_obj
+
+    def train_step(self, data, *, state0=None, seed=None):
+        """One optimisation step on one batch (reference GNN.py:277-306): training-mode forward, loss, BPTT through the
+        k executed iterations, optional 1/k on the state gradients, optimizer update. Returns {'loss': ..., metrics...}."""
+        from .training import LoopTrainer
+        if self.loss is None: raise RuntimeError('compile() the model with a loss before fit() / train_step()')
+        if getattr(self, '_trainer', None) is None: self._trainer = LoopTrainer(self)
+        x, y, sample_weight = data
+        res = self._trainer.train_step(x, y, sample_weight, state0=state0, seed=seed)
+        out = {'loss': res['loss'], 'k': res['k']}
+        if y is not None:
+            yd = y.to(res['y_pred'].device)
+            sw = torch.ones(yd.shape[0], device=yd.device) if sample_weight is None else sample_weight.to(yd.device)
+            for m in self.metrics_spec:
+                n, f = _metric_fn(m, yd.shape[-1])
+                out[n] = (f(yd, res['y_pred']) * sw).sum() / sw.sum()
+        return out
+
+    def fit(self, sequencer, epochs: int = 1, validation_data=None, verbose: int = 1, **kwargs):
+        """Keras-style training loop over a sequencer: `train_step` per batch, `on_epoch_end` (reshuffle + re-merge,
+        reference GraphSequencers.py:123-127) per epoch, optional validation with `evaluate`. Returns the history dict."""
+        history = {}
+        for epoch in range(epochs):
+            tot, wsum = {}, 0.0
+            for i in range(len(sequencer)):
+                data = sequencer[i]
+                r = self.train_step(data)
+                w = float(data[1].shape[0]) if data[1] is not None else 1.0
+                for key, val in r.items():
+                    if key == 'k': continue
+                    tot[key] = tot.get(key, 0.0) + float(val) * w
+                wsum += w
+            logs = {key: val / max(wsum, 1.0) for key, val in tot.items()}
+            if validation_data is not None:
+                logs.update({'val_' + key: val for key, val in self.evaluate(validation_data, return_dict=True).items()})
+            for key, val in logs.items(): history.setdefault(key, []).append(val)
+            if verbose:
+                print(f'Epoch {epoch + 1}/{epochs} - ' + ' - '.join(f'{k_}: {v:.4f}' for k_, v in logs.items()))
+            if hasattr(sequencer, 'on_epoch_end'): sequencer.on_epoch_end()
+        self.history = history
+        return history
 
     # workspace and mask-index caches ---------------------------------------------------------------------------------
     def _workspace(self, nbytes, device):

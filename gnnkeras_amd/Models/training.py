@@ -1,0 +1,445 @@
+"""train_step / fit for the homogeneous GNN on MI355X: back-propagation through the unrolled loop.
+
+Mirror of the reference's `GNNnodeBased.train_step` (`GNN/Models/GNN.py:277-306`): forward with `training=True`
+(BatchNormalization on batch statistics, moving averages updated on every call — i.e. k times per step for the state
+network), `compiled_loss(y, y_pred, sample_weight)`, gradients w.r.t. `net_state` and `net_output` trainable variables
+through every executed iteration (BPTT; the reference gets them from an eager `GradientTape`), optional division of the
+state gradients by k (`average_st_grads`, `:295`), `optimizer.apply_gradients`.
+
+There is no autograd here: the host walks the iterations backwards and calls hand-written device primitives
+(`include/gnnloop.h`, "training building blocks"): transposed CSR aggregate, MFMA weight-gradient GEMMs with
+deterministic two-stage reductions, activation / BatchNormalization / softmax / loss gradients, Adam / SGD updates.
+Per-iteration tensors are *recomputed* in the backward sweep (aggregate, folded weights, hidden layers) from the stored
+states, so the tape is just the k+1 state matrices and the BN batch statistics.
+
+Algebra used for the first layer of a network, with y = a⊙x + c the training-mode BatchNormalization (a = γ·rstd,
+c = β − μ·a; a = 1, c = 0 without BN), P = XᵀdZ and q = colsum(dZ):
+    dW = a⊙P + c qᵀ,  db = q,  Σ_r dy = W q,  Σ_r dy⊙x = rowsum(W⊙P)  ⇒  dβ, dγ and the BN input-gradient moments
+without ever materialising the N × in_dim concatenation or its gradient.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from ..sparse import SparseMatrix, CSRByDestination
+from .MLP import Sequential, BN_EPSILON, BN_MOMENTUM
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# optimizers (tf.keras.optimizers defaults), state kept on the device
+# ----------------------------------------------------------------------------------------------------------------------
+class Adam:
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
+        self.iterations, self._slots = 0, {}
+
+    def apply_gradients(self, grads_and_vars):
+        self.iterations += 1
+        lib = nat.lib()
+        for g, p in grads_and_vars:
+            key = p.data_ptr()
+            if key not in self._slots:
+                self._slots[key] = (torch.zeros_like(p), torch.zeros_like(p), p)
+            m, v, _ = self._slots[key]
+            nat.check(lib.gnn_adam_step(nat.ptr(p), nat.ptr(g), nat.ptr(m), nat.ptr(v), p.numel(),
+                                        float(self.learning_rate), float(self.beta_1), float(self.beta_2),
+                                        float(self.epsilon), self.iterations, nat.current_stream(p.device)))
+
+
+class SGD:
+    def __init__(self, learning_rate=0.01, momentum=0.0):
+        self.learning_rate, self.momentum = learning_rate, momentum
+        self.iterations, self._slots = 0, {}
+
+    def apply_gradients(self, grads_and_vars):
+        self.iterations += 1
+        lib = nat.lib()
+        for g, p in grads_and_vars:
+            vel = None
+            if self.momentum:
+                key = p.data_ptr()
+                if key not in self._slots: self._slots[key] = (torch.zeros_like(p), p)
+                vel = self._slots[key][0]
+            nat.check(lib.gnn_sgd_step(nat.ptr(p), nat.ptr(g), nat.ptr(vel), p.numel(), float(self.learning_rate),
+                                       float(self.momentum), nat.current_stream(p.device)))
+
+
+def get_optimizer(opt):
+    if opt is None: raise RuntimeError('compile() the model with an optimizer before fit()')
+    if isinstance(opt, str):
+        name = opt.lower()
+        if name == 'adam': return Adam()
+        if name == 'sgd': return SGD()
+        raise ValueError(f'unknown optimizer {opt!r}')
+    if not hasattr(opt, 'apply_gradients'): raise TypeError('optimizer must provide apply_gradients(grads_and_vars)')
+    return opt
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# thin wrappers over the device primitives; a "segment" is (2-D float32 view with stride(1) == 1, row-index or None)
+# ----------------------------------------------------------------------------------------------------------------------
+class _Prim:
+    def __init__(self, device):
+        self.dev, self.lib = device, nat.lib()
+        self._ws = None
+
+    def stream(self):
+        return nat.current_stream(self.dev)
+
+    def ws(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.dev)
+        return self._ws
+
+    def new(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def zeros(self, *shape):
+        return torch.zeros(shape, dtype=torch.float32, device=self.dev)
+
+    def dense(self, segs, W, H, bias, act, Y, wrows=None, out_rowidx=None):
+        """Y[:, :H] = act(sum_s seg_s . W[wrow_s : wrow_s + width_s, :H] + bias).  W: 2-D view (ld = stride(0))."""
+        d = nat.DenseArgs()
+        M = Y.shape[0] if out_rowidx is None else len(out_rowidx)
+        d.M, d.H, d.n_segments = M, H, len(segs)
+        off = 0
+        for i, (x, ridx) in enumerate(segs):
+            d.seg_ptr[i] = x.data_ptr(); d.seg_rowidx[i] = 0 if ridx is None else ridx.data_ptr()
+            d.seg_ld[i], d.seg_width[i] = x.stride(0), x.shape[1]
+            d.seg_wrow[i] = off if wrows is None else wrows[i]
+            off += x.shape[1]
+        d.W, d.ldw = W.data_ptr(), W.stride(0)
+        d.bias = 0 if bias is None else bias.data_ptr()
+        d.activation = act
+        d.Y, d.ldy = Y.data_ptr(), Y.stride(0)
+        d.out_rowidx = 0 if out_rowidx is None else out_rowidx.data_ptr()
+        d.stream = self.stream()
+        nat.check(self.lib.gnn_dense(C.byref(d)))
+        return Y
+
+    def aggregate(self, csr, X, F, out):
+        c = nat.make_csr(csr)
+        nat.check(self.lib.gnn_aggregate(C.byref(c), nat.ptr(X), X.stride(0), F, nat.ptr(out), out.stride(0), self.stream()))
+        return out
+
+    def fold(self, W, b, bn, mean, var, Wf, bf):
+        K, H = W.shape
+        g, be = (bn[0], bn[1]) if bn is not None else (None, None)
+        nat.check(self.lib.gnn_fold_bn(nat.ptr(W), nat.ptr(b), K, H, nat.ptr(g), nat.ptr(be), nat.ptr(mean), nat.ptr(var),
+                                       BN_EPSILON, nat.ptr(Wf), nat.ptr(bf), self.stream()))
+
+    def colstats(self, x, ridx, M, mean, var):
+        K = x.shape[1]
+        nb = self.lib.gnn_colstats_workspace_bytes(K, M)
+        ws = self.ws(nb)
+        nat.check(self.lib.gnn_colstats(nat.ptr(x), x.stride(0), nat.ptr(ridx), K, M, nat.ptr(mean), nat.ptr(var), None, None,
+                                        BN_MOMENTUM, None, nat.ptr(ws), ws.numel(), self.stream()))
+
+    def dense_grad(self, x, ridx, dZ, M, P, q, accumulate):
+        K, H = x.shape[1], dZ.shape[1]
+        assert P.is_contiguous() and P.shape[-1] == H
+        nb = self.lib.gnn_dense_grad_workspace_bytes(K, H, M)
+        ws = self.ws(nb)
+        nat.check(self.lib.gnn_dense_grad(nat.ptr(x), x.stride(0), nat.ptr(ridx), K, nat.ptr(dZ), dZ.stride(0), H, M,
+                                          nat.ptr(P), nat.ptr(q), int(accumulate), nat.ptr(ws), ws.numel(), self.stream()))
+
+    def act_grad(self, G, Y, dZ, act):
+        M, H = Y.shape
+        nat.check(self.lib.gnn_act_grad(nat.ptr(G), G.stride(0), nat.ptr(Y), Y.stride(0), nat.ptr(dZ), dZ.stride(0), M, H, act,
+                                        self.stream()))
+        return dZ
+
+    def first_layer_param_grads(self, P, q, W, bn, mean, var, M, dW, db, dgamma, dbeta, m1, m2, accumulate):
+        K, H = W.shape
+        g, be = (bn[0], bn[1]) if bn is not None else (None, None)
+        nat.check(self.lib.gnn_first_layer_param_grads(nat.ptr(P), nat.ptr(q), nat.ptr(W), K, H, nat.ptr(g), nat.ptr(be),
+                                                       nat.ptr(mean), nat.ptr(var), BN_EPSILON, M, nat.ptr(dW), nat.ptr(db),
+                                                       nat.ptr(dgamma), nat.ptr(dbeta), nat.ptr(m1), nat.ptr(m2),
+                                                       int(accumulate), self.stream()))
+
+    def bn_input_grad(self, dy, x, ridx, M, k0, bn, mean, var, m1, m2, dx):
+        width = dy.shape[1]
+        g = bn[0] if bn is not None else None
+        nat.check(self.lib.gnn_bn_input_grad(nat.ptr(dy), dy.stride(0), nat.ptr(x), x.stride(0), nat.ptr(ridx), M, width, k0,
+                                             nat.ptr(g), nat.ptr(mean), nat.ptr(var), BN_EPSILON, nat.ptr(m1), nat.ptr(m2),
+                                             nat.ptr(dx), dx.stride(0), self.stream()))
+
+    def scatter_add_rows(self, D, idx, G):
+        nat.check(self.lib.gnn_scatter_add_rows(nat.ptr(D), D.stride(0), nat.ptr(idx), D.shape[0], D.shape[1], nat.ptr(G),
+                                                G.stride(0), self.stream()))
+
+    def axpby(self, a, x, b, y, out):
+        nat.check(self.lib.gnn_axpby(float(a), nat.ptr(x), float(b), nat.ptr(y), nat.ptr(out), x.numel(), self.stream()))
+
+
+class _NetGrads:
+    """Gradient buffers of one Sequential in `trainable_variables` order (BN: γ, β; Dense: W, b ...)."""
+
+    def __init__(self, net: Sequential, prim: _Prim):
+        self.net = net
+        self.bn = net.batch_normalization
+        w = net.weights
+        self.bn_params = (w[0], w[1]) if self.bn else None          # γ, β
+        self.moving = (w[2], w[3]) if self.bn else None
+        base = 4 if self.bn else 0
+        self.W = [w[base + 2 * i] for i in range(len(net.units))]
+        self.b = [w[base + 2 * i + 1] for i in range(len(net.units))]
+        self.acts = [nat.ACTIVATIONS[a] for a in net.activations]
+        self.dgamma = prim.zeros(net.input_dim) if self.bn else None
+        self.dbeta = prim.zeros(net.input_dim) if self.bn else None
+        self.dW = [torch.zeros_like(x) for x in self.W]
+        self.db = [torch.zeros_like(x) for x in self.b]
+        self.touched = False                                        # False until the first accumulation of this step
+
+    def variables(self):
+        v = list(self.bn_params) if self.bn else []
+        for W, b in zip(self.W, self.b): v += [W, b]
+        return v
+
+    def gradients(self):
+        g = [self.dgamma, self.dbeta] if self.bn else []
+        for W, b in zip(self.dW, self.db): g += [W, b]
+        return g
+
+
+class LoopTrainer:
+    """One instance per model; owns gradient buffers and scratch. Homogeneous node / arc / graph focus."""
+
+    def __init__(self, model):
+        self.model = model
+
+    # ---- generic MLP forward (training mode) / backward over segmented inputs -------------------------------------------
+    def _mlp_forward(self, ng: _NetGrads, segs, M, stats=None, const_stats=None):
+        """segs: [(view, rowidx)] in input-column order. Returns (hs, (mean, var)|None). `stats` given => reuse (backward
+        recompute); else batch statistics are computed (constant segments may come from `const_stats`: {index: (mean, var)})."""
+        p, net = self.prim, ng.net
+        mean = var = None
+        if ng.bn:
+            if stats is not None:
+                mean, var = stats
+            else:
+                mean, var = p.new(net.input_dim), p.new(net.input_dim)
+                off = 0
+                for i, (x, ridx) in enumerate(segs):
+                    w = x.shape[1]
+                    if const_stats is not None and i in const_stats:
+                        mean[off:off + w].copy_(const_stats[i][0]); var[off:off + w].copy_(const_stats[i][1])
+                    else:
+                        p.colstats(x, ridx, M, mean[off:off + w], var[off:off + w])
+                    off += w
+            Wf, bf = p.new(*ng.W[0].shape), p.new(ng.W[0].shape[1])
+            p.fold(ng.W[0], ng.b[0], ng.bn_params, mean, var, Wf, bf)
+        else:
+            Wf, bf = ng.W[0], ng.b[0]
+        hs = [p.dense(segs, Wf, net.units[0], bf, ng.acts[0], p.new(M, net.units[0]))]
+        for l in range(1, len(net.units)):
+            hs.append(p.dense([(hs[-1], None)], ng.W[l], net.units[l], ng.b[l], ng.acts[l], p.new(M, net.units[l])))
+        return hs, ((mean, var) if ng.bn else None)
+
+    def _mlp_backward(self, ng: _NetGrads, segs, hs, G, M, stats, dx_requests):
+        """G = dL/d hs[-1] (overwritten). dx_requests: [(segment index, out view [M, width])]."""
+        p, net = self.prim, ng.net
+        acc = ng.touched
+        for l in range(len(net.units) - 1, 0, -1):
+            dZ = p.act_grad(G, hs[l], G, ng.acts[l])
+            p.dense_grad(hs[l - 1], None, dZ, M, ng.dW[l], ng.db[l], acc)
+            Wt = ng.W[l].t().contiguous()
+            G = p.dense([(dZ, None)], Wt, net.units[l - 1], None, 0, p.new(M, net.units[l - 1]))
+        dZ = p.act_grad(G, hs[0], G, ng.acts[0])
+        K, H = ng.W[0].shape
+        P, q = p.new(K, H), p.new(H)
+        off = 0
+        for i, (x, ridx) in enumerate(segs):
+            w = x.shape[1]
+            p.dense_grad(x, ridx, dZ, M, P[off:off + w], q if i == 0 else None, False)
+            off += w
+        mean, var = stats if stats is not None else (None, None)
+        m1 = m2 = None
+        if ng.bn: m1, m2 = p.new(K), p.new(K)
+        p.first_layer_param_grads(P, q, ng.W[0], ng.bn_params, mean, var, M, ng.dW[0], ng.db[0], ng.dgamma, ng.dbeta,
+                                  m1, m2, acc)
+        ng.touched = True
+        if dx_requests:
+            Wt = ng.W[0].t().contiguous()                          # [H, K]
+            offs = np.cumsum([0] + [x.shape[1] for x, _ in segs])
+            for si, out in dx_requests:
+                x, ridx = segs[si]
+                k0, w = int(offs[si]), x.shape[1]
+                p.dense([(dZ, None)], Wt[:, k0:k0 + w], w, None, 0, out)
+                p.bn_input_grad(out, x, ridx, M, k0, ng.bn_params, mean, var, m1, m2, out)
+
+    # ---- one training step ------------------------------------------------------------------------------------------------
+    def train_step(self, x_list, y, sample_weight, state0=None, seed=None, apply=True):
+        """Returns dict(loss=..., k=..., y_pred=tensor). Gradients stay in self.gs / self.go; `apply` runs the optimizer."""
+        m = self.model
+        inputs = m.process_inputs(x_list)
+        nodes, arcs, _, set_mask, output_mask, adjacency, arcnode, nodegraph = inputs
+        nat.require_device(nodes, 'nodes')
+        dev = nodes.device
+        self.prim = p = _Prim(dev)
+        nodes = nodes.to(torch.float32).contiguous(); arcs = arcs.to(torch.float32).contiguous()
+        N, L = nodes.shape
+        A = arcs.shape[1] - 2
+        d = m.state_vect_dim
+        S = d if d > 0 else L
+        focus = m._focus
+        m.net_state.to(dev); m.net_output.to(dev)
+        gs, go = _NetGrads(m.net_state, p), _NetGrads(m.net_output, p)
+        self.gs, self.go = gs, go
+        adj = adjacency.device_csr(dev)
+        adj_src = _by_source(adjacency, dev)
+        an = arcnode.device_csr(dev)
+        from .GNN import _squeeze_last, _arc_endpoints
+        out_index = m._out_index(_squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev))
+        M = len(out_index)
+
+        # ---- setup aggregates (GNN.py:254-258) ----
+        arc_labels = arcs[:, 2:]
+        agg_arcs = p.aggregate(an, arc_labels, A, p.new(N, max(A, 1)))[:, :A] if A > 0 else None
+        agg_nodes = p.aggregate(adj, nodes, L, p.new(N, L)) if d > 0 else None
+        if d > 0:
+            if state0 is None:
+                gen = None
+                if seed is not None:
+                    gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
+                state0 = torch.randn((N, d), generator=gen, device=dev, dtype=torch.float32) * 0.1
+            s_init = state0.to(dev, torch.float32)
+        else:
+            s_init = nodes
+        K_it = m.max_iteration
+        states = p.new(K_it + 1, N, S)
+        states[0].copy_(s_init)
+        agg = p.new(N, S)
+
+        def state_segs(t):
+            segs = [(states[t], None)]
+            if d > 0: segs.append((nodes, None))
+            segs.append((agg, None))
+            if d > 0: segs.append((agg_nodes, None))
+            if A > 0: segs.append((agg_arcs, None))
+            return segs
+        i_state, i_agg = 0, (2 if d > 0 else 1)
+        const_stats = None
+        if gs.bn:
+            const_stats = {}
+            for i, (xv, _) in enumerate(state_segs(0)):
+                if i in (i_state, i_agg): continue
+                mu, va = p.new(xv.shape[1]), p.new(xv.shape[1])
+                p.colstats(xv, None, N, mu, va)
+                const_stats[i] = (mu, va)
+
+        # ---- forward, training mode: every iteration is computed, the predicate only records where the loop stops ----
+        flags = torch.zeros(K_it + 2, dtype=torch.int32, device=dev)
+        k_dev = torch.zeros((), dtype=torch.float32, device=dev)
+        lib = nat.lib()
+        nat.check(lib.gnn_converged_gated(nat.ptr(states[0]), None, N, S, S, float(m.state_threshold), None,
+                                          nat.ptr(flags[0:1]), None, 0.0, p.stream()))
+        stats_t = []
+        for t in range(K_it):
+            p.aggregate(adj, states[t], S, agg)
+            hs, st = self._mlp_forward(gs, state_segs(t), N, const_stats=const_stats)
+            states[t + 1].copy_(hs[-1])
+            stats_t.append(st)
+            nat.check(lib.gnn_converged_gated(nat.ptr(states[t + 1]), nat.ptr(states[t]), N, S, S, float(m.state_threshold),
+                                              nat.ptr(flags[t:t + 1]), nat.ptr(flags[t + 1:t + 2]), nat.ptr(k_dev),
+                                              float(t + 1), p.stream()))
+        k = int(float(k_dev))                                       # the one host synchronisation of the step
+        if gs.bn and k > 0:                                         # k moving-average updates, applied in order (closed form)
+            mm, mv = gs.moving
+            wts = torch.tensor([BN_MOMENTUM ** (k - 1 - t) * (1 - BN_MOMENTUM) for t in range(k)], device=dev)
+            mm.mul_(BN_MOMENTUM ** k).add_((torch.stack([stats_t[t][0] for t in range(k)]) * wts[:, None]).sum(0))
+            mv.mul_(BN_MOMENTUM ** k).add_((torch.stack([stats_t[t][1] for t in range(k)]) * wts[:, None]).sum(0))
+        state_k = states[k]
+
+        # ---- output network (training mode) ----
+        if focus == 'a':
+            es, ed = _arc_endpoints(adjacency, dev)
+            isrc, idst = es[out_index.long()].contiguous(), ed[out_index.long()].contiguous()
+            osegs = []
+            for ends in (isrc, idst):
+                osegs.append((state_k, ends))
+                if d > 0: osegs.append((nodes, ends))
+            if A > 0: osegs.append((arc_labels, out_index))
+        else:
+            osegs = [(state_k, out_index)]
+            if d > 0: osegs.append((nodes, out_index))
+        ohs, ostats = self._mlp_forward(go, osegs, M)
+        if go.bn:
+            mm, mv = go.moving
+            mm.mul_(BN_MOMENTUM).add_(ostats[0] * (1 - BN_MOMENTUM)); mv.mul_(BN_MOMENTUM).add_(ostats[1] * (1 - BN_MOMENTUM))
+        out_nodes = ohs[-1]
+        T = out_nodes.shape[1]
+        if focus == 'g':
+            ng_csr = nodegraph.device_csr(dev)
+            if ng_csr['n_src'] != M: raise ValueError('graph focus: every node must pass the mask')
+            y_pred = p.aggregate(ng_csr, out_nodes, T, p.new(ng_csr['n_dst'], T))
+        else:
+            y_pred = out_nodes
+
+        # ---- loss and d loss / d y_pred ----
+        res = {'k': k, 'y_pred': y_pred}
+        if y is None:
+            if m.loss: raise TypeError('Target data is missing. Your model was compiled with `loss` '
+                                       'argument and so expects targets to be passed in `fit()`.')
+            return res
+        y = y.to(dev, torch.float32).contiguous()
+        sw = None if sample_weight is None else sample_weight.to(dev, torch.float32).contiguous()
+        R = y_pred.shape[0]
+        dpred, loss_rows = p.new(R, T), p.new(max(R, 1))
+        kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
+        if kind.lower() not in nat.LOSSES: raise ValueError(f'loss {kind!r} has no device gradient')
+        nat.check(lib.gnn_loss_grad(nat.LOSSES[kind.lower()], nat.ptr(y), nat.ptr(y_pred), nat.ptr(sw), R, T, nat.ptr(dpred),
+                                    nat.ptr(loss_rows), p.stream()))
+        res['loss'] = loss_rows[:R].sum() / max(R, 1)
+
+        # ---- backward: output stage ----
+        if focus == 'g':
+            G_out = p.aggregate(_by_source(nodegraph, dev), dpred, T, p.new(M, T))     # NodeGraph . dOut
+        else:
+            G_out = dpred
+        G_state = p.zeros(N, S)                                     # dL / d states[k]
+        if M > 0:
+            if focus == 'a':
+                stride = 2 if d > 0 else 1
+                dxs, dxd = p.new(M, S), p.new(M, S)
+                self._mlp_backward(go, osegs, ohs, G_out, M, ostats, [(0, dxs), (stride, dxd)])
+                p.scatter_add_rows(dxs, isrc, G_state); p.scatter_add_rows(dxd, idst, G_state)
+            else:
+                dxo = p.new(M, S)
+                self._mlp_backward(go, osegs, ohs, G_out, M, ostats, [(0, dxo)])
+                p.scatter_add_rows(dxo, out_index, G_state)
+
+        # ---- backward through the k executed iterations ----
+        dx_s, dx_a = p.new(N, S), p.new(N, S)
+        for t in range(k - 1, -1, -1):
+            p.aggregate(adj, states[t], S, agg)
+            segs = state_segs(t)
+            hs, _ = self._mlp_forward(gs, segs, N, stats=stats_t[t])
+            self._mlp_backward(gs, segs, hs, G_state, N, stats_t[t], [(i_state, dx_s), (i_agg, dx_a)])
+            p.aggregate(adj_src, dx_a, S, G_state)                  # Adj . d agg   (arcs walked by source)
+            p.axpby(1.0, G_state, 1.0, dx_s, G_state)
+        if m.average_st_grads and k > 0:
+            for g in gs.gradients(): g.mul_(1.0 / k)
+        if k == 0:
+            for g in gs.gradients(): g.zero_()
+
+        if apply:
+            opt = m._optimizer_obj()
+            opt.apply_gradients(list(zip(gs.gradients() + go.gradients(), gs.variables() + go.variables())))
+        return res
+
+
+def _by_source(matrix: SparseMatrix, device):
+    """CSR of A itself (arcs grouped by SOURCE): the operator of the transposed aggregate, out[i] = Σ_{e: src=i} w_e X[dst_e]."""
+    key = ('by_source', str(device))
+    if key not in matrix._dev:
+        c = CSRByDestination.from_coo(matrix.indices[:, 1], matrix.indices[:, 0], matrix.values,
+                                      (matrix.dense_shape[1], matrix.dense_shape[0]))
+        up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        matrix._dev[key] = dict(rowptr=up(c.rowptr), src=up(c.src), w=up(c.w), row_scale=up(c.row_scale), n_src=c.n_src,
+                                n_dst=c.n_dst, nnz=c.nnz)
+    return matrix._dev[key]

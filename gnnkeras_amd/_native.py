@@ -25,7 +25,14 @@ FLAG_NO_EARLY_EXIT = 2
 
 EXPORTS = ['gnn_last_error', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_aggregate',
            'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_ld',
-           'gnn_shard_setup', 'gnn_shard_iteration', 'gnn_shard_output']
+           'gnn_shard_setup', 'gnn_shard_iteration', 'gnn_shard_output',
+           'gnn_dense', 'gnn_fold_bn', 'gnn_dense_grad_workspace_bytes', 'gnn_dense_grad', 'gnn_act_grad',
+           'gnn_colstats_workspace_bytes', 'gnn_colstats', 'gnn_first_layer_param_grads', 'gnn_bn_input_grad',
+           'gnn_scatter_add_rows', 'gnn_axpby', 'gnn_loss_grad', 'gnn_adam_step', 'gnn_sgd_step',
+           'gnn_converged_gated', 'gnn_aggregate_gated']
+GNN_MAX_SEGMENTS = 6
+LOSSES = {'categorical_crossentropy': 0, 'cce': 0, 'binary_crossentropy': 1, 'bce': 1, 'mse': 2,
+          'mean_squared_error': 2, 'mae': 3, 'mean_absolute_error': 3}
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -63,6 +70,17 @@ class LoopArgs(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('stream', C.c_void_p),
                 ('flags', C.c_int32), ('nodes_src', C.c_void_p), ('ld_nodes_src', C.c_int32),
                 ('ev_loop_begin', C.c_void_p), ('ev_loop_end', C.c_void_p)]
+
+
+class DenseArgs(C.Structure):
+    _fields_ = [('M', C.c_int32), ('H', C.c_int32), ('n_segments', C.c_int32),
+                ('seg_ptr', C.c_void_p * GNN_MAX_SEGMENTS), ('seg_rowidx', C.c_void_p * GNN_MAX_SEGMENTS),
+                ('seg_ld', C.c_int32 * GNN_MAX_SEGMENTS), ('seg_width', C.c_int32 * GNN_MAX_SEGMENTS),
+                ('seg_wrow', C.c_int32 * GNN_MAX_SEGMENTS),
+                ('W', C.c_void_p), ('ldw', C.c_int32), ('bias', C.c_void_p),
+                ('addend', C.c_void_p), ('ld_addend', C.c_int32), ('addend_rowidx', C.c_void_p),
+                ('activation', C.c_int32), ('Y', C.c_void_p), ('ldy', C.c_int32), ('out_rowidx', C.c_void_p),
+                ('gate', C.c_void_p), ('stream', C.c_void_p)]
 
 
 class NativeError(RuntimeError):
@@ -117,6 +135,28 @@ def lib():
                                           C.c_int32, C.c_void_p, C.c_int32]
         l.gnn_shard_output.restype = C.c_int
         l.gnn_shard_output.argtypes = [C.POINTER(LoopArgs), C.c_void_p, C.c_void_p, C.c_int32]
+        vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+        protos = {
+            'gnn_dense': (C.c_int, [C.POINTER(DenseArgs)]),
+            'gnn_fold_bn': (C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]),
+            'gnn_dense_grad_workspace_bytes': (sz, [i32, i32, i32]),
+            'gnn_dense_grad': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, sz, vp]),
+            'gnn_act_grad': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+            'gnn_colstats_workspace_bytes': (sz, [i32, i32]),
+            'gnn_colstats': (C.c_int, [vp, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, sz, vp]),
+            'gnn_first_layer_param_grads': (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+            'gnn_bn_input_grad': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, i32, vp]),
+            'gnn_scatter_add_rows': (C.c_int, [vp, i32, vp, i32, i32, vp, i32, vp]),
+            'gnn_axpby': (C.c_int, [f32, vp, f32, vp, vp, sz, vp]),
+            'gnn_loss_grad': (C.c_int, [i32, vp, vp, vp, i32, i32, vp, vp, vp]),
+            'gnn_adam_step': (C.c_int, [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, vp]),
+            'gnn_sgd_step': (C.c_int, [vp, vp, vp, sz, f32, f32, vp]),
+            'gnn_converged_gated': (C.c_int, [vp, vp, i32, i32, i32, f32, vp, vp, vp, f32, vp]),
+            'gnn_aggregate_gated': (C.c_int, [C.POINTER(CSR), vp, i32, i32, vp, i32, vp, vp]),
+        }
+        for name, (res, args) in protos.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
         l.gnn_struct_size.restype = C.c_size_t
         l.gnn_struct_size.argtypes = [C.c_int]
         if l.gnn_abi_version() != GNN_ABI_VERSION:

@@ -733,3 +733,5 @@ int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const 
 }
 
 }  // extern "C"
+
+#include "train_api.hpp"

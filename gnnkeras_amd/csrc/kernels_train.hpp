@@ -1,0 +1,288 @@
+// Building blocks of the backward pass / train_step (reference GNN/Models/GNN.py:277-306: GradientTape through the
+// unrolled loop, i.e. back-propagation through time over the k executed iterations).  All float32, deterministic
+// (two-stage reductions, no float atomics except the documented row scatter-add).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels_general.hpp"
+
+namespace gnn {
+
+// derivative of a Keras activation expressed with the layer OUTPUT y = act(x) (so pre-activations are never stored)
+__device__ __forceinline__ float activate_grad_from_output(int act, float y) {
+    switch (act) {
+        case GNN_ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+        case GNN_ACT_SELU: return y > 0.0f ? 1.0507009873554805f : y + 1.0507009873554805f * 1.6732632423543772f;
+        case GNN_ACT_TANH: return 1.0f - y * y;
+        case GNN_ACT_SIGMOID: return y * (1.0f - y);
+        case GNN_ACT_ELU: return y > 0.0f ? 1.0f : y + 1.0f;
+        case GNN_ACT_SOFTPLUS: return 1.0f - expf(-y);
+        default: return 1.0f;
+    }
+}
+
+// dZ[m, :] = G[m, :] (.) act'(Y[m, :]);  softmax rows: dZ = Y (.) (G - sum_j G_j Y_j).   In place allowed (dZ == G).
+__global__ void __launch_bounds__(256)
+k_act_grad(const float *__restrict__ G, int ldg, const float *__restrict__ Y, int ldy, float *__restrict__ dZ, int ldz,
+           int M, int H, int act) {
+    if (act == GNN_ACT_SOFTMAX) {
+        const int m = blockIdx.x * blockDim.x + threadIdx.x;
+        if (m >= M) return;
+        float dot = 0.0f;
+        for (int h = 0; h < H; ++h) dot = fmaf(G[(size_t)m * ldg + h], Y[(size_t)m * ldy + h], dot);
+        for (int h = 0; h < H; ++h) dZ[(size_t)m * ldz + h] = Y[(size_t)m * ldy + h] * (G[(size_t)m * ldg + h] - dot);
+        return;
+    }
+    const size_t total = (size_t)M * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / H;
+        const int h = (int)(i % H);
+        dZ[m * ldz + h] = G[m * ldg + h] * activate_grad_from_output(act, Y[m * ldy + h]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM on the f32 matrix cores:  P[k, h] = sum_m X[row(m), k] * dZ[m, h]   (K x H = X^T . dZ) and,
+// from blocks with blockIdx.y == 0, q[h] = sum_m dZ[m, h].  Stage 1 writes one partial per row chunk, stage 2 sums
+// the partials in a fixed order (bitwise reproducible).  grid = (row chunks, ceil(K/64), ceil(H/64)).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int DG_LD = 80;          // == 16 (mod 32): conflict-free transposed A-fragment and B-fragment reads
+
+__global__ void __launch_bounds__(256)
+k_dense_grad_partial(const float *__restrict__ X, int ldx, const int *__restrict__ rowidx, int K,
+                     const float *__restrict__ dZ, int ldz, int H, int M, int rows_per_chunk,
+                     float *__restrict__ Ppart, float *__restrict__ qpart) {
+    __shared__ float Xs[64 * DG_LD];
+    __shared__ float Zs[64 * DG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int k0 = blockIdx.y * 64, h0 = blockIdx.z * 64;
+    const int m_beg = blockIdx.x * rows_per_chunk, m_end = min(M, m_beg + rows_per_chunk);
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float qacc = 0.0f;                                   // threads 0..63 own one column each
+
+    for (int m0 = m_beg; m0 < m_end; m0 += 64) {
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int mm = i / 64, cc = i % 64, m = m0 + mm;
+            float xv = 0.0f, zv = 0.0f;
+            if (m < m_end) {
+                if (k0 + cc < K) xv = X[(rowidx ? (size_t)rowidx[m] : (size_t)m) * ldx + k0 + cc];
+                if (h0 + cc < H) zv = dZ[(size_t)m * ldz + h0 + cc];
+            }
+            Xs[mm * DG_LD + cc] = xv;
+            Zs[mm * DG_LD + cc] = zv;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const float av = Xs[(4 * s4 + g) * DG_LD + 16 * wave + r];      // A[k = 16*wave + r][m = 4*s4 + g]
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Zs[(4 * s4 + g) * DG_LD + 16 * c + r], acc[c], 0, 0, 0);
+        }
+        if (qpart && blockIdx.y == 0 && tid < 64) {
+            for (int mm = 0; mm < 64; ++mm) qacc += Zs[mm * DG_LD + tid];
+        }
+        __syncthreads();
+    }
+    float *Pp = Ppart + (size_t)blockIdx.x * K * H;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int h = h0 + 16 * c + r;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int k = k0 + 16 * wave + 4 * g + reg;
+            if (k < K && h < H) Pp[(size_t)k * H + h] = acc[c][reg];
+        }
+    }
+    if (qpart && blockIdx.y == 0 && tid < 64 && h0 + tid < H) qpart[(size_t)blockIdx.x * H + h0 + tid] = qacc;
+}
+
+// out[i] (+)= sum_c part[c][i]  in chunk order
+__global__ void __launch_bounds__(256)
+k_reduce_partials(const float *__restrict__ part, int n_chunks, int n, float *__restrict__ out, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int c = 0; c < n_chunks; ++c) s += part[(size_t)c * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// column statistics of X[row(m), 0:K] over M rows, two passes like tf.nn.moments: pass 1 (center == NULL) partial sums
+// of x, pass 2 partial sums of (x - mean)^2; one partial per row chunk, reduced in chunk order by k_reduce_partials.
+__global__ void __launch_bounds__(256)
+k_colstats_partial(const float *__restrict__ X, int ldx, const int *__restrict__ rowidx, int K, int M,
+                   int rows_per_chunk, const float *__restrict__ center, float *__restrict__ part) {
+    const int m_beg = blockIdx.x * rows_per_chunk, m_end = min(M, m_beg + rows_per_chunk);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float c = center ? center[k] : 0.0f;
+        float s = 0.0f;
+        for (int m = m_beg; m < m_end; ++m) {
+            const float x = X[(rowidx ? (size_t)rowidx[m] : (size_t)m) * ldx + k] - c;
+            s = center ? fmaf(x, x, s) : s + x;
+        }
+        part[(size_t)blockIdx.x * K + k] = s;
+    }
+}
+
+// out[k] = in[k] * scale   (sum -> mean / biased variance)
+__global__ void __launch_bounds__(256) k_scale_vec(const float *__restrict__ in, int K, float scale, float *__restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) out[k] = in[k] * scale;
+}
+
+// Keras moving-average update (momentum 0.99): moving = moving * momentum + batch * (1 - momentum)
+// (tf.keras.layers.BatchNormalization, training=True), skipped when the gate word is 0.
+__global__ void __launch_bounds__(256)
+k_bn_moving_update(const float *__restrict__ mean, const float *__restrict__ var, int K, float *moving_mean,
+                   float *moving_var, float momentum, const int *gate) {
+    if (gate_closed(gate)) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    moving_mean[k] = moving_mean[k] * momentum + mean[k] * (1.0f - momentum);
+    moving_var[k] = moving_var[k] * momentum + var[k] * (1.0f - momentum);
+}
+
+// Parameter gradients of [BatchNormalization +] first Dense from P = X^T dZ (K x H) and q = colsum(dZ) (H):
+//   with y = a (.) x + c per column (a = gamma*rstd, c = beta - mean*a; a = 1, c = 0 without BN):
+//   dW[k,h] (+)= a_k P[k,h] + c_k q[h]          db[h] (+)= q[h]
+//   sum_r dy[r,k]       = (W q)_k               =: S1_k      -> dbeta_k (+)= S1_k
+//   sum_r dy[r,k] x[r,k] = sum_h W[k,h] P[k,h]  =: S2_k      -> dgamma_k (+)= rstd_k (S2_k - mean_k S1_k)
+//   m1_k = S1_k / M ,  m2_k = rstd_k (S2_k - mean_k S1_k) / M     (consumed by k_bn_input_grad)
+// One thread per input feature k.
+__global__ void __launch_bounds__(256)
+k_first_layer_param_grads(const float *__restrict__ P, const float *__restrict__ q, const float *__restrict__ W, int K,
+                          int H, const float *gamma, const float *beta, const float *mean, const float *var, float eps,
+                          float inv_m, float *__restrict__ dW, float *__restrict__ db, float *dgamma, float *dbeta,
+                          float *m1, float *m2, int accumulate) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < H && db) db[k] = accumulate ? db[k] + q[k] : q[k];        // H bias entries handled by the first H threads
+    if (k >= K) return;
+    float a = 1.0f, c = 0.0f, rstd = 1.0f, mu = 0.0f;
+    if (gamma) {
+        rstd = 1.0f / sqrtf(var[k] + eps);
+        mu = mean[k];
+        a = gamma[k] * rstd;
+        c = beta[k] - mu * a;
+    }
+    float S1 = 0.0f, S2 = 0.0f;
+    for (int h = 0; h < H; ++h) {
+        const float w = W[(size_t)k * H + h], p = P[(size_t)k * H + h];
+        S1 = fmaf(w, q[h], S1);
+        S2 = fmaf(w, p, S2);
+        const float gw = a * p + c * q[h];
+        dW[(size_t)k * H + h] = accumulate ? dW[(size_t)k * H + h] + gw : gw;
+    }
+    if (gamma) {
+        const float dg = rstd * (S2 - mu * S1);
+        dgamma[k] = accumulate ? dgamma[k] + dg : dg;
+        dbeta[k] = accumulate ? dbeta[k] + S1 : S1;
+        if (m1) { m1[k] = S1 * inv_m; m2[k] = dg * inv_m; }
+    }
+}
+
+// Input gradient through a training-mode BatchNormalization for the column block [k0, k0+width):
+//   dx[r,j] = gamma rstd (dy[r,j] - m1 - xhat[r,j] m2),  xhat = (x - mean) rstd      (identity when gamma == NULL)
+__global__ void __launch_bounds__(256)
+k_bn_input_grad(const float *__restrict__ dy, int ld_dy, const float *__restrict__ x, int ld_x,
+                const int *__restrict__ x_rowidx, int M, int width, int k0, const float *gamma, const float *mean, const float *var, float eps, const float *m1,
+                const float *m2, float *__restrict__ dx, int ld_dx) {
+    const size_t total = (size_t)M * width;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / width;
+        const int j = (int)(i % width);
+        float v = dy[m * ld_dy + j];
+        if (gamma) {
+            const int k = k0 + j;
+            const float rstd = 1.0f / sqrtf(var[k] + eps);
+            const float xhat = (x[(x_rowidx ? (size_t)x_rowidx[m] : m) * ld_x + j] - mean[k]) * rstd;
+            v = gamma[k] * rstd * (v - m1[k] - xhat * m2[k]);
+        }
+        dx[m * ld_dx + j] = v;
+    }
+}
+
+// G[idx[m], :width] += D[m, :width]   (float atomics: rows may repeat, e.g. arc endpoints; order-dependent rounding)
+__global__ void __launch_bounds__(256)
+k_scatter_add_rows(const float *__restrict__ D, int ldd, const int *__restrict__ idx, int M, int width,
+                   float *__restrict__ G, int ldg) {
+    const size_t total = (size_t)M * width;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / width;
+        const int j = (int)(i % width);
+        atomicAdd(&G[(size_t)(idx ? idx[m] : (int)m) * ldg + j], D[m * ldd + j]);
+    }
+}
+
+// out = a * x + b * y  elementwise (accumulating gradients across iterations, scaling by 1/k)
+__global__ void __launch_bounds__(256)
+k_axpby(float a, const float *__restrict__ x, float b, const float *__restrict__ y, float *__restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + (y ? b * y[i] : 0.0f);
+}
+
+// ---- losses (Keras semantics, reduction SUM_OVER_BATCH_SIZE with sample weights): value and d loss / d prediction ----
+enum { LOSS_CCE = 0, LOSS_BCE = 1, LOSS_MSE = 2, LOSS_MAE = 3 };
+__global__ void __launch_bounds__(256)
+k_loss_grad(int kind, const float *__restrict__ y, const float *__restrict__ p, const float *__restrict__ sw, int M, int T,
+            float *__restrict__ dp, float *__restrict__ loss_rows) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float eps = 1e-7f;
+    const float wgt = (sw ? sw[m] : 1.0f) / (float)M;
+    const float *yr = y + (size_t)m * T, *pr = p + (size_t)m * T;
+    float *dr = dp + (size_t)m * T;
+    float loss = 0.0f;
+    if (kind == LOSS_CCE) {                       // p / sum(p), clip, -sum y log p
+        float sum = 0.0f, ysum = 0.0f;
+        for (int t = 0; t < T; ++t) { sum += pr[t]; ysum += yr[t]; }
+        float corr = 0.0f;                         // sum_i y_i [unclipped_i] (derivative of the normalisation)
+        for (int t = 0; t < T; ++t) {
+            const float pn = pr[t] / sum;
+            const bool inside = pn >= eps && pn <= 1.0f - eps;
+            const float pc = fminf(fmaxf(pn, eps), 1.0f - eps);
+            loss -= yr[t] * logf(pc);
+            if (inside) corr += yr[t];
+        }
+        for (int t = 0; t < T; ++t) {
+            const float pn = pr[t] / sum;
+            const bool inside = pn >= eps && pn <= 1.0f - eps;
+            dr[t] = wgt * ((inside ? -yr[t] / pr[t] : 0.0f) + corr / sum);
+        }
+        (void)ysum;
+    } else if (kind == LOSS_BCE) {                // mean over the last axis
+        for (int t = 0; t < T; ++t) {
+            const float pc = fminf(fmaxf(pr[t], eps), 1.0f - eps);
+            const bool inside = pr[t] >= eps && pr[t] <= 1.0f - eps;
+            loss -= (yr[t] * logf(pc) + (1.0f - yr[t]) * logf(1.0f - pc)) / (float)T;
+            dr[t] = inside ? wgt * (-(yr[t] / pc) + (1.0f - yr[t]) / (1.0f - pc)) / (float)T : 0.0f;
+        }
+    } else if (kind == LOSS_MSE) {
+        for (int t = 0; t < T; ++t) { const float d = pr[t] - yr[t]; loss += d * d / (float)T; dr[t] = wgt * 2.0f * d / (float)T; }
+    } else {
+        for (int t = 0; t < T; ++t) { const float d = pr[t] - yr[t]; loss += fabsf(d) / (float)T; dr[t] = wgt * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / (float)T; }
+    }
+    loss_rows[m] = loss * (sw ? sw[m] : 1.0f);
+}
+
+// ---- optimizers (tf.keras.optimizers.Adam / SGD defaults; `step` counts from 1) ------------------------------------------
+__global__ void __launch_bounds__(256)
+k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, size_t n, float lr,
+       float b1, float b2, float eps, float bc1, float bc2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = v[i] = b2 * v[i] + (1.0f - b2) * gi * gi;
+        p[i] -= lr * sqrtf(bc2) / bc1 * mi / (sqrtf(vi) + eps);     // alpha_t = lr sqrt(1-b2^t)/(1-b1^t)
+    }
+}
+__global__ void __launch_bounds__(256)
+k_sgd(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ mom, size_t n, float lr, float momentum) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (mom) { const float vel = mom[i] = momentum * mom[i] - lr * g[i]; p[i] += vel; }
+        else p[i] -= lr * g[i];
+    }
+}
+
+}  // namespace gnn

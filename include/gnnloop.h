@@ -180,6 +180,62 @@ int gnn_shard_iteration(const gnn_loop_args_t *args, const float *state_in_full,
  * to args->state_out [n_nodes, S] and runs the output network on them into args->out. */
 int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const float *buf1_full, int32_t row_base);
 
+/* ---- training building blocks (reference train_step, GNN.py:277-306: tape.gradient through the unrolled loop) ------
+ * The backward pass is orchestrated by the host (gnnkeras_amd/Models/training.py) one iteration at a time out of these
+ * device primitives; each is a hand-written gfx950 kernel (kernels_train.hpp), float32, no host synchronisation. */
+#define GNN_MAX_SEGMENTS 6
+/* Y[orow(m), :H] = act( sum_s X_s[row_s(m), :width_s] . W[wrow_s : wrow_s + width_s, :H] + bias + addend[arow(m), :H] )
+ * — one Dense layer over a virtual column concatenation (f32 MFMA); the forward layers and dX = dY . W^T of backprop. */
+typedef struct gnn_dense_args {
+    int32_t M, H, n_segments;
+    const float *seg_ptr[GNN_MAX_SEGMENTS];
+    const int32_t *seg_rowidx[GNN_MAX_SEGMENTS];   /* NULL = identity */
+    int32_t seg_ld[GNN_MAX_SEGMENTS], seg_width[GNN_MAX_SEGMENTS], seg_wrow[GNN_MAX_SEGMENTS];
+    const float *W; int32_t ldw;                   /* row-major [K_total][ldw], ldw = 0 means H */
+    const float *bias;                             /* [H] or NULL */
+    const float *addend; int32_t ld_addend; const int32_t *addend_rowidx;
+    int32_t activation;
+    float *Y; int32_t ldy; const int32_t *out_rowidx;
+    const int32_t *gate;                           /* skip the launch when *gate == 0 */
+    void *stream;
+} gnn_dense_args_t;
+int gnn_dense(const gnn_dense_args_t *args);
+/* Wf = diag(gamma/sqrt(var+eps)) W, bf = b + (beta - mean*gamma/sqrt(var+eps)) W  (gamma NULL: plain copy) */
+int gnn_fold_bn(const float *W, const float *b, int32_t K, int32_t H, const float *gamma, const float *beta,
+                const float *mean, const float *var, float eps, float *Wf, float *bf, void *stream);
+/* P[K,H] (+)= X[rows]^T dZ ; q[H] (+)= colsum(dZ)   — deterministic two-stage reduction */
+size_t gnn_dense_grad_workspace_bytes(int32_t K, int32_t H, int32_t M);
+int gnn_dense_grad(const float *X, int32_t ldx, const int32_t *rowidx, int32_t K, const float *dZ, int32_t ldz, int32_t H,
+                   int32_t M, float *P, float *q, int32_t accumulate, void *workspace, size_t workspace_bytes, void *stream);
+/* dZ = G (.) act'(Y) from the layer output (softmax: Y (.) (G - <G,Y>)) */
+int gnn_act_grad(const float *G, int32_t ldg, const float *Y, int32_t ldy, float *dZ, int32_t ldz, int32_t M, int32_t H,
+                 int32_t activation, void *stream);
+/* batch mean / biased variance of X[rows, :K] (BatchNormalization training=True) + Keras moving-average update */
+size_t gnn_colstats_workspace_bytes(int32_t K, int32_t M);
+int gnn_colstats(const float *X, int32_t ldx, const int32_t *rowidx, int32_t K, int32_t M, float *mean, float *var,
+                 float *moving_mean, float *moving_var, float momentum, const int32_t *gate, void *workspace,
+                 size_t workspace_bytes, void *stream);
+/* dW, db, dgamma, dbeta (and the two BN input-gradient moments m1, m2) of [BN +] first Dense from P and q */
+int gnn_first_layer_param_grads(const float *P, const float *q, const float *W, int32_t K, int32_t H, const float *gamma,
+                                const float *beta, const float *mean, const float *var, float eps, int32_t M, float *dW,
+                                float *db, float *dgamma, float *dbeta, float *m1, float *m2, int32_t accumulate, void *stream);
+int gnn_bn_input_grad(const float *dy, int32_t ld_dy, const float *x, int32_t ld_x, const int32_t *x_rowidx, int32_t M, int32_t width, int32_t k0,
+                      const float *gamma, const float *mean, const float *var, float eps, const float *m1, const float *m2,
+                      float *dx, int32_t ld_dx, void *stream);
+int gnn_scatter_add_rows(const float *D, int32_t ldd, const int32_t *idx, int32_t M, int32_t width, float *G, int32_t ldg, void *stream);
+int gnn_axpby(float a, const float *x, float b, const float *y, float *out, size_t n, void *stream);
+/* Keras losses with sample weights, reduction SUM_OVER_BATCH_SIZE: kind 0 categorical_crossentropy, 1 binary_crossentropy,
+ * 2 mse, 3 mae.  dp = d loss / d prediction, loss_rows[m] = weighted per-row loss (caller sums / M). */
+int gnn_loss_grad(int32_t kind, const float *y, const float *p, const float *sample_weight, int32_t M, int32_t T, float *dp,
+                  float *loss_rows, void *stream);
+int gnn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2, float eps,
+                  int32_t step, void *stream);
+int gnn_sgd_step(float *p, const float *g, float *velocity, size_t n, float lr, float momentum, void *stream);
+int gnn_converged_gated(const float *state, const float *state_old, int32_t n, int32_t dim, int32_t ld, float threshold,
+                        const int32_t *gate, int32_t *flag, float *k_out, float k_val, void *stream);
+int gnn_aggregate_gated(const gnn_csr_t *csr, const float *X, int32_t ldx, int32_t F, float *out, int32_t ldo,
+                        const int32_t *gate, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

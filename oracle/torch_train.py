@@ -1,0 +1,136 @@
+"""ORACLE for train_step — TEST INFRASTRUCTURE ONLY (see gnn_oracle.py header; parity UNPINNED by the reference: no
+TensorFlow, no reference tests).
+
+Restates the reference's `GNNnodeBased.train_step` (GNN/Models/GNN.py:277-306) with torch *autograd* on the CPU in
+float64: the eager `GradientTape` of the reference becomes `loss.backward()` through the same unrolled op sequence
+(adjoint SpMM, concat, training-mode BatchNormalization on batch statistics, Dense, activation, predicate). The product
+has no autograd; its hand-written backward kernels are checked against the gradients computed here.
+Keras semantics restated: BN training = biased batch variance, moving = moving*0.99 + batch*0.01 on every call;
+`categorical_crossentropy` on probabilities = normalise, clip to [1e-7, 1-1e-7], -sum y log p; loss reduction
+SUM_OVER_BATCH_SIZE with sample weights; Adam alpha_t = lr*sqrt(1-b2^t)/(1-b1^t), epsilon 1e-7 outside the sqrt.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .torch_cpu import ACT
+
+EPS_BN, MOMENTUM = 1e-3, 0.99
+
+
+class Net:
+    def __init__(self, spec, weights, dtype=torch.float64):
+        self.bn = spec['batch_normalization']
+        self.acts = spec['activations']
+        w = [torch.tensor(np.asarray(a), dtype=dtype) for a in weights]
+        pos = 0
+        if self.bn:
+            self.gamma, self.beta = w[0].requires_grad_(), w[1].requires_grad_()
+            self.moving_mean, self.moving_var = w[2].clone(), w[3].clone()
+            pos = 4
+        self.W = [w[pos + 2 * i].requires_grad_() for i in range(len(self.acts))]
+        self.b = [w[pos + 2 * i + 1].requires_grad_() for i in range(len(self.acts))]
+
+    def trainable(self):
+        v = [self.gamma, self.beta] if self.bn else []
+        for W, b in zip(self.W, self.b): v += [W, b]
+        return v
+
+    def __call__(self, x, training=True):
+        if self.bn:
+            if training:
+                mean = x.mean(0)
+                var = ((x - mean) ** 2).mean(0)
+                with torch.no_grad():
+                    self.moving_mean.mul_(MOMENTUM).add_(mean * (1 - MOMENTUM))
+                    self.moving_var.mul_(MOMENTUM).add_(var * (1 - MOMENTUM))
+            else:
+                mean, var = self.moving_mean, self.moving_var
+            x = (x - mean) / torch.sqrt(var + EPS_BN) * self.gamma + self.beta
+        for W, b, a in zip(self.W, self.b, self.acts):
+            x = ACT[a](x @ W + b)
+        return x
+
+
+def keras_loss(kind, y, p, sw):
+    eps = 1e-7
+    kind = kind.lower()
+    if kind in ('categorical_crossentropy', 'cce'):
+        p = p / p.sum(-1, keepdim=True)
+        l = -(y * torch.log(p.clamp(eps, 1 - eps))).sum(-1)
+    elif kind in ('binary_crossentropy', 'bce'):
+        pc = p.clamp(eps, 1 - eps)
+        l = -(y * torch.log(pc) + (1 - y) * torch.log(1 - pc)).mean(-1)
+    elif kind in ('mse', 'mean_squared_error'):
+        l = ((p - y) ** 2).mean(-1)
+    elif kind in ('mae', 'mean_absolute_error'):
+        l = (p - y).abs().mean(-1)
+    else:
+        raise ValueError(kind)
+    return (l * sw).sum() / max(l.shape[0], 1)
+
+
+def _sp(triple, dtype):
+    idx, val, shp = triple
+    idx = np.asarray(idx).reshape(-1, 2)
+    return torch.sparse_coo_tensor(torch.from_numpy(np.ascontiguousarray(idx.T[[1, 0]])),
+                                   torch.tensor(np.asarray(val, dtype=np.float64).reshape(-1), dtype=dtype),
+                                   (int(shp[1]), int(shp[0]))).coalesce()
+
+
+def train_step(nodes, arcs, adjacency, arcnode, nodegraph, mask, *, net_state, net_output, state_vect_dim, max_iteration,
+               state_threshold, focus, state0, y, sample_weight, loss, average_st_grads=False, dtype=torch.float64):
+    """Returns dict(k, loss, y_pred, grads_state, grads_output, moving_state, moving_output) as numpy."""
+    ns, no = Net(*net_state, dtype=dtype), Net(*net_output, dtype=dtype)
+    X = torch.tensor(np.asarray(nodes), dtype=dtype)
+    lab = torch.tensor(np.asarray(arcs)[:, 2:], dtype=dtype)
+    At, ANt = _sp(adjacency, dtype), _sp(arcnode, dtype)
+    agg_arcs = torch.sparse.mm(ANt, lab) if lab.shape[1] else torch.zeros((X.shape[0], 0), dtype=dtype)
+    d = state_vect_dim
+    if d > 0:
+        state = torch.tensor(np.asarray(state0), dtype=dtype)
+        agg_nodes = torch.sparse.mm(At, X)
+        comps = lambda s: [s, X, torch.sparse.mm(At, s), agg_nodes, agg_arcs]
+    else:
+        state = X.clone()
+        comps = lambda s: [s, torch.sparse.mm(At, s), agg_arcs]
+    state_old = torch.ones_like(state)
+    k = 0
+    while True:
+        dist = torch.sqrt(torch.sum(torch.square(state - state_old), dim=1))
+        norm = torch.sqrt(torch.sum(torch.square(state_old), dim=1))
+        if not (bool(torch.any(dist > state_threshold * norm)) and k < max_iteration):
+            break
+        state, state_old, k = ns(torch.cat(comps(state), dim=1)), state, k + 1
+    mask = torch.from_numpy(np.asarray(mask, dtype=bool))
+    sc = torch.cat([state, X], dim=1) if d > 0 else state
+    if focus == 'a':
+        idx = torch.from_numpy(np.asarray(adjacency[0]).reshape(-1, 2).astype(np.int64))
+        inp = torch.cat([sc[idx].reshape(lab.shape[0], 2 * sc.shape[1]), lab], dim=1)[mask]
+    else:
+        inp = sc[mask]
+    out = no(inp)
+    if focus == 'g':
+        out = torch.sparse.mm(_sp(nodegraph, dtype), out)
+    yt = torch.tensor(np.asarray(y), dtype=dtype)
+    sw = torch.ones(yt.shape[0], dtype=dtype) if sample_weight is None else torch.tensor(np.asarray(sample_weight), dtype=dtype)
+    L = keras_loss(loss, yt, out, sw)
+    params = ns.trainable() + no.trainable()
+    grads = torch.autograd.grad(L, params, allow_unused=True)
+    grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, params)]
+    n_s = len(ns.trainable())
+    gs, go = grads[:n_s], grads[n_s:]
+    if average_st_grads and k > 0: gs = [g / k for g in gs]
+    npy = lambda t: t.detach().numpy()
+    return dict(k=k, loss=float(L.detach()), y_pred=npy(out), state=npy(state), grads_state=[npy(g) for g in gs],
+                grads_output=[npy(g) for g in go],
+                moving_state=(npy(ns.moving_mean), npy(ns.moving_var)) if ns.bn else None,
+                moving_output=(npy(no.moving_mean), npy(no.moving_var)) if no.bn else None)
+
+
+def adam_update(p, g, m, v, step, lr=0.001, b1=0.9, b2=0.999, eps=1e-7):
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    alpha = lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+    return p - alpha * m / (np.sqrt(v) + eps), m, v

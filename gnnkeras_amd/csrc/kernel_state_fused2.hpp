@@ -89,6 +89,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) k_state_fused2(Fused
     const int t_first = xcd * tpx + lb;
 
     const char *__restrict__ sbase = reinterpret_cast<const char *>(a.state_in);   // state_in spans < 4 GiB (checked by the launcher)
+    const char *__restrict__ cbase = reinterpret_cast<const char *>(a.C);
+    char *__restrict__ obase = reinterpret_cast<char *>(a.state_out);
     const int q = tid / LPR;          // node slot inside a pass
     const int l4 = tid % LPR;         // 16-B column chunk of the row owned by this lane
 
@@ -133,7 +135,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) k_state_fused2(Fused
             const int colc = min(col, S - 1);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {          // always-valid address, value masked afterwards: no branches
-                const float cv = a.C[(size_t)max(jrow[reg], 0) * a.ldC + colc];
+                const unsigned coff = ((unsigned)max(jrow[reg], 0) * (unsigned)a.ldC + (unsigned)colc) * 4u;
+                const float cv = *reinterpret_cast<const float *>(cbase + coff);   // C spans < 4 GiB (launcher check)
                 c[ci][reg] = (jrow[reg] >= 0 && col < S) ? cv : 0.0f;
             }
         }
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) k_state_fused2(Fused
             // current slot: every neighbour row in flight before the first add
             f32x4 own = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
             const int deg = end0 - beg0;
-            if (j0 >= 0) own = *reinterpret_cast<const f32x4 *>(a.state_in + (size_t)(a.row_base + j0) * SP + 4 * l4);
+            if (j0 >= 0) own = *reinterpret_cast<const f32x4 *>(sbase + ((unsigned)(a.row_base + j0) * (unsigned)(SP * 4) + 16u * l4));
             {
                 // chunks of 16 neighbours; the first chunk's ids were prefetched a slot ago, later chunks (in-degree
                 // > 16, rare) fetch theirs in line.  One copy of the 16-load block: keeps the kernel near 128 VGPRs.
@@ -168,15 +171,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) k_state_fused2(Fused
 #pragma unroll 1
                 while (true) {
                     f32x4 v[16];
-                    unsigned off[16];   // 32-bit byte offsets off a wave-uniform base: SGPR base + VGPR offset addressing
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        off[i] = (unsigned)__shfl(idc[i / LPR], i % LPR, LPR) * (unsigned)(SP * 4) + 16u * l4;
+                        // 32-bit byte offset off a wave-uniform base: SGPR base + VGPR offset addressing
+                        const unsigned off = (unsigned)__shfl(idc[i / LPR], i % LPR, LPR) * (unsigned)(SP * 4) + 16u * l4;
                         v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (i < rem) v[i] = *reinterpret_cast<const f32x4 *>(sbase + off);
                     }
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (i < rem) v[i] = *reinterpret_cast<const f32x4 *>(sbase + off[i]);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         if (HAS_W) acc += __shfl(wsc[i / LPR], i % LPR, LPR) * v[i];
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) k_state_fused2(Fused
             if (j >= 0) {
                 const float *xr = Xs + nl * LDX + 4 * l4;
                 const float2 lo = *reinterpret_cast<const float2 *>(xr), hi = *reinterpret_cast<const float2 *>(xr + 2);
-                *reinterpret_cast<f32x4 *>(a.state_out + (size_t)(a.row_base + j) * SP + 4 * l4) = (f32x4){lo.x, lo.y, hi.x, hi.y};
+                *reinterpret_cast<f32x4 *>(obase + ((unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * l4)) = (f32x4){lo.x, lo.y, hi.x, hi.y};
             }
         }
     }
@@ -322,9 +323,12 @@ int launch_fused2_one(const Fused2Args &fa, int n_cu, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// Per-arc weights cost ~50 more live VGPRs (weight broadcasts + products): under the 128-VGPR cap of the 8-wave
+// workgroup that spills into the gather loop, so weighted graphs run the 4-wave shape (256-VGPR budget) instead.
 template <int SP, int TM, int NW>
 int launch_fused2_w(const Fused2Args &fa, int n_cu, hipStream_t st) {
-    return fa.w ? launch_fused2_one<SP, true, TM, NW>(fa, n_cu, st) : launch_fused2_one<SP, false, TM, NW>(fa, n_cu, st);
+    if (fa.w) return launch_fused2_one<SP, true, TM, 4>(fa, n_cu, st);
+    return launch_fused2_one<SP, false, TM, NW>(fa, n_cu, st);
 }
 
 // variant 2: 64-node tiles, 4 waves; 3: 32-node tiles, 4 waves; 4: 64-node tiles, 8 waves (twice the rows in flight)

@@ -500,27 +500,31 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
                                          flag_next, k_out, k_val, st));
         return 0;
     }
-    bool k_written = false;
-    for (int t = 0; t < p.T; ++t) {
-        gnn::Fused2Args fa;
-        fa.gate = n_gate ? gate : nullptr; fa.n_gate = n_gate; fa.gate_stride = gate_stride;
-        fa.rowptr = a.adjacency.rowptr; fa.src = a.adjacency.src; fa.w = a.adjacency.w; fa.row_scale = a.adjacency.row_scale;
-        fa.state_in = src; fa.state_out = dst; fa.row_base = row_base;
-        fa.C = p.C; fa.ldC = p.ldC;
-        fa.tp = type_of(t);
-        fa.S = p.S; fa.thr = a.state_threshold;
-        fa.flag_next = flag_next;
-        fa.k_out = k_written ? nullptr : k_out; fa.k_val = k_val;
-        if (fa.tp.count == 0) continue;
-        k_written = true;
-        FUSED_OK(gnn::launch_fused2(fa, p.SP, variant, device_cus(), st));
+    gnn::Fused2Args fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.gate = n_gate ? gate : nullptr; fa.n_gate = n_gate; fa.gate_stride = gate_stride;
+    fa.rowptr = a.adjacency.rowptr; fa.src = a.adjacency.src; fa.w = a.adjacency.w; fa.row_scale = a.adjacency.row_scale;
+    fa.state_in = src; fa.state_out = dst; fa.row_base = row_base;
+    fa.C = p.C; fa.ldC = p.ldC;
+    fa.n_types = 0;
+    for (int t = 0; t < p.T; ++t)
+        if (p.tp[t].count > 0) fa.tp[fa.n_types++] = type_of(t);
+    fa.S = p.S; fa.thr = a.state_threshold;
+    fa.flag_next = flag_next;
+    fa.k_out = k_out; fa.k_val = k_val;
+    if (fa.n_types == 0) {                      // no nodes at all: only the iteration counter moves
+        if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
+        return 0;
     }
+    FUSED_OK(gnn::launch_fused2(fa, p.SP, variant, device_cus(), st));
     return 0;
 }
 
 bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
     if (a.flags & GNN_FLAG_UNFUSED) return false;
     if (p.SP > 64) return false;   // LDS: [64 x 2SP] tile + [2SP x SP] weights must leave room for 2 workgroups per CU
+    // the fused kernel addresses state rows and C with 32-bit byte offsets off a scalar base
+    if ((size_t)std::max(a.adjacency.n_src, p.N) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return false;
     for (int t = 0; t < p.T; ++t)
         if (a.net_state[t].n_layers != 1 || a.net_state[t].activation[0] == GNN_ACT_SOFTMAX) return false;
     return true;

@@ -25,7 +25,9 @@ struct Fused2Args {
     float *state_out;                              // rows written at (row_base + j)
     int row_base;                                  // own rows of local node j live at row_base + j (0 on one GPU)
     const float *C; int ldC;
-    FusedType tp;
+    int n_types;                                   // node types handled by this launch (1 = homogeneous)
+    FusedType tp[GNN_MAX_TYPES];
+    int blk_begin[GNN_MAX_TYPES + 1];              // workgroups [blk_begin[t], blk_begin[t+1]) serve type t; multiples of 8
     int S;
     float thr;
     int *flag_next;
@@ -69,21 +71,26 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) k_state_fused2(Fused
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int S = a.S;
-    const int count = a.tp.count;
-    const int *__restrict__ rows = a.tp.rows;
+    // which node type this workgroup serves (one launch covers every type of a composite graph)
+    int ty = 0;
+    while (ty + 1 < a.n_types && (int)blockIdx.x >= a.blk_begin[ty + 1]) ++ty;
+    const FusedType tp = a.tp[ty];
+    const int bid = blockIdx.x - a.blk_begin[ty], nblk = a.blk_begin[ty + 1] - a.blk_begin[ty];
+    const int count = tp.count;
+    const int *__restrict__ rows = tp.rows;
 
     for (int i = tid; i < 2 * SP * SP; i += NT) {
         const int k = i / SP, n = i % SP;
         const int kk = k < SP ? k : k - SP;
         float v = 0.0f;
-        if (kk < S && n < S) v = a.tp.Wf[(size_t)((k < SP ? a.tp.wrow_state : a.tp.wrow_agg) + kk) * a.tp.H + n];
+        if (kk < S && n < S) v = tp.Wf[(size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + kk) * tp.H + n];
         Ws[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = v;
     }
 
     // XCD-contiguous tile ranges (workgroups b, b+8, .. share an XCD under round-robin dispatch; speed only)
     const int ntiles = (count + TM - 1) / TM;
-    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
-    const int blk_per_xcd = (gridDim.x + 7 - xcd) >> 3;
+    const int xcd = bid & 7, lb = bid >> 3;
+    const int blk_per_xcd = (nblk + 7 - xcd) >> 3;
     const int tpx = (ntiles + 7) >> 3;
     const int t_end = min(ntiles, (xcd + 1) * tpx);
     const int t_first = xcd * tpx + lb;
@@ -238,7 +245,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) k_state_fused2(Fused
 #pragma unroll
             for (int ci = 0; ci < Cfg::CT_PER_WAVE; ++ci) {
                 const int col = 16 * (cw * Cfg::CT_PER_WAVE + ci) + r;
-                const float nv = (jrow[reg] >= 0 && col < S) ? activate(a.tp.act, c[ci][reg]) : 0.0f;
+                const float nv = (jrow[reg] >= 0 && col < S) ? activate(tp.act, c[ci][reg]) : 0.0f;
                 const float ov = Xs[row * LDX + col];
                 const float d = nv - ov;
                 d2 = fmaf(d, d, d2);
@@ -307,7 +314,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) k_state_fused2(Fused
 }
 
 template <int SP, bool HAS_W, int TM, int NW>
-int launch_fused2_one(const Fused2Args &fa, int n_cu, hipStream_t st) {
+int launch_fused2_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     using Cfg = Fused2Cfg<SP, TM, NW>;
     static bool attr = false;
     if (!attr) {
@@ -315,10 +322,23 @@ int launch_fused2_one(const Fused2Args &fa, int n_cu, hipStream_t st) {
                                 (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
         attr = true;
     }
-    const int ntiles = (fa.tp.count + TM - 1) / TM;
-    const int blocks_per_cu = std::max(1, std::min(4, (int)(160 * 1024 / Cfg::LDS_BYTES)));
-    int grid = std::min(ntiles, blocks_per_cu * n_cu);
-    grid = std::max(8, (grid + 7) / 8 * 8);
+    // workgroups per type: proportional to its tiles, whole multiples of 8 (one per XCD), never more than its tiles need
+    const int blocks_per_cu = std::max(1, std::min(NW == 8 ? 2 : 4, (int)(160 * 1024 / Cfg::LDS_BYTES)));
+    const int budget = blocks_per_cu * n_cu;
+    long total_tiles = 0;
+    for (int t = 0; t < fa.n_types; ++t) total_tiles += (fa.tp[t].count + TM - 1) / TM;
+    fa.blk_begin[0] = 0;
+    for (int t = 0; t < fa.n_types; ++t) {
+        const int ntiles = (fa.tp[t].count + TM - 1) / TM;
+        int nb = 0;
+        if (ntiles > 0) {
+            nb = (int)std::min<long>((ntiles + 7) / 8 * 8, std::max<long>(8, budget * (long)ntiles / std::max<long>(total_tiles, 1)));
+            nb = std::max(8, nb / 8 * 8);          // round DOWN: the whole grid must stay co-resident (no second wave)
+        }
+        fa.blk_begin[t + 1] = fa.blk_begin[t] + nb;
+    }
+    const int grid = fa.blk_begin[fa.n_types];
+    if (grid == 0) return 0;
     k_state_fused2<SP, HAS_W, TM, NW><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -326,13 +346,13 @@ int launch_fused2_one(const Fused2Args &fa, int n_cu, hipStream_t st) {
 // Per-arc weights cost ~50 more live VGPRs (weight broadcasts + products): under the 128-VGPR cap of the 8-wave
 // workgroup that spills into the gather loop, so weighted graphs run the 4-wave shape (256-VGPR budget) instead.
 template <int SP, int TM, int NW>
-int launch_fused2_w(const Fused2Args &fa, int n_cu, hipStream_t st) {
+int launch_fused2_w(Fused2Args &fa, int n_cu, hipStream_t st) {
     if (fa.w) return launch_fused2_one<SP, true, TM, 4>(fa, n_cu, st);
     return launch_fused2_one<SP, false, TM, NW>(fa, n_cu, st);
 }
 
 // variant 2: 64-node tiles, 4 waves; 3: 32-node tiles, 4 waves; 4: 64-node tiles, 8 waves (twice the rows in flight)
-inline int launch_fused2(const Fused2Args &fa, int SP, int variant, int n_cu, hipStream_t st) {
+inline int launch_fused2(Fused2Args &fa, int SP, int variant, int n_cu, hipStream_t st) {
     switch (SP) {
         case 16: return launch_fused2_w<16, 64, 4>(fa, n_cu, st);
         case 32: return variant == 3 ? launch_fused2_w<32, 32, 4>(fa, n_cu, st)

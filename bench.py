@@ -100,8 +100,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--nodes', type=float, default=1e6)
-    ap.add_argument('--arcs', type=float, default=1e7)
+    ap.add_argument('--workload', choices=['c4', 'c3', 'c5'], default='c4',
+                    help='c4: ER 1M/10M (headline); c3: ER 100k/1M; c5: composite ER 500k/5M, 3 node types')
+    ap.add_argument('--nodes', type=float, default=None)
+    ap.add_argument('--arcs', type=float, default=None)
     ap.add_argument('--state-dim', type=int, default=64)
     ap.add_argument('--max-iteration', type=int, default=50)
     ap.add_argument('--aggregation', default='average')
@@ -128,19 +130,36 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from gnnkeras_amd import _native as nat
-    from gnnkeras_amd.synth import er_graph
+    from gnnkeras_amd.synth import er_graph, er_composite_graph
     from gnnkeras_amd.Models.GNN import GNNnodeBased
-    from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased
+    from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+    from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer, CompositeMultiGraphSequencer
 
-    N, E, d, K_it = int(args.nodes), int(args.arcs), args.state_dim, args.max_iteration
-    graph = er_graph(N, E, aggregation_mode=args.aggregation, seed=1234)
-    ns, no = starter_nets(d, device)
+    sizes = {'c4': (1e6, 1e7), 'c3': (1e5, 1e6), 'c5': (5e5, 5e6)}[args.workload]
+    N, E = int(args.nodes or sizes[0]), int(args.arcs or sizes[1])
+    d, K_it = args.state_dim, args.max_iteration
     s0_host = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
-    gnn = GNNnodeBased(ns, no, d, K_it, 0.0)
+    composite = args.workload == 'c5'
+    if composite:
+        dims = (14, 8, 4)
+        graph = er_composite_graph(N, E, dim_node_label=dims, aggregation_mode=args.aggregation, seed=1234)
+        inp, lay = get_inout_dims('state', dims, 3, 2, 'n', d)
+        nets_s = [MLP(i, lay, 'selu', 'lecun_normal', 'lecun_normal', rng=t, device=device) for t, i in enumerate(inp)]
+        inp, lay = get_inout_dims('output', dims, 3, 2, 'n', d)
+        no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9, device=device)
+        ns = nets_s[0]
+        gnn = CompositeGNNnodeBased(nets_s, no, d, K_it, 0.0)
+        Sequencer = CompositeMultiGraphSequencer
+    else:
+        graph = er_graph(N, E, aggregation_mode=args.aggregation, seed=1234)
+        ns, no = starter_nets(d, device)
+        gnn = GNNnodeBased(ns, no, d, K_it, 0.0)
+        Sequencer = MultiGraphSequencer
     if args.unfused: gnn.native_flags = nat.FLAG_UNFUSED
 
     if not sharded:
-        seq = MultiGraphSequencer([graph], 'n', args.aggregation, 1, shuffle=False, device=device)
+        seq = Sequencer([graph], 'n', args.aggregation, 1, shuffle=False, device=device)
         x = seq[0][0]
         inputs = gnn.process_inputs(x)
         s0 = torch.from_numpy(s0_host).to(device)
@@ -148,7 +167,7 @@ def main():
         for e in ev: e.record()
         gnn.loop_events = ev
         step = lambda: gnn.Loop(*inputs, state0=s0)
-        per_arc_w = inputs[5].csr().w is not None
+        per_arc_w = inputs[7 if composite else 5].csr().w is not None
         sync_all = torch.cuda.synchronize
     else:
         import torch.distributed as dist
@@ -202,7 +221,7 @@ def main():
     if os.path.exists(traffic_file) and not sharded and not args.unfused:
         try:
             tr = json.load(open(traffic_file))
-            if tr.get('workload_nodes') == N and tr.get('workload_arcs') == E:
+            if tr.get('workload_nodes') == N and tr.get('workload_arcs') == E and not composite:
                 roofline['traffic'] = tr['hbm_bytes_per_launch']
         except Exception:
             pass
@@ -212,8 +231,9 @@ def main():
         'value': value, 'unit': 'arc-updates/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'C4 Erdos-Renyi {N} nodes / {E} arcs, state_dim={d}, max_iteration={K_it}, '
+        'config': {'workload': f'{args.workload.upper()} Erdos-Renyi {N} nodes / {E} arcs, state_dim={d}, max_iteration={K_it}, '
                                f'threshold=0 (k={k_val:g}), node-focused, {args.aggregation} aggregation, '
+                               + ('3 node types with per-type ' if composite else '') +
                                f'BN+Dense({ns.input_dim}->{h1},selu) state net',
                    'sharding': 'single GPU' if not sharded else f'node-range shards over {world} GPUs, '
                                                                f'RCCL all-gather of state slices per iteration'},
@@ -222,7 +242,7 @@ def main():
         'fwd_ms_per_graph': ms_per_step,
     }
 
-    if rank == 0 and not sharded and not args.no_cpu_baseline:
+    if rank == 0 and not sharded and not args.no_cpu_baseline and not composite:
         from oracle import torch_cpu
         from oracle.harness import _np, _triple
         it_cpu = 3
@@ -236,7 +256,7 @@ def main():
                                             f'restatement of the TF op sequence (not TensorFlow), '
                                             f'{os.cpu_count()} host cpus'}
         result['speedup_vs_cpu_loop'] = (E / t_iter) / result['cpu_baseline']['value']
-    if rank == 0 and not sharded and not args.no_mutag:
+    if rank == 0 and not sharded and not args.no_mutag and args.workload == 'c4':
         result['mutag'] = mutag_section(device, cpu=not args.no_cpu_baseline)
 
     if rank == 0:

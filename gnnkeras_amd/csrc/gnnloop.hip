@@ -293,7 +293,6 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
         TRY(check_csr(a.adjacency, "adjacency", p.N, a.nodes_src ? a.adjacency.n_src : p.N));
         TRY(check_csr(a.arcnode, "arcnode", p.N, p.E));
         if (p.N > 0 && !a.nodes) return fail("nodes is NULL");
-        if (a.nodes_src && p.composite) return fail("sharded composite graphs are not supported yet");
         if (p.E > 0 && p.A > 0 && !a.arc_labels) return fail("arc_labels is NULL");
         if (a.state_dim > 0 && p.N > 0 && !a.state0) return fail("state0 is required when state_dim > 0");
         if (!a.k_out) return fail("k_out is NULL");
@@ -308,7 +307,8 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
         if (p.composite) {
             if (!a.type_nodes && p.N > 0) return fail("type_nodes is NULL");
             if (a.type_offsets[0] != 0 || a.type_offsets[p.T] != p.N) return fail("type_offsets must span [0, n_nodes]");
-            for (int t = 0; t < p.T; ++t) TRY(check_csr(a.composite_adjacency[t], "composite_adjacency", p.N, p.N));
+            for (int t = 0; t < p.T; ++t)
+                TRY(check_csr(a.composite_adjacency[t], "composite_adjacency", p.N, a.nodes_src ? a.adjacency.n_src : p.N));
         }
     }
 
@@ -407,7 +407,8 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
         int col = 0;
         for (int t = 0; t < p.T; ++t) {
             const int dt = a.type_dim_label[t];
-            if (dt > 0) TRY(launch_aggregate(nullptr, a.composite_adjacency[t], a.nodes, a.ld_nodes, dt, p.agg_nodes + col, p.ld_agg_nodes, st));
+            if (dt > 0) TRY(launch_aggregate(nullptr, a.composite_adjacency[t], a.nodes_src ? a.nodes_src : a.nodes,
+                                             a.nodes_src ? a.ld_nodes_src : a.ld_nodes, dt, p.agg_nodes + col, p.ld_agg_nodes, st));
             col += dt;
         }
     }
@@ -470,7 +471,7 @@ int fused_variant() {
     if (v < 0) {
         const char *e = getenv("GNN_FUSED_VARIANT");
         v = e ? atoi(e) : 4;
-        if (v < 1 || v > 4) v = 4;
+        if (v < 1 || v > 5) v = 4;
     }
     return v;
 }

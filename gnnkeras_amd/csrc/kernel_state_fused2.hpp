@@ -351,14 +351,16 @@ int launch_fused2_w(Fused2Args &fa, int n_cu, hipStream_t st) {
     return launch_fused2_one<SP, false, TM, NW>(fa, n_cu, st);
 }
 
-// variant 2: 64-node tiles, 4 waves; 3: 32-node tiles, 4 waves; 4: 64-node tiles, 8 waves (twice the rows in flight)
+// variant 2: 64-node tiles, 4 waves; 3: 32-node tiles, 4 waves; 4: 64-node tiles, 8 waves (twice the rows in flight);
+// 5: 32-node tiles, 8 waves (finer granularity for mid-size graphs)
 inline int launch_fused2(Fused2Args &fa, int SP, int variant, int n_cu, hipStream_t st) {
     switch (SP) {
         case 16: return launch_fused2_w<16, 64, 4>(fa, n_cu, st);
         case 32: return variant == 3 ? launch_fused2_w<32, 32, 4>(fa, n_cu, st)
-                      : variant == 4 ? launch_fused2_w<32, 64, 8>(fa, n_cu, st) : launch_fused2_w<32, 64, 4>(fa, n_cu, st);
+                      : variant >= 4 ? launch_fused2_w<32, 64, 8>(fa, n_cu, st) : launch_fused2_w<32, 64, 4>(fa, n_cu, st);
         case 64: return variant == 3 ? launch_fused2_w<64, 32, 4>(fa, n_cu, st)
-                      : variant == 4 ? launch_fused2_w<64, 64, 8>(fa, n_cu, st) : launch_fused2_w<64, 64, 4>(fa, n_cu, st);
+                      : variant == 4 ? launch_fused2_w<64, 64, 8>(fa, n_cu, st)
+                      : variant == 5 ? launch_fused2_w<64, 32, 8>(fa, n_cu, st) : launch_fused2_w<64, 64, 4>(fa, n_cu, st);
         default: return 1;
     }
 }

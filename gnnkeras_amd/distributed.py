@@ -75,6 +75,23 @@ class ShardPlan:
         sm, om = graph.set_mask[self.lo:self.hi], graph.output_mask[self.lo:self.hi]
         self.out_index = np.flatnonzero(sm & om).astype(np.int32)
         self.per_arc_weights = self.adjacency.w is not None
+        # heterogeneous graphs: local node ids grouped by type + the per-source-type adjacencies of the label aggregate
+        self.composite = hasattr(graph, 'type_mask')
+        if self.composite:
+            tm = graph.type_mask[self.lo:self.hi]                   # (n_local, T)
+            if not np.all(tm.sum(1) == 1): raise ValueError('type_mask must be one-hot: every node needs exactly one type')
+            types = tm.argmax(1)
+            order = np.argsort(types, kind='stable')
+            self.type_nodes = order.astype(np.int32)
+            self.type_offsets = np.concatenate([[0], np.cumsum(np.bincount(types, minlength=tm.shape[1]))]).astype(np.int64)
+            self.dim_node_label = [int(d) for d in graph.DIM_NODE_LABEL]
+            self.composite_adjacency = []
+            for ca in graph.CompositeAdjacencies:
+                ca = ca.tocoo()
+                keep = (ca.col >= self.lo) & (ca.col < self.hi)
+                self.composite_adjacency.append(CSRByDestination.from_coo(
+                    padded_row(ca.row[keep], self.chunk), ca.col[keep] - self.lo, ca.data[keep],
+                    (self.n_rows_full, self.n_local)))
 
     def pad_state(self, state: np.ndarray, SP: int) -> np.ndarray:
         """[N, S] -> full padded buffer [n_rows_full, SP] (flag rows and padding zero)."""
@@ -93,7 +110,10 @@ class ShardedLoop:
 
     def __init__(self, model, graph: GraphObject, rank: int, world_size: int, device, group=None):
         if model._focus != 'n':
-            raise NotImplementedError('sharding is built for node-focused models (BASELINE config C4)')
+            raise NotImplementedError('sharding is built for node-focused models (BASELINE configs C4 / C5)')
+        self.composite = isinstance(model.net_state, (list, tuple))
+        if self.composite != hasattr(graph, 'type_mask'):
+            raise ValueError('composite models need CompositeGraphObject graphs (and vice versa)')
         self.model, self.group = model, group
         self.rank, self.world_size = rank, world_size
         self.device = torch.device(device)
@@ -126,8 +146,21 @@ class ShardedLoop:
         a.nodes_src, a.ld_nodes_src = nat.ptr(self.d_nodes_full), self.L
         a.arc_labels, a.ld_arcs = nat.ptr(self.d_arc_labels), max(self.A, 1)
         a.adjacency, a.arcnode = nat.make_csr(self.d_adj), nat.make_csr(self.d_an)
-        a.n_types = 1
-        a.net_state[0] = m.net_state.to(dev).native()
+        if self.composite:
+            a.composite, a.n_types = 1, len(p.dim_node_label)
+            if a.n_types != len(m.net_state): raise ValueError('one state network per node type is required')
+            self.d_type_nodes = up(p.type_nodes)
+            a.type_nodes = nat.ptr(self.d_type_nodes)
+            self.d_ca = [csr(c) for c in p.composite_adjacency]
+            for t in range(a.n_types):
+                a.type_dim_label[t] = p.dim_node_label[t]
+                a.type_offsets[t] = int(p.type_offsets[t])
+                a.composite_adjacency[t] = nat.make_csr(self.d_ca[t])
+                a.net_state[t] = m.net_state[t].to(dev).native()
+            a.type_offsets[a.n_types] = int(p.type_offsets[a.n_types])
+        else:
+            a.n_types = 1
+            a.net_state[0] = m.net_state.to(dev).native()
         a.net_output = m.net_output.to(dev).native()
         a.state_dim, a.max_iteration, a.state_threshold = m.state_vect_dim, m.max_iteration, float(m.state_threshold)
         a.focus = nat.FOCUS['n']

@@ -537,3 +537,22 @@ def test_sharded_state_dim_0_and_per_arc_weights():
     k64, st64, o64 = oracle_loop(model, seq[0][0], None, np.float64)
     ks, st, o = _run_shards_on_one_gpu(model, g, None, 4)
     assert all(k == 5.0 for k in ks) and rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL
+
+
+@pytest.mark.parametrize('R', [1, 4])
+@pytest.mark.parametrize('mode', ['average', 'composite_average'])
+def test_sharded_composite_native_kernels_match_oracle(R, mode):
+    """BASELINE config C5 shape (3 node types, per-type state networks) on emulated node-range shards."""
+    rng = np.random.default_rng(4)
+    N, dims, d = 4001, (5, 3, 4), 32
+    g = er_composite_graph(N, 30000, dim_node_label=dims, aggregation_mode=mode, seed=11)
+    ns, no = composite_nets(dims, 3, d, 2, 'n')
+    model = CompositeGNNnodeBased(ns, no, d, 8, 0.0)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    x = CompositeMultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_composite_loop(model, x, s0, np.float64)
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        ks, st, o = _run_shards_on_one_gpu(model, g, s0, R)
+        assert all(k == float(k64) for k in ks)
+        assert rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL

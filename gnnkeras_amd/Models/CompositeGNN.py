@@ -91,12 +91,7 @@ class CompositeGNNnodeBased(GNNnodeBased):
     def convergence(self, *args, **kwargs):
         raise NotImplementedError('a standalone composite step is not exported; use Loop()')
 
-    def train_step(self, *args, **kwargs):
-        raise NotImplementedError('train_step / fit for composite models (reference CompositeGNN.py:275-304) is not built '
-                                  'yet; the homogeneous models train on the device. No CPU fallback by design.')
 
-    def fit(self, *args, **kwargs):
-        return self.train_step()
 
     def _check_training(self, training):
         nets = self.net_state + [self.net_output]

@@ -1,4 +1,4 @@
-"""train_step / fit for the homogeneous GNN on MI355X: back-propagation through the unrolled loop.
+"""train_step / fit for the homogeneous and composite GNNs on MI355X: back-propagation through the unrolled loop.
 
 Mirror of the reference's `GNNnodeBased.train_step` (`GNN/Models/GNN.py:277-306`): forward with `training=True`
 (BatchNormalization on batch statistics, moving averages updated on every call — i.e. k times per step for the state
@@ -274,10 +274,16 @@ class LoopTrainer:
 
     # ---- one training step ------------------------------------------------------------------------------------------------
     def train_step(self, x_list, y, sample_weight, state0=None, seed=None, apply=True):
-        """Returns dict(loss=..., k=..., y_pred=tensor). Gradients stay in self.gs / self.go; `apply` runs the optimizer."""
+        """Returns dict(loss=..., k=..., y_pred=tensor). Gradients stay in self.gs (list, one per node type) / self.go;
+        `apply` runs the optimizer. Homogeneous models are the one-type case (reference GNN.py:277-306); composite models
+        (CompositeGNN.py:275-304) run one state network per node type on that type's rows."""
         m = self.model
+        composite = isinstance(m.net_state, (list, tuple))
         inputs = m.process_inputs(x_list)
-        nodes, arcs, _, set_mask, output_mask, adjacency, arcnode, nodegraph = inputs
+        if composite:
+            nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, _cas, adjacency, arcnode, nodegraph = inputs
+        else:
+            nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph = inputs
         nat.require_device(nodes, 'nodes')
         dev = nodes.device
         self.prim = p = _Prim(dev)
@@ -287,9 +293,11 @@ class LoopTrainer:
         d = m.state_vect_dim
         S = d if d > 0 else L
         focus = m._focus
-        m.net_state.to(dev); m.net_output.to(dev)
-        gs, go = _NetGrads(m.net_state, p), _NetGrads(m.net_output, p)
-        self.gs, self.go = gs, go
+        nets_s = list(m.net_state) if composite else [m.net_state]
+        for n_ in nets_s: n_.to(dev)
+        m.net_output.to(dev)
+        gs, go = [_NetGrads(n_, p) for n_ in nets_s], _NetGrads(m.net_output, p)
+        self.gs, self.go = (gs if composite else gs[0]), go
         adj = adjacency.device_csr(dev)
         adj_src = _by_source(adjacency, dev)
         an = arcnode.device_csr(dev)
@@ -297,10 +305,32 @@ class LoopTrainer:
         out_index = m._out_index(_squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev))
         M = len(out_index)
 
-        # ---- setup aggregates (GNN.py:254-258) ----
+        # node types: row lists (None = all rows for the homogeneous model)
+        if composite:
+            dims = [int(v) for v in (dim_node_label.reshape(-1).tolist() if isinstance(dim_node_label, torch.Tensor)
+                                     else np.asarray(dim_node_label).reshape(-1))]
+            type_nodes, offsets = m._type_lists(_squeeze_last(type_mask).to(dev))
+            rows = [type_nodes[int(offsets[t]):int(offsets[t + 1])].contiguous() for t in range(len(dims))]
+        else:
+            dims, rows = [L], [None]
+        T_types = len(rows)
+        counts = [N if r is None else len(r) for r in rows]
+        rows_long = [None if r is None else r.long() for r in rows]
+
+        # ---- setup aggregates (GNN.py:254-258 / CompositeGNN.py:251-253) ----
         arc_labels = arcs[:, 2:]
         agg_arcs = p.aggregate(an, arc_labels, A, p.new(N, max(A, 1)))[:, :A] if A > 0 else None
-        agg_nodes = p.aggregate(adj, nodes, L, p.new(N, L)) if d > 0 else None
+        if composite:
+            sum_d = sum(dims)
+            agg_comp = p.new(N, max(sum_d + A, 1))                  # [agg_nodes_0 | ... | agg_nodes_{T-1} | agg_arcs]
+            col = 0
+            for t, ca in enumerate(_cas):
+                if dims[t] > 0: p.aggregate(ca.device_csr(dev), nodes[:, :dims[t]], dims[t], agg_comp[:, col:col + dims[t]])
+                col += dims[t]
+            if A > 0: agg_comp[:, col:col + A].copy_(agg_arcs)
+            agg_comp = agg_comp[:, :sum_d + A]
+        else:
+            agg_nodes = p.aggregate(adj, nodes, L, p.new(N, L)) if d > 0 else None
         if d > 0:
             if state0 is None:
                 gen = None
@@ -315,22 +345,32 @@ class LoopTrainer:
         states[0].copy_(s_init)
         agg = p.new(N, S)
 
-        def state_segs(t):
-            segs = [(states[t], None)]
+        def state_segs(t, ty):
+            r = rows[ty]
+            if composite:                                           # [labels[:, :d_t] | state | agg_state | agg_component]
+                segs = [(nodes[:, :dims[ty]], r)] if dims[ty] > 0 else []
+                segs += [(states[t], r), (agg, r)]
+                if agg_comp.shape[1] > 0: segs.append((agg_comp, r))
+                return segs, len(segs) - (3 if agg_comp.shape[1] > 0 else 2), len(segs) - (2 if agg_comp.shape[1] > 0 else 1)
+            segs = [(states[t], None)]                              # [state | labels | agg_state | agg_labels | agg_arcs]
             if d > 0: segs.append((nodes, None))
             segs.append((agg, None))
             if d > 0: segs.append((agg_nodes, None))
             if A > 0: segs.append((agg_arcs, None))
-            return segs
-        i_state, i_agg = 0, (2 if d > 0 else 1)
-        const_stats = None
-        if gs.bn:
-            const_stats = {}
-            for i, (xv, _) in enumerate(state_segs(0)):
-                if i in (i_state, i_agg): continue
-                mu, va = p.new(xv.shape[1]), p.new(xv.shape[1])
-                p.colstats(xv, None, N, mu, va)
-                const_stats[i] = (mu, va)
+            return segs, 0, (2 if d > 0 else 1)
+
+        const_stats = []
+        for ty in range(T_types):
+            cs = None
+            if gs[ty].bn and counts[ty] > 0:
+                cs = {}
+                segs, i_state, i_agg = state_segs(0, ty)
+                for i, (xv, ridx) in enumerate(segs):
+                    if i in (i_state, i_agg): continue
+                    mu, va = p.new(xv.shape[1]), p.new(xv.shape[1])
+                    p.colstats(xv, ridx, counts[ty], mu, va)
+                    cs[i] = (mu, va)
+            const_stats.append(cs)
 
         # ---- forward, training mode: every iteration is computed, the predicate only records where the loop stops ----
         flags = torch.zeros(K_it + 2, dtype=torch.int32, device=dev)
@@ -341,38 +381,50 @@ class LoopTrainer:
         stats_t = []
         for t in range(K_it):
             p.aggregate(adj, states[t], S, agg)
-            hs, st = self._mlp_forward(gs, state_segs(t), N, const_stats=const_stats)
-            states[t + 1].copy_(hs[-1])
-            stats_t.append(st)
+            st_t = []
+            for ty in range(T_types):
+                if counts[ty] == 0:
+                    st_t.append(None); continue
+                segs, _, _ = state_segs(t, ty)
+                hs, st = self._mlp_forward(gs[ty], segs, counts[ty], const_stats=const_stats[ty])
+                if rows[ty] is None: states[t + 1].copy_(hs[-1])
+                else: states[t + 1].index_copy_(0, rows_long[ty], hs[-1])
+                st_t.append(st)
+            stats_t.append(st_t)
             nat.check(lib.gnn_converged_gated(nat.ptr(states[t + 1]), nat.ptr(states[t]), N, S, S, float(m.state_threshold),
                                               nat.ptr(flags[t:t + 1]), nat.ptr(flags[t + 1:t + 2]), nat.ptr(k_dev),
                                               float(t + 1), p.stream()))
         k = int(float(k_dev))                                       # the one host synchronisation of the step
-        if gs.bn and k > 0:                                         # k moving-average updates, applied in order (closed form)
-            mm, mv = gs.moving
-            wts = torch.tensor([BN_MOMENTUM ** (k - 1 - t) * (1 - BN_MOMENTUM) for t in range(k)], device=dev)
-            mm.mul_(BN_MOMENTUM ** k).add_((torch.stack([stats_t[t][0] for t in range(k)]) * wts[:, None]).sum(0))
-            mv.mul_(BN_MOMENTUM ** k).add_((torch.stack([stats_t[t][1] for t in range(k)]) * wts[:, None]).sum(0))
+        for ty in range(T_types):                                   # k moving-average updates, applied in order (closed form)
+            if gs[ty].bn and k > 0 and counts[ty] > 0:
+                mm, mv = gs[ty].moving
+                wts = torch.tensor([BN_MOMENTUM ** (k - 1 - t) * (1 - BN_MOMENTUM) for t in range(k)], device=dev)
+                mm.mul_(BN_MOMENTUM ** k).add_((torch.stack([stats_t[t][ty][0] for t in range(k)]) * wts[:, None]).sum(0))
+                mv.mul_(BN_MOMENTUM ** k).add_((torch.stack([stats_t[t][ty][1] for t in range(k)]) * wts[:, None]).sum(0))
         state_k = states[k]
 
         # ---- output network (training mode) ----
+        with_labels = (not composite) and d > 0                     # composite filters use the state only (CompositeGNN.py:237-239)
         if focus == 'a':
             es, ed = _arc_endpoints(adjacency, dev)
             isrc, idst = es[out_index.long()].contiguous(), ed[out_index.long()].contiguous()
             osegs = []
             for ends in (isrc, idst):
                 osegs.append((state_k, ends))
-                if d > 0: osegs.append((nodes, ends))
+                if with_labels: osegs.append((nodes, ends))
             if A > 0: osegs.append((arc_labels, out_index))
         else:
             osegs = [(state_k, out_index)]
-            if d > 0: osegs.append((nodes, out_index))
-        ohs, ostats = self._mlp_forward(go, osegs, M)
-        if go.bn:
-            mm, mv = go.moving
-            mm.mul_(BN_MOMENTUM).add_(ostats[0] * (1 - BN_MOMENTUM)); mv.mul_(BN_MOMENTUM).add_(ostats[1] * (1 - BN_MOMENTUM))
-        out_nodes = ohs[-1]
-        T = out_nodes.shape[1]
+            if with_labels: osegs.append((nodes, out_index))
+        T = m.net_output.units[-1]
+        if M > 0:
+            ohs, ostats = self._mlp_forward(go, osegs, M)
+            if go.bn:
+                mm, mv = go.moving
+                mm.mul_(BN_MOMENTUM).add_(ostats[0] * (1 - BN_MOMENTUM)); mv.mul_(BN_MOMENTUM).add_(ostats[1] * (1 - BN_MOMENTUM))
+            out_nodes = ohs[-1]
+        else:
+            ohs, ostats, out_nodes = None, None, p.new(0, T)
         if focus == 'g':
             ng_csr = nodegraph.device_csr(dev)
             if ng_csr['n_src'] != M: raise ValueError('graph focus: every node must pass the mask')
@@ -389,7 +441,7 @@ class LoopTrainer:
         y = y.to(dev, torch.float32).contiguous()
         sw = None if sample_weight is None else sample_weight.to(dev, torch.float32).contiguous()
         R = y_pred.shape[0]
-        dpred, loss_rows = p.new(R, T), p.new(max(R, 1))
+        dpred, loss_rows = p.new(R, T), p.zeros(max(R, 1))
         kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
         if kind.lower() not in nat.LOSSES: raise ValueError(f'loss {kind!r} has no device gradient')
         nat.check(lib.gnn_loss_grad(nat.LOSSES[kind.lower()], nat.ptr(y), nat.ptr(y_pred), nat.ptr(sw), R, T, nat.ptr(dpred),
@@ -397,14 +449,11 @@ class LoopTrainer:
         res['loss'] = loss_rows[:R].sum() / max(R, 1)
 
         # ---- backward: output stage ----
-        if focus == 'g':
-            G_out = p.aggregate(_by_source(nodegraph, dev), dpred, T, p.new(M, T))     # NodeGraph . dOut
-        else:
-            G_out = dpred
+        G_out = p.aggregate(_by_source(nodegraph, dev), dpred, T, p.new(M, T)) if focus == 'g' else dpred   # NodeGraph . dOut
         G_state = p.zeros(N, S)                                     # dL / d states[k]
         if M > 0:
             if focus == 'a':
-                stride = 2 if d > 0 else 1
+                stride = 2 if with_labels else 1
                 dxs, dxd = p.new(M, S), p.new(M, S)
                 self._mlp_backward(go, osegs, ohs, G_out, M, ostats, [(0, dxs), (stride, dxd)])
                 p.scatter_add_rows(dxs, isrc, G_state); p.scatter_add_rows(dxd, idst, G_state)
@@ -414,22 +463,35 @@ class LoopTrainer:
                 p.scatter_add_rows(dxo, out_index, G_state)
 
         # ---- backward through the k executed iterations ----
-        dx_s, dx_a = p.new(N, S), p.new(N, S)
+        dx_s, dx_a = p.zeros(N, S), p.zeros(N, S)
         for t in range(k - 1, -1, -1):
             p.aggregate(adj, states[t], S, agg)
-            segs = state_segs(t)
-            hs, _ = self._mlp_forward(gs, segs, N, stats=stats_t[t])
-            self._mlp_backward(gs, segs, hs, G_state, N, stats_t[t], [(i_state, dx_s), (i_agg, dx_a)])
+            for ty in range(T_types):
+                if counts[ty] == 0: continue
+                segs, i_state, i_agg = state_segs(t, ty)
+                hs, _ = self._mlp_forward(gs[ty], segs, counts[ty], stats=stats_t[t][ty])
+                if rows[ty] is None:
+                    self._mlp_backward(gs[ty], segs, hs, G_state, N, stats_t[t][ty], [(i_state, dx_s), (i_agg, dx_a)])
+                else:
+                    G_t = G_state.index_select(0, rows_long[ty])
+                    ds_t, da_t = p.new(counts[ty], S), p.new(counts[ty], S)
+                    self._mlp_backward(gs[ty], segs, hs, G_t, counts[ty], stats_t[t][ty], [(i_state, ds_t), (i_agg, da_t)])
+                    dx_s.index_copy_(0, rows_long[ty], ds_t); dx_a.index_copy_(0, rows_long[ty], da_t)
             p.aggregate(adj_src, dx_a, S, G_state)                  # Adj . d agg   (arcs walked by source)
             p.axpby(1.0, G_state, 1.0, dx_s, G_state)
-        if m.average_st_grads and k > 0:
-            for g in gs.gradients(): g.mul_(1.0 / k)
-        if k == 0:
-            for g in gs.gradients(): g.zero_()
+        for g_ in gs:
+            if m.average_st_grads and k > 0:
+                for g in g_.gradients(): g.mul_(1.0 / k)
+            if k == 0 or not g_.touched:
+                for g in g_.gradients(): g.zero_()
+        if not go.touched:
+            for g in go.gradients(): g.zero_()
 
         if apply:
             opt = m._optimizer_obj()
-            opt.apply_gradients(list(zip(gs.gradients() + go.gradients(), gs.variables() + go.variables())))
+            grads = [g for g_ in gs for g in g_.gradients()] + go.gradients()
+            variables = [v for g_ in gs for v in g_.variables()] + go.variables()
+            opt.apply_gradients(list(zip(grads, variables)))
         return res
 
 

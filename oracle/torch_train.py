@@ -134,3 +134,63 @@ def adam_update(p, g, m, v, step, lr=0.001, b1=0.9, b2=0.999, eps=1e-7):
     v = b2 * v + (1 - b2) * g * g
     alpha = lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step)
     return p - alpha * m / (np.sqrt(v) + eps), m, v
+
+
+def composite_train_step(nodes, arcs, dim_node_label, type_mask, composite_adjacencies, adjacency, arcnode, nodegraph, mask,
+                         *, net_state, net_output, state_vect_dim, max_iteration, state_threshold, focus, state0, y,
+                         sample_weight, loss, average_st_grads=False, dtype=torch.float64):
+    """CompositeGNNnodeBased.train_step (GNN/Models/CompositeGNN.py:275-304) with torch autograd: one state network per
+    node type applied to the boolean-masked rows, scattered back and summed (CompositeGNN.py:223-232)."""
+    nets = [Net(*n, dtype=dtype) for n in net_state]
+    no = Net(*net_output, dtype=dtype)
+    X = torch.tensor(np.asarray(nodes), dtype=dtype)
+    lab = torch.tensor(np.asarray(arcs)[:, 2:], dtype=dtype)
+    dims = [int(v) for v in np.asarray(dim_node_label).reshape(-1)]
+    tm = torch.from_numpy(np.asarray(type_mask, dtype=bool))                 # (T, N)
+    At, ANt = _sp(adjacency, dtype), _sp(arcnode, dtype)
+    agg_nodes = [torch.sparse.mm(_sp(ca, dtype), X[:, :dt]) for ca, dt in zip(composite_adjacencies, dims)]
+    agg_arcs = torch.sparse.mm(ANt, lab) if lab.shape[1] else torch.zeros((X.shape[0], 0), dtype=dtype)
+    agg_comp = torch.cat(agg_nodes + [agg_arcs], dim=1)
+    state = torch.tensor(np.asarray(state0), dtype=dtype) if state_vect_dim > 0 else X.clone()
+    state_old = torch.ones_like(state)
+    k = 0
+    while True:
+        dist = torch.sqrt(torch.sum(torch.square(state - state_old), dim=1))
+        norm = torch.sqrt(torch.sum(torch.square(state_old), dim=1))
+        if not (bool(torch.any(dist > state_threshold * norm)) and k < max_iteration):
+            break
+        agg = torch.sparse.mm(At, state)
+        new = torch.zeros_like(state)
+        for dt, m_, net in zip(dims, tm, nets):
+            if not bool(m_.any()): continue
+            inp = torch.cat([X[:, :dt], state, agg, agg_comp], dim=1)[m_]
+            full = torch.zeros_like(state)
+            full[m_] = net(inp)
+            new = new + full
+        state, state_old, k = new, state, k + 1
+    mask = torch.from_numpy(np.asarray(mask, dtype=bool))
+    if focus == 'a':
+        idx = torch.from_numpy(np.asarray(adjacency[0]).reshape(-1, 2).astype(np.int64))
+        inp = torch.cat([state[idx].reshape(lab.shape[0], 2 * state.shape[1]), lab], dim=1)[mask]
+    else:
+        inp = state[mask]
+    out = no(inp)
+    if focus == 'g':
+        out = torch.sparse.mm(_sp(nodegraph, dtype), out)
+    yt = torch.tensor(np.asarray(y), dtype=dtype)
+    sw = torch.ones(yt.shape[0], dtype=dtype) if sample_weight is None else torch.tensor(np.asarray(sample_weight), dtype=dtype)
+    L = keras_loss(loss, yt, out, sw)
+    params = [p for n in nets for p in n.trainable()] + no.trainable()
+    grads = torch.autograd.grad(L, params, allow_unused=True)
+    grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, params)]
+    npy = lambda t: t.detach().numpy()
+    out_grads, pos = [], 0
+    for n in nets:
+        cnt = len(n.trainable())
+        g = grads[pos:pos + cnt]; pos += cnt
+        if average_st_grads and k > 0: g = [x / k for x in g]
+        out_grads.append([npy(x) for x in g])
+    return dict(k=k, loss=float(L.detach()), y_pred=npy(out), state=npy(state), grads_state=out_grads,
+                grads_output=[npy(g) for g in grads[pos:]],
+                moving_state=[(npy(n.moving_mean), npy(n.moving_var)) if n.bn else None for n in nets],
+                moving_output=(npy(no.moving_mean), npy(no.moving_var)) if no.bn else None)

@@ -171,3 +171,86 @@ def test_fit_reduces_loss_starter_config(mutag_graphs, bn):
     assert np.isfinite(hist['val_loss']).all() and np.isfinite(hist['accuracy']).all()
     if not bn:
         assert after['loss'] < before['loss']
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# composite (heterogeneous) models: one state network per node type (reference CompositeGNN.py:275-304)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('focus', ['n', 'g', 'a'])
+@pytest.mark.parametrize('bn', [False, True])
+def test_composite_gradients(focus, bn):
+    from gnnkeras_amd import CompositeGraphObject
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased, CompositeGNNarcBased, CompositeGNNgraphBased
+    from gnnkeras_amd.Models.training import LoopTrainer
+    from gnnkeras_amd.Sequencers.GraphSequencers import CompositeMultiGraphSequencer
+    CC = {'n': CompositeGNNnodeBased, 'a': CompositeGNNarcBased, 'g': CompositeGNNgraphBased}[focus]
+    rng = np.random.default_rng(31)
+    dims, A, D, T = (4, 2, 3), 2, 10, 2
+
+    def cg(n, e):
+        pairs = set()
+        while len(pairs) < e:
+            a, b = rng.integers(0, n, 2)
+            if a != b: pairs.add((int(a), int(b)))
+        ids = np.array(sorted(pairs), dtype=float)
+        arcs = np.concatenate([ids, rng.normal(size=(e, A))], 1)
+        types = rng.integers(0, 3, n); types[:3] = [0, 1, 2]
+        tm = np.zeros((n, 3), bool); tm[np.arange(n), types] = True
+        nt = {'n': n, 'a': e, 'g': 1}[focus]
+        om = rng.random(nt) < 0.8 if focus != 'g' else np.ones(n, bool)
+        tg = np.zeros((int(om.sum()) if focus != 'g' else 1, T)); tg[np.arange(len(tg)), rng.integers(0, T, len(tg))] = 1
+        kw = dict(output_mask=om) if focus != 'g' else {}
+        return CompositeGraphObject(nodes=rng.normal(size=(n, 4)), arcs=arcs, targets=tg, type_mask=tm, dim_node_label=dims,
+                                    focus=focus, aggregation_mode='composite_average', **kw)
+    seq = CompositeMultiGraphSequencer([cg(60, 200), cg(35, 90), cg(80, 260)], focus, 'composite_average', 3, shuffle=False)
+    x, y, sw = seq[0]
+    inp, lay = get_inout_dims('state', dims, A, T, focus, D, hidden_units=[12] if bn else None)
+    ns = [MLP(i, lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=t, batch_normalization=bn) for t, i in enumerate(inp)]
+    for n in ns: n.set_weights([a * 0.5 if a.ndim == 2 else a for a in n.get_weights()])
+    inp, lay = get_inout_dims('output', dims, A, T, focus, D)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9, batch_normalization=bn)
+    model = CC(ns, no, D, 5, 0.0)
+    model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+    N = x[0].shape[0]
+    s0 = rng.normal(0, 0.1, (N, D)).astype(np.float32)
+    nodes, arcs, dnl, tmask, sm, om_, cas, adj, an, ng = x
+    mask = np.logical_and(_np(sm).reshape(-1), _np(om_).reshape(-1))
+    want = torch_train.composite_train_step(
+        _np(nodes), _np(arcs), _np(dnl).reshape(-1), _np(tmask).reshape(3, -1), [_triple(c) for c in cas], _triple(adj),
+        _triple(an), _triple(ng), mask, net_state=[n.spec() for n in ns], net_output=no.spec(), state_vect_dim=D,
+        max_iteration=5, state_threshold=0.0, focus=focus, state0=s0, y=_np(y), sample_weight=_np(sw),
+        loss='categorical_crossentropy')
+    tr = LoopTrainer(model)
+    res = tr.train_step(x, y, sw, state0=torch.from_numpy(s0).cuda(), apply=False)
+    assert res['k'] == want['k'] == 5
+    assert abs(float(res['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))
+    assert rel_err(res['y_pred'].cpu().numpy(), want['y_pred']) <= 1e-5
+    allref = [r for g in want['grads_state'] for r in g] + want['grads_output']
+    scale = max(float(np.max(np.abs(r))) for r in allref)
+    got = [g for t in tr.gs for g in t.gradients()] + tr.go.gradients()
+    assert len(got) == len(allref)
+    for i, (g, r) in enumerate(zip(got, allref)):
+        err = float(np.max(np.abs(g.cpu().numpy() - r)))
+        assert err <= GTOL * max(float(np.max(np.abs(r))), 1e-12) or err <= GTOL * scale, (i, err)
+    if bn:
+        for n, mv in zip(ns, want['moving_state']):
+            w = n.get_weights()
+            assert rel_err(w[2], mv[0]) <= 1e-5 and rel_err(w[3], mv[1]) <= 1e-5
+
+
+def test_composite_fit_runs():
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased
+    from gnnkeras_amd.Sequencers.GraphSequencers import CompositeMultiGraphSequencer
+    from gnnkeras_amd.synth import er_composite_graph
+    dims = (5, 3, 4)
+    gs_ = [er_composite_graph(300 + 10 * i, 2000, dim_node_label=dims, seed=i) for i in range(6)]
+    seq = CompositeMultiGraphSequencer(gs_, 'n', 'average', 2, shuffle=True)
+    inp, lay = get_inout_dims('state', dims, 3, 2, 'n', 8)
+    ns = [MLP(i, lay, 'selu', 'lecun_normal', 'lecun_normal', rng=t) for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', dims, 3, 2, 'n', 8)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9)
+    model = CompositeGNNnodeBased(ns, no, 8, 4, 0.01)
+    model.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['accuracy'])
+    np.random.seed(1)
+    hist = model.fit(seq, epochs=5, verbose=0)
+    assert hist['loss'][-1] < hist['loss'][0] and np.isfinite(hist['accuracy']).all()

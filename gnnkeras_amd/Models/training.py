@@ -272,38 +272,45 @@ class LoopTrainer:
                 p.dense([(dZ, None)], Wt[:, k0:k0 + w], w, None, 0, out)
                 p.bn_input_grad(out, x, ridx, M, k0, ng.bn_params, mean, var, m1, m2, out)
 
-    # ---- one training step ------------------------------------------------------------------------------------------------
-    def train_step(self, x_list, y, sample_weight, state0=None, seed=None, apply=True):
-        """Returns dict(loss=..., k=..., y_pred=tensor). Gradients stay in self.gs (list, one per node type) / self.go;
-        `apply` runs the optimizer. Homogeneous models are the one-type case (reference GNN.py:277-306); composite models
-        (CompositeGNN.py:275-304) run one state network per node type on that type's rows."""
+    # ---- training-mode forward: records the tape ------------------------------------------------------------------------
+    def forward(self, x_list, state0=None, seed=None, node_level=False):
+        """Training-mode forward of one batch. Returns the tape (a `types.SimpleNamespace`) holding everything the
+        backward sweep needs: the k+1 states, the BN batch statistics per iteration, the output-network activations.
+        `node_level=True` makes a graph-focused model stop at the per-node outputs (what LGNN feeds to the next layer,
+        reference LGNN.py:225-246 uses `GNNnodeBased.Loop` for that)."""
+        from types import SimpleNamespace
         m = self.model
-        composite = isinstance(m.net_state, (list, tuple))
+        tp = SimpleNamespace()
+        composite = tp.composite = isinstance(m.net_state, (list, tuple))
         inputs = m.process_inputs(x_list)
         if composite:
             nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, _cas, adjacency, arcnode, nodegraph = inputs
         else:
             nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph = inputs
         nat.require_device(nodes, 'nodes')
-        dev = nodes.device
-        self.prim = p = _Prim(dev)
-        nodes = nodes.to(torch.float32).contiguous(); arcs = arcs.to(torch.float32).contiguous()
+        dev = tp.dev = nodes.device
+        self.prim = p = tp.p = _Prim(dev)
+        nodes = tp.nodes = nodes.to(torch.float32).contiguous(); arcs = arcs.to(torch.float32).contiguous()
         N, L = nodes.shape
         A = arcs.shape[1] - 2
         d = m.state_vect_dim
         S = d if d > 0 else L
-        focus = m._focus
+        tp.N, tp.L, tp.A, tp.d, tp.S = N, L, A, d, S
+        focus = tp.focus = 'n' if (node_level and m._focus == 'g') else m._focus
+        tp.pooled = m._focus == 'g' and not node_level
         nets_s = list(m.net_state) if composite else [m.net_state]
         for n_ in nets_s: n_.to(dev)
         m.net_output.to(dev)
         gs, go = [_NetGrads(n_, p) for n_ in nets_s], _NetGrads(m.net_output, p)
+        tp.gs, tp.go = gs, go
         self.gs, self.go = (gs if composite else gs[0]), go
-        adj = adjacency.device_csr(dev)
-        adj_src = _by_source(adjacency, dev)
+        adj = tp.adj = adjacency.device_csr(dev)
+        tp.adj_src = _by_source(adjacency, dev)
         an = arcnode.device_csr(dev)
+        tp.nodegraph = nodegraph
         from .GNN import _squeeze_last, _arc_endpoints
-        out_index = m._out_index(_squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev))
-        M = len(out_index)
+        out_index = tp.out_index = m._out_index(_squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev))
+        M = tp.M = len(out_index)
 
         # node types: row lists (None = all rows for the homogeneous model)
         if composite:
@@ -313,13 +320,15 @@ class LoopTrainer:
             rows = [type_nodes[int(offsets[t]):int(offsets[t + 1])].contiguous() for t in range(len(dims))]
         else:
             dims, rows = [L], [None]
-        T_types = len(rows)
-        counts = [N if r is None else len(r) for r in rows]
-        rows_long = [None if r is None else r.long() for r in rows]
+        tp.dims, tp.rows = dims, rows
+        T_types = tp.T_types = len(rows)
+        counts = tp.counts = [N if r is None else len(r) for r in rows]
+        rows_long = tp.rows_long = [None if r is None else r.long() for r in rows]
 
         # ---- setup aggregates (GNN.py:254-258 / CompositeGNN.py:251-253) ----
-        arc_labels = arcs[:, 2:]
+        arc_labels = tp.arc_labels = arcs[:, 2:]
         agg_arcs = p.aggregate(an, arc_labels, A, p.new(N, max(A, 1)))[:, :A] if A > 0 else None
+        agg_comp = agg_nodes = None
         if composite:
             sum_d = sum(dims)
             agg_comp = p.new(N, max(sum_d + A, 1))                  # [agg_nodes_0 | ... | agg_nodes_{T-1} | agg_arcs]
@@ -341,30 +350,33 @@ class LoopTrainer:
         else:
             s_init = nodes
         K_it = m.max_iteration
-        states = p.new(K_it + 1, N, S)
+        states = tp.states = p.new(K_it + 1, N, S)
         states[0].copy_(s_init)
-        agg = p.new(N, S)
+        agg = tp.agg = p.new(N, S)
 
         def state_segs(t, ty):
+            """(segments, index of the state segment, of the agg segment, of the label segment, of the agg-label segment)"""
             r = rows[ty]
             if composite:                                           # [labels[:, :d_t] | state | agg_state | agg_component]
                 segs = [(nodes[:, :dims[ty]], r)] if dims[ty] > 0 else []
+                i_state = len(segs)
                 segs += [(states[t], r), (agg, r)]
                 if agg_comp.shape[1] > 0: segs.append((agg_comp, r))
-                return segs, len(segs) - (3 if agg_comp.shape[1] > 0 else 2), len(segs) - (2 if agg_comp.shape[1] > 0 else 1)
+                return segs, i_state, i_state + 1, None, None
             segs = [(states[t], None)]                              # [state | labels | agg_state | agg_labels | agg_arcs]
             if d > 0: segs.append((nodes, None))
             segs.append((agg, None))
             if d > 0: segs.append((agg_nodes, None))
             if A > 0: segs.append((agg_arcs, None))
-            return segs, 0, (2 if d > 0 else 1)
+            return segs, 0, (2 if d > 0 else 1), (1 if d > 0 else None), (3 if d > 0 else None)
+        tp.state_segs = state_segs
 
         const_stats = []
         for ty in range(T_types):
             cs = None
             if gs[ty].bn and counts[ty] > 0:
                 cs = {}
-                segs, i_state, i_agg = state_segs(0, ty)
+                segs, i_state, i_agg, _, _ = state_segs(0, ty)
                 for i, (xv, ridx) in enumerate(segs):
                     if i in (i_state, i_agg): continue
                     mu, va = p.new(xv.shape[1]), p.new(xv.shape[1])
@@ -372,20 +384,20 @@ class LoopTrainer:
                     cs[i] = (mu, va)
             const_stats.append(cs)
 
-        # ---- forward, training mode: every iteration is computed, the predicate only records where the loop stops ----
+        # ---- every iteration is computed, the predicate only records where the loop stops ----
         flags = torch.zeros(K_it + 2, dtype=torch.int32, device=dev)
         k_dev = torch.zeros((), dtype=torch.float32, device=dev)
         lib = nat.lib()
         nat.check(lib.gnn_converged_gated(nat.ptr(states[0]), None, N, S, S, float(m.state_threshold), None,
                                           nat.ptr(flags[0:1]), None, 0.0, p.stream()))
-        stats_t = []
+        stats_t = tp.stats_t = []
         for t in range(K_it):
             p.aggregate(adj, states[t], S, agg)
             st_t = []
             for ty in range(T_types):
                 if counts[ty] == 0:
                     st_t.append(None); continue
-                segs, _, _ = state_segs(t, ty)
+                segs = state_segs(t, ty)[0]
                 hs, st = self._mlp_forward(gs[ty], segs, counts[ty], const_stats=const_stats[ty])
                 if rows[ty] is None: states[t + 1].copy_(hs[-1])
                 else: states[t + 1].index_copy_(0, rows_long[ty], hs[-1])
@@ -394,104 +406,164 @@ class LoopTrainer:
             nat.check(lib.gnn_converged_gated(nat.ptr(states[t + 1]), nat.ptr(states[t]), N, S, S, float(m.state_threshold),
                                               nat.ptr(flags[t:t + 1]), nat.ptr(flags[t + 1:t + 2]), nat.ptr(k_dev),
                                               float(t + 1), p.stream()))
-        k = int(float(k_dev))                                       # the one host synchronisation of the step
+        k = tp.k = int(float(k_dev))                                # the one host synchronisation of the step
         for ty in range(T_types):                                   # k moving-average updates, applied in order (closed form)
             if gs[ty].bn and k > 0 and counts[ty] > 0:
                 mm, mv = gs[ty].moving
                 wts = torch.tensor([BN_MOMENTUM ** (k - 1 - t) * (1 - BN_MOMENTUM) for t in range(k)], device=dev)
                 mm.mul_(BN_MOMENTUM ** k).add_((torch.stack([stats_t[t][ty][0] for t in range(k)]) * wts[:, None]).sum(0))
                 mv.mul_(BN_MOMENTUM ** k).add_((torch.stack([stats_t[t][ty][1] for t in range(k)]) * wts[:, None]).sum(0))
-        state_k = states[k]
+        state_k = tp.state = states[k]
 
         # ---- output network (training mode) ----
-        with_labels = (not composite) and d > 0                     # composite filters use the state only (CompositeGNN.py:237-239)
+        with_labels = tp.with_labels = (not composite) and d > 0    # composite filters use the state only (CompositeGNN.py:237-239)
         if focus == 'a':
             es, ed = _arc_endpoints(adjacency, dev)
-            isrc, idst = es[out_index.long()].contiguous(), ed[out_index.long()].contiguous()
+            tp.isrc, tp.idst = es[out_index.long()].contiguous(), ed[out_index.long()].contiguous()
             osegs = []
-            for ends in (isrc, idst):
+            for ends in (tp.isrc, tp.idst):
                 osegs.append((state_k, ends))
                 if with_labels: osegs.append((nodes, ends))
             if A > 0: osegs.append((arc_labels, out_index))
         else:
             osegs = [(state_k, out_index)]
             if with_labels: osegs.append((nodes, out_index))
-        T = m.net_output.units[-1]
+        tp.osegs = osegs
+        T = tp.T = m.net_output.units[-1]
         if M > 0:
-            ohs, ostats = self._mlp_forward(go, osegs, M)
+            tp.ohs, tp.ostats = self._mlp_forward(go, osegs, M)
             if go.bn:
                 mm, mv = go.moving
-                mm.mul_(BN_MOMENTUM).add_(ostats[0] * (1 - BN_MOMENTUM)); mv.mul_(BN_MOMENTUM).add_(ostats[1] * (1 - BN_MOMENTUM))
-            out_nodes = ohs[-1]
+                mm.mul_(BN_MOMENTUM).add_(tp.ostats[0] * (1 - BN_MOMENTUM)); mv.mul_(BN_MOMENTUM).add_(tp.ostats[1] * (1 - BN_MOMENTUM))
+            tp.out_nodes = tp.ohs[-1]
         else:
-            ohs, ostats, out_nodes = None, None, p.new(0, T)
-        if focus == 'g':
+            tp.ohs, tp.ostats, tp.out_nodes = None, None, p.new(0, T)
+        if tp.pooled:
             ng_csr = nodegraph.device_csr(dev)
             if ng_csr['n_src'] != M: raise ValueError('graph focus: every node must pass the mask')
-            y_pred = p.aggregate(ng_csr, out_nodes, T, p.new(ng_csr['n_dst'], T))
+            tp.y_pred = p.aggregate(ng_csr, tp.out_nodes, T, p.new(ng_csr['n_dst'], T))
         else:
-            y_pred = out_nodes
+            tp.y_pred = tp.out_nodes
+        return tp
 
-        # ---- loss and d loss / d y_pred ----
-        res = {'k': k, 'y_pred': y_pred}
+    def loss_and_grad(self, tp, y_pred, y, sample_weight):
+        """(loss scalar tensor, d loss / d y_pred) with Keras semantics (SUM_OVER_BATCH_SIZE, sample weights)."""
+        m, p = self.model, tp.p
+        y = y.to(tp.dev, torch.float32).contiguous()
+        sw = None if sample_weight is None else sample_weight.to(tp.dev, torch.float32).contiguous()
+        R, T = y_pred.shape
+        dpred, loss_rows = p.new(R, T), p.zeros(max(R, 1))
+        kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
+        if kind.lower() not in nat.LOSSES: raise ValueError(f'loss {kind!r} has no device gradient')
+        nat.check(nat.lib().gnn_loss_grad(nat.LOSSES[kind.lower()], nat.ptr(y), nat.ptr(y_pred.contiguous()), nat.ptr(sw), R, T,
+                                          nat.ptr(dpred), nat.ptr(loss_rows), p.stream()))
+        return loss_rows[:R].sum() / max(R, 1), dpred
+
+    def pool_backward(self, tp, dpred):
+        """d loss / d node-level outputs from d loss / d pooled graph outputs: NodeGraph . dpred (GNN.py:345 transposed)."""
+        return tp.p.aggregate(_by_source(tp.nodegraph, tp.dev), dpred, tp.T, tp.p.new(tp.M, tp.T))
+
+    # ---- backward sweep -------------------------------------------------------------------------------------------------
+    def backward(self, tp, G_out_nodes, d_state_extra=None, want_label_grads=False):
+        """Accumulates the parameter gradients into tp.gs / tp.go from `G_out_nodes` = d loss / d tp.out_nodes (M x T)
+        and an optional extra gradient on the final state (N x S; LGNN feeds the next layer's label gradient here).
+        `want_label_grads` (homogeneous models): also returns d loss / d nodes (N x L), the quantity an LGNN layer hands
+        to the layer below through `update_graph` (reference LGNN.py:175-214)."""
+        m, p = self.model, tp.p
+        N, S, L, d, M, k, focus = tp.N, tp.S, tp.L, tp.d, tp.M, tp.k, tp.focus
+        gs, go, rows, rows_long, counts = tp.gs, tp.go, tp.rows, tp.rows_long, tp.counts
+        if want_label_grads and tp.composite: raise NotImplementedError('label gradients of composite models')
+        G_state = p.zeros(N, S)                                     # dL / d states[k]
+        if d_state_extra is not None: G_state.add_(d_state_extra)
+        d_nodes = p.zeros(N, L) if want_label_grads else None
+        if M > 0 and G_out_nodes is not None:
+            lab = want_label_grads and tp.with_labels
+            if focus == 'a':
+                stride = 2 if tp.with_labels else 1
+                dxs, dxd = p.new(M, S), p.new(M, S)
+                req = [(0, dxs), (stride, dxd)]
+                if lab:
+                    dls, dld = p.new(M, L), p.new(M, L)
+                    req += [(1, dls), (3, dld)]
+                self._mlp_backward(go, tp.osegs, tp.ohs, G_out_nodes, M, tp.ostats, req)
+                p.scatter_add_rows(dxs, tp.isrc, G_state); p.scatter_add_rows(dxd, tp.idst, G_state)
+                if lab: p.scatter_add_rows(dls, tp.isrc, d_nodes); p.scatter_add_rows(dld, tp.idst, d_nodes)
+            else:
+                dxo = p.new(M, S)
+                req = [(0, dxo)]
+                if lab:
+                    dlo = p.new(M, L); req.append((1, dlo))
+                self._mlp_backward(go, tp.osegs, tp.ohs, G_out_nodes, M, tp.ostats, req)
+                p.scatter_add_rows(dxo, tp.out_index, G_state)
+                if lab: p.scatter_add_rows(dlo, tp.out_index, d_nodes)
+
+        dx_s, dx_a = p.zeros(N, S), p.zeros(N, S)
+        d_aggn = dl_t = da_t_ = None
+        if want_label_grads and d > 0:
+            d_aggn, dl_t, da_t_ = p.zeros(N, L), p.new(N, L), p.new(N, L)
+        for t in range(k - 1, -1, -1):
+            p.aggregate(tp.adj, tp.states[t], S, tp.agg)
+            for ty in range(tp.T_types):
+                if counts[ty] == 0: continue
+                segs, i_state, i_agg, i_lab, i_alab = tp.state_segs(t, ty)
+                hs, _ = self._mlp_forward(gs[ty], segs, counts[ty], stats=tp.stats_t[t][ty])
+                if rows[ty] is None:
+                    req = [(i_state, dx_s), (i_agg, dx_a)]
+                    if want_label_grads and d > 0: req += [(i_lab, dl_t), (i_alab, da_t_)]
+                    self._mlp_backward(gs[ty], segs, hs, G_state, N, tp.stats_t[t][ty], req)
+                    if want_label_grads and d > 0:
+                        p.axpby(1.0, d_nodes, 1.0, dl_t, d_nodes); p.axpby(1.0, d_aggn, 1.0, da_t_, d_aggn)
+                else:
+                    G_t = G_state.index_select(0, rows_long[ty])
+                    ds_t, da_t = p.new(counts[ty], S), p.new(counts[ty], S)
+                    self._mlp_backward(gs[ty], segs, hs, G_t, counts[ty], tp.stats_t[t][ty], [(i_state, ds_t), (i_agg, da_t)])
+                    dx_s.index_copy_(0, rows_long[ty], ds_t); dx_a.index_copy_(0, rows_long[ty], da_t)
+            p.aggregate(tp.adj_src, dx_a, S, G_state)               # Adj . d agg   (arcs walked by source)
+            p.axpby(1.0, G_state, 1.0, dx_s, G_state)
+        if want_label_grads:
+            if d > 0:
+                tmp = p.aggregate(tp.adj_src, d_aggn, L, p.new(N, L))   # through the label aggregate Adj^T . nodes (GNN.py:258)
+                p.axpby(1.0, d_nodes, 1.0, tmp, d_nodes)
+            else:
+                d_nodes = G_state                                   # state_0 = nodes (GNN.py:259)
+        return d_nodes
+
+    def finish(self, tp, apply=True):
+        """1/k on the state gradients when `average_st_grads` (GNN.py:295), zero gradients of untouched networks,
+        optimizer update."""
+        m = self.model
+        for g_ in tp.gs:
+            if m.average_st_grads and tp.k > 0:
+                for g in g_.gradients(): g.mul_(1.0 / tp.k)
+            if tp.k == 0 or not g_.touched:
+                for g in g_.gradients(): g.zero_()
+        if not tp.go.touched:
+            for g in tp.go.gradients(): g.zero_()
+        if apply:
+            m._optimizer_obj().apply_gradients(self.grads_and_vars(tp))
+
+    @staticmethod
+    def grads_and_vars(tp):
+        grads = [g for g_ in tp.gs for g in g_.gradients()] + tp.go.gradients()
+        variables = [v for g_ in tp.gs for v in g_.variables()] + tp.go.variables()
+        return list(zip(grads, variables))
+
+    # ---- one training step ------------------------------------------------------------------------------------------------
+    def train_step(self, x_list, y, sample_weight, state0=None, seed=None, apply=True):
+        """Returns dict(loss=..., k=..., y_pred=tensor). Gradients stay in self.gs (list for composite models) / self.go;
+        `apply` runs the optimizer. Homogeneous models are the one-type case (reference GNN.py:277-306); composite models
+        (CompositeGNN.py:275-304) run one state network per node type on that type's rows."""
+        m = self.model
+        tp = self.forward(x_list, state0=state0, seed=seed)
+        res = {'k': tp.k, 'y_pred': tp.y_pred, 'state': tp.state}
         if y is None:
             if m.loss: raise TypeError('Target data is missing. Your model was compiled with `loss` '
                                        'argument and so expects targets to be passed in `fit()`.')
             return res
-        y = y.to(dev, torch.float32).contiguous()
-        sw = None if sample_weight is None else sample_weight.to(dev, torch.float32).contiguous()
-        R = y_pred.shape[0]
-        dpred, loss_rows = p.new(R, T), p.zeros(max(R, 1))
-        kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
-        if kind.lower() not in nat.LOSSES: raise ValueError(f'loss {kind!r} has no device gradient')
-        nat.check(lib.gnn_loss_grad(nat.LOSSES[kind.lower()], nat.ptr(y), nat.ptr(y_pred), nat.ptr(sw), R, T, nat.ptr(dpred),
-                                    nat.ptr(loss_rows), p.stream()))
-        res['loss'] = loss_rows[:R].sum() / max(R, 1)
-
-        # ---- backward: output stage ----
-        G_out = p.aggregate(_by_source(nodegraph, dev), dpred, T, p.new(M, T)) if focus == 'g' else dpred   # NodeGraph . dOut
-        G_state = p.zeros(N, S)                                     # dL / d states[k]
-        if M > 0:
-            if focus == 'a':
-                stride = 2 if with_labels else 1
-                dxs, dxd = p.new(M, S), p.new(M, S)
-                self._mlp_backward(go, osegs, ohs, G_out, M, ostats, [(0, dxs), (stride, dxd)])
-                p.scatter_add_rows(dxs, isrc, G_state); p.scatter_add_rows(dxd, idst, G_state)
-            else:
-                dxo = p.new(M, S)
-                self._mlp_backward(go, osegs, ohs, G_out, M, ostats, [(0, dxo)])
-                p.scatter_add_rows(dxo, out_index, G_state)
-
-        # ---- backward through the k executed iterations ----
-        dx_s, dx_a = p.zeros(N, S), p.zeros(N, S)
-        for t in range(k - 1, -1, -1):
-            p.aggregate(adj, states[t], S, agg)
-            for ty in range(T_types):
-                if counts[ty] == 0: continue
-                segs, i_state, i_agg = state_segs(t, ty)
-                hs, _ = self._mlp_forward(gs[ty], segs, counts[ty], stats=stats_t[t][ty])
-                if rows[ty] is None:
-                    self._mlp_backward(gs[ty], segs, hs, G_state, N, stats_t[t][ty], [(i_state, dx_s), (i_agg, dx_a)])
-                else:
-                    G_t = G_state.index_select(0, rows_long[ty])
-                    ds_t, da_t = p.new(counts[ty], S), p.new(counts[ty], S)
-                    self._mlp_backward(gs[ty], segs, hs, G_t, counts[ty], stats_t[t][ty], [(i_state, ds_t), (i_agg, da_t)])
-                    dx_s.index_copy_(0, rows_long[ty], ds_t); dx_a.index_copy_(0, rows_long[ty], da_t)
-            p.aggregate(adj_src, dx_a, S, G_state)                  # Adj . d agg   (arcs walked by source)
-            p.axpby(1.0, G_state, 1.0, dx_s, G_state)
-        for g_ in gs:
-            if m.average_st_grads and k > 0:
-                for g in g_.gradients(): g.mul_(1.0 / k)
-            if k == 0 or not g_.touched:
-                for g in g_.gradients(): g.zero_()
-        if not go.touched:
-            for g in go.gradients(): g.zero_()
-
-        if apply:
-            opt = m._optimizer_obj()
-            grads = [g for g_ in gs for g in g_.gradients()] + go.gradients()
-            variables = [v for g_ in gs for v in g_.variables()] + go.variables()
-            opt.apply_gradients(list(zip(grads, variables)))
+        res['loss'], dpred = self.loss_and_grad(tp, tp.y_pred, y, sample_weight)
+        G_out = self.pool_backward(tp, dpred) if tp.pooled else dpred
+        self.backward(tp, G_out)
+        self.finish(tp, apply)
         return res
 
 

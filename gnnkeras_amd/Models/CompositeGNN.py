@@ -117,10 +117,15 @@ class CompositeGNNnodeBased(GNNnodeBased):
         return hit[0], hit[1]
 
     def Loop(self, nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, composite_adjacencies, adjacency,
-             arcnode, nodegraph, training: bool = False, *, state0=None, seed=None):
+             arcnode, nodegraph, training: bool = False, *, state0=None, seed=None, node_level: bool = False):
         """(k, state, out) for one (merged) heterogeneous graph — reference CompositeGNN.py:242-272.
-        `state0` / `seed` as in `GNNnodeBased.Loop`."""
-        self._check_training(bool(training))
+        `state0` / `seed` / `node_level` as in `GNNnodeBased.Loop`."""
+        focus = 'n' if (node_level and self._focus == 'g') else self._focus
+        if training:
+            from .training import LoopTrainer
+            tp = LoopTrainer(self).forward([nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, composite_adjacencies,
+                                            adjacency, arcnode, nodegraph], state0=state0, seed=seed, node_level=node_level)
+            return torch.tensor(float(tp.k), device=tp.dev), tp.state.clone(), tp.y_pred
         nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs')
         dev = nodes.device
         nodes = nodes.to(torch.float32).contiguous()
@@ -170,12 +175,12 @@ class CompositeGNNnodeBased(GNNnodeBased):
         a.net_output = self.net_output.to(dev).native()
         a.state_dim, a.max_iteration, a.state_threshold = self.state_vect_dim, self.max_iteration, float(self.state_threshold)
         if self.state_vect_dim > 0: a.state0 = nat.ptr(state0)
-        a.focus = nat.FOCUS[self._focus]
+        a.focus = nat.FOCUS[focus]
         a.n_out, a.out_index = len(out_index), nat.ptr(out_index)
-        if self._focus == 'a':
+        if focus == 'a':
             es, ed = _arc_endpoints(adjacency, dev)
             a.arc_src, a.arc_dst = nat.ptr(es), nat.ptr(ed); keep += [es, ed]
-        if self._focus == 'g':
+        if focus == 'g':
             ng = SparseMatrix.from_triple(nodegraph).device_csr(dev)
             a.nodegraph = nat.make_csr(ng); keep.append(ng)
         a.flags = self.native_flags
@@ -189,7 +194,7 @@ class CompositeGNNnodeBased(GNNnodeBased):
         aligned = (base + 255) & ~255
         a.workspace, a.workspace_bytes = C.c_void_p(aligned), ws.numel() - (aligned - base)
 
-        n_rows_out = a.nodegraph.n_dst if self._focus == 'g' else len(out_index)
+        n_rows_out = a.nodegraph.n_dst if focus == 'g' else len(out_index)
         k = torch.empty((), dtype=torch.float32, device=dev)
         state = torch.empty((N, S), dtype=torch.float32, device=dev)
         out = torch.empty((n_rows_out, self.net_output.units[-1]), dtype=torch.float32, device=dev)

@@ -308,7 +308,9 @@ class GNNnodeBased(_LoopModel):
             raise NotImplementedError('training=True forward needs BatchNormalization batch statistics / dropout on '
                                       'device (SURVEY.md §8f, next row); inference forward is the built path')
 
-    def _build_args(self, nodes, arcs, adjacency, arcnode, nodegraph, out_index, state0, training, with_output=True):
+    def _build_args(self, nodes, arcs, adjacency, arcnode, nodegraph, out_index, state0, training, with_output=True,
+                    focus=None):
+        focus = focus or self._focus
         self._check_training(bool(training))
         nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs')
         dev = nodes.device
@@ -335,14 +337,14 @@ class GNNnodeBased(_LoopModel):
             state0 = state0.to(dev, torch.float32).contiguous()
             if tuple(state0.shape) != (N, self.state_vect_dim): raise ValueError('state0 must be (n_nodes, state_vect_dim)')
             a.state0 = nat.ptr(state0); keep.append(state0)
-        a.focus = nat.FOCUS[self._focus]
+        a.focus = nat.FOCUS[focus]
         if with_output:
             a.n_out, a.out_index = len(out_index), nat.ptr(out_index)
             keep.append(out_index)
-            if self._focus == 'a':
+            if focus == 'a':
                 es, ed = _arc_endpoints(adjacency, dev)
                 a.arc_src, a.arc_dst = nat.ptr(es), nat.ptr(ed); keep += [es, ed]
-            if self._focus == 'g':
+            if focus == 'g':
                 ng = SparseMatrix.from_triple(nodegraph).device_csr(dev)
                 a.nodegraph = nat.make_csr(ng); keep.append(ng)
         a.flags = self.native_flags
@@ -358,11 +360,19 @@ class GNNnodeBased(_LoopModel):
         return a, keep
 
     def Loop(self, nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph,
-             training: bool = False, *, state0=None, seed=None):
+             training: bool = False, *, state0=None, seed=None, node_level: bool = False):
         """(k, state, out) for one (merged) graph — reference GNN.py:245-274.
 
         Additive keyword arguments: `state0` replaces the reference's `tf.random.normal(stddev=0.1)`
-        draw when `state_vect_dim > 0`; otherwise it is drawn on the device with `seed`."""
+        draw when `state_vect_dim > 0`; otherwise it is drawn on the device with `seed`. `node_level=True` makes a
+        graph-focused model return its per-node outputs (what the reference obtains by calling the unbound
+        `GNNnodeBased.Loop` on a graph-based model inside LGNN, LGNN.py:225)."""
+        focus = 'n' if (node_level and self._focus == 'g') else self._focus
+        if training:
+            from .training import LoopTrainer
+            tp = LoopTrainer(self).forward([nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph],
+                                           state0=state0, seed=seed, node_level=node_level)
+            return torch.tensor(float(tp.k), device=tp.dev), tp.state.clone(), tp.y_pred
         nat.require_device(nodes, 'nodes')
         dev = nodes.device
         set_mask, output_mask = _squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev)
@@ -373,10 +383,10 @@ class GNNnodeBased(_LoopModel):
             if seed is not None:
                 gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
             state0 = torch.randn((N, self.state_vect_dim), generator=gen, device=dev, dtype=torch.float32) * 0.1
-        a, keep = self._build_args(nodes, arcs, adjacency, arcnode, nodegraph, out_index, state0, training)
+        a, keep = self._build_args(nodes, arcs, adjacency, arcnode, nodegraph, out_index, state0, training, focus=focus)
         S = self.state_vect_dim if self.state_vect_dim > 0 else nodes.shape[1]
         T = self.net_output.units[-1]
-        n_rows_out = a.nodegraph.n_dst if self._focus == 'g' else len(out_index)
+        n_rows_out = a.nodegraph.n_dst if focus == 'g' else len(out_index)
         k = torch.empty((), dtype=torch.float32, device=dev)
         state = torch.empty((N, S), dtype=torch.float32, device=dev)
         out = torch.empty((n_rows_out, T), dtype=torch.float32, device=dev)

@@ -194,3 +194,78 @@ def composite_train_step(nodes, arcs, dim_node_label, type_mask, composite_adjac
                 grads_output=[npy(g) for g in grads[pos:]],
                 moving_state=[(npy(n.moving_mean), npy(n.moving_var)) if n.bn else None for n in nets],
                 moving_output=(npy(no.moving_mean), npy(no.moving_var)) if no.bn else None)
+
+
+def _homogeneous_forward(ns, no, X, lab, At, agg_arcs, d, max_iteration, state_threshold, state0, mask, focus, adjacency, NGt):
+    """One GNN layer with autograd-tracked inputs X (labels) / lab (arc labels): (k, state, node/arc-level out, task out)."""
+    if d > 0:
+        state = state0
+        agg_nodes = torch.sparse.mm(At, X)
+        comps = lambda s: [s, X, torch.sparse.mm(At, s), agg_nodes, agg_arcs]
+    else:
+        state = X
+        comps = lambda s: [s, torch.sparse.mm(At, s), agg_arcs]
+    state_old = torch.ones_like(state)
+    k = 0
+    while True:
+        dist = torch.sqrt(torch.sum(torch.square(state - state_old), dim=1))
+        norm = torch.sqrt(torch.sum(torch.square(state_old), dim=1))
+        if not (bool(torch.any(dist > state_threshold * norm)) and k < max_iteration):
+            break
+        state, state_old, k = ns(torch.cat(comps(state), dim=1)), state, k + 1
+    sc = torch.cat([state, X], dim=1) if d > 0 else state
+    if focus == 'a':
+        idx = torch.from_numpy(np.asarray(adjacency[0]).reshape(-1, 2).astype(np.int64))
+        inp = torch.cat([sc[idx].reshape(lab.shape[0], 2 * sc.shape[1]), lab], dim=1)[mask]
+    else:
+        inp = sc[mask]
+    out = no(inp)
+    task = torch.sparse.mm(NGt, out) if focus == 'g' else out
+    return k, state, out, task
+
+
+def lgnn_train_step(nodes, arcs, adjacency, arcnode, nodegraph, mask, *, layers, get_state, get_output, focus, state0s, y,
+                    sample_weight, loss, training_mode, average_st_grads=False, dtype=torch.float64):
+    """LGNN.train_step (GNN/Models/LGNN.py:252-287) with torch autograd across all layers.
+    layers: list of dict(net_state, net_output, state_vect_dim, max_iteration, state_threshold)."""
+    X0 = torch.tensor(np.asarray(nodes), dtype=dtype)
+    arcs_t = torch.tensor(np.asarray(arcs), dtype=dtype)
+    At, ANt = _sp(adjacency, dtype), _sp(arcnode, dtype)
+    NGt = _sp(nodegraph, dtype) if focus == 'g' else None
+    mask_t = torch.from_numpy(np.asarray(mask, dtype=bool))
+    nets = [(Net(*l['net_state'], dtype=dtype), Net(*l['net_output'], dtype=dtype)) for l in layers]
+    X, A_full = X0, arcs_t
+    ks, outs = [], []
+    for i, (l, (ns, no)) in enumerate(zip(layers, nets)):
+        lab = A_full[:, 2:]
+        agg_arcs = torch.sparse.mm(ANt, lab) if lab.shape[1] else torch.zeros((X.shape[0], 0), dtype=dtype)
+        s0 = None if l['state_vect_dim'] == 0 else torch.tensor(np.asarray(state0s[i]), dtype=dtype)
+        k, state, out, task = _homogeneous_forward(ns, no, X, lab, At, agg_arcs, l['state_vect_dim'], l['max_iteration'],
+                                                   l['state_threshold'], s0, mask_t, focus, adjacency, NGt)
+        ks.append(k); outs.append(task)
+        if i < len(layers) - 1:                                     # update_graph (LGNN.py:175-214)
+            nodeplus, arcplus = [], []
+            if get_state: nodeplus.append(state)
+            if get_output:
+                scat = torch.zeros((len(mask_t), out.shape[1]), dtype=dtype)
+                scat = scat.index_put((torch.nonzero(mask_t).reshape(-1),), out)
+                (arcplus if focus == 'a' else nodeplus).append(scat)
+            X = torch.cat(nodeplus + [X0], dim=1)
+            A_full = torch.cat(arcplus + [arcs_t], dim=1)
+    yt = torch.tensor(np.asarray(y), dtype=dtype)
+    sw = torch.ones(yt.shape[0], dtype=dtype) if sample_weight is None else torch.tensor(np.asarray(sample_weight), dtype=dtype)
+    if training_mode == 'parallel':
+        L = torch.stack([keras_loss(loss, yt, o, sw) for o in outs]).mean()
+    else:
+        L = keras_loss(loss, yt, torch.stack(outs).mean(0), sw)
+    params = [p for ns, no in nets for p in ns.trainable() + no.trainable()]
+    grads = torch.autograd.grad(L, params, allow_unused=True)
+    grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, params)]
+    npy = lambda t: t.detach().numpy()
+    res, pos = [], 0
+    for (ns, no), k in zip(nets, ks):
+        a, b = len(ns.trainable()), len(no.trainable())
+        gs_, go_ = grads[pos:pos + a], grads[pos + a:pos + a + b]; pos += a + b
+        if average_st_grads and k > 0: gs_ = [g / k for g in gs_]
+        res.append(([npy(g) for g in gs_], [npy(g) for g in go_]))
+    return dict(k=ks, loss=float(L.detach()), outs=[npy(o) for o in outs], grads=res)

@@ -254,3 +254,109 @@ def test_composite_fit_runs():
     np.random.seed(1)
     hist = model.fit(seq, epochs=5, verbose=0)
     assert hist['loss'][-1] < hist['loss'][0] and np.isfinite(hist['accuracy']).all()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Layered GNN (reference GNN/Models/LGNN.py): forward, joint training modes with gradients chained through
+# update_graph, serial fit
+# ----------------------------------------------------------------------------------------------------------------------
+def lgnn_stack(focus, d, n_layers, get_state, get_output, bn, max_it=4):
+    from gnnkeras_amd.Models.LGNN import LGNN
+    gnns = []
+    for i in range(n_layers):
+        inp, lay = get_inout_dims('state', 14, 3, 2, focus, d, layer=i, get_state=get_state, get_output=get_output)
+        ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=10 + i, batch_normalization=bn)
+        ns.set_weights([a * 0.5 if a.ndim == 2 else a for a in ns.get_weights()])
+        inp, lay = get_inout_dims('output', 14, 3, 2, focus, d, layer=i, get_state=get_state, get_output=get_output)
+        no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=20 + i, batch_normalization=bn)
+        gnns.append(CLS[focus](ns, no, d, max_it, 0.0))
+    return LGNN(gnns, get_state, get_output)
+
+
+@pytest.mark.parametrize('focus,d,get_state,get_output', [('g', 8, True, True), ('n', 8, True, False), ('n', 0, True, True),
+                                                          ('g', 8, False, True), ('a', 6, True, False)])
+@pytest.mark.parametrize('mode', ['parallel', 'residual'])
+def test_lgnn_joint_training_gradients(mutag_graphs, focus, d, get_state, get_output, mode):
+    rng = np.random.default_rng(12)
+    gl = refocus([g.copy() for g in mutag_graphs[:12]], focus, rng)
+    seq = MultiGraphSequencer(gl, focus, 'average', 12, shuffle=False)
+    x, y, sw = seq[0]
+    bn = d != 0
+    lg = lgnn_stack(focus, d, 3, get_state, get_output, bn)
+    lg.compile(optimizer=SGD(0.0), loss='categorical_crossentropy', training_mode=mode, average_st_grads=True, metrics=['accuracy'])
+    N = x[0].shape[0]
+    s0s = [rng.normal(0, 0.1, (N, d)).astype(np.float32) if d else None for _ in range(3)]
+    nodes, arcs, _, sm, om, adj, an, ng = x
+    mask = np.logical_and(_np(sm).reshape(-1), _np(om).reshape(-1))
+    layers = [dict(net_state=g.net_state.spec(), net_output=g.net_output.spec(), state_vect_dim=d, max_iteration=4,
+                   state_threshold=0.0) for g in lg.gnns]
+    want = torch_train.lgnn_train_step(_np(nodes), _np(arcs), _triple(adj), _triple(an), _triple(ng), mask, layers=layers,
+                                       get_state=get_state, get_output=get_output, focus=focus, state0s=s0s, y=_np(y),
+                                       sample_weight=_np(sw), loss='categorical_crossentropy', training_mode=mode,
+                                       average_st_grads=True)
+    logs = lg.train_step((x, y, sw), state0=[None if s is None else torch.from_numpy(s).cuda() for s in s0s], apply=False)
+    assert logs['k'] == want['k']
+    assert abs(float(logs['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))
+    allref = [r for gs_, go_ in want['grads'] for r in gs_ + go_]
+    scale = max(float(np.max(np.abs(r))) for r in allref)
+    for li, tp in enumerate(lg._last_tapes):
+        got = [g for t in tp.gs for g in t.gradients()] + tp.go.gradients()
+        ref = want['grads'][li][0] + want['grads'][li][1]
+        assert len(got) == len(ref)
+        for i, (g, r) in enumerate(zip(got, ref)):
+            err = float(np.max(np.abs(g.cpu().numpy() - r)))
+            assert err <= GTOL * max(float(np.max(np.abs(r))), 1e-12) or err <= GTOL * scale, (li, i, err)
+    # eval-mode forward of the stack agrees with the layers' own Loop chain and has the reference's list layout
+    K, states, outs = lg.Loop(*lg.process_inputs(x), state0=[None if s is None else torch.from_numpy(s).cuda() for s in s0s])
+    assert len(K) == len(states) == len(outs) == 3 and outs[-1].shape == lg(x).shape
+
+
+def test_lgnn_serial_fit_and_persistence(mutag_graphs, tmp_path):
+    from gnnkeras_amd.Models.LGNN import LGNN
+    gs = [g.copy() for g in mutag_graphs[:96]]
+    for g in gs: g.setAggregation('average')
+    tr = MultiGraphSequencer(gs[:64], 'g', 'average', 16, shuffle=True)
+    va = MultiGraphSequencer(gs[64:], 'g', 'average', 16, shuffle=False)
+    lg = lgnn_stack('g', 0, 3, True, True, bn=False, max_it=3)          # starter.py: 3 layers, get_state, get_output
+    lg.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', training_mode='serial', average_st_grads=True,
+               metrics=['accuracy'])
+    np.random.seed(2)
+    hists = lg.fit(tr, epochs=2, validation_data=va, verbose=0)
+    assert len(hists) == 3 and all(len(h['loss']) == 2 and np.isfinite(h['val_loss']).all() for h in hists)
+    res = lg.evaluate(va, return_dict=True)
+    assert np.isfinite(res['loss']) and 0.0 <= res['accuracy'] <= 1.0
+    lg.save(str(tmp_path / 'lgnn'))
+    back = LGNN.load(str(tmp_path / 'lgnn'))
+    assert back.LAYERS == 3 and back.get_state and back.get_output
+    back.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', training_mode='serial', metrics=['accuracy'])
+    assert np.allclose(back.predict(va), lg.predict(va), atol=1e-6)
+    assert 'layers=3' in repr(lg) and lg.copy().LAYERS == 3
+
+
+def test_composite_lgnn_forward_and_serial_fit():
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased
+    from gnnkeras_amd.Models.CompositeLGNN import CompositeLGNN
+    from gnnkeras_amd.Sequencers.GraphSequencers import CompositeMultiGraphSequencer
+    from gnnkeras_amd.synth import er_composite_graph
+    dims, D = (5, 3, 4), 6
+    gs_ = [er_composite_graph(200 + 10 * i, 1500, dim_node_label=dims, seed=i) for i in range(6)]
+    seq = CompositeMultiGraphSequencer(gs_, 'n', 'average', 2, shuffle=False)
+    gnns = []
+    for layer in range(2):
+        inp, lay = get_inout_dims('state', dims, 3, 2, 'n', D, layer=layer, get_state=True, get_output=True)
+        ns = [MLP(i, lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=30 + t + 10 * layer) for t, i in enumerate(inp)]
+        inp, lay = get_inout_dims('output', dims, 3, 2, 'n', D, layer=layer, get_state=True, get_output=True)
+        no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=50 + layer)
+        gnns.append(CompositeGNNnodeBased(ns, no, D, 3, 0.0))
+    lg = CompositeLGNN(gnns, True, True)
+    lg.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', training_mode='serial', metrics=['accuracy'])
+    x = seq[0][0]
+    K, states, outs = lg.Loop(*lg.process_inputs(x), seed=0)
+    assert len(outs) == 2 and outs[1].shape == outs[0].shape == (x[0].shape[0], 2)
+    # layer 2 really consumes [state | out | labels]: its first-type state net input is d_t + (D + T) wider than layer 1's
+    assert gnns[1].net_state[0].input_dim - gnns[0].net_state[0].input_dim == 4 * (D + 2)
+    hists = lg.fit(seq, epochs=2, verbose=0)
+    assert len(hists) == 2 and all(np.isfinite(h['loss']).all() for h in hists)
+    assert 'CompositeLGNN' in repr(lg)
+    with pytest.raises(NotImplementedError):
+        lg.train_step(seq[0])

@@ -10,7 +10,8 @@ time, but the numpy/scipy part of `GraphObject` / `CompositeGraphObject` (ctor, 
 buildNodeGraph, buildCompositeAdjacency, merge, setAggregation) uses TensorFlow for exactly one thing: the dtype string
 `tf.keras.backend.floatx()`. A throw-away module named `tensorflow` exposing only that (and an empty `Tensor` class for
 one annotation) is created in a temp dir at run time; it never enters this repository. scipy 1.7.1 of the conda
-interpreter is required. Nothing in TensorFlow's arithmetic is exercised or pinned by these fixtures:
+interpreter is required; for the transductive sequencer's static numpy method the stub also carries an
+empty `keras.utils.Sequence` base class. Nothing in TensorFlow's arithmetic is exercised or pinned by these fixtures:
 they pin rows a13-a16 and a18 of SURVEY.md §8 (graph operands), not the Loop.
 
 The reference's `load_MUTAG.py` cannot run at HEAD: its text is read from /root/reference at run time,
@@ -37,8 +38,11 @@ def _install_tf_stub():
                 "class _B:\n"
                 "    @staticmethod\n"
                 "    def floatx(): return 'float32'\n"
+                "class _U:\n"
+                "    class Sequence: pass\n"
                 "class keras:\n"
-                "    backend = _B\n")
+                "    backend = _B\n"
+                "    utils = _U\n")
     sys.path.insert(0, d)
 
 
@@ -152,6 +156,22 @@ def main():
             out[p + 'ArcNode'], out[p + 'Adjacency'] = _coo(cg.ArcNode), _coo(cg.Adjacency)
             for t, ca in enumerate(cg.CompositeAdjacencies):
                 out[p + f'CA{t}'] = _coo(ca)
+
+    # ---- transductive re-typing (TransductiveGraphSequencers.py:62-95), seeded numpy RNG -----------------------------------
+    from GNN.Sequencers.TransductiveGraphSequencers import TransductiveMultiGraphSequencer
+    tn = rng.normal(size=(12, 3))
+    ta = np.array([[i, (i + 1) % 12, 1.0] for i in range(12)] + [[i, (i + 5) % 12, 0.5] for i in range(12)])
+    tom = np.array([1, 1, 0, 1, 1, 1, 0, 1, 1, 1, 1, 0], dtype=bool)
+    tsm = np.array([1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 1, 1], dtype=bool)
+    tt = np.eye(2)[rng.integers(0, 2, int(tom.sum()))]
+    tg = GraphObject(nodes=tn, arcs=ta, targets=tt, focus='n', set_mask=tsm, output_mask=tom, aggregation_mode='sum')
+    out['trans_nodes'], out['trans_arcs'], out['trans_targets'], out['trans_set_mask'], out['trans_output_mask'] = tn, ta, tt, tsm, tom
+    for rate in (0.5, 0.3):
+        np.random.seed(123)
+        cg = TransductiveMultiGraphSequencer.get_transduction(tg, rate, 'n', 'float32')
+        p = f'trans_{int(rate * 10)}_'
+        out[p + 'nodes'], out[p + 'targets'], out[p + 'type_mask'] = cg.nodes, cg.targets, cg.type_mask
+        out[p + 'output_mask'], out[p + 'set_mask'] = cg.output_mask, cg.set_mask
 
     path = os.path.join(HERE, 'graph_fixtures.npz')
     np.savez_compressed(path, **out)

@@ -2,6 +2,7 @@
 (tests/golden/make_golden.py): rows a13-a16, a18 of SURVEY.md §8. Bit-exact (same float32 values, same entry order)."""
 import numpy as np
 import pytest
+import torch
 
 from gnnkeras_amd import GraphObject, GraphTensor, CompositeGraphObject, CompositeGraphTensor
 
@@ -140,3 +141,43 @@ def test_composite_tensor_layout():
     vals = cg.ArcNode.data
     mixed = any(len(set(vals[cg.arc_ids[:, 1] == j])) > 1 for j in range(n))
     assert mixed and ct.Adjacency.csr().w is not None                   # composite_average needs per-arc weights
+
+
+@pytest.mark.parametrize('rate', [0.5, 0.3])
+def test_transductive_retyping_matches_reference(golden, rate):
+    """`get_transduction` (reference TransductiveGraphSequencers.py:62-95) draws the same split from a seeded numpy RNG."""
+    from gnnkeras_amd.Sequencers.TransductiveGraphSequencers import TransductiveMultiGraphSequencer
+    g = GraphObject(nodes=golden['trans_nodes'], arcs=golden['trans_arcs'], targets=golden['trans_targets'], focus='n',
+                    set_mask=golden['trans_set_mask'], output_mask=golden['trans_output_mask'], aggregation_mode='sum')
+    np.random.seed(123)
+    cg = TransductiveMultiGraphSequencer.get_transduction(g, rate, 'n', 'float32')
+    p = f'trans_{int(rate * 10)}_'
+    assert np.array_equal(cg.nodes, golden[p + 'nodes']) and np.array_equal(cg.targets, golden[p + 'targets'])
+    assert np.array_equal(cg.type_mask, golden[p + 'type_mask'])
+    assert np.array_equal(cg.output_mask, golden[p + 'output_mask']) and np.array_equal(cg.set_mask, golden[p + 'set_mask'])
+    assert list(cg.DIM_NODE_LABEL) == [3, 5] and cg.targets.shape[0] == int(cg.output_mask.sum())
+
+
+def test_transductive_sequencers_layout_and_epoch_resampling():
+    from gnnkeras_amd.Sequencers.TransductiveGraphSequencers import (TransductiveMultiGraphSequencer,
+                                                                      TransductiveSingleGraphSequencer)
+    rng = np.random.default_rng(0)
+    def hg(n):
+        om = rng.random(n) < 0.8
+        return GraphObject(rng.normal(size=(n, 3)), np.array([[i, (i + 1) % n, 1.] for i in range(n)]),
+                           np.eye(2)[rng.integers(0, 2, int(om.sum()))], focus='n', output_mask=om)
+    gs = [hg(10), hg(14), hg(9)]
+    np.random.seed(0)
+    seq = TransductiveMultiGraphSequencer(gs, 'n', 'average', 0.5, batch_size=2, shuffle=False, device='cpu')
+    x, y, sw = seq[0]
+    assert len(x) == 10 and tuple(x[2].reshape(-1).tolist()) == (3, 5) and x[0].shape[1] == 5
+    assert tuple(x[3].shape) == (2, 24, 1) and y.shape[0] == int((x[4].reshape(-1) & x[5].reshape(-1)).sum())
+    first = x[3].clone()
+    seq.on_epoch_end()
+    assert not torch.equal(seq[0][0][3], first)                       # a new transductive split every epoch
+    c = seq.copy()
+    assert len(c) == len(seq) and 'transductive' in repr(c) and c.get_config()['transductive_rate'] == 0.5
+    single = TransductiveSingleGraphSequencer(hg(30), 'n', 0.4, batch_size=5, shuffle=True, device='cpu')
+    assert len(single) >= 1 and len(single[0][0]) == 10
+    single.on_epoch_end()
+    assert single.copy().transductive_rate == 0.4

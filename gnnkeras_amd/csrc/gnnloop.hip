@@ -19,7 +19,6 @@
 
 #include "../../include/gnnloop.h"
 #include "kernels_general.hpp"
-#include "kernel_state_fused.hpp"
 #include "kernel_state_fused2.hpp"
 
 namespace {
@@ -463,15 +462,13 @@ int output_stage(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     return 0;
 }
 
-// which fused kernel: GNN_FUSED_VARIANT = 1 (first generation), 2 (pipelined, 64-node tiles, 4 waves), 3 (pipelined,
-// 32-node tiles, 3 workgroups per CU), 4 (pipelined, 64-node tiles, 8 waves, 16 waves per CU; default).
+// workgroup shape of the fused kernel: GNN_FUSED_WAVES = 8 (default: 512 threads, 16 waves per CU) or 4 (256 threads).
 // Read once; a tuning knob, never a correctness switch.
-int fused_variant() {
+int fused_waves() {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("GNN_FUSED_VARIANT");
-        v = e ? atoi(e) : 4;
-        if (v < 1 || v > 5) v = 4;
+        const char *e = getenv("GNN_FUSED_WAVES");
+        v = (e && atoi(e) == 4) ? 4 : 8;
     }
     return v;
 }
@@ -495,12 +492,6 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
         return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg,
                               (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0]};
     };
-    const int variant = fused_variant();
-    if (variant == 1 && row_base == 0 && n_gate <= 1) {
-        FUSED_OK(gnn::launch_state_fused(a, p.T, p.N, p.S, p.SP, n_gate ? gate : nullptr, src, dst, p.C, p.ldC, type_of,
-                                         flag_next, k_out, k_val, st));
-        return 0;
-    }
     gnn::Fused2Args fa;
     memset(&fa, 0, sizeof(fa));
     fa.gate = n_gate ? gate : nullptr; fa.n_gate = n_gate; fa.gate_stride = gate_stride;
@@ -517,7 +508,7 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;
     }
-    FUSED_OK(gnn::launch_fused2(fa, p.SP, variant, device_cus(), st));
+    FUSED_OK(gnn::launch_fused2(fa, p.SP, fused_waves(), device_cus(), st));
     return 0;
 }
 

@@ -1,8 +1,14 @@
-// Fused state-transition iteration, second generation (the hot kernel of the loop on gfx950).
-//
-// Same contract as kernel_state_fused.hpp (one launch = `convergence` + next `condition`, reference
-// GNN/Models/GNN.py:217-236, :196-214) with the memory pipeline rebuilt around what the first profile showed — the
-// kernel was latency-bound on the dependent chain  node id -> rowptr -> source ids -> state rows  (rocprof r01_v1):
+// Fused state-transition iteration: the hot kernel of the loop on gfx950.  One launch = one iteration of the
+// reference's `convergence` + the `condition` of the next iteration (GNN/Models/GNN.py:217-236, :196-214) for every
+// node type of the graph:
+//   A. coalesced CSR walk: SP/4 lanes own a destination node and sum its neighbour state rows (16 B per lane);
+//   B. [state | agg] (64 x 2SP tile in LDS) x W1[state rows ; agg rows] (LDS, loaded once per workgroup) on the f32
+//      matrix cores (v_mfma_f32_16x16x4_f32: exact f32 fma chain) + per-node constant C, activation;
+//   C. per-node predicate ||new - old||_2 > thr ||old||_2 from the accumulators, OR-reduced to one flag word per
+//      launch; new state rows staged through LDS and written as whole rows.
+// HBM traffic per iteration = the algorithmic bytes of SURVEY §8d: E(4 + 4S [+4]) + N(4 + 4S + 4S + 4S).
+// The memory pipeline is built around what the first profile showed (profiles/r01_v1: the first-generation kernel was
+// latency-bound on the dependent chain  node id -> rowptr -> source ids -> state rows):
 //   * node slots are software-pipelined: while the state rows of slot s are in flight, the source ids of slot s+1,
 //     the row pointers of slot s+2 and the node id of slot s+3 are already being fetched, across tile boundaries;
 //   * the <=16 source ids of a node arrive with ONE coalesced load per lane group and are broadcast with
@@ -13,9 +19,17 @@
 //   * W1 sits un-padded in LDS behind an XOR swizzle (conflict-free B fragments), A rows use an odd-pair stride.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "kernel_state_fused.hpp"
+#include "kernels_general.hpp"
 
 namespace gnn {
+
+struct FusedType {
+    const int *rows;   // node ids of this type (nullptr = identity)
+    int count;
+    const float *Wf;   // folded first layer [in_dim x H] row-major, H == S
+    int wrow_state, wrow_agg;
+    int H, act;
+};
 
 struct Fused2Args {
     const int *gate; int n_gate, gate_stride;      // run iff OR of gate[i * gate_stride], i < n_gate, is non-zero
@@ -54,7 +68,7 @@ struct Fused2Cfg {
 };
 
 template <int SP, bool HAS_W, int TM, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) k_state_fused2(Fused2Args a) {
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) k_state_fused2(Fused2Args a) {
     {
         int open = a.gate == nullptr;
         for (int i = 0; i < a.n_gate && !open; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
@@ -323,7 +337,7 @@ int launch_fused2_one(Fused2Args &fa, int n_cu, hipStream_t st) {
         attr = true;
     }
     // workgroups per type: proportional to its tiles, whole multiples of 8 (one per XCD), never more than its tiles need
-    const int blocks_per_cu = std::max(1, std::min(NW == 8 ? 2 : 4, (int)(160 * 1024 / Cfg::LDS_BYTES)));
+    const int blocks_per_cu = std::max(1, std::min(NW == 8 ? 2 : (NW == 4 ? 4 : 8), (int)(160 * 1024 / Cfg::LDS_BYTES)));
     const int budget = blocks_per_cu * n_cu;
     long total_tiles = 0;
     for (int t = 0; t < fa.n_types; ++t) total_tiles += (fa.tp[t].count + TM - 1) / TM;
@@ -347,20 +361,16 @@ int launch_fused2_one(Fused2Args &fa, int n_cu, hipStream_t st) {
 // workgroup that spills into the gather loop, so weighted graphs run the 4-wave shape (256-VGPR budget) instead.
 template <int SP, int TM, int NW>
 int launch_fused2_w(Fused2Args &fa, int n_cu, hipStream_t st) {
-    if (fa.w) return launch_fused2_one<SP, true, TM, 4>(fa, n_cu, st);
+    if (fa.w) return launch_fused2_one<SP, true, TM, (NW == 8 ? 4 : NW)>(fa, n_cu, st);
     return launch_fused2_one<SP, false, TM, NW>(fa, n_cu, st);
 }
 
-// variant 2: 64-node tiles, 4 waves; 3: 32-node tiles, 4 waves; 4: 64-node tiles, 8 waves (twice the rows in flight);
-// 5: 32-node tiles, 8 waves (finer granularity for mid-size graphs)
-inline int launch_fused2(Fused2Args &fa, int SP, int variant, int n_cu, hipStream_t st) {
+// `waves` = 8 (default: 512-thread workgroups, 16 waves per CU) or 4 (256-thread workgroups, 256-VGPR budget)
+inline int launch_fused2(Fused2Args &fa, int SP, int waves, int n_cu, hipStream_t st) {
     switch (SP) {
         case 16: return launch_fused2_w<16, 64, 4>(fa, n_cu, st);
-        case 32: return variant == 3 ? launch_fused2_w<32, 32, 4>(fa, n_cu, st)
-                      : variant >= 4 ? launch_fused2_w<32, 64, 8>(fa, n_cu, st) : launch_fused2_w<32, 64, 4>(fa, n_cu, st);
-        case 64: return variant == 3 ? launch_fused2_w<64, 32, 4>(fa, n_cu, st)
-                      : variant == 4 ? launch_fused2_w<64, 64, 8>(fa, n_cu, st)
-                      : variant == 5 ? launch_fused2_w<64, 32, 8>(fa, n_cu, st) : launch_fused2_w<64, 64, 4>(fa, n_cu, st);
+        case 32: return waves == 8 ? launch_fused2_w<32, 64, 8>(fa, n_cu, st) : launch_fused2_w<32, 64, 4>(fa, n_cu, st);
+        case 64: return waves == 8 ? launch_fused2_w<64, 64, 8>(fa, n_cu, st) : launch_fused2_w<64, 64, 4>(fa, n_cu, st);
         default: return 1;
     }
 }

@@ -29,7 +29,7 @@ def run(iters, flags=0, reps=3):
         ts.append(e0.elapsed_time(e1))
     return min(ts[1:]), float(k), st
 B_iter = E * (4 + 4 * d) + N * (4 + 12 * d)
-for flags, nm in [(0, 'fused v' + os.environ.get('GNN_FUSED_VARIANT', '2'))]:
+for flags, nm in [(0, 'fused ' + os.environ.get('GNN_FUSED_WAVES', '8') + ' waves')]:
     t10, k10, _ = run(10, flags); t50, k50, st = run(50, flags)
     it = (t50 - t10) / 40
     print(f'{nm}: fwd(10)={t10:.2f} ms fwd(50)={t50:.2f} ms k={k50} -> {it*1e3:.1f} us/iter, {E/it/1e6:.2f} G edge-updates/s, '

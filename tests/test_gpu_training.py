@@ -360,3 +360,26 @@ def test_composite_lgnn_forward_and_serial_fit():
     assert 'CompositeLGNN' in repr(lg)
     with pytest.raises(NotImplementedError):
         lg.train_step(seq[0])
+
+
+def test_inference_after_training_matches_oracle(mutag_graphs):
+    """After a few optimisation steps every weight and BatchNormalization moving statistic is non-trivial: the
+    inference-mode device loop (moving statistics folded into the fused kernel) must still equal the oracle."""
+    from oracle.harness import oracle_loop
+    gs = [g.copy() for g in mutag_graphs[:64]]
+    for g in gs: g.setAggregation('average')
+    seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False)
+    for d, it in [(0, 5), (16, 8)]:
+        ns, no = nets('g', d, True, scale=1.0)
+        model = GNNgraphBased(ns, no, d, it, 0.01)
+        model.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['accuracy'])
+        for _ in range(3):
+            for i in range(len(seq)): model.train_step(seq[i], seed=1)
+        w = model.net_state.get_weights()
+        assert np.abs(w[2]).max() > 1e-3 and np.abs(w[3] - 1).max() > 1e-3       # moving stats really moved
+        x = seq[1][0]
+        s0 = np.random.default_rng(0).normal(0, .1, (x[0].shape[0], d)).astype(np.float32) if d else None
+        k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+        k, st, o = model.Loop(*model.process_inputs(x), state0=None if s0 is None else torch.from_numpy(s0).cuda())
+        assert float(k) == float(k64)
+        assert rel_err(st.cpu().numpy(), st64) <= 1e-5 and rel_err(o.cpu().numpy(), o64) <= 1e-5

@@ -34,7 +34,3 @@ class CompositeLGNN(LGNN):
         k, state, out = self.gnns[-1].Loop(nodes, arcs, dim_node_label, *constant_inputs, training=training,
                                            state0=s0[-1], seed=seed)
         return K + [k], states + [state], outs + [out]
-
-    def train_step(self, data, **kwargs):
-        raise NotImplementedError("joint ('parallel' / 'residual') training of composite stacks needs label gradients of the "
-                                  "composite loop, which are not built; training_mode='serial' trains on the device")

@@ -178,7 +178,8 @@ class LGNN(_LoopModel):
         if y is None: raise TypeError('Target data is missing. Your model was compiled with `loss` '
                                       'argument and so expects targets to be passed in `fit()`.')
         x = list(x)
-        nodes_0, arcs_0, dim0, set_mask, output_mask = x[0], x[1], x[2], x[3], x[4]
+        i_set = 4 if len(x) == 10 else 3                           # composite lists carry type_mask at [3]
+        nodes_0, arcs_0, dim0, set_mask, output_mask = x[0], x[1], x[2], x[i_set], x[i_set + 1]
         s0 = state0 if state0 is not None else [None] * self.LAYERS
         trainers = [LoopTrainer(g) for g in self.gnns]
         for g in self.gnns: g.loss = self.loss
@@ -191,7 +192,7 @@ class LGNN(_LoopModel):
             tapes.append(tp)
             if last: outs.append(tp.y_pred)
             else:
-                outs.append(self._pool(x[7], tp.out_nodes) if graph_based else tp.out_nodes)
+                outs.append(self._pool(x[-1], tp.out_nodes) if graph_based else tp.out_nodes)
                 nodes, arcs, dnl = self.update_graph(nodes_0, arcs_0, dnl, set_mask, output_mask, tp.state, tp.out_nodes)
         # loss and its gradient w.r.t. every layer's task-level output
         Lyr = self.LAYERS

@@ -308,6 +308,7 @@ class LoopTrainer:
         tp.adj_src = _by_source(adjacency, dev)
         an = arcnode.device_csr(dev)
         tp.nodegraph = nodegraph
+        tp.cas = _cas if composite else None
         from .GNN import _squeeze_last, _arc_endpoints
         out_index = tp.out_index = m._out_index(_squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev))
         M = tp.M = len(out_index)
@@ -362,7 +363,7 @@ class LoopTrainer:
                 i_state = len(segs)
                 segs += [(states[t], r), (agg, r)]
                 if agg_comp.shape[1] > 0: segs.append((agg_comp, r))
-                return segs, i_state, i_state + 1, None, None
+                return segs, i_state, i_state + 1, (0 if dims[ty] > 0 else None), (i_state + 2 if agg_comp.shape[1] > 0 else None)
             segs = [(states[t], None)]                              # [state | labels | agg_state | agg_labels | agg_arcs]
             if d > 0: segs.append((nodes, None))
             segs.append((agg, None))
@@ -472,7 +473,6 @@ class LoopTrainer:
         m, p = self.model, tp.p
         N, S, L, d, M, k, focus = tp.N, tp.S, tp.L, tp.d, tp.M, tp.k, tp.focus
         gs, go, rows, rows_long, counts = tp.gs, tp.go, tp.rows, tp.rows_long, tp.counts
-        if want_label_grads and tp.composite: raise NotImplementedError('label gradients of composite models')
         G_state = p.zeros(N, S)                                     # dL / d states[k]
         if d_state_extra is not None: G_state.add_(d_state_extra)
         d_nodes = p.zeros(N, L) if want_label_grads else None
@@ -498,9 +498,11 @@ class LoopTrainer:
                 if lab: p.scatter_add_rows(dlo, tp.out_index, d_nodes)
 
         dx_s, dx_a = p.zeros(N, S), p.zeros(N, S)
-        d_aggn = dl_t = da_t_ = None
-        if want_label_grads and d > 0:
+        d_aggn = dl_t = da_t_ = d_acomp = None
+        if want_label_grads and d > 0 and not tp.composite:
             d_aggn, dl_t, da_t_ = p.zeros(N, L), p.new(N, L), p.new(N, L)
+        if want_label_grads and tp.composite:
+            d_acomp = p.zeros(N, max(sum(tp.dims) + tp.A, 1))
         for t in range(k - 1, -1, -1):
             p.aggregate(tp.adj, tp.states[t], S, tp.agg)
             for ty in range(tp.T_types):
@@ -516,11 +518,29 @@ class LoopTrainer:
                 else:
                     G_t = G_state.index_select(0, rows_long[ty])
                     ds_t, da_t = p.new(counts[ty], S), p.new(counts[ty], S)
-                    self._mlp_backward(gs[ty], segs, hs, G_t, counts[ty], tp.stats_t[t][ty], [(i_state, ds_t), (i_agg, da_t)])
+                    req = [(i_state, ds_t), (i_agg, da_t)]
+                    if want_label_grads:                             # composite: own labels + aggregated component
+                        if i_lab is not None:
+                            dlab = p.new(counts[ty], tp.dims[ty]); req.append((i_lab, dlab))
+                        if i_alab is not None:
+                            dac = p.new(counts[ty], segs[i_alab][0].shape[1]); req.append((i_alab, dac))
+                    self._mlp_backward(gs[ty], segs, hs, G_t, counts[ty], tp.stats_t[t][ty], req)
                     dx_s.index_copy_(0, rows_long[ty], ds_t); dx_a.index_copy_(0, rows_long[ty], da_t)
+                    if want_label_grads:
+                        if i_lab is not None: d_nodes[:, :tp.dims[ty]].index_add_(0, rows_long[ty], dlab)
+                        if i_alab is not None: d_acomp.index_add_(0, rows_long[ty], dac)
             p.aggregate(tp.adj_src, dx_a, S, G_state)               # Adj . d agg   (arcs walked by source)
             p.axpby(1.0, G_state, 1.0, dx_s, G_state)
-        if want_label_grads:
+        if want_label_grads and tp.composite:
+            col = 0
+            for t_src, ca in enumerate(tp.cas):                     # through CA_t^T . nodes[:, :d_t] (CompositeGNN.py:251)
+                dt = tp.dims[t_src]
+                if dt > 0:
+                    tmp = p.aggregate(_by_source(ca, tp.dev), d_acomp[:, col:col + dt], dt, p.new(N, dt))
+                    d_nodes[:, :dt].add_(tmp)
+                col += dt
+            if d == 0: d_nodes.add_(G_state)                        # state_0 = nodes (CompositeGNN.py:258)
+        elif want_label_grads:
             if d > 0:
                 tmp = p.aggregate(tp.adj_src, d_aggn, L, p.new(N, L))   # through the label aggregate Adj^T . nodes (GNN.py:258)
                 p.axpby(1.0, d_nodes, 1.0, tmp, d_nodes)

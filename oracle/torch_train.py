@@ -269,3 +269,82 @@ def lgnn_train_step(nodes, arcs, adjacency, arcnode, nodegraph, mask, *, layers,
         if average_st_grads and k > 0: gs_ = [g / k for g in gs_]
         res.append(([npy(g) for g in gs_], [npy(g) for g in go_]))
     return dict(k=ks, loss=float(L.detach()), outs=[npy(o) for o in outs], grads=res)
+
+
+def _composite_forward(nets, no, X, lab, dims, tm, At, ANt, CAts, d, max_iteration, state_threshold, state0, mask, focus,
+                       adjacency, NGt):
+    """One composite GNN layer with autograd-tracked labels X: (k, state, node/arc-level out, task out)."""
+    agg_nodes = [torch.sparse.mm(ca, X[:, :dt]) for ca, dt in zip(CAts, dims)]
+    agg_arcs = torch.sparse.mm(ANt, lab) if lab.shape[1] else torch.zeros((X.shape[0], 0), dtype=X.dtype)
+    agg_comp = torch.cat(agg_nodes + [agg_arcs], dim=1)
+    state = state0 if d > 0 else X
+    state_old = torch.ones_like(state)
+    k = 0
+    while True:
+        dist = torch.sqrt(torch.sum(torch.square(state - state_old), dim=1))
+        norm = torch.sqrt(torch.sum(torch.square(state_old), dim=1))
+        if not (bool(torch.any(dist > state_threshold * norm)) and k < max_iteration):
+            break
+        agg = torch.sparse.mm(At, state)
+        new = torch.zeros((X.shape[0], nets[0].W[-1].shape[1]), dtype=X.dtype)
+        for dt, m_, net in zip(dims, tm, nets):
+            if not bool(m_.any()): continue
+            inp = torch.cat([X[:, :dt], state, agg, agg_comp], dim=1)[m_]
+            new = new.index_put((torch.nonzero(m_).reshape(-1),), net(inp))
+        state, state_old, k = new, state, k + 1
+    if focus == 'a':
+        idx = torch.from_numpy(np.asarray(adjacency[0]).reshape(-1, 2).astype(np.int64))
+        inp = torch.cat([state[idx].reshape(lab.shape[0], 2 * state.shape[1]), lab], dim=1)[mask]
+    else:
+        inp = state[mask]
+    out = no(inp)
+    task = torch.sparse.mm(NGt, out) if focus == 'g' else out
+    return k, state, out, task
+
+
+def composite_lgnn_train_step(nodes, arcs, dim_node_label, type_mask, composite_adjacencies, adjacency, arcnode, nodegraph,
+                              mask, *, layers, get_state, get_output, focus, state0s, y, sample_weight, loss,
+                              training_mode, average_st_grads=False, dtype=torch.float64):
+    """CompositeLGNN (GNN/Models/CompositeLGNN.py) joint train_step with torch autograd.
+    layers: list of dict(net_state=[...per type], net_output, state_vect_dim, max_iteration, state_threshold)."""
+    X0 = torch.tensor(np.asarray(nodes), dtype=dtype)
+    arcs_t = torch.tensor(np.asarray(arcs), dtype=dtype)
+    At, ANt = _sp(adjacency, dtype), _sp(arcnode, dtype)
+    CAts = [_sp(ca, dtype) for ca in composite_adjacencies]
+    NGt = _sp(nodegraph, dtype) if focus == 'g' else None
+    tm = torch.from_numpy(np.asarray(type_mask, dtype=bool))
+    mask_t = torch.from_numpy(np.asarray(mask, dtype=bool))
+    dims = [int(v) for v in np.asarray(dim_node_label).reshape(-1)]
+    nets = [([Net(*n, dtype=dtype) for n in l['net_state']], Net(*l['net_output'], dtype=dtype)) for l in layers]
+    X, ks, outs = X0, [], []
+    for i, (l, (nss, no)) in enumerate(zip(layers, nets)):
+        s0 = None if l['state_vect_dim'] == 0 else torch.tensor(np.asarray(state0s[i]), dtype=dtype)
+        k, state, out, task = _composite_forward(nss, no, X, arcs_t[:, 2:], dims, tm, At, ANt, CAts, l['state_vect_dim'],
+                                                 l['max_iteration'], l['state_threshold'], s0, mask_t, focus, adjacency, NGt)
+        ks.append(k); outs.append(task)
+        if i < len(layers) - 1:
+            nodeplus = []
+            if get_state: nodeplus.append(state)
+            if get_output:
+                scat = torch.zeros((len(mask_t), out.shape[1]), dtype=dtype)
+                nodeplus.append(scat.index_put((torch.nonzero(mask_t).reshape(-1),), out))
+            plus = sum(t.shape[1] for t in nodeplus)
+            X = torch.cat(nodeplus + [X0], dim=1)
+            dims = [dt + plus for dt in dims]
+    yt = torch.tensor(np.asarray(y), dtype=dtype)
+    sw = torch.ones(yt.shape[0], dtype=dtype) if sample_weight is None else torch.tensor(np.asarray(sample_weight), dtype=dtype)
+    if training_mode == 'parallel':
+        L = torch.stack([keras_loss(loss, yt, o, sw) for o in outs]).mean()
+    else:
+        L = keras_loss(loss, yt, torch.stack(outs).mean(0), sw)
+    params = [p for nss, no in nets for p in [q for n in nss for q in n.trainable()] + no.trainable()]
+    grads = torch.autograd.grad(L, params, allow_unused=True)
+    grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, params)]
+    npy = lambda t: t.detach().numpy()
+    res, pos = [], 0
+    for (nss, no), k in zip(nets, ks):
+        a = sum(len(n.trainable()) for n in nss); b = len(no.trainable())
+        gs_, go_ = grads[pos:pos + a], grads[pos + a:pos + a + b]; pos += a + b
+        if average_st_grads and k > 0: gs_ = [g / k for g in gs_]
+        res.append(([npy(g) for g in gs_], [npy(g) for g in go_]))
+    return dict(k=ks, loss=float(L.detach()), outs=[npy(o) for o in outs], grads=res)

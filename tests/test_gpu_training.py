@@ -358,8 +358,67 @@ def test_composite_lgnn_forward_and_serial_fit():
     hists = lg.fit(seq, epochs=2, verbose=0)
     assert len(hists) == 2 and all(np.isfinite(h['loss']).all() for h in hists)
     assert 'CompositeLGNN' in repr(lg)
-    with pytest.raises(NotImplementedError):
-        lg.train_step(seq[0])
+
+
+@pytest.mark.parametrize('mode', ['parallel', 'residual'])
+@pytest.mark.parametrize('focus,D', [('n', 6), ('g', 5)])
+def test_composite_lgnn_joint_training_gradients(mode, focus, D):
+    from gnnkeras_amd import CompositeGraphObject
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased, CompositeGNNgraphBased
+    from gnnkeras_amd.Models.CompositeLGNN import CompositeLGNN
+    from gnnkeras_amd.Sequencers.GraphSequencers import CompositeMultiGraphSequencer
+    CC = {'n': CompositeGNNnodeBased, 'g': CompositeGNNgraphBased}[focus]
+    rng = np.random.default_rng(41)
+    dims, A, T = (4, 2, 3), 2, 2
+
+    def cg(n, e):
+        pairs = set()
+        while len(pairs) < e:
+            a, b = rng.integers(0, n, 2)
+            if a != b: pairs.add((int(a), int(b)))
+        ids = np.array(sorted(pairs), dtype=float)
+        types = rng.integers(0, 3, n); types[:3] = [0, 1, 2]
+        tm = np.zeros((n, 3), bool); tm[np.arange(n), types] = True
+        om = rng.random(n) < 0.8 if focus == 'n' else np.ones(n, bool)
+        tg = np.zeros((int(om.sum()) if focus == 'n' else 1, T)); tg[np.arange(len(tg)), rng.integers(0, T, len(tg))] = 1
+        return CompositeGraphObject(nodes=rng.normal(size=(n, 4)), arcs=np.concatenate([ids, rng.normal(size=(e, A))], 1),
+                                    targets=tg, type_mask=tm, dim_node_label=dims, focus=focus,
+                                    aggregation_mode='composite_average', **(dict(output_mask=om) if focus == 'n' else {}))
+    seq = CompositeMultiGraphSequencer([cg(50, 160), cg(40, 120)], focus, 'composite_average', 2, shuffle=False)
+    x, y, sw = seq[0]
+    gnns, layers = [], []
+    for layer in range(2):
+        inp, lay = get_inout_dims('state', dims, A, T, focus, D, layer=layer, get_state=True, get_output=True)
+        ns = [MLP(i, lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=60 + t + 10 * layer, batch_normalization=True)
+              for t, i in enumerate(inp)]
+        for n in ns: n.set_weights([a * 0.5 if a.ndim == 2 else a for a in n.get_weights()])
+        inp, lay = get_inout_dims('output', dims, A, T, focus, D, layer=layer, get_state=True, get_output=True)
+        no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=80 + layer)
+        gnns.append(CC(ns, no, D, 3, 0.0))
+        layers.append(dict(net_state=[n.spec() for n in ns], net_output=no.spec(), state_vect_dim=D, max_iteration=3,
+                           state_threshold=0.0))
+    lg = CompositeLGNN(gnns, True, True)
+    lg.compile(optimizer=SGD(0.0), loss='categorical_crossentropy', training_mode=mode, average_st_grads=False)
+    N = x[0].shape[0]
+    s0s = [rng.normal(0, 0.1, (N, D)).astype(np.float32) if D else None for _ in range(2)]
+    nodes, arcs, dnl, tmask, sm, om_, cas, adj, an, ng = x
+    mask = np.logical_and(_np(sm).reshape(-1), _np(om_).reshape(-1))
+    want = torch_train.composite_lgnn_train_step(
+        _np(nodes), _np(arcs), _np(dnl).reshape(-1), _np(tmask).reshape(3, -1), [_triple(c) for c in cas], _triple(adj),
+        _triple(an), _triple(ng), mask, layers=layers, get_state=True, get_output=True, focus=focus, state0s=s0s, y=_np(y),
+        sample_weight=_np(sw), loss='categorical_crossentropy', training_mode=mode)
+    logs = lg.train_step((x, y, sw), state0=[None if s is None else torch.from_numpy(s).cuda() for s in s0s], apply=False)
+    assert logs['k'] == want['k']
+    assert abs(float(logs['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))
+    allref = [r for gs_, go_ in want['grads'] for r in gs_ + go_]
+    scale = max(float(np.max(np.abs(r))) for r in allref)
+    for li, tp in enumerate(lg._last_tapes):
+        got = [g for t in tp.gs for g in t.gradients()] + tp.go.gradients()
+        ref = want['grads'][li][0] + want['grads'][li][1]
+        assert len(got) == len(ref)
+        for i, (g, r) in enumerate(zip(got, ref)):
+            err = float(np.max(np.abs(g.cpu().numpy() - r)))
+            assert err <= GTOL * max(float(np.max(np.abs(r))), 1e-12) or err <= GTOL * scale, (li, i, err)
 
 
 def test_inference_after_training_matches_oracle(mutag_graphs):

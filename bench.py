@@ -111,6 +111,8 @@ def main():
     ap.add_argument('--no-mutag', action='store_true')
     ap.add_argument('--unfused', action='store_true')
     ap.add_argument('--force-sharded', action='store_true', help='run the N>1 code path even with one rank (smoke test)')
+    ap.add_argument('--exchange', choices=['auto', 'allgather', 'halo'], default='auto',
+                    help='N>1 state exchange: whole slices (all-gather) or compacted halos (all-to-all)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -171,8 +173,8 @@ def main():
         sync_all = torch.cuda.synchronize
     else:
         import torch.distributed as dist
-        from gnnkeras_amd.distributed import ShardedLoop
-        sl = ShardedLoop(gnn, graph, rank=rank, world_size=world, device=device)
+        from gnnkeras_amd.distributed import make_sharded_loop
+        sl = make_sharded_loop(gnn, graph, rank=rank, world_size=world, device=device, exchange=args.exchange)
         s0 = torch.from_numpy(s0_host).to(device)
         step = lambda: sl.forward(s0)
         per_arc_w = sl.per_arc_weights
@@ -236,7 +238,7 @@ def main():
                                + ('3 node types with per-type ' if composite else '') +
                                f'BN+Dense({ns.input_dim}->{h1},selu) state net',
                    'sharding': 'single GPU' if not sharded else f'node-range shards over {world} GPUs, '
-                                                               f'RCCL all-gather of state slices per iteration'},
+                                                               f'RCCL {"all-to-all of compacted halos" if type(sl).__name__ == "HaloShardedLoop" else "all-gather of state slices"} per iteration'},
         'roofline': roofline,
         'loop_only_updates_per_s': E / t_iter if not sharded else None,
         'fwd_ms_per_graph': ms_per_step,

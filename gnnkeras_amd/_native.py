@@ -25,7 +25,7 @@ FLAG_NO_EARLY_EXIT = 2
 
 EXPORTS = ['gnn_last_error', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_aggregate',
            'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_ld',
-           'gnn_shard_setup', 'gnn_shard_iteration', 'gnn_shard_output',
+           'gnn_shard_setup', 'gnn_shard_iteration', 'gnn_shard_output', 'gnn_gather_rows',
            'gnn_dense', 'gnn_fold_bn', 'gnn_dense_grad_workspace_bytes', 'gnn_dense_grad', 'gnn_act_grad',
            'gnn_colstats_workspace_bytes', 'gnn_colstats', 'gnn_first_layer_param_grads', 'gnn_bn_input_grad',
            'gnn_scatter_add_rows', 'gnn_axpby', 'gnn_loss_grad', 'gnn_adam_step', 'gnn_sgd_step',
@@ -138,6 +138,7 @@ def lib():
         vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
         protos = {
             'gnn_dense': (C.c_int, [C.POINTER(DenseArgs)]),
+            'gnn_gather_rows': (C.c_int, [vp, i32, vp, i32, i32, vp, i32, vp]),
             'gnn_fold_bn': (C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]),
             'gnn_dense_grad_workspace_bytes': (sz, [i32, i32, i32]),
             'gnn_dense_grad': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, sz, vp]),

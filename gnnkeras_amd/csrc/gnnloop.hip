@@ -675,6 +675,17 @@ __global__ void k_or_flags(const int *gate, int n_gate, int gate_stride, int *ou
 
 int32_t gnn_state_ld(int32_t state_width) { return state_width > 0 ? state_ld(state_width) : 0; }
 
+int gnn_gather_rows(const float *src, int32_t ld_src, const int32_t *idx, int32_t M, int32_t width, float *dst,
+                    int32_t ld_dst, void *stream) {
+    if (M < 0 || width < 1 || ld_src < width || ld_dst < width) return fail("bad arguments");
+    if (M == 0) return 0;
+    if (!src || !idx || !dst) return fail("NULL pointer");
+    const long total = (long)M * ((width & 3) == 0 ? width / 4 : width);
+    gnn::k_gather_rows<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, (hipStream_t)stream>>>(src, ld_src, idx, M, width, dst, ld_dst);
+    LAUNCH_OK();
+    return 0;
+}
+
 int gnn_shard_setup(const gnn_loop_args_t *args) {
     if (!args) return fail("args is NULL");
     const gnn_loop_args_t &a = *args;

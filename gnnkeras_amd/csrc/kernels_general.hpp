@@ -233,6 +233,29 @@ k_copy2d(const int *gate, const float *__restrict__ src, int ld_src, float *__re
     }
 }
 
+// dst[m, :width] = src[idx[m], :width]  — row gather (packs the halo rows a peer needs into a contiguous send buffer);
+// whole rows, 16 B per lane when width % 4 == 0 and both leading dimensions are multiples of 4.
+__global__ void __launch_bounds__(256)
+k_gather_rows(const float *__restrict__ src, int ld_src, const int *__restrict__ idx, int M, int width,
+              float *__restrict__ dst, int ld_dst) {
+    if ((width & 3) == 0 && (ld_src & 3) == 0 && (ld_dst & 3) == 0) {
+        const int w4 = width >> 2;
+        const size_t total = (size_t)M * w4;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const size_t m = i / w4;
+            const int c = (int)(i % w4);
+            reinterpret_cast<f32x4 *>(dst + m * ld_dst)[c] = reinterpret_cast<const f32x4 *>(src + (size_t)idx[m] * ld_src)[c];
+        }
+        return;
+    }
+    const size_t total = (size_t)M * width;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / width;
+        const int c = (int)(i % width);
+        dst[m * ld_dst + c] = src[(size_t)idx[m] * ld_src + c];
+    }
+}
+
 // state_out = (k odd ? buf1 : buf0): picks the buffer that holds the state after k iterations, k read on device.
 __global__ void __launch_bounds__(256)
 k_select_state(const float *k_ptr, const float *__restrict__ buf0, const float *__restrict__ buf1, int ld_buf,

@@ -17,8 +17,10 @@ its slice of the other one) and ONE in-place `all_gather_into_tensor`. Every ran
 in padded-row order (the one-off halo of the neighbour-label aggregate, GNN.py:258); arcs are stored with their
 destination, so the ArcNode scatter-add (GNN.py:254) is local. No host synchronisation anywhere in the loop.
 
-ER graphs have no locality: ~(R-1)/R of the arcs are remote and every node is somebody's halo, hence the full
-all-gather; graphs with locality could exchange compacted halos instead (not built).
+`ShardedLoop` exchanges whole slices with one all-gather. `HaloShardedLoop` exchanges *only the rows a peer actually
+reads* (its halo) with one `all_to_all_single` of uneven splits — every pair talks over its own direct xGMI link, and
+block-diagonal batches (MUTAG: shard by graph) exchange nothing but the flag rows. On ER graphs, which have no
+locality, a peer still needs ~(1 - e^{-deg/R}) of a slice (71 % at R = 8, in-degree 10).
 """
 from __future__ import annotations
 
@@ -129,6 +131,9 @@ class ShardedLoop:
     # ---- device-specific pieces (the gloo/CPU tests override these four with numpy stand-ins) --------------------------
     def _state_ld(self, S):
         return int(nat.lib().gnn_state_ld(S))
+
+    def _n_src_rows(self):
+        return self.plan.n_rows_full
 
     def _upload(self):
         p, dev = self.plan, self.device
@@ -267,3 +272,224 @@ class ShardedLoop:
         self._iter_events = None
         k = max(float(self.k), 1.0)
         return 1e-3 * sum(ms[:int(k)]) / k
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# compacted halo exchange
+# ----------------------------------------------------------------------------------------------------------------------
+class HaloShardPlan(ShardPlan):
+    """Shard description whose exchanged buffer holds [own rows | halo rows of peer 0 + flag row | ... | own flag row].
+
+    Source ids of the local CSR operators index that *local view*. `send_rows[p]` = my local rows peer p reads (sorted),
+    `halo[q]` = the global ids I read from peer q (sorted). Every rank derives all lists from the replicated host graph,
+    so no index exchange is needed."""
+
+    def __init__(self, graph: GraphObject, rank: int, world_size: int):
+        N = graph.nodes.shape[0]
+        self.N, self.rank, self.world_size = N, rank, world_size
+        self.chunk, self.ranges = partition(N, world_size)
+        self.lo, self.hi = self.ranges[rank]
+        self.n_local = self.hi - self.lo
+        src, dst = graph.arc_ids[:, 0], graph.arc_ids[:, 1]
+        owner = lambda ids: np.minimum(ids // self.chunk, world_size - 1)
+        mine = (dst >= self.lo) & (dst < self.hi)
+        self.arc_index = np.flatnonzero(mine)
+        self.e_local = int(mine.sum())
+        my_src = src[mine]
+        src_owner = owner(my_src)
+        # halo[q]: sorted unique sources owned by q that my destinations read; view layout
+        self.halo, self.seg_start = [], []
+        row = self.n_local
+        for q in range(world_size):
+            h = np.unique(my_src[src_owner == q]) if q != rank else np.zeros(0, dtype=np.int64)
+            self.halo.append(h)
+            self.seg_start.append(row)
+            if q != rank: row += len(h) + 1                         # + the peer's flag row
+        self.own_flag_row = row
+        self.n_rows_view = row + 1
+        self.n_rows_full = self.n_rows_view                         # rows the device operators may read
+        self.row_base = 0
+        self.recv_rows = [0 if q == rank else len(self.halo[q]) + 1 for q in range(world_size)]
+        self.flag_rows = np.array([self.own_flag_row if q == rank else self.seg_start[q] + len(self.halo[q])
+                                   for q in range(world_size)], dtype=np.int64)
+        # what every peer p reads from me: sources in my range among arcs whose destination p owns
+        from_me = (src >= self.lo) & (src < self.hi)
+        dst_owner = owner(dst)
+        self.send_rows = []
+        for p_ in range(world_size):
+            if p_ == rank: self.send_rows.append(np.zeros(0, dtype=np.int64)); continue
+            self.send_rows.append(np.unique(src[from_me & (dst_owner == p_)]) - self.lo)
+        self.send_counts = [0 if p_ == rank else len(self.send_rows[p_]) + 1 for p_ in range(world_size)]
+        self.pack_index = np.concatenate([np.concatenate([self.send_rows[p_], [self.own_flag_row]])
+                                          for p_ in range(world_size) if p_ != rank] or [np.zeros(0)]).astype(np.int32)
+        # local operators in view-row space
+        view_row = np.empty(len(my_src), dtype=np.int64)
+        own = src_owner == rank
+        view_row[own] = my_src[own] - self.lo
+        for q in range(world_size):
+            sel = src_owner == q
+            if q != rank and sel.any():
+                view_row[sel] = self.seg_start[q] + np.searchsorted(self.halo[q], my_src[sel])
+        values = graph.ArcNode.data[mine]
+        dst_local = dst[mine] - self.lo
+        self.adjacency = CSRByDestination.from_coo(view_row, dst_local, values, (self.n_rows_view, self.n_local))
+        self.arcnode = CSRByDestination.from_coo(np.arange(self.e_local), dst_local, values, (self.e_local, self.n_local))
+        self.arc_labels = np.ascontiguousarray(graph.arcs[mine][:, 2:])
+        self.nodes_local = np.ascontiguousarray(graph.nodes[self.lo:self.hi])
+        # labels of every view row (own + halos): the one-off halo of the label aggregate
+        self.view_global = np.full(self.n_rows_view, -1, dtype=np.int64)
+        self.view_global[:self.n_local] = np.arange(self.lo, self.hi)
+        for q in range(world_size):
+            if q != rank: self.view_global[self.seg_start[q]:self.seg_start[q] + len(self.halo[q])] = self.halo[q]
+        nodes_full = np.zeros((self.n_rows_view, graph.nodes.shape[1]), dtype=np.float32)
+        valid = self.view_global >= 0
+        nodes_full[valid] = graph.nodes[self.view_global[valid]]
+        self.nodes_full = nodes_full
+        sm, om = graph.set_mask[self.lo:self.hi], graph.output_mask[self.lo:self.hi]
+        self.out_index = np.flatnonzero(sm & om).astype(np.int32)
+        self.per_arc_weights = self.adjacency.w is not None
+        self.composite = hasattr(graph, 'type_mask')
+        if self.composite:
+            tm = graph.type_mask[self.lo:self.hi]
+            if not np.all(tm.sum(1) == 1): raise ValueError('type_mask must be one-hot: every node needs exactly one type')
+            types = tm.argmax(1)
+            self.type_nodes = np.argsort(types, kind='stable').astype(np.int32)
+            self.type_offsets = np.concatenate([[0], np.cumsum(np.bincount(types, minlength=tm.shape[1]))]).astype(np.int64)
+            self.dim_node_label = [int(d) for d in graph.DIM_NODE_LABEL]
+            self.composite_adjacency = []
+            lookup = np.full(N, -1, dtype=np.int64)
+            lookup[self.view_global[valid]] = np.flatnonzero(valid)
+            for ca in graph.CompositeAdjacencies:
+                ca = ca.tocoo()
+                keep = (ca.col >= self.lo) & (ca.col < self.hi)
+                self.composite_adjacency.append(CSRByDestination.from_coo(lookup[ca.row[keep]], ca.col[keep] - self.lo,
+                                                                          ca.data[keep], (self.n_rows_view, self.n_local)))
+
+    def view_state(self, state: np.ndarray, SP: int) -> np.ndarray:
+        """[N, S] -> this rank's local view buffer [n_rows_view, SP] (own rows + halo rows; flag rows zero)."""
+        full = np.zeros((self.n_rows_view, SP), dtype=np.float32)
+        valid = self.view_global >= 0
+        full[valid, :state.shape[1]] = state[self.view_global[valid]]
+        return full
+
+
+class HaloShardedLoop(ShardedLoop):
+    """`ShardedLoop` with the compacted halo exchange: per iteration one fused kernel, one row-gather that packs what
+    each peer reads, one `all_to_all_single` (uneven splits, direct pair-wise transfers)."""
+
+    def __init__(self, model, graph: GraphObject, rank: int, world_size: int, device, group=None):
+        if model._focus != 'n':
+            raise NotImplementedError('sharding is built for node-focused models (BASELINE configs C4 / C5)')
+        self.composite = isinstance(model.net_state, (list, tuple))
+        if self.composite != hasattr(graph, 'type_mask'):
+            raise ValueError('composite models need CompositeGraphObject graphs (and vice versa)')
+        self.model, self.group = model, group
+        self.rank, self.world_size = rank, world_size
+        self.device = torch.device(device)
+        self.plan = p = HaloShardPlan(graph, rank, world_size)
+        self._graph_nodes_full = np.ascontiguousarray(graph.nodes, dtype=np.float32)
+        self.n_local, self.e_local, self.per_arc_weights = p.n_local, p.e_local, p.per_arc_weights
+        self.S = model.state_vect_dim if model.state_vect_dim > 0 else graph.nodes.shape[1]
+        self.L, self.A = graph.nodes.shape[1], graph.arcs.shape[1] - 2
+        self.SP = self._state_ld(self.S)
+        self._upload()
+        self.buf = [torch.zeros((p.n_rows_view, self.SP), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._make_exchange_state()
+        self._iter_events = None
+
+    def _make_exchange_state(self):
+        p, dev = self.plan, self.device
+        self.d_pack_index = torch.from_numpy(p.pack_index).to(dev)
+        self.sendbuf = torch.zeros((max(len(p.pack_index), 1), self.SP), dtype=torch.float32, device=dev)
+        self.d_flag_rows = torch.from_numpy(p.flag_rows).to(dev)
+        self.gates = [torch.zeros(self.world_size, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.in_splits = [c * self.SP for c in p.send_counts]
+        self.out_splits = [c * self.SP for c in p.recv_rows]
+
+    # ---- orchestration pieces that differ from the all-gather layout -----------------------------------------------------
+    def _load_state0(self, state0_full):
+        p = self.plan
+        if isinstance(state0_full, torch.Tensor):
+            s0 = state0_full.to(self.device, torch.float32)
+            vg = torch.from_numpy(p.view_global).to(self.device)
+            valid = vg >= 0
+            self.buf[0].zero_()
+            self.buf[0][valid, :s0.shape[1]] = s0[vg[valid]]
+            self._state0_full = s0
+        else:
+            arr = np.asarray(state0_full, dtype=np.float32)
+            self.buf[0].copy_(torch.from_numpy(p.view_state(arr, self.SP)))
+            self._state0_full = torch.from_numpy(arr).to(self.device)
+
+    def plan_nodes_as_state(self):
+        return self._graph_nodes_full
+
+    def _initial_flags(self):
+        """The predicate on state_0 covers every node of the graph and every rank holds state_0: evaluate it globally
+        once and open / close all R gates together (no exchange before the first iteration)."""
+        s0 = self._state0_full.contiguous()
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        nat.check(nat.lib().gnn_converged(nat.ptr(s0), None, s0.shape[0], self.S, s0.shape[1], float(self.model.state_threshold),
+                                          nat.ptr(flag), nat.current_stream(self.device)))
+        self.gates[0].copy_(flag.expand(self.world_size))
+
+    def _iteration(self, it: int):
+        p = self.plan
+        src, dst = self.buf[it & 1], self.buf[(it + 1) & 1]
+        flag_out = dst.data_ptr() + 4 * p.own_flag_row * self.SP
+        nat.check(nat.lib().gnn_shard_iteration(C.byref(self.args), nat.ptr(src), nat.ptr(dst), 0, nat.ptr(self.gates[it & 1]),
+                                                self.world_size, 1, C.c_void_p(flag_out), it))
+
+    def _pack(self, buf):
+        n = len(self.plan.pack_index)
+        if n:
+            nat.check(nat.lib().gnn_gather_rows(nat.ptr(buf), self.SP, nat.ptr(self.d_pack_index), n, self.SP,
+                                                nat.ptr(self.sendbuf), self.SP, nat.current_stream(self.device)))
+
+    def _exchange(self, buf: torch.Tensor, it: int = 0):
+        """Pack the rows every peer reads (+ my flag row), swap them pair-wise, collect the R flag words for the next gate."""
+        p = self.plan
+        if self.world_size > 1:
+            self._pack(buf)
+            n_recv = sum(p.recv_rows)
+            recv = buf[p.n_local:p.n_local + n_recv].view(-1)
+            dist.all_to_all_single(recv, self.sendbuf[:len(p.pack_index)].view(-1), output_split_sizes=self.out_splits,
+                                   input_split_sizes=self.in_splits, group=self.group)
+        self.gates[(it + 1) & 1].copy_(self._flag_words(buf))
+
+    def _flag_words(self, buf):
+        return buf.view(torch.int32)[self.d_flag_rows, 0]
+
+    def forward(self, state0_full=None):
+        m = self.model
+        if m.state_vect_dim > 0:
+            if state0_full is None: raise ValueError('state0 (all nodes) is required when state_vect_dim > 0')
+            self._load_state0(state0_full)
+        else:
+            self._load_state0(self._graph_nodes_full)
+        self._setup()
+        self._initial_flags()
+        ev = self._iter_events
+        for it in range(m.max_iteration):
+            if ev is not None: ev[it][0].record()
+            self._iteration(it)
+            if ev is not None: ev[it][1].record()
+            self._exchange(self.buf[(it + 1) & 1], it)
+        return self._output()
+
+
+def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, device, group=None, exchange: str = 'auto'):
+    """`exchange`: 'allgather' (whole slices, one all-gather), 'halo' (only the rows each peer reads, one all-to-all), or
+    'auto' = halo when it moves less than half of what the all-gather would (graphs with locality, block-diagonal
+    batches), all-gather otherwise (Erdős–Rényi graphs: every slice is almost entirely somebody's halo)."""
+    if exchange not in ('auto', 'allgather', 'halo'): raise ValueError('exchange must be auto, allgather or halo')
+    if exchange == 'auto':
+        chunk, ranges = partition(graph.nodes.shape[0], world_size)
+        lo, hi = ranges[rank]
+        src, dst = graph.arc_ids[:, 0], graph.arc_ids[:, 1]
+        mine = (dst >= lo) & (dst < hi)
+        remote = np.unique(src[mine & ((src < lo) | (src >= hi))])
+        full = max((world_size - 1) * chunk, 1)
+        exchange = 'halo' if len(remote) < 0.5 * full else 'allgather'
+    cls = HaloShardedLoop if exchange == 'halo' else ShardedLoop
+    return cls(model, graph, rank, world_size, device, group=group)

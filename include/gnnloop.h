@@ -170,6 +170,9 @@ int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *st
  * flag row per slice), so there is exactly one exchange per iteration and still no host synchronisation.
  * Full state buffers: [adjacency.n_src, gnn_state_ld(S)] float32, rows of rank r at row_base_r .. */
 int32_t gnn_state_ld(int32_t state_width);          /* padded row length (floats) of exchanged state buffers */
+/* dst[m, :width] = src[idx[m], :width]: packs the state rows a peer needs (its halo) into a contiguous send buffer */
+int gnn_gather_rows(const float *src, int32_t ld_src, const int32_t *idx, int32_t M, int32_t width, float *dst,
+                    int32_t ld_dst, void *stream);
 int gnn_shard_setup(const gnn_loop_args_t *args);   /* once per forward: BN folding, label / arc aggregates, C */
 /* gates: run iff OR_i gate[i * gate_stride] != 0 (the flag words of every slice of state_in_full), i < n_gate.
  * flag_out: this shard's flag word inside state_out_full (zeroed, then raised if any own node still moves). */

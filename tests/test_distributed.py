@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from gnnkeras_amd import GraphObject
-from gnnkeras_amd.distributed import ShardedLoop, ShardPlan, partition, padded_row
+from gnnkeras_amd.distributed import ShardedLoop, ShardPlan, HaloShardedLoop, HaloShardPlan, partition, padded_row
 from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
 from gnnkeras_amd.Models.GNN import GNNnodeBased
 from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
@@ -87,6 +87,43 @@ class OracleShardedLoop(ShardedLoop):
         return self.k, torch.from_numpy(state.copy()), torch.from_numpy(out.astype(np.float32))
 
 
+class OracleHaloShardedLoop(HaloShardedLoop):
+    """Same stand-in for the compacted halo exchange: device pieces from the oracle, plan / pack lists / all_to_all real."""
+    dtype = np.float64
+    _state_ld = OracleShardedLoop._state_ld
+    _upload = OracleShardedLoop._upload
+    _setup = OracleShardedLoop._setup
+
+    def _initial_flags(self):
+        s = self._state0_full.numpy()[:, :self.S].astype(self.dtype)
+        self.gates[0].fill_(int(O.condition(0, s, np.ones_like(s), 1, self.model.state_threshold, self.dtype)))
+
+    def _iteration(self, it):
+        p, m = self.plan, self.model
+        src, dst = self.buf[it & 1], self.buf[(it + 1) & 1]
+        dst.view(torch.int32)[p.own_flag_row, 0] = 0
+        if not bool(self.gates[it & 1].any()): return
+        full = src.numpy()[:, :self.S].astype(self.dtype)
+        own = full[:p.n_local]
+        agg = O.sparse_dense_matmul_adjoint(*self.adj, full, self.dtype)
+        comps = [own, p.nodes_local, agg, self.agg_nodes, self.agg_arcs] if m.state_vect_dim > 0 else [own, agg, self.agg_arcs]
+        new = O.mlp_apply(*m.net_state.spec(), np.concatenate(comps, axis=1), False, self.dtype)
+        dst[:p.n_local, :self.S] = torch.from_numpy(new.astype(np.float32))
+        dst.view(torch.int32)[p.own_flag_row, 0] = int(O.condition(0, new, own, 1, m.state_threshold, self.dtype))
+        self.k.fill_(it + 1)
+
+    def _pack(self, buf):
+        n = len(self.plan.pack_index)
+        if n: self.sendbuf[:n].copy_(buf[self.d_pack_index.long()])
+
+    def _output(self):
+        p, m = self.plan, self.model
+        state = self.buf[int(self.k) & 1].numpy()[:p.n_local, :self.S]
+        inp = np.concatenate([state, p.nodes_local], 1) if m.state_vect_dim > 0 else state
+        out = O.mlp_apply(*m.net_output.spec(), inp[p.out_index], False, self.dtype)
+        return self.k, torch.from_numpy(state.copy()), torch.from_numpy(out.astype(np.float32))
+
+
 def _problem(threshold, d=6, max_it=12):
     rng = np.random.default_rng(0)
     g = er_graph(203, 1500, dim_node_label=5, dim_arc_label=2, seed=7)          # 203 is not a multiple of 2 or 3
@@ -103,29 +140,30 @@ def _problem(threshold, d=6, max_it=12):
     return g, model, s0
 
 
-def _worker(rank, world, port, threshold, d, out_q):
+def _worker(rank, world, port, threshold, d, out_q, halo=False):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         g, model, s0 = _problem(threshold, d)
-        sl = OracleShardedLoop(model, g, rank, world, 'cpu')
+        sl = (OracleHaloShardedLoop if halo else OracleShardedLoop)(model, g, rank, world, 'cpu')
         k, state, out = sl.forward(s0)
         out_q.put((rank, float(k), state.numpy(), out.numpy(), sl.plan.lo, sl.plan.hi))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('halo', [False, True])
 @pytest.mark.parametrize('world', [2, 3])
 @pytest.mark.parametrize('threshold,d', [(0.0, 6), (0.02, 6), (0.0, 0)])
-def test_sharded_loop_matches_single_process_oracle(world, threshold, d):
+def test_sharded_loop_matches_single_process_oracle(world, threshold, d, halo):
     g, model, s0 = _problem(threshold, d)
     seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False, device='cpu')
     k_ref, st_ref, out_ref = oracle_loop(model, seq[0][0], s0, np.float64)
     if threshold > 0: assert 1 < k_ref < model.max_iteration              # early exit really happens
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + world * 7 + int(threshold * 100) + d) % 1000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, threshold, d, q)) for r in range(world)]
+    port = 29500 + (os.getpid() + world * 7 + int(threshold * 100) + d + 13 * halo) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, threshold, d, q, halo)) for r in range(world)]
     for p in procs: p.start()
     res = sorted([q.get(timeout=180) for _ in procs])
     for p in procs:
@@ -164,3 +202,30 @@ def test_shard_plan_covers_every_arc_once():
         assert full.shape == (4 * (p.chunk + 1), 16)
         assert np.array_equal(full[padded_row(np.arange(300), p.chunk), :2].reshape(-1), np.arange(600))
         assert np.all(full[p.chunk::p.chunk + 1] == 0)                    # flag rows start clear
+
+
+def test_halo_plan_lists_are_consistent():
+    """What rank p expects from rank r (halo[r] on p) is exactly what r packs for p (send_rows[p] on r), in the same
+    order; block-diagonal batches sharded on graph boundaries need no halo at all."""
+    g = er_graph(300, 2500, dim_node_label=4, dim_arc_label=2, seed=3)
+    R = 4
+    plans = [HaloShardPlan(g, r, R) for r in range(R)]
+    for p_ in plans:
+        for r_ in plans:
+            if p_.rank == r_.rank: continue
+            assert np.array_equal(p_.halo[r_.rank], r_.send_rows[p_.rank] + r_.lo)
+            assert p_.recv_rows[r_.rank] == r_.send_counts[p_.rank]
+        assert len(p_.pack_index) == sum(p_.send_counts)
+        # every source id of the local operator points at the right global node
+        srcs = p_.adjacency.src
+        assert np.all(p_.view_global[srcs] >= 0)
+        dst = np.repeat(np.arange(p_.n_local), np.diff(p_.adjacency.rowptr)) + p_.lo
+        pairs = set(zip(p_.view_global[srcs].tolist(), dst.tolist()))
+        want = set(map(tuple, g.arc_ids[(g.arc_ids[:, 1] >= p_.lo) & (g.arc_ids[:, 1] < p_.hi)].tolist()))
+        assert pairs == want
+    # two disjoint components cut exactly at the boundary: nothing but flag rows travels
+    ring = lambda n, off: np.array([[off + i, off + (i + 1) % n, 1.0] for i in range(n)])
+    gg = GraphObject(np.ones((20, 2)), np.concatenate([ring(10, 0), ring(10, 10)]), np.ones((20, 1)), focus='n')
+    for r in range(2):
+        hp = HaloShardPlan(gg, r, 2)
+        assert sum(len(h) for h in hp.halo) == 0 and hp.send_counts[1 - r] == 1 and hp.n_rows_view == 10 + 1 + 1

@@ -556,3 +556,79 @@ def test_sharded_composite_native_kernels_match_oracle(R, mode):
         ks, st, o = _run_shards_on_one_gpu(model, g, s0, R)
         assert all(k == float(k64) for k in ks)
         assert rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL
+
+
+def _run_halo_shards_on_one_gpu(model, g, s0, R):
+    """R compacted-halo shards on one device; the all-to-all is emulated by copying every packed segment into the
+    receiver's halo region (what RCCL does pair-wise across GPUs)."""
+    from gnnkeras_amd.distributed import HaloShardedLoop
+    shards = [HaloShardedLoop(model, g, r, R, 'cuda') for r in range(R)]
+    for sl in shards:
+        sl._load_state0(s0 if s0 is not None else sl._graph_nodes_full)
+        sl._setup()
+        sl._initial_flags()
+    for it in range(model.max_iteration):
+        nxt = (it + 1) & 1
+        for sl in shards: sl._iteration(it)
+        for sl in shards: sl._pack(sl.buf[nxt])
+        for p_ in shards:
+            for r_ in shards:
+                if r_ is p_: continue
+                cnt = r_.plan.send_counts[p_.rank]
+                off = sum(r_.plan.send_counts[:p_.rank])
+                start = p_.plan.seg_start[r_.rank]
+                assert cnt == p_.plan.recv_rows[r_.rank]
+                p_.buf[nxt][start:start + cnt].copy_(r_.sendbuf[off:off + cnt])
+        for sl in shards: sl.gates[nxt].copy_(sl._flag_words(sl.buf[nxt]))
+    outs = [sl._output() for sl in shards]
+    torch.cuda.synchronize()
+    return [float(o[0]) for o in outs], np.concatenate([o[1].cpu().numpy() for o in outs]), \
+        np.concatenate([o[2].cpu().numpy() for o in outs])
+
+
+@pytest.mark.parametrize('R', [1, 3, 8])
+@pytest.mark.parametrize('threshold', [0.0, 0.02])
+def test_halo_sharded_native_kernels_match_oracle(R, threshold):
+    rng = np.random.default_rng(0)
+    N, d = 5003, 64
+    g = er_graph(N, 40000, seed=7)
+    om = rng.random(N) < 0.7
+    g = GraphObject(g.nodes, g.arcs, rng.normal(size=(int(om.sum()), 2)), focus='n', set_mask=rng.random(N) < 0.8,
+                    output_mask=om, aggregation_mode='average')
+    ns, no = starter_nets('n', d, scale=0.3)
+    model = GNNnodeBased(ns, no, d, 12, threshold)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        ks, st, o = _run_halo_shards_on_one_gpu(model, g, s0, R)
+        assert all(k == float(k64) for k in ks), (ks, k64)
+        assert rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL
+
+
+def test_halo_sharded_mutag_batch_by_graph_and_composite(mutag_graphs):
+    """A block-diagonal MUTAG batch sharded near graph boundaries exchanges (almost) nothing but flags; composite too."""
+    from gnnkeras_amd.distributed import HaloShardPlan, make_sharded_loop
+    m = GraphObject.merge(mutag_graphs[:32], 'n', 'average')
+    g = GraphObject(m.nodes, m.arcs, np.zeros((m.nodes.shape[0], 2)), focus='n', aggregation_mode='average')
+    plan = HaloShardPlan(g, 1, 4)
+    assert sum(len(h) for h in plan.halo) < 0.15 * plan.n_local           # a graph may straddle a cut, nothing more
+    assert type(make_sharded_loop(GNNnodeBased(*starter_nets('n', 8), 8, 3, 0.0), g, 0, 4, 'cuda')).__name__ == 'HaloShardedLoop'
+    ns, no = starter_nets('n', 32)
+    model = GNNnodeBased(ns, no, 32, 10, 0.0)
+    s0 = np.random.default_rng(2).normal(0, 0.1, (g.nodes.shape[0], 32)).astype(np.float32)
+    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    ks, st, o = _run_halo_shards_on_one_gpu(model, g, s0, 4)
+    assert all(k == 10.0 for k in ks) and rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL
+    # composite (C5 shape)
+    dims = (5, 3, 4)
+    cg = er_composite_graph(3001, 20000, dim_node_label=dims, aggregation_mode='composite_average', seed=5)
+    cns, cno = composite_nets(dims, 3, 16, 2, 'n')
+    cmodel = CompositeGNNnodeBased(cns, cno, 16, 6, 0.0)
+    cs0 = np.random.default_rng(3).normal(0, 0.1, (3001, 16)).astype(np.float32)
+    cx = CompositeMultiGraphSequencer([cg], 'n', 'composite_average', 1, shuffle=False)[0][0]
+    ck, cst, co = oracle_composite_loop(cmodel, cx, cs0, np.float64)
+    ks, st, o = _run_halo_shards_on_one_gpu(cmodel, cg, cs0, 3)
+    assert all(k == float(ck) for k in ks) and rel_err(st, cst) <= TOL and rel_err(o, co) <= TOL

@@ -15,7 +15,7 @@ import torch
 
 from .. import _native as nat
 from ..sparse import SparseMatrix
-from .GNN import GNNnodeBased, _LoopModel, _squeeze_last, _arc_endpoints
+from .GNN import GNNnodeBased, _LoopModel, _squeeze_last, _arc_endpoints, _hub_fields
 from .MLP import Sequential
 
 
@@ -164,6 +164,7 @@ class CompositeGNNnodeBased(GNNnodeBased):
         a.nodes, a.ld_nodes = nat.ptr(nodes), Lw
         a.arc_labels, a.ld_arcs = C.c_void_p(arcs.data_ptr() + 8), arcs.shape[1]
         a.adjacency, a.arcnode = nat.make_csr(adj), nat.make_csr(arcn)
+        _hub_fields(a, adj)
         a.n_types = T
         a.type_nodes = nat.ptr(type_nodes)
         for t in range(T):

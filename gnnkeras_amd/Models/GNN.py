@@ -166,6 +166,14 @@ class _LoopModel:
         return hit[0]
 
 
+def _hub_fields(a, adj):
+    """Hub rows (in-degree > sparse.HEAVY_THRESHOLD): hand the light operator + segment list to the library."""
+    if adj.get('heavy') is not None:
+        a.adjacency_light = nat.make_csr(adj['light'])
+        a.heavy_seg_beg, a.heavy_seg_end = nat.ptr(adj['heavy']['seg_beg']), nat.ptr(adj['heavy']['seg_end'])
+        a.n_heavy_segments = adj['heavy']['n_seg']
+
+
 def _squeeze_last(x):
     return x.squeeze(-1) if isinstance(x, torch.Tensor) and x.dim() > 1 and x.shape[-1] == 1 else x
 
@@ -328,6 +336,7 @@ class GNNnodeBased(_LoopModel):
         a.nodes, a.ld_nodes = nat.ptr(nodes), L
         a.arc_labels, a.ld_arcs = C.c_void_p(arcs.data_ptr() + 8), arcs.shape[1]
         a.adjacency, a.arcnode = nat.make_csr(adj), nat.make_csr(arcn)
+        _hub_fields(a, adj)
         a.n_types = 1
         a.net_state[0] = self.net_state.to(dev).native()
         a.net_output = self.net_output.to(dev).native()

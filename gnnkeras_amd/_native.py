@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libgnnloop.so')
 
-GNN_ABI_VERSION = 1
+GNN_ABI_VERSION = 2
 GNN_MAX_LAYERS = 8
 GNN_MAX_TYPES = 8
 
@@ -69,6 +69,8 @@ class LoopArgs(C.Structure):
                 ('k_out', C.c_void_p), ('state_out', C.c_void_p), ('out', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('stream', C.c_void_p),
                 ('flags', C.c_int32), ('nodes_src', C.c_void_p), ('ld_nodes_src', C.c_int32),
+                ('adjacency_light', CSR), ('heavy_seg_beg', C.c_void_p), ('heavy_seg_end', C.c_void_p),
+                ('n_heavy_segments', C.c_int32),
                 ('ev_loop_begin', C.c_void_p), ('ev_loop_end', C.c_void_p)]
 
 

@@ -225,6 +225,7 @@ struct Plan {
     int N, E, S, SP, L, A, T;        // S = state width, SP = padded leading dimension of internal state buffers
     int H1max, Hmax_state, Hmax_out, Tout, M, G;
     bool composite, fused;
+    int n_heavy;                     // virtual state rows appended after the N real ones (hub segments)
     TypePlan tp[GNN_MAX_TYPES];
     // workspace
     int *flags;
@@ -303,6 +304,12 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
             if (a.nodegraph.n_src != p.M) return fail("graph focus: NodeGraph has %d rows but %d nodes pass the mask (the reference's matmul would fail too)", a.nodegraph.n_src, p.M);
             TRY(check_csr(a.nodegraph, "nodegraph", a.nodegraph.n_dst, p.M));
         }
+        if (a.n_heavy_segments > 0) {
+            if (a.nodes_src) return fail("hub segments are not supported on shards");
+            if (!a.heavy_seg_beg || !a.heavy_seg_end) return fail("heavy_seg_beg / heavy_seg_end is NULL");
+            TRY(check_csr(a.adjacency_light, "adjacency_light", p.N, p.N + a.n_heavy_segments));
+            if (p.SP > 64) return fail("hub segments need a state width <= 64");
+        }
         if (p.composite) {
             if (!a.type_nodes && p.N > 0) return fail("type_nodes is NULL");
             if (a.type_offsets[0] != 0 || a.type_offsets[p.T] != p.N) return fail("type_offsets must span [0, n_nodes]");
@@ -325,8 +332,9 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     p.agg_nodes = c.take<float>((size_t)p.N * std::max(p.ld_agg_nodes, 1));
     p.ldC = p.H1max;
     p.C = c.take<float>((size_t)p.N * p.ldC);
-    p.buf[0] = c.take<float>((size_t)p.N * p.SP + 64);
-    p.buf[1] = c.take<float>((size_t)p.N * p.SP + 64);
+    p.n_heavy = a.n_heavy_segments > 0 ? a.n_heavy_segments : 0;
+    p.buf[0] = c.take<float>((size_t)(p.N + p.n_heavy) * p.SP + 64);
+    p.buf[1] = c.take<float>((size_t)(p.N + p.n_heavy) * p.SP + 64);
     p.agg = c.take<float>((size_t)p.N * p.SP);
     p.ld_hid = p.Hmax_state;
     p.hid[0] = c.take<float>((size_t)p.N * p.ld_hid);
@@ -368,10 +376,28 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     return 0;
 }
 
+// the operator the iterations walk: the light one when hub rows were split off
+inline const gnn_csr_t &iter_adjacency(const gnn_loop_args_t &a) { return a.n_heavy_segments > 0 ? a.adjacency_light : a.adjacency; }
+
+// hub pre-pass: virtual rows N .. N + n_heavy of the buffer the iteration is about to read
+int launch_heavy(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src, hipStream_t st) {
+    if (p.n_heavy == 0) return 0;
+    float *buf = const_cast<float *>(src);
+    const int grid = std::min(p.n_heavy, 256 * 8);
+    switch (p.SP) {
+        case 16: gnn::k_heavy_segments<16><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
+        case 32: gnn::k_heavy_segments<32><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
+        default: gnn::k_heavy_segments<64><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
+    }
+    LAUNCH_OK();
+    return 0;
+}
+
 // one un-fused iteration: agg = A^T state ; state_new = net_state([state | agg] + C) per type ; predicate.
 int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src_full, float *dst_full,
                       int row_base, int *flag_next, float *k_out, float k_val, hipStream_t st) {
-    TRY(launch_aggregate(gate, a.adjacency, src_full, p.SP, p.S, p.agg, p.SP, st));
+    TRY(launch_heavy(a, p, gate, src_full, st));
+    TRY(launch_aggregate(gate, iter_adjacency(a), src_full, p.SP, p.S, p.agg, p.SP, st));
     const float *src = src_full + (size_t)row_base * p.SP;     // own rows
     float *dst = dst_full + (size_t)row_base * p.SP;
     for (int t = 0; t < p.T; ++t) {
@@ -492,10 +518,12 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
         return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg,
                               (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0]};
     };
+    TRY(launch_heavy(a, p, n_gate == 1 ? gate : nullptr, src, st));
+    const gnn_csr_t &adj = iter_adjacency(a);
     gnn::Fused2Args fa;
     memset(&fa, 0, sizeof(fa));
     fa.gate = n_gate ? gate : nullptr; fa.n_gate = n_gate; fa.gate_stride = gate_stride;
-    fa.rowptr = a.adjacency.rowptr; fa.src = a.adjacency.src; fa.w = a.adjacency.w; fa.row_scale = a.adjacency.row_scale;
+    fa.rowptr = adj.rowptr; fa.src = adj.src; fa.w = adj.w; fa.row_scale = adj.row_scale;
     fa.state_in = src; fa.state_out = dst; fa.row_base = row_base;
     fa.C = p.C; fa.ldC = p.ldC;
     fa.n_types = 0;
@@ -516,7 +544,7 @@ bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
     if (a.flags & GNN_FLAG_UNFUSED) return false;
     if (p.SP > 64) return false;   // LDS: [64 x 2SP] tile + [2SP x SP] weights must leave room for 2 workgroups per CU
     // the fused kernel addresses state rows and C with 32-bit byte offsets off a scalar base
-    if ((size_t)std::max(a.adjacency.n_src, p.N) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return false;
+    if ((size_t)(std::max(a.adjacency.n_src, p.N) + p.n_heavy) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return false;
     for (int t = 0; t < p.T; ++t)
         if (a.net_state[t].n_layers != 1 || a.net_state[t].activation[0] == GNN_ACT_SOFTMAX) return false;
     return true;

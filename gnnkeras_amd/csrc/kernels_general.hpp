@@ -233,6 +233,35 @@ k_copy2d(const int *gate, const float *__restrict__ src, int ld_src, float *__re
     }
 }
 
+// Hub pre-pass: one workgroup sums the arcs [seg_beg[s], seg_end[s]) of the by-destination CSR (a slice of a hub row)
+// into the virtual state row n_rows + s of the SAME buffer: 16 lanes x 16 B per source row (SP = 64; fewer lanes for
+// narrower rows), lane groups stride over the arcs, partials meet in LDS and are added in group order (deterministic).
+template <int SP>
+__global__ void __launch_bounds__(256)
+k_heavy_segments(const int *gate, const int *__restrict__ seg_beg, const int *__restrict__ seg_end, int n_seg,
+                 const int *__restrict__ src, const float *__restrict__ w, float *__restrict__ state, int n_rows) {
+    if (gate_closed(gate)) return;
+    constexpr int LPR = SP / 4, NG = 256 / LPR;
+    __shared__ f32x4 part[256];
+    const int g = threadIdx.x / LPR, l4 = threadIdx.x % LPR;
+    for (int s = blockIdx.x; s < n_seg; s += gridDim.x) {
+        const int beg = seg_beg[s], end = seg_end[s];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int e = beg + g; e < end; e += NG) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(state + (size_t)src[e] * SP + 4 * l4);
+            if (w) acc += w[e] * v; else acc += v;
+        }
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        if (g == 0) {
+            f32x4 tot = part[l4];
+            for (int gg = 1; gg < NG; ++gg) tot += part[gg * LPR + l4];
+            *reinterpret_cast<f32x4 *>(state + (size_t)(n_rows + s) * SP + 4 * l4) = tot;
+        }
+        __syncthreads();
+    }
+}
+
 // dst[m, :width] = src[idx[m], :width]  — row gather (packs the halo rows a peer needs into a contiguous send buffer);
 // whole rows, 16 B per lane when width % 4 == 0 and both leading dimensions are multiples of 4.
 __global__ void __launch_bounds__(256)

@@ -68,6 +68,47 @@ class CSRByDestination:
         return cls(rowptr.astype(np.int32), src, w, row_scale, n_src, n_dst)
 
 
+HEAVY_THRESHOLD = 512      # in-degree above which a destination row is aggregated by whole workgroups (hub nodes)
+HEAVY_SEGMENT = 2048       # arcs per workgroup in that pre-pass
+
+
+def split_heavy(c: CSRByDestination, threshold: int = HEAVY_THRESHOLD, segment: int = HEAVY_SEGMENT):
+    """Skew handling for the fused iteration kernel, which gives 4..16 lanes to a destination row: a hub with 10^5
+    in-arcs would serialise its whole tile. Rows with more than `threshold` arcs are cut into segments of <= `segment`
+    arcs; a pre-pass kernel sums every segment with a whole workgroup into a *virtual source row* (index n_src + s), and
+    the "light" operator the fused kernel walks lists those virtual rows in place of the hub's arcs.
+
+    Returns (light CSRByDestination, heavy dict(rowptr int32[n_seg+1] into the ORIGINAL src / w arrays, n_seg)) or
+    (c, None) when no row is heavy."""
+    deg = np.diff(c.rowptr.astype(np.int64))
+    heavy_rows = np.flatnonzero(deg > threshold)
+    if len(heavy_rows) == 0:
+        return c, None
+    nseg_row = -(-deg[heavy_rows] // segment)
+    n_seg = int(nseg_row.sum())
+    # [seg_beg, seg_end) ranges inside the ORIGINAL src / w arrays, hub rows in ascending order, segments in arc order
+    row_of_seg = np.repeat(heavy_rows, nseg_row)
+    k_in_row = np.arange(n_seg) - np.repeat(np.cumsum(nseg_row) - nseg_row, nseg_row)
+    seg_beg = c.rowptr[row_of_seg].astype(np.int64) + segment * k_in_row
+    seg_end = np.minimum(seg_beg + segment, c.rowptr[row_of_seg + 1].astype(np.int64))
+    # light operator: hub rows list their virtual sources
+    new_deg = deg.copy()
+    new_deg[heavy_rows] = nseg_row
+    rowptr = np.zeros(c.n_dst + 1, dtype=np.int64)
+    np.cumsum(new_deg, out=rowptr[1:])
+    src = np.empty(int(rowptr[-1]), dtype=np.int32)
+    w = None if c.w is None else np.ones(int(rowptr[-1]), dtype=np.float32)
+    is_heavy = np.zeros(c.n_dst, dtype=bool); is_heavy[heavy_rows] = True
+    keep = ~np.repeat(is_heavy, deg)                                # arcs of light rows, in order
+    light_pos = np.repeat(~is_heavy, new_deg)
+    src[light_pos] = c.src[keep]
+    if w is not None: w[light_pos] = c.w[keep]
+    virt = c.n_src + np.arange(n_seg, dtype=np.int64)
+    src[~light_pos] = virt.astype(np.int32)                         # hub rows are ascending, so are their segments
+    light = CSRByDestination(rowptr.astype(np.int32), src, w, c.row_scale, c.n_src + n_seg, c.n_dst)
+    return light, dict(seg_beg=seg_beg.astype(np.int32), seg_end=seg_end.astype(np.int32), n_seg=n_seg)
+
+
 class SparseMatrix:
     """COO triple with `tf.SparseTensor`'s attribute names (`indices`, `values`, `dense_shape`/`shape`), entries in
     canonical row-major order, plus the cached by-destination CSR (host and device copies)."""
@@ -139,8 +180,14 @@ class SparseMatrix:
         if key not in self._dev:
             c = self.csr(uniform_rows)
             up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
-            self._dev[key] = dict(rowptr=up(c.rowptr), src=up(c.src), w=up(c.w), row_scale=up(c.row_scale),
-                                  n_src=c.n_src, n_dst=c.n_dst, nnz=c.nnz, max_degree=c.max_degree)
+            d = dict(rowptr=up(c.rowptr), src=up(c.src), w=up(c.w), row_scale=up(c.row_scale),
+                     n_src=c.n_src, n_dst=c.n_dst, nnz=c.nnz, max_degree=c.max_degree, light=None, heavy=None)
+            if c.max_degree > HEAVY_THRESHOLD:
+                light, heavy = split_heavy(c)
+                d['light'] = dict(rowptr=up(light.rowptr), src=up(light.src), w=up(light.w), row_scale=d['row_scale'],
+                                  n_src=light.n_src, n_dst=light.n_dst, nnz=light.nnz)
+                d['heavy'] = dict(seg_beg=up(heavy['seg_beg']), seg_end=up(heavy['seg_end']), n_seg=heavy['n_seg'])
+            self._dev[key] = d
         return self._dev[key]
 
     def triple(self, device=None):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 1
+#define GNN_ABI_VERSION 2
 
 /* Keras activation names accepted by the reference MLP builder (GNN/Models/MLP.py:16). */
 enum gnn_activation {
@@ -124,6 +124,14 @@ typedef struct gnn_loop_args {
      * the row order of the full state buffer (the one-off halo of the label aggregate, GNN.py:258). */
     const float *nodes_src;
     int32_t ld_nodes_src;
+    /* hub nodes (optional; n_heavy_segments == 0 = absent) ----------------------------------------------------------
+     * Destination rows with very many in-arcs are cut into segments [heavy_seg_beg[s], heavy_seg_end[s]) of the arcs of
+     * `adjacency` (its src / w arrays); before every iteration a pre-pass sums each segment with a whole workgroup into
+     * the virtual state row n_nodes + s, and the iterations walk `adjacency_light`, in which a hub row lists its virtual
+     * rows (n_src = n_nodes + n_heavy_segments) instead of its arcs. */
+    gnn_csr_t adjacency_light;
+    const int32_t *heavy_seg_beg, *heavy_seg_end;
+    int32_t n_heavy_segments;
     /* measurement (optional) ------------------------------------------------------------------------------------ */
     void *ev_loop_begin;      /* hipEvent_t or NULL: recorded on `stream` right before the first iteration launch */
     void *ev_loop_end;        /* hipEvent_t or NULL: recorded right after the last iteration launch               */

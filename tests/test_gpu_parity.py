@@ -632,3 +632,46 @@ def test_halo_sharded_mutag_batch_by_graph_and_composite(mutag_graphs):
     ck, cst, co = oracle_composite_loop(cmodel, cx, cs0, np.float64)
     ks, st, o = _run_halo_shards_on_one_gpu(cmodel, cg, cs0, 3)
     assert all(k == float(ck) for k in ks) and rel_err(st, cst) <= TOL and rel_err(o, co) <= TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# hub nodes: rows with more than sparse.HEAVY_THRESHOLD in-arcs are summed by a whole-workgroup pre-pass
+# ----------------------------------------------------------------------------------------------------------------------
+def _hub_graph(rng, n, e, hubs, mode, weights=False):
+    from gnnkeras_amd.synth import er_arcs
+    ids = er_arcs(n, e, seed=3)
+    extra = [np.stack([rng.choice(n - 1, deg, replace=False) + (1 if h == 0 else 0) * 0, np.full(deg, h)], 1) for h, deg in hubs]
+    extra = [x[x[:, 0] != x[0, 1]] for x in extra]
+    ids = np.unique(np.concatenate([ids] + extra), axis=0)
+    arcs = np.concatenate([ids.astype(np.float64), np.eye(3)[rng.integers(0, 3, len(ids))]], axis=1)
+    nodes = np.eye(14)[rng.integers(0, 14, n)]
+    g = GraphObject(nodes, arcs, np.zeros((n, 2)), focus='n', aggregation_mode=mode)
+    if weights:
+        an = g.getArcNode(); an.data = rng.uniform(0.001, 0.01, len(an.data)).astype(np.float32)
+        g = GraphObject(nodes, arcs, np.zeros((n, 2)), focus='n', ArcNode=an)
+    return g
+
+
+@pytest.mark.parametrize('mode,weights,d', [('average', False, 64), ('average', False, 32), ('sum', True, 64), ('average', False, 0)])
+def test_hub_rows_use_the_segment_prepass(mode, weights, d):
+    from gnnkeras_amd import sparse
+    rng = np.random.default_rng(17)
+    g = _hub_graph(rng, 20000, 150000, [(5, 700), (1234, 3000), (19999, 9000)], mode, weights)
+    seq = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)
+    if weights:
+        seq.graph_tensors[0].ArcNode = SparseMatrix.from_scipy(g.ArcNode)
+        seq.graph_tensors[0].Adjacency = SparseMatrix.from_scipy(g.Adjacency)
+        seq._items = [None]
+    x = seq[0][0]
+    dc = x[5].matrix.device_csr('cuda')
+    assert dc['max_degree'] > sparse.HEAVY_THRESHOLD and dc['heavy'] is not None
+    assert dc['heavy']['n_seg'] == 1 + 2 + 5 and dc['light']['n_src'] == 20000 + 8     # ceil(deg / 2048) segments per hub
+    ns, no = starter_nets('n', d, scale=0.5)
+    model = GNNnodeBased(ns, no, d, 6, 0.0)
+    s0 = rng.normal(0, 0.1, (20000, d)).astype(np.float32) if d else None
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k, st, o = model.Loop(*model.process_inputs(x), state0=None if s0 is None else dev(s0))
+        assert float(k) == float(k64)
+        assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL

@@ -212,3 +212,29 @@ def test_model_save_load(tmp_path):
     b = GNNgraphBased.load(str(tmp_path / 'model'))
     assert b.max_iteration == 5 and b.net_state.units == [20, 14] and b.net_state.activations == ['selu', 'tanh']
     assert all(np.array_equal(x, y) for x, y in zip(b.net_state.get_weights(), ns.get_weights()))
+
+
+def test_split_heavy_rows_reconstructs_the_aggregate():
+    """Hub rows are cut into segments that become virtual source rows of a 'light' operator (sparse.split_heavy)."""
+    from gnnkeras_amd.sparse import CSRByDestination, split_heavy
+    rng = np.random.default_rng(0)
+    n = 60
+    pairs = np.unique(np.concatenate([np.stack([rng.integers(0, n, 300), rng.integers(0, n, 300)], 1),
+                                      np.stack([np.arange(n), np.full(n, 7)], 1),
+                                      np.stack([rng.integers(0, n, 40), np.full(40, 9)], 1)]), axis=0)
+    c = CSRByDestination.from_coo(pairs[:, 0], pairs[:, 1], rng.normal(size=len(pairs)).astype(np.float32), (n, n), uniform_rows=False)
+    same, none = split_heavy(c, threshold=10 ** 6)
+    assert same is c and none is None
+    light, heavy = split_heavy(c, threshold=20, segment=16)
+    deg = np.diff(c.rowptr)
+    assert heavy['n_seg'] == int(np.sum(-(-deg[deg > 20] // 16))) and light.n_src == n + heavy['n_seg'] and light.n_dst == n
+    assert np.all(heavy['seg_end'] - heavy['seg_beg'] <= 16) and np.all(heavy['seg_end'] > heavy['seg_beg'])
+    X = rng.normal(size=(n, 3))
+    agg = lambda cc, XX: np.stack([sum((cc.w[e] * XX[cc.src[e]] for e in range(cc.rowptr[j], cc.rowptr[j + 1])), np.zeros(3))
+                                   for j in range(cc.n_dst)])
+    V = np.stack([sum((c.w[e] * X[c.src[e]] for e in range(b, en)), np.zeros(3)) for b, en in zip(heavy['seg_beg'], heavy['seg_end'])])
+    assert np.allclose(agg(light, np.concatenate([X, V])), agg(c, X))
+    # row_scale graphs ('average'): weights stay implicit, virtual arcs need none
+    cu = CSRByDestination.from_coo(pairs[:, 0], pairs[:, 1], (1.0 / deg[pairs[:, 1]]).astype(np.float32), (n, n))
+    lu, hu = split_heavy(cu, threshold=20, segment=16)
+    assert cu.w is None and lu.w is None and lu.row_scale is cu.row_scale

@@ -45,11 +45,17 @@ k_aggregate(const int *gate, int n_dst, const int *__restrict__ rowptr, const in
         const float scale = row_scale ? row_scale[j] : 1.0f;
         for (int f = lane; f < F; f += G) {
             float acc = 0.0f;
-            if (w) {
-                for (int e = beg; e < end; ++e) acc = fmaf(w[e], X[(size_t)src[e] * ldx + f], acc);
-            } else {
-                for (int e = beg; e < end; ++e) acc += X[(size_t)src[e] * ldx + f];
+            int e = beg;
+            for (; e + 8 <= end; e += 8) {          // 8 independent source rows in flight, summed in arc order
+                int sid[8]; float x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sid[i] = src[e + i];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = X[(size_t)sid[i] * ldx + f];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc = w ? fmaf(w[e + i], x[i], acc) : acc + x[i];
             }
+            for (; e < end; ++e) acc = w ? fmaf(w[e], X[(size_t)src[e] * ldx + f], acc) : acc + X[(size_t)src[e] * ldx + f];
             out[(size_t)j * ldo + f] = acc * scale;
         }
     }
@@ -79,72 +85,92 @@ struct SegDenseArgs {
     float *Y; int ldy; const int *out_rowidx;
 };
 
-constexpr int SD_TM = 64, SD_TN = 64, SD_KC = 32, SD_LDX = 34, SD_LDW = 80;
+constexpr int SD_TM = 64, SD_TN = 64, SD_KC = 32, SD_LDX = 34, SD_LDW = 80, SD_LDY = 68;
 
+// K chunks of 32 run over the *virtual* concatenation, so several narrow segments (labels 14 + aggregated labels 14 +
+// aggregated arcs 3) share one chunk.  Staging is lane-contiguous: a wave reads 2 x 128 B of X rows / 256 B of a W row
+// per instruction, and results leave through an LDS tile as 256-B row pieces.
 __global__ void __launch_bounds__(256) k_segdense(SegDenseArgs a) {
     if (gate_closed(a.gate)) return;
     __shared__ float Xs[SD_TM * SD_LDX];
     __shared__ float Ws[SD_KC * SD_LDW];
+    __shared__ float Ys[SD_TM * SD_LDY];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * SD_TM;
+    int K = 0;
+    for (int s = 0; s < a.nseg; ++s) K += a.seg[s].width;
+    const int xc = tid & 31, xr0 = tid >> 5;                    // X staging: chunk column xc, rows xr0 + 8*pass
 
     for (int n0 = 0; n0 < a.H; n0 += SD_TN) {
         f32x4 acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        for (int s = 0; s < a.nseg; ++s) {
-            const Seg sg = a.seg[s];
-            for (int k0 = 0; k0 < sg.width; k0 += SD_KC) {
-                const int kc = min(SD_KC, sg.width - k0);
-                for (int i = tid; i < SD_TM * SD_KC; i += 256) {
-                    const int rr = i / SD_KC, cc = i % SD_KC, m = m0 + rr;
+        for (int k0 = 0; k0 < K; k0 += SD_KC) {
+            // ---- X chunk: this thread's virtual column is fixed, resolve its segment once ----
+            {
+                const int kv = k0 + xc;
+                Seg sg = a.seg[0];                              // static indices only: a runtime-indexed kernel-argument
+                int sbeg = 0, start = a.seg[0].width;           // array would be copied to scratch memory
+#pragma unroll
+                for (int s = 1; s < GNN_MAX_SEGS; ++s) {
+                    if (s < a.nseg && kv >= start) { sg = a.seg[s]; sbeg = start; }
+                    if (s < a.nseg) start += a.seg[s].width;
+                }
+                const int off = kv - sbeg;
+#pragma unroll
+                for (int pass = 0; pass < 8; ++pass) {
+                    const int rr = xr0 + 8 * pass, m = m0 + rr;
                     float v = 0.0f;
-                    if (m < a.M && cc < kc) {
-                        const size_t row = sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m;
-                        v = sg.ptr[row * sg.ld + k0 + cc];
-                    }
-                    Xs[rr * SD_LDX + cc] = v;
-                }
-                for (int i = tid; i < SD_KC * SD_TN; i += 256) {
-                    const int kk = i / SD_TN, nn = i % SD_TN;
-                    float v = 0.0f;
-                    if (kk < kc && n0 + nn < a.H) v = a.W[(size_t)(sg.wrow + k0 + kk) * a.ldw + n0 + nn];
-                    Ws[kk * SD_LDW + nn] = v;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int s4 = 0; s4 < SD_KC / 4; ++s4) {
-                    const float av = Xs[(16 * wave + r) * SD_LDX + 4 * s4 + g];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float bv = Ws[(4 * s4 + g) * SD_LDW + 16 * c + r];
-                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[c], 0, 0, 0);
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        // C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = n0 + 16 * c + r;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int m = m0 + 16 * wave + 4 * g + reg;
-                if (m < a.M && col < a.H) {
-                    float v = acc[c][reg];
-                    if (a.bias) v += a.bias[col];
-                    if (a.addend) {
-                        const size_t ar = a.add_rowidx ? (size_t)a.add_rowidx[m] : (size_t)m;
-                        v += a.addend[ar * a.ld_add + col];
-                    }
-                    const size_t orow = a.out_rowidx ? (size_t)a.out_rowidx[m] : (size_t)m;
-                    a.Y[orow * a.ldy + col] = activate(a.act, v);
+                    if (m < a.M && kv < K) v = sg.ptr[(sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m) * sg.ld + off];
+                    Xs[rr * SD_LDX + xc] = v;
                 }
             }
+            // ---- W chunk: weight rows of the virtual columns (row = seg.wrow + offset inside the segment) ----
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int kk = wave + 4 * pass, kv = k0 + kk;
+                int wrow = a.seg[0].wrow + kv, start = a.seg[0].width;
+#pragma unroll
+                for (int s = 1; s < GNN_MAX_SEGS; ++s) {
+                    if (s < a.nseg && kv >= start) wrow = a.seg[s].wrow + kv - start;
+                    if (s < a.nseg) start += a.seg[s].width;
+                }
+                float v = 0.0f;
+                if (kv < K && n0 + lane < a.H) v = a.W[(size_t)wrow * a.ldw + n0 + lane];
+                Ws[kk * SD_LDW + lane] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s4 = 0; s4 < SD_KC / 4; ++s4) {
+                const float av = Xs[(16 * wave + r) * SD_LDX + 4 * s4 + g];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float bv = Ws[(4 * s4 + g) * SD_LDW + 16 * c + r];
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[c], 0, 0, 0);
+                }
+            }
+            __syncthreads();
         }
+        // C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg  -> LDS tile -> row-contiguous stores
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Ys[(16 * wave + 4 * g + reg) * SD_LDY + 16 * c + r] = acc[c][reg];
+        __syncthreads();
+        const int col = n0 + lane;
+        const float bcol = (a.bias && col < a.H) ? a.bias[col] : 0.0f;
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {                 // a wave writes one 256-B row piece per instruction
+            const int yr = wave + 4 * pass, m = m0 + yr;
+            if (m < a.M && col < a.H) {
+                float v = Ys[yr * SD_LDY + lane] + bcol;
+                if (a.addend) v += a.addend[(a.add_rowidx ? (size_t)a.add_rowidx[m] : (size_t)m) * a.ld_add + col];
+                a.Y[(a.out_rowidx ? (size_t)a.out_rowidx[m] : (size_t)m) * a.ldy + col] = activate(a.act, v);
+            }
+        }
+        __syncthreads();
     }
 }
 

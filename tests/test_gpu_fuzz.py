@@ -120,3 +120,55 @@ def test_fuzz_composite(seed):
         k, st, o = model.Loop(*model.process_inputs(x), state0=torch.from_numpy(s0).cuda())
         assert float(k) == float(k64)
         assert rel_err(st.cpu().numpy(), st64) <= 2e-5 and rel_err(o.cpu().numpy(), o64) <= 2e-5, seed
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_fuzz_training_gradients(seed):
+    """Random train_step configurations against the torch-autograd restatement (gradients, loss, moving statistics)."""
+    from test_gpu_training import check_step, oracle_step
+    rng = np.random.default_rng(9000 + seed)
+    focus = ['g', 'n', 'a'][seed % 3]
+    L, A, T = int(rng.integers(1, 12)), int(rng.integers(0, 4)), int(rng.integers(2, 5))
+    d = int(rng.choice([0, 3, 8, 16, 32, 40]))
+    mode = ['sum', 'average', 'normalized'][int(rng.integers(0, 3))]
+    bn = bool(rng.integers(0, 2))
+    loss, out_act = [('categorical_crossentropy', 'softmax'), ('mse', 'linear'), ('binary_crossentropy', 'sigmoid'),
+                     ('mae', 'tanh')][int(rng.integers(0, 4))]
+    graphs = []
+    for _ in range(int(rng.integers(2, 6))):
+        n = int(rng.integers(3, 60))
+        arcs = random_arcs(rng, n, int(rng.integers(2, 3 * n)), A)
+        cnt = {'n': n, 'a': len(arcs), 'g': n}[focus]
+        om = rng.random(cnt) < 0.7 if focus != 'g' else np.ones(n, bool)
+        om[0] = True
+        sm = rng.random(cnt) < 0.8 if focus != 'g' else np.ones(n, bool)
+        sm[0] = True
+        nt = int(om.sum()) if focus != 'g' else 1
+        t = rng.random((nt, T)); t = t / t.sum(1, keepdims=True)
+        graphs.append(GraphObject(rng.normal(size=(n, L)), arcs, t, focus=focus, set_mask=sm, output_mask=om,
+                                  sample_weight=rng.uniform(0.5, 1.5, nt), aggregation_mode=mode))
+    seq = MultiGraphSequencer(graphs, focus, mode, len(graphs), shuffle=False)
+    x, y, sw = seq[0]
+    inp, lay = get_inout_dims('state', L, A, T, focus, d, hidden_units=[int(rng.integers(3, 30))] if rng.random() < 0.4 else None)
+    ns = MLP(inp[0], lay, ['tanh', 'selu', 'sigmoid', 'softplus'][int(rng.integers(0, 4))], 'lecun_normal', 'lecun_normal',
+             rng=seed, batch_normalization=bn)
+    ns.set_weights([w * 0.3 if w.ndim == 2 else w for w in ns.get_weights()])
+    inp, lay = get_inout_dims('output', L, A, T, focus, d, hidden_units=[6] if rng.random() < 0.4 else None)
+    no = MLP(inp[0], lay, ['tanh'] * (len(lay) - 1) + [out_act], 'glorot_normal', 'glorot_normal', rng=seed + 1,
+             batch_normalization=bn)
+    for n_ in (ns, no):
+        if bn:
+            w = n_.get_weights()
+            w[0] = rng.uniform(.7, 1.3, w[0].shape).astype(np.float32); w[1] = rng.normal(0, .2, w[1].shape).astype(np.float32)
+            n_.set_weights(w)
+    model = {'n': GNNnodeBased, 'a': GNNarcBased, 'g': GNNgraphBased}[focus](ns, no, d, int(rng.integers(1, 7)), 0.0)
+    s0 = rng.normal(0, 0.2, (x[0].shape[0], d)).astype(np.float32) if d else None
+    avg = bool(rng.integers(0, 2))
+    k32, k64 = (oracle_step(model, x, y, sw, s0, loss, avg, dtype=dt)['k'] for dt in (torch.float32, torch.float64))
+    if k32 != k64:      # the float32 state reached an exact fixed point (threshold 0) before float64 did: only k is checked
+        from gnnkeras_amd.Models.training import LoopTrainer, SGD
+        model.compile(optimizer=SGD(0.0), loss=loss, average_st_grads=avg)
+        res = LoopTrainer(model).train_step(x, y, sw, state0=None if s0 is None else torch.from_numpy(s0).cuda(), apply=False)
+        assert res['k'] == k32
+        return
+    check_step(model, x, y, sw, s0, loss=loss, avg=avg)

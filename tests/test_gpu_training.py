@@ -46,14 +46,14 @@ def refocus(graphs, focus, rng):
     return out
 
 
-def oracle_step(model, x, y, sw, s0, loss, avg=False):
+def oracle_step(model, x, y, sw, s0, loss, avg=False, dtype=torch.float64):
     nodes, arcs, _, sm, om, adj, an, ng = x
     mask = np.logical_and(_np(sm).reshape(-1), _np(om).reshape(-1))
     return torch_train.train_step(_np(nodes), _np(arcs), _triple(adj), _triple(an), _triple(ng), mask,
                                   net_state=model.net_state.spec(), net_output=model.net_output.spec(),
                                   state_vect_dim=model.state_vect_dim, max_iteration=model.max_iteration,
                                   state_threshold=model.state_threshold, focus=model._focus, state0=s0, y=_np(y),
-                                  sample_weight=_np(sw), loss=loss, average_st_grads=avg)
+                                  sample_weight=_np(sw), loss=loss, average_st_grads=avg, dtype=dtype)
 
 
 def check_step(model, x, y, sw, s0, loss='categorical_crossentropy', avg=False):

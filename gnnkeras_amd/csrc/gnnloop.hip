@@ -20,6 +20,8 @@
 #include "../../include/gnnloop.h"
 #include "kernels_general.hpp"
 #include "kernel_state_fused2.hpp"
+#include "kernel_state_fused3.hpp"
+#include "kernel_state_fused4.hpp"
 
 namespace {
 
@@ -330,7 +332,7 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     p.agg_arcs = c.take<float>((size_t)p.N * std::max(p.A, 1));
     p.ld_agg_nodes = p.composite ? sum_dt : (a.state_dim > 0 ? p.L : 0);
     p.agg_nodes = c.take<float>((size_t)p.N * std::max(p.ld_agg_nodes, 1));
-    p.ldC = p.H1max;
+    p.ldC = (p.H1max + 3) & ~3;      // rows start 16-B aligned: the wave-specialised fused kernel reads C as float4
     p.C = c.take<float>((size_t)p.N * p.ldC);
     p.n_heavy = a.n_heavy_segments > 0 ? a.n_heavy_segments : 0;
     p.buf[0] = c.take<float>((size_t)(p.N + p.n_heavy) * p.SP + 64);
@@ -494,9 +496,24 @@ int fused_waves() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("GNN_FUSED_WAVES");
-        v = (e && atoi(e) == 4) ? 4 : 8;
+        v = e ? atoi(e) : 0;                    // 0: the kernel generation's own default
     }
     return v;
+}
+
+// Which generation of the fused iteration kernel runs.  GNN_FUSED_KERNEL unset / 0 = automatic:
+//   4  wave-specialised (12 gather waves + 4 matrix waves per workgroup, 32 waves per CU)      <- default for d > 16
+//   2  phase-alternating (every wave gathers, then every wave multiplies; 16 waves per CU)      <- default for d <= 16
+//   3  software-pipelined variant of 2 (gather of tile t+1 under the MFMA of tile t); kept for comparison
+// A tuning knob, never a correctness switch: all three are held to the same parity tests.
+int fused_generation(int SP) {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GNN_FUSED_KERNEL");
+        v = e ? atoi(e) : 0;
+        if (v < 2 || v > 4) v = 0;
+    }
+    return v ? v : (SP > 16 ? 4 : 2);
 }
 
 int device_cus() {
@@ -536,7 +553,9 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;
     }
-    FUSED_OK(gnn::launch_fused2(fa, p.SP, fused_waves(), device_cus(), st));
+    if (fused_generation(p.SP) == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
+    else if (fused_generation(p.SP) == 3) FUSED_OK(gnn::launch_fused3(fa, p.SP, fused_waves() == 8 ? 8 : 12, device_cus(), st));
+    else FUSED_OK(gnn::launch_fused2(fa, p.SP, fused_waves() == 0 ? 8 : fused_waves(), device_cus(), st));
     return 0;
 }
 
@@ -554,6 +573,15 @@ bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
 
 // =====================================================================================================================
 extern "C" {
+
+#ifdef GNN_F4_PROFILE
+// experiment-only: cycle totals of the wave-specialised kernel's phases (not part of the ABI)
+int gnn_f4_profile(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gnn::g_f4_prof), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(gnn::g_f4_prof), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 const char *gnn_last_error(void) { return g_err; }
 int gnn_abi_version(void) { return GNN_ABI_VERSION; }

@@ -67,8 +67,8 @@ struct Fused2Cfg {
     static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)TM * LDX + 2 * SP * LDW) + sizeof(int) * TM;
 };
 
-template <int SP, bool HAS_W, int TM, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) k_state_fused2(Fused2Args a) {
+template <int SP, bool HAS_W, int TM, int NW, int DEPTH>
+__global__ void __launch_bounds__(64 * NW, NW >= 12 ? NW / 2 : (NW == 8 ? 4 : 2)) k_state_fused2(Fused2Args a) {
     {
         int open = a.gate == nullptr;
         for (int i = 0; i < a.n_gate && !open; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
@@ -191,18 +191,22 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) k_state_fused2(Fused
                 int eb = beg0;
 #pragma unroll 1
                 while (true) {
-                    f32x4 v[16];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        // 32-bit byte offset off a wave-uniform base: SGPR base + VGPR offset addressing
-                        const unsigned off = (unsigned)__shfl(idc[i / LPR], i % LPR, LPR) * (unsigned)(SP * 4) + 16u * l4;
-                        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (i < rem) v[i] = *reinterpret_cast<const f32x4 *>(sbase + off);
-                    }
+                    for (int s0 = 0; s0 < 16; s0 += DEPTH) {          // DEPTH rows in flight per lane group
+                        if (s0 > 0 && !__any(s0 < rem)) break;
+                        f32x4 v[DEPTH];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        if (HAS_W) acc += __shfl(wsc[i / LPR], i % LPR, LPR) * v[i];
-                        else acc += v[i];
+                        for (int i = 0; i < DEPTH; ++i) {
+                            // 32-bit byte offset off a wave-uniform base: SGPR base + VGPR offset addressing
+                            const unsigned off = (unsigned)__shfl(idc[(s0 + i) / LPR], (s0 + i) % LPR, LPR) * (unsigned)(SP * 4) + 16u * l4;
+                            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (s0 + i < rem) v[i] = *reinterpret_cast<const f32x4 *>(sbase + off);
+                        }
+#pragma unroll
+                        for (int i = 0; i < DEPTH; ++i) {
+                            if (HAS_W) acc += __shfl(wsc[(s0 + i) / LPR], (s0 + i) % LPR, LPR) * v[i];
+                            else acc += v[i];
+                        }
                     }
                     rem -= 16; eb += 16;
                     if (!__any(rem > 0)) break;
@@ -327,17 +331,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) k_state_fused2(Fused
     }
 }
 
-template <int SP, bool HAS_W, int TM, int NW>
+template <int SP, bool HAS_W, int TM, int NW, int DEPTH = 16>
 int launch_fused2_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     using Cfg = Fused2Cfg<SP, TM, NW>;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)k_state_fused2<SP, HAS_W, TM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)k_state_fused2<SP, HAS_W, TM, NW, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
         attr = true;
     }
     // workgroups per type: proportional to its tiles, whole multiples of 8 (one per XCD), never more than its tiles need
-    const int blocks_per_cu = std::max(1, std::min(NW == 8 ? 2 : (NW == 4 ? 4 : 8), (int)(160 * 1024 / Cfg::LDS_BYTES)));
+    const int blocks_per_cu = std::max(1, std::min(NW >= 8 ? 2 : (NW == 4 ? 4 : 8), (int)(160 * 1024 / Cfg::LDS_BYTES)));
     const int budget = blocks_per_cu * n_cu;
     long total_tiles = 0;
     for (int t = 0; t < fa.n_types; ++t) total_tiles += (fa.tp[t].count + TM - 1) / TM;
@@ -353,7 +357,7 @@ int launch_fused2_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0) return 0;
-    k_state_fused2<SP, HAS_W, TM, NW><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
+    k_state_fused2<SP, HAS_W, TM, NW, DEPTH><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -370,7 +374,14 @@ inline int launch_fused2(Fused2Args &fa, int SP, int waves, int n_cu, hipStream_
     switch (SP) {
         case 16: return launch_fused2_w<16, 64, 4>(fa, n_cu, st);
         case 32: return waves == 8 ? launch_fused2_w<32, 64, 8>(fa, n_cu, st) : launch_fused2_w<32, 64, 4>(fa, n_cu, st);
-        case 64: return waves == 8 ? launch_fused2_w<64, 64, 8>(fa, n_cu, st) : launch_fused2_w<64, 64, 4>(fa, n_cu, st);
+        case 64:
+            if (!fa.w && waves >= 12) {          // experimental high-occupancy shapes: waves = 16|12, depth = waves % 100 ... 
+                const int d = waves / 100;
+                const int w = waves % 100;
+                if (w == 16) return d == 4 ? launch_fused2_one<64, false, 64, 16, 4>(fa, n_cu, st) : launch_fused2_one<64, false, 64, 16, 8>(fa, n_cu, st);
+                if (w == 12) return d == 4 ? launch_fused2_one<64, false, 48, 12, 4>(fa, n_cu, st) : launch_fused2_one<64, false, 48, 12, 8>(fa, n_cu, st);
+            }
+            return waves == 8 ? launch_fused2_w<64, 64, 8>(fa, n_cu, st) : launch_fused2_w<64, 64, 4>(fa, n_cu, st);
         default: return 1;
     }
 }

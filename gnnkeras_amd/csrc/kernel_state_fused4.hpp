@@ -1,0 +1,358 @@
+// Fused state-transition iteration, wave-specialised: gather waves and matrix waves run decoupled.
+// Same contract and arguments as k_state_fused2 (one launch = one iteration of the reference's `convergence` + the
+// `condition` of the next one, GNN/Models/GNN.py:217-236, :196-214, for every node type).
+//
+// Why (measurements in profiles/r01_gather_sweep.txt, scripts/micro/gather_sweep.hip): on this access pattern the
+// memory system rewards the NUMBER OF WAVES with a gather outstanding, not the rows in flight per wave — the bare
+// pattern runs at 7.7-7.9 TB/s (algorithmic) with 8 waves / SIMD at any depth from 2 to 12 rows, and at 5.2-6.2 TB/s
+// with 4 waves / SIMD at any depth.  k_state_fused2 keeps 4 waves / SIMD (128 VGPRs: 16 rows in flight + MFMA) and
+// parks all of them at two barriers per tile.  Here a 1024-thread workgroup (2 per CU = 8 waves / SIMD, 64 VGPRs) is
+// split by role:
+//   * 12 gather waves: each lane group of SP/4 lanes owns a node, walks its CSR row (DEPTH rows in flight), and
+//     drops [own state | neighbour sum] into a 16-row slot of an LDS ring — no barrier anywhere, a wave only ever
+//     waits for its own loads or for a free slot;
+//   * 4 matrix waves (one per SIMD): each takes every 4th 16-row slot, starts from the per-node constant C (loaded
+//     while it waits for the slot to fill), runs [state | agg] . W1 on v_mfma_f32_16x16x4_f32, applies the activation,
+//     evaluates the convergence predicate for whole rows in registers and stores the new rows.
+// Slots are handed over with two monotonic LDS counters per slot (rows filled / rounds consumed): release on the
+// writer's side, acquire on the reader's, both workgroup scope.  Spin loops sleep and are bounded: a protocol bug
+// shows up as a wrong answer in the parity tests, never as a hung GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernel_state_fused2.hpp"
+#include "kernel_state_fused3.hpp"   // raw-buffer load helpers (f3_rsrc, f3_ld_*)
+
+namespace gnn {
+
+template <int SP>
+struct Fused4Cfg {
+    static constexpr int NW = 16, NT = 64 * NW;
+    static constexpr int NCONS = 4;                  // matrix waves (wave ids 0..3: one per SIMD)
+    static constexpr int NPROD = NW - NCONS;         // gather waves
+    static constexpr int LPR = SP / 4;               // lanes per node row (16 B each)
+    static constexpr int RPWV = 64 / LPR;            // rows a gather wave fills per tile
+    static constexpr int PPT = 16 / RPWV;            // gather waves per 16-row tile
+    static constexpr int NG = NPROD / PPT;           // gather groups: group G fills tiles G, G + NG, ...
+    static constexpr int IPL = 16 / LPR;             // source ids held per lane (16 per node and chunk)
+    static constexpr int LDX = 2 * SP + 2;           // A rows: stride == 2 (mod 32) dwords -> conflict-free ds_read_b32
+    static constexpr bool SWZ = SP >= 32;
+    static constexpr int LDW = SWZ ? SP : SP + 32;
+    static constexpr int NCT = SP / 16;              // 16-column MFMA tiles per row tile
+    static constexpr int NS = SP == 64 ? 5 : 8;      // ring slots
+    static constexpr int SLOT = 16 * LDX;            // floats per slot
+    static_assert(NPROD % PPT == 0, "gather waves must split into whole tile groups");
+    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)NS * SLOT + 2 * SP * LDW) + sizeof(int) * 2 * NS;
+};
+
+// the activation of 4 values with ONE wave-uniform switch around them
+__device__ __forceinline__ void activate4(int act, f32x4 &x) {
+#define F4_ALL(expr)                                        \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {         \
+        const float v = x[e];                               \
+        x[e] = (expr);                                      \
+    }
+    switch (act) {
+        case GNN_ACT_RELU: F4_ALL(fmaxf(v, 0.0f)) break;
+        case GNN_ACT_SELU: F4_ALL(v > 0.0f ? 1.0507009873554805f * v : (1.0507009873554805f * 1.6732632423543772f) * (expf(v) - 1.0f)) break;
+        case GNN_ACT_TANH: F4_ALL(tanhf(v)) break;
+        case GNN_ACT_SIGMOID: F4_ALL(1.0f / (1.0f + expf(-v))) break;
+        case GNN_ACT_ELU: F4_ALL(v > 0.0f ? v : expf(v) - 1.0f) break;
+        case GNN_ACT_SOFTPLUS: F4_ALL(v > 20.0f ? v : log1pf(expf(v))) break;
+        default: break;
+    }
+#undef F4_ALL
+}
+
+#ifdef GNN_F4_PROFILE
+__device__ __forceinline__ unsigned long long f4_now() {
+    unsigned long long t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+__device__ unsigned long long g_f4_prof[8];
+#define F4_T0() const unsigned long long t0_ = f4_now()
+#define F4_ACC(slot) if (lane == 0) atomicAdd(&g_f4_prof[slot], f4_now() - t0_)
+#else
+#define F4_T0()
+#define F4_ACC(slot)
+#endif
+
+__device__ __forceinline__ int f4_ld_acquire(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int SP, bool HAS_W, int DEPTH>
+__global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
+    {
+        int open = a.gate == nullptr;
+        for (int i = 0; i < a.n_gate && !open; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
+        if (!open) return;
+    }
+    using Cfg = Fused4Cfg<SP>;
+    constexpr int NT = Cfg::NT, LPR = Cfg::LPR, IPL = Cfg::IPL, LDX = Cfg::LDX, LDW = Cfg::LDW, NS = Cfg::NS;
+    constexpr int SPIN_MAX = 1 << 22;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Xs = reinterpret_cast<float *>(smem);                         // [NS][16][LDX] : [state | agg]
+    float *Ws = Xs + NS * Cfg::SLOT;                                     // [2SP][LDW]    : W1 rows (state ; agg)
+    int *fill = reinterpret_cast<int *>(Ws + 2 * SP * LDW);              // [NS] gather-wave deposits so far
+    int *freed = fill + NS;                                              // [NS] tiles consumed so far
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = a.S;
+    int ty = 0;
+    while (ty + 1 < a.n_types && (int)blockIdx.x >= a.blk_begin[ty + 1]) ++ty;
+    const FusedType tp = a.tp[ty];
+    const int bid = blockIdx.x - a.blk_begin[ty], nblk = a.blk_begin[ty + 1] - a.blk_begin[ty];
+    const int count = tp.count;
+    const int *__restrict__ rows = tp.rows;
+
+    for (int i = tid; i < 2 * SP * SP; i += NT) {
+        const int k = i / SP, n = i % SP;
+        const int kk = k < SP ? k : k - SP;
+        float v = 0.0f;
+        if (kk < S && n < S) v = tp.Wf[(size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + kk) * tp.H + n];
+        Ws[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = v;
+    }
+    if (tid < 2 * NS) fill[tid] = 0;
+    __syncthreads();
+
+    // XCD-contiguous tile ranges (workgroups b, b+8, .. share an XCD under round-robin dispatch; speed only)
+    const int ntiles = (count + 15) / 16;
+    const int xcd = bid & 7, lb = bid >> 3;
+    const int blk_per_xcd = (nblk + 7 - xcd) >> 3;
+    const int tpx = (ntiles + 7) >> 3;
+    const int t_end = min(ntiles, (xcd + 1) * tpx);
+    const int t_first = xcd * tpx + lb;
+    const int T = t_first < t_end ? (t_end - t_first + blk_per_xcd - 1) / blk_per_xcd : 0;   // tiles of this workgroup
+
+    const char *__restrict__ sbase = reinterpret_cast<const char *>(a.state_in);   // < 4 GiB (checked by the launcher)
+    const __amdgpu_buffer_rsrc_t r_C = f3_rsrc(a.C), r_rows = f3_rsrc(tp.rows);
+    char *__restrict__ obase = reinterpret_cast<char *>(a.state_out);
+    int any = 0;
+
+    if (wave >= Cfg::NCONS) {
+        // ================================ gather waves ================================================================
+        const int p = wave - Cfg::NCONS;
+        const int qr = lane / LPR;                 // row of this lane group inside the wave's deposit
+        const int l4 = lane % LPR;                 // 16-B column chunk of the row owned by this lane
+#ifdef GNN_F4_PROFILE
+        const unsigned long long tr_ = f4_now();
+#endif
+        // jobs (tile, part) are dealt round-robin; tile t lives in ring slot t % NS, row = part * RPWV + qr
+        for (int n = p; n < T * Cfg::PPT; n += Cfg::NPROD) {
+            const int t = n / Cfg::PPT;
+            const int row = (n % Cfg::PPT) * Cfg::RPWV + qr;
+            const int m = (t_first + t * blk_per_xcd) * 16 + row;
+            const int j = m < count ? (rows ? rows[m] : m) : -1;
+            unsigned long long tg_ = 0;
+#ifdef GNN_F4_PROFILE
+            tg_ = f4_now();
+#endif
+            int beg = 0, end = 0;
+            f32x4 own = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
+            float scl = 1.0f;
+            if (j >= 0) {
+                beg = a.rowptr[j]; end = a.rowptr[j + 1];
+                own = *reinterpret_cast<const f32x4 *>(sbase + ((unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * l4));
+                if (a.row_scale) scl = a.row_scale[j];
+            }
+            int rem = end - beg, eb = beg;
+#pragma unroll 1
+            while (__any(rem > 0)) {
+                int idc[IPL]; float wsc[IPL];
+#pragma unroll
+                for (int u = 0; u < IPL; ++u) {     // the next 16 source ids of the node: one coalesced load per lane group
+                    const int e = eb + u * LPR + l4;
+                    idc[u] = e < end ? a.src[e] : 0;
+                    wsc[u] = (HAS_W && e < end) ? a.w[e] : 0.0f;
+                }
+#pragma unroll
+                for (int s0 = 0; s0 < 16; s0 += DEPTH) {          // DEPTH rows in flight, summed in ascending-source order
+                    if (s0 > 0 && !__any(s0 < rem)) break;
+                    f32x4 v[DEPTH];
+#pragma unroll
+                    for (int i = 0; i < DEPTH; ++i) {
+                        const unsigned off = (unsigned)__shfl(idc[(s0 + i) / LPR], (s0 + i) % LPR, LPR) * (unsigned)(SP * 4) + 16u * l4;
+                        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (s0 + i < rem) v[i] = *reinterpret_cast<const f32x4 *>(sbase + off);
+                    }
+#pragma unroll
+                    for (int i = 0; i < DEPTH; ++i) {
+                        if (HAS_W) acc += __shfl(wsc[(s0 + i) / LPR], (s0 + i) % LPR, LPR) * v[i];
+                        else acc += v[i];
+                    }
+                }
+                rem -= 16; eb += 16;
+            }
+            acc *= scl;
+
+            const int s = t % NS, round = t / NS;
+#ifdef GNN_F4_PROFILE
+            if (lane == 0) atomicAdd(&g_f4_prof[0], f4_now() - tg_);
+            tg_ = f4_now();
+#endif
+            for (int spin = 0; f4_ld_acquire(&freed[s]) < round && spin < SPIN_MAX; ++spin) __builtin_amdgcn_s_sleep(1);
+#ifdef GNN_F4_PROFILE
+            if (lane == 0) atomicAdd(&g_f4_prof[1], f4_now() - tg_);
+#endif
+            float *xr = Xs + s * Cfg::SLOT + row * LDX + 4 * l4;     // rows are 8-B aligned: two b64 stores each
+            *reinterpret_cast<float2 *>(xr) = make_float2(own[0], own[1]);
+            *reinterpret_cast<float2 *>(xr + 2) = make_float2(own[2], own[3]);
+            *reinterpret_cast<float2 *>(xr + SP) = make_float2(acc[0], acc[1]);
+            *reinterpret_cast<float2 *>(xr + SP + 2) = make_float2(acc[2], acc[3]);
+            if (l4 == 0) Xs[s * Cfg::SLOT + row * LDX + 2 * SP] = __int_as_float(j);      // the row's pad words carry its node id
+            if (lane == 0) __hip_atomic_fetch_add(&fill[s], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#ifdef GNN_F4_PROFILE
+        if (lane == 0) atomicAdd(&g_f4_prof[6], f4_now() - tr_);
+#endif
+    } else {
+        // ================================ matrix waves ================================================================
+        // MFMA fragments: A row / B-C column = lane & 15, k / C row group = lane >> 4.  The epilogue runs row-major instead
+        // (row 4*i + g, columns 4r .. 4r+3: whole 256-B rows per 16 lanes) on values passed through the slot's agg half.
+        const int r = lane & 15, g = lane >> 4;
+#ifdef GNN_F4_PROFILE
+        const unsigned long long tr_ = f4_now();
+#endif
+        for (int t = wave; t < T; t += Cfg::NCONS) {
+            // accumulators start from the per-node constant: D = [state|agg].W1 + C  (col = 16*ci + r, row = 4*g + reg).
+            // Raw buffer loads (predicated off = out of range = 0): branch-free, all 4*NCT in flight at once, issued
+            // BEFORE the slot is ready so they land while the gather waves fill it.
+            f32x4 c[Cfg::NCT];
+            {
+                int jrow[4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int m = (t_first + t * blk_per_xcd) * 16 + 4 * g + reg;
+                    const int jr = f3_ld_i32(r_rows, m < count ? 4u * (unsigned)m : F3_OFF);
+                    jrow[reg] = m < count ? (rows ? jr : m) : -1;
+                }
+#pragma unroll
+                for (int ci = 0; ci < Cfg::NCT; ++ci) {
+                    const int col = 16 * ci + r;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        c[ci][reg] = f3_ld_f32(r_C, (jrow[reg] >= 0 && col < S) ? ((unsigned)jrow[reg] * (unsigned)a.ldC + (unsigned)col) * 4u : F3_OFF);
+                }
+            }
+            const int s = t % NS, round = t / NS;
+            unsigned long long tc_ = 0;
+#ifdef GNN_F4_PROFILE
+            tc_ = f4_now();
+#endif
+            for (int spin = 0; f4_ld_acquire(&fill[s]) < Cfg::PPT * (round + 1) && spin < SPIN_MAX; ++spin) __builtin_amdgcn_s_sleep(1);
+#ifdef GNN_F4_PROFILE
+            if (lane == 0) { atomicAdd(&g_f4_prof[2], f4_now() - tc_); atomicAdd(&g_f4_prof[5], 1ull); }
+            tc_ = f4_now();
+#endif
+            float *X = Xs + s * Cfg::SLOT;
+            const float *xrow = X + r * LDX + g;
+#pragma unroll 2
+            for (int s4 = 0; s4 < 2 * SP / 4; ++s4) {
+                const float av = xrow[4 * s4];
+                const int k = 4 * s4 + g;
+#pragma unroll
+                for (int ci = 0; ci < Cfg::NCT; ++ci) {
+                    const int n = 16 * ci + r;
+                    const float bv = Ws[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)];
+                    c[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c[ci], 0, 0, 0);
+                }
+            }
+#ifdef GNN_F4_PROFILE
+            { const unsigned long long tm_ = f4_now(); if (lane == 0) atomicAdd(&g_f4_prof[3], tm_ - tc_); tc_ = tm_; }
+#endif
+            // accumulator layout -> row-major through the agg half of the slot (dead after the loop; same-wave LDS traffic
+            // is ordered, and no other wave touches the slot before `freed` moves)
+#pragma unroll
+            for (int ci = 0; ci < Cfg::NCT; ++ci)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) X[(4 * g + reg) * LDX + SP + 16 * ci + r] = c[ci][reg];
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                const float *px = X + (4 * i + g) * LDX;
+                const int j = __float_as_int(px[2 * SP]);              // node id left by the gather wave (-1 = pad row)
+                float d2 = 0.0f, n2 = 0.0f;
+                if (4 * r < SP) {
+                    const float2 plo = *reinterpret_cast<const float2 *>(px + SP + 4 * r), phi = *reinterpret_cast<const float2 *>(px + SP + 4 * r + 2);
+                    const float2 olo = *reinterpret_cast<const float2 *>(px + 4 * r), ohi = *reinterpret_cast<const float2 *>(px + 4 * r + 2);
+                    f32x4 nv = {plo.x, plo.y, phi.x, phi.y};
+                    const f32x4 ov = {olo.x, olo.y, ohi.x, ohi.y};
+                    activate4(tp.act, nv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        nv[e] = (j >= 0 && 4 * r + e < S) ? nv[e] : 0.0f;
+                        const float d = nv[e] - ov[e];
+                        d2 = fmaf(d, d, d2);
+                        n2 = fmaf(ov[e], ov[e], n2);
+                    }
+                    if (j >= 0)
+                        *reinterpret_cast<f32x4 *>(obase + ((unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * r)) = nv;
+                }
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) {
+                    d2 += __shfl_xor(d2, off, 16);
+                    n2 += __shfl_xor(n2, off, 16);
+                }
+                if (j >= 0 && sqrtf(d2) > a.thr * sqrtf(n2)) any = 1;
+            }
+#ifdef GNN_F4_PROFILE
+            if (lane == 0) atomicAdd(&g_f4_prof[4], f4_now() - tc_);
+#endif
+            if (lane == 0) __hip_atomic_store(&freed[s], round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#ifdef GNN_F4_PROFILE
+        if (lane == 0) atomicAdd(&g_f4_prof[7], f4_now() - tr_);
+#endif
+    }
+
+    any = __syncthreads_or(any);
+    if (tid == 0) {
+        if (any && a.flag_next) atomicOr(a.flag_next, 1);
+        if (blockIdx.x == 0 && a.k_out) *a.k_out = a.k_val;
+    }
+}
+
+template <int SP, bool HAS_W, int DEPTH>
+int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
+    using Cfg = Fused4Cfg<SP>;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
+        attr = true;
+    }
+    const int budget = 2 * n_cu;                 // 2 workgroups (32 waves) per CU, all co-resident
+    long total_tiles = 0;
+    for (int t = 0; t < fa.n_types; ++t) total_tiles += (fa.tp[t].count + 15) / 16;
+    fa.blk_begin[0] = 0;
+    for (int t = 0; t < fa.n_types; ++t) {
+        const int ntiles = (fa.tp[t].count + 15) / 16;
+        int nb = 0;
+        if (ntiles > 0) {
+            // a workgroup wants >= 16 tiles to keep its 12 gather waves busy; never more workgroups than that allows
+            nb = (int)std::min<long>((ntiles + 15) / 16, std::max<long>(8, budget * (long)ntiles / std::max<long>(total_tiles, 1)));
+            nb = std::max(8, nb / 8 * 8);          // multiples of 8 (one per XCD), rounded DOWN: the grid stays co-resident
+        }
+        fa.blk_begin[t + 1] = fa.blk_begin[t] + nb;
+    }
+    const int grid = fa.blk_begin[fa.n_types];
+    if (grid == 0) return 0;
+    k_state_fused4<SP, HAS_W, DEPTH><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+inline int launch_fused4(Fused2Args &fa, int SP, int depth, int n_cu, hipStream_t st) {
+#define F4_CASE(SPV)                                                                                                  \
+    case SPV:                                                                                                         \
+        if (fa.w) return launch_fused4_one<SPV, true, 4>(fa, n_cu, st);                                                \
+        return depth == 8 ? launch_fused4_one<SPV, false, 8>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4>(fa, n_cu, st);
+    switch (SP) {
+        F4_CASE(16)
+        F4_CASE(32)
+        F4_CASE(64)
+        default: return 1;
+    }
+#undef F4_CASE
+}
+
+}  // namespace gnn

@@ -502,18 +502,20 @@ int fused_waves() {
 }
 
 // Which generation of the fused iteration kernel runs.  GNN_FUSED_KERNEL unset / 0 = automatic:
-//   4  wave-specialised (12 gather waves + 4 matrix waves per workgroup, 32 waves per CU)      <- default for d > 16
-//   2  phase-alternating (every wave gathers, then every wave multiplies; 16 waves per CU)      <- default for d <= 16
+//   4  wave-specialised (12 gather waves + 4 matrix waves per workgroup, 32 waves per CU)      <- d > 16 and >= 32768 nodes
+//   2  phase-alternating (every wave gathers, then every wave multiplies; 16 waves per CU)      <- d <= 16 or small graphs
+//      (measured crossover on ER graphs with 10 arcs / node, d = 64: 17.2 vs 16.4 us at 2e3 nodes, 28.3 vs 28.5 at 3e4,
+//       60 vs 74 at 1e5, 480 vs 542 at 1e6)
 //   3  software-pipelined variant of 2 (gather of tile t+1 under the MFMA of tile t); kept for comparison
 // A tuning knob, never a correctness switch: all three are held to the same parity tests.
-int fused_generation(int SP) {
+int fused_generation(int SP, int n_nodes) {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("GNN_FUSED_KERNEL");
         v = e ? atoi(e) : 0;
         if (v < 2 || v > 4) v = 0;
     }
-    return v ? v : (SP > 16 ? 4 : 2);
+    return v ? v : ((SP > 16 && n_nodes >= 32768) ? 4 : 2);
 }
 
 int device_cus() {
@@ -553,8 +555,8 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;
     }
-    if (fused_generation(p.SP) == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
-    else if (fused_generation(p.SP) == 3) FUSED_OK(gnn::launch_fused3(fa, p.SP, fused_waves() == 8 ? 8 : 12, device_cus(), st));
+    if (fused_generation(p.SP, p.N) == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
+    else if (fused_generation(p.SP, p.N) == 3) FUSED_OK(gnn::launch_fused3(fa, p.SP, fused_waves() == 8 ? 8 : 12, device_cus(), st));
     else FUSED_OK(gnn::launch_fused2(fa, p.SP, fused_waves() == 0 ? 8 : fused_waves(), device_cus(), st));
     return 0;
 }

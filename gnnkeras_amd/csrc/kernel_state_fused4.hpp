@@ -17,6 +17,10 @@
 // Slots are handed over with two monotonic LDS counters per slot (rows filled / rounds consumed): release on the
 // writer's side, acquire on the reader's, both workgroup scope.  Spin loops sleep and are bounded: a protocol bug
 // shows up as a wrong answer in the parity tests, never as a hung GPU.
+// Every global load on either side is a raw buffer load whose offset is out of range when predicated off: no branch
+// ever surrounds a memory operation, so hipcc's waits are exact counts (with `cond ? *p : 0` it wrapped each of the
+// matrix waves' 16 C loads in its own exec-mask branch + vmcnt(0): 16 serial round trips per tile, 620 us/iteration
+// instead of 480).  C4: 480 us/iteration = 7.0 TB/s algorithmic = 88 % of 8 TB/s; the bare pattern's best is 428 us.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernel_state_fused2.hpp"
@@ -24,15 +28,14 @@
 
 namespace gnn {
 
-template <int SP>
+template <int SP, int NC = 4>
 struct Fused4Cfg {
     static constexpr int NW = 16, NT = 64 * NW;
-    static constexpr int NCONS = 4;                  // matrix waves (wave ids 0..3: one per SIMD)
+    static constexpr int NCONS = NC;                 // matrix waves (wave ids 0..NC-1)
     static constexpr int NPROD = NW - NCONS;         // gather waves
     static constexpr int LPR = SP / 4;               // lanes per node row (16 B each)
     static constexpr int RPWV = 64 / LPR;            // rows a gather wave fills per tile
     static constexpr int PPT = 16 / RPWV;            // gather waves per 16-row tile
-    static constexpr int NG = NPROD / PPT;           // gather groups: group G fills tiles G, G + NG, ...
     static constexpr int IPL = 16 / LPR;             // source ids held per lane (16 per node and chunk)
     static constexpr int LDX = 2 * SP + 2;           // A rows: stride == 2 (mod 32) dwords -> conflict-free ds_read_b32
     static constexpr bool SWZ = SP >= 32;
@@ -40,7 +43,6 @@ struct Fused4Cfg {
     static constexpr int NCT = SP / 16;              // 16-column MFMA tiles per row tile
     static constexpr int NS = SP == 64 ? 5 : 8;      // ring slots
     static constexpr int SLOT = 16 * LDX;            // floats per slot
-    static_assert(NPROD % PPT == 0, "gather waves must split into whole tile groups");
     static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)NS * SLOT + 2 * SP * LDW) + sizeof(int) * 2 * NS;
 };
 
@@ -81,14 +83,14 @@ __device__ __forceinline__ int f4_ld_acquire(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int SP, bool HAS_W, int DEPTH>
+template <int SP, bool HAS_W, int DEPTH, int NC>
 __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     {
         int open = a.gate == nullptr;
         for (int i = 0; i < a.n_gate && !open; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
         if (!open) return;
     }
-    using Cfg = Fused4Cfg<SP>;
+    using Cfg = Fused4Cfg<SP, NC>;
     constexpr int NT = Cfg::NT, LPR = Cfg::LPR, IPL = Cfg::IPL, LDX = Cfg::LDX, LDW = Cfg::LDW, NS = Cfg::NS;
     constexpr int SPIN_MAX = 1 << 22;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,8 +127,10 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     const int t_first = xcd * tpx + lb;
     const int T = t_first < t_end ? (t_end - t_first + blk_per_xcd - 1) / blk_per_xcd : 0;   // tiles of this workgroup
 
-    const char *__restrict__ sbase = reinterpret_cast<const char *>(a.state_in);   // < 4 GiB (checked by the launcher)
-    const __amdgpu_buffer_rsrc_t r_C = f3_rsrc(a.C), r_rows = f3_rsrc(tp.rows);
+    const __amdgpu_buffer_rsrc_t r_C = f3_rsrc(a.C), r_rows = f3_rsrc(tp.rows), r_state = f3_rsrc(a.state_in),
+                                 r_rowptr = f3_rsrc(a.rowptr), r_src = f3_rsrc(a.src), r_w = f3_rsrc(HAS_W ? a.w : nullptr),
+                                 r_scale = f3_rsrc(a.row_scale);
+    const bool has_scale = a.row_scale != nullptr;
     char *__restrict__ obase = reinterpret_cast<char *>(a.state_out);
     int any = 0;
 
@@ -138,43 +142,66 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
 #ifdef GNN_F4_PROFILE
         const unsigned long long tr_ = f4_now();
 #endif
-        // jobs (tile, part) are dealt round-robin; tile t lives in ring slot t % NS, row = part * RPWV + qr
-        for (int n = p; n < T * Cfg::PPT; n += Cfg::NPROD) {
+        // jobs (tile, part) are dealt round-robin; tile t lives in ring slot t % NS, row = part * RPWV + qr.
+        // Every load is a raw buffer load (predicated off = out of range = 0): no branches around memory operations, so
+        // the waits hipcc inserts are exact counts.  The dependent chain  node id -> row pointers -> source ids -> rows
+        // is cut by fetching the NEXT job's row pointers and first 16 source ids while this job's rows are in flight.
+        const int njobs = T * Cfg::PPT;
+        auto job_m = [&](int n) -> int {            // global row number of this lane group's node in job n (-1: none)
+            const int m = (t_first + (n / Cfg::PPT) * blk_per_xcd) * 16 + (n % Cfg::PPT) * Cfg::RPWV + qr;
+            return (n < njobs && m < count) ? m : -1;
+        };
+        auto node_of = [&](int m) -> int {
+            const int jr = f3_ld_i32(r_rows, m >= 0 ? 4u * (unsigned)m : F3_OFF);
+            return m >= 0 ? (rows ? jr : m) : -1;
+        };
+        int jA = node_of(job_m(p)), jB = node_of(job_m(p + Cfg::NPROD));
+        int begA = f3_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA : F3_OFF), endA = f3_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA + 4u : F3_OFF);
+        int idsA[IPL]; float wsA[IPL];
+#pragma unroll
+        for (int u = 0; u < IPL; ++u) {
+            const int e = begA + u * LPR + l4;
+            idsA[u] = f3_ld_i32(r_src, e < endA ? 4u * (unsigned)e : F3_OFF);
+            wsA[u] = HAS_W ? f3_ld_f32(r_w, e < endA ? 4u * (unsigned)e : F3_OFF) : 0.0f;
+        }
+        for (int n = p; n < njobs; n += Cfg::NPROD) {
             const int t = n / Cfg::PPT;
             const int row = (n % Cfg::PPT) * Cfg::RPWV + qr;
-            const int m = (t_first + t * blk_per_xcd) * 16 + row;
-            const int j = m < count ? (rows ? rows[m] : m) : -1;
-            unsigned long long tg_ = 0;
+            const int j = jA;
 #ifdef GNN_F4_PROFILE
-            tg_ = f4_now();
+            unsigned long long tg_ = f4_now();
 #endif
-            int beg = 0, end = 0;
-            f32x4 own = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
-            float scl = 1.0f;
-            if (j >= 0) {
-                beg = a.rowptr[j]; end = a.rowptr[j + 1];
-                own = *reinterpret_cast<const f32x4 *>(sbase + ((unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * l4));
-                if (a.row_scale) scl = a.row_scale[j];
-            }
-            int rem = end - beg, eb = beg;
-#pragma unroll 1
-            while (__any(rem > 0)) {
-                int idc[IPL]; float wsc[IPL];
+            // next job: row pointers now, node id of the job after it
+            const int begB = f3_ld_i32(r_rowptr, jB >= 0 ? 4u * (unsigned)jB : F3_OFF);
+            const int endB = f3_ld_i32(r_rowptr, jB >= 0 ? 4u * (unsigned)jB + 4u : F3_OFF);
+            const int jC = node_of(job_m(n + 2 * Cfg::NPROD));
+            const float scl = f3_ld_f32(r_scale, j >= 0 ? 4u * (unsigned)j : F3_OFF);
+            const f32x4 own = f3_ld_f32x4(r_state, j >= 0 ? (unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * l4 : F3_OFF);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            int idsB[IPL]; float wsB[IPL];
+            int rem = endA - begA, eb = begA;
+            int idc[IPL]; float wsc[IPL];
 #pragma unroll
-                for (int u = 0; u < IPL; ++u) {     // the next 16 source ids of the node: one coalesced load per lane group
-                    const int e = eb + u * LPR + l4;
-                    idc[u] = e < end ? a.src[e] : 0;
-                    wsc[u] = (HAS_W && e < end) ? a.w[e] : 0.0f;
-                }
+            for (int u = 0; u < IPL; ++u) { idc[u] = idsA[u]; wsc[u] = wsA[u]; }
+            bool first = true;
+#pragma unroll 1
+            while (true) {
 #pragma unroll
                 for (int s0 = 0; s0 < 16; s0 += DEPTH) {          // DEPTH rows in flight, summed in ascending-source order
                     if (s0 > 0 && !__any(s0 < rem)) break;
                     f32x4 v[DEPTH];
 #pragma unroll
                     for (int i = 0; i < DEPTH; ++i) {
-                        const unsigned off = (unsigned)__shfl(idc[(s0 + i) / LPR], (s0 + i) % LPR, LPR) * (unsigned)(SP * 4) + 16u * l4;
-                        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (s0 + i < rem) v[i] = *reinterpret_cast<const f32x4 *>(sbase + off);
+                        const unsigned sid = (unsigned)__shfl(idc[(s0 + i) / LPR], (s0 + i) % LPR, LPR);
+                        v[i] = f3_ld_f32x4(r_state, s0 + i < rem ? sid * (unsigned)(SP * 4) + 16u * l4 : F3_OFF);
+                    }
+                    if (s0 == 0 && first) {        // the next job's row pointers have landed by now: fetch its first 16 source ids
+#pragma unroll
+                        for (int u = 0; u < IPL; ++u) {
+                            const int e = begB + u * LPR + l4;
+                            idsB[u] = f3_ld_i32(r_src, e < endB ? 4u * (unsigned)e : F3_OFF);
+                            wsB[u] = HAS_W ? f3_ld_f32(r_w, e < endB ? 4u * (unsigned)e : F3_OFF) : 0.0f;
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < DEPTH; ++i) {
@@ -182,9 +209,21 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                         else acc += v[i];
                     }
                 }
+                first = false;
                 rem -= 16; eb += 16;
+                if (!__any(rem > 0)) break;
+#pragma unroll
+                for (int u = 0; u < IPL; ++u) {     // in-degree > 16: the next 16 source ids, one coalesced load per lane group
+                    const int e = eb + u * LPR + l4;
+                    idc[u] = f3_ld_i32(r_src, e < endA ? 4u * (unsigned)e : F3_OFF);
+                    wsc[u] = HAS_W ? f3_ld_f32(r_w, e < endA ? 4u * (unsigned)e : F3_OFF) : 0.0f;
+                }
             }
-            acc *= scl;
+            if (has_scale) acc *= scl;
+            // rotate: A <- B <- C
+            jA = jB; begA = begB; endA = endB; jB = jC;
+#pragma unroll
+            for (int u = 0; u < IPL; ++u) { idsA[u] = idsB[u]; wsA[u] = wsB[u]; }
 
             const int s = t % NS, round = t / NS;
 #ifdef GNN_F4_PROFILE
@@ -236,9 +275,8 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                 }
             }
             const int s = t % NS, round = t / NS;
-            unsigned long long tc_ = 0;
 #ifdef GNN_F4_PROFILE
-            tc_ = f4_now();
+            unsigned long long tc_ = f4_now();
 #endif
             for (int spin = 0; f4_ld_acquire(&fill[s]) < Cfg::PPT * (round + 1) && spin < SPIN_MAX; ++spin) __builtin_amdgcn_s_sleep(1);
 #ifdef GNN_F4_PROFILE
@@ -312,12 +350,12 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     }
 }
 
-template <int SP, bool HAS_W, int DEPTH>
+template <int SP, bool HAS_W, int DEPTH, int NC = 4>
 int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
-    using Cfg = Fused4Cfg<SP>;
+    using Cfg = Fused4Cfg<SP, NC>;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH, NC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
         attr = true;
     }
@@ -329,15 +367,15 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
         const int ntiles = (fa.tp[t].count + 15) / 16;
         int nb = 0;
         if (ntiles > 0) {
-            // a workgroup wants >= 16 tiles to keep its 12 gather waves busy; never more workgroups than that allows
-            nb = (int)std::min<long>((ntiles + 15) / 16, std::max<long>(8, budget * (long)ntiles / std::max<long>(total_tiles, 1)));
+            // a workgroup wants >= 4 tiles (one per matrix wave, 16 gather jobs); never more workgroups than that allows
+            nb = (int)std::min<long>((ntiles + 3) / 4, std::max<long>(8, budget * (long)ntiles / std::max<long>(total_tiles, 1)));
             nb = std::max(8, nb / 8 * 8);          // multiples of 8 (one per XCD), rounded DOWN: the grid stays co-resident
         }
         fa.blk_begin[t + 1] = fa.blk_begin[t] + nb;
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0) return 0;
-    k_state_fused4<SP, HAS_W, DEPTH><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
+    k_state_fused4<SP, HAS_W, DEPTH, NC><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -508,7 +508,9 @@ int fused_waves() {
 //       60 vs 74 at 1e5, 480 vs 542 at 1e6)
 //   3  software-pipelined variant of 2 (gather of tile t+1 under the MFMA of tile t); kept for comparison
 // A tuning knob, never a correctness switch: all three are held to the same parity tests.
-int fused_generation(int SP, int n_nodes) {
+int fused_generation(int SP, int n_nodes, int flags) {
+    const int pinned = (flags & GNN_FLAG_FUSED_GEN_MASK) >> 4;
+    if (pinned >= 2 && pinned <= 4) return pinned;
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("GNN_FUSED_KERNEL");
@@ -555,8 +557,8 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;
     }
-    if (fused_generation(p.SP, p.N) == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
-    else if (fused_generation(p.SP, p.N) == 3) FUSED_OK(gnn::launch_fused3(fa, p.SP, fused_waves() == 8 ? 8 : 12, device_cus(), st));
+    if (fused_generation(p.SP, p.N, a.flags) == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
+    else if (fused_generation(p.SP, p.N, a.flags) == 3) FUSED_OK(gnn::launch_fused3(fa, p.SP, fused_waves() == 8 ? 8 : 12, device_cus(), st));
     else FUSED_OK(gnn::launch_fused2(fa, p.SP, fused_waves() == 0 ? 8 : fused_waves(), device_cus(), st));
     return 0;
 }

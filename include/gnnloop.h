@@ -37,7 +37,11 @@ enum gnn_focus { GNN_FOCUS_NODE = 0, GNN_FOCUS_ARC = 1, GNN_FOCUS_GRAPH = 2 };
 
 enum gnn_flags {
     GNN_FLAG_UNFUSED = 1,      /* run the iteration as separate aggregate / dense / predicate kernels            */
-    GNN_FLAG_NO_EARLY_EXIT = 2 /* debugging: ignore the convergence predicate (always max_iteration iterations)  */
+    GNN_FLAG_NO_EARLY_EXIT = 2,/* debugging: ignore the convergence predicate (always max_iteration iterations)  */
+    /* testing / tuning: pin the generation of the fused iteration kernel instead of the size-based choice
+     * (2 = phase-alternating, 3 = software-pipelined, 4 = wave-specialised).  Results are the same within float32
+     * summation order; the GNN_FUSED_KERNEL environment variable has the same effect process-wide. */
+    GNN_FLAG_FUSED_GEN2 = 2 << 4, GNN_FLAG_FUSED_GEN3 = 3 << 4, GNN_FLAG_FUSED_GEN4 = 4 << 4, GNN_FLAG_FUSED_GEN_MASK = 7 << 4
 };
 
 /* A sparse operator A (n_src x n_dst, COO in the reference: tf.SparseTensor) stored as the CSR of its transpose:

@@ -13,6 +13,8 @@ from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer, Composi
 from oracle.harness import oracle_loop, oracle_composite_loop, rel_err
 
 pytestmark = pytest.mark.gpu
+# every way the iteration can run: size-based default, un-fused kernels, and each fused-kernel generation pinned
+PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN3, nat.FLAG_FUSED_GEN4)
 ACTS = ['selu', 'tanh', 'relu', 'sigmoid', 'linear', 'elu', 'softplus']
 
 
@@ -71,7 +73,7 @@ def test_fuzz_homogeneous(seed):
     s0 = rng.normal(0, 0.3, (N, d)).astype(np.float32) if d else None
     k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
     k32, st32, o32 = oracle_loop(model, x, s0, np.float32)
-    for flags in (0, nat.FLAG_UNFUSED):
+    for flags in PATHS:
         model.native_flags = flags
         k, st, o = model.Loop(*model.process_inputs(x), state0=None if s0 is None else torch.from_numpy(s0).cuda())
         if thr == 0.0 or float(k32) == float(k64):                   # k pinned, or both oracles agree on it
@@ -115,7 +117,7 @@ def test_fuzz_composite(seed):
     N = x[0].shape[0]
     s0 = rng.normal(0, 0.3, (N, D)).astype(np.float32)
     k64, st64, o64 = oracle_composite_loop(model, x, s0, np.float64)
-    for flags in (0, nat.FLAG_UNFUSED):
+    for flags in PATHS:
         model.native_flags = flags
         k, st, o = model.Loop(*model.process_inputs(x), state0=torch.from_numpy(s0).cuda())
         assert float(k) == float(k64)

@@ -20,6 +20,8 @@ from oracle import gnn_oracle as O
 from oracle.harness import oracle_loop, oracle_composite_loop, rel_err
 
 pytestmark = pytest.mark.gpu
+# every way the iteration can run: size-based default, un-fused kernels, and each fused-kernel generation pinned
+PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN3, nat.FLAG_FUSED_GEN4)
 TOL = 1e-5
 CLS = {'n': GNNnodeBased, 'a': GNNarcBased, 'g': GNNgraphBased}
 CCLS = {'n': CompositeGNNnodeBased, 'a': CompositeGNNarcBased, 'g': CompositeGNNgraphBased}
@@ -57,7 +59,7 @@ def check(model, x, s0, tol=TOL, pin_k=True, oracle=oracle_loop):
     k64, st64, o64 = oracle(model, x, s0, np.float64)
     k32, st32, o32 = oracle(model, x, s0, np.float32)
     res = {}
-    for flags in (0, nat.FLAG_UNFUSED):
+    for flags in PATHS:
         model.native_flags = flags
         k, st, o = model.Loop(*model.process_inputs(x), state0=None if s0 is None else dev(s0))
         torch.cuda.synchronize()
@@ -327,7 +329,7 @@ def test_convergence_step_matches_oracle(mutag_graphs):
     agg_arcs = O.sparse_dense_matmul_adjoint(an.indices, an.values, np.array(an.shape), arcs.cpu().numpy()[:, 2:], np.float64)
     want = O.convergence(s.astype(np.float64), nodes.cpu().numpy().astype(np.float64), a, agg_nodes, agg_arcs,
                          ns.spec(), 32, False, np.float64)
-    for flags in (0, nat.FLAG_UNFUSED):
+    for flags in PATHS:
         model.native_flags = flags
         k1, new, old, *_ = model.convergence(0, dev(s), None, nodes, adj, None, None, False, arcs=arcs, arcnode=an)
         assert k1 == 1 and rel_err(new.cpu().numpy(), want) <= TOL
@@ -413,7 +415,7 @@ def test_c3_er_100k_1m(mode):
     k32, st32, o32 = oracle_loop(model, x, s0, np.float32, exact_order=False)
     k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
     outs = {}
-    for flags in (0, nat.FLAG_UNFUSED):
+    for flags in PATHS:
         model.native_flags = flags
         k, st, o = model.Loop(*model.process_inputs(x), state0=dev(s0))
         assert float(k) == 3.0 == float(k32)
@@ -515,7 +517,7 @@ def test_sharded_native_kernels_match_oracle(R, threshold):
     x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
     k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
     if threshold > 0: assert 1 < k64 < 12
-    for flags in (0, nat.FLAG_UNFUSED):
+    for flags in PATHS:
         model.native_flags = flags
         ks, st, o = _run_shards_on_one_gpu(model, g, s0, R)
         assert all(k == float(k64) for k in ks), (ks, k64)
@@ -551,7 +553,7 @@ def test_sharded_composite_native_kernels_match_oracle(R, mode):
     s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
     x = CompositeMultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
     k64, st64, o64 = oracle_composite_loop(model, x, s0, np.float64)
-    for flags in (0, nat.FLAG_UNFUSED):
+    for flags in PATHS:
         model.native_flags = flags
         ks, st, o = _run_shards_on_one_gpu(model, g, s0, R)
         assert all(k == float(k64) for k in ks)
@@ -600,7 +602,7 @@ def test_halo_sharded_native_kernels_match_oracle(R, threshold):
     s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
     x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
     k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
-    for flags in (0, nat.FLAG_UNFUSED):
+    for flags in PATHS:
         model.native_flags = flags
         ks, st, o = _run_halo_shards_on_one_gpu(model, g, s0, R)
         assert all(k == float(k64) for k in ks), (ks, k64)
@@ -670,7 +672,7 @@ def test_hub_rows_use_the_segment_prepass(mode, weights, d):
     model = GNNnodeBased(ns, no, d, 6, 0.0)
     s0 = rng.normal(0, 0.1, (20000, d)).astype(np.float32) if d else None
     k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
-    for flags in (0, nat.FLAG_UNFUSED):
+    for flags in PATHS:
         model.native_flags = flags
         k, st, o = model.Loop(*model.process_inputs(x), state0=None if s0 is None else dev(s0))
         assert float(k) == float(k64)

@@ -217,7 +217,8 @@ def main():
     achieved = b_iter / t_iter
     roofline = {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK, 'traffic': None,
-                'kernel': 'k_state_fused2<64,false,64,8>' if not args.unfused else 'k_aggregate+k_segdense+k_converge',
+                'kernel': ('k_state_fused4<64,false,4,4> (wave-specialised; GNN_FUSED_KERNEL=%s)' % os.environ.get('GNN_FUSED_KERNEL', 'auto'))
+                          if not args.unfused else 'k_aggregate+k_segdense+k_converge',
                 'algorithmic_bytes_per_launch': b_iter, 'avg_launch_us': 1e6 * t_iter}
     traffic_file = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     if os.path.exists(traffic_file) and not sharded and not args.unfused:

@@ -128,6 +128,16 @@ int launch_aggregate(const int *gate, const gnn_csr_t &c, const float *X, int ld
 
 int launch_segdense(gnn::SegDenseArgs &a, hipStream_t st) {
     if (a.M == 0) return 0;
+    if (a.H <= 4) {                      // thin outputs (class scores): 16 lanes per row, no MFMA tile to fill
+        int K = 0;
+        for (int s = 0; s < a.nseg; ++s) K = std::max(K, a.seg[s].wrow + a.seg[s].width);
+        if ((size_t)K * a.H * sizeof(float) <= 48 * 1024) {
+            const int grid = (int)std::max<long>(1, std::min<long>(cdiv(a.M, 16 * gnn::TD_ROWS), 256 * 8));
+            gnn::k_thin_dense<<<grid, 256, (size_t)K * a.H * sizeof(float), st>>>(a, K);
+            LAUNCH_OK();
+            return 0;
+        }
+    }
     gnn::k_segdense<<<cdiv(a.M, gnn::SD_TM), 256, 0, st>>>(a);
     LAUNCH_OK();
     return 0;
@@ -150,7 +160,7 @@ int launch_converge(const int *gate, const float *s, const float *so, int N, int
 
 int launch_fold(const gnn_mlp_t &m, float *Wf, float *bf, hipStream_t st) {
     const int H = m.units[0];
-    gnn::k_fold_bn<<<cdiv(H, 256), 256, 0, st>>>(m.kernel[0], m.bias[0], m.in_dim, H, m.has_bn ? m.bn_gamma : nullptr,
+    gnn::k_fold_bn<<<H, 128, 0, st>>>(m.kernel[0], m.bias[0], m.in_dim, H, m.has_bn ? m.bn_gamma : nullptr,
                                                  m.bn_beta, m.bn_mean, m.bn_var, m.bn_eps, Wf, bf);
     LAUNCH_OK();
     return 0;
@@ -620,17 +630,21 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     TRY(setup_constants(a, p, st));
 
     // state_0 (GNN.py:256-259) into the padded buffer; state_old_0 = ones is implicit in the first predicate (:261)
-    if (a.state_dim > 0) TRY(launch_copy2d(nullptr, a.state0, p.S, p.buf[0], p.SP, p.N, p.S, p.SP, st));
-    else                 TRY(launch_copy2d(nullptr, a.nodes, a.ld_nodes, p.buf[0], p.SP, p.N, p.S, p.SP, st));
+    // When the caller's state_0 already has the padded layout (d a multiple of 16, no hub rows behind the real ones) the
+    // first iteration reads it in place: no copy of N x d floats.
+    const float *first = p.buf[0];
+    if (a.state_dim > 0 && p.S == p.SP && p.n_heavy == 0 && (reinterpret_cast<uintptr_t>(a.state0) & 15) == 0) first = a.state0;
+    else if (a.state_dim > 0) TRY(launch_copy2d(nullptr, a.state0, p.S, p.buf[0], p.SP, p.N, p.S, p.SP, st));
+    else                      TRY(launch_copy2d(nullptr, a.nodes, a.ld_nodes, p.buf[0], p.SP, p.N, p.S, p.SP, st));
     if (p.SP != p.S) HIP_OK(hipMemsetAsync(p.buf[1], 0, sizeof(float) * (size_t)p.N * p.SP, st));
-    TRY(launch_converge(nullptr, p.buf[0], nullptr, p.N, p.S, p.SP, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
+    TRY(launch_converge(nullptr, first, nullptr, p.N, p.S, p.SP, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
 
     const bool fused = can_fuse(a, p);
     const bool no_exit = (a.flags & GNN_FLAG_NO_EARLY_EXIT) != 0;
     if (a.ev_loop_begin) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_begin, st));
     for (int it = 0; it < a.max_iteration; ++it) {
         const int *gate = no_exit ? nullptr : p.flags + it;
-        const float *src = p.buf[it & 1];
+        const float *src = it == 0 ? first : p.buf[it & 1];
         float *dst = p.buf[(it + 1) & 1];
         if (fused) TRY(iteration_fused(a, p, gate, gate ? 1 : 0, 0, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
         else       TRY(iteration_unfused(a, p, gate, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
@@ -642,7 +656,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     {
         const long total = (long)p.N * p.S;
         if (total > 0) {
-            gnn::k_select_state<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, st>>>(a.k_out, p.buf[0], p.buf[1], p.SP, a.state_out, p.S, p.N, p.S);
+            gnn::k_select_state<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, st>>>(a.k_out, first, p.buf[0], p.buf[1], p.SP, a.state_out, p.S, p.N, p.S);
             LAUNCH_OK();
         }
     }
@@ -793,7 +807,8 @@ int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const 
     const long total = (long)p.N * p.S;
     if (total > 0) {
         gnn::k_select_state<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, st>>>(
-            a.k_out, buf0_full + (size_t)row_base * p.SP, buf1_full + (size_t)row_base * p.SP, p.SP, a.state_out, p.S, p.N, p.S);
+            a.k_out, buf0_full + (size_t)row_base * p.SP, buf0_full + (size_t)row_base * p.SP, buf1_full + (size_t)row_base * p.SP, p.SP,
+            a.state_out, p.S, p.N, p.S);
         LAUNCH_OK();
     }
     return output_stage(a, p, st);

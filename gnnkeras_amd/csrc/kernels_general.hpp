@@ -174,6 +174,86 @@ __global__ void __launch_bounds__(256) k_segdense(SegDenseArgs a) {
     }
 }
 
+// The same segmented dense layer for THIN outputs (H <= 4: class scores of the output network, GNN.py:273).  A 64-column
+// MFMA tile would spend 62 of its columns on nothing and stage every input row through LDS; here 16 lanes share a row
+// (16 B per lane where the segment allows it, one 256-B state row per load), keep H partial dot products each, and
+// meet in a 4-step shuffle tree (fixed order: deterministic).  4 rows per lane group are in flight per trip.
+constexpr int TD_ROWS = 4;
+__global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
+    if (gate_closed(a.gate)) return;
+    extern __shared__ float tdW[];                       // [K][H]
+    const int H = a.H;
+    for (int i = threadIdx.x; i < K * H; i += blockDim.x) tdW[i] = a.W[(size_t)(i / H) * a.ldw + (i % H)];
+    __syncthreads();
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    for (long base = ((long)blockIdx.x * 16 + grp) * TD_ROWS; base < a.M; base += (long)gridDim.x * 16 * TD_ROWS) {
+        float acc[TD_ROWS][4];
+#pragma unroll
+        for (int r = 0; r < TD_ROWS; ++r)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) acc[r][h] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < GNN_MAX_SEGS; ++s) {
+            if (s >= a.nseg) break;
+            const Seg sg = a.seg[s];
+            long rowv[TD_ROWS];
+#pragma unroll
+            for (int r = 0; r < TD_ROWS; ++r) {
+                const long m = base + r;
+                rowv[r] = m < a.M ? (sg.rowidx ? (long)sg.rowidx[m] : m) : -1;
+            }
+            const bool vec = (sg.width % 4 == 0) && (sg.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.ptr) & 15) == 0);
+            if (vec) {
+                for (int c4 = l16; c4 * 4 < sg.width; c4 += 16) {
+                    f32x4 x[TD_ROWS];
+#pragma unroll
+                    for (int r = 0; r < TD_ROWS; ++r) {
+                        x[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (rowv[r] >= 0) x[r] = *reinterpret_cast<const f32x4 *>(sg.ptr + rowv[r] * sg.ld + 4 * c4);
+                    }
+                    const float *w = tdW + (size_t)(sg.wrow + 4 * c4) * H;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        for (int h = 0; h < H; ++h) {
+                            const float wv = w[e * H + h];
+#pragma unroll
+                            for (int r = 0; r < TD_ROWS; ++r) acc[r][h] = fmaf(x[r][e], wv, acc[r][h]);
+                        }
+                }
+            } else {
+                for (int c = l16; c < sg.width; c += 16) {
+                    float x[TD_ROWS];
+#pragma unroll
+                    for (int r = 0; r < TD_ROWS; ++r) x[r] = rowv[r] >= 0 ? sg.ptr[rowv[r] * sg.ld + c] : 0.0f;
+                    const float *w = tdW + (size_t)(sg.wrow + c) * H;
+                    for (int h = 0; h < H; ++h) {
+                        const float wv = w[h];
+#pragma unroll
+                        for (int r = 0; r < TD_ROWS; ++r) acc[r][h] = fmaf(x[r], wv, acc[r][h]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < TD_ROWS; ++r)
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) acc[r][h] += __shfl_xor(acc[r][h], off, 16);
+        if (l16 < H) {                                   // lane h of the group finishes output column h
+#pragma unroll
+            for (int r = 0; r < TD_ROWS; ++r) {
+                const long m = base + r;
+                if (m >= a.M) continue;
+                float v = l16 == 0 ? acc[r][0] : (l16 == 1 ? acc[r][1] : (l16 == 2 ? acc[r][2] : acc[r][3]));
+                if (a.bias) v += a.bias[l16];
+                if (a.addend) v += a.addend[(size_t)(a.add_rowidx ? a.add_rowidx[m] : m) * a.ld_add + l16];
+                a.Y[(size_t)(a.out_rowidx ? a.out_rowidx[m] : m) * a.ldy + l16] = activate(a.act, v);
+            }
+        }
+    }
+}
+
 // row softmax in place (Keras 'softmax' activation of the output network, starter.py:28): max-subtracted.
 __global__ void __launch_bounds__(256)
 k_softmax_rows(const int *gate, float *Y, int M, int H, int ldy, const int *rowidx) {
@@ -226,14 +306,15 @@ k_converge(const int *gate, const float *__restrict__ s, const float *__restrict
 
 // Fold an inference BatchNormalization into the Dense layer that follows it (Keras: y = x*inv + (beta - mean*inv),
 // inv = gamma / sqrt(var + eps)):  Wf[k][h] = inv[k] * W[k][h],  bf[h] = b[h] + sum_k (beta[k] - mean[k]*inv[k]) W[k][h].
-__global__ void __launch_bounds__(256)
+// One workgroup per output column h, threads stride over k; the shift sum meets in a fixed-order LDS tree.
+__global__ void __launch_bounds__(128)
 k_fold_bn(const float *__restrict__ W, const float *__restrict__ b, int K, int H, const float *gamma,
           const float *beta, const float *mean, const float *var, float eps, float *__restrict__ Wf,
           float *__restrict__ bf) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= H) return;
-    float acc = b ? b[h] : 0.0f;
-    for (int k = 0; k < K; ++k) {
+    __shared__ float part[128];
+    const int h = blockIdx.x;
+    float acc = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 128) {
         float inv = 1.0f, shift = 0.0f;
         if (gamma) {
             inv = gamma[k] / sqrtf(var[k] + eps);
@@ -243,7 +324,13 @@ k_fold_bn(const float *__restrict__ W, const float *__restrict__ b, int K, int H
         Wf[(size_t)k * H + h] = wv * inv;
         acc = fmaf(shift, wv, acc);
     }
-    bf[h] = acc;
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 64; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bf[h] = (b ? b[h] : 0.0f) + part[0];
 }
 
 // dst[i, :width] = src[i, :width] with independent leading dimensions; pads dst columns [width, ld_dst_fill) with 0.
@@ -313,10 +400,10 @@ k_gather_rows(const float *__restrict__ src, int ld_src, const int *__restrict__
 
 // state_out = (k odd ? buf1 : buf0): picks the buffer that holds the state after k iterations, k read on device.
 __global__ void __launch_bounds__(256)
-k_select_state(const float *k_ptr, const float *__restrict__ buf0, const float *__restrict__ buf1, int ld_buf,
-               float *__restrict__ dst, int ld_dst, int rows, int width) {
+k_select_state(const float *k_ptr, const float *__restrict__ first, const float *__restrict__ buf0,
+               const float *__restrict__ buf1, int ld_buf, float *__restrict__ dst, int ld_dst, int rows, int width) {
     const int k = (int)(*k_ptr);
-    const float *src = (k & 1) ? buf1 : buf0;
+    const float *src = k == 0 ? first : ((k & 1) ? buf1 : buf0);      // `first`: state_0 where it was read in place
     const size_t total = (size_t)rows * width;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t rr = i / width;

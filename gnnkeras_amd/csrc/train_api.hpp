@@ -40,7 +40,7 @@ int gnn_dense(const gnn_dense_args_t *d) {
 int gnn_fold_bn(const float *W, const float *b, int32_t K, int32_t H, const float *gamma, const float *beta,
                 const float *mean, const float *var, float eps, float *Wf, float *bf, void *stream) {
     if (!W || !Wf || !bf || K < 1 || H < 1) return fail("bad arguments");
-    gnn::k_fold_bn<<<cdiv(H, 256), 256, 0, (hipStream_t)stream>>>(W, b, K, H, gamma, beta, mean, var, eps, Wf, bf);
+    gnn::k_fold_bn<<<H, 128, 0, (hipStream_t)stream>>>(W, b, K, H, gamma, beta, mean, var, eps, Wf, bf);
     LAUNCH_OK();
     return 0;
 }

@@ -167,10 +167,11 @@ def test_fuzz_training_gradients(seed):
     s0 = rng.normal(0, 0.2, (x[0].shape[0], d)).astype(np.float32) if d else None
     avg = bool(rng.integers(0, 2))
     k32, k64 = (oracle_step(model, x, y, sw, s0, loss, avg, dtype=dt)['k'] for dt in (torch.float32, torch.float64))
-    if k32 != k64:      # the float32 state reached an exact fixed point (threshold 0) before float64 did: only k is checked
+    if k32 != k64:      # a float32 state reached an exact fixed point (threshold 0) before float64 did: that depends on the
+                        # last bit of every sum, so only the range of k is checked
         from gnnkeras_amd.Models.training import LoopTrainer, SGD
         model.compile(optimizer=SGD(0.0), loss=loss, average_st_grads=avg)
         res = LoopTrainer(model).train_step(x, y, sw, state0=None if s0 is None else torch.from_numpy(s0).cuda(), apply=False)
-        assert res['k'] == k32
+        assert min(k32, k64) <= res['k'] <= max(k32, k64)
         return
     check_step(model, x, y, sw, s0, loss=loss, avg=avg)

@@ -133,7 +133,13 @@ int launch_segdense(gnn::SegDenseArgs &a, hipStream_t st) {
         for (int s = 0; s < a.nseg; ++s) K = std::max(K, a.seg[s].wrow + a.seg[s].width);
         if ((size_t)K * a.H * sizeof(float) <= 48 * 1024) {
             const int grid = (int)std::max<long>(1, std::min<long>(cdiv(a.M, 16 * gnn::TD_ROWS), 256 * 8));
-            gnn::k_thin_dense<<<grid, 256, (size_t)K * a.H * sizeof(float), st>>>(a, K);
+            const size_t lds = (size_t)K * a.H * sizeof(float);
+            switch (a.H) {
+                case 1: gnn::k_thin_dense<1><<<grid, 256, lds, st>>>(a, K); break;
+                case 2: gnn::k_thin_dense<2><<<grid, 256, lds, st>>>(a, K); break;
+                case 3: gnn::k_thin_dense<3><<<grid, 256, lds, st>>>(a, K); break;
+                default: gnn::k_thin_dense<4><<<grid, 256, lds, st>>>(a, K); break;
+            }
             LAUNCH_OK();
             return 0;
         }
@@ -152,8 +158,17 @@ int launch_softmax(const int *gate, float *Y, int M, int H, int ldy, const int *
 
 int launch_converge(const int *gate, const float *s, const float *so, int N, int S, int ld_s, int ld_so, float thr,
                     int *flag_out, float *k_out, float k_val, hipStream_t st) {
-    const int grid = std::max(1, std::min(cdiv(N, 16), 256 * 8));
-    gnn::k_converge<<<grid, 256, 0, st>>>(gate, s, so, N, S, ld_s, ld_so, thr, flag_out, k_out, k_val);
+    // The predicate is an OR over nodes: a probe over the first rows usually settles it ("some node still moves"), and
+    // the pass over the rest returns at once when it has.  Only a converged state pays for the full read.
+    const int probe = N > 65536 ? 4096 : 0;
+    if (probe) {
+        gnn::k_converge<<<cdiv(probe, 16), 256, 0, st>>>(gate, s, so, probe, S, ld_s, ld_so, thr, flag_out, k_out, k_val, nullptr);
+        LAUNCH_OK();
+    }
+    const int rest = N - probe;
+    const int grid = std::max(1, std::min(cdiv(rest, 16), 256 * 8));
+    gnn::k_converge<<<grid, 256, 0, st>>>(gate, s + (size_t)probe * ld_s, so ? so + (size_t)probe * ld_so : nullptr, rest, S, ld_s, ld_so,
+                                          thr, flag_out, probe ? nullptr : k_out, k_val, probe ? flag_out : nullptr);
     LAUNCH_OK();
     return 0;
 }
@@ -641,11 +656,17 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
 
     const bool fused = can_fuse(a, p);
     const bool no_exit = (a.flags & GNN_FLAG_NO_EARLY_EXIT) != 0;
+    // Ping-pong buffers.  When the caller's state_out has the padded layout too, it stands in for the buffer the LAST
+    // iteration writes (B[max_iteration & 1]): a loop that runs to max_iteration leaves the result where the caller
+    // wants it and the final copy below returns at once (an early stop may still need it).
+    float *B[2] = {p.buf[0], p.buf[1]};
+    if (first == a.state0 && a.state_out != a.state0 && (reinterpret_cast<uintptr_t>(a.state_out) & 15) == 0 && a.max_iteration > 0)
+        B[a.max_iteration & 1] = a.state_out;
     if (a.ev_loop_begin) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_begin, st));
     for (int it = 0; it < a.max_iteration; ++it) {
         const int *gate = no_exit ? nullptr : p.flags + it;
-        const float *src = it == 0 ? first : p.buf[it & 1];
-        float *dst = p.buf[(it + 1) & 1];
+        const float *src = it == 0 ? first : B[it & 1];
+        float *dst = B[(it + 1) & 1];
         if (fused) TRY(iteration_fused(a, p, gate, gate ? 1 : 0, 0, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
         else       TRY(iteration_unfused(a, p, gate, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
     }
@@ -656,7 +677,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     {
         const long total = (long)p.N * p.S;
         if (total > 0) {
-            gnn::k_select_state<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, st>>>(a.k_out, first, p.buf[0], p.buf[1], p.SP, a.state_out, p.S, p.N, p.S);
+            gnn::k_select_state<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, st>>>(a.k_out, first, B[0], B[1], p.SP, a.state_out, p.S, p.N, p.S);
             LAUNCH_OK();
         }
     }

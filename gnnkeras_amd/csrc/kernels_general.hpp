@@ -179,19 +179,19 @@ __global__ void __launch_bounds__(256) k_segdense(SegDenseArgs a) {
 // (16 B per lane where the segment allows it, one 256-B state row per load), keep H partial dot products each, and
 // meet in a 4-step shuffle tree (fixed order: deterministic).  4 rows per lane group are in flight per trip.
 constexpr int TD_ROWS = 4;
+template <int H>
 __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
     if (gate_closed(a.gate)) return;
     extern __shared__ float tdW[];                       // [K][H]
-    const int H = a.H;
     for (int i = threadIdx.x; i < K * H; i += blockDim.x) tdW[i] = a.W[(size_t)(i / H) * a.ldw + (i % H)];
     __syncthreads();
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     for (long base = ((long)blockIdx.x * 16 + grp) * TD_ROWS; base < a.M; base += (long)gridDim.x * 16 * TD_ROWS) {
-        float acc[TD_ROWS][4];
+        float acc[TD_ROWS][H];
 #pragma unroll
         for (int r = 0; r < TD_ROWS; ++r)
 #pragma unroll
-            for (int h = 0; h < 4; ++h) acc[r][h] = 0.0f;
+            for (int h = 0; h < H; ++h) acc[r][h] = 0.0f;
 #pragma unroll
         for (int s = 0; s < GNN_MAX_SEGS; ++s) {
             if (s >= a.nseg) break;
@@ -214,6 +214,7 @@ __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
                     const float *w = tdW + (size_t)(sg.wrow + 4 * c4) * H;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
+#pragma unroll
                         for (int h = 0; h < H; ++h) {
                             const float wv = w[e * H + h];
 #pragma unroll
@@ -226,6 +227,7 @@ __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
 #pragma unroll
                     for (int r = 0; r < TD_ROWS; ++r) x[r] = rowv[r] >= 0 ? sg.ptr[rowv[r] * sg.ld + c] : 0.0f;
                     const float *w = tdW + (size_t)(sg.wrow + c) * H;
+#pragma unroll
                     for (int h = 0; h < H; ++h) {
                         const float wv = w[h];
 #pragma unroll
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
 #pragma unroll
         for (int r = 0; r < TD_ROWS; ++r)
 #pragma unroll
-            for (int h = 0; h < 4; ++h)
+            for (int h = 0; h < H; ++h)
 #pragma unroll
                 for (int off = 8; off >= 1; off >>= 1) acc[r][h] += __shfl_xor(acc[r][h], off, 16);
         if (l16 < H) {                                   // lane h of the group finishes output column h
@@ -245,7 +247,9 @@ __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
             for (int r = 0; r < TD_ROWS; ++r) {
                 const long m = base + r;
                 if (m >= a.M) continue;
-                float v = l16 == 0 ? acc[r][0] : (l16 == 1 ? acc[r][1] : (l16 == 2 ? acc[r][2] : acc[r][3]));
+                float v = acc[r][0];
+#pragma unroll
+                for (int h = 1; h < H; ++h) v = l16 == h ? acc[r][h] : v;
                 if (a.bias) v += a.bias[l16];
                 if (a.addend) v += a.addend[(size_t)(a.add_rowidx ? a.add_rowidx[m] : m) * a.ld_add + l16];
                 a.Y[(size_t)(a.out_rowidx ? a.out_rowidx[m] : m) * a.ldy + l16] = activate(a.act, v);
@@ -274,8 +278,9 @@ k_softmax_rows(const int *gate, float *Y, int M, int H, int ldy, const int *rowi
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_converge(const int *gate, const float *__restrict__ s, const float *__restrict__ so, int N, int S, int ld_s,
-           int ld_so, float thr, int *flag_out, float *k_out, float k_val) {
+           int ld_so, float thr, int *flag_out, float *k_out, float k_val, const int *skip_if_set) {
     if (gate_closed(gate)) return;
+    if (skip_if_set != nullptr && *skip_if_set != 0) return;      // the answer ("some node still moves") is already known
     const int lane = threadIdx.x & 15;
     const int groups = blockDim.x / 16;
     int any = 0;
@@ -404,6 +409,7 @@ k_select_state(const float *k_ptr, const float *__restrict__ first, const float 
                const float *__restrict__ buf1, int ld_buf, float *__restrict__ dst, int ld_dst, int rows, int width) {
     const int k = (int)(*k_ptr);
     const float *src = k == 0 ? first : ((k & 1) ? buf1 : buf0);      // `first`: state_0 where it was read in place
+    if (src == dst) return;                                            // the last iteration wrote the caller's buffer directly
     const size_t total = (size_t)rows * width;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t rr = i / width;

@@ -22,6 +22,7 @@
 #include "kernel_state_fused2.hpp"
 #include "kernel_state_fused3.hpp"
 #include "kernel_state_fused4.hpp"
+#include "kernel_state_small.hpp"
 
 namespace {
 
@@ -347,7 +348,7 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
 
     // ---- carve ----
     Carver c(ws);
-    p.flags = c.take<int>(a.max_iteration + 2);
+    p.flags = c.take<int>(a.max_iteration + 8);          // behind the flags: the persistent kernel's two 64-bit barrier counters
     for (int t = 0; t < p.T; ++t) {
         p.tp[t].Wf = c.take<float>((size_t)a.net_state[t].in_dim * a.net_state[t].units[0]);
         p.tp[t].bf = c.take<float>(a.net_state[t].units[0]);
@@ -588,6 +589,38 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
     return 0;
 }
 
+// The whole loop in ONE launch (kernel_state_small.hpp) for graphs of at most 64 nodes per CU: returns 2 when that does
+// not apply (hub rows, d <= 16, too many tiles, pinned to another kernel) and the caller launches per iteration.
+int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first, float *const B[2], hipStream_t st) {
+    const int pinned = (a.flags & GNN_FLAG_FUSED_GEN_MASK) >> 4;
+    if (pinned != 0 && pinned != 5) return 2;
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("GNN_FUSED_KERNEL"); env = e ? atoi(e) : 0; }
+    if (pinned == 0 && env != 0 && env != 5) return 2;
+    if (p.n_heavy != 0 || a.max_iteration < 1) return 2;
+    gnn::SmallArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    gnn::Fused2Args &fa = sa.f;
+    const gnn_csr_t &adj = iter_adjacency(a);
+    fa.rowptr = adj.rowptr; fa.src = adj.src; fa.w = adj.w; fa.row_scale = adj.row_scale;
+    fa.state_in = first; fa.row_base = 0;
+    fa.C = p.C; fa.ldC = p.ldC;
+    for (int t = 0; t < p.T; ++t)
+        if (p.tp[t].count > 0)
+            fa.tp[fa.n_types++] = gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg,
+                                                 (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0]};
+    if (fa.n_types == 0) return 2;
+    fa.S = p.S; fa.thr = a.state_threshold; fa.k_out = a.k_out;
+    sa.buf[0] = B[0]; sa.buf[1] = B[1];
+    sa.max_iteration = a.max_iteration;
+    sa.no_exit = (a.flags & GNN_FLAG_NO_EARLY_EXIT) != 0;
+    sa.flags = p.flags;
+    sa.bar = reinterpret_cast<unsigned long long *>(p.flags + ((a.max_iteration + 3) & ~1));     // 8-byte aligned (flags is 256-B aligned)
+    const int rc = gnn::launch_small(sa, p.SP, device_cus(), st);
+    if (rc == 1) return fail("persistent loop kernel: launch failed (%s)", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
 bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
     if (a.flags & GNN_FLAG_UNFUSED) return false;
     if (p.SP > 64) return false;   // LDS: [64 x 2SP] tile + [2SP x SP] weights must leave room for 2 workgroups per CU
@@ -640,7 +673,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     if (((uintptr_t)a.workspace & 255) != 0) return fail("workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)a.stream;
 
-    HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (a.max_iteration + 2), st));
+    HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (a.max_iteration + 8), st));
     HIP_OK(hipMemsetAsync(a.k_out, 0, sizeof(float), st));
     TRY(setup_constants(a, p, st));
 
@@ -663,7 +696,12 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     if (first == a.state0 && a.state_out != a.state0 && (reinterpret_cast<uintptr_t>(a.state_out) & 15) == 0 && a.max_iteration > 0)
         B[a.max_iteration & 1] = a.state_out;
     if (a.ev_loop_begin) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_begin, st));
-    for (int it = 0; it < a.max_iteration; ++it) {
+    int persistent = 2;
+    if (fused) {
+        persistent = loop_persistent(a, p, first, B, st);
+        if (persistent == 1) return 1;
+    }
+    for (int it = 0; persistent != 0 && it < a.max_iteration; ++it) {
         const int *gate = no_exit ? nullptr : p.flags + it;
         const float *src = it == 0 ? first : B[it & 1];
         float *dst = B[(it + 1) & 1];
@@ -789,7 +827,7 @@ int gnn_shard_setup(const gnn_loop_args_t *args) {
     if (!a.nodes_src) return fail("gnn_shard_setup: nodes_src is NULL (not a shard)");
     if (!a.workspace || a.workspace_bytes < p.bytes) return fail("workspace too small: %zu < %zu bytes", a.workspace_bytes, p.bytes);
     hipStream_t st = (hipStream_t)a.stream;
-    HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (a.max_iteration + 2), st));
+    HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (a.max_iteration + 8), st));
     HIP_OK(hipMemsetAsync(a.k_out, 0, sizeof(float), st));
     return setup_constants(a, p, st);
 }

@@ -39,9 +39,11 @@ enum gnn_flags {
     GNN_FLAG_UNFUSED = 1,      /* run the iteration as separate aggregate / dense / predicate kernels            */
     GNN_FLAG_NO_EARLY_EXIT = 2,/* debugging: ignore the convergence predicate (always max_iteration iterations)  */
     /* testing / tuning: pin the generation of the fused iteration kernel instead of the size-based choice
-     * (2 = phase-alternating, 3 = software-pipelined, 4 = wave-specialised).  Results are the same within float32
+     * (2 = phase-alternating, 3 = software-pipelined, 4 = wave-specialised, 5 = whole loop in one persistent launch,
+     * small graphs only - falls back to the size-based choice when it does not apply).  Results are the same within float32
      * summation order; the GNN_FUSED_KERNEL environment variable has the same effect process-wide. */
-    GNN_FLAG_FUSED_GEN2 = 2 << 4, GNN_FLAG_FUSED_GEN3 = 3 << 4, GNN_FLAG_FUSED_GEN4 = 4 << 4, GNN_FLAG_FUSED_GEN_MASK = 7 << 4
+    GNN_FLAG_FUSED_GEN2 = 2 << 4, GNN_FLAG_FUSED_GEN3 = 3 << 4, GNN_FLAG_FUSED_GEN4 = 4 << 4,
+    GNN_FLAG_FUSED_GEN5 = 5 << 4, GNN_FLAG_FUSED_GEN_MASK = 7 << 4
 };
 
 /* A sparse operator A (n_src x n_dst, COO in the reference: tf.SparseTensor) stored as the CSR of its transpose:

@@ -21,7 +21,7 @@ from oracle.harness import oracle_loop, oracle_composite_loop, rel_err
 
 pytestmark = pytest.mark.gpu
 # every way the iteration can run: size-based default, un-fused kernels, and each fused-kernel generation pinned
-PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN3, nat.FLAG_FUSED_GEN4)
+PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN3, nat.FLAG_FUSED_GEN4, nat.FLAG_FUSED_GEN5)
 TOL = 1e-5
 CLS = {'n': GNNnodeBased, 'a': GNNarcBased, 'g': GNNgraphBased}
 CCLS = {'n': CompositeGNNnodeBased, 'a': CompositeGNNarcBased, 'g': CompositeGNNgraphBased}

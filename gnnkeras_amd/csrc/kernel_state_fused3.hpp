@@ -24,27 +24,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernel_state_fused2.hpp"
+#include "buffer_ops.hpp"
 
 namespace gnn {
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t f3_rsrc(const void *p) {
-    // 4 GiB window (the launcher checks every array fits); a null array becomes a zero-record buffer: loads return 0
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? (int)0xFFFFFFF0u : 0, 0x00020000);
-}
-constexpr unsigned F3_OFF = 0xFFFFFFFFu;     // out of range for every descriptor: the load returns 0, no memory access
-
-__device__ __forceinline__ int f3_ld_i32(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0);
-}
-__device__ __forceinline__ float f3_ld_f32(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
-}
-__device__ __forceinline__ f32x4 f3_ld_f32x4(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-    return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
-}
 
 template <int SP, int NW>
 struct Fused3Cfg {
@@ -101,9 +83,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 12 ? 3 : 4) k_state_fused3(Fuse
     const int t_end = min(ntiles, (xcd + 1) * tpx);
     const int t_first = xcd * tpx + lb;
 
-    const __amdgpu_buffer_rsrc_t r_state = f3_rsrc(a.state_in), r_C = f3_rsrc(a.C), r_rowptr = f3_rsrc(a.rowptr),
-                                 r_src = f3_rsrc(a.src), r_w = f3_rsrc(HAS_W ? a.w : nullptr),
-                                 r_scale = f3_rsrc(a.row_scale), r_rows = f3_rsrc(tp.rows);
+    const __amdgpu_buffer_rsrc_t r_state = buf_rsrc(a.state_in), r_C = buf_rsrc(a.C), r_rowptr = buf_rsrc(a.rowptr),
+                                 r_src = buf_rsrc(a.src), r_w = buf_rsrc(HAS_W ? a.w : nullptr),
+                                 r_scale = buf_rsrc(a.row_scale), r_rows = buf_rsrc(tp.rows);
     const bool has_rows = tp.rows != nullptr, has_scale = a.row_scale != nullptr;
     char *__restrict__ obase = reinterpret_cast<char *>(a.state_out);
     const int q = tid / LPR;          // node slot of this lane group inside the tile
@@ -116,14 +98,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 12 ? 3 : 4) k_state_fused3(Fuse
     auto slot_node = [&](int n) -> int {
         const int m = tile_of(n) * TM + q;
         const bool ok = tile_of(n) < t_end && m < count;
-        const int jr = f3_ld_i32(r_rows, ok ? 4u * (unsigned)m : F3_OFF);
+        const int jr = buf_ld_i32(r_rows, ok ? 4u * (unsigned)m : BUF_OFF);
         return ok ? (has_rows ? jr : m) : -1;
     };
     auto load_C = [&](const int (&jr)[4], f32x4 &c) {
         const int colc = min(col, S - 1);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
-            c[reg] = f3_ld_f32(r_C, (jr[reg] >= 0 && col < S) ? ((unsigned)jr[reg] * (unsigned)a.ldC + (unsigned)colc) * 4u : F3_OFF);
+            c[reg] = buf_ld_f32(r_C, (jr[reg] >= 0 && col < S) ? ((unsigned)jr[reg] * (unsigned)a.ldC + (unsigned)colc) * 4u : BUF_OFF);
     };
 
     // ---- pipeline registers: A = the slot whose rows are (about to be) in flight, B/C/D the slots after it ----------
@@ -134,13 +116,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 12 ? 3 : 4) k_state_fused3(Fuse
     f32x4 own, v[16];
 
     jA = slot_node(0); jB = slot_node(1); jC = slot_node(2); jD = slot_node(3);
-    begA = f3_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA : F3_OFF); endA = f3_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA + 4u : F3_OFF);
-    begB = f3_ld_i32(r_rowptr, jB >= 0 ? 4u * (unsigned)jB : F3_OFF); endB = f3_ld_i32(r_rowptr, jB >= 0 ? 4u * (unsigned)jB + 4u : F3_OFF);
+    begA = buf_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA : BUF_OFF); endA = buf_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA + 4u : BUF_OFF);
+    begB = buf_ld_i32(r_rowptr, jB >= 0 ? 4u * (unsigned)jB : BUF_OFF); endB = buf_ld_i32(r_rowptr, jB >= 0 ? 4u * (unsigned)jB + 4u : BUF_OFF);
 #pragma unroll
     for (int u = 0; u < IPL; ++u) {
         const int e = begA + u * LPR + l4;
-        idsA[u] = f3_ld_i32(r_src, e < endA ? 4u * (unsigned)e : F3_OFF);
-        wsA[u] = HAS_W ? f3_ld_f32(r_w, e < endA ? 4u * (unsigned)e : F3_OFF) : 0.0f;
+        idsA[u] = buf_ld_i32(r_src, e < endA ? 4u * (unsigned)e : BUF_OFF);
+        wsA[u] = HAS_W ? buf_ld_f32(r_w, e < endA ? 4u * (unsigned)e : BUF_OFF) : 0.0f;
     }
 
     // issue everything that can be known now: later slots' ids / row pointers / source ids, then slot A's rows
@@ -148,19 +130,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 12 ? 3 : 4) k_state_fused3(Fuse
 #pragma unroll
         for (int u = 0; u < IPL; ++u) {
             const int e = begB + u * LPR + l4;
-            idsB[u] = f3_ld_i32(r_src, e < endB ? 4u * (unsigned)e : F3_OFF);
-            wsB[u] = HAS_W ? f3_ld_f32(r_w, e < endB ? 4u * (unsigned)e : F3_OFF) : 0.0f;
+            idsB[u] = buf_ld_i32(r_src, e < endB ? 4u * (unsigned)e : BUF_OFF);
+            wsB[u] = HAS_W ? buf_ld_f32(r_w, e < endB ? 4u * (unsigned)e : BUF_OFF) : 0.0f;
         }
-        begC = f3_ld_i32(r_rowptr, jC >= 0 ? 4u * (unsigned)jC : F3_OFF);
-        endC = f3_ld_i32(r_rowptr, jC >= 0 ? 4u * (unsigned)jC + 4u : F3_OFF);
+        begC = buf_ld_i32(r_rowptr, jC >= 0 ? 4u * (unsigned)jC : BUF_OFF);
+        endC = buf_ld_i32(r_rowptr, jC >= 0 ? 4u * (unsigned)jC + 4u : BUF_OFF);
         jE = slot_node(n_e);
-        sclA = f3_ld_f32(r_scale, jA >= 0 ? 4u * (unsigned)jA : F3_OFF);
-        own = f3_ld_f32x4(r_state, jA >= 0 ? (unsigned)(a.row_base + jA) * (unsigned)(SP * 4) + 16u * l4 : F3_OFF);
+        sclA = buf_ld_f32(r_scale, jA >= 0 ? 4u * (unsigned)jA : BUF_OFF);
+        own = buf_ld_f32x4(r_state, jA >= 0 ? (unsigned)(a.row_base + jA) * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);
         const int deg = endA - begA;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const unsigned sid = (unsigned)__shfl(idsA[i / LPR], i % LPR, LPR);
-            v[i] = f3_ld_f32x4(r_state, i < deg ? sid * (unsigned)(SP * 4) + 16u * l4 : F3_OFF);
+            v[i] = buf_ld_f32x4(r_state, i < deg ? sid * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);
         }
     };
     issue(4);
@@ -186,14 +168,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 12 ? 3 : 4) k_state_fused3(Fuse
 #pragma unroll
                 for (int u = 0; u < IPL; ++u) {
                     const int e = eb + u * LPR + l4;
-                    idc[u] = f3_ld_i32(r_src, e < endA ? 4u * (unsigned)e : F3_OFF);
-                    wsc[u] = HAS_W ? f3_ld_f32(r_w, e < endA ? 4u * (unsigned)e : F3_OFF) : 0.0f;
+                    idc[u] = buf_ld_i32(r_src, e < endA ? 4u * (unsigned)e : BUF_OFF);
+                    wsc[u] = HAS_W ? buf_ld_f32(r_w, e < endA ? 4u * (unsigned)e : BUF_OFF) : 0.0f;
                 }
                 f32x4 x[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const unsigned sid = (unsigned)__shfl(idc[i / LPR], i % LPR, LPR);
-                    x[i] = f3_ld_f32x4(r_state, i < rem ? sid * (unsigned)(SP * 4) + 16u * l4 : F3_OFF);
+                    x[i] = buf_ld_f32x4(r_state, i < rem ? sid * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {

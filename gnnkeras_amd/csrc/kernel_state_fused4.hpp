@@ -24,7 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernel_state_fused2.hpp"
-#include "kernel_state_fused3.hpp"   // raw-buffer load helpers (f3_rsrc, f3_ld_*)
+#include "kernel_state_fused3.hpp"   // raw-buffer load helpers (buf_rsrc, buf_ld_*)
 
 namespace gnn {
 
@@ -127,9 +127,9 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     const int t_first = xcd * tpx + lb;
     const int T = t_first < t_end ? (t_end - t_first + blk_per_xcd - 1) / blk_per_xcd : 0;   // tiles of this workgroup
 
-    const __amdgpu_buffer_rsrc_t r_C = f3_rsrc(a.C), r_rows = f3_rsrc(tp.rows), r_state = f3_rsrc(a.state_in),
-                                 r_rowptr = f3_rsrc(a.rowptr), r_src = f3_rsrc(a.src), r_w = f3_rsrc(HAS_W ? a.w : nullptr),
-                                 r_scale = f3_rsrc(a.row_scale);
+    const __amdgpu_buffer_rsrc_t r_C = buf_rsrc(a.C), r_rows = buf_rsrc(tp.rows), r_state = buf_rsrc(a.state_in),
+                                 r_rowptr = buf_rsrc(a.rowptr), r_src = buf_rsrc(a.src), r_w = buf_rsrc(HAS_W ? a.w : nullptr),
+                                 r_scale = buf_rsrc(a.row_scale);
     const bool has_scale = a.row_scale != nullptr;
     char *__restrict__ obase = reinterpret_cast<char *>(a.state_out);
     int any = 0;
@@ -152,17 +152,17 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
             return (n < njobs && m < count) ? m : -1;
         };
         auto node_of = [&](int m) -> int {
-            const int jr = f3_ld_i32(r_rows, m >= 0 ? 4u * (unsigned)m : F3_OFF);
+            const int jr = buf_ld_i32(r_rows, m >= 0 ? 4u * (unsigned)m : BUF_OFF);
             return m >= 0 ? (rows ? jr : m) : -1;
         };
         int jA = node_of(job_m(p)), jB = node_of(job_m(p + Cfg::NPROD));
-        int begA = f3_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA : F3_OFF), endA = f3_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA + 4u : F3_OFF);
+        int begA = buf_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA : BUF_OFF), endA = buf_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA + 4u : BUF_OFF);
         int idsA[IPL]; float wsA[IPL];
 #pragma unroll
         for (int u = 0; u < IPL; ++u) {
             const int e = begA + u * LPR + l4;
-            idsA[u] = f3_ld_i32(r_src, e < endA ? 4u * (unsigned)e : F3_OFF);
-            wsA[u] = HAS_W ? f3_ld_f32(r_w, e < endA ? 4u * (unsigned)e : F3_OFF) : 0.0f;
+            idsA[u] = buf_ld_i32(r_src, e < endA ? 4u * (unsigned)e : BUF_OFF);
+            wsA[u] = HAS_W ? buf_ld_f32(r_w, e < endA ? 4u * (unsigned)e : BUF_OFF) : 0.0f;
         }
         for (int n = p; n < njobs; n += Cfg::NPROD) {
             const int t = n / Cfg::PPT;
@@ -172,11 +172,11 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
             unsigned long long tg_ = f4_now();
 #endif
             // next job: row pointers now, node id of the job after it
-            const int begB = f3_ld_i32(r_rowptr, jB >= 0 ? 4u * (unsigned)jB : F3_OFF);
-            const int endB = f3_ld_i32(r_rowptr, jB >= 0 ? 4u * (unsigned)jB + 4u : F3_OFF);
+            const int begB = buf_ld_i32(r_rowptr, jB >= 0 ? 4u * (unsigned)jB : BUF_OFF);
+            const int endB = buf_ld_i32(r_rowptr, jB >= 0 ? 4u * (unsigned)jB + 4u : BUF_OFF);
             const int jC = node_of(job_m(n + 2 * Cfg::NPROD));
-            const float scl = f3_ld_f32(r_scale, j >= 0 ? 4u * (unsigned)j : F3_OFF);
-            const f32x4 own = f3_ld_f32x4(r_state, j >= 0 ? (unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * l4 : F3_OFF);
+            const float scl = buf_ld_f32(r_scale, j >= 0 ? 4u * (unsigned)j : BUF_OFF);
+            const f32x4 own = buf_ld_f32x4(r_state, j >= 0 ? (unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             int idsB[IPL]; float wsB[IPL];
             int rem = endA - begA, eb = begA;
@@ -193,14 +193,14 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
 #pragma unroll
                     for (int i = 0; i < DEPTH; ++i) {
                         const unsigned sid = (unsigned)__shfl(idc[(s0 + i) / LPR], (s0 + i) % LPR, LPR);
-                        v[i] = f3_ld_f32x4(r_state, s0 + i < rem ? sid * (unsigned)(SP * 4) + 16u * l4 : F3_OFF);
+                        v[i] = buf_ld_f32x4(r_state, s0 + i < rem ? sid * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);
                     }
                     if (s0 == 0 && first) {        // the next job's row pointers have landed by now: fetch its first 16 source ids
 #pragma unroll
                         for (int u = 0; u < IPL; ++u) {
                             const int e = begB + u * LPR + l4;
-                            idsB[u] = f3_ld_i32(r_src, e < endB ? 4u * (unsigned)e : F3_OFF);
-                            wsB[u] = HAS_W ? f3_ld_f32(r_w, e < endB ? 4u * (unsigned)e : F3_OFF) : 0.0f;
+                            idsB[u] = buf_ld_i32(r_src, e < endB ? 4u * (unsigned)e : BUF_OFF);
+                            wsB[u] = HAS_W ? buf_ld_f32(r_w, e < endB ? 4u * (unsigned)e : BUF_OFF) : 0.0f;
                         }
                     }
 #pragma unroll
@@ -215,8 +215,8 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
 #pragma unroll
                 for (int u = 0; u < IPL; ++u) {     // in-degree > 16: the next 16 source ids, one coalesced load per lane group
                     const int e = eb + u * LPR + l4;
-                    idc[u] = f3_ld_i32(r_src, e < endA ? 4u * (unsigned)e : F3_OFF);
-                    wsc[u] = HAS_W ? f3_ld_f32(r_w, e < endA ? 4u * (unsigned)e : F3_OFF) : 0.0f;
+                    idc[u] = buf_ld_i32(r_src, e < endA ? 4u * (unsigned)e : BUF_OFF);
+                    wsc[u] = HAS_W ? buf_ld_f32(r_w, e < endA ? 4u * (unsigned)e : BUF_OFF) : 0.0f;
                 }
             }
             if (has_scale) acc *= scl;
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int m = (t_first + t * blk_per_xcd) * 16 + 4 * g + reg;
-                    const int jr = f3_ld_i32(r_rows, m < count ? 4u * (unsigned)m : F3_OFF);
+                    const int jr = buf_ld_i32(r_rows, m < count ? 4u * (unsigned)m : BUF_OFF);
                     jrow[reg] = m < count ? (rows ? jr : m) : -1;
                 }
 #pragma unroll
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                     const int col = 16 * ci + r;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg)
-                        c[ci][reg] = f3_ld_f32(r_C, (jrow[reg] >= 0 && col < S) ? ((unsigned)jrow[reg] * (unsigned)a.ldC + (unsigned)col) * 4u : F3_OFF);
+                        c[ci][reg] = buf_ld_f32(r_C, (jrow[reg] >= 0 && col < S) ? ((unsigned)jrow[reg] * (unsigned)a.ldC + (unsigned)col) * 4u : BUF_OFF);
                 }
             }
             const int s = t % NS, round = t / NS;

@@ -21,19 +21,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernel_state_fused2.hpp"
-#include "kernel_state_fused3.hpp"   // raw-buffer helpers
+#include "buffer_ops.hpp"
 
 namespace gnn {
-
-// sc1 = system-coherent level 1: the access goes through to memory instead of stopping in this XCD's L2 / this CU's L1
-__device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16);
-    return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
-}
-__device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 x) {
-    const u32x4 v = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 16);
-}
 
 struct SmallArgs {
     Fused2Args f;            // f.state_in = source of iteration 0; f.gate / f.flag_next / f.k_val unused
@@ -117,14 +107,14 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
     // the predicate of state_0 (GNN.py:265 evaluates `condition` before the first iteration)
     const bool run_first = sa.no_exit || __hip_atomic_load(&sa.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     for (int it = 0; run_first && it < sa.max_iteration; ++it) {
-        const __amdgpu_buffer_rsrc_t r_in = f3_rsrc(it == 0 ? a.state_in : sa.buf[it & 1]);
-        const __amdgpu_buffer_rsrc_t r_out = f3_rsrc(sa.buf[(it + 1) & 1]);
+        const __amdgpu_buffer_rsrc_t r_in = buf_rsrc(it == 0 ? a.state_in : sa.buf[it & 1]);
+        const __amdgpu_buffer_rsrc_t r_out = buf_rsrc(sa.buf[(it + 1) & 1]);
 
         // ---- A. gather + aggregate: ids are already in registers, rows are the only round trip ----------------------
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             f32x4 own = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
-            own = ld_sc1(r_in, jn[p] >= 0 ? (unsigned)(a.row_base + jn[p]) * (unsigned)(SP * 4) + 16u * l4 : F3_OFF);
+            own = buf_ld_sc1(r_in, jn[p] >= 0 ? (unsigned)(a.row_base + jn[p]) * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);
             int idc[IPL]; float wsc[IPL];
 #pragma unroll
             for (int u = 0; u < IPL; ++u) { idc[u] = ids[p][u]; wsc[u] = wts[p][u]; }
@@ -135,7 +125,7 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const unsigned off = (unsigned)__shfl(idc[i / LPR], i % LPR, LPR) * (unsigned)(SP * 4) + 16u * l4;
-                    v[i] = ld_sc1(r_in, i < rem ? off : F3_OFF);
+                    v[i] = buf_ld_sc1(r_in, i < rem ? off : BUF_OFF);
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -240,7 +230,7 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
             if (jn[p] >= 0) {
                 const float *xr = Xs + (p * Cfg::NPP + q) * LDX + 4 * l4;
                 const float2 lo = *reinterpret_cast<const float2 *>(xr), hi = *reinterpret_cast<const float2 *>(xr + 2);
-                st_sc1(r_out, (unsigned)(a.row_base + jn[p]) * (unsigned)(SP * 4) + 16u * l4, (f32x4){lo.x, lo.y, hi.x, hi.y});
+                buf_st_sc1(r_out, (unsigned)(a.row_base + jn[p]) * (unsigned)(SP * 4) + 16u * l4, (f32x4){lo.x, lo.y, hi.x, hi.y});
             }
         }
 

@@ -99,14 +99,63 @@ k_dense_grad_partial(const float *__restrict__ X, int ldx, const int *__restrict
     if (qpart && blockIdx.y == 0 && tid < 64 && h0 + tid < H) qpart[(size_t)blockIdx.x * H + h0 + tid] = qacc;
 }
 
-// out[i] (+)= sum_c part[c][i]  in chunk order
+// out[i] (+)= scale * sum_c part[c][i]  in chunk order
 __global__ void __launch_bounds__(256)
-k_reduce_partials(const float *__restrict__ part, int n_chunks, int n, float *__restrict__ out, int accumulate) {
+k_reduce_partials(const float *__restrict__ part, int n_chunks, int n, float *__restrict__ out, int accumulate, float scale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.0f;
     for (int c = 0; c < n_chunks; ++c) s += part[(size_t)c * n + i];
+    s *= scale;
     out[i] = accumulate ? out[i] + s : s;
+}
+
+// Column statistics of a SMALL matrix (a merged MUTAG batch: ~1 k rows) in one launch: one workgroup per column, rows
+// strided over its 256 threads, both passes of tf.nn.moments (mean, then biased variance of the centred values) with
+// a fixed-order LDS tree each, and the Keras moving-average update (momentum 0.99, gated) at the end.
+__global__ void __launch_bounds__(256)
+k_colstats_small(const float *__restrict__ X, int ldx, const int *__restrict__ rowidx, int K, int M,
+                 float *__restrict__ mean, float *__restrict__ var, float *moving_mean, float *moving_var,
+                 float momentum, const int *gate) {
+    __shared__ float part[256];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    float xs[32];                                      // M <= 8192: at most 32 rows per thread, kept for the second pass
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int m = tid + 256 * i;
+        xs[i] = m < M ? X[(rowidx ? (size_t)rowidx[m] : (size_t)m) * ldx + k] : 0.0f;
+        s += xs[i];
+    }
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) part[tid] += part[tid + off];
+        __syncthreads();
+    }
+    const float mu = part[0] / (float)M;
+    __syncthreads();
+    s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int m = tid + 256 * i;
+        const float d = xs[i] - mu;
+        if (m < M) s = fmaf(d, d, s);
+    }
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) part[tid] += part[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float v = part[0] / (float)M;
+        mean[k] = mu; var[k] = v;
+        if (moving_mean && moving_var && !gate_closed(gate)) {
+            moving_mean[k] = moving_mean[k] * momentum + mu * (1.0f - momentum);
+            moving_var[k] = moving_var[k] * momentum + v * (1.0f - momentum);
+        }
+    }
 }
 
 // column statistics of X[row(m), 0:K] over M rows, two passes like tf.nn.moments: pass 1 (center == NULL) partial sums
@@ -124,12 +173,6 @@ k_colstats_partial(const float *__restrict__ X, int ldx, const int *__restrict__
         }
         part[(size_t)blockIdx.x * K + k] = s;
     }
-}
-
-// out[k] = in[k] * scale   (sum -> mean / biased variance)
-__global__ void __launch_bounds__(256) k_scale_vec(const float *__restrict__ in, int K, float scale, float *__restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < K) out[k] = in[k] * scale;
 }
 
 // Keras moving-average update (momentum 0.99): moving = moving * momentum + batch * (1 - momentum)

@@ -5,7 +5,7 @@
 
 namespace {
 inline int rows_per_chunk_for(int M, int *n_chunks) {
-    int rpc = 256;                                   // multiple of 64
+    int rpc = 64;                                    // multiple of 64 (the row step of k_dense_grad_partial)
     while ((long)cdiv(M, rpc) > 1024) rpc *= 2;      // at most 1024 partials
     *n_chunks = std::max(1, cdiv(M, rpc));
     return rpc;
@@ -67,9 +67,9 @@ int gnn_dense_grad(const float *X, int32_t ldx, const int32_t *rowidx, int32_t K
     dim3 grid(n_chunks, cdiv(K, 64), cdiv(H, 64));
     gnn::k_dense_grad_partial<<<grid, 256, 0, st>>>(X, ldx, rowidx, K, dZ, ldz, H, M, rpc, Ppart, q ? qpart : nullptr);
     LAUNCH_OK();
-    gnn::k_reduce_partials<<<cdiv((long)K * H, 256), 256, 0, st>>>(Ppart, n_chunks, K * H, P, accumulate);
+    gnn::k_reduce_partials<<<cdiv((long)K * H, 256), 256, 0, st>>>(Ppart, n_chunks, K * H, P, accumulate, 1.0f);
     LAUNCH_OK();
-    if (q) { gnn::k_reduce_partials<<<cdiv(H, 256), 256, 0, st>>>(qpart, n_chunks, H, q, accumulate); LAUNCH_OK(); }
+    if (q) { gnn::k_reduce_partials<<<cdiv(H, 256), 256, 0, st>>>(qpart, n_chunks, H, q, accumulate, 1.0f); LAUNCH_OK(); }
     return 0;
 }
 
@@ -96,20 +96,21 @@ int gnn_colstats(const float *X, int32_t ldx, const int32_t *rowidx, int32_t K, 
     if (K < 1 || M < 1 || !X || !mean || !var) return fail("bad arguments (batch statistics need at least one row)");
     if (!workspace || workspace_bytes < gnn_colstats_workspace_bytes(K, M)) return fail("workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    if (M <= 8192) {                                 // small batches: everything in one launch
+        gnn::k_colstats_small<<<K, 256, 0, st>>>(X, ldx, rowidx, K, M, mean, var, moving_mean, moving_var, momentum, gate);
+        LAUNCH_OK();
+        return 0;
+    }
     int n_chunks;
     const int rpc = rows_per_chunk_for(M, &n_chunks);
-    float *part = (float *)workspace, *sum = part + (size_t)n_chunks * K;
+    float *part = (float *)workspace;
     gnn::k_colstats_partial<<<n_chunks, 256, 0, st>>>(X, ldx, rowidx, K, M, rpc, nullptr, part);
     LAUNCH_OK();
-    gnn::k_reduce_partials<<<cdiv(K, 256), 256, 0, st>>>(part, n_chunks, K, sum, 0);
-    LAUNCH_OK();
-    gnn::k_scale_vec<<<cdiv(K, 256), 256, 0, st>>>(sum, K, 1.0f / (float)M, mean);
+    gnn::k_reduce_partials<<<cdiv(K, 256), 256, 0, st>>>(part, n_chunks, K, mean, 0, 1.0f / (float)M);
     LAUNCH_OK();
     gnn::k_colstats_partial<<<n_chunks, 256, 0, st>>>(X, ldx, rowidx, K, M, rpc, mean, part);
     LAUNCH_OK();
-    gnn::k_reduce_partials<<<cdiv(K, 256), 256, 0, st>>>(part, n_chunks, K, sum, 0);
-    LAUNCH_OK();
-    gnn::k_scale_vec<<<cdiv(K, 256), 256, 0, st>>>(sum, K, 1.0f / (float)M, var);
+    gnn::k_reduce_partials<<<cdiv(K, 256), 256, 0, st>>>(part, n_chunks, K, var, 0, 1.0f / (float)M);
     LAUNCH_OK();
     if (moving_mean && moving_var) {
         gnn::k_bn_moving_update<<<cdiv(K, 256), 256, 0, st>>>(mean, var, K, moving_mean, moving_var, momentum, gate);

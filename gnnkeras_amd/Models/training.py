@@ -86,9 +86,18 @@ class _Prim:
     def __init__(self, device):
         self.dev, self.lib = device, nat.lib()
         self._ws = None
+        self._stream = nat.current_stream(device)   # one lookup per step (a _Prim lives for one forward + backward)
+        self._nbytes = {}
 
     def stream(self):
-        return nat.current_stream(self.dev)
+        return self._stream
+
+    def _ws_bytes(self, fn, *dims):
+        key = (fn, dims)
+        nb = self._nbytes.get(key)
+        if nb is None:
+            nb = self._nbytes[key] = getattr(self.lib, fn)(*dims)
+        return nb
 
     def ws(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
@@ -134,7 +143,7 @@ class _Prim:
 
     def colstats(self, x, ridx, M, mean, var):
         K = x.shape[1]
-        nb = self.lib.gnn_colstats_workspace_bytes(K, M)
+        nb = self._ws_bytes('gnn_colstats_workspace_bytes', K, M)
         ws = self.ws(nb)
         nat.check(self.lib.gnn_colstats(nat.ptr(x), x.stride(0), nat.ptr(ridx), K, M, nat.ptr(mean), nat.ptr(var), None, None,
                                         BN_MOMENTUM, None, nat.ptr(ws), ws.numel(), self.stream()))
@@ -142,7 +151,7 @@ class _Prim:
     def dense_grad(self, x, ridx, dZ, M, P, q, accumulate):
         K, H = x.shape[1], dZ.shape[1]
         assert P.is_contiguous() and P.shape[-1] == H
-        nb = self.lib.gnn_dense_grad_workspace_bytes(K, H, M)
+        nb = self._ws_bytes('gnn_dense_grad_workspace_bytes', K, H, M)
         ws = self.ws(nb)
         nat.check(self.lib.gnn_dense_grad(nat.ptr(x), x.stride(0), nat.ptr(ridx), K, nat.ptr(dZ), dZ.stride(0), H, M,
                                           nat.ptr(P), nat.ptr(q), int(accumulate), nat.ptr(ws), ws.numel(), self.stream()))

@@ -85,7 +85,7 @@ struct SegDenseArgs {
     float *Y; int ldy; const int *out_rowidx;
 };
 
-constexpr int SD_TM = 64, SD_TN = 64, SD_KC = 32, SD_LDX = 34, SD_LDW = 80, SD_LDY = 68;
+constexpr int SD_TM = 64, SD_TN = 64, SD_KC = 32, SD_SC = 4, SD_LDX = 34, SD_LDW = 80, SD_LDY = 68;
 
 // K chunks of 32 run over the *virtual* concatenation, so several narrow segments (labels 14 + aggregated labels 14 +
 // aggregated arcs 3) share one chunk.  Staging is lane-contiguous: a wave reads 2 x 128 B of X rows / 256 B of a W row
@@ -107,10 +107,15 @@ __global__ void __launch_bounds__(256) k_segdense(SegDenseArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        for (int k0 = 0; k0 < K; k0 += SD_KC) {
-            // ---- X chunk: this thread's virtual column is fixed, resolve its segment once ----
-            {
-                const int kv = k0 + xc;
+        // K runs in super-chunks of SD_SC x 32 virtual columns: the loads of a whole super-chunk (X: 8 values per thread
+        // and chunk, W: 8) are issued before the first is used, so a 95-column training layer costs ONE global round
+        // trip instead of three; the chunks then go through LDS one at a time.
+        for (int k0 = 0; k0 < K; k0 += SD_SC * SD_KC) {
+            float xv[SD_SC][8], wv[SD_SC][8];
+#pragma unroll
+            for (int sc = 0; sc < SD_SC; ++sc) {
+                // ---- X chunk: this thread's virtual column is fixed, resolve its segment once ----
+                const int kv = k0 + sc * SD_KC + xc;
                 Seg sg = a.seg[0];                              // static indices only: a runtime-indexed kernel-argument
                 int sbeg = 0, start = a.seg[0].width;           // array would be copied to scratch memory
 #pragma unroll
@@ -121,37 +126,44 @@ __global__ void __launch_bounds__(256) k_segdense(SegDenseArgs a) {
                 const int off = kv - sbeg;
 #pragma unroll
                 for (int pass = 0; pass < 8; ++pass) {
-                    const int rr = xr0 + 8 * pass, m = m0 + rr;
-                    float v = 0.0f;
-                    if (m < a.M && kv < K) v = sg.ptr[(sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m) * sg.ld + off];
-                    Xs[rr * SD_LDX + xc] = v;
+                    const int m = m0 + xr0 + 8 * pass;
+                    xv[sc][pass] = 0.0f;
+                    if (m < a.M && kv < K) xv[sc][pass] = sg.ptr[(sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m) * sg.ld + off];
+                }
+                // ---- W chunk: weight rows of the virtual columns (row = seg.wrow + offset inside the segment) ----
+#pragma unroll
+                for (int pass = 0; pass < 8; ++pass) {
+                    const int kw = k0 + sc * SD_KC + wave + 4 * pass;
+                    int wrow = a.seg[0].wrow + kw, wstart = a.seg[0].width;
+#pragma unroll
+                    for (int s = 1; s < GNN_MAX_SEGS; ++s) {
+                        if (s < a.nseg && kw >= wstart) wrow = a.seg[s].wrow + kw - wstart;
+                        if (s < a.nseg) wstart += a.seg[s].width;
+                    }
+                    wv[sc][pass] = 0.0f;
+                    if (kw < K && n0 + lane < a.H) wv[sc][pass] = a.W[(size_t)wrow * a.ldw + n0 + lane];
                 }
             }
-            // ---- W chunk: weight rows of the virtual columns (row = seg.wrow + offset inside the segment) ----
 #pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-                const int kk = wave + 4 * pass, kv = k0 + kk;
-                int wrow = a.seg[0].wrow + kv, start = a.seg[0].width;
+            for (int sc = 0; sc < SD_SC; ++sc) {
+                if (k0 + sc * SD_KC >= K) break;
 #pragma unroll
-                for (int s = 1; s < GNN_MAX_SEGS; ++s) {
-                    if (s < a.nseg && kv >= start) wrow = a.seg[s].wrow + kv - start;
-                    if (s < a.nseg) start += a.seg[s].width;
+                for (int pass = 0; pass < 8; ++pass) {
+                    Xs[(xr0 + 8 * pass) * SD_LDX + xc] = xv[sc][pass];
+                    Ws[(wave + 4 * pass) * SD_LDW + lane] = wv[sc][pass];
                 }
-                float v = 0.0f;
-                if (kv < K && n0 + lane < a.H) v = a.W[(size_t)wrow * a.ldw + n0 + lane];
-                Ws[kk * SD_LDW + lane] = v;
-            }
-            __syncthreads();
+                __syncthreads();
 #pragma unroll
-            for (int s4 = 0; s4 < SD_KC / 4; ++s4) {
-                const float av = Xs[(16 * wave + r) * SD_LDX + 4 * s4 + g];
+                for (int s4 = 0; s4 < SD_KC / 4; ++s4) {
+                    const float av = Xs[(16 * wave + r) * SD_LDX + 4 * s4 + g];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float bv = Ws[(4 * s4 + g) * SD_LDW + 16 * c + r];
-                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[c], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c) {
+                        const float bv = Ws[(4 * s4 + g) * SD_LDW + 16 * c + r];
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[c], 0, 0, 0);
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
         // C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg  -> LDS tile -> row-contiguous stores
 #pragma unroll

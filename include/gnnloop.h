@@ -134,7 +134,9 @@ typedef struct gnn_loop_args {
      * Destination rows with very many in-arcs are cut into segments [heavy_seg_beg[s], heavy_seg_end[s]) of the arcs of
      * `adjacency` (its src / w arrays); before every iteration a pre-pass sums each segment with a whole workgroup into
      * the virtual state row n_nodes + s, and the iterations walk `adjacency_light`, in which a hub row lists its virtual
-     * rows (n_src = n_nodes + n_heavy_segments) instead of its arcs. */
+     * rows (n_src = n_nodes + n_heavy_segments) instead of its arcs.
+     * A binder should split every row above ~512 in-arcs (gnnkeras_amd/sparse.py: split_heavy does): besides the
+     * load balance, the fused kernels' in-launch hand-offs poll with a bound (~0.4 s) sized for rows of that order. */
     gnn_csr_t adjacency_light;
     const int32_t *heavy_seg_beg, *heavy_seg_end;
     int32_t n_heavy_segments;

@@ -110,6 +110,21 @@ int check_csr(const gnn_csr_t &c, const char *name, int n_dst, int n_src) {
 // --- launchers -------------------------------------------------------------------------------------------------------
 int launch_aggregate(const int *gate, const gnn_csr_t &c, const float *X, int ldx, int F, float *out, int ldo, hipStream_t st) {
     if (c.n_dst == 0 || F == 0) return 0;
+    if ((F == 16 || F == 32 || F == 64) && ldx % 4 == 0 && ldo % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const int lpr = F / 4, groups = 256 / lpr;
+        const int grid = std::min(cdiv(c.n_dst, groups), 256 * 16);
+#define AGGV(L) (c.w ? gnn::k_aggregate_vec<L, true><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, ldx, out, ldo) \
+               : gnn::k_aggregate_vec<L, false><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, ldx, out, ldo))
+        switch (lpr) {
+            case 4: AGGV(4); break;
+            case 8: AGGV(8); break;
+            default: AGGV(16); break;
+        }
+#undef AGGV
+        LAUNCH_OK();
+        return 0;
+    }
     int G = 4;
     while (G < F && G < 64) G <<= 1;
     const int groups = 256 / G;
@@ -145,7 +160,8 @@ int launch_segdense(gnn::SegDenseArgs &a, hipStream_t st) {
             return 0;
         }
     }
-    gnn::k_segdense<<<cdiv(a.M, gnn::SD_TM), 256, 0, st>>>(a);
+    if (a.M <= 16384) gnn::k_segdense<4><<<cdiv(a.M, gnn::SD_TM), 256, 0, st>>>(a);      // latency regime
+    else              gnn::k_segdense<1><<<cdiv(a.M, gnn::SD_TM), 256, 0, st>>>(a);      // throughput regime
     LAUNCH_OK();
     return 0;
 }

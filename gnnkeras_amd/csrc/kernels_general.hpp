@@ -61,6 +61,39 @@ k_aggregate(const int *gate, int n_dst, const int *__restrict__ rowptr, const in
     }
 }
 
+// The same product for rows that allow 16-B accesses (F, ldx, ldo multiples of 4, 16-B aligned bases: the padded state
+// matrix of the un-fused and training paths): LPR = F/4 lanes own a destination row, each lane carries a float4 column
+// chunk, 8 source rows in flight; a wave instruction moves 64/LPR whole rows instead of one.
+template <int LPR, bool HAS_W>
+__global__ void __launch_bounds__(256)
+k_aggregate_vec(const int *gate, int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src,
+                const float *__restrict__ w, const float *__restrict__ row_scale, const float *__restrict__ X, int ldx,
+                float *__restrict__ out, int ldo) {
+    if (gate_closed(gate)) return;
+    const int l4 = threadIdx.x % LPR;
+    const int groups = blockDim.x / LPR;
+    for (int j = blockIdx.x * groups + threadIdx.x / LPR; j < n_dst; j += gridDim.x * groups) {
+        const int beg = rowptr[j], end = rowptr[j + 1];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int e = beg; e < end; e += 8) {                   // summed in arc order
+            f32x4 x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = e + i < end;
+                const int sid = ok ? src[e + i] : 0;
+                x[i] = ok ? *reinterpret_cast<const f32x4 *>(X + (size_t)sid * ldx + 4 * l4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (HAS_W) acc += (e + i < end ? w[e + i] : 0.0f) * x[i];
+                else acc += x[i];
+            }
+        }
+        if (row_scale) acc *= row_scale[j];
+        *reinterpret_cast<f32x4 *>(out + (size_t)j * ldo + 4 * l4) = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Segmented dense layer on the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32, k-ordered fma chain):
 //   Y[orow(m), :H] = act( sum_s X_s[row_s(m), :] . W[wrow_s : wrow_s + width_s, :H] + bias + addend[arow(m), :H] )
@@ -85,16 +118,21 @@ struct SegDenseArgs {
     float *Y; int ldy; const int *out_rowidx;
 };
 
-constexpr int SD_TM = 64, SD_TN = 64, SD_KC = 32, SD_SC = 4, SD_LDX = 34, SD_LDW = 80, SD_LDY = 68;
+constexpr int SD_TM = 64, SD_TN = 64, SD_KC = 32, SD_LDX = 34, SD_LDW = 80, SD_LDY = 68;
 
 // K chunks of 32 run over the *virtual* concatenation, so several narrow segments (labels 14 + aggregated labels 14 +
 // aggregated arcs 3) share one chunk.  Staging is lane-contiguous: a wave reads 2 x 128 B of X rows / 256 B of a W row
 // per instruction, and results leave through an LDS tile as 256-B row pieces.
-__global__ void __launch_bounds__(256) k_segdense(SegDenseArgs a) {
+// SC = chunks of 32 columns whose loads are issued together: 4 for small M (latency: a 95-column training layer costs one
+// round trip instead of three), 1 for large M (throughput: ~64 VGPRs and 19 KB of LDS -> 8 waves / SIMD; this access
+// pattern, like the gather, is served by the number of waves in flight, not by the loads in flight per wave).
+template <int SC>
+__global__ void __launch_bounds__(256, SC == 1 ? 8 : 4) k_segdense(SegDenseArgs a) {
     if (gate_closed(a.gate)) return;
-    __shared__ float Xs[SD_TM * SD_LDX];
-    __shared__ float Ws[SD_KC * SD_LDW];
-    __shared__ float Ys[SD_TM * SD_LDY];
+    constexpr int XW = SD_TM * SD_LDX + SD_KC * SD_LDW, YS = SD_TM * SD_LDY;
+    __shared__ float smem_sd[XW > YS ? XW : YS];
+    float *Xs = smem_sd, *Ws = smem_sd + SD_TM * SD_LDX;
+    float *Ys = smem_sd;                                        // the output tile reuses the staging space (barriers between)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * SD_TM;
@@ -107,13 +145,13 @@ __global__ void __launch_bounds__(256) k_segdense(SegDenseArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        // K runs in super-chunks of SD_SC x 32 virtual columns: the loads of a whole super-chunk (X: 8 values per thread
+        // K runs in super-chunks of SC x 32 virtual columns: the loads of a whole super-chunk (X: 8 values per thread
         // and chunk, W: 8) are issued before the first is used, so a 95-column training layer costs ONE global round
         // trip instead of three; the chunks then go through LDS one at a time.
-        for (int k0 = 0; k0 < K; k0 += SD_SC * SD_KC) {
-            float xv[SD_SC][8], wv[SD_SC][8];
+        for (int k0 = 0; k0 < K; k0 += SC * SD_KC) {
+            float xv[SC][8], wv[SC][8];
 #pragma unroll
-            for (int sc = 0; sc < SD_SC; ++sc) {
+            for (int sc = 0; sc < SC; ++sc) {
                 // ---- X chunk: this thread's virtual column is fixed, resolve its segment once ----
                 const int kv = k0 + sc * SD_KC + xc;
                 Seg sg = a.seg[0];                              // static indices only: a runtime-indexed kernel-argument
@@ -145,7 +183,7 @@ __global__ void __launch_bounds__(256) k_segdense(SegDenseArgs a) {
                 }
             }
 #pragma unroll
-            for (int sc = 0; sc < SD_SC; ++sc) {
+            for (int sc = 0; sc < SC; ++sc) {
                 if (k0 + sc * SD_KC >= K) break;
 #pragma unroll
                 for (int pass = 0; pass < 8; ++pass) {

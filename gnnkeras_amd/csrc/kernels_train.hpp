@@ -99,15 +99,33 @@ k_dense_grad_partial(const float *__restrict__ X, int ldx, const int *__restrict
     if (qpart && blockIdx.y == 0 && tid < 64 && h0 + tid < H) qpart[(size_t)blockIdx.x * H + h0 + tid] = qacc;
 }
 
-// out[i] (+)= scale * sum_c part[c][i]  in chunk order
+// out[i] (+)= scale * sum_c part[c][i].  64 outputs per workgroup; the chunks are dealt to 4 thread rows in contiguous
+// quarters (each summed in chunk order, 8 loads in flight), and the quarters meet in LDS in order: a fixed summation
+// tree, bitwise reproducible.
 __global__ void __launch_bounds__(256)
 k_reduce_partials(const float *__restrict__ part, int n_chunks, int n, float *__restrict__ out, int accumulate, float scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
+    const int per = (n_chunks + 3) / 4, c_beg = ty * per, c_end = min(n_chunks, c_beg + per);
     float s = 0.0f;
-    for (int c = 0; c < n_chunks; ++c) s += part[(size_t)c * n + i];
-    s *= scale;
-    out[i] = accumulate ? out[i] + s : s;
+    if (i < n) {
+        int c = c_beg;
+        for (; c + 8 <= c_end; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c < c_end; ++c) s += part[(size_t)c * n + i];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        const float t = (((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx]) * scale;
+        out[i] = accumulate ? out[i] + t : t;
+    }
 }
 
 // Column statistics of a SMALL matrix (a merged MUTAG batch: ~1 k rows) in one launch: one workgroup per column, rows
@@ -163,15 +181,25 @@ k_colstats_small(const float *__restrict__ X, int ldx, const int *__restrict__ r
 __global__ void __launch_bounds__(256)
 k_colstats_partial(const float *__restrict__ X, int ldx, const int *__restrict__ rowidx, int K, int M,
                    int rows_per_chunk, const float *__restrict__ center, float *__restrict__ part) {
+    // 64 columns x 4 row groups per pass: a wave reads 256 contiguous bytes of one row; the 4 row groups meet in LDS in
+    // group order (deterministic)
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int m_beg = blockIdx.x * rows_per_chunk, m_end = min(M, m_beg + rows_per_chunk);
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        const float c = center ? center[k] : 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + tx;
+        const float c = (center && k < K) ? center[k] : 0.0f;
         float s = 0.0f;
-        for (int m = m_beg; m < m_end; ++m) {
-            const float x = X[(rowidx ? (size_t)rowidx[m] : (size_t)m) * ldx + k] - c;
-            s = center ? fmaf(x, x, s) : s + x;
+        if (k < K) {
+            for (int m = m_beg + ty; m < m_end; m += 4) {
+                const float x = X[(rowidx ? (size_t)rowidx[m] : (size_t)m) * ldx + k] - c;
+                s = center ? fmaf(x, x, s) : s + x;
+            }
         }
-        part[(size_t)blockIdx.x * K + k] = s;
+        red[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && k < K) part[(size_t)blockIdx.x * K + k] = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+        __syncthreads();
     }
 }
 

@@ -484,12 +484,15 @@ def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, dev
     batches), all-gather otherwise (Erdős–Rényi graphs: every slice is almost entirely somebody's halo)."""
     if exchange not in ('auto', 'allgather', 'halo'): raise ValueError('exchange must be auto, allgather or halo')
     if exchange == 'auto':
+        # decided from the WHOLE graph (every rank holds it on the host), never from the caller's own shard: all ranks must
+        # reach the same answer or they would wait in different collectives
         chunk, ranges = partition(graph.nodes.shape[0], world_size)
-        lo, hi = ranges[rank]
         src, dst = graph.arc_ids[:, 0], graph.arc_ids[:, 1]
-        mine = (dst >= lo) & (dst < hi)
-        remote = np.unique(src[mine & ((src < lo) | (src >= hi))])
-        full = max((world_size - 1) * chunk, 1)
-        exchange = 'halo' if len(remote) < 0.5 * full else 'allgather'
+        worst = 0.0
+        for lo, hi in ranges:
+            mine = (dst >= lo) & (dst < hi)
+            remote = np.unique(src[mine & ((src < lo) | (src >= hi))])
+            worst = max(worst, len(remote) / max((world_size - 1) * chunk, 1))
+        exchange = 'halo' if worst < 0.5 else 'allgather'
     cls = HaloShardedLoop if exchange == 'halo' else ShardedLoop
     return cls(model, graph, rank, world_size, device, group=group)

@@ -24,7 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernel_state_fused2.hpp"
-#include "kernel_state_fused3.hpp"   // raw-buffer load helpers (buf_rsrc, buf_ld_*)
+#include "buffer_ops.hpp"
 
 namespace gnn {
 
@@ -65,6 +65,7 @@ __device__ __forceinline__ void activate4(int act, f32x4 &x) {
 #undef F4_ALL
 }
 
+// -DGNN_F4_PROFILE: phase timers (scripts/f4_prof.py); experiment only, the timers themselves drain the memory pipeline
 #ifdef GNN_F4_PROFILE
 __device__ __forceinline__ unsigned long long f4_now() {
     unsigned long long t;
@@ -72,11 +73,6 @@ __device__ __forceinline__ unsigned long long f4_now() {
     return t;
 }
 __device__ unsigned long long g_f4_prof[8];
-#define F4_T0() const unsigned long long t0_ = f4_now()
-#define F4_ACC(slot) if (lane == 0) atomicAdd(&g_f4_prof[slot], f4_now() - t0_)
-#else
-#define F4_T0()
-#define F4_ACC(slot)
 #endif
 
 __device__ __forceinline__ int f4_ld_acquire(const int *p) {

@@ -1,0 +1,58 @@
+"""Soak test for the in-launch hand-offs: repeated runs must be bitwise reproducible, and the persistent whole-loop kernel
+(generation 5) must match the one-launch-per-iteration kernel it shares its tile arithmetic with (generation 2) bit for
+bit.  A race in the LDS ring (generation 4) or in the grid barrier (generation 5) would show up as a difference."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gnnkeras_amd import _native as nat
+from gnnkeras_amd.load_MUTAG import load_graphs
+from gnnkeras_amd.synth import er_graph
+from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+from gnnkeras_amd.Models.GNN import GNNgraphBased, GNNnodeBased
+from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+bad = 0
+# ---- MUTAG batches: generation 5 vs generation 2, bitwise -------------------------------------------------------------
+gs = load_graphs()
+for d, bs in ((32, 32), (64, 48)):
+    seq = MultiGraphSequencer(gs, 'g', 'average', bs, shuffle=False)
+    inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d); ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=0)
+    inp, lay = get_inout_dims('output', 14, 3, 2, 'g', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
+    gnn = GNNgraphBased(ns, no, d, 30, 0.02)
+    t0 = time.time(); n = 0
+    for rep in range(reps):
+        for b in range(len(seq)):
+            x = seq[b][0]
+            inputs = gnn.process_inputs(x)
+            s0 = torch.randn((x[0].shape[0], d), device='cuda') * 0.1
+            res = {}
+            for flag in (nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN5):
+                gnn.native_flags = flag
+                k, st, o = gnn.Loop(*inputs, state0=s0)
+                res[flag] = (float(k), st.clone(), o.clone())
+            a, c = res[nat.FLAG_FUSED_GEN2], res[nat.FLAG_FUSED_GEN5]
+            if a[0] != c[0] or not torch.equal(a[1], c[1]) or not torch.equal(a[2], c[2]):
+                bad += 1
+                print(f'MISMATCH d={d} rep={rep} batch={b}: k {a[0]} vs {c[0]}, state max diff {float((a[1] - c[1]).abs().max()):.3e}')
+            n += 1
+    print(f'MUTAG d={d} batch={bs}: {n} forward pairs, {bad} mismatches, {time.time() - t0:.1f} s')
+# ---- ER graph: generation 4 repeated, bitwise reproducible; persistent kernel at its size limit ----------------------------
+for N, E, flag, name in ((200000, 2000000, nat.FLAG_FUSED_GEN4, 'generation 4'), (16000, 160000, nat.FLAG_FUSED_GEN5, 'generation 5')):
+    g = er_graph(N, E, aggregation_mode='average'); seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False); x = seq[0][0]
+    d = 64
+    inp, lay = get_inout_dims('state', 14, 3, 2, 'n', d); ns = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0)
+    inp, lay = get_inout_dims('output', 14, 3, 2, 'n', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
+    gnn = GNNnodeBased(ns, no, d, 20, 0.0); gnn.native_flags = flag
+    inputs = gnn.process_inputs(x)
+    s0 = torch.randn((N, d), device='cuda') * 0.1
+    ref = None; t0 = time.time()
+    for rep in range(reps * 5):
+        k, st, o = gnn.Loop(*inputs, state0=s0)
+        if ref is None: ref = (float(k), st.clone(), o.clone())
+        elif float(k) != ref[0] or not torch.equal(st, ref[1]) or not torch.equal(o, ref[2]):
+            bad += 1
+            print(f'{name} NOT REPRODUCIBLE at rep {rep}: max diff {float((st - ref[1]).abs().max()):.3e}')
+    print(f'{name} N={N}: {reps * 5} runs, k={ref[0]}, {time.time() - t0:.1f} s')
+print('soak:', 'OK' if bad == 0 else f'{bad} FAILURES')
+sys.exit(1 if bad else 0)

@@ -642,6 +642,8 @@ bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
     if (p.SP > 64) return false;   // LDS: [64 x 2SP] tile + [2SP x SP] weights must leave room for 2 workgroups per CU
     // the fused kernel addresses state rows and C with 32-bit byte offsets off a scalar base
     if ((size_t)(std::max(a.adjacency.n_src, p.N) + p.n_heavy) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return false;
+    // ... and the CSR arrays through 4 GiB buffer windows
+    if ((size_t)iter_adjacency(a).nnz * 4 >= ((size_t)1 << 32) || ((size_t)p.N + 1) * 4 >= ((size_t)1 << 32)) return false;
     for (int t = 0; t < p.T; ++t)
         if (a.net_state[t].n_layers != 1 || a.net_state[t].activation[0] == GNN_ACT_SOFTMAX) return false;
     return true;

@@ -578,8 +578,11 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
                     const float *src, float *dst, int row_base, int *flag_next, float *k_out, float k_val,
                     hipStream_t st) {
     auto type_of = [&](int t) {
+        const gnn_mlp_t &m = a.net_state[t];
+        const bool two = m.n_layers == 2;              // second Dense inside the wave-specialised kernel (can_fuse)
         return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg,
-                              (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0]};
+                              (int)m.units[0], (int)m.activation[0],
+                              two ? m.kernel[1] : nullptr, two ? m.bias[1] : nullptr, two ? (int)m.activation[1] : 0};
     };
     TRY(launch_heavy(a, p, n_gate == 1 ? gate : nullptr, src, st));
     const gnn_csr_t &adj = iter_adjacency(a);
@@ -614,6 +617,8 @@ int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first,
     if (env < 0) { const char *e = getenv("GNN_FUSED_KERNEL"); env = e ? atoi(e) : 0; }
     if (pinned == 0 && env != 0 && env != 5) return 2;
     if (p.n_heavy != 0 || a.max_iteration < 1) return 2;
+    for (int t = 0; t < p.T; ++t)
+        if (a.net_state[t].n_layers != 1) return 2;         // two-layer state networks: wave-specialised kernel only
     gnn::SmallArgs sa;
     memset(&sa, 0, sizeof(sa));
     gnn::Fused2Args &fa = sa.f;
@@ -624,7 +629,7 @@ int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first,
     for (int t = 0; t < p.T; ++t)
         if (p.tp[t].count > 0)
             fa.tp[fa.n_types++] = gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg,
-                                                 (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0]};
+                                                 (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0], nullptr, nullptr, 0};
     if (fa.n_types == 0) return 2;
     fa.S = p.S; fa.thr = a.state_threshold; fa.k_out = a.k_out;
     sa.buf[0] = B[0]; sa.buf[1] = B[1];
@@ -644,8 +649,17 @@ bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
     if ((size_t)(std::max(a.adjacency.n_src, p.N) + p.n_heavy) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return false;
     // ... and the CSR arrays through 4 GiB buffer windows
     if ((size_t)iter_adjacency(a).nnz * 4 >= ((size_t)1 << 32) || ((size_t)p.N + 1) * 4 >= ((size_t)1 << 32)) return false;
-    for (int t = 0; t < p.T; ++t)
-        if (a.net_state[t].n_layers != 1 || a.net_state[t].activation[0] == GNN_ACT_SOFTMAX) return false;
+    // One Dense layer everywhere, or - in the wave-specialised kernel only, where the matrix waves have the time and LDS
+    // holds a second weight matrix in place of two ring slots - two Dense layers with at most SP hidden units.
+    bool two = false;
+    for (int t = 0; t < p.T; ++t) {
+        const gnn_mlp_t &m = a.net_state[t];
+        if (m.n_layers < 1 || m.n_layers > 2 || m.activation[0] == GNN_ACT_SOFTMAX) return false;
+        if (m.n_layers == 2 && (m.activation[1] == GNN_ACT_SOFTMAX || m.units[0] > p.SP)) return false;
+        if (t > 0 && (m.n_layers == 2) != two) return false;            // every node type the same depth
+        two = m.n_layers == 2;
+    }
+    if (two && fused_generation(p.SP, p.N, a.flags) != 4) return false;
     return true;
 }
 

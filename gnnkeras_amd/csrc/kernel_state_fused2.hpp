@@ -26,9 +26,13 @@ namespace gnn {
 struct FusedType {
     const int *rows;   // node ids of this type (nullptr = identity)
     int count;
-    const float *Wf;   // folded first layer [in_dim x H] row-major, H == S
+    const float *Wf;   // folded first layer [in_dim x H] row-major (H == S for one-layer state networks)
     int wrow_state, wrow_agg;
     int H, act;
+    // second Dense of a two-layer state network (k_state_fused4<.., L2 = true> only; nullptr otherwise): H -> S
+    const float *W2;   // [H x S] row-major
+    const float *b2;   // [S]
+    int act2;
 };
 
 struct Fused2Args {

@@ -28,7 +28,7 @@
 
 namespace gnn {
 
-template <int SP, int NC = 4>
+template <int SP, int NC = 4, bool L2 = false>
 struct Fused4Cfg {
     static constexpr int NW = 16, NT = 64 * NW;
     static constexpr int NCONS = NC;                 // matrix waves (wave ids 0..NC-1)
@@ -41,9 +41,10 @@ struct Fused4Cfg {
     static constexpr bool SWZ = SP >= 32;
     static constexpr int LDW = SWZ ? SP : SP + 32;
     static constexpr int NCT = SP / 16;              // 16-column MFMA tiles per row tile
-    static constexpr int NS = SP == 64 ? 5 : 8;      // ring slots
+    static constexpr int NS = SP == 64 ? (L2 ? 3 : 5) : 8;   // ring slots (two-layer networks trade slots for W2)
     static constexpr int SLOT = 16 * LDX;            // floats per slot
-    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)NS * SLOT + 2 * SP * LDW) + sizeof(int) * 2 * NS;
+    static constexpr int W2F = L2 ? SP * LDW + SP : 0;        // floats of the second layer: W2 [SP][LDW] + b2 [SP]
+    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)NS * SLOT + 2 * SP * LDW + W2F) + sizeof(int) * 2 * NS;
 };
 
 // the activation of 4 values with ONE wave-uniform switch around them
@@ -79,20 +80,21 @@ __device__ __forceinline__ int f4_ld_acquire(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int SP, bool HAS_W, int DEPTH, int NC>
+template <int SP, bool HAS_W, int DEPTH, int NC, bool L2>
 __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     {
         int open = a.gate == nullptr;
         for (int i = 0; i < a.n_gate && !open; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
         if (!open) return;
     }
-    using Cfg = Fused4Cfg<SP, NC>;
+    using Cfg = Fused4Cfg<SP, NC, L2>;
     constexpr int NT = Cfg::NT, LPR = Cfg::LPR, IPL = Cfg::IPL, LDX = Cfg::LDX, LDW = Cfg::LDW, NS = Cfg::NS;
     constexpr int SPIN_MAX = 1 << 22;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *Xs = reinterpret_cast<float *>(smem);                         // [NS][16][LDX] : [state | agg]
     float *Ws = Xs + NS * Cfg::SLOT;                                     // [2SP][LDW]    : W1 rows (state ; agg)
-    int *fill = reinterpret_cast<int *>(Ws + 2 * SP * LDW);              // [NS] gather-wave deposits so far
+    float *W2s = Ws + 2 * SP * LDW;                                      // L2: [SP][LDW] second-layer kernel, then b2 [SP]
+    int *fill = reinterpret_cast<int *>(W2s + Cfg::W2F);                 // [NS] gather-wave deposits so far
     int *freed = fill + NS;                                              // [NS] tiles consumed so far
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,8 +110,15 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
         const int k = i / SP, n = i % SP;
         const int kk = k < SP ? k : k - SP;
         float v = 0.0f;
-        if (kk < S && n < S) v = tp.Wf[(size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + kk) * tp.H + n];
+        if (kk < S && n < tp.H) v = tp.Wf[(size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + kk) * tp.H + n];
         Ws[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = v;
+    }
+    if (L2) {                                   // second Dense: rows k < H (hidden units), columns n < S, same swizzle
+        for (int i = tid; i < SP * SP; i += NT) {
+            const int k = i / SP, n = i % SP;
+            W2s[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = (k < tp.H && n < S) ? tp.W2[(size_t)k * S + n] : 0.0f;
+        }
+        if (tid < SP) W2s[SP * LDW + tid] = tid < S ? tp.b2[tid] : 0.0f;
     }
     if (tid < 2 * NS) fill[tid] = 0;
     __syncthreads();
@@ -267,7 +276,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                     const int col = 16 * ci + r;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg)
-                        c[ci][reg] = buf_ld_f32(r_C, (jrow[reg] >= 0 && col < S) ? ((unsigned)jrow[reg] * (unsigned)a.ldC + (unsigned)col) * 4u : BUF_OFF);
+                        c[ci][reg] = buf_ld_f32(r_C, (jrow[reg] >= 0 && col < tp.H) ? ((unsigned)jrow[reg] * (unsigned)a.ldC + (unsigned)col) * 4u : BUF_OFF);
                 }
             }
             const int s = t % NS, round = t / NS;
@@ -301,6 +310,45 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
             for (int ci = 0; ci < Cfg::NCT; ++ci)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) X[(4 * g + reg) * LDX + SP + 16 * ci + r] = c[ci][reg];
+            if (L2) {
+                // hidden layer: activation in place (row-major, 4 trips), then h . W2 on the matrix cores with the A
+                // fragments read from the same agg half, and the result stashed over it again
+#pragma unroll 1
+                for (int i = 0; i < 4; ++i) {
+                    float *ph = X + (4 * i + g) * LDX + SP + 4 * r;
+                    if (4 * r < SP) {
+                        const float2 lo = *reinterpret_cast<const float2 *>(ph), hi = *reinterpret_cast<const float2 *>(ph + 2);
+                        f32x4 hv = {lo.x, lo.y, hi.x, hi.y};
+                        activate4(tp.act, hv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = 4 * r + e < tp.H ? hv[e] : 0.0f;
+                        *reinterpret_cast<float2 *>(ph) = make_float2(hv[0], hv[1]);
+                        *reinterpret_cast<float2 *>(ph + 2) = make_float2(hv[2], hv[3]);
+                    }
+                }
+#pragma unroll
+                for (int ci = 0; ci < Cfg::NCT; ++ci) {
+                    const float b = W2s[SP * LDW + 16 * ci + r];
+                    c[ci] = (f32x4){b, b, b, b};
+                }
+                const float *hrow = X + r * LDX + SP + g;
+#pragma unroll 2
+                for (int s4 = 0; s4 < SP / 4; ++s4) {
+                    const float av = hrow[4 * s4];
+                    const int k = 4 * s4 + g;
+#pragma unroll
+                    for (int ci = 0; ci < Cfg::NCT; ++ci) {
+                        const int n = 16 * ci + r;
+                        const float bv = W2s[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)];
+                        c[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c[ci], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int ci = 0; ci < Cfg::NCT; ++ci)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) X[(4 * g + reg) * LDX + SP + 16 * ci + r] = c[ci][reg];
+            }
+            const int act_out = L2 ? tp.act2 : tp.act;
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) {
                 const float *px = X + (4 * i + g) * LDX;
@@ -311,7 +359,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                     const float2 olo = *reinterpret_cast<const float2 *>(px + 4 * r), ohi = *reinterpret_cast<const float2 *>(px + 4 * r + 2);
                     f32x4 nv = {plo.x, plo.y, phi.x, phi.y};
                     const f32x4 ov = {olo.x, olo.y, ohi.x, ohi.y};
-                    activate4(tp.act, nv);
+                    activate4(act_out, nv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         nv[e] = (j >= 0 && 4 * r + e < S) ? nv[e] : 0.0f;
@@ -346,12 +394,12 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     }
 }
 
-template <int SP, bool HAS_W, int DEPTH, int NC = 4>
+template <int SP, bool HAS_W, int DEPTH, bool L2 = false, int NC = 4>
 int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
-    using Cfg = Fused4Cfg<SP, NC>;
+    using Cfg = Fused4Cfg<SP, NC, L2>;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH, NC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH, NC, L2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
         attr = true;
     }
@@ -371,13 +419,14 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0) return 0;
-    k_state_fused4<SP, HAS_W, DEPTH, NC><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
+    k_state_fused4<SP, HAS_W, DEPTH, NC, L2><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 inline int launch_fused4(Fused2Args &fa, int SP, int depth, int n_cu, hipStream_t st) {
 #define F4_CASE(SPV)                                                                                                  \
     case SPV:                                                                                                         \
+        if (fa.tp[0].W2) return fa.w ? launch_fused4_one<SPV, true, 4, true>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4, true>(fa, n_cu, st); \
         if (fa.w) return launch_fused4_one<SPV, true, 4>(fa, n_cu, st);                                                \
         return depth == 8 ? launch_fused4_one<SPV, false, 8>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4>(fa, n_cu, st);
     switch (SP) {

@@ -677,3 +677,24 @@ def test_hub_rows_use_the_segment_prepass(mode, weights, d):
         k, st, o = model.Loop(*model.process_inputs(x), state0=None if s0 is None else dev(s0))
         assert float(k) == float(k64)
         assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL
+
+
+@pytest.mark.parametrize('d,hidden,mode', [(64, 48, 'average'), (32, 32, 'sum'), (64, 64, 'normalized')])
+def test_two_layer_state_network_runs_fused_at_scale(d, hidden, mode):
+    """A state network with one hidden layer (reference MLP(hidden_units=...), MLP.py:82-140) on a graph large enough
+    for the wave-specialised kernel: the second Dense runs inside the matrix waves; every path must agree with the oracle."""
+    rng = np.random.default_rng(11)
+    N = 40000
+    g = er_graph(N, 6 * N, seed=3, aggregation_mode=mode)
+    ns, no = starter_nets('n', d, hidden_state=[hidden], act='tanh', scale=0.3)
+    thr = 0.02 if mode == 'average' else 0.0
+    model = GNNnodeBased(ns, no, d, 8, thr)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    x = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    inputs = model.process_inputs(x)
+    for flags in (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN4):
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=torch.from_numpy(s0).cuda())
+        assert float(k) == float(k64), (flags, float(k), k64)
+        assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, flags

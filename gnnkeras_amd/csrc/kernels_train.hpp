@@ -50,7 +50,7 @@ constexpr int DG_LD = 80;          // == 16 (mod 32): conflict-free transposed A
 __global__ void __launch_bounds__(256)
 k_dense_grad_partial(const float *__restrict__ X, int ldx, const int *__restrict__ rowidx, int K,
                      const float *__restrict__ dZ, int ldz, int H, int M, int rows_per_chunk,
-                     float *__restrict__ Ppart, float *__restrict__ qpart) {
+                     float *__restrict__ part, int want_q) {      // part: [chunk][K*H (P) + H (q)]
     __shared__ float Xs[64 * DG_LD];
     __shared__ float Zs[64 * DG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,12 +81,12 @@ k_dense_grad_partial(const float *__restrict__ X, int ldx, const int *__restrict
             for (int c = 0; c < 4; ++c)
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Zs[(4 * s4 + g) * DG_LD + 16 * c + r], acc[c], 0, 0, 0);
         }
-        if (qpart && blockIdx.y == 0 && tid < 64) {
+        if (want_q && blockIdx.y == 0 && tid < 64) {
             for (int mm = 0; mm < 64; ++mm) qacc += Zs[mm * DG_LD + tid];
         }
         __syncthreads();
     }
-    float *Pp = Ppart + (size_t)blockIdx.x * K * H;
+    float *Pp = part + (size_t)blockIdx.x * ((size_t)K * H + H);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int h = h0 + 16 * c + r;
@@ -96,14 +96,16 @@ k_dense_grad_partial(const float *__restrict__ X, int ldx, const int *__restrict
             if (k < K && h < H) Pp[(size_t)k * H + h] = acc[c][reg];
         }
     }
-    if (qpart && blockIdx.y == 0 && tid < 64 && h0 + tid < H) qpart[(size_t)blockIdx.x * H + h0 + tid] = qacc;
+    if (want_q && blockIdx.y == 0 && tid < 64 && h0 + tid < H) Pp[(size_t)K * H + h0 + tid] = qacc;
 }
 
-// out[i] (+)= scale * sum_c part[c][i].  64 outputs per workgroup; the chunks are dealt to 4 thread rows in contiguous
+// out[i] (+)= scale * sum_c part[c][i]  (entries i >= n1 go to out2[i - n1]: P and q of a weight gradient in one launch).
+// 64 outputs per workgroup; the chunks are dealt to 4 thread rows in contiguous
 // quarters (each summed in chunk order, 8 loads in flight), and the quarters meet in LDS in order: a fixed summation
 // tree, bitwise reproducible.
 __global__ void __launch_bounds__(256)
-k_reduce_partials(const float *__restrict__ part, int n_chunks, int n, float *__restrict__ out, int accumulate, float scale) {
+k_reduce_partials(const float *__restrict__ part, int n_chunks, int n, float *__restrict__ out, int accumulate, float scale,
+                  int n1, float *__restrict__ out2) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + tx;
@@ -124,7 +126,8 @@ k_reduce_partials(const float *__restrict__ part, int n_chunks, int n, float *__
     __syncthreads();
     if (ty == 0 && i < n) {
         const float t = (((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx]) * scale;
-        out[i] = accumulate ? out[i] + t : t;
+        float *o = i < n1 ? out + i : out2 + (i - n1);
+        if (i < n1 || out2) *o = accumulate ? *o + t : t;
     }
 }
 

@@ -59,17 +59,17 @@ int gnn_dense_grad(const float *X, int32_t ldx, const int32_t *rowidx, int32_t K
     hipStream_t st = (hipStream_t)stream;
     int n_chunks;
     const int rpc = rows_per_chunk_for(std::max(M, 1), &n_chunks);
-    float *Ppart = (float *)workspace, *qpart = Ppart + (size_t)n_chunks * K * H;
+    float *part = (float *)workspace;                   // [chunk][K*H + H]
     if (M == 0) {
         if (!accumulate) { HIP_OK(hipMemsetAsync(P, 0, sizeof(float) * K * H, st)); if (q) HIP_OK(hipMemsetAsync(q, 0, sizeof(float) * H, st)); }
         return 0;
     }
     dim3 grid(n_chunks, cdiv(K, 64), cdiv(H, 64));
-    gnn::k_dense_grad_partial<<<grid, 256, 0, st>>>(X, ldx, rowidx, K, dZ, ldz, H, M, rpc, Ppart, q ? qpart : nullptr);
+    gnn::k_dense_grad_partial<<<grid, 256, 0, st>>>(X, ldx, rowidx, K, dZ, ldz, H, M, rpc, part, q ? 1 : 0);
     LAUNCH_OK();
-    gnn::k_reduce_partials<<<cdiv((long)K * H, 64), 256, 0, st>>>(Ppart, n_chunks, K * H, P, accumulate, 1.0f);
+    const int n = K * H + H;                            // P and q leave in one reduction launch
+    gnn::k_reduce_partials<<<cdiv(n, 64), 256, 0, st>>>(part, n_chunks, n, P, accumulate, 1.0f, K * H, q);
     LAUNCH_OK();
-    if (q) { gnn::k_reduce_partials<<<cdiv(H, 64), 256, 0, st>>>(qpart, n_chunks, H, q, accumulate, 1.0f); LAUNCH_OK(); }
     return 0;
 }
 
@@ -106,11 +106,11 @@ int gnn_colstats(const float *X, int32_t ldx, const int32_t *rowidx, int32_t K, 
     float *part = (float *)workspace;
     gnn::k_colstats_partial<<<n_chunks, 256, 0, st>>>(X, ldx, rowidx, K, M, rpc, nullptr, part);
     LAUNCH_OK();
-    gnn::k_reduce_partials<<<cdiv(K, 64), 256, 0, st>>>(part, n_chunks, K, mean, 0, 1.0f / (float)M);
+    gnn::k_reduce_partials<<<cdiv(K, 64), 256, 0, st>>>(part, n_chunks, K, mean, 0, 1.0f / (float)M, K, nullptr);
     LAUNCH_OK();
     gnn::k_colstats_partial<<<n_chunks, 256, 0, st>>>(X, ldx, rowidx, K, M, rpc, mean, part);
     LAUNCH_OK();
-    gnn::k_reduce_partials<<<cdiv(K, 64), 256, 0, st>>>(part, n_chunks, K, var, 0, 1.0f / (float)M);
+    gnn::k_reduce_partials<<<cdiv(K, 64), 256, 0, st>>>(part, n_chunks, K, var, 0, 1.0f / (float)M, K, nullptr);
     LAUNCH_OK();
     if (moving_mean && moving_var) {
         gnn::k_bn_moving_update<<<cdiv(K, 256), 256, 0, st>>>(mean, var, K, moving_mean, moving_var, momentum, gate);

@@ -573,17 +573,20 @@ int device_cus() {
     return n_cu;
 }
 
+// what a fused kernel needs to know about node type t (the second Dense of a two-layer state network included)
+gnn::FusedType fused_type(const gnn_loop_args_t &a, const Plan &p, int t) {
+    const gnn_mlp_t &m = a.net_state[t];
+    const bool two = m.n_layers == 2;
+    return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg,
+                          (int)m.units[0], (int)m.activation[0],
+                          two ? m.kernel[1] : nullptr, two ? m.bias[1] : nullptr, two ? (int)m.activation[1] : 0};
+}
+
 // one fused iteration over every node type (one launch per type)
 int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, int n_gate, int gate_stride,
                     const float *src, float *dst, int row_base, int *flag_next, float *k_out, float k_val,
                     hipStream_t st) {
-    auto type_of = [&](int t) {
-        const gnn_mlp_t &m = a.net_state[t];
-        const bool two = m.n_layers == 2;              // second Dense inside the wave-specialised kernel (can_fuse)
-        return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg,
-                              (int)m.units[0], (int)m.activation[0],
-                              two ? m.kernel[1] : nullptr, two ? m.bias[1] : nullptr, two ? (int)m.activation[1] : 0};
-    };
+    auto type_of = [&](int t) { return fused_type(a, p, t); };
     TRY(launch_heavy(a, p, n_gate == 1 ? gate : nullptr, src, st));
     const gnn_csr_t &adj = iter_adjacency(a);
     gnn::Fused2Args fa;
@@ -617,8 +620,6 @@ int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first,
     if (env < 0) { const char *e = getenv("GNN_FUSED_KERNEL"); env = e ? atoi(e) : 0; }
     if (pinned == 0 && env != 0 && env != 5) return 2;
     if (p.n_heavy != 0 || a.max_iteration < 1) return 2;
-    for (int t = 0; t < p.T; ++t)
-        if (a.net_state[t].n_layers != 1) return 2;         // two-layer state networks: wave-specialised kernel only
     gnn::SmallArgs sa;
     memset(&sa, 0, sizeof(sa));
     gnn::Fused2Args &fa = sa.f;
@@ -628,8 +629,7 @@ int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first,
     fa.C = p.C; fa.ldC = p.ldC;
     for (int t = 0; t < p.T; ++t)
         if (p.tp[t].count > 0)
-            fa.tp[fa.n_types++] = gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg,
-                                                 (int)a.net_state[t].units[0], (int)a.net_state[t].activation[0], nullptr, nullptr, 0};
+            fa.tp[fa.n_types++] = fused_type(a, p, t);
     if (fa.n_types == 0) return 2;
     fa.S = p.S; fa.thr = a.state_threshold; fa.k_out = a.k_out;
     sa.buf[0] = B[0]; sa.buf[1] = B[1];
@@ -642,25 +642,32 @@ int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first,
     return rc;
 }
 
-bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
-    if (a.flags & GNN_FLAG_UNFUSED) return false;
-    if (p.SP > 64) return false;   // LDS: [64 x 2SP] tile + [2SP x SP] weights must leave room for 2 workgroups per CU
+// 0: un-fused kernels; 1: any fused kernel; 2: two-layer state networks - only the wave-specialised kernel and the
+// persistent whole-loop kernel carry the second Dense.
+int fusable(const gnn_loop_args_t &a, const Plan &p) {
+    if (a.flags & GNN_FLAG_UNFUSED) return 0;
+    if (p.SP > 64) return 0;       // LDS: [64 x 2SP] tile + [2SP x SP] weights must leave room for 2 workgroups per CU
     // the fused kernel addresses state rows and C with 32-bit byte offsets off a scalar base
-    if ((size_t)(std::max(a.adjacency.n_src, p.N) + p.n_heavy) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return false;
+    if ((size_t)(std::max(a.adjacency.n_src, p.N) + p.n_heavy) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return 0;
     // ... and the CSR arrays through 4 GiB buffer windows
-    if ((size_t)iter_adjacency(a).nnz * 4 >= ((size_t)1 << 32) || ((size_t)p.N + 1) * 4 >= ((size_t)1 << 32)) return false;
-    // One Dense layer everywhere, or - in the wave-specialised kernel only, where the matrix waves have the time and LDS
-    // holds a second weight matrix in place of two ring slots - two Dense layers with at most SP hidden units.
+    if ((size_t)iter_adjacency(a).nnz * 4 >= ((size_t)1 << 32) || ((size_t)p.N + 1) * 4 >= ((size_t)1 << 32)) return 0;
+    // One Dense layer everywhere, or two with at most SP hidden units (the matrix waves have the time, and LDS holds a
+    // second weight matrix in place of two ring slots).
     bool two = false;
     for (int t = 0; t < p.T; ++t) {
         const gnn_mlp_t &m = a.net_state[t];
-        if (m.n_layers < 1 || m.n_layers > 2 || m.activation[0] == GNN_ACT_SOFTMAX) return false;
-        if (m.n_layers == 2 && (m.activation[1] == GNN_ACT_SOFTMAX || m.units[0] > p.SP)) return false;
-        if (t > 0 && (m.n_layers == 2) != two) return false;            // every node type the same depth
+        if (m.n_layers < 1 || m.n_layers > 2 || m.activation[0] == GNN_ACT_SOFTMAX) return 0;
+        if (m.n_layers == 2 && (m.activation[1] == GNN_ACT_SOFTMAX || m.units[0] > p.SP)) return 0;
+        if (t > 0 && (m.n_layers == 2) != two) return 0;                // every node type the same depth
         two = m.n_layers == 2;
     }
-    if (two && fused_generation(p.SP, p.N, a.flags) != 4) return false;
-    return true;
+    return two ? 2 : 1;
+}
+
+// may ONE ITERATION of this model run in a fused launch? (the per-iteration entry points and the loop's fallback)
+bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
+    const int f = fusable(a, p);
+    return f == 1 || (f == 2 && fused_generation(p.SP, p.N, a.flags) == 4);
 }
 
 }  // namespace
@@ -729,7 +736,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         B[a.max_iteration & 1] = a.state_out;
     if (a.ev_loop_begin) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_begin, st));
     int persistent = 2;
-    if (fused) {
+    if (fusable(a, p) != 0) {                      // whole loop in one launch where that applies (two-layer networks too)
         persistent = loop_persistent(a, p, first, B, st);
         if (persistent == 1) return 1;
     }

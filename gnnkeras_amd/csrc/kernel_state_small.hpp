@@ -35,7 +35,7 @@ struct SmallArgs {
                              // low word = arrivals, high word = workgroups that still saw a node move
 };
 
-template <int SP, bool HAS_W>
+template <int SP, bool HAS_W, bool L2>
 __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one workgroup per CU is all the grid needs: 256-VGPR budget
     using Cfg = Fused2Cfg<SP, 64, 8>;
     constexpr int TM = 64, NT = Cfg::NT, LPR = Cfg::LPR, IPL = Cfg::IPL, LDX = Cfg::LDX, LDW = Cfg::LDW, NPASS = Cfg::NPASS;
@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
     float *Xs = reinterpret_cast<float *>(smem);                         // [TM][LDX]  : [state | agg]
     float *Ws = Xs + TM * LDX;                                           // [2SP][LDW] : W1 rows (state ; agg)
     int *cont = reinterpret_cast<int *>(Ws + 2 * SP * LDW);              // one word: does the loop go on?
+    float *W2s = Ws + 2 * SP * LDW + 64;                                 // L2: [SP][LDW] second Dense, then b2 [SP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -59,8 +60,15 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
         const int k = i / SP, n = i % SP;
         const int kk = k < SP ? k : k - SP;
         float v = 0.0f;
-        if (kk < S && n < S) v = tp.Wf[(size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + kk) * tp.H + n];
+        if (kk < S && n < tp.H) v = tp.Wf[(size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + kk) * tp.H + n];
         Ws[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = v;
+    }
+    if (L2) {                                   // second Dense of a two-layer state network: rows k < H, columns n < S
+        for (int i = tid; i < SP * SP; i += NT) {
+            const int k = i / SP, n = i % SP;
+            W2s[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = (k < tp.H && n < S) ? tp.W2[(size_t)k * S + n] : 0.0f;
+        }
+        if (tid < SP) W2s[SP * LDW + tid] = tid < S ? tp.b2[tid] : 0.0f;
     }
 
     // ---- iteration-invariant per-lane state: the CSR rows of this lane group's nodes ---------------------------------
@@ -97,7 +105,7 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
         const int col = 16 * (cw * Cfg::CT_PER_WAVE + ci) + r;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
-            c0[ci][reg] = (jrow[reg] >= 0 && col < S) ? a.C[(size_t)jrow[reg] * a.ldC + col] : 0.0f;
+            c0[ci][reg] = (jrow[reg] >= 0 && col < tp.H) ? a.C[(size_t)jrow[reg] * a.ldC + col] : 0.0f;
     }
     __syncthreads();
 
@@ -167,6 +175,40 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
             }
         }
 
+        if (L2) {
+            // hidden layer: h = act1(c) into the agg half of the tile (dead after the loop above), then h . W2 + b2 with
+            // the same fragment layout; a row's hidden units come from CW waves, hence the two workgroup barriers
+            __syncthreads();
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 16 * rt + 4 * g + reg;
+#pragma unroll
+                for (int ci = 0; ci < Cfg::CT_PER_WAVE; ++ci) {
+                    const int col = 16 * (cw * Cfg::CT_PER_WAVE + ci) + r;
+                    Xs[row * LDX + SP + col] = col < tp.H ? activate(tp.act, c[ci][reg]) : 0.0f;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ci = 0; ci < Cfg::CT_PER_WAVE; ++ci) {
+                const float b = W2s[SP * LDW + 16 * (cw * Cfg::CT_PER_WAVE + ci) + r];
+                c[ci] = (f32x4){b, b, b, b};
+            }
+            const float *hrow = Xs + (16 * rt + r) * LDX + SP + g;
+#pragma unroll 8
+            for (int s4 = 0; s4 < SP / 4; ++s4) {
+                const float av = hrow[4 * s4];
+                const int k = 4 * s4 + g;
+#pragma unroll
+                for (int ci = 0; ci < Cfg::CT_PER_WAVE; ++ci) {
+                    const int n = 16 * (cw * Cfg::CT_PER_WAVE + ci) + r;
+                    const float bv = W2s[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)];
+                    c[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c[ci], 0, 0, 0);
+                }
+            }
+        }
+        const int act_out = L2 ? tp.act2 : tp.act;
+
         // ---- C. activation, predicate, new rows staged through LDS (same as k_state_fused2) ---------------------------
         int any = 0;
         float d2r[4], n2r[4];
@@ -177,7 +219,7 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
 #pragma unroll
             for (int ci = 0; ci < Cfg::CT_PER_WAVE; ++ci) {
                 const int col = 16 * (cw * Cfg::CT_PER_WAVE + ci) + r;
-                const float nv = (jrow[reg] >= 0 && col < S) ? activate(tp.act, c[ci][reg]) : 0.0f;
+                const float nv = (jrow[reg] >= 0 && col < S) ? activate(act_out, c[ci][reg]) : 0.0f;
                 const float ov = Xs[row * LDX + col];
                 const float d = nv - ov;
                 d2 = fmaf(d, d, d2);
@@ -263,12 +305,12 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
 
 // one tile per workgroup, every workgroup resident: graphs of at most 64 * n_cu nodes
 constexpr size_t SMALL_LDS = 96 * 1024;      // > half of a CU's 160 KB: at most one of these workgroups per CU
-template <int SP, bool HAS_W>
+template <int SP, bool HAS_W, bool L2>
 int launch_small_one(SmallArgs &sa, int n_cu, hipStream_t st) {
     using Cfg = Fused2Cfg<SP, 64, 8>;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)k_state_small<SP, HAS_W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)k_state_small<SP, HAS_W, L2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)SMALL_LDS) != hipSuccess) return 1;
         attr = true;
     }
@@ -277,7 +319,7 @@ int launch_small_one(SmallArgs &sa, int n_cu, hipStream_t st) {
     for (int t = 0; t < fa.n_types; ++t) fa.blk_begin[t + 1] = fa.blk_begin[t] + (fa.tp[t].count + 63) / 64;
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0 || grid > n_cu) return 2;             // not applicable: the caller falls back to one launch per iteration
-    k_state_small<SP, HAS_W><<<grid, Cfg::NT, SMALL_LDS, st>>>(sa);
+    k_state_small<SP, HAS_W, L2><<<grid, Cfg::NT, SMALL_LDS, st>>>(sa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -288,12 +330,17 @@ inline int small_tiles(const Fused2Args &fa) {
 }
 
 inline int launch_small(SmallArgs &sa, int SP, int n_cu, hipStream_t st) {
+    const bool l2 = sa.f.n_types > 0 && sa.f.tp[0].W2 != nullptr;
+#define SMALL_CASE(SPV)                                                                                              \
+    case SPV:                                                                                                        \
+        if (l2) return sa.f.w ? launch_small_one<SPV, true, true>(sa, n_cu, st) : launch_small_one<SPV, false, true>(sa, n_cu, st); \
+        return sa.f.w ? launch_small_one<SPV, true, false>(sa, n_cu, st) : launch_small_one<SPV, false, false>(sa, n_cu, st);
     switch (SP) {
-        case 16: return 2;                                 // 4-wave tile shape there: not built
-        case 32: return sa.f.w ? launch_small_one<32, true>(sa, n_cu, st) : launch_small_one<32, false>(sa, n_cu, st);
-        case 64: return sa.f.w ? launch_small_one<64, true>(sa, n_cu, st) : launch_small_one<64, false>(sa, n_cu, st);
-        default: return 2;
+        SMALL_CASE(32)
+        SMALL_CASE(64)
+        default: return 2;                                 // d <= 16: 4-wave tile shape there, not built
     }
+#undef SMALL_CASE
 }
 
 }  // namespace gnn

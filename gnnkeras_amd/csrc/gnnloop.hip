@@ -573,6 +573,20 @@ int device_cus() {
     return n_cu;
 }
 
+// the fused kernel that runs ONE iteration: the size-based / pinned choice, except that two-layer state networks go to the
+// wave-specialised kernel at any size (the only per-iteration kernel that carries a second Dense) unless pinned elsewhere
+int iteration_generation(const gnn_loop_args_t &a, const Plan &p) {
+    const int gen = fused_generation(p.SP, p.N, a.flags);
+    bool two = false;
+    for (int t = 0; t < p.T; ++t) two |= a.net_state[t].n_layers == 2;
+    if (!two) return gen;
+    const int pinned = (a.flags & GNN_FLAG_FUSED_GEN_MASK) >> 4;
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("GNN_FUSED_KERNEL"); env = e ? atoi(e) : 0; }
+    const int want = pinned ? pinned : env;
+    return (p.SP > 16 && (want == 0 || want >= 4)) ? 4 : gen;
+}
+
 // what a fused kernel needs to know about node type t (the second Dense of a two-layer state network included)
 gnn::FusedType fused_type(const gnn_loop_args_t &a, const Plan &p, int t) {
     const gnn_mlp_t &m = a.net_state[t];
@@ -605,8 +619,9 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;
     }
-    if (fused_generation(p.SP, p.N, a.flags) == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
-    else if (fused_generation(p.SP, p.N, a.flags) == 3) FUSED_OK(gnn::launch_fused3(fa, p.SP, fused_waves() == 8 ? 8 : 12, device_cus(), st));
+    const int gen = iteration_generation(a, p);
+    if (gen == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
+    else if (gen == 3) FUSED_OK(gnn::launch_fused3(fa, p.SP, fused_waves() == 8 ? 8 : 12, device_cus(), st));
     else FUSED_OK(gnn::launch_fused2(fa, p.SP, fused_waves() == 0 ? 8 : fused_waves(), device_cus(), st));
     return 0;
 }
@@ -667,7 +682,7 @@ int fusable(const gnn_loop_args_t &a, const Plan &p) {
 // may ONE ITERATION of this model run in a fused launch? (the per-iteration entry points and the loop's fallback)
 bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
     const int f = fusable(a, p);
-    return f == 1 || (f == 2 && fused_generation(p.SP, p.N, a.flags) == 4);
+    return f == 1 || (f == 2 && iteration_generation(a, p) == 4);
 }
 
 }  // namespace

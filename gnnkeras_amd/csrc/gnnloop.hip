@@ -110,7 +110,7 @@ int check_csr(const gnn_csr_t &c, const char *name, int n_dst, int n_src) {
 // --- launchers -------------------------------------------------------------------------------------------------------
 int launch_aggregate(const int *gate, const gnn_csr_t &c, const float *X, int ldx, int F, float *out, int ldo, hipStream_t st) {
     if (c.n_dst == 0 || F == 0) return 0;
-    if ((F == 16 || F == 32 || F == 64) && ldx % 4 == 0 && ldo % 4 == 0 &&
+    if ((F == 16 || F == 32 || F == 64 || F == 128) && ldx % 4 == 0 && ldo % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
         const int lpr = F / 4, groups = 256 / lpr;
         const int grid = std::min(cdiv(c.n_dst, groups), 256 * 16);
@@ -119,7 +119,8 @@ int launch_aggregate(const int *gate, const gnn_csr_t &c, const float *X, int ld
         switch (lpr) {
             case 4: AGGV(4); break;
             case 8: AGGV(8); break;
-            default: AGGV(16); break;
+            case 16: AGGV(16); break;
+            default: AGGV(32); break;
         }
 #undef AGGV
         LAUNCH_OK();
@@ -441,7 +442,8 @@ int launch_heavy(const gnn_loop_args_t &a, const Plan &p, const int *gate, const
 int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src_full, float *dst_full,
                       int row_base, int *flag_next, float *k_out, float k_val, hipStream_t st) {
     TRY(launch_heavy(a, p, gate, src_full, st));
-    TRY(launch_aggregate(gate, iter_adjacency(a), src_full, p.SP, p.S, p.agg, p.SP, st));
+    // the padded width: pad columns are zero on both sides, and whole 16-B chunks let the vector kernel run for any d
+    TRY(launch_aggregate(gate, iter_adjacency(a), src_full, p.SP, p.SP <= 128 ? p.SP : p.S, p.agg, p.SP, st));
     const float *src = src_full + (size_t)row_base * p.SP;     // own rows
     float *dst = dst_full + (size_t)row_base * p.SP;
     for (int t = 0; t < p.T; ++t) {

@@ -12,7 +12,10 @@ from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased, CompositeGNN
 from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer, CompositeMultiGraphSequencer
 from oracle.harness import oracle_loop, oracle_composite_loop, rel_err
 
+import os
+
 pytestmark = pytest.mark.gpu
+FUZZ_SCALE = int(os.environ.get('GNN_FUZZ_SCALE', '1'))      # GNN_FUZZ_SCALE=10 runs ten times as many seeds (offline soak)
 # every way the iteration can run: size-based default, un-fused kernels, and each fused-kernel generation pinned
 PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN3, nat.FLAG_FUSED_GEN4, nat.FLAG_FUSED_GEN5)
 ACTS = ['selu', 'tanh', 'relu', 'sigmoid', 'linear', 'elu', 'softplus']
@@ -38,7 +41,7 @@ def random_nets_bn(nets, rng):
             n.set_weights(w)
 
 
-@pytest.mark.parametrize('seed', range(40))
+@pytest.mark.parametrize('seed', range(40 * FUZZ_SCALE))
 def test_fuzz_homogeneous(seed):
     rng = np.random.default_rng(1000 + seed)
     focus = ['n', 'a', 'g'][seed % 3]
@@ -50,7 +53,8 @@ def test_fuzz_homogeneous(seed):
     graphs = []
     for _ in range(int(rng.integers(1, 5))):
         n = int(rng.integers(2, 120))
-        arcs = random_arcs(rng, n, int(rng.integers(0, 4 * n)), A)
+        # 'normalized' divides by the number of arcs: an arc-less graph raises ZeroDivisionError there, as in the reference
+        arcs = random_arcs(rng, n, int(rng.integers(1 if mode == 'normalized' else 0, 4 * n)), A)
         cnt = {'n': n, 'a': len(arcs), 'g': n}[focus]
         om = rng.random(cnt) < 0.7 if focus != 'g' else np.ones(n, bool)
         sm = rng.random(cnt) < 0.8 if focus != 'g' else np.ones(n, bool)
@@ -76,13 +80,23 @@ def test_fuzz_homogeneous(seed):
     for flags in PATHS:
         model.native_flags = flags
         k, st, o = model.Loop(*model.process_inputs(x), state0=None if s0 is None else torch.from_numpy(s0).cuda())
-        if thr == 0.0 or float(k32) == float(k64):                   # k pinned, or both oracles agree on it
-            assert float(k) == float(k64), (seed, float(k), k64)
+        if float(k) == float(k64):
             assert rel_err(st.cpu().numpy(), st64) <= 2e-5 and rel_err(o.cpu().numpy(), o64) <= 2e-5, seed
+        elif thr == 0.0:
+            # threshold 0 stops only at an EXACT float32 fixed point (narrow states, saturating activations): which
+            # iteration that happens at depends on the last bit of every sum, so the device may stop before float64
+            # does; its state must then agree with the float64 run cut at the same iteration
+            assert float(k) < float(k64), (seed, float(k), k64)
+            model.max_iteration, keep = int(float(k)), model.max_iteration
+            _, st_cut, o_cut = oracle_loop(model, x, s0, np.float64)
+            model.max_iteration = keep
+            assert rel_err(st.cpu().numpy(), st_cut) <= 2e-5 and rel_err(o.cpu().numpy(), o_cut) <= 2e-5, seed
+        else:
+            assert float(k32) != float(k64), (seed, float(k), k32, k64)    # a borderline predicate: the oracles disagree too
         assert np.isfinite(st.cpu().numpy()).all() and np.isfinite(o.cpu().numpy()).all()
 
 
-@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.parametrize('seed', range(16 * FUZZ_SCALE))
 def test_fuzz_composite(seed):
     rng = np.random.default_rng(5000 + seed)
     focus = ['n', 'a', 'g'][seed % 3]
@@ -124,7 +138,7 @@ def test_fuzz_composite(seed):
         assert rel_err(st.cpu().numpy(), st64) <= 2e-5 and rel_err(o.cpu().numpy(), o64) <= 2e-5, seed
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', range(24 * FUZZ_SCALE))
 def test_fuzz_training_gradients(seed):
     """Random train_step configurations against the torch-autograd restatement (gradients, loss, moving statistics)."""
     from test_gpu_training import check_step, oracle_step

@@ -65,7 +65,9 @@ def check_step(model, x, y, sw, s0, loss='categorical_crossentropy', avg=False):
     res = tr.train_step(x, y, sw, state0=None if s0 is None else torch.from_numpy(s0).cuda(), apply=False)
     assert res['k'] == want['k']
     assert abs(float(res['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))
-    assert rel_err(res['y_pred'].cpu().numpy(), want['y_pred']) <= 1e-5
+    # training mode: BatchNormalization on the statistics of a small batch multiplies rounding by 1/sigma of thin columns;
+    # the inference bar (1e-5) is checked in test_gpu_parity.py, here 5e-5 (1.5e-5 seen once in 576 random configurations)
+    assert rel_err(res['y_pred'].cpu().numpy(), want['y_pred']) <= 5e-5
     for name, got, ref in [('state', tr.gs.gradients(), want['grads_state']), ('output', tr.go.gradients(), want['grads_output'])]:
         assert len(got) == len(ref)
         for i, (g, r) in enumerate(zip(got, ref)):
@@ -224,7 +226,9 @@ def test_composite_gradients(focus, bn):
     res = tr.train_step(x, y, sw, state0=torch.from_numpy(s0).cuda(), apply=False)
     assert res['k'] == want['k'] == 5
     assert abs(float(res['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))
-    assert rel_err(res['y_pred'].cpu().numpy(), want['y_pred']) <= 1e-5
+    # training mode: BatchNormalization on the statistics of a small batch multiplies rounding by 1/sigma of thin columns;
+    # the inference bar (1e-5) is checked in test_gpu_parity.py, here 5e-5 (1.5e-5 seen once in 576 random configurations)
+    assert rel_err(res['y_pred'].cpu().numpy(), want['y_pred']) <= 5e-5
     allref = [r for g in want['grads_state'] for r in g] + want['grads_output']
     scale = max(float(np.max(np.abs(r))) for r in allref)
     got = [g for t in tr.gs for g in t.gradients()] + tr.go.gradients()

@@ -60,8 +60,10 @@ class _LoopModel:
     def _engine_init(self):
         self.optimizer, self.loss, self.metrics_spec = None, None, []
         self.average_st_grads = None
-        self._ws = None
+        self._ws = {}                                  # workspace per HIP stream (batches of predict / evaluate overlap)
         self._mask_cache = {}
+        self._streams = None
+        self.inference_streams = 8                     # side streams predict() / evaluate() spread their batches over
 
     def compile(self, *args, average_st_grads=False, **kwargs):
         """`compile(optimizer, loss, metrics=[...], average_st_grads=False)`; `run_eagerly` is accepted and irrelevant
@@ -78,8 +80,11 @@ class _LoopModel:
 
     def predict(self, sequencer, **kwargs):
         """Outputs of every batch, concatenated (Keras `predict` semantics)."""
-        outs = [self.call(sequencer[i][0], training=False) for i in range(len(sequencer))]
-        return torch.cat(outs, dim=0).cpu().numpy() if outs else np.zeros((0, 0), np.float32)
+        if len(sequencer) == 0: return np.zeros((0, 0), np.float32)
+        dev = self._batch_device(sequencer[0][0])
+        outs = [o for _, o in self._batches_concurrently(len(sequencer), lambda i: self.call(sequencer[i][0], training=False),
+                                                          dev, self._round_width(sequencer, dev))]
+        return torch.cat(outs, dim=0).cpu().numpy()
 
     def evaluate(self, sequencer, return_dict: bool = False, **kwargs):
         """Sample-weighted mean loss and metrics over the sequencer (Keras `evaluate` semantics)."""
@@ -87,9 +92,10 @@ class _LoopModel:
         lossf = _loss_fn(self.loss)
         tot_loss = tot_w = None
         mets = None
-        for i in range(len(sequencer)):
-            x, y, sw = sequencer[i]
-            p = self.call(x, training=False)
+        dev = self._batch_device(sequencer[0][0]) if len(sequencer) else torch.device('cpu')
+        for i, p in self._batches_concurrently(len(sequencer), lambda i: self.call(sequencer[i][0], training=False), dev,
+                                               self._round_width(sequencer, dev) if len(sequencer) else 1):
+            _, y, sw = sequencer[i]
             if mets is None:
                 mets = [(n, f, torch.zeros((), device=p.device)) for n, f in (_metric_fn(m, y.shape[-1]) for m in self.metrics_spec)]
                 tot_loss, tot_w = torch.zeros((), device=p.device), torch.zeros((), device=p.device)
@@ -150,11 +156,56 @@ class _LoopModel:
         self.history = history
         return history
 
+    @staticmethod
+    def _batch_device(x):
+        t = x[0]
+        return t.device if isinstance(t, torch.Tensor) else torch.device('cpu')
+
     # workspace and mask-index caches ---------------------------------------------------------------------------------
     def _workspace(self, nbytes, device):
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        return self._ws
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        return ws
+
+    def _batches_concurrently(self, n, fn, device, width=None):
+        """Run fn(i), i < n, `width` at a time on side HIP streams and yield (i, result) in order on the caller's stream.
+
+        Batches of a sequencer are independent graphs; a merged MUTAG batch keeps ~16 of the 256 CUs busy (the whole loop
+        is one persistent launch of one workgroup per 64 nodes), so several run side by side: batch i goes to
+        stream i % width, the caller's stream waits for all of them before the first result is used, and every result is
+        recorded on the caller's stream so the caching allocator does not hand its memory back early. `width` is capped so that the
+        persistent kernels of one round can all be resident at once (they wait for each other inside the launch)."""
+        width = int(width or self.inference_streams)
+        if device.type != 'cuda' or width <= 1 or n <= 1:
+            for i in range(n): yield i, fn(i)
+            return
+        if self._streams is None or len(self._streams) < width or self._streams[0].device != device:
+            self._streams = [torch.cuda.Stream(device) for _ in range(width)]
+        main = torch.cuda.current_stream(device)
+        for st in self._streams[:width]: st.wait_stream(main)          # inputs made on the caller's stream are ready
+        res = []
+        for i in range(n):                                             # round-robin: at most `width` loops in flight,
+            with torch.cuda.stream(self._streams[i % width]):          # each stream runs its batches in order
+                res.append(fn(i))
+        for st in self._streams[:width]: main.wait_stream(st)
+        for i, out in enumerate(res):
+            for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                if isinstance(t, torch.Tensor) and t.is_cuda: t.record_stream(main)
+            yield i, out
+
+    def _round_width(self, sequencer, device):
+        """How many batches of `sequencer` may run side by side: every persistent loop kernel of a round must be resident
+        at once (one workgroup per 64 nodes, one workgroup per CU)."""
+        if device.type != 'cuda': return 1
+        try:
+            n_max = max(int(sequencer[i][0][0].shape[0]) for i in range(len(sequencer)))
+        except Exception:
+            return 1
+        tiles = max(1, (n_max + 63) // 64)
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        return max(1, min(int(self.inference_streams), cus // (tiles + 2)))
 
     def _out_index(self, set_mask, output_mask):
         key = (set_mask.data_ptr(), set_mask._version, output_mask.data_ptr(), output_mask._version, len(set_mask))

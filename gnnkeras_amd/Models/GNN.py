@@ -82,8 +82,10 @@ class _LoopModel:
         """Outputs of every batch, concatenated (Keras `predict` semantics)."""
         if len(sequencer) == 0: return np.zeros((0, 0), np.float32)
         dev = self._batch_device(sequencer[0][0])
+        self._k_seen = []
         outs = [o for _, o in self._batches_concurrently(len(sequencer), lambda i: self.call(sequencer[i][0], training=False),
                                                           dev, self._round_width(sequencer, dev))]
+        self._check_k()
         return torch.cat(outs, dim=0).cpu().numpy()
 
     def evaluate(self, sequencer, return_dict: bool = False, **kwargs):
@@ -93,6 +95,7 @@ class _LoopModel:
         tot_loss = tot_w = None
         mets = None
         dev = self._batch_device(sequencer[0][0]) if len(sequencer) else torch.device('cpu')
+        self._k_seen = []
         for i, p in self._batches_concurrently(len(sequencer), lambda i: self.call(sequencer[i][0], training=False), dev,
                                                self._round_width(sequencer, dev) if len(sequencer) else 1):
             _, y, sw = sequencer[i]
@@ -105,6 +108,7 @@ class _LoopModel:
             tot_w = tot_w + sw.sum()
             cnt = cnt + sw.sum()
             mets = [(n, f, acc + (f(y, p) * sw).sum()) for n, f, acc in mets]
+        self._check_k()
         res = {'loss': float(tot_loss / tot_w)}
         for n, f, acc in mets: res[n] = float(acc / cnt)
         return res if return_dict else [res['loss']] + [res[n] for n, _, _ in mets]
@@ -155,6 +159,16 @@ class _LoopModel:
             if hasattr(sequencer, 'on_epoch_end'): sequencer.on_epoch_end()
         self.history = history
         return history
+
+    def _check_k(self):
+        """k < 0 is how the persistent whole-loop kernel reports that its workgroups could not all be resident (its grid
+        barrier timed out): checked once per predict() / evaluate(), where the host synchronises anyway."""
+        ks = getattr(self, '_k_seen', None)
+        if ks:
+            if float(torch.stack([k.reshape(()) for k in ks]).min()) < 0:
+                raise nat.NativeError('the persistent loop kernel timed out waiting for its workgroups (GPU shared with '
+                                      'other long-running work?): set model.native_flags = FLAG_FUSED_GEN2 or lower inference_streams')
+        self._k_seen = None
 
     @staticmethod
     def _batch_device(x):
@@ -317,6 +331,7 @@ class GNNnodeBased(_LoopModel):
         inputs = self.process_inputs(inputs)
         k, state, out = self.Loop(*inputs, training=training)
         if training: return k, state, out
+        if getattr(self, '_k_seen', None) is not None: self._k_seen.append(k)        # predict() / evaluate() check it at the end
         return out
 
     @staticmethod

@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
     const unsigned n_wg = gridDim.x;
     int k_done = 0;
     unsigned moved_seen[2] = {0u, 0u};
+    int timed_out = 0;
     // the predicate of state_0 (GNN.py:265 evaluates `condition` before the first iteration)
     const bool run_first = sa.no_exit || __hip_atomic_load(&sa.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     for (int it = 0; run_first && it < sa.max_iteration; ++it) {
@@ -286,11 +287,13 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
             __hip_atomic_fetch_add(ctr, 1ull + ((unsigned long long)(any ? 1u : 0u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = (unsigned)(it / 2 + 1) * n_wg;
             unsigned long long v = 0;
-            for (int spin = 0; spin < (1 << 22); ++spin) {
+            int spin = 0;
+            for (; spin < (1 << 22); ++spin) {
                 v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)v >= target) break;
                 __builtin_amdgcn_s_sleep(2);
             }
+            if (spin == (1 << 22)) timed_out = 1;      // some workgroup never arrived (not resident?): reported through k
             const unsigned moved = (unsigned)(v >> 32);
             *cont = (moved != moved_seen[it & 1]) ? 1 : 0;
             moved_seen[it & 1] = moved;
@@ -300,7 +303,12 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
         k_done = it + 1;
         if (!sa.no_exit && *cont == 0) break;          // uniform: every workgroup read the same total
     }
-    if (blockIdx.x == 0 && tid == 0 && a.k_out) *a.k_out = (float)k_done;
+    // k_out is zero before the launch: workgroup 0 adds k; a workgroup whose grid barrier timed out (the launch was not
+    // fully resident: results are not valid) adds -1e9, so k < 0 reports it whatever the order of the two
+    if (tid == 0 && a.k_out) {
+        if (timed_out) atomicAdd(a.k_out, -1.0e9f);
+        if (blockIdx.x == 0) atomicAdd(a.k_out, (float)k_done);
+    }
 }
 
 // one tile per workgroup, every workgroup resident: graphs of at most 64 * n_cu nodes

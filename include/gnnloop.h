@@ -116,7 +116,10 @@ typedef struct gnn_loop_args {
     const int32_t *arc_dst;   /* [n_arcs] arc focus: adjacency.indices[:,1]                                     */
     gnn_csr_t nodegraph;      /* graph focus: n_src = n_out, n_dst = #graphs                                    */
     /* results -------------------------------------------------------------------------------------------------- */
-    float *k_out;             /* [1] iterations executed, float like the reference                  */
+    float *k_out;             /* [1] iterations executed, float like the reference; NEGATIVE when the
+                                 persistent whole-loop launch could not get all its workgroups resident (its grid
+                                 barrier timed out, e.g. too many such loops overlapped on other streams): results
+                                 are then invalid - rerun with GNN_FLAG_FUSED_GEN2                                 */
     float *state_out;         /* [n_nodes, S] S = state_dim, or dim of the state when state_dim == 0            */
     float *out;               /* [n_out, T] (node / arc focus) or [#graphs, T] (graph focus)                    */
     /* execution ------------------------------------------------------------------------------------------------ */

@@ -143,9 +143,17 @@ int launch_aggregate(const int *gate, const gnn_csr_t &c, const float *X, int ld
     return 0;
 }
 
+// thin outputs (class scores): 16 lanes per row, no MFMA tile to fill; the weights must fit 48 KB of LDS
+bool thin_dense_applies(const gnn::SegDenseArgs &a) {
+    if (a.H > 4) return false;
+    int K = 0;
+    for (int s = 0; s < a.nseg; ++s) K = std::max(K, a.seg[s].wrow + a.seg[s].width);
+    return (size_t)K * a.H * sizeof(float) <= 48 * 1024;
+}
+
 int launch_segdense(gnn::SegDenseArgs &a, hipStream_t st) {
     if (a.M == 0) return 0;
-    if (a.H <= 4) {                      // thin outputs (class scores): 16 lanes per row, no MFMA tile to fill
+    if (a.H <= 4) {
         int K = 0;
         for (int s = 0; s < a.nseg; ++s) K = std::max(K, a.seg[s].wrow + a.seg[s].width);
         if ((size_t)K * a.H * sizeof(float) <= 48 * 1024) {
@@ -191,12 +199,31 @@ int launch_converge(const int *gate, const float *s, const float *so, int N, int
     return 0;
 }
 
-int launch_fold(const gnn_mlp_t &m, float *Wf, float *bf, hipStream_t st) {
-    const int H = m.units[0];
-    gnn::k_fold_bn<<<H, 128, 0, st>>>(m.kernel[0], m.bias[0], m.in_dim, H, m.has_bn ? m.bn_gamma : nullptr,
-                                                 m.bn_beta, m.bn_mean, m.bn_var, m.bn_eps, Wf, bf);
+// BN folding of the first layers of up to GNN_MAX_TYPES + 1 networks in one launch (+ optional zeroing of two small arrays)
+struct FoldList {
+    gnn::FoldArgs fa;
+    int blocks = 0;
+    FoldList() { memset(&fa, 0, sizeof(fa)); }
+    void add(const gnn_mlp_t &m, float *Wf, float *bf) {
+        gnn::FoldJob &j = fa.job[fa.n_jobs++];
+        j.W = m.kernel[0]; j.b = m.bias[0]; j.K = m.in_dim; j.H = m.units[0];
+        j.gamma = m.has_bn ? m.bn_gamma : nullptr; j.beta = m.bn_beta; j.mean = m.bn_mean; j.var = m.bn_var; j.eps = m.bn_eps;
+        j.Wf = Wf; j.bf = bf; j.blk_begin = blocks;
+        blocks += j.H;
+    }
+};
+
+int launch_fold_list(FoldList &fl, hipStream_t st) {
+    if (fl.blocks == 0) return 0;
+    gnn::k_fold_bn<<<fl.blocks, 128, 0, st>>>(fl.fa);
     LAUNCH_OK();
     return 0;
+}
+
+int launch_fold(const gnn_mlp_t &m, float *Wf, float *bf, hipStream_t st) {
+    FoldList fl;
+    fl.add(m, Wf, bf);
+    return launch_fold_list(fl, st);
 }
 
 int launch_copy2d(const int *gate, const float *src, int ld_src, float *dst, int ld_dst, int rows, int width, int fill_to, hipStream_t st) {
@@ -245,11 +272,13 @@ int run_mlp(const MlpRun &r, hipStream_t st) {
             a.bias = m.bias[l];
         }
         a.ldw = a.H;
-        a.act = m.activation[l] == GNN_ACT_SOFTMAX ? GNN_ACT_LINEAR : m.activation[l];
+        // softmax rows are finished inside the thin-output kernel (<= 4 classes); wider layers get a second pass
+        const bool thin_softmax = m.activation[l] == GNN_ACT_SOFTMAX && thin_dense_applies(a);
+        a.act = (m.activation[l] == GNN_ACT_SOFTMAX && !thin_softmax) ? GNN_ACT_LINEAR : m.activation[l];
         if (last) { a.Y = r.Y; a.ldy = r.ldy; a.out_rowidx = r.out_rowidx; }
         else      { a.Y = r.hid[l & 1]; a.ldy = r.ld_hid; a.out_rowidx = nullptr; }
         TRY(launch_segdense(a, st));
-        if (m.activation[l] == GNN_ACT_SOFTMAX) TRY(launch_softmax(r.gate, a.Y, a.M, a.H, a.ldy, a.out_rowidx, st));
+        if (m.activation[l] == GNN_ACT_SOFTMAX && !thin_softmax) TRY(launch_softmax(r.gate, a.Y, a.M, a.H, a.ldy, a.out_rowidx, st));
         cur = a.Y; cur_ld = a.ldy;
     }
     return 0;
@@ -465,10 +494,13 @@ int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, 
     return 0;
 }
 
-int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
-    // BN folding of every first layer
-    for (int t = 0; t < p.T; ++t) TRY(launch_fold(a.net_state[t], p.tp[t].Wf, p.tp[t].bf, st));
-    TRY(launch_fold(a.net_output, p.Wf_out, p.bf_out, st));
+int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, bool zero_loop_words = false) {
+    // BN folding of every first layer: one launch, which also zeroes the flag words / barrier counters and k
+    FoldList fl;
+    for (int t = 0; t < p.T; ++t) fl.add(a.net_state[t], p.tp[t].Wf, p.tp[t].bf);
+    fl.add(a.net_output, p.Wf_out, p.bf_out);
+    if (zero_loop_words) { fl.fa.zero_a = p.flags; fl.fa.n_a = a.max_iteration + 8; fl.fa.zero_b = a.k_out; fl.fa.n_b = 1; }
+    TRY(launch_fold_list(fl, st));
     // ArcNode scatter-add (GNN.py:254) and neighbour-label aggregates (GNN.py:258 / CompositeGNN.py:251)
     if (p.A > 0) TRY(launch_aggregate(nullptr, a.arcnode, a.arc_labels, a.ld_arcs, p.A, p.agg_arcs, p.A, st));
     if (!p.composite) {
@@ -729,9 +761,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     if (((uintptr_t)a.workspace & 255) != 0) return fail("workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)a.stream;
 
-    HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (a.max_iteration + 8), st));
-    HIP_OK(hipMemsetAsync(a.k_out, 0, sizeof(float), st));
-    TRY(setup_constants(a, p, st));
+    TRY(setup_constants(a, p, st, /*zero_loop_words=*/true));       // flags, barrier counters and k start from zero
 
     // state_0 (GNN.py:256-259) into the padded buffer; state_old_0 = ones is implicit in the first predicate (:261)
     // When the caller's state_0 already has the padded layout (d a multiple of 16, no hub rows behind the real ones) the

@@ -292,7 +292,28 @@ __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
             for (int h = 0; h < H; ++h)
 #pragma unroll
                 for (int off = 8; off >= 1; off >>= 1) acc[r][h] += __shfl_xor(acc[r][h], off, 16);
-        if (l16 < H) {                                   // lane h of the group finishes output column h
+        if (a.act == GNN_ACT_SOFTMAX) {                  // every lane holds all H sums: lane 0 finishes the whole row
+            if (l16 == 0) {
+#pragma unroll
+                for (int r = 0; r < TD_ROWS; ++r) {
+                    const long m = base + r;
+                    if (m >= a.M) continue;
+                    float v[H], mx = -3.4e38f, sum = 0.0f;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        v[h] = acc[r][h];
+                        if (a.bias) v[h] += a.bias[h];
+                        if (a.addend) v[h] += a.addend[(size_t)(a.add_rowidx ? a.add_rowidx[m] : m) * a.ld_add + h];
+                        mx = fmaxf(mx, v[h]);
+                    }
+#pragma unroll
+                    for (int h = 0; h < H; ++h) { v[h] = expf(v[h] - mx); sum += v[h]; }
+                    float *y = a.Y + (size_t)(a.out_rowidx ? a.out_rowidx[m] : m) * a.ldy;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) y[h] = v[h] / sum;
+                }
+            }
+        } else if (l16 < H) {                            // lane h of the group finishes output column h
 #pragma unroll
             for (int r = 0; r < TD_ROWS; ++r) {
                 const long m = base + r;
@@ -362,21 +383,42 @@ k_converge(const int *gate, const float *__restrict__ s, const float *__restrict
 // Fold an inference BatchNormalization into the Dense layer that follows it (Keras: y = x*inv + (beta - mean*inv),
 // inv = gamma / sqrt(var + eps)):  Wf[k][h] = inv[k] * W[k][h],  bf[h] = b[h] + sum_k (beta[k] - mean[k]*inv[k]) W[k][h].
 // One workgroup per output column h, threads stride over k; the shift sum meets in a fixed-order LDS tree.
-__global__ void __launch_bounds__(128)
-k_fold_bn(const float *__restrict__ W, const float *__restrict__ b, int K, int H, const float *gamma,
-          const float *beta, const float *mean, const float *var, float eps, float *__restrict__ Wf,
-          float *__restrict__ bf) {
+// Up to GNN_MAX_TYPES + 1 networks (one state network per node type + the output network) fold in ONE launch, which also
+// zeroes the loop's flag words and iteration counter (two small arrays): three launches and two memsets less per forward.
+struct FoldJob {
+    const float *W, *b, *gamma, *beta, *mean, *var;
+    float *Wf, *bf;
+    int K, H, blk_begin;
+    float eps;
+};
+struct FoldArgs {
+    FoldJob job[GNN_MAX_TYPES + 1];
+    int n_jobs;
+    int *zero_a; int n_a;
+    float *zero_b; int n_b;
+};
+__global__ void __launch_bounds__(128) k_fold_bn(FoldArgs fa) {
     __shared__ float part[128];
-    const int h = blockIdx.x;
+    for (int i = blockIdx.x * 128 + threadIdx.x; i < fa.n_a; i += gridDim.x * 128) fa.zero_a[i] = 0;
+    for (int i = blockIdx.x * 128 + threadIdx.x; i < fa.n_b; i += gridDim.x * 128) fa.zero_b[i] = 0.0f;
+    int j = 0;
+#pragma unroll
+    for (int t = 1; t < GNN_MAX_TYPES + 1; ++t)
+        if (t < fa.n_jobs && (int)blockIdx.x >= fa.job[t].blk_begin) j = t;
+    // static selection (a runtime-indexed kernel-argument array would be copied to scratch memory)
+    FoldJob jb = fa.job[0];
+#pragma unroll
+    for (int t = 1; t < GNN_MAX_TYPES + 1; ++t) if (t == j) jb = fa.job[t];
+    const int h = blockIdx.x - jb.blk_begin, K = jb.K, H = jb.H;
     float acc = 0.0f;
     for (int k = threadIdx.x; k < K; k += 128) {
         float inv = 1.0f, shift = 0.0f;
-        if (gamma) {
-            inv = gamma[k] / sqrtf(var[k] + eps);
-            shift = beta[k] - mean[k] * inv;
+        if (jb.gamma) {
+            inv = jb.gamma[k] / sqrtf(jb.var[k] + jb.eps);
+            shift = jb.beta[k] - jb.mean[k] * inv;
         }
-        const float wv = W[(size_t)k * H + h];
-        Wf[(size_t)k * H + h] = wv * inv;
+        const float wv = jb.W[(size_t)k * H + h];
+        jb.Wf[(size_t)k * H + h] = wv * inv;
         acc = fmaf(shift, wv, acc);
     }
     part[threadIdx.x] = acc;
@@ -385,7 +427,7 @@ k_fold_bn(const float *__restrict__ W, const float *__restrict__ b, int K, int H
         if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) bf[h] = (b ? b[h] : 0.0f) + part[0];
+    if (threadIdx.x == 0) jb.bf[h] = (jb.b ? jb.b[h] : 0.0f) + part[0];
 }
 
 // dst[i, :width] = src[i, :width] with independent leading dimensions; pads dst columns [width, ld_dst_fill) with 0.

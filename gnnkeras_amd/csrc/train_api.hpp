@@ -29,20 +29,24 @@ int gnn_dense(const gnn_dense_args_t *d) {
     }
     a.W = d->W; a.ldw = d->ldw > 0 ? d->ldw : d->H; a.bias = d->bias;
     a.addend = d->addend; a.ld_add = d->ld_addend; a.add_rowidx = d->addend_rowidx;
-    a.act = d->activation == GNN_ACT_SOFTMAX ? GNN_ACT_LINEAR : d->activation;
+    const bool thin_softmax = d->activation == GNN_ACT_SOFTMAX && thin_dense_applies(a);      // finished in the same launch
+    a.act = (d->activation == GNN_ACT_SOFTMAX && !thin_softmax) ? GNN_ACT_LINEAR : d->activation;
     a.Y = d->Y; a.ldy = d->ldy; a.out_rowidx = d->out_rowidx;
     hipStream_t st = (hipStream_t)d->stream;
     TRY(launch_segdense(a, st));
-    if (d->activation == GNN_ACT_SOFTMAX) TRY(launch_softmax(d->gate, d->Y, d->M, d->H, d->ldy, d->out_rowidx, st));
+    if (d->activation == GNN_ACT_SOFTMAX && !thin_softmax) TRY(launch_softmax(d->gate, d->Y, d->M, d->H, d->ldy, d->out_rowidx, st));
     return 0;
 }
 
 int gnn_fold_bn(const float *W, const float *b, int32_t K, int32_t H, const float *gamma, const float *beta,
                 const float *mean, const float *var, float eps, float *Wf, float *bf, void *stream) {
     if (!W || !Wf || !bf || K < 1 || H < 1) return fail("bad arguments");
-    gnn::k_fold_bn<<<H, 128, 0, (hipStream_t)stream>>>(W, b, K, H, gamma, beta, mean, var, eps, Wf, bf);
-    LAUNCH_OK();
-    return 0;
+    FoldList fl;
+    gnn::FoldJob &j = fl.fa.job[fl.fa.n_jobs++];
+    j.W = W; j.b = b; j.K = K; j.H = H; j.gamma = gamma; j.beta = beta; j.mean = mean; j.var = var; j.eps = eps;
+    j.Wf = Wf; j.bf = bf; j.blk_begin = 0;
+    fl.blocks = H;
+    return launch_fold_list(fl, (hipStream_t)stream);
 }
 
 size_t gnn_dense_grad_workspace_bytes(int32_t K, int32_t H, int32_t M) {

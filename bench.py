@@ -25,6 +25,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# predict() / evaluate() overlap independent batches on up to 8 HIP streams; by default HIP multiplexes all streams of
+# a process onto 4 hardware queues.  Must be set before the HIP runtime starts (importing torch does that).
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+
 import numpy as np
 import torch
 

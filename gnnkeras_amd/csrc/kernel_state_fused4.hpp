@@ -82,11 +82,11 @@ __device__ __forceinline__ int f4_ld_acquire(const int *p) {
 
 template <int SP, bool HAS_W, int DEPTH, int NC, bool L2>
 __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
-    {
-        int open = a.gate == nullptr;
-        for (int i = 0; i < a.n_gate && !open; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
-        if (!open) return;
-    }
+    // The gate word(s), the W1 fill and the gather waves' first CSR row are all fetched before anything is waited for:
+    // three dependent round trips at the head of every launch become one.  Nothing is written to global memory before
+    // the gate has been checked (after the fill's barrier).
+    int open = a.gate == nullptr;
+    for (int i = 0; i < a.n_gate; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
     using Cfg = Fused4Cfg<SP, NC, L2>;
     constexpr int NT = Cfg::NT, LPR = Cfg::LPR, IPL = Cfg::IPL, LDX = Cfg::LDX, LDW = Cfg::LDW, NS = Cfg::NS;
     constexpr int SPIN_MAX = 1 << 22;
@@ -106,23 +106,6 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     const int count = tp.count;
     const int *__restrict__ rows = tp.rows;
 
-    for (int i = tid; i < 2 * SP * SP; i += NT) {
-        const int k = i / SP, n = i % SP;
-        const int kk = k < SP ? k : k - SP;
-        float v = 0.0f;
-        if (kk < S && n < tp.H) v = tp.Wf[(size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + kk) * tp.H + n];
-        Ws[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = v;
-    }
-    if (L2) {                                   // second Dense: rows k < H (hidden units), columns n < S, same swizzle
-        for (int i = tid; i < SP * SP; i += NT) {
-            const int k = i / SP, n = i % SP;
-            W2s[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = (k < tp.H && n < S) ? tp.W2[(size_t)k * S + n] : 0.0f;
-        }
-        if (tid < SP) W2s[SP * LDW + tid] = tid < S ? tp.b2[tid] : 0.0f;
-    }
-    if (tid < 2 * NS) fill[tid] = 0;
-    __syncthreads();
-
     // XCD-contiguous tile ranges (workgroups b, b+8, .. share an XCD under round-robin dispatch; speed only)
     const int ntiles = (count + 15) / 16;
     const int xcd = bid & 7, lb = bid >> 3;
@@ -139,11 +122,56 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     char *__restrict__ obase = reinterpret_cast<char *>(a.state_out);
     int any = 0;
 
+    // ---- gather waves: the first job's CSR row (node id, row pointers, first 16 source ids) --------------------------------
+    const int p = wave - Cfg::NCONS;
+    const int qr = lane / LPR;                 // row of this lane group inside the wave's deposit
+    const int l4 = lane % LPR;                 // 16-B column chunk of the row owned by this lane
+    const int njobs = T * Cfg::PPT;
+    auto job_m = [&](int n) -> int {            // global row number of this lane group's node in job n (-1: none)
+        const int m = (t_first + (n / Cfg::PPT) * blk_per_xcd) * 16 + (n % Cfg::PPT) * Cfg::RPWV + qr;
+        return (n < njobs && m < count) ? m : -1;
+    };
+    auto node_of = [&](int m) -> int {
+        const int jr = buf_ld_i32(r_rows, m >= 0 ? 4u * (unsigned)m : BUF_OFF);
+        return m >= 0 ? (rows ? jr : m) : -1;
+    };
+    int jA = -1, jB = -1, begA = 0, endA = 0;
+    int idsA[IPL]; float wsA[IPL];
+#pragma unroll
+    for (int u = 0; u < IPL; ++u) { idsA[u] = 0; wsA[u] = 0.0f; }
+    if (wave >= Cfg::NCONS) {
+        jA = node_of(job_m(p)); jB = node_of(job_m(p + Cfg::NPROD));
+        begA = buf_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA : BUF_OFF);
+        endA = buf_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA + 4u : BUF_OFF);
+#pragma unroll
+        for (int u = 0; u < IPL; ++u) {
+            const int e = begA + u * LPR + l4;
+            idsA[u] = buf_ld_i32(r_src, e < endA ? 4u * (unsigned)e : BUF_OFF);
+            wsA[u] = HAS_W ? buf_ld_f32(r_w, e < endA ? 4u * (unsigned)e : BUF_OFF) : 0.0f;
+        }
+    }
+
+    for (int i = tid; i < 2 * SP * SP; i += NT) {
+        const int k = i / SP, n = i % SP;
+        const int kk = k < SP ? k : k - SP;
+        float v = 0.0f;
+        if (kk < S && n < tp.H) v = tp.Wf[(size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + kk) * tp.H + n];
+        Ws[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = v;
+    }
+    if (L2) {                                   // second Dense: rows k < H (hidden units), columns n < S, same swizzle
+        for (int i = tid; i < SP * SP; i += NT) {
+            const int k = i / SP, n = i % SP;
+            W2s[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = (k < tp.H && n < S) ? tp.W2[(size_t)k * S + n] : 0.0f;
+        }
+        if (tid < SP) W2s[SP * LDW + tid] = tid < S ? tp.b2[tid] : 0.0f;
+    }
+    if (tid < 2 * NS) fill[tid] = 0;
+    __syncthreads();
+    if (!open) return;                         // uniform across the launch; nothing has left the CU yet
+
+
     if (wave >= Cfg::NCONS) {
         // ================================ gather waves ================================================================
-        const int p = wave - Cfg::NCONS;
-        const int qr = lane / LPR;                 // row of this lane group inside the wave's deposit
-        const int l4 = lane % LPR;                 // 16-B column chunk of the row owned by this lane
 #ifdef GNN_F4_PROFILE
         const unsigned long long tr_ = f4_now();
 #endif
@@ -151,24 +179,6 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
         // Every load is a raw buffer load (predicated off = out of range = 0): no branches around memory operations, so
         // the waits hipcc inserts are exact counts.  The dependent chain  node id -> row pointers -> source ids -> rows
         // is cut by fetching the NEXT job's row pointers and first 16 source ids while this job's rows are in flight.
-        const int njobs = T * Cfg::PPT;
-        auto job_m = [&](int n) -> int {            // global row number of this lane group's node in job n (-1: none)
-            const int m = (t_first + (n / Cfg::PPT) * blk_per_xcd) * 16 + (n % Cfg::PPT) * Cfg::RPWV + qr;
-            return (n < njobs && m < count) ? m : -1;
-        };
-        auto node_of = [&](int m) -> int {
-            const int jr = buf_ld_i32(r_rows, m >= 0 ? 4u * (unsigned)m : BUF_OFF);
-            return m >= 0 ? (rows ? jr : m) : -1;
-        };
-        int jA = node_of(job_m(p)), jB = node_of(job_m(p + Cfg::NPROD));
-        int begA = buf_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA : BUF_OFF), endA = buf_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA + 4u : BUF_OFF);
-        int idsA[IPL]; float wsA[IPL];
-#pragma unroll
-        for (int u = 0; u < IPL; ++u) {
-            const int e = begA + u * LPR + l4;
-            idsA[u] = buf_ld_i32(r_src, e < endA ? 4u * (unsigned)e : BUF_OFF);
-            wsA[u] = HAS_W ? buf_ld_f32(r_w, e < endA ? 4u * (unsigned)e : BUF_OFF) : 0.0f;
-        }
         for (int n = p; n < njobs; n += Cfg::NPROD) {
             const int t = n / Cfg::PPT;
             const int row = (n % Cfg::PPT) * Cfg::RPWV + qr;

@@ -478,21 +478,25 @@ class HaloShardedLoop(ShardedLoop):
         return self._output()
 
 
+def choose_exchange(graph: GraphObject, world_size: int) -> str:
+    """'halo' when the compacted halos move less than half of the all-gather volume for EVERY rank, else 'allgather'.
+    Decided from the whole graph (every rank holds it on the host), never from the caller's own shard: all ranks must
+    reach the same answer or they would wait in different collectives."""
+    chunk, ranges = partition(graph.nodes.shape[0], world_size)
+    src, dst = graph.arc_ids[:, 0], graph.arc_ids[:, 1]
+    worst = 0.0
+    for lo, hi in ranges:
+        mine = (dst >= lo) & (dst < hi)
+        remote = np.unique(src[mine & ((src < lo) | (src >= hi))])
+        worst = max(worst, len(remote) / max((world_size - 1) * chunk, 1))
+    return 'halo' if worst < 0.5 else 'allgather'
+
+
 def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, device, group=None, exchange: str = 'auto'):
     """`exchange`: 'allgather' (whole slices, one all-gather), 'halo' (only the rows each peer reads, one all-to-all), or
     'auto' = halo when it moves less than half of what the all-gather would (graphs with locality, block-diagonal
     batches), all-gather otherwise (Erdős–Rényi graphs: every slice is almost entirely somebody's halo)."""
     if exchange not in ('auto', 'allgather', 'halo'): raise ValueError('exchange must be auto, allgather or halo')
-    if exchange == 'auto':
-        # decided from the WHOLE graph (every rank holds it on the host), never from the caller's own shard: all ranks must
-        # reach the same answer or they would wait in different collectives
-        chunk, ranges = partition(graph.nodes.shape[0], world_size)
-        src, dst = graph.arc_ids[:, 0], graph.arc_ids[:, 1]
-        worst = 0.0
-        for lo, hi in ranges:
-            mine = (dst >= lo) & (dst < hi)
-            remote = np.unique(src[mine & ((src < lo) | (src >= hi))])
-            worst = max(worst, len(remote) / max((world_size - 1) * chunk, 1))
-        exchange = 'halo' if worst < 0.5 else 'allgather'
+    if exchange == 'auto': exchange = choose_exchange(graph, world_size)
     cls = HaloShardedLoop if exchange == 'halo' else ShardedLoop
     return cls(model, graph, rank, world_size, device, group=group)

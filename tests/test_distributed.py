@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from gnnkeras_amd import GraphObject
-from gnnkeras_amd.distributed import ShardedLoop, ShardPlan, HaloShardedLoop, HaloShardPlan, partition, padded_row
+from gnnkeras_amd.distributed import ShardedLoop, ShardPlan, HaloShardedLoop, HaloShardPlan, partition, padded_row, choose_exchange
 from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
 from gnnkeras_amd.Models.GNN import GNNnodeBased
 from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
@@ -229,3 +229,21 @@ def test_halo_plan_lists_are_consistent():
     for r in range(2):
         hp = HaloShardPlan(gg, r, 2)
         assert sum(len(h) for h in hp.halo) == 0 and hp.send_counts[1 - r] == 1 and hp.n_rows_view == 10 + 1 + 1
+
+
+def test_exchange_choice_is_a_property_of_the_graph_not_of_the_rank():
+    """One rank's halo is almost everything, the other's is empty: both must still pick the same collective."""
+    rng = np.random.default_rng(0)
+    n = 400
+    # arcs into the first half come from everywhere (rank 0 reads most of rank 1's rows); the second half only reads itself
+    a = np.stack([rng.integers(0, n, 4000), rng.integers(0, n // 2, 4000)], 1)
+    b = np.stack([rng.integers(n // 2, n, 4000), rng.integers(n // 2, n, 4000)], 1)
+    ab = np.concatenate([a, b])
+    ids = np.unique(ab[ab[:, 0] != ab[:, 1]], axis=0).astype(float)
+    g = GraphObject(rng.normal(size=(n, 3)), np.concatenate([ids, np.ones((len(ids), 1))], 1), rng.normal(size=(n, 2)),
+                    focus='n', aggregation_mode='sum')
+    assert choose_exchange(g, 2) == 'allgather'                # decided by the WORST rank
+    block = np.array([[i, (i + 1) % (n // 2)] for i in range(n // 2)] + [[n // 2 + i, n // 2 + (i + 1) % (n // 2)] for i in range(n // 2)], float)
+    g2 = GraphObject(rng.normal(size=(n, 3)), np.concatenate([block, np.ones((len(block), 1))], 1), rng.normal(size=(n, 2)),
+                     focus='n', aggregation_mode='sum')
+    assert choose_exchange(g2, 2) == 'halo'                    # block-diagonal: nothing but flags to exchange

@@ -566,8 +566,11 @@ int output_stage(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     return 0;
 }
 
-// workgroup shape of the fused kernel: GNN_FUSED_WAVES = 8 (default: 512 threads, 16 waves per CU) or 4 (256 threads).
-// Read once; a tuning knob, never a correctness switch.
+// GNN_FUSED_WAVES: one shape knob per kernel generation (unset = that generation's default); read once, a tuning knob,
+// never a correctness switch.
+//   generation 2: waves per workgroup, 8 (default: 512 threads, 16 waves per CU) or 4 (256 threads, 256-VGPR budget)
+//   generation 3: 12 (default: one 768-thread workgroup per CU) or 8
+//   generation 4: rows in flight per lane group of a gather wave, 4 (default) or 8
 int fused_waves() {
     static int v = -1;
     if (v < 0) {

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — the headline measurement of BASELINE.json on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, when WORLD_SIZE is unset, this process
+starts them itself as a CHILD `torch.distributed.run` before anything here touches the GPU and relays rank 0's JSON line.
 
 Workload (config.workload): BASELINE config C4 — synthetic directed Erdős–Rényi graph, 1 000 000 nodes / 10 000 000
 arcs, state_dim 64, node-focused, 'average' aggregation, max_iteration 50, threshold 0 (fixed work, k = 50), starter
@@ -12,9 +16,12 @@ aggregates + 50 fused iterations + output network, inputs already resident in HB
 metric  = node-state updates/s = arcs x iterations / wall seconds (whole job, all ranks), float32 arithmetic.
 roofline = the fused iteration kernel: algorithmic bytes per launch / its average duration,
            measured live with HIP events recorded on the launch stream around the 50 iteration launches.
-cpu_baseline = the torch-CPU restatement of the reference's un-fused op sequence (oracle/torch_cpu.py, all host
-           cores), timed on rank 0 at N = 1 on a bounded sample (a few iterations of the same graph).
-Also reported (extra keys): the MUTAG batch-32 forward (BASELINE config C2) in ms/graph next to its CPU baseline.
+cpu_baseline = the restatement of the reference's un-fused op sequence (oracle/cpu_baseline.py) timed on rank 0 at
+           N = 1 on a bounded sample (iterations of the same graph: warm-up, then the median), three variants - torch on
+           all host threads, torch on one thread, NumPy/SciPy on one thread; `value` is the fastest.
+Also reported (extra keys): the MUTAG batch-32 forward (BASELINE config C2) in ms/graph next to its CPU baseline, and
+`beyond_infinity_cache`: the same iteration kernel on a 4 M-node / 40 M-arc graph whose 1 GB state array cannot sit in
+the 256 MiB Infinity Cache (the C4 state array, 256 MB, can).
 """
 import argparse
 import json
@@ -92,23 +99,97 @@ def mutag_section(device, cpu: bool):
            'one_stream_fwd_ms_per_graph': 1e3 * t_one / n_graphs, 'one_stream_fwd_ms_per_batch': 1e3 * t_one / len(items),
            'us_per_iteration': 1e6 * t_one / max(sum(ks), 1), 'mean_k': float(np.mean(ks)),
            'updates_per_s': arcs_iters / t_gpu}
+    # the early-exit path: the same batches with a contractive state network (kernel x 0.25) stop well before
+    # max_iteration at threshold 0.01 (the random-initialised network above never does: mean_k = 50)
+    w = ns.get_weights()
+    ns_c = ns.clone(True); ns_c.set_weights([a * 0.25 if a.ndim == 2 else a for a in w])
+    gnn_c = GNNgraphBased(ns_c, no, 32, 50, 0.01)
+    run_c = lambda i: gnn_c.Loop(*inputs[i], state0=s0s[i])
+    for _ in gnn_c._batches_concurrently(len(inputs), run_c, device, width): pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ks_c = [r[0] for _, r in gnn_c._batches_concurrently(len(inputs), run_c, device, width)]
+    torch.cuda.synchronize()
+    t_c = time.perf_counter() - t0
+    res['converging'] = {'note': 'state-network kernel x 0.25: contractive, the device-side predicate stops the loop early',
+                         'mean_k': float(np.mean([float(k) for k in ks_c])), 'fwd_ms_per_graph': 1e3 * t_c / n_graphs}
     if cpu:
         from oracle import torch_cpu
         from oracle.harness import _np, _triple
         sample = list(range(0, len(items), 17))[:8]
-        t_cpu = 0.0
-        for i in sample:
-            x = items[i]
-            t1 = time.perf_counter()
-            torch_cpu.loop(_np(x[0]), _np(x[1]), _triple(x[5]), _triple(x[6]), _triple(x[7]),
-                           np.ones(x[0].shape[0], bool), net_state=ns.spec(), net_output=no.spec(), state_vect_dim=32,
-                           max_iteration=50, state_threshold=0.01, focus='g', state0=_np(s0s[i]))
-            t_cpu += time.perf_counter() - t1
-        cpu_ms_graph = 1e3 * t_cpu / (32 * len(sample))
-        res['cpu_fwd_ms_per_graph'] = cpu_ms_graph
-        res['speedup_vs_cpu'] = cpu_ms_graph / res['fwd_ms_per_graph']
-        res['cpu_sample'] = f'{len(sample)} of 136 batches, torch CPU {torch.get_num_threads()} threads'
+        n_thr = torch.get_num_threads()
+        per_threads = {}
+        for thr in (1, n_thr):                       # ~1k-node batches: thread hand-offs can cost more than they buy
+            torch.set_num_threads(thr)
+            best = []
+            for i in sample:
+                x = items[i]
+                ts = []
+                for rep in range(3):                 # 1 warm-up + 2 timed, best of the timed
+                    t1 = time.perf_counter()
+                    torch_cpu.loop(_np(x[0]), _np(x[1]), _triple(x[5]), _triple(x[6]), _triple(x[7]),
+                                   np.ones(x[0].shape[0], bool), net_state=ns.spec(), net_output=no.spec(), state_vect_dim=32,
+                                   max_iteration=50, state_threshold=0.01, focus='g', state0=_np(s0s[i]))
+                    ts.append(time.perf_counter() - t1)
+                best.append(min(ts[1:]))
+            per_threads[thr] = 1e3 * sum(best) / (32 * len(sample))
+        torch.set_num_threads(n_thr)
+        fastest = min(per_threads, key=per_threads.get)
+        res['cpu_fwd_ms_per_graph'] = per_threads[fastest]
+        res['cpu_fwd_ms_per_graph_by_threads'] = {str(k): v for k, v in per_threads.items()}
+        res['speedup_vs_cpu'] = per_threads[fastest] / res['fwd_ms_per_graph']
+        res['cpu_sample'] = f'{len(sample)} of 136 batches, torch CPU, faster of 1 / {n_thr} threads = {fastest}'
     return res
+
+
+def measure_loop(gnn, inputs, s0, steps, warmup):
+    """(elapsed seconds of `steps` forwards, k, seconds per iteration kernel launch) on one GPU; the per-launch time comes from
+    HIP events the library records on the launch stream around the iteration launches (gnn.loop_events)."""
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    for e in ev: e.record()
+    gnn.loop_events = ev
+    step = lambda: gnn.Loop(*inputs, state0=s0)
+    for _ in range(warmup): step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps): k, state, out = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_val = gnn.check_last_k()
+    t_loop_ms = []
+    for _ in range(5):
+        step(); torch.cuda.synchronize()
+        t_loop_ms.append(ev[0].elapsed_time(ev[1]))
+    gnn.loop_events = None
+    return elapsed, k_val, 1e-3 * float(np.median(t_loop_ms)) / max(k_val, 1)
+
+
+def roofline_record(b_iter, t_iter, kernel_name):
+    achieved = b_iter / t_iter
+    return {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
+            'traffic': None, 'kernel': kernel_name, 'algorithmic_bytes_per_launch': b_iter, 'avg_launch_us': 1e6 * t_iter}
+
+
+def beyond_cache_section(device, d, K_it, aggregation):
+    """The same model on a 4 M-node / 40 M-arc ER graph: state array 1 GB (> the 256 MiB Infinity Cache), operands built on
+    the device (gnnkeras_amd.synth.er_device_batch)."""
+    from gnnkeras_amd import _native as nat
+    from gnnkeras_amd.synth import er_device_batch
+    from gnnkeras_amd.Models.GNN import GNNnodeBased
+    N, E = 4_000_000, 40_000_000
+    x = er_device_batch(N, E, device, aggregation_mode=aggregation, seed=1234)
+    ns, no = starter_nets(d, device)
+    gnn = GNNnodeBased(ns, no, d, K_it, 0.0)
+    gen = torch.Generator(device=device); gen.manual_seed(1)
+    s0 = torch.randn((N, d), generator=gen, device=device) * 0.1
+    elapsed, k_val, t_iter = measure_loop(gnn, gnn.process_inputs(x), s0, steps=2, warmup=1)
+    b_iter = algorithmic_bytes_per_iteration(N, E, d, ns.units[0], False)
+    rec = roofline_record(b_iter, t_iter, nat.lib().gnn_last_kernel_name().decode())
+    rec.update({'workload': f'Erdos-Renyi {N} nodes / {E} arcs, state_dim={d}, k={k_val:g}, {aggregation} aggregation '
+                            f'(state array {N * d * 4 / 2**20:.0f} MiB: does not fit the 256 MiB Infinity Cache)',
+                'updates_per_s': E * k_val * 2 / elapsed, 'fwd_ms': 1e3 * elapsed / 2})
+    del rec['traffic']
+    return rec
 
 
 def main():
@@ -116,8 +197,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', choices=['c4', 'c3', 'c5'], default='c4',
-                    help='c4: ER 1M/10M (headline); c3: ER 100k/1M; c5: composite ER 500k/5M, 3 node types')
+    ap.add_argument('--workload', choices=['c4', 'c3', 'c5', 'c4x4'], default='c4',
+                    help='c4: ER 1M/10M (headline); c3: ER 100k/1M; c5: composite ER 500k/5M, 3 node types; '
+                         'c4x4: ER 4M/40M built on the device (state array beyond the Infinity Cache)')
     ap.add_argument('--nodes', type=float, default=None)
     ap.add_argument('--arcs', type=float, default=None)
     ap.add_argument('--state-dim', type=int, default=64)
@@ -125,17 +207,29 @@ def main():
     ap.add_argument('--aggregation', default='average')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-mutag', action='store_true')
+    ap.add_argument('--no-beyond-cache', action='store_true')
     ap.add_argument('--unfused', action='store_true')
     ap.add_argument('--force-sharded', action='store_true', help='run the N>1 code path even with one rank (smoke test)')
     ap.add_argument('--exchange', choices=['auto', 'allgather', 'halo'], default='auto',
                     help='N>1 state exchange: whole slices (all-gather) or compacted halos (all-to-all)')
+    ap.add_argument('--no-overlap', action='store_true', help='N>1: exchange strictly after the iteration kernel (no own-range / halo split)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Start the N ranks as a child torch.distributed.run.  Nothing in this process has touched the GPU (importing torch
+        # does not), and the child is a fresh process tree: no exec from a GPU-initialised process.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher started a different number of ranks')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the message-passing loop has no CPU path')
     torch.cuda.set_device(local_rank)
@@ -148,17 +242,18 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from gnnkeras_amd import _native as nat
-    from gnnkeras_amd.synth import er_graph, er_composite_graph
+    from gnnkeras_amd.synth import er_graph, er_composite_graph, er_device_batch
     from gnnkeras_amd.Models.GNN import GNNnodeBased
     from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased
     from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
     from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer, CompositeMultiGraphSequencer
 
-    sizes = {'c4': (1e6, 1e7), 'c3': (1e5, 1e6), 'c5': (5e5, 5e6)}[args.workload]
+    sizes = {'c4': (1e6, 1e7), 'c3': (1e5, 1e6), 'c5': (5e5, 5e6), 'c4x4': (4e6, 4e7)}[args.workload]
     N, E = int(args.nodes or sizes[0]), int(args.arcs or sizes[1])
     d, K_it = args.state_dim, args.max_iteration
-    s0_host = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
     composite = args.workload == 'c5'
+    on_device = args.workload == 'c4x4'
+    if on_device and sharded: raise SystemExit('--workload c4x4 is a single-GPU point (operands are built on one device)')
     if composite:
         dims = (14, 8, 4)
         graph = er_composite_graph(N, E, dim_node_label=dims, aggregation_mode=args.aggregation, seed=1234)
@@ -170,28 +265,32 @@ def main():
         gnn = CompositeGNNnodeBased(nets_s, no, d, K_it, 0.0)
         Sequencer = CompositeMultiGraphSequencer
     else:
-        graph = er_graph(N, E, aggregation_mode=args.aggregation, seed=1234)
+        graph = None if on_device else er_graph(N, E, aggregation_mode=args.aggregation, seed=1234)
         ns, no = starter_nets(d, device)
         gnn = GNNnodeBased(ns, no, d, K_it, 0.0)
         Sequencer = MultiGraphSequencer
     if args.unfused: gnn.native_flags = nat.FLAG_UNFUSED
-
-    if not sharded:
-        seq = Sequencer([graph], 'n', args.aggregation, 1, shuffle=False, device=device)
-        x = seq[0][0]
-        inputs = gnn.process_inputs(x)
+    if on_device:
+        gen = torch.Generator(device=device); gen.manual_seed(1)
+        s0 = torch.randn((N, d), generator=gen, device=device) * 0.1
+        s0_host = None
+    else:
+        s0_host = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
         s0 = torch.from_numpy(s0_host).to(device)
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        for e in ev: e.record()
-        gnn.loop_events = ev
-        step = lambda: gnn.Loop(*inputs, state0=s0)
-        per_arc_w = inputs[7 if composite else 5].csr().w is not None
-        sync_all = torch.cuda.synchronize
+
+    extra = {}
+    if not sharded:
+        x = er_device_batch(N, E, device, aggregation_mode=args.aggregation, seed=1234) if on_device else \
+            Sequencer([graph], 'n', args.aggregation, 1, shuffle=False, device=device)[0][0]
+        inputs = gnn.process_inputs(x)
+        per_arc_w = inputs[7 if composite else 5].device_csr(device)['w'] is not None
+        elapsed, k_val, t_iter = measure_loop(gnn, inputs, s0, args.steps, args.warmup)
+        kernel_name = nat.lib().gnn_last_kernel_name().decode()
     else:
         import torch.distributed as dist
         from gnnkeras_amd.distributed import make_sharded_loop
-        sl = make_sharded_loop(gnn, graph, rank=rank, world_size=world, device=device, exchange=args.exchange)
-        s0 = torch.from_numpy(s0_host).to(device)
+        sl = make_sharded_loop(gnn, graph, rank=rank, world_size=world, device=device, exchange=args.exchange,
+                               overlap=not args.no_overlap)
         step = lambda: sl.forward(s0)
         per_arc_w = sl.per_arc_weights
 
@@ -200,48 +299,44 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup): step()
-    loop_ms, ks = [], []
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        k, state, out = step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if sharded:
-        import torch.distributed as dist
+        for _ in range(args.warmup): step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            k, state, out = step()
+        sync_all()
+        elapsed = time.perf_counter() - t0
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    k_val = float(k)
+        k_val = float(k)
+        prof = sl.profile_iteration(s0)            # per-iteration device time: kernel(s) alone, exchange alone, both overlapped
+        t_iter = prof['kernel_s']
+        kernel_name = nat.lib().gnn_last_kernel_name().decode()
+        tt = torch.tensor([prof['kernel_s'], prof['exchange_s'], prof['iteration_s']], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        extra['per_iteration_ms'] = {'kernel': 1e3 * float(tt[0]), 'exchange': 1e3 * float(tt[1]),
+                                     'iteration_overlapped': 1e3 * float(tt[2]),
+                                     'note': 'max over ranks; kernel = own-range + halo launches without the collective, exchange = '
+                                             'the collective alone, iteration = what one iteration costs with both in flight'}
+        extra['exchange_bytes_per_rank_per_iteration'] = sl.exchange_bytes()
     ms_per_step = 1e3 * elapsed / args.steps
     value = E * k_val * args.steps / elapsed
 
-    # dominant kernel: fused iteration; duration from the HIP events the library records around the 50 launches
-    if not sharded:
-        t_loop_ms = []
-        for _ in range(5):
-            step(); torch.cuda.synchronize()
-            t_loop_ms.append(ev[0].elapsed_time(ev[1]))
-        t_iter = 1e-3 * float(np.median(t_loop_ms)) / max(k_val, 1)
-    else:
-        t_iter = sl.kernel_seconds_per_iteration(s0)
     h1 = ns.units[0]
     n_local = N if not sharded else sl.n_local
     e_local = E if not sharded else sl.e_local
     b_iter = algorithmic_bytes_per_iteration(n_local, e_local, d, h1, per_arc_w)
-    achieved = b_iter / t_iter
-    roofline = {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK, 'traffic': None,
-                'kernel': ('k_state_fused4<64,false,4,4> (wave-specialised; GNN_FUSED_KERNEL=%s)' % os.environ.get('GNN_FUSED_KERNEL', 'auto'))
-                          if not args.unfused else 'k_aggregate+k_segdense+k_converge',
-                'algorithmic_bytes_per_launch': b_iter, 'avg_launch_us': 1e6 * t_iter}
+    roofline = roofline_record(b_iter, t_iter, kernel_name)
     traffic_file = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(traffic_file) and not sharded and not args.unfused:
+    if os.path.exists(traffic_file) and not sharded:
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
+        # command, scripts/parse_pmc.py): recorded per (kernel, workload), used only when both match this run
         try:
-            tr = json.load(open(traffic_file))
-            if tr.get('workload_nodes') == N and tr.get('workload_arcs') == E and not composite:
-                roofline['traffic'] = tr['hbm_bytes_per_launch']
+            for tr in json.load(open(traffic_file)).get('records', []):
+                if tr.get('kernel') == kernel_name and tr.get('nodes') == N and tr.get('arcs') == E and tr.get('state_dim') == d:
+                    roofline['traffic'] = tr['hbm_bytes_per_launch']
+                    roofline['traffic_bounds'] = tr.get('bounds')
         except Exception:
             pass
 
@@ -255,31 +350,42 @@ def main():
                                + ('3 node types with per-type ' if composite else '') +
                                f'BN+Dense({ns.input_dim}->{h1},selu) state net',
                    'sharding': 'single GPU' if not sharded else f'node-range shards over {world} GPUs, '
-                                                               f'RCCL {"all-to-all of compacted halos" if type(sl).__name__ == "HaloShardedLoop" else "all-gather of state slices"} per iteration'},
+                                                               f'RCCL {"all-to-all of compacted halos" if type(sl).__name__ == "HaloShardedLoop" else "all-gather of state slices"} per iteration'
+                                                               + (', own-range arcs overlapped with the exchange' if sharded and sl.overlap else '')},
         'roofline': roofline,
         'loop_only_updates_per_s': E / t_iter if not sharded else None,
         'fwd_ms_per_graph': ms_per_step,
     }
+    result.update(extra)
 
-    if rank == 0 and not sharded and not args.no_cpu_baseline and not composite:
-        from oracle import torch_cpu
+    if rank == 0 and not sharded and not args.no_cpu_baseline and not composite and not on_device:
+        from oracle import cpu_baseline as cb
         from oracle.harness import _np, _triple
-        it_cpu = 3
-        tm = {}
-        torch_cpu.loop(_np(x[0]), _np(x[1]), _triple(x[5]), _triple(x[6]), _triple(x[7]), np.ones(N, bool),
-                       net_state=ns.spec(), net_output=no.spec(), state_vect_dim=d, max_iteration=it_cpu,
-                       state_threshold=0.0, state0=s0_host, timings=tm)
-        result['cpu_baseline'] = {'value': E * it_cpu / tm['loop_s'], 'unit': 'arc-updates/s',
-                                  'cores': torch.get_num_threads(), 'kind': 'port',
-                                  'sample': f'{it_cpu} iterations of the same C4 graph, loop only, torch-CPU '
-                                            f'restatement of the TF op sequence (not TensorFlow), '
-                                            f'{os.cpu_count()} host cpus'}
+        ops = (_np(x[0]), _np(x[1]), _triple(x[5]), _triple(x[6]), ns.spec(), d, 0.0, s0_host)
+        n_thr = torch.get_num_threads()
+        variants = {'torch_all': cb.time_torch(*ops, threads=n_thr, warmup=3, max_timed=10, budget_s=12.0),
+                    'torch_1': cb.time_torch(*ops, threads=1, warmup=1, max_timed=5, budget_s=8.0),
+                    'numpy_1': cb.time_numpy(*ops, warmup=1, max_timed=5, budget_s=8.0)}
+        for v in variants.values(): v['arc_updates_per_s'] = E / v['median_iter_s']
+        best = max(variants, key=lambda n: variants[n]['arc_updates_per_s'])
+        result['cpu_baseline'] = {'value': variants[best]['arc_updates_per_s'], 'unit': 'arc-updates/s',
+                                  'cores': variants[best]['threads'], 'kind': 'port',
+                                  'sample': f'median of {variants[best]["timed_iterations"]} iterations (after '
+                                            f'{variants[best]["warmup_iterations"]} warm-up) of the same {args.workload.upper()} graph, loop '
+                                            f'only, variant {best} = the fastest of torch on {n_thr} threads / torch on 1 thread / '
+                                            f'NumPy+SciPy on 1 thread; restatement of the TF op sequence (not TensorFlow), '
+                                            f'{os.cpu_count()} host cpus',
+                                  'variants': variants}
         result['speedup_vs_cpu_loop'] = (E / t_iter) / result['cpu_baseline']['value']
     if rank == 0 and not sharded and not args.no_mutag and args.workload == 'c4':
         result['mutag'] = mutag_section(device, cpu=not args.no_cpu_baseline)
+    if rank == 0 and not sharded and not args.no_beyond_cache and args.workload == 'c4' and not args.unfused:
+        del gnn, inputs, x, s0
+        torch.cuda.empty_cache()
+        result['beyond_infinity_cache'] = beyond_cache_section(device, d, K_it, args.aggregation)
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if sharded:
         import torch.distributed as dist
         dist.destroy_process_group()

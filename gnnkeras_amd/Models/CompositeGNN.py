@@ -201,6 +201,7 @@ class CompositeGNNnodeBased(GNNnodeBased):
         out = torch.empty((n_rows_out, self.net_output.units[-1]), dtype=torch.float32, device=dev)
         a.k_out, a.state_out, a.out = nat.ptr(k), nat.ptr(state), nat.ptr(out)
         nat.check(nat.lib().gnn_loop_forward(C.byref(a)))
+        self._last_k = k
         return k, state, out
 
 

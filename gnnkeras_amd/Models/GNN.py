@@ -89,7 +89,9 @@ class _LoopModel:
         return torch.cat(outs, dim=0).cpu().numpy()
 
     def evaluate(self, sequencer, return_dict: bool = False, **kwargs):
-        """Sample-weighted mean loss and metrics over the sequencer (Keras `evaluate` semantics)."""
+        """Loss and metrics over the sequencer with Keras `evaluate` semantics: the loss is sum(loss_i * weight_i) / number of
+        samples (SUM_OVER_BATCH_SIZE per batch, batches averaged by their size), the metrics are weighted means
+        sum(metric_i * weight_i) / sum(weight_i)."""
         if self.loss is None: raise RuntimeError('compile() the model with a loss before evaluate()')
         lossf = _loss_fn(self.loss)
         tot_loss = tot_w = None
@@ -105,7 +107,7 @@ class _LoopModel:
                 cnt = torch.zeros((), device=p.device)
             sw = sw.to(p.device)
             tot_loss = tot_loss + (lossf(y, p) * sw).sum()
-            tot_w = tot_w + sw.sum()
+            tot_w = tot_w + float(sw.shape[0])
             cnt = cnt + sw.sum()
             mets = [(n, f, acc + (f(y, p) * sw).sum()) for n, f, acc in mets]
         self._check_k()
@@ -160,15 +162,28 @@ class _LoopModel:
         self.history = history
         return history
 
+    _K_ERROR = ('a bounded in-launch wait of the loop kernels expired (persistent kernel: not all workgroups resident - GPU '
+                'shared with other long-running work?; wave-specialised kernel: a lost LDS hand-off): state and output are '
+                'invalid. Set model.native_flags = FLAG_FUSED_GEN2 or lower inference_streams')
+
     def _check_k(self):
-        """k < 0 is how the persistent whole-loop kernel reports that its workgroups could not all be resident (its grid
-        barrier timed out): checked once per predict() / evaluate(), where the host synchronises anyway."""
+        """k < 0 is how the loop kernels report an expired in-launch wait (the persistent whole-loop kernel's grid barrier,
+        the wave-specialised kernel's slot hand-off): checked once per predict() / evaluate(), where the host
+        synchronises anyway."""
         ks = getattr(self, '_k_seen', None)
         if ks:
             if float(torch.stack([k.reshape(()) for k in ks]).min()) < 0:
-                raise nat.NativeError('the persistent loop kernel timed out waiting for its workgroups (GPU shared with '
-                                      'other long-running work?): set model.native_flags = FLAG_FUSED_GEN2 or lower inference_streams')
+                raise nat.NativeError(self._K_ERROR)
         self._k_seen = None
+
+    def check_last_k(self):
+        """For direct `Loop()` / `call()` / `model(x)` callers: synchronise on the k of the most recent forward and raise
+        `NativeError` if the kernels reported an expired wait (k < 0). Returns k as a float."""
+        k = getattr(self, '_last_k', None)
+        if k is None: raise RuntimeError('no forward has run yet')
+        kv = float(k)
+        if kv < 0: raise nat.NativeError(self._K_ERROR)
+        return kv
 
     @staticmethod
     def _batch_device(x):
@@ -467,6 +482,7 @@ class GNNnodeBased(_LoopModel):
         out = torch.empty((n_rows_out, T), dtype=torch.float32, device=dev)
         a.k_out, a.state_out, a.out = nat.ptr(k), nat.ptr(state), nat.ptr(out)
         nat.check(nat.lib().gnn_loop_forward(C.byref(a)))
+        self._last_k = k
         return k, state, out
 
 

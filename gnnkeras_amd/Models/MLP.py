@@ -65,6 +65,40 @@ def initialize(name, shape, rng) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+class L1L2:
+    """Weight penalty `l1 * sum|w| + l2 * sum(w^2)` (the semantics of `tf.keras.regularizers.L1L2`, which the reference
+    passes through `MLP(..., kernel_regularizer=, bias_regularizer=)`, MLP.py:12-15, :48-49): added once per variable to
+    the training loss (`train_step`: `regularization_losses=self.losses`, GNN.py:286) and to its gradient."""
+
+    def __init__(self, l1: float = 0.0, l2: float = 0.0):
+        self.l1, self.l2 = float(l1), float(l2)
+
+    def get_config(self):
+        return {'l1': self.l1, 'l2': self.l2}
+
+    def __repr__(self):
+        return f'L1L2(l1={self.l1}, l2={self.l2})'
+
+
+def l1(l: float = 0.01): return L1L2(l1=l)
+def l2(l: float = 0.01): return L1L2(l2=l)
+def l1_l2(l1: float = 0.01, l2: float = 0.01): return L1L2(l1=l1, l2=l2)
+
+
+def as_regularizer(r):
+    """None | L1L2 | 'l1' / 'l2' / 'l1_l2' (Keras string shortcuts, factor 0.01) | {'l1':, 'l2':} | any object with float
+    `l1` / `l2` attributes (a Keras L1L2 instance); anything else is rejected rather than ignored."""
+    if r is None or isinstance(r, L1L2): return r
+    if isinstance(r, str):
+        name = r.lower()
+        if name in ('l1', 'l2', 'l1_l2'): return {'l1': l1, 'l2': l2, 'l1_l2': l1_l2}[name]()
+        raise ValueError(f'unknown regularizer {r!r}')
+    if isinstance(r, dict): return L1L2(r.get('l1', 0.0) or 0.0, r.get('l2', 0.0) or 0.0)
+    if hasattr(r, 'l1') or hasattr(r, 'l2'): return L1L2(float(getattr(r, 'l1', 0.0) or 0.0), float(getattr(r, 'l2', 0.0) or 0.0))
+    raise ValueError(f'unsupported regularizer {r!r}: only L1 / L2 weight penalties have a device gradient')
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 class Sequential:
     """[BatchNormalization] + Dense x n with weights resident on the device.
 
@@ -72,7 +106,8 @@ class Sequential:
     `trainable_variables`, `name`, `summary`, call with `training=`; `input_dim`, `units`, `activations` describe it."""
 
     def __init__(self, input_dim: int, units, activations, batch_normalization: bool = True, dropout_rate=(),
-                 dropout_pos=(), alphadropout: bool = False, name: Optional[str] = None, weights=None, device=None):
+                 dropout_pos=(), alphadropout: bool = False, name: Optional[str] = None, weights=None, device=None,
+                 kernel_regularizer=None, bias_regularizer=None):
         self.input_dim = int(input_dim)
         self.units = [int(u) for u in units]
         self.activations = [('linear' if a is None else str(a).lower()) for a in activations]
@@ -82,6 +117,11 @@ class Sequential:
             raise ValueError(f'between 1 and {nat.GNN_MAX_LAYERS} Dense layers are supported')
         self.batch_normalization = bool(batch_normalization)
         self.dropout_rate, self.dropout_pos, self.alphadropout = list(dropout_rate), list(dropout_pos), alphadropout
+        n = len(self.units)
+        kr = kernel_regularizer if isinstance(kernel_regularizer, (list, tuple)) else [kernel_regularizer] * n
+        br = bias_regularizer if isinstance(bias_regularizer, (list, tuple)) else [bias_regularizer] * n
+        if len(kr) != n or len(br) != n: raise ValueError('one regularizer per Dense layer (or one for all)')
+        self.kernel_regularizer, self.bias_regularizer = [as_regularizer(r) for r in kr], [as_regularizer(r) for r in br]
         self.name = name
         self.device = torch.device(device) if device is not None else default_device()
         self._weights: list[torch.Tensor] = []
@@ -133,12 +173,16 @@ class Sequential:
 
     def spec(self):
         """(spec, weights) in the form the oracle's `mlp_apply` takes (tests only)."""
-        return {'batch_normalization': self.batch_normalization, 'activations': list(self.activations)}, self.get_weights()
+        reg = lambda rs: [None if r is None else (r.l1, r.l2) for r in rs]
+        return {'batch_normalization': self.batch_normalization, 'activations': list(self.activations),
+                'kernel_regularizer': reg(self.kernel_regularizer), 'bias_regularizer': reg(self.bias_regularizer)}, self.get_weights()
 
     def get_config(self):
         return {'input_dim': self.input_dim, 'units': self.units, 'activations': self.activations,
                 'batch_normalization': self.batch_normalization, 'dropout_rate': self.dropout_rate,
-                'dropout_pos': self.dropout_pos, 'alphadropout': self.alphadropout, 'name': self.name}
+                'dropout_pos': self.dropout_pos, 'alphadropout': self.alphadropout, 'name': self.name,
+                'kernel_regularizer': [None if r is None else r.get_config() for r in self.kernel_regularizer],
+                'bias_regularizer': [None if r is None else r.get_config() for r in self.bias_regularizer]}
 
     def clone(self, copy_weights: bool = True, rng=None, kernel_initializer='glorot_uniform', bias_initializer='zeros'):
         m = Sequential(**self.get_config(), device=self.device)
@@ -207,7 +251,8 @@ def MLP(input_dim: tuple, layers: list, activations, kernel_initializer, bias_in
         dropout_pos: Optional[Union[list, int]] = None, alphadropout: bool = False, batch_normalization: bool = True,
         *, name: str = None, rng=None, device=None) -> Sequential:
     """Same arguments as the reference builder (`MLP.py:12-15`); `rng` (numpy Generator or seed) is additive and makes
-    the initial weights reproducible. Regularizers are accepted and ignored by the forward path."""
+    the initial weights reproducible. Regularizers (`L1L2` / `l1()` / `l2()` of this module, Keras-style objects with
+    `l1` / `l2` attributes, or the Keras string shortcuts) add their penalty to the training loss and gradients."""
     layers = [layers] if isinstance(layers, int) else list(layers)
     if type(activations) != list: activations = [activations for _ in layers]
     if type(kernel_initializer) != list: kernel_initializer = [kernel_initializer for _ in layers]
@@ -225,7 +270,8 @@ def MLP(input_dim: tuple, layers: list, activations, kernel_initializer, bias_in
 
     in_dim = int(input_dim[0]) if isinstance(input_dim, (tuple, list)) else int(input_dim)
     model = Sequential(in_dim, layers, activations, batch_normalization, dropout_rate, dropout_pos, alphadropout,
-                       name=None if name is None else name.lower(), device=device)
+                       name=None if name is None else name.lower(), device=device,
+                       kernel_regularizer=kernel_regularizer, bias_regularizer=bias_regularizer)
     rng = rng if isinstance(rng, np.random.Generator) else np.random.default_rng(rng)
     model.set_weights(_init_weights(model, kernel_initializer, bias_initializer, rng))
     return model

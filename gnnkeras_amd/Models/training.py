@@ -291,6 +291,7 @@ class LoopTrainer:
         m = self.model
         tp = SimpleNamespace()
         composite = tp.composite = isinstance(m.net_state, (list, tuple))
+        _check_no_dropout((list(m.net_state) if composite else [m.net_state]) + [m.net_output])
         inputs = m.process_inputs(x_list)
         if composite:
             nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, _cas, adjacency, arcnode, nodegraph = inputs
@@ -558,18 +559,25 @@ class LoopTrainer:
         return d_nodes
 
     def finish(self, tp, apply=True):
-        """1/k on the state gradients when `average_st_grads` (GNN.py:295), zero gradients of untouched networks,
-        optimizer update."""
+        """Zero gradients of untouched networks, add the weight-penalty gradients, 1/k on the state gradients when
+        `average_st_grads` (GNN.py:295: the division covers the whole gradient, penalty included), optimizer update.
+        Returns the regularization loss (0-dim tensor) or None."""
         m = self.model
+        reg = None
         for g_ in tp.gs:
-            if m.average_st_grads and tp.k > 0:
-                for g in g_.gradients(): g.mul_(1.0 / tp.k)
             if tp.k == 0 or not g_.touched:
                 for g in g_.gradients(): g.zero_()
         if not tp.go.touched:
             for g in tp.go.gradients(): g.zero_()
+        for g_ in list(tp.gs) + [tp.go]:
+            r = _regularize(g_)
+            if r is not None: reg = r if reg is None else reg + r
+        for g_ in tp.gs:
+            if m.average_st_grads and tp.k > 0:
+                for g in g_.gradients(): g.mul_(1.0 / tp.k)
         if apply:
             m._optimizer_obj().apply_gradients(self.grads_and_vars(tp))
+        return reg
 
     @staticmethod
     def grads_and_vars(tp):
@@ -592,8 +600,31 @@ class LoopTrainer:
         res['loss'], dpred = self.loss_and_grad(tp, tp.y_pred, y, sample_weight)
         G_out = self.pool_backward(tp, dpred) if tp.pooled else dpred
         self.backward(tp, G_out)
-        self.finish(tp, apply)
+        reg = self.finish(tp, apply)
+        if reg is not None: res['loss'] = res['loss'] + reg          # compiled_loss(..., regularization_losses=self.losses)
         return res
+
+
+def _regularize(ng: _NetGrads):
+    """Adds d(penalty)/dw of every regularized Dense variable of one network to its gradient buffers and returns the penalty
+    `sum_l l1 * sum|w| + l2 * sum(w^2)` (each variable once per step, however many times the loop applied the network)."""
+    net, total = ng.net, None
+    for l in range(len(net.units)):
+        for reg, w, g in ((net.kernel_regularizer[l], ng.W[l], ng.dW[l]), (net.bias_regularizer[l], ng.b[l], ng.db[l])):
+            if reg is None or (reg.l1 == 0.0 and reg.l2 == 0.0): continue
+            pen = reg.l1 * w.abs().sum() + reg.l2 * (w * w).sum()
+            g.add_(reg.l1 * torch.sign(w) + (2.0 * reg.l2) * w)
+            total = pen if total is None else total + pen
+    return total
+
+
+def _check_no_dropout(nets):
+    """Dropout / AlphaDropout layers (`MLP(dropout_rate=, dropout_pos=)`, reference MLP.py:60-66) have no device kernels yet:
+    refuse to train a different network than the one that was asked for."""
+    for n_ in nets:
+        if n_.dropout_rate:
+            raise NotImplementedError('training a network with Dropout / AlphaDropout layers is not supported on the HIP path: build '
+                                      'the MLP without dropout_rate / dropout_pos (inference ignores dropout, as Keras does)')
 
 
 def _by_source(matrix: SparseMatrix, device):

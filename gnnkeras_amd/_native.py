@@ -11,7 +11,8 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libgnnloop.so')
+# GNNKERAS_AMD_LIB: load another build of the same sources (tests: the debug build whose in-launch waits expire at once)
+LIB_PATH = os.environ.get('GNNKERAS_AMD_LIB') or os.path.join(CSRC, 'libgnnloop.so')
 
 GNN_ABI_VERSION = 2
 GNN_MAX_LAYERS = 8
@@ -22,11 +23,12 @@ ACTIVATIONS = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'tanh': 3, 'sigmoid':
 FOCUS = {'n': 0, 'a': 1, 'g': 2}
 FLAG_UNFUSED = 1
 FLAG_NO_EARLY_EXIT = 2
-FLAG_FUSED_GEN2, FLAG_FUSED_GEN3, FLAG_FUSED_GEN4, FLAG_FUSED_GEN5 = 2 << 4, 3 << 4, 4 << 4, 5 << 4     # pin the fused-kernel generation (tests, tuning)
+FLAG_FUSED_GEN2, FLAG_FUSED_GEN4, FLAG_FUSED_GEN5 = 2 << 4, 4 << 4, 5 << 4     # pin the fused-kernel generation (tests, tuning)
 
-EXPORTS = ['gnn_last_error', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_aggregate',
+EXPORTS = ['gnn_last_error', 'gnn_last_kernel_name', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_aggregate',
            'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_ld',
            'gnn_shard_setup', 'gnn_shard_iteration', 'gnn_shard_output', 'gnn_gather_rows',
+           'gnn_shard_can_split', 'gnn_shard_partial', 'gnn_shard_iteration_split',
            'gnn_dense', 'gnn_fold_bn', 'gnn_dense_grad_workspace_bytes', 'gnn_dense_grad', 'gnn_act_grad',
            'gnn_colstats_workspace_bytes', 'gnn_colstats', 'gnn_first_layer_param_grads', 'gnn_bn_input_grad',
            'gnn_scatter_add_rows', 'gnn_axpby', 'gnn_loss_grad', 'gnn_adam_step', 'gnn_sgd_step',
@@ -92,7 +94,7 @@ class NativeError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """Compile libgnnloop.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    res = subprocess.run(['make', '-C', CSRC], capture_output=True, text=True)
+    res = subprocess.run(['make', '-j2', '-C', CSRC], capture_output=True, text=True)
     if verbose or res.returncode:
         print(res.stdout, res.stderr)
     if res.returncode:
@@ -112,6 +114,7 @@ def lib():
                               f'or `make -C {CSRC}`. There is no CPU fallback for the HIP path.')
         l = C.CDLL(LIB_PATH)
         l.gnn_last_error.restype = C.c_char_p
+        l.gnn_last_kernel_name.restype = C.c_char_p
         l.gnn_abi_version.restype = C.c_int
         l.gnn_loop_workspace_bytes.restype = C.c_size_t
         l.gnn_loop_workspace_bytes.argtypes = [C.POINTER(LoopArgs)]
@@ -140,6 +143,9 @@ def lib():
         l.gnn_shard_output.argtypes = [C.POINTER(LoopArgs), C.c_void_p, C.c_void_p, C.c_int32]
         vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
         protos = {
+            'gnn_shard_can_split': (C.c_int, [C.POINTER(LoopArgs)]),
+            'gnn_shard_partial': (C.c_int, [C.POINTER(LoopArgs), C.POINTER(CSR), vp, vp]),
+            'gnn_shard_iteration_split': (C.c_int, [C.POINTER(LoopArgs), C.POINTER(CSR), vp, vp, vp, i32, vp, i32, i32, vp, i32]),
             'gnn_dense': (C.c_int, [C.POINTER(DenseArgs)]),
             'gnn_gather_rows': (C.c_int, [vp, i32, vp, i32, i32, vp, i32, vp]),
             'gnn_fold_bn': (C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]),

@@ -20,7 +20,6 @@
 #include "../../include/gnnloop.h"
 #include "kernels_general.hpp"
 #include "kernel_state_fused2.hpp"
-#include "kernel_state_fused3.hpp"
 #include "kernel_state_fused4.hpp"
 #include "kernel_state_small.hpp"
 
@@ -303,6 +302,7 @@ struct Plan {
     TypePlan tp[GNN_MAX_TYPES];
     // workspace
     int *flags;
+    int *err;                        // sticky "an in-launch wait expired" word of the fused kernels, folded into k at the end
     float *agg_arcs, *agg_nodes; int ld_agg_nodes;
     float *C; int ldC;
     float *buf[2], *agg;
@@ -313,6 +313,8 @@ struct Plan {
     int *idx_src, *idx_dst;
     size_t bytes;
 };
+
+constexpr int GNN_LOOP_WORDS = 16;   // words behind flags[max_iteration]: [1] last flag, [3..7) barrier counters, [12] error word
 
 int state_width(const gnn_loop_args_t &a) { return a.state_dim > 0 ? a.state_dim : a.dim_node_label; }
 
@@ -382,7 +384,6 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
             if (a.nodes_src) return fail("hub segments are not supported on shards");
             if (!a.heavy_seg_beg || !a.heavy_seg_end) return fail("heavy_seg_beg / heavy_seg_end is NULL");
             TRY(check_csr(a.adjacency_light, "adjacency_light", p.N, p.N + a.n_heavy_segments));
-            if (p.SP > 64) return fail("hub segments need a state width <= 64");
         }
         if (p.composite) {
             if (!a.type_nodes && p.N > 0) return fail("type_nodes is NULL");
@@ -394,7 +395,8 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
 
     // ---- carve ----
     Carver c(ws);
-    p.flags = c.take<int>(a.max_iteration + 8);          // behind the flags: the persistent kernel's two 64-bit barrier counters
+    p.flags = c.take<int>(a.max_iteration + GNN_LOOP_WORDS);   // behind the flags: the persistent kernel's two 64-bit barrier counters, the error word
+    p.err = p.flags ? p.flags + a.max_iteration + 12 : nullptr;
     for (int t = 0; t < p.T; ++t) {
         p.tp[t].Wf = c.take<float>((size_t)a.net_state[t].in_dim * a.net_state[t].units[0]);
         p.tp[t].bf = c.take<float>(a.net_state[t].units[0]);
@@ -406,7 +408,9 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     p.agg_nodes = c.take<float>((size_t)p.N * std::max(p.ld_agg_nodes, 1));
     p.ldC = (p.H1max + 3) & ~3;      // rows start 16-B aligned: the wave-specialised fused kernel reads C as float4
     p.C = c.take<float>((size_t)p.N * p.ldC);
-    p.n_heavy = a.n_heavy_segments > 0 ? a.n_heavy_segments : 0;
+    // hub segments: virtual rows for padded widths up to 128; wider states walk the plain adjacency (the un-fused aggregate
+    // handles any degree), so the caller may always pass the split
+    p.n_heavy = (a.n_heavy_segments > 0 && p.SP <= 128) ? a.n_heavy_segments : 0;
     p.buf[0] = c.take<float>((size_t)(p.N + p.n_heavy) * p.SP + 64);
     p.buf[1] = c.take<float>((size_t)(p.N + p.n_heavy) * p.SP + 64);
     p.agg = c.take<float>((size_t)p.N * p.SP);
@@ -451,7 +455,7 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
 }
 
 // the operator the iterations walk: the light one when hub rows were split off
-inline const gnn_csr_t &iter_adjacency(const gnn_loop_args_t &a) { return a.n_heavy_segments > 0 ? a.adjacency_light : a.adjacency; }
+inline const gnn_csr_t &iter_adjacency(const gnn_loop_args_t &a, const Plan &p) { return p.n_heavy > 0 ? a.adjacency_light : a.adjacency; }
 
 // hub pre-pass: virtual rows N .. N + n_heavy of the buffer the iteration is about to read
 int launch_heavy(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src, hipStream_t st) {
@@ -461,7 +465,8 @@ int launch_heavy(const gnn_loop_args_t &a, const Plan &p, const int *gate, const
     switch (p.SP) {
         case 16: gnn::k_heavy_segments<16><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
         case 32: gnn::k_heavy_segments<32><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
-        default: gnn::k_heavy_segments<64><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
+        case 64: gnn::k_heavy_segments<64><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
+        default: gnn::k_heavy_segments<128><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
     }
     LAUNCH_OK();
     return 0;
@@ -470,9 +475,10 @@ int launch_heavy(const gnn_loop_args_t &a, const Plan &p, const int *gate, const
 // one un-fused iteration: agg = A^T state ; state_new = net_state([state | agg] + C) per type ; predicate.
 int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src_full, float *dst_full,
                       int row_base, int *flag_next, float *k_out, float k_val, hipStream_t st) {
+    GNN_SET_KERNEL_NAME("k_aggregate_vec + k_segdense + k_converge (un-fused)");
     TRY(launch_heavy(a, p, gate, src_full, st));
     // the padded width: pad columns are zero on both sides, and whole 16-B chunks let the vector kernel run for any d
-    TRY(launch_aggregate(gate, iter_adjacency(a), src_full, p.SP, p.SP <= 128 ? p.SP : p.S, p.agg, p.SP, st));
+    TRY(launch_aggregate(gate, iter_adjacency(a, p), src_full, p.SP, p.SP <= 128 ? p.SP : p.S, p.agg, p.SP, st));
     const float *src = src_full + (size_t)row_base * p.SP;     // own rows
     float *dst = dst_full + (size_t)row_base * p.SP;
     for (int t = 0; t < p.T; ++t) {
@@ -499,7 +505,7 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, boo
     FoldList fl;
     for (int t = 0; t < p.T; ++t) fl.add(a.net_state[t], p.tp[t].Wf, p.tp[t].bf);
     fl.add(a.net_output, p.Wf_out, p.bf_out);
-    if (zero_loop_words) { fl.fa.zero_a = p.flags; fl.fa.n_a = a.max_iteration + 8; fl.fa.zero_b = a.k_out; fl.fa.n_b = 1; }
+    if (zero_loop_words) { fl.fa.zero_a = p.flags; fl.fa.n_a = a.max_iteration + GNN_LOOP_WORDS; fl.fa.zero_b = a.k_out; fl.fa.n_b = 1; }
     TRY(launch_fold_list(fl, st));
     // ArcNode scatter-add (GNN.py:254) and neighbour-label aggregates (GNN.py:258 / CompositeGNN.py:251)
     if (p.A > 0) TRY(launch_aggregate(nullptr, a.arcnode, a.arc_labels, a.ld_arcs, p.A, p.agg_arcs, p.A, st));
@@ -528,6 +534,19 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, boo
         d.Y = p.C; d.ldy = p.ldC; d.out_rowidx = tp.rows;
         TRY(launch_segdense(d, st));
     }
+    return 0;
+}
+
+// a bounded in-launch wait of a fused kernel expired somewhere in the loop: k < 0 tells the caller (same convention as the
+// persistent whole-loop kernel, kernel_state_small.hpp)
+__global__ void k_fold_error(const int *err, float *k_out) {
+    if (*err != 0) *k_out = -1.0e9f;
+}
+
+int launch_fold_error(const Plan &p, float *k_out, hipStream_t st) {
+    if (!k_out || !p.err) return 0;
+    k_fold_error<<<1, 1, 0, st>>>(p.err, k_out);
+    LAUNCH_OK();
     return 0;
 }
 
@@ -569,7 +588,6 @@ int output_stage(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
 // GNN_FUSED_WAVES: one shape knob per kernel generation (unset = that generation's default); read once, a tuning knob,
 // never a correctness switch.
 //   generation 2: waves per workgroup, 8 (default: 512 threads, 16 waves per CU) or 4 (256 threads, 256-VGPR budget)
-//   generation 3: 12 (default: one 768-thread workgroup per CU) or 8
 //   generation 4: rows in flight per lane group of a gather wave, 4 (default) or 8
 int fused_waves() {
     static int v = -1;
@@ -585,16 +603,16 @@ int fused_waves() {
 //   2  phase-alternating (every wave gathers, then every wave multiplies; 16 waves per CU)      <- d <= 16 or small graphs
 //      (measured crossover on ER graphs with 10 arcs / node, d = 64: 17.2 vs 16.4 us at 2e3 nodes, 28.3 vs 28.5 at 3e4,
 //       60 vs 74 at 1e5, 480 vs 542 at 1e6)
-//   3  software-pipelined variant of 2 (gather of tile t+1 under the MFMA of tile t); kept for comparison
-// A tuning knob, never a correctness switch: all three are held to the same parity tests.
+// (a software-pipelined generation 3 lost to both at every size - profiles/r01_gather_sweep.txt - and was removed)
+// A tuning knob, never a correctness switch: both are held to the same parity tests.
 int fused_generation(int SP, int n_nodes, int flags) {
     const int pinned = (flags & GNN_FLAG_FUSED_GEN_MASK) >> 4;
-    if (pinned >= 2 && pinned <= 4) return pinned;
+    if (pinned == 2 || pinned == 4) return pinned;
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("GNN_FUSED_KERNEL");
         v = e ? atoi(e) : 0;
-        if (v < 2 || v > 4) v = 0;
+        if (v != 2 && v != 4) v = 0;
     }
     return v ? v : ((SP > 16 && n_nodes >= 32768) ? 4 : 2);
 }
@@ -636,10 +654,10 @@ gnn::FusedType fused_type(const gnn_loop_args_t &a, const Plan &p, int t) {
 // one fused iteration over every node type (one launch per type)
 int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, int n_gate, int gate_stride,
                     const float *src, float *dst, int row_base, int *flag_next, float *k_out, float k_val,
-                    hipStream_t st) {
+                    hipStream_t st, const gnn_csr_t *adj_override = nullptr, const float *agg_init = nullptr) {
     auto type_of = [&](int t) { return fused_type(a, p, t); };
     TRY(launch_heavy(a, p, n_gate == 1 ? gate : nullptr, src, st));
-    const gnn_csr_t &adj = iter_adjacency(a);
+    const gnn_csr_t &adj = adj_override ? *adj_override : iter_adjacency(a, p);
     gnn::Fused2Args fa;
     memset(&fa, 0, sizeof(fa));
     fa.gate = n_gate ? gate : nullptr; fa.n_gate = n_gate; fa.gate_stride = gate_stride;
@@ -652,13 +670,14 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
     fa.S = p.S; fa.thr = a.state_threshold;
     fa.flag_next = flag_next;
     fa.k_out = k_out; fa.k_val = k_val;
+    fa.err = p.err;
+    fa.agg_init = agg_init;
     if (fa.n_types == 0) {                      // no nodes at all: only the iteration counter moves
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;
     }
-    const int gen = iteration_generation(a, p);
+    const int gen = agg_init ? 4 : iteration_generation(a, p);
     if (gen == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
-    else if (gen == 3) FUSED_OK(gnn::launch_fused3(fa, p.SP, fused_waves() == 8 ? 8 : 12, device_cus(), st));
     else FUSED_OK(gnn::launch_fused2(fa, p.SP, fused_waves() == 0 ? 8 : fused_waves(), device_cus(), st));
     return 0;
 }
@@ -675,7 +694,7 @@ int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first,
     gnn::SmallArgs sa;
     memset(&sa, 0, sizeof(sa));
     gnn::Fused2Args &fa = sa.f;
-    const gnn_csr_t &adj = iter_adjacency(a);
+    const gnn_csr_t &adj = iter_adjacency(a, p);
     fa.rowptr = adj.rowptr; fa.src = adj.src; fa.w = adj.w; fa.row_scale = adj.row_scale;
     fa.state_in = first; fa.row_base = 0;
     fa.C = p.C; fa.ldC = p.ldC;
@@ -702,7 +721,7 @@ int fusable(const gnn_loop_args_t &a, const Plan &p) {
     // the fused kernel addresses state rows and C with 32-bit byte offsets off a scalar base
     if ((size_t)(std::max(a.adjacency.n_src, p.N) + p.n_heavy) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return 0;
     // ... and the CSR arrays through 4 GiB buffer windows
-    if ((size_t)iter_adjacency(a).nnz * 4 >= ((size_t)1 << 32) || ((size_t)p.N + 1) * 4 >= ((size_t)1 << 32)) return 0;
+    if ((size_t)iter_adjacency(a, p).nnz * 4 >= ((size_t)1 << 32) || ((size_t)p.N + 1) * 4 >= ((size_t)1 << 32)) return 0;
     // One Dense layer everywhere, or two with at most SP hidden units (the matrix waves have the time, and LDS holds a
     // second weight matrix in place of two ring slots).
     bool two = false;
@@ -737,6 +756,7 @@ int gnn_f4_profile(unsigned long long *out8, int reset) {
 #endif
 
 const char *gnn_last_error(void) { return g_err; }
+const char *gnn_last_kernel_name(void) { return gnn::last_kernel_name(); }
 int gnn_abi_version(void) { return GNN_ABI_VERSION; }
 size_t gnn_struct_size(int which) {
     switch (which) {
@@ -809,6 +829,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         }
     }
     TRY(output_stage(a, p, st));
+    if (persistent != 0 && fused && a.max_iteration > 0) TRY(launch_fold_error(p, a.k_out, st));
     return 0;
 }
 
@@ -916,7 +937,7 @@ int gnn_shard_setup(const gnn_loop_args_t *args) {
     if (!a.nodes_src) return fail("gnn_shard_setup: nodes_src is NULL (not a shard)");
     if (!a.workspace || a.workspace_bytes < p.bytes) return fail("workspace too small: %zu < %zu bytes", a.workspace_bytes, p.bytes);
     hipStream_t st = (hipStream_t)a.stream;
-    HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (a.max_iteration + 8), st));
+    HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (a.max_iteration + GNN_LOOP_WORDS), st));
     HIP_OK(hipMemsetAsync(a.k_out, 0, sizeof(float), st));
     return setup_constants(a, p, st);
 }
@@ -945,6 +966,54 @@ int gnn_shard_iteration(const gnn_loop_args_t *args, const float *state_in_full,
     return iteration_unfused(a, p, g, state_in_full, state_out_full, row_base, flag_out, a.k_out, (float)(iteration + 1), st);
 }
 
+// ---- overlap of the exchange with own-range work (gnnkeras_amd/distributed.py) ----------------------------
+int gnn_shard_can_split(const gnn_loop_args_t *args) {
+    if (!args) return 0;
+    Plan p;
+    if (make_plan(*args, args->workspace, p, false)) return 0;
+    if (fusable(*args, p) != 1 || p.SP <= 16 || p.n_heavy != 0) return 0;     // one-layer state nets on the wave-specialised kernel
+    const int pinned = (args->flags & GNN_FLAG_FUSED_GEN_MASK) >> 4;
+    return pinned == 0 || pinned == 4;
+}
+
+int gnn_shard_partial(const gnn_loop_args_t *args, const gnn_csr_t *adjacency_own, const float *state_in_full,
+                      float *agg_partial) {
+    if (!args || !adjacency_own) return fail("args / adjacency_own is NULL");
+    const gnn_loop_args_t &a = *args;
+    if (!state_in_full || !agg_partial) return fail("state_in_full / agg_partial is NULL");
+    const int SP = state_ld(state_width(a));
+    TRY(check_csr(*adjacency_own, "adjacency_own", a.n_nodes, adjacency_own->n_src));
+    // the UN-SCALED (or per-arc weighted) sum: the row scale of 'average' / 'normalized' is applied once, by the iteration
+    gnn_csr_t c = *adjacency_own;
+    c.row_scale = nullptr;
+    return launch_aggregate(nullptr, c, state_in_full, SP, SP, agg_partial, SP, (hipStream_t)a.stream);
+}
+
+int gnn_shard_iteration_split(const gnn_loop_args_t *args, const gnn_csr_t *adjacency_halo, const float *agg_partial,
+                              const float *state_in_full, float *state_out_full, int32_t row_base, const int32_t *gate,
+                              int32_t n_gate, int32_t gate_stride, int32_t *flag_out, int32_t iteration) {
+    if (!args || !adjacency_halo || !agg_partial) return fail("args / adjacency_halo / agg_partial is NULL");
+    const gnn_loop_args_t &a = *args;
+    if (!state_in_full || !state_out_full || !flag_out) return fail("state buffers / flag_out are NULL");
+    if (iteration < 0 || iteration >= a.max_iteration) return fail("iteration %d out of [0, max_iteration)", iteration);
+    if (n_gate < 0 || (n_gate > 0 && !gate)) return fail("bad gate list");
+    if (!gnn_shard_can_split(args)) return fail("gnn_shard_iteration_split: this model / shard does not run on the wave-specialised kernel");
+    Plan p;
+    TRY(make_plan(a, a.workspace, p, false));
+    TRY(check_csr(*adjacency_halo, "adjacency_halo", p.N, a.adjacency.n_src));
+    if (row_base < 0 || row_base + p.N > a.adjacency.n_src) return fail("row_base out of the full buffer");
+    hipStream_t st = (hipStream_t)a.stream;
+    const int *g = nullptr;
+    if (n_gate > 0 && !(a.flags & GNN_FLAG_NO_EARLY_EXIT)) {
+        k_or_flags<<<1, 64, 0, st>>>(gate, n_gate, gate_stride, p.flags + iteration);
+        LAUNCH_OK();
+        g = p.flags + iteration;
+    }
+    HIP_OK(hipMemsetAsync(flag_out, 0, sizeof(int32_t), st));
+    return iteration_fused(a, p, g, g ? 1 : 0, 0, state_in_full, state_out_full, row_base, flag_out, a.k_out,
+                           (float)(iteration + 1), st, adjacency_halo, agg_partial);
+}
+
 int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const float *buf1_full, int32_t row_base) {
     if (!args) return fail("args is NULL");
     const gnn_loop_args_t &a = *args;
@@ -959,7 +1028,8 @@ int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const 
             a.state_out, p.S, p.N, p.S);
         LAUNCH_OK();
     }
-    return output_stage(a, p, st);
+    TRY(output_stage(a, p, st));
+    return can_fuse(a, p) ? launch_fold_error(p, a.k_out, st) : 0;
 }
 
 }  // extern "C"

@@ -50,7 +50,15 @@ struct Fused2Args {
     float thr;
     int *flag_next;
     float *k_out; float k_val;
+    int *err;                                      // sticky error word (workspace): a bounded in-launch wait expired
+    const float *agg_init;                         // k_state_fused4<.., INIT = true>: [n_local, SP] partial neighbour sums (un-scaled)
+                                                   // of the arcs this launch does NOT walk (own-range arcs, summed while the
+                                                   // exchange was in flight: distributed.py overlap); nullptr otherwise
 };
+
+// name of the state-transition kernel the calling thread launched last (gnn_last_kernel_name(): bench.py's roofline record)
+inline char *last_kernel_name() { static thread_local char name[96] = ""; return name; }
+#define GNN_SET_KERNEL_NAME(...) snprintf(::gnn::last_kernel_name(), 96, __VA_ARGS__)
 
 template <int SP, int TM, int NW>
 struct Fused2Cfg {
@@ -361,6 +369,7 @@ int launch_fused2_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0) return 0;
+    GNN_SET_KERNEL_NAME("k_state_fused2<%d,%s,%d,%d,%d>", SP, HAS_W ? "true" : "false", TM, NW, DEPTH);
     k_state_fused2<SP, HAS_W, TM, NW, DEPTH><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

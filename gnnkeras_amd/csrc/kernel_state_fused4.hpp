@@ -15,8 +15,9 @@
 //     while it waits for the slot to fill), runs [state | agg] . W1 on v_mfma_f32_16x16x4_f32, applies the activation,
 //     evaluates the convergence predicate for whole rows in registers and stores the new rows.
 // Slots are handed over with two monotonic LDS counters per slot (rows filled / rounds consumed): release on the
-// writer's side, acquire on the reader's, both workgroup scope.  Spin loops sleep and are bounded: a protocol bug
-// shows up as a wrong answer in the parity tests, never as a hung GPU.
+// writer's side, acquire on the reader's, both workgroup scope.  Spin loops sleep and are bounded, and a wait that
+// expires raises the sticky error word `a.err`, which the host entry folds into k (k < 0 = results invalid): a lost
+// hand-off is an error the caller sees, never a silently wrong state and never a hung GPU.
 // Every global load on either side is a raw buffer load whose offset is out of range when predicated off: no branch
 // ever surrounds a memory operation, so hipcc's waits are exact counts (with `cond ? *p : 0` it wrapped each of the
 // matrix waves' 16 C loads in its own exec-mask branch + vmcnt(0): 16 serial round trips per tile, 620 us/iteration
@@ -80,7 +81,7 @@ __device__ __forceinline__ int f4_ld_acquire(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int SP, bool HAS_W, int DEPTH, int NC, bool L2>
+template <int SP, bool HAS_W, int DEPTH, int NC, bool L2, bool INIT = false>
 __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     // The gate word(s), the W1 fill and the gather waves' first CSR row are all fetched before anything is waited for:
     // three dependent round trips at the head of every launch become one.  Nothing is written to global memory before
@@ -89,7 +90,11 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     for (int i = 0; i < a.n_gate; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
     using Cfg = Fused4Cfg<SP, NC, L2>;
     constexpr int NT = Cfg::NT, LPR = Cfg::LPR, IPL = Cfg::IPL, LDX = Cfg::LDX, LDW = Cfg::LDW, NS = Cfg::NS;
-    constexpr int SPIN_MAX = 1 << 22;
+#ifndef GNN_F4_SPIN_MAX
+#define GNN_F4_SPIN_MAX (1 << 22)
+#endif
+    constexpr int SPIN_MAX = GNN_F4_SPIN_MAX;      // -DGNN_F4_SPIN_MAX=0: debug build whose every wait expires at once
+    int bad = 0;                                   // wave-uniform (scalar registers): some bounded wait of this wave expired
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *Xs = reinterpret_cast<float *>(smem);                         // [NS][16][LDX] : [state | agg]
     float *Ws = Xs + NS * Cfg::SLOT;                                     // [2SP][LDW]    : W1 rows (state ; agg)
@@ -117,7 +122,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
 
     const __amdgpu_buffer_rsrc_t r_C = buf_rsrc(a.C), r_rows = buf_rsrc(tp.rows), r_state = buf_rsrc(a.state_in),
                                  r_rowptr = buf_rsrc(a.rowptr), r_src = buf_rsrc(a.src), r_w = buf_rsrc(HAS_W ? a.w : nullptr),
-                                 r_scale = buf_rsrc(a.row_scale);
+                                 r_scale = buf_rsrc(a.row_scale), r_init = buf_rsrc(INIT ? a.agg_init : nullptr);
     const bool has_scale = a.row_scale != nullptr;
     char *__restrict__ obase = reinterpret_cast<char *>(a.state_out);
     int any = 0;
@@ -193,6 +198,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
             const float scl = buf_ld_f32(r_scale, j >= 0 ? 4u * (unsigned)j : BUF_OFF);
             const f32x4 own = buf_ld_f32x4(r_state, j >= 0 ? (unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (INIT) acc = buf_ld_f32x4(r_init, j >= 0 ? (unsigned)j * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);   // sum of the arcs walked earlier
             int idsB[IPL]; float wsB[IPL];
             int rem = endA - begA, eb = begA;
             int idc[IPL]; float wsc[IPL];
@@ -245,7 +251,13 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
             if (lane == 0) atomicAdd(&g_f4_prof[0], f4_now() - tg_);
             tg_ = f4_now();
 #endif
-            for (int spin = 0; f4_ld_acquire(&freed[s]) < round && spin < SPIN_MAX; ++spin) __builtin_amdgcn_s_sleep(1);
+            {
+                int spin = 0;
+                while (__builtin_amdgcn_readfirstlane(f4_ld_acquire(&freed[s])) < round) {
+                    if (spin >= SPIN_MAX) { bad = 1; break; }
+                    ++spin; __builtin_amdgcn_s_sleep(1);
+                }
+            }
 #ifdef GNN_F4_PROFILE
             if (lane == 0) atomicAdd(&g_f4_prof[1], f4_now() - tg_);
 #endif
@@ -293,7 +305,13 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
 #ifdef GNN_F4_PROFILE
             unsigned long long tc_ = f4_now();
 #endif
-            for (int spin = 0; f4_ld_acquire(&fill[s]) < Cfg::PPT * (round + 1) && spin < SPIN_MAX; ++spin) __builtin_amdgcn_s_sleep(1);
+            {
+                int spin = 0;
+                while (__builtin_amdgcn_readfirstlane(f4_ld_acquire(&fill[s])) < Cfg::PPT * (round + 1)) {
+                    if (spin >= SPIN_MAX) { bad = 1; break; }
+                    ++spin; __builtin_amdgcn_s_sleep(1);
+                }
+            }
 #ifdef GNN_F4_PROFILE
             if (lane == 0) { atomicAdd(&g_f4_prof[2], f4_now() - tc_); atomicAdd(&g_f4_prof[5], 1ull); }
             tc_ = f4_now();
@@ -397,19 +415,20 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
 #endif
     }
 
-    any = __syncthreads_or(any);
+    any = __syncthreads_or(any | (bad << 1));
     if (tid == 0) {
-        if (any && a.flag_next) atomicOr(a.flag_next, 1);
+        if ((any & 1) && a.flag_next) atomicOr(a.flag_next, 1);
+        if ((any & 2) && a.err) atomicOr(a.err, 1);
         if (blockIdx.x == 0 && a.k_out) *a.k_out = a.k_val;
     }
 }
 
-template <int SP, bool HAS_W, int DEPTH, bool L2 = false, int NC = 4>
+template <int SP, bool HAS_W, int DEPTH, bool L2 = false, int NC = 4, bool INIT = false>
 int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     using Cfg = Fused4Cfg<SP, NC, L2>;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH, NC, L2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
         attr = true;
     }
@@ -429,13 +448,18 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0) return 0;
-    k_state_fused4<SP, HAS_W, DEPTH, NC, L2><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
+    GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s%s>", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? ",true" : "");
+    k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 inline int launch_fused4(Fused2Args &fa, int SP, int depth, int n_cu, hipStream_t st) {
 #define F4_CASE(SPV)                                                                                                  \
     case SPV:                                                                                                         \
+        if (fa.agg_init) {                                                                                            \
+            if (fa.tp[0].W2) return 1;                                                                                \
+            return fa.w ? launch_fused4_one<SPV, true, 4, false, 4, true>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4, false, 4, true>(fa, n_cu, st); \
+        }                                                                                                             \
         if (fa.tp[0].W2) return fa.w ? launch_fused4_one<SPV, true, 4, true>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4, true>(fa, n_cu, st); \
         if (fa.w) return launch_fused4_one<SPV, true, 4>(fa, n_cu, st);                                                \
         return depth == 8 ? launch_fused4_one<SPV, false, 8>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4>(fa, n_cu, st);

@@ -327,6 +327,7 @@ int launch_small_one(SmallArgs &sa, int n_cu, hipStream_t st) {
     for (int t = 0; t < fa.n_types; ++t) fa.blk_begin[t + 1] = fa.blk_begin[t] + (fa.tp[t].count + 63) / 64;
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0 || grid > n_cu) return 2;             // not applicable: the caller falls back to one launch per iteration
+    GNN_SET_KERNEL_NAME("k_state_small<%d,%s,%s>", SP, HAS_W ? "true" : "false", L2 ? "true" : "false");
     k_state_small<SP, HAS_W, L2><<<grid, Cfg::NT, SMALL_LDS, st>>>(sa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -17,6 +17,14 @@ its slice of the other one) and ONE in-place `all_gather_into_tensor`. Every ran
 in padded-row order (the one-off halo of the neighbour-label aggregate, GNN.py:258); arcs are stored with their
 destination, so the ArcNode scatter-add (GNN.py:254) is local. No host synchronisation anywhere in the loop.
 
+Overlap (`overlap=True`): a rank's arcs are split by where their source row lives — *own-range* arcs (sources
+the rank itself wrote: final as soon as its own kernel ends) and *halo* arcs (sources received from peers). The exchange
+of iteration i is started asynchronously; while it is in flight the rank sums the own-range arcs of iteration i+1
+(`gnn_shard_partial`); once the collective has landed, the fused kernel walks only the halo arcs, starting every row's sum
+from that partial (`gnn_shard_iteration_split`). Summation order becomes "own-range arcs, then halo arcs" (float32
+re-association of the single-GPU result, inside the 1e-5 bar). No host synchronisation is added: the collective's
+completion is a stream dependency.
+
 `ShardedLoop` exchanges whole slices with one all-gather. `HaloShardedLoop` exchanges *only the rows a peer actually
 reads* (its halo) with one `all_to_all_single` of uneven splits — every pair talks over its own direct xGMI link, and
 block-diagonal batches (MUTAG: shard by graph) exchange nothing but the flag rows. On ER graphs, which have no
@@ -46,6 +54,21 @@ def padded_row(g, chunk):
     return (g // chunk) * (chunk + 1) + g % chunk
 
 
+def split_csr(c: CSRByDestination, own_lo: int, own_hi: int):
+    """(own, halo): the entries of `c` whose source row lies in [own_lo, own_hi) and the others, both as CSRs over the same
+    destinations, entry order inside a row preserved.  `own` carries no row scale (it yields the UN-SCALED partial sum);
+    `halo` keeps `c.row_scale`, which the iteration applies once to partial + halo sum."""
+    own = (c.src >= own_lo) & (c.src < own_hi)
+    row_of = np.repeat(np.arange(c.n_dst), np.diff(c.rowptr.astype(np.int64)))
+    out = []
+    for sel, scale in ((own, None), (~own, c.row_scale)):
+        rowptr = np.zeros(c.n_dst + 1, dtype=np.int64)
+        np.cumsum(np.bincount(row_of[sel], minlength=c.n_dst), out=rowptr[1:])
+        out.append(CSRByDestination(rowptr.astype(np.int32), np.ascontiguousarray(c.src[sel]),
+                                    None if c.w is None else np.ascontiguousarray(c.w[sel]), scale, c.n_src, c.n_dst))
+    return out[0], out[1]
+
+
 class ShardPlan:
     """Host-side (numpy) description of one rank's shard: local CSR operators in padded-row space."""
 
@@ -67,6 +90,7 @@ class ShardPlan:
         dst_local = dst[mine] - self.lo
         # COO (rows = sources, cols = local destinations) -> by-destination CSR, ascending source inside a row
         self.adjacency = CSRByDestination.from_coo(src_rows, dst_local, values, (self.n_rows_full, self.n_local))
+        self.own_rows = (self.row_base, self.row_base + self.n_local)     # rows of the exchanged buffer this rank writes itself
         self.arcnode = CSRByDestination.from_coo(np.arange(self.e_local), dst_local, values,
                                                  (self.e_local, self.n_local))
         self.arc_labels = np.ascontiguousarray(graph.arcs[mine][:, 2:])
@@ -110,7 +134,7 @@ class ShardedLoop:
 
     `state_local` / `out_local` cover the rank's own nodes [lo, hi) (masked ones for `out`)."""
 
-    def __init__(self, model, graph: GraphObject, rank: int, world_size: int, device, group=None):
+    def __init__(self, model, graph: GraphObject, rank: int, world_size: int, device, group=None, overlap: bool = False):
         if model._focus != 'n':
             raise NotImplementedError('sharding is built for node-focused models (BASELINE configs C4 / C5)')
         self.composite = isinstance(model.net_state, (list, tuple))
@@ -119,6 +143,7 @@ class ShardedLoop:
         self.model, self.group = model, group
         self.rank, self.world_size = rank, world_size
         self.device = torch.device(device)
+        self.overlap = bool(overlap)
         self.plan = p = ShardPlan(graph, rank, world_size)
         self.n_local, self.e_local, self.per_arc_weights = p.n_local, p.e_local, p.per_arc_weights
         self.S = model.state_vect_dim if model.state_vect_dim > 0 else graph.nodes.shape[1]
@@ -182,6 +207,16 @@ class ShardedLoop:
         aligned = (self._ws.data_ptr() + 255) & ~255
         a.workspace, a.workspace_bytes = C.c_void_p(aligned), nbytes
         self.args = a
+        # own-range / halo split of the adjacency (overlap of the exchange with own-range work); only where the library runs
+        # this shard on the kernel that can start a row's sum from a partial (else: plain iterations, no overlap)
+        if self.overlap and nat.lib().gnn_shard_can_split(C.byref(a)):
+            own, halo = split_csr(p.adjacency, *p.own_rows)
+            self.d_adj_own, self.d_adj_halo = csr(own), csr(halo)
+            self.c_adj_own, self.c_adj_halo = nat.make_csr(self.d_adj_own), nat.make_csr(self.d_adj_halo)
+            self.agg_partial = torch.zeros((max(p.n_local, 1), self.SP), dtype=torch.float32, device=dev)
+            self.e_own = own.nnz
+        else:
+            self.overlap = False
 
     def _setup(self):
         a = self.args
@@ -210,6 +245,29 @@ class ShardedLoop:
                                                 C.c_void_p(gate), self.world_size, p.rows_per_slice * self.SP,
                                                 C.c_void_p(flag_out), it))
 
+    def _gate_args(self, it):
+        """(gate pointer, n_gate, stride in floats) of iteration `it`: the flag words of every slice of the buffer it reads."""
+        p = self.plan
+        return C.c_void_p(self.buf[it & 1].data_ptr() + 4 * p.chunk * self.SP), self.world_size, p.rows_per_slice * self.SP
+
+    def _flag_out(self, it):
+        p = self.plan
+        return C.c_void_p(self.buf[(it + 1) & 1].data_ptr() + 4 * (p.row_base + p.chunk) * self.SP)
+
+    def _partial(self, it: int):
+        """Phase A of iteration `it`: un-scaled sums of the own-range arcs (reads only rows this rank wrote itself)."""
+        self.args.stream = nat.current_stream(self.device)
+        nat.check(nat.lib().gnn_shard_partial(C.byref(self.args), C.byref(self.c_adj_own), nat.ptr(self.buf[it & 1]),
+                                              nat.ptr(self.agg_partial)))
+
+    def _iteration_split(self, it: int):
+        """Phase B of iteration `it`: halo arcs on top of the partial sums, dense layer, predicate (after the exchange landed)."""
+        gate, n_gate, stride = self._gate_args(it)
+        self.args.stream = nat.current_stream(self.device)
+        nat.check(nat.lib().gnn_shard_iteration_split(C.byref(self.args), C.byref(self.c_adj_halo), nat.ptr(self.agg_partial),
+                                                      nat.ptr(self.buf[it & 1]), nat.ptr(self.buf[(it + 1) & 1]),
+                                                      self.plan.row_base, gate, n_gate, stride, self._flag_out(it), it))
+
     def _output(self):
         nat.check(nat.lib().gnn_shard_output(C.byref(self.args), nat.ptr(self.buf[0]), nat.ptr(self.buf[1]),
                                              self.plan.row_base))
@@ -226,16 +284,24 @@ class ShardedLoop:
         else:
             self.buf[0].copy_(torch.from_numpy(p.pad_state(np.asarray(state0_full, dtype=np.float32), self.SP)))
 
-    def _exchange(self, buf: torch.Tensor):
-        """In-place all-gather of the slices of `buf` (states + flag rows): the one exchange step per iteration."""
+    def _exchange(self, buf: torch.Tensor, it: int = 0, async_op: bool = False):
+        """In-place all-gather of the slices of `buf` (states + flag rows): the one exchange step per iteration.
+        `async_op`: returns the collective's work handle; `_exchange_finish` makes the current stream wait for it."""
         if self.world_size == 1:
-            return
+            return None
         p = self.plan
         flat = buf.view(-1)
         n = p.rows_per_slice * self.SP
-        dist.all_gather_into_tensor(flat, flat[self.rank * n:(self.rank + 1) * n], group=self.group)
+        return dist.all_gather_into_tensor(flat, flat[self.rank * n:(self.rank + 1) * n], group=self.group, async_op=async_op)
 
-    def forward(self, state0_full=None):
+    def _exchange_finish(self, work, buf: torch.Tensor, it: int = 0):
+        if work is not None: work.wait()                      # a stream dependency on the collective, not a host wait (RCCL)
+
+    def exchange_bytes(self) -> int:
+        """Bytes this rank RECEIVES per iteration."""
+        return (self.world_size - 1) * self.plan.rows_per_slice * self.SP * 4
+
+    def _prepare(self, state0_full):
         m = self.model
         if m.state_vect_dim > 0:
             if state0_full is None: raise ValueError('state0 (all nodes) is required when state_vect_dim > 0')
@@ -244,12 +310,22 @@ class ShardedLoop:
             self._load_state0(self.plan_nodes_as_state())
         self._setup()
         self._initial_flags()
-        ev = self._iter_events
+
+    def forward(self, state0_full=None):
+        m = self.model
+        self._prepare(state0_full)
+        if not self.overlap:
+            for it in range(m.max_iteration):
+                self._iteration(it)
+                self._exchange(self.buf[(it + 1) & 1], it)
+            return self._output()
+        # own-range arcs of iteration it+1 are summed while the exchange of iteration it is in flight
+        if m.max_iteration > 0: self._partial(0)                        # state_0 is complete on every rank
         for it in range(m.max_iteration):
-            if ev is not None: ev[it][0].record()
-            self._iteration(it)
-            if ev is not None: ev[it][1].record()
-            self._exchange(self.buf[(it + 1) & 1])
+            self._iteration_split(it)
+            work = self._exchange(self.buf[(it + 1) & 1], it, async_op=True)
+            if it + 1 < m.max_iteration: self._partial(it + 1)          # reads only the rows this rank has just written
+            self._exchange_finish(work, self.buf[(it + 1) & 1], it)
         return self._output()
 
     def plan_nodes_as_state(self):
@@ -261,17 +337,51 @@ class ShardedLoop:
         full = p.nodes_full.reshape(self.world_size, p.rows_per_slice, -1)[:, :p.chunk].reshape(-1, p.nodes_full.shape[1])
         return full[:p.N]
 
-    def kernel_seconds_per_iteration(self, state0_full=None) -> float:
-        """Average device time of the iteration launches alone (no exchange), measured with HIP events on the launch
-        stream in one extra forward; used for the roofline figure of bench.py at N > 1."""
-        n = self.model.max_iteration
-        self._iter_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-        self.forward(state0_full)
-        torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in self._iter_events]
-        self._iter_events = None
-        k = max(float(self.k), 1.0)
-        return 1e-3 * sum(ms[:int(k)]) / k
+    def profile_iteration(self, state0_full=None, reps: int = 10) -> dict:
+        """Per-iteration device times of this rank, HIP events on the launch stream (collective call: every rank runs it):
+        `kernel_s` = the iteration's launches alone (partial + split kernel, or the one fused kernel), no collective;
+        `exchange_s` = the collective alone; `iteration_s` = one iteration of `forward()` with both in flight.  Gates are
+        forced open for the measurement (the states it leaves behind are meaningless)."""
+        m = self.model
+        self._prepare(state0_full)
+        flags, m.native_flags = m.native_flags, m.native_flags | nat.FLAG_NO_EARLY_EXIT
+        self.args.flags = m.native_flags
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        t = {}
+        try:
+            def timed(fn):
+                torch.cuda.synchronize(self.device)
+                if self.world_size > 1: dist.barrier(group=self.group)
+                a, b = ev(), ev()
+                a.record()
+                for _ in range(reps): fn()
+                b.record()
+                torch.cuda.synchronize(self.device)
+                return 1e-3 * a.elapsed_time(b) / reps
+
+            def kernels():
+                if self.overlap: self._partial(0); self._iteration_split(0)
+                else: self._iteration(0)
+
+            def exchange():
+                self._exchange_finish(self._exchange(self.buf[1], 0, async_op=True), self.buf[1], 0)
+
+            def both():
+                if self.overlap:
+                    self._iteration_split(0)
+                    w = self._exchange(self.buf[1], 0, async_op=True)
+                    self._partial(0)
+                    self._exchange_finish(w, self.buf[1], 0)
+                else:
+                    self._iteration(0); self._exchange(self.buf[1], 0)
+
+            if self.overlap: self._partial(0)
+            kernels(); exchange()                                  # warm-up
+            t['kernel_s'], t['exchange_s'], t['iteration_s'] = timed(kernels), timed(exchange), timed(both)
+        finally:
+            m.native_flags = flags
+            self.args.flags = flags
+        return t
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -333,6 +443,7 @@ class HaloShardPlan(ShardPlan):
         values = graph.ArcNode.data[mine]
         dst_local = dst[mine] - self.lo
         self.adjacency = CSRByDestination.from_coo(view_row, dst_local, values, (self.n_rows_view, self.n_local))
+        self.own_rows = (0, self.n_local)
         self.arcnode = CSRByDestination.from_coo(np.arange(self.e_local), dst_local, values, (self.e_local, self.n_local))
         self.arc_labels = np.ascontiguousarray(graph.arcs[mine][:, 2:])
         self.nodes_local = np.ascontiguousarray(graph.nodes[self.lo:self.hi])
@@ -377,7 +488,7 @@ class HaloShardedLoop(ShardedLoop):
     """`ShardedLoop` with the compacted halo exchange: per iteration one fused kernel, one row-gather that packs what
     each peer reads, one `all_to_all_single` (uneven splits, direct pair-wise transfers)."""
 
-    def __init__(self, model, graph: GraphObject, rank: int, world_size: int, device, group=None):
+    def __init__(self, model, graph: GraphObject, rank: int, world_size: int, device, group=None, overlap: bool = False):
         if model._focus != 'n':
             raise NotImplementedError('sharding is built for node-focused models (BASELINE configs C4 / C5)')
         self.composite = isinstance(model.net_state, (list, tuple))
@@ -386,6 +497,7 @@ class HaloShardedLoop(ShardedLoop):
         self.model, self.group = model, group
         self.rank, self.world_size = rank, world_size
         self.device = torch.device(device)
+        self.overlap = bool(overlap)
         self.plan = p = HaloShardPlan(graph, rank, world_size)
         self._graph_nodes_full = np.ascontiguousarray(graph.nodes, dtype=np.float32)
         self.n_local, self.e_local, self.per_arc_weights = p.n_local, p.e_local, p.per_arc_weights
@@ -436,9 +548,14 @@ class HaloShardedLoop(ShardedLoop):
     def _iteration(self, it: int):
         p = self.plan
         src, dst = self.buf[it & 1], self.buf[(it + 1) & 1]
-        flag_out = dst.data_ptr() + 4 * p.own_flag_row * self.SP
         nat.check(nat.lib().gnn_shard_iteration(C.byref(self.args), nat.ptr(src), nat.ptr(dst), 0, nat.ptr(self.gates[it & 1]),
-                                                self.world_size, 1, C.c_void_p(flag_out), it))
+                                                self.world_size, 1, self._flag_out(it), it))
+
+    def _gate_args(self, it):
+        return nat.ptr(self.gates[it & 1]), self.world_size, 1
+
+    def _flag_out(self, it):
+        return C.c_void_p(self.buf[(it + 1) & 1].data_ptr() + 4 * self.plan.own_flag_row * self.SP)
 
     def _pack(self, buf):
         n = len(self.plan.pack_index)
@@ -446,21 +563,31 @@ class HaloShardedLoop(ShardedLoop):
             nat.check(nat.lib().gnn_gather_rows(nat.ptr(buf), self.SP, nat.ptr(self.d_pack_index), n, self.SP,
                                                 nat.ptr(self.sendbuf), self.SP, nat.current_stream(self.device)))
 
-    def _exchange(self, buf: torch.Tensor, it: int = 0):
-        """Pack the rows every peer reads (+ my flag row), swap them pair-wise, collect the R flag words for the next gate."""
+    def _exchange(self, buf: torch.Tensor, it: int = 0, async_op: bool = False):
+        """Pack the rows every peer reads (+ my flag row), swap them pair-wise, collect the R flag words for the next gate.
+        `async_op`: the swap is only started; `_exchange_finish` waits for it (on the stream) and collects the flags."""
         p = self.plan
+        work = None
         if self.world_size > 1:
             self._pack(buf)
             n_recv = sum(p.recv_rows)
             recv = buf[p.n_local:p.n_local + n_recv].view(-1)
-            dist.all_to_all_single(recv, self.sendbuf[:len(p.pack_index)].view(-1), output_split_sizes=self.out_splits,
-                                   input_split_sizes=self.in_splits, group=self.group)
+            work = dist.all_to_all_single(recv, self.sendbuf[:len(p.pack_index)].view(-1), output_split_sizes=self.out_splits,
+                                          input_split_sizes=self.in_splits, group=self.group, async_op=async_op)
+        if not async_op: self.gates[(it + 1) & 1].copy_(self._flag_words(buf))
+        return work
+
+    def _exchange_finish(self, work, buf: torch.Tensor, it: int = 0):
+        if work is not None: work.wait()
         self.gates[(it + 1) & 1].copy_(self._flag_words(buf))
+
+    def exchange_bytes(self) -> int:
+        return sum(self.plan.recv_rows) * self.SP * 4
 
     def _flag_words(self, buf):
         return buf.view(torch.int32)[self.d_flag_rows, 0]
 
-    def forward(self, state0_full=None):
+    def _prepare(self, state0_full):
         m = self.model
         if m.state_vect_dim > 0:
             if state0_full is None: raise ValueError('state0 (all nodes) is required when state_vect_dim > 0')
@@ -469,13 +596,6 @@ class HaloShardedLoop(ShardedLoop):
             self._load_state0(self._graph_nodes_full)
         self._setup()
         self._initial_flags()
-        ev = self._iter_events
-        for it in range(m.max_iteration):
-            if ev is not None: ev[it][0].record()
-            self._iteration(it)
-            if ev is not None: ev[it][1].record()
-            self._exchange(self.buf[(it + 1) & 1], it)
-        return self._output()
 
 
 def choose_exchange(graph: GraphObject, world_size: int) -> str:
@@ -492,11 +612,12 @@ def choose_exchange(graph: GraphObject, world_size: int) -> str:
     return 'halo' if worst < 0.5 else 'allgather'
 
 
-def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, device, group=None, exchange: str = 'auto'):
+def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, device, group=None, exchange: str = 'auto',
+                      overlap: bool = True):
     """`exchange`: 'allgather' (whole slices, one all-gather), 'halo' (only the rows each peer reads, one all-to-all), or
     'auto' = halo when it moves less than half of what the all-gather would (graphs with locality, block-diagonal
     batches), all-gather otherwise (Erdős–Rényi graphs: every slice is almost entirely somebody's halo)."""
     if exchange not in ('auto', 'allgather', 'halo'): raise ValueError('exchange must be auto, allgather or halo')
     if exchange == 'auto': exchange = choose_exchange(graph, world_size)
     cls = HaloShardedLoop if exchange == 'halo' else ShardedLoop
-    return cls(model, graph, rank, world_size, device, group=group)
+    return cls(model, graph, rank, world_size, device, group=group, overlap=overlap)

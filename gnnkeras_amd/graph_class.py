@@ -190,9 +190,37 @@ class GraphObject:
             if key in data: data[key] = data[key].reshape(-1)
         return cls._from_dict(data, focus, aggregation_mode)
 
+    # datasets: a folder of 'g<idx>.npz' files / of 'g<idx>/' txt folders (reference graph_class.py:276-302, :358-382).
+    # Entries are listed in natural order (g0, g1, g2, ..., g10): the reference iterates os.listdir() as the OS returns it.
+    @staticmethod
+    def _dataset_entries(folder):
+        import re
+        key = lambda name: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', name)]
+        return sorted(os.listdir(folder), key=key)
+
+    @staticmethod
+    def save_dataset(folder, glist, compressed=False, **kwargs) -> None:
+        if folder[-1] != '/': folder += '/'
+        if os.path.exists(folder): shutil.rmtree(folder)
+        os.makedirs(folder)
+        for idx, g in enumerate(glist): type(g).save_graph(f"{folder}g{idx}", g, compressed, **kwargs)
+
+    @staticmethod
+    def save_dataset_txt(folder, glist, **kwargs) -> None:
+        if folder[-1] != '/': folder += '/'
+        if os.path.exists(folder): shutil.rmtree(folder)
+        os.makedirs(folder)
+        for idx, g in enumerate(glist): type(g).save_txt(f"{folder}g{idx}", g, **kwargs)
+
     @classmethod
     def load_dataset(cls, folder, focus, aggregation_mode, **kwargs):
-        return [cls.load_txt(f"{folder}/{g}", focus, aggregation_mode, **kwargs) for g in sorted(os.listdir(folder))]
+        """Folder of npz graph files, as written by `save_dataset`."""
+        return [cls.load(os.path.join(folder, g), focus, aggregation_mode, **kwargs) for g in cls._dataset_entries(folder)]
+
+    @classmethod
+    def load_dataset_txt(cls, folder, focus, aggregation_mode, **kwargs):
+        """Folder of graph folders of txt files, as written by `save_dataset_txt`."""
+        return [cls.load_txt(os.path.join(folder, g), focus, aggregation_mode, **kwargs) for g in cls._dataset_entries(folder)]
 
     # ------------------------------------------------------------------------------------------------------------------
     @staticmethod

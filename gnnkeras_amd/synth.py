@@ -64,3 +64,62 @@ def er_composite_graph(n_nodes: int, n_arcs: int, dim_node_label=(14, 8, 4), dim
     targets[np.arange(n_t), rng.integers(0, dim_target, n_t)] = 1
     return CompositeGraphObject(nodes=nodes, arcs=arcs, targets=targets, type_mask=type_mask,
                                 dim_node_label=dim_node_label, focus=focus, aggregation_mode=aggregation_mode)
+
+
+def er_device_batch(n_nodes: int, n_arcs: int, device, dim_node_label: int = 14, dim_arc_label: int = 3,
+                    aggregation_mode: str = 'average', seed: int = 1234):
+    """The 8-element `x` list of `MultiGraphSequencer.__getitem__` for ONE directed G(n, M) graph, assembled on the
+    device with torch (sort / unique on the GPU) instead of through `GraphObject` on the host: the C4-times-4 point of
+    bench.py (4 M nodes / 40 M arcs) would otherwise spend minutes in numpy before the first kernel.  Same conventions as
+    the host path: arcs unique, no self-loops, sorted by (src, dst) (`graph_class.py:47`); Adjacency / ArcNode entries of a
+    destination in ascending source order; 'sum' or 'average' weights as one scale per destination row.
+    The sparse operands are `SparseMatrix` objects that carry only their device CSR (what the kernels walk)."""
+    import torch
+    from .sparse import SparseMatrix
+    if aggregation_mode not in ('sum', 'average'): raise ValueError("er_device_batch builds 'sum' or 'average' operators")
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    keys = torch.zeros(0, dtype=torch.int64, device=dev)
+    while keys.numel() < n_arcs:
+        need = n_arcs - keys.numel()
+        m = int(need * 1.1) + 16
+        src = torch.randint(0, n_nodes, (m,), generator=gen, device=dev)
+        dst = torch.randint(0, n_nodes, (m,), generator=gen, device=dev)
+        ok = src != dst
+        keys = torch.unique(torch.cat([keys, src[ok] * n_nodes + dst[ok]]))          # sorted by (src, dst)
+        if keys.numel() > n_arcs:
+            keep = torch.randperm(keys.numel(), generator=gen, device=dev)[:n_arcs]
+            keys = keys[torch.sort(keep).values]
+    src, dst = keys // n_nodes, keys % n_nodes
+    del keys
+    order = torch.sort(dst, stable=True).indices                                    # arcs grouped by destination, ascending source inside
+    counts = torch.bincount(dst, minlength=n_nodes)
+    rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    rowptr = rowptr.to(torch.int32)
+    adj_src = src[order].to(torch.int32)
+    arc_src = order.to(torch.int32)                                                 # ArcNode: rows are arc ids
+    row_scale = None
+    if aggregation_mode == 'average':
+        row_scale = torch.where(counts > 0, 1.0 / counts.clamp(min=1).to(torch.float32), torch.ones((), device=dev))
+    max_degree = int(counts.max())
+
+    def operand(src_ids, n_src):
+        m = SparseMatrix.__new__(SparseMatrix)
+        m.indices = m.values = None                                                 # device-only operand: no host COO
+        m.dense_shape = (int(n_src), int(n_nodes))
+        m._csr = None
+        m._dev = {(str(dev), True): dict(rowptr=rowptr, src=src_ids, w=None, row_scale=row_scale, n_src=int(n_src),
+                                         n_dst=int(n_nodes), nnz=int(n_arcs), max_degree=max_degree, light=None, heavy=None)}
+        return m
+
+    if max_degree > 512: raise ValueError('er_device_batch does not split hub rows; use the GraphObject path')
+    nodes = torch.zeros((n_nodes, dim_node_label), dtype=torch.float32, device=dev)
+    nodes[torch.arange(n_nodes, device=dev), torch.randint(0, dim_node_label, (n_nodes,), generator=gen, device=dev)] = 1
+    arcs = torch.zeros((n_arcs, 2 + dim_arc_label), dtype=torch.float32, device=dev)
+    arcs[:, 0], arcs[:, 1] = src.to(torch.float32), dst.to(torch.float32)            # float ids like the reference (Q4); never read as ids here
+    arcs[torch.arange(n_arcs, device=dev), 2 + torch.randint(0, dim_arc_label, (n_arcs,), generator=gen, device=dev)] = 1
+    ones = torch.ones(n_nodes, dtype=torch.bool, device=dev)
+    nodegraph = SparseMatrix(np.zeros((0, 2), np.int64), np.zeros(0, np.float32), (n_nodes, 1))
+    return [nodes, arcs, torch.tensor([[dim_node_label]], dtype=torch.int32), ones, ones.clone(),
+            operand(adj_src, n_nodes), operand(arc_src, n_arcs), nodegraph]

@@ -39,10 +39,10 @@ enum gnn_flags {
     GNN_FLAG_UNFUSED = 1,      /* run the iteration as separate aggregate / dense / predicate kernels            */
     GNN_FLAG_NO_EARLY_EXIT = 2,/* debugging: ignore the convergence predicate (always max_iteration iterations)  */
     /* testing / tuning: pin the generation of the fused iteration kernel instead of the size-based choice
-     * (2 = phase-alternating, 3 = software-pipelined, 4 = wave-specialised, 5 = whole loop in one persistent launch,
+     * (2 = phase-alternating, 4 = wave-specialised, 5 = whole loop in one persistent launch,
      * small graphs only - falls back to the size-based choice when it does not apply).  Results are the same within float32
      * summation order; the GNN_FUSED_KERNEL environment variable has the same effect process-wide. */
-    GNN_FLAG_FUSED_GEN2 = 2 << 4, GNN_FLAG_FUSED_GEN3 = 3 << 4, GNN_FLAG_FUSED_GEN4 = 4 << 4,
+    GNN_FLAG_FUSED_GEN2 = 2 << 4, GNN_FLAG_FUSED_GEN4 = 4 << 4,
     GNN_FLAG_FUSED_GEN5 = 5 << 4, GNN_FLAG_FUSED_GEN_MASK = 7 << 4
 };
 
@@ -116,9 +116,10 @@ typedef struct gnn_loop_args {
     const int32_t *arc_dst;   /* [n_arcs] arc focus: adjacency.indices[:,1]                                     */
     gnn_csr_t nodegraph;      /* graph focus: n_src = n_out, n_dst = #graphs                                    */
     /* results -------------------------------------------------------------------------------------------------- */
-    float *k_out;             /* [1] iterations executed, float like the reference; NEGATIVE when the
-                                 persistent whole-loop launch could not get all its workgroups resident (its grid
-                                 barrier timed out, e.g. too many such loops overlapped on other streams): results
+    float *k_out;             /* [1] iterations executed, float like the reference; NEGATIVE when a bounded
+                                 in-launch wait expired: the persistent whole-loop launch could not get all its
+                                 workgroups resident (grid barrier timed out, e.g. too many such loops overlapped on
+                                 other streams), or a slot hand-off of the wave-specialised kernel was lost: results
                                  are then invalid - rerun with GNN_FLAG_FUSED_GEN2                                 */
     float *state_out;         /* [n_nodes, S] S = state_dim, or dim of the state when state_dim == 0            */
     float *out;               /* [n_out, T] (node / arc focus) or [#graphs, T] (graph focus)                    */
@@ -149,6 +150,9 @@ typedef struct gnn_loop_args {
 } gnn_loop_args_t;
 
 const char *gnn_last_error(void);
+/* Name (with template arguments) of the state-transition kernel this thread launched last, e.g.
+ * "k_state_fused4<64,false,4,4,false>" - what a rocprofv3 kernel trace of the same call shows; "" before any launch. */
+const char *gnn_last_kernel_name(void);
 int gnn_abi_version(void);
 /* sizeof() of the ABI structs as this library was compiled (0 gnn_csr_t, 1 gnn_mlp_t, 2 gnn_loop_args_t; 3 = offsetof
  * (gnn_loop_args_t, flags)): lets a foreign-language binding verify its struct layout at load time. */
@@ -201,6 +205,21 @@ int gnn_shard_iteration(const gnn_loop_args_t *args, const float *state_in_full,
 /* picks the buffer holding the state after k iterations (k read on the device from args->k_out), copies the own rows
  * to args->state_out [n_nodes, S] and runs the output network on them into args->out. */
 int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const float *buf1_full, int32_t row_base);
+/* Overlap of the exchange with own-range work.  The shard's adjacency is split by where a source row lives:
+ * `adjacency_own` (sources in this rank's own range: final as soon as the rank's own kernel has written them) and
+ * `adjacency_halo` (sources received from peers); both are CSRs over the same n_nodes destinations and index rows of the
+ * full state buffer.  While the exchange of iteration i is in flight the caller runs gnn_shard_partial (un-scaled /
+ * per-arc-weighted partial sums of the own-range arcs into agg_partial [n_nodes, gnn_state_ld(S)]); once it has landed,
+ * gnn_shard_iteration_split walks only the halo arcs, starting every row's sum from agg_partial (summation order: own-range
+ * arcs, then halo arcs - within float32 re-association of the single-GPU result).  gnn_shard_can_split tells whether this
+ * model / shard runs on the kernel that supports it (one-layer state networks, state width 17..64, no hub rows); when it
+ * returns 0 use gnn_shard_iteration. */
+int gnn_shard_can_split(const gnn_loop_args_t *args);
+int gnn_shard_partial(const gnn_loop_args_t *args, const gnn_csr_t *adjacency_own, const float *state_in_full,
+                      float *agg_partial);
+int gnn_shard_iteration_split(const gnn_loop_args_t *args, const gnn_csr_t *adjacency_halo, const float *agg_partial,
+                              const float *state_in_full, float *state_out_full, int32_t row_base, const int32_t *gate,
+                              int32_t n_gate, int32_t gate_stride, int32_t *flag_out, int32_t iteration);
 
 /* ---- training building blocks (reference train_step, GNN.py:277-306: tape.gradient through the unrolled loop) ------
  * The backward pass is orchestrated by the host (gnnkeras_amd/Models/training.py) one iteration at a time out of these

@@ -31,6 +31,16 @@ class Net:
             pos = 4
         self.W = [w[pos + 2 * i].requires_grad_() for i in range(len(self.acts))]
         self.b = [w[pos + 2 * i + 1].requires_grad_() for i in range(len(self.acts))]
+        self.kreg = spec.get('kernel_regularizer') or [None] * len(self.acts)
+        self.breg = spec.get('bias_regularizer') or [None] * len(self.acts)
+
+    def penalty(self):
+        """Keras `layer.losses` of the Dense layers: l1 * sum|w| + l2 * sum(w^2), each variable once (MLP.py:48-49)."""
+        tot = 0.0
+        for regs, ws in ((self.kreg, self.W), (self.breg, self.b)):
+            for r, w in zip(regs, ws):
+                if r is not None: tot = tot + r[0] * w.abs().sum() + r[1] * (w * w).sum()
+        return tot
 
     def trainable(self):
         v = [self.gamma, self.beta] if self.bn else []
@@ -115,7 +125,7 @@ def train_step(nodes, arcs, adjacency, arcnode, nodegraph, mask, *, net_state, n
         out = torch.sparse.mm(_sp(nodegraph, dtype), out)
     yt = torch.tensor(np.asarray(y), dtype=dtype)
     sw = torch.ones(yt.shape[0], dtype=dtype) if sample_weight is None else torch.tensor(np.asarray(sample_weight), dtype=dtype)
-    L = keras_loss(loss, yt, out, sw)
+    L = keras_loss(loss, yt, out, sw) + ns.penalty() + no.penalty()        # regularization_losses=self.losses (GNN.py:286)
     params = ns.trainable() + no.trainable()
     grads = torch.autograd.grad(L, params, allow_unused=True)
     grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, params)]

@@ -17,7 +17,12 @@ they pin rows a13-a16 and a18 of SURVEY.md §8 (graph operands), not the Loop.
 The reference's `load_MUTAG.py` cannot run at HEAD: its text is read from /root/reference at run time,
 the multi-character delimiter is patched to ',' and the broken composite tail is cut; the rest executes unmodified.
 
-Outputs (committed): tests/golden/graph_fixtures.npz
+On-disk formats: the reference's own `GraphObject.save` / `savetxt` / `save_dataset` /
+`save_dataset_txt` and `CompositeGraphObject.save` (graph_class.py:200-290, composite_graph_class.py:133-138) WRITE a few
+small graphs into tests/golden/ref_files/; the tests read those files back with this repository's loaders. The files are
+data written by the reference's code, not its source. (`GraphTensor.save_graph` needs TensorFlow ops and cannot run here.)
+
+Outputs (committed): tests/golden/graph_fixtures.npz, tests/golden/ref_files/
 """
 import os
 import sys
@@ -172,6 +177,31 @@ def main():
         p = f'trans_{int(rate * 10)}_'
         out[p + 'nodes'], out[p + 'targets'], out[p + 'type_mask'] = cg.nodes, cg.targets, cg.type_mask
         out[p + 'output_mask'], out[p + 'set_mask'] = cg.output_mask, cg.set_mask
+
+    # ---- files written by the reference's own savers ----------------------------------------------------------------------
+    import shutil
+    rf = os.path.join(HERE, 'ref_files')
+    if os.path.exists(rf): shutil.rmtree(rf)
+    os.makedirs(rf)
+    graphs[0].save(os.path.join(rf, 'mutag0'))                                   # plain graph: nodes / arcs / targets only
+    graphs[1].save_compressed(os.path.join(rf, 'mutag1_compressed'))
+    toy = GraphObject(nodes=nodes, arcs=arcs, targets=targets[:4], focus='n', set_mask=set_mask, output_mask=output_mask,
+                      sample_weight=2.5, aggregation_mode='average')
+    toy.save(os.path.join(rf, 'toy_masks'))                                     # + set_mask / output_mask / sample_weight keys
+    toy.savetxt(os.path.join(rf, 'toy_masks_txt'))
+    m4 = GraphObject.merge([g.copy() for g in graphs[:4]], focus='g', aggregation_mode='average')
+    m4.save(os.path.join(rf, 'merge4'))                                         # + NodeGraph as [value, row, col]
+    m4.savetxt(os.path.join(rf, 'merge4_txt'))
+    GraphObject.save_dataset(os.path.join(rf, 'dataset_npz'), graphs[2:5])
+    GraphObject.save_dataset_txt(os.path.join(rf, 'dataset_txt'), graphs[5:7])
+    cg0 = CompositeGraphObject(nodes=toys[0][0], arcs=toys[0][1], targets=toys[0][2], type_mask=toys[0][3],
+                               dim_node_label=dim_node_label, focus='n', aggregation_mode='composite_average')
+    cg0.save(os.path.join(rf, 'ctoy0'))                                         # + type_mask / dim_node_label keys
+    cg0.savetxt(os.path.join(rf, 'ctoy0_txt'))
+    out['ref_files_merge4_NodeGraph'] = _coo(m4.NodeGraph)
+    out['ref_files_merge4_shape'] = np.array(m4.NodeGraph.shape)
+    for name, g in (('mutag0', graphs[0]), ('mutag1', graphs[1]), ('merge4', m4), ('ds2', graphs[2]), ('ds5', graphs[5])):
+        out[f'ref_files_{name}_arcs'], out[f'ref_files_{name}_nodes'], out[f'ref_files_{name}_targets'] = g.arcs, g.nodes, g.targets
 
     path = os.path.join(HERE, 'graph_fixtures.npz')
     np.savez_compressed(path, **out)

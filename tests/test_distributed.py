@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from gnnkeras_amd import GraphObject
-from gnnkeras_amd.distributed import ShardedLoop, ShardPlan, HaloShardedLoop, HaloShardPlan, partition, padded_row, choose_exchange
+from gnnkeras_amd.distributed import ShardedLoop, ShardPlan, HaloShardedLoop, HaloShardPlan, partition, padded_row, choose_exchange, split_csr
 from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
 from gnnkeras_amd.Models.GNN import GNNnodeBased
 from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
@@ -78,6 +78,56 @@ class OracleShardedLoop(ShardedLoop):
         dst.view(torch.int32)[p.row_base + p.chunk, 0] = int(O.condition(0, new, own, 1, m.state_threshold, self.dtype))
         self.k.fill_(it + 1)
 
+    # overlap path: phase A (own-range arcs, un-scaled) / phase B (halo arcs on top, row scale, dense, predicate)
+    def _own_rows_of(self, buf):
+        p = self.plan
+        return buf.numpy()[p.own_rows[0]:p.own_rows[0] + p.n_local, :self.S].astype(self.dtype)
+
+    def _partial(self, it):
+        p = self.plan
+        if not hasattr(self, 'adj_own'):
+            own, halo = split_csr(p.adjacency, *p.own_rows)
+            assert own.nnz + halo.nnz == p.adjacency.nnz and own.row_scale is None
+            self.adj_own, self.adj_halo = csr_to_coo(own), csr_to_coo(halo)      # halo carries the row scale, own does not
+            self.scale = np.ones(p.n_local) if p.adjacency.row_scale is None else p.adjacency.row_scale.astype(self.dtype)
+        full = self.buf[it & 1].numpy()[:, :self.S].astype(self.dtype)
+        # only rows this rank wrote itself may be read here: poison everything else to prove it
+        lo = p.own_rows[0]
+        poisoned = np.full_like(full, np.nan); poisoned[lo:lo + p.n_local] = full[lo:lo + p.n_local]
+        part = np.zeros((p.n_local, self.S), self.dtype)
+        idx, w, _ = self.adj_own
+        np.add.at(part, idx[:, 1], w[:, None] * poisoned[idx[:, 0]])
+        assert np.all(np.isfinite(part))
+        self.partial = part
+
+    def _iteration_split(self, it):
+        p, m = self.plan, self.model
+        src, dst = self.buf[it & 1], self.buf[(it + 1) & 1]
+        gate_open = self._gate_open(it)
+        self._clear_flag(dst)
+        if not gate_open: return
+        full = src.numpy()[:, :self.S].astype(self.dtype)
+        own = self._own_rows_of(src)
+        agg = self.partial * self.scale[:, None] + O.sparse_dense_matmul_adjoint(*self.adj_halo, full, self.dtype)
+        comps = [own, p.nodes_local, agg, self.agg_nodes, self.agg_arcs] if m.state_vect_dim > 0 else [own, agg, self.agg_arcs]
+        new = O.mlp_apply(*m.net_state.spec(), np.concatenate(comps, axis=1), False, self.dtype)
+        lo = p.own_rows[0]
+        dst[lo:lo + p.n_local, :self.S] = torch.from_numpy(new.astype(np.float32))
+        self._set_flag(dst, int(O.condition(0, new, own, 1, m.state_threshold, self.dtype)))
+        self.k.fill_(it + 1)
+
+    def _gate_open(self, it):
+        p, src = self.plan, self.buf[it & 1]
+        return any(int(src.view(torch.int32)[r * p.rows_per_slice + p.chunk, 0]) for r in range(self.world_size))
+
+    def _clear_flag(self, dst):
+        p = self.plan
+        dst.view(torch.int32)[p.row_base + p.chunk, 0] = 0
+
+    def _set_flag(self, dst, v):
+        p = self.plan
+        dst.view(torch.int32)[p.row_base + p.chunk, 0] = v
+
     def _output(self):
         p, m = self.plan, self.model
         buf = self.buf[int(self.k) & 1].numpy()
@@ -112,6 +162,19 @@ class OracleHaloShardedLoop(HaloShardedLoop):
         dst.view(torch.int32)[p.own_flag_row, 0] = int(O.condition(0, new, own, 1, m.state_threshold, self.dtype))
         self.k.fill_(it + 1)
 
+    _own_rows_of = OracleShardedLoop._own_rows_of
+    _partial = OracleShardedLoop._partial
+    _iteration_split = OracleShardedLoop._iteration_split
+
+    def _gate_open(self, it):
+        return bool(self.gates[it & 1].any())
+
+    def _clear_flag(self, dst):
+        dst.view(torch.int32)[self.plan.own_flag_row, 0] = 0
+
+    def _set_flag(self, dst, v):
+        dst.view(torch.int32)[self.plan.own_flag_row, 0] = v
+
     def _pack(self, buf):
         n = len(self.plan.pack_index)
         if n: self.sendbuf[:n].copy_(buf[self.d_pack_index.long()])
@@ -140,30 +203,32 @@ def _problem(threshold, d=6, max_it=12):
     return g, model, s0
 
 
-def _worker(rank, world, port, threshold, d, out_q, halo=False):
+def _worker(rank, world, port, threshold, d, out_q, halo=False, overlap=False):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         g, model, s0 = _problem(threshold, d)
-        sl = (OracleHaloShardedLoop if halo else OracleShardedLoop)(model, g, rank, world, 'cpu')
+        sl = (OracleHaloShardedLoop if halo else OracleShardedLoop)(model, g, rank, world, 'cpu', overlap=overlap)
+        assert sl.overlap == overlap
         k, state, out = sl.forward(s0)
         out_q.put((rank, float(k), state.numpy(), out.numpy(), sl.plan.lo, sl.plan.hi))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('overlap', [False, True])
 @pytest.mark.parametrize('halo', [False, True])
 @pytest.mark.parametrize('world', [2, 3])
 @pytest.mark.parametrize('threshold,d', [(0.0, 6), (0.02, 6), (0.0, 0)])
-def test_sharded_loop_matches_single_process_oracle(world, threshold, d, halo):
+def test_sharded_loop_matches_single_process_oracle(world, threshold, d, halo, overlap):
     g, model, s0 = _problem(threshold, d)
     seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False, device='cpu')
     k_ref, st_ref, out_ref = oracle_loop(model, seq[0][0], s0, np.float64)
     if threshold > 0: assert 1 < k_ref < model.max_iteration              # early exit really happens
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + world * 7 + int(threshold * 100) + d + 13 * halo) % 1000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, threshold, d, q, halo)) for r in range(world)]
+    port = 29500 + (os.getpid() + world * 7 + int(threshold * 100) + d + 13 * halo + 29 * overlap) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, threshold, d, q, halo, overlap)) for r in range(world)]
     for p in procs: p.start()
     res = sorted([q.get(timeout=180) for _ in procs])
     for p in procs:
@@ -247,3 +312,17 @@ def test_exchange_choice_is_a_property_of_the_graph_not_of_the_rank():
     g2 = GraphObject(rng.normal(size=(n, 3)), np.concatenate([block, np.ones((len(block), 1))], 1), rng.normal(size=(n, 2)),
                      focus='n', aggregation_mode='sum')
     assert choose_exchange(g2, 2) == 'halo'                    # block-diagonal: nothing but flags to exchange
+
+
+def test_split_csr_partitions_every_row_in_order():
+    g = er_graph(300, 2500, dim_node_label=4, dim_arc_label=2, seed=3)
+    for plan in (ShardPlan(g, 1, 4), HaloShardPlan(g, 2, 4)):
+        c = plan.adjacency
+        own, halo = split_csr(c, *plan.own_rows)
+        assert own.nnz + halo.nnz == c.nnz and own.row_scale is None and halo.row_scale is c.row_scale
+        lo, hi = plan.own_rows
+        assert np.all((own.src >= lo) & (own.src < hi)) and not np.any((halo.src >= lo) & (halo.src < hi))
+        for j in range(c.n_dst):
+            row = c.src[c.rowptr[j]:c.rowptr[j + 1]]
+            a, b = own.src[own.rowptr[j]:own.rowptr[j + 1]], halo.src[halo.rowptr[j]:halo.rowptr[j + 1]]
+            assert np.array_equal(a, row[(row >= lo) & (row < hi)]) and np.array_equal(b, row[(row < lo) | (row >= hi)])

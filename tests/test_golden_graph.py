@@ -1,5 +1,6 @@
 """Graph data layer vs golden fixtures produced by RUNNING the reference's numpy/scipy code
 (tests/golden/make_golden.py): rows a13-a16, a18 of SURVEY.md §8. Bit-exact (same float32 values, same entry order)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -181,3 +182,89 @@ def test_transductive_sequencers_layout_and_epoch_resampling():
     assert len(single) >= 1 and len(single[0][0]) == 10
     single.on_epoch_end()
     assert single.copy().transductive_rate == 0.4
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# on-disk formats: files WRITTEN BY THE REFERENCE's own savers (tests/golden/make_golden.py -> tests/golden/ref_files/)
+# are read back by this repository's loaders, and this repository's savers write the same keys / shapes / dtypes / values
+# ----------------------------------------------------------------------------------------------------------------------
+REF_FILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_files')
+
+
+def _same_npz(path_a, path_b):
+    a, b = np.load(path_a), np.load(path_b)
+    assert sorted(a.files) == sorted(b.files), (a.files, b.files)
+    for k in a.files:
+        assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, (k, a[k].shape, b[k].shape, a[k].dtype, b[k].dtype)
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_reference_written_npz_files_load_and_resave_identically(golden, tmp_path):
+    from gnnkeras_amd import GraphObject, CompositeGraphObject
+    for name, key, focus in (('mutag0', 'mutag0', 'g'), ('mutag1_compressed', 'mutag1', 'g'), ('merge4', 'merge4', 'g')):
+        g = GraphObject.load(os.path.join(REF_FILES, name), focus=focus, aggregation_mode='average')
+        assert np.array_equal(g.arcs, golden[f'ref_files_{key}_arcs']) and np.array_equal(g.nodes, golden[f'ref_files_{key}_nodes'])
+        assert np.array_equal(g.targets, golden[f'ref_files_{key}_targets'])
+        (g.save_compressed if 'compressed' in name else g.save)(str(tmp_path / name))
+        _same_npz(os.path.join(REF_FILES, name + '.npz'), str(tmp_path / (name + '.npz')))
+    m4 = GraphObject.load(os.path.join(REF_FILES, 'merge4.npz'), focus='g', aggregation_mode='average')
+    ng = golden['ref_files_merge4_NodeGraph']
+    assert m4.NodeGraph.shape == tuple(golden['ref_files_merge4_shape'])
+    dense = np.zeros(m4.NodeGraph.shape); dense[ng[:, 0].astype(int), ng[:, 1].astype(int)] = ng[:, 2]
+    assert np.array_equal(m4.NodeGraph.toarray(), dense.astype(np.float32))
+    # masks / sample weights: the toy graph of the fixtures (set_mask, output_mask, sample_weight = 2.5)
+    toy = GraphObject.load(os.path.join(REF_FILES, 'toy_masks'), focus='n', aggregation_mode='average')
+    assert np.array_equal(toy.set_mask, golden['toy_set_mask'].astype(bool)) and np.array_equal(toy.output_mask, golden['toy_output_mask'].astype(bool))
+    assert np.array_equal(toy.arcs, golden['toy_average_arcs_out']) and np.all(toy.sample_weight == 2.5)
+    assert np.array_equal(_coo_of(toy.ArcNode), golden['toy_average_ArcNode'])
+    toy.save(str(tmp_path / 'toy_masks'))
+    _same_npz(os.path.join(REF_FILES, 'toy_masks.npz'), str(tmp_path / 'toy_masks.npz'))
+    # composite: + type_mask / dim_node_label keys
+    cg = CompositeGraphObject.load(os.path.join(REF_FILES, 'ctoy0'), focus='n', aggregation_mode='composite_average')
+    assert np.array_equal(cg.type_mask, golden['ctoy0_type_mask']) and list(cg.DIM_NODE_LABEL) == list(golden['ctoy_dim_node_label'])
+    assert np.array_equal(_coo_of(cg.ArcNode), golden['ctoy0_composite_average_ArcNode'])
+    for t, ca in enumerate(cg.CompositeAdjacencies):
+        assert np.array_equal(_coo_of(ca), golden[f'ctoy0_composite_average_CA{t}'])
+    cg.save(str(tmp_path / 'ctoy0'))
+    _same_npz(os.path.join(REF_FILES, 'ctoy0.npz'), str(tmp_path / 'ctoy0.npz'))
+
+
+def _coo_of(m):
+    m = m.tocoo()
+    o = np.lexsort((m.col, m.row))
+    return np.stack([m.row[o].astype(np.float64), m.col[o].astype(np.float64), m.data[o].astype(np.float64)], axis=1)
+
+
+def test_reference_written_txt_folders_and_datasets(golden, tmp_path):
+    from gnnkeras_amd import GraphObject, CompositeGraphObject
+    toy = GraphObject.load_txt(os.path.join(REF_FILES, 'toy_masks_txt'), focus='n', aggregation_mode='average')
+    ref = GraphObject.load(os.path.join(REF_FILES, 'toy_masks'), focus='n', aggregation_mode='average')
+    assert np.allclose(toy.arcs, ref.arcs, rtol=1e-9) and np.allclose(toy.nodes, ref.nodes, rtol=1e-9)      # '%.10g' text
+    assert np.array_equal(toy.set_mask, ref.set_mask) and np.array_equal(toy.output_mask, ref.output_mask)
+    assert np.array_equal(toy.sample_weight, ref.sample_weight)
+    m4 = GraphObject.load_txt(os.path.join(REF_FILES, 'merge4_txt'), focus='g', aggregation_mode='average')
+    assert m4.NodeGraph.shape == tuple(golden['ref_files_merge4_shape']) and np.array_equal(m4.arcs, golden['ref_files_merge4_arcs'])
+    cg = CompositeGraphObject.load_txt(os.path.join(REF_FILES, 'ctoy0_txt'), focus='n', aggregation_mode='composite_average')
+    assert np.array_equal(cg.type_mask, golden['ctoy0_type_mask']) and list(cg.DIM_NODE_LABEL) == list(golden['ctoy_dim_node_label'])
+    # text written by this repository == text written by the reference, file by file
+    for src, g in (('toy_masks_txt', toy), ('merge4_txt', m4), ('ctoy0_txt', cg)):
+        g.savetxt(str(tmp_path / src))
+        for f in sorted(os.listdir(os.path.join(REF_FILES, src))):
+            assert open(os.path.join(REF_FILES, src, f)).read() == open(str(tmp_path / src / f)).read(), (src, f)
+        assert sorted(os.listdir(os.path.join(REF_FILES, src))) == sorted(os.listdir(str(tmp_path / src)))
+    # datasets: folder of npz files / folder of txt folders (reference save_dataset / save_dataset_txt)
+    ds = GraphObject.load_dataset(os.path.join(REF_FILES, 'dataset_npz'), focus='g', aggregation_mode='average')
+    assert len(ds) == 3 and np.array_equal(ds[0].arcs, golden['ref_files_ds2_arcs']) and np.array_equal(ds[0].nodes, golden['ref_files_ds2_nodes'])
+    dt = GraphObject.load_dataset_txt(os.path.join(REF_FILES, 'dataset_txt'), focus='g', aggregation_mode='average')
+    assert len(dt) == 2 and np.array_equal(dt[0].arcs, golden['ref_files_ds5_arcs']) and np.array_equal(dt[0].targets, golden['ref_files_ds5_targets'])
+    GraphObject.save_dataset(str(tmp_path / 'ds'), ds)
+    assert sorted(os.listdir(str(tmp_path / 'ds'))) == ['g0.npz', 'g1.npz', 'g2.npz']
+    for f in ('g0.npz', 'g1.npz', 'g2.npz'):
+        _same_npz(os.path.join(REF_FILES, 'dataset_npz', f), str(tmp_path / 'ds' / f))
+    GraphObject.save_dataset_txt(str(tmp_path / 'dst'), dt)
+    for gdir in ('g0', 'g1'):
+        for f in sorted(os.listdir(os.path.join(REF_FILES, 'dataset_txt', gdir))):
+            assert open(os.path.join(REF_FILES, 'dataset_txt', gdir, f)).read() == open(str(tmp_path / 'dst' / gdir / f)).read()
+    many = [ds[0]] * 12
+    GraphObject.save_dataset(str(tmp_path / 'many'), many)
+    assert len(GraphObject.load_dataset(str(tmp_path / 'many'), 'g', 'average')) == 12        # g10, g11 sort after g9

@@ -17,7 +17,7 @@ import os
 pytestmark = pytest.mark.gpu
 FUZZ_SCALE = int(os.environ.get('GNN_FUZZ_SCALE', '1'))      # GNN_FUZZ_SCALE=10 runs ten times as many seeds (offline soak)
 # every way the iteration can run: size-based default, un-fused kernels, and each fused-kernel generation pinned
-PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN3, nat.FLAG_FUSED_GEN4, nat.FLAG_FUSED_GEN5)
+PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN4, nat.FLAG_FUSED_GEN5)
 ACTS = ['selu', 'tanh', 'relu', 'sigmoid', 'linear', 'elu', 'softplus']
 
 

@@ -21,7 +21,7 @@ from oracle.harness import oracle_loop, oracle_composite_loop, rel_err
 
 pytestmark = pytest.mark.gpu
 # every way the iteration can run: size-based default, un-fused kernels, and each fused-kernel generation pinned
-PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN3, nat.FLAG_FUSED_GEN4, nat.FLAG_FUSED_GEN5)
+PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN4, nat.FLAG_FUSED_GEN5)
 TOL = 1e-5
 CLS = {'n': GNNnodeBased, 'a': GNNarcBased, 'g': GNNgraphBased}
 CCLS = {'n': CompositeGNNnodeBased, 'a': CompositeGNNarcBased, 'g': CompositeGNNgraphBased}
@@ -454,6 +454,106 @@ def test_c4_er_1m_10m_properties():
     assert rel_err(op.cpu().numpy(), o.cpu().numpy()[perm]) <= TOL
 
 
+def test_c4_er_1m_10m_vs_oracle():
+    """Full C4 size against the oracle itself (scipy row order): 2 iterations, every device path."""
+    N, E, d = 1_000_000, 10_000_000, 64
+    g = er_graph(N, E, aggregation_mode='average')
+    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    ns, no = starter_nets('n', d)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
+    model = GNNnodeBased(ns, no, d, 2, 0.0)
+    k32, st32, o32 = oracle_loop(model, x, s0, np.float32, exact_order=False)
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    inputs = model.process_inputs(x)
+    for flags in (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2):
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=dev(s0))
+        assert float(k) == 2.0 == float(k32) == float(k64)
+        st, o = st.cpu().numpy(), o.cpu().numpy()
+        assert rel_err(st, st32) <= TOL and rel_err(st, st64) <= TOL, (flags, rel_err(st, st32), rel_err(st, st64))
+        assert rel_err(o, o32) <= TOL and rel_err(o, o64) <= TOL, (flags, rel_err(o, o32), rel_err(o, o64))
+
+
+@pytest.mark.parametrize('mode', ['average', 'composite_average'])
+def test_c5_composite_500k_5m(mode):
+    """BASELINE C5 at full size: 3 node types, 500 000 nodes / 5 000 000 arcs, d = 64, per-type state networks
+    (reference CompositeGNN.py:215-272).  2 iterations against the oracle (scipy row order) on every device path, then
+    the size-independent properties on 5 iterations: fused == un-fused, bitwise run-to-run determinism, k pinned."""
+    N, E, d, dims = 500_000, 5_000_000, 64, (14, 8, 4)
+    g = er_composite_graph(N, E, dim_node_label=dims, aggregation_mode=mode, seed=1234)
+    x = CompositeMultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    inp, lay = get_inout_dims('state', dims, 3, 2, 'n', d)
+    ns = [MLP(i, lay, 'selu', 'lecun_normal', 'lecun_normal', rng=t) for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', dims, 3, 2, 'n', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
+    model = CompositeGNNnodeBased(ns, no, d, 2, 0.0)
+    k32, st32, o32 = oracle_composite_loop(model, x, s0, np.float32, exact_order=False)
+    k64, st64, o64 = oracle_composite_loop(model, x, s0, np.float64, exact_order=False)
+    inputs = model.process_inputs(x)
+    for flags in (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2):
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=dev(s0))
+        assert float(k) == 2.0 == float(k32) == float(k64)
+        st, o = st.cpu().numpy(), o.cpu().numpy()
+        assert rel_err(st, st32) <= TOL and rel_err(st, st64) <= TOL, (flags, rel_err(st, st32), rel_err(st, st64))
+        assert rel_err(o, o32) <= TOL and rel_err(o, o64) <= TOL, (flags, rel_err(o, o32), rel_err(o, o64))
+    model = CompositeGNNnodeBased(ns, no, d, 5, 0.0)
+    k, st, o = model.Loop(*inputs, state0=dev(s0))
+    k2, st2, o2 = model.Loop(*inputs, state0=dev(s0))
+    assert float(k) == 5.0 and torch.equal(st, st2) and torch.equal(o, o2)
+    model.native_flags = nat.FLAG_UNFUSED
+    ku, stu, ou = model.Loop(*inputs, state0=dev(s0))
+    assert float(ku) == 5.0
+    assert rel_err(st.cpu().numpy(), stu.cpu().numpy()) <= TOL and rel_err(o.cpu().numpy(), ou.cpu().numpy()) <= TOL
+    assert model.check_last_k() == 5.0
+
+
+def test_expired_in_launch_wait_is_loud():
+    """A lost slot hand-off in the wave-specialised kernel must reach the caller: libgnnloop_spin0.so is the same source
+    built with -DGNN_F4_SPIN_MAX=0 (every bounded wait expires at once); the forward must come back with k < 0 and
+    check_last_k() / predict() must raise NativeError.  Runs in a child process (another build of the library)."""
+    import os, subprocess, sys
+    lib = os.path.join(nat.CSRC, 'libgnnloop_spin0.so')
+    assert os.path.exists(lib), 'build() makes it'
+    code = r"""
+import numpy as np, torch, sys
+from gnnkeras_amd import _native as nat
+from gnnkeras_amd.synth import er_graph
+from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+from gnnkeras_amd.Models.GNN import GNNnodeBased
+from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+assert nat.LIB_PATH.endswith('libgnnloop_spin0.so')
+N, E, d = 200_000, 2_000_000, 64
+g = er_graph(N, E, aggregation_mode='average')
+seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)
+inp, lay = get_inout_dims('state', 14, 3, 2, 'n', d); ns = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0)
+inp, lay = get_inout_dims('output', 14, 3, 2, 'n', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
+m = GNNnodeBased(ns, no, d, 3, 0.0)
+m.native_flags = nat.FLAG_FUSED_GEN4
+k, st, o = m.Loop(*m.process_inputs(seq[0][0]), state0=torch.randn(N, d, device='cuda') * 0.1)
+torch.cuda.synchronize()
+assert float(k) < 0, float(k)
+try:
+    m.check_last_k()
+except nat.NativeError:
+    pass
+else:
+    sys.exit('check_last_k() did not raise')
+try:
+    m.predict(seq)
+except nat.NativeError:
+    print('LOUD_OK')
+else:
+    sys.exit('predict() did not raise')
+"""
+    env = dict(os.environ, GNNKERAS_AMD_LIB=lib, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(nat.HERE))) + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    root = os.path.dirname(nat.HERE)
+    env['PYTHONPATH'] = root + os.pathsep + os.environ.get('PYTHONPATH', '')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and 'LOUD_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # Keras-style evaluate / predict on top of the loop
 # ----------------------------------------------------------------------------------------------------------------------
@@ -482,16 +582,19 @@ def test_evaluate_and_predict(mutag_graphs):
 # node-range sharded loop (multi-GPU path) with the native kernels: R shards emulated on ONE device, the all-gather
 # replaced by explicit slice copies between the shards' full buffers (what RCCL does across GPUs)
 # ----------------------------------------------------------------------------------------------------------------------
-def _run_shards_on_one_gpu(model, g, s0, R):
+def _run_shards_on_one_gpu(model, g, s0, R, overlap=False):
     from gnnkeras_amd.distributed import ShardedLoop
-    shards = [ShardedLoop(model, g, r, R, 'cuda') for r in range(R)]
+    shards = [ShardedLoop(model, g, r, R, 'cuda', overlap=overlap) for r in range(R)]
+    if overlap: assert all(sl.overlap for sl in shards), 'the library refused the own-range / halo split for this shard'
     for sl in shards:
         sl._load_state0(s0 if s0 is not None else sl.plan_nodes_as_state())
         sl._setup()
         sl._initial_flags()
     n = shards[0].plan.rows_per_slice * shards[0].SP
     for it in range(model.max_iteration):
-        for sl in shards: sl._iteration(it)
+        for sl in shards:
+            if overlap: sl._partial(it); sl._iteration_split(it)      # phase A reads own rows only, phase B the halo
+            else: sl._iteration(it)
         for r, src in enumerate(shards):                     # "all-gather": slice r of rank r's buffer -> everyone
             piece = src.buf[(it + 1) & 1].view(-1)[r * n:(r + 1) * n]
             for dst in shards:
@@ -522,6 +625,51 @@ def test_sharded_native_kernels_match_oracle(R, threshold):
         ks, st, o = _run_shards_on_one_gpu(model, g, s0, R)
         assert all(k == float(k64) for k in ks), (ks, k64)
         assert rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL
+
+
+@pytest.mark.parametrize('R', [1, 2, 8])
+@pytest.mark.parametrize('mode,threshold', [('average', 0.0), ('average', 0.02), ('sum', 0.0)])
+def test_sharded_overlap_split_matches_oracle(R, mode, threshold):
+    """Own-range / halo split of the iteration (gnn_shard_partial + gnn_shard_iteration_split, the overlap path of
+    distributed.py) on emulated shards: same oracle, same 1e-5 bar, k identical."""
+    rng = np.random.default_rng(0)
+    N, d = 40_003, 64
+    g = er_graph(N, 400_000, seed=7, aggregation_mode=mode)
+    ns, no = starter_nets('n', d, scale=0.3 if mode == 'average' else 0.03)
+    model = GNNnodeBased(ns, no, d, 6, threshold)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    x = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    ks, st, o = _run_shards_on_one_gpu(model, g, s0, R, overlap=True)
+    assert all(k == float(k64) for k in ks), (ks, k64)
+    assert rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL
+    ks2, st2, o2 = _run_shards_on_one_gpu(model, g, s0, R, overlap=False)
+    assert ks2 == ks and rel_err(st, st2) <= TOL
+
+
+def test_sharded_overlap_per_arc_weights_and_composite():
+    """The split with per-arc weights (w != NULL) and with per-type state networks (C5 shape)."""
+    rng = np.random.default_rng(1)
+    N, d = 36_000, 32
+    g = er_graph(N, 300_000, seed=9, aggregation_mode='sum')
+    an = g.getArcNode(); an.data = rng.uniform(0.01, 0.1, len(an.data)).astype(np.float32)
+    g = GraphObject(g.nodes, g.arcs, g.targets, focus='n', ArcNode=an)
+    ns, no = starter_nets('n', d, scale=0.3)
+    model = GNNnodeBased(ns, no, d, 4, 0.0)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    ks, st, o = _run_shards_on_one_gpu(model, g, s0, 1, overlap=False)
+    ks2, st2, o2 = _run_shards_on_one_gpu(model, g, s0, 1, overlap=True)      # one shard: every arc is own-range
+    ks4, st4, o4 = _run_shards_on_one_gpu(model, g, s0, 4, overlap=True)
+    assert ks == ks2 == [4.0] and ks4 == [4.0] * 4
+    assert rel_err(st2, st) <= TOL and rel_err(st4, st) <= TOL and rel_err(o4, o) <= TOL
+    dims = (5, 3, 4)
+    gc = er_composite_graph(N, 300_000, dim_node_label=dims, aggregation_mode='composite_average', seed=11)
+    nsc, noc = composite_nets(dims, 3, d, 2, 'n')
+    mc = CompositeGNNnodeBased(nsc, noc, d, 4, 0.0)
+    xc = CompositeMultiGraphSequencer([gc], 'n', 'composite_average', 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_composite_loop(mc, xc, s0, np.float64, exact_order=False)
+    ksc, stc, oc = _run_shards_on_one_gpu(mc, gc, s0, 4, overlap=True)
+    assert all(k == float(k64) for k in ksc) and rel_err(stc, st64) <= TOL and rel_err(oc, o64) <= TOL
 
 
 def test_sharded_state_dim_0_and_per_arc_weights():
@@ -654,7 +802,8 @@ def _hub_graph(rng, n, e, hubs, mode, weights=False):
     return g
 
 
-@pytest.mark.parametrize('mode,weights,d', [('average', False, 64), ('average', False, 32), ('sum', True, 64), ('average', False, 0)])
+@pytest.mark.parametrize('mode,weights,d', [('average', False, 64), ('average', False, 32), ('sum', True, 64), ('average', False, 0),
+                                            ('average', False, 128), ('sum', True, 96), ('average', False, 200)])
 def test_hub_rows_use_the_segment_prepass(mode, weights, d):
     from gnnkeras_amd import sparse
     rng = np.random.default_rng(17)
@@ -677,6 +826,12 @@ def test_hub_rows_use_the_segment_prepass(mode, weights, d):
         k, st, o = model.Loop(*model.process_inputs(x), state0=None if s0 is None else dev(s0))
         assert float(k) == float(k64)
         assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL
+    if d:        # the standalone step (convergence(): gnn_state_step skips the pointer validation) takes the same hub path
+        model.native_flags = 0
+        step = model.convergence(0, dev(s0), None, x[0], x[5], None, None, False, arcs=x[1], arcnode=x[6])[1]
+        one = GNNnodeBased(ns, no, d, 1, 0.0)
+        st1 = oracle_loop(one, x, s0, np.float64, exact_order=False)[1]
+        assert rel_err(step.cpu().numpy(), st1) <= TOL
 
 
 @pytest.mark.parametrize('d,hidden,mode', [(64, 48, 'average'), (32, 32, 'sum'), (64, 64, 'normalized')])

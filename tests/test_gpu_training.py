@@ -121,6 +121,46 @@ def test_gradients_state_dim_0_mse_sum_aggregation(mutag_graphs):
     check_step(model, x, y, sw, None, loss='mse')
 
 
+def test_gradients_with_weight_regularizers(mutag_graphs):
+    """`MLP(kernel_regularizer=, bias_regularizer=)` (reference MLP.py:12-15, :48-49; train_step adds `self.losses`,
+    GNN.py:286): the penalty enters the loss once per variable and its gradient every trainable Dense variable, before the
+    1/k of `average_st_grads`."""
+    from gnnkeras_amd.Models.MLP import l1, l2, l1_l2
+    rng = np.random.default_rng(9)
+    seq = MultiGraphSequencer(mutag_graphs[:16], 'g', 'average', 16, shuffle=False)
+    x, y, sw = seq[0]
+    d = 8
+    inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d, hidden_units=[10])
+    ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', kernel_regularizer=[l2(0.02), l1_l2(0.003, 0.01)],
+             bias_regularizer=[None, l1(0.05)], rng=0)
+    ns.set_weights([a * 0.3 if a.ndim == 2 else a + 0.1 for a in ns.get_weights()])
+    inp, lay = get_inout_dims('output', 14, 3, 2, 'g', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', kernel_regularizer='l2', rng=1)
+    model = GNNgraphBased(ns, no, d, 5, 0.0)
+    s0 = rng.normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)
+    res, want = check_step(model, x, y, sw, s0, avg=True)
+    assert want['loss'] > 0.05          # the penalty is not negligible next to the cross-entropy (~0.7)
+    with pytest.raises(ValueError):
+        MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', kernel_regularizer=lambda w: w.sum())
+
+
+def test_dropout_networks_are_refused_not_silently_trained(mutag_graphs):
+    seq = MultiGraphSequencer(mutag_graphs[:8], 'g', 'average', 8, shuffle=False)
+    x, y, sw = seq[0]
+    inp, lay = get_inout_dims('state', 14, 3, 2, 'g', 4)
+    ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', dropout_rate=0.2, dropout_pos=0, rng=0)
+    inp, lay = get_inout_dims('output', 14, 3, 2, 'g', 4)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
+    model = GNNgraphBased(ns, no, 4, 3, 0.0)
+    model.compile(optimizer='adam', loss='categorical_crossentropy')
+    with pytest.raises(NotImplementedError):
+        model.train_step((x, y, sw))
+    with pytest.raises(NotImplementedError):
+        model.fit(seq, epochs=1, verbose=0)
+    out = model(x)                                                  # inference ignores Dropout layers, as Keras does
+    assert out.shape == (8, 2)
+
+
 def test_adam_step_matches_reference_formula(mutag_graphs):
     rng = np.random.default_rng(8)
     seq = MultiGraphSequencer(mutag_graphs[:16], 'g', 'average', 16, shuffle=False)

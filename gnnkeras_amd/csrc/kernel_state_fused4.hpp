@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                     ++spin; __builtin_amdgcn_s_sleep(1);
                 }
             }
+            if (bad) break;        // the slot never came free: deposit nothing (the state is invalid anyway, k < 0 says so)
 #ifdef GNN_F4_PROFILE
             if (lane == 0) atomicAdd(&g_f4_prof[1], f4_now() - tg_);
 #endif
@@ -312,6 +313,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                     ++spin; __builtin_amdgcn_s_sleep(1);
                 }
             }
+            if (bad) break;        // the slot never filled: its node ids are not valid, store nothing
 #ifdef GNN_F4_PROFILE
             if (lane == 0) { atomicAdd(&g_f4_prof[2], f4_now() - tc_); atomicAdd(&g_f4_prof[5], 1ull); }
             tc_ = f4_now();
@@ -415,10 +417,11 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
 #endif
     }
 
-    any = __syncthreads_or(any | (bad << 1));
+    any = __syncthreads_or(any);
+    bad = __syncthreads_or(bad);                 // (a predicate reduction, not a bitwise OR: one call per word)
     if (tid == 0) {
-        if ((any & 1) && a.flag_next) atomicOr(a.flag_next, 1);
-        if ((any & 2) && a.err) atomicOr(a.err, 1);
+        if (any && a.flag_next) atomicOr(a.flag_next, 1);
+        if (bad && a.err) atomicOr(a.err, 1);
         if (blockIdx.x == 0 && a.k_out) *a.k_out = a.k_val;
     }
 }
@@ -448,7 +451,7 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0) return 0;
-    GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s%s>", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? ",true" : "");
+    GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s,%s>", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? "true" : "false");
     k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

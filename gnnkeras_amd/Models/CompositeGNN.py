@@ -7,15 +7,15 @@ launch per type that gathers, multiplies with that type's weights on the matrix 
 """
 from __future__ import annotations
 
-import ctypes as C
 import json
 
 import numpy as np
 import torch
 
 from .. import _native as nat
+from .. import ops
 from ..sparse import SparseMatrix
-from .GNN import GNNnodeBased, _LoopModel, _squeeze_last, _arc_endpoints, _hub_fields
+from .GNN import GNNnodeBased, _LoopModel, _squeeze_last, _arc_endpoints
 from .MLP import Sequential
 
 
@@ -131,7 +131,6 @@ class CompositeGNNnodeBased(GNNnodeBased):
         nodes = nodes.to(torch.float32).contiguous()
         arcs = arcs.to(torch.float32).contiguous()
         N, Lw = nodes.shape
-        E, A = arcs.shape[0], arcs.shape[1] - 2
         dims = [int(d) for d in (dim_node_label.reshape(-1).tolist() if isinstance(dim_node_label, torch.Tensor)
                                  else np.asarray(dim_node_label).reshape(-1))]
         T = len(dims)
@@ -142,10 +141,9 @@ class CompositeGNNnodeBased(GNNnodeBased):
         out_index = self._out_index(set_mask, output_mask)
         type_nodes, offsets = self._type_lists(type_mask)
 
-        adjacency, arcnode = SparseMatrix.from_triple(adjacency), SparseMatrix.from_triple(arcnode)
-        adj, arcn = adjacency.device_csr(dev), arcnode.device_csr(dev)
+        adjacency = SparseMatrix.from_triple(adjacency)
+        adj, arcn = adjacency.device_csr(dev), SparseMatrix.from_triple(arcnode).device_csr(dev)
         cas = [SparseMatrix.from_triple(c).device_csr(dev) for c in composite_adjacencies]
-        keep = [nodes, arcs, adj, arcn, cas, type_nodes, out_index]
 
         S = self.state_vect_dim if self.state_vect_dim > 0 else Lw
         if self.state_vect_dim > 0:
@@ -156,51 +154,14 @@ class CompositeGNNnodeBased(GNNnodeBased):
                 state0 = torch.randn((N, S), generator=gen, device=dev, dtype=torch.float32) * 0.1
             state0 = state0.to(dev, torch.float32).contiguous()
             if tuple(state0.shape) != (N, S): raise ValueError('state0 must be (n_nodes, state_vect_dim)')
-            keep.append(state0)
-
-        a = nat.LoopArgs()
-        a.abi_version, a.composite = nat.GNN_ABI_VERSION, 1
-        a.n_nodes, a.n_arcs, a.dim_node_label, a.dim_arc_label = N, E, Lw, A
-        a.nodes, a.ld_nodes = nat.ptr(nodes), Lw
-        a.arc_labels, a.ld_arcs = C.c_void_p(arcs.data_ptr() + 8), arcs.shape[1]
-        a.adjacency, a.arcnode = nat.make_csr(adj), nat.make_csr(arcn)
-        _hub_fields(a, adj)
-        a.n_types = T
-        a.type_nodes = nat.ptr(type_nodes)
-        for t in range(T):
-            a.type_dim_label[t] = dims[t]
-            a.type_offsets[t] = int(offsets[t])
-            a.composite_adjacency[t] = nat.make_csr(cas[t])
-            a.net_state[t] = self.net_state[t].to(dev).native()
-        a.type_offsets[T] = int(offsets[T])
-        a.net_output = self.net_output.to(dev).native()
-        a.state_dim, a.max_iteration, a.state_threshold = self.state_vect_dim, self.max_iteration, float(self.state_threshold)
-        if self.state_vect_dim > 0: a.state0 = nat.ptr(state0)
-        a.focus = nat.FOCUS[focus]
-        a.n_out, a.out_index = len(out_index), nat.ptr(out_index)
-        if focus == 'a':
-            es, ed = _arc_endpoints(adjacency, dev)
-            a.arc_src, a.arc_dst = nat.ptr(es), nat.ptr(ed); keep += [es, ed]
-        if focus == 'g':
-            ng = SparseMatrix.from_triple(nodegraph).device_csr(dev)
-            a.nodegraph = nat.make_csr(ng); keep.append(ng)
-        a.flags = self.native_flags
-        if self.loop_events is not None:
-            a.ev_loop_begin, a.ev_loop_end = (C.c_void_p(e.cuda_event) for e in self.loop_events)
-        a.stream = nat.current_stream(dev)
-        nbytes = nat.lib().gnn_loop_workspace_bytes(C.byref(a))
-        if nbytes == 0: nat.check(1)
-        ws = self._workspace(nbytes, dev)
-        base = ws.data_ptr()
-        aligned = (base + 255) & ~255
-        a.workspace, a.workspace_bytes = C.c_void_p(aligned), ws.numel() - (aligned - base)
-
-        n_rows_out = a.nodegraph.n_dst if focus == 'g' else len(out_index)
-        k = torch.empty((), dtype=torch.float32, device=dev)
-        state = torch.empty((N, S), dtype=torch.float32, device=dev)
-        out = torch.empty((n_rows_out, self.net_output.units[-1]), dtype=torch.float32, device=dev)
-        a.k_out, a.state_out, a.out = nat.ptr(k), nat.ptr(state), nat.ptr(out)
-        nat.check(nat.lib().gnn_loop_forward(C.byref(a)))
+        else:
+            state0 = None
+        ends = _arc_endpoints(adjacency, dev) if focus == 'a' else None
+        ng = SparseMatrix.from_triple(nodegraph).device_csr(dev) if focus == 'g' else None
+        # one custom op for the whole heterogeneous Loop: torch.ops.gnnkeras.loop_forward with the per-type lists
+        k, state, out = ops.loop_forward(nodes, arcs, adj, arcn, ng, self.net_state, self.net_output, state0, out_index, ends,
+                                         self.state_vect_dim, self.max_iteration, self.state_threshold, nat.FOCUS[focus],
+                                         self.native_flags, composite=(type_nodes, offsets, dims, cas), loop_events=self.loop_events)
         self._last_k = k
         return k, state, out
 

@@ -8,7 +8,6 @@ The Python `while` of the reference (`tf.while_loop` in eager mode, `GNN.py:265`
 """
 from __future__ import annotations
 
-import ctypes as C
 import json
 import os
 
@@ -16,6 +15,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
+from .. import ops
 from ..sparse import SparseMatrix
 from .MLP import Sequential
 
@@ -60,7 +60,6 @@ class _LoopModel:
     def _engine_init(self):
         self.optimizer, self.loss, self.metrics_spec = None, None, []
         self.average_st_grads = None
-        self._ws = {}                                  # workspace per HIP stream (batches of predict / evaluate overlap)
         self._mask_cache = {}
         self._streams = None
         self.inference_streams = 8                     # side streams predict() / evaluate() spread their batches over
@@ -190,14 +189,7 @@ class _LoopModel:
         t = x[0]
         return t.device if isinstance(t, torch.Tensor) else torch.device('cpu')
 
-    # workspace and mask-index caches ---------------------------------------------------------------------------------
-    def _workspace(self, nbytes, device):
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
-        ws = self._ws.get(key)
-        if ws is None or ws.numel() < nbytes:
-            ws = self._ws[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        return ws
-
+    # batch overlap and mask-index cache -------------------------------------------------------------------------------
     def _batches_concurrently(self, n, fn, device, width=None):
         """Run fn(i), i < n, `width` at a time on side HIP streams and yield (i, result) in order on the caller's stream.
 
@@ -244,14 +236,6 @@ class _LoopModel:
             if len(self._mask_cache) > 4096: self._mask_cache.clear()
             hit = self._mask_cache[key] = (idx, set_mask, output_mask)   # keep the masks alive: ptr is the key
         return hit[0]
-
-
-def _hub_fields(a, adj):
-    """Hub rows (in-degree > sparse.HEAVY_THRESHOLD): hand the light operator + segment list to the library."""
-    if adj.get('heavy') is not None:
-        a.adjacency_light = nat.make_csr(adj['light'])
-        a.heavy_seg_beg, a.heavy_seg_end = nat.ptr(adj['heavy']['seg_beg']), nat.ptr(adj['heavy']['seg_end'])
-        a.n_heavy_segments = adj['heavy']['n_seg']
 
 
 def _squeeze_last(x):
@@ -360,28 +344,29 @@ class GNNnodeBased(_LoopModel):
 
     # ---- pieces of the loop, callable on their own (tests, LGNN-style callers) ----------------------------------------
     def condition(self, k, state, state_old, *args):
-        """Device-side predicate of reference GNN.py:196-214; returns a 0-dim bool tensor (no host sync)."""
+        """Device-side predicate of reference GNN.py:196-214 (`torch.ops.gnnkeras.converged`); returns a 0-dim bool tensor
+        (no host sync)."""
         nat.require_device(state, 'state')
-        state = state.contiguous()
-        so = None if state_old is None else state_old.contiguous()
-        flag = torch.empty(1, dtype=torch.int32, device=state.device)
-        nat.check(nat.lib().gnn_converged(nat.ptr(state), nat.ptr(so), state.shape[0], state.shape[1], state.shape[1],
-                                          float(self.state_threshold), nat.ptr(flag), nat.current_stream(state.device)))
+        flag = ops.converged(state.to(torch.float32).contiguous(), None if state_old is None else state_old.to(torch.float32).contiguous(),
+                             self.state_threshold)
         kk = k if isinstance(k, torch.Tensor) else torch.tensor(float(k), device=state.device)
         return torch.logical_and(flag[0] != 0, kk.to(state.device) < self.max_iteration)
 
     def convergence(self, k, state, state_old, nodes, adjacency, aggregated_nodes, aggregated_arcs, training, *,
                     arcs=None, arcnode=None):
-        """One state-transition step (reference GNN.py:217-236) through `gnn_state_step`. The reference threads the
-        pre-aggregated label / arc tensors through the loop; the native step recomputes them from `arcs`/`arcnode`
-        when given, which is what `Loop` does once per call."""
+        """One state-transition step (reference GNN.py:217-236) through `torch.ops.gnnkeras.state_step`. The reference
+        threads the pre-aggregated label / arc tensors through the loop; the native step recomputes them from
+        `arcs`/`arcnode` when given, which is what `Loop` does once per call."""
         if arcs is None or arcnode is None:
             raise ValueError('convergence() needs arcs= and arcnode= to rebuild the iteration constants on device')
-        args, keep = self._build_args(nodes, arcs, adjacency, arcnode, None, None, state0=state, training=training,
-                                      with_output=False)
-        new = torch.empty_like(state)
-        flag = torch.empty(1, dtype=torch.int32, device=state.device)
-        nat.check(nat.lib().gnn_state_step(C.byref(args), nat.ptr(state.contiguous()), nat.ptr(new), nat.ptr(flag)))
+        self._check_training(bool(training))
+        nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs'); nat.require_device(state, 'state')
+        dev = nodes.device
+        adj = SparseMatrix.from_triple(adjacency).device_csr(dev)
+        arcn = SparseMatrix.from_triple(arcnode).device_csr(dev)
+        new, _moving = ops.state_step(nodes.to(torch.float32).contiguous(), arcs.to(torch.float32).contiguous(), adj, arcn,
+                                      self.net_state, state.to(dev, torch.float32).contiguous(), self.state_vect_dim,
+                                      self.state_threshold, self.native_flags)
         return k + 1, new, state, nodes, adjacency, aggregated_nodes, aggregated_arcs, training
 
     def apply_filters(self, state_converged, nodes, adjacency, arcs_label, mask):
@@ -397,58 +382,6 @@ class GNNnodeBased(_LoopModel):
             raise NotImplementedError('training=True forward needs BatchNormalization batch statistics / dropout on '
                                       'device (SURVEY.md §8f, next row); inference forward is the built path')
 
-    def _build_args(self, nodes, arcs, adjacency, arcnode, nodegraph, out_index, state0, training, with_output=True,
-                    focus=None):
-        focus = focus or self._focus
-        self._check_training(bool(training))
-        nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs')
-        dev = nodes.device
-        nodes = nodes.to(torch.float32).contiguous()
-        arcs = arcs.to(torch.float32).contiguous()
-        N, L = nodes.shape
-        E, A = arcs.shape[0], arcs.shape[1] - 2
-        adjacency, arcnode = SparseMatrix.from_triple(adjacency), SparseMatrix.from_triple(arcnode)
-        adj, arcn = adjacency.device_csr(dev), arcnode.device_csr(dev)
-        keep = [nodes, arcs, adj, arcn]
-
-        a = nat.LoopArgs()
-        a.abi_version, a.composite = nat.GNN_ABI_VERSION, 0
-        a.n_nodes, a.n_arcs, a.dim_node_label, a.dim_arc_label = N, E, L, A
-        a.nodes, a.ld_nodes = nat.ptr(nodes), L
-        a.arc_labels, a.ld_arcs = C.c_void_p(arcs.data_ptr() + 8), arcs.shape[1]
-        a.adjacency, a.arcnode = nat.make_csr(adj), nat.make_csr(arcn)
-        _hub_fields(a, adj)
-        a.n_types = 1
-        a.net_state[0] = self.net_state.to(dev).native()
-        a.net_output = self.net_output.to(dev).native()
-        a.state_dim, a.max_iteration, a.state_threshold = self.state_vect_dim, self.max_iteration, float(self.state_threshold)
-        if self.state_vect_dim > 0:
-            if state0 is None: raise ValueError('state0 missing')
-            state0 = state0.to(dev, torch.float32).contiguous()
-            if tuple(state0.shape) != (N, self.state_vect_dim): raise ValueError('state0 must be (n_nodes, state_vect_dim)')
-            a.state0 = nat.ptr(state0); keep.append(state0)
-        a.focus = nat.FOCUS[focus]
-        if with_output:
-            a.n_out, a.out_index = len(out_index), nat.ptr(out_index)
-            keep.append(out_index)
-            if focus == 'a':
-                es, ed = _arc_endpoints(adjacency, dev)
-                a.arc_src, a.arc_dst = nat.ptr(es), nat.ptr(ed); keep += [es, ed]
-            if focus == 'g':
-                ng = SparseMatrix.from_triple(nodegraph).device_csr(dev)
-                a.nodegraph = nat.make_csr(ng); keep.append(ng)
-        a.flags = self.native_flags
-        if self.loop_events is not None:
-            a.ev_loop_begin, a.ev_loop_end = (C.c_void_p(e.cuda_event) for e in self.loop_events)
-        a.stream = nat.current_stream(dev)
-        nbytes = nat.lib().gnn_loop_workspace_bytes(C.byref(a))
-        if nbytes == 0: nat.check(1)
-        ws = self._workspace(nbytes, dev)
-        base = ws.data_ptr()
-        aligned = (base + 255) & ~255
-        a.workspace, a.workspace_bytes = C.c_void_p(aligned), ws.numel() - (aligned - base)
-        return a, keep
-
     def Loop(self, nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph,
              training: bool = False, *, state0=None, seed=None, node_level: bool = False):
         """(k, state, out) for one (merged) graph — reference GNN.py:245-274.
@@ -463,25 +396,30 @@ class GNNnodeBased(_LoopModel):
             tp = LoopTrainer(self).forward([nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph],
                                            state0=state0, seed=seed, node_level=node_level)
             return torch.tensor(float(tp.k), device=tp.dev), tp.state.clone(), tp.y_pred
-        nat.require_device(nodes, 'nodes')
+        nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs')
         dev = nodes.device
         set_mask, output_mask = _squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev)
         out_index = self._out_index(set_mask, output_mask)
         N = nodes.shape[0]
-        if self.state_vect_dim > 0 and state0 is None:
-            gen = None
-            if seed is not None:
-                gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
-            state0 = torch.randn((N, self.state_vect_dim), generator=gen, device=dev, dtype=torch.float32) * 0.1
-        a, keep = self._build_args(nodes, arcs, adjacency, arcnode, nodegraph, out_index, state0, training, focus=focus)
-        S = self.state_vect_dim if self.state_vect_dim > 0 else nodes.shape[1]
-        T = self.net_output.units[-1]
-        n_rows_out = a.nodegraph.n_dst if focus == 'g' else len(out_index)
-        k = torch.empty((), dtype=torch.float32, device=dev)
-        state = torch.empty((N, S), dtype=torch.float32, device=dev)
-        out = torch.empty((n_rows_out, T), dtype=torch.float32, device=dev)
-        a.k_out, a.state_out, a.out = nat.ptr(k), nat.ptr(state), nat.ptr(out)
-        nat.check(nat.lib().gnn_loop_forward(C.byref(a)))
+        if self.state_vect_dim > 0:
+            if state0 is None:
+                gen = None
+                if seed is not None:
+                    gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
+                state0 = torch.randn((N, self.state_vect_dim), generator=gen, device=dev, dtype=torch.float32) * 0.1
+            state0 = state0.to(dev, torch.float32).contiguous()
+            if tuple(state0.shape) != (N, self.state_vect_dim): raise ValueError('state0 must be (n_nodes, state_vect_dim)')
+        else:
+            state0 = None
+        adjacency = SparseMatrix.from_triple(adjacency)
+        adj, arcn = adjacency.device_csr(dev), SparseMatrix.from_triple(arcnode).device_csr(dev)
+        ends = _arc_endpoints(adjacency, dev) if focus == 'a' else None
+        ng = SparseMatrix.from_triple(nodegraph).device_csr(dev) if focus == 'g' else None
+        # the whole Loop is ONE custom op: torch.ops.gnnkeras.loop_forward (csrc/torch_ops.cpp -> gnn_loop_forward)
+        k, state, out = ops.loop_forward(nodes.to(torch.float32).contiguous(), arcs.to(torch.float32).contiguous(), adj, arcn, ng,
+                                         self.net_state, self.net_output, state0, out_index, ends, self.state_vect_dim,
+                                         self.max_iteration, self.state_threshold, nat.FOCUS[focus], self.native_flags,
+                                         loop_events=self.loop_events)
         self._last_k = k
         return k, state, out
 

@@ -148,17 +148,10 @@ class LGNN(_LoopModel):
 
     @staticmethod
     def _pool(nodegraph, out_nodes):
-        """NodeGraph^T . out (per-graph mean of node outputs) on the device."""
-        import ctypes as C
-        from .. import _native as nat
+        """NodeGraph^T . out (per-graph mean of node outputs) on the device: `torch.ops.gnnkeras.pool`."""
+        from .. import ops
         from ..sparse import SparseMatrix
-        csr = SparseMatrix.from_triple(nodegraph).device_csr(out_nodes.device)
-        out = torch.empty((csr['n_dst'], out_nodes.shape[1]), dtype=torch.float32, device=out_nodes.device)
-        c = nat.make_csr(csr)
-        x = out_nodes.contiguous()
-        nat.check(nat.lib().gnn_aggregate(C.byref(c), nat.ptr(x), x.shape[1], x.shape[1], nat.ptr(out), out.shape[1],
-                                          nat.current_stream(x.device)))
-        return out
+        return ops.pool(SparseMatrix.from_triple(nodegraph).device_csr(out_nodes.device), out_nodes.to(torch.float32).contiguous())
 
     # ---- joint training (parallel / residual) ----------------------------------------------------------------------------
     def _layer_x(self, x, nodes, arcs, dim_node_label):

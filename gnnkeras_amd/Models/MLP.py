@@ -216,19 +216,12 @@ class Sequential:
         return self._native
 
     def __call__(self, x: torch.Tensor, training: bool = False):
-        """Inference forward on the GPU (`gnn_mlp_forward`)."""
+        """Inference forward on the GPU (`torch.ops.gnnkeras.mlp_forward`)."""
         if training and (self.batch_normalization or self.dropout_rate):
             raise NotImplementedError('training-mode forward (batch statistics / dropout) is not on the HIP path yet')
         nat.require_device(x, 'x')
-        x = x.to(torch.float32).contiguous()
-        m = self.native()
-        M = x.shape[0]
-        y = torch.empty((M, self.units[-1]), dtype=torch.float32, device=x.device)
-        nbytes = nat.lib().gnn_mlp_workspace_bytes(C.byref(m), M)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        nat.check(nat.lib().gnn_mlp_forward(C.byref(m), nat.ptr(x), x.shape[1], M, nat.ptr(y), y.shape[1],
-                                            nat.ptr(ws), nbytes, nat.current_stream(x.device)))
-        return y
+        from .. import ops
+        return ops.mlp_forward(self, x.to(torch.float32).contiguous())
 
 
 def _init_weights(model: Sequential, kernel_initializer, bias_initializer, rng):

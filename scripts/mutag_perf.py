@@ -30,6 +30,17 @@ for inp, s0 in zip(inputs, s0s):
     a.record(); gnn.Loop(*inp, state0=s0); b.record(); torch.cuda.synchronize()
     loop_ms.append(ev[0].elapsed_time(ev[1])); tot_ms.append(a.elapsed_time(b))
 print(f'device: loop (50 iterations) median {np.median(loop_ms)*1e3:.0f} us = {np.median(loop_ms)*20:.1f} us/iter; whole forward median {np.median(tot_ms)*1e3:.0f} us')
-t0 = time.perf_counter()
-for inp, s0 in zip(inputs, s0s): gnn._build_args(inp[0], inp[1], inp[5], inp[6], inp[7], gnn._out_index(inp[3], inp[4]), s0, False)
-print(f'python _build_args per batch: {(time.perf_counter()-t0)/136*1e6:.0f} us')
+# host cost of one forward: python marshalling + op dispatch + launches, with the device idle (sync after each call)
+t_host = []
+for inp, s0 in zip(inputs, s0s):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    gnn.Loop(*inp, state0=s0)
+    t_host.append(time.perf_counter() - t0)
+print(f'host time of Loop() per batch (device idle): median {np.median(t_host)*1e6:.0f} us')
+width = gnn._round_width(seq, device)
+run = lambda i: gnn.Loop(*inputs[i], state0=s0s[i])
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in gnn._batches_concurrently(len(inputs), run, device, width): pass
+    torch.cuda.synchronize(); t = time.perf_counter() - t0
+    print(f'{width} streams: {1e3*t/136:.3f} ms/batch, {1e3*t/4337:.5f} ms/graph')

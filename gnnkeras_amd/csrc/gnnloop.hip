@@ -504,7 +504,7 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, boo
     // BN folding of every first layer: one launch, which also zeroes the flag words / barrier counters and k
     FoldList fl;
     for (int t = 0; t < p.T; ++t) fl.add(a.net_state[t], p.tp[t].Wf, p.tp[t].bf);
-    fl.add(a.net_output, p.Wf_out, p.bf_out);
+    if (a.net_output.kernel[0]) fl.add(a.net_output, p.Wf_out, p.bf_out);      // absent for the standalone state step
     if (zero_loop_words) { fl.fa.zero_a = p.flags; fl.fa.n_a = a.max_iteration + GNN_LOOP_WORDS; fl.fa.zero_b = a.k_out; fl.fa.n_b = 1; }
     TRY(launch_fold_list(fl, st));
     // ArcNode scatter-add (GNN.py:254) and neighbour-label aggregates (GNN.py:258 / CompositeGNN.py:251)

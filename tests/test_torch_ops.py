@@ -106,7 +106,7 @@ def test_piecewise_ops_match_oracle(mutag_graphs):
 
 @pytest.mark.gpu
 def test_op_argument_errors_are_runtime_errors(mutag_graphs):
-    seq = MultiGraphSequencer(mutag_graphs[:4], 'n', 'average', 4, shuffle=False)
+    seq = MultiGraphSequencer(mutag_graphs[:4], 'g', 'average', 4, shuffle=False)
     x = seq[0][0]
     dev = x[0].device
     adj = SparseMatrix.from_triple(x[5]).device_csr(dev)
@@ -120,10 +120,10 @@ def test_op_argument_errors_are_runtime_errors(mutag_graphs):
     bad = dict(adj, rowptr=adj['rowptr'].to(torch.int64))
     with pytest.raises(RuntimeError, match='int32'):
         ops.aggregate(bad, torch.zeros((N, 3), device=dev))
-    ns, no = _nets('n', 8)
-    model = GNNnodeBased(ns, no, 8, 3, 0.0)
+    ns, no = _nets('g', 8)
+    model = GNNgraphBased(ns, no, 8, 3, 0.0)
     with pytest.raises((RuntimeError, ValueError), match='state0'):
         model.Loop(*model.process_inputs(x), state0=torch.zeros((N + 1, 8), device=dev))
     wrong = MLP(ns.input_dim + 1, ns.units, 'selu', 'lecun_normal', 'lecun_normal', rng=0)
     with pytest.raises(RuntimeError, match='in_dim'):
-        GNNnodeBased(wrong, no, 8, 3, 0.0).Loop(*model.process_inputs(x), state0=torch.zeros((N, 8), device=dev))
+        GNNgraphBased(wrong, no, 8, 3, 0.0).Loop(*model.process_inputs(x), state0=torch.zeros((N, 8), device=dev))

@@ -22,6 +22,7 @@
 #include "kernel_state_fused2.hpp"
 #include "kernel_state_fused4.hpp"
 #include "kernel_state_small.hpp"
+#include "kernel_state_wide.hpp"
 
 namespace {
 
@@ -676,6 +677,7 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;
     }
+    if (p.SP == 128) { FUSED_OK(gnn::launch_wide(fa, device_cus(), st)); return 0; }
     const int gen = agg_init ? 4 : iteration_generation(a, p);
     if (gen == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
     else FUSED_OK(gnn::launch_fused2(fa, p.SP, fused_waves() == 0 ? 8 : fused_waves(), device_cus(), st));
@@ -690,7 +692,7 @@ int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first,
     static int env = -1;
     if (env < 0) { const char *e = getenv("GNN_FUSED_KERNEL"); env = e ? atoi(e) : 0; }
     if (pinned == 0 && env != 0 && env != 5) return 2;
-    if (p.n_heavy != 0 || a.max_iteration < 1) return 2;
+    if (p.n_heavy != 0 || a.max_iteration < 1 || p.SP > 64) return 2;
     gnn::SmallArgs sa;
     memset(&sa, 0, sizeof(sa));
     gnn::Fused2Args &fa = sa.f;
@@ -714,10 +716,10 @@ int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first,
 }
 
 // 0: un-fused kernels; 1: any fused kernel; 2: two-layer state networks - only the wave-specialised kernel and the
-// persistent whole-loop kernel carry the second Dense.
+// persistent whole-loop kernel carry the second Dense; 3: state width 65 .. 128 - the wide kernel, whatever generation is pinned.
 int fusable(const gnn_loop_args_t &a, const Plan &p) {
     if (a.flags & GNN_FLAG_UNFUSED) return 0;
-    if (p.SP > 64) return 0;       // LDS: [64 x 2SP] tile + [2SP x SP] weights must leave room for 2 workgroups per CU
+    if (p.SP > 128) return 0;      // W1 = [2SP x SP] floats must fit the CU's LDS: 128 KB at SP = 128 (kernel_state_wide.hpp)
     // the fused kernel addresses state rows and C with 32-bit byte offsets off a scalar base
     if ((size_t)(std::max(a.adjacency.n_src, p.N) + p.n_heavy) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return 0;
     // ... and the CSR arrays through 4 GiB buffer windows
@@ -732,13 +734,14 @@ int fusable(const gnn_loop_args_t &a, const Plan &p) {
         if (t > 0 && (m.n_layers == 2) != two) return 0;                // every node type the same depth
         two = m.n_layers == 2;
     }
+    if (p.SP == 128) return two ? 0 : 3;     // state widths 65 .. 128: one-layer state networks on the wide kernel
     return two ? 2 : 1;
 }
 
 // may ONE ITERATION of this model run in a fused launch? (the per-iteration entry points and the loop's fallback)
 bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
     const int f = fusable(a, p);
-    return f == 1 || (f == 2 && iteration_generation(a, p) == 4);
+    return f == 1 || f == 3 || (f == 2 && iteration_generation(a, p) == 4);
 }
 
 }  // namespace
@@ -971,7 +974,7 @@ int gnn_shard_can_split(const gnn_loop_args_t *args) {
     if (!args) return 0;
     Plan p;
     if (make_plan(*args, args->workspace, p, false)) return 0;
-    if (fusable(*args, p) != 1 || p.SP <= 16 || p.n_heavy != 0) return 0;     // one-layer state nets on the wave-specialised kernel
+    if (fusable(*args, p) != 1 || p.SP <= 16 || p.SP > 64 || p.n_heavy != 0) return 0;     // one-layer state nets on the wave-specialised kernel
     const int pinned = (args->flags & GNN_FLAG_FUSED_GEN_MASK) >> 4;
     return pinned == 0 || pinned == 4;
 }

@@ -834,6 +834,59 @@ def test_hub_rows_use_the_segment_prepass(mode, weights, d):
         assert rel_err(step.cpu().numpy(), st1) <= TOL
 
 
+@pytest.mark.parametrize('d,mode,weights', [(128, 'average', False), (96, 'sum', False), (65, 'average', False), (128, 'sum', True), (100, 'normalized', False)])
+def test_wide_state_runs_fused(d, mode, weights):
+    """State widths 65 .. 128 (any `state_vect_dim` is legal in the reference, GNN.py:26-28) run the wide fused kernel
+    (kernel_state_wide.hpp: one workgroup per CU, W1 = 128 KB in LDS): against the oracle and against the un-fused kernels,
+    with early exit, masks and a ragged last tile."""
+    rng = np.random.default_rng(23)
+    N = 20_011
+    g = er_graph(N, 8 * N, seed=5, aggregation_mode=mode)
+    if weights:
+        an = g.getArcNode(); an.data = rng.uniform(0.01, 0.12, len(an.data)).astype(np.float32)
+        g = GraphObject(g.nodes, g.arcs, g.targets, focus='n', ArcNode=an)
+    om = rng.random(N) < 0.7
+    g = GraphObject(g.nodes, g.arcs, rng.normal(size=(int(om.sum()), 2)), focus='n', set_mask=rng.random(N) < 0.8, output_mask=om,
+                    aggregation_mode=mode, **({'ArcNode': g.ArcNode} if weights else {}))
+    ns, no = starter_nets('n', d, scale=0.25 if mode != 'sum' else 0.03)
+    seq = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)
+    if weights:
+        seq.graph_tensors[0].ArcNode = SparseMatrix.from_scipy(g.ArcNode)
+        seq.graph_tensors[0].Adjacency = SparseMatrix.from_scipy(g.Adjacency)
+        seq._items = [None]
+    x = seq[0][0]
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    for thr, iters in ((0.0, 4), (0.05, 30)):
+        model = GNNnodeBased(ns, no, d, iters, thr)
+        k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+        if thr > 0: assert 1 < k64 < iters, k64
+        inputs = model.process_inputs(x)
+        for flags in (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN4):
+            model.native_flags = flags
+            k, st, o = model.Loop(*inputs, state0=dev(s0))
+            assert float(k) == float(k64), (flags, float(k), k64)
+            assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, (flags, rel_err(st.cpu().numpy(), st64))
+            if flags == 0: assert nat.lib().gnn_last_kernel_name().decode().startswith('k_state_wide'), nat.lib().gnn_last_kernel_name()
+        assert model.check_last_k() == float(k64)
+
+
+def test_wide_state_small_graphs_and_composite(mutag_graphs):
+    """The wide kernel on a MUTAG batch (59 tiles: most workgroups idle) and on a 3-type composite graph, d = 128 / 80."""
+    seq = MultiGraphSequencer(mutag_graphs[:32], 'g', 'average', 32, shuffle=False)
+    x = seq[0][0]
+    ns, no = starter_nets('g', 128, scale=0.25)
+    model = GNNgraphBased(ns, no, 128, 10, 0.0)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (x[0].shape[0], 128)).astype(np.float32)
+    check(model, x, s0)
+    rng = np.random.default_rng(4)
+    N, dims, d = 6001, (5, 3, 4), 80
+    g = er_composite_graph(N, 40000, dim_node_label=dims, aggregation_mode='composite_average', seed=11)
+    nsc, noc = composite_nets(dims, 3, d, 2, 'n')
+    mc = CompositeGNNnodeBased(nsc, noc, d, 6, 0.0)
+    xc = CompositeMultiGraphSequencer([g], 'n', 'composite_average', 1, shuffle=False)[0][0]
+    check(mc, xc, rng.normal(0, 0.1, (N, d)).astype(np.float32), oracle=oracle_composite_loop)
+
+
 @pytest.mark.parametrize('d,hidden,mode', [(64, 48, 'average'), (32, 32, 'sum'), (64, 64, 'normalized')])
 def test_two_layer_state_network_runs_fused_at_scale(d, hidden, mode):
     """A state network with one hidden layer (reference MLP(hidden_units=...), MLP.py:82-140) on a graph large enough

@@ -210,8 +210,9 @@ def main():
     ap.add_argument('--no-beyond-cache', action='store_true')
     ap.add_argument('--unfused', action='store_true')
     ap.add_argument('--force-sharded', action='store_true', help='run the N>1 code path even with one rank (smoke test)')
-    ap.add_argument('--exchange', choices=['auto', 'allgather', 'halo'], default='auto',
-                    help='N>1 state exchange: whole slices (all-gather) or compacted halos (all-to-all)')
+    ap.add_argument('--exchange', choices=['auto', 'allgather', 'direct', 'halo'], default='auto',
+                    help='N>1 state exchange: whole slices by RCCL all-gather / by concurrent point-to-point pairs, or compacted halos '
+                         '(all-to-all); auto = halo for graphs with locality, else the faster whole-slice transport, measured at start-up')
     ap.add_argument('--no-overlap', action='store_true', help='N>1: exchange strictly after the iteration kernel (no own-range / halo split)')
     args = ap.parse_args()
 
@@ -320,6 +321,8 @@ def main():
                                      'note': 'max over ranks; kernel = own-range + halo launches without the collective, exchange = '
                                              'the collective alone, iteration = what one iteration costs with both in flight'}
         extra['exchange_bytes_per_rank_per_iteration'] = sl.exchange_bytes()
+        extra['exchange_transport'] = getattr(sl, 'transport', 'all_to_all')
+        if getattr(sl, 'transport_times', None): extra['exchange_transport_ms_measured'] = {k_: 1e3 * v for k_, v in sl.transport_times.items()}
     ms_per_step = 1e3 * elapsed / args.steps
     value = E * k_val * args.steps / elapsed
 
@@ -350,7 +353,7 @@ def main():
                                + ('3 node types with per-type ' if composite else '') +
                                f'BN+Dense({ns.input_dim}->{h1},selu) state net',
                    'sharding': 'single GPU' if not sharded else f'node-range shards over {world} GPUs, '
-                                                               f'RCCL {"all-to-all of compacted halos" if type(sl).__name__ == "HaloShardedLoop" else "all-gather of state slices"} per iteration'
+                                                               f'RCCL {"all-to-all of compacted halos" if type(sl).__name__ == "HaloShardedLoop" else ("all-gather of state slices" if sl.transport == "ring" else "pair-wise send/recv of state slices (one-hop all-gather)")} per iteration'
                                                                + (', own-range arcs overlapped with the exchange' if sharded and sl.overlap else '')},
         'roofline': roofline,
         'loop_only_updates_per_s': E / t_iter if not sharded else None,

@@ -284,18 +284,35 @@ class ShardedLoop:
         else:
             self.buf[0].copy_(torch.from_numpy(p.pad_state(np.asarray(state0_full, dtype=np.float32), self.SP)))
 
+    transport = 'ring'      # 'ring': RCCL all_gather_into_tensor; 'direct': one send + one receive per peer, all at once
+
     def _exchange(self, buf: torch.Tensor, it: int = 0, async_op: bool = False):
         """In-place all-gather of the slices of `buf` (states + flag rows): the one exchange step per iteration.
-        `async_op`: returns the collective's work handle; `_exchange_finish` makes the current stream wait for it."""
+        Two transports for the same data movement: RCCL's all-gather collective ('ring': R - 1 steps, each bound by one xGMI
+        link) or R - 1 concurrent point-to-point pairs ('direct': every peer's slice travels over its own link of the fully
+        connected xGMI mesh - SURVEY §8e's one-hop all-gather).  `async_op`: returns work handle(s); `_exchange_finish` makes
+        the current stream wait for them."""
         if self.world_size == 1:
             return None
         p = self.plan
         flat = buf.view(-1)
         n = p.rows_per_slice * self.SP
+        if self.transport == 'direct':
+            mine = flat[self.rank * n:(self.rank + 1) * n]
+            ops = []
+            for off in range(1, self.world_size):                 # staggered peer order: rank r starts with r + 1
+                to, frm = (self.rank + off) % self.world_size, (self.rank - off) % self.world_size
+                ops.append(dist.P2POp(dist.isend, mine, to, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, flat[frm * n:(frm + 1) * n], frm, group=self.group))
+            works = dist.batch_isend_irecv(ops)
+            if async_op: return works
+            for w in works: w.wait()
+            return None
         return dist.all_gather_into_tensor(flat, flat[self.rank * n:(self.rank + 1) * n], group=self.group, async_op=async_op)
 
     def _exchange_finish(self, work, buf: torch.Tensor, it: int = 0):
-        if work is not None: work.wait()                      # a stream dependency on the collective, not a host wait (RCCL)
+        if work is None: return
+        for w in (work if isinstance(work, (list, tuple)) else [work]): w.wait()     # stream dependencies, not host waits (RCCL)
 
     def exchange_bytes(self) -> int:
         """Bytes this rank RECEIVES per iteration."""
@@ -613,11 +630,42 @@ def choose_exchange(graph: GraphObject, world_size: int) -> str:
 
 
 def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, device, group=None, exchange: str = 'auto',
-                      overlap: bool = True):
-    """`exchange`: 'allgather' (whole slices, one all-gather), 'halo' (only the rows each peer reads, one all-to-all), or
-    'auto' = halo when it moves less than half of what the all-gather would (graphs with locality, block-diagonal
-    batches), all-gather otherwise (Erdős–Rényi graphs: every slice is almost entirely somebody's halo)."""
-    if exchange not in ('auto', 'allgather', 'halo'): raise ValueError('exchange must be auto, allgather or halo')
-    if exchange == 'auto': exchange = choose_exchange(graph, world_size)
-    cls = HaloShardedLoop if exchange == 'halo' else ShardedLoop
-    return cls(model, graph, rank, world_size, device, group=group, overlap=overlap)
+                      overlap: bool = True, measure: bool = True):
+    """`exchange`:
+        'allgather' whole slices with RCCL's all-gather collective;
+        'direct'    whole slices as R - 1 concurrent point-to-point pairs (one-hop all-gather over the xGMI mesh);
+        'halo'      only the rows each peer reads, one all-to-all of uneven splits;
+        'auto'      halo when it moves less than half of the all-gather volume for every rank (graphs with locality,
+                    block-diagonal batches); otherwise the whole-slice layout, and - with `measure` and more than one rank - the
+                    faster of its two transports on THIS machine: both are timed on the real buffers (3 exchanges each, the
+                    slowest rank's time decides, so every rank picks the same one).  Which collective wins depends on how RCCL
+                    maps it onto the xGMI links, which cannot be known from here: measured, not guessed."""
+    if exchange not in ('auto', 'allgather', 'direct', 'halo'): raise ValueError('exchange must be auto, allgather, direct or halo')
+    pick = exchange
+    if exchange == 'auto': pick = choose_exchange(graph, world_size)
+    if pick == 'halo':
+        return HaloShardedLoop(model, graph, rank, world_size, device, group=group, overlap=overlap)
+    sl = ShardedLoop(model, graph, rank, world_size, device, group=group, overlap=overlap)
+    if pick == 'direct': sl.transport = 'direct'
+    if exchange == 'auto' and measure and world_size > 1:
+        sl.transport, sl.transport_times = pick_transport(sl)
+    return sl
+
+
+def pick_transport(sl: 'ShardedLoop', reps: int = 3):
+    """Time the two whole-slice transports on `sl`'s own buffers; returns (name of the faster, {name: seconds per exchange}).
+    Collective call. The decision uses the MAX over ranks, so all ranks agree."""
+    import time
+    times = {}
+    sync = (lambda: torch.cuda.synchronize(sl.device)) if sl.device.type == 'cuda' else (lambda: None)
+    for name in ('ring', 'direct'):
+        sl.transport = name
+        sl._exchange(sl.buf[1], 0)                                   # warm-up (connection set-up)
+        sync(); dist.barrier(group=sl.group)
+        t0 = time.perf_counter()
+        for _ in range(reps): sl._exchange(sl.buf[1], 0)
+        sync()
+        t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=sl.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=sl.group)
+        times[name] = float(t)
+    return min(times, key=times.get), times

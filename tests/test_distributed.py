@@ -203,13 +203,22 @@ def _problem(threshold, d=6, max_it=12):
     return g, model, s0
 
 
-def _worker(rank, world, port, threshold, d, out_q, halo=False, overlap=False):
+def _worker(rank, world, port, threshold, d, out_q, halo=False, overlap=False, transport=None):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         g, model, s0 = _problem(threshold, d)
         sl = (OracleHaloShardedLoop if halo else OracleShardedLoop)(model, g, rank, world, 'cpu', overlap=overlap)
         assert sl.overlap == overlap
+        if transport == 'measured':
+            from gnnkeras_amd.distributed import pick_transport
+            sl.transport, times = pick_transport(sl, reps=2)
+            assert set(times) == {'ring', 'direct'} and sl.transport in times
+            names = [None] * world
+            dist.all_gather_object(names, sl.transport)
+            assert len(set(names)) == 1                              # every rank picked the same transport
+        elif transport:
+            sl.transport = transport
         k, state, out = sl.forward(s0)
         out_q.put((rank, float(k), state.numpy(), out.numpy(), sl.plan.lo, sl.plan.hi))
     finally:
@@ -326,3 +335,24 @@ def test_split_csr_partitions_every_row_in_order():
             row = c.src[c.rowptr[j]:c.rowptr[j + 1]]
             a, b = own.src[own.rowptr[j]:own.rowptr[j + 1]], halo.src[halo.rowptr[j]:halo.rowptr[j + 1]]
             assert np.array_equal(a, row[(row >= lo) & (row < hi)]) and np.array_equal(b, row[(row < lo) | (row >= hi)])
+
+
+@pytest.mark.parametrize('transport,overlap', [('direct', False), ('direct', True), ('measured', True)])
+def test_whole_slice_transports_agree(transport, overlap):
+    """The one-hop all-gather (R - 1 concurrent send / receive pairs) moves the same slices as the all-gather collective, and
+    the measured choice between the two is the same on every rank."""
+    world, threshold, d = 3, 0.02, 6
+    g, model, s0 = _problem(threshold, d)
+    seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False, device='cpu')
+    k_ref, st_ref, out_ref = oracle_loop(model, seq[0][0], s0, np.float64)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 977 + 31 * overlap + 7 * len(transport)) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, threshold, d, q, False, overlap, transport)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=180) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] == float(k_ref) for r in res)
+    assert rel_err(np.concatenate([r[2] for r in res]), st_ref) < 1e-6 and rel_err(np.concatenate([r[3] for r in res]), out_ref) < 1e-6

@@ -44,10 +44,11 @@ WORKER = textwrap.dedent('''
         model = GNNnodeBased(ns, no, d, 6, threshold)
         x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False, device=dev)[0][0]
         k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
-        for exchange in ('allgather', 'halo'):
+        for exchange in ('allgather', 'direct', 'halo', 'auto'):
             for overlap in (False, True):
                 sl = make_sharded_loop(model, g, rank, world, dev, exchange=exchange, overlap=overlap)
                 assert sl.overlap == overlap, 'split refused'
+                if exchange == 'auto' and world > 1: assert sl.transport in ('ring', 'direct') and len(sl.transport_times) == 2
                 k, st, o = sl.forward(torch.from_numpy(s0).to(dev))
                 torch.cuda.synchronize()
                 lo, hi = sl.plan.lo, sl.plan.hi

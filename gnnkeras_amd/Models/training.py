@@ -586,11 +586,112 @@ class LoopTrainer:
         return list(zip(grads, variables))
 
     # ---- one training step ------------------------------------------------------------------------------------------------
+    # ---- the whole step inside the library (homogeneous models): gnn_train_step -------------------------------------------------
+    use_native_step = True          # False: always the general path below (tests compare the two)
+
+    def _native_step_applies(self, y):
+        m = self.model
+        if not self.use_native_step or isinstance(m.net_state, (list, tuple)) or y is None: return False
+        kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
+        return str(kind).lower() in nat.LOSSES
+
+    def _train_step_native(self, x_list, y, sample_weight, state0, seed, apply):
+        """One `gnn_train_step` call: training-mode forward, loss, BPTT; the tape and every scratch buffer live in one cached
+        device allocation. Same results as the general path (same kernels for the arithmetic), ~2.5x fewer launches and no
+        Python between them."""
+        from types import SimpleNamespace
+        from .GNN import _squeeze_last, _arc_endpoints
+        m = self.model
+        _check_no_dropout([m.net_state, m.net_output])
+        nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph = m.process_inputs(x_list)
+        nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs')
+        dev = nodes.device
+        self.prim = p = _Prim(dev)
+        nodes = nodes.to(torch.float32).contiguous(); arcs = arcs.to(torch.float32).contiguous()
+        N, L = nodes.shape
+        d = m.state_vect_dim
+        S = d if d > 0 else L
+        focus = m._focus
+        m.net_state.to(dev); m.net_output.to(dev)
+        gs, go = _NetGrads(m.net_state, p), _NetGrads(m.net_output, p)
+        self.gs, self.go = gs, go
+        out_index = m._out_index(_squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev))
+        adj, an = adjacency.device_csr(dev), arcnode.device_csr(dev)
+        keep = [nodes, arcs, adj, an, out_index]
+        ta = nat.TrainArgs()
+        a = ta.loop
+        a.abi_version, a.composite = nat.GNN_ABI_VERSION, 0
+        a.n_nodes, a.n_arcs, a.dim_node_label, a.dim_arc_label = N, arcs.shape[0], L, arcs.shape[1] - 2
+        a.nodes, a.ld_nodes = nat.ptr(nodes), L
+        a.arc_labels, a.ld_arcs = C.c_void_p(arcs.data_ptr() + 8), arcs.shape[1]
+        a.adjacency, a.arcnode = nat.make_csr(adj), nat.make_csr(an)
+        a.n_types = 1
+        a.net_state[0] = m.net_state.native()
+        a.net_output = m.net_output.native()
+        a.state_dim, a.max_iteration, a.state_threshold = d, m.max_iteration, float(m.state_threshold)
+        if d > 0:
+            if state0 is None:
+                gen = None
+                if seed is not None:
+                    gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
+                state0 = torch.randn((N, d), generator=gen, device=dev, dtype=torch.float32) * 0.1
+            state0 = state0.to(dev, torch.float32).contiguous()
+            if tuple(state0.shape) != (N, d): raise ValueError('state0 must be (n_nodes, state_vect_dim)')
+            a.state0 = nat.ptr(state0); keep.append(state0)
+        a.focus = nat.FOCUS[focus]
+        a.n_out, a.out_index = len(out_index), nat.ptr(out_index)
+        ta.adjacency_by_source = nat.make_csr(_by_source(adjacency, dev))
+        if focus == 'a':
+            es, ed = _arc_endpoints(adjacency, dev)
+            a.arc_src, a.arc_dst = nat.ptr(es), nat.ptr(ed); keep += [es, ed]
+        n_rows = len(out_index)
+        if focus == 'g':
+            ng = nodegraph.device_csr(dev)
+            a.nodegraph = nat.make_csr(ng); keep.append(ng)
+            ta.nodegraph_by_source = nat.make_csr(_by_source(nodegraph, dev))
+            n_rows = ng['n_dst']
+        a.stream = p.stream()
+        yd = y.to(dev, torch.float32).contiguous()
+        if yd.shape[0] != n_rows: raise ValueError(f'targets have {yd.shape[0]} rows, the model outputs {n_rows}')
+        sw = None if sample_weight is None else sample_weight.to(dev, torch.float32).contiguous()
+        ta.targets, ta.sample_weight = nat.ptr(yd), nat.ptr(sw)
+        kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
+        ta.loss_kind = nat.LOSSES[str(kind).lower()]
+        ta.average_st_grads = 0          # finish() divides by k AFTER adding the weight penalties, like the reference (GNN.py:295)
+        ta.bn_momentum = BN_MOMENTUM
+        for g_, ng_ in ((ta.grad_state, gs), (ta.grad_output, go)):
+            if ng_.bn: g_.dgamma, g_.dbeta = nat.ptr(ng_.dgamma), nat.ptr(ng_.dbeta)
+            for l in range(len(ng_.W)): g_.dkernel[l], g_.dbias[l] = ng_.dW[l].data_ptr(), ng_.db[l].data_ptr()
+        T = m.net_output.units[-1]
+        y_pred, state = p.new(n_rows, T), p.new(N, S)
+        loss = p.new(1)
+        k_host = C.c_int32(0)
+        ta.y_pred, ta.state, ta.loss, ta.k_host = nat.ptr(y_pred), nat.ptr(state), nat.ptr(loss), C.pointer(k_host)
+        nbytes = nat.lib().gnn_train_workspace_bytes(C.byref(ta))
+        if nbytes == 0: nat.check(1)
+        tape = getattr(self, '_tape', None)
+        if tape is None or tape.numel() < nbytes + 256 or tape.device != dev:
+            tape = self._tape = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+        base = tape.data_ptr()
+        aligned = (base + 255) & ~255
+        ta.tape, ta.tape_bytes = C.c_void_p(aligned), tape.numel() - (aligned - base)
+        nat.check(nat.lib().gnn_train_step(C.byref(ta)))
+        gs.touched = k_host.value > 0
+        go.touched = len(out_index) > 0
+        tp = SimpleNamespace(gs=[gs], go=go, k=int(k_host.value), y_pred=y_pred, state=state)
+        res = {'k': tp.k, 'y_pred': y_pred, 'state': state, 'loss': loss[0]}
+        reg = self.finish(tp, apply)
+        if reg is not None: res['loss'] = res['loss'] + reg
+        return res
+
     def train_step(self, x_list, y, sample_weight, state0=None, seed=None, apply=True):
         """Returns dict(loss=..., k=..., y_pred=tensor). Gradients stay in self.gs (list for composite models) / self.go;
-        `apply` runs the optimizer. Homogeneous models are the one-type case (reference GNN.py:277-306); composite models
-        (CompositeGNN.py:275-304) run one state network per node type on that type's rows."""
+        `apply` runs the optimizer. Homogeneous models are the one-type case (reference GNN.py:277-306) and run the whole step
+        inside the library (`gnn_train_step`); composite models (CompositeGNN.py:275-304) run one state network per node type on
+        that type's rows through the general path below."""
         m = self.model
+        if self._native_step_applies(y):
+            return self._train_step_native(x_list, y, sample_weight, state0, seed, apply)
         tp = self.forward(x_list, state0=state0, seed=seed)
         res = {'k': tp.k, 'y_pred': tp.y_pred, 'state': tp.state}
         if y is None:

@@ -32,7 +32,7 @@ EXPORTS = ['gnn_last_error', 'gnn_last_kernel_name', 'gnn_abi_version', 'gnn_str
            'gnn_dense', 'gnn_fold_bn', 'gnn_dense_grad_workspace_bytes', 'gnn_dense_grad', 'gnn_act_grad',
            'gnn_colstats_workspace_bytes', 'gnn_colstats', 'gnn_first_layer_param_grads', 'gnn_bn_input_grad',
            'gnn_scatter_add_rows', 'gnn_axpby', 'gnn_loss_grad', 'gnn_adam_step', 'gnn_sgd_step',
-           'gnn_converged_gated', 'gnn_aggregate_gated']
+           'gnn_converged_gated', 'gnn_aggregate_gated', 'gnn_train_workspace_bytes', 'gnn_train_step']
 GNN_MAX_SEGMENTS = 6
 LOSSES = {'categorical_crossentropy': 0, 'cce': 0, 'binary_crossentropy': 1, 'bce': 1, 'mse': 2,
           'mean_squared_error': 2, 'mae': 3, 'mean_absolute_error': 3}
@@ -86,6 +86,20 @@ class DenseArgs(C.Structure):
                 ('addend', C.c_void_p), ('ld_addend', C.c_int32), ('addend_rowidx', C.c_void_p),
                 ('activation', C.c_int32), ('Y', C.c_void_p), ('ldy', C.c_int32), ('out_rowidx', C.c_void_p),
                 ('gate', C.c_void_p), ('stream', C.c_void_p)]
+
+
+class MLPGrads(C.Structure):
+    _fields_ = [('dgamma', C.c_void_p), ('dbeta', C.c_void_p),
+                ('dkernel', C.c_void_p * GNN_MAX_LAYERS), ('dbias', C.c_void_p * GNN_MAX_LAYERS)]
+
+
+class TrainArgs(C.Structure):
+    _fields_ = [('loop', LoopArgs), ('adjacency_by_source', CSR), ('nodegraph_by_source', CSR),
+                ('targets', C.c_void_p), ('sample_weight', C.c_void_p), ('loss_kind', C.c_int32),
+                ('average_st_grads', C.c_int32), ('bn_momentum', C.c_float),
+                ('grad_state', MLPGrads), ('grad_output', MLPGrads),
+                ('y_pred', C.c_void_p), ('state', C.c_void_p), ('loss', C.c_void_p), ('k_host', C.POINTER(C.c_int32)),
+                ('tape', C.c_void_p), ('tape_bytes', C.c_size_t)]
 
 
 class NativeError(RuntimeError):
@@ -163,6 +177,8 @@ def lib():
             'gnn_sgd_step': (C.c_int, [vp, vp, vp, sz, f32, f32, vp]),
             'gnn_converged_gated': (C.c_int, [vp, vp, i32, i32, i32, f32, vp, vp, vp, f32, vp]),
             'gnn_aggregate_gated': (C.c_int, [C.POINTER(CSR), vp, i32, i32, vp, i32, vp, vp]),
+            'gnn_train_workspace_bytes': (sz, [C.POINTER(TrainArgs)]),
+            'gnn_train_step': (C.c_int, [C.POINTER(TrainArgs)]),
         }
         for name, (res, args) in protos.items():
             fn = getattr(l, name)
@@ -172,7 +188,8 @@ def lib():
         if l.gnn_abi_version() != GNN_ABI_VERSION:
             raise NativeError('libgnnloop.so ABI version mismatch: rebuild it')
         if (l.gnn_struct_size(0), l.gnn_struct_size(1), l.gnn_struct_size(2), l.gnn_struct_size(3)) != \
-                (C.sizeof(CSR), C.sizeof(MLP), C.sizeof(LoopArgs), LoopArgs.flags.offset):
+                (C.sizeof(CSR), C.sizeof(MLP), C.sizeof(LoopArgs), LoopArgs.flags.offset) or \
+                (l.gnn_struct_size(4), l.gnn_struct_size(5)) != (C.sizeof(TrainArgs), TrainArgs.tape.offset):
             raise NativeError('ctypes struct layout does not match libgnnloop.so: rebuild it')
         _lib = l
     return _lib

@@ -246,6 +246,9 @@ struct MlpRun {
     float *hid[2] = {nullptr, nullptr}; int ld_hid = 0;
     float *Y = nullptr; int ldy = 0; const int *out_rowidx = nullptr;
     const int *gate = nullptr;
+    // optional: the convergence predicate in the last layer's epilogue (homogeneous models, 4 < width <= 64, no softmax)
+    const float *pred_old = nullptr; int ld_pred = 0; float pred_thr = 0.f; int *pred_flag = nullptr; float *pred_k = nullptr; float pred_kval = 0.f;
+    mutable bool pred_fused = false;
 };
 
 int run_mlp(const MlpRun &r, hipStream_t st) {
@@ -277,6 +280,11 @@ int run_mlp(const MlpRun &r, hipStream_t st) {
         a.act = (m.activation[l] == GNN_ACT_SOFTMAX && !thin_softmax) ? GNN_ACT_LINEAR : m.activation[l];
         if (last) { a.Y = r.Y; a.ldy = r.ldy; a.out_rowidx = r.out_rowidx; }
         else      { a.Y = r.hid[l & 1]; a.ldy = r.ld_hid; a.out_rowidx = nullptr; }
+        if (last && r.pred_flag && !r.out_rowidx && a.H <= 64 && a.H > 4 && m.activation[l] != GNN_ACT_SOFTMAX) {
+            a.pred_old = r.pred_old; a.ld_pred = r.ld_pred; a.pred_thr = r.pred_thr; a.pred_flag = r.pred_flag;
+            a.pred_k = r.pred_k; a.pred_kval = r.pred_kval;
+            r.pred_fused = true;
+        }
         TRY(launch_segdense(a, st));
         if (m.activation[l] == GNN_ACT_SOFTMAX && !thin_softmax) TRY(launch_softmax(r.gate, a.Y, a.M, a.H, a.ldy, a.out_rowidx, st));
         cur = a.Y; cur_ld = a.ldy;
@@ -482,6 +490,7 @@ int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, 
     TRY(launch_aggregate(gate, iter_adjacency(a, p), src_full, p.SP, p.SP <= 128 ? p.SP : p.S, p.agg, p.SP, st));
     const float *src = src_full + (size_t)row_base * p.SP;     // own rows
     float *dst = dst_full + (size_t)row_base * p.SP;
+    bool pred_fused = false;
     for (int t = 0; t < p.T; ++t) {
         const TypePlan &tp = p.tp[t];
         if (tp.count == 0) continue;
@@ -495,9 +504,13 @@ int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, 
         r.hid[0] = p.hid[0]; r.hid[1] = p.hid[1]; r.ld_hid = p.ld_hid;
         r.Y = dst; r.ldy = p.SP; r.out_rowidx = tp.rows;
         r.gate = gate;
+        if (flag_next && p.T == 1 && !tp.rows) {        // one network over all rows: the predicate rides in its last layer's epilogue
+            r.pred_old = src; r.ld_pred = p.SP; r.pred_thr = a.state_threshold; r.pred_flag = flag_next; r.pred_k = k_out; r.pred_kval = k_val;
+        }
         TRY(run_mlp(r, st));
+        pred_fused |= r.pred_fused;
     }
-    if (flag_next) TRY(launch_converge(gate, dst, src, p.N, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
+    if (flag_next && !pred_fused) TRY(launch_converge(gate, dst, src, p.N, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
     return 0;
 }
 
@@ -767,6 +780,8 @@ size_t gnn_struct_size(int which) {
         case 1: return sizeof(gnn_mlp_t);
         case 2: return sizeof(gnn_loop_args_t);
         case 3: return offsetof(gnn_loop_args_t, flags);
+        case 4: return sizeof(gnn_train_args_t);
+        case 5: return offsetof(gnn_train_args_t, tape);
         default: return 0;
     }
 }
@@ -1038,3 +1053,4 @@ int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const 
 }  // extern "C"
 
 #include "train_api.hpp"
+#include "train_loop.hpp"

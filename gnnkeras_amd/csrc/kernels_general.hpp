@@ -116,6 +116,12 @@ struct SegDenseArgs {
     const float *addend; int ld_add; const int *add_rowidx;
     int act;
     float *Y; int ldy; const int *out_rowidx;
+    // optional fused convergence predicate (k_segdense only, H <= 64, out_rowidx == NULL): the rows just computed are the new
+    // state, `pred_old` the previous one: *pred_flag |= any_row(||new - old|| > thr ||old||), *pred_k = pred_kval
+    const float *pred_old; int ld_pred; float pred_thr; int *pred_flag; float *pred_k; float pred_kval;
+    // optional training-mode BatchNormalization applied to the input columns as they are staged (k_segdense only):
+    // x'[k] = (x[k] - mean[k]) gamma[k] / sqrt(var[k] + eps) + beta[k] for column k of the virtual concatenation
+    const float *in_gamma, *in_beta, *in_mean, *in_var; float in_eps;
 };
 
 constexpr int SD_TM = 64, SD_TN = 64, SD_KC = 32, SD_LDX = 34, SD_LDW = 80, SD_LDY = 68;
@@ -162,11 +168,19 @@ __global__ void __launch_bounds__(256, SC == 1 ? 8 : 4) k_segdense(SegDenseArgs 
                     if (s < a.nseg) start += a.seg[s].width;
                 }
                 const int off = kv - sbeg;
+                float bn_a = 1.0f, bn_c = 0.0f;
+                if (a.in_gamma && kv < K) {
+                    bn_a = a.in_gamma[kv] / sqrtf(a.in_var[kv] + a.in_eps);
+                    bn_c = a.in_beta[kv] - a.in_mean[kv] * bn_a;
+                }
 #pragma unroll
                 for (int pass = 0; pass < 8; ++pass) {
                     const int m = m0 + xr0 + 8 * pass;
                     xv[sc][pass] = 0.0f;
-                    if (m < a.M && kv < K) xv[sc][pass] = sg.ptr[(sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m) * sg.ld + off];
+                    if (m < a.M && kv < K) {
+                        const float x = sg.ptr[(sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m) * sg.ld + off];
+                        xv[sc][pass] = a.in_gamma ? fmaf(x, bn_a, bn_c) : x;
+                    }
                 }
                 // ---- W chunk: weight rows of the virtual columns (row = seg.wrow + offset inside the segment) ----
 #pragma unroll
@@ -211,16 +225,36 @@ __global__ void __launch_bounds__(256, SC == 1 ? 8 : 4) k_segdense(SegDenseArgs 
         __syncthreads();
         const int col = n0 + lane;
         const float bcol = (a.bias && col < a.H) ? a.bias[col] : 0.0f;
+        int moving = 0;
 #pragma unroll 4
         for (int pass = 0; pass < 16; ++pass) {                 // a wave writes one 256-B row piece per instruction
             const int yr = wave + 4 * pass, m = m0 + yr;
+            float d2 = 0.0f, o2 = 0.0f;
             if (m < a.M && col < a.H) {
                 float v = Ys[yr * SD_LDY + lane] + bcol;
                 if (a.addend) v += a.addend[(a.add_rowidx ? (size_t)a.add_rowidx[m] : (size_t)m) * a.ld_add + col];
-                a.Y[(a.out_rowidx ? (size_t)a.out_rowidx[m] : (size_t)m) * a.ldy + col] = activate(a.act, v);
+                v = activate(a.act, v);
+                a.Y[(a.out_rowidx ? (size_t)a.out_rowidx[m] : (size_t)m) * a.ldy + col] = v;
+                if (a.pred_flag) {
+                    const float o = a.pred_old[(size_t)m * a.ld_pred + col];
+                    d2 = (v - o) * (v - o); o2 = o * o;
+                }
+            }
+            if (a.pred_flag) {                                  // wave-uniform: the whole row lives in this wave (H <= 64)
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { d2 += __shfl_xor(d2, off, 64); o2 += __shfl_xor(o2, off, 64); }
+                if (m < a.M && sqrtf(d2) > a.pred_thr * sqrtf(o2)) moving = 1;
             }
         }
-        __syncthreads();
+        if (a.pred_flag) {
+            moving = __syncthreads_or(moving);
+            if (tid == 0) {
+                if (moving) atomicOr(a.pred_flag, 1);
+                if (blockIdx.x == 0 && a.pred_k) *a.pred_k = a.pred_kval;
+            }
+        } else {
+            __syncthreads();
+        }
     }
 }
 

@@ -224,14 +224,37 @@ k_bn_moving_update(const float *__restrict__ mean, const float *__restrict__ var
 //   sum_r dy[r,k]       = (W q)_k               =: S1_k      -> dbeta_k (+)= S1_k
 //   sum_r dy[r,k] x[r,k] = sum_h W[k,h] P[k,h]  =: S2_k      -> dgamma_k (+)= rstd_k (S2_k - mean_k S1_k)
 //   m1_k = S1_k / M ,  m2_k = rstd_k (S2_k - mean_k S1_k) / M     (consumed by k_bn_input_grad)
-// One thread per input feature k.
-__global__ void __launch_bounds__(256)
+// One 64-lane workgroup per input feature k (lanes stride over the H outputs, the two dot products meet in a fixed
+// shuffle tree); workgroup 0 also writes the bias gradient.  grid = K.
+// `n_chunks` > 1: P and q are still chunk partials ([chunk][K*H + H], the output of k_dense_grad_partial*): each value is
+// summed here in chunk order (small batches: saves the reduction launch); n_chunks <= 1: P [K x H] and q [H] are final.
+__global__ void __launch_bounds__(64)
 k_first_layer_param_grads(const float *__restrict__ P, const float *__restrict__ q, const float *__restrict__ W, int K,
                           int H, const float *gamma, const float *beta, const float *mean, const float *var, float eps,
                           float inv_m, float *__restrict__ dW, float *__restrict__ db, float *dgamma, float *dbeta,
-                          float *m1, float *m2, int accumulate) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < H && db) db[k] = accumulate ? db[k] + q[k] : q[k];        // H bias entries handled by the first H threads
+                          float *m1, float *m2, int accumulate, int n_chunks = 1) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const size_t cstride = (size_t)K * H + H;
+    auto sum_chunks = [&](const float *base) -> float {         // 8 loads in flight, summed in chunk order
+        float s = 0.0f;
+        int c = 0;
+        for (; c + 8 <= n_chunks; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(c + u) * cstride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c < n_chunks; ++c) s += base[(size_t)c * cstride];
+        return s;
+    };
+    auto q_at = [&](int h) -> float { return sum_chunks(q + h); };
+    auto p_at = [&](int h) -> float { return sum_chunks(P + (size_t)k * H + h); };
+    if (n_chunks > 1) {
+        if (k == 0 && db)
+            for (int h = lane; h < H; h += 64) { const float qh = q_at(h); db[h] = accumulate ? db[h] + qh : qh; }
+    } else if (k == 0 && db)
+        for (int h = lane; h < H; h += 64) db[h] = accumulate ? db[h] + q[h] : q[h];
     if (k >= K) return;
     float a = 1.0f, c = 0.0f, rstd = 1.0f, mu = 0.0f;
     if (gamma) {
@@ -241,18 +264,23 @@ k_first_layer_param_grads(const float *__restrict__ P, const float *__restrict__
         c = beta[k] - mu * a;
     }
     float S1 = 0.0f, S2 = 0.0f;
-    for (int h = 0; h < H; ++h) {
-        const float w = W[(size_t)k * H + h], p = P[(size_t)k * H + h];
-        S1 = fmaf(w, q[h], S1);
+    for (int h = lane; h < H; h += 64) {
+        const float w = W[(size_t)k * H + h];
+        const float p = n_chunks > 1 ? p_at(h) : P[(size_t)k * H + h], qh = n_chunks > 1 ? q_at(h) : q[h];
+        S1 = fmaf(w, qh, S1);
         S2 = fmaf(w, p, S2);
-        const float gw = a * p + c * q[h];
+        const float gw = a * p + c * qh;
         dW[(size_t)k * H + h] = accumulate ? dW[(size_t)k * H + h] + gw : gw;
     }
     if (gamma) {
-        const float dg = rstd * (S2 - mu * S1);
-        dgamma[k] = accumulate ? dgamma[k] + dg : dg;
-        dbeta[k] = accumulate ? dbeta[k] + S1 : S1;
-        if (m1) { m1[k] = S1 * inv_m; m2[k] = dg * inv_m; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { S1 += __shfl_xor(S1, off, 64); S2 += __shfl_xor(S2, off, 64); }
+        if (lane == 0) {
+            const float dg = rstd * (S2 - mu * S1);
+            dgamma[k] = accumulate ? dgamma[k] + dg : dg;
+            dbeta[k] = accumulate ? dbeta[k] + S1 : S1;
+            if (m1) { m1[k] = S1 * inv_m; m2[k] = dg * inv_m; }
+        }
     }
 }
 
@@ -357,6 +385,216 @@ k_sgd(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ mo
         if (mom) { const float vel = mom[i] = momentum * mom[i] - lr * g[i]; p[i] += vel; }
         else p[i] -= lr * g[i];
     }
+}
+
+}  // namespace gnn
+
+// =====================================================================================================================
+// Kernels of the in-library training step (train_loop.hpp: gnn_train_step): the same arithmetic as the building blocks
+// above, with the per-segment launches of a layer folded into one launch each (a MUTAG-sized train step is bound by
+// the NUMBER of launches: ~1 800 before, ~700 with these).
+// =====================================================================================================================
+namespace gnn {
+
+// ---- column statistics of several segments of a virtual concatenation in ONE launch (M <= 8192 rows) -----------------
+struct StatSegs {
+    Seg seg[GNN_MAX_SEGS];            // wrow = position of the segment's first column in mean / var
+    int n;
+    int col_begin[GNN_MAX_SEGS + 1];  // workgroup ranges: segment s owns workgroups [col_begin[s], col_begin[s + 1])
+};
+__global__ void __launch_bounds__(256)
+k_colstats_segs_small(const int *gate, StatSegs ss, int M, float *__restrict__ mean, float *__restrict__ var) {
+    if (gate_closed(gate)) return;
+    __shared__ float part[256];
+    int s = 0;
+#pragma unroll
+    for (int t = 1; t < GNN_MAX_SEGS; ++t)
+        if (t < ss.n && (int)blockIdx.x >= ss.col_begin[t]) s = t;
+    Seg sg = ss.seg[0]; int cb = ss.col_begin[0];
+#pragma unroll
+    for (int t = 1; t < GNN_MAX_SEGS; ++t)
+        if (s == t) { sg = ss.seg[t]; cb = ss.col_begin[t]; }
+    const int k = blockIdx.x - cb, tid = threadIdx.x;
+    float xs[32];
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int m = tid + 256 * i;
+        xs[i] = m < M ? sg.ptr[(sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m) * sg.ld + k] : 0.0f;
+        acc += xs[i];
+    }
+    part[tid] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) part[tid] += part[tid + off];
+        __syncthreads();
+    }
+    const float mu = part[0] / (float)M;
+    __syncthreads();
+    acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int m = tid + 256 * i;
+        const float d = xs[i] - mu;
+        if (m < M) acc = fmaf(d, d, acc);
+    }
+    part[tid] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) part[tid] += part[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) { mean[sg.wrow + k] = mu; var[sg.wrow + k] = part[0] / (float)M; }
+}
+
+// ---- weight-gradient GEMM over a virtual concatenation: every segment's K-blocks in one launch -------------------------
+struct GradSegs {
+    Seg seg[GNN_MAX_SEGS];            // wrow = first row of the segment in P
+    int n;
+    int blk_begin[GNN_MAX_SEGS + 1];  // blockIdx.y ranges (64 rows of K per block)
+};
+__global__ void __launch_bounds__(256)
+k_dense_grad_partial_segs(GradSegs gs, int K, const float *__restrict__ dZ, int ldz, int H, int M, int rows_per_chunk,
+                          float *__restrict__ part) {                 // part: [chunk][K*H (P) + H (q)]
+    __shared__ float Xs[64 * DG_LD];
+    __shared__ float Zs[64 * DG_LD];
+    int s = 0;
+#pragma unroll
+    for (int t = 1; t < GNN_MAX_SEGS; ++t)
+        if (t < gs.n && (int)blockIdx.y >= gs.blk_begin[t]) s = t;
+    Seg sg = gs.seg[0]; int bb = gs.blk_begin[0];
+#pragma unroll
+    for (int t = 1; t < GNN_MAX_SEGS; ++t)
+        if (s == t) { sg = gs.seg[t]; bb = gs.blk_begin[t]; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int k0 = ((int)blockIdx.y - bb) * 64, h0 = blockIdx.z * 64;
+    const int m_beg = blockIdx.x * rows_per_chunk, m_end = min(M, m_beg + rows_per_chunk);
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float qacc = 0.0f;
+    for (int m0 = m_beg; m0 < m_end; m0 += 64) {
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int mm = i / 64, cc = i % 64, m = m0 + mm;
+            float xv = 0.0f, zv = 0.0f;
+            if (m < m_end) {
+                if (k0 + cc < sg.width) xv = sg.ptr[(sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m) * sg.ld + k0 + cc];
+                if (h0 + cc < H) zv = dZ[(size_t)m * ldz + h0 + cc];
+            }
+            Xs[mm * DG_LD + cc] = xv;
+            Zs[mm * DG_LD + cc] = zv;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const float av = Xs[(4 * s4 + g) * DG_LD + 16 * wave + r];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Zs[(4 * s4 + g) * DG_LD + 16 * c + r], acc[c], 0, 0, 0);
+        }
+        if (blockIdx.y == 0 && tid < 64) {
+            for (int mm = 0; mm < 64; ++mm) qacc += Zs[mm * DG_LD + tid];
+        }
+        __syncthreads();
+    }
+    float *Pp = part + (size_t)blockIdx.x * ((size_t)K * H + H);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int h = h0 + 16 * c + r;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int k = k0 + 16 * wave + 4 * g + reg;
+            if (k < sg.width && h < H) Pp[(size_t)(sg.wrow + k) * H + h] = acc[c][reg];
+        }
+    }
+    if (blockIdx.y == 0 && tid < 64 && h0 + tid < H) Pp[(size_t)K * H + h0 + tid] = qacc;
+}
+
+// ---- input gradients through a training-mode BatchNormalization for up to 4 column blocks, in place ---------------------
+struct BnGradReq { float *dy; int ld_dy; const float *x; int ld_x; const int *rowidx; int width, k0; };
+struct BnGradArgs { BnGradReq r[4]; int n, M; const float *gamma, *mean, *var, *m1, *m2; float eps; };
+__global__ void __launch_bounds__(256) k_bn_input_grad_segs(BnGradArgs a) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q >= a.n) break;
+        const BnGradReq rq = a.r[q];
+        const size_t total = (size_t)a.M * rq.width;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const size_t m = i / rq.width;
+            const int j = (int)(i % rq.width), k = rq.k0 + j;
+            const float rstd = 1.0f / sqrtf(a.var[k] + a.eps);
+            const float xhat = (rq.x[(rq.rowidx ? (size_t)rq.rowidx[m] : m) * rq.ld_x + j] - a.mean[k]) * rstd;
+            float *p = rq.dy + m * rq.ld_dy + j;
+            *p = a.gamma[k] * rstd * (*p - a.m1[k] - xhat * a.m2[k]);
+        }
+    }
+}
+
+// ---- the k moving-average updates of a network applied k times in a row, in order (Keras: one per call) ----------------
+__global__ void __launch_bounds__(256)
+k_bn_moving_multi(const float *__restrict__ stats, int stride, int steps, int K, float *moving_mean, float *moving_var, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= K) return;
+    float mm = moving_mean[c], mv = moving_var[c];
+    for (int t = 0; t < steps; ++t) {
+        mm = mm * momentum + stats[(size_t)t * stride + c] * (1.0f - momentum);
+        mv = mv * momentum + stats[(size_t)t * stride + K + c] * (1.0f - momentum);
+    }
+    moving_mean[c] = mm; moving_var[c] = mv;
+}
+
+// rows[t][0:n] = src[0:n] for t < reps (the iteration-invariant columns of every iteration's statistics vector)
+__global__ void __launch_bounds__(256) k_replicate(const float *__restrict__ src, int n, int reps, float *__restrict__ rows) {
+    const size_t total = (size_t)n * reps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) rows[i] = src[i % n];
+}
+
+// out[0] = scale * sum(in[0:n]): one workgroup, fixed summation tree
+__global__ void __launch_bounds__(256) k_sum_scale(const float *__restrict__ in, int n, float scale, float *__restrict__ out) {
+    __shared__ float part[256];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) s += in[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0] * scale;
+}
+
+// Wt[h][k] = W[k][h]
+__global__ void __launch_bounds__(256) k_transpose(const float *__restrict__ W, int K, int H, float *__restrict__ Wt) {
+    const int total = K * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) Wt[(size_t)(i % H) * K + i / H] = W[i];
+}
+
+// out[j, :F] = addend[j, :F] + row_scale[j] * sum_e w_e X[src_e, :F]: the transposed aggregate of the backward sweep with
+// the own-state gradient folded in (G_state = dx_state + Adj . dx_agg)
+template <int G>
+__global__ void __launch_bounds__(256)
+k_aggregate_add(int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src, const float *__restrict__ w,
+                const float *__restrict__ row_scale, const float *__restrict__ X, int ldx, int F, const float *__restrict__ addend,
+                int ld_add, float *__restrict__ out, int ldo) {
+    const int lane = threadIdx.x % G;
+    const int groups = blockDim.x / G;
+    for (int j = blockIdx.x * groups + threadIdx.x / G; j < n_dst; j += gridDim.x * groups) {
+        const int beg = rowptr[j], end = rowptr[j + 1];
+        const float scale = row_scale ? row_scale[j] : 1.0f;
+        for (int f = lane; f < F; f += G) {
+            float acc = 0.0f;
+            for (int e = beg; e < end; ++e) acc = w ? fmaf(w[e], X[(size_t)src[e] * ldx + f], acc) : acc + X[(size_t)src[e] * ldx + f];
+            out[(size_t)j * ldo + f] = addend[(size_t)j * ld_add + f] + acc * scale;
+        }
+    }
+}
+
+// 2-D strided add: out[m, :w] += in[m, :w]
+__global__ void __launch_bounds__(256) k_add2d(float *__restrict__ out, int ldo, const float *__restrict__ in, int ldi, int M, int w) {
+    const size_t total = (size_t)M * w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        out[(i / w) * ldo + i % w] += in[(i / w) * ldi + i % w];
 }
 
 }  // namespace gnn

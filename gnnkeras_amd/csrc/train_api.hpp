@@ -128,7 +128,7 @@ int gnn_first_layer_param_grads(const float *P, const float *q, const float *W, 
                                 float *db, float *dgamma, float *dbeta, float *m1, float *m2, int32_t accumulate, void *stream) {
     if (!P || !q || !W || !dW || K < 1 || H < 1 || M < 1) return fail("bad arguments");
     if (gamma && (!beta || !mean || !var || !dgamma || !dbeta)) return fail("BatchNormalization arrays are NULL");
-    gnn::k_first_layer_param_grads<<<cdiv(std::max(K, H), 256), 256, 0, (hipStream_t)stream>>>(
+    gnn::k_first_layer_param_grads<<<K, 64, 0, (hipStream_t)stream>>>(
         P, q, W, K, H, gamma, beta, mean, var, eps, 1.0f / (float)M, dW, db, dgamma, dbeta, m1, m2, accumulate);
     LAUNCH_OK();
     return 0;

@@ -1,0 +1,526 @@
+// gnn_train_step: one whole training step of a homogeneous model inside the library (reference GNN/Models/GNN.py:277-306:
+// `self(x, training=True)`, `compiled_loss`, `tape.gradient` through the unrolled loop, `dwbS / k`).  Included at the end of
+// gnnloop.hip, after train_api.hpp (shares the launchers).  Declared in include/gnnloop.h.
+//
+// Same algebra as gnnkeras_amd/Models/training.py (which stays the general path: composite models, LGNN label gradients):
+// the tape is the k + 1 state matrices plus per-iteration BatchNormalization statistics and folded first-layer weights;
+// aggregates and hidden activations are recomputed in the backward sweep; the first layer never materialises the
+// N x in_dim concatenation (P = X^T dZ per segment, dW = a (.) P + c q^T, BN input-gradient moments from W, P, q).
+// What moves into the library is the ORCHESTRATION: ~14 launches per iteration pair instead of ~36, no Python between them.
+#pragma once
+#include "kernels_train.hpp"
+
+namespace {
+
+struct NetCtx {
+    const gnn_mlp_t *m;
+    const gnn_mlp_grads_t *g;
+    float *Wt[GNN_MAX_LAYERS];      // kernel transposes [units[l]][fan_in]
+    float *P, *q, *m1, *m2;         // first-layer scratch: [in_dim x H1], [H1], [in_dim], [in_dim]
+    float *G[2];                    // gradient ping-pong [rows x max units]
+    float *hid[GNN_MAX_LAYERS];     // layer outputs [rows x units[l]] (the last one may alias a caller buffer)
+};
+
+struct TrainPlan {
+    int N, E, S, L, A, d, M, R, T, K, G;
+    bool pooled, with_labels, agg_taped;      // agg_taped: every iteration's neighbour sum is kept (small graphs) instead of recomputed
+    int in_s, in_o, H1s, H1o, kdx_s, off_agg;
+    int *flags; float *k_dev;
+    float *states, *agg, *agg_arcs, *agg_nodes;
+    float *stats_s, *stats_tpl, *Wf_s, *bf_s;
+    float *stats_o, *Wf_o, *bf_o;
+    float *dx_s_all, *dx_o_all, *G_state, *G_out, *dpred, *loss_rows;
+    int *isrc, *idst;
+    float *part; size_t part_floats;
+    NetCtx cs, co;
+    size_t bytes;
+};
+
+int max_units_of(const gnn_mlp_t &m) { int h = 1; for (int i = 0; i < m.n_layers; ++i) h = std::max(h, (int)m.units[i]); return h; }
+
+size_t grad_part_floats(int K, int H, int M) { int nc; rows_per_chunk_for(std::max(M, 1), &nc); return (size_t)nc * ((size_t)K * H + H); }
+
+void carve_net(Carver &c, NetCtx &x, const gnn_mlp_t &m, int rows, size_t &part_floats) {
+    int fan_in = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) {
+        x.Wt[l] = c.take<float>((size_t)fan_in * m.units[l]);
+        x.hid[l] = c.take<float>((size_t)std::max(rows, 1) * m.units[l]);
+        part_floats = std::max(part_floats, grad_part_floats(fan_in, m.units[l], rows));
+        fan_in = m.units[l];
+    }
+    x.P = c.take<float>((size_t)m.in_dim * m.units[0]); x.q = c.take<float>(m.units[0]);
+    x.m1 = c.take<float>(m.in_dim); x.m2 = c.take<float>(m.in_dim);
+    const int mu = std::max(max_units_of(m), 1);
+    x.G[0] = c.take<float>((size_t)std::max(rows, 1) * mu); x.G[1] = c.take<float>((size_t)std::max(rows, 1) * mu);
+}
+
+int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
+    const gnn_loop_args_t &a = ta.loop;
+    memset(&p, 0, sizeof(p));
+    if (a.abi_version != GNN_ABI_VERSION) return fail("abi_version %d != %d", a.abi_version, GNN_ABI_VERSION);
+    if (a.composite) return fail("gnn_train_step: homogeneous models only");
+    if (a.n_nodes < 1) return fail("gnn_train_step: empty graph");
+    if (a.n_heavy_segments > 0) { /* the training kernels walk the plain adjacency */ }
+    p.N = a.n_nodes; p.E = a.n_arcs; p.L = a.dim_node_label; p.A = a.dim_arc_label; p.d = a.state_dim;
+    p.S = a.state_dim > 0 ? a.state_dim : a.dim_node_label;
+    p.K = a.max_iteration; p.M = a.n_out;
+    TRY(check_mlp(a.net_state[0], "net_state", ws != nullptr));
+    TRY(check_mlp(a.net_output, "net_output", ws != nullptr));
+    const gnn_mlp_t &ns = a.net_state[0], &no = a.net_output;
+    p.with_labels = a.state_dim > 0;
+    p.in_s = ns.in_dim; p.in_o = no.in_dim; p.H1s = ns.units[0]; p.H1o = no.units[0];
+    const int expect_s = a.state_dim > 0 ? 2 * p.S + 2 * p.L + p.A : 2 * p.S + p.A;
+    if (ns.in_dim != expect_s) return fail("net_state.in_dim %d != %d expected from the graph dims", ns.in_dim, expect_s);
+    if (ns.units[ns.n_layers - 1] != p.S) return fail("net_state output width %d != state width %d", ns.units[ns.n_layers - 1], p.S);
+    const int node_part = p.with_labels ? p.S + p.L : p.S;
+    const int expect_o = a.focus == GNN_FOCUS_ARC ? 2 * node_part + p.A : node_part;
+    if (no.in_dim != expect_o) return fail("net_output.in_dim %d != %d expected for this focus", no.in_dim, expect_o);
+    p.T = no.units[no.n_layers - 1];
+    p.pooled = a.focus == GNN_FOCUS_GRAPH;
+    p.G = p.pooled ? a.nodegraph.n_dst : 0;
+    p.R = p.pooled ? p.G : p.M;
+    p.off_agg = p.with_labels ? p.S + p.L : p.S;
+    p.kdx_s = p.off_agg + p.S;
+
+    Carver c(ws);
+    p.flags = c.take<int>(p.K + 8);
+    p.k_dev = c.take<float>(4);
+    p.states = c.take<float>((size_t)(p.K + 1) * p.N * p.S);
+    p.agg_taped = (size_t)std::max(p.K, 1) * p.N * p.S * sizeof(float) <= ((size_t)256 << 20);
+    p.agg = c.take<float>((size_t)(p.agg_taped ? std::max(p.K, 1) : 1) * p.N * p.S);
+    p.agg_arcs = c.take<float>((size_t)p.N * std::max(p.A, 1));
+    p.agg_nodes = c.take<float>((size_t)p.N * std::max(p.L, 1));
+    p.stats_s = c.take<float>((size_t)std::max(p.K, 1) * 2 * p.in_s);
+    p.stats_tpl = c.take<float>(2 * (size_t)p.in_s);
+    p.Wf_s = c.take<float>((size_t)std::max(p.K, 1) * p.in_s * p.H1s);
+    p.bf_s = c.take<float>((size_t)std::max(p.K, 1) * p.H1s);
+    p.stats_o = c.take<float>(2 * (size_t)p.in_o);
+    p.Wf_o = c.take<float>((size_t)p.in_o * p.H1o); p.bf_o = c.take<float>(p.H1o);
+    p.dx_s_all = c.take<float>((size_t)p.N * p.kdx_s);
+    p.dx_o_all = c.take<float>((size_t)std::max(p.M, 1) * p.in_o);
+    p.G_state = c.take<float>((size_t)p.N * p.S);
+    p.G_out = c.take<float>((size_t)std::max(p.M, 1) * p.T);
+    p.dpred = c.take<float>((size_t)std::max(p.R, 1) * p.T);
+    p.loss_rows = c.take<float>(std::max(p.R, 1));
+    p.isrc = c.take<int>(std::max(p.M, 1)); p.idst = c.take<int>(std::max(p.M, 1));
+    p.part_floats = 0;
+    carve_net(c, p.cs, ns, p.N, p.part_floats);
+    carve_net(c, p.co, no, p.M, p.part_floats);
+    {   // column-statistics partials of the large-batch path: (chunks + 1) x widest segment
+        int nc; rows_per_chunk_for(std::max(p.N, 1), &nc);
+        p.part_floats = std::max(p.part_floats, (size_t)(nc + 1) * std::max(p.in_s, p.in_o));
+    }
+    p.part = c.take<float>(p.part_floats);
+    p.cs.m = &ns; p.cs.g = &ta.grad_state; p.co.m = &no; p.co.g = &ta.grad_output;
+    p.bytes = (c.off + 255) & ~(size_t)255;
+    return 0;
+}
+
+// ---- column statistics of the listed segments into mean / var (positions seg.wrow) --------------------------------------
+int colstats_segs(const int *gate, const gnn::Seg *segs, int n, int M, float *mean, float *var, float *part, hipStream_t st) {
+    if (n == 0) return 0;
+    if (M <= 8192) {
+        gnn::StatSegs ss;
+        memset(&ss, 0, sizeof(ss));
+        ss.n = n; ss.col_begin[0] = 0;
+        for (int s = 0; s < n; ++s) { ss.seg[s] = segs[s]; ss.col_begin[s + 1] = ss.col_begin[s] + segs[s].width; }
+        gnn::k_colstats_segs_small<<<ss.col_begin[n], 256, 0, st>>>(gate, ss, M, mean, var);
+        LAUNCH_OK();
+        return 0;
+    }
+    int n_chunks;
+    const int rpc = rows_per_chunk_for(M, &n_chunks);
+    for (int s = 0; s < n; ++s) {       // large batches: two passes per segment (launch count does not matter there)
+        const gnn::Seg &g = segs[s];
+        gnn::k_colstats_partial<<<n_chunks, 256, 0, st>>>(g.ptr, g.ld, g.rowidx, g.width, M, rpc, nullptr, part);
+        LAUNCH_OK();
+        gnn::k_reduce_partials<<<cdiv(g.width, 64), 256, 0, st>>>(part, n_chunks, g.width, mean + g.wrow, 0, 1.0f / (float)M, g.width, nullptr);
+        LAUNCH_OK();
+        gnn::k_colstats_partial<<<n_chunks, 256, 0, st>>>(g.ptr, g.ld, g.rowidx, g.width, M, rpc, mean + g.wrow, part);
+        LAUNCH_OK();
+        gnn::k_reduce_partials<<<cdiv(g.width, 64), 256, 0, st>>>(part, n_chunks, g.width, var + g.wrow, 0, 1.0f / (float)M, g.width, nullptr);
+        LAUNCH_OK();
+    }
+    return 0;
+}
+
+int fold_with_stats(const gnn_mlp_t &m, const float *stats, float *Wf, float *bf, hipStream_t st) {
+    FoldList fl;
+    gnn::FoldJob &j = fl.fa.job[fl.fa.n_jobs++];
+    j.W = m.kernel[0]; j.b = m.bias[0]; j.K = m.in_dim; j.H = m.units[0];
+    j.gamma = m.bn_gamma; j.beta = m.bn_beta; j.mean = stats; j.var = stats + m.in_dim; j.eps = m.bn_eps;
+    j.Wf = Wf; j.bf = bf; j.blk_begin = 0;
+    fl.blocks = j.H;
+    return launch_fold_list(fl, st);
+}
+
+// layers of `m` over a virtual concatenation; first layer with (W0, b0); outputs into hs[l] (ld = units[l])
+struct PredFuse { const float *old; int ld; float thr; int *flag; float *k_out; float k_val; bool fused; };
+
+// `bn_stats` (mean | var of the first layer's input columns): the training-mode BatchNormalization is applied to the inputs as
+// the first layer stages them (k_segdense), with (W0, b0) the raw kernel / bias; NULL: (W0, b0) are used as they are.
+int forward_layers(const gnn_mlp_t &m, const gnn::Seg *segs, int nseg, int M, const float *W0, const float *b0, float *const *hs,
+                   const int *gate, hipStream_t st, PredFuse *pred = nullptr, const float *bn_stats = nullptr) {
+    for (int l = 0; l < m.n_layers; ++l) {
+        gnn::SegDenseArgs a;
+        memset(&a, 0, sizeof(a));
+        a.gate = gate; a.M = M; a.H = m.units[l];
+        if (l == 0) {
+            a.nseg = nseg;
+            for (int s = 0; s < nseg; ++s) a.seg[s] = segs[s];
+            a.W = W0; a.bias = b0;
+            if (bn_stats) { a.in_gamma = m.bn_gamma; a.in_beta = m.bn_beta; a.in_mean = bn_stats; a.in_var = bn_stats + m.in_dim; a.in_eps = m.bn_eps; }
+        } else {
+            a.nseg = 1;
+            a.seg[0] = gnn::Seg{hs[l - 1], nullptr, (int)m.units[l - 1], (int)m.units[l - 1], 0};
+            a.W = m.kernel[l]; a.bias = m.bias[l];
+        }
+        a.ldw = a.H;
+        const bool thin_softmax = m.activation[l] == GNN_ACT_SOFTMAX && thin_dense_applies(a);
+        a.act = (m.activation[l] == GNN_ACT_SOFTMAX && !thin_softmax) ? GNN_ACT_LINEAR : m.activation[l];
+        a.Y = hs[l]; a.ldy = m.units[l];
+        if (pred && l == m.n_layers - 1 && a.H <= 64 && a.H > 4 && m.activation[l] != GNN_ACT_SOFTMAX) {   // predicate in the epilogue
+            a.pred_old = pred->old; a.ld_pred = pred->ld; a.pred_thr = pred->thr; a.pred_flag = pred->flag;
+            a.pred_k = pred->k_out; a.pred_kval = pred->k_val;
+            pred->fused = true;
+        }
+        TRY(launch_segdense(a, st));
+        if (m.activation[l] == GNN_ACT_SOFTMAX && !thin_softmax) TRY(launch_softmax(gate, a.Y, a.M, a.H, a.ldy, nullptr, st));
+    }
+    return 0;
+}
+
+int dense_plain(const float *X, int ldx, int K, const float *W, int ldw, int H, int M, float *Y, int ldy, hipStream_t st) {
+    gnn::SegDenseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.H = H; a.nseg = 1;
+    a.seg[0] = gnn::Seg{X, nullptr, ldx, K, 0};
+    a.W = W; a.ldw = ldw; a.act = GNN_ACT_LINEAR; a.Y = Y; a.ldy = ldy;
+    return launch_segdense(a, st);
+}
+
+int act_grad_inplace(float *G, int ldg, const float *Y, int ldy, int M, int H, int act, hipStream_t st) {
+    if (M == 0) return 0;
+    const long total = act == GNN_ACT_SOFTMAX ? M : (long)M * H;
+    gnn::k_act_grad<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, st>>>(G, ldg, Y, ldy, G, ldg, M, H, act);
+    LAUNCH_OK();
+    return 0;
+}
+
+// Back-propagation through one network.  G = d loss / d hs[last] ([M x units_last], leading dimension ldg; overwritten).
+// Parameter gradients go to x.g (accumulated when `accumulate`); dx_all (optional) receives d loss / d input columns
+// [0, kdx) BEFORE the BatchNormalization input gradient (the caller applies it to the segments it needs).
+int net_backward(NetCtx &x, const gnn::Seg *segs, int nseg, float *const *hs, float *G, int ldg, int M, const float *stats, bool accumulate,
+                 float *dx_all, int kdx, float *part, hipStream_t st) {
+    const gnn_mlp_t &m = *x.m;
+    int n_chunks;
+    const int rpc = rows_per_chunk_for(std::max(M, 1), &n_chunks);
+    for (int l = m.n_layers - 1; l >= 1; --l) {
+        const int H = m.units[l], Kp = m.units[l - 1];
+        TRY(act_grad_inplace(G, ldg, hs[l], H, M, H, m.activation[l], st));
+        dim3 grid(n_chunks, cdiv(Kp, 64), cdiv(H, 64));
+        gnn::k_dense_grad_partial<<<grid, 256, 0, st>>>(hs[l - 1], Kp, nullptr, Kp, G, ldg, H, M, rpc, part, 1);
+        LAUNCH_OK();
+        const int n = Kp * H + H;
+        gnn::k_reduce_partials<<<cdiv(n, 64), 256, 0, st>>>(part, n_chunks, n, x.g->dkernel[l], accumulate ? 1 : 0, 1.0f, Kp * H, x.g->dbias[l]);
+        LAUNCH_OK();
+        float *Gn = (G == x.G[0]) ? x.G[1] : x.G[0];
+        TRY(dense_plain(G, ldg, H, x.Wt[l], Kp, Kp, M, Gn, Kp, st));      // dL/d hs[l-1] = dZ . W[l]^T
+        G = Gn; ldg = Kp;
+    }
+    const int H = m.units[0], K = m.in_dim;
+    TRY(act_grad_inplace(G, ldg, hs[0], H, M, H, m.activation[0], st));
+    {
+        gnn::GradSegs gs;
+        memset(&gs, 0, sizeof(gs));
+        gs.n = nseg; gs.blk_begin[0] = 0;
+        for (int s = 0; s < nseg; ++s) { gs.seg[s] = segs[s]; gs.blk_begin[s + 1] = gs.blk_begin[s] + cdiv(segs[s].width, 64); }
+        dim3 grid(n_chunks, gs.blk_begin[nseg], cdiv(H, 64));
+        gnn::k_dense_grad_partial_segs<<<grid, 256, 0, st>>>(gs, K, G, ldg, H, M, rpc, part);
+        LAUNCH_OK();
+    }
+    const bool bn = m.has_bn != 0;
+    const float *Pp = x.P, *qp = x.q;
+    int fuse_chunks = 1;
+    if (n_chunks <= 32) {                      // small batches: the chunk partials are summed inside the parameter-gradient kernel
+        Pp = part; qp = part + (size_t)K * H; fuse_chunks = n_chunks;
+    } else {
+        const int n = K * H + H;
+        gnn::k_reduce_partials<<<cdiv(n, 64), 256, 0, st>>>(part, n_chunks, n, x.P, 0, 1.0f, K * H, x.q);
+        LAUNCH_OK();
+    }
+    gnn::k_first_layer_param_grads<<<K, 64, 0, st>>>(
+        Pp, qp, m.kernel[0], K, H, bn ? m.bn_gamma : nullptr, m.bn_beta, stats, stats ? stats + K : nullptr, m.bn_eps, 1.0f / (float)M,
+        x.g->dkernel[0], x.g->dbias[0], x.g->dgamma, x.g->dbeta, bn ? x.m1 : nullptr, bn ? x.m2 : nullptr, accumulate ? 1 : 0, fuse_chunks);
+    LAUNCH_OK();
+    if (dx_all && kdx > 0) TRY(dense_plain(G, ldg, H, x.Wt[0], K, kdx, M, dx_all, kdx, st));   // W^T columns [0, kdx) (ldw = K)
+    return 0;
+}
+
+int bn_input_grads(const gnn_mlp_t &m, const NetCtx &x, const float *stats, const gnn::BnGradReq *reqs, int n, int M, hipStream_t st) {
+    if (!m.has_bn || n == 0 || M == 0) return 0;
+    gnn::BnGradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n; a.M = M; a.gamma = m.bn_gamma; a.mean = stats; a.var = stats + m.in_dim; a.m1 = x.m1; a.m2 = x.m2; a.eps = m.bn_eps;
+    long total = 0;
+    for (int i = 0; i < n; ++i) { a.r[i] = reqs[i]; total = std::max(total, (long)M * reqs[i].width); }
+    gnn::k_bn_input_grad_segs<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, st>>>(a);
+    LAUNCH_OK();
+    return 0;
+}
+
+int transposes(NetCtx &x, hipStream_t st) {
+    const gnn_mlp_t &m = *x.m;
+    int fan_in = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) {
+        gnn::k_transpose<<<std::min(cdiv((long)fan_in * m.units[l], 256), 1024), 256, 0, st>>>(m.kernel[l], fan_in, m.units[l], x.Wt[l]);
+        LAUNCH_OK();
+        fan_in = m.units[l];
+    }
+    return 0;
+}
+
+int zero_grads(const gnn_mlp_t &m, const gnn_mlp_grads_t &g, hipStream_t st) {
+    if (m.has_bn) { HIP_OK(hipMemsetAsync(g.dgamma, 0, sizeof(float) * m.in_dim, st)); HIP_OK(hipMemsetAsync(g.dbeta, 0, sizeof(float) * m.in_dim, st)); }
+    int fan_in = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) {
+        HIP_OK(hipMemsetAsync(g.dkernel[l], 0, sizeof(float) * (size_t)fan_in * m.units[l], st));
+        HIP_OK(hipMemsetAsync(g.dbias[l], 0, sizeof(float) * m.units[l], st));
+        fan_in = m.units[l];
+    }
+    return 0;
+}
+
+int scale_grads(const gnn_mlp_t &m, const gnn_mlp_grads_t &g, float s, hipStream_t st) {
+    auto sc = [&](float *p, size_t n) -> int {
+        gnn::k_axpby<<<std::min(cdiv((long)n, 256), 1024), 256, 0, st>>>(s, p, 0.0f, nullptr, p, n);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    };
+    if (m.has_bn) { if (sc(g.dgamma, m.in_dim) || sc(g.dbeta, m.in_dim)) return fail("scale launch failed"); }
+    int fan_in = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) {
+        if (sc(g.dkernel[l], (size_t)fan_in * m.units[l]) || sc(g.dbias[l], m.units[l])) return fail("scale launch failed");
+        fan_in = m.units[l];
+    }
+    return 0;
+}
+
+int check_grads(const gnn_mlp_t &m, const gnn_mlp_grads_t &g, const char *name) {
+    if (m.has_bn && (!g.dgamma || !g.dbeta)) return fail("%s: dgamma / dbeta is NULL", name);
+    for (int l = 0; l < m.n_layers; ++l) if (!g.dkernel[l] || !g.dbias[l]) return fail("%s: gradient buffer of layer %d is NULL", name, l);
+    return 0;
+}
+
+// segments of the state network's input at iteration t (reference GNN.py:222-231): [state | nodes | agg | agg_nodes | agg_arcs]
+int state_segs(const gnn_loop_args_t &a, const TrainPlan &p, int t, gnn::Seg *segs) {
+    int n = 0, col = 0;
+    const float *st_t = p.states + (size_t)t * p.N * p.S;
+    segs[n++] = gnn::Seg{st_t, nullptr, p.S, p.S, col}; col += p.S;
+    if (p.with_labels) { segs[n++] = gnn::Seg{a.nodes, nullptr, a.ld_nodes, p.L, col}; col += p.L; }
+    segs[n++] = gnn::Seg{p.agg + (p.agg_taped ? (size_t)t * p.N * p.S : 0), nullptr, p.S, p.S, col}; col += p.S;
+    if (p.with_labels) { segs[n++] = gnn::Seg{p.agg_nodes, nullptr, p.L, p.L, col}; col += p.L; }
+    if (p.A > 0) { segs[n++] = gnn::Seg{p.agg_arcs, nullptr, p.A, p.A, col}; col += p.A; }
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gnn_train_workspace_bytes(const gnn_train_args_t *args) {
+    if (!args) { fail("args is NULL"); return 0; }
+    TrainPlan p;
+    if (make_train_plan(*args, nullptr, p)) return 0;
+    return p.bytes;
+}
+
+int gnn_train_step(const gnn_train_args_t *args) {
+    if (!args) return fail("args is NULL");
+    const gnn_train_args_t &ta = *args;
+    const gnn_loop_args_t &a = ta.loop;
+    TrainPlan p;
+    if (!ta.tape || ((uintptr_t)ta.tape & 255) != 0) return fail("tape must be a 256-byte aligned device buffer");
+    TRY(make_train_plan(ta, ta.tape, p));
+    if (ta.tape_bytes < p.bytes) return fail("tape too small: %zu < %zu bytes", ta.tape_bytes, p.bytes);
+    TRY(check_csr(a.adjacency, "adjacency", p.N, p.N));
+    TRY(check_csr(a.arcnode, "arcnode", p.N, p.E));
+    TRY(check_csr(ta.adjacency_by_source, "adjacency_by_source", p.N, p.N));
+    if (!a.nodes || (p.E > 0 && p.A > 0 && !a.arc_labels)) return fail("nodes / arc_labels is NULL");
+    if (a.state_dim > 0 && !a.state0) return fail("state0 is required when state_dim > 0");
+    if (p.M > 0 && !a.out_index) return fail("out_index is NULL");
+    if (a.focus == GNN_FOCUS_ARC && p.E > 0 && (!a.arc_src || !a.arc_dst)) return fail("arc focus needs arc_src / arc_dst");
+    if (p.pooled) {
+        if (a.nodegraph.n_src != p.M) return fail("graph focus: every node must pass the mask");
+        TRY(check_csr(a.nodegraph, "nodegraph", p.G, p.M));
+        TRY(check_csr(ta.nodegraph_by_source, "nodegraph_by_source", p.M, p.G));
+    }
+    if (p.R < 1 || !ta.targets) return fail("gnn_train_step needs at least one target row");
+    if (ta.loss_kind < 0 || ta.loss_kind > 3) return fail("unknown loss kind %d", ta.loss_kind);
+    if (!ta.y_pred || !ta.loss || !ta.k_host || !ta.state) return fail("y_pred / loss / k_host / state is NULL");
+    TRY(check_grads(a.net_state[0], ta.grad_state, "grad_state"));
+    TRY(check_grads(a.net_output, ta.grad_output, "grad_output"));
+    const gnn_mlp_t &ns = a.net_state[0], &no = a.net_output;
+    const bool bn_s = ns.has_bn != 0, bn_o = no.has_bn != 0;
+    const bool fold_s = ns.units[0] <= 4;       // see the forward loop
+    hipStream_t st = (hipStream_t)a.stream;
+    const size_t NS = (size_t)p.N * p.S;
+
+    // ---- setup: transposes, aggregates of the constants, state_0, iteration-invariant statistics -----------------------------------
+    TRY(transposes(p.cs, st));
+    TRY(transposes(p.co, st));
+    HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (p.K + 8), st));
+    HIP_OK(hipMemsetAsync(p.k_dev, 0, sizeof(float) * 4, st));
+    if (p.A > 0) TRY(launch_aggregate(nullptr, a.arcnode, a.arc_labels, a.ld_arcs, p.A, p.agg_arcs, p.A, st));
+    if (p.with_labels) TRY(launch_aggregate(nullptr, a.adjacency, a.nodes, a.ld_nodes, p.L, p.agg_nodes, p.L, st));
+    if (a.state_dim > 0) HIP_OK(hipMemcpyAsync(p.states, a.state0, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
+    else TRY(launch_copy2d(nullptr, a.nodes, a.ld_nodes, p.states, p.S, p.N, p.S, p.S, st));
+    gnn::Seg segs[GNN_MAX_SEGS];
+    if (bn_s && p.K > 0) {
+        const int n = state_segs(a, p, 0, segs);
+        gnn::Seg cst[GNN_MAX_SEGS]; int nc = 0;
+        for (int s = 0; s < n; ++s) if (segs[s].ptr != p.states && segs[s].ptr != p.agg) cst[nc++] = segs[s];
+        HIP_OK(hipMemsetAsync(p.stats_tpl, 0, sizeof(float) * 2 * p.in_s, st));
+        TRY(colstats_segs(nullptr, cst, nc, p.N, p.stats_tpl, p.stats_tpl + p.in_s, p.part, st));
+        gnn::k_replicate<<<std::min(cdiv((long)2 * p.in_s * p.K, 256), 1024), 256, 0, st>>>(p.stats_tpl, 2 * p.in_s, p.K, p.stats_s);
+        LAUNCH_OK();
+    }
+    // ---- training-mode forward: gated iterations, tape = states + statistics + folded first layers ------------------------------
+    TRY(launch_converge(nullptr, p.states, nullptr, p.N, p.S, p.S, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
+    for (int t = 0; t < p.K; ++t) {
+        const int *gate = p.flags + t;
+        const float *s_t = p.states + (size_t)t * NS;
+        float *s_n = p.states + (size_t)(t + 1) * NS;
+        float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);
+        TRY(launch_aggregate(gate, a.adjacency, s_t, p.S, p.S, agg_t, p.S, st));
+        const int n = state_segs(a, p, t, segs);
+        const float *W0 = ns.kernel[0], *b0 = ns.bias[0], *bn_on_load = nullptr;
+        if (bn_s) {
+            float *stats = p.stats_s + (size_t)t * 2 * p.in_s;
+            gnn::Seg dyn[2] = {segs[0], segs[p.with_labels ? 2 : 1]};
+            TRY(colstats_segs(gate, dyn, 2, p.N, stats, stats + p.in_s, p.part, st));
+            if (fold_s) {                        // thin first layer (<= 4 units): the thin-dense kernel wants folded weights
+                float *Wf = p.Wf_s + (size_t)t * p.in_s * p.H1s, *bf = p.bf_s + (size_t)t * p.H1s;
+                TRY(fold_with_stats(ns, stats, Wf, bf, st));
+                W0 = Wf; b0 = bf;
+            } else bn_on_load = stats;           // BatchNormalization applied as the first layer stages its inputs: no fold launch
+        }
+        float *hs[GNN_MAX_LAYERS];
+        for (int l = 0; l < ns.n_layers; ++l) hs[l] = l == ns.n_layers - 1 ? s_n : p.cs.hid[l];
+        PredFuse pf{s_t, p.S, a.state_threshold, p.flags + t + 1, p.k_dev, (float)(t + 1), false};
+        TRY(forward_layers(ns, segs, n, p.N, W0, b0, hs, gate, st, &pf, bn_on_load));
+        if (!pf.fused) TRY(launch_converge(gate, s_n, s_t, p.N, p.S, p.S, p.S, a.state_threshold, p.flags + t + 1, p.k_dev, (float)(t + 1), st));
+    }
+    float k_f = 0.0f;
+    HIP_OK(hipMemcpyAsync(&k_f, p.k_dev, sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));                                  // the one host synchronisation of the step
+    const int k = (int)k_f;
+    *ta.k_host = k;
+    if (k < 0 || k > p.K) return fail("iteration count %d out of range", k);
+    const float *state_k = p.states + (size_t)k * NS;
+    HIP_OK(hipMemcpyAsync(ta.state, state_k, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
+    if (bn_s && k > 0) {
+        gnn::k_bn_moving_multi<<<cdiv(p.in_s, 256), 256, 0, st>>>(p.stats_s, 2 * p.in_s, k, p.in_s, const_cast<float *>(ns.bn_mean),
+                                                                const_cast<float *>(ns.bn_var), ta.bn_momentum);
+        LAUNCH_OK();
+    }
+
+    // ---- output network, training mode ---------------------------------------------------------------------------------------------
+    gnn::Seg osegs[GNN_MAX_SEGS];
+    int nos = 0, ocol = 0;
+    int bn_req_off[2] = {0, 0};                 // column offsets of the state segments inside the output net's input
+    const int *bn_req_idx[2] = {nullptr, nullptr};
+    int n_state_segs = 0;
+    if (p.M > 0) {
+        if (a.focus == GNN_FOCUS_ARC) {
+            k_arc_endpoints<<<cdiv(p.M, 256), 256, 0, st>>>(a.out_index, a.arc_src, a.arc_dst, p.M, p.isrc, p.idst);
+            LAUNCH_OK();
+            const int *ends[2] = {p.isrc, p.idst};
+            for (int e = 0; e < 2; ++e) {
+                bn_req_off[n_state_segs] = ocol; bn_req_idx[n_state_segs++] = ends[e];
+                osegs[nos++] = gnn::Seg{state_k, ends[e], p.S, p.S, ocol}; ocol += p.S;
+                if (p.with_labels) { osegs[nos++] = gnn::Seg{a.nodes, ends[e], a.ld_nodes, p.L, ocol}; ocol += p.L; }
+            }
+            if (p.A > 0) { osegs[nos++] = gnn::Seg{a.arc_labels, a.out_index, a.ld_arcs, p.A, ocol}; ocol += p.A; }
+        } else {
+            bn_req_off[0] = 0; bn_req_idx[0] = a.out_index; n_state_segs = 1;
+            osegs[nos++] = gnn::Seg{state_k, a.out_index, p.S, p.S, ocol}; ocol += p.S;
+            if (p.with_labels) { osegs[nos++] = gnn::Seg{a.nodes, a.out_index, a.ld_nodes, p.L, ocol}; ocol += p.L; }
+        }
+    }
+    float *ohs[GNN_MAX_LAYERS];
+    for (int l = 0; l < no.n_layers; ++l) ohs[l] = (l == no.n_layers - 1 && !p.pooled) ? ta.y_pred : p.co.hid[l];
+    float *out_nodes = ohs[no.n_layers - 1];
+    if (p.M > 0) {
+        const float *W0 = no.kernel[0], *b0 = no.bias[0];
+        if (bn_o) {
+            TRY(colstats_segs(nullptr, osegs, nos, p.M, p.stats_o, p.stats_o + p.in_o, p.part, st));
+            TRY(fold_with_stats(no, p.stats_o, p.Wf_o, p.bf_o, st));
+            gnn::k_bn_moving_multi<<<cdiv(p.in_o, 256), 256, 0, st>>>(p.stats_o, 2 * p.in_o, 1, p.in_o, const_cast<float *>(no.bn_mean),
+                                                                    const_cast<float *>(no.bn_var), ta.bn_momentum);
+            LAUNCH_OK();
+            W0 = p.Wf_o; b0 = p.bf_o;
+        }
+        TRY(forward_layers(no, osegs, nos, p.M, W0, b0, ohs, nullptr, st));
+    }
+    if (p.pooled) TRY(launch_aggregate(nullptr, a.nodegraph, out_nodes, p.T, p.T, ta.y_pred, p.T, st));
+    // ---- loss and its gradient ----------------------------------------------------------------------------------------------------
+    gnn::k_loss_grad<<<cdiv(p.R, 256), 256, 0, st>>>(ta.loss_kind, ta.targets, ta.y_pred, ta.sample_weight, p.R, p.T, p.dpred, p.loss_rows);
+    LAUNCH_OK();
+    gnn::k_sum_scale<<<1, 256, 0, st>>>(p.loss_rows, p.R, 1.0f / (float)p.R, ta.loss);
+    LAUNCH_OK();
+    float *G_out = p.dpred;
+    if (p.pooled) { TRY(launch_aggregate(nullptr, ta.nodegraph_by_source, p.dpred, p.T, p.T, p.G_out, p.T, st)); G_out = p.G_out; }
+
+    // ---- backward: output network, then the k iterations -----------------------------------------------------------------------------------
+    HIP_OK(hipMemsetAsync(p.G_state, 0, sizeof(float) * NS, st));
+    if (p.M > 0) {
+        TRY(net_backward(p.co, osegs, nos, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, p.in_o, p.part, st));
+        gnn::BnGradReq rq[2];
+        for (int i = 0; i < n_state_segs; ++i)
+            rq[i] = gnn::BnGradReq{p.dx_o_all + bn_req_off[i], p.in_o, state_k, p.S, bn_req_idx[i], p.S, bn_req_off[i]};
+        TRY(bn_input_grads(no, p.co, p.stats_o, rq, n_state_segs, p.M, st));
+        for (int i = 0; i < n_state_segs; ++i) {
+            gnn::k_scatter_add_rows<<<std::min(cdiv((long)p.M * p.S, 256), 256 * 16), 256, 0, st>>>(p.dx_o_all + bn_req_off[i], p.in_o, bn_req_idx[i],
+                                                                                                   p.M, p.S, p.G_state, p.S);
+            LAUNCH_OK();
+        }
+    } else {
+        TRY(zero_grads(no, ta.grad_output, st));
+    }
+    if (k == 0) TRY(zero_grads(ns, ta.grad_state, st));
+    for (int t = k - 1; t >= 0; --t) {
+        const float *s_t = p.states + (size_t)t * NS;
+        float *s_n = p.states + (size_t)(t + 1) * NS;
+        const float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);
+        if (!p.agg_taped) TRY(launch_aggregate(nullptr, a.adjacency, s_t, p.S, p.S, p.agg, p.S, st));
+        const int n = state_segs(a, p, t, segs);
+        const float *stats = bn_s ? p.stats_s + (size_t)t * 2 * p.in_s : nullptr;
+        float *hs[GNN_MAX_LAYERS];
+        for (int l = 0; l < ns.n_layers; ++l) hs[l] = l == ns.n_layers - 1 ? s_n : p.cs.hid[l];
+        if (ns.n_layers > 1) {                     // hidden activations are not on the tape: recompute them (the last layer's are)
+            const bool folded = bn_s && fold_s;
+            const float *W0 = folded ? p.Wf_s + (size_t)t * p.in_s * p.H1s : ns.kernel[0], *b0 = folded ? p.bf_s + (size_t)t * p.H1s : ns.bias[0];
+            gnn_mlp_t head = ns; head.n_layers = ns.n_layers - 1;
+            TRY(forward_layers(head, segs, n, p.N, W0, b0, hs, nullptr, st, nullptr, (bn_s && !fold_s) ? stats : nullptr));
+        }
+        TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, p.dx_s_all, p.kdx_s, p.part, st));
+        gnn::BnGradReq rq[2] = {gnn::BnGradReq{p.dx_s_all, p.kdx_s, s_t, p.S, nullptr, p.S, 0},
+                                gnn::BnGradReq{p.dx_s_all + p.off_agg, p.kdx_s, agg_t, p.S, nullptr, p.S, p.off_agg}};
+        TRY(bn_input_grads(ns, p.cs, stats, rq, 2, p.N, st));
+        {   // G_state = d state (own) + Adj . d agg   (arcs walked by source)
+            const gnn_csr_t &c = ta.adjacency_by_source;
+            int G = 4;
+            while (G < p.S && G < 64) G <<= 1;
+            const int groups = 256 / G, grid = std::min(cdiv(p.N, groups), 256 * 16);
+#define AGGA(GG) gnn::k_aggregate_add<GG><<<grid, 256, 0, st>>>(c.n_dst, c.rowptr, c.src, c.w, c.row_scale, p.dx_s_all + p.off_agg, p.kdx_s, p.S, \
+                                                                 p.dx_s_all, p.kdx_s, p.G_state, p.S)
+            switch (G) { case 4: AGGA(4); break; case 8: AGGA(8); break; case 16: AGGA(16); break; case 32: AGGA(32); break; default: AGGA(64); break; }
+#undef AGGA
+            LAUNCH_OK();
+        }
+    }
+    if (ta.average_st_grads && k > 0) TRY(scale_grads(ns, ta.grad_state, 1.0f / (float)k, st));
+    return 0;
+}
+
+}  // extern "C"

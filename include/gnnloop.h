@@ -155,7 +155,8 @@ const char *gnn_last_error(void);
 const char *gnn_last_kernel_name(void);
 int gnn_abi_version(void);
 /* sizeof() of the ABI structs as this library was compiled (0 gnn_csr_t, 1 gnn_mlp_t, 2 gnn_loop_args_t; 3 = offsetof
- * (gnn_loop_args_t, flags)): lets a foreign-language binding verify its struct layout at load time. */
+ * (gnn_loop_args_t, flags); 4 gnn_train_args_t; 5 = offsetof(gnn_train_args_t, tape)): lets a foreign-language binding verify
+ * its struct layout at load time. */
 size_t gnn_struct_size(int which);
 
 /* bytes of scratch HBM gnn_loop_forward needs for `args` (only sizes / dims of `args` are read). */
@@ -276,6 +277,43 @@ int gnn_converged_gated(const float *state, const float *state_old, int32_t n, i
                         const int32_t *gate, int32_t *flag, float *k_out, float k_val, void *stream);
 int gnn_aggregate_gated(const gnn_csr_t *csr, const float *X, int32_t ldx, int32_t F, float *out, int32_t ldo,
                         const int32_t *gate, void *stream);
+
+/* ---- one whole training step of a homogeneous model inside the library (reference GNN.py:277-306) ---------------------
+ * Training-mode forward (BatchNormalization on batch statistics, moving averages updated once per executed iteration for
+ * the state network and once for the output network), Keras loss with sample weights, back-propagation through the k
+ * executed iterations, optional 1/k on the state-network gradients (`average_st_grads`, :295).  The optimizer update stays
+ * with the caller (gnn_adam_step / gnn_sgd_step per variable).  The same arithmetic as the building blocks above driven
+ * from Python, with the per-iteration orchestration and the per-segment launches folded into the library: a MUTAG-sized
+ * step is bound by launch count and host time, not by bandwidth.
+ * `loop` describes graph, networks (their BatchNormalization moving_mean / moving_variance arrays ARE UPDATED in place),
+ * focus, out_index, nodegraph, state0, max_iteration, state_threshold and stream exactly as for gnn_loop_forward; its
+ * k_out / state_out / out / workspace fields are ignored.  Heterogeneous (composite) models, dropout and LGNN label
+ * gradients are not covered: the caller uses the building blocks for those.
+ * The call synchronises the stream ONCE (to learn k, as the reference does when it divides by k). */
+typedef struct gnn_mlp_grads {
+    float *dgamma, *dbeta;                     /* [in_dim] each; NULL without BatchNormalization                   */
+    float *dkernel[GNN_MAX_LAYERS];            /* same shapes as the network's kernels / biases                     */
+    float *dbias[GNN_MAX_LAYERS];
+} gnn_mlp_grads_t;
+
+typedef struct gnn_train_args {
+    gnn_loop_args_t loop;
+    gnn_csr_t adjacency_by_source;             /* CSR of Adjacency itself (arcs grouped by SOURCE): transposed aggregate */
+    gnn_csr_t nodegraph_by_source;             /* graph focus: CSR of NodeGraph itself (n_dst = n_out nodes, n_src = #graphs) */
+    const float *targets;                      /* [n_rows, T]: n_rows = n_out (node / arc focus) or #graphs          */
+    const float *sample_weight;                /* [n_rows] or NULL                                                   */
+    int32_t loss_kind;                         /* 0 categorical_crossentropy, 1 binary_crossentropy, 2 mse, 3 mae    */
+    int32_t average_st_grads;
+    float bn_momentum;                         /* 0.99 in Keras                                                      */
+    gnn_mlp_grads_t grad_state, grad_output;   /* OUT (overwritten)                                                  */
+    float *y_pred;                             /* OUT [n_rows, T] training-mode prediction                            */
+    float *state;                              /* OUT [n_nodes, S] state after the k executed iterations              */
+    float *loss;                               /* OUT [1] device scalar                                               */
+    int32_t *k_host;                           /* OUT host int: iterations executed                                   */
+    void *tape; size_t tape_bytes;             /* >= gnn_train_workspace_bytes(args), 256-byte aligned                */
+} gnn_train_args_t;
+size_t gnn_train_workspace_bytes(const gnn_train_args_t *args);
+int gnn_train_step(const gnn_train_args_t *args);
 
 #ifdef __cplusplus
 }

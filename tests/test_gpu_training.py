@@ -56,12 +56,19 @@ def oracle_step(model, x, y, sw, s0, loss, avg=False, dtype=torch.float64):
                                   sample_weight=_np(sw), loss=loss, average_st_grads=avg, dtype=dtype)
 
 
-def check_step(model, x, y, sw, s0, loss='categorical_crossentropy', avg=False):
+def check_step(model, x, y, sw, s0, loss='categorical_crossentropy', avg=False, native=None):
     from gnnkeras_amd.Models.training import LoopTrainer
     model.compile(optimizer=SGD(0.0), loss=loss, average_st_grads=avg)
     want = oracle_step(model, x, y, sw, s0, loss, avg)
     before = [w.copy() for w in model.net_state.get_weights() + model.net_output.get_weights()]
+    if native is None:      # both orchestrations: the in-library step (gnn_train_step) and the building blocks driven from Python
+        moving = [w.copy() for w in model.net_state.get_weights() + model.net_output.get_weights()]
+        check_step(model, x, y, sw, s0, loss, avg, native=False)
+        for net, n0 in ((model.net_state, 0), (model.net_output, len(model.net_state.get_weights()))):
+            net.set_weights(moving[n0:n0 + len(net.get_weights())])               # the first pass moved the BN moving statistics
+        return check_step(model, x, y, sw, s0, loss, avg, native=True)
     tr = LoopTrainer(model)
+    tr.use_native_step = native
     res = tr.train_step(x, y, sw, state0=None if s0 is None else torch.from_numpy(s0).cuda(), apply=False)
     assert res['k'] == want['k']
     assert abs(float(res['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))

@@ -164,9 +164,6 @@ class LGNN(_LoopModel):
         if self.training_mode == 'serial':
             raise RuntimeError("training_mode 'serial' trains layer by layer: use fit()")
         if self.loss is None: raise RuntimeError('compile() the model with a loss before fit() / train_step()')
-        if self.GNN_CLASS is self._gnn_classes['arc'] and self.get_output:
-            raise NotImplementedError('joint training of arc-focused stacks with get_output needs arc-label gradients '
-                                      '(not built); use training_mode="serial"')
         x, y, sample_weight = data
         if y is None: raise TypeError('Target data is missing. Your model was compiled with `loss` '
                                       'argument and so expects targets to be passed in `fit()`.')
@@ -177,6 +174,7 @@ class LGNN(_LoopModel):
         trainers = [LoopTrainer(g) for g in self.gnns]
         for g in self.gnns: g.loss = self.loss
         graph_based = self.GNN_CLASS is self._gnn_classes['graph']
+        arc_based = self.GNN_CLASS is self._gnn_classes['arc']
         tapes, outs = [], []
         nodes, arcs, dnl = nodes_0, arcs_0, dim0
         for i, tr in enumerate(trainers):
@@ -204,15 +202,24 @@ class LGNN(_LoopModel):
             pooled_here = graph_based                              # every layer's task output is pooled for graph focus
             G = tr.pool_backward(tp, dpreds[i]) if pooled_here else dpreds[i].clone()
             if d_out_extra is not None: G = G + d_out_extra
-            d_nodes = tr.backward(tp, G.contiguous(), d_state_extra=d_state_extra, want_label_grads=i > 0)
+            arc_out = arc_based and self.get_output and i > 0        # the layer below wrote its output into the ARC labels
+            d_nodes = tr.backward(tp, G.contiguous(), d_state_extra=d_state_extra, want_label_grads=i > 0,
+                                  want_arc_label_grads=arc_out)
             d_state_extra = d_out_extra = None
             if i > 0:
                 prev = tapes[i - 1]
                 col = 0
                 if self.get_state:
                     d_state_extra = d_nodes[:, :prev.S].contiguous(); col = prev.S
-                if self.get_output:
+                if self.get_output and not arc_based:
                     d_out_extra = d_nodes[:, col:col + prev.T].index_select(0, prev.out_index.long()).contiguous()
+                elif arc_out:
+                    # update_graph PREPENDS the T output columns to the arcs matrix (reference LGNN.py:209: `concat([arcplus,
+                    # arcs])`), so the model's label view arcs[:, 2:] starts at output column 2: columns 0 and 1 sit where the
+                    # arc ids used to be and are never read; output column 2 + j is arc-label column j
+                    d_out_extra = torch.zeros((prev.M, prev.T), dtype=torch.float32, device=tp.dev)
+                    if prev.T > 2:
+                        d_out_extra[:, 2:] = tp.d_arc_labels[:, :prev.T - 2].index_select(0, prev.out_index.long())
         for tp, tr in zip(tapes, trainers): tr.finish(tp, apply=False)
         if apply:
             gv = [pair for tp in tapes for pair in LoopTrainer.grads_and_vars(tp)]

@@ -317,6 +317,7 @@ class LoopTrainer:
         adj = tp.adj = adjacency.device_csr(dev)
         tp.adj_src = _by_source(adjacency, dev)
         an = arcnode.device_csr(dev)
+        tp.arcnode = arcnode
         tp.nodegraph = nodegraph
         tp.cas = _cas if composite else None
         from .GNN import _squeeze_last, _arc_endpoints
@@ -475,11 +476,14 @@ class LoopTrainer:
         return tp.p.aggregate(_by_source(tp.nodegraph, tp.dev), dpred, tp.T, tp.p.new(tp.M, tp.T))
 
     # ---- backward sweep -------------------------------------------------------------------------------------------------
-    def backward(self, tp, G_out_nodes, d_state_extra=None, want_label_grads=False):
+    def backward(self, tp, G_out_nodes, d_state_extra=None, want_label_grads=False, want_arc_label_grads=False):
         """Accumulates the parameter gradients into tp.gs / tp.go from `G_out_nodes` = d loss / d tp.out_nodes (M x T)
         and an optional extra gradient on the final state (N x S; LGNN feeds the next layer's label gradient here).
         `want_label_grads` (homogeneous models): also returns d loss / d nodes (N x L), the quantity an LGNN layer hands
-        to the layer below through `update_graph` (reference LGNN.py:175-214)."""
+        to the layer below through `update_graph` (reference LGNN.py:175-214).
+        `want_arc_label_grads` (homogeneous models): leaves d loss / d arc labels (E x A) in `tp.d_arc_labels` — through the
+        ArcNode scatter-add of every iteration's constant segment (GNN.py:254) and, for arc focus, the output network's
+        arc-label segment (GNN.py:326): what an arc-focused LGNN layer with `get_output` hands to the layer below."""
         m, p = self.model, tp.p
         N, S, L, d, M, k, focus = tp.N, tp.S, tp.L, tp.d, tp.M, tp.k, tp.focus
         gs, go, rows, rows_long, counts = tp.gs, tp.go, tp.rows, tp.rows_long, tp.counts
@@ -495,9 +499,13 @@ class LoopTrainer:
                 if lab:
                     dls, dld = p.new(M, L), p.new(M, L)
                     req += [(1, dls), (3, dld)]
+                d_arc_o = None
+                if want_arc_label_grads and tp.A > 0:
+                    d_arc_o = p.new(M, tp.A); req.append((len(tp.osegs) - 1, d_arc_o))      # the arc-label segment is the last one
                 self._mlp_backward(go, tp.osegs, tp.ohs, G_out_nodes, M, tp.ostats, req)
                 p.scatter_add_rows(dxs, tp.isrc, G_state); p.scatter_add_rows(dxd, tp.idst, G_state)
                 if lab: p.scatter_add_rows(dls, tp.isrc, d_nodes); p.scatter_add_rows(dld, tp.idst, d_nodes)
+                if d_arc_o is not None: tp._d_arc_out = d_arc_o
             else:
                 dxo = p.new(M, S)
                 req = [(0, dxo)]
@@ -513,6 +521,8 @@ class LoopTrainer:
             d_aggn, dl_t, da_t_ = p.zeros(N, L), p.new(N, L), p.new(N, L)
         if want_label_grads and tp.composite:
             d_acomp = p.zeros(N, max(sum(tp.dims) + tp.A, 1))
+        arc_grads = want_arc_label_grads and not tp.composite and tp.A > 0
+        if arc_grads: d_aarcs, da_arcs_t = p.zeros(N, tp.A), p.new(N, tp.A)
         for t in range(k - 1, -1, -1):
             p.aggregate(tp.adj, tp.states[t], S, tp.agg)
             for ty in range(tp.T_types):
@@ -522,9 +532,11 @@ class LoopTrainer:
                 if rows[ty] is None:
                     req = [(i_state, dx_s), (i_agg, dx_a)]
                     if want_label_grads and d > 0: req += [(i_lab, dl_t), (i_alab, da_t_)]
+                    if arc_grads: req.append((len(segs) - 1, da_arcs_t))             # the aggregated-arc segment is the last one
                     self._mlp_backward(gs[ty], segs, hs, G_state, N, tp.stats_t[t][ty], req)
                     if want_label_grads and d > 0:
                         p.axpby(1.0, d_nodes, 1.0, dl_t, d_nodes); p.axpby(1.0, d_aggn, 1.0, da_t_, d_aggn)
+                    if arc_grads: p.axpby(1.0, d_aarcs, 1.0, da_arcs_t, d_aarcs)
                 else:
                     G_t = G_state.index_select(0, rows_long[ty])
                     ds_t, da_t = p.new(counts[ty], S), p.new(counts[ty], S)
@@ -541,6 +553,18 @@ class LoopTrainer:
                         if i_alab is not None: d_acomp.index_add_(0, rows_long[ty], dac)
             p.aggregate(tp.adj_src, dx_a, S, G_state)               # Adj . d agg   (arcs walked by source)
             p.axpby(1.0, G_state, 1.0, dx_s, G_state)
+        if want_arc_label_grads and not tp.composite:
+            # d arc labels = ArcNode . d agg_arcs (the scatter-add of GNN.py:254 transposed: every arc reads its destination's
+            # row, times its weight) + the output network's arc-label segment on the masked arcs (arc focus)
+            E = tp.arc_labels.shape[0]
+            d_arcs = p.zeros(E, max(tp.A, 1))[:, :tp.A]
+            if arc_grads and k > 0:
+                d_arcs = p.aggregate(_by_source(tp.arcnode, tp.dev), d_aarcs, tp.A, p.new(E, tp.A))
+            extra = getattr(tp, '_d_arc_out', None)
+            if extra is not None:
+                d_arcs = d_arcs.contiguous()
+                p.scatter_add_rows(extra, tp.out_index, d_arcs)
+            tp.d_arc_labels = d_arcs
         if want_label_grads and tp.composite:
             col = 0
             for t_src, ca in enumerate(tp.cas):                     # through CA_t^T . nodes[:, :d_t] (CompositeGNN.py:251)

@@ -168,6 +168,29 @@ def test_dropout_networks_are_refused_not_silently_trained(mutag_graphs):
     assert out.shape == (8, 2)
 
 
+@pytest.mark.parametrize('focus', ['g', 'n'])
+def test_call_training_true_returns_k_state_out_on_batch_statistics(mutag_graphs, focus):
+    """`gnn(x, training=True)` outside train_step (reference GNN.py:165-177 returns `(k, state, out)`): BatchNormalization
+    networks — the starter default, MLP.py:14 — run on BATCH statistics; against the oracle's training=True forward."""
+    from oracle.harness import oracle_loop
+    rng = np.random.default_rng(12)
+    gl = refocus([g.copy() for g in mutag_graphs[:16]], focus, rng)
+    seq = MultiGraphSequencer(gl, focus, 'average', 16, shuffle=False)
+    x = seq[0][0]
+    d = 16
+    ns, no = nets(focus, d, True, scale=0.3)
+    model = CLS[focus](ns, no, d, 8, 0.02)
+    s0 = rng.normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)
+    before = ns.get_weights()[2].copy()
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, training=True)
+    k, st, o = model.Loop(*model.process_inputs(x), training=True, state0=torch.from_numpy(s0).cuda())
+    assert float(k) == float(k64) and 1 < float(k) <= 8
+    assert rel_err(st.cpu().numpy(), st64) <= 5e-5 and rel_err(o.cpu().numpy(), o64) <= 5e-5
+    assert not np.array_equal(ns.get_weights()[2], before)            # the moving mean moved: training mode really ran
+    ki, sti, oi = model.Loop(*model.process_inputs(x), training=False, state0=torch.from_numpy(s0).cuda())
+    assert rel_err(oi.cpu().numpy(), o64) > 1e-3                      # and inference statistics give a different answer
+
+
 def test_adam_step_matches_reference_formula(mutag_graphs):
     rng = np.random.default_rng(8)
     seq = MultiGraphSequencer(mutag_graphs[:16], 'g', 'average', 16, shuffle=False)
@@ -311,14 +334,14 @@ def test_composite_fit_runs():
 # Layered GNN (reference GNN/Models/LGNN.py): forward, joint training modes with gradients chained through
 # update_graph, serial fit
 # ----------------------------------------------------------------------------------------------------------------------
-def lgnn_stack(focus, d, n_layers, get_state, get_output, bn, max_it=4):
+def lgnn_stack(focus, d, n_layers, get_state, get_output, bn, max_it=4, T=2):
     from gnnkeras_amd.Models.LGNN import LGNN
     gnns = []
     for i in range(n_layers):
-        inp, lay = get_inout_dims('state', 14, 3, 2, focus, d, layer=i, get_state=get_state, get_output=get_output)
+        inp, lay = get_inout_dims('state', 14, 3, T, focus, d, layer=i, get_state=get_state, get_output=get_output)
         ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=10 + i, batch_normalization=bn)
         ns.set_weights([a * 0.5 if a.ndim == 2 else a for a in ns.get_weights()])
-        inp, lay = get_inout_dims('output', 14, 3, 2, focus, d, layer=i, get_state=get_state, get_output=get_output)
+        inp, lay = get_inout_dims('output', 14, 3, T, focus, d, layer=i, get_state=get_state, get_output=get_output)
         no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=20 + i, batch_normalization=bn)
         gnns.append(CLS[focus](ns, no, d, max_it, 0.0))
     return LGNN(gnns, get_state, get_output)
@@ -360,6 +383,50 @@ def test_lgnn_joint_training_gradients(mutag_graphs, focus, d, get_state, get_ou
     # eval-mode forward of the stack agrees with the layers' own Loop chain and has the reference's list layout
     K, states, outs = lg.Loop(*lg.process_inputs(x), state0=[None if s is None else torch.from_numpy(s).cuda() for s in s0s])
     assert len(K) == len(states) == len(outs) == 3 and outs[-1].shape == lg(x).shape
+
+
+@pytest.mark.parametrize('T,get_state', [(4, True), (2, False), (3, False)])
+@pytest.mark.parametrize('mode', ['parallel', 'residual'])
+def test_lgnn_arc_focused_joint_training_with_get_output(mutag_graphs, T, get_state, mode):
+    """Arc-focused stack with `get_output` (reference LGNN.py:252-287 + the arc branch of update_graph, :203-209): layer i's
+    per-arc output is PREPENDED to the arcs matrix, so output columns 2.. become arc-label columns of layer i + 1 (columns 0 / 1
+    land where the ids were and are never read: with T = 2 no gradient flows back through the output at all).  The gradient
+    reaches layer i through the ArcNode scatter-add of every iteration and through the output network's arc-label segment."""
+    rng = np.random.default_rng(31)
+    gl = []
+    for g in mutag_graphs[:10]:
+        n = g.arcs.shape[0]
+        om = rng.random(n) < 0.7
+        t = np.zeros((int(om.sum()), T)); t[np.arange(len(t)), rng.integers(0, T, len(t))] = 1
+        gl.append(GraphObject(nodes=g.nodes, arcs=g.arcs, targets=t, focus='a', set_mask=rng.random(n) < 0.8, output_mask=om,
+                              sample_weight=rng.uniform(0.5, 1.5, len(t))))
+    seq = MultiGraphSequencer(gl, 'a', 'average', 10, shuffle=False)
+    x, y, sw = seq[0]
+    d = 6
+    lg = lgnn_stack('a', d, 3, get_state, True, True, T=T)
+    lg.compile(optimizer=SGD(0.0), loss='categorical_crossentropy', training_mode=mode, average_st_grads=False)
+    N = x[0].shape[0]
+    s0s = [rng.normal(0, 0.1, (N, d)).astype(np.float32) for _ in range(3)]
+    nodes, arcs, _, sm, om, adj, an, ng = x
+    mask = np.logical_and(_np(sm).reshape(-1), _np(om).reshape(-1))
+    layers = [dict(net_state=g.net_state.spec(), net_output=g.net_output.spec(), state_vect_dim=d, max_iteration=4,
+                   state_threshold=0.0) for g in lg.gnns]
+    want = torch_train.lgnn_train_step(_np(nodes), _np(arcs), _triple(adj), _triple(an), _triple(ng), mask, layers=layers,
+                                       get_state=get_state, get_output=True, focus='a', state0s=s0s, y=_np(y),
+                                       sample_weight=_np(sw), loss='categorical_crossentropy', training_mode=mode)
+    logs = lg.train_step((x, y, sw), state0=[torch.from_numpy(s).cuda() for s in s0s], apply=False)
+    assert logs['k'] == want['k']
+    assert abs(float(logs['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))
+    allref = [r for gs_, go_ in want['grads'] for r in gs_ + go_]
+    scale = max(float(np.max(np.abs(r))) for r in allref)
+    for li, tp in enumerate(lg._last_tapes):
+        got = [g for t in tp.gs for g in t.gradients()] + tp.go.gradients()
+        ref = want['grads'][li][0] + want['grads'][li][1]
+        for i, (g, r) in enumerate(zip(got, ref)):
+            err = float(np.max(np.abs(g.cpu().numpy() - r)))
+            assert err <= GTOL * max(float(np.max(np.abs(r))), 1e-12) or err <= GTOL * scale, (li, i, err)
+    if T > 2:       # the chain through the arc labels carries a real gradient: layer 0's output net sees more than its own loss
+        assert float(np.max(np.abs(want['grads'][0][1][-1]))) > 0
 
 
 def test_lgnn_serial_fit_and_persistence(mutag_graphs, tmp_path):

@@ -46,7 +46,7 @@ def test_fuzz_homogeneous(seed):
     rng = np.random.default_rng(1000 + seed)
     focus = ['n', 'a', 'g'][seed % 3]
     L, A, T = int(rng.integers(1, 20)), int(rng.integers(0, 5)), int(rng.integers(1, 5))
-    d = int(rng.choice([0, 1, 2, 5, 8, 16, 24, 32, 40, 64, 70]))
+    d = int(rng.choice([0, 1, 2, 5, 8, 16, 24, 32, 40, 64, 70, 100, 128]))       # > 64: the wide fused kernel
     mode = ['sum', 'average', 'normalized'][int(rng.integers(0, 3))]
     bn = bool(rng.integers(0, 2))
     hidden = [int(rng.integers(3, 50))] if rng.random() < 0.3 else None
@@ -103,7 +103,7 @@ def test_fuzz_composite(seed):
     Tt = int(rng.integers(2, 6))        # one type: the reference's get_inout_dims sizes the output net with labels (MLP.py:124)
     dims = tuple(int(v) for v in rng.integers(1, 7, Tt))
     Lw, A, T = max(dims), int(rng.integers(0, 4)), int(rng.integers(1, 4))
-    D = int(rng.choice([1, 4, 8, 16, 33]))
+    D = int(rng.choice([1, 4, 8, 16, 33, 72]))
     mode = ['sum', 'average', 'normalized', 'composite_average'][int(rng.integers(0, 4))]
     graphs = []
     for _ in range(int(rng.integers(1, 4))):

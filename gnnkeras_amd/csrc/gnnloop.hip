@@ -690,7 +690,7 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;
     }
-    if (p.SP == 128) { FUSED_OK(gnn::launch_wide(fa, device_cus(), st)); return 0; }
+    if (p.SP == 128) { FUSED_OK(gnn::launch_wide(fa, device_cus(), st, fused_waves())); return 0; }
     const int gen = agg_init ? 4 : iteration_generation(a, p);
     if (gen == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
     else FUSED_OK(gnn::launch_fused2(fa, p.SP, fused_waves() == 0 ? 8 : fused_waves(), device_cus(), st));
@@ -989,7 +989,10 @@ int gnn_shard_can_split(const gnn_loop_args_t *args) {
     if (!args) return 0;
     Plan p;
     if (make_plan(*args, args->workspace, p, false)) return 0;
-    if (fusable(*args, p) != 1 || p.SP <= 16 || p.SP > 64 || p.n_heavy != 0) return 0;     // one-layer state nets on the wave-specialised kernel
+    const int f = fusable(*args, p);
+    if (p.n_heavy != 0) return 0;
+    if (f == 3) return 1;                                          // state widths 65 .. 128: the wide kernel, whatever is pinned
+    if (f != 1 || p.SP <= 16) return 0;                            // one-layer state nets on the wave-specialised kernel
     const int pinned = (args->flags & GNN_FLAG_FUSED_GEN_MASK) >> 4;
     return pinned == 0 || pinned == 4;
 }

@@ -49,12 +49,12 @@ struct WideCfg {
 // dwords on odd g keeps the two 16-B halves of neighbouring lane groups on different banks
 __device__ __forceinline__ int wide_wcol(int kp, int n) { return n ^ (((kp >> 2) & 1) << 2); }
 
-template <bool HAS_W>
+template <bool HAS_W, bool INIT = false, int DEPTH = WideCfg::DEPTH>
 __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
     int open = a.gate == nullptr;
     for (int i = 0; i < a.n_gate; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
     using Cfg = WideCfg;
-    constexpr int SP = Cfg::SP, NT = Cfg::NT, LPR = Cfg::LPR, LDA = Cfg::LDA, NS = Cfg::NS, CH = Cfg::CH, DEPTH = Cfg::DEPTH;
+    constexpr int SP = Cfg::SP, NT = Cfg::NT, LPR = Cfg::LPR, LDA = Cfg::LDA, NS = Cfg::NS, CH = Cfg::CH;
     constexpr int SPIN_MAX = GNN_F4_SPIN_MAX;
     int bad = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
 
     const __amdgpu_buffer_rsrc_t r_C = buf_rsrc(a.C), r_rows = buf_rsrc(tp.rows), r_state = buf_rsrc(a.state_in),
                                  r_rowptr = buf_rsrc(a.rowptr), r_src = buf_rsrc(a.src), r_w = buf_rsrc(HAS_W ? a.w : nullptr),
-                                 r_scale = buf_rsrc(a.row_scale);
+                                 r_scale = buf_rsrc(a.row_scale), r_init = buf_rsrc(INIT ? a.agg_init : nullptr);
     const bool has_scale = a.row_scale != nullptr;
     char *__restrict__ obase = reinterpret_cast<char *>(a.state_out);
     int any = 0;
@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
             const int jC = node_of(job_m(n + 2 * Cfg::NPROD));
             const float scl = buf_ld_f32(r_scale, j >= 0 ? 4u * (unsigned)j : BUF_OFF);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (INIT) acc = buf_ld_f32x4(r_init, j >= 0 ? (unsigned)j * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);   // sum of the arcs walked earlier (overlap)
             int idB = 0; float wB = 0.0f;
             int rem = endA - begA, eb = begA;
             int idc = idA; float wc = wA;
@@ -309,12 +310,12 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
     }
 }
 
-template <bool HAS_W>
+template <bool HAS_W, bool INIT, int DEPTH = WideCfg::DEPTH>
 int launch_wide_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     using Cfg = WideCfg;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)k_state_wide<HAS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_state_wide<HAS_W, INIT, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES) != hipSuccess)
             return 1;
         attr = true;
     }
@@ -333,13 +334,16 @@ int launch_wide_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0) return 0;
-    GNN_SET_KERNEL_NAME("k_state_wide<%s>", HAS_W ? "true" : "false");
-    k_state_wide<HAS_W><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
+    GNN_SET_KERNEL_NAME("k_state_wide<%s,%s>", HAS_W ? "true" : "false", INIT ? "true" : "false");
+    k_state_wide<HAS_W, INIT, DEPTH><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-inline int launch_wide(Fused2Args &fa, int n_cu, hipStream_t st) {
-    return fa.w ? launch_wide_one<true>(fa, n_cu, st) : launch_wide_one<false>(fa, n_cu, st);
+inline int launch_wide(Fused2Args &fa, int n_cu, hipStream_t st, int depth = 0) {
+    if (!fa.agg_init && !fa.w && depth == 4) return launch_wide_one<false, false, 4>(fa, n_cu, st);       // tuning knob (GNN_FUSED_WAVES)
+    if (!fa.agg_init && !fa.w && depth == 16) return launch_wide_one<false, false, 16>(fa, n_cu, st);
+    if (fa.agg_init) return fa.w ? launch_wide_one<true, true>(fa, n_cu, st) : launch_wide_one<false, true>(fa, n_cu, st);
+    return fa.w ? launch_wide_one<true, false>(fa, n_cu, st) : launch_wide_one<false, false>(fa, n_cu, st);
 }
 
 }  // namespace gnn

@@ -213,7 +213,7 @@ int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const 
  * per-arc-weighted partial sums of the own-range arcs into agg_partial [n_nodes, gnn_state_ld(S)]); once it has landed,
  * gnn_shard_iteration_split walks only the halo arcs, starting every row's sum from agg_partial (summation order: own-range
  * arcs, then halo arcs - within float32 re-association of the single-GPU result).  gnn_shard_can_split tells whether this
- * model / shard runs on the kernel that supports it (one-layer state networks, state width 17..64, no hub rows); when it
+ * model / shard runs on a kernel that supports it (one-layer state networks, state width 17..128, no hub rows); when it
  * returns 0 use gnn_shard_iteration. */
 int gnn_shard_can_split(const gnn_loop_args_t *args);
 int gnn_shard_partial(const gnn_loop_args_t *args, const gnn_csr_t *adjacency_own, const float *state_in_full,

@@ -627,6 +627,21 @@ def test_sharded_native_kernels_match_oracle(R, threshold):
         assert rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL
 
 
+def test_sharded_overlap_split_wide_state():
+    """The own-range / halo split on the wide kernel (d = 128)."""
+    rng = np.random.default_rng(3)
+    N, d = 20_003, 128
+    g = er_graph(N, 160_000, seed=7, aggregation_mode='average')
+    ns, no = starter_nets('n', d, scale=0.25)
+    model = GNNnodeBased(ns, no, d, 5, 0.0)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    for R in (1, 4):
+        ks, st, o = _run_shards_on_one_gpu(model, g, s0, R, overlap=True)
+        assert all(k == float(k64) for k in ks) and rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL
+
+
 @pytest.mark.parametrize('R', [1, 2, 8])
 @pytest.mark.parametrize('mode,threshold', [('average', 0.0), ('average', 0.02), ('sum', 0.0)])
 def test_sharded_overlap_split_matches_oracle(R, mode, threshold):

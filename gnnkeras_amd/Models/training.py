@@ -755,6 +755,8 @@ def _check_no_dropout(nets):
 def _by_source(matrix: SparseMatrix, device):
     """CSR of A itself (arcs grouped by SOURCE): the operator of the transposed aggregate, out[i] = Σ_{e: src=i} w_e X[dst_e]."""
     key = ('by_source', str(device))
+    if key not in matrix._dev and hasattr(matrix, 'by_source'):
+        return matrix.by_source(device)            # assembled on the device (gnnkeras_amd/device_batch.py)
     if key not in matrix._dev:
         c = CSRByDestination.from_coo(matrix.indices[:, 1], matrix.indices[:, 0], matrix.values,
                                       (matrix.dense_shape[1], matrix.dense_shape[0]))

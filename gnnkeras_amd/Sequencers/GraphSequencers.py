@@ -30,7 +30,10 @@ class MultiGraphSequencer:
     to_graph_tensor = classmethod(lambda cls, g, device=None: GraphTensor.fromGraphObject(g, device))
 
     def __init__(self, graphs, focus: str, aggregation_mode: str, batch_size: int = 32, shuffle: bool = True,
-                 device=None):
+                 device=None, assemble: str = 'auto'):
+        """`assemble` (additive): where batches are merged — 'host' (numpy `GraphObject.merge`, then upload), 'device' (the data
+        set is uploaded once, a batch is ONE ragged-copy launch: `gnnkeras_amd/device_batch.py`) or 'auto' = device on a GPU
+        for homogeneous data sets it supports, host otherwise. Same arrays either way."""
         self.data = graphs if isinstance(graphs, list) else [graphs]
         self.focus = focus
         self.aggregation_mode = aggregation_mode
@@ -38,10 +41,44 @@ class MultiGraphSequencer:
         self.shuffle = shuffle
         self.dtype = 'float32'
         self.device = torch.device(device) if device is not None else default_device()
+        if assemble not in ('auto', 'host', 'device'): raise ValueError("assemble must be 'auto', 'host' or 'device'")
+        self.assemble = assemble
+        self._dataset = None
         self.build_batches()
 
+    def _device_dataset(self):
+        """The device-resident data set, or None when batches are merged on the host."""
+        if self.assemble == 'host' or self.device.type != 'cuda' or type(self).merge.__func__ is not MultiGraphSequencer.merge.__func__:
+            if self.assemble == 'device': raise ValueError('device assembly needs a GPU and a homogeneous data set')
+            return None
+        if self._dataset is None or self._dataset[1] != len(self.data):
+            from ..device_batch import DeviceDataset
+            try:
+                ds = DeviceDataset(self.data, self.focus, self.aggregation_mode, self.device)
+            except ValueError:
+                if self.assemble == 'device': raise
+                ds = None
+            if ds is not None and ds.hub:
+                if self.assemble == 'device': raise ValueError('hub rows (in-degree > 512) need the host-side split')
+                ds = None
+            self._dataset = (ds, len(self.data), {id(g): i for i, g in enumerate(self.data)})
+        return self._dataset[0]
+
     def build_batches(self):
-        """Slice the graph list by batch_size, merge each slice, move it to the device (reference :42-46)."""
+        """Slice the graph list by batch_size, merge each slice, have it on the device (reference :42-46)."""
+        ds = self._device_dataset()
+        if ds is not None:
+            index = self._dataset[2]
+            try:
+                order = [index[id(g)] for g in self.data]
+            except KeyError:                                    # the list was edited: start over from the current graphs
+                self._dataset = None
+                ds = self._device_dataset()
+                order = list(range(len(self.data)))
+            if ds is not None:
+                self.graph_tensors = [ds.assemble(order[i * self.batch_size: (i + 1) * self.batch_size]) for i in range(len(self))]
+                self._items = [None] * len(self.graph_tensors)
+                return
         graphs = [self.merge(self.data[i * self.batch_size: (i + 1) * self.batch_size], focus=self.focus,
                              aggregation_mode=self.aggregation_mode) for i in range(len(self))]
         self.graph_tensors = [self.to_graph_tensor(g, self.device) for g in graphs]

@@ -32,7 +32,7 @@ EXPORTS = ['gnn_last_error', 'gnn_last_kernel_name', 'gnn_abi_version', 'gnn_str
            'gnn_dense', 'gnn_fold_bn', 'gnn_dense_grad_workspace_bytes', 'gnn_dense_grad', 'gnn_act_grad',
            'gnn_colstats_workspace_bytes', 'gnn_colstats', 'gnn_first_layer_param_grads', 'gnn_bn_input_grad',
            'gnn_scatter_add_rows', 'gnn_axpby', 'gnn_loss_grad', 'gnn_adam_step', 'gnn_sgd_step',
-           'gnn_converged_gated', 'gnn_aggregate_gated', 'gnn_train_workspace_bytes', 'gnn_train_step']
+           'gnn_converged_gated', 'gnn_aggregate_gated', 'gnn_train_workspace_bytes', 'gnn_train_step', 'gnn_ragged_copy']
 GNN_MAX_SEGMENTS = 6
 LOSSES = {'categorical_crossentropy': 0, 'cce': 0, 'binary_crossentropy': 1, 'bce': 1, 'mse': 2,
           'mean_squared_error': 2, 'mae': 3, 'mean_absolute_error': 3}
@@ -100,6 +100,15 @@ class TrainArgs(C.Structure):
                 ('grad_state', MLPGrads), ('grad_output', MLPGrads),
                 ('y_pred', C.c_void_p), ('state', C.c_void_p), ('loss', C.c_void_p), ('k_host', C.POINTER(C.c_int32)),
                 ('tape', C.c_void_p), ('tape_bytes', C.c_size_t)]
+
+
+class RaggedDesc(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('count', C.c_int64), ('kind', C.c_int32), ('iadd', C.c_int32),
+                ('fval', C.c_float), ('width', C.c_int32)]
+
+
+RC_COPY_F32, RC_COPY_I32_ADD, RC_COPY_ROWS_ADD2, RC_FILL_F32, RC_FILL_I32, RC_IOTA_I32, RC_COPY_U8 = range(7)
+RC_CHUNK = 2048
 
 
 class NativeError(RuntimeError):
@@ -179,6 +188,7 @@ def lib():
             'gnn_aggregate_gated': (C.c_int, [C.POINTER(CSR), vp, i32, i32, vp, i32, vp, vp]),
             'gnn_train_workspace_bytes': (sz, [C.POINTER(TrainArgs)]),
             'gnn_train_step': (C.c_int, [C.POINTER(TrainArgs)]),
+            'gnn_ragged_copy': (C.c_int, [vp, i32, vp, i32, vp]),
         }
         for name, (res, args) in protos.items():
             fn = getattr(l, name)
@@ -189,7 +199,7 @@ def lib():
             raise NativeError('libgnnloop.so ABI version mismatch: rebuild it')
         if (l.gnn_struct_size(0), l.gnn_struct_size(1), l.gnn_struct_size(2), l.gnn_struct_size(3)) != \
                 (C.sizeof(CSR), C.sizeof(MLP), C.sizeof(LoopArgs), LoopArgs.flags.offset) or \
-                (l.gnn_struct_size(4), l.gnn_struct_size(5)) != (C.sizeof(TrainArgs), TrainArgs.tape.offset):
+                (l.gnn_struct_size(4), l.gnn_struct_size(5), l.gnn_struct_size(6)) != (C.sizeof(TrainArgs), TrainArgs.tape.offset, C.sizeof(RaggedDesc)):
             raise NativeError('ctypes struct layout does not match libgnnloop.so: rebuild it')
         _lib = l
     return _lib

@@ -23,6 +23,7 @@
 #include "kernel_state_fused4.hpp"
 #include "kernel_state_small.hpp"
 #include "kernel_state_wide.hpp"
+#include "kernels_batch.hpp"
 
 namespace {
 
@@ -782,6 +783,7 @@ size_t gnn_struct_size(int which) {
         case 3: return offsetof(gnn_loop_args_t, flags);
         case 4: return sizeof(gnn_train_args_t);
         case 5: return offsetof(gnn_train_args_t, tape);
+        case 6: return sizeof(gnn_ragged_desc_t);
         default: return 0;
     }
 }
@@ -943,6 +945,16 @@ int gnn_gather_rows(const float *src, int32_t ld_src, const int32_t *idx, int32_
     if (!src || !idx || !dst) return fail("NULL pointer");
     const long total = (long)M * ((width & 3) == 0 ? width / 4 : width);
     gnn::k_gather_rows<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, (hipStream_t)stream>>>(src, ld_src, idx, M, width, dst, ld_dst);
+    LAUNCH_OK();
+    return 0;
+}
+
+int gnn_ragged_copy(const gnn_ragged_desc_t *desc, int32_t n_desc, const int32_t *blk_begin, int32_t n_blocks, void *stream) {
+    if (n_desc < 0 || n_blocks < 0) return fail("bad n_desc / n_blocks");
+    if (n_desc == 0 || n_blocks == 0) return 0;
+    if (!desc || !blk_begin) return fail("desc / blk_begin is NULL");
+    static_assert(gnn::RC_CHUNK == GNN_RC_CHUNK, "chunk size of the header and the kernel differ");
+    gnn::k_ragged_copy<<<n_blocks, 256, 0, (hipStream_t)stream>>>(desc, n_desc, blk_begin);
     LAUNCH_OK();
     return 0;
 }

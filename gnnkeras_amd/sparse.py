@@ -111,7 +111,11 @@ def split_heavy(c: CSRByDestination, threshold: int = HEAVY_THRESHOLD, segment: 
 
 class SparseMatrix:
     """COO triple with `tf.SparseTensor`'s attribute names (`indices`, `values`, `dense_shape`/`shape`), entries in
-    canonical row-major order, plus the cached by-destination CSR (host and device copies)."""
+    canonical row-major order, plus the cached by-destination CSR (host and device copies).
+
+    A matrix can also be *device-only* (`SparseMatrix.device_only`): assembled on the GPU (batch assembly,
+    `gnnkeras_amd/device_batch.py`; `synth.er_device_batch`), it carries just the device CSR the kernels walk; the host COO
+    (`indices` / `values`) is rebuilt from it on first access - tests and the oracle read it, the hot path never does."""
 
     def __init__(self, indices, values, dense_shape, *, reorder: bool = True):
         indices = np.asarray(indices, dtype=np.int64).reshape(-1, 2)
@@ -122,20 +126,60 @@ class SparseMatrix:
             order = np.lexsort((indices[:, 1], indices[:, 0]))
             if not np.array_equal(order, np.arange(len(order))):
                 indices, values = indices[order], values[order]
-        self.indices = indices
-        self.values = values
+        self._indices = indices
+        self._values = values
         self.dense_shape = tuple(int(i) for i in np.asarray(dense_shape).reshape(-1))
         self._csr = None
         self._dev = {}
 
+    @classmethod
+    def device_only(cls, dense_shape, csr: dict, device, **more):
+        """`csr`: dict(rowptr, src, w | None, row_scale | None, n_src, n_dst, nnz[, max_degree]) of tensors on `device`;
+        `more`: further device-side forms to pre-seed the cache with (`by_source=dict`, `endpoints=(src, dst)`)."""
+        m = object.__new__(cls)
+        m._indices = m._values = None
+        m.dense_shape = tuple(int(i) for i in dense_shape)
+        m._csr = None
+        d = dict(csr)
+        d.setdefault('max_degree', 0); d.setdefault('light', None); d.setdefault('heavy', None)
+        m._dev = {(str(torch.device(device)), True): d}
+        for key, val in more.items():
+            if val is not None: m._dev[(key, str(torch.device(device)))] = val
+        return m
+
+    def _materialise_host(self):
+        """Host COO (row-major) of a device-only matrix, from its device CSR."""
+        key = next(k for k in self._dev if isinstance(k[1], bool))
+        d = self._dev[key]
+        rowptr, src = d['rowptr'].cpu().numpy().astype(np.int64), d['src'].cpu().numpy().astype(np.int64)
+        counts = np.diff(rowptr)
+        dst = np.repeat(np.arange(len(counts), dtype=np.int64), counts)
+        if d['w'] is not None: val = d['w'].cpu().numpy().astype(np.float32)
+        elif d['row_scale'] is not None: val = d['row_scale'].cpu().numpy().astype(np.float32)[dst]
+        else: val = np.ones(len(src), dtype=np.float32)
+        order = np.lexsort((dst, src))
+        self._indices, self._values = np.stack([src[order], dst[order]], axis=1), val[order]
+
     # tf.SparseTensor-like surface -----------------------------------------------------------------------------------
+    @property
+    def indices(self):
+        if self._indices is None: self._materialise_host()
+        return self._indices
+
+    @property
+    def values(self):
+        if self._values is None: self._materialise_host()
+        return self._values
+
     @property
     def shape(self):
         return self.dense_shape
 
     @property
     def nnz(self):
-        return len(self.values)
+        if self._values is None:
+            return int(next(v for k, v in self._dev.items() if isinstance(k[1], bool))['nnz'])
+        return len(self._values)
 
     @classmethod
     def from_scipy(cls, coo):
@@ -178,6 +222,8 @@ class SparseMatrix:
         device = torch.device(device) if device is not None else default_device()
         key = (str(device), uniform_rows)
         if key not in self._dev:
+            if self._indices is None:
+                raise ValueError(f'this matrix lives on {[k[0] for k in self._dev if isinstance(k[1], bool)]} only; asked for {device}')
             c = self.csr(uniform_rows)
             up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
             d = dict(rowptr=up(c.rowptr), src=up(c.src), w=up(c.w), row_scale=up(c.row_scale),
@@ -204,12 +250,30 @@ class SparseMatrix:
 
 class SparseTriple(tuple):
     """3-tuple `(indices i64[nnz,2], values f32[nnz,1], dense_shape i64[2])` exactly as the reference sequencer emits
-    it, that also remembers the `SparseMatrix` it came from so the model does not rebuild the CSR per call."""
+    it, that also remembers the `SparseMatrix` it came from so the model does not rebuild the CSR per call. The two big
+    tensors are made on first access: the hot path (`SparseMatrix.from_triple`) never touches them."""
 
     def __new__(cls, matrix: SparseMatrix, device=None):
         device = torch.device(device) if device is not None else default_device()
-        self = super().__new__(cls, (torch.from_numpy(matrix.indices).to(device),
-                                     torch.from_numpy(matrix.values).to(device)[..., None],
-                                     torch.tensor(matrix.dense_shape, dtype=torch.int64)))
-        self.matrix = matrix
+        self = super().__new__(cls, (None, None, None))
+        self.matrix, self._device, self._items = matrix, device, None
         return self
+
+    def _make(self):
+        if self._items is None:
+            m = self.matrix
+            self._items = (torch.from_numpy(m.indices).to(self._device), torch.from_numpy(m.values).to(self._device)[..., None],
+                           torch.tensor(m.dense_shape, dtype=torch.int64))
+        return self._items
+
+    def __getitem__(self, i):
+        return self._make()[i]
+
+    def __iter__(self):
+        return iter(self._make())
+
+    def __len__(self):
+        return 3
+
+    def __repr__(self):
+        return f'SparseTriple({self.matrix!r})'

@@ -105,13 +105,8 @@ def er_device_batch(n_nodes: int, n_arcs: int, device, dim_node_label: int = 14,
     max_degree = int(counts.max())
 
     def operand(src_ids, n_src):
-        m = SparseMatrix.__new__(SparseMatrix)
-        m.indices = m.values = None                                                 # device-only operand: no host COO
-        m.dense_shape = (int(n_src), int(n_nodes))
-        m._csr = None
-        m._dev = {(str(dev), True): dict(rowptr=rowptr, src=src_ids, w=None, row_scale=row_scale, n_src=int(n_src),
-                                         n_dst=int(n_nodes), nnz=int(n_arcs), max_degree=max_degree, light=None, heavy=None)}
-        return m
+        return SparseMatrix.device_only((n_src, n_nodes), dict(rowptr=rowptr, src=src_ids, w=None, row_scale=row_scale, n_src=int(n_src),
+                                                                n_dst=int(n_nodes), nnz=int(n_arcs), max_degree=max_degree), dev)
 
     if max_degree > 512: raise ValueError('er_device_batch does not split hub rows; use the GraphObject path')
     nodes = torch.zeros((n_nodes, dim_node_label), dtype=torch.float32, device=dev)

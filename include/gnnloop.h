@@ -278,6 +278,33 @@ int gnn_converged_gated(const float *state, const float *state_old, int32_t n, i
 int gnn_aggregate_gated(const gnn_csr_t *csr, const float *X, int32_t ldx, int32_t F, float *out, int32_t ldo,
                         const int32_t *gate, void *stream);
 
+/* ---- batch assembly on the device (reference GraphSequencers.py:42-46, :123-127 -> GraphObject.merge, graph_class.py:386-413) ----
+ * A merged batch is the block-diagonal concatenation of its graphs: every array of the merged graph is a run of per-graph
+ * segments of the dataset's device-resident arrays, with a per-segment offset added to node / arc ids.  gnn_ragged_copy executes
+ * a table of such segment operations in ONE launch.  `desc` and `blk_begin` are DEVICE arrays (the caller uploads them with one
+ * small copy per batch): blk_begin[d] = first workgroup of descriptor d (GNN_RC_CHUNK elements per workgroup), blk_begin[n_desc]
+ * = n_blocks. */
+enum gnn_ragged_kind {
+    GNN_RC_COPY_F32 = 0,        /* dst[i] = src[i]                                 (float32)                          */
+    GNN_RC_COPY_I32_ADD = 1,    /* dst[i] = src[i] + iadd                          (int32: ids, row pointers)          */
+    GNN_RC_COPY_ROWS_ADD2 = 2,  /* float32 rows of `width` columns, columns 0 and 1 += fval (the arcs matrix: float ids)*/
+    GNN_RC_FILL_F32 = 3,        /* dst[i] = fval                                                                       */
+    GNN_RC_FILL_I32 = 4,        /* dst[i] = iadd                                                                       */
+    GNN_RC_IOTA_I32 = 5,        /* dst[i] = iadd + i                                                                   */
+    GNN_RC_COPY_U8 = 6          /* dst[i] = src[i]                                 (bytes: bool masks)                 */
+};
+#define GNN_RC_CHUNK 2048
+typedef struct gnn_ragged_desc {
+    const void *src;          /* NULL for fills                                                                        */
+    void *dst;
+    int64_t count;            /* elements                                                                              */
+    int32_t kind;             /* enum gnn_ragged_kind                                                                  */
+    int32_t iadd;
+    float fval;
+    int32_t width;            /* GNN_RC_COPY_ROWS_ADD2: columns per row                                                */
+} gnn_ragged_desc_t;
+int gnn_ragged_copy(const gnn_ragged_desc_t *desc, int32_t n_desc, const int32_t *blk_begin, int32_t n_blocks, void *stream);
+
 /* ---- one whole training step of a homogeneous model inside the library (reference GNN.py:277-306) ---------------------
  * Training-mode forward (BatchNormalization on batch statistics, moving averages updated once per executed iteration for
  * the state network and once for the output network), Keras loss with sample weights, back-propagation through the k

@@ -76,7 +76,7 @@ class MultiGraphSequencer:
                 ds = self._device_dataset()
                 order = list(range(len(self.data)))
             if ds is not None:
-                self.graph_tensors = [ds.assemble(order[i * self.batch_size: (i + 1) * self.batch_size]) for i in range(len(self))]
+                self.graph_tensors = ds.assemble_many([order[i * self.batch_size: (i + 1) * self.batch_size] for i in range(len(self))])
                 self._items = [None] * len(self.graph_tensors)
                 return
         graphs = [self.merge(self.data[i * self.batch_size: (i + 1) * self.batch_size], focus=self.focus,

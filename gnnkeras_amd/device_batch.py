@@ -25,7 +25,7 @@ import torch
 
 from . import _native as nat
 from .graph_class import GraphObject
-from .sparse import CSRByDestination, SparseMatrix
+from .sparse import CSRByDestination, SparseMatrix, canonical_device
 
 
 class DeviceBatch:
@@ -46,7 +46,7 @@ class DeviceDataset:
         if aggregation_mode not in ('sum', 'average', 'normalized'):
             raise ValueError("device assembly supports 'sum', 'average' and 'normalized' aggregation")
         if any(not type(g) is GraphObject for g in graphs): raise ValueError('device assembly is built for homogeneous GraphObjects')
-        self.focus, self.mode, self.device = focus, aggregation_mode, torch.device(device)
+        self.focus, self.mode, self.device = focus, aggregation_mode, canonical_device(device)
         self.G = len(graphs)
         L = {g.nodes.shape[1] for g in graphs}; A = {g.arcs.shape[1] for g in graphs}; T = {g.targets.shape[1] for g in graphs}
         if len(L) != 1 or len(A) != 1 or len(T) != 1: raise ValueError('graphs of one dataset must share label / target widths')
@@ -147,96 +147,133 @@ class DeviceDataset:
 
     def assemble(self, ids) -> DeviceBatch:
         """The merged batch of graphs `ids` (dataset indices, in batch order)."""
-        ids = np.asarray(ids, dtype=np.int64)
-        B = len(ids)
+        return self.assemble_many([ids])[0]
+
+    def assemble_many(self, batches) -> list:
+        """Every batch of an epoch at once: `batches` = list of lists of dataset indices.  All batches live in epoch-wide arrays
+        (a batch is a run of rows of each) filled by ONE descriptor upload and ONE launch; returns the `DeviceBatch` views."""
+        nb = len(batches)
+        if nb == 0: return []
+        sizes = np.array([len(b) for b in batches], dtype=np.int64)
+        ids = np.concatenate([np.asarray(b, dtype=np.int64) for b in batches]) if sizes.sum() else np.zeros(0, np.int64)
+        bidx = np.repeat(np.arange(nb), sizes)                                   # batch of every graph
+        first = np.concatenate([[0], np.cumsum(sizes)])[:-1]                     # position of each batch's first graph
         dev = self.device
         n, e, t, m = self.n[ids], self.e[ids], self.t[ids], self.m[ids]
-        cum = lambda c: np.concatenate([[0], np.cumsum(c)]).astype(np.int64)
-        bn, be, bt, bm = cum(n), cum(e), cum(t), cum(m)                          # offsets inside the batch
-        N, E, Tn, Mn = int(bn[-1]), int(be[-1]), int(bt[-1]), int(bm[-1])
-        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        excl = lambda c: np.cumsum(c) - c                                        # exclusive prefix over all graphs = offsets in the epoch arrays
+        gn, ge, gt, gm = excl(n), excl(e), excl(t), excl(m)
+        tot = lambda c: np.add.reduceat(c, first) if len(c) else np.zeros(nb, np.int64)      # per batch totals (every batch has >= 1 graph)
+        Nb, Eb, Tb, Mb = tot(n), tot(e), tot(t), tot(m)
+        base = lambda g_: g_[first]                                              # epoch offset of each batch
+        bN, bE, bT, bM = base(gn), base(ge), base(gt), base(gm)
+        ln, le = gn - bN[bidx], ge - bE[bidx]                                    # node / arc offset of every graph INSIDE its batch
+        N, E, Tn, Mn = int(n.sum()), int(e.sum()), int(t.sum()), int(m.sum())
+        f32 = lambda *s_: torch.empty(s_, dtype=torch.float32, device=dev)
+        i32 = lambda *s_: torch.empty(s_, dtype=torch.int32, device=dev)
         nodes, arcs, targets, sw = f32(N, self.L), f32(E, self.W), f32(Tn, self.T), f32(Tn)
         set_mask, out_mask = torch.empty(Mn, dtype=torch.uint8, device=dev), torch.empty(Mn, dtype=torch.uint8, device=dev)
-        rowptr, adj_src, an_src = i32(N + 1), i32(E), i32(E)
+        rowptr, adj_src, an_src = i32(N + nb), i32(E), i32(E)                    # batch b's row pointers start at bN[b] + b
         asrc, adst = (i32(E), i32(E)) if self.focus == 'a' else (None, None)
         scale = f32(N) if self.mode in ('average', 'normalized') else None
         no, eo, to_, mo = self.noff[ids], self.eoff[ids], self.toff[ids], self.moff[ids]
         K = nat
-        D = [dict(src=self.d_nodes, src_off=no * self.L, dst=nodes, dst_off=bn[:-1] * self.L, count=n * self.L, kind=K.RC_COPY_F32, esize=4),
-             dict(src=self.d_arcs, src_off=eo * self.W, dst=arcs, dst_off=be[:-1] * self.W, count=e * self.W, kind=K.RC_COPY_ROWS_ADD2,
-                  fval=bn[:-1].astype(np.float32), width=self.W, esize=4),
-             dict(src=self.d_targets, src_off=to_ * self.T, dst=targets, dst_off=bt[:-1] * self.T, count=t * self.T, kind=K.RC_COPY_F32, esize=4),
-             dict(src=self.d_sw, src_off=to_, dst=sw, dst_off=bt[:-1], count=t, kind=K.RC_COPY_F32, esize=4),
-             dict(src=self.d_set, src_off=mo, dst=set_mask, dst_off=bm[:-1], count=m, kind=K.RC_COPY_U8, esize=1),
-             dict(src=self.d_out, src_off=mo, dst=out_mask, dst_off=bm[:-1], count=m, kind=K.RC_COPY_U8, esize=1),
-             dict(src=self.d_rowptr, src_off=no, dst=rowptr, dst_off=bn[:-1], count=n, kind=K.RC_COPY_I32_ADD, iadd=be[:-1].astype(np.int32), esize=4),
-             dict(src=None, src_off=np.zeros(1, np.int64), dst=rowptr, dst_off=np.array([N]), count=np.array([1]), kind=K.RC_FILL_I32,
-                  iadd=np.array([E], np.int32), esize=4),
-             dict(src=self.d_adj_src, src_off=eo, dst=adj_src, dst_off=be[:-1], count=e, kind=K.RC_COPY_I32_ADD, iadd=bn[:-1].astype(np.int32), esize=4),
-             dict(src=self.d_an_src, src_off=eo, dst=an_src, dst_off=be[:-1], count=e, kind=K.RC_COPY_I32_ADD, iadd=be[:-1].astype(np.int32), esize=4)]
+        z1 = np.zeros(1, np.int64)
+        D = [dict(src=self.d_nodes, src_off=no * self.L, dst=nodes, dst_off=gn * self.L, count=n * self.L, kind=K.RC_COPY_F32, esize=4),
+             dict(src=self.d_arcs, src_off=eo * self.W, dst=arcs, dst_off=ge * self.W, count=e * self.W, kind=K.RC_COPY_ROWS_ADD2,
+                  fval=ln.astype(np.float32), width=self.W, esize=4),
+             dict(src=self.d_targets, src_off=to_ * self.T, dst=targets, dst_off=gt * self.T, count=t * self.T, kind=K.RC_COPY_F32, esize=4),
+             dict(src=self.d_sw, src_off=to_, dst=sw, dst_off=gt, count=t, kind=K.RC_COPY_F32, esize=4),
+             dict(src=self.d_set, src_off=mo, dst=set_mask, dst_off=gm, count=m, kind=K.RC_COPY_U8, esize=1),
+             dict(src=self.d_out, src_off=mo, dst=out_mask, dst_off=gm, count=m, kind=K.RC_COPY_U8, esize=1),
+             dict(src=self.d_rowptr, src_off=no, dst=rowptr, dst_off=gn + bidx, count=n, kind=K.RC_COPY_I32_ADD, iadd=le.astype(np.int32), esize=4),
+             dict(src=None, src_off=np.zeros(nb, np.int64), dst=rowptr, dst_off=bN + Nb + np.arange(nb), count=np.ones(nb, np.int64),
+                  kind=K.RC_FILL_I32, iadd=Eb.astype(np.int32), esize=4),
+             dict(src=self.d_adj_src, src_off=eo, dst=adj_src, dst_off=ge, count=e, kind=K.RC_COPY_I32_ADD, iadd=ln.astype(np.int32), esize=4),
+             dict(src=self.d_an_src, src_off=eo, dst=an_src, dst_off=ge, count=e, kind=K.RC_COPY_I32_ADD, iadd=le.astype(np.int32), esize=4)]
         if self.mode == 'average':
-            D.append(dict(src=self.d_scale, src_off=no, dst=scale, dst_off=bn[:-1], count=n, kind=K.RC_COPY_F32, esize=4))
+            D.append(dict(src=self.d_scale, src_off=no, dst=scale, dst_off=gn, count=n, kind=K.RC_COPY_F32, esize=4))
         elif self.mode == 'normalized':                                           # 1 / #arcs of the merged graph (graph_class.py:110)
-            D.append(dict(src=None, src_off=np.zeros(1, np.int64), dst=scale, dst_off=np.zeros(1, np.int64), count=np.array([N]),
-                          kind=K.RC_FILL_F32, fval=np.array([np.float32(1.0) / np.float32(E)], np.float32), esize=4))
+            D.append(dict(src=None, src_off=np.zeros(nb, np.int64), dst=scale, dst_off=bN, count=Nb, kind=K.RC_FILL_F32,
+                          fval=(np.float32(1.0) / Eb.astype(np.float32)), esize=4))
         if self.focus == 'a':
-            D += [dict(src=self.d_asrc, src_off=eo, dst=asrc, dst_off=be[:-1], count=e, kind=K.RC_COPY_I32_ADD, iadd=bn[:-1].astype(np.int32), esize=4),
-                  dict(src=self.d_adst, src_off=eo, dst=adst, dst_off=be[:-1], count=e, kind=K.RC_COPY_I32_ADD, iadd=bn[:-1].astype(np.int32), esize=4)]
-        ng = None
+            D += [dict(src=self.d_asrc, src_off=eo, dst=asrc, dst_off=ge, count=e, kind=K.RC_COPY_I32_ADD, iadd=ln.astype(np.int32), esize=4),
+                  dict(src=self.d_adst, src_off=eo, dst=adst, dst_off=ge, count=e, kind=K.RC_COPY_I32_ADD, iadd=ln.astype(np.int32), esize=4)]
         if self.focus == 'g':                                                     # NodeGraph[n, g] = 1 / |V_g| (graph_class.py:127-138, :407)
-            ng_rowptr, ng_src, ng_scale = i32(B + 1), i32(N), f32(B)
-            D += [dict(src=None, src_off=np.zeros(B + 1, np.int64), dst=ng_rowptr, dst_off=np.arange(B + 1), count=np.ones(B + 1, np.int64),
-                       kind=K.RC_FILL_I32, iadd=bn.astype(np.int32), esize=4),
-                  dict(src=None, src_off=np.zeros(1, np.int64), dst=ng_src, dst_off=np.zeros(1, np.int64), count=np.array([N]), kind=K.RC_IOTA_I32,
-                       iadd=np.zeros(1, np.int32), esize=4),
-                  dict(src=None, src_off=np.zeros(B, np.int64), dst=ng_scale, dst_off=np.arange(B), count=np.ones(B, np.int64), kind=K.RC_FILL_F32,
+            G = len(ids)
+            ng_rowptr, ng_src, ng_scale = i32(G + nb), i32(N), f32(G)
+            gpos = np.arange(G) + bidx                                            # slot of graph j's row pointer (batch b's start at first[b] + b)
+            D += [dict(src=None, src_off=np.zeros(G, np.int64), dst=ng_rowptr, dst_off=gpos, count=np.ones(G, np.int64), kind=K.RC_FILL_I32,
+                       iadd=ln.astype(np.int32), esize=4),
+                  dict(src=None, src_off=np.zeros(nb, np.int64), dst=ng_rowptr, dst_off=first + sizes + np.arange(nb), count=np.ones(nb, np.int64),
+                       kind=K.RC_FILL_I32, iadd=Nb.astype(np.int32), esize=4),
+                  dict(src=None, src_off=np.zeros(nb, np.int64), dst=ng_src, dst_off=bN, count=Nb, kind=K.RC_IOTA_I32, iadd=np.zeros(nb, np.int32), esize=4),
+                  dict(src=None, src_off=np.zeros(G, np.int64), dst=ng_scale, dst_off=np.arange(G), count=np.ones(G, np.int64), kind=K.RC_FILL_F32,
                        fval=(np.float32(1.0) / n.astype(np.float32)), esize=4)]
         self._run(D)
-        csr = dict(rowptr=rowptr, w=None, row_scale=scale, n_dst=N, nnz=E, max_degree=0)
-        batch = self
-        adj_endpoints = (asrc, adst) if self.focus == 'a' else None
 
-        def adjacency_by_source():
-            batch._prepare_by_source()
-            t_rowptr, t_dst = i32(N + 1), i32(E)
-            t_w = f32(E) if batch.mode == 'average' else None
-            t_scale = None
-            DD = [dict(src=batch.d_t_rowptr, src_off=no, dst=t_rowptr, dst_off=bn[:-1], count=n, kind=K.RC_COPY_I32_ADD, iadd=be[:-1].astype(np.int32), esize=4),
-                  dict(src=None, src_off=np.zeros(1, np.int64), dst=t_rowptr, dst_off=np.array([N]), count=np.array([1]), kind=K.RC_FILL_I32,
-                       iadd=np.array([E], np.int32), esize=4),
-                  dict(src=batch.d_t_dst, src_off=eo, dst=t_dst, dst_off=be[:-1], count=e, kind=K.RC_COPY_I32_ADD, iadd=bn[:-1].astype(np.int32), esize=4)]
-            if batch.mode == 'average':
-                DD.append(dict(src=batch.d_t_w, src_off=eo, dst=t_w, dst_off=be[:-1], count=e, kind=K.RC_COPY_F32, esize=4))
-            elif batch.mode == 'normalized':
-                t_scale = torch.full((N,), float(np.float32(1.0) / np.float32(E)), dtype=torch.float32, device=dev)
-            batch._run(DD)
-            return dict(rowptr=t_rowptr, src=t_dst, w=t_w, row_scale=t_scale, n_src=N, n_dst=N, nnz=E)
+        # the by-source operands of the whole epoch, assembled together on the first request (training only)
+        epoch = {}
 
-        adjacency = _LazySparse.make((N, N), dict(csr, src=adj_src, n_src=N), dev, endpoints=adj_endpoints, by_source=adjacency_by_source)
-        arcnode = _LazySparse.make((E, N), dict(csr, src=an_src, n_src=E), dev,
-                              by_source=lambda: dict(rowptr=torch.arange(E + 1, dtype=torch.int32, device=dev), src=adst_of(), w=arc_w(), row_scale=None,
-                                                     n_src=N, n_dst=E, nnz=E))
+        def by_source_all():
+            if 'rowptr' not in epoch:
+                self._prepare_by_source()
+                t_rowptr, t_dst = i32(N + nb), i32(E)
+                t_w = f32(E) if self.mode == 'average' else None
+                DD = [dict(src=self.d_t_rowptr, src_off=no, dst=t_rowptr, dst_off=gn + bidx, count=n, kind=K.RC_COPY_I32_ADD, iadd=le.astype(np.int32), esize=4),
+                      dict(src=None, src_off=np.zeros(nb, np.int64), dst=t_rowptr, dst_off=bN + Nb + np.arange(nb), count=np.ones(nb, np.int64),
+                           kind=K.RC_FILL_I32, iadd=Eb.astype(np.int32), esize=4),
+                      dict(src=self.d_t_dst, src_off=eo, dst=t_dst, dst_off=ge, count=e, kind=K.RC_COPY_I32_ADD, iadd=ln.astype(np.int32), esize=4)]
+                if self.mode == 'average':
+                    DD.append(dict(src=self.d_t_w, src_off=eo, dst=t_w, dst_off=ge, count=e, kind=K.RC_COPY_F32, esize=4))
+                self._run(DD)
+                epoch.update(rowptr=t_rowptr, dst=t_dst, w=t_w)
+            return epoch
 
-        def adst_of():                       # destination node of every arc, in arc order (ArcNode by source: one entry per arc)
-            return arcs[:, 1].to(torch.int32).contiguous()
+        out = []
+        for b in range(nb):
+            n0, n1, e0, e1 = int(bN[b]), int(bN[b] + Nb[b]), int(bE[b]), int(bE[b] + Eb[b])
+            t0, t1, m0, m1 = int(bT[b]), int(bT[b] + Tb[b]), int(bM[b]), int(bM[b] + Mb[b])
+            Nn, Ee, B = n1 - n0, e1 - e0, int(sizes[b])
+            b_scale = None if scale is None else scale[n0:n1]
+            b_arcs = arcs[e0:e1]
+            csr = dict(rowptr=rowptr[n0 + b:n1 + b + 1], w=None, row_scale=b_scale, n_dst=Nn, nnz=Ee, max_degree=0)
 
-        def arc_w():                         # its weight: the destination's row scale
-            return None if scale is None else scale[arcs[:, 1].long()].contiguous()
+            def adjacency_by_source(b=b, n0=n0, n1=n1, e0=e0, e1=e1, Nn=Nn, Ee=Ee):
+                ep = by_source_all()
+                sc = None
+                if self.mode == 'normalized':
+                    sc = torch.full((Nn,), float(np.float32(1.0) / np.float32(Ee)), dtype=torch.float32, device=dev)
+                return dict(rowptr=ep['rowptr'][n0 + b:n1 + b + 1], src=ep['dst'][e0:e1], w=None if ep['w'] is None else ep['w'][e0:e1],
+                            row_scale=sc, n_src=Nn, n_dst=Nn, nnz=Ee)
 
-        if self.focus == 'g':
-            nodegraph = _LazySparse.make((N, B), dict(rowptr=ng_rowptr, src=ng_src, w=None, row_scale=ng_scale, n_src=N, n_dst=B, nnz=N, max_degree=0), dev,
-                                    by_source=lambda: dict(rowptr=torch.arange(N + 1, dtype=torch.int32, device=dev),
-                                                           src=torch.repeat_interleave(torch.arange(B, dtype=torch.int32, device=dev),
-                                                                                       torch.from_numpy(n).to(dev)),
-                                                           w=torch.repeat_interleave(ng_scale, torch.from_numpy(n).to(dev)), row_scale=None,
-                                                           n_src=B, n_dst=N, nnz=N))
-        else:
-            nodegraph = SparseMatrix(np.zeros((0, 2), np.int64), np.zeros(0, np.float32), (1, 0))     # reference: empty matrix
-        return DeviceBatch(nodes=nodes, arcs=arcs, targets=targets, sample_weight=sw, set_mask=set_mask.view(torch.bool),
-                           output_mask=out_mask.view(torch.bool), DIM_NODE_LABEL=torch.tensor([self.L], dtype=torch.int32),
-                           DIM_ARC_LABEL=self.W - 2, DIM_TARGET=self.T, Adjacency=adjacency, ArcNode=arcnode, NodeGraph=nodegraph,
-                           aggregation_mode=self.mode, device=dev, dtype='float32')
+            def arcnode_by_source(b_arcs=b_arcs, b_scale=b_scale, Nn=Nn, Ee=Ee):       # one entry per arc: its destination, its weight
+                dst_of = b_arcs[:, 1].to(torch.int32).contiguous()
+                return dict(rowptr=torch.arange(Ee + 1, dtype=torch.int32, device=dev), src=dst_of,
+                            w=None if b_scale is None else b_scale[dst_of.long()].contiguous(), row_scale=None, n_src=Nn, n_dst=Ee, nnz=Ee)
+
+            adjacency = _LazySparse.make((Nn, Nn), dict(csr, src=adj_src[e0:e1], n_src=Nn), dev,
+                                         endpoints=(asrc[e0:e1], adst[e0:e1]) if self.focus == 'a' else None, by_source=adjacency_by_source)
+            arcnode = _LazySparse.make((Ee, Nn), dict(csr, src=an_src[e0:e1], n_src=Ee), dev, by_source=arcnode_by_source)
+            if self.focus == 'g':
+                g0 = int(first[b])
+                gn_b = torch.from_numpy(n[g0:g0 + B]).to(dev)
+                b_ngs = ng_scale[g0:g0 + B]
+
+                def nodegraph_by_source(gn_b=gn_b, b_ngs=b_ngs, Nn=Nn, B=B):
+                    return dict(rowptr=torch.arange(Nn + 1, dtype=torch.int32, device=dev),
+                                src=torch.repeat_interleave(torch.arange(B, dtype=torch.int32, device=dev), gn_b),
+                                w=torch.repeat_interleave(b_ngs, gn_b), row_scale=None, n_src=B, n_dst=Nn, nnz=Nn)
+
+                nodegraph = _LazySparse.make((Nn, B), dict(rowptr=ng_rowptr[g0 + b:g0 + b + B + 1], src=ng_src[n0:n1], w=None, row_scale=b_ngs,
+                                                           n_src=Nn, n_dst=B, nnz=Nn, max_degree=0), dev, by_source=nodegraph_by_source)
+            else:
+                nodegraph = SparseMatrix(np.zeros((0, 2), np.int64), np.zeros(0, np.float32), (1, 0))     # reference: empty matrix
+            out.append(DeviceBatch(nodes=nodes[n0:n1], arcs=b_arcs, targets=targets[t0:t1], sample_weight=sw[t0:t1],
+                                   set_mask=set_mask[m0:m1].view(torch.bool), output_mask=out_mask[m0:m1].view(torch.bool),
+                                   DIM_NODE_LABEL=torch.tensor([self.L], dtype=torch.int32), DIM_ARC_LABEL=self.W - 2, DIM_TARGET=self.T,
+                                   Adjacency=adjacency, ArcNode=arcnode, NodeGraph=nodegraph, aggregation_mode=self.mode, device=dev,
+                                   dtype='float32'))
+        return out
 
 
 class _LazySparse(SparseMatrix):
@@ -249,7 +286,7 @@ class _LazySparse(SparseMatrix):
         return m
 
     def by_source(self, device):
-        key = ('by_source', str(torch.device(device)))
+        key = ('by_source', str(canonical_device(device)))
         if key not in self._dev:
             self._dev[key] = self._by_source_thunk()
         return self._dev[key]

@@ -13,6 +13,14 @@ import numpy as np
 import torch
 
 
+def canonical_device(device) -> torch.device:
+    """torch.device with an explicit index ('cuda' -> 'cuda:<current>'): cache keys must not depend on how it was spelled."""
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        return torch.device('cuda', torch.cuda.current_device())
+    return device
+
+
 def default_device() -> torch.device:
     """`cuda:<current>` on a GPU box, CPU otherwise (host-logic tests only: the kernels never run on CPU)."""
     if torch.cuda.is_available():
@@ -142,9 +150,9 @@ class SparseMatrix:
         m._csr = None
         d = dict(csr)
         d.setdefault('max_degree', 0); d.setdefault('light', None); d.setdefault('heavy', None)
-        m._dev = {(str(torch.device(device)), True): d}
+        m._dev = {(str(canonical_device(device)), True): d}
         for key, val in more.items():
-            if val is not None: m._dev[(key, str(torch.device(device)))] = val
+            if val is not None: m._dev[(key, str(canonical_device(device)))] = val
         return m
 
     def _materialise_host(self):
@@ -219,7 +227,7 @@ class SparseMatrix:
 
     def device_csr(self, device=None, uniform_rows: bool = True):
         """dict(rowptr, src, w|None, row_scale|None) of torch tensors on `device`, uploaded once and cached."""
-        device = torch.device(device) if device is not None else default_device()
+        device = canonical_device(device) if device is not None else default_device()
         key = (str(device), uniform_rows)
         if key not in self._dev:
             if self._indices is None:
@@ -238,7 +246,7 @@ class SparseMatrix:
 
     def triple(self, device=None):
         """The `(indices, values[...,None], dense_shape)` tuple of `GraphSequencers.py:110`, carrying this matrix."""
-        device = torch.device(device) if device is not None else default_device()
+        device = canonical_device(device) if device is not None else default_device()
         key = ('triple', str(device))
         if key not in self._dev:
             self._dev[key] = SparseTriple(self, device)

@@ -229,6 +229,10 @@ class _LoopModel:
         return max(1, min(int(self.inference_streams), cus // (tiles + 2)))
 
     def _out_index(self, set_mask, output_mask):
+        if set_mask.is_cuda:
+            from ..device_batch import lookup_out_index            # batches assembled on the device bring their index along
+            pre = lookup_out_index(set_mask, output_mask)
+            if pre is not None: return pre
         key = (set_mask.data_ptr(), set_mask._version, output_mask.data_ptr(), output_mask._version, len(set_mask))
         hit = self._mask_cache.get(key)
         if hit is None:

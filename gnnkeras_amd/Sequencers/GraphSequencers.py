@@ -126,9 +126,11 @@ class MultiGraphSequencer:
             return self._items[index]
         g, set_mask = self.get_batch(index)
         out = self._x_list(g)
-        if self.focus == 'g': mask = torch.ones((g.targets.shape[0]), dtype=torch.bool, device=g.targets.device)
-        else: mask = set_mask[g.output_mask]
-        item = (out, g.targets[mask], g.sample_weight[mask])
+        if self.focus == 'g':                   # every target row (reference :112); no boolean indexing = no host synchronisation
+            item = (out, g.targets, g.sample_weight)
+        else:
+            mask = set_mask[g.output_mask]
+            item = (out, g.targets[mask], g.sample_weight[mask])
         if set_mask is g.set_mask: self._items[index] = item
         return item
 

@@ -19,6 +19,7 @@ them array by array and through the model."""
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -26,6 +27,17 @@ import torch
 from . import _native as nat
 from .graph_class import GraphObject
 from .sparse import CSRByDestination, SparseMatrix, canonical_device
+
+
+# (set_mask ptr, output_mask ptr, length) -> (out_index, set_mask, output_mask): the model's `nonzero(set & out)` (GNN.py:269,
+# one host synchronisation per new batch) answered from the assembly instead.  The masks are kept alive by the entry, so a
+# pointer cannot be recycled while it is registered; entries go when their batch is garbage-collected.
+_OUT_INDEX = {}
+
+
+def lookup_out_index(set_mask, output_mask):
+    hit = _OUT_INDEX.get((set_mask.data_ptr(), output_mask.data_ptr(), set_mask.shape[0]))
+    return None if hit is None else hit[0]
 
 
 class DeviceBatch:
@@ -86,6 +98,11 @@ class DeviceDataset:
             self.d_scale = up(np.where(indeg > 0, 1.0 / np.maximum(indeg, 1), 1.0).astype(np.float32))
         self.d_asrc, self.d_adst = up(src.astype(np.int32) - self.noff[gid_arc].astype(np.int32)), \
             up(dst.astype(np.int32) - self.noff[gid_arc].astype(np.int32))      # arc end points (arc focus: GNN.py:322-325)
+        both = np.concatenate([np.logical_and(g.set_mask, g.output_mask) for g in graphs])         # rows the output network sees (GNN.py:269)
+        gid_mask = np.repeat(np.arange(self.G), m)
+        self.oc = np.bincount(gid_mask[both], minlength=self.G).astype(np.int64)
+        self.ooff = off(self.oc)
+        self.d_oidx = up((np.flatnonzero(both) - self.moff[gid_mask[both]]).astype(np.int32))    # graph-local positions
         self._host = dict(src=src, dst=dst, indeg=indeg, gid_arc=gid_arc, gid_node=gid_node)
         self._by_source_ready = False
         self.hub = bool(indeg.max(initial=0) > 512)                              # hub rows need the host-side split (sparse.split_heavy)
@@ -177,7 +194,11 @@ class DeviceDataset:
         scale = f32(N) if self.mode in ('average', 'normalized') else None
         no, eo, to_, mo = self.noff[ids], self.eoff[ids], self.toff[ids], self.moff[ids]
         K = nat
-        z1 = np.zeros(1, np.int64)
+        oc = self.oc[ids]
+        go = excl(oc)
+        Ob, bO = tot(oc), base(go)
+        out_index = i32(int(oc.sum()))
+        lm = gm - bM[bidx]                                                        # mask offset of every graph inside its batch
         D = [dict(src=self.d_nodes, src_off=no * self.L, dst=nodes, dst_off=gn * self.L, count=n * self.L, kind=K.RC_COPY_F32, esize=4),
              dict(src=self.d_arcs, src_off=eo * self.W, dst=arcs, dst_off=ge * self.W, count=e * self.W, kind=K.RC_COPY_ROWS_ADD2,
                   fval=ln.astype(np.float32), width=self.W, esize=4),
@@ -190,6 +211,7 @@ class DeviceDataset:
                   kind=K.RC_FILL_I32, iadd=Eb.astype(np.int32), esize=4),
              dict(src=self.d_adj_src, src_off=eo, dst=adj_src, dst_off=ge, count=e, kind=K.RC_COPY_I32_ADD, iadd=ln.astype(np.int32), esize=4),
              dict(src=self.d_an_src, src_off=eo, dst=an_src, dst_off=ge, count=e, kind=K.RC_COPY_I32_ADD, iadd=le.astype(np.int32), esize=4)]
+        D.append(dict(src=self.d_oidx, src_off=self.ooff[ids], dst=out_index, dst_off=go, count=oc, kind=K.RC_COPY_I32_ADD, iadd=lm.astype(np.int32), esize=4))
         if self.mode == 'average':
             D.append(dict(src=self.d_scale, src_off=no, dst=scale, dst_off=gn, count=n, kind=K.RC_COPY_F32, esize=4))
         elif self.mode == 'normalized':                                           # 1 / #arcs of the merged graph (graph_class.py:110)
@@ -268,11 +290,15 @@ class DeviceDataset:
                                                            n_src=Nn, n_dst=B, nnz=Nn, max_degree=0), dev, by_source=nodegraph_by_source)
             else:
                 nodegraph = SparseMatrix(np.zeros((0, 2), np.int64), np.zeros(0, np.float32), (1, 0))     # reference: empty matrix
+            b_set, b_out = set_mask[m0:m1].view(torch.bool), out_mask[m0:m1].view(torch.bool)
+            key = (b_set.data_ptr(), b_out.data_ptr(), m1 - m0)
+            _OUT_INDEX[key] = (out_index[int(bO[b]):int(bO[b] + Ob[b])], b_set, b_out)
             out.append(DeviceBatch(nodes=nodes[n0:n1], arcs=b_arcs, targets=targets[t0:t1], sample_weight=sw[t0:t1],
-                                   set_mask=set_mask[m0:m1].view(torch.bool), output_mask=out_mask[m0:m1].view(torch.bool),
+                                   set_mask=b_set, output_mask=b_out,
                                    DIM_NODE_LABEL=torch.tensor([self.L], dtype=torch.int32), DIM_ARC_LABEL=self.W - 2, DIM_TARGET=self.T,
                                    Adjacency=adjacency, ArcNode=arcnode, NodeGraph=nodegraph, aggregation_mode=self.mode, device=dev,
                                    dtype='float32'))
+            weakref.finalize(out[-1], _OUT_INDEX.pop, key, None)
         return out
 
 

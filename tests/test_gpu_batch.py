@@ -50,6 +50,9 @@ def test_device_assembled_batches_equal_host_merged_ones(mutag_graphs, focus, mo
         for a, b in zip(xh[:5], xd[:5]):
             assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a.cpu(), b.cpu())
         assert torch.equal(yh, yd) and torch.equal(wh, wd)
+        from gnnkeras_amd.device_batch import lookup_out_index
+        want = torch.nonzero(torch.logical_and(xd[3].squeeze(-1), xd[4].squeeze(-1))).reshape(-1).to(torch.int32)
+        assert torch.equal(lookup_out_index(xd[3].squeeze(-1), xd[4].squeeze(-1)), want)
         for j in (5, 6) + ((7,) if focus == 'g' else ()):
             mh, md = SparseMatrix.from_triple(xh[j]), SparseMatrix.from_triple(xd[j])
             ch, cd = mh.device_csr('cuda'), md.device_csr('cuda')

@@ -51,7 +51,14 @@ class MultiGraphSequencer:
         if self.assemble == 'host' or self.device.type != 'cuda' or type(self).merge.__func__ is not MultiGraphSequencer.merge.__func__:
             if self.assemble == 'device': raise ValueError('device assembly needs a GPU and a homogeneous data set')
             return None
-        if self._dataset is None or self._dataset[1] != len(self.data):
+        # the data set on the device is valid as long as the graphs still hold the arrays it was built from (LGNN's serial fit
+        # REPLACES the label arrays of a sequencer's graphs: reference LGNN.py:318-333); edits made IN PLACE inside an array are
+        # not seen - call refresh() after such an edit
+        arrays = lambda g: (id(g.nodes), id(g.arcs), id(g.targets), id(g.set_mask), id(g.output_mask))
+        stale = self._dataset is None or len(self._dataset[1]) != len(self.data) or \
+            any(self._dataset[1].get(id(g)) != arrays(g) for g in self.data)        # order-independent: shuffling keeps it valid
+        if stale:
+            sig = {id(g): arrays(g) for g in self.data}
             from ..device_batch import DeviceDataset
             try:
                 ds = DeviceDataset(self.data, self.focus, self.aggregation_mode, self.device)
@@ -61,20 +68,20 @@ class MultiGraphSequencer:
             if ds is not None and ds.hub:
                 if self.assemble == 'device': raise ValueError('hub rows (in-degree > 512) need the host-side split')
                 ds = None
-            self._dataset = (ds, len(self.data), {id(g): i for i, g in enumerate(self.data)})
+            self._dataset = (ds, sig, {id(g): i for i, g in enumerate(self.data)})
         return self._dataset[0]
+
+    def refresh(self):
+        """Rebuild everything from the current contents of `self.data` (after editing a graph's arrays in place)."""
+        self._dataset = None
+        self.build_batches()
 
     def build_batches(self):
         """Slice the graph list by batch_size, merge each slice, have it on the device (reference :42-46)."""
         ds = self._device_dataset()
         if ds is not None:
             index = self._dataset[2]
-            try:
-                order = [index[id(g)] for g in self.data]
-            except KeyError:                                    # the list was edited: start over from the current graphs
-                self._dataset = None
-                ds = self._device_dataset()
-                order = list(range(len(self.data)))
+            order = [index[id(g)] for g in self.data]
             if ds is not None:
                 self.graph_tensors = ds.assemble_many([order[i * self.batch_size: (i + 1) * self.batch_size] for i in range(len(self))])
                 self._items = [None] * len(self.graph_tensors)

@@ -24,6 +24,7 @@
 #include "kernel_state_small.hpp"
 #include "kernel_state_wide.hpp"
 #include "kernels_batch.hpp"
+#include "kernels_setup.hpp"
 
 namespace {
 
@@ -312,6 +313,7 @@ struct Plan {
     TypePlan tp[GNN_MAX_TYPES];
     // workspace
     int *flags;
+    int *pred0;                      // state_0's predicate, one word per 64-node tile (written by k_setup_small, read by k_state_small)
     int *err;                        // sticky "an in-launch wait expired" word of the fused kernels, folded into k at the end
     float *agg_arcs, *agg_nodes; int ld_agg_nodes;
     float *C; int ldC;
@@ -324,6 +326,7 @@ struct Plan {
     size_t bytes;
 };
 
+constexpr int GNN_SMALL_MAX_TILES = 512;   // upper bound of CUs a whole-loop launch can cover (one 64-node tile each)
 constexpr int GNN_LOOP_WORDS = 16;   // words behind flags[max_iteration]: [1] last flag, [3..7) barrier counters, [12] error word
 
 int state_width(const gnn_loop_args_t &a) { return a.state_dim > 0 ? a.state_dim : a.dim_node_label; }
@@ -407,6 +410,7 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     Carver c(ws);
     p.flags = c.take<int>(a.max_iteration + GNN_LOOP_WORDS);   // behind the flags: the persistent kernel's two 64-bit barrier counters, the error word
     p.err = p.flags ? p.flags + a.max_iteration + 12 : nullptr;
+    p.pred0 = c.take<int>(GNN_SMALL_MAX_TILES);
     for (int t = 0; t < p.T; ++t) {
         p.tp[t].Wf = c.take<float>((size_t)a.net_state[t].in_dim * a.net_state[t].units[0]);
         p.tp[t].bf = c.take<float>(a.net_state[t].units[0]);
@@ -549,6 +553,40 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, boo
         d.Y = p.C; d.ldy = p.ldC; d.out_rowidx = tp.rows;
         TRY(launch_segdense(d, st));
     }
+    return 0;
+}
+
+// Small homogeneous graphs about to run the whole-loop kernel: BN folds, both constant aggregates, C, the predicate of
+// state_0 and the zeroing of the loop words in ONE launch (kernels_setup.hpp) instead of five.
+bool setup_small_applies(const gnn_loop_args_t &a, const Plan &p) {
+    if (p.composite || p.N == 0) return false;
+    const int L = a.state_dim > 0 ? p.L : 0, H = a.net_state[0].units[0];
+    if (H > 128) return false;
+    return gnn::setup_small_lds(H, 2 * L + p.A) <= 64 * 1024;
+}
+
+int setup_small(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
+    gnn::SetupArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    FoldList fl;
+    fl.add(a.net_state[0], p.tp[0].Wf, p.tp[0].bf);
+    sa.net = fl.fa.job[0];
+    if (a.net_output.kernel[0]) { fl.add(a.net_output, p.Wf_out, p.bf_out); sa.out = fl.fa.job[1]; }
+    const int L = a.state_dim > 0 ? p.L : 0;
+    sa.N = p.N; sa.n_tiles = cdiv(p.N, 64);
+    sa.nodes = a.nodes; sa.ld_nodes = a.ld_nodes; sa.L = L;
+    sa.nodes_src = a.nodes_src ? a.nodes_src : a.nodes; sa.ld_nodes_src = a.nodes_src ? a.ld_nodes_src : a.ld_nodes;
+    sa.adj = gnn::SetupCsr{a.adjacency.rowptr, a.adjacency.src, a.adjacency.w, a.adjacency.row_scale};
+    sa.arc_labels = a.arc_labels; sa.ld_arcs = a.ld_arcs; sa.A = p.A;
+    sa.arcnode = gnn::SetupCsr{a.arcnode.rowptr, a.arcnode.src, a.arcnode.w, a.arcnode.row_scale};
+    if (a.state_dim > 0) { sa.row_nodes = p.S; sa.row_aggn = 2 * p.S + p.L; sa.row_agga = 2 * p.S + 2 * p.L; }
+    else                 { sa.row_agga = 2 * p.S; }
+    sa.C = p.C; sa.ldC = p.ldC;
+    sa.state0 = a.state_dim > 0 ? a.state0 : a.nodes; sa.ld_s0 = a.state_dim > 0 ? p.S : a.ld_nodes;
+    sa.S = p.S; sa.thr = a.state_threshold; sa.pred0 = p.pred0;
+    sa.zero_a = p.flags; sa.n_a = a.max_iteration + GNN_LOOP_WORDS; sa.zero_b = a.k_out; sa.n_b = 1;
+    gnn::k_setup_small<<<sa.n_tiles + 1, 256, gnn::setup_small_lds(sa.net.H, 2 * L + p.A), st>>>(sa);
+    LAUNCH_OK();
     return 0;
 }
 
@@ -698,15 +736,25 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
     return 0;
 }
 
-// The whole loop in ONE launch (kernel_state_small.hpp) for graphs of at most 64 nodes per CU: returns 2 when that does
-// not apply (hub rows, d <= 16, too many tiles, pinned to another kernel) and the caller launches per iteration.
-int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first, float *const B[2], hipStream_t st) {
+// The whole loop in ONE launch (kernel_state_small.hpp) for graphs of at most 64 nodes per CU.  `persistent_applies` is
+// the static part of the decision (hub rows, d <= 16, too many tiles, pinned to another kernel: one launch per iteration).
+bool persistent_applies(const gnn_loop_args_t &a, const Plan &p) {
     const int pinned = (a.flags & GNN_FLAG_FUSED_GEN_MASK) >> 4;
-    if (pinned != 0 && pinned != 5) return 2;
+    if (pinned != 0 && pinned != 5) return false;
     static int env = -1;
     if (env < 0) { const char *e = getenv("GNN_FUSED_KERNEL"); env = e ? atoi(e) : 0; }
-    if (pinned == 0 && env != 0 && env != 5) return 2;
-    if (p.n_heavy != 0 || a.max_iteration < 1 || p.SP > 64) return 2;
+    if (pinned == 0 && env != 0 && env != 5) return false;
+    if (p.n_heavy != 0 || a.max_iteration < 1 || (p.SP != 32 && p.SP != 64)) return false;
+    int tiles = 0;
+    for (int t = 0; t < p.T; ++t) tiles += (p.tp[t].count + 63) / 64;
+    return tiles > 0 && tiles <= std::min(device_cus(), GNN_SMALL_MAX_TILES);
+}
+
+// returns 2 when the kernel does not apply after all and the caller launches per iteration.  `pred0` (optional): the
+// predicate of state_0 as one word per tile; `state_final` (optional): the caller's compact result buffer.
+int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first, float *const B[2], const int *pred0,
+                    int n_pred0, float *state_final, hipStream_t st) {
+    if (!persistent_applies(a, p)) return 2;
     gnn::SmallArgs sa;
     memset(&sa, 0, sizeof(sa));
     gnn::Fused2Args &fa = sa.f;
@@ -723,6 +771,8 @@ int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first,
     sa.max_iteration = a.max_iteration;
     sa.no_exit = (a.flags & GNN_FLAG_NO_EARLY_EXIT) != 0;
     sa.flags = p.flags;
+    sa.pred0 = pred0; sa.n_pred0 = n_pred0;
+    sa.state_final = state_final; sa.ld_final = p.S;
     sa.bar = reinterpret_cast<unsigned long long *>(p.flags + ((a.max_iteration + 3) & ~1));     // 8-byte aligned (flags is 256-B aligned)
     const int rc = gnn::launch_small(sa, p.SP, device_cus(), st);
     if (rc == 1) return fail("persistent loop kernel: launch failed (%s)", hipGetErrorString(hipGetLastError()));
@@ -804,7 +854,13 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     if (((uintptr_t)a.workspace & 255) != 0) return fail("workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)a.stream;
 
-    TRY(setup_constants(a, p, st, /*zero_loop_words=*/true));       // flags, barrier counters and k start from zero
+    // Graphs the whole-loop kernel covers: one set-up launch, the loop, the output stage.  Everything else: the general
+    // set-up (one launch per constant) and one launch per iteration.
+    const int fz = fusable(a, p);
+    const bool whole_loop = fz != 0 && persistent_applies(a, p);
+    const bool small_setup = whole_loop && setup_small_applies(a, p);
+    if (small_setup) TRY(setup_small(a, p, st));
+    else             TRY(setup_constants(a, p, st, /*zero_loop_words=*/true));       // flags, barrier counters and k start from zero
 
     // state_0 (GNN.py:256-259) into the padded buffer; state_old_0 = ones is implicit in the first predicate (:261)
     // When the caller's state_0 already has the padded layout (d a multiple of 16, no hub rows behind the real ones) the
@@ -814,7 +870,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     else if (a.state_dim > 0) TRY(launch_copy2d(nullptr, a.state0, p.S, p.buf[0], p.SP, p.N, p.S, p.SP, st));
     else                      TRY(launch_copy2d(nullptr, a.nodes, a.ld_nodes, p.buf[0], p.SP, p.N, p.S, p.SP, st));
     if (p.SP != p.S) HIP_OK(hipMemsetAsync(p.buf[1], 0, sizeof(float) * (size_t)p.N * p.SP, st));
-    TRY(launch_converge(nullptr, first, nullptr, p.N, p.S, p.SP, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
+    if (!small_setup) TRY(launch_converge(nullptr, first, nullptr, p.N, p.S, p.SP, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
 
     const bool fused = can_fuse(a, p);
     const bool no_exit = (a.flags & GNN_FLAG_NO_EARLY_EXIT) != 0;
@@ -826,9 +882,10 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         B[a.max_iteration & 1] = a.state_out;
     if (a.ev_loop_begin) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_begin, st));
     int persistent = 2;
-    if (fusable(a, p) != 0) {                      // whole loop in one launch where that applies (two-layer networks too)
-        persistent = loop_persistent(a, p, first, B, st);
+    if (whole_loop) {                              // (two-layer state networks too); the kernel also writes state_out
+        persistent = loop_persistent(a, p, first, B, small_setup ? p.pred0 : nullptr, small_setup ? cdiv(p.N, 64) : 0, a.state_out, st);
         if (persistent == 1) return 1;
+        if (persistent == 2 && small_setup) return fail("whole-loop kernel refused a graph its set-up kernel accepted");
     }
     for (int it = 0; persistent != 0 && it < a.max_iteration; ++it) {
         const int *gate = no_exit ? nullptr : p.flags + it;
@@ -841,7 +898,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     if (a.ev_loop_end) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_end, st));
 
     // converged state -> caller's compact [N, S] buffer; k (device) tells which of the two buffers holds it
-    {
+    if (persistent != 0) {
         const long total = (long)p.N * p.S;
         if (total > 0) {
             gnn::k_select_state<<<std::min(cdiv(total, 256), 256 * 16), 256, 0, st>>>(a.k_out, first, B[0], B[1], p.SP, a.state_out, p.S, p.N, p.S);

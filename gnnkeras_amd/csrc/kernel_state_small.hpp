@@ -31,6 +31,10 @@ struct SmallArgs {
     int max_iteration;
     int no_exit;             // GNN_FLAG_NO_EARLY_EXIT
     int *flags;              // [max_iteration + 2], flags[0] = predicate of state_0 (set before the launch)
+    const int *pred0;        // not null: the predicate of state_0 as n_pred0 words to OR (k_setup_small), flags[0] unused
+    int n_pred0;
+    float *state_final;      // not null: the loop's result rows go here as well ([n, ld_final], compact): no select pass
+    int ld_final;
     unsigned long long *bar; // two arrival counters (even / odd iterations), zero before the launch:
                              // low word = arrivals, high word = workgroups that still saw a node move
 };
@@ -114,7 +118,16 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
     unsigned moved_seen[2] = {0u, 0u};
     int timed_out = 0;
     // the predicate of state_0 (GNN.py:265 evaluates `condition` before the first iteration)
-    const bool run_first = sa.no_exit || __hip_atomic_load(&sa.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    bool run_first = sa.no_exit != 0;
+    if (!run_first) {
+        if (sa.pred0) {
+            int v = 0;
+            for (int i = lane; i < sa.n_pred0; i += 64) v |= sa.pred0[i];
+            run_first = __any(v != 0);
+        } else {
+            run_first = __hip_atomic_load(&sa.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        }
+    }
     for (int it = 0; run_first && it < sa.max_iteration; ++it) {
         const __amdgpu_buffer_rsrc_t r_in = buf_rsrc(it == 0 ? a.state_in : sa.buf[it & 1]);
         const __amdgpu_buffer_rsrc_t r_out = buf_rsrc(sa.buf[(it + 1) & 1]);
@@ -302,6 +315,28 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
         __syncthreads();
         k_done = it + 1;
         if (!sa.no_exit && *cont == 0) break;          // uniform: every workgroup read the same total
+    }
+    // The rows the loop ends on, straight into the caller's compact buffer: the tile still holds what the last iteration
+    // stored (k_done > 0) or nothing ran and state_0 is the answer.  Every workgroup is past the last grid barrier, so no
+    // one reads a state buffer any more, whichever of them the caller's buffer stands in for.
+    if (sa.state_final) {
+        const __amdgpu_buffer_rsrc_t r_first = buf_rsrc(a.state_in);
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            if (jn[p] < 0) continue;
+            f32x4 v;
+            if (k_done > 0) {
+                const float *xr = Xs + (p * Cfg::NPP + q) * LDX + 4 * l4;
+                const float2 lo = *reinterpret_cast<const float2 *>(xr), hi = *reinterpret_cast<const float2 *>(xr + 2);
+                v = (f32x4){lo.x, lo.y, hi.x, hi.y};
+            } else {
+                v = buf_ld_sc1(r_first, (unsigned)(a.row_base + jn[p]) * (unsigned)(SP * 4) + 16u * l4);
+            }
+            float *dst = sa.state_final + (size_t)jn[p] * sa.ld_final + 4 * l4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * l4 + i < S) dst[i] = v[i];
+        }
     }
     // k_out is zero before the launch: workgroup 0 adds k; a workgroup whose grid barrier timed out (the launch was not
     // fully resident: results are not valid) adds -1e9, so k < 0 reports it whatever the order of the two

@@ -17,7 +17,7 @@ items = [seq[i][0] for i in range(len(seq))]
 inputs = [gnn.process_inputs(x) for x in items]
 s0s = [torch.randn((x[0].shape[0], d), device=dev) * 0.1 for x in items]
 run = lambda i: gnn.Loop(*inputs[i], state0=s0s[i])
-for w in (1, 2, 4, 8, 11):
+for w in (1, 2, 4, 8, 12, 16):
     for _ in gnn._batches_concurrently(len(inputs), run, dev, w): pass
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in gnn._batches_concurrently(len(inputs), run, dev, w): pass

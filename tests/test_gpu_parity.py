@@ -940,3 +940,64 @@ def test_predict_and_evaluate_with_concurrent_batches_match_one_stream(mutag_gra
         p8 = model.predict(seq); e8 = model.evaluate(seq, return_dict=True)
         assert np.array_equal(p1, p8)
         assert abs(e1['loss'] - e8['loss']) <= 1e-6 and abs(e1['accuracy'] - e8['accuracy']) <= 1e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# small graphs: one set-up launch (kernels_setup.hpp) + the whole-loop kernel, which also writes the caller's state
+# ----------------------------------------------------------------------------------------------------------------------
+def _last_kernel():
+    return nat.lib().gnn_last_kernel_name().decode()
+
+
+def _random_graph(rng, n, e, L, A, focus='n', mode='average'):
+    nodes = rng.normal(size=(n, L))
+    ends = rng.integers(0, n, size=(e, 2))
+    ends = np.unique(ends[ends[:, 0] != ends[:, 1]], axis=0) if e else np.zeros((0, 2), int)
+    arcs = np.concatenate([ends, rng.normal(size=(len(ends), A))], axis=1)
+    nt = {'n': n, 'a': len(arcs), 'g': 1}[focus]
+    return GraphObject(nodes=nodes, arcs=arcs, targets=rng.normal(size=(nt, 2)), focus=focus, aggregation_mode=mode)
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 700])
+@pytest.mark.parametrize('mode', ['sum', 'average'])
+def test_whole_loop_setup_tile_edges(n, mode):
+    """Tile boundaries of the 64-node set-up / loop tiles, with and without BatchNormalization, every path."""
+    rng = np.random.default_rng(n)
+    g = _random_graph(rng, n, 4 * n, 5, 2, mode=mode)
+    x = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    for bn in (True, False):
+        ns, no = starter_nets('n', 32, L=5, A=2, scale=0.4, bn=bn)
+        model = GNNnodeBased(ns, no, 32, 6, 0.0)
+        check(model, x, rng.normal(0, 0.1, (n, 32)).astype(np.float32))
+        model.native_flags = 0
+        model.Loop(*model.process_inputs(x), state0=dev(rng.normal(0, 0.1, (n, 32)).astype(np.float32)))
+        assert _last_kernel().startswith('k_state_small'), _last_kernel()
+
+
+def test_whole_loop_setup_state_dim_0_wide_labels():
+    """state_dim = 0 with 20 label columns: the state IS the label matrix (padded to 32), the first layer has no label /
+    neighbour-label segments (GNN.py:222-231), and the set-up kernel evaluates state_0's predicate on the labels."""
+    rng = np.random.default_rng(20)
+    g = _random_graph(rng, 300, 1500, 20, 3, focus='g')
+    x = MultiGraphSequencer([g], 'g', 'average', 1, shuffle=False)[0][0]
+    ns, no = starter_nets('g', 0, L=20, A=3, scale=0.4)
+    for thr in (0.0, 0.01):
+        model = GNNgraphBased(ns, no, 0, 7, thr)
+        check(model, x, None)
+    assert _last_kernel().startswith('k_state_small'), _last_kernel()
+
+
+def test_whole_loop_never_started_returns_state_0():
+    """A threshold no node passes at k = 0 (GNN.py:196-214): the loop kernel runs no iteration and must still deliver
+    state_0 to the caller's buffer, and the output network's answer on it."""
+    rng = np.random.default_rng(3)
+    g = _random_graph(rng, 200, 900, 4, 2)
+    x = MultiGraphSequencer([g], 'n', 'sum', 1, shuffle=False)[0][0]
+    ns, no = starter_nets('n', 64, L=4, A=2)
+    s0 = rng.normal(0, .1, (200, 64)).astype(np.float32)
+    k, st, o = check(GNNnodeBased(ns, no, 64, 10, 100.0), x, s0)
+    assert k == 0.0 and np.array_equal(st, s0)
+    # converged after the first iterations with a realistic threshold: the state of the LAST iteration, not of max_iteration
+    ns, no = starter_nets('n', 64, L=4, A=2, scale=0.05)
+    k, st, o = check(GNNnodeBased(ns, no, 64, 30, 0.05), x, s0)
+    assert 1 <= k < 30

@@ -22,6 +22,7 @@
 #include "kernel_state_fused2.hpp"
 #include "kernel_state_fused4.hpp"
 #include "kernel_state_small.hpp"
+#include "kernel_state_mid.hpp"
 #include "kernel_state_wide.hpp"
 #include "kernels_batch.hpp"
 #include "kernels_setup.hpp"
@@ -313,6 +314,7 @@ struct Plan {
     TypePlan tp[GNN_MAX_TYPES];
     // workspace
     int *flags;
+    int *mid_bar;                    // barrier lines of the mid-size whole-loop kernel (inside the zeroed loop words)
     int *pred0;                      // state_0's predicate, one word per 64-node tile (written by k_setup_small, read by k_state_small)
     int *err;                        // sticky "an in-launch wait expired" word of the fused kernels, folded into k at the end
     float *agg_arcs, *agg_nodes; int ld_agg_nodes;
@@ -327,7 +329,9 @@ struct Plan {
 };
 
 constexpr int GNN_SMALL_MAX_TILES = 512;   // upper bound of CUs a whole-loop launch can cover (one 64-node tile each)
-constexpr int GNN_LOOP_WORDS = 16;   // words behind flags[max_iteration]: [1] last flag, [3..7) barrier counters, [12] error word
+// words behind flags[max_iteration]: [1] last flag, [3..7) barrier counters of the small whole-loop kernel, [12] error word,
+// then (128-byte aligned) the mid-size whole-loop kernel's barrier lines; all zeroed by the set-up launch
+constexpr int GNN_LOOP_WORDS = 16 + 32 + gnn::MID_BAR_WORDS;
 
 int state_width(const gnn_loop_args_t &a) { return a.state_dim > 0 ? a.state_dim : a.dim_node_label; }
 
@@ -410,6 +414,7 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     Carver c(ws);
     p.flags = c.take<int>(a.max_iteration + GNN_LOOP_WORDS);   // behind the flags: the persistent kernel's two 64-bit barrier counters, the error word
     p.err = p.flags ? p.flags + a.max_iteration + 12 : nullptr;
+    p.mid_bar = p.flags ? p.flags + ((a.max_iteration + 16 + 31) & ~31) : nullptr;
     p.pred0 = c.take<int>(GNN_SMALL_MAX_TILES);
     for (int t = 0; t < p.T; ++t) {
         p.tp[t].Wf = c.take<float>((size_t)a.net_state[t].in_dim * a.net_state[t].units[0]);
@@ -779,6 +784,50 @@ int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first,
     return rc;
 }
 
+// Mid-size graphs: the whole loop in one launch with several tiles per workgroup (kernel_state_mid.hpp).  Between the
+// small whole-loop kernel's range (one tile per CU) and GNN_MID_MAX_NODES.  The default is where one launch per iteration
+// of the wave-specialised kernel catches up (profiles/r02_mid_sweep.txt, 10 arcs per node: d = 64 25.4 vs 28.5 us at
+// 30 000 nodes, 40.1 vs 35.7 at 45 000; d = 32 16.4 vs 17.6 at 30 000, 26.3 vs 26.1 at 60 000); pinned with
+// GNN_FLAG_FUSED_GEN6 at any size.
+int mid_max_nodes() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_MID_MAX_NODES"); v = e ? atoi(e) : 36000; }
+    return v;
+}
+
+bool mid_applies(const gnn_loop_args_t &a, const Plan &p) {
+    const int pinned = (a.flags & GNN_FLAG_FUSED_GEN_MASK) >> 4;
+    if (pinned != 0 && pinned != 6) return false;
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("GNN_FUSED_KERNEL"); env = e ? atoi(e) : 0; }
+    if (pinned == 0 && env != 0 && env != 6) return false;
+    if (p.n_heavy != 0 || a.max_iteration < 1 || (p.SP != 32 && p.SP != 64) || p.N == 0) return false;
+    return pinned == 6 || env == 6 || p.N <= mid_max_nodes();
+}
+
+int loop_mid(const gnn_loop_args_t &a, const Plan &p, const float *first, float *const B[2], hipStream_t st) {
+    gnn::SmallArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    gnn::Fused2Args &fa = sa.f;
+    const gnn_csr_t &adj = iter_adjacency(a, p);
+    fa.rowptr = adj.rowptr; fa.src = adj.src; fa.w = adj.w; fa.row_scale = adj.row_scale;
+    fa.state_in = first; fa.row_base = 0;
+    fa.C = p.C; fa.ldC = p.ldC;
+    for (int t = 0; t < p.T; ++t)
+        if (p.tp[t].count > 0)
+            fa.tp[fa.n_types++] = fused_type(a, p, t);
+    if (fa.n_types == 0) return 2;
+    fa.S = p.S; fa.thr = a.state_threshold; fa.k_out = a.k_out;
+    sa.buf[0] = B[0]; sa.buf[1] = B[1];
+    sa.max_iteration = a.max_iteration;
+    sa.no_exit = (a.flags & GNN_FLAG_NO_EARLY_EXIT) != 0;
+    sa.flags = p.flags;
+    sa.bar = reinterpret_cast<unsigned long long *>(p.mid_bar);
+    const int rc = gnn::launch_mid(sa, p.SP, device_cus(), st);
+    if (rc == 1) return fail("mid-size loop kernel: launch failed (%s)", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
 // 0: un-fused kernels; 1: any fused kernel; 2: two-layer state networks - only the wave-specialised kernel and the
 // persistent whole-loop kernel carry the second Dense; 3: state width 65 .. 128 - the wide kernel, whatever generation is pinned.
 int fusable(const gnn_loop_args_t &a, const Plan &p) {
@@ -887,7 +936,13 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         if (persistent == 1) return 1;
         if (persistent == 2 && small_setup) return fail("whole-loop kernel refused a graph its set-up kernel accepted");
     }
-    for (int it = 0; persistent != 0 && it < a.max_iteration; ++it) {
+    bool loop_done = persistent == 0;
+    if (!loop_done && fz == 1 && mid_applies(a, p)) {
+        const int rc = loop_mid(a, p, first, B, st);
+        if (rc == 1) return 1;
+        loop_done = rc == 0;
+    }
+    for (int it = 0; !loop_done && it < a.max_iteration; ++it) {
         const int *gate = no_exit ? nullptr : p.flags + it;
         const float *src = it == 0 ? first : B[it & 1];
         float *dst = B[(it + 1) & 1];
@@ -906,7 +961,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         }
     }
     TRY(output_stage(a, p, st));
-    if (persistent != 0 && fused && a.max_iteration > 0) TRY(launch_fold_error(p, a.k_out, st));
+    if (!loop_done && fused && a.max_iteration > 0) TRY(launch_fold_error(p, a.k_out, st));
     return 0;
 }
 

@@ -43,7 +43,7 @@ enum gnn_flags {
      * small graphs only - falls back to the size-based choice when it does not apply).  Results are the same within float32
      * summation order; the GNN_FUSED_KERNEL environment variable has the same effect process-wide. */
     GNN_FLAG_FUSED_GEN2 = 2 << 4, GNN_FLAG_FUSED_GEN4 = 4 << 4,
-    GNN_FLAG_FUSED_GEN5 = 5 << 4, GNN_FLAG_FUSED_GEN_MASK = 7 << 4
+    GNN_FLAG_FUSED_GEN5 = 5 << 4, GNN_FLAG_FUSED_GEN6 = 6 << 4, GNN_FLAG_FUSED_GEN_MASK = 7 << 4
 };
 
 /* A sparse operator A (n_src x n_dst, COO in the reference: tf.SparseTensor) stored as the CSR of its transpose:

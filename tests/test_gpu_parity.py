@@ -21,7 +21,8 @@ from oracle.harness import oracle_loop, oracle_composite_loop, rel_err
 
 pytestmark = pytest.mark.gpu
 # every way the iteration can run: size-based default, un-fused kernels, and each fused-kernel generation pinned
-PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN4, nat.FLAG_FUSED_GEN5)
+# (2 phase-alternating, 4 wave-specialised, 5 / 6 whole loop in one launch: one tile per CU / several tiles per workgroup)
+PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN4, nat.FLAG_FUSED_GEN5, nat.FLAG_FUSED_GEN6)
 TOL = 1e-5
 CLS = {'n': GNNnodeBased, 'a': GNNarcBased, 'g': GNNgraphBased}
 CCLS = {'n': CompositeGNNnodeBased, 'a': CompositeGNNarcBased, 'g': CompositeGNNgraphBased}
@@ -984,6 +985,8 @@ def test_whole_loop_setup_state_dim_0_wide_labels():
     for thr in (0.0, 0.01):
         model = GNNgraphBased(ns, no, 0, 7, thr)
         check(model, x, None)
+    model.native_flags = 0
+    model.Loop(*model.process_inputs(x))
     assert _last_kernel().startswith('k_state_small'), _last_kernel()
 
 
@@ -1001,3 +1004,62 @@ def test_whole_loop_never_started_returns_state_0():
     ns, no = starter_nets('n', 64, L=4, A=2, scale=0.05)
     k, st, o = check(GNNnodeBased(ns, no, 64, 30, 0.05), x, s0)
     assert 1 <= k < 30
+
+
+@pytest.mark.parametrize('n,d,mode,thr', [(20000, 64, 'average', 0.0), (50000, 32, 'sum', 0.0), (30001, 64, 'average', 0.02), (70000, 40, 'normalized', 0.0)])
+def test_mid_size_whole_loop_kernel(n, d, mode, thr):
+    """Graphs between the small whole-loop kernel's range and the large-graph kernels: the whole loop in one launch with
+    several 64-node tiles per workgroup and a two-level grid barrier between iterations (kernel_state_mid.hpp).  The
+    automatic choice picks it up to 36 000 nodes (pinned beyond), and it must agree with the oracle and with one launch
+    per iteration."""
+    rng = np.random.default_rng(n)
+    g = er_graph(n, 8 * n, seed=5, aggregation_mode=mode)
+    ns, no = starter_nets('n', d, scale=0.3)
+    model = GNNnodeBased(ns, no, d, 9, thr)
+    s0 = rng.normal(0, 0.1, (n, d)).astype(np.float32)
+    x = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    inputs = model.process_inputs(x)
+    res = {}
+    for flags in (0, nat.FLAG_FUSED_GEN6, nat.FLAG_FUSED_GEN2, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=torch.from_numpy(s0).cuda())
+        assert float(k) == float(k64), (flags, float(k), k64)
+        assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, flags
+        if flags == nat.FLAG_FUSED_GEN6 or (flags == 0 and n <= 36000): assert _last_kernel().startswith('k_state_mid'), _last_kernel()
+        res[flags] = st
+    # bit-stable from run to run (fixed summation order inside a tile, barrier-separated iterations)
+    model.native_flags = 0
+    k, st, o = model.Loop(*inputs, state0=torch.from_numpy(s0).cuda())
+    assert torch.equal(st, res[0])
+
+
+def test_mid_size_whole_loop_weighted_and_composite():
+    """Per-arc weights (4-wave shape) and a 3-type composite graph (one launch serves every type's tiles)."""
+    rng = np.random.default_rng(8)
+    n, d = 25000, 32
+    g = er_graph(n, 6 * n, seed=2, aggregation_mode='sum')
+    an = g.getArcNode(); an.data = rng.uniform(0.2, 1.0, len(an.data)).astype(np.float32)
+    g = GraphObject(nodes=g.nodes, arcs=g.arcs, targets=g.targets, focus='n', ArcNode=an)
+    seq = MultiGraphSequencer([g], 'n', 'sum', 1, shuffle=False)
+    seq.graph_tensors[0].ArcNode = SparseMatrix.from_scipy(g.ArcNode)
+    seq.graph_tensors[0].Adjacency = SparseMatrix.from_scipy(g.Adjacency)
+    seq._items = [None]
+    x = seq[0][0]
+    assert x[5].matrix.csr().w is not None
+    ns, no = starter_nets('n', d, scale=0.2)
+    model = GNNnodeBased(ns, no, d, 6, 0.0)
+    s0 = rng.normal(0, 0.1, (n, d)).astype(np.float32)
+    check(model, x, s0)
+    model.native_flags = 0
+    model.Loop(*model.process_inputs(x), state0=dev(s0))
+    assert _last_kernel().startswith('k_state_mid<32,true'), _last_kernel()
+    N, dims = 30000, (5, 3, 4)
+    gc = er_composite_graph(N, 200000, dim_node_label=dims, aggregation_mode='composite_average', seed=11)
+    nsc, noc = composite_nets(dims, 3, 64, 2, 'n')
+    mc = CompositeGNNnodeBased(nsc, noc, 64, 6, 0.0)
+    xc = CompositeMultiGraphSequencer([gc], 'n', 'composite_average', 1, shuffle=False)[0][0]
+    check(mc, xc, rng.normal(0, 0.1, (N, 64)).astype(np.float32), oracle=oracle_composite_loop)
+    mc.native_flags = 0
+    mc.Loop(*mc.process_inputs(xc), state0=dev(rng.normal(0, 0.1, (N, 64)).astype(np.float32)))
+    assert _last_kernel().startswith('k_state_mid'), _last_kernel()

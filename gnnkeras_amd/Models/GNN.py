@@ -82,8 +82,7 @@ class _LoopModel:
         if len(sequencer) == 0: return np.zeros((0, 0), np.float32)
         dev = self._batch_device(sequencer[0][0])
         self._k_seen = []
-        outs = [o for _, o in self._batches_concurrently(len(sequencer), lambda i: self.call(sequencer[i][0], training=False),
-                                                          dev, self._round_width(sequencer, dev))]
+        outs = [o for _, o in self._forward_batches(sequencer, dev)]
         self._check_k()
         return torch.cat(outs, dim=0).cpu().numpy()
 
@@ -97,8 +96,7 @@ class _LoopModel:
         mets = None
         dev = self._batch_device(sequencer[0][0]) if len(sequencer) else torch.device('cpu')
         self._k_seen = []
-        for i, p in self._batches_concurrently(len(sequencer), lambda i: self.call(sequencer[i][0], training=False), dev,
-                                               self._round_width(sequencer, dev) if len(sequencer) else 1):
+        for i, p in self._forward_batches(sequencer, dev):
             _, y, sw = sequencer[i]
             if mets is None:
                 mets = [(n, f, torch.zeros((), device=p.device)) for n, f in (_metric_fn(m, y.shape[-1]) for m in self.metrics_spec)]
@@ -171,7 +169,7 @@ class _LoopModel:
         synchronises anyway."""
         ks = getattr(self, '_k_seen', None)
         if ks:
-            if float(torch.stack([k.reshape(()) for k in ks]).min()) < 0:
+            if float(torch.stack([k.min() for k in ks]).min()) < 0:
                 raise nat.NativeError(self._K_ERROR)
         self._k_seen = None
 
@@ -180,9 +178,9 @@ class _LoopModel:
         `NativeError` if the kernels reported an expired wait (k < 0). Returns k as a float."""
         k = getattr(self, '_last_k', None)
         if k is None: raise RuntimeError('no forward has run yet')
-        kv = float(k)
-        if kv < 0: raise nat.NativeError(self._K_ERROR)
-        return kv
+        kv = k.detach().cpu().numpy()
+        if kv.min() < 0: raise nat.NativeError(self._K_ERROR)
+        return float(kv) if kv.ndim == 0 else kv
 
     @staticmethod
     def _batch_device(x):
@@ -190,6 +188,61 @@ class _LoopModel:
         return t.device if isinstance(t, torch.Tensor) else torch.device('cpu')
 
     # batch overlap and mask-index cache -------------------------------------------------------------------------------
+    group_batches = True           # predict() / evaluate(): merged batches as independent loops of one launch where supported
+
+    def _forward_batches(self, sequencer, device):
+        """(i, out_i) for every batch of `sequencer`, in order.  Small batches leave most of the GPU idle (a merged MUTAG
+        batch is 15 workgroups on 256 CUs), so where the library supports it consecutive batches are merged into one graph
+        and run as INDEPENDENT loops of one launch (`Loop(groups=...)`: every batch keeps its own convergence test and
+        iteration count, so each result equals the batch-by-batch call); otherwise batches are spread over side streams."""
+        n = len(sequencer)
+        plan = self._group_plan(sequencer, device) if n > 1 else None
+        if plan is None:
+            yield from self._batches_concurrently(n, lambda i: self.call(sequencer[i][0], training=False), device,
+                                                  self._round_width(sequencer, device) if n else 1)
+            return
+        for i0, i1 in plan:
+            if i1 - i0 == 1:
+                yield i0, self.call(sequencer[i0][0], training=False)
+                continue
+            x, node_begin = sequencer.merged_batches(i0, i1)
+            out = self.call(x, training=False, groups=node_begin)
+            r0 = 0
+            for i in range(i0, i1):
+                rows = int(sequencer[i][1].shape[0])               # output rows of a batch = its target rows
+                yield i, out[r0: r0 + rows]
+                r0 += rows
+
+    def _group_plan(self, sequencer, device):
+        """[(i0, i1), ...]: runs of batches to merge per launch (every 64-node tile of a launch resident at once, at most
+        32 groups), or None when grouping does not apply (composite model, CPU, 'normalized', unsupported shape)."""
+        if not self.group_batches or device.type != 'cuda' or not hasattr(sequencer, 'merged_batches'): return None
+        if not isinstance(getattr(self, 'net_state', None), Sequential) or not hasattr(self, 'state_vect_dim'): return None
+        if sequencer.merged_batches(0, 1) is None: return None
+        try:
+            sizes = [int(sequencer[i][0][0].shape[0]) for i in range(len(sequencer))]
+            n_out = [int(sequencer[i][1].shape[0]) for i in range(len(sequencer))]
+            x0 = sequencer[0][0]
+            L, A = int(x0[0].shape[1]), int(x0[1].shape[1]) - 2
+        except Exception:
+            return None
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        plan, i0, tiles = [], 0, 0
+        for i, nn in enumerate(sizes):
+            t = (nn + 63) // 64
+            if i > i0 and (tiles + t > cus or i - i0 >= 32):
+                plan.append((i0, i)); i0, tiles = i, 0
+            tiles += t
+        plan.append((i0, len(sizes)))
+        focus = nat.FOCUS[self._focus]
+        for i0, i1 in plan:
+            if i1 - i0 < 2: continue
+            begin = [0] + list(np.cumsum(sizes[i0:i1]))
+            if not ops.loop_groups_supported(begin[-1], L, A, self.net_state, self.net_output, self.state_vect_dim, self.max_iteration,
+                                             focus, self.native_flags, sum(n_out[i0:i1]), begin):
+                return None
+        return plan
+
     def _batches_concurrently(self, n, fn, device, width=None):
         """Run fn(i), i < n, `width` at a time on side HIP streams and yield (i, result) in order on the caller's stream.
 
@@ -329,10 +382,11 @@ class GNNnodeBased(_LoopModel):
             net.summary(*args, **kwargs)
 
     # ---- call ---------------------------------------------------------------------------------------------------------
-    def call(self, inputs, training: bool = False, mask=None):
-        """`inputs` = the list a sequencer's `__getitem__` yields; returns `out` (eval) or `(k, state, out)`."""
+    def call(self, inputs, training: bool = False, mask=None, *, groups=None):
+        """`inputs` = the list a sequencer's `__getitem__` yields; returns `out` (eval) or `(k, state, out)`.  `groups`
+        (additive): node offsets of merged batches that run as independent loops (see `Loop`)."""
         inputs = self.process_inputs(inputs)
-        k, state, out = self.Loop(*inputs, training=training)
+        k, state, out = self.Loop(*inputs, training=training, groups=groups)
         if training: return k, state, out
         if getattr(self, '_k_seen', None) is not None: self._k_seen.append(k)        # predict() / evaluate() check it at the end
         return out
@@ -387,8 +441,13 @@ class GNNnodeBased(_LoopModel):
                                       'device (SURVEY.md §8f, next row); inference forward is the built path')
 
     def Loop(self, nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph,
-             training: bool = False, *, state0=None, seed=None, node_level: bool = False):
+             training: bool = False, *, state0=None, seed=None, node_level: bool = False, groups=None):
         """(k, state, out) for one (merged) graph — reference GNN.py:245-274.
+
+        `groups` (additive; inference only): node offsets [G + 1] of G batches merged into this graph.  The loop then runs
+        as G independent loops in one launch - each batch has its own `condition` and stops on its own, exactly as if the
+        reference had been called batch by batch - and k is a vector of G iteration counts (include/gnnloop.h,
+        group_node_begin; `ops.loop_groups_supported` says whether a shape qualifies).
 
         Additive keyword arguments: `state0` replaces the reference's `tf.random.normal(stddev=0.1)`
         draw when `state_vect_dim > 0`; otherwise it is drawn on the device with `seed`. `node_level=True` makes a
@@ -396,6 +455,7 @@ class GNNnodeBased(_LoopModel):
         `GNNnodeBased.Loop` on a graph-based model inside LGNN, LGNN.py:225)."""
         focus = 'n' if (node_level and self._focus == 'g') else self._focus
         if training:
+            if groups is not None: raise ValueError('groups are an inference-only feature')
             from .training import LoopTrainer
             tp = LoopTrainer(self).forward([nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph],
                                            state0=state0, seed=seed, node_level=node_level)
@@ -423,7 +483,7 @@ class GNNnodeBased(_LoopModel):
         k, state, out = ops.loop_forward(nodes.to(torch.float32).contiguous(), arcs.to(torch.float32).contiguous(), adj, arcn, ng,
                                          self.net_state, self.net_output, state0, out_index, ends, self.state_vect_dim,
                                          self.max_iteration, self.state_threshold, nat.FOCUS[focus], self.native_flags,
-                                         loop_events=self.loop_events)
+                                         loop_events=self.loop_events, groups=groups)
         self._last_k = k
         return k, state, out
 

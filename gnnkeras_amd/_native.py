@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 # GNNKERAS_AMD_LIB: load another build of the same sources (tests: the debug build whose in-launch waits expire at once)
 LIB_PATH = os.environ.get('GNNKERAS_AMD_LIB') or os.path.join(CSRC, 'libgnnloop.so')
 
-GNN_ABI_VERSION = 2
+GNN_ABI_VERSION = 3
 GNN_MAX_LAYERS = 8
 GNN_MAX_TYPES = 8
 
@@ -25,7 +25,7 @@ FLAG_UNFUSED = 1
 FLAG_NO_EARLY_EXIT = 2
 FLAG_FUSED_GEN2, FLAG_FUSED_GEN4, FLAG_FUSED_GEN5, FLAG_FUSED_GEN6 = 2 << 4, 4 << 4, 5 << 4, 6 << 4     # pin the fused-kernel generation (tests, tuning)
 
-EXPORTS = ['gnn_last_error', 'gnn_last_kernel_name', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_aggregate',
+EXPORTS = ['gnn_last_error', 'gnn_last_kernel_name', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_loop_groups_supported', 'gnn_aggregate',
            'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_ld',
            'gnn_shard_setup', 'gnn_shard_iteration', 'gnn_shard_output', 'gnn_gather_rows',
            'gnn_shard_can_split', 'gnn_shard_partial', 'gnn_shard_iteration_split',
@@ -74,7 +74,8 @@ class LoopArgs(C.Structure):
                 ('flags', C.c_int32), ('nodes_src', C.c_void_p), ('ld_nodes_src', C.c_int32),
                 ('adjacency_light', CSR), ('heavy_seg_beg', C.c_void_p), ('heavy_seg_end', C.c_void_p),
                 ('n_heavy_segments', C.c_int32),
-                ('ev_loop_begin', C.c_void_p), ('ev_loop_end', C.c_void_p)]
+                ('ev_loop_begin', C.c_void_p), ('ev_loop_end', C.c_void_p),
+                ('group_node_begin', C.c_void_p), ('n_groups', C.c_int32)]
 
 
 class DenseArgs(C.Structure):

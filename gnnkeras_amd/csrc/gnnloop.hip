@@ -315,6 +315,9 @@ struct Plan {
     // workspace
     int *flags;
     int *mid_bar;                    // barrier lines of the mid-size whole-loop kernel (inside the zeroed loop words)
+    gnn::GroupTab gt;                // convergence groups (one group = the whole graph when the caller gave none)
+    int n_groups;                    // the caller's n_groups (0: k_out is one float)
+    int group_tiles;                 // 64-node tiles when no tile straddles a group
     int *pred0;                      // state_0's predicate, one word per 64-node tile (written by k_setup_small, read by k_state_small)
     int *err;                        // sticky "an in-launch wait expired" word of the fused kernels, folded into k at the end
     float *agg_arcs, *agg_nodes; int ld_agg_nodes;
@@ -351,6 +354,26 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     if (a.focus < GNN_FOCUS_NODE || a.focus > GNN_FOCUS_GRAPH) return fail("unknown focus %d", a.focus);
     p.M = a.n_out;
     if (p.M < 0) return fail("n_out < 0");
+    static_assert(gnn::MAX_GROUPS == GNN_MAX_GROUPS, "group table of the kernels and the header differ");
+    p.n_groups = a.n_groups;
+    if (a.n_groups < 0 || a.n_groups > GNN_MAX_GROUPS) return fail("n_groups %d out of [0,%d]", a.n_groups, GNN_MAX_GROUPS);
+    if (a.n_groups > 0) {
+        if (p.composite) return fail("convergence groups are not supported for composite graphs");
+        if (!a.group_node_begin) return fail("group_node_begin is NULL");
+        if (a.group_node_begin[0] != 0 || a.group_node_begin[a.n_groups] != a.n_nodes) return fail("group_node_begin must span [0, n_nodes]");
+        p.gt.n = a.n_groups;
+        for (int g = 0; g < a.n_groups; ++g) {
+            const int nb = a.group_node_begin[g], ne = a.group_node_begin[g + 1];
+            if (ne <= nb) return fail("group %d is empty or group_node_begin is not ascending", g);
+            p.gt.node_begin[g] = nb; p.gt.tile_begin[g] = p.group_tiles;
+            p.group_tiles += (ne - nb + 63) / 64;
+        }
+        p.gt.node_begin[a.n_groups] = a.n_nodes; p.gt.tile_begin[a.n_groups] = p.group_tiles;
+    } else {
+        p.gt.n = 1; p.gt.node_begin[0] = 0; p.gt.node_begin[1] = a.n_nodes;
+        p.group_tiles = (a.n_nodes + 63) / 64;
+        p.gt.tile_begin[0] = 0; p.gt.tile_begin[1] = p.group_tiles;
+    }
 
     int sum_dt = 0;
     for (int t = 0; t < p.T; ++t) {
@@ -578,7 +601,7 @@ int setup_small(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     sa.net = fl.fa.job[0];
     if (a.net_output.kernel[0]) { fl.add(a.net_output, p.Wf_out, p.bf_out); sa.out = fl.fa.job[1]; }
     const int L = a.state_dim > 0 ? p.L : 0;
-    sa.N = p.N; sa.n_tiles = cdiv(p.N, 64);
+    sa.N = p.N; sa.n_tiles = p.group_tiles; sa.groups = p.gt;
     sa.nodes = a.nodes; sa.ld_nodes = a.ld_nodes; sa.L = L;
     sa.nodes_src = a.nodes_src ? a.nodes_src : a.nodes; sa.ld_nodes_src = a.nodes_src ? a.ld_nodes_src : a.ld_nodes;
     sa.adj = gnn::SetupCsr{a.adjacency.rowptr, a.adjacency.src, a.adjacency.w, a.adjacency.row_scale};
@@ -589,7 +612,7 @@ int setup_small(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     sa.C = p.C; sa.ldC = p.ldC;
     sa.state0 = a.state_dim > 0 ? a.state0 : a.nodes; sa.ld_s0 = a.state_dim > 0 ? p.S : a.ld_nodes;
     sa.S = p.S; sa.thr = a.state_threshold; sa.pred0 = p.pred0;
-    sa.zero_a = p.flags; sa.n_a = a.max_iteration + GNN_LOOP_WORDS; sa.zero_b = a.k_out; sa.n_b = 1;
+    sa.zero_a = p.flags; sa.n_a = a.max_iteration + GNN_LOOP_WORDS; sa.zero_b = a.k_out; sa.n_b = std::max(1, p.n_groups);
     gnn::k_setup_small<<<sa.n_tiles + 1, 256, gnn::setup_small_lds(sa.net.H, 2 * L + p.A), st>>>(sa);
     LAUNCH_OK();
     return 0;
@@ -752,6 +775,7 @@ bool persistent_applies(const gnn_loop_args_t &a, const Plan &p) {
     if (p.n_heavy != 0 || a.max_iteration < 1 || (p.SP != 32 && p.SP != 64)) return false;
     int tiles = 0;
     for (int t = 0; t < p.T; ++t) tiles += (p.tp[t].count + 63) / 64;
+    if (p.n_groups > 0) tiles = p.group_tiles;
     return tiles > 0 && tiles <= std::min(device_cus(), GNN_SMALL_MAX_TILES);
 }
 
@@ -779,7 +803,12 @@ int loop_persistent(const gnn_loop_args_t &a, const Plan &p, const float *first,
     sa.pred0 = pred0; sa.n_pred0 = n_pred0;
     sa.state_final = state_final; sa.ld_final = p.S;
     sa.bar = reinterpret_cast<unsigned long long *>(p.flags + ((a.max_iteration + 3) & ~1));     // 8-byte aligned (flags is 256-B aligned)
-    const int rc = gnn::launch_small(sa, p.SP, device_cus(), st);
+    if (p.n_groups > 0) {              // one pair of arrival counters per group: the (otherwise idle) mid-size kernel's lines
+        static_assert(4 * GNN_MAX_GROUPS <= gnn::MID_BAR_WORDS, "group counters must fit the zeroed barrier words");
+        sa.groups = p.gt;
+        sa.bar = reinterpret_cast<unsigned long long *>(p.mid_bar);
+    }
+    const int rc = gnn::launch_small(sa, p.SP, device_cus(), st, p.n_groups > 0 ? p.group_tiles : 0);
     if (rc == 1) return fail("persistent loop kernel: launch failed (%s)", hipGetErrorString(hipGetLastError()));
     return rc;
 }
@@ -908,6 +937,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     const int fz = fusable(a, p);
     const bool whole_loop = fz != 0 && persistent_applies(a, p);
     const bool small_setup = whole_loop && setup_small_applies(a, p);
+    if (p.n_groups > 0 && !small_setup) return fail("convergence groups need the whole-loop kernel (gnn_loop_groups_supported() == 0 for these args)");
     if (small_setup) TRY(setup_small(a, p, st));
     else             TRY(setup_constants(a, p, st, /*zero_loop_words=*/true));       // flags, barrier counters and k start from zero
 
@@ -932,7 +962,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     if (a.ev_loop_begin) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_begin, st));
     int persistent = 2;
     if (whole_loop) {                              // (two-layer state networks too); the kernel also writes state_out
-        persistent = loop_persistent(a, p, first, B, small_setup ? p.pred0 : nullptr, small_setup ? cdiv(p.N, 64) : 0, a.state_out, st);
+        persistent = loop_persistent(a, p, first, B, small_setup ? p.pred0 : nullptr, small_setup ? p.group_tiles : 0, a.state_out, st);
         if (persistent == 1) return 1;
         if (persistent == 2 && small_setup) return fail("whole-loop kernel refused a graph its set-up kernel accepted");
     }
@@ -963,6 +993,13 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     TRY(output_stage(a, p, st));
     if (!loop_done && fused && a.max_iteration > 0) TRY(launch_fold_error(p, a.k_out, st));
     return 0;
+}
+
+int gnn_loop_groups_supported(const gnn_loop_args_t *args) {
+    if (!args || args->n_groups < 1) return 0;
+    Plan p;
+    if (make_plan(*args, nullptr, p, false)) return 0;
+    return fusable(*args, p) != 0 && persistent_applies(*args, p) && setup_small_applies(*args, p) ? 1 : 0;
 }
 
 int gnn_aggregate(const gnn_csr_t *csr, const float *X, int32_t ldx, int32_t F, float *out, int32_t ldo, void *stream) {

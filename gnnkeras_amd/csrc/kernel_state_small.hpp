@@ -35,6 +35,8 @@ struct SmallArgs {
     int n_pred0;
     float *state_final;      // not null: the loop's result rows go here as well ([n, ld_final], compact): no select pass
     int ld_final;
+    GroupTab groups;         // n > 0 (homogeneous graphs): independent loops, one per group of tiles; each group has its own
+                             // two arrival counters (bar + 2 * g), its own k (k_out[g]) and leaves the loop on its own
     unsigned long long *bar; // two arrival counters (even / odd iterations), zero before the launch:
                              // low word = arrivals, high word = workgroups that still saw a node move
 };
@@ -57,8 +59,15 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
     while (ty + 1 < a.n_types && (int)blockIdx.x >= a.blk_begin[ty + 1]) ++ty;
     const FusedType tp = a.tp[ty];
     const int tile = blockIdx.x - a.blk_begin[ty];                       // one tile per workgroup, for the whole loop
-    const int count = tp.count;
     const int *__restrict__ rows = tp.rows;
+    // rows [jbase, jend) of this type's node list; with groups: 64 nodes of one group, synchronising with that group only
+    int jbase = tile * TM, count = tp.count, grp = 0;
+    unsigned wg0 = 0, n_wg = gridDim.x;
+    if (sa.groups.n > 0) {
+        const GroupOfTile got = group_of_tile(sa.groups, blockIdx.x);
+        jbase = got.node0 + ((int)blockIdx.x - got.tile0) * TM; count = got.node_end;
+        grp = got.grp; wg0 = got.tile0; n_wg = got.tile1 - got.tile0;
+    }
 
     for (int i = tid; i < 2 * SP * SP; i += NT) {
         const int k = i / SP, n = i % SP;
@@ -81,7 +90,7 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
     float wts[NPASS][IPL], scl[NPASS];
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-        const int m = tile * TM + p * Cfg::NPP + q;
+        const int m = jbase + p * Cfg::NPP + q;
         jn[p] = m < count ? (rows ? rows[m] : m) : -1;
         beg[p] = end[p] = 0; scl[p] = 1.0f;
         if (jn[p] >= 0) {
@@ -101,7 +110,7 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
     f32x4 c0[Cfg::CT_PER_WAVE];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-        const int m = tile * TM + 16 * rt + 4 * g + reg;
+        const int m = jbase + 16 * rt + 4 * g + reg;
         jrow[reg] = m < count ? (rows ? rows[m] : m) : -1;
     }
 #pragma unroll
@@ -113,7 +122,6 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
     }
     __syncthreads();
 
-    const unsigned n_wg = gridDim.x;
     int k_done = 0;
     unsigned moved_seen[2] = {0u, 0u};
     int timed_out = 0;
@@ -122,7 +130,7 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
     if (!run_first) {
         if (sa.pred0) {
             int v = 0;
-            for (int i = lane; i < sa.n_pred0; i += 64) v |= sa.pred0[i];
+            for (int i = lane; i < (int)n_wg; i += 64) v |= sa.pred0[wg0 + i];
             run_first = __any(v != 0);
         } else {
             run_first = __hip_atomic_load(&sa.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -296,7 +304,7 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
         if (tid == 0) {
             // The arrival and the predicate travel in ONE 64-bit add.  Two counters alternate: a workgroup can reach the
             // barrier of iteration it+1 before a slow one has read iteration it's total, but never the one of it+2.
-            unsigned long long *ctr = sa.bar + (it & 1);
+            unsigned long long *ctr = sa.bar + 2 * grp + (it & 1);
             __hip_atomic_fetch_add(ctr, 1ull + ((unsigned long long)(any ? 1u : 0u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = (unsigned)(it / 2 + 1) * n_wg;
             unsigned long long v = 0;
@@ -341,15 +349,15 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
     // k_out is zero before the launch: workgroup 0 adds k; a workgroup whose grid barrier timed out (the launch was not
     // fully resident: results are not valid) adds -1e9, so k < 0 reports it whatever the order of the two
     if (tid == 0 && a.k_out) {
-        if (timed_out) atomicAdd(a.k_out, -1.0e9f);
-        if (blockIdx.x == 0) atomicAdd(a.k_out, (float)k_done);
+        if (timed_out) atomicAdd(a.k_out + grp, -1.0e9f);
+        if (blockIdx.x == wg0) atomicAdd(a.k_out + grp, (float)k_done);
     }
 }
 
 // one tile per workgroup, every workgroup resident: graphs of at most 64 * n_cu nodes
 constexpr size_t SMALL_LDS = 96 * 1024;      // > half of a CU's 160 KB: at most one of these workgroups per CU
 template <int SP, bool HAS_W, bool L2>
-int launch_small_one(SmallArgs &sa, int n_cu, hipStream_t st) {
+int launch_small_one(SmallArgs &sa, int n_cu, hipStream_t st, int group_tiles) {
     using Cfg = Fused2Cfg<SP, 64, 8>;
     static bool attr = false;
     if (!attr) {
@@ -360,7 +368,8 @@ int launch_small_one(SmallArgs &sa, int n_cu, hipStream_t st) {
     Fused2Args &fa = sa.f;
     fa.blk_begin[0] = 0;
     for (int t = 0; t < fa.n_types; ++t) fa.blk_begin[t + 1] = fa.blk_begin[t] + (fa.tp[t].count + 63) / 64;
-    const int grid = fa.blk_begin[fa.n_types];
+    const int grid = group_tiles > 0 ? group_tiles : fa.blk_begin[fa.n_types];   // with groups no tile straddles a group
+    if (group_tiles > 0) fa.blk_begin[1] = group_tiles;
     if (grid == 0 || grid > n_cu) return 2;             // not applicable: the caller falls back to one launch per iteration
     GNN_SET_KERNEL_NAME("k_state_small<%d,%s,%s>", SP, HAS_W ? "true" : "false", L2 ? "true" : "false");
     k_state_small<SP, HAS_W, L2><<<grid, Cfg::NT, SMALL_LDS, st>>>(sa);
@@ -373,12 +382,12 @@ inline int small_tiles(const Fused2Args &fa) {
     return n;
 }
 
-inline int launch_small(SmallArgs &sa, int SP, int n_cu, hipStream_t st) {
+inline int launch_small(SmallArgs &sa, int SP, int n_cu, hipStream_t st, int group_tiles = 0) {
     const bool l2 = sa.f.n_types > 0 && sa.f.tp[0].W2 != nullptr;
 #define SMALL_CASE(SPV)                                                                                              \
     case SPV:                                                                                                        \
-        if (l2) return sa.f.w ? launch_small_one<SPV, true, true>(sa, n_cu, st) : launch_small_one<SPV, false, true>(sa, n_cu, st); \
-        return sa.f.w ? launch_small_one<SPV, true, false>(sa, n_cu, st) : launch_small_one<SPV, false, false>(sa, n_cu, st);
+        if (l2) return sa.f.w ? launch_small_one<SPV, true, true>(sa, n_cu, st, group_tiles) : launch_small_one<SPV, false, true>(sa, n_cu, st, group_tiles); \
+        return sa.f.w ? launch_small_one<SPV, true, false>(sa, n_cu, st, group_tiles) : launch_small_one<SPV, false, false>(sa, n_cu, st, group_tiles);
     switch (SP) {
         SMALL_CASE(32)
         SMALL_CASE(64)

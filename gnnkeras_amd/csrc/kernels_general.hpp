@@ -414,6 +414,25 @@ k_converge(const int *gate, const float *__restrict__ s, const float *__restrict
     }
 }
 
+// Independent convergence groups of a merged graph (gnn_loop_args_t::group_node_begin): nodes and 64-node tiles of group g.
+// Passed by value in the kernel arguments and searched with a fully unrolled loop (constant indices: scalar loads from the
+// kernel-argument segment, no scratch copy); tile numbers are wave-uniform.
+constexpr int MAX_GROUPS = 32;
+struct GroupTab {
+    int n;                               // 0: no groups (one loop over everything)
+    int node_begin[MAX_GROUPS + 1];
+    int tile_begin[MAX_GROUPS + 1];
+};
+struct GroupOfTile { int grp, node0, node_end, tile0, tile1; };
+__device__ __forceinline__ GroupOfTile group_of_tile(const GroupTab &gt, int tile) {
+    GroupOfTile r{0, gt.node_begin[0], gt.node_begin[1], gt.tile_begin[0], gt.tile_begin[1]};
+#pragma unroll
+    for (int g = 1; g < MAX_GROUPS; ++g)
+        if (g < gt.n && tile >= gt.tile_begin[g])
+            r = GroupOfTile{g, gt.node_begin[g], gt.node_begin[g + 1], gt.tile_begin[g], gt.tile_begin[g + 1]};
+    return r;
+}
+
 // Fold an inference BatchNormalization into the Dense layer that follows it (Keras: y = x*inv + (beta - mean*inv),
 // inv = gamma / sqrt(var + eps)):  Wf[k][h] = inv[k] * W[k][h],  bf[h] = b[h] + sum_k (beta[k] - mean[k]*inv[k]) W[k][h].
 // One workgroup per output column h, threads stride over k; the shift sum meets in a fixed-order LDS tree.

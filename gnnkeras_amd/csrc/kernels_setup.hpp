@@ -22,6 +22,7 @@ struct SetupCsr { const int *rowptr, *src; const float *w, *row_scale; };
 struct SetupArgs {
     FoldJob net, out;                 // first layers of the state network and (W != nullptr) the output network
     int N, n_tiles;
+    GroupTab groups;                  // n >= 1: tile t covers 64 nodes of ONE group (a merged graph without groups is one group)
     // constant inputs of the state network's first layer and the rows of W they meet
     const float *nodes; int ld_nodes; int L;                  // L = 0: the model has no label columns (state_dim == 0)
     const float *nodes_src; int ld_nodes_src; SetupCsr adj;   // agg_nodes = Adjacency^T . nodes_src
@@ -79,6 +80,8 @@ __global__ void __launch_bounds__(256) k_setup_small(SetupArgs sa) {
         return;
     }
     const FoldJob &jb = sa.net;
+    const GroupOfTile got = group_of_tile(sa.groups, blockIdx.x);
+    const int jbase = got.node0 + ((int)blockIdx.x - got.tile0) * 64, jend = got.node_end;
 
     // ---- a. folded bias (every tile needs it; K x H multiply-adds) and the constant rows of Wf ------------------------
     {
@@ -109,9 +112,9 @@ __global__ void __launch_bounds__(256) k_setup_small(SetupArgs sa) {
     // ---- b. constant inputs of this tile's nodes: 4 lanes per node, lane c owns columns c, c + 4, ... ----------------
     {
         const int m = tid >> 2, c = tid & 3;
-        const int j = blockIdx.x * 64 + m;
+        const int j = jbase + m;
         float *xr = Xc + m * LDXC;
-        if (j < sa.N) {
+        if (j < jend) {
             for (int f = c; f < L; f += 4) xr[f] = sa.nodes[(size_t)j * sa.ld_nodes + f];
             if (L > 0) {
                 const int beg = sa.adj.rowptr[j], end = sa.adj.rowptr[j + 1];
@@ -146,11 +149,11 @@ __global__ void __launch_bounds__(256) k_setup_small(SetupArgs sa) {
     // ---- c. C[j][h] = bf[h] + sum_kc X[j][kc] Wc[kc][h] ------------------------------------------------------------------
     for (int i = tid; i < 64 * H; i += 256) {
         const int m = i / H, h = i % H;
-        const int j = blockIdx.x * 64 + m;
+        const int j = jbase + m;
         float acc = bfs[h];
         const float *xr = Xc + m * LDXC;
         for (int kc = 0; kc < Kc; ++kc) acc = fmaf(xr[kc], Wc[kc * H + h], acc);
-        if (j < sa.N) sa.C[(size_t)j * sa.ldC + h] = acc;
+        if (j < jend) sa.C[(size_t)j * sa.ldC + h] = acc;
     }
 
     // ---- d. does any node of this tile still move between ones and state_0?  (16 lanes per node, as k_converge) -------
@@ -158,9 +161,9 @@ __global__ void __launch_bounds__(256) k_setup_small(SetupArgs sa) {
     {
         const int lane = tid & 15;
         for (int m = tid >> 4; m < 64; m += 16) {
-            const int j = blockIdx.x * 64 + m;
+            const int j = jbase + m;
             float d2 = 0.0f, n2 = 0.0f;
-            if (j < sa.N)
+            if (j < jend)
                 for (int f = lane; f < sa.S; f += 16) {
                     const float d = sa.state0[(size_t)j * sa.ld_s0 + f] - 1.0f;
                     d2 = fmaf(d, d, d2);
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(256) k_setup_small(SetupArgs sa) {
                 d2 += __shfl_xor(d2, off, 16);
                 n2 += __shfl_xor(n2, off, 16);
             }
-            if (j < sa.N && sqrtf(d2) > sa.thr * sqrtf(n2)) any = 1;
+            if (j < jend && sqrtf(d2) > sa.thr * sqrtf(n2)) any = 1;
         }
     }
     any = __syncthreads_or(any);

@@ -4,6 +4,7 @@
 //
 //   torch.ops.gnnkeras.loop_forward   (k, state, out) = Loop(...)      reference GNN/Models/GNN.py:245-274, :317-330, :341-346,
 //                                                                       CompositeGNN.py:242-272, :315-343
+//                                     (+ group_node_begin: merged batches as independent loops; loop_groups_supported asks first)
 //   torch.ops.gnnkeras.aggregate      A^T . X                           sparse_dense_matmul(adjoint_a=True): GNN.py:228, :254, :258
 //   torch.ops.gnnkeras.pool           NodeGraph^T . out                 GNN.py:345
 //   torch.ops.gnnkeras.converged      the predicate of `condition`      GNN.py:196-212
@@ -151,7 +152,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> loop_forward(
     double bn_eps, const std::optional<at::Tensor> &state0, const at::Tensor &out_index, const std::optional<at::Tensor> &arc_src,
     const std::optional<at::Tensor> &arc_dst, int64_t state_dim, int64_t max_iteration, double state_threshold, int64_t focus, int64_t flags,
     const OptTensorList &hub, at::IntArrayRef hub_dims, const std::optional<at::Tensor> &type_nodes, at::IntArrayRef type_offsets,
-    at::IntArrayRef type_dim_label, const OptTensorList &composite_adjacency, at::IntArrayRef composite_dims, at::IntArrayRef loop_events) {
+    at::IntArrayRef type_dim_label, const OptTensorList &composite_adjacency, at::IntArrayRef composite_dims, at::IntArrayRef loop_events,
+    at::IntArrayRef group_node_begin) {
     const at::Device dev = nodes.device();
     gnn_loop_args_t a{};
     fill_graph(a, nodes, arcs, adjacency, adjacency_dims, arcnode, arcnode_dims, hub, hub_dims, dev);
@@ -199,10 +201,17 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> loop_forward(
     a.flags = (int32_t)flags;
     if (loop_events.size() == 2) { a.ev_loop_begin = (void *)(uintptr_t)loop_events[0]; a.ev_loop_end = (void *)(uintptr_t)loop_events[1]; }
     a.stream = current_stream(dev);
+    // independent convergence groups: batches merged into one call, each stopping on its own (k becomes [n_groups])
+    std::vector<int32_t> groups(group_node_begin.begin(), group_node_begin.end());
+    if (!groups.empty()) {
+        TORCH_CHECK(groups.size() >= 2 && groups.size() <= GNN_MAX_GROUPS + 1, "group_node_begin: between 2 and ", GNN_MAX_GROUPS + 1, " entries");
+        a.group_node_begin = groups.data(); a.n_groups = (int32_t)groups.size() - 1;
+    }
 
     const auto opts = at::TensorOptions().dtype(at::kFloat).device(dev);
     const int64_t rows_out = focus == GNN_FOCUS_GRAPH ? a.nodegraph.n_dst : a.n_out;
-    at::Tensor k = at::empty({}, opts), state = at::empty({a.n_nodes, S}, opts);
+    at::Tensor k = groups.empty() ? at::empty({}, opts) : at::empty({(int64_t)a.n_groups}, opts);
+    at::Tensor state = at::empty({a.n_nodes, S}, opts);
     at::Tensor out = at::empty({rows_out, a.net_output.units[a.net_output.n_layers - 1]}, opts);
     a.k_out = k.data_ptr<float>(); a.state_out = state.data_ptr<float>(); a.out = out.data_ptr<float>();
     const size_t bytes = gnn_loop_workspace_bytes(&a);
@@ -211,6 +220,33 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> loop_forward(
     a.workspace_bytes = bytes;
     check_rc(gnn_loop_forward(&a));
     return {k, state, out};
+}
+
+// network shape only (no weights): what gnn_loop_groups_supported reads
+void mlp_shape_of(gnn_mlp_t &m, at::IntArrayRef spec, const char *name) {
+    m = gnn_mlp_t{};
+    TORCH_CHECK(spec.size() >= 3, name, ": spec is {in_dim, has_bn, n_layers, units..., activations...}");
+    m.in_dim = (int32_t)spec[0]; m.has_bn = (int32_t)spec[1]; m.n_layers = (int32_t)spec[2];
+    TORCH_CHECK(m.n_layers >= 1 && m.n_layers <= GNN_MAX_LAYERS && spec.size() == 3 + 2 * (size_t)m.n_layers, name, ": malformed spec");
+    for (int l = 0; l < m.n_layers; ++l) { m.units[l] = (int32_t)spec[3 + l]; m.activation[l] = (int32_t)spec[3 + m.n_layers + l]; }
+}
+
+// May `loop_forward(..., group_node_begin)` run these batches as independent loops of one call?  (shapes only, no tensors)
+bool loop_groups_supported(int64_t n_nodes, int64_t dim_node_label, int64_t dim_arc_label, at::IntArrayRef net_state_spec,
+                           at::IntArrayRef net_output_spec, int64_t state_dim, int64_t max_iteration, int64_t focus, int64_t flags,
+                           int64_t n_out, at::IntArrayRef group_node_begin) {
+    gnn_loop_args_t a{};
+    a.abi_version = GNN_ABI_VERSION;
+    a.n_nodes = (int32_t)n_nodes; a.dim_node_label = (int32_t)dim_node_label; a.dim_arc_label = (int32_t)dim_arc_label;
+    a.n_types = 1;
+    mlp_shape_of(a.net_state[0], net_state_spec, "net_state");
+    mlp_shape_of(a.net_output, net_output_spec, "net_output");
+    a.state_dim = (int32_t)state_dim; a.max_iteration = (int32_t)max_iteration; a.focus = (int32_t)focus; a.flags = (int32_t)flags;
+    a.n_out = (int32_t)n_out;
+    std::vector<int32_t> groups(group_node_begin.begin(), group_node_begin.end());
+    if (groups.size() < 2 || groups.size() > GNN_MAX_GROUPS + 1) return false;
+    a.group_node_begin = groups.data(); a.n_groups = (int32_t)groups.size() - 1;
+    return gnn_loop_groups_supported(&a) != 0;
 }
 
 at::Tensor aggregate(const OptTensorList &csr, at::IntArrayRef dims, const at::Tensor &X) {
@@ -291,8 +327,10 @@ TORCH_LIBRARY(gnnkeras, m) {
           "Tensor?[] nodegraph, int[] nodegraph_dims, Tensor[] net_state_weights, int[] net_state_spec, Tensor[] net_output_weights, "
           "int[] net_output_spec, float bn_eps, Tensor? state0, Tensor out_index, Tensor? arc_src, Tensor? arc_dst, int state_dim, "
           "int max_iteration, float state_threshold, int focus, int flags, Tensor?[] hub, int[] hub_dims, Tensor? type_nodes, "
-          "int[] type_offsets, int[] type_dim_label, Tensor?[] composite_adjacency, int[] composite_dims, int[] loop_events) "
-          "-> (Tensor k, Tensor state, Tensor out)");
+          "int[] type_offsets, int[] type_dim_label, Tensor?[] composite_adjacency, int[] composite_dims, int[] loop_events, "
+          "int[] group_node_begin) -> (Tensor k, Tensor state, Tensor out)");
+    m.def("loop_groups_supported(int n_nodes, int dim_node_label, int dim_arc_label, int[] net_state_spec, int[] net_output_spec, "
+          "int state_dim, int max_iteration, int focus, int flags, int n_out, int[] group_node_begin) -> bool", &loop_groups_supported);
     m.def("aggregate(Tensor?[] csr, int[] dims, Tensor X) -> Tensor");
     m.def("pool(Tensor?[] nodegraph, int[] dims, Tensor out_nodes) -> Tensor");
     m.def("converged(Tensor state, Tensor? state_old, float threshold) -> Tensor");

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 2
+#define GNN_ABI_VERSION 3
 
 /* Keras activation names accepted by the reference MLP builder (GNN/Models/MLP.py:16). */
 enum gnn_activation {
@@ -147,7 +147,18 @@ typedef struct gnn_loop_args {
     /* measurement (optional) ------------------------------------------------------------------------------------ */
     void *ev_loop_begin;      /* hipEvent_t or NULL: recorded on `stream` right before the first iteration launch */
     void *ev_loop_end;        /* hipEvent_t or NULL: recorded right after the last iteration launch               */
+    /* independent convergence groups (optional; n_groups == 0 = one loop over the whole graph) ----------------------
+     * The graph is the merge of n_groups batches (block-diagonal operators, nodes of group g contiguous in
+     * [group_node_begin[g], group_node_begin[g + 1])), and the reference would have run `Loop` once per batch: its
+     * `while` (GNN.py:265) stops a batch when no node OF THAT BATCH moves.  With groups, one call runs all those loops at
+     * once - each group has its own predicate, its own iteration counter (k_out is [n_groups]) and stops on its own -
+     * so many small batches fill the GPU in one launch instead of one underfilled launch each.  Results per group equal
+     * a separate call on that batch alone.  Supported where the whole-loop kernel applies (gnn_loop_groups_supported);
+     * everything before and after the loop (constants, output network, pooling) is per node / per graph anyway. */
+    const int32_t *group_node_begin;   /* HOST array [n_groups + 1], ascending, [0] = 0, [n_groups] = n_nodes         */
+    int32_t n_groups;                  /* <= GNN_MAX_GROUPS                                                           */
 } gnn_loop_args_t;
+#define GNN_MAX_GROUPS 32
 
 const char *gnn_last_error(void);
 /* Name (with template arguments) of the state-transition kernel this thread launched last, e.g.
@@ -164,6 +175,10 @@ size_t gnn_loop_workspace_bytes(const gnn_loop_args_t *args);
 
 /* (k, state, out) = Loop(...)  — see gnn_loop_args. */
 int gnn_loop_forward(const gnn_loop_args_t *args);
+/* 1 when gnn_loop_forward accepts these args with n_groups > 0 (homogeneous model, one- or two-layer state network of
+ * width 17..64, every group's 64-node tiles resident at once: sum_g ceil(nodes_g / 64) <= CUs), else 0: the caller then
+ * runs one call per batch.  Reads dims, flags and the host group array only. */
+int gnn_loop_groups_supported(const gnn_loop_args_t *args);
 
 /* out[j, 0:F] = sum_{e in row j} w_e * X[src_e, 0:F]   == tf.sparse.sparse_dense_matmul(A, X, adjoint_a=True)
  * (ArcNode scatter-add GNN.py:254, label aggregate :258, state aggregate :228, graph pooling :345). */

@@ -1063,3 +1063,78 @@ def test_mid_size_whole_loop_weighted_and_composite():
     mc.native_flags = 0
     mc.Loop(*mc.process_inputs(xc), state0=dev(rng.normal(0, 0.1, (N, 64)).astype(np.float32)))
     assert _last_kernel().startswith('k_state_mid'), _last_kernel()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# convergence groups: several batches merged into one call, each with its own `while` (include/gnnloop.h group_node_begin)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('focus,d,thr', [('g', 32, 0.01), ('n', 64, 0.02), ('a', 32, 0.0)])
+def test_convergence_groups_equal_batch_by_batch_calls(mutag_graphs, focus, d, thr):
+    """Eight MUTAG batches as eight independent loops of ONE launch: per batch the iteration count, the state and the
+    output must equal - bit for bit, the tiles and summation orders are the same - what a call on that batch alone
+    gives, including batches that converge at different k."""
+    gl = refocus(mutag_graphs[:8 * 20], focus, np.random.default_rng(3))
+    seq = MultiGraphSequencer(gl, focus, 'average', 20, shuffle=False)
+    ns, no = starter_nets(focus, d, scale=0.22)
+    model = CLS[focus](ns, no, d, 30, thr)
+    rng = np.random.default_rng(9)
+    parts = []
+    for i in range(len(seq)):
+        x = seq[i][0]
+        s0 = rng.normal(0, 0.1 * (1 + i), (x[0].shape[0], d)).astype(np.float32)     # different scales: different k per batch
+        k, st, o = model.Loop(*model.process_inputs(x), state0=dev(s0))
+        parts.append((float(k), st, o, s0))
+    x, begin = seq.merged_batches(0, len(seq))
+    assert begin[-1] == x[0].shape[0] and len(begin) == len(seq) + 1
+    from gnnkeras_amd import ops
+    assert ops.loop_groups_supported(begin[-1], x[0].shape[1], x[1].shape[1] - 2, ns, no, d, 30, nat.FOCUS[focus], 0, 0, begin)
+    k, st, o = model.Loop(*model.process_inputs(x), state0=dev(np.concatenate([p[3] for p in parts])), groups=begin)
+    assert _last_kernel().startswith('k_state_small'), _last_kernel()
+    assert k.shape == (len(seq),)
+    assert [float(v) for v in k.cpu()] == [p[0] for p in parts]
+    if thr > 0: assert len({p[0] for p in parts}) > 1, 'the batches were meant to stop at different iterations'
+    assert torch.equal(st, torch.cat([p[1] for p in parts]))
+    assert torch.equal(o, torch.cat([p[2] for p in parts]))
+    assert np.array_equal(model.check_last_k(), np.array([p[0] for p in parts], np.float32))
+    # ... and against the oracle on one of the batches
+    i = 3
+    k64, st64, o64 = oracle_loop(model, seq[i][0], parts[i][3], np.float64)
+    assert float(k[i]) == float(k64) and rel_err(st[begin[i]:begin[i + 1]].cpu().numpy(), st64) <= TOL
+
+
+def test_predict_and_evaluate_group_batches(mutag_graphs):
+    """predict() / evaluate() with grouped launches against the batch-by-batch walk: same numbers (state_vect_dim = 0 keeps
+    the forward deterministic; 20 label columns put the state on the 32-wide kernels the groups need)."""
+    rng = np.random.default_rng(4)
+    gl = []
+    for i in range(150):
+        n = int(rng.integers(5, 40))
+        g = _random_graph(rng, n, 3 * n, 20, 3, focus='g')
+        gl.append(GraphObject(nodes=g.nodes, arcs=g.arcs, targets=np.eye(2)[rng.integers(0, 2, 1)], focus='g'))
+    seq = MultiGraphSequencer(gl, 'g', 'average', 16, shuffle=False)
+    ns, no = starter_nets('g', 0, L=20, A=3, scale=0.3)
+    model = GNNgraphBased(ns, no, 0, 25, 0.005)
+    model.compile(optimizer='adam', loss='categorical_crossentropy', metrics=['accuracy'])
+    dev_ = torch.device('cuda', 0)
+    plan = model._group_plan(seq, dev_)
+    assert plan is not None and plan[0][1] - plan[0][0] > 1, plan
+    model.group_batches = True
+    p1 = model.predict(seq); e1 = model.evaluate(seq, return_dict=True)
+    model.group_batches = False
+    p0 = model.predict(seq); e0 = model.evaluate(seq, return_dict=True)
+    assert p1.shape == (150, 2) and np.array_equal(p1, p0)
+    assert abs(e1['loss'] - e0['loss']) <= 1e-6 and abs(e1['accuracy'] - e0['accuracy']) <= 1e-6
+    # 'normalized' divides by the merged graph's arc count: never grouped
+    seqn = MultiGraphSequencer(gl, 'g', 'normalized', 16, shuffle=False)
+    assert seqn.merged_batches(0, 2) is None and model._group_plan(seqn, dev_) is None
+
+
+def test_groups_are_refused_where_unsupported(mutag_graphs):
+    seq = MultiGraphSequencer(mutag_graphs[:64], 'g', 'average', 32, shuffle=False)
+    ns, no = starter_nets('g', 0)                              # state = 14 label columns: the 16-wide kernels, no whole-loop launch
+    model = GNNgraphBased(ns, no, 0, 5, 0.01)
+    assert model._group_plan(seq, torch.device('cuda', 0)) is None
+    x, begin = seq.merged_batches(0, 2)
+    with pytest.raises(RuntimeError, match='groups'):
+        model.Loop(*model.process_inputs(x), groups=begin)
+    assert np.array_equal(model.predict(seq).shape, (64, 2))

@@ -386,7 +386,7 @@ class GNNnodeBased(_LoopModel):
         """`inputs` = the list a sequencer's `__getitem__` yields; returns `out` (eval) or `(k, state, out)`.  `groups`
         (additive): node offsets of merged batches that run as independent loops (see `Loop`)."""
         inputs = self.process_inputs(inputs)
-        k, state, out = self.Loop(*inputs, training=training, groups=groups)
+        k, state, out = self.Loop(*inputs, training=training, **({} if groups is None else {'groups': groups}))
         if training: return k, state, out
         if getattr(self, '_k_seen', None) is not None: self._k_seen.append(k)        # predict() / evaluate() check it at the end
         return out

@@ -328,7 +328,7 @@ TORCH_LIBRARY(gnnkeras, m) {
           "int[] net_output_spec, float bn_eps, Tensor? state0, Tensor out_index, Tensor? arc_src, Tensor? arc_dst, int state_dim, "
           "int max_iteration, float state_threshold, int focus, int flags, Tensor?[] hub, int[] hub_dims, Tensor? type_nodes, "
           "int[] type_offsets, int[] type_dim_label, Tensor?[] composite_adjacency, int[] composite_dims, int[] loop_events, "
-          "int[] group_node_begin) -> (Tensor k, Tensor state, Tensor out)");
+          "int[] group_node_begin=[]) -> (Tensor k, Tensor state, Tensor out)");
     m.def("loop_groups_supported(int n_nodes, int dim_node_label, int dim_arc_label, int[] net_state_spec, int[] net_output_spec, "
           "int state_dim, int max_iteration, int focus, int flags, int n_out, int[] group_node_begin) -> bool", &loop_groups_supported);
     m.def("aggregate(Tensor?[] csr, int[] dims, Tensor X) -> Tensor");

@@ -1,6 +1,8 @@
 """Soak test for the in-launch hand-offs: repeated runs must be bitwise reproducible, and the persistent whole-loop kernel
-(generation 5) must match the one-launch-per-iteration kernel it shares its tile arithmetic with (generation 2) bit for
-bit.  A race in the LDS ring (generation 4) or in the grid barrier (generation 5) would show up as a difference."""
+(generation 5) must agree with the one-launch-per-iteration kernel it shares its tile arithmetic with (generation 2): same
+iteration count, states within 1e-5 (the two paths compute the per-node constant C in different summation orders - one
+set-up launch against the general MFMA dense - so they are no longer bit-equal).  A race in the LDS ring (generation 4)
+or in a grid barrier (generations 5 and 6) would show up as a run-to-run difference."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -27,18 +29,23 @@ for d, bs in ((32, 32), (64, 48)):
             inputs = gnn.process_inputs(x)
             s0 = torch.randn((x[0].shape[0], d), device='cuda') * 0.1
             res = {}
-            for flag in (nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN5):
-                gnn.native_flags = flag
+            for flag in (nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN5, -1):
+                gnn.native_flags = nat.FLAG_FUSED_GEN5 if flag < 0 else flag
                 k, st, o = gnn.Loop(*inputs, state0=s0)
                 res[flag] = (float(k), st.clone(), o.clone())
-            a, c = res[nat.FLAG_FUSED_GEN2], res[nat.FLAG_FUSED_GEN5]
-            if a[0] != c[0] or not torch.equal(a[1], c[1]) or not torch.equal(a[2], c[2]):
+            a, c, c2 = res[nat.FLAG_FUSED_GEN2], res[nat.FLAG_FUSED_GEN5], res[-1]
+            if c[0] != c2[0] or not torch.equal(c[1], c2[1]) or not torch.equal(c[2], c2[2]):
                 bad += 1
-                print(f'MISMATCH d={d} rep={rep} batch={b}: k {a[0]} vs {c[0]}, state max diff {float((a[1] - c[1]).abs().max()):.3e}')
+                print(f'NOT REPRODUCIBLE d={d} rep={rep} batch={b}: k {c[0]} vs {c2[0]}, state max diff {float((c[1] - c2[1]).abs().max()):.3e}')
+            rel = float((a[1] - c[1]).abs().max() / a[1].abs().max())
+            if a[0] != c[0] or rel > 1e-5:
+                bad += 1
+                print(f'MISMATCH d={d} rep={rep} batch={b}: k {a[0]} vs {c[0]}, state rel diff {rel:.3e}')
             n += 1
     print(f'MUTAG d={d} batch={bs}: {n} forward pairs, {bad} mismatches, {time.time() - t0:.1f} s')
 # ---- ER graph: generation 4 repeated, bitwise reproducible; persistent kernel at its size limit ----------------------------
-for N, E, flag, name in ((200000, 2000000, nat.FLAG_FUSED_GEN4, 'generation 4'), (16000, 160000, nat.FLAG_FUSED_GEN5, 'generation 5')):
+for N, E, flag, name in ((200000, 2000000, nat.FLAG_FUSED_GEN4, 'generation 4'), (16000, 160000, nat.FLAG_FUSED_GEN5, 'generation 5'),
+                          (30000, 300000, nat.FLAG_FUSED_GEN6, 'generation 6')):
     g = er_graph(N, E, aggregation_mode='average'); seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False); x = seq[0][0]
     d = 64
     inp, lay = get_inout_dims('state', 14, 3, 2, 'n', d); ns = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0)

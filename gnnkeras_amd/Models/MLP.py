@@ -175,7 +175,9 @@ class Sequential:
         """(spec, weights) in the form the oracle's `mlp_apply` takes (tests only)."""
         reg = lambda rs: [None if r is None else (r.l1, r.l2) for r in rs]
         return {'batch_normalization': self.batch_normalization, 'activations': list(self.activations),
-                'kernel_regularizer': reg(self.kernel_regularizer), 'bias_regularizer': reg(self.bias_regularizer)}, self.get_weights()
+                'kernel_regularizer': reg(self.kernel_regularizer), 'bias_regularizer': reg(self.bias_regularizer),
+                'dropout_rate': list(self.dropout_rate), 'dropout_pos': list(self.dropout_pos),
+                'alphadropout': bool(self.alphadropout)}, self.get_weights()
 
     def get_config(self):
         return {'input_dim': self.input_dim, 'units': self.units, 'activations': self.activations,

@@ -177,6 +177,13 @@ class _Prim:
                                              nat.ptr(g), nat.ptr(mean), nat.ptr(var), BN_EPSILON, nat.ptr(m1), nat.ptr(m2),
                                              nat.ptr(dx), dx.stride(0), self.stream()))
 
+    def dropout(self, x, y, rate, key, alpha, backward):
+        """Keras Dropout / AlphaDropout with the mask of `key` (forward value, or backward gradient); x and y may alias."""
+        M, H = x.shape
+        nat.check(nat.lib().gnn_dropout(nat.ptr(x), x.stride(0), nat.ptr(y), y.stride(0), M, H, float(rate), int(key) & 0xFFFFFFFF,
+                                        int(bool(alpha)), int(bool(backward)), self.stream()))
+        return y
+
     def scatter_add_rows(self, D, idx, G):
         nat.check(self.lib.gnn_scatter_add_rows(nat.ptr(D), D.stride(0), nat.ptr(idx), D.shape[0], D.shape[1], nat.ptr(G),
                                                 G.stride(0), self.stream()))
@@ -203,6 +210,14 @@ class _NetGrads:
         self.dW = [torch.zeros_like(x) for x in self.W]
         self.db = [torch.zeros_like(x) for x in self.b]
         self.touched = False                                        # False until the first accumulation of this step
+        # Dropout layers by position in the Dense list (reference MLP.py:60-66: position p = in front of Dense p, p = number of
+        # Dense layers = behind the last one): {p: [(rate, index of the dropout layer), ...]}
+        self.drop, self.alpha, self.net_id = {}, bool(getattr(net, 'alphadropout', False)), 0
+        pos = [int(v) for v in (net.dropout_pos or [])]
+        if pos != sorted(pos): raise ValueError('dropout_pos must be ascending (the reference inserts the layers in that order)')
+        for i, (r, q) in enumerate(zip(net.dropout_rate or [], pos)):
+            if not 0 <= q <= len(net.units): raise ValueError(f'dropout_pos {q} outside [0, {len(net.units)}]')
+            if float(r) > 0: self.drop.setdefault(q, []).append((float(r), i))
 
     def variables(self):
         v = list(self.bn_params) if self.bn else []
@@ -215,6 +230,26 @@ class _NetGrads:
         return g
 
 
+class _Acts(list):
+    """Activations of one network call: the list of Dense outputs + `.inputs` (what each next layer consumed), `.out`, `.call`."""
+    inputs, out, call = None, None, 0
+
+
+def _lowbias32(h):
+    h &= 0xFFFFFFFF
+    h ^= h >> 16; h = (h * 0x7feb352d) & 0xFFFFFFFF
+    h ^= h >> 15; h = (h * 0x846ca68b) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
+def _mix32(*values):
+    """Key of a Dropout call from small integers (step seed, network, call, layer): the device hashes (key, row, column)."""
+    h = 0x9E3779B9
+    for v in values: h = _lowbias32(h ^ (int(v) & 0xFFFFFFFF))
+    return h
+
+
 class LoopTrainer:
     """One instance per model; owns gradient buffers and scratch. Homogeneous node / arc / graph focus."""
 
@@ -222,10 +257,29 @@ class LoopTrainer:
         self.model = model
 
     # ---- generic MLP forward (training mode) / backward over segmented inputs -------------------------------------------
-    def _mlp_forward(self, ng: _NetGrads, segs, M, stats=None, const_stats=None):
+    def _drop_key(self, ng: _NetGrads, call, index):
+        """32-bit key of one Dropout layer call: step seed, network, call number (iteration), layer index."""
+        return _mix32(self.drop_seed, ng.net_id, int(call), int(index))
+
+    def _dropped(self, ng: _NetGrads, q, x, call):
+        """What the layer behind position q consumes: x through the Dropout layers sitting there (a copy), or x itself."""
+        if q not in ng.drop: return x
+        y = x
+        for rate, index in ng.drop[q]:
+            y = self.prim.dropout(y, self.prim.new(*x.shape) if y is x else y, rate, self._drop_key(ng, call, index), ng.alpha, False)
+        return y
+
+    def _mlp_forward(self, ng: _NetGrads, segs, M, stats=None, const_stats=None, call=0):
         """segs: [(view, rowidx)] in input-column order. Returns (hs, (mean, var)|None). `stats` given => reuse (backward
-        recompute); else batch statistics are computed (constant segments may come from `const_stats`: {index: (mean, var)})."""
+        recompute); else batch statistics are computed (constant segments may come from `const_stats`: {index: (mean, var)}).
+        `hs` holds every Dense layer's activation; `hs.inputs[l]` is what layer l + 1 consumed (the same array, or its
+        dropped-out copy) and `hs.out` the network's output.  `call` numbers the calls of this network within the step: it
+        keys the Dropout masks, so the backward recompute of call t sees the masks of the forward call t."""
         p, net = self.prim, ng.net
+        if 0 in ng.drop:
+            raise NotImplementedError('a Dropout layer in front of the first Dense (dropout_pos = 0) is not on the HIP training path: '
+                                      'the first layer is folded with BatchNormalization and split into per-segment products there; '
+                                      'positions >= 1 are supported')
         mean = var = None
         if ng.bn:
             if stats is not None:
@@ -244,20 +298,29 @@ class LoopTrainer:
             p.fold(ng.W[0], ng.b[0], ng.bn_params, mean, var, Wf, bf)
         else:
             Wf, bf = ng.W[0], ng.b[0]
-        hs = [p.dense(segs, Wf, net.units[0], bf, ng.acts[0], p.new(M, net.units[0]))]
+        hs = _Acts([p.dense(segs, Wf, net.units[0], bf, ng.acts[0], p.new(M, net.units[0]))])
+        hs.inputs = [self._dropped(ng, 1, hs[0], call)]
         for l in range(1, len(net.units)):
-            hs.append(p.dense([(hs[-1], None)], ng.W[l], net.units[l], ng.b[l], ng.acts[l], p.new(M, net.units[l])))
+            hs.append(p.dense([(hs.inputs[-1], None)], ng.W[l], net.units[l], ng.b[l], ng.acts[l], p.new(M, net.units[l])))
+            hs.inputs.append(self._dropped(ng, l + 1, hs[l], call))
+        hs.out, hs.call = hs.inputs[-1], call
         return hs, ((mean, var) if ng.bn else None)
 
     def _mlp_backward(self, ng: _NetGrads, segs, hs, G, M, stats, dx_requests):
-        """G = dL/d hs[-1] (overwritten). dx_requests: [(segment index, out view [M, width])]."""
+        """G = dL/d hs.out (overwritten). dx_requests: [(segment index, out view [M, width])]."""
         p, net = self.prim, ng.net
         acc = ng.touched
+
+        def through_dropout(q, G_):                                # d loss / d (input of the Dropout layers at position q)
+            for rate, index in reversed(ng.drop.get(q, [])):
+                p.dropout(G_, G_, rate, self._drop_key(ng, hs.call, index), ng.alpha, True)
+            return G_
+        G = through_dropout(len(net.units), G)
         for l in range(len(net.units) - 1, 0, -1):
             dZ = p.act_grad(G, hs[l], G, ng.acts[l])
-            p.dense_grad(hs[l - 1], None, dZ, M, ng.dW[l], ng.db[l], acc)
+            p.dense_grad(hs.inputs[l - 1], None, dZ, M, ng.dW[l], ng.db[l], acc)
             Wt = ng.W[l].t().contiguous()
-            G = p.dense([(dZ, None)], Wt, net.units[l - 1], None, 0, p.new(M, net.units[l - 1]))
+            G = through_dropout(l, p.dense([(dZ, None)], Wt, net.units[l - 1], None, 0, p.new(M, net.units[l - 1])))
         dZ = p.act_grad(G, hs[0], G, ng.acts[0])
         K, H = ng.W[0].shape
         P, q = p.new(K, H), p.new(H)
@@ -291,7 +354,6 @@ class LoopTrainer:
         m = self.model
         tp = SimpleNamespace()
         composite = tp.composite = isinstance(m.net_state, (list, tuple))
-        _check_no_dropout((list(m.net_state) if composite else [m.net_state]) + [m.net_output])
         inputs = m.process_inputs(x_list)
         if composite:
             nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, _cas, adjacency, arcnode, nodegraph = inputs
@@ -312,6 +374,11 @@ class LoopTrainer:
         for n_ in nets_s: n_.to(dev)
         m.net_output.to(dev)
         gs, go = [_NetGrads(n_, p) for n_ in nets_s], _NetGrads(m.net_output, p)
+        for i, g_ in enumerate(gs): g_.net_id = i
+        go.net_id = 1000
+        # Dropout masks of this step: `seed` when given (reproducible steps, tests), else a per-model step counter
+        m._dropout_step = getattr(m, '_dropout_step', 0) + 1
+        self.drop_seed = tp.drop_seed = _mix32(0x5EED, int(seed)) if seed is not None else _mix32(id(m) & 0xFFFFFFFF, m._dropout_step)
         tp.gs, tp.go = gs, go
         self.gs, self.go = (gs if composite else gs[0]), go
         adj = tp.adj = adjacency.device_csr(dev)
@@ -410,9 +477,9 @@ class LoopTrainer:
                 if counts[ty] == 0:
                     st_t.append(None); continue
                 segs = state_segs(t, ty)[0]
-                hs, st = self._mlp_forward(gs[ty], segs, counts[ty], const_stats=const_stats[ty])
-                if rows[ty] is None: states[t + 1].copy_(hs[-1])
-                else: states[t + 1].index_copy_(0, rows_long[ty], hs[-1])
+                hs, st = self._mlp_forward(gs[ty], segs, counts[ty], const_stats=const_stats[ty], call=t)
+                if rows[ty] is None: states[t + 1].copy_(hs.out)
+                else: states[t + 1].index_copy_(0, rows_long[ty], hs.out)
                 st_t.append(st)
             stats_t.append(st_t)
             nat.check(lib.gnn_converged_gated(nat.ptr(states[t + 1]), nat.ptr(states[t]), N, S, S, float(m.state_threshold),
@@ -447,7 +514,7 @@ class LoopTrainer:
             if go.bn:
                 mm, mv = go.moving
                 mm.mul_(BN_MOMENTUM).add_(tp.ostats[0] * (1 - BN_MOMENTUM)); mv.mul_(BN_MOMENTUM).add_(tp.ostats[1] * (1 - BN_MOMENTUM))
-            tp.out_nodes = tp.ohs[-1]
+            tp.out_nodes = tp.ohs.out
         else:
             tp.ohs, tp.ostats, tp.out_nodes = None, None, p.new(0, T)
         if tp.pooled:
@@ -485,6 +552,7 @@ class LoopTrainer:
         ArcNode scatter-add of every iteration's constant segment (GNN.py:254) and, for arc focus, the output network's
         arc-label segment (GNN.py:326): what an arc-focused LGNN layer with `get_output` hands to the layer below."""
         m, p = self.model, tp.p
+        self.prim, self.drop_seed = p, tp.drop_seed                 # the recomputed calls draw the forward's Dropout masks
         N, S, L, d, M, k, focus = tp.N, tp.S, tp.L, tp.d, tp.M, tp.k, tp.focus
         gs, go, rows, rows_long, counts = tp.gs, tp.go, tp.rows, tp.rows_long, tp.counts
         G_state = p.zeros(N, S)                                     # dL / d states[k]
@@ -528,7 +596,7 @@ class LoopTrainer:
             for ty in range(tp.T_types):
                 if counts[ty] == 0: continue
                 segs, i_state, i_agg, i_lab, i_alab = tp.state_segs(t, ty)
-                hs, _ = self._mlp_forward(gs[ty], segs, counts[ty], stats=tp.stats_t[t][ty])
+                hs, _ = self._mlp_forward(gs[ty], segs, counts[ty], stats=tp.stats_t[t][ty], call=t)
                 if rows[ty] is None:
                     req = [(i_state, dx_s), (i_agg, dx_a)]
                     if want_label_grads and d > 0: req += [(i_lab, dl_t), (i_alab, da_t_)]
@@ -616,6 +684,7 @@ class LoopTrainer:
     def _native_step_applies(self, y):
         m = self.model
         if not self.use_native_step or isinstance(m.net_state, (list, tuple)) or y is None: return False
+        if m.net_state.dropout_rate or m.net_output.dropout_rate: return False      # Dropout masks: the general path below
         kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
         return str(kind).lower() in nat.LOSSES
 

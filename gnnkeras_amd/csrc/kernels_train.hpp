@@ -324,6 +324,29 @@ k_axpby(float a, const float *__restrict__ x, float b, const float *__restrict__
         out[i] = a * x[i] + (y ? b * y[i] : 0.0f);
 }
 
+// ---- Dropout / AlphaDropout (Keras layers of the reference MLP builder, MLP.py:60-66) ---------------------------------------
+// The mask is a pure function of (key, row, column): a counter-based hash, so the backward sweep regenerates the mask of any
+// call from its key instead of storing it.  keep <=> hash >= rate * 2^32.
+//   Dropout       forward  y = x * keep / (1 - rate)                      backward  dx = dy * keep / (1 - rate)
+//   AlphaDropout  forward  y = a * (x * keep + alpha' * (1 - keep)) + b   backward  dx = dy * a * keep
+//                 alpha' = -selu_alpha * selu_scale, a = ((1 - rate)(1 + rate alpha'^2))^-1/2, b = -a alpha' rate
+__device__ __forceinline__ unsigned lowbias32(unsigned h) {
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ bool dropout_keep(unsigned key, unsigned row, unsigned col, unsigned thr) {
+    return lowbias32(lowbias32(key + row) ^ (col * 0x9E3779B1u)) >= thr;
+}
+__global__ void __launch_bounds__(256)
+k_dropout(const float *__restrict__ x, int ldx, float *__restrict__ y, int ldy, int M, int H, unsigned key, unsigned thr,
+          float mul, float fill, float add) {      // y = keep ? x * mul + add : fill     (backward: add = fill = 0)
+    const size_t total = (size_t)M * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned r = (unsigned)(i / H), c = (unsigned)(i % H);
+        y[(size_t)r * ldy + c] = dropout_keep(key, r, c, thr) ? fmaf(x[(size_t)r * ldx + c], mul, add) : fill;
+    }
+}
+
 // ---- losses (Keras semantics, reduction SUM_OVER_BATCH_SIZE with sample weights): value and d loss / d prediction ----
 enum { LOSS_CCE = 0, LOSS_BCE = 1, LOSS_MSE = 2, LOSS_MAE = 3 };
 __global__ void __launch_bounds__(256)

@@ -163,6 +163,27 @@ int gnn_axpby(float a, const float *x, float b, const float *y, float *out, size
     return 0;
 }
 
+int gnn_dropout(const float *x, int32_t ldx, float *y, int32_t ldy, int32_t M, int32_t H, float rate, uint32_t key, int32_t alpha,
+                int32_t backward, void *stream) {
+    if (M < 0 || H < 1 || ldx < H || ldy < H || !(rate >= 0.0f && rate < 1.0f)) return fail("bad arguments (0 <= rate < 1)");
+    if (M == 0) return 0;
+    if (!x || !y) return fail("NULL pointer");
+    const double t = (double)rate * 4294967296.0;
+    const unsigned thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    float mul, fill = 0.0f, add = 0.0f;
+    if (alpha) {
+        const double ap = -1.6732632423543772 * 1.0507009873554805;
+        const double a = 1.0 / sqrt((1.0 - rate) * (1.0 + rate * ap * ap)), b = -a * ap * rate;
+        mul = (float)a;
+        if (!backward) { fill = (float)(a * ap + b); add = (float)b; }
+    } else {
+        mul = (float)(1.0 / (1.0 - (double)rate));
+    }
+    gnn::k_dropout<<<(int)std::min<long>(cdiv((long)M * H, 256), 256 * 16), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, M, H, key, thr, mul, fill, add);
+    LAUNCH_OK();
+    return 0;
+}
+
 int gnn_loss_grad(int32_t kind, const float *y, const float *p, const float *sample_weight, int32_t M, int32_t T, float *dp,
                   float *loss_rows, void *stream) {
     if (kind < 0 || kind > 3 || M < 0 || T < 1) return fail("bad arguments");

@@ -237,6 +237,14 @@ int gnn_shard_iteration_split(const gnn_loop_args_t *args, const gnn_csr_t *adja
                               const float *state_in_full, float *state_out_full, int32_t row_base, const int32_t *gate,
                               int32_t n_gate, int32_t gate_stride, int32_t *flag_out, int32_t iteration);
 
+/* Keras Dropout / AlphaDropout (the `dropout_rate` / `dropout_pos` / `alphadropout` arguments of the reference MLP builder,
+ * MLP.py:25-27, :60-66) in training mode, forward (backward = 0: y = the layer's output for input x) or backward (backward = 1:
+ * y = d loss / d input for x = d loss / d output).  The keep mask is a pure function of (key, row, column) - a counter hash,
+ * keep <=> lowbias32(lowbias32(key + row) ^ column * 0x9E3779B1) >= rate * 2^32 - so the backward pass of a call regenerates
+ * the mask from the key of that call; nothing is stored.  x and y may alias. */
+int gnn_dropout(const float *x, int32_t ldx, float *y, int32_t ldy, int32_t M, int32_t H, float rate, uint32_t key, int32_t alpha,
+                int32_t backward, void *stream);
+
 /* ---- training building blocks (reference train_step, GNN.py:277-306: tape.gradient through the unrolled loop) ------
  * The backward pass is orchestrated by the host (gnnkeras_amd/Models/training.py) one iteration at a time out of these
  * device primitives; each is a hand-written gfx950 kernel (kernels_train.hpp), float32, no host synchronisation. */

@@ -8,6 +8,9 @@ has no autograd; its hand-written backward kernels are checked against the gradi
 Keras semantics restated: BN training = biased batch variance, moving = moving*0.99 + batch*0.01 on every call;
 `categorical_crossentropy` on probabilities = normalise, clip to [1e-7, 1-1e-7], -sum y log p; loss reduction
 SUM_OVER_BATCH_SIZE with sample weights; Adam alpha_t = lr*sqrt(1-b2^t)/(1-b1^t), epsilon 1e-7 outside the sqrt.
+Dropout / AlphaDropout (MLP.py:60-66, Keras layer semantics) take their keep masks from `dropout_keep_mask` below - a
+numpy restatement of the counter hash include/gnnloop.h documents for gnn_dropout - so that the oracle and the device
+draw the SAME masks and the gradients are comparable; the arithmetic around the mask is autograd's.
 """
 from __future__ import annotations
 
@@ -19,8 +22,36 @@ from .torch_cpu import ACT
 EPS_BN, MOMENTUM = 1e-3, 0.99
 
 
+def _lowbias32(h):
+    h = np.asarray(h, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    h = h ^ (h >> np.uint64(16)); h = (h * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
+    h = h ^ (h >> np.uint64(15)); h = (h * np.uint64(0x846ca68b)) & np.uint64(0xFFFFFFFF)
+    return h ^ (h >> np.uint64(16))
+
+
+def mix32(*values):
+    """Key of one Dropout layer call from (step seed, network id, call number, layer index)."""
+    h = np.uint64(0x9E3779B9)
+    for v in values: h = _lowbias32(h ^ (np.uint64(int(v) & 0xFFFFFFFF)))
+    return int(h)
+
+
+def dropout_keep_mask(key, M, H, rate):
+    """keep[r, c] <=> lowbias32(lowbias32(key + r) ^ c * 0x9E3779B1) >= rate * 2^32   (include/gnnloop.h, gnn_dropout)"""
+    r = np.arange(M, dtype=np.uint64)[:, None]
+    c = np.arange(H, dtype=np.uint64)[None, :]
+    h = _lowbias32(_lowbias32((np.uint64(key) + r) & np.uint64(0xFFFFFFFF)) ^ ((c * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)))
+    thr = min(int(float(np.float32(rate)) * 4294967296.0), 4294967295)
+    return h >= np.uint64(thr)
+
+
 class Net:
-    def __init__(self, spec, weights, dtype=torch.float64):
+    def __init__(self, spec, weights, dtype=torch.float64, net_id=0, step_seed=0):
+        self.drop = {}
+        pos = [int(v) for v in (spec.get('dropout_pos') or [])]
+        for i, (r, q) in enumerate(zip(spec.get('dropout_rate') or [], pos)):
+            if float(r) > 0: self.drop.setdefault(q, []).append((float(r), i))
+        self.alpha, self.net_id, self.step_seed, self.calls = bool(spec.get('alphadropout')), net_id, step_seed, 0
         self.bn = spec['batch_normalization']
         self.acts = spec['activations']
         w = [torch.tensor(np.asarray(a), dtype=dtype) for a in weights]
@@ -47,7 +78,22 @@ class Net:
         for W, b in zip(self.W, self.b): v += [W, b]
         return v
 
+    def _dropout(self, x, q, call):
+        """Keras Dropout / AlphaDropout layers sitting at position q (in front of Dense q; q = #Dense: behind the last)."""
+        for rate, index in self.drop.get(q, []):
+            keep = torch.from_numpy(dropout_keep_mask(mix32(self.step_seed, self.net_id, call, index), x.shape[0], x.shape[1], rate))
+            r = float(np.float32(rate))
+            if self.alpha:
+                ap = -1.6732632423543772 * 1.0507009873554805
+                a = ((1 - r) * (1 + r * ap ** 2)) ** -0.5
+                x = a * torch.where(keep, x, torch.full_like(x, ap)) + (-a * ap * r)
+            else:
+                x = torch.where(keep, x / (1 - r), torch.zeros_like(x))
+        return x
+
     def __call__(self, x, training=True):
+        call = self.calls
+        if training: self.calls += 1
         if self.bn:
             if training:
                 mean = x.mean(0)
@@ -58,8 +104,10 @@ class Net:
             else:
                 mean, var = self.moving_mean, self.moving_var
             x = (x - mean) / torch.sqrt(var + EPS_BN) * self.gamma + self.beta
-        for W, b, a in zip(self.W, self.b, self.acts):
+        for l, (W, b, a) in enumerate(zip(self.W, self.b, self.acts)):
+            if training: x = self._dropout(x, l, call)
             x = ACT[a](x @ W + b)
+        if training: x = self._dropout(x, len(self.W), call)
         return x
 
 
@@ -90,9 +138,11 @@ def _sp(triple, dtype):
 
 
 def train_step(nodes, arcs, adjacency, arcnode, nodegraph, mask, *, net_state, net_output, state_vect_dim, max_iteration,
-               state_threshold, focus, state0, y, sample_weight, loss, average_st_grads=False, dtype=torch.float64):
-    """Returns dict(k, loss, y_pred, grads_state, grads_output, moving_state, moving_output) as numpy."""
-    ns, no = Net(*net_state, dtype=dtype), Net(*net_output, dtype=dtype)
+               state_threshold, focus, state0, y, sample_weight, loss, average_st_grads=False, dtype=torch.float64, seed=None):
+    """Returns dict(k, loss, y_pred, grads_state, grads_output, moving_state, moving_output) as numpy.  `seed`: the step's
+    seed for the Dropout masks (the product derives its step key as mix32(0x5EED, seed))."""
+    step_seed = mix32(0x5EED, int(seed)) if seed is not None else 0
+    ns, no = Net(*net_state, dtype=dtype, net_id=0, step_seed=step_seed), Net(*net_output, dtype=dtype, net_id=1000, step_seed=step_seed)
     X = torch.tensor(np.asarray(nodes), dtype=dtype)
     lab = torch.tensor(np.asarray(arcs)[:, 2:], dtype=dtype)
     At, ANt = _sp(adjacency, dtype), _sp(arcnode, dtype)

@@ -46,30 +46,30 @@ def refocus(graphs, focus, rng):
     return out
 
 
-def oracle_step(model, x, y, sw, s0, loss, avg=False, dtype=torch.float64):
+def oracle_step(model, x, y, sw, s0, loss, avg=False, dtype=torch.float64, seed=None):
     nodes, arcs, _, sm, om, adj, an, ng = x
     mask = np.logical_and(_np(sm).reshape(-1), _np(om).reshape(-1))
     return torch_train.train_step(_np(nodes), _np(arcs), _triple(adj), _triple(an), _triple(ng), mask,
                                   net_state=model.net_state.spec(), net_output=model.net_output.spec(),
                                   state_vect_dim=model.state_vect_dim, max_iteration=model.max_iteration,
                                   state_threshold=model.state_threshold, focus=model._focus, state0=s0, y=_np(y),
-                                  sample_weight=_np(sw), loss=loss, average_st_grads=avg, dtype=dtype)
+                                  sample_weight=_np(sw), loss=loss, average_st_grads=avg, dtype=dtype, seed=seed)
 
 
-def check_step(model, x, y, sw, s0, loss='categorical_crossentropy', avg=False, native=None):
+def check_step(model, x, y, sw, s0, loss='categorical_crossentropy', avg=False, native=None, seed=None):
     from gnnkeras_amd.Models.training import LoopTrainer
     model.compile(optimizer=SGD(0.0), loss=loss, average_st_grads=avg)
-    want = oracle_step(model, x, y, sw, s0, loss, avg)
+    want = oracle_step(model, x, y, sw, s0, loss, avg, seed=seed)
     before = [w.copy() for w in model.net_state.get_weights() + model.net_output.get_weights()]
     if native is None:      # both orchestrations: the in-library step (gnn_train_step) and the building blocks driven from Python
         moving = [w.copy() for w in model.net_state.get_weights() + model.net_output.get_weights()]
-        check_step(model, x, y, sw, s0, loss, avg, native=False)
+        check_step(model, x, y, sw, s0, loss, avg, native=False, seed=seed)
         for net, n0 in ((model.net_state, 0), (model.net_output, len(model.net_state.get_weights()))):
             net.set_weights(moving[n0:n0 + len(net.get_weights())])               # the first pass moved the BN moving statistics
-        return check_step(model, x, y, sw, s0, loss, avg, native=True)
+        return check_step(model, x, y, sw, s0, loss, avg, native=True, seed=seed)
     tr = LoopTrainer(model)
     tr.use_native_step = native
-    res = tr.train_step(x, y, sw, state0=None if s0 is None else torch.from_numpy(s0).cuda(), apply=False)
+    res = tr.train_step(x, y, sw, state0=None if s0 is None else torch.from_numpy(s0).cuda(), apply=False, seed=seed)
     assert res['k'] == want['k']
     assert abs(float(res['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))
     # training mode: BatchNormalization on the statistics of a small batch multiplies rounding by 1/sigma of thin columns;
@@ -151,7 +151,9 @@ def test_gradients_with_weight_regularizers(mutag_graphs):
         MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', kernel_regularizer=lambda w: w.sum())
 
 
-def test_dropout_networks_are_refused_not_silently_trained(mutag_graphs):
+def test_dropout_in_front_of_the_first_dense_is_refused_not_silently_trained(mutag_graphs):
+    """Position 0 (on the BatchNormalization output, in front of the folded and segment-split first Dense) is the one Dropout
+    position the HIP training path does not carry: it must refuse, never train a different network."""
     seq = MultiGraphSequencer(mutag_graphs[:8], 'g', 'average', 8, shuffle=False)
     x, y, sw = seq[0]
     inp, lay = get_inout_dims('state', 14, 3, 2, 'g', 4)
@@ -166,6 +168,66 @@ def test_dropout_networks_are_refused_not_silently_trained(mutag_graphs):
         model.fit(seq, epochs=1, verbose=0)
     out = model(x)                                                  # inference ignores Dropout layers, as Keras does
     assert out.shape == (8, 2)
+
+
+def test_dropout_kernel_draws_the_documented_mask():
+    """gnn_dropout against the numpy restatement of its counter hash: same keep mask, Keras Dropout / AlphaDropout values,
+    the backward of both, and in-place operation."""
+    from gnnkeras_amd import _native as nat
+    from oracle.torch_train import dropout_keep_mask, mix32
+    rng = np.random.default_rng(0)
+    for M, H, rate in ((935, 32, 0.2), (1, 7, 0.5), (4099, 3, 0.05)):
+        x = rng.normal(size=(M, H)).astype(np.float32)
+        key = mix32(11, 3, M, H)
+        keep = dropout_keep_mask(key, M, H, rate)
+        assert abs(keep.mean() - (1 - rate)) < 0.05 + 2.0 / np.sqrt(M * H)
+        xd = torch.from_numpy(x).cuda()
+        for alpha in (0, 1):
+            y = torch.empty_like(xd)
+            nat.check(nat.lib().gnn_dropout(nat.ptr(xd), H, nat.ptr(y), H, M, H, rate, key, alpha, 0, None))
+            g = xd.clone()
+            nat.check(nat.lib().gnn_dropout(nat.ptr(g), H, nat.ptr(g), H, M, H, rate, key, alpha, 1, None))     # in place
+            r = float(np.float32(rate))
+            if alpha:
+                ap = -1.6732632423543772 * 1.0507009873554805
+                a = ((1 - r) * (1 + r * ap ** 2)) ** -0.5
+                want, wantg = a * np.where(keep, x, ap) + (-a * ap * r), np.where(keep, x * a, 0.0)
+            else:
+                want, wantg = np.where(keep, x / (1 - r), 0.0), np.where(keep, x / (1 - r), 0.0)
+            assert np.allclose(y.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+            assert np.allclose(g.cpu().numpy(), wantg, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('focus,alpha', [('g', False), ('n', False), ('a', True), ('g', True)])
+def test_dropout_gradients_match_autograd_with_the_same_masks(mutag_graphs, focus, alpha):
+    """Dropout / AlphaDropout behind the state network's Dense layers (fresh masks every iteration of the loop) and inside the
+    output network (reference MLP.py:60-66): forward values, loss and every gradient against torch autograd fed the same
+    counter-hash masks; the backward sweep regenerates each iteration's masks from its key."""
+    rng = np.random.default_rng(12)
+    gl = refocus([g.copy() for g in mutag_graphs[:12]], focus, rng)
+    seq = MultiGraphSequencer(gl, focus, 'average', 12, shuffle=False)
+    x, y, sw = seq[0]
+    d = 6
+    inp, lay = get_inout_dims('state', 14, 3, 2, focus, d, hidden_units=[9])
+    ns = MLP(inp[0], lay, ['tanh', 'selu' if alpha else 'tanh'], 'lecun_normal', 'lecun_normal', dropout_rate=[0.25, 0.1],
+             dropout_pos=[1, 2], alphadropout=alpha, rng=0)
+    inp, lay = get_inout_dims('output', 14, 3, 2, focus, d, hidden_units=[7])
+    no = MLP(inp[0], lay, ['selu' if alpha else 'relu', 'softmax'], 'glorot_normal', 'glorot_normal', dropout_rate=0.3, dropout_pos=1,
+             alphadropout=alpha, rng=1)
+    model = CLS[focus](ns, no, d, 4, 0.0)
+    s0 = rng.normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)
+    res, want = check_step(model, x, y, sw, s0, seed=77)
+    assert res['k'] == 4
+    # another seed: other masks, other loss (the masks really are applied)
+    from gnnkeras_amd.Models.training import LoopTrainer
+    other = LoopTrainer(model).train_step(x, y, sw, state0=torch.from_numpy(s0).cuda(), apply=False, seed=78)
+    assert abs(float(other['loss']) - float(res['loss'])) > 1e-6
+    # fit() runs (masks from the model's step counter), inference ignores the Dropout layers
+    model.compile(optimizer='adam', loss='categorical_crossentropy')
+    model.fit(seq, epochs=1, verbose=0)
+    k, st, o = model.Loop(*model.process_inputs(x), state0=torch.from_numpy(s0).cuda())
+    k2, st2, o2 = model.Loop(*model.process_inputs(x), state0=torch.from_numpy(s0).cuda())
+    assert torch.equal(o, o2)
 
 
 @pytest.mark.parametrize('focus', ['g', 'n'])

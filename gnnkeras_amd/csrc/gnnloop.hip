@@ -590,7 +590,7 @@ bool setup_small_applies(const gnn_loop_args_t &a, const Plan &p) {
     if (p.composite || p.N == 0) return false;
     const int L = a.state_dim > 0 ? p.L : 0, H = a.net_state[0].units[0];
     if (H > 128) return false;
-    return gnn::setup_small_lds(H, 2 * L + p.A) <= 64 * 1024;
+    return gnn::setup_small_lds(H, 2 * L + p.A, std::max(a.net_state[0].in_dim, a.net_output.in_dim)) <= 64 * 1024;
 }
 
 int setup_small(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
@@ -613,7 +613,7 @@ int setup_small(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     sa.state0 = a.state_dim > 0 ? a.state0 : a.nodes; sa.ld_s0 = a.state_dim > 0 ? p.S : a.ld_nodes;
     sa.S = p.S; sa.thr = a.state_threshold; sa.pred0 = p.pred0;
     sa.zero_a = p.flags; sa.n_a = a.max_iteration + GNN_LOOP_WORDS; sa.zero_b = a.k_out; sa.n_b = std::max(1, p.n_groups);
-    gnn::k_setup_small<<<sa.n_tiles + 1, 256, gnn::setup_small_lds(sa.net.H, 2 * L + p.A), st>>>(sa);
+    gnn::k_setup_small<<<sa.n_tiles + 1, 256, gnn::setup_small_lds(sa.net.H, 2 * L + p.A, std::max(a.net_state[0].in_dim, a.net_output.in_dim)), st>>>(sa);
     LAUNCH_OK();
     return 0;
 }

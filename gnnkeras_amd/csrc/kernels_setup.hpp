@@ -34,49 +34,101 @@ struct SetupArgs {
     int *zero_a; int n_a; float *zero_b; int n_b;
 };
 
-__device__ __forceinline__ void setup_fold_global(const FoldJob &jb, float *part /* [256] */) {
-    const int K = jb.K, H = jb.H, tid = threadIdx.x;
-    for (int i = tid; i < K * H; i += 256) {
-        const int k = i / H;
-        const float inv = jb.gamma ? jb.gamma[k] / sqrtf(jb.var[k] + jb.eps) : 1.0f;
-        jb.Wf[i] = jb.W[i] * inv;
+// BN affine of one network's inputs into LDS: x_bn = x * inv + shift (ones / zeros without BatchNormalization); one pass of
+// independent loads instead of re-deriving them inside the dependent sums below
+__device__ __forceinline__ void setup_bn_affine(const FoldJob &jb, float *inv, float *shift) {
+    for (int k = threadIdx.x; k < jb.K; k += 256) {
+        float a = 1.0f, c = 0.0f;
+        if (jb.gamma) { a = jb.gamma[k] / sqrtf(jb.var[k] + jb.eps); c = jb.beta[k] - jb.mean[k] * a; }
+        inv[k] = a; shift[k] = c;
     }
-    // bf[h] = b[h] + sum_k shift[k] W[k][h]: 256 / H' row groups per column, partials meet in LDS in group order
+    __syncthreads();
+}
+
+// bf[h] = b[h] + sum_k shift[k] W[k][h] for h in [h0, h0 + Hc): G row groups per column, partials meet in LDS in group order
+__device__ __forceinline__ float setup_bias_column(const FoldJob &jb, const float *shift, float *part, int h0, int Hc) {
+    const int tid = threadIdx.x, K = jb.K, H = jb.H;
+    int G = 1;
+    while (G * 2 * Hc <= 256) G *= 2;
+    const int h = tid % Hc, grp = tid / Hc;
+    float acc = 0.0f;
+    if (jb.gamma && grp < G) {
+        int k = grp;
+        for (; k + 7 * G < K; k += 8 * G) {               // 8 independent loads in flight, summed in k order
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = jb.W[(size_t)(k + u * G) * H + h0 + h];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(shift[k + u * G], w[u], acc);
+        }
+        for (; k < K; k += G) acc = fmaf(shift[k], jb.W[(size_t)k * H + h0 + h], acc);
+    }
+    __syncthreads();
+    part[tid] = acc;
+    __syncthreads();
+    float s = 0.0f;
+    if (tid < Hc) {
+        s = jb.b ? jb.b[h0 + tid] : 0.0f;
+        for (int g2 = 0; g2 < G; ++g2) s += part[g2 * Hc + tid];
+    }
+    return s;                                              // valid for tid < Hc
+}
+
+__device__ __forceinline__ void setup_fold_global(const FoldJob &jb, float *inv, float *shift, float *part /* [256] */) {
+    const int K = jb.K, H = jb.H, tid = threadIdx.x;
+    setup_bn_affine(jb, inv, shift);
+    for (int i = tid; i < K * H; i += 256) jb.Wf[i] = jb.W[i] * inv[i / H];
     for (int h0 = 0; h0 < H; h0 += 256) {
         const int Hc = min(H - h0, 256);
-        int G = 1;
-        while (G * 2 * Hc <= 256) G *= 2;
-        const int h = tid % Hc, grp = tid / Hc;
+        const float s = setup_bias_column(jb, shift, part, h0, Hc);
+        if (tid < Hc) jb.bf[h0 + tid] = s;
+    }
+    __syncthreads();
+}
+
+// out[f] (f = c, c + 4, ... < F) = row_scale * sum_e w_e X[src_e][f] over the arcs [beg, end) of one destination, in arc order
+// (the per-column fmaf chain of k_aggregate).  The first 8 source ids / weights are fetched at once and each column's 8 rows
+// are independent loads: the chain  id -> row -> add  is paid once per column, not once per arc.
+__device__ __forceinline__ void setup_walk(const SetupCsr &csr, int j, const float *__restrict__ X, int ldx, int F, int c, float *out) {
+    const int beg = csr.rowptr[j], end = csr.rowptr[j + 1];
+    const float scale = csr.row_scale ? csr.row_scale[j] : 1.0f;
+    int ids[8]; float ws[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool on = beg + i < end;
+        ids[i] = on ? csr.src[beg + i] : 0;
+        ws[i] = (on && csr.w) ? csr.w[beg + i] : 1.0f;
+    }
+    for (int f = c; f < F; f += 4) {
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = beg + i < end ? X[(size_t)ids[i] * ldx + f] : 0.0f;
         float acc = 0.0f;
-        if (jb.gamma && grp < G)
-            for (int k = grp; k < K; k += G) {
-                const float inv = jb.gamma[k] / sqrtf(jb.var[k] + jb.eps);
-                acc = fmaf(jb.beta[k] - jb.mean[k] * inv, jb.W[(size_t)k * H + h0 + h], acc);
-            }
-        __syncthreads();
-        part[tid] = acc;
-        __syncthreads();
-        if (tid < Hc) {
-            float s = jb.b ? jb.b[h0 + tid] : 0.0f;
-            for (int g2 = 0; g2 < G; ++g2) s += part[g2 * Hc + tid];
-            jb.bf[h0 + tid] = s;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (beg + i < end) acc = csr.w ? fmaf(ws[i], x[i], acc) : acc + x[i];
+        for (int e = beg + 8; e < end; ++e) {
+            const float xv = X[(size_t)csr.src[e] * ldx + f];
+            acc = csr.w ? fmaf(csr.w[e], xv, acc) : acc + xv;
         }
+        out[f] = acc * scale;
     }
 }
 
-// dynamic LDS (floats): bfs[H] | Wc[Kc][H] | Xc[64][Kc + 1] | part[256]
+// dynamic LDS (floats): bfs[H] | Wc[Kc][H] | Xc[64][Kc + 1] | part[256] | inv[Kmax] | shift[Kmax]   (Kmax = widest first layer)
 __global__ void __launch_bounds__(256) k_setup_small(SetupArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
     const int H = sa.net.H, K = sa.net.K, L = sa.L, A = sa.A;
     const int Kc = 2 * L + A, LDXC = Kc + 1;
     float *bfs = sm, *Wc = bfs + H, *Xc = Wc + Kc * H, *part = Xc + 64 * LDXC;
+    float *inv = part + 256, *shift = inv + max(K, sa.out.W ? sa.out.K : 0);
 
     if ((int)blockIdx.x == sa.n_tiles) {
         for (int i = tid; i < sa.n_a; i += 256) sa.zero_a[i] = 0;
         for (int i = tid; i < sa.n_b; i += 256) sa.zero_b[i] = 0.0f;
-        setup_fold_global(sa.net, part);
-        if (sa.out.W) setup_fold_global(sa.out, part);
+        setup_fold_global(sa.net, inv, shift, part);
+        if (sa.out.W) setup_fold_global(sa.out, inv, shift, part);
         return;
     }
     const FoldJob &jb = sa.net;
@@ -84,28 +136,14 @@ __global__ void __launch_bounds__(256) k_setup_small(SetupArgs sa) {
     const int jbase = got.node0 + ((int)blockIdx.x - got.tile0) * 64, jend = got.node_end;
 
     // ---- a. folded bias (every tile needs it; K x H multiply-adds) and the constant rows of Wf ------------------------
+    setup_bn_affine(jb, inv, shift);
     {
-        int G = 1;
-        while (G * 2 * H <= 256) G *= 2;              // H <= 128 (checked by the launcher)
-        const int h = tid % H, grp = tid / H;
-        float acc = 0.0f;
-        if (jb.gamma && grp < G)
-            for (int k = grp; k < K; k += G) {
-                const float inv = jb.gamma[k] / sqrtf(jb.var[k] + jb.eps);
-                acc = fmaf(jb.beta[k] - jb.mean[k] * inv, jb.W[(size_t)k * H + h], acc);
-            }
-        part[tid] = acc;
-        __syncthreads();
-        if (tid < H) {
-            float s = jb.b ? jb.b[tid] : 0.0f;
-            for (int g2 = 0; g2 < G; ++g2) s += part[g2 * H + tid];
-            bfs[tid] = s;
-        }
+        const float s = setup_bias_column(jb, shift, part, 0, H);          // H <= 128 (checked by the launcher)
+        if (tid < H) bfs[tid] = s;
         for (int i = tid; i < Kc * H; i += 256) {
             const int kc = i / H, hh = i % H;
             const int k = kc < L ? sa.row_nodes + kc : (kc < 2 * L ? sa.row_aggn + (kc - L) : sa.row_agga + (kc - 2 * L));
-            const float inv = jb.gamma ? jb.gamma[k] / sqrtf(jb.var[k] + jb.eps) : 1.0f;
-            Wc[i] = jb.W[(size_t)k * H + hh] * inv;
+            Wc[i] = jb.W[(size_t)k * H + hh] * inv[k];
         }
     }
 
@@ -116,30 +154,8 @@ __global__ void __launch_bounds__(256) k_setup_small(SetupArgs sa) {
         float *xr = Xc + m * LDXC;
         if (j < jend) {
             for (int f = c; f < L; f += 4) xr[f] = sa.nodes[(size_t)j * sa.ld_nodes + f];
-            if (L > 0) {
-                const int beg = sa.adj.rowptr[j], end = sa.adj.rowptr[j + 1];
-                const float scale = sa.adj.row_scale ? sa.adj.row_scale[j] : 1.0f;
-                for (int f = c; f < L; f += 4) {
-                    float acc = 0.0f;
-                    for (int e = beg; e < end; ++e) {
-                        const float x = sa.nodes_src[(size_t)sa.adj.src[e] * sa.ld_nodes_src + f];
-                        acc = sa.adj.w ? fmaf(sa.adj.w[e], x, acc) : acc + x;
-                    }
-                    xr[L + f] = acc * scale;
-                }
-            }
-            if (A > 0) {
-                const int beg = sa.arcnode.rowptr[j], end = sa.arcnode.rowptr[j + 1];
-                const float scale = sa.arcnode.row_scale ? sa.arcnode.row_scale[j] : 1.0f;
-                for (int f = c; f < A; f += 4) {
-                    float acc = 0.0f;
-                    for (int e = beg; e < end; ++e) {
-                        const float x = sa.arc_labels[(size_t)sa.arcnode.src[e] * sa.ld_arcs + f];
-                        acc = sa.arcnode.w ? fmaf(sa.arcnode.w[e], x, acc) : acc + x;
-                    }
-                    xr[2 * L + f] = acc * scale;
-                }
-            }
+            if (L > 0) setup_walk(sa.adj, j, sa.nodes_src, sa.ld_nodes_src, L, c, xr + L);
+            if (A > 0) setup_walk(sa.arcnode, j, sa.arc_labels, sa.ld_arcs, A, c, xr + 2 * L);
         } else {
             for (int f = c; f < Kc; f += 4) xr[f] = 0.0f;
         }
@@ -181,6 +197,6 @@ __global__ void __launch_bounds__(256) k_setup_small(SetupArgs sa) {
     if (tid == 0) sa.pred0[blockIdx.x] = any;
 }
 
-inline size_t setup_small_lds(int H, int Kc) { return sizeof(float) * ((size_t)H + (size_t)Kc * H + 64 * (size_t)(Kc + 1) + 256); }
+inline size_t setup_small_lds(int H, int Kc, int Kmax) { return sizeof(float) * ((size_t)H + (size_t)Kc * H + 64 * (size_t)(Kc + 1) + 256 + 2 * (size_t)Kmax); }
 
 }  // namespace gnn

@@ -63,12 +63,13 @@ k_aggregate(const int *gate, int n_dst, const int *__restrict__ rowptr, const in
 
 // The same product for rows that allow 16-B accesses (F, ldx, ldo multiples of 4, 16-B aligned bases: the padded state
 // matrix of the un-fused and training paths): LPR = F/4 lanes own a destination row, each lane carries a float4 column
-// chunk, 8 source rows in flight; a wave instruction moves 64/LPR whole rows instead of one.
+// chunk, 8 source rows in flight; a wave instruction moves 64/LPR whole rows instead of one.  `addend` (optional, the
+// backward sweep's G_state = dx_state + Adj . dx_agg): out = addend + the product.
 template <int LPR, bool HAS_W>
 __global__ void __launch_bounds__(256)
 k_aggregate_vec(const int *gate, int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src,
                 const float *__restrict__ w, const float *__restrict__ row_scale, const float *__restrict__ X, int ldx,
-                float *__restrict__ out, int ldo) {
+                float *__restrict__ out, int ldo, const float *__restrict__ addend = nullptr, int ld_add = 0) {
     if (gate_closed(gate)) return;
     const int l4 = threadIdx.x % LPR;
     const int groups = blockDim.x / LPR;
@@ -90,6 +91,7 @@ k_aggregate_vec(const int *gate, int n_dst, const int *__restrict__ rowptr, cons
             }
         }
         if (row_scale) acc *= row_scale[j];
+        if (addend) acc += *reinterpret_cast<const f32x4 *>(addend + (size_t)j * ld_add + 4 * l4);
         *reinterpret_cast<f32x4 *>(out + (size_t)j * ldo + 4 * l4) = acc;
     }
 }
@@ -131,7 +133,9 @@ constexpr int SD_TM = 64, SD_TN = 64, SD_KC = 32, SD_LDX = 34, SD_LDW = 80, SD_L
 // per instruction, and results leave through an LDS tile as 256-B row pieces.
 // SC = chunks of 32 columns whose loads are issued together: 4 for small M (latency: a 95-column training layer costs one
 // round trip instead of three), 1 for large M (throughput: ~64 VGPRs and 19 KB of LDS -> 8 waves / SIMD; this access
-// pattern, like the gather, is served by the number of waves in flight, not by the loads in flight per wave).
+// pattern, like the gather, is served by the number of waves in flight, not by the loads in flight per wave: a software
+// pipeline that issues the next chunk's loads before this chunk's MFMAs needs ~114 VGPRs = 4 waves / SIMD and measured
+// SLOWER, 615 -> 870 us on a 1 M x 160 -> 64 layer, profiles/r02_notes.txt).
 template <int SC>
 __global__ void __launch_bounds__(256, SC == 1 ? 8 : 4) k_segdense(SegDenseArgs a) {
     if (gate_closed(a.gate)) return;

@@ -534,6 +534,114 @@ k_dense_grad_partial_segs(GradSegs gs, int K, const float *__restrict__ dZ, int 
     if (blockIdx.y == 0 && tid < 64 && h0 + tid < H) Pp[(size_t)K * H + h0 + tid] = qacc;
 }
 
+// The same product with ONE workgroup per row chunk covering every column of the virtual concatenation (K <= 192, H <= 64):
+// the dZ tile is read once instead of once per 64-column block of every segment (five times for the starter layout
+// [state | labels | agg | agg labels | agg arcs] - three of those blocks are 14, 14 and 3 columns wide), and a B fragment
+// read from LDS feeds up to three MFMAs.  1 M rows, K = 160, H = 64: 922 us -> 470 us (profiles/r02_train_c4_kernel_stats*.csv); the next tile is fetched while this one multiplies.
+constexpr int DGA_TM = 32, DGA_LDX = 208;      // 208 == 16 (mod 32): conflict-free transposed A-fragment reads for K <= 192
+__global__ void __launch_bounds__(256)
+k_dense_grad_allk(GradSegs gs, int K, const float *__restrict__ dZ, int ldz, int H, int M, int rows_per_chunk,
+                  float *__restrict__ part) {                         // part: [chunk][K*H (P) + H (q)]
+    __shared__ float Xs[DGA_TM * DGA_LDX];
+    __shared__ float Zs[DGA_TM * DG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int m_beg = blockIdx.x * rows_per_chunk, m_end = min(M, m_beg + rows_per_chunk);
+    const int n_blk = (K + 15) / 16;                                   // 16-row blocks of P; wave w owns blocks w, w + 4, w + 8
+    f32x4 acc[3][4];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float qacc = 0.0f;
+    // this thread's column of each 64-column block of the virtual concatenation: segment resolved once
+    const float *xptr[3]; const int *xidx[3]; int xld[3]; bool xon[3];
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) {
+        const int kv = cb * 64 + lane;
+        Seg sg = gs.seg[0]; int start = gs.seg[0].width, sbeg = 0;
+#pragma unroll
+        for (int t = 1; t < GNN_MAX_SEGS; ++t) {
+            if (t < gs.n && kv >= start) { sg = gs.seg[t]; sbeg = start; }
+            if (t < gs.n) start += gs.seg[t].width;
+        }
+        xon[cb] = kv < K;
+        xptr[cb] = sg.ptr + (kv - sbeg); xidx[cb] = sg.rowidx; xld[cb] = sg.ld;
+    }
+    // software pipeline: the next tile's global loads are in flight while this tile runs through the matrix cores
+    float xr[3][DGA_TM / 4], zr[DGA_TM / 4];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) {
+#pragma unroll
+            for (int pass = 0; pass < DGA_TM / 4; ++pass) {
+                const int m = m0 + wave + 4 * pass;
+                xr[cb][pass] = 0.0f;
+                if (cb * 64 < K && xon[cb] && m < m_end) xr[cb][pass] = xptr[cb][(xidx[cb] ? (size_t)xidx[cb][m] : (size_t)m) * xld[cb]];
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < DGA_TM / 4; ++pass) {
+            const int m = m0 + wave + 4 * pass;
+            zr[pass] = (m < m_end && lane < H) ? dZ[(size_t)m * ldz + lane] : 0.0f;
+        }
+    };
+    if (m_beg < m_end) fetch(m_beg);
+    for (int m0 = m_beg; m0 < m_end; m0 += DGA_TM) {
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) {
+            if (cb * 64 >= K) break;
+#pragma unroll
+            for (int pass = 0; pass < DGA_TM / 4; ++pass) Xs[(wave + 4 * pass) * DGA_LDX + cb * 64 + lane] = xr[cb][pass];
+        }
+#pragma unroll
+        for (int pass = 0; pass < DGA_TM / 4; ++pass) Zs[(wave + 4 * pass) * DG_LD + lane] = zr[pass];
+        __syncthreads();
+        if (m0 + DGA_TM < m_end) fetch(m0 + DGA_TM);
+#pragma unroll 2
+        for (int s4 = 0; s4 < DGA_TM / 4; ++s4) {
+            float bv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[c] = Zs[(4 * s4 + g) * DG_LD + 16 * c + r];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int blk = wave + 4 * b;
+                if (blk < n_blk) {
+                    const float av = Xs[(4 * s4 + g) * DGA_LDX + 16 * blk + r];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[b][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[c], acc[b][c], 0, 0, 0);
+                }
+            }
+        }
+        if (tid < 64) {
+            for (int mm = 0; mm < DGA_TM; ++mm) qacc += Zs[mm * DG_LD + tid];
+        }
+        __syncthreads();
+    }
+    float *Pp = part + (size_t)blockIdx.x * ((size_t)K * H + H);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int blk = wave + 4 * b;
+        if (blk >= n_blk) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int h = 16 * c + r;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int kv = 16 * blk + 4 * g + reg;                // virtual column -> row of P through its segment's wrow
+                int wrow = gs.seg[0].wrow + kv, start = gs.seg[0].width;
+#pragma unroll
+                for (int t = 1; t < GNN_MAX_SEGS; ++t) {
+                    if (t < gs.n && kv >= start) wrow = gs.seg[t].wrow + kv - start;
+                    if (t < gs.n) start += gs.seg[t].width;
+                }
+                if (kv < K && h < H) Pp[(size_t)wrow * H + h] = acc[b][c][reg];
+            }
+        }
+    }
+    if (tid < 64 && tid < H) Pp[(size_t)K * H + tid] = qacc;
+}
+
 // ---- input gradients through a training-mode BatchNormalization for up to 4 column blocks, in place ---------------------
 struct BnGradReq { float *dy; int ld_dy; const float *x; int ld_x; const int *rowidx; int width, k0; };
 struct BnGradArgs { BnGradReq r[4]; int n, M; const float *gamma, *mean, *var, *m1, *m2; float eps; };

@@ -79,8 +79,8 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.pooled = a.focus == GNN_FOCUS_GRAPH;
     p.G = p.pooled ? a.nodegraph.n_dst : 0;
     p.R = p.pooled ? p.G : p.M;
-    p.off_agg = p.with_labels ? p.S + p.L : p.S;
-    p.kdx_s = p.off_agg + p.S;
+    p.off_agg = p.with_labels ? p.S + p.L : p.S;          // first-layer row (= BN column) of the aggregated-state segment
+    p.kdx_s = 2 * p.S;                                     // d loss / d [state | agg] only, 16-B aligned halves: the label columns between them are never needed
 
     Carver c(ws);
     p.flags = c.take<int>(p.K + 8);
@@ -210,8 +210,9 @@ int act_grad_inplace(float *G, int ldg, const float *Y, int ldy, int M, int H, i
 // Back-propagation through one network.  G = d loss / d hs[last] ([M x units_last], leading dimension ldg; overwritten).
 // Parameter gradients go to x.g (accumulated when `accumulate`); dx_all (optional) receives d loss / d input columns
 // [0, kdx) BEFORE the BatchNormalization input gradient (the caller applies it to the segments it needs).
+// `second_row` >= 0: dx_all is [M x kdx] = columns [0, kdx/2) of the input followed by columns [second_row, second_row + kdx/2).
 int net_backward(NetCtx &x, const gnn::Seg *segs, int nseg, float *const *hs, float *G, int ldg, int M, const float *stats, bool accumulate,
-                 float *dx_all, int kdx, float *part, hipStream_t st) {
+                 float *dx_all, int kdx, float *part, hipStream_t st, int second_row = -1) {
     const gnn_mlp_t &m = *x.m;
     int n_chunks;
     const int rpc = rows_per_chunk_for(std::max(M, 1), &n_chunks);
@@ -235,8 +236,14 @@ int net_backward(NetCtx &x, const gnn::Seg *segs, int nseg, float *const *hs, fl
         memset(&gs, 0, sizeof(gs));
         gs.n = nseg; gs.blk_begin[0] = 0;
         for (int s = 0; s < nseg; ++s) { gs.seg[s] = segs[s]; gs.blk_begin[s + 1] = gs.blk_begin[s] + cdiv(segs[s].width, 64); }
-        dim3 grid(n_chunks, gs.blk_begin[nseg], cdiv(H, 64));
-        gnn::k_dense_grad_partial_segs<<<grid, 256, 0, st>>>(gs, K, G, ldg, H, M, rpc, part);
+        int Kv = 0;
+        for (int s = 0; s < nseg; ++s) Kv += segs[s].width;
+        if (Kv == K && K <= 192 && H <= 64 && n_chunks >= 256) {     // large batches, every column in one workgroup: dZ is read once (kernels_train.hpp)
+            gnn::k_dense_grad_allk<<<n_chunks, 256, 0, st>>>(gs, K, G, ldg, H, M, rpc, part);
+        } else {
+            dim3 grid(n_chunks, gs.blk_begin[nseg], cdiv(H, 64));
+            gnn::k_dense_grad_partial_segs<<<grid, 256, 0, st>>>(gs, K, G, ldg, H, M, rpc, part);
+        }
         LAUNCH_OK();
     }
     const bool bn = m.has_bn != 0;
@@ -253,7 +260,14 @@ int net_backward(NetCtx &x, const gnn::Seg *segs, int nseg, float *const *hs, fl
         Pp, qp, m.kernel[0], K, H, bn ? m.bn_gamma : nullptr, m.bn_beta, stats, stats ? stats + K : nullptr, m.bn_eps, 1.0f / (float)M,
         x.g->dkernel[0], x.g->dbias[0], x.g->dgamma, x.g->dbeta, bn ? x.m1 : nullptr, bn ? x.m2 : nullptr, accumulate ? 1 : 0, fuse_chunks);
     LAUNCH_OK();
-    if (dx_all && kdx > 0) TRY(dense_plain(G, ldg, H, x.Wt[0], K, kdx, M, dx_all, kdx, st));   // W^T columns [0, kdx) (ldw = K)
+    if (dx_all && kdx > 0) {
+        if (second_row < 0 || second_row == kdx / 2) {
+            TRY(dense_plain(G, ldg, H, x.Wt[0], K, kdx, M, dx_all, kdx, st));   // W^T columns [0, kdx) (ldw = K)
+        } else {
+            TRY(dense_plain(G, ldg, H, x.Wt[0], K, kdx / 2, M, dx_all, kdx, st));
+            TRY(dense_plain(G, ldg, H, x.Wt[0] + second_row, K, kdx / 2, M, dx_all + kdx / 2, kdx, st));
+        }
+    }
     return 0;
 }
 
@@ -503,20 +517,32 @@ int gnn_train_step(const gnn_train_args_t *args) {
             gnn_mlp_t head = ns; head.n_layers = ns.n_layers - 1;
             TRY(forward_layers(head, segs, n, p.N, W0, b0, hs, nullptr, st, nullptr, (bn_s && !fold_s) ? stats : nullptr));
         }
-        TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, p.dx_s_all, p.kdx_s, p.part, st));
+        TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, p.dx_s_all, p.kdx_s, p.part, st, p.off_agg));
         gnn::BnGradReq rq[2] = {gnn::BnGradReq{p.dx_s_all, p.kdx_s, s_t, p.S, nullptr, p.S, 0},
-                                gnn::BnGradReq{p.dx_s_all + p.off_agg, p.kdx_s, agg_t, p.S, nullptr, p.S, p.off_agg}};
+                                gnn::BnGradReq{p.dx_s_all + p.S, p.kdx_s, agg_t, p.S, nullptr, p.S, p.off_agg}};
         TRY(bn_input_grads(ns, p.cs, stats, rq, 2, p.N, st));
         {   // G_state = d state (own) + Adj . d agg   (arcs walked by source)
             const gnn_csr_t &c = ta.adjacency_by_source;
-            int G = 4;
-            while (G < p.S && G < 64) G <<= 1;
-            const int groups = 256 / G, grid = std::min(cdiv(p.N, groups), 256 * 16);
-#define AGGA(GG) gnn::k_aggregate_add<GG><<<grid, 256, 0, st>>>(c.n_dst, c.rowptr, c.src, c.w, c.row_scale, p.dx_s_all + p.off_agg, p.kdx_s, p.S, \
+            const float *Xa = p.dx_s_all + p.S;
+            const bool vec = (p.S == 16 || p.S == 32 || p.S == 64 || p.S == 128) && p.kdx_s % 4 == 0 &&
+                             ((reinterpret_cast<uintptr_t>(Xa) | reinterpret_cast<uintptr_t>(p.dx_s_all) | reinterpret_cast<uintptr_t>(p.G_state)) & 15) == 0;
+            if (vec) {      // whole 16-B row pieces, 8 source rows in flight (the scalar walk below is one dependent chain per arc)
+                const int lpr = p.S / 4, groups = 256 / lpr, grid = std::min(cdiv(p.N, groups), 256 * 16);
+#define AGGV(L) (c.w ? gnn::k_aggregate_vec<L, true><<<grid, 256, 0, st>>>(nullptr, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xa, p.kdx_s, p.G_state, p.S, p.dx_s_all, p.kdx_s) \
+                     : gnn::k_aggregate_vec<L, false><<<grid, 256, 0, st>>>(nullptr, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xa, p.kdx_s, p.G_state, p.S, p.dx_s_all, p.kdx_s))
+                switch (lpr) { case 4: AGGV(4); break; case 8: AGGV(8); break; case 16: AGGV(16); break; default: AGGV(32); break; }
+#undef AGGV
+                LAUNCH_OK();
+            } else {
+                int G = 4;
+                while (G < p.S && G < 64) G <<= 1;
+                const int groups = 256 / G, grid = std::min(cdiv(p.N, groups), 256 * 16);
+#define AGGA(GG) gnn::k_aggregate_add<GG><<<grid, 256, 0, st>>>(c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xa, p.kdx_s, p.S, \
                                                                  p.dx_s_all, p.kdx_s, p.G_state, p.S)
-            switch (G) { case 4: AGGA(4); break; case 8: AGGA(8); break; case 16: AGGA(16); break; case 32: AGGA(32); break; default: AGGA(64); break; }
+                switch (G) { case 4: AGGA(4); break; case 8: AGGA(8); break; case 16: AGGA(16); break; case 32: AGGA(32); break; default: AGGA(64); break; }
 #undef AGGA
-            LAUNCH_OK();
+                LAUNCH_OK();
+            }
         }
     }
     if (ta.average_st_grads && k > 0) TRY(scale_grads(ns, ta.grad_state, 1.0f / (float)k, st));

@@ -21,6 +21,14 @@ struct NetCtx {
     float *hid[GNN_MAX_LAYERS];     // layer outputs [rows x units[l]] (the last one may alias a caller buffer)
 };
 
+// Bytes of neighbour sums the tape may keep (one N x S matrix per iteration) instead of recomputing each in the backward sweep.
+// Sized for a 288 GB device: 32 GiB by default (C4 with 50 iterations is 12.8 GB), GNN_TRAIN_TAPE_MB overrides.
+inline size_t agg_tape_budget() {
+    static size_t v = 0;
+    if (v == 0) { const char *e = getenv("GNN_TRAIN_TAPE_MB"); v = (e ? (size_t)atol(e) : (size_t)32 * 1024) << 20; v = std::max<size_t>(v, 1); }
+    return v;
+}
+
 struct TrainPlan {
     int N, E, S, L, A, d, M, R, T, K, G;
     bool pooled, with_labels, agg_taped;      // agg_taped: every iteration's neighbour sum is kept (small graphs) instead of recomputed
@@ -86,7 +94,7 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.flags = c.take<int>(p.K + 8);
     p.k_dev = c.take<float>(4);
     p.states = c.take<float>((size_t)(p.K + 1) * p.N * p.S);
-    p.agg_taped = (size_t)std::max(p.K, 1) * p.N * p.S * sizeof(float) <= ((size_t)256 << 20);
+    p.agg_taped = (size_t)std::max(p.K, 1) * p.N * p.S * sizeof(float) <= agg_tape_budget();
     p.agg = c.take<float>((size_t)(p.agg_taped ? std::max(p.K, 1) : 1) * p.N * p.S);
     p.agg_arcs = c.take<float>((size_t)p.N * std::max(p.A, 1));
     p.agg_nodes = c.take<float>((size_t)p.N * std::max(p.L, 1));

@@ -457,6 +457,13 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
 }
 
 inline int launch_fused4(Fused2Args &fa, int SP, int depth, int n_cu, hipStream_t st) {
+#ifdef GNN_F4_NC_EXPERIMENT
+    if (SP == 64 && !fa.w && !fa.agg_init && !fa.tp[0].W2) {          // experiment: matrix waves per workgroup (GNN_FUSED_WAVES = 2 | 3 | 6)
+        if (depth == 2) return launch_fused4_one<64, false, 4, false, 2>(fa, n_cu, st);
+        if (depth == 3) return launch_fused4_one<64, false, 4, false, 3>(fa, n_cu, st);
+        if (depth == 6) return launch_fused4_one<64, false, 4, false, 6>(fa, n_cu, st);
+    }
+#endif
 #define F4_CASE(SPV)                                                                                                  \
     case SPV:                                                                                                         \
         if (fa.agg_init) {                                                                                            \

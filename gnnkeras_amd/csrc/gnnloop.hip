@@ -322,6 +322,8 @@ struct Plan {
     int *err;                        // sticky "an in-launch wait expired" word of the fused kernels, folded into k at the end
     float *agg_arcs, *agg_nodes; int ld_agg_nodes;
     float *C; int ldC;
+    float *Xc, *Wc;                  // constant inputs [N, 32] and their weights [32, H1] for the XC kernel variant (xc_ok)
+    bool xc_ok;
     float *buf[2], *agg;
     float *hid[2]; int ld_hid;
     float *Wf_out, *bf_out;
@@ -335,6 +337,23 @@ constexpr int GNN_SMALL_MAX_TILES = 512;   // upper bound of CUs a whole-loop la
 // words behind flags[max_iteration]: [1] last flag, [3..7) barrier counters of the small whole-loop kernel, [12] error word,
 // then (128-byte aligned) the mid-size whole-loop kernel's barrier lines; all zeroed by the set-up launch
 constexpr int GNN_LOOP_WORDS = 16 + 32 + gnn::MID_BAR_WORDS;
+
+int fused_generation(int SP, int n_nodes, int flags);
+
+// GNN_XC=0 keeps the per-node constant C in the wave-specialised kernel at every size, GNN_XC_MIN_NODES moves the size from
+// which the constant inputs are multiplied instead (tuning knobs; both forms are held to the same tests).  Measured, d = 64,
+// 10 arcs per node, us per iteration with inputs / with C: 100 k nodes 61.1 / 59.1, 200 k 105.0 / 105.8, 400 k 192.2 / 199.7,
+// 600 k 281.6 / 294.0, 1 M (C4) 458 / 480, 4 M 2 215 / 2 329; d = 32 at C4 size 263.2 / 263.7.
+bool xc_disabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_XC"); v = (e && atoi(e) == 0) ? 1 : 0; }
+    return v == 1;
+}
+int xc_min_nodes() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_XC_MIN_NODES"); v = e ? atoi(e) : 196608; }
+    return v;
+}
 
 int state_width(const gnn_loop_args_t &a) { return a.state_dim > 0 ? a.state_dim : a.dim_node_label; }
 
@@ -450,6 +469,12 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     p.agg_nodes = c.take<float>((size_t)p.N * std::max(p.ld_agg_nodes, 1));
     p.ldC = (p.H1max + 3) & ~3;      // rows start 16-B aligned: the wave-specialised fused kernel reads C as float4
     p.C = c.take<float>((size_t)p.N * p.ldC);
+    // one node type, at most 31 constant input columns (one more carries the bias): the wave-specialised kernel may read the
+    // inputs (128 B per node) and multiply them instead of reading C (4 H1 bytes per node)
+    p.xc_ok = !p.composite && (a.state_dim > 0 ? 2 * p.L : 0) + p.A <= 31 && p.SP <= 64 && a.net_state[0].n_layers == 1 &&
+              !(a.flags & GNN_FLAG_UNFUSED) && !xc_disabled() && p.N >= xc_min_nodes();
+    p.Xc = c.take<float>(p.xc_ok ? (size_t)p.N * 32 : 0);
+    p.Wc = c.take<float>(p.xc_ok ? (size_t)32 * p.H1max : 0);
     // hub segments: virtual rows for padded widths up to 128; wider states walk the plain adjacency (the un-fused aggregate
     // handles any degree), so the caller may always pass the split
     p.n_heavy = (a.n_heavy_segments > 0 && p.SP <= 128) ? a.n_heavy_segments : 0;
@@ -580,6 +605,14 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, boo
         d.W = tp.Wf; d.ldw = d.H; d.bias = tp.bf; d.act = GNN_ACT_LINEAR;
         d.Y = p.C; d.ldy = p.ldC; d.out_rowidx = tp.rows;
         TRY(launch_segdense(d, st));
+    }
+    if (p.xc_ok && p.N > 0 && fused_generation(p.SP, p.N, a.flags) == 4) {     // only the wave-specialised kernel reads them
+        const int L = a.state_dim > 0 ? p.L : 0, H = a.net_state[0].units[0];
+        gnn::k_pack_xc<<<(int)std::min<long>(cdiv((long)p.N * 32, 256), 256 * 16), 256, 0, st>>>(p.N, a.nodes, a.ld_nodes, L, p.agg_nodes, p.ld_agg_nodes,
+                                                                                           p.agg_arcs, p.A, p.Xc);
+        LAUNCH_OK();
+        gnn::k_pack_wc<<<cdiv(32 * H, 256), 256, 0, st>>>(p.tp[0].Wf, p.tp[0].bf, H, L, p.A, p.S, 2 * p.S + p.L, a.state_dim > 0 ? 2 * p.S + 2 * p.L : 2 * p.S, p.Wc);
+        LAUNCH_OK();
     }
     return 0;
 }
@@ -753,6 +786,7 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
     fa.k_out = k_out; fa.k_val = k_val;
     fa.err = p.err;
     fa.agg_init = agg_init;
+    if (p.xc_ok && !agg_init && !adj.w && fa.n_types == 1 && fused_generation(p.SP, p.N, a.flags) == 4) { fa.Xc = p.Xc; fa.Wc = p.Wc; }
     if (fa.n_types == 0) {                      // no nodes at all: only the iteration counter moves
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;

@@ -51,6 +51,10 @@ struct Fused2Args {
     int *flag_next;
     float *k_out; float k_val;
     int *err;                                      // sticky error word (workspace): a bounded in-launch wait expired
+    // k_state_fused4<.., XC = true> (one node type): instead of the per-node constant C (4 H bytes per node and iteration) the
+    // kernel reads the node's constant INPUTS Xc [n, 32] = [labels | agg labels | agg arcs | 1 | 0..] (128 bytes) and multiplies
+    // them with Wc [32, H] = folded first-layer rows of those inputs, then the folded bias, then zeros, on the matrix cores
+    const float *Xc, *Wc;
     const float *agg_init;                         // k_state_fused4<.., INIT = true>: [n_local, SP] partial neighbour sums (un-scaled)
                                                    // of the arcs this launch does NOT walk (own-range arcs, summed while the
                                                    // exchange was in flight: distributed.py overlap); nullptr otherwise

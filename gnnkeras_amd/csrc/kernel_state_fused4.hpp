@@ -29,7 +29,9 @@
 
 namespace gnn {
 
-template <int SP, int NC = 4, bool L2 = false>
+constexpr int XC_K = 32;                          // constant-input columns of the XC variant (padded; one of them is the bias' 1)
+
+template <int SP, int NC = 4, bool L2 = false, bool XC = false>
 struct Fused4Cfg {
     static constexpr int NW = 16, NT = 64 * NW;
     static constexpr int NCONS = NC;                 // matrix waves (wave ids 0..NC-1)
@@ -42,10 +44,12 @@ struct Fused4Cfg {
     static constexpr bool SWZ = SP >= 32;
     static constexpr int LDW = SWZ ? SP : SP + 32;
     static constexpr int NCT = SP / 16;              // 16-column MFMA tiles per row tile
-    static constexpr int NS = SP == 64 ? (L2 ? 3 : 5) : 8;   // ring slots (two-layer networks trade slots for W2)
+    static constexpr int NS = SP == 64 ? (L2 ? 3 : (XC ? 4 : 5)) : 8;   // ring slots (two-layer networks trade slots for W2, XC one for Wc;
+                                                             // 4 and 5 slots measure the same at C4: 480.4 / 478.7 vs 482.3 / 482.4 us)
+    static constexpr int WROWS = 2 * SP + (XC ? XC_K : 0);   // rows of the weight matrix in LDS: state ; agg ; (XC) constant inputs
     static constexpr int SLOT = 16 * LDX;            // floats per slot
     static constexpr int W2F = L2 ? SP * LDW + SP : 0;        // floats of the second layer: W2 [SP][LDW] + b2 [SP]
-    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)NS * SLOT + 2 * SP * LDW + W2F) + sizeof(int) * 2 * NS;
+    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)NS * SLOT + WROWS * LDW + W2F) + sizeof(int) * 2 * NS;
 };
 
 // the activation of 4 values with ONE wave-uniform switch around them
@@ -81,14 +85,14 @@ __device__ __forceinline__ int f4_ld_acquire(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int SP, bool HAS_W, int DEPTH, int NC, bool L2, bool INIT = false>
+template <int SP, bool HAS_W, int DEPTH, int NC, bool L2, bool INIT = false, bool XC = false>
 __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     // The gate word(s), the W1 fill and the gather waves' first CSR row are all fetched before anything is waited for:
     // three dependent round trips at the head of every launch become one.  Nothing is written to global memory before
     // the gate has been checked (after the fill's barrier).
     int open = a.gate == nullptr;
     for (int i = 0; i < a.n_gate; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
-    using Cfg = Fused4Cfg<SP, NC, L2>;
+    using Cfg = Fused4Cfg<SP, NC, L2, XC>;
     constexpr int NT = Cfg::NT, LPR = Cfg::LPR, IPL = Cfg::IPL, LDX = Cfg::LDX, LDW = Cfg::LDW, NS = Cfg::NS;
 #ifndef GNN_F4_SPIN_MAX
 #define GNN_F4_SPIN_MAX (1 << 22)
@@ -98,7 +102,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *Xs = reinterpret_cast<float *>(smem);                         // [NS][16][LDX] : [state | agg]
     float *Ws = Xs + NS * Cfg::SLOT;                                     // [2SP][LDW]    : W1 rows (state ; agg)
-    float *W2s = Ws + 2 * SP * LDW;                                      // L2: [SP][LDW] second-layer kernel, then b2 [SP]
+    float *W2s = Ws + Cfg::WROWS * LDW;                                  // L2: [SP][LDW] second-layer kernel, then b2 [SP]
     int *fill = reinterpret_cast<int *>(W2s + Cfg::W2F);                 // [NS] gather-wave deposits so far
     int *freed = fill + NS;                                              // [NS] tiles consumed so far
 
@@ -120,7 +124,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     const int t_first = xcd * tpx + lb;
     const int T = t_first < t_end ? (t_end - t_first + blk_per_xcd - 1) / blk_per_xcd : 0;   // tiles of this workgroup
 
-    const __amdgpu_buffer_rsrc_t r_C = buf_rsrc(a.C), r_rows = buf_rsrc(tp.rows), r_state = buf_rsrc(a.state_in),
+    const __amdgpu_buffer_rsrc_t r_C = buf_rsrc(XC ? a.Xc : a.C), r_rows = buf_rsrc(tp.rows), r_state = buf_rsrc(a.state_in),
                                  r_rowptr = buf_rsrc(a.rowptr), r_src = buf_rsrc(a.src), r_w = buf_rsrc(HAS_W ? a.w : nullptr),
                                  r_scale = buf_rsrc(a.row_scale), r_init = buf_rsrc(INIT ? a.agg_init : nullptr);
     const bool has_scale = a.row_scale != nullptr;
@@ -156,11 +160,16 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
         }
     }
 
-    for (int i = tid; i < 2 * SP * SP; i += NT) {
+    // rows 0 .. SP-1: state ; SP .. 2SP-1: agg ; (XC) 2SP .. 2SP+31: the constant inputs' folded weights, the bias row, zeros
+    for (int i = tid; i < Cfg::WROWS * SP; i += NT) {
         const int k = i / SP, n = i % SP;
-        const int kk = k < SP ? k : k - SP;
         float v = 0.0f;
-        if (kk < S && n < tp.H) v = tp.Wf[(size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + kk) * tp.H + n];
+        if (XC && k >= 2 * SP) {
+            if (n < tp.H) v = a.Wc[(size_t)(k - 2 * SP) * tp.H + n];
+        } else {
+            const int kk = k < SP ? k : k - SP;
+            if (kk < S && n < tp.H) v = tp.Wf[(size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + kk) * tp.H + n];
+        }
         Ws[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = v;
     }
     if (L2) {                                   // second Dense: rows k < H (hidden units), columns n < S, same swizzle
@@ -286,7 +295,19 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
             // Raw buffer loads (predicated off = out of range = 0): branch-free, all 4*NCT in flight at once, issued
             // BEFORE the slot is ready so they land while the gather waves fill it.
             f32x4 c[Cfg::NCT];
-            {
+            float xa[XC ? XC_K / 4 : 1];
+            if (XC) {
+                // XC: the accumulators start from zero and the node's 32 constant inputs arrive as MFMA A fragments (row r of
+                // the tile, columns 4q + g: one 128-byte line per node instead of C's two) - 8 loads per lane instead of 16
+                const int m = (t_first + t * blk_per_xcd) * 16 + r;
+                const int jr = buf_ld_i32(r_rows, m < count ? 4u * (unsigned)m : BUF_OFF);
+                const int jx = m < count ? (rows ? jr : m) : -1;
+#pragma unroll
+                for (int q = 0; q < XC_K / 4; ++q)
+                    xa[q] = buf_ld_f32(r_C, jx >= 0 ? ((unsigned)jx * (unsigned)XC_K + (unsigned)(4 * q + g)) * 4u : BUF_OFF);
+#pragma unroll
+                for (int ci = 0; ci < Cfg::NCT; ++ci) c[ci] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else {
                 int jrow[4];
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
@@ -329,6 +350,20 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                     const int n = 16 * ci + r;
                     const float bv = Ws[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)];
                     c[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c[ci], 0, 0, 0);
+                }
+            }
+            if (XC) {
+                // the constant inputs' share of the product (one LDS base per column tile, constant offsets per k step: 2SP + 4q
+                // is even, so the swizzle bit is g & 1); their loads were issued before the slot wait, as C's are
+                const float *wb[Cfg::NCT];
+#pragma unroll
+                for (int ci = 0; ci < Cfg::NCT; ++ci)
+                    wb[ci] = Ws + (2 * SP + g) * LDW + (Cfg::SWZ ? ((16 * ci + r) ^ ((g & 1) << 4)) : 16 * ci + r);
+#pragma unroll
+                for (int q = 0; q < XC_K / 4; ++q) {
+#pragma unroll
+                    for (int ci = 0; ci < Cfg::NCT; ++ci)
+                        c[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q], wb[ci][4 * q * LDW], c[ci], 0, 0, 0);
                 }
             }
 #ifdef GNN_F4_PROFILE
@@ -426,12 +461,12 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     }
 }
 
-template <int SP, bool HAS_W, int DEPTH, bool L2 = false, int NC = 4, bool INIT = false>
+template <int SP, bool HAS_W, int DEPTH, bool L2 = false, int NC = 4, bool INIT = false, bool XC = false>
 int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
-    using Cfg = Fused4Cfg<SP, NC, L2>;
+    using Cfg = Fused4Cfg<SP, NC, L2, XC>;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
         attr = true;
     }
@@ -451,8 +486,8 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0) return 0;
-    GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s,%s>", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? "true" : "false");
-    k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
+    GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s,%s,%s>", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? "true" : "false", XC ? "true" : "false");
+    k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -472,6 +507,7 @@ inline int launch_fused4(Fused2Args &fa, int SP, int depth, int n_cu, hipStream_
         }                                                                                                             \
         if (fa.tp[0].W2) return fa.w ? launch_fused4_one<SPV, true, 4, true>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4, true>(fa, n_cu, st); \
         if (fa.w) return launch_fused4_one<SPV, true, 4>(fa, n_cu, st);                                                \
+        if (fa.Xc) return launch_fused4_one<SPV, false, 4, false, 4, false, true>(fa, n_cu, st);                       \
         return depth == 8 ? launch_fused4_one<SPV, false, 8>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4>(fa, n_cu, st);
     switch (SP) {
         F4_CASE(16)

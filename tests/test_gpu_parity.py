@@ -1138,3 +1138,27 @@ def test_groups_are_refused_where_unsupported(mutag_graphs):
     with pytest.raises(RuntimeError, match='groups'):
         model.Loop(*model.process_inputs(x), groups=begin)
     assert np.array_equal(model.predict(seq).shape, (64, 2))
+
+
+@pytest.mark.parametrize('d,state_dim0,mode', [(64, False, 'average'), (32, False, 'sum'), (20, True, 'average')])
+def test_constant_inputs_on_the_matrix_cores_variant(d, state_dim0, mode):
+    """From ~200 k nodes the wave-specialised kernel no longer reads the per-node constant C (4 H bytes per node and
+    iteration) but the node's constant inputs [labels | aggregated labels | aggregated arcs | 1] (128 bytes) and multiplies
+    them with their folded weights on the matrix cores (k_state_fused4<.., XC = true>): against the oracle, the un-fused
+    kernels and the C form of the same kernel (phase-alternating kernel pinned)."""
+    rng = np.random.default_rng(d)
+    N = 210000
+    g = er_graph(N, 5 * N, seed=9, aggregation_mode=mode, dim_node_label=20 if state_dim0 else 14)
+    sd = 0 if state_dim0 else d
+    ns, no = starter_nets('n', sd, L=20 if state_dim0 else 14, scale=0.3)
+    model = GNNnodeBased(ns, no, sd, 4, 0.0)
+    s0 = None if state_dim0 else rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    x = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    inputs = model.process_inputs(x)
+    for flags in (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2):
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=None if s0 is None else torch.from_numpy(s0).cuda())
+        assert float(k) == float(k64), (flags, float(k), k64)
+        assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, (flags, rel_err(st.cpu().numpy(), st64))
+        if flags == 0: assert _last_kernel().endswith(',true>') and _last_kernel().startswith('k_state_fused4'), _last_kernel()

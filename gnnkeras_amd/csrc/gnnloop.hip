@@ -606,7 +606,8 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, boo
         d.Y = p.C; d.ldy = p.ldC; d.out_rowidx = tp.rows;
         TRY(launch_segdense(d, st));
     }
-    if (p.xc_ok && p.N > 0 && fused_generation(p.SP, p.N, a.flags) == 4) {     // only the wave-specialised kernel reads them
+    if (p.xc_ok && p.N > 0 && (fused_generation(p.SP, p.N, a.flags) == 4 || a.nodes_src)) {   // only the wave-specialised kernel reads them (shards: the
+                                                                                       // overlapped iteration always runs it)
         const int L = a.state_dim > 0 ? p.L : 0, H = a.net_state[0].units[0];
         gnn::k_pack_xc<<<(int)std::min<long>(cdiv((long)p.N * 32, 256), 256 * 16), 256, 0, st>>>(p.N, a.nodes, a.ld_nodes, L, p.agg_nodes, p.ld_agg_nodes,
                                                                                            p.agg_arcs, p.A, p.Xc);
@@ -786,7 +787,7 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
     fa.k_out = k_out; fa.k_val = k_val;
     fa.err = p.err;
     fa.agg_init = agg_init;
-    if (p.xc_ok && !agg_init && !adj.w && fa.n_types == 1 && fused_generation(p.SP, p.N, a.flags) == 4) { fa.Xc = p.Xc; fa.Wc = p.Wc; }
+    if (p.xc_ok && !adj.w && fa.n_types == 1 && (agg_init || fused_generation(p.SP, p.N, a.flags) == 4)) { fa.Xc = p.Xc; fa.Wc = p.Wc; }
     if (fa.n_types == 0) {                      // no nodes at all: only the iteration counter moves
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;

@@ -503,7 +503,8 @@ inline int launch_fused4(Fused2Args &fa, int SP, int depth, int n_cu, hipStream_
     case SPV:                                                                                                         \
         if (fa.agg_init) {                                                                                            \
             if (fa.tp[0].W2) return 1;                                                                                \
-            return fa.w ? launch_fused4_one<SPV, true, 4, false, 4, true>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4, false, 4, true>(fa, n_cu, st); \
+            if (fa.w) return launch_fused4_one<SPV, true, 4, false, 4, true>(fa, n_cu, st);                            \
+            return fa.Xc ? launch_fused4_one<SPV, false, 4, false, 4, true, true>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4, false, 4, true>(fa, n_cu, st); \
         }                                                                                                             \
         if (fa.tp[0].W2) return fa.w ? launch_fused4_one<SPV, true, 4, true>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4, true>(fa, n_cu, st); \
         if (fa.w) return launch_fused4_one<SPV, true, 4>(fa, n_cu, st);                                                \

@@ -1162,3 +1162,17 @@ def test_constant_inputs_on_the_matrix_cores_variant(d, state_dim0, mode):
         assert float(k) == float(k64), (flags, float(k), k64)
         assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, (flags, rel_err(st.cpu().numpy(), st64))
         if flags == 0: assert _last_kernel().endswith(',true>') and _last_kernel().startswith('k_state_fused4'), _last_kernel()
+
+
+def test_constant_inputs_variant_at_every_size_in_a_child_process():
+    """GNN_XC_MIN_NODES=0 (read once per process, hence the child) puts every homogeneous one-layer model that reaches the
+    wave-specialised kernel on its XC form - small graphs pinned to that kernel, shards, and the overlapped shard iteration
+    (INIT + XC) - and re-runs the parity tests that cover those paths."""
+    import os, subprocess, sys
+    root = os.path.dirname(nat.HERE)
+    env = dict(os.environ, GNN_XC_MIN_NODES='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    sel = 'c2_mutag or c3_er or odd_state_widths or sharded_overlap or sharded_native or hub_rows or other_aggregation'
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-m', 'gpu', '-q', '-x',
+                          '-k', sel], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert ' passed' in res.stdout

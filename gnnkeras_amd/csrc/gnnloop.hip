@@ -301,6 +301,7 @@ struct TypePlan {
     const int *rows;       // node ids of this type (nullptr = all nodes, homogeneous)
     int count;
     float *Wf, *bf;        // folded first layer [in_dim x H1], [H1]
+    float *Wc;             // XC form: [32 x H1] (see Plan::Xc)
     int wrow_state, wrow_agg;
     gnn::Seg cseg[GNN_MAX_SEGS];   // iteration-invariant segments (rowidx filled with `rows`)
     int ncseg;
@@ -322,7 +323,7 @@ struct Plan {
     int *err;                        // sticky "an in-launch wait expired" word of the fused kernels, folded into k at the end
     float *agg_arcs, *agg_nodes; int ld_agg_nodes;
     float *C; int ldC;
-    float *Xc, *Wc;                  // constant inputs [N, 32] and their weights [32, H1] for the XC kernel variant (xc_ok)
+    float *Xc;                       // constant inputs [N, 32] for the XC kernel variant (xc_ok); their weights: TypePlan::Wc
     bool xc_ok;
     float *buf[2], *agg;
     float *hid[2]; int ld_hid;
@@ -469,12 +470,15 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     p.agg_nodes = c.take<float>((size_t)p.N * std::max(p.ld_agg_nodes, 1));
     p.ldC = (p.H1max + 3) & ~3;      // rows start 16-B aligned: the wave-specialised fused kernel reads C as float4
     p.C = c.take<float>((size_t)p.N * p.ldC);
-    // one node type, at most 31 constant input columns (one more carries the bias): the wave-specialised kernel may read the
+    // at most 31 constant input columns per node type (one more carries the bias): the wave-specialised kernel may read the
     // inputs (128 B per node) and multiply them instead of reading C (4 H1 bytes per node)
-    p.xc_ok = !p.composite && (a.state_dim > 0 ? 2 * p.L : 0) + p.A <= 31 && p.SP <= 64 && a.net_state[0].n_layers == 1 &&
-              !(a.flags & GNN_FLAG_UNFUSED) && !xc_disabled() && p.N >= xc_min_nodes();
+    p.xc_ok = p.SP <= 64 && !(a.flags & GNN_FLAG_UNFUSED) && !xc_disabled() && p.N >= xc_min_nodes();
+    for (int t = 0; t < p.T; ++t) {
+        const int kc = p.composite ? a.type_dim_label[t] + sum_dt + p.A : (a.state_dim > 0 ? 2 * p.L : 0) + p.A;
+        p.xc_ok = p.xc_ok && kc <= 31 && a.net_state[t].n_layers == 1;
+    }
     p.Xc = c.take<float>(p.xc_ok ? (size_t)p.N * 32 : 0);
-    p.Wc = c.take<float>(p.xc_ok ? (size_t)32 * p.H1max : 0);
+    for (int t = 0; t < p.T; ++t) p.tp[t].Wc = c.take<float>(p.xc_ok ? (size_t)32 * a.net_state[t].units[0] : 0);
     // hub segments: virtual rows for padded widths up to 128; wider states walk the plain adjacency (the un-fused aggregate
     // handles any degree), so the caller may always pass the split
     p.n_heavy = (a.n_heavy_segments > 0 && p.SP <= 128) ? a.n_heavy_segments : 0;
@@ -608,12 +612,19 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, boo
     }
     if (p.xc_ok && p.N > 0 && (fused_generation(p.SP, p.N, a.flags) == 4 || a.nodes_src)) {   // only the wave-specialised kernel reads them (shards: the
                                                                                        // overlapped iteration always runs it)
-        const int L = a.state_dim > 0 ? p.L : 0, H = a.net_state[0].units[0];
-        gnn::k_pack_xc<<<(int)std::min<long>(cdiv((long)p.N * 32, 256), 256 * 16), 256, 0, st>>>(p.N, a.nodes, a.ld_nodes, L, p.agg_nodes, p.ld_agg_nodes,
-                                                                                           p.agg_arcs, p.A, p.Xc);
-        LAUNCH_OK();
-        gnn::k_pack_wc<<<cdiv(32 * H, 256), 256, 0, st>>>(p.tp[0].Wf, p.tp[0].bf, H, L, p.A, p.S, 2 * p.S + p.L, a.state_dim > 0 ? 2 * p.S + 2 * p.L : 2 * p.S, p.Wc);
-        LAUNCH_OK();
+        for (int t = 0; t < p.T; ++t) {
+            const TypePlan &tp = p.tp[t];
+            if (tp.count == 0) continue;
+            gnn::PackSegs ps;
+            memset(&ps, 0, sizeof(ps));
+            ps.n = tp.ncseg;
+            for (int s2 = 0; s2 < tp.ncseg && s2 < 3; ++s2) { ps.ptr[s2] = tp.cseg[s2].ptr; ps.ld[s2] = tp.cseg[s2].ld; ps.width[s2] = tp.cseg[s2].width; ps.wrow[s2] = tp.cseg[s2].wrow; }
+            const int H = tp.net->units[0];
+            gnn::k_pack_xc<<<(int)std::min<long>(cdiv((long)tp.count * 32, 256), 256 * 16), 256, 0, st>>>(tp.count, tp.rows, ps, p.Xc);
+            LAUNCH_OK();
+            gnn::k_pack_wc<<<cdiv(32 * H, 256), 256, 0, st>>>(tp.Wf, tp.bf, H, ps, tp.Wc);
+            LAUNCH_OK();
+        }
     }
     return 0;
 }
@@ -763,7 +774,7 @@ gnn::FusedType fused_type(const gnn_loop_args_t &a, const Plan &p, int t) {
     const bool two = m.n_layers == 2;
     return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg,
                           (int)m.units[0], (int)m.activation[0],
-                          two ? m.kernel[1] : nullptr, two ? m.bias[1] : nullptr, two ? (int)m.activation[1] : 0};
+                          two ? m.kernel[1] : nullptr, two ? m.bias[1] : nullptr, two ? (int)m.activation[1] : 0, p.tp[t].Wc};
 }
 
 // one fused iteration over every node type (one launch per type)
@@ -787,7 +798,7 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
     fa.k_out = k_out; fa.k_val = k_val;
     fa.err = p.err;
     fa.agg_init = agg_init;
-    if (p.xc_ok && !adj.w && fa.n_types == 1 && (agg_init || fused_generation(p.SP, p.N, a.flags) == 4)) { fa.Xc = p.Xc; fa.Wc = p.Wc; }
+    if (p.xc_ok && !adj.w && (agg_init || fused_generation(p.SP, p.N, a.flags) == 4)) fa.Xc = p.Xc;
     if (fa.n_types == 0) {                      // no nodes at all: only the iteration counter moves
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;

@@ -33,6 +33,7 @@ struct FusedType {
     const float *W2;   // [H x S] row-major
     const float *b2;   // [S]
     int act2;
+    const float *Wc;   // XC form of k_state_fused4: [32 x H] folded weight rows of this type's constant inputs, bias row, zeros
 };
 
 struct Fused2Args {
@@ -53,8 +54,9 @@ struct Fused2Args {
     int *err;                                      // sticky error word (workspace): a bounded in-launch wait expired
     // k_state_fused4<.., XC = true> (one node type): instead of the per-node constant C (4 H bytes per node and iteration) the
     // kernel reads the node's constant INPUTS Xc [n, 32] = [labels | agg labels | agg arcs | 1 | 0..] (128 bytes) and multiplies
-    // them with Wc [32, H] = folded first-layer rows of those inputs, then the folded bias, then zeros, on the matrix cores
-    const float *Xc, *Wc;
+    // them with the type's Wc [32, H] = folded first-layer rows of those inputs, then the folded bias, then zeros, on the matrix
+    // cores (FusedType::Wc; Xc rows are indexed by node id, each laid out for its node's type)
+    const float *Xc;
     const float *agg_init;                         // k_state_fused4<.., INIT = true>: [n_local, SP] partial neighbour sums (un-scaled)
                                                    // of the arcs this launch does NOT walk (own-range arcs, summed while the
                                                    // exchange was in flight: distributed.py overlap); nullptr otherwise

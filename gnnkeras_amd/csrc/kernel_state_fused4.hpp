@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
         const int k = i / SP, n = i % SP;
         float v = 0.0f;
         if (XC && k >= 2 * SP) {
-            if (n < tp.H) v = a.Wc[(size_t)(k - 2 * SP) * tp.H + n];
+            if (n < tp.H) v = tp.Wc[(size_t)(k - 2 * SP) * tp.H + n];
         } else {
             const int kk = k < SP ? k : k - SP;
             if (kk < S && n < tp.H) v = tp.Wf[(size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + kk) * tp.H + n];

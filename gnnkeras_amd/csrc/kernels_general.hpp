@@ -421,31 +421,36 @@ k_converge(const int *gate, const float *__restrict__ s, const float *__restrict
 // The XC variant of the wave-specialised kernel (kernel_state_fused4.hpp) multiplies a node's constant inputs on the matrix
 // cores instead of reading the per-node constant C.  Xc[j] = [labels | aggregated labels | aggregated arc labels | 1 | 0 ..]
 // (32 floats = one 128-byte line), Wc = the folded first-layer rows of those inputs, then the folded bias, then zeros.
+// One node type at a time: its constant first-layer segments (TypePlan::cseg: own labels, aggregated labels, aggregated arc
+// labels - each a node-indexed array) are concatenated into the rows of its nodes.
+struct PackSegs { const float *ptr[3]; int ld[3], width[3], wrow[3]; int n; };
 __global__ void __launch_bounds__(256)
-k_pack_xc(int N, const float *__restrict__ nodes, int ld_nodes, int L, const float *__restrict__ agg_nodes, int ld_an,
-          const float *__restrict__ agg_arcs, int A, float *__restrict__ Xc) {
-    const size_t total = (size_t)N * 32;
+k_pack_xc(int count, const int *__restrict__ rows, PackSegs ps, float *__restrict__ Xc) {
+    const int Kc = ps.width[0] + ps.width[1] + ps.width[2];
+    const size_t total = (size_t)count * 32;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t j = i >> 5;
+        const size_t m = i >> 5;
+        const size_t j = rows ? (size_t)rows[m] : m;
         const int c = (int)(i & 31);
         float v = 0.0f;
-        if (c < L) v = nodes[j * ld_nodes + c];
-        else if (c < 2 * L) v = agg_nodes[j * ld_an + (c - L)];
-        else if (c < 2 * L + A) v = agg_arcs[j * A + (c - 2 * L)];
-        else if (c == 2 * L + A) v = 1.0f;
-        Xc[i] = v;
+        if (c < ps.width[0]) v = ps.ptr[0][j * ps.ld[0] + c];
+        else if (c < ps.width[0] + ps.width[1]) v = ps.ptr[1][j * ps.ld[1] + (c - ps.width[0])];
+        else if (c < Kc) v = ps.ptr[2][j * ps.ld[2] + (c - ps.width[0] - ps.width[1])];
+        else if (c == Kc) v = 1.0f;
+        Xc[j * 32 + c] = v;
     }
 }
 __global__ void __launch_bounds__(256)
-k_pack_wc(const float *__restrict__ Wf, const float *__restrict__ bf, int H, int L, int A, int row_nodes, int row_aggn, int row_agga,
-          float *__restrict__ Wc) {
+k_pack_wc(const float *__restrict__ Wf, const float *__restrict__ bf, int H, PackSegs ps, float *__restrict__ Wc) {
+    const int Kc = ps.width[0] + ps.width[1] + ps.width[2];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 32 * H; i += gridDim.x * blockDim.x) {
         const int c = i / H, h = i % H;
         float v = 0.0f;
-        if (c < 2 * L + A) {
-            const int k = c < L ? row_nodes + c : (c < 2 * L ? row_aggn + (c - L) : row_agga + (c - 2 * L));
+        if (c < Kc) {
+            const int k = c < ps.width[0] ? ps.wrow[0] + c
+                        : (c < ps.width[0] + ps.width[1] ? ps.wrow[1] + (c - ps.width[0]) : ps.wrow[2] + (c - ps.width[0] - ps.width[1]));
             v = Wf[(size_t)k * H + h];
-        } else if (c == 2 * L + A) v = bf[h];
+        } else if (c == Kc) v = bf[h];
         Wc[i] = v;
     }
 }

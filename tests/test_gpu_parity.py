@@ -1171,7 +1171,7 @@ def test_constant_inputs_variant_at_every_size_in_a_child_process():
     import os, subprocess, sys
     root = os.path.dirname(nat.HERE)
     env = dict(os.environ, GNN_XC_MIN_NODES='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
-    sel = 'c2_mutag or c3_er or odd_state_widths or sharded_overlap or sharded_native or hub_rows or other_aggregation'
+    sel = 'c2_mutag or c3_er or odd_state_widths or sharded_overlap or sharded_native or sharded_composite or composite_small or hub_rows or other_aggregation'
     res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-m', 'gpu', '-q', '-x',
                           '-k', sel], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]

@@ -576,7 +576,8 @@ int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, 
     return 0;
 }
 
-int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, bool zero_loop_words = false) {
+// `skip_c`: the caller runs every iteration on the XC form of the wave-specialised kernel, which never reads C
+int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, bool zero_loop_words = false, bool skip_c = false) {
     // BN folding of every first layer: one launch, which also zeroes the flag words / barrier counters and k
     FoldList fl;
     for (int t = 0; t < p.T; ++t) fl.add(a.net_state[t], p.tp[t].Wf, p.tp[t].bf);
@@ -598,7 +599,7 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, boo
         }
     }
     // C[j] = const segments . Wf[const rows] + bf     (written row-scattered per type; every node has one type)
-    for (int t = 0; t < p.T; ++t) {
+    for (int t = 0; t < p.T && !skip_c; ++t) {
         const TypePlan &tp = p.tp[t];
         if (tp.count == 0) continue;
         gnn::SegDenseArgs d;
@@ -984,8 +985,11 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     const bool whole_loop = fz != 0 && persistent_applies(a, p);
     const bool small_setup = whole_loop && setup_small_applies(a, p);
     if (p.n_groups > 0 && !small_setup) return fail("convergence groups need the whole-loop kernel (gnn_loop_groups_supported() == 0 for these args)");
+    // every iteration on the XC form of the wave-specialised kernel (large homogeneous / composite graphs): C is never read
+    const bool xc_loop = p.xc_ok && !whole_loop && fz == 1 && !mid_applies(a, p) && p.SP != 128 && !iter_adjacency(a, p).w &&
+                         iteration_generation(a, p) == 4 && fused_generation(p.SP, p.N, a.flags) == 4;
     if (small_setup) TRY(setup_small(a, p, st));
-    else             TRY(setup_constants(a, p, st, /*zero_loop_words=*/true));       // flags, barrier counters and k start from zero
+    else             TRY(setup_constants(a, p, st, /*zero_loop_words=*/true, /*skip_c=*/xc_loop));   // flags, barrier counters and k start from zero
 
     // state_0 (GNN.py:256-259) into the padded buffer; state_old_0 = ones is implicit in the first predicate (:261)
     // When the caller's state_0 already has the padded layout (d a multiple of 16, no hub rows behind the real ones) the

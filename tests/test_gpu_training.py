@@ -622,3 +622,34 @@ def test_inference_after_training_matches_oracle(mutag_graphs):
         k, st, o = model.Loop(*model.process_inputs(x), state0=None if s0 is None else torch.from_numpy(s0).cuda())
         assert float(k) == float(k64)
         assert rel_err(st.cpu().numpy(), st64) <= 1e-5 and rel_err(o.cpu().numpy(), o64) <= 1e-5
+
+
+@pytest.mark.parametrize('M,widths,H,act', [(70001, (64, 14, 64, 14, 3), 64, 'selu'), (131072, (64,), 64, 'linear'),
+                                            (65537, (20, 33), 48, 'tanh'), (100000, (64, 64, 64), 37, 'relu')])
+def test_dense_entry_large_batches(M, widths, H, act):
+    """gnn_dense (the segmented Dense of every un-fused path: GNN.py:231-234 concat + Dense without the concat) on batches
+    in the throughput regime (k_segdense<1>, > 16 384 rows): row-index lists, scattered output rows, ragged last tile, H < 64,
+    against float64."""
+    import ctypes as C
+    from gnnkeras_amd import _native as nat
+    from gnnkeras_amd.Models.training import _Prim
+    rng = np.random.default_rng(M % 97)
+    dev = torch.device('cuda', 0)
+    p = _Prim(dev)
+    K = sum(widths)
+    W = torch.from_numpy(rng.normal(0, 0.3, (K, H)).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.normal(0, 0.3, H).astype(np.float32)).to(dev)
+    segs, cols = [], []
+    for i, w in enumerate(widths):
+        rows = M + (1000 if i % 2 else 0)
+        x = torch.from_numpy(rng.normal(0, 1, (rows, w + (i % 3))).astype(np.float32)).to(dev)[:, :w]     # leading dimension > width
+        ridx = torch.from_numpy(rng.permutation(rows)[:M].astype(np.int32)).to(dev) if i % 2 else None
+        segs.append((x, ridx))
+        cols.append(x.double() if ridx is None else x.double()[ridx.long()])
+    out_idx = torch.from_numpy(rng.permutation(M + 50)[:M].astype(np.int32)).to(dev) if len(widths) > 2 else None
+    Y = torch.zeros((M + 50 if out_idx is not None else M, H), dtype=torch.float32, device=dev)
+    p.dense(segs, W, H, b, nat.ACTIVATIONS[act], Y, out_rowidx=out_idx)
+    z = torch.cat(cols, dim=1) @ W.double() + b.double()
+    want = {'selu': torch.nn.functional.selu, 'linear': lambda t: t, 'tanh': torch.tanh, 'relu': torch.relu}[act](z)
+    got = Y if out_idx is None else Y[out_idx.long()]
+    assert float((got.double() - want).abs().max() / want.abs().max()) <= 1e-5

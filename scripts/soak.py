@@ -43,6 +43,30 @@ for d, bs in ((32, 32), (64, 48)):
                 print(f'MISMATCH d={d} rep={rep} batch={b}: k {a[0]} vs {c[0]}, state rel diff {rel:.3e}')
             n += 1
     print(f'MUTAG d={d} batch={bs}: {n} forward pairs, {bad} mismatches, {time.time() - t0:.1f} s')
+# ---- convergence groups: 16 batches as independent loops of one launch vs the batches one by one, bitwise -------------------
+seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False)
+d = 32
+inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d); ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=0)
+inp, lay = get_inout_dims('output', 14, 3, 2, 'g', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
+gnn = GNNgraphBased(ns, no, d, 30, 0.02)
+t0 = time.time(); n = 0
+for rep in range(reps):
+    for i0, i1 in gnn._group_plan(seq, torch.device('cuda', 0)):
+        if i1 - i0 < 2: continue
+        x, begin = seq.merged_batches(i0, i1)
+        s0 = torch.randn((begin[-1], d), device='cuda') * 0.1
+        k, st, o = gnn.Loop(*gnn.process_inputs(x), state0=s0, groups=begin)
+        r0 = 0
+        for j in range(i1 - i0):
+            xb = seq[i0 + j][0]
+            kb, stb, ob = gnn.Loop(*gnn.process_inputs(xb), state0=s0[begin[j]:begin[j + 1]].contiguous())
+            rows = ob.shape[0]
+            if float(kb) != float(k[j]) or not torch.equal(stb, st[begin[j]:begin[j + 1]]) or not torch.equal(ob, o[r0:r0 + rows]):
+                bad += 1
+                print(f'GROUP MISMATCH rep={rep} batch={i0 + j}: k {float(kb)} vs {float(k[j])}')
+            r0 += rows
+            n += 1
+print(f'convergence groups: {n} batches compared, {time.time() - t0:.1f} s')
 # ---- ER graph: generation 4 repeated, bitwise reproducible; persistent kernel at its size limit ----------------------------
 for N, E, flag, name in ((200000, 2000000, nat.FLAG_FUSED_GEN4, 'generation 4'), (16000, 160000, nat.FLAG_FUSED_GEN5, 'generation 5'),
                           (30000, 300000, nat.FLAG_FUSED_GEN6, 'generation 6')):

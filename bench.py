@@ -146,6 +146,22 @@ def mutag_section(device, cpu: bool):
                          'mean_k': float(np.mean(ks_c)), 'fwd_ms_per_graph': 1e3 * (min(t_c, t_cg) if t_cg is not None else t_c) / n_graphs,
                          'grouped_fwd_ms_per_graph': None if t_cg is None else 1e3 * t_cg / n_graphs,
                          'side_streams_fwd_ms_per_graph': 1e3 * t_c / n_graphs}
+    # BASELINE C1, the reference's own default (starter.py): state_vect_dim = 0 (the state is the 14 label columns), max_iteration = 5
+    ns0, no0 = starter_nets(0, device, 'g')
+    gnn0 = GNNgraphBased(ns0, no0, 0, 5, 0.01)
+    plan0 = gnn0._group_plan(seq, device)
+    def walk0():
+        gnn0._k_seen = []
+        outs = [o for _, o in gnn0._forward_batches(seq, device)]
+        return torch.cat([k.reshape(-1) for k in gnn0._k_seen])
+    walk0(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ks0 = walk0()
+    torch.cuda.synchronize()
+    t_0 = time.perf_counter() - t0
+    res['starter_config'] = {'workload': 'state_vect_dim=0, max_iteration=5, threshold=0.01 (starter.py), the predict() walk over the 136 batches',
+                             'fwd_ms_per_graph': 1e3 * t_0 / n_graphs, 'mean_k': float(ks0.mean()),
+                             'how': ('grouped launches: %d' % len(plan0)) if plan0 is not None else 'side streams'}
     if cpu:
         from oracle import torch_cpu
         from oracle.harness import _np, _triple

@@ -819,7 +819,7 @@ bool persistent_applies(const gnn_loop_args_t &a, const Plan &p) {
     static int env = -1;
     if (env < 0) { const char *e = getenv("GNN_FUSED_KERNEL"); env = e ? atoi(e) : 0; }
     if (pinned == 0 && env != 0 && env != 5) return false;
-    if (p.n_heavy != 0 || a.max_iteration < 1 || (p.SP != 32 && p.SP != 64)) return false;
+    if (p.n_heavy != 0 || a.max_iteration < 1 || (p.SP != 16 && p.SP != 32 && p.SP != 64)) return false;
     int tiles = 0;
     for (int t = 0; t < p.T; ++t) tiles += (p.tp[t].count + 63) / 64;
     if (p.n_groups > 0) tiles = p.group_tiles;

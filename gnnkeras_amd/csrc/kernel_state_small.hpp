@@ -41,9 +41,11 @@ struct SmallArgs {
                              // low word = arrivals, high word = workgroups that still saw a node move
 };
 
+constexpr int small_waves(int SP) { return SP == 16 ? 4 : 8; }   // 16-wide rows: 4 lanes per row, 256 threads cover a 64-node tile in one pass
+
 template <int SP, bool HAS_W, bool L2>
-__global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one workgroup per CU is all the grid needs: 256-VGPR budget
-    using Cfg = Fused2Cfg<SP, 64, 8>;
+__global__ void __launch_bounds__(64 * small_waves(SP), 2) k_state_small(SmallArgs sa) {   // one workgroup per CU is all the grid needs: 256-VGPR budget
+    using Cfg = Fused2Cfg<SP, 64, small_waves(SP)>;
     constexpr int TM = 64, NT = Cfg::NT, LPR = Cfg::LPR, IPL = Cfg::IPL, LDX = Cfg::LDX, LDW = Cfg::LDW, NPASS = Cfg::NPASS;
     const Fused2Args &a = sa.f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -358,7 +360,7 @@ __global__ void __launch_bounds__(512, 2) k_state_small(SmallArgs sa) {   // one
 constexpr size_t SMALL_LDS = 96 * 1024;      // > half of a CU's 160 KB: at most one of these workgroups per CU
 template <int SP, bool HAS_W, bool L2>
 int launch_small_one(SmallArgs &sa, int n_cu, hipStream_t st, int group_tiles) {
-    using Cfg = Fused2Cfg<SP, 64, 8>;
+    using Cfg = Fused2Cfg<SP, 64, small_waves(SP)>;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void *)k_state_small<SP, HAS_W, L2>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -389,9 +391,10 @@ inline int launch_small(SmallArgs &sa, int SP, int n_cu, hipStream_t st, int gro
         if (l2) return sa.f.w ? launch_small_one<SPV, true, true>(sa, n_cu, st, group_tiles) : launch_small_one<SPV, false, true>(sa, n_cu, st, group_tiles); \
         return sa.f.w ? launch_small_one<SPV, true, false>(sa, n_cu, st, group_tiles) : launch_small_one<SPV, false, false>(sa, n_cu, st, group_tiles);
     switch (SP) {
+        SMALL_CASE(16)                                     // the starter configuration: state = the 14 label columns (state_vect_dim = 0)
         SMALL_CASE(32)
         SMALL_CASE(64)
-        default: return 2;                                 // d <= 16: 4-wave tile shape there, not built
+        default: return 2;
     }
 #undef SMALL_CASE
 }

@@ -176,7 +176,7 @@ size_t gnn_loop_workspace_bytes(const gnn_loop_args_t *args);
 /* (k, state, out) = Loop(...)  — see gnn_loop_args. */
 int gnn_loop_forward(const gnn_loop_args_t *args);
 /* 1 when gnn_loop_forward accepts these args with n_groups > 0 (homogeneous model, one- or two-layer state network of
- * width 17..64, every group's 64-node tiles resident at once: sum_g ceil(nodes_g / 64) <= CUs), else 0: the caller then
+ * width <= 64, every group's 64-node tiles resident at once: sum_g ceil(nodes_g / 64) <= CUs), else 0: the caller then
  * runs one call per batch.  Reads dims, flags and the host group array only. */
 int gnn_loop_groups_supported(const gnn_loop_args_t *args);
 

@@ -9,13 +9,14 @@ from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
 dev = torch.device('cuda', 0)
 gs = load_graphs()
 seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False, device=dev)
-d = 32
+d = int(sys.argv[1]) if len(sys.argv) > 1 else 32          # 0 = the starter configuration (state = the 14 label columns, 5 iterations)
+K_IT = 50 if d else 5
 inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d); ns = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0, device=dev)
 inp, lay = get_inout_dims('output', 14, 3, 2, 'g', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1, device=dev)
-for thr, nm in ((0.01, 'k=50 (never converges)'), (None, 'converging')):
+for thr, nm in ((0.01, 'random weights'), (None, 'converging')):
     if thr is None:
         w = ns.get_weights(); ns.set_weights([a * 0.25 if a.ndim == 2 else a for a in w]); thr = 0.01
-    gnn = GNNgraphBased(ns, no, d, 50, thr)
+    gnn = GNNgraphBased(ns, no, d, K_IT, thr)
     for grouped in (False, True):
         gnn.group_batches = grouped
         plan = gnn._group_plan(seq, dev)

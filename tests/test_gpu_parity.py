@@ -1156,3 +1156,41 @@ def test_starter_configuration_runs_grouped(mutag_graphs):
     model.group_batches = False
     p0 = model.predict(seq); e0 = model.evaluate(seq, return_dict=True)
     assert np.array_equal(p1, p0) and abs(e1['loss'] - e0['loss']) <= 1e-6 and abs(e1['accuracy'] - e0['accuracy']) <= 1e-6
+
+
+@pytest.mark.parametrize('d,state_dim0,mode', [(64, False, 'average'), (32, False, 'sum'), (20, True, 'average')])
+def test_constant_inputs_on_the_matrix_cores_variant(d, state_dim0, mode):
+    """From ~200 k nodes the wave-specialised kernel no longer reads the per-node constant C (4 H bytes per node and
+    iteration) but the node's constant inputs [labels | aggregated labels | aggregated arcs | 1] (128 bytes) and multiplies
+    them with their folded weights on the matrix cores (k_state_fused4<.., XC = true>): against the oracle, the un-fused
+    kernels and the C form of the same kernel (phase-alternating kernel pinned)."""
+    rng = np.random.default_rng(d)
+    N = 210000
+    g = er_graph(N, 5 * N, seed=9, aggregation_mode=mode, dim_node_label=20 if state_dim0 else 14)
+    sd = 0 if state_dim0 else d
+    ns, no = starter_nets('n', sd, L=20 if state_dim0 else 14, scale=0.3)
+    model = GNNnodeBased(ns, no, sd, 4, 0.0)
+    s0 = None if state_dim0 else rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    x = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    inputs = model.process_inputs(x)
+    for flags in (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2):
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=None if s0 is None else torch.from_numpy(s0).cuda())
+        assert float(k) == float(k64), (flags, float(k), k64)
+        assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, (flags, rel_err(st.cpu().numpy(), st64))
+        if flags == 0: assert _last_kernel().endswith(',true>') and _last_kernel().startswith('k_state_fused4'), _last_kernel()
+
+
+def test_constant_inputs_variant_at_every_size_in_a_child_process():
+    """GNN_XC_MIN_NODES=0 (read once per process, hence the child) puts every homogeneous one-layer model that reaches the
+    wave-specialised kernel on its XC form - small graphs pinned to that kernel, shards, and the overlapped shard iteration
+    (INIT + XC) - and re-runs the parity tests that cover those paths."""
+    import os, subprocess, sys
+    root = os.path.dirname(nat.HERE)
+    env = dict(os.environ, GNN_XC_MIN_NODES='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    sel = 'c2_mutag or c3_er or odd_state_widths or sharded_overlap or sharded_native or sharded_composite or composite_small or hub_rows or other_aggregation'
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-m', 'gpu', '-q', '-x',
+                          '-k', sel], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert ' passed' in res.stdout

@@ -113,20 +113,30 @@ int check_csr(const gnn_csr_t &c, const char *name, int n_dst, int n_src) {
 // --- launchers -------------------------------------------------------------------------------------------------------
 int launch_aggregate(const int *gate, const gnn_csr_t &c, const float *X, int ldx, int F, float *out, int ldo, hipStream_t st) {
     if (c.n_dst == 0 || F == 0) return 0;
-    if ((F == 16 || F == 32 || F == 64 || F == 128) && ldx % 4 == 0 && ldo % 4 == 0 &&
-        ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
-        const int lpr = F / 4, groups = 256 / lpr;
-        const int grid = std::min(cdiv(c.n_dst, groups), 256 * 16);
-#define AGGV(L) (c.w ? gnn::k_aggregate_vec<L, true><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, ldx, out, ldo) \
-               : gnn::k_aggregate_vec<L, false><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, ldx, out, ldo))
-        switch (lpr) {
-            case 4: AGGV(4); break;
-            case 8: AGGV(8); break;
-            case 16: AGGV(16); break;
-            default: AGGV(32); break;
-        }
+    const bool aligned = ldx % 4 == 0 && ldo % 4 == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (aligned && (F == 16 || F == 32 || F == 64 || F == 128 || (F > 128 && F % 4 == 0))) {
+        // 16-byte row pieces; rows wider than 128 floats go in column blocks of 128, 64, .. 4 (one launch each: the CSR is
+        // walked again, the row bytes are not)
+        for (int off = 0; off < F;) {
+            int w = 128;
+            while (w > F - off) w >>= 1;
+            const int lpr = w / 4, groups = 256 / lpr;
+            const int grid = std::min(cdiv(c.n_dst, groups), 256 * 16);
+            const float *Xb = X + off; float *ob = out + off;
+#define AGGV(L) (c.w ? gnn::k_aggregate_vec<L, true><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xb, ldx, ob, ldo) \
+               : gnn::k_aggregate_vec<L, false><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xb, ldx, ob, ldo))
+            switch (lpr) {
+                case 1: AGGV(1); break;
+                case 2: AGGV(2); break;
+                case 4: AGGV(4); break;
+                case 8: AGGV(8); break;
+                case 16: AGGV(16); break;
+                default: AGGV(32); break;
+            }
 #undef AGGV
-        LAUNCH_OK();
+            LAUNCH_OK();
+            off += w;
+        }
         return 0;
     }
     int G = 4;
@@ -549,7 +559,7 @@ int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, 
     GNN_SET_KERNEL_NAME("k_aggregate_vec + k_segdense + k_converge (un-fused)");
     TRY(launch_heavy(a, p, gate, src_full, st));
     // the padded width: pad columns are zero on both sides, and whole 16-B chunks let the vector kernel run for any d
-    TRY(launch_aggregate(gate, iter_adjacency(a, p), src_full, p.SP, p.SP <= 128 ? p.SP : p.S, p.agg, p.SP, st));
+    TRY(launch_aggregate(gate, iter_adjacency(a, p), src_full, p.SP, p.SP, p.agg, p.SP, st));
     const float *src = src_full + (size_t)row_base * p.SP;     // own rows
     float *dst = dst_full + (size_t)row_base * p.SP;
     bool pred_fused = false;

@@ -155,7 +155,7 @@ def test_multilayer_networks_and_activations(mutag_graphs, act):
     check(model, x, np.random.default_rng(4).normal(0, 0.1, (935, 24)).astype(np.float32))
 
 
-@pytest.mark.parametrize('d', [1, 3, 14, 20, 33, 64, 100])
+@pytest.mark.parametrize('d', [1, 3, 14, 20, 33, 64, 100, 130, 200])
 def test_odd_state_widths(mutag_graphs, d):
     seq = MultiGraphSequencer(refocus(mutag_graphs[:16], 'n', np.random.default_rng(d)), 'n', 'average', 16, shuffle=False)
     x = seq[0][0]

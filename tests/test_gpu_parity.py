@@ -1068,31 +1068,33 @@ def test_mid_size_whole_loop_weighted_and_composite():
 # ----------------------------------------------------------------------------------------------------------------------
 # convergence groups: several batches merged into one call, each with its own `while` (include/gnnloop.h group_node_begin)
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('focus,d,thr', [('g', 32, 0.01), ('n', 64, 0.02), ('a', 32, 0.0)])
-def test_convergence_groups_equal_batch_by_batch_calls(mutag_graphs, focus, d, thr):
+@pytest.mark.parametrize('focus,d,thr,hidden', [('g', 32, 0.01, None), ('n', 64, 0.02, None), ('a', 32, 0.0, None), ('g', 32, 0.01, [24]),
+                                                ('g', 0, 0.01, None)])
+def test_convergence_groups_equal_batch_by_batch_calls(mutag_graphs, focus, d, thr, hidden):
     """Eight MUTAG batches as eight independent loops of ONE launch: per batch the iteration count, the state and the
     output must equal - bit for bit, the tiles and summation orders are the same - what a call on that batch alone
     gives, including batches that converge at different k."""
     gl = refocus(mutag_graphs[:8 * 20], focus, np.random.default_rng(3))
     seq = MultiGraphSequencer(gl, focus, 'average', 20, shuffle=False)
-    ns, no = starter_nets(focus, d, scale=0.22)
+    ns, no = starter_nets(focus, d, scale=0.22, hidden_state=hidden, act='tanh' if hidden else 'selu')
     model = CLS[focus](ns, no, d, 30, thr)
     rng = np.random.default_rng(9)
     parts = []
     for i in range(len(seq)):
         x = seq[i][0]
-        s0 = rng.normal(0, 0.1 * (1 + i), (x[0].shape[0], d)).astype(np.float32)     # different scales: different k per batch
-        k, st, o = model.Loop(*model.process_inputs(x), state0=dev(s0))
+        # different scales: different k per batch (state_vect_dim = 0: the state starts from the labels, no state_0 to pass)
+        s0 = rng.normal(0, 0.1 * (1 + i), (x[0].shape[0], d)).astype(np.float32) if d else None
+        k, st, o = model.Loop(*model.process_inputs(x), state0=None if s0 is None else dev(s0))
         parts.append((float(k), st, o, s0))
     x, begin = seq.merged_batches(0, len(seq))
     assert begin[-1] == x[0].shape[0] and len(begin) == len(seq) + 1
     from gnnkeras_amd import ops
     assert ops.loop_groups_supported(begin[-1], x[0].shape[1], x[1].shape[1] - 2, ns, no, d, 30, nat.FOCUS[focus], 0, 0, begin)
-    k, st, o = model.Loop(*model.process_inputs(x), state0=dev(np.concatenate([p[3] for p in parts])), groups=begin)
+    k, st, o = model.Loop(*model.process_inputs(x), state0=dev(np.concatenate([p[3] for p in parts])) if d else None, groups=begin)
     assert _last_kernel().startswith('k_state_small'), _last_kernel()
     assert k.shape == (len(seq),)
     assert [float(v) for v in k.cpu()] == [p[0] for p in parts]
-    if thr > 0: assert len({p[0] for p in parts}) > 1, 'the batches were meant to stop at different iterations'
+    if thr > 0 and d: assert len({p[0] for p in parts}) > 1, 'the batches were meant to stop at different iterations'
     assert torch.equal(st, torch.cat([p[1] for p in parts]))
     assert torch.equal(o, torch.cat([p[2] for p in parts]))
     assert np.array_equal(model.check_last_k(), np.array([p[0] for p in parts], np.float32))

@@ -57,6 +57,11 @@ def algorithmic_bytes_per_iteration(n_nodes, n_arcs, d, h1, per_arc_weights):
     return n_arcs * (4 + 4 * d + (4 if per_arc_weights else 0)) + n_nodes * (4 + 8 * d + 4 * h1)
 
 
+def nat_kernel():
+    from gnnkeras_amd import _native as nat
+    return nat.lib().gnn_last_kernel_name().decode()
+
+
 def mutag_section(device, cpu: bool):
     """BASELINE C2: all 136 MUTAG batches of 32 graphs, d = 32, max_iteration = 50, threshold 0.01."""
     from gnnkeras_amd.load_MUTAG import load_graphs
@@ -94,13 +99,17 @@ def mutag_section(device, cpu: bool):
     # ... and the way they walk it where the library supports convergence groups: runs of batches merged into one graph
     # whose batches are independent loops of ONE launch (own predicate, own k: include/gnnloop.h group_node_begin)
     plan = gnn._group_plan(seq, device)
+    s0_cat = {id(bs): torch.cat([s0s[b] for b in bs]) for bs in (plan or []) if len(bs) > 1}     # (predict() draws state_0 per launch)
     def grouped(model):
-        out = []
-        for i0, i1 in plan:
-            x, begin = seq.merged_batches(i0, i1)
-            k, st, o = model.Loop(*model.process_inputs(x), state0=torch.cat(s0s[i0:i1]), groups=begin if i1 - i0 > 1 else None)
-            out.append(k.reshape(-1))
-        return torch.cat(out)
+        ks_b = [None] * len(items)
+        for bs in plan:
+            if len(bs) == 1:
+                k, st, o = model.Loop(*inputs[bs[0]], state0=s0s[bs[0]])
+            else:
+                x, begin = seq.merged_batches(bs)
+                k, st, o = model.Loop(*model.process_inputs(x), state0=s0_cat[id(bs)], groups=begin)
+            for j, b in enumerate(bs): ks_b[b] = k.reshape(-1)[j]
+        return torch.stack(ks_b)
     t_grp = None
     if plan is not None:
         grouped(gnn); torch.cuda.synchronize()
@@ -114,7 +123,7 @@ def mutag_section(device, cpu: bool):
     res = {'workload': 'MUTAG (TU Mutagenicity) 4337 graphs as 136 batches of 32, state_dim=32, max_iteration=50, '
                        'threshold=0.01, graph-focused forward',
            'fwd_ms_per_graph': 1e3 * t_best / n_graphs, 'fwd_ms_per_batch': 1e3 * t_best / len(items),
-           'how': ('grouped launches: %d launches of up to 32 batches, each batch an independent loop' % len(plan)) if t_best == t_grp
+           'how': ('grouped launches: %d launch(es), each batch an independent loop (%s)' % (len(plan), nat_kernel())) if t_best == t_grp
                   else '%d side streams' % width,
            'grouped_fwd_ms_per_graph': None if t_grp is None else 1e3 * t_grp / n_graphs,
            'side_streams_fwd_ms_per_graph': 1e3 * t_gpu / n_graphs, 'concurrent_batches': width,
@@ -141,7 +150,8 @@ def mutag_section(device, cpu: bool):
         ks_cg = grouped(gnn_c)
         torch.cuda.synchronize()
         t_cg = time.perf_counter() - t0
-        assert [float(v) for v in ks_cg.cpu()] == ks_c
+        # (another kernel, other summation orders: a batch sitting exactly on the threshold may stop one iteration apart)
+        assert max(abs(a_ - b_) for a_, b_ in zip([float(v) for v in ks_cg.cpu()], ks_c)) <= 1
     res['converging'] = {'note': 'state-network kernel x 0.25: contractive, the device-side predicate stops the loop early',
                          'mean_k': float(np.mean(ks_c)), 'fwd_ms_per_graph': 1e3 * (min(t_c, t_cg) if t_cg is not None else t_c) / n_graphs,
                          'grouped_fwd_ms_per_graph': None if t_cg is None else 1e3 * t_cg / n_graphs,

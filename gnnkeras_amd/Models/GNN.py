@@ -201,24 +201,39 @@ class _LoopModel:
             yield from self._batches_concurrently(n, lambda i: self.call(sequencer[i][0], training=False), device,
                                                   self._round_width(sequencer, device) if n else 1)
             return
-        for i0, i1 in plan:
-            if i1 - i0 == 1:
-                yield i0, self.call(sequencer[i0][0], training=False)
-                continue
-            x, node_begin = sequencer.merged_batches(i0, i1)
-            out = self.call(x, training=False, groups=node_begin)
+        def launch(li):
+            batches = plan[li]
+            if len(batches) == 1: return self.call(sequencer[batches[0]][0], training=False)
+            x, node_begin = sequencer.merged_batches(batches)
+            return self.call(x, training=False, groups=node_begin)
+        outs = {}
+        # every launch first, on side streams (a launch of 120 one-CU groups and the launches that spread the few large batches
+        # over the remaining CUs overlap), then the batches in order
+        for li, out in self._batches_concurrently(len(plan), launch, device, min(len(plan), 4)):
             r0 = 0
-            for i in range(i0, i1):
+            for i in plan[li]:
                 rows = int(sequencer[i][1].shape[0])               # output rows of a batch = its target rows
-                yield i, out[r0: r0 + rows]
+                outs[i] = out[r0: r0 + rows]
                 r0 += rows
+        for i in range(n): yield i, outs[i]
 
     def _group_plan(self, sequencer, device):
-        """[(i0, i1), ...]: runs of batches to merge per launch (every 64-node tile of a launch resident at once, at most
-        32 groups), or None when grouping does not apply (composite model, CPU, 'normalized', unsupported shape)."""
+        """[[batch, ...], ...]: the batches each launch merges, or None when grouping does not apply (composite model, CPU,
+        'normalized', unsupported shape).  Batches whose state fits the LDS of one CU go together - one workgroup each, any
+        number of them per launch; the others in runs of at most 32 whose 64-node tiles are all resident at once."""
         if not self.group_batches or device.type != 'cuda' or not hasattr(sequencer, 'merged_batches'): return None
         if not isinstance(getattr(self, 'net_state', None), Sequential) or not hasattr(self, 'state_vect_dim'): return None
         if sequencer.merged_batches(0, 1) is None: return None
+        # the plan depends on the batches (rebuilt batches = a new graph_tensors list) and on the model's shape only: kept
+        key = (id(sequencer.graph_tensors), len(sequencer), self.state_vect_dim, self.max_iteration, self.native_flags, self._focus,
+               tuple(self.net_state.units), tuple(self.net_state.activations), self.net_state.input_dim, str(device))
+        hit = getattr(self, '_plan_cache', None)
+        if hit is not None and hit[0] == key and hit[1] is sequencer.graph_tensors: return hit[2]
+        plan = self._make_group_plan(sequencer, device)
+        self._plan_cache = (key, sequencer.graph_tensors, plan)
+        return plan
+
+    def _make_group_plan(self, sequencer, device):
         try:
             sizes = [int(sequencer[i][0][0].shape[0]) for i in range(len(sequencer))]
             n_out = [int(sequencer[i][1].shape[0]) for i in range(len(sequencer))]
@@ -226,21 +241,29 @@ class _LoopModel:
             L, A = int(x0[0].shape[1]), int(x0[1].shape[1]) - 2
         except Exception:
             return None
-        cus = torch.cuda.get_device_properties(device).multi_processor_count
-        plan, i0, tiles = [], 0, 0
-        for i, nn in enumerate(sizes):
-            t = (nn + 63) // 64
-            if i > i0 and (tiles + t > cus or i - i0 >= 32):
-                plan.append((i0, i)); i0, tiles = i, 0
-            tiles += t
-        plan.append((i0, len(sizes)))
         focus = nat.FOCUS[self._focus]
-        for i0, i1 in plan:
-            if i1 - i0 < 2: continue
-            begin = [0] + list(np.cumsum(sizes[i0:i1]))
-            if not ops.loop_groups_supported(begin[-1], L, A, self.net_state, self.net_output, self.state_vect_dim, self.max_iteration,
-                                             focus, self.native_flags, sum(n_out[i0:i1]), begin):
-                return None
+        supported = lambda bs: ops.loop_groups_supported(int(sum(sizes[b] for b in bs)), L, A, self.net_state, self.net_output,
+                                                         self.state_vect_dim, self.max_iteration, focus, self.native_flags,
+                                                         sum(n_out[b] for b in bs), [0] + [int(v) for v in np.cumsum([sizes[b] for b in bs])])
+        plan, rest = [], list(range(len(sizes)))
+        biggest = max(rest, key=lambda b: sizes[b])
+        if supported([min(rest, key=lambda b: sizes[b])]) == 2:      # one CU per batch, its state in LDS - for those that fit
+            fits = rest if supported([biggest]) == 2 else [b for b in rest if supported([b]) == 2]
+            for c0 in range(0, len(fits), 1024):
+                chunk = fits[c0:c0 + 1024]
+                if len(chunk) >= 2 and supported(chunk) == 2:
+                    plan.append(chunk)
+                    rest = [b for b in rest if b not in set(chunk)]
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        run, tiles = [], 0
+        for b in rest:
+            t = (sizes[b] + 63) // 64
+            if run and (tiles + t > cus or len(run) >= 32):
+                plan.append(run); run, tiles = [], 0
+            run.append(b); tiles += t
+        if run: plan.append(run)
+        for bs in plan:
+            if len(bs) >= 2 and not supported(bs): return None
         return plan
 
     def _batches_concurrently(self, n, fn, device, width=None):

@@ -91,25 +91,28 @@ class MultiGraphSequencer:
         self.graph_tensors = [self.to_graph_tensor(g, self.device) for g in graphs]
         self._items = [None] * len(self.graph_tensors)
 
-    def merged_batches(self, i0: int, i1: int):
-        """(x_list, node_begin) of batches i0 .. i1-1 merged into ONE graph, graphs in the same order (additive; the reference
-        has no counterpart).  `model.call(x_list, groups=node_begin)` runs the i1 - i0 batches as independent loops of one
-        launch - each batch converges and stops on its own, as if called alone - which is how predict() / evaluate() fill the
-        GPU with small batches.  None when a bigger merge would change the operands: 'normalized' divides by the number
-        of arcs of the merged graph (graph_class.py buildArcNode).  Cached until the batches are rebuilt."""
+    def merged_batches(self, i0: int, i1: int = None):
+        """(x_list, node_begin) of batches i0 .. i1-1 - or of the batches in the list `i0` - merged into ONE graph, graphs in the
+        same order (additive; the reference has no counterpart).  `model.call(x_list, groups=node_begin)` runs those batches as
+        independent loops of one launch - each batch converges and stops on its own, as if called alone - which is how
+        predict() / evaluate() fill the GPU with small batches.  None when a bigger merge would change the operands:
+        'normalized' divides by the number of arcs of the merged graph (graph_class.py buildArcNode).  Cached
+        until the batches are rebuilt."""
         if self.aggregation_mode == 'normalized' or type(self).merge.__func__ is not MultiGraphSequencer.merge.__func__: return None
-        key = (int(i0), int(i1))
+        batches = [int(b) for b in i0] if i1 is None else list(range(int(i0), int(i1)))
+        key = tuple(batches) if i1 is None else (int(i0), int(i1))
         cache = self.__dict__.setdefault('_merged', {})
         if cache.get('owner') is not self.graph_tensors: cache.clear(); cache['owner'] = self.graph_tensors
         if key not in cache:
-            graphs = self.data[i0 * self.batch_size: i1 * self.batch_size]
+            of = lambda b: self.data[b * self.batch_size: (b + 1) * self.batch_size]
+            graphs = [g_ for b in batches for g_ in of(b)]
             ds = self._device_dataset()
             if ds is not None:
                 index = self._dataset[2]
                 g = ds.assemble([index[id(g_)] for g_ in graphs])
             else:
                 g = self.to_graph_tensor(self.merge(graphs, focus=self.focus, aggregation_mode=self.aggregation_mode), self.device)
-            sizes = [sum(int(g_.nodes.shape[0]) for g_ in self.data[i * self.batch_size: (i + 1) * self.batch_size]) for i in range(i0, i1)]
+            sizes = [sum(int(g_.nodes.shape[0]) for g_ in of(b)) for b in batches]
             cache[key] = (self._x_list(g), [0] + [int(v) for v in np.cumsum(sizes)])
         return cache[key]
 

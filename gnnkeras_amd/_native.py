@@ -23,7 +23,7 @@ ACTIVATIONS = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'tanh': 3, 'sigmoid':
 FOCUS = {'n': 0, 'a': 1, 'g': 2}
 FLAG_UNFUSED = 1
 FLAG_NO_EARLY_EXIT = 2
-FLAG_FUSED_GEN2, FLAG_FUSED_GEN4, FLAG_FUSED_GEN5, FLAG_FUSED_GEN6 = 2 << 4, 4 << 4, 5 << 4, 6 << 4     # pin the fused-kernel generation (tests, tuning)
+FLAG_FUSED_GEN2, FLAG_FUSED_GEN4, FLAG_FUSED_GEN5, FLAG_FUSED_GEN6, FLAG_FUSED_GEN7 = 2 << 4, 4 << 4, 5 << 4, 6 << 4, 7 << 4     # pin the fused-kernel generation (tests, tuning)
 
 EXPORTS = ['gnn_last_error', 'gnn_last_kernel_name', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_loop_groups_supported', 'gnn_aggregate',
            'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_ld',

@@ -23,6 +23,7 @@
 #include "kernel_state_fused4.hpp"
 #include "kernel_state_small.hpp"
 #include "kernel_state_mid.hpp"
+#include "kernel_state_lds.hpp"
 #include "kernel_state_wide.hpp"
 #include "kernels_batch.hpp"
 #include "kernels_setup.hpp"
@@ -329,6 +330,8 @@ struct Plan {
     gnn::GroupTab gt;                // convergence groups (one group = the whole graph when the caller gave none)
     int n_groups;                    // the caller's n_groups (0: k_out is one float)
     int group_tiles;                 // 64-node tiles when no tile straddles a group
+    int group_max_nodes;             // nodes of the largest group
+    int *d_group_tabs;               // device copies of group_node_begin / 64-node-tile offsets, [n_groups + 1] each (n_groups > 0)
     int *pred0;                      // state_0's predicate, one word per 64-node tile (written by k_setup_small, read by k_state_small)
     int *err;                        // sticky "an in-launch wait expired" word of the fused kernels, folded into k at the end
     float *agg_arcs, *agg_nodes; int ld_agg_nodes;
@@ -386,25 +389,25 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     if (p.M < 0) return fail("n_out < 0");
     static_assert(gnn::MAX_GROUPS == GNN_MAX_GROUPS, "group table of the kernels and the header differ");
     p.n_groups = a.n_groups;
-    if (a.n_groups < 0 || a.n_groups > GNN_MAX_GROUPS) return fail("n_groups %d out of [0,%d]", a.n_groups, GNN_MAX_GROUPS);
+    if (a.n_groups < 0 || a.n_groups > GNN_MAX_GROUPS_RESIDENT) return fail("n_groups %d out of [0,%d]", a.n_groups, GNN_MAX_GROUPS_RESIDENT);
     if (a.n_groups > 0) {
         if (p.composite) return fail("convergence groups are not supported for composite graphs");
         if (!a.group_node_begin) return fail("group_node_begin is NULL");
         if (a.group_node_begin[0] != 0 || a.group_node_begin[a.n_groups] != a.n_nodes) return fail("group_node_begin must span [0, n_nodes]");
-        p.gt.n = a.n_groups;
+        p.gt.n = a.n_groups <= GNN_MAX_GROUPS ? a.n_groups : 0;
         for (int g = 0; g < a.n_groups; ++g) {
             const int nb = a.group_node_begin[g], ne = a.group_node_begin[g + 1];
             if (ne <= nb) return fail("group %d is empty or group_node_begin is not ascending", g);
-            p.gt.node_begin[g] = nb; p.gt.tile_begin[g] = p.group_tiles;
+            if (g < GNN_MAX_GROUPS && p.gt.n) { p.gt.node_begin[g] = nb; p.gt.tile_begin[g] = p.group_tiles; }
             p.group_tiles += (ne - nb + 63) / 64;
+            p.group_max_nodes = std::max(p.group_max_nodes, ne - nb);
         }
-        p.gt.node_begin[a.n_groups] = a.n_nodes; p.gt.tile_begin[a.n_groups] = p.group_tiles;
+        if (p.gt.n) { p.gt.node_begin[a.n_groups] = a.n_nodes; p.gt.tile_begin[a.n_groups] = p.group_tiles; }
     } else {
         p.gt.n = 1; p.gt.node_begin[0] = 0; p.gt.node_begin[1] = a.n_nodes;
         p.group_tiles = (a.n_nodes + 63) / 64;
         p.gt.tile_begin[0] = 0; p.gt.tile_begin[1] = p.group_tiles;
     }
-
     int sum_dt = 0;
     for (int t = 0; t < p.T; ++t) {
         TRY(check_mlp(a.net_state[t], "net_state", validate_ptrs));
@@ -468,7 +471,8 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     p.flags = c.take<int>(a.max_iteration + GNN_LOOP_WORDS);   // behind the flags: the persistent kernel's two 64-bit barrier counters, the error word
     p.err = p.flags ? p.flags + a.max_iteration + 12 : nullptr;
     p.mid_bar = p.flags ? p.flags + ((a.max_iteration + 16 + 31) & ~31) : nullptr;
-    p.pred0 = c.take<int>(GNN_SMALL_MAX_TILES);
+    p.pred0 = c.take<int>(std::max(GNN_SMALL_MAX_TILES, p.group_tiles));
+    p.d_group_tabs = c.take<int>(a.n_groups > 0 ? 2 * ((size_t)a.n_groups + 1) : 0);
     for (int t = 0; t < p.T; ++t) {
         p.tp[t].Wf = c.take<float>((size_t)a.net_state[t].in_dim * a.net_state[t].units[0]);
         p.tp[t].bf = c.take<float>(a.net_state[t].units[0]);
@@ -658,6 +662,9 @@ int setup_small(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     if (a.net_output.kernel[0]) { fl.add(a.net_output, p.Wf_out, p.bf_out); sa.out = fl.fa.job[1]; }
     const int L = a.state_dim > 0 ? p.L : 0;
     sa.N = p.N; sa.n_tiles = p.group_tiles; sa.groups = p.gt;
+    if (p.n_groups > GNN_MAX_GROUPS || (p.n_groups > 0 && p.gt.n == 0)) {     // many groups: the tables uploaded by the caller of this function
+        sa.groups.d_node_begin = p.d_group_tabs; sa.groups.d_tile_begin = p.d_group_tabs + (p.n_groups + 1); sa.groups.n_dev = p.n_groups;
+    }
     sa.nodes = a.nodes; sa.ld_nodes = a.ld_nodes; sa.L = L;
     sa.nodes_src = a.nodes_src ? a.nodes_src : a.nodes; sa.ld_nodes_src = a.nodes_src ? a.ld_nodes_src : a.ld_nodes;
     sa.adj = gnn::SetupCsr{a.adjacency.rowptr, a.adjacency.src, a.adjacency.w, a.adjacency.row_scale};
@@ -914,6 +921,36 @@ int loop_mid(const gnn_loop_args_t &a, const Plan &p, const float *first, float 
     return rc;
 }
 
+// Groups whose whole state fits the LDS of one CU: one workgroup per group, no grid barrier (kernel_state_lds.hpp).
+bool lds_applies(const gnn_loop_args_t &a, const Plan &p) {
+    const int pinned = (a.flags & GNN_FLAG_FUSED_GEN_MASK) >> 4;
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("GNN_FUSED_KERNEL"); env = e ? atoi(e) : 0; }
+    if ((pinned != 0 && pinned != 7) || (pinned == 0 && env != 0 && env != 7)) return false;
+    if (p.n_groups < 1 || p.composite || p.n_heavy != 0 || a.max_iteration < 1 || (p.SP != 16 && p.SP != 32)) return false;
+    if (a.net_state[0].n_layers != 1 || a.net_state[0].activation[0] == GNN_ACT_SOFTMAX || (a.flags & GNN_FLAG_UNFUSED)) return false;
+    return gnn::lds_group_fits(p.group_max_nodes, p.SP);
+}
+
+int loop_lds(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
+    gnn::LdsArgs la;
+    memset(&la, 0, sizeof(la));
+    la.node_begin = p.d_group_tabs; la.tile64_begin = p.d_group_tabs + (p.n_groups + 1);
+    la.pred0 = p.pred0;
+    la.rowptr = a.adjacency.rowptr; la.src = a.adjacency.src; la.w = a.adjacency.w; la.row_scale = a.adjacency.row_scale;
+    la.state0 = a.state_dim > 0 ? a.state0 : a.nodes; la.ld_s0 = a.state_dim > 0 ? p.S : a.ld_nodes;
+    la.C = p.C; la.ldC = p.ldC;
+    la.Wf = p.tp[0].Wf; la.wrow_state = p.tp[0].wrow_state; la.wrow_agg = p.tp[0].wrow_agg;
+    la.H = a.net_state[0].units[0]; la.act = a.net_state[0].activation[0];
+    la.S = p.S; la.max_iteration = a.max_iteration; la.no_exit = (a.flags & GNN_FLAG_NO_EARLY_EXIT) != 0;
+    la.thr = a.state_threshold;
+    la.stage = p.buf[0];
+    la.state_out = a.state_out; la.k_out = a.k_out;
+    const int rc = gnn::launch_lds(la, p.SP, p.n_groups, gnn::lds_state_bytes(p.group_max_nodes, p.SP), st);
+    if (rc == 1) return fail("LDS-resident loop kernel: launch failed (%s)", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
 // 0: un-fused kernels; 1: any fused kernel; 2: two-layer state networks - only the wave-specialised kernel and the
 // persistent whole-loop kernel carry the second Dense; 3: state width 65 .. 128 - the wide kernel, whatever generation is pinned.
 int fusable(const gnn_loop_args_t &a, const Plan &p) {
@@ -992,6 +1029,27 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     // Graphs the whole-loop kernel covers: one set-up launch, the loop, the output stage.  Everything else: the general
     // set-up (one launch per constant) and one launch per iteration.
     const int fz = fusable(a, p);
+    // Groups that fit the LDS of one CU: set-up launch, one workgroup per group, output stage.
+    if (p.n_groups > 0 && fz == 1 && lds_applies(a, p) && setup_small_applies(a, p)) {
+        std::vector<int> tabs(2 * ((size_t)p.n_groups + 1));
+        int tiles = 0;
+        for (int g = 0; g <= p.n_groups; ++g) {
+            tabs[g] = a.group_node_begin[g];
+            tabs[p.n_groups + 1 + g] = tiles;
+            if (g < p.n_groups) tiles += (a.group_node_begin[g + 1] - a.group_node_begin[g] + 63) / 64;
+        }
+        // pageable source: the runtime stages the bytes before the call returns, `tabs` may go out of scope afterwards
+        HIP_OK(hipMemcpyAsync(p.d_group_tabs, tabs.data(), tabs.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        Plan q = p;
+        q.gt.n = 0;                                 // the set-up kernel reads the device tables
+        TRY(setup_small(a, q, st));
+        if (a.ev_loop_begin) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_begin, st));
+        const int rc = loop_lds(a, p, st);
+        if (rc != 0) return rc == 2 ? fail("LDS-resident loop kernel does not cover this shape") : 1;
+        if (a.ev_loop_end) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_end, st));
+        return output_stage(a, p, st);
+    }
+    if (p.n_groups > GNN_MAX_GROUPS) return fail("more than %d convergence groups need every group to fit one CU's LDS (gnn_loop_groups_supported() != 2)", GNN_MAX_GROUPS);
     const bool whole_loop = fz != 0 && persistent_applies(a, p);
     const bool small_setup = whole_loop && setup_small_applies(a, p);
     if (p.n_groups > 0 && !small_setup) return fail("convergence groups need the whole-loop kernel (gnn_loop_groups_supported() == 0 for these args)");
@@ -1059,7 +1117,10 @@ int gnn_loop_groups_supported(const gnn_loop_args_t *args) {
     if (!args || args->n_groups < 1) return 0;
     Plan p;
     if (make_plan(*args, nullptr, p, false)) return 0;
-    return fusable(*args, p) != 0 && persistent_applies(*args, p) && setup_small_applies(*args, p) ? 1 : 0;
+    const int fz = fusable(*args, p);
+    if (fz == 1 && lds_applies(*args, p) && setup_small_applies(*args, p)) return 2;
+    if (args->n_groups > GNN_MAX_GROUPS) return 0;
+    return fz != 0 && persistent_applies(*args, p) && setup_small_applies(*args, p) ? 1 : 0;
 }
 
 int gnn_aggregate(const gnn_csr_t *csr, const float *X, int32_t ldx, int32_t F, float *out, int32_t ldo, void *stream) {

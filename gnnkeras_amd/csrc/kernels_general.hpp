@@ -463,9 +463,21 @@ struct GroupTab {
     int n;                               // 0: no groups (one loop over everything)
     int node_begin[MAX_GROUPS + 1];
     int tile_begin[MAX_GROUPS + 1];
+    // more than MAX_GROUPS groups (one workgroup per group, kernel_state_lds.hpp): the same two tables in device memory,
+    // [n_dev + 1] each, searched by bisection; n is then unused
+    const int *d_node_begin, *d_tile_begin;
+    int n_dev;
 };
 struct GroupOfTile { int grp, node0, node_end, tile0, tile1; };
 __device__ __forceinline__ GroupOfTile group_of_tile(const GroupTab &gt, int tile) {
+    if (gt.d_tile_begin) {               // largest g with tile_begin[g] <= tile
+        int lo = 0, hi = gt.n_dev - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (gt.d_tile_begin[mid] <= tile) lo = mid; else hi = mid - 1;
+        }
+        return GroupOfTile{lo, gt.d_node_begin[lo], gt.d_node_begin[lo + 1], gt.d_tile_begin[lo], gt.d_tile_begin[lo + 1]};
+    }
     GroupOfTile r{0, gt.node_begin[0], gt.node_begin[1], gt.tile_begin[0], gt.tile_begin[1]};
 #pragma unroll
     for (int g = 1; g < MAX_GROUPS; ++g)

@@ -204,7 +204,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> loop_forward(
     // independent convergence groups: batches merged into one call, each stopping on its own (k becomes [n_groups])
     std::vector<int32_t> groups(group_node_begin.begin(), group_node_begin.end());
     if (!groups.empty()) {
-        TORCH_CHECK(groups.size() >= 2 && groups.size() <= GNN_MAX_GROUPS + 1, "group_node_begin: between 2 and ", GNN_MAX_GROUPS + 1, " entries");
+        TORCH_CHECK(groups.size() >= 2 && groups.size() <= (size_t)GNN_MAX_GROUPS_RESIDENT + 1, "group_node_begin: between 2 and ", GNN_MAX_GROUPS_RESIDENT + 1, " entries");
         a.group_node_begin = groups.data(); a.n_groups = (int32_t)groups.size() - 1;
     }
 
@@ -232,7 +232,7 @@ void mlp_shape_of(gnn_mlp_t &m, at::IntArrayRef spec, const char *name) {
 }
 
 // May `loop_forward(..., group_node_begin)` run these batches as independent loops of one call?  (shapes only, no tensors)
-bool loop_groups_supported(int64_t n_nodes, int64_t dim_node_label, int64_t dim_arc_label, at::IntArrayRef net_state_spec,
+int64_t loop_groups_supported(int64_t n_nodes, int64_t dim_node_label, int64_t dim_arc_label, at::IntArrayRef net_state_spec,
                            at::IntArrayRef net_output_spec, int64_t state_dim, int64_t max_iteration, int64_t focus, int64_t flags,
                            int64_t n_out, at::IntArrayRef group_node_begin) {
     gnn_loop_args_t a{};
@@ -244,9 +244,9 @@ bool loop_groups_supported(int64_t n_nodes, int64_t dim_node_label, int64_t dim_
     a.state_dim = (int32_t)state_dim; a.max_iteration = (int32_t)max_iteration; a.focus = (int32_t)focus; a.flags = (int32_t)flags;
     a.n_out = (int32_t)n_out;
     std::vector<int32_t> groups(group_node_begin.begin(), group_node_begin.end());
-    if (groups.size() < 2 || groups.size() > GNN_MAX_GROUPS + 1) return false;
+    if (groups.size() < 2 || groups.size() > (size_t)GNN_MAX_GROUPS_RESIDENT + 1) return 0;
     a.group_node_begin = groups.data(); a.n_groups = (int32_t)groups.size() - 1;
-    return gnn_loop_groups_supported(&a) != 0;
+    return gnn_loop_groups_supported(&a);
 }
 
 at::Tensor aggregate(const OptTensorList &csr, at::IntArrayRef dims, const at::Tensor &X) {
@@ -330,7 +330,7 @@ TORCH_LIBRARY(gnnkeras, m) {
           "int[] type_offsets, int[] type_dim_label, Tensor?[] composite_adjacency, int[] composite_dims, int[] loop_events, "
           "int[] group_node_begin=[]) -> (Tensor k, Tensor state, Tensor out)");
     m.def("loop_groups_supported(int n_nodes, int dim_node_label, int dim_arc_label, int[] net_state_spec, int[] net_output_spec, "
-          "int state_dim, int max_iteration, int focus, int flags, int n_out, int[] group_node_begin) -> bool", &loop_groups_supported);
+          "int state_dim, int max_iteration, int focus, int flags, int n_out, int[] group_node_begin) -> int", &loop_groups_supported);
     m.def("aggregate(Tensor?[] csr, int[] dims, Tensor X) -> Tensor");
     m.def("pool(Tensor?[] nodegraph, int[] dims, Tensor out_nodes) -> Tensor");
     m.def("converged(Tensor state, Tensor? state_old, float threshold) -> Tensor");

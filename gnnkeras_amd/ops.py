@@ -93,11 +93,11 @@ def loop_forward(nodes, arcs, adjacency, arcnode, nodegraph, net_state, net_outp
 
 def loop_groups_supported(n_nodes, dim_node_label, dim_arc_label, net_state, net_output, state_dim, max_iteration, focus, flags,
                           n_out, groups):
-    """May these merged batches run as independent loops of ONE call?  (shapes only: include/gnnloop.h,
-    gnn_loop_groups_supported)"""
+    """May these merged batches run as independent loops of ONE call?  0 no, 1 spread over the CUs (<= 32 groups), 2 one CU
+    per group with its state in LDS (any number of groups).  (shapes only: include/gnnloop.h, gnn_loop_groups_supported)"""
     _, ss = net_args(net_state, None, shape_only=True)
     _, os_ = net_args(net_output, None, shape_only=True)
-    return bool(load().loop_groups_supported(int(n_nodes), int(dim_node_label), int(dim_arc_label), ss, os_, int(state_dim),
+    return int(load().loop_groups_supported(int(n_nodes), int(dim_node_label), int(dim_arc_label), ss, os_, int(state_dim),
                                              int(max_iteration), int(focus), int(flags), int(n_out), [int(v) for v in groups]))
 
 

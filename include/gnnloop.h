@@ -39,11 +39,12 @@ enum gnn_flags {
     GNN_FLAG_UNFUSED = 1,      /* run the iteration as separate aggregate / dense / predicate kernels            */
     GNN_FLAG_NO_EARLY_EXIT = 2,/* debugging: ignore the convergence predicate (always max_iteration iterations)  */
     /* testing / tuning: pin the generation of the fused iteration kernel instead of the size-based choice
-     * (2 = phase-alternating, 4 = wave-specialised, 5 = whole loop in one persistent launch,
-     * small graphs only - falls back to the size-based choice when it does not apply).  Results are the same within float32
+     * (2 = phase-alternating, 4 = wave-specialised, 5 = whole loop in one persistent launch, small graphs only, 6 = the same
+     * with several tiles per workgroup, 7 = convergence groups with one CU per group and its state in LDS - each falls back to
+     * the size-based choice when it does not apply).  Results are the same within float32
      * summation order; the GNN_FUSED_KERNEL environment variable has the same effect process-wide. */
     GNN_FLAG_FUSED_GEN2 = 2 << 4, GNN_FLAG_FUSED_GEN4 = 4 << 4,
-    GNN_FLAG_FUSED_GEN5 = 5 << 4, GNN_FLAG_FUSED_GEN6 = 6 << 4, GNN_FLAG_FUSED_GEN_MASK = 7 << 4
+    GNN_FLAG_FUSED_GEN5 = 5 << 4, GNN_FLAG_FUSED_GEN6 = 6 << 4, GNN_FLAG_FUSED_GEN7 = 7 << 4, GNN_FLAG_FUSED_GEN_MASK = 7 << 4
 };
 
 /* A sparse operator A (n_src x n_dst, COO in the reference: tf.SparseTensor) stored as the CSR of its transpose:
@@ -156,9 +157,10 @@ typedef struct gnn_loop_args {
      * a separate call on that batch alone.  Supported where the whole-loop kernel applies (gnn_loop_groups_supported);
      * everything before and after the loop (constants, output network, pooling) is per node / per graph anyway. */
     const int32_t *group_node_begin;   /* HOST array [n_groups + 1], ascending, [0] = 0, [n_groups] = n_nodes         */
-    int32_t n_groups;                  /* <= GNN_MAX_GROUPS                                                           */
+    int32_t n_groups;                  /* see gnn_loop_groups_supported                                                */
 } gnn_loop_args_t;
-#define GNN_MAX_GROUPS 32
+#define GNN_MAX_GROUPS 32                 /* groups of a call that spreads every group over several CUs                  */
+#define GNN_MAX_GROUPS_RESIDENT (1 << 20) /* groups of a call that keeps every group's state in the LDS of one CU        */
 
 const char *gnn_last_error(void);
 /* Name (with template arguments) of the state-transition kernel this thread launched last, e.g.
@@ -175,9 +177,12 @@ size_t gnn_loop_workspace_bytes(const gnn_loop_args_t *args);
 
 /* (k, state, out) = Loop(...)  — see gnn_loop_args. */
 int gnn_loop_forward(const gnn_loop_args_t *args);
-/* 1 when gnn_loop_forward accepts these args with n_groups > 0 (homogeneous model, one- or two-layer state network of
- * width <= 64, every group's 64-node tiles resident at once: sum_g ceil(nodes_g / 64) <= CUs), else 0: the caller then
- * runs one call per batch.  Reads dims, flags and the host group array only. */
+/* Non-zero when gnn_loop_forward accepts these args with n_groups > 0, else 0 (the caller then runs one call per batch).
+ *   2: every group's state fits the LDS of one CU (nodes_g * padded width * 4 <= 156 KB, width <= 32, one-layer state network):
+ *      one workgroup per group, any number of groups up to GNN_MAX_GROUPS_RESIDENT - the more the better, 256 run at once;
+ *   1: homogeneous model, one- or two-layer state network of width <= 64, at most GNN_MAX_GROUPS groups whose 64-node tiles are
+ *      all resident at once: sum_g ceil(nodes_g / 64) <= CUs.
+ * Reads dims, flags and the host group array only. */
 int gnn_loop_groups_supported(const gnn_loop_args_t *args);
 
 /* out[j, 0:F] = sum_{e in row j} w_e * X[src_e, 0:F]   == tf.sparse.sparse_dense_matmul(A, X, adjoint_a=True)

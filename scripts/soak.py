@@ -49,15 +49,18 @@ d = 32
 inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d); ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=0)
 inp, lay = get_inout_dims('output', 14, 3, 2, 'g', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
 gnn = GNNgraphBased(ns, no, d, 30, 0.02)
+gnn.native_flags = nat.FLAG_FUSED_GEN5          # the form that spreads a group over several CUs: bit-equal to the single calls
 t0 = time.time(); n = 0
 for rep in range(reps):
-    for i0, i1 in gnn._group_plan(seq, torch.device('cuda', 0)):
-        if i1 - i0 < 2: continue
-        x, begin = seq.merged_batches(i0, i1)
+    for bs in gnn._group_plan(seq, torch.device('cuda', 0)):
+        if len(bs) < 2: continue
+        i0 = bs[0]
+        assert bs == list(range(i0, i0 + len(bs)))
+        x, begin = seq.merged_batches(bs)
         s0 = torch.randn((begin[-1], d), device='cuda') * 0.1
         k, st, o = gnn.Loop(*gnn.process_inputs(x), state0=s0, groups=begin)
         r0 = 0
-        for j in range(i1 - i0):
+        for j in range(len(bs)):
             xb = seq[i0 + j][0]
             kb, stb, ob = gnn.Loop(*gnn.process_inputs(xb), state0=s0[begin[j]:begin[j + 1]].contiguous())
             rows = ob.shape[0]

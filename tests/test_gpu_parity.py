@@ -1090,7 +1090,10 @@ def test_convergence_groups_equal_batch_by_batch_calls(mutag_graphs, focus, d, t
     assert begin[-1] == x[0].shape[0] and len(begin) == len(seq) + 1
     from gnnkeras_amd import ops
     assert ops.loop_groups_supported(begin[-1], x[0].shape[1], x[1].shape[1] - 2, ns, no, d, 30, nat.FOCUS[focus], 0, 0, begin)
-    k, st, o = model.Loop(*model.process_inputs(x), state0=dev(np.concatenate([p[3] for p in parts])) if d else None, groups=begin)
+    s0_all = dev(np.concatenate([p[3] for p in parts])) if d else None
+    # the form that spreads every group over several CUs (pinned): bit for bit the batch-by-batch results
+    model.native_flags = nat.FLAG_FUSED_GEN5
+    k, st, o = model.Loop(*model.process_inputs(x), state0=s0_all, groups=begin)
     assert _last_kernel().startswith('k_state_small'), _last_kernel()
     assert k.shape == (len(seq),)
     assert [float(v) for v in k.cpu()] == [p[0] for p in parts]
@@ -1098,10 +1101,54 @@ def test_convergence_groups_equal_batch_by_batch_calls(mutag_graphs, focus, d, t
     assert torch.equal(st, torch.cat([p[1] for p in parts]))
     assert torch.equal(o, torch.cat([p[2] for p in parts]))
     assert np.array_equal(model.check_last_k(), np.array([p[0] for p in parts], np.float32))
+    # the automatic choice: one CU per group with its state in LDS where a group fits (width <= 32, one-layer network) - other
+    # summation orders, so within the parity tolerance instead of bit-equal; same iteration counts
+    model.native_flags = 0
+    k2, st2, o2 = model.Loop(*model.process_inputs(x), state0=s0_all, groups=begin)
+    lds = d <= 32 and hidden is None
+    assert _last_kernel().startswith('k_state_lds' if lds else 'k_state_small'), _last_kernel()
+    assert [float(v) for v in k2.cpu()] == [p[0] for p in parts]
+    assert rel_err(st2.cpu().numpy(), st.cpu().numpy()) <= TOL and rel_err(o2.cpu().numpy(), o.cpu().numpy()) <= TOL
+    k, st, o = k2, st2, o2
     # ... and against the oracle on one of the batches
     i = 3
     k64, st64, o64 = oracle_loop(model, seq[i][0], parts[i][3], np.float64)
     assert float(k[i]) == float(k64) and rel_err(st[begin[i]:begin[i + 1]].cpu().numpy(), st64) <= TOL
+
+
+def test_many_groups_one_cu_each_with_the_state_in_lds(mutag_graphs):
+    """The 136 MUTAG batches (4 337 graphs, 131 k nodes) the way predict() plans them: every batch whose state fits the LDS of one
+    CU in ONE launch, one workgroup per batch (kernel_state_lds.hpp) - all of them at 16-wide states, all but the largest at
+    32-wide - and the rest spread over several CUs each.  Iteration counts, states and outputs against the batch-by-batch calls,
+    two batches against the oracle."""
+    seq = MultiGraphSequencer(mutag_graphs, 'g', 'average', 32, shuffle=False)
+    for d, K_it in ((32, 30), (0, 5)):
+        ns, no = starter_nets('g', d, scale=0.22)
+        model = GNNgraphBased(ns, no, d, K_it, 0.01)
+        rng = np.random.default_rng(1)
+        plan = model._group_plan(seq, torch.device('cuda', 0))
+        assert plan is not None and sorted(b for bs in plan for b in bs) == list(range(len(seq)))
+        assert len(plan[0]) >= (len(seq) if d == 0 else 100), [len(bs) for bs in plan]
+        s0s = [rng.normal(0, 0.1, (seq[i][0][0].shape[0], d)).astype(np.float32) if d else None for i in range(len(seq))]
+        ks_single = {}
+        for li, bs in enumerate(plan):
+            if len(bs) < 2: continue
+            x, begin = seq.merged_batches(bs)
+            k, st, o = model.Loop(*model.process_inputs(x), state0=dev(np.concatenate([s0s[b] for b in bs])) if d else None, groups=begin)
+            assert _last_kernel().startswith('k_state_lds' if li == 0 else 'k_state_small'), (li, _last_kernel())
+            assert k.shape == (len(bs),)
+            r0 = 0
+            for j, b in enumerate(bs):
+                kb, stb, ob = model.Loop(*model.process_inputs(seq[b][0]), state0=None if s0s[b] is None else dev(s0s[b]))
+                ks_single[b] = float(kb)
+                assert float(k[j]) == float(kb), (b, float(k[j]), float(kb))
+                assert rel_err(st[begin[j]:begin[j + 1]].cpu().numpy(), stb.cpu().numpy()) <= TOL, b
+                assert rel_err(o[r0:r0 + ob.shape[0]].cpu().numpy(), ob.cpu().numpy()) <= TOL, b
+                r0 += ob.shape[0]
+            if li == 0:
+                for j in (0, len(bs) - 1):
+                    k64, st64, o64 = oracle_loop(model, seq[bs[j]][0], s0s[bs[j]], np.float64)
+                    assert float(k[j]) == float(k64) and rel_err(st[begin[j]:begin[j + 1]].cpu().numpy(), st64) <= TOL
 
 
 def test_predict_and_evaluate_group_batches(mutag_graphs):
@@ -1119,13 +1166,13 @@ def test_predict_and_evaluate_group_batches(mutag_graphs):
     model.compile(optimizer='adam', loss='categorical_crossentropy', metrics=['accuracy'])
     dev_ = torch.device('cuda', 0)
     plan = model._group_plan(seq, dev_)
-    assert plan is not None and plan[0][1] - plan[0][0] > 1, plan
+    assert plan is not None and len(plan[0]) > 1, plan
     model.group_batches = True
     p1 = model.predict(seq); e1 = model.evaluate(seq, return_dict=True)
     model.group_batches = False
     p0 = model.predict(seq); e0 = model.evaluate(seq, return_dict=True)
-    assert p1.shape == (150, 2) and np.array_equal(p1, p0)
-    assert abs(e1['loss'] - e0['loss']) <= 1e-6 and abs(e1['accuracy'] - e0['accuracy']) <= 1e-6
+    assert p1.shape == (150, 2) and rel_err(p1, p0) <= TOL             # (grouped: one CU per batch, other summation orders)
+    assert abs(e1['loss'] - e0['loss']) <= 1e-5 and abs(e1['accuracy'] - e0['accuracy']) <= 1e-6
     # 'normalized' divides by the merged graph's arc count: never grouped
     seqn = MultiGraphSequencer(gl, 'g', 'normalized', 16, shuffle=False)
     assert seqn.merged_batches(0, 2) is None and model._group_plan(seqn, dev_) is None
@@ -1154,10 +1201,10 @@ def test_starter_configuration_runs_grouped(mutag_graphs):
     plan = model._group_plan(seq, torch.device('cuda', 0))
     assert plan is not None and len(plan) < len(seq), plan
     p1 = model.predict(seq); e1 = model.evaluate(seq, return_dict=True)
-    assert _last_kernel().startswith('k_state_small<16'), _last_kernel()
+    assert _last_kernel().startswith('k_state_lds<16'), _last_kernel()
     model.group_batches = False
     p0 = model.predict(seq); e0 = model.evaluate(seq, return_dict=True)
-    assert np.array_equal(p1, p0) and abs(e1['loss'] - e0['loss']) <= 1e-6 and abs(e1['accuracy'] - e0['accuracy']) <= 1e-6
+    assert rel_err(p1, p0) <= TOL and abs(e1['loss'] - e0['loss']) <= 1e-5 and abs(e1['accuracy'] - e0['accuracy']) <= 1e-6
 
 
 @pytest.mark.parametrize('d,state_dim0,mode', [(64, False, 'average'), (32, False, 'sum'), (20, True, 'average')])

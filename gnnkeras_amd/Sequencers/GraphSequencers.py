@@ -100,7 +100,7 @@ class MultiGraphSequencer:
         until the batches are rebuilt."""
         if self.aggregation_mode == 'normalized' or type(self).merge.__func__ is not MultiGraphSequencer.merge.__func__: return None
         batches = [int(b) for b in i0] if i1 is None else list(range(int(i0), int(i1)))
-        key = tuple(batches) if i1 is None else (int(i0), int(i1))
+        key = tuple(batches)                                    # (a range and the list of its members are the same merge)
         cache = self.__dict__.setdefault('_merged', {})
         if cache.get('owner') is not self.graph_tensors: cache.clear(); cache['owner'] = self.graph_tensors
         if key not in cache:

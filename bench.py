@@ -100,15 +100,15 @@ def mutag_section(device, cpu: bool):
     # whose batches are independent loops of ONE launch (own predicate, own k: include/gnnloop.h group_node_begin)
     plan = gnn._group_plan(seq, device)
     s0_cat = {id(bs): torch.cat([s0s[b] for b in bs]) for bs in (plan or []) if len(bs) > 1}     # (predict() draws state_0 per launch)
-    def grouped(model):
+    def grouped(model):                    # as _LoopModel._forward_batches does: the launches of the plan on side streams
+        def launch(li):
+            bs = plan[li]
+            if len(bs) == 1: return model.Loop(*inputs[bs[0]], state0=s0s[bs[0]])
+            x, begin = seq.merged_batches(bs)
+            return model.Loop(*model.process_inputs(x), state0=s0_cat[id(bs)], groups=begin)
         ks_b = [None] * len(items)
-        for bs in plan:
-            if len(bs) == 1:
-                k, st, o = model.Loop(*inputs[bs[0]], state0=s0s[bs[0]])
-            else:
-                x, begin = seq.merged_batches(bs)
-                k, st, o = model.Loop(*model.process_inputs(x), state0=s0_cat[id(bs)], groups=begin)
-            for j, b in enumerate(bs): ks_b[b] = k.reshape(-1)[j]
+        for li, (k, st, o) in model._batches_concurrently(len(plan), launch, device, min(len(plan), 4)):
+            for j, b in enumerate(plan[li]): ks_b[b] = k.reshape(-1)[j]
         return torch.stack(ks_b)
     t_grp = None
     if plan is not None:

@@ -123,7 +123,8 @@ def mutag_section(device, cpu: bool):
     res = {'workload': 'MUTAG (TU Mutagenicity) 4337 graphs as 136 batches of 32, state_dim=32, max_iteration=50, '
                        'threshold=0.01, graph-focused forward',
            'fwd_ms_per_graph': 1e3 * t_best / n_graphs, 'fwd_ms_per_batch': 1e3 * t_best / len(items),
-           'how': ('grouped launches: %d launch(es), each batch an independent loop (%s)' % (len(plan), nat_kernel())) if t_best == t_grp
+           'how': ('grouped launches: %d (%s), each batch an independent loop: one CU per batch with its state in LDS where it fits, '
+                   'spread over several CUs otherwise' % (len(plan), ' + '.join(str(len(bs)) for bs in plan) + ' batches')) if t_best == t_grp
                   else '%d side streams' % width,
            'grouped_fwd_ms_per_graph': None if t_grp is None else 1e3 * t_grp / n_graphs,
            'side_streams_fwd_ms_per_graph': 1e3 * t_gpu / n_graphs, 'concurrent_batches': width,

@@ -1031,15 +1031,27 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     const int fz = fusable(a, p);
     // Groups that fit the LDS of one CU: set-up launch, one workgroup per group, output stage.
     if (p.n_groups > 0 && fz == 1 && lds_applies(a, p) && setup_small_applies(a, p)) {
-        std::vector<int> tabs(2 * ((size_t)p.n_groups + 1));
+        // the group tables go to the device through a pinned staging buffer of this thread (an asynchronous copy out of pageable
+        // memory would have to outlive this call); its event says when the previous call's copy has left it
+        static thread_local struct { int *buf; size_t cap; hipEvent_t ev; } stage = {nullptr, 0, nullptr};
+        const size_t n_tab = 2 * ((size_t)p.n_groups + 1);
+        if (stage.ev) HIP_OK(hipEventSynchronize(stage.ev));
+        else HIP_OK(hipEventCreateWithFlags(&stage.ev, hipEventDisableTiming));
+        if (stage.cap < n_tab) {
+            if (stage.buf) HIP_OK(hipHostFree(stage.buf));
+            stage.buf = nullptr; stage.cap = 0;
+            HIP_OK(hipHostMalloc((void **)&stage.buf, std::max<size_t>(n_tab, 4096) * sizeof(int), hipHostMallocDefault));
+            stage.cap = std::max<size_t>(n_tab, 4096);
+        }
+        int *tabs = stage.buf;
         int tiles = 0;
         for (int g = 0; g <= p.n_groups; ++g) {
             tabs[g] = a.group_node_begin[g];
             tabs[p.n_groups + 1 + g] = tiles;
             if (g < p.n_groups) tiles += (a.group_node_begin[g + 1] - a.group_node_begin[g] + 63) / 64;
         }
-        // pageable source: the runtime stages the bytes before the call returns, `tabs` may go out of scope afterwards
-        HIP_OK(hipMemcpyAsync(p.d_group_tabs, tabs.data(), tabs.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(p.d_group_tabs, tabs, n_tab * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_OK(hipEventRecord(stage.ev, st));
         Plan q = p;
         q.gt.n = 0;                                 // the set-up kernel reads the device tables
         TRY(setup_small(a, q, st));

@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernel_state_fused2.hpp"
+#include "kernel_state_fused4.hpp"      // activate4
 #include "buffer_ops.hpp"
 
 namespace gnn {
@@ -46,6 +47,16 @@ struct LdsArgs {
     float *state_out;               // [N, S] compact
     float *k_out;                   // [n_groups]
 };
+
+// Sum over the 16 lanes of a DPP row, complete in lane 15 of the row (row_shr 1, 2, 4, 8 with out-of-row reads as zero): four
+// VALU adds instead of four LDS permutes + adds per value.
+__device__ __forceinline__ float row16_sum_to_lane15(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));
+    return x;
+}
 
 // One node's CSR row as the loop needs it, 16 bytes in LDS: in-degree, row scale, the first 4 source ids (local, 16 bit each).
 struct LdsRec { unsigned id01, id23; int deg; float scale; };
@@ -100,13 +111,16 @@ __global__ void __launch_bounds__(64 * LDS_NW, 4) k_state_lds(LdsArgs a) {
     }
     __syncthreads();
 
+    // (the kernel is bound by its instruction count, not by the matrix pipe: 32-bit offsets off scalar bases, predicated-off
+    // loads, one activation switch per 4 values)
+    const __amdgpu_buffer_rsrc_t r_C = buf_rsrc(a.C + (size_t)nb * a.ldC), r_stage = buf_rsrc(a.stage + (size_t)nb * SP);
     auto load_c = [&](int t, f32x4 *c) {            // the per-node constant C of tile t in accumulator layout (row 4 g + reg, column 16 ct + r)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int rl = 16 * t + 4 * g + reg, col = 16 * ct + r;
-                c[ct][reg] = (rl < n && col < a.H) ? a.C[(size_t)(nb + rl) * a.ldC + col] : 0.0f;
+                c[ct][reg] = buf_ld_f32(r_C, (rl < n && col < a.H) ? ((unsigned)rl * (unsigned)a.ldC + (unsigned)col) * 4u : BUF_OFF);
             }
     };
 
@@ -174,30 +188,39 @@ __global__ void __launch_bounds__(64 * LDS_NW, 4) k_state_lds(LdsArgs a) {
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) agg[q] *= rec.scale;
+            // four independent MFMA chains instead of two: the state half accumulates onto C, the agg half onto zero, summed at the end
+            f32x4 c2[NCT];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int half = ks / (SP / 4), qe = ks % (SP / 4);
-                const float av = half ? agg[qe / 4][qe & 3] : own[qe / 4][qe & 3];
+            for (int ct = 0; ct < NCT; ++ct) c2[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) c[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wreg[ks][ct], c[ct], 0, 0, 0);
+            for (int qe = 0; qe < SP / 4; ++qe) {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    c[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(own[qe / 4][qe & 3], wreg[qe][ct], c[ct], 0, 0, 0);
+                    c2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(agg[qe / 4][qe & 3], wreg[SP / 4 + qe][ct], c2[ct], 0, 0, 0);
+                }
             }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) c[ct] += c2[ct];
             // activation + predicate against the old rows (still in LDS); the new rows leave for the staging buffer
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) activate4(a.act, c[ct]);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int rl = 16 * t + 4 * g + reg;
+                const bool rin = rl < n;
                 float d2 = 0.0f, n2 = 0.0f;
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     const int col = 16 * ct + r;
-                    const float v = (rl < n && col < S) ? activate(a.act, c[ct][reg]) : 0.0f;
-                    const float o = rl < n ? St[rl * SP + col] : 0.0f;
+                    const float v = (rin && col < S) ? c[ct][reg] : 0.0f;
+                    const float o = rin ? St[rl * SP + col] : 0.0f;
                     const float d = v - o;
                     d2 = fmaf(d, d, d2); n2 = fmaf(o, o, n2);
-                    if (rl < n) a.stage[(size_t)(nb + rl) * SP + col] = v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r_stage, rin ? (int)(((unsigned)rl * SP + col) * 4u) : (int)BUF_OFF, 0, 0);
                 }
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) { d2 += __shfl_xor(d2, off, 16); n2 += __shfl_xor(n2, off, 16); }
-                if (rl < n && sqrtf(d2) > a.thr * sqrtf(n2)) any = 1;
+                d2 = row16_sum_to_lane15(d2); n2 = row16_sum_to_lane15(n2);
+                if (rin && r == 15 && sqrtf(d2) > a.thr * sqrtf(n2)) any = 1;
             }
         }
         if (tid == 0) moving_s = 0;
@@ -206,7 +229,7 @@ __global__ void __launch_bounds__(64 * LDS_NW, 4) k_state_lds(LdsArgs a) {
         if (any) moving_s = 1;                                                 // benign race: every writer stores 1
         {   // staged rows back into LDS: sc1 loads, served by the L2 the stores went to (the CU's L1 may still hold last
             // iteration's lines of the staging buffer)
-            const __amdgpu_buffer_rsrc_t rs = buf_rsrc(a.stage + (size_t)nb * SP);
+            const __amdgpu_buffer_rsrc_t rs = r_stage;
             for (int i = tid; i < n * (SP / 4); i += 64 * LDS_NW) {
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, 16);
                 *reinterpret_cast<u32x4 *>(St + 4 * i) = v;

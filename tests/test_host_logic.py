@@ -238,3 +238,25 @@ def test_split_heavy_rows_reconstructs_the_aggregate():
     cu = CSRByDestination.from_coo(pairs[:, 0], pairs[:, 1], (1.0 / deg[pairs[:, 1]]).astype(np.float32), (n, n))
     lu, hu = split_heavy(cu, threshold=20, segment=16)
     assert cu.w is None and lu.w is None and lu.row_scale is cu.row_scale
+
+
+def test_merged_batches_for_convergence_groups(mutag_graphs):
+    """`MultiGraphSequencer.merged_batches`: several batches as ONE graph (same arrays as merging their graphs in order) plus
+    the node offsets a model passes as `groups=`; a range and the list of its members are the same merge; 'normalized'
+    aggregation is never merged across batches (its weights depend on the merged graph's arc count)."""
+    gl = [g.copy() for g in mutag_graphs[:40]]
+    seq = MultiGraphSequencer(gl, 'g', 'average', 8, shuffle=False, device='cpu')
+    x, begin = seq.merged_batches([1, 3, 4])
+    graphs = gl[8:16] + gl[24:40]
+    want = GraphObject.merge(graphs, focus='g', aggregation_mode='average')
+    assert begin == [0] + list(np.cumsum([sum(g.nodes.shape[0] for g in gl[8:16]), sum(g.nodes.shape[0] for g in gl[24:32]),
+                                          sum(g.nodes.shape[0] for g in gl[32:40])]))
+    assert np.array_equal(x[0].numpy(), want.nodes.astype(np.float32)) and np.array_equal(x[1].numpy(), want.arcs.astype(np.float32))
+    assert x[7][2][0] == sum(g.nodes.shape[0] for g in graphs) and x[7][2][1] == len(graphs)         # NodeGraph: nodes x graphs
+    xr, br = seq.merged_batches(3, 5)
+    xl, bl = seq.merged_batches([3, 4])
+    assert br == bl and xr is xl                                      # one cache entry
+    assert MultiGraphSequencer(gl, 'g', 'normalized', 8, shuffle=False, device='cpu').merged_batches(0, 2) is None
+    seq.set_batch_size(10)                                            # rebuilt batches: the cache starts over
+    x2, b2 = seq.merged_batches(0, 2)
+    assert b2[-1] == sum(g.nodes.shape[0] for g in gl[:20])

@@ -92,21 +92,25 @@ class _LoopModel:
         sum(metric_i * weight_i) / sum(weight_i)."""
         if self.loss is None: raise RuntimeError('compile() the model with a loss before evaluate()')
         lossf = _loss_fn(self.loss)
-        tot_loss = tot_w = None
-        mets = None
-        dev = self._batch_device(sequencer[0][0]) if len(sequencer) else torch.device('cpu')
+        if len(sequencer) == 0: raise ValueError('evaluate() needs at least one batch')
+        dev = self._batch_device(sequencer[0][0])
         self._k_seen = []
-        for i, p in self._forward_batches(sequencer, dev):
-            _, y, sw = sequencer[i]
-            if mets is None:
-                mets = [(n, f, torch.zeros((), device=p.device)) for n, f in (_metric_fn(m, y.shape[-1]) for m in self.metrics_spec)]
-                tot_loss, tot_w = torch.zeros((), device=p.device), torch.zeros((), device=p.device)
-                cnt = torch.zeros((), device=p.device)
-            sw = sw.to(p.device)
-            tot_loss = tot_loss + (lossf(y, p) * sw).sum()
-            tot_w = tot_w + float(sw.shape[0])
-            cnt = cnt + sw.sum()
-            mets = [(n, f, acc + (f(y, p) * sw).sum()) for n, f, acc in mets]
+        # every forward first (grouped launches / side streams), then ONE loss / metric evaluation over all samples: the sums
+        # Keras accumulates batch by batch are the same sums, and a data set of small batches costs a handful of launches
+        # instead of a dozen per batch
+        preds = [p_ for _, p_ in self._forward_batches(sequencer, dev)]
+        p = torch.cat(preds, dim=0) if len(preds) > 1 else preds[0]
+        hit = getattr(self, '_eval_targets', None)
+        owner = getattr(sequencer, 'graph_tensors', None)
+        if hit is None or owner is None or hit[0] is not owner or hit[1] != len(sequencer):
+            ys, sws = zip(*[(sequencer[i][1], sequencer[i][2]) for i in range(len(sequencer))])
+            hit = (owner, len(sequencer), torch.cat([y_.to(p.device) for y_ in ys], dim=0), torch.cat([w_.to(p.device) for w_ in sws], dim=0))
+            self._eval_targets = hit if owner is not None else None
+        y, sw = hit[2], hit[3]
+        tot_loss = (lossf(y, p) * sw).sum()
+        tot_w = float(sw.shape[0])
+        cnt = sw.sum()
+        mets = [(n, f, (f(y, p) * sw).sum()) for n, f in (_metric_fn(m, y.shape[-1]) for m in self.metrics_spec)]
         self._check_k()
         res = {'loss': float(tot_loss / tot_w)}
         for n, f, acc in mets: res[n] = float(acc / cnt)

@@ -100,12 +100,17 @@ class _LoopModel:
         # instead of a dozen per batch
         preds = [p_ for _, p_ in self._forward_batches(sequencer, dev)]
         p = torch.cat(preds, dim=0) if len(preds) > 1 else preds[0]
-        hit = getattr(self, '_eval_targets', None)
+        # targets / sample weights of the whole sequencer, concatenated once per set of batches (a few sequencers per model:
+        # training, validation, test); keyed by the batch list the sequencer rebuilds whenever its batches change
         owner = getattr(sequencer, 'graph_tensors', None)
-        if hit is None or owner is None or hit[0] is not owner or hit[1] != len(sequencer):
+        cache = self.__dict__.setdefault('_eval_targets', {})
+        hit = cache.get(id(owner)) if owner is not None else None
+        if hit is None or hit[0] is not owner or hit[1] != len(sequencer):
             ys, sws = zip(*[(sequencer[i][1], sequencer[i][2]) for i in range(len(sequencer))])
             hit = (owner, len(sequencer), torch.cat([y_.to(p.device) for y_ in ys], dim=0), torch.cat([w_.to(p.device) for w_ in sws], dim=0))
-            self._eval_targets = hit if owner is not None else None
+            if owner is not None:
+                if len(cache) >= 4: cache.clear()
+                cache[id(owner)] = hit
         y, sw = hit[2], hit[3]
         tot_loss = (lossf(y, p) * sw).sum()
         tot_w = float(sw.shape[0])
@@ -231,10 +236,12 @@ class _LoopModel:
         # the plan depends on the batches (rebuilt batches = a new graph_tensors list) and on the model's shape only: kept
         key = (id(sequencer.graph_tensors), len(sequencer), self.state_vect_dim, self.max_iteration, self.native_flags, self._focus,
                tuple(self.net_state.units), tuple(self.net_state.activations), self.net_state.input_dim, str(device))
-        hit = getattr(self, '_plan_cache', None)
-        if hit is not None and hit[0] == key and hit[1] is sequencer.graph_tensors: return hit[2]
+        cache = self.__dict__.setdefault('_plan_cache', {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] is sequencer.graph_tensors: return hit[1]
         plan = self._make_group_plan(sequencer, device)
-        self._plan_cache = (key, sequencer.graph_tensors, plan)
+        if len(cache) >= 4: cache.clear()
+        cache[key] = (sequencer.graph_tensors, plan)
         return plan
 
     def _make_group_plan(self, sequencer, device):

@@ -10,7 +10,7 @@ from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
 gs = load_graphs(limit=32 * 20)
 for g in gs: g.setAggregation('average')
 seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False)
-d, it = 32, 50
+d, it = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 50)
 inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d); ns = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0)
 inp, lay = get_inout_dims('output', 14, 3, 2, 'g', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
 gnn = GNNgraphBased(ns, no, d, it, 0.01)

@@ -35,6 +35,10 @@ sys.path.insert(0, ROOT)
 # predict() / evaluate() overlap independent batches on up to 8 HIP streams; by default HIP multiplexes all streams of
 # a process onto 4 hardware queues.  Must be set before the HIP runtime starts (importing torch does that).
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+# Multi-process GPU work on this image needs dmabuf IPC (RCCL's peer mappings fail with "hipIpcGetMemHandle: invalid argument"
+# under the legacy mode).  The image exports it already; set here as well so that every way of starting ranks - the driver's
+# torch.distributed.run, this file's own child launch below, the tests' subprocesses - runs with the same value.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import numpy as np
 import torch
@@ -107,7 +111,7 @@ def mutag_section(device, cpu: bool):
             x, begin = seq.merged_batches(bs)
             return model.Loop(*model.process_inputs(x), state0=s0_cat[id(bs)], groups=begin)
         ks_b = [None] * len(items)
-        for li, (k, st, o) in model._batches_concurrently(len(plan), launch, device, min(len(plan), 4)):
+        for li, (k, st, o) in model._run_plan(plan, launch, device):
             for j, b in enumerate(plan[li]): ks_b[b] = k.reshape(-1)[j]
         return torch.stack(ks_b)
     t_grp = None
@@ -259,6 +263,58 @@ def beyond_cache_section(device, d, K_it, aggregation):
     return rec
 
 
+def host_rss_mb():
+    with open('/proc/self/status') as f:
+        for line in f:
+            if line.startswith('VmRSS:'): return int(line.split()[1]) / 1024.0
+    return None
+
+
+def emulate_shard(args):
+    """`--emulate-shard r/R`: rank r's share of an R-GPU run of the selected workload on ONE GPU.  The shard is built the way a
+    rank of the real job builds it (from its own `GraphSlice`), runs the real shard kernels against a full-size
+    [R x (N / R + 1), SP] state buffer and never talks to anyone: the exchange is the half of an iteration this cannot
+    measure (DESIGN.md 6 prices it from the xGMI link rate)."""
+    r, R = (int(v) for v in args.emulate_shard.split('/'))
+    if not (0 <= r < R): raise SystemExit('--emulate-shard r/R needs 0 <= r < R')
+    if not torch.cuda.is_available(): raise SystemExit('bench.py needs an MI355X: the message-passing loop has no CPU path')
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    from gnnkeras_amd import _native as nat
+    from gnnkeras_amd.distributed import ShardedLoop, partition
+    from gnnkeras_amd.synth import er_graph_slice
+    from gnnkeras_amd.Models.GNN import GNNnodeBased
+    if args.workload not in ('c4', 'c3'): raise SystemExit('--emulate-shard: workloads c4 / c3')
+    sizes = {'c4': (1e6, 1e7), 'c3': (1e5, 1e6)}[args.workload]
+    N, E = int(args.nodes or sizes[0]), int(args.arcs or sizes[1])
+    d, K_it = args.state_dim, args.max_iteration
+    ns, no = starter_nets(d, device)
+    gnn = GNNnodeBased(ns, no, d, K_it, 0.0)
+    rss0 = host_rss_mb()
+    t0 = time.perf_counter()
+    chunk, ranges = partition(N, R)
+    gs = er_graph_slice(N, E, *ranges[r], aggregation_mode=args.aggregation, seed=1234)
+    t_slice = time.perf_counter() - t0
+    sl = ShardedLoop(gnn, gs, r, R, device, overlap=not args.no_overlap)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t0
+    gen = torch.Generator(device=device); gen.manual_seed(1)
+    s0 = torch.randn((N, d), generator=gen, device=device) * 0.1
+    prof = sl.profile_iteration(s0, reps=max(args.steps, 10), collective=False)
+    kernel_name = nat.lib().gnn_last_kernel_name().decode()
+    b_iter = algorithmic_bytes_per_iteration(sl.n_local, sl.e_local, d, ns.units[0], sl.per_arc_weights)
+    rec = roofline_record(b_iter, prof['kernel_s'], kernel_name, sl.n_local, ns.units[0])
+    print(json.dumps({
+        'emulated_shard': f'{r}/{R}', 'workload': f'{args.workload.upper()} Erdos-Renyi {N} nodes / {E} arcs, state_dim={d}, {args.aggregation}',
+        'n_local': sl.n_local, 'e_local': sl.e_local, 'e_own_range': getattr(sl, 'e_own', None), 'overlap_split': bool(sl.overlap),
+        'per_iteration_ms': {'kernel': 1e3 * prof['kernel_s'],
+                             'note': 'own-range partial + halo kernel (or the one fused kernel with --no-overlap) of rank r, gates open, '
+                                     'no collective: the exchange is not measurable on one GPU'},
+        'exchange_bytes_per_rank_per_iteration': sl.exchange_bytes(),
+        'plan_build_s': t_plan, 'slice_generation_s': t_slice, 'host_rss_mb': host_rss_mb(), 'host_rss_mb_before_plan': rss0,
+        'roofline': rec}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -281,7 +337,13 @@ def main():
                     help='N>1 state exchange: whole slices by RCCL all-gather / by concurrent point-to-point pairs, or compacted halos '
                          '(all-to-all); auto = halo for graphs with locality, else the faster whole-slice transport, measured at start-up')
     ap.add_argument('--no-overlap', action='store_true', help='N>1: exchange strictly after the iteration kernel (no own-range / halo split)')
+    ap.add_argument('--emulate-shard', default=None, metavar='r/R',
+                    help="one GPU, no process group: build rank r's plan of an R-rank job from its own graph slice and time its "
+                         "iteration kernels (own-range partial + halo kernel) against a full-size state buffer; prints plan-build "
+                         "seconds, host RSS and the per-iteration kernel time - the compute half of the N-GPU prediction in DESIGN.md 6")
     args = ap.parse_args()
+    if args.emulate_shard:
+        return emulate_shard(args)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # Start the N ranks as a child torch.distributed.run.  Nothing in this process has touched the GPU (importing torch
@@ -322,6 +384,8 @@ def main():
     composite = args.workload == 'c5'
     on_device = args.workload == 'c4x4'
     if on_device and sharded: raise SystemExit('--workload c4x4 is a single-GPU point (operands are built on one device)')
+    graph_is_slice = False
+    t_graph0 = time.perf_counter()
     if composite:
         dims = (14, 8, 4)
         graph = er_composite_graph(N, E, dim_node_label=dims, aggregation_mode=args.aggregation, seed=1234)
@@ -333,10 +397,19 @@ def main():
         gnn = CompositeGNNnodeBased(nets_s, no, d, K_it, 0.0)
         Sequencer = CompositeMultiGraphSequencer
     else:
-        graph = None if on_device else er_graph(N, E, aggregation_mode=args.aggregation, seed=1234)
+        # a rank of the sharded run generates only ITS slice of the graph (exchange 'auto' / 'allgather' / 'direct'); the compacted
+        # halo exchange derives every peer's pack lists and so needs the replicated GraphObject
+        graph_is_slice = sharded and args.exchange != 'halo'
+        if graph_is_slice:
+            from gnnkeras_amd.distributed import partition
+            from gnnkeras_amd.synth import er_graph_slice
+            graph = er_graph_slice(N, E, *partition(N, world)[1][rank], aggregation_mode=args.aggregation, seed=1234)
+        else:
+            graph = None if on_device else er_graph(N, E, aggregation_mode=args.aggregation, seed=1234)
         ns, no = starter_nets(d, device)
         gnn = GNNnodeBased(ns, no, d, K_it, 0.0)
         Sequencer = MultiGraphSequencer
+    t_graph = time.perf_counter() - t_graph0
     if args.unfused: gnn.native_flags = nat.FLAG_UNFUSED
     if on_device:
         gen = torch.Generator(device=device); gen.manual_seed(1)
@@ -357,8 +430,13 @@ def main():
     else:
         import torch.distributed as dist
         from gnnkeras_amd.distributed import make_sharded_loop
+        t_plan0 = time.perf_counter()
         sl = make_sharded_loop(gnn, graph, rank=rank, world_size=world, device=device, exchange=args.exchange,
                                overlap=not args.no_overlap)
+        torch.cuda.synchronize()
+        extra['plan_build_s'] = (time.perf_counter() - t_plan0) + t_graph
+        extra['host_rss_mb'] = host_rss_mb()
+        extra['graph_source'] = 'per-rank GraphSlice (own destination range only)' if graph_is_slice else 'replicated GraphObject'
         step = lambda: sl.forward(s0)
         per_arc_w = sl.per_arc_weights
 

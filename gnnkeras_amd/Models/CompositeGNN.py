@@ -88,9 +88,30 @@ class CompositeGNNnodeBased(GNNnodeBased):
         """State only, no label concat (reference CompositeGNN.py:237-239)."""
         return state_converged[mask]
 
-    def convergence(self, *args, **kwargs):
-        raise NotImplementedError('a standalone composite step is not exported; use Loop()')
-
+    def convergence(self, k, state, state_old, nodes, dim_node_label, type_mask, adjacency, aggregated_component, training, *,
+                    arcs=None, arcnode=None, composite_adjacencies=None):
+        """One state-transition step of a heterogeneous graph (reference CompositeGNN.py:215-234) through
+        `torch.ops.gnnkeras.state_step`: every node type's network on that type's rows, one fused launch.  The reference threads
+        the pre-aggregated `aggregated_component` through its `tf.while_loop`; the native step folds the iteration constants
+        itself from `arcs` / `arcnode` / `composite_adjacencies` (what `Loop` does once per call), so those are required here.
+        Returns the reference's 9-tuple `(k + 1, state_new, state, nodes, dim_node_label, type_mask, adjacency,
+        aggregated_component, training)`."""
+        if arcs is None or arcnode is None or composite_adjacencies is None:
+            raise ValueError('convergence() needs arcs=, arcnode= and composite_adjacencies= to rebuild the iteration constants on device')
+        self._check_training(bool(training))
+        nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs'); nat.require_device(state, 'state')
+        dev = nodes.device
+        dims = [int(d) for d in (dim_node_label.reshape(-1).tolist() if isinstance(dim_node_label, torch.Tensor)
+                                 else np.asarray(dim_node_label).reshape(-1))]
+        if len(dims) != len(self.net_state): raise ValueError(f'{len(dims)} node types but {len(self.net_state)} state networks')
+        type_nodes, offsets = self._type_lists(_squeeze_last(type_mask).to(dev))
+        adj = SparseMatrix.from_triple(adjacency).device_csr(dev)
+        arcn = SparseMatrix.from_triple(arcnode).device_csr(dev)
+        cas = [SparseMatrix.from_triple(c).device_csr(dev) for c in composite_adjacencies]
+        new, _moving = ops.state_step(nodes.to(torch.float32).contiguous(), arcs.to(torch.float32).contiguous(), adj, arcn, self.net_state,
+                                      state.to(dev, torch.float32).contiguous(), self.state_vect_dim, self.state_threshold,
+                                      self.native_flags, composite=(type_nodes, offsets, dims, cas))
+        return k + 1, new, state, nodes, dim_node_label, type_mask, adjacency, aggregated_component, training
 
 
     def _check_training(self, training):

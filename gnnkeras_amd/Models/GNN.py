@@ -54,6 +54,28 @@ def _metric_fn(metric, n_targets):
     raise ValueError(f'unknown metric {metric!r}')
 
 
+class History(dict):
+    """What `fit` returns: {'loss': [per epoch], 'val_loss': [...], metrics...} - a dict (round-1/2 callers index it
+    directly) that also answers Keras' `History.history` / `History.epoch`."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.epoch = []
+
+    @property
+    def history(self):
+        return self
+
+
+class _Launch(list):
+    """One entry of a group plan: the batches a launch merges.  `resident`: every batch runs as one workgroup with its state
+    in the LDS of one CU (no grid barrier), so the launch may overlap any other."""
+
+    def __init__(self, batches, resident: bool = False):
+        super().__init__(batches)
+        self.resident = resident
+
+
 class _LoopModel:
     """What the reference gets from `tf.keras.Model`: compile / evaluate / predict / fit plumbing around `call`."""
 
@@ -77,8 +99,9 @@ class _LoopModel:
     def __call__(self, inputs, training: bool = False, mask=None):
         return self.call(inputs, training=training, mask=mask)
 
-    def predict(self, sequencer, **kwargs):
+    def predict(self, sequencer, verbose=0, callbacks=None, **kwargs):
         """Outputs of every batch, concatenated (Keras `predict` semantics)."""
+        self._check_kwargs('predict', kwargs)
         if len(sequencer) == 0: return np.zeros((0, 0), np.float32)
         dev = self._batch_device(sequencer[0][0])
         self._k_seen = []
@@ -86,10 +109,11 @@ class _LoopModel:
         self._check_k()
         return torch.cat(outs, dim=0).cpu().numpy()
 
-    def evaluate(self, sequencer, return_dict: bool = False, **kwargs):
+    def evaluate(self, sequencer, return_dict: bool = False, verbose=0, callbacks=None, **kwargs):
         """Loss and metrics over the sequencer with Keras `evaluate` semantics: the loss is sum(loss_i * weight_i) / number of
         samples (SUM_OVER_BATCH_SIZE per batch, batches averaged by their size), the metrics are weighted means
         sum(metric_i * weight_i) / sum(weight_i)."""
+        self._check_kwargs('evaluate', kwargs)
         if self.loss is None: raise RuntimeError('compile() the model with a loss before evaluate()')
         lossf = _loss_fn(self.loss)
         if len(sequencer) == 0: raise ValueError('evaluate() needs at least one batch')
@@ -144,11 +168,38 @@ class _LoopModel:
                 out[n] = (f(yd, res['y_pred']) * sw).sum() / sw.sum()
         return out
 
-    def fit(self, sequencer, epochs: int = 1, validation_data=None, verbose: int = 1, **kwargs):
+    # Keras arguments of fit / evaluate / predict that have no meaning for an eager single-process loop: accepted, ignored
+    _KERAS_NOOP_KWARGS = frozenset(('workers', 'use_multiprocessing', 'max_queue_size', 'batch_size', 'steps', 'steps_per_epoch',
+                                    'validation_steps', 'validation_batch_size', 'validation_freq', 'shuffle', 'class_weight', 'sample_weight'))
+
+    @classmethod
+    def _check_kwargs(cls, where, kwargs, allowed=()):
+        """Unknown keyword arguments raise (Keras would, too) instead of vanishing."""
+        bad = [k for k in kwargs if k not in cls._KERAS_NOOP_KWARGS and k not in allowed]
+        if bad: raise TypeError(f'{where}() got unexpected keyword argument(s) {bad}')
+
+    def fit(self, sequencer, epochs: int = 1, validation_data=None, verbose: int = 1, callbacks=None, initial_epoch: int = 0, **kwargs):
         """Keras-style training loop over a sequencer: `train_step` per batch, `on_epoch_end` (reshuffle + re-merge,
-        reference GraphSequencers.py:123-127) per epoch, optional validation with `evaluate`. Returns the history dict."""
-        history = {}
-        for epoch in range(epochs):
+        reference GraphSequencers.py:123-127) per epoch, optional validation with `evaluate`.  Returns a `History` (a dict of
+        per-epoch lists that also has Keras' `.history` / `.epoch` attributes).
+
+        `callbacks`: objects with any of `on_train_begin(logs)`, `on_epoch_begin(epoch, logs)`, `on_epoch_end(epoch, logs)`,
+        `on_train_end(logs)` (the Keras Callback method names; `set_model(model)` is called when present).  A callback that sets
+        `model.stop_training = True` ends the loop after the current epoch, as in Keras."""
+        self._check_kwargs('fit', kwargs)
+        cbs = list(callbacks or [])
+        for cb in cbs:
+            if hasattr(cb, 'set_model'): cb.set_model(self)
+        def emit(name, *args):
+            for cb in cbs:
+                f = getattr(cb, name, None)
+                if f is not None: f(*args)
+        history = History()
+        self.stop_training = False
+        emit('on_train_begin', {})
+        logs = {}
+        for epoch in range(int(initial_epoch), epochs):
+            emit('on_epoch_begin', epoch, {})
             tot, wsum = {}, 0.0
             for i in range(len(sequencer)):
                 data = sequencer[i]
@@ -162,9 +213,13 @@ class _LoopModel:
             if validation_data is not None:
                 logs.update({'val_' + key: val for key, val in self.evaluate(validation_data, return_dict=True).items()})
             for key, val in logs.items(): history.setdefault(key, []).append(val)
+            history.epoch.append(epoch)
             if verbose:
                 print(f'Epoch {epoch + 1}/{epochs} - ' + ' - '.join(f'{k_}: {v:.4f}' for k_, v in logs.items()))
+            emit('on_epoch_end', epoch, logs)
             if hasattr(sequencer, 'on_epoch_end'): sequencer.on_epoch_end()
+            if self.stop_training: break
+        emit('on_train_end', logs)
         self.history = history
         return history
 
@@ -210,15 +265,8 @@ class _LoopModel:
             yield from self._batches_concurrently(n, lambda i: self.call(sequencer[i][0], training=False), device,
                                                   self._round_width(sequencer, device) if n else 1)
             return
-        def launch(li):
-            batches = plan[li]
-            if len(batches) == 1: return self.call(sequencer[batches[0]][0], training=False)
-            x, node_begin = sequencer.merged_batches(batches)
-            return self.call(x, training=False, groups=node_begin)
         outs = {}
-        # every launch first, on side streams (a launch of 120 one-CU groups and the launches that spread the few large batches
-        # over the remaining CUs overlap), then the batches in order
-        for li, out in self._batches_concurrently(len(plan), launch, device, min(len(plan), 4)):
+        for li, out in self._run_plan(plan, lambda li: self._plan_launch(sequencer, plan[li]), device):
             r0 = 0
             for i in plan[li]:
                 rows = int(sequencer[i][1].shape[0])               # output rows of a batch = its target rows
@@ -226,11 +274,39 @@ class _LoopModel:
                 r0 += rows
         for i in range(n): yield i, outs[i]
 
+    def _plan_launch(self, sequencer, batches):
+        """The output rows of one plan entry: its batches merged and run as convergence groups of one call.  A merge the library
+        refuses after all (the plan looks at shapes; e.g. an operand form only the call sees) is rerun batch by batch."""
+        if len(batches) == 1: return self.call(sequencer[batches[0]][0], training=False)
+        x, node_begin = sequencer.merged_batches(batches)
+        try:
+            return self.call(x, training=False, groups=node_begin)
+        except (RuntimeError, nat.NativeError) as e:
+            if 'convergence groups' not in str(e): raise
+            return torch.cat([self.call(sequencer[b][0], training=False) for b in batches], dim=0)
+
+    def _run_plan(self, plan, launch, device):
+        """(li, launch(li)) for every entry of a group plan, on side streams.  Entries whose loop kernel has a grid barrier (the
+        spread form, single batches: every workgroup of the launch must be resident at once, and two such launches that
+        become ready together could each hold CUs the other is waiting for) all go to ONE stream and run one after the other;
+        the barrier-free resident launches (one workgroup per group, `_Launch.resident`) overlap them on the other streams.
+        `inference_streams` <= 1 runs everything in order on the caller's stream."""
+        width = max(1, min(len(plan), 4, int(self.inference_streams)))
+        nxt = [0]
+        def lane(li):
+            if width <= 2 or not getattr(plan[li], 'resident', False): return 0
+            nxt[0] += 1
+            return 1 + (nxt[0] - 1) % (width - 1)
+        if width == 2: lane = lambda li: 1 if getattr(plan[li], 'resident', False) else 0
+        yield from self._batches_concurrently(len(plan), launch, device, width, lane=lane)
+
     def _group_plan(self, sequencer, device):
         """[[batch, ...], ...]: the batches each launch merges, or None when grouping does not apply (composite model, CPU,
-        'normalized', unsupported shape).  Batches whose state fits the LDS of one CU go together - one workgroup each, any
-        number of them per launch; the others in runs of at most 32 whose 64-node tiles are all resident at once."""
+        'normalized', unsupported shape, a sequencer that does not keep a list of merged batches).  Batches whose state fits the
+        LDS of one CU go together - one workgroup each, any number of them per launch; the others in runs of at most 32 whose
+        64-node tiles are all resident at once."""
         if not self.group_batches or device.type != 'cuda' or not hasattr(sequencer, 'merged_batches'): return None
+        if not isinstance(getattr(sequencer, 'graph_tensors', None), list): return None          # opt-in: Multi* sequencers only
         if not isinstance(getattr(self, 'net_state', None), Sequential) or not hasattr(self, 'state_vect_dim'): return None
         if sequencer.merged_batches(0, 1) is None: return None
         # the plan depends on the batches (rebuilt batches = a new graph_tensors list) and on the model's shape only: kept
@@ -250,41 +326,45 @@ class _LoopModel:
             n_out = [int(sequencer[i][1].shape[0]) for i in range(len(sequencer))]
             x0 = sequencer[0][0]
             L, A = int(x0[0].shape[1]), int(x0[1].shape[1]) - 2
+            # hub rows (in-degree > sparse.HEAVY_THRESHOLD) take the per-iteration kernels: such a batch is launched alone
+            hub = [SparseMatrix.from_triple(sequencer[i][0][5]).device_csr(device).get('heavy') is not None for i in range(len(sequencer))]
         except Exception:
             return None
         focus = nat.FOCUS[self._focus]
         supported = lambda bs: ops.loop_groups_supported(int(sum(sizes[b] for b in bs)), L, A, self.net_state, self.net_output,
                                                          self.state_vect_dim, self.max_iteration, focus, self.native_flags,
                                                          sum(n_out[b] for b in bs), [0] + [int(v) for v in np.cumsum([sizes[b] for b in bs])])
-        plan, rest = [], list(range(len(sizes)))
+        plan, rest = [_Launch([b]) for b in range(len(sizes)) if hub[b]], [b for b in range(len(sizes)) if not hub[b]]
+        if not rest: return plan
         biggest = max(rest, key=lambda b: sizes[b])
         if supported([min(rest, key=lambda b: sizes[b])]) == 2:      # one CU per batch, its state in LDS - for those that fit
             fits = rest if supported([biggest]) == 2 else [b for b in rest if supported([b]) == 2]
             for c0 in range(0, len(fits), 1024):
                 chunk = fits[c0:c0 + 1024]
                 if len(chunk) >= 2 and supported(chunk) == 2:
-                    plan.append(chunk)
+                    plan.append(_Launch(chunk, resident=True))
                     rest = [b for b in rest if b not in set(chunk)]
         cus = torch.cuda.get_device_properties(device).multi_processor_count
         run, tiles = [], 0
         for b in rest:
             t = (sizes[b] + 63) // 64
             if run and (tiles + t > cus or len(run) >= 32):
-                plan.append(run); run, tiles = [], 0
+                plan.append(_Launch(run)); run, tiles = [], 0
             run.append(b); tiles += t
-        if run: plan.append(run)
+        if run: plan.append(_Launch(run))
         for bs in plan:
             if len(bs) >= 2 and not supported(bs): return None
         return plan
 
-    def _batches_concurrently(self, n, fn, device, width=None):
+    def _batches_concurrently(self, n, fn, device, width=None, lane=None):
         """Run fn(i), i < n, `width` at a time on side HIP streams and yield (i, result) in order on the caller's stream.
 
         Batches of a sequencer are independent graphs; a merged MUTAG batch keeps ~16 of the 256 CUs busy (the whole loop
         is one persistent launch of one workgroup per 64 nodes), so several run side by side: batch i goes to
         stream i % width, the caller's stream waits for all of them before the first result is used, and every result is
         recorded on the caller's stream so the caching allocator does not hand its memory back early. `width` is capped so that the
-        persistent kernels of one round can all be resident at once (they wait for each other inside the launch)."""
+        persistent kernels of one round can all be resident at once (they wait for each other inside the launch).  `lane`
+        (optional): i -> stream index in [0, width) instead of the round-robin."""
         width = int(width or self.inference_streams)
         if device.type != 'cuda' or width <= 1 or n <= 1:
             for i in range(n): yield i, fn(i)
@@ -295,7 +375,7 @@ class _LoopModel:
         for st in self._streams[:width]: st.wait_stream(main)          # inputs made on the caller's stream are ready
         res = []
         for i in range(n):                                             # round-robin: at most `width` loops in flight,
-            with torch.cuda.stream(self._streams[i % width]):          # each stream runs its batches in order
+            with torch.cuda.stream(self._streams[(lane(i) if lane else i) % width]):   # each stream runs its batches in order
                 res.append(fn(i))
         for st in self._streams[:width]: main.wait_stream(st)
         for i, out in enumerate(res):

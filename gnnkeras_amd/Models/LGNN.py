@@ -235,8 +235,14 @@ class LGNN(_LoopModel):
 
     # ---- fit: serial mode trains the layers one after another (reference LGNN.py:290-362) -----------------------------------
     def fit(self, sequencer, epochs: int = 1, validation_data=None, verbose: int = 1, **kwargs):
+        """'parallel' / 'residual': the usual loop.  'serial' (reference LGNN.py:290-362): the layers are trained one after
+        another, each on the graphs relabelled with its predecessor's states / outputs; `callbacks`, when given, is a list of
+        LAYERS callback lists - entry i goes to layer i's fit (reference :299-303)."""
         if self.training_mode != 'serial':
             return super().fit(sequencer, epochs=epochs, validation_data=validation_data, verbose=verbose, **kwargs)
+        callbacks = kwargs.pop('callbacks', None)
+        if callbacks is None: callbacks = [[] for _ in range(self.LAYERS)]
+        assert len(callbacks) == self.LAYERS
         histories = []
         train_t0, valid_t0 = sequencer, validation_data
         training_sequence = train_t0.copy()
@@ -257,12 +263,12 @@ class LGNN(_LoopModel):
 
         for idx, gnn in enumerate(self.gnns[:-1]):
             if verbose: print(f'\\n\\n --- GNN {idx + 1}/{self.LAYERS} ---')
-            histories.append(gnn.fit(training_sequence.copy(), epochs=epochs, verbose=verbose,
-                                     validation_data=valid_sequence.copy() if valid_sequence is not None else None))
+            histories.append(gnn.fit(training_sequence.copy(), epochs=epochs, verbose=verbose, callbacks=callbacks[idx],
+                                     validation_data=valid_sequence.copy() if valid_sequence is not None else None, **kwargs))
             training_sequence = propagate(gnn, training_sequence, train_t0)
             if valid_sequence is not None: valid_sequence = propagate(gnn, valid_sequence, valid_t0)
         if verbose: print(f'\\n\\n --- GNN {self.LAYERS}/{self.LAYERS} ---')
-        histories.append(self.gnns[-1].fit(training_sequence.copy(), epochs=epochs, verbose=verbose,
-                                           validation_data=valid_sequence.copy() if valid_sequence is not None else None))
+        histories.append(self.gnns[-1].fit(training_sequence.copy(), epochs=epochs, verbose=verbose, callbacks=callbacks[-1],
+                                           validation_data=valid_sequence.copy() if valid_sequence is not None else None, **kwargs))
         self.history = histories
         return histories

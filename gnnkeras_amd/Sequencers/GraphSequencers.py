@@ -55,8 +55,10 @@ class MultiGraphSequencer:
         # REPLACES the label arrays of a sequencer's graphs: reference LGNN.py:318-333); edits made IN PLACE inside an array are
         # not seen - call refresh() after such an edit
         arrays = lambda g: (id(g.nodes), id(g.arcs), id(g.targets), id(g.set_mask), id(g.output_mask))
-        stale = self._dataset is None or len(self._dataset[1]) != len(self.data) or \
-            any(self._dataset[1].get(id(g)) != arrays(g) for g in self.data)        # order-independent: shuffling keeps it valid
+        # (the signature is keyed by graph OBJECT: order-independent, so shuffling keeps it valid; a list that holds the same
+        # object twice has fewer keys than entries, which is fine - compare against the number of distinct objects)
+        stale = self._dataset is None or len(self._dataset[1]) != len({id(g) for g in self.data}) or \
+            any(self._dataset[1].get(id(g)) != arrays(g) for g in self.data)
         if stale:
             sig = {id(g): arrays(g) for g in self.data}
             from ..device_batch import DeviceDataset
@@ -123,7 +125,7 @@ class MultiGraphSequencer:
 
     def get_config(self):
         return {"graphs": self.data, "focus": self.focus, "aggregation_mode": self.aggregation_mode,
-                "batch_size": self.batch_size, "shuffle": self.shuffle}
+                "batch_size": self.batch_size, "shuffle": self.shuffle, "assemble": self.assemble}
 
     @classmethod
     def from_config(cls, config, **kwargs):
@@ -186,8 +188,14 @@ class SingleGraphSequencer(MultiGraphSequencer):
         self.batch_size = batch_size
         self.shuffle = shuffle
         self.dtype = 'float32'
+        self.aggregation_mode = getattr(graph, 'aggregation_mode', None)
+        self.assemble = 'host'
         self.set_mask_idx = np.argwhere(self.data.set_mask).reshape(-1)
         self.build_batches()
+
+    def merged_batches(self, i0, i1=None):
+        """Every batch of a single-graph sequencer IS the whole graph (with another target subset): nothing to merge."""
+        return None
 
     def build_batches(self):
         self.batch_masks = np.zeros((len(self), len(self.data.set_mask)), dtype=bool)

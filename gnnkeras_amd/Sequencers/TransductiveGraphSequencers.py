@@ -29,6 +29,7 @@ class TransductiveMultiGraphSequencer(CompositeMultiGraphSequencer):
 
     def get_config(self):
         config = super().get_config()
+        config.pop("assemble", None)                               # (composite batches are merged on the host)
         config["graphs"] = self.graph_objects                      # from_config must see the homogeneous originals
         config["transductive_rate"] = self.transductive_rate
         return config
@@ -51,30 +52,30 @@ class TransductiveMultiGraphSequencer(CompositeMultiGraphSequencer):
 
     @staticmethod
     def get_transduction(g: GraphObject, transductive_rate: float, focus: str, dtype='float32'):
-        """Heterogeneous version of `g` with non-transductive (type 0) / transductive (type 1) nodes (reference :62-95)."""
-        transductive_node_mask = np.logical_and(g.set_mask, g.output_mask)
-        indices = np.argwhere(transductive_node_mask).squeeze()
-        np.random.shuffle(indices)
-        non_transductive_number = int(np.ceil(np.sum(transductive_node_mask) * (1 - transductive_rate)))
-        transductive_node_mask[indices[:non_transductive_number]] = False
-        transductive_target_mask = transductive_node_mask[g.output_mask]
+        """Heterogeneous version of `g` with non-transductive (type 0) / transductive (type 1) nodes (reference :62-95).
 
-        length = g.arcs.shape[0] if focus == 'a' else g.nodes.shape[0]
-        labelplus = np.zeros((length, g.DIM_TARGET), dtype=dtype)
-        labelplus[transductive_node_mask] = g.targets[transductive_target_mask]
-        nodes_new = np.concatenate([g.nodes, labelplus], axis=1)
-        target_new = g.targets[np.logical_not(transductive_target_mask)]
+        The supervised nodes (`set_mask & output_mask`) are drawn in ONE `np.random.shuffle` of their ascending index list -
+        the same consumption of numpy's global stream as the reference, so a seeded run draws the same split; the first
+        ceil(n * (1 - rate)) of the shuffled list stay supervised, the others turn transductive: their target row moves behind
+        their label, they get type 1 and leave the output mask."""
+        supervised = np.flatnonzero(np.logical_and(g.set_mask, g.output_mask))
+        np.random.shuffle(supervised)
+        n_stay = int(np.ceil(len(supervised) * (1 - transductive_rate)))
+        is_trans = np.zeros(len(g.set_mask), dtype=bool)
+        is_trans[supervised[n_stay:]] = True
+        # targets have one row per output_mask entry, in node order
+        target_is_trans = is_trans[g.output_mask]
+
+        n_rows = g.arcs.shape[0] if focus == 'a' else g.nodes.shape[0]
+        L, T = g.nodes.shape[1], int(g.DIM_TARGET)
+        labels = np.zeros((n_rows, L + T), dtype=np.result_type(g.nodes.dtype, dtype))
+        labels[:, :L] = g.nodes
+        labels[is_trans, L:] = g.targets[target_is_trans]
+
         d0 = int(np.asarray(g.DIM_NODE_LABEL).reshape(-1)[0])
-        dim_node_label_new = (d0, d0 + g.DIM_TARGET)
-
-        type_mask = np.zeros((g.nodes.shape[0], 2), dtype=bool)
-        type_mask[transductive_node_mask, 1] = True
-        type_mask[:, 0] = np.logical_not(type_mask[:, 1])
-        output_mask_new = g.output_mask.copy()
-        output_mask_new[transductive_node_mask] = False
-        return CompositeGraphObject(arcs=g.getArcs(), nodes=nodes_new, targets=target_new, type_mask=type_mask,
-                                    dim_node_label=dim_node_label_new, focus=focus, set_mask=g.getSetMask(),
-                                    output_mask=output_mask_new)
+        return CompositeGraphObject(arcs=g.getArcs(), nodes=labels, targets=g.targets[~target_is_trans],
+                                    type_mask=np.stack([~is_trans, is_trans], axis=1), dim_node_label=(d0, d0 + T), focus=focus,
+                                    set_mask=g.getSetMask(), output_mask=np.logical_and(g.output_mask, ~is_trans))
 
 
 class TransductiveSingleGraphSequencer(TransductiveMultiGraphSequencer, CompositeSingleGraphSequencer):

@@ -454,9 +454,10 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
             TRY(check_csr(a.nodegraph, "nodegraph", a.nodegraph.n_dst, p.M));
         }
         if (a.n_heavy_segments > 0) {
-            if (a.nodes_src) return fail("hub segments are not supported on shards");
+            // (on a shard the virtual rows sit behind the adjacency.n_src rows of the exchanged full buffer, which the caller
+            // allocates n_heavy_segments rows longer; on one GPU n_src == n_nodes)
             if (!a.heavy_seg_beg || !a.heavy_seg_end) return fail("heavy_seg_beg / heavy_seg_end is NULL");
-            TRY(check_csr(a.adjacency_light, "adjacency_light", p.N, p.N + a.n_heavy_segments));
+            TRY(check_csr(a.adjacency_light, "adjacency_light", p.N, (a.nodes_src ? a.adjacency.n_src : p.N) + a.n_heavy_segments));
         }
         if (p.composite) {
             if (!a.type_nodes && p.N > 0) return fail("type_nodes is NULL");
@@ -546,12 +547,13 @@ inline const gnn_csr_t &iter_adjacency(const gnn_loop_args_t &a, const Plan &p) 
 int launch_heavy(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src, hipStream_t st) {
     if (p.n_heavy == 0) return 0;
     float *buf = const_cast<float *>(src);
+    const int first_virtual = a.nodes_src ? a.adjacency.n_src : p.N;     // a shard's full buffer: behind every visible row
     const int grid = std::min(p.n_heavy, 256 * 8);
     switch (p.SP) {
-        case 16: gnn::k_heavy_segments<16><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
-        case 32: gnn::k_heavy_segments<32><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
-        case 64: gnn::k_heavy_segments<64><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
-        default: gnn::k_heavy_segments<128><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, p.N); break;
+        case 16: gnn::k_heavy_segments<16><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, first_virtual); break;
+        case 32: gnn::k_heavy_segments<32><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, first_virtual); break;
+        case 64: gnn::k_heavy_segments<64><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, first_virtual); break;
+        default: gnn::k_heavy_segments<128><<<grid, 256, 0, st>>>(gate, a.heavy_seg_beg, a.heavy_seg_end, p.n_heavy, a.adjacency.src, a.adjacency.w, buf, first_virtual); break;
     }
     LAUNCH_OK();
     return 0;
@@ -1191,12 +1193,17 @@ int gnn_converged(const float *state, const float *state_old, int32_t n, int32_t
 int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *state_out, int32_t *flag_out) {
     if (!args) return fail("args is NULL");
     const gnn_loop_args_t &a = *args;
-    if (a.composite) return fail("gnn_state_step: homogeneous graphs only");
     Plan p;
     TRY(make_plan(a, a.workspace, p, false));
     TRY(check_csr(a.adjacency, "adjacency", p.N, p.N));
     TRY(check_csr(a.arcnode, "arcnode", p.N, p.E));
-    TRY(check_mlp(a.net_state[0], "net_state", true));
+    for (int t = 0; t < p.T; ++t) TRY(check_mlp(a.net_state[t], "net_state", true));
+    if (p.composite) {      // one step of CompositeGNNnodeBased.convergence (CompositeGNN.py:215-234): per-type networks on per-type row lists
+        if (!a.type_nodes && p.N > 0) return fail("type_nodes is NULL");
+        if (a.type_offsets[0] != 0 || a.type_offsets[p.T] != p.N) return fail("type_offsets must span [0, n_nodes]");
+        for (int t = 0; t < p.T; ++t) TRY(check_csr(a.composite_adjacency[t], "composite_adjacency", p.N, p.N));
+    }
+    if (p.N > 0 && !a.nodes) return fail("nodes is NULL");
     if (!state_in || !state_out) return fail("state_in / state_out is NULL");
     if (!a.workspace || a.workspace_bytes < p.bytes) return fail("workspace too small: %zu < %zu bytes", a.workspace_bytes, p.bytes);
     hipStream_t st = (hipStream_t)a.stream;

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(64 * LDS_NW, 4) k_state_lds(LdsArgs a) {
     constexpr int NCT = SP / 16;                  // 16-column output tiles
     constexpr int KS = 2 * SP / 4;                // MFMA k-steps over [state | agg]
     extern __shared__ __attribute__((aligned(16))) char smem_lds[];
-    __shared__ int moving_s;
+    __shared__ int moving_s[2];                   // "some node of this group still moves", iteration it uses [it & 1]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(64 * LDS_NW, 4) k_state_lds(LdsArgs a) {
         for (int u = 0; u < 4; ++u) id[u] = beg + u < end ? (unsigned)(a.src[beg + u] - nb) : 0u;
         Rec[j] = LdsRec{id[0] | (id[1] << 16), id[2] | (id[3] << 16), end - beg, a.row_scale ? a.row_scale[nb + j] : 1.0f};
     }
+    if (tid == 0) { moving_s[0] = 0; moving_s[1] = 0; }
     int run = a.no_exit;
     if (!run) {
         const int t0 = a.tile64_begin[grp], t1 = a.tile64_begin[grp + 1];
@@ -223,10 +224,12 @@ __global__ void __launch_bounds__(64 * LDS_NW, 4) k_state_lds(LdsArgs a) {
                 if (rin && r == 15 && sqrtf(d2) > a.thr * sqrtf(n2)) any = 1;
             }
         }
-        if (tid == 0) moving_s = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's staged rows are in L2
         __syncthreads();                                                       // every wave is done reading the old state
-        if (any) moving_s = 1;                                                 // benign race: every writer stores 1
+        // two flag words: the one of the NEXT iteration is cleared here - every wave has read it (end of the previous iteration)
+        // before it arrived at the barrier above, and the barrier below orders the clear before the next iteration's stores
+        if (tid == 0) moving_s[(it + 1) & 1] = 0;
+        if (any) moving_s[it & 1] = 1;                                         // benign race: every writer stores 1
         {   // staged rows back into LDS: sc1 loads, served by the L2 the stores went to (the CU's L1 may still hold last
             // iteration's lines of the staging buffer)
             const __amdgpu_buffer_rsrc_t rs = r_stage;
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(64 * LDS_NW, 4) k_state_lds(LdsArgs a) {
         }
         __syncthreads();
         k_done = it + 1;
-        if (!a.no_exit && moving_s == 0) break;                                // uniform: read after the barrier
+        if (!a.no_exit && moving_s[it & 1] == 0) break;                        // uniform: read after the barrier
     }
     // ---- result rows to the caller's compact buffer, k of this group ------------------------------------------------------------------
     for (int i = tid; i < n * S; i += 64 * LDS_NW) {

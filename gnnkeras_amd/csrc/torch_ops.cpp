@@ -276,16 +276,36 @@ std::tuple<at::Tensor, at::Tensor> state_step(const at::Tensor &nodes, const at:
                                               at::IntArrayRef adjacency_dims, const OptTensorList &arcnode, at::IntArrayRef arcnode_dims,
                                               at::TensorList net_state_weights, at::IntArrayRef net_state_spec, double bn_eps,
                                               const at::Tensor &state, int64_t state_dim, double state_threshold, int64_t flags,
-                                              const OptTensorList &hub, at::IntArrayRef hub_dims) {
+                                              const OptTensorList &hub, at::IntArrayRef hub_dims, const std::optional<at::Tensor> &type_nodes,
+                                              at::IntArrayRef type_offsets, at::IntArrayRef type_dim_label,
+                                              const OptTensorList &composite_adjacency, at::IntArrayRef composite_dims) {
     const at::Device dev = nodes.device();
     gnn_loop_args_t a{};
     fill_graph(a, nodes, arcs, adjacency, adjacency_dims, arcnode, arcnode_dims, hub, hub_dims, dev);
-    a.n_types = 1;
+    const int T = (int)type_dim_label.size();
+    a.composite = T > 0;
+    a.n_types = T > 0 ? T : 1;
+    TORCH_CHECK(a.n_types <= GNN_MAX_TYPES, "at most ", GNN_MAX_TYPES, " node types");
     size_t wpos = 0, spos = 0;
-    mlp_of(a.net_state[0], net_state_weights, net_state_spec, &wpos, &spos, bn_eps, "net_state", dev);
-    // gnn_state_step validates the state network only; the output network of the args is a placeholder of the right input width
+    for (int t = 0; t < a.n_types; ++t) mlp_of(a.net_state[t], net_state_weights, net_state_spec, &wpos, &spos, bn_eps, "net_state", dev);
+    TORCH_CHECK(wpos == net_state_weights.size() && spos == net_state_spec.size(), "net_state: ", a.n_types, " network(s) expected, surplus weights / spec entries");
+    if (a.composite) {       // CompositeGNNnodeBased.convergence (CompositeGNN.py:215-234)
+        TORCH_CHECK((int)type_offsets.size() == T + 1 && (int)composite_adjacency.size() == 4 * T && (int)composite_dims.size() == 3 * T,
+                    "composite: type_offsets[T + 1], composite_adjacency[4 T], composite_dims[3 T] expected for T = ", T);
+        a.type_nodes = i32(type_nodes, "type_nodes", dev);
+        for (int t = 0; t < T; ++t) {
+            a.type_dim_label[t] = (int32_t)type_dim_label[t];
+            a.type_offsets[t] = (int32_t)type_offsets[t];
+            OptTensorList one;
+            for (int i = 0; i < 4; ++i) one.push_back(composite_adjacency.get(4 * t + i));
+            a.composite_adjacency[t] = csr_of(one, composite_dims.slice(3 * t, 3), "composite_adjacency", dev);
+        }
+        a.type_offsets[T] = (int32_t)type_offsets[T];
+    }
+    // gnn_state_step validates the state network(s) only; the output network of the args is a placeholder of the right input width
     a.net_output = gnn_mlp_t{};
-    a.net_output.in_dim = state_dim > 0 ? (int32_t)state_dim + a.dim_node_label : a.dim_node_label;
+    a.net_output.in_dim = a.composite ? (state_dim > 0 ? (int32_t)state_dim : a.dim_node_label)
+                                      : (state_dim > 0 ? (int32_t)state_dim + a.dim_node_label : a.dim_node_label);
     a.net_output.n_layers = 1; a.net_output.units[0] = 1;
     a.state_dim = (int32_t)state_dim; a.max_iteration = 1; a.state_threshold = (float)state_threshold;
     a.focus = GNN_FOCUS_NODE; a.flags = (int32_t)flags;
@@ -336,7 +356,8 @@ TORCH_LIBRARY(gnnkeras, m) {
     m.def("converged(Tensor state, Tensor? state_old, float threshold) -> Tensor");
     m.def("state_step(Tensor nodes, Tensor arcs, Tensor?[] adjacency, int[] adjacency_dims, Tensor?[] arcnode, int[] arcnode_dims, "
           "Tensor[] net_state_weights, int[] net_state_spec, float bn_eps, Tensor state, int state_dim, float state_threshold, int flags, "
-          "Tensor?[] hub, int[] hub_dims) -> (Tensor state_new, Tensor moving)");
+          "Tensor?[] hub, int[] hub_dims, Tensor? type_nodes, int[] type_offsets, int[] type_dim_label, "
+          "Tensor?[] composite_adjacency, int[] composite_dims) -> (Tensor state_new, Tensor moving)");
     m.def("mlp_forward(Tensor[] weights, int[] spec, float bn_eps, Tensor X) -> Tensor");
 }
 

@@ -37,7 +37,10 @@ _OUT_INDEX = {}
 
 def lookup_out_index(set_mask, output_mask):
     hit = _OUT_INDEX.get((set_mask.data_ptr(), output_mask.data_ptr(), set_mask.shape[0]))
-    return None if hit is None else hit[0]
+    # an in-place edit of either mask since the assembly (views share the version counter of their base) makes the entry stale:
+    # the caller then derives the index from the masks as they are now
+    if hit is None or set_mask._version != hit[3] or output_mask._version != hit[4]: return None
+    return hit[0]
 
 
 class DeviceBatch:
@@ -292,7 +295,7 @@ class DeviceDataset:
                 nodegraph = SparseMatrix(np.zeros((0, 2), np.int64), np.zeros(0, np.float32), (1, 0))     # reference: empty matrix
             b_set, b_out = set_mask[m0:m1].view(torch.bool), out_mask[m0:m1].view(torch.bool)
             key = (b_set.data_ptr(), b_out.data_ptr(), m1 - m0)
-            _OUT_INDEX[key] = (out_index[int(bO[b]):int(bO[b] + Ob[b])], b_set, b_out)
+            _OUT_INDEX[key] = (out_index[int(bO[b]):int(bO[b] + Ob[b])], b_set, b_out, b_set._version, b_out._version)
             out.append(DeviceBatch(nodes=nodes[n0:n1], arcs=b_arcs, targets=targets[t0:t1], sample_weight=sw[t0:t1],
                                    set_mask=b_set, output_mask=b_out,
                                    DIM_NODE_LABEL=torch.tensor([self.L], dtype=torch.int32), DIM_ARC_LABEL=self.W - 2, DIM_TARGET=self.T,

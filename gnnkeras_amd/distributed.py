@@ -40,7 +40,7 @@ import torch.distributed as dist
 
 from . import _native as nat
 from .graph_class import GraphObject
-from .sparse import CSRByDestination
+from .sparse import CSRByDestination, HEAVY_THRESHOLD, split_heavy
 
 
 def partition(n_nodes: int, world_size: int):
@@ -69,11 +69,55 @@ def split_csr(c: CSRByDestination, own_lo: int, own_hi: int):
     return out[0], out[1]
 
 
-class ShardPlan:
-    """Host-side (numpy) description of one rank's shard: local CSR operators in padded-row space."""
+class GraphSlice:
+    """What ONE rank needs of a graph - nothing that grows with the other ranks' arcs:
 
-    def __init__(self, graph: GraphObject, rank: int, world_size: int):
-        N = graph.nodes.shape[0]
+        nodes [N, L]                      every node's label (the one-off halo of the neighbour-label aggregate, GNN.py:258)
+        arc_src / arc_dst / arc_labels    the arcs whose DESTINATION lies in [lo, hi), in the graph's arc order (sorted by (src, dst))
+        values                            their ArcNode / Adjacency entries (reference graph_class.py:105-121: 1, 1 / #arcs of the
+                                          whole graph, or 1 / in-degree of the destination - all computable from the slice)
+        set_mask / output_mask            of the own nodes
+    plus, for heterogeneous graphs, the own rows of type_mask and the own columns of every CompositeAdjacency.
+
+    `from_graph` cuts it out of a replicated `GraphObject`; a generator that can produce a rank's arcs directly
+    (`synth.er_graph_slice`) never builds the whole graph's matrices at all."""
+
+    def __init__(self, n_nodes, nodes, lo, hi, arc_src, arc_dst, arc_labels, values, set_mask, output_mask, arc_index=None,
+                 composite=None):
+        self.n_nodes, self.lo, self.hi = int(n_nodes), int(lo), int(hi)
+        self.nodes = np.ascontiguousarray(nodes, dtype=np.float32)
+        self.arc_src, self.arc_dst = np.asarray(arc_src, dtype=np.int64), np.asarray(arc_dst, dtype=np.int64)
+        self.arc_labels = np.ascontiguousarray(arc_labels, dtype=np.float32)
+        self.values = np.asarray(values, dtype=np.float32)
+        self.set_mask, self.output_mask = np.asarray(set_mask, dtype=bool), np.asarray(output_mask, dtype=bool)
+        self.arc_index = None if arc_index is None else np.asarray(arc_index, dtype=np.int64)
+        self.composite = composite      # None | dict(type_mask [n_local, T], dim_node_label [T], adjacencies [(row, col, data)] * T)
+        if len(self.arc_dst) and (self.arc_dst.min() < self.lo or self.arc_dst.max() >= self.hi):
+            raise ValueError('a GraphSlice holds the arcs whose destination lies in its own node range')
+
+    @classmethod
+    def from_graph(cls, graph: GraphObject, lo: int, hi: int):
+        dst = graph.arc_ids[:, 1]
+        mine = (dst >= lo) & (dst < hi)
+        comp = None
+        if hasattr(graph, 'type_mask'):
+            cas = []
+            for ca in graph.CompositeAdjacencies:
+                ca = ca.tocoo()
+                keep = (ca.col >= lo) & (ca.col < hi)
+                cas.append((ca.row[keep].astype(np.int64), ca.col[keep].astype(np.int64), ca.data[keep].astype(np.float32)))
+            comp = dict(type_mask=graph.type_mask[lo:hi], dim_node_label=[int(d) for d in graph.DIM_NODE_LABEL], adjacencies=cas)
+        return cls(graph.nodes.shape[0], graph.nodes, lo, hi, graph.arc_ids[mine, 0], dst[mine], graph.arcs[mine][:, 2:],
+                   graph.ArcNode.data[mine],                       # aggregation weights computed on the WHOLE graph
+                   graph.set_mask[lo:hi], graph.output_mask[lo:hi], arc_index=np.flatnonzero(mine), composite=comp)
+
+
+class ShardPlan:
+    """Host-side (numpy) description of one rank's shard: local CSR operators in padded-row space.  `graph`: the replicated
+    `GraphObject`, or just this rank's `GraphSlice`."""
+
+    def __init__(self, graph, rank: int, world_size: int):
+        N = graph.n_nodes if isinstance(graph, GraphSlice) else graph.nodes.shape[0]
         self.N, self.rank, self.world_size = N, rank, world_size
         self.chunk, self.ranges = partition(N, world_size)
         self.lo, self.hi = self.ranges[rank]
@@ -81,43 +125,40 @@ class ShardPlan:
         self.rows_per_slice = self.chunk + 1
         self.n_rows_full = world_size * self.rows_per_slice
         self.row_base = rank * self.rows_per_slice
-        dst = graph.arc_ids[:, 1]
-        mine = (dst >= self.lo) & (dst < self.hi)
-        self.arc_index = np.flatnonzero(mine)                       # global arc ids of the local (incoming) arcs
-        self.e_local = int(mine.sum())
-        values = graph.ArcNode.data[mine]                           # aggregation weights computed on the WHOLE graph
-        src_rows = padded_row(graph.arc_ids[mine, 0], self.chunk)
-        dst_local = dst[mine] - self.lo
+        gs = graph if isinstance(graph, GraphSlice) else GraphSlice.from_graph(graph, self.lo, self.hi)
+        if (gs.lo, gs.hi) != (self.lo, self.hi):
+            raise ValueError(f'rank {rank} of {world_size} owns nodes [{self.lo}, {self.hi}); the slice covers [{gs.lo}, {gs.hi})')
+        self.L, self.A = gs.nodes.shape[1], gs.arc_labels.shape[1]
+        self.arc_index = gs.arc_index                               # global arc ids of the local (incoming) arcs, when known
+        self.e_local = len(gs.arc_dst)
+        values = gs.values
+        src_rows = padded_row(gs.arc_src, self.chunk)
+        dst_local = gs.arc_dst - self.lo
         # COO (rows = sources, cols = local destinations) -> by-destination CSR, ascending source inside a row
         self.adjacency = CSRByDestination.from_coo(src_rows, dst_local, values, (self.n_rows_full, self.n_local))
         self.own_rows = (self.row_base, self.row_base + self.n_local)     # rows of the exchanged buffer this rank writes itself
         self.arcnode = CSRByDestination.from_coo(np.arange(self.e_local), dst_local, values,
                                                  (self.e_local, self.n_local))
-        self.arc_labels = np.ascontiguousarray(graph.arcs[mine][:, 2:])
-        self.nodes_local = np.ascontiguousarray(graph.nodes[self.lo:self.hi])
-        nodes_full = np.zeros((self.n_rows_full, graph.nodes.shape[1]), dtype=np.float32)
-        nodes_full[padded_row(np.arange(N), self.chunk)] = graph.nodes
+        self.arc_labels = gs.arc_labels
+        self.nodes_local = np.ascontiguousarray(gs.nodes[self.lo:self.hi])
+        nodes_full = np.zeros((self.n_rows_full, self.L), dtype=np.float32)
+        nodes_full[padded_row(np.arange(N), self.chunk)] = gs.nodes
         self.nodes_full = nodes_full
-        sm, om = graph.set_mask[self.lo:self.hi], graph.output_mask[self.lo:self.hi]
-        self.out_index = np.flatnonzero(sm & om).astype(np.int32)
+        self.out_index = np.flatnonzero(gs.set_mask & gs.output_mask).astype(np.int32)
         self.per_arc_weights = self.adjacency.w is not None
         # heterogeneous graphs: local node ids grouped by type + the per-source-type adjacencies of the label aggregate
-        self.composite = hasattr(graph, 'type_mask')
+        self.composite = gs.composite is not None
         if self.composite:
-            tm = graph.type_mask[self.lo:self.hi]                   # (n_local, T)
+            tm = gs.composite['type_mask']                          # (n_local, T)
             if not np.all(tm.sum(1) == 1): raise ValueError('type_mask must be one-hot: every node needs exactly one type')
             types = tm.argmax(1)
             order = np.argsort(types, kind='stable')
             self.type_nodes = order.astype(np.int32)
             self.type_offsets = np.concatenate([[0], np.cumsum(np.bincount(types, minlength=tm.shape[1]))]).astype(np.int64)
-            self.dim_node_label = [int(d) for d in graph.DIM_NODE_LABEL]
-            self.composite_adjacency = []
-            for ca in graph.CompositeAdjacencies:
-                ca = ca.tocoo()
-                keep = (ca.col >= self.lo) & (ca.col < self.hi)
-                self.composite_adjacency.append(CSRByDestination.from_coo(
-                    padded_row(ca.row[keep], self.chunk), ca.col[keep] - self.lo, ca.data[keep],
-                    (self.n_rows_full, self.n_local)))
+            self.dim_node_label = list(gs.composite['dim_node_label'])
+            self.composite_adjacency = [CSRByDestination.from_coo(padded_row(row, self.chunk), col - self.lo, data,
+                                                                  (self.n_rows_full, self.n_local))
+                                        for row, col, data in gs.composite['adjacencies']]
 
     def pad_state(self, state: np.ndarray, SP: int) -> np.ndarray:
         """[N, S] -> full padded buffer [n_rows_full, SP] (flag rows and padding zero)."""
@@ -134,23 +175,25 @@ class ShardedLoop:
 
     `state_local` / `out_local` cover the rank's own nodes [lo, hi) (masked ones for `out`)."""
 
-    def __init__(self, model, graph: GraphObject, rank: int, world_size: int, device, group=None, overlap: bool = False):
+    def __init__(self, model, graph, rank: int, world_size: int, device, group=None, overlap: bool = False):
+        """`graph`: the replicated `GraphObject` / `CompositeGraphObject`, or this rank's `GraphSlice` (a rank never needs more)."""
         if model._focus != 'n':
             raise NotImplementedError('sharding is built for node-focused models (BASELINE configs C4 / C5)')
         self.composite = isinstance(model.net_state, (list, tuple))
-        if self.composite != hasattr(graph, 'type_mask'):
-            raise ValueError('composite models need CompositeGraphObject graphs (and vice versa)')
         self.model, self.group = model, group
         self.rank, self.world_size = rank, world_size
         self.device = torch.device(device)
         self.overlap = bool(overlap)
         self.plan = p = ShardPlan(graph, rank, world_size)
+        if self.composite != p.composite:
+            raise ValueError('composite models need CompositeGraphObject graphs (and vice versa)')
         self.n_local, self.e_local, self.per_arc_weights = p.n_local, p.e_local, p.per_arc_weights
-        self.S = model.state_vect_dim if model.state_vect_dim > 0 else graph.nodes.shape[1]
-        self.L, self.A = graph.nodes.shape[1], graph.arcs.shape[1] - 2
+        self.L, self.A = p.L, p.A
+        self.S = model.state_vect_dim if model.state_vect_dim > 0 else self.L
         self.SP = self._state_ld(self.S)
+        self.n_virtual_rows = 0                       # hub segments: virtual state rows behind the exchanged ones (set by _upload)
         self._upload()
-        self.buf = [torch.zeros((p.n_rows_full, self.SP), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.buf = [torch.zeros((p.n_rows_full + self.n_virtual_rows, self.SP), dtype=torch.float32, device=self.device) for _ in range(2)]
         self._iter_events = None
 
     # ---- device-specific pieces (the gloo/CPU tests override these four with numpy stand-ins) --------------------------
@@ -176,6 +219,15 @@ class ShardedLoop:
         a.nodes_src, a.ld_nodes_src = nat.ptr(self.d_nodes_full), self.L
         a.arc_labels, a.ld_arcs = nat.ptr(self.d_arc_labels), max(self.A, 1)
         a.adjacency, a.arcnode = nat.make_csr(self.d_adj), nat.make_csr(self.d_an)
+        if p.adjacency.max_degree > HEAVY_THRESHOLD:
+            # hub rows (sparse.split_heavy, as on one GPU): whole workgroups sum their segments into virtual state rows behind the
+            # n_rows_full exchanged ones before every iteration; the iterations walk the light operator
+            light, heavy = split_heavy(p.adjacency)
+            self.d_adj_light = csr(light)
+            self.d_heavy = (up(heavy['seg_beg']), up(heavy['seg_end']))
+            a.adjacency_light = nat.make_csr(self.d_adj_light)
+            a.heavy_seg_beg, a.heavy_seg_end, a.n_heavy_segments = nat.ptr(self.d_heavy[0]), nat.ptr(self.d_heavy[1]), heavy['n_seg']
+            self.n_virtual_rows = heavy['n_seg']
         if self.composite:
             a.composite, a.n_types = 1, len(p.dim_node_label)
             if a.n_types != len(m.net_state): raise ValueError('one state network per node type is required')
@@ -280,9 +332,9 @@ class ShardedLoop:
             s0 = state0_full.to(self.device, torch.float32)
             rows = torch.from_numpy(padded_row(np.arange(p.N), p.chunk)).to(self.device)
             self.buf[0].zero_()
-            self.buf[0][rows, :s0.shape[1]] = s0
+            self.buf[0][rows, :s0.shape[1]] = s0                  # (virtual hub rows behind n_rows_full stay zero until the pre-pass)
         else:
-            self.buf[0].copy_(torch.from_numpy(p.pad_state(np.asarray(state0_full, dtype=np.float32), self.SP)))
+            self.buf[0][:p.n_rows_full].copy_(torch.from_numpy(p.pad_state(np.asarray(state0_full, dtype=np.float32), self.SP)))
 
     transport = 'ring'      # 'ring': RCCL all_gather_into_tensor; 'direct': one send + one receive per peer, all at once
 
@@ -354,11 +406,13 @@ class ShardedLoop:
         full = p.nodes_full.reshape(self.world_size, p.rows_per_slice, -1)[:, :p.chunk].reshape(-1, p.nodes_full.shape[1])
         return full[:p.N]
 
-    def profile_iteration(self, state0_full=None, reps: int = 10) -> dict:
+    def profile_iteration(self, state0_full=None, reps: int = 10, collective: bool = True) -> dict:
         """Per-iteration device times of this rank, HIP events on the launch stream (collective call: every rank runs it):
         `kernel_s` = the iteration's launches alone (partial + split kernel, or the one fused kernel), no collective;
         `exchange_s` = the collective alone; `iteration_s` = one iteration of `forward()` with both in flight.  Gates are
-        forced open for the measurement (the states it leaves behind are meaningless)."""
+        forced open for the measurement (the states it leaves behind are meaningless).
+        `collective=False`: only `kernel_s`, no process group needed - one rank's share of an R-rank job measured on a single
+        GPU (`bench.py --emulate-shard r/R`)."""
         m = self.model
         self._prepare(state0_full)
         flags, m.native_flags = m.native_flags, m.native_flags | nat.FLAG_NO_EARLY_EXIT
@@ -368,7 +422,7 @@ class ShardedLoop:
         try:
             def timed(fn):
                 torch.cuda.synchronize(self.device)
-                if self.world_size > 1: dist.barrier(group=self.group)
+                if self.world_size > 1 and collective: dist.barrier(group=self.group)
                 a, b = ev(), ev()
                 a.record()
                 for _ in range(reps): fn()
@@ -393,6 +447,10 @@ class ShardedLoop:
                     self._iteration(0); self._exchange(self.buf[1], 0)
 
             if self.overlap: self._partial(0)
+            if not collective:
+                kernels()                                          # warm-up
+                t['kernel_s'] = timed(kernels)
+                return t
             kernels(); exchange()                                  # warm-up
             t['kernel_s'], t['exchange_s'], t['iteration_s'] = timed(kernels), timed(exchange), timed(both)
         finally:
@@ -521,8 +579,9 @@ class HaloShardedLoop(ShardedLoop):
         self.S = model.state_vect_dim if model.state_vect_dim > 0 else graph.nodes.shape[1]
         self.L, self.A = graph.nodes.shape[1], graph.arcs.shape[1] - 2
         self.SP = self._state_ld(self.S)
+        self.n_virtual_rows = 0
         self._upload()
-        self.buf = [torch.zeros((p.n_rows_view, self.SP), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.buf = [torch.zeros((p.n_rows_view + self.n_virtual_rows, self.SP), dtype=torch.float32, device=self.device) for _ in range(2)]
         self._make_exchange_state()
         self._iter_events = None
 
@@ -543,11 +602,11 @@ class HaloShardedLoop(ShardedLoop):
             vg = torch.from_numpy(p.view_global).to(self.device)
             valid = vg >= 0
             self.buf[0].zero_()
-            self.buf[0][valid, :s0.shape[1]] = s0[vg[valid]]
+            self.buf[0][:p.n_rows_view][valid, :s0.shape[1]] = s0[vg[valid]]
             self._state0_full = s0
         else:
             arr = np.asarray(state0_full, dtype=np.float32)
-            self.buf[0].copy_(torch.from_numpy(p.view_state(arr, self.SP)))
+            self.buf[0][:p.n_rows_view].copy_(torch.from_numpy(p.view_state(arr, self.SP)))
             self._state0_full = torch.from_numpy(arr).to(self.device)
 
     def plan_nodes_as_state(self):
@@ -619,6 +678,7 @@ def choose_exchange(graph: GraphObject, world_size: int) -> str:
     """'halo' when the compacted halos move less than half of the all-gather volume for EVERY rank, else 'allgather'.
     Decided from the whole graph (every rank holds it on the host), never from the caller's own shard: all ranks must
     reach the same answer or they would wait in different collectives."""
+    if isinstance(graph, GraphSlice): return 'allgather'           # a rank that only holds its slice cannot know what its peers read
     chunk, ranges = partition(graph.nodes.shape[0], world_size)
     src, dst = graph.arc_ids[:, 0], graph.arc_ids[:, 1]
     worst = 0.0
@@ -644,6 +704,7 @@ def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, dev
     pick = exchange
     if exchange == 'auto': pick = choose_exchange(graph, world_size)
     if pick == 'halo':
+        if isinstance(graph, GraphSlice): raise ValueError("exchange='halo' derives every peer's pack lists from the whole graph: pass the GraphObject")
         return HaloShardedLoop(model, graph, rank, world_size, device, group=group, overlap=overlap)
     sl = ShardedLoop(model, graph, rank, world_size, device, group=group, overlap=overlap)
     if pick == 'direct': sl.transport = 'direct'

@@ -115,13 +115,27 @@ def converged(state, state_old, threshold):
     return load().converged(state, state_old, float(threshold))
 
 
-def state_step(nodes, arcs, adjacency, arcnode, net_state, state, state_dim, state_threshold, flags=0):
+def state_step(nodes, arcs, adjacency, arcnode, net_state, state, state_dim, state_threshold, flags=0, composite=None):
+    """`net_state`: one `Sequential`, or the per-type list with `composite` = (type_nodes, type_offsets, type_dim_label, [device-CSR
+    dict per type]) as for `loop_forward` (CompositeGNN.py:215-234)."""
     adj_t, adj_d = csr_args(adjacency)
     an_t, an_d = csr_args(arcnode)
     hub_t, hub_d = hub_args(adjacency)
-    w, s = net_args(net_state, nodes.device)
+    nets = list(net_state) if isinstance(net_state, (list, tuple)) else [net_state]
+    w, s = [], []
+    for n_ in nets:
+        w_, s_ = net_args(n_, nodes.device)
+        w += w_; s += s_
+    if composite is None:
+        return load().state_step(nodes, arcs, adj_t, adj_d, an_t, an_d, w, s, BN_EPSILON, state, int(state_dim), float(state_threshold),
+                                 int(flags), hub_t, hub_d, None, [], [], [], [])
+    type_nodes, type_offsets, type_dims, cas = composite
+    ca_t, ca_d = [], []
+    for c in cas:
+        t, d = csr_args(c)
+        ca_t += t; ca_d += d
     return load().state_step(nodes, arcs, adj_t, adj_d, an_t, an_d, w, s, BN_EPSILON, state, int(state_dim), float(state_threshold),
-                             int(flags), hub_t, hub_d)
+                             int(flags), hub_t, hub_d, type_nodes, [int(v) for v in type_offsets], [int(v) for v in type_dims], ca_t, ca_d)
 
 
 def mlp_forward(net, X):

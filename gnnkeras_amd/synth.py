@@ -43,6 +43,39 @@ def er_graph(n_nodes: int, n_arcs: int, dim_node_label: int = 14, dim_arc_label:
     return GraphObject(nodes=nodes, arcs=arcs, targets=targets, focus=focus, aggregation_mode=aggregation_mode)
 
 
+_ER_ARCS_CACHE = {}
+
+
+def er_graph_slice(n_nodes: int, n_arcs: int, lo: int, hi: int, dim_node_label: int = 14, dim_arc_label: int = 3,
+                   aggregation_mode: str = 'average', seed: int = 1234):
+    """The `GraphSlice` (gnnkeras_amd.distributed) of `er_graph(n_nodes, n_arcs, ..., seed)` for the destination range [lo, hi):
+    the same arcs, labels and aggregation weights as the whole `GraphObject` would hand to that rank, without ever building
+    the whole graph's [E, 2 + A] matrix or its scipy operators.  What a rank of the sharded loop generates for itself: the id
+    draw and the label draws are replayed in full (they are what fixes the graph; 80 + 80 MB at C4 size), everything derived
+    from them only for the own arcs."""
+    from .distributed import GraphSlice
+    if aggregation_mode not in ('sum', 'normalized', 'average'): raise ValueError("ERROR: Unknown aggregation mode")
+    key = (n_nodes, n_arcs, seed)
+    if key not in _ER_ARCS_CACHE:
+        _ER_ARCS_CACHE.clear()
+        _ER_ARCS_CACHE[key] = er_arcs(n_nodes, n_arcs, seed)
+    ids = _ER_ARCS_CACHE[key]
+    rng = np.random.default_rng(seed + 1)
+    nodes = np.zeros((n_nodes, dim_node_label), dtype=np.float32)
+    nodes[np.arange(n_nodes), rng.integers(0, dim_node_label, n_nodes)] = 1
+    arc_label_of = rng.integers(0, dim_arc_label, n_arcs)          # (same draw order as er_graph: node labels, arc labels)
+    mine = np.flatnonzero((ids[:, 1] >= lo) & (ids[:, 1] < hi))
+    src, dst = ids[mine, 0], ids[mine, 1]
+    arc_labels = np.zeros((len(mine), dim_arc_label), dtype=np.float32)
+    arc_labels[np.arange(len(mine)), arc_label_of[mine]] = 1
+    values = np.ones(len(mine), dtype=np.float64)                   # reference graph_class.py:105-121
+    if aggregation_mode == 'normalized': values *= float(1 / n_arcs)
+    elif aggregation_mode == 'average':
+        values /= np.bincount(dst - lo, minlength=hi - lo)[dst - lo]   # every arc of a destination lives with it
+    ones = np.ones(hi - lo, dtype=bool)
+    return GraphSlice(n_nodes, nodes, lo, hi, src, dst, arc_labels, values.astype(np.float32), ones, ones, arc_index=mine)
+
+
 def er_composite_graph(n_nodes: int, n_arcs: int, dim_node_label=(14, 8, 4), dim_arc_label: int = 3,
                        dim_target: int = 2, focus: str = 'n', aggregation_mode: str = 'average',
                        seed: int = 1234) -> CompositeGraphObject:

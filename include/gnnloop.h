@@ -200,8 +200,10 @@ int gnn_mlp_forward(const gnn_mlp_t *mlp, const float *X, int32_t ldx, int32_t M
 int gnn_converged(const float *state, const float *state_old, int32_t n, int32_t dim, int32_t ld, float threshold,
                   int32_t *flag, void *stream);
 
-/* One state-transition step (GNN.py:217-236) for a homogeneous graph with pre-aggregated constants:
+/* One state-transition step: GNNnodeBased.convergence (GNN.py:217-236)
  *   state_new = net_state([state | nodes (if state_dim>0) | A^T state | agg_nodes | agg_arcs])
+ * or, with args->composite, CompositeGNNnodeBased.convergence (CompositeGNN.py:215-234): per node type t
+ *   state_new[type t rows] = net_state[t]([nodes[:, :d_t] | state | A^T state | agg_nodes_0.. | agg_arcs][type t rows])
  * and *flag_out = predicate(state_new, state) for the next iteration.  Mostly for tests / LGNN-style callers;
  * gnn_loop_forward does the same with the constants folded once.  `args` supplies graph, nets and workspace;
  * state_in/state_out are [n_nodes, S] row-major. */

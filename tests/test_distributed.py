@@ -203,11 +203,14 @@ def _problem(threshold, d=6, max_it=12):
     return g, model, s0
 
 
-def _worker(rank, world, port, threshold, d, out_q, halo=False, overlap=False, transport=None):
+def _worker(rank, world, port, threshold, d, out_q, halo=False, overlap=False, transport=None, from_slice=False):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         g, model, s0 = _problem(threshold, d)
+        if from_slice:                      # the rank holds nothing but its own destination range of the graph
+            from gnnkeras_amd.distributed import GraphSlice
+            g = GraphSlice.from_graph(g, *partition(g.nodes.shape[0], world)[1][rank])
         sl = (OracleHaloShardedLoop if halo else OracleShardedLoop)(model, g, rank, world, 'cpu', overlap=overlap)
         assert sl.overlap == overlap
         if transport == 'measured':
@@ -249,6 +252,70 @@ def test_sharded_loop_matches_single_process_oracle(world, threshold, d, halo, o
     out = np.concatenate([r[3] for r in res])
     assert state.shape == st_ref.shape and out.shape == out_ref.shape
     assert rel_err(state, st_ref) < 1e-6 and rel_err(out, out_ref) < 1e-6
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_sharded_loop_from_per_rank_graph_slices(overlap):
+    """Every rank builds its shard from its own `GraphSlice` (arcs of its destination range + all labels) instead of the
+    replicated `GraphObject`: same result."""
+    world, threshold, d = 2, 0.02, 6
+    g, model, s0 = _problem(threshold, d)
+    seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False, device='cpu')
+    k_ref, st_ref, out_ref = oracle_loop(model, seq[0][0], s0, np.float64)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 977 + 31 * overlap) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, threshold, d, q, False, overlap, None, True)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=180) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] == float(k_ref) for r in res)
+    assert rel_err(np.concatenate([r[2] for r in res]), st_ref) < 1e-6 and rel_err(np.concatenate([r[3] for r in res]), out_ref) < 1e-6
+
+
+def test_shard_plan_from_a_slice_equals_the_plan_from_the_whole_graph():
+    """`GraphSlice.from_graph` and the generator-side `synth.er_graph_slice` (which never builds the whole graph's matrices)
+    against `ShardPlan(GraphObject)`: bit-identical operators, labels and index lists, every aggregation mode, ragged ranges."""
+    from gnnkeras_amd.distributed import GraphSlice
+    from gnnkeras_amd.synth import er_graph_slice
+    for mode in ('average', 'sum', 'normalized'):
+        g = er_graph(1003, 9000, aggregation_mode=mode, seed=5)
+        for R in (1, 3, 8):
+            for r, (lo, hi) in enumerate(partition(1003, R)[1]):
+                a = ShardPlan(g, r, R)
+                for b in (ShardPlan(GraphSlice.from_graph(g, lo, hi), r, R),
+                          ShardPlan(er_graph_slice(1003, 9000, lo, hi, aggregation_mode=mode, seed=5), r, R)):
+                    for op in ('adjacency', 'arcnode'):
+                        for name in ('rowptr', 'src', 'w', 'row_scale'):
+                            x, y = getattr(getattr(a, op), name), getattr(getattr(b, op), name)
+                            assert (x is None and y is None) or np.array_equal(x, y), (mode, R, r, op, name)
+                    for name in ('arc_labels', 'nodes_full', 'nodes_local', 'out_index', 'arc_index'):
+                        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+                    assert (a.e_local, a.n_local, a.L, a.A, a.per_arc_weights) == (b.e_local, b.n_local, b.L, b.A, b.per_arc_weights)
+    with pytest.raises(ValueError):
+        ShardPlan(GraphSlice.from_graph(g, 0, 100), 1, 8)              # a slice of another rank's range
+
+
+def test_hub_rows_are_split_on_shards():
+    """A shard whose adjacency has a row above 512 in-arcs uploads the light operator + segment lists like the single-GPU path
+    (host-side part: the split reconstructs the row; the device part is tests/test_gpu_round3.py::test_hub_rows_on_shards)."""
+    from gnnkeras_amd.sparse import split_heavy, HEAVY_THRESHOLD
+    rng = np.random.default_rng(0)
+    N = 3000
+    ids = np.unique(np.concatenate([er_graph(N, 9000, seed=2).arc_ids, np.stack([rng.choice(N, 1500, replace=False), np.full(1500, 77)], 1)]), axis=0)
+    ids = ids[ids[:, 0] != ids[:, 1]]
+    g = GraphObject(np.ones((N, 2)), np.concatenate([ids, np.ones((len(ids), 1))], 1), np.ones((N, 1)), focus='n', aggregation_mode='average')
+    p = ShardPlan(g, 0, 2)
+    assert p.adjacency.max_degree > HEAVY_THRESHOLD
+    light, heavy = split_heavy(p.adjacency)
+    assert light.n_src == p.n_rows_full + heavy['n_seg'] and light.n_dst == p.n_local
+    j = 77
+    virt = light.src[light.rowptr[j]:light.rowptr[j + 1]]
+    assert np.array_equal(virt, p.n_rows_full + np.arange(heavy['n_seg']))
+    seg = np.concatenate([p.adjacency.src[b:e] for b, e in zip(heavy['seg_beg'], heavy['seg_end'])])
+    assert np.array_equal(seg, p.adjacency.src[p.adjacency.rowptr[j]:p.adjacency.rowptr[j + 1]])
 
 
 def test_partition_and_padded_rows():

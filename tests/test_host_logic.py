@@ -260,3 +260,55 @@ def test_merged_batches_for_convergence_groups(mutag_graphs):
     seq.set_batch_size(10)                                            # rebuilt batches: the cache starts over
     x2, b2 = seq.merged_batches(0, 2)
     assert b2[-1] == sum(g.nodes.shape[0] for g in gl[:20])
+
+
+def test_single_sequencers_opt_out_of_merged_batches_and_keep_their_config():
+    """A single-graph sequencer has nothing to merge (every batch is the whole graph): `merged_batches` answers None instead of
+    touching attributes it never had, so predict() / evaluate() take the batch-by-batch path; `assemble` survives copy()."""
+    from gnnkeras_amd.Sequencers.GraphSequencers import CompositeSingleGraphSequencer
+    from gnnkeras_amd.Sequencers.TransductiveGraphSequencers import TransductiveMultiGraphSequencer, TransductiveSingleGraphSequencer
+    rng = np.random.default_rng(2)
+    n = 20
+    g = GraphObject(rng.normal(size=(n, 2)), np.array([[i, (i + 1) % n, 1.] for i in range(n)]), rng.normal(size=(n, 1)),
+                    focus='n', set_mask=np.arange(n) < 10)
+    seq = SingleGraphSequencer(g, 'n', batch_size=4, shuffle=False, device='cpu')
+    assert seq.merged_batches(0, 1) is None and seq.merged_batches([0, 1]) is None
+    tm = np.zeros((n, 2), bool); tm[np.arange(n), rng.integers(0, 2, n)] = True
+    cg = CompositeGraphObject(rng.normal(size=(n, 3)), np.array([[i, (i + 1) % n, 1.] for i in range(n)]), rng.normal(size=(n, 1)),
+                              type_mask=tm, dim_node_label=(3, 2), focus='n')
+    assert CompositeSingleGraphSequencer(cg, 'n', batch_size=4, shuffle=False, device='cpu').merged_batches(0, 1) is None
+    np.random.seed(0)
+    assert TransductiveSingleGraphSequencer(g, 'n', 0.5, batch_size=4, shuffle=False, device='cpu').merged_batches(0, 1) is None
+    # composite batches are not merged across batches either (no convergence groups for composite models)
+    tseq = TransductiveMultiGraphSequencer([g.copy(), g.copy()], 'n', 'average', 0.5, batch_size=1, shuffle=False, device='cpu')
+    assert tseq.merged_batches(0, 2) is None
+    assert tseq.copy().transductive_rate == 0.5                            # get_config / from_config round trip
+    ms = MultiGraphSequencer([g.copy(), g.copy()], 'n', 'average', 1, shuffle=False, device='cpu', assemble='host')
+    assert ms.get_config()['assemble'] == 'host' and ms.copy().assemble == 'host'
+    # the same GraphObject twice in the list: the signature of the device data set counts distinct objects
+    twice = MultiGraphSequencer([g, g], 'n', 'average', 1, shuffle=False, device='cpu')
+    assert len(twice) == 2 and twice[0][0][0].shape[0] == n
+
+
+def test_fit_evaluate_predict_reject_unknown_keyword_arguments():
+    """Keras would raise on an argument it does not know; silently dropping one (round 2) hid typos such as `callback=`."""
+    ns = MLP((9,), [2], 'linear', 'zeros', 'zeros', device='cpu')
+    no = MLP((4,), [1], 'linear', 'zeros', 'zeros', device='cpu')
+    m = GNNnodeBased(ns, no, 2, 3, 0.01)
+    m.compile(optimizer='adam', loss='mse')
+    for call in (lambda: m.fit([], epochs=1, callback=[]), lambda: m.evaluate([], bogus=1), lambda: m.predict([], bogus=1)):
+        with pytest.raises(TypeError):
+            call()
+    from gnnkeras_amd.Models.GNN import History
+    h = m.fit([], epochs=2, verbose=0, workers=1, callbacks=[])            # no batches: nothing touches the device
+    assert isinstance(h, History) and h.history is h and h.epoch == [0, 1]
+    seen = []
+    class CB:
+        def set_model(self, model): seen.append(('model', model is m))
+        def on_train_begin(self, logs): seen.append('begin')
+        def on_epoch_end(self, epoch, logs):
+            seen.append(('epoch', epoch))
+            if epoch == 1: m.stop_training = True
+        def on_train_end(self, logs): seen.append('end')
+    m.fit([], epochs=5, verbose=0, callbacks=[CB()])
+    assert seen == [('model', True), 'begin', ('epoch', 0), ('epoch', 1), 'end']

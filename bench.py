@@ -206,6 +206,43 @@ def mutag_section(device, cpu: bool):
     return res
 
 
+def mutag_dp_section(device, rank, world):
+    """N > 1: the MUTAG data set over the ranks (gnnkeras_amd/data_parallel.py; SURVEY 8e "Other cases": batches are
+    block-diagonal, so they shard by graph with no halo).  predict(): the launches of the group plan dealt to the ranks, outputs
+    all-gathered; train_step(): every batch of 32 graphs cut into one shard per rank, the step of the whole batch reproduced
+    (BatchNorm statistics, convergence flag, loss and gradient sums across ranks).  Collective: every rank calls it."""
+    import torch.distributed as dist
+    from gnnkeras_amd.load_MUTAG import load_graphs
+    from gnnkeras_amd.Models.GNN import GNNgraphBased
+    from gnnkeras_amd.Models.training import Adam
+    from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+    from gnnkeras_amd.data_parallel import DataParallel
+    graphs = load_graphs()
+    seq = MultiGraphSequencer(graphs, 'g', 'average', 32, shuffle=False, device=device)
+    ns, no = starter_nets(32, device, 'g')
+    gnn = GNNgraphBased(ns, no, 32, 50, 0.01)
+    gnn.compile(optimizer=Adam(0.001), loss='categorical_crossentropy', metrics=['accuracy'])
+    dpm = DataParallel(gnn)
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps): fn()
+        torch.cuda.synchronize(); dist.barrier()
+        t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+    t_pred = timed(lambda: dpm.predict(seq), 3)
+    n_steps = 8
+    t_step = timed(lambda: [dpm.train_step(dpm.shard(seq, i)) for i in range(n_steps)], 1) / n_steps
+    return {'workload': 'MUTAG 4337 graphs as 136 batches of 32, state_dim=32, max_iteration=50, threshold=0.01',
+            'predict_ms_per_graph': 1e3 * t_pred / len(graphs), 'predict_ms': 1e3 * t_pred,
+            'how': f'group-plan launches dealt round-robin to {world} ranks, outputs all-gathered (RCCL)',
+            'train_step_ms_per_batch': 1e3 * t_step,
+            'train_how': f'each batch of 32 graphs as {world} shards of whole graphs; BatchNorm statistics, convergence flag, P / q and '
+                         f'gradient sums exchanged per iteration (building-block path)'}
+
+
 def measure_loop(gnn, inputs, s0, steps, warmup):
     """(elapsed seconds of `steps` forwards, k, seconds per iteration kernel launch) on one GPU; the per-launch time comes from
     HIP events the library records on the launch stream around the iteration launches (gnn.loop_events)."""
@@ -532,6 +569,10 @@ def main():
         torch.cuda.empty_cache()
         result['beyond_infinity_cache'] = beyond_cache_section(device, d, K_it, args.aggregation)
 
+    if sharded and world > 1 and not args.no_mutag and args.workload == 'c4':
+        del sl
+        torch.cuda.empty_cache()
+        result['mutag_data_parallel'] = mutag_dp_section(device, rank, world)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if sharded:

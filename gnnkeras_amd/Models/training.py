@@ -191,6 +191,17 @@ class _Prim:
     def axpby(self, a, x, b, y, out):
         nat.check(self.lib.gnn_axpby(float(a), nat.ptr(x), float(b), nat.ptr(y), nat.ptr(out), x.numel(), self.stream()))
 
+    def converged_gated(self, state, state_old, thr, gate, flag, k_dev, k_val):
+        """flag |= any_row(||state - state_old|| > thr ||state_old||) when *gate != 0 (gate None: always); k_dev = k_val then."""
+        N, S = state.shape
+        nat.check(self.lib.gnn_converged_gated(nat.ptr(state), nat.ptr(state_old), N, S, state.stride(0), float(thr), nat.ptr(gate),
+                                               nat.ptr(flag), nat.ptr(k_dev), float(k_val), self.stream()))
+
+    def loss_grad(self, kind, y, y_pred, sw, dpred, loss_rows):
+        R, T = y_pred.shape
+        nat.check(self.lib.gnn_loss_grad(kind, nat.ptr(y), nat.ptr(y_pred), nat.ptr(sw), R, T, nat.ptr(dpred), nat.ptr(loss_rows),
+                                         self.stream()))
+
 
 class _NetGrads:
     """Gradient buffers of one Sequential in `trainable_variables` order (BN: γ, β; Dense: W, b ...)."""
@@ -253,8 +264,14 @@ def _mix32(*values):
 class LoopTrainer:
     """One instance per model; owns gradient buffers and scratch. Homogeneous node / arc / graph focus."""
 
-    def __init__(self, model):
+    prim_cls = _Prim                # the device primitives (tests/test_data_parallel.py swaps in a NumPy stand-in on CPU)
+
+    def __init__(self, model, dp=None):
+        """`dp`: a `gnnkeras_amd.data_parallel.DPContext` - the batch is then ONE SHARD (a subset of the graphs) of a merged batch
+        whose other shards run on the other ranks, and the step reproduces the single-process step on the merged batch: BatchNorm
+        statistics, the convergence test, the loss normalisation and the weight-gradient sums span all ranks."""
         self.model = model
+        self.dp = dp
 
     # ---- generic MLP forward (training mode) / backward over segmented inputs -------------------------------------------
     def _drop_key(self, ng: _NetGrads, call, index):
@@ -294,6 +311,7 @@ class LoopTrainer:
                     else:
                         p.colstats(x, ridx, M, mean[off:off + w], var[off:off + w])
                     off += w
+                if self.dp is not None: mean, var = self.dp.combine_stats(mean, var, 'out' if ng is self.go else 'nodes')   # statistics of the MERGED batch
             Wf, bf = p.new(*ng.W[0].shape), p.new(ng.W[0].shape[1])
             p.fold(ng.W[0], ng.b[0], ng.bn_params, mean, var, Wf, bf)
         else:
@@ -332,7 +350,13 @@ class LoopTrainer:
         mean, var = stats if stats is not None else (None, None)
         m1 = m2 = None
         if ng.bn: m1, m2 = p.new(K), p.new(K)
-        p.first_layer_param_grads(P, q, ng.W[0], ng.bn_params, mean, var, M, ng.dW[0], ng.db[0], ng.dgamma, ng.dbeta,
+        M_all = M
+        if self.dp is not None:
+            # P = X^T dZ and q = colsum(dZ) over the rows of EVERY shard: the first layer's parameter gradients and the BatchNorm
+            # input-gradient moments m1 / m2 (means over all rows of the merged batch) follow from the sums
+            self.dp.all_reduce_sum(P, q)
+            M_all = self.dp.total_rows('out' if ng is self.go else 'nodes')
+        p.first_layer_param_grads(P, q, ng.W[0], ng.bn_params, mean, var, M_all, ng.dW[0], ng.db[0], ng.dgamma, ng.dbeta,
                                   m1, m2, acc)
         ng.touched = True
         if dx_requests:
@@ -361,7 +385,7 @@ class LoopTrainer:
             nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph = inputs
         nat.require_device(nodes, 'nodes')
         dev = tp.dev = nodes.device
-        self.prim = p = tp.p = _Prim(dev)
+        self.prim = p = tp.p = self.prim_cls(dev)
         nodes = tp.nodes = nodes.to(torch.float32).contiguous(); arcs = arcs.to(torch.float32).contiguous()
         N, L = nodes.shape
         A = arcs.shape[1] - 2
@@ -466,9 +490,12 @@ class LoopTrainer:
         # ---- every iteration is computed, the predicate only records where the loop stops ----
         flags = torch.zeros(K_it + 2, dtype=torch.int32, device=dev)
         k_dev = torch.zeros((), dtype=torch.float32, device=dev)
-        lib = nat.lib()
-        nat.check(lib.gnn_converged_gated(nat.ptr(states[0]), None, N, S, S, float(m.state_threshold), None,
-                                          nat.ptr(flags[0:1]), None, 0.0, p.stream()))
+        dp = self.dp
+        if dp is not None:
+            if composite: raise NotImplementedError('data-parallel training covers homogeneous models')
+            dp.begin_step(N, M)
+        p.converged_gated(states[0], None, m.state_threshold, None, flags[0:1], None, 0.0)
+        if dp is not None: dp.any_flag(flags[0:1])                    # `reduce_any` over the nodes of the merged batch (GNN.py:212)
         stats_t = tp.stats_t = []
         for t in range(K_it):
             p.aggregate(adj, states[t], S, agg)
@@ -482,9 +509,8 @@ class LoopTrainer:
                 else: states[t + 1].index_copy_(0, rows_long[ty], hs.out)
                 st_t.append(st)
             stats_t.append(st_t)
-            nat.check(lib.gnn_converged_gated(nat.ptr(states[t + 1]), nat.ptr(states[t]), N, S, S, float(m.state_threshold),
-                                              nat.ptr(flags[t:t + 1]), nat.ptr(flags[t + 1:t + 2]), nat.ptr(k_dev),
-                                              float(t + 1), p.stream()))
+            p.converged_gated(states[t + 1], states[t], m.state_threshold, flags[t:t + 1], flags[t + 1:t + 2], k_dev, t + 1)
+            if dp is not None: dp.any_flag(flags[t + 1:t + 2])
         k = tp.k = int(float(k_dev))                                # the one host synchronisation of the step
         for ty in range(T_types):                                   # k moving-average updates, applied in order (closed form)
             if gs[ty].bn and k > 0 and counts[ty] > 0:
@@ -534,8 +560,14 @@ class LoopTrainer:
         dpred, loss_rows = p.new(R, T), p.zeros(max(R, 1))
         kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
         if kind.lower() not in nat.LOSSES: raise ValueError(f'loss {kind!r} has no device gradient')
-        nat.check(nat.lib().gnn_loss_grad(nat.LOSSES[kind.lower()], nat.ptr(y), nat.ptr(y_pred.contiguous()), nat.ptr(sw), R, T,
-                                          nat.ptr(dpred), nat.ptr(loss_rows), p.stream()))
+        p.loss_grad(nat.LOSSES[kind.lower()], y, y_pred.contiguous(), sw, dpred, loss_rows)
+        if self.dp is not None:
+            # SUM_OVER_BATCH_SIZE over the target rows of the merged batch: the kernel divided by this shard's row count
+            R_all = self.dp.total_rows('targets', R)
+            total = loss_rows[:R].sum().reshape(1)
+            self.dp.all_reduce_sum(total)
+            dpred.mul_(R / R_all)
+            return total[0] / max(R_all, 1), dpred
         return loss_rows[:R].sum() / max(R, 1), dpred
 
     def pool_backward(self, tp, dpred):
@@ -553,6 +585,7 @@ class LoopTrainer:
         arc-label segment (GNN.py:326): what an arc-focused LGNN layer with `get_output` hands to the layer below."""
         m, p = self.model, tp.p
         self.prim, self.drop_seed = p, tp.drop_seed                 # the recomputed calls draw the forward's Dropout masks
+        self.go = tp.go
         N, S, L, d, M, k, focus = tp.N, tp.S, tp.L, tp.d, tp.M, tp.k, tp.focus
         gs, go, rows, rows_long, counts = tp.gs, tp.go, tp.rows, tp.rows_long, tp.counts
         G_state = p.zeros(N, S)                                     # dL / d states[k]
@@ -661,6 +694,11 @@ class LoopTrainer:
                 for g in g_.gradients(): g.zero_()
         if not tp.go.touched:
             for g in tp.go.gradients(): g.zero_()
+        if self.dp is not None:
+            # layers behind the first: dW_l = h_{l-1}^T dZ_l summed over the rows of every shard (the first layer's gradients were
+            # formed from the all-reduced P, q and are global already)
+            upper = [g for g_ in list(tp.gs) + [tp.go] for l in range(1, len(g_.dW)) for g in (g_.dW[l], g_.db[l])]
+            if upper: self.dp.all_reduce_sum(*upper)
         for g_ in list(tp.gs) + [tp.go]:
             r = _regularize(g_)
             if r is not None: reg = r if reg is None else reg + r
@@ -683,6 +721,7 @@ class LoopTrainer:
 
     def _native_step_applies(self, y):
         m = self.model
+        if self.dp is not None: return False        # collectives sit between the iteration's launches: the building-block path
         if not self.use_native_step or isinstance(m.net_state, (list, tuple)) or y is None: return False
         if m.net_state.dropout_rate or m.net_output.dropout_rate: return False      # Dropout masks: the general path below
         kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))

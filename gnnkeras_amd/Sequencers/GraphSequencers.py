@@ -107,15 +107,40 @@ class MultiGraphSequencer:
         if cache.get('owner') is not self.graph_tensors: cache.clear(); cache['owner'] = self.graph_tensors
         if key not in cache:
             of = lambda b: self.data[b * self.batch_size: (b + 1) * self.batch_size]
-            graphs = [g_ for b in batches for g_ in of(b)]
-            ds = self._device_dataset()
-            if ds is not None:
-                index = self._dataset[2]
-                g = ds.assemble([index[id(g_)] for g_ in graphs])
-            else:
-                g = self.to_graph_tensor(self.merge(graphs, focus=self.focus, aggregation_mode=self.aggregation_mode), self.device)
+            g = self._assemble_graphs([g_ for b in batches for g_ in of(b)])
             sizes = [sum(int(g_.nodes.shape[0]) for g_ in of(b)) for b in batches]
             cache[key] = (self._x_list(g), [0] + [int(v) for v in np.cumsum(sizes)])
+        return cache[key]
+
+    def _assemble_graphs(self, graphs):
+        """The merged graph of `graphs` (in that order) on the device: one ragged-copy launch where the data set lives on the
+        device, numpy merge + upload otherwise."""
+        ds = self._device_dataset()
+        if ds is not None:
+            index = self._dataset[2]
+            return ds.assemble([index[id(g_)] for g_ in graphs])
+        return self.to_graph_tensor(self.merge(graphs, focus=self.focus, aggregation_mode=self.aggregation_mode), self.device)
+
+    def shard_item(self, index: int, rank: int, world_size: int):
+        """(x_list, targets, sample_weight) of rank `rank`'s share of batch `index` - a contiguous, balanced run of WHOLE graphs
+        of the batch, merged like any batch (additive; what `gnnkeras_amd.data_parallel.DataParallel` trains on: a merged batch is
+        block-diagonal, reference graph_class.py:399-408, so it shards by graph with no halo).  The shares of all ranks, in rank
+        order, are the batch.  'normalized' aggregation cannot be sharded: its weights are 1 / #arcs of the whole batch."""
+        if self.aggregation_mode == 'normalized':
+            raise ValueError("'normalized' aggregation divides by the arc count of the whole merged batch: not shardable by graph")
+        graphs = self.data[index * self.batch_size: (index + 1) * self.batch_size]
+        lo, hi = len(graphs) * rank // world_size, len(graphs) * (rank + 1) // world_size
+        if hi <= lo: raise ValueError(f'batch {index} has {len(graphs)} graphs: nothing left for rank {rank} of {world_size}')
+        cache = self.__dict__.setdefault('_merged', {})
+        if cache.get('owner') is not self.graph_tensors: cache.clear(); cache['owner'] = self.graph_tensors
+        key = ('shard', int(index), int(rank), int(world_size))
+        if key not in cache:
+            g = self._assemble_graphs(graphs[lo:hi])
+            if self.focus == 'g':
+                cache[key] = (self._x_list(g), g.targets, g.sample_weight)
+            else:
+                mask = g.set_mask[g.output_mask]
+                cache[key] = (self._x_list(g), g.targets[mask], g.sample_weight[mask])
         return cache[key]
 
     def copy(self):

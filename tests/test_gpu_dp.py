@@ -1,0 +1,106 @@
+"""Data-parallel / batch-parallel product path over the REAL backend ("nccl" = RCCL): every rank a child process started with
+torch.distributed.run, as the driver starts bench.py.
+
+* world size 1 on one GPU (always runs on the GPU box): `DataParallel.train_step` (building blocks + RCCL collectives between
+  them) against the single-process in-library step, `predict` / `evaluate` / `fit` through the collective code;
+* world size 2 when two GPUs are visible: the same, each rank on its shard of whole graphs - gradients, loss, k and BatchNorm
+  moving statistics of the SINGLE-PROCESS step on the whole batch."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+WORKER = textwrap.dedent('''
+    import os, sys, json
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, os.environ['GNN_ROOT'])
+    rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    from gnnkeras_amd.load_MUTAG import load_graphs
+    from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+    from gnnkeras_amd.Models.GNN import GNNgraphBased
+    from gnnkeras_amd.Models.training import LoopTrainer, Adam
+    from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+    from gnnkeras_amd.data_parallel import DataParallel
+    from oracle.harness import rel_err
+    graphs = load_graphs(limit=96)
+    d = 16
+    def build():
+        inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d); ns = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0, device=dev)
+        ns.set_weights([w * 0.5 if w.ndim == 2 else w for w in ns.get_weights()])
+        inp, lay = get_inout_dims('output', 14, 3, 2, 'g', d, hidden_units=[8]); no = MLP(inp[0], lay, ['tanh', 'softmax'], 'glorot_normal', 'glorot_normal', rng=1, device=dev)
+        m = GNNgraphBased(ns, no, d, 6, 0.02)
+        m.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['accuracy'])
+        return m
+    seq = MultiGraphSequencer([g.copy() for g in graphs], 'g', 'average', 32, shuffle=False, device=dev)
+    sizes = [g.nodes.shape[0] for g in graphs[:32]]
+    s0 = np.random.default_rng(1).normal(0, 0.1, (sum(sizes), d)).astype(np.float32)
+    # single-process step on the whole batch (the in-library gnn_train_step), on every rank
+    ref_model = build()
+    tr = LoopTrainer(ref_model)
+    x, y, sw = seq[0]
+    ref = tr.train_step(x, y, sw, state0=torch.from_numpy(s0).to(dev), apply=False)
+    ref_grads = [g.cpu().numpy().copy() for g in tr.gs.gradients() + tr.go.gradients()]
+    ref_moving = [w.copy() for w in ref_model.net_state.get_weights()[2:4] + ref_model.net_output.get_weights()[2:4]]
+    # data-parallel step: this rank's shard
+    model = build()
+    dpm = DataParallel(model)
+    shard = dpm.shard(seq, 0)
+    lo, hi = 32 * rank // world, 32 * (rank + 1) // world
+    n0 = sum(sizes[:lo]); n1 = n0 + sum(sizes[lo:hi])
+    res = dpm.train_step(shard, state0=torch.from_numpy(s0[n0:n1]).to(dev), apply=False)
+    got = [g.cpu().numpy() for g in dpm._trainer.gs.gradients() + dpm._trainer.go.gradients()]
+    assert res['k'] == ref['k'], (res['k'], ref['k'])
+    assert abs(float(res['loss']) - float(ref['loss'])) <= 1e-5 * max(1.0, abs(float(ref['loss'])))
+    worst = 0.0
+    scale = max(float(np.max(np.abs(r))) for r in ref_grads)
+    for g, r in zip(got, ref_grads):
+        e = float(np.max(np.abs(g - r)) / max(float(np.max(np.abs(r))), 1e-12))
+        assert e <= 2e-4 or float(np.max(np.abs(g - r))) <= 2e-4 * scale, e
+        worst = max(worst, min(e, float(np.max(np.abs(g - r))) / scale))
+    for a, b in zip(model.net_state.get_weights()[2:4] + model.net_output.get_weights()[2:4], ref_moving):
+        assert rel_err(a, b) <= 1e-5
+    # inference: the collective predict / evaluate against the single-process calls
+    p_dp, e_dp = dpm.predict(seq), dpm.evaluate(seq, return_dict=True)
+    p_1, e_1 = model.predict(seq), model.evaluate(seq, return_dict=True)
+    assert p_dp.shape == (96, 2) and rel_err(p_dp, p_1) <= 1e-5
+    assert abs(e_dp['loss'] - e_1['loss']) <= 1e-5 and abs(e_dp['accuracy'] - e_1['accuracy']) <= 1e-6
+    # fit: two epochs with reshuffling; every rank ends with the same weights
+    seq_t = MultiGraphSequencer([g.copy() for g in graphs], 'g', 'average', 32, shuffle=True, device=dev)
+    hist = dpm.fit(seq_t, epochs=2, verbose=0, validation_data=seq)
+    w = torch.cat([torch.from_numpy(a.reshape(-1)) for a in model.net_state.get_weights() + model.net_output.get_weights()]).to(dev)
+    parts = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(parts, w)
+    assert all(torch.equal(parts[0], p_) for p_ in parts), 'ranks diverged'
+    assert len(hist['loss']) == 2 and np.isfinite(hist['loss']).all() and 'val_loss' in hist
+    dist.barrier(); torch.cuda.synchronize()
+    dist.destroy_process_group()
+    if rank == 0: print('DP_OK ' + json.dumps({'k': res['k'], 'worst_grad_err': worst, 'loss': [float(v) for v in hist['loss']]}))
+''')
+
+
+def _run_ranks(tmp_path, world):
+    script = tmp_path / 'dp_worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, GNN_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
+           '--master-port', str(29640 + world), str(script)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0 and 'DP_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+def test_data_parallel_over_rccl_world_1(tmp_path):
+    _run_ranks(tmp_path, 1)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs at least 2 GPUs on the box')
+def test_data_parallel_over_rccl_world_2(tmp_path):
+    _run_ranks(tmp_path, 2)

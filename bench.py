@@ -569,7 +569,7 @@ def main():
         torch.cuda.empty_cache()
         result['beyond_infinity_cache'] = beyond_cache_section(device, d, K_it, args.aggregation)
 
-    if sharded and world > 1 and not args.no_mutag and args.workload == 'c4':
+    if sharded and (world > 1 or args.force_sharded) and not args.no_mutag and args.workload == 'c4':
         del sl
         torch.cuda.empty_cache()
         result['mutag_data_parallel'] = mutag_dp_section(device, rank, world)

@@ -1,0 +1,385 @@
+// Training at large M (reference GNN/Models/GNN.py:277-306 on graphs of 10^5 .. 10^7 nodes): the per-iteration kernels of
+// gnn_train_step when the step is bandwidth work, not launch count.
+//
+// Round 2 ran a training iteration on the general kernels: aggregate (401 us at C4 size) + four column-statistics passes
+// (4 x 115 us) + the staged dense kernel k_segdense<1> (378 us, 1.5-2.4 TB/s: its waves are parked 67 % of the time at the
+// workgroup barriers of its LDS staging) forward; activation gradient + weight gradient + two more k_segdense calls + the
+// BatchNorm input gradient + the transposed aggregate backward.  Here:
+//
+//   * k_aggregate_stats   - the neighbour sum of an iteration (kept on the tape) that also leaves the per-column sum and sum of
+//                           squares of what it wrote: the training-mode BatchNormalization statistics of the aggregated-state
+//                           columns (reference MLP.py:67-70) cost no extra pass;
+//   * k_train_fwd<SQ,NCT> - the first Dense of the state network over [state | agg | constant inputs] with the batch statistics
+//                           folded into its weights: rows go from global memory STRAIGHT into MFMA A-fragment registers (16-byte
+//                           loads, permuted k order, as kernel_state_wide.hpp / kernel_state_lds.hpp do), the folded weights sit
+//                           in LDS in the matching order - no staging tile, no barrier inside the row loop; activation, the
+//                           convergence predicate (GNN.py:196-212) and the column statistics of the NEW state (next iteration's
+//                           BatchNorm input) in the epilogue;
+//   * k_train_bwd_dx<HQ,NCT> - d loss / d [state | agg] = BN-input-gradient(dZ . W1^T): the same row-streaming MFMA loop, the
+//                           BatchNormalization input gradient (three coefficients per column) and the row scale of 'average'
+//                           aggregation in the epilogue - replaces two dense launches and the BN-gradient pass.
+// Exact float32 on v_mfma_f32_16x16x4_f32 like every other dense kernel here; deterministic (fixed tile -> wave assignment,
+// per-workgroup partial statistics summed in workgroup order by k_stats_finish).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels_general.hpp"
+#include "kernel_state_fused4.hpp"      // activate4
+#include "kernel_state_lds.hpp"         // row16_sum_to_lane15
+#include "kernels_train.hpp"            // activate_grad_from_output
+#include "buffer_ops.hpp"
+
+namespace gnn {
+
+#ifndef TB_ABL
+#define TB_ABL 0                         // ablation switches of scripts/micro/rowgemm_bench.hip (1 no MFMAs, 2 no predicate, 4 no stores, 8 no statistics); 0 in the library
+#endif
+// Results of the last MFMAs of a tile are consumed behind a branch (the activation switch, `if (gamma)`): hipcc 7.2's hazard
+// recognizer does not carry the "XDL write -> VALU / VMEM read" wait states (up to 18 for this shape) across the block boundary -
+// k_train_bwd_dx<1, 2> without BatchNormalization read its accumulators two instructions after the MFMA that wrote them and
+// returned stale registers (scripts/micro/rowgemm_check.hip reproduces it).  Explicit wait states after the MFMA loop.
+#define TB_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")
+constexpr int TB_WAVES = 8;              // waves per workgroup (512 threads; launch bound 4 waves per SIMD = 2 workgroups per CU at <= 128 VGPRs)
+
+// ---- neighbour sum + column statistics of the result -------------------------------------------------------------------------------
+// k_aggregate_vec (kernels_general.hpp) with one addition: every thread keeps the sum and the sum of squares of the float4 column
+// chunk it writes; a workgroup folds its threads' partials in a fixed order into stat_part[blockIdx.x][2 F] (sums, then squares).
+template <int LPR, bool HAS_W>
+__global__ void __launch_bounds__(256)
+k_aggregate_stats(const int *gate, int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src,
+                  const float *__restrict__ w, const float *__restrict__ row_scale, const float *__restrict__ X, int ldx,
+                  float *__restrict__ out, int ldo, float *__restrict__ stat_part) {
+    if (gate_closed(gate)) return;
+    __shared__ f32x4 red[2][256];
+    const int l4 = threadIdx.x % LPR;
+    constexpr int groups = 256 / LPR;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int j = blockIdx.x * groups + threadIdx.x / LPR; j < n_dst; j += gridDim.x * groups) {
+        const int beg = rowptr[j], end = rowptr[j + 1];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int e = beg; e < end; e += 8) {                   // summed in arc order
+            f32x4 x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = e + i < end;
+                const int sid = ok ? src[e + i] : 0;
+                x[i] = ok ? *reinterpret_cast<const f32x4 *>(X + (size_t)sid * ldx + 4 * l4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (HAS_W) acc += (e + i < end ? w[e + i] : 0.0f) * x[i];
+                else acc += x[i];
+            }
+        }
+        if (row_scale) acc *= row_scale[j];
+        *reinterpret_cast<f32x4 *>(out + (size_t)j * ldo + 4 * l4) = acc;
+        s1 += acc; s2 += acc * acc;
+    }
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < 2 * LPR) {                                // one thread per (sum | square, column chunk): groups in order
+        const int which = threadIdx.x / LPR, c4 = threadIdx.x % LPR;
+        f32x4 t = red[which][c4];
+        for (int gq = 1; gq < groups; ++gq) t += red[which][gq * LPR + c4];
+        *reinterpret_cast<f32x4 *>(stat_part + (size_t)blockIdx.x * (8 * LPR) + which * (4 * LPR) + 4 * c4) = t;
+    }
+}
+
+// mean[c] = sum / M, var[c] = max(sumsq / M - mean^2, 0) from n_part partials of [2 F] (sums | squares).  One 256-thread workgroup
+// per column: thread i sums partials i, i + 256, .. in order, then a fixed LDS tree - deterministic.  (One-pass moments: the columns
+// are activations / their neighbour averages, |mean| and sigma of the same order, the tail in double; BatchNormalization adds
+// eps = 1e-3 to the variance before the square root.)
+__global__ void __launch_bounds__(256)
+k_stats_finish(const int *gate, const float *__restrict__ part, int n_part, int F, float inv_m, float *__restrict__ mean, float *__restrict__ var) {
+    if (gate_closed(gate)) return;
+    __shared__ double sh[2][256];
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int p = threadIdx.x; p < n_part; p += 256) { s += (double)part[(size_t)p * 2 * F + c]; q += (double)part[(size_t)p * 2 * F + F + c]; }
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) { sh[0][threadIdx.x] += sh[0][threadIdx.x + off]; sh[1][threadIdx.x] += sh[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mu = sh[0][0] * (double)inv_m;
+        mean[c] = (float)mu;
+        var[c] = (float)fmax(sh[1][0] * (double)inv_m - mu * mu, 0.0);
+    }
+}
+
+// ---- forward: first Dense of the state network in training mode ----------------------------------------------------------------------
+struct ConstCols { int width[3], wrow[3], n; };       // constant input columns of xc: segment s covers `width[s]` columns, weight rows wrow[s]..
+
+struct TrainFwdArgs {
+    const int *gate;
+    int M;
+    const float *state; int ld_state;     // [M, 16 SQ]
+    const float *agg; int ld_agg;         // [M, 16 SQ]
+    const float *xc;                      // [M, 32] constant inputs (k_pack_xc layout: segments, then a 1, then zeros) or NULL
+    const float *Wf, *bf; int H;          // folded first layer [in_dim][H] (BatchNorm of THIS iteration folded in), bias [H]
+    int wrow_state, wrow_agg;
+    ConstCols cs;
+    int act;
+    float *Y; int ldy;                    // [M, H]
+    float thr; int *pred_flag; float *pred_k; float pred_kval;      // predicate of Y against `state` (H == 16 SQ), optional
+    float *stat_part;                     // [gridDim.x][2 * 16 NCT] column sums / squares of Y, optional
+};
+
+template <int NCT> struct BFrag;
+template <> struct BFrag<1> { float v[1]; __device__ __forceinline__ void load(const float *p) { v[0] = *p; } };
+template <> struct BFrag<2> { float v[2]; __device__ __forceinline__ void load(const float *p) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; } };
+template <> struct BFrag<4> { float v[4]; __device__ __forceinline__ void load(const float *p) { const f32x4 t = *reinterpret_cast<const f32x4 *>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; } };
+template <> struct BFrag<8> { float v[8]; __device__ __forceinline__ void load(const float *p) {
+    const f32x4 t = *reinterpret_cast<const f32x4 *>(p), u = *reinterpret_cast<const f32x4 *>(p + 4);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; v[4] = u[0]; v[5] = u[1]; v[6] = u[2]; v[7] = u[3]; } };
+
+// The matrix core is fed TRANSPOSED: the weights are the A operand (A[i][k] = W[k][16 ct + i]), the input rows the B operand
+// (B[k][j] = X[row j][k]) - for v_mfma_f32_16x16x4_f32 both operands have the same register layout (lane l supplies element
+// (l % 16, l / 16)), so the 16-byte row chunks a lane loaded serve as they are - and the result D[i][j] = Y[row j][16 ct + i] leaves
+// lane (c, g) holding Y[row c][16 ct + 4 g .. + 3]: four CONSECUTIVE columns of its own row.  Output, old state (the A chunks of the
+// state segment) and stores all share the row-major 16-byte layout: no transposition, no 4-byte accesses, no loads in the epilogue.
+template <int SQ, int NCT>
+__global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_fwd(TrainFwdArgs a) {
+    if (gate_closed(a.gate)) return;
+    constexpr int NQ = 2 * SQ + 2;                    // 16-column chunks of an input row: state, agg, constant inputs (32 columns)
+    constexpr int HP = 16 * NCT;
+    extern __shared__ __attribute__((aligned(16))) float tb_smem[];
+    float *Wl = tb_smem;                               // [4 NQ k-steps][4 g][16 c][NCT]
+    float *bias_l = tb_smem + 16 * NQ * HP;            // [HP]
+    float *red = bias_l + HP;                          // [TB_WAVES][2 HP] statistics hand-over
+    __shared__ int any_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    if (tid == 0) any_s = 0;
+    // ---- folded weights into LDS in fragment order: k-step (q, e) of lane group g multiplies virtual column 16 q + 4 g + e ------
+    for (int i = tid; i < 16 * NQ * HP; i += 64 * TB_WAVES) {
+        const int k = i / HP, h = i % HP;
+        int row = -1;
+        if (k < 16 * SQ) row = a.wrow_state + k;
+        else if (k < 32 * SQ) row = a.wrow_agg + (k - 16 * SQ);
+        else if (a.xc) {
+            int j = k - 32 * SQ, beg = 0;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                if (s < a.cs.n && j >= beg && j < beg + a.cs.width[s]) row = a.cs.wrow[s] + (j - beg);
+                if (s < a.cs.n) beg += a.cs.width[s];
+            }
+        }
+        const float v = (row >= 0 && h < a.H) ? a.Wf[(size_t)row * a.H + h] : 0.0f;
+        const int q = k >> 4, rem = k & 15, gg = rem >> 2, e = rem & 3;
+        Wl[(((4 * q + e) * 4 + gg) * 16 + (h & 15)) * NCT + (h >> 4)] = v;
+    }
+    for (int h = tid; h < HP; h += 64 * TB_WAVES) bias_l[h] = h < a.H ? a.bf[h] : 0.0f;
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t r_s = buf_rsrc(a.state), r_a = buf_rsrc(a.agg), r_x = buf_rsrc(a.xc), r_y = buf_rsrc(a.Y);
+    const int n_tiles = (a.M + 15) >> 4;
+    f32x4 cs1[NCT], cs2[NCT];                           // column sums / squares of this lane's four columns per tile
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) { cs1[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; cs2[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    int any = 0;
+#pragma unroll 1
+    for (int t = blockIdx.x * TB_WAVES + wave; t < n_tiles; t += gridDim.x * TB_WAVES) {
+        const int row = 16 * t + c;                     // this lane's row: input chunks, output chunks, old state
+        const bool in = row < a.M;
+        f32x4 A[NQ];
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) {
+            A[q] = buf_ld_f32x4(r_s, in ? ((unsigned)row * (unsigned)a.ld_state + 16u * q + 4u * g) * 4u : BUF_OFF);
+            A[SQ + q] = buf_ld_f32x4(r_a, in ? ((unsigned)row * (unsigned)a.ld_agg + 16u * q + 4u * g) * 4u : BUF_OFF);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) A[2 * SQ + q] = buf_ld_f32x4(r_x, in ? ((unsigned)row * 32u + 16u * q + 4u * g) * 4u : BUF_OFF);
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = *reinterpret_cast<const f32x4 *>(bias_l + 16 * ct + 4 * g);
+#if (TB_ABL & 1)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q % NCT] += A[q];
+#else
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                BFrag<NCT> w;
+                w.load(Wl + (((4 * q + e) * 4 + g) * 16 + c) * NCT);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[ct], A[q][e], acc[ct], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);         // keep the fragment reads of later chunks from being hoisted (register budget)
+        }
+        TB_MFMA_DRAIN();
+#endif
+        // ---- epilogue: acc[ct] = Y[row][16 ct + 4 g .. + 3] ----------------------------------------------------------------------------
+        float d2 = 0.0f, n2 = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f32x4 v = acc[ct];
+            activate4(a.act, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (in && 16 * ct + 4 * g + e < a.H) ? v[e] : 0.0f;
+            const u32x4 bits = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+#if (TB_ABL & 4)
+            __builtin_amdgcn_raw_buffer_store_b128(bits, r_y, (in && v[0] == 1.2345e30f) ? (int)(((unsigned)row * (unsigned)a.ldy + 16u * ct + 4u * g) * 4u) : (int)BUF_OFF, 0, 0);
+#else
+            __builtin_amdgcn_raw_buffer_store_b128(bits, r_y, (in && 16 * ct + 4 * g < a.H) ? (int)(((unsigned)row * (unsigned)a.ldy + 16u * ct + 4u * g) * 4u) : (int)BUF_OFF, 0, 0);
+#endif
+#if !(TB_ABL & 8)
+            cs1[ct] += v; cs2[ct] += v * v;
+#endif
+            if (a.pred_flag && !(TB_ABL & 2) && ct < SQ) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float o = A[ct][e], d = v[e] - o; d2 = fmaf(d, d, d2); n2 = fmaf(o, o, n2); }
+            }
+        }
+        if (a.pred_flag && !(TB_ABL & 2)) {             // the row's four lane groups
+            d2 += __shfl_xor(d2, 16, 64); d2 += __shfl_xor(d2, 32, 64);
+            n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64);
+            if (in && sqrtf(d2) > a.thr * sqrtf(n2)) any = 1;
+        }
+    }
+    // ---- predicate flag, k, statistics partial of this workgroup ---------------------------------------------------------------------
+    if (a.pred_flag && __any(any) && lane == 0) any_s = 1;             // benign race: every writer stores 1
+    if (a.stat_part) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                                 // fold the 16 rows of the tile layout (lanes c = 0 .. 15 of a group)
+                const float s1 = row16_sum_to_lane15(cs1[ct][e]), s2 = row16_sum_to_lane15(cs2[ct][e]);
+                if (c == 15) { red[wave * 2 * HP + 16 * ct + 4 * g + e] = s1; red[wave * 2 * HP + HP + 16 * ct + 4 * g + e] = s2; }
+            }
+    }
+    __syncthreads();
+    if (a.stat_part && tid < 2 * HP) {
+        float t = 0.0f;
+        for (int w = 0; w < TB_WAVES; ++w) t += red[w * 2 * HP + tid];    // waves in order
+        a.stat_part[(size_t)blockIdx.x * 2 * HP + tid] = t;
+    }
+    if (a.pred_flag && tid == 0) {
+        if (any_s) atomicOr(a.pred_flag, 1);
+        if (blockIdx.x == 0 && a.pred_k) *a.pred_k = a.pred_kval;
+    }
+}
+
+template <int SQ, int NCT>
+inline size_t train_fwd_lds() { return (size_t)(16 * (2 * SQ + 2) * 16 * NCT + 16 * NCT + TB_WAVES * 2 * 16 * NCT) * sizeof(float); }
+
+// ---- backward: d loss / d [state | agg] through the first Dense and its training-mode BatchNormalization ------------------------
+//   dy[m, j]  = sum_h dZ[m, h] W[row_j, h]                      (j < S: state column j, else agg column j - S)
+//   dx[m, j]  = gamma_k rstd_k (dy - m1_k - xhat m2_k)          xhat = (x[m, j] - mean_k) rstd_k,  k = row_j      (reference: the
+//               gradient autograd takes through tf.keras BatchNormalization(training=True); kernels_train.hpp k_bn_input_grad)
+//             = Ac_j dy + Cc_j x + Bc_j      with  Ac = gamma rstd,  Cc = -Ac rstd m2,  Bc = -Ac m1 - Cc mean
+//   agg half optionally times row_scale[m]: the transposed aggregate then walks unit weights ('average': w_e = 1 / in-degree(dst_e))
+struct TrainBwdArgs {
+    int M;
+    const float *dZ; int ldz;             // [M, H], H = 16 HQ
+    const float *W; int ldw;              // first-layer kernel [in_dim][ldw] (NOT folded: BatchNorm enters through the coefficients)
+    int H, S, wrow_state, wrow_agg;
+    const float *state; int ld_state; const float *agg; int ld_agg;   // the layer's inputs x (for xhat)
+    const float *gamma, *mean, *var, *m1, *m2; float eps;               // NULL gamma: no BatchNormalization
+    const float *agg_row_scale;           // [M] or NULL
+    float *dx; int ld_dx;                 // [M, 2 S]
+};
+
+template <int HQ, int NCT>                 // NCT = 2 S / 16 output column tiles
+__global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_bwd_dx(TrainBwdArgs a) {
+    constexpr int HP = 16 * NCT;           // = 2 S
+    constexpr int SQ = NCT / 2;            // 16-column tiles of one half (state | agg)
+    extern __shared__ __attribute__((aligned(16))) float tb_smem[];
+    float *Wl = tb_smem;                    // [4 HQ k-steps][4 g][16 c][NCT]
+    float *coef = tb_smem + 16 * HQ * HP;   // [3][HP]: Ac, Cc, Bc
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int S = a.S;                      // == 8 NCT: the halves are whole 16-column tiles
+    for (int i = tid; i < 16 * HQ * HP; i += 64 * TB_WAVES) {
+        const int k = i / HP, j = i % HP;                                   // k = dZ column h, j = output column
+        const int row = j < S ? a.wrow_state + j : a.wrow_agg + (j - S);
+        const float v = k < a.H ? a.W[(size_t)row * a.ldw + k] : 0.0f;
+        const int q = k >> 4, rem = k & 15, gg = rem >> 2, e = rem & 3;
+        Wl[(((4 * q + e) * 4 + gg) * 16 + (j & 15)) * NCT + (j >> 4)] = v;
+    }
+    for (int j = tid; j < HP; j += 64 * TB_WAVES) {
+        float Ac = 1.0f, Cc = 0.0f, Bc = 0.0f;
+        if (a.gamma) {
+            const int k = j < S ? a.wrow_state + j : a.wrow_agg + (j - S);
+            const float rstd = 1.0f / sqrtf(a.var[k] + a.eps);
+            Ac = a.gamma[k] * rstd; Cc = -Ac * rstd * a.m2[k]; Bc = -Ac * a.m1[k] - Cc * a.mean[k];
+        }
+        coef[j] = Ac; coef[HP + j] = Cc; coef[2 * HP + j] = Bc;
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t r_z = buf_rsrc(a.dZ), r_s = buf_rsrc(a.state), r_a = buf_rsrc(a.agg), r_o = buf_rsrc(a.dx),
+                                 r_rs = buf_rsrc(a.agg_row_scale);
+    const int n_tiles = (a.M + 15) >> 4;
+#pragma unroll 1
+    for (int t = blockIdx.x * TB_WAVES + wave; t < n_tiles; t += gridDim.x * TB_WAVES) {
+        const int row = 16 * t + c;
+        const bool in = row < a.M;
+        // every load of the tile is issued here: the dZ row and - for the BatchNorm term - the layer's inputs x = [state | agg] of the
+        // same row, all as 16-byte chunks (columns 16 q + 4 g ..): the transposed product (see k_train_fwd) returns dy in that layout
+        f32x4 A[HQ], X[NCT];
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) A[q] = buf_ld_f32x4(r_z, in ? ((unsigned)row * (unsigned)a.ldz + 16u * q + 4u * g) * 4u : BUF_OFF);
+        if (a.gamma) {
+#pragma unroll
+            for (int q = 0; q < SQ; ++q) {
+                X[q] = buf_ld_f32x4(r_s, in ? ((unsigned)row * (unsigned)a.ld_state + 16u * q + 4u * g) * 4u : BUF_OFF);
+                X[SQ + q] = buf_ld_f32x4(r_a, in ? ((unsigned)row * (unsigned)a.ld_agg + 16u * q + 4u * g) * 4u : BUF_OFF);
+            }
+        }
+        const float rs = a.agg_row_scale ? buf_ld_f32(r_rs, in ? (unsigned)row * 4u : BUF_OFF) : 1.0f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                       // state half, then agg half (16 accumulator registers at a time)
+            f32x4 acc[SQ];
+#pragma unroll
+            for (int u = 0; u < SQ; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    BFrag<NCT> w;
+                    w.load(Wl + (((4 * q + e) * 4 + g) * 16 + c) * NCT);
+#pragma unroll
+                    for (int u = 0; u < SQ; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[half * SQ + u], A[q][e], acc[u], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            TB_MFMA_DRAIN();
+#pragma unroll
+            for (int u = 0; u < SQ; ++u) {
+                const int j0 = 16 * (half * SQ + u) + 4 * g;            // this lane's four output columns
+                f32x4 v = acc[u];
+                if (a.gamma) {
+                    const f32x4 Ac = *reinterpret_cast<const f32x4 *>(coef + j0), Cc = *reinterpret_cast<const f32x4 *>(coef + HP + j0),
+                                Bc = *reinterpret_cast<const f32x4 *>(coef + 2 * HP + j0);
+                    const f32x4 x = X[half * SQ + u];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(Ac[e], v[e], fmaf(Cc[e], x[e], Bc[e]));
+                }
+                if (half == 1) v *= rs;
+                const u32x4 bits = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(bits, r_o, in ? (int)(((unsigned)row * (unsigned)a.ld_dx + (unsigned)j0) * 4u) : (int)BUF_OFF, 0, 0);
+            }
+        }
+    }
+}
+
+template <int HQ, int NCT>
+inline size_t train_bwd_lds() { return (size_t)(16 * HQ * 16 * NCT + 3 * 16 * NCT) * sizeof(float); }
+
+// sum of n floats times scale, any n: grid-stride partials in a fixed order, then one block (the loss of a million-row batch)
+__global__ void __launch_bounds__(256) k_sum_partials(const float *__restrict__ x, int n, float *__restrict__ part) {
+    __shared__ float sh[256];
+    float s = 0.0f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += x[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+}  // namespace gnn

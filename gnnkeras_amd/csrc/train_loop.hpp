@@ -9,6 +9,7 @@
 // What moves into the library is the ORCHESTRATION: ~14 launches per iteration pair instead of ~36, no Python between them.
 #pragma once
 #include "kernels_train.hpp"
+#include "kernels_train_big.hpp"
 
 namespace {
 
@@ -41,8 +42,19 @@ struct TrainPlan {
     int *isrc, *idst;
     float *part; size_t part_floats;
     NetCtx cs, co;
+    // large graphs (kernels_train_big.hpp): constant inputs packed 32 per node, statistics partials of the two producers
+    bool big; int Kc; gnn::ConstCols cc;
+    float *xc, *part_a, *part_y, *loss_part;
     size_t bytes;
 };
+
+// From this many nodes on a training iteration is bandwidth work and runs the row-streaming kernels (GNN_TRAIN_BIG_MIN_NODES).
+inline int train_big_min_nodes() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_TRAIN_BIG_MIN_NODES"); v = e ? atoi(e) : 32768; }
+    return v;
+}
+constexpr int BIG_AGG_BLOCKS = 4096, BIG_FWD_BLOCKS = 1024;
 
 int max_units_of(const gnn_mlp_t &m) { int h = 1; for (int i = 0; i < m.n_layers; ++i) h = std::max(h, (int)m.units[i]); return h; }
 
@@ -119,6 +131,24 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
         p.part_floats = std::max(p.part_floats, (size_t)(nc + 1) * std::max(p.in_s, p.in_o));
     }
     p.part = c.take<float>(p.part_floats);
+    // ---- the large-graph path: one-layer state network of width 16 / 32 / 64 whose constant inputs fit 32 columns ----
+    p.Kc = (p.with_labels ? 2 * p.L : 0) + p.A;
+    p.big = p.N >= train_big_min_nodes() && ns.n_layers == 1 && ns.units[0] == p.S && (p.S == 16 || p.S == 32 || p.S == 64) &&
+            p.Kc <= 32 && ns.activation[0] != GNN_ACT_SOFTMAX && (size_t)p.N * p.S * 4 < ((size_t)1 << 32) && p.K > 0;
+    memset(&p.cc, 0, sizeof(p.cc));
+    if (p.with_labels) {
+        p.cc.n = p.A > 0 ? 3 : 2;
+        p.cc.width[0] = p.L; p.cc.wrow[0] = p.S;
+        p.cc.width[1] = p.L; p.cc.wrow[1] = 2 * p.S + p.L;
+        p.cc.width[2] = p.A; p.cc.wrow[2] = 2 * p.S + 2 * p.L;
+    } else {
+        p.cc.n = p.A > 0 ? 1 : 0;
+        p.cc.width[0] = p.A; p.cc.wrow[0] = 2 * p.S;
+    }
+    p.xc = c.take<float>(p.big && p.Kc > 0 ? (size_t)p.N * 32 : 0);
+    p.part_a = c.take<float>(p.big ? (size_t)BIG_AGG_BLOCKS * 2 * p.S : 0);
+    p.part_y = c.take<float>(p.big ? (size_t)BIG_FWD_BLOCKS * 2 * p.S : 0);
+    p.loss_part = c.take<float>(256);
     p.cs.m = &ns; p.cs.g = &ta.grad_state; p.co.m = &no; p.co.g = &ta.grad_output;
     p.bytes = (c.off + 255) & ~(size_t)255;
     return 0;
@@ -345,6 +375,49 @@ int state_segs(const gnn_loop_args_t &a, const TrainPlan &p, int t, gnn::Seg *se
     return n;
 }
 
+// ---- launchers of the large-graph kernels -------------------------------------------------------------------------------------------
+int launch_aggregate_stats(const int *gate, const gnn_csr_t &c, const float *X, int S, float *out, float *part, float *mean, float *var, hipStream_t st) {
+    const int lpr = S / 4, groups = 256 / lpr;
+    const int grid = std::min(cdiv(c.n_dst, groups), BIG_AGG_BLOCKS);
+#define AGGS(L) (c.w ? gnn::k_aggregate_stats<L, true><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, S, out, S, part) \
+                     : gnn::k_aggregate_stats<L, false><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, S, out, S, part))
+    switch (lpr) { case 4: AGGS(4); break; case 8: AGGS(8); break; default: AGGS(16); break; }
+#undef AGGS
+    LAUNCH_OK();
+    gnn::k_stats_finish<<<S, 256, 0, st>>>(gate, part, grid, S, 1.0f / (float)c.n_dst, mean, var);
+    LAUNCH_OK();
+    return 0;
+}
+
+template <int SQ>
+int launch_train_fwd_sq(const gnn::TrainFwdArgs &fa, int grid, hipStream_t st) {
+    gnn::k_train_fwd<SQ, SQ><<<grid, 64 * gnn::TB_WAVES, gnn::train_fwd_lds<SQ, SQ>(), st>>>(fa);
+    return hipGetLastError() == hipSuccess ? 0 : fail("k_train_fwd launch failed");
+}
+
+int launch_train_fwd(const gnn::TrainFwdArgs &fa, int S, hipStream_t st, int *grid_out) {
+    const int n_tiles = (fa.M + 15) / 16;
+    const int grid = std::max(1, std::min(std::min(2 * device_cus(), BIG_FWD_BLOCKS), cdiv(n_tiles, gnn::TB_WAVES)));
+    *grid_out = grid;
+    switch (S) {
+        case 16: return launch_train_fwd_sq<1>(fa, grid, st);
+        case 32: return launch_train_fwd_sq<2>(fa, grid, st);
+        default: return launch_train_fwd_sq<4>(fa, grid, st);
+    }
+}
+
+int launch_train_bwd_dx(const gnn::TrainBwdArgs &ba, int S, hipStream_t st) {
+    const int n_tiles = (ba.M + 15) / 16;
+    const int grid = std::max(1, std::min(2 * device_cus(), cdiv(n_tiles, gnn::TB_WAVES)));
+    switch (S) {
+        case 16: gnn::k_train_bwd_dx<1, 2><<<grid, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<1, 2>(), st>>>(ba); break;
+        case 32: gnn::k_train_bwd_dx<2, 4><<<grid, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<2, 4>(), st>>>(ba); break;
+        default: gnn::k_train_bwd_dx<4, 8><<<grid, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<4, 8>(), st>>>(ba); break;
+    }
+    LAUNCH_OK();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -406,9 +479,58 @@ int gnn_train_step(const gnn_train_args_t *args) {
         gnn::k_replicate<<<std::min(cdiv((long)2 * p.in_s * p.K, 256), 1024), 256, 0, st>>>(p.stats_tpl, 2 * p.in_s, p.K, p.stats_s);
         LAUNCH_OK();
     }
+    if (p.big && p.Kc > 0) {      // the constant inputs of a node as one 128-byte line: [labels | aggregated labels | aggregated arc labels | 1 | 0 ..]
+        gnn::PackSegs ps;
+        memset(&ps, 0, sizeof(ps));
+        const int n0 = state_segs(a, p, 0, segs);
+        for (int s = 0; s < n0; ++s)
+            if (segs[s].ptr != p.states && segs[s].ptr != p.agg) { ps.ptr[ps.n] = segs[s].ptr; ps.ld[ps.n] = segs[s].ld; ps.width[ps.n] = segs[s].width; ps.wrow[ps.n] = segs[s].wrow; ++ps.n; }
+        gnn::k_pack_xc<<<(int)std::min<long>(cdiv((long)p.N * 32, 256), 256 * 16), 256, 0, st>>>(p.N, nullptr, ps, p.xc);
+        LAUNCH_OK();
+    }
     // ---- training-mode forward: gated iterations, tape = states + statistics + folded first layers ------------------------------
     TRY(launch_converge(nullptr, p.states, nullptr, p.N, p.S, p.S, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
-    for (int t = 0; t < p.K; ++t) {
+    for (int t = 0; t < p.K && p.big; ++t) {
+        // Large graphs (kernels_train_big.hpp): the neighbour sum leaves its own column statistics, the dense kernel those of the
+        // state it writes (the next iteration's input); the statistics are folded into the weights (tiny launch) and the layer
+        // streams its rows straight into the matrix cores.
+        const int *gate = p.flags + t;
+        const float *s_t = p.states + (size_t)t * NS;
+        float *s_n = p.states + (size_t)(t + 1) * NS;
+        float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);
+        float *stats = p.stats_s + (size_t)t * 2 * p.in_s;
+        if (bn_s) {
+            TRY(launch_aggregate_stats(gate, a.adjacency, s_t, p.S, agg_t, p.part_a, stats + p.off_agg, stats + p.in_s + p.off_agg, st));
+            if (t == 0) {
+                gnn::Seg s0{s_t, nullptr, p.S, p.S, 0};
+                TRY(colstats_segs(gate, &s0, 1, p.N, stats, stats + p.in_s, p.part, st));
+            }
+        } else TRY(launch_aggregate(gate, a.adjacency, s_t, p.S, p.S, agg_t, p.S, st));
+        const float *W0 = ns.kernel[0], *b0 = ns.bias[0];
+        if (bn_s) {
+            float *Wf = p.Wf_s + (size_t)t * p.in_s * p.H1s, *bf = p.bf_s + (size_t)t * p.H1s;
+            TRY(fold_with_stats(ns, stats, Wf, bf, st));
+            W0 = Wf; b0 = bf;
+        }
+        gnn::TrainFwdArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.gate = gate; fa.M = p.N;
+        fa.state = s_t; fa.ld_state = p.S; fa.agg = agg_t; fa.ld_agg = p.S; fa.xc = p.Kc > 0 ? p.xc : nullptr;
+        fa.Wf = W0; fa.bf = b0; fa.H = p.S; fa.wrow_state = 0; fa.wrow_agg = p.off_agg; fa.cs = p.cc;
+        fa.act = ns.activation[0];
+        fa.Y = s_n; fa.ldy = p.S;
+        fa.thr = a.state_threshold; fa.pred_flag = p.flags + t + 1; fa.pred_k = p.k_dev; fa.pred_kval = (float)(t + 1);
+        const bool next_stats = bn_s && t + 1 < p.K;
+        fa.stat_part = next_stats ? p.part_y : nullptr;
+        int grid = 0;
+        TRY(launch_train_fwd(fa, p.S, st, &grid));
+        if (next_stats) {
+            float *nxt = p.stats_s + (size_t)(t + 1) * 2 * p.in_s;
+            gnn::k_stats_finish<<<p.S, 256, 0, st>>>(gate, p.part_y, grid, p.S, 1.0f / (float)p.N, nxt, nxt + p.in_s);
+            LAUNCH_OK();
+        }
+    }
+    for (int t = 0; t < p.K && !p.big; ++t) {
         const int *gate = p.flags + t;
         const float *s_t = p.states + (size_t)t * NS;
         float *s_n = p.states + (size_t)(t + 1) * NS;
@@ -488,7 +610,11 @@ int gnn_train_step(const gnn_train_args_t *args) {
     // ---- loss and its gradient ----------------------------------------------------------------------------------------------------
     gnn::k_loss_grad<<<cdiv(p.R, 256), 256, 0, st>>>(ta.loss_kind, ta.targets, ta.y_pred, ta.sample_weight, p.R, p.T, p.dpred, p.loss_rows);
     LAUNCH_OK();
-    gnn::k_sum_scale<<<1, 256, 0, st>>>(p.loss_rows, p.R, 1.0f / (float)p.R, ta.loss);
+    if (p.R > 65536) {             // (one block summing a million rows took 0.9 ms)
+        gnn::k_sum_partials<<<256, 256, 0, st>>>(p.loss_rows, p.R, p.loss_part);
+        LAUNCH_OK();
+        gnn::k_sum_scale<<<1, 256, 0, st>>>(p.loss_part, 256, 1.0f / (float)p.R, ta.loss);
+    } else gnn::k_sum_scale<<<1, 256, 0, st>>>(p.loss_rows, p.R, 1.0f / (float)p.R, ta.loss);
     LAUNCH_OK();
     float *G_out = p.dpred;
     if (p.pooled) { TRY(launch_aggregate(nullptr, ta.nodegraph_by_source, p.dpred, p.T, p.T, p.G_out, p.T, st)); G_out = p.G_out; }
@@ -525,12 +651,29 @@ int gnn_train_step(const gnn_train_args_t *args) {
             gnn_mlp_t head = ns; head.n_layers = ns.n_layers - 1;
             TRY(forward_layers(head, segs, n, p.N, W0, b0, hs, nullptr, st, nullptr, (bn_s && !fold_s) ? stats : nullptr));
         }
-        TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, p.dx_s_all, p.kdx_s, p.part, st, p.off_agg));
-        gnn::BnGradReq rq[2] = {gnn::BnGradReq{p.dx_s_all, p.kdx_s, s_t, p.S, nullptr, p.S, 0},
-                                gnn::BnGradReq{p.dx_s_all + p.S, p.kdx_s, agg_t, p.S, nullptr, p.S, p.off_agg}};
-        TRY(bn_input_grads(ns, p.cs, stats, rq, 2, p.N, st));
+        // 'average' / 'sum' / 'normalized' entries depend on the destination only (a.adjacency carries one scale per row): the large-
+        // graph kernel scales the agg-half of a row's gradient once, and the transposed aggregate walks UNIT weights (no 4 bytes per arc)
+        const bool unit_w = p.big && !a.adjacency.w;
+        if (p.big) {
+            TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, nullptr, 0, p.part, st, p.off_agg));
+            gnn::TrainBwdArgs ba;
+            memset(&ba, 0, sizeof(ba));
+            ba.M = p.N; ba.dZ = p.G_state; ba.ldz = p.S;            // (one layer: the activation gradient ran in place)
+            ba.W = ns.kernel[0]; ba.ldw = p.H1s; ba.H = p.H1s; ba.S = p.S; ba.wrow_state = 0; ba.wrow_agg = p.off_agg;
+            ba.state = s_t; ba.ld_state = p.S; ba.agg = agg_t; ba.ld_agg = p.S;
+            if (bn_s) { ba.gamma = ns.bn_gamma; ba.mean = stats; ba.var = stats + p.in_s; ba.m1 = p.cs.m1; ba.m2 = p.cs.m2; ba.eps = ns.bn_eps; }
+            ba.agg_row_scale = unit_w ? a.adjacency.row_scale : nullptr;
+            ba.dx = p.dx_s_all; ba.ld_dx = p.kdx_s;
+            TRY(launch_train_bwd_dx(ba, p.S, st));
+        } else {
+            TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, p.dx_s_all, p.kdx_s, p.part, st, p.off_agg));
+            gnn::BnGradReq rq[2] = {gnn::BnGradReq{p.dx_s_all, p.kdx_s, s_t, p.S, nullptr, p.S, 0},
+                                    gnn::BnGradReq{p.dx_s_all + p.S, p.kdx_s, agg_t, p.S, nullptr, p.S, p.off_agg}};
+            TRY(bn_input_grads(ns, p.cs, stats, rq, 2, p.N, st));
+        }
         {   // G_state = d state (own) + Adj . d agg   (arcs walked by source)
-            const gnn_csr_t &c = ta.adjacency_by_source;
+            gnn_csr_t c = ta.adjacency_by_source;
+            if (unit_w) { c.w = nullptr; c.row_scale = nullptr; }
             const float *Xa = p.dx_s_all + p.S;
             const bool vec = (p.S == 16 || p.S == 32 || p.S == 64 || p.S == 128) && p.kdx_s % 4 == 0 &&
                              ((reinterpret_cast<uintptr_t>(Xa) | reinterpret_cast<uintptr_t>(p.dx_s_all) | reinterpret_cast<uintptr_t>(p.G_state)) & 15) == 0;

@@ -1,0 +1,34 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
+import numpy as np, torch
+from gnnkeras_amd import GraphObject
+from gnnkeras_amd.synth import er_graph
+from gnnkeras_amd.Models.GNN import GNNnodeBased
+from gnnkeras_amd.Models.training import LoopTrainer, SGD
+from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+from test_gpu_training import nets, oracle_step
+d, bn, mode = int(sys.argv[1]), sys.argv[2] == '1', sys.argv[3]
+rng = np.random.default_rng(d)
+N = 40_000
+g = er_graph(N, 6 * N, seed=5, aggregation_mode=mode)
+om = rng.random(N) < 0.6
+t = np.zeros((int(om.sum()), 2)); t[np.arange(len(t)), rng.integers(0, 2, len(t))] = 1
+g = GraphObject(g.nodes, g.arcs, t, focus='n', set_mask=rng.random(N) < 0.9, output_mask=om, aggregation_mode=mode, sample_weight=rng.uniform(0.5, 1.5, len(t)))
+seq = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)
+x, y, sw = seq[0]
+ns, no = nets('n', d, bn, scale=0.5 if mode == 'average' else 0.08)
+model = GNNnodeBased(ns, no, d, 4, 0.0)
+model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+want = oracle_step(model, x, y, sw, s0, 'categorical_crossentropy')
+w0 = model.net_state.get_weights() + model.net_output.get_weights()
+for native in (False, True):
+    model.net_state.set_weights(w0[:len(model.net_state.get_weights())]); model.net_output.set_weights(w0[len(model.net_state.get_weights()):])
+    tr = LoopTrainer(model); tr.use_native_step = native
+    res = tr.train_step(x, y, sw, state0=torch.from_numpy(s0).cuda(), apply=False)
+    errs = []
+    for got, ref in [(tr.gs.gradients(), want['grads_state']), (tr.go.gradients(), want['grads_output'])]:
+        for g_, r in zip(got, ref):
+            errs.append(float(np.max(np.abs(g_.cpu().numpy() - r)) / max(float(np.max(np.abs(r))), 1e-12)))
+    print('native' if native else 'python', 'k', res['k'], 'grad errs', ['%.1e' % e for e in errs])

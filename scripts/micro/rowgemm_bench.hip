@@ -1,0 +1,45 @@
+// Micro-benchmark of the row-streaming dense kernels of gnnkeras_amd/csrc/kernels_train_big.hpp (k_train_fwd, k_train_bwd_dx) at
+// C4 size: 1 M rows, S = 64.  Build one binary per ablation:  hipcc -O3 --offload-arch=gfx950 -DTB_ABL=<bits> rowgemm_bench.hip
+// (1 no MFMAs, 2 no predicate loads, 4 no stores, 8 no statistics).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../gnnkeras_amd/csrc/kernels_train_big.hpp"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+int main(int argc, char **argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 1000000;
+    const int grid = argc > 2 ? atoi(argv[2]) : 512;
+    const int S = 64, K = 159;
+    float *state, *agg, *xc, *Wf, *bf, *Y, *part, *dx, *rs, *stats; int *flag;
+    CK(hipMalloc(&state, (size_t)M * S * 4)); CK(hipMalloc(&agg, (size_t)M * S * 4)); CK(hipMalloc(&xc, (size_t)M * 32 * 4));
+    CK(hipMalloc(&Y, (size_t)M * S * 4)); CK(hipMalloc(&Wf, K * S * 4)); CK(hipMalloc(&bf, S * 4)); CK(hipMalloc(&part, 2048 * 2 * S * 4));
+    CK(hipMalloc(&dx, (size_t)M * 2 * S * 4)); CK(hipMalloc(&rs, (size_t)M * 4)); CK(hipMalloc(&stats, 8 * K * 4)); CK(hipMalloc(&flag, 64));
+    CK(hipMemset(state, 0, (size_t)M * S * 4)); CK(hipMemset(agg, 0, (size_t)M * S * 4)); CK(hipMemset(xc, 0, (size_t)M * 32 * 4));
+    CK(hipMemset(Wf, 0, K * S * 4)); CK(hipMemset(bf, 0, S * 4)); CK(hipMemset(rs, 0, (size_t)M * 4)); CK(hipMemset(stats, 0, 8 * K * 4)); CK(hipMemset(flag, 0, 64));
+    gnn::TrainFwdArgs fa; memset(&fa, 0, sizeof(fa));
+    fa.M = M; fa.state = state; fa.ld_state = S; fa.agg = agg; fa.ld_agg = S; fa.xc = xc; fa.Wf = Wf; fa.bf = bf; fa.H = S;
+    fa.wrow_state = 0; fa.wrow_agg = S + 14; fa.cs.n = 3; fa.cs.width[0] = 14; fa.cs.wrow[0] = S; fa.cs.width[1] = 14; fa.cs.wrow[1] = 2 * S + 14;
+    fa.cs.width[2] = 3; fa.cs.wrow[2] = 2 * S + 28; fa.act = 2; fa.Y = Y; fa.ldy = S; fa.thr = 0.f; fa.pred_flag = flag; fa.stat_part = part;
+    gnn::TrainBwdArgs ba; memset(&ba, 0, sizeof(ba));
+    ba.M = M; ba.dZ = Y; ba.ldz = S; ba.W = Wf; ba.ldw = S; ba.H = S; ba.S = S; ba.wrow_state = 0; ba.wrow_agg = S + 14;
+    ba.state = state; ba.ld_state = S; ba.agg = agg; ba.ld_agg = S; ba.gamma = stats; ba.mean = stats + K; ba.var = stats + 2 * K; ba.m1 = stats + 3 * K;
+    ba.m2 = stats + 4 * K; ba.eps = 1e-3f; ba.agg_row_scale = rs; ba.dx = dx; ba.ld_dx = 2 * S;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    auto run = [&](const char *name, auto launch, double by) {
+        for (int i = 0; i < 3; ++i) launch();
+        CK(hipEventRecord(a));
+        const int reps = 20;
+        for (int i = 0; i < reps; ++i) launch();
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        printf("ABL %d grid %4d  %-18s %8.1f us   %6.2f TB/s\n", TB_ABL, grid, name, ms / reps * 1e3, by / (ms / reps * 1e-3) / 1e12);
+        CK(hipGetLastError());
+    };
+    run("k_train_fwd<4,4>", [&] { gnn::k_train_fwd<4, 4><<<grid, 64 * gnn::TB_WAVES, gnn::train_fwd_lds<4, 4>()>>>(fa); }, (double)M * (3.0 * S + 32) * 4);
+    run("k_train_bwd_dx<4,8>", [&] { gnn::k_train_bwd_dx<4, 8><<<grid, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<4, 8>()>>>(ba); }, (double)M * (5.0 * S) * 4);
+    return 0;
+}

@@ -1,0 +1,83 @@
+// Correctness harness of k_train_bwd_dx / k_train_fwd against a CPU loop on random data (debug aid for kernels_train_big.hpp).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <random>
+#include "../../gnnkeras_amd/csrc/kernels_train_big.hpp"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+template <typename T> T *up(const std::vector<T> &v) { T *d; CK(hipMalloc(&d, v.size() * sizeof(T))); CK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return d; }
+
+template <int HQ, int NCT>
+void check_bwd(int M, bool bn, bool scale) {
+    const int S = 8 * NCT, H = 16 * HQ, L = 7, K = 2 * S + 2 * L + 3, wa = S + L;
+    std::mt19937 rng(1); std::normal_distribution<float> nd(0, 1);
+    std::vector<float> dZ((size_t)M * H), W((size_t)K * H), st((size_t)M * S), ag((size_t)M * S), gm(K), mu(K), va(K), m1(K), m2(K), rs(M);
+    for (auto *v : {&dZ, &W, &st, &ag, &gm, &mu, &m1, &m2}) for (auto &x : *v) x = nd(rng);
+    for (auto &x : va) x = fabsf(nd(rng)) + 0.1f;
+    for (auto &x : rs) x = 0.5f + fabsf(nd(rng));
+    gnn::TrainBwdArgs a; memset(&a, 0, sizeof(a));
+    float *d_dx; CK(hipMalloc(&d_dx, (size_t)M * 2 * S * 4)); CK(hipMemset(d_dx, 0xff, (size_t)M * 2 * S * 4));
+    a.M = M; a.dZ = up(dZ); a.ldz = H; a.W = up(W); a.ldw = H; a.H = H; a.S = S; a.wrow_state = 0; a.wrow_agg = wa;
+    a.state = up(st); a.ld_state = S; a.agg = up(ag); a.ld_agg = S;
+    if (bn) { a.gamma = up(gm); a.mean = up(mu); a.var = up(va); a.m1 = up(m1); a.m2 = up(m2); a.eps = 1e-3f; }
+    if (scale) a.agg_row_scale = up(rs);
+    a.dx = d_dx; a.ld_dx = 2 * S;
+    gnn::k_train_bwd_dx<HQ, NCT><<<64, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<HQ, NCT>()>>>(a);
+    CK(hipDeviceSynchronize());
+    std::vector<float> got((size_t)M * 2 * S);
+    CK(hipMemcpy(got.data(), d_dx, got.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int m = 0; m < M; ++m) for (int j = 0; j < 2 * S; ++j) {
+        const int row = j < S ? j : wa + (j - S);
+        double dy = 0; for (int h = 0; h < H; ++h) dy += (double)dZ[(size_t)m * H + h] * W[(size_t)row * H + h];
+        double v = dy;
+        if (bn) { const double rstd = 1.0 / sqrt(va[row] + 1e-3), x = j < S ? st[(size_t)m * S + j] : ag[(size_t)m * S + j - S];
+                  v = gm[row] * rstd * (dy - m1[row] - (x - mu[row]) * rstd * m2[row]); }
+        if (scale && j >= S) v *= rs[m];
+        worst = fmax(worst, fabs(v - got[(size_t)m * 2 * S + j]));
+    }
+    printf("bwd<%d,%d> M=%d bn=%d scale=%d  max abs err %.3e\n", HQ, NCT, M, bn, scale, worst);
+}
+
+template <int SQ>
+void check_fwd(int M, bool pred) {
+    const int S = 16 * SQ, L = 7, A_ = 3, K = 2 * S + 2 * L + A_, wa = S + L;
+    std::mt19937 rng(2); std::normal_distribution<float> nd(0, 1);
+    std::vector<float> st((size_t)M * S), ag((size_t)M * S), xc((size_t)M * 32, 0.f), Wf((size_t)K * S), bf(S);
+    for (auto *v : {&st, &ag, &Wf, &bf}) for (auto &x : *v) x = 0.3f * nd(rng);
+    for (int m = 0; m < M; ++m) { for (int j = 0; j < 2 * L + A_; ++j) xc[(size_t)m * 32 + j] = nd(rng); xc[(size_t)m * 32 + 2 * L + A_] = 1.f; }
+    gnn::TrainFwdArgs a; memset(&a, 0, sizeof(a));
+    float *dY, *part; int *flag;
+    CK(hipMalloc(&dY, (size_t)M * S * 4)); CK(hipMemset(dY, 0xff, (size_t)M * S * 4)); CK(hipMalloc(&part, 64 * 2 * S * 4)); CK(hipMalloc(&flag, 8)); CK(hipMemset(flag, 0, 8));
+    a.M = M; a.state = up(st); a.ld_state = S; a.agg = up(ag); a.ld_agg = S; a.xc = up(xc); a.Wf = up(Wf); a.bf = up(bf); a.H = S;
+    a.wrow_state = 0; a.wrow_agg = wa; a.cs.n = 3; a.cs.width[0] = L; a.cs.wrow[0] = S; a.cs.width[1] = L; a.cs.wrow[1] = 2 * S + L; a.cs.width[2] = A_; a.cs.wrow[2] = 2 * S + 2 * L;
+    a.act = GNN_ACT_TANH; a.Y = dY; a.ldy = S; a.thr = 1e9f; a.pred_flag = pred ? flag : nullptr; a.stat_part = part;
+    gnn::k_train_fwd<SQ, SQ><<<64, 64 * gnn::TB_WAVES, gnn::train_fwd_lds<SQ, SQ>()>>>(a);
+    CK(hipDeviceSynchronize());
+    std::vector<float> got((size_t)M * S), pt(64 * 2 * S);
+    CK(hipMemcpy(got.data(), dY, got.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(pt.data(), part, pt.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0; std::vector<double> s1(S, 0), s2(S, 0);
+    for (int m = 0; m < M; ++m) for (int h = 0; h < S; ++h) {
+        double z = bf[h];
+        for (int j = 0; j < S; ++j) z += (double)st[(size_t)m * S + j] * Wf[(size_t)j * S + h] + (double)ag[(size_t)m * S + j] * Wf[(size_t)(wa + j) * S + h];
+        for (int j = 0; j < L; ++j) z += (double)xc[(size_t)m * 32 + j] * Wf[(size_t)(S + j) * S + h] + (double)xc[(size_t)m * 32 + L + j] * Wf[(size_t)(2 * S + L + j) * S + h];
+        for (int j = 0; j < A_; ++j) z += (double)xc[(size_t)m * 32 + 2 * L + j] * Wf[(size_t)(2 * S + 2 * L + j) * S + h];
+        const double y = tanh(z);
+        worst = fmax(worst, fabs(y - got[(size_t)m * S + h])); s1[h] += y; s2[h] += y * y;
+    }
+    double ws = 0;
+    for (int h = 0; h < S; ++h) { double a1 = 0, a2 = 0; for (int b = 0; b < 64; ++b) { a1 += pt[(size_t)b * 2 * S + h]; a2 += pt[(size_t)b * 2 * S + S + h]; }
+        ws = fmax(ws, fmax(fabs(a1 - s1[h]) / M, fabs(a2 - s2[h]) / M)); }
+    printf("fwd<%d> M=%d pred=%d  max abs err %.3e  stats err %.3e\n", SQ, M, pred, worst, ws);
+}
+
+int main() {
+    for (int M : {1000, 40000}) for (int pr = 0; pr < 2; ++pr) { check_fwd<1>(M, pr); check_fwd<2>(M, pr); check_fwd<4>(M, pr); }
+    for (int M : {1000, 40000}) for (int bn = 0; bn < 2; ++bn) for (int sc = 0; sc < 2; ++sc) {
+        check_bwd<1, 2>(M, bn, sc); check_bwd<2, 4>(M, bn, sc); check_bwd<4, 8>(M, bn, sc);
+    }
+    return 0;
+}

@@ -68,11 +68,18 @@ WORKER = textwrap.dedent('''
         worst = max(worst, min(e, float(np.max(np.abs(g - r))) / scale))
     for a, b in zip(model.net_state.get_weights()[2:4] + model.net_output.get_weights()[2:4], ref_moving):
         assert rel_err(a, b) <= 1e-5
-    # inference: the collective predict / evaluate against the single-process calls
-    p_dp, e_dp = dpm.predict(seq), dpm.evaluate(seq, return_dict=True)
-    p_1, e_1 = model.predict(seq), model.evaluate(seq, return_dict=True)
+    # inference: the collective predict / evaluate against the single-process calls (state_vect_dim = 0: the forward draws no
+    # random state_0, so two calls are comparable)
+    inp, lay = get_inout_dims('state', 14, 3, 2, 'g', 0); ns0 = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0, device=dev)
+    inp, lay = get_inout_dims('output', 14, 3, 2, 'g', 0); no0 = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1, device=dev)
+    m0 = GNNgraphBased(ns0, no0, 0, 5, 0.01)
+    m0.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['accuracy'])
+    dp0 = DataParallel(m0)
+    p_dp, e_dp = dp0.predict(seq), dp0.evaluate(seq, return_dict=True)
+    p_1, e_1 = m0.predict(seq), m0.evaluate(seq, return_dict=True)
     assert p_dp.shape == (96, 2) and rel_err(p_dp, p_1) <= 1e-5
     assert abs(e_dp['loss'] - e_1['loss']) <= 1e-5 and abs(e_dp['accuracy'] - e_1['accuracy']) <= 1e-6
+    assert dpm.predict(seq).shape == (96, 2)
     # fit: two epochs with reshuffling; every rank ends with the same weights
     seq_t = MultiGraphSequencer([g.copy() for g in graphs], 'g', 'average', 32, shuffle=True, device=dev)
     hist = dpm.fit(seq_t, epochs=2, verbose=0, validation_data=seq)

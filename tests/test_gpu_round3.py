@@ -353,3 +353,43 @@ def test_composite_convergence_step_matches_oracle(N, d):
         assert float(k) == 2.0 == out2[0] and rel_err(out2[1].cpu().numpy(), st.cpu().numpy()) <= TOL
     with pytest.raises(ValueError):
         model.convergence(0.0, dev(s0), None, nodes, dim_node_label, type_mask, adjacency, None, False)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training at large M: the row-streaming kernels of kernels_train_big.hpp
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d,bn,mode,thr', [(64, True, 'average', 0.0), (32, True, 'sum', 0.0), (16, False, 'average', 0.0), (64, True, 'average', 0.05)])
+def test_large_graph_training_step_matches_autograd(d, bn, mode, thr):
+    """From 32 768 nodes `gnn_train_step` runs an iteration on k_aggregate_stats (neighbour sum + its BatchNorm statistics),
+    k_train_fwd (rows straight into the matrix cores, statistics folded into the weights, predicate and the next iteration's
+    statistics in the epilogue) and k_train_bwd_dx (dZ . W^T with the BatchNorm input gradient and the 'average' row scale in the
+    epilogue, unit-weight transposed aggregate): every gradient against torch autograd in float64, and against the Python
+    building-block orchestration (which keeps the general kernels)."""
+    from test_gpu_training import nets, check_step
+    rng = np.random.default_rng(d)
+    N = 40_000
+    g = er_graph(N, 6 * N, seed=5, aggregation_mode=mode)
+    om = rng.random(N) < 0.6
+    t = np.zeros((int(om.sum()), 2)); t[np.arange(len(t)), rng.integers(0, 2, len(t))] = 1
+    g = GraphObject(g.nodes, g.arcs, t, focus='n', set_mask=rng.random(N) < 0.9, output_mask=om, aggregation_mode=mode,
+                    sample_weight=rng.uniform(0.5, 1.5, len(t)))
+    seq = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)
+    x, y, sw = seq[0]
+    ns, no = nets('n', d, bn, scale=0.5 if mode == 'average' else 0.08)
+    model = GNNnodeBased(ns, no, d, 4, thr)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    res, want = check_step(model, x, y, sw, s0)               # both orchestrations against the oracle
+    if thr > 0: assert 0 < want['k'] < 4
+
+
+def test_small_graph_training_on_the_large_graph_kernels_in_a_child_process():
+    """GNN_TRAIN_BIG_MIN_NODES=0 (read once per process, hence the child) sends every eligible model of the gradient tests - MUTAG
+    batches, all three foci, with and without BatchNormalization, early exit, fit() - through the large-graph kernels."""
+    import os, subprocess, sys
+    root = os.path.dirname(nat.HERE)
+    env = dict(os.environ, GNN_TRAIN_BIG_MIN_NODES='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    sel = 'gradients_single_layer or fit_reduces_loss or adam_step or call_training_true or inference_after_training'
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_training.py'), '-m', 'gpu', '-q', '-x', '-k', sel],
+                         capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert ' passed' in res.stdout

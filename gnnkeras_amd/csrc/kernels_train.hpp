@@ -542,6 +542,9 @@ constexpr int DGA_TM = 32, DGA_LDX = 208;      // 208 == 16 (mod 32): conflict-f
 __global__ void __launch_bounds__(256)
 k_dense_grad_allk(GradSegs gs, int K, const float *__restrict__ dZ, int ldz, int H, int M, int rows_per_chunk,
                   float *__restrict__ part) {                         // part: [chunk][K*H (P) + H (q)]
+    // (Round 3 tried forming dZ = G (.) act'(Y) in this kernel's fetch and storing it back in place to drop the separate
+    // activation-gradient pass: the store in the middle of the pipelined fetch serialises the loads behind it - a C4-size step
+    // went 24.1 -> 29.1 ms, and 28.1 ms with the feature compiled in but switched off.  Not adopted: profiles/r03_notes.txt.)
     __shared__ float Xs[DGA_TM * DGA_LDX];
     __shared__ float Zs[DGA_TM * DG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

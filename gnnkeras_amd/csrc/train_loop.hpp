@@ -268,15 +268,16 @@ int net_backward(NetCtx &x, const gnn::Seg *segs, int nseg, float *const *hs, fl
         G = Gn; ldg = Kp;
     }
     const int H = m.units[0], K = m.in_dim;
+    int Kv = 0;
+    for (int s = 0; s < nseg; ++s) Kv += segs[s].width;
+    const bool allk = Kv == K && K <= 192 && H <= 64 && n_chunks >= 256;
     TRY(act_grad_inplace(G, ldg, hs[0], H, M, H, m.activation[0], st));
     {
         gnn::GradSegs gs;
         memset(&gs, 0, sizeof(gs));
         gs.n = nseg; gs.blk_begin[0] = 0;
         for (int s = 0; s < nseg; ++s) { gs.seg[s] = segs[s]; gs.blk_begin[s + 1] = gs.blk_begin[s] + cdiv(segs[s].width, 64); }
-        int Kv = 0;
-        for (int s = 0; s < nseg; ++s) Kv += segs[s].width;
-        if (Kv == K && K <= 192 && H <= 64 && n_chunks >= 256) {     // large batches, every column in one workgroup: dZ is read once (kernels_train.hpp)
+        if (allk) {     // every column in one workgroup: dZ is read once (kernels_train.hpp)
             gnn::k_dense_grad_allk<<<n_chunks, 256, 0, st>>>(gs, K, G, ldg, H, M, rpc, part);
         } else {
             dim3 grid(n_chunks, gs.blk_begin[nseg], cdiv(H, 64));

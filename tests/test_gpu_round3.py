@@ -358,7 +358,7 @@ def test_composite_convergence_step_matches_oracle(N, d):
 # ----------------------------------------------------------------------------------------------------------------------
 # training at large M: the row-streaming kernels of kernels_train_big.hpp
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('d,bn,mode,thr', [(64, True, 'average', 0.0), (32, True, 'sum', 0.0), (16, False, 'average', 0.0), (64, True, 'average', -1.0)])
+@pytest.mark.parametrize('d,bn,mode,thr', [(64, True, 'average', 0.0), (32, True, 'sum', 0.0), (16, False, 'average', 0.0), (32, False, 'average', -1.0)])
 def test_large_graph_training_step_matches_autograd(d, bn, mode, thr):
     """From 32 768 nodes `gnn_train_step` runs an iteration on k_aggregate_stats (neighbour sum + its BatchNorm statistics),
     k_train_fwd (rows straight into the matrix cores, statistics folded into the weights, predicate and the next iteration's
@@ -375,14 +375,15 @@ def test_large_graph_training_step_matches_autograd(d, bn, mode, thr):
                     sample_weight=rng.uniform(0.5, 1.5, len(t)))
     seq = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)
     x, y, sw = seq[0]
-    ns, no = nets('n', d, bn, scale=0.5 if mode == 'average' else 0.08)
+    ns, no = nets('n', d, bn, scale=(0.5 if thr >= 0 else 0.1) if mode == 'average' else 0.08)      # (early exit: a contractive network)
     s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
     if thr < 0:                                               # early exit: a threshold at which the oracle stops after 1 .. 3 iterations
         from test_gpu_training import oracle_step
-        for thr in (0.3, 1.0, 2.0, 4.0, 8.0):
-            k = oracle_step(GNNnodeBased(ns, no, d, 4, thr), x, y, sw, s0, 'categorical_crossentropy')['k']
+        seen = {}
+        for thr in (0.05, 0.1, 0.2, 0.4, 0.8):
+            k = seen[thr] = oracle_step(GNNnodeBased(ns, no, d, 4, thr), x, y, sw, s0, 'categorical_crossentropy')['k']
             if 0 < k < 4: break
-        assert 0 < k < 4, 'no threshold with an early exit found'
+        assert 0 < k < 4, f'no threshold with an early exit found: {seen}'
     model = GNNnodeBased(ns, no, d, 4, thr)
     res, want = check_step(model, x, y, sw, s0)               # both orchestrations against the oracle
 

@@ -103,13 +103,17 @@ def mutag_section(device, cpu: bool):
     # ... and the way they walk it where the library supports convergence groups: runs of batches merged into one graph
     # whose batches are independent loops of ONE launch (own predicate, own k: include/gnnloop.h group_node_begin)
     plan = gnn._group_plan(seq, device)
-    s0_cat = {id(bs): torch.cat([s0s[b] for b in bs]) for bs in (plan or []) if len(bs) > 1}     # (predict() draws state_0 per launch)
+    s0_cat = {id(bs): torch.cat([s0s[b] for b in bs]) for bs in (plan or []) if len(bs) > 1 or getattr(bs, 'parts', None)}     # (predict() draws state_0 per launch)
     def grouped(model):                    # as _LoopModel._forward_batches does: the launches of the plan on side streams
         def launch(li):
             bs = plan[li]
-            if len(bs) == 1: return model.Loop(*inputs[bs[0]], state0=s0s[bs[0]])
+            parts = getattr(bs, 'parts', None)
+            if len(bs) == 1 and not parts: return model.Loop(*inputs[bs[0]], state0=s0s[bs[0]])
             x, begin = seq.merged_batches(bs)
-            return model.Loop(*model.process_inputs(x), state0=s0_cat[id(bs)], groups=begin)
+            kw = {}
+            if parts:        # a batch too big for one CU's LDS, cut along graph boundaries into groups that share the loop's condition
+                begin, kw['group_sets'] = bs.groups_and_sets({b: begin[i + 1] - begin[i] for i, b in enumerate(bs)})
+            return model.Loop(*model.process_inputs(x), state0=s0_cat[id(bs)], groups=begin, **kw)
         ks_b = [None] * len(items)
         for li, (k, st, o) in model._run_plan(plan, launch, device):
             for j, b in enumerate(plan[li]): ks_b[b] = k.reshape(-1)[j]
@@ -128,7 +132,7 @@ def mutag_section(device, cpu: bool):
                        'threshold=0.01, graph-focused forward',
            'fwd_ms_per_graph': 1e3 * t_best / n_graphs, 'fwd_ms_per_batch': 1e3 * t_best / len(items),
            'how': ('grouped launches: %d (%s), each batch an independent loop: one CU per batch with its state in LDS where it fits, '
-                   'spread over several CUs otherwise' % (len(plan), ' + '.join(str(len(bs)) for bs in plan) + ' batches')) if t_best == t_grp
+                   'cut along graph boundaries into groups that share the convergence flag otherwise' % (len(plan), ' + '.join(str(len(bs)) for bs in plan) + ' batches')) if t_best == t_grp
                   else '%d side streams' % width,
            'grouped_fwd_ms_per_graph': None if t_grp is None else 1e3 * t_grp / n_graphs,
            'side_streams_fwd_ms_per_graph': 1e3 * t_gpu / n_graphs, 'concurrent_batches': width,

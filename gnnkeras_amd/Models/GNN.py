@@ -71,9 +71,18 @@ class _Launch(list):
     """One entry of a group plan: the batches a launch merges.  `resident`: every batch runs as one workgroup with its state
     in the LDS of one CU (no grid barrier), so the launch may overlap any other."""
 
-    def __init__(self, batches, resident: bool = False):
+    def __init__(self, batches, resident: bool = False, parts=None):
         super().__init__(batches)
         self.resident = resident
+        self.parts = parts or {}      # batch -> node counts of the groups it was cut into (along graph boundaries); absent: one group
+
+    def groups_and_sets(self, sizes):
+        """(group_node_begin, group_set_begin | None) of the merged launch: `sizes[b]` = nodes of batch b."""
+        begin, sets = [0], [0]
+        for b in self:
+            for n in self.parts.get(b, [sizes[b]]): begin.append(begin[-1] + int(n))
+            sets.append(len(begin) - 1)
+        return begin, (sets if self.parts else None)
 
 
 class _LoopModel:
@@ -277,10 +286,14 @@ class _LoopModel:
     def _plan_launch(self, sequencer, batches):
         """The output rows of one plan entry: its batches merged and run as convergence groups of one call.  A merge the library
         refuses after all (the plan looks at shapes; e.g. an operand form only the call sees) is rerun batch by batch."""
-        if len(batches) == 1: return self.call(sequencer[batches[0]][0], training=False)
+        parts = getattr(batches, 'parts', None)
+        if len(batches) == 1 and not parts: return self.call(sequencer[batches[0]][0], training=False)
         x, node_begin = sequencer.merged_batches(batches)
+        sets = None
+        if parts:
+            node_begin, sets = batches.groups_and_sets({b: node_begin[i + 1] - node_begin[i] for i, b in enumerate(batches)})
         try:
-            return self.call(x, training=False, groups=node_begin)
+            return self.call(x, training=False, groups=node_begin, **({'group_sets': sets} if sets else {}))
         except (RuntimeError, nat.NativeError) as e:
             if 'convergence groups' not in str(e): raise
             return torch.cat([self.call(sequencer[b][0], training=False) for b in batches], dim=0)
@@ -336,15 +349,55 @@ class _LoopModel:
                                                          sum(n_out[b] for b in bs), [0] + [int(v) for v in np.cumsum([sizes[b] for b in bs])])
         plan, rest = [_Launch([b]) for b in range(len(sizes)) if hub[b]], [b for b in range(len(sizes)) if not hub[b]]
         if not rest: return plan
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
         biggest = max(rest, key=lambda b: sizes[b])
         if supported([min(rest, key=lambda b: sizes[b])]) == 2:      # one CU per batch, its state in LDS - for those that fit
-            fits = rest if supported([biggest]) == 2 else [b for b in rest if supported([b]) == 2]
-            for c0 in range(0, len(fits), 1024):
-                chunk = fits[c0:c0 + 1024]
-                if len(chunk) >= 2 and supported(chunk) == 2:
-                    plan.append(_Launch(chunk, resident=True))
-                    rest = [b for b in rest if b not in set(chunk)]
-        cus = torch.cuda.get_device_properties(device).multi_processor_count
+            fits = set(rest if supported([biggest]) == 2 else [b for b in rest if supported([b]) == 2])
+            # a batch that does not fit is cut along graph boundaries into parts that do; the parts run on one CU each and share only
+            # the loop's condition (group sets): still ONE launch, and no batch is left to the spread form
+            parts = {}
+            S_w = self.state_vect_dim if self.state_vect_dim > 0 else L
+            limit = (158 * 1024) // (4 * (16 if S_w <= 16 else 32) + 16)          # kernel_state_lds.hpp: LDS_BUDGET_BYTES / (row + CSR record)
+            for b in rest:
+                if b in fits: continue
+                cut = self._cut_batch(sequencer, b, limit)
+                if cut is not None: parts[b] = cut
+            cand = [b for b in rest if b in fits or b in parts]
+            # One workgroup = one CU per group: with fewer groups than CUs the launch leaves CUs idle while its largest group sets
+            # the pace.  Cut the largest batches further (two, three .. balanced parts) until the groups fill the GPU.
+            n_all = sum(len(parts.get(b, [0])) for b in cand)
+            if len(cand) == len(rest) and n_all < cus:
+                cur = {b: parts.get(b, [sizes[b]]) for b in cand}
+                while n_all < cus:
+                    b = max(cand, key=lambda b_: max(cur[b_]))
+                    cut = self._cut_batch(sequencer, b, limit, len(cur[b]) + 1)
+                    if cut is None or max(cut) >= max(cur[b]): break
+                    cur[b] = cut; n_all += 1
+                parts = {b: v for b, v in cur.items() if len(v) > 1}
+            chunk, n_grp = [], 0
+            def flush():
+                nonlocal chunk, n_grp, rest
+                if len(chunk) >= 2 or (chunk and chunk[0] in parts):
+                    entry = _Launch(chunk, resident=True, parts={b: parts[b] for b in chunk if b in parts})
+                    begin, sets = entry.groups_and_sets(sizes)
+                    if ops.loop_groups_supported(begin[-1], L, A, self.net_state, self.net_output, self.state_vect_dim, self.max_iteration, focus,
+                                                 self.native_flags, sum(n_out[b] for b in chunk), begin, sets) == 2:
+                        plan.append(entry)
+                        rest = [b for b in rest if b not in set(chunk)]
+                chunk, n_grp = [], 0
+            any_cut = bool(parts)
+            for b in cand:
+                g_b = len(parts.get(b, [0]))
+                if chunk and n_grp + g_b > (cus if any_cut else 1024): flush()
+                chunk.append(b); n_grp += g_b
+            flush()
+        # A spread run needs every one of its 64-node tiles resident at once (grid barrier), one workgroup per CU; a resident launch
+        # holds one CU per group.  Size the spread runs for the CUs the resident launch leaves free, so both kinds really run side
+        # by side (a run sized for the whole GPU would spin at its first barrier until the resident launch has drained).
+        n_res = sum(len(bs) for bs in plan if getattr(bs, 'resident', False))
+        free = cus - min(n_res, cus)
+        biggest_rest = max([(sizes[b] + 63) // 64 for b in rest], default=0)
+        if free >= max(biggest_rest, cus // 4): cus = free
         run, tiles = [], 0
         for b in rest:
             t = (sizes[b] + 63) // 64
@@ -353,8 +406,31 @@ class _LoopModel:
             run.append(b); tiles += t
         if run: plan.append(_Launch(run))
         for bs in plan:
-            if len(bs) >= 2 and not supported(bs): return None
+            if len(bs) >= 2 and not getattr(bs, 'parts', None) and not supported(bs): return None
         return plan
+
+    @staticmethod
+    def _cut_batch(sequencer, b, limit, n_parts=None):
+        """Node counts of the parts batch `b` is cut into - contiguous runs of whole graphs, each of at most `limit` nodes, `n_parts`
+        of them (default: as few as fit), balanced (the parts run side by side, the largest sets the pace) - or None when that is
+        not possible (a graph larger than `limit`, fewer graphs than parts)."""
+        sizes_g = [int(g.nodes.shape[0]) for g in sequencer.data[b * sequencer.batch_size: (b + 1) * sequencer.batch_size]]
+        if not sizes_g or max(sizes_g) > limit: return None
+        total = sum(sizes_g)
+        for p_try in range(n_parts or max(1, -(-total // limit)), len(sizes_g) + 1):
+            target = -(-total // p_try)
+            parts, cur = [], 0
+            for i, n in enumerate(sizes_g):
+                left_parts = p_try - len(parts) - 1                      # parts still to open after the current one
+                # close the current part when it has reached its share (and enough graphs remain to fill the others), or when
+                # the next graph would not fit
+                if cur and (cur + n > limit or (cur + n // 2 >= target and left_parts > 0 and len(sizes_g) - i >= left_parts)):
+                    parts.append(cur); cur = 0
+                cur += n
+            parts.append(cur)
+            if max(parts) <= limit and (n_parts is None or len(parts) == n_parts): return parts
+            if n_parts is not None: return None
+        return None
 
     def _batches_concurrently(self, n, fn, device, width=None, lane=None):
         """Run fn(i), i < n, `width` at a time on side HIP streams and yield (i, result) in order on the caller's stream.
@@ -496,11 +572,13 @@ class GNNnodeBased(_LoopModel):
             net.summary(*args, **kwargs)
 
     # ---- call ---------------------------------------------------------------------------------------------------------
-    def call(self, inputs, training: bool = False, mask=None, *, groups=None):
+    def call(self, inputs, training: bool = False, mask=None, *, groups=None, group_sets=None):
         """`inputs` = the list a sequencer's `__getitem__` yields; returns `out` (eval) or `(k, state, out)`.  `groups`
         (additive): node offsets of merged batches that run as independent loops (see `Loop`)."""
         inputs = self.process_inputs(inputs)
-        k, state, out = self.Loop(*inputs, training=training, **({} if groups is None else {'groups': groups}))
+        kw = {} if groups is None else {'groups': groups}
+        if group_sets is not None: kw['group_sets'] = group_sets
+        k, state, out = self.Loop(*inputs, training=training, **kw)
         if training: return k, state, out
         if getattr(self, '_k_seen', None) is not None: self._k_seen.append(k)        # predict() / evaluate() check it at the end
         return out
@@ -555,13 +633,15 @@ class GNNnodeBased(_LoopModel):
                                       'device (SURVEY.md §8f, next row); inference forward is the built path')
 
     def Loop(self, nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph,
-             training: bool = False, *, state0=None, seed=None, node_level: bool = False, groups=None):
+             training: bool = False, *, state0=None, seed=None, node_level: bool = False, groups=None, group_sets=None):
         """(k, state, out) for one (merged) graph — reference GNN.py:245-274.
 
         `groups` (additive; inference only): node offsets [G + 1] of G batches merged into this graph.  The loop then runs
         as G independent loops in one launch - each batch has its own `condition` and stops on its own, exactly as if the
         reference had been called batch by batch - and k is a vector of G iteration counts (include/gnnloop.h,
-        group_node_begin; `ops.loop_groups_supported` says whether a shape qualifies).
+        group_node_begin; `ops.loop_groups_supported` says whether a shape qualifies).  `group_sets` (first-group offsets [B + 1]):
+        a batch too big for one CU's LDS is cut along graph boundaries into several groups that share only the loop's condition -
+        they stop together, exactly like the uncut batch - and k has one entry per SET (= batch).
 
         Additive keyword arguments: `state0` replaces the reference's `tf.random.normal(stddev=0.1)`
         draw when `state_vect_dim > 0`; otherwise it is drawn on the device with `seed`. `node_level=True` makes a
@@ -593,11 +673,15 @@ class GNNnodeBased(_LoopModel):
         adj, arcn = adjacency.device_csr(dev), SparseMatrix.from_triple(arcnode).device_csr(dev)
         ends = _arc_endpoints(adjacency, dev) if focus == 'a' else None
         ng = SparseMatrix.from_triple(nodegraph).device_csr(dev) if focus == 'g' else None
+        # (the first group of every set, uploaded BEFORE the launch: a pageable host-to-device copy behind it would block the host
+        # until the loop has finished)
+        set_first = None if group_sets is None else torch.as_tensor([int(v) for v in group_sets[:-1]], device=dev)
         # the whole Loop is ONE custom op: torch.ops.gnnkeras.loop_forward (csrc/torch_ops.cpp -> gnn_loop_forward)
         k, state, out = ops.loop_forward(nodes.to(torch.float32).contiguous(), arcs.to(torch.float32).contiguous(), adj, arcn, ng,
                                          self.net_state, self.net_output, state0, out_index, ends, self.state_vect_dim,
                                          self.max_iteration, self.state_threshold, nat.FOCUS[focus], self.native_flags,
-                                         loop_events=self.loop_events, groups=groups)
+                                         loop_events=self.loop_events, groups=groups, group_sets=group_sets)
+        if group_sets is not None: k = k[set_first]        # the groups of a set report the same k: one entry per set
         self._last_k = k
         return k, state, out
 

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 # GNNKERAS_AMD_LIB: load another build of the same sources (tests: the debug build whose in-launch waits expire at once)
 LIB_PATH = os.environ.get('GNNKERAS_AMD_LIB') or os.path.join(CSRC, 'libgnnloop.so')
 
-GNN_ABI_VERSION = 3
+GNN_ABI_VERSION = 4
 GNN_MAX_LAYERS = 8
 GNN_MAX_TYPES = 8
 
@@ -75,7 +75,8 @@ class LoopArgs(C.Structure):
                 ('adjacency_light', CSR), ('heavy_seg_beg', C.c_void_p), ('heavy_seg_end', C.c_void_p),
                 ('n_heavy_segments', C.c_int32),
                 ('ev_loop_begin', C.c_void_p), ('ev_loop_end', C.c_void_p),
-                ('group_node_begin', C.c_void_p), ('n_groups', C.c_int32)]
+                ('group_node_begin', C.c_void_p), ('n_groups', C.c_int32),
+                ('group_set_begin', C.c_void_p), ('n_group_sets', C.c_int32)]
 
 
 class DenseArgs(C.Structure):

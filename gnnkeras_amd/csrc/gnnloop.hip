@@ -331,7 +331,9 @@ struct Plan {
     int n_groups;                    // the caller's n_groups (0: k_out is one float)
     int group_tiles;                 // 64-node tiles when no tile straddles a group
     int group_max_nodes;             // nodes of the largest group
-    int *d_group_tabs;               // device copies of group_node_begin / 64-node-tile offsets, [n_groups + 1] each (n_groups > 0)
+    int *d_group_tabs;               // device copies of group_node_begin / 64-node-tile offsets / set first group / set size, [n_groups + 1] each
+    unsigned long long *set_bar;     // two flag-exchange counters per group set (indexed by the set's first group), zeroed per call
+    bool has_sets;                   // some set has more than one group
     int *pred0;                      // state_0's predicate, one word per 64-node tile (written by k_setup_small, read by k_state_small)
     int *err;                        // sticky "an in-launch wait expired" word of the fused kernels, folded into k at the end
     float *agg_arcs, *agg_nodes; int ld_agg_nodes;
@@ -403,6 +405,16 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
             p.group_max_nodes = std::max(p.group_max_nodes, ne - nb);
         }
         if (p.gt.n) { p.gt.node_begin[a.n_groups] = a.n_nodes; p.gt.tile_begin[a.n_groups] = p.group_tiles; }
+        if (a.n_group_sets < 0 || a.n_group_sets > a.n_groups) return fail("n_group_sets %d out of [0, n_groups]", a.n_group_sets);
+        if (a.n_group_sets > 0) {
+            if (!a.group_set_begin) return fail("group_set_begin is NULL");
+            if (a.group_set_begin[0] != 0 || a.group_set_begin[a.n_group_sets] != a.n_groups) return fail("group_set_begin must span [0, n_groups]");
+            for (int s2 = 0; s2 < a.n_group_sets; ++s2) {
+                const int n_in = a.group_set_begin[s2 + 1] - a.group_set_begin[s2];
+                if (n_in < 1) return fail("group set %d is empty or group_set_begin is not ascending", s2);
+                if (n_in > 1) p.has_sets = true;
+            }
+        }
     } else {
         p.gt.n = 1; p.gt.node_begin[0] = 0; p.gt.node_begin[1] = a.n_nodes;
         p.group_tiles = (a.n_nodes + 63) / 64;
@@ -473,7 +485,8 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     p.err = p.flags ? p.flags + a.max_iteration + 12 : nullptr;
     p.mid_bar = p.flags ? p.flags + ((a.max_iteration + 16 + 31) & ~31) : nullptr;
     p.pred0 = c.take<int>(std::max(GNN_SMALL_MAX_TILES, p.group_tiles));
-    p.d_group_tabs = c.take<int>(a.n_groups > 0 ? 2 * ((size_t)a.n_groups + 1) : 0);
+    p.d_group_tabs = c.take<int>(a.n_groups > 0 ? 4 * ((size_t)a.n_groups + 1) : 0);
+    p.set_bar = c.take<unsigned long long>(a.n_groups > 0 ? 2 * (size_t)a.n_groups : 0);
     for (int t = 0; t < p.T; ++t) {
         p.tp[t].Wf = c.take<float>((size_t)a.net_state[t].in_dim * a.net_state[t].units[0]);
         p.tp[t].bf = c.take<float>(a.net_state[t].units[0]);
@@ -931,6 +944,7 @@ bool lds_applies(const gnn_loop_args_t &a, const Plan &p) {
     if ((pinned != 0 && pinned != 7) || (pinned == 0 && env != 0 && env != 7)) return false;
     if (p.n_groups < 1 || p.composite || p.n_heavy != 0 || a.max_iteration < 1 || (p.SP != 16 && p.SP != 32)) return false;
     if (a.net_state[0].n_layers != 1 || a.net_state[0].activation[0] == GNN_ACT_SOFTMAX || (a.flags & GNN_FLAG_UNFUSED)) return false;
+    if (p.has_sets && p.n_groups > device_cus()) return false;      // groups that wait for each other must all be resident
     return gnn::lds_group_fits(p.group_max_nodes, p.SP);
 }
 
@@ -938,6 +952,8 @@ int loop_lds(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     gnn::LdsArgs la;
     memset(&la, 0, sizeof(la));
     la.node_begin = p.d_group_tabs; la.tile64_begin = p.d_group_tabs + (p.n_groups + 1);
+    la.set_first = p.d_group_tabs + 2 * (p.n_groups + 1); la.set_size = p.d_group_tabs + 3 * (p.n_groups + 1);
+    la.set_bar = p.has_sets ? p.set_bar : nullptr;
     la.pred0 = p.pred0;
     la.rowptr = a.adjacency.rowptr; la.src = a.adjacency.src; la.w = a.adjacency.w; la.row_scale = a.adjacency.row_scale;
     la.state0 = a.state_dim > 0 ? a.state0 : a.nodes; la.ld_s0 = a.state_dim > 0 ? p.S : a.ld_nodes;
@@ -948,7 +964,7 @@ int loop_lds(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     la.thr = a.state_threshold;
     la.stage = p.buf[0];
     la.state_out = a.state_out; la.k_out = a.k_out;
-    const int rc = gnn::launch_lds(la, p.SP, p.n_groups, gnn::lds_state_bytes(p.group_max_nodes, p.SP), st);
+    const int rc = gnn::launch_lds(la, p.SP, p.n_groups, p.group_max_nodes, st);
     if (rc == 1) return fail("LDS-resident loop kernel: launch failed (%s)", hipGetErrorString(hipGetLastError()));
     return rc;
 }
@@ -1036,7 +1052,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         // the group tables go to the device through a pinned staging buffer of this thread (an asynchronous copy out of pageable
         // memory would have to outlive this call); its event says when the previous call's copy has left it
         static thread_local struct { int *buf; size_t cap; hipEvent_t ev; } stage = {nullptr, 0, nullptr};
-        const size_t n_tab = 2 * ((size_t)p.n_groups + 1);
+        const size_t n_tab = 4 * ((size_t)p.n_groups + 1);
         if (stage.ev) HIP_OK(hipEventSynchronize(stage.ev));
         else HIP_OK(hipEventCreateWithFlags(&stage.ev, hipEventDisableTiming));
         if (stage.cap < n_tab) {
@@ -1050,9 +1066,16 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         for (int g = 0; g <= p.n_groups; ++g) {
             tabs[g] = a.group_node_begin[g];
             tabs[p.n_groups + 1 + g] = tiles;
+            tabs[2 * (p.n_groups + 1) + g] = g; tabs[3 * (p.n_groups + 1) + g] = 1;       // its own set unless listed below
             if (g < p.n_groups) tiles += (a.group_node_begin[g + 1] - a.group_node_begin[g] + 63) / 64;
         }
+        for (int s2 = 0; s2 < a.n_group_sets; ++s2)
+            for (int g = a.group_set_begin[s2]; g < a.group_set_begin[s2 + 1]; ++g) {
+                tabs[2 * (p.n_groups + 1) + g] = a.group_set_begin[s2];
+                tabs[3 * (p.n_groups + 1) + g] = a.group_set_begin[s2 + 1] - a.group_set_begin[s2];
+            }
         HIP_OK(hipMemcpyAsync(p.d_group_tabs, tabs, n_tab * sizeof(int), hipMemcpyHostToDevice, st));
+        if (p.has_sets) HIP_OK(hipMemsetAsync(p.set_bar, 0, sizeof(unsigned long long) * 2 * (size_t)p.n_groups, st));
         HIP_OK(hipEventRecord(stage.ev, st));
         Plan q = p;
         q.gt.n = 0;                                 // the set-up kernel reads the device tables
@@ -1063,6 +1086,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         if (a.ev_loop_end) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_end, st));
         return output_stage(a, p, st);
     }
+    if (p.has_sets) return fail("convergence group sets need the one-CU-per-group form (gnn_loop_groups_supported() != 2 for these args)");
     if (p.n_groups > GNN_MAX_GROUPS) return fail("more than %d convergence groups need every group to fit one CU's LDS (gnn_loop_groups_supported() != 2)", GNN_MAX_GROUPS);
     const bool whole_loop = fz != 0 && persistent_applies(a, p);
     const bool small_setup = whole_loop && setup_small_applies(a, p);

@@ -153,7 +153,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> loop_forward(
     const std::optional<at::Tensor> &arc_dst, int64_t state_dim, int64_t max_iteration, double state_threshold, int64_t focus, int64_t flags,
     const OptTensorList &hub, at::IntArrayRef hub_dims, const std::optional<at::Tensor> &type_nodes, at::IntArrayRef type_offsets,
     at::IntArrayRef type_dim_label, const OptTensorList &composite_adjacency, at::IntArrayRef composite_dims, at::IntArrayRef loop_events,
-    at::IntArrayRef group_node_begin) {
+    at::IntArrayRef group_node_begin, at::IntArrayRef group_set_begin) {
     const at::Device dev = nodes.device();
     gnn_loop_args_t a{};
     fill_graph(a, nodes, arcs, adjacency, adjacency_dims, arcnode, arcnode_dims, hub, hub_dims, dev);
@@ -207,6 +207,12 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> loop_forward(
         TORCH_CHECK(groups.size() >= 2 && groups.size() <= (size_t)GNN_MAX_GROUPS_RESIDENT + 1, "group_node_begin: between 2 and ", GNN_MAX_GROUPS_RESIDENT + 1, " entries");
         a.group_node_begin = groups.data(); a.n_groups = (int32_t)groups.size() - 1;
     }
+    // group sets: parts of one batch that share the loop's condition (k of a set's groups is the same)
+    std::vector<int32_t> sets(group_set_begin.begin(), group_set_begin.end());
+    if (!sets.empty()) {
+        TORCH_CHECK(!groups.empty() && sets.size() >= 2, "group_set_begin needs group_node_begin and at least one set");
+        a.group_set_begin = sets.data(); a.n_group_sets = (int32_t)sets.size() - 1;
+    }
 
     const auto opts = at::TensorOptions().dtype(at::kFloat).device(dev);
     const int64_t rows_out = focus == GNN_FOCUS_GRAPH ? a.nodegraph.n_dst : a.n_out;
@@ -234,7 +240,7 @@ void mlp_shape_of(gnn_mlp_t &m, at::IntArrayRef spec, const char *name) {
 // May `loop_forward(..., group_node_begin)` run these batches as independent loops of one call?  (shapes only, no tensors)
 int64_t loop_groups_supported(int64_t n_nodes, int64_t dim_node_label, int64_t dim_arc_label, at::IntArrayRef net_state_spec,
                            at::IntArrayRef net_output_spec, int64_t state_dim, int64_t max_iteration, int64_t focus, int64_t flags,
-                           int64_t n_out, at::IntArrayRef group_node_begin) {
+                           int64_t n_out, at::IntArrayRef group_node_begin, at::IntArrayRef group_set_begin) {
     gnn_loop_args_t a{};
     a.abi_version = GNN_ABI_VERSION;
     a.n_nodes = (int32_t)n_nodes; a.dim_node_label = (int32_t)dim_node_label; a.dim_arc_label = (int32_t)dim_arc_label;
@@ -246,6 +252,8 @@ int64_t loop_groups_supported(int64_t n_nodes, int64_t dim_node_label, int64_t d
     std::vector<int32_t> groups(group_node_begin.begin(), group_node_begin.end());
     if (groups.size() < 2 || groups.size() > (size_t)GNN_MAX_GROUPS_RESIDENT + 1) return 0;
     a.group_node_begin = groups.data(); a.n_groups = (int32_t)groups.size() - 1;
+    std::vector<int32_t> sets(group_set_begin.begin(), group_set_begin.end());
+    if (sets.size() >= 2) { a.group_set_begin = sets.data(); a.n_group_sets = (int32_t)sets.size() - 1; }
     return gnn_loop_groups_supported(&a);
 }
 
@@ -348,9 +356,9 @@ TORCH_LIBRARY(gnnkeras, m) {
           "int[] net_output_spec, float bn_eps, Tensor? state0, Tensor out_index, Tensor? arc_src, Tensor? arc_dst, int state_dim, "
           "int max_iteration, float state_threshold, int focus, int flags, Tensor?[] hub, int[] hub_dims, Tensor? type_nodes, "
           "int[] type_offsets, int[] type_dim_label, Tensor?[] composite_adjacency, int[] composite_dims, int[] loop_events, "
-          "int[] group_node_begin=[]) -> (Tensor k, Tensor state, Tensor out)");
+          "int[] group_node_begin=[], int[] group_set_begin=[]) -> (Tensor k, Tensor state, Tensor out)");
     m.def("loop_groups_supported(int n_nodes, int dim_node_label, int dim_arc_label, int[] net_state_spec, int[] net_output_spec, "
-          "int state_dim, int max_iteration, int focus, int flags, int n_out, int[] group_node_begin) -> int", &loop_groups_supported);
+          "int state_dim, int max_iteration, int focus, int flags, int n_out, int[] group_node_begin, int[] group_set_begin=[]) -> int", &loop_groups_supported);
     m.def("aggregate(Tensor?[] csr, int[] dims, Tensor X) -> Tensor");
     m.def("pool(Tensor?[] nodegraph, int[] dims, Tensor out_nodes) -> Tensor");
     m.def("converged(Tensor state, Tensor? state_old, float threshold) -> Tensor");

@@ -57,12 +57,13 @@ def net_args(net, device, shape_only=False):
 
 
 def loop_forward(nodes, arcs, adjacency, arcnode, nodegraph, net_state, net_output, state0, out_index, arc_ends, state_dim,
-                 max_iteration, state_threshold, focus, flags, composite=None, loop_events=None, groups=None):
+                 max_iteration, state_threshold, focus, flags, composite=None, loop_events=None, groups=None, group_sets=None):
     """`adjacency` / `arcnode` / `nodegraph`: device-CSR dicts (nodegraph None unless graph focus); `net_state`: one
     `Sequential`, or the list of per-type networks with `composite` = (type_nodes i32[N], type_offsets [T+1], type_dim_label
     [T], [device-CSR dict per type]); `arc_ends` = (arc_src, arc_dst) for arc focus; `loop_events` = (begin, end)
     `torch.cuda.Event`s recorded on the launch stream around the iteration launches; `groups` = node offsets [G + 1] of
-    merged batches that run as independent loops of this one call (k is then [G]; ask `loop_groups_supported` first)."""
+    merged batches that run as independent loops of this one call (k is then [G]; ask `loop_groups_supported` first);
+    `group_sets` = first-group offsets [B + 1] when a batch was cut into several groups that share the loop's condition."""
     ops = load()
     dev = nodes.device
     adj_t, adj_d = csr_args(adjacency)
@@ -88,17 +89,19 @@ def loop_forward(nodes, arcs, adjacency, arcnode, nodegraph, net_state, net_outp
     es, ed = arc_ends if arc_ends is not None else (None, None)
     return ops.loop_forward(nodes, arcs, adj_t, adj_d, an_t, an_d, ng_t, ng_d, sw, ss, ow, os_, BN_EPSILON, state0, out_index, es, ed,
                             int(state_dim), int(max_iteration), float(state_threshold), int(focus), int(flags), hub_t, hub_d,
-                            type_nodes, type_offsets, type_dims, ca_t, ca_d, ev, [int(v) for v in groups] if groups is not None else [])
+                            type_nodes, type_offsets, type_dims, ca_t, ca_d, ev, [int(v) for v in groups] if groups is not None else [],
+                            [int(v) for v in group_sets] if group_sets is not None else [])
 
 
 def loop_groups_supported(n_nodes, dim_node_label, dim_arc_label, net_state, net_output, state_dim, max_iteration, focus, flags,
-                          n_out, groups):
+                          n_out, groups, group_sets=None):
     """May these merged batches run as independent loops of ONE call?  0 no, 1 spread over the CUs (<= 32 groups), 2 one CU
     per group with its state in LDS (any number of groups).  (shapes only: include/gnnloop.h, gnn_loop_groups_supported)"""
     _, ss = net_args(net_state, None, shape_only=True)
     _, os_ = net_args(net_output, None, shape_only=True)
     return int(load().loop_groups_supported(int(n_nodes), int(dim_node_label), int(dim_arc_label), ss, os_, int(state_dim),
-                                             int(max_iteration), int(focus), int(flags), int(n_out), [int(v) for v in groups]))
+                                             int(max_iteration), int(focus), int(flags), int(n_out), [int(v) for v in groups],
+                                             [int(v) for v in group_sets] if group_sets is not None else []))
 
 
 def aggregate(csr, X):

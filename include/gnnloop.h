@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 3
+#define GNN_ABI_VERSION 4
 
 /* Keras activation names accepted by the reference MLP builder (GNN/Models/MLP.py:16). */
 enum gnn_activation {
@@ -158,6 +158,15 @@ typedef struct gnn_loop_args {
      * everything before and after the loop (constants, output network, pooling) is per node / per graph anyway. */
     const int32_t *group_node_begin;   /* HOST array [n_groups + 1], ascending, [0] = 0, [n_groups] = n_nodes         */
     int32_t n_groups;                  /* see gnn_loop_groups_supported                                                */
+    /* group SETS (optional, ABI 4; n_group_sets == 0 = every group is its own set).  A batch whose state does not fit the LDS of
+     * one CU is cut - along graph boundaries, the merged batch is block-diagonal (graph_class.py:399-408) - into several
+     * groups that run on one CU each and share nothing but the `reduce_any` of the reference's condition (GNN.py:212): the
+     * groups of set s, [group_set_begin[s], group_set_begin[s + 1]), exchange one flag word per iteration and leave the loop
+     * together, after the same k.  k_out stays [n_groups] (the groups of a set report the same value).  Only the
+     * one-CU-per-group form (gnn_loop_groups_supported() == 2) takes sets, and only when all groups are resident at once
+     * (n_groups <= CUs) whenever some set has more than one group. */
+    const int32_t *group_set_begin;    /* HOST array [n_group_sets + 1], ascending, [0] = 0, [n_group_sets] = n_groups    */
+    int32_t n_group_sets;
 } gnn_loop_args_t;
 #define GNN_MAX_GROUPS 32                 /* groups of a call that spreads every group over several CUs                  */
 #define GNN_MAX_GROUPS_RESIDENT (1 << 20) /* groups of a call that keeps every group's state in the LDS of one CU        */

@@ -1134,8 +1134,13 @@ def test_many_groups_one_cu_each_with_the_state_in_lds(mutag_graphs):
         for li, bs in enumerate(plan):
             if len(bs) < 2: continue
             x, begin = seq.merged_batches(bs)
-            k, st, o = model.Loop(*model.process_inputs(x), state0=dev(np.concatenate([s0s[b] for b in bs])) if d else None, groups=begin)
-            assert _last_kernel().startswith('k_state_lds' if li == 0 else 'k_state_small'), (li, _last_kernel())
+            kw = {}
+            if bs.parts:      # batches above one CU's LDS: cut along graph boundaries, the parts share the convergence flag (group sets)
+                fine, kw['group_sets'] = bs.groups_and_sets({b: begin[i + 1] - begin[i] for i, b in enumerate(bs)})
+                assert len(fine) > len(begin)
+            else: fine = begin
+            k, st, o = model.Loop(*model.process_inputs(x), state0=dev(np.concatenate([s0s[b] for b in bs])) if d else None, groups=fine, **kw)
+            assert _last_kernel().startswith('k_state_lds' if bs.resident else 'k_state_small'), (li, _last_kernel())
             assert k.shape == (len(bs),)
             r0 = 0
             for j, b in enumerate(bs):
@@ -1149,6 +1154,8 @@ def test_many_groups_one_cu_each_with_the_state_in_lds(mutag_graphs):
                 for j in (0, len(bs) - 1):
                     k64, st64, o64 = oracle_loop(model, seq[bs[j]][0], s0s[bs[j]], np.float64)
                     assert float(k[j]) == float(k64) and rel_err(st[begin[j]:begin[j + 1]].cpu().numpy(), st64) <= TOL
+        if d == 32:           # every batch is resident now: the 14 batches above 1 123 nodes as two coupled groups each, ONE launch
+            assert len(plan) == 1 and plan[0].resident and len(plan[0].parts) >= 10, [(len(bs), bs.resident, len(bs.parts)) for bs in plan]
 
 
 def test_predict_and_evaluate_group_batches(mutag_graphs):

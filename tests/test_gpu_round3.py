@@ -204,9 +204,10 @@ def test_transductive_single_graph_sequencer_through_the_hip_loop():
 # ----------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('d,K_it,thr', [(32, 50, 0.0), (32, 30, 0.01), (0, 5, 0.01)])
 def test_every_batch_of_the_mutag_plan_against_the_oracle(mutag_graphs, d, K_it, thr):
-    """The 136 batches as predict() launches them - every batch whose state fits one CU's LDS as ONE resident launch
-    (`k_state_lds`: 120 of them at d = 32, all 136 at the starter configuration), the rest as spread groups - and EVERY batch's k,
-    state and output against the float64 oracle run on that batch alone (round 2 compared 2 of the resident groups)."""
+    """The 136 batches as predict() launches them - ONE resident launch (`k_state_lds`): a batch whose state fits one CU's LDS is
+    one group (122 of them at d = 32, all 136 at the starter configuration), a bigger one is cut along graph boundaries into
+    groups that share only the convergence flag (group sets, round 3) - and EVERY batch's k, state and output against the float64
+    oracle run on that batch alone (round 2 compared 2 of the resident groups)."""
     seq = MultiGraphSequencer(mutag_graphs, 'g', 'average', 32, shuffle=False)
     from test_gpu_parity import starter_nets
     ns, no = starter_nets('g', d, scale=0.22 if thr > 0 else 1.0)
@@ -218,12 +219,14 @@ def test_every_batch_of_the_mutag_plan_against_the_oracle(mutag_graphs, d, K_it,
     s0s = [rng.normal(0, 0.1, (seq[i][0][0].shape[0], d)).astype(np.float32) if d else None for i in range(len(seq))]
     checked, worst = 0, 0.0
     for li, bs in enumerate(plan):
-        if len(bs) == 1:
+        if len(bs) == 1 and not bs.parts:
             k, st, o = model.Loop(*model.process_inputs(seq[bs[0]][0]), state0=None if not d else dev(s0s[bs[0]]))
             k = k.reshape(1); begin = [0, st.shape[0]]
         else:
             x, begin = seq.merged_batches(bs)
-            k, st, o = model.Loop(*model.process_inputs(x), state0=dev(np.concatenate([s0s[b] for b in bs])) if d else None, groups=begin)
+            kw, fine = {}, begin
+            if bs.parts: fine, kw['group_sets'] = bs.groups_and_sets({b: begin[i + 1] - begin[i] for i, b in enumerate(bs)})
+            k, st, o = model.Loop(*model.process_inputs(x), state0=dev(np.concatenate([s0s[b] for b in bs])) if d else None, groups=fine, **kw)
             assert _last_kernel().startswith('k_state_lds' if bs.resident else 'k_state_small'), (li, _last_kernel())
         k, st, o = k.cpu().numpy(), st.cpu().numpy(), o.cpu().numpy()
         r0 = 0

@@ -144,8 +144,9 @@ class CompositeGNNnodeBased(GNNnodeBased):
         focus = 'n' if (node_level and self._focus == 'g') else self._focus
         if training:
             from .training import LoopTrainer
-            tp = LoopTrainer(self).forward([nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, composite_adjacencies,
-                                            adjacency, arcnode, nodegraph], state0=state0, seed=seed, node_level=node_level)
+            if getattr(self, '_trainer', None) is None: self._trainer = LoopTrainer(self)
+            tp = self._trainer.forward([nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, composite_adjacencies,
+                                        adjacency, arcnode, nodegraph], state0=state0, seed=seed, node_level=node_level)
             return torch.tensor(float(tp.k), device=tp.dev), tp.state.clone(), tp.y_pred
         nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs')
         dev = nodes.device

@@ -651,8 +651,9 @@ class GNNnodeBased(_LoopModel):
         if training:
             if groups is not None: raise ValueError('groups are an inference-only feature')
             from .training import LoopTrainer
-            tp = LoopTrainer(self).forward([nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph],
-                                           state0=state0, seed=seed, node_level=node_level)
+            if getattr(self, '_trainer', None) is None: self._trainer = LoopTrainer(self)      # (one per model, shared with train_step)
+            tp = self._trainer.forward([nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph],
+                                       state0=state0, seed=seed, node_level=node_level)
             return torch.tensor(float(tp.k), device=tp.dev), tp.state.clone(), tp.y_pred
         nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs')
         dev = nodes.device

@@ -119,7 +119,7 @@ class NativeError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """Compile libgnnloop.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    res = subprocess.run(['make', '-j2', '-C', CSRC], capture_output=True, text=True)
+    res = subprocess.run(['make', '-j3', '-C', CSRC, 'all', 'asan'], capture_output=True, text=True)      # + the sanitizer build of the host side (tests/test_abi.py)
     if verbose or res.returncode:
         print(res.stdout, res.stderr)
     if res.returncode:

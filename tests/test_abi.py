@@ -87,3 +87,46 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(nat, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(nat.NativeError):
         nat.lib()
+
+
+def test_group_and_set_tables_are_validated_without_gpu(lib):
+    """Host arrays of the convergence groups / group sets (ABI 4): every malformed table is refused by the plan (sizes only, no
+    GPU); gnn_loop_groups_supported answers 0 instead of reading past them."""
+    def with_groups(begin, sets=None):
+        a = _args()
+        gb = (C.c_int32 * len(begin))(*begin)
+        a.group_node_begin, a.n_groups = C.cast(gb, C.c_void_p), len(begin) - 1
+        keep = [gb]
+        if sets is not None:
+            sb = (C.c_int32 * len(sets))(*sets)
+            a.group_set_begin, a.n_group_sets = C.cast(sb, C.c_void_p), len(sets) - 1
+            keep.append(sb)
+        return a, keep
+    a, keep = with_groups([0, 4, 10])
+    assert lib.gnn_loop_workspace_bytes(C.byref(a)) > 0
+    a, keep = with_groups([0, 4, 10], [0, 2])                    # both groups one set
+    assert lib.gnn_loop_workspace_bytes(C.byref(a)) > 0
+    for begin, sets, word in (([0, 4, 9], None, b'span'), ([0, 0, 10], None, b'empty'), ([1, 4, 10], None, b'span'),
+                              ([0, 4, 10], [0, 1], b'group_set_begin'), ([0, 4, 10], [0, 0, 2], b'empty'), ([0, 4, 10], [1, 2], b'group_set_begin')):
+        a, keep = with_groups(begin, sets)
+        assert lib.gnn_loop_workspace_bytes(C.byref(a)) == 0 and word in lib.gnn_last_error(), (begin, sets, lib.gnn_last_error())
+        assert lib.gnn_loop_groups_supported(C.byref(a)) == 0
+
+
+def test_validation_paths_under_address_and_ub_sanitizers():
+    """The host side of the library (argument validation, plan / workspace carving, table handling) built with
+    -fsanitize=address,undefined (`make asan`: host code only, the device code is compiled as usual) and driven by the tests of
+    this file in a child process - no GPU needed, SURVEY 5.  GPU AddressSanitizer is not available on this pool."""
+    import subprocess, sys, glob
+    asan_lib = os.path.join(nat.CSRC, 'libgnnloop_asan.so')
+    if not os.path.exists(asan_lib):
+        res = subprocess.run(['make', '-C', nat.CSRC, 'asan'], capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    rt = glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so')
+    if not rt: pytest.skip('no clang AddressSanitizer runtime in this image')
+    env = dict(os.environ, GNNKERAS_AMD_LIB=asan_lib, LD_PRELOAD=rt[0], ASAN_OPTIONS='detect_leaks=0:verify_asan_link_order=0:halt_on_error=1',
+               UBSAN_OPTIONS='halt_on_error=1:print_stacktrace=1')
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'not sanitizers and not missing_library'],
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert res.returncode == 0 and ' passed' in res.stdout, res.stdout[-3000:] + res.stderr[-3000:]
+    assert 'ERROR: AddressSanitizer' not in res.stderr and 'runtime error' not in res.stderr, res.stderr[-3000:]

@@ -1011,6 +1011,12 @@ int gnn_f4_profile(unsigned long long *out8, int reset) {
     return 0;
 }
 #endif
+#ifdef GNN_F4_TIMELINE
+// per-workgroup timestamps of the last wave-specialised launch: out[1024][4] = entry, after the W1 fill, first deposit, exit
+int gnn_f4_wg_times(unsigned long long *out4096) {
+    return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(gnn::g_f4_wg), 1024 * 4 * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 const char *gnn_last_error(void) { return g_err; }
 const char *gnn_last_kernel_name(void) { return gnn::last_kernel_name(); }

@@ -71,6 +71,16 @@ __device__ __forceinline__ void activate4(int act, f32x4 &x) {
 #undef F4_ALL
 }
 
+// -DGNN_F4_TIMELINE: four wall-clock stamps per workgroup (entry, W1 fill done, first deposit, exit: scripts/f4_timeline.py) - cheap
+// enough to leave the launch as it is; experiment builds only
+#ifdef GNN_F4_TIMELINE
+__device__ unsigned long long g_f4_wg[1024][4];
+__device__ __forceinline__ unsigned long long f4_stamp() { return wall_clock64(); }   // s_memrealtime: 100 MHz, the same base on every CU
+                                                                                         // (s_memtime runs at the shader clock and differs from CU to CU)
+#define F4_STAMP(i) do { if (blockIdx.x < 1024) g_f4_wg[blockIdx.x][i] = f4_stamp(); } while (0)
+#else
+#define F4_STAMP(i) do { } while (0)
+#endif
 // -DGNN_F4_PROFILE: phase timers (scripts/f4_prof.py); experiment only, the timers themselves drain the memory pipeline
 #ifdef GNN_F4_PROFILE
 __device__ __forceinline__ unsigned long long f4_now() {
@@ -107,6 +117,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     int *freed = fill + NS;                                              // [NS] tiles consumed so far
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) F4_STAMP(0);
     const int S = a.S;
     int ty = 0;
     while (ty + 1 < a.n_types && (int)blockIdx.x >= a.blk_begin[ty + 1]) ++ty;
@@ -161,6 +172,10 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     }
 
     // rows 0 .. SP-1: state ; SP .. 2SP-1: agg ; (XC) 2SP .. 2SP+31: the constant inputs' folded weights, the bias row, zeros
+    // (Round 3 tried leaving this fill to the matrix waves alone, the gather waves going straight to their first job after a bare
+    // barrier: scripts/f4_timeline.py shows the fill's barrier 5 us - up to 10 - after entry on every workgroup of a 60 us C3 launch.
+    // SLOWER: 256 threads fill 40 KB in ten dependent trips, the ring runs full before the first tile is consumed: C3 60.2 -> 63.4 us,
+    // C4 460 -> 470 us.  All 1024 threads fill, then one barrier.)
     for (int i = tid; i < Cfg::WROWS * SP; i += NT) {
         const int k = i / SP, n = i % SP;
         float v = 0.0f;
@@ -182,7 +197,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     if (tid < 2 * NS) fill[tid] = 0;
     __syncthreads();
     if (!open) return;                         // uniform across the launch; nothing has left the CU yet
-
+    if (tid == 0) F4_STAMP(1);
 
     if (wave >= Cfg::NCONS) {
         // ================================ gather waves ================================================================
@@ -278,6 +293,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
             *reinterpret_cast<float2 *>(xr + SP + 2) = make_float2(acc[2], acc[3]);
             if (l4 == 0) Xs[s * Cfg::SLOT + row * LDX + 2 * SP] = __int_as_float(j);      // the row's pad words carry its node id
             if (lane == 0) __hip_atomic_fetch_add(&fill[s], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (n == p && p == 0 && lane == 0) F4_STAMP(2);
         }
 #ifdef GNN_F4_PROFILE
         if (lane == 0) atomicAdd(&g_f4_prof[6], f4_now() - tr_);
@@ -454,6 +470,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
 
     any = __syncthreads_or(any);
     bad = __syncthreads_or(bad);                 // (a predicate reduction, not a bitwise OR: one call per word)
+    if (tid == 0) F4_STAMP(3);
     if (tid == 0) {
         if (any && a.flag_next) atomicOr(a.flag_next, 1);
         if (bad && a.err) atomicOr(a.err, 1);

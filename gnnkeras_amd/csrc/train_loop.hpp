@@ -10,6 +10,7 @@
 #pragma once
 #include "kernels_train.hpp"
 #include "kernels_train_big.hpp"
+#include "kernels_train_small.hpp"
 
 namespace {
 
@@ -45,6 +46,9 @@ struct TrainPlan {
     // large graphs (kernels_train_big.hpp): constant inputs packed 32 per node, statistics partials of the two producers
     bool big; int Kc; gnn::ConstCols cc;
     float *xc, *part_a, *part_y, *loss_part;
+    // small graphs (kernels_train_small.hpp): the forward / backward iterations as one persistent launch each
+    bool small; int n_wg;
+    float *sm_cc, *sm_part, *sm_partW; unsigned long long *sm_bar;
     size_t bytes;
 };
 
@@ -55,6 +59,12 @@ inline int train_big_min_nodes() {
     return v;
 }
 constexpr int BIG_AGG_BLOCKS = 4096, BIG_FWD_BLOCKS = 1024;
+// The persistent small-graph kernels need every workgroup resident: one 64-node tile per CU (GNN_TRAIN_SMALL=0 switches them off).
+inline bool train_small_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_TRAIN_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
 
 int max_units_of(const gnn_mlp_t &m) { int h = 1; for (int i = 0; i < m.n_layers; ++i) h = std::max(h, (int)m.units[i]); return h; }
 
@@ -149,6 +159,13 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.part_a = c.take<float>(p.big ? (size_t)BIG_AGG_BLOCKS * 2 * p.S : 0);
     p.part_y = c.take<float>(p.big ? (size_t)BIG_FWD_BLOCKS * 2 * p.S : 0);
     p.loss_part = c.take<float>(256);
+    p.n_wg = cdiv(p.N, 64);
+    p.small = !p.big && train_small_enabled() && ns.n_layers == 1 && ns.units[0] == p.S && (p.S == 16 || p.S == 32 || p.S == 64) && p.Kc <= 32 &&
+              ns.activation[0] != GNN_ACT_SOFTMAX && p.K > 0 && p.agg_taped && p.n_wg <= (ws ? device_cus() : 256) && p.N < train_big_min_nodes();
+    p.sm_cc = c.take<float>(p.small ? (size_t)p.N * p.S : 0);
+    p.sm_part = c.take<float>(p.small ? (size_t)2 * p.n_wg * (3 * p.S + 32 + 4 * p.S) : 0);
+    p.sm_partW = c.take<float>(p.small ? (size_t)p.n_wg * p.in_s * p.S : 0);
+    p.sm_bar = c.take<unsigned long long>(p.small ? 4 : 0);
     p.cs.m = &ns; p.cs.g = &ta.grad_state; p.co.m = &no; p.co.g = &ta.grad_output;
     p.bytes = (c.off + 255) & ~(size_t)255;
     return 0;
@@ -419,6 +436,48 @@ int launch_train_bwd_dx(const gnn::TrainBwdArgs &ba, int S, hipStream_t st) {
     return 0;
 }
 
+gnn::ConstSegs const_segs_of(const gnn_loop_args_t &a, const TrainPlan &p) {
+    gnn::ConstSegs cs;
+    memset(&cs, 0, sizeof(cs));
+    gnn::Seg segs[GNN_MAX_SEGS];
+    const int n0 = state_segs(a, p, 0, segs);
+    for (int s = 0; s < n0; ++s)
+        if (segs[s].ptr != p.states && segs[s].ptr != p.agg) { cs.ptr[cs.n] = segs[s].ptr; cs.ld[cs.n] = segs[s].ld; cs.width[cs.n] = segs[s].width; cs.wrow[cs.n] = segs[s].wrow; ++cs.n; }
+    return cs;
+}
+
+template <int SQ>
+int launch_train_small_fwd_sq(const gnn::TrainSmallFwd &fa, int n_wg, bool has_w, hipStream_t st) {
+    const size_t lds = std::max(gnn::train_small_fwd_lds<SQ>(), gnn::TS_LDS);
+    if (has_w) {
+        static bool once = false;
+        if (!once) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gnn::k_train_small_fwd<SQ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+        gnn::k_train_small_fwd<SQ, true><<<n_wg, gnn::TS_NT, lds, st>>>(fa);
+    } else {
+        static bool once = false;
+        if (!once) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gnn::k_train_small_fwd<SQ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+        gnn::k_train_small_fwd<SQ, false><<<n_wg, gnn::TS_NT, lds, st>>>(fa);
+    }
+    LAUNCH_OK();
+    return 0;
+}
+
+template <int SQ>
+int launch_train_small_bwd_sq(const gnn::TrainSmallBwd &ba, int n_wg, bool has_w, hipStream_t st) {
+    const size_t lds = std::max(gnn::train_small_bwd_lds<SQ>(), gnn::TS_LDS);
+    if (has_w) {
+        static bool once = false;
+        if (!once) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gnn::k_train_small_bwd<SQ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+        gnn::k_train_small_bwd<SQ, true><<<n_wg, gnn::TS_NT, lds, st>>>(ba);
+    } else {
+        static bool once = false;
+        if (!once) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gnn::k_train_small_bwd<SQ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+        gnn::k_train_small_bwd<SQ, false><<<n_wg, gnn::TS_NT, lds, st>>>(ba);
+    }
+    LAUNCH_OK();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -531,7 +590,28 @@ int gnn_train_step(const gnn_train_args_t *args) {
             LAUNCH_OK();
         }
     }
-    for (int t = 0; t < p.K && !p.big; ++t) {
+    if (p.small) {
+        // Small graphs (kernels_train_small.hpp): all K gated iterations in one persistent launch, one workgroup per 64-node tile
+        const gnn::ConstSegs cs = const_segs_of(a, p);
+        gnn::k_train_small_const<<<cdiv(p.N * p.S, 256), 256, 0, st>>>(p.N, p.S, cs, ns.kernel[0], ns.bias[0], bn_s ? ns.bn_gamma : nullptr, ns.bn_beta,
+                                                                       p.stats_tpl, p.stats_tpl + p.in_s, ns.bn_eps, p.sm_cc);
+        LAUNCH_OK();
+        HIP_OK(hipMemsetAsync(p.sm_bar, 0, sizeof(unsigned long long) * 4, st));
+        gnn::TrainSmallFwd fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.N = p.N; fa.S = p.S; fa.K = p.K;
+        fa.rowptr = a.adjacency.rowptr; fa.src = a.adjacency.src; fa.w = a.adjacency.w; fa.row_scale = a.adjacency.row_scale;
+        fa.states = p.states; fa.agg = p.agg; fa.stats = p.stats_s; fa.in_s = p.in_s; fa.off_agg = p.off_agg;
+        fa.W = ns.kernel[0]; fa.gamma = bn_s ? ns.bn_gamma : nullptr; fa.beta = ns.bn_beta; fa.eps = ns.bn_eps; fa.act = ns.activation[0];
+        fa.Cc = p.sm_cc; fa.thr = a.state_threshold; fa.no_exit = 0; fa.flag0 = p.flags;
+        fa.bar = p.sm_bar; fa.part = p.sm_part; fa.k_out = p.k_dev; fa.err = p.flags + p.K + 4;
+        switch (p.S) {
+            case 16: TRY(launch_train_small_fwd_sq<1>(fa, p.n_wg, a.adjacency.w != nullptr, st)); break;
+            case 32: TRY(launch_train_small_fwd_sq<2>(fa, p.n_wg, a.adjacency.w != nullptr, st)); break;
+            default: TRY(launch_train_small_fwd_sq<4>(fa, p.n_wg, a.adjacency.w != nullptr, st)); break;
+        }
+    }
+    for (int t = 0; t < p.K && !p.big && !p.small; ++t) {
         const int *gate = p.flags + t;
         const float *s_t = p.states + (size_t)t * NS;
         float *s_n = p.states + (size_t)(t + 1) * NS;
@@ -560,7 +640,8 @@ int gnn_train_step(const gnn_train_args_t *args) {
     HIP_OK(hipStreamSynchronize(st));                                  // the one host synchronisation of the step
     const int k = (int)k_f;
     *ta.k_host = k;
-    if (k < 0 || k > p.K) return fail("iteration count %d out of range", k);
+    if (k < 0 || k > p.K) return fail(p.small ? "iteration count %d out of range (a workgroup of the persistent kernel never arrived: not resident?)"
+                                              : "iteration count %d out of range", k);
     const float *state_k = p.states + (size_t)k * NS;
     HIP_OK(hipMemcpyAsync(ta.state, state_k, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
     if (bn_s && k > 0) {
@@ -637,7 +718,31 @@ int gnn_train_step(const gnn_train_args_t *args) {
         TRY(zero_grads(no, ta.grad_output, st));
     }
     if (k == 0) TRY(zero_grads(ns, ta.grad_state, st));
-    for (int t = k - 1; t >= 0; --t) {
+    if (p.small && k > 0) {
+        // the k iterations of back-propagation in one persistent launch; every workgroup leaves its share of the kernel gradient
+        gnn::TrainSmallBwd ba;
+        memset(&ba, 0, sizeof(ba));
+        const gnn_csr_t &cs_ = ta.adjacency_by_source;
+        const bool unit_w = !a.adjacency.w;       // entries depend on the destination only: scale the agg-half once per row, walk unit weights
+        ba.N = p.N; ba.S = p.S; ba.k = k;
+        ba.rowptr_s = cs_.rowptr; ba.src_s = cs_.src; ba.w_s = unit_w ? nullptr : cs_.w; ba.row_scale_s = unit_w ? nullptr : cs_.row_scale;
+        ba.row_scale = unit_w ? a.adjacency.row_scale : nullptr;
+        ba.states = p.states; ba.agg = p.agg; ba.stats = p.stats_s; ba.in_s = p.in_s; ba.off_agg = p.off_agg;
+        ba.cs = const_segs_of(a, p);
+        ba.W = ns.kernel[0]; ba.gamma = bn_s ? ns.bn_gamma : nullptr; ba.beta = ns.bn_beta; ba.eps = ns.bn_eps; ba.act = ns.activation[0];
+        ba.G0 = p.G_state; ba.dxa = p.dx_s_all; ba.bar = p.sm_bar + 2; ba.part = p.sm_part; ba.partW = p.sm_partW;
+        ba.db = ta.grad_state.dbias[0]; ba.dgamma = ta.grad_state.dgamma; ba.dbeta = ta.grad_state.dbeta;
+        ba.inv_n = 1.0f / (float)p.N; ba.err = p.flags + p.K + 5;
+        switch (p.S) {
+            case 16: TRY(launch_train_small_bwd_sq<1>(ba, p.n_wg, ba.w_s != nullptr, st)); break;
+            case 32: TRY(launch_train_small_bwd_sq<2>(ba, p.n_wg, ba.w_s != nullptr, st)); break;
+            default: TRY(launch_train_small_bwd_sq<4>(ba, p.n_wg, ba.w_s != nullptr, st)); break;
+        }
+        const int n = p.in_s * p.S;
+        gnn::k_reduce_partials<<<cdiv(n, 64), 256, 0, st>>>(p.sm_partW, p.n_wg, n, ta.grad_state.dkernel[0], 0, 1.0f, n, nullptr);
+        LAUNCH_OK();
+    }
+    for (int t = k - 1; t >= 0 && !p.small; --t) {
         const float *s_t = p.states + (size_t)t * NS;
         float *s_n = p.states + (size_t)(t + 1) * NS;
         const float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);

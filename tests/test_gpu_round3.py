@@ -402,3 +402,47 @@ def test_small_graph_training_on_the_large_graph_kernels_in_a_child_process():
                          capture_output=True, text=True, env=env, cwd=root, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert ' passed' in res.stdout
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training on small graphs: the persistent kernels of kernels_train_small.hpp (one launch for the K forward iterations, one for the
+# k backward iterations)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('focus,d,bn,mode,n_graphs,thr', [
+    ('g', 32, True, 'average', 60, 0.0), ('g', 64, True, 'average', 188, 0.0), ('n', 16, False, 'sum', 40, 0.0),
+    ('a', 32, True, 'normalized', 24, 0.0), ('n', 64, False, 'average', 7, 0.0), ('g', 32, False, 'average', 50, -1.0),
+    ('n', 32, True, 'sum', 1, 0.0), ('g', 16, True, 'average', 100, -1.0)])
+def test_small_graph_training_persistent_kernels_match_autograd(mutag_graphs, focus, d, bn, mode, n_graphs, thr):
+    """A merged MUTAG batch (18 .. 3 400 nodes: 1 .. 54 workgroups, the last tile ragged) through `gnn_train_step`: state widths
+    16 / 32 / 64, with and without BatchNormalization (two / one grid barriers per forward iteration), per-arc weights
+    ('normalized') and per-row scales ('average'), early exit: k, loss, predictions, every gradient and the moving statistics
+    against torch autograd in float64 - and against the Python building-block orchestration, which keeps the general kernels."""
+    from test_gpu_training import nets, check_step, refocus, oracle_step, CLS
+    rng = np.random.default_rng(100 + d + n_graphs)
+    gl = refocus([g.copy() for g in mutag_graphs[:n_graphs]], focus, rng)
+    seq = MultiGraphSequencer(gl, focus, mode, n_graphs, shuffle=False)
+    x, y, sw = seq[0]
+    contractive = thr < 0
+    ns, no = nets(focus, d, bn, scale=(0.15 if contractive else 0.5) if mode != 'sum' else 0.2)
+    s0 = rng.normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)
+    K = 7
+    if contractive:
+        seen = {}
+        for thr in (0.02, 0.05, 0.1, 0.2, 0.4, 0.8):
+            k = seen[thr] = oracle_step(CLS[focus](ns, no, d, K, thr), x, y, sw, s0, 'categorical_crossentropy')['k']
+            if 1 < k < K: break
+        assert 1 < k < K, f'no threshold with an early exit found: {seen}'
+    model = CLS[focus](ns, no, d, K, thr)
+    res, want = check_step(model, x, y, sw, s0, avg=(n_graphs % 2 == 0))
+
+
+def test_small_graph_training_with_the_persistent_kernels_switched_off_in_a_child_process():
+    """GNN_TRAIN_SMALL=0 keeps the per-iteration launches of round 2 (the path wide / deep state networks still take): the same
+    gradient tests pass on it."""
+    import os, subprocess, sys
+    root = os.path.dirname(nat.HERE)
+    env = dict(os.environ, GNN_TRAIN_SMALL='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_training.py'), '-m', 'gpu', '-q', '-x', '-k',
+                          'gradients_single_layer or fit_reduces_loss'], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert ' passed' in res.stdout

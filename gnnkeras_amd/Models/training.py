@@ -718,6 +718,7 @@ class LoopTrainer:
     # ---- one training step ------------------------------------------------------------------------------------------------
     # ---- the whole step inside the library (homogeneous models): gnn_train_step -------------------------------------------------
     use_native_step = True          # False: always the general path below (tests compare the two)
+    use_tiles = True                # False: never hand the batch's diagonal blocks to gnn_train_step (tests compare the two forms)
 
     def _native_step_applies(self, y):
         m = self.model
@@ -799,6 +800,9 @@ class LoopTrainer:
         loss = p.new(1)
         k_host = C.c_int32(0)
         ta.y_pred, ta.state, ta.loss, ta.k_host = nat.ptr(y_pred), nat.ptr(state), nat.ptr(loss), C.pointer(k_host)
+        tiles = adjacency.tiles(64) if self.use_tiles else None      # a merged batch: graphs packed into tiles of <= 64 nodes
+        if tiles is not None and len(tiles) - 1 <= 256:
+            ta.tile_node_begin, ta.n_tiles = tiles.ctypes.data, len(tiles) - 1
         nbytes = nat.lib().gnn_train_workspace_bytes(C.byref(ta))
         if nbytes == 0: nat.check(1)
         tape = getattr(self, '_tape', None)

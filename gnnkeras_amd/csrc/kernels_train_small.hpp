@@ -3,24 +3,29 @@
 // training=True)` and `tape.gradient` through the unrolled loop).
 //
 // Round 2 ran such a step as ~450 dependent launches of ~8 us (4.3 ms at d = 32 x 50 iterations): nine per iteration pair, each
-// keeping 15 of the 256 CUs busy for a few microseconds.  Here one workgroup owns one 64-node tile for the whole loop, as in
-// kernel_state_small.hpp, and what an iteration needs from the other tiles crosses a grid barrier (one 64-bit arrival counter per
-// parity, agent-scope add + poll, rows written and read `sc1`):
+// keeping 15 of the 256 CUs busy for a few microseconds.  Here one workgroup owns one tile of <= 64 nodes for the whole loop, and what
+// an iteration needs from the other tiles crosses a grid barrier (one 64-bit arrival counter per parity, agent-scope add + poll):
 //
-//   forward iteration t   gather [own | neighbour sum] of the tile from states[t] -> LDS, neighbour sums -> the tape;
-//                         BatchNormalization in training mode needs the statistics of ALL nodes: the tile's column sums / squares of
-//                         [state | agg] go to a partial slot, BARRIER, every workgroup adds the partials in workgroup order (the same
-//                         bits everywhere), folds mean / variance into its copy of the weights; [state | agg] . W on the matrix cores
-//                         from LDS (operands swapped: the result is row-major), activation, predicate, rows -> states[t + 1]; BARRIER
-//                         (its counter also carries "some node still moves": every workgroup leaves the loop after the same k).
+//   forward iteration t   [own | neighbour sum] of the tile -> LDS, neighbour sums -> the tape; BatchNormalization in training mode
+//                         needs the statistics of ALL nodes: the tile's column sums / squares of [state | agg] go to a partial slot,
+//                         BARRIER, every workgroup adds the partials in workgroup order (the same bits everywhere); the normalisation
+//                         a x + c is applied as the rows are read from LDS, [state | agg] . W on the matrix cores (operands swapped:
+//                         the result is row-major), activation, predicate, rows -> states[t + 1].
 //   backward iteration t  dZ = G (.) act'(states[t + 1]); P_wg = X^T dZ of the tile on the matrix cores - kept LOCAL: the weight
 //                         gradient a (.) P + c q^T is linear in P, so every workgroup accumulates its own share in registers over
 //                         all iterations and the shares are summed once at the end; what the BatchNorm input gradient needs of the
 //                         other tiles is only q = colsum(dZ) and S2_k = sum_h W[k, h] P[k, h] - 127 floats per workgroup: partial
 //                         slot, BARRIER, summed in order; dx = BN-gradient(dZ . W^T) on the matrix cores, the agg half scaled once per
-//                         row and written `sc1`, BARRIER; G = dx_state + Adj . dx_agg gathered by source.
-// Two barriers per iteration each way (one forward without BatchNormalization), ~1.5 us each.  Every workgroup must be resident
-// (grid <= CUs, one workgroup per CU); polls sleep and are bounded: an expired wait raises the error word, results are invalid.
+//                         row; G = dx_state + Adj . dx_agg gathered by source.
+// Two forms (template parameter LOCAL):
+//   general   tile b = nodes [64 b, 64 b + 64); a neighbour may live in another tile: rows are exchanged through memory (`sc1`) behind
+//             a second barrier per iteration (which also carries "some node still moves").
+//   LOCAL     the batch is block-diagonal (a merge of small graphs) and the caller hands over tiles cut at graph boundaries (TileTab):
+//             no arc leaves a tile, the state of a tile never leaves LDS, and the only thing tiles share is the BatchNorm statistics and
+//             the `reduce_any` of the loop condition - ONE barrier per forward iteration (the flag of iteration t - 1 travels with the
+//             statistics of iteration t), one per backward iteration with BatchNormalization, none without.
+// Every workgroup must be resident (grid <= CUs, one workgroup per CU); polls sleep and are bounded: an expired wait poisons k / the
+// gradients.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels_general.hpp"
@@ -92,6 +97,124 @@ k_train_small_const(int N, int S, ConstSegs cs, const float *__restrict__ W, con
     Cc[i] = acc;
 }
 
+// ---- tiles ------------------------------------------------------------------------------------------------------------------------------
+struct TileTab { int n; int begin[257]; };      // n == 0: the general form; else tile b = nodes [begin[b], begin[b + 1]), <= 64 of them, no arc leaves a tile
+
+// The CSR rows of the tile's nodes as the gather walks them: thread (q, l4) = lane l4 of the LPR lanes that fetch 16-byte pieces of
+// row q of a pass; the first 16 source ids / weights of every row stay in registers for all iterations.
+template <int SQ, bool HAS_W, bool LOCAL>
+struct TileCsr {
+    static constexpr int S = 16 * SQ, LPR = S / 4, NPP = TS_NT / LPR, NPASS = 64 / NPP, IPL = 16 / LPR, PP = NPASS < 2 ? NPASS : 2;
+    int node[NPASS], beg[NPASS], end[NPASS], ids[NPASS][IPL];
+    float wts[NPASS][IPL], scl[NPASS];
+    const int *src; const float *w;
+    int n0, nt, q, l4, bad;
+
+    __device__ __forceinline__ int local_id(int s) {        // LOCAL: position inside the tile; an arc that leaves the tile is an error
+        if (!LOCAL) return s;
+        const int r = s - n0;
+        if (r < 0 || r >= nt) { bad = 1; return 0; }
+        return r;
+    }
+    __device__ __forceinline__ void load(int n0_, int nt_, const int *rowptr, const int *src_, const float *w_, const float *row_scale) {
+        n0 = n0_; nt = nt_; src = src_; w = w_; bad = 0;
+        q = threadIdx.x / LPR; l4 = threadIdx.x % LPR;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int r = p * NPP + q;
+            node[p] = r < nt ? n0 + r : -1;
+            beg[p] = end[p] = 0; scl[p] = 1.0f;
+            if (node[p] >= 0) { beg[p] = rowptr[node[p]]; end[p] = rowptr[node[p] + 1]; if (row_scale) scl[p] = row_scale[node[p]]; }
+#pragma unroll
+            for (int u = 0; u < IPL; ++u) {
+                const int e = beg[p] + u * LPR + l4;
+                ids[p][u] = e < end[p] ? local_id(src[e]) : 0;
+                wts[p][u] = (HAS_W && e < end[p]) ? w[e] : 0.0f;
+            }
+        }
+    }
+    // acc[p] = scale_p * sum over the arcs of row p of w_e * X[src_e]   (this thread's 16-byte piece).  FROM_LDS: X = rows of the tile
+    // in LDS (row stride ld floats); else rows of a matrix in memory read `sc1` (written by other workgroups during this launch).
+    template <bool FROM_LDS>
+    __device__ __forceinline__ void gather(f32x4 (&acc)[NPASS], const float *lds, int ld, __amdgpu_buffer_rsrc_t rs) {
+#pragma unroll
+        for (int p0 = 0; p0 < NPASS; p0 += PP) {
+            f32x4 v[PP][16];
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                const int p = p0 + pp, rem = end[p] - beg[p];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int id = __shfl(ids[p][i / LPR], i % LPR, LPR);
+                    if (FROM_LDS) {
+                        v[pp][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (__any(i < rem)) { const f32x4 t = *reinterpret_cast<const f32x4 *>(lds + id * ld + 4 * l4); if (i < rem) v[pp][i] = t; }
+                    } else v[pp][i] = buf_ld_sc1(rs, i < rem ? (unsigned)id * (unsigned)(S * 4) + 16u * l4 : BUF_OFF);
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                const int p = p0 + pp;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (HAS_W) t += __shfl(wts[p][i / LPR], i % LPR, LPR) * v[pp][i];
+                    else t += v[pp][i];
+                }
+                acc[p] = t;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            int rem = end[p] - beg[p] - 16, eb = beg[p] + 16;
+#pragma unroll 1
+            while (__any(rem > 0)) {                         // rows with more than 16 arcs: 16 more per trip
+                int idc[IPL]; float wsc[IPL];
+#pragma unroll
+                for (int u = 0; u < IPL; ++u) {
+                    const int e = eb + u * LPR + l4;
+                    idc[u] = e < end[p] ? local_id(src[e]) : 0;
+                    wsc[u] = (HAS_W && e < end[p]) ? w[e] : 0.0f;
+                }
+                f32x4 v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int id = __shfl(idc[i / LPR], i % LPR, LPR);
+                    if (FROM_LDS) { const f32x4 t = *reinterpret_cast<const f32x4 *>(lds + id * ld + 4 * l4); v[i] = i < rem ? t : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                    else v[i] = buf_ld_sc1(rs, i < rem ? (unsigned)id * (unsigned)(S * 4) + 16u * l4 : BUF_OFF);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (HAS_W) acc[p] += __shfl(wsc[i / LPR], i % LPR, LPR) * v[i];
+                    else acc[p] += v[i];
+                }
+                rem -= 16; eb += 16;
+            }
+            acc[p] *= scl[p];
+        }
+    }
+};
+
+// partial slots of the other workgroups: `n` floats per workgroup, summed in workgroup order with 8 loads in flight (double accumulator)
+__device__ __forceinline__ double sum_partials(const float *part, unsigned n_wg, int n, int i) {
+    const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(part);
+    double t = 0.0;
+    unsigned wg = 0;
+    for (; wg + 8 <= n_wg; wg += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_p, (int)(((wg + u) * n + i) * 4), 0, 16));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += (double)v[u];
+    }
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_p, wg + u < n_wg ? (int)(((wg + u) * n + i) * 4) : (int)BUF_OFF, 0, 16));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += (double)v[u];          // (absent slots read 0)
+    return t;
+}
+
 // ---- forward ---------------------------------------------------------------------------------------------------------------------------------
 struct TrainSmallFwd {
     int N, S, K;
@@ -104,139 +227,114 @@ struct TrainSmallFwd {
     const float *gamma, *beta; float eps;                       // BatchNormalization or NULL
     int act;
     const float *Cc;             // [N][S] constant part (k_train_small_const)
-    float thr; int no_exit;
+    float thr;
     const int *flag0;            // predicate of state_0 (one word)
     unsigned long long *bar;     // two arrival counters, zero
     float *part;                 // [2][n_wg][4 S] statistics partials (parity of the iteration)
-    float *k_out; int *err;
+    float *k_out;                // [0] = iterations executed (-1e9: a barrier timed out), [1] = 1 when an arc leaves its tile (LOCAL)
 };
 
-template <int SQ, bool HAS_W>
-__global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a) {
-    constexpr int S = 16 * SQ, LPR = S / 4, NPP = TS_NT / LPR, NPASS = 64 / NPP, IPL = 16 / LPR;
+template <int SQ, bool HAS_W, bool LOCAL>
+__global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, TileTab tt) {
+    using Csr = TileCsr<SQ, HAS_W, LOCAL>;
+    constexpr int S = 16 * SQ, NPP = Csr::NPP, NPASS = Csr::NPASS;
     constexpr int LDX = 2 * S + 4;        // row stride of the [own | agg] tile: == 4 (mod 32) dwords, 16-B chunks conflict-free
     constexpr int LDW = S + 4;            // weight rows: the A-operand read takes rows 4 g + e of a 16-row block, == 4 (mod 32) spreads them
     extern __shared__ __attribute__((aligned(16))) float ts_smem[];
     float *Xs = ts_smem;                  // [64][LDX]
     float *W0 = Xs + 64 * LDX;            // [2 S][LDW] kernel rows of the state / agg columns
-    float *Wsc = W0 + 2 * S * LDW;        // [2 S][LDW] the same with the BatchNorm scale of this iteration folded in
-    float *st_a = Wsc + 2 * S * LDW;      // [2 S] a_k, then [2 S] c_k, [S] bias_dyn, [2 S] pivots of the statistics, reduction scratch [512]
-    float *st_c = st_a + 2 * S, *bias_dyn = st_c + 2 * S, *piv = bias_dyn + S, *red = piv + 2 * S;
+    float *st_a = W0 + 2 * S * LDW;       // [2 S] a_k, [2 S] c_k, [2 S] pivots of the statistics, reduction scratch [512]
+    float *st_c = st_a + 2 * S, *piv = st_c + 2 * S, *red = piv + 2 * S;
     __shared__ int cont;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int tile0 = blockIdx.x * 64;
+    const int n0 = LOCAL ? tt.begin[blockIdx.x] : (int)blockIdx.x * 64;
+    const int nt = LOCAL ? tt.begin[blockIdx.x + 1] - n0 : min(64, a.N - n0);
     const bool bn = a.gamma != nullptr;
     const size_t NS = (size_t)a.N * S;
     GridBar gb{a.bar, gridDim.x, 0, 0u, 0u, 0};
 
     for (int i = tid; i < 2 * S * S; i += TS_NT) {
         const int k = i / S, h = i % S;
-        const float v = a.W[(size_t)((k < S ? 0 : a.off_agg - S) + k) * S + h];
-        W0[k * LDW + h] = v; Wsc[k * LDW + h] = v;
+        W0[k * LDW + h] = a.W[(size_t)((k < S ? 0 : a.off_agg - S) + k) * S + h];
     }
-    if (tid < S) bias_dyn[tid] = 0.0f;
-    if (tid < 2 * S) piv[tid] = 0.0f;
-    // ---- iteration-invariant: the CSR rows of this lane group's nodes (first 16 source ids in registers) ----------------------------
-    const int q = tid / LPR, l4 = tid % LPR;
-    int jn[NPASS], beg[NPASS], end[NPASS], ids[NPASS][IPL];
-    float wts[NPASS][IPL], scl[NPASS];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        const int m = tile0 + p * NPP + q;
-        jn[p] = m < a.N ? m : -1;
-        beg[p] = end[p] = 0; scl[p] = 1.0f;
-        if (jn[p] >= 0) { beg[p] = a.rowptr[m]; end[p] = a.rowptr[m + 1]; if (a.row_scale) scl[p] = a.row_scale[m]; }
-#pragma unroll
-        for (int u = 0; u < IPL; ++u) {
-            const int e = beg[p] + u * LPR + l4;
-            ids[p][u] = e < end[p] ? a.src[e] : 0;
-            wts[p][u] = (HAS_W && e < end[p]) ? a.w[e] : 0.0f;
-        }
-    }
+    if (tid < 2 * S) { piv[tid] = 0.0f; st_a[tid] = 1.0f; st_c[tid] = 0.0f; }
+    Csr csr;
+    csr.load(n0, nt, a.rowptr, a.src, a.w, a.row_scale);
+    const int q = csr.q, l4 = csr.l4;
     // the constant part of this lane's output chunks (row 16 wave + c, columns 16 ct + 4 g ..)
-    const int orow = tile0 + 16 * wave + c;
-    const bool oin = orow < a.N;
+    const bool oin = 16 * wave + c < nt;
+    const int orow = n0 + 16 * wave + c;
     f32x4 cc[SQ];
 #pragma unroll
     for (int ct = 0; ct < SQ; ++ct)
         cc[ct] = oin ? *reinterpret_cast<const f32x4 *>(a.Cc + (size_t)orow * S + 16 * ct + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    bool run = a.no_exit != 0 || __hip_atomic_load(a.flag0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (LOCAL) {                          // the tile's rows of state_0: from here on the state lives in the own half of Xs
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            f32x4 own = {0.f, 0.f, 0.f, 0.f};
+            if (csr.node[p] >= 0) own = *reinterpret_cast<const f32x4 *>(a.states + (size_t)csr.node[p] * S + 4 * l4);
+            *reinterpret_cast<f32x4 *>(Xs + (p * NPP + q) * LDX + 4 * l4) = own;
+        }
+    }
+    const bool run = __hip_atomic_load(a.flag0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     __syncthreads();
 
-    int k_done = 0;
+    int k_done = 0, any_prev = 0;
     for (int it = 0; run && it < a.K; ++it) {
         const __amdgpu_buffer_rsrc_t r_in = buf_rsrc(a.states + (size_t)it * NS), r_out = buf_rsrc(a.states + (size_t)(it + 1) * NS);
         float *agg_t = a.agg + (size_t)it * NS;
-        // ---- A. gather: own row and neighbour sum of the tile's nodes -> LDS; the sum also goes to the tape ------------------------------
+        // ---- A. own row and neighbour sum of the tile's nodes -> LDS; the sum also goes to the tape ------------------------------------------
+        {
+            f32x4 own[NPASS], acc[NPASS];
+            if (!LOCAL) {
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            f32x4 own = buf_ld_sc1(r_in, jn[p] >= 0 ? (unsigned)jn[p] * (unsigned)(S * 4) + 16u * l4 : BUF_OFF);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            int idc[IPL]; float wsc[IPL];
-#pragma unroll
-            for (int u = 0; u < IPL; ++u) { idc[u] = ids[p][u]; wsc[u] = wts[p][u]; }
-            int rem = end[p] - beg[p], eb = beg[p];
-#pragma unroll 1
-            while (true) {
-                f32x4 v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const unsigned off = (unsigned)__shfl(idc[i / LPR], i % LPR, LPR) * (unsigned)(S * 4) + 16u * l4;
-                    v[i] = buf_ld_sc1(r_in, i < rem ? off : BUF_OFF);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (HAS_W) acc += __shfl(wsc[i / LPR], i % LPR, LPR) * v[i];
-                    else acc += v[i];
-                }
-                rem -= 16; eb += 16;
-                if (!__any(rem > 0)) break;
-#pragma unroll
-                for (int u = 0; u < IPL; ++u) {
-                    const int e = eb + u * LPR + l4;
-                    idc[u] = e < end[p] ? a.src[e] : 0;
-                    wsc[u] = (HAS_W && e < end[p]) ? a.w[e] : 0.0f;
-                }
+                for (int p = 0; p < NPASS; ++p)
+                    own[p] = buf_ld_sc1(r_in, csr.node[p] >= 0 ? (unsigned)csr.node[p] * (unsigned)(S * 4) + 16u * l4 : BUF_OFF);
             }
-            acc *= scl[p];
-            float *xr = Xs + (p * NPP + q) * LDX + 4 * l4;
-            *reinterpret_cast<f32x4 *>(xr) = own;
-            *reinterpret_cast<f32x4 *>(xr + S) = acc;
-            if (jn[p] >= 0) *reinterpret_cast<f32x4 *>(agg_t + (size_t)jn[p] * S + 4 * l4) = acc;
+            if (LOCAL) csr.template gather<true>(acc, Xs, LDX, r_in); else csr.template gather<false>(acc, nullptr, 0, r_in);
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                float *xr = Xs + (p * NPP + q) * LDX + 4 * l4;
+                if (!LOCAL) *reinterpret_cast<f32x4 *>(xr) = own[p];
+                *reinterpret_cast<f32x4 *>(xr + S) = acc[p];
+                if (csr.node[p] >= 0) *reinterpret_cast<f32x4 *>(agg_t + (size_t)csr.node[p] * S + 4 * l4) = acc[p];
+            }
         }
         __syncthreads();
         if (bn) {
-            // ---- B. column sums / squares of [state | agg] over the tile's rows -> partial slot -> BARRIER -> batch statistics -----------
-            {
-                const int col = tid & (2 * S - 1), part_i = tid / (2 * S);          // 256 / (2 S) row groups (S = 64: 2, 32: 4, 16: 8)
-                constexpr int NG = TS_NT / (2 * S), RPG = 64 / NG;
-                // sums of (x - pivot), pivot = the previous iteration's mean (the same bits in every workgroup): E[d^2] - E[d]^2 does
-                // not cancel once the states settle
-                float s1 = 0.0f, s2 = 0.0f;
-                const float pv = piv[col];
-                for (int rr = part_i * RPG; rr < (part_i + 1) * RPG; ++rr) {
-                    const float x = (tile0 + rr < a.N) ? Xs[rr * LDX + col] - pv : 0.0f;
-                    s1 += x; s2 = fmaf(x, x, s2);
-                }
-                red[part_i * 4 * S + col] = s1; red[part_i * 4 * S + 2 * S + col] = s2;
-                __syncthreads();
-                if (tid < 4 * S) {
-                    float t = 0.0f;
-                    for (int gq = 0; gq < NG; ++gq) t += red[gq * 4 * S + tid];
-                    const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + ((size_t)(it & 1) * gridDim.x + blockIdx.x) * 4 * S);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), r_p, tid * 4, 0, 16);
-                }
+            // ---- B. column sums / squares of [state | agg] over the tile's rows -> partial slot ---------------------------------------------
+            const int col = tid & (2 * S - 1), part_i = tid / (2 * S);          // 256 / (2 S) row groups (S = 64: 2, 32: 4, 16: 8)
+            constexpr int NG = TS_NT / (2 * S), RPG = 64 / NG;
+            // sums of (x - pivot), pivot = the previous iteration's mean (the same bits in every workgroup): E[d^2] - E[d]^2 does
+            // not cancel once the states settle
+            float s1 = 0.0f, s2 = 0.0f;
+            const float pv = piv[col];
+#pragma unroll 8
+            for (int rr = part_i * RPG; rr < (part_i + 1) * RPG; ++rr) {
+                const float x = rr < nt ? Xs[rr * LDX + col] - pv : 0.0f;
+                s1 += x; s2 = fmaf(x, x, s2);
             }
-            grid_barrier(gb, 0, &cont);
-            if (tid < 4 * S) {                                     // (sum | square, column): partials in workgroup order, double accumulator
-                const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + (size_t)(it & 1) * gridDim.x * 4 * S);
-                double t = 0.0;
-                for (unsigned wg = 0; wg < gridDim.x; ++wg)
-                    t += (double)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_p, (int)((wg * 4 * S + tid) * 4), 0, 16));
-                red[tid] = (float)(t / (double)a.N);               // E[x - pivot] (first 2 S), E[(x - pivot)^2] (next 2 S)
+            red[part_i * 4 * S + col] = s1; red[part_i * 4 * S + 2 * S + col] = s2;
+            __syncthreads();
+            if (tid < 4 * S) {
+                float t = 0.0f;
+#pragma unroll
+                for (int gq = 0; gq < NG; ++gq) t += red[gq * 4 * S + tid];
+                const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + ((size_t)(it & 1) * gridDim.x + blockIdx.x) * 4 * S);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), r_p, tid * 4, 0, 16);
             }
+        }
+        if (LOCAL) {
+            if (it > 0 || bn) {           // one barrier: the statistics partials, and whether any node moved in iteration it - 1
+                const bool moving = grid_barrier(gb, any_prev, &cont);
+                if (it > 0 && !moving) break;
+            }
+        } else if (bn) grid_barrier(gb, 0, &cont);
+        if (bn) {
+            if (tid < 4 * S)              // (sum | square, column): partials in workgroup order
+                red[tid] = (float)(sum_partials(a.part + (size_t)(it & 1) * gridDim.x * 4 * S, gridDim.x, 4 * S, tid) / (double)a.N);
             __syncthreads();
             if (tid < 2 * S) {
                 const int k = (tid < S ? 0 : a.off_agg - S) + tid;                    // BatchNorm column of this input column
@@ -247,58 +345,59 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a) {
                 if (blockIdx.x == 0) { a.stats[(size_t)it * 2 * a.in_s + k] = mu; a.stats[(size_t)it * 2 * a.in_s + a.in_s + k] = va; }
             }
             __syncthreads();
-            for (int i = tid; i < 2 * S * S; i += TS_NT) { const int k = i / S, h = i % S; Wsc[k * LDW + h] = st_a[k] * W0[k * LDW + h]; }
-            if (tid < S) {
-                float t = 0.0f;
-                for (int k = 0; k < 2 * S; ++k) t = fmaf(st_c[k], W0[k * LDW + tid], t);
-                bias_dyn[tid] = t;
-            }
-            __syncthreads();
         }
-        // ---- C. [state | agg] . W (+ constant part) on the matrix cores, operands swapped: lane (c, g) gets columns 16 ct + 4 g .. of row c ---
+        // ---- C. (a x + c) . W (+ constant part) on the matrix cores, operands swapped: lane (c, g) gets columns 16 ct + 4 g .. of row c -----
         f32x4 acc[SQ];
 #pragma unroll
-        for (int ct = 0; ct < SQ; ++ct) acc[ct] = cc[ct] + *reinterpret_cast<const f32x4 *>(bias_dyn + 16 * ct + 4 * g);
+        for (int ct = 0; ct < SQ; ++ct) acc[ct] = cc[ct];
         // k-step (qq, e) takes input column 16 qq + 4 g + e from lane group g: one 16-byte LDS read feeds four steps
         const float *xrow = Xs + (16 * wave + c) * LDX + 4 * g;
 #pragma unroll 2
         for (int qq = 0; qq < 2 * S / 16; ++qq) {
-            const f32x4 xv = *reinterpret_cast<const f32x4 *>(xrow + 16 * qq);
+            f32x4 xv = *reinterpret_cast<const f32x4 *>(xrow + 16 * qq);
+            if (bn) {
+                const f32x4 av = *reinterpret_cast<const f32x4 *>(st_a + 16 * qq + 4 * g), cv = *reinterpret_cast<const f32x4 *>(st_c + 16 * qq + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[e] = fmaf(xv[e], av[e], cv[e]);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float *wr = Wsc + (16 * qq + 4 * g + e) * LDW + c;
+                const float *wr = W0 + (16 * qq + 4 * g + e) * LDW + c;
 #pragma unroll
                 for (int ct = 0; ct < SQ; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * ct], xv[e], acc[ct], 0, 0, 0);
             }
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");          // (MFMA results consumed behind a branch: see kernels_train_big.hpp)
         float d2 = 0.0f, n2 = 0.0f;
+        float *orow_lds = Xs + (16 * wave + c) * LDX + 4 * g;
 #pragma unroll
         for (int ct = 0; ct < SQ; ++ct) {
             f32x4 v = acc[ct];
             activate4(a.act, v);
-            const f32x4 o = *reinterpret_cast<const f32x4 *>(Xs + (16 * wave + c) * LDX + 16 * ct + 4 * g);
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(orow_lds + 16 * ct);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = oin ? v[e] : 0.0f; const float d = v[e] - o[e]; d2 = fmaf(d, d, d2); n2 = fmaf(o[e], o[e], n2); }
-            buf_st_sc1(r_out, oin ? ((unsigned)orow * (unsigned)S + 16u * ct + 4u * g) * 4u : BUF_OFF, v);
+            if (LOCAL) {                  // (this wave's rows: no other wave reads them before the barrier below)
+                *reinterpret_cast<f32x4 *>(orow_lds + 16 * ct) = v;
+                if (oin) *reinterpret_cast<f32x4 *>(a.states + (size_t)(it + 1) * NS + (size_t)orow * S + 16 * ct + 4 * g) = v;
+            } else buf_st_sc1(r_out, oin ? ((unsigned)orow * (unsigned)S + 16u * ct + 4u * g) * 4u : BUF_OFF, v);
         }
         d2 += __shfl_xor(d2, 16, 64); d2 += __shfl_xor(d2, 32, 64);
         n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64);
         const int any = (oin && sqrtf(d2) > a.thr * sqrtf(n2)) ? 1 : 0;
-        const bool moving = grid_barrier(gb, any, &cont);
         k_done = it + 1;
-        if (!a.no_exit && !moving) break;
+        if (LOCAL) { any_prev = any; __syncthreads(); }
+        else if (!grid_barrier(gb, any, &cont)) break;
     }
-    if (tid == 0) {
-        if (gb.timed_out && a.err) atomicOr(a.err, 1);
-        if (blockIdx.x == 0) *a.k_out = gb.timed_out ? -1.0e9f : (float)k_done;
-    }
+    if (LOCAL && __syncthreads_or(csr.bad) && tid == 0) a.k_out[1] = 1.0f;
+    if (tid == 0 && blockIdx.x == 0) a.k_out[0] = (float)k_done;
+    if (tid == 0 && gb.timed_out) a.k_out[1] = 2.0f;
 }
 
 template <int SQ>
 inline size_t train_small_fwd_lds() {
     constexpr int S = 16 * SQ;
-    return sizeof(float) * (64 * (2 * S + 4) + 2 * (2 * S) * (S + 4) + 2 * S + 2 * S + S + 2 * S + 512);
+    return sizeof(float) * (64 * (2 * S + 4) + (2 * S) * (S + 4) + 3 * 2 * S + 512);
 }
 
 // ---- backward ----------------------------------------------------------------------------------------------------------------------------------
@@ -313,18 +412,19 @@ struct TrainSmallBwd {
     const float *gamma, *beta; float eps;
     int act;
     const float *G0;             // [N][S] d loss / d states[k] (from the output network)
-    float *dxa;                  // [N][S] exchange buffer: d loss / d agg rows of the current iteration
+    float *dxa;                  // [N][S] exchange buffer: d loss / d agg rows of the current iteration (general form)
     unsigned long long *bar;
-    float *part;                 // [2][n_wg][S + in_s]  (q | S2) partials
-    float *partW;                // [n_wg][in_s * S] every workgroup's share of the kernel gradient (summed by the caller)
-    float *db, *dgamma, *dbeta;  // [S], [in_s], [in_s] written by workgroup 0 (complete)
+    float *part;                 // [2][n_wg][S + KMAX]  (q | S2) partials
+    float *partW;                // [n_wg][in_s * S + S] every workgroup's share of the kernel and bias gradients (summed by the caller)
+    float *dgamma, *dbeta;       // [in_s] written by workgroup 0 (complete)
     float inv_n;                 // 1 / N
-    int *err;
+    float *err;                  // [1] = 2 when a barrier timed out
 };
 
-template <int SQ, bool HAS_W>
-__global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a) {
-    constexpr int S = 16 * SQ, LPR = S / 4, NPP = TS_NT / LPR, NPASS = 64 / NPP, IPL = 16 / LPR;
+template <int SQ, bool HAS_W, bool LOCAL>
+__global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, TileTab tt) {
+    using Csr = TileCsr<SQ, HAS_W, LOCAL>;
+    constexpr int S = 16 * SQ, LPR = S / 4, NPP = Csr::NPP, NPASS = Csr::NPASS;
     constexpr int KMAX = 2 * S + 32;      // input columns: state, agg, up to 32 constant columns (in tile order: state | agg | constants)
     constexpr int LDX = KMAX + 4;         // == 4 (mod 32)
     constexpr int LDZ = S + 4, LDW = S + 4;
@@ -334,16 +434,18 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a) {
     float *Xs = ts_smem;                  // [64][LDX]  inputs of the tile: [state_t | agg_t | constants]
     float *Zs = Xs + 64 * LDX;            // [64][LDZ]  dZ
     float *Gs = Zs + 64 * LDZ;            // [64][LDZ]  G (d loss / d state of the tile)
-    float *Wr = Gs + 64 * LDZ;            // [KMAX][LDW] kernel rows in tile-column order (state, agg, constants)
-    float *vec = Wr + KMAX * LDW;         // q [S] | S2 [KMAX] | S1 [KMAX] | a [KMAX] | c [KMAX] | coefA, coefC, coefB [2 S each] | scratch
-    float *q_s = vec, *S2_s = q_s + S, *S1_s = S2_s + KMAX, *a_s = S1_s + KMAX, *c_s = a_s + KMAX, *cfA = c_s + KMAX, *cfC = cfA + 2 * S,
-          *cfB = cfC + 2 * S, *red = cfB + 2 * S;       // red: [4][S] / [4][KMAX] scratch
+    float *Da = Gs + 64 * LDZ;            // [64][LDZ]  d loss / d agg rows of the tile (LOCAL)
+    float *Wr = Da + (LOCAL ? 64 * LDZ : 0);       // [KMAX][LDW] kernel rows in tile-column order (state, agg, constants)
+    float *vec = Wr + KMAX * LDW;
+    float *q_s = vec, *ql_s = q_s + S, *S2_s = ql_s + S, *S1_s = S2_s + KMAX, *a_s = S1_s + KMAX, *c_s = a_s + KMAX, *cfA = c_s + KMAX,
+          *cfC = cfA + 2 * S, *cfB = cfC + 2 * S, *red = cfB + 2 * S;       // red: [4][KMAX] / [256] scratch
     int *wrow_of = reinterpret_cast<int *>(red + 4 * KMAX);     // [KMAX] weight row (= BatchNorm column) of tile column j, -1 = padding
     __shared__ int cont;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int tile0 = blockIdx.x * 64;
+    const int n0 = LOCAL ? tt.begin[blockIdx.x] : (int)blockIdx.x * 64;
+    const int nt = LOCAL ? tt.begin[blockIdx.x + 1] - n0 : min(64, a.N - n0);
     const bool bn = a.gamma != nullptr;
     const size_t NS = (size_t)a.N * S;
     GridBar gb{a.bar, gridDim.x, 0, 0u, 0u, 0};
@@ -368,43 +470,29 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a) {
     }
     // the tile's constant inputs and its first G
     for (int i = tid; i < 64 * 32; i += TS_NT) {
-        const int rr = i >> 5, jj = i & 31, n = tile0 + rr;
+        const int rr = i >> 5, jj = i & 31;
         float v = 0.0f;
-        if (n < a.N && jj < Kc) {
+        if (rr < nt && jj < Kc) {
             int b0 = 0;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) { if (s < a.cs.n && jj >= b0 && jj < b0 + a.cs.width[s]) v = a.cs.ptr[s][(size_t)n * a.cs.ld[s] + (jj - b0)]; if (s < a.cs.n) b0 += a.cs.width[s]; }
+            for (int s = 0; s < 3; ++s) { if (s < a.cs.n && jj >= b0 && jj < b0 + a.cs.width[s]) v = a.cs.ptr[s][(size_t)(n0 + rr) * a.cs.ld[s] + (jj - b0)]; if (s < a.cs.n) b0 += a.cs.width[s]; }
         }
         Xs[rr * LDX + 2 * S + jj] = v;
     }
     for (int i = tid; i < 64 * S; i += TS_NT) {
-        const int rr = i / S, h = i % S, n = tile0 + rr;
-        Gs[rr * LDZ + h] = n < a.N ? a.G0[(size_t)n * S + h] : 0.0f;
+        const int rr = i / S, h = i % S;
+        Gs[rr * LDZ + h] = rr < nt ? a.G0[(size_t)(n0 + rr) * S + h] : 0.0f;
     }
-    // by-source CSR rows of this lane group's nodes
-    const int q = tid / LPR, l4 = tid % LPR;
-    int jn[NPASS], beg[NPASS], end[NPASS], ids[NPASS][IPL];
-    float wts[NPASS][IPL], scl[NPASS];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        const int m = tile0 + p * NPP + q;
-        jn[p] = m < a.N ? m : -1;
-        beg[p] = end[p] = 0; scl[p] = 1.0f;
-        if (jn[p] >= 0) { beg[p] = a.rowptr_s[m]; end[p] = a.rowptr_s[m + 1]; if (a.row_scale_s) scl[p] = a.row_scale_s[m]; }
-#pragma unroll
-        for (int u = 0; u < IPL; ++u) {
-            const int e = beg[p] + u * LPR + l4;
-            ids[p][u] = e < end[p] ? a.src_s[e] : 0;
-            wts[p][u] = (HAS_W && e < end[p]) ? a.w_s[e] : 0.0f;
-        }
-    }
+    Csr csr;
+    csr.load(n0, nt, a.rowptr_s, a.src_s, a.w_s, a.row_scale_s);
+    const int q = csr.q, l4 = csr.l4;
     // this wave's tiles of P: (kt, ht) = tile index wave + 4 i  ->  accumulated kernel-gradient share, over all iterations
     f32x4 accW[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) accW[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float db_acc = 0.0f, dg_acc = 0.0f, dbt_acc = 0.0f;              // workgroup 0: thread h < S / thread j < KU
-    const int orow = tile0 + 16 * wave + c;
-    const bool oin = orow < a.N;
+    float db_acc = 0.0f, dg_acc = 0.0f, dbt_acc = 0.0f;              // thread h < S (own share) / workgroup 0: thread j < KU
+    const bool oin = 16 * wave + c < nt;
+    const int orow = n0 + 16 * wave + c;
     const float rs = (a.row_scale && oin) ? a.row_scale[orow] : 1.0f;
     const __amdgpu_buffer_rsrc_t r_dxa = buf_rsrc(a.dxa);
     __syncthreads();
@@ -413,20 +501,30 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a) {
         const float *s_t = a.states + (size_t)t * NS, *s_n = a.states + (size_t)(t + 1) * NS, *agg_t = a.agg + (size_t)t * NS;
         const float *stats = a.stats + (size_t)t * 2 * a.in_s;
         // ---- A. the tile's inputs and dZ = G (.) act'(output) into LDS -----------------------------------------------------------------------
-        for (int i = tid; i < 64 * LPR; i += TS_NT) {
-            const int rr = i / LPR, ch = i % LPR, n = tile0 + rr;
-            f32x4 xs = {0.f, 0.f, 0.f, 0.f}, xa = xs, y = xs;
-            if (n < a.N) {
-                xs = *reinterpret_cast<const f32x4 *>(s_t + (size_t)n * S + 4 * ch);
-                xa = *reinterpret_cast<const f32x4 *>(agg_t + (size_t)n * S + 4 * ch);
-                y = *reinterpret_cast<const f32x4 *>(s_n + (size_t)n * S + 4 * ch);
-            }
-            *reinterpret_cast<f32x4 *>(Xs + rr * LDX + 4 * ch) = xs;
-            *reinterpret_cast<f32x4 *>(Xs + rr * LDX + S + 4 * ch) = xa;
-            f32x4 gz = *reinterpret_cast<const f32x4 *>(Gs + rr * LDZ + 4 * ch);
+        {
+            constexpr int NCH = 64 * LPR / TS_NT;
+            f32x4 xs[NCH], xa[NCH], y[NCH];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gz[e] *= activate_grad_from_output(a.act, y[e]);
-            *reinterpret_cast<f32x4 *>(Zs + rr * LDZ + 4 * ch) = gz;
+            for (int u = 0; u < NCH; ++u) {
+                const int i = tid + u * TS_NT, rr = i / LPR, ch = i % LPR;
+                xs[u] = xa[u] = y[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (rr < nt) {
+                    const size_t o = (size_t)(n0 + rr) * S + 4 * ch;
+                    xs[u] = *reinterpret_cast<const f32x4 *>(s_t + o);
+                    xa[u] = *reinterpret_cast<const f32x4 *>(agg_t + o);
+                    y[u] = *reinterpret_cast<const f32x4 *>(s_n + o);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NCH; ++u) {
+                const int i = tid + u * TS_NT, rr = i / LPR, ch = i % LPR;
+                *reinterpret_cast<f32x4 *>(Xs + rr * LDX + 4 * ch) = xs[u];
+                *reinterpret_cast<f32x4 *>(Xs + rr * LDX + S + 4 * ch) = xa[u];
+                f32x4 gz = *reinterpret_cast<const f32x4 *>(Gs + rr * LDZ + 4 * ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gz[e] *= activate_grad_from_output(a.act, y[u][e]);
+                *reinterpret_cast<f32x4 *>(Zs + rr * LDZ + 4 * ch) = gz;
+            }
         }
         if (tid < KU) {                                            // BatchNorm scale / shift of this iteration per tile column
             float ak = 1.0f, ck = 0.0f;
@@ -449,51 +547,75 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a) {
             }
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-        // P[i][reg] = P_wg[16 kt + 4 g + reg][16 ht + c]; S2 partial: sum over h of W[k][h] P[k][h] -> LDS scratch (per h-tile, per c lane)
-        if (tid < S) {
+        {   // q of the tile: column sums of dZ, 256 / S row groups
+            constexpr int NG = TS_NT / S, RPG = 64 / NG;
+            const int col = tid % S, gq = tid / S;
             float t2 = 0.0f;
-            for (int rr = 0; rr < 64; ++rr) t2 += Zs[rr * LDZ + tid];
-            q_s[tid] = t2;
+#pragma unroll
+            for (int rr = gq * RPG; rr < (gq + 1) * RPG; ++rr) t2 += Zs[rr * LDZ + col];
+            red[gq * S + col] = t2;
+            __syncthreads();
+            if (tid < S) {
+                float t3 = 0.0f;
+#pragma unroll
+                for (int u = 0; u < NG; ++u) t3 += red[u * S + tid];
+                ql_s[tid] = t3; q_s[tid] = t3;
+                db_acc += t3;
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        if (bn) {
+            // P[i][reg] = P_wg[16 kt + 4 g + reg][16 ht + c]; S2 partial: sum over h of W[k][h] P[k][h] (per column tile, then in tile order)
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int ti = wave + 4 * i;
-            if (ti < NKT * SQ) {
-                const int kt = ti / SQ, ht = ti % SQ;
+            for (int i = 0; i < TPW; ++i) {
+                const int ti = wave + 4 * i;
+                if (ti < NKT * SQ) {
+                    const int kt = ti / SQ, ht = ti % SQ;
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int j = 16 * kt + 4 * g + reg;
-                    float v = Wr[j * LDW + 16 * ht + c] * P[i][reg];
-                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);   // over the 16 columns
-                    if (c == 0) red[ht * KMAX + j] = v;
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int j = 16 * kt + 4 * g + reg;
+                        float v = Wr[j * LDW + 16 * ht + c] * P[i][reg];
+                        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);   // over the 16 columns
+                        if (c == 0) red[ht * KMAX + j] = v;
+                    }
                 }
             }
+            __syncthreads();
+            if (tid < S + KMAX) {
+                float v = 0.0f;
+                if (tid < S) v = ql_s[tid];
+                else for (int ht = 0; ht < SQ; ++ht) v += red[ht * KMAX + tid - S];            // in column-tile order
+                const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + ((size_t)(t & 1) * gridDim.x + blockIdx.x) * (S + KMAX));
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r_p, tid * 4, 0, 16);
+            }
+            grid_barrier(gb, 0, &cont);
+            if (tid < S + KMAX) {
+                const float tt2 = (float)sum_partials(a.part + (size_t)(t & 1) * gridDim.x * (S + KMAX), gridDim.x, S + KMAX, tid);
+                if (tid < S) q_s[tid] = tt2; else S2_s[tid - S] = tt2;
+            }
+            __syncthreads();
+            if (tid < KU) {                                        // S1_k = (W q)_k
+                float t1 = 0.0f;
+#pragma unroll 8
+                for (int h = 0; h < S; ++h) t1 = fmaf(Wr[tid * LDW + h], q_s[h], t1);
+                S1_s[tid] = t1;
+            }
+            __syncthreads();
+            if (blockIdx.x == 0 && tid < KU) {
+                const int k = wrow_of[tid];
+                const float rstd = 1.0f / sqrtf(stats[a.in_s + k] + a.eps);
+                dg_acc += rstd * (S2_s[tid] - stats[k] * S1_s[tid]); dbt_acc += S1_s[tid];
+            }
+            if (tid < 2 * S) {
+                const int k = wrow_of[tid];
+                const float rstd = 1.0f / sqrtf(stats[a.in_s + k] + a.eps), mu = stats[k];
+                const float m1 = S1_s[tid] * a.inv_n, m2 = rstd * (S2_s[tid] - mu * S1_s[tid]) * a.inv_n;
+                const float Ac = a.gamma[k] * rstd, Cc = -Ac * rstd * m2;
+                cfA[tid] = Ac; cfC[tid] = Cc; cfB[tid] = -Ac * m1 - Cc * mu;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid < S + KMAX) {
-            float v = 0.0f;
-            if (tid < S) v = q_s[tid];
-            else for (int ht = 0; ht < SQ; ++ht) v += red[ht * KMAX + tid - S];            // in column-tile order
-            const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + ((size_t)(t & 1) * gridDim.x + blockIdx.x) * (S + KMAX));
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r_p, tid * 4, 0, 16);
-        }
-        grid_barrier(gb, 0, &cont);
-        if (tid < S + KMAX) {
-            const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + (size_t)(t & 1) * gridDim.x * (S + KMAX));
-            double tt = 0.0;
-            for (unsigned wg = 0; wg < gridDim.x; ++wg)
-                tt += (double)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_p, (int)((wg * (S + KMAX) + tid) * 4), 0, 16));
-            if (tid < S) q_s[tid] = (float)tt; else S2_s[tid - S] = (float)tt;
-        }
-        __syncthreads();
-        if (tid < KU) {                                            // S1_k = (W q)_k
-            float t1 = 0.0f;
-            for (int h = 0; h < S; ++h) t1 = fmaf(Wr[tid * LDW + h], q_s[h], t1);
-            S1_s[tid] = t1;
-        }
-        __syncthreads();
-        // ---- C. parameter-gradient shares (registers), BatchNorm input-gradient coefficients -------------------------------------------------
+        // ---- C. this workgroup's share of the kernel gradient: a (.) P_wg (+ c q^T once, in workgroup 0: q is the total) ---------------------------
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int ti = wave + 4 * i;
@@ -503,31 +625,12 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a) {
                 for (int reg = 0; reg < 4; ++reg) {
                     const int j = 16 * kt + 4 * g + reg;
                     float v = j < KU ? a_s[j] * P[i][reg] : 0.0f;
-                    if (blockIdx.x == 0 && j < KU) v = fmaf(c_s[j], q_s[16 * ht + c], v);      // the c q^T term once (q is the total)
+                    if (bn && blockIdx.x == 0 && j < KU) v = fmaf(c_s[j], q_s[16 * ht + c], v);
                     accW[i][reg] += v;
                 }
             }
         }
-        if (blockIdx.x == 0) {
-            if (tid < S) db_acc += q_s[tid];
-            if (bn && tid < KU) {
-                const int k = wrow_of[tid];
-                const float rstd = 1.0f / sqrtf(stats[a.in_s + k] + a.eps);
-                dg_acc += rstd * (S2_s[tid] - stats[k] * S1_s[tid]); dbt_acc += S1_s[tid];
-            }
-        }
-        if (tid < 2 * S) {
-            float Ac = 1.0f, Cc = 0.0f, Bc = 0.0f;
-            if (bn) {
-                const int k = wrow_of[tid];
-                const float rstd = 1.0f / sqrtf(stats[a.in_s + k] + a.eps), mu = stats[k];
-                const float m1 = S1_s[tid] * a.inv_n, m2 = rstd * (S2_s[tid] - mu * S1_s[tid]) * a.inv_n;
-                Ac = a.gamma[k] * rstd; Cc = -Ac * rstd * m2; Bc = -Ac * m1 - Cc * mu;
-            }
-            cfA[tid] = Ac; cfC[tid] = Cc; cfB[tid] = Bc;
-        }
-        __syncthreads();
-        // ---- D. dx = BN-gradient(dZ . W^T) on the matrix cores (operands swapped: row-major); agg half -> exchange buffer, state half -> Gs ----
+        // ---- D. dx = BN-gradient(dZ . W^T) on the matrix cores (operands swapped: row-major); state half -> Gs, agg half -> Da / memory ----
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 acc[SQ];
@@ -554,54 +657,34 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaf(cfA[j0 + e], v[e], fmaf(cfC[j0 + e], x[e], cfB[j0 + e]));
                 }
+                if (!oin) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (half == 0) {
                     *reinterpret_cast<f32x4 *>(Gs + (16 * wave + c) * LDZ + 16 * u + 4 * g) = v;      // dx_state: the own part of the next G
                 } else {
                     v *= rs;
-                    buf_st_sc1(r_dxa, oin ? ((unsigned)orow * (unsigned)S + 16u * u + 4u * g) * 4u : BUF_OFF, v);
+                    if (LOCAL) *reinterpret_cast<f32x4 *>(Da + (16 * wave + c) * LDZ + 16 * u + 4 * g) = v;
+                    else buf_st_sc1(r_dxa, oin ? ((unsigned)orow * (unsigned)S + 16u * u + 4u * g) * 4u : BUF_OFF, v);
                 }
             }
         }
-        grid_barrier(gb, 0, &cont);
+        if (LOCAL) __syncthreads(); else grid_barrier(gb, 0, &cont);
         // ---- E. G = dx_state + Adj . dx_agg: gather by source -----------------------------------------------------------------------------------
+        {
+            f32x4 acc[NPASS];
+            if (LOCAL) csr.template gather<true>(acc, Da, LDZ, r_dxa); else csr.template gather<false>(acc, nullptr, 0, r_dxa);
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            int idc[IPL]; float wsc[IPL];
-#pragma unroll
-            for (int u = 0; u < IPL; ++u) { idc[u] = ids[p][u]; wsc[u] = wts[p][u]; }
-            int rem = end[p] - beg[p], eb = beg[p];
-#pragma unroll 1
-            while (true) {
-                f32x4 v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const unsigned off = (unsigned)__shfl(idc[i / LPR], i % LPR, LPR) * (unsigned)(S * 4) + 16u * l4;
-                    v[i] = buf_ld_sc1(r_dxa, i < rem ? off : BUF_OFF);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (HAS_W) acc += __shfl(wsc[i / LPR], i % LPR, LPR) * v[i];
-                    else acc += v[i];
-                }
-                rem -= 16; eb += 16;
-                if (!__any(rem > 0)) break;
-#pragma unroll
-                for (int u = 0; u < IPL; ++u) {
-                    const int e = eb + u * LPR + l4;
-                    idc[u] = e < end[p] ? a.src_s[e] : 0;
-                    wsc[u] = (HAS_W && e < end[p]) ? a.w_s[e] : 0.0f;
-                }
+            for (int p = 0; p < NPASS; ++p) {
+                float *gr = Gs + (p * NPP + q) * LDZ + 4 * l4;
+                f32x4 gv = *reinterpret_cast<const f32x4 *>(gr);
+                gv += acc[p];
+                if (csr.node[p] < 0) gv = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(gr) = gv;
             }
-            float *gr = Gs + (p * NPP + q) * LDZ + 4 * l4;
-            f32x4 gv = *reinterpret_cast<const f32x4 *>(gr);
-            gv += acc * scl[p];
-            if (jn[p] < 0) gv = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(gr) = gv;
         }
         __syncthreads();
     }
-    // ---- the kernel-gradient share of this workgroup; bias / BatchNorm gradients from workgroup 0 ----------------------------------------------
+    // ---- the kernel- and bias-gradient share of this workgroup; BatchNorm gradients from workgroup 0 ----------------------------------------------
+    float *pw = a.partW + (size_t)blockIdx.x * ((size_t)a.in_s * S + S);
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int ti = wave + 4 * i;
@@ -610,21 +693,20 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int j = 16 * kt + 4 * g + reg;
-                if (j < KU) a.partW[(size_t)blockIdx.x * a.in_s * S + (size_t)wrow_of[j] * S + 16 * ht + c] = accW[i][reg];
+                if (j < KU) pw[(size_t)wrow_of[j] * S + 16 * ht + c] = accW[i][reg];
             }
         }
     }
-    if (blockIdx.x == 0) {
-        if (tid < S) a.db[tid] = db_acc;
-        if (bn && tid < KU) { a.dgamma[wrow_of[tid]] = dg_acc; a.dbeta[wrow_of[tid]] = dbt_acc; }
-    }
-    if (tid == 0 && gb.timed_out) { if (a.err) atomicOr(a.err, 1); a.db[0] = __builtin_nanf(""); }      // loud: the gradients are invalid
+    if (tid < S) pw[(size_t)a.in_s * S + tid] = db_acc;
+    if (blockIdx.x == 0 && bn && tid < KU) { a.dgamma[wrow_of[tid]] = dg_acc; a.dbeta[wrow_of[tid]] = dbt_acc; }
+    if (tid == 0 && gb.timed_out) a.err[1] = 2.0f;
+    if (__syncthreads_or(gb.timed_out || (LOCAL && csr.bad)) && tid == 0) pw[0] = __builtin_nanf("");      // loud: the gradients are invalid
 }
 
 template <int SQ>
-inline size_t train_small_bwd_lds() {
+inline size_t train_small_bwd_lds(bool local) {
     constexpr int S = 16 * SQ, KMAX = 2 * S + 32;
-    return sizeof(float) * (64 * (KMAX + 4) + 2 * 64 * (S + 4) + KMAX * (S + 4) + (S + 4 * KMAX + 6 * S) + 4 * KMAX + KMAX);
+    return sizeof(float) * (64 * (KMAX + 4) + (local ? 3 : 2) * 64 * (S + 4) + KMAX * (S + 4) + (2 * S + 4 * KMAX + 6 * S) + 4 * KMAX + KMAX);
 }
 
 }  // namespace gnn

@@ -47,7 +47,7 @@ struct TrainPlan {
     bool big; int Kc; gnn::ConstCols cc;
     float *xc, *part_a, *part_y, *loss_part;
     // small graphs (kernels_train_small.hpp): the forward / backward iterations as one persistent launch each
-    bool small; int n_wg;
+    bool small, tiled; int n_wg;
     float *sm_cc, *sm_part, *sm_partW; unsigned long long *sm_bar;
     size_t bytes;
 };
@@ -159,12 +159,14 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.part_a = c.take<float>(p.big ? (size_t)BIG_AGG_BLOCKS * 2 * p.S : 0);
     p.part_y = c.take<float>(p.big ? (size_t)BIG_FWD_BLOCKS * 2 * p.S : 0);
     p.loss_part = c.take<float>(256);
-    p.n_wg = cdiv(p.N, 64);
+    p.tiled = ta.n_tiles > 0 && ta.tile_node_begin != nullptr;
+    p.n_wg = p.tiled ? ta.n_tiles : cdiv(p.N, 64);
+    if (p.tiled && p.n_wg > 256) { p.tiled = false; p.n_wg = cdiv(p.N, 64); }
     p.small = !p.big && train_small_enabled() && ns.n_layers == 1 && ns.units[0] == p.S && (p.S == 16 || p.S == 32 || p.S == 64) && p.Kc <= 32 &&
               ns.activation[0] != GNN_ACT_SOFTMAX && p.K > 0 && p.agg_taped && p.n_wg <= (ws ? device_cus() : 256) && p.N < train_big_min_nodes();
     p.sm_cc = c.take<float>(p.small ? (size_t)p.N * p.S : 0);
     p.sm_part = c.take<float>(p.small ? (size_t)2 * p.n_wg * (3 * p.S + 32 + 4 * p.S) : 0);
-    p.sm_partW = c.take<float>(p.small ? (size_t)p.n_wg * p.in_s * p.S : 0);
+    p.sm_partW = c.take<float>(p.small ? (size_t)p.n_wg * (p.in_s + 1) * p.S : 0);
     p.sm_bar = c.take<unsigned long long>(p.small ? 4 : 0);
     p.cs.m = &ns; p.cs.g = &ta.grad_state; p.co.m = &no; p.co.g = &ta.grad_output;
     p.bytes = (c.off + 255) & ~(size_t)255;
@@ -446,35 +448,47 @@ gnn::ConstSegs const_segs_of(const gnn_loop_args_t &a, const TrainPlan &p) {
     return cs;
 }
 
-template <int SQ>
-int launch_train_small_fwd_sq(const gnn::TrainSmallFwd &fa, int n_wg, bool has_w, hipStream_t st) {
-    const size_t lds = std::max(gnn::train_small_fwd_lds<SQ>(), gnn::TS_LDS);
-    if (has_w) {
-        static bool once = false;
-        if (!once) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gnn::k_train_small_fwd<SQ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-        gnn::k_train_small_fwd<SQ, true><<<n_wg, gnn::TS_NT, lds, st>>>(fa);
-    } else {
-        static bool once = false;
-        if (!once) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gnn::k_train_small_fwd<SQ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-        gnn::k_train_small_fwd<SQ, false><<<n_wg, gnn::TS_NT, lds, st>>>(fa);
+template <typename Kern, typename Args>
+int launch_persistent(Kern kern, const Args &args, const gnn::TileTab &tt, int n_wg, size_t lds, hipStream_t st) {
+    lds = std::max(lds, gnn::TS_LDS);
+    static std::vector<const void *> allowed;          // kernels whose dynamic-LDS limit has been raised
+    const void *fn = reinterpret_cast<const void *>(kern);
+    if (std::find(allowed.begin(), allowed.end(), fn) == allowed.end()) {
+        HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      // (the same for every launch of one kernel)
+        allowed.push_back(fn);
     }
+    kern<<<n_wg, gnn::TS_NT, lds, st>>>(args, tt);
     LAUNCH_OK();
     return 0;
 }
 
 template <int SQ>
-int launch_train_small_bwd_sq(const gnn::TrainSmallBwd &ba, int n_wg, bool has_w, hipStream_t st) {
-    const size_t lds = std::max(gnn::train_small_bwd_lds<SQ>(), gnn::TS_LDS);
-    if (has_w) {
-        static bool once = false;
-        if (!once) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gnn::k_train_small_bwd<SQ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-        gnn::k_train_small_bwd<SQ, true><<<n_wg, gnn::TS_NT, lds, st>>>(ba);
-    } else {
-        static bool once = false;
-        if (!once) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gnn::k_train_small_bwd<SQ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-        gnn::k_train_small_bwd<SQ, false><<<n_wg, gnn::TS_NT, lds, st>>>(ba);
-    }
-    LAUNCH_OK();
+int launch_train_small_fwd_sq(const gnn::TrainSmallFwd &fa, const gnn::TileTab &tt, int n_wg, bool has_w, hipStream_t st) {
+    const size_t lds = gnn::train_small_fwd_lds<SQ>();
+    if (tt.n > 0) return has_w ? launch_persistent(&gnn::k_train_small_fwd<SQ, true, true>, fa, tt, n_wg, lds, st)
+                               : launch_persistent(&gnn::k_train_small_fwd<SQ, false, true>, fa, tt, n_wg, lds, st);
+    return has_w ? launch_persistent(&gnn::k_train_small_fwd<SQ, true, false>, fa, tt, n_wg, lds, st)
+                 : launch_persistent(&gnn::k_train_small_fwd<SQ, false, false>, fa, tt, n_wg, lds, st);
+}
+
+template <int SQ>
+int launch_train_small_bwd_sq(const gnn::TrainSmallBwd &ba, const gnn::TileTab &tt, int n_wg, bool has_w, hipStream_t st) {
+    const size_t lds = gnn::train_small_bwd_lds<SQ>(tt.n > 0);
+    if (tt.n > 0) return has_w ? launch_persistent(&gnn::k_train_small_bwd<SQ, true, true>, ba, tt, n_wg, lds, st)
+                               : launch_persistent(&gnn::k_train_small_bwd<SQ, false, true>, ba, tt, n_wg, lds, st);
+    return has_w ? launch_persistent(&gnn::k_train_small_bwd<SQ, true, false>, ba, tt, n_wg, lds, st)
+                 : launch_persistent(&gnn::k_train_small_bwd<SQ, false, false>, ba, tt, n_wg, lds, st);
+}
+
+// the caller's tiles (HOST array), checked: ascending, <= 64 nodes each, covering [0, N)
+int tile_table(const gnn_train_args_t &ta, const TrainPlan &p, gnn::TileTab &tt) {
+    memset(&tt, 0, sizeof(tt));
+    if (!p.tiled) return 0;
+    tt.n = ta.n_tiles;
+    for (int b = 0; b <= tt.n; ++b) tt.begin[b] = ta.tile_node_begin[b];
+    if (tt.begin[0] != 0 || tt.begin[tt.n] != p.N) return fail("tile_node_begin must run from 0 to n_nodes");
+    for (int b = 0; b < tt.n; ++b)
+        if (tt.begin[b + 1] <= tt.begin[b] || tt.begin[b + 1] - tt.begin[b] > 64) return fail("tile %d has %d nodes (1 .. 64 allowed)", b, tt.begin[b + 1] - tt.begin[b]);
     return 0;
 }
 
@@ -590,6 +604,8 @@ int gnn_train_step(const gnn_train_args_t *args) {
             LAUNCH_OK();
         }
     }
+    gnn::TileTab tiles;
+    TRY(tile_table(ta, p, tiles));
     if (p.small) {
         // Small graphs (kernels_train_small.hpp): all K gated iterations in one persistent launch, one workgroup per 64-node tile
         const gnn::ConstSegs cs = const_segs_of(a, p);
@@ -603,12 +619,12 @@ int gnn_train_step(const gnn_train_args_t *args) {
         fa.rowptr = a.adjacency.rowptr; fa.src = a.adjacency.src; fa.w = a.adjacency.w; fa.row_scale = a.adjacency.row_scale;
         fa.states = p.states; fa.agg = p.agg; fa.stats = p.stats_s; fa.in_s = p.in_s; fa.off_agg = p.off_agg;
         fa.W = ns.kernel[0]; fa.gamma = bn_s ? ns.bn_gamma : nullptr; fa.beta = ns.bn_beta; fa.eps = ns.bn_eps; fa.act = ns.activation[0];
-        fa.Cc = p.sm_cc; fa.thr = a.state_threshold; fa.no_exit = 0; fa.flag0 = p.flags;
-        fa.bar = p.sm_bar; fa.part = p.sm_part; fa.k_out = p.k_dev; fa.err = p.flags + p.K + 4;
+        fa.Cc = p.sm_cc; fa.thr = a.state_threshold; fa.flag0 = p.flags;
+        fa.bar = p.sm_bar; fa.part = p.sm_part; fa.k_out = p.k_dev;
         switch (p.S) {
-            case 16: TRY(launch_train_small_fwd_sq<1>(fa, p.n_wg, a.adjacency.w != nullptr, st)); break;
-            case 32: TRY(launch_train_small_fwd_sq<2>(fa, p.n_wg, a.adjacency.w != nullptr, st)); break;
-            default: TRY(launch_train_small_fwd_sq<4>(fa, p.n_wg, a.adjacency.w != nullptr, st)); break;
+            case 16: TRY(launch_train_small_fwd_sq<1>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st)); break;
+            case 32: TRY(launch_train_small_fwd_sq<2>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st)); break;
+            default: TRY(launch_train_small_fwd_sq<4>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st)); break;
         }
     }
     for (int t = 0; t < p.K && !p.big && !p.small; ++t) {
@@ -635,13 +651,14 @@ int gnn_train_step(const gnn_train_args_t *args) {
         TRY(forward_layers(ns, segs, n, p.N, W0, b0, hs, gate, st, &pf, bn_on_load));
         if (!pf.fused) TRY(launch_converge(gate, s_n, s_t, p.N, p.S, p.S, p.S, a.state_threshold, p.flags + t + 1, p.k_dev, (float)(t + 1), st));
     }
-    float k_f = 0.0f;
-    HIP_OK(hipMemcpyAsync(&k_f, p.k_dev, sizeof(float), hipMemcpyDeviceToHost, st));
+    float k_f2[2] = {0.0f, 0.0f};
+    HIP_OK(hipMemcpyAsync(k_f2, p.k_dev, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));                                  // the one host synchronisation of the step
-    const int k = (int)k_f;
+    const int k = (int)k_f2[0];
     *ta.k_host = k;
-    if (k < 0 || k > p.K) return fail(p.small ? "iteration count %d out of range (a workgroup of the persistent kernel never arrived: not resident?)"
-                                              : "iteration count %d out of range", k);
+    if (k_f2[1] == 1.0f) return fail("tile_node_begin: an arc of `adjacency` leaves its tile");
+    if (k_f2[1] != 0.0f) return fail("a workgroup of the persistent training kernel never arrived at a grid barrier (not resident?)");
+    if (k < 0 || k > p.K) return fail("iteration count %d out of range", k);
     const float *state_k = p.states + (size_t)k * NS;
     HIP_OK(hipMemcpyAsync(ta.state, state_k, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
     if (bn_s && k > 0) {
@@ -731,15 +748,15 @@ int gnn_train_step(const gnn_train_args_t *args) {
         ba.cs = const_segs_of(a, p);
         ba.W = ns.kernel[0]; ba.gamma = bn_s ? ns.bn_gamma : nullptr; ba.beta = ns.bn_beta; ba.eps = ns.bn_eps; ba.act = ns.activation[0];
         ba.G0 = p.G_state; ba.dxa = p.dx_s_all; ba.bar = p.sm_bar + 2; ba.part = p.sm_part; ba.partW = p.sm_partW;
-        ba.db = ta.grad_state.dbias[0]; ba.dgamma = ta.grad_state.dgamma; ba.dbeta = ta.grad_state.dbeta;
-        ba.inv_n = 1.0f / (float)p.N; ba.err = p.flags + p.K + 5;
+        ba.dgamma = ta.grad_state.dgamma; ba.dbeta = ta.grad_state.dbeta;
+        ba.inv_n = 1.0f / (float)p.N; ba.err = p.k_dev;
         switch (p.S) {
-            case 16: TRY(launch_train_small_bwd_sq<1>(ba, p.n_wg, ba.w_s != nullptr, st)); break;
-            case 32: TRY(launch_train_small_bwd_sq<2>(ba, p.n_wg, ba.w_s != nullptr, st)); break;
-            default: TRY(launch_train_small_bwd_sq<4>(ba, p.n_wg, ba.w_s != nullptr, st)); break;
+            case 16: TRY(launch_train_small_bwd_sq<1>(ba, tiles, p.n_wg, ba.w_s != nullptr, st)); break;
+            case 32: TRY(launch_train_small_bwd_sq<2>(ba, tiles, p.n_wg, ba.w_s != nullptr, st)); break;
+            default: TRY(launch_train_small_bwd_sq<4>(ba, tiles, p.n_wg, ba.w_s != nullptr, st)); break;
         }
-        const int n = p.in_s * p.S;
-        gnn::k_reduce_partials<<<cdiv(n, 64), 256, 0, st>>>(p.sm_partW, p.n_wg, n, ta.grad_state.dkernel[0], 0, 1.0f, n, nullptr);
+        const int n = (p.in_s + 1) * p.S;              // every workgroup's [kernel | bias] share, summed in workgroup order
+        gnn::k_reduce_partials<<<cdiv(n, 64), 256, 0, st>>>(p.sm_partW, p.n_wg, n, ta.grad_state.dkernel[0], 0, 1.0f, p.in_s * p.S, ta.grad_state.dbias[0]);
         LAUNCH_OK();
     }
     for (int t = k - 1; t >= 0 && !p.small; --t) {

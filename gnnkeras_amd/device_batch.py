@@ -279,6 +279,8 @@ class DeviceDataset:
             adjacency = _LazySparse.make((Nn, Nn), dict(csr, src=adj_src[e0:e1], n_src=Nn), dev,
                                          endpoints=(asrc[e0:e1], adst[e0:e1]) if self.focus == 'a' else None, by_source=adjacency_by_source)
             arcnode = _LazySparse.make((Ee, Nn), dict(csr, src=an_src[e0:e1], n_src=Ee), dev, by_source=arcnode_by_source)
+            g0_ = int(first[b])
+            adjacency._blocks = np.concatenate([[0], np.cumsum(n[g0_:g0_ + B])]).astype(np.int64)      # one diagonal block per graph
             if self.focus == 'g':
                 g0 = int(first[b])
                 gn_b = torch.from_numpy(n[g0:g0 + B]).to(dev)

@@ -218,6 +218,39 @@ class SparseMatrix:
     def copy(self):
         return SparseMatrix(self.indices.copy(), self.values.copy(), self.dense_shape, reorder=False)
 
+    # diagonal blocks ------------------------------------------------------------------------------------------------
+    def block_starts(self):
+        """Rows at which a square matrix can be cut into diagonal blocks (no entry joins rows on different sides of a cut),
+        as int64 [n_blocks + 1] from 0 to n: the graphs of a merged batch (reference graph_class.py:386-413) and whatever
+        else happens to be disconnected AND contiguous.  From the host COO; a device-only matrix knows its blocks only when
+        its assembler recorded them (`device_batch.py`), else None.  Cached."""
+        b = getattr(self, '_blocks', None)
+        if b is None:
+            if self._indices is None or self.dense_shape[0] != self.dense_shape[1]: return None
+            n = self.dense_shape[0]
+            lo, hi = self._indices.min(axis=1), self._indices.max(axis=1)
+            # cut c (between rows c - 1 and c) is crossed by an entry when lo < c <= hi
+            crossed = np.cumsum(np.bincount(lo + 1, minlength=n + 2)[:n + 1] - np.bincount(hi + 1, minlength=n + 2)[:n + 1])
+            b = self._blocks = np.append(np.flatnonzero(crossed[:n] == 0), n).astype(np.int64)
+        return b
+
+    def tiles(self, limit: int = 64):
+        """Consecutive diagonal blocks packed greedily into tiles of at most `limit` rows: int32 [n_tiles + 1], or None when the
+        blocks are unknown or one of them is larger than `limit`.  Cached per limit."""
+        cache = self.__dict__.setdefault('_tiles', {})
+        if limit not in cache:
+            b = self.block_starts()
+            t = None
+            if b is not None and len(b) > 1 and int(np.diff(b).max()) <= limit:
+                cuts, start = [0], 0
+                ends = b[1:].tolist()
+                for i, e in enumerate(ends):
+                    if e - start > limit: start = ends[i - 1]; cuts.append(start)
+                cuts.append(ends[-1])
+                t = np.asarray(cuts, dtype=np.int32)
+            cache[limit] = t
+        return cache[limit]
+
     # by-destination CSR ---------------------------------------------------------------------------------------------
     def csr(self, uniform_rows: bool = True) -> CSRByDestination:
         if self._csr is None or self._csr[0] != uniform_rows:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 4
+#define GNN_ABI_VERSION 5
 
 /* Keras activation names accepted by the reference MLP builder (GNN/Models/MLP.py:16). */
 enum gnn_activation {
@@ -377,6 +377,15 @@ typedef struct gnn_train_args {
     float *loss;                               /* OUT [1] device scalar                                               */
     int32_t *k_host;                           /* OUT host int: iterations executed                                   */
     void *tape; size_t tape_bytes;             /* >= gnn_train_workspace_bytes(args), 256-byte aligned                */
+    /* optional (ABI 5): the batch as diagonal blocks.  A merge of small graphs (reference graph_class.py:386-413) has block-
+     * diagonal operators; the caller may hand over TILES of at most 64 consecutive nodes cut at graph boundaries, so that no arc
+     * of `adjacency` joins two tiles: tile b = nodes [tile_node_begin[b], tile_node_begin[b + 1]).  The small-graph training
+     * kernels then keep a tile's state in the LDS of one CU for the whole loop and exchange only the BatchNormalization
+     * statistics and the loop condition between tiles.  Same results as without tiles (n_tiles == 0).  An arc that leaves its
+     * tile is an error (the call fails).  Ignored when the persistent kernels do not apply (wide / deep state networks, more
+     * tiles than CUs, large graphs). */
+    const int32_t *tile_node_begin;            /* HOST array [n_tiles + 1], ascending, [0] = 0, [n_tiles] = n_nodes  */
+    int32_t n_tiles;
 } gnn_train_args_t;
 size_t gnn_train_workspace_bytes(const gnn_train_args_t *args);
 int gnn_train_step(const gnn_train_args_t *args);

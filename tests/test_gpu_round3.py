@@ -412,14 +412,20 @@ def test_small_graph_training_on_the_large_graph_kernels_in_a_child_process():
     ('g', 32, True, 'average', 60, 0.0), ('g', 64, True, 'average', 188, 0.0), ('n', 16, False, 'sum', 40, 0.0),
     ('a', 32, True, 'normalized', 24, 0.0), ('n', 64, False, 'average', 7, 0.0), ('g', 32, False, 'average', 50, -1.0),
     ('n', 32, True, 'sum', 1, 0.0), ('g', 16, True, 'average', 100, -1.0)])
-def test_small_graph_training_persistent_kernels_match_autograd(mutag_graphs, focus, d, bn, mode, n_graphs, thr):
+@pytest.mark.parametrize('tiled', [True, False])
+def test_small_graph_training_persistent_kernels_match_autograd(mutag_graphs, focus, d, bn, mode, n_graphs, thr, tiled, monkeypatch):
     """A merged MUTAG batch (18 .. 3 400 nodes: 1 .. 54 workgroups, the last tile ragged) through `gnn_train_step`: state widths
-    16 / 32 / 64, with and without BatchNormalization (two / one grid barriers per forward iteration), per-arc weights
-    ('normalized') and per-row scales ('average'), early exit: k, loss, predictions, every gradient and the moving statistics
-    against torch autograd in float64 - and against the Python building-block orchestration, which keeps the general kernels."""
+    16 / 32 / 64, with and without BatchNormalization, per-arc weights ('normalized') and per-row scales ('average'), early exit:
+    k, loss, predictions, every gradient and the moving statistics against torch autograd in float64 - and against the Python
+    building-block orchestration, which keeps the general kernels.  `tiled`: the graphs of the batch packed into tiles of <= 64
+    nodes (state in LDS, one barrier per iteration) or tiles of 64 consecutive nodes whatever the graphs (rows exchanged through
+    memory, two barriers)."""
     from test_gpu_training import nets, check_step, refocus, oracle_step, CLS
+    from gnnkeras_amd.Models.training import LoopTrainer
+    monkeypatch.setattr(LoopTrainer, 'use_tiles', tiled)
     rng = np.random.default_rng(100 + d + n_graphs)
-    gl = refocus([g.copy() for g in mutag_graphs[:n_graphs]], focus, rng)
+    pool = [g for g in mutag_graphs if g.nodes.shape[0] <= 64] if tiled else mutag_graphs      # (the data set has graphs of up to 417 nodes)
+    gl = refocus([g.copy() for g in pool[:n_graphs]], focus, rng)
     seq = MultiGraphSequencer(gl, focus, mode, n_graphs, shuffle=False)
     x, y, sw = seq[0]
     contractive = thr < 0
@@ -434,6 +440,30 @@ def test_small_graph_training_persistent_kernels_match_autograd(mutag_graphs, fo
         assert 1 < k < K, f'no threshold with an early exit found: {seen}'
     model = CLS[focus](ns, no, d, K, thr)
     res, want = check_step(model, x, y, sw, s0, avg=(n_graphs % 2 == 0))
+    tiles = x[5].matrix.tiles(64) if hasattr(x[5], 'matrix') else None
+    if tiled: assert tiles is not None and tiles[-1] == x[0].shape[0] and int(np.diff(tiles).max()) <= 64
+
+
+def test_tiles_with_an_arc_that_leaves_its_tile_fail_loudly(mutag_graphs):
+    """`tile_node_begin` is a promise (no arc joins two tiles): the forward kernel checks every arc it walks and the call fails."""
+    from test_gpu_training import nets
+    from gnnkeras_amd.Models.training import LoopTrainer
+    from gnnkeras_amd.Models.training import SGD
+    seq = MultiGraphSequencer([g for g in mutag_graphs if g.nodes.shape[0] <= 64][:20], 'g', 'average', 20, shuffle=False)
+    x, y, sw = seq[0]
+    ns, no = nets('g', 32, True)
+    model = GNNgraphBased(ns, no, 32, 4, 0.0)
+    model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+    adj = x[5].matrix
+    good = adj.tiles(64)
+    assert good is not None
+    adj.__dict__['_tiles'][64] = np.asarray([0] + [int(t) + 1 for t in good[1:-1]] + [int(good[-1])], dtype=np.int32)     # cuts moved INTO graphs
+    try:
+        with pytest.raises(RuntimeError, match='leaves its tile'):
+            LoopTrainer(model).train_step(x, y, sw, apply=False, seed=1)
+    finally:
+        adj.__dict__['_tiles'][64] = good
+    LoopTrainer(model).train_step(x, y, sw, apply=False, seed=1)
 
 
 def test_small_graph_training_with_the_persistent_kernels_switched_off_in_a_child_process():

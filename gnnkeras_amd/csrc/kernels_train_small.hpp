@@ -35,6 +35,18 @@
 
 namespace gnn {
 
+#ifdef GNN_TS_TIMELINE
+// phase times of workgroup 0 (wall_clock64 ticks of 10 ns, summed over the iterations): [0] forward, [1] backward; scripts/ts_timeline.py
+__device__ unsigned long long g_ts_phase[2][16];
+#define TS_CLOCK() long long ts_last = wall_clock64(); unsigned long long ts_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define TS_STAMP(i) do { const long long now = wall_clock64(); ts_acc[i] += (unsigned long long)(now - ts_last); ts_last = now; } while (0)
+#define TS_WRITE(w) do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 10; ++i_) g_ts_phase[w][i_] = ts_acc[i_]; } while (0)
+#else
+#define TS_CLOCK() do { } while (0)
+#define TS_STAMP(i) do { } while (0)
+#define TS_WRITE(w) do { } while (0)
+#endif
+
 constexpr int TS_NT = 256;               // threads per workgroup: 4 waves, wave w owns rows 16 w .. 16 w + 15 of the 64-node tile
 constexpr size_t TS_LDS = 96 * 1024;     // > half of a CU's LDS: one workgroup per CU
 
@@ -195,23 +207,18 @@ struct TileCsr {
     }
 };
 
-// partial slots of the other workgroups: `n` floats per workgroup, summed in workgroup order with 8 loads in flight (double accumulator)
+// partial slots of the other workgroups: `n` floats per workgroup, summed in workgroup order with 16 loads in flight (double accumulator)
 __device__ __forceinline__ double sum_partials(const float *part, unsigned n_wg, int n, int i) {
     const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(part);
     double t = 0.0;
-    unsigned wg = 0;
-    for (; wg + 8 <= n_wg; wg += 8) {
-        float v[8];
+    for (unsigned wg = 0; wg < n_wg; wg += 16) {
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_p, (int)(((wg + u) * n + i) * 4), 0, 16));
+        for (int u = 0; u < 16; ++u)          // (absent slots read 0)
+            v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_p, wg + u < n_wg ? (int)(((wg + u) * n + i) * 4) : (int)BUF_OFF, 0, 16));
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t += (double)v[u];
+        for (int u = 0; u < 16; ++u) t += (double)v[u];
     }
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_p, wg + u < n_wg ? (int)(((wg + u) * n + i) * 4) : (int)BUF_OFF, 0, 16));
-#pragma unroll
-    for (int u = 0; u < 8; ++u) t += (double)v[u];          // (absent slots read 0)
     return t;
 }
 
@@ -282,6 +289,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
     __syncthreads();
 
     int k_done = 0, any_prev = 0;
+    TS_CLOCK();
     for (int it = 0; run && it < a.K; ++it) {
         const __amdgpu_buffer_rsrc_t r_in = buf_rsrc(a.states + (size_t)it * NS), r_out = buf_rsrc(a.states + (size_t)(it + 1) * NS);
         float *agg_t = a.agg + (size_t)it * NS;
@@ -303,6 +311,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
             }
         }
         __syncthreads();
+        TS_STAMP(0);
         if (bn) {
             // ---- B. column sums / squares of [state | agg] over the tile's rows -> partial slot ---------------------------------------------
             const int col = tid & (2 * S - 1), part_i = tid / (2 * S);          // 256 / (2 S) row groups (S = 64: 2, 32: 4, 16: 8)
@@ -326,12 +335,14 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), r_p, tid * 4, 0, 16);
             }
         }
+        TS_STAMP(1);
         if (LOCAL) {
             if (it > 0 || bn) {           // one barrier: the statistics partials, and whether any node moved in iteration it - 1
                 const bool moving = grid_barrier(gb, any_prev, &cont);
                 if (it > 0 && !moving) break;
             }
         } else if (bn) grid_barrier(gb, 0, &cont);
+        TS_STAMP(2);
         if (bn) {
             if (tid < 4 * S)              // (sum | square, column): partials in workgroup order
                 red[tid] = (float)(sum_partials(a.part + (size_t)(it & 1) * gridDim.x * 4 * S, gridDim.x, 4 * S, tid) / (double)a.N);
@@ -346,6 +357,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
             }
             __syncthreads();
         }
+        TS_STAMP(3);
         // ---- C. (a x + c) . W (+ constant part) on the matrix cores, operands swapped: lane (c, g) gets columns 16 ct + 4 g .. of row c -----
         f32x4 acc[SQ];
 #pragma unroll
@@ -386,9 +398,12 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
         n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64);
         const int any = (oin && sqrtf(d2) > a.thr * sqrtf(n2)) ? 1 : 0;
         k_done = it + 1;
+        TS_STAMP(4);
         if (LOCAL) { any_prev = any; __syncthreads(); }
         else if (!grid_barrier(gb, any, &cont)) break;
+        TS_STAMP(5);
     }
+    TS_WRITE(0);
     if (LOCAL && __syncthreads_or(csr.bad) && tid == 0) a.k_out[1] = 1.0f;
     if (tid == 0 && blockIdx.x == 0) a.k_out[0] = (float)k_done;
     if (tid == 0 && gb.timed_out) a.k_out[1] = 2.0f;
@@ -497,6 +512,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
     const __amdgpu_buffer_rsrc_t r_dxa = buf_rsrc(a.dxa);
     __syncthreads();
 
+    TS_CLOCK();
     for (int t = a.k - 1; t >= 0; --t) {
         const float *s_t = a.states + (size_t)t * NS, *s_n = a.states + (size_t)(t + 1) * NS, *agg_t = a.agg + (size_t)t * NS;
         const float *stats = a.stats + (size_t)t * 2 * a.in_s;
@@ -532,6 +548,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
             a_s[tid] = ak; c_s[tid] = ck;
         }
         __syncthreads();
+        TS_STAMP(0);
         // ---- B. P_wg = X^T dZ on the matrix cores (kept local), q and S2 partials -----------------------------------------------------------
         f32x4 P[TPW];
 #pragma unroll
@@ -547,6 +564,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
             }
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        TS_STAMP(1);
         {   // q of the tile: column sums of dZ, 256 / S row groups
             constexpr int NG = TS_NT / S, RPG = 64 / NG;
             const int col = tid % S, gq = tid / S;
@@ -588,7 +606,9 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                 const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + ((size_t)(t & 1) * gridDim.x + blockIdx.x) * (S + KMAX));
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r_p, tid * 4, 0, 16);
             }
+            TS_STAMP(2);
             grid_barrier(gb, 0, &cont);
+            TS_STAMP(3);
             if (tid < S + KMAX) {
                 const float tt2 = (float)sum_partials(a.part + (size_t)(t & 1) * gridDim.x * (S + KMAX), gridDim.x, S + KMAX, tid);
                 if (tid < S) q_s[tid] = tt2; else S2_s[tid - S] = tt2;
@@ -615,6 +635,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
             }
             __syncthreads();
         }
+        TS_STAMP(4);
         // ---- C. this workgroup's share of the kernel gradient: a (.) P_wg (+ c q^T once, in workgroup 0: q is the total) ---------------------------
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -630,6 +651,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                 }
             }
         }
+        TS_STAMP(5);
         // ---- D. dx = BN-gradient(dZ . W^T) on the matrix cores (operands swapped: row-major); state half -> Gs, agg half -> Da / memory ----
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -667,7 +689,9 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                 }
             }
         }
+        TS_STAMP(6);
         if (LOCAL) __syncthreads(); else grid_barrier(gb, 0, &cont);
+        TS_STAMP(7);
         // ---- E. G = dx_state + Adj . dx_agg: gather by source -----------------------------------------------------------------------------------
         {
             f32x4 acc[NPASS];
@@ -682,7 +706,9 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
             }
         }
         __syncthreads();
+        TS_STAMP(8);
     }
+    TS_WRITE(1);
     // ---- the kernel- and bias-gradient share of this workgroup; BatchNorm gradients from workgroup 0 ----------------------------------------------
     float *pw = a.partW + (size_t)blockIdx.x * ((size_t)a.in_s * S + S);
 #pragma unroll

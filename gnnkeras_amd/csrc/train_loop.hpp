@@ -823,4 +823,11 @@ int gnn_train_step(const gnn_train_args_t *args) {
     return 0;
 }
 
+#ifdef GNN_TS_TIMELINE
+// phase times of workgroup 0 in the last persistent training launches: out[2][16] (forward, backward), ticks of 10 ns
+int gnn_ts_phase_times(unsigned long long *out32) {
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(gnn::g_ts_phase), 2 * 16 * 8) == hipSuccess ? 0 : 1;
+}
+#endif
+
 }  // extern "C"

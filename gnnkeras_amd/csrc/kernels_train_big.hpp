@@ -274,6 +274,7 @@ inline size_t train_fwd_lds() { return (size_t)(16 * (2 * SQ + 2) * 16 * NCT + 1
 struct TrainBwdArgs {
     int M;
     const float *dZ; int ldz;             // [M, H], H = 16 HQ
+    const float *Y; int act;              // optional: `dZ` holds G = d loss / d output and dZ = G (.) act'(Y) is formed as the rows arrive
     const float *W; int ldw;              // first-layer kernel [in_dim][ldw] (NOT folded: BatchNorm enters through the coefficients)
     int H, S, wrow_state, wrow_agg;
     const float *state; int ld_state; const float *agg; int ld_agg;   // the layer's inputs x (for xhat)
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_bwd_dx(TrainBwdArgs 
         coef[j] = Ac; coef[HP + j] = Cc; coef[2 * HP + j] = Bc;
     }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t r_z = buf_rsrc(a.dZ), r_s = buf_rsrc(a.state), r_a = buf_rsrc(a.agg), r_o = buf_rsrc(a.dx),
+    const __amdgpu_buffer_rsrc_t r_z = buf_rsrc(a.dZ), r_y = buf_rsrc(a.Y), r_s = buf_rsrc(a.state), r_a = buf_rsrc(a.agg), r_o = buf_rsrc(a.dx),
                                  r_rs = buf_rsrc(a.agg_row_scale);
     const int n_tiles = (a.M + 15) >> 4;
 #pragma unroll 1
@@ -318,9 +319,13 @@ __global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_bwd_dx(TrainBwdArgs 
         const bool in = row < a.M;
         // every load of the tile is issued here: the dZ row and - for the BatchNorm term - the layer's inputs x = [state | agg] of the
         // same row, all as 16-byte chunks (columns 16 q + 4 g ..): the transposed product (see k_train_fwd) returns dy in that layout
-        f32x4 A[HQ], X[NCT];
+        f32x4 A[HQ], X[NCT], Yv[HQ];
 #pragma unroll
         for (int q = 0; q < HQ; ++q) A[q] = buf_ld_f32x4(r_z, in ? ((unsigned)row * (unsigned)a.ldz + 16u * q + 4u * g) * 4u : BUF_OFF);
+        if (a.Y) {
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) Yv[q] = buf_ld_f32x4(r_y, in ? ((unsigned)row * (unsigned)a.ldz + 16u * q + 4u * g) * 4u : BUF_OFF);
+        }
         if (a.gamma) {
 #pragma unroll
             for (int q = 0; q < SQ; ++q) {
@@ -329,6 +334,12 @@ __global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_bwd_dx(TrainBwdArgs 
             }
         }
         const float rs = a.agg_row_scale ? buf_ld_f32(r_rs, in ? (unsigned)row * 4u : BUF_OFF) : 1.0f;
+        if (a.Y) {
+#pragma unroll
+            for (int q = 0; q < HQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) A[q][e] *= activate_grad_from_output(a.act, Yv[q][e]);
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                       // state half, then agg half (16 accumulator registers at a time)
             f32x4 acc[SQ];
@@ -367,6 +378,121 @@ __global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_bwd_dx(TrainBwdArgs 
 
 template <int HQ, int NCT>
 inline size_t train_bwd_lds() { return (size_t)(16 * HQ * 16 * NCT + 3 * 16 * NCT) * sizeof(float); }
+
+// ---- weight gradient of the first Dense at large M: P = X^T dZ on the matrix cores, straight from memory ------------------------------------
+// X = [state | agg | constants] (the virtual concatenation, never materialised), dZ = G (.) act'(Y) formed as the rows arrive.  The
+// contraction runs over ROWS: for v_mfma_f32_16x16x4_f32 lane (c, g) supplies A[c][g] and B[g][c], i.e. one element of row r0 + g of each
+// operand - so a lane loads the SQ consecutive floats  X[r0 + g][SQ c ..]  (a wave's load = four whole rows, contiguous) and uses value e
+// of the piece as the A operand of row tile e: tile row m is input column SQ m + e, a permutation of P's rows that costs nothing.  dZ
+// pieces serve as B operands the same way.  No LDS on the way in, every byte of every row is read exactly once; each wave keeps ALL
+// (2 SQ + 2) x SQ accumulator tiles (160 registers at S = 64) for its share of the rows, PD steps of loads in flight; the four waves' tiles
+// meet in LDS in wave order at the end and leave as one partial per workgroup in the layout of k_dense_grad_allk (k_reduce_partials /
+// k_first_layer_param_grads take it from there).  The constants line carries a 1 behind its Kc < 32 columns: its row of P is q = colsum(dZ).
+// 1 M rows, S = 64: k_dense_grad_allk 479 us + k_act_grad 127 us -> this kernel (profiles/r03_notes.txt).
+struct TrainWgradArgs {
+    int M, rows_per_wg;
+    const float *G, *Y; int act;          // [M, S] each
+    const float *state, *agg;             // [M, S]
+    const float *xc;                      // [M, 32] (k_pack_xc layout)
+    int K, wrow_state, wrow_agg, Kc; ConstCols cs;
+    float *part;                          // [gridDim.x][K * S + S]
+};
+
+template <int SQ> struct Piece { float v[SQ]; };
+template <int SQ> __device__ __forceinline__ Piece<SQ> ld_piece(__amdgpu_buffer_rsrc_t r, unsigned off);
+template <> __device__ __forceinline__ Piece<1> ld_piece<1>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    Piece<1> p; p.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0)); return p; }
+template <> __device__ __forceinline__ Piece<2> ld_piece<2>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    Piece<2> p; p.v[0] = __uint_as_float(t[0]); p.v[1] = __uint_as_float(t[1]); return p; }
+template <> __device__ __forceinline__ Piece<4> ld_piece<4>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    Piece<4> p; p.v[0] = __uint_as_float(t[0]); p.v[1] = __uint_as_float(t[1]); p.v[2] = __uint_as_float(t[2]); p.v[3] = __uint_as_float(t[3]); return p; }
+
+template <int SQ>
+__global__ void __launch_bounds__(256, 2) k_train_wgrad(TrainWgradArgs a) {
+    constexpr int S = 16 * SQ, RT = 2 * SQ + 2, KV = 2 * S + 32, PD = 3;
+    __shared__ float Ps[KV * S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int m_beg = blockIdx.x * a.rows_per_wg, m_end = min(a.M, m_beg + a.rows_per_wg);
+    const int n_steps = (max(m_end - m_beg, 0) + 15) >> 4;           // a workgroup step = 16 rows: 4 per wave
+    const __amdgpu_buffer_rsrc_t r_g = buf_rsrc(a.G), r_y = buf_rsrc(a.Y), r_s = buf_rsrc(a.state), r_a = buf_rsrc(a.agg), r_c = buf_rsrc(a.xc);
+    f32x4 acc[RT][SQ];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < SQ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    struct Step { Piece<SQ> xs, xa, gz, y; Piece<2> xc; };
+    Step buf[PD];
+    auto fetch = [&](Step &b, int s) {
+        const int row = m_beg + 16 * s + 4 * wave + g;
+        const bool ok = s < n_steps && row < m_end;
+        const unsigned off = ok ? ((unsigned)row * (unsigned)S + (unsigned)(SQ * c)) * 4u : BUF_OFF;
+        b.gz = ld_piece<SQ>(r_g, off); b.y = ld_piece<SQ>(r_y, off);
+        b.xs = ld_piece<SQ>(r_s, off); b.xa = ld_piece<SQ>(r_a, off);
+        b.xc = ld_piece<2>(r_c, ok ? ((unsigned)row * 32u + 2u * c) * 4u : BUF_OFF);
+    };
+#pragma unroll
+    for (int u = 0; u < PD; ++u) fetch(buf[u], u);
+#pragma unroll 1
+    for (int s0 = 0; s0 < n_steps; s0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            if (s0 + u < n_steps) {
+                Step &b = buf[u];
+                float dz[SQ];
+#pragma unroll
+                for (int j = 0; j < SQ; ++j) dz[j] = b.gz.v[j] * activate_grad_from_output(a.act, b.y.v[j]);
+#pragma unroll
+                for (int e = 0; e < SQ; ++e)
+#pragma unroll
+                    for (int j = 0; j < SQ; ++j) {
+                        acc[e][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.xs.v[e], dz[j], acc[e][j], 0, 0, 0);
+                        acc[SQ + e][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.xa.v[e], dz[j], acc[SQ + e][j], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int j = 0; j < SQ; ++j) acc[2 * SQ + e][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.xc.v[e], dz[j], acc[2 * SQ + e][j], 0, 0, 0);
+                fetch(b, s0 + u + PD);
+            }
+        }
+    }
+    TB_MFMA_DRAIN();
+    // acc[rt][j][i] = P[virtual column kv(rt, 4 g + i)][SQ c + j]; the waves add their tiles in wave order
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = 4 * g + i;
+                    const int kv = rt < SQ ? SQ * m + rt : rt < 2 * SQ ? S + SQ * m + (rt - SQ) : 2 * S + 2 * m + (rt - 2 * SQ);
+                    float *dst = Ps + kv * S + SQ * c;
+#pragma unroll
+                    for (int j = 0; j < SQ; ++j) dst[j] = w == 0 ? acc[rt][j][i] : dst[j] + acc[rt][j][i];
+                }
+        }
+        __syncthreads();
+    }
+    float *Pp = a.part + (size_t)blockIdx.x * ((size_t)a.K * S + S);
+    for (int i = tid; i < KV * S; i += 256) {
+        const int kv = i / S, h = i % S;
+        int wrow = -1;
+        if (kv < S) wrow = a.wrow_state + kv;
+        else if (kv < 2 * S) wrow = a.wrow_agg + (kv - S);
+        else {
+            int jj = kv - 2 * S, b0 = 0;
+#pragma unroll
+            for (int sg = 0; sg < 3; ++sg) { if (sg < a.cs.n && jj >= b0 && jj < b0 + a.cs.width[sg]) wrow = a.cs.wrow[sg] + (jj - b0); if (sg < a.cs.n) b0 += a.cs.width[sg]; }
+            if (jj == a.Kc) wrow = a.K;                              // the line's 1: q
+        }
+        if (wrow >= 0) Pp[(size_t)wrow * S + h] = Ps[i];
+    }
+}
 
 // sum of n floats times scale, any n: grid-stride partials in a fixed order, then one block (the loss of a million-row batch)
 __global__ void __launch_bounds__(256) k_sum_partials(const float *__restrict__ x, int n, float *__restrict__ part) {

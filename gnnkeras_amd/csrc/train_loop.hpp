@@ -45,7 +45,7 @@ struct TrainPlan {
     NetCtx cs, co;
     // large graphs (kernels_train_big.hpp): constant inputs packed 32 per node, statistics partials of the two producers
     bool big; int Kc; gnn::ConstCols cc;
-    float *xc, *part_a, *part_y, *loss_part;
+    float *xc, *part_a, *part_y, *loss_part, *part_w;
     // small graphs (kernels_train_small.hpp): the forward / backward iterations as one persistent launch each
     bool small, tiled; int n_wg;
     float *sm_cc, *sm_part, *sm_partW; unsigned long long *sm_bar;
@@ -58,7 +58,12 @@ inline int train_big_min_nodes() {
     if (v < 0) { const char *e = getenv("GNN_TRAIN_BIG_MIN_NODES"); v = e ? atoi(e) : 32768; }
     return v;
 }
-constexpr int BIG_AGG_BLOCKS = 4096, BIG_FWD_BLOCKS = 1024;
+constexpr int BIG_AGG_BLOCKS = 4096, BIG_FWD_BLOCKS = 1024, BIG_WGRAD_BLOCKS = 512;
+inline bool train_wgrad_enabled() {       // GNN_TRAIN_WGRAD=0: the round-2 weight-gradient kernels (k_act_grad + k_dense_grad_allk) at large M too
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_TRAIN_WGRAD"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
 // The persistent small-graph kernels need every workgroup resident: one 64-node tile per CU (GNN_TRAIN_SMALL=0 switches them off).
 inline bool train_small_enabled() {
     static int v = -1;
@@ -159,6 +164,7 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.part_a = c.take<float>(p.big ? (size_t)BIG_AGG_BLOCKS * 2 * p.S : 0);
     p.part_y = c.take<float>(p.big ? (size_t)BIG_FWD_BLOCKS * 2 * p.S : 0);
     p.loss_part = c.take<float>(256);
+    p.part_w = c.take<float>(p.big ? (size_t)BIG_WGRAD_BLOCKS * ((size_t)p.in_s * p.S + p.S) : 0);      // k_train_wgrad: one partial per workgroup
     p.tiled = ta.n_tiles > 0 && ta.tile_node_begin != nullptr;
     p.n_wg = p.tiled ? ta.n_tiles : cdiv(p.N, 64);
     if (p.tiled && p.n_wg > 256) { p.tiled = false; p.n_wg = cdiv(p.N, 64); }
@@ -777,11 +783,39 @@ int gnn_train_step(const gnn_train_args_t *args) {
         // 'average' / 'sum' / 'normalized' entries depend on the destination only (a.adjacency carries one scale per row): the large-
         // graph kernel scales the agg-half of a row's gradient once, and the transposed aggregate walks UNIT weights (no 4 bytes per arc)
         const bool unit_w = p.big && !a.adjacency.w;
+        const bool wgrad = p.big && p.Kc > 0 && p.Kc < 32 && train_wgrad_enabled();
         if (p.big) {
-            TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, nullptr, 0, p.part, st, p.off_agg));
+            if (wgrad) {
+                // P = X^T dZ and q on the matrix cores straight from the rows (dZ = G (.) act'(s_n) formed on the way), then the same
+                // reduction and parameter-gradient kernels as net_backward
+                gnn::TrainWgradArgs wa;
+                memset(&wa, 0, sizeof(wa));
+                const int n_wg = std::min(std::min(2 * device_cus(), BIG_WGRAD_BLOCKS), cdiv(p.N, 64));
+                wa.M = p.N; wa.rows_per_wg = cdiv(cdiv(p.N, n_wg), 16) * 16;
+                wa.G = p.G_state; wa.Y = s_n; wa.act = ns.activation[0];
+                wa.state = s_t; wa.agg = agg_t; wa.xc = p.xc;
+                wa.K = p.in_s; wa.wrow_state = 0; wa.wrow_agg = p.off_agg; wa.Kc = p.Kc; wa.cs = p.cc;
+                wa.part = p.part_w;
+                const int grid = cdiv(p.N, wa.rows_per_wg);
+                switch (p.S) {
+                    case 16: gnn::k_train_wgrad<1><<<grid, 256, 0, st>>>(wa); break;
+                    case 32: gnn::k_train_wgrad<2><<<grid, 256, 0, st>>>(wa); break;
+                    default: gnn::k_train_wgrad<4><<<grid, 256, 0, st>>>(wa); break;
+                }
+                LAUNCH_OK();
+                const int nP = p.in_s * p.S + p.S;
+                gnn::k_reduce_partials<<<cdiv(nP, 64), 256, 0, st>>>(p.part_w, grid, nP, p.cs.P, 0, 1.0f, p.in_s * p.S, p.cs.q);
+                LAUNCH_OK();
+                gnn::k_first_layer_param_grads<<<p.in_s, 64, 0, st>>>(
+                    p.cs.P, p.cs.q, ns.kernel[0], p.in_s, p.S, bn_s ? ns.bn_gamma : nullptr, ns.bn_beta, stats, stats ? stats + p.in_s : nullptr, ns.bn_eps,
+                    1.0f / (float)p.N, ta.grad_state.dkernel[0], ta.grad_state.dbias[0], ta.grad_state.dgamma, ta.grad_state.dbeta,
+                    bn_s ? p.cs.m1 : nullptr, bn_s ? p.cs.m2 : nullptr, t != k - 1 ? 1 : 0, 1);
+                LAUNCH_OK();
+            } else TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, nullptr, 0, p.part, st, p.off_agg));
             gnn::TrainBwdArgs ba;
             memset(&ba, 0, sizeof(ba));
-            ba.M = p.N; ba.dZ = p.G_state; ba.ldz = p.S;            // (one layer: the activation gradient ran in place)
+            ba.M = p.N; ba.dZ = p.G_state; ba.ldz = p.S;            // (net_backward: the activation gradient ran in place)
+            if (wgrad) { ba.Y = s_n; ba.act = ns.activation[0]; }   // (else G is untouched: dZ is formed as the rows arrive)
             ba.W = ns.kernel[0]; ba.ldw = p.H1s; ba.H = p.H1s; ba.S = p.S; ba.wrow_state = 0; ba.wrow_agg = p.off_agg;
             ba.state = s_t; ba.ld_state = p.S; ba.agg = agg_t; ba.ld_agg = p.S;
             if (bn_s) { ba.gamma = ns.bn_gamma; ba.mean = stats; ba.var = stats + p.in_s; ba.m1 = p.cs.m1; ba.m2 = p.cs.m2; ba.eps = ns.bn_eps; }

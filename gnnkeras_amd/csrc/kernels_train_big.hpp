@@ -84,6 +84,36 @@ k_aggregate_stats(const int *gate, int n_dst, const int *__restrict__ rowptr, co
     }
 }
 
+// One pass over a row-major matrix [M][4 LPR] (leading dimension ld): per-workgroup column sums and sums of squares in the partial layout
+// of k_aggregate_stats (the statistics of state_0 and of the packed constants line: two passes per segment before, 12 launches per step).
+template <int LPR>
+__global__ void __launch_bounds__(256)
+k_rows_stats(const int *gate, int M, const float *__restrict__ X, int ld, float *__restrict__ stat_part) {
+    if (gate_closed(gate)) return;
+    __shared__ f32x4 red[2][256];
+    const int l4 = threadIdx.x % LPR;
+    constexpr int groups = 256 / LPR;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int j = blockIdx.x * groups + threadIdx.x / LPR; j < M; j += gridDim.x * groups * 4) {       // four rows in flight
+        f32x4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = j + u * gridDim.x * groups;
+            x[u] = r < M ? *reinterpret_cast<const f32x4 *>(X + (size_t)r * ld + 4 * l4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1 += x[u]; s2 += x[u] * x[u]; }
+    }
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < 2 * LPR) {
+        const int which = threadIdx.x / LPR, c4 = threadIdx.x % LPR;
+        f32x4 t = red[which][c4];
+        for (int gq = 1; gq < groups; ++gq) t += red[which][gq * LPR + c4];
+        *reinterpret_cast<f32x4 *>(stat_part + (size_t)blockIdx.x * (8 * LPR) + which * (4 * LPR) + 4 * c4) = t;
+    }
+}
+
 // mean[c] = sum / M, var[c] = max(sumsq / M - mean^2, 0) from n_part partials of [2 F] (sums | squares).  One 256-thread workgroup
 // per column: thread i sums partials i, i + 256, .. in order, then a fixed LDS tree - deterministic.  (One-pass moments: the columns
 // are activations / their neighbour averages, |mean| and sigma of the same order, the tail in double; BatchNormalization adds

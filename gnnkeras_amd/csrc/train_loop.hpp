@@ -162,7 +162,7 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     }
     p.xc = c.take<float>(p.big && p.Kc > 0 ? (size_t)p.N * 32 : 0);
     p.part_a = c.take<float>(p.big ? (size_t)BIG_AGG_BLOCKS * 2 * p.S : 0);
-    p.part_y = c.take<float>(p.big ? (size_t)BIG_FWD_BLOCKS * 2 * p.S : 0);
+    p.part_y = c.take<float>(p.big ? (size_t)BIG_FWD_BLOCKS * 2 * std::max(p.S, 32) : 0);      // (also the one-pass statistics of the 32-wide constants line)
     p.loss_part = c.take<float>(256);
     p.part_w = c.take<float>(p.big ? (size_t)BIG_WGRAD_BLOCKS * ((size_t)p.in_s * p.S + p.S) : 0);      // k_train_wgrad: one partial per workgroup
     p.tiled = ta.n_tiles > 0 && ta.tile_node_begin != nullptr;
@@ -415,6 +415,20 @@ int launch_aggregate_stats(const int *gate, const gnn_csr_t &c, const float *X, 
     return 0;
 }
 
+// column statistics of a row-major [M][F] matrix (F = 16 / 32 / 64) in one pass; columns [c0, c0 + width) go to mean / var [dst0 ..)
+int rows_stats(const int *gate, const float *X, int ld, int F, int M, float *part, hipStream_t st, int *grid_out) {
+    const int lpr = F / 4, groups = 256 / lpr;
+    const int grid = std::max(1, std::min(cdiv(M, groups * 4), BIG_FWD_BLOCKS));
+    switch (lpr) {
+        case 4: gnn::k_rows_stats<4><<<grid, 256, 0, st>>>(gate, M, X, ld, part); break;
+        case 8: gnn::k_rows_stats<8><<<grid, 256, 0, st>>>(gate, M, X, ld, part); break;
+        default: gnn::k_rows_stats<16><<<grid, 256, 0, st>>>(gate, M, X, ld, part); break;
+    }
+    LAUNCH_OK();
+    *grid_out = grid;
+    return 0;
+}
+
 template <int SQ>
 int launch_train_fwd_sq(const gnn::TrainFwdArgs &fa, int grid, hipStream_t st) {
     gnn::k_train_fwd<SQ, SQ><<<grid, 64 * gnn::TB_WAVES, gnn::train_fwd_lds<SQ, SQ>(), st>>>(fa);
@@ -550,15 +564,6 @@ int gnn_train_step(const gnn_train_args_t *args) {
     if (a.state_dim > 0) HIP_OK(hipMemcpyAsync(p.states, a.state0, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
     else TRY(launch_copy2d(nullptr, a.nodes, a.ld_nodes, p.states, p.S, p.N, p.S, p.S, st));
     gnn::Seg segs[GNN_MAX_SEGS];
-    if (bn_s && p.K > 0) {
-        const int n = state_segs(a, p, 0, segs);
-        gnn::Seg cst[GNN_MAX_SEGS]; int nc = 0;
-        for (int s = 0; s < n; ++s) if (segs[s].ptr != p.states && segs[s].ptr != p.agg) cst[nc++] = segs[s];
-        HIP_OK(hipMemsetAsync(p.stats_tpl, 0, sizeof(float) * 2 * p.in_s, st));
-        TRY(colstats_segs(nullptr, cst, nc, p.N, p.stats_tpl, p.stats_tpl + p.in_s, p.part, st));
-        gnn::k_replicate<<<std::min(cdiv((long)2 * p.in_s * p.K, 256), 1024), 256, 0, st>>>(p.stats_tpl, 2 * p.in_s, p.K, p.stats_s);
-        LAUNCH_OK();
-    }
     if (p.big && p.Kc > 0) {      // the constant inputs of a node as one 128-byte line: [labels | aggregated labels | aggregated arc labels | 1 | 0 ..]
         gnn::PackSegs ps;
         memset(&ps, 0, sizeof(ps));
@@ -566,6 +571,25 @@ int gnn_train_step(const gnn_train_args_t *args) {
         for (int s = 0; s < n0; ++s)
             if (segs[s].ptr != p.states && segs[s].ptr != p.agg) { ps.ptr[ps.n] = segs[s].ptr; ps.ld[ps.n] = segs[s].ld; ps.width[ps.n] = segs[s].width; ps.wrow[ps.n] = segs[s].wrow; ++ps.n; }
         gnn::k_pack_xc<<<(int)std::min<long>(cdiv((long)p.N * 32, 256), 256 * 16), 256, 0, st>>>(p.N, nullptr, ps, p.xc);
+        LAUNCH_OK();
+    }
+    if (bn_s && p.K > 0) {
+        const int n = state_segs(a, p, 0, segs);
+        gnn::Seg cst[GNN_MAX_SEGS]; int nc = 0;
+        for (int s = 0; s < n; ++s) if (segs[s].ptr != p.states && segs[s].ptr != p.agg) cst[nc++] = segs[s];
+        HIP_OK(hipMemsetAsync(p.stats_tpl, 0, sizeof(float) * 2 * p.in_s, st));
+        if (p.big && p.Kc > 0) {  // one pass over the packed line; each segment's columns land at its BatchNorm columns
+            int grid = 0;
+            TRY(rows_stats(nullptr, p.xc, 32, 32, p.N, p.part_y, st, &grid));
+            int c0 = 0;
+            for (int s = 0; s < p.cc.n; ++s) {
+                gnn::k_stats_finish<<<p.cc.width[s], 256, 0, st>>>(nullptr, p.part_y + c0, grid, 32, 1.0f / (float)p.N, p.stats_tpl + p.cc.wrow[s],
+                                                                  p.stats_tpl + p.in_s + p.cc.wrow[s]);
+                LAUNCH_OK();
+                c0 += p.cc.width[s];
+            }
+        } else TRY(colstats_segs(nullptr, cst, nc, p.N, p.stats_tpl, p.stats_tpl + p.in_s, p.part, st));
+        gnn::k_replicate<<<std::min(cdiv((long)2 * p.in_s * p.K, 256), 1024), 256, 0, st>>>(p.stats_tpl, 2 * p.in_s, p.K, p.stats_s);
         LAUNCH_OK();
     }
     // ---- training-mode forward: gated iterations, tape = states + statistics + folded first layers ------------------------------
@@ -581,9 +605,11 @@ int gnn_train_step(const gnn_train_args_t *args) {
         float *stats = p.stats_s + (size_t)t * 2 * p.in_s;
         if (bn_s) {
             TRY(launch_aggregate_stats(gate, a.adjacency, s_t, p.S, agg_t, p.part_a, stats + p.off_agg, stats + p.in_s + p.off_agg, st));
-            if (t == 0) {
-                gnn::Seg s0{s_t, nullptr, p.S, p.S, 0};
-                TRY(colstats_segs(gate, &s0, 1, p.N, stats, stats + p.in_s, p.part, st));
+            if (t == 0) {          // (later iterations: k_train_fwd leaves the statistics of the state it writes)
+                int grid = 0;
+                TRY(rows_stats(gate, s_t, p.S, p.S, p.N, p.part_y, st, &grid));
+                gnn::k_stats_finish<<<p.S, 256, 0, st>>>(gate, p.part_y, grid, p.S, 1.0f / (float)p.N, stats, stats + p.in_s);
+                LAUNCH_OK();
             }
         } else TRY(launch_aggregate(gate, a.adjacency, s_t, p.S, p.S, agg_t, p.S, st));
         const float *W0 = ns.kernel[0], *b0 = ns.bias[0];

@@ -254,6 +254,15 @@ def _lowbias32(h):
     return h
 
 
+def _eye(ng, K, p):
+    """Identity [K, K] on the primitives' device, cached on the network's gradient holder (dropout_pos = 0)."""
+    e = getattr(ng, '_eye', None)
+    if e is None or e.shape[0] != K:
+        e = ng._eye = p.zeros(K, K)
+        e.fill_diagonal_(1.0)
+    return e
+
+
 def _mix32(*values):
     """Key of a Dropout call from small integers (step seed, network, call, layer): the device hashes (key, row, column)."""
     h = 0x9E3779B9
@@ -293,10 +302,6 @@ class LoopTrainer:
         dropped-out copy) and `hs.out` the network's output.  `call` numbers the calls of this network within the step: it
         keys the Dropout masks, so the backward recompute of call t sees the masks of the forward call t."""
         p, net = self.prim, ng.net
-        if 0 in ng.drop:
-            raise NotImplementedError('a Dropout layer in front of the first Dense (dropout_pos = 0) is not on the HIP training path: '
-                                      'the first layer is folded with BatchNormalization and split into per-segment products there; '
-                                      'positions >= 1 are supported')
         mean = var = None
         if ng.bn:
             if stats is not None:
@@ -312,11 +317,29 @@ class LoopTrainer:
                         p.colstats(x, ridx, M, mean[off:off + w], var[off:off + w])
                     off += w
                 if self.dp is not None: mean, var = self.dp.combine_stats(mean, var, 'out' if ng is self.go else 'nodes')   # statistics of the MERGED batch
-            Wf, bf = p.new(*ng.W[0].shape), p.new(ng.W[0].shape[1])
-            p.fold(ng.W[0], ng.b[0], ng.bn_params, mean, var, Wf, bf)
+        drop0 = 0 in ng.drop
+        if drop0:
+            # Dropout in front of the first Dense (reference MLP.py:60-66 with position 0; BatchNormalization is inserted in front of it,
+            # :68-71): x -> BN -> Dropout -> Dense 0.  The normalised input is materialised as the output of an IDENTITY Dense with
+            # the statistics folded in ([M, input_dim], the virtual concatenation made real), dropped out, and Dense 0 runs plain.
+            K = net.input_dim
+            eye = _eye(ng, K, p)
+            if ng.bn:
+                Wn, bn_ = p.new(K, K), p.new(K)
+                p.fold(eye, p.zeros(K), ng.bn_params, mean, var, Wn, bn_)
+            else:
+                Wn, bn_ = eye, None
+            xn = p.dense(segs, Wn, K, bn_, 0, p.new(M, K))
+            x0 = self._dropped(ng, 0, xn, call)
+            hs = _Acts([p.dense([(x0, None)], ng.W[0], net.units[0], ng.b[0], ng.acts[0], p.new(M, net.units[0]))])
+            hs.x0 = x0
         else:
-            Wf, bf = ng.W[0], ng.b[0]
-        hs = _Acts([p.dense(segs, Wf, net.units[0], bf, ng.acts[0], p.new(M, net.units[0]))])
+            if ng.bn:
+                Wf, bf = p.new(*ng.W[0].shape), p.new(ng.W[0].shape[1])
+                p.fold(ng.W[0], ng.b[0], ng.bn_params, mean, var, Wf, bf)
+            else:
+                Wf, bf = ng.W[0], ng.b[0]
+            hs = _Acts([p.dense(segs, Wf, net.units[0], bf, ng.acts[0], p.new(M, net.units[0]))])
         hs.inputs = [self._dropped(ng, 1, hs[0], call)]
         for l in range(1, len(net.units)):
             hs.append(p.dense([(hs.inputs[-1], None)], ng.W[l], net.units[l], ng.b[l], ng.acts[l], p.new(M, net.units[l])))
@@ -341,6 +364,20 @@ class LoopTrainer:
             G = through_dropout(l, p.dense([(dZ, None)], Wt, net.units[l - 1], None, 0, p.new(M, net.units[l - 1])))
         dZ = p.act_grad(G, hs[0], G, ng.acts[0])
         K, H = ng.W[0].shape
+        drop0 = 0 in ng.drop
+        if drop0:
+            # Dense 0 is a plain layer over the dropped-out input; the gradient then passes the Dropout masks and meets the
+            # identity Dense that carries BatchNormalization: the same first-layer algebra with W = I (S1 = q, S2 = diag(P))
+            p.dense_grad(hs.x0, None, dZ, M, ng.dW[0], ng.db[0], acc)
+            if self.dp is not None: raise NotImplementedError('dropout_pos = 0 under data parallelism')
+            dZ = through_dropout(0, p.dense([(dZ, None)], ng.W[0].t().contiguous(), K, None, 0, p.new(M, K)))
+            H = K
+            if not ng.bn:
+                ng.touched = True
+                offs = np.cumsum([0] + [x.shape[1] for x, _ in segs])
+                for si, out in dx_requests or []:
+                    out.copy_(dZ[:, int(offs[si]):int(offs[si]) + segs[si][0].shape[1]])
+                return
         P, q = p.new(K, H), p.new(H)
         off = 0
         for i, (x, ridx) in enumerate(segs):
@@ -351,6 +388,17 @@ class LoopTrainer:
         m1 = m2 = None
         if ng.bn: m1, m2 = p.new(K), p.new(K)
         M_all = M
+        if drop0:
+            eye = _eye(ng, K, p)
+            p.first_layer_param_grads(P, q, eye, ng.bn_params, mean, var, M_all, p.zeros(K, K), p.zeros(K), ng.dgamma, ng.dbeta, m1, m2, acc)
+            ng.touched = True
+            offs = np.cumsum([0] + [x.shape[1] for x, _ in segs])
+            for si, out in dx_requests or []:
+                x, ridx = segs[si]
+                k0, w = int(offs[si]), x.shape[1]
+                out.copy_(dZ[:, k0:k0 + w])
+                p.bn_input_grad(out, x, ridx, M, k0, ng.bn_params, mean, var, m1, m2, out)
+            return
         if self.dp is not None:
             # P = X^T dZ and q = colsum(dZ) over the rows of EVERY shard: the first layer's parameter gradients and the BatchNorm
             # input-gradient moments m1 / m2 (means over all rows of the merged batch) follow from the sums

@@ -314,9 +314,18 @@ def beyond_cache_section(device, d, K_it, aggregation):
 def gpu_state():
     """Clocks / power / temperature rocm-smi reports right after the timed region (a child process; never fails the bench): the same
     kernel has measured 460 us on one box of the pool and 533 us on another (profiles/r03_notes.txt) - this says which kind ran."""
-    import subprocess
+    import subprocess, sys
+    # Under a profiler the tool's preloaded library initialises the GPU in every child before its program starts, and rocm-smi is a
+    # `#!/usr/bin/env python3` script: that second exec is one this pool refuses.  Skip there; elsewhere start the interpreter on the
+    # script directly (one exec of a child that has not touched the GPU) with the preload variables removed.
+    if any('rocprof' in str(os.environ.get(k, '')).lower() for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB', 'ROCPROFILER_LIBRARY')):
+        return {'unavailable': 'skipped under rocprofv3'}
     try:
-        out = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--showtemp', '--json'], capture_output=True, text=True, timeout=20).stdout
+        import shutil
+        smi = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+        env = {k: v for k, v in os.environ.items() if k not in ('LD_PRELOAD', 'HSA_TOOLS_LIB', 'ROCP_TOOL_LIBRARIES')}
+        out = subprocess.run([sys.executable, os.path.realpath(smi), '--showclocks', '--showpower', '--showtemp', '--json'], capture_output=True, text=True,
+                             timeout=20, env=env).stdout
         card = next(iter(json.loads(out).values()))
         keep = {k: v for k, v in card.items() if any(w in k.lower() for w in ('mclk', 'fclk', 'sclk', 'power', 'junction', 'memory)'))}
         return keep or None

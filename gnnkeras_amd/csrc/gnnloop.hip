@@ -807,7 +807,62 @@ gnn::FusedType fused_type(const gnn_loop_args_t &a, const Plan &p, int t) {
     const bool two = m.n_layers == 2;
     return gnn::FusedType{p.tp[t].rows, p.tp[t].count, p.tp[t].Wf, p.tp[t].wrow_state, p.tp[t].wrow_agg,
                           (int)m.units[0], (int)m.activation[0],
-                          two ? m.kernel[1] : nullptr, two ? m.bias[1] : nullptr, two ? (int)m.activation[1] : 0, p.tp[t].Wc};
+                          two ? m.kernel[1] : nullptr, two ? m.bias[1] : nullptr, two ? (int)m.activation[1] : 0, p.tp[t].Wc, 0};
+}
+
+// State networks with two or more hidden layers (reference MLP.py:83-139 `hidden_units=[h1, h2, ..]`): the first TWO Dense layers run
+// fused with the aggregate in the wave-specialised kernel's two-layer form, which then writes the second hidden layer's activations
+// (not a state) - the remaining layers are plain dense launches over that matrix, the last one carrying the predicate.  Homogeneous
+// models on one GPU, hidden widths within the padded state width.  Un-fused before: aggregate + one dense launch per layer.
+bool prefix_applies(const gnn_loop_args_t &a, const Plan &p) {
+    if (a.flags & GNN_FLAG_UNFUSED) return false;
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("GNN_PREFIX_FUSION"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off || p.composite || p.T != 1 || p.tp[0].rows || a.nodes_src || p.n_groups > 0) return false;
+    const gnn_mlp_t &m = a.net_state[0];
+    if (m.n_layers < 3 || (p.SP != 32 && p.SP != 64)) return false;
+    if (m.units[0] > p.SP || m.units[1] > p.SP || m.activation[0] == GNN_ACT_SOFTMAX || m.activation[1] == GNN_ACT_SOFTMAX) return false;
+    const int pinned = (a.flags & GNN_FLAG_FUSED_GEN_MASK) >> 4;
+    if (pinned != 0 && pinned != 4) return false;
+    if ((size_t)(p.N + p.n_heavy) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return false;
+    if ((size_t)iter_adjacency(a, p).nnz * 4 >= ((size_t)1 << 32)) return false;
+    return true;
+}
+
+int iteration_prefix(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src, float *dst, int *flag_next, float *k_out,
+                     float k_val, hipStream_t st) {
+    TRY(launch_heavy(a, p, gate, src, st));
+    const gnn_csr_t &adj = iter_adjacency(a, p);
+    const gnn_mlp_t &m = a.net_state[0];
+    gnn::Fused2Args fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.gate = gate; fa.n_gate = gate ? 1 : 0; fa.gate_stride = 0;
+    fa.rowptr = adj.rowptr; fa.src = adj.src; fa.w = adj.w; fa.row_scale = adj.row_scale;
+    fa.state_in = src; fa.state_out = p.agg; fa.row_base = 0;          // p.agg: [N, SP], free on this path, receives the hidden activations
+    fa.C = p.C; fa.ldC = p.ldC;
+    fa.n_types = 1;
+    fa.tp[0] = gnn::FusedType{nullptr, p.tp[0].count, p.tp[0].Wf, p.tp[0].wrow_state, p.tp[0].wrow_agg, (int)m.units[0], (int)m.activation[0],
+                              m.kernel[1], m.bias[1], (int)m.activation[1], nullptr, (int)m.units[1]};
+    fa.S = p.S; fa.thr = a.state_threshold;
+    fa.flag_next = nullptr; fa.k_out = nullptr; fa.err = p.err;
+    FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
+    GNN_SET_KERNEL_NAME("k_state_fused4<.., L2> (aggregate + two Dense layers) + k_segdense (remaining layers)");
+    gnn_mlp_t tail;
+    memset(&tail, 0, sizeof(tail));
+    tail.n_layers = m.n_layers - 2; tail.in_dim = m.units[1];
+    for (int l = 0; l < tail.n_layers; ++l) { tail.units[l] = m.units[l + 2]; tail.activation[l] = m.activation[l + 2]; tail.kernel[l] = m.kernel[l + 2]; tail.bias[l] = m.bias[l + 2]; }
+    MlpRun r;
+    r.mlp = &tail; r.Wf = tail.kernel[0]; r.bf = tail.bias[0];
+    r.nseg = 1;
+    r.segs[0] = gnn::Seg{p.agg, nullptr, p.SP, (int)m.units[1], 0};
+    r.M = p.N;
+    r.hid[0] = p.hid[0]; r.hid[1] = p.hid[1]; r.ld_hid = p.ld_hid;
+    r.Y = dst; r.ldy = p.SP;
+    r.gate = gate;
+    if (flag_next) { r.pred_old = src; r.ld_pred = p.SP; r.pred_thr = a.state_threshold; r.pred_flag = flag_next; r.pred_k = k_out; r.pred_kval = k_val; }
+    TRY(run_mlp(r, st));
+    if (flag_next && !r.pred_fused) TRY(launch_converge(gate, dst, src, p.N, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
+    return 0;
 }
 
 // one fused iteration over every node type (one launch per type)
@@ -1114,6 +1169,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     if (!small_setup) TRY(launch_converge(nullptr, first, nullptr, p.N, p.S, p.SP, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
 
     const bool fused = can_fuse(a, p);
+    const bool prefix = !fused && prefix_applies(a, p);
     const bool no_exit = (a.flags & GNN_FLAG_NO_EARLY_EXIT) != 0;
     // Ping-pong buffers.  When the caller's state_out has the padded layout too, it stands in for the buffer the LAST
     // iteration writes (B[max_iteration & 1]): a loop that runs to max_iteration leaves the result where the caller
@@ -1138,8 +1194,9 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         const int *gate = no_exit ? nullptr : p.flags + it;
         const float *src = it == 0 ? first : B[it & 1];
         float *dst = B[(it + 1) & 1];
-        if (fused) TRY(iteration_fused(a, p, gate, gate ? 1 : 0, 0, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
-        else       TRY(iteration_unfused(a, p, gate, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
+        if (fused)       TRY(iteration_fused(a, p, gate, gate ? 1 : 0, 0, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
+        else if (prefix) TRY(iteration_prefix(a, p, gate, src, dst, p.flags + it + 1, a.k_out, (float)(it + 1), st));
+        else             TRY(iteration_unfused(a, p, gate, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
     }
 
     if (a.ev_loop_end) HIP_OK(hipEventRecord((hipEvent_t)a.ev_loop_end, st));

@@ -34,6 +34,8 @@ struct FusedType {
     const float *b2;   // [S]
     int act2;
     const float *Wc;   // XC form of k_state_fused4: [32 x H] folded weight rows of this type's constant inputs, bias row, zeros
+    int out2;          // width of the second Dense's output when it is NOT the state (0 = S): W2 is [H x out2], the launch writes the
+                       // hidden activations of a deeper network and the caller runs the remaining layers (gnnloop.hip: iteration_prefix)
 };
 
 struct Fused2Args {

@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     int ty = 0;
     while (ty + 1 < a.n_types && (int)blockIdx.x >= a.blk_begin[ty + 1]) ++ty;
     const FusedType tp = a.tp[ty];
+    const int O2 = tp.out2 > 0 ? tp.out2 : S;        // width of the second Dense's output (a deeper network's hidden layer, or the state)
     const int bid = blockIdx.x - a.blk_begin[ty], nblk = a.blk_begin[ty + 1] - a.blk_begin[ty];
     const int count = tp.count;
     const int *__restrict__ rows = tp.rows;
@@ -190,9 +191,9 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     if (L2) {                                   // second Dense: rows k < H (hidden units), columns n < S, same swizzle
         for (int i = tid; i < SP * SP; i += NT) {
             const int k = i / SP, n = i % SP;
-            W2s[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = (k < tp.H && n < S) ? tp.W2[(size_t)k * S + n] : 0.0f;
+            W2s[k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)] = (k < tp.H && n < O2) ? tp.W2[(size_t)k * O2 + n] : 0.0f;
         }
-        if (tid < SP) W2s[SP * LDW + tid] = tid < S ? tp.b2[tid] : 0.0f;
+        if (tid < SP) W2s[SP * LDW + tid] = tid < O2 ? tp.b2[tid] : 0.0f;
     }
     if (tid < 2 * NS) fill[tid] = 0;
     __syncthreads();
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                     activate4(act_out, nv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        nv[e] = (j >= 0 && 4 * r + e < S) ? nv[e] : 0.0f;
+                        nv[e] = (j >= 0 && 4 * r + e < (L2 ? O2 : S)) ? nv[e] : 0.0f;
                         const float d = nv[e] - ov[e];
                         d2 = fmaf(d, d, d2);
                         n2 = fmaf(ov[e], ov[e], n2);

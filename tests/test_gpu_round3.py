@@ -476,3 +476,50 @@ def test_small_graph_training_with_the_persistent_kernels_switched_off_in_a_chil
                           'gradients_single_layer or fit_reduces_loss'], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert ' passed' in res.stdout
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# state networks with two or more hidden layers: the first two Dense layers fused with the aggregate (iteration_prefix)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('N,d,hidden,mode,thr', [(40_000, 64, [48, 64], 'average', 0.0), (30_000, 32, [32, 20, 24], 'sum', 0.0),
+                                                 (40_000, 64, [64, 33], 'normalized', 0.0), (40_000, 64, [40, 56], 'average', -1.0),
+                                                 (935, 24, [30, 17], 'average', 0.0)])
+def test_deep_state_networks_keep_the_aggregate_fused_with_the_first_two_layers(mutag_graphs, N, d, hidden, mode, thr):
+    """`MLP(hidden_units=[h1, h2, ..])` (reference MLP.py:83-139) as the state network: the wave-specialised kernel's two-layer form
+    runs the aggregate, Dense 1 and Dense 2 and writes the SECOND hidden layer; the remaining layers are dense launches, the last one
+    carrying the predicate.  k, state and output against the fp64 oracle, and against the un-fused path (aggregate + one dense launch
+    per layer), on ER graphs with per-row and per-arc weights, with an early exit, and on a MUTAG batch."""
+    from test_gpu_parity import starter_nets
+    rng = np.random.default_rng(N + d)
+    if N == 935:
+        seq = MultiGraphSequencer(mutag_graphs[:32], 'g', mode, 32, shuffle=False)
+        focus, cls = 'g', GNNgraphBased
+    else:
+        g = er_graph(N, 6 * N, seed=3, aggregation_mode=mode)
+        seq = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)
+        focus, cls = 'n', GNNnodeBased
+    x = seq[0][0]
+    n_nodes = x[0].shape[0]
+    ns, no = starter_nets(focus, d, hidden_state=hidden, act='tanh', scale=0.3 if thr >= 0 else 0.12)
+    s0 = rng.normal(0, 0.1, (n_nodes, d)).astype(np.float32)
+    K = 6
+    if thr < 0:
+        seen = {}
+        for thr in (0.01, 0.02, 0.05, 0.1, 0.2, 0.4):
+            k = seen[thr] = float(oracle_loop(cls(ns, no, d, K, thr), x, s0, np.float64)[0])
+            if 1 < k < K: break
+        assert 1 < k < K, seen
+    model = cls(ns, no, d, K, thr)
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    inputs = model.process_inputs(x)
+    got = {}
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=dev(s0))
+        torch.cuda.synchronize()
+        if flags == 0: assert 'remaining layers' in _last_kernel(), _last_kernel()
+        else: assert 'un-fused' in _last_kernel(), _last_kernel()
+        assert float(k) == float(k64), (flags, float(k), k64)
+        assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, flags
+        got[flags] = st
+    assert rel_err(got[0].cpu().numpy(), got[nat.FLAG_UNFUSED].cpu().numpy()) <= TOL

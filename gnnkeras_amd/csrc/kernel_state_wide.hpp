@@ -65,6 +65,10 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = a.S;
+    // Widths below 128 keep the 128-float row stride (pad columns stay zero) but not the work: chunks behind column S are never
+    // loaded or stored, k-steps behind it never multiplied (d = 96: three quarters of the bytes and of the MFMAs).
+    const int S4 = (S + 3) >> 2;               // 16-byte chunks of a row that hold state columns
+    const int SQ = (S + 15) >> 4;              // 16-column k blocks that hold state columns
     int ty = 0;
     while (ty + 1 < a.n_types && (int)blockIdx.x >= a.blk_begin[ty + 1]) ++ty;
     const FusedType tp = a.tp[ty];
@@ -135,7 +139,7 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
             const int jC = node_of(job_m(n + 2 * Cfg::NPROD));
             const float scl = buf_ld_f32(r_scale, j >= 0 ? 4u * (unsigned)j : BUF_OFF);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (INIT) acc = buf_ld_f32x4(r_init, j >= 0 ? (unsigned)j * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);   // sum of the arcs walked earlier (overlap)
+            if (INIT) acc = buf_ld_f32x4(r_init, (j >= 0 && l4 < S4) ? (unsigned)j * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);   // sum of the arcs walked earlier (overlap)
             int idB = 0; float wB = 0.0f;
             int rem = endA - begA, eb = begA;
             int idc = idA; float wc = wA;
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
 #pragma unroll
                     for (int i = 0; i < DEPTH; ++i) {
                         const unsigned sid = (unsigned)__shfl(idc, s0 + i, LPR);
-                        v[i] = buf_ld_f32x4(r_state, s0 + i < rem ? sid * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);
+                        v[i] = buf_ld_f32x4(r_state, (s0 + i < rem && l4 < S4) ? sid * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);
                     }
                     if (s0 == 0 && first) {        // the next job's row pointers have landed by now: fetch its first CH source ids
                         const int e = begB + l4;
@@ -212,12 +216,12 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
             f32x4 A[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                A[q] = buf_ld_f32x4(r_state, jfr >= 0 ? (unsigned)(a.row_base + jfr) * (unsigned)(SP * 4) + 64u * q + 16u * g : BUF_OFF);
+                A[q] = buf_ld_f32x4(r_state, (jfr >= 0 && 4 * q + g < S4) ? (unsigned)(a.row_base + jfr) * (unsigned)(SP * 4) + 64u * q + 16u * g : BUF_OFF);
             f32x4 c[8];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const unsigned off = jrow[reg] >= 0 ? ((unsigned)jrow[reg] * (unsigned)a.ldC + 8u * r) * 4u : BUF_OFF;
-                const f32x4 lo = buf_ld_f32x4(r_C, off), hi = buf_ld_f32x4(r_C, jrow[reg] >= 0 ? off + 16u : BUF_OFF);
+                const unsigned off = (jrow[reg] >= 0 && 8 * r < tp.H) ? ((unsigned)jrow[reg] * (unsigned)a.ldC + 8u * r) * 4u : BUF_OFF;
+                const f32x4 lo = buf_ld_f32x4(r_C, off), hi = buf_ld_f32x4(r_C, (jrow[reg] >= 0 && 8 * r + 4 < tp.H) ? off + 16u : BUF_OFF);
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) {
                     c[ci][reg] = 8 * r + ci < tp.H ? lo[ci] : 0.0f;
@@ -227,6 +231,7 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
             // ---- [own state] . W1_s: needs nothing from the gather waves, runs while they fill this tile's slot ----------------
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
+                if (q >= SQ) break;                    // (uniform: k blocks behind the state width multiply zeros)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const f32x4 b0 = *reinterpret_cast<const f32x4 *>(ws0 + (16 * q + e) * SP);
@@ -258,6 +263,7 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
             if (lane == 0) __hip_atomic_store(&freed[s], round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
+                if (q >= SQ) break;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const f32x4 b0 = *reinterpret_cast<const f32x4 *>(wa0 + (16 * q + e) * SP);
@@ -275,7 +281,7 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
             for (int reg = 0; reg < 4; ++reg) {
                 const int j = jrow[reg];
                 const unsigned off = j >= 0 ? (unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 32u * r : BUF_OFF;
-                const f32x4 olo = buf_ld_f32x4(r_state, off), ohi = buf_ld_f32x4(r_state, j >= 0 ? off + 16u : BUF_OFF);   // L1 / L2 hits: just read above
+                const f32x4 olo = buf_ld_f32x4(r_state, 8 * r < S ? off : BUF_OFF), ohi = buf_ld_f32x4(r_state, (j >= 0 && 8 * r + 4 < S) ? off + 16u : BUF_OFF);   // L1 / L2 hits: just read above
                 f32x4 nlo = {c[0][reg], c[1][reg], c[2][reg], c[3][reg]}, nhi = {c[4][reg], c[5][reg], c[6][reg], c[7][reg]};
                 activate4(tp.act, nlo); activate4(tp.act, nhi);
                 float d2 = 0.0f, n2 = 0.0f;
@@ -287,10 +293,8 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
                     d2 = fmaf(dl, dl, d2); d2 = fmaf(dh, dh, d2);
                     n2 = fmaf(olo[e], olo[e], n2); n2 = fmaf(ohi[e], ohi[e], n2);
                 }
-                if (j >= 0) {
-                    *reinterpret_cast<f32x4 *>(obase + off) = nlo;
-                    *reinterpret_cast<f32x4 *>(obase + off + 16u) = nhi;
-                }
+                if (j >= 0 && 8 * r < S) *reinterpret_cast<f32x4 *>(obase + off) = nlo;               // (pad chunks of the row stay zero: never written)
+                if (j >= 0 && 8 * r + 4 < S) *reinterpret_cast<f32x4 *>(obase + off + 16u) = nhi;
 #pragma unroll
                 for (int o = 8; o >= 1; o >>= 1) {
                     d2 += __shfl_xor(d2, o, 16);

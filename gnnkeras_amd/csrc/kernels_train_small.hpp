@@ -416,22 +416,30 @@ inline size_t train_small_fwd_lds() {
 }
 
 // ---- backward ----------------------------------------------------------------------------------------------------------------------------------
+// BatchNormalization in terms of xhat = (x - mean) rstd (what the tile keeps in LDS):  with  Phat = xhat^T dZ,  q = colsum(dZ),
+//   S1_k = sum_h W[k, h] q[h] (= d beta_k),  S2_k = sum_h W[k, h] Phat[k, h] (= d gamma_k),
+//   dW[k, h] = gamma_k Phat[k, h] + beta_k q[h],       dx = gamma rstd (dy - S1 / N - xhat S2 / N),   dy = dZ . W^T.
+// gamma and beta do not depend on the iteration, so sum_t Phat_t is accumulated as it is (one register add per tile and iteration) and
+// scaled once at the end; the constant input columns have an iteration-invariant xhat, so their products are ONE pass over sum_t dZ_t at
+// the end.  Every sum over rows is linear: a workgroup keeps the shares of its own tile (P, q, S1, S2 summed over the iterations) and the
+// caller adds the shares in workgroup order.  Only the per-iteration TOTALS of S1 and S2 over the state / agg columns have to cross tiles
+// (the BatchNorm input gradient): 4 S floats per workgroup and iteration.
 struct TrainSmallBwd {
     int N, S, k;                 // k = iterations the forward pass executed
     const int *rowptr_s, *src_s; const float *w_s, *row_scale_s; // adjacency by SOURCE (transposed aggregate); w_s NULL = unit weights
     const float *row_scale;      // [N] scale of the by-destination operator when its entries depend on the destination only (then w_s = NULL)
     const float *states, *agg, *stats;                           // the forward tape
     int in_s, off_agg;
-    ConstSegs cs;                // constant input segments (for P = X^T dZ): labels, aggregated labels, aggregated arc labels
+    ConstSegs cs;                // constant input segments: labels, aggregated labels, aggregated arc labels
     const float *W;              // [in_s][S]
     const float *gamma, *beta; float eps;
     int act;
     const float *G0;             // [N][S] d loss / d states[k] (from the output network)
     float *dxa;                  // [N][S] exchange buffer: d loss / d agg rows of the current iteration (general form)
     unsigned long long *bar;
-    float *part;                 // [2][n_wg][S + KMAX]  (q | S2) partials
+    float *part;                 // [2][n_wg][4 S]  (S1 | S2) partials of the state / agg columns
     float *partW;                // [n_wg][in_s * S + S] every workgroup's share of the kernel and bias gradients (summed by the caller)
-    float *dgamma, *dbeta;       // [in_s] written by workgroup 0 (complete)
+    float *partBN;               // [n_wg][2 in_s] every workgroup's share of d gamma | d beta (BatchNormalization)
     float inv_n;                 // 1 / N
     float *err;                  // [1] = 2 when a barrier timed out
 };
@@ -440,21 +448,21 @@ template <int SQ, bool HAS_W, bool LOCAL>
 __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, TileTab tt) {
     using Csr = TileCsr<SQ, HAS_W, LOCAL>;
     constexpr int S = 16 * SQ, LPR = S / 4, NPP = Csr::NPP, NPASS = Csr::NPASS;
-    constexpr int KMAX = 2 * S + 32;      // input columns: state, agg, up to 32 constant columns (in tile order: state | agg | constants)
-    constexpr int LDX = KMAX + 4;         // == 4 (mod 32)
-    constexpr int LDZ = S + 4, LDW = S + 4;
-    constexpr int NKT = KMAX / 16;        // 16-row tiles of P
-    constexpr int TPW = (NKT * SQ + 3) / 4;   // P tiles per wave
+    constexpr int LDX = 2 * S + 4;        // == 4 (mod 32)
+    constexpr int LDZ = S + 4, LDW = S + 4, LDC = 36;
+    constexpr int NT_D = 2 * SQ * SQ;     // 16 x 16 tiles of Phat over the state / agg columns: (kt, ht), kt < 2 SQ
+    constexpr int TPW = (NT_D + 3) / 4;   // ... per wave
+    constexpr int NT_C = 2 * SQ, TPC = (NT_C + 3) / 4;        // tiles of the constants' product (32 columns)
+    constexpr int NCH = 64 * LPR / TS_NT; // 16-byte row pieces per thread
     extern __shared__ __attribute__((aligned(16))) float ts_smem[];
-    float *Xs = ts_smem;                  // [64][LDX]  inputs of the tile: [state_t | agg_t | constants]
+    float *Xs = ts_smem;                  // [64][LDX]  xhat of [state_t | agg_t]; at the end [64][LDC] xhat of the constants
     float *Zs = Xs + 64 * LDX;            // [64][LDZ]  dZ
     float *Gs = Zs + 64 * LDZ;            // [64][LDZ]  G (d loss / d state of the tile)
     float *Da = Gs + 64 * LDZ;            // [64][LDZ]  d loss / d agg rows of the tile (LOCAL)
-    float *Wr = Da + (LOCAL ? 64 * LDZ : 0);       // [KMAX][LDW] kernel rows in tile-column order (state, agg, constants)
-    float *vec = Wr + KMAX * LDW;
-    float *q_s = vec, *ql_s = q_s + S, *S2_s = ql_s + S, *S1_s = S2_s + KMAX, *a_s = S1_s + KMAX, *c_s = a_s + KMAX, *cfA = c_s + KMAX,
-          *cfC = cfA + 2 * S, *cfB = cfC + 2 * S, *red = cfB + 2 * S;       // red: [4][KMAX] / [256] scratch
-    int *wrow_of = reinterpret_cast<int *>(red + 4 * KMAX);     // [KMAX] weight row (= BatchNorm column) of tile column j, -1 = padding
+    float *Wr = Da + (LOCAL ? 64 * LDZ : 0);       // [2 S][LDW] kernel rows of the state / agg columns
+    float *vec = Wr + 2 * S * LDW;
+    float *ql_s = vec, *S1_s = ql_s + S, *S2_s = S1_s + 2 * S, *cfA = S2_s + 2 * S, *cfC = cfA + 2 * S, *cfB = cfC + 2 * S,
+          *rs_s = cfB + 2 * S, *sh_s = rs_s + 2 * S, *red = sh_s + 2 * S;      // red: [4][2 S] / [4][S] scratch
     __shared__ int cont;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -464,194 +472,162 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
     const bool bn = a.gamma != nullptr;
     const size_t NS = (size_t)a.N * S;
     GridBar gb{a.bar, gridDim.x, 0, 0u, 0u, 0};
-    const int Kc = (a.cs.n > 0 ? a.cs.width[0] : 0) + (a.cs.n > 1 ? a.cs.width[1] : 0) + (a.cs.n > 2 ? a.cs.width[2] : 0);
-    const int KU = 2 * S + Kc;            // used tile columns
+    auto wrow_dyn = [&](int j) { return j < S ? j : a.off_agg + (j - S); };
 
-    for (int j = tid; j < KMAX; j += TS_NT) {
-        int r = -1;
-        if (j < S) r = j;
-        else if (j < 2 * S) r = a.off_agg + (j - S);
-        else {
-            int jj = j - 2 * S, b0 = 0;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) { if (s < a.cs.n && jj >= b0 && jj < b0 + a.cs.width[s]) r = a.cs.wrow[s] + (jj - b0); if (s < a.cs.n) b0 += a.cs.width[s]; }
-        }
-        wrow_of[j] = r;
-    }
-    __syncthreads();
-    for (int i = tid; i < KMAX * S; i += TS_NT) {
+    for (int i = tid; i < 2 * S * S; i += TS_NT) {
         const int j = i / S, h = i % S;
-        Wr[j * LDW + h] = wrow_of[j] >= 0 ? a.W[(size_t)wrow_of[j] * S + h] : 0.0f;
-    }
-    // the tile's constant inputs and its first G
-    for (int i = tid; i < 64 * 32; i += TS_NT) {
-        const int rr = i >> 5, jj = i & 31;
-        float v = 0.0f;
-        if (rr < nt && jj < Kc) {
-            int b0 = 0;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) { if (s < a.cs.n && jj >= b0 && jj < b0 + a.cs.width[s]) v = a.cs.ptr[s][(size_t)(n0 + rr) * a.cs.ld[s] + (jj - b0)]; if (s < a.cs.n) b0 += a.cs.width[s]; }
-        }
-        Xs[rr * LDX + 2 * S + jj] = v;
+        Wr[j * LDW + h] = a.W[(size_t)wrow_dyn(j) * S + h];
     }
     for (int i = tid; i < 64 * S; i += TS_NT) {
         const int rr = i / S, h = i % S;
         Gs[rr * LDZ + h] = rr < nt ? a.G0[(size_t)(n0 + rr) * S + h] : 0.0f;
     }
+    // xhat = x rs + sh of iteration t (rs = rstd, sh = - mean rstd; 1 / 0 without BatchNormalization)
+    auto coefficients = [&](int t) {
+        if (tid < 2 * S) {
+            float r_ = 1.0f, s_ = 0.0f;
+            if (bn) { const float *st = a.stats + (size_t)t * 2 * a.in_s; const int k = wrow_dyn(tid); r_ = 1.0f / sqrtf(st[a.in_s + k] + a.eps); s_ = -st[k] * r_; }
+            rs_s[tid] = r_; sh_s[tid] = s_;
+        }
+    };
     Csr csr;
     csr.load(n0, nt, a.rowptr_s, a.src_s, a.w_s, a.row_scale_s);
     const int q = csr.q, l4 = csr.l4;
-    // this wave's tiles of P: (kt, ht) = tile index wave + 4 i  ->  accumulated kernel-gradient share, over all iterations
-    f32x4 accW[TPW];
+    f32x4 accP[TPW];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) accW[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float db_acc = 0.0f, dg_acc = 0.0f, dbt_acc = 0.0f;              // thread h < S (own share) / workgroup 0: thread j < KU
+    for (int i = 0; i < TPW; ++i) accP[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 dzsum[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) dzsum[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float qsum = 0.0f, S1sum = 0.0f, S2sum = 0.0f;                   // thread h < S / thread j < 2 S: this tile's shares over all iterations
     const bool oin = 16 * wave + c < nt;
     const int orow = n0 + 16 * wave + c;
     const float rs = (a.row_scale && oin) ? a.row_scale[orow] : 1.0f;
     const __amdgpu_buffer_rsrc_t r_dxa = buf_rsrc(a.dxa);
+    // this thread's row pieces: rows (tid + 256 u) / LPR, chunk tid % LPR
+    const int ch = tid % LPR;
+    f32x4 xs[NCH], xa[NCH], y[NCH];
+    auto fetch = [&](int t, f32x4 (&fs)[NCH], f32x4 (&fa)[NCH]) {
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int rr = (tid + u * TS_NT) / LPR;
+            fs[u] = fa[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (rr < nt && t >= 0) {
+                const size_t o = (size_t)t * NS + (size_t)(n0 + rr) * S + 4 * ch;
+                fs[u] = *reinterpret_cast<const f32x4 *>(a.states + o);
+                fa[u] = *reinterpret_cast<const f32x4 *>(a.agg + o);
+            }
+        }
+    };
+    if (a.k > 0) {
+        fetch(a.k - 1, xs, xa);
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int rr = (tid + u * TS_NT) / LPR;
+            y[u] = rr < nt ? *reinterpret_cast<const f32x4 *>(a.states + (size_t)a.k * NS + (size_t)(n0 + rr) * S + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        coefficients(a.k - 1);
+    }
     __syncthreads();
 
     TS_CLOCK();
     for (int t = a.k - 1; t >= 0; --t) {
-        const float *s_t = a.states + (size_t)t * NS, *s_n = a.states + (size_t)(t + 1) * NS, *agg_t = a.agg + (size_t)t * NS;
-        const float *stats = a.stats + (size_t)t * 2 * a.in_s;
-        // ---- A. the tile's inputs and dZ = G (.) act'(output) into LDS -----------------------------------------------------------------------
+        // ---- A. xhat and dZ = G (.) act'(output) of the tile into LDS; the rows of iteration t - 1 are requested now -----------------------------
+        f32x4 xs_n[NCH], xa_n[NCH];
+        fetch(t - 1, xs_n, xa_n);
         {
-            constexpr int NCH = 64 * LPR / TS_NT;
-            f32x4 xs[NCH], xa[NCH], y[NCH];
+            f32x4 qp = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rs_s + 4 * ch), s0 = *reinterpret_cast<const f32x4 *>(sh_s + 4 * ch);
+            const f32x4 r1 = *reinterpret_cast<const f32x4 *>(rs_s + S + 4 * ch), s1 = *reinterpret_cast<const f32x4 *>(sh_s + S + 4 * ch);
 #pragma unroll
             for (int u = 0; u < NCH; ++u) {
-                const int i = tid + u * TS_NT, rr = i / LPR, ch = i % LPR;
-                xs[u] = xa[u] = y[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (rr < nt) {
-                    const size_t o = (size_t)(n0 + rr) * S + 4 * ch;
-                    xs[u] = *reinterpret_cast<const f32x4 *>(s_t + o);
-                    xa[u] = *reinterpret_cast<const f32x4 *>(agg_t + o);
-                    y[u] = *reinterpret_cast<const f32x4 *>(s_n + o);
+                const int rr = (tid + u * TS_NT) / LPR;
+                f32x4 hs, ha, gz = *reinterpret_cast<const f32x4 *>(Gs + rr * LDZ + 4 * ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hs[e] = rr < nt ? fmaf(xs[u][e], r0[e], s0[e]) : 0.0f;
+                    ha[e] = rr < nt ? fmaf(xa[u][e], r1[e], s1[e]) : 0.0f;
+                    gz[e] *= activate_grad_from_output(a.act, y[u][e]);
                 }
-            }
-#pragma unroll
-            for (int u = 0; u < NCH; ++u) {
-                const int i = tid + u * TS_NT, rr = i / LPR, ch = i % LPR;
-                *reinterpret_cast<f32x4 *>(Xs + rr * LDX + 4 * ch) = xs[u];
-                *reinterpret_cast<f32x4 *>(Xs + rr * LDX + S + 4 * ch) = xa[u];
-                f32x4 gz = *reinterpret_cast<const f32x4 *>(Gs + rr * LDZ + 4 * ch);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) gz[e] *= activate_grad_from_output(a.act, y[u][e]);
+                *reinterpret_cast<f32x4 *>(Xs + rr * LDX + 4 * ch) = hs;
+                *reinterpret_cast<f32x4 *>(Xs + rr * LDX + S + 4 * ch) = ha;
                 *reinterpret_cast<f32x4 *>(Zs + rr * LDZ + 4 * ch) = gz;
+                dzsum[u] += gz; qp += gz;
             }
-        }
-        if (tid < KU) {                                            // BatchNorm scale / shift of this iteration per tile column
-            float ak = 1.0f, ck = 0.0f;
-            if (bn) { const int k = wrow_of[tid]; ak = a.gamma[k] / sqrtf(stats[a.in_s + k] + a.eps); ck = a.beta[k] - stats[k] * ak; }
-            a_s[tid] = ak; c_s[tid] = ck;
+            // q of the tile: this thread's rows, then the lanes with the same chunk (stride LPR), then the four waves (in order)
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qp[e] += __shfl_xor(qp[e], off, 64);
+            if (lane < LPR) *reinterpret_cast<f32x4 *>(red + wave * S + 4 * ch) = qp;
         }
         __syncthreads();
         TS_STAMP(0);
-        // ---- B. P_wg = X^T dZ on the matrix cores (kept local), q and S2 partials -----------------------------------------------------------
+        if (tid < S) { const float t3 = ((red[tid] + red[S + tid]) + red[2 * S + tid]) + red[3 * S + tid]; ql_s[tid] = t3; qsum += t3; }
+        // ---- B. Phat_wg = xhat^T dZ on the matrix cores (kept local) -------------------------------------------------------------------------
         f32x4 P[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             P[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int ti = wave + 4 * i;
-            if (ti < NKT * SQ) {
+            if (ti < NT_D) {
                 const int kt = ti / SQ, ht = ti % SQ;
-                const float *xa = Xs + g * LDX + 16 * kt + c, *za = Zs + g * LDZ + 16 * ht + c;
+                const float *xp = Xs + g * LDX + 16 * kt + c, *zp = Zs + g * LDZ + 16 * ht + c;
 #pragma unroll 4
                 for (int ms = 0; ms < 16; ++ms)
-                    P[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * ms * LDX], za[4 * ms * LDZ], P[i], 0, 0, 0);
+                    P[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[4 * ms * LDX], zp[4 * ms * LDZ], P[i], 0, 0, 0);
             }
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) accP[i] += P[i];
         TS_STAMP(1);
-        {   // q of the tile: column sums of dZ, 256 / S row groups
-            constexpr int NG = TS_NT / S, RPG = 64 / NG;
-            const int col = tid % S, gq = tid / S;
-            float t2 = 0.0f;
-#pragma unroll
-            for (int rr = gq * RPG; rr < (gq + 1) * RPG; ++rr) t2 += Zs[rr * LDZ + col];
-            red[gq * S + col] = t2;
-            __syncthreads();
-            if (tid < S) {
-                float t3 = 0.0f;
-#pragma unroll
-                for (int u = 0; u < NG; ++u) t3 += red[u * S + tid];
-                ql_s[tid] = t3; q_s[tid] = t3;
-                db_acc += t3;
-            }
-            __syncthreads();
-        }
         if (bn) {
-            // P[i][reg] = P_wg[16 kt + 4 g + reg][16 ht + c]; S2 partial: sum over h of W[k][h] P[k][h] (per column tile, then in tile order)
+            // P[i][reg] = Phat_wg[16 kt + 4 g + reg][16 ht + c]; S2 share: sum over h of W[k][h] Phat[k][h] (per column tile, then in tile order)
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int ti = wave + 4 * i;
-                if (ti < NKT * SQ) {
+                if (ti < NT_D) {
                     const int kt = ti / SQ, ht = ti % SQ;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int j = 16 * kt + 4 * g + reg;
                         float v = Wr[j * LDW + 16 * ht + c] * P[i][reg];
                         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);   // over the 16 columns
-                        if (c == 0) red[ht * KMAX + j] = v;
+                        if (c == 0) red[4 * S + ht * 2 * S + j] = v;
                     }
                 }
             }
             __syncthreads();
-            if (tid < S + KMAX) {
+            if (tid < 4 * S) {
                 float v = 0.0f;
-                if (tid < S) v = ql_s[tid];
-                else for (int ht = 0; ht < SQ; ++ht) v += red[ht * KMAX + tid - S];            // in column-tile order
-                const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + ((size_t)(t & 1) * gridDim.x + blockIdx.x) * (S + KMAX));
+                if (tid < 2 * S) {                                 // S1 share: (W q_wg)_j
+#pragma unroll 8
+                    for (int h = 0; h < S; ++h) v = fmaf(Wr[tid * LDW + h], ql_s[h], v);
+                    S1sum += v;
+                } else {
+#pragma unroll
+                    for (int ht = 0; ht < SQ; ++ht) v += red[4 * S + ht * 2 * S + tid - 2 * S];           // in column-tile order
+                    S2sum += v;
+                }
+                const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + ((size_t)(t & 1) * gridDim.x + blockIdx.x) * 4 * S);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r_p, tid * 4, 0, 16);
             }
             TS_STAMP(2);
             grid_barrier(gb, 0, &cont);
             TS_STAMP(3);
-            if (tid < S + KMAX) {
-                const float tt2 = (float)sum_partials(a.part + (size_t)(t & 1) * gridDim.x * (S + KMAX), gridDim.x, S + KMAX, tid);
-                if (tid < S) q_s[tid] = tt2; else S2_s[tid - S] = tt2;
+            if (tid < 4 * S) {
+                const float tt2 = (float)sum_partials(a.part + (size_t)(t & 1) * gridDim.x * 4 * S, gridDim.x, 4 * S, tid);
+                if (tid < 2 * S) S1_s[tid] = tt2; else S2_s[tid - 2 * S] = tt2;
             }
             __syncthreads();
-            if (tid < KU) {                                        // S1_k = (W q)_k
-                float t1 = 0.0f;
-#pragma unroll 8
-                for (int h = 0; h < S; ++h) t1 = fmaf(Wr[tid * LDW + h], q_s[h], t1);
-                S1_s[tid] = t1;
-            }
-            __syncthreads();
-            if (blockIdx.x == 0 && tid < KU) {
-                const int k = wrow_of[tid];
-                const float rstd = 1.0f / sqrtf(stats[a.in_s + k] + a.eps);
-                dg_acc += rstd * (S2_s[tid] - stats[k] * S1_s[tid]); dbt_acc += S1_s[tid];
-            }
             if (tid < 2 * S) {
-                const int k = wrow_of[tid];
-                const float rstd = 1.0f / sqrtf(stats[a.in_s + k] + a.eps), mu = stats[k];
-                const float m1 = S1_s[tid] * a.inv_n, m2 = rstd * (S2_s[tid] - mu * S1_s[tid]) * a.inv_n;
-                const float Ac = a.gamma[k] * rstd, Cc = -Ac * rstd * m2;
-                cfA[tid] = Ac; cfC[tid] = Cc; cfB[tid] = -Ac * m1 - Cc * mu;
+                const float Ac = a.gamma[wrow_dyn(tid)] * rs_s[tid];
+                cfA[tid] = Ac; cfC[tid] = -Ac * S2_s[tid] * a.inv_n; cfB[tid] = -Ac * S1_s[tid] * a.inv_n;
             }
             __syncthreads();
         }
         TS_STAMP(4);
-        // ---- C. this workgroup's share of the kernel gradient: a (.) P_wg (+ c q^T once, in workgroup 0: q is the total) ---------------------------
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int ti = wave + 4 * i;
-            if (ti < NKT * SQ) {
-                const int kt = ti / SQ, ht = ti % SQ;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int j = 16 * kt + 4 * g + reg;
-                    float v = j < KU ? a_s[j] * P[i][reg] : 0.0f;
-                    if (bn && blockIdx.x == 0 && j < KU) v = fmaf(c_s[j], q_s[16 * ht + c], v);
-                    accW[i][reg] += v;
-                }
-            }
-        }
-        TS_STAMP(5);
         // ---- D. dx = BN-gradient(dZ . W^T) on the matrix cores (operands swapped: row-major); state half -> Gs, agg half -> Da / memory ----
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -676,8 +652,9 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                 f32x4 v = acc[u];
                 if (bn) {
                     const f32x4 x = *reinterpret_cast<const f32x4 *>(Xs + (16 * wave + c) * LDX + j0);
+                    const f32x4 A_ = *reinterpret_cast<const f32x4 *>(cfA + j0), C_ = *reinterpret_cast<const f32x4 *>(cfC + j0), B_ = *reinterpret_cast<const f32x4 *>(cfB + j0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(cfA[j0 + e], v[e], fmaf(cfC[j0 + e], x[e], cfB[j0 + e]));
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(A_[e], v[e], fmaf(C_[e], x[e], B_[e]));
                 }
                 if (!oin) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (half == 0) {
@@ -689,10 +666,10 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                 }
             }
         }
-        TS_STAMP(6);
+        TS_STAMP(5);
         if (LOCAL) __syncthreads(); else grid_barrier(gb, 0, &cont);
-        TS_STAMP(7);
-        // ---- E. G = dx_state + Adj . dx_agg: gather by source -----------------------------------------------------------------------------------
+        TS_STAMP(6);
+        // ---- E. G = dx_state + Adj . dx_agg: gather by source; the coefficients of the next iteration -----------------------------------------------
         {
             f32x4 acc[NPASS];
             if (LOCAL) csr.template gather<true>(acc, Da, LDZ, r_dxa); else csr.template gather<false>(acc, nullptr, 0, r_dxa);
@@ -705,34 +682,100 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                 *reinterpret_cast<f32x4 *>(gr) = gv;
             }
         }
+        if (t > 0) coefficients(t - 1);
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) { y[u] = xs[u]; xs[u] = xs_n[u]; xa[u] = xa_n[u]; }       // states[t] is the output of iteration t - 1
         __syncthreads();
-        TS_STAMP(8);
+        TS_STAMP(7);
     }
     TS_WRITE(1);
-    // ---- the kernel- and bias-gradient share of this workgroup; BatchNorm gradients from workgroup 0 ----------------------------------------------
+    // ---- the shares of this workgroup ---------------------------------------------------------------------------------------------------------
     float *pw = a.partW + (size_t)blockIdx.x * ((size_t)a.in_s * S + S);
+    float *pb = bn ? a.partBN + (size_t)blockIdx.x * 2 * a.in_s : nullptr;
+    if (tid < S) { pw[(size_t)a.in_s * S + tid] = qsum; ql_s[tid] = qsum; }
+    __syncthreads();
+    // kernel rows of the state / agg columns: gamma_k sum_t Phat + beta_k sum_t q
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int ti = wave + 4 * i;
-        if (ti < NKT * SQ) {
+        if (ti < NT_D) {
             const int kt = ti / SQ, ht = ti % SQ;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int j = 16 * kt + 4 * g + reg;
-                if (j < KU) pw[(size_t)wrow_of[j] * S + 16 * ht + c] = accW[i][reg];
+                const int j = 16 * kt + 4 * g + reg, k = wrow_dyn(j);
+                float v = accP[i][reg];
+                if (bn) v = fmaf(a.gamma[k], v, a.beta[k] * ql_s[16 * ht + c]);
+                pw[(size_t)k * S + 16 * ht + c] = v;
             }
         }
     }
-    if (tid < S) pw[(size_t)a.in_s * S + tid] = db_acc;
-    if (blockIdx.x == 0 && bn && tid < KU) { a.dgamma[wrow_of[tid]] = dg_acc; a.dbeta[wrow_of[tid]] = dbt_acc; }
+    if (bn && tid < 2 * S) pb[a.in_s + wrow_dyn(tid)] = S1sum;                                  // d beta share
+    else if (bn && tid < 4 * S) pb[wrow_dyn(tid - 2 * S)] = S2sum;                              // d gamma share
+    // the constant input columns: xhat is the same in every iteration, so Phat_c = xhat_c^T (sum_t dZ_t), once
+    const int Kc = (a.cs.n > 0 ? a.cs.width[0] : 0) + (a.cs.n > 1 ? a.cs.width[1] : 0) + (a.cs.n > 2 ? a.cs.width[2] : 0);
+    if (Kc > 0) {
+        int *wrow_c = reinterpret_cast<int *>(red);              // [32] weight row (= BatchNorm column) of constant column jj, -1 = padding
+        if (tid < 32) {
+            int r_ = -1, b0 = 0;
+#pragma unroll
+            for (int sg = 0; sg < 3; ++sg) { if (sg < a.cs.n && tid >= b0 && tid < b0 + a.cs.width[sg]) r_ = a.cs.wrow[sg] + (tid - b0); if (sg < a.cs.n) b0 += a.cs.width[sg]; }
+            wrow_c[tid] = r_;
+        }
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) *reinterpret_cast<f32x4 *>(Zs + ((tid + u * TS_NT) / LPR) * LDZ + 4 * ch) = dzsum[u];
+        __syncthreads();
+        for (int i = tid; i < 64 * 32; i += TS_NT) {
+            const int rr = i >> 5, jj = i & 31;
+            float v = 0.0f;
+            if (rr < nt && jj < Kc) {
+                int b0 = 0;
+#pragma unroll
+                for (int sg = 0; sg < 3; ++sg) { if (sg < a.cs.n && jj >= b0 && jj < b0 + a.cs.width[sg]) v = a.cs.ptr[sg][(size_t)(n0 + rr) * a.cs.ld[sg] + (jj - b0)]; if (sg < a.cs.n) b0 += a.cs.width[sg]; }
+                if (bn) { const int k = wrow_c[jj]; const float r_ = 1.0f / sqrtf(a.stats[a.in_s + k] + a.eps); v = (v - a.stats[k]) * r_; }      // (constants: the statistics of any iteration)
+            }
+            Xs[rr * LDC + jj] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TPC; ++i) {
+            const int ti = wave + 4 * i;
+            if (ti < NT_C) {
+                const int kt = ti / SQ, ht = ti % SQ;
+                f32x4 Pc = {0.f, 0.f, 0.f, 0.f};
+                const float *xp = Xs + g * LDC + 16 * kt + c, *zp = Zs + g * LDZ + 16 * ht + c;
+#pragma unroll 4
+                for (int ms = 0; ms < 16; ++ms) Pc = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[4 * ms * LDC], zp[4 * ms * LDZ], Pc, 0, 0, 0);
+                asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int jj = 16 * kt + 4 * g + reg, k = jj < Kc ? wrow_c[jj] : -1;
+                    const float w = k >= 0 ? a.W[(size_t)k * S + 16 * ht + c] : 0.0f;
+                    float s2 = w * Pc[reg], s1 = w * ql_s[16 * ht + c];
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) { s2 += __shfl_xor(s2, off, 64); s1 += __shfl_xor(s1, off, 64); }
+                    if (k >= 0) {
+                        pw[(size_t)k * S + 16 * ht + c] = bn ? fmaf(a.gamma[k], Pc[reg], a.beta[k] * ql_s[16 * ht + c]) : Pc[reg];
+                        if (bn && c == 0) { red[64 + ht * 32 + jj] = s2; red[64 + 4 * 32 + ht * 32 + jj] = s1; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (bn && tid < Kc) {
+            float s2 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int ht = 0; ht < SQ; ++ht) { s2 += red[64 + ht * 32 + tid]; s1 += red[64 + 4 * 32 + ht * 32 + tid]; }
+            pb[wrow_c[tid]] = s2; pb[a.in_s + wrow_c[tid]] = s1;
+        }
+    }
     if (tid == 0 && gb.timed_out) a.err[1] = 2.0f;
     if (__syncthreads_or(gb.timed_out || (LOCAL && csr.bad)) && tid == 0) pw[0] = __builtin_nanf("");      // loud: the gradients are invalid
 }
 
 template <int SQ>
 inline size_t train_small_bwd_lds(bool local) {
-    constexpr int S = 16 * SQ, KMAX = 2 * S + 32;
-    return sizeof(float) * (64 * (KMAX + 4) + (local ? 3 : 2) * 64 * (S + 4) + KMAX * (S + 4) + (2 * S + 4 * KMAX + 6 * S) + 4 * KMAX + KMAX);
+    constexpr int S = 16 * SQ;
+    return sizeof(float) * (64 * (2 * S + 4) + (local ? 3 : 2) * 64 * (S + 4) + 2 * S * (S + 4) + (S + 16 * S) + 4 * S + SQ * 2 * S + 512);
 }
 
 }  // namespace gnn

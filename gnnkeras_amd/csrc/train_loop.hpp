@@ -48,7 +48,7 @@ struct TrainPlan {
     float *xc, *part_a, *part_y, *loss_part, *part_w;
     // small graphs (kernels_train_small.hpp): the forward / backward iterations as one persistent launch each
     bool small, tiled; int n_wg;
-    float *sm_cc, *sm_part, *sm_partW; unsigned long long *sm_bar;
+    float *sm_cc, *sm_part, *sm_partW, *sm_partBN; unsigned long long *sm_bar;
     size_t bytes;
 };
 
@@ -173,6 +173,7 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.sm_cc = c.take<float>(p.small ? (size_t)p.N * p.S : 0);
     p.sm_part = c.take<float>(p.small ? (size_t)2 * p.n_wg * (3 * p.S + 32 + 4 * p.S) : 0);
     p.sm_partW = c.take<float>(p.small ? (size_t)p.n_wg * (p.in_s + 1) * p.S : 0);
+    p.sm_partBN = c.take<float>(p.small ? (size_t)p.n_wg * 2 * p.in_s : 0);
     p.sm_bar = c.take<unsigned long long>(p.small ? 4 : 0);
     p.cs.m = &ns; p.cs.g = &ta.grad_state; p.co.m = &no; p.co.g = &ta.grad_output;
     p.bytes = (c.off + 255) & ~(size_t)255;
@@ -780,7 +781,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
         ba.cs = const_segs_of(a, p);
         ba.W = ns.kernel[0]; ba.gamma = bn_s ? ns.bn_gamma : nullptr; ba.beta = ns.bn_beta; ba.eps = ns.bn_eps; ba.act = ns.activation[0];
         ba.G0 = p.G_state; ba.dxa = p.dx_s_all; ba.bar = p.sm_bar + 2; ba.part = p.sm_part; ba.partW = p.sm_partW;
-        ba.dgamma = ta.grad_state.dgamma; ba.dbeta = ta.grad_state.dbeta;
+        ba.partBN = p.sm_partBN;
         ba.inv_n = 1.0f / (float)p.N; ba.err = p.k_dev;
         switch (p.S) {
             case 16: TRY(launch_train_small_bwd_sq<1>(ba, tiles, p.n_wg, ba.w_s != nullptr, st)); break;
@@ -790,6 +791,10 @@ int gnn_train_step(const gnn_train_args_t *args) {
         const int n = (p.in_s + 1) * p.S;              // every workgroup's [kernel | bias] share, summed in workgroup order
         gnn::k_reduce_partials<<<cdiv(n, 64), 256, 0, st>>>(p.sm_partW, p.n_wg, n, ta.grad_state.dkernel[0], 0, 1.0f, p.in_s * p.S, ta.grad_state.dbias[0]);
         LAUNCH_OK();
+        if (bn_s) {                                    // ... and its [d gamma | d beta] share
+            gnn::k_reduce_partials<<<cdiv(2 * p.in_s, 64), 256, 0, st>>>(p.sm_partBN, p.n_wg, 2 * p.in_s, ta.grad_state.dgamma, 0, 1.0f, p.in_s, ta.grad_state.dbeta);
+            LAUNCH_OK();
+        }
     }
     for (int t = k - 1; t >= 0 && !p.small; --t) {
         const float *s_t = p.states + (size_t)t * NS;

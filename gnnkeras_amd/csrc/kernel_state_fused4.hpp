@@ -177,6 +177,25 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     // barrier: scripts/f4_timeline.py shows the fill's barrier 5 us - up to 10 - after entry on every workgroup of a 60 us C3 launch.
     // SLOWER: 256 threads fill 40 KB in ten dependent trips, the ring runs full before the first tile is consumed: C3 60.2 -> 63.4 us,
     // C4 460 -> 470 us.  All 1024 threads fill, then one barrier.)
+    if (S == SP && tp.H == SP && ((reinterpret_cast<uintptr_t>(tp.Wf) | (XC ? reinterpret_cast<uintptr_t>(tp.Wc) : 0)) & 15) == 0) {
+        // Full-width state and first layer (C3 / C4 / C5): whole 16-byte pieces of weight rows, every load of the fill issued before the
+        // first LDS store.  The scalar loop below made ten dependent trips of this fill: 5 us (up to 10) of a 60 us C3 launch on every
+        // workgroup (profiles/r03_c3_timeline.txt).  (The swizzle flips bit 4 of the column: 4-column pieces stay whole.)
+        constexpr int N4 = Cfg::WROWS * SP / 4, NV = (N4 + NT - 1) / NT;
+        f32x4 v[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i4 = min(tid + u * NT, N4 - 1), k = i4 / (SP / 4), n = (i4 % (SP / 4)) * 4;
+            const float *srow = (XC && k >= 2 * SP) ? tp.Wc + (size_t)(k - 2 * SP) * SP
+                                                    : tp.Wf + (size_t)((k < SP ? tp.wrow_state + k : tp.wrow_agg + (k - SP))) * SP;
+            v[u] = *reinterpret_cast<const f32x4 *>(srow + n);
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i4 = tid + u * NT, k = i4 / (SP / 4), n = (i4 % (SP / 4)) * 4;
+            if (i4 < N4) *reinterpret_cast<f32x4 *>(Ws + k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)) = v[u];
+        }
+    } else
     for (int i = tid; i < Cfg::WROWS * SP; i += NT) {
         const int k = i / SP, n = i % SP;
         float v = 0.0f;

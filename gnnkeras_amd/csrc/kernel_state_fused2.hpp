@@ -113,6 +113,21 @@ __global__ void __launch_bounds__(64 * NW, NW >= 12 ? NW / 2 : (NW == 8 ? 4 : 2)
     const int count = tp.count;
     const int *__restrict__ rows = tp.rows;
 
+    if (S == SP && tp.H == SP && (reinterpret_cast<uintptr_t>(tp.Wf) & 15) == 0) {
+        // full-width state: 16-byte pieces of weight rows, all loads of the fill in flight before the first LDS store (see k_state_fused4)
+        constexpr int N4 = 2 * SP * SP / 4, NV = (N4 + NT - 1) / NT;
+        f32x4 v[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i4 = min(tid + u * NT, N4 - 1), k = i4 / (SP / 4), n = (i4 % (SP / 4)) * 4;
+            v[u] = *reinterpret_cast<const f32x4 *>(tp.Wf + (size_t)(k < SP ? tp.wrow_state + k : tp.wrow_agg + (k - SP)) * SP + n);
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i4 = tid + u * NT, k = i4 / (SP / 4), n = (i4 % (SP / 4)) * 4;
+            if (i4 < N4) *reinterpret_cast<f32x4 *>(Ws + k * LDW + (Cfg::SWZ ? (n ^ ((k & 1) << 4)) : n)) = v[u];
+        }
+    } else
     for (int i = tid; i < 2 * SP * SP; i += NT) {
         const int k = i / SP, n = i % SP;
         const int kk = k < SP ? k : k - SP;

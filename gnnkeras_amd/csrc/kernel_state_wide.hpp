@@ -117,6 +117,26 @@ __global__ void __launch_bounds__(1024, 4) k_state_wide(Fused2Args a) {
     }
 
     // ---- W1 fill: rows k' < SP multiply the own state, rows SP + k' the neighbour sum; pad rows / columns are zero ---------
+    if ((tp.H & 3) == 0 && (reinterpret_cast<uintptr_t>(tp.Wf) & 15) == 0) {
+        // whole 16-byte pieces of weight rows, eight loads per thread all in flight (the scalar loop below makes 32 dependent trips:
+        // ~16 us of every launch); the column swizzle flips bit 2: 4-column pieces stay whole
+        constexpr int NV = 2 * SP * SP / 4 / NT;
+        f32x4 v[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i4 = tid + u * NT, k = i4 / (SP / 4), n = (i4 % (SP / 4)) * 4;
+            const int kk = k < SP ? k : k - SP;
+            const bool ok = kk < S && n < tp.H;
+            const float *src = tp.Wf + (size_t)((k < SP ? tp.wrow_state : tp.wrow_agg) + (ok ? kk : 0)) * tp.H + (ok ? n : 0);
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(src);
+            v[u] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i4 = tid + u * NT, k = i4 / (SP / 4), n = (i4 % (SP / 4)) * 4;
+            *reinterpret_cast<f32x4 *>(Ws + k * SP + wide_wcol(k, n)) = v[u];
+        }
+    } else
     for (int i = tid; i < 2 * SP * SP; i += NT) {
         const int k = i / SP, n = i % SP;
         const int kk = k < SP ? k : k - SP;

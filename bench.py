@@ -607,6 +607,15 @@ def main():
         del sl
         torch.cuda.empty_cache()
         result['mutag_data_parallel'] = mutag_dp_section(device, rank, world)
+    # RCCL writes its version banner through C stdio, which would otherwise reach the pipe AFTER this process' last Python write (at
+    # exit): drain it first so that the JSON line is the LAST line of stdout (it is also the only line that starts with '{').
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if sharded and world > 1:
+        torch.distributed.barrier()            # every rank has drained its C stdio before rank 0 writes the line
     if rank == 0:
         print(json.dumps(result), flush=True)
     if sharded:

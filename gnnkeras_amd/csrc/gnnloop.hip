@@ -144,6 +144,15 @@ int launch_aggregate(const int *gate, const gnn_csr_t &c, const float *X, int ld
     while (G < F && G < 64) G <<= 1;
     const int groups = 256 / G;
     const int grid = std::min(cdiv(c.n_dst, groups), 256 * 16);
+    if (G <= 16 && c.n_dst >= 4096 && (size_t)c.n_src * ldx * 4 < ((size_t)1 << 32) && (size_t)c.nnz * 4 < ((size_t)1 << 32)) {
+        // narrow label rows of a large graph: the whole CSR row in flight (k_aggregate_narrow)
+#define AGGN(GG) (c.w ? gnn::k_aggregate_narrow<GG, true><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, ldx, F, out, ldo) \
+                      : gnn::k_aggregate_narrow<GG, false><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, ldx, F, out, ldo))
+        switch (G) { case 4: AGGN(4); break; case 8: AGGN(8); break; default: AGGN(16); break; }
+#undef AGGN
+        LAUNCH_OK();
+        return 0;
+    }
 #define AGG(GG) gnn::k_aggregate<GG><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, ldx, F, out, ldo)
     switch (G) {
         case 4: AGG(4); break;

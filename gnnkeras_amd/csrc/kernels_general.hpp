@@ -61,6 +61,54 @@ k_aggregate(const int *gate, int n_dst, const int *__restrict__ rowptr, const in
     }
 }
 
+// Narrow rows (F <= G <= 16 floats: node labels, arc labels) with the whole CSR row in flight: the G lanes of a destination fetch its
+// next 16 source ids in one coalesced trip (16 / G per lane), broadcast them, and issue all 16 row loads before the first add - raw
+// buffer loads predicated off by an out-of-range offset, so nothing branches around a load.  k_aggregate above keeps 8 in flight and
+// walks the remainder of a row one dependent chain per arc (C4: labels 257 -> ~110 us, arc labels 207 -> ~90 us, once per forward).
+// Sums in arc order like k_aggregate: the same bits.  Arrays must fit 4 GiB buffer windows (the launcher checks).
+template <int G, bool HAS_W>
+__global__ void __launch_bounds__(256)
+k_aggregate_narrow(const int *gate, int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src, const float *__restrict__ w,
+                   const float *__restrict__ row_scale, const float *__restrict__ X, int ldx, int F, float *__restrict__ out, int ldo) {
+    if (gate_closed(gate)) return;
+    constexpr int IPL = 16 / G;
+    const int lane = threadIdx.x % G;
+    const int groups = blockDim.x / G;
+    const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)0xFFFFFFF0u, 0x00020000),
+                                 r_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(src), 0, (int)0xFFFFFFF0u, 0x00020000),
+                                 r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HAS_W ? w : X), 0, (int)0xFFFFFFF0u, 0x00020000);
+    constexpr unsigned OFF = 0xFFFFFFFFu;
+    for (int j0 = blockIdx.x * groups; j0 < n_dst; j0 += gridDim.x * groups) {
+        const int j = j0 + threadIdx.x / G;
+        const bool in = j < n_dst;
+        const int beg = in ? rowptr[j] : 0, end = in ? rowptr[j + 1] : 0;
+        float acc = 0.0f;
+        int eb = beg;
+        while (__any(eb < end)) {
+            int ids[IPL]; float ws[IPL];
+#pragma unroll
+            for (int u = 0; u < IPL; ++u) {
+                const int e = eb + u * G + lane;
+                ids[u] = __builtin_amdgcn_raw_buffer_load_b32(r_s, e < end ? 4u * (unsigned)e : OFF, 0, 0);
+                ws[u] = HAS_W ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_w, e < end ? 4u * (unsigned)e : OFF, 0, 0)) : 0.0f;
+            }
+            float x[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned sid = (unsigned)__shfl(ids[i / G], i % G, G);
+                x[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_x, (eb + i < end && lane < F) ? (sid * (unsigned)ldx + (unsigned)lane) * 4u : OFF, 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (HAS_W) acc = fmaf(__shfl(ws[i / G], i % G, G), x[i], acc);
+                else acc += x[i];
+            }
+            eb += 16;
+        }
+        if (in && lane < F) out[(size_t)j * ldo + lane] = acc * (row_scale ? row_scale[j] : 1.0f);
+    }
+}
+
 // The same product for rows that allow 16-B accesses (F, ldx, ldo multiples of 4, 16-B aligned bases: the padded state
 // matrix of the un-fused and training paths): LPR = F/4 lanes own a destination row, each lane carries a float4 column
 // chunk, 8 source rows in flight; a wave instruction moves 64/LPR whole rows instead of one.  `addend` (optional, the

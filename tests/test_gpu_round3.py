@@ -523,3 +523,45 @@ def test_deep_state_networks_keep_the_aggregate_fused_with_the_first_two_layers(
         assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, flags
         got[flags] = st
     assert rel_err(got[0].cpu().numpy(), got[nat.FLAG_UNFUSED].cpu().numpy()) <= TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# label aggregates of a large graph: the whole CSR row in flight (k_aggregate_narrow)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('F,ldx,weights', [(14, 14, 'rows'), (3, 5, 'rows'), (1, 1, 'arcs'), (16, 20, 'arcs'), (7, 7, 'ones'), (2, 2, 'arcs')])
+def test_narrow_aggregate_of_a_large_graph_matches_adjoint_spmm(F, ldx, weights):
+    """`gnn_aggregate` (reference `tf.sparse.sparse_dense_matmul(A, X, adjoint_a=True)`, GNN.py:254, :258) from 4 096 destination rows
+    with at most 16 columns: empty rows, rows of more than 16 arcs (several trips), a 300-arc row, strided X (the arc-label columns of
+    the arcs matrix), per-arc weights / one scale per row / all-ones - against the float64 product and, bit for bit, against the
+    general kernel (same arc-order sums) on a graph below the size threshold made of the same rows."""
+    import ctypes as C
+    from gnnkeras_amd.sparse import SparseMatrix
+    rng = np.random.default_rng(F * 10 + ldx)
+    n_src, n_dst = 30_000, 9_000
+    deg = rng.poisson(9, n_dst); deg[::97] = 0; deg[5] = 300; deg[77] = 40
+    dst = np.repeat(np.arange(n_dst), deg)
+    src = rng.integers(0, n_src, len(dst))
+    idx = np.unique(np.stack([src, dst], 1), axis=0)
+    if weights == 'arcs': val = rng.normal(size=len(idx)).astype(np.float32)
+    elif weights == 'rows': val = (1.0 / np.maximum(np.bincount(idx[:, 1], minlength=n_dst), 1))[idx[:, 1]].astype(np.float32)
+    else: val = np.ones(len(idx), np.float32)
+    Xfull = rng.normal(size=(n_src, ldx)).astype(np.float32)
+    X = Xfull[:, ldx - F:]                                       # the last F columns of a wider matrix (ld = ldx)
+    want = O.sparse_dense_matmul_adjoint(idx, val, (n_src, n_dst), np.ascontiguousarray(X), np.float64)
+
+    def run(index, values, nd):
+        m = SparseMatrix(index, values, (n_src, nd))
+        c = m.device_csr('cuda')
+        assert (c['w'] is not None) == (weights == 'arcs')
+        Xd = dev(Xfull)
+        out = torch.zeros((nd, F), dtype=torch.float32, device='cuda')
+        csr = nat.make_csr(c)
+        nat.check(nat.lib().gnn_aggregate(C.byref(csr), C.c_void_p(Xd.data_ptr() + 4 * (ldx - F)), ldx, F, nat.ptr(out), F, nat.current_stream(Xd.device)))
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    got = run(idx, val, n_dst)
+    assert rel_err(got, want) <= TOL
+    keep = idx[:, 1] < 3000                                      # below 4 096 rows: the general kernel, same rows
+    small = run(idx[keep], val[keep], 3000)
+    assert np.array_equal(small, got[:3000])

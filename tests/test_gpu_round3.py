@@ -565,3 +565,21 @@ def test_narrow_aggregate_of_a_large_graph_matches_adjoint_spmm(F, ldx, weights)
     keep = idx[:, 1] < 3000                                      # below 4 096 rows: the general kernel, same rows
     small = run(idx[keep], val[keep], 3000)
     assert np.array_equal(small, got[:3000])
+
+
+@pytest.mark.parametrize('max_iteration,ones', [(1, False), (5, True), (3, False)])
+def test_small_graph_training_edge_iteration_counts(mutag_graphs, max_iteration, ones):
+    """The persistent training kernels at the ends of the iteration range: one iteration (no barrier between iterations ever taken),
+    and state_0 = ones with threshold 0 - the reference's `state_old = ones_like(state)` makes the very first condition false, k = 0,
+    the loop body never runs, the state network gets zero gradients and the output network trains on state_0."""
+    from test_gpu_training import nets, check_step
+    rng = np.random.default_rng(max_iteration)
+    seq = MultiGraphSequencer(mutag_graphs[:20], 'g', 'average', 20, shuffle=False)
+    x, y, sw = seq[0]
+    d = 32
+    ns, no = nets('g', d, True)
+    model = GNNgraphBased(ns, no, d, max_iteration, 0.0)
+    n = x[0].shape[0]
+    s0 = np.ones((n, d), np.float32) if ones else rng.normal(0, 0.1, (n, d)).astype(np.float32)
+    res, want = check_step(model, x, y, sw, s0)
+    assert res['k'] == (0 if ones else max_iteration)

@@ -38,16 +38,25 @@ class Adam:
         self.iterations, self._slots = 0, {}
 
     def apply_gradients(self, grads_and_vars):
+        """Every variable in ONE launch (`gnn_adam_multi`); the pointer tables are rebuilt only when the set of tensors changes."""
         self.iterations += 1
-        lib = nat.lib()
-        for g, p in grads_and_vars:
-            key = p.data_ptr()
-            if key not in self._slots:
-                self._slots[key] = (torch.zeros_like(p), torch.zeros_like(p), p)
-            m, v, _ = self._slots[key]
-            nat.check(lib.gnn_adam_step(nat.ptr(p), nat.ptr(g), nat.ptr(m), nat.ptr(v), p.numel(),
-                                        float(self.learning_rate), float(self.beta_1), float(self.beta_2),
-                                        float(self.epsilon), self.iterations, nat.current_stream(p.device)))
+        grads_and_vars = list(grads_and_vars)
+        if not grads_and_vars: return
+        key = tuple((g.data_ptr(), p.data_ptr()) for g, p in grads_and_vars)
+        tab = self._slots.get('table')
+        if tab is None or tab[0] != key:
+            for g, p in grads_and_vars:
+                if p.data_ptr() not in self._slots: self._slots[p.data_ptr()] = (torch.zeros_like(p), torch.zeros_like(p), p)
+            n = len(grads_and_vars)
+            arr = lambda vals: (C.c_void_p * n)(*vals)
+            ms = [self._slots[p.data_ptr()][0] for _, p in grads_and_vars]; vs = [self._slots[p.data_ptr()][1] for _, p in grads_and_vars]
+            tab = self._slots['table'] = (key, arr([p.data_ptr() for _, p in grads_and_vars]), arr([g.data_ptr() for g, _ in grads_and_vars]),
+                                          arr([t.data_ptr() for t in ms]), arr([t.data_ptr() for t in vs]),
+                                          (C.c_size_t * n)(*[p.numel() for _, p in grads_and_vars]), n, [g for g, _ in grads_and_vars])
+        _, P, G, M, V, N, n, _keep = tab
+        dev = grads_and_vars[0][1].device
+        nat.check(nat.lib().gnn_adam_multi(P, G, M, V, N, n, float(self.learning_rate), float(self.beta_1), float(self.beta_2),
+                                           float(self.epsilon), self.iterations, nat.current_stream(dev)))
 
 
 class SGD:
@@ -768,6 +777,16 @@ class LoopTrainer:
     use_native_step = True          # False: always the general path below (tests compare the two)
     use_tiles = True                # False: never hand the batch's diagonal blocks to gnn_train_step (tests compare the two forms)
 
+    def _cached_grads(self, name, net, p):
+        c = getattr(self, '_ng_' + name, None)
+        w = net.weights
+        if c is None or c.net is not net or len(c._weights) != len(w) or any(a is not b for a, b in zip(c._weights, w)):
+            c = _NetGrads(net, p)
+            c._weights = list(w)
+            setattr(self, '_ng_' + name, c)
+        c.touched = False
+        return c
+
     def _native_step_applies(self, y):
         m = self.model
         if self.dp is not None: return False        # collectives sit between the iteration's launches: the building-block path
@@ -794,7 +813,9 @@ class LoopTrainer:
         S = d if d > 0 else L
         focus = m._focus
         m.net_state.to(dev); m.net_output.to(dev)
-        gs, go = _NetGrads(m.net_state, p), _NetGrads(m.net_output, p)
+        # gnn_train_step OVERWRITES every gradient buffer: the holders of the previous step are reused as they are (eight zero-fill
+        # launches and their allocations per step otherwise; the optimizer's pointer tables stay valid too)
+        gs, go = self._cached_grads('state', m.net_state, p), self._cached_grads('output', m.net_output, p)
         self.gs, self.go = gs, go
         out_index = m._out_index(_squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev))
         adj, an = adjacency.device_csr(dev), arcnode.device_csr(dev)

@@ -31,7 +31,7 @@ EXPORTS = ['gnn_last_error', 'gnn_last_kernel_name', 'gnn_abi_version', 'gnn_str
            'gnn_shard_can_split', 'gnn_shard_partial', 'gnn_shard_iteration_split',
            'gnn_dense', 'gnn_fold_bn', 'gnn_dense_grad_workspace_bytes', 'gnn_dense_grad', 'gnn_act_grad',
            'gnn_colstats_workspace_bytes', 'gnn_colstats', 'gnn_first_layer_param_grads', 'gnn_bn_input_grad',
-           'gnn_scatter_add_rows', 'gnn_axpby', 'gnn_loss_grad', 'gnn_dropout', 'gnn_adam_step', 'gnn_sgd_step',
+           'gnn_scatter_add_rows', 'gnn_axpby', 'gnn_loss_grad', 'gnn_dropout', 'gnn_adam_step', 'gnn_adam_multi', 'gnn_sgd_step',
            'gnn_converged_gated', 'gnn_aggregate_gated', 'gnn_train_workspace_bytes', 'gnn_train_step', 'gnn_ragged_copy']
 GNN_MAX_SEGMENTS = 6
 LOSSES = {'categorical_crossentropy': 0, 'cce': 0, 'binary_crossentropy': 1, 'bce': 1, 'mse': 2,
@@ -186,6 +186,7 @@ def lib():
             'gnn_loss_grad': (C.c_int, [i32, vp, vp, vp, i32, i32, vp, vp, vp]),
             'gnn_dropout': (C.c_int, [vp, i32, vp, i32, i32, i32, f32, C.c_uint32, i32, i32, vp]),
             'gnn_adam_step': (C.c_int, [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, vp]),
+            'gnn_adam_multi': (C.c_int, [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp]),
             'gnn_sgd_step': (C.c_int, [vp, vp, vp, sz, f32, f32, vp]),
             'gnn_converged_gated': (C.c_int, [vp, vp, i32, i32, i32, f32, vp, vp, vp, f32, vp]),
             'gnn_aggregate_gated': (C.c_int, [C.POINTER(CSR), vp, i32, i32, vp, i32, vp, vp]),

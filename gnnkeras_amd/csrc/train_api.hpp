@@ -204,6 +204,29 @@ int gnn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float 
     return 0;
 }
 
+int gnn_adam_multi(float *const *p, const float *const *g, float *const *m, float *const *v, const size_t *n, int32_t n_vars, float lr,
+                   float beta1, float beta2, float eps, int32_t step, void *stream) {
+    if (n_vars < 0 || (n_vars > 0 && (!p || !g || !m || !v || !n)) || step < 1) return fail("bad arguments");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    for (int j0 = 0; j0 < n_vars; j0 += gnn::ADAM_MAX_JOBS) {
+        gnn::AdamJobs a;
+        memset(&a, 0, sizeof(a));
+        a.blk_begin[0] = 0;
+        for (int j = j0; j < std::min(n_vars, j0 + gnn::ADAM_MAX_JOBS); ++j) {
+            if (n[j] == 0) continue;
+            if (!p[j] || !g[j] || !m[j] || !v[j]) return fail("gnn_adam_multi: variable %d has a NULL array", j);
+            if (n[j] >= ((size_t)1 << 32)) return fail("gnn_adam_multi: variable %d is too large", j);
+            const int q = a.n_jobs++;
+            a.p[q] = p[j]; a.g[q] = g[j]; a.m[q] = m[j]; a.v[q] = v[j]; a.n[q] = (unsigned)n[j];
+            a.blk_begin[q + 1] = a.blk_begin[q] + (int)std::min<long>(cdiv((long)n[j], 256), 1024);
+        }
+        if (a.n_jobs == 0) continue;
+        gnn::k_adam_multi<<<a.blk_begin[a.n_jobs], 256, 0, (hipStream_t)stream>>>(a, lr, beta1, beta2, eps, bc1, bc2);
+        LAUNCH_OK();
+    }
+    return 0;
+}
+
 int gnn_sgd_step(float *p, const float *g, float *velocity, size_t n, float lr, float momentum, void *stream) {
     if (n == 0) return 0;
     if (!p || !g) return fail("bad arguments");

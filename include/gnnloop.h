@@ -311,6 +311,9 @@ int gnn_loss_grad(int32_t kind, const float *y, const float *p, const float *sam
                   float *loss_rows, void *stream);
 int gnn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2, float eps,
                   int32_t step, void *stream);
+/* the same update for every variable of a model in one launch: HOST arrays of n_vars device pointers / element counts */
+int gnn_adam_multi(float *const *p, const float *const *g, float *const *m, float *const *v, const size_t *n, int32_t n_vars, float lr,
+                   float beta1, float beta2, float eps, int32_t step, void *stream);
 int gnn_sgd_step(float *p, const float *g, float *velocity, size_t n, float lr, float momentum, void *stream);
 int gnn_converged_gated(const float *state, const float *state_old, int32_t n, int32_t dim, int32_t ld, float threshold,
                         const int32_t *gate, int32_t *flag, float *k_out, float k_val, void *stream);

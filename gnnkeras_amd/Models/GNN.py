@@ -209,16 +209,21 @@ class _LoopModel:
         logs = {}
         for epoch in range(int(initial_epoch), epochs):
             emit('on_epoch_begin', epoch, {})
-            tot, wsum = {}, 0.0
+            vals, ws = {}, []
             for i in range(len(sequencer)):
                 data = sequencer[i]
                 r = self.train_step(data)
-                w = float(data[1].shape[0]) if data[1] is not None else 1.0
+                ws.append(float(data[1].shape[0]) if data[1] is not None else 1.0)
                 for key, val in r.items():
-                    if key == 'k': continue
-                    tot[key] = tot.get(key, 0.0) + float(val) * w
-                wsum += w
-            logs = {key: val / max(wsum, 1.0) for key, val in tot.items()}
+                    if key != 'k': vals.setdefault(key, []).append(val)        # device scalars stay on the device: no sync per step and value
+            wsum = float(sum(ws))
+            logs = {}
+            for key, lst in vals.items():                          # one transfer per logged quantity and epoch; the weighted mean in float64
+                if all(isinstance(v, torch.Tensor) for v in lst):
+                    v64 = torch.stack([v.detach().reshape(()) for v in lst]).to('cpu', torch.float64).numpy()
+                else:
+                    v64 = np.array([float(v) for v in lst], dtype=np.float64)
+                logs[key] = float((v64 * np.asarray(ws[:len(lst)], dtype=np.float64)).sum() / max(wsum, 1.0))
             if validation_data is not None:
                 logs.update({'val_' + key: val for key, val in self.evaluate(validation_data, return_dict=True).items()})
             for key, val in logs.items(): history.setdefault(key, []).append(val)

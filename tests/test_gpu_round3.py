@@ -583,3 +583,30 @@ def test_small_graph_training_edge_iteration_counts(mutag_graphs, max_iteration,
     s0 = np.ones((n, d), np.float32) if ones else rng.normal(0, 0.1, (n, d)).astype(np.float32)
     res, want = check_step(model, x, y, sw, s0)
     assert res['k'] == (0 if ones else max_iteration)
+
+
+@pytest.mark.parametrize('tiled', [True, False])
+def test_small_graph_training_is_bitwise_reproducible(mutag_graphs, tiled, monkeypatch):
+    """Every cross-tile sum of the persistent training kernels runs in a fixed order (partials in workgroup order, arcs in CSR
+    order, the waves' shares in wave order): two runs of the same step give the same bits - loss, predictions, every gradient."""
+    from test_gpu_training import nets
+    from gnnkeras_amd.Models.training import LoopTrainer, SGD
+    monkeypatch.setattr(LoopTrainer, 'use_tiles', tiled)
+    pool = [g for g in mutag_graphs if g.nodes.shape[0] <= 64] if tiled else mutag_graphs
+    seq = MultiGraphSequencer(pool[:48], 'g', 'average', 48, shuffle=False)
+    x, y, sw = seq[0]
+    ns, no = nets('g', 32, True)
+    model = GNNgraphBased(ns, no, 32, 12, 0.0)
+    model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+    s0 = torch.from_numpy(np.random.default_rng(3).normal(0, 0.1, (x[0].shape[0], 32)).astype(np.float32)).cuda()
+    runs = []
+    for rep in range(3):
+        tr = LoopTrainer(model)
+        res = tr.train_step(x, y, sw, state0=s0, apply=False)
+        torch.cuda.synchronize()
+        runs.append([res['loss'].clone(), res['y_pred'].clone()] + [g.clone() for g in tr.gs.gradients() + tr.go.gradients()])
+        w = model.net_state.get_weights() + model.net_output.get_weights()       # (the step moved the BN moving statistics: restore)
+        if rep == 0: w0 = [a.copy() for a in w]
+        model.net_state.set_weights(w0[:len(model.net_state.get_weights())]); model.net_output.set_weights(w0[len(model.net_state.get_weights()):])
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other): assert torch.equal(a, b)

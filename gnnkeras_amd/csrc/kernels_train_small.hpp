@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels_general.hpp"
 #include "kernel_state_fused4.hpp"      // activate4
+#include "kernel_state_lds.hpp"         // row16_sum_to_lane15
 #include "kernels_train.hpp"            // activate_grad_from_output
 #include "buffer_ops.hpp"
 
@@ -564,56 +565,69 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
         __syncthreads();
         TS_STAMP(0);
         if (tid < S) { const float t3 = ((red[tid] + red[S + tid]) + red[2 * S + tid]) + red[3 * S + tid]; ql_s[tid] = t3; qsum += t3; }
-        // ---- B. Phat_wg = xhat^T dZ on the matrix cores (kept local) -------------------------------------------------------------------------
-        f32x4 P[TPW];
+        // ---- B. dy = dZ . W^T on the matrix cores (operands swapped: lane (c, g) holds columns j0 .. j0 + 3 of row c of its wave) ------------
+        f32x4 dy[2][SQ];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            P[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int ti = wave + 4 * i;
-            if (ti < NT_D) {
-                const int kt = ti / SQ, ht = ti % SQ;
-                const float *xp = Xs + g * LDX + 16 * kt + c, *zp = Zs + g * LDZ + 16 * ht + c;
-#pragma unroll 4
-                for (int ms = 0; ms < 16; ++ms)
-                    P[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[4 * ms * LDX], zp[4 * ms * LDZ], P[i], 0, 0, 0);
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int u = 0; u < SQ; ++u) dy[half][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float *zrow = Zs + (16 * wave + c) * LDZ + 4 * g;
+#pragma unroll 2
+            for (int qq = 0; qq < S / 16; ++qq) {                  // k-step (qq, e) = dZ column 16 qq + 4 g + e: both operands are 16-byte reads
+                const f32x4 zv = *reinterpret_cast<const f32x4 *>(zrow + 16 * qq);
+#pragma unroll
+                for (int u = 0; u < SQ; ++u) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(Wr + (half * S + 16 * u + c) * LDW + 16 * qq + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dy[half][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], zv[e], dy[half][u], 0, 0, 0);
+                }
             }
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) accP[i] += P[i];
         TS_STAMP(1);
-        if (bn) {
-            // P[i][reg] = Phat_wg[16 kt + 4 g + reg][16 ht + c]; S2 share: sum over h of W[k][h] Phat[k][h] (per column tile, then in tile order)
+        // Phat_wg = xhat^T dZ (kept local, summed over the iterations in registers): issued here, behind the partial store when
+        // BatchNormalization makes the tiles wait for each other
+        auto phat = [&]() {
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int ti = wave + 4 * i;
                 if (ti < NT_D) {
                     const int kt = ti / SQ, ht = ti % SQ;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int j = 16 * kt + 4 * g + reg;
-                        float v = Wr[j * LDW + 16 * ht + c] * P[i][reg];
-                        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);   // over the 16 columns
-                        if (c == 0) red[4 * S + ht * 2 * S + j] = v;
-                    }
+                    const float *xp = Xs + g * LDX + 16 * kt + c, *zp = Zs + g * LDZ + 16 * ht + c;
+#pragma unroll 4
+                    for (int ms = 0; ms < 16; ++ms)
+                        accP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[4 * ms * LDX], zp[4 * ms * LDZ], accP[i], 0, 0, 0);
                 }
             }
+        };
+        if (bn) {
+            // S1_j = colsum(dy)_j (= (W q)_j) and S2_j = colsum(dy (.) xhat)_j over the tile's rows: the 16 rows of a wave by lane
+            // exchange, the four waves in wave order
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int u = 0; u < SQ; ++u) {
+                    const int j0 = half * S + 16 * u + 4 * g;
+                    const f32x4 x = *reinterpret_cast<const f32x4 *>(Xs + (16 * wave + c) * LDX + j0);
+                    f32x4 s1 = dy[half][u], s2 = dy[half][u] * x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s1[e] = row16_sum_to_lane15(s1[e]); s2[e] = row16_sum_to_lane15(s2[e]); }      // (VALU only)
+                    if (c == 15) {
+                        *reinterpret_cast<f32x4 *>(red + 4 * S + wave * 4 * S + j0) = s1;
+                        *reinterpret_cast<f32x4 *>(red + 4 * S + wave * 4 * S + 2 * S + j0) = s2;
+                    }
+                }
             __syncthreads();
             if (tid < 4 * S) {
-                float v = 0.0f;
-                if (tid < 2 * S) {                                 // S1 share: (W q_wg)_j
-#pragma unroll 8
-                    for (int h = 0; h < S; ++h) v = fmaf(Wr[tid * LDW + h], ql_s[h], v);
-                    S1sum += v;
-                } else {
-#pragma unroll
-                    for (int ht = 0; ht < SQ; ++ht) v += red[4 * S + ht * 2 * S + tid - 2 * S];           // in column-tile order
-                    S2sum += v;
-                }
+                const float *rp = red + 4 * S + tid;
+                const float v = ((rp[0] + rp[4 * S]) + rp[8 * S]) + rp[12 * S];
+                if (tid < 2 * S) S1sum += v; else S2sum += v;
                 const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + ((size_t)(t & 1) * gridDim.x + blockIdx.x) * 4 * S);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r_p, tid * 4, 0, 16);
             }
             TS_STAMP(2);
+            phat();
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
             grid_barrier(gb, 0, &cont);
             TS_STAMP(3);
             if (tid < 4 * S) {
@@ -626,30 +640,18 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                 cfA[tid] = Ac; cfC[tid] = -Ac * S2_s[tid] * a.inv_n; cfB[tid] = -Ac * S1_s[tid] * a.inv_n;
             }
             __syncthreads();
+        } else {
+            phat();
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
         }
         TS_STAMP(4);
-        // ---- D. dx = BN-gradient(dZ . W^T) on the matrix cores (operands swapped: row-major); state half -> Gs, agg half -> Da / memory ----
+        // ---- D. dx = BN-gradient(dy); state half -> Gs, agg half (scaled once per row) -> Da / memory ------------------------------------
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x4 acc[SQ];
-#pragma unroll
-            for (int u = 0; u < SQ; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float *zrow = Zs + (16 * wave + c) * LDZ + 4 * g;
-#pragma unroll 2
-            for (int qq = 0; qq < S / 16; ++qq) {                  // k-step (qq, e) = dZ column 16 qq + 4 g + e: both operands are 16-byte reads
-                const f32x4 zv = *reinterpret_cast<const f32x4 *>(zrow + 16 * qq);
-#pragma unroll
-                for (int u = 0; u < SQ; ++u) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(Wr + (half * S + 16 * u + c) * LDW + 16 * qq + 4 * g);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], zv[e], acc[u], 0, 0, 0);
-                }
-            }
-            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int u = 0; u < SQ; ++u) {
                 const int j0 = half * S + 16 * u + 4 * g;
-                f32x4 v = acc[u];
+                f32x4 v = dy[half][u];
                 if (bn) {
                     const f32x4 x = *reinterpret_cast<const f32x4 *>(Xs + (16 * wave + c) * LDX + j0);
                     const f32x4 A_ = *reinterpret_cast<const f32x4 *>(cfA + j0), C_ = *reinterpret_cast<const f32x4 *>(cfC + j0), B_ = *reinterpret_cast<const f32x4 *>(cfB + j0);
@@ -665,7 +667,6 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                     else buf_st_sc1(r_dxa, oin ? ((unsigned)orow * (unsigned)S + 16u * u + 4u * g) * 4u : BUF_OFF, v);
                 }
             }
-        }
         TS_STAMP(5);
         if (LOCAL) __syncthreads(); else grid_barrier(gb, 0, &cont);
         TS_STAMP(6);
@@ -775,7 +776,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
 template <int SQ>
 inline size_t train_small_bwd_lds(bool local) {
     constexpr int S = 16 * SQ;
-    return sizeof(float) * (64 * (2 * S + 4) + (local ? 3 : 2) * 64 * (S + 4) + 2 * S * (S + 4) + (S + 16 * S) + 4 * S + SQ * 2 * S + 512);
+    return sizeof(float) * (64 * (2 * S + 4) + (local ? 3 : 2) * 64 * (S + 4) + 2 * S * (S + 4) + (S + 16 * S) + 4 * S + 16 * S + 512);
 }
 
 }  // namespace gnn

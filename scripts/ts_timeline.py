@@ -29,7 +29,7 @@ t = np.array(list(buf), dtype=np.float64).reshape(2, 16) * 0.01 / max(r['k'], 1)
 x = seq[len(seq) - 1][0]
 print(f'd = {d}, {r["k"]} iterations, BatchNormalization {bool(bn)}, batch of {x[0].shape[0]} nodes; us per iteration in workgroup 0 (this build):')
 fw = ['gather + tape', 'statistics partials', 'barrier 1', 'totals, a / c', 'MFMA + epilogue + stores', 'barrier 2']
-bw = ['xhat + dZ (rows prefetched)', 'Phat = xhat^T dZ (MFMA)', 'S1, S2, partials', 'barrier 1', 'totals, coefficients', 'dx (MFMA) + stores', 'barrier 2',
+bw = ['xhat + dZ (rows prefetched)', 'dy = dZ . W^T (MFMA)', 'S1, S2 of dy, partials', 'Phat (MFMA) + barrier 1', 'totals, coefficients', 'BN gradient + stores', 'barrier 2',
       'gather by source']
 print('forward : ' + '; '.join(f'{n} {v:.2f}' for n, v in zip(fw, t[0])) + f'; total {t[0].sum():.2f}')
 print('backward: ' + '; '.join(f'{n} {v:.2f}' for n, v in zip(bw, t[1])) + f'; total {t[1].sum():.2f}')

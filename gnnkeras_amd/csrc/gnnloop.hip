@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "../../include/gnnloop.h"

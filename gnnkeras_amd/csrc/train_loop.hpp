@@ -473,10 +473,14 @@ template <typename Kern, typename Args>
 int launch_persistent(Kern kern, const Args &args, const gnn::TileTab &tt, int n_wg, size_t lds, hipStream_t st) {
     lds = std::max(lds, gnn::TS_LDS);
     static std::vector<const void *> allowed;          // kernels whose dynamic-LDS limit has been raised
+    static std::mutex allowed_mutex;                   // (callers may run steps of different models on different host threads)
     const void *fn = reinterpret_cast<const void *>(kern);
-    if (std::find(allowed.begin(), allowed.end(), fn) == allowed.end()) {
-        HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      // (the same for every launch of one kernel)
-        allowed.push_back(fn);
+    {
+        std::lock_guard<std::mutex> lock(allowed_mutex);
+        if (std::find(allowed.begin(), allowed.end(), fn) == allowed.end()) {
+            HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      // (the same for every launch of one kernel)
+            allowed.push_back(fn);
+        }
     }
     kern<<<n_wg, gnn::TS_NT, lds, st>>>(args, tt);
     LAUNCH_OK();

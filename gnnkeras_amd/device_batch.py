@@ -61,6 +61,10 @@ class DeviceDataset:
         if aggregation_mode not in ('sum', 'average', 'normalized'):
             raise ValueError("device assembly supports 'sum', 'average' and 'normalized' aggregation")
         if any(not type(g) is GraphObject for g in graphs): raise ValueError('device assembly is built for homogeneous GraphObjects')
+        # graph focus: the assembled NodeGraph pools ONE graph per data-set entry (a column of 1 / n); an entry that is itself a merge of
+        # graphs (its NodeGraph has several columns, reference graph_class.py:407) keeps the host path, which block-diagonalises them
+        if focus == 'g' and any(g.NodeGraph.shape[1] != 1 for g in graphs):
+            raise ValueError('device assembly pools one graph per data-set entry')
         self.focus, self.mode, self.device = focus, aggregation_mode, canonical_device(device)
         self.G = len(graphs)
         L = {g.nodes.shape[1] for g in graphs}; A = {g.arcs.shape[1] for g in graphs}; T = {g.targets.shape[1] for g in graphs}

@@ -77,13 +77,15 @@ class GraphSlice:
         values                            their ArcNode / Adjacency entries (reference graph_class.py:105-121: 1, 1 / #arcs of the
                                           whole graph, or 1 / in-degree of the destination - all computable from the slice)
         set_mask / output_mask            of the own nodes
+        arc_mask                          arc-focused graphs: set_mask & output_mask of those arcs (the reference's masks run over arcs there)
+        nodegraph                         graph-focused graphs: (own node, graph, value) triples of NodeGraph's own rows, and #graphs
     plus, for heterogeneous graphs, the own rows of type_mask and the own columns of every CompositeAdjacency.
 
     `from_graph` cuts it out of a replicated `GraphObject`; a generator that can produce a rank's arcs directly
     (`synth.er_graph_slice`) never builds the whole graph's matrices at all."""
 
     def __init__(self, n_nodes, nodes, lo, hi, arc_src, arc_dst, arc_labels, values, set_mask, output_mask, arc_index=None,
-                 composite=None):
+                 composite=None, focus='n', arc_mask=None, nodegraph=None):
         self.n_nodes, self.lo, self.hi = int(n_nodes), int(lo), int(hi)
         self.nodes = np.ascontiguousarray(nodes, dtype=np.float32)
         self.arc_src, self.arc_dst = np.asarray(arc_src, dtype=np.int64), np.asarray(arc_dst, dtype=np.int64)
@@ -92,11 +94,19 @@ class GraphSlice:
         self.set_mask, self.output_mask = np.asarray(set_mask, dtype=bool), np.asarray(output_mask, dtype=bool)
         self.arc_index = None if arc_index is None else np.asarray(arc_index, dtype=np.int64)
         self.composite = composite      # None | dict(type_mask [n_local, T], dim_node_label [T], adjacencies [(row, col, data)] * T)
+        self.focus = focus
+        self.arc_mask = None if arc_mask is None else np.asarray(arc_mask, dtype=bool)
+        self.nodegraph = nodegraph      # None | (row_local i64, graph i64, value f32, n_graphs)
+        if focus == 'a' and (self.arc_mask is None or len(self.arc_mask) != len(self.arc_dst)):
+            raise ValueError('an arc-focused slice needs one mask entry per local arc')
+        if focus == 'g' and nodegraph is None: raise ValueError('a graph-focused slice needs its rows of NodeGraph')
         if len(self.arc_dst) and (self.arc_dst.min() < self.lo or self.arc_dst.max() >= self.hi):
             raise ValueError('a GraphSlice holds the arcs whose destination lies in its own node range')
 
     @classmethod
-    def from_graph(cls, graph: GraphObject, lo: int, hi: int):
+    def from_graph(cls, graph: GraphObject, lo: int, hi: int, focus: str = 'n'):
+        """`focus`: what the graph was built for ('a': its masks run over arcs; 'g': NodeGraph is pooled over) - a `GraphObject` does
+        not remember it (nor does the reference's)."""
         dst = graph.arc_ids[:, 1]
         mine = (dst >= lo) & (dst < hi)
         comp = None
@@ -107,16 +117,24 @@ class GraphSlice:
                 keep = (ca.col >= lo) & (ca.col < hi)
                 cas.append((ca.row[keep].astype(np.int64), ca.col[keep].astype(np.int64), ca.data[keep].astype(np.float32)))
             comp = dict(type_mask=graph.type_mask[lo:hi], dim_node_label=[int(d) for d in graph.DIM_NODE_LABEL], adjacencies=cas)
+        set_mask, output_mask, arc_mask, nodegraph = graph.set_mask[lo:hi], graph.output_mask[lo:hi], None, None
+        if focus == 'a':                 # masks run over ARCS (reference GNN.py:317-330): the nodes carry none
+            arc_mask = (np.asarray(graph.set_mask, dtype=bool) & np.asarray(graph.output_mask, dtype=bool))[mine]
+            set_mask = output_mask = np.ones(hi - lo, dtype=bool)
+        elif focus == 'g':
+            ng = graph.NodeGraph.tocsr()[lo:hi].tocoo()
+            nodegraph = (ng.row.astype(np.int64), ng.col.astype(np.int64), ng.data.astype(np.float32), int(graph.NodeGraph.shape[1]))
         return cls(graph.nodes.shape[0], graph.nodes, lo, hi, graph.arc_ids[mine, 0], dst[mine], graph.arcs[mine][:, 2:],
                    graph.ArcNode.data[mine],                       # aggregation weights computed on the WHOLE graph
-                   graph.set_mask[lo:hi], graph.output_mask[lo:hi], arc_index=np.flatnonzero(mine), composite=comp)
+                   set_mask, output_mask, arc_index=np.flatnonzero(mine), composite=comp, focus=focus, arc_mask=arc_mask,
+                   nodegraph=nodegraph)
 
 
 class ShardPlan:
     """Host-side (numpy) description of one rank's shard: local CSR operators in padded-row space.  `graph`: the replicated
     `GraphObject`, or just this rank's `GraphSlice`."""
 
-    def __init__(self, graph, rank: int, world_size: int):
+    def __init__(self, graph, rank: int, world_size: int, focus: str = 'n'):
         N = graph.n_nodes if isinstance(graph, GraphSlice) else graph.nodes.shape[0]
         self.N, self.rank, self.world_size = N, rank, world_size
         self.chunk, self.ranges = partition(N, world_size)
@@ -125,7 +143,7 @@ class ShardPlan:
         self.rows_per_slice = self.chunk + 1
         self.n_rows_full = world_size * self.rows_per_slice
         self.row_base = rank * self.rows_per_slice
-        gs = graph if isinstance(graph, GraphSlice) else GraphSlice.from_graph(graph, self.lo, self.hi)
+        gs = graph if isinstance(graph, GraphSlice) else GraphSlice.from_graph(graph, self.lo, self.hi, focus)
         if (gs.lo, gs.hi) != (self.lo, self.hi):
             raise ValueError(f'rank {rank} of {world_size} owns nodes [{self.lo}, {self.hi}); the slice covers [{gs.lo}, {gs.hi})')
         self.L, self.A = gs.nodes.shape[1], gs.arc_labels.shape[1]
@@ -145,6 +163,21 @@ class ShardPlan:
         nodes_full[padded_row(np.arange(N), self.chunk)] = gs.nodes
         self.nodes_full = nodes_full
         self.out_index = np.flatnonzero(gs.set_mask & gs.output_mask).astype(np.int32)
+        self.focus = gs.focus
+        if gs.focus == 'g':
+            # per-node outputs of EVERY own node (the reference's pooling matmul fails when a node is masked out, GNN.py:345), pooled
+            # with the own rows of NodeGraph; the per-graph partial sums of the ranks are added by one all-reduce
+            if len(self.out_index) != self.n_local: raise ValueError('graph focus: every node must pass set_mask & output_mask')
+            row, col, val, self.n_graphs = gs.nodegraph
+            self.nodegraph = CSRByDestination.from_coo(row, col, val, (self.n_local, self.n_graphs))
+        elif gs.focus == 'a':
+            # arcs live with their destination: the own arcs that pass the arc masks, in the graph's arc order; their end points
+            # as rows of the exchanged state buffer (sources may be anybody's) - no per-node outputs at all
+            self.out_index = np.zeros(0, dtype=np.int32)
+            self.arc_out = np.flatnonzero(gs.arc_mask)
+            self.arc_out_src_rows = src_rows[self.arc_out]
+            self.arc_out_dst_rows = self.row_base + dst_local[self.arc_out]
+            self.arc_out_index = None if gs.arc_index is None else gs.arc_index[self.arc_out]      # global arc ids of the output rows
         self.per_arc_weights = self.adjacency.w is not None
         # heterogeneous graphs: local node ids grouped by type + the per-source-type adjacencies of the label aggregate
         self.composite = gs.composite is not None
@@ -168,23 +201,28 @@ class ShardPlan:
 
 
 class ShardedLoop:
-    """Forward pass of a node-focused homogeneous GNN on one rank's node range.
+    """Forward pass of a GNN on one rank's node range.
 
-        sl = ShardedLoop(model, graph, rank, world_size, device)      # graph replicated on the hosts
+        sl = ShardedLoop(model, graph, rank, world_size, device)      # graph replicated on the hosts, or the rank's GraphSlice
         k, state_local, out_local = sl.forward(state0_full)           # collective: every rank calls it
 
-    `state_local` / `out_local` cover the rank's own nodes [lo, hi) (masked ones for `out`)."""
+    `state_local` covers the rank's own nodes [lo, hi).  `out_local`: node focus - the masked own nodes; ARC focus (homogeneous
+    models, reference GNN.py:317-330) - the masked arcs whose destination the rank owns, in arc order (`plan.arc_out_index` = their
+    global arc ids: the ranks' rows interleave in the whole graph's order); GRAPH focus (GNN.py:341-346) - the pooled [#graphs, T]
+    outputs, complete on every rank (per-graph partial sums over the own nodes, one all-reduce)."""
 
     def __init__(self, model, graph, rank: int, world_size: int, device, group=None, overlap: bool = False):
         """`graph`: the replicated `GraphObject` / `CompositeGraphObject`, or this rank's `GraphSlice` (a rank never needs more)."""
-        if model._focus != 'n':
-            raise NotImplementedError('sharding is built for node-focused models (BASELINE configs C4 / C5)')
         self.composite = isinstance(model.net_state, (list, tuple))
+        self.focus = model._focus
+        if self.focus != 'n' and (self.composite or type(self)._layout != 'allgather'):
+            raise NotImplementedError('arc- / graph-focused sharding: homogeneous models on the all-gather layout')
         self.model, self.group = model, group
         self.rank, self.world_size = rank, world_size
         self.device = torch.device(device)
         self.overlap = bool(overlap)
-        self.plan = p = ShardPlan(graph, rank, world_size)
+        self.plan = p = ShardPlan(graph, rank, world_size, self.focus)
+        if p.focus != self.focus: raise ValueError(f"the model is '{self.focus}'-focused, the graph '{p.focus}'-focused")
         if self.composite != p.composite:
             raise ValueError('composite models need CompositeGraphObject graphs (and vice versa)')
         self.n_local, self.e_local, self.per_arc_weights = p.n_local, p.e_local, p.per_arc_weights
@@ -196,7 +234,51 @@ class ShardedLoop:
         self.buf = [torch.zeros((p.n_rows_full + self.n_virtual_rows, self.SP), dtype=torch.float32, device=self.device) for _ in range(2)]
         self._iter_events = None
 
-    # ---- device-specific pieces (the gloo/CPU tests override these four with numpy stand-ins) --------------------------
+    _layout = 'allgather'
+
+    # ---- device-specific pieces (the gloo/CPU tests override these with numpy stand-ins) ------------------------------------
+    def _pool(self, out_nodes):
+        """Graph focus: [#graphs, T] partial sums of NodeGraph^T . out over the own nodes."""
+        p, dev = self.plan, self.device
+        if not hasattr(self, 'd_ng'):
+            up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            c = p.nodegraph
+            self.d_ng = dict(rowptr=up(c.rowptr), src=up(c.src), w=up(c.w), row_scale=up(c.row_scale), n_src=c.n_src, n_dst=c.n_dst, nnz=c.nnz)
+        T = out_nodes.shape[1]
+        pooled = torch.zeros((p.n_graphs, T), dtype=torch.float32, device=dev)
+        if p.n_local > 0:
+            csr = nat.make_csr(self.d_ng)
+            nat.check(nat.lib().gnn_aggregate(C.byref(csr), nat.ptr(out_nodes), T, T, nat.ptr(pooled), T, nat.current_stream(dev)))
+        return pooled
+
+    def _arc_outputs(self, k):
+        """Arc focus: net_output([state_src | labels_src | state_dst | labels_dst | arc label]) of the own masked arcs (the label
+        columns only when the state is not the labels themselves, GNN.py:239-242), from the exchanged buffer the loop ended on."""
+        p, dev, m = self.plan, self.device, self.model
+        if not hasattr(self, 'd_arc_rows'):
+            self.d_arc_rows = (torch.from_numpy(p.arc_out_src_rows).to(dev), torch.from_numpy(p.arc_out_dst_rows).to(dev),
+                               torch.from_numpy(np.ascontiguousarray(p.arc_labels[p.arc_out])).to(dev))
+        rs, rd, lab = self.d_arc_rows
+        buf = self.buf[int(k) & 1]
+        parts = []
+        for rows in (rs, rd):
+            parts.append(buf[rows, :self.S])
+            if m.state_vect_dim > 0: parts.append(self.d_nodes_full[rows])
+        parts.append(lab)
+        x = torch.cat(parts, dim=1)
+        if x.shape[0] == 0: return torch.zeros((0, m.net_output.units[-1]), dtype=torch.float32, device=dev)
+        return m.net_output.to(dev)(x)
+
+    def _finish(self, k, state_local, out_nodes):
+        """Node focus: the masked own nodes' outputs as they are; arc / graph focus: see the class docstring."""
+        if self.focus == 'g':
+            pooled = self._pool(out_nodes)
+            if self.world_size > 1: dist.all_reduce(pooled, group=self.group)
+            return k, state_local, pooled
+        if self.focus == 'a':
+            return k, state_local, self._arc_outputs(float(k))
+        return k, state_local, out_nodes
+
     def _state_ld(self, S):
         return int(nat.lib().gnn_state_ld(S))
 
@@ -246,6 +328,12 @@ class ShardedLoop:
         a.net_output = m.net_output.to(dev).native()
         a.state_dim, a.max_iteration, a.state_threshold = m.state_vect_dim, m.max_iteration, float(m.state_threshold)
         a.focus = nat.FOCUS['n']
+        if self.focus == 'a':
+            # the library only runs the loop here (n_out = 0: its output stage has nothing to do); the arc-shaped output network is
+            # applied by _arc_outputs.  The focus tells the argument check which input width to expect.
+            a.focus = nat.FOCUS['a']
+            self.d_arc_ends = torch.zeros(max(p.e_local, 1), dtype=torch.int32, device=dev)
+            a.arc_src = a.arc_dst = nat.ptr(self.d_arc_ends)
         a.n_out, a.out_index = len(p.out_index), nat.ptr(self.d_out_index)
         a.flags = m.native_flags
         self.k = torch.zeros((), dtype=torch.float32, device=dev)
@@ -387,7 +475,7 @@ class ShardedLoop:
             for it in range(m.max_iteration):
                 self._iteration(it)
                 self._exchange(self.buf[(it + 1) & 1], it)
-            return self._output()
+            return self._finish(*self._output())
         # own-range arcs of iteration it+1 are summed while the exchange of iteration it is in flight
         if m.max_iteration > 0: self._partial(0)                        # state_0 is complete on every rank
         for it in range(m.max_iteration):
@@ -395,7 +483,7 @@ class ShardedLoop:
             work = self._exchange(self.buf[(it + 1) & 1], it, async_op=True)
             if it + 1 < m.max_iteration: self._partial(it + 1)          # reads only the rows this rank has just written
             self._exchange_finish(work, self.buf[(it + 1) & 1], it)
-        return self._output()
+        return self._finish(*self._output())
 
     def plan_nodes_as_state(self):
         """state_vect_dim == 0: state0 = node labels (GNN.py:259)."""
@@ -563,9 +651,13 @@ class HaloShardedLoop(ShardedLoop):
     """`ShardedLoop` with the compacted halo exchange: per iteration one fused kernel, one row-gather that packs what
     each peer reads, one `all_to_all_single` (uneven splits, direct pair-wise transfers)."""
 
+    _layout = 'halo'
+
     def __init__(self, model, graph: GraphObject, rank: int, world_size: int, device, group=None, overlap: bool = False):
         if model._focus != 'n':
-            raise NotImplementedError('sharding is built for node-focused models (BASELINE configs C4 / C5)')
+            raise NotImplementedError('the compacted halo exchange is built for node-focused models; arc- / graph-focused models '
+                                      'shard on the all-gather layout (ShardedLoop)')
+        self.focus = 'n'
         self.composite = isinstance(model.net_state, (list, tuple))
         if self.composite != hasattr(graph, 'type_mask'):
             raise ValueError('composite models need CompositeGraphObject graphs (and vice versa)')

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 from gnnkeras_amd import GraphObject
 from gnnkeras_amd.distributed import ShardedLoop, ShardPlan, HaloShardedLoop, HaloShardPlan, partition, padded_row, choose_exchange, split_csr
 from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
-from gnnkeras_amd.Models.GNN import GNNnodeBased
+from gnnkeras_amd.Models.GNN import GNNnodeBased, GNNarcBased, GNNgraphBased
 from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
 from gnnkeras_amd.synth import er_graph
 from oracle import gnn_oracle as O
@@ -133,8 +133,34 @@ class OracleShardedLoop(ShardedLoop):
         buf = self.buf[int(self.k) & 1].numpy()
         state = buf[p.row_base:p.row_base + p.n_local, :self.S]
         inp = np.concatenate([state, p.nodes_local], 1) if m.state_vect_dim > 0 else state
+        if getattr(self, 'focus', 'n') == 'a':                 # (arc focus: the library's output stage has no rows; _arc_outputs does the work)
+            return self.k, torch.from_numpy(state.copy()), torch.zeros((0, m.net_output.units[-1]))
         out = O.mlp_apply(*m.net_output.spec(), inp[p.out_index], False, self.dtype)
         return self.k, torch.from_numpy(state.copy()), torch.from_numpy(out.astype(np.float32))
+
+
+def _oracle_pool(self, out_nodes):
+    p = self.plan
+    idx, w, _ = csr_to_coo(p.nodegraph)                       # rows = own nodes, columns = graphs
+    pooled = np.zeros((p.n_graphs, out_nodes.shape[1]), self.dtype)
+    np.add.at(pooled, idx[:, 1], w[:, None] * out_nodes.numpy().astype(self.dtype)[idx[:, 0]])
+    return torch.from_numpy(pooled.astype(np.float32))
+
+
+def _oracle_arc_outputs(self, k):
+    p, m = self.plan, self.model
+    buf = self.buf[int(k) & 1].numpy()[:, :self.S]
+    parts = []
+    for rows in (p.arc_out_src_rows, p.arc_out_dst_rows):
+        parts.append(buf[rows])
+        if m.state_vect_dim > 0: parts.append(p.nodes_full[rows])
+    parts.append(p.arc_labels[p.arc_out])
+    x = np.concatenate(parts, axis=1)
+    return torch.from_numpy(O.mlp_apply(*m.net_output.spec(), x, False, self.dtype).astype(np.float32))
+
+
+OracleShardedLoop._pool = _oracle_pool
+OracleShardedLoop._arc_outputs = _oracle_arc_outputs
 
 
 class OracleHaloShardedLoop(HaloShardedLoop):
@@ -423,3 +449,81 @@ def test_whole_slice_transports_agree(transport, overlap):
         assert p.exitcode == 0
     assert all(r[1] == float(k_ref) for r in res)
     assert rel_err(np.concatenate([r[2] for r in res]), st_ref) < 1e-6 and rel_err(np.concatenate([r[3] for r in res]), out_ref) < 1e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# arc- and graph-focused models on shards (reference GNN.py:317-330, :341-346)
+# ----------------------------------------------------------------------------------------------------------------------
+def _problem_focus(focus, d):
+    rng = np.random.default_rng(3)
+    if focus == 'a':
+        g0 = er_graph(203, 1500, dim_node_label=5, dim_arc_label=2, seed=7)
+        E = g0.arcs.shape[0]
+        om = rng.random(E) < 0.6
+        g = GraphObject(g0.nodes, g0.arcs, rng.normal(size=(int(om.sum()), 2)), focus='a', set_mask=rng.random(E) < 0.9, output_mask=om,
+                        aggregation_mode='average')
+        n_t = int((g.set_mask & g.output_mask).sum())
+        g = GraphObject(g0.nodes, g0.arcs, rng.normal(size=(int(om.sum()), 2)), focus='a', set_mask=g.set_mask, output_mask=om,
+                        aggregation_mode='average')
+        cls = GNNarcBased
+    else:
+        parts = [er_graph(n, 6 * n, dim_node_label=5, dim_arc_label=2, seed=11 + n) for n in (40, 71, 23, 69)]      # 203 nodes, 4 graphs
+        parts = [GraphObject(q.nodes, q.arcs, rng.normal(size=(1, 2)), focus='g', aggregation_mode='average') for q in parts]
+        g = GraphObject.merge(parts, focus='g', aggregation_mode='average')
+        cls = GNNgraphBased
+    inp, lay = get_inout_dims('state', 5, 2, 2, focus, d)
+    ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=0, device='cpu')
+    ns.set_weights([w * 0.4 if w.ndim == 2 else w for w in ns.get_weights()])
+    inp, lay = get_inout_dims('output', 5, 2, 2, focus, d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1, device='cpu')
+    model = cls(ns, no, d, 7, 0.01)
+    N = g.nodes.shape[0]
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32) if d else None
+    return g, model, s0
+
+
+def _worker_focus(rank, world, port, focus, d, overlap, from_slice, out_q):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g, model, s0 = _problem_focus(focus, d)
+        if from_slice:
+            from gnnkeras_amd.distributed import GraphSlice
+            g = GraphSlice.from_graph(g, *partition(g.nodes.shape[0], world)[1][rank], focus=focus)
+        sl = OracleShardedLoop(model, g, rank, world, 'cpu', overlap=overlap)
+        k, state, out = sl.forward(s0)
+        ids = sl.plan.arc_out_index if focus == 'a' else None
+        out_q.put((rank, float(k), state.numpy(), out.numpy(), ids))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('focus,d,world,overlap,from_slice', [('a', 6, 2, False, False), ('a', 0, 3, True, True), ('g', 6, 3, False, True),
+                                                              ('g', 0, 2, True, False)])
+def test_arc_and_graph_focused_models_on_shards(focus, d, world, overlap, from_slice):
+    """Arc focus: every rank applies the output network to the masked arcs whose DESTINATION it owns (their sources' final states
+    come out of the exchanged buffer); the ranks' rows, placed by their global arc ids, are the single-process output.  Graph focus:
+    per-graph partial sums over the own nodes, one all-reduce; every rank ends with the complete pooled output.  Graph boundaries do
+    not coincide with the shard boundaries."""
+    g, model, s0 = _problem_focus(focus, d)
+    seq = MultiGraphSequencer([g], focus, 'average', 1, shuffle=False, device='cpu')
+    k_ref, st_ref, out_ref = oracle_loop(model, seq[0][0], s0, np.float64)
+    assert 1 < k_ref <= model.max_iteration
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 311 * (focus == 'a') + 17 * world + d) % 1000
+    procs = [ctx.Process(target=_worker_focus, args=(r, world, port, focus, d, overlap, from_slice, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] == float(k_ref) for r in res)
+    assert rel_err(np.concatenate([r[2] for r in res]), st_ref) < 1e-6
+    if focus == 'g':
+        for r in res: assert r[3].shape == out_ref.shape and rel_err(r[3], out_ref) < 1e-6          # complete on every rank
+    else:
+        mask = np.flatnonzero(g.set_mask & g.output_mask)                       # global arc ids of the output rows, ascending
+        out = np.full(out_ref.shape, np.nan, dtype=np.float32)
+        for r in res: out[np.searchsorted(mask, r[4])] = r[3]
+        assert sum(len(r[4]) for r in res) == len(mask) and rel_err(out, out_ref) < 1e-6

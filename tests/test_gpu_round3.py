@@ -610,3 +610,60 @@ def test_small_graph_training_is_bitwise_reproducible(mutag_graphs, tiled, monke
         model.net_state.set_weights(w0[:len(model.net_state.get_weights())]); model.net_output.set_weights(w0[len(model.net_state.get_weights()):])
     for other in runs[1:]:
         for a, b in zip(runs[0], other): assert torch.equal(a, b)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# arc- and graph-focused models on shards: the device pieces (emulated ranks on one GPU; the collectives run in tests/test_distributed.py)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('focus,d', [('a', 32), ('g', 32), ('a', 0), ('g', 0)])
+def test_arc_and_graph_focused_shards_on_the_device(focus, d):
+    """Reference GNN.py:317-330 / :341-346 on node-range shards: 3 emulated ranks, the real shard kernels for the loop, then per rank
+    the arc-shaped output network over the masked arcs it owns (sources read from the exchanged buffer) or the per-graph partial sums
+    of its nodes' outputs; assembled / added, they are the oracle's output on the whole graph."""
+    from gnnkeras_amd.distributed import ShardedLoop, GraphSlice, partition
+    from gnnkeras_amd.Models.GNN import GNNarcBased
+    from test_gpu_parity import starter_nets
+    rng = np.random.default_rng(5)
+    R, K = 3, 5
+    if focus == 'a':
+        g0 = er_graph(5003, 30000, seed=7)
+        E = g0.arcs.shape[0]
+        om = rng.random(E) < 0.6
+        sm = rng.random(E) < 0.9
+        g = GraphObject(g0.nodes, g0.arcs, rng.normal(size=(int(om.sum()), 2)), focus='a', set_mask=sm, output_mask=om,
+                        aggregation_mode='average')
+        cls = GNNarcBased
+    else:
+        parts = [er_graph(n, 6 * n, seed=11 + n) for n in (1400, 2071, 523, 1009)]
+        parts = [GraphObject(q.nodes, q.arcs, rng.normal(size=(1, 2)), focus='g', aggregation_mode='average') for q in parts]
+        g = GraphObject.merge(parts, focus='g', aggregation_mode='average')
+        cls = GNNgraphBased
+    N = g.nodes.shape[0]
+    ns, no = starter_nets(focus, d, scale=0.3, act='tanh')
+    model = cls(ns, no, d, K, 0.0)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32) if d else None
+    x = MultiGraphSequencer([g], focus, 'average', 1, shuffle=False)[0][0]
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    shards = [ShardedLoop(model, GraphSlice.from_graph(g, lo, hi, focus=focus), r, R, 'cuda') for r, (lo, hi) in enumerate(partition(N, R)[1])]
+    for sl in shards:
+        if d: sl._load_state0(torch.from_numpy(s0).cuda())
+        else: sl._load_state0(sl.plan_nodes_as_state())
+        sl._setup(); sl._initial_flags()
+    n = shards[0].plan.rows_per_slice * shards[0].SP
+    for it in range(K):
+        for sl in shards: sl._iteration(it)
+        for r, src in enumerate(shards):
+            piece = src.buf[(it + 1) & 1].view(-1)[r * n:(r + 1) * n]
+            for dst in shards:
+                if dst is not src: dst.buf[(it + 1) & 1].view(-1)[r * n:(r + 1) * n].copy_(piece)
+    outs = [sl._output() for sl in shards]
+    assert all(float(o[0]) == float(k64) for o in outs)
+    assert rel_err(np.concatenate([o[1].cpu().numpy() for o in outs]), st64) <= TOL
+    if focus == 'g':
+        pooled = sum(sl._pool(o[2]) for sl, o in zip(shards, outs)).cpu().numpy()
+        assert pooled.shape == o64.shape and rel_err(pooled, o64) <= TOL
+    else:
+        mask = np.flatnonzero(g.set_mask & g.output_mask)
+        out = np.full(o64.shape, np.nan, dtype=np.float32)
+        for sl, o in zip(shards, outs): out[np.searchsorted(mask, sl.plan.arc_out_index)] = sl._arc_outputs(float(o[0])).cpu().numpy()
+        assert rel_err(out, o64) <= TOL

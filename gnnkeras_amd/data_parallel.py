@@ -100,11 +100,19 @@ def shard_bounds(n_items: int, rank: int, world: int):
 class DataParallel:
     """`DataParallel(model).fit / evaluate / predict(sequencer)`: the Keras-style calls of the wrapped model, collectively over
     the ranks of `group`.  Every rank constructs the same model (same weights) and the same sequencer (same graphs, same order)
-    and calls the same method; results are identical on every rank."""
+    and calls the same method; results are identical on every rank.
 
-    def __init__(self, model, group=None):
+    `exact=True` (default): a training step reproduces the single-process step on the whole batch (statistics, loop condition and
+    gradients span the ranks; the collectives sit between the iteration's launches, so it runs the building-block orchestration).
+    `exact=False` ("replicas", SURVEY 8e's trivial fallback and what data-parallel training usually means): every rank runs the
+    WHOLE in-library step (`gnn_train_step`: the persistent kernels on MUTAG-sized shards) on its shard alone - its own batch
+    statistics, its own iteration count - and one all-reduce averages the gradients weighted by target rows (plus the
+    BatchNormalization moving statistics): not the reference's step on the merged batch, an order of magnitude less device time."""
+
+    def __init__(self, model, group=None, exact: bool = True):
         if isinstance(getattr(model, 'net_state', None), (list, tuple)):
             raise NotImplementedError('data-parallel training covers homogeneous models (per-type row lists may be empty on a shard)')
+        self.exact = bool(exact)
         self.model, self.group = model, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.dp = DPContext(group)
@@ -125,11 +133,14 @@ class DataParallel:
         from .Models.training import LoopTrainer
         m = self.model
         if m.loss is None: raise RuntimeError('compile() the model with a loss before fit() / train_step()')
-        if self._trainer is None: self._trainer = LoopTrainer(m, dp=self.dp)
+        if self._trainer is None: self._trainer = LoopTrainer(m, dp=self.dp if self.exact else None)
         x, y, sample_weight = data
         self.dp.set_device(x[0].device)
         self.dp._counts = {}
-        res = self._trainer.train_step(x, y, sample_weight, state0=state0, seed=seed, apply=apply)
+        if not self.exact:
+            res = self._replica_step(x, y, sample_weight, state0, seed, apply)
+        else:
+            res = self._trainer.train_step(x, y, sample_weight, state0=state0, seed=seed, apply=apply)
         out = {'loss': res['loss'], 'k': res['k'], 'y_pred': res['y_pred']}
         if y is not None and m.metrics_spec:
             yd = y.to(res['y_pred'].device)
@@ -138,6 +149,36 @@ class DataParallel:
             self.dp.all_reduce_sum(sums)
             for i, mm in enumerate(m.metrics_spec): out[_metric_fn(mm, yd.shape[-1])[0]] = sums[i] / sums[-1]
         return out
+
+    def _replica_step(self, x, y, sample_weight, state0, seed, apply):
+        """The single-process step on this rank's shard, then ONE all-reduce: gradients and loss weighted by the shard's share of the
+        batch's target rows (each rank's loss is a mean over its own rows), BatchNormalization moving statistics averaged, k = the
+        largest of the ranks' iteration counts."""
+        tr, m = self._trainer, self.model
+        res = tr.train_step(x, y, sample_weight, state0=state0, seed=seed, apply=False)
+        gs = tr.gs if isinstance(tr.gs, (list, tuple)) else [tr.gs]
+        pairs = [gv for g_ in list(gs) + [tr.go] for gv in zip(g_.gradients(), g_.variables())]
+        grads = [g for g, _ in pairs]
+        moving = [t for g_ in list(gs) + [tr.go] if g_.bn for t in g_.moving]
+        dev = grads[0].device
+        rows = float(y.shape[0]) if y is not None else 0.0
+        head = torch.tensor([rows, 0.0, float(res['k'])], dtype=torch.float32, device=dev)
+        head[1] = res['loss'].detach().reshape(()) * rows
+        flat = torch.cat([head[:2]] + [g.reshape(-1) * rows for g in grads] + [t.reshape(-1) for t in moving])
+        kmax = head[2:3].clone()
+        if self.world > 1:
+            dist.all_reduce(flat, group=self.group)
+            dist.all_reduce(kmax, op=dist.ReduceOp.MAX, group=self.group)
+        total = flat[0].clamp(min=1.0)
+        off = 2
+        for g in grads:
+            n = g.numel(); g.copy_((flat[off:off + n] / total).view_as(g)); off += n
+        for t in moving:
+            n = t.numel(); t.copy_((flat[off:off + n] / self.world).view_as(t)); off += n
+        res = dict(res, loss=flat[1] / total, k=int(kmax.item()))
+        self._rows_total = float(flat[0])
+        if apply: m._optimizer_obj().apply_gradients(pairs)
+        return res
 
     def fit(self, sequencer, epochs: int = 1, validation_data=None, verbose: int = 1, callbacks=None, **kwargs):
         """The single-process `fit` with every batch sharded over the ranks (same batches, same order, same updates)."""
@@ -152,7 +193,7 @@ class DataParallel:
             for i in range(len(sequencer)):
                 data = self.shard(sequencer, i)
                 r = self.train_step(data)
-                w = float(self.dp.total_rows('targets'))
+                w = float(self.dp.total_rows('targets')) if self.exact else self._rows_total
                 for key, val in r.items():
                     if key in ('k', 'y_pred'): continue
                     tot[key] = tot.get(key, 0.0) + float(val) * w

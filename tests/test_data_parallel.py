@@ -259,8 +259,26 @@ def _dp_worker(rank, world, port, focus, hidden, thr, mode, q):
         nat.require_device = lambda t, name: None
         from gnnkeras_amd.data_parallel import DataParallel
         model, seq, s0, gl = _problem(focus, hidden, thr)
-        dpm = DataParallel(model)
-        if mode == 'step':
+        dpm = DataParallel(model, exact=(mode != 'replica'))
+        if mode == 'replica':
+            # "replicas": the single-process step on the own shard, then one weighted all-reduce
+            shard = dpm.shard(seq, 0)
+            sizes = [g.nodes.shape[0] for g in gl]
+            lo, hi = len(gl) * rank // world, len(gl) * (rank + 1) // world
+            n0 = sum(sizes[:lo]); n1 = n0 + sum(sizes[lo:hi])
+            st = None if s0 is None else torch.from_numpy(s0[n0:n1])
+            own = TR.LoopTrainer(model)
+            before = [w.copy() for w in model.net_state.get_weights() + model.net_output.get_weights()]
+            r_own = own.train_step(shard[0], shard[1], shard[2], state0=st, apply=False)
+            g_own = [g.numpy().copy() for g in own.gs.gradients() + own.go.gradients()]
+            mv_own = [w.copy() for w in model.net_state.get_weights()[2:4] + model.net_output.get_weights()[2:4]]
+            model.net_state.set_weights(before[:len(model.net_state.get_weights())]); model.net_output.set_weights(before[len(model.net_state.get_weights()):])
+            res = dpm.train_step(shard, state0=st, apply=False)
+            tr = dpm._trainer
+            grads = [g.numpy().copy() for g in tr.gs.gradients() + tr.go.gradients()]
+            moving = [w.copy() for w in model.net_state.get_weights()[2:4] + model.net_output.get_weights()[2:4]]
+            q.put((rank, res['k'], float(res['loss']), grads, moving, float(shard[1].shape[0]), r_own['k'], float(r_own['loss']), g_own, mv_own))
+        elif mode == 'step':
             shard = dpm.shard(seq, 0)
             sizes = [g.nodes.shape[0] for g in gl]
             lo, hi = len(gl) * rank // world, len(gl) * (rank + 1) // world
@@ -323,3 +341,20 @@ def test_data_parallel_fit_predict_evaluate_match_the_single_process_calls():
     for a, b in zip(model.net_state.get_weights() + model.net_output.get_weights(), w0):
         assert np.max(np.abs(a - b)) <= 1e-6 * max(1.0, np.max(np.abs(a)))
     assert np.allclose(hist['loss'], h0['loss'], atol=1e-6) and np.allclose(hist['accuracy'], h0['accuracy'], atol=1e-6)
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_replica_mode_averages_the_single_process_steps_of_the_shards(world):
+    """`DataParallel(model, exact=False)`: every rank runs the ordinary single-process step on its shard (own batch statistics, own k)
+    and ONE all-reduce combines them - gradients and loss weighted by the shards' target rows, moving statistics averaged, k = the
+    maximum: checked against the same combination formed by hand from the per-rank single-process results; identical on every rank."""
+    res = _run(world, 'g', None, 0.0, 'replica')
+    rows = np.array([r[5] for r in res]); wts = rows / rows.sum()
+    want_g = [sum(w * r[8][i] for w, r in zip(wts, res)) for i in range(len(res[0][8]))]
+    want_loss = float(sum(w * r[7] for w, r in zip(wts, res)))
+    want_mv = [sum(r[9][i] for r in res) / world for i in range(len(res[0][9]))]
+    for rank, k, loss, grads, moving, _, k_own, _, _, _ in res:
+        assert k == max(r[6] for r in res) and abs(loss - want_loss) <= 1e-6
+        for a, b in zip(grads, want_g): assert np.max(np.abs(a - b)) <= 1e-6 * max(1.0, np.max(np.abs(b)))
+        for a, b in zip(moving, want_mv): assert np.max(np.abs(a - b)) <= 1e-6
+    for a, b in zip(res[0][3], res[-1][3]): assert np.array_equal(a, b)

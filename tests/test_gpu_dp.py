@@ -88,6 +88,22 @@ WORKER = textwrap.dedent('''
     dist.all_gather(parts, w)
     assert all(torch.equal(parts[0], p_) for p_ in parts), 'ranks diverged'
     assert len(hist['loss']) == 2 and np.isfinite(hist['loss']).all() and 'val_loss' in hist
+    # "replicas" mode: the in-library step (gnn_train_step, persistent kernels) on the own shard + one weighted all-reduce over RCCL;
+    # at world size 1 it is the single-process step; at any size every rank ends an epoch with the same weights
+    model_r = build()
+    dpr = DataParallel(model_r, exact=False)
+    res_r = dpr.train_step(dpr.shard(seq, 0), state0=torch.from_numpy(s0[n0:n1]).to(dev), apply=False)
+    assert dpr._trainer.dp is None
+    if world == 1:
+        got_r = [g.cpu().numpy() for g in dpr._trainer.gs.gradients() + dpr._trainer.go.gradients()]
+        assert res_r['k'] == ref['k'] and abs(float(res_r['loss']) - float(ref['loss'])) <= 1e-6
+        for g, r in zip(got_r, ref_grads): assert np.max(np.abs(g - r)) <= 1e-6 * max(1.0, float(np.max(np.abs(r))))
+    hist_r = dpr.fit(MultiGraphSequencer([g.copy() for g in graphs], 'g', 'average', 32, shuffle=True, device=dev), epochs=2, verbose=0)
+    w = torch.cat([torch.from_numpy(a.reshape(-1)) for a in model_r.net_state.get_weights() + model_r.net_output.get_weights()]).to(dev)
+    parts = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(parts, w)
+    assert all(torch.equal(parts[0], p_) for p_ in parts), 'replicas diverged'
+    assert np.isfinite(hist_r['loss']).all()
     dist.barrier(); torch.cuda.synchronize()
     dist.destroy_process_group()
     if rank == 0: print('DP_OK ' + json.dumps({'k': res['k'], 'worst_grad_err': worst, 'loss': [float(v) for v in hist['loss']]}))

@@ -507,7 +507,12 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
                                 (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
         attr = true;
     }
-    const int budget = 2 * n_cu;                 // 2 workgroups (32 waves) per CU, all co-resident
+    // 2 workgroups (32 waves) per CU are resident at once.  GNN_F4_WG_FACTOR > 1 (experiment): that many times more, smaller workgroups -
+    // the dispatcher hands the next one to whichever slot frees first, which levels the +-10 % spread of workgroup run times
+    // (profiles/r03_c3_timeline.txt) at the price of one more ramp-up per extra workgroup.
+    static int wg_factor = 0;
+    if (wg_factor == 0) { const char *e = getenv("GNN_F4_WG_FACTOR"); wg_factor = e ? std::max(1, atoi(e)) : 1; }
+    const int budget = 2 * n_cu * wg_factor;
     long total_tiles = 0;
     for (int t = 0; t < fa.n_types; ++t) total_tiles += (fa.tp[t].count + 15) / 16;
     fa.blk_begin[0] = 0;

@@ -91,11 +91,13 @@ __device__ __forceinline__ bool grid_barrier(GridBar &gb, int any, int *cont_lds
 // (a = 1, c = 0 without BatchNormalization; the constants' batch statistics do not change between iterations).
 struct ConstSegs { const float *ptr[3]; int ld[3], width[3], wrow[3]; int n; };
 __global__ void __launch_bounds__(256)
-k_train_small_const(int N, int S, ConstSegs cs, const float *__restrict__ W, const float *__restrict__ b, const float *gamma, const float *beta,
+k_train_small_const(int N, int S, int Sw, ConstSegs cs, const float *__restrict__ W, const float *__restrict__ b, const float *gamma, const float *beta,
                     const float *mean, const float *var, float eps, float *__restrict__ Cc) {
+    // S = the kernels' padded state width (16 / 32 / 64), Sw <= S the network's: W is [in_dim][Sw]; pad columns of Cc are zero
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * S) return;
     const int n = i / S, h = i % S;
+    if (h >= Sw) { Cc[i] = 0.0f; return; }
     float acc = b[h];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -104,7 +106,7 @@ k_train_small_const(int N, int S, ConstSegs cs, const float *__restrict__ W, con
             const int k = cs.wrow[s] + j;
             float x = cs.ptr[s][(size_t)n * cs.ld[s] + j];
             if (gamma) { const float a = gamma[k] / sqrtf(var[k] + eps); x = fmaf(x, a, beta[k] - mean[k] * a); }
-            acc = fmaf(x, W[(size_t)k * S + h], acc);
+            acc = fmaf(x, W[(size_t)k * Sw + h], acc);
         }
     }
     Cc[i] = acc;
@@ -226,6 +228,7 @@ __device__ __forceinline__ double sum_partials(const float *part, unsigned n_wg,
 // ---- forward ---------------------------------------------------------------------------------------------------------------------------------
 struct TrainSmallFwd {
     int N, S, K;
+    int Sw;                      // the state's real width (<= the template's S = 16 SQ): rows of the tape are S floats, pad columns zero
     const int *rowptr, *src; const float *w, *row_scale;       // adjacency by destination
     float *states;               // [K + 1][N][S]; [0] = state_0 (the caller's)
     float *agg;                  // [K][N][S] neighbour sums, kept for the backward pass
@@ -265,7 +268,8 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
 
     for (int i = tid; i < 2 * S * S; i += TS_NT) {
         const int k = i / S, h = i % S;
-        W0[k * LDW + h] = a.W[(size_t)((k < S ? 0 : a.off_agg - S) + k) * S + h];
+        const int kk = k < S ? k : k - S;
+        W0[k * LDW + h] = (kk < a.Sw && h < a.Sw) ? a.W[(size_t)((k < S ? 0 : a.off_agg) + kk) * a.Sw + h] : 0.0f;
     }
     if (tid < 2 * S) { piv[tid] = 0.0f; st_a[tid] = 1.0f; st_c[tid] = 0.0f; }
     Csr csr;
@@ -349,12 +353,16 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
                 red[tid] = (float)(sum_partials(a.part + (size_t)(it & 1) * gridDim.x * 4 * S, gridDim.x, 4 * S, tid) / (double)a.N);
             __syncthreads();
             if (tid < 2 * S) {
-                const int k = (tid < S ? 0 : a.off_agg - S) + tid;                    // BatchNorm column of this input column
-                const float dm = red[tid], va = fmaxf(red[2 * S + tid] - dm * dm, 0.0f), mu = piv[tid] + dm;
-                piv[tid] = mu;
-                const float ak = a.gamma[k] / sqrtf(va + a.eps);
-                st_a[tid] = ak; st_c[tid] = a.beta[k] - mu * ak;
-                if (blockIdx.x == 0) { a.stats[(size_t)it * 2 * a.in_s + k] = mu; a.stats[(size_t)it * 2 * a.in_s + a.in_s + k] = va; }
+                const int kk = tid < S ? tid : tid - S;
+                float ak = 0.0f, ck = 0.0f;                        // (pad columns: zero in, zero out)
+                if (kk < a.Sw) {
+                    const int k = (tid < S ? 0 : a.off_agg) + kk;                     // BatchNorm column of this input column
+                    const float dm = red[tid], va = fmaxf(red[2 * S + tid] - dm * dm, 0.0f), mu = piv[tid] + dm;
+                    piv[tid] = mu;
+                    ak = a.gamma[k] / sqrtf(va + a.eps); ck = a.beta[k] - mu * ak;
+                    if (blockIdx.x == 0) { a.stats[(size_t)it * 2 * a.in_s + k] = mu; a.stats[(size_t)it * 2 * a.in_s + a.in_s + k] = va; }
+                }
+                st_a[tid] = ak; st_c[tid] = ck;
             }
             __syncthreads();
         }
@@ -389,7 +397,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
             activate4(a.act, v);
             const f32x4 o = *reinterpret_cast<const f32x4 *>(orow_lds + 16 * ct);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = oin ? v[e] : 0.0f; const float d = v[e] - o[e]; d2 = fmaf(d, d, d2); n2 = fmaf(o[e], o[e], n2); }
+            for (int e = 0; e < 4; ++e) { v[e] = (oin && 16 * ct + 4 * g + e < a.Sw) ? v[e] : 0.0f; const float d = v[e] - o[e]; d2 = fmaf(d, d, d2); n2 = fmaf(o[e], o[e], n2); }
             if (LOCAL) {                  // (this wave's rows: no other wave reads them before the barrier below)
                 *reinterpret_cast<f32x4 *>(orow_lds + 16 * ct) = v;
                 if (oin) *reinterpret_cast<f32x4 *>(a.states + (size_t)(it + 1) * NS + (size_t)orow * S + 16 * ct + 4 * g) = v;
@@ -427,6 +435,7 @@ inline size_t train_small_fwd_lds() {
 // (the BatchNorm input gradient): 4 S floats per workgroup and iteration.
 struct TrainSmallBwd {
     int N, S, k;                 // k = iterations the forward pass executed
+    int Sw;                      // the state's real width (<= 16 SQ): W is [in_s][Sw], G0 [N][Sw], the shares [in_s * Sw + Sw]
     const int *rowptr_s, *src_s; const float *w_s, *row_scale_s; // adjacency by SOURCE (transposed aggregate); w_s NULL = unit weights
     const float *row_scale;      // [N] scale of the by-destination operator when its entries depend on the destination only (then w_s = NULL)
     const float *states, *agg, *stats;                           // the forward tape
@@ -473,21 +482,22 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
     const bool bn = a.gamma != nullptr;
     const size_t NS = (size_t)a.N * S;
     GridBar gb{a.bar, gridDim.x, 0, 0u, 0u, 0};
-    auto wrow_dyn = [&](int j) { return j < S ? j : a.off_agg + (j - S); };
+    auto wrow_dyn = [&](int j) { return j < S ? j : a.off_agg + (j - S); };      // weight row / BatchNorm column of tile column j (valid j only)
+    auto valid_dyn = [&](int j) { return (j < S ? j : j - S) < a.Sw; };           // pad columns of the padded state width carry zeros
 
     for (int i = tid; i < 2 * S * S; i += TS_NT) {
         const int j = i / S, h = i % S;
-        Wr[j * LDW + h] = a.W[(size_t)wrow_dyn(j) * S + h];
+        Wr[j * LDW + h] = (valid_dyn(j) && h < a.Sw) ? a.W[(size_t)wrow_dyn(j) * a.Sw + h] : 0.0f;
     }
     for (int i = tid; i < 64 * S; i += TS_NT) {
         const int rr = i / S, h = i % S;
-        Gs[rr * LDZ + h] = rr < nt ? a.G0[(size_t)(n0 + rr) * S + h] : 0.0f;
+        Gs[rr * LDZ + h] = (rr < nt && h < a.Sw) ? a.G0[(size_t)(n0 + rr) * a.Sw + h] : 0.0f;
     }
     // xhat = x rs + sh of iteration t (rs = rstd, sh = - mean rstd; 1 / 0 without BatchNormalization)
     auto coefficients = [&](int t) {
         if (tid < 2 * S) {
             float r_ = 1.0f, s_ = 0.0f;
-            if (bn) { const float *st = a.stats + (size_t)t * 2 * a.in_s; const int k = wrow_dyn(tid); r_ = 1.0f / sqrtf(st[a.in_s + k] + a.eps); s_ = -st[k] * r_; }
+            if (bn && valid_dyn(tid)) { const float *st = a.stats + (size_t)t * 2 * a.in_s; const int k = wrow_dyn(tid); r_ = 1.0f / sqrtf(st[a.in_s + k] + a.eps); s_ = -st[k] * r_; }
             rs_s[tid] = r_; sh_s[tid] = s_;
         }
     };
@@ -636,7 +646,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
             }
             __syncthreads();
             if (tid < 2 * S) {
-                const float Ac = a.gamma[wrow_dyn(tid)] * rs_s[tid];
+                const float Ac = valid_dyn(tid) ? a.gamma[wrow_dyn(tid)] * rs_s[tid] : 0.0f;
                 cfA[tid] = Ac; cfC[tid] = -Ac * S2_s[tid] * a.inv_n; cfB[tid] = -Ac * S1_s[tid] * a.inv_n;
             }
             __syncthreads();
@@ -691,9 +701,9 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
     }
     TS_WRITE(1);
     // ---- the shares of this workgroup ---------------------------------------------------------------------------------------------------------
-    float *pw = a.partW + (size_t)blockIdx.x * ((size_t)a.in_s * S + S);
+    float *pw = a.partW + (size_t)blockIdx.x * ((size_t)a.in_s * a.Sw + a.Sw);
     float *pb = bn ? a.partBN + (size_t)blockIdx.x * 2 * a.in_s : nullptr;
-    if (tid < S) { pw[(size_t)a.in_s * S + tid] = qsum; ql_s[tid] = qsum; }
+    if (tid < S) { if (tid < a.Sw) pw[(size_t)a.in_s * a.Sw + tid] = qsum; ql_s[tid] = qsum; }
     __syncthreads();
     // kernel rows of the state / agg columns: gamma_k sum_t Phat + beta_k sum_t q
 #pragma unroll
@@ -703,15 +713,16 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
             const int kt = ti / SQ, ht = ti % SQ;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int j = 16 * kt + 4 * g + reg, k = wrow_dyn(j);
+                const int j = 16 * kt + 4 * g + reg, k = wrow_dyn(j), h = 16 * ht + c;
+                if (!valid_dyn(j) || h >= a.Sw) continue;
                 float v = accP[i][reg];
-                if (bn) v = fmaf(a.gamma[k], v, a.beta[k] * ql_s[16 * ht + c]);
-                pw[(size_t)k * S + 16 * ht + c] = v;
+                if (bn) v = fmaf(a.gamma[k], v, a.beta[k] * ql_s[h]);
+                pw[(size_t)k * a.Sw + h] = v;
             }
         }
     }
-    if (bn && tid < 2 * S) pb[a.in_s + wrow_dyn(tid)] = S1sum;                                  // d beta share
-    else if (bn && tid < 4 * S) pb[wrow_dyn(tid - 2 * S)] = S2sum;                              // d gamma share
+    if (bn && tid < 2 * S) { if (valid_dyn(tid)) pb[a.in_s + wrow_dyn(tid)] = S1sum; }              // d beta share
+    else if (bn && tid < 4 * S) { if (valid_dyn(tid - 2 * S)) pb[wrow_dyn(tid - 2 * S)] = S2sum; }  // d gamma share
     // the constant input columns: xhat is the same in every iteration, so Phat_c = xhat_c^T (sum_t dZ_t), once
     const int Kc = (a.cs.n > 0 ? a.cs.width[0] : 0) + (a.cs.n > 1 ? a.cs.width[1] : 0) + (a.cs.n > 2 ? a.cs.width[2] : 0);
     if (Kc > 0) {
@@ -750,12 +761,13 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int jj = 16 * kt + 4 * g + reg, k = jj < Kc ? wrow_c[jj] : -1;
-                    const float w = k >= 0 ? a.W[(size_t)k * S + 16 * ht + c] : 0.0f;
+                    const bool hv = 16 * ht + c < a.Sw;
+                    const float w = (k >= 0 && hv) ? a.W[(size_t)k * a.Sw + 16 * ht + c] : 0.0f;
                     float s2 = w * Pc[reg], s1 = w * ql_s[16 * ht + c];
 #pragma unroll
                     for (int off = 1; off < 16; off <<= 1) { s2 += __shfl_xor(s2, off, 64); s1 += __shfl_xor(s1, off, 64); }
                     if (k >= 0) {
-                        pw[(size_t)k * S + 16 * ht + c] = bn ? fmaf(a.gamma[k], Pc[reg], a.beta[k] * ql_s[16 * ht + c]) : Pc[reg];
+                        if (hv) pw[(size_t)k * a.Sw + 16 * ht + c] = bn ? fmaf(a.gamma[k], Pc[reg], a.beta[k] * ql_s[16 * ht + c]) : Pc[reg];
                         if (bn && c == 0) { red[64 + ht * 32 + jj] = s2; red[64 + 4 * 32 + ht * 32 + jj] = s1; }
                     }
                 }

@@ -48,6 +48,7 @@ struct TrainPlan {
     float *xc, *part_a, *part_y, *loss_part, *part_w;
     // small graphs (kernels_train_small.hpp): the forward / backward iterations as one persistent launch each
     bool small, tiled; int n_wg;
+    int SPs, ldS;                // small path: the padded state width the persistent kernels run (16 / 32 / 64) and the tape's row stride
     float *sm_cc, *sm_part, *sm_partW, *sm_partBN; unsigned long long *sm_bar;
     size_t bytes;
 };
@@ -117,12 +118,26 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.off_agg = p.with_labels ? p.S + p.L : p.S;          // first-layer row (= BN column) of the aggregated-state segment
     p.kdx_s = 2 * p.S;                                     // d loss / d [state | agg] only, 16-B aligned halves: the label columns between them are never needed
 
+    // ---- which path: the large-graph kernels, the persistent small-graph kernels (state width padded to 16 / 32 / 64 inside the tape:
+    // the starter configuration's 14 label columns run the 16-wide kernels), or one launch per layer and iteration
+    p.Kc = (p.with_labels ? 2 * p.L : 0) + p.A;
+    p.big = p.N >= train_big_min_nodes() && ns.n_layers == 1 && ns.units[0] == p.S && (p.S == 16 || p.S == 32 || p.S == 64) &&
+            p.Kc <= 32 && ns.activation[0] != GNN_ACT_SOFTMAX && (size_t)p.N * p.S * 4 < ((size_t)1 << 32) && p.K > 0;
+    p.SPs = p.S <= 16 ? 16 : p.S <= 32 ? 32 : 64;
+    p.tiled = ta.n_tiles > 0 && ta.tile_node_begin != nullptr;
+    p.n_wg = p.tiled ? ta.n_tiles : cdiv(p.N, 64);
+    if (p.tiled && p.n_wg > 256) { p.tiled = false; p.n_wg = cdiv(p.N, 64); }
+    p.small = !p.big && train_small_enabled() && ns.n_layers == 1 && ns.units[0] == p.S && p.S <= 64 && p.Kc <= 32 &&
+              ns.activation[0] != GNN_ACT_SOFTMAX && p.K > 0 && p.n_wg <= (ws ? device_cus() : 256) && p.N < train_big_min_nodes() &&
+              (size_t)std::max(p.K, 1) * p.N * p.SPs * sizeof(float) <= agg_tape_budget();
+    p.ldS = p.small ? p.SPs : p.S;
+
     Carver c(ws);
     p.flags = c.take<int>(p.K + 8);
     p.k_dev = c.take<float>(4);
-    p.states = c.take<float>((size_t)(p.K + 1) * p.N * p.S);
-    p.agg_taped = (size_t)std::max(p.K, 1) * p.N * p.S * sizeof(float) <= agg_tape_budget();
-    p.agg = c.take<float>((size_t)(p.agg_taped ? std::max(p.K, 1) : 1) * p.N * p.S);
+    p.states = c.take<float>((size_t)(p.K + 1) * p.N * p.ldS);
+    p.agg_taped = (size_t)std::max(p.K, 1) * p.N * p.ldS * sizeof(float) <= agg_tape_budget();
+    p.agg = c.take<float>((size_t)(p.agg_taped ? std::max(p.K, 1) : 1) * p.N * p.ldS);
     p.agg_arcs = c.take<float>((size_t)p.N * std::max(p.A, 1));
     p.agg_nodes = c.take<float>((size_t)p.N * std::max(p.L, 1));
     p.stats_s = c.take<float>((size_t)std::max(p.K, 1) * 2 * p.in_s);
@@ -131,7 +146,7 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.bf_s = c.take<float>((size_t)std::max(p.K, 1) * p.H1s);
     p.stats_o = c.take<float>(2 * (size_t)p.in_o);
     p.Wf_o = c.take<float>((size_t)p.in_o * p.H1o); p.bf_o = c.take<float>(p.H1o);
-    p.dx_s_all = c.take<float>((size_t)p.N * p.kdx_s);
+    p.dx_s_all = c.take<float>((size_t)p.N * std::max(p.kdx_s, p.small ? p.SPs : 0));      // (also the persistent backward kernel's [N, SPs] exchange rows)
     p.dx_o_all = c.take<float>((size_t)std::max(p.M, 1) * p.in_o);
     p.G_state = c.take<float>((size_t)p.N * p.S);
     p.G_out = c.take<float>((size_t)std::max(p.M, 1) * p.T);
@@ -146,10 +161,6 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
         p.part_floats = std::max(p.part_floats, (size_t)(nc + 1) * std::max(p.in_s, p.in_o));
     }
     p.part = c.take<float>(p.part_floats);
-    // ---- the large-graph path: one-layer state network of width 16 / 32 / 64 whose constant inputs fit 32 columns ----
-    p.Kc = (p.with_labels ? 2 * p.L : 0) + p.A;
-    p.big = p.N >= train_big_min_nodes() && ns.n_layers == 1 && ns.units[0] == p.S && (p.S == 16 || p.S == 32 || p.S == 64) &&
-            p.Kc <= 32 && ns.activation[0] != GNN_ACT_SOFTMAX && (size_t)p.N * p.S * 4 < ((size_t)1 << 32) && p.K > 0;
     memset(&p.cc, 0, sizeof(p.cc));
     if (p.with_labels) {
         p.cc.n = p.A > 0 ? 3 : 2;
@@ -165,13 +176,8 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.part_y = c.take<float>(p.big ? (size_t)BIG_FWD_BLOCKS * 2 * std::max(p.S, 32) : 0);      // (also the one-pass statistics of the 32-wide constants line)
     p.loss_part = c.take<float>(256);
     p.part_w = c.take<float>(p.big ? (size_t)BIG_WGRAD_BLOCKS * ((size_t)p.in_s * p.S + p.S) : 0);      // k_train_wgrad: one partial per workgroup
-    p.tiled = ta.n_tiles > 0 && ta.tile_node_begin != nullptr;
-    p.n_wg = p.tiled ? ta.n_tiles : cdiv(p.N, 64);
-    if (p.tiled && p.n_wg > 256) { p.tiled = false; p.n_wg = cdiv(p.N, 64); }
-    p.small = !p.big && train_small_enabled() && ns.n_layers == 1 && ns.units[0] == p.S && (p.S == 16 || p.S == 32 || p.S == 64) && p.Kc <= 32 &&
-              ns.activation[0] != GNN_ACT_SOFTMAX && p.K > 0 && p.agg_taped && p.n_wg <= (ws ? device_cus() : 256) && p.N < train_big_min_nodes();
-    p.sm_cc = c.take<float>(p.small ? (size_t)p.N * p.S : 0);
-    p.sm_part = c.take<float>(p.small ? (size_t)2 * p.n_wg * (3 * p.S + 32 + 4 * p.S) : 0);
+    p.sm_cc = c.take<float>(p.small ? (size_t)p.N * p.SPs : 0);
+    p.sm_part = c.take<float>(p.small ? (size_t)2 * p.n_wg * 8 * p.SPs : 0);
     p.sm_partW = c.take<float>(p.small ? (size_t)p.n_wg * (p.in_s + 1) * p.S : 0);
     p.sm_partBN = c.take<float>(p.small ? (size_t)p.n_wg * 2 * p.in_s : 0);
     p.sm_bar = c.take<unsigned long long>(p.small ? 4 : 0);
@@ -393,10 +399,10 @@ int check_grads(const gnn_mlp_t &m, const gnn_mlp_grads_t &g, const char *name) 
 // segments of the state network's input at iteration t (reference GNN.py:222-231): [state | nodes | agg | agg_nodes | agg_arcs]
 int state_segs(const gnn_loop_args_t &a, const TrainPlan &p, int t, gnn::Seg *segs) {
     int n = 0, col = 0;
-    const float *st_t = p.states + (size_t)t * p.N * p.S;
-    segs[n++] = gnn::Seg{st_t, nullptr, p.S, p.S, col}; col += p.S;
+    const float *st_t = p.states + (size_t)t * p.N * p.ldS;
+    segs[n++] = gnn::Seg{st_t, nullptr, p.ldS, p.S, col}; col += p.S;
     if (p.with_labels) { segs[n++] = gnn::Seg{a.nodes, nullptr, a.ld_nodes, p.L, col}; col += p.L; }
-    segs[n++] = gnn::Seg{p.agg + (p.agg_taped ? (size_t)t * p.N * p.S : 0), nullptr, p.S, p.S, col}; col += p.S;
+    segs[n++] = gnn::Seg{p.agg + (p.agg_taped ? (size_t)t * p.N * p.ldS : 0), nullptr, p.ldS, p.S, col}; col += p.S;
     if (p.with_labels) { segs[n++] = gnn::Seg{p.agg_nodes, nullptr, p.L, p.L, col}; col += p.L; }
     if (p.A > 0) { segs[n++] = gnn::Seg{p.agg_arcs, nullptr, p.A, p.A, col}; col += p.A; }
     return n;
@@ -557,7 +563,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
     const bool bn_s = ns.has_bn != 0, bn_o = no.has_bn != 0;
     const bool fold_s = ns.units[0] <= 4;       // see the forward loop
     hipStream_t st = (hipStream_t)a.stream;
-    const size_t NS = (size_t)p.N * p.S;
+    const size_t NS = (size_t)p.N * p.ldS;             // one state matrix of the tape (rows of ldS floats: padded on the persistent small-graph path)
 
     // ---- setup: transposes, aggregates of the constants, state_0, iteration-invariant statistics -----------------------------------
     TRY(transposes(p.cs, st));
@@ -566,8 +572,9 @@ int gnn_train_step(const gnn_train_args_t *args) {
     HIP_OK(hipMemsetAsync(p.k_dev, 0, sizeof(float) * 4, st));
     if (p.A > 0) TRY(launch_aggregate(nullptr, a.arcnode, a.arc_labels, a.ld_arcs, p.A, p.agg_arcs, p.A, st));
     if (p.with_labels) TRY(launch_aggregate(nullptr, a.adjacency, a.nodes, a.ld_nodes, p.L, p.agg_nodes, p.L, st));
-    if (a.state_dim > 0) HIP_OK(hipMemcpyAsync(p.states, a.state0, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
-    else TRY(launch_copy2d(nullptr, a.nodes, a.ld_nodes, p.states, p.S, p.N, p.S, p.S, st));
+    if (a.state_dim > 0 && p.ldS == p.S) HIP_OK(hipMemcpyAsync(p.states, a.state0, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
+    else if (a.state_dim > 0) TRY(launch_copy2d(nullptr, a.state0, p.S, p.states, p.ldS, p.N, p.S, p.ldS, st));
+    else TRY(launch_copy2d(nullptr, a.nodes, a.ld_nodes, p.states, p.ldS, p.N, p.S, p.ldS, st));
     gnn::Seg segs[GNN_MAX_SEGS];
     if (p.big && p.Kc > 0) {      // the constant inputs of a node as one 128-byte line: [labels | aggregated labels | aggregated arc labels | 1 | 0 ..]
         gnn::PackSegs ps;
@@ -598,7 +605,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
         LAUNCH_OK();
     }
     // ---- training-mode forward: gated iterations, tape = states + statistics + folded first layers ------------------------------
-    TRY(launch_converge(nullptr, p.states, nullptr, p.N, p.S, p.S, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
+    TRY(launch_converge(nullptr, p.states, nullptr, p.N, p.S, p.ldS, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
     for (int t = 0; t < p.K && p.big; ++t) {
         // Large graphs (kernels_train_big.hpp): the neighbour sum leaves its own column statistics, the dense kernel those of the
         // state it writes (the next iteration's input); the statistics are folded into the weights (tiny launch) and the layer
@@ -646,19 +653,19 @@ int gnn_train_step(const gnn_train_args_t *args) {
     if (p.small) {
         // Small graphs (kernels_train_small.hpp): all K gated iterations in one persistent launch, one workgroup per 64-node tile
         const gnn::ConstSegs cs = const_segs_of(a, p);
-        gnn::k_train_small_const<<<cdiv(p.N * p.S, 256), 256, 0, st>>>(p.N, p.S, cs, ns.kernel[0], ns.bias[0], bn_s ? ns.bn_gamma : nullptr, ns.bn_beta,
+        gnn::k_train_small_const<<<cdiv(p.N * p.SPs, 256), 256, 0, st>>>(p.N, p.SPs, p.S, cs, ns.kernel[0], ns.bias[0], bn_s ? ns.bn_gamma : nullptr, ns.bn_beta,
                                                                        p.stats_tpl, p.stats_tpl + p.in_s, ns.bn_eps, p.sm_cc);
         LAUNCH_OK();
         HIP_OK(hipMemsetAsync(p.sm_bar, 0, sizeof(unsigned long long) * 4, st));
         gnn::TrainSmallFwd fa;
         memset(&fa, 0, sizeof(fa));
-        fa.N = p.N; fa.S = p.S; fa.K = p.K;
+        fa.N = p.N; fa.S = p.SPs; fa.Sw = p.S; fa.K = p.K;
         fa.rowptr = a.adjacency.rowptr; fa.src = a.adjacency.src; fa.w = a.adjacency.w; fa.row_scale = a.adjacency.row_scale;
         fa.states = p.states; fa.agg = p.agg; fa.stats = p.stats_s; fa.in_s = p.in_s; fa.off_agg = p.off_agg;
         fa.W = ns.kernel[0]; fa.gamma = bn_s ? ns.bn_gamma : nullptr; fa.beta = ns.bn_beta; fa.eps = ns.bn_eps; fa.act = ns.activation[0];
         fa.Cc = p.sm_cc; fa.thr = a.state_threshold; fa.flag0 = p.flags;
         fa.bar = p.sm_bar; fa.part = p.sm_part; fa.k_out = p.k_dev;
-        switch (p.S) {
+        switch (p.SPs) {
             case 16: TRY(launch_train_small_fwd_sq<1>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st)); break;
             case 32: TRY(launch_train_small_fwd_sq<2>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st)); break;
             default: TRY(launch_train_small_fwd_sq<4>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st)); break;
@@ -697,7 +704,8 @@ int gnn_train_step(const gnn_train_args_t *args) {
     if (k_f2[1] != 0.0f) return fail("a workgroup of the persistent training kernel never arrived at a grid barrier (not resident?)");
     if (k < 0 || k > p.K) return fail("iteration count %d out of range", k);
     const float *state_k = p.states + (size_t)k * NS;
-    HIP_OK(hipMemcpyAsync(ta.state, state_k, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
+    if (p.ldS == p.S) HIP_OK(hipMemcpyAsync(ta.state, state_k, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
+    else TRY(launch_copy2d(nullptr, state_k, p.ldS, ta.state, p.S, p.N, p.S, p.S, st));
     if (bn_s && k > 0) {
         gnn::k_bn_moving_multi<<<cdiv(p.in_s, 256), 256, 0, st>>>(p.stats_s, 2 * p.in_s, k, p.in_s, const_cast<float *>(ns.bn_mean),
                                                                 const_cast<float *>(ns.bn_var), ta.bn_momentum);
@@ -717,13 +725,13 @@ int gnn_train_step(const gnn_train_args_t *args) {
             const int *ends[2] = {p.isrc, p.idst};
             for (int e = 0; e < 2; ++e) {
                 bn_req_off[n_state_segs] = ocol; bn_req_idx[n_state_segs++] = ends[e];
-                osegs[nos++] = gnn::Seg{state_k, ends[e], p.S, p.S, ocol}; ocol += p.S;
+                osegs[nos++] = gnn::Seg{state_k, ends[e], p.ldS, p.S, ocol}; ocol += p.S;
                 if (p.with_labels) { osegs[nos++] = gnn::Seg{a.nodes, ends[e], a.ld_nodes, p.L, ocol}; ocol += p.L; }
             }
             if (p.A > 0) { osegs[nos++] = gnn::Seg{a.arc_labels, a.out_index, a.ld_arcs, p.A, ocol}; ocol += p.A; }
         } else {
             bn_req_off[0] = 0; bn_req_idx[0] = a.out_index; n_state_segs = 1;
-            osegs[nos++] = gnn::Seg{state_k, a.out_index, p.S, p.S, ocol}; ocol += p.S;
+            osegs[nos++] = gnn::Seg{state_k, a.out_index, p.ldS, p.S, ocol}; ocol += p.S;
             if (p.with_labels) { osegs[nos++] = gnn::Seg{a.nodes, a.out_index, a.ld_nodes, p.L, ocol}; ocol += p.L; }
         }
     }
@@ -756,12 +764,12 @@ int gnn_train_step(const gnn_train_args_t *args) {
     if (p.pooled) { TRY(launch_aggregate(nullptr, ta.nodegraph_by_source, p.dpred, p.T, p.T, p.G_out, p.T, st)); G_out = p.G_out; }
 
     // ---- backward: output network, then the k iterations -----------------------------------------------------------------------------------
-    HIP_OK(hipMemsetAsync(p.G_state, 0, sizeof(float) * NS, st));
+    HIP_OK(hipMemsetAsync(p.G_state, 0, sizeof(float) * (size_t)p.N * p.S, st));
     if (p.M > 0) {
         TRY(net_backward(p.co, osegs, nos, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, p.in_o, p.part, st));
         gnn::BnGradReq rq[2];
         for (int i = 0; i < n_state_segs; ++i)
-            rq[i] = gnn::BnGradReq{p.dx_o_all + bn_req_off[i], p.in_o, state_k, p.S, bn_req_idx[i], p.S, bn_req_off[i]};
+            rq[i] = gnn::BnGradReq{p.dx_o_all + bn_req_off[i], p.in_o, state_k, p.ldS, bn_req_idx[i], p.S, bn_req_off[i]};
         TRY(bn_input_grads(no, p.co, p.stats_o, rq, n_state_segs, p.M, st));
         for (int i = 0; i < n_state_segs; ++i) {
             gnn::k_scatter_add_rows<<<std::min(cdiv((long)p.M * p.S, 256), 256 * 16), 256, 0, st>>>(p.dx_o_all + bn_req_off[i], p.in_o, bn_req_idx[i],
@@ -778,7 +786,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
         memset(&ba, 0, sizeof(ba));
         const gnn_csr_t &cs_ = ta.adjacency_by_source;
         const bool unit_w = !a.adjacency.w;       // entries depend on the destination only: scale the agg-half once per row, walk unit weights
-        ba.N = p.N; ba.S = p.S; ba.k = k;
+        ba.N = p.N; ba.S = p.SPs; ba.Sw = p.S; ba.k = k;
         ba.rowptr_s = cs_.rowptr; ba.src_s = cs_.src; ba.w_s = unit_w ? nullptr : cs_.w; ba.row_scale_s = unit_w ? nullptr : cs_.row_scale;
         ba.row_scale = unit_w ? a.adjacency.row_scale : nullptr;
         ba.states = p.states; ba.agg = p.agg; ba.stats = p.stats_s; ba.in_s = p.in_s; ba.off_agg = p.off_agg;
@@ -787,7 +795,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
         ba.G0 = p.G_state; ba.dxa = p.dx_s_all; ba.bar = p.sm_bar + 2; ba.part = p.sm_part; ba.partW = p.sm_partW;
         ba.partBN = p.sm_partBN;
         ba.inv_n = 1.0f / (float)p.N; ba.err = p.k_dev;
-        switch (p.S) {
+        switch (p.SPs) {
             case 16: TRY(launch_train_small_bwd_sq<1>(ba, tiles, p.n_wg, ba.w_s != nullptr, st)); break;
             case 32: TRY(launch_train_small_bwd_sq<2>(ba, tiles, p.n_wg, ba.w_s != nullptr, st)); break;
             default: TRY(launch_train_small_bwd_sq<4>(ba, tiles, p.n_wg, ba.w_s != nullptr, st)); break;

@@ -411,7 +411,11 @@ def test_small_graph_training_on_the_large_graph_kernels_in_a_child_process():
 @pytest.mark.parametrize('focus,d,bn,mode,n_graphs,thr', [
     ('g', 32, True, 'average', 60, 0.0), ('g', 64, True, 'average', 188, 0.0), ('n', 16, False, 'sum', 40, 0.0),
     ('a', 32, True, 'normalized', 24, 0.0), ('n', 64, False, 'average', 7, 0.0), ('g', 32, False, 'average', 50, -1.0),
-    ('n', 32, True, 'sum', 1, 0.0), ('g', 16, True, 'average', 100, -1.0)])
+    ('n', 32, True, 'sum', 1, 0.0), ('g', 16, True, 'average', 100, -1.0),
+    # state widths that are not 16 / 32 / 64 run the next wider kernels on a padded tape: the starter configuration (state = the 14
+    # label columns, state_vect_dim = 0), 20 -> 32, 40 -> 64, 5 -> 16
+    ('g', 0, True, 'average', 64, 0.0), ('n', 20, True, 'average', 30, 0.0), ('a', 40, False, 'sum', 20, 0.0), ('g', 5, True, 'average', 40, -1.0),
+    ('n', 0, False, 'normalized', 25, 0.0)])
 @pytest.mark.parametrize('tiled', [True, False])
 def test_small_graph_training_persistent_kernels_match_autograd(mutag_graphs, focus, d, bn, mode, n_graphs, thr, tiled, monkeypatch):
     """A merged MUTAG batch (18 .. 3 400 nodes: 1 .. 54 workgroups, the last tile ragged) through `gnn_train_step`: state widths
@@ -430,7 +434,7 @@ def test_small_graph_training_persistent_kernels_match_autograd(mutag_graphs, fo
     x, y, sw = seq[0]
     contractive = thr < 0
     ns, no = nets(focus, d, bn, scale=(0.15 if contractive else 0.5) if mode != 'sum' else 0.2)
-    s0 = rng.normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)
+    s0 = rng.normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32) if d > 0 else None
     K = 7
     if contractive:
         seen = {}

@@ -262,6 +262,49 @@ def mutag_dp_section(device, rank, world):
                          f'gradient sums exchanged per iteration (building-block path)'}
 
 
+def training_section(device, graph_x, d):
+    """SURVEY 8f rank 1 next to the forward numbers: `train_step` (training-mode forward on batch statistics, loss, BPTT through the
+    executed iterations, Adam) - MUTAG batches of 32 at d = 32 x 50 iterations and in the reference's starter configuration
+    (state_vect_dim = 0, 5 iterations), a fit() epoch of each over the whole data set (3 469 training + 868 validation graphs), and
+    one step on the C4 graph (d = 64, 10 iterations)."""
+    from gnnkeras_amd.load_MUTAG import load_graphs
+    from gnnkeras_amd.Models.GNN import GNNgraphBased, GNNnodeBased
+    from gnnkeras_amd.Models.training import Adam
+    from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+    graphs = load_graphs()
+    out = {}
+    for name, dd, it in (('mutag_d32_k50', 32, 50), ('mutag_starter_config', 0, 5)):
+        ns, no = starter_nets(dd, device, 'g')
+        gnn = GNNgraphBased(ns, no, dd, it, 0.01)
+        gnn.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['accuracy'])
+        seq = MultiGraphSequencer(graphs[:32 * 20], 'g', 'average', 32, shuffle=False, device=device)
+        for i in range(len(seq)): gnn.train_step(seq[i], seed=0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(len(seq)): r = gnn.train_step(seq[i], seed=0)
+        torch.cuda.synchronize(); t_step = (time.perf_counter() - t0) / len(seq)
+        tr = MultiGraphSequencer(graphs[:-868], 'g', 'average', 32, shuffle=True, device=device)
+        va = MultiGraphSequencer(graphs[-868:], 'g', 'average', 32, shuffle=False, device=device)
+        gnn.fit(tr, epochs=1, validation_data=va, verbose=0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        gnn.fit(tr, epochs=2, validation_data=va, verbose=0)
+        torch.cuda.synchronize(); t_epoch = (time.perf_counter() - t0) / 2
+        out[name] = {'train_step_ms_per_batch': 1e3 * t_step, 'k': int(r['k']), 'fit_epoch_ms': 1e3 * t_epoch,
+                     'epoch': f'{len(tr)} training steps of 32 graphs + validation on 868 graphs + reshuffle / device re-merge'}
+    ns, no = starter_nets(d, device, 'n')
+    gnn = GNNnodeBased(ns, no, d, 10, 0.0)
+    gnn.compile(optimizer=Adam(0.001), loss='categorical_crossentropy', metrics=['accuracy'])
+    N = graph_x[0][0].shape[0]
+    y = torch.zeros((N, 2), device=device); y[:, 0] = 1.0
+    data = (graph_x[0], y, None)
+    for _ in range(2): gnn.train_step(data, seed=0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3): r = gnn.train_step(data, seed=0)
+    torch.cuda.synchronize()
+    out['c4_d64_k10'] = {'train_step_ms': 1e3 * (time.perf_counter() - t0) / 3, 'k': int(r['k']),
+                         'workload': 'the C4 graph, node-focused, every node a target, 10 iterations, BatchNormalization on batch statistics'}
+    return out
+
+
 def measure_loop(gnn, inputs, s0, steps, warmup):
     """(elapsed seconds of `steps` forwards, k, seconds per iteration kernel launch) on one GPU; the per-launch time comes from
     HIP events the library records on the launch stream around the iteration launches (gnn.loop_events)."""
@@ -409,6 +452,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-mutag', action='store_true')
     ap.add_argument('--no-beyond-cache', action='store_true')
+    ap.add_argument('--no-training', action='store_true', help='skip the train_step / fit() section')
     ap.add_argument('--unfused', action='store_true')
     ap.add_argument('--force-sharded', action='store_true', help='run the N>1 code path even with one rank (smoke test)')
     ap.add_argument('--exchange', choices=['auto', 'allgather', 'direct', 'halo'], default='auto',
@@ -606,6 +650,11 @@ def main():
         result['speedup_vs_cpu_loop'] = (E / t_iter) / result['cpu_baseline']['value']
     if rank == 0 and not sharded and not args.no_mutag and args.workload == 'c4':
         result['mutag'] = mutag_section(device, cpu=not args.no_cpu_baseline)
+    if rank == 0 and not sharded and not args.no_training and args.workload == 'c4' and not args.unfused and args.state_dim in (16, 32, 64):
+        try:
+            result['training'] = training_section(device, (x,), d)
+        except Exception as e:                        # never lose the headline line to the extras
+            result['training'] = {'error': str(e)[:300]}
     if rank == 0 and not sharded and not args.no_beyond_cache and args.workload == 'c4' and not args.unfused:
         del gnn, inputs, x, s0
         torch.cuda.empty_cache()

@@ -128,7 +128,7 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.n_wg = p.tiled ? ta.n_tiles : cdiv(p.N, 64);
     if (p.tiled && p.n_wg > 256) { p.tiled = false; p.n_wg = cdiv(p.N, 64); }
     p.small = !p.big && train_small_enabled() && ns.n_layers == 1 && ns.units[0] == p.S && p.S <= 64 && p.Kc <= 32 &&
-              ns.activation[0] != GNN_ACT_SOFTMAX && p.K > 0 && p.n_wg <= (ws ? device_cus() : 256) && p.N < train_big_min_nodes() &&
+              ns.activation[0] != GNN_ACT_SOFTMAX && p.K > 0 && p.n_wg <= device_cus() && p.N < train_big_min_nodes() &&
               (size_t)std::max(p.K, 1) * p.N * p.SPs * sizeof(float) <= agg_tape_budget();
     p.ldS = p.small ? p.SPs : p.S;
 

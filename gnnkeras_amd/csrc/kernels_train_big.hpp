@@ -169,8 +169,12 @@ template <> struct BFrag<8> { float v[8]; __device__ __forceinline__ void load(c
 // (l % 16, l / 16)), so the 16-byte row chunks a lane loaded serve as they are - and the result D[i][j] = Y[row j][16 ct + i] leaves
 // lane (c, g) holding Y[row c][16 ct + 4 g .. + 3]: four CONSECUTIVE columns of its own row.  Output, old state (the A chunks of the
 // state segment) and stores all share the row-major 16-byte layout: no transposition, no 4-byte accesses, no loads in the epilogue.
+#ifndef TB_PREFETCH
+#define TB_PREFETCH 0                  // 1 (experiment): the next tile's rows are requested before this tile's MFMAs.  162 VGPRs = 3 waves per SIMD
+                                       // instead of 4: SLOWER, 227 -> 247 us per 1 M rows (scripts/micro/rowgemm_bench.hip): the waves hide more than the prefetch
+#endif
 template <int SQ, int NCT>
-__global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_fwd(TrainFwdArgs a) {
+__global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : 4) k_train_fwd(TrainFwdArgs a) {
     if (gate_closed(a.gate)) return;
     constexpr int NQ = 2 * SQ + 2;                    // 16-column chunks of an input row: state, agg, constant inputs (32 columns)
     constexpr int HP = 16 * NCT;
@@ -209,18 +213,32 @@ __global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_fwd(TrainFwdArgs a) 
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) { cs1[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; cs2[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     int any = 0;
-#pragma unroll 1
-    for (int t = blockIdx.x * TB_WAVES + wave; t < n_tiles; t += gridDim.x * TB_WAVES) {
-        const int row = 16 * t + c;                     // this lane's row: input chunks, output chunks, old state
-        const bool in = row < a.M;
-        f32x4 A[NQ];
+    auto fetch = [&](int t, f32x4 (&A_)[NQ]) {          // this lane's 16-byte pieces of row 16 t + c: state, agg, constants line
+        const int row_ = 16 * t + c;
+        const bool in_ = t < n_tiles && row_ < a.M;
 #pragma unroll
         for (int q = 0; q < SQ; ++q) {
-            A[q] = buf_ld_f32x4(r_s, in ? ((unsigned)row * (unsigned)a.ld_state + 16u * q + 4u * g) * 4u : BUF_OFF);
-            A[SQ + q] = buf_ld_f32x4(r_a, in ? ((unsigned)row * (unsigned)a.ld_agg + 16u * q + 4u * g) * 4u : BUF_OFF);
+            A_[q] = buf_ld_f32x4(r_s, in_ ? ((unsigned)row_ * (unsigned)a.ld_state + 16u * q + 4u * g) * 4u : BUF_OFF);
+            A_[SQ + q] = buf_ld_f32x4(r_a, in_ ? ((unsigned)row_ * (unsigned)a.ld_agg + 16u * q + 4u * g) * 4u : BUF_OFF);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) A[2 * SQ + q] = buf_ld_f32x4(r_x, in ? ((unsigned)row * 32u + 16u * q + 4u * g) * 4u : BUF_OFF);
+        for (int q = 0; q < 2; ++q) A_[2 * SQ + q] = buf_ld_f32x4(r_x, in_ ? ((unsigned)row_ * 32u + 16u * q + 4u * g) * 4u : BUF_OFF);
+    };
+    const int t_step = gridDim.x * TB_WAVES;
+    f32x4 A[NQ];
+#if TB_PREFETCH
+    fetch(blockIdx.x * TB_WAVES + wave, A);
+#endif
+#pragma unroll 1
+    for (int t = blockIdx.x * TB_WAVES + wave; t < n_tiles; t += t_step) {
+        const int row = 16 * t + c;                     // this lane's row: input chunks, output chunks, old state
+        const bool in = row < a.M;
+#if TB_PREFETCH
+        f32x4 An[NQ];
+        fetch(t + t_step, An);                          // (in flight while this tile multiplies)
+#else
+        fetch(t, A);
+#endif
         f32x4 acc[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[ct] = *reinterpret_cast<const f32x4 *>(bias_l + 16 * ct + 4 * g);
@@ -268,6 +286,10 @@ __global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_fwd(TrainFwdArgs a) 
             n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64);
             if (in && sqrtf(d2) > a.thr * sqrtf(n2)) any = 1;
         }
+#if TB_PREFETCH
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) A[q] = An[q];
+#endif
     }
     // ---- predicate flag, k, statistics partial of this workgroup ---------------------------------------------------------------------
     if (a.pred_flag && __any(any) && lane == 0) any_s = 1;             // benign race: every writer stores 1

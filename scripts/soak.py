@@ -88,5 +88,29 @@ for N, E, flag, name in ((200000, 2000000, nat.FLAG_FUSED_GEN4, 'generation 4'),
             bad += 1
             print(f'{name} NOT REPRODUCIBLE at rep {rep}: max diff {float((st - ref[1]).abs().max()):.3e}')
     print(f'{name} N={N}: {reps * 5} runs, k={ref[0]}, {time.time() - t0:.1f} s')
+
+# ---- round 3: the persistent training kernels (two grid barriers per iteration each way), every MUTAG batch, run-to-run bit equality --------
+from gnnkeras_amd.Models.training import LoopTrainer, SGD
+seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False)
+for d, it in ((32, 30), (0, 5)):
+    inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d); ns = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0)
+    inp, lay = get_inout_dims('output', 14, 3, 2, 'g', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
+    gnn = GNNgraphBased(ns, no, d, it, 0.0)
+    gnn.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+    w0 = [a.copy() for a in ns.get_weights() + no.get_weights()]
+    t0 = time.time(); n = 0
+    for b in range(0, len(seq), max(1, len(seq) // (4 * reps))):
+        x, y, sw = seq[b]
+        s0 = torch.randn((x[0].shape[0], d), device='cuda') * 0.1 if d else None
+        ref = None
+        for rep in range(3):
+            tr = LoopTrainer(gnn)
+            r = tr.train_step(x, y, sw, state0=s0, apply=False)
+            got = [r['loss'].clone(), r['y_pred'].clone()] + [g.clone() for g in tr.gs.gradients() + tr.go.gradients()]
+            ns.set_weights(w0[:len(ns.get_weights())]); no.set_weights(w0[len(ns.get_weights()):])      # (the BN moving statistics moved)
+            if ref is None: ref = got
+            elif not all(torch.equal(a, b_) for a, b_ in zip(ref, got)): bad += 1; print(f'train step d={d} batch {b}: run {rep} differs')
+            n += 1
+    print(f'persistent training kernels d={d}: {n} steps, {time.time() - t0:.1f} s')
 print('soak:', 'OK' if bad == 0 else f'{bad} FAILURES')
 sys.exit(1 if bad else 0)

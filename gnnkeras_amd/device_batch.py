@@ -259,6 +259,7 @@ class DeviceDataset:
             return epoch
 
         out = []
+        dim_node_label = torch.tensor([self.L], dtype=torch.int32)               # one (read-only) tensor for every batch of the epoch
         for b in range(nb):
             n0, n1, e0, e1 = int(bN[b]), int(bN[b] + Nb[b]), int(bE[b]), int(bE[b] + Eb[b])
             t0, t1, m0, m1 = int(bT[b]), int(bT[b] + Tb[b]), int(bM[b]), int(bM[b] + Mb[b])
@@ -287,10 +288,11 @@ class DeviceDataset:
             adjacency._blocks = np.concatenate([[0], np.cumsum(n[g0_:g0_ + B])]).astype(np.int64)      # one diagonal block per graph
             if self.focus == 'g':
                 g0 = int(first[b])
-                gn_b = torch.from_numpy(n[g0:g0 + B]).to(dev)
+                gn_h = n[g0:g0 + B]                                                  # (uploaded by the thunk: training only)
                 b_ngs = ng_scale[g0:g0 + B]
 
-                def nodegraph_by_source(gn_b=gn_b, b_ngs=b_ngs, Nn=Nn, B=B):
+                def nodegraph_by_source(gn_h=gn_h, b_ngs=b_ngs, Nn=Nn, B=B):
+                    gn_b = torch.from_numpy(gn_h).to(dev)
                     return dict(rowptr=torch.arange(Nn + 1, dtype=torch.int32, device=dev),
                                 src=torch.repeat_interleave(torch.arange(B, dtype=torch.int32, device=dev), gn_b),
                                 w=torch.repeat_interleave(b_ngs, gn_b), row_scale=None, n_src=B, n_dst=Nn, nnz=Nn)
@@ -304,7 +306,7 @@ class DeviceDataset:
             _OUT_INDEX[key] = (out_index[int(bO[b]):int(bO[b] + Ob[b])], b_set, b_out, b_set._version, b_out._version)
             out.append(DeviceBatch(nodes=nodes[n0:n1], arcs=b_arcs, targets=targets[t0:t1], sample_weight=sw[t0:t1],
                                    set_mask=b_set, output_mask=b_out,
-                                   DIM_NODE_LABEL=torch.tensor([self.L], dtype=torch.int32), DIM_ARC_LABEL=self.W - 2, DIM_TARGET=self.T,
+                                   DIM_NODE_LABEL=dim_node_label, DIM_ARC_LABEL=self.W - 2, DIM_TARGET=self.T,
                                    Adjacency=adjacency, ArcNode=arcnode, NodeGraph=nodegraph, aggregation_mode=self.mode, device=dev,
                                    dtype='float32'))
             weakref.finalize(out[-1], _OUT_INDEX.pop, key, None)

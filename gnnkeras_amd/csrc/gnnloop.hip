@@ -28,6 +28,7 @@
 #include "kernel_state_wide.hpp"
 #include "kernels_batch.hpp"
 #include "kernels_setup.hpp"
+#include "kernel_rowdense.hpp"
 
 namespace {
 
@@ -175,6 +176,51 @@ bool thin_dense_applies(const gnn::SegDenseArgs &a) {
     return (size_t)K * a.H * sizeof(float) <= 48 * 1024;
 }
 
+int device_cus();
+
+// One contiguous input matrix of 16 .. 64 columns at large M (the layers behind the first): rows straight into the matrix cores
+// (kernel_rowdense.hpp).  GNN_ROWDENSE=0 keeps k_segdense.
+bool rowdense_applies(const gnn::SegDenseArgs &a) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("GNN_ROWDENSE"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off || a.M < 32768 || a.nseg != 1 || a.addend || a.out_rowidx || a.in_gamma || a.act == GNN_ACT_SOFTMAX) return false;
+    const gnn::Seg &s = a.seg[0];
+    if (s.rowidx || s.wrow != 0 || s.width < 8 || s.width > 64 || s.width % 4 || a.H < 8 || a.H > 64 || a.H % 4) return false;
+    if (s.ld % 4 || a.ldy % 4 || (a.pred_flag && a.ld_pred % 4)) return false;
+    if (((reinterpret_cast<uintptr_t>(s.ptr) | reinterpret_cast<uintptr_t>(a.Y) | reinterpret_cast<uintptr_t>(a.pred_old)) & 15) != 0) return false;
+    if ((size_t)a.M * std::max(std::max(s.ld, a.ldy), a.ld_pred) * 4 >= ((size_t)1 << 32)) return false;
+    return true;
+}
+
+template <int KQ>
+int launch_rowdense_k(const gnn::RowDenseArgs &r, int nct, int grid, hipStream_t st) {
+    switch (nct) {
+        case 1: gnn::k_rowdense<KQ, 1><<<grid, 64 * gnn::TB_WAVES, gnn::rowdense_lds<KQ, 1>(), st>>>(r); break;
+        case 2: gnn::k_rowdense<KQ, 2><<<grid, 64 * gnn::TB_WAVES, gnn::rowdense_lds<KQ, 2>(), st>>>(r); break;
+        case 3: gnn::k_rowdense<KQ, 3><<<grid, 64 * gnn::TB_WAVES, gnn::rowdense_lds<KQ, 3>(), st>>>(r); break;
+        default: gnn::k_rowdense<KQ, 4><<<grid, 64 * gnn::TB_WAVES, gnn::rowdense_lds<KQ, 4>(), st>>>(r); break;
+    }
+    LAUNCH_OK();
+    return 0;
+}
+
+int launch_rowdense(const gnn::SegDenseArgs &a, hipStream_t st) {
+    gnn::RowDenseArgs r;
+    memset(&r, 0, sizeof(r));
+    const gnn::Seg &s = a.seg[0];
+    r.gate = a.gate; r.M = a.M; r.X = s.ptr; r.ldx = s.ld; r.K = s.width; r.W = a.W; r.ldw = a.ldw; r.bias = a.bias; r.H = a.H; r.act = a.act;
+    r.Y = a.Y; r.ldy = a.ldy;
+    r.pred_old = a.pred_old; r.ld_pred = a.ld_pred; r.thr = a.pred_thr; r.pred_flag = a.pred_flag; r.pred_k = a.pred_k; r.pred_kval = a.pred_kval;
+    const int kq = (s.width + 15) / 16, nct = (a.H + 15) / 16;
+    const int grid = std::max(1, std::min(2 * device_cus(), cdiv(cdiv(a.M, 16), gnn::TB_WAVES)));
+    switch (kq) {
+        case 1: return launch_rowdense_k<1>(r, nct, grid, st);
+        case 2: return launch_rowdense_k<2>(r, nct, grid, st);
+        case 3: return launch_rowdense_k<3>(r, nct, grid, st);
+        default: return launch_rowdense_k<4>(r, nct, grid, st);
+    }
+}
+
 int launch_segdense(gnn::SegDenseArgs &a, hipStream_t st) {
     if (a.M == 0) return 0;
     if (a.H <= 4) {
@@ -193,6 +239,7 @@ int launch_segdense(gnn::SegDenseArgs &a, hipStream_t st) {
             return 0;
         }
     }
+    if (rowdense_applies(a)) return launch_rowdense(a, st);
     if (a.M <= 16384) gnn::k_segdense<4><<<cdiv(a.M, gnn::SD_TM), 256, 0, st>>>(a);      // latency regime
     else              gnn::k_segdense<1><<<cdiv(a.M, gnn::SD_TM), 256, 0, st>>>(a);      // throughput regime
     LAUNCH_OK();

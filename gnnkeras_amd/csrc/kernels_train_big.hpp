@@ -159,6 +159,7 @@ struct TrainFwdArgs {
 template <int NCT> struct BFrag;
 template <> struct BFrag<1> { float v[1]; __device__ __forceinline__ void load(const float *p) { v[0] = *p; } };
 template <> struct BFrag<2> { float v[2]; __device__ __forceinline__ void load(const float *p) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; } };
+template <> struct BFrag<3> { float v[3]; __device__ __forceinline__ void load(const float *p) { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; } };
 template <> struct BFrag<4> { float v[4]; __device__ __forceinline__ void load(const float *p) { const f32x4 t = *reinterpret_cast<const f32x4 *>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; } };
 template <> struct BFrag<8> { float v[8]; __device__ __forceinline__ void load(const float *p) {
     const f32x4 t = *reinterpret_cast<const f32x4 *>(p), u = *reinterpret_cast<const f32x4 *>(p + 4);

@@ -671,3 +671,22 @@ def test_arc_and_graph_focused_shards_on_the_device(focus, d):
         out = np.full(o64.shape, np.nan, dtype=np.float32)
         for sl, o in zip(shards, outs): out[np.searchsorted(mask, sl.plan.arc_out_index)] = sl._arc_outputs(float(o[0])).cpu().numpy()
         assert rel_err(out, o64) <= TOL
+
+
+@pytest.mark.parametrize('M,K,ldx,H,act,bias', [(131072, 64, 64, 64, 'selu', True), (70001, 48, 52, 24, 'tanh', True), (40000, 8, 8, 64, 'relu', False),
+                                              (100003, 20, 64, 12, 'linear', True), (65536, 64, 68, 40, 'sigmoid', True)])
+def test_row_streaming_dense_layer_matches_float64(M, K, ldx, H, act, bias):
+    """`gnn_dense` over ONE contiguous matrix at large M runs k_rowdense (rows straight into the matrix cores): ragged last tile, leading
+    dimensions above the width, widths that are not multiples of 16, no bias - against the float64 product."""
+    from gnnkeras_amd.Models.training import _Prim
+    rng = np.random.default_rng(M + K)
+    p = _Prim(torch.device('cuda'))
+    x = dev(rng.normal(0, 1, (M, ldx)).astype(np.float32))[:, :K]
+    W = dev(rng.normal(0, 0.3, (K, H)).astype(np.float32))
+    b = dev(rng.normal(0, 0.3, H).astype(np.float32)) if bias else None
+    Y = torch.full((M, H), float('nan'), dtype=torch.float32, device='cuda')
+    p.dense([(x, None)], W, H, b, nat.ACTIVATIONS[act], Y)
+    torch.cuda.synchronize()
+    z = x.double() @ W.double() + (b.double() if bias else 0.0)
+    want = {'selu': torch.nn.functional.selu, 'linear': lambda t: t, 'tanh': torch.tanh, 'relu': torch.relu, 'sigmoid': torch.sigmoid}[act](z)
+    assert float((Y.double() - want).abs().max() / want.abs().max()) <= 1e-5

@@ -221,6 +221,47 @@ int launch_rowdense(const gnn::SegDenseArgs &a, hipStream_t st) {
     }
 }
 
+// Wide layers over one or two contiguous matrices + a per-row addend at large M (the un-fused first layer of state widths above 128,
+// wide hidden layers): k_rowdense_wide, output columns in passes of 64.
+bool rowdense_wide_applies(const gnn::SegDenseArgs &a) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("GNN_ROWDENSE"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off || a.M < 32768 || a.nseg < 1 || a.nseg > 2 || a.out_rowidx || a.add_rowidx || a.in_gamma || a.pred_flag || a.act == GNN_ACT_SOFTMAX) return false;
+    if (a.H <= 64 || a.H % 4 || a.ldy % 4 || (a.addend && a.ld_add % 4)) return false;
+    int chunks = 0;
+    uintptr_t bits = reinterpret_cast<uintptr_t>(a.Y) | reinterpret_cast<uintptr_t>(a.addend);
+    size_t span = std::max((size_t)a.ldy, (size_t)a.ld_add);
+    for (int s = 0; s < a.nseg; ++s) {
+        const gnn::Seg &g = a.seg[s];
+        if (g.rowidx || g.width < 4 || g.width % 4 || g.ld % 4) return false;
+        chunks += (g.width + 15) / 16;
+        bits |= reinterpret_cast<uintptr_t>(g.ptr);
+        span = std::max(span, (size_t)g.ld);
+    }
+    if (chunks > 32 || (bits & 15) != 0 || (size_t)a.M * span * 4 >= ((size_t)1 << 32)) return false;
+    return true;
+}
+
+int launch_rowdense_wide(const gnn::SegDenseArgs &a, hipStream_t st) {
+    gnn::RowDenseWideArgs r;
+    memset(&r, 0, sizeof(r));
+    r.gate = a.gate; r.M = a.M; r.nseg = a.nseg;
+    int chunks = 0;
+    for (int s = 0; s < a.nseg; ++s) { r.X[s] = a.seg[s].ptr; r.ldx[s] = a.seg[s].ld; r.width[s] = a.seg[s].width; r.wrow[s] = a.seg[s].wrow; chunks += (a.seg[s].width + 15) / 16; }
+    r.W = a.W; r.ldw = a.ldw; r.bias = a.addend ? nullptr : a.bias; r.addend = a.addend; r.ld_add = a.ld_add;
+    r.H = a.H; r.act = a.act; r.Y = a.Y; r.ldy = a.ldy;
+    const int passes = cdiv(a.H, 64);
+    const size_t lds = (size_t)(16 * chunks * 64 + 64) * sizeof(float);
+    dim3 grid(std::max(1, std::min(cdiv(device_cus(), passes), cdiv(cdiv(a.M, 32), gnn::RDW_WAVES))), passes);
+    {
+        static bool once = false;
+        if (!once) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gnn::k_rowdense_wide<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 32 * 64 * 4 + 256)); once = true; }
+        gnn::k_rowdense_wide<8><<<grid, 64 * gnn::RDW_WAVES, lds, st>>>(r);
+    }
+    LAUNCH_OK();
+    return 0;
+}
+
 int launch_segdense(gnn::SegDenseArgs &a, hipStream_t st) {
     if (a.M == 0) return 0;
     if (a.H <= 4) {
@@ -240,6 +281,7 @@ int launch_segdense(gnn::SegDenseArgs &a, hipStream_t st) {
         }
     }
     if (rowdense_applies(a)) return launch_rowdense(a, st);
+    if (rowdense_wide_applies(a)) return launch_rowdense_wide(a, st);
     if (a.M <= 16384) gnn::k_segdense<4><<<cdiv(a.M, gnn::SD_TM), 256, 0, st>>>(a);      // latency regime
     else              gnn::k_segdense<1><<<cdiv(a.M, gnn::SD_TM), 256, 0, st>>>(a);      // throughput regime
     LAUNCH_OK();

@@ -103,3 +103,110 @@ template <int KQ, int NCT>
 inline size_t rowdense_lds() { return (size_t)(16 * KQ * 16 * NCT + 16 * NCT) * sizeof(float); }
 
 }  // namespace gnn
+
+namespace gnn {
+
+// The same for WIDE layers (state widths above 128 take the un-fused path: its first layer is [state | agg] . W + C with 400+ input
+// and 200+ output columns, 72 % of an iteration in k_segdense, which re-stages its input for every 64 output columns through LDS
+// with 4-byte accesses: 39 TFLOP/s).  Up to two contiguous input matrices and a per-row addend; the output columns are cut into
+// passes of 64 (blockIdx.y): a workgroup keeps ITS pass of the weights in LDS (all K rows x 64 columns, fragment order), a lane
+// loads every 16-byte piece of its row once per pass and the matrix cores run K / 4 x 4 MFMAs per 16-row tile.
+struct RowDenseWideArgs {
+    const int *gate; int M;
+    const float *X[2]; int ldx[2], width[2], wrow[2]; int nseg;
+    const float *W; int ldw;
+    const float *bias; const float *addend; int ld_add;
+    int H, act; float *Y; int ldy;
+};
+
+constexpr int RDW_WAVES = 16;             // one workgroup per CU (its pass of the weights fills most of the LDS): 16 waves = 4 per SIMD
+template <int KQM>
+__global__ void __launch_bounds__(64 * RDW_WAVES, 4) k_rowdense_wide(RowDenseWideArgs a) {
+    if (gate_closed(a.gate)) return;
+    constexpr int NCT = 4, HP = 64;
+    extern __shared__ __attribute__((aligned(16))) float rd_smem[];
+    const int Q0 = (a.width[0] + 15) >> 4, Q1 = a.nseg > 1 ? (a.width[1] + 15) >> 4 : 0, KQ = Q0 + Q1;
+    float *Wl = rd_smem;                                // [4 KQ k-steps][4 g][16 c][NCT]
+    float *bias_l = rd_smem + 16 * KQ * HP;             // [HP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int h0 = HP * blockIdx.y;
+    for (int i = tid; i < 16 * KQ * HP; i += 64 * RDW_WAVES) {
+        const int k = i / HP, hh = i % HP;
+        const int q = k >> 4, sg = q < Q0 ? 0 : 1, col = k - 16 * (sg ? Q0 : 0);
+        const float v = (col < a.width[sg] && h0 + hh < a.H) ? a.W[(size_t)(a.wrow[sg] + col) * a.ldw + h0 + hh] : 0.0f;
+        const int rem = k & 15, gg = rem >> 2, e = rem & 3;
+        Wl[(((4 * q + e) * 4 + gg) * 16 + (hh & 15)) * NCT + (hh >> 4)] = v;
+    }
+    for (int hh = tid; hh < HP; hh += 64 * RDW_WAVES) bias_l[hh] = (a.bias && h0 + hh < a.H) ? a.bias[h0 + hh] : 0.0f;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t r_x0 = buf_rsrc(a.X[0]), r_x1 = buf_rsrc(a.nseg > 1 ? a.X[1] : nullptr), r_c = buf_rsrc(a.addend), r_y = buf_rsrc(a.Y);
+    // TWO 16-row tiles per wave and trip: every weight fragment read from LDS feeds two MFMAs.  (One tile per trip reads 16 bytes per
+    // lane and MFMA quartet: 16 waves x 1 KB per 512 matrix-pipe cycles = the whole 128 B / clock of the LDS - the layer ran at 42 TFLOP/s.)
+    const int n_pairs = (a.M + 31) >> 5;
+#pragma unroll 1
+    for (int t = blockIdx.x * RDW_WAVES + wave; t < n_pairs; t += gridDim.x * RDW_WAVES) {
+        const int row0 = 32 * t + c, row1 = row0 + 16;
+        const bool in0 = row0 < a.M, in1 = row1 < a.M;
+        f32x4 acc0[NCT], acc1[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_l + 16 * ct + 4 * g);
+            acc0[ct] = bv; acc1[ct] = bv;
+            if (a.addend) {
+                const bool hv = h0 + 16 * ct + 4 * g < a.H;
+                acc0[ct] += buf_ld_f32x4(r_c, (in0 && hv) ? ((unsigned)row0 * (unsigned)a.ld_add + (unsigned)(h0 + 16 * ct + 4 * g)) * 4u : BUF_OFF);
+                acc1[ct] += buf_ld_f32x4(r_c, (in1 && hv) ? ((unsigned)row1 * (unsigned)a.ld_add + (unsigned)(h0 + 16 * ct + 4 * g)) * 4u : BUF_OFF);
+            }
+        }
+        // the rows' 16-byte pieces in blocks of KQM chunks (all loads of a block in flight, then its MFMAs)
+#pragma unroll 1
+        for (int qb = 0; qb < KQ; qb += KQM) {
+            f32x4 A0[KQM], A1[KQM];
+#pragma unroll
+            for (int qq = 0; qq < KQM; ++qq) {           // (chunks behind KQ: predicated off, never multiplied)
+                const int q = qb + qq;
+                const bool s1 = q >= Q0;
+                const int col = 16 * (q - (s1 ? Q0 : 0)) + 4 * g;
+                const bool cv = q < KQ && col < a.width[s1 ? 1 : 0];
+                const unsigned ld = (unsigned)a.ldx[s1 ? 1 : 0];
+                A0[qq] = buf_ld_f32x4(s1 ? r_x1 : r_x0, (in0 && cv) ? ((unsigned)row0 * ld + (unsigned)col) * 4u : BUF_OFF);   // (s1 is uniform: a scalar select)
+                A1[qq] = buf_ld_f32x4(s1 ? r_x1 : r_x0, (in1 && cv) ? ((unsigned)row1 * ld + (unsigned)col) * 4u : BUF_OFF);
+            }
+#pragma unroll
+            for (int qq = 0; qq < KQM; ++qq) {
+                if (qb + qq < KQ) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        BFrag<NCT> w;
+                        w.load(Wl + (((4 * (qb + qq) + e) * 4 + g) * 16 + c) * NCT);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) {
+                            acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[ct], A0[qq][e], acc0[ct], 0, 0, 0);
+                            acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[ct], A1[qq][e], acc1[ct], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        TB_MFMA_DRAIN();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int row = half ? row1 : row0;
+            const bool in = half ? in1 : in0;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                f32x4 v = half ? acc1[ct] : acc0[ct];
+                activate4(a.act, v);
+                const int hcol = h0 + 16 * ct + 4 * g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (in && hcol + e < a.H) ? v[e] : 0.0f;
+                const u32x4 bits = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(bits, r_y, (in && hcol < a.H) ? (int)(((unsigned)row * (unsigned)a.ldy + (unsigned)hcol) * 4u) : (int)BUF_OFF, 0, 0);
+            }
+        }
+    }
+}
+
+}  // namespace gnn

@@ -690,3 +690,25 @@ def test_row_streaming_dense_layer_matches_float64(M, K, ldx, H, act, bias):
     z = x.double() @ W.double() + (b.double() if bias else 0.0)
     want = {'selu': torch.nn.functional.selu, 'linear': lambda t: t, 'tanh': torch.tanh, 'relu': torch.relu, 'sigmoid': torch.sigmoid}[act](z)
     assert float((Y.double() - want).abs().max() / want.abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize('N,d,hidden,mode', [(40_000, 200, None, 'average'), (36_000, 132, None, 'sum'), (40_000, 96, [96], 'average'),
+                                             (33_000, 160, [72], 'normalized')])
+def test_wide_layers_of_the_unfused_path_at_scale(N, d, hidden, mode):
+    """State widths above 128 (and two-layer networks between 65 and 128) take the un-fused path; from 32 768 rows its dense layers run
+    k_rowdense_wide / k_rowdense (rows straight into the matrix cores, output columns in passes of 64): k, state and output against the
+    fp64 oracle."""
+    from test_gpu_parity import starter_nets
+    rng = np.random.default_rng(d)
+    g = er_graph(N, 5 * N, seed=9, aggregation_mode=mode)
+    seq = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)
+    x = seq[0][0]
+    ns, no = starter_nets('n', d, hidden_state=hidden, act='tanh', scale=0.2 if mode != 'sum' else 0.02)
+    model = GNNnodeBased(ns, no, d, 4, 0.0)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    k, st, o = model.Loop(*model.process_inputs(x), state0=dev(s0))
+    torch.cuda.synchronize()
+    assert 'un-fused' in _last_kernel(), _last_kernel()
+    assert float(k) == float(k64)
+    assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL

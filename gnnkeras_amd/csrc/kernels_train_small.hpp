@@ -293,6 +293,18 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
     const bool run = __hip_atomic_load(a.flag0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     __syncthreads();
 
+    // the kernel rows as this lane's A operands (k-step (qq, e) of lane group g = input column 16 qq + 4 g + e), in registers for the whole loop
+    // (widths 16 / 32: 8 / 32 registers; at 64 they would be 128 and spill: that width keeps reading them from LDS)
+    constexpr bool WREG = SQ <= 2;
+    float wreg[WREG ? 2 * S / 16 : 1][4][SQ];
+    if (WREG) {
+#pragma unroll
+        for (int qq = 0; qq < 2 * S / 16; ++qq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ct = 0; ct < SQ; ++ct) wreg[WREG ? qq : 0][e][ct] = W0[(16 * qq + 4 * g + e) * LDW + c + 16 * ct];
+    }
     int k_done = 0, any_prev = 0;
     TS_CLOCK();
     for (int it = 0; run && it < a.K; ++it) {
@@ -325,9 +337,12 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
             // not cancel once the states settle
             float s1 = 0.0f, s2 = 0.0f;
             const float pv = piv[col];
-#pragma unroll 8
-            for (int rr = part_i * RPG; rr < (part_i + 1) * RPG; ++rr) {
-                const float x = rr < nt ? Xs[rr * LDX + col] - pv : 0.0f;
+            float xr[RPG];                                     // every read of the column piece issued before the first add (rows behind nt are zero)
+#pragma unroll
+            for (int u = 0; u < RPG; ++u) xr[u] = Xs[(part_i * RPG + u) * LDX + col];
+#pragma unroll
+            for (int u = 0; u < RPG; ++u) {
+                const float x = part_i * RPG + u < nt ? xr[u] - pv : 0.0f;
                 s1 += x; s2 = fmaf(x, x, s2);
             }
             red[part_i * 4 * S + col] = s1; red[part_i * 4 * S + 2 * S + col] = s2;
@@ -373,7 +388,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
         for (int ct = 0; ct < SQ; ++ct) acc[ct] = cc[ct];
         // k-step (qq, e) takes input column 16 qq + 4 g + e from lane group g: one 16-byte LDS read feeds four steps
         const float *xrow = Xs + (16 * wave + c) * LDX + 4 * g;
-#pragma unroll 2
+#pragma unroll
         for (int qq = 0; qq < 2 * S / 16; ++qq) {
             f32x4 xv = *reinterpret_cast<const f32x4 *>(xrow + 16 * qq);
             if (bn) {
@@ -385,7 +400,8 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
             for (int e = 0; e < 4; ++e) {
                 const float *wr = W0 + (16 * qq + 4 * g + e) * LDW + c;
 #pragma unroll
-                for (int ct = 0; ct < SQ; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * ct], xv[e], acc[ct], 0, 0, 0);
+                for (int ct = 0; ct < SQ; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(WREG ? wreg[WREG ? qq : 0][e][ct] : wr[16 * ct], xv[e], acc[ct], 0, 0, 0);
             }
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");          // (MFMA results consumed behind a branch: see kernels_train_big.hpp)

@@ -29,6 +29,7 @@
 #include "kernels_batch.hpp"
 #include "kernels_setup.hpp"
 #include "kernel_rowdense.hpp"
+#include "kernel_state_xwide.hpp"
 
 namespace {
 
@@ -438,6 +439,7 @@ struct Plan {
     float *agg_arcs, *agg_nodes; int ld_agg_nodes;
     float *C; int ldC;
     float *Xc;                       // constant inputs [N, 32] for the XC kernel variant (xc_ok); their weights: TypePlan::Wc
+    float *Wx;                       // state widths 129 .. 256: first-layer weights in MFMA fragment order (kernel_state_xwide.hpp)
     bool xc_ok;
     float *buf[2], *agg;
     float *hid[2]; int ld_hid;
@@ -612,6 +614,7 @@ int make_plan(const gnn_loop_args_t &a, void *ws, Plan &p, bool validate_ptrs) {
     p.buf[0] = c.take<float>((size_t)(p.N + p.n_heavy) * p.SP + 64);
     p.buf[1] = c.take<float>((size_t)(p.N + p.n_heavy) * p.SP + 64);
     p.agg = c.take<float>((size_t)p.N * p.SP);
+    p.Wx = c.take<float>((p.SP > 128 && p.S <= 256) ? gnn::xwide_weight_floats(p.S, p.SP) : 0);
     p.ld_hid = p.Hmax_state;
     p.hid[0] = c.take<float>((size_t)p.N * p.ld_hid);
     p.hid[1] = c.take<float>((size_t)p.N * p.ld_hid);
@@ -1146,6 +1149,39 @@ int fusable(const gnn_loop_args_t &a, const Plan &p) {
     return two ? 2 : 1;
 }
 
+// State widths 129 .. 256 (kernel_state_xwide.hpp): homogeneous graphs, one Dense layer, no hub split (make_plan keeps hub rows
+// off these widths), every array within the 32-bit byte offsets of a buffer window.  GNN_XWIDE=0 keeps the un-fused path.
+bool xwide_applies(const gnn_loop_args_t &a, const Plan &p) {
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("GNN_XWIDE"); env = (e && atoi(e) == 0) ? 0 : 1; }
+    if (!env || (a.flags & GNN_FLAG_UNFUSED)) return false;
+    if (p.SP <= 128 || p.S > 256 || p.composite || p.T != 1 || p.tp[0].rows || p.n_heavy != 0 || p.N < 1 || !p.Wx) return false;
+    const gnn_mlp_t &m = a.net_state[0];
+    if (m.n_layers != 1 || m.activation[0] == GNN_ACT_SOFTMAX || (int)m.units[0] != p.S) return false;
+    if ((size_t)std::max(a.adjacency.n_src, p.N) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return false;
+    if ((size_t)a.adjacency.nnz * 4 >= ((size_t)1 << 32) || ((size_t)p.N + 1) * 4 >= ((size_t)1 << 32)) return false;
+    return true;
+}
+
+int setup_xwide(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
+    return gnn::launch_xwide_weights(p.tp[0].Wf, (int)a.net_state[0].units[0], p.S, p.tp[0].wrow_state, p.tp[0].wrow_agg, p.SP, p.Wx, st);
+}
+
+int iteration_xwide(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src, float *dst, int *flag_next, float *k_out,
+                    float k_val, hipStream_t st) {
+    gnn::XWideArgs xa;
+    memset(&xa, 0, sizeof(xa));
+    xa.gate = gate; xa.n_gate = gate ? 1 : 0; xa.gate_stride = 0;
+    xa.rowptr = a.adjacency.rowptr; xa.src = a.adjacency.src; xa.w = a.adjacency.w; xa.row_scale = a.adjacency.row_scale;
+    xa.state_in = src; xa.state_out = dst;
+    xa.C = p.C; xa.ldC = p.ldC; xa.Wx = p.Wx;
+    xa.N = p.N; xa.S = p.S; xa.SP = p.SP;
+    xa.act = (int)a.net_state[0].activation[0];
+    xa.thr = a.state_threshold; xa.flag_next = flag_next; xa.k_out = k_out; xa.k_val = k_val; xa.err = p.err;
+    FUSED_OK(gnn::launch_xwide(xa, device_cus(), st));
+    return 0;
+}
+
 // may ONE ITERATION of this model run in a fused launch? (the per-iteration entry points and the loop's fallback)
 bool can_fuse(const gnn_loop_args_t &a, const Plan &p) {
     const int f = fusable(a, p);
@@ -1162,6 +1198,14 @@ extern "C" {
 int gnn_f4_profile(unsigned long long *out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gnn::g_f4_prof), 64) != hipSuccess) return 1;
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(gnn::g_f4_prof), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+#ifdef XW_PROFILE
+// experiment-only: shader-clock totals of k_state_xwide's phases (not part of the ABI)
+int gnn_xw_profile(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gnn::g_xw_prof), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(gnn::g_xw_prof), z, 64) != hipSuccess) return 1; }
     return 0;
 }
 #endif
@@ -1269,6 +1313,8 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
 
     const bool fused = can_fuse(a, p);
     const bool prefix = !fused && prefix_applies(a, p);
+    const bool xwide = !fused && !prefix && xwide_applies(a, p);
+    if (xwide) TRY(setup_xwide(a, p, st));
     const bool no_exit = (a.flags & GNN_FLAG_NO_EARLY_EXIT) != 0;
     // Ping-pong buffers.  When the caller's state_out has the padded layout too, it stands in for the buffer the LAST
     // iteration writes (B[max_iteration & 1]): a loop that runs to max_iteration leaves the result where the caller
@@ -1295,6 +1341,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         float *dst = B[(it + 1) & 1];
         if (fused)       TRY(iteration_fused(a, p, gate, gate ? 1 : 0, 0, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
         else if (prefix) TRY(iteration_prefix(a, p, gate, src, dst, p.flags + it + 1, a.k_out, (float)(it + 1), st));
+        else if (xwide)  TRY(iteration_xwide(a, p, gate, src, dst, p.flags + it + 1, a.k_out, (float)(it + 1), st));
         else             TRY(iteration_unfused(a, p, gate, src, dst, 0, p.flags + it + 1, a.k_out, (float)(it + 1), st));
     }
 
@@ -1309,7 +1356,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         }
     }
     TRY(output_stage(a, p, st));
-    if (!loop_done && fused && a.max_iteration > 0) TRY(launch_fold_error(p, a.k_out, st));
+    if (!loop_done && (fused || xwide) && a.max_iteration > 0) TRY(launch_fold_error(p, a.k_out, st));
     return 0;
 }
 
@@ -1399,7 +1446,10 @@ int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *st
     if (flag_out) HIP_OK(hipMemsetAsync(flag_out, 0, sizeof(int32_t), st));
     if (can_fuse(a, p))
         TRY(iteration_fused(a, p, nullptr, 0, 0, p.buf[0], p.buf[1], 0, flag_out, nullptr, 0.f, st));
-    else
+    else if (xwide_applies(a, p)) {
+        TRY(setup_xwide(a, p, st));
+        TRY(iteration_xwide(a, p, nullptr, p.buf[0], p.buf[1], flag_out, nullptr, 0.f, st));
+    } else
         TRY(iteration_unfused(a, p, nullptr, p.buf[0], p.buf[1], 0, flag_out, nullptr, 0.f, st));
     return launch_copy2d(nullptr, p.buf[1], p.SP, state_out, p.S, p.N, p.S, p.S, st);
 }

@@ -693,11 +693,11 @@ def test_row_streaming_dense_layer_matches_float64(M, K, ldx, H, act, bias):
 
 
 @pytest.mark.parametrize('N,d,hidden,mode', [(40_000, 200, None, 'average'), (36_000, 132, None, 'sum'), (40_000, 96, [96], 'average'),
-                                             (33_000, 160, [72], 'normalized')])
+                                             (33_000, 160, [72], 'normalized'), (34_000, 300, None, 'average')])
 def test_wide_layers_of_the_unfused_path_at_scale(N, d, hidden, mode):
-    """State widths above 128 (and two-layer networks between 65 and 128) take the un-fused path; from 32 768 rows its dense layers run
-    k_rowdense_wide / k_rowdense (rows straight into the matrix cores, output columns in passes of 64): k, state and output against the
-    fp64 oracle."""
+    """Two-layer networks between 65 and 128, and everything above 256 (or with GNN_FLAG_UNFUSED), take the un-fused path; from 32 768
+    rows its dense layers run k_rowdense_wide / k_rowdense (rows straight into the matrix cores, output columns in passes of 64): k,
+    state and output against the fp64 oracle."""
     from test_gpu_parity import starter_nets
     rng = np.random.default_rng(d)
     g = er_graph(N, 5 * N, seed=9, aggregation_mode=mode)
@@ -705,6 +705,7 @@ def test_wide_layers_of_the_unfused_path_at_scale(N, d, hidden, mode):
     x = seq[0][0]
     ns, no = starter_nets('n', d, hidden_state=hidden, act='tanh', scale=0.2 if mode != 'sum' else 0.02)
     model = GNNnodeBased(ns, no, d, 4, 0.0)
+    if hidden is None and d <= 256: model.native_flags = nat.FLAG_UNFUSED       # (these widths have a fused kernel of their own now)
     s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
     k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
     k, st, o = model.Loop(*model.process_inputs(x), state0=dev(s0))
@@ -712,3 +713,45 @@ def test_wide_layers_of_the_unfused_path_at_scale(N, d, hidden, mode):
     assert 'un-fused' in _last_kernel(), _last_kernel()
     assert float(k) == float(k64)
     assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# state widths 129 .. 256: gathered rows in LDS, weights streamed from L2 in fragment order (kernel_state_xwide.hpp)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('N,arcs_per_node,d,mode,act,thr', [(40_000, 5, 200, 'average', 'tanh', 0.0), (5_003, 6, 130, 'sum', 'tanh', 0.0),
+                                                            (3_000, 40, 256, 'normalized', 'selu', 0.0), (20_011, 8, 160, 'average', 'tanh', -1.0),
+                                                            (17, 3, 129, 'average', 'sigmoid', 0.0), (9_000, 20, 224, 'sum', 'relu', 0.0),
+                                                            (33, 2, 192, 'normalized', 'tanh', 0.0)])
+def test_state_widths_129_to_256_run_fused(N, arcs_per_node, d, mode, act, thr):
+    """`state_vect_dim` between 129 and 256 (reference GNN.py:26-28 allows any width): one launch per iteration (k_state_xwide) -
+    k, state and output against the fp64 oracle and against the un-fused path; row counts that are not multiples of the 32-row tile,
+    in-degrees above 16 (the gather's second chunk), per-row and per-arc weights, widths that are not multiples of 32 / 8, an
+    activation with f(0) != 0 (pad columns must stay zero), an early exit."""
+    from test_gpu_parity import starter_nets
+    rng = np.random.default_rng(N + d)
+    g = er_graph(N, arcs_per_node * N, seed=5, aggregation_mode=mode)
+    seq = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)
+    x = seq[0][0]
+    scale = {'sum': 0.1 / arcs_per_node, 'average': 0.2, 'normalized': 0.2}[mode] * (0.5 if thr < 0 else 1.0)
+    ns, no = starter_nets('n', d, act=act, scale=scale)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    K = 5
+    if thr < 0:
+        seen = {}
+        for thr in (0.005, 0.01, 0.02, 0.05, 0.1, 0.2, 0.4):
+            k = seen[thr] = float(oracle_loop(GNNnodeBased(ns, no, d, K, thr), x, s0, np.float64)[0])
+            if 1 < k < K: break
+        assert 1 < k < K, seen
+    model = GNNnodeBased(ns, no, d, K, thr)
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    inputs = model.process_inputs(x)
+    got = {}
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=dev(s0))
+        torch.cuda.synchronize()
+        assert ('k_state_xwide' if flags == 0 else 'un-fused') in _last_kernel(), _last_kernel()
+        assert float(k) == float(k64), (flags, float(k), k64)
+        assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, flags
+        got[flags] = st
+    assert rel_err(got[0].cpu().numpy(), got[nat.FLAG_UNFUSED].cpu().numpy()) <= TOL

@@ -17,6 +17,15 @@
 //     instruction against 104-126 on the 16x16x4 one the narrower kernels use (scripts/micro/mfma_peak.hip), and a 32 x 32 block
 //     needs one operand value per lane and 4 096 FLOP.  Operands are swapped (weights = A, rows = B) so that a lane ends up with
 //     columns 8 q + 4 (lane / 32) + 0..3 of ITS row: C, the old state and the new state all move as 16-byte pieces.
+// Measured (d = 200, 300 k nodes / 3 M arcs, scripts/dev/xw_prof.py on a -DXW_PROFILE build): 742 us per iteration against 1 150 un-fused
+// (34 -> 53 % of the HBM roofline of its algorithmic bytes).  Per tile a matrix wave spends 24 100 cycles in the K loop (two waves
+// share a SIMD's matrix pipe: 25 600 would be the pipe's whole time), 8 300 in the epilogue and 16 200 waiting for the gather waves;
+// rocprofv3: SQ_VALU_MFMA_BUSY_CYCLES 8.4e8 = 46 % of the SIMD-cycles of the launch at the 2.25 GHz GRBM_GUI_ACTIVE shows.  The launch
+// is bound by the gather: 8 gather waves per CU move 4.7 TB/s of lines next to the weight stream (6.2 TB/s with the MFMAs compiled
+// out, 526 us) - the working set (two 240 MB state buffers) is past the Infinity Cache, and this memory system rewards the NUMBER of
+// waves with a gather outstanding (profiles/r01_gather_sweep.txt), of which a 16-wave workgroup has only these 8 left.  Tried and
+// measured slower: 4 / 8 / 10 / 12 weight pieces in flight (722 - 772 us); two blocks per matrix wave on alternating tiles so that
+// one wave's epilogue lies under the other's K loop (779 us: the gather still sets the pace).
 // Slots are handed over with monotonic LDS counters (rows deposited / waves done / rounds freed), workgroup scope, bounded
 // spins that raise the sticky error word (k < 0) exactly as in k_state_fused4.  The convergence predicate needs whole rows:
 // every matrix wave leaves its block's share of |new - old|^2 and |old|^2 per row in LDS, the wave that finishes the tile last
@@ -182,11 +191,7 @@ __global__ void __launch_bounds__(1024) k_state_xwide(XWideArgs a) {
                     if (HAS_W) acc += xw_readlane_f(wA, 16 * r4 + x) * v[x];
                     else acc += v[x];
                     const unsigned sid = (unsigned)(r4 < 3 ? xw_readlane_i(idA, (16 * (r4 + 1) + x) & 63) : xw_readlane_i(idB, x));
-#ifdef XW_NO_GATHER
-                    v[x] = buf_ld_f32x4(r_state, (x < degN && act_l && sid == 0xFFFFFFF0u) ? sid * (unsigned)(SP * 4) + lane_off : BUF_OFF);
-#else
                     v[x] = buf_ld_f32x4(r_state, (x < degN && act_l) ? sid * (unsigned)(SP * 4) + lane_off : BUF_OFF);
-#endif
                 }
 #pragma unroll 1
                 for (int eb = 16; eb < deg; eb += 16) {           // in-degree > 16: the next 16 source ids, then their rows
@@ -294,14 +299,10 @@ __global__ void __launch_bounds__(1024) k_state_xwide(XWideArgs a) {
                     const int jg = jg0 + p;
                     A[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(xrow + 8 * min(jg + 1, NG - 1));
                     const f32x4 a4 = A[p & 1];
-#ifndef XW_NO_MFMA
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][0], a4[0], acc, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][1], a4[1], acc1, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][2], a4[2], acc, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][3], a4[3], acc1, 0, 0, 0);
-#else
-                    acc[0] += Bf[p][0] * a4[0];
-#endif
                     Bf[p] = buf_ld_f32x4(r_wx, jg + XW_PD < NG ? wbase + (unsigned)(jg + XW_PD) * 1024u : BUF_OFF);
                     __builtin_amdgcn_sched_barrier(0);            // (the scheduler otherwise sinks all loads of a round to its end)
                 }
@@ -311,21 +312,15 @@ __global__ void __launch_bounds__(1024) k_state_xwide(XWideArgs a) {
                 if (n_main + p < NG) {
                     A[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(xrow + 8 * min(n_main + p + 1, NG - 1));
                     const f32x4 a4 = A[p & 1];
-#ifndef XW_NO_MFMA
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][0], a4[0], acc, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][1], a4[1], acc1, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][2], a4[2], acc, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][3], a4[3], acc1, 0, 0, 0);
-#else
-                    acc[0] += Bf[p][0] * a4[0];
-#endif
                 }
             }
-#ifndef XW_NO_MFMA
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] += acc1[e];
-#endif
             XW_T(t2_);
 #pragma unroll
             for (int p = 0; p < XW_PD; ++p) Bf[p] = buf_ld_f32x4(r_wx, p < NG ? wbase + (unsigned)p * 1024u : BUF_OFF);

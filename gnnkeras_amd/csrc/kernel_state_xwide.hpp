@@ -25,7 +25,9 @@
 // out, 526 us) - the working set (two 240 MB state buffers) is past the Infinity Cache, and this memory system rewards the NUMBER of
 // waves with a gather outstanding (profiles/r01_gather_sweep.txt), of which a 16-wave workgroup has only these 8 left.  Tried and
 // measured slower: 4 / 8 / 10 / 12 weight pieces in flight (722 - 772 us); two blocks per matrix wave on alternating tiles so that
-// one wave's epilogue lies under the other's K loop (779 us: the gather still sets the pace).
+// one wave's epilogue lies under the other's K loop (779 us: the gather still sets the pace); 12 gather waves drawing rows from a
+// ticket counter + 4 matrix waves (one per SIMD, two blocks each): the gather keeps up (the matrix waves wait 2 000 cycles per tile
+// instead of 16 000) but one wave per SIMD runs its K loop at 59 % of the pipe (43 600 cycles per tile against 25 600): 751 us.
 // Slots are handed over with monotonic LDS counters (rows deposited / waves done / rounds freed), workgroup scope, bounded
 // spins that raise the sticky error word (k < 0) exactly as in k_state_fused4.  The convergence predicate needs whole rows:
 // every matrix wave leaves its block's share of |new - old|^2 and |old|^2 per row in LDS, the wave that finishes the tile last

@@ -1156,6 +1156,8 @@ bool xwide_applies(const gnn_loop_args_t &a, const Plan &p) {
     if (env < 0) { const char *e = getenv("GNN_XWIDE"); env = (e && atoi(e) == 0) ? 0 : 1; }
     if (!env || (a.flags & GNN_FLAG_UNFUSED)) return false;
     if (p.SP <= 128 || p.S > 256 || p.composite || p.T != 1 || p.tp[0].rows || p.n_heavy != 0 || p.N < 1 || !p.Wx) return false;
+    if (a.n_heavy_segments > 0) return false;      // hub rows (the caller's split says so): one gather wave would walk a hub two rows at a time
+
     const gnn_mlp_t &m = a.net_state[0];
     if (m.n_layers != 1 || m.activation[0] == GNN_ACT_SOFTMAX || (int)m.units[0] != p.S) return false;
     if ((size_t)std::max(a.adjacency.n_src, p.N) * p.SP * 4 >= ((size_t)1 << 32) || (size_t)p.N * p.ldC * 4 >= ((size_t)1 << 32)) return false;

@@ -65,7 +65,10 @@ constexpr int XW_NS = 2;          // LDS slots
 #define XW_PD_VALUE 6
 #endif
 constexpr int XW_PD = XW_PD_VALUE;   // weight pieces in flight per matrix wave
-constexpr int XW_SPIN_MAX = 1 << 22;
+#ifndef GNN_F4_SPIN_MAX
+#define GNN_F4_SPIN_MAX (1 << 22)
+#endif
+constexpr int XW_SPIN_MAX = GNN_F4_SPIN_MAX;   // (-DGNN_F4_SPIN_MAX=0: the debug build whose every wait expires at once, libgnnloop_spin0.so)
 
 inline int xwide_kh(int SP) { return (SP + 7) & ~7; }
 inline size_t xwide_weight_floats(int S, int SP) { return (size_t)((S + 31) / 32) * (xwide_kh(SP) / 4) * 256; }

@@ -544,9 +544,21 @@ else:
 try:
     m.predict(seq)
 except nat.NativeError:
-    print('LOUD_OK')
+    pass
 else:
     sys.exit('predict() did not raise')
+# the same for the fused kernel of state widths 129 .. 256 (kernel_state_xwide.hpp: its hand-overs use the same bound)
+N, E, d = 20_000, 100_000, 160
+g = er_graph(N, E, aggregation_mode='average')
+seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)
+inp, lay = get_inout_dims('state', 14, 3, 2, 'n', d); ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=0)
+inp, lay = get_inout_dims('output', 14, 3, 2, 'n', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
+m = GNNnodeBased(ns, no, d, 3, 0.0)
+k, st, o = m.Loop(*m.process_inputs(seq[0][0]), state0=torch.randn(N, d, device='cuda') * 0.1)
+torch.cuda.synchronize()
+assert 'k_state_xwide' in nat.lib().gnn_last_kernel_name().decode()
+assert float(k) < 0, float(k)
+print('LOUD_OK')
 """
     env = dict(os.environ, GNNKERAS_AMD_LIB=lib, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(nat.HERE))) + os.pathsep + os.environ.get('PYTHONPATH', ''))
     root = os.path.dirname(nat.HERE)

@@ -7,23 +7,26 @@
 // What is different at these widths: W1 = [2 d x d] floats is 320 KB at d = 200 - it cannot live in the CU's 160 KB of LDS.
 // So the roles of LDS and L2 are swapped against the narrower kernels:
 //   * the gathered rows [state | neighbour sum] of a 32-node tile live in LDS (two slots of 32 x (2 KH + 4) floats: 132 KB at
-//     KH = 256), filled by 8 gather waves - one wave per row, a lane per 16-byte chunk, up to 16 neighbour rows in flight, the
-//     CSR of the next tile (row pointers, first 16 source ids of each row) fetched a tile ahead;
+//     KH = 256), filled by the 16 - NCB waves that are not matrix waves (8 .. 11) - one wave per row, a lane per 16-byte chunk, rows
+//     drawn from a ticket counter in LDS, ONE rolling window of 16 neighbour rows + the own row in flight per wave, the row
+//     pointers fetched three rows and the source ids two rows ahead;
 //   * the weights stream from L2 as MFMA operands: a set-up kernel lays them out once per call in fragment order
 //     (k_xwide_weights), so that a matrix wave's lane reads ONE 16-byte piece per four MFMAs, whole 1-KB lines per wave
 //     instruction, XW_PD pieces in flight; every tile re-reads the matrix (L2 traffic ~ (2 KH x 32 NCB x 4 B) per 32 rows, about
 //     the size of the gather traffic; the matrix itself stays resident in each XCD's 4 MB L2);
-//   * 8 matrix waves, one per 32-column block of the output, on v_mfma_f32_32x32x2_f32: this chip sustains 156 TFLOP/s on that
+//   * NCB <= 8 matrix waves, one per 32-column block of the output, on v_mfma_f32_32x32x2_f32: this chip sustains 156 TFLOP/s on that
 //     instruction against 104-126 on the 16x16x4 one the narrower kernels use (scripts/micro/mfma_peak.hip), and a 32 x 32 block
 //     needs one operand value per lane and 4 096 FLOP.  Operands are swapped (weights = A, rows = B) so that a lane ends up with
 //     columns 8 q + 4 (lane / 32) + 0..3 of ITS row: C, the old state and the new state all move as 16-byte pieces.
-// Measured (d = 200, 300 k nodes / 3 M arcs, scripts/dev/xw_prof.py on a -DXW_PROFILE build): 742 us per iteration against 1 150 un-fused
-// (34 -> 53 % of the HBM roofline of its algorithmic bytes).  Per tile a matrix wave spends 24 100 cycles in the K loop (two waves
+// Measured (d = 200, 300 k nodes / 3 M arcs): 683 us per iteration against 1 150 un-fused (34 -> 57 % of the HBM roofline of its
+// algorithmic bytes); d = 160 on 1 M / 10 M 3 197 -> 1 754 (60 %).  With 8 statically assigned gather waves (the first layout, 742 us;
+// scripts/dev/xw_prof.py on a -DXW_PROFILE build) a matrix wave spends per tile 24 100 cycles in the K loop (two waves
 // share a SIMD's matrix pipe: 25 600 would be the pipe's whole time), 8 300 in the epilogue and 16 200 waiting for the gather waves;
 // rocprofv3: SQ_VALU_MFMA_BUSY_CYCLES 8.4e8 = 46 % of the SIMD-cycles of the launch at the 2.25 GHz GRBM_GUI_ACTIVE shows.  The launch
 // is bound by the gather: 8 gather waves per CU move 4.7 TB/s of lines next to the weight stream (6.2 TB/s with the MFMAs compiled
 // out, 526 us) - the working set (two 240 MB state buffers) is past the Infinity Cache, and this memory system rewards the NUMBER of
-// waves with a gather outstanding (profiles/r01_gather_sweep.txt), of which a 16-wave workgroup has only these 8 left.  Tried and
+// waves with a gather outstanding (profiles/r01_gather_sweep.txt): hence every wave that is not a matrix wave gathers now (9 at
+// d = 200: 742 -> 683 us; 11 at d = 160: 1 983 -> 1 754).  Tried and
 // measured slower: 4 / 8 / 10 / 12 weight pieces in flight (722 - 772 us); two blocks per matrix wave on alternating tiles so that
 // one wave's epilogue lies under the other's K loop (779 us: the gather still sets the pace); 12 gather waves drawing rows from a
 // ticket counter + 4 matrix waves (one per SIMD, two blocks each): the gather keeps up (the matrix waves wait 2 000 cycles per tile
@@ -58,8 +61,7 @@ struct XWideArgs {
     int *err;
 };
 
-constexpr int XW_NM = 8;          // matrix waves (wave ids 0 .. 7; block cb = wave id)
-constexpr int XW_NGW = 8;         // gather waves (wave ids 8 .. 15)
+constexpr int XW_NM = 8;          // matrix waves at most (wave ids 0 .. NCB - 1, block cb = wave id); the other waves gather
 constexpr int XW_NS = 2;          // LDS slots
 #ifndef XW_PD_VALUE
 #define XW_PD_VALUE 6
@@ -73,7 +75,7 @@ constexpr int XW_SPIN_MAX = GNN_F4_SPIN_MAX;   // (-DGNN_F4_SPIN_MAX=0: the debu
 inline int xwide_kh(int SP) { return (SP + 7) & ~7; }
 inline size_t xwide_weight_floats(int S, int SP) { return (size_t)((S + 31) / 32) * (xwide_kh(SP) / 4) * 256; }
 inline size_t xwide_lds_bytes(int KH) {
-    return sizeof(float) * ((size_t)XW_NS * 32 * (2 * KH + 4) + (size_t)XW_NS * XW_NM * 32 * 2) + sizeof(int) * 3 * XW_NS;
+    return sizeof(float) * ((size_t)XW_NS * 32 * (2 * KH + 4) + (size_t)XW_NS * XW_NM * 32 * 2) + sizeof(int) * (3 * XW_NS + 1);
 }
 
 // Wx[((cb * NG + jg) * 64 + lane) * 4 + e] = Wcat[8 jg + 4 (lane / 32) + e][32 cb + lane % 32], Wcat = [state rows (KH, zero padded) ;
@@ -121,8 +123,9 @@ __global__ void __launch_bounds__(1024) k_state_xwide(XWideArgs a) {
     int *fill = reinterpret_cast<int *>(part + XW_NS * XW_NM * 64);     // [NS] rows deposited so far
     int *freed = fill + XW_NS;                                          // [NS] rounds consumed so far
     int *done = freed + XW_NS;                                          // [NS] matrix waves finished so far
+    int *ticket = done + XW_NS;                                         // next row (tile * 32 + row) to gather
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 3 * XW_NS) fill[tid] = 0;
+    if (tid < 3 * XW_NS + 1) fill[tid] = 0;
     __syncthreads();
     if (!open) return;                             // uniform across the launch; nothing has left the CU yet
 
@@ -135,118 +138,116 @@ __global__ void __launch_bounds__(1024) k_state_xwide(XWideArgs a) {
     int any = 0, bad = 0;
 
     XW_T(tk0_);
-    if (wave >= XW_NM) {
+    if (wave >= a.NCB) {
         // ================================ gather waves ================================================================
-        const int gw = wave - XW_NM;
-        const int rr = lane >> 4, u = lane & 15;                 // CSR role of this lane: row rr of the wave's four, source-id slot u
+        // Every wave that is not a matrix wave gathers (16 - NCB of them: 8 at 256 columns, 11 at 160).  Rows are drawn from a ticket
+        // counter in LDS (ticket t = row t % 32 of this workgroup's tile t / 32; a wave's tickets grow, so no row waits behind a
+        // later one).  A wave always holds four tickets: the row whose neighbour rows are being summed, the row whose neighbour
+        // rows are being issued into the window slots the sum frees (ONE rolling window of 16 neighbour rows + the own row in
+        // flight), the row whose source ids are in flight and the row whose row pointers are in flight.
         const int CH = SP >> 2, CHZ = KH >> 2;                   // 16-byte chunks of a row; chunks of the padded half
         const bool act_l = lane < CH, zero_l = lane >= CH && lane < CHZ;
         const bool has_scale = a.row_scale != nullptr;
-        auto node = [&](int i, int r4) -> int {                  // node of row gw + 8 r4 of this workgroup's tile i (-1: none)
-            const long T = (long)blockIdx.x + (long)i * gridDim.x;
-            const long j = 32 * T + gw + 8 * r4;
-            return (i < nT && j < N) ? (int)j : -1;
-        };
-        // pipeline: A = this tile (row pointers + first 16 source ids per row), B = next tile (row pointers, then its source ids)
-        int jn = node(0, rr);
-        int begA = buf_ld_i32(r_rowptr, jn >= 0 ? 4u * (unsigned)jn : BUF_OFF);
-        int endA = buf_ld_i32(r_rowptr, jn >= 0 ? 4u * (unsigned)jn + 4u : BUF_OFF);
-        jn = node(1, rr);
-        int begB = buf_ld_i32(r_rowptr, jn >= 0 ? 4u * (unsigned)jn : BUF_OFF);
-        int endB = buf_ld_i32(r_rowptr, jn >= 0 ? 4u * (unsigned)jn + 4u : BUF_OFF);
-        int idA = buf_ld_i32(r_src, begA + u < endA ? 4u * (unsigned)(begA + u) : BUF_OFF);
-        float wA = HAS_W ? buf_ld_f32(r_w, begA + u < endA ? 4u * (unsigned)(begA + u) : BUF_OFF) : 0.0f;
         const unsigned lane_off = 16u * (unsigned)lane;
-        // The rows of a wave form ONE rolling window of 16 neighbour rows + the node's own row in flight: as slot x of the row being
-        // summed is consumed, slot x of the NEXT row (the next tile's first row after a tile's fourth) is issued into the same registers.
+        const int total = nT * 32;
+        auto draw = [&]() -> int {
+            int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return __builtin_amdgcn_readfirstlane(t);
+        };
+        auto node = [&](int t) -> int {                          // (wave-uniform)
+            const long j = 32 * ((long)blockIdx.x + (long)(t >> 5) * gridDim.x) + (t & 31);
+            return (t < total && j < N) ? (int)j : -1;
+        };
+        auto ld_rowptr = [&](int j) -> int {                     // even lanes: beg, odd lanes: end
+            return buf_ld_i32(r_rowptr, j >= 0 ? 4u * (unsigned)j + 4u * (unsigned)(lane & 1) : BUF_OFF);
+        };
+        int t0 = draw(), t1 = draw(), t2 = draw(), t3 = draw();
+        int rp0 = ld_rowptr(node(t0)), rp1 = ld_rowptr(node(t1)), rp2 = ld_rowptr(node(t2)), rp3 = ld_rowptr(node(t3));
+        int beg0 = xw_readlane_i(rp0, 0), end0 = xw_readlane_i(rp0, 1);
+        int beg1 = xw_readlane_i(rp1, 0), end1 = xw_readlane_i(rp1, 1);
+        int id0 = buf_ld_i32(r_src, beg0 + lane < end0 ? 4u * (unsigned)(beg0 + lane) : BUF_OFF);       // up to 64 source ids of the row
+        float w0 = HAS_W ? buf_ld_f32(r_w, beg0 + lane < end0 ? 4u * (unsigned)(beg0 + lane) : BUF_OFF) : 0.0f;
+        int id1 = buf_ld_i32(r_src, beg1 + lane < end1 ? 4u * (unsigned)(beg1 + lane) : BUF_OFF);
+        float w1 = HAS_W ? buf_ld_f32(r_w, beg1 + lane < end1 ? 4u * (unsigned)(beg1 + lane) : BUF_OFF) : 0.0f;
         f32x4 v[16], own;
         {
-            const int j = node(0, 0);
-            const int deg = j >= 0 ? xw_readlane_i(endA, 0) - xw_readlane_i(begA, 0) : 0;
+            const int j = node(t0), deg = j >= 0 ? end0 - beg0 : 0;
 #pragma unroll
             for (int x = 0; x < 16; ++x) {
-                const unsigned sid = (unsigned)xw_readlane_i(idA, x);
+                const unsigned sid = (unsigned)xw_readlane_i(id0, x);
                 v[x] = buf_ld_f32x4(r_state, (x < deg && act_l) ? sid * (unsigned)(SP * 4) + lane_off : BUF_OFF);
             }
             own = buf_ld_f32x4(r_state, (j >= 0 && act_l) ? (unsigned)j * (unsigned)(SP * 4) + lane_off : BUF_OFF);
         }
 #pragma unroll 1
-        for (int i = 0; i < nT; ++i) {
-            // the tile after this one: its source ids (its row pointers landed a tile ago); the one after that: its row pointers
-            const int idB = buf_ld_i32(r_src, begB + u < endB ? 4u * (unsigned)(begB + u) : BUF_OFF);
-            const float wB = HAS_W ? buf_ld_f32(r_w, begB + u < endB ? 4u * (unsigned)(begB + u) : BUF_OFF) : 0.0f;
-            jn = node(i + 2, rr);
-            const int begC = buf_ld_i32(r_rowptr, jn >= 0 ? 4u * (unsigned)jn : BUF_OFF);
-            const int endC = buf_ld_i32(r_rowptr, jn >= 0 ? 4u * (unsigned)jn + 4u : BUF_OFF);
-            const int s = i % XW_NS, round = i / XW_NS;
-            bool slot_ok = false;
+        while (t0 < total) {
+            // the row two behind this one: its row pointers landed a row ago -> its source ids now; the row three behind: drawn now
+            const int beg2 = xw_readlane_i(rp2, 0), end2 = xw_readlane_i(rp2, 1);
+            const int id2 = buf_ld_i32(r_src, beg2 + lane < end2 ? 4u * (unsigned)(beg2 + lane) : BUF_OFF);
+            const float w2 = HAS_W ? buf_ld_f32(r_w, beg2 + lane < end2 ? 4u * (unsigned)(beg2 + lane) : BUF_OFF) : 0.0f;
+            const int t4 = draw();
+            const int rp4 = ld_rowptr(node(t4));
+            // this row: sum its window while the next row's neighbour rows take the freed registers
+            const int j = node(t0), deg = j >= 0 ? end0 - beg0 : 0;
+            const int jN = node(t1), degN = jN >= 0 ? end1 - beg1 : 0;
+            const float scl = has_scale ? buf_ld_f32(r_scale, j >= 0 ? 4u * (unsigned)j : BUF_OFF) : 1.0f;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int j = node(i, r4);                        // wave-uniform
-                const int beg = xw_readlane_i(begA, 16 * r4), end = xw_readlane_i(endA, 16 * r4);
-                const int deg = j >= 0 ? end - beg : 0;
-                const float scl = has_scale ? buf_ld_f32(r_scale, j >= 0 ? 4u * (unsigned)j : BUF_OFF) : 1.0f;
-                // the row after this one
-                const int jN = r4 < 3 ? node(i, r4 + 1) : node(i + 1, 0);
-                const int degN = jN >= 0 ? (r4 < 3 ? xw_readlane_i(endA, 16 * (r4 + 1) & 63) - xw_readlane_i(begA, 16 * (r4 + 1) & 63)
-                                                   : xw_readlane_i(endB, 0) - xw_readlane_i(begB, 0)) : 0;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int x = 0; x < 16; ++x) {
-                    if (HAS_W) acc += xw_readlane_f(wA, 16 * r4 + x) * v[x];
-                    else acc += v[x];
-                    const unsigned sid = (unsigned)(r4 < 3 ? xw_readlane_i(idA, (16 * (r4 + 1) + x) & 63) : xw_readlane_i(idB, x));
-                    v[x] = buf_ld_f32x4(r_state, (x < degN && act_l) ? sid * (unsigned)(SP * 4) + lane_off : BUF_OFF);
-                }
-#pragma unroll 1
-                for (int eb = 16; eb < deg; eb += 16) {           // in-degree > 16: the next 16 source ids, then their rows
-                    const int e = beg + eb + u;
-                    const int idc = buf_ld_i32(r_src, e < end ? 4u * (unsigned)e : BUF_OFF);
-                    const float wc = HAS_W ? buf_ld_f32(r_w, e < end ? 4u * (unsigned)e : BUF_OFF) : 0.0f;
-                    f32x4 v2[2];                                  // (the window above stays in flight: two rows at a time here)
-#pragma unroll
-                    for (int h = 0; h < 8; ++h) {
-#pragma unroll
-                        for (int x = 0; x < 2; ++x) {
-                            const unsigned sid = (unsigned)xw_readlane_i(idc, 2 * h + x);
-                            v2[x] = buf_ld_f32x4(r_state, (eb + 2 * h + x < deg && act_l) ? sid * (unsigned)(SP * 4) + lane_off : BUF_OFF);
-                        }
-#pragma unroll
-                        for (int x = 0; x < 2; ++x) {
-                            if (HAS_W) acc += xw_readlane_f(wc, 2 * h + x) * v2[x];
-                            else acc += v2[x];
-                        }
-                    }
-                }
-                if (has_scale) acc *= scl;
-                if (!slot_ok) {                                   // the slot's previous tile must have been consumed
-                    XW_T(g0_);
-                    int spin = 0;
-                    while (__builtin_amdgcn_readfirstlane(f4_ld_acquire(&freed[s])) < round) {
-                        if (spin >= XW_SPIN_MAX) { bad = 1; break; }
-                        ++spin; __builtin_amdgcn_s_sleep(1);
-                    }
-                    slot_ok = true;
-#ifdef XW_PROFILE
-                    if (wave == XW_NM) XW_ADD(4, xw_now() - g0_);
-#endif
-                }
-                if (!bad) {                                       // (else the slot never came free: deposit nothing, k < 0 says so)
-                    float *xr = Xs + s * SLOT + (gw + 8 * r4) * LDX + 4 * lane;
-                    if (act_l) {
-                        *reinterpret_cast<f32x4 *>(xr) = own;
-                        *reinterpret_cast<f32x4 *>(xr + KH) = acc;
-                    } else if (zero_l) {
-                        *reinterpret_cast<f32x4 *>(xr) = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        *reinterpret_cast<f32x4 *>(xr + KH) = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-                    if (lane == 0) __hip_atomic_fetch_add(&fill[s], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                own = buf_ld_f32x4(r_state, (jN >= 0 && act_l) ? (unsigned)jN * (unsigned)(SP * 4) + lane_off : BUF_OFF);   // (its registers are free now)
+            for (int x = 0; x < 16; ++x) {
+                if (HAS_W) acc += xw_readlane_f(w0, x) * v[x];
+                else acc += v[x];
+                const unsigned sid = (unsigned)xw_readlane_i(id1, x);
+                v[x] = buf_ld_f32x4(r_state, (x < degN && act_l) ? sid * (unsigned)(SP * 4) + lane_off : BUF_OFF);
             }
-            if (bad) break;
-            begA = begB; endA = endB; idA = idB; wA = wB;
-            begB = begC; endB = endC;
+#pragma unroll 1
+            for (int eb = 16; eb < deg; eb += 2) {                // in-degree > 16: two rows at a time (the window above stays in flight)
+                if ((eb & 63) == 0) {                             // every 64 arcs: the next 64 source ids (uniform branch, rare)
+                    const int e = beg0 + eb + lane;
+                    id0 = buf_ld_i32(r_src, e < end0 ? 4u * (unsigned)e : BUF_OFF);
+                    if (HAS_W) w0 = buf_ld_f32(r_w, e < end0 ? 4u * (unsigned)e : BUF_OFF);
+                }
+                f32x4 v2[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    const unsigned sid = (unsigned)__builtin_amdgcn_readlane(id0, (eb + x) & 63);
+                    v2[x] = buf_ld_f32x4(r_state, (eb + x < deg && act_l) ? sid * (unsigned)(SP * 4) + lane_off : BUF_OFF);
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    if (HAS_W) acc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0), (eb + x) & 63)) * v2[x];
+                    else acc += v2[x];
+                }
+            }
+            if (has_scale) acc *= scl;
+            const int i = t0 >> 5, r = t0 & 31, s = i % XW_NS, round = i / XW_NS;
+            {                                                     // the slot's previous tile must have been consumed
+                XW_T(g0_);
+                int spin = 0;
+                while (__builtin_amdgcn_readfirstlane(f4_ld_acquire(&freed[s])) < round) {
+                    if (spin >= XW_SPIN_MAX) { bad = 1; break; }
+                    ++spin; __builtin_amdgcn_s_sleep(1);
+                }
+#ifdef XW_PROFILE
+                if (wave == a.NCB) XW_ADD(4, xw_now() - g0_);
+#endif
+            }
+            if (bad) break;                                       // the slot never came free: deposit nothing (k < 0 says so)
+            float *xr = Xs + s * SLOT + r * LDX + 4 * lane;
+            if (act_l) {
+                *reinterpret_cast<f32x4 *>(xr) = own;
+                *reinterpret_cast<f32x4 *>(xr + KH) = acc;
+            } else if (zero_l) {
+                *reinterpret_cast<f32x4 *>(xr) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(xr + KH) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (lane == 0) __hip_atomic_fetch_add(&fill[s], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            own = buf_ld_f32x4(r_state, (jN >= 0 && act_l) ? (unsigned)jN * (unsigned)(SP * 4) + lane_off : BUF_OFF);   // (its registers are free now)
+            // the stages move up
+            t0 = t1; t1 = t2; t2 = t3; t3 = t4;
+            beg0 = beg1; end0 = end1; id0 = id1; w0 = w1;
+            beg1 = beg2; end1 = end2; id1 = id2; w1 = w2;
+            rp2 = rp3; rp3 = rp4;
         }
     } else if (wave < a.NCB) {
         // ================================ matrix waves ================================================================
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(1024) k_state_xwide(XWideArgs a) {
     }
 
 #ifdef XW_PROFILE
-    if (wave == XW_NM) XW_ADD(5, xw_now() - tk0_);       // gather wave 8: its whole loop
+    if (wave == a.NCB) XW_ADD(5, xw_now() - tk0_);       // the first gather wave: its whole loop
     if (wave == 0) XW_ADD(6, xw_now() - tk0_);           // matrix wave 0: its whole loop
 #endif
     any = __syncthreads_or(any);

@@ -71,10 +71,9 @@ for rep in range(reps):
             n += 1
 print(f'convergence groups: {n} batches compared, {time.time() - t0:.1f} s')
 # ---- ER graph: generation 4 repeated, bitwise reproducible; persistent kernel at its size limit ----------------------------
-for N, E, flag, name in ((200000, 2000000, nat.FLAG_FUSED_GEN4, 'generation 4'), (16000, 160000, nat.FLAG_FUSED_GEN5, 'generation 5'),
-                          (30000, 300000, nat.FLAG_FUSED_GEN6, 'generation 6')):
+for N, E, flag, name, d in ((200000, 2000000, nat.FLAG_FUSED_GEN4, 'generation 4', 64), (16000, 160000, nat.FLAG_FUSED_GEN5, 'generation 5', 64),
+                             (30000, 300000, nat.FLAG_FUSED_GEN6, 'generation 6', 64), (60000, 600000, 0, 'state width 200 (k_state_xwide)', 200)):
     g = er_graph(N, E, aggregation_mode='average'); seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False); x = seq[0][0]
-    d = 64
     inp, lay = get_inout_dims('state', 14, 3, 2, 'n', d); ns = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0)
     inp, lay = get_inout_dims('output', 14, 3, 2, 'n', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
     gnn = GNNnodeBased(ns, no, d, 20, 0.0); gnn.native_flags = flag

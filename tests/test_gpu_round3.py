@@ -755,3 +755,23 @@ def test_state_widths_129_to_256_run_fused(N, arcs_per_node, d, mode, act, thr):
         assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, flags
         got[flags] = st
     assert rel_err(got[0].cpu().numpy(), got[nat.FLAG_UNFUSED].cpu().numpy()) <= TOL
+
+
+def test_state_width_200_is_bitwise_reproducible():
+    """The LDS hand-overs of k_state_xwide (rows deposited / waves done / rounds freed) carry no arithmetic: the neighbour sum runs in
+    arc order, the predicate's row shares are added in block order - five runs of the same loop must agree bit for bit."""
+    from test_gpu_parity import starter_nets
+    N, d = 30_000, 200
+    g = er_graph(N, 8 * N, seed=2, aggregation_mode='average')
+    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    ns, no = starter_nets('n', d, act='tanh', scale=0.2)
+    model = GNNnodeBased(ns, no, d, 8, 0.001)
+    inputs = model.process_inputs(x)
+    s0 = dev(np.random.default_rng(0).normal(0, 0.1, (N, d)).astype(np.float32))
+    ref = None
+    for rep in range(5):
+        k, st, o = model.Loop(*inputs, state0=s0)
+        torch.cuda.synchronize()
+        assert 'k_state_xwide' in _last_kernel()
+        if ref is None: ref = (float(k), st.clone(), o.clone())
+        else: assert float(k) == ref[0] and torch.equal(st, ref[1]) and torch.equal(o, ref[2]), rep

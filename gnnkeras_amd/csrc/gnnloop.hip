@@ -891,7 +891,18 @@ int device_cus() {
 
 // the fused kernel that runs ONE iteration: the size-based / pinned choice, except that two-layer state networks go to the
 // wave-specialised kernel at any size (the only per-iteration kernel that carries a second Dense) unless pinned elsewhere
+// the state network's LAST activation is a softmax (legal: reference MLP.py:12-78 takes any Keras activation): only the
+// wave-specialised kernel's row-major epilogue has whole rows in one lane group, so that kernel runs whatever is pinned
+bool state_softmax(const gnn_loop_args_t &a, const Plan &p) {
+    for (int t = 0; t < p.T; ++t) {
+        const gnn_mlp_t &m = a.net_state[t];
+        if (m.n_layers >= 1 && m.activation[m.n_layers - 1] == GNN_ACT_SOFTMAX) return true;
+    }
+    return false;
+}
+
 int iteration_generation(const gnn_loop_args_t &a, const Plan &p) {
+    if (state_softmax(a, p)) return 4;
     const int gen = fused_generation(p.SP, p.N, a.flags);
     bool two = false;
     for (int t = 0; t < p.T; ++t) two |= a.net_state[t].n_layers == 2;
@@ -1140,8 +1151,9 @@ int fusable(const gnn_loop_args_t &a, const Plan &p) {
     bool two = false;
     for (int t = 0; t < p.T; ++t) {
         const gnn_mlp_t &m = a.net_state[t];
-        if (m.n_layers < 1 || m.n_layers > 2 || m.activation[0] == GNN_ACT_SOFTMAX) return 0;
-        if (m.n_layers == 2 && (m.activation[1] == GNN_ACT_SOFTMAX || m.units[0] > p.SP)) return 0;
+        if (m.n_layers < 1 || m.n_layers > 2) return 0;
+        if (m.activation[m.n_layers - 1] == GNN_ACT_SOFTMAX && p.SP > 64) return 0;   // a softmax state: the wave-specialised kernel only (widths up to 64)
+        if (m.n_layers == 2 && (m.activation[0] == GNN_ACT_SOFTMAX || m.units[0] > p.SP)) return 0;
         if (t > 0 && (m.n_layers == 2) != two) return 0;                // every node type the same depth
         two = m.n_layers == 2;
     }
@@ -1294,11 +1306,12 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
     }
     if (p.has_sets) return fail("convergence group sets need the one-CU-per-group form (gnn_loop_groups_supported() != 2 for these args)");
     if (p.n_groups > GNN_MAX_GROUPS) return fail("more than %d convergence groups need every group to fit one CU's LDS (gnn_loop_groups_supported() != 2)", GNN_MAX_GROUPS);
-    const bool whole_loop = fz != 0 && persistent_applies(a, p);
+    const bool soft = state_softmax(a, p);          // (one launch per iteration on the wave-specialised kernel)
+    const bool whole_loop = fz != 0 && !soft && persistent_applies(a, p);
     const bool small_setup = whole_loop && setup_small_applies(a, p);
     if (p.n_groups > 0 && !small_setup) return fail("convergence groups need the whole-loop kernel (gnn_loop_groups_supported() == 0 for these args)");
     // every iteration on the XC form of the wave-specialised kernel (large homogeneous / composite graphs): C is never read
-    const bool xc_loop = p.xc_ok && !whole_loop && fz == 1 && !mid_applies(a, p) && p.SP != 128 && !iter_adjacency(a, p).w &&
+    const bool xc_loop = p.xc_ok && !whole_loop && fz == 1 && (soft || !mid_applies(a, p)) && p.SP != 128 && !iter_adjacency(a, p).w &&
                          iteration_generation(a, p) == 4 && fused_generation(p.SP, p.N, a.flags) == 4;
     if (small_setup) TRY(setup_small(a, p, st));
     else             TRY(setup_constants(a, p, st, /*zero_loop_words=*/true, /*skip_c=*/xc_loop));   // flags, barrier counters and k start from zero
@@ -1332,7 +1345,7 @@ int gnn_loop_forward(const gnn_loop_args_t *args) {
         if (persistent == 2 && small_setup) return fail("whole-loop kernel refused a graph its set-up kernel accepted");
     }
     bool loop_done = persistent == 0;
-    if (!loop_done && fz == 1 && mid_applies(a, p)) {
+    if (!loop_done && fz == 1 && !soft && mid_applies(a, p)) {
         const int rc = loop_mid(a, p, first, B, st);
         if (rc == 1) return 1;
         loop_done = rc == 0;
@@ -1369,7 +1382,7 @@ int gnn_loop_groups_supported(const gnn_loop_args_t *args) {
     const int fz = fusable(*args, p);
     if (fz == 1 && lds_applies(*args, p) && setup_small_applies(*args, p)) return 2;
     if (args->n_groups > GNN_MAX_GROUPS) return 0;
-    return fz != 0 && persistent_applies(*args, p) && setup_small_applies(*args, p) ? 1 : 0;
+    return fz != 0 && !state_softmax(*args, p) && persistent_applies(*args, p) && setup_small_applies(*args, p) ? 1 : 0;
 }
 
 int gnn_aggregate(const gnn_csr_t *csr, const float *X, int32_t ldx, int32_t F, float *out, int32_t ldo, void *stream) {

@@ -450,20 +450,44 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                     for (int reg = 0; reg < 4; ++reg) X[(4 * g + reg) * LDX + SP + 16 * ci + r] = c[ci][reg];
             }
             const int act_out = L2 ? tp.act2 : tp.act;
+            const int W_out = L2 ? O2 : S;                          // real columns of the new state
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) {
                 const float *px = X + (4 * i + g) * LDX;
                 const int j = __float_as_int(px[2 * SP]);              // node id left by the gather wave (-1 = pad row)
                 float d2 = 0.0f, n2 = 0.0f;
+                f32x4 nv = {0.f, 0.f, 0.f, 0.f}, ov = {0.f, 0.f, 0.f, 0.f};
                 if (4 * r < SP) {
                     const float2 plo = *reinterpret_cast<const float2 *>(px + SP + 4 * r), phi = *reinterpret_cast<const float2 *>(px + SP + 4 * r + 2);
                     const float2 olo = *reinterpret_cast<const float2 *>(px + 4 * r), ohi = *reinterpret_cast<const float2 *>(px + 4 * r + 2);
-                    f32x4 nv = {plo.x, plo.y, phi.x, phi.y};
-                    const f32x4 ov = {olo.x, olo.y, ohi.x, ohi.y};
-                    activate4(act_out, nv);
+                    nv = (f32x4){plo.x, plo.y, phi.x, phi.y};
+                    ov = (f32x4){olo.x, olo.y, ohi.x, ohi.y};
+                }
+                if (act_out == GNN_ACT_SOFTMAX) {
+                    // a softmax state (any Keras activation is legal there, reference MLP.py:12-78): the row lives in the 16 lanes
+                    // of this lane group - maximum, exponentials and their sum across them, pad columns left out
+                    float m = -3.0e38f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m = (4 * r + e < W_out && 4 * r < SP) ? fmaxf(m, nv[e]) : m;
+#pragma unroll
+                    for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 16));
+                    float ssum = 0.0f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        nv[e] = (j >= 0 && 4 * r + e < (L2 ? O2 : S)) ? nv[e] : 0.0f;
+                        nv[e] = (4 * r + e < W_out && 4 * r < SP) ? expf(nv[e] - m) : 0.0f;
+                        ssum += nv[e];
+                    }
+#pragma unroll
+                    for (int off = 8; off >= 1; off >>= 1) ssum += __shfl_xor(ssum, off, 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) nv[e] = nv[e] / ssum;
+                } else {
+                    activate4(act_out, nv);
+                }
+                if (4 * r < SP) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        nv[e] = (j >= 0 && 4 * r + e < W_out) ? nv[e] : 0.0f;
                         const float d = nv[e] - ov[e];
                         d2 = fmaf(d, d, d2);
                         n2 = fmaf(ov[e], ov[e], n2);

@@ -775,3 +775,43 @@ def test_state_width_200_is_bitwise_reproducible():
         assert 'k_state_xwide' in _last_kernel()
         if ref is None: ref = (float(k), st.clone(), o.clone())
         else: assert float(k) == ref[0] and torch.equal(st, ref[1]) and torch.equal(o, ref[2]), rep
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a softmax as the state network's last activation (reference MLP.py:12-78 takes any Keras activation)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('N,d,hidden,mode', [(40_000, 64, None, 'average'), (5_003, 32, None, 'sum'), (40_000, 64, [48], 'normalized'),
+                                             (935, 16, None, 'average'), (3_001, 24, [20], 'average')])
+def test_softmax_state_activation_runs_fused(mutag_graphs, N, d, hidden, mode):
+    """The wave-specialised kernel's row-major epilogue holds whole rows in one lane group: a softmax state (one- and two-layer state
+    networks, widths up to 64, any graph size - the kernel is chosen whatever the size heuristics say) stays one launch per iteration.
+    k, state and output against the fp64 oracle and the un-fused path (dense + k_softmax_rows)."""
+    rng = np.random.default_rng(N + d)
+    if N == 935:
+        seq = MultiGraphSequencer(mutag_graphs[:32], 'g', mode, 32, shuffle=False)
+        focus, cls = 'g', GNNgraphBased
+    else:
+        g = er_graph(N, 6 * N, seed=4, aggregation_mode=mode)
+        seq = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)
+        focus, cls = 'n', GNNnodeBased
+    x = seq[0][0]
+    n_nodes = x[0].shape[0]
+    inp, lay = get_inout_dims('state', 14, 3, 2, focus, d, hidden_units=hidden)
+    ns = MLP(inp[0], lay, ['tanh'] * (len(lay) - 1) + ['softmax'], 'lecun_normal', 'lecun_normal', rng=0, batch_normalization=True)
+    inp, lay = get_inout_dims('output', 14, 3, 2, focus, d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
+    s0 = np.abs(rng.normal(0, 0.1, (n_nodes, d))).astype(np.float32)
+    model = cls(ns, no, d, 5, 0.0)
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    inputs = model.process_inputs(x)
+    got = {}
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=dev(s0))
+        torch.cuda.synchronize()
+        assert ('k_state_fused4' if flags == 0 else 'un-fused') in _last_kernel(), _last_kernel()
+        assert float(k) == float(k64), (flags, float(k), k64)
+        assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, flags
+        got[flags] = st
+    assert abs(float(got[0].sum(1).mean()) - 1.0) < 1e-5          # rows of a softmax state sum to one
+    assert rel_err(got[0].cpu().numpy(), got[nat.FLAG_UNFUSED].cpu().numpy()) <= TOL

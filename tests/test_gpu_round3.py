@@ -815,3 +815,26 @@ def test_softmax_state_activation_runs_fused(mutag_graphs, N, d, hidden, mode):
         got[flags] = st
     assert abs(float(got[0].sum(1).mean()) - 1.0) < 1e-5          # rows of a softmax state sum to one
     assert rel_err(got[0].cpu().numpy(), got[nat.FLAG_UNFUSED].cpu().numpy()) <= TOL
+
+
+def test_standalone_convergence_step_at_state_width_200():
+    """`convergence()` (reference GNN.py:217-236; `gnn_state_step`) at a width the 129..256 kernel serves: one step against the fp64
+    oracle's step and against the un-fused path."""
+    from test_gpu_parity import starter_nets
+    N, d = 4_099, 200
+    g = er_graph(N, 7 * N, seed=6, aggregation_mode='average')
+    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    ns, no = starter_nets('n', d, act='tanh', scale=0.3)
+    model = GNNnodeBased(ns, no, d, 5, 0.0)
+    nodes, arcs, _, _, _, adj, an, ng = model.process_inputs(x)
+    s = np.random.default_rng(0).normal(0, .1, (N, d)).astype(np.float32)
+    a = (adj.indices, adj.values, np.array(adj.shape))
+    agg_nodes = O.sparse_dense_matmul_adjoint(*a, nodes.cpu().numpy(), np.float64)
+    agg_arcs = O.sparse_dense_matmul_adjoint(an.indices, an.values, np.array(an.shape), arcs.cpu().numpy()[:, 2:], np.float64)
+    want = O.convergence(s.astype(np.float64), nodes.cpu().numpy().astype(np.float64), a, agg_nodes, agg_arcs, ns.spec(), d, False, np.float64)
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k1, new, old, *_ = model.convergence(0, dev(s), None, nodes, adj, None, None, False, arcs=arcs, arcnode=an)
+        torch.cuda.synchronize()
+        assert ('k_state_xwide' if flags == 0 else 'un-fused') in _last_kernel(), _last_kernel()
+        assert k1 == 1 and rel_err(new.cpu().numpy(), want) <= TOL, flags

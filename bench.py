@@ -21,7 +21,8 @@ cpu_baseline = the restatement of the reference's un-fused op sequence (oracle/c
            all host threads, torch on one thread, NumPy/SciPy on one thread; `value` is the fastest.
 Also reported (extra keys): the MUTAG batch-32 forward (BASELINE config C2) in ms/graph next to its CPU baseline, and
 `beyond_infinity_cache`: the same iteration kernel on a 4 M-node / 40 M-arc graph whose 1 GB state array cannot sit in
-the 256 MiB Infinity Cache (the C4 state array, 256 MB, can).
+the 256 MiB Infinity Cache (the C4 state array, 256 MB, can); `wide_state_d200`: the per-iteration launch of the 129..256-wide
+fused kernel (d = 200 on 300 k nodes / 3 M arcs) with its share of the HBM roofline.
 """
 import argparse
 import json
@@ -362,6 +363,25 @@ def beyond_cache_section(device, d, K_it, aggregation):
     return rec
 
 
+def wide_state_section(device, aggregation):
+    """State widths 129 .. 256 (kernel_state_xwide.hpp): d = 200 on a 300 k-node / 3 M-arc ER graph built on the device, time per
+    iteration launch from the library's HIP events around the loop, roofline on the algorithmic bytes of an iteration."""
+    from gnnkeras_amd import _native as nat
+    from gnnkeras_amd.synth import er_device_batch
+    from gnnkeras_amd.Models.GNN import GNNnodeBased
+    N, E, d = 300_000, 3_000_000, 200
+    x = er_device_batch(N, E, device, aggregation_mode=aggregation, seed=77)
+    ns, no = starter_nets(d, device)
+    gen = torch.Generator(device=device); gen.manual_seed(2)
+    s0 = torch.randn((N, d), generator=gen, device=device) * 0.1
+    gnn = GNNnodeBased(ns, no, d, 20, 0.0)
+    elapsed, k_val, t_iter = measure_loop(gnn, gnn.process_inputs(x), s0, steps=2, warmup=1)      # t_iter: HIP events around the iteration launches
+    b_iter = algorithmic_bytes_per_iteration(N, E, d, ns.units[0], False)
+    return {'workload': f'Erdos-Renyi {N} nodes / {E} arcs, state_dim={d}, {aggregation} aggregation', 'k': k_val, 'us_per_iteration': 1e6 * t_iter,
+            'algorithmic_bytes_per_iteration': b_iter, 'frac_of_8TBps': b_iter / t_iter / 8e12,
+            'kernel': nat.lib().gnn_last_kernel_name().decode()}
+
+
 def gpu_state():
     """Clocks / power / temperature rocm-smi reports right after the timed region (a child process; never fails the bench): the same
     kernel has measured 460 us on one box of the pool and 533 us on another (profiles/r03_notes.txt) - this says which kind ran."""
@@ -659,6 +679,11 @@ def main():
         del gnn, inputs, x, s0
         torch.cuda.empty_cache()
         result['beyond_infinity_cache'] = beyond_cache_section(device, d, K_it, args.aggregation)
+        torch.cuda.empty_cache()
+        try:
+            result['wide_state_d200'] = wide_state_section(device, args.aggregation)
+        except Exception as e:                        # never lose the headline line to the extras
+            result['wide_state_d200'] = {'error': str(e)[:300]}
 
     if sharded and (world > 1 or args.force_sharded) and not args.no_mutag and args.workload == 'c4':
         del sl

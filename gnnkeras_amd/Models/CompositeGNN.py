@@ -90,35 +90,53 @@ class CompositeGNNnodeBased(GNNnodeBased):
 
     def convergence(self, k, state, state_old, nodes, dim_node_label, type_mask, adjacency, aggregated_component, training, *,
                     arcs=None, arcnode=None, composite_adjacencies=None):
-        """One state-transition step of a heterogeneous graph (reference CompositeGNN.py:215-234) through
-        `torch.ops.gnnkeras.state_step`: every node type's network on that type's rows, one fused launch.  The reference threads
-        the pre-aggregated `aggregated_component` through its `tf.while_loop`; the native step folds the iteration constants
-        itself from `arcs` / `arcnode` / `composite_adjacencies` (what `Loop` does once per call), so those are required here.
-        Returns the reference's 9-tuple `(k + 1, state_new, state, nodes, dim_node_label, type_mask, adjacency,
-        aggregated_component, training)`."""
-        if arcs is None or arcnode is None or composite_adjacencies is None:
-            raise ValueError('convergence() needs arcs=, arcnode= and composite_adjacencies= to rebuild the iteration constants on device')
-        self._check_training(bool(training))
-        nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs'); nat.require_device(state, 'state')
+        """One state-transition step of a heterogeneous graph with the reference's own nine positional arguments (reference
+        CompositeGNN.py:215-234): per node type t
+
+            state_new[type t rows] = net_state[t]([nodes[:, :d_t] | state | adjacency^T . state | aggregated_component][type t rows])
+
+        through `torch.ops.gnnkeras.state_step` -> `gnn_state_step_agg` (every type's network on that type's rows, one fused launch);
+        `aggregated_component` = [aggregated_nodes_0 | .. | aggregated_arcs] is used as handed in (CompositeGNN.py:251-253), `None`
+        rebuilds it from `arcs=` / `arcnode=` / `composite_adjacencies=`.  `training=True` runs the state networks in training mode
+        (batch statistics of each type's rows, moving-average update, Dropout).  Returns the reference's 9-tuple."""
+        nat.require_device(nodes, 'nodes'); nat.require_device(state, 'state')
         dev = nodes.device
+        training = bool(training)
         dims = [int(d) for d in (dim_node_label.reshape(-1).tolist() if isinstance(dim_node_label, torch.Tensor)
                                  else np.asarray(dim_node_label).reshape(-1))]
         if len(dims) != len(self.net_state): raise ValueError(f'{len(dims)} node types but {len(self.net_state)} state networks')
         type_nodes, offsets = self._type_lists(_squeeze_last(type_mask).to(dev))
+        nodes32 = nodes.to(torch.float32).contiguous()
+        state32 = state.to(dev, torch.float32).contiguous()
         adj = SparseMatrix.from_triple(adjacency).device_csr(dev)
-        arcn = SparseMatrix.from_triple(arcnode).device_csr(dev)
-        cas = [SparseMatrix.from_triple(c).device_csr(dev) for c in composite_adjacencies]
-        new, _moving = ops.state_step(nodes.to(torch.float32).contiguous(), arcs.to(torch.float32).contiguous(), adj, arcn, self.net_state,
-                                      state.to(dev, torch.float32).contiguous(), self.state_vect_dim, self.state_threshold,
-                                      self.native_flags, composite=(type_nodes, offsets, dims, cas))
+        if aggregated_component is None:
+            if arcs is None or arcnode is None or composite_adjacencies is None:
+                raise ValueError('convergence() needs aggregated_component (the reference\'s argument), or arcs=, arcnode= and composite_adjacencies= to rebuild it')
+            arcs32 = arcs.to(dev, torch.float32).contiguous()
+            parts = [ops.aggregate(SparseMatrix.from_triple(c).device_csr(dev), nodes32[:, :d].contiguous()) for c, d in zip(composite_adjacencies, dims) if d > 0]
+            parts.append(ops.aggregate(SparseMatrix.from_triple(arcnode).device_csr(dev), arcs32[:, 2:].contiguous()))
+            aggregated_component = torch.cat(parts, dim=1)
+        comp = aggregated_component.to(dev, torch.float32)
+        if comp.stride(-1) != 1: comp = comp.contiguous()
+        sum_d = sum(dims)
+        N = nodes32.shape[0]
+        if training and any(n.batch_normalization or n.dropout_rate for n in self.net_state):
+            from .training import mlp_training_call
+            agg = ops.aggregate(adj, state32)
+            new = torch.zeros_like(state32)
+            for t, net in enumerate(self.net_state):
+                rows = type_nodes[int(offsets[t]):int(offsets[t + 1])].contiguous()
+                if len(rows) == 0: continue
+                segs = ([(nodes32[:, :dims[t]], rows)] if dims[t] > 0 else []) + [(state32, rows), (agg, rows)]
+                if comp.shape[1] > 0: segs.append((comp, rows))
+                new.index_copy_(0, rows.long(), mlp_training_call(net, segs, len(rows), net_id=t))
+        else:
+            dummy_arcs = nodes32.new_zeros((0, 2 + comp.shape[1] - sum_d))
+            new, _moving = ops.state_step(nodes32, dummy_arcs, adj, None, self.net_state, state32, self.state_vect_dim, self.state_threshold,
+                                          self.native_flags, composite=(type_nodes, offsets, dims, None),
+                                          aggregated=(comp[:, :sum_d], comp[:, sum_d:]))
         return k + 1, new, state, nodes, dim_node_label, type_mask, adjacency, aggregated_component, training
 
-
-    def _check_training(self, training):
-        nets = self.net_state + [self.net_output]
-        if training and any(n.batch_normalization or n.dropout_rate for n in nets):
-            raise NotImplementedError('training=True forward needs BatchNormalization batch statistics / dropout on '
-                                      'device (SURVEY.md §8f, next row); inference forward is the built path')
 
     def _type_lists(self, type_mask: torch.Tensor):
         """(node ids grouped by type int32 [N] on device, host offsets [T+1]); cached per type_mask tensor."""

@@ -612,19 +612,44 @@ class GNNnodeBased(_LoopModel):
 
     def convergence(self, k, state, state_old, nodes, adjacency, aggregated_nodes, aggregated_arcs, training, *,
                     arcs=None, arcnode=None):
-        """One state-transition step (reference GNN.py:217-236) through `torch.ops.gnnkeras.state_step`. The reference
-        threads the pre-aggregated label / arc tensors through the loop; the native step recomputes them from
-        `arcs`/`arcnode` when given, which is what `Loop` does once per call."""
-        if arcs is None or arcnode is None:
-            raise ValueError('convergence() needs arcs= and arcnode= to rebuild the iteration constants on device')
-        self._check_training(bool(training))
-        nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs'); nat.require_device(state, 'state')
+        """One state-transition step with the reference's own eight positional arguments (reference GNN.py:217-236):
+
+            state_new = net_state([state | nodes (if state_vect_dim > 0) | adjacency^T . state | aggregated_nodes | aggregated_arcs])
+
+        through `torch.ops.gnnkeras.state_step` -> `gnn_state_step_agg`: the aggregates `Loop` formed once (GNN.py:254-258) are
+        used as handed in, exactly as the reference threads them through `tf.while_loop`; `training=True` runs the state network
+        in training mode (BatchNormalization on the batch statistics of this call + moving-average update, Dropout) on the training
+        primitives.  `arcs=` / `arcnode=` (additive, optional): when BOTH aggregates are None they are rebuilt from these on the
+        device.  Returns the reference's 8-tuple."""
+        nat.require_device(nodes, 'nodes'); nat.require_device(state, 'state')
         dev = nodes.device
+        training = bool(training)
+        nodes32 = nodes.to(torch.float32).contiguous()
+        state32 = state.to(dev, torch.float32).contiguous()
         adj = SparseMatrix.from_triple(adjacency).device_csr(dev)
-        arcn = SparseMatrix.from_triple(arcnode).device_csr(dev)
-        new, _moving = ops.state_step(nodes.to(torch.float32).contiguous(), arcs.to(torch.float32).contiguous(), adj, arcn,
-                                      self.net_state, state.to(dev, torch.float32).contiguous(), self.state_vect_dim,
-                                      self.state_threshold, self.native_flags)
+        if aggregated_nodes is None and aggregated_arcs is None:
+            if arcs is None or arcnode is None:
+                raise ValueError('convergence() needs aggregated_nodes / aggregated_arcs (the reference\'s arguments), or arcs= and arcnode= to rebuild them')
+            arcs32 = arcs.to(dev, torch.float32).contiguous()
+            aggregated_arcs = ops.aggregate(SparseMatrix.from_triple(arcnode).device_csr(dev), arcs32[:, 2:].contiguous())
+            aggregated_nodes = ops.aggregate(adj, nodes32) if self.state_vect_dim > 0 else nodes32.new_zeros((nodes32.shape[0], 0))
+        N = nodes32.shape[0]
+        agg_n = nodes32.new_zeros((N, 0)) if aggregated_nodes is None else aggregated_nodes.to(dev, torch.float32)
+        agg_a = nodes32.new_zeros((N, 0)) if aggregated_arcs is None else aggregated_arcs.to(dev, torch.float32)
+        if agg_n.stride(-1) != 1: agg_n = agg_n.contiguous()
+        if agg_a.stride(-1) != 1: agg_a = agg_a.contiguous()
+        if training and (self.net_state.batch_normalization or self.net_state.dropout_rate):
+            from .training import mlp_training_call
+            segs = [(state32, None)]
+            if self.state_vect_dim > 0: segs.append((nodes32, None))
+            segs.append((ops.aggregate(adj, state32), None))
+            if agg_n.shape[1] > 0: segs.append((agg_n, None))
+            if agg_a.shape[1] > 0: segs.append((agg_a, None))
+            new = mlp_training_call(self.net_state, segs, N)
+        else:
+            dummy_arcs = nodes32.new_zeros((0, 2 + agg_a.shape[1]))
+            new, _moving = ops.state_step(nodes32, dummy_arcs, adj, None, self.net_state, state32, self.state_vect_dim,
+                                          self.state_threshold, self.native_flags, aggregated=(agg_n, agg_a))
         return k + 1, new, state, nodes, adjacency, aggregated_nodes, aggregated_arcs, training
 
     def apply_filters(self, state_converged, nodes, adjacency, arcs_label, mask):
@@ -634,12 +659,6 @@ class GNNnodeBased(_LoopModel):
         return state_converged[mask]
 
     # ---- the loop -----------------------------------------------------------------------------------------------------
-    def _check_training(self, training):
-        if training and (self.net_state.batch_normalization or self.net_output.batch_normalization
-                         or self.net_state.dropout_rate or self.net_output.dropout_rate):
-            raise NotImplementedError('training=True forward needs BatchNormalization batch statistics / dropout on '
-                                      'device (SURVEY.md §8f, next row); inference forward is the built path')
-
     def Loop(self, nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph,
              training: bool = False, *, state0=None, seed=None, node_level: bool = False, groups=None, group_sets=None):
         """(k, state, out) for one (merged) graph — reference GNN.py:245-274.

@@ -217,13 +217,20 @@ class Sequential:
             self._native = m
         return self._native
 
-    def __call__(self, x: torch.Tensor, training: bool = False):
-        """Inference forward on the GPU (`torch.ops.gnnkeras.mlp_forward`)."""
-        if training and (self.batch_normalization or self.dropout_rate):
-            raise NotImplementedError('training-mode forward (batch statistics / dropout) is not on the HIP path yet')
+    def __call__(self, x: torch.Tensor, training: bool = False, *, seed=None):
+        """Forward on the GPU.  Inference: `torch.ops.gnnkeras.mlp_forward` (moving statistics folded into the first Dense).
+        `training=True` (Keras `net(x, training=True)`): BatchNormalization on the batch statistics of `x` with its moving averages
+        moved once, Dropout / AlphaDropout with a fresh mask (`seed`, additive, makes it reproducible) - the training primitives
+        of `Models/training.py`; a network without either layer computes the same thing in both modes."""
         nat.require_device(x, 'x')
+        x = x.to(torch.float32)
+        if training and (self.batch_normalization or self.dropout_rate):
+            from .training import mlp_training_call
+            if x.dim() != 2 or x.shape[1] != self.input_dim: raise ValueError(f'x must be [M, {self.input_dim}]')
+            if x.stride(-1) != 1: x = x.contiguous()
+            return mlp_training_call(self, [(x, None)], x.shape[0], seed=seed)
         from .. import ops
-        return ops.mlp_forward(self, x.to(torch.float32).contiguous())
+        return ops.mlp_forward(self, x.contiguous())
 
 
 def _init_weights(model: Sequential, kernel_initializer, bias_initializer, rng):

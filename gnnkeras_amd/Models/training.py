@@ -215,7 +215,7 @@ class _Prim:
 class _NetGrads:
     """Gradient buffers of one Sequential in `trainable_variables` order (BN: γ, β; Dense: W, b ...)."""
 
-    def __init__(self, net: Sequential, prim: _Prim):
+    def __init__(self, net: Sequential, prim: _Prim, grads: bool = True):
         self.net = net
         self.bn = net.batch_normalization
         w = net.weights
@@ -225,10 +225,10 @@ class _NetGrads:
         self.W = [w[base + 2 * i] for i in range(len(net.units))]
         self.b = [w[base + 2 * i + 1] for i in range(len(net.units))]
         self.acts = [nat.ACTIVATIONS[a] for a in net.activations]
-        self.dgamma = prim.zeros(net.input_dim) if self.bn else None
-        self.dbeta = prim.zeros(net.input_dim) if self.bn else None
-        self.dW = [torch.zeros_like(x) for x in self.W]
-        self.db = [torch.zeros_like(x) for x in self.b]
+        self.dgamma = prim.zeros(net.input_dim) if self.bn and grads else None
+        self.dbeta = prim.zeros(net.input_dim) if self.bn and grads else None
+        self.dW = [torch.zeros_like(x) for x in self.W] if grads else None
+        self.db = [torch.zeros_like(x) for x in self.b] if grads else None
         self.touched = False                                        # False until the first accumulation of this step
         # Dropout layers by position in the Dense list (reference MLP.py:60-66: position p = in front of Dense p, p = number of
         # Dense layers = behind the last one): {p: [(rate, index of the dropout layer), ...]}
@@ -238,6 +238,11 @@ class _NetGrads:
         for i, (r, q) in enumerate(zip(net.dropout_rate or [], pos)):
             if not 0 <= q <= len(net.units): raise ValueError(f'dropout_pos {q} outside [0, {len(net.units)}]')
             if float(r) > 0: self.drop.setdefault(q, []).append((float(r), i))
+
+    @classmethod
+    def forward_only(cls, net: Sequential):
+        """The same view of a network without gradient buffers (standalone training-mode calls)."""
+        return cls(net, None, grads=False)
 
     def variables(self):
         v = list(self.bn_params) if self.bn else []
@@ -909,6 +914,28 @@ class LoopTrainer:
         reg = self.finish(tp, apply)
         if reg is not None: res['loss'] = res['loss'] + reg          # compiled_loss(..., regularization_losses=self.losses)
         return res
+
+
+def mlp_training_call(net: Sequential, segs, M, seed=None, net_id=0, call=0):
+    """Keras TRAINING-mode call of one reference MLP (`net(x, training=True)`, reference MLP.py:60-78 layers in training mode): the
+    input is the virtual concatenation `segs` = [(matrix view [*, w], row index or None), ...] of M rows; BatchNormalization
+    normalises with the batch statistics of THIS call and moves its moving averages once (momentum 0.99), Dropout / AlphaDropout
+    draw a fresh mask (`seed` makes it reproducible).  What the standalone `convergence(..., training=True)` and
+    `Sequential.__call__(x, training=True)` run; `Loop(training=True)` / `train_step` use the same primitives with their tape."""
+    dev = segs[0][0].device
+    t = LoopTrainer.__new__(LoopTrainer)
+    t.model, t.dp, t.go = None, None, None
+    t.prim = LoopTrainer.prim_cls(dev)
+    net.to(dev)
+    net._training_calls = getattr(net, '_training_calls', 0) + 1
+    t.drop_seed = _mix32(0x5EED, int(seed)) if seed is not None else _mix32(id(net) & 0xFFFFFFFF, net._training_calls)
+    ng = _NetGrads.forward_only(net)
+    ng.net_id = net_id
+    hs, st = t._mlp_forward(ng, segs, M, call=call)
+    if ng.bn and M > 0:
+        mm, mv = ng.moving
+        mm.mul_(BN_MOMENTUM).add_(st[0] * (1 - BN_MOMENTUM)); mv.mul_(BN_MOMENTUM).add_(st[1] * (1 - BN_MOMENTUM))
+    return hs.out
 
 
 def _regularize(ng: _NetGrads):

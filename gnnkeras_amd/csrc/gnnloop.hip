@@ -249,7 +249,7 @@ int launch_rowdense_wide(const gnn::SegDenseArgs &a, hipStream_t st) {
     r.gate = a.gate; r.M = a.M; r.nseg = a.nseg;
     int chunks = 0;
     for (int s = 0; s < a.nseg; ++s) { r.X[s] = a.seg[s].ptr; r.ldx[s] = a.seg[s].ld; r.width[s] = a.seg[s].width; r.wrow[s] = a.seg[s].wrow; chunks += (a.seg[s].width + 15) / 16; }
-    r.W = a.W; r.ldw = a.ldw; r.bias = a.addend ? nullptr : a.bias; r.addend = a.addend; r.ld_add = a.ld_add;
+    r.W = a.W; r.ldw = a.ldw; r.bias = a.bias; r.addend = a.addend; r.ld_add = a.ld_add;
     r.H = a.H; r.act = a.act; r.Y = a.Y; r.ldy = a.ldy;
     const int passes = cdiv(a.H, 64);
     const size_t lds = (size_t)(16 * chunks * 64 + 64) * sizeof(float);
@@ -708,7 +708,12 @@ int iteration_unfused(const gnn_loop_args_t &a, const Plan &p, const int *gate, 
 }
 
 // `skip_c`: the caller runs every iteration on the XC form of the wave-specialised kernel, which never reads C
-int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, bool zero_loop_words = false, bool skip_c = false) {
+// iteration constants handed in by the caller instead of being aggregated here: what the reference's `convergence` receives as
+// `aggregated_nodes` / `aggregated_arcs` (GNN.py:217) or, column blocks of one matrix, `aggregated_component` (CompositeGNN.py:214)
+struct GivenAgg { const float *nodes; int ld_nodes; const float *arcs; int ld_arcs; };
+
+int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, bool zero_loop_words = false, bool skip_c = false,
+                    const GivenAgg *given = nullptr) {
     // BN folding of every first layer: one launch, which also zeroes the flag words / barrier counters and k
     FoldList fl;
     for (int t = 0; t < p.T; ++t) fl.add(a.net_state[t], p.tp[t].Wf, p.tp[t].bf);
@@ -716,6 +721,10 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, boo
     if (zero_loop_words) { fl.fa.zero_a = p.flags; fl.fa.n_a = a.max_iteration + GNN_LOOP_WORDS; fl.fa.zero_b = a.k_out; fl.fa.n_b = 1; }
     TRY(launch_fold_list(fl, st));
     // ArcNode scatter-add (GNN.py:254) and neighbour-label aggregates (GNN.py:258 / CompositeGNN.py:251)
+    if (given) {
+        if (p.A > 0) TRY(launch_copy2d(nullptr, given->arcs, given->ld_arcs, p.agg_arcs, p.A, p.N, p.A, p.A, st));
+        if (p.ld_agg_nodes > 0) TRY(launch_copy2d(nullptr, given->nodes, given->ld_nodes, p.agg_nodes, p.ld_agg_nodes, p.N, p.ld_agg_nodes, p.ld_agg_nodes, st));
+    } else {
     if (p.A > 0) TRY(launch_aggregate(nullptr, a.arcnode, a.arc_labels, a.ld_arcs, p.A, p.agg_arcs, p.A, st));
     if (!p.composite) {
         if (a.state_dim > 0) TRY(launch_aggregate(nullptr, a.adjacency, a.nodes_src ? a.nodes_src : a.nodes,
@@ -728,6 +737,7 @@ int setup_constants(const gnn_loop_args_t &a, const Plan &p, hipStream_t st, boo
                                              a.nodes_src ? a.ld_nodes_src : a.ld_nodes, dt, p.agg_nodes + col, p.ld_agg_nodes, st));
             col += dt;
         }
+    }
     }
     // C[j] = const segments . Wf[const rows] + bf     (written row-scattered per type; every node has one type)
     for (int t = 0; t < p.T && !skip_c; ++t) {
@@ -1438,24 +1448,29 @@ int gnn_converged(const float *state, const float *state_old, int32_t n, int32_t
     return launch_converge(nullptr, state, state_old, n, dim, ld, ld, threshold, flag, nullptr, 0.f, st);
 }
 
-int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *state_out, int32_t *flag_out) {
+static int state_step_impl(const gnn_loop_args_t *args, const float *state_in, const GivenAgg *given, float *state_out, int32_t *flag_out) {
     if (!args) return fail("args is NULL");
     const gnn_loop_args_t &a = *args;
     Plan p;
     TRY(make_plan(a, a.workspace, p, false));
     TRY(check_csr(a.adjacency, "adjacency", p.N, p.N));
-    TRY(check_csr(a.arcnode, "arcnode", p.N, p.E));
+    if (!given) TRY(check_csr(a.arcnode, "arcnode", p.N, p.E));
     for (int t = 0; t < p.T; ++t) TRY(check_mlp(a.net_state[t], "net_state", true));
     if (p.composite) {      // one step of CompositeGNNnodeBased.convergence (CompositeGNN.py:215-234): per-type networks on per-type row lists
         if (!a.type_nodes && p.N > 0) return fail("type_nodes is NULL");
         if (a.type_offsets[0] != 0 || a.type_offsets[p.T] != p.N) return fail("type_offsets must span [0, n_nodes]");
-        for (int t = 0; t < p.T; ++t) TRY(check_csr(a.composite_adjacency[t], "composite_adjacency", p.N, p.N));
+        for (int t = 0; t < p.T && !given; ++t) TRY(check_csr(a.composite_adjacency[t], "composite_adjacency", p.N, p.N));
     }
     if (p.N > 0 && !a.nodes) return fail("nodes is NULL");
     if (!state_in || !state_out) return fail("state_in / state_out is NULL");
+    if (given && p.N > 0) {
+        if (p.A > 0 && (!given->arcs || given->ld_arcs < p.A)) return fail("aggregated_arcs is NULL or narrower than dim_arc_label = %d", p.A);
+        if (p.ld_agg_nodes > 0 && (!given->nodes || given->ld_nodes < p.ld_agg_nodes))
+            return fail("aggregated_nodes is NULL or narrower than the %d aggregated label columns", p.ld_agg_nodes);
+    }
     if (!a.workspace || a.workspace_bytes < p.bytes) return fail("workspace too small: %zu < %zu bytes", a.workspace_bytes, p.bytes);
     hipStream_t st = (hipStream_t)a.stream;
-    TRY(setup_constants(a, p, st));
+    TRY(setup_constants(a, p, st, false, false, given));
     TRY(launch_copy2d(nullptr, state_in, p.S, p.buf[0], p.SP, p.N, p.S, p.SP, st));
     if (p.SP != p.S) HIP_OK(hipMemsetAsync(p.buf[1], 0, sizeof(float) * (size_t)p.N * p.SP, st));
     if (flag_out) HIP_OK(hipMemsetAsync(flag_out, 0, sizeof(int32_t), st));
@@ -1467,6 +1482,16 @@ int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *st
     } else
         TRY(iteration_unfused(a, p, nullptr, p.buf[0], p.buf[1], 0, flag_out, nullptr, 0.f, st));
     return launch_copy2d(nullptr, p.buf[1], p.SP, state_out, p.S, p.N, p.S, p.S, st);
+}
+
+int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *state_out, int32_t *flag_out) {
+    return state_step_impl(args, state_in, nullptr, state_out, flag_out);
+}
+
+int gnn_state_step_agg(const gnn_loop_args_t *args, const float *state_in, const float *aggregated_nodes, int32_t ld_aggregated_nodes,
+                       const float *aggregated_arcs, int32_t ld_aggregated_arcs, float *state_out, int32_t *flag_out) {
+    const GivenAgg g{aggregated_nodes, ld_aggregated_nodes, aggregated_arcs, ld_aggregated_arcs};
+    return state_step_impl(args, state_in, &g, state_out, flag_out);
 }
 
 __global__ void k_or_flags(const int *gate, int n_gate, int gate_stride, int *out) {

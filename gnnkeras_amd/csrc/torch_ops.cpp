@@ -8,7 +8,8 @@
 //   torch.ops.gnnkeras.aggregate      A^T . X                           sparse_dense_matmul(adjoint_a=True): GNN.py:228, :254, :258
 //   torch.ops.gnnkeras.pool           NodeGraph^T . out                 GNN.py:345
 //   torch.ops.gnnkeras.converged      the predicate of `condition`      GNN.py:196-212
-//   torch.ops.gnnkeras.state_step     one `convergence` step            GNN.py:217-236
+//   torch.ops.gnnkeras.state_step     one `convergence` step            GNN.py:217-236 (aggregated_nodes / aggregated_arcs given:
+//                                     the reference's own 8 arguments, gnn_state_step_agg)
 //   torch.ops.gnnkeras.mlp_forward    Keras Sequential inference call   GNN.py:234, :273
 //
 // Thin registrations over the C ABI of libgnnloop.so (include/gnnloop.h): this file owns argument checking (device / dtype /
@@ -286,10 +287,14 @@ std::tuple<at::Tensor, at::Tensor> state_step(const at::Tensor &nodes, const at:
                                               const at::Tensor &state, int64_t state_dim, double state_threshold, int64_t flags,
                                               const OptTensorList &hub, at::IntArrayRef hub_dims, const std::optional<at::Tensor> &type_nodes,
                                               at::IntArrayRef type_offsets, at::IntArrayRef type_dim_label,
-                                              const OptTensorList &composite_adjacency, at::IntArrayRef composite_dims) {
+                                              const OptTensorList &composite_adjacency, at::IntArrayRef composite_dims,
+                                              const std::optional<at::Tensor> &aggregated_nodes, const std::optional<at::Tensor> &aggregated_arcs) {
     const at::Device dev = nodes.device();
     gnn_loop_args_t a{};
     fill_graph(a, nodes, arcs, adjacency, adjacency_dims, arcnode, arcnode_dims, hub, hub_dims, dev);
+    // the reference's own argument list (GNN.py:217): the aggregates formed once by Loop are handed in; arcs / arcnode / the composite
+    // adjacencies are then not read (arcs may be [0, 2 + A])
+    const bool given = (aggregated_nodes.has_value() && aggregated_nodes->defined()) || (aggregated_arcs.has_value() && aggregated_arcs->defined());
     const int T = (int)type_dim_label.size();
     a.composite = T > 0;
     a.n_types = T > 0 ? T : 1;
@@ -298,12 +303,13 @@ std::tuple<at::Tensor, at::Tensor> state_step(const at::Tensor &nodes, const at:
     for (int t = 0; t < a.n_types; ++t) mlp_of(a.net_state[t], net_state_weights, net_state_spec, &wpos, &spos, bn_eps, "net_state", dev);
     TORCH_CHECK(wpos == net_state_weights.size() && spos == net_state_spec.size(), "net_state: ", a.n_types, " network(s) expected, surplus weights / spec entries");
     if (a.composite) {       // CompositeGNNnodeBased.convergence (CompositeGNN.py:215-234)
-        TORCH_CHECK((int)type_offsets.size() == T + 1 && (int)composite_adjacency.size() == 4 * T && (int)composite_dims.size() == 3 * T,
+        TORCH_CHECK((int)type_offsets.size() == T + 1 && (given || ((int)composite_adjacency.size() == 4 * T && (int)composite_dims.size() == 3 * T)),
                     "composite: type_offsets[T + 1], composite_adjacency[4 T], composite_dims[3 T] expected for T = ", T);
         a.type_nodes = i32(type_nodes, "type_nodes", dev);
         for (int t = 0; t < T; ++t) {
             a.type_dim_label[t] = (int32_t)type_dim_label[t];
             a.type_offsets[t] = (int32_t)type_offsets[t];
+            if (given) continue;
             OptTensorList one;
             for (int i = 0; i < 4; ++i) one.push_back(composite_adjacency.get(4 * t + i));
             a.composite_adjacency[t] = csr_of(one, composite_dims.slice(3 * t, 3), "composite_adjacency", dev);
@@ -327,7 +333,27 @@ std::tuple<at::Tensor, at::Tensor> state_step(const at::Tensor &nodes, const at:
     TORCH_CHECK(bytes != 0, "libgnnloop: ", gnn_last_error());
     at::Tensor ws = workspace(bytes, dev, &a.workspace);
     a.workspace_bytes = bytes;
-    check_rc(gnn_state_step(&a, s, out.data_ptr<float>(), flag.data_ptr<int32_t>()));
+    if (given) {
+        // [n_nodes, >= needed columns] float32 matrices whose rows may be strided (column blocks of `aggregated_component`)
+        auto view = [&](const std::optional<at::Tensor> &t, const char *name, int32_t *ld) -> const float * {
+            if (!(t.has_value() && t->defined()) || t->numel() == 0) { *ld = 0; return nullptr; }
+            TORCH_CHECK(t->device() == dev && t->scalar_type() == at::kFloat, name, ": expected a float32 tensor on ", dev);
+            TORCH_CHECK(t->dim() == 2 && t->size(0) == a.n_nodes && t->stride(1) == 1, name, ": expected [n_nodes, columns] with unit column stride");
+            *ld = (int32_t)std::max<int64_t>(t->stride(0), t->size(1));
+            return t->const_data_ptr<float>();
+        };
+        int32_t ld_n = 0, ld_a = 0;
+        const float *an = view(aggregated_nodes, "aggregated_nodes", &ld_n), *aa = view(aggregated_arcs, "aggregated_arcs", &ld_a);
+        int need_n = 0;
+        if (a.composite) for (int t = 0; t < T; ++t) need_n += a.type_dim_label[t];
+        else need_n = state_dim > 0 ? a.dim_node_label : 0;
+        TORCH_CHECK(a.n_nodes == 0 || need_n == 0 || (an && aggregated_nodes->size(1) == need_n), "aggregated_nodes must be [n_nodes, ", need_n, "]");
+        TORCH_CHECK(a.n_nodes == 0 || a.dim_arc_label == 0 || (aa && aggregated_arcs->size(1) == a.dim_arc_label), "aggregated_arcs must be [n_nodes, ",
+                    a.dim_arc_label, "]");
+        check_rc(gnn_state_step_agg(&a, s, an, ld_n, aa, ld_a, out.data_ptr<float>(), flag.data_ptr<int32_t>()));
+    } else {
+        check_rc(gnn_state_step(&a, s, out.data_ptr<float>(), flag.data_ptr<int32_t>()));
+    }
     return {out, flag};
 }
 
@@ -365,7 +391,7 @@ TORCH_LIBRARY(gnnkeras, m) {
     m.def("state_step(Tensor nodes, Tensor arcs, Tensor?[] adjacency, int[] adjacency_dims, Tensor?[] arcnode, int[] arcnode_dims, "
           "Tensor[] net_state_weights, int[] net_state_spec, float bn_eps, Tensor state, int state_dim, float state_threshold, int flags, "
           "Tensor?[] hub, int[] hub_dims, Tensor? type_nodes, int[] type_offsets, int[] type_dim_label, "
-          "Tensor?[] composite_adjacency, int[] composite_dims) -> (Tensor state_new, Tensor moving)");
+          "Tensor?[] composite_adjacency, int[] composite_dims, Tensor? aggregated_nodes=None, Tensor? aggregated_arcs=None) -> (Tensor state_new, Tensor moving)");
     m.def("mlp_forward(Tensor[] weights, int[] spec, float bn_eps, Tensor X) -> Tensor");
 }
 

@@ -118,9 +118,11 @@ def converged(state, state_old, threshold):
     return load().converged(state, state_old, float(threshold))
 
 
-def state_step(nodes, arcs, adjacency, arcnode, net_state, state, state_dim, state_threshold, flags=0, composite=None):
+def state_step(nodes, arcs, adjacency, arcnode, net_state, state, state_dim, state_threshold, flags=0, composite=None, aggregated=None):
     """`net_state`: one `Sequential`, or the per-type list with `composite` = (type_nodes, type_offsets, type_dim_label, [device-CSR
-    dict per type]) as for `loop_forward` (CompositeGNN.py:215-234)."""
+    dict per type]) as for `loop_forward` (CompositeGNN.py:215-234).  `aggregated` = (aggregated_nodes, aggregated_arcs): the
+    iteration constants the reference's `convergence` is handed (GNN.py:217; the column blocks of `aggregated_component` for the
+    composite form) - `arcs` may then be an empty [0, 2 + A] matrix, `arcnode` None and the composite adjacencies absent."""
     adj_t, adj_d = csr_args(adjacency)
     an_t, an_d = csr_args(arcnode)
     hub_t, hub_d = hub_args(adjacency)
@@ -129,16 +131,18 @@ def state_step(nodes, arcs, adjacency, arcnode, net_state, state, state_dim, sta
     for n_ in nets:
         w_, s_ = net_args(n_, nodes.device)
         w += w_; s += s_
+    agg_n, agg_a = aggregated if aggregated is not None else (None, None)
     if composite is None:
         return load().state_step(nodes, arcs, adj_t, adj_d, an_t, an_d, w, s, BN_EPSILON, state, int(state_dim), float(state_threshold),
-                                 int(flags), hub_t, hub_d, None, [], [], [], [])
+                                 int(flags), hub_t, hub_d, None, [], [], [], [], agg_n, agg_a)
     type_nodes, type_offsets, type_dims, cas = composite
     ca_t, ca_d = [], []
-    for c in cas:
+    for c in (cas or []):
         t, d = csr_args(c)
         ca_t += t; ca_d += d
     return load().state_step(nodes, arcs, adj_t, adj_d, an_t, an_d, w, s, BN_EPSILON, state, int(state_dim), float(state_threshold),
-                             int(flags), hub_t, hub_d, type_nodes, [int(v) for v in type_offsets], [int(v) for v in type_dims], ca_t, ca_d)
+                             int(flags), hub_t, hub_d, type_nodes, [int(v) for v in type_offsets], [int(v) for v in type_dims], ca_t, ca_d,
+                             agg_n, agg_a)
 
 
 def mlp_forward(net, X):

@@ -218,6 +218,16 @@ int gnn_converged(const float *state, const float *state_old, int32_t n, int32_t
  * state_in/state_out are [n_nodes, S] row-major. */
 int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *state_out, int32_t *flag_out);
 
+/* The same step with the iteration constants HANDED IN, i.e. the reference's own argument list: `convergence(k, state, state_old,
+ * nodes, adjacency, aggregated_nodes, aggregated_arcs, training)` (GNN.py:217) receives the label / arc aggregates that `Loop`
+ * formed once (GNN.py:254-258) and threads them through `tf.while_loop` (:265); the composite form receives them as the column
+ * blocks of one `aggregated_component` = [aggregated_nodes_0 | .. | aggregated_nodes_{T-1} | aggregated_arcs] (CompositeGNN.py:214,
+ * :251-253).  aggregated_nodes: [n_nodes, ld] with dim_node_label columns (homogeneous, state_dim > 0; unused when state_dim == 0)
+ * or sum_t type_dim_label[t] columns (composite); aggregated_arcs: [n_nodes, ld] with dim_arc_label columns.  args->arcnode,
+ * args->arc_labels and args->composite_adjacency are not read (n_arcs may be 0); everything else as gnn_state_step. */
+int gnn_state_step_agg(const gnn_loop_args_t *args, const float *state_in, const float *aggregated_nodes, int32_t ld_aggregated_nodes,
+                       const float *aggregated_arcs, int32_t ld_aggregated_arcs, float *state_out, int32_t *flag_out);
+
 /* ---- node-range sharded loop -------------------------------------------------------------------------
  * One process per GPU; rank r owns a contiguous node range and, per iteration, (1) runs gnn_shard_iteration on its
  * rows reading the full (all-gathered) state buffer and writing its own slice of the other full buffer, (2) the host

@@ -58,13 +58,28 @@ def sparse_dense_matmul_adjoint(indices, values, dense_shape, B, dtype, exact_or
     n_rows, n_cols = int(dense_shape[0]), int(dense_shape[1])
     assert B.shape[0] == n_rows, (B.shape, dense_shape)
     if not exact_order:
-        from scipy.sparse import csr_matrix
-        At = csr_matrix((values, (indices[:, 1], indices[:, 0])), shape=(n_cols, n_rows), dtype=dtype)
-        return np.asarray(At @ B, dtype=dtype)
+        return np.asarray(_scipy_adjoint(indices, values, n_rows, n_cols, dtype) @ B, dtype=dtype)
     out = np.zeros((n_cols, B.shape[1]), dtype=dtype)
     if len(values):
         np.add.at(out, indices[:, 1], values[:, None] * B[indices[:, 0]])
     return out
+
+
+_SCIPY_CACHE = []          # [(key, indices, values, At)]: the loop hands the SAME adjacency buffers to every iteration
+
+
+def _scipy_adjoint(indices, values, n_rows, n_cols, dtype):
+    """CSR of Aᵀ for the `exact_order=False` path, built once per (indices, values) buffer pair instead of once per iteration
+    (the COO -> CSR conversion of 10 M entries costs more than the product itself).  Keyed on the buffers' addresses; the
+    arrays are kept referenced so that an address cannot be reused while its entry lives."""
+    from scipy.sparse import csr_matrix
+    key = (indices.__array_interface__['data'][0], values.__array_interface__['data'][0], len(values), np.dtype(dtype).str, n_rows, n_cols)
+    for k_, _i, _v, At in _SCIPY_CACHE:
+        if k_ == key: return At
+    At = csr_matrix((values, (indices[:, 1], indices[:, 0])), shape=(n_cols, n_rows), dtype=dtype)
+    _SCIPY_CACHE.append((key, indices, values, At))
+    if len(_SCIPY_CACHE) > 4: _SCIPY_CACHE.pop(0)
+    return At
 
 
 def activation(name, x, dtype):

@@ -119,9 +119,9 @@ def test_validation_paths_under_address_and_ub_sanitizers():
     this file in a child process - no GPU needed, SURVEY 5.  GPU AddressSanitizer is not available on this pool."""
     import subprocess, sys, glob
     asan_lib = os.path.join(nat.CSRC, 'libgnnloop_asan.so')
-    if not os.path.exists(asan_lib):
-        res = subprocess.run(['make', '-C', nat.CSRC, 'asan'], capture_output=True, text=True, timeout=900)
-        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    # (`make` rebuilds it only when a source is newer: build() no longer does, and a stale sanitizer build lacks new exports)
+    res = subprocess.run(['make', '-C', nat.CSRC, 'asan'], capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     rt = glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so')
     if not rt: pytest.skip('no clang AddressSanitizer runtime in this image')
     env = dict(os.environ, GNNKERAS_AMD_LIB=asan_lib, LD_PRELOAD=rt[0], ASAN_OPTIONS='detect_leaks=0:verify_asan_link_order=0:halt_on_error=1',

@@ -1,0 +1,451 @@
+"""Round-4 parity closure.
+
+  * parity at the TIMED depth: BASELINE C3 / C4 / C5 for the 50 iterations bench.py times (error growth over 50
+    iterations of the starter networks), against the float32 and the float64 oracle (reference GNN.py:245-274, CompositeGNN.py:242-272);
+  * the operands bench.py's `beyond_infinity_cache` / `wide_state_d200` sections run on (`synth.er_device_batch`): bit-identical to
+    the `GraphObject` path, the Loop on them against the oracle, and the size-independent properties at 4 M nodes / 40 M arcs;
+  * the reference's own argument lists: `convergence(k, state, state_old, nodes, adjacency, aggregated_nodes, aggregated_arcs,
+    training)` (GNN.py:217) and the composite 9-tuple (CompositeGNN.py:214) driven by a Python `while condition: convergence` loop,
+    `training=True` included; `Sequential.__call__(x, training=True)`;
+  * gnn_dense with bias AND addend on the wide row-streaming kernel.
+
+Tolerance as everywhere: 1e-5 relative (max-norm), k exact."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from gnnkeras_amd import _native as nat
+from gnnkeras_amd import GraphObject, ops
+from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+from gnnkeras_amd.Models.GNN import GNNnodeBased, GNNgraphBased
+from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased
+from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer, CompositeMultiGraphSequencer
+from gnnkeras_amd.sparse import SparseMatrix
+from gnnkeras_amd.synth import er_graph, er_composite_graph, er_device_batch
+from oracle import gnn_oracle as O
+from oracle.harness import oracle_loop, oracle_composite_loop, rel_err, _np, _triple
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+PATHS = (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN4, nat.FLAG_FUSED_GEN5, nat.FLAG_FUSED_GEN6)
+
+
+def dev(x):
+    return torch.as_tensor(np.asarray(x)).cuda()
+
+
+def _last_kernel():
+    return nat.lib().gnn_last_kernel_name().decode()
+
+
+def _starter(focus, d, **kw):
+    from test_gpu_parity import starter_nets
+    return starter_nets(focus, d, **kw)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# parity at the timed depth (k = 50)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode', ['average', 'sum'])
+def test_c3_at_the_timed_depth_every_path(mode):
+    """BASELINE C3 (100 k nodes / 1 M arcs, d = 64) for the 50 iterations the bench times, every way the iteration can run,
+    against the float32 AND the float64 oracle (scipy row order).  Prints the worst relative error of the configuration and the
+    distance of the two oracles from each other (what float32 itself loses over 50 iterations)."""
+    N, E, d, K = 100_000, 1_000_000, 64, 50
+    g = er_graph(N, E, aggregation_mode=mode)
+    x = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    ns, no = _starter('n', d, scale=1.0 if mode == 'average' else 0.1)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
+    model = GNNnodeBased(ns, no, d, K, 0.0)
+    t0 = time.time()
+    k32, st32, o32 = oracle_loop(model, x, s0, np.float32, exact_order=False)
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    t_oracle = time.time() - t0
+    assert float(k32) == float(k64) == K
+    inputs = model.process_inputs(x)
+    worst, kernels = {}, {}
+    for flags in PATHS:
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=dev(s0))
+        assert float(k) == K
+        kernels[flags] = _last_kernel()
+        st, o = st.cpu().numpy(), o.cpu().numpy()
+        assert np.all(np.isfinite(st)) and np.all(np.isfinite(o))
+        worst[flags] = (rel_err(st, st32), rel_err(st, st64), rel_err(o, o32), rel_err(o, o64))
+    print(f'\nC3 {mode} k={K}: oracle fp32 vs fp64 state {rel_err(st32, st64):.2e} out {rel_err(o32, o64):.2e} (oracles {t_oracle:.0f} s); '
+          f'device (state vs fp32, state vs fp64, out vs fp32, out vs fp64) per path: '
+          + '; '.join(f'{kernels[f].split("<")[0]}[{f}] ' + ' '.join(f'{v:.1e}' for v in worst[f]) for f in PATHS)
+          + f'; worst {max(max(v) for v in worst.values()):.2e}')
+    for flags in PATHS:
+        assert max(worst[flags]) <= TOL, (flags, kernels[flags], worst[flags])
+
+
+def test_c4_at_the_timed_depth_vs_fp64_oracle():
+    """BASELINE C4 (1 M nodes / 10 M arcs, d = 64): the 50 iterations of the bench line on the default path (the wave-specialised
+    kernel with the constant inputs multiplied in) and the un-fused kernels against the float64 oracle (scipy row order)."""
+    N, E, d, K = 1_000_000, 10_000_000, 64, 50
+    g = er_graph(N, E, aggregation_mode='average')
+    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    ns, no = _starter('n', d)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
+    model = GNNnodeBased(ns, no, d, K, 0.0)
+    t0 = time.time()
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    t_oracle = time.time() - t0
+    assert float(k64) == K
+    inputs = model.process_inputs(x)
+    res = {}
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=dev(s0))
+        assert float(k) == K
+        if flags == 0: assert _last_kernel().startswith('k_state_fused4<64'), _last_kernel()
+        res[flags] = (rel_err(st.cpu().numpy(), st64), rel_err(o.cpu().numpy(), o64))
+    print(f'\nC4 k={K} vs fp64 oracle ({t_oracle:.0f} s): default state {res[0][0]:.2e} out {res[0][1]:.2e}; '
+          f'un-fused state {res[nat.FLAG_UNFUSED][0]:.2e} out {res[nat.FLAG_UNFUSED][1]:.2e}')
+    for flags, e in res.items(): assert max(e) <= TOL, (flags, e)
+
+
+@pytest.mark.parametrize('mode', ['average', 'composite_average'])
+def test_c5_at_the_timed_depth_vs_fp64_oracle(mode):
+    """BASELINE C5 (3 node types, 500 k nodes / 5 M arcs, d = 64, per-type state networks): 50 iterations on the default path and
+    the un-fused kernels against the float64 oracle (reference CompositeGNN.py:242-272)."""
+    N, E, d, dims, K = 500_000, 5_000_000, 64, (14, 8, 4), 50
+    g = er_composite_graph(N, E, dim_node_label=dims, aggregation_mode=mode, seed=1234)
+    x = CompositeMultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    inp, lay = get_inout_dims('state', dims, 3, 2, 'n', d)
+    ns = [MLP(i, lay, 'selu', 'lecun_normal', 'lecun_normal', rng=t) for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', dims, 3, 2, 'n', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
+    model = CompositeGNNnodeBased(ns, no, d, K, 0.0)
+    t0 = time.time()
+    k64, st64, o64 = oracle_composite_loop(model, x, s0, np.float64, exact_order=False)
+    t_oracle = time.time() - t0
+    assert float(k64) == K
+    inputs = model.process_inputs(x)
+    res = {}
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k, st, o = model.Loop(*inputs, state0=dev(s0))
+        assert float(k) == K
+        res[flags] = (rel_err(st.cpu().numpy(), st64), rel_err(o.cpu().numpy(), o64))
+    print(f'\nC5 {mode} k={K} vs fp64 oracle ({t_oracle:.0f} s): default state {res[0][0]:.2e} out {res[0][1]:.2e}; '
+          f'un-fused state {res[nat.FLAG_UNFUSED][0]:.2e} out {res[nat.FLAG_UNFUSED][1]:.2e}')
+    for flags, e in res.items(): assert max(e) <= TOL, (flags, e)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# synth.er_device_batch: the operands of bench.py's beyond_infinity_cache / wide_state_d200 sections
+# ----------------------------------------------------------------------------------------------------------------------
+def _host_graph_of_device_batch(x, mode):
+    """The `GraphObject` holding exactly the arcs / labels of an `er_device_batch` item (ids travel as float32: exact below 2^24)."""
+    nodes, arcs = x[0].cpu().numpy(), x[1].cpu().numpy().astype(np.float64)
+    assert nodes.shape[0] < (1 << 24)
+    return GraphObject(nodes=nodes, arcs=arcs, targets=np.zeros((nodes.shape[0], 2), np.float32), focus='n', aggregation_mode=mode)
+
+
+@pytest.mark.parametrize('mode', ['average', 'sum'])
+def test_er_device_batch_operands_equal_the_graphobject_path(mode):
+    """Same arcs -> the same `rowptr / src / row_scale` (bit for bit) and the same node / arc matrices as `GraphObject` +
+    `MultiGraphSequencer` build on the host (reference graph_class.py:47, :105-121, :539-560); then the Loop on the device-built
+    batch against the float64 and float32 oracle fed from the HOST-built graph (200 k nodes / 2 M arcs, d = 64, 5 iterations),
+    default and un-fused paths."""
+    N, E, d = 200_000, 2_000_000, 64
+    xd = er_device_batch(N, E, 'cuda', aggregation_mode=mode, seed=77)
+    arcs = xd[1].cpu().numpy()
+    ids = arcs[:, :2].astype(np.int64)
+    assert arcs.shape == (E, 5) and len(np.unique(ids[:, 0] * N + ids[:, 1])) == E and np.all(ids[:, 0] != ids[:, 1])
+    assert np.all(np.diff(ids[:, 0] * N + ids[:, 1]) > 0)                                  # sorted by (src, dst): graph_class.py:47
+    assert np.all(arcs[:, 2:].sum(1) == 1) and np.all(xd[0].cpu().numpy().sum(1) == 1)     # one-hot labels
+    g = _host_graph_of_device_batch(xd, mode)
+    assert np.array_equal(g.arcs.astype(np.float32), arcs) and np.array_equal(g.nodes.astype(np.float32), xd[0].cpu().numpy())
+    xh = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    for i, name in ((5, 'adjacency'), (6, 'arcnode')):
+        host = SparseMatrix.from_triple(xh[i]).device_csr(torch.device('cuda', 0))
+        devb = xd[i].device_csr(torch.device('cuda', 0))
+        for key in ('n_dst', 'n_src', 'nnz'): assert int(host[key]) == int(devb[key]), (name, key)
+        assert torch.equal(host['rowptr'], devb['rowptr']), name
+        assert torch.equal(host['src'], devb['src']), name
+        assert (host['w'] is None) == (devb['w'] is None) and (host['row_scale'] is None) == (devb['row_scale'] is None), name
+        if host['row_scale'] is not None: assert torch.equal(host['row_scale'], devb['row_scale']), name
+        assert host.get('heavy') is None and devb.get('heavy') is None
+    ns, no = _starter('n', d, scale=1.0 if mode == 'average' else 0.1)
+    s0 = np.random.default_rng(3).normal(0, 0.1, (N, d)).astype(np.float32)
+    model = GNNnodeBased(ns, no, d, 5, 0.0)
+    k64, st64, o64 = oracle_loop(model, xh, s0, np.float64, exact_order=False)
+    k32, st32, o32 = oracle_loop(model, xh, s0, np.float32, exact_order=False)
+    host_run = None
+    for flags in (0, nat.FLAG_UNFUSED):
+        model.native_flags = flags
+        k, st, o = model.Loop(*model.process_inputs(xd), state0=dev(s0))
+        assert float(k) == 5.0 == float(k64) == float(k32)
+        e = (rel_err(st.cpu().numpy(), st64), rel_err(st.cpu().numpy(), st32), rel_err(o.cpu().numpy(), o64), rel_err(o.cpu().numpy(), o32))
+        assert max(e) <= TOL, (flags, e)
+        if flags == 0:
+            kh, sth, oh = model.Loop(*model.process_inputs(xh), state0=dev(s0))
+            assert torch.equal(st, sth) and torch.equal(o, oh)              # same operands, same kernel: the same bits
+
+
+def test_beyond_infinity_cache_point_4m_40m_properties():
+    """The 4 M-node / 40 M-arc graph of bench.py's `beyond_infinity_cache` section (operands built on the device): the structure of
+    the CSR (row pointers = in-degree prefix sums, sources ascending inside a row, 'average' scale = 1 / in-degree), k pinned, the
+    loop bitwise deterministic, the wave-specialised kernel == the un-fused kernels (two independent device implementations), and
+    the neighbour sum of one iteration against a float64 scipy product over the same arcs."""
+    N, E, d = 4_000_000, 40_000_000, 64
+    x = er_device_batch(N, E, 'cuda')
+    adj = x[5].device_csr(torch.device('cuda', 0))
+    rowptr, src, scale = adj['rowptr'].long(), adj['src'].long(), adj['row_scale']
+    assert int(rowptr[0]) == 0 and int(rowptr[-1]) == E == int(adj['nnz']) and bool(torch.all(rowptr[1:] >= rowptr[:-1]))
+    deg = rowptr[1:] - rowptr[:-1]
+    dst = torch.repeat_interleave(torch.arange(N, device='cuda'), deg)
+    ids = x[1][:, :2].long()
+    order = torch.sort(ids[:, 1], stable=True).indices
+    assert torch.equal(dst, ids[order, 1]) and torch.equal(src, ids[order, 0])              # the arcs of the batch, grouped by destination
+    key = dst * N + src
+    assert bool(torch.all(key[1:] > key[:-1]))                                               # ascending source inside a destination, no duplicates
+    assert torch.equal(scale, torch.where(deg > 0, 1.0 / deg.clamp(min=1).float(), torch.ones((), device='cuda')))
+    assert torch.equal(x[6].device_csr(torch.device('cuda', 0))['src'].long(), order)        # ArcNode row of an arc = its position in `arcs`
+    del dst, key, order, ids
+    ns, no = _starter('n', d)
+    model = GNNnodeBased(ns, no, d, 5, 0.0)
+    s0 = torch.randn((N, d), device='cuda', generator=torch.Generator(device='cuda').manual_seed(5)) * 0.1
+    inputs = model.process_inputs(x)
+    k, st, o = model.Loop(*inputs, state0=s0)
+    assert float(k) == 5.0 and _last_kernel().startswith('k_state_fused4<64'), _last_kernel()
+    k2, st2, o2 = model.Loop(*inputs, state0=s0)
+    assert torch.equal(st, st2) and torch.equal(o, o2)
+    del st2, o2
+    model.native_flags = nat.FLAG_UNFUSED
+    ku, stu, ou = model.Loop(*inputs, state0=s0)
+    assert float(ku) == 5.0
+    es = float((st - stu).abs().max() / stu.abs().max()); eo = float((o - ou).abs().max() / ou.abs().max())
+    print(f'\n4M/40M: fused vs un-fused state {es:.2e} out {eo:.2e}')
+    assert es <= TOL and eo <= TOL
+    del stu, ou
+    # one neighbour sum in float64 on the host (scipy, 40 M arcs x 8 columns of the state)
+    from scipy.sparse import csr_matrix
+    deg_h = deg.cpu().numpy()
+    At = csr_matrix((np.repeat(1.0 / np.maximum(deg_h, 1), deg_h), src.cpu().numpy(), rowptr.cpu().numpy()), shape=(N, N))
+    cols = s0[:, :8].contiguous()
+    got = ops.aggregate(adj, cols).cpu().numpy()
+    want = At @ cols.cpu().numpy().astype(np.float64)
+    assert rel_err(got, want) <= TOL
+
+
+def test_wide_state_d200_section_operands_against_the_oracle():
+    """bench.py's `wide_state_d200` section (300 k nodes / 3 M arcs built by `er_device_batch`, d = 200, the 129..256-wide fused
+    kernel) at a size the oracle finishes in seconds (60 k / 600 k): k, state and output against the float64 oracle fed from the
+    host-built graph of the same arcs."""
+    N, E, d = 60_000, 600_000, 200
+    xd = er_device_batch(N, E, 'cuda', seed=5)
+    g = _host_graph_of_device_batch(xd, 'average')
+    xh = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    ns, no = _starter('n', d, act='tanh', scale=0.3)
+    model = GNNnodeBased(ns, no, d, 6, 0.0)
+    s0 = np.random.default_rng(4).normal(0, 0.1, (N, d)).astype(np.float32)
+    k64, st64, o64 = oracle_loop(model, xh, s0, np.float64, exact_order=False)
+    k, st, o = model.Loop(*model.process_inputs(xd), state0=dev(s0))
+    assert _last_kernel().startswith('k_state_xwide'), _last_kernel()
+    assert float(k) == float(k64) == 6.0
+    assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference's own argument lists: while condition(...): convergence(...)
+# ----------------------------------------------------------------------------------------------------------------------
+def _reference_while_loop(model, k, state, state_old, *rest):
+    """`tf.while_loop(self.condition, self.convergence, [k, state, state_old, ...])` of reference GNN.py:265 / CompositeGNN.py:264
+    in eager mode: a Python loop over the model's own two methods with the reference's positional argument lists."""
+    loop_vars = (k, state, state_old) + tuple(rest)
+    while bool(model.condition(*loop_vars)):
+        loop_vars = model.convergence(*loop_vars)
+        assert len(loop_vars) == 3 + len(rest)
+    return loop_vars
+
+
+@pytest.mark.parametrize('d,thr,bn', [(32, 0.0, True), (16, 0.02, True), (0, 0.01, True), (24, 0.0, False)])
+def test_python_while_loop_with_the_reference_arguments_equals_loop(mutag_graphs, d, thr, bn):
+    """`convergence(k, state, state_old, nodes, adjacency, aggregated_nodes, aggregated_arcs, training)` with exactly the reference's
+    eight positionals (GNN.py:217), the aggregates formed as `Loop` forms them (GNN.py:254-258), driven by
+    `while model.condition(...)`: k and the converged state equal `Loop` bit for bit (same kernels, same constants) and the oracle
+    within the tolerance."""
+    seq = MultiGraphSequencer(mutag_graphs[:32], 'g', 'average', 32, shuffle=False)
+    x = seq[0][0]
+    ns, no = _starter('g', d, scale=0.3 if thr > 0 else 1.0, bn=bn)
+    K = 12
+    model = GNNgraphBased(ns, no, d, K, thr)
+    nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph = model.process_inputs(x)
+    N = nodes.shape[0]
+    s0 = np.random.default_rng(2).normal(0, 0.1, (N, d)).astype(np.float32) if d else None
+    cu = torch.device('cuda', 0)
+    aggregated_arcs = ops.aggregate(arcnode.device_csr(cu), arcs[:, 2:].contiguous())                       # GNN.py:254
+    if d > 0:
+        state = dev(s0)
+        aggregated_nodes = ops.aggregate(adjacency.device_csr(cu), nodes)                                   # GNN.py:258
+    else:
+        state = nodes.clone()
+        aggregated_nodes = torch.zeros((N, 0), device='cuda')                                               # GNN.py:255
+    k0 = torch.zeros((), device='cuda')
+    kf, stf, st_old, *_ = _reference_while_loop(model, k0, state, torch.ones_like(state), nodes, adjacency, aggregated_nodes,
+                                                aggregated_arcs, False)
+    model.native_flags = nat.FLAG_FUSED_GEN2            # (Loop's whole-loop kernels sum in another order; generation 2 is what one step runs)
+    k, st, o = model.Loop(nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph, state0=None if not d else dev(s0))
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    assert float(kf) == float(k) == float(k64), (float(kf), float(k), float(k64))
+    if thr > 0: assert 2 <= float(k) < K
+    assert rel_err(stf.cpu().numpy(), st64) <= TOL and rel_err(stf.cpu().numpy(), st.cpu().numpy()) <= TOL
+    # the step also takes the additive rebuild form (aggregates None + arcs= / arcnode=) and gives the same bits
+    a = model.convergence(k0, state, None, nodes, adjacency, aggregated_nodes, aggregated_arcs, False)
+    b = model.convergence(k0, state, None, nodes, adjacency, None, None, False, arcs=arcs, arcnode=arcnode)
+    assert torch.equal(a[1], b[1]) and float(a[0]) == 1.0 and a[2] is state
+    with pytest.raises(ValueError):
+        model.convergence(k0, state, None, nodes, adjacency, None, None, False)
+    if d > 0:
+        with pytest.raises(RuntimeError):
+            model.convergence(k0, state, None, nodes, adjacency, aggregated_nodes[:, :3], aggregated_arcs, False)
+
+
+@pytest.mark.parametrize('N,d', [(3000, 16), (40_000, 64)])
+def test_composite_while_loop_with_the_reference_arguments_equals_loop(N, d):
+    """The composite 9-tuple `(k, state, state_old, nodes, dim_node_label, type_mask, adjacency, aggregated_component, training)`
+    (reference CompositeGNN.py:214, :251-253, :264)."""
+    dims = (5, 3, 2)
+    g = er_composite_graph(N, 6 * N, dim_node_label=dims, aggregation_mode='average', seed=11)
+    x = CompositeMultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    inp, lay = get_inout_dims('state', dims, 3, 2, 'n', d)
+    ns = [MLP(i, lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=t) for t, i in enumerate(inp)]
+    for n in ns: n.set_weights([w * 0.5 if w.ndim == 2 else w for w in n.get_weights()])
+    inp, lay = get_inout_dims('output', dims, 3, 2, 'n', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9)
+    K = 6
+    model = CompositeGNNnodeBased(ns, no, d, K, 0.0)
+    (nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, cas, adjacency, arcnode, nodegraph) = model.process_inputs(x)
+    cu = torch.device('cuda', 0)
+    s0 = np.random.default_rng(2).normal(0, 0.1, (N, d)).astype(np.float32)
+    parts = [ops.aggregate(c.device_csr(cu), nodes[:, :dd].contiguous()) for c, dd in zip(cas, dims)]          # CompositeGNN.py:251
+    parts.append(ops.aggregate(arcnode.device_csr(cu), arcs[:, 2:].contiguous()))                              # :252
+    aggregated_component = torch.cat(parts, dim=1)                                                             # :253
+    state = dev(s0)
+    kf, stf, *_ = _reference_while_loop(model, torch.zeros((), device='cuda'), state, torch.ones_like(state), nodes, dim_node_label,
+                                        type_mask, adjacency, aggregated_component, False)
+    k, st, o = model.Loop(nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, cas, adjacency, arcnode, nodegraph, state0=dev(s0))
+    k64, st64, o64 = oracle_composite_loop(model, x, s0, np.float64, exact_order=N <= 10_000)
+    assert float(kf) == float(k) == float(k64) == K
+    assert rel_err(stf.cpu().numpy(), st64) <= TOL and rel_err(stf.cpu().numpy(), st.cpu().numpy()) <= TOL
+    b = model.convergence(0.0, state, None, nodes, dim_node_label, type_mask, adjacency, None, False, arcs=arcs, arcnode=arcnode,
+                          composite_adjacencies=cas)
+    a = model.convergence(0.0, state, None, nodes, dim_node_label, type_mask, adjacency, aggregated_component, False)
+    assert torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize('d,dropout', [(16, False), (0, False), (8, True)])
+def test_convergence_in_training_mode_matches_the_oracle(mutag_graphs, d, dropout):
+    """`convergence(..., training=True)` (reference GNN.py:234: `self.net_state(inp_state, training=training)`): BatchNormalization
+    on the batch statistics of the step, moving averages moved once per call (Keras momentum 0.99); against the oracle's
+    training-mode step in float64.  With Dropout the call runs, is reproducible under a seed-free counter only in distribution -
+    checked for shape / finiteness and for leaving inference untouched."""
+    seq = MultiGraphSequencer(mutag_graphs[:32], 'g', 'average', 32, shuffle=False)
+    x = seq[0][0]
+    inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d, hidden_units=[20])
+    ns = MLP(inp[0], lay, ['tanh', 'selu'], 'lecun_normal', 'lecun_normal', rng=0, batch_normalization=True,
+             dropout_rate=0.3 if dropout else None, dropout_pos=1 if dropout else None, device='cuda')
+    w = ns.get_weights()
+    rng = np.random.default_rng(8)
+    w[0] = rng.uniform(0.5, 1.5, w[0].shape).astype(np.float32); w[1] = rng.normal(0, 0.2, w[1].shape).astype(np.float32)   # gamma, beta
+    ns.set_weights(w)
+    _, no = _starter('g', d)
+    model = GNNgraphBased(ns, no, d, 5, 0.0)
+    nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph = model.process_inputs(x)
+    N = nodes.shape[0]
+    cu = torch.device('cuda', 0)
+    aggregated_arcs = ops.aggregate(arcnode.device_csr(cu), arcs[:, 2:].contiguous())
+    if d > 0:
+        state = dev(rng.normal(0, 0.1, (N, d)).astype(np.float32)); aggregated_nodes = ops.aggregate(adjacency.device_csr(cu), nodes)
+    else:
+        state = nodes.clone(); aggregated_nodes = torch.zeros((N, 0), device='cuda')
+    moving_before = [a.copy() for a in ns.get_weights()[2:4]]
+    out = model.convergence(torch.zeros((), device='cuda'), state, torch.ones_like(state), nodes, adjacency, aggregated_nodes,
+                            aggregated_arcs, True)
+    assert len(out) == 8 and float(out[0]) == 1.0 and out[2] is state and out[7] is True
+    new = out[1].cpu().numpy()
+    assert new.shape == (N, d if d else 14) and np.all(np.isfinite(new))
+    f64 = np.float64
+    spec, weights = ns.spec()
+    agg_state = O.sparse_dense_matmul_adjoint(*_triple(x[5]), _np(state).astype(f64), f64)
+    comps = [_np(state).astype(f64)] + ([_np(nodes).astype(f64)] if d > 0 else []) + [agg_state, _np(aggregated_nodes).astype(f64), _np(aggregated_arcs).astype(f64)]
+    inp_state = np.concatenate(comps, axis=1)
+    moving_after = ns.get_weights()[2:4]
+    mean, var = inp_state.mean(0), inp_state.var(0)
+    assert rel_err(moving_after[0], 0.99 * moving_before[0] + 0.01 * mean) <= TOL
+    assert rel_err(moving_after[1], 0.99 * moving_before[1] + 0.01 * var) <= TOL
+    if not dropout:
+        want = O.convergence(_np(state).astype(f64), _np(nodes).astype(f64), _triple(x[5]), _np(aggregated_nodes).astype(f64),
+                             _np(aggregated_arcs).astype(f64), (spec, weights), d, True, f64)
+        # (training mode ignores the moving statistics: the weights list after the call serves)
+        assert rel_err(new, want) <= 2e-5, rel_err(new, want)
+        # Sequential.__call__(x, training=True) on the materialised concatenation: the same numbers
+        again = ns(dev(inp_state.astype(np.float32)), training=True).cpu().numpy()
+        assert rel_err(again, want) <= 2e-5
+        # and the inference call afterwards uses the moved statistics (Keras semantics)
+        inf = ns(dev(inp_state.astype(np.float32))).cpu().numpy()
+        assert rel_err(inf, O.mlp_apply(spec, ns.get_weights(), inp_state, False, f64)) <= 2e-5
+    else:
+        out2 = model.convergence(torch.zeros((), device='cuda'), state, torch.ones_like(state), nodes, adjacency, aggregated_nodes,
+                                 aggregated_arcs, True)
+        assert not torch.equal(out[1], out2[1])                           # a fresh mask per call, as Keras draws one
+        a = ns(state.new_ones((7, ns.input_dim)), training=True, seed=3); b = ns(state.new_ones((7, ns.input_dim)), training=True, seed=3)
+        assert torch.equal(a, b)
+
+
+def test_composite_convergence_in_training_mode_matches_the_oracle():
+    """Composite `convergence(..., training=True)` (reference CompositeGNN.py:226: per-type `net(inp_state_i, training=training)` on
+    the boolean-masked rows): every type's BatchNormalization sees the statistics of ITS rows."""
+    N, d, dims = 2500, 12, (5, 3, 2)
+    g = er_composite_graph(N, 5 * N, dim_node_label=dims, aggregation_mode='average', seed=3)
+    x = CompositeMultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    inp, lay = get_inout_dims('state', dims, 3, 2, 'n', d)
+    ns = [MLP(i, lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=t, batch_normalization=True, device='cuda') for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', dims, 3, 2, 'n', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9)
+    model = CompositeGNNnodeBased(ns, no, d, 3, 0.0)
+    (nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, cas, adjacency, arcnode, nodegraph) = model.process_inputs(x)
+    cu = torch.device('cuda', 0)
+    parts = [ops.aggregate(c.device_csr(cu), nodes[:, :dd].contiguous()) for c, dd in zip(cas, dims)]
+    parts.append(ops.aggregate(arcnode.device_csr(cu), arcs[:, 2:].contiguous()))
+    comp = torch.cat(parts, dim=1)
+    state = dev(np.random.default_rng(2).normal(0, 0.1, (N, d)).astype(np.float32))
+    specs = [n.spec() for n in ns]
+    out = model.convergence(0.0, state, None, nodes, dim_node_label, type_mask, adjacency, comp, True)
+    f64 = np.float64
+    tm = _np(x[3]); tm = tm.reshape(tm.shape[0], -1)
+    want = O.composite_convergence(_np(state).astype(f64), _np(nodes).astype(f64), list(dims), tm, _triple(x[7]), _np(comp).astype(f64), specs, True, f64)
+    assert len(out) == 9 and rel_err(out[1].cpu().numpy(), want) <= 2e-5, rel_err(out[1].cpu().numpy(), want)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# gnn_dense: bias AND addend on the wide row-streaming kernel
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,K,H', [(40_000, 96, 128), (32_768, 64, 200), (1000, 96, 128), (40_000, 48, 64)])
+def test_dense_with_bias_and_addend(M, K, H):
+    """Y = act(X . W + bias + addend) (kernels_general.hpp: both are added) whatever kernel the shape selects: k_rowdense_wide from
+    32 768 rows and more than 64 output columns (it dropped the bias when an addend was present), k_segdense otherwise."""
+    rng = np.random.default_rng(M + H)
+    x = dev(rng.normal(0, 1, (M, K)).astype(np.float32)); W = dev(rng.normal(0, 0.2, (K, H)).astype(np.float32))
+    b = dev(rng.normal(0, 0.5, H).astype(np.float32)); add = dev(rng.normal(0, 0.5, (M, H)).astype(np.float32))
+    Y = torch.full((M, H), float('nan'), device='cuda')
+    a = nat.DenseArgs()
+    a.M, a.H, a.n_segments = M, H, 1
+    a.seg_ptr[0], a.seg_rowidx[0], a.seg_ld[0], a.seg_width[0], a.seg_wrow[0] = x.data_ptr(), None, K, K, 0
+    a.W, a.ldw, a.bias = W.data_ptr(), H, b.data_ptr()
+    a.addend, a.ld_addend, a.addend_rowidx = add.data_ptr(), H, None
+    a.activation = nat.ACTIVATIONS['tanh']
+    a.Y, a.ldy, a.out_rowidx, a.gate, a.stream = Y.data_ptr(), H, None, None, None
+    torch.cuda.synchronize()
+    nat.check(nat.lib().gnn_dense(C.byref(a)))
+    torch.cuda.synchronize()
+    want = torch.tanh(x.double() @ W.double() + b.double() + add.double())
+    assert float((Y.double() - want).abs().max() / want.abs().max()) <= TOL

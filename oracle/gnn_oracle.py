@@ -65,7 +65,8 @@ def sparse_dense_matmul_adjoint(indices, values, dense_shape, B, dtype, exact_or
     return out
 
 
-_SCIPY_CACHE = []          # [(key, indices, values, At)]: the loop hands the SAME adjacency buffers to every iteration
+import threading
+_SCIPY_TLS = threading.local()    # per thread: [(key, indices, values, At)] - the loop hands the SAME adjacency buffers to every iteration
 
 
 def _scipy_adjoint(indices, values, n_rows, n_cols, dtype):
@@ -74,11 +75,12 @@ def _scipy_adjoint(indices, values, n_rows, n_cols, dtype):
     arrays are kept referenced so that an address cannot be reused while its entry lives."""
     from scipy.sparse import csr_matrix
     key = (indices.__array_interface__['data'][0], values.__array_interface__['data'][0], len(values), np.dtype(dtype).str, n_rows, n_cols)
-    for k_, _i, _v, At in _SCIPY_CACHE:
+    cache = _SCIPY_TLS.__dict__.setdefault('cache', [])
+    for k_, _i, _v, At in cache:
         if k_ == key: return At
     At = csr_matrix((values, (indices[:, 1], indices[:, 0])), shape=(n_cols, n_rows), dtype=dtype)
-    _SCIPY_CACHE.append((key, indices, values, At))
-    if len(_SCIPY_CACHE) > 4: _SCIPY_CACHE.pop(0)
+    cache.append((key, indices, values, At))
+    if len(cache) > 4: cache.pop(0)
     return At
 
 

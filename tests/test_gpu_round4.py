@@ -49,21 +49,82 @@ def _starter(focus, d, **kw):
 # ----------------------------------------------------------------------------------------------------------------------
 # parity at the timed depth (k = 50)
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('mode', ['average', 'sum'])
-def test_c3_at_the_timed_depth_every_path(mode):
-    """BASELINE C3 (100 k nodes / 1 M arcs, d = 64) for the 50 iterations the bench times, every way the iteration can run,
-    against the float32 AND the float64 oracle (scipy row order).  Prints the worst relative error of the configuration and the
-    distance of the two oracles from each other (what float32 itself loses over 50 iterations)."""
-    N, E, d, K = 100_000, 1_000_000, 64, 50
+# The float64 oracle needs 25 s (C3) to 2 min (C4) for 50 iterations, most of it single-threaded NumPy: the deep tests' oracle runs
+# (graph build included) are started TOGETHER on worker threads by whichever deep test runs first - NumPy / SciPy / BLAS release
+# the GIL - so the suite pays the longest of them once instead of their sum.
+_DEEP_K = 50
+_DEEP_FUTURES = {}
+
+
+def _deep_c3(mode):
+    N, E, d = 100_000, 1_000_000, 64
     g = er_graph(N, E, aggregation_mode=mode)
     x = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
     ns, no = _starter('n', d, scale=1.0 if mode == 'average' else 0.1)
     s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
-    model = GNNnodeBased(ns, no, d, K, 0.0)
+    model = GNNnodeBased(ns, no, d, _DEEP_K, 0.0)
     t0 = time.time()
-    k32, st32, o32 = oracle_loop(model, x, s0, np.float32, exact_order=False)
-    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
-    t_oracle = time.time() - t0
+    r32 = oracle_loop(model, x, s0, np.float32, exact_order=False)
+    r64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    return dict(x=x, model=model, s0=s0, r32=r32, r64=r64, t=time.time() - t0)
+
+
+def _deep_c4():
+    N, E, d = 1_000_000, 10_000_000, 64
+    g = er_graph(N, E, aggregation_mode='average')
+    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    ns, no = _starter('n', d)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
+    model = GNNnodeBased(ns, no, d, _DEEP_K, 0.0)
+    t0 = time.time()
+    r64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    return dict(x=x, model=model, s0=s0, r64=r64, t=time.time() - t0)
+
+
+def _deep_c5(mode):
+    N, E, d, dims = 500_000, 5_000_000, 64, (14, 8, 4)
+    g = er_composite_graph(N, E, dim_node_label=dims, aggregation_mode=mode, seed=1234)
+    x = CompositeMultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    inp, lay = get_inout_dims('state', dims, 3, 2, 'n', d)
+    ns = [MLP(i, lay, 'selu', 'lecun_normal', 'lecun_normal', rng=t) for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', dims, 3, 2, 'n', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
+    model = CompositeGNNnodeBased(ns, no, d, _DEEP_K, 0.0)
+    t0 = time.time()
+    r64 = oracle_composite_loop(model, x, s0, np.float64, exact_order=False)
+    r32 = oracle_composite_loop(model, x, s0, np.float32, exact_order=False)
+    return dict(x=x, model=model, s0=s0, r32=r32, r64=r64, t=time.time() - t0)
+
+
+_DEEP_JOBS = {'test_c3_at_the_timed_depth_every_path[average]': lambda: _deep_c3('average'),
+              'test_c3_at_the_timed_depth_every_path[sum]': lambda: _deep_c3('sum'),
+              'test_c4_at_the_timed_depth_vs_fp64_oracle': _deep_c4,
+              'test_c5_at_the_timed_depth_vs_fp64_oracle[average]': lambda: _deep_c5('average'),
+              'test_c5_at_the_timed_depth_vs_fp64_oracle[composite_average]': lambda: _deep_c5('composite_average')}
+
+
+def _deep(request):
+    """The oracle results of the calling deep test; the first call starts the jobs of every SELECTED deep test."""
+    if not _DEEP_FUTURES:
+        from concurrent.futures import ThreadPoolExecutor
+        torch.cuda.init()
+        pool = ThreadPoolExecutor(max_workers=len(_DEEP_JOBS))
+        selected = {it.name for it in request.session.items}
+        for name in sorted(_DEEP_JOBS, key=lambda n: 'c4' not in n):          # the longest first
+            if name in selected: _DEEP_FUTURES[name] = pool.submit(_DEEP_JOBS[name])
+        pool.shutdown(wait=False)
+    return _DEEP_FUTURES.pop(request.node.name).result()
+
+
+@pytest.mark.parametrize('mode', ['average', 'sum'])
+def test_c3_at_the_timed_depth_every_path(request, mode):
+    """BASELINE C3 (100 k nodes / 1 M arcs, d = 64) for the 50 iterations the bench times, every way the iteration can run,
+    against the float32 AND the float64 oracle (scipy row order).  Prints the worst relative error of the configuration and the
+    distance of the two oracles from each other (what float32 itself loses over 50 iterations)."""
+    r = _deep(request)
+    model, x, s0, K = r['model'], r['x'], r['s0'], _DEEP_K
+    (k32, st32, o32), (k64, st64, o64) = r['r32'], r['r64']
     assert float(k32) == float(k64) == K
     inputs = model.process_inputs(x)
     worst, kernels = {}, {}
@@ -75,7 +136,7 @@ def test_c3_at_the_timed_depth_every_path(mode):
         st, o = st.cpu().numpy(), o.cpu().numpy()
         assert np.all(np.isfinite(st)) and np.all(np.isfinite(o))
         worst[flags] = (rel_err(st, st32), rel_err(st, st64), rel_err(o, o32), rel_err(o, o64))
-    print(f'\nC3 {mode} k={K}: oracle fp32 vs fp64 state {rel_err(st32, st64):.2e} out {rel_err(o32, o64):.2e} (oracles {t_oracle:.0f} s); '
+    print(f'\nC3 {mode} k={K}: oracle fp32 vs fp64 state {rel_err(st32, st64):.2e} out {rel_err(o32, o64):.2e} (oracles {r["t"]:.0f} s); '
           f'device (state vs fp32, state vs fp64, out vs fp32, out vs fp64) per path: '
           + '; '.join(f'{kernels[f].split("<")[0]}[{f}] ' + ' '.join(f'{v:.1e}' for v in worst[f]) for f in PATHS)
           + f'; worst {max(max(v) for v in worst.values()):.2e}')
@@ -83,18 +144,12 @@ def test_c3_at_the_timed_depth_every_path(mode):
         assert max(worst[flags]) <= TOL, (flags, kernels[flags], worst[flags])
 
 
-def test_c4_at_the_timed_depth_vs_fp64_oracle():
+def test_c4_at_the_timed_depth_vs_fp64_oracle(request):
     """BASELINE C4 (1 M nodes / 10 M arcs, d = 64): the 50 iterations of the bench line on the default path (the wave-specialised
     kernel with the constant inputs multiplied in) and the un-fused kernels against the float64 oracle (scipy row order)."""
-    N, E, d, K = 1_000_000, 10_000_000, 64, 50
-    g = er_graph(N, E, aggregation_mode='average')
-    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
-    ns, no = _starter('n', d)
-    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
-    model = GNNnodeBased(ns, no, d, K, 0.0)
-    t0 = time.time()
-    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
-    t_oracle = time.time() - t0
+    r = _deep(request)
+    model, x, s0, K = r['model'], r['x'], r['s0'], _DEEP_K
+    k64, st64, o64 = r['r64']
     assert float(k64) == K
     inputs = model.process_inputs(x)
     res = {}
@@ -104,28 +159,25 @@ def test_c4_at_the_timed_depth_vs_fp64_oracle():
         assert float(k) == K
         if flags == 0: assert _last_kernel().startswith('k_state_fused4<64'), _last_kernel()
         res[flags] = (rel_err(st.cpu().numpy(), st64), rel_err(o.cpu().numpy(), o64))
-    print(f'\nC4 k={K} vs fp64 oracle ({t_oracle:.0f} s): default state {res[0][0]:.2e} out {res[0][1]:.2e}; '
-          f'un-fused state {res[nat.FLAG_UNFUSED][0]:.2e} out {res[nat.FLAG_UNFUSED][1]:.2e}')
+    print(f'\nC4 k={K} vs fp64 oracle ({r["t"]:.0f} s): default state {res[0][0]:.2e} out {res[0][1]:.2e}; '
+          f'un-fused state {res[nat.FLAG_UNFUSED][0]:.2e} out {res[nat.FLAG_UNFUSED][1]:.2e}; max|state| {np.abs(st64).max():.2f}')
     for flags, e in res.items(): assert max(e) <= TOL, (flags, e)
 
 
 @pytest.mark.parametrize('mode', ['average', 'composite_average'])
-def test_c5_at_the_timed_depth_vs_fp64_oracle(mode):
+def test_c5_at_the_timed_depth_vs_fp64_oracle(request, mode):
     """BASELINE C5 (3 node types, 500 k nodes / 5 M arcs, d = 64, per-type state networks): 50 iterations on the default path and
-    the un-fused kernels against the float64 oracle (reference CompositeGNN.py:242-272)."""
-    N, E, d, dims, K = 500_000, 5_000_000, 64, (14, 8, 4), 50
-    g = er_composite_graph(N, E, dim_node_label=dims, aggregation_mode=mode, seed=1234)
-    x = CompositeMultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
-    inp, lay = get_inout_dims('state', dims, 3, 2, 'n', d)
-    ns = [MLP(i, lay, 'selu', 'lecun_normal', 'lecun_normal', rng=t) for t, i in enumerate(inp)]
-    inp, lay = get_inout_dims('output', dims, 3, 2, 'n', d)
-    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9)
-    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
-    model = CompositeGNNnodeBased(ns, no, d, K, 0.0)
-    t0 = time.time()
-    k64, st64, o64 = oracle_composite_loop(model, x, s0, np.float64, exact_order=False)
-    t_oracle = time.time() - t0
-    assert float(k64) == K
+    the un-fused kernels against the float64 oracle (reference CompositeGNN.py:242-272).
+
+    SURVEY H4 in the open: the starter networks are not contractive, and with 'composite_average' aggregation 50 iterations of
+    them amplify float32 rounding beyond 1e-5 in the OUTPUT - for the reference's own float32 arithmetic as much as for the device
+    (the float32 oracle's distance from the float64 one is printed and bounds the assertion; measured on MI355X: state 4.2e-6 on the
+    device, output 4.7e-5 default / 5.7e-5 un-fused).  The state stays inside 1e-5 in both modes, the output in 'average' mode too."""
+    r = _deep(request)
+    model, x, s0, K = r['model'], r['x'], r['s0'], _DEEP_K
+    (k32, st32, o32), (k64, st64, o64) = r['r32'], r['r64']
+    assert float(k64) == float(k32) == K
+    ref_st, ref_o = rel_err(st32, st64), rel_err(o32, o64)          # what float32 itself loses: the reference's arithmetic against float64
     inputs = model.process_inputs(x)
     res = {}
     for flags in (0, nat.FLAG_UNFUSED):
@@ -133,9 +185,13 @@ def test_c5_at_the_timed_depth_vs_fp64_oracle(mode):
         k, st, o = model.Loop(*inputs, state0=dev(s0))
         assert float(k) == K
         res[flags] = (rel_err(st.cpu().numpy(), st64), rel_err(o.cpu().numpy(), o64))
-    print(f'\nC5 {mode} k={K} vs fp64 oracle ({t_oracle:.0f} s): default state {res[0][0]:.2e} out {res[0][1]:.2e}; '
-          f'un-fused state {res[nat.FLAG_UNFUSED][0]:.2e} out {res[nat.FLAG_UNFUSED][1]:.2e}')
-    for flags, e in res.items(): assert max(e) <= TOL, (flags, e)
+    print(f'\nC5 {mode} k={K} vs fp64 oracle ({r["t"]:.0f} s): default state {res[0][0]:.2e} out {res[0][1]:.2e}; '
+          f'un-fused state {res[nat.FLAG_UNFUSED][0]:.2e} out {res[nat.FLAG_UNFUSED][1]:.2e}; float32 oracle vs float64 oracle: '
+          f'state {ref_st:.2e} out {ref_o:.2e}; max|state| {np.abs(st64).max():.2f}')
+    for flags, (es, eo) in res.items():
+        assert es <= max(TOL, 2 * ref_st), (flags, es, ref_st)
+        assert eo <= max(TOL, 2 * ref_o), (flags, eo, ref_o)
+        if mode == 'average': assert max(es, eo) <= TOL
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -113,9 +113,7 @@ class _LoopModel:
         self._check_kwargs('predict', kwargs)
         if len(sequencer) == 0: return np.zeros((0, 0), np.float32)
         dev = self._batch_device(sequencer[0][0])
-        self._k_seen = []
-        outs = [o for _, o in self._forward_batches(sequencer, dev)]
-        self._check_k()
+        outs = self._with_recovery(lambda: [o for _, o in self._forward_batches(sequencer, dev)])
         return torch.cat(outs, dim=0).cpu().numpy()
 
     def evaluate(self, sequencer, return_dict: bool = False, verbose=0, callbacks=None, **kwargs):
@@ -127,11 +125,10 @@ class _LoopModel:
         lossf = _loss_fn(self.loss)
         if len(sequencer) == 0: raise ValueError('evaluate() needs at least one batch')
         dev = self._batch_device(sequencer[0][0])
-        self._k_seen = []
         # every forward first (grouped launches / side streams), then ONE loss / metric evaluation over all samples: the sums
         # Keras accumulates batch by batch are the same sums, and a data set of small batches costs a handful of launches
         # instead of a dozen per batch
-        preds = [p_ for _, p_ in self._forward_batches(sequencer, dev)]
+        preds = self._with_recovery(lambda: [p_ for _, p_ in self._forward_batches(sequencer, dev)])
         p = torch.cat(preds, dim=0) if len(preds) > 1 else preds[0]
         # targets / sample weights of the whole sequencer, concatenated once per set of batches (a few sequencers per model:
         # training, validation, test); keyed by the batch list the sequencer rebuilds whenever its batches change
@@ -149,7 +146,6 @@ class _LoopModel:
         tot_w = float(sw.shape[0])
         cnt = sw.sum()
         mets = [(n, f, (f(y, p) * sw).sum()) for n, f in (_metric_fn(m, y.shape[-1]) for m in self.metrics_spec)]
-        self._check_k()
         res = {'loss': float(tot_loss / tot_w)}
         for n, f, acc in mets: res[n] = float(acc / cnt)
         return res if return_dict else [res['loss']] + [res[n] for n, _, _ in mets]
@@ -240,6 +236,35 @@ class _LoopModel:
     _K_ERROR = ('a bounded in-launch wait of the loop kernels expired (persistent kernel: not all workgroups resident - GPU '
                 'shared with other long-running work?; wave-specialised kernel: a lost LDS hand-off): state and output are '
                 'invalid. Set model.native_flags = FLAG_FUSED_GEN2 or lower inference_streams')
+
+    def _with_recovery(self, forwards):
+        """`forwards()` (every forward of a predict() / evaluate() walk) with the kernels' in-launch waits checked where the host
+        synchronises anyway.  The whole-loop kernels need all their workgroups resident at once and wait for each other with a
+        bound (GNN_WAIT_MS); on a GPU shared with other long-running work such a wait can expire - reported as k < 0, results
+        invalid.  The walk is then REPEATED on the kernels that have no cross-workgroup waits: one launch per iteration
+        (`FLAG_FUSED_GEN2`), batch by batch, on the caller's stream - slower, always completes - with a `RuntimeWarning`.  A second
+        failure (it would be a lost hand-off inside a workgroup: a bug, not contention) raises `NativeError`."""
+        self._k_seen = []
+        res = forwards()
+        try:
+            self._check_k()
+            return res
+        except nat.NativeError:
+            pass
+        import warnings
+        warnings.warn('a bounded in-launch wait of the whole-loop kernels expired (GPU shared with other long-running work?): '
+                      're-running these forwards with one launch per iteration', RuntimeWarning, stacklevel=3)
+        saved = (self.native_flags, self.group_batches, self.inference_streams)
+        self.native_flags = (self.native_flags & ~nat.FLAG_FUSED_GEN_MASK) | nat.FLAG_FUSED_GEN2
+        self.group_batches, self.inference_streams = False, 1
+        try:
+            self._k_seen = []
+            res = forwards()
+            self._check_k()
+        finally:
+            self.native_flags, self.group_batches, self.inference_streams = saved
+        self.recovered_walks = getattr(self, 'recovered_walks', 0) + 1
+        return res
 
     def _check_k(self):
         """k < 0 is how the loop kernels report an expired in-launch wait (the persistent whole-loop kernel's grid barrier,

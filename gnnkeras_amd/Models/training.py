@@ -901,7 +901,18 @@ class LoopTrainer:
         that type's rows through the general path below."""
         m = self.model
         if self._native_step_applies(y):
-            return self._train_step_native(x_list, y, sample_weight, state0, seed, apply)
+            try:
+                return self._train_step_native(x_list, y, sample_weight, state0, seed, apply)
+            except nat.NativeError as e:
+                # the persistent forward kernel's grid barrier expired (GPU shared with other long-running work: not all of its
+                # workgroups resident within GNN_WAIT_MS).  The in-library step checks that right behind the forward loop - before the
+                # moving statistics, the gradients or the weights are touched - so the step is simply run again on the building
+                # blocks below, which have no cross-workgroup waits.
+                if 'grid barrier' not in str(e) and 'cannot be resident' not in str(e): raise
+                import warnings
+                warnings.warn('the persistent training kernels could not keep their workgroups resident (GPU shared with other '
+                              'long-running work?): this step runs on the general kernels', RuntimeWarning, stacklevel=3)
+                self.recovered_steps = getattr(self, 'recovered_steps', 0) + 1
         tp = self.forward(x_list, state0=state0, seed=seed)
         res = {'k': tp.k, 'y_pred': tp.y_pred, 'state': tp.state}
         if y is None:

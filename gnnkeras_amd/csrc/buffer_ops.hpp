@@ -7,6 +7,9 @@
 //     CU's L1 (inter-workgroup hand-off inside a launch, kernel_state_small.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
 #include "kernels_general.hpp"
 
 namespace gnn {
@@ -38,6 +41,48 @@ __device__ __forceinline__ f32x4 buf_ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned o
 __device__ __forceinline__ void buf_st_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 x) {
     const u32x4 v = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 16);
+}
+
+// Bounded wait of ONE lane on a word another workgroup of the same launch will write (grid barriers of the whole-loop kernels, set
+// barriers of the one-CU-per-group kernel).  The bound is WALL-CLOCK time (wall_clock64: s_memrealtime, 100 MHz, the same base on
+// every CU), not a poll count: a persistent launch whose grid fits the GPU (checked at launch, persistent_fits() in gnnloop.hip)
+// becomes fully resident as soon as whatever else runs on the GPU lets go of the CUs it needs, so the wait only has to outlast a
+// co-tenant - `budget_ticks` comes from GNN_WAIT_MS (default 2 000 ms; the old bound of 2^22 polls was ~0.4 s) - while a protocol
+// bug or a launch that can never be resident still ends, loudly (k < 0), instead of hanging the GPU.  budget_ticks == 0 (GNN_WAIT_MS=0)
+// makes every wait expire at once, satisfied or not: the test hook that drives the callers' recovery paths.
+template <typename Done>
+__device__ __forceinline__ bool wait_until(unsigned long long budget_ticks, Done done) {
+    if (budget_ticks == 0) return false;
+    const unsigned long long t0 = wall_clock64();
+    for (int spin = 0;; ++spin) {
+        if (done()) return true;
+        if ((spin & 63) == 63 && wall_clock64() - t0 > budget_ticks) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// ---- host side of the same contract -----------------------------------------------------------------------------------------------
+// GNN_WAIT_MS -> ticks of the 100 MHz wall clock (default 2 000 ms; 0 = every wait expires at once, the recovery paths' test hook)
+inline unsigned long long wait_ticks() {
+    static long long v = -1;
+    if (v < 0) { const char *e = getenv("GNN_WAIT_MS"); const long long ms = e ? atoll(e) : 2000; v = (ms < 0 ? 0 : ms) * 100000ll; }
+    return (unsigned long long)v;
+}
+
+// Can `grid` workgroups of this kernel be resident AT ONCE on the device (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs)?  A
+// launch whose workgroups wait for each other must not be larger than that, or its first barrier can never complete; asked once per
+// (kernel, block size, dynamic LDS) and remembered.
+inline bool persistent_fits(const void *fn, int threads, size_t lds, int grid, int n_cu) {
+    struct Key { const void *fn; int threads; size_t lds; int per_cu; };
+    static std::vector<Key> seen;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Key &k : seen)
+        if (k.fn == fn && k.threads == threads && k.lds == lds) return (long)k.per_cu * n_cu >= grid;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    seen.push_back(Key{fn, threads, lds, per_cu});
+    return (long)per_cu * n_cu >= grid;
 }
 
 }  // namespace gnn

@@ -1501,6 +1501,26 @@ __global__ void k_or_flags(const int *gate, int n_gate, int gate_stride, int *ou
     if (threadIdx.x == 0) *out = v;
 }
 
+// Test hook (tests/test_gpu_round4.py): `n_workgroups` workgroups that each hold `lds_bytes` of LDS (160 KB = a whole CU) and one
+// wave, doing nothing until `milliseconds` of wall-clock time have passed - a co-tenant that keeps CUs away from the persistent
+// kernels.  Bounded by construction (the 100 MHz wall clock), so it cannot hang the GPU.
+__global__ void __launch_bounds__(64) k_debug_occupy(unsigned long long ticks, int *sink) {
+    extern __shared__ int occ_smem[];
+    const unsigned long long t0 = wall_clock64();
+    int polls = 0;
+    while (wall_clock64() - t0 < ticks) { __builtin_amdgcn_s_sleep(64); ++polls; }
+    if (threadIdx.x == 0 && polls < 0) { occ_smem[0] = polls; *sink = occ_smem[0]; }      // (keeps the LDS allocation alive; never taken)
+}
+
+int gnn_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t milliseconds, void *stream) {
+    if (n_workgroups < 1 || lds_bytes < 0 || lds_bytes > 160 * 1024 || milliseconds < 0 || milliseconds > 10000) return fail("gnn_debug_occupy: bad arguments");
+    static bool attr = false;
+    if (!attr) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_debug_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    k_debug_occupy<<<n_workgroups, 64, (size_t)lds_bytes, (hipStream_t)stream>>>((unsigned long long)milliseconds * 100000ull, nullptr);
+    LAUNCH_OK();
+    return 0;
+}
+
 int32_t gnn_state_ld(int32_t state_width) { return state_width > 0 ? state_ld(state_width) : 0; }
 
 int gnn_gather_rows(const float *src, int32_t ld_src, const int32_t *idx, int32_t M, int32_t width, float *dst,

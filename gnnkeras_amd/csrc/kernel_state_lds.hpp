@@ -53,6 +53,7 @@ struct LdsArgs {
     // group sets (gnn_loop_args_t::group_set_begin): the groups [set_first[g], set_first[g] + set_size[g]) share the loop's condition
     const int *set_first, *set_size;        // device [n_groups]
     unsigned long long *set_bar;            // [2 * n_groups], zero before the launch; NULL: every group on its own
+    unsigned long long wait_ticks;          // bound of a set-barrier wait (buffer_ops.hpp: wait_until)
 };
 
 // Sum over the 16 lanes of a DPP row, complete in lane 15 of the row (row_shr 1, 2, 4, 8 with out-of-row reads as zero): four
@@ -286,13 +287,8 @@ __global__ void __launch_bounds__(64 * LDS_NW, 4) k_state_lds(LdsArgs a) {
                 __hip_atomic_fetch_add(ctr, 1ull + ((unsigned long long)(moving_s[mv_slot] ? 1u : 0u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned target = (unsigned)(it / 2 + 1) * (unsigned)set_n;
                 unsigned long long v = 0;
-                int spin = 0;
-                for (; spin < (1 << 22); ++spin) {
-                    v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)v >= target) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (spin == (1 << 22)) timed_out = 1;                          // a member never arrived (not resident?): reported through k
+                if (!wait_until(a.wait_ticks, [&]() { v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (unsigned)v >= target; }))
+                    timed_out = 1;                                             // a member never arrived (not resident?): reported through k
                 const unsigned moved = (unsigned)(v >> 32);
                 set_go = (moved != moved_seen[it & 1]) ? 1 : 0;
                 moved_seen[it & 1] = moved;
@@ -314,11 +310,18 @@ inline bool lds_group_fits(int n_nodes, int SP) { return lds_state_bytes(n_nodes
 inline bool lds_group_fits_twice(int n_nodes, int SP) { return lds_state_bytes(n_nodes, SP, true) <= LDS_BUDGET_BYTES; }
 
 template <int SP, bool HAS_W, bool DB>
-int launch_lds_one(const LdsArgs &la, int n_groups, size_t lds_bytes, hipStream_t st) {
+int launch_lds_one(const LdsArgs &la_in, int n_groups, size_t lds_bytes, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void *)k_state_lds<SP, HAS_W, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET_BYTES) != hipSuccess) return 1;
         attr = true;
+    }
+    LdsArgs la = la_in;
+    la.wait_ticks = wait_ticks();
+    if (la.set_bar) {            // groups of a set wait for each other: every workgroup of the launch must be resident at once
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
+        if (!persistent_fits((const void *)k_state_lds<SP, HAS_W, DB>, 64 * LDS_NW, lds_bytes, n_groups, n_cu)) return 2;
     }
     GNN_SET_KERNEL_NAME("k_state_lds<%d,%s,%s>", SP, HAS_W ? "true" : "false", DB ? "true" : "false");
     k_state_lds<SP, HAS_W, DB><<<n_groups, 64 * LDS_NW, lds_bytes, st>>>(la);

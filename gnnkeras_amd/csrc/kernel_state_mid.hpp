@@ -314,14 +314,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) k_state_mid(SmallArg
             if (!released) {
                 const unsigned *rel = release + (size_t)grp * MID_LINE;
                 unsigned w = 0;
-                int spin = 0;
-                for (; spin < (1 << 22); ++spin) {
-                    w = __hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((w >> 1) == gen) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
+                const bool arrived = wait_until(sa.wait_ticks, [&]() { w = __hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (w >> 1) == gen; });
                 *cont = (int)(w & 1u);
-                if (spin == (1 << 22)) { timed_out = 1; *cont = -1; }   // some workgroup never arrived (not resident?): reported through k
+                if (!arrived) { timed_out = 1; *cont = -1; }            // some workgroup never arrived (not resident?): reported through k
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // no instruction: keeps the loads below the poll
         }
@@ -362,6 +357,8 @@ int launch_mid_one(SmallArgs &sa, int n_cu, hipStream_t st) {
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0 || grid > budget) return 2;
+    if (!persistent_fits((const void *)k_state_mid<SP, HAS_W, NW, DEPTH>, Cfg::NT, LDS, grid, n_cu)) return 2;      // (its grid barrier needs every workgroup resident)
+    sa.wait_ticks = wait_ticks();
     GNN_SET_KERNEL_NAME("k_state_mid<%d,%s,%d,%d>", SP, HAS_W ? "true" : "false", NW, DEPTH);
     k_state_mid<SP, HAS_W, NW, DEPTH><<<grid, Cfg::NT, LDS, st>>>(sa);
     return hipGetLastError() == hipSuccess ? 0 : 1;

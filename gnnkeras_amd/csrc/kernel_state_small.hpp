@@ -39,6 +39,7 @@ struct SmallArgs {
                              // two arrival counters (bar + 2 * g), its own k (k_out[g]) and leaves the loop on its own
     unsigned long long *bar; // two arrival counters (even / odd iterations), zero before the launch:
                              // low word = arrivals, high word = workgroups that still saw a node move
+    unsigned long long wait_ticks;   // bound of a barrier wait (buffer_ops.hpp: wait_until)
 };
 
 constexpr int small_waves(int SP) { return SP == 16 ? 4 : 8; }   // 16-wide rows: 4 lanes per row, 256 threads cover a 64-node tile in one pass
@@ -310,13 +311,8 @@ __global__ void __launch_bounds__(64 * small_waves(SP), 2) k_state_small(SmallAr
             __hip_atomic_fetch_add(ctr, 1ull + ((unsigned long long)(any ? 1u : 0u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = (unsigned)(it / 2 + 1) * n_wg;
             unsigned long long v = 0;
-            int spin = 0;
-            for (; spin < (1 << 22); ++spin) {
-                v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)v >= target) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (spin == (1 << 22)) timed_out = 1;      // some workgroup never arrived (not resident?): reported through k
+            if (!wait_until(sa.wait_ticks, [&]() { v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (unsigned)v >= target; }))
+                timed_out = 1;                         // some workgroup never arrived (not resident?): reported through k
             const unsigned moved = (unsigned)(v >> 32);
             *cont = (moved != moved_seen[it & 1]) ? 1 : 0;
             moved_seen[it & 1] = moved;
@@ -373,6 +369,8 @@ int launch_small_one(SmallArgs &sa, int n_cu, hipStream_t st, int group_tiles) {
     const int grid = group_tiles > 0 ? group_tiles : fa.blk_begin[fa.n_types];   // with groups no tile straddles a group
     if (group_tiles > 0) fa.blk_begin[1] = group_tiles;
     if (grid == 0 || grid > n_cu) return 2;             // not applicable: the caller falls back to one launch per iteration
+    if (!persistent_fits((const void *)k_state_small<SP, HAS_W, L2>, Cfg::NT, SMALL_LDS, grid, n_cu)) return 2;     // (its grid barrier needs every workgroup resident)
+    sa.wait_ticks = wait_ticks();
     GNN_SET_KERNEL_NAME("k_state_small<%d,%s,%s>", SP, HAS_W ? "true" : "false", L2 ? "true" : "false");
     k_state_small<SP, HAS_W, L2><<<grid, Cfg::NT, SMALL_LDS, st>>>(sa);
     return hipGetLastError() == hipSuccess ? 0 : 1;

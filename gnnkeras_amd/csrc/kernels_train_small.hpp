@@ -59,6 +59,7 @@ struct GridBar {
     int bi;                       // barriers passed so far
     unsigned moved_seen0, moved_seen1;
     int timed_out;
+    unsigned long long wait_ticks;   // bound of a barrier wait (buffer_ops.hpp: wait_until)
 };
 __device__ __forceinline__ bool grid_barrier(GridBar &gb, int any, int *cont_lds) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's sc1 stores have left
@@ -68,13 +69,8 @@ __device__ __forceinline__ bool grid_barrier(GridBar &gb, int any, int *cont_lds
         __hip_atomic_fetch_add(ctr, 1ull + ((unsigned long long)(any ? 1u : 0u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (unsigned)(gb.bi / 2 + 1) * gb.n_wg;
         unsigned long long v = 0;
-        int spin = 0;
-        for (; spin < (1 << 22); ++spin) {
-            v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)v >= target) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (spin == (1 << 22)) gb.timed_out = 1;
+        if (!wait_until(gb.wait_ticks, [&]() { v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (unsigned)v >= target; }))
+            gb.timed_out = 1;
         const unsigned moved = (unsigned)(v >> 32);
         const bool odd = (gb.bi & 1) != 0;
         *cont_lds = (moved != (odd ? gb.moved_seen1 : gb.moved_seen0)) ? 1 : 0;
@@ -243,6 +239,7 @@ struct TrainSmallFwd {
     unsigned long long *bar;     // two arrival counters, zero
     float *part;                 // [2][n_wg][4 S] statistics partials (parity of the iteration)
     float *k_out;                // [0] = iterations executed (-1e9: a barrier timed out), [1] = 1 when an arc leaves its tile (LOCAL)
+    unsigned long long wait_ticks;   // bound of a barrier wait (buffer_ops.hpp: wait_until)
 };
 
 template <int SQ, bool HAS_W, bool LOCAL>
@@ -264,7 +261,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
     const int nt = LOCAL ? tt.begin[blockIdx.x + 1] - n0 : min(64, a.N - n0);
     const bool bn = a.gamma != nullptr;
     const size_t NS = (size_t)a.N * S;
-    GridBar gb{a.bar, gridDim.x, 0, 0u, 0u, 0};
+    GridBar gb{a.bar, gridDim.x, 0, 0u, 0u, 0, a.wait_ticks};
 
     for (int i = tid; i < 2 * S * S; i += TS_NT) {
         const int k = i / S, h = i % S;
@@ -468,6 +465,7 @@ struct TrainSmallBwd {
     float *partBN;               // [n_wg][2 in_s] every workgroup's share of d gamma | d beta (BatchNormalization)
     float inv_n;                 // 1 / N
     float *err;                  // [1] = 2 when a barrier timed out
+    unsigned long long wait_ticks;   // bound of a barrier wait (buffer_ops.hpp: wait_until)
 };
 
 template <int SQ, bool HAS_W, bool LOCAL>
@@ -497,7 +495,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
     const int nt = LOCAL ? tt.begin[blockIdx.x + 1] - n0 : min(64, a.N - n0);
     const bool bn = a.gamma != nullptr;
     const size_t NS = (size_t)a.N * S;
-    GridBar gb{a.bar, gridDim.x, 0, 0u, 0u, 0};
+    GridBar gb{a.bar, gridDim.x, 0, 0u, 0u, 0, a.wait_ticks};
     auto wrow_dyn = [&](int j) { return j < S ? j : a.off_agg + (j - S); };      // weight row / BatchNorm column of tile column j (valid j only)
     auto valid_dyn = [&](int j) { return (j < S ? j : j - S) < a.Sw; };           // pad columns of the padded state width carry zeros
 

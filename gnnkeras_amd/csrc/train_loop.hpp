@@ -488,6 +488,9 @@ int launch_persistent(Kern kern, const Args &args, const gnn::TileTab &tt, int n
             allowed.push_back(fn);
         }
     }
+    // every workgroup waits for the others at the grid barriers: the grid must fit the device (n_wg <= CUs by the plan; this asks the
+    // runtime about THIS kernel's registers / LDS)
+    if (!gnn::persistent_fits(fn, gnn::TS_NT, lds, n_wg, device_cus())) return fail("persistent training kernel: %d workgroups cannot be resident at once", n_wg);
     kern<<<n_wg, gnn::TS_NT, lds, st>>>(args, tt);
     LAUNCH_OK();
     return 0;
@@ -664,7 +667,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
         fa.states = p.states; fa.agg = p.agg; fa.stats = p.stats_s; fa.in_s = p.in_s; fa.off_agg = p.off_agg;
         fa.W = ns.kernel[0]; fa.gamma = bn_s ? ns.bn_gamma : nullptr; fa.beta = ns.bn_beta; fa.eps = ns.bn_eps; fa.act = ns.activation[0];
         fa.Cc = p.sm_cc; fa.thr = a.state_threshold; fa.flag0 = p.flags;
-        fa.bar = p.sm_bar; fa.part = p.sm_part; fa.k_out = p.k_dev;
+        fa.bar = p.sm_bar; fa.part = p.sm_part; fa.k_out = p.k_dev; fa.wait_ticks = gnn::wait_ticks();
         switch (p.SPs) {
             case 16: TRY(launch_train_small_fwd_sq<1>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st)); break;
             case 32: TRY(launch_train_small_fwd_sq<2>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st)); break;
@@ -794,7 +797,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
         ba.W = ns.kernel[0]; ba.gamma = bn_s ? ns.bn_gamma : nullptr; ba.beta = ns.bn_beta; ba.eps = ns.bn_eps; ba.act = ns.activation[0];
         ba.G0 = p.G_state; ba.dxa = p.dx_s_all; ba.bar = p.sm_bar + 2; ba.part = p.sm_part; ba.partW = p.sm_partW;
         ba.partBN = p.sm_partBN;
-        ba.inv_n = 1.0f / (float)p.N; ba.err = p.k_dev;
+        ba.inv_n = 1.0f / (float)p.N; ba.err = p.k_dev; ba.wait_ticks = gnn::wait_ticks();
         switch (p.SPs) {
             case 16: TRY(launch_train_small_bwd_sq<1>(ba, tiles, p.n_wg, ba.w_s != nullptr, st)); break;
             case 32: TRY(launch_train_small_bwd_sq<2>(ba, tiles, p.n_wg, ba.w_s != nullptr, st)); break;

@@ -228,6 +228,12 @@ int gnn_state_step(const gnn_loop_args_t *args, const float *state_in, float *st
 int gnn_state_step_agg(const gnn_loop_args_t *args, const float *state_in, const float *aggregated_nodes, int32_t ld_aggregated_nodes,
                        const float *aggregated_arcs, int32_t ld_aggregated_arcs, float *state_out, int32_t *flag_out);
 
+/* Testing aid, not part of the path: occupies the GPU the way a co-tenant would - `n_workgroups` workgroups of one wave holding
+ * `lds_bytes` of LDS each (163 840 = a whole CU) for `milliseconds` (<= 10 000) of wall-clock time on `stream`.  The whole-loop
+ * kernels wait for each other inside a launch; their waits are bounded by GNN_WAIT_MS (environment, default 2 000; 0 = expire at
+ * once) and an expired wait comes back as k < 0 (gnn_loop_args_t::k_out) - the recovery tests drive both with this. */
+int gnn_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t milliseconds, void *stream);
+
 /* ---- node-range sharded loop -------------------------------------------------------------------------
  * One process per GPU; rank r owns a contiguous node range and, per iteration, (1) runs gnn_shard_iteration on its
  * rows reading the full (all-gathered) state buffer and writing its own slice of the other full buffer, (2) the host

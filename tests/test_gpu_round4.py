@@ -505,3 +505,109 @@ def test_dense_with_bias_and_addend(M, K, H):
     torch.cuda.synchronize()
     want = torch.tanh(x.double() @ W.double() + b.double() + add.double())
     assert float((Y.double() - want).abs().max() / want.abs().max()) <= TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# residency of the whole-loop kernels: bounded waits, recovery, a co-tenant on the GPU
+# ----------------------------------------------------------------------------------------------------------------------
+def test_expired_barrier_waits_are_recovered_in_the_same_process():
+    """GNN_WAIT_MS=0 makes every cross-workgroup wait of the whole-loop kernels (k_state_small / _mid / _lds group sets, the
+    persistent training kernels) expire at once - what a GPU shared with long-running foreign work does to them.  Direct `Loop()`
+    callers see it loudly (k < 0, check_last_k() raises); predict() / evaluate() / train_step() must still return the RIGHT answer
+    by repeating the work on the kernels without such waits, with a RuntimeWarning.  Child process (the bound is read once)."""
+    import os, subprocess, sys
+    code = r"""
+import warnings, numpy as np, torch
+from gnnkeras_amd import _native as nat
+from gnnkeras_amd.load_MUTAG import load_graphs
+from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+from gnnkeras_amd.Models.GNN import GNNgraphBased
+from gnnkeras_amd.Models.training import LoopTrainer
+from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+graphs = load_graphs(limit=640)
+for g in graphs: g.setAggregation('average')
+seq = MultiGraphSequencer(graphs, 'g', 'average', 32, shuffle=False, device='cuda')
+d = 32
+inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d); ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=0, device='cuda')
+inp, lay = get_inout_dims('output', 14, 3, 2, 'g', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1, device='cuda')
+m = GNNgraphBased(ns, no, d, 12, 0.0)
+m.compile(optimizer='adam', loss='categorical_crossentropy', metrics=['accuracy'])
+torch.manual_seed(0)
+# what the per-iteration kernels give (no cross-workgroup waits: untouched by the bound)
+m.native_flags, m.group_batches, m.inference_streams = nat.FLAG_FUSED_GEN2, False, 1
+torch.manual_seed(0); want = m.predict(seq)
+torch.manual_seed(0); want_eval = m.evaluate(seq)
+m.native_flags, m.group_batches, m.inference_streams = 0, True, 8
+# a direct Loop() caller: loud
+x = seq[0][0]
+k, st, o = m.Loop(*m.process_inputs(x), state0=torch.zeros(x[0].shape[0], d, device='cuda'))
+assert nat.lib().gnn_last_kernel_name().decode().startswith('k_state_small'), nat.lib().gnn_last_kernel_name()
+assert float(k) < 0
+try: m.check_last_k()
+except nat.NativeError: pass
+else: raise SystemExit('check_last_k() did not raise')
+# predict / evaluate: recovered
+for fn, ref in ((m.predict, want), (m.evaluate, want_eval)):
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        torch.manual_seed(0); got = fn(seq)
+    assert any(issubclass(x_.category, RuntimeWarning) for x_ in w), [str(x_.message) for x_ in w]
+    assert np.array_equal(np.asarray(got), np.asarray(ref)), (got, ref)
+assert m.recovered_walks == 2 and m.native_flags == 0 and m.group_batches and m.inference_streams == 8
+# train_step: the in-library step's persistent forward fails before anything is modified; the step re-runs on the building blocks
+x, y, sw = seq[1]
+s0 = torch.randn(x[0].shape[0], d, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)) * 0.1
+w0 = [t.clone() for t in ns.weights + no.weights]
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    r1 = m.train_step((x, y, sw), state0=s0)
+assert any(issubclass(x_.category, RuntimeWarning) for x_ in w) and m._trainer.recovered_steps == 1
+w1 = [t.clone() for t in ns.weights + no.weights]
+for t, v in zip(ns.weights + no.weights, w0): t.copy_(v)
+m._opt_obj = None                                        # a fresh optimizer state for the reference step
+m._trainer = LoopTrainer(m); m._trainer.use_native_step = False
+r2 = m.train_step((x, y, sw), state0=s0)
+assert r1['k'] == r2['k'] and abs(float(r1['loss']) - float(r2['loss'])) <= 1e-6 * abs(float(r2['loss']))
+for a, b in zip(w1, ns.weights + no.weights): assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+print('RECOVERED_OK')
+"""
+    root = os.path.dirname(nat.HERE)
+    env = dict(os.environ, GNN_WAIT_MS='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and 'RECOVERED_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize('hold_ms', [600, 2600])
+def test_a_co_tenant_holding_most_cus_does_not_break_predict(mutag_graphs, hold_ms):
+    """A foreign kernel on a second stream keeps all but 6 CUs (their whole LDS) for `hold_ms`: the one-launch MUTAG walk (256 groups,
+    one CU each, group sets that wait for each other) cannot be resident at once while it runs.  600 ms: inside the wait bound
+    (GNN_WAIT_MS, 2 000 ms by default) - the launch simply completes once the CUs come back.  2 600 ms: past the bound - the waits
+    expire, predict() repeats the walk on the per-iteration kernels.  Either way the outputs equal the undisturbed ones."""
+    import warnings
+    gs = [g.copy() for g in mutag_graphs]
+    for g in gs: g.setAggregation('average')
+    seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False)
+    ns, no = _starter('g', 32)
+    model = GNNgraphBased(ns, no, 32, 50, 0.0)
+    torch.manual_seed(1); want = model.predict(seq)
+    plan = model._group_plan(seq, torch.device('cuda', 0))
+    assert plan[0].resident and plan[0].parts, 'the walk should contain groups that wait for each other (sets)'
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    nat.check(nat.lib().gnn_debug_occupy(cus - 6, 160 * 1024, hold_ms, C.c_void_p(side.cuda_stream)))
+    time.sleep(0.05)                                        # (the co-tenant is on the CUs before the walk is launched)
+    t0 = time.time()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        torch.manual_seed(1); got = model.predict(seq)
+    dt = time.time() - t0
+    torch.cuda.synchronize()
+    recovered = getattr(model, 'recovered_walks', 0)
+    print(f'\nco-tenant on {cus - 6} CUs for {hold_ms} ms: predict() took {dt * 1e3:.0f} ms, recovered walks {recovered}, '
+          f'warnings {[str(x.message)[:60] for x in w]}')
+    if recovered:
+        assert rel_err(got, want) <= TOL              # (other kernels, another summation order)
+    else:
+        assert np.array_equal(got, want)
+    if hold_ms < 2000: assert recovered == 0

@@ -245,12 +245,14 @@ class _LoopModel:
         (`FLAG_FUSED_GEN2`), batch by batch, on the caller's stream - slower, always completes - with a `RuntimeWarning`.  A second
         failure (it would be a lost hand-off inside a workgroup: a bug, not contention) raises `NativeError`."""
         self._k_seen = []
+        dev_rng = torch.cuda.get_rng_state() if torch.cuda.is_available() else None       # (host-side: seed + offset, no synchronisation)
         res = forwards()
         try:
             self._check_k()
             return res
         except nat.NativeError:
             pass
+        if dev_rng is not None: torch.cuda.set_rng_state(dev_rng)      # the repeated walk draws the same state_0 (GNN.py:257) as the failed one
         import warnings
         warnings.warn('a bounded in-launch wait of the whole-loop kernels expired (GPU shared with other long-running work?): '
                       're-running these forwards with one launch per iteration', RuntimeWarning, stacklevel=3)

@@ -527,7 +527,7 @@ from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
 graphs = load_graphs(limit=640)
 for g in graphs: g.setAggregation('average')
 seq = MultiGraphSequencer(graphs, 'g', 'average', 32, shuffle=False, device='cuda')
-d = 32
+d = 0            # the starter configuration's state = the 14 label columns: no random state_0, so every walk is comparable bit for bit
 inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d); ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=0, device='cuda')
 inp, lay = get_inout_dims('output', 14, 3, 2, 'g', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1, device='cuda')
 m = GNNgraphBased(ns, no, d, 12, 0.0)
@@ -540,7 +540,7 @@ torch.manual_seed(0); want_eval = m.evaluate(seq)
 m.native_flags, m.group_batches, m.inference_streams = 0, True, 8
 # a direct Loop() caller: loud
 x = seq[0][0]
-k, st, o = m.Loop(*m.process_inputs(x), state0=torch.zeros(x[0].shape[0], d, device='cuda'))
+k, st, o = m.Loop(*m.process_inputs(x))
 assert nat.lib().gnn_last_kernel_name().decode().startswith('k_state_small'), nat.lib().gnn_last_kernel_name()
 assert float(k) < 0
 try: m.check_last_k()
@@ -556,7 +556,7 @@ for fn, ref in ((m.predict, want), (m.evaluate, want_eval)):
 assert m.recovered_walks == 2 and m.native_flags == 0 and m.group_batches and m.inference_streams == 8
 # train_step: the in-library step's persistent forward fails before anything is modified; the step re-runs on the building blocks
 x, y, sw = seq[1]
-s0 = torch.randn(x[0].shape[0], d, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)) * 0.1
+s0 = None
 w0 = [t.clone() for t in ns.weights + no.weights]
 with warnings.catch_warnings(record=True) as w:
     warnings.simplefilter('always')
@@ -579,7 +579,7 @@ print('RECOVERED_OK')
 
 @pytest.mark.parametrize('hold_ms', [600, 2600])
 def test_a_co_tenant_holding_most_cus_does_not_break_predict(mutag_graphs, hold_ms):
-    """A foreign kernel on a second stream keeps all but 6 CUs (their whole LDS) for `hold_ms`: the one-launch MUTAG walk (256 groups,
+    """A foreign kernel on a second stream keeps all but ONE CU (their whole LDS) for `hold_ms`: the one-launch MUTAG walk (256 groups,
     one CU each, group sets that wait for each other) cannot be resident at once while it runs.  600 ms: inside the wait bound
     (GNN_WAIT_MS, 2 000 ms by default) - the launch simply completes once the CUs come back.  2 600 ms: past the bound - the waits
     expire, predict() repeats the walk on the per-iteration kernels.  Either way the outputs equal the undisturbed ones."""
@@ -595,7 +595,7 @@ def test_a_co_tenant_holding_most_cus_does_not_break_predict(mutag_graphs, hold_
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
-    nat.check(nat.lib().gnn_debug_occupy(cus - 6, 160 * 1024, hold_ms, C.c_void_p(side.cuda_stream)))
+    nat.check(nat.lib().gnn_debug_occupy(cus - 1, 160 * 1024, hold_ms, C.c_void_p(side.cuda_stream)))
     time.sleep(0.05)                                        # (the co-tenant is on the CUs before the walk is launched)
     t0 = time.time()
     with warnings.catch_warnings(record=True) as w:
@@ -604,10 +604,11 @@ def test_a_co_tenant_holding_most_cus_does_not_break_predict(mutag_graphs, hold_
     dt = time.time() - t0
     torch.cuda.synchronize()
     recovered = getattr(model, 'recovered_walks', 0)
-    print(f'\nco-tenant on {cus - 6} CUs for {hold_ms} ms: predict() took {dt * 1e3:.0f} ms, recovered walks {recovered}, '
+    print(f'\nco-tenant on {cus - 1} CUs for {hold_ms} ms: predict() took {dt * 1e3:.0f} ms, recovered walks {recovered}, '
           f'warnings {[str(x.message)[:60] for x in w]}')
     if recovered:
         assert rel_err(got, want) <= TOL              # (other kernels, another summation order)
     else:
         assert np.array_equal(got, want)
     if hold_ms < 2000: assert recovered == 0
+    else: assert recovered == 1 and any(issubclass(x.category, RuntimeWarning) for x in w)      # (groups of a set can never be resident together on one CU)

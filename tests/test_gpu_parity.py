@@ -547,11 +547,11 @@ else:
 import warnings
 with warnings.catch_warnings(record=True) as w:
     warnings.simplefilter('always')
-    got = m.predict(seq)
+    torch.manual_seed(7); got = m.predict(seq)
 assert any(issubclass(x.category, RuntimeWarning) for x in w), [str(x.message) for x in w]
 assert m.recovered_walks == 1 and m.native_flags == nat.FLAG_FUSED_GEN4, (getattr(m, 'recovered_walks', None), m.native_flags)
 m.native_flags = nat.FLAG_FUSED_GEN2
-want = m.predict(seq)
+torch.manual_seed(7); want = m.predict(seq)
 assert m.recovered_walks == 1 and np.isfinite(got).all()
 assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), np.abs(got - want).max()      # (state_0 is drawn at random: same draws, see _with_recovery)
 m.native_flags = nat.FLAG_FUSED_GEN4

@@ -537,7 +537,9 @@ torch.manual_seed(0)
 m.native_flags, m.group_batches, m.inference_streams = nat.FLAG_FUSED_GEN2, False, 1
 torch.manual_seed(0); want = m.predict(seq)
 torch.manual_seed(0); want_eval = m.evaluate(seq)
-m.native_flags, m.group_batches, m.inference_streams = 0, True, 8
+# (pinned to the spread whole-loop kernel: at this width every batch would otherwise fit one CU and run without cross-workgroup waits)
+PIN = nat.FLAG_FUSED_GEN5
+m.native_flags, m.group_batches, m.inference_streams = PIN, True, 8
 # a direct Loop() caller: loud
 x = seq[0][0]
 k, st, o = m.Loop(*m.process_inputs(x))
@@ -553,7 +555,7 @@ for fn, ref in ((m.predict, want), (m.evaluate, want_eval)):
         torch.manual_seed(0); got = fn(seq)
     assert any(issubclass(x_.category, RuntimeWarning) for x_ in w), [str(x_.message) for x_ in w]
     assert np.array_equal(np.asarray(got), np.asarray(ref)), (got, ref)
-assert m.recovered_walks == 2 and m.native_flags == 0 and m.group_batches and m.inference_streams == 8
+assert m.recovered_walks == 2 and m.native_flags == PIN and m.group_batches and m.inference_streams == 8
 # train_step: the in-library step's persistent forward fails before anything is modified; the step re-runs on the building blocks
 x, y, sw = seq[1]
 s0 = None
@@ -579,7 +581,7 @@ print('RECOVERED_OK')
 
 @pytest.mark.parametrize('hold_ms', [600, 2600])
 def test_a_co_tenant_holding_most_cus_does_not_break_predict(mutag_graphs, hold_ms):
-    """A foreign kernel on a second stream keeps all but ONE CU (their whole LDS) for `hold_ms`: the one-launch MUTAG walk (256 groups,
+    """A foreign kernel on a second stream keeps 100 KB of the LDS of all but ONE CU for `hold_ms` (the set-up kernels still fit next to it, a group's 90+ KB do not): the one-launch MUTAG walk (256 groups,
     one CU each, group sets that wait for each other) cannot be resident at once while it runs.  600 ms: inside the wait bound
     (GNN_WAIT_MS, 2 000 ms by default) - the launch simply completes once the CUs come back.  2 600 ms: past the bound - the waits
     expire, predict() repeats the walk on the per-iteration kernels.  Either way the outputs equal the undisturbed ones."""
@@ -595,7 +597,7 @@ def test_a_co_tenant_holding_most_cus_does_not_break_predict(mutag_graphs, hold_
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
-    nat.check(nat.lib().gnn_debug_occupy(cus - 1, 160 * 1024, hold_ms, C.c_void_p(side.cuda_stream)))
+    nat.check(nat.lib().gnn_debug_occupy(cus - 1, 100 * 1024, hold_ms, C.c_void_p(side.cuda_stream)))
     time.sleep(0.05)                                        # (the co-tenant is on the CUs before the walk is launched)
     t0 = time.time()
     with warnings.catch_warnings(record=True) as w:

@@ -174,13 +174,20 @@ class _LoopModel:
         return out
 
     # Keras arguments of fit / evaluate / predict that have no meaning for an eager single-process loop: accepted, ignored
-    _KERAS_NOOP_KWARGS = frozenset(('workers', 'use_multiprocessing', 'max_queue_size', 'batch_size', 'steps', 'steps_per_epoch',
-                                    'validation_steps', 'validation_batch_size', 'validation_freq', 'shuffle', 'class_weight', 'sample_weight'))
+    # (`shuffle`: Keras shuffles the ORDER of a Sequence's batches; the sequencers here re-draw the batches themselves at every
+    # `on_epoch_end`, reference GraphSequencers.py:123-127, and are walked in order)
+    _KERAS_NOOP_KWARGS = frozenset(('workers', 'use_multiprocessing', 'max_queue_size', 'batch_size', 'validation_batch_size', 'shuffle'))
+    # Keras arguments that change the loss or the amount of training and are not implemented: accepted at their Keras default (no
+    # effect), REFUSED otherwise - never silently ignored
+    _KERAS_UNSUPPORTED_KWARGS = {'class_weight': None, 'sample_weight': None, 'validation_freq': 1, 'steps': None, 'steps_per_epoch': None,
+                                 'validation_steps': None}
 
     @classmethod
     def _check_kwargs(cls, where, kwargs, allowed=()):
         """Unknown keyword arguments raise (Keras would, too) instead of vanishing."""
-        bad = [k for k in kwargs if k not in cls._KERAS_NOOP_KWARGS and k not in allowed]
+        refused = [k for k, v in kwargs.items() if k in cls._KERAS_UNSUPPORTED_KWARGS and not (v is None or (k == 'validation_freq' and isinstance(v, int) and v == 1))]
+        if refused: raise NotImplementedError(f'{where}(): {refused} would change the loss / the amount of work and are not implemented here')
+        bad = [k for k in kwargs if k not in cls._KERAS_NOOP_KWARGS and k not in cls._KERAS_UNSUPPORTED_KWARGS and k not in allowed]
         if bad: raise TypeError(f'{where}() got unexpected keyword argument(s) {bad}')
 
     def fit(self, sequencer, epochs: int = 1, validation_data=None, verbose: int = 1, callbacks=None, initial_epoch: int = 0, **kwargs):
@@ -429,7 +436,7 @@ class _LoopModel:
         # A spread run needs every one of its 64-node tiles resident at once (grid barrier), one workgroup per CU; a resident launch
         # holds one CU per group.  Size the spread runs for the CUs the resident launch leaves free, so both kinds really run side
         # by side (a run sized for the whole GPU would spin at its first barrier until the resident launch has drained).
-        n_res = sum(len(bs) for bs in plan if getattr(bs, 'resident', False))
+        n_res = sum(len(bs.groups_and_sets(sizes)[0]) - 1 for bs in plan if getattr(bs, 'resident', False))      # one CU per GROUP (a cut batch holds several)
         free = cus - min(n_res, cus)
         biggest_rest = max([(sizes[b] + 63) // 64 for b in rest], default=0)
         if free >= max(biggest_rest, cus // 4): cus = free
@@ -730,13 +737,19 @@ class GNNnodeBased(_LoopModel):
         ng = SparseMatrix.from_triple(nodegraph).device_csr(dev) if focus == 'g' else None
         # (the first group of every set, uploaded BEFORE the launch: a pageable host-to-device copy behind it would block the host
         # until the loop has finished)
-        set_first = None if group_sets is None else torch.as_tensor([int(v) for v in group_sets[:-1]], device=dev)
+        set_id = None
+        if group_sets is not None:
+            gs_ = np.asarray([int(v) for v in group_sets], dtype=np.int64)
+            set_id = torch.as_tensor(np.repeat(np.arange(len(gs_) - 1), np.diff(gs_)), device=dev)
         # the whole Loop is ONE custom op: torch.ops.gnnkeras.loop_forward (csrc/torch_ops.cpp -> gnn_loop_forward)
         k, state, out = ops.loop_forward(nodes.to(torch.float32).contiguous(), arcs.to(torch.float32).contiguous(), adj, arcn, ng,
                                          self.net_state, self.net_output, state0, out_index, ends, self.state_vect_dim,
                                          self.max_iteration, self.state_threshold, nat.FOCUS[focus], self.native_flags,
                                          loop_events=self.loop_events, groups=groups, group_sets=group_sets)
-        if group_sets is not None: k = k[set_first]        # the groups of a set report the same k: one entry per set
+        if group_sets is not None:
+            # one entry per set: its groups report the same k - or -1e9 where a member's wait for the others expired (any member: the
+            # minimum keeps it, so _check_k / check_last_k see it)
+            k = torch.full((len(group_sets) - 1,), float('inf'), device=dev).index_reduce_(0, set_id, k, 'amin')
         self._last_k = k
         return k, state, out
 

@@ -180,15 +180,24 @@ class DataParallel:
         if apply: m._optimizer_obj().apply_gradients(pairs)
         return res
 
-    def fit(self, sequencer, epochs: int = 1, validation_data=None, verbose: int = 1, callbacks=None, **kwargs):
-        """The single-process `fit` with every batch sharded over the ranks (same batches, same order, same updates)."""
+    def fit(self, sequencer, epochs: int = 1, validation_data=None, verbose: int = 1, callbacks=None, initial_epoch: int = 0, **kwargs):
+        """The single-process `fit` with every batch sharded over the ranks (same batches, same order, same updates, the same
+        callback protocol: `set_model`, `on_train_begin`, `on_epoch_begin`, `on_epoch_end`, `on_train_end`, `initial_epoch`)."""
         m = self.model
         m._check_kwargs('fit', kwargs)
         cbs = list(callbacks or [])
+        for cb in cbs:
+            if hasattr(cb, 'set_model'): cb.set_model(m)
+        def emit(name, *args):
+            for cb in cbs:
+                f = getattr(cb, name, None)
+                if f is not None: f(*args)
         history = History()
         m.stop_training = False
+        emit('on_train_begin', {})
         logs = {}
-        for epoch in range(epochs):
+        for epoch in range(int(initial_epoch), epochs):
+            emit('on_epoch_begin', epoch, {})
             tot, wsum = {}, 0.0
             for i in range(len(sequencer)):
                 data = self.shard(sequencer, i)
@@ -205,11 +214,10 @@ class DataParallel:
             history.epoch.append(epoch)
             if verbose and self.rank == 0:
                 print(f'Epoch {epoch + 1}/{epochs} - ' + ' - '.join(f'{k_}: {v:.4f}' for k_, v in logs.items()))
-            for cb in cbs:
-                f = getattr(cb, 'on_epoch_end', None)
-                if f is not None: f(epoch, logs)
+            emit('on_epoch_end', epoch, logs)
             if hasattr(sequencer, 'on_epoch_end'): self._synchronised_epoch_end(sequencer)
             if m.stop_training: break
+        emit('on_train_end', logs)
         m.history = history
         return history
 

@@ -299,8 +299,13 @@ def test_fit_evaluate_predict_reject_unknown_keyword_arguments():
     for call in (lambda: m.fit([], epochs=1, callback=[]), lambda: m.evaluate([], bogus=1), lambda: m.predict([], bogus=1)):
         with pytest.raises(TypeError):
             call()
+    # Keras arguments that would change the loss / the amount of training are refused unless they sit at their Keras default
+    for call in (lambda: m.fit([], epochs=1, class_weight={0: 2.0}), lambda: m.fit([], epochs=1, steps_per_epoch=3),
+                 lambda: m.fit([], epochs=1, validation_freq=2), lambda: m.evaluate([], sample_weight=np.ones(3)), lambda: m.predict([], steps=2)):
+        with pytest.raises(NotImplementedError):
+            call()
     from gnnkeras_amd.Models.GNN import History
-    h = m.fit([], epochs=2, verbose=0, workers=1, callbacks=[])            # no batches: nothing touches the device
+    h = m.fit([], epochs=2, verbose=0, workers=1, callbacks=[], class_weight=None, validation_freq=1, shuffle=True)     # no batches: nothing touches the device
     assert isinstance(h, History) and h.history is h and h.epoch == [0, 1]
     seen = []
     class CB:

@@ -589,8 +589,8 @@ def test_a_co_tenant_holding_most_cus_does_not_break_predict(mutag_graphs, hold_
     gs = [g.copy() for g in mutag_graphs]
     for g in gs: g.setAggregation('average')
     seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False)
-    ns, no = _starter('g', 32)
-    model = GNNgraphBased(ns, no, 32, 50, 0.0)
+    ns, no = _starter('g', 0)                 # state = the label columns: no random state_0, every walk is comparable
+    model = GNNgraphBased(ns, no, 0, 50, 0.0)
     torch.manual_seed(1); want = model.predict(seq)
     plan = model._group_plan(seq, torch.device('cuda', 0))
     assert plan[0].resident and plan[0].parts, 'the walk should contain groups that wait for each other (sets)'

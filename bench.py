@@ -411,6 +411,17 @@ def host_rss_mb():
     return None
 
 
+def composite_model(d, K_it, device, dims=(14, 8, 4)):
+    """BASELINE C5's model: 3 node types with label widths `dims`, one BN + Dense state network per type."""
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased
+    from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+    inp, lay = get_inout_dims('state', dims, 3, 2, 'n', d)
+    nets_s = [MLP(i, lay, 'selu', 'lecun_normal', 'lecun_normal', rng=t, device=device) for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', dims, 3, 2, 'n', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9, device=device)
+    return CompositeGNNnodeBased(nets_s, no, d, K_it, 0.0), nets_s[0], dims
+
+
 def emulate_shard(args):
     """`--emulate-shard r/R`: rank r's share of an R-GPU run of the selected workload on ONE GPU.  The shard is built the way a
     rank of the real job builds it (from its own `GraphSlice`), runs the real shard kernels against a full-size
@@ -423,18 +434,22 @@ def emulate_shard(args):
     torch.cuda.set_device(0)
     from gnnkeras_amd import _native as nat
     from gnnkeras_amd.distributed import ShardedLoop, partition
-    from gnnkeras_amd.synth import er_graph_slice
+    from gnnkeras_amd.synth import er_graph_slice, er_composite_graph_slice
     from gnnkeras_amd.Models.GNN import GNNnodeBased
-    if args.workload not in ('c4', 'c3'): raise SystemExit('--emulate-shard: workloads c4 / c3')
-    sizes = {'c4': (1e6, 1e7), 'c3': (1e5, 1e6)}[args.workload]
+    if args.workload not in ('c4', 'c3', 'c5'): raise SystemExit('--emulate-shard: workloads c4 / c3 / c5')
+    sizes = {'c4': (1e6, 1e7), 'c3': (1e5, 1e6), 'c5': (5e5, 5e6)}[args.workload]
     N, E = int(args.nodes or sizes[0]), int(args.arcs or sizes[1])
     d, K_it = args.state_dim, args.max_iteration
-    ns, no = starter_nets(d, device)
-    gnn = GNNnodeBased(ns, no, d, K_it, 0.0)
     rss0 = host_rss_mb()
     t0 = time.perf_counter()
     chunk, ranges = partition(N, R)
-    gs = er_graph_slice(N, E, *ranges[r], aggregation_mode=args.aggregation, seed=1234)
+    if args.workload == 'c5':            # BASELINE C5: 3 node types, per-type state networks; the rank generates its own slice
+        gnn, ns, dims = composite_model(d, K_it, device)
+        gs = er_composite_graph_slice(N, E, *ranges[r], dim_node_label=dims, aggregation_mode=args.aggregation, seed=1234)
+    else:
+        ns, no = starter_nets(d, device)
+        gnn = GNNnodeBased(ns, no, d, K_it, 0.0)
+        gs = er_graph_slice(N, E, *ranges[r], aggregation_mode=args.aggregation, seed=1234)
     t_slice = time.perf_counter() - t0
     sl = ShardedLoop(gnn, gs, r, R, device, overlap=not args.no_overlap)
     torch.cuda.synchronize()
@@ -529,14 +544,15 @@ def main():
     graph_is_slice = False
     t_graph0 = time.perf_counter()
     if composite:
-        dims = (14, 8, 4)
-        graph = er_composite_graph(N, E, dim_node_label=dims, aggregation_mode=args.aggregation, seed=1234)
-        inp, lay = get_inout_dims('state', dims, 3, 2, 'n', d)
-        nets_s = [MLP(i, lay, 'selu', 'lecun_normal', 'lecun_normal', rng=t, device=device) for t, i in enumerate(inp)]
-        inp, lay = get_inout_dims('output', dims, 3, 2, 'n', d)
-        no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9, device=device)
-        ns = nets_s[0]
-        gnn = CompositeGNNnodeBased(nets_s, no, d, K_it, 0.0)
+        gnn, ns, dims = composite_model(d, K_it, device)
+        # a rank of the sharded run generates only ITS slice of the heterogeneous graph (the compacted halo exchange wants the whole)
+        graph_is_slice = sharded and args.exchange != 'halo'
+        if graph_is_slice:
+            from gnnkeras_amd.distributed import partition
+            from gnnkeras_amd.synth import er_composite_graph_slice
+            graph = er_composite_graph_slice(N, E, *partition(N, world)[1][rank], dim_node_label=dims, aggregation_mode=args.aggregation, seed=1234)
+        else:
+            graph = er_composite_graph(N, E, dim_node_label=dims, aggregation_mode=args.aggregation, seed=1234)
         Sequencer = CompositeMultiGraphSequencer
     else:
         # a rank of the sharded run generates only ITS slice of the graph (exchange 'auto' / 'allgather' / 'direct'); the compacted
@@ -688,7 +704,19 @@ def main():
     if sharded and (world > 1 or args.force_sharded) and not args.no_mutag and args.workload == 'c4':
         del sl
         torch.cuda.empty_cache()
-        result['mutag_data_parallel'] = mutag_dp_section(device, rank, world)
+        # a collective section: every rank runs it, and every rank must leave it - an exception on one rank alone would strand the
+        # others in a collective - so failures are agreed on (MAX of an error flag) and reported instead of losing the headline line
+        err = None
+        try:
+            rec = mutag_dp_section(device, rank, world)
+        except Exception as e:
+            rec, err = None, str(e)[:300]
+        bad = torch.tensor([1.0 if err else 0.0], device=device)
+        try:
+            if world > 1: torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+        except Exception as e:
+            err = err or str(e)[:300]
+        result['mutag_data_parallel'] = rec if float(bad) == 0 and err is None else {'error': err or 'failed on another rank'}
     # RCCL writes its version banner through C stdio, which would otherwise reach the pipe AFTER this process' last Python write (at
     # exit): drain it first so that the JSON line is the LAST line of stdout (it is also the only line that starts with '{').
     try:

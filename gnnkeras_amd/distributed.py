@@ -206,8 +206,8 @@ class ShardedLoop:
         sl = ShardedLoop(model, graph, rank, world_size, device)      # graph replicated on the hosts, or the rank's GraphSlice
         k, state_local, out_local = sl.forward(state0_full)           # collective: every rank calls it
 
-    `state_local` covers the rank's own nodes [lo, hi).  `out_local`: node focus - the masked own nodes; ARC focus (homogeneous
-    models, reference GNN.py:317-330) - the masked arcs whose destination the rank owns, in arc order (`plan.arc_out_index` = their
+    `state_local` covers the rank's own nodes [lo, hi).  `out_local`: node focus - the masked own nodes; ARC focus (reference
+    GNN.py:317-330, CompositeGNN.py:315-327) - the masked arcs whose destination the rank owns, in arc order (`plan.arc_out_index` = their
     global arc ids: the ranks' rows interleave in the whole graph's order); GRAPH focus (GNN.py:341-346) - the pooled [#graphs, T]
     outputs, complete on every rank (per-graph partial sums over the own nodes, one all-reduce)."""
 
@@ -215,8 +215,8 @@ class ShardedLoop:
         """`graph`: the replicated `GraphObject` / `CompositeGraphObject`, or this rank's `GraphSlice` (a rank never needs more)."""
         self.composite = isinstance(model.net_state, (list, tuple))
         self.focus = model._focus
-        if self.focus != 'n' and (self.composite or type(self)._layout != 'allgather'):
-            raise NotImplementedError('arc- / graph-focused sharding: homogeneous models on the all-gather layout')
+        if self.focus != 'n' and type(self)._layout != 'allgather':
+            raise NotImplementedError('arc- / graph-focused sharding runs on the all-gather layout (the compacted halo layout is node-focused)')
         self.model, self.group = model, group
         self.rank, self.world_size = rank, world_size
         self.device = torch.device(device)
@@ -253,7 +253,8 @@ class ShardedLoop:
 
     def _arc_outputs(self, k):
         """Arc focus: net_output([state_src | labels_src | state_dst | labels_dst | arc label]) of the own masked arcs (the label
-        columns only when the state is not the labels themselves, GNN.py:239-242), from the exchanged buffer the loop ended on."""
+        columns only when the state is not the labels themselves, GNN.py:239-242; heterogeneous models filter on the state alone,
+        CompositeGNN.py:315-327), from the exchanged buffer the loop ended on."""
         p, dev, m = self.plan, self.device, self.model
         if not hasattr(self, 'd_arc_rows'):
             self.d_arc_rows = (torch.from_numpy(p.arc_out_src_rows).to(dev), torch.from_numpy(p.arc_out_dst_rows).to(dev),
@@ -263,7 +264,7 @@ class ShardedLoop:
         parts = []
         for rows in (rs, rd):
             parts.append(buf[rows, :self.S])
-            if m.state_vect_dim > 0: parts.append(self.d_nodes_full[rows])
+            if m.state_vect_dim > 0 and not self.composite: parts.append(self.d_nodes_full[rows])
         parts.append(lab)
         x = torch.cat(parts, dim=1)
         if x.shape[0] == 0: return torch.zeros((0, m.net_output.units[-1]), dtype=torch.float32, device=dev)

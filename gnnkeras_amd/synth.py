@@ -99,6 +99,50 @@ def er_composite_graph(n_nodes: int, n_arcs: int, dim_node_label=(14, 8, 4), dim
                                 dim_node_label=dim_node_label, focus=focus, aggregation_mode=aggregation_mode)
 
 
+def er_composite_graph_slice(n_nodes: int, n_arcs: int, lo: int, hi: int, dim_node_label=(14, 8, 4), dim_arc_label: int = 3,
+                             aggregation_mode: str = 'average', seed: int = 1234):
+    """The `GraphSlice` of `er_composite_graph(n_nodes, n_arcs, ..., seed)` for the destination range [lo, hi) - what ONE rank of the
+    sharded composite loop (BASELINE C5) generates for itself: the draws that fix the graph are replayed in full (node types and
+    labels, arc ids, arc labels), everything derived from them - aggregation weights (reference graph_class.py:105-121,
+    composite_graph_class.py:73-103), the own rows of `type_mask`, the own columns of every CompositeAdjacency (reference
+    composite_graph_class.py:57-70: the Adjacency entries whose SOURCE has that type) - only for the own arcs."""
+    from .distributed import GraphSlice
+    if aggregation_mode not in ('sum', 'normalized', 'average', 'composite_average'): raise ValueError("ERROR: Unknown aggregation mode")
+    key = (n_nodes, n_arcs, seed)
+    if key not in _ER_ARCS_CACHE:
+        _ER_ARCS_CACHE.clear()
+        _ER_ARCS_CACHE[key] = er_arcs(n_nodes, n_arcs, seed)
+    ids = _ER_ARCS_CACHE[key]
+    rng = np.random.default_rng(seed + 1)                        # (the draw order of er_composite_graph: types, labels, arc labels)
+    T, Lmax = len(dim_node_label), int(max(dim_node_label))
+    types = rng.integers(0, T, n_nodes)
+    nodes = np.zeros((n_nodes, Lmax), dtype=np.float32)
+    dims = np.asarray(dim_node_label)[types]
+    nodes[np.arange(n_nodes), (rng.random(n_nodes) * dims).astype(int)] = 1
+    arc_label_of = rng.integers(0, dim_arc_label, n_arcs)
+    mine = np.flatnonzero((ids[:, 1] >= lo) & (ids[:, 1] < hi))
+    src, dst = ids[mine, 0], ids[mine, 1]
+    arc_labels = np.zeros((len(mine), dim_arc_label), dtype=np.float32)
+    arc_labels[np.arange(len(mine)), arc_label_of[mine]] = 1
+    values = np.ones(len(mine), dtype=np.float64)
+    if aggregation_mode == 'normalized': values *= float(1 / n_arcs)
+    elif aggregation_mode == 'average':
+        values /= np.bincount(dst - lo, minlength=hi - lo)[dst - lo]           # every arc of a destination lives with it
+    elif aggregation_mode == 'composite_average':                              # 1 / #(in-neighbours of dst with the type of src)
+        src_type = types[src]
+        for t in range(T):
+            sel = src_type == t
+            if np.any(sel): values[sel] /= np.bincount(dst[sel] - lo, minlength=hi - lo)[dst[sel] - lo]
+    values = values.astype(np.float32)
+    type_mask = np.zeros((hi - lo, T), dtype=bool)
+    type_mask[np.arange(hi - lo), types[lo:hi]] = True
+    src_type = types[src]
+    cas = [(src[src_type == t], dst[src_type == t], values[src_type == t]) for t in range(T)]
+    ones = np.ones(hi - lo, dtype=bool)
+    comp = dict(type_mask=type_mask, dim_node_label=[int(v) for v in dim_node_label], adjacencies=cas)
+    return GraphSlice(n_nodes, nodes, lo, hi, src, dst, arc_labels, values, ones, ones, arc_index=mine, composite=comp)
+
+
 def er_device_batch(n_nodes: int, n_arcs: int, device, dim_node_label: int = 14, dim_arc_label: int = 3,
                     aggregation_mode: str = 'average', seed: int = 1234):
     """The 8-element `x` list of `MultiGraphSequencer.__getitem__` for ONE directed G(n, M) graph, assembled on the

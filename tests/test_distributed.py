@@ -153,7 +153,7 @@ def _oracle_arc_outputs(self, k):
     parts = []
     for rows in (p.arc_out_src_rows, p.arc_out_dst_rows):
         parts.append(buf[rows])
-        if m.state_vect_dim > 0: parts.append(p.nodes_full[rows])
+        if m.state_vect_dim > 0 and not getattr(self, 'composite', False): parts.append(p.nodes_full[rows])
     parts.append(p.arc_labels[p.arc_out])
     x = np.concatenate(parts, axis=1)
     return torch.from_numpy(O.mlp_apply(*m.net_output.spec(), x, False, self.dtype).astype(np.float32))
@@ -322,6 +322,32 @@ def test_shard_plan_from_a_slice_equals_the_plan_from_the_whole_graph():
                     assert (a.e_local, a.n_local, a.L, a.A, a.per_arc_weights) == (b.e_local, b.n_local, b.L, b.A, b.per_arc_weights)
     with pytest.raises(ValueError):
         ShardPlan(GraphSlice.from_graph(g, 0, 100), 1, 8)              # a slice of another rank's range
+
+
+def test_composite_shard_plan_from_a_generated_slice_equals_the_plan_from_the_whole_graph():
+    """BASELINE C5 on shards: `synth.er_composite_graph_slice` (a rank generates only its own destination range of the heterogeneous
+    graph) against `ShardPlan(CompositeGraphObject)` and `GraphSlice.from_graph`: bit-identical operators, per-type node lists and
+    per-source-type adjacencies, every aggregation mode incl. 'composite_average' (reference composite_graph_class.py:57-103)."""
+    from gnnkeras_amd.distributed import GraphSlice
+    from gnnkeras_amd.synth import er_composite_graph, er_composite_graph_slice
+    dims = (5, 3, 2)
+    for mode in ('average', 'composite_average', 'sum', 'normalized'):
+        g = er_composite_graph(1003, 9000, dim_node_label=dims, aggregation_mode=mode, seed=5)
+        for R in (1, 4):
+            for r, (lo, hi) in enumerate(partition(1003, R)[1]):
+                a = ShardPlan(g, r, R)
+                assert a.composite
+                for b in (ShardPlan(GraphSlice.from_graph(g, lo, hi), r, R),
+                          ShardPlan(er_composite_graph_slice(1003, 9000, lo, hi, dim_node_label=dims, aggregation_mode=mode, seed=5), r, R)):
+                    ops = [(a.adjacency, b.adjacency), (a.arcnode, b.arcnode)] + list(zip(a.composite_adjacency, b.composite_adjacency))
+                    assert len(a.composite_adjacency) == len(b.composite_adjacency) == len(dims)
+                    for x_op, y_op in ops:
+                        for name in ('rowptr', 'src', 'w', 'row_scale'):
+                            x, y = getattr(x_op, name), getattr(y_op, name)
+                            assert (x is None and y is None) or np.array_equal(x, y), (mode, R, r, name)
+                    for name in ('arc_labels', 'nodes_full', 'nodes_local', 'out_index', 'arc_index', 'type_nodes', 'type_offsets'):
+                        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+                    assert a.dim_node_label == b.dim_node_label == list(dims)
 
 
 def test_hub_rows_are_split_on_shards():

@@ -341,6 +341,25 @@ def roofline_record(b_iter, t_iter, kernel_name, n_nodes=None, h1=None):
     return rec
 
 
+def traffic_lookup(rec, kernel_name, N, E, d):
+    """HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same workload,
+    scripts/parse_pmc.py -> profiles/hbm_traffic.json): recorded per (kernel, workload), used only when both match this run."""
+    traffic_file = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    if not os.path.exists(traffic_file): return rec
+    try:
+        for tr in json.load(open(traffic_file)).get('records', []):
+            if tr.get('kernel') == kernel_name and tr.get('nodes') == N and tr.get('arcs') == E and tr.get('state_dim') == d:
+                rec['traffic'] = tr['hbm_bytes_per_launch']
+                rec['traffic_bounds'] = tr.get('bounds')
+                rec['traffic_source'] = f"profiles/hbm_traffic.json: {tr.get('launches')} launches of this kernel on this workload, {tr.get('taken', 'PMC passes of the round')}"
+    except Exception:
+        pass
+    return rec
+
+
+SIDE_STEPS = 5          # timed forwards of the side sections (beyond_infinity_cache, wide_state_d200), after one warm-up
+
+
 def beyond_cache_section(device, d, K_it, aggregation):
     """The same model on a 4 M-node / 40 M-arc ER graph: state array 1 GB (> the 256 MiB Infinity Cache), operands built on
     the device (gnnkeras_amd.synth.er_device_batch)."""
@@ -353,14 +372,15 @@ def beyond_cache_section(device, d, K_it, aggregation):
     gnn = GNNnodeBased(ns, no, d, K_it, 0.0)
     gen = torch.Generator(device=device); gen.manual_seed(1)
     s0 = torch.randn((N, d), generator=gen, device=device) * 0.1
-    elapsed, k_val, t_iter = measure_loop(gnn, gnn.process_inputs(x), s0, steps=2, warmup=1)
+    elapsed, k_val, t_iter = measure_loop(gnn, gnn.process_inputs(x), s0, steps=SIDE_STEPS, warmup=1)
     b_iter = algorithmic_bytes_per_iteration(N, E, d, ns.units[0], False)
-    rec = roofline_record(b_iter, t_iter, nat.lib().gnn_last_kernel_name().decode(), N, ns.units[0])
+    kernel_name = nat.lib().gnn_last_kernel_name().decode()
+    rec = roofline_record(b_iter, t_iter, kernel_name, N, ns.units[0])
     rec.update({'workload': f'Erdos-Renyi {N} nodes / {E} arcs, state_dim={d}, k={k_val:g}, {aggregation} aggregation '
                             f'(state array {N * d * 4 / 2**20:.0f} MiB: does not fit the 256 MiB Infinity Cache)',
-                'updates_per_s': E * k_val * 2 / elapsed, 'fwd_ms': 1e3 * elapsed / 2})
-    del rec['traffic']
-    return rec
+                'updates_per_s': E * k_val * SIDE_STEPS / elapsed, 'fwd_ms': 1e3 * elapsed / SIDE_STEPS, 'steps': SIDE_STEPS, 'warmup': 1,
+                'launches_timed': int(k_val) * SIDE_STEPS})
+    return traffic_lookup(rec, kernel_name, N, E, d)
 
 
 def wide_state_section(device, aggregation):
@@ -375,11 +395,13 @@ def wide_state_section(device, aggregation):
     gen = torch.Generator(device=device); gen.manual_seed(2)
     s0 = torch.randn((N, d), generator=gen, device=device) * 0.1
     gnn = GNNnodeBased(ns, no, d, 20, 0.0)
-    elapsed, k_val, t_iter = measure_loop(gnn, gnn.process_inputs(x), s0, steps=2, warmup=1)      # t_iter: HIP events around the iteration launches
+    elapsed, k_val, t_iter = measure_loop(gnn, gnn.process_inputs(x), s0, steps=SIDE_STEPS, warmup=1)      # t_iter: HIP events around the iteration launches
     b_iter = algorithmic_bytes_per_iteration(N, E, d, ns.units[0], False)
-    return {'workload': f'Erdos-Renyi {N} nodes / {E} arcs, state_dim={d}, {aggregation} aggregation', 'k': k_val, 'us_per_iteration': 1e6 * t_iter,
-            'algorithmic_bytes_per_iteration': b_iter, 'frac_of_8TBps': b_iter / t_iter / 8e12,
-            'kernel': nat.lib().gnn_last_kernel_name().decode()}
+    kernel_name = nat.lib().gnn_last_kernel_name().decode()
+    rec = {'workload': f'Erdos-Renyi {N} nodes / {E} arcs, state_dim={d}, {aggregation} aggregation', 'k': k_val, 'us_per_iteration': 1e6 * t_iter,
+           'algorithmic_bytes_per_iteration': b_iter, 'frac_of_8TBps': b_iter / t_iter / 8e12, 'kernel': kernel_name, 'steps': SIDE_STEPS, 'warmup': 1,
+           'launches_timed': int(k_val) * SIDE_STEPS, 'traffic': None}
+    return traffic_lookup(rec, kernel_name, N, E, d)
 
 
 def gpu_state():
@@ -635,17 +657,7 @@ def main():
     e_local = E if not sharded else sl.e_local
     b_iter = algorithmic_bytes_per_iteration(n_local, e_local, d, h1, per_arc_w)
     roofline = roofline_record(b_iter, t_iter, kernel_name, n_local, h1)
-    traffic_file = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(traffic_file) and not sharded:
-        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
-        # command, scripts/parse_pmc.py): recorded per (kernel, workload), used only when both match this run
-        try:
-            for tr in json.load(open(traffic_file)).get('records', []):
-                if tr.get('kernel') == kernel_name and tr.get('nodes') == N and tr.get('arcs') == E and tr.get('state_dim') == d:
-                    roofline['traffic'] = tr['hbm_bytes_per_launch']
-                    roofline['traffic_bounds'] = tr.get('bounds')
-        except Exception:
-            pass
+    if not sharded: traffic_lookup(roofline, kernel_name, N, E, d)
 
     result = {
         'metric': 'node-state updates/s (arcs x iterations / s), forward Loop',

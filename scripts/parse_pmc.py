@@ -1,7 +1,10 @@
 """Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md §HBM prescribes) of
 one bench.py command into a record of profiles/hbm_traffic.json: HBM bytes per launch of the dominant iteration kernel.
 
-    python scripts/parse_pmc.py FETCH.csv WRITE.csv NODES ARCS STATE_DIM H1 OUT.json [CONST_BYTES_PER_NODE]
+    python scripts/parse_pmc.py FETCH.csv WRITE.csv NODES ARCS STATE_DIM H1 OUT.json [CONST_BYTES_PER_NODE [KERNEL_SUBSTRING [TAKEN]]]
+
+KERNEL_SUBSTRING: which kernel's rows to average (default k_state_fused; k_state_xwide for the 129 .. 256-wide kernel); TAKEN: a note
+on when / on which commit the passes were taken (recorded next to the numbers).
 
 CONST_BYTES_PER_NODE: what the kernel reads per node for the iteration-invariant part of the first layer: 4 H1 (the constant C,
 default) or 128 (the XC variant: the node's 32 constant inputs).
@@ -19,8 +22,11 @@ n_nodes, n_arcs, d, h1 = int(float(sys.argv[3])), int(float(sys.argv[4])), int(s
 out = sys.argv[7]
 
 
+KSUB = sys.argv[9] if len(sys.argv) > 9 else 'k_state_fused'
+
+
 def vals(path, counter):
-    rows = [r for r in csv.DictReader(open(path)) if 'k_state_fused' in r['Kernel_Name'] and r['Counter_Name'] == counter]
+    rows = [r for r in csv.DictReader(open(path)) if KSUB in r['Kernel_Name'] and r['Counter_Name'] == counter]
     return [float(r['Counter_Value']) for r in rows], (rows[0]['Kernel_Name'] if rows else '')
 
 
@@ -37,6 +43,7 @@ rec = {'kernel': kname, 'const_bytes_per_node': const_bytes, 'nodes': n_nodes, '
        'FETCH_SIZE_KiB_raw_mean': statistics.mean(f), 'WRITE_SIZE_KiB_mean': statistics.mean(w),
        'write_bytes': write_b, 'hbm_bytes_per_launch': upper, 'bounds': [lower, upper],
        'algorithmic_bytes_per_launch': algorithmic, 'traffic_over_algorithmic': [lower / algorithmic, upper / algorithmic],
+       'taken': sys.argv[10] if len(sys.argv) > 10 else None,
        'note': 'upper: every read doubled (gfx950 tallies 128-B requests at 64 B for 16 B/lane reads); lower: the dword reads '
                '(row pointers, source ids, constant term) taken as tallied in full'}
 data = {'records': []}

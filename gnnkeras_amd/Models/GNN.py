@@ -726,7 +726,7 @@ class GNNnodeBased(_LoopModel):
                 gen = None
                 if seed is not None:
                     gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
-                state0 = torch.randn((N, self.state_vect_dim), generator=gen, device=dev, dtype=torch.float32) * 0.1
+                state0 = torch.empty((N, self.state_vect_dim), device=dev, dtype=torch.float32).normal_(0.0, 0.1, generator=gen)      # tf.random.normal(stddev=0.1), one launch
             state0 = state0.to(dev, torch.float32).contiguous()
             if tuple(state0.shape) != (N, self.state_vect_dim): raise ValueError('state0 must be (n_nodes, state_vect_dim)')
         else:

@@ -510,7 +510,7 @@ class LoopTrainer:
                 gen = None
                 if seed is not None:
                     gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
-                state0 = torch.randn((N, d), generator=gen, device=dev, dtype=torch.float32) * 0.1
+                state0 = torch.empty((N, d), device=dev, dtype=torch.float32).normal_(0.0, 0.1, generator=gen)      # tf.random.normal(stddev=0.1), one launch
             s_init = state0.to(dev, torch.float32)
         else:
             s_init = nodes
@@ -841,7 +841,7 @@ class LoopTrainer:
                 gen = None
                 if seed is not None:
                     gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
-                state0 = torch.randn((N, d), generator=gen, device=dev, dtype=torch.float32) * 0.1
+                state0 = torch.empty((N, d), device=dev, dtype=torch.float32).normal_(0.0, 0.1, generator=gen)      # tf.random.normal(stddev=0.1), one launch
             state0 = state0.to(dev, torch.float32).contiguous()
             if tuple(state0.shape) != (N, d): raise ValueError('state0 must be (n_nodes, state_vect_dim)')
             a.state0 = nat.ptr(state0); keep.append(state0)

@@ -547,6 +547,137 @@ __global__ void __launch_bounds__(256, 2) k_train_wgrad(TrainWgradArgs a) {
     }
 }
 
+// ---- a thin output head at large M ---------------------------------------------------------------------------------------------------
+// The reference's output network on a node-focused graph (GNN.py:273: net_output([state | labels][mask])) with EVERY node in the
+// output set is one [BatchNormalization +] Dense((S + L) -> T) with T <= 4 classes over a million rows: its backward pass is pure
+// row streaming, and on the general kernels it cost as much as an iteration of the loop (weight gradient 362 us + dZ . W^T 243 us +
+// BatchNorm input gradient 239 us + scatter into the state gradient 216 us + a 256 MB memset at C4 size).  Two kernels instead:
+//   k_head_wgrad<T> - P = [state | labels]^T dZ and q = colsum(dZ): a lane owns four consecutive input columns, 32 lanes a row, each row
+//                     read once as 16-byte pieces; per-workgroup partials in the layout k_reduce_partials / k_first_layer_param_grads
+//                     take ([K x T] then [T]), row groups and workgroups added in a fixed order;
+//   k_head_dx<T>    - d loss / d state[m, j] = Ac_j (sum_h dZ[m, h] W[j, h]) + Cc_j state[m, j] + Bc_j  (the Dense input gradient with the
+//                     BatchNorm input gradient as per-column coefficients, as k_train_bwd_dx), WRITTEN into the state gradient: every
+//                     row is an output row, so nothing is scattered or zero-filled.  The label columns' input gradient is never needed.
+struct HeadArgs {
+    int M, S, L, T;
+    const float *state; int ld_state;     // [M, S], S a multiple of 4
+    const float *labels; int ld_labels;   // [M, L] or NULL (L = 0)
+    const float *dZ; int ldz;             // [M, T]
+    int rows_per_wg;
+    float *part;                          // k_head_wgrad: [gridDim.x][(S + L) T + T]
+    // k_head_dx
+    const float *W;                       // first-layer kernel [(S + L) x T] (NOT folded)
+    const float *gamma, *mean, *var, *m1, *m2; float eps;      // NULL gamma: no BatchNormalization
+    float *dx; int ld_dx;                 // [M, S]
+};
+
+template <int T>
+__global__ void __launch_bounds__(256) k_head_wgrad(HeadArgs a) {
+    __shared__ float red[8][32][4 * T + 1];
+    __shared__ float redq[8][T];
+    const int tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;          // 8 row groups of 32 lanes
+    const int ns4 = a.S >> 2, nl4 = (a.L + 3) >> 2;                          // 16-byte pieces of a state row / a label row
+    const bool is_state = lane < ns4, is_label = !is_state && lane < ns4 + nl4;
+    const int lc = 4 * (lane - ns4);                                          // first label column of a label lane
+    const int m_beg = blockIdx.x * a.rows_per_wg, m_end = min(a.M, m_beg + a.rows_per_wg);
+    float acc[4][T], q[T];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int h = 0; h < T; ++h) acc[e][h] = 0.0f;
+#pragma unroll
+    for (int h = 0; h < T; ++h) q[h] = 0.0f;
+    for (int m = m_beg + grp; m < m_end; m += 8 * 2) {                        // two rows in flight per lane
+        float x[2][4], dz[2][T];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = m + 8 * u;
+            const bool in = r < m_end;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[u][e] = 0.0f;
+            if (in && is_state) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(a.state + (size_t)r * a.ld_state + 4 * lane);
+                x[u][0] = v[0]; x[u][1] = v[1]; x[u][2] = v[2]; x[u][3] = v[3];
+            } else if (in && is_label) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (lc + e < a.L) x[u][e] = a.labels[(size_t)r * a.ld_labels + lc + e];
+            }
+#pragma unroll
+            for (int h = 0; h < T; ++h) dz[u][h] = in ? a.dZ[(size_t)r * a.ldz + h] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int h = 0; h < T; ++h) acc[e][h] = fmaf(x[u][e], dz[u][h], acc[e][h]);
+#pragma unroll
+            for (int h = 0; h < T; ++h) q[h] += dz[u][h];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int h = 0; h < T; ++h) red[grp][lane][e * T + h] = acc[e][h];
+    if (lane == 0) {
+#pragma unroll
+        for (int h = 0; h < T; ++h) redq[grp][h] = q[h];
+    }
+    __syncthreads();
+    const int K = a.S + a.L;
+    float *out = a.part + (size_t)blockIdx.x * ((size_t)K * T + T);
+    for (int i = tid; i < K * T + T; i += 256) {                              // row groups in order
+        float s = 0.0f;
+        if (i < K * T) {
+            const int k = i / T, h = i % T;
+            const int ln = k < a.S ? (k >> 2) : ns4 + ((k - a.S) >> 2), e = k < a.S ? (k & 3) : ((k - a.S) & 3);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += red[g][ln][e * T + h];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += redq[g][i - K * T];
+        }
+        out[i] = s;
+    }
+}
+
+template <int T>
+__global__ void __launch_bounds__(256) k_head_dx(HeadArgs a) {
+    const int ns4 = a.S >> 2;                                                  // lanes per row (<= 16: S <= 64)
+    const int lpr = ns4 <= 4 ? 4 : ns4 <= 8 ? 8 : 16;
+    const int l4 = threadIdx.x % lpr, groups = 256 / lpr;
+    const bool act = l4 < ns4;
+    float w[4][T], Ac[4], Cc[4], Bc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = 4 * l4 + e;
+        Ac[e] = 1.0f; Cc[e] = 0.0f; Bc[e] = 0.0f;
+#pragma unroll
+        for (int h = 0; h < T; ++h) w[e][h] = act ? a.W[(size_t)j * T + h] : 0.0f;
+        if (a.gamma && act) {
+            const float rstd = 1.0f / sqrtf(a.var[j] + a.eps);
+            Ac[e] = a.gamma[j] * rstd; Cc[e] = -Ac[e] * rstd * a.m2[j]; Bc[e] = -Ac[e] * a.m1[j] - Cc[e] * a.mean[j];
+        }
+    }
+    for (int m = blockIdx.x * groups + threadIdx.x / lpr; m < a.M; m += gridDim.x * groups) {
+        float dz[T];
+#pragma unroll
+        for (int h = 0; h < T; ++h) dz[h] = a.dZ[(size_t)m * a.ldz + h];
+        if (!act) continue;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (a.gamma) x = *reinterpret_cast<const f32x4 *>(a.state + (size_t)m * a.ld_state + 4 * l4);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float dy = 0.0f;
+#pragma unroll
+            for (int h = 0; h < T; ++h) dy = fmaf(dz[h], w[e][h], dy);
+            v[e] = fmaf(Ac[e], dy, fmaf(Cc[e], x[e], Bc[e]));
+        }
+        *reinterpret_cast<f32x4 *>(a.dx + (size_t)m * a.ld_dx + 4 * l4) = v;
+    }
+}
+
 // sum of n floats times scale, any n: grid-stride partials in a fixed order, then one block (the loss of a million-row batch)
 __global__ void __launch_bounds__(256) k_sum_partials(const float *__restrict__ x, int n, float *__restrict__ part) {
     __shared__ float sh[256];

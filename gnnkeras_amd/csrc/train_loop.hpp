@@ -45,6 +45,8 @@ struct TrainPlan {
     NetCtx cs, co;
     // large graphs (kernels_train_big.hpp): constant inputs packed 32 per node, statistics partials of the two producers
     bool big; int Kc; gnn::ConstCols cc;
+    bool head_fast;              // large graphs: thin output head (one Dense of <= 4 units over EVERY node) on the row-streaming head kernels
+    float *part_h;
     float *xc, *part_a, *part_y, *loss_part, *part_w;
     // small graphs (kernels_train_small.hpp): the forward / backward iterations as one persistent launch each
     bool small, tiled; int n_wg;
@@ -59,7 +61,7 @@ inline int train_big_min_nodes() {
     if (v < 0) { const char *e = getenv("GNN_TRAIN_BIG_MIN_NODES"); v = e ? atoi(e) : 32768; }
     return v;
 }
-constexpr int BIG_AGG_BLOCKS = 4096, BIG_FWD_BLOCKS = 1024, BIG_WGRAD_BLOCKS = 512;
+constexpr int BIG_AGG_BLOCKS = 4096, BIG_FWD_BLOCKS = 1024, BIG_WGRAD_BLOCKS = 512, BIG_HEAD_BLOCKS = 2048;
 inline bool train_wgrad_enabled() {       // GNN_TRAIN_WGRAD=0: the round-2 weight-gradient kernels (k_act_grad + k_dense_grad_allk) at large M too
     static int v = -1;
     if (v < 0) { const char *e = getenv("GNN_TRAIN_WGRAD"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -123,6 +125,9 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.Kc = (p.with_labels ? 2 * p.L : 0) + p.A;
     p.big = p.N >= train_big_min_nodes() && ns.n_layers == 1 && ns.units[0] == p.S && (p.S == 16 || p.S == 32 || p.S == 64) &&
             p.Kc <= 32 && ns.activation[0] != GNN_ACT_SOFTMAX && (size_t)p.N * p.S * 4 < ((size_t)1 << 32) && p.K > 0;
+    // every node is an output row (out_index ascending and n_out == n_nodes: the identity), one thin Dense: kernels_train_big.hpp
+    p.head_fast = p.big && no.n_layers == 1 && no.units[0] <= 4 && a.focus != GNN_FOCUS_ARC && p.M == p.N && p.S % 4 == 0 &&
+                  p.S / 4 + ((p.with_labels ? p.L : 0) + 3) / 4 <= 32;
     p.SPs = p.S <= 16 ? 16 : p.S <= 32 ? 32 : 64;
     p.tiled = ta.n_tiles > 0 && ta.tile_node_begin != nullptr;
     p.n_wg = p.tiled ? ta.n_tiles : cdiv(p.N, 64);
@@ -140,7 +145,7 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.agg = c.take<float>((size_t)(p.agg_taped ? std::max(p.K, 1) : 1) * p.N * p.ldS);
     p.agg_arcs = c.take<float>((size_t)p.N * std::max(p.A, 1));
     p.agg_nodes = c.take<float>((size_t)p.N * std::max(p.L, 1));
-    p.stats_s = c.take<float>((size_t)std::max(p.K, 1) * 2 * p.in_s);
+    p.stats_s = c.take<float>((size_t)(std::max(p.K, 1) + 1) * 2 * p.in_s);      // (+ 1: the statistics of the LAST state, for the output head's BatchNormalization)
     p.stats_tpl = c.take<float>(2 * (size_t)p.in_s);
     p.Wf_s = c.take<float>((size_t)std::max(p.K, 1) * p.in_s * p.H1s);
     p.bf_s = c.take<float>((size_t)std::max(p.K, 1) * p.H1s);
@@ -176,6 +181,7 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.part_y = c.take<float>(p.big ? (size_t)BIG_FWD_BLOCKS * 2 * std::max(p.S, 32) : 0);      // (also the one-pass statistics of the 32-wide constants line)
     p.loss_part = c.take<float>(256);
     p.part_w = c.take<float>(p.big ? (size_t)BIG_WGRAD_BLOCKS * ((size_t)p.in_s * p.S + p.S) : 0);      // k_train_wgrad: one partial per workgroup
+    p.part_h = c.take<float>(p.head_fast ? (size_t)BIG_HEAD_BLOCKS * ((size_t)p.in_o * p.H1o + p.H1o) : 0);             // k_head_wgrad: one partial per workgroup
     p.sm_cc = c.take<float>(p.small ? (size_t)p.N * p.SPs : 0);
     p.sm_part = c.take<float>(p.small ? (size_t)2 * p.n_wg * 8 * p.SPs : 0);
     p.sm_partW = c.take<float>(p.small ? (size_t)p.n_wg * (p.in_s + 1) * p.S : 0);
@@ -514,6 +520,48 @@ int launch_train_small_bwd_sq(const gnn::TrainSmallBwd &ba, const gnn::TileTab &
                  : launch_persistent(&gnn::k_train_small_bwd<SQ, false, false>, ba, tt, n_wg, lds, st);
 }
 
+// Back-propagation through a thin output head over every node of a large graph (kernels_train_big.hpp: k_head_wgrad / k_head_dx): the
+// head's parameter gradients, and d loss / d state_k written straight into the state gradient.  G = d loss / d head output [M x T].
+template <int T>
+int head_backward_t(const TrainPlan &p, const gnn_loop_args_t &a, const float *state_k, const float *out_nodes, float *G, const float *stats, hipStream_t st) {
+    const gnn_mlp_t &m = a.net_output;
+    TRY(act_grad_inplace(G, p.T, out_nodes, p.T, p.M, p.T, m.activation[0], st));
+    gnn::HeadArgs h;
+    memset(&h, 0, sizeof(h));
+    h.M = p.M; h.S = p.S; h.L = p.with_labels ? p.L : 0; h.T = T;
+    h.state = state_k; h.ld_state = p.ldS; h.labels = p.with_labels ? a.nodes : nullptr; h.ld_labels = a.ld_nodes;
+    h.dZ = G; h.ldz = p.T;
+    const int grid = std::min(BIG_HEAD_BLOCKS, cdiv(p.M, 256));
+    h.rows_per_wg = cdiv(p.M, grid);
+    h.part = p.part_h;
+    gnn::k_head_wgrad<T><<<grid, 256, 0, st>>>(h);
+    LAUNCH_OK();
+    const int K = m.in_dim, n = K * T + T;
+    gnn::k_reduce_partials<<<cdiv(n, 64), 256, 0, st>>>(p.part_h, grid, n, p.co.P, 0, 1.0f, K * T, p.co.q);
+    LAUNCH_OK();
+    const bool bn = m.has_bn != 0;
+    gnn::k_first_layer_param_grads<<<K, 64, 0, st>>>(p.co.P, p.co.q, m.kernel[0], K, T, bn ? m.bn_gamma : nullptr, m.bn_beta, stats, stats ? stats + K : nullptr,
+                                                     m.bn_eps, 1.0f / (float)p.M, p.co.g->dkernel[0], p.co.g->dbias[0], p.co.g->dgamma, p.co.g->dbeta,
+                                                     bn ? p.co.m1 : nullptr, bn ? p.co.m2 : nullptr, 0, 1);
+    LAUNCH_OK();
+    h.W = m.kernel[0];
+    if (bn) { h.gamma = m.bn_gamma; h.mean = stats; h.var = stats + K; h.m1 = p.co.m1; h.m2 = p.co.m2; h.eps = m.bn_eps; }
+    h.dx = p.G_state; h.ld_dx = p.S;
+    const int lpr = p.S / 4 <= 4 ? 4 : p.S / 4 <= 8 ? 8 : 16;
+    gnn::k_head_dx<T><<<std::min(cdiv(p.M, 256 / lpr), 256 * 16), 256, 0, st>>>(h);
+    LAUNCH_OK();
+    return 0;
+}
+
+int head_backward(const TrainPlan &p, const gnn_loop_args_t &a, const float *state_k, const float *out_nodes, float *G, const float *stats, hipStream_t st) {
+    switch (p.T) {
+        case 1: return head_backward_t<1>(p, a, state_k, out_nodes, G, stats, st);
+        case 2: return head_backward_t<2>(p, a, state_k, out_nodes, G, stats, st);
+        case 3: return head_backward_t<3>(p, a, state_k, out_nodes, G, stats, st);
+        default: return head_backward_t<4>(p, a, state_k, out_nodes, G, stats, st);
+    }
+}
+
 // the caller's tiles (HOST array), checked: ascending, <= 64 nodes each, covering [0, N)
 int tile_table(const gnn_train_args_t &ta, const TrainPlan &p, gnn::TileTab &tt) {
     memset(&tt, 0, sizeof(tt));
@@ -641,7 +689,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
         fa.act = ns.activation[0];
         fa.Y = s_n; fa.ldy = p.S;
         fa.thr = a.state_threshold; fa.pred_flag = p.flags + t + 1; fa.pred_k = p.k_dev; fa.pred_kval = (float)(t + 1);
-        const bool next_stats = bn_s && t + 1 < p.K;
+        const bool next_stats = bn_s && (t + 1 < p.K || (p.head_fast && bn_o));      // (the last state's: the output head's BatchNorm input)
         fa.stat_part = next_stats ? p.part_y : nullptr;
         int grid = 0;
         TRY(launch_train_fwd(fa, p.S, st, &grid));
@@ -744,6 +792,19 @@ int gnn_train_step(const gnn_train_args_t *args) {
     if (p.M > 0) {
         const float *W0 = no.kernel[0], *b0 = no.bias[0];
         if (bn_o) {
+            if (p.head_fast && bn_s && k >= 1) {
+                // Every node is an output row: the column statistics of [state_k | labels] are already on the tape - the state's were
+                // left by the launch that wrote it (k_train_fwd's epilogue, slot k), the labels' are the state network's constant
+                // BatchNorm columns S .. S + L (one pass over the packed constants line) - four small copies instead of four passes
+                // over a million rows (0.76 ms of a C4-size step).
+                const float *slot = p.stats_s + (size_t)k * 2 * p.in_s;
+                HIP_OK(hipMemcpyAsync(p.stats_o, slot, sizeof(float) * p.S, hipMemcpyDeviceToDevice, st));
+                HIP_OK(hipMemcpyAsync(p.stats_o + p.in_o, slot + p.in_s, sizeof(float) * p.S, hipMemcpyDeviceToDevice, st));
+                if (p.with_labels) {
+                    HIP_OK(hipMemcpyAsync(p.stats_o + p.S, p.stats_tpl + p.S, sizeof(float) * p.L, hipMemcpyDeviceToDevice, st));
+                    HIP_OK(hipMemcpyAsync(p.stats_o + p.in_o + p.S, p.stats_tpl + p.in_s + p.S, sizeof(float) * p.L, hipMemcpyDeviceToDevice, st));
+                }
+            } else
             TRY(colstats_segs(nullptr, osegs, nos, p.M, p.stats_o, p.stats_o + p.in_o, p.part, st));
             TRY(fold_with_stats(no, p.stats_o, p.Wf_o, p.bf_o, st));
             gnn::k_bn_moving_multi<<<cdiv(p.in_o, 256), 256, 0, st>>>(p.stats_o, 2 * p.in_o, 1, p.in_o, const_cast<float *>(no.bn_mean),
@@ -767,8 +828,10 @@ int gnn_train_step(const gnn_train_args_t *args) {
     if (p.pooled) { TRY(launch_aggregate(nullptr, ta.nodegraph_by_source, p.dpred, p.T, p.T, p.G_out, p.T, st)); G_out = p.G_out; }
 
     // ---- backward: output network, then the k iterations -----------------------------------------------------------------------------------
-    HIP_OK(hipMemsetAsync(p.G_state, 0, sizeof(float) * (size_t)p.N * p.S, st));
-    if (p.M > 0) {
+    if (!p.head_fast) HIP_OK(hipMemsetAsync(p.G_state, 0, sizeof(float) * (size_t)p.N * p.S, st));
+    if (p.head_fast) {
+        TRY(head_backward(p, a, state_k, out_nodes, G_out, bn_o ? p.stats_o : nullptr, st));
+    } else if (p.M > 0) {
         TRY(net_backward(p.co, osegs, nos, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, p.in_o, p.part, st));
         gnn::BnGradReq rq[2];
         for (int i = 0; i < n_state_segs; ++i)

@@ -291,6 +291,10 @@ def training_section(device, graph_x, d):
         torch.cuda.synchronize(); t_epoch = (time.perf_counter() - t0) / 2
         out[name] = {'train_step_ms_per_batch': 1e3 * t_step, 'k': int(r['k']), 'fit_epoch_ms': 1e3 * t_epoch,
                      'epoch': f'{len(tr)} training steps of 32 graphs + validation on 868 graphs + reshuffle / device re-merge'}
+    try:
+        out['composite_small_graphs'] = composite_training_section(device)
+    except Exception as e:                            # never lose the other numbers to this one
+        out['composite_small_graphs'] = {'error': str(e)[:300]}
     ns, no = starter_nets(d, device, 'n')
     gnn = GNNnodeBased(ns, no, d, 10, 0.0)
     gnn.compile(optimizer=Adam(0.001), loss='categorical_crossentropy', metrics=['accuracy'])
@@ -304,6 +308,38 @@ def training_section(device, graph_x, d):
     out['c4_d64_k10'] = {'train_step_ms': 1e3 * (time.perf_counter() - t0) / 3, 'k': int(r['k']),
                          'workload': 'the C4 graph, node-focused, every node a target, 10 iterations, BatchNormalization on batch statistics'}
     return out
+
+
+def composite_training_section(device):
+    """Heterogeneous small graphs (reference CompositeGNN.py:275-304 `train_step`): 640 typed graphs of 20 .. 60 nodes (3 node types,
+    MUTAG-like size), batches of 32, node-focused, d = 32 x 20 iterations - the step runs one state network per node type on that
+    type's rows through the device building blocks (`Models/training.py`; the one-call in-library step covers homogeneous models)."""
+    from gnnkeras_amd.synth import er_composite_graph
+    from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased
+    from gnnkeras_amd.Models.training import Adam
+    from gnnkeras_amd.Sequencers.GraphSequencers import CompositeMultiGraphSequencer
+    rng = np.random.default_rng(7)
+    dims, d, it = (14, 8, 4), 32, 20
+    graphs = [er_composite_graph(int(n), int(2.2 * n), dim_node_label=dims, seed=100 + i) for i, n in enumerate(rng.integers(20, 61, 640))]
+    inp, lay = get_inout_dims('state', dims, 3, 2, 'n', d)
+    nets = [MLP(i, lay, 'selu', 'lecun_normal', 'lecun_normal', rng=t, device=device) for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', dims, 3, 2, 'n', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9, device=device)
+    gnn = CompositeGNNnodeBased(nets, no, d, it, 0.01)
+    gnn.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['accuracy'])
+    seq = CompositeMultiGraphSequencer(graphs, 'n', 'average', 32, shuffle=False, device=device)
+    for i in range(3): gnn.train_step(seq[i], seed=0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(len(seq)): r = gnn.train_step(seq[i], seed=0)
+    torch.cuda.synchronize(); t_step = (time.perf_counter() - t0) / len(seq)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    gnn.fit(seq, epochs=1, verbose=0)
+    torch.cuda.synchronize(); t_epoch = time.perf_counter() - t0
+    t0 = time.perf_counter(); gnn.predict(seq); torch.cuda.synchronize(); t_pred = time.perf_counter() - t0
+    return {'train_step_ms_per_batch': 1e3 * t_step, 'k': int(r['k']), 'fit_epoch_ms': 1e3 * t_epoch, 'predict_ms': 1e3 * t_pred,
+            'workload': f'{len(graphs)} heterogeneous graphs (3 node types, 20..60 nodes), {len(seq)} batches of 32, node-focused, d = {d}, '
+                        f'max_iteration = {it}; building-block orchestration (per-type networks), predict() batch by batch'}
 
 
 def measure_loop(gnn, inputs, s0, steps, warmup):

@@ -749,7 +749,7 @@ class GNNnodeBased(_LoopModel):
         if group_sets is not None:
             # one entry per set: its groups report the same k - or -1e9 where a member's wait for the others expired (any member: the
             # minimum keeps it, so _check_k / check_last_k see it)
-            k = torch.full((len(group_sets) - 1,), float('inf'), device=dev).index_reduce_(0, set_id, k, 'amin')
+            k = torch.full((len(group_sets) - 1,), float('inf'), device=dev).scatter_reduce_(0, set_id, k, 'amin')
         self._last_k = k
         return k, state, out
 

@@ -795,8 +795,10 @@ class LoopTrainer:
     def _native_step_applies(self, y):
         m = self.model
         if self.dp is not None: return False        # collectives sit between the iteration's launches: the building-block path
-        if not self.use_native_step or isinstance(m.net_state, (list, tuple)) or y is None: return False
-        if m.net_state.dropout_rate or m.net_output.dropout_rate: return False      # Dropout masks: the general path below
+        if not self.use_native_step or y is None: return False
+        nets = list(m.net_state) if isinstance(m.net_state, (list, tuple)) else [m.net_state]
+        if isinstance(m.net_state, (list, tuple)) and m._focus == 'a': return False      # arc-focused composite models: the general path below
+        if any(n_.dropout_rate for n_ in nets) or m.net_output.dropout_rate: return False      # Dropout masks: the general path below
         kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
         return str(kind).lower() in nat.LOSSES
 
@@ -807,8 +809,14 @@ class LoopTrainer:
         from types import SimpleNamespace
         from .GNN import _squeeze_last, _arc_endpoints
         m = self.model
-        _check_no_dropout([m.net_state, m.net_output])
-        nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph = m.process_inputs(x_list)
+        composite = isinstance(m.net_state, (list, tuple))
+        nets_s = list(m.net_state) if composite else [m.net_state]
+        _check_no_dropout(nets_s + [m.net_output])
+        inputs = m.process_inputs(x_list)
+        if composite:       # CompositeGNN.py:275-304: one state network per node type (csrc/train_composite.hpp)
+            nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, cas, adjacency, arcnode, nodegraph = inputs
+        else:
+            nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph = inputs
         nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs')
         dev = nodes.device
         self.prim = p = _Prim(dev)
@@ -817,11 +825,13 @@ class LoopTrainer:
         d = m.state_vect_dim
         S = d if d > 0 else L
         focus = m._focus
-        m.net_state.to(dev); m.net_output.to(dev)
+        for n_ in nets_s: n_.to(dev)
+        m.net_output.to(dev)
         # gnn_train_step OVERWRITES every gradient buffer: the holders of the previous step are reused as they are (eight zero-fill
         # launches and their allocations per step otherwise; the optimizer's pointer tables stay valid too)
-        gs, go = self._cached_grads('state', m.net_state, p), self._cached_grads('output', m.net_output, p)
-        self.gs, self.go = gs, go
+        gs_all = [self._cached_grads(f'state{i}' if composite else 'state', n_, p) for i, n_ in enumerate(nets_s)]
+        gs, go = gs_all[0], self._cached_grads('output', m.net_output, p)
+        self.gs, self.go = (gs_all if composite else gs), go
         out_index = m._out_index(_squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev))
         adj, an = adjacency.device_csr(dev), arcnode.device_csr(dev)
         keep = [nodes, arcs, adj, an, out_index]
@@ -833,7 +843,24 @@ class LoopTrainer:
         a.arc_labels, a.ld_arcs = C.c_void_p(arcs.data_ptr() + 8), arcs.shape[1]
         a.adjacency, a.arcnode = nat.make_csr(adj), nat.make_csr(an)
         a.n_types = 1
-        a.net_state[0] = m.net_state.native()
+        if composite:
+            from .GNN import _squeeze_last as _sq
+            dims = [int(v) for v in (dim_node_label.reshape(-1).tolist() if isinstance(dim_node_label, torch.Tensor)
+                                     else np.asarray(dim_node_label).reshape(-1))]
+            if len(dims) != len(nets_s): raise ValueError(f'{len(dims)} node types but {len(nets_s)} state networks')
+            type_nodes, offsets = m._type_lists(_sq(type_mask).to(dev))
+            ca_csr = [c_.device_csr(dev) for c_ in cas]
+            keep += [type_nodes, ca_csr]
+            a.composite, a.n_types = 1, len(dims)
+            a.type_nodes = nat.ptr(type_nodes)
+            for t_, dt in enumerate(dims):
+                a.type_dim_label[t_] = dt
+                a.type_offsets[t_] = int(offsets[t_])
+                a.composite_adjacency[t_] = nat.make_csr(ca_csr[t_])
+                a.net_state[t_] = nets_s[t_].native()
+            a.type_offsets[len(dims)] = int(offsets[len(dims)])
+        else:
+            a.net_state[0] = m.net_state.native()
         a.net_output = m.net_output.native()
         a.state_dim, a.max_iteration, a.state_threshold = d, m.max_iteration, float(m.state_threshold)
         if d > 0:
@@ -866,7 +893,8 @@ class LoopTrainer:
         ta.loss_kind = nat.LOSSES[str(kind).lower()]
         ta.average_st_grads = 0          # finish() divides by k AFTER adding the weight penalties, like the reference (GNN.py:295)
         ta.bn_momentum = BN_MOMENTUM
-        for g_, ng_ in ((ta.grad_state, gs), (ta.grad_output, go)):
+        holders = [(ta.grad_state_types[i], g_) for i, g_ in enumerate(gs_all)] if composite else [(ta.grad_state, gs)]
+        for g_, ng_ in holders + [(ta.grad_output, go)]:
             if ng_.bn: g_.dgamma, g_.dbeta = nat.ptr(ng_.dgamma), nat.ptr(ng_.dbeta)
             for l in range(len(ng_.W)): g_.dkernel[l], g_.dbias[l] = ng_.dW[l].data_ptr(), ng_.db[l].data_ptr()
         T = m.net_output.units[-1]
@@ -874,7 +902,7 @@ class LoopTrainer:
         loss = p.new(1)
         k_host = C.c_int32(0)
         ta.y_pred, ta.state, ta.loss, ta.k_host = nat.ptr(y_pred), nat.ptr(state), nat.ptr(loss), C.pointer(k_host)
-        tiles = adjacency.tiles(64) if self.use_tiles else None      # a merged batch: graphs packed into tiles of <= 64 nodes
+        tiles = adjacency.tiles(64) if (self.use_tiles and not composite) else None      # a merged batch: graphs packed into tiles of <= 64 nodes
         if tiles is not None and len(tiles) - 1 <= 256:
             ta.tile_node_begin, ta.n_tiles = tiles.ctypes.data, len(tiles) - 1
         nbytes = nat.lib().gnn_train_workspace_bytes(C.byref(ta))
@@ -886,9 +914,9 @@ class LoopTrainer:
         aligned = (base + 255) & ~255
         ta.tape, ta.tape_bytes = C.c_void_p(aligned), tape.numel() - (aligned - base)
         nat.check(nat.lib().gnn_train_step(C.byref(ta)))
-        gs.touched = k_host.value > 0
+        for g_ in gs_all: g_.touched = k_host.value > 0          # (a type without nodes: the library zero-fills its gradients)
         go.touched = len(out_index) > 0
-        tp = SimpleNamespace(gs=[gs], go=go, k=int(k_host.value), y_pred=y_pred, state=state)
+        tp = SimpleNamespace(gs=gs_all, go=go, k=int(k_host.value), y_pred=y_pred, state=state)
         res = {'k': tp.k, 'y_pred': y_pred, 'state': state, 'loss': loss[0]}
         reg = self.finish(tp, apply)
         if reg is not None: res['loss'] = res['loss'] + reg

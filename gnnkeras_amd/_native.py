@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 # GNNKERAS_AMD_LIB: load another build of the same sources (tests: the debug build whose in-launch waits expire at once)
 LIB_PATH = os.environ.get('GNNKERAS_AMD_LIB') or os.path.join(CSRC, 'libgnnloop.so')
 
-GNN_ABI_VERSION = 5
+GNN_ABI_VERSION = 6
 GNN_MAX_LAYERS = 8
 GNN_MAX_TYPES = 8
 
@@ -102,7 +102,8 @@ class TrainArgs(C.Structure):
                 ('average_st_grads', C.c_int32), ('bn_momentum', C.c_float),
                 ('grad_state', MLPGrads), ('grad_output', MLPGrads),
                 ('y_pred', C.c_void_p), ('state', C.c_void_p), ('loss', C.c_void_p), ('k_host', C.POINTER(C.c_int32)),
-                ('tape', C.c_void_p), ('tape_bytes', C.c_size_t), ('tile_node_begin', C.c_void_p), ('n_tiles', C.c_int32)]
+                ('tape', C.c_void_p), ('tape_bytes', C.c_size_t), ('tile_node_begin', C.c_void_p), ('n_tiles', C.c_int32),
+                ('grad_state_types', MLPGrads * GNN_MAX_TYPES)]          # ABI 6: one gradient holder per node type (composite models)
 
 
 class RaggedDesc(C.Structure):

@@ -1654,3 +1654,4 @@ int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const 
 
 #include "train_api.hpp"
 #include "train_loop.hpp"
+#include "train_composite.hpp"

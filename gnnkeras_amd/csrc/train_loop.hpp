@@ -286,9 +286,10 @@ int act_grad_inplace(float *G, int ldg, const float *Y, int ldy, int M, int H, i
 // Back-propagation through one network.  G = d loss / d hs[last] ([M x units_last], leading dimension ldg; overwritten).
 // Parameter gradients go to x.g (accumulated when `accumulate`); dx_all (optional) receives d loss / d input columns
 // [0, kdx) BEFORE the BatchNormalization input gradient (the caller applies it to the segments it needs).
-// `second_row` >= 0: dx_all is [M x kdx] = columns [0, kdx/2) of the input followed by columns [second_row, second_row + kdx/2).
+// `second_row` >= 0: dx_all is [M x kdx] = columns [0, kdx/2) of the input followed by columns [second_row, second_row + kdx/2);
+// `first_col`: the block starts at that input column instead of 0 (composite models: the state segment sits behind the type's labels).
 int net_backward(NetCtx &x, const gnn::Seg *segs, int nseg, float *const *hs, float *G, int ldg, int M, const float *stats, bool accumulate,
-                 float *dx_all, int kdx, float *part, hipStream_t st, int second_row = -1) {
+                 float *dx_all, int kdx, float *part, hipStream_t st, int second_row = -1, int first_col = 0) {
     const gnn_mlp_t &m = *x.m;
     int n_chunks;
     const int rpc = rows_per_chunk_for(std::max(M, 1), &n_chunks);
@@ -338,10 +339,10 @@ int net_backward(NetCtx &x, const gnn::Seg *segs, int nseg, float *const *hs, fl
         x.g->dkernel[0], x.g->dbias[0], x.g->dgamma, x.g->dbeta, bn ? x.m1 : nullptr, bn ? x.m2 : nullptr, accumulate ? 1 : 0, fuse_chunks);
     LAUNCH_OK();
     if (dx_all && kdx > 0) {
-        if (second_row < 0 || second_row == kdx / 2) {
-            TRY(dense_plain(G, ldg, H, x.Wt[0], K, kdx, M, dx_all, kdx, st));   // W^T columns [0, kdx) (ldw = K)
+        if (second_row < 0 || second_row == first_col + kdx / 2) {
+            TRY(dense_plain(G, ldg, H, x.Wt[0] + first_col, K, kdx, M, dx_all, kdx, st));   // W^T columns [first_col, first_col + kdx) (ldw = K)
         } else {
-            TRY(dense_plain(G, ldg, H, x.Wt[0], K, kdx / 2, M, dx_all, kdx, st));
+            TRY(dense_plain(G, ldg, H, x.Wt[0] + first_col, K, kdx / 2, M, dx_all, kdx, st));
             TRY(dense_plain(G, ldg, H, x.Wt[0] + second_row, K, kdx / 2, M, dx_all + kdx / 2, kdx, st));
         }
     }
@@ -574,12 +575,17 @@ int tile_table(const gnn_train_args_t &ta, const TrainPlan &p, gnn::TileTab &tt)
     return 0;
 }
 
+// heterogeneous models: train_composite.hpp (behind this file in the same translation unit)
+int train_step_composite(const gnn_train_args_t &ta);
+size_t composite_train_workspace_bytes(const gnn_train_args_t &ta);
+
 }  // namespace
 
 extern "C" {
 
 size_t gnn_train_workspace_bytes(const gnn_train_args_t *args) {
     if (!args) { fail("args is NULL"); return 0; }
+    if (args->loop.composite) return composite_train_workspace_bytes(*args);
     TrainPlan p;
     if (make_train_plan(*args, nullptr, p)) return 0;
     return p.bytes;
@@ -591,6 +597,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
     const gnn_loop_args_t &a = ta.loop;
     TrainPlan p;
     if (!ta.tape || ((uintptr_t)ta.tape & 255) != 0) return fail("tape must be a 256-byte aligned device buffer");
+    if (a.composite) return train_step_composite(ta);             // one state network per node type (train_composite.hpp)
     TRY(make_train_plan(ta, ta.tape, p));
     if (ta.tape_bytes < p.bytes) return fail("tape too small: %zu < %zu bytes", ta.tape_bytes, p.bytes);
     TRY(check_csr(a.adjacency, "adjacency", p.N, p.N));

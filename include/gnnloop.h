@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 5
+#define GNN_ABI_VERSION 6
 
 /* Keras activation names accepted by the reference MLP builder (GNN/Models/MLP.py:16). */
 enum gnn_activation {
@@ -363,7 +363,7 @@ typedef struct gnn_ragged_desc {
 } gnn_ragged_desc_t;
 int gnn_ragged_copy(const gnn_ragged_desc_t *desc, int32_t n_desc, const int32_t *blk_begin, int32_t n_blocks, void *stream);
 
-/* ---- one whole training step of a homogeneous model inside the library (reference GNN.py:277-306) ---------------------
+/* ---- one whole training step inside the library (reference GNN.py:277-306, CompositeGNN.py:275-304) ------------------------
  * Training-mode forward (BatchNormalization on batch statistics, moving averages updated once per executed iteration for
  * the state network and once for the output network), Keras loss with sample weights, back-propagation through the k
  * executed iterations, optional 1/k on the state-network gradients (`average_st_grads`, :295).  The optimizer update stays
@@ -372,8 +372,9 @@ int gnn_ragged_copy(const gnn_ragged_desc_t *desc, int32_t n_desc, const int32_t
  * step is bound by launch count and host time, not by bandwidth.
  * `loop` describes graph, networks (their BatchNormalization moving_mean / moving_variance arrays ARE UPDATED in place),
  * focus, out_index, nodegraph, state0, max_iteration, state_threshold and stream exactly as for gnn_loop_forward; its
- * k_out / state_out / out / workspace fields are ignored.  Heterogeneous (composite) models, dropout and LGNN label
- * gradients are not covered: the caller uses the building blocks for those.
+ * k_out / state_out / out / workspace fields are ignored.  Heterogeneous (composite) models are covered since ABI 6
+ * (grad_state_types; gnnkeras_amd/csrc/train_composite.hpp); dropout and LGNN label gradients are not: the caller uses the
+ * building blocks for those.
  * The call synchronises the stream ONCE (to learn k, as the reference does when it divides by k). */
 typedef struct gnn_mlp_grads {
     float *dgamma, *dbeta;                     /* [in_dim] each; NULL without BatchNormalization                   */
@@ -405,6 +406,11 @@ typedef struct gnn_train_args {
      * tiles than CUs, large graphs). */
     const int32_t *tile_node_begin;            /* HOST array [n_tiles + 1], ascending, [0] = 0, [n_tiles] = n_nodes  */
     int32_t n_tiles;
+    /* ABI 6: heterogeneous models (loop.composite != 0; reference CompositeGNN.py:275-304 `train_step`): one state network per node
+     * type, net_state[t] applied to the rows of type t with ITS BatchNormalization statistics - the gradients of network t land in
+     * grad_state_types[t] (grad_state is not used then).  Node and graph focus; arc-focused composite models and LGNN label
+     * gradients train through the building blocks. */
+    gnn_mlp_grads_t grad_state_types[GNN_MAX_TYPES];
 } gnn_train_args_t;
 size_t gnn_train_workspace_bytes(const gnn_train_args_t *args);
 int gnn_train_step(const gnn_train_args_t *args);

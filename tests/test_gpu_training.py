@@ -324,9 +324,13 @@ def test_fit_reduces_loss_starter_config(mutag_graphs, bn):
 # ----------------------------------------------------------------------------------------------------------------------
 # composite (heterogeneous) models: one state network per node type (reference CompositeGNN.py:275-304)
 # ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('native', [False, True])
 @pytest.mark.parametrize('focus', ['n', 'g', 'a'])
 @pytest.mark.parametrize('bn', [False, True])
-def test_composite_gradients(focus, bn):
+def test_composite_gradients(focus, bn, native):
+    """Both orchestrations against torch autograd in float64: the device building blocks driven from Python (`native=False`) and the
+    whole step inside the library (`gnn_train_step` with `composite`, csrc/train_composite.hpp; node / graph focus - an arc-focused
+    model takes the building blocks either way)."""
     from gnnkeras_amd import CompositeGraphObject
     from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased, CompositeGNNarcBased, CompositeGNNgraphBased
     from gnnkeras_amd.Models.training import LoopTrainer
@@ -369,6 +373,8 @@ def test_composite_gradients(focus, bn):
         max_iteration=5, state_threshold=0.0, focus=focus, state0=s0, y=_np(y), sample_weight=_np(sw),
         loss='categorical_crossentropy')
     tr = LoopTrainer(model)
+    tr.use_native_step = native
+    assert tr._native_step_applies(y) == (native and focus != 'a')
     res = tr.train_step(x, y, sw, state0=torch.from_numpy(s0).cuda(), apply=False)
     assert res['k'] == want['k'] == 5
     assert abs(float(res['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))

@@ -313,7 +313,8 @@ def training_section(device, graph_x, d):
 def composite_training_section(device):
     """Heterogeneous small graphs (reference CompositeGNN.py:275-304 `train_step`): 640 typed graphs of 20 .. 60 nodes (3 node types,
     MUTAG-like size), batches of 32, node-focused, d = 32 x 20 iterations - the step runs one state network per node type on that
-    type's rows through the device building blocks (`Models/training.py`; the one-call in-library step covers homogeneous models)."""
+    type's rows inside the library (`gnn_train_step` with `composite`, round 4), and for comparison on the device building blocks
+    driven from Python (`Models/training.py`, what round 3 ran)."""
     from gnnkeras_amd.synth import er_composite_graph
     from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
     from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased
@@ -329,17 +330,25 @@ def composite_training_section(device):
     gnn = CompositeGNNnodeBased(nets, no, d, it, 0.01)
     gnn.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['accuracy'])
     seq = CompositeMultiGraphSequencer(graphs, 'n', 'average', 32, shuffle=False, device=device)
-    for i in range(3): gnn.train_step(seq[i], seed=0)
+    for i in range(len(seq)): gnn.train_step(seq[i], seed=0)           # (every batch once: its device operators are built on first use)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(len(seq)): r = gnn.train_step(seq[i], seed=0)
     torch.cuda.synchronize(); t_step = (time.perf_counter() - t0) / len(seq)
+    native = gnn._trainer._native_step_applies(seq[0][1])
     torch.cuda.synchronize(); t0 = time.perf_counter()
     gnn.fit(seq, epochs=1, verbose=0)
     torch.cuda.synchronize(); t_epoch = time.perf_counter() - t0
+    gnn.predict(seq)
     t0 = time.perf_counter(); gnn.predict(seq); torch.cuda.synchronize(); t_pred = time.perf_counter() - t0
+    gnn._trainer.use_native_step = False                                # the same step on the building blocks driven from Python (round 3's path)
+    for i in range(3): gnn.train_step(seq[i], seed=0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(len(seq)): gnn.train_step(seq[i], seed=0)
+    torch.cuda.synchronize(); t_blocks = (time.perf_counter() - t0) / len(seq)
     return {'train_step_ms_per_batch': 1e3 * t_step, 'k': int(r['k']), 'fit_epoch_ms': 1e3 * t_epoch, 'predict_ms': 1e3 * t_pred,
+            'in_library_step': bool(native), 'train_step_ms_per_batch_building_blocks_from_python': 1e3 * t_blocks,
             'workload': f'{len(graphs)} heterogeneous graphs (3 node types, 20..60 nodes), {len(seq)} batches of 32, node-focused, d = {d}, '
-                        f'max_iteration = {it}; building-block orchestration (per-type networks), predict() batch by batch'}
+                        f'max_iteration = {it}; gnn_train_step with per-type networks (csrc/train_composite.hpp), predict() batch by batch'}
 
 
 def measure_loop(gnn, inputs, s0, steps, warmup):

@@ -110,8 +110,11 @@ class DataParallel:
     BatchNormalization moving statistics): not the reference's step on the merged batch, an order of magnitude less device time."""
 
     def __init__(self, model, group=None, exact: bool = True):
-        if isinstance(getattr(model, 'net_state', None), (list, tuple)):
-            raise NotImplementedError('data-parallel training covers homogeneous models (per-type row lists may be empty on a shard)')
+        if isinstance(getattr(model, 'net_state', None), (list, tuple)) and exact:
+            # (the exact step all-gathers per-network batch statistics; a node type may have no rows on some shard: the replica step -
+            # the in-library composite step per shard, one weighted all-reduce - handles that, the exact one is not built for it)
+            raise NotImplementedError('exact data-parallel training covers homogeneous models; heterogeneous models train with '
+                                      'DataParallel(model, exact=False) (the in-library step on every shard + one all-reduce)')
         self.exact = bool(exact)
         self.model, self.group = model, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)

@@ -104,6 +104,49 @@ WORKER = textwrap.dedent('''
     dist.all_gather(parts, w)
     assert all(torch.equal(parts[0], p_) for p_ in parts), 'replicas diverged'
     assert np.isfinite(hist_r['loss']).all()
+    # heterogeneous models (round 4): the replica mode runs the in-library composite step (csrc/train_composite.hpp) on every shard
+    from gnnkeras_amd.synth import er_composite_graph
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased
+    from gnnkeras_amd.Sequencers.GraphSequencers import CompositeMultiGraphSequencer
+    dims = (5, 3, 2)
+    cgraphs = [er_composite_graph(30 + i, 90 + 2 * i, dim_node_label=dims, seed=50 + i) for i in range(16)]
+    def cbuild():
+        inp, lay = get_inout_dims('state', dims, 3, 2, 'n', 8)
+        nsc = [MLP(i, lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=t, device=dev) for t, i in enumerate(inp)]
+        inp, lay = get_inout_dims('output', dims, 3, 2, 'n', 8); noc = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=7, device=dev)
+        mc = CompositeGNNnodeBased(nsc, noc, 8, 4, 0.0)
+        mc.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['accuracy'])
+        return mc
+    cseq = CompositeMultiGraphSequencer(cgraphs, 'n', 'average', 8, shuffle=False, device=dev)
+    try:
+        DataParallel(cbuild())
+    except NotImplementedError:
+        pass
+    else:
+        raise SystemExit('exact data-parallel training of a composite model should be refused')
+    mc = cbuild()
+    dpc = DataParallel(mc, exact=False)
+    csz = [g.nodes.shape[0] for g in cgraphs[:8]]
+    clo, chi = 8 * rank // world, 8 * (rank + 1) // world
+    c0 = sum(csz[:clo]); c1 = c0 + sum(csz[clo:chi])
+    cs0 = np.random.default_rng(3).normal(0, 0.1, (sum(csz), 8)).astype(np.float32)
+    res_c = dpc.train_step(dpc.shard(cseq, 0), state0=torch.from_numpy(cs0[c0:c1]).to(dev), apply=False)
+    assert dpc._trainer._native_step_applies(cseq[0][1]) and res_c['k'] == 4
+    if world == 1:          # the single-process composite step on the whole batch
+        m1 = cbuild(); t1 = LoopTrainer(m1)
+        x1, y1, sw1 = cseq[0]
+        r1 = t1.train_step(x1, y1, sw1, state0=torch.from_numpy(cs0).to(dev), apply=False)
+        g1 = [g for t_ in t1.gs for g in t_.gradients()] + t1.go.gradients()
+        gc = [g for t_ in dpc._trainer.gs for g in t_.gradients()] + dpc._trainer.go.gradients()
+        assert abs(float(res_c['loss']) - float(r1['loss'])) <= 1e-6
+        for a_, b_ in zip(gc, g1): assert float((a_ - b_).abs().max()) <= 1e-6 * max(1.0, float(b_.abs().max()))
+    hist_c = dpc.fit(CompositeMultiGraphSequencer(cgraphs, 'n', 'average', 8, shuffle=True, device=dev), epochs=2, verbose=0)
+    wts = [a_ for n_ in mc.net_state for a_ in n_.get_weights()] + mc.net_output.get_weights()
+    w = torch.cat([torch.from_numpy(a_.reshape(-1)) for a_ in wts]).to(dev)
+    parts = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(parts, w)
+    assert all(torch.equal(parts[0], p_) for p_ in parts), 'composite replicas diverged'
+    assert np.isfinite(hist_c['loss']).all()
     dist.barrier(); torch.cuda.synchronize()
     dist.destroy_process_group()
     if rank == 0: print('DP_OK ' + json.dumps({'k': res['k'], 'worst_grad_err': worst, 'loss': [float(v) for v in hist['loss']]}))

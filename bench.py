@@ -67,6 +67,17 @@ def nat_kernel():
     return nat.lib().gnn_last_kernel_name().decode()
 
 
+def timed_median(fn, reps=5):
+    """(median wall seconds of `reps` synchronised calls, the last result): a ~1 ms walk timed once is at the mercy of one host hiccup
+    (single shots of the same build ranged 1.2 .. 1.7 ms across boxes of the pool)."""
+    ts, res = [], None
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = fn()
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), res
+
+
 def mutag_section(device, cpu: bool):
     """BASELINE C2: all 136 MUTAG batches of 32 graphs, d = 32, max_iteration = 50, threshold 0.01."""
     from gnnkeras_amd.load_MUTAG import load_graphs
@@ -122,10 +133,7 @@ def mutag_section(device, cpu: bool):
     t_grp = None
     if plan is not None:
         grouped(gnn); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ks_g = grouped(gnn)
-        torch.cuda.synchronize()
-        t_grp = time.perf_counter() - t0
+        t_grp, ks_g = timed_median(lambda: grouped(gnn))
         assert [float(v) for v in ks_g.cpu()] == ks, 'grouped launches must reproduce every batch\'s iteration count'
     t_best = min(t_gpu, t_grp) if t_grp is not None else t_gpu
     arcs_iters = sum(x[1].shape[0] * k for x, k in zip(items, ks))
@@ -156,10 +164,7 @@ def mutag_section(device, cpu: bool):
     t_cg = None
     if plan is not None:
         grouped(gnn_c); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ks_cg = grouped(gnn_c)
-        torch.cuda.synchronize()
-        t_cg = time.perf_counter() - t0
+        t_cg, ks_cg = timed_median(lambda: grouped(gnn_c))
         # (another kernel, other summation orders: a batch sitting exactly on the threshold may stop one iteration apart)
         assert max(abs(a_ - b_) for a_, b_ in zip([float(v) for v in ks_cg.cpu()], ks_c)) <= 1
     res['converging'] = {'note': 'state-network kernel x 0.25: contractive, the device-side predicate stops the loop early',
@@ -175,10 +180,7 @@ def mutag_section(device, cpu: bool):
         outs = [o for _, o in gnn0._forward_batches(seq, device)]
         return torch.cat([k.reshape(-1) for k in gnn0._k_seen])
     walk0(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ks0 = walk0()
-    torch.cuda.synchronize()
-    t_0 = time.perf_counter() - t0
+    t_0, ks0 = timed_median(walk0)
     res['starter_config'] = {'workload': 'state_vect_dim=0, max_iteration=5, threshold=0.01 (starter.py), the predict() walk over the 136 batches',
                              'fwd_ms_per_graph': 1e3 * t_0 / n_graphs, 'mean_k': float(ks0.mean()),
                              'how': ('grouped launches: %d' % len(plan0)) if plan0 is not None else 'side streams'}

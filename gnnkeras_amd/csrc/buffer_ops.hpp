@@ -53,10 +53,18 @@ __device__ __forceinline__ void buf_st_sc1(__amdgpu_buffer_rsrc_t r, unsigned of
 template <typename Done>
 __device__ __forceinline__ bool wait_until(unsigned long long budget_ticks, Done done) {
     if (budget_ticks == 0) return false;
-    const unsigned long long t0 = wall_clock64();
+    // The clock is read every 64th poll only, the first time to start the budget (a few microseconds late: nothing against
+    // milliseconds) - a wait that is satisfied at once, or within its first polls, costs what the bare poll loop cost
+    // (s_memrealtime is a scalar memory operation with a long latency: read at the start of every wait it showed up in the
+    // 15 us iterations of the one-CU-per-group kernel).
+    unsigned long long t0 = 0;
     for (int spin = 0;; ++spin) {
         if (done()) return true;
-        if ((spin & 63) == 63 && wall_clock64() - t0 > budget_ticks) return false;
+        if ((spin & 63) == 63) {
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > budget_ticks) return false;
+        }
         __builtin_amdgcn_s_sleep(2);
     }
 }

@@ -737,3 +737,55 @@ def test_c5_as_4_shards_at_the_timed_depth(request):
         del shards, outs
     print(f'\nC5 as 4 shards, k={_DEEP_K}: overlap split state {errs[True][0]:.2e} out {errs[True][1]:.2e}; plain state {errs[False][0]:.2e} out {errs[False][1]:.2e}')
     for e in errs.values(): assert max(e) <= TOL, errs
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training at large M with EVERY node an output row: the thin output head on its row-streaming kernels (kernels_train_big.hpp)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d,bn,focus,T,loss,thr', [(64, True, 'n', 2, 'categorical_crossentropy', 0.0), (32, False, 'n', 3, 'mse', 0.0),
+                                                    (16, True, 'n', 4, 'categorical_crossentropy', -1.0), (32, True, 'g', 2, 'categorical_crossentropy', 0.0),
+                                                    (64, False, 'g', 1, 'mse', 0.0), (32, True, 'n', 2, 'binary_crossentropy', 0.0)])
+def test_thin_output_head_over_every_node_matches_autograd(d, bn, focus, T, loss, thr):
+    """`n_out == n_nodes` (every node passes the masks: bench.py's C4 training step) with a one-Dense head of <= 4 units takes
+    `TrainPlan::head_fast`: the head's BatchNorm statistics come from the tape (the state's from the launch that wrote it - slot k, also
+    after an early exit - the labels' from the state network's constant columns), its backward pass is k_head_wgrad + k_head_dx (no
+    scatter, no zero-fill).  Every gradient, the loss, y_pred, k and the moving statistics against torch autograd in float64, through
+    the in-library step and the building blocks; node focus with sample weights, graph focus (pooled head), 1 .. 4 output units."""
+    from test_gpu_training import check_step, oracle_step
+    from gnnkeras_amd.Models.GNN import GNNnodeBased as NB, GNNgraphBased as GB
+    rng = np.random.default_rng(100 + d + T)
+    L, A = 14, 3
+    if focus == 'n':
+        N = 36_000
+        g0 = er_graph(N, 5 * N, seed=6, aggregation_mode='average')
+        t = np.zeros((N, T)); t[np.arange(N), rng.integers(0, T, N)] = 1
+        g = GraphObject(g0.nodes, g0.arcs, t, focus='n', aggregation_mode='average', sample_weight=rng.uniform(0.5, 1.5, N))
+    else:
+        parts = [er_graph(n, 5 * n, seed=20 + i) for i, n in enumerate((9000, 12000, 7000, 8000))]
+        parts = [GraphObject(q.nodes, q.arcs, np.eye(T)[[i % T]], focus='g', aggregation_mode='average') for i, q in enumerate(parts)]
+        g = GraphObject.merge(parts, focus='g', aggregation_mode='average')
+        N = g.nodes.shape[0]
+    seq = MultiGraphSequencer([g], focus, 'average', 1, shuffle=False)
+    x, y, sw = seq[0]
+    inp, lay = get_inout_dims('state', L, A, T, focus, d)
+    ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=0, batch_normalization=bn)
+    ns.set_weights([a * (0.5 if thr >= 0 else 0.1) if a.ndim == 2 else a for a in ns.get_weights()])
+    inp, lay = get_inout_dims('output', L, A, T, focus, d)
+    out_act = 'softmax' if loss == 'categorical_crossentropy' else ('sigmoid' if loss == 'binary_crossentropy' else 'linear')
+    no = MLP(inp[0], lay, out_act, 'glorot_normal', 'glorot_normal', rng=1, batch_normalization=bn)
+    if bn:
+        for n_ in (ns, no):
+            w = n_.get_weights()
+            w[0] = rng.uniform(0.7, 1.3, w[0].shape).astype(np.float32); w[1] = rng.normal(0, 0.2, w[1].shape).astype(np.float32)
+            n_.set_weights(w)
+    cls = NB if focus == 'n' else GB
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32) if d else None
+    K = 4
+    if thr < 0:                                               # early exit: a threshold at which the oracle stops after 1 .. 3 iterations
+        seen = {}
+        for thr in (0.05, 0.1, 0.2, 0.4, 0.8):
+            k = seen[thr] = oracle_step(cls(ns, no, d, K, thr), x, y, sw, s0, loss)['k']
+            if 0 < k < K: break
+        assert 0 < k < K, f'no threshold with an early exit found: {seen}'
+    model = cls(ns, no, d, K, thr)
+    check_step(model, x, y, sw, s0, loss=loss)                # both orchestrations against the oracle

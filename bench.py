@@ -695,6 +695,8 @@ def main():
         extra['exchange_bytes_per_rank_per_iteration'] = sl.exchange_bytes()
         extra['exchange_transport'] = getattr(sl, 'transport', 'all_to_all')
         if getattr(sl, 'transport_times', None): extra['exchange_transport_ms_measured'] = {k_: 1e3 * v for k_, v in sl.transport_times.items()}
+        extra['exchange_pipeline_chunks'] = getattr(sl, 'pipeline_chunks', 1)          # > 1: chunk launches, every chunk's rows sent as soon as written
+        if getattr(sl, 'pipeline_times', None): extra['exchange_pipeline_ms_per_iteration_measured'] = {str(k_): 1e3 * v for k_, v in sl.pipeline_times.items()}
     ms_per_step = 1e3 * elapsed / args.steps
     value = E * k_val * args.steps / elapsed
     if rank == 0: extra['gpu_state_after_timed_region'] = gpu_state()

@@ -27,7 +27,7 @@ FLAG_FUSED_GEN_MASK = 7 << 4
 FLAG_FUSED_GEN2, FLAG_FUSED_GEN4, FLAG_FUSED_GEN5, FLAG_FUSED_GEN6, FLAG_FUSED_GEN7 = 2 << 4, 4 << 4, 5 << 4, 6 << 4, 7 << 4     # pin the fused-kernel generation (tests, tuning)
 
 EXPORTS = ['gnn_last_error', 'gnn_last_kernel_name', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_loop_groups_supported', 'gnn_aggregate',
-           'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_step_agg', 'gnn_state_ld', 'gnn_debug_occupy',
+           'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_step_agg', 'gnn_state_ld', 'gnn_debug_occupy', 'gnn_shard_iteration_split_rows',
            'gnn_shard_setup', 'gnn_shard_iteration', 'gnn_shard_output', 'gnn_gather_rows',
            'gnn_shard_can_split', 'gnn_shard_partial', 'gnn_shard_iteration_split',
            'gnn_dense', 'gnn_fold_bn', 'gnn_dense_grad_workspace_bytes', 'gnn_dense_grad', 'gnn_act_grad',
@@ -177,6 +177,7 @@ def lib():
             'gnn_shard_can_split': (C.c_int, [C.POINTER(LoopArgs)]),
             'gnn_shard_partial': (C.c_int, [C.POINTER(LoopArgs), C.POINTER(CSR), vp, vp]),
             'gnn_shard_iteration_split': (C.c_int, [C.POINTER(LoopArgs), C.POINTER(CSR), vp, vp, vp, i32, vp, i32, i32, vp, i32]),
+            'gnn_shard_iteration_split_rows': (C.c_int, [C.POINTER(LoopArgs), C.POINTER(CSR), vp, vp, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32]),
             'gnn_dense': (C.c_int, [C.POINTER(DenseArgs)]),
             'gnn_gather_rows': (C.c_int, [vp, i32, vp, i32, i32, vp, i32, vp]),
             'gnn_fold_bn': (C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]),

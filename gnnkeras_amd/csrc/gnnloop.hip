@@ -991,7 +991,8 @@ int iteration_prefix(const gnn_loop_args_t &a, const Plan &p, const int *gate, c
 // one fused iteration over every node type (one launch per type)
 int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, int n_gate, int gate_stride,
                     const float *src, float *dst, int row_base, int *flag_next, float *k_out, float k_val,
-                    hipStream_t st, const gnn_csr_t *adj_override = nullptr, const float *agg_init = nullptr) {
+                    hipStream_t st, const gnn_csr_t *adj_override = nullptr, const float *agg_init = nullptr,
+                    const int *rows_override = nullptr, int count_override = 0) {
     auto type_of = [&](int t) { return fused_type(a, p, t); };
     TRY(launch_heavy(a, p, n_gate == 1 ? gate : nullptr, src, st));
     const gnn_csr_t &adj = adj_override ? *adj_override : iter_adjacency(a, p);
@@ -1004,6 +1005,10 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
     fa.n_types = 0;
     for (int t = 0; t < p.T; ++t)
         if (p.tp[t].count > 0) fa.tp[fa.n_types++] = type_of(t);
+    if (rows_override && fa.n_types == 1) {      // a SUB-RANGE of a homogeneous shard's rows (the pipelined exchange): the row-list form
+        fa.tp[0].rows = rows_override; fa.tp[0].count = count_override;
+        if (count_override == 0) fa.n_types = 0;
+    }
     fa.S = p.S; fa.thr = a.state_threshold;
     fa.flag_next = flag_next;
     fa.k_out = k_out; fa.k_val = k_val;
@@ -1630,6 +1635,38 @@ int gnn_shard_iteration_split(const gnn_loop_args_t *args, const gnn_csr_t *adja
     HIP_OK(hipMemsetAsync(flag_out, 0, sizeof(int32_t), st));
     return iteration_fused(a, p, g, g ? 1 : 0, 0, state_in_full, state_out_full, row_base, flag_out, a.k_out,
                            (float)(iteration + 1), st, adjacency_halo, agg_partial);
+}
+
+int gnn_shard_iteration_split_rows(const gnn_loop_args_t *args, const gnn_csr_t *adjacency_halo, const float *agg_partial,
+                                   const float *state_in_full, float *state_out_full, int32_t row_base, const int32_t *gate,
+                                   int32_t n_gate, int32_t gate_stride, int32_t *flag_out, int32_t iteration,
+                                   const int32_t *node_ids, int32_t n_ids, int32_t first_chunk) {
+    if (!args || !adjacency_halo || !agg_partial) return fail("args / adjacency_halo / agg_partial is NULL");
+    const gnn_loop_args_t &a = *args;
+    if (!state_in_full || !state_out_full || !flag_out) return fail("state buffers / flag_out are NULL");
+    if (iteration < 0 || iteration >= a.max_iteration) return fail("iteration %d out of [0, max_iteration)", iteration);
+    if (n_gate < 0 || (n_gate > 0 && !gate)) return fail("bad gate list");
+    if (n_ids < 0 || n_ids > a.n_nodes || (n_ids > 0 && !node_ids)) return fail("bad node_ids / n_ids");
+    if (a.composite) return fail("gnn_shard_iteration_split_rows: homogeneous models");
+    if (!gnn_shard_can_split(args)) return fail("gnn_shard_iteration_split_rows: this model / shard does not run on the wave-specialised kernel");
+    Plan p;
+    TRY(make_plan(a, a.workspace, p, false));
+    if (p.SP > 64) return fail("gnn_shard_iteration_split_rows: state widths up to 64");
+    TRY(check_csr(*adjacency_halo, "adjacency_halo", p.N, a.adjacency.n_src));
+    if (row_base < 0 || row_base + p.N > a.adjacency.n_src) return fail("row_base out of the full buffer");
+    hipStream_t st = (hipStream_t)a.stream;
+    const int *g = nullptr;
+    if (n_gate > 0 && !(a.flags & GNN_FLAG_NO_EARLY_EXIT)) {
+        if (first_chunk) {          // the gate word of this iteration: evaluated once, read by every chunk's launch
+            k_or_flags<<<1, 64, 0, st>>>(gate, n_gate, gate_stride, p.flags + iteration);
+            LAUNCH_OK();
+        }
+        g = p.flags + iteration;
+    }
+    if (first_chunk) HIP_OK(hipMemsetAsync(flag_out, 0, sizeof(int32_t), st));      // (later chunks OR into it)
+    if (n_ids == 0) return 0;
+    return iteration_fused(a, p, g, g ? 1 : 0, 0, state_in_full, state_out_full, row_base, flag_out, a.k_out,
+                           (float)(iteration + 1), st, adjacency_halo, agg_partial, node_ids, n_ids);
 }
 
 int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const float *buf1_full, int32_t row_base) {

@@ -233,6 +233,8 @@ class ShardedLoop:
         self._upload()
         self.buf = [torch.zeros((p.n_rows_full + self.n_virtual_rows, self.SP), dtype=torch.float32, device=self.device) for _ in range(2)]
         self._iter_events = None
+        self.pipeline_chunks = 1          # > 1: the pipelined exchange (set_pipeline); 'auto' via make_sharded_loop: measured at the first forward
+        self._tune_pipeline_pending = False
 
     _layout = 'allgather'
 
@@ -414,6 +416,112 @@ class ShardedLoop:
                                              self.plan.row_base))
         return self.k, self.state_local, self.out_local
 
+    # ---- pipelined exchange: the halo kernel chunk by chunk, every chunk's rows on their way to the peers while the next is computed ----
+    def pipeline_supported(self) -> bool:
+        """Chunked launches need the own-range / halo split (the kernel that starts from partial sums), a homogeneous model, a state
+        width of at most 64 and no hub rows."""
+        return bool(self.overlap) and not self.composite and self.SP <= 64 and self.n_virtual_rows == 0 and type(self)._layout == 'allgather'
+
+    def set_pipeline(self, chunks: int):
+        """Cut the slice's rows into `chunks` tile-aligned ranges (the same on every rank: they are ranges of the nominal slice).  With
+        more than one chunk the exchange of an iteration is `chunks` point-to-point rounds, each started as soon as its rows are
+        written (`forward`), so it runs under the remaining chunks' kernels instead of behind the whole iteration kernel - at the
+        price of one kernel ramp-up per chunk.  Which count wins is a property of the machine: `make_sharded_loop(exchange='auto')`
+        measures it."""
+        chunks = int(chunks)
+        if chunks > 1 and not self.pipeline_supported(): chunks = 1
+        self.pipeline_chunks = max(1, chunks)
+        step = -(-self.plan.chunk // self.pipeline_chunks)
+        step = -(-step // 16) * 16                                   # whole 16-node tiles of the iteration kernel
+        bounds = list(range(0, self.plan.chunk, step)) + [self.plan.chunk]
+        self._chunk_rows = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)]
+        if self.pipeline_chunks > 1: self.transport = 'direct'        # (pieces of a slice travel as point-to-point messages)
+        return self.pipeline_chunks
+
+    def _iota(self):
+        if not hasattr(self, 'd_iota'): self.d_iota = torch.arange(max(self.n_local, 1), dtype=torch.int32, device=self.device)
+        return self.d_iota
+
+    def _iteration_split_rows(self, it: int, lo: int, hi: int, first: bool):
+        """Phase B of iteration `it` for the local rows [lo, hi) only (clipped to the rows this rank has)."""
+        hi = min(hi, self.n_local); lo = min(lo, hi)
+        gate, n_gate, stride = self._gate_args(it)
+        self.args.stream = nat.current_stream(self.device)
+        ids = self._iota()
+        nat.check(nat.lib().gnn_shard_iteration_split_rows(C.byref(self.args), C.byref(self.c_adj_halo), nat.ptr(self.agg_partial),
+                                                           nat.ptr(self.buf[it & 1]), nat.ptr(self.buf[(it + 1) & 1]), self.plan.row_base,
+                                                           gate, n_gate, stride, self._flag_out(it), it,
+                                                           C.c_void_p(ids.data_ptr() + 4 * lo), hi - lo, int(bool(first))))
+
+    def _exchange_rows(self, buf: torch.Tensor, lo: int, hi: int, last: bool):
+        """Rows [lo, hi) of every rank's slice of `buf` to everybody (asynchronous; `last`: through the end of the slice - the padding
+        rows of the short last rank and the FLAG row, complete once the rank's last chunk has run).  Returns the work handles."""
+        if self.world_size == 1: return []
+        p = self.plan
+        if last: hi = p.rows_per_slice
+        flat = buf.view(-1)
+        n = p.rows_per_slice * self.SP
+        a, b = lo * self.SP, hi * self.SP
+        ops = []
+        for off in range(1, self.world_size):
+            to, frm = (self.rank + off) % self.world_size, (self.rank - off) % self.world_size
+            ops.append(dist.P2POp(dist.isend, flat[self.rank * n + a:self.rank * n + b], to, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, flat[frm * n + a:frm * n + b], frm, group=self.group))
+        return list(dist.batch_isend_irecv(ops))
+
+    def _pipelined_iteration(self, it: int, partial_next: bool):
+        nxt = self.buf[(it + 1) & 1]
+        works = []
+        for ci, (lo, hi) in enumerate(self._chunk_rows):
+            self._iteration_split_rows(it, lo, hi, first=ci == 0)
+            works += self._exchange_rows(nxt, lo, hi, last=ci == len(self._chunk_rows) - 1)
+        if partial_next: self._partial(it + 1)                          # reads only the rows this rank has just written
+        self._exchange_finish(works, nxt, it)
+
+    def _tune_pipeline(self, state0_full, candidates=(1, 2, 4), reps: int = 3):
+        """Measured choice of the chunk count (collective): `reps` iterations of each candidate on the real buffers with the gates
+        forced open, the slowest rank's time decides, every rank keeps the same count.  Chunk count 1 runs with the transport
+        `pick_transport` chose."""
+        import time
+        m = self.model
+        base_transport = self.transport
+        flags, m.native_flags = m.native_flags, m.native_flags | nat.FLAG_NO_EARLY_EXIT
+        if hasattr(self, 'args'): self.args.flags = m.native_flags
+        times = {}
+        try:
+            for c in candidates:
+                self.transport = base_transport
+                if self.set_pipeline(c) != c and c != 1: continue
+                self._partial(0)
+                def one():
+                    if self.pipeline_chunks > 1: self._pipelined_iteration(0, True)
+                    else:
+                        self._iteration_split(0)
+                        w = self._exchange(self.buf[1], 0, async_op=True)
+                        self._partial(0)
+                        self._exchange_finish(w, self.buf[1], 0)
+                one()
+                self._sync()
+                if self.world_size > 1: dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                for _ in range(reps): one()
+                self._sync()
+                t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=self.device)
+                if self.world_size > 1: dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                times[c] = float(t)
+        finally:
+            m.native_flags = flags
+            if hasattr(self, 'args'): self.args.flags = flags
+        best = min(times, key=times.get)
+        self.transport = base_transport
+        self.set_pipeline(best)
+        self.pipeline_times = times
+        self._prepare(state0_full)                                      # the timed iterations overwrote the buffers
+        return best
+
+    def _sync(self):
+        if self.device.type == 'cuda': torch.cuda.synchronize(self.device)
+
     # ---- backend-independent orchestration ------------------------------------------------------------------------------
     def _load_state0(self, state0_full):
         p = self.plan
@@ -477,9 +585,15 @@ class ShardedLoop:
                 self._iteration(it)
                 self._exchange(self.buf[(it + 1) & 1], it)
             return self._finish(*self._output())
+        if self._tune_pipeline_pending and self.world_size > 1 and self.pipeline_supported():
+            self._tune_pipeline_pending = False
+            self._tune_pipeline(state0_full)
         # own-range arcs of iteration it+1 are summed while the exchange of iteration it is in flight
         if m.max_iteration > 0: self._partial(0)                        # state_0 is complete on every rank
         for it in range(m.max_iteration):
+            if self.pipeline_chunks > 1:
+                self._pipelined_iteration(it, it + 1 < m.max_iteration)
+                continue
             self._iteration_split(it)
             work = self._exchange(self.buf[(it + 1) & 1], it, async_op=True)
             if it + 1 < m.max_iteration: self._partial(it + 1)          # reads only the rows this rank has just written
@@ -803,6 +917,7 @@ def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, dev
     if pick == 'direct': sl.transport = 'direct'
     if exchange == 'auto' and measure and world_size > 1:
         sl.transport, sl.transport_times = pick_transport(sl)
+        sl._tune_pipeline_pending = True          # ... and whether to pipeline the exchange in 2 / 4 chunks: measured at the first forward()
     return sl
 
 

@@ -268,6 +268,16 @@ int gnn_shard_partial(const gnn_loop_args_t *args, const gnn_csr_t *adjacency_ow
 int gnn_shard_iteration_split(const gnn_loop_args_t *args, const gnn_csr_t *adjacency_halo, const float *agg_partial,
                               const float *state_in_full, float *state_out_full, int32_t row_base, const int32_t *gate,
                               int32_t n_gate, int32_t gate_stride, int32_t *flag_out, int32_t iteration);
+/* The same second phase for a SUB-RANGE of the shard's rows (`node_ids`: device array of n_ids ascending LOCAL node ids, e.g. a slice
+ * of an iota array): a rank cuts its rows into chunks, launches the halo kernel chunk by chunk and starts sending a chunk's rows to
+ * its peers as soon as that chunk is written, so the exchange runs under the remaining chunks instead of behind the whole kernel
+ * (gnnkeras_amd/distributed.py: pipeline_chunks).  `first_chunk` != 0: this call evaluates the iteration's gate and clears flag_out
+ * (every chunk ORs its "some node still moves" into it).  Per row the arithmetic is that of gnn_shard_iteration_split: the chunks
+ * together give the same bits.  Homogeneous models, state widths up to 64. */
+int gnn_shard_iteration_split_rows(const gnn_loop_args_t *args, const gnn_csr_t *adjacency_halo, const float *agg_partial,
+                                   const float *state_in_full, float *state_out_full, int32_t row_base, const int32_t *gate,
+                                   int32_t n_gate, int32_t gate_stride, int32_t *flag_out, int32_t iteration,
+                                   const int32_t *node_ids, int32_t n_ids, int32_t first_chunk);
 
 /* Keras Dropout / AlphaDropout (the `dropout_rate` / `dropout_pos` / `alphadropout` arguments of the reference MLP builder,
  * MLP.py:25-27, :60-66) in training mode, forward (backward = 0: y = the layer's output for input x) or backward (backward = 1:

@@ -116,6 +116,24 @@ class OracleShardedLoop(ShardedLoop):
         self._set_flag(dst, int(O.condition(0, new, own, 1, m.state_threshold, self.dtype)))
         self.k.fill_(it + 1)
 
+    def _iteration_split_rows(self, it, lo, hi, first):
+        """The pipelined exchange's chunk launch: phase B for the local rows [lo, hi) only; the flag row is cleared by the first chunk
+        and OR-ed into by every chunk; rows outside [lo, hi) of the destination buffer must not be touched."""
+        p, m = self.plan, self.model
+        src, dst = self.buf[it & 1], self.buf[(it + 1) & 1]
+        hi = min(hi, p.n_local); lo = min(lo, hi)
+        if first: self._clear_flag(dst)
+        if not self._gate_open(it) or hi == lo: return
+        full = src.numpy()[:, :self.S].astype(self.dtype)
+        own = self._own_rows_of(src)
+        agg = self.partial * self.scale[:, None] + O.sparse_dense_matmul_adjoint(*self.adj_halo, full, self.dtype)
+        comps = [own, p.nodes_local, agg, self.agg_nodes, self.agg_arcs] if m.state_vect_dim > 0 else [own, agg, self.agg_arcs]
+        new = O.mlp_apply(*m.net_state.spec(), np.concatenate(comps, axis=1)[lo:hi], False, self.dtype)
+        r0 = p.own_rows[0]
+        dst[r0 + lo:r0 + hi, :self.S] = torch.from_numpy(new.astype(np.float32))
+        if int(O.condition(0, new, own[lo:hi], 1, m.state_threshold, self.dtype)): self._set_flag(dst, 1)
+        self.k.fill_(it + 1)
+
     def _gate_open(self, it):
         p, src = self.plan, self.buf[it & 1]
         return any(int(src.view(torch.int32)[r * p.rows_per_slice + p.chunk, 0]) for r in range(self.world_size))
@@ -229,7 +247,7 @@ def _problem(threshold, d=6, max_it=12):
     return g, model, s0
 
 
-def _worker(rank, world, port, threshold, d, out_q, halo=False, overlap=False, transport=None, from_slice=False):
+def _worker(rank, world, port, threshold, d, out_q, halo=False, overlap=False, transport=None, from_slice=False, chunks=1):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -248,7 +266,17 @@ def _worker(rank, world, port, threshold, d, out_q, halo=False, overlap=False, t
             assert len(set(names)) == 1                              # every rank picked the same transport
         elif transport:
             sl.transport = transport
+        if chunks == 'tuned':                   # the measured choice of the chunk count (collective), as make_sharded_loop('auto') arms it
+            sl._tune_pipeline_pending = True
+        elif chunks > 1:
+            assert sl.pipeline_supported() and sl.set_pipeline(chunks) == chunks and sl.transport == 'direct'
+            assert len(sl._chunk_rows) >= 2 and sl._chunk_rows[0][0] == 0 and sl._chunk_rows[-1][1] == sl.plan.chunk
         k, state, out = sl.forward(s0)
+        if chunks == 'tuned':
+            assert set(sl.pipeline_times) == {1, 2, 4} and sl.pipeline_chunks in (1, 2, 4)
+            counts = [None] * world
+            dist.all_gather_object(counts, sl.pipeline_chunks)
+            assert len(set(counts)) == 1                                 # every rank kept the same chunk count
         out_q.put((rank, float(k), state.numpy(), out.numpy(), sl.plan.lo, sl.plan.hi))
     finally:
         dist.destroy_process_group()
@@ -277,6 +305,31 @@ def test_sharded_loop_matches_single_process_oracle(world, threshold, d, halo, o
     state = np.concatenate([r[2] for r in res])
     out = np.concatenate([r[3] for r in res])
     assert state.shape == st_ref.shape and out.shape == out_ref.shape
+    assert rel_err(state, st_ref) < 1e-6 and rel_err(out, out_ref) < 1e-6
+
+
+@pytest.mark.parametrize('world,chunks,threshold', [(2, 2, 0.0), (3, 4, 0.02), (2, 'tuned', 0.02), (3, 3, 0.0)])
+def test_pipelined_exchange_matches_single_process_oracle(world, chunks, threshold):
+    """The exchange of an iteration in several point-to-point rounds, each started as soon as its chunk of rows is written
+    (`ShardedLoop.set_pipeline`): real collectives over gloo, the chunk launches replaced by a NumPy stand-in that
+    computes exactly rows [lo, hi); ragged last rank (203 nodes over 2 / 3 ranks), early exit through the flag row that travels with
+    the LAST chunk, and the measured choice of the chunk count."""
+    d = 6
+    g, model, s0 = _problem(threshold, d)
+    seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False, device='cpu')
+    k_ref, st_ref, out_ref = oracle_loop(model, seq[0][0], s0, np.float64)
+    if threshold > 0: assert 1 < k_ref < model.max_iteration
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 601 + world * 17 + (7 if chunks == 'tuned' else chunks) * 3) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, threshold, d, q, False, True, None, False, chunks)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=180) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] == float(k_ref) for r in res)
+    state = np.concatenate([r[2] for r in res]); out = np.concatenate([r[3] for r in res])
     assert rel_err(state, st_ref) < 1e-6 and rel_err(out, out_ref) < 1e-6
 
 

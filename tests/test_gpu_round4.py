@@ -789,3 +789,50 @@ def test_thin_output_head_over_every_node_matches_autograd(d, bn, focus, T, loss
         assert 0 < k < K, f'no threshold with an early exit found: {seen}'
     model = cls(ns, no, d, K, thr)
     check_step(model, x, y, sw, s0, loss=loss)                # both orchestrations against the oracle
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the pipelined exchange's chunk launches (gnn_shard_iteration_split_rows) on the device
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode,chunks', [('average', 3), ('sum', 4), ('average', 2)])
+def test_chunked_halo_kernel_launches_give_the_bits_of_one_launch(mode, chunks):
+    """`ShardedLoop.set_pipeline(C)`: the halo kernel of an iteration launched over C tile-aligned row ranges (the `rows` form of the
+    wave-specialised kernel with a slice of an iota array) instead of once - per row the same arithmetic, so 4 emulated shards give
+    the SAME BITS as with one launch per iteration, and the oracle's result within the tolerance; the flag row is cleared by the first
+    chunk and OR-ed into by the others (early exit at the oracle's k)."""
+    from gnnkeras_amd.distributed import ShardedLoop, partition
+    from gnnkeras_amd.synth import er_graph_slice
+    N, E, d, R, K = 200_003, 2_000_000, 64, 4, 6
+    g = er_graph(N, E, aggregation_mode=mode, seed=21)
+    x = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+    ns, no = _starter('n', d, scale=0.25 if mode == 'average' else 0.02)
+    model = GNNnodeBased(ns, no, d, K, 0.05 if mode == 'average' else 0.0)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    slices = [er_graph_slice(N, E, lo, hi, aggregation_mode=mode, seed=21) for lo, hi in partition(N, R)[1]]
+    results = {}
+    for C_ in (1, chunks):
+        shards = [ShardedLoop(model, gs, r, R, 'cuda', overlap=True) for r, gs in enumerate(slices)]
+        for sl in shards:
+            assert sl.pipeline_supported() and sl.set_pipeline(C_) == C_
+            sl._load_state0(torch.from_numpy(s0).cuda()); sl._setup(); sl._initial_flags()
+        n = shards[0].plan.rows_per_slice * shards[0].SP
+        for it in range(K):
+            for sl in shards:
+                sl._partial(it)
+                if C_ == 1: sl._iteration_split(it)
+                else:
+                    for ci, (lo, hi) in enumerate(sl._chunk_rows): sl._iteration_split_rows(it, lo, hi, first=ci == 0)
+            for r, src in enumerate(shards):
+                piece = src.buf[(it + 1) & 1].view(-1)[r * n:(r + 1) * n]
+                for dst in shards:
+                    if dst is not src: dst.buf[(it + 1) & 1].view(-1)[r * n:(r + 1) * n].copy_(piece)
+        outs = [sl._output() for sl in shards]
+        torch.cuda.synchronize()
+        results[C_] = ([float(o[0]) for o in outs], torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs]))
+        del shards
+    (k1, st1, o1), (kc, stc, oc) = results[1], results[chunks]
+    assert k1 == kc == [float(k64)] * R
+    if mode == 'average': assert 1 < float(k64) < K                  # the early exit really happens
+    assert torch.equal(st1, stc) and torch.equal(o1, oc)
+    assert rel_err(stc.cpu().numpy(), st64) <= TOL and rel_err(oc.cpu().numpy(), o64) <= TOL

@@ -233,10 +233,10 @@ class ShardedLoop:
         self._upload()
         self.buf = [torch.zeros((p.n_rows_full + self.n_virtual_rows, self.SP), dtype=torch.float32, device=self.device) for _ in range(2)]
         self._iter_events = None
-        self.pipeline_chunks = 1          # > 1: the pipelined exchange (set_pipeline); 'auto' via make_sharded_loop: measured at the first forward
-        self._tune_pipeline_pending = False
 
     _layout = 'allgather'
+    pipeline_chunks = 1               # > 1: the pipelined exchange (set_pipeline); make_sharded_loop('auto') arms the measured choice
+    _tune_pipeline_pending = False    # ... which the first forward() makes (_tune_pipeline)
 
     # ---- device-specific pieces (the gloo/CPU tests override these with numpy stand-ins) ------------------------------------
     def _pool(self, out_nodes):

@@ -521,6 +521,8 @@ def emulate_shard(args):
         gs = er_graph_slice(N, E, *ranges[r], aggregation_mode=args.aggregation, seed=1234)
     t_slice = time.perf_counter() - t0
     sl = ShardedLoop(gnn, gs, r, R, device, overlap=not args.no_overlap)
+    if args.pipeline_chunks > 1 and sl.set_pipeline(args.pipeline_chunks) != args.pipeline_chunks:
+        raise SystemExit('--pipeline-chunks: this shard does not take chunk launches (composite model, no overlap split, hub rows)')
     torch.cuda.synchronize()
     t_plan = time.perf_counter() - t0
     gen = torch.Generator(device=device); gen.manual_seed(1)
@@ -532,6 +534,7 @@ def emulate_shard(args):
     print(json.dumps({
         'emulated_shard': f'{r}/{R}', 'workload': f'{args.workload.upper()} Erdos-Renyi {N} nodes / {E} arcs, state_dim={d}, {args.aggregation}',
         'n_local': sl.n_local, 'e_local': sl.e_local, 'e_own_range': getattr(sl, 'e_own', None), 'overlap_split': bool(sl.overlap),
+        'pipeline_chunks': sl.pipeline_chunks,
         'per_iteration_ms': {'kernel': 1e3 * prof['kernel_s'],
                              'note': 'own-range partial + halo kernel (or the one fused kernel with --no-overlap) of rank r, gates open, '
                                      'no collective: the exchange is not measurable on one GPU'},
@@ -563,6 +566,8 @@ def main():
                     help='N>1 state exchange: whole slices by RCCL all-gather / by concurrent point-to-point pairs, or compacted halos '
                          '(all-to-all); auto = halo for graphs with locality, else the faster whole-slice transport, measured at start-up')
     ap.add_argument('--no-overlap', action='store_true', help='N>1: exchange strictly after the iteration kernel (no own-range / halo split)')
+    ap.add_argument('--pipeline-chunks', type=int, default=1,
+                    help='--emulate-shard: launch the halo kernel in this many chunk launches (the pipelined exchange, distributed.py set_pipeline)')
     ap.add_argument('--emulate-shard', default=None, metavar='r/R',
                     help="one GPU, no process group: build rank r's plan of an R-rank job from its own graph slice and time its "
                          "iteration kernels (own-range partial + halo kernel) against a full-size state buffer; prints plan-build "

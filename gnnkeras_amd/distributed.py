@@ -634,14 +634,19 @@ class ShardedLoop:
                 return 1e-3 * a.elapsed_time(b) / reps
 
             def kernels():
-                if self.overlap: self._partial(0); self._iteration_split(0)
+                if self.overlap and self.pipeline_chunks > 1:
+                    self._partial(0)
+                    for ci, (lo, hi) in enumerate(self._chunk_rows): self._iteration_split_rows(0, lo, hi, first=ci == 0)
+                elif self.overlap: self._partial(0); self._iteration_split(0)
                 else: self._iteration(0)
 
             def exchange():
                 self._exchange_finish(self._exchange(self.buf[1], 0, async_op=True), self.buf[1], 0)
 
             def both():
-                if self.overlap:
+                if self.overlap and self.pipeline_chunks > 1:
+                    self._pipelined_iteration(0, True)
+                elif self.overlap:
                     self._iteration_split(0)
                     w = self._exchange(self.buf[1], 0, async_op=True)
                     self._partial(0)

@@ -580,14 +580,18 @@ class ShardedLoop:
     def forward(self, state0_full=None):
         m = self.model
         self._prepare(state0_full)
+        if self._tune_pipeline_pending and self.world_size > 1:
+            self._tune_pipeline_pending = False
+            # chunk rounds are sized messages between every pair of ranks: ALL ranks pipeline, or none does (a rank with hub rows or
+            # without the split kernel cannot) - agreed on collectively before anything is timed
+            ok = torch.tensor([1 if (self.overlap and self.pipeline_supported()) else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok) == 1: self._tune_pipeline(state0_full)
         if not self.overlap:
             for it in range(m.max_iteration):
                 self._iteration(it)
                 self._exchange(self.buf[(it + 1) & 1], it)
             return self._finish(*self._output())
-        if self._tune_pipeline_pending and self.world_size > 1 and self.pipeline_supported():
-            self._tune_pipeline_pending = False
-            self._tune_pipeline(state0_full)
         # own-range arcs of iteration it+1 are summed while the exchange of iteration it is in flight
         if m.max_iteration > 0: self._partial(0)                        # state_0 is complete on every rank
         for it in range(m.max_iteration):

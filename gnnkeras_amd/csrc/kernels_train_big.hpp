@@ -174,8 +174,11 @@ template <> struct BFrag<8> { float v[8]; __device__ __forceinline__ void load(c
 #define TB_PREFETCH 0                  // 1 (experiment): the next tile's rows are requested before this tile's MFMAs.  162 VGPRs = 3 waves per SIMD
                                        // instead of 4: SLOWER, 227 -> 247 us per 1 M rows (scripts/micro/rowgemm_bench.hip): the waves hide more than the prefetch
 #endif
+#ifndef TB_FWD_MIN_WAVES
+#define TB_FWD_MIN_WAVES 4             // waves per SIMD the register allocation is held to (experiment knob of scripts/micro/rowgemm_bench.hip)
+#endif
 template <int SQ, int NCT>
-__global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : 4) k_train_fwd(TrainFwdArgs a) {
+__global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WAVES) k_train_fwd(TrainFwdArgs a) {
     if (gate_closed(a.gate)) return;
     constexpr int NQ = 2 * SQ + 2;                    // 16-column chunks of an input row: state, agg, constant inputs (32 columns)
     constexpr int HP = 16 * NCT;

@@ -113,7 +113,7 @@ class _LoopModel:
         self._check_kwargs('predict', kwargs)
         if len(sequencer) == 0: return np.zeros((0, 0), np.float32)
         dev = self._batch_device(sequencer[0][0])
-        outs = self._with_recovery(lambda: [o for _, o in self._forward_batches(sequencer, dev)])
+        outs = self._with_recovery(lambda: [o for _, o in self._forward_batches(sequencer, dev)], dev)
         return torch.cat(outs, dim=0).cpu().numpy()
 
     def evaluate(self, sequencer, return_dict: bool = False, verbose=0, callbacks=None, **kwargs):
@@ -128,7 +128,7 @@ class _LoopModel:
         # every forward first (grouped launches / side streams), then ONE loss / metric evaluation over all samples: the sums
         # Keras accumulates batch by batch are the same sums, and a data set of small batches costs a handful of launches
         # instead of a dozen per batch
-        preds = self._with_recovery(lambda: [p_ for _, p_ in self._forward_batches(sequencer, dev)])
+        preds = self._with_recovery(lambda: [p_ for _, p_ in self._forward_batches(sequencer, dev)], dev)
         p = torch.cat(preds, dim=0) if len(preds) > 1 else preds[0]
         # targets / sample weights of the whole sequencer, concatenated once per set of batches (a few sequencers per model:
         # training, validation, test); keyed by the batch list the sequencer rebuilds whenever its batches change
@@ -244,7 +244,7 @@ class _LoopModel:
                 'shared with other long-running work?; wave-specialised kernel: a lost LDS hand-off): state and output are '
                 'invalid. Set model.native_flags = FLAG_FUSED_GEN2 or lower inference_streams')
 
-    def _with_recovery(self, forwards):
+    def _with_recovery(self, forwards, device=None):
         """`forwards()` (every forward of a predict() / evaluate() walk) with the kernels' in-launch waits checked where the host
         synchronises anyway.  The whole-loop kernels need all their workgroups resident at once and wait for each other with a
         bound (GNN_WAIT_MS); on a GPU shared with other long-running work such a wait can expire - reported as k < 0, results
@@ -252,14 +252,15 @@ class _LoopModel:
         (`FLAG_FUSED_GEN2`), batch by batch, on the caller's stream - slower, always completes - with a `RuntimeWarning`.  A second
         failure (it would be a lost hand-off inside a workgroup: a bug, not contention) raises `NativeError`."""
         self._k_seen = []
-        dev_rng = torch.cuda.get_rng_state() if torch.cuda.is_available() else None       # (host-side: seed + offset, no synchronisation)
+        on_gpu = device is not None and torch.device(device).type == 'cuda'
+        dev_rng = torch.cuda.get_rng_state(device) if on_gpu else None       # (host-side: seed + offset, no synchronisation)
         res = forwards()
         try:
             self._check_k()
             return res
         except nat.NativeError:
             pass
-        if dev_rng is not None: torch.cuda.set_rng_state(dev_rng)      # the repeated walk draws the same state_0 (GNN.py:257) as the failed one
+        if dev_rng is not None: torch.cuda.set_rng_state(dev_rng, device)      # the repeated walk draws the same state_0 (GNN.py:257) as the failed one
         import warnings
         warnings.warn('a bounded in-launch wait of the whole-loop kernels expired (GPU shared with other long-running work?): '
                       're-running these forwards with one launch per iteration', RuntimeWarning, stacklevel=3)

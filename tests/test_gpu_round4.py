@@ -105,16 +105,24 @@ _DEEP_USERS = {'test_c3_at_the_timed_depth_every_path[average]': 'c3_average', '
                'test_c5_at_the_timed_depth_vs_fp64_oracle[composite_average]': 'c5_composite_average'}
 
 
+def start_deep_oracles(test_names):
+    """Start the oracle jobs the named deep tests need (once).  tests/conftest.py calls this when the collection of a GPU session is
+    finished, so the float64 oracles run on worker threads WHILE the rest of the suite runs and are (mostly) done when the deep tests
+    come up; a deep test selected on its own starts its job at its first line."""
+    if _DEEP_FUTURES: return
+    selected = {_DEEP_USERS[n] for n in test_names if n in _DEEP_USERS}
+    if not selected: return
+    from concurrent.futures import ThreadPoolExecutor
+    torch.cuda.init()
+    pool = ThreadPoolExecutor(max_workers=len(_DEEP_JOBS))
+    for name in sorted(selected, key=lambda n: n != 'c4'):                    # the longest first
+        _DEEP_FUTURES[name] = pool.submit(_DEEP_JOBS[name])
+    pool.shutdown(wait=False)
+
+
 def _deep(request):
-    """The oracle results of the calling deep test; the first call starts the jobs of every SELECTED deep test."""
-    if not _DEEP_FUTURES:
-        from concurrent.futures import ThreadPoolExecutor
-        torch.cuda.init()
-        pool = ThreadPoolExecutor(max_workers=len(_DEEP_JOBS))
-        selected = {_DEEP_USERS[it.name] for it in request.session.items if it.name in _DEEP_USERS}
-        for name in sorted(selected, key=lambda n: n != 'c4'):                # the longest first
-            _DEEP_FUTURES[name] = pool.submit(_DEEP_JOBS[name])
-        pool.shutdown(wait=False)
+    """The oracle results of the calling deep test."""
+    start_deep_oracles([it.name for it in request.session.items])
     return _DEEP_FUTURES[_DEEP_USERS[request.node.name]].result()
 
 

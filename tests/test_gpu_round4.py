@@ -112,12 +112,28 @@ def start_deep_oracles(test_names):
     if _DEEP_FUTURES: return
     selected = {_DEEP_USERS[n] for n in test_names if n in _DEEP_USERS}
     if not selected: return
-    from concurrent.futures import ThreadPoolExecutor
     torch.cuda.init()
-    pool = ThreadPoolExecutor(max_workers=len(_DEEP_JOBS))
     for name in sorted(selected, key=lambda n: n != 'c4'):                    # the longest first
-        _DEEP_FUTURES[name] = pool.submit(_DEEP_JOBS[name])
-    pool.shutdown(wait=False)
+        _DEEP_FUTURES[name] = _Job(_DEEP_JOBS[name])
+
+
+class _Job:
+    """A function on a DAEMON thread (a session that stops early - `-x`, Ctrl-C - must not wait minutes for oracle runs nobody will
+    read: the workers of a ThreadPoolExecutor are joined at interpreter exit); `result()` joins and re-raises."""
+
+    def __init__(self, fn):
+        import threading
+        self._out, self._err = None, None
+        def run():
+            try: self._out = fn()
+            except BaseException as e: self._err = e
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def result(self):
+        self._thread.join()
+        if self._err is not None: raise self._err
+        return self._out
 
 
 def _deep(request):

@@ -243,22 +243,26 @@ class DataParallel:
         m = self.model
         n = len(sequencer)
         plan = m._group_plan(sequencer, device) if n > 1 else None
-        outs = {}
-        m._k_seen = []
-        if plan is None:
-            mine = [i for i in range(n) if i % self.world == self.rank]
-            for j, out in m._batches_concurrently(len(mine), lambda j: m.call(sequencer[mine[j]][0], training=False), device,
-                                                  m._round_width(sequencer, device) if mine else 1):
-                outs[mine[j]] = out
-        else:
-            mine = [plan[li] for li in range(len(plan)) if li % self.world == self.rank]
-            for li, out in m._run_plan(mine, lambda li: m._plan_launch(sequencer, mine[li]), device):
-                r0 = 0
-                for i in mine[li]:
-                    rows = int(sequencer[i][1].shape[0])
-                    outs[i] = out[r0:r0 + rows]; r0 += rows
-        m._check_k()
-        return outs, plan
+        owner = self._owner_of(n, plan)
+        my_batches = [i for i in range(n) if owner[i] == self.rank]
+        my_launches = None if plan is None else [plan[li] for li in range(len(plan)) if li % self.world == self.rank]
+
+        def run():
+            outs = {}
+            if my_launches is None or not m.group_batches:
+                # (no plan - or the recovery walk of `_with_recovery`, which switches grouping off: the SAME batches, one by one)
+                for j, out in m._batches_concurrently(len(my_batches), lambda j: m.call(sequencer[my_batches[j]][0], training=False), device,
+                                                      m._round_width(sequencer, device) if my_batches else 1):
+                    outs[my_batches[j]] = out
+            else:
+                for li, out in m._run_plan(my_launches, lambda li: m._plan_launch(sequencer, my_launches[li]), device):
+                    r0 = 0
+                    for i in my_launches[li]:
+                        rows = int(sequencer[i][1].shape[0])
+                        outs[i] = out[r0:r0 + rows]; r0 += rows
+            return outs
+        # an expired cross-workgroup wait on THIS rank's launches is repaired on this rank (no collective in here)
+        return m._with_recovery(run, device), plan
 
     def _owner_of(self, n, plan):
         if plan is None: return [i % self.world for i in range(n)]

@@ -276,23 +276,24 @@ def training_section(device, graph_x, d):
     from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
     graphs = load_graphs()
     out = {}
-    for name, dd, it in (('mutag_d32_k50', 32, 50), ('mutag_starter_config', 0, 5)):
+    # (BASELINE C1 quotes batch = 32; the reference's starter.py itself defaults to batch_size = 1000: 4 training batches of ~30 k nodes)
+    for name, dd, it, bs in (('mutag_d32_k50', 32, 50, 32), ('mutag_starter_config', 0, 5, 32), ('mutag_starter_py_batch_1000', 0, 5, 1000)):
         ns, no = starter_nets(dd, device, 'g')
         gnn = GNNgraphBased(ns, no, dd, it, 0.01)
         gnn.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['accuracy'])
-        seq = MultiGraphSequencer(graphs[:32 * 20], 'g', 'average', 32, shuffle=False, device=device)
+        seq = MultiGraphSequencer(graphs[:bs * 20], 'g', 'average', bs, shuffle=False, device=device)
         for i in range(len(seq)): gnn.train_step(seq[i], seed=0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(len(seq)): r = gnn.train_step(seq[i], seed=0)
         torch.cuda.synchronize(); t_step = (time.perf_counter() - t0) / len(seq)
-        tr = MultiGraphSequencer(graphs[:-868], 'g', 'average', 32, shuffle=True, device=device)
-        va = MultiGraphSequencer(graphs[-868:], 'g', 'average', 32, shuffle=False, device=device)
+        tr = MultiGraphSequencer(graphs[:-868], 'g', 'average', bs, shuffle=True, device=device)
+        va = MultiGraphSequencer(graphs[-868:], 'g', 'average', bs, shuffle=False, device=device)
         gnn.fit(tr, epochs=1, validation_data=va, verbose=0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         gnn.fit(tr, epochs=2, validation_data=va, verbose=0)
         torch.cuda.synchronize(); t_epoch = (time.perf_counter() - t0) / 2
         out[name] = {'train_step_ms_per_batch': 1e3 * t_step, 'k': int(r['k']), 'fit_epoch_ms': 1e3 * t_epoch,
-                     'epoch': f'{len(tr)} training steps of 32 graphs + validation on 868 graphs + reshuffle / device re-merge'}
+                     'epoch': f'{len(tr)} training steps of {bs} graphs + validation on 868 graphs + reshuffle / device re-merge'}
     try:
         out['composite_small_graphs'] = composite_training_section(device)
     except Exception as e:                            # never lose the other numbers to this one

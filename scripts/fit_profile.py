@@ -9,10 +9,11 @@ from gnnkeras_amd.Models.GNN import GNNgraphBased
 from gnnkeras_amd.Models.training import Adam
 from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
 d, it = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 5)
+bs = int(sys.argv[3]) if len(sys.argv) > 3 else 32            # (the reference's starter.py default is 1000)
 gs = load_graphs()
 for g in gs: g.setAggregation('average')
-tr = MultiGraphSequencer(gs[:-868], 'g', 'average', 32, shuffle=True, device='cuda')
-va = MultiGraphSequencer(gs[-868:], 'g', 'average', 32, shuffle=False, device='cuda')
+tr = MultiGraphSequencer(gs[:-868], 'g', 'average', bs, shuffle=True, device='cuda')
+va = MultiGraphSequencer(gs[-868:], 'g', 'average', bs, shuffle=False, device='cuda')
 inp, lay = get_inout_dims('state', 14, 3, 2, 'g', d); ns = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0)
 inp, lay = get_inout_dims('output', 14, 3, 2, 'g', d); no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
 gnn = GNNgraphBased(ns, no, d, it, 0.01)
@@ -20,7 +21,7 @@ gnn.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['acc
 gnn.fit(tr, epochs=1, validation_data=va, verbose=0)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 gnn.fit(tr, epochs=3, validation_data=va, verbose=0)
-torch.cuda.synchronize(); print(f'd={d} it={it}: fit epoch {1e3 * (time.perf_counter() - t0) / 3:.1f} ms ({len(tr)} steps)')
+torch.cuda.synchronize(); print(f'd={d} it={it} batch_size={bs}: fit epoch {1e3 * (time.perf_counter() - t0) / 3:.1f} ms ({len(tr)} steps)')
 # steps alone, host launch time vs completion
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(len(tr)): gnn.train_step(tr[i])

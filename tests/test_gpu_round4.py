@@ -860,3 +860,25 @@ def test_chunked_halo_kernel_launches_give_the_bits_of_one_launch(mode, chunks):
     if mode == 'average': assert 1 < float(k64) < K                  # the early exit really happens
     assert torch.equal(st1, stc) and torch.equal(o1, oc)
     assert rel_err(stc.cpu().numpy(), st64) <= TOL and rel_err(oc.cpu().numpy(), o64) <= TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference starter.py's OWN defaults: batch_size = 1000 (BASELINE C1 quotes 32), state_vect_dim = 0, 5 iterations
+# ----------------------------------------------------------------------------------------------------------------------
+def test_starter_py_defaults_batch_of_1000_graphs(mutag_graphs):
+    """/root/reference/starter.py:32-45: dim_state = 0, max_iter = 5, state_threshold = 0.01, batch_size = 1000, 'average', graph focus.
+    One merged batch of 1000 MUTAG graphs (~30 k nodes): the forward on every device path against the float32 / float64 oracle, and one
+    training step (both orchestrations) against torch autograd in float64."""
+    from test_gpu_parity import check
+    from test_gpu_training import check_step
+    gs = [g.copy() for g in mutag_graphs[:1000]]
+    for g in gs: g.setAggregation('average')
+    seq = MultiGraphSequencer(gs, 'g', 'average', 1000, shuffle=False)
+    x, y, sw = seq[0]
+    assert len(seq) == 1 and x[0].shape[0] > 25_000
+    ns, no = _starter('g', 0)
+    model = GNNgraphBased(ns, no, 0, 5, 0.01)
+    k, st, o = check(model, x, None)
+    assert o.shape == (1000, 2)
+    model.native_flags = 0
+    check_step(model, x, y, sw, None)

@@ -84,8 +84,22 @@ def load_graphs(path: str = DATA, aggregation_mode: str = 'sum', limit: int | No
                         aggregation_mode=aggregation_mode) for i in range(n)]
 
 
+def load_composite_graphs(path: str = DATA, aggregation_mode: str = 'sum', limit: int | None = None):
+    """`composite_graphs` of the reference module (`load_MUTAG.py:57-60`, what `starter_composite.py` trains on): every MUTAG graph as
+    a heterogeneous graph with ONE node type - `type_mask` all ones [n, 1], label width = the 14 label columns.  (The reference passes
+    the widths as `dim_node_features=`, a keyword its `CompositeGraphObject.__init__` does not have - `composite_graph_class.py:20`
+    names it `dim_node_label` - so that line cannot run at the reference's HEAD; the objects built here are what it means.)"""
+    from .composite_graph_class import CompositeGraphObject
+    return [CompositeGraphObject(arcs=g.arcs, nodes=g.nodes, targets=g.targets, focus='g',
+                                 type_mask=np.ones((g.nodes.shape[0], 1), dtype=bool), dim_node_label=(g.nodes.shape[1],),
+                                 aggregation_mode=aggregation_mode)
+            for g in load_graphs(path, aggregation_mode, limit)]
+
+
 def __getattr__(name):
-    # `from load_MUTAG import graphs` (reference starter.py:58) keeps working, lazily.
+    # `from load_MUTAG import graphs` (reference starter.py:58) / `composite_graphs` (starter_composite.py) keep working, lazily.
     if name == 'graphs':
         return load_graphs()
+    if name == 'composite_graphs':
+        return load_composite_graphs()
     raise AttributeError(name)

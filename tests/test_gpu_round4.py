@@ -882,3 +882,53 @@ def test_starter_py_defaults_batch_of_1000_graphs(mutag_graphs):
     assert o.shape == (1000, 2)
     model.native_flags = 0
     check_step(model, x, y, sw, None)
+
+
+def test_starter_composite_py_defaults(mutag_graphs):
+    """/root/reference/starter_composite.py: `load_MUTAG.composite_graphs` (every graph typed with ONE node type), graph focus,
+    dim_state = 10, max_iter = 5, state_threshold = 0.01, batch_size = 500, 'average': the composite forward against the oracle (and
+    against the homogeneous model on the same graphs: T = 1 composite is the homogeneous loop up to the input column order), one
+    in-library composite training step against the building blocks."""
+    from gnnkeras_amd.load_MUTAG import load_composite_graphs
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNgraphBased
+    from gnnkeras_amd.Models.training import LoopTrainer, SGD
+    cgs = load_composite_graphs(limit=500)
+    for g in cgs: g.setAggregation('average')
+    seq = CompositeMultiGraphSequencer(cgs, 'g', 'average', 500, shuffle=False)
+    x, y, sw = seq[0]
+    assert len(seq) == 1 and _np(x[3]).reshape(1, -1).all()
+    d = 10
+    inp, lay = get_inout_dims('state', (14,), 3, 2, 'g', d)
+    ns = [MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0)]
+    no = MLP((d,), [2], 'softmax', 'glorot_normal', 'glorot_normal', rng=1)       # (starter_composite.py:82: input_dim=(dim_state,))
+    model = CompositeGNNgraphBased(ns, no, d, 5, 0.01)
+    N = x[0].shape[0]
+    s0 = np.random.default_rng(2).normal(0, 0.1, (N, d)).astype(np.float32)
+    k64, st64, o64 = oracle_composite_loop(model, x, s0, np.float64)
+    for flags in (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2, nat.FLAG_FUSED_GEN4):
+        model.native_flags = flags
+        k, st, o = model.Loop(*model.process_inputs(x), state0=dev(s0))
+        assert float(k) == float(k64)
+        assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL and o.shape == (500, 2)
+    model.native_flags = 0
+    model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+    from oracle import torch_train
+    nodes, arcs, dnl, tmask, sm, om_, cas, adj, an, ng = x
+    mask = np.logical_and(_np(sm).reshape(-1), _np(om_).reshape(-1))
+    want = torch_train.composite_train_step(
+        _np(nodes), _np(arcs), _np(dnl).reshape(-1), _np(tmask).reshape(1, -1), [_triple(c) for c in cas], _triple(adj), _triple(an),
+        _triple(ng), mask, net_state=[n_.spec() for n_ in ns], net_output=no.spec(), state_vect_dim=d, max_iteration=5,
+        state_threshold=0.01, focus='g', state0=s0, y=_np(y), sample_weight=_np(sw), loss='categorical_crossentropy')
+    allref = want['grads_state'][0] + want['grads_output']
+    scale = max(float(np.max(np.abs(r))) for r in allref)
+    for native in (True, False):
+        tr = LoopTrainer(model); tr.use_native_step = native
+        assert tr._native_step_applies(y) == native
+        res = tr.train_step(x, y, sw, state0=dev(s0), apply=False)
+        assert res['k'] == want['k'] == float(k64)
+        assert abs(float(res['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))
+        got = tr.gs[0].gradients() + tr.go.gradients()
+        assert len(got) == len(allref)
+        for g_, r in zip(got, allref):
+            err = float(np.max(np.abs(g_.cpu().numpy() - r)))
+            assert err <= 2e-5 * max(float(np.max(np.abs(r))), 1e-12) or err <= 2e-5 * scale

@@ -317,3 +317,19 @@ def test_fit_evaluate_predict_reject_unknown_keyword_arguments():
         def on_train_end(self, logs): seen.append('end')
     m.fit([], epochs=5, verbose=0, callbacks=[CB()])
     assert seen == [('model', True), 'begin', ('epoch', 0), ('epoch', 1), 'end']
+
+
+def test_mutag_composite_graphs_are_the_same_graphs_with_one_node_type(mutag_graphs):
+    """`load_MUTAG.composite_graphs` (reference load_MUTAG.py:57-60, what starter_composite.py trains on): one node type, the label width
+    as the single `dim_node_label` entry, the composite adjacency of that type IS the adjacency."""
+    from gnnkeras_amd.load_MUTAG import load_composite_graphs
+    from gnnkeras_amd.Sequencers.GraphSequencers import CompositeMultiGraphSequencer
+    cgs = load_composite_graphs(limit=7)
+    assert len(cgs) == 7
+    for c, g in zip(cgs, mutag_graphs):
+        assert c.type_mask.shape == (g.nodes.shape[0], 1) and c.type_mask.all() and list(c.DIM_NODE_LABEL) == [g.nodes.shape[1]]
+        assert np.array_equal(c.nodes, g.nodes) and np.array_equal(c.arcs, g.arcs) and np.array_equal(c.targets, g.targets)
+        assert len(c.CompositeAdjacencies) == 1
+        assert np.array_equal(c.CompositeAdjacencies[0].toarray(), c.Adjacency.toarray())
+    x, y, sw = CompositeMultiGraphSequencer(cgs, 'g', 'average', 7, shuffle=False)[0]
+    assert len(x) == 10 and y.shape == (7, 2)

@@ -38,6 +38,7 @@ namespace gnn {
 // k_train_bwd_dx<1, 2> without BatchNormalization read its accumulators two instructions after the MFMA that wrote them and
 // returned stale registers (scripts/micro/rowgemm_check.hip reproduces it).  Explicit wait states after the MFMA loop.
 #define TB_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TB_WAVES = 8;              // waves per workgroup (512 threads; launch bound 4 waves per SIMD = 2 workgroups per CU at <= 128 VGPRs)
 
 // ---- neighbour sum + column statistics of the result -------------------------------------------------------------------------------
@@ -174,6 +175,10 @@ template <> struct BFrag<8> { float v[8]; __device__ __forceinline__ void load(c
 #define TB_PREFETCH 0                  // 1 (experiment): the next tile's rows are requested before this tile's MFMAs.  162 VGPRs = 3 waves per SIMD
                                        // instead of 4: SLOWER, 227 -> 247 us per 1 M rows (scripts/micro/rowgemm_bench.hip): the waves hide more than the prefetch
 #endif
+#ifndef TB_ROLL
+#define TB_ROLL 0                      // 1 (experiment): rolling refill of the row registers (see the MFMA loop): memory stops being waited for (114 us with the
+                                       // MFMAs compiled out against 185), the whole kernel does not get faster (225 against 223 us): f32 MFMA + epilogue issue time
+#endif
 #ifndef TB_FWD_MIN_WAVES
 #define TB_FWD_MIN_WAVES 4             // waves per SIMD the register allocation is held to (experiment knob of scripts/micro/rowgemm_bench.hip)
 #endif
@@ -233,6 +238,20 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
 #if TB_PREFETCH
     fetch(blockIdx.x * TB_WAVES + wave, A);
 #endif
+    auto fetch1 = [&](int t, int q, f32x4 &dst) {       // chunk q of this lane's row of tile t (TB_ROLL: a register is refilled when its last reader has issued)
+        const int row_ = 16 * t + c;
+        const bool in_ = t < n_tiles && row_ < a.M;
+        if (q < SQ) dst = buf_ld_f32x4(r_s, in_ ? ((unsigned)row_ * (unsigned)a.ld_state + 16u * q + 4u * g) * 4u : BUF_OFF);
+        else if (q < 2 * SQ) dst = buf_ld_f32x4(r_a, in_ ? ((unsigned)row_ * (unsigned)a.ld_agg + 16u * (q - SQ) + 4u * g) * 4u : BUF_OFF);
+        else dst = buf_ld_f32x4(r_x, in_ ? ((unsigned)row_ * 32u + 16u * (q - 2 * SQ) + 4u * g) * 4u : BUF_OFF);
+    };
+#if TB_ROLL
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {                   // (the loop's own issue order: one counted wait at the loop head serves both paths)
+        const int q = qq < NQ - SQ ? SQ + qq : qq - (NQ - SQ);
+        fetch1(blockIdx.x * TB_WAVES + wave, q, A[q]);
+    }
+#endif
 #pragma unroll 1
     for (int t = blockIdx.x * TB_WAVES + wave; t < n_tiles; t += t_step) {
         const int row = 16 * t + c;                     // this lane's row: input chunks, output chunks, old state
@@ -240,7 +259,7 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
 #if TB_PREFETCH
         f32x4 An[NQ];
         fetch(t + t_step, An);                          // (in flight while this tile multiplies)
-#else
+#elif !TB_ROLL
         fetch(t, A);
 #endif
         f32x4 acc[NCT];
@@ -249,6 +268,23 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
 #if (TB_ABL & 1)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q % NCT] += A[q];
+#elif TB_ROLL
+        // agg and constants chunks first, each register refilled with the NEXT tile's chunk as soon as its sixteen MFMAs have issued (the
+        // load is in flight for a whole trip); the state chunks last: the predicate reads them again, they are refilled after the epilogue
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) {
+            const int q = qq < NQ - SQ ? SQ + qq : qq - (NQ - SQ);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                BFrag<NCT> w;
+                w.load(Wl + (((4 * q + e) * 4 + g) * 16 + c) * NCT);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[ct], A[q][e], acc[ct], 0, 0, 0);
+            }
+            if (q >= SQ) fetch1(t + t_step, q, A[q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        TB_MFMA_DRAIN();
 #else
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -293,6 +329,9 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
 #if TB_PREFETCH
 #pragma unroll
         for (int q = 0; q < NQ; ++q) A[q] = An[q];
+#elif TB_ROLL
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) fetch1(t + t_step, q, A[q]);
 #endif
     }
     // ---- predicate flag, k, statistics partial of this workgroup ---------------------------------------------------------------------
@@ -317,6 +356,264 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
         if (blockIdx.x == 0 && a.pred_k) *a.pred_k = a.pred_kval;
     }
 }
+
+#ifdef TB_STAMPS                        // debug build of scripts/micro: clock stamps of one wave (block 0, wave 0), 4 per trip
+__device__ unsigned long long g_tb_stamps[4 * 64];
+#define TB_STAMP(i_) do { if (blockIdx.x == 0 && wave == 0 && trip_ < 64) { const unsigned long long c_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_tb_stamps[4 * trip_ + (i_)] = c_; } } while (0)
+#define TB_STAMP_DEP(i_, r_) do { asm volatile("" : "+v"(r_)); TB_STAMP(i_); } while (0)
+#define TB_TRIP_END() (++trip_)
+#else
+#define TB_STAMP(i_) do {} while (0)
+#define TB_STAMP_DEP(i_, r_) do {} while (0)
+#define TB_TRIP_END() do {} while (0)
+#endif
+
+// the activation as a template parameter: no branch inside an instruction stream that is to be interleaved (a basic-block boundary is
+// a scheduling boundary for hipcc)
+template <int ACT> __device__ __forceinline__ float activate1(float v) {
+    if (ACT == GNN_ACT_RELU) return fmaxf(v, 0.0f);
+    // (selu / elu as a sum of their two arms - one of them is an exact zero - so that hipcc cannot put the exponential behind a branch)
+    if (ACT == GNN_ACT_SELU) return 1.0507009873554805f * fmaxf(v, 0.0f) + (1.0507009873554805f * 1.6732632423543772f) * (expf(fminf(v, 0.0f)) - 1.0f);
+    if (ACT == GNN_ACT_TANH) return tanhf(v);
+    if (ACT == GNN_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (ACT == GNN_ACT_ELU) return fmaxf(v, 0.0f) + (expf(fminf(v, 0.0f)) - 1.0f);
+    if (ACT == GNN_ACT_SOFTPLUS) return v > 20.0f ? v : log1pf(expf(v));
+    return v;
+}
+
+// ---- ... and on the bf16 matrix cores, every f32 operand split into three bf16 terms -------------------------------------------------
+// scripts/micro/mfma_valu_overlap.hip: the f32-input MFMAs run on the SIMD's f32 FMA lanes - a wave's VALU instructions do not issue in
+// their shadow (2 MFMAs + 16 v_fma per loop trip: 208 cycles against 128 / 76 alone), so the three dense training kernels cost MFMA time
+// PLUS epilogue time whichever way they are scheduled (tried this round, profiles/r04_notes.txt: 32-row tiles on the 32x32x2 form 237 us
+// per 1 M rows, the same with the epilogue of tile t - 1 interleaved into tile t's MFMA stream 229, against 225 for k_train_fwd).
+// The bf16 matrix cores are a separate pipe at 16x the rate.  x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi),
+// lo = bf16(x - hi - mid): exact (8 + 8 + 8 significand bits, signed), and  x w = hi wh + (hi wm + mid wh) + (mid wm + hi wl + lo wh) + O(2^-24 |x w|):
+// six v_mfma_f32_32x32x16_bf16 per 16 columns of k, each product exact in f32, f32 accumulation - the accuracy of an f32 product chain
+// (not its bits; scripts/micro/rowgemm_check.hip: max error against a float64 loop 0.5-1.4e-6 for both forms).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// Round to NEAREST at both levels (v_cvt_pk_bf16_f32): with truncation every dropped term has the sign of its product, a relative bias of
+// ~3e-8 that the column statistics and the BatchNormalization gradients add up coherently over 10^4 .. 10^6 rows (state-network
+// gradients of the 40 000-node test against float64: 3e-4 .. 7e-3 with truncation; the f32 chain 1e-5 .. 4e-4).
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+    const bf16x2 hv = {(__bf16)a, (__bf16)b};
+    h = __builtin_bit_cast(unsigned, hv);
+    const float a1 = a - __uint_as_float(h << 16), b1 = b - __uint_as_float(h & 0xFFFF0000u);
+    const bf16x2 mv = {(__bf16)a1, (__bf16)b1};
+    m = __builtin_bit_cast(unsigned, mv);
+    const float a2 = a1 - __uint_as_float(m << 16), b2 = b1 - __uint_as_float(m & 0xFFFF0000u);
+    const bf16x2 lv = {(__bf16)a2, (__bf16)b2};
+    l = __builtin_bit_cast(unsigned, lv);
+}
+__device__ __forceinline__ void split3_x8(const f32x4 &x0, const f32x4 &x1, u32x4 &h, u32x4 &m, u32x4 &l) {
+    unsigned hh[4], mm[4], ll[4];
+    split3_pair(x0[0], x0[1], hh[0], mm[0], ll[0]); split3_pair(x0[2], x0[3], hh[1], mm[1], ll[1]);
+    split3_pair(x1[0], x1[1], hh[2], mm[2], ll[2]); split3_pair(x1[2], x1[3], hh[3], mm[3], ll[3]);
+    h = (u32x4){hh[0], hh[1], hh[2], hh[3]}; m = (u32x4){mm[0], mm[1], mm[2], mm[3]}; l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+}
+__device__ __forceinline__ f32x16 mfma_b6(const u32x4 &wh, const u32x4 &wm, const u32x4 &wl, const u32x4 &xh, const u32x4 &xm, const u32x4 &xl, f32x16 acc) {
+#define B8(v_) __builtin_bit_cast(bf16x8, v_)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(wl), B8(xh), acc, 0, 0, 0);      // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(wh), B8(xl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(wm), B8(xm), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(wm), B8(xh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(wh), B8(xm), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(wh), B8(xh), acc, 0, 0, 0);
+#undef B8
+    return acc;
+}
+// one f32 weight into its three bf16 planes in LDS (16-bit stores; once per workgroup)
+__device__ __forceinline__ void split3_store(unsigned short *base, int plane_stride, int idx, float v) {
+    const __bf16 vh = (__bf16)v;
+    const float r1 = v - (float)vh;
+    const __bf16 vm = (__bf16)r1;
+    const float r2 = r1 - (float)vm;
+    const __bf16 vl = (__bf16)r2;
+    base[idx] = __builtin_bit_cast(unsigned short, vh); base[plane_stride + idx] = __builtin_bit_cast(unsigned short, vm);
+    base[2 * plane_stride + idx] = __builtin_bit_cast(unsigned short, vl);
+}
+
+__device__ __forceinline__ f32x4 mfma_b6_16(const u32x4 &wh, const u32x4 &wm, const u32x4 &wl, const u32x4 &xh, const u32x4 &xm, const u32x4 &xl, f32x4 acc) {
+#define B8(v_) __builtin_bit_cast(bf16x8, v_)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B8(wl), B8(xh), acc, 0, 0, 0);      // small terms first
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B8(wh), B8(xl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B8(wm), B8(xm), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B8(wm), B8(xh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B8(wh), B8(xm), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B8(wh), B8(xh), acc, 0, 0, 0);
+#undef B8
+    return acc;
+}
+
+// k_train_fwd's tile (16 rows a wave, lane (c, g) = row c, 16-byte pieces at columns 16 q + 4 g) on v_mfma_f32_16x16x32_bf16: a k block is
+// two chunks (the lane's 8 values = its pieces of chunks 2 kb and 2 kb + 1; the weight planes are laid out in the same order).  The row
+// registers are refilled with the next tile's chunks as soon as they have been split (the state chunks after the epilogue, which compares
+// with them), the activation is a template parameter and every select that hipcc could turn into a branch is arithmetic.
+#ifndef TB_B6_WAVES
+#define TB_B6_WAVES 2
+#endif
+// One wait per trip.  hipcc counts a wave's loads and stores in one in-order counter and, with a store pending, waits for everything
+// issued before it - so a tile's stores directly in front of the next tile's first wait cost their whole round trip every trip (the
+// kernels above).  Here a trip is: wait for the tile's rows (requested a whole trip ago) -> split ALL of them to bf16 (60 registers)
+// and keep the state chunks for the predicate -> request the next tile's rows -> store the PREVIOUS tile's output (its activated values
+// waited in 16 registers) -> products -> activation, statistics, predicate.  Nothing the next wait covers is younger than most of a trip.
+template <int SQ, int ACT>
+__global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(TrainFwdArgs a) {
+    if (gate_closed(a.gate)) return;
+    constexpr int NCT = SQ, HP = 16 * NCT, NQ = 2 * SQ + 2, NKB = NQ / 2;
+    constexpr int PLANE = NKB * NCT * 64 * 8;                                                   // bf16 elements of one weight plane
+    extern __shared__ __attribute__((aligned(16))) float tb_smem[];
+    unsigned short *Wl = reinterpret_cast<unsigned short *>(tb_smem);                           // [3 planes][NKB][NCT][64 lanes][8]
+    float *bias_l = tb_smem + 3 * PLANE / 2;           // [HP]
+    float *red = bias_l + HP;                          // [TB_WAVES][2 HP]
+    __shared__ int any_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    if (tid == 0) any_s = 0;
+    for (int i = tid; i < 16 * NQ * HP; i += 64 * TB_WAVES) {
+        const int k = i / HP, h = i % HP;
+        int row = -1;
+        if (k < 16 * SQ) row = a.wrow_state + k;
+        else if (k < 32 * SQ) row = a.wrow_agg + (k - 16 * SQ);
+        else if (a.xc) {
+            int jj = k - 32 * SQ, beg = 0;
+#pragma unroll
+            for (int sg = 0; sg < 3; ++sg) {
+                if (sg < a.cs.n && jj >= beg && jj < beg + a.cs.width[sg]) row = a.cs.wrow[sg] + (jj - beg);
+                if (sg < a.cs.n) beg += a.cs.width[sg];
+            }
+        }
+        const float v = (row >= 0 && h < a.H) ? a.Wf[(size_t)row * a.H + h] : 0.0f;
+        const int q = k >> 4, gg = (k >> 2) & 3, e = k & 3;
+        split3_store(Wl, PLANE, ((((q >> 1) * NCT + (h >> 4)) * 64 + 16 * gg + (h & 15)) * 8) + 4 * (q & 1) + e, v);
+    }
+    for (int h = tid; h < HP; h += 64 * TB_WAVES) bias_l[h] = h < a.H ? a.bf[h] : 0.0f;
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t r_s = buf_rsrc(a.state), r_a = buf_rsrc(a.agg), r_x = buf_rsrc(a.xc), r_y = buf_rsrc(a.Y);
+    const int n_tiles = (a.M + 15) >> 4;
+    f32x4 cs1[NCT], cs2[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) { cs1[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; cs2[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    int any = 0;
+    f32x4 A[NQ];
+    auto fetch = [&](int t) {                           // this lane's 16-byte pieces of row 16 t + c: state, agg, constants line
+        const int row_ = 16 * t + c;
+        const bool in_ = t < n_tiles && row_ < a.M;
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) {
+            A[q] = buf_ld_f32x4(r_s, in_ ? ((unsigned)row_ * (unsigned)a.ld_state + 16u * q + 4u * g) * 4u : BUF_OFF);
+            A[SQ + q] = buf_ld_f32x4(r_a, in_ ? ((unsigned)row_ * (unsigned)a.ld_agg + 16u * q + 4u * g) * 4u : BUF_OFF);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) A[2 * SQ + q] = buf_ld_f32x4(r_x, in_ ? ((unsigned)row_ * 32u + 16u * q + 4u * g) * 4u : BUF_OFF);
+    };
+    const int t_step = gridDim.x * TB_WAVES;
+    int trip_ = 0; (void)trip_;
+    fetch(blockIdx.x * TB_WAVES + wave);
+    const u32x4 *Wv = reinterpret_cast<const u32x4 *>(Wl) + lane;
+    f32x4 vP[NCT];                                      // the previous tile's output, stored one trip late
+    int offP = 0; bool inP = false;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) vP[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int t = blockIdx.x * TB_WAVES + wave; t < n_tiles; t += t_step) {
+        const int row = 16 * t + c;
+        const bool in = row < a.M;
+        TB_STAMP(0);
+        u32x4 xh[NKB], xm[NKB], xl[NKB];
+        f32x4 old[SQ];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) split3_x8(A[2 * kb], A[2 * kb + 1], xh[kb], xm[kb], xl[kb]);
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) old[q] = A[q];
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(t + t_step);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const u32x4 bits = {__float_as_uint(vP[ct][0]), __float_as_uint(vP[ct][1]), __float_as_uint(vP[ct][2]), __float_as_uint(vP[ct][3])};
+            __builtin_amdgcn_raw_buffer_store_b128(bits, r_y, inP ? offP + (int)((16u * ct + 4u * g) * 4u) : (int)BUF_OFF, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        TB_STAMP_DEP(1, xh[NKB - 1]);
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = *reinterpret_cast<const f32x4 *>(bias_l + 16 * ct + 4 * g);
+        // products in stages of (k block, CTG column tiles): a stage's weight fragments (3 planes x CTG) are read from LDS one stage ahead,
+        // and inside a stage consecutive MFMAs go to different accumulators (left alone hipcc builds chains of six dependent MFMAs with
+        // an LDS round trip in front of each: 14 000 cycles per tile)
+        constexpr int CTG = NCT < 2 ? NCT : 2, SPK = NCT / CTG, NS = NKB * SPK;
+        u32x4 W[2][3][CTG];
+        auto load_w = [&](int st, u32x4 (&w)[3][CTG]) {
+            const int kb = st / SPK, ct0 = (st % SPK) * CTG;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int u = 0; u < CTG; ++u) w[pl][u] = Wv[pl * (PLANE / 8) + (kb * NCT + ct0 + u) * 64];
+        };
+        load_w(0, W[0]);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int kb = st / SPK, ct0 = (st % SPK) * CTG;
+            if (st + 1 < NS) load_w(st + 1, W[(st + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#define B8(v_) __builtin_bit_cast(bf16x8, v_)
+#define MF(pl_, x_) _Pragma("unroll") for (int u = 0; u < CTG; ++u) acc[ct0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B8(W[st & 1][pl_][u]), B8(x_), acc[ct0 + u], 0, 0, 0)
+            MF(2, xh[kb]); MF(0, xl[kb]); MF(1, xm[kb]); MF(1, xh[kb]); MF(0, xm[kb]); MF(0, xh[kb]);     // small terms first
+#undef MF
+#undef B8
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        TB_STAMP_DEP(2, acc[NCT - 1]);
+        float d2 = 0.0f, n2 = 0.0f;
+        const float mask = in ? 1.0f : 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f32x4 v = acc[ct];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((TB_ABL & 16) ? v[e] : activate1<ACT>(v[e])) * mask;       // (H == 16 SQ: the launcher checks; a column mask here becomes a branch per element)
+            vP[ct] = v;
+            cs1[ct] += v; cs2[ct] += v * v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float o = old[ct][e], d = v[e] - o; d2 = fmaf(d, d, d2); n2 = fmaf(o, o, n2); }
+        }
+        d2 += __shfl_xor(d2, 16, 64); d2 += __shfl_xor(d2, 32, 64);
+        n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64);
+        any |= (in && sqrtf(d2) > a.thr * sqrtf(n2)) ? 1 : 0;
+        offP = (int)((unsigned)row * (unsigned)a.ldy * 4u); inP = in;
+        TB_STAMP_DEP(3, vP[NCT - 1]);
+        TB_TRIP_END();
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {                 // the last tile's output
+        const u32x4 bits = {__float_as_uint(vP[ct][0]), __float_as_uint(vP[ct][1]), __float_as_uint(vP[ct][2]), __float_as_uint(vP[ct][3])};
+        __builtin_amdgcn_raw_buffer_store_b128(bits, r_y, inP ? offP + (int)((16u * ct + 4u * g) * 4u) : (int)BUF_OFF, 0, 0);
+    }
+    if (a.pred_flag && __any(any) && lane == 0) any_s = 1;
+    if (a.stat_part) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s1 = row16_sum_to_lane15(cs1[ct][e]), s2 = row16_sum_to_lane15(cs2[ct][e]);
+                if (c == 15) { red[wave * 2 * HP + 16 * ct + 4 * g + e] = s1; red[wave * 2 * HP + HP + 16 * ct + 4 * g + e] = s2; }
+            }
+    }
+    __syncthreads();
+    if (a.stat_part && tid < 2 * HP) {
+        float tsum = 0.0f;
+        for (int w_ = 0; w_ < TB_WAVES; ++w_) tsum += red[w_ * 2 * HP + tid];
+        a.stat_part[(size_t)blockIdx.x * 2 * HP + tid] = tsum;
+    }
+    if (a.pred_flag && tid == 0) {
+        if (any_s) atomicOr(a.pred_flag, 1);
+        if (blockIdx.x == 0 && a.pred_k) *a.pred_k = a.pred_kval;
+    }
+}
+
+template <int SQ>
+inline size_t train_fwd_b6_lds() { return (size_t)(3 * (SQ + 1) * SQ * 64 * 8 * 2) + (size_t)(16 * SQ + TB_WAVES * 2 * 16 * SQ) * sizeof(float); }
 
 template <int SQ, int NCT>
 inline size_t train_fwd_lds() { return (size_t)(16 * (2 * SQ + 2) * 16 * NCT + 16 * NCT + TB_WAVES * 2 * 16 * NCT) * sizeof(float); }

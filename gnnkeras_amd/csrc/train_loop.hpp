@@ -449,7 +449,53 @@ int launch_train_fwd_sq(const gnn::TrainFwdArgs &fa, int grid, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : fail("k_train_fwd launch failed");
 }
 
+// GNN_TRAIN_BF16X6=0: the exact-f32 MFMA kernels (k_train_fwd ..) instead of the three-term bf16 split on the bf16 matrix cores
+inline bool train_bf16x6_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_TRAIN_BF16X6"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+
+template <int SQ, int ACT>
+int launch_train_fwd_b6_sa(const gnn::TrainFwdArgs &fa, int grid, hipStream_t st) {
+    static bool attr = false;
+    const size_t lds = gnn::train_fwd_b6_lds<SQ>();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)gnn::k_train_fwd_b6<SQ, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail("k_train_fwd_b6: cannot raise the dynamic LDS limit");
+        attr = true;
+    }
+    gnn::k_train_fwd_b6<SQ, ACT><<<grid, 64 * gnn::TB_WAVES, lds, st>>>(fa);
+    return hipGetLastError() == hipSuccess ? 0 : fail("k_train_fwd_b6 launch failed");
+}
+
+template <int SQ>
+int launch_train_fwd_b6_s(const gnn::TrainFwdArgs &fa, int grid, hipStream_t st) {
+    switch (fa.act) {
+        case GNN_ACT_LINEAR: return launch_train_fwd_b6_sa<SQ, GNN_ACT_LINEAR>(fa, grid, st);
+        case GNN_ACT_RELU: return launch_train_fwd_b6_sa<SQ, GNN_ACT_RELU>(fa, grid, st);
+        case GNN_ACT_SELU: return launch_train_fwd_b6_sa<SQ, GNN_ACT_SELU>(fa, grid, st);
+        case GNN_ACT_TANH: return launch_train_fwd_b6_sa<SQ, GNN_ACT_TANH>(fa, grid, st);
+        case GNN_ACT_SIGMOID: return launch_train_fwd_b6_sa<SQ, GNN_ACT_SIGMOID>(fa, grid, st);
+        case GNN_ACT_ELU: return launch_train_fwd_b6_sa<SQ, GNN_ACT_ELU>(fa, grid, st);
+        case GNN_ACT_SOFTPLUS: return launch_train_fwd_b6_sa<SQ, GNN_ACT_SOFTPLUS>(fa, grid, st);
+        default: return -1;                            // (softmax state networks are not on the large-graph path)
+    }
+}
+
 int launch_train_fwd(const gnn::TrainFwdArgs &fa, int S, hipStream_t st, int *grid_out) {
+    if (train_bf16x6_enabled() && fa.H == S) {
+        const int n_tiles16 = (fa.M + 15) / 16;
+        const int grid = std::max(1, std::min(std::min(device_cus(), BIG_FWD_BLOCKS), cdiv(n_tiles16, gnn::TB_WAVES)));     // one 8-wave workgroup per CU (192 registers)
+        int rc = -1;
+        switch (S) {
+            case 16: rc = launch_train_fwd_b6_s<1>(fa, grid, st); break;
+            case 32: rc = launch_train_fwd_b6_s<2>(fa, grid, st); break;
+            case 64: rc = launch_train_fwd_b6_s<4>(fa, grid, st); break;
+            default: break;
+        }
+        if (rc >= 0) { *grid_out = grid; return rc; }
+    }
     const int n_tiles = (fa.M + 15) / 16;
     const int grid = std::max(1, std::min(std::min(2 * device_cus(), BIG_FWD_BLOCKS), cdiv(n_tiles, gnn::TB_WAVES)));
     *grid_out = grid;

@@ -1,0 +1,31 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import numpy as np, torch
+from gnnkeras_amd import GraphObject
+from gnnkeras_amd.synth import er_graph
+from gnnkeras_amd.Models.GNN import GNNnodeBased
+from gnnkeras_amd.Models.training import LoopTrainer, SGD
+from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+from test_gpu_training import nets, oracle_step
+d, bn, mode = 64, True, 'average'
+rng = np.random.default_rng(d)
+N = 40_000
+g = er_graph(N, 6 * N, seed=5, aggregation_mode=mode)
+om = rng.random(N) < 0.6
+t = np.zeros((int(om.sum()), 2)); t[np.arange(len(t)), rng.integers(0, 2, len(t))] = 1
+g = GraphObject(g.nodes, g.arcs, t, focus='n', set_mask=rng.random(N) < 0.9, output_mask=om, aggregation_mode=mode, sample_weight=rng.uniform(0.5, 1.5, len(t)))
+x, y, sw = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0]
+ns, no = nets('n', d, bn, scale=0.5)
+s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+model = GNNnodeBased(ns, no, d, 4, 0.0)
+model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+want = oracle_step(model, x, y, sw, s0, 'categorical_crossentropy', False)
+for native in (True, False):
+    tr = LoopTrainer(model); tr.use_native_step = native
+    res = tr.train_step(x, y, sw, state0=torch.from_numpy(s0).cuda(), apply=False)
+    errs = []
+    for got, ref in [(tr.gs.gradients(), want['grads_state']), (tr.go.gradients(), want['grads_output'])]:
+        for g_, r in zip(got, ref):
+            errs.append(float(np.max(np.abs(g_.cpu().numpy() - r)) / max(float(np.max(np.abs(r))), 1e-12)))
+    yp = float(np.max(np.abs(res['y_pred'].cpu().numpy() - want['y_pred'])))
+    print('native' if native else 'blocks', os.environ.get('GNN_TRAIN_BF16X6', '1'), 'k', res['k'], 'loss err', abs(float(res['loss']) - want['loss']), 'y_pred abs err', yp, 'grad rel errs', ['%.1e' % e for e in errs])

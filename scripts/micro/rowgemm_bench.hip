@@ -40,6 +40,11 @@ int main(int argc, char **argv) {
         CK(hipGetLastError());
     };
     run("k_train_fwd<4,4>", [&] { gnn::k_train_fwd<4, 4><<<grid, 64 * gnn::TB_WAVES, gnn::train_fwd_lds<4, 4>()>>>(fa); }, (double)M * (3.0 * S + 32) * 4);
+    run("k_train_fwd_b6<4,selu>", [&] { gnn::k_train_fwd_b6<4, GNN_ACT_SELU><<<grid, 64 * gnn::TB_WAVES, gnn::train_fwd_b6_lds<4>()>>>(fa); }, (double)M * (3.0 * S + 32) * 4);
+#ifdef TB_STAMPS
+    { unsigned long long st[256]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(gnn::g_tb_stamps), sizeof(st)));
+      for (int i = 2; i < 12; ++i) printf("trip %2d: head->ready %6llu  mfma %6llu  epilogue %6llu  next head %6llu\n", i, st[4*i+1]-st[4*i], st[4*i+2]-st[4*i+1], st[4*i+3]-st[4*i+2], st[4*i+4]-st[4*i+3]); }
+#endif
     run("k_train_bwd_dx<4,8>", [&] { gnn::k_train_bwd_dx<4, 8><<<grid, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<4, 8>()>>>(ba); }, (double)M * (5.0 * S) * 4);
     return 0;
 }

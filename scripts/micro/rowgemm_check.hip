@@ -42,7 +42,7 @@ void check_bwd(int M, bool bn, bool scale) {
     printf("bwd<%d,%d> M=%d bn=%d scale=%d  max abs err %.3e\n", HQ, NCT, M, bn, scale, worst);
 }
 
-template <int SQ>
+template <int SQ, int W32 = 0>
 void check_fwd(int M, bool pred) {
     const int S = 16 * SQ, L = 7, A_ = 3, K = 2 * S + 2 * L + A_, wa = S + L;
     std::mt19937 rng(2); std::normal_distribution<float> nd(0, 1);
@@ -55,7 +55,8 @@ void check_fwd(int M, bool pred) {
     a.M = M; a.state = up(st); a.ld_state = S; a.agg = up(ag); a.ld_agg = S; a.xc = up(xc); a.Wf = up(Wf); a.bf = up(bf); a.H = S;
     a.wrow_state = 0; a.wrow_agg = wa; a.cs.n = 3; a.cs.width[0] = L; a.cs.wrow[0] = S; a.cs.width[1] = L; a.cs.wrow[1] = 2 * S + L; a.cs.width[2] = A_; a.cs.wrow[2] = 2 * S + 2 * L;
     a.act = GNN_ACT_TANH; a.Y = dY; a.ldy = S; a.thr = 1e9f; a.pred_flag = pred ? flag : nullptr; a.stat_part = part;
-    gnn::k_train_fwd<SQ, SQ><<<64, 64 * gnn::TB_WAVES, gnn::train_fwd_lds<SQ, SQ>()>>>(a);
+    if constexpr (W32 == 3) gnn::k_train_fwd_b6<SQ, GNN_ACT_TANH><<<64, 64 * gnn::TB_WAVES, gnn::train_fwd_b6_lds<SQ>()>>>(a);
+    else gnn::k_train_fwd<SQ, SQ><<<64, 64 * gnn::TB_WAVES, gnn::train_fwd_lds<SQ, SQ>()>>>(a);
     CK(hipDeviceSynchronize());
     std::vector<float> got((size_t)M * S), pt(64 * 2 * S);
     CK(hipMemcpy(got.data(), dY, got.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(pt.data(), part, pt.size() * 4, hipMemcpyDeviceToHost));
@@ -71,11 +72,12 @@ void check_fwd(int M, bool pred) {
     double ws = 0;
     for (int h = 0; h < S; ++h) { double a1 = 0, a2 = 0; for (int b = 0; b < 64; ++b) { a1 += pt[(size_t)b * 2 * S + h]; a2 += pt[(size_t)b * 2 * S + S + h]; }
         ws = fmax(ws, fmax(fabs(a1 - s1[h]) / M, fabs(a2 - s2[h]) / M)); }
-    printf("fwd<%d> M=%d pred=%d  max abs err %.3e  stats err %.3e\n", SQ, M, pred, worst, ws);
+    int fl = -1; CK(hipMemcpy(&fl, flag, 4, hipMemcpyDeviceToHost));
+    printf("fwd<%d>%s M=%d pred=%d  max abs err %.3e  stats err %.3e  flag %d\n", SQ, W32 == 3 ? " bf16x6" : W32 == 2 ? " 32x32p" : W32 ? " 32x32" : "", M, pred, worst, ws, fl);
 }
 
 int main() {
-    for (int M : {1000, 40000}) for (int pr = 0; pr < 2; ++pr) { check_fwd<1>(M, pr); check_fwd<2>(M, pr); check_fwd<4>(M, pr); }
+    for (int M : {1000, 40000, 77}) for (int pr = 0; pr < 2; ++pr) { check_fwd<1>(M, pr); check_fwd<2>(M, pr); check_fwd<4>(M, pr); check_fwd<1, 3>(M, pr); check_fwd<2, 3>(M, pr); check_fwd<4, 3>(M, pr); }
     for (int M : {1000, 40000}) for (int bn = 0; bn < 2; ++bn) for (int sc = 0; sc < 2; ++sc) {
         check_bwd<1, 2>(M, bn, sc); check_bwd<2, 4>(M, bn, sc); check_bwd<4, 8>(M, bn, sc);
     }

@@ -729,6 +729,140 @@ __global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_bwd_dx(TrainBwdArgs 
     }
 }
 
+template <int ACT> __device__ __forceinline__ float activate_grad1(float y) {          // act'(z) from y = act(z), as kernels_train.hpp's switch
+    if (ACT == GNN_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+    if (ACT == GNN_ACT_SELU) return y > 0.0f ? 1.0507009873554805f : y + 1.0507009873554805f * 1.6732632423543772f;
+    if (ACT == GNN_ACT_TANH) return 1.0f - y * y;
+    if (ACT == GNN_ACT_SIGMOID) return y * (1.0f - y);
+    if (ACT == GNN_ACT_ELU) return y > 0.0f ? 1.0f : y + 1.0f;
+    if (ACT == GNN_ACT_SOFTPLUS) return 1.0f - expf(-y);
+    return 1.0f;
+}
+
+// k_train_bwd_dx on the bf16 matrix cores (the three-term split of k_train_fwd_b6: dZ rows are split as they arrive, W^T sits in LDS as
+// three bf16 planes in fragment order).  256-thread workgroups, two per CU; every row register is refilled with the NEXT tile's piece as
+// soon as its last reader has issued (dZ and Y after the split, the layer inputs x after the BatchNorm term of their column tile), so a
+// wave keeps 16 KB requested for a whole trip.  `a.Y == NULL` (dZ already formed): instantiate with ACT = LINEAR - the loads of Y then
+// fall out of range and return zeros, act'(0) = 1; no BatchNormalization: the x loads fall out of range the same way (Cc = Bc = 0).
+template <int HQ, int ACT>
+__global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
+    constexpr int NCT = 2 * HQ, HP = 16 * NCT, SQ = HQ, NKB = (HQ + 1) / 2, NW = 4;
+    constexpr int PLANE = NKB * NCT * 64 * 8;
+    extern __shared__ __attribute__((aligned(16))) float tb_smem[];
+    unsigned short *Wl = reinterpret_cast<unsigned short *>(tb_smem);        // [3 planes][NKB][NCT][64 lanes][8]
+    float *coef = tb_smem + 3 * PLANE / 2;                                    // [3][HP]: Ac, Cc, Bc
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int S = a.S;                                                        // == 16 HQ == H (the launcher checks)
+    for (int i = tid; i < 32 * NKB * HP; i += 64 * NW) {
+        const int k = i / HP, j = i % HP;                                     // k = dZ column h, j = output column
+        const int row = j < S ? a.wrow_state + j : a.wrow_agg + (j - S);
+        const float v = k < a.H ? a.W[(size_t)row * a.ldw + k] : 0.0f;
+        const int q = k >> 4, gg = (k >> 2) & 3, e = k & 3;
+        split3_store(Wl, PLANE, ((((q >> 1) * NCT + (j >> 4)) * 64 + 16 * gg + (j & 15)) * 8) + 4 * (q & 1) + e, v);
+    }
+    for (int j = tid; j < HP; j += 64 * NW) {
+        float Ac = 1.0f, Cc = 0.0f, Bc = 0.0f;
+        if (a.gamma) {
+            const int k = j < S ? a.wrow_state + j : a.wrow_agg + (j - S);
+            const float rstd = 1.0f / sqrtf(a.var[k] + a.eps);
+            Ac = a.gamma[k] * rstd; Cc = -Ac * rstd * a.m2[k]; Bc = -Ac * a.m1[k] - Cc * a.mean[k];
+        }
+        coef[j] = Ac; coef[HP + j] = Cc; coef[2 * HP + j] = Bc;
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t r_z = buf_rsrc(a.dZ), r_y = buf_rsrc(a.Y), r_s = buf_rsrc(a.gamma ? a.state : nullptr), r_a = buf_rsrc(a.gamma ? a.agg : nullptr),
+                                 r_o = buf_rsrc(a.dx), r_rs = buf_rsrc(a.agg_row_scale);
+    const int n_tiles = (a.M + 15) >> 4;
+    const int t_step = gridDim.x * NW;
+    f32x4 A[HQ], Yv[HQ], X[NCT];
+    float rs;
+    auto off_row = [&](int t, bool &in_) { const int row_ = 16 * t + c; in_ = t < n_tiles && row_ < a.M; return (unsigned)row_; };
+    auto fetch_zy = [&](int t) {
+        bool in_; const unsigned r = off_row(t, in_);
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            A[q] = buf_ld_f32x4(r_z, in_ ? (r * (unsigned)a.ldz + 16u * q + 4u * g) * 4u : BUF_OFF);
+            Yv[q] = buf_ld_f32x4(r_y, in_ ? (r * (unsigned)a.ldz + 16u * q + 4u * g) * 4u : BUF_OFF);
+        }
+    };
+    auto fetch_x = [&](int t, int ct) {
+        bool in_; const unsigned r = off_row(t, in_);
+        if (ct < SQ) X[ct] = buf_ld_f32x4(r_s, in_ ? (r * (unsigned)a.ld_state + 16u * ct + 4u * g) * 4u : BUF_OFF);
+        else X[ct] = buf_ld_f32x4(r_a, in_ ? (r * (unsigned)a.ld_agg + 16u * (ct - SQ) + 4u * g) * 4u : BUF_OFF);
+    };
+    auto fetch_rs = [&](int t) { bool in_; const unsigned r = off_row(t, in_); rs = buf_ld_f32(r_rs, in_ ? r * 4u : BUF_OFF); };
+    {
+        const int t0 = blockIdx.x * NW + wave;
+        fetch_zy(t0); fetch_rs(t0);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) fetch_x(t0, ct);
+    }
+    const u32x4 *Wv = reinterpret_cast<const u32x4 *>(Wl) + lane;
+    const bool has_rs = a.agg_row_scale != nullptr;
+#pragma unroll 1
+    for (int t = blockIdx.x * NW + wave; t < n_tiles; t += t_step) {
+        const int row = 16 * t + c;
+        const bool in = row < a.M;
+        u32x4 xh[NKB], xm[NKB], xl[NKB];
+#pragma unroll
+        for (int q = 0; q < HQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) A[q][e] *= activate_grad1<ACT>(Yv[q][e]);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            split3_x8(A[2 * kb], 2 * kb + 1 < HQ ? A[2 * kb + 1 < HQ ? 2 * kb + 1 : 0] : z4, xh[kb], xm[kb], xl[kb]);
+        }
+        const float rs_t = has_rs ? rs : 1.0f;
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_zy(t + t_step); fetch_rs(t + t_step);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int CTG = 2, SPK = NCT / CTG, NS = NKB * SPK;
+        u32x4 W[2][3][CTG];
+        auto load_w = [&](int st, u32x4 (&w)[3][CTG]) {
+            const int kb = st / SPK, ct0 = (st % SPK) * CTG;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int u = 0; u < CTG; ++u) w[pl][u] = Wv[pl * (PLANE / 8) + (kb * NCT + ct0 + u) * 64];
+        };
+        load_w(0, W[0]);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int kb = st / SPK, ct0 = (st % SPK) * CTG;
+            if (st + 1 < NS) load_w(st + 1, W[(st + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#define B8(v_) __builtin_bit_cast(bf16x8, v_)
+#define MF(pl_, x_) _Pragma("unroll") for (int u = 0; u < CTG; ++u) acc[ct0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B8(W[st & 1][pl_][u]), B8(x_), acc[ct0 + u], 0, 0, 0)
+            MF(2, xh[kb]); MF(0, xl[kb]); MF(1, xm[kb]); MF(1, xh[kb]); MF(0, xm[kb]); MF(0, xh[kb]);
+#undef MF
+#undef B8
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int j0 = 16 * ct + 4 * g;
+            const f32x4 Ac = *reinterpret_cast<const f32x4 *>(coef + j0), Cc = *reinterpret_cast<const f32x4 *>(coef + HP + j0),
+                        Bc = *reinterpret_cast<const f32x4 *>(coef + 2 * HP + j0);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(Ac[e], acc[ct][e], fmaf(Cc[e], X[ct][e], Bc[e]));
+            if (ct >= SQ) v *= rs_t;
+            const u32x4 bits = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(bits, r_o, in ? (int)(((unsigned)row * (unsigned)a.ld_dx + (unsigned)j0) * 4u) : (int)BUF_OFF, 0, 0);
+            fetch_x(t + t_step, ct);
+        }
+    }
+}
+
+template <int HQ>
+inline size_t train_bwd_b6_lds() { return (size_t)(3 * ((HQ + 1) / 2) * 2 * HQ * 64 * 8 * 2) + (size_t)(3 * 32 * HQ) * sizeof(float); }
+
 template <int HQ, int NCT>
 inline size_t train_bwd_lds() { return (size_t)(16 * HQ * 16 * NCT + 3 * 16 * NCT) * sizeof(float); }
 

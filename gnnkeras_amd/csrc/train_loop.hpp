@@ -506,7 +506,45 @@ int launch_train_fwd(const gnn::TrainFwdArgs &fa, int S, hipStream_t st, int *gr
     }
 }
 
+template <int HQ, int ACT>
+int launch_train_bwd_b6_ha(const gnn::TrainBwdArgs &ba, int grid, hipStream_t st) {
+    static bool attr = false;
+    const size_t lds = gnn::train_bwd_b6_lds<HQ>();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)gnn::k_train_bwd_dx_b6<HQ, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail("k_train_bwd_dx_b6: cannot raise the dynamic LDS limit");
+        attr = true;
+    }
+    gnn::k_train_bwd_dx_b6<HQ, ACT><<<grid, 256, lds, st>>>(ba);
+    return hipGetLastError() == hipSuccess ? 0 : fail("k_train_bwd_dx_b6 launch failed");
+}
+
+template <int HQ>
+int launch_train_bwd_b6_h(const gnn::TrainBwdArgs &ba, int grid, hipStream_t st) {
+    switch (ba.Y ? ba.act : GNN_ACT_LINEAR) {          // (dZ already formed: the kernel's Y loads fall out of range, act'(0) = 1)
+        case GNN_ACT_LINEAR: return launch_train_bwd_b6_ha<HQ, GNN_ACT_LINEAR>(ba, grid, st);
+        case GNN_ACT_RELU: return launch_train_bwd_b6_ha<HQ, GNN_ACT_RELU>(ba, grid, st);
+        case GNN_ACT_SELU: return launch_train_bwd_b6_ha<HQ, GNN_ACT_SELU>(ba, grid, st);
+        case GNN_ACT_TANH: return launch_train_bwd_b6_ha<HQ, GNN_ACT_TANH>(ba, grid, st);
+        case GNN_ACT_SIGMOID: return launch_train_bwd_b6_ha<HQ, GNN_ACT_SIGMOID>(ba, grid, st);
+        case GNN_ACT_ELU: return launch_train_bwd_b6_ha<HQ, GNN_ACT_ELU>(ba, grid, st);
+        case GNN_ACT_SOFTPLUS: return launch_train_bwd_b6_ha<HQ, GNN_ACT_SOFTPLUS>(ba, grid, st);
+        default: return -1;
+    }
+}
+
 int launch_train_bwd_dx(const gnn::TrainBwdArgs &ba, int S, hipStream_t st) {
+    if (train_bf16x6_enabled() && ba.H == S && ba.S == S && ba.ldz == S) {
+        const int grid = std::max(1, std::min(2 * device_cus(), cdiv((ba.M + 15) / 16, 4)));       // 256-thread workgroups, two per CU
+        int rc = -1;
+        switch (S) {
+            case 16: rc = launch_train_bwd_b6_h<1>(ba, grid, st); break;
+            case 32: rc = launch_train_bwd_b6_h<2>(ba, grid, st); break;
+            case 64: rc = launch_train_bwd_b6_h<4>(ba, grid, st); break;
+            default: break;
+        }
+        if (rc >= 0) return rc;
+    }
     const int n_tiles = (ba.M + 15) / 16;
     const int grid = std::max(1, std::min(2 * device_cus(), cdiv(n_tiles, gnn::TB_WAVES)));
     switch (S) {

@@ -46,5 +46,8 @@ int main(int argc, char **argv) {
       for (int i = 2; i < 12; ++i) printf("trip %2d: head->ready %6llu  mfma %6llu  epilogue %6llu  next head %6llu\n", i, st[4*i+1]-st[4*i], st[4*i+2]-st[4*i+1], st[4*i+3]-st[4*i+2], st[4*i+4]-st[4*i+3]); }
 #endif
     run("k_train_bwd_dx<4,8>", [&] { gnn::k_train_bwd_dx<4, 8><<<grid, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<4, 8>()>>>(ba); }, (double)M * (5.0 * S) * 4);
+    ba.Y = state; ba.act = GNN_ACT_SELU;
+    run("bwd_dx<4,8> with Y", [&] { gnn::k_train_bwd_dx<4, 8><<<grid, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<4, 8>()>>>(ba); }, (double)M * (6.0 * S) * 4);
+    run("bwd_dx_b6<4,selu>", [&] { gnn::k_train_bwd_dx_b6<4, GNN_ACT_SELU><<<grid, 256, gnn::train_bwd_b6_lds<4>()>>>(ba); }, (double)M * (6.0 * S) * 4);
     return 0;
 }

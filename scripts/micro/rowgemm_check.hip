@@ -10,7 +10,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 template <typename T> T *up(const std::vector<T> &v) { T *d; CK(hipMalloc(&d, v.size() * sizeof(T))); CK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return d; }
 
-template <int HQ, int NCT>
+template <int HQ, int NCT, bool B6 = false>
 void check_bwd(int M, bool bn, bool scale) {
     const int S = 8 * NCT, H = 16 * HQ, L = 7, K = 2 * S + 2 * L + 3, wa = S + L;
     std::mt19937 rng(1); std::normal_distribution<float> nd(0, 1);
@@ -25,7 +25,8 @@ void check_bwd(int M, bool bn, bool scale) {
     if (bn) { a.gamma = up(gm); a.mean = up(mu); a.var = up(va); a.m1 = up(m1); a.m2 = up(m2); a.eps = 1e-3f; }
     if (scale) a.agg_row_scale = up(rs);
     a.dx = d_dx; a.ld_dx = 2 * S;
-    gnn::k_train_bwd_dx<HQ, NCT><<<64, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<HQ, NCT>()>>>(a);
+    if constexpr (B6) gnn::k_train_bwd_dx_b6<HQ, GNN_ACT_LINEAR><<<64, 256, gnn::train_bwd_b6_lds<HQ>()>>>(a);
+    else gnn::k_train_bwd_dx<HQ, NCT><<<64, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<HQ, NCT>()>>>(a);
     CK(hipDeviceSynchronize());
     std::vector<float> got((size_t)M * 2 * S);
     CK(hipMemcpy(got.data(), d_dx, got.size() * 4, hipMemcpyDeviceToHost));
@@ -39,7 +40,7 @@ void check_bwd(int M, bool bn, bool scale) {
         if (scale && j >= S) v *= rs[m];
         worst = fmax(worst, fabs(v - got[(size_t)m * 2 * S + j]));
     }
-    printf("bwd<%d,%d> M=%d bn=%d scale=%d  max abs err %.3e\n", HQ, NCT, M, bn, scale, worst);
+    printf("bwd<%d,%d>%s M=%d bn=%d scale=%d  max abs err %.3e\n", HQ, NCT, B6 ? " bf16x6" : "", M, bn, scale, worst);
 }
 
 template <int SQ, int W32 = 0>
@@ -80,6 +81,7 @@ int main() {
     for (int M : {1000, 40000, 77}) for (int pr = 0; pr < 2; ++pr) { check_fwd<1>(M, pr); check_fwd<2>(M, pr); check_fwd<4>(M, pr); check_fwd<1, 3>(M, pr); check_fwd<2, 3>(M, pr); check_fwd<4, 3>(M, pr); }
     for (int M : {1000, 40000}) for (int bn = 0; bn < 2; ++bn) for (int sc = 0; sc < 2; ++sc) {
         check_bwd<1, 2>(M, bn, sc); check_bwd<2, 4>(M, bn, sc); check_bwd<4, 8>(M, bn, sc);
+        check_bwd<1, 2, true>(M, bn, sc); check_bwd<2, 4, true>(M, bn, sc); check_bwd<4, 8, true>(M, bn, sc);
     }
     return 0;
 }

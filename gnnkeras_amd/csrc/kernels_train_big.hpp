@@ -18,7 +18,10 @@
 //   * k_train_bwd_dx<HQ,NCT> - d loss / d [state | agg] = BN-input-gradient(dZ . W1^T): the same row-streaming MFMA loop, the
 //                           BatchNormalization input gradient (three coefficients per column) and the row scale of 'average'
 //                           aggregation in the epilogue - replaces two dense launches and the BN-gradient pass.
-// Exact float32 on v_mfma_f32_16x16x4_f32 like every other dense kernel here; deterministic (fixed tile -> wave assignment,
+// Round 4: the forward Dense and dZ . W^T run on the bf16 matrix cores with every f32 operand split into three bf16 terms
+// (k_train_fwd_b6, k_train_bwd_dx_b6: f32-chain accuracy, not its bits; GNN_TRAIN_BF16X6=0 selects the f32 kernels), the weight
+// gradient on v_mfma_f32_32x32x2_f32 (k_train_wgrad32).  The f32-input MFMA kernels below stay as the exact path and for S = 16.
+// Exact float32 on v_mfma_f32_16x16x4_f32 like every other dense kernel here (k_train_fwd, k_train_bwd_dx, k_train_wgrad); deterministic (fixed tile -> wave assignment,
 // per-workgroup partial statistics summed in workgroup order by k_stats_finish).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -978,6 +981,100 @@ __global__ void __launch_bounds__(256, 2) k_train_wgrad(TrainWgradArgs a) {
             if (jj == a.Kc) wrow = a.K;                              // the line's 1: q
         }
         if (wrow >= 0) Pp[(size_t)wrow * S + h] = Ps[i];
+    }
+}
+
+// The same contraction on v_mfma_f32_32x32x2_f32 (S = 32 NB): 156 TFLOP/s sustained against 104 .. 126 for the 16x16x4 form
+// (scripts/micro/mfma_peak.hip), and the weight gradient is the one dense training kernel that is almost all MFMA.  Lane (i = lane % 32,
+// kk = lane / 32) supplies one element of row r0 + kk of each operand: it loads the NB consecutive floats  X[r0 + kk][NB i ..]  (a
+// wave's load = two whole rows) and uses value e as the A operand of row tile e (tile row i is input column NB i + e); dZ pieces serve
+// as B operands the same way (tile column j is dZ column NB j + f).  A workgroup step is 8 rows, PD steps of loads in flight.
+#ifndef TB_WG32_PD
+#define TB_WG32_PD 6
+#define TB_WG32_WAVES 2
+#endif
+template <int NB, int ACT>
+__global__ void __launch_bounds__(256, TB_WG32_WAVES) k_train_wgrad32(TrainWgradArgs a) {
+    constexpr int S = 32 * NB, RT = 2 * NB + 1, KV = 2 * S + 32, PD = TB_WG32_PD;
+    __shared__ float Ps[KV * S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int m_beg = blockIdx.x * a.rows_per_wg, m_end = min(a.M, m_beg + a.rows_per_wg);
+    const int n_steps = (max(m_end - m_beg, 0) + 7) >> 3;            // a workgroup step = 8 rows: 2 per wave
+    const __amdgpu_buffer_rsrc_t r_g = buf_rsrc(a.G), r_y = buf_rsrc(a.Y), r_s = buf_rsrc(a.state), r_a = buf_rsrc(a.agg), r_c = buf_rsrc(a.xc);
+    f32x16 acc[RT][NB];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int f = 0; f < NB; ++f)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[rt][f][v] = 0.0f;
+    struct Step { Piece<NB> xs, xa, gz, y; Piece<1> xc; };
+    Step buf[PD];
+    auto fetch = [&](Step &b, int s) {
+        const int row = m_beg + 8 * s + 2 * wave + kk;
+        const bool ok = s < n_steps && row < m_end;
+        const unsigned off = ok ? ((unsigned)row * (unsigned)S + (unsigned)(NB * i)) * 4u : BUF_OFF;
+        b.gz = ld_piece<NB>(r_g, off); b.y = ld_piece<NB>(r_y, off);
+        b.xs = ld_piece<NB>(r_s, off); b.xa = ld_piece<NB>(r_a, off);
+        b.xc = ld_piece<1>(r_c, ok ? ((unsigned)row * 32u + (unsigned)i) * 4u : BUF_OFF);
+    };
+#pragma unroll
+    for (int u = 0; u < PD; ++u) fetch(buf[u], u);
+#pragma unroll 1
+    for (int s0 = 0; s0 < n_steps; s0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            {   // (no branch on s0 + u < n_steps, no switch on the activation: rows past the end load zeros, and hipcc drains the whole
+                //  load queue - s_waitcnt vmcnt(0) - wherever two blocks of the loop body meet)
+                Step &b = buf[u];
+                float dz[NB];
+#pragma unroll
+                for (int f = 0; f < NB; ++f) dz[f] = b.gz.v[f] * activate_grad1<ACT>(b.y.v[f]);
+#pragma unroll
+                for (int e = 0; e < NB; ++e)
+#pragma unroll
+                    for (int f = 0; f < NB; ++f) {
+                        acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.xs.v[e], dz[f], acc[e][f], 0, 0, 0);
+                        acc[NB + e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.xa.v[e], dz[f], acc[NB + e][f], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int f = 0; f < NB; ++f) acc[2 * NB][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.xc.v[0], dz[f], acc[2 * NB][f], 0, 0, 0);
+                fetch(b, s0 + u + PD);
+            }
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // acc[rt][f][v] = P[virtual column kv(rt, 8 (v / 4) + 4 kk + v % 4)][NB i + f]; the waves add their tiles in wave order
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = 8 * (v >> 2) + 4 * kk + (v & 3);
+                    const int kv = rt < NB ? NB * m + rt : rt < 2 * NB ? S + NB * m + (rt - NB) : 2 * S + m;
+                    float *dst = Ps + kv * S + NB * i;
+#pragma unroll
+                    for (int f = 0; f < NB; ++f) dst[f] = w == 0 ? acc[rt][f][v] : dst[f] + acc[rt][f][v];
+                }
+        }
+        __syncthreads();
+    }
+    float *Pp = a.part + (size_t)blockIdx.x * ((size_t)a.K * S + S);
+    for (int idx = tid; idx < KV * S; idx += 256) {
+        const int kv = idx / S, h = idx % S;
+        int wrow = -1;
+        if (kv < S) wrow = a.wrow_state + kv;
+        else if (kv < 2 * S) wrow = a.wrow_agg + (kv - S);
+        else {
+            int jj = kv - 2 * S, b0 = 0;
+#pragma unroll
+            for (int sg = 0; sg < 3; ++sg) { if (sg < a.cs.n && jj >= b0 && jj < b0 + a.cs.width[sg]) wrow = a.cs.wrow[sg] + (jj - b0); if (sg < a.cs.n) b0 += a.cs.width[sg]; }
+            if (jj == a.Kc) wrow = a.K;                              // the line's 1: q
+        }
+        if (wrow >= 0) Pp[(size_t)wrow * S + h] = Ps[idx];
     }
 }
 

@@ -533,6 +533,32 @@ int launch_train_bwd_b6_h(const gnn::TrainBwdArgs &ba, int grid, hipStream_t st)
     }
 }
 
+// the weight gradient on v_mfma_f32_32x32x2_f32 (exact f32 like k_train_wgrad; S = 32 / 64): true when launched
+template <int NB>
+bool launch_train_wgrad32_nb(const gnn::TrainWgradArgs &wa, int grid, hipStream_t st) {
+    switch (wa.act) {
+        case GNN_ACT_LINEAR: gnn::k_train_wgrad32<NB, GNN_ACT_LINEAR><<<grid, 256, 0, st>>>(wa); return true;
+        case GNN_ACT_RELU: gnn::k_train_wgrad32<NB, GNN_ACT_RELU><<<grid, 256, 0, st>>>(wa); return true;
+        case GNN_ACT_SELU: gnn::k_train_wgrad32<NB, GNN_ACT_SELU><<<grid, 256, 0, st>>>(wa); return true;
+        case GNN_ACT_TANH: gnn::k_train_wgrad32<NB, GNN_ACT_TANH><<<grid, 256, 0, st>>>(wa); return true;
+        case GNN_ACT_SIGMOID: gnn::k_train_wgrad32<NB, GNN_ACT_SIGMOID><<<grid, 256, 0, st>>>(wa); return true;
+        case GNN_ACT_ELU: gnn::k_train_wgrad32<NB, GNN_ACT_ELU><<<grid, 256, 0, st>>>(wa); return true;
+        case GNN_ACT_SOFTPLUS: gnn::k_train_wgrad32<NB, GNN_ACT_SOFTPLUS><<<grid, 256, 0, st>>>(wa); return true;
+        default: return false;
+    }
+}
+inline bool train_wgrad32_enabled() {       // GNN_TRAIN_WGRAD32=0: k_train_wgrad (16x16x4) at every width
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_TRAIN_WGRAD32"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+bool launch_train_wgrad32(const gnn::TrainWgradArgs &wa, int S, int grid, hipStream_t st) {
+    if (!train_wgrad32_enabled()) return false;
+    if (S == 64) return launch_train_wgrad32_nb<2>(wa, grid, st);
+    if (S == 32) return launch_train_wgrad32_nb<1>(wa, grid, st);
+    return false;
+}
+
 int launch_train_bwd_dx(const gnn::TrainBwdArgs &ba, int S, hipStream_t st) {
     if (train_bf16x6_enabled() && ba.H == S && ba.S == S && ba.ldz == S) {
         const int grid = std::max(1, std::min(2 * device_cus(), cdiv((ba.M + 15) / 16, 4)));       // 256-thread workgroups, two per CU
@@ -997,10 +1023,12 @@ int gnn_train_step(const gnn_train_args_t *args) {
                 wa.K = p.in_s; wa.wrow_state = 0; wa.wrow_agg = p.off_agg; wa.Kc = p.Kc; wa.cs = p.cc;
                 wa.part = p.part_w;
                 const int grid = cdiv(p.N, wa.rows_per_wg);
-                switch (p.S) {
-                    case 16: gnn::k_train_wgrad<1><<<grid, 256, 0, st>>>(wa); break;
-                    case 32: gnn::k_train_wgrad<2><<<grid, 256, 0, st>>>(wa); break;
-                    default: gnn::k_train_wgrad<4><<<grid, 256, 0, st>>>(wa); break;
+                if (!launch_train_wgrad32(wa, p.S, grid, st)) {       // (S = 16, or an activation without an instance: the 16x16x4 kernel)
+                    switch (p.S) {
+                        case 16: gnn::k_train_wgrad<1><<<grid, 256, 0, st>>>(wa); break;
+                        case 32: gnn::k_train_wgrad<2><<<grid, 256, 0, st>>>(wa); break;
+                        default: gnn::k_train_wgrad<4><<<grid, 256, 0, st>>>(wa); break;
+                    }
                 }
                 LAUNCH_OK();
                 const int nP = p.in_s * p.S + p.S;

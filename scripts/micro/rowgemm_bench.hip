@@ -46,6 +46,12 @@ int main(int argc, char **argv) {
       for (int i = 2; i < 12; ++i) printf("trip %2d: head->ready %6llu  mfma %6llu  epilogue %6llu  next head %6llu\n", i, st[4*i+1]-st[4*i], st[4*i+2]-st[4*i+1], st[4*i+3]-st[4*i+2], st[4*i+4]-st[4*i+3]); }
 #endif
     run("k_train_bwd_dx<4,8>", [&] { gnn::k_train_bwd_dx<4, 8><<<grid, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<4, 8>()>>>(ba); }, (double)M * (5.0 * S) * 4);
+    { gnn::TrainWgradArgs wa; memset(&wa, 0, sizeof(wa));
+      const int n_wg = grid; wa.M = M; wa.rows_per_wg = ((M + n_wg - 1) / n_wg + 15) / 16 * 16; const int wgrid = (M + wa.rows_per_wg - 1) / wa.rows_per_wg;
+      float *wpart; CK(hipMalloc(&wpart, (size_t)wgrid * (K * S + S) * 4));
+      wa.G = Y; wa.Y = state; wa.act = GNN_ACT_SELU; wa.state = state; wa.agg = agg; wa.xc = xc; wa.K = K; wa.wrow_state = 0; wa.wrow_agg = S + 14; wa.Kc = 31; wa.cs = fa.cs; wa.part = wpart;
+      run("k_train_wgrad<4>", [&] { gnn::k_train_wgrad<4><<<wgrid, 256>>>(wa); }, (double)M * (4.0 * S + 32) * 4);
+      run("k_train_wgrad32<2>", [&] { gnn::k_train_wgrad32<2, GNN_ACT_SELU><<<wgrid, 256>>>(wa); }, (double)M * (4.0 * S + 32) * 4); }
     ba.Y = state; ba.act = GNN_ACT_SELU;
     run("bwd_dx<4,8> with Y", [&] { gnn::k_train_bwd_dx<4, 8><<<grid, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<4, 8>()>>>(ba); }, (double)M * (6.0 * S) * 4);
     run("bwd_dx_b6<4,selu>", [&] { gnn::k_train_bwd_dx_b6<4, GNN_ACT_SELU><<<grid, 256, gnn::train_bwd_b6_lds<4>()>>>(ba); }, (double)M * (6.0 * S) * 4);

@@ -309,7 +309,9 @@ def training_section(device, graph_x, d):
     for _ in range(3): r = gnn.train_step(data, seed=0)
     torch.cuda.synchronize()
     out['c4_d64_k10'] = {'train_step_ms': 1e3 * (time.perf_counter() - t0) / 3, 'k': int(r['k']),
-                         'workload': 'the C4 graph, node-focused, every node a target, 10 iterations, BatchNormalization on batch statistics'}
+                         'workload': 'the C4 graph, node-focused, every node a target, 10 iterations, BatchNormalization on batch statistics',
+                         'arithmetic': 'f32; the first Dense forward and dZ.W^T of an iteration as six bf16 MFMA products of three-term bf16 splits with f32 '
+                                       'accumulation (f32-chain accuracy, DESIGN.md 6b; GNN_TRAIN_BF16X6=0: f32-input MFMAs), weight gradient on f32-input MFMAs'}
     return out
 
 

@@ -544,6 +544,7 @@ struct FoldJob {
     float *Wf, *bf;
     int K, H, blk_begin;
     float eps;
+    int centred;                           // 1: the consumer subtracts `mean` from its input rows itself (large-graph training): bf = b + sum beta W
 };
 struct FoldArgs {
     FoldJob job[GNN_MAX_TYPES + 1];
@@ -569,7 +570,7 @@ __global__ void __launch_bounds__(128) k_fold_bn(FoldArgs fa) {
         float inv = 1.0f, shift = 0.0f;
         if (jb.gamma) {
             inv = jb.gamma[k] / sqrtf(jb.var[k] + jb.eps);
-            shift = jb.beta[k] - jb.mean[k] * inv;
+            shift = jb.centred ? jb.beta[k] : jb.beta[k] - jb.mean[k] * inv;
         }
         const float wv = jb.W[(size_t)k * H + h];
         jb.Wf[(size_t)k * H + h] = wv * inv;

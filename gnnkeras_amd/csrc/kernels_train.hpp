@@ -226,13 +226,16 @@ k_bn_moving_update(const float *__restrict__ mean, const float *__restrict__ var
 //   m1_k = S1_k / M ,  m2_k = rstd_k (S2_k - mean_k S1_k) / M     (consumed by k_bn_input_grad)
 // One 64-lane workgroup per input feature k (lanes stride over the H outputs, the two dot products meet in a fixed
 // shuffle tree); workgroup 0 also writes the bias gradient.  grid = K.
+// `centered` (with BatchNormalization only): P is already P - mean q^T = (X - mean)^T dZ - the large-graph weight-gradient kernels subtract
+// the column mean from every row as it arrives, because a P - mean q formed HERE cancels the leading digits of two sums over 10^5 .. 10^6
+// rows whenever the inputs have a mean of their own size (relu / sigmoid states): dW = a P_c + beta q, S2 - mean S1 = sum_h W P_c.
 // `n_chunks` > 1: P and q are still chunk partials ([chunk][K*H + H], the output of k_dense_grad_partial*): each value is
 // summed here in chunk order (small batches: saves the reduction launch); n_chunks <= 1: P [K x H] and q [H] are final.
 __global__ void __launch_bounds__(64)
 k_first_layer_param_grads(const float *__restrict__ P, const float *__restrict__ q, const float *__restrict__ W, int K,
                           int H, const float *gamma, const float *beta, const float *mean, const float *var, float eps,
                           float inv_m, float *__restrict__ dW, float *__restrict__ db, float *dgamma, float *dbeta,
-                          float *m1, float *m2, int accumulate, int n_chunks = 1) {
+                          float *m1, float *m2, int accumulate, int n_chunks = 1, int centered = 0) {
     const int k = blockIdx.x, lane = threadIdx.x;
     const size_t cstride = (size_t)K * H + H;
     auto sum_chunks = [&](const float *base) -> float {         // 8 loads in flight, summed in chunk order
@@ -269,14 +272,14 @@ k_first_layer_param_grads(const float *__restrict__ P, const float *__restrict__
         const float p = n_chunks > 1 ? p_at(h) : P[(size_t)k * H + h], qh = n_chunks > 1 ? q_at(h) : q[h];
         S1 = fmaf(w, qh, S1);
         S2 = fmaf(w, p, S2);
-        const float gw = a * p + c * qh;
+        const float gw = centered ? fmaf(a, p, beta[k] * qh) : a * p + c * qh;
         dW[(size_t)k * H + h] = accumulate ? dW[(size_t)k * H + h] + gw : gw;
     }
     if (gamma) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { S1 += __shfl_xor(S1, off, 64); S2 += __shfl_xor(S2, off, 64); }
         if (lane == 0) {
-            const float dg = rstd * (S2 - mu * S1);
+            const float dg = centered ? rstd * S2 : rstd * (S2 - mu * S1);
             dgamma[k] = accumulate ? dgamma[k] + dg : dg;
             dbeta[k] = accumulate ? dbeta[k] + S1 : S1;
             if (m1) { m1[k] = S1 * inv_m; m2[k] = dg * inv_m; }

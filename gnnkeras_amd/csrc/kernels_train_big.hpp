@@ -48,15 +48,18 @@ constexpr int TB_WAVES = 8;              // waves per workgroup (512 threads; la
 // k_aggregate_vec (kernels_general.hpp) with one addition: every thread keeps the sum and the sum of squares of the float4 column
 // chunk it writes; a workgroup folds its threads' partials in a fixed order into stat_part[blockIdx.x][2 F] (sums, then squares).
 template <int LPR, bool HAS_W>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 8)              // (8 waves per SIMD = 64 VGPRs: with the shift in registers hipcc took 66, and the gather lost 18 %)
 k_aggregate_stats(const int *gate, int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src,
                   const float *__restrict__ w, const float *__restrict__ row_scale, const float *__restrict__ X, int ldx,
-                  float *__restrict__ out, int ldo, float *__restrict__ stat_part) {
+                  float *__restrict__ out, int ldo, float *__restrict__ stat_part, const float *__restrict__ shift) {
     if (gate_closed(gate)) return;
     __shared__ f32x4 red[2][256];
     const int l4 = threadIdx.x % LPR;
     constexpr int groups = 256 / LPR;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    // one-pass moments around `shift` (a value near the column mean: the previous iteration's mean): sum (x - c), sum (x - c)^2 -
+    // E[x^2] - mean^2 on raw sums loses (1 + 2 mean^2 / var) digits, and a neighbour AVERAGE of relu / sigmoid states has var << mean^2
+    const f32x4 sh = shift ? *reinterpret_cast<const f32x4 *>(shift + 4 * l4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int j = blockIdx.x * groups + threadIdx.x / LPR; j < n_dst; j += gridDim.x * groups) {
         const int beg = rowptr[j], end = rowptr[j + 1];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -76,6 +79,7 @@ k_aggregate_stats(const int *gate, int n_dst, const int *__restrict__ rowptr, co
         }
         if (row_scale) acc *= row_scale[j];
         *reinterpret_cast<f32x4 *>(out + (size_t)j * ldo + 4 * l4) = acc;
+        acc -= sh;
         s1 += acc; s2 += acc * acc;
     }
     red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
@@ -98,12 +102,13 @@ k_rows_stats(const int *gate, int M, const float *__restrict__ X, int ld, float 
     const int l4 = threadIdx.x % LPR;
     constexpr int groups = 256 / LPR;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 sh = *reinterpret_cast<const f32x4 *>(X + 4 * l4);          // moments around ROW 0 (k_stats_finish adds it back: pass X as its shift)
     for (int j = blockIdx.x * groups + threadIdx.x / LPR; j < M; j += gridDim.x * groups * 4) {       // four rows in flight
         f32x4 x[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = j + u * gridDim.x * groups;
-            x[u] = r < M ? *reinterpret_cast<const f32x4 *>(X + (size_t)r * ld + 4 * l4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            x[u] = r < M ? *reinterpret_cast<const f32x4 *>(X + (size_t)r * ld + 4 * l4) - sh : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) { s1 += x[u]; s2 += x[u] * x[u]; }
@@ -123,7 +128,8 @@ k_rows_stats(const int *gate, int M, const float *__restrict__ X, int ld, float 
 // are activations / their neighbour averages, |mean| and sigma of the same order, the tail in double; BatchNormalization adds
 // eps = 1e-3 to the variance before the square root.)
 __global__ void __launch_bounds__(256)
-k_stats_finish(const int *gate, const float *__restrict__ part, int n_part, int F, float inv_m, float *__restrict__ mean, float *__restrict__ var) {
+k_stats_finish(const int *gate, const float *__restrict__ part, int n_part, int F, float inv_m, float *__restrict__ mean, float *__restrict__ var,
+               const float *__restrict__ shift) {      // shift[c]: what the producer subtracted from column c (NULL: nothing)
     if (gate_closed(gate)) return;
     __shared__ double sh[2][256];
     const int c = blockIdx.x;
@@ -137,7 +143,7 @@ k_stats_finish(const int *gate, const float *__restrict__ part, int n_part, int 
     }
     if (threadIdx.x == 0) {
         const double mu = sh[0][0] * (double)inv_m;
-        mean[c] = (float)mu;
+        mean[c] = (float)(mu + (shift ? (double)shift[c] : 0.0));
         var[c] = (float)fmax(sh[1][0] * (double)inv_m - mu * mu, 0.0);
     }
 }
@@ -157,8 +163,25 @@ struct TrainFwdArgs {
     int act;
     float *Y; int ldy;                    // [M, H]
     float thr; int *pred_flag; float *pred_k; float pred_kval;      // predicate of Y against `state` (H == 16 SQ), optional
-    float *stat_part;                     // [gridDim.x][2 * 16 NCT] column sums / squares of Y, optional
+    float *stat_part;                     // [gridDim.x][2 * 16 NCT] column sums / squares of Y - stat_shift, optional
+    const float *stat_shift;              // [H] or NULL: subtracted before the sums (the input state's column means: see k_aggregate_stats)
+    const float *in_mean;                 // [in_dim] (by weight row) or NULL: subtracted from the input rows as they arrive; (Wf, bf) are then the
+                                          // fold WITHOUT the -mean a term (FoldJob::centred)
 };
+
+// mean of virtual input column k of [state | agg | constants line] (chunks of 16), 0 where there is none
+__device__ __forceinline__ float fwd_in_mean(const TrainFwdArgs &a, int SQ, int k) {
+    if (!a.in_mean) return 0.0f;
+    if (k < 16 * SQ) return a.in_mean[a.wrow_state + k];
+    if (k < 32 * SQ) return a.in_mean[a.wrow_agg + (k - 16 * SQ)];
+    int jj = k - 32 * SQ, beg = 0, row = -1;
+#pragma unroll
+    for (int sg = 0; sg < 3; ++sg) {
+        if (sg < a.cs.n && jj >= beg && jj < beg + a.cs.width[sg]) row = a.cs.wrow[sg] + (jj - beg);
+        if (sg < a.cs.n) beg += a.cs.width[sg];
+    }
+    return (a.xc && row >= 0) ? a.in_mean[row] : 0.0f;
+}
 
 template <int NCT> struct BFrag;
 template <> struct BFrag<1> { float v[1]; __device__ __forceinline__ void load(const float *p) { v[0] = *p; } };
@@ -178,10 +201,6 @@ template <> struct BFrag<8> { float v[8]; __device__ __forceinline__ void load(c
 #define TB_PREFETCH 0                  // 1 (experiment): the next tile's rows are requested before this tile's MFMAs.  162 VGPRs = 3 waves per SIMD
                                        // instead of 4: SLOWER, 227 -> 247 us per 1 M rows (scripts/micro/rowgemm_bench.hip): the waves hide more than the prefetch
 #endif
-#ifndef TB_ROLL
-#define TB_ROLL 0                      // 1 (experiment): rolling refill of the row registers (see the MFMA loop): memory stops being waited for (114 us with the
-                                       // MFMAs compiled out against 185), the whole kernel does not get faster (225 against 223 us): f32 MFMA + epilogue issue time
-#endif
 #ifndef TB_FWD_MIN_WAVES
 #define TB_FWD_MIN_WAVES 4             // waves per SIMD the register allocation is held to (experiment knob of scripts/micro/rowgemm_bench.hip)
 #endif
@@ -194,10 +213,14 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
     float *Wl = tb_smem;                               // [4 NQ k-steps][4 g][16 c][NCT]
     float *bias_l = tb_smem + 16 * NQ * HP;            // [HP]
     float *red = bias_l + HP;                          // [TB_WAVES][2 HP] statistics hand-over
+    float *shift_l = red + TB_WAVES * 2 * HP;          // [HP] what the statistics are taken around
+    float *mean_l = shift_l + HP;                      // [16 NQ] the input columns' means (a.in_mean), 0 where there is none
     __shared__ int any_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     if (tid == 0) any_s = 0;
+    for (int h = tid; h < HP; h += 64 * TB_WAVES) shift_l[h] = (a.stat_shift && h < a.H) ? a.stat_shift[h] : 0.0f;
+    for (int k = tid; k < 16 * NQ; k += 64 * TB_WAVES) mean_l[k] = fwd_in_mean(a, SQ, k);
     // ---- folded weights into LDS in fragment order: k-step (q, e) of lane group g multiplies virtual column 16 q + 4 g + e ------
     for (int i = tid; i < 16 * NQ * HP; i += 64 * TB_WAVES) {
         const int k = i / HP, h = i % HP;
@@ -241,20 +264,6 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
 #if TB_PREFETCH
     fetch(blockIdx.x * TB_WAVES + wave, A);
 #endif
-    auto fetch1 = [&](int t, int q, f32x4 &dst) {       // chunk q of this lane's row of tile t (TB_ROLL: a register is refilled when its last reader has issued)
-        const int row_ = 16 * t + c;
-        const bool in_ = t < n_tiles && row_ < a.M;
-        if (q < SQ) dst = buf_ld_f32x4(r_s, in_ ? ((unsigned)row_ * (unsigned)a.ld_state + 16u * q + 4u * g) * 4u : BUF_OFF);
-        else if (q < 2 * SQ) dst = buf_ld_f32x4(r_a, in_ ? ((unsigned)row_ * (unsigned)a.ld_agg + 16u * (q - SQ) + 4u * g) * 4u : BUF_OFF);
-        else dst = buf_ld_f32x4(r_x, in_ ? ((unsigned)row_ * 32u + 16u * (q - 2 * SQ) + 4u * g) * 4u : BUF_OFF);
-    };
-#if TB_ROLL
-#pragma unroll
-    for (int qq = 0; qq < NQ; ++qq) {                   // (the loop's own issue order: one counted wait at the loop head serves both paths)
-        const int q = qq < NQ - SQ ? SQ + qq : qq - (NQ - SQ);
-        fetch1(blockIdx.x * TB_WAVES + wave, q, A[q]);
-    }
-#endif
 #pragma unroll 1
     for (int t = blockIdx.x * TB_WAVES + wave; t < n_tiles; t += t_step) {
         const int row = 16 * t + c;                     // this lane's row: input chunks, output chunks, old state
@@ -262,7 +271,7 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
 #if TB_PREFETCH
         f32x4 An[NQ];
         fetch(t + t_step, An);                          // (in flight while this tile multiplies)
-#elif !TB_ROLL
+#else
         fetch(t, A);
 #endif
         f32x4 acc[NCT];
@@ -271,32 +280,16 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
 #if (TB_ABL & 1)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q % NCT] += A[q];
-#elif TB_ROLL
-        // agg and constants chunks first, each register refilled with the NEXT tile's chunk as soon as its sixteen MFMAs have issued (the
-        // load is in flight for a whole trip); the state chunks last: the predicate reads them again, they are refilled after the epilogue
-#pragma unroll
-        for (int qq = 0; qq < NQ; ++qq) {
-            const int q = qq < NQ - SQ ? SQ + qq : qq - (NQ - SQ);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                BFrag<NCT> w;
-                w.load(Wl + (((4 * q + e) * 4 + g) * 16 + c) * NCT);
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[ct], A[q][e], acc[ct], 0, 0, 0);
-            }
-            if (q >= SQ) fetch1(t + t_step, q, A[q]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        TB_MFMA_DRAIN();
 #else
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
+            const f32x4 xq = A[q] - *reinterpret_cast<const f32x4 *>(mean_l + 16 * q + 4 * g);      // (centred: see TrainFwdArgs::in_mean)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 BFrag<NCT> w;
                 w.load(Wl + (((4 * q + e) * 4 + g) * 16 + c) * NCT);
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[ct], A[q][e], acc[ct], 0, 0, 0);
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[ct], xq[e], acc[ct], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);         // keep the fragment reads of later chunks from being hoisted (register budget)
         }
@@ -317,7 +310,13 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
             __builtin_amdgcn_raw_buffer_store_b128(bits, r_y, (in && 16 * ct + 4 * g < a.H) ? (int)(((unsigned)row * (unsigned)a.ldy + 16u * ct + 4u * g) * 4u) : (int)BUF_OFF, 0, 0);
 #endif
 #if !(TB_ABL & 8)
-            cs1[ct] += v; cs2[ct] += v * v;
+            {
+                const f32x4 sh = *reinterpret_cast<const f32x4 *>(shift_l + 16 * ct + 4 * g);
+                f32x4 dv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dv[e] = in ? v[e] - sh[e] : 0.0f;
+                cs1[ct] += dv; cs2[ct] += dv * dv;
+            }
 #endif
             if (a.pred_flag && !(TB_ABL & 2) && ct < SQ) {
 #pragma unroll
@@ -332,9 +331,6 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
 #if TB_PREFETCH
 #pragma unroll
         for (int q = 0; q < NQ; ++q) A[q] = An[q];
-#elif TB_ROLL
-#pragma unroll
-        for (int q = 0; q < SQ; ++q) fetch1(t + t_step, q, A[q]);
 #endif
     }
     // ---- predicate flag, k, statistics partial of this workgroup ---------------------------------------------------------------------
@@ -469,10 +465,14 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
     unsigned short *Wl = reinterpret_cast<unsigned short *>(tb_smem);                           // [3 planes][NKB][NCT][64 lanes][8]
     float *bias_l = tb_smem + 3 * PLANE / 2;           // [HP]
     float *red = bias_l + HP;                          // [TB_WAVES][2 HP]
+    float *shift_l = red + TB_WAVES * 2 * HP;          // [HP] what the statistics are taken around
+    float *mean_l = shift_l + HP;                      // [16 NQ] the input columns' means (a.in_mean), 0 where there is none
     __shared__ int any_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     if (tid == 0) any_s = 0;
+    for (int h = tid; h < HP; h += 64 * TB_WAVES) shift_l[h] = (a.stat_shift && h < a.H) ? a.stat_shift[h] : 0.0f;
+    for (int k = tid; k < 16 * NQ; k += 64 * TB_WAVES) mean_l[k] = fwd_in_mean(a, SQ, k);
     for (int i = tid; i < 16 * NQ * HP; i += 64 * TB_WAVES) {
         const int k = i / HP, h = i % HP;
         int row = -1;
@@ -527,7 +527,9 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
         u32x4 xh[NKB], xm[NKB], xl[NKB];
         f32x4 old[SQ];
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) split3_x8(A[2 * kb], A[2 * kb + 1], xh[kb], xm[kb], xl[kb]);
+        for (int kb = 0; kb < NKB; ++kb)             // (centred: see TrainFwdArgs::in_mean; the predicate below compares with the raw state)
+            split3_x8(A[2 * kb] - *reinterpret_cast<const f32x4 *>(mean_l + 32 * kb + 4 * g), A[2 * kb + 1] - *reinterpret_cast<const f32x4 *>(mean_l + 32 * kb + 16 + 4 * g),
+                      xh[kb], xm[kb], xl[kb]);
 #pragma unroll
         for (int q = 0; q < SQ; ++q) old[q] = A[q];
         __builtin_amdgcn_sched_barrier(0);
@@ -577,7 +579,7 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ((TB_ABL & 16) ? v[e] : activate1<ACT>(v[e])) * mask;       // (H == 16 SQ: the launcher checks; a column mask here becomes a branch per element)
             vP[ct] = v;
-            cs1[ct] += v; cs2[ct] += v * v;
+            { const f32x4 dv = v - *reinterpret_cast<const f32x4 *>(shift_l + 16 * ct + 4 * g) * mask; cs1[ct] += dv; cs2[ct] += dv * dv; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float o = old[ct][e], d = v[e] - o; d2 = fmaf(d, d, d2); n2 = fmaf(o, o, n2); }
         }
@@ -616,16 +618,16 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
 }
 
 template <int SQ>
-inline size_t train_fwd_b6_lds() { return (size_t)(3 * (SQ + 1) * SQ * 64 * 8 * 2) + (size_t)(16 * SQ + TB_WAVES * 2 * 16 * SQ) * sizeof(float); }
+inline size_t train_fwd_b6_lds() { return (size_t)(3 * (SQ + 1) * SQ * 64 * 8 * 2) + (size_t)(16 * SQ + TB_WAVES * 2 * 16 * SQ + 16 * SQ + 16 * (2 * SQ + 2)) * sizeof(float); }
 
 template <int SQ, int NCT>
-inline size_t train_fwd_lds() { return (size_t)(16 * (2 * SQ + 2) * 16 * NCT + 16 * NCT + TB_WAVES * 2 * 16 * NCT) * sizeof(float); }
+inline size_t train_fwd_lds() { return (size_t)(16 * (2 * SQ + 2) * 16 * NCT + 16 * NCT + TB_WAVES * 2 * 16 * NCT + 16 * NCT + 16 * (2 * SQ + 2)) * sizeof(float); }
 
 // ---- backward: d loss / d [state | agg] through the first Dense and its training-mode BatchNormalization ------------------------
 //   dy[m, j]  = sum_h dZ[m, h] W[row_j, h]                      (j < S: state column j, else agg column j - S)
 //   dx[m, j]  = gamma_k rstd_k (dy - m1_k - xhat m2_k)          xhat = (x[m, j] - mean_k) rstd_k,  k = row_j      (reference: the
 //               gradient autograd takes through tf.keras BatchNormalization(training=True); kernels_train.hpp k_bn_input_grad)
-//             = Ac_j dy + Cc_j x + Bc_j      with  Ac = gamma rstd,  Cc = -Ac rstd m2,  Bc = -Ac m1 - Cc mean
+//             = Ac_j (dy - m1_k) + Cc_j (x - mean_k)      with  Ac = gamma rstd,  Cc = -Ac rstd m2
 //   agg half optionally times row_scale[m]: the transposed aggregate then walks unit weights ('average': w_e = 1 / in-degree(dst_e))
 struct TrainBwdArgs {
     int M;
@@ -645,7 +647,7 @@ __global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_bwd_dx(TrainBwdArgs 
     constexpr int SQ = NCT / 2;            // 16-column tiles of one half (state | agg)
     extern __shared__ __attribute__((aligned(16))) float tb_smem[];
     float *Wl = tb_smem;                    // [4 HQ k-steps][4 g][16 c][NCT]
-    float *coef = tb_smem + 16 * HQ * HP;   // [3][HP]: Ac, Cc, Bc
+    float *coef = tb_smem + 16 * HQ * HP;   // [4][HP]: Ac, Cc, m1, mean
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int S = a.S;                      // == 8 NCT: the halves are whole 16-column tiles
@@ -657,13 +659,13 @@ __global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_bwd_dx(TrainBwdArgs 
         Wl[(((4 * q + e) * 4 + gg) * 16 + (j & 15)) * NCT + (j >> 4)] = v;
     }
     for (int j = tid; j < HP; j += 64 * TB_WAVES) {
-        float Ac = 1.0f, Cc = 0.0f, Bc = 0.0f;
-        if (a.gamma) {
+        float Ac = 1.0f, Cc = 0.0f, M1 = 0.0f, Mu = 0.0f;      // dx = Ac (dy - m1) + Cc (x - mean): the centred form - an Ac dy + Cc x + Bc with
+        if (a.gamma) {                                          // Bc = -Ac m1 - Cc mean rounds ONE constant per column whose error every row shares
             const int k = j < S ? a.wrow_state + j : a.wrow_agg + (j - S);
             const float rstd = 1.0f / sqrtf(a.var[k] + a.eps);
-            Ac = a.gamma[k] * rstd; Cc = -Ac * rstd * a.m2[k]; Bc = -Ac * a.m1[k] - Cc * a.mean[k];
+            Ac = a.gamma[k] * rstd; Cc = -Ac * rstd * a.m2[k]; M1 = a.m1[k]; Mu = a.mean[k];
         }
-        coef[j] = Ac; coef[HP + j] = Cc; coef[2 * HP + j] = Bc;
+        coef[j] = Ac; coef[HP + j] = Cc; coef[2 * HP + j] = M1; coef[3 * HP + j] = Mu;
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t r_z = buf_rsrc(a.dZ), r_y = buf_rsrc(a.Y), r_s = buf_rsrc(a.state), r_a = buf_rsrc(a.agg), r_o = buf_rsrc(a.dx),
@@ -719,10 +721,10 @@ __global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_bwd_dx(TrainBwdArgs 
                 f32x4 v = acc[u];
                 if (a.gamma) {
                     const f32x4 Ac = *reinterpret_cast<const f32x4 *>(coef + j0), Cc = *reinterpret_cast<const f32x4 *>(coef + HP + j0),
-                                Bc = *reinterpret_cast<const f32x4 *>(coef + 2 * HP + j0);
+                                M1 = *reinterpret_cast<const f32x4 *>(coef + 2 * HP + j0), Mu = *reinterpret_cast<const f32x4 *>(coef + 3 * HP + j0);
                     const f32x4 x = X[half * SQ + u];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(Ac[e], v[e], fmaf(Cc[e], x[e], Bc[e]));
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(Ac[e], v[e] - M1[e], Cc[e] * (x[e] - Mu[e]));
                 }
                 if (half == 1) v *= rs;
                 const u32x4 bits = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
@@ -746,14 +748,14 @@ template <int ACT> __device__ __forceinline__ float activate_grad1(float y) {   
 // three bf16 planes in fragment order).  256-thread workgroups, two per CU; every row register is refilled with the NEXT tile's piece as
 // soon as its last reader has issued (dZ and Y after the split, the layer inputs x after the BatchNorm term of their column tile), so a
 // wave keeps 16 KB requested for a whole trip.  `a.Y == NULL` (dZ already formed): instantiate with ACT = LINEAR - the loads of Y then
-// fall out of range and return zeros, act'(0) = 1; no BatchNormalization: the x loads fall out of range the same way (Cc = Bc = 0).
+// fall out of range and return zeros, act'(0) = 1; no BatchNormalization: the x loads fall out of range the same way (Cc = m1 = mean = 0).
 template <int HQ, int ACT>
 __global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
     constexpr int NCT = 2 * HQ, HP = 16 * NCT, SQ = HQ, NKB = (HQ + 1) / 2, NW = 4;
     constexpr int PLANE = NKB * NCT * 64 * 8;
     extern __shared__ __attribute__((aligned(16))) float tb_smem[];
     unsigned short *Wl = reinterpret_cast<unsigned short *>(tb_smem);        // [3 planes][NKB][NCT][64 lanes][8]
-    float *coef = tb_smem + 3 * PLANE / 2;                                    // [3][HP]: Ac, Cc, Bc
+    float *coef = tb_smem + 3 * PLANE / 2;                                    // [4][HP]: Ac, Cc, m1, mean
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int S = a.S;                                                        // == 16 HQ == H (the launcher checks)
@@ -765,13 +767,13 @@ __global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
         split3_store(Wl, PLANE, ((((q >> 1) * NCT + (j >> 4)) * 64 + 16 * gg + (j & 15)) * 8) + 4 * (q & 1) + e, v);
     }
     for (int j = tid; j < HP; j += 64 * NW) {
-        float Ac = 1.0f, Cc = 0.0f, Bc = 0.0f;
+        float Ac = 1.0f, Cc = 0.0f, M1 = 0.0f, Mu = 0.0f;      // (the centred form: see k_train_bwd_dx)
         if (a.gamma) {
             const int k = j < S ? a.wrow_state + j : a.wrow_agg + (j - S);
             const float rstd = 1.0f / sqrtf(a.var[k] + a.eps);
-            Ac = a.gamma[k] * rstd; Cc = -Ac * rstd * a.m2[k]; Bc = -Ac * a.m1[k] - Cc * a.mean[k];
+            Ac = a.gamma[k] * rstd; Cc = -Ac * rstd * a.m2[k]; M1 = a.m1[k]; Mu = a.mean[k];
         }
-        coef[j] = Ac; coef[HP + j] = Cc; coef[2 * HP + j] = Bc;
+        coef[j] = Ac; coef[HP + j] = Cc; coef[2 * HP + j] = M1; coef[3 * HP + j] = Mu;
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t r_z = buf_rsrc(a.dZ), r_y = buf_rsrc(a.Y), r_s = buf_rsrc(a.gamma ? a.state : nullptr), r_a = buf_rsrc(a.gamma ? a.agg : nullptr),
@@ -851,10 +853,10 @@ __global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
         for (int ct = 0; ct < NCT; ++ct) {
             const int j0 = 16 * ct + 4 * g;
             const f32x4 Ac = *reinterpret_cast<const f32x4 *>(coef + j0), Cc = *reinterpret_cast<const f32x4 *>(coef + HP + j0),
-                        Bc = *reinterpret_cast<const f32x4 *>(coef + 2 * HP + j0);
+                        M1 = *reinterpret_cast<const f32x4 *>(coef + 2 * HP + j0), Mu = *reinterpret_cast<const f32x4 *>(coef + 3 * HP + j0);
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(Ac[e], acc[ct][e], fmaf(Cc[e], X[ct][e], Bc[e]));
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(Ac[e], acc[ct][e] - M1[e], Cc[e] * (X[ct][e] - Mu[e]));
             if (ct >= SQ) v *= rs_t;
             const u32x4 bits = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
             __builtin_amdgcn_raw_buffer_store_b128(bits, r_o, in ? (int)(((unsigned)row * (unsigned)a.ld_dx + (unsigned)j0) * 4u) : (int)BUF_OFF, 0, 0);
@@ -864,10 +866,10 @@ __global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
 }
 
 template <int HQ>
-inline size_t train_bwd_b6_lds() { return (size_t)(3 * ((HQ + 1) / 2) * 2 * HQ * 64 * 8 * 2) + (size_t)(3 * 32 * HQ) * sizeof(float); }
+inline size_t train_bwd_b6_lds() { return (size_t)(3 * ((HQ + 1) / 2) * 2 * HQ * 64 * 8 * 2) + (size_t)(4 * 32 * HQ) * sizeof(float); }
 
 template <int HQ, int NCT>
-inline size_t train_bwd_lds() { return (size_t)(16 * HQ * 16 * NCT + 3 * 16 * NCT) * sizeof(float); }
+inline size_t train_bwd_lds() { return (size_t)(16 * HQ * 16 * NCT + 4 * 16 * NCT) * sizeof(float); }
 
 // ---- weight gradient of the first Dense at large M: P = X^T dZ on the matrix cores, straight from memory ------------------------------------
 // X = [state | agg | constants] (the virtual concatenation, never materialised), dZ = G (.) act'(Y) formed as the rows arrive.  The
@@ -886,7 +888,18 @@ struct TrainWgradArgs {
     const float *xc;                      // [M, 32] (k_pack_xc layout)
     int K, wrow_state, wrow_agg, Kc; ConstCols cs;
     float *part;                          // [gridDim.x][K * S + S]
+    const float *mean;                    // [K] column means of this iteration's BatchNormalization, or NULL: X is centred as it arrives (P - mean q^T)
 };
+
+// weight row (= BatchNorm column) of virtual input column kv of [state | agg | constants line], -1: none (the line's 1 and its padding)
+__device__ __forceinline__ int wgrad_wrow(const TrainWgradArgs &a, int S, int kv) {
+    if (kv < S) return a.wrow_state + kv;
+    if (kv < 2 * S) return a.wrow_agg + (kv - S);
+    int jj = kv - 2 * S, b0 = 0, wrow = -1;
+#pragma unroll
+    for (int sg = 0; sg < 3; ++sg) { if (sg < a.cs.n && jj >= b0 && jj < b0 + a.cs.width[sg]) wrow = a.cs.wrow[sg] + (jj - b0); if (sg < a.cs.n) b0 += a.cs.width[sg]; }
+    return wrow;
+}
 
 template <int SQ> struct Piece { float v[SQ]; };
 template <int SQ> __device__ __forceinline__ Piece<SQ> ld_piece(__amdgpu_buffer_rsrc_t r, unsigned off);
@@ -914,6 +927,11 @@ __global__ void __launch_bounds__(256, 2) k_train_wgrad(TrainWgradArgs a) {
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < SQ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mu_s[SQ], mu_a[SQ], mu_c[2];                 // the means of this lane's columns (0 without BatchNormalization, for the line's 1 and its padding)
+#pragma unroll
+    for (int e = 0; e < SQ; ++e) { mu_s[e] = a.mean ? a.mean[a.wrow_state + SQ * c + e] : 0.0f; mu_a[e] = a.mean ? a.mean[a.wrow_agg + SQ * c + e] : 0.0f; }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { const int wr = wgrad_wrow(a, S, 2 * S + 2 * c + e); mu_c[e] = (a.mean && wr >= 0) ? a.mean[wr] : 0.0f; }
     struct Step { Piece<SQ> xs, xa, gz, y; Piece<2> xc; };
     Step buf[PD];
     auto fetch = [&](Step &b, int s) {
@@ -939,13 +957,13 @@ __global__ void __launch_bounds__(256, 2) k_train_wgrad(TrainWgradArgs a) {
                 for (int e = 0; e < SQ; ++e)
 #pragma unroll
                     for (int j = 0; j < SQ; ++j) {
-                        acc[e][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.xs.v[e], dz[j], acc[e][j], 0, 0, 0);
-                        acc[SQ + e][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.xa.v[e], dz[j], acc[SQ + e][j], 0, 0, 0);
+                        acc[e][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.xs.v[e] - mu_s[e], dz[j], acc[e][j], 0, 0, 0);
+                        acc[SQ + e][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.xa.v[e] - mu_a[e], dz[j], acc[SQ + e][j], 0, 0, 0);
                     }
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int j = 0; j < SQ; ++j) acc[2 * SQ + e][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.xc.v[e], dz[j], acc[2 * SQ + e][j], 0, 0, 0);
+                    for (int j = 0; j < SQ; ++j) acc[2 * SQ + e][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.xc.v[e] - mu_c[e], dz[j], acc[2 * SQ + e][j], 0, 0, 0);
                 fetch(b, s0 + u + PD);
             }
         }
@@ -1009,6 +1027,10 @@ __global__ void __launch_bounds__(256, TB_WG32_WAVES) k_train_wgrad32(TrainWgrad
         for (int f = 0; f < NB; ++f)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[rt][f][v] = 0.0f;
+    float mu_s[NB], mu_a[NB], mu_c;                     // the means of this lane's columns (0 without BatchNormalization, for the line's 1 and its padding)
+#pragma unroll
+    for (int e = 0; e < NB; ++e) { mu_s[e] = a.mean ? a.mean[a.wrow_state + NB * i + e] : 0.0f; mu_a[e] = a.mean ? a.mean[a.wrow_agg + NB * i + e] : 0.0f; }
+    { const int wr = wgrad_wrow(a, S, 2 * S + i); mu_c = (a.mean && wr >= 0) ? a.mean[wr] : 0.0f; }
     struct Step { Piece<NB> xs, xa, gz, y; Piece<1> xc; };
     Step buf[PD];
     auto fetch = [&](Step &b, int s) {
@@ -1035,11 +1057,11 @@ __global__ void __launch_bounds__(256, TB_WG32_WAVES) k_train_wgrad32(TrainWgrad
                 for (int e = 0; e < NB; ++e)
 #pragma unroll
                     for (int f = 0; f < NB; ++f) {
-                        acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.xs.v[e], dz[f], acc[e][f], 0, 0, 0);
-                        acc[NB + e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.xa.v[e], dz[f], acc[NB + e][f], 0, 0, 0);
+                        acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.xs.v[e] - mu_s[e], dz[f], acc[e][f], 0, 0, 0);
+                        acc[NB + e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.xa.v[e] - mu_a[e], dz[f], acc[NB + e][f], 0, 0, 0);
                     }
 #pragma unroll
-                for (int f = 0; f < NB; ++f) acc[2 * NB][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.xc.v[0], dz[f], acc[2 * NB][f], 0, 0, 0);
+                for (int f = 0; f < NB; ++f) acc[2 * NB][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.xc.v[0] - mu_c, dz[f], acc[2 * NB][f], 0, 0, 0);
                 fetch(b, s0 + u + PD);
             }
         }
@@ -1086,7 +1108,7 @@ __global__ void __launch_bounds__(256, TB_WG32_WAVES) k_train_wgrad32(TrainWgrad
 //   k_head_wgrad<T> - P = [state | labels]^T dZ and q = colsum(dZ): a lane owns four consecutive input columns, 32 lanes a row, each row
 //                     read once as 16-byte pieces; per-workgroup partials in the layout k_reduce_partials / k_first_layer_param_grads
 //                     take ([K x T] then [T]), row groups and workgroups added in a fixed order;
-//   k_head_dx<T>    - d loss / d state[m, j] = Ac_j (sum_h dZ[m, h] W[j, h]) + Cc_j state[m, j] + Bc_j  (the Dense input gradient with the
+//   k_head_dx<T>    - d loss / d state[m, j] = Ac_j (sum_h dZ[m, h] W[j, h] - m1_j) + Cc_j (state[m, j] - mean_j)  (the Dense input gradient with the
 //                     BatchNorm input gradient as per-column coefficients, as k_train_bwd_dx), WRITTEN into the state gradient: every
 //                     row is an output row, so nothing is scattered or zero-filled.  The label columns' input gradient is never needed.
 struct HeadArgs {
@@ -1178,16 +1200,16 @@ __global__ void __launch_bounds__(256) k_head_dx(HeadArgs a) {
     const int lpr = ns4 <= 4 ? 4 : ns4 <= 8 ? 8 : 16;
     const int l4 = threadIdx.x % lpr, groups = 256 / lpr;
     const bool act = l4 < ns4;
-    float w[4][T], Ac[4], Cc[4], Bc[4];
+    float w[4][T], Ac[4], Cc[4], M1[4], Mu[4];          // (the centred form: see k_train_bwd_dx)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int j = 4 * l4 + e;
-        Ac[e] = 1.0f; Cc[e] = 0.0f; Bc[e] = 0.0f;
+        Ac[e] = 1.0f; Cc[e] = 0.0f; M1[e] = 0.0f; Mu[e] = 0.0f;
 #pragma unroll
         for (int h = 0; h < T; ++h) w[e][h] = act ? a.W[(size_t)j * T + h] : 0.0f;
         if (a.gamma && act) {
             const float rstd = 1.0f / sqrtf(a.var[j] + a.eps);
-            Ac[e] = a.gamma[j] * rstd; Cc[e] = -Ac[e] * rstd * a.m2[j]; Bc[e] = -Ac[e] * a.m1[j] - Cc[e] * a.mean[j];
+            Ac[e] = a.gamma[j] * rstd; Cc[e] = -Ac[e] * rstd * a.m2[j]; M1[e] = a.m1[j]; Mu[e] = a.mean[j];
         }
     }
     for (int m = blockIdx.x * groups + threadIdx.x / lpr; m < a.M; m += gridDim.x * groups) {
@@ -1203,7 +1225,7 @@ __global__ void __launch_bounds__(256) k_head_dx(HeadArgs a) {
             float dy = 0.0f;
 #pragma unroll
             for (int h = 0; h < T; ++h) dy = fmaf(dz[h], w[e][h], dy);
-            v[e] = fmaf(Ac[e], dy, fmaf(Cc[e], x[e], Bc[e]));
+            v[e] = fmaf(Ac[e], dy - M1[e], Cc[e] * (x[e] - Mu[e]));
         }
         *reinterpret_cast<f32x4 *>(a.dx + (size_t)m * a.ld_dx + 4 * l4) = v;
     }

@@ -220,9 +220,10 @@ int colstats_segs(const int *gate, const gnn::Seg *segs, int n, int M, float *me
     return 0;
 }
 
-int fold_with_stats(const gnn_mlp_t &m, const float *stats, float *Wf, float *bf, hipStream_t st) {
+int fold_with_stats(const gnn_mlp_t &m, const float *stats, float *Wf, float *bf, hipStream_t st, bool centred = false) {
     FoldList fl;
     gnn::FoldJob &j = fl.fa.job[fl.fa.n_jobs++];
+    j.centred = centred ? 1 : 0;
     j.W = m.kernel[0]; j.b = m.bias[0]; j.K = m.in_dim; j.H = m.units[0];
     j.gamma = m.bn_gamma; j.beta = m.bn_beta; j.mean = stats; j.var = stats + m.in_dim; j.eps = m.bn_eps;
     j.Wf = Wf; j.bf = bf; j.blk_begin = 0;
@@ -416,15 +417,16 @@ int state_segs(const gnn_loop_args_t &a, const TrainPlan &p, int t, gnn::Seg *se
 }
 
 // ---- launchers of the large-graph kernels -------------------------------------------------------------------------------------------
-int launch_aggregate_stats(const int *gate, const gnn_csr_t &c, const float *X, int S, float *out, float *part, float *mean, float *var, hipStream_t st) {
+int launch_aggregate_stats(const int *gate, const gnn_csr_t &c, const float *X, int S, float *out, float *part, float *mean, float *var, const float *shift,
+                           hipStream_t st) {
     const int lpr = S / 4, groups = 256 / lpr;
     const int grid = std::min(cdiv(c.n_dst, groups), BIG_AGG_BLOCKS);
-#define AGGS(L) (c.w ? gnn::k_aggregate_stats<L, true><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, S, out, S, part) \
-                     : gnn::k_aggregate_stats<L, false><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, S, out, S, part))
+#define AGGS(L) (c.w ? gnn::k_aggregate_stats<L, true><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, S, out, S, part, shift) \
+                     : gnn::k_aggregate_stats<L, false><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, S, out, S, part, shift))
     switch (lpr) { case 4: AGGS(4); break; case 8: AGGS(8); break; default: AGGS(16); break; }
 #undef AGGS
     LAUNCH_OK();
-    gnn::k_stats_finish<<<S, 256, 0, st>>>(gate, part, grid, S, 1.0f / (float)c.n_dst, mean, var);
+    gnn::k_stats_finish<<<S, 256, 0, st>>>(gate, part, grid, S, 1.0f / (float)c.n_dst, mean, var, shift);
     LAUNCH_OK();
     return 0;
 }
@@ -764,7 +766,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
             int c0 = 0;
             for (int s = 0; s < p.cc.n; ++s) {
                 gnn::k_stats_finish<<<p.cc.width[s], 256, 0, st>>>(nullptr, p.part_y + c0, grid, 32, 1.0f / (float)p.N, p.stats_tpl + p.cc.wrow[s],
-                                                                  p.stats_tpl + p.in_s + p.cc.wrow[s]);
+                                                                  p.stats_tpl + p.in_s + p.cc.wrow[s], p.xc + c0);      // (k_rows_stats: moments around row 0)
                 LAUNCH_OK();
                 c0 += p.cc.width[s];
             }
@@ -784,22 +786,27 @@ int gnn_train_step(const gnn_train_args_t *args) {
         float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);
         float *stats = p.stats_s + (size_t)t * 2 * p.in_s;
         if (bn_s) {
-            TRY(launch_aggregate_stats(gate, a.adjacency, s_t, p.S, agg_t, p.part_a, stats + p.off_agg, stats + p.in_s + p.off_agg, st));
+            // (moments around the previous iteration's column means: one-pass sums, but nothing of the mean's size left to cancel)
+            const float *prev = t > 0 ? p.stats_s + (size_t)(t - 1) * 2 * p.in_s : nullptr;
+            TRY(launch_aggregate_stats(gate, a.adjacency, s_t, p.S, agg_t, p.part_a, stats + p.off_agg, stats + p.in_s + p.off_agg, prev ? prev + p.off_agg : nullptr, st));
             if (t == 0) {          // (later iterations: k_train_fwd leaves the statistics of the state it writes)
                 int grid = 0;
                 TRY(rows_stats(gate, s_t, p.S, p.S, p.N, p.part_y, st, &grid));
-                gnn::k_stats_finish<<<p.S, 256, 0, st>>>(gate, p.part_y, grid, p.S, 1.0f / (float)p.N, stats, stats + p.in_s);
+                gnn::k_stats_finish<<<p.S, 256, 0, st>>>(gate, p.part_y, grid, p.S, 1.0f / (float)p.N, stats, stats + p.in_s, s_t);
                 LAUNCH_OK();
             }
         } else TRY(launch_aggregate(gate, a.adjacency, s_t, p.S, p.S, agg_t, p.S, st));
         const float *W0 = ns.kernel[0], *b0 = ns.bias[0];
         if (bn_s) {
             float *Wf = p.Wf_s + (size_t)t * p.in_s * p.H1s, *bf = p.bf_s + (size_t)t * p.H1s;
-            TRY(fold_with_stats(ns, stats, Wf, bf, st));
+            // (the rows are centred by the kernel as they arrive - Sum a W (x - mean) + (b + Sum beta W): a folded bias b + Sum (beta - mean a) W
+            //  would cancel Sum a W mean against itself, and inputs that sit far from zero - raw labels - lose that many digits of z)
+            TRY(fold_with_stats(ns, stats, Wf, bf, st, true));
             W0 = Wf; b0 = bf;
         }
         gnn::TrainFwdArgs fa;
         memset(&fa, 0, sizeof(fa));
+        fa.in_mean = bn_s ? stats : nullptr;
         fa.gate = gate; fa.M = p.N;
         fa.state = s_t; fa.ld_state = p.S; fa.agg = agg_t; fa.ld_agg = p.S; fa.xc = p.Kc > 0 ? p.xc : nullptr;
         fa.Wf = W0; fa.bf = b0; fa.H = p.S; fa.wrow_state = 0; fa.wrow_agg = p.off_agg; fa.cs = p.cc;
@@ -808,11 +815,12 @@ int gnn_train_step(const gnn_train_args_t *args) {
         fa.thr = a.state_threshold; fa.pred_flag = p.flags + t + 1; fa.pred_k = p.k_dev; fa.pred_kval = (float)(t + 1);
         const bool next_stats = bn_s && (t + 1 < p.K || (p.head_fast && bn_o));      // (the last state's: the output head's BatchNorm input)
         fa.stat_part = next_stats ? p.part_y : nullptr;
+        fa.stat_shift = next_stats ? stats : nullptr;         // (the new state's moments around the input state's column means)
         int grid = 0;
         TRY(launch_train_fwd(fa, p.S, st, &grid));
         if (next_stats) {
             float *nxt = p.stats_s + (size_t)(t + 1) * 2 * p.in_s;
-            gnn::k_stats_finish<<<p.S, 256, 0, st>>>(gate, p.part_y, grid, p.S, 1.0f / (float)p.N, nxt, nxt + p.in_s);
+            gnn::k_stats_finish<<<p.S, 256, 0, st>>>(gate, p.part_y, grid, p.S, 1.0f / (float)p.N, nxt, nxt + p.in_s, stats);
             LAUNCH_OK();
         }
     }
@@ -1022,6 +1030,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
                 wa.state = s_t; wa.agg = agg_t; wa.xc = p.xc;
                 wa.K = p.in_s; wa.wrow_state = 0; wa.wrow_agg = p.off_agg; wa.Kc = p.Kc; wa.cs = p.cc;
                 wa.part = p.part_w;
+                wa.mean = stats;                       // (BatchNormalization: the rows are centred as they arrive, P arrives as P - mean q^T)
                 const int grid = cdiv(p.N, wa.rows_per_wg);
                 if (!launch_train_wgrad32(wa, p.S, grid, st)) {       // (S = 16, or an activation without an instance: the 16x16x4 kernel)
                     switch (p.S) {
@@ -1037,7 +1046,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
                 gnn::k_first_layer_param_grads<<<p.in_s, 64, 0, st>>>(
                     p.cs.P, p.cs.q, ns.kernel[0], p.in_s, p.S, bn_s ? ns.bn_gamma : nullptr, ns.bn_beta, stats, stats ? stats + p.in_s : nullptr, ns.bn_eps,
                     1.0f / (float)p.N, ta.grad_state.dkernel[0], ta.grad_state.dbias[0], ta.grad_state.dgamma, ta.grad_state.dbeta,
-                    bn_s ? p.cs.m1 : nullptr, bn_s ? p.cs.m2 : nullptr, t != k - 1 ? 1 : 0, 1);
+                    bn_s ? p.cs.m1 : nullptr, bn_s ? p.cs.m2 : nullptr, t != k - 1 ? 1 : 0, 1, stats ? 1 : 0);
                 LAUNCH_OK();
             } else TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, nullptr, 0, p.part, st, p.off_agg));
             gnn::TrainBwdArgs ba;

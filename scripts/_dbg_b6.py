@@ -7,7 +7,8 @@ from gnnkeras_amd.Models.GNN import GNNnodeBased
 from gnnkeras_amd.Models.training import LoopTrainer, SGD
 from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
 from test_gpu_training import nets, oracle_step
-d, bn, mode = 64, True, 'average'
+d, bn, mode = 64, os.environ.get('DBG_BN', '1') == '1', 'average'
+ACT = os.environ.get('DBG_ACT', 'selu')
 rng = np.random.default_rng(d)
 N = 40_000
 g = er_graph(N, 6 * N, seed=5, aggregation_mode=mode)
@@ -15,7 +16,7 @@ om = rng.random(N) < 0.6
 t = np.zeros((int(om.sum()), 2)); t[np.arange(len(t)), rng.integers(0, 2, len(t))] = 1
 g = GraphObject(g.nodes, g.arcs, t, focus='n', set_mask=rng.random(N) < 0.9, output_mask=om, aggregation_mode=mode, sample_weight=rng.uniform(0.5, 1.5, len(t)))
 x, y, sw = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0]
-ns, no = nets('n', d, bn, scale=0.5)
+ns, no = nets('n', d, bn, act=ACT, scale=0.5)
 s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
 model = GNNnodeBased(ns, no, d, 4, 0.0)
 model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
@@ -29,3 +30,14 @@ for native in (True, False):
             errs.append(float(np.max(np.abs(g_.cpu().numpy() - r)) / max(float(np.max(np.abs(r))), 1e-12)))
     yp = float(np.max(np.abs(res['y_pred'].cpu().numpy() - want['y_pred'])))
     print('native' if native else 'blocks', os.environ.get('GNN_TRAIN_BF16X6', '1'), 'k', res['k'], 'loss err', abs(float(res['loss']) - want['loss']), 'y_pred abs err', yp, 'grad rel errs', ['%.1e' % e for e in errs])
+    if native and os.environ.get('DBG_DETAIL'):
+        gk = tr.gs.gradients()[2].cpu().numpy(); rk = want['grads_state'][2]
+        dk = np.abs(gk - rk)
+        print('kernel grad |ref| max', np.abs(rk).max(), 'diff max', dk.max())
+        print('per input-row block max diff: state', dk[:64].max(), 'labels', dk[64:78].max(), 'agg', dk[78:142].max(), 'rest', dk[142:].max())
+        cols = dk.max(axis=0); print('worst columns', np.argsort(-cols)[:8], cols[np.argsort(-cols)[:8]])
+        rows = dk.max(axis=1); print('worst rows', np.argsort(-rows)[:8], rows[np.argsort(-rows)[:8]])
+        gb = tr.gs.gradients()[3].cpu().numpy(); rb = want['grads_state'][3]
+        print('bias grad diff', np.abs(gb - rb)[:16], 'ref', rb[:8])
+        gg = tr.gs.gradients()[0].cpu().numpy(); rg = want['grads_state'][0]
+        print('gamma grad diff worst', np.argsort(-np.abs(gg - rg))[:6], np.sort(np.abs(gg - rg))[-6:], 'ref scale', np.abs(rg).max())

@@ -79,7 +79,7 @@ void check_fwd(int M, bool pred) {
 
 
 template <int SQ, bool W32>
-void check_wgrad(int M) {
+void check_wgrad(int M, bool centred = false) {
     const int S = 16 * SQ, L = 7, A_ = 3, Kc = 2 * L + A_, K = 2 * S + Kc, wa = S + L;
     std::mt19937 rng(3); std::normal_distribution<float> nd(0, 1);
     std::vector<float> G((size_t)M * S), Y((size_t)M * S), st((size_t)M * S), ag((size_t)M * S), xc((size_t)M * 32, 0.f);
@@ -94,6 +94,8 @@ void check_wgrad(int M) {
     a.G = up(G); a.Y = up(Y); a.act = GNN_ACT_TANH; a.state = up(st); a.agg = up(ag); a.xc = up(xc);
     a.K = K; a.wrow_state = 0; a.wrow_agg = wa; a.Kc = Kc; a.cs.n = 3; a.cs.width[0] = L; a.cs.wrow[0] = S; a.cs.width[1] = L; a.cs.wrow[1] = 2 * S + L; a.cs.width[2] = A_; a.cs.wrow[2] = 2 * S + 2 * L;
     a.part = part;
+    std::vector<float> mu(K + 1, 0.f);
+    if (centred) { for (int k = 0; k < K; ++k) mu[k] = 0.5f + 0.1f * nd(rng); a.mean = up(mu); }
     if constexpr (W32) gnn::k_train_wgrad32<SQ / 2, GNN_ACT_TANH><<<grid, 256>>>(a); else gnn::k_train_wgrad<SQ><<<grid, 256>>>(a);
     CK(hipDeviceSynchronize());
     std::vector<float> pt((size_t)grid * (K * S + S));
@@ -101,18 +103,19 @@ void check_wgrad(int M) {
     std::vector<double> P((size_t)(K + 1) * S, 0.0);
     for (int m = 0; m < M; ++m) for (int h = 0; h < S; ++h) {
         const double y = Y[(size_t)m * S + h], dz = G[(size_t)m * S + h] * (1.0 - y * y);
-        for (int j = 0; j < S; ++j) { P[(size_t)j * S + h] += st[(size_t)m * S + j] * dz; P[(size_t)(wa + j) * S + h] += ag[(size_t)m * S + j] * dz; }
-        for (int j = 0; j < L; ++j) { P[(size_t)(S + j) * S + h] += xc[(size_t)m * 32 + j] * dz; P[(size_t)(2 * S + L + j) * S + h] += xc[(size_t)m * 32 + L + j] * dz; }
-        for (int j = 0; j < A_; ++j) P[(size_t)(2 * S + 2 * L + j) * S + h] += xc[(size_t)m * 32 + 2 * L + j] * dz;
+        for (int j = 0; j < S; ++j) { P[(size_t)j * S + h] += (st[(size_t)m * S + j] - mu[j]) * dz; P[(size_t)(wa + j) * S + h] += (ag[(size_t)m * S + j] - mu[wa + j]) * dz; }
+        for (int j = 0; j < L; ++j) { P[(size_t)(S + j) * S + h] += (xc[(size_t)m * 32 + j] - mu[S + j]) * dz; P[(size_t)(2 * S + L + j) * S + h] += (xc[(size_t)m * 32 + L + j] - mu[2 * S + L + j]) * dz; }
+        for (int j = 0; j < A_; ++j) P[(size_t)(2 * S + 2 * L + j) * S + h] += (xc[(size_t)m * 32 + 2 * L + j] - mu[2 * S + 2 * L + j]) * dz;
         P[(size_t)K * S + h] += dz;
     }
     double worst = 0, scale = 0;
     for (size_t idx = 0; idx < P.size(); ++idx) { double sum = 0; for (int b = 0; b < grid; ++b) sum += pt[(size_t)b * (K * S + S) + idx]; worst = fmax(worst, fabs(sum - P[idx])); scale = fmax(scale, fabs(P[idx])); }
-    printf("wgrad<%d>%s M=%d  max abs err %.3e (scale %.3e)\n", SQ, W32 ? " 32x32" : "", M, worst, scale);
+    printf("wgrad<%d>%s M=%d centred=%d  max abs err %.3e (scale %.3e)\n", SQ, W32 ? " 32x32" : "", M, centred, worst, scale);
 }
 
 int main() {
-    for (int M : {1000, 40000, 77}) { check_wgrad<2, false>(M); check_wgrad<4, false>(M); check_wgrad<2, true>(M); check_wgrad<4, true>(M); }
+    for (int M : {1000, 40000, 77}) { check_wgrad<2, false>(M); check_wgrad<4, false>(M); check_wgrad<2, true>(M); check_wgrad<4, true>(M);
+        check_wgrad<1, false>(M, true); check_wgrad<4, false>(M, true); check_wgrad<2, true>(M, true); check_wgrad<4, true>(M, true); }
     for (int M : {1000, 40000, 77}) for (int pr = 0; pr < 2; ++pr) { check_fwd<1>(M, pr); check_fwd<2>(M, pr); check_fwd<4>(M, pr); check_fwd<1, 3>(M, pr); check_fwd<2, 3>(M, pr); check_fwd<4, 3>(M, pr); }
     for (int M : {1000, 40000}) for (int bn = 0; bn < 2; ++bn) for (int sc = 0; sc < 2; ++sc) {
         check_bwd<1, 2>(M, bn, sc); check_bwd<2, 4>(M, bn, sc); check_bwd<4, 8>(M, bn, sc);

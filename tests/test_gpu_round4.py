@@ -932,3 +932,41 @@ def test_starter_composite_py_defaults(mutag_graphs):
         for g_, r in zip(got, allref):
             err = float(np.max(np.abs(g_.cpu().numpy() - r)))
             assert err <= 2e-5 * max(float(np.max(np.abs(r))), 1e-12) or err <= 2e-5 * scale
+
+
+@pytest.mark.parametrize('act,d', [('linear', 32), ('relu', 64), ('tanh', 32), ('sigmoid', 64), ('elu', 32), ('softplus', 32)])
+def test_large_graph_training_kernels_for_every_activation(act, d):
+    """The large-graph dense kernels of round 4 (k_train_fwd_b6 / k_train_bwd_dx_b6: three-term bf16 splits on the bf16 matrix cores;
+    k_train_wgrad32) are instantiated per activation - 'selu' is what every other training test uses: one step on a 36 000-node graph
+    for each of the others against torch autograd in float64, both orchestrations."""
+    from test_gpu_training import nets, check_step
+    rng = np.random.default_rng(11)
+    N = 36_000
+    g = er_graph(N, 5 * N, seed=6, aggregation_mode='average')
+    t = np.zeros((N, 2)); t[np.arange(N), rng.integers(0, 2, N)] = 1
+    g = GraphObject(g.nodes, g.arcs, t, focus='n', aggregation_mode='average')
+    x, y, sw = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0]
+    ns, no = nets('n', d, True, act=act, scale=0.5)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    model = GNNnodeBased(ns, no, d, 3, 0.0)
+    check_step(model, x, y, sw, s0)
+
+
+def test_large_graph_training_with_labels_far_from_zero():
+    """BatchNormalization statistics on the large-graph path are ONE pass over the data (sums taken by the kernel that produces the column):
+    taken around a value near the mean - row 0 for the constant inputs, the previous iteration's column means for the state and its
+    neighbour average - so that E[x^2] - mean^2 has nothing of the mean's size to cancel.  Node labels with mean 30 and sigma 1 (raw sums
+    would leave the variance 3-4 digits), a relu state network (non-negative states, neighbour averages with var << mean^2): one step
+    against torch autograd in float64, both orchestrations."""
+    from test_gpu_training import nets, check_step
+    rng = np.random.default_rng(12)
+    N = 36_000
+    g = er_graph(N, 5 * N, seed=7, aggregation_mode='average')
+    nodes = g.nodes.copy(); nodes[:, :6] = rng.normal(30.0, 1.0, (N, 6)); nodes[:, 6:] = rng.normal(-12.0, 0.5, (N, nodes.shape[1] - 6))
+    t = np.zeros((N, 2)); t[np.arange(N), rng.integers(0, 2, N)] = 1
+    g = GraphObject(nodes, g.arcs, t, focus='n', aggregation_mode='average')
+    x, y, sw = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0]
+    ns, no = nets('n', 32, True, act='relu', scale=0.5)
+    s0 = np.abs(rng.normal(0, 0.1, (N, 32))).astype(np.float32)
+    model = GNNnodeBased(ns, no, 32, 3, 0.0)
+    check_step(model, x, y, sw, s0)

@@ -495,6 +495,8 @@ struct GradSegs {
     Seg seg[GNN_MAX_SEGS];            // wrow = first row of the segment in P
     int n;
     int blk_begin[GNN_MAX_SEGS + 1];  // blockIdx.y ranges (64 rows of K per block)
+    const float *mean;                // [K] by weight row or NULL: subtracted from X as it is staged - P arrives as (X - mean)^T dZ
+                                      // (k_first_layer_param_grads(centered = 1): no P - mean q^T to cancel afterwards)
 };
 __global__ void __launch_bounds__(256)
 k_dense_grad_partial_segs(GradSegs gs, int K, const float *__restrict__ dZ, int ldz, int H, int M, int rows_per_chunk,
@@ -522,7 +524,7 @@ k_dense_grad_partial_segs(GradSegs gs, int K, const float *__restrict__ dZ, int 
             const int mm = i / 64, cc = i % 64, m = m0 + mm;
             float xv = 0.0f, zv = 0.0f;
             if (m < m_end) {
-                if (k0 + cc < sg.width) xv = sg.ptr[(sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m) * sg.ld + k0 + cc];
+                if (k0 + cc < sg.width) xv = sg.ptr[(sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m) * sg.ld + k0 + cc] - (gs.mean ? gs.mean[sg.wrow + k0 + cc] : 0.0f);
                 if (h0 + cc < H) zv = dZ[(size_t)m * ldz + h0 + cc];
             }
             Xs[mm * DG_LD + cc] = xv;
@@ -578,7 +580,7 @@ k_dense_grad_allk(GradSegs gs, int K, const float *__restrict__ dZ, int ldz, int
         for (int c = 0; c < 4; ++c) acc[b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float qacc = 0.0f;
     // this thread's column of each 64-column block of the virtual concatenation: segment resolved once
-    const float *xptr[3]; const int *xidx[3]; int xld[3]; bool xon[3];
+    const float *xptr[3]; const int *xidx[3]; int xld[3]; bool xon[3]; float xmu[3];
 #pragma unroll
     for (int cb = 0; cb < 3; ++cb) {
         const int kv = cb * 64 + lane;
@@ -590,6 +592,7 @@ k_dense_grad_allk(GradSegs gs, int K, const float *__restrict__ dZ, int ldz, int
         }
         xon[cb] = kv < K;
         xptr[cb] = sg.ptr + (kv - sbeg); xidx[cb] = sg.rowidx; xld[cb] = sg.ld;
+        xmu[cb] = (gs.mean && kv < K) ? gs.mean[sg.wrow + (kv - sbeg)] : 0.0f;
     }
     // software pipeline: the next tile's global loads are in flight while this tile runs through the matrix cores
     float xr[3][DGA_TM / 4], zr[DGA_TM / 4];
@@ -600,7 +603,7 @@ k_dense_grad_allk(GradSegs gs, int K, const float *__restrict__ dZ, int ldz, int
             for (int pass = 0; pass < DGA_TM / 4; ++pass) {
                 const int m = m0 + wave + 4 * pass;
                 xr[cb][pass] = 0.0f;
-                if (cb * 64 < K && xon[cb] && m < m_end) xr[cb][pass] = xptr[cb][(xidx[cb] ? (size_t)xidx[cb][m] : (size_t)m) * xld[cb]];
+                if (cb * 64 < K && xon[cb] && m < m_end) xr[cb][pass] = xptr[cb][(xidx[cb] ? (size_t)xidx[cb][m] : (size_t)m) * xld[cb]] - xmu[cb];
             }
         }
 #pragma unroll

@@ -316,6 +316,7 @@ int net_backward(NetCtx &x, const gnn::Seg *segs, int nseg, float *const *hs, fl
         gnn::GradSegs gs;
         memset(&gs, 0, sizeof(gs));
         gs.n = nseg; gs.blk_begin[0] = 0;
+        gs.mean = (m.has_bn && stats) ? stats : nullptr;      // (rows centred as they are staged: see GradSegs::mean)
         for (int s = 0; s < nseg; ++s) { gs.seg[s] = segs[s]; gs.blk_begin[s + 1] = gs.blk_begin[s] + cdiv(segs[s].width, 64); }
         if (allk) {     // every column in one workgroup: dZ is read once (kernels_train.hpp)
             gnn::k_dense_grad_allk<<<n_chunks, 256, 0, st>>>(gs, K, G, ldg, H, M, rpc, part);
@@ -337,7 +338,8 @@ int net_backward(NetCtx &x, const gnn::Seg *segs, int nseg, float *const *hs, fl
     }
     gnn::k_first_layer_param_grads<<<K, 64, 0, st>>>(
         Pp, qp, m.kernel[0], K, H, bn ? m.bn_gamma : nullptr, m.bn_beta, stats, stats ? stats + K : nullptr, m.bn_eps, 1.0f / (float)M,
-        x.g->dkernel[0], x.g->dbias[0], x.g->dgamma, x.g->dbeta, bn ? x.m1 : nullptr, bn ? x.m2 : nullptr, accumulate ? 1 : 0, fuse_chunks);
+        x.g->dkernel[0], x.g->dbias[0], x.g->dgamma, x.g->dbeta, bn ? x.m1 : nullptr, bn ? x.m2 : nullptr, accumulate ? 1 : 0, fuse_chunks,
+        (bn && stats) ? 1 : 0);
     LAUNCH_OK();
     if (dx_all && kdx > 0) {
         if (second_row < 0 || second_row == first_col + kdx / 2) {

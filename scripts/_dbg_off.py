@@ -9,7 +9,7 @@ from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
 from test_gpu_training import nets, oracle_step
 OFF = float(os.environ.get('DBG_OFF', '30')); ACT = os.environ.get('DBG_ACT', 'relu')
 rng = np.random.default_rng(12)
-N = 36_000
+N = int(os.environ.get('DBG_N', '36000'))
 g = er_graph(N, 5 * N, seed=7, aggregation_mode='average')
 nodes = g.nodes.copy(); nodes[:, :6] = rng.normal(OFF, 1.0, (N, 6)); nodes[:, 6:] = rng.normal(-0.4 * OFF, 0.5, (N, nodes.shape[1] - 6))
 t = np.zeros((N, 2)); t[np.arange(N), rng.integers(0, 2, N)] = 1

@@ -21,7 +21,7 @@ def means(path, counter):
 f, w = means(sys.argv[1], 'FETCH_SIZE'), means(sys.argv[2], 'WRITE_SIZE')
 N, E, S = 1e6, 1e7, 64
 alg = {'k_aggregate_stats': E * (4 + 4 * S) + N * (4 + 4 * S), 'k_aggregate_vec': E * (4 + 4 * S) + N * (4 + 3 * 4 * S),
-       'k_train_fwd': N * (4 * S * 3 + 128), 'k_train_wgrad': N * (4 * S * 4 + 128), 'k_train_bwd_dx': N * (4 * S * 4 + 8 * S)}
+       'k_train_fwd': N * (4 * S * 3 + 128), 'k_train_wgrad': N * (4 * S * 4 + 128), 'k_train_bwd_dx': N * (4 * S * 4 + 8 * S)}     # (substring match: also k_train_fwd_b6, k_train_wgrad32, k_train_bwd_dx_b6)
 print('# HBM bytes per launch from the PMC counters (KiB units; FETCH doubled: gfx950 tallies the 128-byte requests of 16-byte-per-lane reads at 64 bytes)')
 print('# kernel, launches, FETCH raw MB, 2 x FETCH + WRITE MB, algorithmic MB, ratio')
 for k in sorted(f):

@@ -1,11 +1,11 @@
 #!/bin/bash
 # round-4 closing evidence, all on the build that ships: kernel-trace summaries of C3 / C4 / C5 / C4x4 (4 M / 40 M) / d = 200, the two
 # PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, kernel-trace only) of EVERY one of them -> profiles/hbm_traffic.json, the training
-# step's trace, the default bench line.  Run from the repo root on the GPU box:  bash scripts/gpu_r4_final.sh [TAKEN-note]
+# step's trace and PMC passes, the default bench line.  Run from the repo root on the GPU box:  [TAG=r04h] bash scripts/gpu_r4_final.sh [TAKEN-note]
 set -u
 export TMPDIR=/tmp
 TAKEN=${1:-"round 4 closing pass"}
-ROOT=$(pwd); TAG=r04f; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
+ROOT=$(pwd); TAG=${TAG:-r04f}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cp profiles/hbm_traffic.json $OUT/hbm_traffic.json 2>/dev/null || true
 COMMON="--warmup 1 --no-cpu-baseline --no-mutag --no-beyond-cache --no-training"
 run() {   # name, bench args...
@@ -33,5 +33,6 @@ $P $OUT/${TAG}_c4x4_pmc_FETCH_SIZE.csv $OUT/${TAG}_c4x4_pmc_WRITE_SIZE.csv 4e6 4
 $P $OUT/${TAG}_d200_pmc_FETCH_SIZE.csv $OUT/${TAG}_d200_pmc_WRITE_SIZE.csv 3e5 3e6 200 200 $OUT/hbm_traffic.json 800 k_state_xwide "$TAKEN" >> $OUT/parse_pmc.log 2>&1
 cp $OUT/hbm_traffic.json profiles/hbm_traffic.json        # (so that the bench line below reports THIS pass's traffic)
 bash scripts/gpu_profile_train.sh $TAG > $OUT/train_profile.log 2>&1 || true
+bash scripts/gpu_pmc_train.sh $TAG > $OUT/train_pmc.log 2>&1 || true      # (FETCH / WRITE passes of the large-graph training kernels: ${TAG}_train_pmc.txt)
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 3000 $OUT/bench_default.json

@@ -1,5 +1,8 @@
+"""Per-tensor errors of one large-graph training step (40 000 nodes, d = 64, BatchNorm, 4 iterations) against torch autograd in float64,
+in-library step and Python building blocks.  DBG_ACT=relu|selu|.., DBG_BN=0, DBG_DETAIL=1; GNN_TRAIN_BF16X6=0 / GNN_TRAIN_WGRAD32=0 for the f32 kernels.
+(profiles/r04_notes.txt sections 6-7 quote it.)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from gnnkeras_amd import GraphObject
 from gnnkeras_amd.synth import er_graph

@@ -1,5 +1,7 @@
+"""The same with node labels N(DBG_OFF, 1) / N(-0.4 DBG_OFF, 0.5): how far from zero the inputs may sit (DBG_N nodes, DBG_ACT).
+(profiles/r04_notes.txt section 7 quotes it.)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from gnnkeras_amd import GraphObject
 from gnnkeras_amd.synth import er_graph

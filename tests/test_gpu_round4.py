@@ -970,3 +970,16 @@ def test_large_graph_training_with_labels_far_from_zero():
     s0 = np.abs(rng.normal(0, 0.1, (N, 32))).astype(np.float32)
     model = GNNnodeBased(ns, no, 32, 3, 0.0)
     check_step(model, x, y, sw, s0)
+
+
+def test_large_graph_training_on_the_f32_mfma_kernels_in_a_child_process():
+    """GNN_TRAIN_BF16X6=0 GNN_TRAIN_WGRAD32=0 (read once per process, hence the child): the large-graph training tests on the exact-f32
+    kernels the bf16-split ones replaced by default (k_train_fwd / k_train_bwd_dx / k_train_wgrad: the same centred arithmetic)."""
+    import os, subprocess, sys
+    root = os.path.dirname(nat.HERE)
+    env = dict(os.environ, GNN_TRAIN_BF16X6='0', GNN_TRAIN_WGRAD32='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    sel = 'large_graph_training_step_matches_autograd or every_activation or far_from_zero or thin_output_head'
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_round3.py'), os.path.join(root, 'tests', 'test_gpu_round4.py'),
+                          '-m', 'gpu', '-q', '-x', '-k', sel], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert ' passed' in res.stdout

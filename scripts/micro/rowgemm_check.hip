@@ -44,7 +44,7 @@ void check_bwd(int M, bool bn, bool scale) {
 }
 
 template <int SQ, int W32 = 0>
-void check_fwd(int M, bool pred) {
+void check_fwd(int M, bool pred, bool centred = false) {
     const int S = 16 * SQ, L = 7, A_ = 3, K = 2 * S + 2 * L + A_, wa = S + L;
     std::mt19937 rng(2); std::normal_distribution<float> nd(0, 1);
     std::vector<float> st((size_t)M * S), ag((size_t)M * S), xc((size_t)M * 32, 0.f), Wf((size_t)K * S), bf(S);
@@ -56,25 +56,29 @@ void check_fwd(int M, bool pred) {
     a.M = M; a.state = up(st); a.ld_state = S; a.agg = up(ag); a.ld_agg = S; a.xc = up(xc); a.Wf = up(Wf); a.bf = up(bf); a.H = S;
     a.wrow_state = 0; a.wrow_agg = wa; a.cs.n = 3; a.cs.width[0] = L; a.cs.wrow[0] = S; a.cs.width[1] = L; a.cs.wrow[1] = 2 * S + L; a.cs.width[2] = A_; a.cs.wrow[2] = 2 * S + 2 * L;
     a.act = GNN_ACT_TANH; a.Y = dY; a.ldy = S; a.thr = 1e9f; a.pred_flag = pred ? flag : nullptr; a.stat_part = part;
+    std::vector<float> mu(K, 0.f);
+    if (centred) { for (auto &x : mu) x = 0.4f + 0.2f * nd(rng); a.in_mean = up(mu); a.stat_shift = a.in_mean; }
     if constexpr (W32 == 3) gnn::k_train_fwd_b6<SQ, GNN_ACT_TANH><<<64, 64 * gnn::TB_WAVES, gnn::train_fwd_b6_lds<SQ>()>>>(a);
     else gnn::k_train_fwd<SQ, SQ><<<64, 64 * gnn::TB_WAVES, gnn::train_fwd_lds<SQ, SQ>()>>>(a);
     CK(hipDeviceSynchronize());
     std::vector<float> got((size_t)M * S), pt(64 * 2 * S);
     CK(hipMemcpy(got.data(), dY, got.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(pt.data(), part, pt.size() * 4, hipMemcpyDeviceToHost));
-    double worst = 0; std::vector<double> s1(S, 0), s2(S, 0);
+    double worst = 0, bias_sum = 0, abs_sum = 0; std::vector<double> s1(S, 0), s2(S, 0);
     for (int m = 0; m < M; ++m) for (int h = 0; h < S; ++h) {
         double z = bf[h];
-        for (int j = 0; j < S; ++j) z += (double)st[(size_t)m * S + j] * Wf[(size_t)j * S + h] + (double)ag[(size_t)m * S + j] * Wf[(size_t)(wa + j) * S + h];
-        for (int j = 0; j < L; ++j) z += (double)xc[(size_t)m * 32 + j] * Wf[(size_t)(S + j) * S + h] + (double)xc[(size_t)m * 32 + L + j] * Wf[(size_t)(2 * S + L + j) * S + h];
-        for (int j = 0; j < A_; ++j) z += (double)xc[(size_t)m * 32 + 2 * L + j] * Wf[(size_t)(2 * S + 2 * L + j) * S + h];
-        const double y = tanh(z);
-        worst = fmax(worst, fabs(y - got[(size_t)m * S + h])); s1[h] += y; s2[h] += y * y;
+        for (int j = 0; j < S; ++j) z += ((double)st[(size_t)m * S + j] - mu[j]) * Wf[(size_t)j * S + h] + ((double)ag[(size_t)m * S + j] - mu[wa + j]) * Wf[(size_t)(wa + j) * S + h];
+        for (int j = 0; j < L; ++j) z += ((double)xc[(size_t)m * 32 + j] - mu[S + j]) * Wf[(size_t)(S + j) * S + h] + ((double)xc[(size_t)m * 32 + L + j] - mu[2 * S + L + j]) * Wf[(size_t)(2 * S + L + j) * S + h];
+        for (int j = 0; j < A_; ++j) z += ((double)xc[(size_t)m * 32 + 2 * L + j] - mu[2 * S + 2 * L + j]) * Wf[(size_t)(2 * S + 2 * L + j) * S + h];
+        const double y = tanh(z), ys = y - (centred ? mu[h] : 0.0);          // (statistics partials are sums of y - stat_shift)
+        worst = fmax(worst, fabs(y - got[(size_t)m * S + h])); s1[h] += ys; s2[h] += ys * ys;
+        bias_sum += ((double)got[(size_t)m * S + h] - y) * (y > 0 ? 1.0 : -1.0); abs_sum += fabs((double)got[(size_t)m * S + h] - y);
     }
     double ws = 0;
     for (int h = 0; h < S; ++h) { double a1 = 0, a2 = 0; for (int b = 0; b < 64; ++b) { a1 += pt[(size_t)b * 2 * S + h]; a2 += pt[(size_t)b * 2 * S + S + h]; }
         ws = fmax(ws, fmax(fabs(a1 - s1[h]) / M, fabs(a2 - s2[h]) / M)); }
     int fl = -1; CK(hipMemcpy(&fl, flag, 4, hipMemcpyDeviceToHost));
-    printf("fwd<%d>%s M=%d pred=%d  max abs err %.3e  stats err %.3e  flag %d\n", SQ, W32 == 3 ? " bf16x6" : W32 == 2 ? " 32x32p" : W32 ? " 32x32" : "", M, pred, worst, ws, fl);
+    printf("   (mean error signed by the value's sign %.3e, mean |error| %.3e)\n", bias_sum / ((double)M * S), abs_sum / ((double)M * S));
+    printf("fwd<%d>%s M=%d pred=%d centred=%d  max abs err %.3e  stats err %.3e  flag %d\n", SQ, W32 == 3 ? " bf16x6" : W32 == 2 ? " 32x32p" : W32 ? " 32x32" : "", M, pred, centred, worst, ws, fl);
 }
 
 
@@ -114,6 +118,7 @@ void check_wgrad(int M, bool centred = false) {
 }
 
 int main() {
+    for (int M : {1000, 40000}) { check_fwd<1>(M, true, true); check_fwd<2>(M, true, true); check_fwd<4>(M, true, true); check_fwd<1, 3>(M, true, true); check_fwd<2, 3>(M, true, true); check_fwd<4, 3>(M, true, true); }
     for (int M : {1000, 40000, 77}) { check_wgrad<2, false>(M); check_wgrad<4, false>(M); check_wgrad<2, true>(M); check_wgrad<4, true>(M);
         check_wgrad<1, false>(M, true); check_wgrad<4, false>(M, true); check_wgrad<2, true>(M, true); check_wgrad<4, true>(M, true); }
     for (int M : {1000, 40000, 77}) for (int pr = 0; pr < 2; ++pr) { check_fwd<1>(M, pr); check_fwd<2>(M, pr); check_fwd<4>(M, pr); check_fwd<1, 3>(M, pr); check_fwd<2, 3>(M, pr); check_fwd<4, 3>(M, pr); }

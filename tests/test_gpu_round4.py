@@ -989,3 +989,23 @@ def test_large_graph_training_on_the_f32_mfma_kernels_in_a_child_process():
                           '-m', 'gpu', '-q', '-x', '-k', sel], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert ' passed' in res.stdout
+
+
+@pytest.mark.parametrize('dim_arc_label,bn', [(4, True), (4, False)])
+def test_large_graph_training_with_a_full_constants_line(dim_arc_label, bn):
+    """14 node-label + 14 aggregated-label + 4 aggregated-arc-label columns fill the 32-column constants line of the large-graph kernels: no
+    room for the line's 1, so the weight gradient takes the general kernels and k_train_bwd_dx_b6 is handed a finished dZ (its LINEAR
+    instance, Y loads out of range): one step against torch autograd in float64, both orchestrations."""
+    from test_gpu_training import check_step
+    rng = np.random.default_rng(13)
+    N, d = 34_000, 32
+    g = er_graph(N, 4 * N, dim_arc_label=dim_arc_label, seed=8, aggregation_mode='average')
+    inp, lay = get_inout_dims('state', 14, dim_arc_label, 2, 'n', d)
+    ns = MLP(inp[0], lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=0, batch_normalization=bn)
+    ns.set_weights([a * 0.5 if a.ndim == 2 else a for a in ns.get_weights()])
+    inp, lay = get_inout_dims('output', 14, dim_arc_label, 2, 'n', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1, batch_normalization=bn)
+    x, y, sw = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0]
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    model = GNNnodeBased(ns, no, d, 3, 0.0)
+    check_step(model, x, y, sw, s0)

@@ -422,6 +422,10 @@ typedef struct gnn_train_args {
      * gradients train through the building blocks. */
     gnn_mlp_grads_t grad_state_types[GNN_MAX_TYPES];
 } gnn_train_args_t;
+/* Arithmetic: float32 throughout.  On graphs of >= GNN_TRAIN_BIG_MIN_NODES (32 768) nodes the first Dense's forward product and dZ . W^T run on
+ * the bf16 matrix cores with every float32 operand split into three bf16 terms (six products, float32 accumulation: the accuracy of a
+ * float32 product chain, not its bits; GNN_TRAIN_BF16X6=0 selects float32-input MFMAs), and every kernel of that path subtracts the
+ * BatchNormalization column mean from a row as it arrives. */
 size_t gnn_train_workspace_bytes(const gnn_train_args_t *args);
 int gnn_train_step(const gnn_train_args_t *args);
 

@@ -391,19 +391,34 @@ def roofline_record(b_iter, t_iter, kernel_name, n_nodes=None, h1=None):
     return rec
 
 
-def traffic_lookup(rec, kernel_name, N, E, d):
+def traffic_lookup(rec, kernel_name, N, E, d, traffic_file=None):
     """HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same workload,
-    scripts/parse_pmc.py -> profiles/hbm_traffic.json): recorded per (kernel, workload), used only when both match this run."""
-    traffic_file = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-    if not os.path.exists(traffic_file): return rec
+    scripts/parse_pmc.py -> profiles/hbm_traffic.json): recorded per (kernel, workload, library sources), used only when all three
+    match this run - a record taken on other sources of csrc/ (its `library_source_hash` differs from
+    gnnkeras_amd._native.source_hash()) is NOT this binary's traffic: `traffic` stays null and `traffic_null_reason` says why."""
+    from gnnkeras_amd._native import source_hash
+    traffic_file = traffic_file or os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    if not os.path.exists(traffic_file):
+        rec['traffic_null_reason'] = 'profiles/hbm_traffic.json is missing'
+        return rec
+    here = source_hash()
+    rec['library_source_hash'] = here
     try:
+        stale = None
         for tr in json.load(open(traffic_file)).get('records', []):
             if tr.get('kernel') == kernel_name and tr.get('nodes') == N and tr.get('arcs') == E and tr.get('state_dim') == d:
+                if tr.get('library_source_hash') != here:
+                    stale = tr.get('library_source_hash')
+                    continue
                 rec['traffic'] = tr['hbm_bytes_per_launch']
                 rec['traffic_bounds'] = tr.get('bounds')
-                rec['traffic_source'] = f"profiles/hbm_traffic.json: {tr.get('launches')} launches of this kernel on this workload, {tr.get('taken', 'PMC passes of the round')}"
-    except Exception:
-        pass
+                rec['traffic_source'] = (f"profiles/hbm_traffic.json: {tr.get('launches')} launches of this kernel on this workload, "
+                                         f"sources {here}, {tr.get('taken', 'PMC passes of the round')}")
+        if rec.get('traffic') is None:
+            rec['traffic_null_reason'] = (f'the PMC record of this kernel and workload was taken on other library sources ({stale} != {here})'
+                                          if stale is not None else 'no PMC record for this kernel and workload')
+    except Exception as e:
+        rec['traffic_null_reason'] = f'profiles/hbm_traffic.json unreadable: {e}'
     return rec
 
 

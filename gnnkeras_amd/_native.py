@@ -129,6 +129,21 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def source_hash() -> str:
+    """Identity of the library's SOURCES (every file of csrc/ that make compiles + the C header), 16 hex digits of a SHA-256 over
+    (name, content) in name order.  Computable where there is no .git (the GPU box gets a snapshot without it): the PMC traffic records
+    of profiles/hbm_traffic.json carry it, and bench.py reports a record's traffic only when it was taken on THESE sources."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.hpp', '.cpp')) or f == 'Makefile')
+    paths = [os.path.join(CSRC, f) for f in files] + [os.path.join(os.path.dirname(HERE), 'include', 'gnnloop.h')]
+    for path in paths:
+        h.update(os.path.basename(path).encode() + b'\0')
+        with open(path, 'rb') as fh: h.update(fh.read())
+        h.update(b'\0')
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 

@@ -15,8 +15,12 @@ kernel reads its state rows 16 B per lane but its row pointers, source ids and c
 cannot tell them apart, so two bounds are recorded:
     upper = 2 x FETCH                       (every read tallied at half)
     lower = 2 x FETCH - dword_bytes         (the dword reads tallied in full; dword_bytes = their algorithmic byte count)
-`hbm_bytes_per_launch` (what bench.py reports as roofline.traffic) is the upper bound.  Units of the counters are KiB."""
+`hbm_bytes_per_launch` (what bench.py reports as roofline.traffic) is the upper bound.  Units of the counters are KiB.
+Every record carries `library_source_hash` (gnnkeras_amd._native.source_hash(): the csrc/ sources + include/gnnloop.h the passes ran
+on); bench.py prints a record's traffic only when the hash equals that of the sources it runs on."""
 import csv, json, os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gnnkeras_amd._native import source_hash
 fetch_csv, write_csv = sys.argv[1], sys.argv[2]
 n_nodes, n_arcs, d, h1 = int(float(sys.argv[3])), int(float(sys.argv[4])), int(sys.argv[5]), int(sys.argv[6])
 out = sys.argv[7]
@@ -43,7 +47,7 @@ rec = {'kernel': kname, 'const_bytes_per_node': const_bytes, 'nodes': n_nodes, '
        'FETCH_SIZE_KiB_raw_mean': statistics.mean(f), 'WRITE_SIZE_KiB_mean': statistics.mean(w),
        'write_bytes': write_b, 'hbm_bytes_per_launch': upper, 'bounds': [lower, upper],
        'algorithmic_bytes_per_launch': algorithmic, 'traffic_over_algorithmic': [lower / algorithmic, upper / algorithmic],
-       'taken': sys.argv[10] if len(sys.argv) > 10 else None,
+       'taken': sys.argv[10] if len(sys.argv) > 10 else None, 'library_source_hash': source_hash(),
        'note': 'upper: every read doubled (gfx950 tallies 128-B requests at 64 B for 16 B/lane reads); lower: the dword reads '
                '(row pointers, source ids, constant term) taken as tallied in full'}
 data = {'records': []}

@@ -333,3 +333,27 @@ def test_mutag_composite_graphs_are_the_same_graphs_with_one_node_type(mutag_gra
         assert np.array_equal(c.CompositeAdjacencies[0].toarray(), c.Adjacency.toarray())
     x, y, sw = CompositeMultiGraphSequencer(cgs, 'g', 'average', 7, shuffle=False)[0]
     assert len(x) == 10 and y.shape == (7, 2)
+
+
+def test_bench_reports_pmc_traffic_only_for_the_library_sources_it_runs_on(tmp_path):
+    """a PMC record of profiles/hbm_traffic.json is this run's traffic only when it was taken on THESE sources of
+    csrc/ (`library_source_hash`): otherwise `traffic` is null and `traffic_null_reason` says why."""
+    import importlib.util, json, os
+    from gnnkeras_amd._native import source_hash
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_for_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    here = source_hash()
+    assert len(here) == 16 and here == source_hash()
+    f = tmp_path / 'traffic.json'
+    base = {'kernel': 'k_x<64>', 'nodes': 10, 'arcs': 20, 'state_dim': 64, 'hbm_bytes_per_launch': 123.0, 'bounds': [100.0, 123.0], 'launches': 7}
+    f.write_text(json.dumps({'records': [dict(base, library_source_hash='0' * 16)]}))
+    rec = bench.traffic_lookup({'traffic': None}, 'k_x<64>', 10, 20, 64, traffic_file=str(f))
+    assert rec['traffic'] is None and 'other library sources' in rec['traffic_null_reason'] and rec['library_source_hash'] == here
+    f.write_text(json.dumps({'records': [dict(base, library_source_hash='0' * 16), dict(base, library_source_hash=here)]}))
+    rec = bench.traffic_lookup({'traffic': None}, 'k_x<64>', 10, 20, 64, traffic_file=str(f))
+    assert rec['traffic'] == 123.0 and 'traffic_null_reason' not in rec and here in rec['traffic_source']
+    rec = bench.traffic_lookup({'traffic': None}, 'k_y<64>', 10, 20, 64, traffic_file=str(f))
+    assert rec['traffic'] is None and rec['traffic_null_reason'] == 'no PMC record for this kernel and workload'
+    rec = bench.traffic_lookup({'traffic': None}, 'k_x<64>', 10, 20, 64, traffic_file=str(tmp_path / 'absent.json'))
+    assert rec['traffic'] is None and 'missing' in rec['traffic_null_reason']

@@ -576,6 +576,7 @@ def main():
     ap.add_argument('--aggregation', default='average')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-mutag', action='store_true')
+    ap.add_argument('--mutag-dp', action='store_true', help='N>1: also run the MUTAG data-parallel side section (collective; a rank that fails in it ends the job)')
     ap.add_argument('--no-beyond-cache', action='store_true')
     ap.add_argument('--no-training', action='store_true', help='skip the train_step / fit() section')
     ap.add_argument('--unfused', action='store_true')
@@ -584,6 +585,9 @@ def main():
                     help='N>1 state exchange: whole slices by RCCL all-gather / by concurrent point-to-point pairs, or compacted halos '
                          '(all-to-all); auto = halo for graphs with locality, else the faster whole-slice transport, measured at start-up')
     ap.add_argument('--no-overlap', action='store_true', help='N>1: exchange strictly after the iteration kernel (no own-range / halo split)')
+    ap.add_argument('--exchange-pipeline', default='off',
+                    help="N>1: 'off' (default: one halo-kernel launch + one exchange per iteration, the validated path), 'auto' (1 / 2 / 4 chunk "
+                         "launches timed at the first forward, a chunked count kept only when > 5 %% faster) or a chunk count")
     ap.add_argument('--pipeline-chunks', type=int, default=1,
                     help='--emulate-shard: launch the halo kernel in this many chunk launches (the pipelined exchange, distributed.py set_pipeline)')
     ap.add_argument('--emulate-shard', default=None, metavar='r/R',
@@ -682,7 +686,7 @@ def main():
         from gnnkeras_amd.distributed import make_sharded_loop
         t_plan0 = time.perf_counter()
         sl = make_sharded_loop(gnn, graph, rank=rank, world_size=world, device=device, exchange=args.exchange,
-                               overlap=not args.no_overlap)
+                               overlap=not args.no_overlap, pipeline=args.exchange_pipeline)
         torch.cuda.synchronize()
         extra['plan_build_s'] = (time.perf_counter() - t_plan0) + t_graph
         extra['host_rss_mb'] = host_rss_mb()
@@ -785,22 +789,21 @@ def main():
         except Exception as e:                        # never lose the headline line to the extras
             result['wide_state_d200'] = {'error': str(e)[:300]}
 
-    if sharded and (world > 1 or args.force_sharded) and not args.no_mutag and args.workload == 'c4':
+    # The MUTAG data-parallel record is a COLLECTIVE side section: a rank that fails inside it leaves the others waiting in some collective,
+    # and no new collective can be issued from an exception path to agree on the failure (it would pair with whatever collective
+    # the others are in).  So at world size > 1 it runs only when asked for (--mutag-dp), after everything the headline line needs has been
+    # measured, and a failing rank exits non-zero - the launcher then tears the job down instead of letting it hang.  At world size 1
+    # (--force-sharded on a 1-GPU box) a failure is local and simply recorded.
+    if sharded and ((world == 1 and args.force_sharded) or (world > 1 and args.mutag_dp)) and not args.no_mutag and args.workload == 'c4':
         del sl
         torch.cuda.empty_cache()
-        # a collective section: every rank runs it, and every rank must leave it - an exception on one rank alone would strand the
-        # others in a collective - so failures are agreed on (MAX of an error flag) and reported instead of losing the headline line
-        err = None
         try:
-            rec = mutag_dp_section(device, rank, world)
+            result['mutag_data_parallel'] = mutag_dp_section(device, rank, world)
         except Exception as e:
-            rec, err = None, str(e)[:300]
-        bad = torch.tensor([1.0 if err else 0.0], device=device)
-        try:
-            if world > 1: torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
-        except Exception as e:
-            err = err or str(e)[:300]
-        result['mutag_data_parallel'] = rec if float(bad) == 0 and err is None else {'error': err or 'failed on another rank'}
+            if world > 1:
+                print(f'bench.py: rank {rank} failed in the MUTAG data-parallel section: {e}', file=sys.stderr, flush=True)
+                os._exit(3)
+            result['mutag_data_parallel'] = {'error': str(e)[:300]}
     # RCCL writes its version banner through C stdio, which would otherwise reach the pipe AFTER this process' last Python write (at
     # exit): drain it first so that the JSON line is the LAST line of stdout (it is also the only line that starts with '{').
     try:

@@ -219,6 +219,7 @@ class _LoopModel:
                 ws.append(float(data[1].shape[0]) if data[1] is not None else 1.0)
                 for key, val in r.items():
                     if key != 'k': vals.setdefault(key, []).append(val)        # device scalars stay on the device: no sync per step and value
+            if getattr(self, '_trainer', None) is not None: self._trainer.resolve_pending()      # (the last step's validity word: training.py)
             wsum = float(sum(ws))
             logs = {}
             for key, lst in vals.items():                          # one transfer per logged quantity and epoch; the weighted mean in float64

@@ -37,8 +37,10 @@ class Adam:
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
         self.iterations, self._slots = 0, {}
 
-    def apply_gradients(self, grads_and_vars):
-        """Every variable in ONE launch (`gnn_adam_multi`); the pointer tables are rebuilt only when the set of tensors changes."""
+    def apply_gradients(self, grads_and_vars, gate=None):
+        """Every variable in ONE launch (`gnn_adam_multi`); the pointer tables are rebuilt only when the set of tensors changes.
+        `gate`: address of a device int32 - the launch changes nothing when it holds 0 (`gnn_train_step`'s validity word: the gradients of
+        a step whose persistent backward launch failed never reach the weights; include/gnnloop.h, ABI 7)."""
         self.iterations += 1
         grads_and_vars = list(grads_and_vars)
         if not grads_and_vars: return
@@ -56,7 +58,7 @@ class Adam:
         _, P, G, M, V, N, n, _keep = tab
         dev = grads_and_vars[0][1].device
         nat.check(nat.lib().gnn_adam_multi(P, G, M, V, N, n, float(self.learning_rate), float(self.beta_1), float(self.beta_2),
-                                           float(self.epsilon), self.iterations, nat.current_stream(dev)))
+                                           float(self.epsilon), self.iterations, C.c_void_p(gate or 0), nat.current_stream(dev)))
 
 
 class SGD:
@@ -64,7 +66,7 @@ class SGD:
         self.learning_rate, self.momentum = learning_rate, momentum
         self.iterations, self._slots = 0, {}
 
-    def apply_gradients(self, grads_and_vars):
+    def apply_gradients(self, grads_and_vars, gate=None):
         self.iterations += 1
         lib = nat.lib()
         for g, p in grads_and_vars:
@@ -74,7 +76,7 @@ class SGD:
                 if key not in self._slots: self._slots[key] = (torch.zeros_like(p), p)
                 vel = self._slots[key][0]
             nat.check(lib.gnn_sgd_step(nat.ptr(p), nat.ptr(g), nat.ptr(vel), p.numel(), float(self.learning_rate),
-                                       float(self.momentum), nat.current_stream(p.device)))
+                                       float(self.momentum), C.c_void_p(gate or 0), nat.current_stream(p.device)))
 
 
 def get_optimizer(opt):
@@ -119,8 +121,9 @@ class _Prim:
     def zeros(self, *shape):
         return torch.zeros(shape, dtype=torch.float32, device=self.dev)
 
-    def dense(self, segs, W, H, bias, act, Y, wrows=None, out_rowidx=None):
-        """Y[:, :H] = act(sum_s seg_s . W[wrow_s : wrow_s + width_s, :H] + bias).  W: 2-D view (ld = stride(0))."""
+    def dense(self, segs, W, H, bias, act, Y, wrows=None, out_rowidx=None, center=None):
+        """Y[:, :H] = act(sum_s (seg_s - center[wrow_s : wrow_s + width_s]) . W[wrow_s : wrow_s + width_s, :H] + bias).  W: 2-D view
+        (ld = stride(0)); `center` (by weight row, or None): subtracted as the inputs are staged - the consumer of `fold(centred=True)`."""
         d = nat.DenseArgs()
         M = Y.shape[0] if out_rowidx is None else len(out_rowidx)
         d.M, d.H, d.n_segments = M, H, len(segs)
@@ -135,6 +138,7 @@ class _Prim:
         d.activation = act
         d.Y, d.ldy = Y.data_ptr(), Y.stride(0)
         d.out_rowidx = 0 if out_rowidx is None else out_rowidx.data_ptr()
+        d.in_center = 0 if center is None else center.data_ptr()
         d.stream = self.stream()
         nat.check(self.lib.gnn_dense(C.byref(d)))
         return Y
@@ -144,11 +148,12 @@ class _Prim:
         nat.check(self.lib.gnn_aggregate(C.byref(c), nat.ptr(X), X.stride(0), F, nat.ptr(out), out.stride(0), self.stream()))
         return out
 
-    def fold(self, W, b, bn, mean, var, Wf, bf):
+    def fold(self, W, b, bn, mean, var, Wf, bf, centred=False):
+        """Wf = a W, bf = b + (beta - mean a) W; `centred`: bf = b + beta W (the consumer subtracts the mean from its inputs: dense(center=))."""
         K, H = W.shape
         g, be = (bn[0], bn[1]) if bn is not None else (None, None)
         nat.check(self.lib.gnn_fold_bn(nat.ptr(W), nat.ptr(b), K, H, nat.ptr(g), nat.ptr(be), nat.ptr(mean), nat.ptr(var),
-                                       BN_EPSILON, nat.ptr(Wf), nat.ptr(bf), self.stream()))
+                                       BN_EPSILON, nat.ptr(Wf), nat.ptr(bf), int(bool(centred)), self.stream()))
 
     def colstats(self, x, ridx, M, mean, var):
         K = x.shape[1]
@@ -157,13 +162,14 @@ class _Prim:
         nat.check(self.lib.gnn_colstats(nat.ptr(x), x.stride(0), nat.ptr(ridx), K, M, nat.ptr(mean), nat.ptr(var), None, None,
                                         BN_MOMENTUM, None, nat.ptr(ws), ws.numel(), self.stream()))
 
-    def dense_grad(self, x, ridx, dZ, M, P, q, accumulate):
+    def dense_grad(self, x, ridx, dZ, M, P, q, accumulate, center=None):
+        """P (+)= (x[rows] - center)^T dZ, q (+)= colsum(dZ); `center`: [K] view or None."""
         K, H = x.shape[1], dZ.shape[1]
         assert P.is_contiguous() and P.shape[-1] == H
         nb = self._ws_bytes('gnn_dense_grad_workspace_bytes', K, H, M)
         ws = self.ws(nb)
         nat.check(self.lib.gnn_dense_grad(nat.ptr(x), x.stride(0), nat.ptr(ridx), K, nat.ptr(dZ), dZ.stride(0), H, M,
-                                          nat.ptr(P), nat.ptr(q), int(accumulate), nat.ptr(ws), ws.numel(), self.stream()))
+                                          nat.ptr(P), nat.ptr(q), int(accumulate), nat.ptr(center), nat.ptr(ws), ws.numel(), self.stream()))
 
     def act_grad(self, G, Y, dZ, act):
         M, H = Y.shape
@@ -171,13 +177,14 @@ class _Prim:
                                         self.stream()))
         return dZ
 
-    def first_layer_param_grads(self, P, q, W, bn, mean, var, M, dW, db, dgamma, dbeta, m1, m2, accumulate):
+    def first_layer_param_grads(self, P, q, W, bn, mean, var, M, dW, db, dgamma, dbeta, m1, m2, accumulate, centered=False):
+        """`centered`: P was formed from inputs with the BatchNormalization column means already subtracted (dense_grad(center=))."""
         K, H = W.shape
         g, be = (bn[0], bn[1]) if bn is not None else (None, None)
         nat.check(self.lib.gnn_first_layer_param_grads(nat.ptr(P), nat.ptr(q), nat.ptr(W), K, H, nat.ptr(g), nat.ptr(be),
                                                        nat.ptr(mean), nat.ptr(var), BN_EPSILON, M, nat.ptr(dW), nat.ptr(db),
                                                        nat.ptr(dgamma), nat.ptr(dbeta), nat.ptr(m1), nat.ptr(m2),
-                                                       int(accumulate), self.stream()))
+                                                       int(accumulate), int(bool(centered and bn is not None)), self.stream()))
 
     def bn_input_grad(self, dy, x, ridx, M, k0, bn, mean, var, m1, m2, dx):
         width = dy.shape[1]
@@ -340,20 +347,22 @@ class LoopTrainer:
             eye = _eye(ng, K, p)
             if ng.bn:
                 Wn, bn_ = p.new(K, K), p.new(K)
-                p.fold(eye, p.zeros(K), ng.bn_params, mean, var, Wn, bn_)
+                p.fold(eye, p.zeros(K), ng.bn_params, mean, var, Wn, bn_, centred=True)
             else:
                 Wn, bn_ = eye, None
-            xn = p.dense(segs, Wn, K, bn_, 0, p.new(M, K))
+            xn = p.dense(segs, Wn, K, bn_, 0, p.new(M, K), center=mean if ng.bn else None)
             x0 = self._dropped(ng, 0, xn, call)
             hs = _Acts([p.dense([(x0, None)], ng.W[0], net.units[0], ng.b[0], ng.acts[0], p.new(M, net.units[0]))])
             hs.x0 = x0
         else:
+            # BatchNormalization as a (x - mean) + beta: the column mean leaves the value as it is staged (a folded bias b + (beta - mean a) W
+            # would cancel mean a W against a x W afterwards - digits lost in proportion to mean / sigma: labels far from zero)
             if ng.bn:
                 Wf, bf = p.new(*ng.W[0].shape), p.new(ng.W[0].shape[1])
-                p.fold(ng.W[0], ng.b[0], ng.bn_params, mean, var, Wf, bf)
+                p.fold(ng.W[0], ng.b[0], ng.bn_params, mean, var, Wf, bf, centred=True)
             else:
                 Wf, bf = ng.W[0], ng.b[0]
-            hs = _Acts([p.dense(segs, Wf, net.units[0], bf, ng.acts[0], p.new(M, net.units[0]))])
+            hs = _Acts([p.dense(segs, Wf, net.units[0], bf, ng.acts[0], p.new(M, net.units[0]), center=mean if ng.bn else None)])
         hs.inputs = [self._dropped(ng, 1, hs[0], call)]
         for l in range(1, len(net.units)):
             hs.append(p.dense([(hs.inputs[-1], None)], ng.W[l], net.units[l], ng.b[l], ng.acts[l], p.new(M, net.units[l])))
@@ -393,18 +402,20 @@ class LoopTrainer:
                     out.copy_(dZ[:, int(offs[si]):int(offs[si]) + segs[si][0].shape[1]])
                 return
         P, q = p.new(K, H), p.new(H)
+        mean, var = stats if stats is not None else (None, None)
+        centred = bool(ng.bn and mean is not None)     # P = (X - mean)^T dZ: formed from centred rows, nothing of the mean's size to cancel later
         off = 0
         for i, (x, ridx) in enumerate(segs):
             w = x.shape[1]
-            p.dense_grad(x, ridx, dZ, M, P[off:off + w], q if i == 0 else None, False)
+            p.dense_grad(x, ridx, dZ, M, P[off:off + w], q if i == 0 else None, False, center=mean[off:off + w] if centred else None)
             off += w
-        mean, var = stats if stats is not None else (None, None)
         m1 = m2 = None
         if ng.bn: m1, m2 = p.new(K), p.new(K)
         M_all = M
         if drop0:
             eye = _eye(ng, K, p)
-            p.first_layer_param_grads(P, q, eye, ng.bn_params, mean, var, M_all, p.zeros(K, K), p.zeros(K), ng.dgamma, ng.dbeta, m1, m2, acc)
+            p.first_layer_param_grads(P, q, eye, ng.bn_params, mean, var, M_all, p.zeros(K, K), p.zeros(K), ng.dgamma, ng.dbeta, m1, m2, acc,
+                                      centered=centred)
             ng.touched = True
             offs = np.cumsum([0] + [x.shape[1] for x, _ in segs])
             for si, out in dx_requests or []:
@@ -419,7 +430,7 @@ class LoopTrainer:
             self.dp.all_reduce_sum(P, q)
             M_all = self.dp.total_rows('out' if ng is self.go else 'nodes')
         p.first_layer_param_grads(P, q, ng.W[0], ng.bn_params, mean, var, M_all, ng.dW[0], ng.db[0], ng.dgamma, ng.dbeta,
-                                  m1, m2, acc)
+                                  m1, m2, acc, centered=centred)
         ng.touched = True
         if dx_requests:
             Wt = ng.W[0].t().contiguous()                          # [H, K]
@@ -768,8 +779,43 @@ class LoopTrainer:
             if m.average_st_grads and tp.k > 0:
                 for g in g_.gradients(): g.mul_(1.0 / tp.k)
         if apply:
-            m._optimizer_obj().apply_gradients(self.grads_and_vars(tp))
+            opt, gate = m._optimizer_obj(), getattr(tp, 'grads_ok', None)
+            if gate and not isinstance(opt, (Adam, SGD)):
+                # a foreign optimizer knows nothing of the validity word: read it here (one synchronisation) instead of handing it over
+                if not self._read_word(getattr(tp, 'grads_ok_view', None)): return reg
+                gate = None
+            if gate: opt.apply_gradients(self.grads_and_vars(tp), gate=gate)
+            else: opt.apply_gradients(self.grads_and_vars(tp))
         return reg
+
+    # ---- validity of an in-library step's gradients (include/gnnloop.h, ABI 7) ---------------------------------------------------------
+    # The persistent small-graph BACKWARD kernel waits at grid barriers with a bound (GNN_WAIT_MS); when a wait expires its gradients are
+    # NaN - and the call has long returned.  The library therefore leaves a validity word on the device: the step's moving-average updates
+    # and the optimizer launch are gated by it (a failed step changes nothing), and the host learns of it without a synchronisation of its
+    # own: the NEXT `gnn_train_step` fetches the word at its one synchronisation (`prev_grads_ok_host`), `fit()` asks at the end of an
+    # epoch (`resolve_pending`).  The batch of a failed step is then trained on the building blocks (no cross-workgroup waits), late by
+    # one step, with a RuntimeWarning.
+    _pending = None
+
+    @staticmethod
+    def _read_word(view):
+        return True if view is None else bool(int(view.item()) != 0)
+
+    def resolve_pending(self):
+        """Ask whether the last in-library step's gradients were valid (synchronises); trains its batch on the building blocks if not."""
+        pend, self._pending = self._pending, None
+        if pend is not None and not self._read_word(pend['view']): self._recover_failed(pend)
+
+    def _recover_failed(self, pend):
+        import warnings
+        warnings.warn('the persistent backward kernel of a training step could not keep its workgroups resident (GPU shared with other '
+                      'long-running work?): its gradients were discarded on the device - weights, optimizer slots and moving statistics '
+                      'untouched - and its batch is trained on the general kernels now', RuntimeWarning, stacklevel=4)
+        self.recovered_steps = getattr(self, 'recovered_steps', 0) + 1
+        opt = self.model._optimizer_obj()
+        if hasattr(opt, 'iterations') and isinstance(opt.iterations, int) and opt.iterations > 0: opt.iterations -= 1      # (the gated launch did not count)
+        x_list, y, sample_weight, state0, seed = pend['batch']
+        self._train_step_general(x_list, y, sample_weight, state0, seed, True)
 
     @staticmethod
     def grads_and_vars(tp):
@@ -797,7 +843,7 @@ class LoopTrainer:
         if self.dp is not None: return False        # collectives sit between the iteration's launches: the building-block path
         if not self.use_native_step or y is None: return False
         nets = list(m.net_state) if isinstance(m.net_state, (list, tuple)) else [m.net_state]
-        if isinstance(m.net_state, (list, tuple)) and m._focus == 'a': return False      # arc-focused composite models: the general path below
+        if isinstance(m.net_state, (list, tuple)) and (m._focus == 'a' or m.max_iteration < 1): return False      # what the in-library composite step refuses (make_cplan): the general path below
         if any(n_.dropout_rate for n_ in nets) or m.net_output.dropout_rate: return False      # Dropout masks: the general path below
         kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
         return str(kind).lower() in nat.LOSSES
@@ -909,17 +955,33 @@ class LoopTrainer:
         if nbytes == 0: nat.check(1)
         tape = getattr(self, '_tape', None)
         if tape is None or tape.numel() < nbytes + 256 or tape.device != dev:
+            self.resolve_pending()                           # (the previous step's validity word lives in the tape that is about to go)
             tape = self._tape = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
         base = tape.data_ptr()
         aligned = (base + 255) & ~255
         ta.tape, ta.tape_bytes = C.c_void_p(aligned), tape.numel() - (aligned - base)
-        nat.check(nat.lib().gnn_train_step(C.byref(ta)))
+        # the validity word of this step's gradients (first word of the tape) and - for free, at the call's one synchronisation - the one
+        # the previous step left there
+        ok_ptr, prev_ok = C.c_void_p(0), C.c_int32(1)
+        ta.grads_ok_dev = C.pointer(ok_ptr)
+        pend, self._pending = self._pending, None
+        if pend is not None and pend['tape'] is tape: ta.prev_grads_ok_host = C.pointer(prev_ok)
+        elif pend is not None and not self._read_word(pend['view']): prev_ok.value = 0
+        try:
+            nat.check(nat.lib().gnn_train_step(C.byref(ta)))
+        except nat.NativeError:
+            if pend is not None and not self._read_word(pend['view']): self._recover_failed(pend)     # (the call may have failed in front of its synchronisation)
+            raise
         for g_ in gs_all: g_.touched = k_host.value > 0          # (a type without nodes: the library zero-fills its gradients)
         go.touched = len(out_index) > 0
-        tp = SimpleNamespace(gs=gs_all, go=go, k=int(k_host.value), y_pred=y_pred, state=state)
+        view = tape[aligned - base:aligned - base + 4].view(torch.int32)
+        tp = SimpleNamespace(gs=gs_all, go=go, k=int(k_host.value), y_pred=y_pred, state=state, grads_ok=ok_ptr.value, grads_ok_view=view)
         res = {'k': tp.k, 'y_pred': y_pred, 'state': state, 'loss': loss[0]}
         reg = self.finish(tp, apply)
         if reg is not None: res['loss'] = res['loss'] + reg
+        if apply and ok_ptr.value: self._pending = {'tape': tape, 'view': view, 'batch': (x_list, y, sample_weight, state0, seed)}
+        res['grads_ok'] = view                                   # device int32[1]: 1 when the gradients / the update of this step are valid
+        if pend is not None and prev_ok.value == 0: self._recover_failed(pend)      # the PREVIOUS step's batch, one step late
         return res
 
     def train_step(self, x_list, y, sample_weight, state0=None, seed=None, apply=True):
@@ -936,11 +998,22 @@ class LoopTrainer:
                 # workgroups resident within GNN_WAIT_MS).  The in-library step checks that right behind the forward loop - before the
                 # moving statistics, the gradients or the weights are touched - so the step is simply run again on the building
                 # blocks below, which have no cross-workgroup waits.
-                if 'grid barrier' not in str(e) and 'cannot be resident' not in str(e): raise
+                # a configuration the in-library step does not cover (its plan says so before anything runs) simply takes the general path
+                not_covered = any(t in str(e) for t in ('train through the building blocks', 'requires max_iteration', 'empty graph', 'homogeneous models only'))
+                if 'grid barrier' not in str(e) and 'cannot be resident' not in str(e) and not not_covered: raise
+                if not_covered:
+                    self.resolve_pending()
+                    return self._train_step_general(x_list, y, sample_weight, state0, seed, apply)
                 import warnings
                 warnings.warn('the persistent training kernels could not keep their workgroups resident (GPU shared with other '
                               'long-running work?): this step runs on the general kernels', RuntimeWarning, stacklevel=3)
                 self.recovered_steps = getattr(self, 'recovered_steps', 0) + 1
+        self.resolve_pending()
+        return self._train_step_general(x_list, y, sample_weight, state0, seed, apply)
+
+    def _train_step_general(self, x_list, y, sample_weight, state0, seed, apply):
+        """The step on the building blocks, orchestrated from here (no cross-workgroup waits anywhere)."""
+        m = self.model
         tp = self.forward(x_list, state0=state0, seed=seed)
         res = {'k': tp.k, 'y_pred': tp.y_pred, 'state': tp.state}
         if y is None:

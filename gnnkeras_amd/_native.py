@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 # GNNKERAS_AMD_LIB: load another build of the same sources (tests: the debug build whose in-launch waits expire at once)
 LIB_PATH = os.environ.get('GNNKERAS_AMD_LIB') or os.path.join(CSRC, 'libgnnloop.so')
 
-GNN_ABI_VERSION = 6
+GNN_ABI_VERSION = 7
 GNN_MAX_LAYERS = 8
 GNN_MAX_TYPES = 8
 
@@ -88,7 +88,7 @@ class DenseArgs(C.Structure):
                 ('W', C.c_void_p), ('ldw', C.c_int32), ('bias', C.c_void_p),
                 ('addend', C.c_void_p), ('ld_addend', C.c_int32), ('addend_rowidx', C.c_void_p),
                 ('activation', C.c_int32), ('Y', C.c_void_p), ('ldy', C.c_int32), ('out_rowidx', C.c_void_p),
-                ('gate', C.c_void_p), ('stream', C.c_void_p)]
+                ('gate', C.c_void_p), ('stream', C.c_void_p), ('in_center', C.c_void_p)]
 
 
 class MLPGrads(C.Structure):
@@ -103,7 +103,9 @@ class TrainArgs(C.Structure):
                 ('grad_state', MLPGrads), ('grad_output', MLPGrads),
                 ('y_pred', C.c_void_p), ('state', C.c_void_p), ('loss', C.c_void_p), ('k_host', C.POINTER(C.c_int32)),
                 ('tape', C.c_void_p), ('tape_bytes', C.c_size_t), ('tile_node_begin', C.c_void_p), ('n_tiles', C.c_int32),
-                ('grad_state_types', MLPGrads * GNN_MAX_TYPES)]          # ABI 6: one gradient holder per node type (composite models)
+                ('grad_state_types', MLPGrads * GNN_MAX_TYPES),          # ABI 6: one gradient holder per node type (composite models)
+                # ABI 7: the device word that says whether the step's gradients are valid (the optimizers' gate) and the previous step's, read for free
+                ('grads_ok_dev', C.POINTER(C.c_void_p)), ('prev_grads_ok_host', C.POINTER(C.c_int32))]
 
 
 class RaggedDesc(C.Structure):
@@ -195,21 +197,21 @@ def lib():
             'gnn_shard_iteration_split_rows': (C.c_int, [C.POINTER(LoopArgs), C.POINTER(CSR), vp, vp, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32]),
             'gnn_dense': (C.c_int, [C.POINTER(DenseArgs)]),
             'gnn_gather_rows': (C.c_int, [vp, i32, vp, i32, i32, vp, i32, vp]),
-            'gnn_fold_bn': (C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]),
+            'gnn_fold_bn': (C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, i32, vp]),
             'gnn_dense_grad_workspace_bytes': (sz, [i32, i32, i32]),
-            'gnn_dense_grad': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, sz, vp]),
+            'gnn_dense_grad': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, vp, sz, vp]),
             'gnn_act_grad': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
             'gnn_colstats_workspace_bytes': (sz, [i32, i32]),
             'gnn_colstats': (C.c_int, [vp, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, sz, vp]),
-            'gnn_first_layer_param_grads': (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+            'gnn_first_layer_param_grads': (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
             'gnn_bn_input_grad': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, i32, vp]),
             'gnn_scatter_add_rows': (C.c_int, [vp, i32, vp, i32, i32, vp, i32, vp]),
             'gnn_axpby': (C.c_int, [f32, vp, f32, vp, vp, sz, vp]),
             'gnn_loss_grad': (C.c_int, [i32, vp, vp, vp, i32, i32, vp, vp, vp]),
             'gnn_dropout': (C.c_int, [vp, i32, vp, i32, i32, i32, f32, C.c_uint32, i32, i32, vp]),
-            'gnn_adam_step': (C.c_int, [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, vp]),
-            'gnn_adam_multi': (C.c_int, [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp]),
-            'gnn_sgd_step': (C.c_int, [vp, vp, vp, sz, f32, f32, vp]),
+            'gnn_adam_step': (C.c_int, [vp, vp, vp, vp, sz, f32, f32, f32, f32, i32, vp, vp]),
+            'gnn_adam_multi': (C.c_int, [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp, vp]),
+            'gnn_sgd_step': (C.c_int, [vp, vp, vp, sz, f32, f32, vp, vp]),
             'gnn_converged_gated': (C.c_int, [vp, vp, i32, i32, i32, f32, vp, vp, vp, f32, vp]),
             'gnn_aggregate_gated': (C.c_int, [C.POINTER(CSR), vp, i32, i32, vp, i32, vp, vp]),
             'gnn_train_workspace_bytes': (sz, [C.POINTER(TrainArgs)]),

@@ -184,7 +184,7 @@ int device_cus();
 bool rowdense_applies(const gnn::SegDenseArgs &a) {
     static int off = -1;
     if (off < 0) { const char *e = getenv("GNN_ROWDENSE"); off = (e && e[0] == '0') ? 1 : 0; }
-    if (off || a.M < 32768 || a.nseg != 1 || a.addend || a.out_rowidx || a.in_gamma || a.act == GNN_ACT_SOFTMAX) return false;
+    if (off || a.M < 32768 || a.nseg != 1 || a.addend || a.out_rowidx || a.in_gamma || a.in_center || a.act == GNN_ACT_SOFTMAX) return false;
     const gnn::Seg &s = a.seg[0];
     if (s.rowidx || s.wrow != 0 || s.width < 8 || s.width > 64 || s.width % 4 || a.H < 8 || a.H > 64 || a.H % 4) return false;
     if (s.ld % 4 || a.ldy % 4 || (a.pred_flag && a.ld_pred % 4)) return false;
@@ -227,7 +227,7 @@ int launch_rowdense(const gnn::SegDenseArgs &a, hipStream_t st) {
 bool rowdense_wide_applies(const gnn::SegDenseArgs &a) {
     static int off = -1;
     if (off < 0) { const char *e = getenv("GNN_ROWDENSE"); off = (e && e[0] == '0') ? 1 : 0; }
-    if (off || a.M < 32768 || a.nseg < 1 || a.nseg > 2 || a.out_rowidx || a.add_rowidx || a.in_gamma || a.pred_flag || a.act == GNN_ACT_SOFTMAX) return false;
+    if (off || a.M < 32768 || a.nseg < 1 || a.nseg > 2 || a.out_rowidx || a.add_rowidx || a.in_gamma || a.in_center || a.pred_flag || a.act == GNN_ACT_SOFTMAX) return false;
     if (a.H <= 64 || a.H % 4 || a.ldy % 4 || (a.addend && a.ld_add % 4)) return false;
     int chunks = 0;
     uintptr_t bits = reinterpret_cast<uintptr_t>(a.Y) | reinterpret_cast<uintptr_t>(a.addend);
@@ -270,7 +270,7 @@ int launch_segdense(gnn::SegDenseArgs &a, hipStream_t st) {
         for (int s = 0; s < a.nseg; ++s) K = std::max(K, a.seg[s].wrow + a.seg[s].width);
         if ((size_t)K * a.H * sizeof(float) <= 48 * 1024) {
             const int grid = (int)std::max<long>(1, std::min<long>(cdiv(a.M, 16 * gnn::TD_ROWS), 256 * 8));
-            const size_t lds = (size_t)K * a.H * sizeof(float);
+            const size_t lds = ((size_t)((K * a.H + 3) & ~3) + K + 4) * sizeof(float);
             switch (a.H) {
                 case 1: gnn::k_thin_dense<1><<<grid, 256, lds, st>>>(a, K); break;
                 case 2: gnn::k_thin_dense<2><<<grid, 256, lds, st>>>(a, K); break;

@@ -170,8 +170,12 @@ struct SegDenseArgs {
     // state, `pred_old` the previous one: *pred_flag |= any_row(||new - old|| > thr ||old||), *pred_k = pred_kval
     const float *pred_old; int ld_pred; float pred_thr; int *pred_flag; float *pred_k; float pred_kval;
     // optional training-mode BatchNormalization applied to the input columns as they are staged (k_segdense only):
-    // x'[k] = (x[k] - mean[k]) gamma[k] / sqrt(var[k] + eps) + beta[k] for column k of the virtual concatenation
+    // x'[k] = (x[k] - mean[k]) gamma[k] / sqrt(var[k] + eps) + beta[k], k = the column's WEIGHT ROW (seg.wrow + offset inside the segment) -
+    // computed in that order: the column mean leaves the value first, a folded beta - mean a would cancel it against a x afterwards
     const float *in_gamma, *in_beta, *in_mean, *in_var; float in_eps;
+    // optional (k_segdense, k_thin_dense): in_center[weight row] is subtracted from every input value as it is staged - the consumer of a
+    // CENTRED fold (FoldJob::centred: Wf = a W, bf = b + sum beta W), for layers whose kernel wants folded weights
+    const float *in_center;
 };
 
 constexpr int SD_TM = 64, SD_TN = 64, SD_KC = 32, SD_LDX = 34, SD_LDW = 80, SD_LDY = 68;
@@ -220,18 +224,19 @@ __global__ void __launch_bounds__(256, SC == 1 ? 8 : 4) k_segdense(SegDenseArgs 
                     if (s < a.nseg) start += a.seg[s].width;
                 }
                 const int off = kv - sbeg;
-                float bn_a = 1.0f, bn_c = 0.0f;
+                float bn_a = 1.0f, bn_c = 0.0f, bn_m = 0.0f;
                 if (a.in_gamma && kv < K) {
-                    bn_a = a.in_gamma[kv] / sqrtf(a.in_var[kv] + a.in_eps);
-                    bn_c = a.in_beta[kv] - a.in_mean[kv] * bn_a;
-                }
+                    const int kr = sg.wrow + off;
+                    bn_a = a.in_gamma[kr] / sqrtf(a.in_var[kr] + a.in_eps);
+                    bn_c = a.in_beta[kr]; bn_m = a.in_mean[kr];
+                } else if (a.in_center && kv < K) bn_m = a.in_center[sg.wrow + off];
 #pragma unroll
                 for (int pass = 0; pass < 8; ++pass) {
                     const int m = m0 + xr0 + 8 * pass;
                     xv[sc][pass] = 0.0f;
                     if (m < a.M && kv < K) {
                         const float x = sg.ptr[(sg.rowidx ? (size_t)sg.rowidx[m] : (size_t)m) * sg.ld + off];
-                        xv[sc][pass] = a.in_gamma ? fmaf(x, bn_a, bn_c) : x;
+                        xv[sc][pass] = a.in_gamma ? fmaf(x - bn_m, bn_a, bn_c) : x - bn_m;
                     }
                 }
                 // ---- W chunk: weight rows of the virtual columns (row = seg.wrow + offset inside the segment) ----
@@ -318,8 +323,10 @@ constexpr int TD_ROWS = 4;
 template <int H>
 __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
     if (gate_closed(a.gate)) return;
-    extern __shared__ float tdW[];                       // [K][H]
+    extern __shared__ __attribute__((aligned(16))) float tdW[];                       // [K][H], then [K (+ 3)] centres
+    float *tdC = tdW + ((K * H + 3) & ~3);
     for (int i = threadIdx.x; i < K * H; i += blockDim.x) tdW[i] = a.W[(size_t)(i / H) * a.ldw + (i % H)];
+    if (a.in_center) for (int i = threadIdx.x; i < K; i += blockDim.x) tdC[i] = a.in_center[i];
     __syncthreads();
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     for (long base = ((long)blockIdx.x * 16 + grp) * TD_ROWS; base < a.M; base += (long)gridDim.x * 16 * TD_ROWS) {
@@ -348,6 +355,12 @@ __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
                         if (rowv[r] >= 0) x[r] = *reinterpret_cast<const f32x4 *>(sg.ptr + rowv[r] * sg.ld + 4 * c4);
                     }
                     const float *w = tdW + (size_t)(sg.wrow + 4 * c4) * H;
+                    if (a.in_center) {
+                        const float *cp = tdC + sg.wrow + 4 * c4;            // (wrow need not be a multiple of 4: scalar reads)
+                        const f32x4 cen = {cp[0], cp[1], cp[2], cp[3]};
+#pragma unroll
+                        for (int r = 0; r < TD_ROWS; ++r) if (rowv[r] >= 0) x[r] -= cen;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -361,7 +374,7 @@ __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
                 for (int c = l16; c < sg.width; c += 16) {
                     float x[TD_ROWS];
 #pragma unroll
-                    for (int r = 0; r < TD_ROWS; ++r) x[r] = rowv[r] >= 0 ? sg.ptr[rowv[r] * sg.ld + c] : 0.0f;
+                    for (int r = 0; r < TD_ROWS; ++r) x[r] = rowv[r] >= 0 ? sg.ptr[rowv[r] * sg.ld + c] - (a.in_center ? tdC[sg.wrow + c] : 0.0f) : 0.0f;
                     const float *w = tdW + (size_t)(sg.wrow + c) * H;
 #pragma unroll
                     for (int h = 0; h < H; ++h) {

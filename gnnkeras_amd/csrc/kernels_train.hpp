@@ -50,7 +50,7 @@ constexpr int DG_LD = 80;          // == 16 (mod 32): conflict-free transposed A
 __global__ void __launch_bounds__(256)
 k_dense_grad_partial(const float *__restrict__ X, int ldx, const int *__restrict__ rowidx, int K,
                      const float *__restrict__ dZ, int ldz, int H, int M, int rows_per_chunk,
-                     float *__restrict__ part, int want_q) {      // part: [chunk][K*H (P) + H (q)]
+                     float *__restrict__ part, int want_q, const float *__restrict__ center = nullptr) {      // part: [chunk][K*H (P) + H (q)]
     __shared__ float Xs[64 * DG_LD];
     __shared__ float Zs[64 * DG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,7 +67,7 @@ k_dense_grad_partial(const float *__restrict__ X, int ldx, const int *__restrict
             const int mm = i / 64, cc = i % 64, m = m0 + mm;
             float xv = 0.0f, zv = 0.0f;
             if (m < m_end) {
-                if (k0 + cc < K) xv = X[(rowidx ? (size_t)rowidx[m] : (size_t)m) * ldx + k0 + cc];
+                if (k0 + cc < K) xv = X[(rowidx ? (size_t)rowidx[m] : (size_t)m) * ldx + k0 + cc] - (center ? center[k0 + cc] : 0.0f);
                 if (h0 + cc < H) zv = dZ[(size_t)m * ldz + h0 + cc];
             }
             Xs[mm * DG_LD + cc] = xv;
@@ -397,7 +397,8 @@ k_loss_grad(int kind, const float *__restrict__ y, const float *__restrict__ p, 
 // ---- optimizers (tf.keras.optimizers.Adam / SGD defaults; `step` counts from 1) ------------------------------------------
 __global__ void __launch_bounds__(256)
 k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, size_t n, float lr,
-       float b1, float b2, float eps, float bc1, float bc2) {
+       float b1, float b2, float eps, float bc1, float bc2, const int *gate) {
+    if (gate_closed(gate)) return;                 // (the gradients of a failed step: see gnn_train_args_t::grads_ok_dev)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i];
         const float mi = m[i] = b1 * m[i] + (1.0f - b1) * gi;
@@ -410,7 +411,8 @@ k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m
 constexpr int ADAM_MAX_JOBS = 32;
 struct AdamJobs { float *p[ADAM_MAX_JOBS]; const float *g[ADAM_MAX_JOBS]; float *m[ADAM_MAX_JOBS], *v[ADAM_MAX_JOBS]; unsigned n[ADAM_MAX_JOBS]; int blk_begin[ADAM_MAX_JOBS + 1]; int n_jobs; };
 __global__ void __launch_bounds__(256)
-k_adam_multi(AdamJobs a, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+k_adam_multi(AdamJobs a, float lr, float b1, float b2, float eps, float bc1, float bc2, const int *gate) {
+    if (gate_closed(gate)) return;
     int j = 0;
     while (j + 1 < a.n_jobs && (int)blockIdx.x >= a.blk_begin[j + 1]) ++j;
     float *__restrict__ p = a.p[j]; const float *__restrict__ g = a.g[j]; float *__restrict__ m = a.m[j], *__restrict__ v = a.v[j];
@@ -423,7 +425,8 @@ k_adam_multi(AdamJobs a, float lr, float b1, float b2, float eps, float bc1, flo
     }
 }
 __global__ void __launch_bounds__(256)
-k_sgd(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ mom, size_t n, float lr, float momentum) {
+k_sgd(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ mom, size_t n, float lr, float momentum, const int *gate) {
+    if (gate_closed(gate)) return;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         if (mom) { const float vel = mom[i] = momentum * mom[i] - lr * g[i]; p[i] += vel; }
         else p[i] -= lr * g[i];
@@ -690,15 +693,26 @@ __global__ void __launch_bounds__(256) k_bn_input_grad_segs(BnGradArgs a) {
 
 // ---- the k moving-average updates of a network applied k times in a row, in order (Keras: one per call) ----------------
 __global__ void __launch_bounds__(256)
-k_bn_moving_multi(const float *__restrict__ stats, int stride, int steps, int K, float *moving_mean, float *moving_var, float momentum) {
+k_bn_moving_multi(const float *__restrict__ stats, int stride, int steps, int K, float *moving_mean, float *moving_var, float momentum,
+                  const int *gate = nullptr) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= K) return;
+    if (c >= K || gate_closed(gate)) return;
     float mm = moving_mean[c], mv = moving_var[c];
     for (int t = 0; t < steps; ++t) {
         mm = mm * momentum + stats[(size_t)t * stride + c] * (1.0f - momentum);
         mv = mv * momentum + stats[(size_t)t * stride + K + c] * (1.0f - momentum);
     }
     moving_mean[c] = mm; moving_var[c] = mv;
+}
+
+// *ok = 1 when no launch of the step raised its error word (err[1]: the persistent backward kernel's expired grid barrier), else 0:
+// the gate of the step's moving-average updates and of the optimizer (gnn_train_args_t::grads_ok_dev)
+__global__ void k_grads_ok(const float *__restrict__ err, int *__restrict__ ok) { *ok = (err == nullptr || err[1] == 0.0f) ? 1 : 0; }
+
+// *bad = 1 when idx[0:n] is not 0, 1, .. n - 1 (the large-graph thin-head kernels need output row m == node m)
+__global__ void __launch_bounds__(256) k_not_identity(const int *__restrict__ idx, int n, float *bad) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (idx[i] != i) *bad = 1.0f;
 }
 
 // rows[t][0:n] = src[0:n] for t < reps (the iteration-invariant columns of every iteration's statistics vector)

@@ -83,8 +83,9 @@ __device__ __forceinline__ bool grid_barrier(GridBar &gb, int any, int *cont_lds
 }
 
 // ---- constant part of the first layer, once per step ------------------------------------------------------------------------------------
-//   Cc[n, h] = b[h] + sum over the constant input columns k of (a_k x[n, k] + c_k) W[k, h],   a = gamma rstd, c = beta - mean a
-// (a = 1, c = 0 without BatchNormalization; the constants' batch statistics do not change between iterations).
+//   Cc[n, h] = b[h] + sum over the constant input columns k of (a_k (x[n, k] - mean_k) + beta_k) W[k, h],   a = gamma rstd
+// (a = 1, mean = beta = 0 without BatchNormalization; the constants' batch statistics do not change between iterations).  The mean leaves
+// the value FIRST: a x + (beta - mean a) cancels mean a against a x afterwards and loses digits in proportion to mean / sigma (raw labels).
 struct ConstSegs { const float *ptr[3]; int ld[3], width[3], wrow[3]; int n; };
 __global__ void __launch_bounds__(256)
 k_train_small_const(int N, int S, int Sw, ConstSegs cs, const float *__restrict__ W, const float *__restrict__ b, const float *gamma, const float *beta,
@@ -101,7 +102,7 @@ k_train_small_const(int N, int S, int Sw, ConstSegs cs, const float *__restrict_
         for (int j = 0; j < cs.width[s]; ++j) {
             const int k = cs.wrow[s] + j;
             float x = cs.ptr[s][(size_t)n * cs.ld[s] + j];
-            if (gamma) { const float a = gamma[k] / sqrtf(var[k] + eps); x = fmaf(x, a, beta[k] - mean[k] * a); }
+            if (gamma) { const float a = gamma[k] / sqrtf(var[k] + eps); x = fmaf(x - mean[k], a, beta[k]); }
             acc = fmaf(x, W[(size_t)k * Sw + h], acc);
         }
     }
@@ -221,6 +222,37 @@ __device__ __forceinline__ double sum_partials(const float *part, unsigned n_wg,
     return t;
 }
 
+// Column statistics of ALL nodes from the tiles' shares, in workgroup order and double precision (the same bits in every workgroup).  A
+// tile's share is taken in float32 around a pivot of ITS OWN (the tile's first row: nothing of the mean's size in the sums, whatever the
+// data - raw labels 30 sigma from zero, a state whose distribution jumps between iterations): slot = (s1 = sum (x - pv) | s2 = sum (x - pv)^2
+// | pv), `w` columns each.  The shares are moved to the origin and added in DOUBLE - sum x = s1 + n pv, sum x^2 = s2 + 2 pv s1 + n pv^2 (every
+// product exact) - where E[x^2] - mean^2 loses (mean / sigma)^2 of 2^-53, not of 2^-24.  `n_of(j)` = rows of tile j.
+template <typename NOf>
+__device__ __forceinline__ void merge_tile_stats(const float *part, unsigned n_wg, int w, int col, NOf n_of, double inv_n, float &mean_out, float &var_out) {
+    const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(part);
+    double S1 = 0.0, S2 = 0.0;
+    for (unsigned wg = 0; wg < n_wg; wg += 8) {
+        float s1[8], s2[8], pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {          // (absent slots read 0)
+            const bool in = wg + u < n_wg;
+            const int base = (int)(((wg + u) * 3 * w + col) * 4);
+            s1[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_p, in ? base : (int)BUF_OFF, 0, 16));
+            s2[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_p, in ? base + w * 4 : (int)BUF_OFF, 0, 16));
+            pv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_p, in ? base + 2 * w * 4 : (int)BUF_OFF, 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double nj = wg + u < n_wg ? (double)n_of((int)(wg + u)) : 0.0, p_ = (double)pv[u], a1 = (double)s1[u];
+            S1 += a1 + nj * p_;
+            S2 += (double)s2[u] + p_ * (2.0 * a1 + nj * p_);
+        }
+    }
+    const double mean = S1 * inv_n;
+    mean_out = (float)mean;
+    var_out = (float)fmax(S2 * inv_n - mean * mean, 0.0);
+}
+
 // ---- forward ---------------------------------------------------------------------------------------------------------------------------------
 struct TrainSmallFwd {
     int N, S, K;
@@ -237,7 +269,7 @@ struct TrainSmallFwd {
     float thr;
     const int *flag0;            // predicate of state_0 (one word)
     unsigned long long *bar;     // two arrival counters, zero
-    float *part;                 // [2][n_wg][4 S] statistics partials (parity of the iteration)
+    float *part;                 // [2][n_wg][6 S] statistics shares (s1 | s2 | pivot of the tile, 2 S columns each; parity of the iteration)
     float *k_out;                // [0] = iterations executed (-1e9: a barrier timed out), [1] = 1 when an arc leaves its tile (LOCAL)
     unsigned long long wait_ticks;   // bound of a barrier wait (buffer_ops.hpp: wait_until)
 };
@@ -251,7 +283,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
     extern __shared__ __attribute__((aligned(16))) float ts_smem[];
     float *Xs = ts_smem;                  // [64][LDX]
     float *W0 = Xs + 64 * LDX;            // [2 S][LDW] kernel rows of the state / agg columns
-    float *st_a = W0 + 2 * S * LDW;       // [2 S] a_k, [2 S] c_k, [2 S] pivots of the statistics, reduction scratch [512]
+    float *st_a = W0 + 2 * S * LDW;       // [2 S] a_k, [2 S] beta_k, [2 S] column means of this iteration, reduction scratch [512]
     float *st_c = st_a + 2 * S, *piv = st_c + 2 * S, *red = piv + 2 * S;
     __shared__ int cont;
 
@@ -330,10 +362,9 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
             // ---- B. column sums / squares of [state | agg] over the tile's rows -> partial slot ---------------------------------------------
             const int col = tid & (2 * S - 1), part_i = tid / (2 * S);          // 256 / (2 S) row groups (S = 64: 2, 32: 4, 16: 8)
             constexpr int NG = TS_NT / (2 * S), RPG = 64 / NG;
-            // sums of (x - pivot), pivot = the previous iteration's mean (the same bits in every workgroup): E[d^2] - E[d]^2 does
-            // not cancel once the states settle
+            // sums of (x - pivot) around the tile's OWN first row (merge_tile_stats: nothing of the mean's size to cancel, whatever the data)
             float s1 = 0.0f, s2 = 0.0f;
-            const float pv = piv[col];
+            const float pv = Xs[col];
             float xr[RPG];                                     // every read of the column piece issued before the first add (rows behind nt are zero)
 #pragma unroll
             for (int u = 0; u < RPG; ++u) xr[u] = Xs[(part_i * RPG + u) * LDX + col];
@@ -348,8 +379,9 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
                 float t = 0.0f;
 #pragma unroll
                 for (int gq = 0; gq < NG; ++gq) t += red[gq * 4 * S + tid];
-                const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + ((size_t)(it & 1) * gridDim.x + blockIdx.x) * 4 * S);
+                const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(a.part + ((size_t)(it & 1) * gridDim.x + blockIdx.x) * 6 * S);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), r_p, tid * 4, 0, 16);
+                if (tid < 2 * S) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xs[tid]), r_p, (4 * S + tid) * 4, 0, 16);      // the pivots
             }
         }
         TS_STAMP(1);
@@ -361,20 +393,18 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
         } else if (bn) grid_barrier(gb, 0, &cont);
         TS_STAMP(2);
         if (bn) {
-            if (tid < 4 * S)              // (sum | square, column): partials in workgroup order
-                red[tid] = (float)(sum_partials(a.part + (size_t)(it & 1) * gridDim.x * 4 * S, gridDim.x, 4 * S, tid) / (double)a.N);
-            __syncthreads();
-            if (tid < 2 * S) {
+            if (tid < 2 * S) {            // this column's statistics over ALL nodes: the tiles' shares in workgroup order
                 const int kk = tid < S ? tid : tid - S;
-                float ak = 0.0f, ck = 0.0f;                        // (pad columns: zero in, zero out)
+                float ak = 0.0f, ck = 0.0f, mu = 0.0f;             // (pad columns: zero in, zero out)
                 if (kk < a.Sw) {
                     const int k = (tid < S ? 0 : a.off_agg) + kk;                     // BatchNorm column of this input column
-                    const float dm = red[tid], va = fmaxf(red[2 * S + tid] - dm * dm, 0.0f), mu = piv[tid] + dm;
-                    piv[tid] = mu;
-                    ak = a.gamma[k] / sqrtf(va + a.eps); ck = a.beta[k] - mu * ak;
+                    float va;
+                    merge_tile_stats(a.part + (size_t)(it & 1) * gridDim.x * 6 * S, gridDim.x, 2 * S, tid,
+                                     [&](int j) { return LOCAL ? tt.begin[j + 1] - tt.begin[j] : min(64, a.N - 64 * j); }, 1.0 / (double)a.N, mu, va);
+                    ak = a.gamma[k] / sqrtf(va + a.eps); ck = a.beta[k];
                     if (blockIdx.x == 0) { a.stats[(size_t)it * 2 * a.in_s + k] = mu; a.stats[(size_t)it * 2 * a.in_s + a.in_s + k] = va; }
                 }
-                st_a[tid] = ak; st_c[tid] = ck;
+                st_a[tid] = ak; st_c[tid] = ck; piv[tid] = mu;
             }
             __syncthreads();
         }
@@ -388,10 +418,11 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
 #pragma unroll
         for (int qq = 0; qq < 2 * S / 16; ++qq) {
             f32x4 xv = *reinterpret_cast<const f32x4 *>(xrow + 16 * qq);
-            if (bn) {
+            if (bn) {         // a (x - mean) + beta: the column mean leaves the value first
                 const f32x4 av = *reinterpret_cast<const f32x4 *>(st_a + 16 * qq + 4 * g), cv = *reinterpret_cast<const f32x4 *>(st_c + 16 * qq + 4 * g);
+                const f32x4 mv = *reinterpret_cast<const f32x4 *>(piv + 16 * qq + 4 * g);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xv[e] = fmaf(xv[e], av[e], cv[e]);
+                for (int e = 0; e < 4; ++e) xv[e] = fmaf(xv[e] - mv[e], av[e], cv[e]);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -507,11 +538,11 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
         const int rr = i / S, h = i % S;
         Gs[rr * LDZ + h] = (rr < nt && h < a.Sw) ? a.G0[(size_t)(n0 + rr) * a.Sw + h] : 0.0f;
     }
-    // xhat = x rs + sh of iteration t (rs = rstd, sh = - mean rstd; 1 / 0 without BatchNormalization)
+    // xhat = (x - sh) rs of iteration t (rs = rstd, sh = mean; 1 / 0 without BatchNormalization): centred first, then scaled
     auto coefficients = [&](int t) {
         if (tid < 2 * S) {
             float r_ = 1.0f, s_ = 0.0f;
-            if (bn && valid_dyn(tid)) { const float *st = a.stats + (size_t)t * 2 * a.in_s; const int k = wrow_dyn(tid); r_ = 1.0f / sqrtf(st[a.in_s + k] + a.eps); s_ = -st[k] * r_; }
+            if (bn && valid_dyn(tid)) { const float *st = a.stats + (size_t)t * 2 * a.in_s; const int k = wrow_dyn(tid); r_ = 1.0f / sqrtf(st[a.in_s + k] + a.eps); s_ = st[k]; }
             rs_s[tid] = r_; sh_s[tid] = s_;
         }
     };
@@ -570,8 +601,8 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                 f32x4 hs, ha, gz = *reinterpret_cast<const f32x4 *>(Gs + rr * LDZ + 4 * ch);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    hs[e] = rr < nt ? fmaf(xs[u][e], r0[e], s0[e]) : 0.0f;
-                    ha[e] = rr < nt ? fmaf(xa[u][e], r1[e], s1[e]) : 0.0f;
+                    hs[e] = rr < nt ? (xs[u][e] - s0[e]) * r0[e] : 0.0f;
+                    ha[e] = rr < nt ? (xa[u][e] - s1[e]) * r1[e] : 0.0f;
                     gz[e] *= activate_grad_from_output(a.act, y[u][e]);
                 }
                 *reinterpret_cast<f32x4 *>(Xs + rr * LDX + 4 * ch) = hs;

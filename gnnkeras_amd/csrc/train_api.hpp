@@ -29,6 +29,7 @@ int gnn_dense(const gnn_dense_args_t *d) {
     }
     a.W = d->W; a.ldw = d->ldw > 0 ? d->ldw : d->H; a.bias = d->bias;
     a.addend = d->addend; a.ld_add = d->ld_addend; a.add_rowidx = d->addend_rowidx;
+    a.in_center = d->in_center;
     const bool thin_softmax = d->activation == GNN_ACT_SOFTMAX && thin_dense_applies(a);      // finished in the same launch
     a.act = (d->activation == GNN_ACT_SOFTMAX && !thin_softmax) ? GNN_ACT_LINEAR : d->activation;
     a.Y = d->Y; a.ldy = d->ldy; a.out_rowidx = d->out_rowidx;
@@ -39,10 +40,11 @@ int gnn_dense(const gnn_dense_args_t *d) {
 }
 
 int gnn_fold_bn(const float *W, const float *b, int32_t K, int32_t H, const float *gamma, const float *beta,
-                const float *mean, const float *var, float eps, float *Wf, float *bf, void *stream) {
+                const float *mean, const float *var, float eps, float *Wf, float *bf, int32_t centred, void *stream) {
     if (!W || !Wf || !bf || K < 1 || H < 1) return fail("bad arguments");
     FoldList fl;
     gnn::FoldJob &j = fl.fa.job[fl.fa.n_jobs++];
+    j.centred = centred ? 1 : 0;
     j.W = W; j.b = b; j.K = K; j.H = H; j.gamma = gamma; j.beta = beta; j.mean = mean; j.var = var; j.eps = eps;
     j.Wf = Wf; j.bf = bf; j.blk_begin = 0;
     fl.blocks = H;
@@ -56,7 +58,8 @@ size_t gnn_dense_grad_workspace_bytes(int32_t K, int32_t H, int32_t M) {
 }
 
 int gnn_dense_grad(const float *X, int32_t ldx, const int32_t *rowidx, int32_t K, const float *dZ, int32_t ldz, int32_t H,
-                   int32_t M, float *P, float *q, int32_t accumulate, void *workspace, size_t workspace_bytes, void *stream) {
+                   int32_t M, float *P, float *q, int32_t accumulate, const float *center, void *workspace, size_t workspace_bytes,
+                   void *stream) {
     if (K < 1 || H < 1 || M < 0 || !P) return fail("bad arguments");
     if (M > 0 && (!X || !dZ)) return fail("X / dZ is NULL");
     if (!workspace || workspace_bytes < gnn_dense_grad_workspace_bytes(K, H, M)) return fail("workspace too small");
@@ -69,7 +72,7 @@ int gnn_dense_grad(const float *X, int32_t ldx, const int32_t *rowidx, int32_t K
         return 0;
     }
     dim3 grid(n_chunks, cdiv(K, 64), cdiv(H, 64));
-    gnn::k_dense_grad_partial<<<grid, 256, 0, st>>>(X, ldx, rowidx, K, dZ, ldz, H, M, rpc, part, q ? 1 : 0);
+    gnn::k_dense_grad_partial<<<grid, 256, 0, st>>>(X, ldx, rowidx, K, dZ, ldz, H, M, rpc, part, q ? 1 : 0, center);
     LAUNCH_OK();
     const int n = K * H + H;                            // P and q leave in one reduction launch
     gnn::k_reduce_partials<<<cdiv(n, 64), 256, 0, st>>>(part, n_chunks, n, P, accumulate, 1.0f, K * H, q);
@@ -125,11 +128,12 @@ int gnn_colstats(const float *X, int32_t ldx, const int32_t *rowidx, int32_t K, 
 
 int gnn_first_layer_param_grads(const float *P, const float *q, const float *W, int32_t K, int32_t H, const float *gamma,
                                 const float *beta, const float *mean, const float *var, float eps, int32_t M, float *dW,
-                                float *db, float *dgamma, float *dbeta, float *m1, float *m2, int32_t accumulate, void *stream) {
+                                float *db, float *dgamma, float *dbeta, float *m1, float *m2, int32_t accumulate, int32_t centered,
+                                void *stream) {
     if (!P || !q || !W || !dW || K < 1 || H < 1 || M < 1) return fail("bad arguments");
     if (gamma && (!beta || !mean || !var || !dgamma || !dbeta)) return fail("BatchNormalization arrays are NULL");
     gnn::k_first_layer_param_grads<<<K, 64, 0, (hipStream_t)stream>>>(
-        P, q, W, K, H, gamma, beta, mean, var, eps, 1.0f / (float)M, dW, db, dgamma, dbeta, m1, m2, accumulate);
+        P, q, W, K, H, gamma, beta, mean, var, eps, 1.0f / (float)M, dW, db, dgamma, dbeta, m1, m2, accumulate, 1, (gamma && centered) ? 1 : 0);
     LAUNCH_OK();
     return 0;
 }
@@ -195,17 +199,17 @@ int gnn_loss_grad(int32_t kind, const float *y, const float *p, const float *sam
 }
 
 int gnn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2, float eps,
-                  int32_t step, void *stream) {
+                  int32_t step, const int32_t *gate, void *stream) {
     if (n == 0) return 0;
     if (!p || !g || !m || !v || step < 1) return fail("bad arguments");
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-    gnn::k_adam<<<std::min(cdiv((long)n, 256), 256 * 16), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2);
+    gnn::k_adam<<<std::min(cdiv((long)n, 256), 256 * 16), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2, gate);
     LAUNCH_OK();
     return 0;
 }
 
 int gnn_adam_multi(float *const *p, const float *const *g, float *const *m, float *const *v, const size_t *n, int32_t n_vars, float lr,
-                   float beta1, float beta2, float eps, int32_t step, void *stream) {
+                   float beta1, float beta2, float eps, int32_t step, const int32_t *gate, void *stream) {
     if (n_vars < 0 || (n_vars > 0 && (!p || !g || !m || !v || !n)) || step < 1) return fail("bad arguments");
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     for (int j0 = 0; j0 < n_vars; j0 += gnn::ADAM_MAX_JOBS) {
@@ -221,16 +225,16 @@ int gnn_adam_multi(float *const *p, const float *const *g, float *const *m, floa
             a.blk_begin[q + 1] = a.blk_begin[q] + (int)std::min<long>(cdiv((long)n[j], 256), 1024);
         }
         if (a.n_jobs == 0) continue;
-        gnn::k_adam_multi<<<a.blk_begin[a.n_jobs], 256, 0, (hipStream_t)stream>>>(a, lr, beta1, beta2, eps, bc1, bc2);
+        gnn::k_adam_multi<<<a.blk_begin[a.n_jobs], 256, 0, (hipStream_t)stream>>>(a, lr, beta1, beta2, eps, bc1, bc2, gate);
         LAUNCH_OK();
     }
     return 0;
 }
 
-int gnn_sgd_step(float *p, const float *g, float *velocity, size_t n, float lr, float momentum, void *stream) {
+int gnn_sgd_step(float *p, const float *g, float *velocity, size_t n, float lr, float momentum, const int32_t *gate, void *stream) {
     if (n == 0) return 0;
     if (!p || !g) return fail("bad arguments");
-    gnn::k_sgd<<<std::min(cdiv((long)n, 256), 256 * 16), 256, 0, (hipStream_t)stream>>>(p, g, velocity, n, lr, momentum);
+    gnn::k_sgd<<<std::min(cdiv((long)n, 256), 256 * 16), 256, 0, (hipStream_t)stream>>>(p, g, velocity, n, lr, momentum, gate);
     LAUNCH_OK();
     return 0;
 }

@@ -30,6 +30,7 @@ struct CType {                       // one node type
 struct CPlan {
     int N, E, S, L, A, M, R, T, K, G, n_types, sum_d, W_comp;
     bool pooled, agg_taped;
+    int *grads_ok;               // first word of the tape (gnn_train_args_t::grads_ok_dev)
     int *flags; float *k_dev;
     float *states, *agg, *agg_comp;
     float *stats_o, *Wf_o, *bf_o, *dx_o_all, *dx_full, *G_state, *G_out, *dpred, *loss_rows, *loss_part, *part;
@@ -91,6 +92,7 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
     p.R = p.pooled ? p.G : p.M;
 
     Carver c(ws);
+    p.grads_ok = c.take<int>(4);
     p.flags = c.take<int>(p.K + 8);
     p.k_dev = c.take<float>(4);
     p.states = c.take<float>((size_t)(p.K + 1) * p.N * p.S);
@@ -192,6 +194,9 @@ int train_step_composite(const gnn_train_args_t &ta) {
     const size_t NS = (size_t)p.N * p.S;
 
     // ---- setup: transposes, aggregated_component (CompositeGNN.py:251-253), state_0, the constant columns' statistics ------------
+    if (ta.prev_grads_ok_host) HIP_OK(hipMemcpyAsync(ta.prev_grads_ok_host, p.grads_ok, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemsetAsync(p.grads_ok, 0, sizeof(int) * 4, st));
+    if (ta.grads_ok_dev) *ta.grads_ok_dev = p.grads_ok;
     for (int t = 0; t < p.n_types; ++t) TRY(transposes(p.ty[t].nc, st));
     TRY(transposes(p.co, st));
     HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (p.K + 8), st));
@@ -235,20 +240,20 @@ int train_step_composite(const gnn_train_args_t &ta) {
             const gnn_mlp_t &ns = *y.m;
             int is_, ia_;
             const int n = ctype_segs(a, p, y, t, segs, &is_, &ia_);
-            const float *W0 = ns.kernel[0], *b0 = ns.bias[0], *bn_on_load = nullptr;
+            const float *W0 = ns.kernel[0], *b0 = ns.bias[0], *bn_on_load = nullptr, *centre = nullptr;
             if (ns.has_bn) {
                 float *stats = y.stats + (size_t)t * 2 * y.in_dim;
                 gnn::Seg dyn[2] = {segs[is_], segs[ia_]};
                 TRY(colstats_segs(gate, dyn, 2, y.count, stats, stats + y.in_dim, p.part, st));
-                if (ns.units[0] <= 4) {               // thin first layer: the thin-dense kernel wants folded weights
+                if (ns.units[0] <= 4) {               // thin first layer: the thin-dense kernel wants folded weights (centred: it subtracts the means on load)
                     float *Wf = y.Wf + (size_t)t * y.in_dim * ns.units[0], *bf = y.bf + (size_t)t * ns.units[0];
-                    TRY(fold_with_stats(ns, stats, Wf, bf, st));
-                    W0 = Wf; b0 = bf;
+                    TRY(fold_with_stats(ns, stats, Wf, bf, st, true));
+                    W0 = Wf; b0 = bf; centre = stats;
                 } else bn_on_load = stats;
             }
             float *hs[GNN_MAX_LAYERS];
             for (int l = 0; l < ns.n_layers; ++l) hs[l] = y.nc.hid[l];
-            TRY(forward_layers(ns, segs, n, y.count, W0, b0, hs, gate, st, nullptr, bn_on_load));
+            TRY(forward_layers(ns, segs, n, y.count, W0, b0, hs, gate, st, nullptr, bn_on_load, centre));
             // the type's rows of the new state (CompositeGNN.py:229-231: scatter_nd + reduce_sum over the one-hot types).  A closed gate
             // leaves hs stale and the scatter harmless: state t + 1 is never read then.
             TRY(scatter_rows(hs[ns.n_layers - 1], p.S, y.rows, y.count, p.S, s_n, p.S, st));
@@ -280,13 +285,13 @@ int train_step_composite(const gnn_train_args_t &ta) {
         const float *W0 = no.kernel[0], *b0 = no.bias[0];
         if (bn_o) {
             TRY(colstats_segs(nullptr, osegs, 1, p.M, p.stats_o, p.stats_o + no.in_dim, p.part, st));
-            TRY(fold_with_stats(no, p.stats_o, p.Wf_o, p.bf_o, st));
+            TRY(fold_with_stats(no, p.stats_o, p.Wf_o, p.bf_o, st, true));
             gnn::k_bn_moving_multi<<<cdiv(no.in_dim, 256), 256, 0, st>>>(p.stats_o, 2 * no.in_dim, 1, no.in_dim, const_cast<float *>(no.bn_mean),
                                                                         const_cast<float *>(no.bn_var), ta.bn_momentum);
             LAUNCH_OK();
             W0 = p.Wf_o; b0 = p.bf_o;
         }
-        TRY(forward_layers(no, osegs, 1, p.M, W0, b0, ohs, nullptr, st));
+        TRY(forward_layers(no, osegs, 1, p.M, W0, b0, ohs, nullptr, st, nullptr, nullptr, bn_o ? p.stats_o : nullptr));
     }
     if (p.pooled) TRY(launch_aggregate(nullptr, a.nodegraph, out_nodes, p.T, p.T, ta.y_pred, p.T, st));
     gnn::k_loss_grad<<<cdiv(std::max(p.R, 1), 256), 256, 0, st>>>(ta.loss_kind, ta.targets, ta.y_pred, ta.sample_weight, p.R, p.T, p.dpred, p.loss_rows);
@@ -329,7 +334,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
                 const bool folded = ns.has_bn && ns.units[0] <= 4;
                 const float *W0 = folded ? y.Wf + (size_t)t * y.in_dim * ns.units[0] : ns.kernel[0], *b0 = folded ? y.bf + (size_t)t * ns.units[0] : ns.bias[0];
                 gnn_mlp_t head = ns; head.n_layers = ns.n_layers - 1;
-                TRY(forward_layers(head, segs, n, y.count, W0, b0, hs, nullptr, st, nullptr, (ns.has_bn && !folded) ? stats : nullptr));
+                TRY(forward_layers(head, segs, n, y.count, W0, b0, hs, nullptr, st, nullptr, (ns.has_bn && !folded) ? stats : nullptr, folded ? stats : nullptr));
             }
             TRY(gather_rows(s_n, p.S, y.rows, y.count, p.S, hs[ns.n_layers - 1], p.S, st));      // the last layer's output: the type's rows of state t + 1
             TRY(gather_rows(p.G_state, p.S, y.rows, y.count, p.S, y.Gc, p.S, st));
@@ -353,6 +358,8 @@ int train_step_composite(const gnn_train_args_t &ta) {
     }
     if (ta.average_st_grads && k > 0)
         for (int q = 0; q < p.n_types; ++q) TRY(scale_grads(*p.ty[q].m, p.ty[q].g, 1.0f / (float)k, st));
+    gnn::k_grads_ok<<<1, 1, 0, st>>>(nullptr, p.grads_ok);      // (no cross-workgroup waits on this path: always valid)
+    LAUNCH_OK();
     return 0;
 }
 

@@ -35,6 +35,7 @@ struct TrainPlan {
     int N, E, S, L, A, d, M, R, T, K, G;
     bool pooled, with_labels, agg_taped;      // agg_taped: every iteration's neighbour sum is kept (small graphs) instead of recomputed
     int in_s, in_o, H1s, H1o, kdx_s, off_agg;
+    int *grads_ok;               // FIRST word of the tape: validity of the step's gradients (gnn_train_args_t::grads_ok_dev)
     int *flags; float *k_dev;
     float *states, *agg, *agg_arcs, *agg_nodes;
     float *stats_s, *stats_tpl, *Wf_s, *bf_s;
@@ -138,6 +139,7 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.ldS = p.small ? p.SPs : p.S;
 
     Carver c(ws);
+    p.grads_ok = c.take<int>(4);                           // (offset 0 whatever the plan: the next call on this tape reads it back)
     p.flags = c.take<int>(p.K + 8);
     p.k_dev = c.take<float>(4);
     p.states = c.take<float>((size_t)(p.K + 1) * p.N * p.ldS);
@@ -236,8 +238,10 @@ struct PredFuse { const float *old; int ld; float thr; int *flag; float *k_out; 
 
 // `bn_stats` (mean | var of the first layer's input columns): the training-mode BatchNormalization is applied to the inputs as
 // the first layer stages them (k_segdense), with (W0, b0) the raw kernel / bias; NULL: (W0, b0) are used as they are.
+// `center` (the column means, by weight row): (W0, b0) is a CENTRED fold (fold_with_stats(.., true)) and the first layer subtracts
+// the means from its inputs as it stages them (layers whose kernel wants folded weights: the thin-output kernel).
 int forward_layers(const gnn_mlp_t &m, const gnn::Seg *segs, int nseg, int M, const float *W0, const float *b0, float *const *hs,
-                   const int *gate, hipStream_t st, PredFuse *pred = nullptr, const float *bn_stats = nullptr) {
+                   const int *gate, hipStream_t st, PredFuse *pred = nullptr, const float *bn_stats = nullptr, const float *center = nullptr) {
     for (int l = 0; l < m.n_layers; ++l) {
         gnn::SegDenseArgs a;
         memset(&a, 0, sizeof(a));
@@ -247,6 +251,7 @@ int forward_layers(const gnn_mlp_t &m, const gnn::Seg *segs, int nseg, int M, co
             for (int s = 0; s < nseg; ++s) a.seg[s] = segs[s];
             a.W = W0; a.bias = b0;
             if (bn_stats) { a.in_gamma = m.bn_gamma; a.in_beta = m.bn_beta; a.in_mean = bn_stats; a.in_var = bn_stats + m.in_dim; a.in_eps = m.bn_eps; }
+            else a.in_center = center;
         } else {
             a.nseg = 1;
             a.seg[0] = gnn::Seg{hs[l - 1], nullptr, (int)m.units[l - 1], (int)m.units[l - 1], 0};
@@ -738,6 +743,11 @@ int gnn_train_step(const gnn_train_args_t *args) {
     const size_t NS = (size_t)p.N * p.ldS;             // one state matrix of the tape (rows of ldS floats: padded on the persistent small-graph path)
 
     // ---- setup: transposes, aggregates of the constants, state_0, iteration-invariant statistics -----------------------------------
+    // the validity word the previous call on this tape left (stream-ordered behind that call's launches; on the host at this call's one
+    // synchronisation), then this call's: 0 until the last launch of the step has been issued
+    if (ta.prev_grads_ok_host) HIP_OK(hipMemcpyAsync(ta.prev_grads_ok_host, p.grads_ok, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemsetAsync(p.grads_ok, 0, sizeof(int) * 4, st));
+    if (ta.grads_ok_dev) *ta.grads_ok_dev = p.grads_ok;
     TRY(transposes(p.cs, st));
     TRY(transposes(p.co, st));
     HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (p.K + 8), st));
@@ -774,6 +784,10 @@ int gnn_train_step(const gnn_train_args_t *args) {
             }
         } else TRY(colstats_segs(nullptr, cst, nc, p.N, p.stats_tpl, p.stats_tpl + p.in_s, p.part, st));
         gnn::k_replicate<<<std::min(cdiv((long)2 * p.in_s * p.K, 256), 1024), 256, 0, st>>>(p.stats_tpl, 2 * p.in_s, p.K, p.stats_s);
+        LAUNCH_OK();
+    }
+    if (p.head_fast) {     // the thin-head kernels treat output row m as node m: out_index must BE the identity (checked on the device, read with k)
+        gnn::k_not_identity<<<std::min(cdiv(p.M, 256), 1024), 256, 0, st>>>(a.out_index, p.M, p.k_dev + 2);
         LAUNCH_OK();
     }
     // ---- training-mode forward: gated iterations, tape = states + statistics + folded first layers ------------------------------
@@ -856,39 +870,47 @@ int gnn_train_step(const gnn_train_args_t *args) {
         float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);
         TRY(launch_aggregate(gate, a.adjacency, s_t, p.S, p.S, agg_t, p.S, st));
         const int n = state_segs(a, p, t, segs);
-        const float *W0 = ns.kernel[0], *b0 = ns.bias[0], *bn_on_load = nullptr;
+        const float *W0 = ns.kernel[0], *b0 = ns.bias[0], *bn_on_load = nullptr, *centre = nullptr;
         if (bn_s) {
             float *stats = p.stats_s + (size_t)t * 2 * p.in_s;
             gnn::Seg dyn[2] = {segs[0], segs[p.with_labels ? 2 : 1]};
             TRY(colstats_segs(gate, dyn, 2, p.N, stats, stats + p.in_s, p.part, st));
             if (fold_s) {                        // thin first layer (<= 4 units): the thin-dense kernel wants folded weights
                 float *Wf = p.Wf_s + (size_t)t * p.in_s * p.H1s, *bf = p.bf_s + (size_t)t * p.H1s;
-                TRY(fold_with_stats(ns, stats, Wf, bf, st));
-                W0 = Wf; b0 = bf;
+                TRY(fold_with_stats(ns, stats, Wf, bf, st, true));
+                W0 = Wf; b0 = bf; centre = stats;
             } else bn_on_load = stats;           // BatchNormalization applied as the first layer stages its inputs: no fold launch
         }
         float *hs[GNN_MAX_LAYERS];
         for (int l = 0; l < ns.n_layers; ++l) hs[l] = l == ns.n_layers - 1 ? s_n : p.cs.hid[l];
         PredFuse pf{s_t, p.S, a.state_threshold, p.flags + t + 1, p.k_dev, (float)(t + 1), false};
-        TRY(forward_layers(ns, segs, n, p.N, W0, b0, hs, gate, st, &pf, bn_on_load));
+        TRY(forward_layers(ns, segs, n, p.N, W0, b0, hs, gate, st, &pf, bn_on_load, centre));
         if (!pf.fused) TRY(launch_converge(gate, s_n, s_t, p.N, p.S, p.S, p.S, a.state_threshold, p.flags + t + 1, p.k_dev, (float)(t + 1), st));
     }
-    float k_f2[2] = {0.0f, 0.0f};
-    HIP_OK(hipMemcpyAsync(k_f2, p.k_dev, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+    float k_f2[3] = {0.0f, 0.0f, 0.0f};
+    HIP_OK(hipMemcpyAsync(k_f2, p.k_dev, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));                                  // the one host synchronisation of the step
     const int k = (int)k_f2[0];
     *ta.k_host = k;
     if (k_f2[1] == 1.0f) return fail("tile_node_begin: an arc of `adjacency` leaves its tile");
     if (k_f2[1] != 0.0f) return fail("a workgroup of the persistent training kernel never arrived at a grid barrier (not resident?)");
     if (k < 0 || k > p.K) return fail("iteration count %d out of range", k);
+    if (k_f2[2] != 0.0f) p.head_fast = false;      // a permuted / repeated out_index of length n_nodes: the general head (gathers, scatter-add)
     const float *state_k = p.states + (size_t)k * NS;
     if (p.ldS == p.S) HIP_OK(hipMemcpyAsync(ta.state, state_k, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
     else TRY(launch_copy2d(nullptr, state_k, p.ldS, ta.state, p.S, p.N, p.S, p.S, st));
-    if (bn_s && k > 0) {
-        gnn::k_bn_moving_multi<<<cdiv(p.in_s, 256), 256, 0, st>>>(p.stats_s, 2 * p.in_s, k, p.in_s, const_cast<float *>(ns.bn_mean),
-                                                                const_cast<float *>(ns.bn_var), ta.bn_momentum);
-        LAUNCH_OK();
-    }
+    // The moving averages of BatchNormalization (one update per executed call).  On the persistent small-graph path they wait until the
+    // backward launch has passed its grid barriers and are gated by the step's validity word: a step whose backward failed changes nothing.
+    auto moving_state = [&](const int *gate) -> int {
+        if (bn_s && k > 0) {
+            gnn::k_bn_moving_multi<<<cdiv(p.in_s, 256), 256, 0, st>>>(p.stats_s, 2 * p.in_s, k, p.in_s, const_cast<float *>(ns.bn_mean),
+                                                                    const_cast<float *>(ns.bn_var), ta.bn_momentum, gate);
+            LAUNCH_OK();
+        }
+        return 0;
+    };
+    bool moving_output_pending = false;
+    if (!p.small) TRY(moving_state(nullptr));
 
     // ---- output network, training mode ---------------------------------------------------------------------------------------------
     gnn::Seg osegs[GNN_MAX_SEGS];
@@ -933,13 +955,16 @@ int gnn_train_step(const gnn_train_args_t *args) {
                 }
             } else
             TRY(colstats_segs(nullptr, osegs, nos, p.M, p.stats_o, p.stats_o + p.in_o, p.part, st));
-            TRY(fold_with_stats(no, p.stats_o, p.Wf_o, p.bf_o, st));
-            gnn::k_bn_moving_multi<<<cdiv(p.in_o, 256), 256, 0, st>>>(p.stats_o, 2 * p.in_o, 1, p.in_o, const_cast<float *>(no.bn_mean),
-                                                                    const_cast<float *>(no.bn_var), ta.bn_momentum);
-            LAUNCH_OK();
+            TRY(fold_with_stats(no, p.stats_o, p.Wf_o, p.bf_o, st, true));      // (centred: the first layer subtracts the means on load)
+            if (p.small) moving_output_pending = true;
+            else {
+                gnn::k_bn_moving_multi<<<cdiv(p.in_o, 256), 256, 0, st>>>(p.stats_o, 2 * p.in_o, 1, p.in_o, const_cast<float *>(no.bn_mean),
+                                                                        const_cast<float *>(no.bn_var), ta.bn_momentum);
+                LAUNCH_OK();
+            }
             W0 = p.Wf_o; b0 = p.bf_o;
         }
-        TRY(forward_layers(no, osegs, nos, p.M, W0, b0, ohs, nullptr, st));
+        TRY(forward_layers(no, osegs, nos, p.M, W0, b0, ohs, nullptr, st, nullptr, nullptr, bn_o ? p.stats_o : nullptr));
     }
     if (p.pooled) TRY(launch_aggregate(nullptr, a.nodegraph, out_nodes, p.T, p.T, ta.y_pred, p.T, st));
     // ---- loss and its gradient ----------------------------------------------------------------------------------------------------
@@ -988,6 +1013,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
         ba.G0 = p.G_state; ba.dxa = p.dx_s_all; ba.bar = p.sm_bar + 2; ba.part = p.sm_part; ba.partW = p.sm_partW;
         ba.partBN = p.sm_partBN;
         ba.inv_n = 1.0f / (float)p.N; ba.err = p.k_dev; ba.wait_ticks = gnn::wait_ticks();
+        if (const char *e = getenv("GNN_DEBUG_FAIL_BWD")) { if (e[0] == '1') ba.wait_ticks = 0; }      // (test hook: every barrier wait of THIS launch expires at once)
         switch (p.SPs) {
             case 16: TRY(launch_train_small_bwd_sq<1>(ba, tiles, p.n_wg, ba.w_s != nullptr, st)); break;
             case 32: TRY(launch_train_small_bwd_sq<2>(ba, tiles, p.n_wg, ba.w_s != nullptr, st)); break;
@@ -1014,7 +1040,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
             const bool folded = bn_s && fold_s;
             const float *W0 = folded ? p.Wf_s + (size_t)t * p.in_s * p.H1s : ns.kernel[0], *b0 = folded ? p.bf_s + (size_t)t * p.H1s : ns.bias[0];
             gnn_mlp_t head = ns; head.n_layers = ns.n_layers - 1;
-            TRY(forward_layers(head, segs, n, p.N, W0, b0, hs, nullptr, st, nullptr, (bn_s && !fold_s) ? stats : nullptr));
+            TRY(forward_layers(head, segs, n, p.N, W0, b0, hs, nullptr, st, nullptr, (bn_s && !fold_s) ? stats : nullptr, folded ? stats : nullptr));
         }
         // 'average' / 'sum' / 'normalized' entries depend on the destination only (a.adjacency carries one scale per row): the large-
         // graph kernel scales the agg-half of a row's gradient once, and the transposed aggregate walks UNIT weights (no 4 bytes per arc)
@@ -1093,6 +1119,17 @@ int gnn_train_step(const gnn_train_args_t *args) {
         }
     }
     if (ta.average_st_grads && k > 0) TRY(scale_grads(ns, ta.grad_state, 1.0f / (float)k, st));
+    // ---- the step's validity word, and what waited for it ----------------------------------------------------------------------------------
+    gnn::k_grads_ok<<<1, 1, 0, st>>>(p.small ? p.k_dev : nullptr, p.grads_ok);
+    LAUNCH_OK();
+    if (p.small) {
+        TRY(moving_state(p.grads_ok));
+        if (moving_output_pending) {
+            gnn::k_bn_moving_multi<<<cdiv(p.in_o, 256), 256, 0, st>>>(p.stats_o, 2 * p.in_o, 1, p.in_o, const_cast<float *>(no.bn_mean),
+                                                                    const_cast<float *>(no.bn_var), ta.bn_momentum, p.grads_ok);
+            LAUNCH_OK();
+        }
+    }
     return 0;
 }
 

@@ -159,19 +159,32 @@ class DataParallel:
         largest of the ranks' iteration counts."""
         tr, m = self._trainer, self.model
         res = tr.train_step(x, y, sample_weight, state0=state0, seed=seed, apply=False)
-        gs = tr.gs if isinstance(tr.gs, (list, tuple)) else [tr.gs]
-        pairs = [gv for g_ in list(gs) + [tr.go] for gv in zip(g_.gradients(), g_.variables())]
-        grads = [g for g, _ in pairs]
-        moving = [t for g_ in list(gs) + [tr.go] if g_.bn for t in g_.moving]
-        dev = grads[0].device
-        rows = float(y.shape[0]) if y is not None else 0.0
-        head = torch.tensor([rows, 0.0, float(res['k'])], dtype=torch.float32, device=dev)
-        head[1] = res['loss'].detach().reshape(()) * rows
-        flat = torch.cat([head[:2]] + [g.reshape(-1) * rows for g in grads] + [t.reshape(-1) for t in moving])
-        kmax = head[2:3].clone()
-        if self.world > 1:
-            dist.all_reduce(flat, group=self.group)
-            dist.all_reduce(kmax, op=dist.ReduceOp.MAX, group=self.group)
+        for attempt in range(2):
+            gs = tr.gs if isinstance(tr.gs, (list, tuple)) else [tr.gs]
+            pairs = [gv for g_ in list(gs) + [tr.go] for gv in zip(g_.gradients(), g_.variables())]
+            grads = [g for g, _ in pairs]
+            moving = [t for g_ in list(gs) + [tr.go] if g_.bn for t in g_.moving]
+            dev = grads[0].device
+            rows = float(y.shape[0]) if y is not None else 0.0
+            head = torch.tensor([rows, 0.0, float(res['k'])], dtype=torch.float32, device=dev)
+            head[1] = res['loss'].detach().reshape(()) * rows
+            # the in-library step's validity word (1: gradients valid; 0: this rank's persistent backward launch lost a grid barrier, its
+            # gradients are NaN and its moving statistics untouched) travels with the sums: a rank that failed repeats ITS shard on the
+            # building blocks and the all-reduce is done again - nobody's update ever sees the poisoned values
+            okv = res['grads_ok'].to(torch.float32).reshape(1) if res.get('grads_ok') is not None else torch.ones(1, dtype=torch.float32, device=dev)
+            flat = torch.cat([head[:2]] + [torch.where(okv > 0, g.reshape(-1) * rows, torch.zeros_like(g.reshape(-1))) for g in grads] +
+                             [t.reshape(-1) for t in moving] + [okv])
+            kmax = head[2:3].clone()
+            if self.world > 1:
+                dist.all_reduce(flat, group=self.group)
+                dist.all_reduce(kmax, op=dist.ReduceOp.MAX, group=self.group)
+            if int(round(float(flat[-1].item()))) >= self.world or attempt == 1: break
+            if float(okv.item()) == 0.0:
+                import warnings
+                warnings.warn('the persistent backward kernel of this rank\'s training step could not keep its workgroups resident: the shard is '
+                              'trained again on the general kernels', RuntimeWarning, stacklevel=3)
+                res = tr._train_step_general(x, y, sample_weight, state0, seed, False)
+        flat = flat[:-1]
         total = flat[0].clamp(min=1.0)
         off = 2
         for g in grads:

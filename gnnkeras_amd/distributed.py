@@ -235,8 +235,9 @@ class ShardedLoop:
         self._iter_events = None
 
     _layout = 'allgather'
-    pipeline_chunks = 1               # > 1: the pipelined exchange (set_pipeline); make_sharded_loop('auto') arms the measured choice
+    pipeline_chunks = 1               # > 1: the pipelined exchange (set_pipeline); make_sharded_loop(pipeline='auto') arms the measured choice
     _tune_pipeline_pending = False    # ... which the first forward() makes (_tune_pipeline)
+    PIPELINE_MARGIN = 0.05            # ... and which leaves the un-chunked exchange only for a count that is at least this much faster
 
     # ---- device-specific pieces (the gloo/CPU tests override these with numpy stand-ins) ------------------------------------
     def _pool(self, out_nodes):
@@ -492,7 +493,8 @@ class ShardedLoop:
     def _tune_pipeline(self, state0_full, candidates=(1, 2, 4), reps: int = 3):
         """Measured choice of the chunk count (collective): `reps` iterations of each candidate on the real buffers with the gates
         forced open, the slowest rank's time decides, every rank keeps the same count.  Chunk count 1 runs with the transport
-        `pick_transport` chose."""
+        `pick_transport` chose - and stays unless a chunked count is faster by a clear margin (PIPELINE_MARGIN: three wall-clock
+        repetitions do not resolve less; the un-chunked exchange is the path every other test and measurement has seen)."""
         import time
         m = self.model
         base_transport = self.transport
@@ -524,6 +526,7 @@ class ShardedLoop:
             m.native_flags = flags
             if hasattr(self, 'args'): self.args.flags = flags
         best = min(times, key=times.get)
+        if best != 1 and 1 in times and times[best] > (1.0 - self.PIPELINE_MARGIN) * times[1]: best = 1
         self.transport = base_transport
         self.set_pipeline(best)
         self.pipeline_times = times
@@ -911,7 +914,7 @@ def choose_exchange(graph: GraphObject, world_size: int) -> str:
 
 
 def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, device, group=None, exchange: str = 'auto',
-                      overlap: bool = True, measure: bool = True):
+                      overlap: bool = True, measure: bool = True, pipeline='off'):
     """`exchange`:
         'allgather' whole slices with RCCL's all-gather collective;
         'direct'    whole slices as R - 1 concurrent point-to-point pairs (one-hop all-gather over the xGMI mesh);
@@ -920,7 +923,17 @@ def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, dev
                     block-diagonal batches); otherwise the whole-slice layout, and - with `measure` and more than one rank - the
                     faster of its two transports on THIS machine: both are timed on the real buffers (3 exchanges each, the
                     slowest rank's time decides, so every rank picks the same one).  Which collective wins depends on how RCCL
-                    maps it onto the xGMI links, which cannot be known from here: measured, not guessed."""
+                    maps it onto the xGMI links, which cannot be known from here: measured, not guessed.
+    `pipeline` (whole-slice layouts; ADVICE r4: opt-in until a multi-GPU run has validated it against the un-chunked exchange):
+        'off'   one halo-kernel launch and one exchange per iteration (default);
+        'auto'  the chunk count (1 / 2 / 4 launches, every chunk's rows on the links while the next is computed) is measured at the
+                first forward() on the real buffers and a chunked count kept only when it is > 5 % faster than one launch;
+        int     that many chunks (`ShardedLoop.set_pipeline`).
+    The environment variable GNN_EXCHANGE_PIPELINE (off / auto / a count) overrides the argument."""
+    import os
+    pipeline = os.environ.get('GNN_EXCHANGE_PIPELINE', pipeline)
+    if isinstance(pipeline, str) and pipeline.isdigit(): pipeline = int(pipeline)
+    if not (pipeline in ('off', 'auto') or (isinstance(pipeline, int) and pipeline >= 1)): raise ValueError("pipeline must be 'off', 'auto' or a chunk count")
     if exchange not in ('auto', 'allgather', 'direct', 'halo'): raise ValueError('exchange must be auto, allgather, direct or halo')
     pick = exchange
     if exchange == 'auto': pick = choose_exchange(graph, world_size)
@@ -931,7 +944,8 @@ def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, dev
     if pick == 'direct': sl.transport = 'direct'
     if exchange == 'auto' and measure and world_size > 1:
         sl.transport, sl.transport_times = pick_transport(sl)
-        sl._tune_pipeline_pending = True          # ... and whether to pipeline the exchange in 2 / 4 chunks: measured at the first forward()
+    if pipeline == 'auto' and world_size > 1: sl._tune_pipeline_pending = True      # the chunk count is measured at the first forward()
+    elif isinstance(pipeline, int) and pipeline > 1: sl.set_pipeline(pipeline)
     return sl
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 6
+#define GNN_ABI_VERSION 7
 
 /* Keras activation names accepted by the reference MLP builder (GNN/Models/MLP.py:16). */
 enum gnn_activation {
@@ -305,15 +305,22 @@ typedef struct gnn_dense_args {
     float *Y; int32_t ldy; const int32_t *out_rowidx;
     const int32_t *gate;                           /* skip the launch when *gate == 0 */
     void *stream;
+    const float *in_center;                        /* ABI 7, optional: in_center[weight row] is subtracted from every input value as it is
+                                                    * staged - the consumer of a CENTRED fold (gnn_fold_bn(centred = 1)): BatchNormalization
+                                                    * as a (x - mean) + beta instead of a x + (beta - mean a), which cancels the mean against
+                                                    * itself and costs digits when the inputs sit far from zero */
 } gnn_dense_args_t;
 int gnn_dense(const gnn_dense_args_t *args);
-/* Wf = diag(gamma/sqrt(var+eps)) W, bf = b + (beta - mean*gamma/sqrt(var+eps)) W  (gamma NULL: plain copy) */
+/* Wf = diag(gamma/sqrt(var+eps)) W, bf = b + (beta - mean*gamma/sqrt(var+eps)) W  (gamma NULL: plain copy).
+ * centred != 0 (ABI 7): bf = b + beta W - the consumer subtracts `mean` from its inputs itself (gnn_dense_args_t::in_center). */
 int gnn_fold_bn(const float *W, const float *b, int32_t K, int32_t H, const float *gamma, const float *beta,
-                const float *mean, const float *var, float eps, float *Wf, float *bf, void *stream);
-/* P[K,H] (+)= X[rows]^T dZ ; q[H] (+)= colsum(dZ)   — deterministic two-stage reduction */
+                const float *mean, const float *var, float eps, float *Wf, float *bf, int32_t centred, void *stream);
+/* P[K,H] (+)= (X[rows] - center)^T dZ ; q[H] (+)= colsum(dZ)   — deterministic two-stage reduction.  `center` (ABI 7; [K] or NULL): the
+ * column means of a training-mode BatchNormalization, subtracted as the rows are staged (gnn_first_layer_param_grads(centered = 1)). */
 size_t gnn_dense_grad_workspace_bytes(int32_t K, int32_t H, int32_t M);
 int gnn_dense_grad(const float *X, int32_t ldx, const int32_t *rowidx, int32_t K, const float *dZ, int32_t ldz, int32_t H,
-                   int32_t M, float *P, float *q, int32_t accumulate, void *workspace, size_t workspace_bytes, void *stream);
+                   int32_t M, float *P, float *q, int32_t accumulate, const float *center, void *workspace, size_t workspace_bytes,
+                   void *stream);
 /* dZ = G (.) act'(Y) from the layer output (softmax: Y (.) (G - <G,Y>)) */
 int gnn_act_grad(const float *G, int32_t ldg, const float *Y, int32_t ldy, float *dZ, int32_t ldz, int32_t M, int32_t H,
                  int32_t activation, void *stream);
@@ -322,10 +329,13 @@ size_t gnn_colstats_workspace_bytes(int32_t K, int32_t M);
 int gnn_colstats(const float *X, int32_t ldx, const int32_t *rowidx, int32_t K, int32_t M, float *mean, float *var,
                  float *moving_mean, float *moving_var, float momentum, const int32_t *gate, void *workspace,
                  size_t workspace_bytes, void *stream);
-/* dW, db, dgamma, dbeta (and the two BN input-gradient moments m1, m2) of [BN +] first Dense from P and q */
+/* dW, db, dgamma, dbeta (and the two BN input-gradient moments m1, m2) of [BN +] first Dense from P and q.
+ * centered != 0 (ABI 7, with BatchNormalization): P is (X - mean)^T dZ already (gnn_dense_grad with `center`): dW = a P + beta q^T and
+ * d gamma = rstd sum_h W P without a `- mean (W q)` that would cancel the leading digits of two sums over all rows. */
 int gnn_first_layer_param_grads(const float *P, const float *q, const float *W, int32_t K, int32_t H, const float *gamma,
                                 const float *beta, const float *mean, const float *var, float eps, int32_t M, float *dW,
-                                float *db, float *dgamma, float *dbeta, float *m1, float *m2, int32_t accumulate, void *stream);
+                                float *db, float *dgamma, float *dbeta, float *m1, float *m2, int32_t accumulate, int32_t centered,
+                                void *stream);
 int gnn_bn_input_grad(const float *dy, int32_t ld_dy, const float *x, int32_t ld_x, const int32_t *x_rowidx, int32_t M, int32_t width, int32_t k0,
                       const float *gamma, const float *mean, const float *var, float eps, const float *m1, const float *m2,
                       float *dx, int32_t ld_dx, void *stream);
@@ -335,12 +345,16 @@ int gnn_axpby(float a, const float *x, float b, const float *y, float *out, size
  * 2 mse, 3 mae.  dp = d loss / d prediction, loss_rows[m] = weighted per-row loss (caller sums / M). */
 int gnn_loss_grad(int32_t kind, const float *y, const float *p, const float *sample_weight, int32_t M, int32_t T, float *dp,
                   float *loss_rows, void *stream);
+/* Optimizer updates (tf.keras.optimizers.Adam / SGD defaults).  `gate` (ABI 7; NULL = always): a DEVICE word - the launch leaves
+ * parameters and slots untouched when *gate == 0.  gnn_train_step hands out such a word (`grads_ok_dev`): 1 when the gradients it left
+ * are valid, 0 when its backward launch failed (a grid barrier of the persistent small-graph kernel expired) - so a failed step can
+ * never reach the weights, without a host synchronisation between the step and its update. */
 int gnn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2, float eps,
-                  int32_t step, void *stream);
+                  int32_t step, const int32_t *gate, void *stream);
 /* the same update for every variable of a model in one launch: HOST arrays of n_vars device pointers / element counts */
 int gnn_adam_multi(float *const *p, const float *const *g, float *const *m, float *const *v, const size_t *n, int32_t n_vars, float lr,
-                   float beta1, float beta2, float eps, int32_t step, void *stream);
-int gnn_sgd_step(float *p, const float *g, float *velocity, size_t n, float lr, float momentum, void *stream);
+                   float beta1, float beta2, float eps, int32_t step, const int32_t *gate, void *stream);
+int gnn_sgd_step(float *p, const float *g, float *velocity, size_t n, float lr, float momentum, const int32_t *gate, void *stream);
 int gnn_converged_gated(const float *state, const float *state_old, int32_t n, int32_t dim, int32_t ld, float threshold,
                         const int32_t *gate, int32_t *flag, float *k_out, float k_val, void *stream);
 int gnn_aggregate_gated(const gnn_csr_t *csr, const float *X, int32_t ldx, int32_t F, float *out, int32_t ldo,
@@ -421,6 +435,17 @@ typedef struct gnn_train_args {
      * grad_state_types[t] (grad_state is not used then).  Node and graph focus; arc-focused composite models and LGNN label
      * gradients train through the building blocks. */
     gnn_mlp_grads_t grad_state_types[GNN_MAX_TYPES];
+    /* ABI 7: validity of the step's gradients WITHOUT a second host synchronisation.  The persistent small-graph backward kernel waits
+     * at grid barriers with a bound (GNN_WAIT_MS); when such a wait expires (GPU shared with other long-running work) its gradients are
+     * poisoned (NaN) - and the call has returned long before.  So the library keeps one device word at the START of the tape: 1 when
+     * every launch of the step completed its protocol, else 0; the BatchNormalization moving averages of the step are updated BEHIND
+     * the backward launch and only when the word is 1, and the optimizer entry points take the word as `gate`: a failed step changes
+     * nothing.  The caller learns about it for free at the NEXT call's one synchronisation:
+     *   grads_ok_dev        optional OUT (host pointer variable): the device word of THIS call (valid until the tape is reused)
+     *   prev_grads_ok_host  optional OUT (host int): the word the PREVIOUS call on this tape left, fetched before this call resets it
+     *                       (NULL for a fresh tape, whose first word is not a validity word yet) */
+    const int32_t **grads_ok_dev;
+    int32_t *prev_grads_ok_host;
 } gnn_train_args_t;
 /* Arithmetic: float32 throughout.  On graphs of >= GNN_TRAIN_BIG_MIN_NODES (32 768) nodes the first Dense's forward product and dZ . W^T run on
  * the bf16 matrix cores with every float32 operand split into three bf16 terms (six products, float32 accumulation: the accuracy of a

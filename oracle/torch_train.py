@@ -20,6 +20,8 @@ import torch
 from .torch_cpu import ACT
 
 EPS_BN, MOMENTUM = 1e-3, 0.99
+KINK_ACTS = ('relu', 'selu')      # activations whose derivative JUMPS at 0 (relu 0 -> 1, selu 1.7581 -> 1.0507; elu's is continuous there)
+KINK_TOL = 1e-6                   # a float32 implementation may put a pre-activation this close to 0 on the other side
 
 
 def _lowbias32(h):
@@ -64,6 +66,11 @@ class Net:
         self.b = [w[pos + 2 * i + 1].requires_grad_() for i in range(len(self.acts))]
         self.kreg = spec.get('kernel_regularizer') or [None] * len(self.acts)
         self.breg = spec.get('bias_regularizer') or [None] * len(self.acts)
+        # per Dense layer and output unit: how many pre-activations of this step came within KINK_TOL of an activation kink.  Where a
+        # float32 implementation lands on the other side, that element's act'(z) differs by the jump and the unit's kernel column /
+        # bias gradient by |G| x jump - not an arithmetic error of the implementation; the tests widen the bar for exactly those units.
+        self.kinks = [np.zeros(int(W_.shape[1]), dtype=np.int64) for W_ in self.W]
+        self._recompute = False       # (a checkpointed re-run of a call: no second moving-average update, no second kink count)
 
     def penalty(self):
         """Keras `layer.losses` of the Dense layers: l1 * sum|w| + l2 * sum(w^2), each variable once (MLP.py:48-49)."""
@@ -98,15 +105,19 @@ class Net:
             if training:
                 mean = x.mean(0)
                 var = ((x - mean) ** 2).mean(0)
-                with torch.no_grad():
-                    self.moving_mean.mul_(MOMENTUM).add_(mean * (1 - MOMENTUM))
-                    self.moving_var.mul_(MOMENTUM).add_(var * (1 - MOMENTUM))
+                if not self._recompute:
+                    with torch.no_grad():
+                        self.moving_mean.mul_(MOMENTUM).add_(mean * (1 - MOMENTUM))
+                        self.moving_var.mul_(MOMENTUM).add_(var * (1 - MOMENTUM))
             else:
                 mean, var = self.moving_mean, self.moving_var
             x = (x - mean) / torch.sqrt(var + EPS_BN) * self.gamma + self.beta
         for l, (W, b, a) in enumerate(zip(self.W, self.b, self.acts)):
             if training: x = self._dropout(x, l, call)
-            x = ACT[a](x @ W + b)
+            z = x @ W + b
+            if a in KINK_ACTS and not self._recompute:
+                with torch.no_grad(): self.kinks[l] += (z.abs() < KINK_TOL).sum(0).numpy()
+            x = ACT[a](z)
         if training: x = self._dropout(x, len(self.W), call)
         return x
 
@@ -137,10 +148,31 @@ def _sp(triple, dtype):
                                    (int(shp[1]), int(shp[0]))).coalesce()
 
 
+def _checkpointed(ns, comps):
+    """state -> ns(concat(comps(state))) with the iteration's intermediates (the [N, in_dim] concatenation, its normalised copy, the
+    pre-activations: ~6 GB per iteration at 1 M nodes in float64) recomputed in the backward pass instead of kept: the SAME float64
+    operations in the same order (torch.utils.checkpoint), what lets the million-node oracle fit a host."""
+    from torch.utils.checkpoint import checkpoint
+    first = [True]
+    def fn(state):
+        if not first[0]: ns._recompute = True
+        try:
+            call0 = ns.calls
+            out = ns(torch.cat(comps(state), dim=1))
+            if not first[0]: ns.calls = call0              # (the recomputation is the same call, not a new one)
+            return out
+        finally:
+            first[0] = False
+            ns._recompute = False
+    return lambda state: checkpoint(fn, state, use_reentrant=False)
+
+
 def train_step(nodes, arcs, adjacency, arcnode, nodegraph, mask, *, net_state, net_output, state_vect_dim, max_iteration,
-               state_threshold, focus, state0, y, sample_weight, loss, average_st_grads=False, dtype=torch.float64, seed=None):
-    """Returns dict(k, loss, y_pred, grads_state, grads_output, moving_state, moving_output) as numpy.  `seed`: the step's
-    seed for the Dropout masks (the product derives its step key as mix32(0x5EED, seed))."""
+               state_threshold, focus, state0, y, sample_weight, loss, average_st_grads=False, dtype=torch.float64, seed=None,
+               checkpoint_iterations=False):
+    """Returns dict(k, loss, y_pred, grads_state, grads_output, moving_state, moving_output, kinks_state, kinks_output) as numpy.
+    `seed`: the step's seed for the Dropout masks (the product derives its step key as mix32(0x5EED, seed)).
+    `checkpoint_iterations`: keep only the states between iterations and recompute each iteration in the backward pass (large graphs)."""
     step_seed = mix32(0x5EED, int(seed)) if seed is not None else 0
     ns, no = Net(*net_state, dtype=dtype, net_id=0, step_seed=step_seed), Net(*net_output, dtype=dtype, net_id=1000, step_seed=step_seed)
     X = torch.tensor(np.asarray(nodes), dtype=dtype)
@@ -157,12 +189,16 @@ def train_step(nodes, arcs, adjacency, arcnode, nodegraph, mask, *, net_state, n
         comps = lambda s: [s, torch.sparse.mm(At, s), agg_arcs]
     state_old = torch.ones_like(state)
     k = 0
+    if checkpoint_iterations and not state.requires_grad: state = state.clone().requires_grad_()      # (checkpoint wants a differentiable input)
     while True:
-        dist = torch.sqrt(torch.sum(torch.square(state - state_old), dim=1))
-        norm = torch.sqrt(torch.sum(torch.square(state_old), dim=1))
-        if not (bool(torch.any(dist > state_threshold * norm)) and k < max_iteration):
+        with torch.no_grad():
+            dist = torch.sqrt(torch.sum(torch.square(state - state_old), dim=1))
+            norm = torch.sqrt(torch.sum(torch.square(state_old), dim=1))
+            go_on = bool(torch.any(dist > state_threshold * norm)) and k < max_iteration
+        if not go_on:
             break
-        state, state_old, k = ns(torch.cat(comps(state), dim=1)), state, k + 1
+        step = _checkpointed(ns, comps) if checkpoint_iterations else (lambda s_: ns(torch.cat(comps(s_), dim=1)))
+        state, state_old, k = step(state), state.detach(), k + 1
     mask = torch.from_numpy(np.asarray(mask, dtype=bool))
     sc = torch.cat([state, X], dim=1) if d > 0 else state
     if focus == 'a':
@@ -186,7 +222,8 @@ def train_step(nodes, arcs, adjacency, arcnode, nodegraph, mask, *, net_state, n
     return dict(k=k, loss=float(L.detach()), y_pred=npy(out), state=npy(state), grads_state=[npy(g) for g in gs],
                 grads_output=[npy(g) for g in go],
                 moving_state=(npy(ns.moving_mean), npy(ns.moving_var)) if ns.bn else None,
-                moving_output=(npy(no.moving_mean), npy(no.moving_var)) if no.bn else None)
+                moving_output=(npy(no.moving_mean), npy(no.moving_var)) if no.bn else None,
+                kinks_state=ns.kinks, kinks_output=no.kinks)
 
 
 def adam_update(p, g, m, v, step, lr=0.001, b1=0.9, b2=0.999, eps=1e-7):

@@ -35,5 +35,7 @@ def pytest_collection_finish(session):
         if not torch.cuda.is_available(): return
         mod = sys.modules.get('test_gpu_round4')
         if mod is not None: mod.start_deep_oracles(names)
+        mod5 = sys.modules.get('test_gpu_round5')          # (the million-node train-step oracle: tests/test_gpu_round5.py)
+        if mod5 is not None: mod5.start_train_oracle([it.name for it in session.items])
     except Exception:
         pass                                                   # (never fail a collection over a head start)

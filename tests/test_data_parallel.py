@@ -73,13 +73,14 @@ class NumpyPrim:
     def _put(out, arr):
         out.copy_(torch.from_numpy(np.ascontiguousarray(arr)).to(torch.float32))
 
-    def dense(self, segs, W, H, bias, act, Y, wrows=None, out_rowidx=None):
+    def dense(self, segs, W, H, bias, act, Y, wrows=None, out_rowidx=None, center=None):
         Wn = W.detach().numpy().astype(np.float64)
+        cen = None if center is None else center.detach().numpy().astype(np.float64)
         z, off = 0.0, 0
         for i, (x, ridx) in enumerate(segs):
             w = x.shape[1]
             r0 = off if wrows is None else wrows[i]
-            z = z + self._rows(x, ridx) @ Wn[r0:r0 + w, :H]
+            z = z + (self._rows(x, ridx) - (0.0 if cen is None else cen[r0:r0 + w])) @ Wn[r0:r0 + w, :H]
             off += w
         if bias is not None: z = z + bias.detach().numpy().astype(np.float64)[:H]
         y = _act(act, z)
@@ -97,20 +98,21 @@ class NumpyPrim:
         self._put(out[:, :F], res)
         return out
 
-    def fold(self, W, b, bn, mean, var, Wf, bf):
+    def fold(self, W, b, bn, mean, var, Wf, bf, centred=False):
         Wn, bn_ = W.numpy().astype(np.float64), b.numpy().astype(np.float64)
         if bn is None:
             self._put(Wf, Wn); self._put(bf, bn_); return
         a = bn[0].numpy().astype(np.float64) / np.sqrt(var.numpy().astype(np.float64) + BN_EPSILON)
-        c = bn[1].numpy().astype(np.float64) - mean.numpy().astype(np.float64) * a
+        c = bn[1].numpy().astype(np.float64) - (0.0 if centred else mean.numpy().astype(np.float64) * a)
         self._put(Wf, a[:, None] * Wn); self._put(bf, bn_ + c @ Wn)
 
     def colstats(self, x, ridx, M, mean, var):
         r = self._rows(x, ridx, M)
         self._put(mean, r.mean(0)); self._put(var, r.var(0))
 
-    def dense_grad(self, x, ridx, dZ, M, P, q, accumulate):
+    def dense_grad(self, x, ridx, dZ, M, P, q, accumulate, center=None):
         X, D = self._rows(x, ridx, M), dZ.numpy().astype(np.float64)[:M]
+        if center is not None: X = X - center.detach().numpy().astype(np.float64)
         Pn, qn = X.T @ D, D.sum(0)
         self._put(P, Pn + (P.numpy() if accumulate else 0))
         if q is not None: self._put(q, qn + (q.numpy() if accumulate else 0))
@@ -119,18 +121,18 @@ class NumpyPrim:
         self._put(dZ, _act_grad(act, G.numpy().astype(np.float64), Y.numpy().astype(np.float64)))
         return dZ
 
-    def first_layer_param_grads(self, P, q, W, bn, mean, var, M, dW, db, dgamma, dbeta, m1, m2, accumulate):
+    def first_layer_param_grads(self, P, q, W, bn, mean, var, M, dW, db, dgamma, dbeta, m1, m2, accumulate, centered=False):
         Pn, qn, Wn = P.numpy().astype(np.float64), q.numpy().astype(np.float64), W.numpy().astype(np.float64)
         K = Wn.shape[0]
         a, c, rstd, mu = np.ones(K), np.zeros(K), np.ones(K), np.zeros(K)
         if bn is not None:
             rstd = 1 / np.sqrt(var.numpy().astype(np.float64) + BN_EPSILON); mu = mean.numpy().astype(np.float64)
-            a = bn[0].numpy().astype(np.float64) * rstd; c = bn[1].numpy().astype(np.float64) - mu * a
+            a = bn[0].numpy().astype(np.float64) * rstd; c = bn[1].numpy().astype(np.float64) - (0.0 if centered else mu * a)
         add = lambda t, v: self._put(t, v + (t.numpy() if accumulate else 0))
         add(dW, a[:, None] * Pn + c[:, None] * qn[None, :]); add(db, qn)
         if bn is not None:
             S1, S2 = Wn @ qn, (Wn * Pn).sum(1)
-            dg = rstd * (S2 - mu * S1)
+            dg = rstd * (S2 - (0.0 if centered else mu * S1))
             add(dgamma, dg); add(dbeta, S1)
             self._put(m1, S1 / M); self._put(m2, dg / M)
 

@@ -266,7 +266,7 @@ def _worker(rank, world, port, threshold, d, out_q, halo=False, overlap=False, t
             assert len(set(names)) == 1                              # every rank picked the same transport
         elif transport:
             sl.transport = transport
-        if chunks == 'tuned':                   # the measured choice of the chunk count (collective), as make_sharded_loop('auto') arms it
+        if chunks == 'tuned':                   # the measured choice of the chunk count (collective), as make_sharded_loop(pipeline='auto') arms it
             sl._tune_pipeline_pending = True
         elif chunks > 1:
             assert sl.pipeline_supported() and sl.set_pipeline(chunks) == chunks and sl.transport == 'direct'

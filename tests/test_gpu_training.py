@@ -1,6 +1,8 @@
 """train_step / fit on the device vs the torch-autograd restatement of the reference's train_step
-(oracle/torch_train.py, float64). Gradients are checked per trainable variable with max|a-b| / max|b| <= 2e-4
-(float32 accumulation over N rows and k iterations; the forward itself is held to 1e-5)."""
+(oracle/torch_train.py, float64).  Gradients are checked per trainable variable against PER-TENSOR bars (`BARS`: BatchNormalization
+gamma / beta, Dense kernel / bias - max|a-b| relative to the tensor's own largest entry, or to the largest gradient entry of the step
+for tensors that are tiny themselves), widened to `KINK_BAR` only for the output units the float64 oracle saw within 1e-6 of an
+activation kink (relu / selu: act' jumps there, and a float32 pre-activation may sit on the other side - `grad_rows`)."""
 import numpy as np
 import pytest
 import torch
@@ -15,7 +17,58 @@ from oracle.harness import rel_err, _np, _triple
 
 pytestmark = pytest.mark.gpu
 CLS = {'n': GNNnodeBased, 'a': GNNarcBased, 'g': GNNgraphBased}
-GTOL = 2e-4
+GTOL = 2e-4                    # legacy bar (round 2 .. 4: one number for every tensor); still what LGNN's multi-network sums are held to
+# Per-tensor bars of train_step's gradients (round 5; what the kernels meet with margin - profiles/r05_train_tensor_errors.txt):
+BARS = {'gamma': 2e-4, 'beta': 2e-4, 'kernel': 2e-4, 'bias': 2e-4}
+KINK_UNIT = 16.0               # what ONE pre-activation on the other side of a relu / selu kink may move its unit's gradient entries, in units of
+                               # (largest gradient entry of the network) / (rows of the network call): measured 11 (profiles/r04_notes.txt 7: one
+                               # element, 40 000 rows, 2.4e-5 absolute against a largest entry of 0.085)
+Y_PRED_BAR = 5e-5              # training-mode predictions (batch statistics of thin columns amplify rounding; inference: 1e-5 in test_gpu_parity.py)
+
+
+def tensor_kinds(bn, n_layers):
+    return (['gamma', 'beta'] if bn else []) + [k for l in range(n_layers) for k in (f'kernel{l}', f'bias{l}')]
+
+
+def grad_rows(net_name, got, ref, bn, kinks, scale, M):
+    """One row per trainable tensor: its error relative to its own largest entry and to the network's largest gradient entry (`scale`),
+    the bar that applies and whether it holds.  An entry passes when |got - ref| <= bar x max(own largest, scale) + kink allowance.
+    `kinks`: per Dense layer, per output unit, the float64 oracle's count of pre-activations within 1e-6 of a relu / selu kink (None: no
+    allowance).  A float32 implementation may put such an element on the other side of zero, where act' differs by the jump: that is one
+    row's contribution with the wrong factor - not an arithmetic error of the kernels - and moves the unit's kernel column and bias
+    entry (and, through W, gamma / beta and everything below) by at most ~ |G| |x| ~ KINK_UNIT x scale / M per element.  The allowance is
+    counted, per unit, from the oracle; it is zero wherever the oracle saw no such element."""
+    rows = []
+    kinds = tensor_kinds(bn, (len(ref) - (2 if bn else 0)) // 2)
+    total_kinks = 0 if kinks is None else int(sum(int(np.sum(kq)) for kq in kinks))
+    for kind, g, r in zip(kinds, got, ref):
+        g = g.detach().cpu().numpy() if hasattr(g, 'detach') else np.asarray(g)
+        diff = np.abs(g - r)
+        own = max(float(np.max(np.abs(r))), 1e-30)
+        base = kind.rstrip('0123456789')
+        bar = BARS[base]
+        n_unit = np.zeros(diff.shape)
+        if kinks is not None and base in ('kernel', 'bias'):
+            layer = int(kind[len(base):])
+            above = sum(int(np.sum(kinks[l2])) for l2 in range(layer + 1, len(kinks)))     # (a kink further up reaches every entry below)
+            kq = np.asarray(kinks[layer], dtype=np.float64) + above
+            n_unit = np.broadcast_to(kq, diff.shape) if base == 'kernel' else kq
+        elif kinks is not None:
+            n_unit = np.full(diff.shape, float(total_kinks))
+        lim = bar * max(own, scale) + KINK_UNIT * n_unit * scale / max(M, 1)
+        ok = bool(np.all(diff <= lim))
+        clean = diff[n_unit == 0] if np.any(n_unit == 0) else np.zeros(1)
+        rows.append(dict(net=net_name, tensor=kind, err_own=float(np.max(diff)) / own, err_scale=float(np.max(diff)) / max(scale, 1e-30),
+                         err_scale_off_kinks=float(np.max(clean)) / max(scale, 1e-30), kink_elements=int(np.max(n_unit)), bar=bar, ok=ok))
+    return rows
+
+
+def log_rows(tag, rows, **extra):
+    """Append the per-tensor errors to $GNN_TEST_ERRLOG (one JSON line per comparison) - how BARS were chosen and are re-checked."""
+    import json, os
+    path = os.environ.get('GNN_TEST_ERRLOG')
+    if path:
+        with open(path, 'a') as f: f.write(json.dumps(dict(tag=tag, rows=rows, **extra)) + '\n')
 
 
 def nets(focus, d, bn, hidden_state=None, hidden_out=None, act='selu', out_act='softmax', scale=0.5):
@@ -46,14 +99,15 @@ def refocus(graphs, focus, rng):
     return out
 
 
-def oracle_step(model, x, y, sw, s0, loss, avg=False, dtype=torch.float64, seed=None):
+def oracle_step(model, x, y, sw, s0, loss, avg=False, dtype=torch.float64, seed=None, checkpoint_iterations=False):
     nodes, arcs, _, sm, om, adj, an, ng = x
     mask = np.logical_and(_np(sm).reshape(-1), _np(om).reshape(-1))
     return torch_train.train_step(_np(nodes), _np(arcs), _triple(adj), _triple(an), _triple(ng), mask,
                                   net_state=model.net_state.spec(), net_output=model.net_output.spec(),
                                   state_vect_dim=model.state_vect_dim, max_iteration=model.max_iteration,
                                   state_threshold=model.state_threshold, focus=model._focus, state0=s0, y=_np(y),
-                                  sample_weight=_np(sw), loss=loss, average_st_grads=avg, dtype=dtype, seed=seed)
+                                  sample_weight=_np(sw), loss=loss, average_st_grads=avg, dtype=dtype, seed=seed,
+                                  checkpoint_iterations=checkpoint_iterations)
 
 
 def check_step(model, x, y, sw, s0, loss='categorical_crossentropy', avg=False, native=None, seed=None):
@@ -72,15 +126,19 @@ def check_step(model, x, y, sw, s0, loss='categorical_crossentropy', avg=False, 
     res = tr.train_step(x, y, sw, state0=None if s0 is None else torch.from_numpy(s0).cuda(), apply=False, seed=seed)
     assert res['k'] == want['k']
     assert abs(float(res['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))
-    # training mode: BatchNormalization on the statistics of a small batch multiplies rounding by 1/sigma of thin columns;
-    # the inference bar (1e-5) is checked in test_gpu_parity.py, here 5e-5 (1.5e-5 seen once in 576 random configurations)
-    assert rel_err(res['y_pred'].cpu().numpy(), want['y_pred']) <= 5e-5
-    for name, got, ref in [('state', tr.gs.gradients(), want['grads_state']), ('output', tr.go.gradients(), want['grads_output'])]:
+    # training mode: BatchNormalization on the statistics of a small batch multiplies rounding by 1/sigma of thin columns
+    e_pred = rel_err(res['y_pred'].cpu().numpy(), want['y_pred'])
+    rows = []
+    for name, ng_, got, ref, kinks in [('state', tr.gs, tr.gs.gradients(), want['grads_state'], want.get('kinks_state')),
+                                       ('output', tr.go, tr.go.gradients(), want['grads_output'], want.get('kinks_output'))]:
         assert len(got) == len(ref)
-        for i, (g, r) in enumerate(zip(got, ref)):
-            e = float(np.max(np.abs(g.cpu().numpy() - r)) / max(float(np.max(np.abs(r))), 1e-12))
-            scale = max(float(np.max(np.abs(x_))) for x_ in ref)
-            assert e <= GTOL or float(np.max(np.abs(g.cpu().numpy() - r))) <= GTOL * scale, (name, i, e)
+        scale = max(float(np.max(np.abs(x_))) for x_ in ref)
+        rows += grad_rows(name, got, ref, ng_.bn, kinks, scale, int(x[0].shape[0]) if name == 'state' else int(want['y_pred'].shape[0]))
+    import os
+    log_rows(os.environ.get('PYTEST_CURRENT_TEST', ''), rows, native=bool(native), y_pred=e_pred, n_nodes=int(x[0].shape[0]), k=int(res['k']))
+    assert e_pred <= Y_PRED_BAR, e_pred
+    bad = [r_ for r_ in rows if not r_['ok']]
+    assert not bad, bad
     # moving statistics: k updates for the state network, one for the output network
     for net, key in [(model.net_state, 'moving_state'), (model.net_output, 'moving_output')]:
         if net.batch_normalization:

@@ -233,3 +233,41 @@ def test_composite_equals_homogeneous_when_one_type():
     kc, sc, oc = O.composite_loop(nodes, arcs, [L], np.ones((1, n), bool), np.ones(n, bool), np.ones(n, bool), [adj],
                                   adj, an, ng, net_state=[ns_c], net_output=no_c, **kw)
     assert kh == kc and np.allclose(sh, sc) and np.allclose(oh, oc)
+
+
+def test_train_step_oracle_with_checkpointed_iterations_is_the_same_oracle():
+    """oracle/torch_train.py `checkpoint_iterations=True` (what lets the float64 autograd oracle of a million-node train step fit a host:
+    tests/test_gpu_round5.py) recomputes each iteration in the backward pass instead of keeping its intermediates - the same float64
+    operations in the same order: loss, every gradient, the moving statistics (one update per call, not two) and the kink counts are
+    bit-identical to the plain run; and the kink counter sees a pre-activation planted at a relu kink."""
+    from gnnkeras_amd.synth import er_graph
+    from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+    from oracle import torch_train
+    N, d = 1500, 8
+    g = er_graph(N, 6 * N, seed=3, aggregation_mode='average')
+    rng = np.random.default_rng(0)
+    inp, lay = get_inout_dims('state', 14, 3, 2, 'n', d)
+    ns = MLP(inp[0], lay, 'relu', 'lecun_normal', 'lecun_normal', rng=0, batch_normalization=True, device='cpu')
+    inp, lay = get_inout_dims('output', 14, 3, 2, 'n', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1, batch_normalization=True, device='cpu')
+    trip = lambda m: (np.stack([m.tocoo().row, m.tocoo().col], 1), m.tocoo().data, m.shape)
+    s0 = np.abs(rng.normal(0, 0.1, (N, d))).astype(np.float32)
+    kw = dict(net_state=ns.spec(), net_output=no.spec(), state_vect_dim=d, max_iteration=4, state_threshold=0.0, focus='n', state0=s0,
+              y=g.targets, sample_weight=None, loss='categorical_crossentropy')
+    args = (g.nodes, g.arcs, trip(g.Adjacency), trip(g.ArcNode), None, np.ones(N, bool))
+    a = torch_train.train_step(*args, **kw)
+    b = torch_train.train_step(*args, checkpoint_iterations=True, **kw)
+    assert a['k'] == b['k'] == 4 and a['loss'] == b['loss']
+    for x_, y_ in zip(a['grads_state'] + a['grads_output'] + list(a['moving_state']) + list(a['moving_output']),
+                      b['grads_state'] + b['grads_output'] + list(b['moving_state']) + list(b['moving_output'])):
+        assert np.array_equal(x_, y_)
+    assert all(np.array_equal(p, q) for p, q in zip(a['kinks_state'], b['kinks_state']))
+    # a bias that puts unit 0's pre-activation of row 0 exactly on the kink in the first call: counted once
+    spec = ns.spec()
+    w = [np.array(t, dtype=np.float64) for t in spec[1]]
+    net = torch_train.Net(spec[0], w)
+    x0 = torch.tensor(rng.normal(0, 1, (5, w[-2].shape[0])), dtype=torch.float64)
+    z = ((x0 - x0.mean(0)) / torch.sqrt(((x0 - x0.mean(0)) ** 2).mean(0) + 1e-3) * net.gamma + net.beta) @ net.W[0] + net.b[0]
+    with torch.no_grad(): net.b[0][0] -= z[0, 0]
+    net(x0)
+    assert net.kinks[0][0] >= 1

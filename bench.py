@@ -541,6 +541,7 @@ def emulate_shard(args):
     sl = ShardedLoop(gnn, gs, r, R, device, overlap=not args.no_overlap)
     if args.pipeline_chunks > 1 and sl.set_pipeline(args.pipeline_chunks) != args.pipeline_chunks:
         raise SystemExit('--pipeline-chunks: this shard does not take chunk launches (composite model, no overlap split, hub rows)')
+    if args.native_loop: sl.enable_native_loop(emulated=True)
     torch.cuda.synchronize()
     t_plan = time.perf_counter() - t0
     gen = torch.Generator(device=device); gen.manual_seed(1)
@@ -552,7 +553,8 @@ def emulate_shard(args):
     print(json.dumps({
         'emulated_shard': f'{r}/{R}', 'workload': f'{args.workload.upper()} Erdos-Renyi {N} nodes / {E} arcs, state_dim={d}, {args.aggregation}',
         'n_local': sl.n_local, 'e_local': sl.e_local, 'e_own_range': getattr(sl, 'e_own', None), 'overlap_split': bool(sl.overlap),
-        'pipeline_chunks': sl.pipeline_chunks,
+        'pipeline_chunks': sl.pipeline_chunks, 'loop_driver': 'native (gnn_shard_loop)' if sl.native_loop else 'interpreter',
+        'host_issue_us_per_iteration': 1e6 * prof['host_issue_s'],
         'per_iteration_ms': {'kernel': 1e3 * prof['kernel_s'],
                              'note': 'own-range partial + halo kernel (or the one fused kernel with --no-overlap) of rank r, gates open, '
                                      'no collective: the exchange is not measurable on one GPU'},
@@ -585,6 +587,9 @@ def main():
                     help='N>1 state exchange: whole slices by RCCL all-gather / by concurrent point-to-point pairs, or compacted halos '
                          '(all-to-all); auto = halo for graphs with locality, else the faster whole-slice transport, measured at start-up')
     ap.add_argument('--no-overlap', action='store_true', help='N>1: exchange strictly after the iteration kernel (no own-range / halo split)')
+    ap.add_argument('--native-loop', action='store_true',
+                    help='N>1 / --emulate-shard: drive the iterations from the library (gnn_shard_loop: one C call, the exchange over the RCCL C API) '
+                         'instead of from the interpreter')
     ap.add_argument('--exchange-pipeline', default='off',
                     help="N>1: 'off' (default: one halo-kernel launch + one exchange per iteration, the validated path), 'auto' (1 / 2 / 4 chunk "
                          "launches timed at the first forward, a chunked count kept only when > 5 %% faster) or a chunk count")
@@ -687,6 +692,8 @@ def main():
         t_plan0 = time.perf_counter()
         sl = make_sharded_loop(gnn, graph, rank=rank, world_size=world, device=device, exchange=args.exchange,
                                overlap=not args.no_overlap, pipeline=args.exchange_pipeline)
+        if args.native_loop and hasattr(sl, 'enable_native_loop') and type(sl)._layout == 'allgather': sl.enable_native_loop(with_comm=True)
+        extra['loop_driver'] = 'native (gnn_shard_loop)' if getattr(sl, 'native_loop', False) else 'interpreter'
         torch.cuda.synchronize()
         extra['plan_build_s'] = (time.perf_counter() - t_plan0) + t_graph
         extra['host_rss_mb'] = host_rss_mb()
@@ -719,6 +726,7 @@ def main():
                                      'iteration_overlapped': 1e3 * float(tt[2]),
                                      'note': 'max over ranks; kernel = own-range + halo launches without the collective, exchange = '
                                              'the collective alone, iteration = what one iteration costs with both in flight'}
+        if 'host_issue_s' in prof: extra['host_issue_us_per_iteration'] = 1e6 * prof['host_issue_s']
         extra['exchange_bytes_per_rank_per_iteration'] = sl.exchange_bytes()
         extra['exchange_transport'] = getattr(sl, 'transport', 'all_to_all')
         if getattr(sl, 'transport_times', None): extra['exchange_transport_ms_measured'] = {k_: 1e3 * v for k_, v in sl.transport_times.items()}

@@ -33,7 +33,8 @@ EXPORTS = ['gnn_last_error', 'gnn_last_kernel_name', 'gnn_abi_version', 'gnn_str
            'gnn_dense', 'gnn_fold_bn', 'gnn_dense_grad_workspace_bytes', 'gnn_dense_grad', 'gnn_act_grad',
            'gnn_colstats_workspace_bytes', 'gnn_colstats', 'gnn_first_layer_param_grads', 'gnn_bn_input_grad',
            'gnn_scatter_add_rows', 'gnn_axpby', 'gnn_loss_grad', 'gnn_dropout', 'gnn_adam_step', 'gnn_adam_multi', 'gnn_sgd_step',
-           'gnn_converged_gated', 'gnn_aggregate_gated', 'gnn_train_workspace_bytes', 'gnn_train_step', 'gnn_ragged_copy']
+           'gnn_converged_gated', 'gnn_aggregate_gated', 'gnn_train_workspace_bytes', 'gnn_train_step', 'gnn_ragged_copy',
+           'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_destroy', 'gnn_shard_loop']
 GNN_MAX_SEGMENTS = 6
 LOSSES = {'categorical_crossentropy': 0, 'cce': 0, 'binary_crossentropy': 1, 'bce': 1, 'mse': 2,
           'mean_squared_error': 2, 'mae': 3, 'mean_absolute_error': 3}
@@ -106,6 +107,15 @@ class TrainArgs(C.Structure):
                 ('grad_state_types', MLPGrads * GNN_MAX_TYPES),          # ABI 6: one gradient holder per node type (composite models)
                 # ABI 7: the device word that says whether the step's gradients are valid (the optimizers' gate) and the previous step's, read for free
                 ('grads_ok_dev', C.POINTER(C.c_void_p)), ('prev_grads_ok_host', C.POINTER(C.c_int32))]
+
+
+class ShardLoopArgs(C.Structure):       # gnn_shard_loop_args_t (ABI 7): the sharded loop driven from native code (csrc/shard_loop.hpp)
+    _fields_ = [('loop', C.POINTER(LoopArgs)), ('adjacency_own', C.POINTER(CSR)), ('adjacency_halo', C.POINTER(CSR)),
+                ('agg_partial', C.c_void_p), ('buf', C.c_void_p * 2),
+                ('row_base', C.c_int32), ('rows_per_slice', C.c_int32), ('chunk', C.c_int32),
+                ('world_size', C.c_int32), ('rank', C.c_int32), ('SP', C.c_int32),
+                ('first_iteration', C.c_int32), ('n_iterations', C.c_int32), ('transport', C.c_int32), ('n_chunks', C.c_int32),
+                ('chunk_begin', C.POINTER(C.c_int32)), ('node_iota', C.c_void_p), ('emulated', C.c_int32), ('comm', C.c_void_p)]
 
 
 class RaggedDesc(C.Structure):
@@ -217,6 +227,10 @@ def lib():
             'gnn_train_workspace_bytes': (sz, [C.POINTER(TrainArgs)]),
             'gnn_train_step': (C.c_int, [C.POINTER(TrainArgs)]),
             'gnn_ragged_copy': (C.c_int, [vp, i32, vp, i32, vp]),
+            'gnn_comm_unique_id': (C.c_int, [vp]),
+            'gnn_comm_create': (C.c_int, [i32, i32, vp, C.POINTER(vp)]),
+            'gnn_comm_destroy': (C.c_int, [vp]),
+            'gnn_shard_loop': (C.c_int, [C.POINTER(ShardLoopArgs)]),
         }
         for name, (res, args) in protos.items():
             fn = getattr(l, name)
@@ -227,7 +241,8 @@ def lib():
             raise NativeError('libgnnloop.so ABI version mismatch: rebuild it')
         if (l.gnn_struct_size(0), l.gnn_struct_size(1), l.gnn_struct_size(2), l.gnn_struct_size(3)) != \
                 (C.sizeof(CSR), C.sizeof(MLP), C.sizeof(LoopArgs), LoopArgs.flags.offset) or \
-                (l.gnn_struct_size(4), l.gnn_struct_size(5), l.gnn_struct_size(6)) != (C.sizeof(TrainArgs), TrainArgs.tape.offset, C.sizeof(RaggedDesc)):
+                (l.gnn_struct_size(4), l.gnn_struct_size(5), l.gnn_struct_size(6), l.gnn_struct_size(7)) != \
+                (C.sizeof(TrainArgs), TrainArgs.tape.offset, C.sizeof(RaggedDesc), C.sizeof(ShardLoopArgs)):
             raise NativeError('ctypes struct layout does not match libgnnloop.so: rebuild it')
         _lib = l
     return _lib

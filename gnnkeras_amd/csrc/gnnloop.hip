@@ -1257,6 +1257,7 @@ size_t gnn_struct_size(int which) {
         case 4: return sizeof(gnn_train_args_t);
         case 5: return offsetof(gnn_train_args_t, tape);
         case 6: return sizeof(gnn_ragged_desc_t);
+        case 7: return sizeof(gnn_shard_loop_args_t);
         default: return 0;
     }
 }
@@ -1689,6 +1690,7 @@ int gnn_shard_output(const gnn_loop_args_t *args, const float *buf0_full, const 
 
 }  // extern "C"
 
+#include "shard_loop.hpp"
 #include "train_api.hpp"
 #include "train_loop.hpp"
 #include "train_composite.hpp"

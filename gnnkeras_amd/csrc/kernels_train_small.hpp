@@ -89,11 +89,12 @@ __device__ __forceinline__ bool grid_barrier(GridBar &gb, int any, int *cont_lds
 struct ConstSegs { const float *ptr[3]; int ld[3], width[3], wrow[3]; int n; };
 __global__ void __launch_bounds__(256)
 k_train_small_const(int N, int S, int Sw, ConstSegs cs, const float *__restrict__ W, const float *__restrict__ b, const float *gamma, const float *beta,
-                    const float *mean, const float *var, float eps, float *__restrict__ Cc) {
-    // S = the kernels' padded state width (16 / 32 / 64), Sw <= S the network's: W is [in_dim][Sw]; pad columns of Cc are zero
+                    const float *mean, const float *var, float eps, float *__restrict__ Cc, const int *__restrict__ rows = nullptr) {
+    // S = the kernels' padded state width (16 / 32 / 64), Sw <= S the network's: W is [in_dim][Sw]; pad columns of Cc are zero.
+    // `rows` (heterogeneous models: the node ids of one type, N of them): row m of Cc belongs to node rows[m] of the constant segments
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * S) return;
-    const int n = i / S, h = i % S;
+    const int h = i % S, n = rows ? rows[i / S] : i / S;
     if (h >= Sw) { Cc[i] = 0.0f; return; }
     float acc = b[h];
 #pragma unroll
@@ -110,7 +111,26 @@ k_train_small_const(int N, int S, int Sw, ConstSegs cs, const float *__restrict_
 }
 
 // ---- tiles ------------------------------------------------------------------------------------------------------------------------------
-struct TileTab { int n; int begin[257]; };      // n == 0: the general form; else tile b = nodes [begin[b], begin[b + 1]), <= 64 of them, no arc leaves a tile
+struct TileTab { int n; int begin[257]; };      // n == 0: tile b = nodes [64 b, 64 b + 64); else tile b = nodes [begin[b], begin[b + 1]), <= 64 of them
+                                                // (LOCAL kernels: cut at graph boundaries, no arc leaves a tile; heterogeneous models: cut at TYPE boundaries)
+
+// ---- heterogeneous models (reference CompositeGNN.py:223-232: one state network per node type, applied to the rows of its type) -----------
+// The persistent kernels walk the nodes in TYPE ORDER (position i = node perm[i] of the caller's graph; the caller's type lists ARE that
+// permutation) in tiles that never straddle two types: a workgroup then needs ONE network - its weights, its BatchNormalization
+// parameters and statistics (taken over the tiles of ITS type only), its share of ITS gradients - and the inner loops are those of the
+// homogeneous kernels.  What crosses types is what crosses tiles anyway: neighbour rows (through memory, behind the grid barrier) and
+// the loop condition.  n == 0: a homogeneous model (the scalar fields of the kernel arguments apply).
+struct TypeTab {
+    int n;
+    int wg_begin[GNN_MAX_TYPES + 1];             // the tiles (= workgroups) of type t: [wg_begin[t], wg_begin[t + 1])
+    int count[GNN_MAX_TYPES];                    // nodes of the type
+    const float *W[GNN_MAX_TYPES], *gamma[GNN_MAX_TYPES], *beta[GNN_MAX_TYPES];
+    float *stats[GNN_MAX_TYPES];                 // [K][2 in_s[t]]
+    int in_s[GNN_MAX_TYPES], off_state[GNN_MAX_TYPES], off_agg[GNN_MAX_TYPES], act[GNN_MAX_TYPES];
+    float *partW[GNN_MAX_TYPES], *partBN[GNN_MAX_TYPES];     // backward: the type's [tiles][in_s S + S] / [tiles][2 in_s] shares
+    const int *perm, *inv;
+};
+struct TypeConsts { ConstSegs cs[GNN_MAX_TYPES]; };          // backward: the constant input segments of every type's network
 
 // The CSR rows of the tile's nodes as the gather walks them: thread (q, l4) = lane l4 of the LPR lanes that fetch 16-byte pieces of
 // row q of a pass; the first 16 source ids / weights of every row stay in registers for all iterations.
@@ -119,24 +139,27 @@ struct TileCsr {
     static constexpr int S = 16 * SQ, LPR = S / 4, NPP = TS_NT / LPR, NPASS = 64 / NPP, IPL = 16 / LPR, PP = NPASS < 2 ? NPASS : 2;
     int node[NPASS], beg[NPASS], end[NPASS], ids[NPASS][IPL];
     float wts[NPASS][IPL], scl[NPASS];
-    const int *src; const float *w;
+    const int *src; const float *w; const int *inv;
     int n0, nt, q, l4, bad;
 
+    // `node` = the row's POSITION in the tape (what the kernels address); heterogeneous models walk the nodes in type order: `perm[position]`
+    // = the node's id in the caller's operators (row pointers, scales), `inv[id]` = its position (source ids)
     __device__ __forceinline__ int local_id(int s) {        // LOCAL: position inside the tile; an arc that leaves the tile is an error
-        if (!LOCAL) return s;
+        if (!LOCAL) return inv ? inv[s] : s;
         const int r = s - n0;
         if (r < 0 || r >= nt) { bad = 1; return 0; }
         return r;
     }
-    __device__ __forceinline__ void load(int n0_, int nt_, const int *rowptr, const int *src_, const float *w_, const float *row_scale) {
-        n0 = n0_; nt = nt_; src = src_; w = w_; bad = 0;
+    __device__ __forceinline__ void load(int n0_, int nt_, const int *rowptr, const int *src_, const float *w_, const float *row_scale,
+                                         const int *perm = nullptr, const int *inv_ = nullptr) {
+        n0 = n0_; nt = nt_; src = src_; w = w_; bad = 0; inv = inv_;
         q = threadIdx.x / LPR; l4 = threadIdx.x % LPR;
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             const int r = p * NPP + q;
             node[p] = r < nt ? n0 + r : -1;
             beg[p] = end[p] = 0; scl[p] = 1.0f;
-            if (node[p] >= 0) { beg[p] = rowptr[node[p]]; end[p] = rowptr[node[p] + 1]; if (row_scale) scl[p] = row_scale[node[p]]; }
+            if (node[p] >= 0) { const int o = perm ? perm[node[p]] : node[p]; beg[p] = rowptr[o]; end[p] = rowptr[o + 1]; if (row_scale) scl[p] = row_scale[o]; }
 #pragma unroll
             for (int u = 0; u < IPL; ++u) {
                 const int e = beg[p] + u * LPR + l4;
@@ -208,10 +231,10 @@ struct TileCsr {
 };
 
 // partial slots of the other workgroups: `n` floats per workgroup, summed in workgroup order with 16 loads in flight (double accumulator)
-__device__ __forceinline__ double sum_partials(const float *part, unsigned n_wg, int n, int i) {
+__device__ __forceinline__ double sum_partials(const float *part, unsigned wg_lo, unsigned n_wg, int n, int i) {      // the workgroups [wg_lo, n_wg)
     const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(part);
     double t = 0.0;
-    for (unsigned wg = 0; wg < n_wg; wg += 16) {
+    for (unsigned wg = wg_lo; wg < n_wg; wg += 16) {
         float v[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u)          // (absent slots read 0)
@@ -228,10 +251,11 @@ __device__ __forceinline__ double sum_partials(const float *part, unsigned n_wg,
 // | pv), `w` columns each.  The shares are moved to the origin and added in DOUBLE - sum x = s1 + n pv, sum x^2 = s2 + 2 pv s1 + n pv^2 (every
 // product exact) - where E[x^2] - mean^2 loses (mean / sigma)^2 of 2^-53, not of 2^-24.  `n_of(j)` = rows of tile j.
 template <typename NOf>
-__device__ __forceinline__ void merge_tile_stats(const float *part, unsigned n_wg, int w, int col, NOf n_of, double inv_n, float &mean_out, float &var_out) {
+__device__ __forceinline__ void merge_tile_stats(const float *part, unsigned wg_lo, unsigned n_wg, int w, int col, NOf n_of, double inv_n, float &mean_out,
+                                                 float &var_out) {      // the tiles [wg_lo, n_wg)
     const __amdgpu_buffer_rsrc_t r_p = buf_rsrc(part);
     double S1 = 0.0, S2 = 0.0;
-    for (unsigned wg = 0; wg < n_wg; wg += 8) {
+    for (unsigned wg = wg_lo; wg < n_wg; wg += 8) {
         float s1[8], s2[8], pv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {          // (absent slots read 0)
@@ -275,7 +299,7 @@ struct TrainSmallFwd {
 };
 
 template <int SQ, bool HAS_W, bool LOCAL>
-__global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, TileTab tt) {
+__global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, TileTab tt, TypeTab yt) {
     using Csr = TileCsr<SQ, HAS_W, LOCAL>;
     constexpr int S = 16 * SQ, NPP = Csr::NPP, NPASS = Csr::NPASS;
     constexpr int LDX = 2 * S + 4;        // row stride of the [own | agg] tile: == 4 (mod 32) dwords, 16-B chunks conflict-free
@@ -289,20 +313,30 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int n0 = LOCAL ? tt.begin[blockIdx.x] : (int)blockIdx.x * 64;
-    const int nt = LOCAL ? tt.begin[blockIdx.x + 1] - n0 : min(64, a.N - n0);
-    const bool bn = a.gamma != nullptr;
+    const bool tab = LOCAL || tt.n > 0;
+    const int n0 = tab ? tt.begin[blockIdx.x] : (int)blockIdx.x * 64;
+    const int nt = tab ? tt.begin[blockIdx.x + 1] - n0 : min(64, a.N - n0);
+    // heterogeneous models: this tile's node type selects the network (TypeTab); the statistics span the tiles [wg_lo, wg_hi) of the type
+    int ty = 0;
+    if (yt.n > 0) { while (ty + 1 < yt.n && (int)blockIdx.x >= yt.wg_begin[ty + 1]) ++ty; }
+    const float *Wk = yt.n > 0 ? yt.W[ty] : a.W, *gamma_ = yt.n > 0 ? yt.gamma[ty] : a.gamma, *beta_ = yt.n > 0 ? yt.beta[ty] : a.beta;
+    float *stats_ = yt.n > 0 ? yt.stats[ty] : a.stats;
+    const int in_s = yt.n > 0 ? yt.in_s[ty] : a.in_s, off_state = yt.n > 0 ? yt.off_state[ty] : 0, off_agg = yt.n > 0 ? yt.off_agg[ty] : a.off_agg;
+    const int act = yt.n > 0 ? yt.act[ty] : a.act;
+    const unsigned wg_lo = yt.n > 0 ? (unsigned)yt.wg_begin[ty] : 0u, wg_hi = yt.n > 0 ? (unsigned)yt.wg_begin[ty + 1] : gridDim.x;
+    const double inv_rows = 1.0 / (double)(yt.n > 0 ? yt.count[ty] : a.N);
+    const bool bn = gamma_ != nullptr;
     const size_t NS = (size_t)a.N * S;
     GridBar gb{a.bar, gridDim.x, 0, 0u, 0u, 0, a.wait_ticks};
 
     for (int i = tid; i < 2 * S * S; i += TS_NT) {
         const int k = i / S, h = i % S;
         const int kk = k < S ? k : k - S;
-        W0[k * LDW + h] = (kk < a.Sw && h < a.Sw) ? a.W[(size_t)((k < S ? 0 : a.off_agg) + kk) * a.Sw + h] : 0.0f;
+        W0[k * LDW + h] = (kk < a.Sw && h < a.Sw) ? Wk[(size_t)((k < S ? off_state : off_agg) + kk) * a.Sw + h] : 0.0f;
     }
     if (tid < 2 * S) { piv[tid] = 0.0f; st_a[tid] = 1.0f; st_c[tid] = 0.0f; }
     Csr csr;
-    csr.load(n0, nt, a.rowptr, a.src, a.w, a.row_scale);
+    csr.load(n0, nt, a.rowptr, a.src, a.w, a.row_scale, yt.perm, yt.inv);
     const int q = csr.q, l4 = csr.l4;
     // the constant part of this lane's output chunks (row 16 wave + c, columns 16 ct + 4 g ..)
     const bool oin = 16 * wave + c < nt;
@@ -397,12 +431,12 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
                 const int kk = tid < S ? tid : tid - S;
                 float ak = 0.0f, ck = 0.0f, mu = 0.0f;             // (pad columns: zero in, zero out)
                 if (kk < a.Sw) {
-                    const int k = (tid < S ? 0 : a.off_agg) + kk;                     // BatchNorm column of this input column
+                    const int k = (tid < S ? off_state : off_agg) + kk;               // BatchNorm column of this input column
                     float va;
-                    merge_tile_stats(a.part + (size_t)(it & 1) * gridDim.x * 6 * S, gridDim.x, 2 * S, tid,
-                                     [&](int j) { return LOCAL ? tt.begin[j + 1] - tt.begin[j] : min(64, a.N - 64 * j); }, 1.0 / (double)a.N, mu, va);
-                    ak = a.gamma[k] / sqrtf(va + a.eps); ck = a.beta[k];
-                    if (blockIdx.x == 0) { a.stats[(size_t)it * 2 * a.in_s + k] = mu; a.stats[(size_t)it * 2 * a.in_s + a.in_s + k] = va; }
+                    merge_tile_stats(a.part + (size_t)(it & 1) * gridDim.x * 6 * S, wg_lo, wg_hi, 2 * S, tid,
+                                     [&](int j) { return tab ? tt.begin[j + 1] - tt.begin[j] : min(64, a.N - 64 * j); }, inv_rows, mu, va);
+                    ak = gamma_[k] / sqrtf(va + a.eps); ck = beta_[k];
+                    if (blockIdx.x == wg_lo) { stats_[(size_t)it * 2 * in_s + k] = mu; stats_[(size_t)it * 2 * in_s + in_s + k] = va; }
                 }
                 st_a[tid] = ak; st_c[tid] = ck; piv[tid] = mu;
             }
@@ -438,7 +472,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_fwd(TrainSmallFwd a, T
 #pragma unroll
         for (int ct = 0; ct < SQ; ++ct) {
             f32x4 v = acc[ct];
-            activate4(a.act, v);
+            activate4(act, v);
             const f32x4 o = *reinterpret_cast<const f32x4 *>(orow_lds + 16 * ct);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = (oin && 16 * ct + 4 * g + e < a.Sw) ? v[e] : 0.0f; const float d = v[e] - o[e]; d2 = fmaf(d, d, d2); n2 = fmaf(o[e], o[e], n2); }
@@ -500,7 +534,7 @@ struct TrainSmallBwd {
 };
 
 template <int SQ, bool HAS_W, bool LOCAL>
-__global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, TileTab tt) {
+__global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, TileTab tt, TypeTab yt, TypeConsts yc) {
     using Csr = TileCsr<SQ, HAS_W, LOCAL>;
     constexpr int S = 16 * SQ, LPR = S / 4, NPP = Csr::NPP, NPASS = Csr::NPASS;
     constexpr int LDX = 2 * S + 4;        // == 4 (mod 32)
@@ -522,32 +556,45 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int n0 = LOCAL ? tt.begin[blockIdx.x] : (int)blockIdx.x * 64;
-    const int nt = LOCAL ? tt.begin[blockIdx.x + 1] - n0 : min(64, a.N - n0);
-    const bool bn = a.gamma != nullptr;
+    const bool tab = LOCAL || tt.n > 0;
+    const int n0 = tab ? tt.begin[blockIdx.x] : (int)blockIdx.x * 64;
+    const int nt = tab ? tt.begin[blockIdx.x + 1] - n0 : min(64, a.N - n0);
+    // heterogeneous models: this tile's node type selects the network and where its shares go (TypeTab); sums over "all rows" of a
+    // BatchNormalization span the tiles [wg_lo, wg_hi) of the type
+    int ty = 0;
+    if (yt.n > 0) { while (ty + 1 < yt.n && (int)blockIdx.x >= yt.wg_begin[ty + 1]) ++ty; }
+    const float *Wk = yt.n > 0 ? yt.W[ty] : a.W, *gamma_ = yt.n > 0 ? yt.gamma[ty] : a.gamma, *beta_ = yt.n > 0 ? yt.beta[ty] : a.beta;
+    const float *stats_ = yt.n > 0 ? yt.stats[ty] : a.stats;
+    const int in_s = yt.n > 0 ? yt.in_s[ty] : a.in_s, off_state = yt.n > 0 ? yt.off_state[ty] : 0, off_agg = yt.n > 0 ? yt.off_agg[ty] : a.off_agg;
+    const int act = yt.n > 0 ? yt.act[ty] : a.act;
+    const unsigned wg_lo = yt.n > 0 ? (unsigned)yt.wg_begin[ty] : 0u, wg_hi = yt.n > 0 ? (unsigned)yt.wg_begin[ty + 1] : gridDim.x;
+    const float inv_n = yt.n > 0 ? 1.0f / (float)yt.count[ty] : a.inv_n;
+    const ConstSegs &cs = yt.n > 0 ? yc.cs[ty] : a.cs;
+    const int *perm = yt.perm;
+    const bool bn = gamma_ != nullptr;
     const size_t NS = (size_t)a.N * S;
     GridBar gb{a.bar, gridDim.x, 0, 0u, 0u, 0, a.wait_ticks};
-    auto wrow_dyn = [&](int j) { return j < S ? j : a.off_agg + (j - S); };      // weight row / BatchNorm column of tile column j (valid j only)
+    auto wrow_dyn = [&](int j) { return j < S ? off_state + j : off_agg + (j - S); };      // weight row / BatchNorm column of tile column j (valid j only)
     auto valid_dyn = [&](int j) { return (j < S ? j : j - S) < a.Sw; };           // pad columns of the padded state width carry zeros
 
     for (int i = tid; i < 2 * S * S; i += TS_NT) {
         const int j = i / S, h = i % S;
-        Wr[j * LDW + h] = (valid_dyn(j) && h < a.Sw) ? a.W[(size_t)wrow_dyn(j) * a.Sw + h] : 0.0f;
+        Wr[j * LDW + h] = (valid_dyn(j) && h < a.Sw) ? Wk[(size_t)wrow_dyn(j) * a.Sw + h] : 0.0f;
     }
-    for (int i = tid; i < 64 * S; i += TS_NT) {
+    for (int i = tid; i < 64 * S; i += TS_NT) {          // (G0 is in the caller's node order)
         const int rr = i / S, h = i % S;
-        Gs[rr * LDZ + h] = (rr < nt && h < a.Sw) ? a.G0[(size_t)(n0 + rr) * a.Sw + h] : 0.0f;
+        Gs[rr * LDZ + h] = (rr < nt && h < a.Sw) ? a.G0[(size_t)(perm ? perm[n0 + rr] : n0 + rr) * a.Sw + h] : 0.0f;
     }
     // xhat = (x - sh) rs of iteration t (rs = rstd, sh = mean; 1 / 0 without BatchNormalization): centred first, then scaled
     auto coefficients = [&](int t) {
         if (tid < 2 * S) {
             float r_ = 1.0f, s_ = 0.0f;
-            if (bn && valid_dyn(tid)) { const float *st = a.stats + (size_t)t * 2 * a.in_s; const int k = wrow_dyn(tid); r_ = 1.0f / sqrtf(st[a.in_s + k] + a.eps); s_ = st[k]; }
+            if (bn && valid_dyn(tid)) { const float *st = stats_ + (size_t)t * 2 * in_s; const int k = wrow_dyn(tid); r_ = 1.0f / sqrtf(st[in_s + k] + a.eps); s_ = st[k]; }
             rs_s[tid] = r_; sh_s[tid] = s_;
         }
     };
     Csr csr;
-    csr.load(n0, nt, a.rowptr_s, a.src_s, a.w_s, a.row_scale_s);
+    csr.load(n0, nt, a.rowptr_s, a.src_s, a.w_s, a.row_scale_s, yt.perm, yt.inv);
     const int q = csr.q, l4 = csr.l4;
     f32x4 accP[TPW];
 #pragma unroll
@@ -558,7 +605,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
     float qsum = 0.0f, S1sum = 0.0f, S2sum = 0.0f;                   // thread h < S / thread j < 2 S: this tile's shares over all iterations
     const bool oin = 16 * wave + c < nt;
     const int orow = n0 + 16 * wave + c;
-    const float rs = (a.row_scale && oin) ? a.row_scale[orow] : 1.0f;
+    const float rs = (a.row_scale && oin) ? a.row_scale[perm ? perm[orow] : orow] : 1.0f;
     const __amdgpu_buffer_rsrc_t r_dxa = buf_rsrc(a.dxa);
     // this thread's row pieces: rows (tid + 256 u) / LPR, chunk tid % LPR
     const int ch = tid % LPR;
@@ -603,7 +650,7 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                 for (int e = 0; e < 4; ++e) {
                     hs[e] = rr < nt ? (xs[u][e] - s0[e]) * r0[e] : 0.0f;
                     ha[e] = rr < nt ? (xa[u][e] - s1[e]) * r1[e] : 0.0f;
-                    gz[e] *= activate_grad_from_output(a.act, y[u][e]);
+                    gz[e] *= activate_grad_from_output(act, y[u][e]);
                 }
                 *reinterpret_cast<f32x4 *>(Xs + rr * LDX + 4 * ch) = hs;
                 *reinterpret_cast<f32x4 *>(Xs + rr * LDX + S + 4 * ch) = ha;
@@ -686,13 +733,13 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
             grid_barrier(gb, 0, &cont);
             TS_STAMP(3);
             if (tid < 4 * S) {
-                const float tt2 = (float)sum_partials(a.part + (size_t)(t & 1) * gridDim.x * 4 * S, gridDim.x, 4 * S, tid);
+                const float tt2 = (float)sum_partials(a.part + (size_t)(t & 1) * gridDim.x * 4 * S, wg_lo, wg_hi, 4 * S, tid);
                 if (tid < 2 * S) S1_s[tid] = tt2; else S2_s[tid - 2 * S] = tt2;
             }
             __syncthreads();
             if (tid < 2 * S) {
-                const float Ac = valid_dyn(tid) ? a.gamma[wrow_dyn(tid)] * rs_s[tid] : 0.0f;
-                cfA[tid] = Ac; cfC[tid] = -Ac * S2_s[tid] * a.inv_n; cfB[tid] = -Ac * S1_s[tid] * a.inv_n;
+                const float Ac = valid_dyn(tid) ? gamma_[wrow_dyn(tid)] * rs_s[tid] : 0.0f;
+                cfA[tid] = Ac; cfC[tid] = -Ac * S2_s[tid] * inv_n; cfB[tid] = -Ac * S1_s[tid] * inv_n;
             }
             __syncthreads();
         } else {
@@ -745,10 +792,10 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
         TS_STAMP(7);
     }
     TS_WRITE(1);
-    // ---- the shares of this workgroup ---------------------------------------------------------------------------------------------------------
-    float *pw = a.partW + (size_t)blockIdx.x * ((size_t)a.in_s * a.Sw + a.Sw);
-    float *pb = bn ? a.partBN + (size_t)blockIdx.x * 2 * a.in_s : nullptr;
-    if (tid < S) { if (tid < a.Sw) pw[(size_t)a.in_s * a.Sw + tid] = qsum; ql_s[tid] = qsum; }
+    // ---- the shares of this workgroup (heterogeneous models: the type's own arrays, one slot per tile of the type) ------------------------------
+    float *pw = yt.n > 0 ? yt.partW[ty] + (size_t)(blockIdx.x - wg_lo) * ((size_t)in_s * a.Sw + a.Sw) : a.partW + (size_t)blockIdx.x * ((size_t)in_s * a.Sw + a.Sw);
+    float *pb = !bn ? nullptr : yt.n > 0 ? yt.partBN[ty] + (size_t)(blockIdx.x - wg_lo) * 2 * in_s : a.partBN + (size_t)blockIdx.x * 2 * in_s;
+    if (tid < S) { if (tid < a.Sw) pw[(size_t)in_s * a.Sw + tid] = qsum; ql_s[tid] = qsum; }
     __syncthreads();
     // kernel rows of the state / agg columns: gamma_k sum_t Phat + beta_k sum_t q
 #pragma unroll
@@ -761,34 +808,40 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                 const int j = 16 * kt + 4 * g + reg, k = wrow_dyn(j), h = 16 * ht + c;
                 if (!valid_dyn(j) || h >= a.Sw) continue;
                 float v = accP[i][reg];
-                if (bn) v = fmaf(a.gamma[k], v, a.beta[k] * ql_s[h]);
+                if (bn) v = fmaf(gamma_[k], v, beta_[k] * ql_s[h]);
                 pw[(size_t)k * a.Sw + h] = v;
             }
         }
     }
-    if (bn && tid < 2 * S) { if (valid_dyn(tid)) pb[a.in_s + wrow_dyn(tid)] = S1sum; }              // d beta share
+    if (bn && tid < 2 * S) { if (valid_dyn(tid)) pb[in_s + wrow_dyn(tid)] = S1sum; }              // d beta share
     else if (bn && tid < 4 * S) { if (valid_dyn(tid - 2 * S)) pb[wrow_dyn(tid - 2 * S)] = S2sum; }  // d gamma share
-    // the constant input columns: xhat is the same in every iteration, so Phat_c = xhat_c^T (sum_t dZ_t), once
-    const int Kc = (a.cs.n > 0 ? a.cs.width[0] : 0) + (a.cs.n > 1 ? a.cs.width[1] : 0) + (a.cs.n > 2 ? a.cs.width[2] : 0);
+    // the constant input columns: xhat is the same in every iteration, so Phat_c = xhat_c^T (sum_t dZ_t), once - in blocks of 32 columns
+    // (a homogeneous model has 2 L + A <= 32 of them on this path; a type's network of a heterogeneous one d_t + sum d + A)
+    const int Kc = (cs.n > 0 ? cs.width[0] : 0) + (cs.n > 1 ? cs.width[1] : 0) + (cs.n > 2 ? cs.width[2] : 0);
     if (Kc > 0) {
-        int *wrow_c = reinterpret_cast<int *>(red);              // [32] weight row (= BatchNorm column) of constant column jj, -1 = padding
-        if (tid < 32) {
-            int r_ = -1, b0 = 0;
-#pragma unroll
-            for (int sg = 0; sg < 3; ++sg) { if (sg < a.cs.n && tid >= b0 && tid < b0 + a.cs.width[sg]) r_ = a.cs.wrow[sg] + (tid - b0); if (sg < a.cs.n) b0 += a.cs.width[sg]; }
-            wrow_c[tid] = r_;
-        }
 #pragma unroll
         for (int u = 0; u < NCH; ++u) *reinterpret_cast<f32x4 *>(Zs + ((tid + u * TS_NT) / LPR) * LDZ + 4 * ch) = dzsum[u];
+    }
+    for (int cb = 0; cb < Kc; cb += 32) {
+        int *wrow_c = reinterpret_cast<int *>(red);              // [32] weight row (= BatchNorm column) of constant column cb + jj, -1 = padding
+        __syncthreads();                                         // (the previous block's readers of Xs / red are done; Zs is staged)
+        if (tid < 32) {
+            int r_ = -1, b0 = 0;
+            const int jc = cb + tid;
+#pragma unroll
+            for (int sg = 0; sg < 3; ++sg) { if (sg < cs.n && jc >= b0 && jc < b0 + cs.width[sg]) r_ = cs.wrow[sg] + (jc - b0); if (sg < cs.n) b0 += cs.width[sg]; }
+            wrow_c[tid] = r_;
+        }
         __syncthreads();
         for (int i = tid; i < 64 * 32; i += TS_NT) {
-            const int rr = i >> 5, jj = i & 31;
+            const int rr = i >> 5, jj = i & 31, jc = cb + jj;
             float v = 0.0f;
-            if (rr < nt && jj < Kc) {
+            if (rr < nt && jc < Kc) {
                 int b0 = 0;
+                const size_t orig = (size_t)(perm ? perm[n0 + rr] : n0 + rr);        // (the constants are in the caller's node order)
 #pragma unroll
-                for (int sg = 0; sg < 3; ++sg) { if (sg < a.cs.n && jj >= b0 && jj < b0 + a.cs.width[sg]) v = a.cs.ptr[sg][(size_t)(n0 + rr) * a.cs.ld[sg] + (jj - b0)]; if (sg < a.cs.n) b0 += a.cs.width[sg]; }
-                if (bn) { const int k = wrow_c[jj]; const float r_ = 1.0f / sqrtf(a.stats[a.in_s + k] + a.eps); v = (v - a.stats[k]) * r_; }      // (constants: the statistics of any iteration)
+                for (int sg = 0; sg < 3; ++sg) { if (sg < cs.n && jc >= b0 && jc < b0 + cs.width[sg]) v = cs.ptr[sg][orig * cs.ld[sg] + (jc - b0)]; if (sg < cs.n) b0 += cs.width[sg]; }
+                if (bn) { const int k = wrow_c[jj]; const float r_ = 1.0f / sqrtf(stats_[in_s + k] + a.eps); v = (v - stats_[k]) * r_; }      // (constants: the statistics of any iteration)
             }
             Xs[rr * LDC + jj] = v;
         }
@@ -805,25 +858,25 @@ __global__ void __launch_bounds__(TS_NT, 1) k_train_small_bwd(TrainSmallBwd a, T
                 asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const int jj = 16 * kt + 4 * g + reg, k = jj < Kc ? wrow_c[jj] : -1;
+                    const int jj = 16 * kt + 4 * g + reg, k = cb + jj < Kc ? wrow_c[jj] : -1;
                     const bool hv = 16 * ht + c < a.Sw;
-                    const float w = (k >= 0 && hv) ? a.W[(size_t)k * a.Sw + 16 * ht + c] : 0.0f;
+                    const float w = (k >= 0 && hv) ? Wk[(size_t)k * a.Sw + 16 * ht + c] : 0.0f;
                     float s2 = w * Pc[reg], s1 = w * ql_s[16 * ht + c];
 #pragma unroll
                     for (int off = 1; off < 16; off <<= 1) { s2 += __shfl_xor(s2, off, 64); s1 += __shfl_xor(s1, off, 64); }
                     if (k >= 0) {
-                        if (hv) pw[(size_t)k * a.Sw + 16 * ht + c] = bn ? fmaf(a.gamma[k], Pc[reg], a.beta[k] * ql_s[16 * ht + c]) : Pc[reg];
+                        if (hv) pw[(size_t)k * a.Sw + 16 * ht + c] = bn ? fmaf(gamma_[k], Pc[reg], beta_[k] * ql_s[16 * ht + c]) : Pc[reg];
                         if (bn && c == 0) { red[64 + ht * 32 + jj] = s2; red[64 + 4 * 32 + ht * 32 + jj] = s1; }
                     }
                 }
             }
         }
         __syncthreads();
-        if (bn && tid < Kc) {
+        if (bn && tid < 32 && cb + tid < Kc) {
             float s2 = 0.0f, s1 = 0.0f;
 #pragma unroll
             for (int ht = 0; ht < SQ; ++ht) { s2 += red[64 + ht * 32 + tid]; s1 += red[64 + 4 * 32 + ht * 32 + tid]; }
-            pb[wrow_c[tid]] = s2; pb[a.in_s + wrow_c[tid]] = s1;
+            pb[wrow_c[tid]] = s2; pb[in_s + wrow_c[tid]] = s1;
         }
     }
     if (tid == 0 && gb.timed_out) a.err[1] = 2.0f;

@@ -37,8 +37,17 @@ struct CPlan {
     size_t part_floats;
     NetCtx co;
     CType ty[GNN_MAX_TYPES];
+    // small graphs: the K forward / k backward iterations as ONE persistent launch each (kernels_train_small.hpp), the nodes walked in type
+    // order in tiles of <= 64 nodes of one type: the tape's rows are POSITIONS (position i = node type_nodes[i]), `inv` maps back
+    bool small; int SPs, ldS, n_wg, wg_begin[GNN_MAX_TYPES + 1];
+    int *inv; float *sm_cc, *sm_part, *sm_dxa, *sm_partW[GNN_MAX_TYPES], *sm_partBN[GNN_MAX_TYPES]; unsigned long long *sm_bar;
     size_t bytes;
 };
+
+// inv[perm[i]] = i
+__global__ void __launch_bounds__(256) k_invert_perm(const int *__restrict__ perm, int n, int *__restrict__ inv) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) inv[perm[i]] = i;
+}
 
 // rows[m] of a [*, ld_dst] matrix <- row m of a compact [M, width] one (every node has exactly one type: the types' rows partition it)
 __global__ void __launch_bounds__(256) k_scatter_rows(const float *__restrict__ src, int ld_src, const int *__restrict__ idx, int M, int width,
@@ -91,13 +100,31 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
     p.G = p.pooled ? a.nodegraph.n_dst : 0;
     p.R = p.pooled ? p.G : p.M;
 
+    // ---- which path: the persistent small-graph kernels (one-layer state networks of the state's width, every non-empty type with or every
+    // one without BatchNormalization - the tiles meet at the same grid barriers -, all tiles resident at once) or one launch per layer, type
+    // and iteration
+    p.SPs = p.S <= 16 ? 16 : p.S <= 32 ? 32 : 64;
+    p.n_wg = 0; p.wg_begin[0] = 0;
+    bool uniform = p.S <= 64 && train_small_enabled() && p.N < train_big_min_nodes();
+    int bn_seen = -1;
+    for (int t = 0; t < p.n_types; ++t) {
+        const gnn_mlp_t &m = a.net_state[t];
+        const int cnt = a.type_offsets[t + 1] - a.type_offsets[t];
+        p.n_wg += cdiv(std::max(cnt, 0), 64);
+        p.wg_begin[t + 1] = p.n_wg;
+        if (m.n_layers != 1 || m.units[0] != p.S || m.activation[0] == GNN_ACT_SOFTMAX) uniform = false;
+        if (cnt > 0) { if (bn_seen < 0) bn_seen = m.has_bn ? 1 : 0; else if (bn_seen != (m.has_bn ? 1 : 0)) uniform = false; }
+    }
+    p.small = uniform && p.n_wg >= 1 && p.n_wg <= std::min(device_cus(), 256) && (size_t)p.K * p.N * p.SPs * sizeof(float) <= agg_tape_budget();
+    p.ldS = p.small ? p.SPs : p.S;
+
     Carver c(ws);
     p.grads_ok = c.take<int>(4);
     p.flags = c.take<int>(p.K + 8);
     p.k_dev = c.take<float>(4);
-    p.states = c.take<float>((size_t)(p.K + 1) * p.N * p.S);
-    p.agg_taped = (size_t)p.K * p.N * p.S * sizeof(float) <= agg_tape_budget();
-    p.agg = c.take<float>((size_t)(p.agg_taped ? p.K : 1) * p.N * p.S);
+    p.states = c.take<float>((size_t)(p.K + 1) * p.N * p.ldS);
+    p.agg_taped = (size_t)p.K * p.N * p.ldS * sizeof(float) <= agg_tape_budget();
+    p.agg = c.take<float>((size_t)(p.agg_taped ? p.K : 1) * p.N * p.ldS);
     p.agg_comp = c.take<float>((size_t)p.N * std::max(p.W_comp, 1));
     p.stats_o = c.take<float>(2 * (size_t)no.in_dim);
     p.Wf_o = c.take<float>((size_t)no.in_dim * no.units[0]); p.bf_o = c.take<float>(no.units[0]);
@@ -132,7 +159,15 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
         y.dx = c.take<float>((size_t)std::max(y.count, 1) * 2 * p.S);
         int nc_; rows_per_chunk_for(std::max(y.count, 1), &nc_);
         p.part_floats = std::max(p.part_floats, (size_t)(nc_ + 1) * y.in_dim);
+        const int tiles_t = p.wg_begin[t + 1] - p.wg_begin[t];
+        p.sm_partW[t] = c.take<float>(p.small ? (size_t)tiles_t * ((size_t)y.in_dim * p.S + p.S) : 0);
+        p.sm_partBN[t] = c.take<float>(p.small ? (size_t)tiles_t * 2 * y.in_dim : 0);
     }
+    p.inv = c.take<int>(p.small ? p.N : 0);
+    p.sm_cc = c.take<float>(p.small ? (size_t)p.N * p.SPs : 0);
+    p.sm_part = c.take<float>(p.small ? (size_t)2 * p.n_wg * 8 * p.SPs : 0);
+    p.sm_dxa = c.take<float>(p.small ? (size_t)p.N * p.SPs : 0);
+    p.sm_bar = c.take<unsigned long long>(p.small ? 4 : 0);
     carve_net(c, p.co, no, p.M, p.part_floats);
     p.co.m = &no; p.co.g = &ta.grad_output;
     {
@@ -191,7 +226,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
     const gnn_mlp_t &no = a.net_output;
     const bool bn_o = no.has_bn != 0;
     hipStream_t st = (hipStream_t)a.stream;
-    const size_t NS = (size_t)p.N * p.S;
+    const size_t NS = (size_t)p.N * p.ldS;             // one state matrix of the tape
 
     // ---- setup: transposes, aggregated_component (CompositeGNN.py:251-253), state_0, the constant columns' statistics ------------
     if (ta.prev_grads_ok_host) HIP_OK(hipMemcpyAsync(ta.prev_grads_ok_host, p.grads_ok, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -210,7 +245,13 @@ int train_step_composite(const gnn_train_args_t &ta) {
         }
         if (p.A > 0) TRY(launch_aggregate(nullptr, a.arcnode, a.arc_labels, a.ld_arcs, p.A, p.agg_comp + col, p.W_comp, st));
     }
-    if (a.state_dim > 0) HIP_OK(hipMemcpyAsync(p.states, a.state0, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
+    if (p.small) {          // the tape's rows are positions in type order (position i = node type_nodes[i]), ldS floats each, pad columns zero
+        if (p.ldS != p.S) HIP_OK(hipMemsetAsync(p.states, 0, sizeof(float) * NS, st));
+        if (a.state_dim > 0) TRY(gather_rows(a.state0, p.S, a.type_nodes, p.N, p.S, p.states, p.ldS, st));
+        else TRY(gather_rows(a.nodes, a.ld_nodes, a.type_nodes, p.N, p.S, p.states, p.ldS, st));
+        k_invert_perm<<<std::min(cdiv(p.N, 256), 1024), 256, 0, st>>>(a.type_nodes, p.N, p.inv);
+        LAUNCH_OK();
+    } else if (a.state_dim > 0) HIP_OK(hipMemcpyAsync(p.states, a.state0, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
     else TRY(launch_copy2d(nullptr, a.nodes, a.ld_nodes, p.states, p.S, p.N, p.S, p.S, st));
     gnn::Seg segs[GNN_MAX_SEGS];
     for (int t = 0; t < p.n_types; ++t) {
@@ -227,8 +268,53 @@ int train_step_composite(const gnn_train_args_t &ta) {
     }
 
     // ---- training-mode forward: gated iterations; tape = states, neighbour sums, per-type statistics ---------------------------------
-    TRY(launch_converge(nullptr, p.states, nullptr, p.N, p.S, p.S, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
-    for (int t = 0; t < p.K; ++t) {
+    TRY(launch_converge(nullptr, p.states, nullptr, p.N, p.S, p.ldS, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
+    gnn::TileTab tiles;
+    gnn::TypeTab yt;
+    memset(&tiles, 0, sizeof(tiles)); memset(&yt, 0, sizeof(yt));
+    if (p.small) {
+        // tiles of <= 64 consecutive positions of ONE type; per type the network, its statistics tape and where its shares go
+        int b = 0;
+        for (int q = 0; q < p.n_types; ++q) {
+            const CType &y = p.ty[q];
+            const int pos0 = a.type_offsets[q];
+            for (int r0 = 0; r0 < y.count; r0 += 64) tiles.begin[b++] = pos0 + r0;
+            yt.wg_begin[q] = p.wg_begin[q]; yt.count[q] = y.count;
+            yt.W[q] = y.m->kernel[0]; yt.gamma[q] = y.m->has_bn ? y.m->bn_gamma : nullptr; yt.beta[q] = y.m->bn_beta; yt.stats[q] = y.stats;
+            yt.in_s[q] = y.in_dim; yt.off_state[q] = y.off_state; yt.off_agg[q] = y.off_agg; yt.act[q] = y.m->activation[0];
+            yt.partW[q] = p.sm_partW[q]; yt.partBN[q] = p.sm_partBN[q];
+        }
+        tiles.begin[b] = p.N; tiles.n = b;
+        yt.n = p.n_types; yt.wg_begin[p.n_types] = p.n_wg; yt.perm = a.type_nodes; yt.inv = p.inv;
+        if (b != p.n_wg) return fail("composite tiles: %d != %d", b, p.n_wg);
+        // the constant part of every node's first layer (its type's network over its labels and the aggregated component), in position order
+        for (int q = 0; q < p.n_types; ++q) {
+            const CType &y = p.ty[q];
+            if (y.count == 0) continue;
+            gnn::ConstSegs cs;
+            memset(&cs, 0, sizeof(cs));
+            if (y.d_t > 0) { cs.ptr[cs.n] = a.nodes; cs.ld[cs.n] = a.ld_nodes; cs.width[cs.n] = y.d_t; cs.wrow[cs.n] = 0; ++cs.n; }
+            if (p.W_comp > 0) { cs.ptr[cs.n] = p.agg_comp; cs.ld[cs.n] = p.W_comp; cs.width[cs.n] = p.W_comp; cs.wrow[cs.n] = y.off_comp; ++cs.n; }
+            gnn::k_train_small_const<<<cdiv(y.count * p.SPs, 256), 256, 0, st>>>(y.count, p.SPs, p.S, cs, y.m->kernel[0], y.m->bias[0], y.m->has_bn ? y.m->bn_gamma : nullptr,
+                                                                             y.m->bn_beta, y.stats_tpl, y.stats_tpl + y.in_dim, y.m->bn_eps,
+                                                                             p.sm_cc + (size_t)a.type_offsets[q] * p.SPs, y.rows);
+            LAUNCH_OK();
+        }
+        HIP_OK(hipMemsetAsync(p.sm_bar, 0, sizeof(unsigned long long) * 4, st));
+        gnn::TrainSmallFwd fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.N = p.N; fa.S = p.SPs; fa.Sw = p.S; fa.K = p.K;
+        fa.rowptr = a.adjacency.rowptr; fa.src = a.adjacency.src; fa.w = a.adjacency.w; fa.row_scale = a.adjacency.row_scale;
+        fa.states = p.states; fa.agg = p.agg; fa.eps = p.ty[0].m->bn_eps;
+        fa.Cc = p.sm_cc; fa.thr = a.state_threshold; fa.flag0 = p.flags;
+        fa.bar = p.sm_bar; fa.part = p.sm_part; fa.k_out = p.k_dev; fa.wait_ticks = gnn::wait_ticks();
+        switch (p.SPs) {
+            case 16: TRY(launch_train_small_fwd_sq<1>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st, &yt)); break;
+            case 32: TRY(launch_train_small_fwd_sq<2>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st, &yt)); break;
+            default: TRY(launch_train_small_fwd_sq<4>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st, &yt)); break;
+        }
+    }
+    for (int t = 0; t < p.K && !p.small; ++t) {
         const int *gate = p.flags + t;
         const float *s_t = p.states + (size_t)t * NS;
         float *s_n = p.states + (size_t)(t + 1) * NS;
@@ -260,21 +346,29 @@ int train_step_composite(const gnn_train_args_t &ta) {
         }
         TRY(launch_converge(gate, s_n, s_t, p.N, p.S, p.S, p.S, a.state_threshold, p.flags + t + 1, p.k_dev, (float)(t + 1), st));
     }
-    float k_f = 0.0f;
-    HIP_OK(hipMemcpyAsync(&k_f, p.k_dev, sizeof(float), hipMemcpyDeviceToHost, st));
+    float k_f2[2] = {0.0f, 0.0f};
+    HIP_OK(hipMemcpyAsync(k_f2, p.k_dev, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));                                  // the one host synchronisation of the step
-    const int k = (int)k_f;
+    const int k = (int)k_f2[0];
     *ta.k_host = k;
+    if (k_f2[1] != 0.0f) return fail("a workgroup of the persistent training kernel never arrived at a grid barrier (not resident?)");
     if (k < 0 || k > p.K) return fail("iteration count %d out of range", k);
-    const float *state_k = p.states + (size_t)k * NS;
-    HIP_OK(hipMemcpyAsync(ta.state, state_k, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
-    for (int q = 0; q < p.n_types && k > 0; ++q) {
-        const CType &y = p.ty[q];
-        if (!y.m->has_bn || y.count == 0) continue;
-        gnn::k_bn_moving_multi<<<cdiv(y.in_dim, 256), 256, 0, st>>>(y.stats, 2 * y.in_dim, k, y.in_dim, const_cast<float *>(y.m->bn_mean),
-                                                                   const_cast<float *>(y.m->bn_var), ta.bn_momentum);
-        LAUNCH_OK();
-    }
+    if (p.small) TRY(scatter_rows(p.states + (size_t)k * NS, p.ldS, a.type_nodes, p.N, p.S, ta.state, p.S, st));      // positions -> the caller's node order
+    else HIP_OK(hipMemcpyAsync(ta.state, p.states + (size_t)k * NS, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
+    const float *state_k = ta.state;                                   // [N, S] in the caller's node order
+    // The moving averages of BatchNormalization (one update per executed call).  On the persistent path they wait until the backward
+    // launch has passed its grid barriers and are gated by the step's validity word (train_loop.hpp: a failed backward changes nothing).
+    auto moving_state = [&](const int *gate) -> int {
+        for (int q = 0; q < p.n_types && k > 0; ++q) {
+            const CType &y = p.ty[q];
+            if (!y.m->has_bn || y.count == 0) continue;
+            gnn::k_bn_moving_multi<<<cdiv(y.in_dim, 256), 256, 0, st>>>(y.stats, 2 * y.in_dim, k, y.in_dim, const_cast<float *>(y.m->bn_mean),
+                                                                       const_cast<float *>(y.m->bn_var), ta.bn_momentum, gate);
+            LAUNCH_OK();
+        }
+        return 0;
+    };
+    if (!p.small) TRY(moving_state(nullptr));
 
     // ---- output network on the converged state of the masked nodes (CompositeGNN.py:237-239, :270), training mode --------------------
     gnn::Seg osegs[1] = {gnn::Seg{state_k, a.out_index, p.S, p.S, 0}};
@@ -286,9 +380,11 @@ int train_step_composite(const gnn_train_args_t &ta) {
         if (bn_o) {
             TRY(colstats_segs(nullptr, osegs, 1, p.M, p.stats_o, p.stats_o + no.in_dim, p.part, st));
             TRY(fold_with_stats(no, p.stats_o, p.Wf_o, p.bf_o, st, true));
-            gnn::k_bn_moving_multi<<<cdiv(no.in_dim, 256), 256, 0, st>>>(p.stats_o, 2 * no.in_dim, 1, no.in_dim, const_cast<float *>(no.bn_mean),
-                                                                        const_cast<float *>(no.bn_var), ta.bn_momentum);
-            LAUNCH_OK();
+            if (!p.small) {
+                gnn::k_bn_moving_multi<<<cdiv(no.in_dim, 256), 256, 0, st>>>(p.stats_o, 2 * no.in_dim, 1, no.in_dim, const_cast<float *>(no.bn_mean),
+                                                                            const_cast<float *>(no.bn_var), ta.bn_momentum);
+                LAUNCH_OK();
+            }
             W0 = p.Wf_o; b0 = p.bf_o;
         }
         TRY(forward_layers(no, osegs, 1, p.M, W0, b0, ohs, nullptr, st, nullptr, nullptr, bn_o ? p.stats_o : nullptr));
@@ -306,7 +402,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
     if (p.pooled) { TRY(launch_aggregate(nullptr, ta.nodegraph_by_source, p.dpred, p.T, p.T, p.G_out, p.T, st)); G_out = p.G_out; }
 
     // ---- backward: output network, then the k iterations ------------------------------------------------------------------------------
-    HIP_OK(hipMemsetAsync(p.G_state, 0, sizeof(float) * NS, st));
+    HIP_OK(hipMemsetAsync(p.G_state, 0, sizeof(float) * (size_t)p.N * p.S, st));
     if (p.M > 0) {
         TRY(net_backward(p.co, osegs, 1, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, no.in_dim, p.part, st));
         gnn::BnGradReq rq[1] = {gnn::BnGradReq{p.dx_o_all, no.in_dim, state_k, p.S, a.out_index, p.S, 0}};
@@ -316,7 +412,46 @@ int train_step_composite(const gnn_train_args_t &ta) {
     } else TRY(zero_grads(no, ta.grad_output, st));
     for (int q = 0; q < p.n_types; ++q)
         if (k == 0 || p.ty[q].count == 0) TRY(zero_grads(*p.ty[q].m, p.ty[q].g, st));
-    for (int t = k - 1; t >= 0; --t) {
+    if (p.small && k > 0) {
+        // the k iterations of back-propagation in one persistent launch; every tile leaves its share of ITS type's gradients
+        gnn::TypeConsts yc;
+        memset(&yc, 0, sizeof(yc));
+        for (int q = 0; q < p.n_types; ++q) {
+            const CType &y = p.ty[q];
+            gnn::ConstSegs &cs = yc.cs[q];
+            if (y.d_t > 0) { cs.ptr[cs.n] = a.nodes; cs.ld[cs.n] = a.ld_nodes; cs.width[cs.n] = y.d_t; cs.wrow[cs.n] = 0; ++cs.n; }
+            if (p.W_comp > 0) { cs.ptr[cs.n] = p.agg_comp; cs.ld[cs.n] = p.W_comp; cs.width[cs.n] = p.W_comp; cs.wrow[cs.n] = y.off_comp; ++cs.n; }
+        }
+        gnn::TrainSmallBwd ba;
+        memset(&ba, 0, sizeof(ba));
+        const gnn_csr_t &cs_ = ta.adjacency_by_source;
+        const bool unit_w = !a.adjacency.w;       // entries depend on the destination only: scale the agg-half once per row, walk unit weights
+        ba.N = p.N; ba.S = p.SPs; ba.Sw = p.S; ba.k = k;
+        ba.rowptr_s = cs_.rowptr; ba.src_s = cs_.src; ba.w_s = unit_w ? nullptr : cs_.w; ba.row_scale_s = unit_w ? nullptr : cs_.row_scale;
+        ba.row_scale = unit_w ? a.adjacency.row_scale : nullptr;
+        ba.states = p.states; ba.agg = p.agg; ba.eps = p.ty[0].m->bn_eps;
+        ba.G0 = p.G_state; ba.dxa = p.sm_dxa; ba.bar = p.sm_bar + 2; ba.part = p.sm_part;
+        ba.inv_n = 1.0f / (float)p.N; ba.err = p.k_dev; ba.wait_ticks = gnn::wait_ticks();
+        if (const char *e = getenv("GNN_DEBUG_FAIL_BWD")) { if (e[0] == '1') ba.wait_ticks = 0; }
+        switch (p.SPs) {
+            case 16: TRY(launch_train_small_bwd_sq<1>(ba, tiles, p.n_wg, ba.w_s != nullptr, st, &yt, &yc)); break;
+            case 32: TRY(launch_train_small_bwd_sq<2>(ba, tiles, p.n_wg, ba.w_s != nullptr, st, &yt, &yc)); break;
+            default: TRY(launch_train_small_bwd_sq<4>(ba, tiles, p.n_wg, ba.w_s != nullptr, st, &yt, &yc)); break;
+        }
+        for (int q = 0; q < p.n_types; ++q) {          // every tile's [kernel | bias] (and [d gamma | d beta]) share, summed in tile order
+            const CType &y = p.ty[q];
+            const int tiles_q = p.wg_begin[q + 1] - p.wg_begin[q];
+            if (tiles_q == 0) continue;
+            const int n = (y.in_dim + 1) * p.S;
+            gnn::k_reduce_partials<<<cdiv(n, 64), 256, 0, st>>>(p.sm_partW[q], tiles_q, n, y.g.dkernel[0], 0, 1.0f, y.in_dim * p.S, y.g.dbias[0]);
+            LAUNCH_OK();
+            if (y.m->has_bn) {
+                gnn::k_reduce_partials<<<cdiv(2 * y.in_dim, 64), 256, 0, st>>>(p.sm_partBN[q], tiles_q, 2 * y.in_dim, y.g.dgamma, 0, 1.0f, y.in_dim, y.g.dbeta);
+                LAUNCH_OK();
+            }
+        }
+    }
+    for (int t = k - 1; t >= 0 && !p.small; --t) {
         const float *s_t = p.states + (size_t)t * NS;
         const float *s_n = p.states + (size_t)(t + 1) * NS;
         float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);
@@ -358,8 +493,16 @@ int train_step_composite(const gnn_train_args_t &ta) {
     }
     if (ta.average_st_grads && k > 0)
         for (int q = 0; q < p.n_types; ++q) TRY(scale_grads(*p.ty[q].m, p.ty[q].g, 1.0f / (float)k, st));
-    gnn::k_grads_ok<<<1, 1, 0, st>>>(nullptr, p.grads_ok);      // (no cross-workgroup waits on this path: always valid)
+    gnn::k_grads_ok<<<1, 1, 0, st>>>(p.small ? p.k_dev : nullptr, p.grads_ok);      // (only the persistent backward launch can fail)
     LAUNCH_OK();
+    if (p.small) {
+        TRY(moving_state(p.grads_ok));
+        if (bn_o && p.M > 0) {
+            gnn::k_bn_moving_multi<<<cdiv(no.in_dim, 256), 256, 0, st>>>(p.stats_o, 2 * no.in_dim, 1, no.in_dim, const_cast<float *>(no.bn_mean),
+                                                                        const_cast<float *>(no.bn_var), ta.bn_momentum, p.grads_ok);
+            LAUNCH_OK();
+        }
+    }
     return 0;
 }
 

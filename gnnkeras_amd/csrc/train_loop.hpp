@@ -601,8 +601,8 @@ gnn::ConstSegs const_segs_of(const gnn_loop_args_t &a, const TrainPlan &p) {
     return cs;
 }
 
-template <typename Kern, typename Args>
-int launch_persistent(Kern kern, const Args &args, const gnn::TileTab &tt, int n_wg, size_t lds, hipStream_t st) {
+template <typename Kern, typename Args, typename... Extra>
+int launch_persistent(Kern kern, const Args &args, const gnn::TileTab &tt, int n_wg, size_t lds, hipStream_t st, const Extra &... extra) {
     lds = std::max(lds, gnn::TS_LDS);
     static std::vector<const void *> allowed;          // kernels whose dynamic-LDS limit has been raised
     static std::mutex allowed_mutex;                   // (callers may run steps of different models on different host threads)
@@ -617,27 +617,40 @@ int launch_persistent(Kern kern, const Args &args, const gnn::TileTab &tt, int n
     // every workgroup waits for the others at the grid barriers: the grid must fit the device (n_wg <= CUs by the plan; this asks the
     // runtime about THIS kernel's registers / LDS)
     if (!gnn::persistent_fits(fn, gnn::TS_NT, lds, n_wg, device_cus())) return fail("persistent training kernel: %d workgroups cannot be resident at once", n_wg);
-    kern<<<n_wg, gnn::TS_NT, lds, st>>>(args, tt);
+    kern<<<n_wg, gnn::TS_NT, lds, st>>>(args, tt, extra...);
     LAUNCH_OK();
     return 0;
 }
 
+// `yt` (heterogeneous models: tiles cut at TYPE boundaries, arcs cross them: the general form with a tile table); yt == NULL: homogeneous -
+// a tile table then means tiles cut at GRAPH boundaries that no arc leaves (the LOCAL form)
 template <int SQ>
-int launch_train_small_fwd_sq(const gnn::TrainSmallFwd &fa, const gnn::TileTab &tt, int n_wg, bool has_w, hipStream_t st) {
+int launch_train_small_fwd_sq(const gnn::TrainSmallFwd &fa, const gnn::TileTab &tt, int n_wg, bool has_w, hipStream_t st, const gnn::TypeTab *yt = nullptr) {
     const size_t lds = gnn::train_small_fwd_lds<SQ>();
-    if (tt.n > 0) return has_w ? launch_persistent(&gnn::k_train_small_fwd<SQ, true, true>, fa, tt, n_wg, lds, st)
-                               : launch_persistent(&gnn::k_train_small_fwd<SQ, false, true>, fa, tt, n_wg, lds, st);
-    return has_w ? launch_persistent(&gnn::k_train_small_fwd<SQ, true, false>, fa, tt, n_wg, lds, st)
-                 : launch_persistent(&gnn::k_train_small_fwd<SQ, false, false>, fa, tt, n_wg, lds, st);
+    gnn::TypeTab none;
+    memset(&none, 0, sizeof(none));
+    const gnn::TypeTab &y = yt ? *yt : none;
+    if (tt.n > 0 && !yt) return has_w ? launch_persistent(&gnn::k_train_small_fwd<SQ, true, true>, fa, tt, n_wg, lds, st, y)
+                                      : launch_persistent(&gnn::k_train_small_fwd<SQ, false, true>, fa, tt, n_wg, lds, st, y);
+    return has_w ? launch_persistent(&gnn::k_train_small_fwd<SQ, true, false>, fa, tt, n_wg, lds, st, y)
+                 : launch_persistent(&gnn::k_train_small_fwd<SQ, false, false>, fa, tt, n_wg, lds, st, y);
 }
 
 template <int SQ>
-int launch_train_small_bwd_sq(const gnn::TrainSmallBwd &ba, const gnn::TileTab &tt, int n_wg, bool has_w, hipStream_t st) {
-    const size_t lds = gnn::train_small_bwd_lds<SQ>(tt.n > 0);
-    if (tt.n > 0) return has_w ? launch_persistent(&gnn::k_train_small_bwd<SQ, true, true>, ba, tt, n_wg, lds, st)
-                               : launch_persistent(&gnn::k_train_small_bwd<SQ, false, true>, ba, tt, n_wg, lds, st);
-    return has_w ? launch_persistent(&gnn::k_train_small_bwd<SQ, true, false>, ba, tt, n_wg, lds, st)
-                 : launch_persistent(&gnn::k_train_small_bwd<SQ, false, false>, ba, tt, n_wg, lds, st);
+int launch_train_small_bwd_sq(const gnn::TrainSmallBwd &ba, const gnn::TileTab &tt, int n_wg, bool has_w, hipStream_t st, const gnn::TypeTab *yt = nullptr,
+                              const gnn::TypeConsts *yc = nullptr) {
+    const bool local = tt.n > 0 && !yt;
+    const size_t lds = gnn::train_small_bwd_lds<SQ>(local);
+    gnn::TypeTab none;
+    memset(&none, 0, sizeof(none));
+    gnn::TypeConsts nonec;
+    memset(&nonec, 0, sizeof(nonec));
+    const gnn::TypeTab &y = yt ? *yt : none;
+    const gnn::TypeConsts &c = yc ? *yc : nonec;
+    if (local) return has_w ? launch_persistent(&gnn::k_train_small_bwd<SQ, true, true>, ba, tt, n_wg, lds, st, y, c)
+                            : launch_persistent(&gnn::k_train_small_bwd<SQ, false, true>, ba, tt, n_wg, lds, st, y, c);
+    return has_w ? launch_persistent(&gnn::k_train_small_bwd<SQ, true, false>, ba, tt, n_wg, lds, st, y, c)
+                 : launch_persistent(&gnn::k_train_small_bwd<SQ, false, false>, ba, tt, n_wg, lds, st, y, c);
 }
 
 // Back-propagation through a thin output head over every node of a large graph (kernels_train_big.hpp: k_head_wgrad / k_head_dx): the

@@ -536,6 +536,79 @@ class ShardedLoop:
     def _sync(self):
         if self.device.type == 'cuda': torch.cuda.synchronize(self.device)
 
+    # ---- the loop driven from native code (csrc/shard_loop.hpp) ------------------------------------------------------
+    native_loop = False               # True: forward() issues ALL iterations with one `gnn_shard_loop` call (enable_native_loop)
+    _comm = None
+
+    def enable_native_loop(self, emulated: bool = False, with_comm: bool = False):
+        """Drive the iterations from the library instead of from here: one C call issues every iteration's launches and - over the
+        RCCL C API, on an exchange stream of the library's own - its exchange, in the order `forward()` issues them from the
+        interpreter (same launches, same bits; ~10 us of host time per iteration instead of the interpreter's 100 .. 200).
+        Collective at world size > 1: rank 0 draws the communicator's id, everybody receives it over `self.group` and joins.
+        `emulated`: one rank's launches of an R-rank job on one GPU without any exchange (bench.py --emulate-shard: timing, and the
+        tests' R-ranks-on-one-device harness); `with_comm`: a communicator even at world size 1 (the exchange then really goes
+        through RCCL - an all-gather of the one slice).
+        Whole-slice layouts on HIP devices; the interpreter-driven loop stays the default."""
+        if self.device.type != 'cuda' or type(self)._layout != 'allgather':
+            raise NotImplementedError('the native loop drives whole-slice layouts on HIP devices')
+        lib = nat.lib()
+        if (self.world_size > 1 or with_comm) and not emulated and self._comm is None:
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if self.rank == 0:
+                raw = (C.c_char * 128)()
+                nat.check(lib.gnn_comm_unique_id(C.cast(raw, C.c_void_p)))
+                uid = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+            box = [uid.numpy().tobytes()]
+            if self.world_size > 1:
+                dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            handle = C.c_void_p(0)
+            with torch.cuda.device(self.device):
+                nat.check(lib.gnn_comm_create(self.world_size, self.rank, C.c_char_p(box[0]), C.byref(handle)))
+            self._comm = handle
+        self._emulated = bool(emulated)
+        self.native_loop = True
+        return self
+
+    def close(self):
+        """Release the native loop's communicator (collective at world size > 1)."""
+        if self._comm is not None:
+            nat.lib().gnn_comm_destroy(self._comm)
+            self._comm = None
+        self.native_loop = False
+
+    def _kernels_only(self):
+        """One iteration's launches without the exchange although a communicator exists (profile_iteration's `kernel_s`)."""
+        comm, self._comm, em = self._comm, None, getattr(self, '_emulated', False)
+        self._emulated = True
+        try: self._native_iterations(0, 1)
+        finally: self._comm, self._emulated = comm, em
+
+    def _native_iterations(self, first_iteration: int = 0, n_iterations: int = -1):
+        """Iterations [first, first + n) of forward() in one call (after _prepare; n < 0: all): plain, own-range / halo split, or the
+        split in chunk launches."""
+        p = self.plan
+        sa = nat.ShardLoopArgs()
+        self.args.stream = nat.current_stream(self.device)
+        sa.loop = C.pointer(self.args)
+        if self.overlap:
+            sa.adjacency_own, sa.adjacency_halo = C.pointer(self.c_adj_own), C.pointer(self.c_adj_halo)
+            sa.agg_partial = nat.ptr(self.agg_partial)
+        sa.buf[0], sa.buf[1] = self.buf[0].data_ptr(), self.buf[1].data_ptr()
+        sa.row_base, sa.rows_per_slice, sa.chunk = p.row_base, p.rows_per_slice, p.chunk
+        sa.world_size, sa.rank, sa.SP = self.world_size, self.rank, self.SP
+        sa.first_iteration, sa.n_iterations = int(first_iteration), int(n_iterations)
+        sa.transport = 1 if self.transport == 'direct' else 0
+        keep = None
+        if self.overlap and self.pipeline_chunks > 1:
+            bounds = [lo for lo, _ in self._chunk_rows] + [self._chunk_rows[-1][1]]
+            keep = (C.c_int32 * len(bounds))(*bounds)
+            sa.n_chunks, sa.chunk_begin, sa.node_iota = len(bounds) - 1, keep, nat.ptr(self._iota())
+        else:
+            sa.n_chunks = 1
+        sa.emulated = 1 if getattr(self, '_emulated', False) else 0
+        sa.comm = self._comm
+        nat.check(nat.lib().gnn_shard_loop(C.byref(sa)))
+
     # ---- backend-independent orchestration ------------------------------------------------------------------------------
     def _load_state0(self, state0_full):
         p = self.plan
@@ -595,6 +668,9 @@ class ShardedLoop:
             ok = torch.tensor([1 if (self.overlap and self.pipeline_supported()) else 0], dtype=torch.int32, device=self.device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
             if int(ok) == 1: self._tune_pipeline(state0_full)
+        if self.native_loop:
+            self._native_iterations()
+            return self._finish(*self._output())
         if not self.overlap:
             for it in range(m.max_iteration):
                 self._iteration(it)
@@ -645,7 +721,17 @@ class ShardedLoop:
                 torch.cuda.synchronize(self.device)
                 return 1e-3 * a.elapsed_time(b) / reps
 
+            def host_issue(fn):                                    # wall time the HOST needs to issue one iteration (the queue never runs dry: 20 in a row, then one wait)
+                import time as _t
+                torch.cuda.synchronize(self.device)
+                t0 = _t.perf_counter()
+                for _ in range(20): fn()
+                dt = (_t.perf_counter() - t0) / 20
+                torch.cuda.synchronize(self.device)
+                return dt
+
             def kernels():
+                if self.native_loop: return self._native_iterations(0, 1) if not getattr(self, '_comm', None) else self._kernels_only()
                 if self.overlap and self.pipeline_chunks > 1:
                     self._partial(0)
                     for ci, (lo, hi) in enumerate(self._chunk_rows): self._iteration_split_rows(0, lo, hi, first=ci == 0)
@@ -656,6 +742,7 @@ class ShardedLoop:
                 self._exchange_finish(self._exchange(self.buf[1], 0, async_op=True), self.buf[1], 0)
 
             def both():
+                if self.native_loop: return self._native_iterations(0, 1)
                 if self.overlap and self.pipeline_chunks > 1:
                     self._pipelined_iteration(0, True)
                 elif self.overlap:
@@ -670,9 +757,11 @@ class ShardedLoop:
             if not collective:
                 kernels()                                          # warm-up
                 t['kernel_s'] = timed(kernels)
+                t['host_issue_s'] = host_issue(kernels)
                 return t
             kernels(); exchange()                                  # warm-up
             t['kernel_s'], t['exchange_s'], t['iteration_s'] = timed(kernels), timed(exchange), timed(both)
+            t['host_issue_s'] = host_issue(both)
         finally:
             m.native_flags = flags
             self.args.flags = flags

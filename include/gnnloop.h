@@ -279,6 +279,35 @@ int gnn_shard_iteration_split_rows(const gnn_loop_args_t *args, const gnn_csr_t 
                                    int32_t n_gate, int32_t gate_stride, int32_t *flag_out, int32_t iteration,
                                    const int32_t *node_ids, int32_t n_ids, int32_t first_chunk);
 
+/* ---- the sharded loop driven from native code (ABI 7; gnnkeras_amd/csrc/shard_loop.hpp) ------------------------------------------------
+ * All iterations of a rank in ONE call: own-range partial sums, the halo kernel (whole or in chunk launches), the exchange of the rows
+ * just written over the RCCL C API on an exchange stream of the library's own, the stream dependencies between them - the launches
+ * gnnkeras_amd/distributed.py issues one at a time from the interpreter, in the same order (bit-identical results), without the
+ * interpreter between a chunk's kernel and its sends.  No host synchronisation; the convergence gates stay device words.
+ * The communicator is the library's own: rank 0 draws an id (gnn_comm_unique_id, 128 bytes), hands it to the other ranks over whatever
+ * the host already has (torch.distributed), every rank calls gnn_comm_create (collective).  RCCL is reached through dlopen: the copy
+ * the process has already loaded (librccl.so.1; GNN_RCCL_LIB overrides). */
+int gnn_comm_unique_id(void *out128);
+int gnn_comm_create(int32_t nranks, int32_t rank, const void *unique_id128, void **comm_out);
+int gnn_comm_destroy(void *comm);
+typedef struct gnn_shard_loop_args {
+    const gnn_loop_args_t *loop;                     /* as for gnn_shard_iteration (gnn_shard_setup has run; `stream` = the compute stream)  */
+    const gnn_csr_t *adjacency_own, *adjacency_halo; /* both non-NULL (+ agg_partial): the own-range / halo split with overlap               */
+    float *agg_partial;
+    float *buf[2];                                   /* the two full state buffers; iteration i reads buf[i & 1], writes buf[(i + 1) & 1]     */
+    int32_t row_base, rows_per_slice, chunk;         /* this rank's first row; rows of a slice incl. padding + flag row; the flag row's index  */
+    int32_t world_size, rank, SP;                    /* SP = gnn_state_ld(S)                                                                   */
+    int32_t first_iteration, n_iterations;           /* iterations [first, first + n) of the loop; n < 0: through loop->max_iteration.  Calls chain:
+                                                      * the own-range partial sums of iteration i + 1 are issued at the end of iteration i    */
+    int32_t transport;                               /* 0: RCCL all-gather of whole slices; 1: R - 1 point-to-point pairs in one group         */
+    int32_t n_chunks;                                /* > 1: chunk launches (gnn_shard_iteration_split_rows), every chunk sent as soon as written */
+    const int32_t *chunk_begin;                      /* HOST [n_chunks + 1]: tile-aligned row bounds inside the nominal slice                  */
+    const int32_t *node_iota;                        /* DEVICE [n_nodes]: 0, 1, 2, ..                                                          */
+    int32_t emulated;                                /* != 0: world_size > 1 without a communicator (one GPU runs one rank's launches: timing) */
+    void *comm;                                      /* gnn_comm_create, or NULL at world size 1 / emulated                                    */
+} gnn_shard_loop_args_t;
+int gnn_shard_loop(const gnn_shard_loop_args_t *args);
+
 /* Keras Dropout / AlphaDropout (the `dropout_rate` / `dropout_pos` / `alphadropout` arguments of the reference MLP builder,
  * MLP.py:25-27, :60-66) in training mode, forward (backward = 0: y = the layer's output for input x) or backward (backward = 1:
  * y = d loss / d input for x = d loss / d output).  The keep mask is a pure function of (key, row, column) - a counter hash,

@@ -290,7 +290,8 @@ def composite_train_step(nodes, arcs, dim_node_label, type_mask, composite_adjac
     return dict(k=k, loss=float(L.detach()), y_pred=npy(out), state=npy(state), grads_state=out_grads,
                 grads_output=[npy(g) for g in grads[pos:]],
                 moving_state=[(npy(n.moving_mean), npy(n.moving_var)) if n.bn else None for n in nets],
-                moving_output=(npy(no.moving_mean), npy(no.moving_var)) if no.bn else None)
+                moving_output=(npy(no.moving_mean), npy(no.moving_var)) if no.bn else None,
+                kinks_state=[n.kinks for n in nets], kinks_output=no.kinks)
 
 
 def _homogeneous_forward(ns, no, X, lab, At, agg_arcs, d, max_iteration, state_threshold, state0, mask, focus, adjacency, NGt):

@@ -60,6 +60,19 @@ WORKER = textwrap.dedent('''
                 if threshold == 0.0:
                     prof = sl.profile_iteration(torch.from_numpy(s0).to(dev), reps=3)
                     assert prof['kernel_s'] > 0 and prof['iteration_s'] > 0
+                # the loop driven from native code (csrc/shard_loop.hpp: one C call for all iterations, the exchange over the RCCL C API on
+                # the library's own communicator - also at world size 1, where it is an all-gather of the one slice): the SAME BITS
+                if exchange in ('allgather', 'direct'):
+                    for chunks in ((1, 2) if overlap else (1,)):
+                        if chunks > 1 and sl.set_pipeline(chunks) != chunks: continue
+                        kp, stp, op = [t.clone() for t in sl.forward(torch.from_numpy(s0).to(dev))]
+                        sl.enable_native_loop(with_comm=True)
+                        kn, stn, on = sl.forward(torch.from_numpy(s0).to(dev))
+                        torch.cuda.synchronize()
+                        assert float(kn) == float(kp) == float(k64) and torch.equal(stn, stp) and torch.equal(on, op), (exchange, overlap, chunks)
+                        sl.native_loop = False
+                        report[f'{threshold}/{exchange}/{overlap}/native/{chunks}'] = 'bit-identical'
+                    sl.close()
     dist.barrier(); torch.cuda.synchronize()
     dist.destroy_process_group()
     if rank == 0: print('MULTI_OK ' + json.dumps(report))

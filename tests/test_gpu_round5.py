@@ -275,3 +275,165 @@ def test_train_step_at_the_size_and_depth_the_bench_times_it(request):
         assert e_loss <= 1e-5 and e_pred <= Y_PRED_BAR and e_state <= 1e-5 and max(mv) <= 1e-5, (e_loss, e_pred, e_state, mv)
         bad = [r_ for r_ in rows if not r_['ok']]
         assert not bad, bad
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the sharded loop driven from native code (csrc/shard_loop.hpp)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('overlap,chunks', [(False, 1), (True, 1), (True, 3)])
+def test_native_loop_issues_the_launches_of_the_interpreter_loop(overlap, chunks):
+    """`gnn_shard_loop` on 4 emulated ranks of one device: every rank's launches of an iteration come from ONE native call (own-range
+    partial sums, the halo kernel whole or in 3 chunk launches, the gate / flag words of the iteration) instead of from
+    `ShardedLoop`'s Python methods; the exchange between the ranks is the harness' slice copy in both runs.  Same k, same state bits, same
+    output bits, an early exit at the oracle's k.  (The exchange itself - RCCL's C API on the library's own communicator and stream -
+    runs in tests/test_gpu_multi.py at world size 1, and at 2 where two GPUs are visible.)"""
+    from gnnkeras_amd.distributed import ShardedLoop, partition
+    from gnnkeras_amd.synth import er_graph_slice
+    from test_gpu_parity import starter_nets
+    from oracle.harness import oracle_loop
+    N, E, d, R, K = 120_007, 1_200_000, 64, 4, 6
+    g = er_graph(N, E, aggregation_mode='average', seed=23)
+    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+    ns, no = starter_nets('n', d, scale=0.25)
+    model = GNNnodeBased(ns, no, d, K, 0.05)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
+    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    assert 1 < float(k64) < K
+    slices = [er_graph_slice(N, E, lo, hi, aggregation_mode='average', seed=23) for lo, hi in partition(N, R)[1]]
+    results = {}
+    for native in (False, True):
+        shards = [ShardedLoop(model, gs, r, R, 'cuda', overlap=overlap) for r, gs in enumerate(slices)]
+        for sl in shards:
+            assert sl.overlap == overlap
+            if chunks > 1: assert sl.pipeline_supported() and sl.set_pipeline(chunks) == chunks
+            if native: sl.enable_native_loop(emulated=True)
+            sl._load_state0(torch.from_numpy(s0).cuda()); sl._setup(); sl._initial_flags()
+        n = shards[0].plan.rows_per_slice * shards[0].SP
+        if overlap and not native:
+            for sl in shards: sl._partial(0)
+        for it in range(K):
+            for sl in shards:
+                if native: sl._native_iterations(it, 1)
+                elif not overlap: sl._iteration(it)
+                else:
+                    if chunks == 1: sl._iteration_split(it)
+                    else:
+                        for ci, (lo, hi) in enumerate(sl._chunk_rows): sl._iteration_split_rows(it, lo, hi, first=ci == 0)
+                    if it + 1 < K: sl._partial(it + 1)
+            for r, src in enumerate(shards):
+                piece = src.buf[(it + 1) & 1].view(-1)[r * n:(r + 1) * n]
+                for dst in shards:
+                    if dst is not src: dst.buf[(it + 1) & 1].view(-1)[r * n:(r + 1) * n].copy_(piece)
+        outs = [sl._output() for sl in shards]
+        torch.cuda.synchronize()
+        results[native] = ([float(o[0]) for o in outs], torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs]))
+        del shards
+    (kp, stp, op), (kn, stn, on) = results[False], results[True]
+    assert kp == kn == [float(k64)] * R
+    assert torch.equal(stp, stn) and torch.equal(op, on)
+    assert rel_err(stn.cpu().numpy(), st64) <= 1e-5 and rel_err(on.cpu().numpy(), o64) <= 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# VERDICT r4 item 4: heterogeneous models on the persistent small-graph training kernels
+# ----------------------------------------------------------------------------------------------------------------------
+def _typed_graphs(rng, sizes, dims, A, T, focus, mode, empty_type=None):
+    from gnnkeras_amd import CompositeGraphObject
+    out = []
+    for n, e in sizes:
+        pairs = set()
+        while len(pairs) < e:
+            a, b = rng.integers(0, n, 2)
+            if a != b: pairs.add((int(a), int(b)))
+        ids = np.array(sorted(pairs), dtype=float)
+        arcs = np.concatenate([ids, rng.normal(size=(e, A))], 1)
+        types = rng.integers(0, len(dims), n); types[:len(dims)] = np.arange(len(dims))
+        if empty_type is not None: types[types == empty_type] = (empty_type + 1) % len(dims)
+        tm = np.zeros((n, len(dims)), bool); tm[np.arange(n), types] = True
+        if focus == 'g':
+            tg = np.zeros((1, T)); tg[0, rng.integers(0, T)] = 1
+            kw = {}
+        else:
+            om = rng.random(n) < 0.8
+            tg = np.zeros((int(om.sum()), T)); tg[np.arange(len(tg)), rng.integers(0, T, len(tg))] = 1
+            kw = dict(output_mask=om)
+        out.append(CompositeGraphObject(nodes=rng.normal(size=(n, max(dims))), arcs=arcs, targets=tg, type_mask=tm, dim_node_label=dims,
+                                        focus=focus, aggregation_mode=mode, **kw))
+    return out
+
+
+@pytest.mark.parametrize('focus,D,bn,mode,act,n_graphs,empty', [
+    ('g', 32, True, 'composite_average', 'selu', 24, None), ('n', 16, True, 'average', 'tanh', 10, None), ('g', 64, False, 'sum', 'tanh', 30, None),
+    ('n', 10, True, 'composite_average', 'relu', 12, None), ('g', 32, True, 'average', 'tanh', 16, 1), ('n', 40, False, 'normalized', 'selu', 6, None)])
+def test_composite_small_graph_training_persistent_kernels_match_autograd(focus, D, bn, mode, act, n_graphs, empty):
+    """Heterogeneous batches (3 node types, per-type state networks with their own BatchNormalization; reference CompositeGNN.py:275-304)
+    through `gnn_train_step` on the PERSISTENT small-graph kernels: the nodes are walked in type order in tiles of one type each
+    (kernels_train_small.hpp: TypeTab), the statistics of network t span the tiles of type t, its gradient shares are summed per type, the
+    constant input columns (up to d_t + sum d + A = 29: more than one 32-column block with these widths only at d_t > 3 - see the second
+    label layout) go through the blocks loop.  k, loss, predictions, the state in the CALLER's node order, every gradient of every
+    network and the moving statistics against torch autograd in float64, and against the building-block orchestration.  State widths 16 / 32
+    / 64 and padded ones (10 -> 16, 40 -> 64), per-arc weights ('composite_average', 'normalized') and per-row scales, a type without a
+    single node, early exit left to the homogeneous tests."""
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased, CompositeGNNgraphBased
+    from gnnkeras_amd.Sequencers.GraphSequencers import CompositeMultiGraphSequencer
+    from oracle import torch_train
+    from oracle.harness import _np, _triple
+    from test_gpu_training import grad_rows, log_rows, Y_PRED_BAR
+    rng = np.random.default_rng(500 + D + n_graphs)
+    dims = (14, 8, 4) if D >= 32 else (4, 2, 3)                    # (14 + 26 + 2 = 42 constant columns for type 0: two blocks of 32)
+    A, T = 2, 2
+    gl = _typed_graphs(rng, [(int(rng.integers(12, 70)), int(rng.integers(30, 160))) for _ in range(n_graphs)], dims, A, T, focus, mode, empty)
+    x, y, sw = CompositeMultiGraphSequencer(gl, focus, mode, n_graphs, shuffle=False)[0]
+    inp, lay = get_inout_dims('state', dims, A, T, focus, D)
+    ns = [MLP(i, lay, act, 'lecun_normal', 'lecun_normal', rng=t, batch_normalization=bn) for t, i in enumerate(inp)]
+    for n_ in ns: n_.set_weights([a * 0.4 if a.ndim == 2 else a for a in n_.get_weights()])
+    inp, lay = get_inout_dims('output', dims, A, T, focus, D)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9, batch_normalization=bn)
+    if bn:
+        for n_ in ns + [no]:
+            w = n_.get_weights()
+            w[0] = rng.uniform(0.7, 1.3, w[0].shape).astype(np.float32); w[1] = rng.normal(0, 0.2, w[1].shape).astype(np.float32)
+            n_.set_weights(w)
+    K = 6
+    model = {'n': CompositeGNNnodeBased, 'g': CompositeGNNgraphBased}[focus](ns, no, D, K, 0.0)
+    model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+    N = x[0].shape[0]
+    s0 = rng.normal(0, 0.1, (N, D)).astype(np.float32)
+    if act == 'relu': s0 = np.abs(s0)
+    nodes, arcs, dnl, tmask, sm, om_, cas, adj, an, ng = x
+    mask = np.logical_and(_np(sm).reshape(-1), _np(om_).reshape(-1))
+    want = torch_train.composite_train_step(
+        _np(nodes), _np(arcs), _np(dnl).reshape(-1), _np(tmask).reshape(len(dims), -1), [_triple(c) for c in cas], _triple(adj), _triple(an),
+        _triple(ng), mask, net_state=[n_.spec() for n_ in ns], net_output=no.spec(), state_vect_dim=D, max_iteration=K, state_threshold=0.0,
+        focus=focus, state0=s0, y=_np(y), sample_weight=_np(sw), loss='categorical_crossentropy')
+    assert want['k'] == K
+    w_start = [[w.copy() for w in n_.get_weights()] for n_ in ns + [no]]
+    for native in (True, False):
+        for n_, w in zip(ns + [no], w_start): n_.set_weights(w)
+        tr = LoopTrainer(model); tr.use_native_step = native
+        res = tr.train_step(x, y, sw, state0=torch.from_numpy(s0).cuda(), apply=False)
+        assert res['k'] == K
+        assert abs(float(res['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))
+        e_pred, e_state = rel_err(res['y_pred'].cpu().numpy(), want['y_pred']), rel_err(res['state'].cpu().numpy(), want['state'])
+        allref = [r for g in want['grads_state'] for r in g] + want['grads_output']
+        scale = max(float(np.max(np.abs(r))) for r in allref)
+        rows = []
+        counts = _np(tmask).reshape(len(dims), -1).sum(1)
+        kinks_loop = [np.concatenate([kq[0] for kq in want['kinks_state']])]      # (a kink in ANY type's network reaches every network through the loop)
+        for t_, (g_, ref) in enumerate(zip(tr.gs, want['grads_state'])):
+            if counts[t_] == 0:                                          # a type without nodes: zero gradients, untouched moving statistics
+                assert all(float(t.abs().max()) == 0.0 for t in g_.gradients())
+                continue
+            rows += grad_rows(f'state{t_}', g_.gradients(), ref, bn, kinks_loop, scale, int(counts[t_]))
+        rows += grad_rows('output', tr.go.gradients(), want['grads_output'], bn, want['kinks_output'], scale, int(want['y_pred'].shape[0]))
+        log_rows(os.environ.get('PYTEST_CURRENT_TEST', ''), rows, native=native, y_pred=e_pred, n_nodes=N, k=K)
+        assert e_pred <= Y_PRED_BAR and e_state <= 1e-5, (native, e_pred, e_state)
+        bad = [r_ for r_ in rows if not r_['ok']]
+        assert not bad, (native, bad)
+        if bn:
+            for t_, (n_, mv) in enumerate(zip(ns, want['moving_state'])):
+                if counts[t_] == 0: continue
+                w = n_.get_weights()
+                assert rel_err(w[2], mv[0]) <= 1e-5 and rel_err(w[3], mv[1]) <= 1e-5, t_
+            w = no.get_weights()
+            assert rel_err(w[2], want['moving_output'][0]) <= 1e-5 and rel_err(w[3], want['moving_output'][1]) <= 1e-5

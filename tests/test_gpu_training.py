@@ -18,12 +18,14 @@ from oracle.harness import rel_err, _np, _triple
 pytestmark = pytest.mark.gpu
 CLS = {'n': GNNnodeBased, 'a': GNNarcBased, 'g': GNNgraphBased}
 GTOL = 2e-4                    # legacy bar (round 2 .. 4: one number for every tensor); still what LGNN's multi-network sums are held to
-# Per-tensor bars of train_step's gradients (round 5; what the kernels meet with margin - profiles/r05_train_tensor_errors.txt):
-BARS = {'gamma': 2e-4, 'beta': 2e-4, 'kernel': 2e-4, 'bias': 2e-4}
-KINK_UNIT = 16.0               # what ONE pre-activation on the other side of a relu / selu kink may move its unit's gradient entries, in units of
-                               # (largest gradient entry of the network) / (rows of the network call): measured 11 (profiles/r04_notes.txt 7: one
-                               # element, 40 000 rows, 2.4e-5 absolute against a largest entry of 0.085)
-Y_PRED_BAR = 5e-5              # training-mode predictions (batch statistics of thin columns amplify rounding; inference: 1e-5 in test_gpu_parity.py)
+# Per-tensor bars of train_step's gradients (round 5).  Measured on MI355X over the 184 comparisons of the training tests in which the
+# float64 oracle saw NO pre-activation near an activation kink (profiles/r05_train_tensor_errors.txt: 18 .. 1 000 000 rows, both
+# orchestrations, all three foci, fuzzed configurations): worst gamma 5e-7, beta 1.9e-6, kernel 4.9e-6, bias 4.3e-6 - the bars keep 4 x.
+BARS = {'gamma': 2e-5, 'beta': 2e-5, 'kernel': 2e-5, 'bias': 2e-5}
+KINK_UNIT = 16.0               # what ONE pre-activation on the other side of a relu / selu kink may move a network's gradient entries, in units of
+                               # (largest gradient entry of the network) / (rows of the network call).  Measured: 0.12 (125 rows), 1.3 (5 297
+                               # rows), 11 (40 000 rows, profiles/r04_notes.txt 7); n such elements add up like sqrt(n) (independent signs)
+Y_PRED_BAR = 1e-5              # training-mode predictions (worst measured 3.3e-6)
 
 
 def tensor_kinds(bn, n_layers):
@@ -35,31 +37,22 @@ def grad_rows(net_name, got, ref, bn, kinks, scale, M):
     the bar that applies and whether it holds.  An entry passes when |got - ref| <= bar x max(own largest, scale) + kink allowance.
     `kinks`: per Dense layer, per output unit, the float64 oracle's count of pre-activations within 1e-6 of a relu / selu kink (None: no
     allowance).  A float32 implementation may put such an element on the other side of zero, where act' differs by the jump: that is one
-    row's contribution with the wrong factor - not an arithmetic error of the kernels - and moves the unit's kernel column and bias
-    entry (and, through W, gamma / beta and everything below) by at most ~ |G| |x| ~ KINK_UNIT x scale / M per element.  The allowance is
-    counted, per unit, from the oracle; it is zero wherever the oracle saw no such element."""
+    row's contribution with the wrong factor - not an arithmetic error of the kernels.  It moves its unit's kernel column and bias entry
+    directly and, through dZ . W^T and the loop's earlier iterations, every other entry of the network a little: the allowance is
+    KINK_UNIT x sqrt(n) x scale / M for n such elements in the network's calls of this step - and ZERO when the oracle saw none, which is
+    the case in four comparisons out of five."""
     rows = []
     kinds = tensor_kinds(bn, (len(ref) - (2 if bn else 0)) // 2)
     total_kinks = 0 if kinks is None else int(sum(int(np.sum(kq)) for kq in kinks))
+    allowance = KINK_UNIT * float(np.sqrt(total_kinks)) * scale / max(M, 1)
     for kind, g, r in zip(kinds, got, ref):
         g = g.detach().cpu().numpy() if hasattr(g, 'detach') else np.asarray(g)
         diff = np.abs(g - r)
         own = max(float(np.max(np.abs(r))), 1e-30)
-        base = kind.rstrip('0123456789')
-        bar = BARS[base]
-        n_unit = np.zeros(diff.shape)
-        if kinks is not None and base in ('kernel', 'bias'):
-            layer = int(kind[len(base):])
-            above = sum(int(np.sum(kinks[l2])) for l2 in range(layer + 1, len(kinks)))     # (a kink further up reaches every entry below)
-            kq = np.asarray(kinks[layer], dtype=np.float64) + above
-            n_unit = np.broadcast_to(kq, diff.shape) if base == 'kernel' else kq
-        elif kinks is not None:
-            n_unit = np.full(diff.shape, float(total_kinks))
-        lim = bar * max(own, scale) + KINK_UNIT * n_unit * scale / max(M, 1)
-        ok = bool(np.all(diff <= lim))
-        clean = diff[n_unit == 0] if np.any(n_unit == 0) else np.zeros(1)
+        bar = BARS[kind.rstrip('0123456789')]
+        ok = bool(np.all(diff <= bar * max(own, scale) + allowance))
         rows.append(dict(net=net_name, tensor=kind, err_own=float(np.max(diff)) / own, err_scale=float(np.max(diff)) / max(scale, 1e-30),
-                         err_scale_off_kinks=float(np.max(clean)) / max(scale, 1e-30), kink_elements=int(np.max(n_unit)), bar=bar, ok=ok))
+                         kink_elements=total_kinks, kink_allowance_rel_scale=allowance / max(scale, 1e-30), bar=bar, ok=ok))
     return rows
 
 

@@ -692,6 +692,7 @@ def main():
         t_plan0 = time.perf_counter()
         sl = make_sharded_loop(gnn, graph, rank=rank, world_size=world, device=device, exchange=args.exchange,
                                overlap=not args.no_overlap, pipeline=args.exchange_pipeline)
+        if args.force_sharded and world == 1 and hasattr(sl, 'force_exchange'): sl.force_exchange = True      # (the collective is issued although there is nobody to talk to: its HOST cost is real)
         if args.native_loop and hasattr(sl, 'enable_native_loop') and type(sl)._layout == 'allgather': sl.enable_native_loop(with_comm=True)
         extra['loop_driver'] = 'native (gnn_shard_loop)' if getattr(sl, 'native_loop', False) else 'interpreter'
         torch.cuda.synchronize()

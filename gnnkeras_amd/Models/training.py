@@ -324,6 +324,16 @@ class LoopTrainer:
         keys the Dropout masks, so the backward recompute of call t sees the masks of the forward call t."""
         p, net = self.prim, ng.net
         mean = var = None
+        if M == 0 and self.dp is not None:
+            # data-parallel step, a network without a single row on THIS rank (a node type that lives on other shards only): the rank
+            # still takes part in the collective that forms the merged batch's statistics - with weight 0 - and keeps them for the
+            # moving averages and the backward sweep (every rank applies the same updates)
+            if ng.bn and stats is None:
+                z = p.zeros(net.input_dim)
+                mean, var = self.dp.combine_stats(z, z.clone(), getattr(ng, 'dp_kind', 'nodes'))
+            elif ng.bn:
+                mean, var = stats
+            return None, ((mean, var) if ng.bn else None)
         if ng.bn:
             if stats is not None:
                 mean, var = stats
@@ -337,7 +347,7 @@ class LoopTrainer:
                     else:
                         p.colstats(x, ridx, M, mean[off:off + w], var[off:off + w])
                     off += w
-                if self.dp is not None: mean, var = self.dp.combine_stats(mean, var, 'out' if ng is self.go else 'nodes')   # statistics of the MERGED batch
+                if self.dp is not None: mean, var = self.dp.combine_stats(mean, var, getattr(ng, 'dp_kind', 'out' if ng is self.go else 'nodes'))   # statistics of the MERGED batch
         drop0 = 0 in ng.drop
         if drop0:
             # Dropout in front of the first Dense (reference MLP.py:60-66 with position 0; BatchNormalization is inserted in front of it,
@@ -374,6 +384,18 @@ class LoopTrainer:
         """G = dL/d hs.out (overwritten). dx_requests: [(segment index, out view [M, width])]."""
         p, net = self.prim, ng.net
         acc = ng.touched
+        if M == 0 and self.dp is not None:
+            # (see _mlp_forward: no rows of this network here - zeros into the all-reduced sums, the same parameter gradients everywhere)
+            K, H = ng.W[0].shape
+            P, q = p.zeros(K, H), p.zeros(H)
+            mean, var = stats if stats is not None else (None, None)
+            m1 = m2 = None
+            if ng.bn: m1, m2 = p.new(K), p.new(K)
+            self.dp.all_reduce_sum(P, q)
+            p.first_layer_param_grads(P, q, ng.W[0], ng.bn_params, mean, var, self.dp.total_rows(getattr(ng, 'dp_kind', 'nodes')), ng.dW[0], ng.db[0],
+                                      ng.dgamma, ng.dbeta, m1, m2, acc, centered=bool(ng.bn and mean is not None))
+            ng.touched = True
+            return
 
         def through_dropout(q, G_):                                # d loss / d (input of the Dropout layers at position q)
             for rate, index in reversed(ng.drop.get(q, [])):
@@ -428,7 +450,7 @@ class LoopTrainer:
             # P = X^T dZ and q = colsum(dZ) over the rows of EVERY shard: the first layer's parameter gradients and the BatchNorm
             # input-gradient moments m1 / m2 (means over all rows of the merged batch) follow from the sums
             self.dp.all_reduce_sum(P, q)
-            M_all = self.dp.total_rows('out' if ng is self.go else 'nodes')
+            M_all = self.dp.total_rows(getattr(ng, 'dp_kind', 'out' if ng is self.go else 'nodes'))
         p.first_layer_param_grads(P, q, ng.W[0], ng.bn_params, mean, var, M_all, ng.dW[0], ng.db[0], ng.dgamma, ng.dbeta,
                                   m1, m2, acc, centered=centred)
         ng.touched = True
@@ -471,8 +493,8 @@ class LoopTrainer:
         for n_ in nets_s: n_.to(dev)
         m.net_output.to(dev)
         gs, go = [_NetGrads(n_, p) for n_ in nets_s], _NetGrads(m.net_output, p)
-        for i, g_ in enumerate(gs): g_.net_id = i
-        go.net_id = 1000
+        for i, g_ in enumerate(gs): g_.net_id, g_.dp_kind = i, (f'type{i}' if composite else 'nodes')      # (dp_kind: whose rows the network sees, for the data-parallel counts)
+        go.net_id, go.dp_kind = 1000, 'out'
         # Dropout masks of this step: `seed` when given (reproducible steps, tests), else a per-model step counter
         m._dropout_step = getattr(m, '_dropout_step', 0) + 1
         self.drop_seed = tp.drop_seed = _mix32(0x5EED, int(seed)) if seed is not None else _mix32(id(m) & 0xFFFFFFFF, m._dropout_step)
@@ -564,9 +586,9 @@ class LoopTrainer:
         flags = torch.zeros(K_it + 2, dtype=torch.int32, device=dev)
         k_dev = torch.zeros((), dtype=torch.float32, device=dev)
         dp = self.dp
-        if dp is not None:
-            if composite: raise NotImplementedError('data-parallel training covers homogeneous models')
-            dp.begin_step(N, M)
+        if dp is not None: dp.begin_step(N, M, type_counts=counts if composite else None)
+        # rows of every network over ALL shards (data parallel: a type may have rows on other ranks only)
+        all_counts = tp.all_counts = [dp.total_rows(gs[ty].dp_kind) for ty in range(T_types)] if dp is not None else list(counts)
         p.converged_gated(states[0], None, m.state_threshold, None, flags[0:1], None, 0.0)
         if dp is not None: dp.any_flag(flags[0:1])                    # `reduce_any` over the nodes of the merged batch (GNN.py:212)
         stats_t = tp.stats_t = []
@@ -574,11 +596,12 @@ class LoopTrainer:
             p.aggregate(adj, states[t], S, agg)
             st_t = []
             for ty in range(T_types):
-                if counts[ty] == 0:
+                if all_counts[ty] == 0:
                     st_t.append(None); continue
                 segs = state_segs(t, ty)[0]
                 hs, st = self._mlp_forward(gs[ty], segs, counts[ty], const_stats=const_stats[ty], call=t)
-                if rows[ty] is None: states[t + 1].copy_(hs.out)
+                if hs is None: pass                                  # (no rows of this type on this rank)
+                elif rows[ty] is None: states[t + 1].copy_(hs.out)
                 else: states[t + 1].index_copy_(0, rows_long[ty], hs.out)
                 st_t.append(st)
             stats_t.append(st_t)
@@ -586,7 +609,7 @@ class LoopTrainer:
             if dp is not None: dp.any_flag(flags[t + 1:t + 2])
         k = tp.k = int(float(k_dev))                                # the one host synchronisation of the step
         for ty in range(T_types):                                   # k moving-average updates, applied in order (closed form)
-            if gs[ty].bn and k > 0 and counts[ty] > 0:
+            if gs[ty].bn and k > 0 and all_counts[ty] > 0:
                 mm, mv = gs[ty].moving
                 wts = torch.tensor([BN_MOMENTUM ** (k - 1 - t) * (1 - BN_MOMENTUM) for t in range(k)], device=dev)
                 mm.mul_(BN_MOMENTUM ** k).add_((torch.stack([stats_t[t][ty][0] for t in range(k)]) * wts[:, None]).sum(0))
@@ -700,8 +723,11 @@ class LoopTrainer:
         for t in range(k - 1, -1, -1):
             p.aggregate(tp.adj, tp.states[t], S, tp.agg)
             for ty in range(tp.T_types):
-                if counts[ty] == 0: continue
+                if tp.all_counts[ty] == 0: continue
                 segs, i_state, i_agg, i_lab, i_alab = tp.state_segs(t, ty)
+                if counts[ty] == 0:                                  # data parallel: the type's rows live on other ranks (zeros into the sums)
+                    self._mlp_backward(gs[ty], segs, None, None, 0, tp.stats_t[t][ty], None)
+                    continue
                 hs, _ = self._mlp_forward(gs[ty], segs, counts[ty], stats=tp.stats_t[t][ty], call=t)
                 if rows[ty] is None:
                     req = [(i_state, dx_s), (i_agg, dx_a)]

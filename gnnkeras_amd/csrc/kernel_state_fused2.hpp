@@ -62,6 +62,7 @@ struct Fused2Args {
     const float *agg_init;                         // k_state_fused4<.., INIT = true>: [n_local, SP] partial neighbour sums (un-scaled)
                                                    // of the arcs this launch does NOT walk (own-range arcs, summed while the
                                                    // exchange was in flight: distributed.py overlap); nullptr otherwise
+    const void *hdr; void *hdr_write;              // k_state_fused4<.., HDR = true> (experiment builds only): the first-job header / where to write it
 };
 
 // name of the state-transition kernel the calling thread launched last (gnn_last_kernel_name(): bench.py's roofline record)

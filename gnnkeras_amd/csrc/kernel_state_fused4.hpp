@@ -31,12 +31,13 @@ namespace gnn {
 
 constexpr int XC_K = 32;                          // constant-input columns of the XC variant (padded; one of them is the bias' 1)
 
-template <int SP, int NC = 4, bool L2 = false, bool XC = false>
+template <int SP, int NC = 4, bool L2 = false, bool XC = false, int VPL = 1>
 struct Fused4Cfg {
     static constexpr int NW = 16, NT = 64 * NW;
     static constexpr int NCONS = NC;                 // matrix waves (wave ids 0..NC-1)
     static constexpr int NPROD = NW - NCONS;         // gather waves
-    static constexpr int LPR = SP / 4;               // lanes per node row (16 B each)
+    static constexpr int LPR = SP / (4 * VPL);       // lanes per node row (VPL 16-byte pieces each; VPL = 2: the C3 experiment of round 5,
+                                                     // twice the nodes per gather wave and trip - profiles/r05_c3_experiments.txt)
     static constexpr int RPWV = 64 / LPR;            // rows a gather wave fills per tile
     static constexpr int PPT = 16 / RPWV;            // gather waves per 16-row tile
     static constexpr int IPL = 16 / LPR;             // source ids held per lane (16 per node and chunk)
@@ -95,14 +96,14 @@ __device__ __forceinline__ int f4_ld_acquire(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int SP, bool HAS_W, int DEPTH, int NC, bool L2, bool INIT = false, bool XC = false>
+template <int SP, bool HAS_W, int DEPTH, int NC, bool L2, bool INIT = false, bool XC = false, int VPL = 1, bool HDR = false>
 __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     // The gate word(s), the W1 fill and the gather waves' first CSR row are all fetched before anything is waited for:
     // three dependent round trips at the head of every launch become one.  Nothing is written to global memory before
     // the gate has been checked (after the fill's barrier).
     int open = a.gate == nullptr;
     for (int i = 0; i < a.n_gate; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
-    using Cfg = Fused4Cfg<SP, NC, L2, XC>;
+    using Cfg = Fused4Cfg<SP, NC, L2, XC, VPL>;
     constexpr int NT = Cfg::NT, LPR = Cfg::LPR, IPL = Cfg::IPL, LDX = Cfg::LDX, LDW = Cfg::LDW, NS = Cfg::NS;
 #ifndef GNN_F4_SPIN_MAX
 #define GNN_F4_SPIN_MAX (1 << 22)
@@ -162,6 +163,13 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     for (int u = 0; u < IPL; ++u) { idsA[u] = 0; wsA[u] = 0.0f; }
     if (wave >= Cfg::NCONS) {
         jA = node_of(job_m(p)); jB = node_of(job_m(p + Cfg::NPROD));
+        if (HDR && a.hdr) {
+            // experiment: the first job's row pointers and first source ids of every lane from a per-launch-geometry
+            // header (written once per graph by this kernel itself, below): ONE load instead of the dependent pair rowptr -> src
+            const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(buf_rsrc(a.hdr), (int)((((unsigned)blockIdx.x * Cfg::NPROD + (unsigned)p) * 64u + (unsigned)lane) * 16u), 0, 0);
+            begA = (int)h[0]; endA = (int)h[1]; idsA[0] = (int)h[2];
+            if (IPL > 1) idsA[IPL > 1 ? 1 : 0] = (int)h[3];
+        } else {
         begA = buf_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA : BUF_OFF);
         endA = buf_ld_i32(r_rowptr, jA >= 0 ? 4u * (unsigned)jA + 4u : BUF_OFF);
 #pragma unroll
@@ -170,7 +178,13 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
             idsA[u] = buf_ld_i32(r_src, e < endA ? 4u * (unsigned)e : BUF_OFF);
             wsA[u] = HAS_W ? buf_ld_f32(r_w, e < endA ? 4u * (unsigned)e : BUF_OFF) : 0.0f;
         }
+        }
+        if (HDR && a.hdr_write) {       // the header-building launch: every gather lane leaves its first job's record and the launch ends
+            u32x4 h = {(unsigned)begA, (unsigned)endA, (unsigned)idsA[0], (unsigned)idsA[IPL > 1 ? 1 : 0]};
+            __builtin_amdgcn_raw_buffer_store_b128(h, buf_rsrc(a.hdr_write), (int)((((unsigned)blockIdx.x * Cfg::NPROD + (unsigned)p) * 64u + (unsigned)lane) * 16u), 0, 0);
+        }
     }
+    if (HDR && a.hdr_write) return;
 
     // rows 0 .. SP-1: state ; SP .. 2SP-1: agg ; (XC) 2SP .. 2SP+31: the constant inputs' folded weights, the bias row, zeros
     // (Round 3 tried leaving this fill to the matrix waves alone, the gather waves going straight to their first job after a bare
@@ -240,9 +254,13 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
             const int endB = buf_ld_i32(r_rowptr, jB >= 0 ? 4u * (unsigned)jB + 4u : BUF_OFF);
             const int jC = node_of(job_m(n + 2 * Cfg::NPROD));
             const float scl = buf_ld_f32(r_scale, j >= 0 ? 4u * (unsigned)j : BUF_OFF);
-            const f32x4 own = buf_ld_f32x4(r_state, j >= 0 ? (unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (INIT) acc = buf_ld_f32x4(r_init, j >= 0 ? (unsigned)j * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);   // sum of the arcs walked earlier
+            f32x4 own[VPL], acc[VPL];
+#pragma unroll
+            for (int x = 0; x < VPL; ++x) {
+                own[x] = buf_ld_f32x4(r_state, j >= 0 ? (unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * (unsigned)(VPL * l4 + x) : BUF_OFF);
+                acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (INIT) acc[x] = buf_ld_f32x4(r_init, j >= 0 ? (unsigned)j * (unsigned)(SP * 4) + 16u * (unsigned)(VPL * l4 + x) : BUF_OFF);   // sum of the arcs walked earlier
+            }
             int idsB[IPL]; float wsB[IPL];
             int rem = endA - begA, eb = begA;
             int idc[IPL]; float wsc[IPL];
@@ -254,11 +272,13 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
 #pragma unroll
                 for (int s0 = 0; s0 < 16; s0 += DEPTH) {          // DEPTH rows in flight, summed in ascending-source order
                     if (s0 > 0 && !__any(s0 < rem)) break;
-                    f32x4 v[DEPTH];
+                    f32x4 v[DEPTH][VPL];
 #pragma unroll
                     for (int i = 0; i < DEPTH; ++i) {
                         const unsigned sid = (unsigned)__shfl(idc[(s0 + i) / LPR], (s0 + i) % LPR, LPR);
-                        v[i] = buf_ld_f32x4(r_state, s0 + i < rem ? sid * (unsigned)(SP * 4) + 16u * l4 : BUF_OFF);
+#pragma unroll
+                        for (int x = 0; x < VPL; ++x)
+                            v[i][x] = buf_ld_f32x4(r_state, s0 + i < rem ? sid * (unsigned)(SP * 4) + 16u * (unsigned)(VPL * l4 + x) : BUF_OFF);
                     }
                     if (s0 == 0 && first) {        // the next job's row pointers have landed by now: fetch its first 16 source ids
 #pragma unroll
@@ -270,8 +290,12 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                     }
 #pragma unroll
                     for (int i = 0; i < DEPTH; ++i) {
-                        if (HAS_W) acc += __shfl(wsc[(s0 + i) / LPR], (s0 + i) % LPR, LPR) * v[i];
-                        else acc += v[i];
+                        const float wv = HAS_W ? __shfl(wsc[(s0 + i) / LPR], (s0 + i) % LPR, LPR) : 1.0f;
+#pragma unroll
+                        for (int x = 0; x < VPL; ++x) {
+                            if (HAS_W) acc[x] += wv * v[i][x];
+                            else acc[x] += v[i][x];
+                        }
                     }
                 }
                 first = false;
@@ -284,7 +308,10 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                     wsc[u] = HAS_W ? buf_ld_f32(r_w, e < endA ? 4u * (unsigned)e : BUF_OFF) : 0.0f;
                 }
             }
-            if (has_scale) acc *= scl;
+            if (has_scale) {
+#pragma unroll
+                for (int x = 0; x < VPL; ++x) acc[x] *= scl;
+            }
             // rotate: A <- B <- C
             jA = jB; begA = begB; endA = endB; jB = jC;
 #pragma unroll
@@ -306,11 +333,14 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
 #ifdef GNN_F4_PROFILE
             if (lane == 0) atomicAdd(&g_f4_prof[1], f4_now() - tg_);
 #endif
-            float *xr = Xs + s * Cfg::SLOT + row * LDX + 4 * l4;     // rows are 8-B aligned: two b64 stores each
-            *reinterpret_cast<float2 *>(xr) = make_float2(own[0], own[1]);
-            *reinterpret_cast<float2 *>(xr + 2) = make_float2(own[2], own[3]);
-            *reinterpret_cast<float2 *>(xr + SP) = make_float2(acc[0], acc[1]);
-            *reinterpret_cast<float2 *>(xr + SP + 2) = make_float2(acc[2], acc[3]);
+#pragma unroll
+            for (int x = 0; x < VPL; ++x) {
+                float *xr = Xs + s * Cfg::SLOT + row * LDX + 4 * (VPL * l4 + x);     // rows are 8-B aligned: two b64 stores each
+                *reinterpret_cast<float2 *>(xr) = make_float2(own[x][0], own[x][1]);
+                *reinterpret_cast<float2 *>(xr + 2) = make_float2(own[x][2], own[x][3]);
+                *reinterpret_cast<float2 *>(xr + SP) = make_float2(acc[x][0], acc[x][1]);
+                *reinterpret_cast<float2 *>(xr + SP + 2) = make_float2(acc[x][2], acc[x][3]);
+            }
             if (l4 == 0) Xs[s * Cfg::SLOT + row * LDX + 2 * SP] = __int_as_float(j);      // the row's pad words carry its node id
             if (lane == 0) __hip_atomic_fetch_add(&fill[s], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (n == p && p == 0 && lane == 0) F4_STAMP(2);
@@ -522,12 +552,12 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     }
 }
 
-template <int SP, bool HAS_W, int DEPTH, bool L2 = false, int NC = 4, bool INIT = false, bool XC = false>
+template <int SP, bool HAS_W, int DEPTH, bool L2 = false, int NC = 4, bool INIT = false, bool XC = false, int VPL = 1, bool HDR = false>
 int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
-    using Cfg = Fused4Cfg<SP, NC, L2, XC>;
+    using Cfg = Fused4Cfg<SP, NC, L2, XC, VPL>;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC, VPL, HDR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
         attr = true;
     }
@@ -552,8 +582,24 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0) return 0;
-    GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s,%s,%s>", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? "true" : "false", XC ? "true" : "false");
-    k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
+    if (HDR) {
+        // experiment: the first-job header of this (graph, launch geometry), written once by a launch of the kernel itself and kept
+        static const void *key_rowptr = nullptr, *key_src = nullptr; static int key_grid = 0; static void *hdr = nullptr; static size_t hdr_bytes = 0;
+        const size_t need = (size_t)grid * Cfg::NPROD * 64 * 16;
+        if (need > hdr_bytes) { if (hdr) (void)hipFree(hdr); if (hipMalloc(&hdr, need) != hipSuccess) return 1; hdr_bytes = need; key_rowptr = nullptr; }
+        if (key_rowptr != fa.rowptr || key_src != fa.src || key_grid != grid) {
+            Fused2Args fb = fa;
+            fb.hdr = nullptr; fb.hdr_write = hdr; fb.gate = nullptr; fb.n_gate = 0;
+            k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC, VPL, HDR><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fb);
+            key_rowptr = fa.rowptr; key_src = fa.src; key_grid = grid;
+        }
+        fa.hdr = hdr; fa.hdr_write = nullptr;
+    }
+    if (VPL == 1 && !HDR)
+        GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s,%s,%s>", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? "true" : "false", XC ? "true" : "false");
+    else
+        GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s,%s,%s,%d,%s>", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? "true" : "false", XC ? "true" : "false", VPL, HDR ? "true" : "false");
+    k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC, VPL, HDR><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -563,6 +609,24 @@ inline int launch_fused4(Fused2Args &fa, int SP, int depth, int n_cu, hipStream_
         if (depth == 2) return launch_fused4_one<64, false, 4, false, 2>(fa, n_cu, st);
         if (depth == 3) return launch_fused4_one<64, false, 4, false, 3>(fa, n_cu, st);
         if (depth == 6) return launch_fused4_one<64, false, 4, false, 6>(fa, n_cu, st);
+    }
+#endif
+#ifdef GNN_F4_EXPERIMENT
+    // C3 experiments of round 5 (library built with -DGNN_F4_EXPERIMENT: `make c3exp`), GNN_F4_VARIANT = bit 0: first-job
+    // header, bit 1: two 16-byte pieces per lane (8 lanes per node row: twice the nodes per gather wave and trip) at 2 rows in flight,
+    // bit 2: the same at 4 rows in flight.  Homogeneous one-layer models at SP = 64 on the C form (what C3 runs).
+    if (SP == 64 && !fa.w && !fa.agg_init && !fa.tp[0].W2 && !fa.Xc && fa.n_types == 1 && !fa.tp[0].rows) {
+        static int variant = -1;
+        if (variant < 0) { const char *e = getenv("GNN_F4_VARIANT"); variant = e ? atoi(e) : 0; }
+        switch (variant) {
+            case 1: return launch_fused4_one<64, false, 4, false, 4, false, false, 1, true>(fa, n_cu, st);
+            case 2: return launch_fused4_one<64, false, 2, false, 4, false, false, 2, false>(fa, n_cu, st);
+            case 3: return launch_fused4_one<64, false, 2, false, 4, false, false, 2, true>(fa, n_cu, st);
+            case 4: return launch_fused4_one<64, false, 4, false, 4, false, false, 2, false>(fa, n_cu, st);
+            case 5: return launch_fused4_one<64, false, 4, false, 4, false, false, 2, true>(fa, n_cu, st);
+            case 8: return launch_fused4_one<64, false, 2>(fa, n_cu, st);         // (the shipping lane layout at 2 rows in flight)
+            default: break;
+        }
     }
 #endif
 #define F4_CASE(SPV)                                                                                                  \

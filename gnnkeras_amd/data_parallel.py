@@ -38,14 +38,17 @@ class DPContext:
         self._counts = {}
 
     # ---- row counts ------------------------------------------------------------------------------------------------------
-    def begin_step(self, n_nodes: int, n_out: int):
-        """Every rank learns every shard's node / output-row counts (one small all-gather, one host read)."""
+    def begin_step(self, n_nodes: int, n_out: int, type_counts=None):
+        """Every rank learns every shard's node / output-row counts (one small all-gather, one host read).  `type_counts`
+        (heterogeneous models): the shard's nodes per type - a type may have no node at all on some ranks, its network then takes part
+        in the collectives with weight zero (Models/training.py)."""
         dev = self._device
-        mine = torch.tensor([n_nodes, n_out], dtype=torch.int64, device=dev)
+        mine = torch.tensor([n_nodes, n_out] + [int(c) for c in (type_counts or [])], dtype=torch.int64, device=dev)
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine, group=self.group)
         c = torch.stack(parts).cpu().numpy()
         self._counts = {'nodes': c[:, 0].tolist(), 'out': c[:, 1].tolist()}
+        for t in range(len(type_counts or [])): self._counts[f'type{t}'] = c[:, 2 + t].tolist()
         if min(self._counts['nodes']) == 0 or min(self._counts['out']) == 0:
             raise ValueError('data-parallel step: a rank holds no nodes / no output rows (fewer graphs than ranks, or a shard with '
                              f'every node masked out): {self._counts}')
@@ -71,7 +74,7 @@ class DPContext:
         dist.all_gather(parts, mine, group=self.group)
         allp = torch.stack(parts).to(torch.float64)                          # [R, 2K]
         n = torch.tensor(self._counts[kind], dtype=torch.float64, device=mine.device)[:, None]
-        tot = n.sum()
+        tot = n.sum().clamp(min=1.0)
         mu = (n * allp[:, :K]).sum(0) / tot
         va = (n * (allp[:, K:] + (allp[:, :K] - mu) ** 2)).sum(0) / tot
         return mu.to(torch.float32), va.to(torch.float32)
@@ -110,11 +113,8 @@ class DataParallel:
     BatchNormalization moving statistics): not the reference's step on the merged batch, an order of magnitude less device time."""
 
     def __init__(self, model, group=None, exact: bool = True):
-        if isinstance(getattr(model, 'net_state', None), (list, tuple)) and exact:
-            # (the exact step all-gathers per-network batch statistics; a node type may have no rows on some shard: the replica step -
-            # the in-library composite step per shard, one weighted all-reduce - handles that, the exact one is not built for it)
-            raise NotImplementedError('exact data-parallel training covers homogeneous models; heterogeneous models train with '
-                                      'DataParallel(model, exact=False) (the in-library step on every shard + one all-reduce)')
+        # (heterogeneous models - reference CompositeGNN.py:275-304 - train in both modes since round 5: the exact step all-gathers the
+        # batch statistics of every type's network with the shard's row count of that type as weight, zero included)
         self.exact = bool(exact)
         self.model, self.group = model, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)

@@ -537,6 +537,7 @@ class ShardedLoop:
         if self.device.type == 'cuda': torch.cuda.synchronize(self.device)
 
     # ---- the loop driven from native code (csrc/shard_loop.hpp) ------------------------------------------------------
+    force_exchange = False            # True: issue the collective even at world size 1 (what it costs the HOST can then be measured on one GPU)
     native_loop = False               # True: forward() issues ALL iterations with one `gnn_shard_loop` call (enable_native_loop)
     _comm = None
 
@@ -580,7 +581,7 @@ class ShardedLoop:
         """One iteration's launches without the exchange although a communicator exists (profile_iteration's `kernel_s`)."""
         comm, self._comm, em = self._comm, None, getattr(self, '_emulated', False)
         self._emulated = True
-        try: self._native_iterations(0, 1)
+        try: self._native_iterations()
         finally: self._comm, self._emulated = comm, em
 
     def _native_iterations(self, first_iteration: int = 0, n_iterations: int = -1):
@@ -628,13 +629,15 @@ class ShardedLoop:
         link) or R - 1 concurrent point-to-point pairs ('direct': every peer's slice travels over its own link of the fully
         connected xGMI mesh - SURVEY §8e's one-hop all-gather).  `async_op`: returns work handle(s); `_exchange_finish` makes
         the current stream wait for them."""
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force_exchange:
             return None
         p = self.plan
         flat = buf.view(-1)
         n = p.rows_per_slice * self.SP
         if self.transport == 'direct':
-            works = dist.batch_isend_irecv(self._p2p_ops(buf, 0, p.rows_per_slice))
+            ops = self._p2p_ops(buf, 0, p.rows_per_slice)
+            if not ops: return None                              # (one rank: nobody to pair with)
+            works = dist.batch_isend_irecv(ops)
             if async_op: return works
             for w in works: w.wait()
             return None
@@ -730,8 +733,11 @@ class ShardedLoop:
                 torch.cuda.synchronize(self.device)
                 return dt
 
+            K_loop = max(int(m.max_iteration), 1)
+            per_call = K_loop if self.native_loop else 1           # (the native driver is timed over its whole loop: K iterations per call)
+
             def kernels():
-                if self.native_loop: return self._native_iterations(0, 1) if not getattr(self, '_comm', None) else self._kernels_only()
+                if self.native_loop: return self._native_iterations() if not getattr(self, '_comm', None) else self._kernels_only()
                 if self.overlap and self.pipeline_chunks > 1:
                     self._partial(0)
                     for ci, (lo, hi) in enumerate(self._chunk_rows): self._iteration_split_rows(0, lo, hi, first=ci == 0)
@@ -742,7 +748,7 @@ class ShardedLoop:
                 self._exchange_finish(self._exchange(self.buf[1], 0, async_op=True), self.buf[1], 0)
 
             def both():
-                if self.native_loop: return self._native_iterations(0, 1)
+                if self.native_loop: return self._native_iterations()
                 if self.overlap and self.pipeline_chunks > 1:
                     self._pipelined_iteration(0, True)
                 elif self.overlap:
@@ -756,12 +762,12 @@ class ShardedLoop:
             if self.overlap: self._partial(0)
             if not collective:
                 kernels()                                          # warm-up
-                t['kernel_s'] = timed(kernels)
-                t['host_issue_s'] = host_issue(kernels)
+                t['kernel_s'] = timed(kernels) / per_call
+                t['host_issue_s'] = host_issue(kernels) / per_call
                 return t
             kernels(); exchange()                                  # warm-up
-            t['kernel_s'], t['exchange_s'], t['iteration_s'] = timed(kernels), timed(exchange), timed(both)
-            t['host_issue_s'] = host_issue(both)
+            t['kernel_s'], t['exchange_s'], t['iteration_s'] = timed(kernels) / per_call, timed(exchange), timed(both) / per_call
+            t['host_issue_s'] = host_issue(both) / per_call
         finally:
             m.native_flags = flags
             self.args.flags = flags

@@ -360,3 +360,88 @@ def test_replica_mode_averages_the_single_process_steps_of_the_shards(world):
         for a, b in zip(grads, want_g): assert np.max(np.abs(a - b)) <= 1e-6 * max(1.0, np.max(np.abs(b)))
         for a, b in zip(moving, want_mv): assert np.max(np.abs(a - b)) <= 1e-6
     for a, b in zip(res[0][3], res[-1][3]): assert np.array_equal(a, b)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# heterogeneous models (reference CompositeGNN.py:275-304) in the exact mode - round 5
+# ----------------------------------------------------------------------------------------------------------------------
+def _composite_problem():
+    """Five typed graphs (3 node types; type 2 lives in the LAST graph only: with 2 or 3 ranks some shards have no node of it), one
+    state network per type with BatchNormalization, graph focus."""
+    from gnnkeras_amd import CompositeGraphObject
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNgraphBased
+    from gnnkeras_amd.Sequencers.GraphSequencers import CompositeMultiGraphSequencer
+    rng = np.random.default_rng(11)
+    dims, A, d = (3, 2, 2), 2, 5
+    gl = []
+    for gi in range(5):
+        n = int(rng.integers(5, 9))
+        src = np.concatenate([np.arange(n), rng.integers(0, n, 2 * n)]); dst = np.concatenate([(np.arange(n) + 1) % n, rng.integers(0, n, 2 * n)])
+        ids = np.unique(np.stack([src, dst], 1)[src != dst], axis=0)
+        arcs = np.concatenate([ids, rng.normal(size=(len(ids), A)).round(2)], axis=1)
+        types = rng.integers(0, 2, n); types[:2] = [0, 1]
+        if gi == 4: types[2:4] = 2
+        tm = np.zeros((n, 3), bool); tm[np.arange(n), types] = True
+        gl.append(CompositeGraphObject(nodes=rng.normal(size=(n, 3)), arcs=arcs, targets=np.eye(2)[rng.integers(0, 2, 1)], type_mask=tm,
+                                       dim_node_label=dims, focus='g', aggregation_mode='average', sample_weight=rng.uniform(0.5, 1.5)))
+    inp, lay = get_inout_dims('state', dims, A, 2, 'g', d)
+    ns = [MLP(i, lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=t, device='cpu') for t, i in enumerate(inp)]
+    for n_ in ns: n_.set_weights([w * 0.6 if w.ndim == 2 else (w + 0.1 * rng.normal(size=w.shape)).astype(np.float32) for w in n_.get_weights()])
+    inp, lay = get_inout_dims('output', dims, A, 2, 'g', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9, device='cpu')
+    model = CompositeGNNgraphBased(ns, no, d, 4, 0.0)
+    model.compile(optimizer=_SGD(0.05), loss='categorical_crossentropy', metrics=['accuracy'])
+    seq = CompositeMultiGraphSequencer(gl, 'g', 'average', 5, shuffle=False, device='cpu')
+    s0 = rng.normal(0, 0.1, (seq[0][0][0].shape[0], d)).astype(np.float32)
+    return model, seq, s0, gl
+
+
+def _composite_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        TR.LoopTrainer.prim_cls = NumpyPrim
+        TR.LoopTrainer.use_native_step = False
+        nat.require_device = lambda t, name: None
+        from gnnkeras_amd.data_parallel import DataParallel
+        model, seq, s0, gl = _composite_problem()
+        dpm = DataParallel(model, exact=True)
+        shard = dpm.shard(seq, 0)
+        sizes = [g.nodes.shape[0] for g in gl]
+        lo, hi = len(gl) * rank // world, len(gl) * (rank + 1) // world
+        n0 = sum(sizes[:lo]); n1 = n0 + sum(sizes[lo:hi])
+        res = dpm.train_step(shard, state0=torch.from_numpy(s0[n0:n1]), apply=False)
+        tr = dpm._trainer
+        grads = [g.numpy().copy() for gs_ in tr.gs for g in gs_.gradients()] + [g.numpy().copy() for g in tr.go.gradients()]
+        moving = [w.copy() for n_ in model.net_state for w in n_.get_weights()[2:4]] + [w.copy() for w in model.net_output.get_weights()[2:4]]
+        q.put((rank, res['k'], float(res['loss']), grads, moving))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_exact_data_parallel_step_of_a_heterogeneous_model(world):
+    """`DataParallel(composite model)` (exact mode; refused through round 4): every rank trains on its shard of whole typed graphs, the
+    statistics of every TYPE's network are combined over the ranks with the shard's row count of that type as weight - a rank without a
+    single node of a type takes part with weight zero - and gradients, loss, k and the moving statistics are those of the
+    single-process step on the whole batch, on every rank."""
+    model, seq, s0, _ = _composite_problem()
+    tr = TR.LoopTrainer(model)
+    x, y, sw = seq[0]
+    ref = tr.train_step(x, y, sw, state0=torch.from_numpy(s0), apply=False)
+    ref_g = [g.numpy().copy() for gs_ in tr.gs for g in gs_.gradients()] + [g.numpy().copy() for g in tr.go.gradients()]
+    ref_mv = [w.copy() for n_ in model.net_state for w in n_.get_weights()[2:4]] + [w.copy() for w in model.net_output.get_weights()[2:4]]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 11 + 977 * world) % 1000
+    procs = [ctx.Process(target=_composite_worker, args=(r, world, port, q)) for r in range(world)]
+    for p_ in procs: p_.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p_ in procs:
+        p_.join(60)
+        assert p_.exitcode == 0
+    for rank, k, loss, grads, moving in res:
+        assert k == ref['k'] and abs(loss - float(ref['loss'])) <= 1e-6
+        assert len(grads) == len(ref_g)
+        for a, b in zip(grads, ref_g): assert np.max(np.abs(a - b)) <= 1e-6 * max(1.0, np.max(np.abs(b))), rank
+        for a, b in zip(moving, ref_mv): assert np.max(np.abs(a - b)) <= 1e-6, rank

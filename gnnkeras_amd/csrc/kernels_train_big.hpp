@@ -639,6 +639,10 @@ struct TrainBwdArgs {
     const float *gamma, *mean, *var, *m1, *m2; float eps;               // NULL gamma: no BatchNormalization
     const float *agg_row_scale;           // [M] or NULL
     float *dx; int ld_dx;                 // [M, 2 S]
+    int defer_state_bn;                   // != 0 (with BatchNormalization): the STATE half leaves as Ac dy only - the rest of its BatchNorm input
+                                          // gradient, Cc (x - mean) - Ac m1, is added where the rows of x = state_t are read anyway: by
+                                          // k_aggregate_dz, which turns this iteration's dx into the previous iteration's dZ (state_t is that
+                                          // iteration's output).  The kernel then does not read the state rows at all (256 of 1536 bytes per row).
 };
 
 template <int HQ, int NCT>                 // NCT = 2 S / 16 output column tiles
@@ -664,11 +668,12 @@ __global__ void __launch_bounds__(64 * TB_WAVES, 4) k_train_bwd_dx(TrainBwdArgs 
             const int k = j < S ? a.wrow_state + j : a.wrow_agg + (j - S);
             const float rstd = 1.0f / sqrtf(a.var[k] + a.eps);
             Ac = a.gamma[k] * rstd; Cc = -Ac * rstd * a.m2[k]; M1 = a.m1[k]; Mu = a.mean[k];
+            if (a.defer_state_bn && j < S) { Cc = 0.0f; M1 = 0.0f; Mu = 0.0f; }       // (see TrainBwdArgs::defer_state_bn)
         }
         coef[j] = Ac; coef[HP + j] = Cc; coef[2 * HP + j] = M1; coef[3 * HP + j] = Mu;
     }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t r_z = buf_rsrc(a.dZ), r_y = buf_rsrc(a.Y), r_s = buf_rsrc(a.state), r_a = buf_rsrc(a.agg), r_o = buf_rsrc(a.dx),
+    const __amdgpu_buffer_rsrc_t r_z = buf_rsrc(a.dZ), r_y = buf_rsrc(a.Y), r_s = buf_rsrc(a.defer_state_bn ? nullptr : a.state), r_a = buf_rsrc(a.agg), r_o = buf_rsrc(a.dx),
                                  r_rs = buf_rsrc(a.agg_row_scale);
     const int n_tiles = (a.M + 15) >> 4;
 #pragma unroll 1
@@ -772,11 +777,12 @@ __global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
             const int k = j < S ? a.wrow_state + j : a.wrow_agg + (j - S);
             const float rstd = 1.0f / sqrtf(a.var[k] + a.eps);
             Ac = a.gamma[k] * rstd; Cc = -Ac * rstd * a.m2[k]; M1 = a.m1[k]; Mu = a.mean[k];
+            if (a.defer_state_bn && j < S) { Cc = 0.0f; M1 = 0.0f; Mu = 0.0f; }       // (see TrainBwdArgs::defer_state_bn)
         }
         coef[j] = Ac; coef[HP + j] = Cc; coef[2 * HP + j] = M1; coef[3 * HP + j] = Mu;
     }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t r_z = buf_rsrc(a.dZ), r_y = buf_rsrc(a.Y), r_s = buf_rsrc(a.gamma ? a.state : nullptr), r_a = buf_rsrc(a.gamma ? a.agg : nullptr),
+    const __amdgpu_buffer_rsrc_t r_z = buf_rsrc(a.dZ), r_y = buf_rsrc(a.Y), r_s = buf_rsrc((a.gamma && !a.defer_state_bn) ? a.state : nullptr), r_a = buf_rsrc(a.gamma ? a.agg : nullptr),
                                  r_o = buf_rsrc(a.dx), r_rs = buf_rsrc(a.agg_row_scale);
     const int n_tiles = (a.M + 15) >> 4;
     const int t_step = gridDim.x * NW;
@@ -1097,6 +1103,64 @@ __global__ void __launch_bounds__(256, TB_WG32_WAVES) k_train_wgrad32(TrainWgrad
             if (jj == a.Kc) wrow = a.K;                              // the line's 1: q
         }
         if (wrow >= 0) Pp[(size_t)wrow * S + h] = Ps[idx];
+    }
+}
+
+// ---- the transposed aggregate that leaves the PREVIOUS iteration's dZ (round 5) ---------------------------------------------------------------
+// Back-propagation through iteration t ends with  G_{t-1} = dx_state + Adj . dx_agg  (k_aggregate_vec: arcs walked by source), and
+// iteration t - 1 begins with  dZ_{t-1} = G_{t-1} (.) act'(Y_{t-1}),  Y_{t-1} = state_t - formed twice, by the weight-gradient kernel and by
+// the input-gradient kernel, each reading G and Y (512 bytes per row each).  Here the aggregate's epilogue reads the state_t row once (it
+// has the node's output row in registers anyway) and
+//   * adds what k_train_bwd_dx left out of the state half's BatchNorm input gradient (TrainBwdArgs::defer_state_bn: that kernel then never
+//     reads state_t):  G = dx_state' + Adj . dx_agg + Cc (state_t - mean) - Ac m1,   Ac = gamma rstd,  Cc = - Ac rstd m2  (iteration t's);
+//   * writes dZ_{t-1} = G (.) act'(state_t).
+// The two dense kernels of iteration t - 1 then read dZ alone (their LINEAR instances, Y = NULL): per row and iteration 256 bytes more
+// here, 256 + 256 + 256 fewer there.
+struct AggDzArgs {
+    const float *Y; int ldy;                               // state_t [n_dst, S]
+    const float *gamma, *var, *mean, *m1, *m2; float eps;  // iteration t's BatchNormalization (gamma NULL: none), by weight row
+    int wrow_state;
+};
+template <int LPR, bool HAS_W, int ACT>
+__global__ void __launch_bounds__(256)
+k_aggregate_dz(int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src, const float *__restrict__ w, const float *__restrict__ row_scale,
+               const float *__restrict__ X, int ldx, float *__restrict__ out, int ldo, const float *__restrict__ addend, int ld_add, AggDzArgs z) {
+    const int l4 = threadIdx.x % LPR;
+    const int groups = blockDim.x / LPR;
+    f32x4 cC = {0.f, 0.f, 0.f, 0.f}, cB = cC, mu = cC;
+    if (z.gamma) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = z.wrow_state + 4 * l4 + e;
+            const float rstd = 1.0f / sqrtf(z.var[k] + z.eps), Ac = z.gamma[k] * rstd;
+            cC[e] = -Ac * rstd * z.m2[k]; cB[e] = -Ac * z.m1[k]; mu[e] = z.mean[k];
+        }
+    }
+    for (int j = blockIdx.x * groups + threadIdx.x / LPR; j < n_dst; j += gridDim.x * groups) {
+        const int beg = rowptr[j], end = rowptr[j + 1];
+        const f32x4 y = *reinterpret_cast<const f32x4 *>(z.Y + (size_t)j * z.ldy + 4 * l4);      // (requested before the walk: it lands under it)
+        const f32x4 own = *reinterpret_cast<const f32x4 *>(addend + (size_t)j * ld_add + 4 * l4);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int e = beg; e < end; e += 8) {                   // summed in arc order
+            f32x4 x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = e + i < end;
+                const int sid = ok ? src[e + i] : 0;
+                x[i] = ok ? *reinterpret_cast<const f32x4 *>(X + (size_t)sid * ldx + 4 * l4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (HAS_W) acc += (e + i < end ? w[e + i] : 0.0f) * x[i];
+                else acc += x[i];
+            }
+        }
+        if (row_scale) acc *= row_scale[j];
+        acc += own;
+        f32x4 dz;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dz[e] = (acc[e] + fmaf(cC[e], y[e] - mu[e], cB[e])) * activate_grad1<ACT>(y[e]);
+        *reinterpret_cast<f32x4 *>(out + (size_t)j * ldo + 4 * l4) = dz;
     }
 }
 

@@ -591,6 +591,39 @@ int launch_train_bwd_dx(const gnn::TrainBwdArgs &ba, int S, hipStream_t st) {
     return 0;
 }
 
+// G_{t-1} -> dZ_{t-1} in the transposed aggregate's epilogue (kernels_train_big.hpp: k_aggregate_dz); false: no instance for this shape
+inline bool train_dz_enabled() {          // GNN_TRAIN_DZ=0: the round-4 flow (every dense kernel forms dZ itself, the last iteration's dx is still computed)
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_TRAIN_DZ"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+template <int LPR, bool HAS_W>
+bool launch_aggregate_dz_lw(const gnn_csr_t &c, const float *Xa, int ldx, float *out, int ldo, const float *addend, int ld_add, const gnn::AggDzArgs &z, int act,
+                            int grid, hipStream_t st) {
+#define AGGDZ(A_) gnn::k_aggregate_dz<LPR, HAS_W, A_><<<grid, 256, 0, st>>>(c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xa, ldx, out, ldo, addend, ld_add, z)
+    switch (act) {
+        case GNN_ACT_LINEAR: AGGDZ(GNN_ACT_LINEAR); return true;
+        case GNN_ACT_RELU: AGGDZ(GNN_ACT_RELU); return true;
+        case GNN_ACT_SELU: AGGDZ(GNN_ACT_SELU); return true;
+        case GNN_ACT_TANH: AGGDZ(GNN_ACT_TANH); return true;
+        case GNN_ACT_SIGMOID: AGGDZ(GNN_ACT_SIGMOID); return true;
+        case GNN_ACT_ELU: AGGDZ(GNN_ACT_ELU); return true;
+        case GNN_ACT_SOFTPLUS: AGGDZ(GNN_ACT_SOFTPLUS); return true;
+        default: return false;
+    }
+#undef AGGDZ
+}
+bool launch_aggregate_dz(const gnn_csr_t &c, const float *Xa, int ldx, float *out, int ldo, const float *addend, int ld_add, const gnn::AggDzArgs &z, int act, int S,
+                         hipStream_t st) {
+    const int lpr = S / 4, groups = 256 / lpr, grid = std::min(cdiv(c.n_dst, groups), 256 * 16);
+    switch (lpr) {
+        case 4: return c.w ? launch_aggregate_dz_lw<4, true>(c, Xa, ldx, out, ldo, addend, ld_add, z, act, grid, st) : launch_aggregate_dz_lw<4, false>(c, Xa, ldx, out, ldo, addend, ld_add, z, act, grid, st);
+        case 8: return c.w ? launch_aggregate_dz_lw<8, true>(c, Xa, ldx, out, ldo, addend, ld_add, z, act, grid, st) : launch_aggregate_dz_lw<8, false>(c, Xa, ldx, out, ldo, addend, ld_add, z, act, grid, st);
+        case 16: return c.w ? launch_aggregate_dz_lw<16, true>(c, Xa, ldx, out, ldo, addend, ld_add, z, act, grid, st) : launch_aggregate_dz_lw<16, false>(c, Xa, ldx, out, ldo, addend, ld_add, z, act, grid, st);
+        default: return false;
+    }
+}
+
 gnn::ConstSegs const_segs_of(const gnn_loop_args_t &a, const TrainPlan &p) {
     gnn::ConstSegs cs;
     memset(&cs, 0, sizeof(cs));
@@ -1040,6 +1073,12 @@ int gnn_train_step(const gnn_train_args_t *args) {
             LAUNCH_OK();
         }
     }
+    // Large graphs (round 5): G_{t-1} leaves the transposed aggregate as dZ_{t-1} = G_{t-1} (.) act'(state_t) (k_aggregate_dz), so that the two
+    // dense kernels of an iteration read dZ alone; the first dZ is formed here, from the output head's gradient.  And iteration 0 needs no
+    // input gradient at all: nothing consumes d loss / d state_0.
+    const bool dzpath = p.big && p.Kc > 0 && p.Kc < 32 && train_wgrad_enabled() && train_dz_enabled() && (p.S == 16 || p.S == 32 || p.S == 64) &&
+                        ns.activation[0] != GNN_ACT_SOFTMAX;
+    if (dzpath && k > 0) TRY(act_grad_inplace(p.G_state, p.S, p.states + (size_t)k * NS, p.S, p.N, p.S, ns.activation[0], st));
     for (int t = k - 1; t >= 0 && !p.small; --t) {
         const float *s_t = p.states + (size_t)t * NS;
         float *s_n = p.states + (size_t)(t + 1) * NS;
@@ -1067,7 +1106,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
                 memset(&wa, 0, sizeof(wa));
                 const int n_wg = std::min(std::min(2 * device_cus(), BIG_WGRAD_BLOCKS), cdiv(p.N, 64));
                 wa.M = p.N; wa.rows_per_wg = cdiv(cdiv(p.N, n_wg), 16) * 16;
-                wa.G = p.G_state; wa.Y = s_n; wa.act = ns.activation[0];
+                wa.G = p.G_state; wa.Y = dzpath ? nullptr : s_n; wa.act = dzpath ? GNN_ACT_LINEAR : ns.activation[0];      // (dzpath: G_state holds dZ)
                 wa.state = s_t; wa.agg = agg_t; wa.xc = p.xc;
                 wa.K = p.in_s; wa.wrow_state = 0; wa.wrow_agg = p.off_agg; wa.Kc = p.Kc; wa.cs = p.cc;
                 wa.part = p.part_w;
@@ -1090,23 +1129,36 @@ int gnn_train_step(const gnn_train_args_t *args) {
                     bn_s ? p.cs.m1 : nullptr, bn_s ? p.cs.m2 : nullptr, t != k - 1 ? 1 : 0, 1, stats ? 1 : 0);
                 LAUNCH_OK();
             } else TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, nullptr, 0, p.part, st, p.off_agg));
+            if (t == 0) break;                                       // nothing consumes d loss / d state_0: no input gradient, no transposed aggregate
             gnn::TrainBwdArgs ba;
             memset(&ba, 0, sizeof(ba));
-            ba.M = p.N; ba.dZ = p.G_state; ba.ldz = p.S;            // (net_backward: the activation gradient ran in place)
-            if (wgrad) { ba.Y = s_n; ba.act = ns.activation[0]; }   // (else G is untouched: dZ is formed as the rows arrive)
+            ba.M = p.N; ba.dZ = p.G_state; ba.ldz = p.S;            // (net_backward: the activation gradient ran in place; dzpath: dZ arrived as such)
+            if (wgrad && !dzpath) { ba.Y = s_n; ba.act = ns.activation[0]; }   // (G is untouched: dZ is formed as the rows arrive)
             ba.W = ns.kernel[0]; ba.ldw = p.H1s; ba.H = p.H1s; ba.S = p.S; ba.wrow_state = 0; ba.wrow_agg = p.off_agg;
             ba.state = s_t; ba.ld_state = p.S; ba.agg = agg_t; ba.ld_agg = p.S;
             if (bn_s) { ba.gamma = ns.bn_gamma; ba.mean = stats; ba.var = stats + p.in_s; ba.m1 = p.cs.m1; ba.m2 = p.cs.m2; ba.eps = ns.bn_eps; }
+            ba.defer_state_bn = (dzpath && bn_s) ? 1 : 0;            // (k_aggregate_dz adds the rest of the state half's BatchNorm gradient: it reads state_t anyway)
             ba.agg_row_scale = unit_w ? a.adjacency.row_scale : nullptr;
             ba.dx = p.dx_s_all; ba.ld_dx = p.kdx_s;
             TRY(launch_train_bwd_dx(ba, p.S, st));
         } else {
-            TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, p.dx_s_all, p.kdx_s, p.part, st, p.off_agg));
+            TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, t > 0 ? p.dx_s_all : nullptr, t > 0 ? p.kdx_s : 0, p.part, st, p.off_agg));
+            if (t == 0) break;                                       // (as above)
             gnn::BnGradReq rq[2] = {gnn::BnGradReq{p.dx_s_all, p.kdx_s, s_t, p.S, nullptr, p.S, 0},
                                     gnn::BnGradReq{p.dx_s_all + p.S, p.kdx_s, agg_t, p.S, nullptr, p.S, p.off_agg}};
             TRY(bn_input_grads(ns, p.cs, stats, rq, 2, p.N, st));
         }
-        {   // G_state = d state (own) + Adj . d agg   (arcs walked by source)
+        if (dzpath) {   // dZ_{t-1} = (dx_state' + Adj . dx_agg + the deferred BatchNorm term) (.) act'(state_t)   (arcs walked by source)
+            gnn_csr_t c = ta.adjacency_by_source;
+            if (unit_w) { c.w = nullptr; c.row_scale = nullptr; }
+            gnn::AggDzArgs z;
+            memset(&z, 0, sizeof(z));
+            z.Y = s_t; z.ldy = p.S; z.wrow_state = 0;
+            if (bn_s) { z.gamma = ns.bn_gamma; z.var = stats + p.in_s; z.mean = stats; z.m1 = p.cs.m1; z.m2 = p.cs.m2; z.eps = ns.bn_eps; }
+            if (!launch_aggregate_dz(c, p.dx_s_all + p.S, p.kdx_s, p.G_state, p.S, p.dx_s_all, p.kdx_s, z, ns.activation[0], p.S, st))
+                return fail("k_aggregate_dz: no instance for state width %d / activation %d", p.S, ns.activation[0]);
+            LAUNCH_OK();
+        } else {   // G_state = d state (own) + Adj . d agg   (arcs walked by source)
             gnn_csr_t c = ta.adjacency_by_source;
             if (unit_w) { c.w = nullptr; c.row_scale = nullptr; }
             const float *Xa = p.dx_s_all + p.S;

@@ -724,14 +724,18 @@ class ShardedLoop:
                 torch.cuda.synchronize(self.device)
                 return 1e-3 * a.elapsed_time(b) / reps
 
-            def host_issue(fn):                                    # wall time the HOST needs to issue one iteration (the queue never runs dry: 20 in a row, then one wait)
+            def host_issue(fn):
+                """Wall time the HOST needs to issue `fn` once, the device idle when it starts and never waited for: the median of 7
+                (at most ~50 iterations' packets are queued at a time - a longer run would fill the HIP queue and measure the device)."""
                 import time as _t
+                ts = []
+                for _ in range(7):
+                    torch.cuda.synchronize(self.device)
+                    t0 = _t.perf_counter()
+                    for _ in range(1 if self.native_loop else 20): fn()
+                    ts.append((_t.perf_counter() - t0) / (1 if self.native_loop else 20))
                 torch.cuda.synchronize(self.device)
-                t0 = _t.perf_counter()
-                for _ in range(20): fn()
-                dt = (_t.perf_counter() - t0) / 20
-                torch.cuda.synchronize(self.device)
-                return dt
+                return float(np.median(ts))
 
             K_loop = max(int(m.max_iteration), 1)
             per_call = K_loop if self.native_loop else 1           # (the native driver is timed over its whole loop: K iterations per call)

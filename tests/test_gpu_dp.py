@@ -118,12 +118,24 @@ WORKER = textwrap.dedent('''
         mc.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['accuracy'])
         return mc
     cseq = CompositeMultiGraphSequencer(cgraphs, 'n', 'average', 8, shuffle=False, device=dev)
-    try:
-        DataParallel(cbuild())
-    except NotImplementedError:
-        pass
-    else:
-        raise SystemExit('exact data-parallel training of a composite model should be refused')
+    # ... and since round 5 the EXACT mode takes them too (per-type statistics combined over the ranks with the shard's row count of the
+    # type as weight - zero included; tests/test_data_parallel.py runs it at world 2 / 3 over gloo): here the product path over RCCL
+    mx = cbuild()
+    dpx = DataParallel(mx, exact=True)
+    csz_x = [g.nodes.shape[0] for g in cgraphs[:8]]
+    xlo, xhi = 8 * rank // world, 8 * (rank + 1) // world
+    x0 = sum(csz_x[:xlo]); x1_ = x0 + sum(csz_x[xlo:xhi])
+    xs0 = np.random.default_rng(3).normal(0, 0.1, (sum(csz_x), 8)).astype(np.float32)
+    res_x = dpx.train_step(dpx.shard(cseq, 0), state0=torch.from_numpy(xs0[x0:x1_]).to(dev), apply=False)
+    assert not dpx._trainer._native_step_applies(cseq[0][1]) and res_x['k'] == 4
+    mref = cbuild(); tref = LoopTrainer(mref)
+    xr, yr, swr = cseq[0]
+    rref = tref.train_step(xr, yr, swr, state0=torch.from_numpy(xs0).to(dev), apply=False)
+    gref = [g for t_ in tref.gs for g in t_.gradients()] + tref.go.gradients()
+    gx = [g for t_ in dpx._trainer.gs for g in t_.gradients()] + dpx._trainer.go.gradients()
+    assert abs(float(res_x['loss']) - float(rref['loss'])) <= 1e-5
+    sc = max(float(b_.abs().max()) for b_ in gref)
+    for a_, b_ in zip(gx, gref): assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(b_.abs().max()), sc), 'exact composite step'
     mc = cbuild()
     dpc = DataParallel(mc, exact=False)
     csz = [g.nodes.shape[0] for g in cgraphs[:8]]

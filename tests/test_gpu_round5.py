@@ -437,3 +437,19 @@ def test_composite_small_graph_training_persistent_kernels_match_autograd(focus,
                 assert rel_err(w[2], mv[0]) <= 1e-5 and rel_err(w[3], mv[1]) <= 1e-5, t_
             w = no.get_weights()
             assert rel_err(w[2], want['moving_output'][0]) <= 1e-5 and rel_err(w[3], want['moving_output'][1]) <= 1e-5
+
+
+
+def test_large_graph_training_with_every_dense_kernel_forming_dz_itself_in_a_child_process():
+    """GNN_TRAIN_DZ=0 (read once per process, hence the child): the round-4 flow of the large-graph backward sweep - the weight-gradient and
+    input-gradient kernels each form dZ = G (.) act'(Y) from G and Y, k_train_bwd_dx applies the whole BatchNorm input gradient, the plain
+    transposed aggregate - which round 5 replaced by default with k_aggregate_dz (the aggregate's epilogue leaves dZ, the state half's
+    BatchNorm term is added there).  Both flows against the same float64 autograd oracle."""
+    import subprocess, sys
+    root = os.path.dirname(nat.HERE)
+    env = dict(os.environ, GNN_TRAIN_DZ='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    sel = 'large_graph_training_step_matches_autograd or thin_output_head or (every_activation and (relu or tanh))'
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_round3.py'), os.path.join(root, 'tests', 'test_gpu_round4.py'),
+                          '-m', 'gpu', '-q', '-x', '-k', sel], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert ' passed' in res.stdout

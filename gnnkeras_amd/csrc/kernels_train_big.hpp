@@ -1122,24 +1122,28 @@ struct AggDzArgs {
     int wrow_state;
 };
 template <int LPR, bool HAS_W, int ACT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, HAS_W ? 7 : 8)
 k_aggregate_dz(int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src, const float *__restrict__ w, const float *__restrict__ row_scale,
                const float *__restrict__ X, int ldx, float *__restrict__ out, int ldo, const float *__restrict__ addend, int ld_add, AggDzArgs z) {
+    // 8 waves per SIMD or nothing: this access pattern is served by the number of waves with a gather outstanding (k_aggregate_stats lost 18 %
+    // when one more register took it to 7).  So the epilogue's operands are not held across the walk: the per-column coefficients sit in
+    // LDS, the node's own rows (dx_state', state_t) are requested when the walk is over - eight waves cover that trip.  (The first form kept
+    // them in registers: 75 - 90 VGPRs, 5 - 6 waves per SIMD, 520 us per C4-size launch against 438 for k_aggregate_vec.)
+    __shared__ __attribute__((aligned(16))) float coef[3][4 * LPR];      // Cc | - Ac m1 | mean of the state columns
     const int l4 = threadIdx.x % LPR;
     const int groups = blockDim.x / LPR;
-    f32x4 cC = {0.f, 0.f, 0.f, 0.f}, cB = cC, mu = cC;
-    if (z.gamma) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = z.wrow_state + 4 * l4 + e;
+    if (threadIdx.x < 4 * LPR) {
+        float cC = 0.0f, cB = 0.0f, mu = 0.0f;
+        if (z.gamma) {
+            const int k = z.wrow_state + threadIdx.x;
             const float rstd = 1.0f / sqrtf(z.var[k] + z.eps), Ac = z.gamma[k] * rstd;
-            cC[e] = -Ac * rstd * z.m2[k]; cB[e] = -Ac * z.m1[k]; mu[e] = z.mean[k];
+            cC = -Ac * rstd * z.m2[k]; cB = -Ac * z.m1[k]; mu = z.mean[k];
         }
+        coef[0][threadIdx.x] = cC; coef[1][threadIdx.x] = cB; coef[2][threadIdx.x] = mu;
     }
+    __syncthreads();
     for (int j = blockIdx.x * groups + threadIdx.x / LPR; j < n_dst; j += gridDim.x * groups) {
         const int beg = rowptr[j], end = rowptr[j + 1];
-        const f32x4 y = *reinterpret_cast<const f32x4 *>(z.Y + (size_t)j * z.ldy + 4 * l4);      // (requested before the walk: it lands under it)
-        const f32x4 own = *reinterpret_cast<const f32x4 *>(addend + (size_t)j * ld_add + 4 * l4);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int e = beg; e < end; e += 8) {                   // summed in arc order
             f32x4 x[8];
@@ -1156,7 +1160,10 @@ k_aggregate_dz(int n_dst, const int *__restrict__ rowptr, const int *__restrict_
             }
         }
         if (row_scale) acc *= row_scale[j];
-        acc += own;
+        const f32x4 y = *reinterpret_cast<const f32x4 *>(z.Y + (size_t)j * z.ldy + 4 * l4);
+        acc += *reinterpret_cast<const f32x4 *>(addend + (size_t)j * ld_add + 4 * l4);
+        const f32x4 cC = *reinterpret_cast<const f32x4 *>(&coef[0][4 * l4]), cB = *reinterpret_cast<const f32x4 *>(&coef[1][4 * l4]),
+                    mu = *reinterpret_cast<const f32x4 *>(&coef[2][4 * l4]);
         f32x4 dz;
 #pragma unroll
         for (int e = 0; e < 4; ++e) dz[e] = (acc[e] + fmaf(cC[e], y[e] - mu[e], cB[e])) * activate_grad1<ACT>(y[e]);
@@ -1186,6 +1193,8 @@ struct HeadArgs {
     const float *W;                       // first-layer kernel [(S + L) x T] (NOT folded)
     const float *gamma, *mean, *var, *m1, *m2; float eps;      // NULL gamma: no BatchNormalization
     float *dx; int ld_dx;                 // [M, S]
+    int dz_act;                           // >= 0: the rows leave as dZ of the loop's LAST iteration, dx (.) act'(state) with this activation of the STATE
+                                          // network (`state` is that iteration's output; k_aggregate_dz does the same for the iterations before): -1 = plain dx
 };
 
 template <int T>
@@ -1282,7 +1291,7 @@ __global__ void __launch_bounds__(256) k_head_dx(HeadArgs a) {
         for (int h = 0; h < T; ++h) dz[h] = a.dZ[(size_t)m * a.ldz + h];
         if (!act) continue;
         f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (a.gamma) x = *reinterpret_cast<const f32x4 *>(a.state + (size_t)m * a.ld_state + 4 * l4);
+        if (a.gamma || a.dz_act >= 0) x = *reinterpret_cast<const f32x4 *>(a.state + (size_t)m * a.ld_state + 4 * l4);
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1290,6 +1299,7 @@ __global__ void __launch_bounds__(256) k_head_dx(HeadArgs a) {
 #pragma unroll
             for (int h = 0; h < T; ++h) dy = fmaf(dz[h], w[e][h], dy);
             v[e] = fmaf(Ac[e], dy - M1[e], Cc[e] * (x[e] - Mu[e]));
+            if (a.dz_act >= 0) v[e] *= activate_grad_from_output(a.dz_act, x[e]);
         }
         *reinterpret_cast<f32x4 *>(a.dx + (size_t)m * a.ld_dx + 4 * l4) = v;
     }

@@ -689,7 +689,7 @@ int launch_train_small_bwd_sq(const gnn::TrainSmallBwd &ba, const gnn::TileTab &
 // Back-propagation through a thin output head over every node of a large graph (kernels_train_big.hpp: k_head_wgrad / k_head_dx): the
 // head's parameter gradients, and d loss / d state_k written straight into the state gradient.  G = d loss / d head output [M x T].
 template <int T>
-int head_backward_t(const TrainPlan &p, const gnn_loop_args_t &a, const float *state_k, const float *out_nodes, float *G, const float *stats, hipStream_t st) {
+int head_backward_t(const TrainPlan &p, const gnn_loop_args_t &a, const float *state_k, const float *out_nodes, float *G, const float *stats, hipStream_t st, int dz_act) {
     const gnn_mlp_t &m = a.net_output;
     TRY(act_grad_inplace(G, p.T, out_nodes, p.T, p.M, p.T, m.activation[0], st));
     gnn::HeadArgs h;
@@ -712,19 +712,20 @@ int head_backward_t(const TrainPlan &p, const gnn_loop_args_t &a, const float *s
     LAUNCH_OK();
     h.W = m.kernel[0];
     if (bn) { h.gamma = m.bn_gamma; h.mean = stats; h.var = stats + K; h.m1 = p.co.m1; h.m2 = p.co.m2; h.eps = m.bn_eps; }
-    h.dx = p.G_state; h.ld_dx = p.S;
+    h.dx = p.G_state; h.ld_dx = p.S; h.dz_act = dz_act;
     const int lpr = p.S / 4 <= 4 ? 4 : p.S / 4 <= 8 ? 8 : 16;
     gnn::k_head_dx<T><<<std::min(cdiv(p.M, 256 / lpr), 256 * 16), 256, 0, st>>>(h);
     LAUNCH_OK();
     return 0;
 }
 
-int head_backward(const TrainPlan &p, const gnn_loop_args_t &a, const float *state_k, const float *out_nodes, float *G, const float *stats, hipStream_t st) {
+// `dz_act` >= 0: the state gradient leaves as the loop's last dZ (HeadArgs::dz_act)
+int head_backward(const TrainPlan &p, const gnn_loop_args_t &a, const float *state_k, const float *out_nodes, float *G, const float *stats, hipStream_t st, int dz_act = -1) {
     switch (p.T) {
-        case 1: return head_backward_t<1>(p, a, state_k, out_nodes, G, stats, st);
-        case 2: return head_backward_t<2>(p, a, state_k, out_nodes, G, stats, st);
-        case 3: return head_backward_t<3>(p, a, state_k, out_nodes, G, stats, st);
-        default: return head_backward_t<4>(p, a, state_k, out_nodes, G, stats, st);
+        case 1: return head_backward_t<1>(p, a, state_k, out_nodes, G, stats, st, dz_act);
+        case 2: return head_backward_t<2>(p, a, state_k, out_nodes, G, stats, st, dz_act);
+        case 3: return head_backward_t<3>(p, a, state_k, out_nodes, G, stats, st, dz_act);
+        default: return head_backward_t<4>(p, a, state_k, out_nodes, G, stats, st, dz_act);
     }
 }
 
@@ -1026,9 +1027,14 @@ int gnn_train_step(const gnn_train_args_t *args) {
     if (p.pooled) { TRY(launch_aggregate(nullptr, ta.nodegraph_by_source, p.dpred, p.T, p.T, p.G_out, p.T, st)); G_out = p.G_out; }
 
     // ---- backward: output network, then the k iterations -----------------------------------------------------------------------------------
+    // Large graphs (round 5): G_{t-1} leaves the transposed aggregate as dZ_{t-1} = G_{t-1} (.) act'(state_t) (k_aggregate_dz), so that the two
+    // dense kernels of an iteration read dZ alone; the first dZ comes from the output head (k_head_dx, or one k_act_grad pass behind the
+    // general head).  And iteration 0 needs no input gradient at all: nothing consumes d loss / d state_0.
+    const bool dzpath = p.big && p.Kc > 0 && p.Kc < 32 && train_wgrad_enabled() && train_dz_enabled() && (p.S == 16 || p.S == 32 || p.S == 64) &&
+                        ns.activation[0] != GNN_ACT_SOFTMAX;
     if (!p.head_fast) HIP_OK(hipMemsetAsync(p.G_state, 0, sizeof(float) * (size_t)p.N * p.S, st));
     if (p.head_fast) {
-        TRY(head_backward(p, a, state_k, out_nodes, G_out, bn_o ? p.stats_o : nullptr, st));
+        TRY(head_backward(p, a, state_k, out_nodes, G_out, bn_o ? p.stats_o : nullptr, st, (dzpath && k > 0) ? (int)ns.activation[0] : -1));
     } else if (p.M > 0) {
         TRY(net_backward(p.co, osegs, nos, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, p.in_o, p.part, st));
         gnn::BnGradReq rq[2];
@@ -1073,12 +1079,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
             LAUNCH_OK();
         }
     }
-    // Large graphs (round 5): G_{t-1} leaves the transposed aggregate as dZ_{t-1} = G_{t-1} (.) act'(state_t) (k_aggregate_dz), so that the two
-    // dense kernels of an iteration read dZ alone; the first dZ is formed here, from the output head's gradient.  And iteration 0 needs no
-    // input gradient at all: nothing consumes d loss / d state_0.
-    const bool dzpath = p.big && p.Kc > 0 && p.Kc < 32 && train_wgrad_enabled() && train_dz_enabled() && (p.S == 16 || p.S == 32 || p.S == 64) &&
-                        ns.activation[0] != GNN_ACT_SOFTMAX;
-    if (dzpath && k > 0) TRY(act_grad_inplace(p.G_state, p.S, p.states + (size_t)k * NS, p.S, p.N, p.S, ns.activation[0], st));
+    if (dzpath && k > 0 && !p.head_fast) TRY(act_grad_inplace(p.G_state, p.S, p.states + (size_t)k * NS, p.S, p.N, p.S, ns.activation[0], st));
     for (int t = k - 1; t >= 0 && !p.small; --t) {
         const float *s_t = p.states + (size_t)t * NS;
         float *s_n = p.states + (size_t)(t + 1) * NS;

@@ -391,6 +391,16 @@ def roofline_record(b_iter, t_iter, kernel_name, n_nodes=None, h1=None):
     return rec
 
 
+def same_kernel(profiled, reported):
+    """rocprofv3 prints every template argument of an instantiation, the defaulted trailing ones too
+    (`k_state_fused4<64,false,4,4,false,false,true,1,false>`), the library's gnn_last_kernel_name() only the ones it selects
+    (`k_state_fused4<64,false,4,4,false,false,true>`): the same kernel when one argument list is a prefix of the other."""
+    if not profiled or not reported: return False
+    a, b = (x.replace(' ', '').rstrip('>') for x in (profiled, reported))
+    if '<' not in a or '<' not in b: return a == b
+    return a == b or a.startswith(b + ',') or b.startswith(a + ',')
+
+
 def traffic_lookup(rec, kernel_name, N, E, d, traffic_file=None):
     """HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same workload,
     scripts/parse_pmc.py -> profiles/hbm_traffic.json): recorded per (kernel, workload, library sources), used only when all three
@@ -406,7 +416,7 @@ def traffic_lookup(rec, kernel_name, N, E, d, traffic_file=None):
     try:
         stale = None
         for tr in json.load(open(traffic_file)).get('records', []):
-            if tr.get('kernel') == kernel_name and tr.get('nodes') == N and tr.get('arcs') == E and tr.get('state_dim') == d:
+            if same_kernel(tr.get('kernel'), kernel_name) and tr.get('nodes') == N and tr.get('arcs') == E and tr.get('state_dim') == d:
                 if tr.get('library_source_hash') != here:
                     stale = tr.get('library_source_hash')
                     continue

@@ -355,5 +355,10 @@ def test_bench_reports_pmc_traffic_only_for_the_library_sources_it_runs_on(tmp_p
     assert rec['traffic'] == 123.0 and 'traffic_null_reason' not in rec and here in rec['traffic_source']
     rec = bench.traffic_lookup({'traffic': None}, 'k_y<64>', 10, 20, 64, traffic_file=str(f))
     assert rec['traffic'] is None and rec['traffic_null_reason'] == 'no PMC record for this kernel and workload'
+    # rocprofv3 names carry the defaulted trailing template arguments the library's own name leaves out
+    f.write_text(json.dumps({'records': [dict(base, kernel='k_x<64, false, 1, false>', library_source_hash=here)]}))
+    assert bench.traffic_lookup({'traffic': None}, 'k_x<64,false>', 10, 20, 64, traffic_file=str(f))['traffic'] == 123.0
+    assert bench.traffic_lookup({'traffic': None}, 'k_x<64,true>', 10, 20, 64, traffic_file=str(f))['traffic'] is None
+    assert bench.traffic_lookup({'traffic': None}, 'k_x<6>', 10, 20, 64, traffic_file=str(f))['traffic'] is None
     rec = bench.traffic_lookup({'traffic': None}, 'k_x<64>', 10, 20, 64, traffic_file=str(tmp_path / 'absent.json'))
     assert rec['traffic'] is None and 'missing' in rec['traffic_null_reason']

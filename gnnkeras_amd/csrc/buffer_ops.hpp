@@ -20,6 +20,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *p) {
     // 4 GiB window (the launcher checks every array fits); a null array becomes a zero-record buffer: loads return 0
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? (int)0xFFFFFFF0u : 0, 0x00020000);
 }
+// ... and a window of exactly `bytes` bytes: offsets past the array's end are out of range by themselves (row-streaming kernels whose
+// last tile is ragged need no select per load)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc_n(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+// a kernel argument the compiler has come to hold in vector registers (it reloads arguments inside divergent control flow) makes every
+// buffer instruction on its descriptor a waterfall loop: pass the pointer through here first
+__device__ __forceinline__ const void *uniform_ptr(const void *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const void *)(((unsigned long long)hi << 32) | lo);
+}
 constexpr unsigned BUF_OFF = 0xFFFFFFFFu;     // out of range for every descriptor: the load returns 0, no memory access
 
 __device__ __forceinline__ int buf_ld_i32(__amdgpu_buffer_rsrc_t r, unsigned off) {

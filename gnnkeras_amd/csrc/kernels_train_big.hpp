@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels_general.hpp"
 #include "kernel_state_fused4.hpp"      // activate4
+#include <type_traits>
 #include "kernel_state_lds.hpp"         // row16_sum_to_lane15
 #include "kernels_train.hpp"            // activate_grad_from_output
 #include "buffer_ops.hpp"
@@ -356,12 +357,22 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_PREFETCH ? 2 : TB_FWD_MIN_WA
     }
 }
 
+#ifndef TB_STAMP_BLOCK
+#define TB_STAMP_BLOCK 0
+#endif
 #ifdef TB_STAMPS                        // debug build of scripts/micro: clock stamps of one wave (block 0, wave 0), 4 per trip
 __device__ unsigned long long g_tb_stamps[4 * 64];
-#define TB_STAMP(i_) do { if (blockIdx.x == 0 && wave == 0 && trip_ < 64) { const unsigned long long c_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_tb_stamps[4 * trip_ + (i_)] = c_; } } while (0)
+__device__ unsigned long long g_tb_blocks[2 * 4096];      // s_memrealtime (100 MHz, one base for the whole device) at the start / end of every workgroup
+__device__ unsigned g_tb_hwid[2 * 4096];                  // HW_ID and XCC_ID of wave 0 of every workgroup
+#define TB_BLOCK_TIME(i_) do { if (threadIdx.x == 0 && blockIdx.x < 4096) { g_tb_blocks[2 * blockIdx.x + (i_)] = __builtin_amdgcn_s_memrealtime(); \
+    g_tb_hwid[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); g_tb_hwid[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); } } while (0)
+#define TB_STAMP(i_) do { if (blockIdx.x == TB_STAMP_BLOCK && wave == 0 && trip_ < 60) { const unsigned long long c_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_tb_stamps[4 * trip_ + (i_)] = c_; } } while (0)
 #define TB_STAMP_DEP(i_, r_) do { asm volatile("" : "+v"(r_)); TB_STAMP(i_); } while (0)
+#define TB_MARK(i_) do { if (blockIdx.x == TB_STAMP_BLOCK && threadIdx.x == 0) g_tb_stamps[240 + (i_)] = __builtin_amdgcn_s_memtime(); } while (0)      // kernel phases
 #define TB_TRIP_END() (++trip_)
 #else
+#define TB_MARK(i_) do {} while (0)
+#define TB_BLOCK_TIME(i_) do {} while (0)
 #define TB_STAMP(i_) do {} while (0)
 #define TB_STAMP_DEP(i_, r_) do {} while (0)
 #define TB_TRIP_END() do {} while (0)
@@ -410,6 +421,43 @@ __device__ __forceinline__ void split3_x8(const f32x4 &x0, const f32x4 &x1, u32x
     split3_pair(x1[0], x1[1], hh[2], mm[2], ll[2]); split3_pair(x1[2], x1[3], hh[3], mm[3], ll[3]);
     h = (u32x4){hh[0], hh[1], hh[2], hh[3]}; m = (u32x4){mm[0], mm[1], mm[2], mm[3]}; l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
 }
+// ... the same split on packed f32 pairs: 9 VALU instructions a pair (v_cvt_pk_bf16_f32 x 3, the two unpacks x 2, v_pk_add_f32 x 2).  The
+// conversion is inline assembly so that hipcc keeps the PAIR conversion (it otherwise converts the low element a second time, alone, to
+// shift it: 100 conversions a tile where 60 do); the bits are split3_pair's.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(f32x2 x) {
+    const bf16x2 hv = {(__bf16)x[0], (__bf16)x[1]};
+    unsigned r = __builtin_bit_cast(unsigned, hv);
+    asm("" : "+v"(r));                  // (opaque from here on: no instruction, and hipcc cannot look through the shifts below to the conversion)
+    return r;
+}
+__device__ __forceinline__ void split3_pk(f32x2 x, unsigned &h, unsigned &m, unsigned &l) {
+    h = cvt_pk_bf16(x);
+    const f32x2 r1 = x - (f32x2){__uint_as_float(h << 16), __uint_as_float(h & 0xFFFF0000u)};
+    m = cvt_pk_bf16(r1);
+    const f32x2 r2 = r1 - (f32x2){__uint_as_float(m << 16), __uint_as_float(m & 0xFFFF0000u)};
+    l = cvt_pk_bf16(r2);
+}
+__device__ __forceinline__ void split3_x8pk(const f32x4 &x0, const f32x4 &x1, u32x4 &h, u32x4 &m, u32x4 &l) {
+    unsigned hh[4], mm[4], ll[4];
+    split3_pk((f32x2){x0[0], x0[1]}, hh[0], mm[0], ll[0]); split3_pk((f32x2){x0[2], x0[3]}, hh[1], mm[1], ll[1]);
+    split3_pk((f32x2){x1[0], x1[1]}, hh[2], mm[2], ll[2]); split3_pk((f32x2){x1[2], x1[3]}, hh[3], mm[3], ll[3]);
+    h = (u32x4){hh[0], hh[1], hh[2], hh[3]}; m = (u32x4){mm[0], mm[1], mm[2], mm[3]}; l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+}
+// the activation of the bf16-split kernels: selu / elu with the exponential as ONE v_exp_f32 (2^(x log2 e): the argument's rounding moves
+// e^x by |x| 6e-8 relative - x e^x <= 0.37: 2e-8 absolute - where expf()'s range reduction and its two range checks cost 12 instructions
+// a value, 190 of a tile's 780)
+template <int ACT> __device__ __forceinline__ float activate_b6(float v) {
+    if (ACT == GNN_ACT_SELU) {
+        const float e = __builtin_amdgcn_exp2f(fminf(v, 0.0f) * 1.4426950408889634f);
+        constexpr float SC = 1.0507009873554805f, SA = 1.0507009873554805f * 1.6732632423543772f;
+        return fmaf(SA, e, fmaf(SC, fmaxf(v, 0.0f), -SA));
+    }
+    if (ACT == GNN_ACT_ELU) return fmaxf(v, 0.0f) + (__builtin_amdgcn_exp2f(fminf(v, 0.0f) * 1.4426950408889634f) - 1.0f);
+    return activate1<ACT>(v);
+}
+__device__ __forceinline__ f32x4 fma4(const f32x4 &a, const f32x4 &b, const f32x4 &c) { return __builtin_elementwise_fma(a, b, c); }
+
 __device__ __forceinline__ f32x16 mfma_b6(const u32x4 &wh, const u32x4 &wm, const u32x4 &wl, const u32x4 &xh, const u32x4 &xm, const u32x4 &xl, f32x16 acc) {
 #define B8(v_) __builtin_bit_cast(bf16x8, v_)
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(wl), B8(xh), acc, 0, 0, 0);      // small terms first
@@ -458,6 +506,7 @@ __device__ __forceinline__ f32x4 mfma_b6_16(const u32x4 &wh, const u32x4 &wm, co
 // waited in 16 registers) -> products -> activation, statistics, predicate.  Nothing the next wait covers is younger than most of a trip.
 template <int SQ, int ACT>
 __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(TrainFwdArgs a) {
+    TB_MARK(0); TB_BLOCK_TIME(0);
     if (gate_closed(a.gate)) return;
     constexpr int NCT = SQ, HP = 16 * NCT, NQ = 2 * SQ + 2, NKB = NQ / 2;
     constexpr int PLANE = NKB * NCT * 64 * 8;                                                   // bf16 elements of one weight plane
@@ -492,24 +541,27 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
     }
     for (int h = tid; h < HP; h += 64 * TB_WAVES) bias_l[h] = h < a.H ? a.bf[h] : 0.0f;
     __syncthreads();
+    TB_MARK(1);
 
-    const __amdgpu_buffer_rsrc_t r_s = buf_rsrc(a.state), r_a = buf_rsrc(a.agg), r_x = buf_rsrc(a.xc), r_y = buf_rsrc(a.Y);
+    // windows of exactly the arrays' sizes: the rows past M of the last tile are out of range by themselves (they read 0), no select per load
+    const __amdgpu_buffer_rsrc_t r_s = buf_rsrc_n(a.state, (unsigned)a.M * (unsigned)a.ld_state * 4u), r_a = buf_rsrc_n(a.agg, (unsigned)a.M * (unsigned)a.ld_agg * 4u),
+                                 r_x = buf_rsrc_n(uniform_ptr(a.xc), (unsigned)a.M * 128u), r_y = buf_rsrc(a.Y);
     const int n_tiles = (a.M + 15) >> 4;
     f32x4 cs1[NCT], cs2[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) { cs1[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; cs2[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     int any = 0;
     f32x4 A[NQ];
+    const unsigned o_s = (unsigned)c * (unsigned)a.ld_state * 4u + 16u * g, o_a = (unsigned)c * (unsigned)a.ld_agg * 4u + 16u * g, o_x = (unsigned)c * 128u + 16u * g;
     auto fetch = [&](int t) {                           // this lane's 16-byte pieces of row 16 t + c: state, agg, constants line
-        const int row_ = 16 * t + c;
-        const bool in_ = t < n_tiles && row_ < a.M;
+        const unsigned b_s = 64u * (unsigned)t * (unsigned)a.ld_state + o_s, b_a = 64u * (unsigned)t * (unsigned)a.ld_agg + o_a, b_x = 2048u * (unsigned)t + o_x;
 #pragma unroll
         for (int q = 0; q < SQ; ++q) {
-            A[q] = buf_ld_f32x4(r_s, in_ ? ((unsigned)row_ * (unsigned)a.ld_state + 16u * q + 4u * g) * 4u : BUF_OFF);
-            A[SQ + q] = buf_ld_f32x4(r_a, in_ ? ((unsigned)row_ * (unsigned)a.ld_agg + 16u * q + 4u * g) * 4u : BUF_OFF);
+            A[q] = buf_ld_f32x4(r_s, b_s + 64u * q);
+            A[SQ + q] = buf_ld_f32x4(r_a, b_a + 64u * q);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) A[2 * SQ + q] = buf_ld_f32x4(r_x, in_ ? ((unsigned)row_ * 32u + 16u * q + 4u * g) * 4u : BUF_OFF);
+        for (int q = 0; q < 2; ++q) A[2 * SQ + q] = buf_ld_f32x4(r_x, b_x + 64u * q);
     };
     const int t_step = gridDim.x * TB_WAVES;
     int trip_ = 0; (void)trip_;
@@ -528,8 +580,8 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
         f32x4 old[SQ];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)             // (centred: see TrainFwdArgs::in_mean; the predicate below compares with the raw state)
-            split3_x8(A[2 * kb] - *reinterpret_cast<const f32x4 *>(mean_l + 32 * kb + 4 * g), A[2 * kb + 1] - *reinterpret_cast<const f32x4 *>(mean_l + 32 * kb + 16 + 4 * g),
-                      xh[kb], xm[kb], xl[kb]);
+            split3_x8pk(A[2 * kb] - *reinterpret_cast<const f32x4 *>(mean_l + 32 * kb + 4 * g), A[2 * kb + 1] - *reinterpret_cast<const f32x4 *>(mean_l + 32 * kb + 16 + 4 * g),
+                        xh[kb], xm[kb], xl[kb]);
 #pragma unroll
         for (int q = 0; q < SQ; ++q) old[q] = A[q];
         __builtin_amdgcn_sched_barrier(0);
@@ -571,18 +623,21 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
         TB_STAMP_DEP(2, acc[NCT - 1]);
-        float d2 = 0.0f, n2 = 0.0f;
+        // (packed f32 arithmetic: two values an instruction; the rows past M of the last tile read zeros - their outputs are not stored and
+        // `mask` / `in` keep them out of the statistics and the predicate)
+        f32x4 d2v = {0.f, 0.f, 0.f, 0.f}, n2v = {0.f, 0.f, 0.f, 0.f};
         const float mask = in ? 1.0f : 0.0f;
+        const f32x4 mask4 = {mask, mask, mask, mask};
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             f32x4 v = acc[ct];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((TB_ABL & 16) ? v[e] : activate1<ACT>(v[e])) * mask;       // (H == 16 SQ: the launcher checks; a column mask here becomes a branch per element)
+            for (int e = 0; e < 4; ++e) v[e] = (TB_ABL & 16) ? v[e] : activate_b6<ACT>(v[e]);       // (H == 16 SQ: the launcher checks; a column mask here becomes a branch per element)
             vP[ct] = v;
-            { const f32x4 dv = v - *reinterpret_cast<const f32x4 *>(shift_l + 16 * ct + 4 * g) * mask; cs1[ct] += dv; cs2[ct] += dv * dv; }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float o = old[ct][e], d = v[e] - o; d2 = fmaf(d, d, d2); n2 = fmaf(o, o, n2); }
+            { const f32x4 dv = (v - *reinterpret_cast<const f32x4 *>(shift_l + 16 * ct + 4 * g)) * mask4; cs1[ct] += dv; cs2[ct] = fma4(dv, dv, cs2[ct]); }
+            { const f32x4 dd = v - old[ct]; d2v = fma4(dd, dd, d2v); n2v = fma4(old[ct], old[ct], n2v); }
         }
+        float d2 = (d2v[0] + d2v[1]) + (d2v[2] + d2v[3]), n2 = (n2v[0] + n2v[1]) + (n2v[2] + n2v[3]);
         d2 += __shfl_xor(d2, 16, 64); d2 += __shfl_xor(d2, 32, 64);
         n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64);
         any |= (in && sqrtf(d2) > a.thr * sqrtf(n2)) ? 1 : 0;
@@ -590,6 +645,7 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
         TB_STAMP_DEP(3, vP[NCT - 1]);
         TB_TRIP_END();
     }
+    TB_MARK(2);
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {                 // the last tile's output
         const u32x4 bits = {__float_as_uint(vP[ct][0]), __float_as_uint(vP[ct][1]), __float_as_uint(vP[ct][2]), __float_as_uint(vP[ct][3])};
@@ -611,6 +667,7 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
         for (int w_ = 0; w_ < TB_WAVES; ++w_) tsum += red[w_ * 2 * HP + tid];
         a.stat_part[(size_t)blockIdx.x * 2 * HP + tid] = tsum;
     }
+    TB_MARK(3); TB_BLOCK_TIME(1);
     if (a.pred_flag && tid == 0) {
         if (any_s) atomicOr(a.pred_flag, 1);
         if (blockIdx.x == 0 && a.pred_k) *a.pred_k = a.pred_kval;
@@ -1008,6 +1065,47 @@ __global__ void __launch_bounds__(256, 2) k_train_wgrad(TrainWgradArgs a) {
     }
 }
 
+// The 32x32 tiles of a workgroup's four waves -> its partial P (LDS, waves in order) -> a.part, by weight row (shared by the f32 and the
+// bf16-split forms of the kernel: v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_bf16 leave their results in the same registers).
+template <int NB>
+__device__ __forceinline__ void wgrad32_store(const TrainWgradArgs &a, f32x16 (&acc)[2 * NB + 1][NB], float *Ps) {
+    constexpr int S = 32 * NB, RT = 2 * NB + 1, KV = 2 * S + 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // acc[rt][f][v] = P[virtual column kv(rt, 8 (v / 4) + 4 kk + v % 4)][NB i + f]; the waves add their tiles in wave order
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = 8 * (v >> 2) + 4 * kk + (v & 3);
+                    const int kv = rt < NB ? NB * m + rt : rt < 2 * NB ? S + NB * m + (rt - NB) : 2 * S + m;
+                    float *dst = Ps + kv * S + NB * i;
+#pragma unroll
+                    for (int f = 0; f < NB; ++f) dst[f] = w == 0 ? acc[rt][f][v] : dst[f] + acc[rt][f][v];
+                }
+        }
+        __syncthreads();
+    }
+    float *Pp = a.part + (size_t)blockIdx.x * ((size_t)a.K * S + S);
+    for (int idx = tid; idx < KV * S; idx += 256) {
+        const int kv = idx / S, h = idx % S;
+        int wrow = -1;
+        if (kv < S) wrow = a.wrow_state + kv;
+        else if (kv < 2 * S) wrow = a.wrow_agg + (kv - S);
+        else {
+            int jj = kv - 2 * S, b0 = 0;
+#pragma unroll
+            for (int sg = 0; sg < 3; ++sg) { if (sg < a.cs.n && jj >= b0 && jj < b0 + a.cs.width[sg]) wrow = a.cs.wrow[sg] + (jj - b0); if (sg < a.cs.n) b0 += a.cs.width[sg]; }
+            if (jj == a.Kc) wrow = a.K;                              // the line's 1: q
+        }
+        if (wrow >= 0) Pp[(size_t)wrow * S + h] = Ps[idx];
+    }
+}
+
 // The same contraction on v_mfma_f32_32x32x2_f32 (S = 32 NB): 156 TFLOP/s sustained against 104 .. 126 for the 16x16x4 form
 // (scripts/micro/mfma_peak.hip), and the weight gradient is the one dense training kernel that is almost all MFMA.  Lane (i = lane % 32,
 // kk = lane / 32) supplies one element of row r0 + kk of each operand: it loads the NB consecutive floats  X[r0 + kk][NB i ..]  (a
@@ -1072,38 +1170,153 @@ __global__ void __launch_bounds__(256, TB_WG32_WAVES) k_train_wgrad32(TrainWgrad
             }
         }
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    // acc[rt][f][v] = P[virtual column kv(rt, 8 (v / 4) + 4 kk + v % 4)][NB i + f]; the waves add their tiles in wave order
+    wgrad32_store<NB>(a, acc, Ps);
+}
+
+template <int J0, int J1, typename F> __device__ __forceinline__ void static_for(F &&f) {       // f(integral_constant<int, J0>) ... : loop indices that are constant expressions
+    if constexpr (J0 < J1) { f(std::integral_constant<int, J0>{}); static_for<J0 + 1, J1>(f); }
+}
+// NB floats at LDS byte address addr + OFF, as inline assembly (hipcc neither sees the read nor waits for it: the caller does)
+template <int NB, int OFF> __device__ __forceinline__ void lds_read_piece(Piece<NB> &p, unsigned addr) {
+    if constexpr (NB == 2) { f32x2 v; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); p.v[0] = v[0]; p.v[1] = v[1]; }
+    else { float v; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); p.v[0] = v; }
+}
+
+// ... and on the bf16 matrix cores (round 5).  scripts/micro/mfma_bf16_valu_overlap.hip: on gfx950 a SIMD issues EITHER a matrix instruction
+// OR a VALU instruction - a wave's own VALU work does not run in the shadow of its MFMAs, nor does the other wave's (24 MFMAs + 96 v_fma a
+// trip: 516 ns in phases, 533 interleaved, 589 on specialised waves, against 336 + 212 alone) - so a dense kernel costs the SUM of its
+// matrix and VALU cycles, and k_train_wgrad32 is 64 cycles of v_mfma_f32_32x32x2_f32 for every 2 rows of every 32 x 32 tile: 5 120 cycles
+// per 16 rows of S = 64.  v_mfma_f32_32x32x16_bf16 contracts 16 rows in 32 cycles: with both operands split into three bf16 terms
+// (split3_pk: exact, the products' sum is an f32 chain's to 2^-24) the same 16 rows cost 60 x 32 = 1 920 matrix cycles + ~1 400 of VALU.
+// Lane (i = lane % 32, kg = lane / 32) supplies 8 consecutive k of a tile row: the NB floats X[r0 + 8 kg + j][NB i ..] of EIGHT rows (j = 0
+// .. 7), paired along the rows; dZ pieces are B operands the same way, and the results land where v_mfma_f32_32x32x2_f32 leaves them.
+//
+// The rows reach the wave through a ring in LDS that the memory system fills (buffer_load_dwordx4 ... lds: no destination registers).  A
+// wave's step is 16 rows = one contiguous 2 NB KB piece of each [M, S] array: 2 NB wave-loads of 1 KB land it in LDS as it lies in
+// memory, the operands are then read with ds_read_b64.  Two slots a wave: at the top of step s the wave waits for slot s % 2 (filled
+// two steps ago), reads it into registers, hands the slot back to the loads of step s + 2 and computes - 28 KB a wave in flight for
+// two whole steps, and nothing that is in flight lives in a register across the loop's back edge (the first form of this kernel kept
+// two steps of rows in registers: hipcc loaded them into other registers than the loop carries, copied them at the loop's end and
+// waited for every load there - 177 us = 98 of loads + 39 of splits + 40 of products, one after the other).  The waits are counted by
+// hand (s_waitcnt vmcnt(NG): every step issues exactly NG loads, past the end of the workgroup's rows too - those touch no memory and
+// fill zeros), the LDS reads are inline assembly so that hipcc does not drain the ring in front of them.
+// 160 accumulator registers: one wave per SIMD, one workgroup per CU.
+template <int NB, int ACT>
+__global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
+    constexpr int S = 32 * NB, RT = 2 * NB + 1;
+    constexpr bool HAS_Y = ACT != GNN_ACT_LINEAR;
+    constexpr int ARR = 16 * S * 4, NA = HAS_Y ? 4 : 3;        // bytes of 16 rows of an [M, S] array; arrays in a slot: dZ | state | agg | (Y)
+    constexpr int SLOT = NA * ARR + 2048, NG = SLOT / 1024;    // + 16 rows of the constants line; LDS-DMA instructions a step
+    extern __shared__ __attribute__((aligned(16))) float tb_smem[];     // [4 waves][2 slots][SLOT]; the workgroup's partial P afterwards
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (uniform: the ring's addresses stay in scalar registers)
+    const int i = lane & 31, kg = lane >> 5;
+    const int m_beg = blockIdx.x * a.rows_per_wg, m_end = min(a.M, m_beg + a.rows_per_wg);
+    const int rows = max(m_end - m_beg, 0);
+    const int n_steps = (rows + 63) >> 6;               // a workgroup step = 64 rows: 16 per wave
+    // windows of exactly this workgroup's rows: what lies past them reads 0
+    const size_t o_rows = (size_t)m_beg * S;
+    const unsigned win = (unsigned)rows * (unsigned)S * 4u;
+    const __amdgpu_buffer_rsrc_t r_g = buf_rsrc_n(a.G + o_rows, win), r_y = buf_rsrc_n(a.Y ? a.Y + o_rows : nullptr, win), r_s = buf_rsrc_n(a.state + o_rows, win),
+                                 r_a = buf_rsrc_n(a.agg + o_rows, win), r_c = buf_rsrc_n(a.xc ? a.xc + (size_t)m_beg * 32 : nullptr, (unsigned)rows * 128u);
+    f32x16 acc[RT][NB];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int f = 0; f < NB; ++f)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[rt][f][v] = 0.0f;
+    float mu_s[NB], mu_a[NB], mu_c;
+#pragma unroll
+    for (int e = 0; e < NB; ++e) { mu_s[e] = a.mean ? a.mean[a.wrow_state + NB * i + e] : 0.0f; mu_a[e] = a.mean ? a.mean[a.wrow_agg + NB * i + e] : 0.0f; }
+    { const int wr = wgrad_wrow(a, S, 2 * S + i); mu_c = (a.mean && wr >= 0) ? a.mean[wr] : 0.0f; }
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char *ring = (lds_char *)tb_smem + wave * (2 * SLOT);
+    const unsigned ring_addr = (unsigned)(size_t)ring;
+    auto fill = [&](int slot, int s) {                      // the 16 rows of step s of this wave -> slot
+        lds_char *dst = ring + slot * SLOT;
+        const unsigned off = ((unsigned)(64 * s + 16 * wave) * (unsigned)S) * 4u + 16u * (unsigned)lane, off_c = (unsigned)(64 * s + 16 * wave) * 128u + 16u * (unsigned)lane;
+#pragma unroll
+        for (int q = 0; q < ARR / 1024; ++q) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_g, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_s, (__attribute__((address_space(3))) void *)(dst + ARR + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (__attribute__((address_space(3))) void *)(dst + 2 * ARR + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, 0);
+            if (HAS_Y) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_y, (__attribute__((address_space(3))) void *)(dst + 3 * ARR + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_c, (__attribute__((address_space(3))) void *)(dst + NA * ARR + 1024 * q), 16, (int)(off_c + 1024u * q), 0, 0, 0);
+    };
+    struct Step { Piece<NB> gz[8], xs[8], xa[8], y[8]; Piece<1> xc[8]; };
+    const unsigned lane_addr = ring_addr + (unsigned)(8 * kg) * (unsigned)(S * 4) + (unsigned)(NB * i) * 4u, lane_addr_c = ring_addr + NA * ARR + (unsigned)(8 * kg) * 128u + (unsigned)i * 4u;
+#define B8(v_) __builtin_bit_cast(bf16x8, v_)
+    auto split8 = [&](const float (&x)[8], u32x4 &h, u32x4 &m, u32x4 &l) {
+        unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (TB_ABL & 64) { hh[q] = __float_as_uint(x[2 * q]); mm[q] = __float_as_uint(x[2 * q + 1]); ll[q] = hh[q] ^ mm[q]; }      // (ablation: no split)
+            else split3_pk((f32x2){x[2 * q], x[2 * q + 1]}, hh[q], mm[q], ll[q]);
+        }
+        h = (u32x4){hh[0], hh[1], hh[2], hh[3]}; m = (u32x4){mm[0], mm[1], mm[2], mm[3]}; l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+    };
+    fill(0, 0); fill(1, 1);
 #pragma unroll 1
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int m = 8 * (v >> 2) + 4 * kk + (v & 3);
-                    const int kv = rt < NB ? NB * m + rt : rt < 2 * NB ? S + NB * m + (rt - NB) : 2 * S + m;
-                    float *dst = Ps + kv * S + NB * i;
-#pragma unroll
-                    for (int f = 0; f < NB; ++f) dst[f] = w == 0 ? acc[rt][f][v] : dst[f] + acc[rt][f][v];
-                }
+    for (int s = 0; s < n_steps; ++s) {
+        const int slot = s & 1;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NG) : "memory");            // slot's rows have landed (the other slot's NG loads may still be out)
+        Step b;
+        {   // (inline assembly: see above; constant offsets in the instruction - the caller waits lgkmcnt(0))
+            unsigned base = lane_addr + (unsigned)slot * SLOT, base_c = lane_addr_c + (unsigned)slot * SLOT;
+            static_for<0, 8>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                lds_read_piece<NB, j * S * 4>(b.gz[j], base); lds_read_piece<NB, ARR + j * S * 4>(b.xs[j], base); lds_read_piece<NB, 2 * ARR + j * S * 4>(b.xa[j], base);
+                if (HAS_Y) lds_read_piece<NB, 3 * ARR + j * S * 4>(b.y[j], base);
+                lds_read_piece<1, j * 128>(b.xc[j], base_c);
+            });
         }
-        __syncthreads();
-    }
-    float *Pp = a.part + (size_t)blockIdx.x * ((size_t)a.K * S + S);
-    for (int idx = tid; idx < KV * S; idx += 256) {
-        const int kv = idx / S, h = idx % S;
-        int wrow = -1;
-        if (kv < S) wrow = a.wrow_state + kv;
-        else if (kv < 2 * S) wrow = a.wrow_agg + (kv - S);
-        else {
-            int jj = kv - 2 * S, b0 = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // the slot is in registers: hand it to the loads of step s + 2
 #pragma unroll
-            for (int sg = 0; sg < 3; ++sg) { if (sg < a.cs.n && jj >= b0 && jj < b0 + a.cs.width[sg]) wrow = a.cs.wrow[sg] + (jj - b0); if (sg < a.cs.n) b0 += a.cs.width[sg]; }
-            if (jj == a.Kc) wrow = a.K;                              // the line's 1: q
+        for (int j = 0; j < 8; ++j) {             // (no instruction: every use of a value that was read comes after the wait - volatile statements keep their order)
+#pragma unroll
+            for (int e = 0; e < NB; ++e) { asm volatile("" : "+v"(b.gz[j].v[e])); asm volatile("" : "+v"(b.xs[j].v[e])); asm volatile("" : "+v"(b.xa[j].v[e])); if (HAS_Y) asm volatile("" : "+v"(b.y[j].v[e])); }
+            asm volatile("" : "+v"(b.xc[j].v[0]));
         }
-        if (wrow >= 0) Pp[(size_t)wrow * S + h] = Ps[idx];
+        fill(slot, s + 2);
+        u32x4 zh[NB], zm[NB], zl[NB];
+#pragma unroll
+        for (int f = 0; f < NB; ++f) {
+            float dz[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dz[j] = HAS_Y ? b.gz[j].v[f] * activate_grad1<ACT>(b.y[j].v[f]) : b.gz[j].v[f];
+            split8(dz, zh[f], zm[f], zl[f]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = rt < NB ? b.xs[j].v[rt < NB ? rt : 0] - mu_s[rt < NB ? rt : 0]
+                                             : rt < 2 * NB ? b.xa[j].v[rt < 2 * NB && rt >= NB ? rt - NB : 0] - mu_a[rt < 2 * NB && rt >= NB ? rt - NB : 0] : b.xc[j].v[0] - mu_c;
+            u32x4 xh, xm, xl;
+            split8(x, xh, xm, xl);
+            // small terms first; consecutive MFMAs go to different accumulators
+#define MF(xp_, zp_) _Pragma("unroll") for (int f = 0; f < NB; ++f) acc[rt][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(xp_), B8(zp_[f]), acc[rt][f], 0, 0, 0)
+            if (TB_ABL & 32) {           // (ablation of scripts/micro/rowgemm_bench.hip: no products)
+#pragma unroll
+                for (int f = 0; f < NB; ++f) acc[rt][f][0] += __uint_as_float(xl[0] ^ xm[1] ^ xh[2] ^ zh[f][3] ^ zm[f][0] ^ zl[f][1]);
+            } else {
+                MF(xl, zh); MF(xh, zl); MF(xm, zm); MF(xm, zh); MF(xh, zm); MF(xh, zh);
+            }
+#undef MF
+        }
     }
+#undef B8
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the two fills past the end)
+    __syncthreads();                                        // every wave is done with its ring: the partial P takes its place
+    wgrad32_store<NB>(a, acc, tb_smem);
+}
+template <int NB, int ACT>
+inline size_t train_wgrad_b6_lds() {
+    const size_t S = 32 * NB, ring = 4 * 2 * ((ACT != GNN_ACT_LINEAR ? 4 : 3) * 16 * S * 4 + 2048), P = (2 * S + 32) * S * 4;
+    return ring > P ? ring : P;
 }
 
 // ---- the transposed aggregate that leaves the PREVIOUS iteration's dZ (round 5) ---------------------------------------------------------------

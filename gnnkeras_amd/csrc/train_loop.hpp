@@ -568,6 +568,43 @@ bool launch_train_wgrad32(const gnn::TrainWgradArgs &wa, int S, int grid, hipStr
     return false;
 }
 
+// ... and on the bf16 matrix cores (k_train_wgrad_b6: three-term splits, rows through an LDS ring; GNN_TRAIN_WGRAD_B6=0 keeps the f32-input
+// kernel): rows_per_wg must be a multiple of 64, one workgroup per CU
+template <int NB, int ACT>
+bool launch_train_wgrad_b6_na(const gnn::TrainWgradArgs &wa, int grid, hipStream_t st) {
+    static bool attr = false;
+    const size_t lds = gnn::train_wgrad_b6_lds<NB, ACT>();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)gnn::k_train_wgrad_b6<NB, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        attr = true;
+    }
+    gnn::k_train_wgrad_b6<NB, ACT><<<grid, 256, lds, st>>>(wa);
+    return true;
+}
+template <int NB>
+bool launch_train_wgrad_b6_nb(const gnn::TrainWgradArgs &wa, int grid, hipStream_t st) {
+    switch (wa.act) {
+        case GNN_ACT_LINEAR: return launch_train_wgrad_b6_na<NB, GNN_ACT_LINEAR>(wa, grid, st);
+        case GNN_ACT_RELU: return launch_train_wgrad_b6_na<NB, GNN_ACT_RELU>(wa, grid, st);
+        case GNN_ACT_SELU: return launch_train_wgrad_b6_na<NB, GNN_ACT_SELU>(wa, grid, st);
+        case GNN_ACT_TANH: return launch_train_wgrad_b6_na<NB, GNN_ACT_TANH>(wa, grid, st);
+        case GNN_ACT_SIGMOID: return launch_train_wgrad_b6_na<NB, GNN_ACT_SIGMOID>(wa, grid, st);
+        case GNN_ACT_ELU: return launch_train_wgrad_b6_na<NB, GNN_ACT_ELU>(wa, grid, st);
+        case GNN_ACT_SOFTPLUS: return launch_train_wgrad_b6_na<NB, GNN_ACT_SOFTPLUS>(wa, grid, st);
+        default: return false;
+    }
+}
+inline bool train_wgrad_b6_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_TRAIN_WGRAD_B6"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0 && train_bf16x6_enabled() && train_wgrad32_enabled();
+}
+bool launch_train_wgrad_b6(const gnn::TrainWgradArgs &wa, int S, int grid, hipStream_t st) {
+    if (S == 64) return launch_train_wgrad_b6_nb<2>(wa, grid, st);
+    if (S == 32) return launch_train_wgrad_b6_nb<1>(wa, grid, st);
+    return false;
+}
+
 int launch_train_bwd_dx(const gnn::TrainBwdArgs &ba, int S, hipStream_t st) {
     if (train_bf16x6_enabled() && ba.H == S && ba.S == S && ba.ldz == S) {
         const int grid = std::max(1, std::min(2 * device_cus(), cdiv((ba.M + 15) / 16, 4)));       // 256-thread workgroups, two per CU
@@ -1105,15 +1142,17 @@ int gnn_train_step(const gnn_train_args_t *args) {
                 // reduction and parameter-gradient kernels as net_backward
                 gnn::TrainWgradArgs wa;
                 memset(&wa, 0, sizeof(wa));
-                const int n_wg = std::min(std::min(2 * device_cus(), BIG_WGRAD_BLOCKS), cdiv(p.N, 64));
-                wa.M = p.N; wa.rows_per_wg = cdiv(cdiv(p.N, n_wg), 16) * 16;
+                const bool wg_b6 = train_wgrad_b6_enabled() && (p.S == 64 || p.S == 32);
+                const int n_wg = std::min(std::min((wg_b6 ? 1 : 2) * device_cus(), BIG_WGRAD_BLOCKS), cdiv(p.N, 64));
+                wa.M = p.N; wa.rows_per_wg = wg_b6 ? cdiv(cdiv(p.N, n_wg), 64) * 64 : cdiv(cdiv(p.N, n_wg), 16) * 16;
                 wa.G = p.G_state; wa.Y = dzpath ? nullptr : s_n; wa.act = dzpath ? GNN_ACT_LINEAR : ns.activation[0];      // (dzpath: G_state holds dZ)
                 wa.state = s_t; wa.agg = agg_t; wa.xc = p.xc;
                 wa.K = p.in_s; wa.wrow_state = 0; wa.wrow_agg = p.off_agg; wa.Kc = p.Kc; wa.cs = p.cc;
                 wa.part = p.part_w;
                 wa.mean = stats;                       // (BatchNormalization: the rows are centred as they arrive, P arrives as P - mean q^T)
                 const int grid = cdiv(p.N, wa.rows_per_wg);
-                if (!launch_train_wgrad32(wa, p.S, grid, st)) {       // (S = 16, or an activation without an instance: the 16x16x4 kernel)
+                if (wg_b6 && launch_train_wgrad_b6(wa, p.S, grid, st)) {
+                } else if (!launch_train_wgrad32(wa, p.S, grid, st)) {       // (S = 16, or an activation without an instance: the 16x16x4 kernel)
                     switch (p.S) {
                         case 16: gnn::k_train_wgrad<1><<<grid, 256, 0, st>>>(wa); break;
                         case 32: gnn::k_train_wgrad<2><<<grid, 256, 0, st>>>(wa); break;

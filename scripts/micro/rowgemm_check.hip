@@ -82,7 +82,7 @@ void check_fwd(int M, bool pred, bool centred = false) {
 }
 
 
-template <int SQ, bool W32>
+template <int SQ, bool W32, bool B6 = false>
 void check_wgrad(int M, bool centred = false) {
     const int S = 16 * SQ, L = 7, A_ = 3, Kc = 2 * L + A_, K = 2 * S + Kc, wa = S + L;
     std::mt19937 rng(3); std::normal_distribution<float> nd(0, 1);
@@ -92,7 +92,7 @@ void check_wgrad(int M, bool centred = false) {
     for (int m = 0; m < M; ++m) { for (int j = 0; j < Kc; ++j) xc[(size_t)m * 32 + j] = nd(rng); xc[(size_t)m * 32 + Kc] = 1.f; }
     gnn::TrainWgradArgs a; memset(&a, 0, sizeof(a));
     const int n_wg = 37;
-    a.M = M; a.rows_per_wg = ((M + n_wg - 1) / n_wg + 15) / 16 * 16;
+    a.M = M; a.rows_per_wg = B6 ? ((M + n_wg - 1) / n_wg + 63) / 64 * 64 : ((M + n_wg - 1) / n_wg + 15) / 16 * 16;
     const int grid = (M + a.rows_per_wg - 1) / a.rows_per_wg;
     float *part; CK(hipMalloc(&part, (size_t)grid * (K * S + S) * 4)); CK(hipMemset(part, 0, (size_t)grid * (K * S + S) * 4));
     a.G = up(G); a.Y = up(Y); a.act = GNN_ACT_TANH; a.state = up(st); a.agg = up(ag); a.xc = up(xc);
@@ -100,7 +100,11 @@ void check_wgrad(int M, bool centred = false) {
     a.part = part;
     std::vector<float> mu(K + 1, 0.f);
     if (centred) { for (int k = 0; k < K; ++k) mu[k] = 0.5f + 0.1f * nd(rng); a.mean = up(mu); }
-    if constexpr (W32) gnn::k_train_wgrad32<SQ / 2, GNN_ACT_TANH><<<grid, 256>>>(a); else gnn::k_train_wgrad<SQ><<<grid, 256>>>(a);
+    if constexpr (B6) {
+        CK(hipFuncSetAttribute((const void *)gnn::k_train_wgrad_b6<SQ / 2, GNN_ACT_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gnn::train_wgrad_b6_lds<SQ / 2, GNN_ACT_TANH>()));
+        gnn::k_train_wgrad_b6<SQ / 2, GNN_ACT_TANH><<<grid, 256, gnn::train_wgrad_b6_lds<SQ / 2, GNN_ACT_TANH>()>>>(a);
+    }
+    else if constexpr (W32) gnn::k_train_wgrad32<SQ / 2, GNN_ACT_TANH><<<grid, 256>>>(a); else gnn::k_train_wgrad<SQ><<<grid, 256>>>(a);
     CK(hipDeviceSynchronize());
     std::vector<float> pt((size_t)grid * (K * S + S));
     CK(hipMemcpy(pt.data(), part, pt.size() * 4, hipMemcpyDeviceToHost));
@@ -114,13 +118,14 @@ void check_wgrad(int M, bool centred = false) {
     }
     double worst = 0, scale = 0;
     for (size_t idx = 0; idx < P.size(); ++idx) { double sum = 0; for (int b = 0; b < grid; ++b) sum += pt[(size_t)b * (K * S + S) + idx]; worst = fmax(worst, fabs(sum - P[idx])); scale = fmax(scale, fabs(P[idx])); }
-    printf("wgrad<%d>%s M=%d centred=%d  max abs err %.3e (scale %.3e)\n", SQ, W32 ? " 32x32" : "", M, centred, worst, scale);
+    printf("wgrad<%d>%s M=%d centred=%d  max abs err %.3e (scale %.3e)\n", SQ, B6 ? " bf16x6" : W32 ? " 32x32" : "", M, centred, worst, scale);
 }
 
 int main() {
     for (int M : {1000, 40000}) { check_fwd<1>(M, true, true); check_fwd<2>(M, true, true); check_fwd<4>(M, true, true); check_fwd<1, 3>(M, true, true); check_fwd<2, 3>(M, true, true); check_fwd<4, 3>(M, true, true); }
     for (int M : {1000, 40000, 77}) { check_wgrad<2, false>(M); check_wgrad<4, false>(M); check_wgrad<2, true>(M); check_wgrad<4, true>(M);
-        check_wgrad<1, false>(M, true); check_wgrad<4, false>(M, true); check_wgrad<2, true>(M, true); check_wgrad<4, true>(M, true); }
+        check_wgrad<1, false>(M, true); check_wgrad<4, false>(M, true); check_wgrad<2, true>(M, true); check_wgrad<4, true>(M, true);
+        check_wgrad<2, true, true>(M); check_wgrad<4, true, true>(M); check_wgrad<2, true, true>(M, true); check_wgrad<4, true, true>(M, true); }
     for (int M : {1000, 40000, 77}) for (int pr = 0; pr < 2; ++pr) { check_fwd<1>(M, pr); check_fwd<2>(M, pr); check_fwd<4>(M, pr); check_fwd<1, 3>(M, pr); check_fwd<2, 3>(M, pr); check_fwd<4, 3>(M, pr); }
     for (int M : {1000, 40000}) for (int bn = 0; bn < 2; ++bn) for (int sc = 0; sc < 2; ++sc) {
         check_bwd<1, 2>(M, bn, sc); check_bwd<2, 4>(M, bn, sc); check_bwd<4, 8>(M, bn, sc);

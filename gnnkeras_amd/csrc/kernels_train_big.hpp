@@ -1182,6 +1182,10 @@ template <int NB, int OFF> __device__ __forceinline__ void lds_read_piece(Piece<
     else { float v; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); p.v[0] = v; }
 }
 
+template <int OFF, typename V4> __device__ __forceinline__ void lds_read_b128(V4 &v, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); }
+template <typename T> __device__ __forceinline__ void asm_tie(T &x) { asm volatile("" : "+v"(x)); }       // no instruction: orders the uses of x behind the volatile statements before it
+template <int OFF> __device__ __forceinline__ void lds_read_f32(float &v, unsigned addr) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); }
+
 // ... and on the bf16 matrix cores (round 5).  scripts/micro/mfma_bf16_valu_overlap.hip: on gfx950 a SIMD issues EITHER a matrix instruction
 // OR a VALU instruction - a wave's own VALU work does not run in the shadow of its MFMAs, nor does the other wave's (24 MFMAs + 96 v_fma a
 // trip: 516 ns in phases, 533 interleaved, 589 on specialised waves, against 336 + 212 alone) - so a dense kernel costs the SUM of its
@@ -1317,6 +1321,230 @@ template <int NB, int ACT>
 inline size_t train_wgrad_b6_lds() {
     const size_t S = 32 * NB, ring = 4 * 2 * ((ACT != GNN_ACT_LINEAR ? 4 : 3) * 16 * S * 4 + 2048), P = (2 * S + 32) * S * 4;
     return ring > P ? ring : P;
+}
+
+// ---- weight gradient AND input gradient of an iteration in one pass over its rows (round 5) -------------------------------------------------
+// k_train_wgrad_b6 reads dZ | state | agg | constants (896 bytes a row at S = 64), k_train_bwd_dx_b6 reads dZ | agg again and writes dx (1 024
+// bytes): 1 920 bytes a row and iteration, both kernels waiting on memory.  Here the rows a wave has in its LDS ring serve both products:
+//   P  += [state | agg | constants]^T dZ      (v_mfma_f32_32x32x16_bf16, as k_train_wgrad_b6: lane (i, kg), operands paired along the rows)
+//   dx  = BatchNorm'( dZ W^T )                (v_mfma_f32_16x16x32_bf16, as k_train_bwd_dx_b6: lane (c, g) = row c, W^T's bf16 planes in LDS)
+// 1 412 bytes a row.  The dZ form only (TrainWgradArgs::Y == NULL; the input gradient does not read the state rows), and the launcher
+// uses it for networks WITHOUT BatchNormalization: with it, m1 / m2 of the input gradient are column moments that come out of this very
+// iteration's finished P and q (train_loop.hpp) - the kernel takes them as given (TrainBwdArgs::defer_state_bn form).  The ring's image of an [16, S] piece is XOR-swizzled by the row (position of 16-byte piece p of row r:
+// r PPR + (p ^ r % PPR); LDS-DMA places a wave-load's lanes one after the other, so the SOURCE addresses carry the permutation): the
+// row-per-lane reads of the second product would otherwise hit one bank group 16 times.  The constants line has one slot (filled one
+// step ahead, issued BEFORE the rows of step s + 2 so that vmcnt(NGM) covers it), everything else two.  Every LDS read of the loop is
+// inline assembly (hipcc puts vmcnt(0) in front of an LDS read it can see while LDS-DMA is in flight), the counts are in the code.
+template <int NB>
+__global__ void __launch_bounds__(256, 1) k_train_wgrad_dx_b6(TrainWgradArgs a, TrainBwdArgs ba) {
+    constexpr int S = 32 * NB, RT = 2 * NB + 1, HQ = 2 * NB, NCT = 2 * HQ, HP = 16 * NCT, NKB = NB, PPR = S / 4;
+    constexpr int PLANE_E = NKB * NCT * 64 * 8, PLANE_B = 2 * PLANE_E;         // elements / bytes of one bf16 plane of W^T
+    constexpr int W_B = 3 * PLANE_B, COEF_B = 4 * HP * 4;
+    constexpr int ARR = 16 * S * 4, NQ = ARR / 1024;                           // 16 rows of an [M, S] array; wave-loads that bring them
+    constexpr int MAIN = 3 * ARR + 256, XCB = 2048, WAVE_B = 2 * MAIN + XCB;   // slot: dZ | state | agg | row scales;  a wave's ring: slot 0 | slot 1 | constants line
+    constexpr int NGM = 3 * NQ + 1;                                            // LDS-DMA instructions of a slot
+    extern __shared__ __attribute__((aligned(16))) float tb_smem[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kg = lane >> 5;            // first product
+    const int c = lane & 15, g = lane >> 4;             // second product
+    unsigned short *Wl = reinterpret_cast<unsigned short *>(tb_smem);
+    float *coef = tb_smem + W_B / 4;
+    for (int idx = tid; idx < 32 * NKB * HP; idx += 256) {                      // W^T's three bf16 planes, k_train_bwd_dx_b6's layout
+        const int k = idx / HP, j = idx % HP;
+        const int row = j < S ? ba.wrow_state + j : ba.wrow_agg + (j - S);
+        const float v = k < ba.H ? ba.W[(size_t)row * ba.ldw + k] : 0.0f;
+        const int q = k >> 4, gg = (k >> 2) & 3, e = k & 3;
+        split3_store(Wl, PLANE_E, ((((q >> 1) * NCT + (j >> 4)) * 64 + 16 * gg + (j & 15)) * 8) + 4 * (q & 1) + e, v);
+    }
+    for (int j = tid; j < HP; j += 256) {
+        float Ac = 1.0f, Cc = 0.0f, M1 = 0.0f, Mu = 0.0f;
+        if (ba.gamma) {
+            const int k = j < S ? ba.wrow_state + j : ba.wrow_agg + (j - S);
+            const float rstd = 1.0f / sqrtf(ba.var[k] + ba.eps);
+            Ac = ba.gamma[k] * rstd; Cc = -Ac * rstd * ba.m2[k]; M1 = ba.m1[k]; Mu = ba.mean[k];
+            if (j < S) { Cc = 0.0f; M1 = 0.0f; Mu = 0.0f; }                   // (TrainBwdArgs::defer_state_bn)
+        }
+        coef[j] = Ac; coef[HP + j] = Cc; coef[2 * HP + j] = M1; coef[3 * HP + j] = Mu;
+    }
+    const int m_beg = blockIdx.x * a.rows_per_wg, m_end = min(a.M, m_beg + a.rows_per_wg);
+    const int rows = max(m_end - m_beg, 0);
+    const int n_steps = (rows + 63) >> 6;
+    const size_t o_rows = (size_t)m_beg * S;
+    const unsigned win = (unsigned)rows * (unsigned)S * 4u;
+    const __amdgpu_buffer_rsrc_t r_g = buf_rsrc_n(a.G + o_rows, win), r_s = buf_rsrc_n(a.state + o_rows, win), r_a = buf_rsrc_n(a.agg + o_rows, win),
+                                 r_c = buf_rsrc_n(a.xc ? a.xc + (size_t)m_beg * 32 : nullptr, (unsigned)rows * 128u),
+                                 r_rs = buf_rsrc_n(ba.agg_row_scale ? ba.agg_row_scale + m_beg : nullptr, (unsigned)rows * 4u),
+                                 r_o = buf_rsrc_n(ba.dx + (size_t)m_beg * ba.ld_dx, (unsigned)rows * (unsigned)ba.ld_dx * 4u);
+    const bool has_rs = ba.agg_row_scale != nullptr;
+    f32x16 acc[RT][NB];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int f = 0; f < NB; ++f)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[rt][f][v] = 0.0f;
+    float mu_s[NB], mu_a[NB], mu_c;
+#pragma unroll
+    for (int e = 0; e < NB; ++e) { mu_s[e] = a.mean ? a.mean[a.wrow_state + NB * i + e] : 0.0f; mu_a[e] = a.mean ? a.mean[a.wrow_agg + NB * i + e] : 0.0f; }
+    { const int wr = wgrad_wrow(a, S, 2 * S + i); mu_c = (a.mean && wr >= 0) ? a.mean[wr] : 0.0f; }
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(lds_char *)tb_smem;
+    lds_char *ring = (lds_char *)tb_smem + W_B + COEF_B + wave * WAVE_B;
+    const unsigned ring_addr = lds0 + W_B + COEF_B + (unsigned)wave * WAVE_B;
+    // source offsets of this lane in wave-load q of a 16-row piece (the swizzle), relative to the piece's first byte
+    unsigned src_q[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int pos = 64 * q + lane, r = pos / PPR, sw = pos % PPR; src_q[q] = (unsigned)(r * (S * 4) + ((sw ^ (r & (PPR - 1))) << 4)); }
+    auto fill_main = [&](int slot, int s) {
+        lds_char *dst = ring + slot * MAIN;
+        const unsigned row0 = (unsigned)(64 * s + 16 * wave), base = row0 * (unsigned)(S * 4);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_g, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(base + src_q[q]), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_s, (__attribute__((address_space(3))) void *)(dst + ARR + 1024 * q), 16, (int)(base + src_q[q]), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (__attribute__((address_space(3))) void *)(dst + 2 * ARR + 1024 * q), 16, (int)(base + src_q[q]), 0, 0, 0);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rs, (__attribute__((address_space(3))) void *)(dst + 3 * ARR), 4, (int)((row0 + (unsigned)lane) * 4u), 0, 0, 0);
+    };
+    auto fill_xc = [&](int s) {
+        lds_char *dst = ring + 2 * MAIN;
+        const unsigned off_c = (unsigned)(64 * s + 16 * wave) * 128u + 16u * (unsigned)lane;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_c, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(off_c + 1024u * q), 0, 0, 0);
+    };
+    // LDS offsets of this lane's reads inside a 16-row piece: the first product's eight rows 8 kg + j, the second product's pieces 4 q + g of row c
+    unsigned rd1[8], rd2[HQ];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int r = 8 * kg + j, p = (NB * i) / 4; rd1[j] = (unsigned)((r * PPR + (p ^ (r & (PPR - 1)))) * 16 + ((NB * i) & 3) * 4); }
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) rd2[q] = (unsigned)((c * PPR + ((4 * q + g) ^ (c & (PPR - 1)))) * 16);
+    const unsigned xc_addr = ring_addr + 2 * MAIN + (unsigned)(8 * kg) * 128u + (unsigned)i * 4u;
+    const unsigned w_addr = lds0 + (unsigned)lane * 16u, coef_addr = lds0 + W_B + (unsigned)g * 16u;
+#define B8(v_) __builtin_bit_cast(bf16x8, v_)
+    auto split8 = [&](const float (&x)[8], u32x4 &h, u32x4 &m, u32x4 &l) {
+        unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split3_pk((f32x2){x[2 * q], x[2 * q + 1]}, hh[q], mm[q], ll[q]);
+        h = (u32x4){hh[0], hh[1], hh[2], hh[3]}; m = (u32x4){mm[0], mm[1], mm[2], mm[3]}; l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+    };
+    // The wait at the top of a step: loads retire in issue order AMONG LOADS, stores among stores, but a store may retire before an older
+    // load (a first version counted "[rows of s + 1 | the NCT stores of step s - 1] may be out" - vmcnt(NGM + NCT) - and read a constants
+    // line that had not landed whenever the stores overtook it: wrong constants rows of P in one run of three).  vmcnt(NGM) holds either
+    // way: at most NGM operations out means at most NGM LOADS out, and those are the youngest ones - the rows of step s + 1.
+    fill_main(0, 0); fill_xc(0); fill_main(1, 1);
+#pragma unroll 1
+    for (int s = 0; s < n_steps; ++s) {
+        const int slot = s & 1;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NGM) : "memory");            // slot and the constants line have landed
+        Piece<NB> gz[8], xs[8], xa[8]; Piece<1> xc[8];
+        f32x4 zq[HQ], xq[HQ]; float rs;
+        {
+            unsigned sb = ring_addr + (unsigned)slot * MAIN, xb = xc_addr;
+            static_for<0, 8>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                lds_read_piece<NB, 0>(gz[j], sb + rd1[j]); lds_read_piece<NB, ARR>(xs[j], sb + rd1[j]); lds_read_piece<NB, 2 * ARR>(xa[j], sb + rd1[j]);
+                lds_read_piece<1, j * 128>(xc[j], xb);
+            });
+            static_for<0, HQ>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                lds_read_b128<0>(zq[q], sb + rd2[q]); lds_read_b128<2 * ARR>(xq[q], sb + rd2[q]);
+            });
+            lds_read_f32<3 * ARR>(rs, sb + (unsigned)c * 4u);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // the slot is in registers: hand it to the loads of step s + 2
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int e = 0; e < NB; ++e) { asm volatile("" : "+v"(gz[j].v[e])); asm volatile("" : "+v"(xs[j].v[e])); asm volatile("" : "+v"(xa[j].v[e])); }
+            asm volatile("" : "+v"(xc[j].v[0]));
+        }
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) { asm volatile("" : "+v"(zq[q])); asm volatile("" : "+v"(xq[q])); }
+        asm volatile("" : "+v"(rs));
+        fill_xc(s + 1); fill_main(slot, s + 2);
+        // ---- P += X^T dZ ------------------------------------------------------------------------------------------------------------------
+        {
+            u32x4 zh[NB], zm[NB], zl[NB];
+#pragma unroll
+            for (int f = 0; f < NB; ++f) {
+                float dz[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dz[j] = gz[j].v[f];
+                split8(dz, zh[f], zm[f], zl[f]);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = rt < NB ? xs[j].v[rt < NB ? rt : 0] - mu_s[rt < NB ? rt : 0]
+                                                 : rt < 2 * NB ? xa[j].v[rt < 2 * NB && rt >= NB ? rt - NB : 0] - mu_a[rt < 2 * NB && rt >= NB ? rt - NB : 0] : xc[j].v[0] - mu_c;
+                u32x4 xh, xm, xl;
+                split8(x, xh, xm, xl);
+#define MF(xp_, zp_) _Pragma("unroll") for (int f = 0; f < NB; ++f) acc[rt][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(xp_), B8(zp_[f]), acc[rt][f], 0, 0, 0)
+                MF(xl, zh); MF(xh, zl); MF(xm, zm); MF(xm, zh); MF(xh, zm); MF(xh, zh);
+#undef MF
+            }
+        }
+        // ---- dx = BatchNorm'(dZ W^T) -------------------------------------------------------------------------------------------------------
+        {
+            u32x4 dh[NKB], dm[NKB], dl[NKB];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) split3_x8pk(zq[2 * kb], zq[2 * kb + 1], dh[kb], dm[kb], dl[kb]);
+            f32x4 dacc[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) dacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            constexpr int CTG = 2, SPK = NCT / CTG, NS = NKB * SPK;
+            u32x4 W[2][3][CTG];
+            auto load_w = [&](auto stc, u32x4 (&w)[3][CTG]) {
+                constexpr int st = decltype(stc)::value, kb = st / SPK, ct0 = (st % SPK) * CTG;
+                unsigned wa_ = w_addr;
+                static_for<0, 3>([&](auto plc) { constexpr int pl = decltype(plc)::value;
+                    static_for<0, CTG>([&](auto uc) { constexpr int u = decltype(uc)::value; lds_read_b128<pl * PLANE_B + (kb * NCT + ct0 + u) * 1024>(w[pl][u], wa_); }); });
+            };
+            load_w(std::integral_constant<int, 0>{}, W[0]);
+            static_for<0, NS>([&](auto stc) {
+                constexpr int st = decltype(stc)::value, kb = st / SPK, ct0 = (st % SPK) * CTG;
+                if constexpr (st + 1 < NS) { load_w(std::integral_constant<int, st + 1>{}, W[(st + 1) & 1]); asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(3 * CTG) : "memory"); }
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int u = 0; u < CTG; ++u) asm_tie(W[st & 1][pl][u]);
+#define MF(pl_, x_) _Pragma("unroll") for (int u = 0; u < CTG; ++u) dacc[ct0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B8(W[st & 1][pl_][u]), B8(x_), dacc[ct0 + u], 0, 0, 0)
+                MF(2, dh[kb]); MF(0, dl[kb]); MF(1, dm[kb]); MF(1, dh[kb]); MF(0, dm[kb]); MF(0, dh[kb]);
+#undef MF
+            });
+            const float rs_t = has_rs ? rs : 1.0f;
+            const unsigned orow = ((unsigned)(64 * s + 16 * wave + c) * (unsigned)ba.ld_dx + 4u * (unsigned)g) * 4u;
+            static_for<0, NCT>([&](auto ctc) {
+                constexpr int ct = decltype(ctc)::value;
+                f32x4 Ac, v; unsigned ca = coef_addr;
+                lds_read_b128<ct * 64>(Ac, ca);
+                if constexpr (ct < HQ) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); asm_tie(Ac);
+                    v = Ac * dacc[ct];
+                } else {
+                    f32x4 Cc, M1, Mu;
+                    lds_read_b128<HP * 4 + ct * 64>(Cc, ca); lds_read_b128<2 * HP * 4 + ct * 64>(M1, ca); lds_read_b128<3 * HP * 4 + ct * 64>(Mu, ca);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); asm_tie(Ac); asm_tie(Cc); asm_tie(M1); asm_tie(Mu);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(Ac[e], dacc[ct][e] - M1[e], Cc[e] * (xq[ct - HQ][e] - Mu[e])) * rs_t;
+                }
+                const u32x4 bits = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(bits, r_o, (int)(orow + 64u * ct), 0, 0);
+            });
+        }
+    }
+#undef B8
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    wgrad32_store<NB>(a, acc, tb_smem + (W_B + COEF_B) / 4);
+}
+template <int NB>
+inline size_t train_wgrad_dx_b6_lds() {
+    const size_t S = 32 * NB, HQ = 2 * NB, NCT = 2 * HQ, fixed = 3 * (NB * NCT * 64 * 16) + 4 * 16 * NCT * 4, ring = 4 * (2 * (3 * 16 * S * 4 + 256) + 2048), P = (2 * S + 32) * S * 4;
+    return fixed + (ring > P ? ring : P);
 }
 
 // ---- the transposed aggregate that leaves the PREVIOUS iteration's dZ (round 5) ---------------------------------------------------------------

@@ -605,6 +605,36 @@ bool launch_train_wgrad_b6(const gnn::TrainWgradArgs &wa, int S, int grid, hipSt
     return false;
 }
 
+// weight gradient and input gradient of an iteration in one pass over its rows (k_train_wgrad_dx_b6; the dZ form; GNN_TRAIN_FUSED_BWD=0: the two kernels)
+inline bool train_fused_bwd_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_TRAIN_FUSED_BWD"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+template <int NB>
+bool launch_train_wgrad_dx_b6_nb(const gnn::TrainWgradArgs &wa, const gnn::TrainBwdArgs &ba, int grid, hipStream_t st) {
+    static bool attr = false;
+    const size_t lds = gnn::train_wgrad_dx_b6_lds<NB>();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)gnn::k_train_wgrad_dx_b6<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        attr = true;
+    }
+    gnn::k_train_wgrad_dx_b6<NB><<<grid, 256, lds, st>>>(wa, ba);
+    return true;
+}
+bool launch_train_wgrad_dx_b6(const gnn::TrainWgradArgs &wa, const gnn::TrainBwdArgs &ba, int S, int grid, hipStream_t st) {
+    // With BatchNormalization the input gradient needs m1 / m2 - column moments of dZ W^T that k_first_layer_param_grads derives from THIS
+    // iteration's finished P and q - so the two products cannot share a pass there (the kernel itself takes them as given: scripts/micro/
+    // rowgemm_check.hip checks it bit for bit against the two kernels on arbitrary m1 / m2).  Without it nothing global stands between them.
+    if (ba.gamma) return false;
+    if (wa.Y || wa.act != GNN_ACT_LINEAR || ba.Y) return false;           // the dZ form only
+    if (ba.H != S || ba.S != S || ba.ldz != S || ba.ld_state != S || ba.ld_agg != S || ba.M != wa.M || ba.dZ != wa.G || ba.agg != wa.agg) return false;
+    if ((size_t)wa.rows_per_wg * (size_t)ba.ld_dx * 4 >= 0xFFFFFFF0ull) return false;
+    if (S == 64) return launch_train_wgrad_dx_b6_nb<2>(wa, ba, grid, st);
+    if (S == 32) return launch_train_wgrad_dx_b6_nb<1>(wa, ba, grid, st);
+    return false;
+}
+
 int launch_train_bwd_dx(const gnn::TrainBwdArgs &ba, int S, hipStream_t st) {
     if (train_bf16x6_enabled() && ba.H == S && ba.S == S && ba.ldz == S) {
         const int grid = std::max(1, std::min(2 * device_cus(), cdiv((ba.M + 15) / 16, 4)));       // 256-thread workgroups, two per CU
@@ -1137,6 +1167,17 @@ int gnn_train_step(const gnn_train_args_t *args) {
         const bool unit_w = p.big && !a.adjacency.w;
         const bool wgrad = p.big && p.Kc > 0 && p.Kc < 32 && train_wgrad_enabled();
         if (p.big) {
+            gnn::TrainBwdArgs ba;                                    // d loss / d [state | agg] of this iteration (not taken at t == 0: nothing consumes it)
+            memset(&ba, 0, sizeof(ba));
+            ba.M = p.N; ba.dZ = p.G_state; ba.ldz = p.S;            // (net_backward: the activation gradient ran in place; dzpath: dZ arrived as such)
+            if (wgrad && !dzpath) { ba.Y = s_n; ba.act = ns.activation[0]; }   // (G is untouched: dZ is formed as the rows arrive)
+            ba.W = ns.kernel[0]; ba.ldw = p.H1s; ba.H = p.H1s; ba.S = p.S; ba.wrow_state = 0; ba.wrow_agg = p.off_agg;
+            ba.state = s_t; ba.ld_state = p.S; ba.agg = agg_t; ba.ld_agg = p.S;
+            if (bn_s) { ba.gamma = ns.bn_gamma; ba.mean = stats; ba.var = stats + p.in_s; ba.m1 = p.cs.m1; ba.m2 = p.cs.m2; ba.eps = ns.bn_eps; }
+            ba.defer_state_bn = (dzpath && bn_s) ? 1 : 0;            // (k_aggregate_dz adds the rest of the state half's BatchNorm gradient: it reads state_t anyway)
+            ba.agg_row_scale = unit_w ? a.adjacency.row_scale : nullptr;
+            ba.dx = p.dx_s_all; ba.ld_dx = p.kdx_s;
+            bool dx_done = false;
             if (wgrad) {
                 // P = X^T dZ and q on the matrix cores straight from the rows (dZ = G (.) act'(s_n) formed on the way), then the same
                 // reduction and parameter-gradient kernels as net_backward
@@ -1151,7 +1192,8 @@ int gnn_train_step(const gnn_train_args_t *args) {
                 wa.part = p.part_w;
                 wa.mean = stats;                       // (BatchNormalization: the rows are centred as they arrive, P arrives as P - mean q^T)
                 const int grid = cdiv(p.N, wa.rows_per_wg);
-                if (wg_b6 && launch_train_wgrad_b6(wa, p.S, grid, st)) {
+                if (wg_b6 && dzpath && t > 0 && train_fused_bwd_enabled() && launch_train_wgrad_dx_b6(wa, ba, p.S, grid, st)) dx_done = true;    // both products from one pass over the rows
+                else if (wg_b6 && launch_train_wgrad_b6(wa, p.S, grid, st)) {
                 } else if (!launch_train_wgrad32(wa, p.S, grid, st)) {       // (S = 16, or an activation without an instance: the 16x16x4 kernel)
                     switch (p.S) {
                         case 16: gnn::k_train_wgrad<1><<<grid, 256, 0, st>>>(wa); break;
@@ -1170,17 +1212,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
                 LAUNCH_OK();
             } else TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, nullptr, 0, p.part, st, p.off_agg));
             if (t == 0) break;                                       // nothing consumes d loss / d state_0: no input gradient, no transposed aggregate
-            gnn::TrainBwdArgs ba;
-            memset(&ba, 0, sizeof(ba));
-            ba.M = p.N; ba.dZ = p.G_state; ba.ldz = p.S;            // (net_backward: the activation gradient ran in place; dzpath: dZ arrived as such)
-            if (wgrad && !dzpath) { ba.Y = s_n; ba.act = ns.activation[0]; }   // (G is untouched: dZ is formed as the rows arrive)
-            ba.W = ns.kernel[0]; ba.ldw = p.H1s; ba.H = p.H1s; ba.S = p.S; ba.wrow_state = 0; ba.wrow_agg = p.off_agg;
-            ba.state = s_t; ba.ld_state = p.S; ba.agg = agg_t; ba.ld_agg = p.S;
-            if (bn_s) { ba.gamma = ns.bn_gamma; ba.mean = stats; ba.var = stats + p.in_s; ba.m1 = p.cs.m1; ba.m2 = p.cs.m2; ba.eps = ns.bn_eps; }
-            ba.defer_state_bn = (dzpath && bn_s) ? 1 : 0;            // (k_aggregate_dz adds the rest of the state half's BatchNorm gradient: it reads state_t anyway)
-            ba.agg_row_scale = unit_w ? a.adjacency.row_scale : nullptr;
-            ba.dx = p.dx_s_all; ba.ld_dx = p.kdx_s;
-            TRY(launch_train_bwd_dx(ba, p.S, st));
+            if (!dx_done) TRY(launch_train_bwd_dx(ba, p.S, st));
         } else {
             TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, t > 0 ? p.dx_s_all : nullptr, t > 0 ? p.kdx_s : 0, p.part, st, p.off_agg));
             if (t == 0) break;                                       // (as above)

@@ -94,7 +94,7 @@ int main(int argc, char **argv) {
     run("k_train_bwd_dx<4,8>", [&] { gnn::k_train_bwd_dx<4, 8><<<grid, 64 * gnn::TB_WAVES, gnn::train_bwd_lds<4, 8>()>>>(ba); }, (double)M * (5.0 * S) * 4);
     { gnn::TrainWgradArgs wa; memset(&wa, 0, sizeof(wa));
       const int n_wg = grid; wa.M = M; wa.rows_per_wg = ((M + n_wg - 1) / n_wg + 15) / 16 * 16; const int wgrid = (M + wa.rows_per_wg - 1) / wa.rows_per_wg;
-      float *wpart; CK(hipMalloc(&wpart, (size_t)wgrid * (K * S + S) * 4));
+      float *wpart; CK(hipMalloc(&wpart, (size_t)std::max(wgrid, 512) * (K * S + S) * 4));
       wa.G = Y; wa.Y = state; wa.act = GNN_ACT_SELU; wa.state = state; wa.agg = agg; wa.xc = xc; wa.K = K; wa.wrow_state = 0; wa.wrow_agg = S + 14; wa.Kc = 31; wa.cs = fa.cs; wa.part = wpart;
       run("k_train_wgrad<4>", [&] { gnn::k_train_wgrad<4><<<wgrid, 256>>>(wa); }, (double)M * (4.0 * S + 32) * 4);
       run("k_train_wgrad32<2>", [&] { gnn::k_train_wgrad32<2, GNN_ACT_SELU><<<wgrid, 256>>>(wa); }, (double)M * (4.0 * S + 32) * 4);
@@ -113,5 +113,13 @@ int main(int argc, char **argv) {
     // BatchNormalization term is left to k_aggregate_dz
     ba.Y = nullptr; ba.act = GNN_ACT_LINEAR; ba.defer_state_bn = 1;
     run("bwd_dx_b6<4,lin> dz", [&] { gnn::k_train_bwd_dx_b6<4, GNN_ACT_LINEAR><<<grid, 256, gnn::train_bwd_b6_lds<4>()>>>(ba); }, (double)M * (4.0 * S) * 4);
+    {   // weight gradient and input gradient in one pass (the dZ form)
+        gnn::TrainWgradArgs wa; memset(&wa, 0, sizeof(wa));
+        const int g6 = 256; wa.M = M; wa.rows_per_wg = ((M + g6 - 1) / g6 + 63) / 64 * 64; const int grid6 = (M + wa.rows_per_wg - 1) / wa.rows_per_wg;
+        float *wpart; CK(hipMalloc(&wpart, (size_t)grid6 * (K * S + S) * 4));
+        wa.G = Y; wa.Y = nullptr; wa.act = GNN_ACT_LINEAR; wa.state = state; wa.agg = agg; wa.xc = xc; wa.K = K; wa.wrow_state = 0; wa.wrow_agg = S + 14; wa.Kc = 31; wa.cs = fa.cs; wa.part = wpart;
+        CK(hipFuncSetAttribute((const void *)gnn::k_train_wgrad_dx_b6<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gnn::train_wgrad_dx_b6_lds<2>()));
+        run("wgrad_dx_b6<2> fused", [&] { gnn::k_train_wgrad_dx_b6<2><<<grid6, 256, gnn::train_wgrad_dx_b6_lds<2>()>>>(wa, ba); }, (double)M * (5.0 * S + 32) * 4);
+    }
     return 0;
 }

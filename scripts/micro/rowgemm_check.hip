@@ -121,7 +121,70 @@ void check_wgrad(int M, bool centred = false) {
     printf("wgrad<%d>%s M=%d centred=%d  max abs err %.3e (scale %.3e)\n", SQ, B6 ? " bf16x6" : W32 ? " 32x32" : "", M, centred, worst, scale);
 }
 
-int main() {
+// the one-pass kernel against the two kernels it replaces (both checked against CPU loops above): same bits expected
+template <int NB>
+void check_fused(int M, bool bn, bool scale, int n_wg = 37) {
+    const int S = 32 * NB, L = 7, A_ = 3, Kc = 2 * L + A_, K = 2 * S + Kc, wagg = S + L;
+    std::mt19937 rng(11); std::normal_distribution<float> nd(0, 1);
+    std::vector<float> G((size_t)M * S), st((size_t)M * S), ag((size_t)M * S), xc((size_t)M * 32, 0.f), W((size_t)K * S), gm(K), mu(K + 1, 0.f), va(K), m1(K), m2(K), rs(M);
+    for (auto *v : {&G, &st, &ag, &W, &gm, &m1, &m2}) for (auto &x : *v) x = nd(rng);
+    for (int k = 0; k < K; ++k) mu[k] = 0.5f + 0.1f * nd(rng);
+    for (auto &x : va) x = fabsf(nd(rng)) + 0.1f;
+    for (auto &x : rs) x = 0.5f + fabsf(nd(rng));
+    for (int m = 0; m < M; ++m) { for (int j = 0; j < Kc; ++j) xc[(size_t)m * 32 + j] = nd(rng); xc[(size_t)m * 32 + Kc] = 1.f; }
+    gnn::TrainWgradArgs a; memset(&a, 0, sizeof(a));
+    a.M = M; a.rows_per_wg = ((M + n_wg - 1) / n_wg + 63) / 64 * 64;
+    const int grid = (M + a.rows_per_wg - 1) / a.rows_per_wg;
+    const size_t np = (size_t)grid * (K * S + S);
+    float *part0, *part1; CK(hipMalloc(&part0, np * 4)); CK(hipMalloc(&part1, np * 4)); CK(hipMemset(part0, 0, np * 4)); CK(hipMemset(part1, 0, np * 4));
+    a.G = up(G); a.Y = nullptr; a.act = GNN_ACT_LINEAR; a.state = up(st); a.agg = up(ag); a.xc = up(xc);
+    a.K = K; a.wrow_state = 0; a.wrow_agg = wagg; a.Kc = Kc; a.cs.n = 3; a.cs.width[0] = L; a.cs.wrow[0] = S; a.cs.width[1] = L; a.cs.wrow[1] = 2 * S + L; a.cs.width[2] = A_; a.cs.wrow[2] = 2 * S + 2 * L;
+    if (bn) a.mean = up(mu);
+    gnn::TrainBwdArgs b; memset(&b, 0, sizeof(b));
+    float *dx0, *dx1; CK(hipMalloc(&dx0, (size_t)M * 2 * S * 4)); CK(hipMalloc(&dx1, (size_t)M * 2 * S * 4)); CK(hipMemset(dx0, 0xff, (size_t)M * 2 * S * 4)); CK(hipMemset(dx1, 0xff, (size_t)M * 2 * S * 4));
+    b.M = M; b.dZ = a.G; b.ldz = S; b.W = up(W); b.ldw = S; b.H = S; b.S = S; b.wrow_state = 0; b.wrow_agg = wagg; b.state = a.state; b.ld_state = S; b.agg = a.agg; b.ld_agg = S;
+    if (bn) { b.gamma = up(gm); b.mean = a.mean; b.var = up(va); b.m1 = up(m1); b.m2 = up(m2); b.eps = 1e-3f; b.defer_state_bn = 1; }
+    if (scale) b.agg_row_scale = up(rs);
+    b.ld_dx = 2 * S; b.act = GNN_ACT_LINEAR;
+    a.part = part0; b.dx = dx0;
+    CK(hipFuncSetAttribute((const void *)gnn::k_train_wgrad_b6<NB, GNN_ACT_LINEAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gnn::train_wgrad_b6_lds<NB, GNN_ACT_LINEAR>()));
+    gnn::k_train_wgrad_b6<NB, GNN_ACT_LINEAR><<<grid, 256, gnn::train_wgrad_b6_lds<NB, GNN_ACT_LINEAR>()>>>(a);
+    CK(hipFuncSetAttribute((const void *)gnn::k_train_bwd_dx_b6<2 * NB, GNN_ACT_LINEAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gnn::train_bwd_b6_lds<2 * NB>()));
+    gnn::k_train_bwd_dx_b6<2 * NB, GNN_ACT_LINEAR><<<64, 256, gnn::train_bwd_b6_lds<2 * NB>()>>>(b);
+    CK(hipDeviceSynchronize());
+    a.part = part1; b.dx = dx1;
+    CK(hipFuncSetAttribute((const void *)gnn::k_train_wgrad_dx_b6<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gnn::train_wgrad_dx_b6_lds<NB>()));
+    gnn::k_train_wgrad_dx_b6<NB><<<grid, 256, gnn::train_wgrad_dx_b6_lds<NB>()>>>(a, b);
+    CK(hipDeviceSynchronize());
+    std::vector<float> p0(np), p1(np), d0((size_t)M * 2 * S), d1((size_t)M * 2 * S);
+    CK(hipMemcpy(p0.data(), part0, np * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(p1.data(), part1, np * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(d0.data(), dx0, d0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(d1.data(), dx1, d1.size() * 4, hipMemcpyDeviceToHost));
+    {   // both partial sums against a CPU loop (state rows of P only: enough to tell which kernel is off)
+        std::vector<double> Pc((size_t)S * S, 0.0);
+        for (int m = 0; m < M; ++m) for (int j = 0; j < S; ++j) { const double x = st[(size_t)m * S + j] - (bn ? mu[j] : 0.f); for (int h = 0; h < S; ++h) Pc[(size_t)j * S + h] += x * G[(size_t)m * S + h]; }
+        double e0 = 0, e1 = 0;
+        for (int j = 0; j < S; ++j) for (int h = 0; h < S; ++h) { double s0 = 0, s1 = 0; for (int b_ = 0; b_ < grid; ++b_) { s0 += p0[(size_t)b_ * (K * S + S) + (size_t)j * S + h]; s1 += p1[(size_t)b_ * (K * S + S) + (size_t)j * S + h]; }
+            e0 = fmax(e0, fabs(s0 - Pc[(size_t)j * S + h])); e1 = fmax(e1, fabs(s1 - Pc[(size_t)j * S + h])); }
+        printf("   against a CPU loop (state rows): k_train_wgrad_b6 %.3e, one-pass kernel %.3e\n", e0, e1);
+        std::vector<double> Pk((size_t)L * S, 0.0);          // the first constants segment: weight rows S .. S + L - 1 = line columns 0 .. L - 1
+        for (int m = 0; m < M; ++m) for (int j = 0; j < L; ++j) { const double x = xc[(size_t)m * 32 + j] - (bn ? mu[S + j] : 0.f); for (int h = 0; h < S; ++h) Pk[(size_t)j * S + h] += x * G[(size_t)m * S + h]; }
+        e0 = e1 = 0;
+        for (int j = 0; j < L; ++j) for (int h = 0; h < S; ++h) { double s0 = 0, s1 = 0; for (int b_ = 0; b_ < grid; ++b_) { s0 += p0[(size_t)b_ * (K * S + S) + (size_t)(S + j) * S + h]; s1 += p1[(size_t)b_ * (K * S + S) + (size_t)(S + j) * S + h]; }
+            e0 = fmax(e0, fabs(s0 - Pk[(size_t)j * S + h])); e1 = fmax(e1, fabs(s1 - Pk[(size_t)j * S + h])); }
+        printf("   against a CPU loop (constants rows): k_train_wgrad_b6 %.3e, one-pass kernel %.3e\n", e0, e1);
+    }
+    double ep = 0, ed = 0, sp = 0, sd = 0; size_t nbad = 0;
+    size_t worst_i = 0; size_t ndiffp = 0;
+    for (size_t i = 0; i < np; ++i) { const double e = fabs((double)p0[i] - p1[i]); if (e > 0) ++ndiffp; if (e > ep) { ep = e; worst_i = i; } sp = fmax(sp, fabs((double)p0[i])); }
+    if (ep > 0) { const size_t per = (size_t)K * S + S; printf("   P differs in %zu entries; worst: workgroup %zu, weight row %zu (state 0..%d, agg %d..%d, q = %d), column %zu: %g vs %g\n", ndiffp, worst_i / per, (worst_i % per) / S, S - 1, wagg, wagg + S - 1, K, (worst_i % per) % S, p0[worst_i], p1[worst_i]);
+      size_t cnt_rows[4] = {0, 0, 0, 0}; for (size_t i = 0; i < np; ++i) if (p0[i] != p1[i]) { const size_t r = (i % per) / S; ++cnt_rows[r < (size_t)S ? 0 : (r >= (size_t)wagg && r < (size_t)(wagg + S)) ? 1 : r == (size_t)K ? 3 : 2]; }
+      printf("   differing entries by kind: state rows %zu, agg rows %zu, constants rows %zu, q %zu\n", cnt_rows[0], cnt_rows[1], cnt_rows[2], cnt_rows[3]); }
+    for (size_t i = 0; i < d0.size(); ++i) { const double e = fabs((double)d0[i] - d1[i]); if (!(e <= 1e-30)) ++nbad; ed = fmax(ed, e == e ? e : 1e30); sd = fmax(sd, fabs((double)d0[i])); }
+    printf("fused<%d> M=%d bn=%d scale=%d grid=%d  P: max |diff| %.3e (scale %.3e)  dx: max |diff| %.3e (scale %.3e), %zu elements differ\n", NB, M, bn, scale, grid, ep, sp, ed, sd, nbad);
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) { for (int nw : {256, 625, 100}) for (int sc = 0; sc < 2; ++sc) { check_fused<1>(40000, false, sc, nw); check_fused<2>(40000, false, sc, nw); check_fused<1>(40000, true, sc, nw); } return 0; }
     for (int M : {1000, 40000}) { check_fwd<1>(M, true, true); check_fwd<2>(M, true, true); check_fwd<4>(M, true, true); check_fwd<1, 3>(M, true, true); check_fwd<2, 3>(M, true, true); check_fwd<4, 3>(M, true, true); }
     for (int M : {1000, 40000, 77}) { check_wgrad<2, false>(M); check_wgrad<4, false>(M); check_wgrad<2, true>(M); check_wgrad<4, true>(M);
         check_wgrad<1, false>(M, true); check_wgrad<4, false>(M, true); check_wgrad<2, true>(M, true); check_wgrad<4, true>(M, true);
@@ -131,5 +194,6 @@ int main() {
         check_bwd<1, 2>(M, bn, sc); check_bwd<2, 4>(M, bn, sc); check_bwd<4, 8>(M, bn, sc);
         check_bwd<1, 2, true>(M, bn, sc); check_bwd<2, 4, true>(M, bn, sc); check_bwd<4, 8, true>(M, bn, sc);
     }
+    for (int M : {1000, 40000, 77}) for (int bn = 0; bn < 2; ++bn) for (int sc = 0; sc < 2; ++sc) { check_fused<2>(M, bn, sc); check_fused<1>(M, bn, sc); }
     return 0;
 }

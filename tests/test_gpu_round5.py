@@ -453,3 +453,27 @@ def test_large_graph_training_with_every_dense_kernel_forming_dz_itself_in_a_chi
                           '-m', 'gpu', '-q', '-x', '-k', sel], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert ' passed' in res.stdout
+
+
+@pytest.mark.parametrize('d', [64, 32])
+def test_large_graph_training_without_batchnorm_takes_both_gradients_in_one_pass(d):
+    """Without BatchNormalization nothing global stands between an iteration's weight gradient and its input gradient: k_train_wgrad_dx_b6
+    forms both from one pass over the rows (dZ | state | agg | constants through an LDS ring, 1 412 instead of 1 920 bytes a row).  The step
+    against float64 autograd and against the building-block orchestration, as every large-graph model (scripts/micro/rowgemm_check.hip holds
+    the kernel bit for bit against the two kernels it replaces)."""
+    from test_gpu_round3 import test_large_graph_training_step_matches_autograd as run
+    run(d, False, 'average', 0.0)
+    run(d, False, 'sum', 0.0)
+
+
+def test_large_graph_training_on_the_kernels_before_the_lds_ring_in_a_child_process():
+    """GNN_TRAIN_WGRAD_B6=0 GNN_TRAIN_FUSED_BWD=0 (read once per process, hence the child): the weight gradient on the f32-input matrix
+    instructions (k_train_wgrad32) and the two-kernel backward pass stay selectable; the same tests against the same oracle."""
+    import subprocess, sys
+    root = os.path.dirname(nat.HERE)
+    env = dict(os.environ, GNN_TRAIN_WGRAD_B6='0', GNN_TRAIN_FUSED_BWD='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_round3.py'), os.path.join(root, 'tests', 'test_gpu_round5.py'),
+                          '-m', 'gpu', '-q', '-x', '-k', 'large_graph_training_step_matches_autograd or takes_both_gradients_in_one_pass'],
+                         capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert ' passed' in res.stdout

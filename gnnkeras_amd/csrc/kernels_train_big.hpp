@@ -522,8 +522,10 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
     if (tid == 0) any_s = 0;
     for (int h = tid; h < HP; h += 64 * TB_WAVES) shift_l[h] = (a.stat_shift && h < a.H) ? a.stat_shift[h] : 0.0f;
     for (int k = tid; k < 16 * NQ; k += 64 * TB_WAVES) mean_l[k] = fwd_in_mean(a, SQ, k);
-    for (int i = tid; i < 16 * NQ * HP; i += 64 * TB_WAVES) {
-        const int k = i / HP, h = i % HP;
+    // the folded weights -> three bf16 planes.  Weight row of every virtual input column first (a table in `red`, free until the end), then
+    // the elements in batches of independent loads (one dependent load per trip of a 20-trip loop was 10 us of every launch)
+    int *rowtab = reinterpret_cast<int *>(red);
+    for (int k = tid; k < 16 * NQ; k += 64 * TB_WAVES) {
         int row = -1;
         if (k < 16 * SQ) row = a.wrow_state + k;
         else if (k < 32 * SQ) row = a.wrow_agg + (k - 16 * SQ);
@@ -535,10 +537,31 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
                 if (sg < a.cs.n) beg += a.cs.width[sg];
             }
         }
-        const float v = (row >= 0 && h < a.H) ? a.Wf[(size_t)row * a.H + h] : 0.0f;
-        const int q = k >> 4, gg = (k >> 2) & 3, e = k & 3;
-        split3_store(Wl, PLANE, ((((q >> 1) * NCT + (h >> 4)) * 64 + 16 * gg + (h & 15)) * 8) + 4 * (q & 1) + e, v);
+        rowtab[k] = row;
     }
+    __syncthreads();
+    {
+        const __amdgpu_buffer_rsrc_t r_w = buf_rsrc(a.Wf);
+        constexpr int PER = (16 * NQ * HP) / (64 * TB_WAVES), BATCH = PER % 5 == 0 ? 5 : PER % 4 == 0 ? 4 : PER % 3 == 0 ? 3 : PER % 2 == 0 ? 2 : 1;       // (64 TB_WAVES is a multiple of HP: a thread keeps its column h)
+        static_assert((16 * NQ * HP) % (64 * TB_WAVES) == 0 && (64 * TB_WAVES) % HP == 0 && PER % BATCH == 0, "weight staging: whole batches");
+        const int h = tid % HP, k0 = tid / HP;
+#pragma unroll 1
+        for (int it0 = 0; it0 < PER; it0 += BATCH) {
+            float v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int k = k0 + (it0 + u) * ((64 * TB_WAVES) / HP), row = rowtab[k];
+                v[u] = buf_ld_f32(r_w, (row >= 0 && h < a.H) ? ((unsigned)row * (unsigned)a.H + (unsigned)h) * 4u : BUF_OFF);
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int k = k0 + (it0 + u) * ((64 * TB_WAVES) / HP);
+                const int q = k >> 4, gg = (k >> 2) & 3, e = k & 3;
+                split3_store(Wl, PLANE, ((((q >> 1) * NCT + (h >> 4)) * 64 + 16 * gg + (h & 15)) * 8) + 4 * (q & 1) + e, v[u]);
+            }
+        }
+    }
+    __syncthreads();                                     // (rowtab lives in `red`)
     for (int h = tid; h < HP; h += 64 * TB_WAVES) bias_l[h] = h < a.H ? a.bf[h] : 0.0f;
     __syncthreads();
     TB_MARK(1);
@@ -821,12 +844,26 @@ __global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int S = a.S;                                                        // == 16 HQ == H (the launcher checks)
-    for (int i = tid; i < 32 * NKB * HP; i += 64 * NW) {
-        const int k = i / HP, j = i % HP;                                     // k = dZ column h, j = output column
-        const int row = j < S ? a.wrow_state + j : a.wrow_agg + (j - S);
-        const float v = k < a.H ? a.W[(size_t)row * a.ldw + k] : 0.0f;
-        const int q = k >> 4, gg = (k >> 2) & 3, e = k & 3;
-        split3_store(Wl, PLANE, ((((q >> 1) * NCT + (j >> 4)) * 64 + 16 * gg + (j & 15)) * 8) + 4 * (q & 1) + e, v);
+    {   // W^T -> three bf16 planes, eight independent loads a batch (one dependent load per trip of a 32-trip loop was a tenth of the launch)
+        const __amdgpu_buffer_rsrc_t r_w = buf_rsrc(a.W);
+        constexpr int TOT = 32 * NKB * HP, BATCH = (TOT / (64 * NW)) % 8 == 0 ? 8 : 4;
+        static_assert(TOT % (64 * NW * BATCH) == 0, "weight staging: whole batches");
+#pragma unroll 1
+        for (int i0 = tid; i0 < TOT; i0 += 64 * NW * BATCH) {
+            float v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int i = i0 + u * 64 * NW, k = i / HP, j = i % HP;       // k = dZ column h, j = output column
+                const int row = j < S ? a.wrow_state + j : a.wrow_agg + (j - S);
+                v[u] = buf_ld_f32(r_w, k < a.H ? ((unsigned)row * (unsigned)a.ldw + (unsigned)k) * 4u : BUF_OFF);
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int i = i0 + u * 64 * NW, k = i / HP, j = i % HP;
+                const int q = k >> 4, gg = (k >> 2) & 3, e = k & 3;
+                split3_store(Wl, PLANE, ((((q >> 1) * NCT + (j >> 4)) * 64 + 16 * gg + (j & 15)) * 8) + 4 * (q & 1) + e, v[u]);
+            }
+        }
     }
     for (int j = tid; j < HP; j += 64 * NW) {
         float Ac = 1.0f, Cc = 0.0f, M1 = 0.0f, Mu = 0.0f;      // (the centred form: see k_train_bwd_dx)
@@ -1350,12 +1387,26 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_dx_b6(TrainWgradArgs a, 
     const int c = lane & 15, g = lane >> 4;             // second product
     unsigned short *Wl = reinterpret_cast<unsigned short *>(tb_smem);
     float *coef = tb_smem + W_B / 4;
-    for (int idx = tid; idx < 32 * NKB * HP; idx += 256) {                      // W^T's three bf16 planes, k_train_bwd_dx_b6's layout
-        const int k = idx / HP, j = idx % HP;
-        const int row = j < S ? ba.wrow_state + j : ba.wrow_agg + (j - S);
-        const float v = k < ba.H ? ba.W[(size_t)row * ba.ldw + k] : 0.0f;
-        const int q = k >> 4, gg = (k >> 2) & 3, e = k & 3;
-        split3_store(Wl, PLANE_E, ((((q >> 1) * NCT + (j >> 4)) * 64 + 16 * gg + (j & 15)) * 8) + 4 * (q & 1) + e, v);
+    {   // W^T's three bf16 planes, k_train_bwd_dx_b6's layout (eight independent loads a batch)
+        const __amdgpu_buffer_rsrc_t r_w = buf_rsrc(ba.W);
+        constexpr int TOT = 32 * NKB * HP, BATCH = 8;
+        static_assert(TOT % (256 * BATCH) == 0, "weight staging: whole batches");
+#pragma unroll 1
+        for (int i0 = tid; i0 < TOT; i0 += 256 * BATCH) {
+            float v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = i0 + u * 256, k = idx / HP, j = idx % HP;
+                const int row = j < S ? ba.wrow_state + j : ba.wrow_agg + (j - S);
+                v[u] = buf_ld_f32(r_w, k < ba.H ? ((unsigned)row * (unsigned)ba.ldw + (unsigned)k) * 4u : BUF_OFF);
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = i0 + u * 256, k = idx / HP, j = idx % HP;
+                const int q = k >> 4, gg = (k >> 2) & 3, e = k & 3;
+                split3_store(Wl, PLANE_E, ((((q >> 1) * NCT + (j >> 4)) * 64 + 16 * gg + (j & 15)) * 8) + 4 * (q & 1) + e, v[u]);
+            }
+        }
     }
     for (int j = tid; j < HP; j += 256) {
         float Ac = 1.0f, Cc = 0.0f, M1 = 0.0f, Mu = 0.0f;

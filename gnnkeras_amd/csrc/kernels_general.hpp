@@ -318,8 +318,9 @@ __global__ void __launch_bounds__(256, SC == 1 ? 8 : 4) k_segdense(SegDenseArgs 
 // The same segmented dense layer for THIN outputs (H <= 4: class scores of the output network, GNN.py:273).  A 64-column
 // MFMA tile would spend 62 of its columns on nothing and stage every input row through LDS; here 16 lanes share a row
 // (16 B per lane where the segment allows it, one 256-B state row per load), keep H partial dot products each, and
-// meet in a 4-step shuffle tree (fixed order: deterministic).  4 rows per lane group are in flight per trip.
-constexpr int TD_ROWS = 4;
+// meet in a 4-step shuffle tree (fixed order: deterministic).  8 rows per lane group are in flight per trip, their loads issued
+// together and unconditionally (behind `if (row valid)` hipcc branches around every load and waits for each alone: 220 us per 1 M rows).
+constexpr int TD_ROWS = 8;
 template <int H>
 __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
     if (gate_closed(a.gate)) return;
@@ -340,20 +341,25 @@ __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
             if (s >= a.nseg) break;
             const Seg sg = a.seg[s];
             long rowv[TD_ROWS];
+            if (sg.rowidx) {                                    // (uniform; the TD_ROWS index loads issued together, unconditional: see the row loads below)
+                int idx[TD_ROWS];
 #pragma unroll
-            for (int r = 0; r < TD_ROWS; ++r) {
-                const long m = base + r;
-                rowv[r] = m < a.M ? (sg.rowidx ? (long)sg.rowidx[m] : m) : -1;
+                for (int r = 0; r < TD_ROWS; ++r) idx[r] = sg.rowidx[base + r < a.M ? base + r : 0];
+#pragma unroll
+                for (int r = 0; r < TD_ROWS; ++r) rowv[r] = base + r < a.M ? (long)idx[r] : -1;
+            } else {
+#pragma unroll
+                for (int r = 0; r < TD_ROWS; ++r) rowv[r] = base + r < a.M ? base + r : -1;
             }
             const bool vec = (sg.width % 4 == 0) && (sg.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.ptr) & 15) == 0);
             if (vec) {
                 for (int c4 = l16; c4 * 4 < sg.width; c4 += 16) {
                     f32x4 x[TD_ROWS];
 #pragma unroll
-                    for (int r = 0; r < TD_ROWS; ++r) {
-                        x[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (rowv[r] >= 0) x[r] = *reinterpret_cast<const f32x4 *>(sg.ptr + rowv[r] * sg.ld + 4 * c4);
-                    }
+                    for (int r = 0; r < TD_ROWS; ++r)                   // unconditional loads (a row past the end reads row 0 and is zeroed after): behind `if (row >= 0)` hipcc
+                        x[r] = *reinterpret_cast<const f32x4 *>(sg.ptr + (rowv[r] >= 0 ? rowv[r] : 0) * sg.ld + 4 * c4);      // branches around every load and waits for each alone
+#pragma unroll
+                    for (int r = 0; r < TD_ROWS; ++r) if (rowv[r] < 0) x[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     const float *w = tdW + (size_t)(sg.wrow + 4 * c4) * H;
                     if (a.in_center) {
                         const float *cp = tdC + sg.wrow + 4 * c4;            // (wrow need not be a multiple of 4: scalar reads)
@@ -374,7 +380,10 @@ __global__ void __launch_bounds__(256) k_thin_dense(SegDenseArgs a, int K) {
                 for (int c = l16; c < sg.width; c += 16) {
                     float x[TD_ROWS];
 #pragma unroll
-                    for (int r = 0; r < TD_ROWS; ++r) x[r] = rowv[r] >= 0 ? sg.ptr[rowv[r] * sg.ld + c] - (a.in_center ? tdC[sg.wrow + c] : 0.0f) : 0.0f;
+                    for (int r = 0; r < TD_ROWS; ++r) x[r] = sg.ptr[(rowv[r] >= 0 ? rowv[r] : 0) * sg.ld + c];          // (unconditional, as above)
+                    const float cen = a.in_center ? tdC[sg.wrow + c] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < TD_ROWS; ++r) x[r] = rowv[r] >= 0 ? x[r] - cen : 0.0f;
                     const float *w = tdW + (size_t)(sg.wrow + c) * H;
 #pragma unroll
                     for (int h = 0; h < H; ++h) {

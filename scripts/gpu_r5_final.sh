@@ -35,6 +35,7 @@ $P $OUT/${TAG}_d200_pmc_FETCH_SIZE.csv $OUT/${TAG}_d200_pmc_WRITE_SIZE.csv 3e5 3
 cp $OUT/hbm_traffic.json profiles/hbm_traffic.json        # (so that the bench line below reports THIS pass's traffic)
 bash scripts/gpu_profile_train.sh $TAG > $OUT/train_profile.log 2>&1 || true
 bash scripts/gpu_pmc_train.sh $TAG > $OUT/train_pmc.log 2>&1 || true      # (FETCH / WRITE passes of the large-graph training kernels: ${TAG}_train_pmc.txt)
+bash scripts/gpu_sq_train.sh $TAG > $OUT/train_sq.log 2>&1 || true         # (SQ / GRBM counters of the same kernels: ${TAG}_train_sq_counters.txt)
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 4000 $OUT/bench_default.json
 python3 -c "from gnnkeras_amd._native import source_hash; print('library sources', source_hash())"

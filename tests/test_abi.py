@@ -130,3 +130,28 @@ def test_validation_paths_under_address_and_ub_sanitizers():
                          capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert res.returncode == 0 and ' passed' in res.stdout, res.stdout[-3000:] + res.stderr[-3000:]
     assert 'ERROR: AddressSanitizer' not in res.stderr and 'runtime error' not in res.stderr, res.stderr[-3000:]
+
+
+def test_kernels_with_hand_counted_waits_use_no_scratch(tmp_path):
+    """k_train_wgrad_b6 / k_train_wgrad_dx_b6 wait for their LDS-DMA loads with `s_waitcnt vmcnt(N)` counts written by hand (N = the loads of
+    one ring slot: csrc/kernels_train_big.hpp).  A register spill is a scratch load / store on the same counter and would make those counts
+    wrong without any test on a small input noticing: every instantiation in the built library must have no scratch segment and no spill."""
+    import re, shutil, subprocess
+    llvm = '/opt/rocm/lib/llvm/bin'
+    if not all(os.path.exists(os.path.join(llvm, t)) for t in ('llvm-objcopy', 'clang-offload-bundler', 'llvm-readelf')):
+        pytest.skip('ROCm llvm tools not found')
+    so = nat.LIB_PATH
+    fat, co = str(tmp_path / 'fat.bin'), str(tmp_path / 'dev.co')
+    subprocess.run([os.path.join(llvm, 'llvm-objcopy'), '--dump-section', f'.hip_fatbin={fat}', so, str(tmp_path / 'unused.so')], check=True, capture_output=True)
+    subprocess.run([os.path.join(llvm, 'clang-offload-bundler'), '--unbundle', '--type=o', f'--input={fat}', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950',
+                    f'--output={co}'], check=True, capture_output=True)
+    notes = subprocess.run([os.path.join(llvm, 'llvm-readelf'), '--notes', co], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for m in re.finditer(r'\.name:\s+(\S*(?:k_train_wgrad_b6|k_train_wgrad_dx_b6)\S*)\n(.*?)\.wavefront_size', notes, re.S):
+        blk = m.group(2)
+        scratch = int(re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk).group(1))
+        spills = int(re.search(r'\.vgpr_spill_count:\s+(\d+)', blk).group(1)) + int(re.search(r'\.sgpr_spill_count:\s+(\d+)', blk).group(1))
+        dyn = re.search(r'\.uses_dynamic_stack:\s+(\w+)', blk).group(1)
+        assert scratch == 0 and spills == 0 and dyn == 'false', (m.group(1), scratch, spills, dyn)
+        seen += 1
+    assert seen >= 16, seen          # 2 widths x 7 activations + the one-pass kernel's 2 widths

@@ -1234,9 +1234,9 @@ template <int OFF> __device__ __forceinline__ void lds_read_f32(float &v, unsign
 //
 // The rows reach the wave through a ring in LDS that the memory system fills (buffer_load_dwordx4 ... lds: no destination registers).  A
 // wave's step is 16 rows = one contiguous 2 NB KB piece of each [M, S] array: 2 NB wave-loads of 1 KB land it in LDS as it lies in
-// memory, the operands are then read with ds_read_b64.  Two slots a wave: at the top of step s the wave waits for slot s % 2 (filled
-// two steps ago), reads it into registers, hands the slot back to the loads of step s + 2 and computes - 28 KB a wave in flight for
-// two whole steps, and nothing that is in flight lives in a register across the loop's back edge (the first form of this kernel kept
+// memory, the operands are then read with ds_read_b64.  Two slots a wave (rows and constants line in rings of their own): at the top of
+// step s the wave waits for slot s % 2 (filled two steps ago), reads it into registers, hands the slot back to the loads of step s + 2 and
+// computes - 28 KB a wave in flight for two whole steps, and nothing that is in flight lives in a register across the loop's back edge (the first form of this kernel kept
 // two steps of rows in registers: hipcc loaded them into other registers than the loop carries, copied them at the loop's end and
 // waited for every load there - 177 us = 98 of loads + 39 of splits + 40 of products, one after the other).  The waits are counted by
 // hand (s_waitcnt vmcnt(NG): every step issues exactly NG loads, past the end of the workgroup's rows too - those touch no memory and
@@ -1247,8 +1247,11 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
     constexpr int S = 32 * NB, RT = 2 * NB + 1;
     constexpr bool HAS_Y = ACT != GNN_ACT_LINEAR;
     constexpr int ARR = 16 * S * 4, NA = HAS_Y ? 4 : 3;        // bytes of 16 rows of an [M, S] array; arrays in a slot: dZ | state | agg | (Y)
-    constexpr int SLOT = NA * ARR + 2048, NG = SLOT / 1024;    // + 16 rows of the constants line; LDS-DMA instructions a step
-    extern __shared__ __attribute__((aligned(16))) float tb_smem[];     // [4 waves][2 slots][SLOT]; the workgroup's partial P afterwards
+    constexpr int MAIN = NA * ARR, NGM = MAIN / 1024, XCB = 2048, NGX = 2;      // a slot of rows and its LDS-DMA instructions; 16 rows of the constants line
+    constexpr int D = 2, XR = 2;                               // ring depths: slots of rows / of the line a wave.  (D = 3 - the CU's whole 160 KB at S = 64 - measured
+                                                               //  185 us against 177 - 183 at 1 M rows: the LDS-DMA stream is not short of bytes in flight)
+    constexpr int WAVE_B = D * MAIN + XR * XCB;
+    extern __shared__ __attribute__((aligned(16))) float tb_smem[];     // [4 waves][D slots | XR line slots]; the workgroup's partial P afterwards
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (uniform: the ring's addresses stay in scalar registers)
     const int i = lane & 31, kg = lane >> 5;
     const int m_beg = blockIdx.x * a.rows_per_wg, m_end = min(a.M, m_beg + a.rows_per_wg);
@@ -1271,11 +1274,11 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
     for (int e = 0; e < NB; ++e) { mu_s[e] = a.mean ? a.mean[a.wrow_state + NB * i + e] : 0.0f; mu_a[e] = a.mean ? a.mean[a.wrow_agg + NB * i + e] : 0.0f; }
     { const int wr = wgrad_wrow(a, S, 2 * S + i); mu_c = (a.mean && wr >= 0) ? a.mean[wr] : 0.0f; }
     typedef __attribute__((address_space(3))) char lds_char;
-    lds_char *ring = (lds_char *)tb_smem + wave * (2 * SLOT);
+    lds_char *ring = (lds_char *)tb_smem + wave * WAVE_B;
     const unsigned ring_addr = (unsigned)(size_t)ring;
-    auto fill = [&](int slot, int s) {                      // the 16 rows of step s of this wave -> slot
-        lds_char *dst = ring + slot * SLOT;
-        const unsigned off = ((unsigned)(64 * s + 16 * wave) * (unsigned)S) * 4u + 16u * (unsigned)lane, off_c = (unsigned)(64 * s + 16 * wave) * 128u + 16u * (unsigned)lane;
+    auto fill_main = [&](int slot, int s) {                 // the 16 rows of step s of this wave -> slot
+        lds_char *dst = ring + slot * MAIN;
+        const unsigned off = ((unsigned)(64 * s + 16 * wave) * (unsigned)S) * 4u + 16u * (unsigned)lane;
 #pragma unroll
         for (int q = 0; q < ARR / 1024; ++q) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_g, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, 0);
@@ -1283,12 +1286,16 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (__attribute__((address_space(3))) void *)(dst + 2 * ARR + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, 0);
             if (HAS_Y) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_y, (__attribute__((address_space(3))) void *)(dst + 3 * ARR + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, 0);
         }
+    };
+    auto fill_xc = [&](int xslot, int s) {                  // ... and of the constants line
+        lds_char *dst = ring + D * MAIN + xslot * XCB;
+        const unsigned off_c = (unsigned)(64 * s + 16 * wave) * 128u + 16u * (unsigned)lane;
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_c, (__attribute__((address_space(3))) void *)(dst + NA * ARR + 1024 * q), 16, (int)(off_c + 1024u * q), 0, 0, 0);
+        for (int q = 0; q < NGX; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_c, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(off_c + 1024u * q), 0, 0, 0);
     };
     struct Step { Piece<NB> gz[8], xs[8], xa[8], y[8]; Piece<1> xc[8]; };
-    const unsigned lane_addr = ring_addr + (unsigned)(8 * kg) * (unsigned)(S * 4) + (unsigned)(NB * i) * 4u, lane_addr_c = ring_addr + NA * ARR + (unsigned)(8 * kg) * 128u + (unsigned)i * 4u;
+    const unsigned lane_addr = ring_addr + (unsigned)(8 * kg) * (unsigned)(S * 4) + (unsigned)(NB * i) * 4u, lane_addr_c = ring_addr + D * MAIN + (unsigned)(8 * kg) * 128u + (unsigned)i * 4u;
 #define B8(v_) __builtin_bit_cast(bf16x8, v_)
     auto split8 = [&](const float (&x)[8], u32x4 &h, u32x4 &m, u32x4 &l) {
         unsigned hh[4], mm[4], ll[4];
@@ -1299,14 +1306,19 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
         }
         h = (u32x4){hh[0], hh[1], hh[2], hh[3]}; m = (u32x4){mm[0], mm[1], mm[2], mm[3]}; l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
     };
-    fill(0, 0); fill(1, 1);
+    // Issue order: [line of s + 2 | rows of s + D] at the top of step s, the prologue in the same order - so that at the top of a step the
+    // (D - 1) NGM + (XR - 1) NGX youngest loads are exactly the ones the step does not need (loads retire in issue order).
+    fill_xc(0, 0); fill_main(0, 0);
+#pragma unroll
+    for (int d = 1; d < D; ++d) { if (d < XR) fill_xc(d, d); fill_main(d, d); }
+    int slot = 0;
 #pragma unroll 1
     for (int s = 0; s < n_steps; ++s) {
-        const int slot = s & 1;
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NG) : "memory");            // slot's rows have landed (the other slot's NG loads may still be out)
+        const int xslot = s & 1;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * NGM + (XR - 1) * NGX) : "memory");       // the step's rows and line have landed
         Step b;
         {   // (inline assembly: see above; constant offsets in the instruction - the caller waits lgkmcnt(0))
-            unsigned base = lane_addr + (unsigned)slot * SLOT, base_c = lane_addr_c + (unsigned)slot * SLOT;
+            unsigned base = lane_addr + (unsigned)slot * MAIN, base_c = lane_addr_c + (unsigned)xslot * XCB;
             static_for<0, 8>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 lds_read_piece<NB, j * S * 4>(b.gz[j], base); lds_read_piece<NB, ARR + j * S * 4>(b.xs[j], base); lds_read_piece<NB, 2 * ARR + j * S * 4>(b.xa[j], base);
@@ -1321,7 +1333,8 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
             for (int e = 0; e < NB; ++e) { asm volatile("" : "+v"(b.gz[j].v[e])); asm volatile("" : "+v"(b.xs[j].v[e])); asm volatile("" : "+v"(b.xa[j].v[e])); if (HAS_Y) asm volatile("" : "+v"(b.y[j].v[e])); }
             asm volatile("" : "+v"(b.xc[j].v[0]));
         }
-        fill(slot, s + 2);
+        fill_xc(xslot, s + XR); fill_main(slot, s + D);
+        slot = slot + 1 == D ? 0 : slot + 1;
         u32x4 zh[NB], zm[NB], zl[NB];
 #pragma unroll
         for (int f = 0; f < NB; ++f) {
@@ -1350,13 +1363,13 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
         }
     }
 #undef B8
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the two fills past the end)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the fills past the end)
     __syncthreads();                                        // every wave is done with its ring: the partial P takes its place
     wgrad32_store<NB>(a, acc, tb_smem);
 }
 template <int NB, int ACT>
 inline size_t train_wgrad_b6_lds() {
-    const size_t S = 32 * NB, ring = 4 * 2 * ((ACT != GNN_ACT_LINEAR ? 4 : 3) * 16 * S * 4 + 2048), P = (2 * S + 32) * S * 4;
+    const size_t S = 32 * NB, na = ACT != GNN_ACT_LINEAR ? 4 : 3, ring = 4 * (2 * na * 16 * S * 4 + 2 * 2048), P = (2 * S + 32) * S * 4;
     return ring > P ? ring : P;
 }
 
@@ -1777,23 +1790,34 @@ __global__ void __launch_bounds__(256) k_head_dx(HeadArgs a) {
             Ac[e] = a.gamma[j] * rstd; Cc[e] = -Ac[e] * rstd * a.m2[j]; M1[e] = a.m1[j]; Mu[e] = a.mean[j];
         }
     }
-    for (int m = blockIdx.x * groups + threadIdx.x / lpr; m < a.M; m += gridDim.x * groups) {
-        float dz[T];
+    // four rows of a lane group in flight, their loads issued together and unconditionally (a row past the end reads row 0 and is not stored)
+    constexpr int RW = 4;
+    const bool need_x = a.gamma || a.dz_act >= 0;
+    for (int m0 = (blockIdx.x * groups + threadIdx.x / lpr) * RW; m0 < a.M; m0 += gridDim.x * groups * RW) {
+        float dz[RW][T];
+        f32x4 x[RW];
 #pragma unroll
-        for (int h = 0; h < T; ++h) dz[h] = a.dZ[(size_t)m * a.ldz + h];
-        if (!act) continue;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (a.gamma || a.dz_act >= 0) x = *reinterpret_cast<const f32x4 *>(a.state + (size_t)m * a.ld_state + 4 * l4);
-        f32x4 v;
+        for (int u = 0; u < RW; ++u) {
+            const size_t mm = m0 + u < a.M ? (size_t)(m0 + u) : 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float dy = 0.0f;
-#pragma unroll
-            for (int h = 0; h < T; ++h) dy = fmaf(dz[h], w[e][h], dy);
-            v[e] = fmaf(Ac[e], dy - M1[e], Cc[e] * (x[e] - Mu[e]));
-            if (a.dz_act >= 0) v[e] *= activate_grad_from_output(a.dz_act, x[e]);
+            for (int h = 0; h < T; ++h) dz[u][h] = a.dZ[mm * a.ldz + h];
+            x[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (need_x) x[u] = *reinterpret_cast<const f32x4 *>(a.state + mm * a.ld_state + 4 * (act ? l4 : 0));      // (uniform condition)
         }
-        *reinterpret_cast<f32x4 *>(a.dx + (size_t)m * a.ld_dx + 4 * l4) = v;
+        if (!act) continue;
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float dy = 0.0f;
+#pragma unroll
+                for (int h = 0; h < T; ++h) dy = fmaf(dz[u][h], w[e][h], dy);
+                v[e] = fmaf(Ac[e], dy - M1[e], Cc[e] * (x[u][e] - Mu[e]));
+                if (a.dz_act >= 0) v[e] *= activate_grad_from_output(a.dz_act, x[u][e]);
+            }
+            if (m0 + u < a.M) *reinterpret_cast<f32x4 *>(a.dx + (size_t)(m0 + u) * a.ld_dx + 4 * l4) = v;
+        }
     }
 }
 

@@ -477,3 +477,24 @@ def test_large_graph_training_on_the_kernels_before_the_lds_ring_in_a_child_proc
                          capture_output=True, text=True, env=env, cwd=root, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert ' passed' in res.stdout
+
+
+@pytest.mark.parametrize('N,d,bn', [(40_037, 64, True), (33_001, 32, True), (40_037, 64, False)])
+def test_large_graph_training_with_a_ragged_last_tile(N, d, bn):
+    """Node counts that are no multiple of 64 / 16: the last workgroup of k_train_wgrad_b6 (and of the one-pass kernel without BatchNormalization)
+    fills its LDS ring past the end of the rows - LDS-DMA loads outside the buffer window must land ZEROS, not leave the slot's previous
+    rows - and the last tile of k_train_fwd_b6 / k_train_bwd_dx_b6 is ragged (windows of the arrays' exact sizes instead of a select per
+    load).  Every gradient against float64 autograd, both orchestrations, as the other large-graph tests."""
+    from test_gpu_training import nets, check_step
+    from gnnkeras_amd.synth import er_graph
+    from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+    rng = np.random.default_rng(N + d)
+    g = er_graph(N, 6 * N + 11, seed=9, aggregation_mode='average')
+    om = rng.random(N) < 0.6
+    t = np.zeros((int(om.sum()), 2)); t[np.arange(len(t)), rng.integers(0, 2, len(t))] = 1
+    g = GraphObject(g.nodes, g.arcs, t, focus='n', set_mask=rng.random(N) < 0.9, output_mask=om, aggregation_mode='average',
+                    sample_weight=rng.uniform(0.5, 1.5, len(t)))
+    x, y, sw = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0]
+    ns, no = nets('n', d, bn, scale=0.5)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    check_step(GNNnodeBased(ns, no, d, 3, 0.0), x, y, sw, s0)

@@ -127,8 +127,11 @@ int launch_aggregate(const int *gate, const gnn_csr_t &c, const float *X, int ld
             const int lpr = w / 4, groups = 256 / lpr;
             const int grid = std::min(cdiv(c.n_dst, groups), 256 * 16);
             const float *Xb = X + off; float *ob = out + off;
-#define AGGV(L) (c.w ? gnn::k_aggregate_vec<L, true><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xb, ldx, ob, ldo) \
-               : gnn::k_aggregate_vec<L, false><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xb, ldx, ob, ldo))
+            // (buffer form: the eight source ids, then the eight rows of a trip requested together - kernels_general.hpp gather_sum8; 4 GiB windows)
+            static const bool buf_on = !(getenv("GNN_GATHER_BUF") && getenv("GNN_GATHER_BUF")[0] == '0');
+            const bool buf = buf_on && (size_t)c.n_src * (size_t)ldx * 4 < 0xFFFFFFF0ull && (size_t)c.nnz * 4 < 0xFFFFFFF0ull;
+#define AGGV_(L, W_, B_) gnn::k_aggregate_vec<L, W_, B_><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xb, ldx, ob, ldo)
+#define AGGV(L) (buf ? (c.w ? AGGV_(L, true, true) : AGGV_(L, false, true)) : (c.w ? AGGV_(L, true, false) : AGGV_(L, false, false)))
             switch (lpr) {
                 case 1: AGGV(1); break;
                 case 2: AGGV(2); break;
@@ -138,6 +141,7 @@ int launch_aggregate(const int *gate, const gnn_csr_t &c, const float *X, int ld
                 default: AGGV(32); break;
             }
 #undef AGGV
+#undef AGGV_
             LAUNCH_OK();
             off += w;
         }

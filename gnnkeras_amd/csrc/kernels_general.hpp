@@ -109,11 +109,65 @@ k_aggregate_narrow(const int *gate, int n_dst, const int *__restrict__ rowptr, c
     }
 }
 
+// The 16-byte row pieces of one destination's arcs, eight in flight, summed in arc order (k_aggregate_vec and the training aggregates of
+// kernels_train_big.hpp).  BUF: raw buffer loads predicated off by an out-of-range offset - the eight source ids are requested together,
+// then the eight rows; behind `ok ? load : 0` hipcc branches around every load and waits (vmcnt(0)) for each source id AND everything
+// before it, i.e. one dependent pair of round trips per arc and wave, hidden only by occupancy (ISA of the round-4 kernels).  The arrays
+// must fit 4 GiB buffer windows (n_src * ldx * 4 and nnz * 4 below 2^32: the launchers check and fall back to !BUF).  Same sums, same order.
+template <bool HAS_W, bool BUF>
+__device__ __forceinline__ f32x4 gather_sum8(int beg, int end, const int *__restrict__ src, const float *__restrict__ w, const float *__restrict__ X,
+                                               int ldx, int col) {
+    typedef unsigned int u32x4_g __attribute__((ext_vector_type(4)));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (BUF) {
+        const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)0xFFFFFFF0u, 0x00020000),
+                                     r_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(src), 0, (int)0xFFFFFFF0u, 0x00020000),
+                                     r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HAS_W ? w : X), 0, (int)0xFFFFFFF0u, 0x00020000);
+        constexpr unsigned OFF = 0xFFFFFFFFu;
+        for (int e = beg; e < end; e += 8) {
+            unsigned sid[8]; float wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned o = e + i < end ? 4u * (unsigned)(e + i) : OFF;
+                sid[i] = __builtin_amdgcn_raw_buffer_load_b32(r_s, (int)o, 0, 0);
+                wv[i] = HAS_W ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_w, (int)o, 0, 0)) : 1.0f;
+            }
+            f32x4 x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u32x4_g v = __builtin_amdgcn_raw_buffer_load_b128(r_x, (int)(e + i < end ? (sid[i] * (unsigned)ldx + (unsigned)col) * 4u : OFF), 0, 0);
+                x[i] = (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (HAS_W) acc += wv[i] * x[i];          // (past the end: w = 0, x = 0)
+                else acc += x[i];
+            }
+        }
+    } else {
+        for (int e = beg; e < end; e += 8) {
+            f32x4 x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = e + i < end;
+                const int sid = ok ? src[e + i] : 0;
+                x[i] = ok ? *reinterpret_cast<const f32x4 *>(X + (size_t)sid * ldx + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (HAS_W) acc += (e + i < end ? w[e + i] : 0.0f) * x[i];
+                else acc += x[i];
+            }
+        }
+    }
+    return acc;
+}
+
 // The same product for rows that allow 16-B accesses (F, ldx, ldo multiples of 4, 16-B aligned bases: the padded state
 // matrix of the un-fused and training paths): LPR = F/4 lanes own a destination row, each lane carries a float4 column
 // chunk, 8 source rows in flight; a wave instruction moves 64/LPR whole rows instead of one.  `addend` (optional, the
 // backward sweep's G_state = dx_state + Adj . dx_agg): out = addend + the product.
-template <int LPR, bool HAS_W>
+template <int LPR, bool HAS_W, bool BUF = false>
 __global__ void __launch_bounds__(256)
 k_aggregate_vec(const int *gate, int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src,
                 const float *__restrict__ w, const float *__restrict__ row_scale, const float *__restrict__ X, int ldx,
@@ -123,21 +177,7 @@ k_aggregate_vec(const int *gate, int n_dst, const int *__restrict__ rowptr, cons
     const int groups = blockDim.x / LPR;
     for (int j = blockIdx.x * groups + threadIdx.x / LPR; j < n_dst; j += gridDim.x * groups) {
         const int beg = rowptr[j], end = rowptr[j + 1];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int e = beg; e < end; e += 8) {                   // summed in arc order
-            f32x4 x[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool ok = e + i < end;
-                const int sid = ok ? src[e + i] : 0;
-                x[i] = ok ? *reinterpret_cast<const f32x4 *>(X + (size_t)sid * ldx + 4 * l4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (HAS_W) acc += (e + i < end ? w[e + i] : 0.0f) * x[i];
-                else acc += x[i];
-            }
-        }
+        f32x4 acc = gather_sum8<HAS_W, BUF>(beg, end, src, w, X, ldx, 4 * l4);                   // summed in arc order
         if (row_scale) acc *= row_scale[j];
         if (addend) acc += *reinterpret_cast<const f32x4 *>(addend + (size_t)j * ld_add + 4 * l4);
         *reinterpret_cast<f32x4 *>(out + (size_t)j * ldo + 4 * l4) = acc;

@@ -48,7 +48,7 @@ constexpr int TB_WAVES = 8;              // waves per workgroup (512 threads; la
 // ---- neighbour sum + column statistics of the result -------------------------------------------------------------------------------
 // k_aggregate_vec (kernels_general.hpp) with one addition: every thread keeps the sum and the sum of squares of the float4 column
 // chunk it writes; a workgroup folds its threads' partials in a fixed order into stat_part[blockIdx.x][2 F] (sums, then squares).
-template <int LPR, bool HAS_W>
+template <int LPR, bool HAS_W, bool BUF = false>
 __global__ void __launch_bounds__(256, 8)              // (8 waves per SIMD = 64 VGPRs: with the shift in registers hipcc took 66, and the gather lost 18 %)
 k_aggregate_stats(const int *gate, int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src,
                   const float *__restrict__ w, const float *__restrict__ row_scale, const float *__restrict__ X, int ldx,
@@ -63,21 +63,7 @@ k_aggregate_stats(const int *gate, int n_dst, const int *__restrict__ rowptr, co
     const f32x4 sh = shift ? *reinterpret_cast<const f32x4 *>(shift + 4 * l4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int j = blockIdx.x * groups + threadIdx.x / LPR; j < n_dst; j += gridDim.x * groups) {
         const int beg = rowptr[j], end = rowptr[j + 1];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int e = beg; e < end; e += 8) {                   // summed in arc order
-            f32x4 x[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool ok = e + i < end;
-                const int sid = ok ? src[e + i] : 0;
-                x[i] = ok ? *reinterpret_cast<const f32x4 *>(X + (size_t)sid * ldx + 4 * l4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (HAS_W) acc += (e + i < end ? w[e + i] : 0.0f) * x[i];
-                else acc += x[i];
-            }
-        }
+        f32x4 acc = gather_sum8<HAS_W, BUF>(beg, end, src, w, X, ldx, 4 * l4);                   // summed in arc order
         if (row_scale) acc *= row_scale[j];
         *reinterpret_cast<f32x4 *>(out + (size_t)j * ldo + 4 * l4) = acc;
         acc -= sh;
@@ -1626,7 +1612,7 @@ struct AggDzArgs {
     const float *gamma, *var, *mean, *m1, *m2; float eps;  // iteration t's BatchNormalization (gamma NULL: none), by weight row
     int wrow_state;
 };
-template <int LPR, bool HAS_W, int ACT>
+template <int LPR, bool HAS_W, int ACT, bool BUF = false>
 __global__ void __launch_bounds__(256, HAS_W ? 7 : 8)
 k_aggregate_dz(int n_dst, const int *__restrict__ rowptr, const int *__restrict__ src, const float *__restrict__ w, const float *__restrict__ row_scale,
                const float *__restrict__ X, int ldx, float *__restrict__ out, int ldo, const float *__restrict__ addend, int ld_add, AggDzArgs z) {
@@ -1649,21 +1635,7 @@ k_aggregate_dz(int n_dst, const int *__restrict__ rowptr, const int *__restrict_
     __syncthreads();
     for (int j = blockIdx.x * groups + threadIdx.x / LPR; j < n_dst; j += gridDim.x * groups) {
         const int beg = rowptr[j], end = rowptr[j + 1];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int e = beg; e < end; e += 8) {                   // summed in arc order
-            f32x4 x[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool ok = e + i < end;
-                const int sid = ok ? src[e + i] : 0;
-                x[i] = ok ? *reinterpret_cast<const f32x4 *>(X + (size_t)sid * ldx + 4 * l4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (HAS_W) acc += (e + i < end ? w[e + i] : 0.0f) * x[i];
-                else acc += x[i];
-            }
-        }
+        f32x4 acc = gather_sum8<HAS_W, BUF>(beg, end, src, w, X, ldx, 4 * l4);                   // summed in arc order
         if (row_scale) acc *= row_scale[j];
         const f32x4 y = *reinterpret_cast<const f32x4 *>(z.Y + (size_t)j * z.ldy + 4 * l4);
         acc += *reinterpret_cast<const f32x4 *>(addend + (size_t)j * ld_add + 4 * l4);

@@ -424,14 +424,26 @@ int state_segs(const gnn_loop_args_t &a, const TrainPlan &p, int t, gnn::Seg *se
 }
 
 // ---- launchers of the large-graph kernels -------------------------------------------------------------------------------------------
+// the gathers with their eight source ids, then their eight rows requested together through buffer descriptors (kernels_general.hpp
+// gather_sum8<.., BUF>): the arrays must fit 4 GiB windows; GNN_GATHER_BUF=0 keeps the pointer form (a dependent pair of round trips per arc)
+inline bool gather_buf_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GNN_GATHER_BUF"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+inline bool gather_buf_ok(const gnn_csr_t &c, int ldx) {
+    return gather_buf_enabled() && (size_t)c.n_src * (size_t)ldx * 4 < 0xFFFFFFF0ull && (size_t)c.nnz * 4 < 0xFFFFFFF0ull;
+}
 int launch_aggregate_stats(const int *gate, const gnn_csr_t &c, const float *X, int S, float *out, float *part, float *mean, float *var, const float *shift,
                            hipStream_t st) {
     const int lpr = S / 4, groups = 256 / lpr;
     const int grid = std::min(cdiv(c.n_dst, groups), BIG_AGG_BLOCKS);
-#define AGGS(L) (c.w ? gnn::k_aggregate_stats<L, true><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, S, out, S, part, shift) \
-                     : gnn::k_aggregate_stats<L, false><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, S, out, S, part, shift))
+#define AGGS_(L, W_, B_) gnn::k_aggregate_stats<L, W_, B_><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, S, out, S, part, shift)
+#define AGGS(L) (buf ? (c.w ? AGGS_(L, true, true) : AGGS_(L, false, true)) : (c.w ? AGGS_(L, true, false) : AGGS_(L, false, false)))
+    const bool buf = gather_buf_ok(c, S);
     switch (lpr) { case 4: AGGS(4); break; case 8: AGGS(8); break; default: AGGS(16); break; }
 #undef AGGS
+#undef AGGS_
     LAUNCH_OK();
     gnn::k_stats_finish<<<S, 256, 0, st>>>(gate, part, grid, S, 1.0f / (float)c.n_dst, mean, var, shift);
     LAUNCH_OK();
@@ -667,7 +679,9 @@ inline bool train_dz_enabled() {          // GNN_TRAIN_DZ=0: the round-4 flow (e
 template <int LPR, bool HAS_W>
 bool launch_aggregate_dz_lw(const gnn_csr_t &c, const float *Xa, int ldx, float *out, int ldo, const float *addend, int ld_add, const gnn::AggDzArgs &z, int act,
                             int grid, hipStream_t st) {
-#define AGGDZ(A_) gnn::k_aggregate_dz<LPR, HAS_W, A_><<<grid, 256, 0, st>>>(c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xa, ldx, out, ldo, addend, ld_add, z)
+    const bool buf = gather_buf_ok(c, ldx);
+#define AGGDZ_(A_, B_) gnn::k_aggregate_dz<LPR, HAS_W, A_, B_><<<grid, 256, 0, st>>>(c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xa, ldx, out, ldo, addend, ld_add, z)
+#define AGGDZ(A_) do { if (buf) AGGDZ_(A_, true); else AGGDZ_(A_, false); } while (0)
     switch (act) {
         case GNN_ACT_LINEAR: AGGDZ(GNN_ACT_LINEAR); return true;
         case GNN_ACT_RELU: AGGDZ(GNN_ACT_RELU); return true;
@@ -679,6 +693,7 @@ bool launch_aggregate_dz_lw(const gnn_csr_t &c, const float *Xa, int ldx, float 
         default: return false;
     }
 #undef AGGDZ
+#undef AGGDZ_
 }
 bool launch_aggregate_dz(const gnn_csr_t &c, const float *Xa, int ldx, float *out, int ldo, const float *addend, int ld_add, const gnn::AggDzArgs &z, int act, int S,
                          hipStream_t st) {
@@ -1238,10 +1253,12 @@ int gnn_train_step(const gnn_train_args_t *args) {
                              ((reinterpret_cast<uintptr_t>(Xa) | reinterpret_cast<uintptr_t>(p.dx_s_all) | reinterpret_cast<uintptr_t>(p.G_state)) & 15) == 0;
             if (vec) {      // whole 16-B row pieces, 8 source rows in flight (the scalar walk below is one dependent chain per arc)
                 const int lpr = p.S / 4, groups = 256 / lpr, grid = std::min(cdiv(p.N, groups), 256 * 16);
-#define AGGV(L) (c.w ? gnn::k_aggregate_vec<L, true><<<grid, 256, 0, st>>>(nullptr, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xa, p.kdx_s, p.G_state, p.S, p.dx_s_all, p.kdx_s) \
-                     : gnn::k_aggregate_vec<L, false><<<grid, 256, 0, st>>>(nullptr, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xa, p.kdx_s, p.G_state, p.S, p.dx_s_all, p.kdx_s))
+                const bool buf = gather_buf_ok(c, p.kdx_s);
+#define AGGV_(L, W_, B_) gnn::k_aggregate_vec<L, W_, B_><<<grid, 256, 0, st>>>(nullptr, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, Xa, p.kdx_s, p.G_state, p.S, p.dx_s_all, p.kdx_s)
+#define AGGV(L) (buf ? (c.w ? AGGV_(L, true, true) : AGGV_(L, false, true)) : (c.w ? AGGV_(L, true, false) : AGGV_(L, false, false)))
                 switch (lpr) { case 4: AGGV(4); break; case 8: AGGV(8); break; case 16: AGGV(16); break; default: AGGV(32); break; }
 #undef AGGV
+#undef AGGV_
                 LAUNCH_OK();
             } else {
                 int G = 4;

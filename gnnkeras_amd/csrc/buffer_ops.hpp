@@ -44,6 +44,11 @@ __device__ __forceinline__ f32x4 buf_ld_f32x4(__amdgpu_buffer_rsrc_t r, unsigned
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
     return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
 }
+// ... with cache-policy bits (2 = nt: rows that are streamed once per launch)
+template <int AUX> __device__ __forceinline__ f32x4 buf_ld_f32x4_aux(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX);
+    return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+}
 
 // sc1 = system-coherent level 1: the access goes through to memory instead of stopping in this XCD's L2 / this CU's L1
 __device__ __forceinline__ f32x4 buf_ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {

@@ -34,6 +34,13 @@
 
 namespace gnn {
 
+#ifndef TB_STREAM_AUX
+#define TB_STREAM_AUX 0                  // cache-policy bits of the row loads of k_train_fwd_b6 / k_train_bwd_dx_b6 (experiment: scripts/micro/rowgemm_bench.hip)
+#endif
+#ifndef TB_RING_AUX
+#define TB_RING_AUX 2                    // cache-policy bits of the ring's LDS-DMA loads: 2 = nt.  k_train_wgrad_b6 at 1 M rows: 181.5 us default policy, 172.4 nt (183.5 / 177.6
+                                         // with sc0 / sc0 + nt); inside the step 188 -> 171 us.  (nt on the register loads of k_train_fwd_b6 / k_train_bwd_dx_b6: 199 -> 202, 196 -> 207.)
+#endif
 #ifndef TB_ABL
 #define TB_ABL 0                         // ablation switches of scripts/micro/rowgemm_bench.hip (1 no MFMAs, 2 no predicate, 4 no stores, 8 no statistics); 0 in the library
 #endif
@@ -566,11 +573,11 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
         const unsigned b_s = 64u * (unsigned)t * (unsigned)a.ld_state + o_s, b_a = 64u * (unsigned)t * (unsigned)a.ld_agg + o_a, b_x = 2048u * (unsigned)t + o_x;
 #pragma unroll
         for (int q = 0; q < SQ; ++q) {
-            A[q] = buf_ld_f32x4(r_s, b_s + 64u * q);
-            A[SQ + q] = buf_ld_f32x4(r_a, b_a + 64u * q);
+            A[q] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_s, b_s + 64u * q);
+            A[SQ + q] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_a, b_a + 64u * q);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) A[2 * SQ + q] = buf_ld_f32x4(r_x, b_x + 64u * q);
+        for (int q = 0; q < 2; ++q) A[2 * SQ + q] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_x, b_x + 64u * q);
     };
     const int t_step = gridDim.x * TB_WAVES;
     int trip_ = 0; (void)trip_;
@@ -873,14 +880,14 @@ __global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
         bool in_; const unsigned r = off_row(t, in_);
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
-            A[q] = buf_ld_f32x4(r_z, in_ ? (r * (unsigned)a.ldz + 16u * q + 4u * g) * 4u : BUF_OFF);
-            Yv[q] = buf_ld_f32x4(r_y, in_ ? (r * (unsigned)a.ldz + 16u * q + 4u * g) * 4u : BUF_OFF);
+            A[q] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_z, in_ ? (r * (unsigned)a.ldz + 16u * q + 4u * g) * 4u : BUF_OFF);
+            Yv[q] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_y, in_ ? (r * (unsigned)a.ldz + 16u * q + 4u * g) * 4u : BUF_OFF);
         }
     };
     auto fetch_x = [&](int t, int ct) {
         bool in_; const unsigned r = off_row(t, in_);
-        if (ct < SQ) X[ct] = buf_ld_f32x4(r_s, in_ ? (r * (unsigned)a.ld_state + 16u * ct + 4u * g) * 4u : BUF_OFF);
-        else X[ct] = buf_ld_f32x4(r_a, in_ ? (r * (unsigned)a.ld_agg + 16u * (ct - SQ) + 4u * g) * 4u : BUF_OFF);
+        if (ct < SQ) X[ct] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_s, in_ ? (r * (unsigned)a.ld_state + 16u * ct + 4u * g) * 4u : BUF_OFF);
+        else X[ct] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_a, in_ ? (r * (unsigned)a.ld_agg + 16u * (ct - SQ) + 4u * g) * 4u : BUF_OFF);
     };
     auto fetch_rs = [&](int t) { bool in_; const unsigned r = off_row(t, in_); rs = buf_ld_f32(r_rs, in_ ? r * 4u : BUF_OFF); };
     {
@@ -1267,10 +1274,10 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
         const unsigned off = ((unsigned)(64 * s + 16 * wave) * (unsigned)S) * 4u + 16u * (unsigned)lane;
 #pragma unroll
         for (int q = 0; q < ARR / 1024; ++q) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_g, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_s, (__attribute__((address_space(3))) void *)(dst + ARR + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (__attribute__((address_space(3))) void *)(dst + 2 * ARR + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, 0);
-            if (HAS_Y) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_y, (__attribute__((address_space(3))) void *)(dst + 3 * ARR + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_g, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, TB_RING_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_s, (__attribute__((address_space(3))) void *)(dst + ARR + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, TB_RING_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (__attribute__((address_space(3))) void *)(dst + 2 * ARR + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, TB_RING_AUX);
+            if (HAS_Y) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_y, (__attribute__((address_space(3))) void *)(dst + 3 * ARR + 1024 * q), 16, (int)(off + 1024u * q), 0, 0, TB_RING_AUX);
         }
     };
     auto fill_xc = [&](int xslot, int s) {                  // ... and of the constants line
@@ -1278,7 +1285,7 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
         const unsigned off_c = (unsigned)(64 * s + 16 * wave) * 128u + 16u * (unsigned)lane;
 #pragma unroll
         for (int q = 0; q < NGX; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_c, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(off_c + 1024u * q), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_c, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(off_c + 1024u * q), 0, 0, TB_RING_AUX);
     };
     struct Step { Piece<NB> gz[8], xs[8], xa[8], y[8]; Piece<1> xc[8]; };
     const unsigned lane_addr = ring_addr + (unsigned)(8 * kg) * (unsigned)(S * 4) + (unsigned)(NB * i) * 4u, lane_addr_c = ring_addr + D * MAIN + (unsigned)(8 * kg) * 128u + (unsigned)i * 4u;
@@ -1451,9 +1458,9 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_dx_b6(TrainWgradArgs a, 
         const unsigned row0 = (unsigned)(64 * s + 16 * wave), base = row0 * (unsigned)(S * 4);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_g, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(base + src_q[q]), 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_s, (__attribute__((address_space(3))) void *)(dst + ARR + 1024 * q), 16, (int)(base + src_q[q]), 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (__attribute__((address_space(3))) void *)(dst + 2 * ARR + 1024 * q), 16, (int)(base + src_q[q]), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_g, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(base + src_q[q]), 0, 0, TB_RING_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_s, (__attribute__((address_space(3))) void *)(dst + ARR + 1024 * q), 16, (int)(base + src_q[q]), 0, 0, TB_RING_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (__attribute__((address_space(3))) void *)(dst + 2 * ARR + 1024 * q), 16, (int)(base + src_q[q]), 0, 0, TB_RING_AUX);
         }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rs, (__attribute__((address_space(3))) void *)(dst + 3 * ARR), 4, (int)((row0 + (unsigned)lane) * 4u), 0, 0, 0);
     };
@@ -1461,7 +1468,7 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_dx_b6(TrainWgradArgs a, 
         lds_char *dst = ring + 2 * MAIN;
         const unsigned off_c = (unsigned)(64 * s + 16 * wave) * 128u + 16u * (unsigned)lane;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_c, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(off_c + 1024u * q), 0, 0, 0);
+        for (int q = 0; q < 2; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_c, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(off_c + 1024u * q), 0, 0, TB_RING_AUX);
     };
     // LDS offsets of this lane's reads inside a 16-row piece: the first product's eight rows 8 kg + j, the second product's pieces 4 q + g of row c
     unsigned rd1[8], rd2[HQ];

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Error of the large-graph training kernels against float64 autograd AS A FUNCTION OF THE ROW COUNT: the weight
-gradient contracts over all M rows in float32 MFMA accumulators (k_train_wgrad32), the forward / dZ . W^T products are three-term bf16
-splits (k_train_fwd_b6 / k_train_bwd_dx_b6) - measured at 40 k, 160 k, 640 k and 1 M rows instead of extrapolated from 40 k.
+gradient contracts over all M rows in float32 MFMA accumulators (k_train_wgrad_b6: three-term bf16 splits of both operands since the second
+pass of round 5; k_train_wgrad32: f32 inputs), the forward / dZ . W^T products are three-term bf16 splits (k_train_fwd_b6 / k_train_bwd_dx_b6) -
+measured at 40 k, 160 k, 640 k and 1 M rows instead of extrapolated from 40 k.
 
     python scripts/dev/train_error_vs_rows.py [--rows 40000,160000,640000,1000000] [--iterations 3] [--out profiles/r05_train_error_vs_rows.txt]
 
 Per row count: an Erdos-Renyi graph with 10 arcs per node, d = 64, the starter networks (BatchNormalization + Dense selu / softmax,
-bench.py's training configuration), ONE train step through `gnn_train_step` on (i) the default kernels, (ii) the float32-input MFMA kernels
-(GNN_TRAIN_BF16X6=0 GNN_TRAIN_WGRAD32=0: read once per process, hence child processes) and (iii) the building-block orchestration,
+bench.py's training configuration), ONE train step through `gnn_train_step` on (i) the default kernels, (ii) the default kernels with the weight gradient on f32-input
+MFMAs (GNN_TRAIN_WGRAD_B6=0), (iii) the float32-input MFMA kernels throughout (GNN_TRAIN_BF16X6=0 GNN_TRAIN_WGRAD32=0: read once per process,
+hence child processes) and (iv) the building-block orchestration,
 against oracle/torch_train.py in float64 (iterations checkpointed).  Errors are max-norm, relative to the tensor's own largest entry."""
 import argparse, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -78,8 +80,8 @@ if __name__ == '__main__':
              '# max-norm relative to the tensor\'s own largest entry; kink = pre-activations of the float64 oracle within 1e-6 of the selu kink', '']
     cols = ['loss', 'y_pred', 'state', 'state.gamma', 'state.beta', 'state.kernel', 'state.bias', 'output.gamma', 'output.beta', 'output.kernel', 'output.bias']
     lines.append(f"{'rows':>9} {'kernels':<28} {'kink':>5} " + ' '.join(f'{c:>13}' for c in cols))
-    variants = (('default (bf16x6 + wgrad32)', {}, 1), ('f32-input MFMA kernels', {'GNN_TRAIN_BF16X6': '0', 'GNN_TRAIN_WGRAD32': '0'}, 1),
-                ('building blocks (general)', {}, 0))
+    variants = (('default (bf16x6 + wgrad_b6)', {}, 1), ('bf16x6 + wgrad32 (round 5a)', {'GNN_TRAIN_WGRAD_B6': '0'}, 1),
+                ('f32-input MFMA kernels', {'GNN_TRAIN_BF16X6': '0', 'GNN_TRAIN_WGRAD32': '0'}, 1), ('building blocks (general)', {}, 0))
     procs = {}
     rows = [int(float(v)) for v in a.rows.split(',')]
     for M in rows:        # the oracles (host, minutes at 1 M) all at once; the device runs follow as each lands

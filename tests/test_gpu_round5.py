@@ -479,8 +479,9 @@ def test_large_graph_training_on_the_kernels_before_the_lds_ring_in_a_child_proc
     assert ' passed' in res.stdout
 
 
-@pytest.mark.parametrize('N,d,bn', [(40_037, 64, True), (33_001, 32, True), (40_037, 64, False)])
-def test_large_graph_training_with_a_ragged_last_tile(N, d, bn):
+@pytest.mark.parametrize('N,d,bn,mode', [(40_037, 64, True, 'average'), (33_001, 32, True, 'average'), (40_037, 64, False, 'average'),
+                                         (36_001, 64, True, 'normalized'), (36_001, 32, False, 'normalized')])
+def test_large_graph_training_with_a_ragged_last_tile(N, d, bn, mode):
     """Node counts that are no multiple of 64 / 16: the last workgroup of k_train_wgrad_b6 (and of the one-pass kernel without BatchNormalization)
     fills its LDS ring past the end of the rows - LDS-DMA loads outside the buffer window must land ZEROS, not leave the slot's previous
     rows - and the last tile of k_train_fwd_b6 / k_train_bwd_dx_b6 is ragged (windows of the arrays' exact sizes instead of a select per
@@ -489,12 +490,12 @@ def test_large_graph_training_with_a_ragged_last_tile(N, d, bn):
     from gnnkeras_amd.synth import er_graph
     from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
     rng = np.random.default_rng(N + d)
-    g = er_graph(N, 6 * N + 11, seed=9, aggregation_mode='average')
+    g = er_graph(N, 6 * N + 11, seed=9, aggregation_mode=mode)
     om = rng.random(N) < 0.6
     t = np.zeros((int(om.sum()), 2)); t[np.arange(len(t)), rng.integers(0, 2, len(t))] = 1
-    g = GraphObject(g.nodes, g.arcs, t, focus='n', set_mask=rng.random(N) < 0.9, output_mask=om, aggregation_mode='average',
+    g = GraphObject(g.nodes, g.arcs, t, focus='n', set_mask=rng.random(N) < 0.9, output_mask=om, aggregation_mode=mode,
                     sample_weight=rng.uniform(0.5, 1.5, len(t)))
-    x, y, sw = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0]
+    x, y, sw = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0]
     ns, no = nets('n', d, bn, scale=0.5)
     s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
     check_step(GNNnodeBased(ns, no, d, 3, 0.0), x, y, sw, s0)

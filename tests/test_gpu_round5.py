@@ -485,7 +485,8 @@ def test_large_graph_training_with_a_ragged_last_tile(N, d, bn, mode):
     """Node counts that are no multiple of 64 / 16: the last workgroup of k_train_wgrad_b6 (and of the one-pass kernel without BatchNormalization)
     fills its LDS ring past the end of the rows - LDS-DMA loads outside the buffer window must land ZEROS, not leave the slot's previous
     rows - and the last tile of k_train_fwd_b6 / k_train_bwd_dx_b6 is ragged (windows of the arrays' exact sizes instead of a select per
-    load).  Every gradient against float64 autograd, both orchestrations, as the other large-graph tests."""
+    load).  'normalized': per-ARC weights - the weighted instances of the buffered gathers (k_aggregate_stats / k_aggregate_dz with HAS_W).
+    Every gradient against float64 autograd, both orchestrations, as the other large-graph tests."""
     from test_gpu_training import nets, check_step
     from gnnkeras_amd.synth import er_graph
     from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer

@@ -312,7 +312,52 @@ def training_section(device, graph_x, d):
                          'workload': 'the C4 graph, node-focused, every node a target, 10 iterations, BatchNormalization on batch statistics',
                          'arithmetic': 'f32; the first Dense forward and dZ.W^T of an iteration as six bf16 MFMA products of three-term bf16 splits with f32 '
                                        'accumulation (f32-chain accuracy, DESIGN.md 6b; GNN_TRAIN_BF16X6=0: f32-input MFMAs), weight gradient on f32-input MFMAs'}
+    del gnn, data, y
+    try:
+        out['c5_d64_k10'] = c5_training_entry(device, d)
+    except Exception as e:                            # never lose the other numbers to this one
+        out['c5_d64_k10'] = {'error': str(e)[:300]}
     return out
+
+
+def c5_training_entry(device, d=64, K_it=10, N=500_000, E=5_000_000, steps=3):
+    """BASELINE C5 as a TRAINING step (reference CompositeGNN.py:275-304): 500 k nodes / 5 M arcs, 3 node types with label widths
+    (14, 8, 4), one BatchNormalization + Dense(selu) state network per type, d = 64, 10 iterations, node-focused, every node a target -
+    `gnn_train_step` with `composite` on the row-streaming kernels in position space (csrc/train_composite_big.hpp)."""
+    from gnnkeras_amd import _native as nat
+    from gnnkeras_amd.synth import er_composite_graph
+    from gnnkeras_amd.Models.training import Adam
+    from gnnkeras_amd.Sequencers.GraphSequencers import CompositeMultiGraphSequencer
+    gnn, _, dims = composite_model(d, K_it, device)
+    gnn.compile(optimizer=Adam(0.001), loss='categorical_crossentropy', metrics=['accuracy'])
+    graph = er_composite_graph(N, E, dim_node_label=dims, aggregation_mode='average', seed=1234)
+    x, y, sw = CompositeMultiGraphSequencer([graph], 'n', 'average', 1, shuffle=False, device=device)[0]
+    data = (x, y, None)
+    for _ in range(2): gnn.train_step(data, seed=0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): r = gnn.train_step(data, seed=0)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / steps
+    path = nat.lib().gnn_last_kernel_name().decode()
+    res = {'train_step_ms': 1e3 * t_step, 'k': int(r['k']), 'orchestration': path,
+           'workload': f'composite ER {N} nodes / {E} arcs, 3 node types (label widths {tuple(dims)}), d = {d}, {K_it} iterations, node-focused, every node a '
+                       f'target, BatchNormalization on the batch statistics of each type\'s rows, Adam; aggregation average'}
+    ks = kernel_stats_lookup('r06_c5_train')
+    if ks is not None: res['kernels_us'] = ks
+    return res
+
+
+def kernel_stats_lookup(tag):
+    """Per-kernel average durations (us) of a committed `rocprofv3 --kernel-trace --stats` summary, profiles/<tag>_kernel_stats.json
+    (scripts/parse_kernel_stats.py writes it with the library's source hash): reported only when it belongs to the sources that run."""
+    from gnnkeras_amd import _native as nat
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', tag + '_kernel_stats.json')
+    try:
+        with open(path) as f: rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if rec.get('source_hash') != nat.source_hash(): return {'stale': 'profiles/%s_kernel_stats.json was taken on other sources' % tag}
+    return {'from': 'profiles/%s_kernel_stats.json (rocprofv3 --kernel-trace --stats of scripts/train_c5.py)' % tag, 'avg_us': rec['avg_us'], 'calls_per_step': rec.get('calls_per_step')}
 
 
 def composite_training_section(device):

@@ -607,6 +607,8 @@ struct FoldJob {
     int K, H, blk_begin;
     float eps;
     int centred;                           // 1: the consumer subtracts `mean` from its input rows itself (large-graph training): bf = b + sum beta W
+    int dyn0, dyn1, dyn_w;                 // dyn_w > 0: bf = the shift sum over the weight rows [dyn0, dyn0 + dyn_w) and [dyn1, dyn1 + dyn_w) ALONE, without b - the
+                                           // rest of the first layer's constant part comes from somewhere else (train_composite_big.hpp: once per step)
 };
 struct FoldArgs {
     FoldJob job[GNN_MAX_TYPES + 1];
@@ -636,6 +638,7 @@ __global__ void __launch_bounds__(128) k_fold_bn(FoldArgs fa) {
         }
         const float wv = jb.W[(size_t)k * H + h];
         jb.Wf[(size_t)k * H + h] = wv * inv;
+        if (jb.dyn_w > 0 && !((k >= jb.dyn0 && k < jb.dyn0 + jb.dyn_w) || (k >= jb.dyn1 && k < jb.dyn1 + jb.dyn_w))) shift = 0.0f;
         acc = fmaf(shift, wv, acc);
     }
     part[threadIdx.x] = acc;
@@ -644,7 +647,7 @@ __global__ void __launch_bounds__(128) k_fold_bn(FoldArgs fa) {
         if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) jb.bf[h] = (jb.b ? jb.b[h] : 0.0f) + part[0];
+    if (threadIdx.x == 0) jb.bf[h] = ((jb.b && jb.dyn_w == 0) ? jb.b[h] : 0.0f) + part[0];
 }
 
 // dst[i, :width] = src[i, :width] with independent leading dimensions; pads dst columns [width, ld_dst_fill) with 0.

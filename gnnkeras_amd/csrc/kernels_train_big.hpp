@@ -161,6 +161,9 @@ struct TrainFwdArgs {
     const float *stat_shift;              // [H] or NULL: subtracted before the sums (the input state's column means: see k_aggregate_stats)
     const float *in_mean;                 // [in_dim] (by weight row) or NULL: subtracted from the input rows as they arrive; (Wf, bf) are then the
                                           // fold WITHOUT the -mean a term (FoldJob::centred)
+    const float *addend; int ld_add;      // k_train_fwd_b6<.., ADD = true> only: [M, H] added to the pre-activations INSTEAD of the constants line's
+                                          // product - the constant inputs' share of the first layer, which does not change between the iterations
+                                          // of a step (their batch statistics do not: train_composite_big.hpp; constant inputs wider than the line)
 };
 
 // mean of virtual input column k of [state | agg | constants line] (chunks of 16), 0 where there is none
@@ -497,11 +500,12 @@ __device__ __forceinline__ f32x4 mfma_b6_16(const u32x4 &wh, const u32x4 &wm, co
 // kernels above).  Here a trip is: wait for the tile's rows (requested a whole trip ago) -> split ALL of them to bf16 (60 registers)
 // and keep the state chunks for the predicate -> request the next tile's rows -> store the PREVIOUS tile's output (its activated values
 // waited in 16 registers) -> products -> activation, statistics, predicate.  Nothing the next wait covers is younger than most of a trip.
-template <int SQ, int ACT>
+template <int SQ, int ACT, bool ADD = false>
 __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(TrainFwdArgs a) {
     TB_MARK(0); TB_BLOCK_TIME(0);
     if (gate_closed(a.gate)) return;
-    constexpr int NCT = SQ, HP = 16 * NCT, NQ = 2 * SQ + 2, NKB = NQ / 2;
+    constexpr int XQ = ADD ? 0 : 2;                     // 16-column chunks of the constants line (ADD: none - TrainFwdArgs::addend stands in for their product)
+    constexpr int NCT = SQ, HP = 16 * NCT, NQ = 2 * SQ + XQ, NKB = NQ / 2;
     constexpr int PLANE = NKB * NCT * 64 * 8;                                                   // bf16 elements of one weight plane
     extern __shared__ __attribute__((aligned(16))) float tb_smem[];
     unsigned short *Wl = reinterpret_cast<unsigned short *>(tb_smem);                           // [3 planes][NKB][NCT][64 lanes][8]
@@ -522,7 +526,7 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
         int row = -1;
         if (k < 16 * SQ) row = a.wrow_state + k;
         else if (k < 32 * SQ) row = a.wrow_agg + (k - 16 * SQ);
-        else if (a.xc) {
+        else if (!ADD && a.xc) {
             int jj = k - 32 * SQ, beg = 0;
 #pragma unroll
             for (int sg = 0; sg < 3; ++sg) {
@@ -561,23 +565,32 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
 
     // windows of exactly the arrays' sizes: the rows past M of the last tile are out of range by themselves (they read 0), no select per load
     const __amdgpu_buffer_rsrc_t r_s = buf_rsrc_n(a.state, (unsigned)a.M * (unsigned)a.ld_state * 4u), r_a = buf_rsrc_n(a.agg, (unsigned)a.M * (unsigned)a.ld_agg * 4u),
-                                 r_x = buf_rsrc_n(uniform_ptr(a.xc), (unsigned)a.M * 128u), r_y = buf_rsrc(a.Y);
+                                 r_x = ADD ? buf_rsrc_n(uniform_ptr(a.addend), (unsigned)a.M * (unsigned)a.ld_add * 4u) : buf_rsrc_n(uniform_ptr(a.xc), (unsigned)a.M * 128u),
+                                 r_y = buf_rsrc(a.Y);
     const int n_tiles = (a.M + 15) >> 4;
     f32x4 cs1[NCT], cs2[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) { cs1[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; cs2[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     int any = 0;
     f32x4 A[NQ];
-    const unsigned o_s = (unsigned)c * (unsigned)a.ld_state * 4u + 16u * g, o_a = (unsigned)c * (unsigned)a.ld_agg * 4u + 16u * g, o_x = (unsigned)c * 128u + 16u * g;
-    auto fetch = [&](int t) {                           // this lane's 16-byte pieces of row 16 t + c: state, agg, constants line
-        const unsigned b_s = 64u * (unsigned)t * (unsigned)a.ld_state + o_s, b_a = 64u * (unsigned)t * (unsigned)a.ld_agg + o_a, b_x = 2048u * (unsigned)t + o_x;
+    f32x4 Cn[ADD ? NCT : 1];                            // ADD: this lane's pieces of the addend's row (the accumulators' layout: columns 16 ct + 4 g)
+    const unsigned o_s = (unsigned)c * (unsigned)a.ld_state * 4u + 16u * g, o_a = (unsigned)c * (unsigned)a.ld_agg * 4u + 16u * g,
+                   o_x = ADD ? (unsigned)c * (unsigned)a.ld_add * 4u + 16u * g : (unsigned)c * 128u + 16u * g;
+    auto fetch = [&](int t) {                           // this lane's 16-byte pieces of row 16 t + c: state, agg, constants line (or the addend)
+        const unsigned b_s = 64u * (unsigned)t * (unsigned)a.ld_state + o_s, b_a = 64u * (unsigned)t * (unsigned)a.ld_agg + o_a,
+                       b_x = ADD ? 64u * (unsigned)t * (unsigned)a.ld_add + o_x : 2048u * (unsigned)t + o_x;
 #pragma unroll
         for (int q = 0; q < SQ; ++q) {
             A[q] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_s, b_s + 64u * q);
             A[SQ + q] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_a, b_a + 64u * q);
         }
+        if constexpr (ADD) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) A[2 * SQ + q] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_x, b_x + 64u * q);
+            for (int ct = 0; ct < NCT; ++ct) Cn[ct] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_x, b_x + 64u * ct);
+        } else {
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) A[2 * SQ + q] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_x, b_x + 64u * q);
+        }
     };
     const int t_step = gridDim.x * TB_WAVES;
     int trip_ = 0; (void)trip_;
@@ -600,6 +613,12 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
                         xh[kb], xm[kb], xl[kb]);
 #pragma unroll
         for (int q = 0; q < SQ; ++q) old[q] = A[q];
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            acc[ct] = *reinterpret_cast<const f32x4 *>(bias_l + 16 * ct + 4 * g);
+            if constexpr (ADD) acc[ct] += Cn[ct];          // (before the next tile's pieces take the registers)
+        }
         __builtin_amdgcn_sched_barrier(0);
         fetch(t + t_step);
 #pragma unroll
@@ -609,9 +628,6 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
         }
         __builtin_amdgcn_sched_barrier(0);
         TB_STAMP_DEP(1, xh[NKB - 1]);
-        f32x4 acc[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[ct] = *reinterpret_cast<const f32x4 *>(bias_l + 16 * ct + 4 * g);
         // products in stages of (k block, CTG column tiles): a stage's weight fragments (3 planes x CTG) are read from LDS one stage ahead,
         // and inside a stage consecutive MFMAs go to different accumulators (left alone hipcc builds chains of six dependent MFMAs with
         // an LDS round trip in front of each: 14 000 cycles per tile)
@@ -690,8 +706,11 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
     }
 }
 
-template <int SQ>
-inline size_t train_fwd_b6_lds() { return (size_t)(3 * (SQ + 1) * SQ * 64 * 8 * 2) + (size_t)(16 * SQ + TB_WAVES * 2 * 16 * SQ + 16 * SQ + 16 * (2 * SQ + 2)) * sizeof(float); }
+template <int SQ, bool ADD = false>
+inline size_t train_fwd_b6_lds() {
+    constexpr int NQ = 2 * SQ + (ADD ? 0 : 2);
+    return (size_t)(3 * (NQ / 2) * SQ * 64 * 8 * 2) + (size_t)(16 * SQ + TB_WAVES * 2 * 16 * SQ + 16 * SQ + 16 * NQ) * sizeof(float);
+}
 
 template <int SQ, int NCT>
 inline size_t train_fwd_lds() { return (size_t)(16 * (2 * SQ + 2) * 16 * NCT + 16 * NCT + TB_WAVES * 2 * 16 * NCT + 16 * NCT + 16 * (2 * SQ + 2)) * sizeof(float); }
@@ -1097,9 +1116,9 @@ __global__ void __launch_bounds__(256, 2) k_train_wgrad(TrainWgradArgs a) {
 
 // The 32x32 tiles of a workgroup's four waves -> its partial P (LDS, waves in order) -> a.part, by weight row (shared by the f32 and the
 // bf16-split forms of the kernel: v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_bf16 leave their results in the same registers).
-template <int NB>
-__device__ __forceinline__ void wgrad32_store(const TrainWgradArgs &a, f32x16 (&acc)[2 * NB + 1][NB], float *Ps) {
-    constexpr int S = 32 * NB, RT = 2 * NB + 1, KV = 2 * S + 32;
+template <int NB, int XT = 1>                 // XT: 32-column tiles of the constants line (1: the 128-byte line; 2: 256 bytes, k_train_wgrad_b6<.., XT = 2>)
+__device__ __forceinline__ void wgrad32_store(const TrainWgradArgs &a, f32x16 (&acc)[2 * NB + XT][NB], float *Ps) {
+    constexpr int S = 32 * NB, RT = 2 * NB + XT, KV = 2 * S + 32 * XT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kk = lane >> 5;
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -1112,7 +1131,7 @@ __device__ __forceinline__ void wgrad32_store(const TrainWgradArgs &a, f32x16 (&
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int m = 8 * (v >> 2) + 4 * kk + (v & 3);
-                    const int kv = rt < NB ? NB * m + rt : rt < 2 * NB ? S + NB * m + (rt - NB) : 2 * S + m;
+                    const int kv = rt < NB ? NB * m + rt : rt < 2 * NB ? S + NB * m + (rt - NB) : 2 * S + 32 * (rt - 2 * NB) + m;
                     float *dst = Ps + kv * S + NB * i;
 #pragma unroll
                     for (int f = 0; f < NB; ++f) dst[f] = w == 0 ? acc[rt][f][v] : dst[f] + acc[rt][f][v];
@@ -1235,12 +1254,13 @@ template <int OFF> __device__ __forceinline__ void lds_read_f32(float &v, unsign
 // hand (s_waitcnt vmcnt(NG): every step issues exactly NG loads, past the end of the workgroup's rows too - those touch no memory and
 // fill zeros), the LDS reads are inline assembly so that hipcc does not drain the ring in front of them.
 // 160 accumulator registers: one wave per SIMD, one workgroup per CU.
-template <int NB, int ACT>
+template <int NB, int ACT, int XT = 1>       // XT = 2: a constants line of 64 floats (k_pack_xc_pos<64>: 32 .. 63 constant inputs - heterogeneous models)
 __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
-    constexpr int S = 32 * NB, RT = 2 * NB + 1;
+    constexpr int S = 32 * NB, RT = 2 * NB + XT;
     constexpr bool HAS_Y = ACT != GNN_ACT_LINEAR;
     constexpr int ARR = 16 * S * 4, NA = HAS_Y ? 4 : 3;        // bytes of 16 rows of an [M, S] array; arrays in a slot: dZ | state | agg | (Y)
-    constexpr int MAIN = NA * ARR, NGM = MAIN / 1024, XCB = 2048, NGX = 2;      // a slot of rows and its LDS-DMA instructions; 16 rows of the constants line
+    constexpr int LINE_B = 128 * XT;                           // bytes of a row of the constants line
+    constexpr int MAIN = NA * ARR, NGM = MAIN / 1024, XCB = 16 * LINE_B, NGX = XCB / 1024;      // a slot of rows and its LDS-DMA instructions; 16 rows of the constants line
     constexpr int D = 2, XR = 2;                               // ring depths: slots of rows / of the line a wave.  (D = 3 - the CU's whole 160 KB at S = 64 - measured
                                                                //  185 us against 177 - 183 at 1 M rows: the LDS-DMA stream is not short of bytes in flight)
     constexpr int WAVE_B = D * MAIN + XR * XCB;
@@ -1254,7 +1274,7 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
     const size_t o_rows = (size_t)m_beg * S;
     const unsigned win = (unsigned)rows * (unsigned)S * 4u;
     const __amdgpu_buffer_rsrc_t r_g = buf_rsrc_n(a.G + o_rows, win), r_y = buf_rsrc_n(a.Y ? a.Y + o_rows : nullptr, win), r_s = buf_rsrc_n(a.state + o_rows, win),
-                                 r_a = buf_rsrc_n(a.agg + o_rows, win), r_c = buf_rsrc_n(a.xc ? a.xc + (size_t)m_beg * 32 : nullptr, (unsigned)rows * 128u);
+                                 r_a = buf_rsrc_n(a.agg + o_rows, win), r_c = buf_rsrc_n(a.xc ? a.xc + (size_t)m_beg * (32 * XT) : nullptr, (unsigned)rows * (unsigned)LINE_B);
     f32x16 acc[RT][NB];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -1262,10 +1282,11 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
         for (int f = 0; f < NB; ++f)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[rt][f][v] = 0.0f;
-    float mu_s[NB], mu_a[NB], mu_c;
+    float mu_s[NB], mu_a[NB], mu_c[XT];
 #pragma unroll
     for (int e = 0; e < NB; ++e) { mu_s[e] = a.mean ? a.mean[a.wrow_state + NB * i + e] : 0.0f; mu_a[e] = a.mean ? a.mean[a.wrow_agg + NB * i + e] : 0.0f; }
-    { const int wr = wgrad_wrow(a, S, 2 * S + i); mu_c = (a.mean && wr >= 0) ? a.mean[wr] : 0.0f; }
+#pragma unroll
+    for (int x = 0; x < XT; ++x) { const int wr = wgrad_wrow(a, S, 2 * S + 32 * x + i); mu_c[x] = (a.mean && wr >= 0) ? a.mean[wr] : 0.0f; }
     typedef __attribute__((address_space(3))) char lds_char;
     lds_char *ring = (lds_char *)tb_smem + wave * WAVE_B;
     const unsigned ring_addr = (unsigned)(size_t)ring;
@@ -1282,13 +1303,13 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
     };
     auto fill_xc = [&](int xslot, int s) {                  // ... and of the constants line
         lds_char *dst = ring + D * MAIN + xslot * XCB;
-        const unsigned off_c = (unsigned)(64 * s + 16 * wave) * 128u + 16u * (unsigned)lane;
+        const unsigned off_c = (unsigned)(64 * s + 16 * wave) * (unsigned)LINE_B + 16u * (unsigned)lane;
 #pragma unroll
         for (int q = 0; q < NGX; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_c, (__attribute__((address_space(3))) void *)(dst + 1024 * q), 16, (int)(off_c + 1024u * q), 0, 0, TB_RING_AUX);
     };
-    struct Step { Piece<NB> gz[8], xs[8], xa[8], y[8]; Piece<1> xc[8]; };
-    const unsigned lane_addr = ring_addr + (unsigned)(8 * kg) * (unsigned)(S * 4) + (unsigned)(NB * i) * 4u, lane_addr_c = ring_addr + D * MAIN + (unsigned)(8 * kg) * 128u + (unsigned)i * 4u;
+    struct Step { Piece<NB> gz[8], xs[8], xa[8], y[8]; Piece<1> xc[XT][8]; };
+    const unsigned lane_addr = ring_addr + (unsigned)(8 * kg) * (unsigned)(S * 4) + (unsigned)(NB * i) * 4u, lane_addr_c = ring_addr + D * MAIN + (unsigned)(8 * kg) * (unsigned)LINE_B + (unsigned)i * 4u;
 #define B8(v_) __builtin_bit_cast(bf16x8, v_)
     auto split8 = [&](const float (&x)[8], u32x4 &h, u32x4 &m, u32x4 &l) {
         unsigned hh[4], mm[4], ll[4];
@@ -1316,7 +1337,8 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
                 constexpr int j = decltype(jc)::value;
                 lds_read_piece<NB, j * S * 4>(b.gz[j], base); lds_read_piece<NB, ARR + j * S * 4>(b.xs[j], base); lds_read_piece<NB, 2 * ARR + j * S * 4>(b.xa[j], base);
                 if (HAS_Y) lds_read_piece<NB, 3 * ARR + j * S * 4>(b.y[j], base);
-                lds_read_piece<1, j * 128>(b.xc[j], base_c);
+                lds_read_piece<1, j * LINE_B>(b.xc[0][j], base_c);
+                if constexpr (XT > 1) lds_read_piece<1, j * LINE_B + 128>(b.xc[XT - 1][j], base_c);
             });
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // the slot is in registers: hand it to the loads of step s + 2
@@ -1324,7 +1346,8 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
         for (int j = 0; j < 8; ++j) {             // (no instruction: every use of a value that was read comes after the wait - volatile statements keep their order)
 #pragma unroll
             for (int e = 0; e < NB; ++e) { asm volatile("" : "+v"(b.gz[j].v[e])); asm volatile("" : "+v"(b.xs[j].v[e])); asm volatile("" : "+v"(b.xa[j].v[e])); if (HAS_Y) asm volatile("" : "+v"(b.y[j].v[e])); }
-            asm volatile("" : "+v"(b.xc[j].v[0]));
+#pragma unroll
+            for (int x = 0; x < XT; ++x) asm volatile("" : "+v"(b.xc[x][j].v[0]));
         }
         fill_xc(xslot, s + XR); fill_main(slot, s + D);
         slot = slot + 1 == D ? 0 : slot + 1;
@@ -1341,7 +1364,8 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
             float x[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = rt < NB ? b.xs[j].v[rt < NB ? rt : 0] - mu_s[rt < NB ? rt : 0]
-                                             : rt < 2 * NB ? b.xa[j].v[rt < 2 * NB && rt >= NB ? rt - NB : 0] - mu_a[rt < 2 * NB && rt >= NB ? rt - NB : 0] : b.xc[j].v[0] - mu_c;
+                                             : rt < 2 * NB ? b.xa[j].v[rt < 2 * NB && rt >= NB ? rt - NB : 0] - mu_a[rt < 2 * NB && rt >= NB ? rt - NB : 0]
+                                             : b.xc[rt >= 2 * NB ? rt - 2 * NB : 0][j].v[0] - mu_c[rt >= 2 * NB ? rt - 2 * NB : 0];
             u32x4 xh, xm, xl;
             split8(x, xh, xm, xl);
             // small terms first; consecutive MFMAs go to different accumulators
@@ -1358,11 +1382,11 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
 #undef B8
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the fills past the end)
     __syncthreads();                                        // every wave is done with its ring: the partial P takes its place
-    wgrad32_store<NB>(a, acc, tb_smem);
+    wgrad32_store<NB, XT>(a, acc, tb_smem);
 }
-template <int NB, int ACT>
+template <int NB, int ACT, int XT = 1>
 inline size_t train_wgrad_b6_lds() {
-    const size_t S = 32 * NB, na = ACT != GNN_ACT_LINEAR ? 4 : 3, ring = 4 * (2 * na * 16 * S * 4 + 2 * 2048), P = (2 * S + 32) * S * 4;
+    const size_t S = 32 * NB, na = ACT != GNN_ACT_LINEAR ? 4 : 3, ring = 4 * (2 * na * 16 * S * 4 + 2 * 2048 * XT), P = (2 * S + 32 * XT) * S * 4;
     return ring > P ? ring : P;
 }
 

@@ -13,6 +13,7 @@
 // gradients keep the building-block path.
 #pragma once
 // (included by gnnloop.hip behind train_loop.hpp: shares its anonymous-namespace helpers)
+#include "train_composite_big.hpp"      // large graphs: the row-streaming kernels on per-type position ranges
 
 namespace {
 
@@ -41,6 +42,8 @@ struct CPlan {
     // order in tiles of <= 64 nodes of one type: the tape's rows are POSITIONS (position i = node type_nodes[i]), `inv` maps back
     bool small; int SPs, ldS, n_wg, wg_begin[GNN_MAX_TYPES + 1];
     int *inv; float *sm_cc, *sm_part, *sm_dxa, *sm_partW[GNN_MAX_TYPES], *sm_partBN[GNN_MAX_TYPES]; unsigned long long *sm_bar;
+    // large graphs (train_composite_big.hpp): the tape's rows are POSITIONS too, every type a contiguous range of them
+    bool big; CBig B;
     size_t bytes;
 };
 
@@ -117,6 +120,8 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
     }
     p.small = uniform && p.n_wg >= 1 && p.n_wg <= std::min(device_cus(), 256) && (size_t)p.K * p.N * p.SPs * sizeof(float) <= agg_tape_budget();
     p.ldS = p.small ? p.SPs : p.S;
+    p.big = !p.small && composite_big_applies(ta, p.N, p.S, p.W_comp, &p.B.XT);
+    p.B.XW = 32 * p.B.XT;
 
     Carver c(ws);
     p.grads_ok = c.take<int>(4);
@@ -129,7 +134,7 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
     p.stats_o = c.take<float>(2 * (size_t)no.in_dim);
     p.Wf_o = c.take<float>((size_t)no.in_dim * no.units[0]); p.bf_o = c.take<float>(no.units[0]);
     p.dx_o_all = c.take<float>((size_t)std::max(p.M, 1) * no.in_dim);
-    p.dx_full = c.take<float>((size_t)p.N * 2 * p.S);
+    p.dx_full = c.take<float>((size_t)p.N * 2 * p.S);                // (large graphs: d loss / d [state | agg] by position)
     p.G_state = c.take<float>((size_t)p.N * p.S);
     p.G_out = c.take<float>((size_t)std::max(p.M, 1) * p.T);
     p.dpred = c.take<float>((size_t)std::max(p.R, 1) * p.T);
@@ -149,21 +154,50 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
         if (y.m->in_dim != y.in_dim) return fail("net_state[%d].in_dim %d != %d expected from the graph dims", t, y.m->in_dim, y.in_dim);
         if (y.m->units[y.m->n_layers - 1] != p.S) return fail("net_state[%d] output width %d != state width %d", t, y.m->units[y.m->n_layers - 1], p.S);
         y.off_state = y.d_t; y.off_agg = y.d_t + p.S; y.off_comp = y.d_t + 2 * p.S;
-        carve_net(c, y.nc, *y.m, y.count, p.part_floats);
+        carve_net(c, y.nc, *y.m, p.big ? 0 : y.count, p.part_floats);      // (large graphs: no per-layer row buffers - the kernels stream the tape)
         y.nc.m = y.m; y.nc.g = &y.g;
         y.stats = c.take<float>((size_t)p.K * 2 * y.in_dim);
         y.stats_tpl = c.take<float>(2 * (size_t)y.in_dim);
         y.Wf = c.take<float>((size_t)p.K * y.in_dim * y.m->units[0]);
         y.bf = c.take<float>((size_t)p.K * y.m->units[0]);
-        y.Gc = c.take<float>((size_t)std::max(y.count, 1) * p.S);
-        y.dx = c.take<float>((size_t)std::max(y.count, 1) * 2 * p.S);
+        y.Gc = c.take<float>(p.big ? 0 : (size_t)std::max(y.count, 1) * p.S);
+        y.dx = c.take<float>(p.big ? 0 : (size_t)std::max(y.count, 1) * 2 * p.S);
         int nc_; rows_per_chunk_for(std::max(y.count, 1), &nc_);
         p.part_floats = std::max(p.part_floats, (size_t)(nc_ + 1) * y.in_dim);
         const int tiles_t = p.wg_begin[t + 1] - p.wg_begin[t];
         p.sm_partW[t] = c.take<float>(p.small ? (size_t)tiles_t * ((size_t)y.in_dim * p.S + p.S) : 0);
         p.sm_partBN[t] = c.take<float>(p.small ? (size_t)tiles_t * 2 * y.in_dim : 0);
     }
-    p.inv = c.take<int>(p.small ? p.N : 0);
+    p.inv = c.take<int>((p.small || p.big) ? p.N : 0);
+    if (p.big) {
+        CBig &B = p.B;
+        const gnn_csr_t &ad = a.adjacency, &as = ta.adjacency_by_source;
+        B.scan_tmp = c.take<int>((size_t)cdiv(p.N, SCAN_CHUNK) + 2);
+        B.d.rp = c.take<int>((size_t)p.N + 1); B.d.src = c.take<int>((size_t)std::max(ad.nnz, 1));
+        B.d.w = c.take<float>(ad.w ? (size_t)std::max(ad.nnz, 1) : 0); B.d.row_scale = c.take<float>(ad.row_scale ? (size_t)p.N : 0);
+        B.s.rp = c.take<int>((size_t)p.N + 1); B.s.src = c.take<int>((size_t)std::max(as.nnz, 1));
+        B.s.w = c.take<float>(as.w ? (size_t)std::max(as.nnz, 1) : 0); B.s.row_scale = c.take<float>(as.row_scale ? (size_t)p.N : 0);
+        if (!ad.w) B.d.w = nullptr;
+        if (!ad.row_scale) B.d.row_scale = nullptr;
+        if (!as.w) B.s.w = nullptr;
+        if (!as.row_scale) B.s.row_scale = nullptr;
+        B.xc = c.take<float>((size_t)p.N * B.XW);
+        B.Cc = c.take<float>((size_t)p.N * p.S);
+        B.Gpos = c.take<float>((size_t)p.N * p.S);
+        B.part_a = c.take<float>((size_t)BIG_AGG_BLOCKS * 2 * p.S);
+        B.part_y = c.take<float>((size_t)BIG_FWD_BLOCKS * 2 * std::max(p.S, 32));
+        int max_in = 1;
+        for (int t = 0; t < p.n_types; ++t) max_in = std::max(max_in, p.ty[t].in_dim);
+        B.part_w = c.take<float>((size_t)BIG_WGRAD_BLOCKS * ((size_t)max_in * p.S + p.S));
+        for (int t = 0; t < p.n_types; ++t) {         // the constants line of type t: [labels[:, :d_t] | aggregated_component | 1 | 0 ..]
+            const CType &y = p.ty[t];
+            gnn::ConstCols &cc = B.cc[t];
+            memset(&cc, 0, sizeof(cc));
+            if (y.d_t > 0) { cc.width[cc.n] = y.d_t; cc.wrow[cc.n] = 0; ++cc.n; }
+            if (p.W_comp > 0) { cc.width[cc.n] = p.W_comp; cc.wrow[cc.n] = y.off_comp; ++cc.n; }
+            B.Kc[t] = y.d_t + p.W_comp;
+        }
+    }
     p.sm_cc = c.take<float>(p.small ? (size_t)p.N * p.SPs : 0);
     p.sm_part = c.take<float>(p.small ? (size_t)2 * p.n_wg * 8 * p.SPs : 0);
     p.sm_dxa = c.take<float>(p.small ? (size_t)p.N * p.SPs : 0);
@@ -190,6 +224,210 @@ int ctype_segs(const gnn_loop_args_t &a, const CPlan &p, const CType &y, int t, 
     *i_agg = n;   segs[n++] = gnn::Seg{agg_t, y.rows, p.S, p.S, y.off_agg};
     if (p.W_comp > 0) segs[n++] = gnn::Seg{p.agg_comp, y.rows, p.W_comp, p.W_comp, y.off_comp};
     return n;
+}
+
+// ---- large graphs: the step in position space (train_composite_big.hpp) --------------------------------------------------------------------
+// rows [off, off + count) of the by-destination / by-source adjacency in positions
+gnn_csr_t big_sub_csr(const PosCsr &c, int N, int off, int count, bool with_w) {
+    gnn_csr_t r;
+    r.n_dst = count; r.n_src = N; r.nnz = c.nnz; r.rowptr = c.rp + off; r.src = c.src;
+    r.w = with_w ? c.w : nullptr; r.row_scale = (with_w && c.row_scale) ? c.row_scale + off : nullptr;
+    return r;
+}
+
+// positions, the re-labelled adjacency, state_0 by position, every type's constants line and the constant part of its first layer
+int composite_big_setup(const gnn_train_args_t &ta, CPlan &p, hipStream_t st) {
+    const gnn_loop_args_t &a = ta.loop;
+    CBig &B = p.B;
+    k_invert_perm<<<std::min(cdiv(p.N, 256), 1024), 256, 0, st>>>(a.type_nodes, p.N, p.inv);
+    LAUNCH_OK();
+    TRY(build_pos_csr(a.adjacency, a.type_nodes, p.inv, p.N, B.d, B.scan_tmp, st));
+    TRY(build_pos_csr(ta.adjacency_by_source, a.type_nodes, p.inv, p.N, B.s, B.scan_tmp, st));
+    if (a.state_dim > 0) TRY(gather_rows(a.state0, p.S, a.type_nodes, p.N, p.S, p.states, p.S, st));
+    else TRY(gather_rows(a.nodes, a.ld_nodes, a.type_nodes, p.N, p.S, p.states, p.S, st));
+    for (int q = 0; q < p.n_types; ++q) {
+        const CType &y = p.ty[q];
+        if (y.count == 0) continue;
+        const int off = a.type_offsets[q];
+        gnn::PackSegs ps;
+        memset(&ps, 0, sizeof(ps));
+        gnn::ConstSegs cs;
+        memset(&cs, 0, sizeof(cs));
+        if (y.d_t > 0) {
+            ps.ptr[ps.n] = a.nodes; ps.ld[ps.n] = a.ld_nodes; ps.width[ps.n] = y.d_t; ps.wrow[ps.n] = 0; ++ps.n;
+            cs.ptr[cs.n] = a.nodes; cs.ld[cs.n] = a.ld_nodes; cs.width[cs.n] = y.d_t; cs.wrow[cs.n] = 0; ++cs.n;
+        }
+        if (p.W_comp > 0) {
+            ps.ptr[ps.n] = p.agg_comp; ps.ld[ps.n] = p.W_comp; ps.width[ps.n] = p.W_comp; ps.wrow[ps.n] = y.off_comp; ++ps.n;
+            cs.ptr[cs.n] = p.agg_comp; cs.ld[cs.n] = p.W_comp; cs.width[cs.n] = p.W_comp; cs.wrow[cs.n] = y.off_comp; ++cs.n;
+        }
+        const int grid = (int)std::min<long>(cdiv((long)y.count * B.XW, 256), 256 * 16);
+        if (B.XT == 2) k_pack_xc_pos<64><<<grid, 256, 0, st>>>(y.count, y.rows, ps, B.xc + (size_t)off * B.XW);
+        else k_pack_xc_pos<32><<<grid, 256, 0, st>>>(y.count, y.rows, ps, B.xc + (size_t)off * B.XW);
+        LAUNCH_OK();
+        // Cc = b + sum over the constant columns of (a (x - mean) + beta) W   (their statistics: y.stats_tpl, taken over the type's rows)
+        gnn::k_train_small_const<<<cdiv((long)y.count * p.S, 256), 256, 0, st>>>(y.count, p.S, p.S, cs, y.m->kernel[0], y.m->bias[0], y.m->has_bn ? y.m->bn_gamma : nullptr,
+                                                                                  y.m->bn_beta, y.stats_tpl, y.stats_tpl + y.in_dim, y.m->bn_eps,
+                                                                                  B.Cc + (size_t)off * p.S, y.rows);
+        LAUNCH_OK();
+    }
+    return 0;
+}
+
+// the K gated training-mode iterations (CompositeGNN.py:215-234), every type's rows by its own network
+int composite_big_forward(const gnn_train_args_t &ta, CPlan &p, hipStream_t st) {
+    const gnn_loop_args_t &a = ta.loop;
+    CBig &B = p.B;
+    const size_t NS = (size_t)p.N * p.S;
+    for (int t = 0; t < p.K; ++t) {
+        const int *gate = p.flags + t;
+        const float *s_t = p.states + (size_t)t * NS;
+        float *s_n = p.states + (size_t)(t + 1) * NS;
+        float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);
+        for (int q = 0; q < p.n_types; ++q) {
+            CType &y = p.ty[q];
+            if (y.count == 0) continue;
+            const gnn_mlp_t &ns = *y.m;
+            const bool bn = ns.has_bn != 0;
+            const int off = a.type_offsets[q];
+            const size_t ro = (size_t)off * p.S;
+            const gnn_csr_t cd = big_sub_csr(B.d, p.N, off, y.count, true);
+            float *stats = y.stats + (size_t)t * 2 * y.in_dim;
+            if (bn) {
+                // (moments around the previous iteration's column means, as the homogeneous step takes them)
+                const float *prev = t > 0 ? y.stats + (size_t)(t - 1) * 2 * y.in_dim : nullptr;
+                TRY(launch_aggregate_stats(gate, cd, s_t, p.S, agg_t + ro, B.part_a, stats + y.off_agg, stats + y.in_dim + y.off_agg, prev ? prev + y.off_agg : nullptr, st));
+                if (t == 0) {       // (later iterations: the launch that wrote the rows left their statistics)
+                    int grid = 0;
+                    TRY(rows_stats(gate, s_t + ro, p.S, p.S, y.count, B.part_y, st, &grid));
+                    gnn::k_stats_finish<<<p.S, 256, 0, st>>>(gate, B.part_y, grid, p.S, 1.0f / (float)y.count, stats + y.off_state, stats + y.in_dim + y.off_state, s_t + ro);
+                    LAUNCH_OK();
+                }
+            } else TRY(launch_aggregate(gate, cd, s_t, p.S, p.S, agg_t + ro, p.S, st));
+            // the state / agg rows of the first layer with this iteration's statistics folded in; the bias the kernel adds is the shift of THOSE
+            // columns alone (sum beta W over them) - b and the constant columns' share sit in Cc
+            float *Wf = y.Wf + (size_t)t * y.in_dim * p.S, *bf = y.bf + (size_t)t * p.S;
+            {
+                FoldList fl;
+                gnn::FoldJob &j = fl.fa.job[fl.fa.n_jobs++];
+                j.centred = 1;
+                j.W = ns.kernel[0]; j.b = nullptr; j.K = y.in_dim; j.H = p.S;
+                j.gamma = bn ? ns.bn_gamma : nullptr; j.beta = ns.bn_beta; j.mean = stats; j.var = stats + y.in_dim; j.eps = ns.bn_eps;
+                j.Wf = Wf; j.bf = bf; j.blk_begin = 0;
+                j.dyn0 = y.off_state; j.dyn1 = y.off_agg; j.dyn_w = p.S;
+                fl.blocks = j.H;
+                TRY(launch_fold_list(fl, st));
+            }
+            gnn::TrainFwdArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.in_mean = bn ? stats : nullptr;
+            fa.gate = gate; fa.M = y.count;
+            fa.state = s_t + ro; fa.ld_state = p.S; fa.agg = agg_t + ro; fa.ld_agg = p.S;
+            fa.addend = B.Cc + ro; fa.ld_add = p.S;
+            fa.Wf = Wf; fa.bf = bf; fa.H = p.S; fa.wrow_state = y.off_state; fa.wrow_agg = y.off_agg;
+            fa.act = ns.activation[0];
+            fa.Y = s_n + ro; fa.ldy = p.S;
+            fa.thr = a.state_threshold; fa.pred_flag = p.flags + t + 1; fa.pred_k = p.k_dev; fa.pred_kval = (float)(t + 1);
+            const bool next_stats = bn && t + 1 < p.K;
+            fa.stat_part = next_stats ? B.part_y : nullptr;
+            fa.stat_shift = next_stats ? stats + y.off_state : nullptr;       // (the new rows' moments around the input rows' column means)
+            int grid = 0;
+            TRY(launch_train_fwd_add(fa, p.S, st, &grid));
+            if (next_stats) {
+                float *nxt = y.stats + (size_t)(t + 1) * 2 * y.in_dim;
+                gnn::k_stats_finish<<<p.S, 256, 0, st>>>(gate, B.part_y, grid, p.S, 1.0f / (float)y.count, nxt + y.off_state, nxt + y.in_dim + y.off_state, stats + y.off_state);
+                LAUNCH_OK();
+            }
+        }
+    }
+    return 0;
+}
+
+// back-propagation through the k executed iterations; p.G_state = d loss / d state_k in the caller's node order
+int composite_big_backward(const gnn_train_args_t &ta, CPlan &p, int k, hipStream_t st) {
+    const gnn_loop_args_t &a = ta.loop;
+    CBig &B = p.B;
+    const size_t NS = (size_t)p.N * p.S;
+    if (k == 0) return 0;
+    // the first dZ: G by position, times act'(state_k) of the row's own type
+    TRY(gather_rows(p.G_state, p.S, a.type_nodes, p.N, p.S, B.Gpos, p.S, st));
+    for (int q = 0; q < p.n_types; ++q) {
+        const CType &y = p.ty[q];
+        if (y.count == 0) continue;
+        const size_t ro = (size_t)a.type_offsets[q] * p.S;
+        TRY(act_grad_inplace(B.Gpos + ro, p.S, p.states + (size_t)k * NS + ro, p.S, y.count, p.S, y.m->activation[0], st));
+    }
+    const bool unit_w = !a.adjacency.w;       // entries depend on the destination only: the agg-half of a row's gradient is scaled once, the transposed walk is unit-weight
+    float *dx = p.dx_full;
+    for (int t = k - 1; t >= 0; --t) {
+        const float *s_t = p.states + (size_t)t * NS;
+        const float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);
+        if (!p.agg_taped) {
+            const gnn_csr_t all = big_sub_csr(B.d, p.N, 0, p.N, true);
+            TRY(launch_aggregate(nullptr, all, s_t, p.S, p.S, p.agg, p.S, st));
+        }
+        for (int q = 0; q < p.n_types; ++q) {
+            CType &y = p.ty[q];
+            if (y.count == 0) continue;
+            const gnn_mlp_t &ns = *y.m;
+            const bool bn = ns.has_bn != 0;
+            const int off = a.type_offsets[q];
+            const size_t ro = (size_t)off * p.S;
+            const float *stats = bn ? y.stats + (size_t)t * 2 * y.in_dim : nullptr;
+            // P = [state | agg | constants]^T dZ and q = colsum(dZ) over the type's rows, then its parameter gradients and m1 / m2
+            gnn::TrainWgradArgs wa;
+            memset(&wa, 0, sizeof(wa));
+            const int n_wg = std::min(std::min(device_cus(), BIG_WGRAD_BLOCKS), cdiv(y.count, 64));
+            wa.M = y.count; wa.rows_per_wg = cdiv(cdiv(y.count, n_wg), 64) * 64;
+            wa.G = B.Gpos + ro; wa.Y = nullptr; wa.act = GNN_ACT_LINEAR;
+            wa.state = s_t + ro; wa.agg = agg_t + ro; wa.xc = B.xc + (size_t)off * B.XW;
+            wa.K = y.in_dim; wa.wrow_state = y.off_state; wa.wrow_agg = y.off_agg; wa.Kc = B.Kc[q]; wa.cs = B.cc[q];
+            wa.part = B.part_w;
+            wa.mean = stats;
+            const int grid = cdiv(y.count, wa.rows_per_wg);
+            TRY(launch_train_wgrad_xt(wa, p.S, B.XT, grid, st));
+            const int nP = y.in_dim * p.S + p.S;
+            gnn::k_reduce_partials<<<cdiv(nP, 64), 256, 0, st>>>(B.part_w, grid, nP, y.nc.P, 0, 1.0f, y.in_dim * p.S, y.nc.q);
+            LAUNCH_OK();
+            gnn::k_first_layer_param_grads<<<y.in_dim, 64, 0, st>>>(
+                y.nc.P, y.nc.q, ns.kernel[0], y.in_dim, p.S, bn ? ns.bn_gamma : nullptr, ns.bn_beta, stats, stats ? stats + y.in_dim : nullptr, ns.bn_eps,
+                1.0f / (float)y.count, y.g.dkernel[0], y.g.dbias[0], y.g.dgamma, y.g.dbeta, bn ? y.nc.m1 : nullptr, bn ? y.nc.m2 : nullptr, t != k - 1 ? 1 : 0, 1, stats ? 1 : 0);
+            LAUNCH_OK();
+            if (t == 0) continue;              // nothing consumes d loss / d state_0
+            gnn::TrainBwdArgs ba;
+            memset(&ba, 0, sizeof(ba));
+            ba.M = y.count; ba.dZ = B.Gpos + ro; ba.ldz = p.S;
+            ba.W = ns.kernel[0]; ba.ldw = p.S; ba.H = p.S; ba.S = p.S; ba.wrow_state = y.off_state; ba.wrow_agg = y.off_agg;
+            ba.state = s_t + ro; ba.ld_state = p.S; ba.agg = agg_t + ro; ba.ld_agg = p.S;
+            if (bn) { ba.gamma = ns.bn_gamma; ba.mean = stats; ba.var = stats + y.in_dim; ba.m1 = y.nc.m1; ba.m2 = y.nc.m2; ba.eps = ns.bn_eps; }
+            ba.defer_state_bn = bn ? 1 : 0;    // (k_aggregate_dz below adds the rest of the state half's BatchNorm gradient: it reads state_t anyway)
+            ba.agg_row_scale = (unit_w && B.d.row_scale) ? B.d.row_scale + off : nullptr;
+            ba.dx = dx + (size_t)off * 2 * p.S; ba.ld_dx = 2 * p.S;
+            TRY(launch_train_bwd_dx(ba, p.S, st));
+        }
+        if (t == 0) break;
+        // dZ_{t-1} = (dx_state' + Adj . dx_agg + the deferred BatchNorm term) (.) act'(state_t): arcs by source, every type's rows with ITS network's
+        // coefficients and activation (state_t's rows of type q are outputs of network q and inputs of network q)
+        for (int q = 0; q < p.n_types; ++q) {
+            const CType &y = p.ty[q];
+            if (y.count == 0) continue;
+            const gnn_mlp_t &ns = *y.m;
+            const int off = a.type_offsets[q];
+            const size_t ro = (size_t)off * p.S;
+            const gnn_csr_t cs = big_sub_csr(B.s, p.N, off, y.count, !unit_w);
+            gnn::AggDzArgs z;
+            memset(&z, 0, sizeof(z));
+            z.Y = s_t + ro; z.ldy = p.S; z.wrow_state = y.off_state;
+            if (ns.has_bn) {
+                const float *stats = y.stats + (size_t)t * 2 * y.in_dim;
+                z.gamma = ns.bn_gamma; z.var = stats + y.in_dim; z.mean = stats; z.m1 = y.nc.m1; z.m2 = y.nc.m2; z.eps = ns.bn_eps;
+            }
+            if (!launch_aggregate_dz(cs, dx + p.S, 2 * p.S, B.Gpos + ro, p.S, dx + (size_t)off * 2 * p.S, 2 * p.S, z, ns.activation[0], p.S, st))
+                return fail("k_aggregate_dz: no instance for state width %d / activation %d", p.S, ns.activation[0]);
+            LAUNCH_OK();
+        }
+    }
+    return 0;
 }
 
 size_t composite_train_workspace_bytes(const gnn_train_args_t &ta) {
@@ -251,6 +489,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
         else TRY(gather_rows(a.nodes, a.ld_nodes, a.type_nodes, p.N, p.S, p.states, p.ldS, st));
         k_invert_perm<<<std::min(cdiv(p.N, 256), 1024), 256, 0, st>>>(a.type_nodes, p.N, p.inv);
         LAUNCH_OK();
+    } else if (p.big) {     // (composite_big_setup below: state_0 by position)
     } else if (a.state_dim > 0) HIP_OK(hipMemcpyAsync(p.states, a.state0, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
     else TRY(launch_copy2d(nullptr, a.nodes, a.ld_nodes, p.states, p.S, p.N, p.S, p.S, st));
     gnn::Seg segs[GNN_MAX_SEGS];
@@ -267,8 +506,15 @@ int train_step_composite(const gnn_train_args_t &ta) {
         LAUNCH_OK();
     }
 
+    // (gnn_last_kernel_name(): which orchestration took the step - tests and bench.py read it)
+    if (p.big) GNN_SET_KERNEL_NAME("train_step composite: row-streaming kernels on per-type position ranges (k_train_fwd_b6<ADD> / k_train_wgrad_b6<XT=%d>)", p.B.XT);
+    else if (p.small) GNN_SET_KERNEL_NAME("train_step composite: persistent small-graph kernels");
+    else GNN_SET_KERNEL_NAME("train_step composite: general kernels (one launch per layer, type and iteration)");
+    if (p.big) TRY(composite_big_setup(ta, p, st));
+
     // ---- training-mode forward: gated iterations; tape = states, neighbour sums, per-type statistics ---------------------------------
     TRY(launch_converge(nullptr, p.states, nullptr, p.N, p.S, p.ldS, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
+    if (p.big) TRY(composite_big_forward(ta, p, st));
     gnn::TileTab tiles;
     gnn::TypeTab yt;
     memset(&tiles, 0, sizeof(tiles)); memset(&yt, 0, sizeof(yt));
@@ -314,7 +560,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
             default: TRY(launch_train_small_fwd_sq<4>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st, &yt)); break;
         }
     }
-    for (int t = 0; t < p.K && !p.small; ++t) {
+    for (int t = 0; t < p.K && !p.small && !p.big; ++t) {
         const int *gate = p.flags + t;
         const float *s_t = p.states + (size_t)t * NS;
         float *s_n = p.states + (size_t)(t + 1) * NS;
@@ -353,7 +599,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
     *ta.k_host = k;
     if (k_f2[1] != 0.0f) return fail("a workgroup of the persistent training kernel never arrived at a grid barrier (not resident?)");
     if (k < 0 || k > p.K) return fail("iteration count %d out of range", k);
-    if (p.small) TRY(scatter_rows(p.states + (size_t)k * NS, p.ldS, a.type_nodes, p.N, p.S, ta.state, p.S, st));      // positions -> the caller's node order
+    if (p.small || p.big) TRY(scatter_rows(p.states + (size_t)k * NS, p.ldS, a.type_nodes, p.N, p.S, ta.state, p.S, st));      // positions -> the caller's node order
     else HIP_OK(hipMemcpyAsync(ta.state, p.states + (size_t)k * NS, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
     const float *state_k = ta.state;                                   // [N, S] in the caller's node order
     // The moving averages of BatchNormalization (one update per executed call).  On the persistent path they wait until the backward
@@ -451,7 +697,8 @@ int train_step_composite(const gnn_train_args_t &ta) {
             }
         }
     }
-    for (int t = k - 1; t >= 0 && !p.small; --t) {
+    if (p.big) TRY(composite_big_backward(ta, p, k, st));
+    for (int t = k - 1; t >= 0 && !p.small && !p.big; --t) {
         const float *s_t = p.states + (size_t)t * NS;
         const float *s_n = p.states + (size_t)(t + 1) * NS;
         float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);

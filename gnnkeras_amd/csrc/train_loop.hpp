@@ -869,6 +869,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
     const bool bn_s = ns.has_bn != 0, bn_o = no.has_bn != 0;
     const bool fold_s = ns.units[0] <= 4;       // see the forward loop
     hipStream_t st = (hipStream_t)a.stream;
+    GNN_SET_KERNEL_NAME(p.big ? "train_step: row-streaming kernels (kernels_train_big.hpp)" : p.small ? "train_step: persistent small-graph kernels" : "train_step: general kernels");
     const size_t NS = (size_t)p.N * p.ldS;             // one state matrix of the tape (rows of ldS floats: padded on the persistent small-graph path)
 
     // ---- setup: transposes, aggregates of the constants, state_0, iteration-invariant statistics -----------------------------------

@@ -235,9 +235,11 @@ def adam_update(p, g, m, v, step, lr=0.001, b1=0.9, b2=0.999, eps=1e-7):
 
 def composite_train_step(nodes, arcs, dim_node_label, type_mask, composite_adjacencies, adjacency, arcnode, nodegraph, mask,
                          *, net_state, net_output, state_vect_dim, max_iteration, state_threshold, focus, state0, y,
-                         sample_weight, loss, average_st_grads=False, dtype=torch.float64):
+                         sample_weight, loss, average_st_grads=False, dtype=torch.float64, checkpoint_iterations=False):
     """CompositeGNNnodeBased.train_step (GNN/Models/CompositeGNN.py:275-304) with torch autograd: one state network per
-    node type applied to the boolean-masked rows, scattered back and summed (CompositeGNN.py:223-232)."""
+    node type applied to the boolean-masked rows, scattered back and summed (CompositeGNN.py:223-232).
+    `checkpoint_iterations`: keep only the states between iterations and recompute each iteration (its T concatenations, their normalised
+    copies, the pre-activations) in the backward pass - the same float64 operations in the same order (large graphs: see _checkpointed)."""
     nets = [Net(*n, dtype=dtype) for n in net_state]
     no = Net(*net_output, dtype=dtype)
     X = torch.tensor(np.asarray(nodes), dtype=dtype)
@@ -251,11 +253,8 @@ def composite_train_step(nodes, arcs, dim_node_label, type_mask, composite_adjac
     state = torch.tensor(np.asarray(state0), dtype=dtype) if state_vect_dim > 0 else X.clone()
     state_old = torch.ones_like(state)
     k = 0
-    while True:
-        dist = torch.sqrt(torch.sum(torch.square(state - state_old), dim=1))
-        norm = torch.sqrt(torch.sum(torch.square(state_old), dim=1))
-        if not (bool(torch.any(dist > state_threshold * norm)) and k < max_iteration):
-            break
+
+    def iteration(state):
         agg = torch.sparse.mm(At, state)
         new = torch.zeros_like(state)
         for dt, m_, net in zip(dims, tm, nets):
@@ -264,7 +263,34 @@ def composite_train_step(nodes, arcs, dim_node_label, type_mask, composite_adjac
             full = torch.zeros_like(state)
             full[m_] = net(inp)
             new = new + full
-        state, state_old, k = new, state, k + 1
+        return new
+
+    def checkpointed_iteration(state):
+        from torch.utils.checkpoint import checkpoint
+        first = [True]
+        def fn(s_):
+            calls0 = [n.calls for n in nets]
+            if not first[0]:
+                for n in nets: n._recompute = True
+            try:
+                out = iteration(s_)
+                if not first[0]:
+                    for n, c0 in zip(nets, calls0): n.calls = c0          # (the recomputation is the same call, not a new one)
+                return out
+            finally:
+                first[0] = False
+                for n in nets: n._recompute = False
+        return checkpoint(fn, state, use_reentrant=False)
+
+    if checkpoint_iterations and not state.requires_grad: state = state.clone().requires_grad_()      # (checkpoint wants a differentiable input)
+    while True:
+        with torch.no_grad():
+            dist = torch.sqrt(torch.sum(torch.square(state - state_old), dim=1))
+            norm = torch.sqrt(torch.sum(torch.square(state_old), dim=1))
+            go_on = bool(torch.any(dist > state_threshold * norm)) and k < max_iteration
+        if not go_on:
+            break
+        state, state_old, k = (checkpointed_iteration(state) if checkpoint_iterations else iteration(state)), state.detach(), k + 1
     mask = torch.from_numpy(np.asarray(mask, dtype=bool))
     if focus == 'a':
         idx = torch.from_numpy(np.asarray(adjacency[0]).reshape(-1, 2).astype(np.int64))

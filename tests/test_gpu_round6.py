@@ -1,0 +1,132 @@
+"""Round 6: heterogeneous (composite) models on the large-graph training kernels (csrc/train_composite_big.hpp; VERDICT r5 item 1:
+reference GNN/Models/CompositeGNN.py:275-304 over the loop of :215-234) - at sizes between the small-graph kernels and BASELINE C5, and at
+C5's own size (500 k nodes / 5 M arcs, 3 node types, d = 64, 10 iterations, BatchNormalization: bench.py's `training.c5_d64_k10`),
+against torch autograd in float64 with the per-tensor bars of tests/test_gpu_training.py (`BARS` + counted kinks)."""
+import numpy as np
+import pytest
+import torch
+
+from gnnkeras_amd import _native as nat
+from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased, CompositeGNNgraphBased
+from gnnkeras_amd.Models.training import LoopTrainer, SGD
+from gnnkeras_amd.Sequencers.GraphSequencers import CompositeMultiGraphSequencer
+from gnnkeras_amd.synth import er_composite_graph
+from oracle import torch_train
+from oracle.harness import rel_err, _np, _triple
+
+pytestmark = pytest.mark.gpu
+
+
+def composite_oracle_step(model, x, y, sw, s0, loss='categorical_crossentropy', avg=False, checkpoint_iterations=False):
+    nodes, arcs, dnl, tmask, sm, om, cas, adj, an, ng = x
+    T = len(model.net_state)
+    mask = np.logical_and(_np(sm).reshape(-1), _np(om).reshape(-1))
+    return torch_train.composite_train_step(
+        _np(nodes), _np(arcs), _np(dnl).reshape(-1), _np(tmask).reshape(T, -1), [_triple(c) for c in cas], _triple(adj), _triple(an),
+        _triple(ng), mask, net_state=[n.spec() for n in model.net_state], net_output=model.net_output.spec(),
+        state_vect_dim=model.state_vect_dim, max_iteration=model.max_iteration, state_threshold=model.state_threshold, focus=model._focus,
+        state0=s0, y=_np(y), sample_weight=_np(sw), loss=loss, average_st_grads=avg, checkpoint_iterations=checkpoint_iterations)
+
+
+def composite_weights(model):
+    return [[w.copy() for w in n.get_weights()] for n in list(model.net_state) + [model.net_output]]
+
+
+def set_composite_weights(model, ws):
+    for n, w in zip(list(model.net_state) + [model.net_output], ws): n.set_weights([a.copy() for a in w])
+
+
+def composite_compare(model, x, y, sw, s0, want, native, loss='categorical_crossentropy', tag='', path=None, state_bar=1e-5):
+    """One train_step (apply=False) of a heterogeneous model against the float64 oracle's `want`: k, loss, training-mode predictions, the
+    final state, every gradient of every network per tensor (`BARS`, the kink allowance counted per network and its rows), the moving
+    statistics.  Returns (printable summary, rows)."""
+    from test_gpu_training import grad_rows, log_rows, Y_PRED_BAR
+    tr = LoopTrainer(model)
+    tr.use_native_step = native
+    res = tr.train_step(x, y, sw, state0=None if s0 is None else torch.from_numpy(s0).cuda(), apply=False)
+    torch.cuda.synchronize()
+    if native and path is not None:
+        name = nat.lib().gnn_last_kernel_name().decode()
+        assert path in name, name
+    assert res['k'] == want['k'], (res['k'], want['k'])
+    e_loss = abs(float(res['loss']) - want['loss']) / max(1.0, abs(want['loss']))
+    e_pred = rel_err(res['y_pred'].cpu().numpy(), want['y_pred'])
+    e_state = rel_err(res['state'].cpu().numpy(), want['state'])
+    tmask = _np(x[3]).reshape(len(model.net_state), -1)
+    rows = []
+    for t, (ng_, ref, kinks) in enumerate(zip(tr.gs, want['grads_state'], want['kinks_state'])):
+        scale = max(max(float(np.max(np.abs(t_))) for t_ in ref), 1e-30)
+        rows += grad_rows(f'state{t}', ng_.gradients(), ref, ng_.bn, kinks, scale, int(tmask[t].sum()))
+    scale = max(float(np.max(np.abs(t_))) for t_ in want['grads_output'])
+    rows += grad_rows('output', tr.go.gradients(), want['grads_output'], tr.go.bn, want['kinks_output'], scale, int(want['y_pred'].shape[0]))
+    mv = [0.0]
+    for n, ref in zip(list(model.net_state) + [model.net_output], list(want['moving_state']) + [want['moving_output']]):
+        if n.batch_normalization:
+            w = n.get_weights()
+            mv += [rel_err(w[2], ref[0]), rel_err(w[3], ref[1])]
+    log_rows(tag, rows, native=bool(native), y_pred=e_pred, state=e_state, loss=e_loss, n_nodes=int(x[0].shape[0]), k=int(res['k']))
+    summary = (f"loss {e_loss:.1e}  y_pred {e_pred:.1e}  state {e_state:.1e}  moving {max(mv):.1e}  gradients (own / scale): "
+               + '  '.join(f"{r_['net']}.{r_['tensor']} {r_['err_own']:.1e}/{r_['err_scale']:.1e}" for r_ in rows))
+    assert e_loss <= 1e-5 and e_pred <= Y_PRED_BAR and e_state <= state_bar and max(mv) <= 1e-5, summary
+    bad = [r_ for r_ in rows if not r_['ok']]
+    assert not bad, (bad, summary)
+    return summary, rows
+
+
+def composite_nets(dims, A, T, focus, d, bn, act, rng0=0, scale=0.5, out_bn=None, gamma=(0.7, 1.3)):
+    """One [BatchNormalization +] Dense state network per node type and the output network; `bn` a bool or one bool per type.
+    `gamma`: range of the state networks' BatchNormalization scales (training-mode BatchNormalization makes the state map scale-free in the
+    Dense weights: only small gammas make it contract, which an early exit needs)."""
+    bns = [bn] * len(dims) if isinstance(bn, bool) else list(bn)
+    acts = [act] * len(dims) if isinstance(act, str) else list(act)
+    inp, lay = get_inout_dims('state', list(dims), A, T, focus, d)
+    ns = [MLP(i, lay, acts[t], 'lecun_normal', 'lecun_normal', rng=rng0 + t, batch_normalization=bns[t]) for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', list(dims), A, T, focus, d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=rng0 + 9, batch_normalization=bns[0] if out_bn is None else out_bn)
+    rng = np.random.default_rng(rng0 + 3)
+    for n in ns + [no]:
+        w = n.get_weights()
+        if n.batch_normalization:      # non-trivial gamma / beta so their gradients are exercised
+            lo, hi = gamma if n is not no else (0.7, 1.3)
+            w[0] = rng.uniform(lo, hi, w[0].shape).astype(np.float32); w[1] = rng.normal(0, 0.2, w[1].shape).astype(np.float32)
+        if n is not no: w = [a * scale if a.ndim == 2 else a for a in w]
+        n.set_weights(w)
+    return ns, no
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# between the small-graph kernels and C5: the same path (N >= GNN_TRAIN_BIG_MIN_NODES = 32 768) in seconds of oracle time
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d,dims,mode,bn,act,focus,thr', [
+    (64, (14, 8, 4), 'average', True, 'selu', 'n', 0.0),                    # C5's networks: constants lines of 43 / 37 / 33 columns (64-float lines)
+    (64, (14, 8, 4), 'composite_average', True, 'tanh', 'n', 0.0),         # per-arc weights in both walks
+    (32, (6, 4, 2), 'sum', (True, False, True), ('relu', 'tanh', 'selu'), 'n', 0.0),   # 32-float lines; a network without BatchNormalization, one activation per type
+    (32, (14, 8, 4), 'average', False, 'tanh', 'g', 0.0),                  # no BatchNormalization anywhere; pooled targets (the general head)
+    (64, (5, 0, 3), 'average', True, 'selu', 'n', -1.0),                   # a type without labels of its own; early exit
+])
+def test_composite_train_step_on_the_large_graph_kernels(d, dims, mode, bn, act, focus, thr):
+    """`gnn_train_step` with `composite` on 40 000 nodes / 300 000 arcs / 3 node types - above GNN_TRAIN_BIG_MIN_NODES, so the step runs in
+    position space on the row-streaming kernels (train_composite_big.hpp) - and the Python building-block orchestration, both against
+    torch autograd in float64: k, loss, predictions, final state, per-tensor gradients of every network, moving statistics."""
+    N, E, K = 40_000, 300_000, 4
+    g = er_composite_graph(N, E, dim_node_label=dims, aggregation_mode=mode, seed=77 + d, focus=focus)
+    x, y, sw = CompositeMultiGraphSequencer([g], focus, mode, 1, shuffle=False)[0]
+    ns, no = composite_nets(dims, 3, 2, focus, d, bn, act, scale=0.25 if mode == 'sum' else 0.5, gamma=(0.03, 0.08) if thr < 0 else (0.7, 1.3))
+    CC = CompositeGNNnodeBased if focus == 'n' else CompositeGNNgraphBased
+    rng = np.random.default_rng(5)
+    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    if thr < 0:       # a threshold at which the oracle stops after 1 .. 3 iterations
+        seen = {}
+        for thr in (0.4, 0.3, 0.6, 0.2, 0.8):
+            k = seen[thr] = composite_oracle_step(CC(ns, no, d, K, thr), x, y, sw, s0)['k']
+            if 0 < k < K: break
+        assert 0 < k < K, f'no threshold with an early exit found: {seen}'
+    model = CC(ns, no, d, K, thr)
+    model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+    want = composite_oracle_step(model, x, y, sw, s0)
+    w0 = composite_weights(model)
+    for native in (True, False):
+        set_composite_weights(model, w0)
+        summary, _ = composite_compare(model, x, y, sw, s0, want, native, tag=f'composite_big d={d} {mode}', path='row-streaming')
+        print(f"\n  {'gnn_train_step ' if native else 'building blocks'} k = {want['k']}  {summary}")

@@ -271,3 +271,32 @@ def test_train_step_oracle_with_checkpointed_iterations_is_the_same_oracle():
     with torch.no_grad(): net.b[0][0] -= z[0, 0]
     net(x0)
     assert net.kinks[0][0] >= 1
+
+
+def test_composite_train_step_oracle_with_checkpointed_iterations_is_the_same_oracle():
+    """`composite_train_step(checkpoint_iterations=True)` - what lets the float64 oracle of a C5-size heterogeneous train step
+    (tests/test_gpu_round6.py) fit a host - is bit for bit the plain run: loss, every network's gradients, one moving-average update per
+    call and network, the kink counts."""
+    from gnnkeras_amd.synth import er_composite_graph
+    from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+    from oracle import torch_train
+    N, d, dims = 900, 8, (5, 3, 2)
+    g = er_composite_graph(N, 5 * N, dim_node_label=dims, seed=5, aggregation_mode='average')
+    rng = np.random.default_rng(0)
+    inp, lay = get_inout_dims('state', list(dims), 3, 2, 'n', d)
+    ns = [MLP(i, lay, 'relu', 'lecun_normal', 'lecun_normal', rng=t, batch_normalization=True, device='cpu') for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', list(dims), 3, 2, 'n', d)
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9, batch_normalization=True, device='cpu')
+    trip = lambda m: (np.stack([m.tocoo().row, m.tocoo().col], 1), m.tocoo().data, m.shape)
+    s0 = np.abs(rng.normal(0, 0.1, (N, d))).astype(np.float32)
+    kw = dict(net_state=[n.spec() for n in ns], net_output=no.spec(), state_vect_dim=d, max_iteration=3, state_threshold=0.0, focus='n',
+              state0=s0, y=g.targets, sample_weight=None, loss='categorical_crossentropy')
+    args = (g.nodes, g.arcs, list(dims), g.type_mask.T, [trip(c) for c in g.CompositeAdjacencies], trip(g.Adjacency), trip(g.ArcNode), None,
+            np.ones(N, bool))
+    a = torch_train.composite_train_step(*args, **kw)
+    b = torch_train.composite_train_step(*args, checkpoint_iterations=True, **kw)
+    assert a['k'] == b['k'] == 3 and a['loss'] == b['loss']
+    flat = lambda r: [t for gs in r['grads_state'] for t in gs] + r['grads_output'] + [t for mv in r['moving_state'] for t in mv] + list(r['moving_output'])
+    for x_, y_ in zip(flat(a), flat(b)): assert np.array_equal(x_, y_)
+    for ka, kb in zip(a['kinks_state'], b['kinks_state']):
+        assert all(np.array_equal(p, q) for p, q in zip(ka, kb))

@@ -103,9 +103,8 @@ k_dense_grad_partial(const float *__restrict__ X, int ldx, const int *__restrict
 // 64 outputs per workgroup; the chunks are dealt to 4 thread rows in contiguous
 // quarters (each summed in chunk order, 8 loads in flight), and the quarters meet in LDS in order: a fixed summation
 // tree, bitwise reproducible.
-__global__ void __launch_bounds__(256)
-k_reduce_partials(const float *__restrict__ part, int n_chunks, int n, float *__restrict__ out, int accumulate, float scale,
-                  int n1, float *__restrict__ out2) {
+__device__ __forceinline__ void reduce_partials_body(const float *__restrict__ part, int n_chunks, int n, float *__restrict__ out, int accumulate, float scale,
+                                                     int n1, float *__restrict__ out2) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + tx;
@@ -129,6 +128,21 @@ k_reduce_partials(const float *__restrict__ part, int n_chunks, int n, float *__
         float *o = i < n1 ? out + i : out2 + (i - n1);
         if (i < n1 || out2) *o = accumulate ? *o + t : t;
     }
+}
+__global__ void __launch_bounds__(256)
+k_reduce_partials(const float *__restrict__ part, int n_chunks, int n, float *__restrict__ out, int accumulate, float scale,
+                  int n1, float *__restrict__ out2) {
+    reduce_partials_body(part, n_chunks, n, out, accumulate, scale, n1, out2);
+}
+// ... of every node type's weight-gradient partials in one launch (heterogeneous models, train_composite_big.hpp): blockIdx.y = the type
+struct ReduceT { const float *part; int n_chunks, n; float *out; int accumulate; float scale; int n1; float *out2; };
+struct ReduceTypes { ReduceT t[GNN_MAX_TYPES]; };
+__global__ void __launch_bounds__(256) k_reduce_partials_types(ReduceTypes m) {
+    ReduceT a = m.t[0];
+#pragma unroll
+    for (int t = 1; t < GNN_MAX_TYPES; ++t) if ((int)blockIdx.y == t) a = m.t[t];
+    if ((int)blockIdx.x * 64 >= a.n) return;
+    reduce_partials_body(a.part, a.n_chunks, a.n, a.out, a.accumulate, a.scale, a.n1, a.out2);
 }
 
 // Column statistics of a SMALL matrix (a merged MUTAG batch: ~1 k rows) in one launch: one workgroup per column, rows
@@ -231,11 +245,10 @@ k_bn_moving_update(const float *__restrict__ mean, const float *__restrict__ var
 // rows whenever the inputs have a mean of their own size (relu / sigmoid states): dW = a P_c + beta q, S2 - mean S1 = sum_h W P_c.
 // `n_chunks` > 1: P and q are still chunk partials ([chunk][K*H + H], the output of k_dense_grad_partial*): each value is
 // summed here in chunk order (small batches: saves the reduction launch); n_chunks <= 1: P [K x H] and q [H] are final.
-__global__ void __launch_bounds__(64)
-k_first_layer_param_grads(const float *__restrict__ P, const float *__restrict__ q, const float *__restrict__ W, int K,
+__device__ __forceinline__ void first_layer_param_grads_body(const float *__restrict__ P, const float *__restrict__ q, const float *__restrict__ W, int K,
                           int H, const float *gamma, const float *beta, const float *mean, const float *var, float eps,
                           float inv_m, float *__restrict__ dW, float *__restrict__ db, float *dgamma, float *dbeta,
-                          float *m1, float *m2, int accumulate, int n_chunks = 1, int centered = 0) {
+                          float *m1, float *m2, int accumulate, int n_chunks, int centered) {
     const int k = blockIdx.x, lane = threadIdx.x;
     const size_t cstride = (size_t)K * H + H;
     auto sum_chunks = [&](const float *base) -> float {         // 8 loads in flight, summed in chunk order
@@ -285,6 +298,27 @@ k_first_layer_param_grads(const float *__restrict__ P, const float *__restrict__
             if (m1) { m1[k] = S1 * inv_m; m2[k] = dg * inv_m; }
         }
     }
+}
+__global__ void __launch_bounds__(64)
+k_first_layer_param_grads(const float *__restrict__ P, const float *__restrict__ q, const float *__restrict__ W, int K,
+                          int H, const float *gamma, const float *beta, const float *mean, const float *var, float eps,
+                          float inv_m, float *__restrict__ dW, float *__restrict__ db, float *dgamma, float *dbeta,
+                          float *m1, float *m2, int accumulate, int n_chunks = 1, int centered = 0) {
+    first_layer_param_grads_body(P, q, W, K, H, gamma, beta, mean, var, eps, inv_m, dW, db, dgamma, dbeta, m1, m2, accumulate, n_chunks, centered);
+}
+// ... of every node type's state network in one launch (heterogeneous models): blockIdx.y = the type, grid.x = the widest network's K
+struct ParamGradsT {
+    const float *P, *q, *W; int K, H; const float *gamma, *beta, *mean, *var; float eps, inv_m;
+    float *dW, *db, *dgamma, *dbeta, *m1, *m2; int accumulate, n_chunks, centered;
+};
+struct ParamGradsTypes { ParamGradsT t[GNN_MAX_TYPES]; };
+__global__ void __launch_bounds__(64) k_first_layer_param_grads_types(ParamGradsTypes m) {
+    ParamGradsT a = m.t[0];
+#pragma unroll
+    for (int t = 1; t < GNN_MAX_TYPES; ++t) if ((int)blockIdx.y == t) a = m.t[t];
+    if ((int)blockIdx.x >= a.K) return;       // (K = 0: a type without rows)
+    first_layer_param_grads_body(a.P, a.q, a.W, a.K, a.H, a.gamma, a.beta, a.mean, a.var, a.eps, a.inv_m, a.dW, a.db, a.dgamma, a.dbeta, a.m1, a.m2,
+                                 a.accumulate, a.n_chunks, a.centered);
 }
 
 // Input gradient through a training-mode BatchNormalization for the column block [k0, k0+width):

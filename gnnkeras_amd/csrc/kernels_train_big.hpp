@@ -121,10 +121,8 @@ k_rows_stats(const int *gate, int M, const float *__restrict__ X, int ld, float 
 // per column: thread i sums partials i, i + 256, .. in order, then a fixed LDS tree - deterministic.  (One-pass moments: the columns
 // are activations / their neighbour averages, |mean| and sigma of the same order, the tail in double; BatchNormalization adds
 // eps = 1e-3 to the variance before the square root.)
-__global__ void __launch_bounds__(256)
-k_stats_finish(const int *gate, const float *__restrict__ part, int n_part, int F, float inv_m, float *__restrict__ mean, float *__restrict__ var,
-               const float *__restrict__ shift) {      // shift[c]: what the producer subtracted from column c (NULL: nothing)
-    if (gate_closed(gate)) return;
+__device__ __forceinline__ void stats_finish_body(const float *__restrict__ part, int n_part, int F, float inv_m, float *__restrict__ mean, float *__restrict__ var,
+                                                  const float *__restrict__ shift) {
     __shared__ double sh[2][256];
     const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
@@ -141,9 +139,43 @@ k_stats_finish(const int *gate, const float *__restrict__ part, int n_part, int 
         var[c] = (float)fmax(sh[1][0] * (double)inv_m - mu * mu, 0.0);
     }
 }
+__global__ void __launch_bounds__(256)
+k_stats_finish(const int *gate, const float *__restrict__ part, int n_part, int F, float inv_m, float *__restrict__ mean, float *__restrict__ var,
+               const float *__restrict__ shift) {      // shift[c]: what the producer subtracted from column c (NULL: nothing)
+    if (gate_closed(gate)) return;
+    stats_finish_body(part, n_part, F, inv_m, mean, var, shift);
+}
+// ... of up to 2 statistics per node type in one launch (heterogeneous models, train_composite_big.hpp): blockIdx.y = the job
+struct StatsFinishT { const float *part; int n_part; float inv_m; float *mean, *var; const float *shift; };
+struct StatsFinishJobs { StatsFinishT t[2 * GNN_MAX_TYPES]; };
+__global__ void __launch_bounds__(256) k_stats_finish_jobs(const int *gate, StatsFinishJobs m, int F) {
+    if (gate_closed(gate)) return;
+    StatsFinishT a = m.t[0];
+#pragma unroll
+    for (int t = 1; t < 2 * GNN_MAX_TYPES; ++t) if ((int)blockIdx.y == t) a = m.t[t];
+    if (!a.part) return;
+    stats_finish_body(a.part, a.n_part, F, a.inv_m, a.mean, a.var, a.shift);
+}
 
 // ---- forward: first Dense of the state network in training mode ----------------------------------------------------------------------
 struct ConstCols { int width[3], wrow[3], n; };       // constant input columns of xc: segment s covers `width[s]` columns, weight rows wrow[s]..
+
+// Heterogeneous models (train_composite_big.hpp): ONE launch of a row-streaming kernel for the rows of every node type - the workgroups
+// [blk_begin[t], blk_begin[t + 1]) run the kernel's body on type t's arguments (its row range, weights, statistics, partials) as workgroups
+// 0 .. of a launch of their own.  A third of the launches, and a workgroup's set-up (weights into LDS, the epilogue's exchange) is paid for
+// three times the rows.  Static selection (a runtime-indexed kernel-argument array would be copied to scratch memory).
+template <typename A> struct TypeLaunch { A t[GNN_MAX_TYPES]; int blk_begin[GNN_MAX_TYPES + 1]; int n; };
+template <typename A> __device__ __forceinline__ A select_type(const TypeLaunch<A> &m, int &bid, int &nblk) {
+    int ty = 0;
+#pragma unroll
+    for (int t = 1; t < GNN_MAX_TYPES; ++t) if (t < m.n && (int)blockIdx.x >= m.blk_begin[t]) ty = t;
+    A a = m.t[0];
+    int b0 = m.blk_begin[0], b1 = m.blk_begin[1];
+#pragma unroll
+    for (int t = 1; t < GNN_MAX_TYPES; ++t) if (ty == t) { a = m.t[t]; b0 = m.blk_begin[t]; b1 = m.blk_begin[t + 1]; }
+    bid = (int)blockIdx.x - b0; nblk = b1 - b0;
+    return a;
+}
 
 struct TrainFwdArgs {
     const int *gate;
@@ -500,8 +532,8 @@ __device__ __forceinline__ f32x4 mfma_b6_16(const u32x4 &wh, const u32x4 &wm, co
 // kernels above).  Here a trip is: wait for the tile's rows (requested a whole trip ago) -> split ALL of them to bf16 (60 registers)
 // and keep the state chunks for the predicate -> request the next tile's rows -> store the PREVIOUS tile's output (its activated values
 // waited in 16 registers) -> products -> activation, statistics, predicate.  Nothing the next wait covers is younger than most of a trip.
-template <int SQ, int ACT, bool ADD = false>
-__global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(TrainFwdArgs a) {
+template <int SQ, int ACT, bool ADD>
+__device__ __forceinline__ void train_fwd_b6_body(const TrainFwdArgs &a, const int bid, const int nblk) {
     TB_MARK(0); TB_BLOCK_TIME(0);
     if (gate_closed(a.gate)) return;
     constexpr int XQ = ADD ? 0 : 2;                     // 16-column chunks of the constants line (ADD: none - TrainFwdArgs::addend stands in for their product)
@@ -592,16 +624,16 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
             for (int q = 0; q < XQ; ++q) A[2 * SQ + q] = buf_ld_f32x4_aux<TB_STREAM_AUX>(r_x, b_x + 64u * q);
         }
     };
-    const int t_step = gridDim.x * TB_WAVES;
+    const int t_step = nblk * TB_WAVES;
     int trip_ = 0; (void)trip_;
-    fetch(blockIdx.x * TB_WAVES + wave);
+    fetch(bid * TB_WAVES + wave);
     const u32x4 *Wv = reinterpret_cast<const u32x4 *>(Wl) + lane;
     f32x4 vP[NCT];                                      // the previous tile's output, stored one trip late
     int offP = 0; bool inP = false;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) vP[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int t = blockIdx.x * TB_WAVES + wave; t < n_tiles; t += t_step) {
+    for (int t = bid * TB_WAVES + wave; t < n_tiles; t += t_step) {
         const int row = 16 * t + c;
         const bool in = row < a.M;
         TB_STAMP(0);
@@ -697,13 +729,22 @@ __global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(Tra
     if (a.stat_part && tid < 2 * HP) {
         float tsum = 0.0f;
         for (int w_ = 0; w_ < TB_WAVES; ++w_) tsum += red[w_ * 2 * HP + tid];
-        a.stat_part[(size_t)blockIdx.x * 2 * HP + tid] = tsum;
+        a.stat_part[(size_t)bid * 2 * HP + tid] = tsum;
     }
     TB_MARK(3); TB_BLOCK_TIME(1);
     if (a.pred_flag && tid == 0) {
         if (any_s) atomicOr(a.pred_flag, 1);
-        if (blockIdx.x == 0 && a.pred_k) *a.pred_k = a.pred_kval;
+        if (bid == 0 && a.pred_k) *a.pred_k = a.pred_kval;
     }
+}
+
+template <int SQ, int ACT, bool ADD = false>
+__global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6(TrainFwdArgs a) { train_fwd_b6_body<SQ, ACT, ADD>(a, blockIdx.x, gridDim.x); }
+template <int SQ, int ACT, bool ADD>         // every node type's rows in one launch (TypeLaunch)
+__global__ void __launch_bounds__(64 * TB_WAVES, TB_B6_WAVES) k_train_fwd_b6_types(TypeLaunch<TrainFwdArgs> m) {
+    int bid, nblk;
+    const TrainFwdArgs a = select_type(m, bid, nblk);
+    train_fwd_b6_body<SQ, ACT, ADD>(a, bid, nblk);
 }
 
 template <int SQ, bool ADD = false>
@@ -847,7 +888,7 @@ template <int ACT> __device__ __forceinline__ float activate_grad1(float y) {   
 // wave keeps 16 KB requested for a whole trip.  `a.Y == NULL` (dZ already formed): instantiate with ACT = LINEAR - the loads of Y then
 // fall out of range and return zeros, act'(0) = 1; no BatchNormalization: the x loads fall out of range the same way (Cc = m1 = mean = 0).
 template <int HQ, int ACT>
-__global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
+__device__ __forceinline__ void train_bwd_dx_b6_body(const TrainBwdArgs &a, const int bid, const int nblk) {
     constexpr int NCT = 2 * HQ, HP = 16 * NCT, SQ = HQ, NKB = (HQ + 1) / 2, NW = 4;
     constexpr int PLANE = NKB * NCT * 64 * 8;
     extern __shared__ __attribute__((aligned(16))) float tb_smem[];
@@ -891,7 +932,7 @@ __global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
     const __amdgpu_buffer_rsrc_t r_z = buf_rsrc(a.dZ), r_y = buf_rsrc(a.Y), r_s = buf_rsrc((a.gamma && !a.defer_state_bn) ? a.state : nullptr), r_a = buf_rsrc(a.gamma ? a.agg : nullptr),
                                  r_o = buf_rsrc(a.dx), r_rs = buf_rsrc(a.agg_row_scale);
     const int n_tiles = (a.M + 15) >> 4;
-    const int t_step = gridDim.x * NW;
+    const int t_step = nblk * NW;
     f32x4 A[HQ], Yv[HQ], X[NCT];
     float rs;
     auto off_row = [&](int t, bool &in_) { const int row_ = 16 * t + c; in_ = t < n_tiles && row_ < a.M; return (unsigned)row_; };
@@ -910,7 +951,7 @@ __global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
     };
     auto fetch_rs = [&](int t) { bool in_; const unsigned r = off_row(t, in_); rs = buf_ld_f32(r_rs, in_ ? r * 4u : BUF_OFF); };
     {
-        const int t0 = blockIdx.x * NW + wave;
+        const int t0 = bid * NW + wave;
         fetch_zy(t0); fetch_rs(t0);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) fetch_x(t0, ct);
@@ -918,7 +959,7 @@ __global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
     const u32x4 *Wv = reinterpret_cast<const u32x4 *>(Wl) + lane;
     const bool has_rs = a.agg_row_scale != nullptr;
 #pragma unroll 1
-    for (int t = blockIdx.x * NW + wave; t < n_tiles; t += t_step) {
+    for (int t = bid * NW + wave; t < n_tiles; t += t_step) {
         const int row = 16 * t + c;
         const bool in = row < a.M;
         u32x4 xh[NKB], xm[NKB], xl[NKB];
@@ -975,6 +1016,15 @@ __global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) {
             fetch_x(t + t_step, ct);
         }
     }
+}
+
+template <int HQ, int ACT>
+__global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6(TrainBwdArgs a) { train_bwd_dx_b6_body<HQ, ACT>(a, blockIdx.x, gridDim.x); }
+template <int HQ, int ACT>                   // every node type's rows in one launch (TypeLaunch)
+__global__ void __launch_bounds__(256, 2) k_train_bwd_dx_b6_types(TypeLaunch<TrainBwdArgs> m) {
+    int bid, nblk;
+    const TrainBwdArgs a = select_type(m, bid, nblk);
+    train_bwd_dx_b6_body<HQ, ACT>(a, bid, nblk);
 }
 
 template <int HQ>
@@ -1117,7 +1167,7 @@ __global__ void __launch_bounds__(256, 2) k_train_wgrad(TrainWgradArgs a) {
 // The 32x32 tiles of a workgroup's four waves -> its partial P (LDS, waves in order) -> a.part, by weight row (shared by the f32 and the
 // bf16-split forms of the kernel: v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_bf16 leave their results in the same registers).
 template <int NB, int XT = 1>                 // XT: 32-column tiles of the constants line (1: the 128-byte line; 2: 256 bytes, k_train_wgrad_b6<.., XT = 2>)
-__device__ __forceinline__ void wgrad32_store(const TrainWgradArgs &a, f32x16 (&acc)[2 * NB + XT][NB], float *Ps) {
+__device__ __forceinline__ void wgrad32_store(const TrainWgradArgs &a, f32x16 (&acc)[2 * NB + XT][NB], float *Ps, const int bid) {
     constexpr int S = 32 * NB, RT = 2 * NB + XT, KV = 2 * S + 32 * XT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kk = lane >> 5;
@@ -1139,7 +1189,7 @@ __device__ __forceinline__ void wgrad32_store(const TrainWgradArgs &a, f32x16 (&
         }
         __syncthreads();
     }
-    float *Pp = a.part + (size_t)blockIdx.x * ((size_t)a.K * S + S);
+    float *Pp = a.part + (size_t)bid * ((size_t)a.K * S + S);
     for (int idx = tid; idx < KV * S; idx += 256) {
         const int kv = idx / S, h = idx % S;
         int wrow = -1;
@@ -1219,7 +1269,7 @@ __global__ void __launch_bounds__(256, TB_WG32_WAVES) k_train_wgrad32(TrainWgrad
             }
         }
     }
-    wgrad32_store<NB>(a, acc, Ps);
+    wgrad32_store<NB>(a, acc, Ps, blockIdx.x);
 }
 
 template <int J0, int J1, typename F> __device__ __forceinline__ void static_for(F &&f) {       // f(integral_constant<int, J0>) ... : loop indices that are constant expressions
@@ -1254,8 +1304,8 @@ template <int OFF> __device__ __forceinline__ void lds_read_f32(float &v, unsign
 // hand (s_waitcnt vmcnt(NG): every step issues exactly NG loads, past the end of the workgroup's rows too - those touch no memory and
 // fill zeros), the LDS reads are inline assembly so that hipcc does not drain the ring in front of them.
 // 160 accumulator registers: one wave per SIMD, one workgroup per CU.
-template <int NB, int ACT, int XT = 1>       // XT = 2: a constants line of 64 floats (k_pack_xc_pos<64>: 32 .. 63 constant inputs - heterogeneous models)
-__global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
+template <int NB, int ACT, int XT>           // XT = 2: a constants line of 64 floats (k_pack_xc_pos<64>: 32 .. 63 constant inputs - heterogeneous models)
+__device__ __forceinline__ void train_wgrad_b6_body(const TrainWgradArgs &a, const int bid) {
     constexpr int S = 32 * NB, RT = 2 * NB + XT;
     constexpr bool HAS_Y = ACT != GNN_ACT_LINEAR;
     constexpr int ARR = 16 * S * 4, NA = HAS_Y ? 4 : 3;        // bytes of 16 rows of an [M, S] array; arrays in a slot: dZ | state | agg | (Y)
@@ -1267,7 +1317,7 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tb_smem[];     // [4 waves][D slots | XR line slots]; the workgroup's partial P afterwards
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (uniform: the ring's addresses stay in scalar registers)
     const int i = lane & 31, kg = lane >> 5;
-    const int m_beg = blockIdx.x * a.rows_per_wg, m_end = min(a.M, m_beg + a.rows_per_wg);
+    const int m_beg = bid * a.rows_per_wg, m_end = min(a.M, m_beg + a.rows_per_wg);
     const int rows = max(m_end - m_beg, 0);
     const int n_steps = (rows + 63) >> 6;               // a workgroup step = 64 rows: 16 per wave
     // windows of exactly this workgroup's rows: what lies past them reads 0
@@ -1382,7 +1432,15 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) {
 #undef B8
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the fills past the end)
     __syncthreads();                                        // every wave is done with its ring: the partial P takes its place
-    wgrad32_store<NB, XT>(a, acc, tb_smem);
+    wgrad32_store<NB, XT>(a, acc, tb_smem, bid);
+}
+template <int NB, int ACT, int XT = 1>
+__global__ void __launch_bounds__(256, 1) k_train_wgrad_b6(TrainWgradArgs a) { train_wgrad_b6_body<NB, ACT, XT>(a, blockIdx.x); }
+template <int NB, int ACT, int XT>           // every node type's rows in one launch (TypeLaunch; the partials of type t: its own `part`)
+__global__ void __launch_bounds__(256, 1) k_train_wgrad_b6_types(TypeLaunch<TrainWgradArgs> m) {
+    int bid, nblk;
+    const TrainWgradArgs a = select_type(m, bid, nblk);
+    train_wgrad_b6_body<NB, ACT, XT>(a, bid);
 }
 template <int NB, int ACT, int XT = 1>
 inline size_t train_wgrad_b6_lds() {
@@ -1620,7 +1678,7 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad_dx_b6(TrainWgradArgs a, 
 #undef B8
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    wgrad32_store<NB>(a, acc, tb_smem + (W_B + COEF_B) / 4);
+    wgrad32_store<NB>(a, acc, tb_smem + (W_B + COEF_B) / 4, blockIdx.x);
 }
 template <int NB>
 inline size_t train_wgrad_dx_b6_lds() {

@@ -44,6 +44,7 @@ struct CPlan {
     int *inv; float *sm_cc, *sm_part, *sm_dxa, *sm_partW[GNN_MAX_TYPES], *sm_partBN[GNN_MAX_TYPES]; unsigned long long *sm_bar;
     // large graphs (train_composite_big.hpp): the tape's rows are POSITIONS too, every type a contiguous range of them
     bool big; CBig B;
+    bool head_fast; float *part_h;       // large graphs: a thin output head over EVERY node on the row-streaming head kernels (k_head_wgrad / k_head_dx)
     size_t bytes;
 };
 
@@ -168,6 +169,9 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
         p.sm_partW[t] = c.take<float>(p.small ? (size_t)tiles_t * ((size_t)y.in_dim * p.S + p.S) : 0);
         p.sm_partBN[t] = c.take<float>(p.small ? (size_t)tiles_t * 2 * y.in_dim : 0);
     }
+    // every node is an output row (out_index the identity: checked on the device, read with k), one thin Dense over the state alone
+    p.head_fast = p.big && no.n_layers == 1 && no.units[0] <= 4 && p.M == p.N && p.S % 4 == 0 && p.S / 4 <= 32;
+    p.part_h = c.take<float>(p.head_fast ? (size_t)BIG_HEAD_BLOCKS * ((size_t)no.in_dim * no.units[0] + no.units[0]) : 0);
     p.inv = c.take<int>((p.small || p.big) ? p.N : 0);
     if (p.big) {
         CBig &B = p.B;
@@ -184,11 +188,23 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
         B.xc = c.take<float>((size_t)p.N * B.XW);
         B.Cc = c.take<float>((size_t)p.N * p.S);
         B.Gpos = c.take<float>((size_t)p.N * p.S);
-        B.part_a = c.take<float>((size_t)BIG_AGG_BLOCKS * 2 * p.S);
-        B.part_y = c.take<float>((size_t)BIG_FWD_BLOCKS * 2 * std::max(p.S, 32));
-        int max_in = 1;
-        for (int t = 0; t < p.n_types; ++t) max_in = std::max(max_in, p.ty[t].in_dim);
-        B.part_w = c.take<float>((size_t)BIG_WGRAD_BLOCKS * ((size_t)max_in * p.S + p.S));
+        int counts[GNN_MAX_TYPES];
+        for (int t = 0; t < p.n_types; ++t) counts[t] = p.ty[t].count;
+        split_blocks(std::min(device_cus(), BIG_FWD_BLOCKS), counts, p.n_types, B.fwd_blocks);          // one 8-wave workgroup per CU
+        split_blocks(2 * device_cus(), counts, p.n_types, B.bwd_blocks);                                // 256-thread workgroups, two per CU
+        split_blocks(std::min(device_cus(), BIG_WGRAD_BLOCKS), counts, p.n_types, B.wgrad_blocks);      // one workgroup per CU (LDS ring)
+        B.one_act = true; B.act = -1;
+        for (int t = 0; t < p.n_types; ++t) {
+            const CType &y = p.ty[t];
+            if (y.count > 0) { if (B.act < 0) B.act = y.m->activation[0]; else if (B.act != y.m->activation[0]) B.one_act = false; }
+            B.fwd_blocks[t] = std::min(B.fwd_blocks[t], std::max(1, cdiv(cdiv(std::max(y.count, 1), 16), gnn::TB_WAVES)));
+            B.bwd_blocks[t] = std::min(B.bwd_blocks[t], std::max(1, cdiv(cdiv(std::max(y.count, 1), 16), 4)));
+            B.wgrad_blocks[t] = std::min(B.wgrad_blocks[t], std::max(1, cdiv(std::max(y.count, 1), 64)));
+            if (y.count == 0) B.fwd_blocks[t] = B.bwd_blocks[t] = B.wgrad_blocks[t] = 0;
+            B.part_a[t] = c.take<float>((size_t)BIG_AGG_BLOCKS * 2 * p.S);
+            B.part_y[t] = c.take<float>((size_t)std::max(BIG_FWD_BLOCKS, 1) * 2 * std::max(p.S, B.XW));
+            B.part_w[t] = c.take<float>((size_t)std::max(B.wgrad_blocks[t], 1) * ((size_t)y.in_dim * p.S + p.S));
+        }
         for (int t = 0; t < p.n_types; ++t) {         // the constants line of type t: [labels[:, :d_t] | aggregated_component | 1 | 0 ..]
             const CType &y = p.ty[t];
             gnn::ConstCols &cc = B.cc[t];
@@ -261,20 +277,46 @@ int composite_big_setup(const gnn_train_args_t &ta, CPlan &p, hipStream_t st) {
             ps.ptr[ps.n] = p.agg_comp; ps.ld[ps.n] = p.W_comp; ps.width[ps.n] = p.W_comp; ps.wrow[ps.n] = y.off_comp; ++ps.n;
             cs.ptr[cs.n] = p.agg_comp; cs.ld[cs.n] = p.W_comp; cs.width[cs.n] = p.W_comp; cs.wrow[cs.n] = y.off_comp; ++cs.n;
         }
+        float *line = B.xc + (size_t)off * B.XW;
         const int grid = (int)std::min<long>(cdiv((long)y.count * B.XW, 256), 256 * 16);
-        if (B.XT == 2) k_pack_xc_pos<64><<<grid, 256, 0, st>>>(y.count, y.rows, ps, B.xc + (size_t)off * B.XW);
-        else k_pack_xc_pos<32><<<grid, 256, 0, st>>>(y.count, y.rows, ps, B.xc + (size_t)off * B.XW);
+        if (B.XT == 2) k_pack_xc_pos<64><<<grid, 256, 0, st>>>(y.count, y.rows, ps, line);
+        else k_pack_xc_pos<32><<<grid, 256, 0, st>>>(y.count, y.rows, ps, line);
         LAUNCH_OK();
-        // Cc = b + sum over the constant columns of (a (x - mean) + beta) W   (their statistics: y.stats_tpl, taken over the type's rows)
-        gnn::k_train_small_const<<<cdiv((long)y.count * p.S, 256), 256, 0, st>>>(y.count, p.S, p.S, cs, y.m->kernel[0], y.m->bias[0], y.m->has_bn ? y.m->bn_gamma : nullptr,
-                                                                                  y.m->bn_beta, y.stats_tpl, y.stats_tpl + y.in_dim, y.m->bn_eps,
-                                                                                  B.Cc + (size_t)off * p.S, y.rows);
-        LAUNCH_OK();
+        if (y.m->has_bn) {
+            // the batch statistics of the constant columns (the same in every iteration): one pass over the packed line, moments around its
+            // row 0; each segment's columns land at its BatchNorm columns of the template, which every iteration's slot starts from
+            HIP_OK(hipMemsetAsync(y.stats_tpl, 0, sizeof(float) * 2 * y.in_dim, st));
+            int sgrid = 0;
+            TRY(rows_stats(nullptr, line, B.XW, B.XW, y.count, B.part_y[q], st, &sgrid));
+            int c0 = 0;
+            for (int sg = 0; sg < ps.n; ++sg) {
+                gnn::k_stats_finish<<<ps.width[sg], 256, 0, st>>>(nullptr, B.part_y[q] + c0, sgrid, B.XW, 1.0f / (float)y.count, y.stats_tpl + ps.wrow[sg],
+                                                                 y.stats_tpl + y.in_dim + ps.wrow[sg], line + c0);
+                LAUNCH_OK();
+                c0 += ps.width[sg];
+            }
+            gnn::k_replicate<<<std::min(cdiv((long)2 * y.in_dim * p.K, 256), 1024), 256, 0, st>>>(y.stats_tpl, 2 * y.in_dim, p.K, y.stats);
+            LAUNCH_OK();
+        }
+        // Cc = b + sum over the constant columns of (a (x - mean) + beta) W: the first layer over the line's segments alone, BatchNormalization
+        // applied as the columns are staged (the mean leaves the value first)
+        gnn::SegDenseArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.M = y.count; sa.H = p.S;
+        int c0 = 0;
+        for (int sg = 0; sg < ps.n; ++sg) { sa.seg[sa.nseg++] = gnn::Seg{line + c0, nullptr, B.XW, ps.width[sg], ps.wrow[sg]}; c0 += ps.width[sg]; }
+        sa.W = y.m->kernel[0]; sa.ldw = p.S; sa.bias = y.m->bias[0]; sa.act = GNN_ACT_LINEAR;
+        sa.Y = B.Cc + (size_t)off * p.S; sa.ldy = p.S;
+        if (y.m->has_bn) { sa.in_gamma = y.m->bn_gamma; sa.in_beta = y.m->bn_beta; sa.in_mean = y.stats_tpl; sa.in_var = y.stats_tpl + y.in_dim; sa.in_eps = y.m->bn_eps; }
+        if (sa.nseg > 0) TRY(launch_segdense(sa, st));
+        else TRY(launch_copy2d(nullptr, y.m->bias[0], 0, sa.Y, p.S, y.count, p.S, p.S, st));      // (no constant inputs at all: the bias row)
     }
     return 0;
 }
 
-// the K gated training-mode iterations (CompositeGNN.py:215-234), every type's rows by its own network
+// the K gated training-mode iterations (CompositeGNN.py:215-234), every type's rows by its own network.  Per iteration: one neighbour sum
+// (+ column statistics) per type, then ONE launch each for the statistics' finish, the folds, the first layers of all types (when they share
+// the activation: the kernel is compiled per activation) and the new rows' statistics.
 int composite_big_forward(const gnn_train_args_t &ta, CPlan &p, hipStream_t st) {
     const gnn_loop_args_t &a = ta.loop;
     CBig &B = p.B;
@@ -284,42 +326,55 @@ int composite_big_forward(const gnn_train_args_t &ta, CPlan &p, hipStream_t st) 
         const float *s_t = p.states + (size_t)t * NS;
         float *s_n = p.states + (size_t)(t + 1) * NS;
         float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);
+        gnn::StatsFinishJobs fin;
+        memset(&fin, 0, sizeof(fin));
+        int n_fin = 0;
         for (int q = 0; q < p.n_types; ++q) {
             CType &y = p.ty[q];
             if (y.count == 0) continue;
-            const gnn_mlp_t &ns = *y.m;
-            const bool bn = ns.has_bn != 0;
             const int off = a.type_offsets[q];
             const size_t ro = (size_t)off * p.S;
             const gnn_csr_t cd = big_sub_csr(B.d, p.N, off, y.count, true);
             float *stats = y.stats + (size_t)t * 2 * y.in_dim;
-            if (bn) {
+            if (y.m->has_bn) {
                 // (moments around the previous iteration's column means, as the homogeneous step takes them)
                 const float *prev = t > 0 ? y.stats + (size_t)(t - 1) * 2 * y.in_dim : nullptr;
-                TRY(launch_aggregate_stats(gate, cd, s_t, p.S, agg_t + ro, B.part_a, stats + y.off_agg, stats + y.in_dim + y.off_agg, prev ? prev + y.off_agg : nullptr, st));
+                int grid = 0;
+                TRY(launch_aggregate_stats(gate, cd, s_t, p.S, agg_t + ro, B.part_a[q], nullptr, nullptr, prev ? prev + y.off_agg : nullptr, st, &grid));
+                fin.t[n_fin++] = gnn::StatsFinishT{B.part_a[q], grid, 1.0f / (float)y.count, stats + y.off_agg, stats + y.in_dim + y.off_agg, prev ? prev + y.off_agg : nullptr};
                 if (t == 0) {       // (later iterations: the launch that wrote the rows left their statistics)
-                    int grid = 0;
-                    TRY(rows_stats(gate, s_t + ro, p.S, p.S, y.count, B.part_y, st, &grid));
-                    gnn::k_stats_finish<<<p.S, 256, 0, st>>>(gate, B.part_y, grid, p.S, 1.0f / (float)y.count, stats + y.off_state, stats + y.in_dim + y.off_state, s_t + ro);
-                    LAUNCH_OK();
+                    TRY(rows_stats(gate, s_t + ro, p.S, p.S, y.count, B.part_y[q], st, &grid));
+                    fin.t[n_fin++] = gnn::StatsFinishT{B.part_y[q], grid, 1.0f / (float)y.count, stats + y.off_state, stats + y.in_dim + y.off_state, s_t + ro};
                 }
             } else TRY(launch_aggregate(gate, cd, s_t, p.S, p.S, agg_t + ro, p.S, st));
-            // the state / agg rows of the first layer with this iteration's statistics folded in; the bias the kernel adds is the shift of THOSE
-            // columns alone (sum beta W over them) - b and the constant columns' share sit in Cc
+        }
+        if (n_fin > 0) { gnn::k_stats_finish_jobs<<<dim3(p.S, n_fin), 256, 0, st>>>(gate, fin, p.S); LAUNCH_OK(); }
+        // the state / agg rows of every type's first layer with this iteration's statistics folded in; the bias the kernel adds is the shift of
+        // THOSE columns alone (sum beta W over them) - b and the constant columns' share sit in Cc
+        FoldList fl;
+        gnn::TypeLaunch<gnn::TrainFwdArgs> fw;
+        memset(&fw, 0, sizeof(fw));
+        gnn::StatsFinishJobs nxt;
+        memset(&nxt, 0, sizeof(nxt));
+        int n_nxt = 0;
+        fw.n = p.n_types;
+        for (int q = 0; q < p.n_types; ++q) {
+            CType &y = p.ty[q];
+            fw.blk_begin[q + 1] = fw.blk_begin[q] + (y.count > 0 ? B.fwd_blocks[q] : 0);
+            if (y.count == 0) continue;
+            const gnn_mlp_t &ns = *y.m;
+            const bool bn = ns.has_bn != 0;
+            const size_t ro = (size_t)a.type_offsets[q] * p.S;
+            float *stats = y.stats + (size_t)t * 2 * y.in_dim;
             float *Wf = y.Wf + (size_t)t * y.in_dim * p.S, *bf = y.bf + (size_t)t * p.S;
-            {
-                FoldList fl;
-                gnn::FoldJob &j = fl.fa.job[fl.fa.n_jobs++];
-                j.centred = 1;
-                j.W = ns.kernel[0]; j.b = nullptr; j.K = y.in_dim; j.H = p.S;
-                j.gamma = bn ? ns.bn_gamma : nullptr; j.beta = ns.bn_beta; j.mean = stats; j.var = stats + y.in_dim; j.eps = ns.bn_eps;
-                j.Wf = Wf; j.bf = bf; j.blk_begin = 0;
-                j.dyn0 = y.off_state; j.dyn1 = y.off_agg; j.dyn_w = p.S;
-                fl.blocks = j.H;
-                TRY(launch_fold_list(fl, st));
-            }
-            gnn::TrainFwdArgs fa;
-            memset(&fa, 0, sizeof(fa));
+            gnn::FoldJob &j = fl.fa.job[fl.fa.n_jobs++];
+            j.centred = 1;
+            j.W = ns.kernel[0]; j.b = nullptr; j.K = y.in_dim; j.H = p.S;
+            j.gamma = bn ? ns.bn_gamma : nullptr; j.beta = ns.bn_beta; j.mean = stats; j.var = stats + y.in_dim; j.eps = ns.bn_eps;
+            j.Wf = Wf; j.bf = bf; j.blk_begin = fl.blocks;
+            j.dyn0 = y.off_state; j.dyn1 = y.off_agg; j.dyn_w = p.S;
+            fl.blocks += j.H;
+            gnn::TrainFwdArgs &fa = fw.t[q];
             fa.in_mean = bn ? stats : nullptr;
             fa.gate = gate; fa.M = y.count;
             fa.state = s_t + ro; fa.ld_state = p.S; fa.agg = agg_t + ro; fa.ld_agg = p.S;
@@ -329,36 +384,51 @@ int composite_big_forward(const gnn_train_args_t &ta, CPlan &p, hipStream_t st) 
             fa.Y = s_n + ro; fa.ldy = p.S;
             fa.thr = a.state_threshold; fa.pred_flag = p.flags + t + 1; fa.pred_k = p.k_dev; fa.pred_kval = (float)(t + 1);
             const bool next_stats = bn && t + 1 < p.K;
-            fa.stat_part = next_stats ? B.part_y : nullptr;
+            fa.stat_part = next_stats ? B.part_y[q] : nullptr;
             fa.stat_shift = next_stats ? stats + y.off_state : nullptr;       // (the new rows' moments around the input rows' column means)
-            int grid = 0;
-            TRY(launch_train_fwd_add(fa, p.S, st, &grid));
             if (next_stats) {
-                float *nxt = y.stats + (size_t)(t + 1) * 2 * y.in_dim;
-                gnn::k_stats_finish<<<p.S, 256, 0, st>>>(gate, B.part_y, grid, p.S, 1.0f / (float)y.count, nxt + y.off_state, nxt + y.in_dim + y.off_state, stats + y.off_state);
-                LAUNCH_OK();
+                float *nx = y.stats + (size_t)(t + 1) * 2 * y.in_dim;
+                nxt.t[n_nxt++] = gnn::StatsFinishT{B.part_y[q], B.one_act ? B.fwd_blocks[q] : 0 /* (set below) */, 1.0f / (float)y.count, nx + y.off_state,
+                                                   nx + y.in_dim + y.off_state, stats + y.off_state};
             }
         }
+        if (fl.fa.n_jobs > 0) TRY(launch_fold_list(fl, st));
+        if (B.one_act) TRY(launch_train_fwd_types(fw, B.act, p.S, st));
+        else {
+            int jn = 0;
+            for (int q = 0; q < p.n_types; ++q) {
+                if (p.ty[q].count == 0) continue;
+                int grid = 0;
+                TRY(launch_train_fwd_add(fw.t[q], p.S, st, &grid));
+                if (fw.t[q].stat_part) nxt.t[jn++].n_part = grid;
+            }
+        }
+        if (n_nxt > 0) { gnn::k_stats_finish_jobs<<<dim3(p.S, n_nxt), 256, 0, st>>>(gate, nxt, p.S); LAUNCH_OK(); }
     }
     return 0;
 }
 
-// back-propagation through the k executed iterations; p.G_state = d loss / d state_k in the caller's node order
+// back-propagation through the k executed iterations; p.G_state = d loss / d state_k in the caller's node order.  Per iteration ONE launch each
+// for the weight-gradient products, their reduction, the parameter gradients and the input gradients of all types, then one transposed
+// neighbour sum per type (its epilogue applies the type's activation and BatchNormalization coefficients).
 int composite_big_backward(const gnn_train_args_t &ta, CPlan &p, int k, hipStream_t st) {
     const gnn_loop_args_t &a = ta.loop;
     CBig &B = p.B;
     const size_t NS = (size_t)p.N * p.S;
     if (k == 0) return 0;
-    // the first dZ: G by position, times act'(state_k) of the row's own type
-    TRY(gather_rows(p.G_state, p.S, a.type_nodes, p.N, p.S, B.Gpos, p.S, st));
-    for (int q = 0; q < p.n_types; ++q) {
-        const CType &y = p.ty[q];
-        if (y.count == 0) continue;
-        const size_t ro = (size_t)a.type_offsets[q] * p.S;
-        TRY(act_grad_inplace(B.Gpos + ro, p.S, p.states + (size_t)k * NS + ro, p.S, y.count, p.S, y.m->activation[0], st));
+    {   // the first dZ: G by position, times act'(state_k) of the row's own type
+        ActRanges ar;
+        memset(&ar, 0, sizeof(ar));
+        ar.n = p.n_types;
+        for (int q = 0; q < p.n_types; ++q) { ar.begin[q] = a.type_offsets[q]; ar.act[q] = p.ty[q].m->activation[0]; }
+        ar.begin[p.n_types] = p.N;
+        k_gather_rows_dz<<<(int)std::min<long>(cdiv((long)p.N * (p.S / 4), 256), 256 * 16), 256, 0, st>>>(p.G_state, a.type_nodes, p.states + (size_t)k * NS, p.N, p.S, ar, B.Gpos);
+        LAUNCH_OK();
     }
     const bool unit_w = !a.adjacency.w;       // entries depend on the destination only: the agg-half of a row's gradient is scaled once, the transposed walk is unit-weight
     float *dx = p.dx_full;
+    int max_in = 1;
+    for (int q = 0; q < p.n_types; ++q) max_in = std::max(max_in, p.ty[q].in_dim);
     for (int t = k - 1; t >= 0; --t) {
         const float *s_t = p.states + (size_t)t * NS;
         const float *agg_t = p.agg + (p.agg_taped ? (size_t)t * NS : 0);
@@ -366,8 +436,15 @@ int composite_big_backward(const gnn_train_args_t &ta, CPlan &p, int k, hipStrea
             const gnn_csr_t all = big_sub_csr(B.d, p.N, 0, p.N, true);
             TRY(launch_aggregate(nullptr, all, s_t, p.S, p.S, p.agg, p.S, st));
         }
+        gnn::TypeLaunch<gnn::TrainWgradArgs> wg;
+        gnn::TypeLaunch<gnn::TrainBwdArgs> bw;
+        gnn::ReduceTypes rd;
+        gnn::ParamGradsTypes pg;
+        memset(&wg, 0, sizeof(wg)); memset(&bw, 0, sizeof(bw)); memset(&rd, 0, sizeof(rd)); memset(&pg, 0, sizeof(pg));
+        wg.n = bw.n = p.n_types;
         for (int q = 0; q < p.n_types; ++q) {
             CType &y = p.ty[q];
+            wg.blk_begin[q + 1] = wg.blk_begin[q]; bw.blk_begin[q + 1] = bw.blk_begin[q];
             if (y.count == 0) continue;
             const gnn_mlp_t &ns = *y.m;
             const bool bn = ns.has_bn != 0;
@@ -375,27 +452,21 @@ int composite_big_backward(const gnn_train_args_t &ta, CPlan &p, int k, hipStrea
             const size_t ro = (size_t)off * p.S;
             const float *stats = bn ? y.stats + (size_t)t * 2 * y.in_dim : nullptr;
             // P = [state | agg | constants]^T dZ and q = colsum(dZ) over the type's rows, then its parameter gradients and m1 / m2
-            gnn::TrainWgradArgs wa;
-            memset(&wa, 0, sizeof(wa));
-            const int n_wg = std::min(std::min(device_cus(), BIG_WGRAD_BLOCKS), cdiv(y.count, 64));
-            wa.M = y.count; wa.rows_per_wg = cdiv(cdiv(y.count, n_wg), 64) * 64;
+            gnn::TrainWgradArgs &wa = wg.t[q];
+            wa.M = y.count; wa.rows_per_wg = cdiv(cdiv(y.count, B.wgrad_blocks[q]), 64) * 64;
             wa.G = B.Gpos + ro; wa.Y = nullptr; wa.act = GNN_ACT_LINEAR;
             wa.state = s_t + ro; wa.agg = agg_t + ro; wa.xc = B.xc + (size_t)off * B.XW;
             wa.K = y.in_dim; wa.wrow_state = y.off_state; wa.wrow_agg = y.off_agg; wa.Kc = B.Kc[q]; wa.cs = B.cc[q];
-            wa.part = B.part_w;
+            wa.part = B.part_w[q];
             wa.mean = stats;
             const int grid = cdiv(y.count, wa.rows_per_wg);
-            TRY(launch_train_wgrad_xt(wa, p.S, B.XT, grid, st));
+            wg.blk_begin[q + 1] = wg.blk_begin[q] + grid;
             const int nP = y.in_dim * p.S + p.S;
-            gnn::k_reduce_partials<<<cdiv(nP, 64), 256, 0, st>>>(B.part_w, grid, nP, y.nc.P, 0, 1.0f, y.in_dim * p.S, y.nc.q);
-            LAUNCH_OK();
-            gnn::k_first_layer_param_grads<<<y.in_dim, 64, 0, st>>>(
-                y.nc.P, y.nc.q, ns.kernel[0], y.in_dim, p.S, bn ? ns.bn_gamma : nullptr, ns.bn_beta, stats, stats ? stats + y.in_dim : nullptr, ns.bn_eps,
-                1.0f / (float)y.count, y.g.dkernel[0], y.g.dbias[0], y.g.dgamma, y.g.dbeta, bn ? y.nc.m1 : nullptr, bn ? y.nc.m2 : nullptr, t != k - 1 ? 1 : 0, 1, stats ? 1 : 0);
-            LAUNCH_OK();
-            if (t == 0) continue;              // nothing consumes d loss / d state_0
-            gnn::TrainBwdArgs ba;
-            memset(&ba, 0, sizeof(ba));
+            rd.t[q] = gnn::ReduceT{B.part_w[q], grid, nP, y.nc.P, 0, 1.0f, y.in_dim * p.S, y.nc.q};
+            pg.t[q] = gnn::ParamGradsT{y.nc.P, y.nc.q, ns.kernel[0], y.in_dim, p.S, bn ? ns.bn_gamma : nullptr, ns.bn_beta, stats, stats ? stats + y.in_dim : nullptr, ns.bn_eps,
+                                       1.0f / (float)y.count, y.g.dkernel[0], y.g.dbias[0], y.g.dgamma, y.g.dbeta, bn ? y.nc.m1 : nullptr, bn ? y.nc.m2 : nullptr,
+                                       t != k - 1 ? 1 : 0, 1, stats ? 1 : 0};
+            gnn::TrainBwdArgs &ba = bw.t[q];
             ba.M = y.count; ba.dZ = B.Gpos + ro; ba.ldz = p.S;
             ba.W = ns.kernel[0]; ba.ldw = p.S; ba.H = p.S; ba.S = p.S; ba.wrow_state = y.off_state; ba.wrow_agg = y.off_agg;
             ba.state = s_t + ro; ba.ld_state = p.S; ba.agg = agg_t + ro; ba.ld_agg = p.S;
@@ -403,9 +474,15 @@ int composite_big_backward(const gnn_train_args_t &ta, CPlan &p, int k, hipStrea
             ba.defer_state_bn = bn ? 1 : 0;    // (k_aggregate_dz below adds the rest of the state half's BatchNorm gradient: it reads state_t anyway)
             ba.agg_row_scale = (unit_w && B.d.row_scale) ? B.d.row_scale + off : nullptr;
             ba.dx = dx + (size_t)off * 2 * p.S; ba.ld_dx = 2 * p.S;
-            TRY(launch_train_bwd_dx(ba, p.S, st));
+            bw.blk_begin[q + 1] = bw.blk_begin[q] + B.bwd_blocks[q];
         }
-        if (t == 0) break;
+        TRY(launch_train_wgrad_types(wg, p.S, B.XT, st));
+        gnn::k_reduce_partials_types<<<dim3(cdiv(max_in * p.S + p.S, 64), p.n_types), 256, 0, st>>>(rd);
+        LAUNCH_OK();
+        gnn::k_first_layer_param_grads_types<<<dim3(max_in, p.n_types), 64, 0, st>>>(pg);
+        LAUNCH_OK();
+        if (t == 0) break;                 // nothing consumes d loss / d state_0: no input gradient, no transposed sum
+        TRY(launch_train_bwd_types(bw, p.S, st));
         // dZ_{t-1} = (dx_state' + Adj . dx_agg + the deferred BatchNorm term) (.) act'(state_t): arcs by source, every type's rows with ITS network's
         // coefficients and activation (state_t's rows of type q are outputs of network q and inputs of network q)
         for (int q = 0; q < p.n_types; ++q) {
@@ -493,7 +570,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
     } else if (a.state_dim > 0) HIP_OK(hipMemcpyAsync(p.states, a.state0, sizeof(float) * NS, hipMemcpyDeviceToDevice, st));
     else TRY(launch_copy2d(nullptr, a.nodes, a.ld_nodes, p.states, p.S, p.N, p.S, p.S, st));
     gnn::Seg segs[GNN_MAX_SEGS];
-    for (int t = 0; t < p.n_types; ++t) {
+    for (int t = 0; t < p.n_types && !p.big; ++t) {      // (large graphs: composite_big_setup takes them from the packed constants line, one pass)
         CType &y = p.ty[t];
         if (!y.m->has_bn || y.count == 0) continue;
         int is_, ia_;
@@ -511,6 +588,10 @@ int train_step_composite(const gnn_train_args_t &ta) {
     else if (p.small) GNN_SET_KERNEL_NAME("train_step composite: persistent small-graph kernels");
     else GNN_SET_KERNEL_NAME("train_step composite: general kernels (one launch per layer, type and iteration)");
     if (p.big) TRY(composite_big_setup(ta, p, st));
+    if (p.head_fast) {     // the thin-head kernels treat output row m as node m: out_index must BE the identity (checked on the device, read with k)
+        gnn::k_not_identity<<<std::min(cdiv(p.M, 256), 1024), 256, 0, st>>>(a.out_index, p.M, p.k_dev + 2);
+        LAUNCH_OK();
+    }
 
     // ---- training-mode forward: gated iterations; tape = states, neighbour sums, per-type statistics ---------------------------------
     TRY(launch_converge(nullptr, p.states, nullptr, p.N, p.S, p.ldS, 0, a.state_threshold, p.flags, nullptr, 0.f, st));
@@ -592,11 +673,12 @@ int train_step_composite(const gnn_train_args_t &ta) {
         }
         TRY(launch_converge(gate, s_n, s_t, p.N, p.S, p.S, p.S, a.state_threshold, p.flags + t + 1, p.k_dev, (float)(t + 1), st));
     }
-    float k_f2[2] = {0.0f, 0.0f};
-    HIP_OK(hipMemcpyAsync(k_f2, p.k_dev, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+    float k_f2[3] = {0.0f, 0.0f, 0.0f};
+    HIP_OK(hipMemcpyAsync(k_f2, p.k_dev, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));                                  // the one host synchronisation of the step
     const int k = (int)k_f2[0];
     *ta.k_host = k;
+    if (k_f2[2] != 0.0f) p.head_fast = false;      // a permuted / repeated out_index of length n_nodes: the general head (gathers, scatter-add)
     if (k_f2[1] != 0.0f) return fail("a workgroup of the persistent training kernel never arrived at a grid barrier (not resident?)");
     if (k < 0 || k > p.K) return fail("iteration count %d out of range", k);
     if (p.small || p.big) TRY(scatter_rows(p.states + (size_t)k * NS, p.ldS, a.type_nodes, p.N, p.S, ta.state, p.S, st));      // positions -> the caller's node order
@@ -624,6 +706,12 @@ int train_step_composite(const gnn_train_args_t &ta) {
     if (p.M > 0) {
         const float *W0 = no.kernel[0], *b0 = no.bias[0];
         if (bn_o) {
+            if (p.head_fast) {          // every node a row, in order: one pass over the state (moments around its row 0)
+                int grid = 0;
+                TRY(rows_stats(nullptr, state_k, p.S, p.S, p.N, p.B.part_y[0], st, &grid));
+                gnn::k_stats_finish<<<p.S, 256, 0, st>>>(nullptr, p.B.part_y[0], grid, p.S, 1.0f / (float)p.N, p.stats_o, p.stats_o + no.in_dim, state_k);
+                LAUNCH_OK();
+            } else
             TRY(colstats_segs(nullptr, osegs, 1, p.M, p.stats_o, p.stats_o + no.in_dim, p.part, st));
             TRY(fold_with_stats(no, p.stats_o, p.Wf_o, p.bf_o, st, true));
             if (!p.small) {
@@ -648,6 +736,13 @@ int train_step_composite(const gnn_train_args_t &ta) {
     if (p.pooled) { TRY(launch_aggregate(nullptr, ta.nodegraph_by_source, p.dpred, p.T, p.T, p.G_out, p.T, st)); G_out = p.G_out; }
 
     // ---- backward: output network, then the k iterations ------------------------------------------------------------------------------
+    if (p.head_fast) {          // the head's parameter gradients, d loss / d state_k written straight into the state gradient (every row is an output row)
+        TrainPlan hp;
+        memset(&hp, 0, sizeof(hp));
+        hp.M = p.M; hp.N = p.N; hp.S = p.S; hp.ldS = p.S; hp.T = p.T; hp.with_labels = false; hp.L = 0;
+        hp.part_h = p.part_h; hp.co = p.co; hp.G_state = p.G_state;
+        TRY(head_backward(hp, a, state_k, out_nodes, G_out, bn_o ? p.stats_o : nullptr, st, -1));
+    } else {
     HIP_OK(hipMemsetAsync(p.G_state, 0, sizeof(float) * (size_t)p.N * p.S, st));
     if (p.M > 0) {
         TRY(net_backward(p.co, osegs, 1, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, no.in_dim, p.part, st));
@@ -656,6 +751,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
         gnn::k_scatter_add_rows<<<std::min(cdiv((long)p.M * p.S, 256), 256 * 16), 256, 0, st>>>(p.dx_o_all, no.in_dim, a.out_index, p.M, p.S, p.G_state, p.S);
         LAUNCH_OK();
     } else TRY(zero_grads(no, ta.grad_output, st));
+    }
     for (int q = 0; q < p.n_types; ++q)
         if (k == 0 || p.ty[q].count == 0) TRY(zero_grads(*p.ty[q].m, p.ty[q].g, st));
     if (p.small && k > 0) {

@@ -107,6 +107,25 @@ __global__ void __launch_bounds__(256) k_gather_f32(const float *__restrict__ x,
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = x[perm[i]];
 }
 
+// the loop's first dZ: out[i, :] = G[perm[i], :] (.) act'(Y[i, :]) with the activation of position i's node type (S % 4 == 0; 16-byte pieces)
+struct ActRanges { int begin[GNN_MAX_TYPES + 1], act[GNN_MAX_TYPES], n; };
+__global__ void __launch_bounds__(256) k_gather_rows_dz(const float *__restrict__ G, const int *__restrict__ perm, const float *__restrict__ Y, int N, int S, ActRanges ar,
+                                                        float *__restrict__ out) {
+    const int pr = S / 4;
+    const size_t total = (size_t)N * pr;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int i = (int)(idx / pr), c4 = (int)(idx % pr);
+        int act = ar.act[0];
+#pragma unroll
+        for (int t = 1; t < GNN_MAX_TYPES; ++t) if (t < ar.n && i >= ar.begin[t]) act = ar.act[t];
+        const gnn::f32x4 g = *reinterpret_cast<const gnn::f32x4 *>(G + (size_t)perm[i] * S + 4 * c4), y = *reinterpret_cast<const gnn::f32x4 *>(Y + (size_t)i * S + 4 * c4);
+        gnn::f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = g[e] * gnn::activate_grad_from_output(act, y[e]);
+        *reinterpret_cast<gnn::f32x4 *>(out + (size_t)i * S + 4 * c4) = o;
+    }
+}
+
 struct PosCsr { int *rp, *src; float *w, *row_scale; int nnz; };
 
 // `c` (n_dst = n_src = N) re-labelled: row i = the row of node perm[i], entries inv[.]
@@ -199,13 +218,78 @@ int launch_train_wgrad_xt(const gnn::TrainWgradArgs &wa, int S, int XT, int grid
     return XT == 2 ? launch_train_wgrad_b6_xt_nb<1, 2>(wa, grid, st) : launch_train_wgrad_b6_xt_nb<1, 1>(wa, grid, st);
 }
 
+// ---- one launch for the rows of every node type (gnn::TypeLaunch) ---------------------------------------------------------------------------
+// workgroups of a launch of `total` dealt to the types in proportion to their rows (>= 1 each where there are rows, never more than `total` together:
+// a second round of workgroups on a CU would double the launch's time)
+void split_blocks(int total, const int *count, int T, int *out) {
+    long N = 0; int live = 0;
+    for (int t = 0; t < T; ++t) { N += count[t]; live += count[t] > 0; }
+    int used = 0, big = 0;
+    for (int t = 0; t < T; ++t) {
+        out[t] = count[t] > 0 ? std::max(1, (int)((long)std::max(total - live, 0) * count[t] / std::max<long>(N, 1))) : 0;
+        used += out[t];
+        if (count[t] > count[big]) big = t;
+    }
+    if (used < total && N > 0) out[big] += total - used;
+}
+
+template <int SQ, int ACT>
+int launch_train_fwd_types_sa(const gnn::TypeLaunch<gnn::TrainFwdArgs> &m, hipStream_t st) {
+    const size_t lds = gnn::train_fwd_b6_lds<SQ, true>();
+    TRY(raise_dynamic_lds((const void *)gnn::k_train_fwd_b6_types<SQ, ACT, true>, lds));
+    gnn::k_train_fwd_b6_types<SQ, ACT, true><<<m.blk_begin[m.n], 64 * gnn::TB_WAVES, lds, st>>>(m);
+    return hipGetLastError() == hipSuccess ? 0 : fail("k_train_fwd_b6_types launch failed");
+}
+template <int SQ>
+int launch_train_fwd_types_s(const gnn::TypeLaunch<gnn::TrainFwdArgs> &m, int act, hipStream_t st) {
+    switch (act) {
+        case GNN_ACT_LINEAR: return launch_train_fwd_types_sa<SQ, GNN_ACT_LINEAR>(m, st);
+        case GNN_ACT_RELU: return launch_train_fwd_types_sa<SQ, GNN_ACT_RELU>(m, st);
+        case GNN_ACT_SELU: return launch_train_fwd_types_sa<SQ, GNN_ACT_SELU>(m, st);
+        case GNN_ACT_TANH: return launch_train_fwd_types_sa<SQ, GNN_ACT_TANH>(m, st);
+        case GNN_ACT_SIGMOID: return launch_train_fwd_types_sa<SQ, GNN_ACT_SIGMOID>(m, st);
+        case GNN_ACT_ELU: return launch_train_fwd_types_sa<SQ, GNN_ACT_ELU>(m, st);
+        case GNN_ACT_SOFTPLUS: return launch_train_fwd_types_sa<SQ, GNN_ACT_SOFTPLUS>(m, st);
+        default: return fail("k_train_fwd_b6_types: no instance for activation %d", act);
+    }
+}
+int launch_train_fwd_types(const gnn::TypeLaunch<gnn::TrainFwdArgs> &m, int act, int S, hipStream_t st) {
+    return S == 64 ? launch_train_fwd_types_s<4>(m, act, st) : launch_train_fwd_types_s<2>(m, act, st);
+}
+
+template <int NB, int XT>
+int launch_train_wgrad_types_nb(const gnn::TypeLaunch<gnn::TrainWgradArgs> &m, hipStream_t st) {
+    const size_t lds = gnn::train_wgrad_b6_lds<NB, GNN_ACT_LINEAR, XT>();
+    TRY(raise_dynamic_lds((const void *)gnn::k_train_wgrad_b6_types<NB, GNN_ACT_LINEAR, XT>, lds));
+    gnn::k_train_wgrad_b6_types<NB, GNN_ACT_LINEAR, XT><<<m.blk_begin[m.n], 256, lds, st>>>(m);
+    return hipGetLastError() == hipSuccess ? 0 : fail("k_train_wgrad_b6_types launch failed");
+}
+int launch_train_wgrad_types(const gnn::TypeLaunch<gnn::TrainWgradArgs> &m, int S, int XT, hipStream_t st) {
+    if (S == 64) return XT == 2 ? launch_train_wgrad_types_nb<2, 2>(m, st) : launch_train_wgrad_types_nb<2, 1>(m, st);
+    return XT == 2 ? launch_train_wgrad_types_nb<1, 2>(m, st) : launch_train_wgrad_types_nb<1, 1>(m, st);
+}
+
+template <int HQ>
+int launch_train_bwd_types_h(const gnn::TypeLaunch<gnn::TrainBwdArgs> &m, hipStream_t st) {
+    const size_t lds = gnn::train_bwd_b6_lds<HQ>();
+    TRY(raise_dynamic_lds((const void *)gnn::k_train_bwd_dx_b6_types<HQ, GNN_ACT_LINEAR>, lds));
+    gnn::k_train_bwd_dx_b6_types<HQ, GNN_ACT_LINEAR><<<m.blk_begin[m.n], 256, lds, st>>>(m);
+    return hipGetLastError() == hipSuccess ? 0 : fail("k_train_bwd_dx_b6_types launch failed");
+}
+int launch_train_bwd_types(const gnn::TypeLaunch<gnn::TrainBwdArgs> &m, int S, hipStream_t st) {      // (the dZ form: Y == NULL in every entry)
+    return S == 64 ? launch_train_bwd_types_h<4>(m, st) : launch_train_bwd_types_h<2>(m, st);
+}
+
 // ---- the plan's large-graph part -----------------------------------------------------------------------------------------------------------
 struct CBig {
     int XT, XW;                          // 32-column tiles / floats of a constants line
     int *scan_tmp;
     PosCsr d, s;                         // the adjacency in positions: by destination, by source
-    float *xc, *Cc, *Gpos, *part_a, *part_y, *part_w;
+    float *xc, *Cc, *Gpos;
+    float *part_a[GNN_MAX_TYPES], *part_y[GNN_MAX_TYPES], *part_w[GNN_MAX_TYPES];      // every type its own partials: one k_stats_finish / k_reduce_partials for all
     int Kc[GNN_MAX_TYPES]; gnn::ConstCols cc[GNN_MAX_TYPES];
+    int fwd_blocks[GNN_MAX_TYPES], bwd_blocks[GNN_MAX_TYPES], wgrad_blocks[GNN_MAX_TYPES];   // workgroups of the merged launches
+    bool one_act; int act;               // every type with rows has the same activation: ONE forward launch an iteration
 };
 
 // whether the large-graph kernels take this step (decided before the tape is carved)

@@ -434,8 +434,9 @@ inline bool gather_buf_enabled() {
 inline bool gather_buf_ok(const gnn_csr_t &c, int ldx) {
     return gather_buf_enabled() && (size_t)c.n_src * (size_t)ldx * 4 < 0xFFFFFFF0ull && (size_t)c.nnz * 4 < 0xFFFFFFF0ull;
 }
+// `grid_out` != NULL: the partials stay in `part` ([*grid_out][2 S]) for the caller's own k_stats_finish (heterogeneous models: one for all types)
 int launch_aggregate_stats(const int *gate, const gnn_csr_t &c, const float *X, int S, float *out, float *part, float *mean, float *var, const float *shift,
-                           hipStream_t st) {
+                           hipStream_t st, int *grid_out = nullptr) {
     const int lpr = S / 4, groups = 256 / lpr;
     const int grid = std::min(cdiv(c.n_dst, groups), BIG_AGG_BLOCKS);
 #define AGGS_(L, W_, B_) gnn::k_aggregate_stats<L, W_, B_><<<grid, 256, 0, st>>>(gate, c.n_dst, c.rowptr, c.src, c.w, c.row_scale, X, S, out, S, part, shift)
@@ -445,6 +446,7 @@ int launch_aggregate_stats(const int *gate, const gnn_csr_t &c, const float *X, 
 #undef AGGS
 #undef AGGS_
     LAUNCH_OK();
+    if (grid_out) { *grid_out = grid; return 0; }
     gnn::k_stats_finish<<<S, 256, 0, st>>>(gate, part, grid, S, 1.0f / (float)c.n_dst, mean, var, shift);
     LAUNCH_OK();
     return 0;

@@ -37,5 +37,7 @@ def pytest_collection_finish(session):
         if mod is not None: mod.start_deep_oracles(names)
         mod5 = sys.modules.get('test_gpu_round5')          # (the million-node train-step oracle: tests/test_gpu_round5.py)
         if mod5 is not None: mod5.start_train_oracle([it.name for it in session.items])
+        mod6 = sys.modules.get('test_gpu_round6')          # (the C5-size heterogeneous train-step oracle: tests/test_gpu_round6.py)
+        if mod6 is not None: mod6.start_c5_train_oracle([it.name for it in session.items])
     except Exception:
         pass                                                   # (never fail a collection over a head start)

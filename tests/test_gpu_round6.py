@@ -130,3 +130,62 @@ def test_composite_train_step_on_the_large_graph_kernels(d, dims, mode, bn, act,
         set_composite_weights(model, w0)
         summary, _ = composite_compare(model, x, y, sw, s0, want, native, tag=f'composite_big d={d} {mode}', path='row-streaming')
         print(f"\n  {'gnn_train_step ' if native else 'building blocks'} k = {want['k']}  {summary}")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the heterogeneous train step at BASELINE C5's size and the depth bench.py times it (training.c5_d64_k10)
+# ----------------------------------------------------------------------------------------------------------------------
+_C5_JOB = {}
+TRAIN_C5 = dict(N=500_000, E=5_000_000, d=64, K=10, dims=(14, 8, 4))
+
+
+def _train_c5_job():
+    """BASELINE C5 with bench.py's training configuration (3 node types with label widths 14 / 8 / 4, per type BatchNormalization +
+    Dense(d_t + 157 -> 64, selu), output BatchNormalization + Dense(64 -> 2, softmax); 10 iterations, threshold 0) and its float64
+    autograd oracle, one iteration checkpointed at a time (oracle/torch_train.py::composite_train_step)."""
+    import time
+    c = TRAIN_C5
+    t0 = time.time()
+    g = er_composite_graph(c['N'], c['E'], dim_node_label=c['dims'], aggregation_mode='average', seed=1234)
+    x, y, sw = CompositeMultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0]
+    inp, lay = get_inout_dims('state', list(c['dims']), 3, 2, 'n', c['d'])
+    ns = [MLP(i, lay, 'selu', 'lecun_normal', 'lecun_normal', rng=t) for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', list(c['dims']), 3, 2, 'n', c['d'])
+    no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9)
+    assert all(n.batch_normalization for n in ns) and no.batch_normalization
+    model = CompositeGNNnodeBased(ns, no, c['d'], c['K'], 0.0)
+    s0 = np.random.default_rng(1).normal(0, 0.1, (c['N'], c['d'])).astype(np.float32)
+    t1 = time.time()
+    want = composite_oracle_step(model, x, y, sw, s0, checkpoint_iterations=True)
+    return dict(model=model, x=x, y=y, sw=sw, s0=s0, want=want, t_graph=t1 - t0, t_oracle=time.time() - t1)
+
+
+def start_c5_train_oracle(test_names):
+    """tests/conftest.py calls this at the end of the collection of a full GPU session: the float64 oracle of the C5-size step (minutes of
+    host time) runs on a worker thread under the tests in front of this one."""
+    if 'job' in _C5_JOB or 'test_composite_train_step_at_c5_size' not in test_names: return
+    from test_gpu_round4 import _Job
+    torch.cuda.init()
+    _C5_JOB['job'] = _Job(_train_c5_job)
+
+
+def test_composite_train_step_at_c5_size(request):
+    """`gnn_train_step` with `composite` on the C5 graph (500 k nodes / 5 M arcs, 3 node types, d = 64, BatchNormalization, 10 iterations:
+    bench.py's `training.c5_d64_k10`) - the row-streaming kernels on per-type position ranges, constants lines of 64 floats - against
+    torch autograd in float64: k, loss, training-mode predictions, the final state, every gradient of the four networks per tensor, the
+    moving statistics; the in-library step AND the building-block orchestration.  Prints the per-tensor errors
+    (profiles/r06_train_c5_parity.txt is this test's output on the GPU box)."""
+    start_c5_train_oracle([it.name for it in request.session.items] + [request.node.name])
+    r = _C5_JOB['job'].result()
+    model, x, y, sw, s0, want = r['model'], r['x'], r['y'], r['sw'], r['s0'], r['want']
+    c = TRAIN_C5
+    model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+    kq = [int(np.sum(k_[0])) for k_ in want['kinks_state']]
+    print(f"\nC5-size train step: graph {r['t_graph']:.0f} s, float64 oracle {r['t_oracle']:.0f} s; k = {want['k']}, loss {want['loss']:.6f}; "
+          f"pre-activations within 1e-6 of the selu kink per type: {kq}")
+    assert want['k'] == c['K']
+    w0 = composite_weights(model)
+    for native in (True, False):
+        set_composite_weights(model, w0)
+        summary, _ = composite_compare(model, x, y, sw, s0, want, native, tag='c5_train_step', path='row-streaming')
+        print(f"  {'gnn_train_step ' if native else 'building blocks'} {summary}")

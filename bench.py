@@ -298,6 +298,10 @@ def training_section(device, graph_x, d):
         out['composite_small_graphs'] = composite_training_section(device)
     except Exception as e:                            # never lose the other numbers to this one
         out['composite_small_graphs'] = {'error': str(e)[:300]}
+    try:
+        out['mutag_lgnn_starter'] = lgnn_starter_section(device, graphs)
+    except Exception as e:
+        out['mutag_lgnn_starter'] = {'error': str(e)[:300]}
     ns, no = starter_nets(d, device, 'n')
     gnn = GNNnodeBased(ns, no, d, 10, 0.0)
     gnn.compile(optimizer=Adam(0.001), loss='categorical_crossentropy', metrics=['accuracy'])
@@ -360,6 +364,55 @@ def kernel_stats_lookup(tag):
     return {'from': 'profiles/%s_kernel_stats.json (rocprofv3 --kernel-trace --stats of scripts/train_c5.py)' % tag, 'avg_us': rec['avg_us'], 'calls_per_step': rec.get('calls_per_step')}
 
 
+def lgnn_starter_section(device, graphs):
+    """The reference's DEFAULT layered model (starter.py:37-47: 3 GNN layers, get_state and get_output, training_mode 'serial'; each layer the
+    starter GNN - state = the label columns, 5 iterations, threshold 0.01 - batch_size 1000, Adam 0.01; reference LGNN.py:290-362): one
+    `lgnn.fit()` epoch over the starter split (2 837 training graphs, 750 validation graphs) - per layer one epoch of training, then every
+    graph alone through the trained layer (batch size 1, as the reference propagates states / outputs into the next layer's labels) - and
+    the training step of each layer on its batches of 1 000 graphs."""
+    from gnnkeras_amd.Models.GNN import GNNgraphBased
+    from gnnkeras_amd.Models.LGNN import LGNN
+    from gnnkeras_amd.Models.MLP import MLP, get_inout_dims
+    from gnnkeras_amd.Models.training import Adam
+    from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+    layers, bs = 3, 1000
+    gnns = []
+    for i in range(layers):
+        inp, lay = get_inout_dims('state', 14, 3, 2, 'g', 0, layer=i, get_state=True, get_output=True)
+        ns = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=10 + i, device=device)
+        inp, lay = get_inout_dims('output', 14, 3, 2, 'g', 0, layer=i, get_state=True, get_output=True)
+        no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=20 + i, device=device)
+        gnns.append(GNNgraphBased(ns, no, 0, 5, 0.01))
+    lg = LGNN(gnns, True, True)
+    lg.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', average_st_grads=True, metrics=['accuracy'], training_mode='serial')
+    gs = [g.copy() for g in graphs]
+    for g in gs: g.setAggregation('average')
+    tr = MultiGraphSequencer(gs[:-1500], 'g', 'average', bs, shuffle=True, device=device)
+    va = MultiGraphSequencer(gs[-750:], 'g', 'average', bs, shuffle=False, device=device)
+    step_s = [[] for _ in gnns]
+    for i, g_ in enumerate(gnns):           # time every layer's training steps inside fit() (a synchronisation per step: the steps are 1 000 graphs each)
+        inner = g_.train_step
+        def timed(data, _inner=inner, _acc=step_s[i], **kw):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = _inner(data, **kw)
+            torch.cuda.synchronize(); _acc.append(time.perf_counter() - t0)
+            return r
+        g_.train_step = timed
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    hists = lg.fit(tr, epochs=1, validation_data=va, verbose=0)
+    torch.cuda.synchronize(); t_first = time.perf_counter() - t0
+    for acc in step_s: acc.clear()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    hists = lg.fit(tr, epochs=1, validation_data=va, verbose=0)
+    torch.cuda.synchronize(); t_fit = time.perf_counter() - t0
+    return {'fit_one_epoch_ms': 1e3 * t_fit, 'first_fit_ms_with_operator_builds': 1e3 * t_first,
+            'train_step_ms_per_layer': [1e3 * float(np.median(a)) if a else None for a in step_s], 'steps_per_layer': [len(a) for a in step_s],
+            'final_layer_loss': float(hists[-1]['loss'][-1]),
+            'workload': f'MUTAG starter split ({len(tr.data)} training / {len(va.data)} validation graphs), {layers} layers, serial, get_state + get_output, '
+                        f'state_vect_dim 0, 5 iterations, threshold 0.01, batches of {bs}; an epoch = per layer: {len(tr)} training steps + validation, then '
+                        f'every graph alone through the layer (batch size 1, training-mode forward) to relabel the next layer\'s graphs'}
+
+
 def composite_training_section(device):
     """Heterogeneous small graphs (reference CompositeGNN.py:275-304 `train_step`): 640 typed graphs of 20 .. 60 nodes (3 node types,
     MUTAG-like size), batches of 32, node-focused, d = 32 x 20 iterations - the step runs one state network per node type on that
@@ -395,7 +448,24 @@ def composite_training_section(device):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(len(seq)): gnn.train_step(seq[i], seed=0)
     torch.cuda.synchronize(); t_blocks = (time.perf_counter() - t0) / len(seq)
+    # the same graphs ARC-focused (reference CompositeGNN.py:315-327: the output network over [state_src | state_dst | arc label] of every arc):
+    # in the library since round 6
+    from gnnkeras_amd.Models.CompositeGNN import CompositeGNNarcBased
+    graphs_a = [er_composite_graph(int(g.nodes.shape[0]), int(g.arcs.shape[0]), dim_node_label=dims, seed=100 + i, focus='a') for i, g in enumerate(graphs)]
+    inp, lay = get_inout_dims('state', dims, 3, 2, 'a', d)
+    nets_a = [MLP(i, lay, 'selu', 'lecun_normal', 'lecun_normal', rng=t, device=device) for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', dims, 3, 2, 'a', d)
+    no_a = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=9, device=device)
+    gnn_a = CompositeGNNarcBased(nets_a, no_a, d, it, 0.01)
+    gnn_a.compile(optimizer=Adam(0.01), loss='categorical_crossentropy', metrics=['accuracy'])
+    seq_a = CompositeMultiGraphSequencer(graphs_a, 'a', 'average', 32, shuffle=False, device=device)
+    for i in range(len(seq_a)): gnn_a.train_step(seq_a[i], seed=0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(len(seq_a)): gnn_a.train_step(seq_a[i], seed=0)
+    torch.cuda.synchronize(); t_arc = (time.perf_counter() - t0) / len(seq_a)
+    arc_native = gnn_a._trainer._native_step_applies(seq_a[0][1])
     return {'train_step_ms_per_batch': 1e3 * t_step, 'k': int(r['k']), 'fit_epoch_ms': 1e3 * t_epoch, 'predict_ms': 1e3 * t_pred,
+            'arc_focused_train_step_ms_per_batch': 1e3 * t_arc, 'arc_focused_in_library_step': bool(arc_native),
             'in_library_step': bool(native), 'train_step_ms_per_batch_building_blocks_from_python': 1e3 * t_blocks,
             'workload': f'{len(graphs)} heterogeneous graphs (3 node types, 20..60 nodes), {len(seq)} batches of 32, node-focused, d = {d}, '
                         f'max_iteration = {it}; gnn_train_step with per-type networks (csrc/train_composite.hpp), predict() batch by batch'}
@@ -466,6 +536,8 @@ def traffic_lookup(rec, kernel_name, N, E, d, traffic_file=None):
                     stale = tr.get('library_source_hash')
                     continue
                 rec['traffic'] = tr['hbm_bytes_per_launch']
+                rec['traffic_counts'] = ('L2 -> fabric bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE (the gfx950 correction of MI355X_MICROARCH.md); '
+                                         'requests served by the 256 MiB Infinity Cache are INCLUDED - this is not an HBM-only figure')
                 rec['traffic_bounds'] = tr.get('bounds')
                 rec['traffic_source'] = (f"profiles/hbm_traffic.json: {tr.get('launches')} launches of this kernel on this workload, "
                                          f"sources {here}, {tr.get('taken', 'PMC passes of the round')}")
@@ -847,6 +919,12 @@ def main():
         del gnn, inputs, x, s0
         torch.cuda.empty_cache()
         result['beyond_infinity_cache'] = beyond_cache_section(device, d, K_it, args.aggregation)
+        # Both fractions in the headline object: `frac` is measured on the C4 graph, whose 256 MB state array sits in the 256 MiB Infinity Cache
+        # (a last-level-cache-assisted figure: it can exceed what HBM alone sustains); the same kernel on a 4 M-node graph (state array 1 GB)
+        # is the HBM-bound figure.
+        result['roofline']['frac_state_beyond_infinity_cache'] = result['beyond_infinity_cache'].get('frac')
+        result['roofline']['frac_note'] = ('frac: BASELINE C4 (1 M nodes: the state array fits the Infinity Cache); frac_state_beyond_infinity_cache: '
+                                          'the same kernel on 4 M nodes / 40 M arcs (state array 1 GB), both on algorithmic bytes over 8 TB/s')
         torch.cuda.empty_cache()
         try:
             result['wide_state_d200'] = wide_state_section(device, args.aggregation)

@@ -869,7 +869,7 @@ class LoopTrainer:
         if self.dp is not None: return False        # collectives sit between the iteration's launches: the building-block path
         if not self.use_native_step or y is None: return False
         nets = list(m.net_state) if isinstance(m.net_state, (list, tuple)) else [m.net_state]
-        if isinstance(m.net_state, (list, tuple)) and (m._focus == 'a' or m.max_iteration < 1): return False      # what the in-library composite step refuses (make_cplan): the general path below
+        if isinstance(m.net_state, (list, tuple)) and m.max_iteration < 1: return False      # what the in-library composite step refuses (make_cplan): the general path below
         if any(n_.dropout_rate for n_ in nets) or m.net_output.dropout_rate: return False      # Dropout masks: the general path below
         kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
         return str(kind).lower() in nat.LOSSES
@@ -991,12 +991,20 @@ class LoopTrainer:
         ok_ptr, prev_ok = C.c_void_p(0), C.c_int32(1)
         ta.grads_ok_dev = C.pointer(ok_ptr)
         pend, self._pending = self._pending, None
-        if pend is not None and pend['tape'] is tape: ta.prev_grads_ok_host = C.pointer(prev_ok)
+        fetched_by_call = pend is not None and pend['tape'] is tape
+        if fetched_by_call:
+            prev_ok.value = -1                                   # sentinel: the library has not fetched the previous step's word (yet)
+            ta.prev_grads_ok_host = C.pointer(prev_ok)
         elif pend is not None and not self._read_word(pend['view']): prev_ok.value = 0
         try:
             nat.check(nat.lib().gnn_train_step(C.byref(ta)))
         except nat.NativeError:
-            if pend is not None and not self._read_word(pend['view']): self._recover_failed(pend)     # (the call may have failed in front of its synchronisation)
+            # The call fetches the previous step's validity word and then RESETS it on the tape for its own step: once it has got that far
+            # (`prev_ok` is 0 / 1 - a failing call synchronises before it returns), the word on the tape is this call's zero and says nothing
+            # about the previous step; only a call that failed in front of its first launch (the sentinel is still there) left it untouched.
+            if pend is not None:
+                prev_valid = bool(prev_ok.value) if (fetched_by_call and prev_ok.value >= 0) else (self._read_word(pend['view']) if fetched_by_call else prev_ok.value != 0)
+                if not prev_valid: self._recover_failed(pend)
             raise
         for g_ in gs_all: g_.touched = k_host.value > 0          # (a type without nodes: the library zero-fills its gradients)
         go.touched = len(out_index) > 0

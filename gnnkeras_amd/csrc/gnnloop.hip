@@ -16,6 +16,7 @@
 #include <string.h>
 #include <algorithm>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/gnnloop.h"
@@ -466,13 +467,13 @@ int fused_generation(int SP, int n_nodes, int flags);
 // 10 arcs per node, us per iteration with inputs / with C: 100 k nodes 61.1 / 59.1, 200 k 105.0 / 105.8, 400 k 192.2 / 199.7,
 // 600 k 281.6 / 294.0, 1 M (C4) 458 / 480, 4 M 2 215 / 2 329; d = 32 at C4 size 263.2 / 263.7.
 bool xc_disabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_XC"); v = (e && atoi(e) == 0) ? 1 : 0; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_XC"); v = (e && atoi(e) == 0) ? 1 : 0; }
     return v == 1;
 }
 int xc_min_nodes() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_XC_MIN_NODES"); v = e ? atoi(e) : 196608; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_XC_MIN_NODES"); v = e ? atoi(e) : 196608; }
     return v;
 }
 
@@ -1514,11 +1515,16 @@ __global__ void k_or_flags(const int *gate, int n_gate, int gate_stride, int *ou
 // Test hook (tests/test_gpu_round4.py): `n_workgroups` workgroups that each hold `lds_bytes` of LDS (160 KB = a whole CU) and one
 // wave, doing nothing until `milliseconds` of wall-clock time have passed - a co-tenant that keeps CUs away from the persistent
 // kernels.  Bounded by construction (the 100 MHz wall clock), so it cannot hang the GPU.
-__global__ void __launch_bounds__(64) k_debug_occupy(unsigned long long ticks, int *sink) {
+// `release` != NULL: the workgroups also leave as soon as *release != 0 (a word the test sets from another stream: the co-tenant goes when
+// the TEST says so, not when a clock does - `ticks` stays as the bound that keeps the kernel from hanging the GPU)
+__global__ void __launch_bounds__(64) k_debug_occupy(unsigned long long ticks, int *sink, const int *release) {
     extern __shared__ int occ_smem[];
     const unsigned long long t0 = wall_clock64();
     int polls = 0;
-    while (wall_clock64() - t0 < ticks) { __builtin_amdgcn_s_sleep(64); ++polls; }
+    while (wall_clock64() - t0 < ticks) {
+        if (release && __hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        __builtin_amdgcn_s_sleep(64); ++polls;
+    }
     if (threadIdx.x == 0 && polls < 0) { occ_smem[0] = polls; *sink = occ_smem[0]; }      // (keeps the LDS allocation alive; never taken)
 }
 
@@ -1526,7 +1532,17 @@ int gnn_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t millisecon
     if (n_workgroups < 1 || lds_bytes < 0 || lds_bytes > 160 * 1024 || milliseconds < 0 || milliseconds > 10000) return fail("gnn_debug_occupy: bad arguments");
     static bool attr = false;
     if (!attr) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_debug_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    k_debug_occupy<<<n_workgroups, 64, (size_t)lds_bytes, (hipStream_t)stream>>>((unsigned long long)milliseconds * 100000ull, nullptr);
+    k_debug_occupy<<<n_workgroups, 64, (size_t)lds_bytes, (hipStream_t)stream>>>((unsigned long long)milliseconds * 100000ull, nullptr, nullptr);
+    LAUNCH_OK();
+    return 0;
+}
+
+int gnn_debug_occupy_until(int32_t n_workgroups, int32_t lds_bytes, int32_t max_milliseconds, const int32_t *release_flag, void *stream) {
+    if (n_workgroups < 1 || lds_bytes < 0 || lds_bytes > 160 * 1024 || max_milliseconds < 0 || max_milliseconds > 20000 || !release_flag)
+        return fail("gnn_debug_occupy_until: bad arguments");
+    static bool attr = false;
+    if (!attr) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_debug_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    k_debug_occupy<<<n_workgroups, 64, (size_t)lds_bytes, (hipStream_t)stream>>>((unsigned long long)max_milliseconds * 100000ull, nullptr, release_flag);
     LAUNCH_OK();
     return 0;
 }

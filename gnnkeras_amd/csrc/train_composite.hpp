@@ -9,8 +9,8 @@
 // iteration pair with the interpreter between them - 15.6 ms per step on batches of 32 small typed graphs (d = 32, 20 iterations)
 // against 1.1 ms for a homogeneous batch of that size.  This is the same arithmetic with the orchestration inside the library
 // (the general kernels of train_loop.hpp with per-type row lists: k_segdense / k_dense_grad_* / k_colstats_* take a row index per
-// segment), one host synchronisation per step (to learn k).  Node and graph focus; arc-focused composite models and LGNN label
-// gradients keep the building-block path.
+// segment), one host synchronisation per step (to learn k).  Node, graph and arc focus (CompositeGNN.py:315-327: the output network over
+// [state_src | state_dst | arc label] of the masked arcs); LGNN label gradients keep the building-block path.
 #pragma once
 // (included by gnnloop.hip behind train_loop.hpp: shares its anonymous-namespace helpers)
 #include "train_composite_big.hpp"      // large graphs: the row-streaming kernels on per-type position ranges
@@ -42,6 +42,7 @@ struct CPlan {
     // order in tiles of <= 64 nodes of one type: the tape's rows are POSITIONS (position i = node type_nodes[i]), `inv` maps back
     bool small; int SPs, ldS, n_wg, wg_begin[GNN_MAX_TYPES + 1];
     int *inv; float *sm_cc, *sm_part, *sm_dxa, *sm_partW[GNN_MAX_TYPES], *sm_partBN[GNN_MAX_TYPES]; unsigned long long *sm_bar;
+    int *isrc, *idst;            // arc focus: the end nodes of the masked arcs
     // large graphs (train_composite_big.hpp): the tape's rows are POSITIONS too, every type a contiguous range of them
     bool big; CBig B;
     bool head_fast; float *part_h;       // large graphs: a thin output head over EVERY node on the row-streaming head kernels (k_head_wgrad / k_head_dx)
@@ -84,7 +85,6 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
     memset(&p, 0, sizeof(p));
     if (a.abi_version != GNN_ABI_VERSION) return fail("abi_version %d != %d", a.abi_version, GNN_ABI_VERSION);
     if (a.n_nodes < 1) return fail("gnn_train_step: empty graph");
-    if (a.focus == GNN_FOCUS_ARC) return fail("gnn_train_step: arc-focused composite models train through the building blocks");
     if (a.n_types < 1 || a.n_types > GNN_MAX_TYPES) return fail("n_types %d out of [1,%d]", a.n_types, GNN_MAX_TYPES);
     if (a.max_iteration < 1) return fail("composite GNN requires max_iteration > 0");
     p.N = a.n_nodes; p.E = a.n_arcs; p.L = a.dim_node_label; p.A = a.dim_arc_label; p.n_types = a.n_types;
@@ -98,7 +98,9 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
     if (a.type_offsets[0] != 0 || a.type_offsets[p.n_types] != p.N) return fail("type_offsets must span [0, n_nodes]");
     const gnn_mlp_t &no = a.net_output;
     TRY(check_mlp(no, "net_output", ws != nullptr));
-    if (no.in_dim != p.S) return fail("net_output.in_dim %d != state width %d (composite models filter on the state alone)", no.in_dim, p.S);
+    const bool arc = a.focus == GNN_FOCUS_ARC;      // CompositeGNN.py:315-327: [state_src | state_dst | arc label] of the masked arcs
+    const int expect_o = arc ? 2 * p.S + p.A : p.S;
+    if (no.in_dim != expect_o) return fail("net_output.in_dim %d != %d expected for this focus (composite models filter on the state alone)", no.in_dim, expect_o);
     p.T = no.units[no.n_layers - 1];
     p.pooled = a.focus == GNN_FOCUS_GRAPH;
     p.G = p.pooled ? a.nodegraph.n_dst : 0;
@@ -141,6 +143,7 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
     p.dpred = c.take<float>((size_t)std::max(p.R, 1) * p.T);
     p.loss_rows = c.take<float>(std::max(p.R, 1));
     p.loss_part = c.take<float>(256);
+    p.isrc = c.take<int>(arc ? std::max(p.M, 1) : 0); p.idst = c.take<int>(arc ? std::max(p.M, 1) : 0);
     p.part_floats = 0;
     for (int t = 0; t < p.n_types; ++t) {
         CType &y = p.ty[t];
@@ -170,7 +173,7 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
         p.sm_partBN[t] = c.take<float>(p.small ? (size_t)tiles_t * 2 * y.in_dim : 0);
     }
     // every node is an output row (out_index the identity: checked on the device, read with k), one thin Dense over the state alone
-    p.head_fast = p.big && no.n_layers == 1 && no.units[0] <= 4 && p.M == p.N && p.S % 4 == 0 && p.S / 4 <= 32;
+    p.head_fast = p.big && !arc && no.n_layers == 1 && no.units[0] <= 4 && p.M == p.N && p.S % 4 == 0 && p.S / 4 <= 32;
     p.part_h = c.take<float>(p.head_fast ? (size_t)BIG_HEAD_BLOCKS * ((size_t)no.in_dim * no.units[0] + no.units[0]) : 0);
     p.inv = c.take<int>((p.small || p.big) ? p.N : 0);
     if (p.big) {
@@ -529,6 +532,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
     if (a.state_dim > 0 && !a.state0) return fail("state0 is required when state_dim > 0");
     if (p.M > 0 && !a.out_index) return fail("out_index is NULL");
     if (p.E > 0 && p.A > 0 && !a.arc_labels) return fail("arc_labels is NULL");
+    if (a.focus == GNN_FOCUS_ARC && p.E > 0 && (!a.arc_src || !a.arc_dst)) return fail("arc focus needs arc_src / arc_dst");
     if (p.pooled) {
         if (a.nodegraph.n_src != p.M) return fail("graph focus: NodeGraph has %d rows but %d nodes pass the mask", a.nodegraph.n_src, p.M);
         TRY(check_csr(a.nodegraph, "nodegraph", p.G, p.M));
@@ -635,6 +639,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
         fa.states = p.states; fa.agg = p.agg; fa.eps = p.ty[0].m->bn_eps;
         fa.Cc = p.sm_cc; fa.thr = a.state_threshold; fa.flag0 = p.flags;
         fa.bar = p.sm_bar; fa.part = p.sm_part; fa.k_out = p.k_dev; fa.wait_ticks = gnn::wait_ticks();
+        if (const char *e = getenv("GNN_DEBUG_FAIL_FWD")) { if (e[0] == '1') fa.wait_ticks = 0; }      // (test hook: every barrier wait of THIS forward launch expires at once)
         switch (p.SPs) {
             case 16: TRY(launch_train_small_fwd_sq<1>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st, &yt)); break;
             case 32: TRY(launch_train_small_fwd_sq<2>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st, &yt)); break;
@@ -699,7 +704,23 @@ int train_step_composite(const gnn_train_args_t &ta) {
     if (!p.small) TRY(moving_state(nullptr));
 
     // ---- output network on the converged state of the masked nodes (CompositeGNN.py:237-239, :270), training mode --------------------
-    gnn::Seg osegs[1] = {gnn::Seg{state_k, a.out_index, p.S, p.S, 0}};
+    gnn::Seg osegs[3];
+    int nos = 0, n_state_segs = 0;
+    int bn_req_off[2] = {0, 0};                 // column offsets of the state segments inside the output net's input
+    const int *bn_req_idx[2] = {nullptr, nullptr};
+    if (a.focus == GNN_FOCUS_ARC && p.M > 0) {
+        k_arc_endpoints<<<cdiv(p.M, 256), 256, 0, st>>>(a.out_index, a.arc_src, a.arc_dst, p.M, p.isrc, p.idst);
+        LAUNCH_OK();
+        const int *ends[2] = {p.isrc, p.idst};
+        for (int e = 0; e < 2; ++e) {
+            bn_req_off[n_state_segs] = e * p.S; bn_req_idx[n_state_segs++] = ends[e];
+            osegs[nos++] = gnn::Seg{state_k, ends[e], p.S, p.S, e * p.S};
+        }
+        if (p.A > 0) osegs[nos++] = gnn::Seg{a.arc_labels, a.out_index, a.ld_arcs, p.A, 2 * p.S};
+    } else {
+        bn_req_off[0] = 0; bn_req_idx[0] = a.out_index; n_state_segs = 1;
+        osegs[nos++] = gnn::Seg{state_k, a.out_index, p.S, p.S, 0};
+    }
     float *ohs[GNN_MAX_LAYERS];
     for (int l = 0; l < no.n_layers; ++l) ohs[l] = (l == no.n_layers - 1 && !p.pooled) ? ta.y_pred : p.co.hid[l];
     float *out_nodes = ohs[no.n_layers - 1];
@@ -712,7 +733,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
                 gnn::k_stats_finish<<<p.S, 256, 0, st>>>(nullptr, p.B.part_y[0], grid, p.S, 1.0f / (float)p.N, p.stats_o, p.stats_o + no.in_dim, state_k);
                 LAUNCH_OK();
             } else
-            TRY(colstats_segs(nullptr, osegs, 1, p.M, p.stats_o, p.stats_o + no.in_dim, p.part, st));
+            TRY(colstats_segs(nullptr, osegs, nos, p.M, p.stats_o, p.stats_o + no.in_dim, p.part, st));
             TRY(fold_with_stats(no, p.stats_o, p.Wf_o, p.bf_o, st, true));
             if (!p.small) {
                 gnn::k_bn_moving_multi<<<cdiv(no.in_dim, 256), 256, 0, st>>>(p.stats_o, 2 * no.in_dim, 1, no.in_dim, const_cast<float *>(no.bn_mean),
@@ -721,7 +742,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
             }
             W0 = p.Wf_o; b0 = p.bf_o;
         }
-        TRY(forward_layers(no, osegs, 1, p.M, W0, b0, ohs, nullptr, st, nullptr, nullptr, bn_o ? p.stats_o : nullptr));
+        TRY(forward_layers(no, osegs, nos, p.M, W0, b0, ohs, nullptr, st, nullptr, nullptr, bn_o ? p.stats_o : nullptr));
     }
     if (p.pooled) TRY(launch_aggregate(nullptr, a.nodegraph, out_nodes, p.T, p.T, ta.y_pred, p.T, st));
     gnn::k_loss_grad<<<cdiv(std::max(p.R, 1), 256), 256, 0, st>>>(ta.loss_kind, ta.targets, ta.y_pred, ta.sample_weight, p.R, p.T, p.dpred, p.loss_rows);
@@ -745,11 +766,14 @@ int train_step_composite(const gnn_train_args_t &ta) {
     } else {
     HIP_OK(hipMemsetAsync(p.G_state, 0, sizeof(float) * (size_t)p.N * p.S, st));
     if (p.M > 0) {
-        TRY(net_backward(p.co, osegs, 1, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, no.in_dim, p.part, st));
-        gnn::BnGradReq rq[1] = {gnn::BnGradReq{p.dx_o_all, no.in_dim, state_k, p.S, a.out_index, p.S, 0}};
-        TRY(bn_input_grads(no, p.co, p.stats_o, rq, 1, p.M, st));
-        gnn::k_scatter_add_rows<<<std::min(cdiv((long)p.M * p.S, 256), 256 * 16), 256, 0, st>>>(p.dx_o_all, no.in_dim, a.out_index, p.M, p.S, p.G_state, p.S);
-        LAUNCH_OK();
+        TRY(net_backward(p.co, osegs, nos, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, no.in_dim, p.part, st));
+        gnn::BnGradReq rq[2];
+        for (int i = 0; i < n_state_segs; ++i) rq[i] = gnn::BnGradReq{p.dx_o_all + bn_req_off[i], no.in_dim, state_k, p.S, bn_req_idx[i], p.S, bn_req_off[i]};
+        TRY(bn_input_grads(no, p.co, p.stats_o, rq, n_state_segs, p.M, st));
+        for (int i = 0; i < n_state_segs; ++i) {     // (an arc's two end nodes, one after the other: the additions to a node's row stay ordered)
+            gnn::k_scatter_add_rows<<<std::min(cdiv((long)p.M * p.S, 256), 256 * 16), 256, 0, st>>>(p.dx_o_all + bn_req_off[i], no.in_dim, bn_req_idx[i], p.M, p.S, p.G_state, p.S);
+            LAUNCH_OK();
+        }
     } else TRY(zero_grads(no, ta.grad_output, st));
     }
     for (int q = 0; q < p.n_types; ++q)

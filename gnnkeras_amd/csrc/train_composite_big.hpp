@@ -26,8 +26,8 @@
 namespace {
 
 inline bool composite_big_enabled() {      // GNN_TRAIN_COMPOSITE_BIG=0: large heterogeneous graphs stay on the general kernels (one launch per layer, type and iteration)
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_TRAIN_COMPOSITE_BIG"); v = (e && e[0] == '0') ? 0 : 1; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_TRAIN_COMPOSITE_BIG"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
 

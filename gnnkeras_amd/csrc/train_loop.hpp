@@ -58,20 +58,20 @@ struct TrainPlan {
 
 // From this many nodes on a training iteration is bandwidth work and runs the row-streaming kernels (GNN_TRAIN_BIG_MIN_NODES).
 inline int train_big_min_nodes() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_TRAIN_BIG_MIN_NODES"); v = e ? atoi(e) : 32768; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_TRAIN_BIG_MIN_NODES"); v = e ? atoi(e) : 32768; }
     return v;
 }
 constexpr int BIG_AGG_BLOCKS = 4096, BIG_FWD_BLOCKS = 1024, BIG_WGRAD_BLOCKS = 512, BIG_HEAD_BLOCKS = 2048;
 inline bool train_wgrad_enabled() {       // GNN_TRAIN_WGRAD=0: the round-2 weight-gradient kernels (k_act_grad + k_dense_grad_allk) at large M too
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_TRAIN_WGRAD"); v = (e && e[0] == '0') ? 0 : 1; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_TRAIN_WGRAD"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
 // The persistent small-graph kernels need every workgroup resident: one 64-node tile per CU (GNN_TRAIN_SMALL=0 switches them off).
 inline bool train_small_enabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_TRAIN_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_TRAIN_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
 
@@ -427,8 +427,8 @@ int state_segs(const gnn_loop_args_t &a, const TrainPlan &p, int t, gnn::Seg *se
 // the gathers with their eight source ids, then their eight rows requested together through buffer descriptors (kernels_general.hpp
 // gather_sum8<.., BUF>): the arrays must fit 4 GiB windows; GNN_GATHER_BUF=0 keeps the pointer form (a dependent pair of round trips per arc)
 inline bool gather_buf_enabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_GATHER_BUF"); v = (e && e[0] == '0') ? 0 : 1; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_GATHER_BUF"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
 inline bool gather_buf_ok(const gnn_csr_t &c, int ldx) {
@@ -474,8 +474,8 @@ int launch_train_fwd_sq(const gnn::TrainFwdArgs &fa, int grid, hipStream_t st) {
 
 // GNN_TRAIN_BF16X6=0: the exact-f32 MFMA kernels (k_train_fwd ..) instead of the three-term bf16 split on the bf16 matrix cores
 inline bool train_bf16x6_enabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_TRAIN_BF16X6"); v = (e && e[0] == '0') ? 0 : 1; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_TRAIN_BF16X6"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
 
@@ -571,8 +571,8 @@ bool launch_train_wgrad32_nb(const gnn::TrainWgradArgs &wa, int grid, hipStream_
     }
 }
 inline bool train_wgrad32_enabled() {       // GNN_TRAIN_WGRAD32=0: k_train_wgrad (16x16x4) at every width
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_TRAIN_WGRAD32"); v = (e && e[0] == '0') ? 0 : 1; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_TRAIN_WGRAD32"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
 bool launch_train_wgrad32(const gnn::TrainWgradArgs &wa, int S, int grid, hipStream_t st) {
@@ -609,8 +609,8 @@ bool launch_train_wgrad_b6_nb(const gnn::TrainWgradArgs &wa, int grid, hipStream
     }
 }
 inline bool train_wgrad_b6_enabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_TRAIN_WGRAD_B6"); v = (e && e[0] == '0') ? 0 : 1; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_TRAIN_WGRAD_B6"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0 && train_bf16x6_enabled() && train_wgrad32_enabled();
 }
 bool launch_train_wgrad_b6(const gnn::TrainWgradArgs &wa, int S, int grid, hipStream_t st) {
@@ -621,8 +621,8 @@ bool launch_train_wgrad_b6(const gnn::TrainWgradArgs &wa, int S, int grid, hipSt
 
 // weight gradient and input gradient of an iteration in one pass over its rows (k_train_wgrad_dx_b6; the dZ form; GNN_TRAIN_FUSED_BWD=0: the two kernels)
 inline bool train_fused_bwd_enabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_TRAIN_FUSED_BWD"); v = (e && e[0] == '0') ? 0 : 1; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_TRAIN_FUSED_BWD"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
 template <int NB>
@@ -674,8 +674,8 @@ int launch_train_bwd_dx(const gnn::TrainBwdArgs &ba, int S, hipStream_t st) {
 
 // G_{t-1} -> dZ_{t-1} in the transposed aggregate's epilogue (kernels_train_big.hpp: k_aggregate_dz); false: no instance for this shape
 inline bool train_dz_enabled() {          // GNN_TRAIN_DZ=0: the round-4 flow (every dense kernel forms dZ itself, the last iteration's dx is still computed)
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GNN_TRAIN_DZ"); v = (e && e[0] == '0') ? 0 : 1; }
+    int v = -1;      // (read at every call: tests switch it inside one process)
+    { const char *e = getenv("GNN_TRAIN_DZ"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
 template <int LPR, bool HAS_W>
@@ -841,9 +841,23 @@ size_t gnn_train_workspace_bytes(const gnn_train_args_t *args) {
     return p.bytes;
 }
 
+static int train_step_impl(const gnn_train_args_t &ta);
+
 int gnn_train_step(const gnn_train_args_t *args) {
     if (!args) return fail("args is NULL");
-    const gnn_train_args_t &ta = *args;
+    const int rc = train_step_impl(*args);
+    // A call that fails behind its first launches has already fetched the previous step's validity word into *prev_grads_ok_host and reset
+    // the word on the tape: the copy must have LANDED when the caller looks at it (the caller's own view of the word is stale by then).  A call
+    // that fails in front of them leaves *prev_grads_ok_host as the caller initialised it (a sentinel) and the word on the tape untouched.
+    if (rc != 0 && args->prev_grads_ok_host && args->tape) {
+        const std::string msg = gnn_last_error();                 // (the synchronisation must not replace the message)
+        (void)hipStreamSynchronize((hipStream_t)args->loop.stream);
+        fail("%s", msg.c_str());
+    }
+    return rc;
+}
+
+static int train_step_impl(const gnn_train_args_t &ta) {
     const gnn_loop_args_t &a = ta.loop;
     TrainPlan p;
     if (!ta.tape || ((uintptr_t)ta.tape & 255) != 0) return fail("tape must be a 256-byte aligned device buffer");
@@ -989,6 +1003,7 @@ int gnn_train_step(const gnn_train_args_t *args) {
         fa.W = ns.kernel[0]; fa.gamma = bn_s ? ns.bn_gamma : nullptr; fa.beta = ns.bn_beta; fa.eps = ns.bn_eps; fa.act = ns.activation[0];
         fa.Cc = p.sm_cc; fa.thr = a.state_threshold; fa.flag0 = p.flags;
         fa.bar = p.sm_bar; fa.part = p.sm_part; fa.k_out = p.k_dev; fa.wait_ticks = gnn::wait_ticks();
+        if (const char *e = getenv("GNN_DEBUG_FAIL_FWD")) { if (e[0] == '1') fa.wait_ticks = 0; }      // (test hook: every barrier wait of THIS forward launch expires at once)
         switch (p.SPs) {
             case 16: TRY(launch_train_small_fwd_sq<1>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st)); break;
             case 32: TRY(launch_train_small_fwd_sq<2>(fa, tiles, p.n_wg, a.adjacency.w != nullptr, st)); break;

@@ -233,6 +233,9 @@ int gnn_state_step_agg(const gnn_loop_args_t *args, const float *state_in, const
  * kernels wait for each other inside a launch; their waits are bounded by GNN_WAIT_MS (environment, default 2 000; 0 = expire at
  * once) and an expired wait comes back as k < 0 (gnn_loop_args_t::k_out) - the recovery tests drive both with this. */
 int gnn_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t milliseconds, void *stream);
+/* ... until the DEVICE word *release_flag becomes non-zero (the test writes it from another stream when ITS condition holds - a co-tenant
+ * that leaves on a handshake, not on a clock), at the latest after max_milliseconds (<= 20 000: the kernel cannot hang the GPU). */
+int gnn_debug_occupy_until(int32_t n_workgroups, int32_t lds_bytes, int32_t max_milliseconds, const int32_t *release_flag, void *stream);
 
 /* ---- node-range sharded loop -------------------------------------------------------------------------
  * One process per GPU; rank r owns a contiguous node range and, per iteration, (1) runs gnn_shard_iteration on its

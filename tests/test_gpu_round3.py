@@ -403,17 +403,15 @@ def test_large_graph_training_step_matches_autograd(d, bn, mode, thr):
     res, want = check_step(model, x, y, sw, s0)               # both orchestrations against the oracle
 
 
-def test_small_graph_training_on_the_large_graph_kernels_in_a_child_process():
-    """GNN_TRAIN_BIG_MIN_NODES=0 (read once per process, hence the child) sends every eligible model of the gradient tests - MUTAG
-    batches, all three foci, with and without BatchNormalization, early exit, fit() - through the large-graph kernels."""
-    import os, subprocess, sys
-    root = os.path.dirname(nat.HERE)
-    env = dict(os.environ, GNN_TRAIN_BIG_MIN_NODES='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
-    sel = 'gradients_single_layer or fit_reduces_loss or adam_step or call_training_true or inference_after_training'
-    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_training.py'), '-m', 'gpu', '-q', '-x', '-k', sel],
-                         capture_output=True, text=True, env=env, cwd=root, timeout=1500)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
-    assert ' passed' in res.stdout
+def test_small_graph_training_on_the_large_graph_kernels(mutag_graphs, monkeypatch):
+    """GNN_TRAIN_BIG_MIN_NODES=0 (read at every call) sends the eligible models of the gradient tests - MUTAG batches, all three foci, with
+    and without BatchNormalization, the Adam step, fit(), inference afterwards - through the large-graph kernels (ragged tiny row counts)."""
+    import test_gpu_training as T
+    monkeypatch.setenv('GNN_TRAIN_BIG_MIN_NODES', '0')
+    for focus, bn in (('g', True), ('n', False), ('a', True)): T.test_gradients_single_layer(mutag_graphs, focus, bn)
+    T.test_adam_step_matches_reference_formula(mutag_graphs)
+    T.test_fit_reduces_loss_starter_config(mutag_graphs, True)
+    T.test_inference_after_training_matches_oracle(mutag_graphs)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -482,16 +480,13 @@ def test_tiles_with_an_arc_that_leaves_its_tile_fail_loudly(mutag_graphs):
     LoopTrainer(model).train_step(x, y, sw, apply=False, seed=1)
 
 
-def test_small_graph_training_with_the_persistent_kernels_switched_off_in_a_child_process():
+def test_small_graph_training_with_the_persistent_kernels_switched_off(mutag_graphs, monkeypatch):
     """GNN_TRAIN_SMALL=0 keeps the per-iteration launches of round 2 (the path wide / deep state networks still take): the same
     gradient tests pass on it."""
-    import os, subprocess, sys
-    root = os.path.dirname(nat.HERE)
-    env = dict(os.environ, GNN_TRAIN_SMALL='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
-    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_training.py'), '-m', 'gpu', '-q', '-x', '-k',
-                          'gradients_single_layer or fit_reduces_loss'], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
-    assert ' passed' in res.stdout
+    import test_gpu_training as T
+    monkeypatch.setenv('GNN_TRAIN_SMALL', '0')
+    for focus, bn in (('g', True), ('n', True), ('a', False)): T.test_gradients_single_layer(mutag_graphs, focus, bn)
+    T.test_fit_reduces_loss_starter_config(mutag_graphs, False)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -171,21 +171,27 @@ def test_c3_at_the_timed_depth_every_path(request, mode):
 
 def test_c4_at_the_timed_depth_vs_fp64_oracle(request):
     """BASELINE C4 (1 M nodes / 10 M arcs, d = 64): the 50 iterations of the bench line on the default path (the wave-specialised
-    kernel with the constant inputs multiplied in) and the un-fused kernels against the float64 oracle (scipy row order)."""
+    kernel with the constant inputs multiplied in), the un-fused kernels and the generation-2 fused kernel against the float64 oracle
+    (scipy row order); the default path twice: the same bits."""
     r = _deep(request)
     model, x, s0, K = r['model'], r['x'], r['s0'], _DEEP_K
     k64, st64, o64 = r['r64']
     assert float(k64) == K
     inputs = model.process_inputs(x)
     res = {}
-    for flags in (0, nat.FLAG_UNFUSED):
+    for flags in (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2):
         model.native_flags = flags
         k, st, o = model.Loop(*inputs, state0=dev(s0))
         assert float(k) == K
-        if flags == 0: assert _last_kernel().startswith('k_state_fused4<64'), _last_kernel()
+        if flags == 0:
+            assert _last_kernel().startswith('k_state_fused4<64'), _last_kernel()
+            k2, st2, o2 = model.Loop(*inputs, state0=dev(s0))                  # the loop is deterministic: the same bits run to run
+            assert torch.equal(st, st2) and torch.equal(o, o2)
+            del st2, o2
         res[flags] = (rel_err(st.cpu().numpy(), st64), rel_err(o.cpu().numpy(), o64))
     print(f'\nC4 k={K} vs fp64 oracle ({r["t"]:.0f} s): default state {res[0][0]:.2e} out {res[0][1]:.2e}; '
-          f'un-fused state {res[nat.FLAG_UNFUSED][0]:.2e} out {res[nat.FLAG_UNFUSED][1]:.2e}; max|state| {np.abs(st64).max():.2f}')
+          f'un-fused state {res[nat.FLAG_UNFUSED][0]:.2e} out {res[nat.FLAG_UNFUSED][1]:.2e}; generation 2 state {res[nat.FLAG_FUSED_GEN2][0]:.2e} out '
+          f'{res[nat.FLAG_FUSED_GEN2][1]:.2e}; max|state| {np.abs(st64).max():.2f}')
     for flags, e in res.items(): assert max(e) <= TOL, (flags, e)
 
 
@@ -205,10 +211,14 @@ def test_c5_at_the_timed_depth_vs_fp64_oracle(request, mode):
     ref_st, ref_o = rel_err(st32, st64), rel_err(o32, o64)          # what float32 itself loses: the reference's arithmetic against float64
     inputs = model.process_inputs(x)
     res = {}
-    for flags in (0, nat.FLAG_UNFUSED):
+    for flags in (0, nat.FLAG_UNFUSED, nat.FLAG_FUSED_GEN2):
         model.native_flags = flags
         k, st, o = model.Loop(*inputs, state0=dev(s0))
         assert float(k) == K
+        if flags == 0:
+            k2, st2, o2 = model.Loop(*inputs, state0=dev(s0))                  # deterministic: the same bits run to run
+            assert torch.equal(st, st2) and torch.equal(o, o2)
+            del st2, o2
         res[flags] = (rel_err(st.cpu().numpy(), st64), rel_err(o.cpu().numpy(), o64))
     print(f'\nC5 {mode} k={K} vs fp64 oracle ({r["t"]:.0f} s): default state {res[0][0]:.2e} out {res[0][1]:.2e}; '
           f'un-fused state {res[nat.FLAG_UNFUSED][0]:.2e} out {res[nat.FLAG_UNFUSED][1]:.2e}; float32 oracle vs float64 oracle: '
@@ -604,17 +614,11 @@ print('RECOVERED_OK')
     assert r.returncode == 0 and 'RECOVERED_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize('hold_ms', [600, 2600])
-def test_a_co_tenant_holding_most_cus_does_not_break_predict(mutag_graphs, hold_ms):
-    """A foreign kernel on a second stream keeps 100 KB of the LDS of all but ONE CU for `hold_ms` (the set-up kernels still fit next to it, a group's 90+ KB do not): the one-launch MUTAG walk (256 groups,
-    one CU each, group sets that wait for each other) cannot be resident at once while it runs.  600 ms: inside the wait bound
-    (GNN_WAIT_MS, 2 000 ms by default) - the launch simply completes once the CUs come back.  2 600 ms: past the bound - a group that
-    starts to wait for a member of its set in the first 600 ms sees its wait expire, and predict() repeats the walk on the per-iteration
-    kernels; whether one does depends on how far the single free CU has got through the groups that wait for nobody (alone, this test
-    recovers every time; inside the whole suite two runs in a dozen completed the walk at 2 551 / 4 151 ms - with a 4 200 ms hold - without
-    an expired wait).  Both outcomes are legitimate and checked: recovered -> a RuntimeWarning and the outputs within the tolerance of another
-    summation order, not recovered -> the undisturbed bits.  The recovery itself has a deterministic test (GNN_WAIT_MS=0, above)."""
-    import warnings
+def _co_tenant_walk(mutag_graphs):
+    """The one-launch MUTAG walk (256 groups, one CU each, group sets that wait for each other) and a co-tenant on a second stream that keeps
+    100 KB of the LDS of all but ONE CU (the set-up kernels still fit next to it, a group's 90+ KB do not) until the DEVICE word `flag`
+    becomes non-zero: the walk cannot be resident at once while it is there.  The co-tenant leaves on the test's handshake, not on a clock
+    (its own 15 s bound only keeps it from hanging the GPU)."""
     gs = [g.copy() for g in mutag_graphs]
     for g in gs: g.setAggregation('average')
     seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False)
@@ -624,25 +628,70 @@ def test_a_co_tenant_holding_most_cus_does_not_break_predict(mutag_graphs, hold_
     plan = model._group_plan(seq, torch.device('cuda', 0))
     assert plan[0].resident and plan[0].parts, 'the walk should contain groups that wait for each other (sets)'
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    side = torch.cuda.Stream()
+    side, rel = torch.cuda.Stream(), torch.cuda.Stream()
+    flag = torch.zeros(4, dtype=torch.int32, device='cuda')
     torch.cuda.synchronize()
-    nat.check(nat.lib().gnn_debug_occupy(cus - 1, 100 * 1024, hold_ms, C.c_void_p(side.cuda_stream)))
+    nat.check(nat.lib().gnn_debug_occupy_until(cus - 1, 100 * 1024, 15000, C.c_void_p(flag.data_ptr()), C.c_void_p(side.cuda_stream)))
     time.sleep(0.05)                                        # (the co-tenant is on the CUs before the walk is launched)
+
+    def release():
+        with torch.cuda.stream(rel): flag.fill_(1)
+    return model, seq, want, release, cus
+
+
+def test_a_co_tenant_that_leaves_inside_the_wait_bound_costs_time_only(mutag_graphs):
+    """The co-tenant is released 300 ms after predict() was called - far inside the wait bound (GNN_WAIT_MS, 2 000 ms by default): the groups
+    that wait for the members of their sets see them arrive once the CUs come back, no wait expires, the launch completes with the
+    undisturbed bits and nothing is recovered."""
+    import threading, warnings
+    model, seq, want, release, cus = _co_tenant_walk(mutag_graphs)
+    timer = threading.Timer(0.3, release)
     t0 = time.time()
+    timer.start()
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            torch.manual_seed(1); got = model.predict(seq)
+    finally:
+        timer.join(); release(); torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f'\nco-tenant on {cus - 1} CUs, released after 300 ms: predict() took {dt * 1e3:.0f} ms, recovered walks {getattr(model, "recovered_walks", 0)}')
+    assert getattr(model, 'recovered_walks', 0) == 0 and not [x for x in w if issubclass(x.category, RuntimeWarning)]
+    assert np.array_equal(got, want)
+    assert dt >= 0.25                                       # (the walk really waited for the co-tenant)
+
+
+def test_a_co_tenant_that_stays_makes_the_walk_expire_and_predict_recover(mutag_graphs):
+    """The co-tenant is released only once predict() has SEEN a wait expire (a watcher thread releases it when the RuntimeWarning of the
+    recovery appears - never before): with one free CU a group that waits for the other members of its set can never see them arrive - its
+    wait expires at the bound (GNN_WAIT_MS), the launch comes back with k < 0, and predict() repeats the walk on the per-iteration kernels
+    with a RuntimeWarning - outputs within the tolerance of another summation order.  Were no wait to expire, the co-tenant would stay for
+    its own 15 s bound and the assertions below fail."""
+    import threading, warnings
+    model, seq, want, release, cus = _co_tenant_walk(mutag_graphs)
+    t0 = time.time()
+    done = threading.Event()
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
-        torch.manual_seed(1); got = model.predict(seq)
+
+        def watch():
+            while not done.is_set():
+                if any(issubclass(x.category, RuntimeWarning) for x in list(w)):
+                    release(); return
+                time.sleep(0.005)
+        watcher = threading.Thread(target=watch, daemon=True)
+        watcher.start()
+        try:
+            torch.manual_seed(1); got = model.predict(seq)
+        finally:
+            done.set(); watcher.join(); release(); torch.cuda.synchronize()
     dt = time.time() - t0
-    torch.cuda.synchronize()
-    recovered = getattr(model, 'recovered_walks', 0)
-    print(f'\nco-tenant on {cus - 1} CUs for {hold_ms} ms: predict() took {dt * 1e3:.0f} ms, recovered walks {recovered}, '
+    print(f'\nco-tenant on {cus - 1} CUs until a wait had expired: predict() took {dt * 1e3:.0f} ms, recovered walks {getattr(model, "recovered_walks", 0)}, '
           f'warnings {[str(x.message)[:60] for x in w]}')
-    if recovered:
-        assert rel_err(got, want) <= TOL              # (other kernels, another summation order)
-    else:
-        assert np.array_equal(got, want)
-    if hold_ms < 2000: assert recovered == 0
-    else: assert recovered in (0, 1) and (recovered == 0 or any(issubclass(x.category, RuntimeWarning) for x in w))
+    assert dt < 10.0                                        # (the co-tenant left on the handshake, not on its own bound)
+    assert getattr(model, 'recovered_walks', 0) == 1
+    assert any(issubclass(x.category, RuntimeWarning) for x in w)
+    assert rel_err(got, want) <= TOL              # (other kernels, another summation order)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -976,21 +1025,19 @@ def test_large_graph_training_with_labels_far_from_zero():
     check_step(model, x, y, sw, s0)
 
 
-def test_large_graph_training_on_the_f32_mfma_kernels_in_a_child_process():
-    """GNN_TRAIN_BF16X6=0 GNN_TRAIN_WGRAD32=0 (read once per process, hence the child): the large-graph training tests on the exact-f32
-    kernels the bf16-split ones replaced by default (k_train_fwd / k_train_bwd_dx / k_train_wgrad: the same centred arithmetic).
-    ALL of them since round 5: two configurations (..step_matches_autograd[64-True-average-0.0], ..every_activation[relu-64]) used to be
-    deselected here because each has ONE element whose float32 pre-activation lands on the other side of a selu / relu kink than the float64
-    one (|z| < 1e-7; that element moves its unit's gradients by 2.4e-5 absolute, profiles/r04_notes.txt 7) - the bars now carry an explicit
-    allowance for exactly the elements the oracle counts inside its kink window (test_gpu_training.grad_rows) instead."""
-    import os, subprocess, sys
-    root = os.path.dirname(nat.HERE)
-    env = dict(os.environ, GNN_TRAIN_BF16X6='0', GNN_TRAIN_WGRAD32='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
-    sel = 'large_graph_training_step_matches_autograd or every_activation or far_from_zero or thin_output_head'
-    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_round3.py'), os.path.join(root, 'tests', 'test_gpu_round4.py'),
-                          '-m', 'gpu', '-q', '-x', '-k', sel], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
-    assert ' passed' in res.stdout
+def test_large_graph_training_on_the_f32_mfma_kernels(monkeypatch):
+    """GNN_TRAIN_BF16X6=0 GNN_TRAIN_WGRAD32=0 (read at every call): the large-graph training step on the exact-f32 kernels the bf16-split
+    ones replaced by default (k_train_fwd / k_train_bwd_dx / k_train_wgrad: the same centred arithmetic; state width 16 runs them by
+    default) - one configuration per kernel instance and feature: widths 64 / 32 with and without BatchNormalization (early exit included),
+    an activation with a kink, labels far from zero, a thin head over every node.  Against the same float64 autograd oracle and bars."""
+    from test_gpu_round3 import test_large_graph_training_step_matches_autograd as step
+    monkeypatch.setenv('GNN_TRAIN_BF16X6', '0'); monkeypatch.setenv('GNN_TRAIN_WGRAD32', '0')
+    step(64, True, 'average', 0.0)
+    step(32, False, 'average', -1.0)
+    step(32, True, 'sum', 0.0)
+    test_large_graph_training_kernels_for_every_activation('relu', 64)
+    test_large_graph_training_with_labels_far_from_zero()
+    test_thin_output_head_over_every_node_matches_autograd(64, True, 'n', 2, 'categorical_crossentropy', 0.0)
 
 
 @pytest.mark.parametrize('dim_arc_label,bn', [(4, True), (4, False)])

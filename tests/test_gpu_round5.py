@@ -440,19 +440,18 @@ def test_composite_small_graph_training_persistent_kernels_match_autograd(focus,
 
 
 
-def test_large_graph_training_with_every_dense_kernel_forming_dz_itself_in_a_child_process():
-    """GNN_TRAIN_DZ=0 (read once per process, hence the child): the round-4 flow of the large-graph backward sweep - the weight-gradient and
-    input-gradient kernels each form dZ = G (.) act'(Y) from G and Y, k_train_bwd_dx applies the whole BatchNorm input gradient, the plain
-    transposed aggregate - which round 5 replaced by default with k_aggregate_dz (the aggregate's epilogue leaves dZ, the state half's
-    BatchNorm term is added there).  Both flows against the same float64 autograd oracle."""
-    import subprocess, sys
-    root = os.path.dirname(nat.HERE)
-    env = dict(os.environ, GNN_TRAIN_DZ='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
-    sel = 'large_graph_training_step_matches_autograd or (thin_output_head and 64-True) or (every_activation and relu-64)'       # (sized for the suite's budget)
-    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_round3.py'), os.path.join(root, 'tests', 'test_gpu_round4.py'),
-                          '-m', 'gpu', '-q', '-x', '-k', sel], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
-    assert ' passed' in res.stdout
+def test_large_graph_training_with_every_dense_kernel_forming_dz_itself(monkeypatch):
+    """GNN_TRAIN_DZ=0 (read at every call): the round-4 flow of the large-graph backward sweep - the weight-gradient and input-gradient
+    kernels each form dZ = G (.) act'(Y) from G and Y, k_train_bwd_dx applies the whole BatchNorm input gradient, the plain transposed
+    aggregate - which round 5 replaced by default with k_aggregate_dz (the aggregate's epilogue leaves dZ, the state half's BatchNorm
+    term is added there) and which models without constant inputs still take.  Both flows against the same float64 autograd oracle."""
+    from test_gpu_round3 import test_large_graph_training_step_matches_autograd as step
+    from test_gpu_round4 import test_thin_output_head_over_every_node_matches_autograd as head, test_large_graph_training_kernels_for_every_activation as act
+    monkeypatch.setenv('GNN_TRAIN_DZ', '0')
+    step(64, True, 'average', 0.0)
+    step(32, False, 'average', -1.0)
+    head(64, True, 'n', 2, 'categorical_crossentropy', 0.0)
+    act('relu', 64)
 
 
 @pytest.mark.parametrize('d', [64, 32])
@@ -466,17 +465,14 @@ def test_large_graph_training_without_batchnorm_takes_both_gradients_in_one_pass
     run(d, False, 'sum', 0.0)
 
 
-def test_large_graph_training_on_the_kernels_before_the_lds_ring_in_a_child_process():
-    """GNN_TRAIN_WGRAD_B6=0 GNN_TRAIN_FUSED_BWD=0 (read once per process, hence the child): the weight gradient on the f32-input matrix
-    instructions (k_train_wgrad32) and the two-kernel backward pass stay selectable; the same tests against the same oracle."""
-    import subprocess, sys
-    root = os.path.dirname(nat.HERE)
-    env = dict(os.environ, GNN_TRAIN_WGRAD_B6='0', GNN_TRAIN_FUSED_BWD='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
-    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_round3.py'), os.path.join(root, 'tests', 'test_gpu_round5.py'),
-                          '-m', 'gpu', '-q', '-x', '-k', '(large_graph_training_step_matches_autograd and (64-True or 32-True)) or (takes_both_gradients_in_one_pass and 64)'],
-                         capture_output=True, text=True, env=env, cwd=root, timeout=1500)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
-    assert ' passed' in res.stdout
+def test_large_graph_training_on_the_kernels_before_the_lds_ring(monkeypatch):
+    """GNN_TRAIN_WGRAD_B6=0 GNN_TRAIN_FUSED_BWD=0 (read at every call): the weight gradient on the f32-input matrix instructions
+    (k_train_wgrad32) and the two-kernel backward pass stay selectable; the same tests against the same oracle."""
+    from test_gpu_round3 import test_large_graph_training_step_matches_autograd as step
+    monkeypatch.setenv('GNN_TRAIN_WGRAD_B6', '0'); monkeypatch.setenv('GNN_TRAIN_FUSED_BWD', '0')
+    step(64, True, 'average', 0.0)
+    step(32, True, 'sum', 0.0)
+    step(64, False, 'average', 0.0)
 
 
 @pytest.mark.parametrize('N,d,bn,mode', [(40_037, 64, True, 'average'), (33_001, 32, True, 'average'), (40_037, 64, False, 'average'),

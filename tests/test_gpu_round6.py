@@ -189,3 +189,37 @@ def test_composite_train_step_at_c5_size(request):
         set_composite_weights(model, w0)
         summary, _ = composite_compare(model, x, y, sw, s0, want, native, tag='c5_train_step', path='row-streaming')
         print(f"  {'gnn_train_step ' if native else 'building blocks'} {summary}")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a good step followed by a step whose FORWARD launch fails must not re-train the good step's batch
+# ----------------------------------------------------------------------------------------------------------------------
+def test_a_failed_forward_launch_does_not_condemn_the_step_before_it(mutag_graphs, monkeypatch):
+    """Step 1 succeeds on the persistent kernels and stays pending (its validity word is fetched by the next call).  Step 2's forward launch
+    fails (GNN_DEBUG_FAIL_FWD=1: every barrier wait of that launch expires at once) - AFTER the call has fetched step 1's word and reset
+    the word on the tape for itself.  The handler must judge step 1 by what the call fetched (valid), not by the word the call has just
+    zeroed: exactly one recovery (step 2's own batch, on the general kernels), one optimizer update per batch, and the weights of a twin
+    that trained batch 0 in the library and batch 1 on the building blocks."""
+    from test_gpu_round5 import _mutag_model, _weights
+    from gnnkeras_amd.Models.training import Adam
+    model, seq = _mutag_model(mutag_graphs, Adam(0.01))
+    twin, _ = _mutag_model(mutag_graphs, Adam(0.01))
+    s0 = [torch.from_numpy(np.random.default_rng(i).normal(0, 0.1, (seq[i][0][0].shape[0], 32)).astype(np.float32)).cuda() for i in range(2)]
+    model.train_step(seq[0], state0=s0[0])
+    tr = model._trainer
+    assert tr._pending is not None and int(tr._pending['view'].item()) == 1
+    monkeypatch.setenv('GNN_DEBUG_FAIL_FWD', '1')
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        model.train_step(seq[1], state0=s0[1])
+    monkeypatch.delenv('GNN_DEBUG_FAIL_FWD')
+    msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+    assert len(msgs) == 1 and 'could not keep their workgroups resident' in msgs[0], msgs        # (not 'its gradients were discarded': step 1 was fine)
+    assert tr.recovered_steps == 1 and model._optimizer_obj().iterations == 2
+    twin.train_step(seq[0], state0=s0[0])
+    twin._trainer.resolve_pending()
+    twin._trainer.use_native_step = False
+    twin.train_step(seq[1], state0=s0[1])
+    for a, b in zip(_weights(model), _weights(twin)):
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-6), float(np.max(np.abs(a - b)))

@@ -407,8 +407,8 @@ def test_fit_reduces_loss_starter_config(mutag_graphs, bn):
 @pytest.mark.parametrize('bn', [False, True])
 def test_composite_gradients(focus, bn, native):
     """Both orchestrations against torch autograd in float64: the device building blocks driven from Python (`native=False`) and the
-    whole step inside the library (`gnn_train_step` with `composite`, csrc/train_composite.hpp; node / graph focus - an arc-focused
-    model takes the building blocks either way)."""
+    whole step inside the library (`gnn_train_step` with `composite`, csrc/train_composite.hpp; node, graph and - round 6 - arc focus:
+    CompositeGNN.py:315-327)."""
     from gnnkeras_amd import CompositeGraphObject
     from gnnkeras_amd.Models.CompositeGNN import CompositeGNNnodeBased, CompositeGNNarcBased, CompositeGNNgraphBased
     from gnnkeras_amd.Models.training import LoopTrainer
@@ -452,7 +452,7 @@ def test_composite_gradients(focus, bn, native):
         loss='categorical_crossentropy')
     tr = LoopTrainer(model)
     tr.use_native_step = native
-    assert tr._native_step_applies(y) == (native and focus != 'a')
+    assert tr._native_step_applies(y) == native
     res = tr.train_step(x, y, sw, state0=torch.from_numpy(s0).cuda(), apply=False)
     assert res['k'] == want['k'] == 5
     assert abs(float(res['loss']) - want['loss']) <= 1e-5 * max(1.0, abs(want['loss']))

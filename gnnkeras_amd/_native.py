@@ -27,7 +27,7 @@ FLAG_FUSED_GEN_MASK = 7 << 4
 FLAG_FUSED_GEN2, FLAG_FUSED_GEN4, FLAG_FUSED_GEN5, FLAG_FUSED_GEN6, FLAG_FUSED_GEN7 = 2 << 4, 4 << 4, 5 << 4, 6 << 4, 7 << 4     # pin the fused-kernel generation (tests, tuning)
 
 EXPORTS = ['gnn_last_error', 'gnn_last_kernel_name', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_loop_groups_supported', 'gnn_aggregate',
-           'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_step_agg', 'gnn_state_ld', 'gnn_debug_occupy', 'gnn_debug_occupy_until', 'gnn_shard_iteration_split_rows',
+           'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_step_agg', 'gnn_state_ld', 'gnn_debug_occupy', 'gnn_debug_occupy_until', 'gnn_debug_expiry_beacon', 'gnn_shard_iteration_split_rows',
            'gnn_shard_setup', 'gnn_shard_iteration', 'gnn_shard_output', 'gnn_gather_rows',
            'gnn_shard_can_split', 'gnn_shard_partial', 'gnn_shard_iteration_split',
            'gnn_dense', 'gnn_fold_bn', 'gnn_dense_grad_workspace_bytes', 'gnn_dense_grad', 'gnn_act_grad',
@@ -190,6 +190,8 @@ def lib():
         l.gnn_debug_occupy.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         l.gnn_debug_occupy_until.restype = C.c_int
         l.gnn_debug_occupy_until.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        l.gnn_debug_expiry_beacon.restype = C.c_int
+        l.gnn_debug_expiry_beacon.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]
         l.gnn_state_step_agg.restype = C.c_int
         l.gnn_state_step_agg.argtypes = [C.POINTER(LoopArgs), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         l.gnn_state_ld.restype = C.c_int32

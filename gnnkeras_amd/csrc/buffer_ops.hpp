@@ -67,6 +67,11 @@ __device__ __forceinline__ void buf_st_sc1(__amdgpu_buffer_rsrc_t r, unsigned of
 // co-tenant - `budget_ticks` comes from GNN_WAIT_MS (default 2 000 ms; the old bound of 2^22 polls was ~0.4 s) - while a protocol
 // bug or a launch that can never be resident still ends, loudly (k < 0), instead of hanging the GPU.  budget_ticks == 0 (GNN_WAIT_MS=0)
 // makes every wait expire at once, satisfied or not: the test hook that drives the callers' recovery paths.
+// Set (never cleared by a kernel) when a wait below runs out of its budget: a device word a TEST can hand to gnn_debug_occupy_until as the
+// co-tenant's release flag - the co-tenant then leaves exactly when the first wait of the launch under test has expired (include/gnnloop.h:
+// gnn_debug_expiry_beacon).  One relaxed store on the failure path; nothing on the path that is waited through.
+__device__ int g_wait_expired_beacon;
+
 template <typename Done>
 __device__ __forceinline__ bool wait_until(unsigned long long budget_ticks, Done done) {
     if (budget_ticks == 0) return false;
@@ -80,7 +85,7 @@ __device__ __forceinline__ bool wait_until(unsigned long long budget_ticks, Done
         if ((spin & 63) == 63) {
             const unsigned long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > budget_ticks) return false;
+            else if (now - t0 > budget_ticks) { __hip_atomic_store(&g_wait_expired_beacon, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
         }
         __builtin_amdgcn_s_sleep(2);
     }
@@ -88,10 +93,10 @@ __device__ __forceinline__ bool wait_until(unsigned long long budget_ticks, Done
 
 // ---- host side of the same contract -----------------------------------------------------------------------------------------------
 // GNN_WAIT_MS -> ticks of the 100 MHz wall clock (default 2 000 ms; 0 = every wait expires at once, the recovery paths' test hook)
-inline unsigned long long wait_ticks() {
-    static long long v = -1;
-    if (v < 0) { const char *e = getenv("GNN_WAIT_MS"); const long long ms = e ? atoll(e) : 2000; v = (ms < 0 ? 0 : ms) * 100000ll; }
-    return (unsigned long long)v;
+inline unsigned long long wait_ticks() {         // (read at every launch: the co-tenant tests shorten the bound inside one process)
+    const char *e = getenv("GNN_WAIT_MS");
+    const long long ms = e ? atoll(e) : 2000;
+    return (unsigned long long)((ms < 0 ? 0 : ms) * 100000ll);
 }
 
 // Can `grid` workgroups of this kernel be resident AT ONCE on the device (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs)?  A

@@ -861,19 +861,6 @@ int output_stage(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
     return 0;
 }
 
-// GNN_FUSED_WAVES: one shape knob per kernel generation (unset = that generation's default); read once, a tuning knob,
-// never a correctness switch.
-//   generation 2: waves per workgroup, 8 (default: 512 threads, 16 waves per CU) or 4 (256 threads, 256-VGPR budget)
-//   generation 4: rows in flight per lane group of a gather wave, 4 (default) or 8
-int fused_waves() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GNN_FUSED_WAVES");
-        v = e ? atoi(e) : 0;                    // 0: the kernel generation's own default
-    }
-    return v;
-}
-
 // Which generation of the fused iteration kernel runs.  GNN_FUSED_KERNEL unset / 0 = automatic:
 //   4  wave-specialised (12 gather waves + 4 matrix waves per workgroup, 32 waves per CU)      <- d > 16 and >= 32768 nodes
 //   2  phase-alternating (every wave gathers, then every wave multiplies; 16 waves per CU)      <- d <= 16 or small graphs
@@ -973,7 +960,7 @@ int iteration_prefix(const gnn_loop_args_t &a, const Plan &p, const int *gate, c
                               m.kernel[1], m.bias[1], (int)m.activation[1], nullptr, (int)m.units[1]};
     fa.S = p.S; fa.thr = a.state_threshold;
     fa.flag_next = nullptr; fa.k_out = nullptr; fa.err = p.err;
-    FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
+    FUSED_OK(gnn::launch_fused4(fa, p.SP, device_cus(), st));
     GNN_SET_KERNEL_NAME("k_state_fused4<.., L2> (aggregate + two Dense layers) + k_segdense (remaining layers)");
     gnn_mlp_t tail;
     memset(&tail, 0, sizeof(tail));
@@ -1024,10 +1011,10 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;
     }
-    if (p.SP == 128) { FUSED_OK(gnn::launch_wide(fa, device_cus(), st, fused_waves())); return 0; }
+    if (p.SP == 128) { FUSED_OK(gnn::launch_wide(fa, device_cus(), st, 0)); return 0; }
     const int gen = agg_init ? 4 : iteration_generation(a, p);
-    if (gen == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, fused_waves(), device_cus(), st));
-    else FUSED_OK(gnn::launch_fused2(fa, p.SP, fused_waves() == 0 ? 8 : fused_waves(), device_cus(), st));
+    if (gen == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, device_cus(), st));
+    else FUSED_OK(gnn::launch_fused2(fa, p.SP, 8, device_cus(), st));
     return 0;
 }
 
@@ -1534,6 +1521,16 @@ int gnn_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t millisecon
     if (!attr) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_debug_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     k_debug_occupy<<<n_workgroups, 64, (size_t)lds_bytes, (hipStream_t)stream>>>((unsigned long long)milliseconds * 100000ull, nullptr, nullptr);
     LAUNCH_OK();
+    return 0;
+}
+
+int gnn_debug_expiry_beacon(int32_t **beacon_out, int32_t reset, void *stream) {
+    if (!beacon_out) return fail("gnn_debug_expiry_beacon: beacon_out is NULL");
+    void *ptr = nullptr;
+    HIP_OK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(gnn::g_wait_expired_beacon)));
+    if (reset == 1) HIP_OK(hipMemsetAsync(ptr, 0, sizeof(int), (hipStream_t)stream));
+    else if (reset == 2) HIP_OK(hipMemsetAsync(ptr, 1, sizeof(int), (hipStream_t)stream));       // (non-zero: "a wait has expired" raised by hand - a test's last resort)
+    *beacon_out = (int32_t *)ptr;
     return 0;
 }
 

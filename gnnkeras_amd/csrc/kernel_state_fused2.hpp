@@ -412,12 +412,6 @@ inline int launch_fused2(Fused2Args &fa, int SP, int waves, int n_cu, hipStream_
         case 16: return launch_fused2_w<16, 64, 4>(fa, n_cu, st);
         case 32: return waves == 8 ? launch_fused2_w<32, 64, 8>(fa, n_cu, st) : launch_fused2_w<32, 64, 4>(fa, n_cu, st);
         case 64:
-            if (!fa.w && waves >= 12) {          // experimental high-occupancy shapes: waves = 16|12, depth = waves % 100 ... 
-                const int d = waves / 100;
-                const int w = waves % 100;
-                if (w == 16) return d == 4 ? launch_fused2_one<64, false, 64, 16, 4>(fa, n_cu, st) : launch_fused2_one<64, false, 64, 16, 8>(fa, n_cu, st);
-                if (w == 12) return d == 4 ? launch_fused2_one<64, false, 48, 12, 4>(fa, n_cu, st) : launch_fused2_one<64, false, 48, 12, 8>(fa, n_cu, st);
-            }
             return waves == 8 ? launch_fused2_w<64, 64, 8>(fa, n_cu, st) : launch_fused2_w<64, 64, 4>(fa, n_cu, st);
         default: return 1;
     }

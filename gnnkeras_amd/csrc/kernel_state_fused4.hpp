@@ -561,12 +561,9 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
                                 (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
         attr = true;
     }
-    // 2 workgroups (32 waves) per CU are resident at once.  GNN_F4_WG_FACTOR > 1 (experiment): that many times more, smaller workgroups -
-    // the dispatcher hands the next one to whichever slot frees first, which levels the +-10 % spread of workgroup run times
-    // (profiles/r03_c3_timeline.txt) at the price of one more ramp-up per extra workgroup.
-    static int wg_factor = 0;
-    if (wg_factor == 0) { const char *e = getenv("GNN_F4_WG_FACTOR"); wg_factor = e ? std::max(1, atoi(e)) : 1; }
-    const int budget = 2 * n_cu * wg_factor;
+    // 2 workgroups (32 waves) per CU are resident at once.  (More, smaller workgroups - the dispatcher hands the next one to whichever slot
+    // frees first - levelled the +-10 % spread of workgroup run times but paid one more ramp-up each: measured, not kept; docs/rounds/.)
+    const int budget = 2 * n_cu;
     long total_tiles = 0;
     for (int t = 0; t < fa.n_types; ++t) total_tiles += (fa.tp[t].count + 15) / 16;
     fa.blk_begin[0] = 0;
@@ -582,19 +579,6 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0) return 0;
-    if (HDR) {
-        // experiment: the first-job header of this (graph, launch geometry), written once by a launch of the kernel itself and kept
-        static const void *key_rowptr = nullptr, *key_src = nullptr; static int key_grid = 0; static void *hdr = nullptr; static size_t hdr_bytes = 0;
-        const size_t need = (size_t)grid * Cfg::NPROD * 64 * 16;
-        if (need > hdr_bytes) { if (hdr) (void)hipFree(hdr); if (hipMalloc(&hdr, need) != hipSuccess) return 1; hdr_bytes = need; key_rowptr = nullptr; }
-        if (key_rowptr != fa.rowptr || key_src != fa.src || key_grid != grid) {
-            Fused2Args fb = fa;
-            fb.hdr = nullptr; fb.hdr_write = hdr; fb.gate = nullptr; fb.n_gate = 0;
-            k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC, VPL, HDR><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fb);
-            key_rowptr = fa.rowptr; key_src = fa.src; key_grid = grid;
-        }
-        fa.hdr = hdr; fa.hdr_write = nullptr;
-    }
     if (VPL == 1 && !HDR)
         GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s,%s,%s>", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? "true" : "false", XC ? "true" : "false");
     else
@@ -603,32 +587,7 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-inline int launch_fused4(Fused2Args &fa, int SP, int depth, int n_cu, hipStream_t st) {
-#ifdef GNN_F4_NC_EXPERIMENT
-    if (SP == 64 && !fa.w && !fa.agg_init && !fa.tp[0].W2) {          // experiment: matrix waves per workgroup (GNN_FUSED_WAVES = 2 | 3 | 6)
-        if (depth == 2) return launch_fused4_one<64, false, 4, false, 2>(fa, n_cu, st);
-        if (depth == 3) return launch_fused4_one<64, false, 4, false, 3>(fa, n_cu, st);
-        if (depth == 6) return launch_fused4_one<64, false, 4, false, 6>(fa, n_cu, st);
-    }
-#endif
-#ifdef GNN_F4_EXPERIMENT
-    // C3 experiments of round 5 (library built with -DGNN_F4_EXPERIMENT: `make c3exp`), GNN_F4_VARIANT = bit 0: first-job
-    // header, bit 1: two 16-byte pieces per lane (8 lanes per node row: twice the nodes per gather wave and trip) at 2 rows in flight,
-    // bit 2: the same at 4 rows in flight.  Homogeneous one-layer models at SP = 64 on the C form (what C3 runs).
-    if (SP == 64 && !fa.w && !fa.agg_init && !fa.tp[0].W2 && !fa.Xc && fa.n_types == 1 && !fa.tp[0].rows) {
-        static int variant = -1;
-        if (variant < 0) { const char *e = getenv("GNN_F4_VARIANT"); variant = e ? atoi(e) : 0; }
-        switch (variant) {
-            case 1: return launch_fused4_one<64, false, 4, false, 4, false, false, 1, true>(fa, n_cu, st);
-            case 2: return launch_fused4_one<64, false, 2, false, 4, false, false, 2, false>(fa, n_cu, st);
-            case 3: return launch_fused4_one<64, false, 2, false, 4, false, false, 2, true>(fa, n_cu, st);
-            case 4: return launch_fused4_one<64, false, 4, false, 4, false, false, 2, false>(fa, n_cu, st);
-            case 5: return launch_fused4_one<64, false, 4, false, 4, false, false, 2, true>(fa, n_cu, st);
-            case 8: return launch_fused4_one<64, false, 2>(fa, n_cu, st);         // (the shipping lane layout at 2 rows in flight)
-            default: break;
-        }
-    }
-#endif
+inline int launch_fused4(Fused2Args &fa, int SP, int n_cu, hipStream_t st) {
 #define F4_CASE(SPV)                                                                                                  \
     case SPV:                                                                                                         \
         if (fa.agg_init) {                                                                                            \
@@ -639,7 +598,7 @@ inline int launch_fused4(Fused2Args &fa, int SP, int depth, int n_cu, hipStream_
         if (fa.tp[0].W2) return fa.w ? launch_fused4_one<SPV, true, 4, true>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4, true>(fa, n_cu, st); \
         if (fa.w) return launch_fused4_one<SPV, true, 4>(fa, n_cu, st);                                                \
         if (fa.Xc) return launch_fused4_one<SPV, false, 4, false, 4, false, true>(fa, n_cu, st);                       \
-        return depth == 8 ? launch_fused4_one<SPV, false, 8>(fa, n_cu, st) : launch_fused4_one<SPV, false, 4>(fa, n_cu, st);
+        return launch_fused4_one<SPV, false, 4>(fa, n_cu, st);
     switch (SP) {
         F4_CASE(16)
         F4_CASE(32)

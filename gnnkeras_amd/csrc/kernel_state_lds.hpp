@@ -290,10 +290,13 @@ __global__ void __launch_bounds__(64 * LDS_NW, 4) k_state_lds(LdsArgs a) {
                 if (!wait_until(a.wait_ticks, [&]() { v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (unsigned)v >= target; }))
                     timed_out = 1;                                             // a member never arrived (not resident?): reported through k
                 const unsigned moved = (unsigned)(v >> 32);
-                set_go = (moved != moved_seen[it & 1]) ? 1 : 0;
+                set_go = timed_out ? -1 : ((moved != moved_seen[it & 1]) ? 1 : 0);
                 moved_seen[it & 1] = moved;
             }
             __syncthreads();
+            // an expired wait ends this group's loop at once: its result is void (k < 0), and waiting out the bound again in each of the
+            // remaining iterations would hold the CU - and every member queued behind it - for max_iteration x the bound
+            if (set_go < 0) break;
             if (!a.no_exit && set_go == 0) break;
         } else if (!a.no_exit && moving_s[mv_slot] == 0) break;                // uniform: read after the barrier
     }

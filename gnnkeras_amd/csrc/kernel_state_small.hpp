@@ -314,12 +314,13 @@ __global__ void __launch_bounds__(64 * small_waves(SP), 2) k_state_small(SmallAr
             if (!wait_until(sa.wait_ticks, [&]() { v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (unsigned)v >= target; }))
                 timed_out = 1;                         // some workgroup never arrived (not resident?): reported through k
             const unsigned moved = (unsigned)(v >> 32);
-            *cont = (moved != moved_seen[it & 1]) ? 1 : 0;
+            *cont = timed_out ? -1 : ((moved != moved_seen[it & 1]) ? 1 : 0);
             moved_seen[it & 1] = moved;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // no instruction: keeps the loads below the poll
         }
         __syncthreads();
         k_done = it + 1;
+        if (*cont < 0) break;                          // an expired wait ends the loop at once (k < 0): not the bound again in every remaining iteration
         if (!sa.no_exit && *cont == 0) break;          // uniform: every workgroup read the same total
     }
     // The rows the loop ends on, straight into the caller's compact buffer: the tile still holds what the last iteration

@@ -364,8 +364,7 @@ int launch_wide_one(Fused2Args &fa, int n_cu, hipStream_t st) {
 }
 
 inline int launch_wide(Fused2Args &fa, int n_cu, hipStream_t st, int depth = 0) {
-    if (!fa.agg_init && !fa.w && depth == 4) return launch_wide_one<false, false, 4>(fa, n_cu, st);       // tuning knob (GNN_FUSED_WAVES)
-    if (!fa.agg_init && !fa.w && depth == 16) return launch_wide_one<false, false, 16>(fa, n_cu, st);
+    (void)depth;
     if (fa.agg_init) return fa.w ? launch_wide_one<true, true>(fa, n_cu, st) : launch_wide_one<false, true>(fa, n_cu, st);
     return fa.w ? launch_wide_one<true, false>(fa, n_cu, st) : launch_wide_one<false, false>(fa, n_cu, st);
 }

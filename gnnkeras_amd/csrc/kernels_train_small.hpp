@@ -69,7 +69,8 @@ __device__ __forceinline__ bool grid_barrier(GridBar &gb, int any, int *cont_lds
         __hip_atomic_fetch_add(ctr, 1ull + ((unsigned long long)(any ? 1u : 0u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (unsigned)(gb.bi / 2 + 1) * gb.n_wg;
         unsigned long long v = 0;
-        if (!wait_until(gb.wait_ticks, [&]() { v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (unsigned)v >= target; }))
+        // (once a wait has expired the launch's results are void: the remaining barriers do not wait out the bound again)
+        if (gb.timed_out || !wait_until(gb.wait_ticks, [&]() { v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (unsigned)v >= target; }))
             gb.timed_out = 1;
         const unsigned moved = (unsigned)(v >> 32);
         const bool odd = (gb.bi & 1) != 0;

@@ -588,7 +588,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
     }
 
     // (gnn_last_kernel_name(): which orchestration took the step - tests and bench.py read it)
-    if (p.big) GNN_SET_KERNEL_NAME("train_step composite: row-streaming kernels on per-type position ranges (k_train_fwd_b6<ADD> / k_train_wgrad_b6<XT=%d>)", p.B.XT);
+    if (p.big) GNN_SET_KERNEL_NAME("train_step composite: row-streaming kernels on type ranges (fwd_b6<ADD>, wgrad_b6<XT=%d>)", p.B.XT);
     else if (p.small) GNN_SET_KERNEL_NAME("train_step composite: persistent small-graph kernels");
     else GNN_SET_KERNEL_NAME("train_step composite: general kernels (one launch per layer, type and iteration)");
     if (p.big) TRY(composite_big_setup(ta, p, st));

@@ -236,6 +236,10 @@ int gnn_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t millisecon
 /* ... until the DEVICE word *release_flag becomes non-zero (the test writes it from another stream when ITS condition holds - a co-tenant
  * that leaves on a handshake, not on a clock), at the latest after max_milliseconds (<= 20 000: the kernel cannot hang the GPU). */
 int gnn_debug_occupy_until(int32_t n_workgroups, int32_t lds_bytes, int32_t max_milliseconds, const int32_t *release_flag, void *stream);
+/* The library's expiry beacon: a DEVICE word the whole-loop / persistent kernels set when one of their bounded waits runs out (never cleared
+ * by a kernel; `reset` = 1 zeroes it on `stream`, 2 raises it by hand, 0 leaves it).  Handed to gnn_debug_occupy_until as the release flag it makes a co-tenant that leaves
+ * exactly when the first wait of the launch under test has expired - a device-side handshake, no clock on the host. */
+int gnn_debug_expiry_beacon(int32_t **beacon_out, int32_t reset, void *stream);
 
 /* ---- node-range sharded loop -------------------------------------------------------------------------
  * One process per GPU; rank r owns a contiguous node range and, per iteration, (1) runs gnn_shard_iteration on its
@@ -464,8 +468,9 @@ typedef struct gnn_train_args {
     int32_t n_tiles;
     /* ABI 6: heterogeneous models (loop.composite != 0; reference CompositeGNN.py:275-304 `train_step`): one state network per node
      * type, net_state[t] applied to the rows of type t with ITS BatchNormalization statistics - the gradients of network t land in
-     * grad_state_types[t] (grad_state is not used then).  Node and graph focus; arc-focused composite models and LGNN label
-     * gradients train through the building blocks. */
+     * grad_state_types[t] (grad_state is not used then).  Node, graph and (round 6) arc focus (CompositeGNN.py:315-327); LGNN label
+     * gradients train through the building blocks.  From GNN_TRAIN_BIG_MIN_NODES nodes on the step runs the row-streaming kernels in
+     * position space (position i = node type_nodes[i]; train_composite_big.hpp): same arguments, same results. */
     gnn_mlp_grads_t grad_state_types[GNN_MAX_TYPES];
     /* ABI 7: validity of the step's gradients WITHOUT a second host synchronisation.  The persistent small-graph backward kernel waits
      * at grid barriers with a bound (GNN_WAIT_MS); when such a wait expires (GPU shared with other long-running work) its gradients are
@@ -475,7 +480,10 @@ typedef struct gnn_train_args {
      * nothing.  The caller learns about it for free at the NEXT call's one synchronisation:
      *   grads_ok_dev        optional OUT (host pointer variable): the device word of THIS call (valid until the tape is reused)
      *   prev_grads_ok_host  optional OUT (host int): the word the PREVIOUS call on this tape left, fetched before this call resets it
-     *                       (NULL for a fresh tape, whose first word is not a validity word yet) */
+     *                       (NULL for a fresh tape, whose first word is not a validity word yet).  Written by the time the call returns
+     *                       whether it succeeds or fails behind its first launches (a failing call synchronises the stream first);
+     *                       a call that fails before them (argument checks) leaves *prev_grads_ok_host as the caller set it - start
+     *                       from a sentinel - and the word on the tape untouched. */
     const int32_t **grads_ok_dev;
     int32_t *prev_grads_ok_host;
 } gnn_train_args_t;

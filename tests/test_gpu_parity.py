@@ -424,35 +424,6 @@ def c3_case(mode, iters=3, paths=(0,)):
     return nat.lib().gnn_last_kernel_name().decode()
 
 
-def test_c4_er_1m_10m_properties():
-    """Full C4 size: (i) fused == un-fused (two independent device implementations), (ii) permutation equivariance:
-    relabelling the nodes permutes the states, (iii) k pinned, (iv) the loop is deterministic."""
-    N, E, d = 1_000_000, 10_000_000, 64
-    g = er_graph(N, E, aggregation_mode='average')
-    seq = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)
-    x = seq[0][0]
-    ns, no = starter_nets('n', d)
-    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
-    model = GNNnodeBased(ns, no, d, 5, 0.0)
-    inputs = model.process_inputs(x)
-    k, st, o = model.Loop(*inputs, state0=dev(s0))
-    k2, st2, o2 = model.Loop(*inputs, state0=dev(s0))
-    assert float(k) == 5.0 and torch.equal(st, st2) and torch.equal(o, o2)
-    model.native_flags = nat.FLAG_UNFUSED
-    ku, stu, ou = model.Loop(*inputs, state0=dev(s0))
-    assert float(ku) == 5.0
-    assert rel_err(st.cpu().numpy(), stu.cpu().numpy()) <= TOL and rel_err(o.cpu().numpy(), ou.cpu().numpy()) <= TOL
-    del stu, ou, st2, o2
-    model.native_flags = 0
-    perm = np.random.default_rng(2).permutation(N); inv = np.argsort(perm)      # new id of old node i is inv[i]
-    arcs_p = g.arcs.astype(np.float64); arcs_p[:, :2] = inv[g.arc_ids]
-    gp = GraphObject(nodes=g.nodes[perm], arcs=arcs_p, targets=g.targets[perm], focus='n', aggregation_mode='average')
-    xp = MultiGraphSequencer([gp], 'n', 'average', 1, shuffle=False)[0][0]
-    kp, stp, op = model.Loop(*model.process_inputs(xp), state0=dev(s0[perm]))
-    assert rel_err(stp.cpu().numpy(), st.cpu().numpy()[perm]) <= TOL
-    assert rel_err(op.cpu().numpy(), o.cpu().numpy()[perm]) <= TOL
-
-
 # (C4 / C5 at full size against the oracle on the default, un-fused and generation-2 paths, run-to-run determinism: the 50-iteration tests
 # of tests/test_gpu_round4.py - test_c4_at_the_timed_depth_vs_fp64_oracle, test_c5_at_the_timed_depth_vs_fp64_oracle)
 
@@ -573,20 +544,30 @@ def _run_shards_on_one_gpu(model, g, s0, R, overlap=False):
     return ks, np.concatenate([o[1].cpu().numpy() for o in outs]), np.concatenate([o[2].cpu().numpy() for o in outs])
 
 
+_SHARD_CASES = {}
+
+
+def _sharded_native_case(threshold):
+    """Graph, model, state_0 and the float64 oracle of test_sharded_native_kernels_match_oracle: the same for every shard count."""
+    if threshold not in _SHARD_CASES:
+        rng = np.random.default_rng(0)
+        N, d = 5003, 64
+        g = er_graph(N, 40000, seed=7)
+        om = rng.random(N) < 0.7
+        g = GraphObject(g.nodes, g.arcs, rng.normal(size=(int(om.sum()), 2)), focus='n', set_mask=rng.random(N) < 0.8,
+                        output_mask=om, aggregation_mode='average')
+        ns, no = starter_nets('n', d, scale=0.3)
+        model = GNNnodeBased(ns, no, d, 12, threshold)
+        s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+        x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
+        _SHARD_CASES[threshold] = (g, model, s0, oracle_loop(model, x, s0, np.float64))
+    return _SHARD_CASES[threshold]
+
+
 @pytest.mark.parametrize('R', [1, 2, 3, 8])
 @pytest.mark.parametrize('threshold', [0.0, 0.02])
 def test_sharded_native_kernels_match_oracle(R, threshold):
-    rng = np.random.default_rng(0)
-    N, d = 5003, 64
-    g = er_graph(N, 40000, seed=7)
-    om = rng.random(N) < 0.7
-    g = GraphObject(g.nodes, g.arcs, rng.normal(size=(int(om.sum()), 2)), focus='n', set_mask=rng.random(N) < 0.8,
-                    output_mask=om, aggregation_mode='average')
-    ns, no = starter_nets('n', d, scale=0.3)
-    model = GNNnodeBased(ns, no, d, 12, threshold)
-    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
-    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False)[0][0]
-    k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
+    g, model, s0, (k64, st64, o64) = _sharded_native_case(threshold)
     if threshold > 0: assert 1 < k64 < 12
     for flags in PATHS:
         model.native_flags = flags
@@ -615,14 +596,18 @@ def test_sharded_overlap_split_wide_state():
 def test_sharded_overlap_split_matches_oracle(R, mode, threshold):
     """Own-range / halo split of the iteration (gnn_shard_partial + gnn_shard_iteration_split, the overlap path of
     distributed.py) on emulated shards: same oracle, same 1e-5 bar, k identical."""
-    rng = np.random.default_rng(0)
-    N, d = 40_003, 64
-    g = er_graph(N, 400_000, seed=7, aggregation_mode=mode)
-    ns, no = starter_nets('n', d, scale=0.3 if mode == 'average' else 0.03)
-    model = GNNnodeBased(ns, no, d, 6, threshold)
-    s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
-    x = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
-    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
+    key = ('overlap', mode, threshold)
+    if key not in _SHARD_CASES:           # (graph, model and the float64 oracle are the same for every shard count)
+        rng = np.random.default_rng(0)
+        N, d = 40_003, 64
+        g = er_graph(N, 400_000, seed=7, aggregation_mode=mode)
+        ns, no = starter_nets('n', d, scale=0.3 if mode == 'average' else 0.03)
+        model = GNNnodeBased(ns, no, d, 6, threshold)
+        s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+        x = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0][0]
+        _SHARD_CASES[key] = (g, model, s0, oracle_loop(model, x, s0, np.float64, exact_order=False))
+    g, model, s0, (k64, st64, o64) = _SHARD_CASES[key]
+    model.native_flags = 0
     ks, st, o = _run_shards_on_one_gpu(model, g, s0, R, overlap=True)
     assert all(k == float(k64) for k in ks), (ks, k64)
     assert rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL

@@ -281,27 +281,8 @@ def _run_slices_on_one_gpu(model, slices, s0, overlap):
     return [float(o[0]) for o in outs], np.concatenate([o[1].cpu().numpy() for o in outs]), np.concatenate([o[2].cpu().numpy() for o in outs])
 
 
-def test_c4_sharded_8_emulated():
-    """BASELINE config 4 - 1 M nodes / 10 M arcs, d = 64, node-range shards over 8 GPUs - at FULL size on one device: 8 shards,
-    each built from its own `er_graph_slice` (what a rank of the real job generates: no rank ever holds the whole graph's
-    operators), the real shard kernels, the all-gather replaced by slice copies; 2 iterations against the float64 oracle on the
-    whole graph (scipy row order), overlap split on and off."""
-    from gnnkeras_amd.distributed import partition
-    from test_gpu_parity import starter_nets
-    N, E, d, R = 1_000_000, 10_000_000, 64, 8
-    g = er_graph(N, E, aggregation_mode='average', seed=1234)
-    x = MultiGraphSequencer([g], 'n', 'average', 1, shuffle=False, device='cpu')[0][0]
-    ns, no = starter_nets('n', d, scale=0.3)
-    model = GNNnodeBased(ns, no, d, 2, 0.0)
-    s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
-    k64, st64, o64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
-    del x, g
-    slices = [er_graph_slice(N, E, lo, hi, aggregation_mode='average', seed=1234) for lo, hi in partition(N, R)[1]]
-    assert sum(len(gs.arc_dst) for gs in slices) == E
-    for overlap in (True, False):
-        ks, st, o = _run_slices_on_one_gpu(model, slices, s0, overlap)
-        assert ks == [2.0] * R == [float(k64)] * R
-        assert st.shape == st64.shape and rel_err(st, st64) <= TOL and rel_err(o, o64) <= TOL, (overlap, rel_err(st, st64))
+# (BASELINE C4 as 8 shards built from per-rank slices, at full size: tests/test_gpu_round4.py::test_c4_as_8_shards_at_the_timed_depth - 50 iterations,
+# overlap split on and off, against the float64 oracle)
 
 
 def test_hub_rows_on_shards():
@@ -392,15 +373,19 @@ def test_large_graph_training_step_matches_autograd(d, bn, mode, thr):
     x, y, sw = seq[0]
     ns, no = nets('n', d, bn, scale=(0.5 if thr >= 0 else 0.1) if mode == 'average' else 0.08)      # (early exit: a contractive network)
     s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    key = ('large_graph_step', d, bn, mode, thr)              # (the inputs are seeded: the alternative-kernel tests re-run a configuration on its oracle result)
     if thr < 0:                                               # early exit: a threshold at which the oracle stops after 1 .. 3 iterations
-        from test_gpu_training import oracle_step
-        seen = {}
-        for thr in (0.05, 0.1, 0.2, 0.4, 0.8):
-            k = seen[thr] = oracle_step(GNNnodeBased(ns, no, d, 4, thr), x, y, sw, s0, 'categorical_crossentropy')['k']
-            if 0 < k < 4: break
-        assert 0 < k < 4, f'no threshold with an early exit found: {seen}'
+        from test_gpu_training import oracle_step, _ORACLE_CACHE
+        if (key, 'thr') not in _ORACLE_CACHE:
+            seen = {}
+            for thr in (0.05, 0.1, 0.2, 0.4, 0.8):
+                k = seen[thr] = oracle_step(GNNnodeBased(ns, no, d, 4, thr), x, y, sw, s0, 'categorical_crossentropy')['k']
+                if 0 < k < 4: break
+            assert 0 < k < 4, f'no threshold with an early exit found: {seen}'
+            _ORACLE_CACHE[(key, 'thr')] = thr
+        thr = _ORACLE_CACHE[(key, 'thr')]
     model = GNNnodeBased(ns, no, d, 4, thr)
-    res, want = check_step(model, x, y, sw, s0)               # both orchestrations against the oracle
+    res, want = check_step(model, x, y, sw, s0, oracle_key=key)      # both orchestrations against the oracle
 
 
 def test_small_graph_training_on_the_large_graph_kernels(mutag_graphs, monkeypatch):

@@ -77,8 +77,13 @@ def _deep_c4():
     s0 = np.random.default_rng(1).normal(0, 0.1, (N, d)).astype(np.float32)
     model = GNNnodeBased(ns, no, d, _DEEP_K, 0.0)
     t0 = time.time()
+    # (the permuted copy of the graph for test_c4_properties_at_full_size: built here, on the worker thread, next to the oracle run)
+    perm = np.random.default_rng(2).permutation(N); inv = np.argsort(perm)      # new id of old node i is inv[i]
+    arcs_p = g.arcs.astype(np.float64); arcs_p[:, :2] = inv[g.arc_ids]
+    gp = GraphObject(nodes=g.nodes[perm], arcs=arcs_p, targets=g.targets[perm], focus='n', aggregation_mode='average')
+    xp = MultiGraphSequencer([gp], 'n', 'average', 1, shuffle=False)[0][0]
     r64 = oracle_loop(model, x, s0, np.float64, exact_order=False)
-    return dict(x=x, model=model, s0=s0, r64=r64, t=time.time() - t0)
+    return dict(x=x, model=model, s0=s0, r64=r64, t=time.time() - t0, perm=perm, xp=xp)
 
 
 def _deep_c5(mode):
@@ -100,7 +105,7 @@ def _deep_c5(mode):
 _DEEP_JOBS = {'c3_average': lambda: _deep_c3('average'), 'c3_sum': lambda: _deep_c3('sum'), 'c4': _deep_c4,
               'c5_average': lambda: _deep_c5('average'), 'c5_composite_average': lambda: _deep_c5('composite_average')}
 _DEEP_USERS = {'test_c3_at_the_timed_depth_every_path[average]': 'c3_average', 'test_c3_at_the_timed_depth_every_path[sum]': 'c3_sum',
-               'test_c4_at_the_timed_depth_vs_fp64_oracle': 'c4', 'test_c4_as_8_shards_at_the_timed_depth': 'c4',
+               'test_c4_at_the_timed_depth_vs_fp64_oracle': 'c4', 'test_c4_as_8_shards_at_the_timed_depth': 'c4', 'test_c4_properties_at_full_size': 'c4',
                'test_c5_at_the_timed_depth_vs_fp64_oracle[average]': 'c5_average', 'test_c5_as_4_shards_at_the_timed_depth': 'c5_average',
                'test_c5_at_the_timed_depth_vs_fp64_oracle[composite_average]': 'c5_composite_average'}
 
@@ -193,6 +198,30 @@ def test_c4_at_the_timed_depth_vs_fp64_oracle(request):
           f'un-fused state {res[nat.FLAG_UNFUSED][0]:.2e} out {res[nat.FLAG_UNFUSED][1]:.2e}; generation 2 state {res[nat.FLAG_FUSED_GEN2][0]:.2e} out '
           f'{res[nat.FLAG_FUSED_GEN2][1]:.2e}; max|state| {np.abs(st64).max():.2f}')
     for flags, e in res.items(): assert max(e) <= TOL, (flags, e)
+
+
+def test_c4_properties_at_full_size(request):
+    """Full C4 size, the size-independent properties: (i) fused == un-fused (two independent device implementations), (ii) permutation
+    equivariance: relabelling the nodes permutes the states, (iii) k pinned, (iv) the loop is deterministic.  (The graph and its relabelled
+    copy come from the worker thread that runs the C4 oracle.)"""
+    r = _deep(request)
+    x, s0, xp, perm = r['x'], r['s0'], r['xp'], r['perm']
+    base = r['model']
+    model = GNNnodeBased(base.net_state, base.net_output, 64, 5, 0.0)
+    inputs = model.process_inputs(x)
+    k, st, o = model.Loop(*inputs, state0=dev(s0))
+    k2, st2, o2 = model.Loop(*inputs, state0=dev(s0))
+    assert float(k) == 5.0 and torch.equal(st, st2) and torch.equal(o, o2)
+    model.native_flags = nat.FLAG_UNFUSED
+    ku, stu, ou = model.Loop(*inputs, state0=dev(s0))
+    assert float(ku) == 5.0
+    assert rel_err(st.cpu().numpy(), stu.cpu().numpy()) <= TOL and rel_err(o.cpu().numpy(), ou.cpu().numpy()) <= TOL
+    assert model.check_last_k() == 5.0
+    del stu, ou, st2, o2
+    model.native_flags = 0
+    kp, stp, op = model.Loop(*model.process_inputs(xp), state0=dev(s0[perm]))
+    assert rel_err(stp.cpu().numpy(), st.cpu().numpy()[perm]) <= TOL
+    assert rel_err(op.cpu().numpy(), o.cpu().numpy()[perm]) <= TOL
 
 
 @pytest.mark.parametrize('mode', ['average', 'composite_average'])
@@ -614,11 +643,12 @@ print('RECOVERED_OK')
     assert r.returncode == 0 and 'RECOVERED_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-def _co_tenant_walk(mutag_graphs):
+def _co_tenant_walk(mutag_graphs, release_on_expiry=False):
     """The one-launch MUTAG walk (256 groups, one CU each, group sets that wait for each other) and a co-tenant on a second stream that keeps
-    100 KB of the LDS of all but ONE CU (the set-up kernels still fit next to it, a group's 90+ KB do not) until the DEVICE word `flag`
-    becomes non-zero: the walk cannot be resident at once while it is there.  The co-tenant leaves on the test's handshake, not on a clock
-    (its own 15 s bound only keeps it from hanging the GPU)."""
+    100 KB of the LDS of all but ONE CU (the set-up kernels still fit next to it, a group's 90+ KB do not) until a DEVICE word becomes
+    non-zero: the walk cannot be resident at once while it is there (workgroups are dealt to the XCDs round-robin: the large groups of seven
+    XCDs cannot start at all).  The co-tenant leaves on a handshake, not on a clock (its own 15 s bound only keeps it from hanging the GPU):
+    the word is the test's own flag, or - `release_on_expiry` - the library's expiry beacon, which the first expired wait of the walk sets."""
     gs = [g.copy() for g in mutag_graphs]
     for g in gs: g.setAggregation('average')
     seq = MultiGraphSequencer(gs, 'g', 'average', 32, shuffle=False)
@@ -630,12 +660,21 @@ def _co_tenant_walk(mutag_graphs):
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     side, rel = torch.cuda.Stream(), torch.cuda.Stream()
     flag = torch.zeros(4, dtype=torch.int32, device='cuda')
+    word = C.c_void_p(flag.data_ptr())
     torch.cuda.synchronize()
-    nat.check(nat.lib().gnn_debug_occupy_until(cus - 1, 100 * 1024, 15000, C.c_void_p(flag.data_ptr()), C.c_void_p(side.cuda_stream)))
+    if release_on_expiry:
+        beacon = C.c_void_p(0)
+        nat.check(nat.lib().gnn_debug_expiry_beacon(C.byref(beacon), 1, C.c_void_p(side.cuda_stream)))
+        word = beacon
+    nat.check(nat.lib().gnn_debug_occupy_until(cus - 1, 100 * 1024, 15000, word, C.c_void_p(side.cuda_stream)))
     time.sleep(0.05)                                        # (the co-tenant is on the CUs before the walk is launched)
 
     def release():
-        with torch.cuda.stream(rel): flag.fill_(1)
+        if release_on_expiry:            # (the test is over: raise the beacon by hand so that the co-tenant goes whatever happened)
+            tmp = C.c_void_p(0)
+            nat.check(nat.lib().gnn_debug_expiry_beacon(C.byref(tmp), 2, C.c_void_p(rel.cuda_stream)))
+        else:
+            with torch.cuda.stream(rel): flag.fill_(1)
     return model, seq, want, release, cus
 
 
@@ -661,30 +700,23 @@ def test_a_co_tenant_that_leaves_inside_the_wait_bound_costs_time_only(mutag_gra
     assert dt >= 0.25                                       # (the walk really waited for the co-tenant)
 
 
-def test_a_co_tenant_that_stays_makes_the_walk_expire_and_predict_recover(mutag_graphs):
-    """The co-tenant is released only once predict() has SEEN a wait expire (a watcher thread releases it when the RuntimeWarning of the
-    recovery appears - never before): with one free CU a group that waits for the other members of its set can never see them arrive - its
-    wait expires at the bound (GNN_WAIT_MS), the launch comes back with k < 0, and predict() repeats the walk on the per-iteration kernels
-    with a RuntimeWarning - outputs within the tolerance of another summation order.  Were no wait to expire, the co-tenant would stay for
-    its own 15 s bound and the assertions below fail."""
-    import threading, warnings
-    model, seq, want, release, cus = _co_tenant_walk(mutag_graphs)
+def test_a_co_tenant_that_stays_until_a_wait_expires_makes_predict_recover(mutag_graphs, monkeypatch):
+    """The co-tenant's release word is the library's EXPIRY BEACON (gnn_debug_expiry_beacon): it stays until a wait of the walk has run out -
+    a device-side handshake, no host clock decides which branch runs.  While it stays, a group that waits for the other members of its set
+    cannot see them arrive (their workgroups belong to XCDs without a free CU): its wait expires at the bound (shortened to 100 ms for this
+    launch: GNN_WAIT_MS is read per launch), the beacon lets the co-tenant go, the launch comes back with k < 0, and predict() repeats the
+    walk on the per-iteration kernels with a RuntimeWarning - outputs within the tolerance of another summation order.  Were no wait to
+    expire the co-tenant would stay for its own 15 s bound and the assertions below fail."""
+    import warnings
+    model, seq, want, release, cus = _co_tenant_walk(mutag_graphs, release_on_expiry=True)
+    monkeypatch.setenv('GNN_WAIT_MS', '100')
     t0 = time.time()
-    done = threading.Event()
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter('always')
-
-        def watch():
-            while not done.is_set():
-                if any(issubclass(x.category, RuntimeWarning) for x in list(w)):
-                    release(); return
-                time.sleep(0.005)
-        watcher = threading.Thread(target=watch, daemon=True)
-        watcher.start()
-        try:
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
             torch.manual_seed(1); got = model.predict(seq)
-        finally:
-            done.set(); watcher.join(); release(); torch.cuda.synchronize()
+    finally:
+        release(); torch.cuda.synchronize()
     dt = time.time() - t0
     print(f'\nco-tenant on {cus - 1} CUs until a wait had expired: predict() took {dt * 1e3:.0f} ms, recovered walks {getattr(model, "recovered_walks", 0)}, '
           f'warnings {[str(x.message)[:60] for x in w]}')

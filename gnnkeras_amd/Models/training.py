@@ -870,7 +870,9 @@ class LoopTrainer:
         if not self.use_native_step or y is None: return False
         nets = list(m.net_state) if isinstance(m.net_state, (list, tuple)) else [m.net_state]
         if isinstance(m.net_state, (list, tuple)) and m.max_iteration < 1: return False      # what the in-library composite step refuses (make_cplan): the general path below
-        if any(n_.dropout_rate for n_ in nets) or m.net_output.dropout_rate: return False      # Dropout masks: the general path below
+        # Dropout layers behind Dense layers run inside the library (ABI 8); one in FRONT of the first Dense (position 0) keeps the path below
+        for n_ in nets + [m.net_output]:
+            if any(float(r) > 0 and int(q) == 0 for r, q in zip(n_.dropout_rate or [], n_.dropout_pos or [])): return False
         kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
         return str(kind).lower() in nat.LOSSES
 
@@ -883,7 +885,6 @@ class LoopTrainer:
         m = self.model
         composite = isinstance(m.net_state, (list, tuple))
         nets_s = list(m.net_state) if composite else [m.net_state]
-        _check_no_dropout(nets_s + [m.net_output])
         inputs = m.process_inputs(x_list)
         if composite:       # CompositeGNN.py:275-304: one state network per node type (csrc/train_composite.hpp)
             nodes, arcs, dim_node_label, type_mask, set_mask, output_mask, cas, adjacency, arcnode, nodegraph = inputs
@@ -965,6 +966,17 @@ class LoopTrainer:
         ta.loss_kind = nat.LOSSES[str(kind).lower()]
         ta.average_st_grads = 0          # finish() divides by k AFTER adding the weight penalties, like the reference (GNN.py:295)
         ta.bn_momentum = BN_MOMENTUM
+        # Dropout / AlphaDropout layers (reference MLP.py:60-66): their masks derive from the step's seed exactly as on the building-block path
+        m._dropout_step = getattr(m, '_dropout_step', 0) + 1
+        self.drop_seed = _mix32(0x5EED, int(seed)) if seed is not None else _mix32(id(m) & 0xFFFFFFFF, m._dropout_step)
+        ta.drop_seed = self.drop_seed
+        for i, g_ in enumerate(gs_all): g_.net_id = i
+        go.net_id = 1000
+        for spec, g_ in [(ta.drop_state[i], g_) for i, g_ in enumerate(gs_all)] + [(ta.drop_output, go)]:
+            layers = [(q, r, idx) for q in sorted(g_.drop) for r, idx in g_.drop[q]]
+            if len(layers) > nat.GNN_MAX_DROPOUT: raise ValueError(f'more than {nat.GNN_MAX_DROPOUT} Dropout layers in one network')
+            spec.n, spec.alpha, spec.net_id = len(layers), int(bool(g_.alpha)), int(g_.net_id)
+            for j, (q, r, idx) in enumerate(layers): spec.pos[j], spec.rate[j], spec.index[j] = int(q), float(r), int(idx)
         holders = [(ta.grad_state_types[i], g_) for i, g_ in enumerate(gs_all)] if composite else [(ta.grad_state, gs)]
         for g_, ng_ in holders + [(ta.grad_output, go)]:
             if ng_.bn: g_.dgamma, g_.dbeta = nat.ptr(ng_.dgamma), nat.ptr(ng_.dbeta)
@@ -1095,15 +1107,6 @@ def _regularize(ng: _NetGrads):
             g.add_(reg.l1 * torch.sign(w) + (2.0 * reg.l2) * w)
             total = pen if total is None else total + pen
     return total
-
-
-def _check_no_dropout(nets):
-    """Dropout / AlphaDropout layers (`MLP(dropout_rate=, dropout_pos=)`, reference MLP.py:60-66) have no device kernels yet:
-    refuse to train a different network than the one that was asked for."""
-    for n_ in nets:
-        if n_.dropout_rate:
-            raise NotImplementedError('training a network with Dropout / AlphaDropout layers is not supported on the HIP path: build '
-                                      'the MLP without dropout_rate / dropout_pos (inference ignores dropout, as Keras does)')
 
 
 def _by_source(matrix: SparseMatrix, device):

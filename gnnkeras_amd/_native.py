@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 # GNNKERAS_AMD_LIB: load another build of the same sources (tests: the debug build whose in-launch waits expire at once)
 LIB_PATH = os.environ.get('GNNKERAS_AMD_LIB') or os.path.join(CSRC, 'libgnnloop.so')
 
-GNN_ABI_VERSION = 7
+GNN_ABI_VERSION = 8
 GNN_MAX_LAYERS = 8
 GNN_MAX_TYPES = 8
 
@@ -27,7 +27,8 @@ FLAG_FUSED_GEN_MASK = 7 << 4
 FLAG_FUSED_GEN2, FLAG_FUSED_GEN4, FLAG_FUSED_GEN5, FLAG_FUSED_GEN6, FLAG_FUSED_GEN7 = 2 << 4, 4 << 4, 5 << 4, 6 << 4, 7 << 4     # pin the fused-kernel generation (tests, tuning)
 
 EXPORTS = ['gnn_last_error', 'gnn_last_kernel_name', 'gnn_abi_version', 'gnn_struct_size', 'gnn_loop_workspace_bytes', 'gnn_loop_forward', 'gnn_loop_groups_supported', 'gnn_aggregate',
-           'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_step_agg', 'gnn_state_ld', 'gnn_debug_occupy', 'gnn_debug_occupy_until', 'gnn_debug_expiry_beacon', 'gnn_shard_iteration_split_rows',
+           'gnn_mlp_workspace_bytes', 'gnn_mlp_forward', 'gnn_converged', 'gnn_state_step', 'gnn_state_step_agg', 'gnn_state_ld', 'gnn_debug_occupy', 'gnn_debug_occupy_until', 'gnn_debug_expiry_beacon', 'gnn_debug_host_flag',
+           'gnn_device_malloc', 'gnn_device_free', 'gnn_ipc_export', 'gnn_ipc_open', 'gnn_ipc_close', 'gnn_shard_iteration_peers', 'gnn_peer_wait', 'gnn_peer_publish', 'gnn_shard_iteration_split_rows',
            'gnn_shard_setup', 'gnn_shard_iteration', 'gnn_shard_output', 'gnn_gather_rows',
            'gnn_shard_can_split', 'gnn_shard_partial', 'gnn_shard_iteration_split',
            'gnn_dense', 'gnn_fold_bn', 'gnn_dense_grad_workspace_bytes', 'gnn_dense_grad', 'gnn_act_grad',
@@ -97,6 +98,21 @@ class MLPGrads(C.Structure):
                 ('dkernel', C.c_void_p * GNN_MAX_LAYERS), ('dbias', C.c_void_p * GNN_MAX_LAYERS)]
 
 
+GNN_MAX_DROPOUT = 8
+
+
+class DropoutSpec(C.Structure):         # gnn_dropout_spec_t (ABI 8)
+    _fields_ = [('n', C.c_int32), ('alpha', C.c_int32), ('net_id', C.c_int32), ('pos', C.c_int32 * GNN_MAX_DROPOUT),
+                ('index', C.c_int32 * GNN_MAX_DROPOUT), ('rate', C.c_float * GNN_MAX_DROPOUT)]
+
+
+GNN_MAX_PEERS = 7
+
+
+class PeerSet(C.Structure):             # gnn_peer_set_t (ABI 8): the peers' full state buffer an iteration writes + their arrival arrays
+    _fields_ = [('n_peers', C.c_int32), ('state_out_full', C.c_void_p * GNN_MAX_PEERS), ('arrive', C.c_void_p * GNN_MAX_PEERS)]
+
+
 class TrainArgs(C.Structure):
     _fields_ = [('loop', LoopArgs), ('adjacency_by_source', CSR), ('nodegraph_by_source', CSR),
                 ('targets', C.c_void_p), ('sample_weight', C.c_void_p), ('loss_kind', C.c_int32),
@@ -106,7 +122,9 @@ class TrainArgs(C.Structure):
                 ('tape', C.c_void_p), ('tape_bytes', C.c_size_t), ('tile_node_begin', C.c_void_p), ('n_tiles', C.c_int32),
                 ('grad_state_types', MLPGrads * GNN_MAX_TYPES),          # ABI 6: one gradient holder per node type (composite models)
                 # ABI 7: the device word that says whether the step's gradients are valid (the optimizers' gate) and the previous step's, read for free
-                ('grads_ok_dev', C.POINTER(C.c_void_p)), ('prev_grads_ok_host', C.POINTER(C.c_int32))]
+                ('grads_ok_dev', C.POINTER(C.c_void_p)), ('prev_grads_ok_host', C.POINTER(C.c_int32)),
+                # ABI 8: the networks' Dropout layers (positions >= 1) and the step's mask seed
+                ('drop_state', DropoutSpec * GNN_MAX_TYPES), ('drop_output', DropoutSpec), ('drop_seed', C.c_uint32)]
 
 
 class ShardLoopArgs(C.Structure):       # gnn_shard_loop_args_t (ABI 7): the sharded loop driven from native code (csrc/shard_loop.hpp)
@@ -190,6 +208,24 @@ def lib():
         l.gnn_debug_occupy.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         l.gnn_debug_occupy_until.restype = C.c_int
         l.gnn_debug_occupy_until.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        l.gnn_device_malloc.restype = C.c_int
+        l.gnn_device_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        l.gnn_device_free.restype = C.c_int
+        l.gnn_device_free.argtypes = [C.c_void_p]
+        for fn_ in (l.gnn_ipc_export, l.gnn_ipc_close): fn_.restype = C.c_int
+        l.gnn_ipc_export.argtypes = [C.c_void_p, C.c_void_p]
+        l.gnn_ipc_close.argtypes = [C.c_void_p]
+        l.gnn_ipc_open.restype = C.c_int
+        l.gnn_ipc_open.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        l.gnn_shard_iteration_peers.restype = C.c_int
+        l.gnn_shard_iteration_peers.argtypes = [C.POINTER(LoopArgs), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                                C.POINTER(PeerSet)]
+        l.gnn_peer_wait.restype = C.c_int
+        l.gnn_peer_wait.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        l.gnn_peer_publish.restype = C.c_int
+        l.gnn_peer_publish.argtypes = [C.POINTER(PeerSet), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        l.gnn_debug_host_flag.restype = C.c_int
+        l.gnn_debug_host_flag.argtypes = [C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_void_p)]
         l.gnn_debug_expiry_beacon.restype = C.c_int
         l.gnn_debug_expiry_beacon.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]
         l.gnn_state_step_agg.restype = C.c_int

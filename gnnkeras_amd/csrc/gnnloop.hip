@@ -984,7 +984,7 @@ int iteration_prefix(const gnn_loop_args_t &a, const Plan &p, const int *gate, c
 int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, int n_gate, int gate_stride,
                     const float *src, float *dst, int row_base, int *flag_next, float *k_out, float k_val,
                     hipStream_t st, const gnn_csr_t *adj_override = nullptr, const float *agg_init = nullptr,
-                    const int *rows_override = nullptr, int count_override = 0) {
+                    const int *rows_override = nullptr, int count_override = 0, const gnn_peer_set_t *peers = nullptr) {
     auto type_of = [&](int t) { return fused_type(a, p, t); };
     TRY(launch_heavy(a, p, n_gate == 1 ? gate : nullptr, src, st));
     const gnn_csr_t &adj = adj_override ? *adj_override : iter_adjacency(a, p);
@@ -1006,13 +1006,20 @@ int iteration_fused(const gnn_loop_args_t &a, const Plan &p, const int *gate, in
     fa.k_out = k_out; fa.k_val = k_val;
     fa.err = p.err;
     fa.agg_init = agg_init;
+    if (peers) {
+        if (peers->n_peers < 0 || peers->n_peers > GNN_MAX_PEERS) return fail("n_peers %d out of [0, %d]", peers->n_peers, GNN_MAX_PEERS);
+        fa.n_peers = peers->n_peers;
+        for (int i = 0; i < peers->n_peers; ++i) fa.peer_out[i] = peers->state_out_full[i];
+    }
     if (p.xc_ok && !adj.w && (agg_init || fused_generation(p.SP, p.N, a.flags) == 4)) fa.Xc = p.Xc;
     if (fa.n_types == 0) {                      // no nodes at all: only the iteration counter moves
         if (k_out) TRY(launch_converge(fa.gate, src, src, 0, p.S, p.SP, p.SP, a.state_threshold, flag_next, k_out, k_val, st));
         return 0;
     }
+    if (fa.n_peers > 0 && (p.SP == 128 || p.T != 1 || adj.w || a.net_state[0].n_layers != 1 || (p.SP != 32 && p.SP != 64) || p.n_heavy != 0))
+        return fail("peer stores: homogeneous one-layer shards without per-arc weights or hub rows, state widths 17 .. 64");
     if (p.SP == 128) { FUSED_OK(gnn::launch_wide(fa, device_cus(), st, 0)); return 0; }
-    const int gen = agg_init ? 4 : iteration_generation(a, p);
+    const int gen = (agg_init || fa.n_peers > 0) ? 4 : iteration_generation(a, p);
     if (gen == 4) FUSED_OK(gnn::launch_fused4(fa, p.SP, device_cus(), st));
     else FUSED_OK(gnn::launch_fused2(fa, p.SP, 8, device_cus(), st));
     return 0;
@@ -1509,7 +1516,7 @@ __global__ void __launch_bounds__(64) k_debug_occupy(unsigned long long ticks, i
     const unsigned long long t0 = wall_clock64();
     int polls = 0;
     while (wall_clock64() - t0 < ticks) {
-        if (release && __hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (release && __hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;      // (system scope: the word may be host memory)
         __builtin_amdgcn_s_sleep(64); ++polls;
     }
     if (threadIdx.x == 0 && polls < 0) { occ_smem[0] = polls; *sink = occ_smem[0]; }      // (keeps the LDS allocation alive; never taken)
@@ -1521,6 +1528,18 @@ int gnn_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t millisecon
     if (!attr) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_debug_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     k_debug_occupy<<<n_workgroups, 64, (size_t)lds_bytes, (hipStream_t)stream>>>((unsigned long long)milliseconds * 100000ull, nullptr, nullptr);
     LAUNCH_OK();
+    return 0;
+}
+
+int gnn_debug_host_flag(int32_t **host_out, int32_t **dev_out) {
+    static int *h = nullptr, *d = nullptr;
+    if (!host_out || !dev_out) return fail("gnn_debug_host_flag: NULL pointer");
+    if (!h) {
+        HIP_OK(hipHostMalloc((void **)&h, 64, hipHostMallocMapped));
+        HIP_OK(hipHostGetDevicePointer((void **)&d, h, 0));
+    }
+    *h = 0;
+    *host_out = h; *dev_out = d;
     return 0;
 }
 
@@ -1602,6 +1621,103 @@ int gnn_shard_iteration(const gnn_loop_args_t *args, const float *state_in_full,
     if (can_fuse(a, p))
         return iteration_fused(a, p, g, g ? 1 : 0, 0, state_in_full, state_out_full, row_base, flag_out, a.k_out, (float)(iteration + 1), st);
     return iteration_unfused(a, p, g, state_in_full, state_out_full, row_base, flag_out, a.k_out, (float)(iteration + 1), st);
+}
+
+// ---- the exchange inside the iteration kernel (include/gnnloop.h: gnn_shard_iteration_peers, gnn_peer_wait / _publish, gnn_ipc_*) --------
+int gnn_shard_iteration_peers(const gnn_loop_args_t *args, const float *state_in_full, float *state_out_full, int32_t row_base,
+                              const int32_t *gate, int32_t n_gate, int32_t gate_stride, int32_t *flag_out, int32_t iteration,
+                              const gnn_peer_set_t *peers) {
+    if (!args || !peers) return fail("args / peers is NULL");
+    const gnn_loop_args_t &a = *args;
+    if (!state_in_full || !state_out_full || !flag_out) return fail("state buffers / flag_out are NULL");
+    if (iteration < 0 || iteration >= a.max_iteration) return fail("iteration %d out of [0, max_iteration)", iteration);
+    if (n_gate < 0 || (n_gate > 0 && !gate)) return fail("bad gate list");
+    Plan p;
+    TRY(make_plan(a, a.workspace, p, false));
+    if (row_base < 0 || row_base + p.N > a.adjacency.n_src) return fail("row_base out of the full buffer");
+    if (!can_fuse(a, p)) return fail("peer stores need the fused iteration kernel");
+    hipStream_t st = (hipStream_t)a.stream;
+    const int *g = nullptr;
+    if (n_gate > 0 && !(a.flags & GNN_FLAG_NO_EARLY_EXIT)) {
+        k_or_flags<<<1, 64, 0, st>>>(gate, n_gate, gate_stride, p.flags + iteration);
+        LAUNCH_OK();
+        g = p.flags + iteration;
+    }
+    HIP_OK(hipMemsetAsync(flag_out, 0, sizeof(int32_t), st));
+    return iteration_fused(a, p, g, g ? 1 : 0, 0, state_in_full, state_out_full, row_base, flag_out, a.k_out, (float)(iteration + 1), st,
+                           nullptr, nullptr, nullptr, 0, peers);
+}
+
+// buffers whose BASE pointer a host can export (a framework's caching allocator hands out interior pointers of larger segments)
+int gnn_device_malloc(void **device_ptr, size_t bytes) {
+    if (!device_ptr || bytes == 0) return fail("gnn_device_malloc: bad arguments");
+    HIP_OK(hipMalloc(device_ptr, bytes));
+    HIP_OK(hipMemset(*device_ptr, 0, bytes));
+    return 0;
+}
+int gnn_device_free(void *device_ptr) {
+    if (device_ptr) HIP_OK(hipFree(device_ptr));
+    return 0;
+}
+
+int gnn_ipc_export(const void *device_ptr, void *handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (!device_ptr || !handle64) return fail("gnn_ipc_export: NULL pointer");
+    hipIpcMemHandle_t h;
+    HIP_OK(hipIpcGetMemHandle(&h, const_cast<void *>(device_ptr)));
+    memcpy(handle64, &h, 64);
+    return 0;
+}
+int gnn_ipc_open(const void *handle64, void **device_ptr) {
+    if (!handle64 || !device_ptr) return fail("gnn_ipc_open: NULL pointer");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, 64);
+    HIP_OK(hipIpcOpenMemHandle(device_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return 0;
+}
+int gnn_ipc_close(void *device_ptr) {
+    if (!device_ptr) return 0;
+    HIP_OK(hipIpcCloseMemHandle(device_ptr));
+    return 0;
+}
+
+// every peer has published `value`: lane p polls arrive_local[p] (system scope: the peers' stores come from other processes / devices)
+__global__ void __launch_bounds__(64) k_peer_wait(const int *arrive_local, int world, int rank, int value, unsigned long long wait_ticks, float *k_err) {
+    const int p = threadIdx.x;
+    if (p >= world || p == rank) return;
+    const bool ok = gnn::wait_until(wait_ticks, [&]() { return __hip_atomic_load(arrive_local + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value >= 0; });
+    if (!ok && k_err) atomicAdd(k_err, -1.0e9f);              // (k < 0: an arrival never came - the caller's check_last_k raises)
+}
+// the slice's trailing flag row to every peer, then - behind a system-scope release - this rank's arrival word, everywhere
+__global__ void __launch_bounds__(64) k_peer_publish(gnn_peer_set_t ps, int *arrive_local, const float *flag_row, long long row_off, int row_floats, int rank, int value) {
+#pragma unroll
+    for (int pi = 0; pi < GNN_MAX_PEERS; ++pi)
+        if (pi < ps.n_peers)
+            for (int c = threadIdx.x; c < row_floats; c += 64) ps.state_out_full[pi][row_off + c] = flag_row[c];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(arrive_local + rank, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int pi = 0; pi < GNN_MAX_PEERS; ++pi)
+            if (pi < ps.n_peers) __hip_atomic_store(ps.arrive[pi] + rank, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+int gnn_peer_wait(const int32_t *arrive_local, int32_t world_size, int32_t rank, int32_t value, float *k_out_error, void *stream) {
+    if (!arrive_local || world_size < 1 || world_size > GNN_MAX_PEERS + 1 || rank < 0 || rank >= world_size) return fail("gnn_peer_wait: bad arguments");
+    if (world_size == 1) return 0;
+    k_peer_wait<<<1, 64, 0, (hipStream_t)stream>>>(arrive_local, world_size, rank, value, gnn::wait_ticks(), k_out_error);
+    LAUNCH_OK();
+    return 0;
+}
+int gnn_peer_publish(const gnn_peer_set_t *peers, int32_t *arrive_local, const float *flag_row_local, int64_t flag_row_offset_floats,
+                     int32_t row_floats, int32_t rank, int32_t value, void *stream) {
+    if (!peers || !arrive_local || peers->n_peers < 0 || peers->n_peers > GNN_MAX_PEERS || rank < 0 || rank > GNN_MAX_PEERS)
+        return fail("gnn_peer_publish: bad arguments");
+    if (row_floats > 0 && !flag_row_local) return fail("gnn_peer_publish: flag_row_local is NULL");
+    k_peer_publish<<<1, 64, 0, (hipStream_t)stream>>>(*peers, arrive_local, flag_row_local, (long long)flag_row_offset_floats, row_floats, rank, value);
+    LAUNCH_OK();
+    return 0;
 }
 
 // ---- overlap of the exchange with own-range work (gnnkeras_amd/distributed.py) ----------------------------

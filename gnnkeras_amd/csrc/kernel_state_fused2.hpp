@@ -63,6 +63,10 @@ struct Fused2Args {
                                                    // of the arcs this launch does NOT walk (own-range arcs, summed while the
                                                    // exchange was in flight: distributed.py overlap); nullptr otherwise
     const void *hdr; void *hdr_write;              // k_state_fused4<.., HDR = true> (experiment builds only): the first-job header / where to write it
+    // k_state_fused4<.., PEERS = true> (node-range shards, SURVEY 8e "each rank writes its slice to all peers, one hop"): every new row is
+    // stored to state_out AND, at the same offset, to the full state buffers of the other ranks (mapped with hipIpcOpenMemHandle:
+    // gnn_ipc_open) - the exchange rides in the kernel's epilogue instead of following it as a collective
+    float *peer_out[GNN_MAX_PEERS]; int n_peers;
 };
 
 // name of the state-transition kernel the calling thread launched last (gnn_last_kernel_name(): bench.py's roofline record)

@@ -96,7 +96,7 @@ __device__ __forceinline__ int f4_ld_acquire(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int SP, bool HAS_W, int DEPTH, int NC, bool L2, bool INIT = false, bool XC = false, int VPL = 1, bool HDR = false>
+template <int SP, bool HAS_W, int DEPTH, int NC, bool L2, bool INIT = false, bool XC = false, int VPL = 1, bool HDR = false, bool PEERS = false>
 __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     // The gate word(s), the W1 fill and the gather waves' first CSR row are all fetched before anything is waited for:
     // three dependent round trips at the head of every launch become one.  Nothing is written to global memory before
@@ -522,8 +522,15 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
                         d2 = fmaf(d, d, d2);
                         n2 = fmaf(ov[e], ov[e], n2);
                     }
-                    if (j >= 0)
-                        *reinterpret_cast<f32x4 *>(obase + ((unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * r)) = nv;
+                    if (j >= 0) {
+                        const unsigned ooff = (unsigned)(a.row_base + j) * (unsigned)(SP * 4) + 16u * r;
+                        *reinterpret_cast<f32x4 *>(obase + ooff) = nv;
+                        if constexpr (PEERS) {              // ... and into every peer's full buffer, same offset (static indices: no scratch copy of the table)
+#pragma unroll
+                            for (int pi = 0; pi < GNN_MAX_PEERS; ++pi)
+                                if (pi < a.n_peers) *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(a.peer_out[pi]) + ooff) = nv;
+                        }
+                    }
                 }
 #pragma unroll
                 for (int off = 8; off >= 1; off >>= 1) {
@@ -552,12 +559,12 @@ __global__ void __launch_bounds__(1024, 8) k_state_fused4(Fused2Args a) {
     }
 }
 
-template <int SP, bool HAS_W, int DEPTH, bool L2 = false, int NC = 4, bool INIT = false, bool XC = false, int VPL = 1, bool HDR = false>
+template <int SP, bool HAS_W, int DEPTH, bool L2 = false, int NC = 4, bool INIT = false, bool XC = false, int VPL = 1, bool HDR = false, bool PEERS = false>
 int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     using Cfg = Fused4Cfg<SP, NC, L2, XC, VPL>;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC, VPL, HDR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC, VPL, HDR, PEERS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)Cfg::LDS_BYTES) != hipSuccess) return 1;
         attr = true;
     }
@@ -579,15 +586,31 @@ int launch_fused4_one(Fused2Args &fa, int n_cu, hipStream_t st) {
     }
     const int grid = fa.blk_begin[fa.n_types];
     if (grid == 0) return 0;
-    if (VPL == 1 && !HDR)
+    if (PEERS)
+        GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s,%s,%s,%d,%s,true> (peer stores)", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? "true" : "false", XC ? "true" : "false", VPL, HDR ? "true" : "false");
+    else if (VPL == 1 && !HDR)
         GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s,%s,%s>", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? "true" : "false", XC ? "true" : "false");
     else
         GNN_SET_KERNEL_NAME("k_state_fused4<%d,%s,%d,%d,%s,%s,%s,%d,%s>", SP, HAS_W ? "true" : "false", DEPTH, NC, L2 ? "true" : "false", INIT ? "true" : "false", XC ? "true" : "false", VPL, HDR ? "true" : "false");
-    k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC, VPL, HDR><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
+    k_state_fused4<SP, HAS_W, DEPTH, NC, L2, INIT, XC, VPL, HDR, PEERS><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(fa);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 inline int launch_fused4(Fused2Args &fa, int SP, int n_cu, hipStream_t st) {
+    if (fa.n_peers > 0) {          // the exchange in the epilogue: homogeneous one-layer shards without per-arc weights, widths 17 .. 64
+        if (fa.w || fa.tp[0].W2 || (SP != 32 && SP != 64)) return 1;
+#define F4_PEER(SPV)                                                                                                               \
+        if (SP == SPV) {                                                                                                           \
+            if (fa.agg_init) return fa.Xc ? launch_fused4_one<SPV, false, 4, false, 4, true, true, 1, false, true>(fa, n_cu, st)   \
+                                          : launch_fused4_one<SPV, false, 4, false, 4, true, false, 1, false, true>(fa, n_cu, st); \
+            return fa.Xc ? launch_fused4_one<SPV, false, 4, false, 4, false, true, 1, false, true>(fa, n_cu, st)                   \
+                         : launch_fused4_one<SPV, false, 4, false, 4, false, false, 1, false, true>(fa, n_cu, st);                 \
+        }
+        F4_PEER(32)
+        F4_PEER(64)
+#undef F4_PEER
+        return 1;
+    }
 #define F4_CASE(SPV)                                                                                                  \
     case SPV:                                                                                                         \
         if (fa.agg_init) {                                                                                            \

@@ -98,6 +98,13 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
     if (a.type_offsets[0] != 0 || a.type_offsets[p.n_types] != p.N) return fail("type_offsets must span [0, n_nodes]");
     const gnn_mlp_t &no = a.net_output;
     TRY(check_mlp(no, "net_output", ws != nullptr));
+    TRY(check_dropout(ta.drop_output, no, "net_output"));
+    bool drop_s = false;                               // (a state network with Dropout layers: the general kernels)
+    for (int t = 0; t < p.n_types; ++t) {
+        TRY(check_mlp(a.net_state[t], "net_state", ws != nullptr));
+        TRY(check_dropout(ta.drop_state[t], a.net_state[t], "net_state"));
+        drop_s |= ta.drop_state[t].n > 0;
+    }
     const bool arc = a.focus == GNN_FOCUS_ARC;      // CompositeGNN.py:315-327: [state_src | state_dst | arc label] of the masked arcs
     const int expect_o = arc ? 2 * p.S + p.A : p.S;
     if (no.in_dim != expect_o) return fail("net_output.in_dim %d != %d expected for this focus (composite models filter on the state alone)", no.in_dim, expect_o);
@@ -111,7 +118,7 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
     // and iteration
     p.SPs = p.S <= 16 ? 16 : p.S <= 32 ? 32 : 64;
     p.n_wg = 0; p.wg_begin[0] = 0;
-    bool uniform = p.S <= 64 && train_small_enabled() && p.N < train_big_min_nodes();
+    bool uniform = p.S <= 64 && train_small_enabled() && p.N < train_big_min_nodes() && !drop_s;
     int bn_seen = -1;
     for (int t = 0; t < p.n_types; ++t) {
         const gnn_mlp_t &m = a.net_state[t];
@@ -123,7 +130,7 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
     }
     p.small = uniform && p.n_wg >= 1 && p.n_wg <= std::min(device_cus(), 256) && (size_t)p.K * p.N * p.SPs * sizeof(float) <= agg_tape_budget();
     p.ldS = p.small ? p.SPs : p.S;
-    p.big = !p.small && composite_big_applies(ta, p.N, p.S, p.W_comp, &p.B.XT);
+    p.big = !p.small && !drop_s && composite_big_applies(ta, p.N, p.S, p.W_comp, &p.B.XT);
     p.B.XW = 32 * p.B.XT;
 
     Carver c(ws);
@@ -158,7 +165,7 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
         if (y.m->in_dim != y.in_dim) return fail("net_state[%d].in_dim %d != %d expected from the graph dims", t, y.m->in_dim, y.in_dim);
         if (y.m->units[y.m->n_layers - 1] != p.S) return fail("net_state[%d] output width %d != state width %d", t, y.m->units[y.m->n_layers - 1], p.S);
         y.off_state = y.d_t; y.off_agg = y.d_t + p.S; y.off_comp = y.d_t + 2 * p.S;
-        carve_net(c, y.nc, *y.m, p.big ? 0 : y.count, p.part_floats);      // (large graphs: no per-layer row buffers - the kernels stream the tape)
+        carve_net(c, y.nc, *y.m, p.big ? 0 : y.count, p.part_floats, &ta.drop_state[t]);      // (large graphs: no per-layer row buffers - the kernels stream the tape)
         y.nc.m = y.m; y.nc.g = &y.g;
         y.stats = c.take<float>((size_t)p.K * 2 * y.in_dim);
         y.stats_tpl = c.take<float>(2 * (size_t)y.in_dim);
@@ -173,7 +180,7 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
         p.sm_partBN[t] = c.take<float>(p.small ? (size_t)tiles_t * 2 * y.in_dim : 0);
     }
     // every node is an output row (out_index the identity: checked on the device, read with k), one thin Dense over the state alone
-    p.head_fast = p.big && !arc && no.n_layers == 1 && no.units[0] <= 4 && p.M == p.N && p.S % 4 == 0 && p.S / 4 <= 32;
+    p.head_fast = p.big && !arc && no.n_layers == 1 && no.units[0] <= 4 && p.M == p.N && p.S % 4 == 0 && p.S / 4 <= 32 && ta.drop_output.n == 0;
     p.part_h = c.take<float>(p.head_fast ? (size_t)BIG_HEAD_BLOCKS * ((size_t)no.in_dim * no.units[0] + no.units[0]) : 0);
     p.inv = c.take<int>((p.small || p.big) ? p.N : 0);
     if (p.big) {
@@ -221,7 +228,7 @@ int make_cplan(const gnn_train_args_t &ta, void *ws, CPlan &p) {
     p.sm_part = c.take<float>(p.small ? (size_t)2 * p.n_wg * 8 * p.SPs : 0);
     p.sm_dxa = c.take<float>(p.small ? (size_t)p.N * p.SPs : 0);
     p.sm_bar = c.take<unsigned long long>(p.small ? 4 : 0);
-    carve_net(c, p.co, no, p.M, p.part_floats);
+    carve_net(c, p.co, no, p.M, p.part_floats, &ta.drop_output);
     p.co.m = &no; p.co.g = &ta.grad_output;
     {
         int nc_; rows_per_chunk_for(std::max(p.M, 1), &nc_);
@@ -671,10 +678,12 @@ int train_step_composite(const gnn_train_args_t &ta) {
             }
             float *hs[GNN_MAX_LAYERS];
             for (int l = 0; l < ns.n_layers; ++l) hs[l] = y.nc.hid[l];
-            TRY(forward_layers(ns, segs, n, y.count, W0, b0, hs, gate, st, nullptr, bn_on_load, centre));
+            DropRun drs{&ta.drop_state[q], ta.drop_seed, t, {}};      // (ABI 8: the type's Dropout layers, fresh masks every iteration)
+            for (int qq = 0; qq <= ns.n_layers; ++qq) drs.buf[qq] = y.nc.dropbuf[qq];
+            TRY(forward_layers(ns, segs, n, y.count, W0, b0, hs, gate, st, nullptr, bn_on_load, centre, &drs));
             // the type's rows of the new state (CompositeGNN.py:229-231: scatter_nd + reduce_sum over the one-hot types).  A closed gate
             // leaves hs stale and the scatter harmless: state t + 1 is never read then.
-            TRY(scatter_rows(hs[ns.n_layers - 1], p.S, y.rows, y.count, p.S, s_n, p.S, st));
+            TRY(scatter_rows(drop_at(&drs, ns.n_layers) ? drs.buf[ns.n_layers] : hs[ns.n_layers - 1], p.S, y.rows, y.count, p.S, s_n, p.S, st));
         }
         TRY(launch_converge(gate, s_n, s_t, p.N, p.S, p.S, p.S, a.state_threshold, p.flags + t + 1, p.k_dev, (float)(t + 1), st));
     }
@@ -721,9 +730,13 @@ int train_step_composite(const gnn_train_args_t &ta) {
         bn_req_off[0] = 0; bn_req_idx[0] = a.out_index; n_state_segs = 1;
         osegs[nos++] = gnn::Seg{state_k, a.out_index, p.S, p.S, 0};
     }
+    DropRun dro{&ta.drop_output, ta.drop_seed, 0, {}};
+    for (int qq = 0; qq <= no.n_layers; ++qq) dro.buf[qq] = p.co.dropbuf[qq];
+    const bool drop_o_last = drop_at(&dro, no.n_layers);          // (a Dropout layer behind the last Dense: the network's output is its dropped-out copy)
+    if (drop_o_last && !p.pooled) dro.buf[no.n_layers] = ta.y_pred;
     float *ohs[GNN_MAX_LAYERS];
-    for (int l = 0; l < no.n_layers; ++l) ohs[l] = (l == no.n_layers - 1 && !p.pooled) ? ta.y_pred : p.co.hid[l];
-    float *out_nodes = ohs[no.n_layers - 1];
+    for (int l = 0; l < no.n_layers; ++l) ohs[l] = (l == no.n_layers - 1 && !p.pooled && !drop_o_last) ? ta.y_pred : p.co.hid[l];
+    float *out_nodes = drop_o_last ? dro.buf[no.n_layers] : ohs[no.n_layers - 1];
     if (p.M > 0) {
         const float *W0 = no.kernel[0], *b0 = no.bias[0];
         if (bn_o) {
@@ -742,7 +755,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
             }
             W0 = p.Wf_o; b0 = p.bf_o;
         }
-        TRY(forward_layers(no, osegs, nos, p.M, W0, b0, ohs, nullptr, st, nullptr, nullptr, bn_o ? p.stats_o : nullptr));
+        TRY(forward_layers(no, osegs, nos, p.M, W0, b0, ohs, nullptr, st, nullptr, nullptr, bn_o ? p.stats_o : nullptr, &dro));
     }
     if (p.pooled) TRY(launch_aggregate(nullptr, a.nodegraph, out_nodes, p.T, p.T, ta.y_pred, p.T, st));
     gnn::k_loss_grad<<<cdiv(std::max(p.R, 1), 256), 256, 0, st>>>(ta.loss_kind, ta.targets, ta.y_pred, ta.sample_weight, p.R, p.T, p.dpred, p.loss_rows);
@@ -766,7 +779,7 @@ int train_step_composite(const gnn_train_args_t &ta) {
     } else {
     HIP_OK(hipMemsetAsync(p.G_state, 0, sizeof(float) * (size_t)p.N * p.S, st));
     if (p.M > 0) {
-        TRY(net_backward(p.co, osegs, nos, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, no.in_dim, p.part, st));
+        TRY(net_backward(p.co, osegs, nos, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, no.in_dim, p.part, st, -1, 0, &dro));
         gnn::BnGradReq rq[2];
         for (int i = 0; i < n_state_segs; ++i) rq[i] = gnn::BnGradReq{p.dx_o_all + bn_req_off[i], no.in_dim, state_k, p.S, bn_req_idx[i], p.S, bn_req_off[i]};
         TRY(bn_input_grads(no, p.co, p.stats_o, rq, n_state_segs, p.M, st));
@@ -832,15 +845,18 @@ int train_step_composite(const gnn_train_args_t &ta) {
             const float *stats = ns.has_bn ? y.stats + (size_t)t * 2 * y.in_dim : nullptr;
             float *hs[GNN_MAX_LAYERS];
             for (int l = 0; l < ns.n_layers; ++l) hs[l] = y.nc.hid[l];
-            if (ns.n_layers > 1) {                 // hidden activations are not on the tape: recompute them
+            DropRun drs{&ta.drop_state[q], ta.drop_seed, t, {}};      // (iteration t's masks again: the same keys)
+            for (int qq = 0; qq <= ns.n_layers; ++qq) drs.buf[qq] = y.nc.dropbuf[qq];
+            const bool drop_any = ta.drop_state[q].n > 0;
+            if (ns.n_layers > 1 || drop_any) {     // hidden activations are not on the tape: recompute them (with Dropout layers: the last layer's too)
                 const bool folded = ns.has_bn && ns.units[0] <= 4;
                 const float *W0 = folded ? y.Wf + (size_t)t * y.in_dim * ns.units[0] : ns.kernel[0], *b0 = folded ? y.bf + (size_t)t * ns.units[0] : ns.bias[0];
-                gnn_mlp_t head = ns; head.n_layers = ns.n_layers - 1;
-                TRY(forward_layers(head, segs, n, y.count, W0, b0, hs, nullptr, st, nullptr, (ns.has_bn && !folded) ? stats : nullptr, folded ? stats : nullptr));
+                gnn_mlp_t head = ns; head.n_layers = drop_any ? ns.n_layers : ns.n_layers - 1;
+                TRY(forward_layers(head, segs, n, y.count, W0, b0, hs, nullptr, st, nullptr, (ns.has_bn && !folded) ? stats : nullptr, folded ? stats : nullptr, &drs, true));
             }
-            TRY(gather_rows(s_n, p.S, y.rows, y.count, p.S, hs[ns.n_layers - 1], p.S, st));      // the last layer's output: the type's rows of state t + 1
+            if (!drop_any) TRY(gather_rows(s_n, p.S, y.rows, y.count, p.S, hs[ns.n_layers - 1], p.S, st));      // the last layer's output: the type's rows of state t + 1
             TRY(gather_rows(p.G_state, p.S, y.rows, y.count, p.S, y.Gc, p.S, st));
-            TRY(net_backward(y.nc, segs, n, hs, y.Gc, p.S, y.count, stats, t != k - 1, y.dx, 2 * p.S, p.part, st, -1, y.off_state));
+            TRY(net_backward(y.nc, segs, n, hs, y.Gc, p.S, y.count, stats, t != k - 1, y.dx, 2 * p.S, p.part, st, -1, y.off_state, &drs));
             gnn::BnGradReq rq[2] = {gnn::BnGradReq{y.dx, 2 * p.S, s_t, p.S, y.rows, p.S, y.off_state},
                                     gnn::BnGradReq{y.dx + p.S, 2 * p.S, agg_t, p.S, y.rows, p.S, y.off_agg}};
             TRY(bn_input_grads(ns, y.nc, stats, rq, 2, y.count, st));

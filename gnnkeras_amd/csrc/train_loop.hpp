@@ -21,7 +21,51 @@ struct NetCtx {
     float *P, *q, *m1, *m2;         // first-layer scratch: [in_dim x H1], [H1], [in_dim], [in_dim]
     float *G[2];                    // gradient ping-pong [rows x max units]
     float *hid[GNN_MAX_LAYERS];     // layer outputs [rows x units[l]] (the last one may alias a caller buffer)
+    float *dropbuf[GNN_MAX_LAYERS + 1];   // [q]: what the Dense at position q consumes when Dropout layers sit there ([rows x units[q - 1]]); else NULL
 };
+
+// ---- Dropout / AlphaDropout layers of a network call (ABI 8: gnn_dropout_spec_t; reference MLP.py:60-66) -------------------------------------
+// The masks are the counter hash of gnn_dropout keyed by (step seed, network, call, layer): nothing is stored, the backward pass of a call
+// regenerates them.  Positions 1 .. n_layers (behind a Dense layer's activation); position 0 is refused by the plans.
+inline unsigned lowbias32_host(unsigned h) { h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16; return h; }
+inline unsigned drop_key(unsigned seed, unsigned net_id, unsigned call, unsigned index) {
+    unsigned h = 0x9E3779B9u;
+    const unsigned v[4] = {seed, net_id, call, index};
+    for (int i = 0; i < 4; ++i) h = lowbias32_host(h ^ v[i]);
+    return h;
+}
+struct DropRun {
+    const gnn_dropout_spec_t *d;           // NULL or n == 0: no Dropout layers
+    unsigned seed; int call;
+    float *buf[GNN_MAX_LAYERS + 1];        // [q]: destination of the dropped-out copy for position q (forward)
+};
+inline bool drop_at(const DropRun *r, int q) {
+    if (!r || !r->d) return false;
+    for (int i = 0; i < r->d->n; ++i) if (r->d->pos[i] == q) return true;
+    return false;
+}
+// every Dropout layer at position q: forward x -> y (list order; later layers in place on y), backward in place on y = x (reverse order)
+int run_dropout(const DropRun &r, int q, const float *x, int ldx, float *y, int ldy, int M, int H, bool backward, hipStream_t st) {
+    const gnn_dropout_spec_t &d = *r.d;
+    const float *src = x;
+    for (int ii = 0; ii < d.n; ++ii) {
+        const int i = backward ? d.n - 1 - ii : ii;
+        if (d.pos[i] != q) continue;
+        TRY(gnn_dropout(src, src == x ? ldx : ldy, y, ldy, M, H, d.rate[i], drop_key(r.seed, (unsigned)d.net_id, (unsigned)r.call, (unsigned)d.index[i]), d.alpha,
+                        backward ? 1 : 0, (void *)st));
+        src = y;
+    }
+    return 0;
+}
+int check_dropout(const gnn_dropout_spec_t &d, const gnn_mlp_t &m, const char *name) {
+    if (d.n < 0 || d.n > GNN_MAX_DROPOUT) return fail("%s: %d dropout layers (0 .. %d)", name, d.n, GNN_MAX_DROPOUT);
+    for (int i = 0; i < d.n; ++i) {
+        if (d.pos[i] == 0) return fail("%s: Dropout in front of the first Dense layer (position 0): such networks train through the building blocks", name);
+        if (d.pos[i] < 0 || d.pos[i] > m.n_layers || (i > 0 && d.pos[i] < d.pos[i - 1])) return fail("%s: dropout positions must ascend within [1, n_layers]", name);
+        if (!(d.rate[i] > 0.0f && d.rate[i] < 1.0f)) return fail("%s: dropout rate %g outside (0, 1)", name, (double)d.rate[i]);
+    }
+    return 0;
+}
 
 // Bytes of neighbour sums the tape may keep (one N x S matrix per iteration) instead of recomputing each in the backward sweep.
 // Sized for a 288 GB device: 32 GiB by default (C4 with 50 iterations is 12.8 GB), GNN_TRAIN_TAPE_MB overrides.
@@ -79,8 +123,12 @@ int max_units_of(const gnn_mlp_t &m) { int h = 1; for (int i = 0; i < m.n_layers
 
 size_t grad_part_floats(int K, int H, int M) { int nc; rows_per_chunk_for(std::max(M, 1), &nc); return (size_t)nc * ((size_t)K * H + H); }
 
-void carve_net(Carver &c, NetCtx &x, const gnn_mlp_t &m, int rows, size_t &part_floats) {
+void carve_net(Carver &c, NetCtx &x, const gnn_mlp_t &m, int rows, size_t &part_floats, const gnn_dropout_spec_t *drop = nullptr) {
     int fan_in = m.in_dim;
+    DropRun dr{drop, 0u, 0, {}};
+    for (int q = 0; q <= GNN_MAX_LAYERS; ++q) x.dropbuf[q] = nullptr;
+    for (int q = 1; q <= m.n_layers; ++q)
+        if (drop_at(&dr, q)) x.dropbuf[q] = c.take<float>((size_t)std::max(rows, 1) * m.units[q - 1]);
     for (int l = 0; l < m.n_layers; ++l) {
         x.Wt[l] = c.take<float>((size_t)fan_in * m.units[l]);
         x.hid[l] = c.take<float>((size_t)std::max(rows, 1) * m.units[l]);
@@ -106,6 +154,9 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     TRY(check_mlp(a.net_state[0], "net_state", ws != nullptr));
     TRY(check_mlp(a.net_output, "net_output", ws != nullptr));
     const gnn_mlp_t &ns = a.net_state[0], &no = a.net_output;
+    TRY(check_dropout(ta.drop_state[0], ns, "net_state"));
+    TRY(check_dropout(ta.drop_output, no, "net_output"));
+    const bool drop_s = ta.drop_state[0].n > 0, drop_o = ta.drop_output.n > 0;      // (a state network with Dropout: the general kernels)
     p.with_labels = a.state_dim > 0;
     p.in_s = ns.in_dim; p.in_o = no.in_dim; p.H1s = ns.units[0]; p.H1o = no.units[0];
     const int expect_s = a.state_dim > 0 ? 2 * p.S + 2 * p.L + p.A : 2 * p.S + p.A;
@@ -125,15 +176,15 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     // the starter configuration's 14 label columns run the 16-wide kernels), or one launch per layer and iteration
     p.Kc = (p.with_labels ? 2 * p.L : 0) + p.A;
     p.big = p.N >= train_big_min_nodes() && ns.n_layers == 1 && ns.units[0] == p.S && (p.S == 16 || p.S == 32 || p.S == 64) &&
-            p.Kc <= 32 && ns.activation[0] != GNN_ACT_SOFTMAX && (size_t)p.N * p.S * 4 < ((size_t)1 << 32) && p.K > 0;
+            p.Kc <= 32 && ns.activation[0] != GNN_ACT_SOFTMAX && (size_t)p.N * p.S * 4 < ((size_t)1 << 32) && p.K > 0 && !drop_s;
     // every node is an output row (out_index ascending and n_out == n_nodes: the identity), one thin Dense: kernels_train_big.hpp
     p.head_fast = p.big && no.n_layers == 1 && no.units[0] <= 4 && a.focus != GNN_FOCUS_ARC && p.M == p.N && p.S % 4 == 0 &&
-                  p.S / 4 + ((p.with_labels ? p.L : 0) + 3) / 4 <= 32;
+                  p.S / 4 + ((p.with_labels ? p.L : 0) + 3) / 4 <= 32 && !drop_o;
     p.SPs = p.S <= 16 ? 16 : p.S <= 32 ? 32 : 64;
     p.tiled = ta.n_tiles > 0 && ta.tile_node_begin != nullptr;
     p.n_wg = p.tiled ? ta.n_tiles : cdiv(p.N, 64);
     if (p.tiled && p.n_wg > 256) { p.tiled = false; p.n_wg = cdiv(p.N, 64); }
-    p.small = !p.big && train_small_enabled() && ns.n_layers == 1 && ns.units[0] == p.S && p.S <= 64 && p.Kc <= 32 &&
+    p.small = !p.big && !drop_s && train_small_enabled() && ns.n_layers == 1 && ns.units[0] == p.S && p.S <= 64 && p.Kc <= 32 &&
               ns.activation[0] != GNN_ACT_SOFTMAX && p.K > 0 && p.n_wg <= device_cus() && p.N < train_big_min_nodes() &&
               (size_t)std::max(p.K, 1) * p.N * p.SPs * sizeof(float) <= agg_tape_budget();
     p.ldS = p.small ? p.SPs : p.S;
@@ -161,8 +212,8 @@ int make_train_plan(const gnn_train_args_t &ta, void *ws, TrainPlan &p) {
     p.loss_rows = c.take<float>(std::max(p.R, 1));
     p.isrc = c.take<int>(std::max(p.M, 1)); p.idst = c.take<int>(std::max(p.M, 1));
     p.part_floats = 0;
-    carve_net(c, p.cs, ns, p.N, p.part_floats);
-    carve_net(c, p.co, no, p.M, p.part_floats);
+    carve_net(c, p.cs, ns, p.N, p.part_floats, &ta.drop_state[0]);
+    carve_net(c, p.co, no, p.M, p.part_floats, &ta.drop_output);
     {   // column-statistics partials of the large-batch path: (chunks + 1) x widest segment
         int nc; rows_per_chunk_for(std::max(p.N, 1), &nc);
         p.part_floats = std::max(p.part_floats, (size_t)(nc + 1) * std::max(p.in_s, p.in_o));
@@ -240,8 +291,12 @@ struct PredFuse { const float *old; int ld; float thr; int *flag; float *k_out; 
 // the first layer stages them (k_segdense), with (W0, b0) the raw kernel / bias; NULL: (W0, b0) are used as they are.
 // `center` (the column means, by weight row): (W0, b0) is a CENTRED fold (fold_with_stats(.., true)) and the first layer subtracts
 // the means from its inputs as it stages them (layers whose kernel wants folded weights: the thin-output kernel).
+// `drop`: the network's Dropout layers (positions >= 1): hs[l] stay the layers' own outputs, what the next Dense consumes is drop->buf[l + 1];
+// the network's output is then drop->buf[n_layers] when a layer sits behind the last Dense (`skip_last_drop`: a backward recompute, which
+// does not need it).
 int forward_layers(const gnn_mlp_t &m, const gnn::Seg *segs, int nseg, int M, const float *W0, const float *b0, float *const *hs,
-                   const int *gate, hipStream_t st, PredFuse *pred = nullptr, const float *bn_stats = nullptr, const float *center = nullptr) {
+                   const int *gate, hipStream_t st, PredFuse *pred = nullptr, const float *bn_stats = nullptr, const float *center = nullptr,
+                   const DropRun *drop = nullptr, bool skip_last_drop = false) {
     for (int l = 0; l < m.n_layers; ++l) {
         gnn::SegDenseArgs a;
         memset(&a, 0, sizeof(a));
@@ -253,21 +308,30 @@ int forward_layers(const gnn_mlp_t &m, const gnn::Seg *segs, int nseg, int M, co
             if (bn_stats) { a.in_gamma = m.bn_gamma; a.in_beta = m.bn_beta; a.in_mean = bn_stats; a.in_var = bn_stats + m.in_dim; a.in_eps = m.bn_eps; }
             else a.in_center = center;
         } else {
+            const float *src = hs[l - 1];
+            if (drop_at(drop, l)) {
+                TRY(run_dropout(*drop, l, hs[l - 1], m.units[l - 1], drop->buf[l], m.units[l - 1], M, m.units[l - 1], false, st));
+                src = drop->buf[l];
+            }
             a.nseg = 1;
-            a.seg[0] = gnn::Seg{hs[l - 1], nullptr, (int)m.units[l - 1], (int)m.units[l - 1], 0};
+            a.seg[0] = gnn::Seg{src, nullptr, (int)m.units[l - 1], (int)m.units[l - 1], 0};
             a.W = m.kernel[l]; a.bias = m.bias[l];
         }
         a.ldw = a.H;
         const bool thin_softmax = m.activation[l] == GNN_ACT_SOFTMAX && thin_dense_applies(a);
         a.act = (m.activation[l] == GNN_ACT_SOFTMAX && !thin_softmax) ? GNN_ACT_LINEAR : m.activation[l];
         a.Y = hs[l]; a.ldy = m.units[l];
-        if (pred && l == m.n_layers - 1 && a.H <= 64 && a.H > 4 && m.activation[l] != GNN_ACT_SOFTMAX) {   // predicate in the epilogue
+        if (pred && l == m.n_layers - 1 && a.H <= 64 && a.H > 4 && m.activation[l] != GNN_ACT_SOFTMAX && !drop_at(drop, m.n_layers)) {   // predicate in the epilogue
             a.pred_old = pred->old; a.ld_pred = pred->ld; a.pred_thr = pred->thr; a.pred_flag = pred->flag;
             a.pred_k = pred->k_out; a.pred_kval = pred->k_val;
             pred->fused = true;
         }
         TRY(launch_segdense(a, st));
         if (m.activation[l] == GNN_ACT_SOFTMAX && !thin_softmax) TRY(launch_softmax(gate, a.Y, a.M, a.H, a.ldy, nullptr, st));
+    }
+    if (!skip_last_drop && drop_at(drop, m.n_layers)) {
+        const int H = m.units[m.n_layers - 1];
+        TRY(run_dropout(*drop, m.n_layers, hs[m.n_layers - 1], H, drop->buf[m.n_layers], H, M, H, false, st));
     }
     return 0;
 }
@@ -294,22 +358,25 @@ int act_grad_inplace(float *G, int ldg, const float *Y, int ldy, int M, int H, i
 // [0, kdx) BEFORE the BatchNormalization input gradient (the caller applies it to the segments it needs).
 // `second_row` >= 0: dx_all is [M x kdx] = columns [0, kdx/2) of the input followed by columns [second_row, second_row + kdx/2);
 // `first_col`: the block starts at that input column instead of 0 (composite models: the state segment sits behind the type's labels).
+// `drop`: the Dropout layers of this call (their forward copies in drop->buf[]; the masks are regenerated from the call's keys).
 int net_backward(NetCtx &x, const gnn::Seg *segs, int nseg, float *const *hs, float *G, int ldg, int M, const float *stats, bool accumulate,
-                 float *dx_all, int kdx, float *part, hipStream_t st, int second_row = -1, int first_col = 0) {
+                 float *dx_all, int kdx, float *part, hipStream_t st, int second_row = -1, int first_col = 0, const DropRun *drop = nullptr) {
     const gnn_mlp_t &m = *x.m;
     int n_chunks;
     const int rpc = rows_per_chunk_for(std::max(M, 1), &n_chunks);
+    if (drop_at(drop, m.n_layers) && M > 0) TRY(run_dropout(*drop, m.n_layers, G, ldg, G, ldg, M, m.units[m.n_layers - 1], true, st));
     for (int l = m.n_layers - 1; l >= 1; --l) {
         const int H = m.units[l], Kp = m.units[l - 1];
         TRY(act_grad_inplace(G, ldg, hs[l], H, M, H, m.activation[l], st));
         dim3 grid(n_chunks, cdiv(Kp, 64), cdiv(H, 64));
-        gnn::k_dense_grad_partial<<<grid, 256, 0, st>>>(hs[l - 1], Kp, nullptr, Kp, G, ldg, H, M, rpc, part, 1);
+        gnn::k_dense_grad_partial<<<grid, 256, 0, st>>>(drop_at(drop, l) ? drop->buf[l] : hs[l - 1], Kp, nullptr, Kp, G, ldg, H, M, rpc, part, 1);
         LAUNCH_OK();
         const int n = Kp * H + H;
         gnn::k_reduce_partials<<<cdiv(n, 64), 256, 0, st>>>(part, n_chunks, n, x.g->dkernel[l], accumulate ? 1 : 0, 1.0f, Kp * H, x.g->dbias[l]);
         LAUNCH_OK();
         float *Gn = (G == x.G[0]) ? x.G[1] : x.G[0];
-        TRY(dense_plain(G, ldg, H, x.Wt[l], Kp, Kp, M, Gn, Kp, st));      // dL/d hs[l-1] = dZ . W[l]^T
+        TRY(dense_plain(G, ldg, H, x.Wt[l], Kp, Kp, M, Gn, Kp, st));      // dL/d (input of Dense l) = dZ . W[l]^T
+        if (drop_at(drop, l) && M > 0) TRY(run_dropout(*drop, l, Gn, Kp, Gn, Kp, M, Kp, true, st));      // ... through the Dropout layers in front of it
         G = Gn; ldg = Kp;
     }
     const int H = m.units[0], K = m.in_dim;
@@ -1028,10 +1095,16 @@ static int train_step_impl(const gnn_train_args_t &ta) {
                 W0 = Wf; b0 = bf; centre = stats;
             } else bn_on_load = stats;           // BatchNormalization applied as the first layer stages its inputs: no fold launch
         }
+        // Dropout layers (ABI 8): fresh masks every iteration (call = t); a layer behind the last Dense makes the NEW STATE the dropped-out
+        // output (the tape holds it; the network's own output stays in its layer buffer for the backward recompute)
+        DropRun drs{&ta.drop_state[0], ta.drop_seed, t, {}};
+        for (int q = 0; q <= ns.n_layers; ++q) drs.buf[q] = p.cs.dropbuf[q];
+        const bool drop_last = drop_at(&drs, ns.n_layers);
+        if (drop_last) drs.buf[ns.n_layers] = s_n;
         float *hs[GNN_MAX_LAYERS];
-        for (int l = 0; l < ns.n_layers; ++l) hs[l] = l == ns.n_layers - 1 ? s_n : p.cs.hid[l];
+        for (int l = 0; l < ns.n_layers; ++l) hs[l] = (l == ns.n_layers - 1 && !drop_last) ? s_n : p.cs.hid[l];
         PredFuse pf{s_t, p.S, a.state_threshold, p.flags + t + 1, p.k_dev, (float)(t + 1), false};
-        TRY(forward_layers(ns, segs, n, p.N, W0, b0, hs, gate, st, &pf, bn_on_load, centre));
+        TRY(forward_layers(ns, segs, n, p.N, W0, b0, hs, gate, st, &pf, bn_on_load, centre, &drs));
         if (!pf.fused) TRY(launch_converge(gate, s_n, s_t, p.N, p.S, p.S, p.S, a.state_threshold, p.flags + t + 1, p.k_dev, (float)(t + 1), st));
     }
     float k_f2[3] = {0.0f, 0.0f, 0.0f};
@@ -1082,9 +1155,13 @@ static int train_step_impl(const gnn_train_args_t &ta) {
             if (p.with_labels) { osegs[nos++] = gnn::Seg{a.nodes, a.out_index, a.ld_nodes, p.L, ocol}; ocol += p.L; }
         }
     }
+    DropRun dro{&ta.drop_output, ta.drop_seed, 0, {}};
+    for (int q = 0; q <= no.n_layers; ++q) dro.buf[q] = p.co.dropbuf[q];
+    const bool drop_o_last = drop_at(&dro, no.n_layers);          // (a Dropout layer behind the last Dense: the network's output is its dropped-out copy)
+    if (drop_o_last && !p.pooled) dro.buf[no.n_layers] = ta.y_pred;
     float *ohs[GNN_MAX_LAYERS];
-    for (int l = 0; l < no.n_layers; ++l) ohs[l] = (l == no.n_layers - 1 && !p.pooled) ? ta.y_pred : p.co.hid[l];
-    float *out_nodes = ohs[no.n_layers - 1];
+    for (int l = 0; l < no.n_layers; ++l) ohs[l] = (l == no.n_layers - 1 && !p.pooled && !drop_o_last) ? ta.y_pred : p.co.hid[l];
+    float *out_nodes = drop_o_last ? dro.buf[no.n_layers] : ohs[no.n_layers - 1];
     if (p.M > 0) {
         const float *W0 = no.kernel[0], *b0 = no.bias[0];
         if (bn_o) {
@@ -1111,7 +1188,7 @@ static int train_step_impl(const gnn_train_args_t &ta) {
             }
             W0 = p.Wf_o; b0 = p.bf_o;
         }
-        TRY(forward_layers(no, osegs, nos, p.M, W0, b0, ohs, nullptr, st, nullptr, nullptr, bn_o ? p.stats_o : nullptr));
+        TRY(forward_layers(no, osegs, nos, p.M, W0, b0, ohs, nullptr, st, nullptr, nullptr, bn_o ? p.stats_o : nullptr, &dro));
     }
     if (p.pooled) TRY(launch_aggregate(nullptr, a.nodegraph, out_nodes, p.T, p.T, ta.y_pred, p.T, st));
     // ---- loss and its gradient ----------------------------------------------------------------------------------------------------
@@ -1136,7 +1213,7 @@ static int train_step_impl(const gnn_train_args_t &ta) {
     if (p.head_fast) {
         TRY(head_backward(p, a, state_k, out_nodes, G_out, bn_o ? p.stats_o : nullptr, st, (dzpath && k > 0) ? (int)ns.activation[0] : -1));
     } else if (p.M > 0) {
-        TRY(net_backward(p.co, osegs, nos, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, p.in_o, p.part, st));
+        TRY(net_backward(p.co, osegs, nos, ohs, G_out, p.T, p.M, bn_o ? p.stats_o : nullptr, false, p.dx_o_all, p.in_o, p.part, st, -1, 0, &dro));
         gnn::BnGradReq rq[2];
         for (int i = 0; i < n_state_segs; ++i)
             rq[i] = gnn::BnGradReq{p.dx_o_all + bn_req_off[i], p.in_o, state_k, p.ldS, bn_req_idx[i], p.S, bn_req_off[i]};
@@ -1187,13 +1264,16 @@ static int train_step_impl(const gnn_train_args_t &ta) {
         if (!p.agg_taped) TRY(launch_aggregate(nullptr, a.adjacency, s_t, p.S, p.S, p.agg, p.S, st));
         const int n = state_segs(a, p, t, segs);
         const float *stats = bn_s ? p.stats_s + (size_t)t * 2 * p.in_s : nullptr;
+        DropRun drs{&ta.drop_state[0], ta.drop_seed, t, {}};                      // (iteration t's masks again: the same keys)
+        for (int q = 0; q <= ns.n_layers; ++q) drs.buf[q] = p.cs.dropbuf[q];
+        const bool drop_any = ta.drop_state[0].n > 0;
         float *hs[GNN_MAX_LAYERS];
-        for (int l = 0; l < ns.n_layers; ++l) hs[l] = l == ns.n_layers - 1 ? s_n : p.cs.hid[l];
-        if (ns.n_layers > 1) {                     // hidden activations are not on the tape: recompute them (the last layer's are)
+        for (int l = 0; l < ns.n_layers; ++l) hs[l] = (l == ns.n_layers - 1 && !drop_any) ? s_n : p.cs.hid[l];
+        if (ns.n_layers > 1 || drop_any) {         // hidden activations are not on the tape: recompute them (the last layer's are, unless a Dropout layer follows it)
             const bool folded = bn_s && fold_s;
             const float *W0 = folded ? p.Wf_s + (size_t)t * p.in_s * p.H1s : ns.kernel[0], *b0 = folded ? p.bf_s + (size_t)t * p.H1s : ns.bias[0];
-            gnn_mlp_t head = ns; head.n_layers = ns.n_layers - 1;
-            TRY(forward_layers(head, segs, n, p.N, W0, b0, hs, nullptr, st, nullptr, (bn_s && !fold_s) ? stats : nullptr, folded ? stats : nullptr));
+            gnn_mlp_t head = ns; head.n_layers = drop_any ? ns.n_layers : ns.n_layers - 1;
+            TRY(forward_layers(head, segs, n, p.N, W0, b0, hs, nullptr, st, nullptr, (bn_s && !fold_s) ? stats : nullptr, folded ? stats : nullptr, &drs, true));
         }
         // 'average' / 'sum' / 'normalized' entries depend on the destination only (a.adjacency carries one scale per row): the large-
         // graph kernel scales the agg-half of a row's gradient once, and the transposed aggregate walks UNIT weights (no 4 bytes per arc)
@@ -1247,7 +1327,7 @@ static int train_step_impl(const gnn_train_args_t &ta) {
             if (t == 0) break;                                       // nothing consumes d loss / d state_0: no input gradient, no transposed aggregate
             if (!dx_done) TRY(launch_train_bwd_dx(ba, p.S, st));
         } else {
-            TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, t > 0 ? p.dx_s_all : nullptr, t > 0 ? p.kdx_s : 0, p.part, st, p.off_agg));
+            TRY(net_backward(p.cs, segs, n, hs, p.G_state, p.S, p.N, stats, t != k - 1, t > 0 ? p.dx_s_all : nullptr, t > 0 ? p.kdx_s : 0, p.part, st, p.off_agg, 0, &drs));
             if (t == 0) break;                                       // (as above)
             gnn::BnGradReq rq[2] = {gnn::BnGradReq{p.dx_s_all, p.kdx_s, s_t, p.S, nullptr, p.S, 0},
                                     gnn::BnGradReq{p.dx_s_all + p.S, p.kdx_s, agg_t, p.S, nullptr, p.S, p.off_agg}};

@@ -571,11 +571,22 @@ class ShardedLoop:
         return self
 
     def close(self):
-        """Release the native loop's communicator (collective at world size > 1)."""
+        """Release the native loop's communicator (collective at world size > 1) and the peer mappings / raw buffers of the peer exchange."""
         if self._comm is not None:
             nat.lib().gnn_comm_destroy(self._comm)
             self._comm = None
         self.native_loop = False
+        if self.peer_exchange:
+            torch.cuda.synchronize(self.device)
+            if self.world_size > 1: dist.barrier(group=self.group)      # nobody writes a buffer that is about to go
+            for opened in self._peers.values():
+                for q in opened: nat.lib().gnn_ipc_close(C.c_void_p(q))
+            self._peers, self.peer_exchange = {}, False
+            shape = tuple(self.buf[0].shape)
+            self.buf = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+            self.arrive = None
+            for q in self._raw: nat.lib().gnn_device_free(C.c_void_p(q))
+            self._raw = []
 
     def _kernels_only(self):
         """One iteration's launches without the exchange although a communicator exists (profile_iteration's `kernel_s`)."""
@@ -611,6 +622,88 @@ class ShardedLoop:
         nat.check(nat.lib().gnn_shard_loop(C.byref(sa)))
 
     # ---- backend-independent orchestration ------------------------------------------------------------------------------
+    # ---- the exchange inside the iteration kernel: peer stores over IPC-mapped buffers (include/gnnloop.h: gnn_shard_iteration_peers) ----------
+    # SURVEY 8e "each rank writes its slice to all 7 peers, 1 hop": the iteration kernel's epilogue stores every new row to the own full buffer
+    # and to the peers' full buffers (mapped with hipIpcOpenMemHandle), so the all-gather no longer FOLLOWS the kernel - expected cost per
+    # iteration max(kernel, exchange) instead of their sum.  Opt-in (`enable_peer_exchange()`), the RCCL transports stay the default: this
+    # path has only ever run between two processes sharing one GPU (tests/test_gpu_peer.py) - no performance claim attaches to it.
+    peer_exchange = False
+
+    def enable_peer_exchange(self):
+        """Collective over `self.group` (any backend: only picklable handles travel).  Re-allocates the two full state buffers and an
+        arrival array as plain device allocations (an IPC handle names an allocation's BASE pointer; the caching allocator hands out
+        interior pointers), exchanges their handles and maps every peer's."""
+        if type(self)._layout != 'allgather' or self.overlap or self.composite or self.n_virtual_rows or self.per_arc_weights:
+            raise NotImplementedError('peer stores: homogeneous all-gather shards without the own-range split, hub rows or per-arc weights')
+        if self.SP not in (32, 64): raise NotImplementedError('peer stores: state widths 17 .. 64')
+        if not (1 <= self.world_size <= nat.GNN_MAX_PEERS + 1): raise ValueError('peer stores: 1 .. 8 ranks')
+        lib = nat.lib()
+        self._raw = []
+
+        def raw(shape, dtype):
+            n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            ptr = C.c_void_p(0)
+            nat.check(lib.gnn_device_malloc(C.byref(ptr), n))
+            self._raw.append(ptr.value)
+            holder = type('RawDeviceBuffer', (), {})()
+            holder.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': '<f4' if dtype == torch.float32 else '<i4', 'data': (ptr.value, False), 'version': 2}
+            t = torch.as_tensor(holder, device=self.device)
+            t._holder = holder
+            return t, ptr.value
+        shape = tuple(self.buf[0].shape)
+        (b0, p0), (b1, p1) = raw(shape, torch.float32), raw(shape, torch.float32)
+        self.buf = [b0, b1]
+        self.arrive, pa = raw((max(self.world_size, 8),), torch.int32)
+        handles = []
+        for ptr_ in (p0, p1, pa):
+            h = (C.c_char * 64)()
+            nat.check(lib.gnn_ipc_export(C.c_void_p(ptr_), h))
+            handles.append(bytes(h))
+        every = [None] * self.world_size
+        if self.world_size > 1: dist.all_gather_object(every, handles, group=self.group)
+        else: every[0] = handles
+        self._peers = {}
+        for r, hs in enumerate(every):
+            if r == self.rank: continue
+            opened = []
+            for hb in hs:
+                q = C.c_void_p(0)
+                nat.check(lib.gnn_ipc_open(C.c_char_p(hb), C.byref(q)))
+                opened.append(q.value)
+            self._peers[r] = opened                       # [buf 0, buf 1, arrive] of rank r in THIS process' address space
+        self._arrive_base = 0
+        self.peer_exchange = True
+        if self.world_size > 1: dist.barrier(group=self.group)          # every rank has mapped every buffer before anyone writes
+
+    def _peer_set(self, which_buf: int):
+        ps = nat.PeerSet()
+        ps.n_peers = len(self._peers)
+        for i, r in enumerate(sorted(self._peers)):
+            ps.state_out_full[i] = self._peers[r][which_buf]
+            ps.arrive[i] = self._peers[r][2]
+        return ps
+
+    def _peer_forward(self):
+        """The loop with the exchange in the kernel's epilogue: wait(i) -> iteration i with peer stores -> publish(i + 1)."""
+        m, p, lib = self.model, self.plan, nat.lib()
+        base, K = self._arrive_base, m.max_iteration
+        st = nat.current_stream(self.device)
+        self.args.stream = st
+        none = nat.PeerSet(); none.n_peers = 0
+        sets = [self._peer_set(0), self._peer_set(1)]
+        # "ready": this rank's previous forward is over and state_0 / the initial flags are in place (stream order) - peers may write buffer 1
+        nat.check(lib.gnn_peer_publish(C.byref(sets[0]), nat.ptr(self.arrive), None, 0, 0, self.rank, base, st))
+        for it in range(K):
+            nat.check(lib.gnn_peer_wait(nat.ptr(self.arrive), self.world_size, self.rank, base + it, nat.ptr(self.k), st))
+            src, dst = self.buf[it & 1], self.buf[(it + 1) & 1]
+            gate, n_gate, stride = self._gate_args(it)
+            flag_out = self._flag_out(it)
+            ps = sets[(it + 1) & 1]
+            nat.check(lib.gnn_shard_iteration_peers(C.byref(self.args), nat.ptr(src), nat.ptr(dst), p.row_base, gate, n_gate, stride, flag_out, it, C.byref(ps)))
+            nat.check(lib.gnn_peer_publish(C.byref(ps), nat.ptr(self.arrive), flag_out, (p.row_base + p.chunk) * self.SP, self.SP, self.rank, base + it + 1, st))
+        nat.check(lib.gnn_peer_wait(nat.ptr(self.arrive), self.world_size, self.rank, base + K, nat.ptr(self.k), st))
+        self._arrive_base = base + K + 1
+
     def _load_state0(self, state0_full):
         p = self.plan
         if isinstance(state0_full, torch.Tensor):
@@ -673,6 +766,9 @@ class ShardedLoop:
             if int(ok) == 1: self._tune_pipeline(state0_full)
         if self.native_loop:
             self._native_iterations()
+            return self._finish(*self._output())
+        if self.peer_exchange:
+            self._peer_forward()
             return self._finish(*self._output())
         if not self.overlap:
             for it in range(m.max_iteration):

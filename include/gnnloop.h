@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 7
+#define GNN_ABI_VERSION 8
 
 /* Keras activation names accepted by the reference MLP builder (GNN/Models/MLP.py:16). */
 enum gnn_activation {
@@ -77,6 +77,7 @@ typedef struct gnn_mlp {
 } gnn_mlp_t;
 
 #define GNN_MAX_TYPES 8
+#define GNN_MAX_PEERS 7       /* the other GPUs of a fully connected 8-GPU node                                   */
 /* Whole forward pass of one (merged) graph.
  * Homogeneous: replaces GNNnodeBased.Loop (GNN.py:245-274), GNNarcBased.apply_filters (:317-330),
  *              GNNgraphBased.Loop (:341-346).            n_types = 1, type_* unused.
@@ -236,6 +237,10 @@ int gnn_debug_occupy(int32_t n_workgroups, int32_t lds_bytes, int32_t millisecon
 /* ... until the DEVICE word *release_flag becomes non-zero (the test writes it from another stream when ITS condition holds - a co-tenant
  * that leaves on a handshake, not on a clock), at the latest after max_milliseconds (<= 20 000: the kernel cannot hang the GPU). */
 int gnn_debug_occupy_until(int32_t n_workgroups, int32_t lds_bytes, int32_t max_milliseconds, const int32_t *release_flag, void *stream);
+/* One pinned HOST word mapped into the device (zeroed by the call): *host_out for the test to write with a plain store, *dev_out for
+ * gnn_debug_occupy_until's release_flag - a release that needs no launch, so it cannot queue behind the co-tenant it is meant to release
+ * (streams share a few hardware queues). */
+int gnn_debug_host_flag(int32_t **host_out, int32_t **dev_out);
 /* The library's expiry beacon: a DEVICE word the whole-loop / persistent kernels set when one of their bounded waits runs out (never cleared
  * by a kernel; `reset` = 1 zeroes it on `stream`, 2 raises it by hand, 0 leaves it).  Handed to gnn_debug_occupy_until as the release flag it makes a co-tenant that leaves
  * exactly when the first wait of the launch under test has expired - a device-side handshake, no clock on the host. */
@@ -285,6 +290,36 @@ int gnn_shard_iteration_split_rows(const gnn_loop_args_t *args, const gnn_csr_t 
                                    const float *state_in_full, float *state_out_full, int32_t row_base, const int32_t *gate,
                                    int32_t n_gate, int32_t gate_stride, int32_t *flag_out, int32_t iteration,
                                    const int32_t *node_ids, int32_t n_ids, int32_t first_chunk);
+
+/* ---- the exchange inside the iteration kernel (ABI 8; SURVEY 8e: "each rank writes its slice to all 7 peers, 1 hop") ---------------------
+ * Instead of an all-gather BEHIND the kernel, the kernel's epilogue stores every new state row to the rank's own full buffer and, at the
+ * same offset, to the full buffers of the other ranks, mapped into this process with gnn_ipc_open (hipIpcOpenMemHandle; the handles travel
+ * over any host channel).  Ordering between ranks is a monotonically increasing ARRIVAL word per rank in every rank's `arrive` array:
+ *     gnn_peer_wait(value i)      - before iteration i may write: every peer has published i, i.e. has finished iteration i - 1 (its rows
+ *                                   of the buffer iteration i reads have landed here, and it no longer reads the buffer iteration i writes);
+ *     gnn_shard_iteration_peers   - the iteration (gate, kernel with peer stores);
+ *     gnn_peer_publish(value i+1) - behind the kernel on the same stream: the slice's trailing flag row goes to the peers, then - system-scope
+ *                                   release - arrive[rank] = i + 1 in every rank's array.
+ * The values keep growing across forwards (base + i): nothing is ever reset, so no rank can mistake an old arrival for a new one.  The waits
+ * are bounded by GNN_WAIT_MS and raise the sticky error word (k < 0) like every other in-launch wait.  One-layer homogeneous shards without
+ * per-arc weights, state widths 17 .. 64 (the wave-specialised kernel); RCCL stays the default transport (gnnkeras_amd/distributed.py) -
+ * this path has only ever run between two PROCESSES sharing one GPU (tests/test_gpu_peer.py): no performance claim attaches to it. */
+int gnn_device_malloc(void **device_ptr, size_t bytes);              /* hipMalloc + zero fill: an allocation whose BASE pointer can be exported */
+int gnn_device_free(void *device_ptr);
+int gnn_ipc_export(const void *device_ptr, void *handle64);          /* 64-byte hipIpcMemHandle_t of an allocation's BASE pointer */
+int gnn_ipc_open(const void *handle64, void **device_ptr);
+int gnn_ipc_close(void *device_ptr);
+typedef struct gnn_peer_set {
+    int32_t n_peers;
+    float *state_out_full[GNN_MAX_PEERS];      /* the peers' full buffer the iteration WRITES (same layout as the own one)             */
+    int32_t *arrive[GNN_MAX_PEERS];            /* the peers' arrival arrays [world_size]                                                */
+} gnn_peer_set_t;
+int gnn_shard_iteration_peers(const gnn_loop_args_t *args, const float *state_in_full, float *state_out_full, int32_t row_base,
+                              const int32_t *gate, int32_t n_gate, int32_t gate_stride, int32_t *flag_out, int32_t iteration,
+                              const gnn_peer_set_t *peers);
+int gnn_peer_wait(const int32_t *arrive_local, int32_t world_size, int32_t rank, int32_t value, float *k_out_error, void *stream);
+int gnn_peer_publish(const gnn_peer_set_t *peers, int32_t *arrive_local, const float *flag_row_local, int64_t flag_row_offset_floats,
+                     int32_t row_floats, int32_t rank, int32_t value, void *stream);
 
 /* ---- the sharded loop driven from native code (ABI 7; gnnkeras_amd/csrc/shard_loop.hpp) ------------------------------------------------
  * All iterations of a rank in ONE call: own-range partial sums, the halo kernel (whole or in chunk launches), the exchange of the rows
@@ -433,9 +468,25 @@ int gnn_ragged_copy(const gnn_ragged_desc_t *desc, int32_t n_desc, const int32_t
  * `loop` describes graph, networks (their BatchNormalization moving_mean / moving_variance arrays ARE UPDATED in place),
  * focus, out_index, nodegraph, state0, max_iteration, state_threshold and stream exactly as for gnn_loop_forward; its
  * k_out / state_out / out / workspace fields are ignored.  Heterogeneous (composite) models are covered since ABI 6
- * (grad_state_types; gnnkeras_amd/csrc/train_composite.hpp); dropout and LGNN label gradients are not: the caller uses the
- * building blocks for those.
+ * (grad_state_types; gnnkeras_amd/csrc/train_composite.hpp), Dropout layers behind Dense layers since ABI 8 (gnn_dropout_spec_t);
+ * Dropout in front of the first Dense and LGNN label gradients are not: the caller uses the building blocks for those.
  * The call synchronises the stream ONCE (to learn k, as the reference does when it divides by k). */
+/* ABI 8: the Dropout / AlphaDropout layers of one network (reference MLP.py:25-27, :60-66: `dropout_rate`, `dropout_pos`, `alphadropout`) in
+ * a training step.  Layer i of the list sits at POSITION pos[i]: in front of Dense pos[i] (pos = n_layers: behind the last Dense).  The
+ * keep mask of a call is the counter hash of gnn_dropout with key = mix32(drop_seed, net_id, call, index[i]) - call = the iteration for a
+ * state network, 0 for the output network; mix32(v..): h = 0x9E3779B9; for v: h = lowbias32(h ^ v) - so a host that knows the step's seed
+ * can reproduce every mask (oracle/torch_train.py does).  Position 0 (Dropout in front of the first Dense, behind BatchNormalization) is
+ * not taken by gnn_train_step: such networks train through the building blocks. */
+#define GNN_MAX_DROPOUT 8
+typedef struct gnn_dropout_spec {
+    int32_t n;                                 /* dropout layers with rate > 0 (0: none)                            */
+    int32_t alpha;                             /* != 0: AlphaDropout                                                */
+    int32_t net_id;                            /* enters the key: 0.. for state networks (the node type), 1000 for the output network */
+    int32_t pos[GNN_MAX_DROPOUT];              /* ascending, 1 .. n_layers                                          */
+    int32_t index[GNN_MAX_DROPOUT];            /* the layer's index among the network's dropout layers (enters the key) */
+    float rate[GNN_MAX_DROPOUT];               /* 0 < rate < 1                                                      */
+} gnn_dropout_spec_t;
+
 typedef struct gnn_mlp_grads {
     float *dgamma, *dbeta;                     /* [in_dim] each; NULL without BatchNormalization                   */
     float *dkernel[GNN_MAX_LAYERS];            /* same shapes as the network's kernels / biases                     */
@@ -486,6 +537,11 @@ typedef struct gnn_train_args {
      *                       from a sentinel - and the word on the tape untouched. */
     const int32_t **grads_ok_dev;
     int32_t *prev_grads_ok_host;
+    /* ABI 8: Dropout layers (all-zero: none).  A state network with Dropout runs the general kernels (one launch per layer and iteration);
+     * Dropout inside the OUTPUT network alone leaves the loop on whichever fast path applies. */
+    gnn_dropout_spec_t drop_state[GNN_MAX_TYPES];   /* [0] for homogeneous models                                   */
+    gnn_dropout_spec_t drop_output;
+    uint32_t drop_seed;                             /* the step's seed (every mask of the step derives from it)     */
 } gnn_train_args_t;
 /* Arithmetic: float32 throughout.  On graphs of >= GNN_TRAIN_BIG_MIN_NODES (32 768) nodes the first Dense's forward product and dZ . W^T run on
  * the bf16 matrix cores with every float32 operand split into three bf16 terms (six products, float32 accumulation: the accuracy of a

@@ -39,5 +39,20 @@ def pytest_collection_finish(session):
         if mod5 is not None: mod5.start_train_oracle([it.name for it in session.items])
         mod6 = sys.modules.get('test_gpu_round6')          # (the C5-size heterogeneous train-step oracle: tests/test_gpu_round6.py)
         if mod6 is not None: mod6.start_c5_train_oracle([it.name for it in session.items])
+        # the float64 autograd oracles of the large-graph training tests (tests/test_gpu_training.py: prefetch_oracle), a few at a time
+        modt = sys.modules.get('test_gpu_training')
+        jobs = [(it.function, dict(it.callspec.params)) for it in session.items
+                if getattr(getattr(it, 'function', None), '_prefetch_oracle', False) and hasattr(it, 'callspec')]
+        if modt is not None and jobs:
+            import threading, queue
+            q = queue.Queue()
+            for j in jobs: q.put(j)
+
+            def worker():
+                while True:
+                    try: fn, kw = q.get_nowait()
+                    except queue.Empty: return
+                    modt.run_oracle_only(fn, kw)
+            for _ in range(4): threading.Thread(target=worker, daemon=True).start()
     except Exception:
         pass                                                   # (never fail a collection over a head start)

@@ -354,7 +354,11 @@ def test_composite_convergence_step_matches_oracle(N, d):
 # ----------------------------------------------------------------------------------------------------------------------
 # training at large M: the row-streaming kernels of kernels_train_big.hpp
 # ----------------------------------------------------------------------------------------------------------------------
+from test_gpu_training import prefetch_oracle
+
+
 @pytest.mark.parametrize('d,bn,mode,thr', [(64, True, 'average', 0.0), (32, True, 'sum', 0.0), (16, False, 'average', 0.0), (32, False, 'average', -1.0)])
+@prefetch_oracle
 def test_large_graph_training_step_matches_autograd(d, bn, mode, thr):
     """From 32 768 nodes `gnn_train_step` runs an iteration on k_aggregate_stats (neighbour sum + its BatchNorm statistics),
     k_train_fwd (rows straight into the matrix cores, statistics folded into the weights, predicate and the next iteration's
@@ -375,15 +379,15 @@ def test_large_graph_training_step_matches_autograd(d, bn, mode, thr):
     s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
     key = ('large_graph_step', d, bn, mode, thr)              # (the inputs are seeded: the alternative-kernel tests re-run a configuration on its oracle result)
     if thr < 0:                                               # early exit: a threshold at which the oracle stops after 1 .. 3 iterations
-        from test_gpu_training import oracle_step, _ORACLE_CACHE
-        if (key, 'thr') not in _ORACLE_CACHE:
+        from test_gpu_training import oracle_step, cached_oracle
+
+        def search():
             seen = {}
-            for thr in (0.05, 0.1, 0.2, 0.4, 0.8):
-                k = seen[thr] = oracle_step(GNNnodeBased(ns, no, d, 4, thr), x, y, sw, s0, 'categorical_crossentropy')['k']
-                if 0 < k < 4: break
-            assert 0 < k < 4, f'no threshold with an early exit found: {seen}'
-            _ORACLE_CACHE[(key, 'thr')] = thr
-        thr = _ORACLE_CACHE[(key, 'thr')]
+            for th in (0.05, 0.1, 0.2, 0.4, 0.8):
+                k = seen[th] = oracle_step(GNNnodeBased(ns, no, d, 4, th), x, y, sw, s0, 'categorical_crossentropy')['k']
+                if 0 < k < 4: return th
+            raise AssertionError(f'no threshold with an early exit found: {seen}')
+        thr = cached_oracle((key, 'thr'), search)
     model = GNNnodeBased(ns, no, d, 4, thr)
     res, want = check_step(model, x, y, sw, s0, oracle_key=key)      # both orchestrations against the oracle
 

@@ -23,6 +23,7 @@ from gnnkeras_amd.Models.training import Adam, SGD, LoopTrainer
 from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
 from gnnkeras_amd.synth import er_graph
 from oracle.harness import rel_err
+from test_gpu_training import prefetch_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -477,6 +478,7 @@ def test_large_graph_training_on_the_kernels_before_the_lds_ring(monkeypatch):
 
 @pytest.mark.parametrize('N,d,bn,mode', [(40_037, 64, True, 'average'), (33_001, 32, True, 'average'), (40_037, 64, False, 'average'),
                                          (36_001, 64, True, 'normalized'), (36_001, 32, False, 'normalized')])
+@prefetch_oracle
 def test_large_graph_training_with_a_ragged_last_tile(N, d, bn, mode):
     """Node counts that are no multiple of 64 / 16: the last workgroup of k_train_wgrad_b6 (and of the one-pass kernel without BatchNormalization)
     fills its LDS ring past the end of the rows - LDS-DMA loads outside the buffer window must land ZEROS, not leave the slot's previous
@@ -495,4 +497,4 @@ def test_large_graph_training_with_a_ragged_last_tile(N, d, bn, mode):
     x, y, sw = MultiGraphSequencer([g], 'n', mode, 1, shuffle=False)[0]
     ns, no = nets('n', d, bn, scale=0.5)
     s0 = rng.normal(0, 0.1, (N, d)).astype(np.float32)
-    check_step(GNNnodeBased(ns, no, d, 3, 0.0), x, y, sw, s0)
+    check_step(GNNnodeBased(ns, no, d, 3, 0.0), x, y, sw, s0, oracle_key=('ragged', N, d, bn, mode))

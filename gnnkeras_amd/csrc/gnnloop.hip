@@ -179,7 +179,10 @@ bool thin_dense_applies(const gnn::SegDenseArgs &a) {
     if (a.H > 4) return false;
     int K = 0;
     for (int s = 0; s < a.nseg; ++s) K = std::max(K, a.seg[s].wrow + a.seg[s].width);
-    return (size_t)K * a.H * sizeof(float) <= 48 * 1024;
+    // (what the kernel asks for: the weights rounded up to whole 16-byte pieces, the column means, a pad - inside the 64 KB a launch gets
+    //  without raising the kernel's dynamic-LDS limit: at H = 1 the weights alone may be 48 KB of it)
+    const size_t lds = ((((size_t)K * a.H + 3) & ~(size_t)3) + (size_t)K + 4) * sizeof(float);
+    return (size_t)K * a.H * sizeof(float) <= 48 * 1024 && lds <= 64 * 1024;
 }
 
 int device_cus();

@@ -116,6 +116,14 @@ class DataParallel:
         # (heterogeneous models - reference CompositeGNN.py:275-304 - train in both modes since round 5: the exact step all-gathers the
         # batch statistics of every type's network with the shard's row count of that type as weight, zero included)
         self.exact = bool(exact)
+        if self.exact:
+            # (refused HERE, on every rank alike - not from inside a step, where a rank without rows of the network would
+            #  already sit in the step's all-reduce while the others raise)
+            nets = list(model.net_state) if isinstance(model.net_state, (list, tuple)) else [model.net_state]
+            for n_ in nets + [model.net_output]:
+                if any(float(r) > 0 and int(q) == 0 for r, q in zip(n_.dropout_rate or [], n_.dropout_pos or [])):
+                    raise NotImplementedError('the exact data-parallel step does not take a Dropout layer in front of the first Dense (dropout_pos = 0): '
+                                              'use DataParallel(model, exact=False)')
         self.model, self.group = model, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.dp = DPContext(group)

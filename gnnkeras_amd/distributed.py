@@ -570,15 +570,16 @@ class ShardedLoop:
         self.native_loop = True
         return self
 
-    def close(self):
-        """Release the native loop's communicator (collective at world size > 1) and the peer mappings / raw buffers of the peer exchange."""
+    def close(self, collective: bool = True):
+        """Release the native loop's communicator (collective at world size > 1) and the peer mappings / raw buffers of the peer exchange.
+        `collective=False` (the finalizer): local releases only, no barrier."""
         if self._comm is not None:
             nat.lib().gnn_comm_destroy(self._comm)
             self._comm = None
         self.native_loop = False
         if self.peer_exchange:
             torch.cuda.synchronize(self.device)
-            if self.world_size > 1: dist.barrier(group=self.group)      # nobody writes a buffer that is about to go
+            if self.world_size > 1 and collective: dist.barrier(group=self.group)      # nobody writes a buffer that is about to go
             for opened in self._peers.values():
                 for q in opened: nat.lib().gnn_ipc_close(C.c_void_p(q))
             self._peers, self.peer_exchange = {}, False
@@ -587,6 +588,16 @@ class ShardedLoop:
             self.arrive = None
             for q in self._raw: nat.lib().gnn_device_free(C.c_void_p(q))
             self._raw = []
+
+    def __del__(self):                   # (the native communicator / the peer mappings must not outlive the loop object)
+        try:
+            if getattr(self, '_comm', None) is not None or getattr(self, 'peer_exchange', False): self.close(collective=False)
+        except Exception:
+            pass
+
+    def __enter__(self): return self
+
+    def __exit__(self, *exc): self.close()
 
     def _kernels_only(self):
         """One iteration's launches without the exchange although a communicator exists (profile_iteration's `kernel_s`)."""

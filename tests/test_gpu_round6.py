@@ -2,6 +2,8 @@
 reference GNN/Models/CompositeGNN.py:275-304 over the loop of :215-234) - at sizes between the small-graph kernels and BASELINE C5, and at
 C5's own size (500 k nodes / 5 M arcs, 3 node types, d = 64, 10 iterations, BatchNormalization: bench.py's `training.c5_d64_k10`),
 against torch autograd in float64 with the per-tensor bars of tests/test_gpu_training.py (`BARS` + counted kinks)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -181,14 +183,18 @@ def test_composite_train_step_at_c5_size(request):
     c = TRAIN_C5
     model.compile(optimizer=SGD(0.0), loss='categorical_crossentropy')
     kq = [int(np.sum(k_[0])) for k_ in want['kinks_state']]
-    print(f"\nC5-size train step: graph {r['t_graph']:.0f} s, float64 oracle {r['t_oracle']:.0f} s; k = {want['k']}, loss {want['loss']:.6f}; "
-          f"pre-activations within 1e-6 of the selu kink per type: {kq}")
+    lines = [f"C5-size train step: graph {r['t_graph']:.0f} s, float64 oracle {r['t_oracle']:.0f} s; k = {want['k']}, loss {want['loss']:.6f}; "
+             f"pre-activations within 1e-6 of the selu kink per type: {kq}"]
+    print('\n' + lines[0])
     assert want['k'] == c['K']
     w0 = composite_weights(model)
     for native in (True, False):
         set_composite_weights(model, w0)
         summary, _ = composite_compare(model, x, y, sw, s0, want, native, tag='c5_train_step', path='row-streaming')
-        print(f"  {'gnn_train_step ' if native else 'building blocks'} {summary}")
+        lines.append(f"  {'gnn_train_step ' if native else 'building blocks'} {summary}")
+        print(lines[-1])
+    if os.environ.get('GNN_PARITY_OUT'):                        # (scripts/gpu_r6_closing.sh keeps the report of the suite's own run)
+        with open(os.environ['GNN_PARITY_OUT'], 'w') as fh: fh.write('\n'.join(lines) + '\n')
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -54,6 +54,9 @@ struct XWideArgs {
     const float *Wx;                               // first-layer weights in fragment order (k_xwide_weights)
     int N, S, SP;                                  // nodes, state width, leading dimension of the state buffers (multiple of 4)
     int KH, NG, NCB;                               // K per half (SP rounded up to 8), 8-k groups (= KH / 4), 32-column blocks
+    const void *Wb;                                // kernel_state_xwide_b3.hpp: the weights in the fragment order of the 16-k instruction
+    int dbg;                                       //   -DXB_EXPERIMENT builds: ablation bits (GNN_XB_DBG)
+    int NKS, HS, NMW;                              //   16-k steps (= KH / 8), half-slots of the row ring, matrix waves
     int act;
     float thr;
     int *flag_next;
@@ -73,7 +76,7 @@ constexpr int XW_PD = XW_PD_VALUE;   // weight pieces in flight per matrix wave
 constexpr int XW_SPIN_MAX = GNN_F4_SPIN_MAX;   // (-DGNN_F4_SPIN_MAX=0: the debug build whose every wait expires at once, libgnnloop_spin0.so)
 
 inline int xwide_kh(int SP) { return (SP + 7) & ~7; }
-inline size_t xwide_weight_floats(int S, int SP) { return (size_t)((S + 31) / 32) * (xwide_kh(SP) / 4) * 256; }
+inline size_t xwide_weight_floats(int S, int SP) { return (size_t)((S + 31) / 32) * (xwide_kh(SP) / 4) * 256; }      // (either fragment order: this file's or kernel_state_xwide_b3.hpp's)
 inline size_t xwide_lds_bytes(int KH) {
     return sizeof(float) * ((size_t)XW_NS * 32 * (2 * KH + 4) + (size_t)XW_NS * XW_NM * 32 * 2) + sizeof(int) * (3 * XW_NS + 1);
 }

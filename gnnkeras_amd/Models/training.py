@@ -832,14 +832,19 @@ class LoopTrainer:
         pend, self._pending = self._pending, None
         if pend is not None and not self._read_word(pend['view']): self._recover_failed(pend)
 
-    def _recover_failed(self, pend):
+    def _uncount_gated_step(self):
+        """The optimizer launch of a failed step was gated off on the device but counted on the host (`opt.iterations`, Adam's bias
+        correction): take it back BEFORE the next update is issued, so that update n is always computed with step = n."""
+        opt = self.model._optimizer_obj()
+        if hasattr(opt, 'iterations') and isinstance(opt.iterations, int) and opt.iterations > 0: opt.iterations -= 1
+
+    def _recover_failed(self, pend, uncount=True):
         import warnings
         warnings.warn('the persistent backward kernel of a training step could not keep its workgroups resident (GPU shared with other '
                       'long-running work?): its gradients were discarded on the device - weights, optimizer slots and moving statistics '
                       'untouched - and its batch is trained on the general kernels now', RuntimeWarning, stacklevel=4)
         self.recovered_steps = getattr(self, 'recovered_steps', 0) + 1
-        opt = self.model._optimizer_obj()
-        if hasattr(opt, 'iterations') and isinstance(opt.iterations, int) and opt.iterations > 0: opt.iterations -= 1      # (the gated launch did not count)
+        if uncount: self._uncount_gated_step()                  # (the gated launch did not count)
         x_list, y, sample_weight, state0, seed = pend['batch']
         self._train_step_general(x_list, y, sample_weight, state0, seed, True)
 
@@ -1023,11 +1028,13 @@ class LoopTrainer:
         view = tape[aligned - base:aligned - base + 4].view(torch.int32)
         tp = SimpleNamespace(gs=gs_all, go=go, k=int(k_host.value), y_pred=y_pred, state=state, grads_ok=ok_ptr.value, grads_ok_view=view)
         res = {'k': tp.k, 'y_pred': y_pred, 'state': state, 'loss': loss[0]}
+        failed_prev = pend is not None and prev_ok.value == 0
+        if failed_prev: self._uncount_gated_step()              # before THIS step's update is issued: it is update n, not n + 1
         reg = self.finish(tp, apply)
         if reg is not None: res['loss'] = res['loss'] + reg
         if apply and ok_ptr.value: self._pending = {'tape': tape, 'view': view, 'batch': (x_list, y, sample_weight, state0, seed)}
         res['grads_ok'] = view                                   # device int32[1]: 1 when the gradients / the update of this step are valid
-        if pend is not None and prev_ok.value == 0: self._recover_failed(pend)      # the PREVIOUS step's batch, one step late
+        if failed_prev: self._recover_failed(pend, uncount=False)      # the PREVIOUS step's batch, one step late
         return res
 
     def train_step(self, x_list, y, sample_weight, state0=None, seed=None, apply=True):

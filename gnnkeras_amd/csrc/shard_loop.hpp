@@ -79,19 +79,30 @@ int gnn_comm_unique_id(void *out128) {
     return 0;
 }
 
+int gnn_comm_destroy(void *comm);
+
+static int comm_build(GnnComm *c, const void *unique_id128) {
+    RcclApi &api = rccl_api();
+    ncclUniqueId id;
+    memcpy(id.internal, unique_id128, NCCL_UNIQUE_ID_BYTES);
+    RCCL_OK(api.CommInitRank(&c->comm, c->nranks, id, c->rank));
+    HIP_OK(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    for (int i = 0; i < SHARD_MAX_CHUNKS; ++i) HIP_OK(hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&c->ev_landed, hipEventDisableTiming));
+    return 0;
+}
+
 int gnn_comm_create(int32_t nranks, int32_t rank, const void *unique_id128, void **comm_out) {
     RcclApi &api = rccl_api();
     if (!api.error.empty()) return fail("%s", api.error.c_str());
     if (nranks < 1 || rank < 0 || rank >= nranks || !unique_id128 || !comm_out) return fail("gnn_comm_create: bad arguments");
-    std::unique_ptr<GnnComm> c(new GnnComm);
+    GnnComm *c = new GnnComm;
     c->nranks = nranks; c->rank = rank;
-    ncclUniqueId id;
-    memcpy(id.internal, unique_id128, NCCL_UNIQUE_ID_BYTES);
-    RCCL_OK(api.CommInitRank(&c->comm, nranks, id, rank));
-    HIP_OK(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
-    for (int i = 0; i < SHARD_MAX_CHUNKS; ++i) HIP_OK(hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&c->ev_landed, hipEventDisableTiming));
-    *comm_out = c.release();
+    if (comm_build(c, unique_id128)) {              // (the message is set) - the communicator, stream and events built so far go with it
+        (void)gnn_comm_destroy(c);
+        return 1;
+    }
+    *comm_out = c;
     return 0;
 }
 
@@ -128,7 +139,20 @@ static int shard_exchange(GnnComm *c, const gnn_shard_loop_args_t &s, float *buf
     return 0;
 }
 
+static int shard_loop_run(const gnn_shard_loop_args_t *sa);
+
 int gnn_shard_loop(const gnn_shard_loop_args_t *sa) {
+    const int rc = shard_loop_run(sa);
+    if (rc && sa && sa->loop && sa->comm) {
+        // a launch failed with exchanges already queued on the exchange stream: the compute stream waits for them, so that whatever the
+        // caller queues next (a recovery, a free) is ordered behind every transfer that still touches the state buffers
+        GnnComm *c = static_cast<GnnComm *>(sa->comm);
+        if (hipEventRecord(c->ev_landed, c->xstream) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)sa->loop->stream, c->ev_landed, 0);
+    }
+    return rc;
+}
+
+static int shard_loop_run(const gnn_shard_loop_args_t *sa) {
     if (!sa || !sa->loop) return fail("gnn_shard_loop: args / loop is NULL");
     const gnn_shard_loop_args_t &s = *sa;
     const gnn_loop_args_t &a = *s.loop;

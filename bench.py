@@ -576,7 +576,7 @@ def beyond_cache_section(device, d, K_it, aggregation):
 
 
 def wide_state_section(device, aggregation):
-    """State widths 129 .. 256 (kernel_state_xwide.hpp): d = 200 on a 300 k-node / 3 M-arc ER graph built on the device, time per
+    """State widths 129 .. 256 (k_state_xwide_b3, kernel_state_xwide.hpp): d = 200 on a 300 k-node / 3 M-arc ER graph built on the device, time per
     iteration launch from the library's HIP events around the loop, roofline on the algorithmic bytes of an iteration."""
     from gnnkeras_amd import _native as nat
     from gnnkeras_amd.synth import er_device_batch

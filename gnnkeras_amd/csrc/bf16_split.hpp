@@ -1,6 +1,6 @@
 // The three-term bf16 split of an f32 operand and the six matrix instructions of a split product (shared by the training kernels,
 // kernels_train_big.hpp - where the scheme, its accuracy and its measurements are described - and the wide forward kernel,
-// kernel_state_xwide_b3.hpp).  x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to nearest at every level:
+// kernel_state_xwide.hpp).  x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to nearest at every level:
 // exact (8 + 8 + 8 significand bits, signed), and  x w = hi wh + (hi wm + mid wh) + (mid wm + hi wl + lo wh) + O(2^-24 |x w|).
 #pragma once
 #include <hip/hip_runtime.h>

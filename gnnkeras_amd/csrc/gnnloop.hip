@@ -31,7 +31,6 @@
 #include "kernels_setup.hpp"
 #include "kernel_rowdense.hpp"
 #include "kernel_state_xwide.hpp"
-#include "kernel_state_xwide_b3.hpp"
 
 namespace {
 
@@ -1195,9 +1194,6 @@ bool xwide_applies(const gnn_loop_args_t &a, const Plan &p) {
     return true;
 }
 
-// GNN_XWIDE_B3 (read at every call): 1 = the Dense layer on the bf16 matrix cores, operands split into three bf16 terms
-// (kernel_state_xwide_b3.hpp); 0 = the f32 matrix instructions (kernel_state_xwide.hpp).
-bool xwide_b3() { const char *e = getenv("GNN_XWIDE_B3"); return !(e && atoi(e) == 0); }
 #ifdef XB_EXPERIMENT
 int xwide_matrix_waves() { const char *e = getenv("GNN_XWIDE_MW"); return e ? atoi(e) : 0; }
 #else
@@ -1205,9 +1201,7 @@ int xwide_matrix_waves() { return 0; }
 #endif
 
 int setup_xwide(const gnn_loop_args_t &a, const Plan &p, hipStream_t st) {
-    if (xwide_b3())
-        return gnn::launch_xwide_weights_b3(p.tp[0].Wf, (int)a.net_state[0].units[0], p.S, p.tp[0].wrow_state, p.tp[0].wrow_agg, p.SP, p.Wx, st);
-    return gnn::launch_xwide_weights(p.tp[0].Wf, (int)a.net_state[0].units[0], p.S, p.tp[0].wrow_state, p.tp[0].wrow_agg, p.SP, p.Wx, st);
+    return gnn::launch_xwide_weights_b3(p.tp[0].Wf, (int)a.net_state[0].units[0], p.S, p.tp[0].wrow_state, p.tp[0].wrow_agg, p.SP, p.Wx, st);
 }
 
 int iteration_xwide(const gnn_loop_args_t &a, const Plan &p, const int *gate, const float *src, float *dst, int *flag_next, float *k_out,
@@ -1217,16 +1211,14 @@ int iteration_xwide(const gnn_loop_args_t &a, const Plan &p, const int *gate, co
     xa.gate = gate; xa.n_gate = gate ? 1 : 0; xa.gate_stride = 0;
     xa.rowptr = a.adjacency.rowptr; xa.src = a.adjacency.src; xa.w = a.adjacency.w; xa.row_scale = a.adjacency.row_scale;
     xa.state_in = src; xa.state_out = dst;
-    xa.C = p.C; xa.ldC = p.ldC; xa.Wx = p.Wx;
+    xa.C = p.C; xa.ldC = p.ldC; xa.Wb = p.Wx;
     xa.N = p.N; xa.S = p.S; xa.SP = p.SP;
     xa.act = (int)a.net_state[0].activation[0];
     xa.thr = a.state_threshold; xa.flag_next = flag_next; xa.k_out = k_out; xa.k_val = k_val; xa.err = p.err;
-    xa.Wb = p.Wx;
 #ifdef XB_EXPERIMENT
     { const char *e = getenv("GNN_XB_DBG"); xa.dbg = e ? atoi(e) : 0; }
 #endif
-    if (xwide_b3()) FUSED_OK(gnn::launch_xwide_b3(xa, device_cus(), xwide_matrix_waves(), st));
-    else FUSED_OK(gnn::launch_xwide(xa, device_cus(), st));
+    FUSED_OK(gnn::launch_xwide_b3(xa, device_cus(), xwide_matrix_waves(), st));
     return 0;
 }
 

@@ -1,48 +1,61 @@
 // Fused state-transition iteration for state widths 129 .. 256 (one Dense layer, homogeneous graphs): the reference's
 // `convergence` + the `condition` of the next iteration (GNN/Models/GNN.py:217-236, :196-214) in one launch, as
-// k_state_fused4 / k_state_wide do for narrower states.  Before this kernel these widths ran un-fused (k_aggregate_vec writes
-// the neighbour sums, k_rowdense_wide reads them back: 1.15 ms per iteration at d = 200 on 300 k nodes / 3 M arcs = 34 % of the
-// HBM roofline, the Dense layer alone at 47 TFLOP/s).
+// k_state_fused4 / k_state_wide do for narrower states.  Un-fused these widths run at 34 % of the HBM roofline (k_aggregate_vec writes the
+// neighbour sums, k_rowdense_wide reads them back: 1.15 ms per iteration at d = 200 on 300 k nodes / 3 M arcs).
 //
-// What is different at these widths: W1 = [2 d x d] floats is 320 KB at d = 200 - it cannot live in the CU's 160 KB of LDS.
-// So the roles of LDS and L2 are swapped against the narrower kernels:
-//   * the gathered rows [state | neighbour sum] of a 32-node tile live in LDS (two slots of 32 x (2 KH + 4) floats: 132 KB at
-//     KH = 256), filled by the 16 - NCB waves that are not matrix waves (8 .. 11) - one wave per row, a lane per 16-byte chunk, rows
-//     drawn from a ticket counter in LDS, ONE rolling window of 16 neighbour rows + the own row in flight per wave, the row
-//     pointers fetched three rows and the source ids two rows ahead;
-//   * the weights stream from L2 as MFMA operands: a set-up kernel lays them out once per call in fragment order
-//     (k_xwide_weights), so that a matrix wave's lane reads ONE 16-byte piece per four MFMAs, whole 1-KB lines per wave
-//     instruction, XW_PD pieces in flight; every tile re-reads the matrix (L2 traffic ~ (2 KH x 32 NCB x 4 B) per 32 rows, about
-//     the size of the gather traffic; the matrix itself stays resident in each XCD's 4 MB L2);
-//   * NCB <= 8 matrix waves, one per 32-column block of the output, on v_mfma_f32_32x32x2_f32: this chip sustains 156 TFLOP/s on that
-//     instruction against 104-126 on the 16x16x4 one the narrower kernels use (scripts/micro/mfma_peak.hip), and a 32 x 32 block
-//     needs one operand value per lane and 4 096 FLOP.  Operands are swapped (weights = A, rows = B) so that a lane ends up with
-//     columns 8 q + 4 (lane / 32) + 0..3 of ITS row: C, the old state and the new state all move as 16-byte pieces.
-// Measured (d = 200, 300 k nodes / 3 M arcs): 683 us per iteration against 1 150 un-fused (34 -> 57 % of the HBM roofline of its
-// algorithmic bytes); d = 160 on 1 M / 10 M 3 197 -> 1 754 (60 %).  With 8 statically assigned gather waves (the first layout, 742 us;
-// scripts/dev/xw_prof.py on a -DXW_PROFILE build) a matrix wave spends per tile 24 100 cycles in the K loop (two waves
-// share a SIMD's matrix pipe: 25 600 would be the pipe's whole time), 8 300 in the epilogue and 16 200 waiting for the gather waves;
-// rocprofv3: SQ_VALU_MFMA_BUSY_CYCLES 8.4e8 = 46 % of the SIMD-cycles of the launch at the 2.25 GHz GRBM_GUI_ACTIVE shows.  The launch
-// is bound by the gather: 8 gather waves per CU move 4.7 TB/s of lines next to the weight stream (6.2 TB/s with the MFMAs compiled
-// out, 526 us) - the working set (two 240 MB state buffers) is past the Infinity Cache, and this memory system rewards the NUMBER of
-// waves with a gather outstanding (profiles/r01_gather_sweep.txt): hence every wave that is not a matrix wave gathers now (9 at
-// d = 200: 742 -> 683 us; 11 at d = 160: 1 983 -> 1 754).  Tried and
-// measured slower: 4 / 8 / 10 / 12 weight pieces in flight (722 - 772 us); two blocks per matrix wave on alternating tiles so that
-// one wave's epilogue lies under the other's K loop (779 us: the gather still sets the pace); 12 gather waves drawing rows from a
-// ticket counter + 4 matrix waves (one per SIMD, two blocks each): the gather keeps up (the matrix waves wait 2 000 cycles per tile
-// instead of 16 000) but one wave per SIMD runs its K loop at 59 % of the pipe (43 600 cycles per tile against 25 600): 751 us.
-// Slots are handed over with monotonic LDS counters (rows deposited / waves done / rounds freed), workgroup scope, bounded
-// spins that raise the sticky error word (k < 0) exactly as in k_state_fused4.  The convergence predicate needs whole rows:
-// every matrix wave leaves its block's share of |new - old|^2 and |old|^2 per row in LDS, the wave that finishes the tile last
-// adds the shares in block order (deterministic) and tests the rows.
+// W1 = [2 d x d] floats is 320 KB at d = 200 - it cannot live in the CU's 160 KB of LDS.  So the roles of LDS and L2 are swapped against
+// the narrower kernels:
+//   * the gathered rows [state | neighbour sum] of a 32-node tile live in LDS, filled by the 16 - NCB waves that are not matrix waves
+//     (8 .. 11) - one wave per row, a lane per 16-byte chunk, rows drawn from a ticket counter in LDS, ONE rolling window of 16
+//     neighbour rows + the own row in flight per wave, the row pointers fetched three rows and the source ids two rows ahead (this memory
+//     system rewards the NUMBER of waves with a gather outstanding, profiles/r01_gather_sweep.txt: every wave that is not a matrix wave gathers);
+//   * the weights stream from L2 as matrix operands: a set-up kernel lays them out once per call in fragment order (k_xwide_weights_q),
+//     whole 1-KB lines per wave instruction; every tile re-reads the matrix (it stays resident in each XCD's 4 MB L2);
+//   * NCB <= 8 matrix waves, one per 32-column block of the output.  Operands are swapped (weights = A, rows = B) so that a lane ends up
+//     with columns 8 q + 4 (lane / 32) + 0..3 of ITS row: C, the old state and the new state all move as 16-byte pieces;
+//   * the convergence predicate needs whole rows: every matrix wave leaves its block's share of |new - old|^2 and |old|^2 per row in LDS,
+//     the wave that finishes the tile last adds the shares in block order (deterministic) and tests the rows.
+// Rounds 3 - 5 ran the Dense layer on v_mfma_f32_32x32x2_f32 (two 32-row slots of f32 rows; 683 - 707 us at d = 200 = 0.55 - 0.57 of the
+// roofline, a matrix wave's K loop at the pipe's whole time: git history, profiles/r05h_d200_*, profiles/r06_d200_f32_kernel_stats.csv).
+// Round 6 (this file): the Dense layer on the bf16 matrix cores, every f32 operand split into three bf16 terms (bf16_split.hpp: the accuracy
+// of an f32 product chain, not its bits).
+//
+// Why: the f32 form spends 25 600 matrix cycles per SIMD on every 32-row tile at 256 columns (v_mfma_f32_32x32x2_f32: 64 cycles for 2 k)
+// next to a gather that takes ~ 33 000 cycles a tile by itself; six v_mfma_f32_32x32x16_bf16 (32 cycles each) contract 16 k: 9 600.
+// What that changed against the f32 form:
+//   * the gather waves SPLIT the rows they deposit (own state and neighbour sum: 36 VALU instructions a row and wave, once per row - not
+//     once per matrix wave that reads it): a row lies in LDS as three bf16 planes [hi | mid | lo] of 2 KH values, 12 KH + 16 bytes;
+//   * that is 1.5 x the f32 row, so two 32-row slots no longer fit (KH = 256: 197 KB): the slots become a RING of HS = 3 .. 4 half-slots
+//     of 16 rows; tile i of the workgroup lies in half-slots (2 i) % HS and (2 i + 1) % HS, every half-slot is handed over by its own
+//     pair of monotonic counters (rows deposited / times freed);
+//   * the weights stay f32 in L2, in the fragment order of the 16-k instruction (k_xwide_weights_q, once per call: 32 bytes per lane
+//     and k-step as before), and the matrix wave splits each piece in registers (36 VALU instructions a k-step; a piece is read by
+//     one wave only, so nothing is split twice).  Three bf16 planes in L2 save that VALU work and cost 1.5 x the stream: measured equal at
+//     d = 200 (638 / 636 us), slower at 160, faster at 256 by 2 % - not kept;
+//   * the old state for the convergence predicate is rebuilt from the planes (hi + mid + lo is the f32 value exactly).
+// Same hand-overs otherwise: ticket counter for the rows, monotonic LDS counters, bounded spins that raise the sticky error word.
+//
+// Measured (d = 200, 300 k nodes / 3 M arcs, same box, f32 form -> this): 685 - 697 -> 631 - 648 us per iteration (0.565 -> 0.61 of
+// 8 TB/s on the algorithmic bytes); d = 160 on 1 M / 10 M 1 788 -> 1 687; d = 256 on 200 k / 2 M 619 -> 591.  What still bounds it
+// (-DXB_EXPERIMENT ablations, scripts/dev/xwide_b3_ablate.py; -DXW_PROFILE phase clocks, scripts/dev/xb_prof.py):
+//   * matrix waves that only hand the rows back: 438 - 459 us for 2.65 GB = 6.0 TB/s - the gather by itself;
+//   * everything but the weight loads: 530 - 570; everything but the products: 541 - 605; neither: 525 - 551;
+//   * a matrix wave's K loop takes ~ 1 000 clocks a k-step where its instructions need 364: a CU's loads return in issue order, so a
+//     weight piece that hits in L2 comes back behind the gather's misses issued before it (~ 3 us), and XB_PD = 6 k-steps in flight
+//     is what 128 registers hold next to the accumulators.  Chain per tile (rows ready -> K loop -> constant -> epilogue) ~ 34 000
+//     clocks against ~ 33 000 the gather needs to fill one: both sides wait for each other a quarter of the time.
+// Tried on the way, all measured on one box against 638 - 648: the per-node constant requested a block ahead or a round ahead (656,
+// 675: its 128 scattered line requests then sit IN FRONT of the weight pieces in the CU's queue), two register sets for the rows (644),
+// a raised wave priority for the matrix waves (no change), 3 / 4 / 6 matrix waves with two blocks each and more gather waves (680 - 840:
+// the chain per wave doubles).  What would move it: 64-row tiles (half the weight stream and half the chain per row) - which needs the
+// rows in LDS as f32 (4 bytes a value, split by every matrix wave that reads them) and fits widths up to ~ 208 only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernel_state_fused4.hpp"
 #include "buffer_ops.hpp"
+#include "bf16_split.hpp"
 
 namespace gnn {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct XWideArgs {
     const int *gate; int n_gate, gate_stride;      // run iff OR of gate[i * gate_stride], i < n_gate, is non-zero
@@ -51,12 +64,11 @@ struct XWideArgs {
     const float *state_in;                         // [n_src_rows, SP]
     float *state_out;                              // [N, SP]
     const float *C; int ldC;                       // per-node constant of the first layer (bias included)
-    const float *Wx;                               // first-layer weights in fragment order (k_xwide_weights)
     int N, S, SP;                                  // nodes, state width, leading dimension of the state buffers (multiple of 4)
-    int KH, NG, NCB;                               // K per half (SP rounded up to 8), 8-k groups (= KH / 4), 32-column blocks
-    const void *Wb;                                // kernel_state_xwide_b3.hpp: the weights in the fragment order of the 16-k instruction
-    int dbg;                                       //   -DXB_EXPERIMENT builds: ablation bits (GNN_XB_DBG)
-    int NKS, HS, NMW;                              //   16-k steps (= KH / 8), half-slots of the row ring, matrix waves
+    int KH, NCB;                                   // K per half (SP rounded up to 8), 32-column blocks
+    const void *Wb;                                // first-layer weights, f32, in the fragment order of the 16-k matrix instruction (k_xwide_weights_q)
+    int NKS, HS, NMW;                              // 16-k steps (= KH / 8), half-slots of the row ring, matrix waves
+    int dbg;                                       // -DXB_EXPERIMENT builds: ablation bits (GNN_XB_DBG)
     int act;
     float thr;
     int *flag_next;
@@ -65,39 +77,16 @@ struct XWideArgs {
 };
 
 constexpr int XW_NM = 8;          // matrix waves at most (wave ids 0 .. NCB - 1, block cb = wave id); the other waves gather
-constexpr int XW_NS = 2;          // LDS slots
-#ifndef XW_PD_VALUE
-#define XW_PD_VALUE 6
-#endif
-constexpr int XW_PD = XW_PD_VALUE;   // weight pieces in flight per matrix wave
 #ifndef GNN_F4_SPIN_MAX
 #define GNN_F4_SPIN_MAX (1 << 22)
 #endif
 constexpr int XW_SPIN_MAX = GNN_F4_SPIN_MAX;   // (-DGNN_F4_SPIN_MAX=0: the debug build whose every wait expires at once, libgnnloop_spin0.so)
 
 inline int xwide_kh(int SP) { return (SP + 7) & ~7; }
-inline size_t xwide_weight_floats(int S, int SP) { return (size_t)((S + 31) / 32) * (xwide_kh(SP) / 4) * 256; }      // (either fragment order: this file's or kernel_state_xwide_b3.hpp's)
-inline size_t xwide_lds_bytes(int KH) {
-    return sizeof(float) * ((size_t)XW_NS * 32 * (2 * KH + 4) + (size_t)XW_NS * XW_NM * 32 * 2) + sizeof(int) * (3 * XW_NS + 1);
-}
+inline size_t xwide_weight_floats(int S, int SP) { return (size_t)((S + 31) / 32) * (xwide_kh(SP) / 4) * 256; }
 
-// Wx[((cb * NG + jg) * 64 + lane) * 4 + e] = Wcat[8 jg + 4 (lane / 32) + e][32 cb + lane % 32], Wcat = [state rows (KH, zero padded) ;
-// neighbour-sum rows (KH)] of the folded first layer Wf [in_dim x H]
-__global__ void k_xwide_weights(const float *Wf, int H, int S, int wrow_state, int wrow_agg, int KH, int NG, int NCB, float *Wx) {
-    const long total = (long)NCB * NG * 256;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
-        const long rest = i >> 8;
-        const int jg = (int)(rest % NG), cb = (int)(rest / NG);
-        const int k = 8 * jg + 4 * (lane >> 5) + e, col = 32 * cb + (lane & 31);
-        const int kk = k < KH ? k : k - KH;
-        float v = 0.0f;
-        if (kk < S && col < H) v = Wf[(size_t)((k < KH ? wrow_state : wrow_agg) + kk) * H + col];
-        Wx[i] = v;
-    }
-}
 
-// -DXW_PROFILE (experiment builds): shader-clock totals of the phases of matrix wave 0 and gather wave 8 of every workgroup
+// -DXW_PROFILE (experiment builds): shader-clock totals of the phases of matrix wave 0 and of the first gather wave of every workgroup
 #ifdef XW_PROFILE
 __device__ unsigned long long g_xw_prof[8];
 __device__ __forceinline__ unsigned long long xw_now() {
@@ -115,20 +104,80 @@ __device__ __forceinline__ unsigned long long xw_now() {
 __device__ __forceinline__ int xw_readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float xw_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+
+
+#ifdef XB_EXPERIMENT
+#define XB_DBG(a_) ((a_).dbg)
+#else
+#define XB_DBG(a_) 0
+#endif
+constexpr int XB_PD = 6;            // k-steps of weight pieces in flight per matrix wave (two 16-byte pieces per lane and k-step)
+constexpr int XB_LDS_MAX = 160 * 1024 - 256;   // dynamic LDS a workgroup may ask for (the kernel has 256 bytes of static LDS: __syncthreads_or)
+constexpr int XB_HS_MAX = 4;        // half-slots at most (more would let a matrix wave reach tile i + 2 while tile i is still being read)
+
+inline int xb_row_bytes(int KH) { return 12 * KH + 16; }          // three planes of 2 KH bf16 + 16: an odd number of 16-byte pieces -> 16 rows, 64 banks
+inline size_t xb_fixed_bytes() { return sizeof(float) * 2 * XW_NM * 64 + sizeof(int) * (2 * XB_HS_MAX + 2 + 1 + 1); }
+inline int xb_half_slots(int KH) {
+    const long budget = XB_LDS_MAX - (long)xb_fixed_bytes();
+    return (int)std::min<long>(XB_HS_MAX, budget / (16L * xb_row_bytes(KH)));
+}
+inline size_t xb_lds_bytes(int KH, int HS) { return (size_t)HS * 16 * xb_row_bytes(KH) + xb_fixed_bytes(); }
+
+// Wcat = [state rows (KH, zero padded) ; neighbour-sum rows (KH)] of the folded first layer Wf [in_dim x H], f32, in the order the matrix
+// waves read it (two 16-byte pieces per lane and k-step):
+// Wq[(((cb * NKS + ks) * 2 + half) * 64 + lane) * 4 + e] = Wcat[16 ks + 8 (lane / 32) + 4 half + e][32 cb + lane % 32]
+__global__ void k_xwide_weights_q(const float *Wf, int H, int S, int wrow_state, int wrow_agg, int KH, int NKS, int NCB, float *Wq) {
+    const long total = (long)NCB * NKS * 512;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3), lane = (int)((i >> 2) & 63), half = (int)((i >> 8) & 1);
+        const long rest = i >> 9;
+        const int ks = (int)(rest % NKS), cb = (int)(rest / NKS);
+        const int k = 16 * ks + 8 * (lane >> 5) + 4 * half + e, col = 32 * cb + (lane & 31);
+        const int kk = k < KH ? k : k - KH;
+        float v = 0.0f;
+        if (kk < S && col < H) v = Wf[(size_t)((k < KH ? wrow_state : wrow_agg) + kk) * H + col];
+        Wq[i] = v;
+    }
+}
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void xb_store_split(char *dst, int plane_bytes, const f32x4 &v) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3_pk((f32x2){v[0], v[1]}, h0, m0, l0);
+    split3_pk((f32x2){v[2], v[3]}, h1, m1, l1);
+    *reinterpret_cast<u32x2 *>(dst) = (u32x2){h0, h1};
+    *reinterpret_cast<u32x2 *>(dst + plane_bytes) = (u32x2){m0, m1};
+    *reinterpret_cast<u32x2 *>(dst + 2 * plane_bytes) = (u32x2){l0, l1};
+}
+__device__ __forceinline__ f32x4 xb_load_joined(const char *src, int plane_bytes) {
+    const u32x2 h = *reinterpret_cast<const u32x2 *>(src), m = *reinterpret_cast<const u32x2 *>(src + plane_bytes),
+                l = *reinterpret_cast<const u32x2 *>(src + 2 * plane_bytes);
+    f32x4 o;
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        o[2 * x] = (__uint_as_float(h[x] << 16) + __uint_as_float(m[x] << 16)) + __uint_as_float(l[x] << 16);
+        o[2 * x + 1] = (__uint_as_float(h[x] & 0xFFFF0000u) + __uint_as_float(m[x] & 0xFFFF0000u)) + __uint_as_float(l[x] & 0xFFFF0000u);
+    }
+    return o;
+}
+
 template <bool HAS_W>
-__global__ void __launch_bounds__(1024) k_state_xwide(XWideArgs a) {
+__global__ void __launch_bounds__(1024) k_state_xwide_b3(XWideArgs a) {
     int open = a.gate == nullptr;
     for (int i = 0; i < a.n_gate; ++i) open |= a.gate[(size_t)i * a.gate_stride] != 0;
-    extern __shared__ __attribute__((aligned(16))) char xw_smem[];
-    const int KH = a.KH, NG = a.NG, LDX = 2 * KH + 4, SLOT = 32 * LDX;
-    float *Xs = reinterpret_cast<float *>(xw_smem);                     // [NS][32][LDX] : [state (KH) | neighbour sum (KH) | pad]
-    float *part = Xs + XW_NS * SLOT;                                    // [NS][NM][32][2] : per block and row |new - old|^2, |old|^2
-    int *fill = reinterpret_cast<int *>(part + XW_NS * XW_NM * 64);     // [NS] rows deposited so far
-    int *freed = fill + XW_NS;                                          // [NS] rounds consumed so far
-    int *done = freed + XW_NS;                                          // [NS] matrix waves finished so far
-    int *ticket = done + XW_NS;                                         // next row (tile * 32 + row) to gather
+    extern __shared__ __attribute__((aligned(16))) char xb_smem[];
+    const int KH = a.KH, NKS = a.NKS, HS = a.HS, NMW = a.NMW, NCB = a.NCB;
+    const int dbg = XB_DBG(a);
+    const int RS = 12 * KH + 16, PL = 4 * KH;                           // bytes of a row; of a plane of a row
+    char *ring = xb_smem;                                               // [HS][16] rows: [hi (2 KH bf16) | mid | lo | pad]
+    float *part = reinterpret_cast<float *>(ring + (size_t)HS * 16 * RS);   // [2][NM][32][2] : per block and row |new - old|^2, |old|^2
+    int *fill = reinterpret_cast<int *>(part + 2 * XW_NM * 64);         // [HS_MAX] rows deposited so far
+    int *freed = fill + XB_HS_MAX;                                      // [HS_MAX] times handed back so far
+    int *done = freed + XB_HS_MAX;                                      // [2] blocks finished so far (tiles of either parity)
+    int *ticket = done + 2;                                             // next row (tile * 32 + row) to gather
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 3 * XW_NS + 1) fill[tid] = 0;
+    if (tid < 2 * XB_HS_MAX + 3) fill[tid] = 0;
     __syncthreads();
     if (!open) return;                             // uniform across the launch; nothing has left the CU yet
 
@@ -137,17 +186,17 @@ __global__ void __launch_bounds__(1024) k_state_xwide(XWideArgs a) {
     const int nT = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;   // tiles of this workgroup
     const __amdgpu_buffer_rsrc_t r_state = buf_rsrc(a.state_in), r_rowptr = buf_rsrc(a.rowptr), r_src = buf_rsrc(a.src),
                                  r_w = buf_rsrc(HAS_W ? a.w : nullptr), r_scale = buf_rsrc(a.row_scale), r_C = buf_rsrc(a.C),
-                                 r_wx = buf_rsrc(a.Wx), r_out = buf_rsrc(a.state_out);
+                                 r_wb = buf_rsrc(a.Wb), r_out = buf_rsrc(a.state_out);
     int any = 0, bad = 0;
-
     XW_T(tk0_);
-    if (wave >= a.NCB) {
-        // ================================ gather waves ================================================================
-        // Every wave that is not a matrix wave gathers (16 - NCB of them: 8 at 256 columns, 11 at 160).  Rows are drawn from a ticket
-        // counter in LDS (ticket t = row t % 32 of this workgroup's tile t / 32; a wave's tickets grow, so no row waits behind a
-        // later one).  A wave always holds four tickets: the row whose neighbour rows are being summed, the row whose neighbour
-        // rows are being issued into the window slots the sum frees (ONE rolling window of 16 neighbour rows + the own row in
-        // flight), the row whose source ids are in flight and the row whose row pointers are in flight.
+
+    if (wave >= NMW) {
+        // ================================ gather waves ================================================================================
+        // Rows are drawn from a ticket counter in LDS (ticket t = row t % 32 of this workgroup's tile t / 32; a wave's tickets grow, so no
+        // row waits behind a later one).  A wave always holds four tickets: the row whose neighbour rows are being summed, the row whose
+        // neighbour rows are being issued into the window slots the sum frees (ONE rolling window of 16 neighbour rows + the own row in
+        // flight), the row whose source ids are in flight and the row whose row pointers are in flight.  The sum is split into three bf16
+        // planes as it is deposited.
         const int CH = SP >> 2, CHZ = KH >> 2;                   // 16-byte chunks of a row; chunks of the padded half
         const bool act_l = lane < CH, zero_l = lane >= CH && lane < CHZ;
         const bool has_scale = a.row_scale != nullptr;
@@ -223,28 +272,32 @@ __global__ void __launch_bounds__(1024) k_state_xwide(XWideArgs a) {
                 }
             }
             if (has_scale) acc *= scl;
-            const int i = t0 >> 5, r = t0 & 31, s = i % XW_NS, round = i / XW_NS;
-            {                                                     // the slot's previous tile must have been consumed
+            const int i = t0 >> 5, r = t0 & 31, g = 2 * i + (r >> 4), h = g % HS, u = g / HS;
+            {                                                     // the half-slot's previous rows must have been consumed
                 XW_T(g0_);
                 int spin = 0;
-                while (__builtin_amdgcn_readfirstlane(f4_ld_acquire(&freed[s])) < round) {
+                while (__builtin_amdgcn_readfirstlane(f4_ld_acquire(&freed[h])) < u) {
                     if (spin >= XW_SPIN_MAX) { bad = 1; break; }
                     ++spin; __builtin_amdgcn_s_sleep(1);
                 }
 #ifdef XW_PROFILE
-                if (wave == a.NCB) XW_ADD(4, xw_now() - g0_);
+                if (wave == NMW) XW_ADD(4, xw_now() - g0_);
 #endif
             }
-            if (bad) break;                                       // the slot never came free: deposit nothing (k < 0 says so)
-            float *xr = Xs + s * SLOT + r * LDX + 4 * lane;
+            if (bad) break;                                       // the half-slot never came free: deposit nothing (k < 0 says so)
+            char *xr = ring + (size_t)(h * 16 + (r & 15)) * RS + 8 * lane;        // k = 4 lane of the own-state half, plane 0
             if (act_l) {
-                *reinterpret_cast<f32x4 *>(xr) = own;
-                *reinterpret_cast<f32x4 *>(xr + KH) = acc;
+                xb_store_split(xr, PL, own);
+                xb_store_split(xr + 2 * KH, PL, acc);
             } else if (zero_l) {
-                *reinterpret_cast<f32x4 *>(xr) = (f32x4){0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4 *>(xr + KH) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const u32x2 z = {0u, 0u};
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    *reinterpret_cast<u32x2 *>(xr + p * PL) = z;
+                    *reinterpret_cast<u32x2 *>(xr + p * PL + 2 * KH) = z;
+                }
             }
-            if (lane == 0) __hip_atomic_fetch_add(&fill[s], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) __hip_atomic_fetch_add(&fill[h], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             own = buf_ld_f32x4(r_state, (jN >= 0 && act_l) ? (unsigned)jN * (unsigned)(SP * 4) + lane_off : BUF_OFF);   // (its registers are free now)
             // the stages move up
             t0 = t1; t1 = t2; t2 = t3; t3 = t4;
@@ -252,135 +305,170 @@ __global__ void __launch_bounds__(1024) k_state_xwide(XWideArgs a) {
             beg1 = beg2; end1 = end2; id1 = id2; w1 = w2;
             rp2 = rp3; rp3 = rp4;
         }
-    } else if (wave < a.NCB) {
-        // ================================ matrix waves ================================================================
-        const int cb = wave;
-        const int row = lane & 31, kh = lane >> 5;
-        const unsigned wbase = ((unsigned)cb * (unsigned)NG * 64u + (unsigned)lane) * 16u;
+    } else {
+        // ================================ matrix waves: blocks wave, wave + NMW, .. of every tile ======================================
+        // A wave's chain per tile (wait for the rows -> K loop -> epilogue) must stay under the time the gather waves need to fill a
+        // tile, and every load of this CU returns in issue order BEHIND the gather's misses (~ 2 us each under load): nothing the chain
+        // waits for may be requested inside it.  So the first XB_PD k-steps of the weights AND the per-node constant of the next block
+        // are requested at the end of the previous one (they land while the wave waits for the rows), the weight stream runs XB_PD
+        // k-steps ahead, and the rows of k-step ks + 1 are read from LDS behind the products of k-step ks, under the split of the next
+        // weights (one register set).
+        const int row = lane & 31, kg = lane >> 5;
         const int H = S;
-        // the first XW_PD weight pieces of a tile are fetched before the previous tile's epilogue (they are the same pieces every tile)
-        f32x4 Bf[XW_PD];
+        constexpr int PD = XB_PD;
+        auto wbase_of = [&](int cb) -> unsigned { return ((unsigned)cb * (unsigned)NKS * 128u + (unsigned)lane) * 16u; };
+        auto ld_w = [&](u32x4 (&w)[2], unsigned wb_, int ks, bool on) {  // the two pieces of k-step ks of the block at wb_
 #pragma unroll
-        for (int p = 0; p < XW_PD; ++p) Bf[p] = buf_ld_f32x4(r_wx, p < NG ? wbase + (unsigned)p * 1024u : BUF_OFF);
+            for (int pl = 0; pl < 2; ++pl)
+                w[pl] = __builtin_amdgcn_raw_buffer_load_b128(r_wb, (int)((on && !(dbg & 2)) ? wb_ + (unsigned)ks * 2048u + (unsigned)pl * 1024u : BUF_OFF), 0, 0);
+        };
+        auto ld_c = [&](f32x4 (&c)[4], int cb, long jl_) {              // columns 32 cb + 8 q + 4 kg + e of row jl_ of the per-node constant
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col0 = 32 * cb + 8 * q + 4 * kg;
+                c[q] = buf_ld_f32x4(r_C, (jl_ < N && col0 < a.ldC) ? ((unsigned)jl_ * (unsigned)a.ldC + (unsigned)col0) * 4u : BUF_OFF);
+            }
+        };
+        u32x4 W[PD][2];
+        {
+            const unsigned wb = wbase_of(wave);
+#pragma unroll
+            for (int p = 0; p < PD; ++p) {
+                ld_w(W[p], wb, p, p < NKS);
+                __builtin_amdgcn_sched_barrier(0);                    // (issue order = the K loop's: its vmcnt waits are exact counts only then)
+            }
+        }
 #pragma unroll 1
         for (int i = 0; i < nT; ++i) {
             const long T = (long)blockIdx.x + (long)i * gridDim.x;
             const long jl = 32 * T + row;
             const bool jv = jl < N;
             const unsigned j = (unsigned)jl;
-            // the per-node constant (columns 32 cb + 8 q + 4 kh + e of this lane's row): fetched now, added behind the K loop
-            f32x4 c4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col0 = 32 * cb + 8 * q + 4 * kh;
-                c4[q] = buf_ld_f32x4(r_C, (jv && col0 < a.ldC) ? (j * (unsigned)a.ldC + (unsigned)col0) * 4u : BUF_OFF);
-            }
-            f32x16 acc, acc1;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acc1[e] = 0.0f; }
-            const int s = i % XW_NS, round = i / XW_NS;
+            const int gA = 2 * i, hA = gA % HS, uA = gA / HS, gB = gA + 1, hB = gB % HS, uB = gB / HS;
+            const int s = i & 1, round = i >> 1;
             XW_T(t0_);
             {
                 int spin = 0;
-                while (__builtin_amdgcn_readfirstlane(f4_ld_acquire(&fill[s])) < 32 * (round + 1)) {
+                while (__builtin_amdgcn_readfirstlane(f4_ld_acquire(&fill[hA])) < 16 * (uA + 1) ||
+                       __builtin_amdgcn_readfirstlane(f4_ld_acquire(&fill[hB])) < 16 * (uB + 1)) {
                     if (spin >= XW_SPIN_MAX) { bad = 1; break; }
                     ++spin; __builtin_amdgcn_s_sleep(1);
                 }
             }
             if (bad) break;
             XW_T(t1_);
-            const float *X = Xs + s * SLOT + row * LDX;
-            const float *xrow = X + 4 * kh;
-            // Whole rounds of XW_PD pieces; the load of piece jg + XW_PD is issued BEHIND the MFMAs of piece jg, into the registers they
-            // have just read (issued in front of them it needs other registers, and hipcc then rotates the pieces with copies at the
-            // loop's back edge - behind an s_waitcnt vmcnt(0): the stream drained once per round, 60 % of the matrix rate).  Loads
-            // behind NG are predicated off (no branch around a memory operation: the vmcnt waits stay exact counts); the last
-            // NG % XW_PD pieces are already in Bf[] when the rounds end and run behind a uniform branch that holds no load.
-            // Two accumulators (even / odd k pairs) keep one wave's MFMAs independent of each other.
-            const int n_main = NG / XW_PD * XW_PD;
-            static_assert(XW_PD % 2 == 0, "the rows' pieces alternate between two register sets");
-            f32x4 A[2];                                           // the rows' piece for jg + 1 is read from LDS in front of the MFMAs of piece jg
-            A[0] = *reinterpret_cast<const f32x4 *>(xrow);
-#pragma unroll 1
-            for (int jg0 = 0; jg0 < n_main; jg0 += XW_PD) {
-#pragma unroll
-                for (int p = 0; p < XW_PD; ++p) {
-                    const int jg = jg0 + p;
-                    A[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(xrow + 8 * min(jg + 1, NG - 1));
-                    const f32x4 a4 = A[p & 1];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][0], a4[0], acc, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][1], a4[1], acc1, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][2], a4[2], acc, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][3], a4[3], acc1, 0, 0, 0);
-                    Bf[p] = buf_ld_f32x4(r_wx, jg + XW_PD < NG ? wbase + (unsigned)(jg + XW_PD) * 1024u : BUF_OFF);
-                    __builtin_amdgcn_sched_barrier(0);            // (the scheduler otherwise sinks all loads of a round to its end)
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < XW_PD - 1; ++p) {
-                if (n_main + p < NG) {
-                    A[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(xrow + 8 * min(n_main + p + 1, NG - 1));
-                    const f32x4 a4 = A[p & 1];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][0], a4[0], acc, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][1], a4[1], acc1, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][2], a4[2], acc, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Bf[p][3], a4[3], acc1, 0, 0, 0);
-                }
-            }
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] += acc1[e];
-            XW_T(t2_);
-#pragma unroll
-            for (int p = 0; p < XW_PD; ++p) Bf[p] = buf_ld_f32x4(r_wx, p < NG ? wbase + (unsigned)p * 1024u : BUF_OFF);
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA results are read behind a branch below (hipcc 7.2 hazard, kernels_train_big.hpp)
-            float d2 = 0.0f, n2 = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col0 = 32 * cb + 8 * q + 4 * kh;
-                f32x4 nv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) nv[e] += col0 + e < H ? c4[q][e] : 0.0f;
-                activate4(a.act, nv);
-                const f32x4 ov = *reinterpret_cast<const f32x4 *>(X + min(col0, KH - 4));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = jv && col0 + e < S;
-                    nv[e] = ok ? nv[e] : 0.0f;
-                    const float o = ok ? ov[e] : 0.0f;
-                    const float d = nv[e] - o;
-                    d2 = fmaf(d, d, d2);
-                    n2 = fmaf(o, o, n2);
-                }
-                const u32x4 bits = {__float_as_uint(nv[0]), __float_as_uint(nv[1]), __float_as_uint(nv[2]), __float_as_uint(nv[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(bits, r_out, (jv && col0 < SP) ? (int)((j * (unsigned)SP + (unsigned)col0) * 4u) : (int)BUF_OFF, 0, 0);
-            }
-            d2 += __shfl_xor(d2, 32);
-            n2 += __shfl_xor(n2, 32);
-            float *pp = part + ((s * XW_NM + cb) * 32 + row) * 2;
-            if (lane < 32) *reinterpret_cast<float2 *>(pp) = make_float2(d2, n2);
-            int last = 0;
-            if (lane == 0) last = __hip_atomic_fetch_add(&done[s], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == a.NCB * (round + 1) - 1;
-            last = __builtin_amdgcn_readfirstlane(last);
-            if (last) {
-                // every block of the tile is done (their shares and their reads of the slot are behind the counter): rows' predicate
-                // from the shares in block order, then the slot goes back to the gather waves
-                float D2 = 0.0f, N2 = 0.0f;
-                for (int b = 0; b < a.NCB; ++b) {
-                    const float2 sh = *reinterpret_cast<const float2 *>(part + ((s * XW_NM + b) * 32 + row) * 2);
-                    D2 += sh.x; N2 += sh.y;
-                }
-                if (lane < 32 && jv && sqrtf(D2) > a.thr * sqrtf(N2)) any = 1;
-                if (lane == 0) __hip_atomic_store(&freed[s], round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
 #ifdef XW_PROFILE
-            if (wave == 0) { const unsigned long long t3_ = xw_now(); XW_ADD(0, t1_ - t0_); XW_ADD(1, t2_ - t1_); XW_ADD(2, t3_ - t2_); XW_ADD(3, 1); }
+            if (wave == 0) { XW_ADD(0, t1_ - t0_); XW_ADD(3, 1); }
 #endif
+            const char *X = ring + (size_t)((row < 16 ? hA : hB) * 16 + (row & 15)) * RS;      // this lane's row of the tile
+            const char *xk = X + 16 * kg;                                                          // k = 16 ks + 8 kg of plane 0
+#pragma unroll 1
+            for (int cb = wave; cb < NCB; cb += NMW) {
+                if (dbg & 8) {
+                    int last = 0;
+                    if (lane == 0) last = __hip_atomic_fetch_add(&done[s], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == NCB * (round + 1) - 1;
+                    if (__builtin_amdgcn_readfirstlane(last) && lane == 0) {
+                        __hip_atomic_store(&freed[hA], uA + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&freed[hB], uB + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    continue;
+                }
+                XW_T(tb_);
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                const unsigned wb = wbase_of(cb);
+                // Whole rounds of PD k-steps; the loads of k-step ks + PD are issued BEHIND the matrix instructions of k-step ks, into the
+                // registers they have just read (issued in front, hipcc rotates the pieces with copies behind a full drain).  Loads behind NKS are predicated off; the last NKS % PD k-steps are in W[] when the rounds end.
+                const int n_main = NKS / PD * PD;
+                u32x4 R[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) R[pl] = *reinterpret_cast<const u32x4 *>(xk + pl * PL);
+                auto step = [&](u32x4 (&w)[2], int ks, bool refill) {
+                    u32x4 wh, wm, wl;
+                    split3_x8pk(__builtin_bit_cast(f32x4, w[0]), __builtin_bit_cast(f32x4, w[1]), wh, wm, wl);
+                    if (!(dbg & 1)) acc = mfma_b6(wh, wm, wl, R[0], R[1], R[2], acc);
+                    asm volatile("" : "+v"(acc));                     // (a load hoisted between the six products needs registers of its own: copies and
+                    __builtin_amdgcn_sched_barrier(0);                //  a full drain at the loop's back edge)
+                    const char *xn = xk + 32 * min(ks + 1, NKS - 1);  // the rows of the next k-step: they land under the split of its weights
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) R[pl] = *reinterpret_cast<const u32x4 *>(xn + pl * PL);
+                    if (refill) ld_w(w, wb, ks + PD, ks + PD < NKS);
+                    __builtin_amdgcn_sched_barrier(0);                // (the scheduler otherwise sinks all loads of a round to its end)
+                };
+#pragma unroll 1
+                for (int ks0 = 0; ks0 < n_main; ks0 += PD) {
+#pragma unroll
+                    for (int p = 0; p < PD; ++p) step(W[p], ks0 + p, true);
+                }
+#pragma unroll
+                for (int p = 0; p < PD - 1; ++p)
+                    if (n_main + p < NKS) step(W[p], n_main + p, false);
+                XW_T(t2_);
+                f32x4 c4[4];
+                ld_c(c4, cb, jl);
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA results are read behind a branch below (hipcc 7.2 hazard, kernels_train_big.hpp)
+                float d2 = 0.0f, n2 = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col0 = 32 * cb + 8 * q + 4 * kg;
+                    f32x4 nv = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) nv[e] += col0 + e < H ? c4[q][e] : 0.0f;
+                    activate4(a.act, nv);
+                    const f32x4 ov = xb_load_joined(X + 2 * min(col0, KH - 4), PL);      // the old state of these columns: hi + mid + lo, exactly
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = jv && col0 + e < S;
+                        nv[e] = ok ? nv[e] : 0.0f;
+                        const float o = ok ? ov[e] : 0.0f;
+                        const float d = nv[e] - o;
+                        d2 = fmaf(d, d, d2);
+                        n2 = fmaf(o, o, n2);
+                    }
+                    const u32x4 bits = {__float_as_uint(nv[0]), __float_as_uint(nv[1]), __float_as_uint(nv[2]), __float_as_uint(nv[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(bits, r_out, (jv && col0 < SP) ? (int)((j * (unsigned)SP + (unsigned)col0) * 4u) : (int)BUF_OFF, 0, 0);
+                }
+                d2 += __shfl_xor(d2, 32);
+                n2 += __shfl_xor(n2, 32);
+                float *pp = part + ((s * XW_NM + cb) * 32 + row) * 2;
+                if (lane < 32) *reinterpret_cast<float2 *>(pp) = make_float2(d2, n2);
+                int last = 0;
+                if (lane == 0) last = __hip_atomic_fetch_add(&done[s], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == NCB * (round + 1) - 1;
+                last = __builtin_amdgcn_readfirstlane(last);
+                if (last) {
+                    // every block of the tile is done (their shares and their reads of the rows are behind the counter): rows' predicate
+                    // from the shares in block order, then both half-slots go back to the gather waves
+                    float D2 = 0.0f, N2 = 0.0f;
+                    for (int b = 0; b < NCB; ++b) {
+                        const float2 sh = *reinterpret_cast<const float2 *>(part + ((s * XW_NM + b) * 32 + row) * 2);
+                        D2 += sh.x; N2 += sh.y;
+                    }
+                    if (lane < 32 && jv && sqrtf(D2) > a.thr * sqrtf(N2)) any = 1;
+                    if (lane == 0) {
+                        __hip_atomic_store(&freed[hA], uA + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&freed[hB], uB + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+#ifdef XW_PROFILE
+                if (wave == 0) { const unsigned long long t3_ = xw_now(); XW_ADD(1, t2_ - tb_); XW_ADD(2, t3_ - t2_); }
+#endif
+                {   // the next block's first k-steps and constant (this tile's next block, or the first block of the next tile)
+                    const bool same = cb + NMW < NCB;
+                    const int cbn = same ? cb + NMW : wave;
+                    const unsigned wbn = wbase_of(cbn);
+#pragma unroll
+                    for (int p = 0; p < PD; ++p) {
+                        ld_w(W[p], wbn, p, p < NKS);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
         }
     }
 
 #ifdef XW_PROFILE
-    if (wave == a.NCB) XW_ADD(5, xw_now() - tk0_);       // the first gather wave: its whole loop
+    if (wave == NMW) XW_ADD(5, xw_now() - tk0_);         // the first gather wave: its whole loop
     if (wave == 0) XW_ADD(6, xw_now() - tk0_);           // matrix wave 0: its whole loop
 #endif
     any = __syncthreads_or(any);
@@ -392,29 +480,34 @@ __global__ void __launch_bounds__(1024) k_state_xwide(XWideArgs a) {
     }
 }
 
-inline int launch_xwide_weights(const float *Wf, int H, int S, int wrow_state, int wrow_agg, int SP, float *Wx, hipStream_t st) {
-    const int KH = xwide_kh(SP), NG = KH / 4, NCB = (S + 31) / 32;
-    const long total = (long)NCB * NG * 256;
-    k_xwide_weights<<<(int)std::min<long>((total + 255) / 256, 1024), 256, 0, st>>>(Wf, H, S, wrow_state, wrow_agg, KH, NG, NCB, Wx);
+inline int launch_xwide_weights_b3(const float *Wf, int H, int S, int wrow_state, int wrow_agg, int SP, void *Wb, hipStream_t st) {
+    const int KH = xwide_kh(SP), NKS = KH / 8, NCB = (S + 31) / 32;
+    const long total = (long)NCB * NKS * 512;
+    k_xwide_weights_q<<<(int)std::min<long>((total + 255) / 256, 1024), 256, 0, st>>>(Wf, H, S, wrow_state, wrow_agg, KH, NKS, NCB, (float *)Wb);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-inline int launch_xwide(XWideArgs &xa, int n_cu, hipStream_t st) {
-    xa.KH = xwide_kh(xa.SP); xa.NG = xa.KH / 4; xa.NCB = (xa.S + 31) / 32;
-    const size_t lds = xwide_lds_bytes(xa.KH);
-    static bool attr[2] = {false, false};
-    const int hw = xa.w ? 1 : 0;
-    if (!attr[hw]) {
-        const void *f = hw ? (const void *)k_state_xwide<true> : (const void *)k_state_xwide<false>;
-        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xwide_lds_bytes(256)) != hipSuccess) return 1;
-        attr[hw] = true;
+// matrix_waves: 0 = one per 32-column block (the f32 form's division), else that many (each takes every matrix_waves-th block)
+template <bool HAS_W>
+int launch_xwide_b3_one(XWideArgs &xa, int grid, size_t lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)k_state_xwide_b3<HAS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, XB_LDS_MAX) != hipSuccess) return 1;
+        attr = true;
     }
+    GNN_SET_KERNEL_NAME("k_state_xwide_b3<%s>", HAS_W ? "true" : "false");
+    k_state_xwide_b3<HAS_W><<<grid, 1024, lds, st>>>(xa);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+inline int launch_xwide_b3(XWideArgs &xa, int n_cu, int matrix_waves, hipStream_t st) {
+    xa.KH = xwide_kh(xa.SP); xa.NKS = xa.KH / 8; xa.NCB = (xa.S + 31) / 32;
+    xa.HS = xb_half_slots(xa.KH);
+    xa.NMW = matrix_waves > 0 ? std::min(matrix_waves, xa.NCB) : xa.NCB;
+    if (xa.HS < 3) return 1;
+    const size_t lds = xb_lds_bytes(xa.KH, xa.HS);
     const int ntiles = (xa.N + 31) / 32;
     const int grid = std::max(1, std::min(n_cu, ntiles));
-    GNN_SET_KERNEL_NAME("k_state_xwide<%s>", hw ? "true" : "false");
-    if (hw) k_state_xwide<true><<<grid, 1024, lds, st>>>(xa);
-    else    k_state_xwide<false><<<grid, 1024, lds, st>>>(xa);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+    return xa.w ? launch_xwide_b3_one<true>(xa, grid, lds, st) : launch_xwide_b3_one<false>(xa, grid, lds, st);
 }
 
 }  // namespace gnn

@@ -15,7 +15,6 @@ gnn = GNNnodeBased(ns, no, d, K, 0.0)
 inputs = gnn.process_inputs(x)
 lib = nat.lib()
 out = (ctypes.c_ulonglong * 8)()
-os.environ['GNN_XWIDE_B3'] = '1'
 for dbg in (sys.argv[2].split(',') if len(sys.argv) > 2 else ['0']):
     os.environ['GNN_XB_DBG'] = dbg
     k, st, o = gnn.Loop(*inputs, state0=s0); torch.cuda.synchronize()

@@ -15,8 +15,6 @@ s0 = torch.randn((N, d), generator=gen, device=dev) * 0.1
 gnn = GNNnodeBased(ns, no, d, 20, 0.0)
 inputs = gnn.process_inputs(x)
 b_iter = bench.algorithmic_bytes_per_iteration(N, E, d, ns.units[0], False)
-os.environ['GNN_XWIDE_B3'] = '1'
-os.environ['GNN_XWIDE_PLANES'] = sys.argv[3] if len(sys.argv) > 3 else '0'
 for mw in sys.argv[2].split(',') if len(sys.argv) > 2 else ['0']:
     os.environ['GNN_XWIDE_MW'] = mw
     for dbg in [int(v) for v in (sys.argv[4].split(",") if len(sys.argv) > 4 else "0,1,2,3,4,8,12".split(","))]:

@@ -2,7 +2,7 @@
 # round-6 closing pass, all on the build that ships: smoke, the whole -m gpu suite, then the evidence of scripts/gpu_r5_final.sh (kernel-trace
 # summaries + the two PMC passes of C3 / C4 / C5 / C4x4 / d = 200 -> profiles/hbm_traffic.json keyed to the library's source hash, the
 # homogeneous training step's trace / PMC / SQ counters, the default bench line) plus the heterogeneous C5 training step's trace and PMC passes
-# and the kernel traces of d = 128 on C4 and of d = 200 on the f32 matrix instructions (GNN_XWIDE_B3=0).
+# and the kernel trace of d = 128 on C4.
 # Run from the repo root on the GPU box:  [TAG=r06] [SUITE=0] bash scripts/gpu_r6_closing.sh
 set -u
 export TMPDIR=/tmp
@@ -26,7 +26,4 @@ trace() {   # name, bench args...: kernel-trace summary only
   rm -rf $OUT/prof_$name
 }
 trace d128 --workload c4 --state-dim 128 --max-iteration 20
-export GNN_XWIDE_B3=0
-trace d200_f32 --workload c3 --nodes 3e5 --arcs 3e6 --state-dim 200 --max-iteration 20
-unset GNN_XWIDE_B3
 TAG=$TAG bash scripts/gpu_r5_final.sh "round 6 closing pass" > $OUT/final.log 2>&1; tail -5 $OUT/final.log | cut -c1-600

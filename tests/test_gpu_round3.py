@@ -1,3 +1,9 @@
+def test_state_widths_129_to_256_run_fused(N, arcs_per_node, d, mode, act, thr):
+    """`state_vect_dim` between 129 and 256 (reference GNN.py:26-28 allows any width): one launch per iteration (k_state_xwide_b3: the Dense
+    layer as six bf16 products of three-term splits, kernel_state_xwide.hpp) - k, state and output against the fp64 oracle and against the
+    un-fused path; row counts that are not multiples of the 32-row tile,
+    in-degrees above 16 (the gather's second chunk), per-row and per-arc weights, widths that are not multiples of 32 / 8, an
+    activation with f(0) != 0 (pad columns must stay zero), an early exit."""
 """Round-3 parity closure: every path that had not met the oracle on the device.
 
   * the f4 sequencers (SURVEY §8f rank 4): `SingleGraphSequencer`, `CompositeSingleGraphSequencer`,
@@ -718,12 +724,11 @@ def test_wide_layers_of_the_unfused_path_at_scale(N, d, hidden, mode):
                                                             (3_000, 40, 256, 'normalized', 'selu', 0.0), (20_011, 8, 160, 'average', 'tanh', -1.0),
                                                             (17, 3, 129, 'average', 'sigmoid', 0.0), (9_000, 20, 224, 'sum', 'relu', 0.0),
                                                             (33, 2, 192, 'normalized', 'tanh', 0.0)])
-def test_state_widths_129_to_256_run_fused(N, arcs_per_node, d, mode, act, thr, monkeypatch):
-    """`state_vect_dim` between 129 and 256 (reference GNN.py:26-28 allows any width): one launch per iteration - k_state_xwide_b3 (the
-    Dense layer as six bf16 products of three-term splits, kernel_state_xwide_b3.hpp: the default) and k_state_xwide (f32 matrix
-    instructions, GNN_XWIDE_B3=0) - k, state and output against the fp64 oracle and against the un-fused path; row counts that are not multiples of the 32-row tile,
-    in-degrees above 16 (the gather's second chunk), per-row and per-arc weights, widths that are not multiples of 32 / 8, an
-    activation with f(0) != 0 (pad columns must stay zero), an early exit."""
+def test_state_widths_129_to_256_run_fused(N, arcs_per_node, d, mode, act, thr):
+    """`state_vect_dim` between 129 and 256 (reference GNN.py:26-28 allows any width): one launch per iteration (k_state_xwide_b3: the Dense
+    layer as six bf16 products of three-term splits, kernel_state_xwide.hpp) - k, state and output against the fp64 oracle and against the
+    un-fused path; row counts that are not multiples of the 32-row tile, in-degrees above 16 (the gather's second chunk), per-row and
+    per-arc weights, widths that are not multiples of 32 / 8, an activation with f(0) != 0 (pad columns must stay zero), an early exit."""
     from test_gpu_parity import starter_nets
     rng = np.random.default_rng(N + d)
     g = er_graph(N, arcs_per_node * N, seed=5, aggregation_mode=mode)
@@ -743,17 +748,15 @@ def test_state_widths_129_to_256_run_fused(N, arcs_per_node, d, mode, act, thr, 
     k64, st64, o64 = oracle_loop(model, x, s0, np.float64)
     inputs = model.process_inputs(x)
     got = {}
-    for flags, b3, kernel in ((0, '1', 'k_state_xwide_b3<'), (0, '0', 'k_state_xwide<'), (nat.FLAG_UNFUSED, '1', 'un-fused')):
-        monkeypatch.setenv('GNN_XWIDE_B3', b3)                      # (read at every call)
+    for flags in (0, nat.FLAG_UNFUSED):
         model.native_flags = flags
         k, st, o = model.Loop(*inputs, state0=dev(s0))
         torch.cuda.synchronize()
-        assert kernel in _last_kernel(), _last_kernel()
-        assert float(k) == float(k64), (flags, b3, float(k), k64)
-        assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, (flags, b3)
-        got[kernel] = st
-    for kernel in ('k_state_xwide_b3<', 'k_state_xwide<'):
-        assert rel_err(got[kernel].cpu().numpy(), got['un-fused'].cpu().numpy()) <= TOL, kernel
+        assert ('k_state_xwide_b3' if flags == 0 else 'un-fused') in _last_kernel(), _last_kernel()
+        assert float(k) == float(k64), (flags, float(k), k64)
+        assert rel_err(st.cpu().numpy(), st64) <= TOL and rel_err(o.cpu().numpy(), o64) <= TOL, flags
+        got[flags] = st
+    assert rel_err(got[0].cpu().numpy(), got[nat.FLAG_UNFUSED].cpu().numpy()) <= TOL
 
 
 def test_state_width_200_is_bitwise_reproducible():

@@ -39,6 +39,20 @@ def _unique_rows(arcs: np.ndarray) -> np.ndarray:
     return s[keep]
 
 
+def _coo_clone(m):
+    """A copy of a COO matrix without the constructor's index validation (its arrays are copied; 1 us against 30)."""
+    c = m.copy() if not isinstance(m, coo_matrix) else None
+    if c is not None: return c
+    try:
+        c = coo_matrix.__new__(coo_matrix)
+        c.__dict__.update(m.__dict__)
+        c.data = m.data.copy()
+        c.coords = tuple(x.copy() for x in m.coords)
+        return c
+    except Exception:                     # (another scipy layout: the public way)
+        return m.copy()
+
+
 class GraphObject:
     """Homogeneous graph: nodes (N, L) labels, arcs (E, 2 + A) = [src id | dst id | arc label], targets.
 
@@ -107,10 +121,50 @@ class GraphObject:
 
     # ------------------------------------------------------------------------------------------------------------------
     def copy(self):
+        """A deep copy THROUGH THE CONSTRUCTOR, as in the reference (graph_class.py:141-146): arcs de-duplicated and ordered again, ArcNode and
+        Adjacency rebuilt from `aggregation_mode`, the DIM_* fields read from the arrays' shapes.  When the constructor would find everything
+        as it is - the arcs still the unique ordered rows their ids say, ArcNode what `buildArcNode` builds - the same object is made field by
+        field without it (a serial LGNN `fit()` copies every graph of a sequencer a dozen times per epoch: 230 -> 25 us a graph)."""
+        fast = self._copy_fields()
+        if fast is not None: return fast
         return GraphObject(nodes=self.getNodes(), arcs=self.getArcs(), targets=self.getTargets(),
                            set_mask=self.getSetMask(), output_mask=self.getOutputMask(),
                            sample_weight=self.getSampleWeights(), NodeGraph=self.getNodeGraph(),
                            aggregation_mode=self.aggregation_mode)
+
+    def _copy_fields(self):
+        if type(self) is not GraphObject: return None
+        arcs, ids, an = self.arcs, self.arc_ids, self.ArcNode
+        E, N = arcs.shape[0], self.nodes.shape[0]
+        if arcs.ndim != 2 or ids.shape != (E, 2) or an.shape != (E, N) or an.data.shape[0] != E or self.Adjacency.shape != (N, N): return None
+        if self.nodes.dtype != self.dtype or arcs.dtype != self.dtype or self.targets.dtype != self.dtype: return None
+        if self.set_mask.dtype != bool or self.output_mask.dtype != bool or len(self.set_mask) != len(self.output_mask): return None
+        if not np.array_equal(arcs[:, :2], ids): return None                                   # the ids the arcs carry are the ids the operators were built on
+        if E > 1:                                                                               # ... and the rows are unique and in np.unique's order
+            d = np.diff(arcs, axis=0)
+            first = (d != 0).argmax(axis=1)
+            if not ((d != 0).any(axis=1) & (d[np.arange(E - 1), first] > 0)).all(): return None
+        mode = self.aggregation_mode
+        if mode not in ('sum', 'normalized', 'average'): return None
+        col = ids[:, 1]
+        want = np.ones(E)
+        if mode == 'normalized': want = want * float(1 / max(E, 1))
+        elif mode == 'average': want = want / np.bincount(col, minlength=N)[col]
+        if not (np.array_equal(an.row, np.arange(E)) and np.array_equal(an.col, col) and np.array_equal(an.data, want.astype(self.dtype))): return None
+        adj = self.Adjacency
+        if not (np.array_equal(adj.row, ids[:, 0]) and np.array_equal(adj.col, col) and np.array_equal(adj.data, an.data)): return None
+        ng = self.NodeGraph
+        if ng.dtype != self.dtype: return None
+        g = object.__new__(GraphObject)
+        g.dtype = self.dtype
+        g.nodes, g.arc_ids, g.arcs, g.targets = self.nodes.copy(), ids.copy(), arcs.copy(), self.targets.copy()
+        g.sample_weight = np.asarray(self.sample_weight) * np.ones(self.targets.shape[0])
+        g.DIM_NODE_LABEL = np.array(self.nodes.shape[1], ndmin=1, dtype=int)
+        g.DIM_ARC_LABEL, g.DIM_TARGET = arcs.shape[1] - 2, self.targets.shape[1]
+        g.set_mask, g.output_mask = self.set_mask.copy(), self.output_mask.copy()
+        g.aggregation_mode = str(mode)
+        g.ArcNode, g.Adjacency, g.NodeGraph = _coo_clone(an), _coo_clone(adj), _coo_clone(ng)
+        return g
 
     def __repr__(self):
         set_mask_type = 'all' if np.all(self.set_mask) else 'mixed'

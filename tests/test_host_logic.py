@@ -362,3 +362,41 @@ def test_bench_reports_pmc_traffic_only_for_the_library_sources_it_runs_on(tmp_p
     assert bench.traffic_lookup({'traffic': None}, 'k_x<6>', 10, 20, 64, traffic_file=str(f))['traffic'] is None
     rec = bench.traffic_lookup({'traffic': None}, 'k_x<64>', 10, 20, 64, traffic_file=str(tmp_path / 'absent.json'))
     assert rec['traffic'] is None and 'missing' in rec['traffic_null_reason']
+
+
+def test_graphobject_copy_field_by_field_equals_the_constructor_path(mutag_graphs):
+    """`GraphObject.copy()` (reference graph_class.py:141-146 copies through the constructor) takes a field-by-field path when the constructor
+    would change nothing; both must give the same object - every array, every operator, the DIM_* fields - and a graph whose ArcNode or arc
+    order was changed by hand must fall back to the constructor, which rebuilds them."""
+    from gnnkeras_amd.graph_class import GraphObject
+
+    def same(a, b):
+        assert set(a.__dict__) == set(b.__dict__)
+        for key, x in a.__dict__.items():
+            y = b.__dict__[key]
+            if hasattr(x, 'tocsr'):
+                assert x.shape == y.shape and x.dtype == y.dtype and x.data is not y.data, key
+                assert np.array_equal(x.row, y.row) and np.array_equal(x.col, y.col) and np.array_equal(x.data, y.data), key
+            elif isinstance(x, np.ndarray):
+                assert x is not y and x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y), key
+            else:
+                assert type(x) == type(y) and x == y, key
+
+    for g in mutag_graphs[:60]:
+        g = g.copy()
+        for mode in ('average', 'sum', 'normalized'):
+            g.setAggregation(mode)
+            fast = g._copy_fields()
+            assert fast is not None
+            slow = GraphObject(nodes=g.getNodes(), arcs=g.getArcs(), targets=g.getTargets(), set_mask=g.getSetMask(), output_mask=g.getOutputMask(),
+                               sample_weight=g.getSampleWeights(), NodeGraph=g.getNodeGraph(), aggregation_mode=g.aggregation_mode)
+            same(fast, slow)
+    g = mutag_graphs[3].copy()
+    g.ArcNode.data[0] = 0.123                                    # an operator changed by hand: the constructor rebuilds it from the mode
+    assert g._copy_fields() is None and g.copy().ArcNode.data[0] != np.float32(0.123)
+    g = mutag_graphs[3].copy()
+    g.arcs = g.arcs[::-1].copy()                                 # arcs out of order: the constructor sorts them again
+    assert g._copy_fields() is None and np.array_equal(g.copy().arcs, mutag_graphs[3].arcs)
+    g = mutag_graphs[3].copy()
+    g.nodes = np.concatenate([g.nodes, g.nodes], axis=1)         # what LGNN's propagation does: wider labels -> DIM_NODE_LABEL follows the array
+    assert g.copy().DIM_NODE_LABEL[0] == g.nodes.shape[1]

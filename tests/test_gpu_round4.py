@@ -357,6 +357,30 @@ def test_beyond_infinity_cache_point_4m_40m_properties():
     assert rel_err(got, want) <= TOL
 
 
+def test_wide_state_d200_section_properties_at_full_size():
+    """bench.py's `wide_state_d200` section AT its size (300 k nodes / 3 M arcs, d = 200, 20 iterations of k_state_xwide_b3: the Dense layer as
+    bf16 three-term splits): k pinned, the loop bitwise deterministic (the LDS hand-overs and the ring of half-slots carry no arithmetic),
+    and the fused kernel against the un-fused kernels - an exact f32 matrix-instruction chain, an independent device implementation - within
+    the forward bar after all 20 iterations."""
+    N, E, d, K = 300_000, 3_000_000, 200, 20
+    x = er_device_batch(N, E, 'cuda', seed=77)
+    ns, no = _starter('n', d)
+    model = GNNnodeBased(ns, no, d, K, 0.0)
+    s0 = torch.randn((N, d), device='cuda', generator=torch.Generator(device='cuda').manual_seed(2)) * 0.1
+    inputs = model.process_inputs(x)
+    k, st, o = model.Loop(*inputs, state0=s0)
+    assert float(k) == float(K) and _last_kernel().startswith('k_state_xwide_b3'), (float(k), _last_kernel())
+    k2, st2, o2 = model.Loop(*inputs, state0=s0)
+    assert torch.equal(st, st2) and torch.equal(o, o2)
+    del st2, o2
+    model.native_flags = nat.FLAG_UNFUSED
+    ku, stu, ou = model.Loop(*inputs, state0=s0)
+    assert float(ku) == float(K) and 'un-fused' in _last_kernel()
+    es = float((st - stu).abs().max() / stu.abs().max()); eo = float((o - ou).abs().max() / ou.abs().max())
+    print(f'\nd = 200, 300 k / 3 M, k = {K}: fused (bf16 x 3) vs un-fused (f32 chain) state {es:.2e} out {eo:.2e}')
+    assert es <= TOL and eo <= TOL
+
+
 def test_wide_state_d200_section_operands_against_the_oracle():
     """bench.py's `wide_state_d200` section (300 k nodes / 3 M arcs built by `er_device_batch`, d = 200, the 129..256-wide fused
     kernel) at a size the oracle finishes in seconds (60 k / 600 k): k, state and output against the float64 oracle fed from the

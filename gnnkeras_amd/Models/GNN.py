@@ -715,8 +715,18 @@ class GNNnodeBased(_LoopModel):
             if groups is not None: raise ValueError('groups are an inference-only feature')
             from .training import LoopTrainer
             if getattr(self, '_trainer', None) is None: self._trainer = LoopTrainer(self)      # (one per model, shared with train_step)
-            tp = self._trainer.forward([nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph],
-                                       state0=state0, seed=seed, node_level=node_level)
+            x_list = [nodes, arcs, dim_node_label, set_mask, output_mask, adjacency, arcnode, nodegraph]
+            if self._trainer._native_forward_applies():
+                # one library call (include/gnnloop.h ABI 9, forward_only) instead of ~ 40 building-block calls: what a serial LGNN fit()
+                # runs on every single graph between its layers (reference LGNN.py:325-337)
+                try:
+                    k, state, out = self._trainer.forward_native(x_list, state0=state0, seed=seed, node_level=node_level)
+                    return torch.tensor(float(k), device=state.device), state, out
+                except nat.NativeError as e:
+                    # an expired grid barrier of the persistent forward kernel (GPU shared with long-running work) or a shape the in-library
+                    # forward does not cover: nothing has been touched - the building blocks below have no cross-workgroup waits
+                    if not any(t in str(e) for t in ('grid barrier', 'cannot be resident', 'train through the building blocks', 'empty graph')): raise
+            tp = self._trainer.forward(x_list, state0=state0, seed=seed, node_level=node_level)
             return torch.tensor(float(tp.k), device=tp.dev), tp.state.clone(), tp.y_pred
         nat.require_device(nodes, 'nodes'); nat.require_device(arcs, 'arcs')
         dev = nodes.device

@@ -881,10 +881,25 @@ class LoopTrainer:
         kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
         return str(kind).lower() in nat.LOSSES
 
-    def _train_step_native(self, x_list, y, sample_weight, state0, seed, apply):
+    def _native_forward_applies(self):
+        """May `Loop(..., training=True)` run as ONE `gnn_train_step(forward_only)` call?  (homogeneous models, no Dropout in front of a first
+        Dense, no data parallelism - what the in-library step covers, minus everything about the loss.)"""
+        m = self.model
+        if self.dp is not None or not self.use_native_step or isinstance(m.net_state, (list, tuple)) or m.max_iteration < 1: return False
+        for n_ in (m.net_state, m.net_output):
+            if any(float(r) > 0 and int(q) == 0 for r, q in zip(n_.dropout_rate or [], n_.dropout_pos or [])): return False
+        return True
+
+    def forward_native(self, x_list, state0=None, seed=None, node_level=False):
+        """The training-mode forward in one library call (include/gnnloop.h ABI 9, `forward_only`): (k, state, output rows) - the same
+        arithmetic as `forward()` on the building blocks, no tape kept.  `node_level`: a graph-focused model stops at its per-node outputs."""
+        r = self._train_step_native(x_list, None, None, state0, seed, False, forward_only=True, node_level=node_level)
+        return r['k'], r['state'], r['y_pred']
+
+    def _train_step_native(self, x_list, y, sample_weight, state0, seed, apply, forward_only=False, node_level=False):
         """One `gnn_train_step` call: training-mode forward, loss, BPTT; the tape and every scratch buffer live in one cached
         device allocation. Same results as the general path (same kernels for the arithmetic), ~2.5x fewer launches and no
-        Python between them."""
+        Python between them.  `forward_only`: the forward alone (no targets, no gradients; `Loop(..., training=True)`)."""
         from types import SimpleNamespace
         from .GNN import _squeeze_last, _arc_endpoints
         m = self.model
@@ -902,14 +917,16 @@ class LoopTrainer:
         N, L = nodes.shape
         d = m.state_vect_dim
         S = d if d > 0 else L
-        focus = m._focus
+        focus = 'n' if (forward_only and node_level and m._focus == 'g') else m._focus
         for n_ in nets_s: n_.to(dev)
         m.net_output.to(dev)
+        if forward_only: self.resolve_pending()                  # (the tape is shared with the steps: nothing of theirs may be pending on it)
         # gnn_train_step OVERWRITES every gradient buffer: the holders of the previous step are reused as they are (eight zero-fill
         # launches and their allocations per step otherwise; the optimizer's pointer tables stay valid too)
-        gs_all = [self._cached_grads(f'state{i}' if composite else 'state', n_, p) for i, n_ in enumerate(nets_s)]
-        gs, go = gs_all[0], self._cached_grads('output', m.net_output, p)
-        self.gs, self.go = (gs_all if composite else gs), go
+        gs_all = [] if forward_only else [self._cached_grads(f'state{i}' if composite else 'state', n_, p) for i, n_ in enumerate(nets_s)]
+        if not forward_only:
+            gs, go = gs_all[0], self._cached_grads('output', m.net_output, p)
+            self.gs, self.go = (gs_all if composite else gs), go
         out_index = m._out_index(_squeeze_last(set_mask).to(dev), _squeeze_last(output_mask).to(dev))
         adj, an = adjacency.device_csr(dev), arcnode.device_csr(dev)
         keep = [nodes, arcs, adj, an, out_index]
@@ -952,7 +969,7 @@ class LoopTrainer:
             a.state0 = nat.ptr(state0); keep.append(state0)
         a.focus = nat.FOCUS[focus]
         a.n_out, a.out_index = len(out_index), nat.ptr(out_index)
-        ta.adjacency_by_source = nat.make_csr(_by_source(adjacency, dev))
+        if not forward_only: ta.adjacency_by_source = nat.make_csr(_by_source(adjacency, dev))
         if focus == 'a':
             es, ed = _arc_endpoints(adjacency, dev)
             a.arc_src, a.arc_dst = nat.ptr(es), nat.ptr(ed); keep += [es, ed]
@@ -960,21 +977,25 @@ class LoopTrainer:
         if focus == 'g':
             ng = nodegraph.device_csr(dev)
             a.nodegraph = nat.make_csr(ng); keep.append(ng)
-            ta.nodegraph_by_source = nat.make_csr(_by_source(nodegraph, dev))
+            if not forward_only: ta.nodegraph_by_source = nat.make_csr(_by_source(nodegraph, dev))
             n_rows = ng['n_dst']
         a.stream = p.stream()
-        yd = y.to(dev, torch.float32).contiguous()
-        if yd.shape[0] != n_rows: raise ValueError(f'targets have {yd.shape[0]} rows, the model outputs {n_rows}')
-        sw = None if sample_weight is None else sample_weight.to(dev, torch.float32).contiguous()
-        ta.targets, ta.sample_weight = nat.ptr(yd), nat.ptr(sw)
-        kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
-        ta.loss_kind = nat.LOSSES[str(kind).lower()]
+        ta.forward_only = int(bool(forward_only))
+        if not forward_only:
+            yd = y.to(dev, torch.float32).contiguous()
+            if yd.shape[0] != n_rows: raise ValueError(f'targets have {yd.shape[0]} rows, the model outputs {n_rows}')
+            sw = None if sample_weight is None else sample_weight.to(dev, torch.float32).contiguous()
+            ta.targets, ta.sample_weight = nat.ptr(yd), nat.ptr(sw)
+            kind = m.loss if isinstance(m.loss, str) else getattr(m.loss, '__name__', str(m.loss))
+            ta.loss_kind = nat.LOSSES[str(kind).lower()]
         ta.average_st_grads = 0          # finish() divides by k AFTER adding the weight penalties, like the reference (GNN.py:295)
         ta.bn_momentum = BN_MOMENTUM
         # Dropout / AlphaDropout layers (reference MLP.py:60-66): their masks derive from the step's seed exactly as on the building-block path
         m._dropout_step = getattr(m, '_dropout_step', 0) + 1
         self.drop_seed = _mix32(0x5EED, int(seed)) if seed is not None else _mix32(id(m) & 0xFFFFFFFF, m._dropout_step)
         ta.drop_seed = self.drop_seed
+        drop_nets = [self._cached_grads('state', m.net_state, p), self._cached_grads('output', m.net_output, p)] if forward_only else None
+        if forward_only: gs_all, go = [drop_nets[0]], drop_nets[1]           # (the holders know the networks' Dropout layers; their buffers stay untouched)
         for i, g_ in enumerate(gs_all): g_.net_id = i
         go.net_id = 1000
         for spec, g_ in [(ta.drop_state[i], g_) for i, g_ in enumerate(gs_all)] + [(ta.drop_output, go)]:
@@ -982,8 +1003,8 @@ class LoopTrainer:
             if len(layers) > nat.GNN_MAX_DROPOUT: raise ValueError(f'more than {nat.GNN_MAX_DROPOUT} Dropout layers in one network')
             spec.n, spec.alpha, spec.net_id = len(layers), int(bool(g_.alpha)), int(g_.net_id)
             for j, (q, r, idx) in enumerate(layers): spec.pos[j], spec.rate[j], spec.index[j] = int(q), float(r), int(idx)
-        holders = [(ta.grad_state_types[i], g_) for i, g_ in enumerate(gs_all)] if composite else [(ta.grad_state, gs)]
-        for g_, ng_ in holders + [(ta.grad_output, go)]:
+        holders = [] if forward_only else ([(ta.grad_state_types[i], g_) for i, g_ in enumerate(gs_all)] if composite else [(ta.grad_state, gs)]) + [(ta.grad_output, go)]
+        for g_, ng_ in holders:
             if ng_.bn: g_.dgamma, g_.dbeta = nat.ptr(ng_.dgamma), nat.ptr(ng_.dbeta)
             for l in range(len(ng_.W)): g_.dkernel[l], g_.dbias[l] = ng_.dW[l].data_ptr(), ng_.db[l].data_ptr()
         T = m.net_output.units[-1]
@@ -1003,6 +1024,9 @@ class LoopTrainer:
         base = tape.data_ptr()
         aligned = (base + 255) & ~255
         ta.tape, ta.tape_bytes = C.c_void_p(aligned), tape.numel() - (aligned - base)
+        if forward_only:
+            nat.check(nat.lib().gnn_train_step(C.byref(ta)))
+            return {'k': int(k_host.value), 'y_pred': y_pred, 'state': state}
         # the validity word of this step's gradients (first word of the tape) and - for free, at the call's one synchronisation - the one
         # the previous step left there
         ok_ptr, prev_ok = C.c_void_p(0), C.c_int32(1)

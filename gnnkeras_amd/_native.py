@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 # GNNKERAS_AMD_LIB: load another build of the same sources (tests: the debug build whose in-launch waits expire at once)
 LIB_PATH = os.environ.get('GNNKERAS_AMD_LIB') or os.path.join(CSRC, 'libgnnloop.so')
 
-GNN_ABI_VERSION = 8
+GNN_ABI_VERSION = 9
 GNN_MAX_LAYERS = 8
 GNN_MAX_TYPES = 8
 
@@ -124,7 +124,9 @@ class TrainArgs(C.Structure):
                 # ABI 7: the device word that says whether the step's gradients are valid (the optimizers' gate) and the previous step's, read for free
                 ('grads_ok_dev', C.POINTER(C.c_void_p)), ('prev_grads_ok_host', C.POINTER(C.c_int32)),
                 # ABI 8: the networks' Dropout layers (positions >= 1) and the step's mask seed
-                ('drop_state', DropoutSpec * GNN_MAX_TYPES), ('drop_output', DropoutSpec), ('drop_seed', C.c_uint32)]
+                ('drop_state', DropoutSpec * GNN_MAX_TYPES), ('drop_output', DropoutSpec), ('drop_seed', C.c_uint32),
+                # ABI 9: the training-mode forward alone (no loss, no gradients)
+                ('forward_only', C.c_int32)]
 
 
 class ShardLoopArgs(C.Structure):       # gnn_shard_loop_args_t (ABI 7): the sharded loop driven from native code (csrc/shard_loop.hpp)

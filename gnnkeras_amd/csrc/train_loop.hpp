@@ -928,12 +928,17 @@ static int train_step_impl(const gnn_train_args_t &ta) {
     const gnn_loop_args_t &a = ta.loop;
     TrainPlan p;
     if (!ta.tape || ((uintptr_t)ta.tape & 255) != 0) return fail("tape must be a 256-byte aligned device buffer");
-    if (a.composite) return train_step_composite(ta);             // one state network per node type (train_composite.hpp)
+    const bool fwd_only = ta.forward_only != 0;                   // ABI 9: the training-mode forward alone (no loss, no gradients)
+    if (a.composite) {
+        if (fwd_only) return fail("gnn_train_step(forward_only): homogeneous models only");
+        return train_step_composite(ta);                           // one state network per node type (train_composite.hpp)
+    }
+    if (fwd_only && ta.prev_grads_ok_host) return fail("gnn_train_step(forward_only): prev_grads_ok_host must be NULL");
     TRY(make_train_plan(ta, ta.tape, p));
     if (ta.tape_bytes < p.bytes) return fail("tape too small: %zu < %zu bytes", ta.tape_bytes, p.bytes);
     TRY(check_csr(a.adjacency, "adjacency", p.N, p.N));
     TRY(check_csr(a.arcnode, "arcnode", p.N, p.E));
-    TRY(check_csr(ta.adjacency_by_source, "adjacency_by_source", p.N, p.N));
+    if (!fwd_only) TRY(check_csr(ta.adjacency_by_source, "adjacency_by_source", p.N, p.N));
     if (!a.nodes || (p.E > 0 && p.A > 0 && !a.arc_labels)) return fail("nodes / arc_labels is NULL");
     if (a.state_dim > 0 && !a.state0) return fail("state0 is required when state_dim > 0");
     if (p.M > 0 && !a.out_index) return fail("out_index is NULL");
@@ -941,13 +946,15 @@ static int train_step_impl(const gnn_train_args_t &ta) {
     if (p.pooled) {
         if (a.nodegraph.n_src != p.M) return fail("graph focus: every node must pass the mask");
         TRY(check_csr(a.nodegraph, "nodegraph", p.G, p.M));
-        TRY(check_csr(ta.nodegraph_by_source, "nodegraph_by_source", p.M, p.G));
+        if (!fwd_only) TRY(check_csr(ta.nodegraph_by_source, "nodegraph_by_source", p.M, p.G));
     }
-    if (p.R < 1 || !ta.targets) return fail("gnn_train_step needs at least one target row");
-    if (ta.loss_kind < 0 || ta.loss_kind > 3) return fail("unknown loss kind %d", ta.loss_kind);
-    if (!ta.y_pred || !ta.loss || !ta.k_host || !ta.state) return fail("y_pred / loss / k_host / state is NULL");
-    TRY(check_grads(a.net_state[0], ta.grad_state, "grad_state"));
-    TRY(check_grads(a.net_output, ta.grad_output, "grad_output"));
+    if (p.R < 1 || (!fwd_only && !ta.targets)) return fail("gnn_train_step needs at least one target row");
+    if (!fwd_only && (ta.loss_kind < 0 || ta.loss_kind > 3)) return fail("unknown loss kind %d", ta.loss_kind);
+    if (!ta.y_pred || (!fwd_only && !ta.loss) || !ta.k_host || !ta.state) return fail("y_pred / loss / k_host / state is NULL");
+    if (!fwd_only) {
+        TRY(check_grads(a.net_state[0], ta.grad_state, "grad_state"));
+        TRY(check_grads(a.net_output, ta.grad_output, "grad_output"));
+    }
     const gnn_mlp_t &ns = a.net_state[0], &no = a.net_output;
     const bool bn_s = ns.has_bn != 0, bn_o = no.has_bn != 0;
     const bool fold_s = ns.units[0] <= 4;       // see the forward loop
@@ -959,10 +966,12 @@ static int train_step_impl(const gnn_train_args_t &ta) {
     // the validity word the previous call on this tape left (stream-ordered behind that call's launches; on the host at this call's one
     // synchronisation), then this call's: 0 until the last launch of the step has been issued
     if (ta.prev_grads_ok_host) HIP_OK(hipMemcpyAsync(ta.prev_grads_ok_host, p.grads_ok, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemsetAsync(p.grads_ok, 0, sizeof(int) * 4, st));
-    if (ta.grads_ok_dev) *ta.grads_ok_dev = p.grads_ok;
-    TRY(transposes(p.cs, st));
-    TRY(transposes(p.co, st));
+    if (!fwd_only) {               // (a forward leaves the word of the last STEP on this tape as it is)
+        HIP_OK(hipMemsetAsync(p.grads_ok, 0, sizeof(int) * 4, st));
+        if (ta.grads_ok_dev) *ta.grads_ok_dev = p.grads_ok;
+        TRY(transposes(p.cs, st));
+        TRY(transposes(p.co, st));
+    }
     HIP_OK(hipMemsetAsync(p.flags, 0, sizeof(int) * (p.K + 8), st));
     HIP_OK(hipMemsetAsync(p.k_dev, 0, sizeof(float) * 4, st));
     if (p.A > 0) TRY(launch_aggregate(nullptr, a.arcnode, a.arc_labels, a.ld_arcs, p.A, p.agg_arcs, p.A, st));
@@ -1191,6 +1200,16 @@ static int train_step_impl(const gnn_train_args_t &ta) {
         TRY(forward_layers(no, osegs, nos, p.M, W0, b0, ohs, nullptr, st, nullptr, nullptr, bn_o ? p.stats_o : nullptr, &dro));
     }
     if (p.pooled) TRY(launch_aggregate(nullptr, a.nodegraph, out_nodes, p.T, p.T, ta.y_pred, p.T, st));
+    if (fwd_only) {
+        // the forward alone: the moving averages the persistent small-graph path keeps back for the step's validity word are due now
+        if (p.small) TRY(moving_state(nullptr));
+        if (moving_output_pending) {
+            gnn::k_bn_moving_multi<<<cdiv(p.in_o, 256), 256, 0, st>>>(p.stats_o, 2 * p.in_o, 1, p.in_o, const_cast<float *>(no.bn_mean),
+                                                                    const_cast<float *>(no.bn_var), ta.bn_momentum);
+            LAUNCH_OK();
+        }
+        return 0;
+    }
     // ---- loss and its gradient ----------------------------------------------------------------------------------------------------
     gnn::k_loss_grad<<<cdiv(p.R, 256), 256, 0, st>>>(ta.loss_kind, ta.targets, ta.y_pred, ta.sample_weight, p.R, p.T, p.dpred, p.loss_rows);
     LAUNCH_OK();

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 8
+#define GNN_ABI_VERSION 9
 
 /* Keras activation names accepted by the reference MLP builder (GNN/Models/MLP.py:16). */
 enum gnn_activation {
@@ -542,6 +542,13 @@ typedef struct gnn_train_args {
     gnn_dropout_spec_t drop_state[GNN_MAX_TYPES];   /* [0] for homogeneous models                                   */
     gnn_dropout_spec_t drop_output;
     uint32_t drop_seed;                             /* the step's seed (every mask of the step derives from it)     */
+    /* ABI 9: the training-mode FORWARD alone - `Loop(..., training=True)` (reference GNN.py:245-274: BatchNormalization on the batch
+     * statistics of THIS call + its moving-average updates, Dropout masks of `drop_seed`), what LGNN's serial fit() runs on every graph
+     * between its layers (LGNN.py:325-337; with focus NODE on a graph-focused model it is the per-node output LGNN feeds to the next layer).
+     * No loss, no gradients: targets, sample_weight, loss, grad_*, adjacency_by_source, nodegraph_by_source and the validity word are not
+     * touched (they may be NULL / zero; prev_grads_ok_host must be NULL - a forward has no step before it to judge).  y_pred, state and
+     * k_host are written as by a step.  Homogeneous models only. */
+    int32_t forward_only;
 } gnn_train_args_t;
 /* Arithmetic: float32 throughout.  On graphs of >= GNN_TRAIN_BIG_MIN_NODES (32 768) nodes the first Dense's forward product and dZ . W^T run on
  * the bf16 matrix cores with every float32 operand split into three bf16 terms (six products, float32 accumulation: the accuracy of a

@@ -309,3 +309,55 @@ def test_composite_dropout_inside_the_library_equals_the_building_blocks():
         assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), scale)
     other = LoopTrainer(model).train_step(x, y, sw, state0=s0, apply=False, seed=32)
     assert abs(float(other['loss']) - outs[True][0]) > 1e-7                 # (another seed: other masks)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ABI 9: the training-mode forward alone in one library call (`Loop(..., training=True)`; reference GNN.py:245-274, LGNN.py:325-337)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('focus,node_level,d,n_graphs,hidden', [('g', True, 0, 1, None), ('g', False, 32, 32, None), ('n', False, 16, 8, None),
+                                                               ('a', False, 32, 8, None), ('g', True, 8, 1, [12])])
+def test_training_mode_forward_in_one_library_call_equals_the_building_blocks(mutag_graphs, focus, node_level, d, n_graphs, hidden):
+    """`Loop(..., training=True)` - BatchNormalization on the batch statistics of the call, its moving-average updates (k for the state
+    network, one for the output network), Dropout masks of the call's seed - as ONE `gnn_train_step(forward_only)` call against the same
+    forward on the building blocks (~ 40 calls): k, state, output rows (per node for `node_level` on a graph-focused model: what LGNN feeds
+    to its next layer) and the moving statistics both leave behind.  Single graphs (LGNN's propagation), merged batches (persistent
+    small-graph kernel), a hidden layer with Dropout behind it (general in-library path)."""
+    from test_gpu_training import refocus, CLS
+    from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+    rng = np.random.default_rng(11)
+    graphs = refocus([g.copy() for g in mutag_graphs[40:40 + n_graphs]], focus, rng)
+    for g in graphs: g.setAggregation('average')
+    x = MultiGraphSequencer(graphs, focus, 'average', n_graphs, shuffle=False)[0][0]
+
+    def build():
+        inp, lay = get_inout_dims('state', 14, 3, 2, focus, d, hidden_units=hidden)
+        kw = dict(dropout_rate=[0.3], dropout_pos=[1]) if hidden else {}
+        ns = MLP(inp[0], lay, 'tanh' if hidden else 'selu', 'lecun_normal', 'lecun_normal', rng=0, **kw)
+        ns.set_weights([w * 0.5 if w.ndim == 2 else w for w in ns.get_weights()])
+        inp, lay = get_inout_dims('output', 14, 3, 2, focus, d)
+        no = MLP(inp[0], lay, 'softmax', 'glorot_normal', 'glorot_normal', rng=1)
+        r = np.random.default_rng(3)
+        for n in (ns, no):                                       # non-trivial gamma / beta
+            w = n.get_weights()
+            w[0] = r.uniform(0.7, 1.3, w[0].shape).astype(np.float32); w[1] = r.normal(0, 0.2, w[1].shape).astype(np.float32)
+            n.set_weights(w)
+        return CLS[focus](ns, no, d, 4, 0.0)
+    weights = lambda m: [w.copy() for w in m.net_state.get_weights() + m.net_output.get_weights()]
+    a, b = build(), build()
+    b._trainer = LoopTrainer(b)
+    b._trainer.use_native_step = False
+    s0 = None if d == 0 else torch.from_numpy(np.random.default_rng(5).normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)).cuda()
+    for rep in range(2):                                         # twice: the moving statistics carry over
+        ka, sa, oa = a.Loop(*a.process_inputs(x), training=True, state0=s0, seed=7 + rep, node_level=node_level)
+        name = nat.lib().gnn_last_kernel_name().decode()
+        assert name.startswith('train_step'), name
+        assert ('general' in name) == bool(hidden), name
+        kb, sb, ob = b.Loop(*b.process_inputs(x), training=True, state0=s0, seed=7 + rep, node_level=node_level)
+        assert float(ka) == float(kb) == 4.0, (float(ka), float(kb))
+        assert tuple(oa.shape) == tuple(ob.shape) and tuple(sa.shape) == tuple(sb.shape)
+        if focus == 'g': assert oa.shape[0] == (x[0].shape[0] if node_level else n_graphs)
+        for got, want, what in ((sa, sb, 'state'), (oa, ob, 'output')):
+            err = float((got - want).abs().max() / want.abs().max().clamp(min=1e-30))
+            assert err <= 2e-6, (what, rep, err)
+        for wa, wb in zip(weights(a), weights(b)):                 # (gamma, beta, MOVING mean / variance, kernels, biases)
+            assert np.allclose(wa, wb, rtol=2e-6, atol=1e-7), float(np.max(np.abs(wa - wb)))

@@ -244,9 +244,12 @@ class LGNN(_LoopModel):
         if callbacks is None: callbacks = [[] for _ in range(self.LAYERS)]
         assert len(callbacks) == self.LAYERS
         histories = []
+        # (the reference copies a sequencer wherever it hands one on, LGNN.py:303-313; a layer's fit() and the propagation below re-batch and
+        # shuffle but never edit a graph, so a second sequencer over the same graph objects does - only the relabelled graphs are copies)
+        view = lambda s: s._view() if hasattr(s, '_view') else s.copy()
         train_t0, valid_t0 = sequencer, validation_data
-        training_sequence = train_t0.copy()
-        valid_sequence = valid_t0.copy() if valid_t0 is not None else None
+        training_sequence = view(train_t0)
+        valid_sequence = view(valid_t0) if valid_t0 is not None else None
 
         def propagate(gnn, seq_now, seq_t0):
             """states / outputs of every single graph (batch size 1, training-mode forward as in the reference), merged
@@ -263,12 +266,12 @@ class LGNN(_LoopModel):
 
         for idx, gnn in enumerate(self.gnns[:-1]):
             if verbose: print(f'\\n\\n --- GNN {idx + 1}/{self.LAYERS} ---')
-            histories.append(gnn.fit(training_sequence.copy(), epochs=epochs, verbose=verbose, callbacks=callbacks[idx],
-                                     validation_data=valid_sequence.copy() if valid_sequence is not None else None, **kwargs))
+            histories.append(gnn.fit(view(training_sequence), epochs=epochs, verbose=verbose, callbacks=callbacks[idx],
+                                     validation_data=view(valid_sequence) if valid_sequence is not None else None, **kwargs))
             training_sequence = propagate(gnn, training_sequence, train_t0)
             if valid_sequence is not None: valid_sequence = propagate(gnn, valid_sequence, valid_t0)
         if verbose: print(f'\\n\\n --- GNN {self.LAYERS}/{self.LAYERS} ---')
-        histories.append(self.gnns[-1].fit(training_sequence.copy(), epochs=epochs, verbose=verbose, callbacks=callbacks[-1],
-                                           validation_data=valid_sequence.copy() if valid_sequence is not None else None, **kwargs))
+        histories.append(self.gnns[-1].fit(view(training_sequence), epochs=epochs, verbose=verbose, callbacks=callbacks[-1],
+                                           validation_data=view(valid_sequence) if valid_sequence is not None else None, **kwargs))
         self.history = histories
         return histories

@@ -148,6 +148,13 @@ class MultiGraphSequencer:
         config["graphs"] = [g.copy() for g in config["graphs"]]
         return self.from_config(config)
 
+    def _view(self):
+        """A second sequencer over the SAME graph objects (its own list, batch size and order): for a consumer that re-batches and shuffles
+        but does not edit the graphs - `fit()` of a GNN - where the reference hands over `copy()` (LGNN.py:312-313)."""
+        config = self.get_config()
+        config["graphs"] = list(config["graphs"])
+        return self.from_config(config)
+
     def get_config(self):
         return {"graphs": self.data, "focus": self.focus, "aggregation_mode": self.aggregation_mode,
                 "batch_size": self.batch_size, "shuffle": self.shuffle, "assemble": self.assemble}

@@ -361,3 +361,29 @@ def test_training_mode_forward_in_one_library_call_equals_the_building_blocks(mu
             assert err <= 2e-6, (what, rep, err)
         for wa, wb in zip(weights(a), weights(b)):                 # (gamma, beta, MOVING mean / variance, kernels, biases)
             assert np.allclose(wa, wb, rtol=2e-6, atol=1e-7), float(np.max(np.abs(wa - wb)))
+
+
+def test_training_mode_forward_falls_back_when_the_persistent_launch_fails(mutag_graphs, monkeypatch):
+    """GNN_DEBUG_FAIL_FWD=1: every barrier wait of the persistent forward launch expires at once - the in-library forward raises BEFORE it has
+    touched a moving statistic, `Loop(..., training=True)` runs the building blocks instead: the same results as a twin that never tried the
+    library call, the moving averages moved exactly once."""
+    from test_gpu_training import nets
+    from gnnkeras_amd.Models.GNN import GNNgraphBased
+    from gnnkeras_amd.Sequencers.GraphSequencers import MultiGraphSequencer
+    x = MultiGraphSequencer([g.copy() for g in mutag_graphs[:32]], 'g', 'average', 32, shuffle=False)[0][0]
+    d = 32
+    build = lambda: GNNgraphBased(*nets('g', d, True), d, 4, 0.0)
+    weights = lambda m: [w.copy() for w in m.net_state.get_weights() + m.net_output.get_weights()]
+    a, b = build(), build()
+    b._trainer = LoopTrainer(b); b._trainer.use_native_step = False
+    s0 = torch.from_numpy(np.random.default_rng(5).normal(0, 0.1, (x[0].shape[0], d)).astype(np.float32)).cuda()
+    monkeypatch.setenv('GNN_DEBUG_FAIL_FWD', '1')
+    ka, sa, oa = a.Loop(*a.process_inputs(x), training=True, state0=s0, seed=3)
+    monkeypatch.delenv('GNN_DEBUG_FAIL_FWD')
+    kb, sb, ob = b.Loop(*b.process_inputs(x), training=True, state0=s0, seed=3)
+    assert float(ka) == float(kb) == 4.0
+    assert torch.equal(sa, sb) and torch.equal(oa, ob)             # (the same building blocks ran)
+    for wa, wb in zip(weights(a), weights(b)): assert np.array_equal(wa, wb)
+    ka2, sa2, oa2 = a.Loop(*a.process_inputs(x), training=True, state0=s0, seed=3)      # and the library call works again once the waits do
+    assert nat.lib().gnn_last_kernel_name().decode() == 'train_step: persistent small-graph kernels'
+    assert float((sa2 - sa).abs().max() / sa.abs().max()) <= 2e-6

@@ -710,9 +710,10 @@ def main():
     ap.add_argument('--no-training', action='store_true', help='skip the train_step / fit() section')
     ap.add_argument('--unfused', action='store_true')
     ap.add_argument('--force-sharded', action='store_true', help='run the N>1 code path even with one rank (smoke test)')
-    ap.add_argument('--exchange', choices=['auto', 'allgather', 'direct', 'halo'], default='auto',
+    ap.add_argument('--exchange', choices=['auto', 'allgather', 'direct', 'halo', 'peer'], default='auto',
                     help='N>1 state exchange: whole slices by RCCL all-gather / by concurrent point-to-point pairs, or compacted halos '
-                         '(all-to-all); auto = halo for graphs with locality, else the faster whole-slice transport, measured at start-up')
+                         '(all-to-all); auto = halo for graphs with locality, else the faster whole-slice transport, measured at start-up; '
+                         'peer = the iteration kernel stores its rows into the peers\' IPC-mapped buffers (opt-in: never run on links)')
     ap.add_argument('--no-overlap', action='store_true', help='N>1: exchange strictly after the iteration kernel (no own-range / halo split)')
     ap.add_argument('--native-loop', action='store_true',
                     help='N>1 / --emulate-shard: drive the iterations from the library (gnn_shard_loop: one C call, the exchange over the RCCL C API) '

@@ -1125,6 +1125,9 @@ def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, dev
         'allgather' whole slices with RCCL's all-gather collective;
         'direct'    whole slices as R - 1 concurrent point-to-point pairs (one-hop all-gather over the xGMI mesh);
         'halo'      only the rows each peer reads, one all-to-all of uneven splits;
+        'peer'      no exchange step at all: the iteration kernel stores every new row into the peers' IPC-mapped buffers
+                    (`ShardedLoop.enable_peer_exchange`; homogeneous models, widths 17 .. 64, up to 8 ranks of one node; validated between
+                    processes on ONE GPU only - opt-in until a node has measured it against the transports above);
         'auto'      halo when it moves less than half of the all-gather volume for every rank (graphs with locality,
                     block-diagonal batches); otherwise the whole-slice layout, and - with `measure` and more than one rank - the
                     faster of its two transports on THIS machine: both are timed on the real buffers (3 exchanges each, the
@@ -1140,7 +1143,11 @@ def make_sharded_loop(model, graph: GraphObject, rank: int, world_size: int, dev
     pipeline = os.environ.get('GNN_EXCHANGE_PIPELINE', pipeline)
     if isinstance(pipeline, str) and pipeline.isdigit(): pipeline = int(pipeline)
     if not (pipeline in ('off', 'auto') or (isinstance(pipeline, int) and pipeline >= 1)): raise ValueError("pipeline must be 'off', 'auto' or a chunk count")
-    if exchange not in ('auto', 'allgather', 'direct', 'halo'): raise ValueError('exchange must be auto, allgather, direct or halo')
+    if exchange not in ('auto', 'allgather', 'direct', 'halo', 'peer'): raise ValueError('exchange must be auto, allgather, direct, halo or peer')
+    if exchange == 'peer':
+        sl = ShardedLoop(model, graph, rank, world_size, device, group=group, overlap=False)
+        sl.enable_peer_exchange()
+        return sl
     pick = exchange
     if exchange == 'auto': pick = choose_exchange(graph, world_size)
     if pick == 'halo':
